@@ -1,0 +1,287 @@
+/*
+ * kai_core.h — C ABI of libkai_core, the MI355X-native scheduling-cycle core.
+ *
+ * This is the drop-in boundary for the reference's hot path.  A cgo shim on the
+ * reference side implements framework.Action (pkg/scheduler/framework/interface.go:41-47) for
+ * allocate|consolidation|reclaim|preempt and one framework.Plugin (interface.go:49-55) whose
+ * OnSessionOpen packs cache.Snapshot() (pkg/scheduler/cache/cluster_info/cluster_info.go:118-228)
+ * into kai_snapshot_soa and calls kai_session_open.  See INTEGRATION.md for the binding.
+ *
+ * Conventions
+ *  - every function returns 0 (KAI_OK) or a negative kai_status; nothing throws, nothing calls back.
+ *  - one caller thread per handle; a handle is not re-entrant; several handles may coexist.
+ *  - all input buffers are caller-owned host memory (C.malloc'd on the Go side; cgo forbids keeping
+ *    Go pointers) and may be freed when the call returns: the library copies them to HBM.
+ *  - output buffers are caller-allocated, with a capacity argument.
+ *  - indices, not names: the host ranks every string once (node names, UIDs, pod-set names) in
+ *    byte-wise order and passes the rank, because the reference's tie-breaks are string compares
+ *    (framework/session.go:480-485 node name; session_plugins.go:227-260 UID).
+ *  - all quantities are float64 exactly as the reference holds them: cpu in milli-cores, memory in
+ *    bytes, gpu in devices, pods as a count (api/resource_info/resource_vector.go:23-36).
+ */
+#ifndef KAI_CORE_H
+#define KAI_CORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAI_ABI_VERSION 1u
+
+/* resource vector layout: api/resource_info/resource_vector.go:23-36 (cpu, memory, gpu, pods, extras…) */
+#define KAI_RES_CPU 0
+#define KAI_RES_MEM 1
+#define KAI_RES_GPU 2
+#define KAI_RES_PODS 3
+#define KAI_MAX_RES 8
+
+/* quota resources of the proportion plugin, in its fixed iteration order
+ * (plugins/proportion/resource_share/resource_quantities.go:20) */
+#define KAI_Q_CPU 0
+#define KAI_Q_MEM 1
+#define KAI_Q_GPU 2
+#define KAI_Q_NRES 3
+
+#define KAI_UNLIMITED (-1.0) /* pkg/common/constants/constants.go:11 */
+
+typedef enum kai_status {
+    KAI_OK = 0,
+    KAI_ERR_INVALID_ARG = -1,
+    KAI_ERR_NO_DEVICE = -2,     /* no usable HIP device: the library never computes on the CPU */
+    KAI_ERR_HIP = -3,           /* a HIP runtime call failed (see kai_last_error) */
+    KAI_ERR_CAPACITY = -4,      /* an output buffer is too small */
+    KAI_ERR_UNSUPPORTED = -5,   /* snapshot needs a feature outside the device path (see kai_pod_flags) */
+    KAI_ERR_STATE = -6,         /* call order violated (e.g. action before session_open) */
+    KAI_ERR_DEVICE_FAULT = -7,  /* the device engine reported an internal fault / spin timeout */
+    KAI_ERR_COMM = -8           /* multi-GPU exchange failed */
+} kai_status;
+
+/* pod status bit-set: api/pod_status/pod_status.go:25-71 */
+typedef enum kai_pod_status {
+    KAI_POD_PENDING = 1 << 0,
+    KAI_POD_GATED = 1 << 1,
+    KAI_POD_ALLOCATED = 1 << 2,
+    KAI_POD_PIPELINED = 1 << 3,
+    KAI_POD_BINDING = 1 << 4,
+    KAI_POD_BOUND = 1 << 5,
+    KAI_POD_RUNNING = 1 << 6,
+    KAI_POD_RELEASING = 1 << 7,
+    KAI_POD_SUCCEEDED = 1 << 8,
+    KAI_POD_FAILED = 1 << 9,
+    KAI_POD_UNKNOWN = 1 << 10,
+    KAI_POD_DELETED = 1 << 11
+} kai_pod_status;
+
+/* node flag bits (host pre-evaluates the per-node booleans the predicates read) */
+#define KAI_NODE_NOT_READY 0x1u      /* scheduler_util/scheduler_utils.go:12-40 says "not fit" */
+#define KAI_NODE_MIG_ENABLED 0x2u    /* api/node_info/node_info.go:704-718 */
+#define KAI_NODE_MIG_MIXED 0x4u      /* MigStrategy == mixed (node_info.go:720-732) */
+#define KAI_NODE_HAS_DRA_GPUS 0x8u   /* node_info.go:95 HasDRAGPUs */
+#define KAI_NODE_GPU_WORKER 0x10u    /* has conf GPUWorkerNodeLabelKey (plugins/predicates/predicates.go:243-259) */
+#define KAI_NODE_CPU_WORKER 0x20u    /* has conf CPUWorkerNodeLabelKey */
+
+/* pod flag bits */
+#define KAI_POD_FOREIGN_SCHEDULER 0x1u /* spec.schedulerName != ours: plugins/proportion/proportion.go:276-285 */
+#define KAI_POD_HAS_TASK_PRIORITY 0x2u /* carries the task-order label: plugins/taskorder/task_order.go:28-63 */
+#define KAI_POD_CPU_FALLBACK 0x4u      /* needs a state-dependent upstream predicate, fractional GPU, MIG, DRA …:
+                                          not placed by the device path (SURVEY §8b fallback rule) */
+
+typedef enum kai_action {
+    KAI_ACTION_ALLOCATE = 0,      /* actions/allocate/allocate.go:46-77 */
+    KAI_ACTION_CONSOLIDATION = 1, /* actions/consolidation/consolidation.go:32-78 */
+    KAI_ACTION_RECLAIM = 2,       /* actions/reclaim/reclaim.go:47-100 */
+    KAI_ACTION_PREEMPT = 3        /* actions/preempt/preempt.go:46-97 */
+} kai_action;
+
+typedef enum kai_op_kind {
+    KAI_OP_ALLOCATE = 0, /* framework/statement.go:297-358  → cache.Bind on commit  */
+    KAI_OP_PIPELINE = 1, /* framework/statement.go:197-295  → cache.TaskPipelined   */
+    KAI_OP_EVICT = 2     /* framework/statement.go:63-126   → cache.Evict           */
+} kai_op_kind;
+
+typedef enum kai_placement_strategy { KAI_BINPACK = 0, KAI_SPREAD = 1 } kai_placement_strategy;
+
+/* plugins of the default tier that register callbacks on the path (conf_util/scheduler_conf_util.go:39-60).
+ * A plugin that is absent registers nothing: its order fn / predicate / score simply does not run. */
+#define KAI_PLUGIN_PREDICATES 0x001u
+#define KAI_PLUGIN_PROPORTION 0x002u
+#define KAI_PLUGIN_PRIORITY 0x004u
+#define KAI_PLUGIN_ELASTIC 0x008u
+#define KAI_PLUGIN_NODEAVAILABILITY 0x010u
+#define KAI_PLUGIN_RESOURCETYPE 0x020u
+#define KAI_PLUGIN_SUBGROUPORDER 0x040u
+#define KAI_PLUGIN_TASKORDER 0x080u
+#define KAI_PLUGIN_NOMINATEDNODE 0x100u
+#define KAI_PLUGIN_NODEPLACEMENT 0x200u
+#define KAI_PLUGIN_MINRUNTIME 0x400u
+#define KAI_PLUGIN_TOPOLOGY 0x800u
+#define KAI_PLUGIN_ALL 0xFFFu
+
+/* knobs of conf.SchedulerParams / plugin arguments that the path reads
+ * (conf/scheduler_conf.go:31-61, plugins/proportion/proportion.go:67-93,
+ *  plugins/nodeplacement/nodeplacement.go:33-47) */
+typedef struct kai_config {
+    uint32_t abi_version;
+    int32_t gpu_strategy;                 /* kai_placement_strategy */
+    int32_t cpu_strategy;
+    double k_value;                       /* proportion kValue (<=0 → 0) */
+    double reclaimer_saturation_multiplier;
+    uint32_t plugins;                     /* KAI_PLUGIN_* bit-set: which plugins of the tier list are loaded */
+    int32_t restrict_node_scheduling;
+    int32_t max_consolidation_preemptees; /* -1 = unlimited */
+    int32_t use_scheduling_signatures;
+    int32_t allow_consolidating_reclaim;
+    int32_t full_hierarchy_fairness;
+    int64_t min_node_gpu_memory;          /* ClusterInfo.MinNodeGPUMemory */
+    int32_t queue_depth[4];               /* per kai_action; -1 = infinite (framework/session.go:398-404) */
+    int32_t engine_mode;                  /* 0 = default; 1 = force brute-force node scans (debug / A-B) */
+    int32_t reserved[7];
+} kai_config;
+
+/* Structure-of-arrays session snapshot.  [R][N] means resource-major: element (r, i) at r*N + i. */
+typedef struct kai_snapshot_soa {
+    uint32_t abi_version;
+    int32_t n_res; /* R, 4..KAI_MAX_RES */
+
+    /* ---- nodes: api/node_info/node_info.go:68-105 ---- */
+    int32_t n_nodes;
+    const double* node_allocatable;   /* [R][N] status.allocatable */
+    const uint32_t* node_flags;       /* [N] KAI_NODE_* */
+    const int32_t* node_gpu_count;    /* [N] nvidia.com/gpu.count label, -1 when absent (node_info.go:619-640) */
+    const uint32_t* node_name_rank;   /* [N] rank of the node name, byte-wise ascending, unique */
+    const int32_t* node_class;        /* [N] column of class_fit */
+
+    /* ---- pods: api/pod_info/pod_info.go:70-112; pods of one job are contiguous ---- */
+    int32_t n_pods;
+    const double* pod_req;            /* [R][P] ResReq incl. pods:=1 (pod_info.go:373-393) */
+    const int32_t* pod_job;           /* [P] */
+    const int32_t* pod_podset;        /* [P] global pod-set index */
+    const int32_t* pod_status;        /* [P] kai_pod_status */
+    const int32_t* pod_node;          /* [P] node index or -1 */
+    const uint32_t* pod_flags;        /* [P] KAI_POD_* flag bits */
+    const int32_t* pod_task_priority; /* [P] value of the task-order label (valid with KAI_POD_HAS_TASK_PRIORITY) */
+    const int64_t* pod_created_ns;    /* [P] Pod.CreationTimestamp */
+    const uint32_t* pod_uid_rank;     /* [P] rank of the pod UID, unique */
+    const int32_t* pod_class;         /* [P] row of class_fit */
+    const int32_t* pod_nominated_node;/* [P] node index of status.nominatedNodeName or -1 */
+
+    /* ---- pod-sets (gang sub-groups): api/podgroup_info/subgroup_info/podset.go:17-29 ---- */
+    int32_t n_podsets;
+    const int32_t* podset_job;           /* [S] */
+    const int32_t* podset_min_available; /* [S] */
+    const uint32_t* podset_name_rank;    /* [S] rank of the pod-set name inside its job */
+
+    /* ---- jobs (PodGroups): api/podgroup_info/job_info.go:65-103 ---- */
+    int32_t n_jobs;
+    const int32_t* job_queue;         /* [J] leaf queue index, -1 if the queue does not exist */
+    const int32_t* job_priority;      /* [J] */
+    const int32_t* job_preemptible;   /* [J] 0/1 (pkg/common/podgroup/preemptible.go:10-26) */
+    const int64_t* job_created_ns;    /* [J] */
+    const uint32_t* job_uid_rank;     /* [J] unique */
+    const int32_t* job_first_pod;     /* [J] */
+    const int32_t* job_n_pods;        /* [J] */
+    const int32_t* job_first_podset;  /* [J] */
+    const int32_t* job_n_podsets;     /* [J] */
+
+    /* ---- queues: api/queue_info/queue_info.go:32-43 ---- */
+    int32_t n_queues;
+    const int32_t* queue_parent;      /* [Q] -1 for top queues */
+    const int32_t* queue_priority;    /* [Q] */
+    const int64_t* queue_created_ns;  /* [Q] */
+    const uint32_t* queue_uid_rank;   /* [Q] unique */
+    const double* queue_deserved;     /* [3][Q] quota; cpu milli, memory in 10^6-byte units as in the CRD, gpu devices; -1 unlimited */
+    const double* queue_limit;        /* [3][Q] */
+    const double* queue_oqw;          /* [3][Q] over-quota weight */
+    const double* queue_usage;        /* [3][Q] normalised historical usage (api/queue_info/quota_info.go) */
+
+    /* ---- static predicate classes (upstream kube-scheduler Filters pre-evaluated by the host) ---- */
+    int32_t n_pod_classes;
+    int32_t n_node_classes;
+    const uint8_t* class_fit;         /* [n_pod_classes][n_node_classes] 1 = every static Filter passes */
+} kai_snapshot_soa;
+
+typedef struct kai_op {
+    int64_t seq;   /* position in commit order */
+    int32_t kind;  /* kai_op_kind */
+    int32_t pod;
+    int32_t node;
+    int32_t job;
+} kai_op;
+
+/* per queue, in KAI_Q_* order: plugins/proportion/resource_share/resource_share.go:12-21 */
+typedef struct kai_queue_share {
+    double fair_share[KAI_Q_NRES];
+    double allocated[KAI_Q_NRES];
+    double allocated_non_preemptible[KAI_Q_NRES];
+    double request[KAI_Q_NRES];
+    double deserved[KAI_Q_NRES];
+    double max_allowed[KAI_Q_NRES];
+} kai_queue_share;
+
+typedef struct kai_node_state {
+    double idle[KAI_MAX_RES];
+    double releasing[KAI_MAX_RES];
+    double used[KAI_MAX_RES];
+} kai_node_state;
+
+/* engine statistics of the last kai_action_execute (measurement) */
+typedef struct kai_action_stats {
+    int64_t decisions;          /* allocateTask executions (ended in allocate / pipeline / fail) */
+    int64_t node_scans;         /* full passes over a node set */
+    int64_t nodes_scanned;      /* Σ node-set sizes over those passes */
+    int64_t jobs_attempted;
+    int64_t jobs_committed;
+    int64_t rollbacks;
+    double kernel_ms;           /* HIP-event time of the action kernel on its stream */
+    double upload_ms;           /* snapshot → HBM (session_open only) */
+    int64_t reserved[8];
+} kai_action_stats;
+
+typedef struct kai_core kai_core; /* opaque */
+
+/* replaces: scheduler.NewScheduler wiring (pkg/scheduler/scheduler.go:53-101); gpu_ids = HIP device ordinals */
+int kai_core_create(const kai_config* cfg, int n_gpus, const int* gpu_ids, kai_core** out);
+int kai_core_destroy(kai_core* core);
+
+/* replaces: framework.OpenSession + every OnSessionOpen on the path (framework/framework.go:32-65):
+ * node accounting from the pods (api/node_info/node_info.go:457-493), proportion totals / queue usage /
+ * fair-share division (plugins/proportion/proportion.go:242-423). */
+int kai_session_open(kai_core* core, const kai_snapshot_soa* snap);
+
+/* replaces: ssn.QueueFairShare / QueueAllocatedResources / QueueDeservedResources
+ * (plugins/proportion/proportion.go:508-521) */
+int kai_queue_shares(kai_core* core, kai_queue_share* out, int cap);
+
+/* replaces: Action.Execute(ssn) (actions/allocate/allocate.go:46-77, reclaim.go:47-100, preempt.go:46-97,
+ * consolidation.go:32-78) up to, not including, the cache side effects of Statement.Commit
+ * (framework/statement.go:536-575): the committed operations come back in commit order and the Go shim
+ * replays them through cache.Bind / cache.Evict / cache.TaskPipelined. */
+int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_cap, int64_t* n_ops);
+
+/* replaces: Session.OrderedNodesByTask + FittingNode for one task (framework/session.go:201-264),
+ * against the session's current node state.  nodeset_bitmap may be NULL (= all nodes).
+ * node_idx_out = -1 when nothing fits. */
+int kai_best_node(kai_core* core, int32_t pod_idx, const uint32_t* nodeset_bitmap, int pipeline_only,
+                  int32_t* node_idx_out, int* is_pipeline_out);
+
+/* session-state read-back (what the shim mirrors into PodInfo.Status/NodeName and NodeInfo.Idle/Releasing) */
+int kai_pod_states(kai_core* core, int32_t* status_out, int32_t* node_out, int cap);
+int kai_node_states(kai_core* core, kai_node_state* out, int cap);
+
+int kai_action_stats_get(kai_core* core, kai_action_stats* out);
+
+/* replaces: framework.CloseSession (framework/framework.go:67-78) — frees the session's HBM */
+int kai_session_close(kai_core* core);
+
+/* human-readable detail for the last non-zero status on this handle (never NULL) */
+const char* kai_last_error(kai_core* core);
+
+/* library build info: "kai_core <abi> gfx950 …" */
+const char* kai_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAI_CORE_H */

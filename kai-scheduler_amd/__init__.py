@@ -1,0 +1,10 @@
+"""kai-scheduler_amd — host side of the MI355X-native KAI scheduling-cycle core.
+
+Holds only what the hot path needs: `csrc/` (HIP kernels + the C ABI of
+include/kai_core.h), `abi` (ctypes mirror + structure-of-arrays snapshot), `core` (the reference's
+Session / Action interface re-exposed over the C ABI) and `synth` (synthetic cluster snapshots of
+BASELINE.json's configs).
+"""
+from . import abi  # noqa: F401
+
+__all__ = ["abi"]

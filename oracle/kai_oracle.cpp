@@ -1,0 +1,852 @@
+// kai_oracle.cpp — TEST INFRASTRUCTURE.  CPU oracle for the KAI scheduling-cycle hot path.
+//
+// A plain C++ restatement (single thread, float64, -ffp-contract=off) of the reference's
+// allocate action and the plugin chain it calls, in the reference's evaluation order.
+// Citations are file:line under /root/reference/pkg/scheduler.  The product library never links
+// this file; tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load liboracle.so as
+// the checker only.
+//
+// Pinned against the reference's own golden tables: tests/golden/*.json (made by tools/go_fixtures.py
+// from the Go test files) — see tests/test_oracle_golden.py.
+//
+// Go-map iteration orders that leak into results are fixed to index order.
+#include <chrono>
+#include <cstring>
+
+#include "oracle_session.hpp"
+
+namespace orc {
+
+// =====================================================================================================
+// snapshot → object graph (what cache.Snapshot + test_utils.BuildSession hand the session)
+// =====================================================================================================
+void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
+    cfg = *c; R = s->n_res;
+    const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues;
+    nodes.resize(N); pods.resize(P); podsets.resize(S); jobs.resize(J); queues.resize(Q);
+    nPodClasses = s->n_pod_classes; nNodeClasses = s->n_node_classes;
+    if (s->class_fit) classFit.assign(s->class_fit, s->class_fit + size_t(nPodClasses) * nNodeClasses);
+
+    auto toResource = [&](const double* base, int stride, int i) {
+        Resource r; r.milliCpu = base[KAI_RES_CPU * stride + i]; r.memory = base[KAI_RES_MEM * stride + i]; r.gpus = base[KAI_RES_GPU * stride + i];
+        for (int k = KAI_RES_PODS; k < R; k++) { double v = base[size_t(k) * stride + i]; if (v != 0) r.scalars[k] = int64_t(v); }  // ResourceFromResourceList skips zero quantities
+        return r;
+    };
+    for (int i = 0; i < N; i++) {  // api/node_info/node_info.go:107-155 NewNodeInfo
+        NodeInfo& n = nodes[i]; n.idx = i; n.nameRank = s->node_name_rank[i]; n.flags = s->node_flags[i];
+        n.gpuCountLabel = s->node_gpu_count ? s->node_gpu_count[i] : -1; n.nodeClass = s->node_class ? s->node_class[i] : 0;
+        n.Allocatable = toResource(s->node_allocatable, N, i); n.Idle = n.Allocatable;
+    }
+    for (int q = 0; q < Q; q++) {
+        QueueInfo& qi = queues[q]; qi.idx = q; qi.uidRank = s->queue_uid_rank[q]; qi.parent = s->queue_parent[q];
+        qi.priority = s->queue_priority[q]; qi.createdNs = s->queue_created_ns[q];
+    }
+    for (int q = 0; q < Q; q++) if (queues[q].parent >= 0) queues[queues[q].parent].children.push_back(q);  // cache/cluster_info/queue.go:95-103
+    for (int k = 0; k < S; k++) { PodSet& ps = podsets[k]; ps.idx = k; ps.job = s->podset_job[k]; ps.minAvailable = s->podset_min_available[k]; ps.nameRank = s->podset_name_rank[k]; }
+    for (int j = 0; j < J; j++) {
+        PodGroupInfo& g = jobs[j]; g.idx = j; g.uidRank = s->job_uid_rank[j]; g.queue = s->job_queue[j]; g.priority = s->job_priority[j];
+        g.preemptible = s->job_preemptible[j] != 0; g.createdNs = s->job_created_ns[j];
+        for (int k = 0; k < s->job_n_podsets[j]; k++) g.podSets.push_back(&podsets[s->job_first_podset[j] + k]);
+        std::sort(g.podSets.begin(), g.podSets.end(), [](PodSet* a, PodSet* b) { return a->nameRank < b->nameRank; });
+    }
+    for (int p = 0; p < P; p++) {  // api/pod_info/pod_info.go:172-214 NewTaskInfo
+        PodInfo& t = pods[p]; t.idx = p; t.uidRank = s->pod_uid_rank[p]; t.job = s->pod_job[p]; t.podset = s->pod_podset[p];
+        t.status = s->pod_status[p]; t.node = s->pod_node[p]; t.flags = s->pod_flags ? s->pod_flags[p] : 0;
+        t.taskPriority = s->pod_task_priority ? s->pod_task_priority[p] : 0; t.createdNs = s->pod_created_ns ? s->pod_created_ns[p] : 0;
+        t.podClass = s->pod_class ? s->pod_class[p] : 0; t.nominatedNode = s->pod_nominated_node ? s->pod_nominated_node[p] : -1;
+        t.resReq.milliCpu = s->pod_req[size_t(KAI_RES_CPU) * P + p]; t.resReq.memory = s->pod_req[size_t(KAI_RES_MEM) * P + p];
+        double g = s->pod_req[size_t(KAI_RES_GPU) * P + p];
+        if (g >= 1) { t.resReq.count = int64_t(g); t.resReq.portion = 1; }  // resource_requirment.go:52-58
+        for (int k = KAI_RES_PODS; k < R; k++) { double v = s->pod_req[size_t(k) * P + p]; if (v != 0) t.resReq.scalars[k] = int64_t(v); }
+    }
+    // jobs own their tasks (job_info.go AddTaskInfo), nodes hold the active-used ones (node_info.go:419-437 AddTasksToNode;
+    // test fixtures add them in sorted-UID order, nodes_fake/nodes.go:289-302 — order-free for whole-GPU pods)
+    for (int p = 0; p < P; p++) if (pods[p].job >= 0) jobs[pods[p].job].AddTaskInfo(&pods[p]);
+    std::vector<int> order(P); for (int p = 0; p < P; p++) order[p] = p;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return pods[a].uidRank < pods[b].uidRank; });
+    for (int p : order) { PodInfo& t = pods[p]; if (IsActiveUsedStatus(t.status) && t.node >= 0 && t.node < N) nodes[t.node].AddTask(&t); }
+}
+
+// =====================================================================================================
+// plugins/proportion
+// =====================================================================================================
+static ResourceQuantities QuantifyResourceRequirements(const ResourceRequirements& r) { return {r.milliCpu, r.memory, r.GetGpusQuota()}; }  // utils/utils.go:15-17
+static ResourceQuantities QuantifyResource(const Resource& r) { return {r.milliCpu, r.memory, r.gpus}; }                                   // utils/utils.go:11-13 (no MIG)
+
+// resource_division.go — all functions below operate on one sibling set, in index order
+namespace resource_division {
+static double getRemainingRequested(QueueAttributes* q, int r) {  // :317-325
+    double requested = q->share[r].GetRequestableShare(), fairShare = q->share[r].FairShare;
+    if (requested < fairShare) return 0;
+    return requested - fairShare;
+}
+static bool isQueueSatisfied(QueueAttributes* q, int r) {  // :253-262
+    const ResourceShare& s = q->share[r];
+    if (s.Request <= s.FairShare) return true;
+    if (s.MaxAllowed != KAI_UNLIMITED && s.MaxAllowed <= s.FairShare) return true;
+    return false;
+}
+struct Remaining { QueueAttributes* queue; double remainingAmount; };
+static double setDeservedResource(double total, std::vector<QueueAttributes*>& queues, int r) {  // :92-109
+    double remaining = total;
+    for (auto* q : queues) {
+        double deserved = q->share[r].Deserved; if (deserved == KAI_UNLIMITED) deserved = total;
+        double amount = std::fmin(deserved, q->share[r].GetRequestableShare());
+        q->share[r].FairShare += amount; remaining -= amount;
+    }
+    return remaining;
+}
+static double divideUpToFairShare(double totalResourceAmount, double kValue, std::vector<QueueAttributes*>& queues, int r, std::map<int, Remaining>& remainingRequested) {  // :164-222
+    for (;;) {
+        bool shouldRunAnotherRound = false; double amountToGiveInCurrentRound = totalResourceAmount;
+        // calcShareWeights :224-251
+        double totalWeights = 0; for (auto* q : queues) if (getRemainingRequested(q, r) > 0) totalWeights += q->share[r].OverQuotaWeight;  // :307-315
+        std::map<int, double> shareWeights; double shareWeightsSum = 0.0;
+        if (totalWeights != 0) for (auto* q : queues) {
+            if (isQueueSatisfied(q, r)) continue;
+            double nWeight = q->share[r].OverQuotaWeight / totalWeights, nUsage = q->share[r].Usage;
+            double w = std::fmax(0, nWeight + kValue * (nWeight - nUsage));
+            shareWeights[q->idx] = w; shareWeightsSum += w;
+        }
+        if (shareWeightsSum == 0) break;
+        for (auto* q : queues) {
+            if (totalResourceAmount == 0) break;
+            if (isQueueSatisfied(q, r)) continue;
+            double requested = getRemainingRequested(q, r);
+            if (q->share[r].OverQuotaWeight == 0) continue;
+            double fairShare = amountToGiveInCurrentRound * (shareWeights[q->idx] / shareWeightsSum);
+            // getResourceToGiveInCurrentRound :283-305
+            double resourceToGive = 0;
+            if (requested <= fairShare) { resourceToGive = requested; remainingRequested.erase(q->idx); }
+            else {
+                double roundFairShare = std::floor(fairShare);
+                if (roundFairShare > 0) resourceToGive = roundFairShare;
+                if (fairShare - resourceToGive > 0) remainingRequested[q->idx] = Remaining{q, fairShare - resourceToGive};
+            }
+            if (resourceToGive == 0) continue;
+            q->share[r].FairShare += resourceToGive; totalResourceAmount -= resourceToGive;
+            shouldRunAnotherRound = shouldRunAnotherRound || requested < fairShare;
+        }
+        if (!shouldRunAnotherRound || totalResourceAmount == 0) break;
+    }
+    return totalResourceAmount;
+}
+static double divideRemainingResource(double total, std::map<int, Remaining>& remainingRequested, int r) {  // :264-281 + :327-357
+    PriorityQueue<Remaining*> pq;
+    pq.lessFn = [](Remaining* const& l, Remaining* const& rr) {
+        if (l->remainingAmount > rr->remainingAmount) return true;
+        if (l->remainingAmount < rr->remainingAmount) return false;
+        if (l->queue->createdNs != rr->queue->createdNs) return l->queue->createdNs < rr->queue->createdNs;
+        return l->queue->uidRank < rr->queue->uidRank;
+    };
+    for (auto& kv : remainingRequested) pq.Push(&kv.second);
+    for (;;) {
+        if (total == 0 || pq.Empty()) break;
+        Remaining* largest = pq.Pop();
+        double give = std::fmin(1, total);
+        largest->queue->share[r].FairShare += give; total -= give;
+    }
+    return total;
+}
+static double divideOverQuotaResource(double total, double kValue, std::vector<QueueAttributes*>& queues, int r) {  // :111-162
+    std::map<int, std::vector<QueueAttributes*>, std::greater<int>> byPriority;  // priorities descending (:157-159)
+    for (auto* q : queues) byPriority[q->priority].push_back(q);
+    std::map<int, std::map<int, Remaining>> remainingRequested; double remaining = total;
+    for (auto& kv : byPriority) {
+        std::map<int, Remaining> fresh;
+        remaining = divideUpToFairShare(remaining, kValue, kv.second, r, fresh);
+        for (auto& x : fresh) remainingRequested[kv.first][x.first] = x.second;
+    }
+    for (auto& kv : byPriority) {
+        if (remaining <= 0) break;
+        auto it = remainingRequested.find(kv.first); if (it == remainingRequested.end() || it->second.empty()) continue;
+        remaining = divideRemainingResource(remaining, it->second, r);
+    }
+    return remaining;
+}
+static void SetResourcesShare(const ResourceQuantities& total, double kValue, std::vector<QueueAttributes*>& queues) {  // :26-44
+    for (int r = 0; r < 3; r++) {
+        double remaining = setDeservedResource(total[r], queues, r);
+        if (remaining > 0) divideOverQuotaResource(remaining, kValue, queues, r);
+    }
+}
+}  // namespace resource_division
+
+static void setFairShareForQueues(Session* ssn, const ResourceQuantities& total, double kValue, std::vector<QueueAttributes*>& queues) {  // proportion.go:410-423
+    if (queues.empty()) return;
+    resource_division::SetResourcesShare(total, kValue, queues);
+    for (auto* q : queues) {
+        std::vector<QueueAttributes*> children; for (int c : q->children) children.push_back(&ssn->qattrs[c]);
+        setFairShareForQueues(ssn, q->GetFairShare(), kValue, children);
+    }
+}
+
+void Session::proportionOnSessionOpen() {  // proportion.go:99-124, 242-423
+    if (!(cfg.plugins & KAI_PLUGIN_PROPORTION)) return;
+    double kValue = cfg.k_value; if (kValue <= 0.0) kValue = 0.0;  // proportion.go:77-84
+    // setTotalResources :252-288
+    totalResource = {0, 0, 0};
+    for (auto& node : nodes) {
+        if (node.flags & KAI_NODE_NOT_READY) continue;
+        bool shouldIgnoreGPUs = cfg.restrict_node_scheduling && !(node.flags & KAI_NODE_GPU_WORKER);
+        ResourceQuantities nr = shouldIgnoreGPUs ? ResourceQuantities{node.Allocatable.milliCpu, node.Allocatable.memory, 0} : QuantifyResource(node.Allocatable);
+        for (auto& kv : node.podInfos) {
+            PodInfo& pi = pods[kv.first];
+            if ((pi.flags & KAI_POD_FOREIGN_SCHEDULER) && IsActiveUsedStatus(kv.second.status)) { auto q = QuantifyResourceRequirements(pi.resReq); for (int r = 0; r < 3; r++) nr[r] -= q[r]; }
+        }
+        for (int r = 0; r < 3; r++) totalResource[r] += nr[r];
+    }
+    // createQueueResourceAttrs :307-345 is done by the caller filling deserved/limit/oqw/usage (needs the snapshot arrays)
+    // updateQueuesCurrentResourceUsage :347-401
+    for (auto& job : jobs) {
+        for (auto& byStatus : job.podStatusIndex) {
+            int status = byStatus.first;
+            if (AllocatedStatus(status)) {
+                for (auto& kv : byStatus.second) {
+                    ResourceQuantities res = QuantifyResourceRequirements(kv.second->accepted);
+                    for (int q = job.queue; q >= 0; q = qattrs[q].parent) for (int r = 0; r < 3; r++) {
+                        qattrs[q].share[r].Allocated += res[r]; qattrs[q].share[r].Request += res[r];
+                        if (!job.IsPreemptibleJob()) qattrs[q].share[r].AllocatedNotPreemptible += res[r];
+                    }
+                }
+            } else if (status == Pending) {
+                for (auto& kv : byStatus.second) {
+                    ResourceQuantities res = QuantifyResourceRequirements(kv.second->resReq);
+                    for (int q = job.queue; q >= 0; q = qattrs[q].parent) for (int r = 0; r < 3; r++) qattrs[q].share[r].Request += res[r];
+                }
+            }
+        }
+    }
+    // setFairShare :403-408
+    std::vector<QueueAttributes*> top; for (auto& q : qattrs) if (q.parent < 0) top.push_back(&q);
+    setFairShareForQueues(this, totalResource, kValue, top);
+}
+
+void Session::allocateHandler(PodInfo* task) {  // proportion.go:443-465
+    if (!(cfg.plugins & KAI_PLUGIN_PROPORTION)) return;
+    PodGroupInfo& job = jobs[task->job]; ResourceQuantities res = QuantifyResourceRequirements(task->accepted);
+    for (int q = job.queue; q >= 0; q = qattrs[q].parent) for (int r = 0; r < 3; r++) {
+        qattrs[q].share[r].Allocated += res[r];
+        if (!job.IsPreemptibleJob()) qattrs[q].share[r].AllocatedNotPreemptible += res[r];
+    }
+}
+void Session::deallocateHandler(PodInfo* task) {  // proportion.go:467-489
+    if (!(cfg.plugins & KAI_PLUGIN_PROPORTION)) return;
+    PodGroupInfo& job = jobs[task->job]; ResourceQuantities res = QuantifyResourceRequirements(task->accepted);
+    for (int q = job.queue; q >= 0; q = qattrs[q].parent) for (int r = 0; r < 3; r++) {
+        qattrs[q].share[r].Allocated -= res[r];
+        if (!job.IsPreemptibleJob()) qattrs[q].share[r].AllocatedNotPreemptible -= res[r];
+    }
+}
+
+// plugins/proportion/queue_order/queue_order.go:19-73
+int Session::queueOrder(int lQi, int rQi, PodGroupInfo* lJob, PodGroupInfo* rJob, const std::vector<PodGroupInfo*>& lVictims, const std::vector<PodGroupInfo*>& rVictims) {
+    QueueAttributes &lQ = qattrs[lQi], &rQ = qattrs[rQi];
+    auto jobReq = [&](PodGroupInfo* j) -> ResourceQuantities { if (!j) return {0, 0, 0}; return QuantifyResource(GetTasksToAllocateInitResource(j, false)); };
+    // prioritizeUnderUtilized :87-98
+    { bool l = rqLess(lQ.GetFairShare(), lQ.GetAllocatedShare()), r = rqLess(rQ.GetFairShare(), rQ.GetAllocatedShare());
+      if (!l && r) return -1; if (l && !r) return 1; }
+    // prioritizeUnderQuotaWithJob :100-125
+    ResourceQuantities lAlloc = lQ.GetAllocatedShare(), rAlloc = rQ.GetAllocatedShare(), lReq = jobReq(lJob), rReq = jobReq(rJob);
+    for (int r = 0; r < 3; r++) { lAlloc[r] += lReq[r]; rAlloc[r] += rReq[r]; }
+    { bool l = rqLessEqual(lAlloc, lQ.GetDeservedShare()), r = rqLessEqual(rAlloc, rQ.GetDeservedShare());
+      if (l && !r) return -1; if (r && !l) return 1; }
+    // prioritizePrioritized :76-85
+    if (lQ.priority > rQ.priority) return -1;
+    if (lQ.priority < rQ.priority) return 1;
+    // penalizeZeroShareWithJob :127-176
+    { auto viol = [](QueueAttributes& q, const ResourceQuantities& withJob) { bool v = false; auto a = q.GetAllocatableShare(); for (int r = 0; r < 3; r++) { if (a[r] != 0) continue; if (withJob[r] > 0) v = true; } return v; };
+      bool l = viol(lQ, lAlloc), r = viol(rQ, rAlloc);
+      if (l && !r) return 1; if (!l && r) return -1; }
+    // prioritizeSmallerResourceShare :178-196 with calculateDominantResourceShareWithJob :242-273
+    { auto withJob = [&](QueueAttributes& q, const ResourceQuantities& req, const std::vector<PodGroupInfo*>& victims) {
+          ResourceQuantities saved = q.GetAllocatedShare();
+          for (int r = 0; r < 3; r++) q.share[r].Allocated += req[r];
+          for (auto* v : victims) { auto va = QuantifyResource(v->allocated); for (int r = 0; r < 3; r++) q.share[r].Allocated -= va[r]; }
+          double s = q.GetDominantResourceShare(totalResource);
+          for (int r = 0; r < 3; r++) q.share[r].Allocated = saved[r];
+          return s; };
+      double l = withJob(lQ, lReq, lVictims), r = withJob(rQ, rReq, rVictims);
+      if (l < r) return -1; if (l > r) return 1; }
+    // prioritizeSmallerResourceShareWithoutTask :198-212
+    { double l = lQ.GetDominantResourceShare(totalResource), r = rQ.GetDominantResourceShare(totalResource);
+      if (l < r) return -1; if (l > r) return 1; }
+    // prioritizeBasedOnAllocatableShare :214-224
+    { auto l = lQ.GetAllocatableShare(), r = rQ.GetAllocatableShare();
+      if (rqLessInAtLeastOneResource(l, r) && rqLessEqual(l, r)) return -1;
+      if (rqLessInAtLeastOneResource(r, l) && rqLessEqual(r, l)) return 1; }
+    // prioritizeBasedOnCreationTime :235-240
+    if (lQ.createdNs < rQ.createdNs) return -1;
+    return 1;
+}
+
+// capacity_policy/max_allowed_check.go:20-66
+bool Session::resultsOverLimit(const ResourceQuantities& req, PodGroupInfo* job) {
+    for (int q = job->queue; q >= 0; q = qattrs[q].parent) for (int r = 0; r < 3; r++) {
+        const ResourceShare& s = qattrs[q].share[r];
+        if (s.MaxAllowed == KAI_UNLIMITED) continue;
+        if (req[r] == 0) continue;
+        if (s.MaxAllowed < s.Allocated + req[r]) return true;
+    }
+    return false;
+}
+// capacity_policy/quota_check.go:27-77
+bool Session::resultsWithNonPreemptibleOverQuota(const ResourceQuantities& req, PodGroupInfo* job) {
+    if (job->IsPreemptibleJob()) return false;
+    for (int q = job->queue; q >= 0; q = qattrs[q].parent) for (int r = 0; r < 3; r++) {
+        const ResourceShare& s = qattrs[q].share[r];
+        if (s.Deserved == KAI_UNLIMITED) continue;
+        if (req[r] == 0) continue;
+        if (s.Deserved < s.AllocatedNotPreemptible + req[r]) return true;
+    }
+    return false;
+}
+bool Session::IsJobOverQueueCapacity(PodGroupInfo* job, const std::vector<PodInfo*>& tasks) {  // capacity_policy.go:26-36,76-84
+    if (!(cfg.plugins & KAI_PLUGIN_PROPORTION)) return false;  // session_plugins.go:315-327 default: schedulable
+    ResourceQuantities q{0, 0, 0};
+    for (auto* pod : tasks) { q[2] += pod->resReq.GetGpusQuota(); q[0] += pod->resReq.milliCpu; q[1] += pod->resReq.memory; }
+    return resultsOverLimit(q, job) || resultsWithNonPreemptibleOverQuota(q, job);
+}
+bool Session::IsTaskAllocationOnNodeOverCapacity(PodInfo* task, PodGroupInfo* job, NodeInfo*) {  // capacity_policy.go:51-61
+    if (!(cfg.plugins & KAI_PLUGIN_PROPORTION)) return false;
+    // NodeInfo.GetRequiredInitQuota (api/node_info/node_info.go:734-744): for a whole-GPU request the GPU term is
+    // ceil(portion*mem/mem*100)/100 = 1 for any count >= 1, 0 for a CPU-only request.
+    ResourceQuantities q{task->resReq.milliCpu, task->resReq.memory, task->resReq.count >= 1 ? std::ceil(task->resReq.portion * 100.0) / 100.0 : 0.0};
+    return resultsOverLimit(q, job) || resultsWithNonPreemptibleOverQuota(q, job);
+}
+
+// =====================================================================================================
+// order functions
+// =====================================================================================================
+static void minAvailableState(PodGroupInfo* g, bool& below, bool& above, bool& exactly) {  // plugins/elastic/elastic.go:53-65
+    exactly = true;
+    for (auto* sg : g->podSets) {
+        int32_t n = int32_t(sg->numActiveAllocatedTasks);
+        if (n < sg->minAvailable) { below = true; above = false; exactly = false; return; }
+        if (n > sg->minAvailable) exactly = false;
+    }
+    below = false; above = !exactly;
+}
+bool Session::JobOrderFn(PodGroupInfo* l, PodGroupInfo* r) {  // session_plugins.go:227-242
+    if (cfg.plugins & KAI_PLUGIN_PRIORITY) {  // plugins/priority/priority.go:41-54
+        if (l->priority > r->priority) return true;
+        if (l->priority < r->priority) return false;
+    }
+    if (cfg.plugins & KAI_PLUGIN_ELASTIC) {  // plugins/elastic/elastic.go:25-51
+        bool lb, la, le, rb, ra, re; minAvailableState(l, lb, la, le); minAvailableState(r, rb, ra, re);
+        if (lb && !rb) return true;
+        if (le && ra) return true;
+        if (!lb && rb) return false;
+        if (la && re) return false;
+    }
+    if (l->createdNs == r->createdNs) return l->uidRank < r->uidRank;
+    return l->createdNs < r->createdNs;
+}
+bool Session::TaskOrderFn(PodInfo* l, PodInfo* r) {  // session_plugins.go:244-260 (kubeflow / ray role labels are absent on the path)
+    if (cfg.plugins & KAI_PLUGIN_TASKORDER) {  // plugins/taskorder/task_order.go:28-63
+        bool ll = l->flags & KAI_POD_HAS_TASK_PRIORITY, rl = r->flags & KAI_POD_HAS_TASK_PRIORITY;
+        if (ll && !rl) return true;
+        if (!ll && rl) return false;
+        if (ll && rl) { if (l->taskPriority > r->taskPriority) return true; if (l->taskPriority < r->taskPriority) return false; }
+    }
+    if (l->createdNs == r->createdNs) return l->uidRank < r->uidRank;
+    return l->createdNs < r->createdNs;
+}
+bool Session::PodSetOrderFn(PodSet* l, PodSet* r) {  // session_plugins.go:262-271 + plugins/subgrouporder/subgroup_order.go:31-62
+    if (!(cfg.plugins & KAI_PLUGIN_SUBGROUPORDER)) return l->nameRank < r->nameRank;
+    int ln = l->numActiveAllocatedTasks, rn = r->numActiveAllocatedTasks;
+    bool lSat = ln >= int(l->minAvailable), rSat = rn >= int(r->minAvailable);
+    if (!lSat && !rSat) return l->nameRank < r->nameRank;
+    if (!lSat) return true;
+    if (!rSat) return false;
+    double lr = double(ln) / double(l->minAvailable), rr = double(rn) / double(r->minAvailable);
+    if (lr < rr) return true;
+    if (rr < lr) return false;
+    return l->nameRank < r->nameRank;
+}
+bool Session::QueueOrderFn(int lQ, int rQ, PodGroupInfo* lJob, PodGroupInfo* rJob, const std::vector<PodGroupInfo*>& lV, const std::vector<PodGroupInfo*>& rV) {  // session_plugins.go:283-299
+    if (cfg.plugins & KAI_PLUGIN_PROPORTION) {
+        int j = queueOrder(lQ, rQ, lJob, rJob, lV, rV);
+        if (j != 0) return j < 0;
+    }
+    if (queues[lQ].createdNs == queues[rQ].createdNs) return queues[lQ].uidRank < queues[rQ].uidRank;
+    return queues[lQ].createdNs < queues[rQ].createdNs;
+}
+
+// =====================================================================================================
+// api/podgroup_info/allocation_info.go
+// =====================================================================================================
+const std::vector<PodInfo*>& Session::GetTasksToAllocate(PodGroupInfo* job, bool isRealAllocation) {  // :27-54
+    if (job->hasTasksToAllocate) return job->tasksToAllocate;
+    std::vector<PodInfo*> out;
+    PriorityQueue<PodSet*> sgq; sgq.lessFn = [this](PodSet* const& a, PodSet* const& b) { return PodSetOrderFn(a, b); };
+    for (auto* ps : job->podSets) sgq.Push(ps);
+    int numUnsatisfied = 0; for (auto* ps : job->podSets) if (ps->numActiveAllocatedTasks < int(ps->minAvailable)) numUnsatisfied++;  // :164-177
+    int maxNumSubGroups = numUnsatisfied > 0 ? numUnsatisfied : 1, numSubGroupsToAllocate = 0;
+    while (!sgq.Empty() && numSubGroupsToAllocate < maxNumSubGroups) {
+        PodSet* next = sgq.Pop();
+        PriorityQueue<PodInfo*> tq; tq.lessFn = [this](PodInfo* const& a, PodInfo* const& b) { return TaskOrderFn(a, b); };
+        for (auto& kv : next->podInfos) if (kv.second->ShouldAllocate(isRealAllocation)) tq.Push(kv.second);  // :115-125
+        if (tq.Empty()) continue;
+        int maxTasks;  // getNumTasksToAllocate :145-153
+        if (next->numActiveAllocatedTasks >= int(next->minAvailable)) { int n = 0; for (auto& kv : next->podInfos) if (kv.second->ShouldAllocate(isRealAllocation)) n++; maxTasks = int(std::fmin(double(n), 1)); }
+        else maxTasks = int(next->minAvailable) - next->numActiveAllocatedTasks;
+        int taken = 0; while (!tq.Empty() && taken < maxTasks) { out.push_back(tq.Pop()); taken++; }
+        numSubGroupsToAllocate += 1;
+    }
+    job->tasksToAllocate = out; job->hasTasksToAllocate = true;
+    return job->tasksToAllocate;
+}
+const Resource& Session::GetTasksToAllocateInitResource(PodGroupInfo* job, bool isRealAllocation) {  // :88-113
+    if (job->hasInitResource) return job->tasksToAllocateInitResource;
+    Resource total;
+    for (auto* task : GetTasksToAllocate(job, isRealAllocation)) if (task->ShouldAllocate(isRealAllocation)) total.Add(task->resReq.AsResource());
+    job->tasksToAllocateInitResource = total; job->hasInitResource = true;
+    return job->tasksToAllocateInitResource;
+}
+
+// =====================================================================================================
+// node ordering and predicates
+// =====================================================================================================
+void Session::NodePreOrderFn(PodInfo* task, const std::vector<NodeInfo*>& fitting) {  // plugins/nodeplacement/nodeplacement.go:82-87, pack.go:35-43,66-86
+    if (!(cfg.plugins & KAI_PLUGIN_NODEPLACEMENT)) return;
+    bool cpuOnly = task->IsCPUOnlyRequest();
+    int strategy = cpuOnly ? cfg.cpu_strategy : cfg.gpu_strategy;
+    if (strategy == KAI_SPREAD) return;
+    int r = cpuOnly ? KAI_RES_CPU : KAI_RES_GPU;
+    double maxA = 0, minA = DBL_MAX;
+    for (auto* node : fitting) {
+        double current = node->NonAllocatedResource(r);
+        if (node->Allocatable.Get(r) == 0) continue;
+        if (current < minA) minA = current;
+        if (current > maxA) maxA = current;
+    }
+    podAllocatableRange[task->idx] = {minA, maxA};
+}
+double Session::NodeOrderFn(PodInfo* task, NodeInfo* node) {  // session_plugins.go:427-437; plugin order conf_util/scheduler_conf_util.go:39-60
+    double score = 0;
+    // nodeavailability (plugins/nodeavailability/nodeavailability.go:29-40)
+    if (cfg.plugins & KAI_PLUGIN_NODEAVAILABILITY) score += node->IsTaskAllocatable(task) ? 100.0 : 0.0;
+    // gpusharingorder (plugins/gpusharingorder/gpusharingorder.go:29-44): no shared-GPU groups on the path
+    score += 0.0;
+    // resourcetype (plugins/resourcetype/resourcetype.go:29-41)
+    if (cfg.plugins & KAI_PLUGIN_RESOURCETYPE) score += (task->IsCPUOnlyRequest() && node->IsCPUOnlyNode()) ? 10.0 : 0.0;
+    // nominatednode (plugins/nominatednode/nominatednode.go:29-41)
+    if (cfg.plugins & KAI_PLUGIN_NOMINATEDNODE) score += (task->nominatedNode >= 0 && task->nominatedNode == node->idx) ? 1000000.0 : 0.0;
+    // nodeplacement (plugins/nodeplacement/nodeplacement.go:75-80)
+    bool cpuOnly = task->IsCPUOnlyRequest(); int r = cpuOnly ? KAI_RES_CPU : KAI_RES_GPU;
+    int strategy = cpuOnly ? cfg.cpu_strategy : cfg.gpu_strategy;
+    double place;
+    if (strategy == KAI_SPREAD) {  // spread.go:16-36
+        double resourceCount = r == KAI_RES_GPU ? double(node->GetNumberOfGPUsInNode()) : node->Allocatable.Get(r);
+        place = resourceCount == 0 ? 0.0 : node->NonAllocatedResource(r) / resourceCount;
+    } else {  // pack.go:20-33,45-64
+        auto range = podAllocatableRange[task->idx];
+        double minA = range.first, maxA = range.second, cur = node->NonAllocatedResource(r), overall = node->Allocatable.Get(r);
+        if (overall == 0) place = 0.0;
+        else if (maxA == 0) place = 0.0;
+        else if (minA == maxA) place = 9.0;
+        else place = 9.0 * (1 - (cur - minA) / (maxA - minA));
+    }
+    if (cfg.plugins & KAI_PLUGIN_NODEPLACEMENT) score += place;
+    // topology (plugins/topology/node_scoring.go:17-35): no preferred level on this path
+    score += 0.0;
+    return score;
+}
+std::vector<NodeInfo*> Session::OrderedNodesByTask(const std::vector<NodeInfo*>& nodeSet, PodInfo* task) {  // session.go:234-264, 466-485
+    NodePreOrderFn(task, nodeSet);
+    std::map<double, std::vector<NodeInfo*>, std::greater<double>> nodeScores;
+    for (auto* node : nodeSet) nodeScores[NodeOrderFn(task, node)].push_back(node);
+    std::vector<NodeInfo*> ordered; ordered.reserve(nodeSet.size());
+    for (auto& kv : nodeScores) {
+        std::sort(kv.second.begin(), kv.second.end(), [](NodeInfo* a, NodeInfo* b) { return a->nameRank < b->nameRank; });
+        ordered.insert(ordered.end(), kv.second.begin(), kv.second.end());
+    }
+    stats.nodeScans++; stats.nodesScanned += int64_t(nodeSet.size());
+    return ordered;
+}
+bool Session::PredicateFn(PodInfo* task, PodGroupInfo* job, NodeInfo* node) {  // plugins/predicates/predicates.go:173-262
+    if (!(cfg.plugins & KAI_PLUGIN_PREDICATES)) return true;
+    if (IsTaskAllocationOnNodeOverCapacity(task, job, node)) return false;
+    // PredicateByNodeResourcesType (api/node_info/node_info.go:315-359) for regular / CPU-only requests
+    if (!task->IsCPUOnlyRequest()) {
+        if (task->resReq.GPUs() > 0 && (node->flags & KAI_NODE_HAS_DRA_GPUS)) return false;
+        if ((node->flags & KAI_NODE_MIG_ENABLED) && (node->flags & KAI_NODE_MIG_MIXED)) return false;
+    }
+    // checkMaxPodsWithGpuGroupReservation :264-285
+    if (!(node->Idle.GetScalar(KAI_RES_PODS) + node->Releasing.GetScalar(KAI_RES_PODS) > 0)) return false;
+    // CheckNodeConditionPredicate (scheduler_util/scheduler_utils.go:12-40)
+    if (node->flags & KAI_NODE_NOT_READY) return false;
+    // upstream kube-scheduler Filters, pre-evaluated per (pod class, node class)
+    if (!classFit.empty() && !classFit[size_t(task->podClass) * nNodeClasses + node->nodeClass]) return false;
+    if (cfg.restrict_node_scheduling) {  // :243-259
+        if (!task->IsCPUOnlyRequest()) { if (!(node->flags & KAI_NODE_GPU_WORKER)) return false; }
+        else if (!(node->flags & KAI_NODE_CPU_WORKER)) return false;
+    }
+    return true;
+}
+bool Session::FittingNode(PodInfo* task, NodeInfo* node) {  // session.go:201-232
+    if (!node->IsTaskAllocatableOnReleasingOrIdle(task)) return false;
+    return PredicateFn(task, &jobs[task->job], node);
+}
+
+// =====================================================================================================
+// framework/statement.go
+// =====================================================================================================
+bool Statement::Evict(PodInfo* task) {
+    PodGroupInfo& job = ssn->jobs[task->job]; if (task->node < 0) return false; NodeInfo& node = ssn->nodes[task->node];
+    int previousStatus = task->status; bool previousIsVirtual = task->isVirtualStatus;
+    job.UpdateTaskStatus(task, Releasing);
+    if (!node.UpdateTask(task)) return false;
+    ssn->deallocateHandler(task);
+    Operation op; op.name = opEvict; op.task = task; op.previousStatus = previousStatus; op.previousNode = node.idx; op.previousIsVirtual = previousIsVirtual;
+    operations.push_back(op); task->isVirtualStatus = true;
+    return true;
+}
+bool Statement::unevict(PodInfo* task, int previousStatus, int nodeIdx, bool previousIsVirtual) {
+    ssn->jobs[task->job].UpdateTaskStatus(task, previousStatus);
+    task->isVirtualStatus = previousIsVirtual;
+    if (nodeIdx >= 0) { NodeInfo& node = ssn->nodes[nodeIdx]; if (node.podInfos.count(task->idx)) node.UpdateTask(task); else node.AddTask(task); }
+    ssn->allocateHandler(task);
+    return true;
+}
+bool Statement::Pipeline(PodInfo* task, int nodeIdx, bool updateTaskIfExistsOnNode) {
+    PodGroupInfo& job = ssn->jobs[task->job]; NodeInfo& node = ssn->nodes[nodeIdx];
+    bool foundOnNode = node.podInfos.count(task->idx) > 0;
+    if (foundOnNode && !updateTaskIfExistsOnNode) return Unevict(task);  // :216-227
+    int previousStatus = task->status;
+    job.UpdateTaskStatus(task, Pipelined);
+    int previousNode = task->node; task->node = nodeIdx; bool previousIsVirtual = task->isVirtualStatus;
+    if (foundOnNode) node.UpdateTask(task); else if (!node.AddTask(task)) return false;
+    ssn->allocateHandler(task);
+    Operation op; op.name = opPipeline; op.task = task; op.previousStatus = previousStatus; op.previousNode = previousNode; op.nextNode = nodeIdx; op.previousIsVirtual = previousIsVirtual;
+    operations.push_back(op); task->isVirtualStatus = true;
+    return true;
+}
+bool Statement::Allocate(PodInfo* task, int nodeIdx) {
+    PodGroupInfo& job = ssn->jobs[task->job]; NodeInfo& node = ssn->nodes[nodeIdx];
+    job.UpdateTaskStatus(task, Allocated);
+    task->node = nodeIdx;
+    if (!node.AddTask(task)) return false;
+    ssn->allocateHandler(task);
+    Operation op; op.name = opAllocate; op.task = task; op.nextNode = nodeIdx; op.previousIsVirtual = task->isVirtualStatus;
+    operations.push_back(op); task->isVirtualStatus = true;
+    return true;
+}
+bool Statement::unallocate(PodInfo* task, bool previousIsVirtual) {
+    ssn->jobs[task->job].UpdateTaskStatus(task, Pending);
+    if (task->node < 0) return false;
+    ssn->nodes[task->node].RemoveTask(task);
+    task->node = -1; task->isVirtualStatus = previousIsVirtual;
+    ssn->deallocateHandler(task);
+    return true;
+}
+bool Statement::unpipeline(PodInfo* task, int previousNode, int previousStatus, bool previousIsVirtual) {
+    ssn->jobs[task->job].UpdateTaskStatus(task, previousStatus);
+    int hostname = task->node; task->node = previousNode; task->isVirtualStatus = previousIsVirtual;
+    if (hostname < 0) return false;
+    ssn->nodes[hostname].RemoveTask(task);
+    ssn->deallocateHandler(task);
+    return true;
+}
+bool Statement::ConvertAllAllocatedToPipelined(int jobIdx) {
+    size_t n = operations.size();
+    for (size_t i = 0; i < n; i++) {  // Go ranges over the slice header captured at loop start
+        Operation op = operations[i];
+        if (op.task->job != jobIdx || op.name != opAllocate) continue;
+        int nodeName = op.task->node;
+        if (!unallocate(op.task, true)) return false;
+        if (!Pipeline(op.task, nodeName, true)) return false;
+    }
+    std::vector<Operation> kept;
+    for (auto& op : operations) if (!(op.name != opUndo && op.task->job == jobIdx && op.name == opAllocate)) kept.push_back(op);
+    operations = kept;
+    return true;
+}
+void Statement::undoOperation(int index) {
+    if (!operationValid(index)) return;
+    Operation op = operations[index];
+    switch (op.name) {
+        case opEvict: unevict(op.task, op.previousStatus, op.previousNode, op.previousIsVirtual); break;
+        case opPipeline: unpipeline(op.task, op.previousNode, op.previousStatus, op.previousIsVirtual); break;
+        case opAllocate: unallocate(op.task, op.previousIsVirtual); break;
+        case opUndo: {  // reverse of an undo = redo the original operation (:606-623)
+            Operation orig = operations[op.operationIndex];
+            switch (orig.name) {
+                case opEvict: Evict(orig.task); break;
+                case opPipeline: Pipeline(orig.task, orig.nextNode, true); break;
+                case opAllocate: Allocate(orig.task, orig.nextNode); break;
+                case opUndo: undoOperation(orig.operationIndex); break;
+            }
+            break;
+        }
+    }
+    Operation u; u.name = opUndo; u.operationIndex = index; operations.push_back(u);
+}
+void Statement::Commit() {
+    for (int i = 0; i < int(operations.size()); i++) {
+        if (!operationValid(i)) continue;
+        Operation& op = operations[i]; if (op.name == opUndo) continue;
+        kai_op out; out.seq = int64_t(ssn->committed.size()); out.pod = op.task->idx; out.job = op.task->job; out.node = op.task->node;
+        switch (op.name) {
+            case opEvict: out.kind = KAI_OP_EVICT; out.node = op.previousNode; op.task->isVirtualStatus = false; break;  // commitEvict :128-150
+            case opPipeline: out.kind = KAI_OP_PIPELINE; break;                                                      // commitPipeline :427-429
+            case opAllocate: out.kind = KAI_OP_ALLOCATE; ssn->jobs[op.task->job].UpdateTaskStatus(op.task, Binding); break;  // commitAllocate → ssn.BindPod (session.go:111-126)
+            default: break;
+        }
+        ssn->committed.push_back(out);
+    }
+    operations.clear();
+}
+
+// =====================================================================================================
+// actions/utils/job_order_by_queue.go
+// =====================================================================================================
+std::function<bool(queueNode* const&, queueNode* const&)> JobsOrderByQueues::buildNodeOrderFn(bool reverseOrder) {  // :280-305
+    return [this, reverseOrder](queueNode* const& l, queueNode* const& r) {
+        if (l->childrenEmpty()) return !reverseOrder;
+        if (r->childrenEmpty()) return reverseOrder;
+        auto lb = getBestJobFromNode(l); auto rb = getBestJobFromNode(r);
+        bool result = ssn->QueueOrderFn(l->queue, r->queue, lb.first, rb.first, lb.second, rb.second);
+        return reverseOrder ? !result : result;
+    };
+}
+std::pair<PodGroupInfo*, std::vector<PodGroupInfo*>> JobsOrderByQueues::getBestJobFromNode(queueNode* node) {  // :309-346
+    if (node->isLeaf) {
+        if (node->childJobs.Empty()) return {nullptr, {}};
+        if (options.VictimQueue) { std::vector<PodGroupInfo*> v = poppedJobsByQueue[node->queue]; v.push_back(node->childJobs.Peek()); return {nullptr, v}; }
+        return {node->childJobs.Peek(), {}};
+    }
+    return getBestJobFromNode(node->childNodes.Peek());
+}
+queueNode* JobsOrderByQueues::getNextNode(PriorityQueue<queueNode*>& pq) {  // :194-217
+    if (pq.Empty()) return nullptr;
+    queueNode* node = pq.Peek();
+    if (node->needsReorder) { pq.Fix(0); node->needsReorder = false; return getNextNode(pq); }
+    if (node->childrenEmpty()) return nullptr;
+    return node;
+}
+queueNode* JobsOrderByQueues::traverseToLeaf(PriorityQueue<queueNode*>& pq) {  // :179-191
+    queueNode* node = getNextNode(pq); if (!node) return nullptr;
+    if (node->isLeaf) return node;
+    return traverseToLeaf(node->childNodes);
+}
+PodGroupInfo* JobsOrderByQueues::PopNextJob() {  // :61-89
+    if (IsEmpty()) return nullptr;
+    queueNode* leaf = traverseToLeaf(rootNodes); if (!leaf) return nullptr;
+    PodGroupInfo* job = leaf->childJobs.Pop();
+    if (options.VictimQueue) poppedJobsByQueue[leaf->queue].push_back(job);
+    handlePopFromNode(leaf);
+    return job;
+}
+void JobsOrderByQueues::handlePopFromNode(queueNode* node) {  // :221-245
+    if (node->childrenLen() == 0) {
+        if (node->parent) node->parent->childNodes.Pop(); else rootNodes.Pop();
+        auto it = queueNodes.find(node->queue);
+        if (it != queueNodes.end() && it->second.get() == node) { graveyard.push_back(std::move(it->second)); queueNodes.erase(it); }
+        if (node->parent) handlePopFromNode(node->parent);
+        return;
+    }
+    markAncestorsForReorder(node);
+}
+void JobsOrderByQueues::ensureAncestorChainForPush(queueNode* childNode, const QueueInfo& childQueue) {  // :134-176
+    if (childQueue.parent < 0) {
+        if (childNode->parent == nullptr) {
+            if (!rootInit) { rootNodes.lessFn = buildNodeOrderFn(options.VictimQueue); rootInit = true; }
+            rootNodes.Push(childNode);
+        }
+        return;
+    }
+    const QueueInfo& parentQueue = ssn->queues[childQueue.parent];
+    bool parentNodeIsNew = queueNodes.find(parentQueue.idx) == queueNodes.end();
+    if (parentNodeIsNew) {
+        auto n = std::make_unique<queueNode>(); n->queue = parentQueue.idx; n->isLeaf = false; n->childNodes.lessFn = buildNodeOrderFn(options.VictimQueue);
+        queueNodes[parentQueue.idx] = std::move(n);
+    }
+    queueNode* parentNode = queueNodes[parentQueue.idx].get();
+    if (childNode->parent == nullptr) { childNode->parent = parentNode; parentNode->childNodes.Push(childNode); }
+    if (parentNodeIsNew) ensureAncestorChainForPush(parentNode, parentQueue);
+}
+void JobsOrderByQueues::PushJob(PodGroupInfo* job) {  // :91-120
+    const QueueInfo& leafQueue = ssn->queues[job->queue];
+    if (!leafQueue.IsLeafQueue()) return;
+    bool needsLinking = queueNodes.find(job->queue) == queueNodes.end();
+    if (needsLinking) {
+        auto n = std::make_unique<queueNode>(); n->queue = job->queue; n->isLeaf = true; n->childJobs.maxQueueSize = options.MaxJobsQueueDepth;
+        bool victim = options.VictimQueue; Session* s = ssn;
+        n->childJobs.lessFn = [s, victim](PodGroupInfo* const& l, PodGroupInfo* const& r) { return victim ? !s->JobOrderFn(l, r) : s->JobOrderFn(l, r); };  // :249-262
+        queueNodes[job->queue] = std::move(n);
+    }
+    queueNode* leaf = queueNodes[job->queue].get();
+    leaf->childJobs.Push(job);
+    if (needsLinking) ensureAncestorChainForPush(leaf, leafQueue);
+    markAncestorsForReorder(leaf);
+}
+void JobsOrderByQueues::InitializeWithJobs(const std::vector<PodGroupInfo*>& jobsToOrder) {  // input_jobs.go:21-68
+    for (auto* job : jobsToOrder) {
+        if (options.FilterUnready && !job->IsReadyForScheduling()) continue;
+        if (options.FilterNonPending && job->GetNumPendingTasks() == 0) continue;
+        if (options.FilterNonPreemptible && !job->IsPreemptibleJob()) continue;
+        bool isJobActive = false; for (auto* t : job->AllPods()) if (IsActiveAllocatedStatus(t->status)) { isJobActive = true; break; }
+        if (options.FilterNonActiveAllocated && !isJobActive) continue;
+        if (job->queue < 0) continue;                          // queue (or its parent) missing
+        if (!ssn->queues[job->queue].IsLeafQueue()) continue;
+        PushJob(job);
+    }
+}
+
+// =====================================================================================================
+// actions/common/allocate.go
+// =====================================================================================================
+bool Session::allocateTaskToNode(Statement& stmt, PodInfo* task, NodeInfo* node, bool isPipelineOnly) {  // :165-174
+    bool taskAllocatable = node->IsTaskAllocatable(task);
+    if (!isPipelineOnly && taskAllocatable) return stmt.Allocate(task, node->idx);
+    return stmt.Pipeline(task, node->idx, !isPipelineOnly);
+}
+bool Session::allocateTask(Statement& stmt, const std::vector<NodeInfo*>& nodeSet, PodInfo* task, bool isPipelineOnly) {  // :121-163
+    // PrePredicateFn (k8s PreFilters + MaxNodeResources, k8s_internal/predicates/maxNodeResources.go:59-96) only short-circuits
+    // a task that no node can fit; the per-node fit below reaches the same verdict, so it is not restated.
+    stats.decisions++;
+    bool success = false;
+    for (auto* node : OrderedNodesByTask(nodeSet, task)) {
+        if (!FittingNode(task, node)) continue;
+        success = allocateTaskToNode(stmt, task, node, isPipelineOnly);
+        if (success) break;
+    }
+    return success;
+}
+bool Session::allocatePodSet(Statement& stmt, const std::vector<NodeInfo*>& nodeSet, PodGroupInfo* job, PodSet*, const std::vector<PodInfo*>& tasks, bool isPipelineOnly) {  // :83-107
+    // SubsetNodesFn without a topology constraint returns the node set unchanged (plugins/topology/job_filtering.go:47-49)
+    int cp = stmt.Checkpoint();
+    bool ok = true;
+    for (auto* task : tasks) if (!allocateTask(stmt, nodeSet, task, isPipelineOnly)) { ok = false; break; }  // allocateTasksOnNodeSet :109-119
+    if (ok) return true;
+    stmt.Rollback(cp); stats.rollbacks++;
+    return false;
+}
+bool Session::AllocateJob(Statement& stmt, const std::vector<NodeInfo*>& nodeSet, PodGroupInfo* job, bool isPipelineOnly) {  // :20-36
+    std::vector<PodInfo*> tasksToAllocate = GetTasksToAllocate(job, !isPipelineOnly);
+    if (IsJobOverQueueCapacity(job, tasksToAllocate)) return false;
+    // allocateSubGroupSet on the root (:38-60): one node set, then allocateSubGroupSetOnNodes (:62-81)
+    int cp = stmt.Checkpoint();
+    std::vector<PodSet*> ordered = job->podSets;  // root's child pod-sets, orderedPodSets :270-277
+    std::sort(ordered.begin(), ordered.end(), [this](PodSet* a, PodSet* b) { return PodSetOrderFn(a, b); });
+    bool ok = true;
+    for (auto* ps : ordered) {
+        std::vector<PodInfo*> podSetTasks; for (auto* t : tasksToAllocate) if (t->podset == ps->idx) podSetTasks.push_back(t);  // filterTasksForPodSet :241-257
+        if (!allocatePodSet(stmt, nodeSet, job, ps, podSetTasks, isPipelineOnly)) { ok = false; break; }
+    }
+    if (ok) return true;
+    stmt.Rollback(cp); stats.rollbacks++;
+    return false;
+}
+
+// =====================================================================================================
+// actions/allocate/allocate.go
+// =====================================================================================================
+void Session::executeAllocate() {
+    JobsOrderInitOptions o; o.FilterNonPending = true; o.FilterUnready = true; o.MaxJobsQueueDepth = cfg.queue_depth[KAI_ACTION_ALLOCATE] == 0 ? -1 : cfg.queue_depth[KAI_ACTION_ALLOCATE];
+    JobsOrderByQueues jobsOrder(this, o);
+    std::vector<PodGroupInfo*> all; for (auto& j : jobs) all.push_back(&j);
+    jobsOrder.InitializeWithJobs(all);
+    std::vector<NodeInfo*> allNodes; for (auto& n : nodes) allNodes.push_back(&n);
+    while (!jobsOrder.IsEmpty()) {
+        PodGroupInfo* job = jobsOrder.PopNextJob(); if (!job) break;
+        Statement stmt(this);
+        stats.jobsAttempted++;
+        // attemptToAllocateJob :79-111
+        bool ok = AllocateJob(stmt, allNodes, job, false);
+        if (ok && job->ShouldPipelineJob()) { if (!stmt.ConvertAllAllocatedToPipelined(job->idx)) ok = false; }
+        if (ok) {
+            stats.jobsCommitted++;
+            stmt.Commit();
+            if (HasTasksToAllocate(job, true)) { jobsOrder.PushJob(job); continue; }
+        } else {
+            stmt.Discard();
+        }
+    }
+}
+
+}  // namespace orc
+
+// =====================================================================================================
+// C entry points (ctypes)
+// =====================================================================================================
+extern "C" {
+
+static void fill_shares(const orc::Session& ssn, kai_queue_share* out) {
+    for (size_t q = 0; q < ssn.qattrs.size(); q++) for (int r = 0; r < 3; r++) {
+        const orc::ResourceShare& s = ssn.qattrs[q].share[r];
+        out[q].fair_share[r] = s.FairShare; out[q].allocated[r] = s.Allocated; out[q].allocated_non_preemptible[r] = s.AllocatedNotPreemptible;
+        out[q].request[r] = s.Request; out[q].deserved[r] = s.Deserved; out[q].max_allowed[r] = s.MaxAllowed;
+    }
+}
+
+// One full cycle: open session, run the listed actions in order, report.
+// shares_open / shares_final / nodes_out / stats may be NULL.  elapsed_ms_out excludes the snapshot load.
+int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const int* actions, int n_actions,
+                   kai_op* ops_out, int64_t ops_cap, int64_t* n_ops, int32_t* pod_status_out, int32_t* pod_node_out,
+                   kai_queue_share* shares_open, kai_queue_share* shares_final, kai_node_state* nodes_out,
+                   kai_action_stats* stats, double* elapsed_ms_out) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || snap->n_res < 4 || snap->n_res > KAI_MAX_RES) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn;
+    ssn.load(cfg, snap);
+    auto t0 = std::chrono::steady_clock::now();
+    // createQueueResourceAttrs (plugins/proportion/proportion.go:307-345)
+    const int Q = snap->n_queues; ssn.qattrs.resize(Q);
+    for (int q = 0; q < Q; q++) {
+        orc::QueueAttributes& a = ssn.qattrs[q]; a.idx = q; a.uidRank = ssn.queues[q].uidRank; a.parent = ssn.queues[q].parent; a.children = ssn.queues[q].children;
+        a.createdNs = ssn.queues[q].createdNs; a.priority = ssn.queues[q].priority;
+        for (int r = 0; r < 3; r++) {
+            double deserved = snap->queue_deserved[r * Q + q], limit = snap->queue_limit[r * Q + q];
+            if (r == KAI_Q_MEM) { deserved = std::fmax(KAI_UNLIMITED, deserved * 1000000.0); limit = std::fmax(KAI_UNLIMITED, limit * 1000000.0); }  // :327-328
+            a.share[r].Deserved = deserved; a.share[r].MaxAllowed = limit; a.share[r].OverQuotaWeight = snap->queue_oqw[r * Q + q];
+            a.share[r].Usage = snap->queue_usage ? snap->queue_usage[r * Q + q] : 0.0;
+        }
+    }
+    ssn.proportionOnSessionOpen();
+    if (shares_open) fill_shares(ssn, shares_open);
+    for (int i = 0; i < n_actions; i++) {
+        switch (actions[i]) {
+            case KAI_ACTION_ALLOCATE: ssn.executeAllocate(); break;
+            default: return KAI_ERR_UNSUPPORTED;
+        }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (elapsed_ms_out) *elapsed_ms_out = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (n_ops) *n_ops = int64_t(ssn.committed.size());
+    if (ops_out) { if (int64_t(ssn.committed.size()) > ops_cap) return KAI_ERR_CAPACITY; std::memcpy(ops_out, ssn.committed.data(), ssn.committed.size() * sizeof(kai_op)); }
+    if (pod_status_out) for (size_t p = 0; p < ssn.pods.size(); p++) pod_status_out[p] = ssn.pods[p].status;
+    if (pod_node_out) for (size_t p = 0; p < ssn.pods.size(); p++) pod_node_out[p] = ssn.pods[p].node;
+    if (shares_final) fill_shares(ssn, shares_final);
+    if (nodes_out) for (size_t n = 0; n < ssn.nodes.size(); n++) for (int r = 0; r < ssn.R; r++) {
+        nodes_out[n].idle[r] = ssn.nodes[n].Idle.Get(r); nodes_out[n].releasing[r] = ssn.nodes[n].Releasing.Get(r); nodes_out[n].used[r] = ssn.nodes[n].Used.Get(r);
+    }
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = ssn.stats.decisions; stats->node_scans = ssn.stats.nodeScans; stats->nodes_scanned = ssn.stats.nodesScanned;
+                 stats->jobs_attempted = ssn.stats.jobsAttempted; stats->jobs_committed = ssn.stats.jobsCommitted; stats->rollbacks = ssn.stats.rollbacks; }
+    return KAI_OK;
+}
+
+// known-answer hooks for the reference's pure-function tests
+double kai_oracle_pack_score(double minA, double maxA, double cur, double overall) {  // plugins/nodeplacement/pack.go:45-64
+    if (overall == 0) return 0.0;
+    if (maxA == 0) return 0.0;
+    if (minA == maxA) return 9.0;
+    return 9.0 * (1 - (cur - minA) / (maxA - minA));
+}
+// resource_division.SetResourcesShare on one sibling set; arrays are [3][Q] in KAI_Q_* order; fair_share_out [3][Q]
+int kai_oracle_set_resources_share(int Q, const double* total, double k_value, const double* deserved, const double* limit, const double* oqw,
+                                   const double* request, const double* usage, const int* priority, const int64_t* created_ns, double* fair_share_out) {
+    std::vector<orc::QueueAttributes> qs(Q); std::vector<orc::QueueAttributes*> ptr;
+    for (int q = 0; q < Q; q++) {
+        qs[q].idx = q; qs[q].uidRank = q; qs[q].priority = priority ? priority[q] : 0; qs[q].createdNs = created_ns ? created_ns[q] : q;
+        for (int r = 0; r < 3; r++) { auto& s = qs[q].share[r]; s.Deserved = deserved[r * Q + q]; s.MaxAllowed = limit[r * Q + q]; s.OverQuotaWeight = oqw[r * Q + q]; s.Request = request[r * Q + q]; s.Usage = usage ? usage[r * Q + q] : 0; }
+        ptr.push_back(&qs[q]);
+    }
+    orc::resource_division::SetResourcesShare({total[0], total[1], total[2]}, k_value, ptr);
+    for (int q = 0; q < Q; q++) for (int r = 0; r < 3; r++) fair_share_out[r * Q + q] = qs[q].share[r].FairShare;
+    return KAI_OK;
+}
+
+const char* kai_oracle_version(void) { return "kai_oracle 1 (CPU restatement; test infrastructure)"; }
+}

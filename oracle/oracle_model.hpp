@@ -1,0 +1,319 @@
+// oracle_model.hpp — TEST INFRASTRUCTURE.  CPU restatement of the reference's session data model.
+//
+// This directory is the parity oracle.  Nothing in the product library links,
+// includes or executes it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+// and only as the checker.  It restates the reference algorithm in plain single-threaded C++ with
+// the reference's own evaluation order; every type cites the Go file it follows
+// (paths relative to /root/reference/pkg/scheduler).
+//
+// Pinning: the restatement is accepted against the reference's own golden tables transcribed by
+// tools/go_fixtures.py into tests/golden/*.json (see tests/test_oracle_golden.py).
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../include/kai_core.h"
+
+namespace orc {
+
+// ---------------------------------------------------------------- pod status: api/pod_status/pod_status.go:25-71
+enum : int {
+    Pending = KAI_POD_PENDING, Gated = KAI_POD_GATED, Allocated = KAI_POD_ALLOCATED, Pipelined = KAI_POD_PIPELINED,
+    Binding = KAI_POD_BINDING, Bound = KAI_POD_BOUND, Running = KAI_POD_RUNNING, Releasing = KAI_POD_RELEASING,
+    Succeeded = KAI_POD_SUCCEEDED, Failed = KAI_POD_FAILED, Unknown = KAI_POD_UNKNOWN, Deleted = KAI_POD_DELETED
+};
+inline bool IsActiveUsedStatus(int s) { return s & (Allocated | Pipelined | Binding | Bound | Running | Releasing); }
+inline bool IsActiveAllocatedStatus(int s) { return s & (Allocated | Pipelined | Binding | Bound | Running); }
+inline bool IsAliveStatus(int s) { return s & (Allocated | Pipelined | Binding | Bound | Running | Pending | Gated); }
+inline bool AllocatedStatus(int s) { return s & (Allocated | Bound | Binding | Running); }
+
+// ---------------------------------------------------------------- api/resource_info/base_resources.go
+// scalar resources are keyed by the resource-vector index (3 = pods, 4.. = extras)
+struct BaseResource {
+    double milliCpu = 0, memory = 0;
+    std::map<int, int64_t> scalars;
+    void Add(const BaseResource& o) {  // base_resources.go:56-63 (deletes a key that reaches 0)
+        milliCpu += o.milliCpu; memory += o.memory;
+        for (auto& kv : o.scalars) { scalars[kv.first] += kv.second; if (scalars[kv.first] == 0) scalars.erase(kv.first); }
+    }
+    void Sub(const BaseResource& o) {  // base_resources.go:65-72
+        milliCpu -= o.milliCpu; memory -= o.memory;
+        for (auto& kv : o.scalars) { scalars[kv.first] -= kv.second; if (scalars[kv.first] == 0) scalars.erase(kv.first); }
+    }
+    double GetScalar(int k) const { auto it = scalars.find(k); return it == scalars.end() ? 0.0 : double(it->second); }
+    bool LessEqual(const BaseResource& rr) const {  // base_resources.go:90-105
+        if (milliCpu > rr.milliCpu) return false;
+        if (memory > rr.memory) return false;
+        for (auto& kv : scalars) { auto it = rr.scalars.find(kv.first); if (it == rr.scalars.end() || kv.second > it->second) return false; }
+        return true;
+    }
+    bool IsEmpty() const {  // base_resources.go:119-130
+        if (milliCpu >= 10.0 || memory >= 10.0 * 1024 * 1024) return false;
+        for (auto& kv : scalars) if (kv.second >= 10) return false;
+        return true;
+    }
+};
+
+// api/resource_info/resource_info.go:16-19
+struct Resource : BaseResource {
+    double gpus = 0;
+    void Add(const Resource& o) { BaseResource::Add(o); gpus += o.gpus; }
+    void Sub(const Resource& o) { BaseResource::Sub(o); gpus -= o.gpus; }
+    double Get(int r) const { return r == KAI_RES_CPU ? milliCpu : r == KAI_RES_MEM ? memory : r == KAI_RES_GPU ? gpus : GetScalar(r); }
+};
+
+// api/resource_info/gpu_resource_requirment.go:230-234 — fixed-point GPU amount
+inline double getExtendedResourceGpus(double portion, int64_t count) {
+    int64_t portionAsDecimals = (int64_t)std::llround(portion * 100.0);  // math.Round: half away from zero
+    return double(portionAsDecimals * count) / 100.0;
+}
+
+// api/resource_info/resource_requirment.go:17-20 (+ gpu_resource_requirment.go:26-32; whole-GPU requests only:
+// fractional / gpu-memory / MIG / DRA pods are flagged KAI_POD_CPU_FALLBACK and never reach the path)
+struct ResourceRequirements : BaseResource {
+    int64_t count = 0; double portion = 0;
+    double GPUs() const { return getExtendedResourceGpus(portion, count); }
+    double GetGpusQuota() const { return GPUs(); }  // gpu_resource_requirment.go:163-178 without mig/dra
+    bool IsEmpty() const {                          // resource_requirment.go:99-104, gpu_resource_requirment.go:89-104
+        if (GPUs() > 0.01) return false;
+        return BaseResource::IsEmpty();
+    }
+    bool LessEqualResource(const Resource& rr) const {  // resource_requirment.go:126-140
+        if (!BaseResource::LessEqual(rr)) return false;
+        if (GPUs() > rr.gpus) return false;
+        return true;
+    }
+    Resource AsResource() const {  // what Resource.AddResourceRequirements adds (resource_info.go:143-155)
+        Resource r; r.milliCpu = milliCpu; r.memory = memory; r.scalars = scalars; r.gpus = GPUs(); return r;
+    }
+};
+
+struct PodGroupInfo; struct PodSet; struct NodeInfo;
+
+// ---------------------------------------------------------------- api/pod_info/pod_info.go:70-112
+struct PodInfo {
+    int idx = -1;            // index in the snapshot (stands for UID; ordering uses uidRank)
+    uint32_t uidRank = 0;
+    int job = -1, podset = -1;
+    int status = Pending;
+    int node = -1;           // NodeName
+    bool isVirtualStatus = false;
+    uint32_t flags = 0;
+    int taskPriority = 0;    // task-order label
+    int64_t createdNs = 0;
+    int podClass = 0;
+    int nominatedNode = -1;
+    ResourceRequirements resReq;
+    ResourceRequirements accepted;  // AcceptedResource, set by NodeInfo.setAcceptedResources
+    bool IsCPUOnlyRequest() const { return !(resReq.GPUs() > 0); }  // pod_info.go:340-347
+    bool ShouldAllocate(bool isRealAllocation) const {               // pod_info.go:518-521
+        return status == Pending || (!isRealAllocation && status == Releasing && isVirtualStatus);
+    }
+};
+
+// ---------------------------------------------------------------- api/podgroup_info/subgroup_info/podset.go
+struct PodSet {
+    int idx = -1; uint32_t nameRank = 0; int job = -1;
+    int32_t minAvailable = 1;
+    std::map<int, PodInfo*> podInfos;  // keyed by pod idx (UID)
+    std::map<int, int> podStatusMap;
+    int numActiveAllocatedTasks = 0, numActiveUsedTasks = 0, numAliveTasks = 0, numGated = 0;
+    void clearOldStatus(PodInfo* ti) {  // podset.go:82-99
+        auto it = podStatusMap.find(ti->idx); if (it == podStatusMap.end()) return;
+        int old = it->second;
+        if (IsActiveAllocatedStatus(old)) numActiveAllocatedTasks -= 1;
+        if (IsActiveUsedStatus(old)) numActiveUsedTasks -= 1;
+        if (IsAliveStatus(old)) numAliveTasks -= 1;
+        if (old == Gated) numGated -= 1;
+        podStatusMap.erase(it); podInfos.erase(ti->idx);
+    }
+    void AssignTask(PodInfo* ti) {  // podset.go:56-77
+        clearOldStatus(ti);
+        if (IsActiveAllocatedStatus(ti->status)) numActiveAllocatedTasks += 1;
+        if (IsActiveUsedStatus(ti->status)) numActiveUsedTasks += 1;
+        if (IsAliveStatus(ti->status)) numAliveTasks += 1;
+        if (ti->status == Gated) numGated += 1;
+        podStatusMap[ti->idx] = ti->status; podInfos[ti->idx] = ti;
+    }
+    bool IsReadyForScheduling() const { return int32_t(numAliveTasks - numGated) >= minAvailable; }  // podset.go:114-120
+    bool IsGangSatisfied() const { return numActiveUsedTasks >= int(minAvailable); }                 // podset.go:122-125
+    bool IsElastic() const { return minAvailable < int32_t(podInfos.size()); }
+};
+
+// ---------------------------------------------------------------- api/podgroup_info/job_info.go:65-103
+struct PodGroupInfo {
+    int idx = -1; uint32_t uidRank = 0;
+    int queue = -1; int32_t priority = 0; bool preemptible = true; int64_t createdNs = 0;
+    std::vector<PodSet*> podSets;  // GetSubGroups(); kept sorted by name rank (Go ranges a map; order-free uses only)
+    Resource allocated;            // job_info.go:78 Allocated
+    std::map<int, std::map<int, PodInfo*>> podStatusIndex;
+    // inner cache (allocation_info.go:31-33,97-99): NOT keyed by isRealAllocation, exactly like the reference
+    bool hasTasksToAllocate = false; std::vector<PodInfo*> tasksToAllocate;
+    bool hasInitResource = false; Resource tasksToAllocateInitResource;
+    bool hasLastStart = false;
+    std::vector<PodInfo*> AllPods() const { std::vector<PodInfo*> v; for (auto* ps : podSets) for (auto& kv : ps->podInfos) v.push_back(kv.second); return v; }
+    bool IsPreemptibleJob() const { return preemptible; }
+    void invalidateTasksCache() { hasTasksToAllocate = false; tasksToAllocate.clear(); hasInitResource = false; }
+    PodSet* podSetOf(PodInfo* t) const { for (auto* ps : podSets) if (ps->idx == t->podset) return ps; return nullptr; }
+    void AddTaskInfo(PodInfo* ti) {  // job_info.go:208-226
+        PodSet* ps = podSetOf(ti); if (!ps) return;
+        ps->AssignTask(ti);
+        podStatusIndex[ti->status][ti->idx] = ti; invalidateTasksCache();
+        if (AllocatedStatus(ti->status)) allocated.Add(ti->resReq.AsResource());
+    }
+    void UpdateTaskStatus(PodInfo* task, int status) {  // job_info.go:228-238 + resetTaskState :272-287
+        if (AllocatedStatus(task->status)) allocated.Sub(task->resReq.AsResource());
+        auto it = podStatusIndex.find(task->status);
+        if (it != podStatusIndex.end()) { it->second.erase(task->idx); if (it->second.empty()) podStatusIndex.erase(it); invalidateTasksCache(); }
+        task->status = status;
+        AddTaskInfo(task);
+    }
+    int GetNumAllocatedTasks() const { int n = 0; for (auto* t : AllPods()) if (AllocatedStatus(t->status)) n++; return n; }
+    int GetNumPendingTasks() const { auto it = podStatusIndex.find(Pending); return it == podStatusIndex.end() ? 0 : int(it->second.size()); }
+    bool IsReadyForScheduling() const { for (auto* ps : podSets) if (!ps->IsReadyForScheduling()) return false; return true; }  // job_info.go:399-406
+    bool IsGangSatisfied() const { for (auto* ps : podSets) if (!ps->IsGangSatisfied()) return false; return true; }
+    bool ShouldPipelineJob() const {  // job_info.go:443-464
+        for (auto* ps : podSets) {
+            bool hasPipelinedTask = false; int activeAllocated = 0;
+            for (auto& kv : ps->podInfos) {
+                if (kv.second->status == Pipelined) hasPipelinedTask = true;
+                else if (IsActiveAllocatedStatus(kv.second->status)) activeAllocated += 1;
+            }
+            if (hasPipelinedTask && activeAllocated < int(ps->minAvailable)) return true;
+        }
+        return false;
+    }
+};
+
+// ---------------------------------------------------------------- api/node_info/node_info.go:68-105
+struct NodeInfo {
+    int idx = -1; uint32_t nameRank = 0; uint32_t flags = 0; int gpuCountLabel = -1; int nodeClass = 0;
+    Resource Idle, Used, Releasing, Allocatable;
+    struct OnNode { int status; Resource tracked; };
+    std::map<int, OnNode> podInfos;  // the node's own copy of the task (status at add time)
+    double NonAllocatedResource(int r) const { return Idle.Get(r) + Releasing.Get(r); }  // node_info.go:164-166
+    Resource NonAllocatedResources() const { Resource x; x.Add(Idle); x.Add(Releasing); return x; }  // :157-162
+    bool IsCPUOnlyNode() const { if (flags & KAI_NODE_MIG_ENABLED) return false; return Allocatable.gpus <= 0 && !(flags & KAI_NODE_HAS_DRA_GPUS); }  // :697-702
+    int64_t GetNumberOfGPUsInNode() const { return gpuCountLabel >= 0 ? gpuCountLabel : int64_t(Allocatable.gpus); }  // :630-637
+    bool isTaskAllocatableOnNonAllocatedResources(const PodInfo* task, const Resource& avail) const {  // :361-382 (regular GPU request)
+        return task->resReq.LessEqualResource(avail);  // isValidGpuPortion is vacuous for whole GPUs (:668-671)
+    }
+    bool IsTaskAllocatable(const PodInfo* task) const {  // :168-188 (no storage claims on the path)
+        if (task->resReq.IsEmpty()) return true;
+        return isTaskAllocatableOnNonAllocatedResources(task, Idle);
+    }
+    bool IsTaskAllocatableOnReleasingOrIdle(const PodInfo* task) const {  // :190-206
+        return isTaskAllocatableOnNonAllocatedResources(task, NonAllocatedResources());
+    }
+    void setAcceptedResources(PodInfo* pi) const { if (!IsActiveUsedStatus(pi->status)) return; pi->accepted = pi->resReq; }  // :746-766
+    void addTaskResources(const Resource& r, int status) {  // :457-493
+        Used.Add(r);
+        switch (status) {
+            case KAI_POD_RELEASING: Releasing.Add(r); Idle.Sub(r); break;
+            case KAI_POD_PIPELINED: Releasing.Sub(r); break;
+            default: Idle.Sub(r);
+        }
+    }
+    void removeTaskResources(const Resource& r, int status) {  // :515-551
+        Used.Sub(r);
+        switch (status) {
+            case KAI_POD_RELEASING: Releasing.Sub(r); Idle.Add(r); break;
+            case KAI_POD_PIPELINED: Releasing.Add(r); break;
+            default: Idle.Add(r);
+        }
+    }
+    bool AddTask(PodInfo* task) {  // :384-417
+        setAcceptedResources(task);
+        if (podInfos.count(task->idx)) return false;  // "task already on node"
+        Resource r = task->accepted.AsResource();     // getAcceptedTaskResourceWithoutSharedGPU for a regular task
+        podInfos[task->idx] = OnNode{task->status, r};
+        addTaskResources(r, task->status);
+        return true;
+    }
+    bool RemoveTask(PodInfo* ti) {  // :495-513 — uses the node's copy, i.e. the status at add time
+        auto it = podInfos.find(ti->idx); if (it == podInfos.end()) return false;
+        OnNode c = it->second; podInfos.erase(it);
+        removeTaskResources(c.tracked, c.status);
+        return true;
+    }
+    bool UpdateTask(PodInfo* ti) { if (!RemoveTask(ti)) return false; return AddTask(ti); }  // :571-576
+};
+
+// ---------------------------------------------------------------- plugins/proportion/resource_share/resource_share.go:12-21
+struct ResourceShare {
+    double Deserved = 0, FairShare = 0, MaxAllowed = 0, OverQuotaWeight = 0, Allocated = 0, AllocatedNotPreemptible = 0, Request = 0, Usage = 0;
+    double GetRequestableShare() const { return MaxAllowed == KAI_UNLIMITED ? Request : std::fmin(MaxAllowed, Request); }  // :41-46
+    double GetAllocatableShare() const {  // :51-61
+        if (Deserved == KAI_UNLIMITED) return MaxAllowed;
+        double allocatable = std::fmax(Deserved, FairShare);
+        if (MaxAllowed != KAI_UNLIMITED) allocatable = std::fmin(MaxAllowed, allocatable);
+        return allocatable;
+    }
+};
+using ResourceQuantities = std::array<double, 3>;  // resource_quantities.go:18 (CPU, Memory, GPU)
+
+// plugins/proportion/resource_share/queue_resource_share.go:21-29
+struct QueueAttributes {
+    int idx = -1; uint32_t uidRank = 0; int parent = -1; std::vector<int> children; int64_t createdNs = 0; int priority = 0;
+    ResourceShare share[3];
+    ResourceQuantities get(double ResourceShare::*f) const { return {share[0].*f, share[1].*f, share[2].*f}; }
+    ResourceQuantities GetFairShare() const { return get(&ResourceShare::FairShare); }
+    ResourceQuantities GetAllocatedShare() const { return get(&ResourceShare::Allocated); }
+    ResourceQuantities GetDeservedShare() const { return get(&ResourceShare::Deserved); }
+    ResourceQuantities GetAllocatableShare() const { return {share[0].GetAllocatableShare(), share[1].GetAllocatableShare(), share[2].GetAllocatableShare()}; }
+    double GetDominantResourceShare(const ResourceQuantities& total) const {  // queue_resource_share.go:142-166
+        double dominant = 0.0;
+        for (int r = 0; r < 3; r++) {
+            double value, allocatableShare = share[r].GetAllocatableShare();
+            if (allocatableShare == KAI_UNLIMITED) allocatableShare = total[r];
+            double allocated = share[r].Allocated;
+            if (allocatableShare == 0) value = allocated * 1000; else value = allocated / allocatableShare;
+            dominant = std::fmax(dominant, value);
+        }
+        return dominant;
+    }
+};
+
+// resource_quantities.go:50-97
+inline int compareQuantities(double q, double o) {
+    if (q == KAI_UNLIMITED) return o == KAI_UNLIMITED ? 0 : 1;
+    if (o == KAI_UNLIMITED) return -1;
+    return q > o ? 1 : q < o ? -1 : 0;
+}
+inline bool rqLess(const ResourceQuantities& a, const ResourceQuantities& b) { for (int r = 0; r < 3; r++) if (a[r] >= b[r]) return false; return true; }
+inline bool rqLessEqual(const ResourceQuantities& a, const ResourceQuantities& b) { for (int r = 0; r < 3; r++) if (compareQuantities(a[r], b[r]) > 0) return false; return true; }
+inline bool rqLessInAtLeastOneResource(const ResourceQuantities& a, const ResourceQuantities& b) { return !rqLessEqual(b, a); }
+
+// api/queue_info/queue_info.go:32-43
+struct QueueInfo { int idx = -1; uint32_t uidRank = 0; int parent = -1; std::vector<int> children; int priority = 0; int64_t createdNs = 0; bool IsLeafQueue() const { return children.empty(); } };
+
+// ---------------------------------------------------------------- scheduler_util/priority_queue.go (container/heap semantics)
+template <class T>
+struct PriorityQueue {
+    std::vector<T> items; std::function<bool(const T&, const T&)> lessFn; int maxQueueSize = -1;
+    bool less(int i, int j) { return lessFn(items[i], items[j]); }
+    void up(int j) { for (;;) { int i = (j - 1) / 2; if (i == j || !less(j, i)) break; std::swap(items[i], items[j]); j = i; } }
+    bool down(int i0, int n) {
+        int i = i0;
+        for (;;) { int j1 = 2 * i + 1; if (j1 >= n || j1 < 0) break; int j = j1; int j2 = j1 + 1; if (j2 < n && less(j2, j1)) j = j2; if (!less(j, i)) break; std::swap(items[i], items[j]); i = j; }
+        return i > i0;
+    }
+    T heapRemove(int i) { int n = int(items.size()) - 1; if (n != i) { std::swap(items[i], items[n]); if (!down(i, n)) up(i); } T x = items.back(); items.pop_back(); return x; }
+    void Push(const T& x) {  // priority_queue.go:48-55
+        items.push_back(x); up(int(items.size()) - 1);
+        if (maxQueueSize != -1 && int(items.size()) > maxQueueSize) heapRemove(maxQueueSize);
+    }
+    T Pop() { int n = int(items.size()) - 1; std::swap(items[0], items[n]); down(0, n); T x = items.back(); items.pop_back(); return x; }
+    const T& Peek() const { return items[0]; }
+    void Fix(int i) { if (!down(i, int(items.size()))) up(i); }
+    bool Empty() const { return items.empty(); }
+    int Len() const { return int(items.size()); }
+};
+
+}  // namespace orc

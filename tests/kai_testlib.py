@@ -1,0 +1,422 @@
+"""Test infrastructure shared by the CPU and GPU suites.
+
+ * `pkg`               — the product's Python host package (directory `kai-scheduler_amd/`, not importable by name)
+ * `Oracle`            — ctypes wrapper of oracle/liboracle.so (the CPU restatement; checker only)
+ * `case_to_snapshot`  — restates the reference's test fixture builders
+                         (pkg/scheduler/test_utils/test_utils_builder.go:94-289, jobs_fake/jobs.go:51-330,
+                          nodes_fake/nodes.go:52-287, resources_fake/resources.go:32-77) so a golden table
+                         transcribed by tools/go_fixtures.py becomes the same session the Go test builds.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib.util
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _load_pkg():
+    name = "kai_scheduler_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "kai-scheduler_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+pkg = _load_pkg()
+abi = pkg.abi
+
+
+# ------------------------------------------------------------------------------------------------ oracle
+class Oracle:
+    """CPU oracle (oracle/liboracle.so).  Builds it on first use; it is test infrastructure, never shipped."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            so = os.path.join(ROOT, "oracle", "liboracle.so")
+            srcs = [os.path.join(ROOT, "oracle", f) for f in ("kai_oracle.cpp", "oracle_model.hpp", "oracle_session.hpp")]
+            if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+            lib = C.CDLL(so)
+            lib.kai_oracle_run.restype = C.c_int
+            lib.kai_oracle_pack_score.restype = C.c_double
+            lib.kai_oracle_pack_score.argtypes = [C.c_double] * 4
+            lib.kai_oracle_set_resources_share.restype = C.c_int
+            cls._lib = lib
+        return cls._lib
+
+    @classmethod
+    def run(cls, snap, cfg=None, actions=("allocate",)):
+        lib = cls.lib()
+        cfg = cfg or abi.default_config()
+        s = snap.as_struct()
+        acts = (C.c_int * len(actions))(*[abi.ACTIONS[a] for a in actions])
+        P, Q, N = snap.n_pods, snap.n_queues, snap.n_nodes
+        cap = max(16, 4 * P)
+        ops = (abi.KaiOp * cap)()
+        n_ops = C.c_int64(0)
+        status = np.zeros(P, np.int32); node = np.zeros(P, np.int32)
+        sh_open = (abi.KaiQueueShare * max(Q, 1))(); sh_fin = (abi.KaiQueueShare * max(Q, 1))()
+        nodes = (abi.KaiNodeState * max(N, 1))()
+        stats = abi.KaiActionStats(); ms = C.c_double(0)
+        rc = lib.kai_oracle_run(C.byref(cfg), C.byref(s), acts, len(actions), ops, C.c_int64(cap), C.byref(n_ops),
+                                status.ctypes.data_as(C.POINTER(C.c_int32)), node.ctypes.data_as(C.POINTER(C.c_int32)),
+                                sh_open, sh_fin, nodes, C.byref(stats), C.byref(ms))
+        if rc != 0:
+            raise RuntimeError(f"oracle rc={rc}")
+        return Result(ops=[(o.kind, o.pod, o.node, o.job) for o in ops[: n_ops.value]], pod_status=status, pod_node=node,
+                      shares_open=shares_to_np(sh_open, Q), shares_final=shares_to_np(sh_fin, Q), nodes=nodes_to_np(nodes, N, snap.n_res),
+                      stats=stats, elapsed_ms=ms.value)
+
+
+class Result:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def shares_to_np(sh, Q):
+    out = {}
+    for f in ("fair_share", "allocated", "allocated_non_preemptible", "request", "deserved", "max_allowed"):
+        out[f] = np.array([[getattr(sh[q], f)[r] for r in range(3)] for q in range(Q)], dtype=np.float64).reshape(Q, 3)
+    return out
+
+
+def nodes_to_np(nodes, N, R):
+    out = {}
+    for f in ("idle", "releasing", "used"):
+        out[f] = np.array([[getattr(nodes[n], f)[r] for r in range(R)] for n in range(N)], dtype=np.float64).reshape(N, R)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ fixtures
+class Unsupported(Exception):
+    """The golden case needs a feature outside the path built so far (documented in DESIGN.md)."""
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        return json.load(f)
+
+
+def _milli(v):  # resource.MustParse(FormatFloat(v)).MilliValue(): cores → milli-cores, rounded up
+    return float(math.ceil(round(v * 1000.0, 6)))
+
+
+def _value(v):  # Quantity.Value(): rounded up to an integer
+    return float(math.ceil(v))
+
+
+def _flatten_subgroups(root):
+    """SubGroupSet.GetAllPodSets (subgroup_info/subgroupset.go:57-69) — returns [(name, minAvailable, constraint, parents)]."""
+    out = []
+
+    def walk(g, parents):
+        for ps in g.get("PodSets", []):
+            out.append((ps["Name"], int(ps["MinAvailable"]), ps.get("TopologyConstraint"), parents))
+        for sg in g.get("SubGroups", []):
+            walk(sg, parents + [sg.get("Name", "")])
+
+    walk(root, [])
+    return out
+
+
+def case_to_snapshot(case, actions=("allocate",)):
+    """→ (Snapshot, KaiConfig, meta).  Raises Unsupported for features outside the built path."""
+    S = abi.POD_STATUS
+    if case.get("Topologies"):
+        raise Unsupported("topology")
+    mocks = case.get("Mocks") or {}
+    cfg = abi.default_config(max_consolidation_preemptees=-1)  # test_utils_builder.go:78-79
+    # addSessionPlugins (test_utils_builder.go:297-321): "predicates" is skipped unless a cache mock exists
+    cache_mock = bool(mocks) and mocks.get("CacheRequirements") is not None and mocks.get("Cache") is None
+    plugins = abi.PLUGIN_ALL
+    if mocks.get("SchedulerConf"):
+        conf = mocks["SchedulerConf"]
+        plugins = 0
+        for tier in conf.get("Tiers", []):
+            for pl in tier.get("Plugins", []):
+                nm = pl.get("Name")
+                if nm in abi.PLUGINS:
+                    plugins |= abi.PLUGINS[nm]
+                args = pl.get("Arguments") or {}
+                if nm == "nodeplacement":
+                    strat = {"binpack": abi.BINPACK, "spread": abi.SPREAD}
+                    for k, v in args.items():
+                        key = {"constants.GPUResource": "gpu", "constants.CPUResource": "cpu"}.get(k, k)
+                        val = {"constants.SpreadStrategy": "spread", "constants.BinpackStrategy": "binpack"}.get(v, v)
+                        if key == "gpu": cfg.gpu_strategy = strat[val]
+                        if key == "cpu": cfg.cpu_strategy = strat[val]
+                if nm == "proportion" and "kValue" in args:
+                    cfg.k_value = float(args["kValue"])
+                if nm in ("gpupack", "gpuspread", "gpusharingorder", "kubeflow", "ray", "dynamicresources", "snapshot", "podaffinity"):
+                    pass
+    if not cache_mock:
+        plugins &= ~abi.PLUGINS["predicates"]
+    cfg.plugins = plugins
+
+    # ---- queues + departments (test_utils_builder.go:94-233)
+    queues = [dict(q) for q in case.get("Queues", [])]
+    departments = [dict(d) for d in case.get("Departments", [])]
+    if not departments and not case.get("DisableDefaultDepartment"):
+        for q in queues:
+            q["ParentQueue"] = "default"
+        departments = [{"Name": "default", "DeservedGPUs": -1.0, "MaxAllowedGPUs": -1.0}]
+    qnames, qrec = [], []
+    for i, q in enumerate(queues):
+        if q.get("V1"):
+            raise Unsupported("v1 queue")
+        rec = dict(name=q["Name"], parent=q.get("ParentQueue", ""), priority=q.get("Priority"), created=i * 60_000_000_000 + i,
+                   deserved=[-1.0, -1.0, float(q.get("DeservedGPUs", 0))],
+                   limit=[-1.0, -1.0, float(q["MaxAllowedGPUs"]) if q.get("MaxAllowedGPUs", 0) != 0 else -1.0],
+                   oqw=[1.0, 1.0, float(q.get("GPUOverQuotaWeight", 0))])
+        if q.get("DeservedCPUs") is not None: rec["deserved"][0] = float(q["DeservedCPUs"])
+        if q.get("DeservedMemory") is not None: rec["deserved"][1] = float(q["DeservedMemory"])
+        if q.get("MaxAllowedCPUs") is not None: rec["limit"][0] = float(q["MaxAllowedCPUs"])
+        if q.get("MaxAllowedMemory") is not None: rec["limit"][1] = float(q["MaxAllowedMemory"])
+        qnames.append(q["Name"]); qrec.append(rec)
+    for i, d in enumerate(departments):
+        rec = dict(name=d["Name"], parent="", priority=None, created=i * 60_000_000_000 + 1000 + i,
+                   deserved=[-1.0, -1.0, float(d.get("DeservedGPUs", 0))],
+                   limit=[-1.0, -1.0, float(d["MaxAllowedGPUs"]) if d.get("MaxAllowedGPUs", 0) != 0 else -1.0],
+                   oqw=[1.0, 1.0, float(d.get("DeservedGPUs", 0))])
+        if d.get("MaxAllowedCPUs") is not None: rec["limit"][0] = float(d["MaxAllowedCPUs"])
+        if d.get("MaxAllowedMemory") is not None: rec["limit"][1] = float(d["MaxAllowedMemory"])
+        if d["Name"] in qnames:  # mergeQueues: departments override same-named queues
+            qrec[qnames.index(d["Name"])] = rec
+        else:
+            qnames.append(d["Name"]); qrec.append(rec)
+    # UpdateQueueHierarchy: orphans (missing parent) are dropped with their subtree (cache/cluster_info/queue.go:105-129)
+    alive = {r["name"] for r in qrec}
+    changed = True
+    while changed:
+        changed = False
+        for r in qrec:
+            if r["name"] in alive and r["parent"] and r["parent"] not in alive:
+                alive.discard(r["name"]); changed = True
+    qrec = [r for r in qrec if r["name"] in alive]
+    qnames = [r["name"] for r in qrec]
+    Q = len(qrec)
+    qidx = {n: i for i, n in enumerate(qnames)}
+
+    # ---- nodes (nodes_fake/nodes.go:52-287)
+    node_names = sorted(case.get("Nodes", {}).keys())
+    nidx = {n: i for i, n in enumerate(node_names)}
+    N = len(node_names)
+    R = 4
+    alloc = np.zeros((R, N)); nflags = np.zeros(N, np.uint32); gpu_count = np.zeros(N, np.int32)
+    for i, nm in enumerate(node_names):
+        nd = case["Nodes"][nm]
+        if nd.get("MigInstances"):
+            raise Unsupported("MIG instances")
+        gpus = int(nd.get("GPUs", 0))
+        mig = nd.get("MigStrategy", "")
+        alloc[abi.RES_CPU, i] = _milli(nd["CPUMillis"]) if nd.get("CPUMillis", 0) > 0 else 20000.0 * 1000.0
+        alloc[abi.RES_MEM, i] = _value(nd["CPUMemory"]) if nd.get("CPUMemory", 0) > 0 else 20e9
+        alloc[abi.RES_GPU, i] = 0 if mig == "mixed" else gpus
+        alloc[abi.RES_PODS, i] = nd["MaxTaskNum"] if nd.get("MaxTaskNum") is not None else 110
+        gpu_count[i] = gpus
+        if mig not in ("", None):  # migEnabledLabel "true" (nodes.go:203-206)
+            nflags[i] |= abi.NODE_MIG_ENABLED
+            if mig == "mixed":
+                nflags[i] |= abi.NODE_MIG_MIXED
+        if nd.get("GpuMemorySynced") is not None or nd.get("GPUMemory"):
+            pass  # only read by gpu-memory requests (unsupported here)
+        if nd.get("Labels"):
+            pass  # topology / custom labels: only the topology plugin reads them
+
+    # ---- jobs & tasks (jobs_fake/jobs.go:51-330)
+    jobs = sorted(enumerate(case.get("Jobs", [])), key=lambda t: -int(t[1].get("Priority", 0)))  # SliceStable by priority desc
+    jobs = [j for _, j in jobs]
+    J = len(jobs)
+    pod_names, pod_job, pod_podset, pod_status, pod_node, pod_flags, pod_prio, pod_aff = [], [], [], [], [], [], [], []
+    req_rows = []
+    podset_job, podset_min, podset_names_l, job_first_podset, job_n_podsets, job_first_pod, job_n_pods = [], [], [], [], [], [], []
+    job_names, job_queue, job_priority, job_preempt, job_created = [], [], [], [], []
+    trees = {}
+    for ji, job in enumerate(jobs):
+        tasks = job.get("Tasks", []) or []
+        if job.get("RequiredGpuMemory", 0):
+            raise Unsupported("gpu memory request")
+        if job.get("RequiredMultiFractionDevicesPerTask") is not None:
+            raise Unsupported("multi-fraction")
+        g = float(job.get("RequiredGPUsPerTask", 0))
+        if g != int(g):
+            raise Unsupported("fractional gpu")
+        job_names.append(job["Name"])
+        job_queue.append(qidx.get(job.get("QueueName", ""), -1))
+        if job_queue[-1] >= 0:  # input_jobs.go:53-59: the queue's parent must exist too (already pruned above)
+            pass
+        prio = int(job.get("Priority", 0))
+        job_priority.append(prio)
+        pre = job.get("Preemptibility", "")
+        job_preempt.append(1 if pre == "preemptible" else 0 if pre == "non-preemptible" else (1 if prio < 100 else 0))
+        age = int(job.get("JobAgeInMinutes", 0))
+        job_created.append((-(age if age != 0 else (J - ji)) * 60_000_000_000) + ji)
+        # pod-sets
+        root = job.get("RootSubGroupSet")
+        sets = []
+        if root:
+            flat = _flatten_subgroups(root)
+            if root.get("SubGroups"):
+                raise Unsupported("nested sub-group sets")
+            if root.get("TopologyConstraint") or any(c for (_, _, c, _) in flat):
+                raise Unsupported("topology constraint")
+            sets = [(n, m) for (n, m, _, _) in flat]
+            trees[job["Name"]] = root
+        names_in_sets = [n for n, _ in sets]
+        if any(not t.get("SubGroupName") for t in tasks) and "default" not in names_in_sets:
+            sets.append(("default", len(tasks)))  # jobs.go:116-123
+        job_first_podset.append(len(podset_job)); job_n_podsets.append(len(sets))
+        set_index = {}
+        for n, m in sets:
+            set_index[n] = len(podset_job)
+            podset_job.append(ji); podset_min.append(int(m)); podset_names_l.append((ji, n))
+        job_first_pod.append(len(pod_names)); job_n_pods.append(len(tasks))
+        for ti, t in enumerate(tasks):
+            if t.get("RequiredMigInstances") or t.get("IsLegacyMigTask"):
+                raise Unsupported("MIG task")
+            if t.get("PodAffinityLabels") or t.get("PodAffinityTopologyKey") or t.get("PodAntiAffinityTopologyKey"):
+                raise Unsupported("inter-pod affinity")
+            if t.get("ResourceClaimNames") or t.get("ResourceClaimTemplates"):
+                raise Unsupported("DRA")
+            if t.get("GPUGroups"):
+                raise Unsupported("shared gpu groups")
+            pod_names.append(f"{job['Name']}-{ti}")
+            pod_job.append(ji)
+            sg = t.get("SubGroupName") or "default"
+            if sg not in set_index:
+                raise Unsupported("task sub-group missing")
+            pod_podset.append(set_index[sg])
+            st = t.get("State", "Pending")
+            pod_status.append(S[st])
+            nn = t.get("NodeName", "")
+            pod_node.append(nidx.get(nn, -1) if nn else -1)
+            fl = 0
+            if t.get("Priority") is not None:
+                fl |= abi.POD_HAS_TASK_PRIORITY
+            pod_flags.append(fl); pod_prio.append(int(t["Priority"]) if t.get("Priority") is not None else 0)
+            pod_aff.append(tuple(sorted(t.get("NodeAffinityNames") or [])))
+            # CalcJobAndPodResources (jobs.go:216-246) + BuildResourceList (resources_fake/resources.go:32-68)
+            if job.get("IsBestEffortJob"):
+                cpu = mem = gp = 0.0
+            else:
+                cpu = _milli(job["RequiredCPUsPerTask"]) if job.get("RequiredCPUsPerTask", 0) != 0 else 1000.0
+                mem = _value(job["RequiredMemoryPerTask"]) if job.get("RequiredMemoryPerTask", 0) != 0 else 1e9
+                gp = float(int(g))
+            if t.get("RequiredGPUs") is not None:
+                gp = float(int(t["RequiredGPUs"]))  # jobs.go:309-312
+            req_rows.append((cpu, mem, gp, 1.0))
+    P = len(pod_names)
+    pod_req = np.zeros((R, P))
+    for p, row in enumerate(req_rows):
+        pod_req[:, p] = row
+
+    # ---- static predicate classes from NodeAffinityNames (tasks_fake/tasks.go:104-122: label kai.scheduler/type == node name)
+    aff_sets = sorted(set(pod_aff))
+    if aff_sets == [()] or not aff_sets:
+        class_fit = np.ones((1, 1), np.uint8); pod_class = np.zeros(P, np.int32); node_class = np.zeros(N, np.int32)
+    else:
+        if () not in aff_sets:
+            aff_sets = [()] + aff_sets
+        class_fit = np.zeros((len(aff_sets), max(N, 1)), np.uint8)
+        for ci, names in enumerate(aff_sets):
+            for i, nm in enumerate(node_names):
+                class_fit[ci, i] = 1 if (not names or nm in names) else 0
+        pod_class = np.array([aff_sets.index(a) for a in pod_aff], np.int32)
+        node_class = np.arange(N, dtype=np.int32)
+
+    # pod-set name rank inside the job
+    ps_rank = np.zeros(len(podset_job), np.uint32)
+    for ji in range(J):
+        idxs = [k for k in range(len(podset_job)) if podset_job[k] == ji]
+        ranks = abi.rank_strings([podset_names_l[k][1] for k in idxs])
+        for k, r in zip(idxs, ranks):
+            ps_rank[k] = r
+
+    snap = abi.Snapshot(n_res=R)
+    snap.node_names, snap.pod_names, snap.job_names, snap.queue_names = node_names, pod_names, job_names, qnames
+    snap.podset_names = [n for (_, n) in podset_names_l]
+    a = snap.arrays
+    a["node_allocatable"] = alloc; a["node_flags"] = nflags; a["node_gpu_count"] = gpu_count
+    a["node_name_rank"] = abi.rank_strings(node_names); a["node_class"] = node_class
+    a["pod_req"] = pod_req; a["pod_job"] = np.array(pod_job, np.int32); a["pod_podset"] = np.array(pod_podset, np.int32)
+    a["pod_status"] = np.array(pod_status, np.int32); a["pod_node"] = np.array(pod_node, np.int32)
+    a["pod_flags"] = np.array(pod_flags, np.uint32); a["pod_task_priority"] = np.array(pod_prio, np.int32)
+    a["pod_created_ns"] = np.zeros(P, np.int64); a["pod_uid_rank"] = abi.rank_strings(pod_names); a["pod_class"] = pod_class
+    a["pod_nominated_node"] = np.full(P, -1, np.int32)
+    a["podset_job"] = np.array(podset_job, np.int32); a["podset_min_available"] = np.array(podset_min, np.int32); a["podset_name_rank"] = ps_rank
+    a["job_queue"] = np.array(job_queue, np.int32); a["job_priority"] = np.array(job_priority, np.int32)
+    a["job_preemptible"] = np.array(job_preempt, np.int32); a["job_created_ns"] = np.array(job_created, np.int64)
+    a["job_uid_rank"] = abi.rank_strings(job_names)
+    a["job_first_pod"] = np.array(job_first_pod, np.int32); a["job_n_pods"] = np.array(job_n_pods, np.int32)
+    a["job_first_podset"] = np.array(job_first_podset, np.int32); a["job_n_podsets"] = np.array(job_n_podsets, np.int32)
+    a["queue_parent"] = np.array([qidx.get(r["parent"], -1) if r["parent"] else -1 for r in qrec], np.int32)
+    a["queue_priority"] = np.array([r["priority"] if r["priority"] is not None else 100 for r in qrec], np.int32)  # constants.DefaultQueuePriority
+    a["queue_created_ns"] = np.array([r["created"] for r in qrec], np.int64)
+    a["queue_uid_rank"] = abi.rank_strings(qnames)
+    a["queue_deserved"] = np.array([[r["deserved"][k] for r in qrec] for k in range(3)], np.float64).reshape(3, Q)
+    a["queue_limit"] = np.array([[r["limit"][k] for r in qrec] for k in range(3)], np.float64).reshape(3, Q)
+    a["queue_oqw"] = np.array([[r["oqw"][k] for r in qrec] for k in range(3)], np.float64).reshape(3, Q)
+    a["class_fit"] = class_fit
+    snap.finalize()
+    meta = dict(name=case.get("Name"), line=case.get("_line"), expected_jobs=case.get("JobExpectedResults") or {},
+                expected_tasks=case.get("TaskExpectedResults") or {}, expected_nodes=case.get("ExpectedNodesResources") or {})
+    return snap, cfg, meta
+
+
+def check_expectations(snap, meta, pod_status, pod_node, nodes=None):
+    """test_utils.MatchExpectedAndRealTasks (test_utils/test_utils.go:121-314): status + node per task. → list of mismatches."""
+    S = abi.POD_STATUS
+    errs = []
+    for jname, exp in meta["expected_jobs"].items():
+        if jname not in snap.job_names:
+            errs.append(f"job {jname} missing"); continue
+        j = snap.job_names.index(jname)
+        first, n = int(snap.job_first_pod[j]), int(snap.job_n_pods[j])
+        gsum = 0.0
+        for p in range(first, first + n):
+            want = S[exp.get("Status", "Pending")] if isinstance(exp.get("Status", "Pending"), str) else exp.get("Status")
+            if int(pod_status[p]) != want:
+                errs.append(f"{snap.pod_names[p]}: status {abi.POD_STATUS_NAME.get(int(pod_status[p]))} want {exp.get('Status')}")
+            if exp.get("NodeName"):
+                got = snap.node_names[pod_node[p]] if pod_node[p] >= 0 else ""
+                if got != exp["NodeName"]:
+                    errs.append(f"{snap.pod_names[p]}: node {got!r} want {exp['NodeName']!r}")
+            gsum += snap.pod_req[abi.RES_GPU, p]
+        if abs(gsum - float(exp.get("GPUsRequired", 0))) > 1e-9:
+            errs.append(f"{jname}: GPUsRequired {gsum} want {exp.get('GPUsRequired', 0)}")
+    for tname, exp in meta["expected_tasks"].items():
+        if tname not in snap.pod_names:
+            continue
+        p = snap.pod_names.index(tname)
+        if int(pod_status[p]) != S[exp.get("Status", "Pending")]:
+            errs.append(f"{tname}: status {abi.POD_STATUS_NAME.get(int(pod_status[p]))} want {exp.get('Status')}")
+        if exp.get("NodeName"):
+            got = snap.node_names[pod_node[p]] if pod_node[p] >= 0 else ""
+            if got != exp["NodeName"]:
+                errs.append(f"{tname}: node {got!r} want {exp['NodeName']!r}")
+    if nodes is not None:
+        for nname, exp in meta["expected_nodes"].items():
+            if nname not in snap.node_names:
+                errs.append(f"node {nname} missing"); continue
+            i = snap.node_names.index(nname)
+            if nodes["releasing"][i, abi.RES_GPU] != float(exp.get("ReleasingGPUs", 0)):
+                errs.append(f"{nname}: releasing gpus {nodes['releasing'][i, abi.RES_GPU]} want {exp.get('ReleasingGPUs', 0)}")
+            if nodes["idle"][i, abi.RES_GPU] != float(exp.get("IdleGPUs", 0)):
+                errs.append(f"{nname}: idle gpus {nodes['idle'][i, abi.RES_GPU]} want {exp.get('IdleGPUs', 0)}")
+    return errs
