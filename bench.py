@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py — pod-placement decisions/s of the scheduling-cycle core on synthetic cluster snapshots.
+
+    python bench.py --gpus 1 --steps K --warmup W [--config C5 --scale 1.0]
+
+A "step" is one scheduling cycle of the hot path over one snapshot that is already resident in HBM:
+kai_session_reset (the OnSessionOpen math: node accounting, proportion totals / usage / fair-share) followed by
+the allocate Action.  The unit of work is one placement decision = one allocateTask (scores every node of the node
+set, picks the best fitting one, ends in allocate / pipeline / fail — SURVEY.md section 8d).
+
+Prints ONE JSON line with the contract's fields plus
+  roofline     — the dominant kernel (k_action) against the HBM roofline, algorithmic bytes = decisions x (N x 128 B + 80 B)
+  cpu_baseline — the CPU oracle (a faithful single-thread restatement of the reference path, kind "port") timed on a
+                 bounded sample of the same workload on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+B_NODE, B_POD_OUT = 128, 80  # algorithmic bytes per node of the node set / per decision
+
+CONFIGS = {"C1": 0, "C2": 1, "C3": 2, "C5": 4}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=os.environ.get("KAI_BENCH_CONFIG", "C5"), choices=sorted(CONFIGS))
+    ap.add_argument("--scale", type=float, default=float(os.environ.get("KAI_BENCH_SCALE", "1.0")))
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="decisions the CPU oracle is timed on (-1 = auto, 0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a MI355X: the scheduling-cycle core has no CPU path"
+
+    import __graft_entry__ as G
+    pkg = G._load_pkg()
+    pkg.load_library()
+
+    idx = CONFIGS[args.config]
+    t0 = time.time()
+    snap, cfg, desc = pkg.synth.config(idx, args.scale)
+    gen_s = time.time() - t0
+    N = snap.n_nodes
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    core = pkg.KaiCore(cfg, gpu_ids=(local_rank,))
+    t0 = time.time()
+    ssn = core.open_session(snap)  # host → HBM once; the timed steps replay from the resident copy
+    upload_s = time.time() - t0
+
+    kernel_ms, open_ms, decisions, placed = [], [], 0, 0
+
+    def step(record):
+        nonlocal decisions, placed
+        ssn.reset()
+        o_ms = ssn.stats().upload_ms
+        ops = ssn.execute("allocate")
+        st = ssn.stats()
+        if record:
+            kernel_ms.append(st.kernel_ms); open_ms.append(o_ms)
+            decisions = int(st.decisions); placed = int(len(ops))
+        return st
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ssn.close(); core.destroy()
+
+    total_decisions = decisions * args.steps * world  # every rank runs its own replica of the workload (see DESIGN.md "Multi-GPU")
+    value = total_decisions / elapsed
+    k_ms = float(np.mean(kernel_ms))
+    alg_bytes = decisions * (N * B_NODE + B_POD_OUT)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    lat = sorted((a + b) for a, b in zip(kernel_ms, open_ms))
+    out = {
+        "metric": "pod placement decisions/sec (allocate action, synthetic snapshot)", "value": value, "unit": "decisions/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc, "nodes": N, "pods": snap.n_pods, "jobs": snap.n_jobs, "queues": snap.n_queues,
+                   "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2],
+                   "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (node-axis sharding not built yet)",
+                   "snapshot_gen_s": round(gen_s, 2), "host_to_hbm_s": round(upload_s, 3)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_action", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+    }
+
+    if rank == 0 and world == 1 and args.cpu_sample != 0:
+        import kai_testlib as T
+        # bounded sample: the oracle walks the SAME snapshot in the same fair order and stops after `sample` decisions
+        sample = args.cpu_sample if args.cpu_sample > 0 else max(50, int(6e7 / max(N, 1)))
+        c2 = T.abi.KaiConfig.from_buffer_copy(cfg)
+        c2.reserved[0] = sample
+        ref = T.Oracle.run(snap, c2, ("allocate",))
+        done = int(ref.stats.decisions)
+        out["cpu_baseline"] = {"value": done / (ref.elapsed_ms * 1e-3), "unit": "decisions/s", "cores": 1, "kind": "port",
+                               "sample": f"first {done} decisions of the same snapshot in {ref.elapsed_ms / 1e3:.1f} s (oracle/liboracle.so, single thread, incl. session open)"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -250,6 +250,10 @@ int kai_core_destroy(kai_core* core);
  * fair-share division (plugins/proportion/proportion.go:242-423). */
 int kai_session_open(kai_core* core, const kai_snapshot_soa* snap);
 
+/* Re-opens the session from the snapshot copy that is already resident in HBM (no host traffic): same math as
+ * kai_session_open.  Lets a caller replay scheduling cycles on one snapshot (benchmarks, what-if runs). */
+int kai_session_reset(kai_core* core);
+
 /* replaces: ssn.QueueFairShare / QueueAllocatedResources / QueueDeservedResources
  * (plugins/proportion/proportion.go:508-521) */
 int kai_queue_shares(kai_core* core, kai_queue_share* out, int cap);

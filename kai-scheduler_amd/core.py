@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's Session / Action interface over the C ABI (libkai_core.so).
+
+    core = KaiCore(cfg)                       # scheduler.NewScheduler  (pkg/scheduler/scheduler.go:53-101)
+    ssn  = core.open_session(snapshot)        # framework.OpenSession   (framework/framework.go:32-65)
+    ops  = ssn.execute("allocate")            # Action.Execute(ssn)     (actions/allocate/allocate.go:46-77)
+    ssn.queue_shares(); ssn.pod_states()      # what the Go shim mirrors back into the Session
+    ssn.close()                               # framework.CloseSession
+
+The library is the only implementation: if it (or a HIP device) is missing this module raises — there is
+no Python or CPU fallback of the path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkai_core.so")
+
+EXPORTS = ["kai_core_create", "kai_core_destroy", "kai_session_open", "kai_queue_shares", "kai_action_execute", "kai_best_node",
+           "kai_pod_states", "kai_node_states", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]
+
+
+class KaiError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__(f"kai_core status {code} ({abi.STATUS_TEXT.get(code, '?')}): {detail}")
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen libkai_core.so and declare prototypes.  Raises if the HIP extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing — build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                                "the scheduling-cycle core has no non-HIP implementation")
+    lib = C.CDLL(path)
+    lib.kai_version.restype = C.c_char_p
+    lib.kai_last_error.restype = C.c_char_p
+    lib.kai_last_error.argtypes = [C.c_void_p]
+    lib.kai_core_create.argtypes = [C.POINTER(abi.KaiConfig), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+    lib.kai_core_destroy.argtypes = [C.c_void_p]
+    lib.kai_session_open.argtypes = [C.c_void_p, C.POINTER(abi.KaiSnapshotSoA)]
+    lib.kai_session_close.argtypes = [C.c_void_p]
+    lib.kai_session_reset.argtypes = [C.c_void_p]
+    lib.kai_queue_shares.argtypes = [C.c_void_p, C.POINTER(abi.KaiQueueShare), C.c_int]
+    lib.kai_action_execute.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.KaiOp), C.c_int64, C.POINTER(C.c_int64)]
+    lib.kai_best_node.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+    lib.kai_pod_states.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
+    lib.kai_node_states.argtypes = [C.c_void_p, C.POINTER(abi.KaiNodeState), C.c_int]
+    lib.kai_action_stats_get.argtypes = [C.c_void_p, C.POINTER(abi.KaiActionStats)]
+    for name in EXPORTS:
+        if name not in ("kai_version", "kai_last_error"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class KaiCore:
+    def __init__(self, cfg: abi.KaiConfig | None = None, gpu_ids=(0,)):
+        self.lib = load_library()
+        self.cfg = cfg or abi.default_config()
+        self.handle = C.c_void_p()
+        ids = (C.c_int * len(gpu_ids))(*gpu_ids)
+        rc = self.lib.kai_core_create(C.byref(self.cfg), len(gpu_ids), ids, C.byref(self.handle))
+        if rc != 0:
+            raise KaiError(rc, "kai_core_create")
+
+    def _check(self, rc):
+        if rc != 0:
+            raise KaiError(rc, self.lib.kai_last_error(self.handle).decode())
+
+    def open_session(self, snap: abi.Snapshot) -> "Session":
+        s = snap.as_struct()
+        self._check(self.lib.kai_session_open(self.handle, C.byref(s)))
+        return Session(self, snap)
+
+    def destroy(self):
+        if self.handle:
+            self.lib.kai_core_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.destroy()
+
+
+class Session:
+    """An open scheduling session resident in HBM."""
+
+    def __init__(self, core: KaiCore, snap: abi.Snapshot):
+        self.core, self.snap = core, snap
+
+    def execute(self, action: str | int):
+        """Run one Action; returns the committed operations [(kind, pod, node, job)] in commit order."""
+        lib, h = self.core.lib, self.core.handle
+        act = abi.ACTIONS[action] if isinstance(action, str) else int(action)
+        cap = 2 * self.snap.n_pods + 64
+        ops = (abi.KaiOp * cap)()
+        n = C.c_int64(0)
+        self.core._check(lib.kai_action_execute(h, act, ops, cap, C.byref(n)))
+        arr = np.frombuffer(ops, dtype=np.dtype([("seq", "<i8"), ("kind", "<i4"), ("pod", "<i4"), ("node", "<i4"), ("job", "<i4")]), count=n.value)
+        return arr.copy()
+
+    def best_node(self, pod: int, pipeline_only: bool = False):
+        node, pipe = C.c_int32(-1), C.c_int(0)
+        self.core._check(self.core.lib.kai_best_node(self.core.handle, pod, None, int(pipeline_only), C.byref(node), C.byref(pipe)))
+        return node.value, bool(pipe.value)
+
+    def queue_shares(self):
+        Q = self.snap.n_queues
+        out = (abi.KaiQueueShare * max(Q, 1))()
+        self.core._check(self.core.lib.kai_queue_shares(self.core.handle, out, max(Q, 1)))
+        res = {}
+        for f in ("fair_share", "allocated", "allocated_non_preemptible", "request", "deserved", "max_allowed"):
+            res[f] = np.array([[getattr(out[q], f)[r] for r in range(3)] for q in range(Q)], dtype=np.float64).reshape(Q, 3)
+        return res
+
+    def pod_states(self):
+        P = self.snap.n_pods
+        st, nd = np.zeros(max(P, 1), np.int32), np.zeros(max(P, 1), np.int32)
+        self.core._check(self.core.lib.kai_pod_states(self.core.handle, st.ctypes.data_as(C.POINTER(C.c_int32)), nd.ctypes.data_as(C.POINTER(C.c_int32)), max(P, 1)))
+        return st[:P], nd[:P]
+
+    def node_states(self):
+        N, R = self.snap.n_nodes, self.snap.n_res
+        out = (abi.KaiNodeState * max(N, 1))()
+        self.core._check(self.core.lib.kai_node_states(self.core.handle, out, max(N, 1)))
+        raw = np.frombuffer(out, dtype=np.float64).reshape(max(N, 1), 3, abi.MAX_RES)
+        return {"idle": raw[:N, 0, :R].copy(), "releasing": raw[:N, 1, :R].copy(), "used": raw[:N, 2, :R].copy()}
+
+    def stats(self) -> abi.KaiActionStats:
+        st = abi.KaiActionStats()
+        self.core._check(self.core.lib.kai_action_stats_get(self.core.handle, C.byref(st)))
+        return st
+
+    def reset(self):
+        """Re-open the session from the HBM-resident snapshot (no host traffic)."""
+        self.core._check(self.core.lib.kai_session_reset(self.core.handle))
+
+    def close(self):
+        self.core.lib.kai_session_close(self.core.handle)

@@ -1,0 +1,375 @@
+// kai_core.hip — C ABI of libkai_core (include/kai_core.h) on top of the gfx950 kernels.
+//
+// Host code here only moves the snapshot into HBM, derives index structures that are pure re-orderings
+// of the input (CSR children, per-queue job lists, each job's pods in TaskOrderFn order), launches the
+// kernels and copies results back.  There is NO CPU implementation of the path in this library: without
+// a HIP device every entry point fails with KAI_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kai_host_prep.hpp"
+#include "kai_kernels.hpp"
+
+using namespace kai;
+
+struct kai_core {
+    kai_config cfg{};
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err = "ok";
+    bool open = false;
+    KaiCtx ctx{};
+    std::vector<void*> bufs;  // session HBM
+    // device-only helpers
+    double* d_jsum = nullptr; int32_t* d_jobs_by_queue = nullptr; int32_t* d_depth_order = nullptr;
+    int32_t *d_lvl_off = nullptr, *d_lvl_parents = nullptr; int n_levels = 0;
+    double *d_weight = nullptr, *d_rem_amt = nullptr; uint8_t* d_rem_has = nullptr;
+    int32_t* d_best_out = nullptr;
+    int32_t *d_status0 = nullptr, *d_node0 = nullptr; QShare* d_shares0 = nullptr;  // HBM-resident initial state for kai_session_reset
+    kai_action_stats stats{};
+};
+
+#define HIP_TRY(core, expr)                                                                                        \
+    do {                                                                                                           \
+        hipError_t _e = (expr);                                                                                    \
+        if (_e != hipSuccess) {                                                                                    \
+            (core)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                       \
+            return KAI_ERR_HIP;                                                                                    \
+        }                                                                                                          \
+    } while (0)
+
+namespace {
+
+template <class T>
+int dalloc(kai_core* core, T** out, size_t n) {
+    void* p = nullptr;
+    HIP_TRY(core, hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+    core->bufs.push_back(p);
+    *out = static_cast<T*>(p);
+    return KAI_OK;
+}
+template <class T>
+int dupload(kai_core* core, const T** out, const T* host, size_t n) {
+    T* p = nullptr;
+    int rc = dalloc(core, &p, n);
+    if (rc) return rc;
+    if (n) HIP_TRY(core, hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, core->stream));
+    *out = p;
+    return KAI_OK;
+}
+template <class T>
+int dzero(kai_core* core, T** out, size_t n) {
+    int rc = dalloc(core, out, n);
+    if (rc) return rc;
+    HIP_TRY(core, hipMemsetAsync(*out, 0, std::max<size_t>(n, 1) * sizeof(T), core->stream));
+    return KAI_OK;
+}
+void free_session(kai_core* core) {
+    for (void* p : core->bufs) (void)hipFree(p);
+    core->bufs.clear();
+    core->open = false;
+}
+int fail(kai_core* core, int code, const char* msg) { core->err = msg; return code; }
+
+
+// session-open kernels over the HBM-resident snapshot (used by kai_session_open and kai_session_reset)
+int launch_open_kernels(kai_core* core) {
+    KaiCtx& c = core->ctx;
+    const int N = c.N, P = c.P, J = c.J, Q = c.Q;
+    const int TB = 256;
+    if (P) hipLaunchKernelGGL(k_node_accounting, dim3((P + TB - 1) / TB), dim3(TB), 0, core->stream, c);
+    if (core->cfg.plugins & KAI_PLUGIN_PROPORTION) {
+        if (N) hipLaunchKernelGGL(k_total_nodes, dim3(std::min(1024, (N + TB - 1) / TB)), dim3(TB), 0, core->stream, c);
+        if (P) hipLaunchKernelGGL(k_total_foreign, dim3((P + TB - 1) / TB), dim3(TB), 0, core->stream, c);
+    }
+    if (J) hipLaunchKernelGGL(k_job_usage, dim3((J + TB - 1) / TB), dim3(TB), 0, core->stream, c, core->d_jsum);
+    if (core->cfg.plugins & KAI_PLUGIN_PROPORTION) {
+        if (Q) hipLaunchKernelGGL(k_leaf_usage, dim3((Q + 3) / 4), dim3(TB), 0, core->stream, c, core->d_jsum, core->d_jobs_by_queue);
+        if (Q) hipLaunchKernelGGL(k_tree_usage, dim3(1), dim3(64), 0, core->stream, c, core->d_depth_order);
+        if (Q) hipLaunchKernelGGL(k_fair_share, dim3(1), dim3(256), 0, core->stream, c, core->d_lvl_off, core->d_lvl_parents, core->n_levels,
+                                  core->d_weight, core->d_rem_amt, core->d_rem_has);
+    }
+    HIP_TRY(core, hipGetLastError());
+    return KAI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* kai_version(void) { return "kai_core abi 1 gfx950 (HIP, device-resident engine)"; }
+
+const char* kai_last_error(kai_core* core) { return core ? core->err.c_str() : "null handle"; }
+
+int kai_core_create(const kai_config* cfg, int n_gpus, const int* gpu_ids, kai_core** out) {
+    if (!cfg || !out || cfg->abi_version != KAI_ABI_VERSION || n_gpus < 1) return KAI_ERR_INVALID_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return KAI_ERR_NO_DEVICE;
+    if (n_gpus != 1) return KAI_ERR_UNSUPPORTED;  // node-axis sharding across GPUs: see DESIGN.md "Multi-GPU"
+    int dev = gpu_ids ? gpu_ids[0] : 0;
+    if (dev < 0 || dev >= count) return KAI_ERR_INVALID_ARG;
+    kai_core* core = new kai_core();
+    core->cfg = *cfg; core->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&core->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&core->ev0) != hipSuccess || hipEventCreate(&core->ev1) != hipSuccess) {
+        delete core;
+        return KAI_ERR_HIP;
+    }
+    *out = core;
+    return KAI_OK;
+}
+
+int kai_core_destroy(kai_core* core) {
+    if (!core) return KAI_ERR_INVALID_ARG;
+    (void)hipSetDevice(core->device);
+    free_session(core);
+    if (core->ev0) (void)hipEventDestroy(core->ev0);
+    if (core->ev1) (void)hipEventDestroy(core->ev1);
+    if (core->stream) (void)hipStreamDestroy(core->stream);
+    delete core;
+    return KAI_OK;
+}
+
+int kai_session_close(kai_core* core) {
+    if (!core) return KAI_ERR_INVALID_ARG;
+    (void)hipSetDevice(core->device);
+    free_session(core);
+    return KAI_OK;
+}
+
+int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
+    if (!core || !s) return KAI_ERR_INVALID_ARG;
+    if (s->abi_version != KAI_ABI_VERSION || s->n_res < 4 || s->n_res > KAI_MAX_RES) return fail(core, KAI_ERR_INVALID_ARG, "bad abi_version / n_res");
+    HIP_TRY(core, hipSetDevice(core->device));
+    free_session(core);
+    const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
+    if (N < 0 || P < 0 || S < 0 || J < 0 || Q < 0) return fail(core, KAI_ERR_INVALID_ARG, "negative dimension");
+    for (int p = 0; p < P; p++) if (s->pod_flags && (s->pod_flags[p] & KAI_POD_CPU_FALLBACK) && s->pod_status[p] == KAI_POD_PENDING)
+        return fail(core, KAI_ERR_UNSUPPORTED, "a pending pod is flagged KAI_POD_CPU_FALLBACK: leave its job to the host path");
+
+    HIP_TRY(core, hipEventRecord(core->ev0, core->stream));
+    KaiCtx& c = core->ctx;
+    c = KaiCtx{};
+    c.N = N; c.P = P; c.S = S; c.J = J; c.Q = Q; c.R = R; c.n_pod_classes = std::max(1, s->n_pod_classes); c.n_node_classes = std::max(1, s->n_node_classes);
+    c.plugins = core->cfg.plugins; c.gpu_strategy = core->cfg.gpu_strategy; c.cpu_strategy = core->cfg.cpu_strategy;
+    c.restrict_nodes = core->cfg.restrict_node_scheduling; c.k_value = core->cfg.k_value <= 0.0 ? 0.0 : core->cfg.k_value;  // proportion.go:77-84
+
+    int rc;
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    // ---- static arrays (optional ones get neutral defaults)
+    std::vector<int32_t> neg1n(N, -1), zeron(N, 0), zerop(P, 0), neg1p(P, -1); std::vector<uint32_t> zeropu(P, 0); std::vector<int64_t> zerop64(P, 0);
+    uint8_t one = 1;
+    TRY(dupload(core, &c.n_alloc, s->node_allocatable, (size_t)R * N));
+    TRY(dupload(core, &c.n_flags, s->node_flags, (size_t)N));
+    TRY(dupload(core, &c.n_gpu_count, s->node_gpu_count ? s->node_gpu_count : neg1n.data(), (size_t)N));
+    TRY(dupload(core, &c.n_name_rank, s->node_name_rank, (size_t)N));
+    TRY(dupload(core, &c.n_class, s->node_class ? s->node_class : zeron.data(), (size_t)N));
+    TRY(dupload(core, &c.p_req, s->pod_req, (size_t)R * P));
+    TRY(dupload(core, &c.p_job, s->pod_job, (size_t)P));
+    TRY(dupload(core, &c.p_podset, s->pod_podset, (size_t)P));
+    TRY(dupload(core, &c.p_flags, s->pod_flags ? s->pod_flags : zeropu.data(), (size_t)P));
+    TRY(dupload(core, &c.p_class, s->pod_class ? s->pod_class : zerop.data(), (size_t)P));
+    TRY(dupload(core, &c.p_nominated, s->pod_nominated_node ? s->pod_nominated_node : neg1p.data(), (size_t)P));
+    TRY(dupload(core, &c.s_job, s->podset_job, (size_t)S));
+    TRY(dupload(core, &c.s_min, s->podset_min_available, (size_t)S));
+    TRY(dupload(core, &c.s_name_rank, s->podset_name_rank, (size_t)S));
+    TRY(dupload(core, &c.j_queue, s->job_queue, (size_t)J));
+    TRY(dupload(core, &c.j_prio, s->job_priority, (size_t)J));
+    TRY(dupload(core, &c.j_preempt, s->job_preemptible, (size_t)J));
+    TRY(dupload(core, &c.j_created, s->job_created_ns, (size_t)J));
+    TRY(dupload(core, &c.j_uid_rank, s->job_uid_rank, (size_t)J));
+    TRY(dupload(core, &c.j_first_pod, s->job_first_pod, (size_t)J));
+    TRY(dupload(core, &c.j_n_pods, s->job_n_pods, (size_t)J));
+    TRY(dupload(core, &c.j_first_ps, s->job_first_podset, (size_t)J));
+    TRY(dupload(core, &c.j_n_ps, s->job_n_podsets, (size_t)J));
+    TRY(dupload(core, &c.q_parent, s->queue_parent, (size_t)Q));
+    TRY(dupload(core, &c.q_prio, s->queue_priority, (size_t)Q));
+    TRY(dupload(core, &c.q_created, s->queue_created_ns, (size_t)Q));
+    TRY(dupload(core, &c.q_uid_rank, s->queue_uid_rank, (size_t)Q));
+    if (s->class_fit && s->n_pod_classes > 0 && s->n_node_classes > 0) TRY(dupload(core, &c.class_fit, s->class_fit, (size_t)s->n_pod_classes * s->n_node_classes));
+    else TRY(dupload(core, &c.class_fit, &one, (size_t)1));
+
+    // ---- index structures (pure re-orderings of the input; kai_host_prep.hpp)
+    HostPrep prep;
+    if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG;
+    TRY(dupload(core, &c.j_pods_sorted, prep.sorted.data(), (size_t)P));
+    TRY(dupload(core, &c.q_child_off, prep.child_off.data(), (size_t)Q + 2));
+    TRY(dupload(core, &c.q_children, prep.children.data(), (size_t)std::max(Q, 1)));
+    TRY(dupload(core, &c.q_job_off, prep.job_off.data(), (size_t)Q + 1));
+    { const int32_t* t; TRY(dupload(core, &t, prep.jobs_by_queue.data(), (size_t)std::max(J, 1))); core->d_jobs_by_queue = const_cast<int32_t*>(t);
+      TRY(dupload(core, &t, prep.depth_order.data(), (size_t)Q)); core->d_depth_order = const_cast<int32_t*>(t);
+      TRY(dupload(core, &t, prep.lvl_off.data(), prep.lvl_off.size())); core->d_lvl_off = const_cast<int32_t*>(t);
+      TRY(dupload(core, &t, prep.lvl_parents.data(), prep.lvl_parents.size())); core->d_lvl_parents = const_cast<int32_t*>(t); }
+    core->n_levels = prep.n_levels;
+
+    // ---- dynamic state
+    double* d;
+    TRY(dalloc(core, &d, (size_t)R * N)); c.n_idle = d;
+    if ((size_t)R * N) HIP_TRY(core, hipMemcpyAsync(c.n_idle, c.n_alloc, (size_t)R * N * sizeof(double), hipMemcpyDeviceToDevice, core->stream));  // NewNodeInfo: Idle = Allocatable
+    TRY(dzero(core, &c.n_rel, (size_t)R * N)); TRY(dzero(core, &c.n_used, (size_t)R * N));
+    { int32_t* t; TRY(dalloc(core, &t, (size_t)P)); c.p_status = t; if (P) HIP_TRY(core, hipMemcpyAsync(t, s->pod_status, (size_t)P * 4, hipMemcpyHostToDevice, core->stream));
+      TRY(dalloc(core, &t, (size_t)P)); c.p_node = t; if (P) HIP_TRY(core, hipMemcpyAsync(t, s->pod_node, (size_t)P * 4, hipMemcpyHostToDevice, core->stream)); }
+    TRY(dzero(core, &c.p_on_node, (size_t)P)); TRY(dzero(core, &c.p_on_node_status, (size_t)P)); TRY(dzero(core, &c.p_virtual, (size_t)P)); TRY(dzero(core, &c.p_accepted, (size_t)P));
+    TRY(dzero(core, &c.s_active_alloc, (size_t)S)); TRY(dzero(core, &c.s_active_used, (size_t)S)); TRY(dzero(core, &c.s_alive, (size_t)S)); TRY(dzero(core, &c.s_gated, (size_t)S)); TRY(dzero(core, &c.s_pipelined, (size_t)S));
+    TRY(dzero(core, &c.j_n_pending, (size_t)J)); TRY(dzero(core, &c.j_tta_valid, (size_t)J)); TRY(dzero(core, &c.j_tta_n, (size_t)J)); TRY(dzero(core, &c.tta, (size_t)P));
+    TRY(dzero(core, &c.j_tta_res, (size_t)3 * J)); TRY(dzero(core, &c.j_allocated, (size_t)3 * J));
+    TRY(dzero(core, &c.jheap, (size_t)J)); TRY(dzero(core, &c.jheap_len, (size_t)Q)); TRY(dzero(core, &c.qheap, (size_t)Q + 1)); TRY(dzero(core, &c.qheap_len, (size_t)Q + 1)); TRY(dzero(core, &c.root_heap, (size_t)Q + 1));
+    TRY(dzero(core, &c.qn_exists, (size_t)Q)); TRY(dzero(core, &c.qn_reorder, (size_t)Q)); TRY(dzero(core, &c.qn_linked, (size_t)Q));
+    c.ops_cap = 4 * P + 64; TRY(dalloc(core, &c.ops, (size_t)c.ops_cap));
+    c.out_cap = (int64_t)2 * P + 64; TRY(dalloc(core, &c.out_ops, (size_t)c.out_cap));
+    TRY(dzero(core, &c.scratch, (size_t)P + 64));
+    TRY(dzero(core, &c.st, (size_t)1));
+    TRY(dzero(core, &core->d_jsum, (size_t)9 * J));
+    TRY(dzero(core, &core->d_weight, (size_t)3 * Q)); TRY(dzero(core, &core->d_rem_amt, (size_t)3 * Q)); TRY(dzero(core, &core->d_rem_has, (size_t)3 * Q));
+    TRY(dzero(core, &core->d_best_out, (size_t)2));
+    { const QShare* t; TRY(dupload(core, &t, prep.shares.data(), prep.shares.size())); c.q_share = const_cast<QShare*>(t); }
+#undef TRY
+#define TRY2(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+    // keep the initial dynamic state in HBM so that kai_session_reset needs no host traffic
+    TRY2(dalloc(core, &core->d_status0, (size_t)P)); TRY2(dalloc(core, &core->d_node0, (size_t)P)); TRY2(dalloc(core, &core->d_shares0, (size_t)std::max(Q, 1) * 3));
+    if (P) { HIP_TRY(core, hipMemcpyAsync(core->d_status0, c.p_status, (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream));
+             HIP_TRY(core, hipMemcpyAsync(core->d_node0, c.p_node, (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream)); }
+    HIP_TRY(core, hipMemcpyAsync(core->d_shares0, c.q_share, (size_t)std::max(Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
+    { int rc2 = launch_open_kernels(core); if (rc2) return rc2; }
+    HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));
+    std::memset(&core->stats, 0, sizeof(core->stats));
+    core->stats.upload_ms = ms;
+    core->open = true; core->err = "ok";
+    return KAI_OK;
+}
+
+int kai_session_reset(kai_core* core) {
+    if (!core) return KAI_ERR_INVALID_ARG;
+    if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
+    HIP_TRY(core, hipSetDevice(core->device));
+    KaiCtx& c = core->ctx;
+    const size_t RN = (size_t)c.R * c.N;
+    HIP_TRY(core, hipEventRecord(core->ev0, core->stream));
+    if (RN) { HIP_TRY(core, hipMemcpyAsync(c.n_idle, c.n_alloc, RN * 8, hipMemcpyDeviceToDevice, core->stream));
+              HIP_TRY(core, hipMemsetAsync(c.n_rel, 0, RN * 8, core->stream)); HIP_TRY(core, hipMemsetAsync(c.n_used, 0, RN * 8, core->stream)); }
+    if (c.P) { HIP_TRY(core, hipMemcpyAsync(c.p_status, core->d_status0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream));
+               HIP_TRY(core, hipMemcpyAsync(c.p_node, core->d_node0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream)); }
+    HIP_TRY(core, hipMemcpyAsync(c.q_share, core->d_shares0, (size_t)std::max(c.Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
+    HIP_TRY(core, hipMemsetAsync(c.st, 0, sizeof(EngineState), core->stream));
+    int rc = launch_open_kernels(core); if (rc) return rc;
+    HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));
+    core->stats.upload_ms = ms;
+    return KAI_OK;
+}
+
+int kai_queue_shares(kai_core* core, kai_queue_share* out, int cap) {
+    if (!core || !out) return KAI_ERR_INVALID_ARG;
+    if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
+    const int Q = core->ctx.Q;
+    if (cap < Q) return fail(core, KAI_ERR_CAPACITY, "kai_queue_shares: cap < n_queues");
+    HIP_TRY(core, hipSetDevice(core->device));
+    std::vector<QShare> h((size_t)std::max(Q, 1) * 3);
+    HIP_TRY(core, hipMemcpyAsync(h.data(), core->ctx.q_share, (size_t)Q * 3 * sizeof(QShare), hipMemcpyDeviceToHost, core->stream));
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    for (int q = 0; q < Q; q++) for (int k = 0; k < 3; k++) {
+        const QShare& x = h[(size_t)q * 3 + k];
+        out[q].fair_share[k] = x.fair; out[q].allocated[k] = x.allocated; out[q].allocated_non_preemptible[k] = x.allocated_np;
+        out[q].request[k] = x.request; out[q].deserved[k] = x.deserved; out[q].max_allowed[k] = x.max_allowed;
+    }
+    return KAI_OK;
+}
+
+int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_cap, int64_t* n_ops) {
+    if (!core || !n_ops) return KAI_ERR_INVALID_ARG;
+    if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
+    if (action != KAI_ACTION_ALLOCATE) return fail(core, KAI_ERR_UNSUPPORTED, "only the allocate action is built so far");
+    HIP_TRY(core, hipSetDevice(core->device));
+    KaiCtx& c = core->ctx;
+    // reset the per-action scalars, keep the proportion totals
+    EngineState st{};
+    HIP_TRY(core, hipMemcpyAsync(&st, c.st, sizeof(st), hipMemcpyDeviceToHost, core->stream));
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    double total[3] = {st.total[0], st.total[1], st.total[2]};
+    st = EngineState{}; st.total[0] = total[0]; st.total[1] = total[1]; st.total[2] = total[2];
+    HIP_TRY(core, hipMemcpyAsync(c.st, &st, sizeof(st), hipMemcpyHostToDevice, core->stream));
+    HIP_TRY(core, hipEventRecord(core->ev0, core->stream));
+    hipLaunchKernelGGL(k_action, dim3(1), dim3(WG), 0, core->stream, c, action);
+    HIP_TRY(core, hipGetLastError());
+    HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
+    HIP_TRY(core, hipMemcpyAsync(&st, c.st, sizeof(st), hipMemcpyDeviceToHost, core->stream));
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));
+    double upload = core->stats.upload_ms;
+    std::memset(&core->stats, 0, sizeof(core->stats));
+    core->stats.upload_ms = upload; core->stats.kernel_ms = ms; core->stats.decisions = st.decisions; core->stats.node_scans = st.node_scans;
+    core->stats.nodes_scanned = st.nodes_scanned; core->stats.jobs_attempted = st.jobs_attempted; core->stats.jobs_committed = st.jobs_committed; core->stats.rollbacks = st.rollbacks;
+    if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d", st.fault); core->err = buf; return KAI_ERR_DEVICE_FAULT; }
+    *n_ops = st.out_len;
+    if (ops_out) {
+        if (st.out_len > ops_cap) return fail(core, KAI_ERR_CAPACITY, "kai_action_execute: ops_cap too small");
+        if (st.out_len) HIP_TRY(core, hipMemcpyAsync(ops_out, c.out_ops, (size_t)st.out_len * sizeof(kai_op), hipMemcpyDeviceToHost, core->stream));
+        HIP_TRY(core, hipStreamSynchronize(core->stream));
+    }
+    return KAI_OK;
+}
+
+int kai_best_node(kai_core* core, int32_t pod_idx, const uint32_t* nodeset_bitmap, int pipeline_only, int32_t* node_idx_out, int* is_pipeline_out) {
+    if (!core || !node_idx_out) return KAI_ERR_INVALID_ARG;
+    if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
+    if (nodeset_bitmap) return fail(core, KAI_ERR_UNSUPPORTED, "node-set bitmaps arrive with the topology plugin");
+    if (pod_idx < 0 || pod_idx >= core->ctx.P) return fail(core, KAI_ERR_INVALID_ARG, "pod index out of range");
+    HIP_TRY(core, hipSetDevice(core->device));
+    hipLaunchKernelGGL(k_best_node, dim3(1), dim3(WG), 0, core->stream, core->ctx, (int)pod_idx, pipeline_only, core->d_best_out);
+    HIP_TRY(core, hipGetLastError());
+    int32_t h[2] = {-1, 0};
+    HIP_TRY(core, hipMemcpyAsync(h, core->d_best_out, sizeof h, hipMemcpyDeviceToHost, core->stream));
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    *node_idx_out = h[0];
+    if (is_pipeline_out) *is_pipeline_out = h[1];
+    return KAI_OK;
+}
+
+int kai_pod_states(kai_core* core, int32_t* status_out, int32_t* node_out, int cap) {
+    if (!core) return KAI_ERR_INVALID_ARG;
+    if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
+    const int P = core->ctx.P;
+    if (cap < P) return fail(core, KAI_ERR_CAPACITY, "kai_pod_states: cap < n_pods");
+    HIP_TRY(core, hipSetDevice(core->device));
+    if (status_out && P) HIP_TRY(core, hipMemcpyAsync(status_out, core->ctx.p_status, (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
+    if (node_out && P) HIP_TRY(core, hipMemcpyAsync(node_out, core->ctx.p_node, (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    return KAI_OK;
+}
+
+int kai_node_states(kai_core* core, kai_node_state* out, int cap) {
+    if (!core || !out) return KAI_ERR_INVALID_ARG;
+    if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
+    const int N = core->ctx.N, R = core->ctx.R;
+    if (cap < N) return fail(core, KAI_ERR_CAPACITY, "kai_node_states: cap < n_nodes");
+    HIP_TRY(core, hipSetDevice(core->device));
+    std::vector<double> idle((size_t)R * N + 1), rel((size_t)R * N + 1), used((size_t)R * N + 1);
+    if (N) {
+        HIP_TRY(core, hipMemcpyAsync(idle.data(), core->ctx.n_idle, (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
+        HIP_TRY(core, hipMemcpyAsync(rel.data(), core->ctx.n_rel, (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
+        HIP_TRY(core, hipMemcpyAsync(used.data(), core->ctx.n_used, (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
+    }
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    for (int n = 0; n < N; n++) {
+        std::memset(&out[n], 0, sizeof(kai_node_state));
+        for (int r = 0; r < R; r++) { out[n].idle[r] = idle[(size_t)r * N + n]; out[n].releasing[r] = rel[(size_t)r * N + n]; out[n].used[r] = used[(size_t)r * N + n]; }
+    }
+    return KAI_OK;
+}
+
+int kai_action_stats_get(kai_core* core, kai_action_stats* out) {
+    if (!core || !out) return KAI_ERR_INVALID_ARG;
+    *out = core->stats;
+    return KAI_OK;
+}
+
+}  // extern "C"

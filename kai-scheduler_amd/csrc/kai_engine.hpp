@@ -1,0 +1,826 @@
+// kai_engine.hpp — device-resident scheduling-cycle engine (MI355X / gfx950).
+//
+// The whole session lives in HBM as structure-of-arrays (KaiCtx).  One persistent kernel executes an
+// Action: lane 0 of wave 0 runs the sequential control flow of the reference (fair job order, gang
+// loop, statement log — all of it inherently serial) and every other wavefront of the
+// launch serves its node scans (filter + score + arg-max over the node SoA).  This header holds the
+// control flow and the per-node arithmetic; kai_kernels.hip holds the cooperative scan, the
+// session-open kernels and the launch code.
+//
+// Everything here is `KAI_HD` so that tests/host_sim can compile the identical control flow for the
+// host to debug it without a GPU.  The product library only ever instantiates the device scanner and
+// fails without a HIP device (see kai_core.cpp); nothing in it runs on the CPU.
+//
+// Reference citations are file:line under pkg/scheduler.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/kai_core.h"
+
+#if defined(__HIPCC__)
+#define KAI_HD __host__ __device__ __forceinline__
+#define KAI_HD_NOINLINE __host__ __device__
+#else
+#define KAI_HD inline
+#define KAI_HD_NOINLINE
+#endif
+
+namespace kai {
+
+// pod status groups: api/pod_status/pod_status.go:64-71
+KAI_HD bool st_active_used(int s) { return s & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING); }
+KAI_HD bool st_active_allocated(int s) { return s & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING); }
+KAI_HD bool st_alive(int s) { return s & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_PENDING | KAI_POD_GATED); }
+KAI_HD bool st_allocated(int s) { return s & (KAI_POD_ALLOCATED | KAI_POD_BOUND | KAI_POD_BINDING | KAI_POD_RUNNING); }
+
+KAI_HD double kmin(double a, double b) { return a < b ? a : b; }  // math.Min / math.Max on finite, non-NaN operands
+KAI_HD double kmax(double a, double b) { return a > b ? a : b; }
+
+// plugins/proportion/resource_share/resource_share.go:12-21
+struct QShare {
+    double deserved, fair, max_allowed, oqw, allocated, allocated_np, request, usage;
+};
+KAI_HD double qs_requestable(const QShare& s) { return s.max_allowed == KAI_UNLIMITED ? s.request : kmin(s.max_allowed, s.request); }  // :41-46
+KAI_HD double qs_allocatable(const QShare& s) {  // :51-61
+    if (s.deserved == KAI_UNLIMITED) return s.max_allowed;
+    double a = kmax(s.deserved, s.fair);
+    if (s.max_allowed != KAI_UNLIMITED) a = kmin(s.max_allowed, a);
+    return a;
+}
+
+enum OpName : int32_t { OP_EVICT = 0, OP_PIPELINE = 1, OP_ALLOCATE = 2, OP_UNDO = 3 };
+// framework/operations.go
+struct StmtOp {
+    int32_t name, pod, prev_status, prev_node, next_node, prev_virtual, op_index, pad;
+};
+
+struct EngineState {  // mutable scalars of the running action
+    int32_t root_len, root_init;
+    int32_t ops_len;
+    int32_t fault;            // != 0: engine gave up (see FAULT_*)
+    int64_t out_len;
+    int64_t decisions, node_scans, nodes_scanned, jobs_attempted, jobs_committed, rollbacks;
+    double total[3];          // proportion totalResource (CPU, Memory, GPU)
+};
+enum { FAULT_NONE = 0, FAULT_OPS_CAP = 1, FAULT_OUT_CAP = 2, FAULT_HEAP = 3, FAULT_INTERNAL = 4, FAULT_SPIN = 5 };
+
+// All pointers are device memory (HBM).  [R][N] arrays are resource-major.
+struct KaiCtx {
+    int32_t N, P, S, J, Q, R, n_pod_classes, n_node_classes;
+    uint32_t plugins; int32_t gpu_strategy, cpu_strategy, restrict_nodes; double k_value;
+    // nodes
+    const double* n_alloc; const uint32_t* n_flags; const int32_t* n_gpu_count; const uint32_t* n_name_rank; const int32_t* n_class;
+    double *n_idle, *n_rel, *n_used;
+    // pods
+    const double* p_req; const int32_t *p_job, *p_podset; const uint32_t* p_flags; const int32_t *p_class, *p_nominated;
+    int32_t *p_status, *p_node, *p_on_node, *p_on_node_status; uint8_t *p_virtual, *p_accepted;
+    // pod-sets
+    const int32_t *s_job, *s_min; const uint32_t* s_name_rank;
+    int32_t *s_active_alloc, *s_active_used, *s_alive, *s_gated, *s_pipelined;
+    // jobs
+    const int32_t *j_queue, *j_prio, *j_preempt; const int64_t* j_created; const uint32_t* j_uid_rank;
+    const int32_t *j_first_pod, *j_n_pods, *j_first_ps, *j_n_ps;
+    const int32_t* j_pods_sorted;  // [P] each job's pods in TaskOrderFn order (session_plugins.go:244-260), same region as the job's pods
+    int32_t *j_n_pending, *j_tta_valid, *j_tta_n, *tta;  // tasks-to-allocate cache (allocation_info.go:31-33), region = job's pod range
+    double *j_tta_res;  // [3][J] init resource of the cached chunk (CPU, Memory, GPU)
+    double *j_allocated;  // [3][J] PodGroupInfo.Allocated
+    // queues
+    const int32_t *q_parent, *q_prio; const int64_t* q_created; const uint32_t* q_uid_rank;
+    const int32_t *q_child_off, *q_children, *q_job_off;  // CSR children; leaf job-heap regions
+    QShare* q_share;  // [Q][3]
+    const uint8_t* class_fit;
+    // job-order tree (actions/utils/job_order_by_queue.go): heaps are array regions
+    int32_t *jheap, *jheap_len, *qheap, *qheap_len, *root_heap; uint8_t *qn_exists, *qn_reorder, *qn_linked;
+    // statement + committed operations
+    StmtOp* ops; int32_t ops_cap; kai_op* out_ops; int64_t out_cap;
+    int32_t* scratch;  // [P] ints
+    EngineState* st;
+};
+
+// ======================================================================================================
+// per-node arithmetic shared by every scanner
+// ======================================================================================================
+struct ScanReq {
+    int32_t pod, cpu_only, best_effort, pod_class, nominated, r_place, strategy, pad;
+    double req[KAI_MAX_RES];
+    double min_a, max_a;  // nodeplacement.setBinpackPreOrder range (plugins/nodeplacement/pack.go:35-43)
+};
+
+KAI_HD bool fits(const KaiCtx& c, const ScanReq& q, int n, bool with_releasing) {
+    // ResourceRequirements.LessEqualResource (api/resource_info/resource_requirment.go:126-140) against Idle, or against
+    // NodeInfo.NonAllocatedResources = 0 + Idle + Releasing (api/node_info/node_info.go:157-162)
+    for (int r = 0; r < c.R; r++) {
+        double req = q.req[r];
+        if (r >= KAI_RES_PODS && !(req > 0)) continue;  // scalar keys exist only for non-zero requests
+        double avail = c.n_idle[(size_t)r * c.N + n];
+        if (with_releasing) avail = avail + c.n_rel[(size_t)r * c.N + n];
+        if (req > avail) return false;
+    }
+    return true;
+}
+
+// plugins/predicates/predicates.go:173-262 minus the queue-capacity step (node independent, done by the control lane)
+KAI_HD bool node_predicates(const KaiCtx& c, const ScanReq& q, int n) {
+    if (!(c.plugins & KAI_PLUGIN_PREDICATES)) return true;
+    uint32_t f = c.n_flags[n];
+    if (!q.cpu_only) {  // NodeInfo.PredicateByNodeResourcesType (api/node_info/node_info.go:315-359)
+        if (f & KAI_NODE_HAS_DRA_GPUS) return false;
+        if ((f & KAI_NODE_MIG_ENABLED) && (f & KAI_NODE_MIG_MIXED)) return false;
+    }
+    double pods = c.n_idle[(size_t)KAI_RES_PODS * c.N + n] + c.n_rel[(size_t)KAI_RES_PODS * c.N + n];  // :264-285
+    if (!(pods > 0)) return false;
+    if (f & KAI_NODE_NOT_READY) return false;
+    if (!c.class_fit[(size_t)q.pod_class * c.n_node_classes + c.n_class[n]]) return false;
+    if (c.restrict_nodes) {
+        if (!q.cpu_only) { if (!(f & KAI_NODE_GPU_WORKER)) return false; }
+        else if (!(f & KAI_NODE_CPU_WORKER)) return false;
+    }
+    return true;
+}
+
+// Σ NodeOrderFns in registration order (framework/session_plugins.go:427-437, conf_util/scheduler_conf_util.go:39-60)
+KAI_HD double node_score(const KaiCtx& c, const ScanReq& q, int n, bool fit_idle) {
+    double score = 0.0;
+    if (c.plugins & KAI_PLUGIN_NODEAVAILABILITY) score += fit_idle ? 100.0 : 0.0;  // plugins/nodeavailability/nodeavailability.go:29-40
+    uint32_t f = c.n_flags[n];
+    if (c.plugins & KAI_PLUGIN_RESOURCETYPE) {  // plugins/resourcetype/resourcetype.go:29-41, node_info.go:697-702
+        bool cpu_only_node = !(f & KAI_NODE_MIG_ENABLED) && c.n_alloc[(size_t)KAI_RES_GPU * c.N + n] <= 0 && !(f & KAI_NODE_HAS_DRA_GPUS);
+        score += (q.cpu_only && cpu_only_node) ? 10.0 : 0.0;
+    }
+    if (c.plugins & KAI_PLUGIN_NOMINATEDNODE) score += (q.nominated >= 0 && q.nominated == n) ? 1000000.0 : 0.0;
+    if (c.plugins & KAI_PLUGIN_NODEPLACEMENT) {
+        int r = q.r_place;
+        double cur = c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n];
+        double overall = c.n_alloc[(size_t)r * c.N + n];
+        double place;
+        if (q.strategy == KAI_SPREAD) {  // plugins/nodeplacement/spread.go:16-36
+            double count = overall;
+            if (r == KAI_RES_GPU) { int lbl = c.n_gpu_count[n]; count = lbl >= 0 ? (double)lbl : (double)(int64_t)overall; }
+            place = count == 0 ? 0.0 : cur / count;
+        } else {  // plugins/nodeplacement/pack.go:45-64
+            if (overall == 0) place = 0.0;
+            else if (q.max_a == 0) place = 0.0;
+            else if (q.min_a == q.max_a) place = 9.0;
+            else place = 9.0 * (1 - (cur - q.min_a) / (q.max_a - q.min_a));
+        }
+        score += place;
+    }
+    return score;
+}
+
+struct ScanResult { int32_t node; };
+
+// ======================================================================================================
+// Engine<Scanner>: the control flow.  Scanner provides
+//    void minmax(const KaiCtx&, int r, double& mn, double& mx)          — pack.go:66-86 over the node set
+//    int  best_node(const KaiCtx&, const ScanReq&)                      — arg-max of (score, -name_rank) over fitting nodes
+// ======================================================================================================
+template <class Scanner>
+struct Engine {
+    KaiCtx c; Scanner& sc;
+    KAI_HD Engine(const KaiCtx& ctx, Scanner& s) : c(ctx), sc(s) {}
+
+    KAI_HD void fault(int code) { if (!c.st->fault) c.st->fault = code; }
+    KAI_HD double preq(int p, int r) const { return c.p_req[(size_t)r * c.P + p]; }
+    KAI_HD bool pod_cpu_only(int p) const { return !(preq(p, KAI_RES_GPU) > 0); }  // pod_info.go:340-347
+    KAI_HD bool pod_best_effort(int p) const {  // ResourceRequirements.IsEmpty (resource_requirment.go:99-104, base_resources.go:119-130)
+        if (preq(p, KAI_RES_GPU) > 0.01) return false;
+        if (preq(p, KAI_RES_CPU) >= 10.0 || preq(p, KAI_RES_MEM) >= 10.0 * 1024 * 1024) return false;
+        for (int r = KAI_RES_PODS; r < c.R; r++) if (preq(p, r) >= 10.0) return false;
+        return true;
+    }
+    KAI_HD bool should_allocate(int p, bool real) const {  // pod_info.go:518-521
+        int s = c.p_status[p];
+        return s == KAI_POD_PENDING || (!real && s == KAI_POD_RELEASING && c.p_virtual[p]);
+    }
+    // quota triple of a pod: utils.QuantifyResourceRequirements (plugins/proportion/utils/utils.go:15-17)
+    KAI_HD double pquota(int p, int k) const { return k == KAI_Q_CPU ? preq(p, KAI_RES_CPU) : k == KAI_Q_MEM ? preq(p, KAI_RES_MEM) : preq(p, KAI_RES_GPU); }
+
+    // ------------------------------------------------------------------ status bookkeeping
+    // PodGroupInfo.UpdateTaskStatus (api/podgroup_info/job_info.go:228-287) + PodSet.AssignTask (subgroup_info/podset.go:56-99)
+    KAI_HD void update_task_status(int p, int status) {
+        int j = c.p_job[p], s = c.p_podset[p], old = c.p_status[p];
+        if (st_allocated(old)) for (int k = 0; k < 3; k++) c.j_allocated[(size_t)k * c.J + j] -= pquota(p, k);
+        if (st_active_allocated(old)) c.s_active_alloc[s]--;
+        if (st_active_used(old)) c.s_active_used[s]--;
+        if (st_alive(old)) c.s_alive[s]--;
+        if (old == KAI_POD_GATED) c.s_gated[s]--;
+        if (old == KAI_POD_PIPELINED) c.s_pipelined[s]--;
+        if (old == KAI_POD_PENDING) c.j_n_pending[j]--;
+        c.p_status[p] = status;
+        if (st_allocated(status)) for (int k = 0; k < 3; k++) c.j_allocated[(size_t)k * c.J + j] += pquota(p, k);
+        if (st_active_allocated(status)) c.s_active_alloc[s]++;
+        if (st_active_used(status)) c.s_active_used[s]++;
+        if (st_alive(status)) c.s_alive[s]++;
+        if (status == KAI_POD_GATED) c.s_gated[s]++;
+        if (status == KAI_POD_PIPELINED) c.s_pipelined[s]++;
+        if (status == KAI_POD_PENDING) c.j_n_pending[j]++;
+        c.j_tta_valid[j] = 0;  // invalidateTasksCache (job_info.go:253-256)
+    }
+
+    // ------------------------------------------------------------------ node accounting (api/node_info/node_info.go)
+    KAI_HD void node_apply(int n, int p, int status, double sign) {  // addTaskResources :457-493 / removeTaskResources :515-551
+        for (int r = 0; r < c.R; r++) {
+            double v = preq(p, r); if (v == 0) continue;
+            size_t i = (size_t)r * c.N + n;
+            c.n_used[i] += sign * v;
+            if (status == KAI_POD_RELEASING) { c.n_rel[i] += sign * v; c.n_idle[i] -= sign * v; }
+            else if (status == KAI_POD_PIPELINED) c.n_rel[i] -= sign * v;
+            else c.n_idle[i] -= sign * v;
+        }
+    }
+    KAI_HD bool node_add_task(int n, int p) {  // AddTask :384-417
+        if (st_active_used(c.p_status[p])) c.p_accepted[p] = 1;  // setAcceptedResources :746-766
+        if (c.p_on_node[p] == n) return false;                    // "task already on node"
+        if (c.p_on_node[p] >= 0) { fault(FAULT_INTERNAL); return false; }  // a pod on two nodes only happens in reclaim scenarios (not built yet)
+        c.p_on_node[p] = n; c.p_on_node_status[p] = c.p_status[p];
+        node_apply(n, p, c.p_status[p], 1.0);
+        return true;
+    }
+    KAI_HD bool node_remove_task(int n, int p) {  // RemoveTask :495-513 — with the status the node's copy was added with
+        if (c.p_on_node[p] != n) return false;
+        node_apply(n, p, c.p_on_node_status[p], -1.0);
+        c.p_on_node[p] = -1;
+        return true;
+    }
+    KAI_HD bool node_update_task(int n, int p) { if (!node_remove_task(n, p)) return false; return node_add_task(n, p); }  // :571-576
+
+    // ------------------------------------------------------------------ proportion event handlers (plugins/proportion/proportion.go:443-489)
+    KAI_HD void queue_event(int p, double sign) {
+        if (!(c.plugins & KAI_PLUGIN_PROPORTION)) return;
+        if (!c.p_accepted[p]) return;  // AcceptedResource is empty until the task was added to a node
+        int j = c.p_job[p]; bool np = !c.j_preempt[j];
+        for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
+            QShare& s = c.q_share[(size_t)q * 3 + k]; double v = pquota(p, k);
+            s.allocated += sign * v;
+            if (np) s.allocated_np += sign * v;
+        }
+    }
+
+    // ------------------------------------------------------------------ Statement (framework/statement.go)
+    KAI_HD int checkpoint() const { return c.st->ops_len; }
+    KAI_HD bool push_op(const StmtOp& o) { if (c.st->ops_len >= c.ops_cap) { fault(FAULT_OPS_CAP); return false; } c.ops[c.st->ops_len++] = o; return true; }
+    KAI_HD bool op_valid(int i) const {  // :652-663 — valid(i) = no undo of i, or that undo is itself undone (iterative form)
+        bool valid = true; int target = i;
+        for (;;) {
+            int u = -1;
+            for (int k = 0; k < c.st->ops_len; k++) if (c.ops[k].name == OP_UNDO && c.ops[k].op_index == target) { u = k; break; }
+            if (u < 0) return valid;
+            valid = !valid; target = u;
+        }
+    }
+    KAI_HD bool stmt_allocate(int p, int n) {  // :297-358
+        update_task_status(p, KAI_POD_ALLOCATED);
+        c.p_node[p] = n;
+        if (!node_add_task(n, p)) return false;
+        queue_event(p, 1.0);
+        StmtOp o{}; o.name = OP_ALLOCATE; o.pod = p; o.next_node = n; o.prev_virtual = c.p_virtual[p]; o.op_index = -1;
+        if (!push_op(o)) return false;
+        c.p_virtual[p] = 1;
+        return true;
+    }
+    KAI_HD bool stmt_pipeline(int p, int n, bool update_if_exists) {  // :197-295
+        bool found_on_node = c.p_on_node[p] == n;
+        if (found_on_node && !update_if_exists) return stmt_unevict_earliest(p);
+        int prev_status = c.p_status[p];
+        update_task_status(p, KAI_POD_PIPELINED);
+        int prev_node = c.p_node[p]; c.p_node[p] = n; int prev_virtual = c.p_virtual[p];
+        if (found_on_node) node_update_task(n, p); else if (!node_add_task(n, p)) return false;
+        queue_event(p, 1.0);
+        StmtOp o{}; o.name = OP_PIPELINE; o.pod = p; o.prev_status = prev_status; o.prev_node = prev_node; o.next_node = n; o.prev_virtual = prev_virtual; o.op_index = -1;
+        if (!push_op(o)) return false;
+        c.p_virtual[p] = 1;
+        return true;
+    }
+    KAI_HD bool stmt_evict(int p) {  // :63-126
+        int n = c.p_node[p]; if (n < 0) return false;
+        int prev_status = c.p_status[p], prev_virtual = c.p_virtual[p];
+        update_task_status(p, KAI_POD_RELEASING);
+        if (!node_update_task(n, p)) return false;
+        queue_event(p, -1.0);
+        StmtOp o{}; o.name = OP_EVICT; o.pod = p; o.prev_status = prev_status; o.prev_node = n; o.prev_virtual = prev_virtual; o.op_index = -1;
+        if (!push_op(o)) return false;
+        c.p_virtual[p] = 1;
+        return true;
+    }
+    KAI_HD void unallocate(int p, int prev_virtual) {  // :391-425
+        update_task_status(p, KAI_POD_PENDING);
+        int n = c.p_node[p];
+        if (n >= 0) node_remove_task(n, p);
+        c.p_node[p] = -1; c.p_virtual[p] = (uint8_t)prev_virtual;
+        queue_event(p, -1.0);
+    }
+    KAI_HD void unpipeline(int p, int prev_node, int prev_status, int prev_virtual) {  // :431-476
+        update_task_status(p, prev_status);
+        int host = c.p_node[p]; c.p_node[p] = prev_node; c.p_virtual[p] = (uint8_t)prev_virtual;
+        if (host >= 0) node_remove_task(host, p);
+        queue_event(p, -1.0);
+    }
+    KAI_HD void unevict(int p, int prev_status, int n, int prev_virtual) {  // :152-195
+        update_task_status(p, prev_status);
+        c.p_virtual[p] = (uint8_t)prev_virtual;
+        if (n >= 0) { if (c.p_on_node[p] == n) node_update_task(n, p); else node_add_task(n, p); }
+        queue_event(p, 1.0);
+    }
+    KAI_HD bool stmt_unevict_earliest(int p) {  // Unevict → undoEarliestValidOperation :478-481,578-600
+        for (int i = 0; i < c.st->ops_len; i++) {
+            if (!op_valid(i)) continue;
+            if (c.ops[i].name != OP_EVICT || c.ops[i].pod != p) continue;
+            undo_operation(i); return true;
+        }
+        return false;
+    }
+    KAI_HD void undo_operation(int index) {  // :602-643
+        if (!op_valid(index)) return;
+        StmtOp op = c.ops[index];
+        switch (op.name) {
+            case OP_EVICT: unevict(op.pod, op.prev_status, op.prev_node, op.prev_virtual); break;
+            case OP_PIPELINE: unpipeline(op.pod, op.prev_node, op.prev_status, op.prev_virtual); break;
+            case OP_ALLOCATE: unallocate(op.pod, op.prev_virtual); break;
+            default: fault(FAULT_INTERNAL); return;  // undo of an undo (= redo) only arises in victim scenarios; not on the allocate path
+        }
+        StmtOp u{}; u.name = OP_UNDO; u.pod = -1; u.op_index = index;
+        push_op(u);
+    }
+    KAI_HD void rollback(int cp) {  // :48-61
+        for (int i = c.st->ops_len - 1; i >= cp; i--) undo_operation(i);
+        c.st->ops_len = cp; c.st->rollbacks++;
+    }
+    KAI_HD void discard() { for (int i = c.st->ops_len - 1; i >= 0; i--) undo_operation(i); c.st->ops_len = 0; }  // :522-534
+    KAI_HD bool convert_all_allocated_to_pipelined(int job) {  // :483-516
+        int n0 = c.st->ops_len;
+        for (int i = 0; i < n0; i++) {
+            StmtOp op = c.ops[i];
+            if (op.name != OP_ALLOCATE || c.p_job[op.pod] != job) continue;
+            int node = c.p_node[op.pod];
+            unallocate(op.pod, 1);
+            if (!stmt_pipeline(op.pod, node, true)) return false;
+        }
+        int w = 0;
+        for (int i = 0; i < c.st->ops_len; i++) {
+            StmtOp op = c.ops[i];
+            if (op.name == OP_ALLOCATE && c.p_job[op.pod] == job) continue;
+            c.ops[w++] = op;
+        }
+        c.st->ops_len = w;
+        return true;
+    }
+    KAI_HD void commit() {  // :536-575 — the cache side effects are replayed by the caller from out_ops
+        for (int i = 0; i < c.st->ops_len; i++) {
+            if (!op_valid(i)) continue;
+            StmtOp op = c.ops[i]; if (op.name == OP_UNDO) continue;
+            if (c.st->out_len >= c.out_cap) { fault(FAULT_OUT_CAP); break; }
+            kai_op o; o.seq = c.st->out_len; o.pod = op.pod; o.job = c.p_job[op.pod]; o.node = c.p_node[op.pod];
+            if (op.name == OP_EVICT) { o.kind = KAI_OP_EVICT; o.node = op.prev_node; c.p_virtual[op.pod] = 0; }
+            else if (op.name == OP_PIPELINE) o.kind = KAI_OP_PIPELINE;
+            else { o.kind = KAI_OP_ALLOCATE; update_task_status(op.pod, KAI_POD_BINDING); }  // ssn.BindPod (framework/session.go:111-126)
+            c.out_ops[c.st->out_len++] = o;
+        }
+        c.st->ops_len = 0;
+    }
+
+    // ------------------------------------------------------------------ order functions
+    KAI_HD void min_available_state(int j, bool& below, bool& above, bool& exactly) const {  // plugins/elastic/elastic.go:53-65
+        exactly = true;
+        for (int k = 0; k < c.j_n_ps[j]; k++) {
+            int s = c.j_first_ps[j] + k; int n = c.s_active_alloc[s], m = c.s_min[s];
+            if (n < m) { below = true; above = false; exactly = false; return; }
+            if (n > m) exactly = false;
+        }
+        below = false; above = !exactly;
+    }
+    KAI_HD bool job_order(int l, int r) const {  // framework/session_plugins.go:227-242
+        if (c.plugins & KAI_PLUGIN_PRIORITY) {
+            if (c.j_prio[l] > c.j_prio[r]) return true;
+            if (c.j_prio[l] < c.j_prio[r]) return false;
+        }
+        if (c.plugins & KAI_PLUGIN_ELASTIC) {
+            bool lb, la, le, rb, ra, re; min_available_state(l, lb, la, le); min_available_state(r, rb, ra, re);
+            if (lb && !rb) return true;
+            if (le && ra) return true;
+            if (!lb && rb) return false;
+            if (la && re) return false;
+        }
+        if (c.j_created[l] == c.j_created[r]) return c.j_uid_rank[l] < c.j_uid_rank[r];
+        return c.j_created[l] < c.j_created[r];
+    }
+    KAI_HD bool podset_order(int l, int r) const {  // session_plugins.go:262-271 + plugins/subgrouporder/subgroup_order.go:31-62
+        if (c.plugins & KAI_PLUGIN_SUBGROUPORDER) {
+            int ln = c.s_active_alloc[l], rn = c.s_active_alloc[r];
+            bool ls = ln >= c.s_min[l], rs = rn >= c.s_min[r];
+            if (!ls && !rs) return c.s_name_rank[l] < c.s_name_rank[r];
+            if (!ls) return true;
+            if (!rs) return false;
+            double lr = (double)ln / (double)c.s_min[l], rr = (double)rn / (double)c.s_min[r];
+            if (lr < rr) return true;
+            if (rr < lr) return false;
+        }
+        return c.s_name_rank[l] < c.s_name_rank[r];
+    }
+
+    // ------------------------------------------------------------------ tasks to allocate (api/podgroup_info/allocation_info.go:27-177)
+    KAI_HD void ensure_tta(int j, bool real) {
+        if (c.j_tta_valid[j]) return;
+        int first = c.j_first_pod[j], np = c.j_n_pods[j], nps = c.j_n_ps[j], ps0 = c.j_first_ps[j];
+        int unsat = 0; for (int k = 0; k < nps; k++) if (c.s_active_alloc[ps0 + k] < c.s_min[ps0 + k]) unsat++;
+        int max_sg = unsat > 0 ? unsat : 1, n_sg = 0, out = 0;
+        // pod-sets leave the priority queue in PodSetOrderFn order: repeated arg-min, podsets per job are few
+        uint64_t taken_lo = 0;  // bitmap for up to 64 pod-sets; larger jobs fall back to the scratch array
+        for (int round = 0; round < nps && n_sg < max_sg; round++) {
+            int best = -1;
+            for (int k = 0; k < nps; k++) {
+                bool taken = k < 64 ? ((taken_lo >> k) & 1) : (c.scratch[first + (k - 64)] != 0);
+                if (taken) continue;
+                if (best < 0 || podset_order(ps0 + k, ps0 + best)) best = k;
+            }
+            if (best < 0) break;
+            if (best < 64) taken_lo |= (1ull << best); else c.scratch[first + (best - 64)] = 1;
+            int s = ps0 + best;
+            int avail = 0; for (int i = 0; i < np; i++) { int p = c.j_pods_sorted[first + i]; if (c.p_podset[p] == s && should_allocate(p, real)) avail++; }
+            if (avail == 0) continue;
+            int max_tasks = c.s_active_alloc[s] >= c.s_min[s] ? (avail < 1 ? avail : 1) : (c.s_min[s] - c.s_active_alloc[s]);  // getNumTasksToAllocate :145-153
+            int got = 0;
+            for (int i = 0; i < np && got < max_tasks; i++) { int p = c.j_pods_sorted[first + i]; if (c.p_podset[p] == s && should_allocate(p, real)) { c.tta[first + out++] = p; got++; } }
+            n_sg++;
+        }
+        if (nps > 64) for (int k = 64; k < nps; k++) c.scratch[first + (k - 64)] = 0;
+        c.j_tta_n[j] = out;
+        double res[3] = {0, 0, 0};  // GetTasksToAllocateInitResource :88-113
+        for (int i = 0; i < out; i++) { int p = c.tta[first + i]; if (should_allocate(p, real)) for (int k = 0; k < 3; k++) res[k] += pquota(p, k); }
+        for (int k = 0; k < 3; k++) c.j_tta_res[(size_t)k * c.J + j] = res[k];
+        c.j_tta_valid[j] = 1;
+    }
+
+    // ------------------------------------------------------------------ proportion: queue order + capacity
+    KAI_HD double dominant_share(int q, const double* add) const {  // resource_share/queue_resource_share.go:142-166
+        double dom = 0.0;
+        for (int k = 0; k < 3; k++) {
+            const QShare& s = c.q_share[(size_t)q * 3 + k];
+            double allocatable = qs_allocatable(s);
+            if (allocatable == KAI_UNLIMITED) allocatable = c.st->total[k];
+            double allocated = s.allocated; if (add) allocated += add[k];
+            double v = allocatable == 0 ? allocated * 1000 : allocated / allocatable;
+            dom = kmax(dom, v);
+        }
+        return dom;
+    }
+    KAI_HD static int cmp_q(double a, double b) {  // resource_quantities.go:80-97
+        if (a == KAI_UNLIMITED) return b == KAI_UNLIMITED ? 0 : 1;
+        if (b == KAI_UNLIMITED) return -1;
+        return a > b ? 1 : a < b ? -1 : 0;
+    }
+    // plugins/proportion/queue_order/queue_order.go:19-73 (allocate ordering: no victims)
+    KAI_HD int queue_order(int lq, int rq, int lj, int rj) {
+        const QShare* L = &c.q_share[(size_t)lq * 3]; const QShare* Rr = &c.q_share[(size_t)rq * 3];
+        {   // prioritizeUnderUtilized :87-98 — FairShare.Less(Allocated) in all three
+            bool lo = true, ro = true;
+            for (int k = 0; k < 3; k++) { if (L[k].fair >= L[k].allocated) lo = false; if (Rr[k].fair >= Rr[k].allocated) ro = false; }
+            if (!lo && ro) return -1;
+            if (lo && !ro) return 1;
+        }
+        double lreq[3] = {0, 0, 0}, rreq[3] = {0, 0, 0};
+        if (lj >= 0) { ensure_tta(lj, false); for (int k = 0; k < 3; k++) lreq[k] = c.j_tta_res[(size_t)k * c.J + lj]; }
+        if (rj >= 0) { ensure_tta(rj, false); for (int k = 0; k < 3; k++) rreq[k] = c.j_tta_res[(size_t)k * c.J + rj]; }
+        double lal[3], ral[3]; for (int k = 0; k < 3; k++) { lal[k] = L[k].allocated + lreq[k]; ral[k] = Rr[k].allocated + rreq[k]; }
+        {   // prioritizeUnderQuotaWithJob :100-125
+            bool ls = true, rs = true;
+            for (int k = 0; k < 3; k++) { if (cmp_q(lal[k], L[k].deserved) > 0) ls = false; if (cmp_q(ral[k], Rr[k].deserved) > 0) rs = false; }
+            if (ls && !rs) return -1;
+            if (rs && !ls) return 1;
+        }
+        if (c.q_prio[lq] > c.q_prio[rq]) return -1;  // prioritizePrioritized :76-85
+        if (c.q_prio[lq] < c.q_prio[rq]) return 1;
+        {   // penalizeZeroShareWithJob :127-176
+            bool lv = false, rv = false;
+            for (int k = 0; k < 3; k++) { if (qs_allocatable(L[k]) == 0 && lal[k] > 0) lv = true; if (qs_allocatable(Rr[k]) == 0 && ral[k] > 0) rv = true; }
+            if (lv && !rv) return 1;
+            if (!lv && rv) return -1;
+        }
+        { double l = dominant_share(lq, lreq), r = dominant_share(rq, rreq); if (l < r) return -1; if (l > r) return 1; }  // :178-196, 242-273
+        { double l = dominant_share(lq, nullptr), r = dominant_share(rq, nullptr); if (l < r) return -1; if (l > r) return 1; }  // :198-212
+        {   // prioritizeBasedOnAllocatableShare :214-224
+            bool l_le = true, r_le = true;
+            for (int k = 0; k < 3; k++) { int cmp = cmp_q(qs_allocatable(L[k]), qs_allocatable(Rr[k])); if (cmp > 0) l_le = false; if (cmp < 0) r_le = false; }
+            if (!r_le && l_le) return -1;  // l.LessInAtLeastOne(r) == !r.LessEqual(l)
+            if (!l_le && r_le) return 1;
+        }
+        if (c.q_created[lq] < c.q_created[rq]) return -1;  // :235-240
+        return 1;
+    }
+    KAI_HD bool queue_order_fn(int lq, int rq, int lj, int rj) {  // framework/session_plugins.go:283-299
+        if (c.plugins & KAI_PLUGIN_PROPORTION) { int v = queue_order(lq, rq, lj, rj); if (v != 0) return v < 0; }
+        if (c.q_created[lq] == c.q_created[rq]) return c.q_uid_rank[lq] < c.q_uid_rank[rq];
+        return c.q_created[lq] < c.q_created[rq];
+    }
+    KAI_HD bool over_limit(int j, const double* req) const {  // capacity_policy/max_allowed_check.go:20-66
+        for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
+            const QShare& s = c.q_share[(size_t)q * 3 + k];
+            if (s.max_allowed == KAI_UNLIMITED) continue;
+            if (req[k] == 0) continue;
+            if (s.max_allowed < s.allocated + req[k]) return true;
+        }
+        return false;
+    }
+    KAI_HD bool np_over_quota(int j, const double* req) const {  // capacity_policy/quota_check.go:27-77
+        if (c.j_preempt[j]) return false;
+        for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
+            const QShare& s = c.q_share[(size_t)q * 3 + k];
+            if (s.deserved == KAI_UNLIMITED) continue;
+            if (req[k] == 0) continue;
+            if (s.deserved < s.allocated_np + req[k]) return true;
+        }
+        return false;
+    }
+    KAI_HD bool job_over_queue_capacity(int j) const {  // capacity_policy.go:26-36,76-84
+        if (!(c.plugins & KAI_PLUGIN_PROPORTION)) return false;
+        double req[3] = {0, 0, 0}; int first = c.j_first_pod[j];
+        for (int i = 0; i < c.j_tta_n[j]; i++) { int p = c.tta[first + i]; req[KAI_Q_GPU] += pquota(p, KAI_Q_GPU); req[KAI_Q_CPU] += pquota(p, KAI_Q_CPU); req[KAI_Q_MEM] += pquota(p, KAI_Q_MEM); }
+        return over_limit(j, req) || np_over_quota(j, req);
+    }
+    KAI_HD bool task_over_capacity(int p) const {  // capacity_policy.go:51-61 with NodeInfo.GetRequiredInitQuota (node_info.go:734-744):
+        if (!(c.plugins & KAI_PLUGIN_PROPORTION)) return false;  // the GPU term is 1 for ANY whole-GPU request, 0 for CPU-only
+        double req[3] = {preq(p, KAI_RES_CPU), preq(p, KAI_RES_MEM), preq(p, KAI_RES_GPU) >= 1 ? 1.0 : 0.0};
+        int j = c.p_job[p];
+        return over_limit(j, req) || np_over_quota(j, req);
+    }
+
+    // ------------------------------------------------------------------ job-order tree (actions/utils/job_order_by_queue.go)
+    // Array heaps with container/heap's exact sift rules (scheduler_util/priority_queue.go).
+    KAI_HD bool q_is_leaf(int q) const { return c.q_child_off[q + 1] == c.q_child_off[q]; }
+    KAI_HD bool node_children_empty(int q) const { return q_is_leaf(q) ? c.jheap_len[q] == 0 : c.qheap_len[q] == 0; }
+    KAI_HD int best_job_from_node(int q) const {  // getBestJobFromNode :309-318 (pending ordering)
+        for (;;) {
+            if (q_is_leaf(q)) return c.jheap_len[q] > 0 ? c.jheap[c.q_job_off[q]] : -1;
+            if (c.qheap_len[q] == 0) return -1;
+            q = c.qheap[c.q_child_off[q]];
+        }
+    }
+    KAI_HD bool node_less(int l, int r) {  // buildNodeOrderFn :280-305
+        if (node_children_empty(l)) return true;
+        if (node_children_empty(r)) return false;
+        return queue_order_fn(l, r, best_job_from_node(l), best_job_from_node(r));
+    }
+    template <class Less> KAI_HD void heap_up(int32_t* h, int j, Less less) {
+        for (;;) { int i = (j - 1) / 2; if (i == j || !less(h[j], h[i])) break; int t = h[i]; h[i] = h[j]; h[j] = t; j = i; }
+    }
+    template <class Less> KAI_HD bool heap_down(int32_t* h, int i0, int n, Less less) {
+        int i = i0;
+        for (;;) {
+            int j1 = 2 * i + 1; if (j1 >= n || j1 < 0) break;
+            int j = j1, j2 = j1 + 1;
+            if (j2 < n && less(h[j2], h[j1])) j = j2;
+            if (!less(h[j], h[i])) break;
+            int t = h[i]; h[i] = h[j]; h[j] = t; i = j;
+        }
+        return i > i0;
+    }
+    struct JobLess { Engine* e; KAI_HD bool operator()(int a, int b) const { return e->job_order(a, b); } };
+    struct NodeLess { Engine* e; KAI_HD bool operator()(int a, int b) const { return e->node_less(a, b); } };
+
+    KAI_HD int32_t* node_heap(int parent) { return parent < 0 ? c.root_heap : c.qheap + c.q_child_off[parent]; }
+    KAI_HD int32_t& node_heap_len(int parent) { return parent < 0 ? c.st->root_len : c.qheap_len[parent]; }
+    KAI_HD void node_heap_push(int parent, int q) { int32_t* h = node_heap(parent); int32_t& n = node_heap_len(parent); h[n++] = q; heap_up(h, n - 1, NodeLess{this}); }
+    KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int32_t& n = node_heap_len(parent); n--; int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); }
+    KAI_HD void node_heap_fix0(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); if (!heap_down(h, 0, n, NodeLess{this})) heap_up(h, 0, NodeLess{this}); }
+
+    KAI_HD void ensure_ancestor_chain(int child) {  // :134-176
+        for (;;) {
+            int parent = c.q_parent[child];
+            if (parent < 0) { if (!c.qn_linked[child]) { c.st->root_init = 1; c.qn_linked[child] = 1; node_heap_push(-1, child); } return; }
+            bool parent_new = !c.qn_exists[parent];
+            if (parent_new) { c.qn_exists[parent] = 1; c.qn_reorder[parent] = 0; c.qn_linked[parent] = 0; c.qheap_len[parent] = 0; }
+            if (!c.qn_linked[child]) { c.qn_linked[child] = 1; node_heap_push(parent, child); }
+            if (!parent_new) return;
+            child = parent;
+        }
+    }
+    KAI_HD void push_job(int j) {  // :91-120
+        int q = c.j_queue[j];
+        if (!q_is_leaf(q)) return;
+        bool needs_linking = !c.qn_exists[q];
+        if (needs_linking) { c.qn_exists[q] = 1; c.qn_reorder[q] = 0; c.qn_linked[q] = 0; c.jheap_len[q] = 0; }
+        int32_t* h = c.jheap + c.q_job_off[q]; int n = c.jheap_len[q];
+        if (n >= c.q_job_off[q + 1] - c.q_job_off[q]) { fault(FAULT_HEAP); return; }
+        h[n] = j; c.jheap_len[q] = n + 1; heap_up(h, n, JobLess{this});
+        if (needs_linking) ensure_ancestor_chain(q);
+        for (int x = q; x >= 0; x = c.q_parent[x]) c.qn_reorder[x] = 1;  // markAncestorsForReorder: parent pointers follow the queue tree
+    }
+    KAI_HD int next_node(int parent) {  // getNextNode :194-217
+        for (;;) {
+            if (node_heap_len(parent) == 0) return -1;
+            int q = node_heap(parent)[0];
+            if (c.qn_reorder[q]) { node_heap_fix0(parent); c.qn_reorder[q] = 0; continue; }
+            if (node_children_empty(q)) return -1;
+            return q;
+        }
+    }
+    KAI_HD void handle_pop_from_node(int q) {  // :221-245
+        for (;;) {
+            int len = q_is_leaf(q) ? c.jheap_len[q] : c.qheap_len[q];
+            if (len != 0) { for (int x = q; x >= 0; x = c.q_parent[x]) c.qn_reorder[x] = 1; return; }
+            int parent = c.q_parent[q];
+            node_heap_pop(parent);  // removeNodeFromParent: the node is at the top of its parent's heap
+            c.qn_exists[q] = 0; c.qn_linked[q] = 0;
+            if (parent < 0) return;
+            q = parent;
+        }
+    }
+    KAI_HD int pop_next_job() {  // :61-89
+        if (!c.st->root_init || c.st->root_len == 0) return -1;
+        int parent = -1, q;
+        for (;;) { q = next_node(parent); if (q < 0) return -1; if (q_is_leaf(q)) break; parent = q; }  // traverseToLeaf :179-191
+        int32_t* h = c.jheap + c.q_job_off[q]; int n = c.jheap_len[q] - 1;
+        int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); c.jheap_len[q] = n;
+        int job = h[n];
+        handle_pop_from_node(q);
+        return job;
+    }
+    KAI_HD bool job_ready(int j) const {  // job_info.go:399-406, podset.go:114-120
+        for (int k = 0; k < c.j_n_ps[j]; k++) { int s = c.j_first_ps[j] + k; if (c.s_alive[s] - c.s_gated[s] < c.s_min[s]) return false; }
+        return true;
+    }
+    KAI_HD void init_jobs_order() {  // InitializeWithJobs (actions/utils/input_jobs.go:21-68) with the allocate filters
+        c.st->root_len = 0; c.st->root_init = 0;
+        for (int q = 0; q < c.Q; q++) { c.qn_exists[q] = 0; c.qn_reorder[q] = 0; c.qn_linked[q] = 0; c.jheap_len[q] = 0; c.qheap_len[q] = 0; }
+        for (int j = 0; j < c.J; j++) {
+            if (!job_ready(j)) continue;               // FilterUnready
+            if (c.j_n_pending[j] == 0) continue;       // FilterNonPending
+            int q = c.j_queue[j];
+            if (q < 0 || !q_is_leaf(q)) continue;
+            push_job(j);
+        }
+    }
+
+    // ------------------------------------------------------------------ actions/common/allocate.go
+    KAI_HD void fill_req(ScanReq& q, int p) {
+        q.pod = p; q.cpu_only = pod_cpu_only(p); q.best_effort = pod_best_effort(p); q.pod_class = c.p_class[p]; q.nominated = c.p_nominated[p];
+        q.r_place = q.cpu_only ? KAI_RES_CPU : KAI_RES_GPU; q.strategy = q.cpu_only ? c.cpu_strategy : c.gpu_strategy;
+        for (int r = 0; r < KAI_MAX_RES; r++) q.req[r] = r < c.R ? preq(p, r) : 0.0;
+        q.min_a = 0; q.max_a = 0;
+    }
+    KAI_HD bool allocate_task(int p, bool pipeline_only) {  // :121-163
+        c.st->decisions++;
+        ScanReq q; fill_req(q, p);
+        // predicates step 1 is node independent on this path (capacity_policy.go:51-61): evaluate it once
+        if ((c.plugins & KAI_PLUGIN_PREDICATES) && task_over_capacity(p)) return false;
+        if ((c.plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) sc.minmax(c, q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
+        int n = sc.best_node(c, q);
+        c.st->node_scans++; c.st->nodes_scanned += c.N;
+        if (n < 0) return false;
+        // allocateTaskToNode :165-174
+        bool allocatable = q.best_effort || fits(c, q, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
+        if (!pipeline_only && allocatable) return stmt_allocate(p, n);
+        return stmt_pipeline(p, n, !pipeline_only);
+    }
+    KAI_HD bool allocate_job(int j, bool pipeline_only) {  // AllocateJob :20-36 → allocateSubGroupSet :38-81 → allocatePodSet :83-119
+        if (c.j_n_ps[j] > 64) { fault(FAULT_INTERNAL); return false; }  // engine limit: 64 pod-sets per job
+        ensure_tta(j, !pipeline_only);
+        if (job_over_queue_capacity(j)) return false;
+        int cp_root = checkpoint();
+        int first = c.j_first_pod[j], nt = c.j_tta_n[j], nps = c.j_n_ps[j], ps0 = c.j_first_ps[j];
+        // the cached chunk is consumed below while statuses change, so snapshot it (Go holds the slice it got)
+        int32_t* chunk = c.scratch + first;
+        for (int i = 0; i < nt; i++) chunk[i] = c.tta[first + i];
+        // orderedPodSets :270-277 — sort.Slice by PodSetOrderFn; the order is re-read at every step because allocating
+        // changes the counters only of pod-sets already visited
+        uint64_t done = 0;
+        for (int round = 0; round < nps; round++) {
+            int best = -1;
+            for (int k = 0; k < nps && k < 64; k++) { if ((done >> k) & 1) continue; if (best < 0 || podset_order(ps0 + k, ps0 + best)) best = k; }
+            if (best < 0) break;
+            done |= 1ull << best;
+            int s = ps0 + best;
+            int cp = checkpoint(); bool ok = true;
+            for (int i = 0; i < nt; i++) { int p = chunk[i]; if (c.p_podset[p] != s) continue; if (!allocate_task(p, pipeline_only)) { ok = false; break; } }
+            if (!ok) { rollback(cp); rollback(cp_root); return false; }
+        }
+        return true;
+    }
+    KAI_HD void execute_allocate() {  // actions/allocate/allocate.go:46-77
+        init_jobs_order();
+        for (;;) {
+            if (c.st->fault) return;
+            int j = pop_next_job(); if (j < 0) break;
+            c.st->ops_len = 0;
+            c.st->jobs_attempted++;
+            bool ok = allocate_job(j, false);
+            if (ok) {  // attemptToAllocateJob :79-111 — ShouldPipelineJob (job_info.go:443-464)
+                bool should_pipeline = false;
+                for (int k = 0; k < c.j_n_ps[j]; k++) { int s = c.j_first_ps[j] + k; if (c.s_pipelined[s] > 0 && (c.s_active_alloc[s] - c.s_pipelined[s]) < c.s_min[s]) should_pipeline = true; }
+                if (should_pipeline && !convert_all_allocated_to_pipelined(j)) ok = false;
+            }
+            if (ok) {
+                c.st->jobs_committed++;
+                commit();
+                if (c.j_n_pending[j] > 0) push_job(j);  // HasTasksToAllocate(job, true)
+            } else {
+                discard();
+            }
+        }
+    }
+};
+
+// ======================================================================================================
+// proportion fair-share division of ONE sibling set for ONE resource
+// (plugins/proportion/resource_division/resource_division.go:33-42, 92-357).  Children are visited in index order
+// (the reference ranges a Go map).  weight / rem_amt / rem_has are per-queue scratch of this resource.
+// ======================================================================================================
+KAI_HD double rd_remaining_requested(const QShare& s) {  // :317-325
+    double requested = qs_requestable(s);
+    if (requested < s.fair) return 0;
+    return requested - s.fair;
+}
+KAI_HD bool rd_satisfied(const QShare& s) {  // :253-262
+    if (s.request <= s.fair) return true;
+    if (s.max_allowed != KAI_UNLIMITED && s.max_allowed <= s.fair) return true;
+    return false;
+}
+KAI_HD double rd_floor(double x) {  // math.Floor for the non-negative finite values that occur here
+    double t = (double)(int64_t)x;
+    return t > x ? t - 1.0 : t;
+}
+KAI_HD void divide_sibling_set(const KaiCtx& c, const int32_t* kids, int nk, int k, double total, double k_value,
+                               double* weight, double* rem_amt, uint8_t* rem_has) {
+    // setDeservedResource :92-109
+    double remaining = total;
+    for (int i = 0; i < nk; i++) {
+        QShare& s = c.q_share[(size_t)kids[i] * 3 + k];
+        double deserved = s.deserved; if (deserved == KAI_UNLIMITED) deserved = total;
+        double amount = kmin(deserved, qs_requestable(s));
+        s.fair += amount; remaining -= amount;
+        rem_has[kids[i]] = 0;
+    }
+    if (!(remaining > 0)) return;
+    // divideOverQuotaResource :111-144 — priorities descending
+    const int64_t NO_PRIO = (int64_t)1 << 40;
+    int64_t bound = NO_PRIO;
+    for (;;) {
+        int64_t p = -NO_PRIO;
+        for (int i = 0; i < nk; i++) { int64_t qp = c.q_prio[kids[i]]; if (qp < bound && qp > p) p = qp; }
+        if (p == -NO_PRIO) break;
+        bound = p;
+        // divideUpToFairShare :164-222 on the queues of priority p
+        double amount_left = remaining;
+        for (;;) {
+            bool another = false; double give_round = amount_left;
+            double total_w = 0;  // getTotalWeightsForUnsatisfied :307-315
+            for (int i = 0; i < nk; i++) { int q = kids[i]; if (c.q_prio[q] != p) continue; const QShare& s = c.q_share[(size_t)q * 3 + k]; if (rd_remaining_requested(s) > 0) total_w += s.oqw; }
+            double w_sum = 0.0;  // calcShareWeights :224-251
+            if (total_w != 0) for (int i = 0; i < nk; i++) {
+                int q = kids[i]; if (c.q_prio[q] != p) continue; const QShare& s = c.q_share[(size_t)q * 3 + k];
+                if (rd_satisfied(s)) continue;
+                double n_w = s.oqw / total_w;
+                double w = kmax(0, n_w + k_value * (n_w - s.usage));
+                weight[q] = w; w_sum += w;
+            }
+            if (w_sum == 0) break;
+            for (int i = 0; i < nk; i++) {
+                int q = kids[i]; if (c.q_prio[q] != p) continue; QShare& s = c.q_share[(size_t)q * 3 + k];
+                if (amount_left == 0) break;
+                if (rd_satisfied(s)) continue;
+                double requested = rd_remaining_requested(s);
+                if (s.oqw == 0) continue;
+                double fair = give_round * (weight[q] / w_sum);
+                double to_give = 0;  // getResourceToGiveInCurrentRound :283-305
+                if (requested <= fair) { to_give = requested; rem_has[q] = 0; }
+                else {
+                    double rf = rd_floor(fair);
+                    if (rf > 0) to_give = rf;
+                    if (fair - to_give > 0) { rem_has[q] = 1; rem_amt[q] = fair - to_give; }
+                }
+                if (to_give == 0) continue;
+                s.fair += to_give; amount_left -= to_give;
+                another = another || requested < fair;
+            }
+            if (!another || amount_left == 0) break;
+        }
+        remaining = amount_left;
+    }
+    // second pass :129-142 — divideRemainingResource :264-281 per priority, largest remainder first
+    bound = NO_PRIO;
+    for (;;) {
+        if (remaining <= 0) break;
+        int64_t p = -NO_PRIO;
+        for (int i = 0; i < nk; i++) { int64_t qp = c.q_prio[kids[i]]; if (qp < bound && qp > p) p = qp; }
+        if (p == -NO_PRIO) break;
+        bound = p;
+        for (;;) {
+            if (remaining == 0) break;
+            int best = -1;  // remainingRequestedOrderFn :337-357
+            for (int i = 0; i < nk; i++) {
+                int q = kids[i]; if (c.q_prio[q] != p || !rem_has[q]) continue;
+                if (best < 0) { best = q; continue; }
+                if (rem_amt[q] > rem_amt[best]) { best = q; continue; }
+                if (rem_amt[q] < rem_amt[best]) continue;
+                if (c.q_created[q] != c.q_created[best]) { if (c.q_created[q] < c.q_created[best]) best = q; continue; }
+                if (c.q_uid_rank[q] < c.q_uid_rank[best]) best = q;
+            }
+            if (best < 0) break;
+            rem_has[best] = 0;
+            double give = kmin(1, remaining);
+            c.q_share[(size_t)best * 3 + k].fair += give; remaining -= give;
+        }
+    }
+}
+
+}  // namespace kai

@@ -1,0 +1,166 @@
+"""Synthetic cluster snapshots of BASELINE.json's configs.
+
+All generators are deterministic in `seed` (base 0x4B4149 + config index), produce integer-valued quantities
+(< 2**53) and distinct creation timestamps so that the reference's order is well defined.
+Node names are `node-%06d` (string order == numeric order) unless `lexi_names` asks for `node-%d`.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import abi
+
+GIB = float(1 << 30)
+SEED0 = 0x4B4149
+
+
+def _queue_tree(levels, rng, total_gpu, zipf=False, limits_frac=0.0, prios=(100,), oqws=(1.0,), usage_max=0.0):
+    """levels=[a,b,..] → a top queues, each with b children, … ; returns dict of arrays + leaf list."""
+    parent, depth_nodes = [], [[-1]]
+    names = []
+    cur = [-1]
+    for li, width in enumerate(levels):
+        nxt = []
+        for p in cur:
+            for k in range(width):
+                idx = len(parent)
+                parent.append(p)
+                names.append(("q" if li == len(levels) - 1 else f"l{li}") + f"-{idx:05d}")
+                nxt.append(idx)
+        cur = nxt
+    Q = len(parent)
+    parent = np.array(parent, np.int32)
+    leaves = np.array(cur, np.int32)
+    deserved = np.full((3, Q), -1.0)
+    limit = np.full((3, Q), -1.0)
+    oqw = np.ones((3, Q))
+    if zipf:
+        w = 1.0 / np.arange(1, len(leaves) + 1) ** 1.1
+        w = w[rng.permutation(len(leaves))]
+        share = np.floor(0.8 * total_gpu * w / w.sum())
+    else:
+        share = np.full(len(leaves), np.floor(total_gpu / max(len(leaves), 1)))
+    deserved[abi.Q_GPU, leaves] = share
+    # inner queues deserve the sum of their children (bottom-up)
+    for q in range(Q - 1, -1, -1):
+        if parent[q] >= 0:
+            if deserved[abi.Q_GPU, parent[q]] < 0:
+                deserved[abi.Q_GPU, parent[q]] = 0
+            deserved[abi.Q_GPU, parent[q]] += deserved[abi.Q_GPU, q]
+    if limits_frac > 0:
+        lim = rng.random(len(leaves)) < limits_frac
+        limit[abi.Q_GPU, leaves[lim]] = 2 * deserved[abi.Q_GPU, leaves[lim]] + 8
+    oqw[abi.Q_GPU, :] = rng.choice(np.array(oqws, float), size=Q)
+    usage = rng.random((3, Q)) * usage_max if usage_max > 0 else np.zeros((3, Q))
+    prio = rng.choice(np.array(prios, np.int32), size=Q).astype(np.int32)
+    created = (np.arange(Q, dtype=np.int64) + 1) * 60_000_000_000
+    return dict(parent=parent, names=names, leaves=leaves, deserved=deserved, limit=limit, oqw=oqw, usage=usage, prio=prio, created=created)
+
+
+def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill=0.3, gpu_mix=((8, 1.0),), cpu_only_frac=0.0,
+                  gang_sizes=(1, 2, 4, 8), gang_p=(0.4, 0.2, 0.2, 0.2), gpus_per_pod=(1, 2, 4, 8), zipf=False, limits_frac=0.0,
+                  queue_prios=(100,), oqws=(1.0,), nonpreempt_frac=0.0, usage_max=0.0, lexi_names=False, single_pod_jobs=False,
+                  uniform_nodes=False, cpu_per_gpu=4000.0, mem_per_gpu=32 * GIB) -> abi.Snapshot:
+    rng = np.random.default_rng(seed)
+    R = 4
+    N = n_nodes
+    # ---- nodes
+    kinds = np.array([g for g, _ in gpu_mix]); probs = np.array([p for _, p in gpu_mix], float); probs /= probs.sum()
+    gpus = kinds[rng.choice(len(kinds), size=N, p=probs)].astype(float) if N else np.zeros(0)
+    alloc = np.zeros((R, N))
+    if uniform_nodes:  # test-fixture defaults (test_utils/nodes_fake/nodes.go:31-36)
+        alloc[abi.RES_CPU] = 20000.0; alloc[abi.RES_MEM] = 20e9
+    else:
+        alloc[abi.RES_CPU] = rng.integers(64, 193, size=N) * 1000.0
+        alloc[abi.RES_MEM] = rng.integers(256, 1025, size=N) * GIB
+    alloc[abi.RES_GPU] = gpus
+    alloc[abi.RES_PODS] = 110
+    node_names = [(f"node-{i}" if lexi_names else f"node-{i:06d}") for i in range(N)]
+    total_gpu = float(gpus.sum())
+    qt = _queue_tree(list(queue_levels), rng, total_gpu, zipf=zipf, limits_frac=limits_frac, prios=queue_prios, oqws=oqws, usage_max=usage_max)
+    leaves = qt["leaves"]
+
+    # ---- pending gangs
+    mean_size = 1.0 if single_pod_jobs else max(float(np.dot(gang_sizes, gang_p)), 1e-9)
+    est = int(n_pending_pods / mean_size * 1.5) + 64
+    sizes = np.ones(est, np.int64) if single_pod_jobs else rng.choice(np.array(gang_sizes), size=est, p=np.array(gang_p))
+    csum = np.cumsum(sizes)
+    nj = int(np.searchsorted(csum, n_pending_pods, side="left")) + 1 if n_pending_pods > 0 else 0
+    sizes = sizes[:nj]
+    if nj:
+        sizes[-1] -= csum[nj - 1] - n_pending_pods  # trim the last gang to hit the pod count exactly
+        if sizes[-1] <= 0:
+            sizes = sizes[:-1]; nj -= 1
+    is_cpu = rng.random(nj) < cpu_only_frac
+    g_pod = np.where(is_cpu, 0, rng.choice(np.array(gpus_per_pod), size=nj)).astype(float)
+    if single_pod_jobs:
+        g_pod = np.where(is_cpu, 0, 1.0)
+    cpu_pod = np.where(is_cpu, rng.integers(1, 17, size=nj) * 1000.0, cpu_per_gpu * g_pod)
+    mem_pod = np.where(is_cpu, 4 * GIB, mem_per_gpu * g_pod)
+    # ---- running filler: one running single-pod job per partly used node
+    used = rng.binomial(gpus.astype(np.int64), prefill) if N else np.zeros(0, np.int64)
+    run_nodes = np.nonzero(used > 0)[0]
+    nr = len(run_nodes)
+    J = nj + nr
+    job_sizes = np.concatenate([sizes, np.ones(nr, np.int64)]).astype(np.int32)
+    first_pod = np.concatenate([[0], np.cumsum(job_sizes)[:-1]]).astype(np.int32) if J else np.zeros(0, np.int32)
+    P = int(job_sizes.sum())
+    pod_job = np.repeat(np.arange(J, dtype=np.int32), job_sizes)
+    pod_req = np.zeros((R, P))
+    pod_req[abi.RES_CPU] = np.repeat(np.concatenate([cpu_pod, 4000.0 * used[run_nodes]]), job_sizes)
+    pod_req[abi.RES_MEM] = np.repeat(np.concatenate([mem_pod, np.minimum(32 * GIB * used[run_nodes], alloc[abi.RES_MEM, run_nodes] - GIB)]), job_sizes)
+    pod_req[abi.RES_GPU] = np.repeat(np.concatenate([g_pod, used[run_nodes].astype(float)]), job_sizes)
+    pod_req[abi.RES_PODS] = 1.0
+    # keep the filler inside its node's cpu
+    fill_cpu = np.minimum(4000.0 * used[run_nodes], alloc[abi.RES_CPU, run_nodes] - 1000.0)
+    pod_req[abi.RES_CPU, P - nr:] = fill_cpu
+    pod_status = np.full(P, abi.POD_STATUS["Pending"], np.int32)
+    pod_node = np.full(P, -1, np.int32)
+    pod_status[P - nr:] = abi.POD_STATUS["Running"]
+    pod_node[P - nr:] = run_nodes
+    nonpre = rng.random(J) < nonpreempt_frac
+    job_prio = np.where(nonpre, rng.choice(np.array([100, 125]), size=J), rng.choice(np.array([50, 75]), size=J) if nonpreempt_frac > 0 else 50).astype(np.int32)
+    job_queue = leaves[rng.integers(0, len(leaves), size=J)].astype(np.int32) if J else np.zeros(0, np.int32)
+    created = (rng.permutation(J).astype(np.int64) + 1) * 60_000_000_000  # distinct, not aligned with index order
+
+    snap = abi.Snapshot(n_res=R)
+    a = snap.arrays
+    a["node_allocatable"] = alloc
+    a["node_flags"] = np.zeros(N, np.uint32)
+    a["node_gpu_count"] = gpus.astype(np.int32)
+    a["node_name_rank"] = abi.rank_strings(node_names) if lexi_names else np.arange(N, dtype=np.uint32)
+    a["pod_req"] = pod_req; a["pod_job"] = pod_job; a["pod_podset"] = pod_job.copy()  # one pod-set ("default") per job
+    a["pod_status"] = pod_status; a["pod_node"] = pod_node
+    a["pod_uid_rank"] = np.arange(P, dtype=np.uint32)  # pod UIDs are zero-padded by construction
+    a["podset_job"] = np.arange(J, dtype=np.int32); a["podset_min_available"] = job_sizes.copy(); a["podset_name_rank"] = np.zeros(J, np.uint32)
+    a["job_queue"] = job_queue; a["job_priority"] = job_prio; a["job_preemptible"] = (job_prio < 100).astype(np.int32)
+    a["job_created_ns"] = created; a["job_uid_rank"] = np.arange(J, dtype=np.uint32)
+    a["job_first_pod"] = first_pod; a["job_n_pods"] = job_sizes; a["job_first_podset"] = np.arange(J, dtype=np.int32); a["job_n_podsets"] = np.ones(J, np.int32)
+    a["queue_parent"] = qt["parent"]; a["queue_priority"] = qt["prio"]; a["queue_created_ns"] = qt["created"]
+    a["queue_uid_rank"] = np.arange(len(qt["parent"]), dtype=np.uint32)
+    a["queue_deserved"] = qt["deserved"]; a["queue_limit"] = qt["limit"]; a["queue_oqw"] = qt["oqw"]; a["queue_usage"] = qt["usage"]
+    snap.node_names = node_names
+    snap.queue_names = qt["names"]
+    snap.finalize()
+    return snap
+
+
+def config(idx: int, scale: float = 1.0) -> tuple[abi.Snapshot, abi.KaiConfig, str]:
+    """BASELINE.json configs[idx] (0-based) → (snapshot, config, description).  `scale` shrinks node and pod counts together."""
+    seed = SEED0 + idx
+    n = lambda x: max(1, int(round(x * scale)))
+    if idx == 0:   # C1: 16 nodes / 64 single-pod jobs, single queue, bin-pack (plumbing)
+        s = make_snapshot(16, 64, seed, queue_levels=(1, 1), prefill=0.0, single_pod_jobs=True, uniform_nodes=True, cpu_per_gpu=1000.0, mem_per_gpu=1e9)
+        return s, abi.default_config(), "C1 16n x 64p single-queue bin-pack"
+    if idx == 1:   # C2: 1k nodes x 10k pods, gangs + bin-pack
+        s = make_snapshot(n(1000), n(10000), seed, queue_levels=(2, 2), prefill=0.3)
+        return s, abi.default_config(), f"C2 {n(1000)}n x {n(10000)}p gangs + bin-pack"
+    if idx == 2:   # C3: 10k x 100k, 2-level queues + proportion/DRF (pure DRF: kValue 0)
+        s = make_snapshot(n(10000), n(100000), seed, queue_levels=(10, 10), prefill=0.3, gpu_mix=((8, .7), (4, .2), (0, .1)), cpu_only_frac=0.2,
+                          zipf=True, limits_frac=0.2, queue_prios=(100, 200), oqws=(1.0, 2.0, 4.0), nonpreempt_frac=0.1)
+        return s, abi.default_config(k_value=0.0), f"C3 {n(10000)}n x {n(100000)}p 2-level queues + DRF"
+    if idx == 4:   # C5: 64k x 1M, 3-level queues, time-based fair-share (kValue 0.5, historical usage)
+        s = make_snapshot(n(65536), n(1000000), seed, queue_levels=(8, 16, 16), prefill=0.3, zipf=True, limits_frac=0.2, queue_prios=(100, 200),
+                          oqws=(1.0, 2.0, 4.0), nonpreempt_frac=0.1, usage_max=0.3)
+        return s, abi.default_config(k_value=0.5), f"C5 {n(65536)}n x {n(1000000)}p full chain + time-based fair-share"
+    raise ValueError("config 3 (topology + consolidation) needs the topology plugin — not built yet")

@@ -751,6 +751,7 @@ void Session::executeAllocate() {
     jobsOrder.InitializeWithJobs(all);
     std::vector<NodeInfo*> allNodes; for (auto& n : nodes) allNodes.push_back(&n);
     while (!jobsOrder.IsEmpty()) {
+        if (cfg.reserved[0] > 0 && stats.decisions >= cfg.reserved[0]) break;  // bounded sample for bench.py's cpu_baseline (oracle-only knob)
         PodGroupInfo* job = jobsOrder.PopNextJob(); if (!job) break;
         Statement stmt(this);
         stats.jobsAttempted++;

@@ -1,0 +1,174 @@
+// host_sim.cpp — TEST INFRASTRUCTURE: compiles the engine's control flow (kai_engine.hpp) for the host.
+//
+// There is no GPU in the development container, so the device engine's sequential control flow
+// (kai::Engine<>, the same header the gfx950 kernel instantiates) is additionally compiled here with
+// plain g++ and a serial node scanner, to debug it against the oracle in the `-m "not gpu"` suite.
+// This is NOT a CPU fallback: libkai_core never contains it, the package never loads it, and every
+// parity claim is made by the `-m gpu` tests through the C ABI on a real MI355X.
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../kai-scheduler_amd/csrc/kai_host_prep.hpp"
+
+using namespace kai;
+
+namespace {
+
+struct HostScanner {  // serial twin of DevScanner / scan_service (kai_kernels.hpp)
+    void minmax(const KaiCtx& c, int r, double& mn, double& mx) {
+        double lo = 1.7976931348623157e308, hi = 0;
+        for (int n = 0; n < c.N; n++) {
+            if (c.n_alloc[(size_t)r * c.N + n] == 0) continue;
+            double cur = c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n];
+            if (cur < lo) lo = cur;
+            if (cur > hi) hi = cur;
+        }
+        mn = lo; mx = hi;
+    }
+    int best_node(const KaiCtx& c, const ScanReq& q) {
+        int best = -1; double bs = 0; uint32_t br = 0;
+        for (int n = 0; n < c.N; n++) {
+            if (!fits(c, q, n, true)) continue;
+            if (!node_predicates(c, q, n)) continue;
+            bool fit_idle = q.best_effort || fits(c, q, n, false);
+            double sc = node_score(c, q, n, fit_idle); uint32_t rk = c.n_name_rank[n];
+            if (best < 0 || sc > bs || (sc == bs && rk < br)) { best = n; bs = sc; br = rk; }
+        }
+        return best;
+    }
+};
+
+template <class T> T* own(std::vector<std::vector<char>>& pool, size_t n) {
+    pool.emplace_back(std::max<size_t>(n, 1) * sizeof(T), 0);
+    return reinterpret_cast<T*>(pool.back().data());
+}
+template <class T> const T* copy(std::vector<std::vector<char>>& pool, const T* src, size_t n) {
+    T* d = own<T>(pool, n);
+    if (n && src) std::memcpy(d, src, n * sizeof(T));
+    return d;
+}
+
+}  // namespace
+
+extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s, const int* actions, int n_actions,
+                               kai_op* ops_out, int64_t ops_cap, int64_t* n_ops, int32_t* pod_status_out, int32_t* pod_node_out,
+                               kai_queue_share* shares_open, kai_queue_share* shares_final, kai_node_state* nodes_out,
+                               kai_action_stats* stats, double* elapsed_ms_out) {
+    if (!cfg || !s || s->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
+    const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
+    std::vector<std::vector<char>> pool;
+    HostPrep prep; std::string err;
+    if (prep.build(*cfg, s, err)) return KAI_ERR_INVALID_ARG;
+    KaiCtx c{};
+    c.N = N; c.P = P; c.S = S; c.J = J; c.Q = Q; c.R = R; c.n_pod_classes = std::max(1, s->n_pod_classes); c.n_node_classes = std::max(1, s->n_node_classes);
+    c.plugins = cfg->plugins; c.gpu_strategy = cfg->gpu_strategy; c.cpu_strategy = cfg->cpu_strategy; c.restrict_nodes = cfg->restrict_node_scheduling;
+    c.k_value = cfg->k_value <= 0.0 ? 0.0 : cfg->k_value;
+    std::vector<int32_t> neg1n(N, -1), zeron(N, 0), zerop(P, 0), neg1p(P, -1); std::vector<uint32_t> zeropu(P, 0); uint8_t one = 1;
+    c.n_alloc = copy(pool, s->node_allocatable, (size_t)R * N); c.n_flags = copy(pool, s->node_flags, N);
+    c.n_gpu_count = copy(pool, s->node_gpu_count ? s->node_gpu_count : neg1n.data(), N); c.n_name_rank = copy(pool, s->node_name_rank, N);
+    c.n_class = copy(pool, s->node_class ? s->node_class : zeron.data(), N);
+    c.p_req = copy(pool, s->pod_req, (size_t)R * P); c.p_job = copy(pool, s->pod_job, P); c.p_podset = copy(pool, s->pod_podset, P);
+    c.p_flags = copy(pool, s->pod_flags ? s->pod_flags : zeropu.data(), P); c.p_class = copy(pool, s->pod_class ? s->pod_class : zerop.data(), P);
+    c.p_nominated = copy(pool, s->pod_nominated_node ? s->pod_nominated_node : neg1p.data(), P);
+    c.s_job = copy(pool, s->podset_job, S); c.s_min = copy(pool, s->podset_min_available, S); c.s_name_rank = copy(pool, s->podset_name_rank, S);
+    c.j_queue = copy(pool, s->job_queue, J); c.j_prio = copy(pool, s->job_priority, J); c.j_preempt = copy(pool, s->job_preemptible, J);
+    c.j_created = copy(pool, s->job_created_ns, J); c.j_uid_rank = copy(pool, s->job_uid_rank, J); c.j_first_pod = copy(pool, s->job_first_pod, J);
+    c.j_n_pods = copy(pool, s->job_n_pods, J); c.j_first_ps = copy(pool, s->job_first_podset, J); c.j_n_ps = copy(pool, s->job_n_podsets, J);
+    c.q_parent = copy(pool, s->queue_parent, Q); c.q_prio = copy(pool, s->queue_priority, Q); c.q_created = copy(pool, s->queue_created_ns, Q); c.q_uid_rank = copy(pool, s->queue_uid_rank, Q);
+    if (s->class_fit && s->n_pod_classes > 0 && s->n_node_classes > 0) c.class_fit = copy(pool, s->class_fit, (size_t)s->n_pod_classes * s->n_node_classes);
+    else c.class_fit = copy(pool, &one, 1);
+    c.j_pods_sorted = copy(pool, prep.sorted.data(), P); c.q_child_off = copy(pool, prep.child_off.data(), Q + 2); c.q_children = copy(pool, prep.children.data(), std::max(Q, 1));
+    c.q_job_off = copy(pool, prep.job_off.data(), Q + 1);
+    c.n_idle = const_cast<double*>(copy(pool, s->node_allocatable, (size_t)R * N)); c.n_rel = own<double>(pool, (size_t)R * N); c.n_used = own<double>(pool, (size_t)R * N);
+    c.p_status = const_cast<int32_t*>(copy(pool, s->pod_status, P)); c.p_node = const_cast<int32_t*>(copy(pool, s->pod_node, P));
+    c.p_on_node = own<int32_t>(pool, P); c.p_on_node_status = own<int32_t>(pool, P); c.p_virtual = own<uint8_t>(pool, P); c.p_accepted = own<uint8_t>(pool, P);
+    c.s_active_alloc = own<int32_t>(pool, S); c.s_active_used = own<int32_t>(pool, S); c.s_alive = own<int32_t>(pool, S); c.s_gated = own<int32_t>(pool, S); c.s_pipelined = own<int32_t>(pool, S);
+    c.j_n_pending = own<int32_t>(pool, J); c.j_tta_valid = own<int32_t>(pool, J); c.j_tta_n = own<int32_t>(pool, J); c.tta = own<int32_t>(pool, P);
+    c.j_tta_res = own<double>(pool, (size_t)3 * J); c.j_allocated = own<double>(pool, (size_t)3 * J);
+    c.jheap = own<int32_t>(pool, J); c.jheap_len = own<int32_t>(pool, Q); c.qheap = own<int32_t>(pool, Q + 1); c.qheap_len = own<int32_t>(pool, Q + 1); c.root_heap = own<int32_t>(pool, Q + 1);
+    c.qn_exists = own<uint8_t>(pool, Q); c.qn_reorder = own<uint8_t>(pool, Q); c.qn_linked = own<uint8_t>(pool, Q);
+    c.ops_cap = 4 * P + 64; c.ops = own<StmtOp>(pool, c.ops_cap); c.out_cap = (int64_t)2 * P + 64; c.out_ops = own<kai_op>(pool, c.out_cap);
+    c.scratch = own<int32_t>(pool, (size_t)P + 64); c.st = own<EngineState>(pool, 1);
+    c.q_share = const_cast<QShare*>(copy(pool, prep.shares.data(), prep.shares.size()));
+    auto t0 = std::chrono::steady_clock::now();
+
+    // ---- serial twins of the session-open kernels (kai_kernels.hpp)
+    for (int p = 0; p < P; p++) {  // k_node_accounting
+        int st = c.p_status[p], n = c.p_node[p];
+        c.p_on_node[p] = -1;
+        if (!st_active_used(st) || n < 0 || n >= N) continue;
+        c.p_on_node[p] = n; c.p_on_node_status[p] = st; c.p_accepted[p] = 1;
+        for (int r = 0; r < R; r++) {
+            double v = c.p_req[(size_t)r * P + p]; if (v == 0) continue; size_t i = (size_t)r * N + n;
+            c.n_used[i] += v;
+            if (st == KAI_POD_RELEASING) { c.n_rel[i] += v; c.n_idle[i] -= v; } else if (st == KAI_POD_PIPELINED) c.n_rel[i] -= v; else c.n_idle[i] -= v;
+        }
+    }
+    if (c.plugins & KAI_PLUGIN_PROPORTION) {  // k_total_nodes + k_total_foreign
+        for (int n = 0; n < N; n++) {
+            uint32_t f = c.n_flags[n]; if (f & KAI_NODE_NOT_READY) continue;
+            bool ignore = c.restrict_nodes && !(f & KAI_NODE_GPU_WORKER);
+            c.st->total[0] += c.n_alloc[(size_t)KAI_RES_CPU * N + n]; c.st->total[1] += c.n_alloc[(size_t)KAI_RES_MEM * N + n];
+            if (!ignore) c.st->total[2] += c.n_alloc[(size_t)KAI_RES_GPU * N + n];
+        }
+        for (int p = 0; p < P; p++) {
+            if (!(c.p_flags[p] & KAI_POD_FOREIGN_SCHEDULER)) continue;
+            int n = c.p_on_node[p]; if (n < 0 || !st_active_used(c.p_on_node_status[p]) || (c.n_flags[n] & KAI_NODE_NOT_READY)) continue;
+            c.st->total[0] -= c.p_req[(size_t)KAI_RES_CPU * P + p]; c.st->total[1] -= c.p_req[(size_t)KAI_RES_MEM * P + p]; c.st->total[2] -= c.p_req[(size_t)KAI_RES_GPU * P + p];
+        }
+    }
+    for (int j = 0; j < J; j++) {  // k_job_usage + k_leaf_usage
+        double al[3] = {0, 0, 0}, rq[3] = {0, 0, 0}, ja[3] = {0, 0, 0}; int pending = 0;
+        for (int i = 0; i < c.j_n_pods[j]; i++) {
+            int p = c.j_first_pod[j] + i, st = c.p_status[p], ps = c.p_podset[p];
+            if (st_active_allocated(st)) c.s_active_alloc[ps]++;
+            if (st_active_used(st)) c.s_active_used[ps]++;
+            if (st_alive(st)) c.s_alive[ps]++;
+            if (st == KAI_POD_GATED) c.s_gated[ps]++;
+            if (st == KAI_POD_PIPELINED) c.s_pipelined[ps]++;
+            if (st == KAI_POD_PENDING) pending++;
+            double q[3] = {c.p_req[(size_t)KAI_RES_CPU * P + p], c.p_req[(size_t)KAI_RES_MEM * P + p], c.p_req[(size_t)KAI_RES_GPU * P + p]};
+            if (st_allocated(st)) { for (int k = 0; k < 3; k++) ja[k] += q[k]; if (c.p_accepted[p]) for (int k = 0; k < 3; k++) { al[k] += q[k]; rq[k] += q[k]; } }
+            else if (st == KAI_POD_PENDING) for (int k = 0; k < 3; k++) rq[k] += q[k];
+        }
+        c.j_n_pending[j] = pending;
+        for (int k = 0; k < 3; k++) c.j_allocated[(size_t)k * J + j] = ja[k];
+        if ((c.plugins & KAI_PLUGIN_PROPORTION) && c.j_queue[j] >= 0) for (int k = 0; k < 3; k++) {
+            QShare& x = c.q_share[(size_t)c.j_queue[j] * 3 + k];
+            x.allocated += al[k]; x.request += rq[k]; if (!c.j_preempt[j]) x.allocated_np += al[k];
+        }
+    }
+    if (c.plugins & KAI_PLUGIN_PROPORTION) {
+        for (int i = 0; i < Q; i++) {  // k_tree_usage
+            int q = prep.depth_order[i], par = c.q_parent[q]; if (par < 0) continue;
+            for (int k = 0; k < 3; k++) { QShare& x = c.q_share[(size_t)q * 3 + k]; QShare& d = c.q_share[(size_t)par * 3 + k]; d.allocated += x.allocated; d.allocated_np += x.allocated_np; d.request += x.request; }
+        }
+        std::vector<double> weight((size_t)3 * std::max(Q, 1)), rem_amt((size_t)3 * std::max(Q, 1)); std::vector<uint8_t> rem_has((size_t)3 * std::max(Q, 1));
+        for (int l = 0; l < prep.n_levels; l++) for (int t = prep.lvl_off[l] * 3; t < prep.lvl_off[l + 1] * 3; t++) {  // k_fair_share
+            int par = prep.lvl_parents[t / 3], k = t % 3;
+            double total = par == Q ? c.st->total[k] : c.q_share[(size_t)par * 3 + k].fair;
+            divide_sibling_set(c, c.q_children + c.q_child_off[par], c.q_child_off[par + 1] - c.q_child_off[par], k, total, c.k_value,
+                               weight.data() + (size_t)k * Q, rem_amt.data() + (size_t)k * Q, rem_has.data() + (size_t)k * Q);
+        }
+    }
+    auto fill = [&](kai_queue_share* out) {
+        for (int q = 0; q < Q; q++) for (int k = 0; k < 3; k++) { const QShare& x = c.q_share[(size_t)q * 3 + k];
+            out[q].fair_share[k] = x.fair; out[q].allocated[k] = x.allocated; out[q].allocated_non_preemptible[k] = x.allocated_np; out[q].request[k] = x.request; out[q].deserved[k] = x.deserved; out[q].max_allowed[k] = x.max_allowed; }
+    };
+    if (shares_open) fill(shares_open);
+    HostScanner sc; Engine<HostScanner> eng(c, sc);
+    for (int i = 0; i < n_actions; i++) { if (actions[i] != KAI_ACTION_ALLOCATE) return KAI_ERR_UNSUPPORTED; eng.execute_allocate(); }
+    auto t1 = std::chrono::steady_clock::now();
+    if (elapsed_ms_out) *elapsed_ms_out = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (c.st->fault) return KAI_ERR_DEVICE_FAULT;
+    if (n_ops) *n_ops = c.st->out_len;
+    if (ops_out) { if (c.st->out_len > ops_cap) return KAI_ERR_CAPACITY; std::memcpy(ops_out, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)); }
+    if (pod_status_out) std::memcpy(pod_status_out, c.p_status, (size_t)P * 4);
+    if (pod_node_out) std::memcpy(pod_node_out, c.p_node, (size_t)P * 4);
+    if (shares_final) fill(shares_final);
+    if (nodes_out) for (int n = 0; n < N; n++) { std::memset(&nodes_out[n], 0, sizeof(kai_node_state)); for (int r = 0; r < R; r++) { nodes_out[n].idle[r] = c.n_idle[(size_t)r * N + n]; nodes_out[n].releasing[r] = c.n_rel[(size_t)r * N + n]; nodes_out[n].used[r] = c.n_used[(size_t)r * N + n]; } }
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; }
+    return KAI_OK;
+}

@@ -1,0 +1,75 @@
+"""Debug aid: the engine's control flow (kai_engine.hpp) compiled for the host must match the oracle bit for bit.
+
+This is NOT the parity claim (that is tests/test_gpu_parity.py on a real MI355X through the C ABI); it exists because
+the development container has no GPU and the control flow is the part that needs a debugger.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import kai_testlib as T
+
+
+class HostSim(T.Oracle):
+    _sim = None
+
+    @classmethod
+    def lib(cls):
+        if cls._sim is None:
+            so = os.path.join(T.ROOT, "tests", "host_sim", "libhostsim.so")
+            src = os.path.join(T.ROOT, "tests", "host_sim", "host_sim.cpp")
+            deps = [src] + [os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", f) for f in ("kai_engine.hpp", "kai_host_prep.hpp")]
+            if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+                subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", so, src])
+            raw = C.CDLL(so)
+            raw.kai_hostsim_run.restype = C.c_int
+
+            class L:
+                kai_oracle_run = raw.kai_hostsim_run
+            cls._sim = L
+        return cls._sim
+
+
+def assert_same(res, ref):
+    assert res.ops == ref.ops
+    assert (res.pod_status == ref.pod_status).all() and (res.pod_node == ref.pod_node).all()
+    for k in ref.shares_open:
+        assert np.array_equal(res.shares_open[k], ref.shares_open[k]), k
+        assert np.array_equal(res.shares_final[k], ref.shares_final[k]), k
+    for k in ref.nodes:
+        assert np.array_equal(res.nodes[k], ref.nodes[k]), k
+
+
+GOLD = [(n, i, c, T.load_golden(n)["actions"]) for n in ("allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups")
+        for i, c in enumerate(T.load_golden(n)["cases"])]
+
+
+@pytest.mark.parametrize("name,i,case,actions", GOLD, ids=[f"{n}[{i}]" for n, i, _, _ in GOLD])
+def test_hostsim_golden(name, i, case, actions):
+    try:
+        snap, cfg, meta = T.case_to_snapshot(case)
+    except T.Unsupported as e:
+        pytest.skip(str(e))
+    res = HostSim.run(snap, cfg, actions)
+    assert not T.check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes)
+    assert_same(res, T.Oracle.run(snap, cfg, actions))
+
+
+@pytest.mark.parametrize("idx,scale", [(0, 1.0), (1, 0.2), (2, 0.03), (4, 0.004)])
+def test_hostsim_synthetic(idx, scale):
+    snap, cfg, _ = T.pkg.synth.config(idx, scale)
+    assert_same(HostSim.run(snap, cfg), T.Oracle.run(snap, cfg))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_hostsim_random_small(seed):
+    rng = np.random.default_rng(seed)
+    snap = T.pkg.synth.make_snapshot(int(rng.integers(1, 40)), int(rng.integers(0, 300)), 1000 + seed, queue_levels=(2, 3), prefill=float(rng.random()) * 0.8,
+                                     gpu_mix=((8, .5), (4, .3), (0, .2)), cpu_only_frac=0.3, zipf=True, limits_frac=0.3, queue_prios=(100, 200),
+                                     oqws=(1.0, 2.0), nonpreempt_frac=0.2, usage_max=0.2, lexi_names=bool(seed % 2))
+    for strat in (T.abi.BINPACK, T.abi.SPREAD):
+        cfg = T.abi.default_config(gpu_strategy=strat, cpu_strategy=strat, k_value=float(seed % 3) * 0.5)
+        assert_same(HostSim.run(snap, cfg), T.Oracle.run(snap, cfg))

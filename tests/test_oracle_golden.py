@@ -1,0 +1,38 @@
+"""The oracle must reproduce the reference's own golden tables — this is what pins it."""
+import pytest
+
+import kai_testlib as T
+
+FILES = ["allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups",
+         "integration_tests__allocate__allocate"]
+
+
+def _cases(name):
+    doc = T.load_golden(name)
+    return [(name, i, c, doc["actions"]) for i, c in enumerate(doc["cases"])]
+
+
+ALL = [x for f in FILES[:4] for x in _cases(f)]
+
+
+@pytest.mark.parametrize("name,i,case,actions", ALL, ids=[f"{n}[{i}]" for n, i, _, _ in ALL])
+def test_oracle_reproduces_reference_expectations(name, i, case, actions):
+    try:
+        snap, cfg, meta = T.case_to_snapshot(case)
+    except T.Unsupported as e:
+        pytest.skip(f"outside the built path: {e}")
+    res = T.Oracle.run(snap, cfg, actions)
+    errs = T.check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes)
+    assert not errs, f"{meta['name']} ({name} line {meta['line']}): {errs}"
+
+
+def test_golden_coverage():
+    """At least the 43 allocate scenarios that are inside the built path must be exercised (not silently skipped)."""
+    ok = 0
+    for name, i, case, actions in ALL:
+        try:
+            T.case_to_snapshot(case)
+            ok += 1
+        except T.Unsupported:
+            pass
+    assert ok >= 43, ok
