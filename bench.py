@@ -116,7 +116,10 @@ def main():
         "config": {"workload": desc, "nodes": N, "pods": snap.n_pods, "jobs": snap.n_jobs, "queues": snap.n_queues,
                    "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2],
                    "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (node-axis sharding not built yet)",
-                   "snapshot_gen_s": round(gen_s, 2), "host_to_hbm_s": round(upload_s, 3)},
+                   "snapshot_gen_s": round(gen_s, 2), "host_to_hbm_s": round(upload_s, 3),
+                   "engine": {"index_queries": int(st.reserved[0]), "block_refreshes": int(st.reserved[1]), "brute_force_scans": int(st.node_scans),
+                              "drained_jobs": int(st.reserved[2]), "drained_decisions": int(st.reserved[3]), "jobs_attempted": int(st.jobs_attempted),
+                              "jobs_committed": int(st.jobs_committed), "control_cycles": {"pop": int(st.reserved[4]), "allocate": int(st.reserved[5]), "commit_discard": int(st.reserved[6]), "total": int(st.reserved[7])}}},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "k_action", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
     }

@@ -1,9 +1,9 @@
 // kai_core.hip — C ABI of libkai_core (include/kai_core.h) on top of the gfx950 kernels.
 //
-// Host code here only moves the snapshot into HBM, derives index structures that are pure re-orderings
-// of the input (CSR children, per-queue job lists, each job's pods in TaskOrderFn order), launches the
-// kernels and copies results back.  There is NO CPU implementation of the path in this library: without
-// a HIP device every entry point fails with KAI_ERR_NO_DEVICE.
+// Host code here only moves the snapshot into HBM, derives index structures that are pure re-orderings / groupings
+// of the input (kai_host_prep.hpp: nodes in name-rank order, CSR children, per-queue job lists, each job's pods in
+// TaskOrderFn order, scan classes), launches the kernels and copies results back.  There is NO CPU implementation of
+// the path in this library: without a HIP device every entry point fails with KAI_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -27,11 +27,12 @@ struct kai_core {
     KaiCtx ctx{};
     std::vector<void*> bufs;  // session HBM
     // device-only helpers
-    double* d_jsum = nullptr; int32_t* d_jobs_by_queue = nullptr; int32_t* d_depth_order = nullptr;
+    double* d_jsum = nullptr; int32_t* d_slot_queue = nullptr;
     int32_t *d_lvl_off = nullptr, *d_lvl_parents = nullptr; int n_levels = 0;
     double *d_weight = nullptr, *d_rem_amt = nullptr; uint8_t* d_rem_has = nullptr;
     int32_t* d_best_out = nullptr;
     int32_t *d_status0 = nullptr, *d_node0 = nullptr; QShare* d_shares0 = nullptr;  // HBM-resident initial state for kai_session_reset
+    std::vector<int32_t> perm;  // engine node index (= name rank) → caller's node index
     kai_action_stats stats{};
 };
 
@@ -77,7 +78,6 @@ void free_session(kai_core* core) {
 }
 int fail(kai_core* core, int code, const char* msg) { core->err = msg; return code; }
 
-
 // session-open kernels over the HBM-resident snapshot (used by kai_session_open and kai_session_reset)
 int launch_open_kernels(kai_core* core) {
     KaiCtx& c = core->ctx;
@@ -90,11 +90,12 @@ int launch_open_kernels(kai_core* core) {
     }
     if (J) hipLaunchKernelGGL(k_job_usage, dim3((J + TB - 1) / TB), dim3(TB), 0, core->stream, c, core->d_jsum);
     if (core->cfg.plugins & KAI_PLUGIN_PROPORTION) {
-        if (Q) hipLaunchKernelGGL(k_leaf_usage, dim3((Q + 3) / 4), dim3(TB), 0, core->stream, c, core->d_jsum, core->d_jobs_by_queue);
-        if (Q) hipLaunchKernelGGL(k_tree_usage, dim3(1), dim3(64), 0, core->stream, c, core->d_depth_order);
+        if (Q) hipLaunchKernelGGL(k_leaf_usage, dim3((Q + 3) / 4), dim3(TB), 0, core->stream, c, core->d_jsum);
+        if (Q) hipLaunchKernelGGL(k_tree_usage, dim3(1), dim3(64), 0, core->stream, c);
         if (Q) hipLaunchKernelGGL(k_fair_share, dim3(1), dim3(256), 0, core->stream, c, core->d_lvl_off, core->d_lvl_parents, core->n_levels,
                                   core->d_weight, core->d_rem_amt, core->d_rem_has);
     }
+    if (c.use_index && c.NB) hipLaunchKernelGGL(k_index_build, dim3((c.NB + 3) / 4), dim3(TB), 0, core->stream, c);
     HIP_TRY(core, hipGetLastError());
     return KAI_OK;
 }
@@ -102,7 +103,7 @@ int launch_open_kernels(kai_core* core) {
 
 extern "C" {
 
-const char* kai_version(void) { return "kai_core abi 1 gfx950 (HIP, device-resident engine)"; }
+const char* kai_version(void) { return "kai_core abi 1 gfx950 (HIP, device-resident engine, class index)"; }
 
 const char* kai_last_error(kai_core* core) { return core ? core->err.c_str() : "null handle"; }
 
@@ -110,7 +111,7 @@ int kai_core_create(const kai_config* cfg, int n_gpus, const int* gpu_ids, kai_c
     if (!cfg || !out || cfg->abi_version != KAI_ABI_VERSION || n_gpus < 1) return KAI_ERR_INVALID_ARG;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return KAI_ERR_NO_DEVICE;
-    if (n_gpus != 1) return KAI_ERR_UNSUPPORTED;  // node-axis sharding across GPUs: see DESIGN.md "Multi-GPU"
+    if (n_gpus != 1) return KAI_ERR_UNSUPPORTED;  // one handle = one scheduling shard on one GPU: see DESIGN.md "Multi-GPU"
     int dev = gpu_ids ? gpu_ids[0] : 0;
     if (dev < 0 || dev >= count) return KAI_ERR_INVALID_ARG;
     kai_core* core = new kai_core();
@@ -159,22 +160,27 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     c.plugins = core->cfg.plugins; c.gpu_strategy = core->cfg.gpu_strategy; c.cpu_strategy = core->cfg.cpu_strategy;
     c.restrict_nodes = core->cfg.restrict_node_scheduling; c.k_value = core->cfg.k_value <= 0.0 ? 0.0 : core->cfg.k_value;  // proportion.go:77-84
 
+    // ---- index structures (pure re-orderings / groupings of the input; kai_host_prep.hpp)
+    HostPrep prep;
+    if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG;
+    core->perm = prep.perm;
+
     int rc;
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
-    // ---- static arrays (optional ones get neutral defaults)
-    std::vector<int32_t> neg1n(N, -1), zeron(N, 0), zerop(P, 0), neg1p(P, -1); std::vector<uint32_t> zeropu(P, 0); std::vector<int64_t> zerop64(P, 0);
+    // ---- static arrays (optional ones get neutral defaults); nodes go up in name-rank order
+    std::vector<int32_t> zerop(P, 0); std::vector<uint32_t> zeropu(P, 0);
     uint8_t one = 1;
-    TRY(dupload(core, &c.n_alloc, s->node_allocatable, (size_t)R * N));
-    TRY(dupload(core, &c.n_flags, s->node_flags, (size_t)N));
-    TRY(dupload(core, &c.n_gpu_count, s->node_gpu_count ? s->node_gpu_count : neg1n.data(), (size_t)N));
-    TRY(dupload(core, &c.n_name_rank, s->node_name_rank, (size_t)N));
-    TRY(dupload(core, &c.n_class, s->node_class ? s->node_class : zeron.data(), (size_t)N));
+    TRY(dupload(core, &c.n_alloc, prep.node_alloc.data(), (size_t)R * N));
+    TRY(dupload(core, &c.n_flags, prep.node_flags.data(), (size_t)N));
+    TRY(dupload(core, &c.n_gpu_count, prep.node_gpu_count.data(), (size_t)N));
+    TRY(dupload(core, &c.n_class, prep.node_class.data(), (size_t)N));
     TRY(dupload(core, &c.p_req, s->pod_req, (size_t)R * P));
     TRY(dupload(core, &c.p_job, s->pod_job, (size_t)P));
     TRY(dupload(core, &c.p_podset, s->pod_podset, (size_t)P));
     TRY(dupload(core, &c.p_flags, s->pod_flags ? s->pod_flags : zeropu.data(), (size_t)P));
     TRY(dupload(core, &c.p_class, s->pod_class ? s->pod_class : zerop.data(), (size_t)P));
-    TRY(dupload(core, &c.p_nominated, s->pod_nominated_node ? s->pod_nominated_node : neg1p.data(), (size_t)P));
+    TRY(dupload(core, &c.p_nominated, prep.pod_nominated.data(), (size_t)P));
+    TRY(dupload(core, &c.p_scls, prep.pod_scls.data(), (size_t)P));
     TRY(dupload(core, &c.s_job, s->podset_job, (size_t)S));
     TRY(dupload(core, &c.s_min, s->podset_min_available, (size_t)S));
     TRY(dupload(core, &c.s_name_rank, s->podset_name_rank, (size_t)S));
@@ -193,19 +199,22 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dupload(core, &c.q_uid_rank, s->queue_uid_rank, (size_t)Q));
     if (s->class_fit && s->n_pod_classes > 0 && s->n_node_classes > 0) TRY(dupload(core, &c.class_fit, s->class_fit, (size_t)s->n_pod_classes * s->n_node_classes));
     else TRY(dupload(core, &c.class_fit, &one, (size_t)1));
-
-    // ---- index structures (pure re-orderings of the input; kai_host_prep.hpp)
-    HostPrep prep;
-    if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG;
     TRY(dupload(core, &c.j_pods_sorted, prep.sorted.data(), (size_t)P));
     TRY(dupload(core, &c.q_child_off, prep.child_off.data(), (size_t)Q + 2));
     TRY(dupload(core, &c.q_children, prep.children.data(), (size_t)std::max(Q, 1)));
     TRY(dupload(core, &c.q_job_off, prep.job_off.data(), (size_t)Q + 1));
-    { const int32_t* t; TRY(dupload(core, &t, prep.jobs_by_queue.data(), (size_t)std::max(J, 1))); core->d_jobs_by_queue = const_cast<int32_t*>(t);
-      TRY(dupload(core, &t, prep.depth_order.data(), (size_t)Q)); core->d_depth_order = const_cast<int32_t*>(t);
+    TRY(dupload(core, &c.jobs_static, prep.jobs_static.data(), (size_t)std::max(J, 1)));
+    TRY(dupload(core, &c.q_depth_order, prep.depth_order.data(), (size_t)Q));
+    { const int32_t* t; TRY(dupload(core, &t, prep.slot_queue.data(), (size_t)std::max(J, 1))); core->d_slot_queue = const_cast<int32_t*>(t);
       TRY(dupload(core, &t, prep.lvl_off.data(), prep.lvl_off.size())); core->d_lvl_off = const_cast<int32_t*>(t);
       TRY(dupload(core, &t, prep.lvl_parents.data(), prep.lvl_parents.size())); core->d_lvl_parents = const_cast<int32_t*>(t); }
     core->n_levels = prep.n_levels;
+    // ---- scan classes + class index
+    c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64;
+    c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked;
+    { int d = core->cfg.queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
+    TRY(dupload(core, &c.cls, prep.classes.data(), prep.classes.size()));
+    TRY(dzero(core, &c.sum1_key, (size_t)std::max(c.C, 1) * std::max(c.NB, 1))); TRY(dzero(core, &c.sum1_node, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)));
 
     // ---- dynamic state
     double* d;
@@ -213,13 +222,16 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     if ((size_t)R * N) HIP_TRY(core, hipMemcpyAsync(c.n_idle, c.n_alloc, (size_t)R * N * sizeof(double), hipMemcpyDeviceToDevice, core->stream));  // NewNodeInfo: Idle = Allocatable
     TRY(dzero(core, &c.n_rel, (size_t)R * N)); TRY(dzero(core, &c.n_used, (size_t)R * N));
     { int32_t* t; TRY(dalloc(core, &t, (size_t)P)); c.p_status = t; if (P) HIP_TRY(core, hipMemcpyAsync(t, s->pod_status, (size_t)P * 4, hipMemcpyHostToDevice, core->stream));
-      TRY(dalloc(core, &t, (size_t)P)); c.p_node = t; if (P) HIP_TRY(core, hipMemcpyAsync(t, s->pod_node, (size_t)P * 4, hipMemcpyHostToDevice, core->stream)); }
+      TRY(dalloc(core, &t, (size_t)P)); c.p_node = t; if (P) HIP_TRY(core, hipMemcpyAsync(t, prep.pod_node.data(), (size_t)P * 4, hipMemcpyHostToDevice, core->stream)); }
     TRY(dzero(core, &c.p_on_node, (size_t)P)); TRY(dzero(core, &c.p_on_node_status, (size_t)P)); TRY(dzero(core, &c.p_virtual, (size_t)P)); TRY(dzero(core, &c.p_accepted, (size_t)P));
     TRY(dzero(core, &c.s_active_alloc, (size_t)S)); TRY(dzero(core, &c.s_active_used, (size_t)S)); TRY(dzero(core, &c.s_alive, (size_t)S)); TRY(dzero(core, &c.s_gated, (size_t)S)); TRY(dzero(core, &c.s_pipelined, (size_t)S));
     TRY(dzero(core, &c.j_n_pending, (size_t)J)); TRY(dzero(core, &c.j_tta_valid, (size_t)J)); TRY(dzero(core, &c.j_tta_n, (size_t)J)); TRY(dzero(core, &c.tta, (size_t)P));
     TRY(dzero(core, &c.j_tta_res, (size_t)3 * J)); TRY(dzero(core, &c.j_allocated, (size_t)3 * J));
-    TRY(dzero(core, &c.jheap, (size_t)J)); TRY(dzero(core, &c.jheap_len, (size_t)Q)); TRY(dzero(core, &c.qheap, (size_t)Q + 1)); TRY(dzero(core, &c.qheap_len, (size_t)Q + 1)); TRY(dzero(core, &c.root_heap, (size_t)Q + 1));
+    TRY(dzero(core, &c.lq_sorted, (size_t)J)); TRY(dzero(core, &c.lq_side, (size_t)J)); TRY(dzero(core, &c.lq_cur, (size_t)Q)); TRY(dzero(core, &c.lq_end, (size_t)Q)); TRY(dzero(core, &c.lq_side_len, (size_t)Q));
+    TRY(dzero(core, &c.j_state, (size_t)J));
+    TRY(dzero(core, &c.qheap, (size_t)Q + 1)); TRY(dzero(core, &c.qheap_len, (size_t)Q + 1)); TRY(dzero(core, &c.root_heap, (size_t)Q + 1));
     TRY(dzero(core, &c.qn_exists, (size_t)Q)); TRY(dzero(core, &c.qn_reorder, (size_t)Q)); TRY(dzero(core, &c.qn_linked, (size_t)Q));
+    TRY(dzero(core, &c.qkey, (size_t)Q)); TRY(dzero(core, &c.qk_valid, (size_t)Q));
     c.ops_cap = 4 * P + 64; TRY(dalloc(core, &c.ops, (size_t)c.ops_cap));
     c.out_cap = (int64_t)2 * P + 64; TRY(dalloc(core, &c.out_ops, (size_t)c.out_cap));
     TRY(dzero(core, &c.scratch, (size_t)P + 64));
@@ -228,17 +240,15 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dzero(core, &core->d_weight, (size_t)3 * Q)); TRY(dzero(core, &core->d_rem_amt, (size_t)3 * Q)); TRY(dzero(core, &core->d_rem_has, (size_t)3 * Q));
     TRY(dzero(core, &core->d_best_out, (size_t)2));
     { const QShare* t; TRY(dupload(core, &t, prep.shares.data(), prep.shares.size())); c.q_share = const_cast<QShare*>(t); }
-#undef TRY
-#define TRY2(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
-
     // keep the initial dynamic state in HBM so that kai_session_reset needs no host traffic
-    TRY2(dalloc(core, &core->d_status0, (size_t)P)); TRY2(dalloc(core, &core->d_node0, (size_t)P)); TRY2(dalloc(core, &core->d_shares0, (size_t)std::max(Q, 1) * 3));
+    TRY(dalloc(core, &core->d_status0, (size_t)P)); TRY(dalloc(core, &core->d_node0, (size_t)P)); TRY(dalloc(core, &core->d_shares0, (size_t)std::max(Q, 1) * 3));
+#undef TRY
     if (P) { HIP_TRY(core, hipMemcpyAsync(core->d_status0, c.p_status, (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream));
              HIP_TRY(core, hipMemcpyAsync(core->d_node0, c.p_node, (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream)); }
     HIP_TRY(core, hipMemcpyAsync(core->d_shares0, c.q_share, (size_t)std::max(Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
     { int rc2 = launch_open_kernels(core); if (rc2) return rc2; }
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
-    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    HIP_TRY(core, hipStreamSynchronize(core->stream));  // prep's host buffers die with this scope
     float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));
     std::memset(&core->stats, 0, sizeof(core->stats));
     core->stats.upload_ms = ms;
@@ -298,7 +308,11 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     st = EngineState{}; st.total[0] = total[0]; st.total[1] = total[1]; st.total[2] = total[2];
     HIP_TRY(core, hipMemcpyAsync(c.st, &st, sizeof(st), hipMemcpyHostToDevice, core->stream));
     HIP_TRY(core, hipEventRecord(core->ev0, core->stream));
+    const int TB = 256;
+    if (c.J) hipLaunchKernelGGL(k_job_init, dim3((c.J + TB - 1) / TB), dim3(TB), 0, core->stream, c);
+    if (c.Q) hipLaunchKernelGGL(k_leaf_init, dim3((c.Q + 3) / 4), dim3(TB), 0, core->stream, c);
     hipLaunchKernelGGL(k_action, dim3(1), dim3(WG), 0, core->stream, c, action);
+    if (c.J) hipLaunchKernelGGL(k_drain, dim3(std::min(2048, (c.J + TB - 1) / TB)), dim3(TB), 0, core->stream, c, core->d_slot_queue);
     HIP_TRY(core, hipGetLastError());
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
     HIP_TRY(core, hipMemcpyAsync(&st, c.st, sizeof(st), hipMemcpyDeviceToHost, core->stream));
@@ -308,12 +322,15 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     std::memset(&core->stats, 0, sizeof(core->stats));
     core->stats.upload_ms = upload; core->stats.kernel_ms = ms; core->stats.decisions = st.decisions; core->stats.node_scans = st.node_scans;
     core->stats.nodes_scanned = st.nodes_scanned; core->stats.jobs_attempted = st.jobs_attempted; core->stats.jobs_committed = st.jobs_committed; core->stats.rollbacks = st.rollbacks;
+    core->stats.reserved[0] = st.index_queries; core->stats.reserved[1] = st.index_refreshes; core->stats.reserved[2] = st.drained_jobs; core->stats.reserved[3] = st.drained_decisions;
+    for (int i = 0; i < 4; i++) core->stats.reserved[4 + i] = st.prof[i == 3 ? 7 : i == 2 ? 3 : i == 1 ? 2 : 0];  // control-lane cycles: pop, allocate, commit/discard, total
     if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d", st.fault); core->err = buf; return KAI_ERR_DEVICE_FAULT; }
     *n_ops = st.out_len;
     if (ops_out) {
         if (st.out_len > ops_cap) return fail(core, KAI_ERR_CAPACITY, "kai_action_execute: ops_cap too small");
         if (st.out_len) HIP_TRY(core, hipMemcpyAsync(ops_out, c.out_ops, (size_t)st.out_len * sizeof(kai_op), hipMemcpyDeviceToHost, core->stream));
         HIP_TRY(core, hipStreamSynchronize(core->stream));
+        for (int64_t i = 0; i < st.out_len; i++) if (ops_out[i].node >= 0) ops_out[i].node = core->perm[ops_out[i].node];  // name rank → caller's index
     }
     return KAI_OK;
 }
@@ -329,7 +346,7 @@ int kai_best_node(kai_core* core, int32_t pod_idx, const uint32_t* nodeset_bitma
     int32_t h[2] = {-1, 0};
     HIP_TRY(core, hipMemcpyAsync(h, core->d_best_out, sizeof h, hipMemcpyDeviceToHost, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));
-    *node_idx_out = h[0];
+    *node_idx_out = h[0] >= 0 ? core->perm[h[0]] : -1;
     if (is_pipeline_out) *is_pipeline_out = h[1];
     return KAI_OK;
 }
@@ -343,6 +360,7 @@ int kai_pod_states(kai_core* core, int32_t* status_out, int32_t* node_out, int c
     if (status_out && P) HIP_TRY(core, hipMemcpyAsync(status_out, core->ctx.p_status, (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
     if (node_out && P) HIP_TRY(core, hipMemcpyAsync(node_out, core->ctx.p_node, (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));
+    if (node_out) for (int p = 0; p < P; p++) if (node_out[p] >= 0) node_out[p] = core->perm[node_out[p]];
     return KAI_OK;
 }
 
@@ -359,9 +377,10 @@ int kai_node_states(kai_core* core, kai_node_state* out, int cap) {
         HIP_TRY(core, hipMemcpyAsync(used.data(), core->ctx.n_used, (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
     }
     HIP_TRY(core, hipStreamSynchronize(core->stream));
-    for (int n = 0; n < N; n++) {
-        std::memset(&out[n], 0, sizeof(kai_node_state));
-        for (int r = 0; r < R; r++) { out[n].idle[r] = idle[(size_t)r * N + n]; out[n].releasing[r] = rel[(size_t)r * N + n]; out[n].used[r] = used[(size_t)r * N + n]; }
+    for (int i = 0; i < N; i++) {
+        kai_node_state& o = out[core->perm[i]];
+        std::memset(&o, 0, sizeof(kai_node_state));
+        for (int r = 0; r < R; r++) { o.idle[r] = idle[(size_t)r * N + i]; o.releasing[r] = rel[(size_t)r * N + i]; o.used[r] = used[(size_t)r * N + i]; }
     }
     return KAI_OK;
 }

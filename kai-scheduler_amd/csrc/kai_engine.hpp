@@ -3,13 +3,22 @@
 // The whole session lives in HBM as structure-of-arrays (KaiCtx).  One persistent kernel executes an
 // Action: lane 0 of wave 0 runs the sequential control flow of the reference (fair job order, gang
 // loop, statement log — all of it inherently serial) and every other wavefront of the
-// launch serves its node scans (filter + score + arg-max over the node SoA).  This header holds the
-// control flow and the per-node arithmetic; kai_kernels.hip holds the cooperative scan, the
-// session-open kernels and the launch code.
+// workgroup serves it: they keep the per-class arg-max index over the node SoA current (class index,
+// below) and run brute-force node scans where the index does not apply.  This header holds the control
+// flow and the per-node arithmetic; kai_kernels.hpp holds the cooperative parts, the session-open /
+// action-init kernels and the launch code.
+//
+// Class index.  Pending pods fall into a few scan classes (same request vector and predicate class).
+// For a class the reference's order over nodes (Σ NodeOrderFns desc, name asc — framework/session.go:234-264,
+// 466-485) is the order of a per-node 64-bit key that depends only on that node's own state (class_key()),
+// so  OrderedNodesByTask + FittingNode  ==  arg-max of the key over the fitting nodes.  The engine keeps, per class,
+// the arg-max of every 64-node block (L1, HBM), of every 64-block super-block (L2, LDS) and of the whole cluster,
+// and after a placement / rollback re-evaluates only the blocks whose nodes changed.  Node indices inside the
+// engine are name ranks (the host permutes), so "name asc" is "index asc".
 //
 // Everything here is `KAI_HD` so that tests/host_sim can compile the identical control flow for the
-// host to debug it without a GPU.  The product library only ever instantiates the device scanner and
-// fails without a HIP device (see kai_core.cpp); nothing in it runs on the CPU.
+// host to debug it without a GPU.  The product library only ever instantiates the device backend and
+// fails without a HIP device (see kai_core.hip); nothing in it runs on the CPU.
 //
 // Reference citations are file:line under pkg/scheduler.
 #pragma once
@@ -54,25 +63,46 @@ struct StmtOp {
     int32_t name, pod, prev_status, prev_node, next_node, prev_virtual, op_index, pad;
 };
 
+// scan class: every pod with the same request vector and static-predicate class (host: kai_host_prep.hpp)
+struct ClassRec {
+    double req[KAI_MAX_RES];
+    int32_t pod_class, cpu_only, best_effort, r_place, strategy, pad[3];
+};
+constexpr int KAI_CMAX = 64;      // classes the index tracks (the most frequent ones); the rest use brute-force scans
+constexpr int KAI_BLOCK = 64;     // nodes per L1 block = one wavefront
+constexpr int KAI_NSB_MAX = 64;   // super-blocks the LDS level holds → the index covers N <= 64*64*64 = 262144 nodes
+constexpr int KAI_MAXD = 16;      // dirty blocks buffered before a refresh is forced
+
+// cached operands of the queue comparator for one queue node (plugins/proportion/queue_order/queue_order.go:19-73)
+struct QKey {
+    double dom_with_job, dom_no_job;
+    int32_t best_job;
+    uint32_t bits;  // 1 over fair share, 2 under quota with job, 4 zero-share violation
+};
+
 struct EngineState {  // mutable scalars of the running action
     int32_t root_len, root_init;
-    int32_t ops_len;
+    int32_t ops_len, n_undo;
     int32_t fault;            // != 0: engine gave up (see FAULT_*)
+    int32_t drain_pending;    // allocate: every class is dead at a committed state → the rest of the queue is counted by k_drain
     int64_t out_len;
     int64_t decisions, node_scans, nodes_scanned, jobs_attempted, jobs_committed, rollbacks;
+    int64_t index_queries, index_refreshes, drained_jobs, drained_decisions;
+    int64_t prof[8];          // control-lane cycles per phase (pop, tta+gate, task, commit/discard, drain check, init, -, total)
     double total[3];          // proportion totalResource (CPU, Memory, GPU)
 };
 enum { FAULT_NONE = 0, FAULT_OPS_CAP = 1, FAULT_OUT_CAP = 2, FAULT_HEAP = 3, FAULT_INTERNAL = 4, FAULT_SPIN = 5 };
 
-// All pointers are device memory (HBM).  [R][N] arrays are resource-major.
+// All pointers are device memory (HBM).  [R][N] arrays are resource-major.  Node index = name rank.
 struct KaiCtx {
     int32_t N, P, S, J, Q, R, n_pod_classes, n_node_classes;
     uint32_t plugins; int32_t gpu_strategy, cpu_strategy, restrict_nodes; double k_value;
+    int32_t C, NB, NSB, use_index, all_tracked, queue_depth, pad0, pad1;
     // nodes
-    const double* n_alloc; const uint32_t* n_flags; const int32_t* n_gpu_count; const uint32_t* n_name_rank; const int32_t* n_class;
+    const double* n_alloc; const uint32_t* n_flags; const int32_t* n_gpu_count; const int32_t* n_class;
     double *n_idle, *n_rel, *n_used;
     // pods
-    const double* p_req; const int32_t *p_job, *p_podset; const uint32_t* p_flags; const int32_t *p_class, *p_nominated;
+    const double* p_req; const int32_t *p_job, *p_podset; const uint32_t* p_flags; const int32_t *p_class, *p_nominated, *p_scls;
     int32_t *p_status, *p_node, *p_on_node, *p_on_node_status; uint8_t *p_virtual, *p_accepted;
     // pod-sets
     const int32_t *s_job, *s_min; const uint32_t* s_name_rank;
@@ -86,11 +116,16 @@ struct KaiCtx {
     double *j_allocated;  // [3][J] PodGroupInfo.Allocated
     // queues
     const int32_t *q_parent, *q_prio; const int64_t* q_created; const uint32_t* q_uid_rank;
-    const int32_t *q_child_off, *q_children, *q_job_off;  // CSR children; leaf job-heap regions
+    const int32_t *q_child_off, *q_children, *q_job_off, *q_depth_order;  // CSR children (virtual root at Q); leaf job regions; deepest first
     QShare* q_share;  // [Q][3]
+    QKey* qkey; uint8_t* qk_valid;
     const uint8_t* class_fit;
-    // job-order tree (actions/utils/job_order_by_queue.go): heaps are array regions
-    int32_t *jheap, *jheap_len, *qheap, *qheap_len, *root_heap; uint8_t *qn_exists, *qn_reorder, *qn_linked;
+    // scan classes + class index
+    const ClassRec* cls; uint64_t* sum1_key; int32_t* sum1_node;  // [C][NB]
+    // job-order tree (actions/utils/job_order_by_queue.go).  Leaves: a sorted region + a side heap; inner nodes: array heaps.
+    const int32_t* jobs_static;  // [J] CSR by q_job_off: each queue's jobs by (priority desc, creation, uid)
+    int32_t *lq_sorted, *lq_cur, *lq_end, *lq_side, *lq_side_len; uint8_t* j_state;
+    int32_t *qheap, *qheap_len, *root_heap; uint8_t *qn_exists, *qn_reorder, *qn_linked;
     // statement + committed operations
     StmtOp* ops; int32_t ops_cap; kai_op* out_ops; int64_t out_cap;
     int32_t* scratch;  // [P] ints
@@ -106,47 +141,47 @@ struct ScanReq {
     double min_a, max_a;  // nodeplacement.setBinpackPreOrder range (plugins/nodeplacement/pack.go:35-43)
 };
 
-KAI_HD bool fits(const KaiCtx& c, const ScanReq& q, int n, bool with_releasing) {
+KAI_HD bool fits(const KaiCtx& c, const double* req, int n, bool with_releasing) {
     // ResourceRequirements.LessEqualResource (api/resource_info/resource_requirment.go:126-140) against Idle, or against
     // NodeInfo.NonAllocatedResources = 0 + Idle + Releasing (api/node_info/node_info.go:157-162)
     for (int r = 0; r < c.R; r++) {
-        double req = q.req[r];
-        if (r >= KAI_RES_PODS && !(req > 0)) continue;  // scalar keys exist only for non-zero requests
+        double rq = req[r];
+        if (r >= KAI_RES_PODS && !(rq > 0)) continue;  // scalar keys exist only for non-zero requests
         double avail = c.n_idle[(size_t)r * c.N + n];
         if (with_releasing) avail = avail + c.n_rel[(size_t)r * c.N + n];
-        if (req > avail) return false;
+        if (rq > avail) return false;
     }
     return true;
 }
 
 // plugins/predicates/predicates.go:173-262 minus the queue-capacity step (node independent, done by the control lane)
-KAI_HD bool node_predicates(const KaiCtx& c, const ScanReq& q, int n) {
+KAI_HD bool node_predicates(const KaiCtx& c, bool cpu_only, int pod_class, int n) {
     if (!(c.plugins & KAI_PLUGIN_PREDICATES)) return true;
     uint32_t f = c.n_flags[n];
-    if (!q.cpu_only) {  // NodeInfo.PredicateByNodeResourcesType (api/node_info/node_info.go:315-359)
+    if (!cpu_only) {  // NodeInfo.PredicateByNodeResourcesType (api/node_info/node_info.go:315-359)
         if (f & KAI_NODE_HAS_DRA_GPUS) return false;
         if ((f & KAI_NODE_MIG_ENABLED) && (f & KAI_NODE_MIG_MIXED)) return false;
     }
     double pods = c.n_idle[(size_t)KAI_RES_PODS * c.N + n] + c.n_rel[(size_t)KAI_RES_PODS * c.N + n];  // :264-285
     if (!(pods > 0)) return false;
     if (f & KAI_NODE_NOT_READY) return false;
-    if (!c.class_fit[(size_t)q.pod_class * c.n_node_classes + c.n_class[n]]) return false;
+    if (!c.class_fit[(size_t)pod_class * c.n_node_classes + c.n_class[n]]) return false;
     if (c.restrict_nodes) {
-        if (!q.cpu_only) { if (!(f & KAI_NODE_GPU_WORKER)) return false; }
+        if (!cpu_only) { if (!(f & KAI_NODE_GPU_WORKER)) return false; }
         else if (!(f & KAI_NODE_CPU_WORKER)) return false;
     }
     return true;
+}
+KAI_HD bool cpu_only_node(const KaiCtx& c, int n) {  // node_info.go:697-702
+    uint32_t f = c.n_flags[n];
+    return !(f & KAI_NODE_MIG_ENABLED) && c.n_alloc[(size_t)KAI_RES_GPU * c.N + n] <= 0 && !(f & KAI_NODE_HAS_DRA_GPUS);
 }
 
 // Σ NodeOrderFns in registration order (framework/session_plugins.go:427-437, conf_util/scheduler_conf_util.go:39-60)
 KAI_HD double node_score(const KaiCtx& c, const ScanReq& q, int n, bool fit_idle) {
     double score = 0.0;
     if (c.plugins & KAI_PLUGIN_NODEAVAILABILITY) score += fit_idle ? 100.0 : 0.0;  // plugins/nodeavailability/nodeavailability.go:29-40
-    uint32_t f = c.n_flags[n];
-    if (c.plugins & KAI_PLUGIN_RESOURCETYPE) {  // plugins/resourcetype/resourcetype.go:29-41, node_info.go:697-702
-        bool cpu_only_node = !(f & KAI_NODE_MIG_ENABLED) && c.n_alloc[(size_t)KAI_RES_GPU * c.N + n] <= 0 && !(f & KAI_NODE_HAS_DRA_GPUS);
-        score += (q.cpu_only && cpu_only_node) ? 10.0 : 0.0;
-    }
+    if (c.plugins & KAI_PLUGIN_RESOURCETYPE) score += (q.cpu_only && cpu_only_node(c, n)) ? 10.0 : 0.0;  // plugins/resourcetype/resourcetype.go:29-41
     if (c.plugins & KAI_PLUGIN_NOMINATEDNODE) score += (q.nominated >= 0 && q.nominated == n) ? 1000000.0 : 0.0;
     if (c.plugins & KAI_PLUGIN_NODEPLACEMENT) {
         int r = q.r_place;
@@ -168,17 +203,53 @@ KAI_HD double node_score(const KaiCtx& c, const ScanReq& q, int n, bool fit_idle
     return score;
 }
 
-struct ScanResult { int32_t node; };
+// The class key: 0 = the node does not pass FittingNode for this class; otherwise a 64-bit value whose order over nodes is the
+// order of the reference's f64 score sum for every task of the class:
+//   bit 63  nodeavailability (+100): the task fits on Idle alone           (dominates 10 + 9)
+//   bit 62  resourcetype (+10): CPU-only task on a CPU-only node           (dominates 9)
+//   bits 0-61  nodeplacement: bin-pack → 2^53-1 - (Idle+Releasing)[r] (the pack score 9·(1-(cur-min)/(max-min)) is strictly
+//              decreasing in cur for the integer quantities the host admits to the index, kai_host_prep.hpp guards);
+//              spread → bit pattern of the f64 score cur/count ∈ [0,1], plus one.
+// The nominated-node bonus (+1e6) concerns one node per pod and is handled by the control lane.
+KAI_HD uint64_t class_key(const KaiCtx& c, const ClassRec& k, int n) {
+    if (!fits(c, k.req, n, true)) return 0;
+    if (!node_predicates(c, k.cpu_only != 0, k.pod_class, n)) return 0;
+    uint64_t key = 0;
+    if ((c.plugins & KAI_PLUGIN_NODEAVAILABILITY) && (k.best_effort || fits(c, k.req, n, false))) key |= 1ull << 63;
+    if ((c.plugins & KAI_PLUGIN_RESOURCETYPE) && k.cpu_only && cpu_only_node(c, n)) key |= 1ull << 62;
+    uint64_t v = 1;
+    if (c.plugins & KAI_PLUGIN_NODEPLACEMENT) {
+        int r = k.r_place;
+        double cur = c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n];
+        if (k.strategy == KAI_SPREAD) {
+            double overall = c.n_alloc[(size_t)r * c.N + n], count = overall;
+            if (r == KAI_RES_GPU) { int lbl = c.n_gpu_count[n]; count = lbl >= 0 ? (double)lbl : (double)(int64_t)overall; }
+            double place = count == 0 ? 0.0 : cur / count;
+            union { double d; uint64_t u; } cv; cv.d = place;
+            v = cv.u + 1;
+        } else {
+            v = (uint64_t)((((int64_t)1 << 53) - 1) - (int64_t)cur);  // cur >= 0 here: a node with a negative free amount fits nothing
+        }
+    }
+    return key | v;
+}
+KAI_HD bool key_better(uint64_t k, int n, uint64_t bk, int bn) { return k > bk || (k == bk && k != 0 && n < bn); }
 
 // ======================================================================================================
-// Engine<Scanner>: the control flow.  Scanner provides
-//    void minmax(const KaiCtx&, int r, double& mn, double& mx)          — pack.go:66-86 over the node set
-//    int  best_node(const KaiCtx&, const ScanReq&)                      — arg-max of (score, -name_rank) over fitting nodes
+// Engine<Backend>: the control flow.  Backend provides
+//    void minmax(const KaiCtx&, int r, double& mn, double& mx)          — pack.go:66-86 over the node set (brute force)
+//    int  best_node(const KaiCtx&, const ScanReq&)                      — arg-max of (score, -index) over fitting nodes (brute force)
+//    void begin(const KaiCtx&)                                          — build the in-LDS levels of the class index
+//    void refresh(const KaiCtx&, const int32_t* blocks, int n)          — node state of these 64-node blocks changed
+//    void class_top(const KaiCtx&, int cls, uint64_t& key, int& node)   — arg-max of class_key over all nodes
+//    bool all_dead(const KaiCtx&)                                       — no class has a fitting node
+//    int64_t clock()
 // ======================================================================================================
-template <class Scanner>
+template <class Backend>
 struct Engine {
-    KaiCtx c; Scanner& sc;
-    KAI_HD Engine(const KaiCtx& ctx, Scanner& s) : c(ctx), sc(s) {}
+    KaiCtx c; Backend& be;
+    int32_t dirty[KAI_MAXD]; int n_dirty = 0; bool fail_no_node = false;
+    KAI_HD Engine(const KaiCtx& ctx, Backend& b) : c(ctx), be(b) {}
 
     KAI_HD void fault(int code) { if (!c.st->fault) c.st->fault = code; }
     KAI_HD double preq(int p, int r) const { return c.p_req[(size_t)r * c.P + p]; }
@@ -195,6 +266,19 @@ struct Engine {
     }
     // quota triple of a pod: utils.QuantifyResourceRequirements (plugins/proportion/utils/utils.go:15-17)
     KAI_HD double pquota(int p, int k) const { return k == KAI_Q_CPU ? preq(p, KAI_RES_CPU) : k == KAI_Q_MEM ? preq(p, KAI_RES_MEM) : preq(p, KAI_RES_GPU); }
+
+    // ------------------------------------------------------------------ class index bookkeeping
+    KAI_HD void flush_index() {
+        if (n_dirty) { be.refresh(c, dirty, n_dirty); c.st->index_refreshes += n_dirty; n_dirty = 0; }
+    }
+    KAI_HD void mark_dirty(int n) {
+        if (!c.use_index) return;
+        int b = n / KAI_BLOCK;
+        for (int i = 0; i < n_dirty; i++) if (dirty[i] == b) return;
+        if (n_dirty == KAI_MAXD) flush_index();
+        dirty[n_dirty++] = b;
+    }
+    KAI_HD void invalidate_path(int q) { for (int x = q; x >= 0; x = c.q_parent[x]) c.qk_valid[x] = 0; }
 
     // ------------------------------------------------------------------ status bookkeeping
     // PodGroupInfo.UpdateTaskStatus (api/podgroup_info/job_info.go:228-287) + PodSet.AssignTask (subgroup_info/podset.go:56-99)
@@ -228,6 +312,7 @@ struct Engine {
             else if (status == KAI_POD_PIPELINED) c.n_rel[i] -= sign * v;
             else c.n_idle[i] -= sign * v;
         }
+        mark_dirty(n);
     }
     KAI_HD bool node_add_task(int n, int p) {  // AddTask :384-417
         if (st_active_used(c.p_status[p])) c.p_accepted[p] = 1;  // setAcceptedResources :746-766
@@ -250,10 +335,13 @@ struct Engine {
         if (!(c.plugins & KAI_PLUGIN_PROPORTION)) return;
         if (!c.p_accepted[p]) return;  // AcceptedResource is empty until the task was added to a node
         int j = c.p_job[p]; bool np = !c.j_preempt[j];
-        for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
-            QShare& s = c.q_share[(size_t)q * 3 + k]; double v = pquota(p, k);
-            s.allocated += sign * v;
-            if (np) s.allocated_np += sign * v;
+        for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) {
+            for (int k = 0; k < 3; k++) {
+                QShare& s = c.q_share[(size_t)q * 3 + k]; double v = pquota(p, k);
+                s.allocated += sign * v;
+                if (np) s.allocated_np += sign * v;
+            }
+            c.qk_valid[q] = 0;
         }
     }
 
@@ -261,6 +349,7 @@ struct Engine {
     KAI_HD int checkpoint() const { return c.st->ops_len; }
     KAI_HD bool push_op(const StmtOp& o) { if (c.st->ops_len >= c.ops_cap) { fault(FAULT_OPS_CAP); return false; } c.ops[c.st->ops_len++] = o; return true; }
     KAI_HD bool op_valid(int i) const {  // :652-663 — valid(i) = no undo of i, or that undo is itself undone (iterative form)
+        if (c.st->n_undo == 0) return true;
         bool valid = true; int target = i;
         for (;;) {
             int u = -1;
@@ -340,13 +429,17 @@ struct Engine {
             default: fault(FAULT_INTERNAL); return;  // undo of an undo (= redo) only arises in victim scenarios; not on the allocate path
         }
         StmtOp u{}; u.name = OP_UNDO; u.pod = -1; u.op_index = index;
-        push_op(u);
+        if (push_op(u)) c.st->n_undo++;
+    }
+    KAI_HD void truncate_ops(int cp) {
+        for (int i = cp; i < c.st->ops_len; i++) if (c.ops[i].name == OP_UNDO) c.st->n_undo--;
+        c.st->ops_len = cp;
     }
     KAI_HD void rollback(int cp) {  // :48-61
         for (int i = c.st->ops_len - 1; i >= cp; i--) undo_operation(i);
-        c.st->ops_len = cp; c.st->rollbacks++;
+        truncate_ops(cp); c.st->rollbacks++;
     }
-    KAI_HD void discard() { for (int i = c.st->ops_len - 1; i >= 0; i--) undo_operation(i); c.st->ops_len = 0; }  // :522-534
+    KAI_HD void discard() { for (int i = c.st->ops_len - 1; i >= 0; i--) undo_operation(i); truncate_ops(0); }  // :522-534
     KAI_HD bool convert_all_allocated_to_pipelined(int job) {  // :483-516
         int n0 = c.st->ops_len;
         for (int i = 0; i < n0; i++) {
@@ -376,30 +469,30 @@ struct Engine {
             else { o.kind = KAI_OP_ALLOCATE; update_task_status(op.pod, KAI_POD_BINDING); }  // ssn.BindPod (framework/session.go:111-126)
             c.out_ops[c.st->out_len++] = o;
         }
-        c.st->ops_len = 0;
+        truncate_ops(0);
     }
 
     // ------------------------------------------------------------------ order functions
-    KAI_HD void min_available_state(int j, bool& below, bool& above, bool& exactly) const {  // plugins/elastic/elastic.go:53-65
-        exactly = true;
+    KAI_HD int min_available_state(int j) const {  // plugins/elastic/elastic.go:53-65 → 0 below, 1 exactly, 2 above
+        bool exactly = true;
         for (int k = 0; k < c.j_n_ps[j]; k++) {
             int s = c.j_first_ps[j] + k; int n = c.s_active_alloc[s], m = c.s_min[s];
-            if (n < m) { below = true; above = false; exactly = false; return; }
+            if (n < m) return 0;
             if (n > m) exactly = false;
         }
-        below = false; above = !exactly;
+        return exactly ? 1 : 2;
     }
     KAI_HD bool job_order(int l, int r) const {  // framework/session_plugins.go:227-242
         if (c.plugins & KAI_PLUGIN_PRIORITY) {
             if (c.j_prio[l] > c.j_prio[r]) return true;
             if (c.j_prio[l] < c.j_prio[r]) return false;
         }
-        if (c.plugins & KAI_PLUGIN_ELASTIC) {
-            bool lb, la, le, rb, ra, re; min_available_state(l, lb, la, le); min_available_state(r, rb, ra, re);
-            if (lb && !rb) return true;
-            if (le && ra) return true;
-            if (!lb && rb) return false;
-            if (la && re) return false;
+        if (c.plugins & KAI_PLUGIN_ELASTIC) {  // plugins/elastic/elastic.go:25-51 — an order on (below < exactly < above)
+            int ls = min_available_state(l), rs = min_available_state(r);
+            if (ls == 0 && rs != 0) return true;
+            if (ls == 1 && rs == 2) return true;
+            if (ls != 0 && rs == 0) return false;
+            if (ls == 2 && rs == 1) return false;
         }
         if (c.j_created[l] == c.j_created[r]) return c.j_uid_rank[l] < c.j_uid_rank[r];
         return c.j_created[l] < c.j_created[r];
@@ -422,31 +515,38 @@ struct Engine {
     KAI_HD void ensure_tta(int j, bool real) {
         if (c.j_tta_valid[j]) return;
         int first = c.j_first_pod[j], np = c.j_n_pods[j], nps = c.j_n_ps[j], ps0 = c.j_first_ps[j];
-        int unsat = 0; for (int k = 0; k < nps; k++) if (c.s_active_alloc[ps0 + k] < c.s_min[ps0 + k]) unsat++;
-        int max_sg = unsat > 0 ? unsat : 1, n_sg = 0, out = 0;
-        // pod-sets leave the priority queue in PodSetOrderFn order: repeated arg-min, podsets per job are few
-        uint64_t taken_lo = 0;  // bitmap for up to 64 pod-sets; larger jobs fall back to the scratch array
-        for (int round = 0; round < nps && n_sg < max_sg; round++) {
-            int best = -1;
-            for (int k = 0; k < nps; k++) {
-                bool taken = k < 64 ? ((taken_lo >> k) & 1) : (c.scratch[first + (k - 64)] != 0);
-                if (taken) continue;
-                if (best < 0 || podset_order(ps0 + k, ps0 + best)) best = k;
+        int out = 0;
+        if (nps == 1) {  // one pod-set: the chunk is the first max_tasks allocatable pods in task order
+            int s = ps0, act = c.s_active_alloc[s], mn = c.s_min[s];
+            int max_tasks = act >= mn ? 1 : mn - act;  // getNumTasksToAllocate :145-153
+            for (int i = 0; i < np && out < max_tasks; i++) { int p = c.j_pods_sorted[first + i]; if (should_allocate(p, real)) c.tta[first + out++] = p; }
+        } else {
+            int unsat = 0; for (int k = 0; k < nps; k++) if (c.s_active_alloc[ps0 + k] < c.s_min[ps0 + k]) unsat++;
+            int max_sg = unsat > 0 ? unsat : 1, n_sg = 0;
+            // pod-sets leave the priority queue in PodSetOrderFn order: repeated arg-min, podsets per job are few
+            uint64_t taken_lo = 0;  // bitmap for up to 64 pod-sets; larger jobs fall back to the scratch array
+            for (int round = 0; round < nps && n_sg < max_sg; round++) {
+                int best = -1;
+                for (int k = 0; k < nps; k++) {
+                    bool taken = k < 64 ? ((taken_lo >> k) & 1) : (c.scratch[first + (k - 64)] != 0);
+                    if (taken) continue;
+                    if (best < 0 || podset_order(ps0 + k, ps0 + best)) best = k;
+                }
+                if (best < 0) break;
+                if (best < 64) taken_lo |= (1ull << best); else c.scratch[first + (best - 64)] = 1;
+                int s = ps0 + best;
+                int avail = 0; for (int i = 0; i < np; i++) { int p = c.j_pods_sorted[first + i]; if (c.p_podset[p] == s && should_allocate(p, real)) avail++; }
+                if (avail == 0) continue;
+                int max_tasks = c.s_active_alloc[s] >= c.s_min[s] ? (avail < 1 ? avail : 1) : (c.s_min[s] - c.s_active_alloc[s]);  // getNumTasksToAllocate :145-153
+                int got = 0;
+                for (int i = 0; i < np && got < max_tasks; i++) { int p = c.j_pods_sorted[first + i]; if (c.p_podset[p] == s && should_allocate(p, real)) { c.tta[first + out++] = p; got++; } }
+                n_sg++;
             }
-            if (best < 0) break;
-            if (best < 64) taken_lo |= (1ull << best); else c.scratch[first + (best - 64)] = 1;
-            int s = ps0 + best;
-            int avail = 0; for (int i = 0; i < np; i++) { int p = c.j_pods_sorted[first + i]; if (c.p_podset[p] == s && should_allocate(p, real)) avail++; }
-            if (avail == 0) continue;
-            int max_tasks = c.s_active_alloc[s] >= c.s_min[s] ? (avail < 1 ? avail : 1) : (c.s_min[s] - c.s_active_alloc[s]);  // getNumTasksToAllocate :145-153
-            int got = 0;
-            for (int i = 0; i < np && got < max_tasks; i++) { int p = c.j_pods_sorted[first + i]; if (c.p_podset[p] == s && should_allocate(p, real)) { c.tta[first + out++] = p; got++; } }
-            n_sg++;
+            if (nps > 64) for (int k = 64; k < nps; k++) c.scratch[first + (k - 64)] = 0;
         }
-        if (nps > 64) for (int k = 64; k < nps; k++) c.scratch[first + (k - 64)] = 0;
         c.j_tta_n[j] = out;
         double res[3] = {0, 0, 0};  // GetTasksToAllocateInitResource :88-113
-        for (int i = 0; i < out; i++) { int p = c.tta[first + i]; if (should_allocate(p, real)) for (int k = 0; k < 3; k++) res[k] += pquota(p, k); }
+        for (int i = 0; i < out; i++) { int p = c.tta[first + i]; for (int k = 0; k < 3; k++) res[k] += pquota(p, k); }
         for (int k = 0; k < 3; k++) c.j_tta_res[(size_t)k * c.J + j] = res[k];
         c.j_tta_valid[j] = 1;
     }
@@ -469,36 +569,49 @@ struct Engine {
         if (b == KAI_UNLIMITED) return -1;
         return a > b ? 1 : a < b ? -1 : 0;
     }
+    // getBestJobFromNode :309-318 (pending ordering)
+    KAI_HD int best_job_from_node(int q) {
+        for (;;) {
+            if (q_is_leaf(q)) return leaf_top(q);
+            if (c.qheap_len[q] == 0) return -1;
+            q = c.qheap[c.q_child_off[q]];
+        }
+    }
+    // operands of queue_order.GetQueueOrderResult for queue q with the best job of its subtree, cached until q's shares or best job change
+    KAI_HD const QKey& queue_key(int q) {
+        QKey& key = c.qkey[q];
+        if (c.qk_valid[q]) return key;
+        const QShare* L = &c.q_share[(size_t)q * 3];
+        int bj = best_job_from_node(q);
+        double req[3] = {0, 0, 0};
+        if (bj >= 0) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = c.j_tta_res[(size_t)k * c.J + bj]; }
+        uint32_t bits = 0;
+        bool over = true, starved = true, viol = false;
+        for (int k = 0; k < 3; k++) {
+            if (L[k].fair >= L[k].allocated) over = false;                    // prioritizeUnderUtilized :87-98 — FairShare.Less(Allocated) in all three
+            double with_job = L[k].allocated + req[k];
+            if (cmp_q(with_job, L[k].deserved) > 0) starved = false;          // prioritizeUnderQuotaWithJob :100-125
+            if (qs_allocatable(L[k]) == 0 && with_job > 0) viol = true;       // penalizeZeroShareWithJob :127-176
+        }
+        if (over) bits |= 1; if (starved) bits |= 2; if (viol) bits |= 4;
+        key.bits = bits; key.best_job = bj;
+        key.dom_with_job = dominant_share(q, req);   // :178-196, 242-273
+        key.dom_no_job = dominant_share(q, nullptr); // :198-212
+        c.qk_valid[q] = 1;
+        return key;
+    }
     // plugins/proportion/queue_order/queue_order.go:19-73 (allocate ordering: no victims)
-    KAI_HD int queue_order(int lq, int rq, int lj, int rj) {
-        const QShare* L = &c.q_share[(size_t)lq * 3]; const QShare* Rr = &c.q_share[(size_t)rq * 3];
-        {   // prioritizeUnderUtilized :87-98 — FairShare.Less(Allocated) in all three
-            bool lo = true, ro = true;
-            for (int k = 0; k < 3; k++) { if (L[k].fair >= L[k].allocated) lo = false; if (Rr[k].fair >= Rr[k].allocated) ro = false; }
-            if (!lo && ro) return -1;
-            if (lo && !ro) return 1;
-        }
-        double lreq[3] = {0, 0, 0}, rreq[3] = {0, 0, 0};
-        if (lj >= 0) { ensure_tta(lj, false); for (int k = 0; k < 3; k++) lreq[k] = c.j_tta_res[(size_t)k * c.J + lj]; }
-        if (rj >= 0) { ensure_tta(rj, false); for (int k = 0; k < 3; k++) rreq[k] = c.j_tta_res[(size_t)k * c.J + rj]; }
-        double lal[3], ral[3]; for (int k = 0; k < 3; k++) { lal[k] = L[k].allocated + lreq[k]; ral[k] = Rr[k].allocated + rreq[k]; }
-        {   // prioritizeUnderQuotaWithJob :100-125
-            bool ls = true, rs = true;
-            for (int k = 0; k < 3; k++) { if (cmp_q(lal[k], L[k].deserved) > 0) ls = false; if (cmp_q(ral[k], Rr[k].deserved) > 0) rs = false; }
-            if (ls && !rs) return -1;
-            if (rs && !ls) return 1;
-        }
+    KAI_HD int queue_order(int lq, int rq) {
+        const QKey kl = queue_key(lq); const QKey kr = queue_key(rq);
+        { bool lo = kl.bits & 1, ro = kr.bits & 1; if (!lo && ro) return -1; if (lo && !ro) return 1; }
+        { bool ls = kl.bits & 2, rs = kr.bits & 2; if (ls && !rs) return -1; if (rs && !ls) return 1; }
         if (c.q_prio[lq] > c.q_prio[rq]) return -1;  // prioritizePrioritized :76-85
         if (c.q_prio[lq] < c.q_prio[rq]) return 1;
-        {   // penalizeZeroShareWithJob :127-176
-            bool lv = false, rv = false;
-            for (int k = 0; k < 3; k++) { if (qs_allocatable(L[k]) == 0 && lal[k] > 0) lv = true; if (qs_allocatable(Rr[k]) == 0 && ral[k] > 0) rv = true; }
-            if (lv && !rv) return 1;
-            if (!lv && rv) return -1;
-        }
-        { double l = dominant_share(lq, lreq), r = dominant_share(rq, rreq); if (l < r) return -1; if (l > r) return 1; }  // :178-196, 242-273
-        { double l = dominant_share(lq, nullptr), r = dominant_share(rq, nullptr); if (l < r) return -1; if (l > r) return 1; }  // :198-212
+        { bool lv = kl.bits & 4, rv = kr.bits & 4; if (lv && !rv) return 1; if (!lv && rv) return -1; }
+        if (kl.dom_with_job < kr.dom_with_job) return -1; if (kl.dom_with_job > kr.dom_with_job) return 1;
+        if (kl.dom_no_job < kr.dom_no_job) return -1; if (kl.dom_no_job > kr.dom_no_job) return 1;
         {   // prioritizeBasedOnAllocatableShare :214-224
+            const QShare* L = &c.q_share[(size_t)lq * 3]; const QShare* Rr = &c.q_share[(size_t)rq * 3];
             bool l_le = true, r_le = true;
             for (int k = 0; k < 3; k++) { int cmp = cmp_q(qs_allocatable(L[k]), qs_allocatable(Rr[k])); if (cmp > 0) l_le = false; if (cmp < 0) r_le = false; }
             if (!r_le && l_le) return -1;  // l.LessInAtLeastOne(r) == !r.LessEqual(l)
@@ -507,8 +620,8 @@ struct Engine {
         if (c.q_created[lq] < c.q_created[rq]) return -1;  // :235-240
         return 1;
     }
-    KAI_HD bool queue_order_fn(int lq, int rq, int lj, int rj) {  // framework/session_plugins.go:283-299
-        if (c.plugins & KAI_PLUGIN_PROPORTION) { int v = queue_order(lq, rq, lj, rj); if (v != 0) return v < 0; }
+    KAI_HD bool queue_order_fn(int lq, int rq) {  // framework/session_plugins.go:283-299
+        if (c.plugins & KAI_PLUGIN_PROPORTION) { int v = queue_order(lq, rq); if (v != 0) return v < 0; }
         if (c.q_created[lq] == c.q_created[rq]) return c.q_uid_rank[lq] < c.q_uid_rank[rq];
         return c.q_created[lq] < c.q_created[rq];
     }
@@ -545,21 +658,22 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ job-order tree (actions/utils/job_order_by_queue.go)
-    // Array heaps with container/heap's exact sift rules (scheduler_util/priority_queue.go).
+    // Leaf queues hold jobs under JobOrderFn, a strict total order (uid ranks are unique), so the pop sequence of the reference's
+    // binary heap is the sorted sequence: a leaf is a sorted region with a cursor (built by k_leaf_init) plus a small array heap
+    // for jobs that come back with a changed key (allocate.go:69-72).  Inner nodes order their children with the proportion
+    // comparator, which is not a total order in every corner, so they stay array heaps with container/heap's exact sift rules
+    // (scheduler_util/priority_queue.go) and the lazy needsReorder protocol.
     KAI_HD bool q_is_leaf(int q) const { return c.q_child_off[q + 1] == c.q_child_off[q]; }
-    KAI_HD bool node_children_empty(int q) const { return q_is_leaf(q) ? c.jheap_len[q] == 0 : c.qheap_len[q] == 0; }
-    KAI_HD int best_job_from_node(int q) const {  // getBestJobFromNode :309-318 (pending ordering)
-        for (;;) {
-            if (q_is_leaf(q)) return c.jheap_len[q] > 0 ? c.jheap[c.q_job_off[q]] : -1;
-            if (c.qheap_len[q] == 0) return -1;
-            q = c.qheap[c.q_child_off[q]];
-        }
+    KAI_HD int leaf_len(int q) const { return (c.lq_end[q] - c.lq_cur[q]) + c.lq_side_len[q]; }
+    KAI_HD int leaf_top(int q) const {
+        int a = c.lq_cur[q] < c.lq_end[q] ? c.lq_sorted[c.q_job_off[q] + c.lq_cur[q]] : -1;
+        int b = c.lq_side_len[q] > 0 ? c.lq_side[c.q_job_off[q]] : -1;
+        if (a < 0) return b;
+        if (b < 0) return a;
+        return job_order(b, a) ? b : a;
     }
-    KAI_HD bool node_less(int l, int r) {  // buildNodeOrderFn :280-305
-        if (node_children_empty(l)) return true;
-        if (node_children_empty(r)) return false;
-        return queue_order_fn(l, r, best_job_from_node(l), best_job_from_node(r));
-    }
+    struct JobLess { const Engine* e; KAI_HD bool operator()(int a, int b) const { return e->job_order(a, b); } };
+    struct NodeLess { Engine* e; KAI_HD bool operator()(int a, int b) const { return e->node_less(a, b); } };
     template <class Less> KAI_HD void heap_up(int32_t* h, int j, Less less) {
         for (;;) { int i = (j - 1) / 2; if (i == j || !less(h[j], h[i])) break; int t = h[i]; h[i] = h[j]; h[j] = t; j = i; }
     }
@@ -574,14 +688,30 @@ struct Engine {
         }
         return i > i0;
     }
-    struct JobLess { Engine* e; KAI_HD bool operator()(int a, int b) const { return e->job_order(a, b); } };
-    struct NodeLess { Engine* e; KAI_HD bool operator()(int a, int b) const { return e->node_less(a, b); } };
-
+    KAI_HD int leaf_pop(int q) {
+        int a = c.lq_cur[q] < c.lq_end[q] ? c.lq_sorted[c.q_job_off[q] + c.lq_cur[q]] : -1;
+        int b = c.lq_side_len[q] > 0 ? c.lq_side[c.q_job_off[q]] : -1;
+        if (b < 0 || (a >= 0 && !job_order(b, a))) { c.lq_cur[q]++; return a; }
+        int32_t* h = c.lq_side + c.q_job_off[q]; int n = c.lq_side_len[q] - 1;
+        int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); c.lq_side_len[q] = n;
+        return b;
+    }
+    KAI_HD void leaf_push(int q, int j) {
+        int32_t* h = c.lq_side + c.q_job_off[q]; int n = c.lq_side_len[q];
+        if (n >= c.q_job_off[q + 1] - c.q_job_off[q]) { fault(FAULT_HEAP); return; }
+        h[n] = j; c.lq_side_len[q] = n + 1; heap_up(h, n, JobLess{this});
+    }
+    KAI_HD bool node_children_empty(int q) const { return q_is_leaf(q) ? leaf_len(q) == 0 : c.qheap_len[q] == 0; }
+    KAI_HD bool node_less(int l, int r) {  // buildNodeOrderFn :280-305
+        if (node_children_empty(l)) return true;
+        if (node_children_empty(r)) return false;
+        return queue_order_fn(l, r);
+    }
     KAI_HD int32_t* node_heap(int parent) { return parent < 0 ? c.root_heap : c.qheap + c.q_child_off[parent]; }
     KAI_HD int32_t& node_heap_len(int parent) { return parent < 0 ? c.st->root_len : c.qheap_len[parent]; }
-    KAI_HD void node_heap_push(int parent, int q) { int32_t* h = node_heap(parent); int32_t& n = node_heap_len(parent); h[n++] = q; heap_up(h, n - 1, NodeLess{this}); }
-    KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int32_t& n = node_heap_len(parent); n--; int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); }
-    KAI_HD void node_heap_fix0(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); if (!heap_down(h, 0, n, NodeLess{this})) heap_up(h, 0, NodeLess{this}); }
+    KAI_HD void node_heap_push(int parent, int q) { int32_t* h = node_heap(parent); int32_t& n = node_heap_len(parent); h[n++] = q; heap_up(h, n - 1, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
+    KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int32_t& n = node_heap_len(parent); n--; int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
+    KAI_HD void node_heap_fix0(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); if (!heap_down(h, 0, n, NodeLess{this})) heap_up(h, 0, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
 
     KAI_HD void ensure_ancestor_chain(int child) {  // :134-176
         for (;;) {
@@ -598,10 +728,9 @@ struct Engine {
         int q = c.j_queue[j];
         if (!q_is_leaf(q)) return;
         bool needs_linking = !c.qn_exists[q];
-        if (needs_linking) { c.qn_exists[q] = 1; c.qn_reorder[q] = 0; c.qn_linked[q] = 0; c.jheap_len[q] = 0; }
-        int32_t* h = c.jheap + c.q_job_off[q]; int n = c.jheap_len[q];
-        if (n >= c.q_job_off[q + 1] - c.q_job_off[q]) { fault(FAULT_HEAP); return; }
-        h[n] = j; c.jheap_len[q] = n + 1; heap_up(h, n, JobLess{this});
+        if (needs_linking) { c.qn_exists[q] = 1; c.qn_reorder[q] = 0; c.qn_linked[q] = 0; }
+        leaf_push(q, j);
+        invalidate_path(q);
         if (needs_linking) ensure_ancestor_chain(q);
         for (int x = q; x >= 0; x = c.q_parent[x]) c.qn_reorder[x] = 1;  // markAncestorsForReorder: parent pointers follow the queue tree
     }
@@ -616,7 +745,7 @@ struct Engine {
     }
     KAI_HD void handle_pop_from_node(int q) {  // :221-245
         for (;;) {
-            int len = q_is_leaf(q) ? c.jheap_len[q] : c.qheap_len[q];
+            int len = q_is_leaf(q) ? leaf_len(q) : c.qheap_len[q];
             if (len != 0) { for (int x = q; x >= 0; x = c.q_parent[x]) c.qn_reorder[x] = 1; return; }
             int parent = c.q_parent[q];
             node_heap_pop(parent);  // removeNodeFromParent: the node is at the top of its parent's heap
@@ -629,26 +758,50 @@ struct Engine {
         if (!c.st->root_init || c.st->root_len == 0) return -1;
         int parent = -1, q;
         for (;;) { q = next_node(parent); if (q < 0) return -1; if (q_is_leaf(q)) break; parent = q; }  // traverseToLeaf :179-191
-        int32_t* h = c.jheap + c.q_job_off[q]; int n = c.jheap_len[q] - 1;
-        int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); c.jheap_len[q] = n;
-        int job = h[n];
+        int job = leaf_pop(q);
+        invalidate_path(q);
         handle_pop_from_node(q);
         return job;
     }
-    KAI_HD bool job_ready(int j) const {  // job_info.go:399-406, podset.go:114-120
-        for (int k = 0; k < c.j_n_ps[j]; k++) { int s = c.j_first_ps[j] + k; if (c.s_alive[s] - c.s_gated[s] < c.s_min[s]) return false; }
-        return true;
-    }
-    KAI_HD void init_jobs_order() {  // InitializeWithJobs (actions/utils/input_jobs.go:21-68) with the allocate filters
-        c.st->root_len = 0; c.st->root_init = 0;
-        for (int q = 0; q < c.Q; q++) { c.qn_exists[q] = 0; c.qn_reorder[q] = 0; c.qn_linked[q] = 0; c.jheap_len[q] = 0; c.qheap_len[q] = 0; }
-        for (int j = 0; j < c.J; j++) {
-            if (!job_ready(j)) continue;               // FilterUnready
-            if (c.j_n_pending[j] == 0) continue;       // FilterNonPending
-            int q = c.j_queue[j];
-            if (q < 0 || !q_is_leaf(q)) continue;
-            push_job(j);
+    // InitializeWithJobs (actions/utils/input_jobs.go:21-68) in the canonical best-first order (see the oracle and DESIGN.md):
+    // the leaves were filled by k_job_init / k_leaf_init; here every inner node links its best child first, then the others
+    // in index order, deepest nodes first, so every node enters its parent's heap with its final key.
+    KAI_HD void link_children(int x) {  // x = queue index, or Q for the virtual root
+        int parent = x == c.Q ? -1 : x;
+        int b0 = c.q_child_off[x], b1 = c.q_child_off[x + 1], best = -1, live = 0;
+        for (int i = b0; i < b1; i++) {
+            int k = c.q_children[i];
+            bool alive = q_is_leaf(k) ? leaf_len(k) > 0 : c.qheap_len[k] > 0;
+            if (!alive) continue;
+            live++;
+            if (best < 0 || node_less(k, best)) best = k;
         }
+        if (!live) return;
+        if (parent >= 0) { c.qn_exists[parent] = 1; c.qn_reorder[parent] = 1; } else c.st->root_init = 1;
+        c.qn_exists[best] = 1; c.qn_linked[best] = 1; c.qn_reorder[best] = 1; node_heap_push(parent, best);
+        for (int i = b0; i < b1; i++) {
+            int k = c.q_children[i]; if (k == best) continue;
+            bool alive = q_is_leaf(k) ? leaf_len(k) > 0 : c.qheap_len[k] > 0;
+            if (!alive) continue;
+            c.qn_exists[k] = 1; c.qn_linked[k] = 1; c.qn_reorder[k] = 1; node_heap_push(parent, k);
+        }
+    }
+    KAI_HD void truncate_leaf(int q, int depth) {  // PriorityQueue.Push with a finite maxQueueSize under sorted pushes keeps the best `depth` jobs
+        while (leaf_len(q) > depth) {
+            int a = c.lq_cur[q] < c.lq_end[q] ? c.lq_sorted[c.q_job_off[q] + c.lq_end[q] - 1] : -1;
+            int32_t* h = c.lq_side + c.q_job_off[q]; int n = c.lq_side_len[q], wi = -1;
+            for (int i = 0; i < n; i++) if (wi < 0 || job_order(h[wi], h[i])) wi = i;
+            if (wi < 0 || (a >= 0 && job_order(h[wi], a))) { c.lq_end[q]--; continue; }
+            h[wi] = h[n - 1]; c.lq_side_len[q] = n - 1;
+            for (int i = (n - 1) / 2; i >= 0; i--) heap_down(h, i, n - 1, JobLess{this});
+        }
+    }
+    KAI_HD void init_jobs_order() {
+        c.st->root_len = 0; c.st->root_init = 0;
+        for (int q = 0; q < c.Q; q++) { c.qn_exists[q] = 0; c.qn_reorder[q] = 0; c.qn_linked[q] = 0; c.qheap_len[q] = 0; c.qk_valid[q] = 0; }
+        if (c.queue_depth > 0) for (int q = 0; q < c.Q; q++) if (q_is_leaf(q)) truncate_leaf(q, c.queue_depth);
+        for (int i = 0; i < c.Q; i++) { int x = c.q_depth_order[i]; if (!q_is_leaf(x)) link_children(x); }
+        link_children(c.Q);
     }
 
     // ------------------------------------------------------------------ actions/common/allocate.go
@@ -658,17 +811,33 @@ struct Engine {
         for (int r = 0; r < KAI_MAX_RES; r++) q.req[r] = r < c.R ? preq(p, r) : 0.0;
         q.min_a = 0; q.max_a = 0;
     }
+    // OrderedNodesByTask + FittingNode for one task (framework/session.go:201-264): the first fitting node in score order, or -1
+    KAI_HD int find_node(int p, bool& allocatable) {
+        int k = c.use_index ? c.p_scls[p] : -1;
+        if (k >= 0) {
+            const ClassRec& cr = c.cls[k];
+            int n = -1; uint64_t key = 0;
+            int nom = (c.plugins & KAI_PLUGIN_NOMINATEDNODE) ? c.p_nominated[p] : -1;
+            if (nom >= 0) { key = class_key(c, cr, nom); if (key) n = nom; }  // +1e6 outranks every other sum (plugins/nominatednode/nominatednode.go:29-41)
+            if (n < 0) { flush_index(); be.class_top(c, k, key, n); c.st->index_queries++; if (!key) n = -1; }
+            if (n >= 0) allocatable = (c.plugins & KAI_PLUGIN_NODEAVAILABILITY) ? (key >> 63) != 0 : (cr.best_effort || fits(c, cr.req, n, false));
+            return n;
+        }
+        ScanReq q; fill_req(q, p);
+        if ((c.plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) be.minmax(c, q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
+        int n = be.best_node(c, q);
+        c.st->node_scans++; c.st->nodes_scanned += c.N;
+        if (n >= 0) allocatable = q.best_effort || fits(c, q.req, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
+        return n;
+    }
     KAI_HD bool allocate_task(int p, bool pipeline_only) {  // :121-163
         c.st->decisions++;
-        ScanReq q; fill_req(q, p);
         // predicates step 1 is node independent on this path (capacity_policy.go:51-61): evaluate it once
         if ((c.plugins & KAI_PLUGIN_PREDICATES) && task_over_capacity(p)) return false;
-        if ((c.plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) sc.minmax(c, q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
-        int n = sc.best_node(c, q);
-        c.st->node_scans++; c.st->nodes_scanned += c.N;
-        if (n < 0) return false;
+        bool allocatable = false;
+        int n = find_node(p, allocatable);
+        if (n < 0) { fail_no_node = true; return false; }
         // allocateTaskToNode :165-174
-        bool allocatable = q.best_effort || fits(c, q, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
         if (!pipeline_only && allocatable) return stmt_allocate(p, n);
         return stmt_pipeline(p, n, !pipeline_only);
     }
@@ -696,14 +865,30 @@ struct Engine {
         }
         return true;
     }
+    // What the allocate loop does with a job once no class has a fitting node (used by k_drain and the host twin): the job is
+    // attempted, passes or fails the queue-capacity gate, and its first task finds no node.  Touches only job j's own cache.
+    KAI_HD void drain_job(int j, int64_t& attempted, int64_t& decisions, int64_t& rollbacks) {
+        attempted++;
+        ensure_tta(j, true);
+        if (job_over_queue_capacity(j)) return;
+        if (c.j_tta_n[j] == 0) return;
+        decisions++; rollbacks += 2;
+    }
     KAI_HD void execute_allocate() {  // actions/allocate/allocate.go:46-77
+        int64_t t0 = be.clock(), t;
+        be.begin(c);
         init_jobs_order();
+        t = be.clock(); c.st->prof[5] += t - t0;
         for (;;) {
-            if (c.st->fault) return;
+            if (c.st->fault) break;
+            int64_t ta = be.clock();
             int j = pop_next_job(); if (j < 0) break;
-            c.st->ops_len = 0;
+            int64_t tb = be.clock(); c.st->prof[0] += tb - ta;
+            c.st->ops_len = 0; c.st->n_undo = 0;
             c.st->jobs_attempted++;
+            fail_no_node = false;
             bool ok = allocate_job(j, false);
+            int64_t tc = be.clock(); c.st->prof[2] += tc - tb;
             if (ok) {  // attemptToAllocateJob :79-111 — ShouldPipelineJob (job_info.go:443-464)
                 bool should_pipeline = false;
                 for (int k = 0; k < c.j_n_ps[j]; k++) { int s = c.j_first_ps[j] + k; if (c.s_pipelined[s] > 0 && (c.s_active_alloc[s] - c.s_pipelined[s]) < c.s_min[s]) should_pipeline = true; }
@@ -716,7 +901,14 @@ struct Engine {
             } else {
                 discard();
             }
+            int64_t td = be.clock(); c.st->prof[3] += td - tc;
+            if (!ok && fail_no_node && c.use_index && c.all_tracked) {  // nothing fits any class any more: the rest of the queue fails job by job
+                flush_index();
+                if (be.all_dead(c)) { c.st->drain_pending = 1; break; }
+            }
+            c.st->prof[4] += be.clock() - td;
         }
+        c.st->prof[7] += be.clock() - t0;
     }
 };
 
@@ -821,6 +1013,26 @@ KAI_HD void divide_sibling_set(const KaiCtx& c, const int32_t* kids, int nk, int
             c.q_share[(size_t)best * 3 + k].fair += give; remaining -= give;
         }
     }
+}
+
+// ======================================================================================================
+// action init, per job and per leaf queue (run by k_job_init / k_leaf_init on the whole chip; host_sim runs them serially)
+// ======================================================================================================
+// InitializeWithJobs filters for the allocate action (actions/utils/input_jobs.go:24-63) + the job's elastic state:
+// 0/1/2 = eligible with minAvailableState below/exactly/above, 3 = filtered out
+KAI_HD uint8_t job_init_state(const KaiCtx& c, int j) {
+    int q = c.j_queue[j];
+    if (q < 0 || c.q_child_off[q + 1] != c.q_child_off[q]) return 3;  // queue missing or not a leaf
+    if (c.j_n_pending[j] == 0) return 3;                               // FilterNonPending
+    bool exactly = true, below = false;
+    for (int k = 0; k < c.j_n_ps[j]; k++) {
+        int s = c.j_first_ps[j] + k;
+        if (c.s_alive[s] - c.s_gated[s] < c.s_min[s]) return 3;       // FilterUnready (job_info.go:399-406, podset.go:114-120)
+        int n = c.s_active_alloc[s], m = c.s_min[s];
+        if (n < m) below = true; else if (n > m) exactly = false;
+    }
+    if (!(c.plugins & KAI_PLUGIN_ELASTIC)) return 0;                   // without the elastic plugin the state does not enter JobOrderFn
+    return below ? 0 : exactly ? 1 : 2;
 }
 
 }  // namespace kai

@@ -1,11 +1,15 @@
 // kai_host_prep.hpp — index structures derived from a kai_snapshot_soa on the host.
 //
-// Pure re-orderings of the input (no scheduling arithmetic): each job's pods in TaskOrderFn order, the queue
-// tree as CSR with a virtual root, per-queue job lists, queues by depth, fair-share levels, and the
-// proportion plugin's per-queue quota records.  Shared by kai_core.hip (uploads them to HBM) and by
-// tests/host_sim (which debugs the engine's control flow without a GPU).
+// Pure re-orderings / groupings of the input (no scheduling arithmetic): nodes permuted into name-rank order, each job's
+// pods in TaskOrderFn order, the queue tree as CSR with a virtual root, each queue's jobs in their static order, queues by
+// depth, fair-share levels, the proportion plugin's per-queue quota records, and the scan classes (pods grouped by request
+// vector + predicate class) with the guards that admit a class to the device's class index.
+// Shared by kai_core.hip (uploads them to HBM) and by tests/host_sim (which debugs the engine's control flow without a GPU).
 #pragma once
 #include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -14,14 +18,35 @@
 namespace kai {
 
 struct HostPrep {
-    std::vector<int32_t> sorted, child_off, children, depth, job_off, jobs_by_queue, depth_order, lvl_off, lvl_parents;
+    std::vector<int32_t> sorted, child_off, children, depth, job_off, jobs_static, slot_queue, depth_order, lvl_off, lvl_parents;
     std::vector<QShare> shares;
     int n_levels = 0;
+    // nodes in name-rank order: perm[i] = caller's index of the node with rank i
+    std::vector<int32_t> perm, node_gpu_count, node_class, pod_node, pod_nominated;
+    std::vector<double> node_alloc; std::vector<uint32_t> node_flags;
+    // scan classes
+    std::vector<ClassRec> classes; std::vector<int32_t> pod_scls; int all_tracked = 1;
 
     // returns 0 or KAI_ERR_INVALID_ARG with err set
     int build(const kai_config& cfg, const kai_snapshot_soa* s, std::string& err) {
-        const int P = s->n_pods, J = s->n_jobs, Q = s->n_queues;
+        const int N = s->n_nodes, P = s->n_pods, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
         auto fail = [&](const char* m) { err = m; return (int)KAI_ERR_INVALID_ARG; };
+        // ---- nodes: permute into name-rank order (framework/session.go:480-485 breaks score ties by node name)
+        perm.assign(N, -1);
+        for (int i = 0; i < N; i++) { uint32_t rk = s->node_name_rank[i]; if (rk >= (uint32_t)N || perm[rk] >= 0) return fail("node_name_rank must be a permutation of 0..N-1"); perm[rk] = i; }
+        node_alloc.resize((size_t)R * N); node_flags.resize(N); node_gpu_count.resize(N); node_class.resize(N);
+        for (int i = 0; i < N; i++) {
+            int o = perm[i];
+            for (int r = 0; r < R; r++) node_alloc[(size_t)r * N + i] = s->node_allocatable[(size_t)r * N + o];
+            node_flags[i] = s->node_flags[o]; node_gpu_count[i] = s->node_gpu_count ? s->node_gpu_count[o] : -1; node_class[i] = s->node_class ? s->node_class[o] : 0;
+            if (node_class[i] < 0 || node_class[i] >= std::max(1, s->n_node_classes)) return fail("node_class out of range");
+        }
+        pod_node.resize(P); pod_nominated.resize(P);
+        for (int p = 0; p < P; p++) {
+            int n = s->pod_node[p]; pod_node[p] = (n >= 0 && n < N) ? (int32_t)s->node_name_rank[n] : -1;
+            int m = s->pod_nominated_node ? s->pod_nominated_node[p] : -1; pod_nominated[p] = (m >= 0 && m < N) ? (int32_t)s->node_name_rank[m] : -1;
+            int pc = s->pod_class ? s->pod_class[p] : 0; if (pc < 0 || pc >= std::max(1, s->n_pod_classes)) return fail("pod_class out of range");
+        }
         // each job's pods in TaskOrderFn order (framework/session_plugins.go:244-260 + plugins/taskorder/task_order.go:28-63)
         sorted.resize(P);
         for (int p = 0; p < P; p++) sorted[p] = p;
@@ -29,7 +54,7 @@ struct HostPrep {
         for (int j = 0; j < J; j++) {
             int b = s->job_first_pod[j], n = s->job_n_pods[j];
             if (b < 0 || n < 0 || b + n > P) return fail("job pod range out of bounds");
-            std::sort(sorted.begin() + b, sorted.begin() + b + n, [&](int l, int r) {
+            if (n > 1) std::sort(sorted.begin() + b, sorted.begin() + b + n, [&](int l, int r) {
                 if (taskorder) {
                     bool ll = s->pod_flags && (s->pod_flags[l] & KAI_POD_HAS_TASK_PRIORITY), rl = s->pod_flags && (s->pod_flags[r] & KAI_POD_HAS_TASK_PRIORITY);
                     if (ll != rl) return ll;
@@ -46,11 +71,21 @@ struct HostPrep {
         for (int i = 0; i < Q + 1; i++) child_off[i + 1] += child_off[i];
         { std::vector<int32_t> fill(child_off.begin(), child_off.end() - 1); for (int q = 0; q < Q; q++) { int par = s->queue_parent[q]; children[fill[par < 0 ? Q : par]++] = q; } }
         for (int q = 0; q < Q; q++) { int d = 0; for (int x = s->queue_parent[q]; x >= 0; x = s->queue_parent[x]) { if (++d > Q) return fail("queue cycle"); } depth[q] = d; }
-        // per-queue job lists (leaf job heaps live in these regions)
-        job_off.assign(Q + 1, 0); jobs_by_queue.assign(std::max(J, 1), 0);
+        // per-queue job lists in the static part of JobOrderFn (session_plugins.go:227-242): priority desc, creation, uid.
+        // The elastic state, the only dynamic operand, is applied on the device (k_leaf_init).
+        job_off.assign(Q + 1, 0); jobs_static.assign(std::max(J, 1), 0); slot_queue.assign(std::max(J, 1), -1);
         for (int j = 0; j < J; j++) { int q = s->job_queue[j]; if (q >= Q) return fail("bad job_queue"); if (q >= 0) job_off[q + 1]++; }
         for (int q = 0; q < Q; q++) job_off[q + 1] += job_off[q];
-        { std::vector<int32_t> fill(job_off.begin(), job_off.end() - 1); for (int j = 0; j < J; j++) { int q = s->job_queue[j]; if (q >= 0) jobs_by_queue[fill[q]++] = j; } }
+        { std::vector<int32_t> fill(job_off.begin(), job_off.end() - 1); for (int j = 0; j < J; j++) { int q = s->job_queue[j]; if (q >= 0) jobs_static[fill[q]++] = j; } }
+        const bool use_prio = cfg.plugins & KAI_PLUGIN_PRIORITY;
+        for (int q = 0; q < Q; q++) {
+            std::sort(jobs_static.begin() + job_off[q], jobs_static.begin() + job_off[q + 1], [&](int l, int r) {
+                if (use_prio && s->job_priority[l] != s->job_priority[r]) return s->job_priority[l] > s->job_priority[r];
+                if (s->job_created_ns[l] != s->job_created_ns[r]) return s->job_created_ns[l] < s->job_created_ns[r];
+                return s->job_uid_rank[l] < s->job_uid_rank[r];
+            });
+            for (int i = job_off[q]; i < job_off[q + 1]; i++) slot_queue[i] = q;
+        }
         depth_order.resize(Q);
         for (int q = 0; q < Q; q++) depth_order[q] = q;
         std::stable_sort(depth_order.begin(), depth_order.end(), [&](int a, int b) { return depth[a] > depth[b]; });
@@ -71,7 +106,71 @@ struct HostPrep {
             if (k == KAI_Q_MEM) { des = std::max(KAI_UNLIMITED, des * 1000000.0); lim = std::max(KAI_UNLIMITED, lim * 1000000.0); }
             x.deserved = des; x.max_allowed = lim; x.oqw = s->queue_oqw[(size_t)k * Q + q]; x.usage = s->queue_usage ? s->queue_usage[(size_t)k * Q + q] : 0.0;
         }
+        build_classes(cfg, s);
         return 0;
+    }
+
+    // Scan classes: pods with the same request vector and static-predicate class see every node identically, so the device
+    // keeps one arg-max index per class (kai_engine.hpp class_key).  A class is admitted only when its key order provably equals
+    // the reference's f64 score order:
+    //   bin-pack on resource r: every node quantity and every pod request of r is an integer <= 2^30 (then distinct
+    //     Idle+Releasing values give pack scores at least 9·2^-30 apart, far above the rounding of the score sum), and for the
+    //     CPU resource every node has Allocatable > 0 (a zero-capacity node scores 0, not by its free amount);
+    //   spread on r: the divisor (gpu.count label or Allocatable) is an integer in [Allocatable, 2^22] so the ratio stays in [0,1]
+    //     and distinct ratios stay distinct after the sum.
+    // The KAI_CMAX most frequent admissible classes among pending pods are indexed; other pods use the brute-force scan.
+    void build_classes(const kai_config& cfg, const kai_snapshot_soa* s) {
+        const int N = s->n_nodes, P = s->n_pods, R = s->n_res;
+        pod_scls.assign(P, -1); classes.clear(); all_tracked = 1;
+        auto integral = [](double v, double lim) { return v >= 0 && v <= lim && v == std::floor(v); };
+        bool ok_res[2] = {true, true};  // [0] = CPU, [1] = GPU as placement resource
+        const int rr[2] = {KAI_RES_CPU, KAI_RES_GPU};
+        for (int t = 0; t < 2; t++) {
+            int r = rr[t]; int strat = t == 0 ? cfg.cpu_strategy : cfg.gpu_strategy;
+            for (int n = 0; n < N && ok_res[t]; n++) {
+                double a = s->node_allocatable[(size_t)r * N + n];
+                if (strat == KAI_SPREAD) {
+                    double cnt = a;
+                    if (r == KAI_RES_GPU && s->node_gpu_count && s->node_gpu_count[n] >= 0) cnt = (double)s->node_gpu_count[n]; else if (r == KAI_RES_GPU) cnt = (double)(int64_t)a;
+                    if (!integral(a, 4194304.0) || !(cnt >= a) || cnt > 4194304.0) ok_res[t] = false;
+                } else {
+                    if (!integral(a, 1073741824.0)) ok_res[t] = false;
+                    if (r == KAI_RES_CPU && a == 0) ok_res[t] = false;
+                }
+            }
+            for (int p = 0; p < P && ok_res[t]; p++) if (!integral(s->pod_req[(size_t)r * P + p], 1073741824.0)) ok_res[t] = false;
+        }
+        if (cfg.engine_mode == 1) { all_tracked = 0; return; }
+        struct Key { double req[KAI_MAX_RES]; int32_t pc; bool operator<(const Key& o) const { int c = std::memcmp(req, o.req, sizeof req); return c ? c < 0 : pc < o.pc; } };
+        std::map<Key, int> ids; std::vector<Key> keys; std::vector<int64_t> freq; std::vector<int32_t> pod_cls(P, -1);
+        for (int p = 0; p < P; p++) {
+            Key k; std::memset(&k, 0, sizeof k);
+            for (int r = 0; r < R; r++) { double v = s->pod_req[(size_t)r * P + p]; k.req[r] = v == 0 ? 0.0 : v; }  // fold -0.0
+            k.pc = s->pod_class ? s->pod_class[p] : 0;
+            auto it = ids.find(k);
+            int id; if (it == ids.end()) { id = (int)keys.size(); ids[k] = id; keys.push_back(k); freq.push_back(0); } else id = it->second;
+            pod_cls[p] = id;
+            if (s->pod_status[p] == KAI_POD_PENDING) freq[id]++;
+        }
+        std::vector<int> order(keys.size()); for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return freq[a] > freq[b]; });
+        std::vector<int> remap(keys.size(), -1);
+        for (int id : order) {
+            const Key& k = keys[id];
+            bool cpu_only = !(k.req[KAI_RES_GPU] > 0);
+            bool admissible = !(cfg.plugins & KAI_PLUGIN_NODEPLACEMENT) || ok_res[cpu_only ? 0 : 1];
+            if (!admissible || (int)classes.size() >= KAI_CMAX) { if (freq[id] > 0) all_tracked = 0; continue; }
+            ClassRec cr; std::memset(&cr, 0, sizeof cr);
+            for (int r = 0; r < KAI_MAX_RES; r++) cr.req[r] = k.req[r];
+            cr.pod_class = k.pc; cr.cpu_only = cpu_only;
+            bool be = !(k.req[KAI_RES_GPU] > 0.01) && !(k.req[KAI_RES_CPU] >= 10.0 || k.req[KAI_RES_MEM] >= 10.0 * 1024 * 1024);
+            for (int r = KAI_RES_PODS; r < R; r++) if (k.req[r] >= 10.0) be = false;
+            cr.best_effort = be; cr.r_place = cpu_only ? KAI_RES_CPU : KAI_RES_GPU; cr.strategy = cpu_only ? cfg.cpu_strategy : cfg.gpu_strategy;
+            remap[id] = (int)classes.size(); classes.push_back(cr);
+        }
+        for (int p = 0; p < P; p++) pod_scls[p] = remap[pod_cls[p]];
+        int NB = (N + KAI_BLOCK - 1) / KAI_BLOCK, NSB = (NB + 63) / 64;
+        if (NSB > KAI_NSB_MAX) { classes.clear(); std::fill(pod_scls.begin(), pod_scls.end(), -1); all_tracked = 0; }  // beyond the LDS level: brute force
     }
 };
 

@@ -1,12 +1,15 @@
 // kai_kernels.hpp — gfx950 kernels of the scheduling-cycle core (included by kai_core.hip only).
 //
 //  * session-open kernels: node accounting from the pods, proportion totals, queue usage roll-up
-//    (segmented reductions pods → job → leaf queue → ancestors), fair-share division per tree level;
-//  * the persistent action kernel: wave 0 / lane 0 drives kai::Engine, the other wavefronts of the
-//    workgroup serve its node scans out of the HBM-resident node SoA (resource-major, so a wavefront reads
-//    64 consecutive nodes of one resource = one 512-byte coalesced request).
+//    (segmented reductions pods → job → leaf queue → ancestors), fair-share division per tree level,
+//    and the class-index build (one wavefront per 64-node block, every scan class);
+//  * action-init kernels: per-job eligibility / elastic state, per-leaf-queue stable compaction into job order;
+//  * the persistent action kernel: wave 0 / lane 0 drives kai::Engine, the other 15 wavefronts of the workgroup
+//    keep the class index current (block refresh) and serve brute-force node scans out of the HBM-resident
+//    node SoA (resource-major, so a wavefront reads 64 consecutive nodes of one resource = one 512-byte request);
+//  * the drain kernel: once no class has a fitting node, the jobs still queued are resolved chip-wide.
 //
-// wave = 64 lanes; workgroup = 1024 threads = 16 wavefronts (1 control + 15 scan waves).
+// wave = 64 lanes; workgroup = 1024 threads = 16 wavefronts (1 control + 15 service waves).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -17,6 +20,7 @@ namespace kai {
 constexpr int WG = 1024;        // threads per workgroup of the action kernel
 constexpr int WAVES = WG / 64;  // 16
 constexpr int SCAN_LANES = WG - 64;
+constexpr int SVC = WAVES - 1;  // service waves
 
 // ------------------------------------------------------------------------------------------------------
 // session open
@@ -103,24 +107,25 @@ __global__ void k_job_usage(KaiCtx c, double* jsum) {
         jsum[(size_t)(0 + k) * c.J + j] = al[k]; jsum[(size_t)(3 + k) * c.J + j] = np ? al[k] : 0.0; jsum[(size_t)(6 + k) * c.J + j] = rq[k];
     }
 }
-// one wavefront per leaf queue: segmented reduction over the queue's jobs (jobs_by_queue is CSR by q_job_off)
-__global__ void k_leaf_usage(KaiCtx c, const double* jsum, const int32_t* jobs_by_queue) {
+// one wavefront per leaf queue: segmented reduction over the queue's jobs (jobs_static is CSR by q_job_off; the sum order is
+// fixed by the lane stride, and the addends are integer-valued, so the result does not depend on it)
+__global__ void k_leaf_usage(KaiCtx c, const double* jsum) {
     int q = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (q >= c.Q) return;
     int lane = threadIdx.x & 63, b = c.q_job_off[q], e = c.q_job_off[q + 1];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = b + lane; i < e; i += 64) { int j = jobs_by_queue[i]; for (int x = 0; x < 9; x++) acc[x] += jsum[(size_t)x * c.J + j]; }
+    for (int i = b + lane; i < e; i += 64) { int j = c.jobs_static[i]; for (int x = 0; x < 9; x++) acc[x] += jsum[(size_t)x * c.J + j]; }
     for (int x = 0; x < 9; x++) acc[x] = wave_sum(acc[x]);
     if (lane == 0) for (int k = 0; k < 3; k++) {
         QShare& s = c.q_share[(size_t)q * 3 + k];
         s.allocated = acc[k]; s.allocated_np = acc[3 + k]; s.request = acc[6 + k]; s.fair = 0;
     }
 }
-// ancestors: queues in decreasing depth push their sums to the parent (depth_order from the host; Q is small)
-__global__ void k_tree_usage(KaiCtx c, const int32_t* depth_order) {
+// ancestors: queues in decreasing depth push their sums to the parent (Q is small)
+__global__ void k_tree_usage(KaiCtx c) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     for (int i = 0; i < c.Q; i++) {
-        int q = depth_order[i], par = c.q_parent[q]; if (par < 0) continue;
+        int q = c.q_depth_order[i], par = c.q_parent[q]; if (par < 0) continue;
         for (int k = 0; k < 3; k++) {
             QShare& s = c.q_share[(size_t)q * 3 + k]; QShare& d = c.q_share[(size_t)par * 3 + k];
             d.allocated += s.allocated; d.allocated_np += s.allocated_np; d.request += s.request;
@@ -146,17 +151,84 @@ __global__ void k_fair_share(KaiCtx c, const int32_t* lvl_off, const int32_t* lv
 }
 
 // ------------------------------------------------------------------------------------------------------
-// the cooperative node scan of the action kernel
+// class index
 // ------------------------------------------------------------------------------------------------------
-enum ScanCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3 };
+__device__ __forceinline__ void wave_argmax(uint64_t& k, int& n) {
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t ok = __shfl_xor((unsigned long long)k, o, 64); int on = __shfl_xor(n, o, 64);
+        if (key_better(ok, on, k, n)) { k = ok; n = on; }
+    }
+}
+// L1 of the class index: one wavefront per 64-node block, every class (node state is read once per class from L1/L2)
+__global__ void k_index_build(KaiCtx c) {
+    int b = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (b >= c.NB) return;
+    int lane = threadIdx.x & 63, n = b * KAI_BLOCK + lane;
+    for (int k = 0; k < c.C; k++) {
+        uint64_t key = n < c.N ? class_key(c, c.cls[k], n) : 0; int bn = n;
+        wave_argmax(key, bn);
+        if (lane == 0) { c.sum1_key[(size_t)k * c.NB + b] = key; c.sum1_node[(size_t)k * c.NB + b] = bn; }
+    }
+}
 
-struct ScanShared {
+// ------------------------------------------------------------------------------------------------------
+// action init
+// ------------------------------------------------------------------------------------------------------
+struct NullBackend {  // kernels that only need the engine's pure helpers
+    __device__ void minmax(const KaiCtx&, int, double&, double&) {}
+    __device__ int best_node(const KaiCtx&, const ScanReq&) { return -1; }
+    __device__ void begin(const KaiCtx&) {}
+    __device__ void refresh(const KaiCtx&, const int32_t*, int) {}
+    __device__ void class_top(const KaiCtx&, int, uint64_t& k, int& n) { k = 0; n = -1; }
+    __device__ bool all_dead(const KaiCtx&) { return false; }
+    __device__ int64_t clock() { return 0; }
+};
+
+__global__ void k_job_init(KaiCtx c) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < c.J) c.j_state[j] = job_init_state(c, j);
+}
+// One wavefront per leaf queue: stable compaction of the eligible "below minAvailable" jobs (host order: priority desc,
+// creation, uid) into the leaf's sorted region; the few jobs in another elastic state go to the leaf's side heap.
+__global__ void k_leaf_init(KaiCtx c) {
+    int q = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (q >= c.Q) return;
+    int lane = threadIdx.x & 63, b = c.q_job_off[q], e = c.q_job_off[q + 1];
+    int cnt = 0, side = 0;
+    const unsigned long long lt = (1ull << lane) - 1;
+    for (int base = b; base < e; base += 64) {
+        int i = base + lane, j = i < e ? c.jobs_static[i] : -1;
+        int st = j >= 0 ? c.j_state[j] : 3;
+        unsigned long long m0 = __ballot(st == 0), m12 = __ballot(st == 1 || st == 2);
+        if (st == 0) c.lq_sorted[b + cnt + __popcll(m0 & lt)] = j;
+        if (st == 1 || st == 2) c.lq_side[b + side + __popcll(m12 & lt)] = j;
+        cnt += __popcll(m0); side += __popcll(m12);
+    }
+    __threadfence_block();
+    if (lane == 0) {
+        c.lq_cur[q] = 0; c.lq_end[q] = cnt; c.lq_side_len[q] = 0;
+        if (side) {
+            NullBackend nb; Engine<NullBackend> eng(c, nb);
+            int32_t* h = c.lq_side + b;
+            for (int i = 0; i < side; i++) { c.lq_side_len[q] = i + 1; eng.heap_up(h, i, typename Engine<NullBackend>::JobLess{&eng}); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// the persistent action kernel
+// ------------------------------------------------------------------------------------------------------
+enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5 };
+
+struct ActShared {
     ScanReq req;
-    int32_t cmd, r, pad0, pad1;
+    int32_t cmd, r, n_dirty, pad0;
+    int32_t dirty[KAI_MAXD];
     double part_min[WAVES], part_max[WAVES];
     unsigned long long part_key[WAVES];  // orderable score bits
-    uint32_t part_rank[WAVES];
     int32_t part_node[WAVES];
+    unsigned long long top_key[KAI_CMAX]; int32_t top_node[KAI_CMAX];
+    unsigned long long s2_key[KAI_CMAX * KAI_NSB_MAX]; int32_t s2_node[KAI_CMAX * KAI_NSB_MAX];
 };
 
 // monotone map f64 → u64 (larger double ⇒ larger key); scores here are finite and ≥ 0 but keep it general
@@ -165,40 +237,90 @@ __device__ __forceinline__ unsigned long long orderable(double d) {
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
-struct DevScanner {
-    ScanShared* sh;
+struct DevBackend {
+    ActShared* sh;
     // control lane side -------------------------------------------------------------------------------
-    __device__ void minmax(const KaiCtx&, int r, double& mn, double& mx) {
-        sh->cmd = CMD_MINMAX; sh->r = r;
+    __device__ void call(int cmd) {
+        sh->cmd = cmd;
         __syncthreads();  // publish the command
-        __syncthreads();  // partials ready
+        __syncthreads();  // results ready
+    }
+    __device__ void minmax(const KaiCtx&, int r, double& mn, double& mx) {
+        sh->r = r; call(CMD_MINMAX);
         double lo = 1.7976931348623157e308, hi = 0;  // math.MaxFloat64, 0 (plugins/nodeplacement/pack.go:66-68)
         for (int w = 1; w < WAVES; w++) { if (sh->part_min[w] < lo) lo = sh->part_min[w]; if (sh->part_max[w] > hi) hi = sh->part_max[w]; }
         mn = lo; mx = hi;
     }
     __device__ int best_node(const KaiCtx&, const ScanReq& q) {
-        sh->req = q; sh->cmd = CMD_BEST;
-        __syncthreads();
-        __syncthreads();
-        int best = -1; unsigned long long bk = 0; uint32_t br = 0;
+        sh->req = q; call(CMD_BEST);
+        int best = -1; unsigned long long bk = 0;
         for (int w = 1; w < WAVES; w++) {
             int n = sh->part_node[w]; if (n < 0) continue;
-            unsigned long long k = sh->part_key[w]; uint32_t rk = sh->part_rank[w];
-            if (best < 0 || k > bk || (k == bk && rk < br)) { best = n; bk = k; br = rk; }
+            unsigned long long k = sh->part_key[w];
+            if (best < 0 || k > bk || (k == bk && n < best)) { best = n; bk = k; }
         }
         return best;
     }
+    __device__ void begin(const KaiCtx& c) { if (c.use_index) call(CMD_BEGIN); }
+    __device__ void refresh(const KaiCtx&, const int32_t* blocks, int n) {
+        for (int i = 0; i < n; i++) sh->dirty[i] = blocks[i];
+        sh->n_dirty = n; call(CMD_REFRESH);
+    }
+    __device__ void class_top(const KaiCtx&, int k, uint64_t& key, int& node) { key = sh->top_key[k]; node = sh->top_node[k]; }
+    __device__ bool all_dead(const KaiCtx& c) { for (int k = 0; k < c.C; k++) if (sh->top_key[k]) return false; return true; }
+    __device__ int64_t clock() { return (int64_t)clock64(); }
     __device__ void finish() { sh->cmd = CMD_EXIT; __syncthreads(); }
 };
 
-// scan-wave side: each of the 15 scan waves owns the nodes  (wave-1)*64 + lane  (mod 960)
-__device__ void scan_service(const KaiCtx& c, ScanShared* sh) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = threadIdx.x - 64;
+// L2 entry (class k, super-block sb) from the 64 L1 entries below it, then the class top from the L2 row
+__device__ __forceinline__ void svc_l2(const KaiCtx& c, ActShared* sh, int k, int sb, int lane) {
+    int e = sb * 64 + lane;
+    uint64_t key = e < c.NB ? c.sum1_key[(size_t)k * c.NB + e] : 0; int n = e < c.NB ? c.sum1_node[(size_t)k * c.NB + e] : 0x7fffffff;
+    wave_argmax(key, n);
+    if (lane == 0) { sh->s2_key[k * KAI_NSB_MAX + sb] = key; sh->s2_node[k * KAI_NSB_MAX + sb] = n; }
+}
+__device__ __forceinline__ void svc_top(const KaiCtx& c, ActShared* sh, int k, int lane) {
+    uint64_t key = lane < c.NSB ? sh->s2_key[k * KAI_NSB_MAX + lane] : 0; int n = lane < c.NSB ? sh->s2_node[k * KAI_NSB_MAX + lane] : 0x7fffffff;
+    wave_argmax(key, n);
+    if (lane == 0) { sh->top_key[k] = key; sh->top_node[k] = n; }
+}
+
+// service-wave side: each of the 15 service waves owns the classes  k ≡ wave-1 (mod 15)  of the class index and the nodes
+// (wave-1)*64 + lane (mod 960) of a brute-force scan
+__device__ void service_loop(const KaiCtx& c, ActShared* sh) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = threadIdx.x - 64, hw = wave - 1;
     for (;;) {
         __syncthreads();  // wait for a command
         int cmd = sh->cmd;
         if (cmd == CMD_EXIT) return;
-        if (cmd == CMD_MINMAX) {  // getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86)
+        if (cmd == CMD_BEGIN) {
+            for (int k = hw; k < c.C; k += SVC) {
+                for (int sb = 0; sb < c.NSB; sb++) svc_l2(c, sh, k, sb, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                svc_top(c, sh, k, lane);
+            }
+        } else if (cmd == CMD_REFRESH) {
+            const int nd = sh->n_dirty;
+            // L1: re-evaluate the dirty blocks for this wave's classes
+            for (int i = 0; i < nd; i++) {
+                int b = sh->dirty[i], n = b * KAI_BLOCK + lane;
+                for (int k = hw; k < c.C; k += SVC) {
+                    uint64_t key = n < c.N ? class_key(c, c.cls[k], n) : 0; int bn = n;
+                    wave_argmax(key, bn);
+                    if (lane == 0) { c.sum1_key[(size_t)k * c.NB + b] = key; c.sum1_node[(size_t)k * c.NB + b] = bn; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // this wave re-reads its own L1 rows
+            for (int k = hw; k < c.C; k += SVC) {
+                for (int i = 0; i < nd; i++) {
+                    int sb = sh->dirty[i] / 64; bool seen = false;
+                    for (int x = 0; x < i; x++) if (sh->dirty[x] / 64 == sb) seen = true;
+                    if (!seen) svc_l2(c, sh, k, sb, lane);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                svc_top(c, sh, k, lane);
+            }
+        } else if (cmd == CMD_MINMAX) {  // getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86)
             int r = sh->r;
             double lo = 1.7976931348623157e308, hi = 0;
             for (int n = slot; n < c.N; n += SCAN_LANES) {
@@ -209,58 +331,78 @@ __device__ void scan_service(const KaiCtx& c, ScanShared* sh) {
             }
             for (int o = 32; o > 0; o >>= 1) { double a = __shfl_xor(lo, o, 64), b = __shfl_xor(hi, o, 64); if (a < lo) lo = a; if (b > hi) hi = b; }
             if (lane == 0) { sh->part_min[wave] = lo; sh->part_max[wave] = hi; }
-        } else {  // CMD_BEST: OrderedNodesByTask + FittingNode collapsed to an arg-max (framework/session.go:201-264, 466-485)
+        } else if (cmd == CMD_BEST) {  // OrderedNodesByTask + FittingNode collapsed to an arg-max (framework/session.go:201-264, 466-485)
             const ScanReq& q = sh->req;
-            int best = -1; unsigned long long bk = 0; uint32_t br = 0;
+            int best = -1; unsigned long long bk = 0;
             for (int n = slot; n < c.N; n += SCAN_LANES) {
-                if (!fits(c, q, n, true)) continue;              // IsTaskAllocatableOnReleasingOrIdle
-                if (!node_predicates(c, q, n)) continue;         // ssn.PredicateFn
-                bool fit_idle = q.best_effort || fits(c, q, n, false);
+                if (!fits(c, q.req, n, true)) continue;                              // IsTaskAllocatableOnReleasingOrIdle
+                if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;  // ssn.PredicateFn
+                bool fit_idle = q.best_effort || fits(c, q.req, n, false);
                 unsigned long long k = orderable(node_score(c, q, n, fit_idle));
-                uint32_t rk = c.n_name_rank[n];
-                if (best < 0 || k > bk || (k == bk && rk < br)) { best = n; bk = k; br = rk; }
+                if (best < 0 || k > bk) { best = n; bk = k; }                        // n ascends: the first of equal scores is the lowest name rank
             }
             for (int o = 32; o > 0; o >>= 1) {
-                int on = __shfl_xor(best, o, 64); unsigned long long ok = __shfl_xor(bk, o, 64); uint32_t orr = __shfl_xor(br, o, 64);
-                if (on >= 0 && (best < 0 || ok > bk || (ok == bk && orr < br))) { best = on; bk = ok; br = orr; }
+                int on = __shfl_xor(best, o, 64); unsigned long long ok = __shfl_xor(bk, o, 64);
+                if (on >= 0 && (best < 0 || ok > bk || (ok == bk && on < best))) { best = on; bk = ok; }
             }
-            if (lane == 0) { sh->part_node[wave] = best; sh->part_key[wave] = bk; sh->part_rank[wave] = br; }
+            if (lane == 0) { sh->part_node[wave] = best; sh->part_key[wave] = bk; }
         }
-        __syncthreads();  // partials ready
+        __syncthreads();  // results ready
     }
 }
 
-// One workgroup; wave 0 lane 0 = control, waves 1..15 = scan service.
+// One workgroup; wave 0 lane 0 = control, waves 1..15 = service.
 __global__ void __launch_bounds__(WG) k_action(KaiCtx c, int action) {
-    __shared__ ScanShared sh;
+    __shared__ ActShared sh;
     if (threadIdx.x == 0) sh.cmd = CMD_NONE;
     __syncthreads();
-    if (threadIdx.x >= 64) { scan_service(c, &sh); return; }
+    if (threadIdx.x >= 64) { service_loop(c, &sh); return; }
     if (threadIdx.x != 0) return;  // the rest of wave 0 idles: s_barrier counts wavefronts, not lanes
-    DevScanner sc{&sh};
-    Engine<DevScanner> eng(c, sc);
+    DevBackend be{&sh};
+    Engine<DevBackend> eng(c, be);
     if (action == KAI_ACTION_ALLOCATE) eng.execute_allocate();
-    sc.finish();
+    be.finish();
 }
 
-// kai_best_node: one OrderedNodesByTask + FittingNode against the current session state
+// Once no class has a fitting node at a committed state, every job still queued is attempted, gated and fails at its first
+// task without changing any state (Engine::drain_job): resolve them chip-wide.  Slot i of a leaf's region holds a job of the
+// sorted part if cur <= pos < end and a job of the side heap if pos < side_len.
+__global__ void k_drain(KaiCtx c, const int32_t* slot_queue) {
+    if (!c.st->drain_pending) return;
+    NullBackend nb; Engine<NullBackend> eng(c, nb);
+    int64_t att = 0, dec = 0, rb = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.J; i += gridDim.x * blockDim.x) {
+        int q = slot_queue[i]; if (q < 0) continue;
+        int pos = i - c.q_job_off[q];
+        if (pos >= c.lq_cur[q] && pos < c.lq_end[q]) eng.drain_job(c.lq_sorted[i], att, dec, rb);
+        if (pos < c.lq_side_len[q]) eng.drain_job(c.lq_side[i], att, dec, rb);
+    }
+    for (int o = 32; o > 0; o >>= 1) { att += __shfl_xor((long long)att, o, 64); dec += __shfl_xor((long long)dec, o, 64); rb += __shfl_xor((long long)rb, o, 64); }
+    if ((threadIdx.x & 63) == 0 && att) {
+        atomicAdd((unsigned long long*)&c.st->jobs_attempted, (unsigned long long)att); atomicAdd((unsigned long long*)&c.st->decisions, (unsigned long long)dec);
+        atomicAdd((unsigned long long*)&c.st->rollbacks, (unsigned long long)rb);
+        atomicAdd((unsigned long long*)&c.st->drained_jobs, (unsigned long long)att); atomicAdd((unsigned long long*)&c.st->drained_decisions, (unsigned long long)dec);
+    }
+}
+
+// kai_best_node: one OrderedNodesByTask + FittingNode against the current session state (brute-force scan)
 __global__ void __launch_bounds__(WG) k_best_node(KaiCtx c, int pod, int pipeline_only, int32_t* out) {
-    __shared__ ScanShared sh;
+    __shared__ ActShared sh;
     if (threadIdx.x == 0) sh.cmd = CMD_NONE;
     __syncthreads();
-    if (threadIdx.x >= 64) { scan_service(c, &sh); return; }
+    if (threadIdx.x >= 64) { service_loop(c, &sh); return; }
     if (threadIdx.x != 0) return;
-    DevScanner sc{&sh};
-    Engine<DevScanner> eng(c, sc);
-    ScanReq q; eng.fill_req(q, pod);
+    DevBackend be{&sh};
+    KaiCtx cb = c; cb.use_index = 0;
+    Engine<DevBackend> eng(cb, be);
     int n = -1, pipe = 0;
     if (!((c.plugins & KAI_PLUGIN_PREDICATES) && eng.task_over_capacity(pod))) {
-        if ((c.plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) sc.minmax(c, q.r_place, q.min_a, q.max_a);
-        n = sc.best_node(c, q);
-        if (n >= 0) { bool allocatable = q.best_effort || fits(c, q, n, false); pipe = (pipeline_only || !allocatable) ? 1 : 0; }
+        bool allocatable = false;
+        n = eng.find_node(pod, allocatable);
+        if (n >= 0) pipe = (pipeline_only || !allocatable) ? 1 : 0;
     }
     out[0] = n; out[1] = pipe;
-    sc.finish();
+    be.finish();
 }
 
 }  // namespace kai

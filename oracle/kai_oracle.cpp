@@ -683,6 +683,13 @@ void JobsOrderByQueues::PushJob(PodGroupInfo* job) {  // :91-120
     markAncestorsForReorder(leaf);
 }
 void JobsOrderByQueues::InitializeWithJobs(const std::vector<PodGroupInfo*>& jobsToOrder) {  // input_jobs.go:21-68
+    // The reference ranges a Go map here, so ANY permutation of the jobs is a possible execution, and the lazily fixed
+    // queue-node heaps (needsReorder, :194-217) are only guaranteed to be valid heaps if no node was linked with a stale
+    // best job.  The oracle fixes the canonical "best-first" permutation: every leaf pushes its jobs in JobOrderFn order and
+    // every inner node links its best child first (then the others in index order), so each node enters its parent's heap
+    // with its final key and every heap is a valid heap when the action starts.
+    const int Q = int(ssn->queues.size());
+    std::vector<std::vector<PodGroupInfo*>> perLeaf(Q);
     for (auto* job : jobsToOrder) {
         if (options.FilterUnready && !job->IsReadyForScheduling()) continue;
         if (options.FilterNonPending && job->GetNumPendingTasks() == 0) continue;
@@ -691,8 +698,36 @@ void JobsOrderByQueues::InitializeWithJobs(const std::vector<PodGroupInfo*>& job
         if (options.FilterNonActiveAllocated && !isJobActive) continue;
         if (job->queue < 0) continue;                          // queue (or its parent) missing
         if (!ssn->queues[job->queue].IsLeafQueue()) continue;
-        PushJob(job);
+        perLeaf[job->queue].push_back(job);
     }
+    const bool victim = options.VictimQueue; Session* s = ssn;
+    for (auto& v : perLeaf) std::stable_sort(v.begin(), v.end(), [s, victim](PodGroupInfo* l, PodGroupInfo* r) { return victim ? s->JobOrderFn(r, l) : s->JobOrderFn(l, r); });
+    // best job of every queue's subtree, bottom-up, and the link order of every inner node
+    std::vector<PodGroupInfo*> best(Q, nullptr);
+    std::vector<std::vector<int>> linkOrder(Q + 1);  // index Q = the virtual root
+    auto canonLess = [&](int l, int r) {             // buildNodeOrderFn :280-305 on the final bests (nothing popped yet)
+        bool result = victim ? s->QueueOrderFn(l, r, nullptr, nullptr, {best[l]}, {best[r]}) : s->QueueOrderFn(l, r, best[l], best[r], {}, {});
+        return victim ? !result : result;
+    };
+    std::function<void(int)> prepare = [&](int x) {
+        std::vector<int> kids;
+        if (x == Q) { for (int q = 0; q < Q; q++) if (ssn->queues[q].parent < 0) kids.push_back(q); }
+        else kids = ssn->queues[x].children;
+        std::vector<int> live;
+        for (int k : kids) {
+            if (ssn->queues[k].IsLeafQueue()) { if (!perLeaf[k].empty()) { best[k] = perLeaf[k][0]; live.push_back(k); } }
+            else { prepare(k); if (best[k]) live.push_back(k); }
+        }
+        if (live.empty()) return;
+        int b = live[0]; for (size_t i = 1; i < live.size(); i++) if (canonLess(live[i], b)) b = live[i];
+        linkOrder[x].push_back(b); for (int k : live) if (k != b) linkOrder[x].push_back(k);
+        if (x != Q) best[x] = best[b];
+    };
+    prepare(Q);
+    std::function<void(int)> emit = [&](int x) {
+        for (int k : linkOrder[x]) { if (ssn->queues[k].IsLeafQueue()) for (auto* job : perLeaf[k]) PushJob(job); else emit(k); }
+    };
+    emit(Q);
 }
 
 // =====================================================================================================

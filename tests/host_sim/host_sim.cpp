@@ -16,7 +16,8 @@ using namespace kai;
 
 namespace {
 
-struct HostScanner {  // serial twin of DevScanner / scan_service (kai_kernels.hpp)
+struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.hpp)
+    std::vector<uint64_t> s2_key, top_key; std::vector<int32_t> s2_node, top_node;
     void minmax(const KaiCtx& c, int r, double& mn, double& mx) {
         double lo = 1.7976931348623157e308, hi = 0;
         for (int n = 0; n < c.N; n++) {
@@ -28,16 +29,43 @@ struct HostScanner {  // serial twin of DevScanner / scan_service (kai_kernels.h
         mn = lo; mx = hi;
     }
     int best_node(const KaiCtx& c, const ScanReq& q) {
-        int best = -1; double bs = 0; uint32_t br = 0;
+        int best = -1; double bs = 0;
         for (int n = 0; n < c.N; n++) {
-            if (!fits(c, q, n, true)) continue;
-            if (!node_predicates(c, q, n)) continue;
-            bool fit_idle = q.best_effort || fits(c, q, n, false);
-            double sc = node_score(c, q, n, fit_idle); uint32_t rk = c.n_name_rank[n];
-            if (best < 0 || sc > bs || (sc == bs && rk < br)) { best = n; bs = sc; br = rk; }
+            if (!fits(c, q.req, n, true)) continue;
+            if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;
+            bool fit_idle = q.best_effort || fits(c, q.req, n, false);
+            double sc = node_score(c, q, n, fit_idle);
+            if (best < 0 || sc > bs) { best = n; bs = sc; }
         }
         return best;
     }
+    void l2(const KaiCtx& c, int k, int sb) {
+        uint64_t bk = 0; int bn = 0x7fffffff;
+        for (int e = sb * 64; e < std::min(c.NB, sb * 64 + 64); e++) { uint64_t key = c.sum1_key[(size_t)k * c.NB + e]; int n = c.sum1_node[(size_t)k * c.NB + e]; if (key_better(key, n, bk, bn)) { bk = key; bn = n; } }
+        s2_key[k * KAI_NSB_MAX + sb] = bk; s2_node[k * KAI_NSB_MAX + sb] = bn;
+    }
+    void top(const KaiCtx& c, int k) {
+        uint64_t bk = 0; int bn = 0x7fffffff;
+        for (int sb = 0; sb < c.NSB; sb++) { uint64_t key = s2_key[k * KAI_NSB_MAX + sb]; int n = s2_node[k * KAI_NSB_MAX + sb]; if (key_better(key, n, bk, bn)) { bk = key; bn = n; } }
+        top_key[k] = bk; top_node[k] = bn;
+    }
+    void begin(const KaiCtx& c) {
+        if (!c.use_index) return;
+        s2_key.assign((size_t)KAI_CMAX * KAI_NSB_MAX, 0); s2_node.assign((size_t)KAI_CMAX * KAI_NSB_MAX, 0); top_key.assign(KAI_CMAX, 0); top_node.assign(KAI_CMAX, 0);
+        for (int k = 0; k < c.C; k++) { for (int sb = 0; sb < c.NSB; sb++) l2(c, k, sb); top(c, k); }
+    }
+    static void build_block(const KaiCtx& c, int k, int b) {
+        uint64_t bk = 0; int bn = b * KAI_BLOCK;
+        for (int n = b * KAI_BLOCK; n < std::min(c.N, (b + 1) * KAI_BLOCK); n++) { uint64_t key = class_key(c, c.cls[k], n); if (key_better(key, n, bk, bn)) { bk = key; bn = n; } }
+        c.sum1_key[(size_t)k * c.NB + b] = bk; c.sum1_node[(size_t)k * c.NB + b] = bn;
+    }
+    void refresh(const KaiCtx& c, const int32_t* blocks, int n) {
+        for (int i = 0; i < n; i++) for (int k = 0; k < c.C; k++) build_block(c, k, blocks[i]);
+        for (int k = 0; k < c.C; k++) { for (int i = 0; i < n; i++) l2(c, k, blocks[i] / 64); top(c, k); }
+    }
+    void class_top(const KaiCtx&, int k, uint64_t& key, int& node) { key = top_key[k]; node = top_node[k]; }
+    bool all_dead(const KaiCtx& c) { for (int k = 0; k < c.C; k++) if (top_key[k]) return false; return true; }
+    int64_t clock() { return 0; }
 };
 
 template <class T> T* own(std::vector<std::vector<char>>& pool, size_t n) {
@@ -65,13 +93,12 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.N = N; c.P = P; c.S = S; c.J = J; c.Q = Q; c.R = R; c.n_pod_classes = std::max(1, s->n_pod_classes); c.n_node_classes = std::max(1, s->n_node_classes);
     c.plugins = cfg->plugins; c.gpu_strategy = cfg->gpu_strategy; c.cpu_strategy = cfg->cpu_strategy; c.restrict_nodes = cfg->restrict_node_scheduling;
     c.k_value = cfg->k_value <= 0.0 ? 0.0 : cfg->k_value;
-    std::vector<int32_t> neg1n(N, -1), zeron(N, 0), zerop(P, 0), neg1p(P, -1); std::vector<uint32_t> zeropu(P, 0); uint8_t one = 1;
-    c.n_alloc = copy(pool, s->node_allocatable, (size_t)R * N); c.n_flags = copy(pool, s->node_flags, N);
-    c.n_gpu_count = copy(pool, s->node_gpu_count ? s->node_gpu_count : neg1n.data(), N); c.n_name_rank = copy(pool, s->node_name_rank, N);
-    c.n_class = copy(pool, s->node_class ? s->node_class : zeron.data(), N);
+    std::vector<int32_t> zerop(P, 0); std::vector<uint32_t> zeropu(P, 0); uint8_t one = 1;
+    c.n_alloc = copy(pool, prep.node_alloc.data(), (size_t)R * N); c.n_flags = copy(pool, prep.node_flags.data(), N);
+    c.n_gpu_count = copy(pool, prep.node_gpu_count.data(), N); c.n_class = copy(pool, prep.node_class.data(), N);
     c.p_req = copy(pool, s->pod_req, (size_t)R * P); c.p_job = copy(pool, s->pod_job, P); c.p_podset = copy(pool, s->pod_podset, P);
     c.p_flags = copy(pool, s->pod_flags ? s->pod_flags : zeropu.data(), P); c.p_class = copy(pool, s->pod_class ? s->pod_class : zerop.data(), P);
-    c.p_nominated = copy(pool, s->pod_nominated_node ? s->pod_nominated_node : neg1p.data(), P);
+    c.p_nominated = copy(pool, prep.pod_nominated.data(), P); c.p_scls = copy(pool, prep.pod_scls.data(), P);
     c.s_job = copy(pool, s->podset_job, S); c.s_min = copy(pool, s->podset_min_available, S); c.s_name_rank = copy(pool, s->podset_name_rank, S);
     c.j_queue = copy(pool, s->job_queue, J); c.j_prio = copy(pool, s->job_priority, J); c.j_preempt = copy(pool, s->job_preemptible, J);
     c.j_created = copy(pool, s->job_created_ns, J); c.j_uid_rank = copy(pool, s->job_uid_rank, J); c.j_first_pod = copy(pool, s->job_first_pod, J);
@@ -80,15 +107,21 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (s->class_fit && s->n_pod_classes > 0 && s->n_node_classes > 0) c.class_fit = copy(pool, s->class_fit, (size_t)s->n_pod_classes * s->n_node_classes);
     else c.class_fit = copy(pool, &one, 1);
     c.j_pods_sorted = copy(pool, prep.sorted.data(), P); c.q_child_off = copy(pool, prep.child_off.data(), Q + 2); c.q_children = copy(pool, prep.children.data(), std::max(Q, 1));
-    c.q_job_off = copy(pool, prep.job_off.data(), Q + 1);
-    c.n_idle = const_cast<double*>(copy(pool, s->node_allocatable, (size_t)R * N)); c.n_rel = own<double>(pool, (size_t)R * N); c.n_used = own<double>(pool, (size_t)R * N);
-    c.p_status = const_cast<int32_t*>(copy(pool, s->pod_status, P)); c.p_node = const_cast<int32_t*>(copy(pool, s->pod_node, P));
+    c.q_job_off = copy(pool, prep.job_off.data(), Q + 1); c.jobs_static = copy(pool, prep.jobs_static.data(), std::max(J, 1)); c.q_depth_order = copy(pool, prep.depth_order.data(), Q);
+    c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64; c.use_index = c.C > 0; c.all_tracked = prep.all_tracked;
+    { int d = cfg->queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
+    c.cls = copy(pool, prep.classes.data(), prep.classes.size());
+    c.sum1_key = own<uint64_t>(pool, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)); c.sum1_node = own<int32_t>(pool, (size_t)std::max(c.C, 1) * std::max(c.NB, 1));
+    c.n_idle = const_cast<double*>(copy(pool, prep.node_alloc.data(), (size_t)R * N)); c.n_rel = own<double>(pool, (size_t)R * N); c.n_used = own<double>(pool, (size_t)R * N);
+    c.p_status = const_cast<int32_t*>(copy(pool, s->pod_status, P)); c.p_node = const_cast<int32_t*>(copy(pool, prep.pod_node.data(), P));
     c.p_on_node = own<int32_t>(pool, P); c.p_on_node_status = own<int32_t>(pool, P); c.p_virtual = own<uint8_t>(pool, P); c.p_accepted = own<uint8_t>(pool, P);
     c.s_active_alloc = own<int32_t>(pool, S); c.s_active_used = own<int32_t>(pool, S); c.s_alive = own<int32_t>(pool, S); c.s_gated = own<int32_t>(pool, S); c.s_pipelined = own<int32_t>(pool, S);
     c.j_n_pending = own<int32_t>(pool, J); c.j_tta_valid = own<int32_t>(pool, J); c.j_tta_n = own<int32_t>(pool, J); c.tta = own<int32_t>(pool, P);
     c.j_tta_res = own<double>(pool, (size_t)3 * J); c.j_allocated = own<double>(pool, (size_t)3 * J);
-    c.jheap = own<int32_t>(pool, J); c.jheap_len = own<int32_t>(pool, Q); c.qheap = own<int32_t>(pool, Q + 1); c.qheap_len = own<int32_t>(pool, Q + 1); c.root_heap = own<int32_t>(pool, Q + 1);
+    c.lq_sorted = own<int32_t>(pool, J); c.lq_side = own<int32_t>(pool, J); c.lq_cur = own<int32_t>(pool, Q); c.lq_end = own<int32_t>(pool, Q); c.lq_side_len = own<int32_t>(pool, Q); c.j_state = own<uint8_t>(pool, J);
+    c.qheap = own<int32_t>(pool, Q + 1); c.qheap_len = own<int32_t>(pool, Q + 1); c.root_heap = own<int32_t>(pool, Q + 1);
     c.qn_exists = own<uint8_t>(pool, Q); c.qn_reorder = own<uint8_t>(pool, Q); c.qn_linked = own<uint8_t>(pool, Q);
+    c.qkey = own<QKey>(pool, Q); c.qk_valid = own<uint8_t>(pool, Q);
     c.ops_cap = 4 * P + 64; c.ops = own<StmtOp>(pool, c.ops_cap); c.out_cap = (int64_t)2 * P + 64; c.out_ops = own<kai_op>(pool, c.out_cap);
     c.scratch = own<int32_t>(pool, (size_t)P + 64); c.st = own<EngineState>(pool, 1);
     c.q_share = const_cast<QShare*>(copy(pool, prep.shares.data(), prep.shares.size()));
@@ -158,17 +191,37 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             out[q].fair_share[k] = x.fair; out[q].allocated[k] = x.allocated; out[q].allocated_non_preemptible[k] = x.allocated_np; out[q].request[k] = x.request; out[q].deserved[k] = x.deserved; out[q].max_allowed[k] = x.max_allowed; }
     };
     if (shares_open) fill(shares_open);
-    HostScanner sc; Engine<HostScanner> eng(c, sc);
-    for (int i = 0; i < n_actions; i++) { if (actions[i] != KAI_ACTION_ALLOCATE) return KAI_ERR_UNSUPPORTED; eng.execute_allocate(); }
+    if (c.use_index) for (int b = 0; b < c.NB; b++) for (int k = 0; k < c.C; k++) HostBackend::build_block(c, k, b);  // k_index_build
+    HostBackend be; Engine<HostBackend> eng(c, be);
+    for (int i = 0; i < n_actions; i++) {
+        if (actions[i] != KAI_ACTION_ALLOCATE) return KAI_ERR_UNSUPPORTED;
+        for (int j = 0; j < J; j++) c.j_state[j] = job_init_state(c, j);  // k_job_init
+        for (int q = 0; q < Q; q++) {                                      // k_leaf_init
+            int b = c.q_job_off[q], e = c.q_job_off[q + 1], cnt = 0; c.lq_side_len[q] = 0;
+            for (int x = b; x < e; x++) { int j = c.jobs_static[x]; int st = c.j_state[j]; if (st == 0) c.lq_sorted[b + cnt++] = j; else if (st != 3) eng.leaf_push(q, j); }
+            c.lq_cur[q] = 0; c.lq_end[q] = cnt;
+        }
+        eng.execute_allocate();
+        if (c.st->drain_pending) {                                         // k_drain
+            for (int x = 0; x < J; x++) {
+                int q = prep.slot_queue[x]; if (q < 0) continue; int pos = x - c.q_job_off[q];
+                int64_t att = 0, dec = 0, rb = 0;
+                if (pos >= c.lq_cur[q] && pos < c.lq_end[q]) eng.drain_job(c.lq_sorted[x], att, dec, rb);
+                if (pos < c.lq_side_len[q]) eng.drain_job(c.lq_side[x], att, dec, rb);
+                c.st->jobs_attempted += att; c.st->decisions += dec; c.st->rollbacks += rb; c.st->drained_jobs += att; c.st->drained_decisions += dec;
+            }
+            c.st->drain_pending = 0;
+        }
+    }
     auto t1 = std::chrono::steady_clock::now();
     if (elapsed_ms_out) *elapsed_ms_out = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (c.st->fault) return KAI_ERR_DEVICE_FAULT;
     if (n_ops) *n_ops = c.st->out_len;
-    if (ops_out) { if (c.st->out_len > ops_cap) return KAI_ERR_CAPACITY; std::memcpy(ops_out, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)); }
+    if (ops_out) { if (c.st->out_len > ops_cap) return KAI_ERR_CAPACITY; std::memcpy(ops_out, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)); for (int64_t i = 0; i < c.st->out_len; i++) if (ops_out[i].node >= 0) ops_out[i].node = prep.perm[ops_out[i].node]; }
     if (pod_status_out) std::memcpy(pod_status_out, c.p_status, (size_t)P * 4);
-    if (pod_node_out) std::memcpy(pod_node_out, c.p_node, (size_t)P * 4);
+    if (pod_node_out) for (int p = 0; p < P; p++) pod_node_out[p] = c.p_node[p] >= 0 ? prep.perm[c.p_node[p]] : -1;
     if (shares_final) fill(shares_final);
-    if (nodes_out) for (int n = 0; n < N; n++) { std::memset(&nodes_out[n], 0, sizeof(kai_node_state)); for (int r = 0; r < R; r++) { nodes_out[n].idle[r] = c.n_idle[(size_t)r * N + n]; nodes_out[n].releasing[r] = c.n_rel[(size_t)r * N + n]; nodes_out[n].used[r] = c.n_used[(size_t)r * N + n]; } }
-    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; }
+    if (nodes_out) for (int n = 0; n < N; n++) { kai_node_state& o = nodes_out[prep.perm[n]]; std::memset(&o, 0, sizeof(kai_node_state)); for (int r = 0; r < R; r++) { o.idle[r] = c.n_idle[(size_t)r * N + n]; o.releasing[r] = c.n_rel[(size_t)r * N + n]; o.used[r] = c.n_used[(size_t)r * N + n]; } }
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; }
     return KAI_OK;
 }
