@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,6 +26,7 @@ struct kai_core {
     std::string err = "ok";
     bool open = false;
     KaiCtx ctx{};
+    KaiCtx* d_ctx = nullptr;  // HBM copy of ctx for the persistent kernel
     std::vector<void*> bufs;  // session HBM
     // device-only helpers
     double* d_jsum = nullptr; int32_t* d_slot_queue = nullptr;
@@ -95,6 +97,7 @@ int launch_open_kernels(kai_core* core) {
         if (Q) hipLaunchKernelGGL(k_fair_share, dim3(1), dim3(256), 0, core->stream, c, core->d_lvl_off, core->d_lvl_parents, core->n_levels,
                                   core->d_weight, core->d_rem_amt, core->d_rem_has);
     }
+    if (Q) hipLaunchKernelGGL(k_qnode_static, dim3((Q + TB - 1) / TB), dim3(TB), 0, core->stream, c);
     if (c.use_index && c.NB) hipLaunchKernelGGL(k_index_build, dim3((c.NB + 3) / 4), dim3(TB), 0, core->stream, c);
     HIP_TRY(core, hipGetLastError());
     return KAI_OK;
@@ -229,9 +232,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dzero(core, &c.j_tta_res, (size_t)3 * J)); TRY(dzero(core, &c.j_allocated, (size_t)3 * J));
     TRY(dzero(core, &c.lq_sorted, (size_t)J)); TRY(dzero(core, &c.lq_side, (size_t)J)); TRY(dzero(core, &c.lq_cur, (size_t)Q)); TRY(dzero(core, &c.lq_end, (size_t)Q)); TRY(dzero(core, &c.lq_side_len, (size_t)Q));
     TRY(dzero(core, &c.j_state, (size_t)J));
-    TRY(dzero(core, &c.qheap, (size_t)Q + 1)); TRY(dzero(core, &c.qheap_len, (size_t)Q + 1)); TRY(dzero(core, &c.root_heap, (size_t)Q + 1));
-    TRY(dzero(core, &c.qn_exists, (size_t)Q)); TRY(dzero(core, &c.qn_reorder, (size_t)Q)); TRY(dzero(core, &c.qn_linked, (size_t)Q));
-    TRY(dzero(core, &c.qkey, (size_t)Q)); TRY(dzero(core, &c.qk_valid, (size_t)Q));
+    TRY(dzero(core, &c.qheap, (size_t)Q + 1)); TRY(dzero(core, &c.root_heap, (size_t)Q + 1)); TRY(dzero(core, &c.qn, (size_t)Q + 1));
     c.ops_cap = 4 * P + 64; TRY(dalloc(core, &c.ops, (size_t)c.ops_cap));
     c.out_cap = (int64_t)2 * P + 64; TRY(dalloc(core, &c.out_ops, (size_t)c.out_cap));
     TRY(dzero(core, &c.scratch, (size_t)P + 64));
@@ -246,6 +247,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     if (P) { HIP_TRY(core, hipMemcpyAsync(core->d_status0, c.p_status, (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream));
              HIP_TRY(core, hipMemcpyAsync(core->d_node0, c.p_node, (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream)); }
     HIP_TRY(core, hipMemcpyAsync(core->d_shares0, c.q_share, (size_t)std::max(Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
+    { KaiCtx* t = nullptr; int rc3 = dalloc(core, &t, (size_t)1); if (rc3) return rc3; core->d_ctx = t; }
+    HIP_TRY(core, hipMemcpyAsync(core->d_ctx, &core->ctx, sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
     { int rc2 = launch_open_kernels(core); if (rc2) return rc2; }
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));  // prep's host buffers die with this scope
@@ -311,7 +314,14 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     const int TB = 256;
     if (c.J) hipLaunchKernelGGL(k_job_init, dim3((c.J + TB - 1) / TB), dim3(TB), 0, core->stream, c);
     if (c.Q) hipLaunchKernelGGL(k_leaf_init, dim3((c.Q + 3) / 4), dim3(TB), 0, core->stream, c);
-    hipLaunchKernelGGL(k_action, dim3(1), dim3(WG), 0, core->stream, c, action);
+    {   // dynamic LDS: upper levels of the class index, plus the job-order tree when it fits beside them (160 KiB per CU)
+        size_t idx_b = lds_index_bytes(c.C, c.NSB), tree_b = lds_tree_bytes(c.Q);
+        const size_t budget = 160 * 1024 - 4096;  // static ActShared + margin
+        int tree_in_lds = (idx_b + tree_b <= budget && !std::getenv("KAI_TREE_IN_HBM")) ? 1 : 0;
+        size_t dyn = idx_b + (tree_in_lds ? tree_b : 0);
+        HIP_TRY(core, hipFuncSetAttribute(reinterpret_cast<const void*>(k_action), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(k_action, dim3(1), dim3(WG), dyn, core->stream, (const KaiCtx*)core->d_ctx, action, tree_in_lds);
+    }
     if (c.J) hipLaunchKernelGGL(k_drain, dim3(std::min(2048, (c.J + TB - 1) / TB)), dim3(TB), 0, core->stream, c, core->d_slot_queue);
     HIP_TRY(core, hipGetLastError());
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
@@ -324,6 +334,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     core->stats.nodes_scanned = st.nodes_scanned; core->stats.jobs_attempted = st.jobs_attempted; core->stats.jobs_committed = st.jobs_committed; core->stats.rollbacks = st.rollbacks;
     core->stats.reserved[0] = st.index_queries; core->stats.reserved[1] = st.index_refreshes; core->stats.reserved[2] = st.drained_jobs; core->stats.reserved[3] = st.drained_decisions;
     for (int i = 0; i < 4; i++) core->stats.reserved[4 + i] = st.prof[i == 3 ? 7 : i == 2 ? 3 : i == 1 ? 2 : 0];  // control-lane cycles: pop, allocate, commit/discard, total
+    if (std::getenv("KAI_PROF")) { std::fprintf(stderr, "kai prof:"); for (int i = 0; i < 16; i++) std::fprintf(stderr, " %lld", (long long)st.prof[i]); std::fprintf(stderr, "\n"); }
     if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d", st.fault); core->err = buf; return KAI_ERR_DEVICE_FAULT; }
     *n_ops = st.out_len;
     if (ops_out) {
@@ -341,7 +352,7 @@ int kai_best_node(kai_core* core, int32_t pod_idx, const uint32_t* nodeset_bitma
     if (nodeset_bitmap) return fail(core, KAI_ERR_UNSUPPORTED, "node-set bitmaps arrive with the topology plugin");
     if (pod_idx < 0 || pod_idx >= core->ctx.P) return fail(core, KAI_ERR_INVALID_ARG, "pod index out of range");
     HIP_TRY(core, hipSetDevice(core->device));
-    hipLaunchKernelGGL(k_best_node, dim3(1), dim3(WG), 0, core->stream, core->ctx, (int)pod_idx, pipeline_only, core->d_best_out);
+    hipLaunchKernelGGL(k_best_node, dim3(1), dim3(WG), 16, core->stream, core->ctx, (int)pod_idx, pipeline_only, core->d_best_out);
     HIP_TRY(core, hipGetLastError());
     int32_t h[2] = {-1, 0};
     HIP_TRY(core, hipMemcpyAsync(h, core->d_best_out, sizeof h, hipMemcpyDeviceToHost, core->stream));

@@ -73,24 +73,33 @@ constexpr int KAI_BLOCK = 64;     // nodes per L1 block = one wavefront
 constexpr int KAI_NSB_MAX = 64;   // super-blocks the LDS level holds → the index covers N <= 64*64*64 = 262144 nodes
 constexpr int KAI_MAXD = 16;      // dirty blocks buffered before a refresh is forced
 
-// cached operands of the queue comparator for one queue node (plugins/proportion/queue_order/queue_order.go:19-73)
-struct QKey {
-    double dom_with_job, dom_no_job;
-    int32_t best_job;
-    uint32_t bits;  // 1 over fair share, 2 under quota with job, 4 zero-share violation
+// One node of the job-order tree (actions/utils/job_order_by_queue.go queueNode) with the cached operands of the queue
+// comparator (plugins/proportion/queue_order/queue_order.go:19-73).  40 bytes, so the whole tree fits the LDS of one CU
+// for a few thousand queues (kai_kernels.hpp puts it there when it does).
+struct QNode {
+    double dom_with_job, dom_no_job;  // dominant share with / without the best job of the subtree
+    int32_t best_job;                 // best job of the subtree (valid with QF_VALID)
+    int32_t prio;                     // queue priority (static)
+    int32_t len;                      // children in the node's heap; for a leaf: jobs queued
+    int32_t heap_off;                 // base of the node's child heap inside qheap (static)
+    int32_t parent;                   // parent queue or -1 (static)
+    uint32_t flags;                   // QF_*
 };
+enum : uint32_t { QF_OVER = 1, QF_STARVED = 2, QF_VIOL = 4, QF_VALID = 8, QF_REORDER = 16, QF_EXISTS = 32, QF_LINKED = 64, QF_LEAF = 128,
+                  QF_TOP = 256 };  // leaf: best_job holds the top job of the leaf (kept across key invalidations, dropped on pop / push)
 
 struct EngineState {  // mutable scalars of the running action
-    int32_t root_len, root_init;
     int32_t ops_len, n_undo;
     int32_t fault;            // != 0: engine gave up (see FAULT_*)
     int32_t drain_pending;    // allocate: every class is dead at a committed state → the rest of the queue is counted by k_drain
     int64_t out_len;
     int64_t decisions, node_scans, nodes_scanned, jobs_attempted, jobs_committed, rollbacks;
     int64_t index_queries, index_refreshes, drained_jobs, drained_decisions;
-    int64_t prof[8];          // control-lane cycles per phase (pop, tta+gate, task, commit/discard, drain check, init, -, total)
+    int64_t prof[16];         // control-lane cycles per phase, see PF_*
     double total[3];          // proportion totalResource (CPU, Memory, GPU)
 };
+enum { PF_POP = 0, PF_ALLOC = 2, PF_FINISH = 3, PF_DRAINCHK = 4, PF_INIT = 5, PF_TOTAL = 7, PF_TTA = 8, PF_GATE = 9, PF_TASKCAP = 10, PF_FIND = 11,
+       PF_REFRESH = 12, PF_STMT = 13, PF_ROLLBACK = 14, PF_PUSH = 15 };
 enum { FAULT_NONE = 0, FAULT_OPS_CAP = 1, FAULT_OUT_CAP = 2, FAULT_HEAP = 3, FAULT_INTERNAL = 4, FAULT_SPIN = 5 };
 
 // All pointers are device memory (HBM).  [R][N] arrays are resource-major.  Node index = name rank.
@@ -118,14 +127,14 @@ struct KaiCtx {
     const int32_t *q_parent, *q_prio; const int64_t* q_created; const uint32_t* q_uid_rank;
     const int32_t *q_child_off, *q_children, *q_job_off, *q_depth_order;  // CSR children (virtual root at Q); leaf job regions; deepest first
     QShare* q_share;  // [Q][3]
-    QKey* qkey; uint8_t* qk_valid;
+    QNode* qn;  // [Q] HBM home of the job-order tree (static fields + leaf lengths set by k_leaf_init)
     const uint8_t* class_fit;
     // scan classes + class index
     const ClassRec* cls; uint64_t* sum1_key; int32_t* sum1_node;  // [C][NB]
     // job-order tree (actions/utils/job_order_by_queue.go).  Leaves: a sorted region + a side heap; inner nodes: array heaps.
     const int32_t* jobs_static;  // [J] CSR by q_job_off: each queue's jobs by (priority desc, creation, uid)
     int32_t *lq_sorted, *lq_cur, *lq_end, *lq_side, *lq_side_len; uint8_t* j_state;
-    int32_t *qheap, *qheap_len, *root_heap; uint8_t *qn_exists, *qn_reorder, *qn_linked;
+    int32_t *qheap, *root_heap;
     // statement + committed operations
     StmtOp* ops; int32_t ops_cap; kai_op* out_ops; int64_t out_cap;
     int32_t* scratch;  // [P] ints
@@ -211,19 +220,62 @@ KAI_HD double node_score(const KaiCtx& c, const ScanReq& q, int n, bool fit_idle
 //              decreasing in cur for the integer quantities the host admits to the index, kai_host_prep.hpp guards);
 //              spread → bit pattern of the f64 score cur/count ∈ [0,1], plus one.
 // The nominated-node bonus (+1e6) concerns one node per pod and is handled by the control lane.
-KAI_HD uint64_t class_key(const KaiCtx& c, const ClassRec& k, int n) {
-    if (!fits(c, k.req, n, true)) return 0;
-    if (!node_predicates(c, k.cpu_only != 0, k.pod_class, n)) return 0;
+// Everything class_key reads of one node, fetched in one batch of independent loads (the refresh path is latency bound).
+struct NodeRegs {
+    double idle[KAI_MAX_RES], rel[KAI_MAX_RES], alloc_cpu, alloc_gpu;
+    uint32_t flags; int32_t ncls, gpu_count;
+};
+KAI_HD void load_node(const KaiCtx& c, int n, NodeRegs& s) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < KAI_MAX_RES; r++) {
+        bool on = r < c.R;
+        s.idle[r] = on ? c.n_idle[(size_t)r * c.N + n] : 0.0;
+        s.rel[r] = on ? c.n_rel[(size_t)r * c.N + n] : 0.0;
+    }
+    s.alloc_cpu = c.n_alloc[(size_t)KAI_RES_CPU * c.N + n]; s.alloc_gpu = c.n_alloc[(size_t)KAI_RES_GPU * c.N + n];
+    s.flags = c.n_flags[n]; s.ncls = c.n_class[n]; s.gpu_count = c.n_gpu_count[n];
+}
+KAI_HD uint64_t class_key_regs(const KaiCtx& c, const ClassRec& k, const NodeRegs& s) {
+    // FittingNode: fit on Idle+Releasing (api/node_info/node_info.go:190-206, 361-382) …
+    bool fit_rel = true, fit_idle = true;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < KAI_MAX_RES; r++) {
+        if (r >= c.R) continue;
+        double rq = k.req[r];
+        if (r >= KAI_RES_PODS && !(rq > 0)) continue;  // scalar keys exist only for non-zero requests
+        if (rq > s.idle[r] + s.rel[r]) fit_rel = false;
+        if (rq > s.idle[r]) fit_idle = false;
+    }
+    if (!fit_rel) return 0;
+    // … and the node-dependent predicates (plugins/predicates/predicates.go:173-262)
+    const bool cpu_node = !(s.flags & KAI_NODE_MIG_ENABLED) && s.alloc_gpu <= 0 && !(s.flags & KAI_NODE_HAS_DRA_GPUS);  // node_info.go:697-702
+    if (c.plugins & KAI_PLUGIN_PREDICATES) {
+        if (!k.cpu_only) {
+            if (s.flags & KAI_NODE_HAS_DRA_GPUS) return 0;
+            if ((s.flags & KAI_NODE_MIG_ENABLED) && (s.flags & KAI_NODE_MIG_MIXED)) return 0;
+        }
+        if (!(s.idle[KAI_RES_PODS] + s.rel[KAI_RES_PODS] > 0)) return 0;
+        if (s.flags & KAI_NODE_NOT_READY) return 0;
+        if (!c.class_fit[(size_t)k.pod_class * c.n_node_classes + s.ncls]) return 0;
+        if (c.restrict_nodes) {
+            if (!k.cpu_only) { if (!(s.flags & KAI_NODE_GPU_WORKER)) return 0; }
+            else if (!(s.flags & KAI_NODE_CPU_WORKER)) return 0;
+        }
+    }
     uint64_t key = 0;
-    if ((c.plugins & KAI_PLUGIN_NODEAVAILABILITY) && (k.best_effort || fits(c, k.req, n, false))) key |= 1ull << 63;
-    if ((c.plugins & KAI_PLUGIN_RESOURCETYPE) && k.cpu_only && cpu_only_node(c, n)) key |= 1ull << 62;
+    if ((c.plugins & KAI_PLUGIN_NODEAVAILABILITY) && (k.best_effort || fit_idle)) key |= 1ull << 63;
+    if ((c.plugins & KAI_PLUGIN_RESOURCETYPE) && k.cpu_only && cpu_node) key |= 1ull << 62;
     uint64_t v = 1;
     if (c.plugins & KAI_PLUGIN_NODEPLACEMENT) {
-        int r = k.r_place;
-        double cur = c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n];
+        const bool gpu = k.r_place == KAI_RES_GPU;
+        double cur = gpu ? s.idle[KAI_RES_GPU] + s.rel[KAI_RES_GPU] : s.idle[KAI_RES_CPU] + s.rel[KAI_RES_CPU];
         if (k.strategy == KAI_SPREAD) {
-            double overall = c.n_alloc[(size_t)r * c.N + n], count = overall;
-            if (r == KAI_RES_GPU) { int lbl = c.n_gpu_count[n]; count = lbl >= 0 ? (double)lbl : (double)(int64_t)overall; }
+            double overall = gpu ? s.alloc_gpu : s.alloc_cpu, count = overall;
+            if (gpu) count = s.gpu_count >= 0 ? (double)s.gpu_count : (double)(int64_t)overall;
             double place = count == 0 ? 0.0 : cur / count;
             union { double d; uint64_t u; } cv; cv.d = place;
             v = cv.u + 1;
@@ -233,6 +285,7 @@ KAI_HD uint64_t class_key(const KaiCtx& c, const ClassRec& k, int n) {
     }
     return key | v;
 }
+KAI_HD uint64_t class_key(const KaiCtx& c, const ClassRec& k, int n) { NodeRegs s; load_node(c, n, s); return class_key_regs(c, k, s); }
 KAI_HD bool key_better(uint64_t k, int n, uint64_t bk, int bn) { return k > bk || (k == bk && k != 0 && n < bn); }
 
 // ======================================================================================================
@@ -240,16 +293,20 @@ KAI_HD bool key_better(uint64_t k, int n, uint64_t bk, int bn) { return k > bk |
 //    void minmax(const KaiCtx&, int r, double& mn, double& mx)          — pack.go:66-86 over the node set (brute force)
 //    int  best_node(const KaiCtx&, const ScanReq&)                      — arg-max of (score, -index) over fitting nodes (brute force)
 //    void begin(const KaiCtx&)                                          — build the in-LDS levels of the class index
-//    void refresh(const KaiCtx&, const int32_t* blocks, int n)          — node state of these 64-node blocks changed
+//    bool dirty_add(int block) / int dirty_count()                      — list of 64-node blocks whose node state changed
+//    void refresh(const KaiCtx&)                                        — re-evaluate the listed blocks, clear the list
 //    void class_top(const KaiCtx&, int cls, uint64_t& key, int& node)   — arg-max of class_key over all nodes
 //    bool all_dead(const KaiCtx&)                                       — no class has a fitting node
+//    void hot(const KaiCtx&, QNode*&, int32_t*& qheap, int32_t*& root_heap) — where the job-order tree lives (LDS if it fits, else HBM)
 //    int64_t clock()
 // ======================================================================================================
 template <class Backend>
 struct Engine {
-    KaiCtx c; Backend& be;
-    int32_t dirty[KAI_MAXD]; int n_dirty = 0; bool fail_no_node = false;
-    KAI_HD Engine(const KaiCtx& ctx, Backend& b) : c(ctx), be(b) {}
+    const KaiCtx& c; Backend& be;
+    bool fail_no_node = false;
+    QNode* qn; int32_t *qheap, *root_heap; int root_len = 0, root_init = 0;
+    double total0, total1, total2;  // proportion totalResource (read-only during an action)
+    KAI_HD Engine(const KaiCtx& ctx, Backend& b) : c(ctx), be(b) { qn = ctx.qn; qheap = ctx.qheap; root_heap = ctx.root_heap; total0 = ctx.st->total[0]; total1 = ctx.st->total[1]; total2 = ctx.st->total[2]; }
 
     KAI_HD void fault(int code) { if (!c.st->fault) c.st->fault = code; }
     KAI_HD double preq(int p, int r) const { return c.p_req[(size_t)r * c.P + p]; }
@@ -268,17 +325,19 @@ struct Engine {
     KAI_HD double pquota(int p, int k) const { return k == KAI_Q_CPU ? preq(p, KAI_RES_CPU) : k == KAI_Q_MEM ? preq(p, KAI_RES_MEM) : preq(p, KAI_RES_GPU); }
 
     // ------------------------------------------------------------------ class index bookkeeping
+    // the dirty-block list lives in the backend (LDS on the device) so that this object holds no dynamically indexed storage
     KAI_HD void flush_index() {
-        if (n_dirty) { be.refresh(c, dirty, n_dirty); c.st->index_refreshes += n_dirty; n_dirty = 0; }
+        int nd = be.dirty_count();
+        if (nd) { int64_t t = be.clock(); be.refresh(c); c.st->index_refreshes += nd; c.st->prof[PF_REFRESH] += be.clock() - t; }
     }
     KAI_HD void mark_dirty(int n) {
         if (!c.use_index) return;
         int b = n / KAI_BLOCK;
-        for (int i = 0; i < n_dirty; i++) if (dirty[i] == b) return;
-        if (n_dirty == KAI_MAXD) flush_index();
-        dirty[n_dirty++] = b;
+        if (be.dirty_add(b)) return;
+        flush_index();  // list full
+        be.dirty_add(b);
     }
-    KAI_HD void invalidate_path(int q) { for (int x = q; x >= 0; x = c.q_parent[x]) c.qk_valid[x] = 0; }
+    KAI_HD void invalidate_path(int q) { for (int x = q; x >= 0; x = qn[x].parent) qn[x].flags &= ~QF_VALID; }
 
     // ------------------------------------------------------------------ status bookkeeping
     // PodGroupInfo.UpdateTaskStatus (api/podgroup_info/job_info.go:228-287) + PodSet.AssignTask (subgroup_info/podset.go:56-99)
@@ -335,13 +394,13 @@ struct Engine {
         if (!(c.plugins & KAI_PLUGIN_PROPORTION)) return;
         if (!c.p_accepted[p]) return;  // AcceptedResource is empty until the task was added to a node
         int j = c.p_job[p]; bool np = !c.j_preempt[j];
-        for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) {
+        for (int q = c.j_queue[j]; q >= 0; q = qn[q].parent) {
             for (int k = 0; k < 3; k++) {
                 QShare& s = c.q_share[(size_t)q * 3 + k]; double v = pquota(p, k);
                 s.allocated += sign * v;
                 if (np) s.allocated_np += sign * v;
             }
-            c.qk_valid[q] = 0;
+            qn[q].flags &= ~QF_VALID;
         }
     }
 
@@ -557,7 +616,7 @@ struct Engine {
         for (int k = 0; k < 3; k++) {
             const QShare& s = c.q_share[(size_t)q * 3 + k];
             double allocatable = qs_allocatable(s);
-            if (allocatable == KAI_UNLIMITED) allocatable = c.st->total[k];
+            if (allocatable == KAI_UNLIMITED) allocatable = k == 0 ? total0 : k == 1 ? total1 : total2;
             double allocated = s.allocated; if (add) allocated += add[k];
             double v = allocatable == 0 ? allocated * 1000 : allocated / allocatable;
             dom = kmax(dom, v);
@@ -569,18 +628,19 @@ struct Engine {
         if (b == KAI_UNLIMITED) return -1;
         return a > b ? 1 : a < b ? -1 : 0;
     }
-    // getBestJobFromNode :309-318 (pending ordering)
+    // getBestJobFromNode :309-318 (pending ordering); a node whose key is valid already knows the best job of its subtree
     KAI_HD int best_job_from_node(int q) {
         for (;;) {
-            if (q_is_leaf(q)) return leaf_top(q);
-            if (c.qheap_len[q] == 0) return -1;
-            q = c.qheap[c.q_child_off[q]];
+            const QNode& n = qn[q];
+            if (n.flags & (QF_VALID | QF_TOP)) return n.best_job;
+            if (n.flags & QF_LEAF) { int t = leaf_top(q); qn[q].best_job = t; qn[q].flags |= QF_TOP; return t; }
+            if (n.len == 0) return -1;
+            q = qheap[n.heap_off];
         }
     }
     // operands of queue_order.GetQueueOrderResult for queue q with the best job of its subtree, cached until q's shares or best job change
-    KAI_HD const QKey& queue_key(int q) {
-        QKey& key = c.qkey[q];
-        if (c.qk_valid[q]) return key;
+    KAI_HD void queue_key(int q) {
+        if (qn[q].flags & QF_VALID) return;
         const QShare* L = &c.q_share[(size_t)q * 3];
         int bj = best_job_from_node(q);
         double req[3] = {0, 0, 0};
@@ -593,21 +653,21 @@ struct Engine {
             if (cmp_q(with_job, L[k].deserved) > 0) starved = false;          // prioritizeUnderQuotaWithJob :100-125
             if (qs_allocatable(L[k]) == 0 && with_job > 0) viol = true;       // penalizeZeroShareWithJob :127-176
         }
-        if (over) bits |= 1; if (starved) bits |= 2; if (viol) bits |= 4;
-        key.bits = bits; key.best_job = bj;
-        key.dom_with_job = dominant_share(q, req);   // :178-196, 242-273
-        key.dom_no_job = dominant_share(q, nullptr); // :198-212
-        c.qk_valid[q] = 1;
-        return key;
+        if (over) bits |= QF_OVER; if (starved) bits |= QF_STARVED; if (viol) bits |= QF_VIOL;
+        double dwj = dominant_share(q, req), dnj = dominant_share(q, nullptr);  // :178-196, 242-273 ; :198-212
+        QNode& n = qn[q];
+        n.best_job = bj; n.dom_with_job = dwj; n.dom_no_job = dnj;
+        n.flags = (n.flags & ~(QF_OVER | QF_STARVED | QF_VIOL)) | bits | QF_VALID;
     }
     // plugins/proportion/queue_order/queue_order.go:19-73 (allocate ordering: no victims)
     KAI_HD int queue_order(int lq, int rq) {
-        const QKey kl = queue_key(lq); const QKey kr = queue_key(rq);
-        { bool lo = kl.bits & 1, ro = kr.bits & 1; if (!lo && ro) return -1; if (lo && !ro) return 1; }
-        { bool ls = kl.bits & 2, rs = kr.bits & 2; if (ls && !rs) return -1; if (rs && !ls) return 1; }
-        if (c.q_prio[lq] > c.q_prio[rq]) return -1;  // prioritizePrioritized :76-85
-        if (c.q_prio[lq] < c.q_prio[rq]) return 1;
-        { bool lv = kl.bits & 4, rv = kr.bits & 4; if (lv && !rv) return 1; if (!lv && rv) return -1; }
+        queue_key(lq); queue_key(rq);
+        const QNode kl = qn[lq]; const QNode kr = qn[rq];
+        { bool lo = kl.flags & QF_OVER, ro = kr.flags & QF_OVER; if (!lo && ro) return -1; if (lo && !ro) return 1; }
+        { bool ls = kl.flags & QF_STARVED, rs = kr.flags & QF_STARVED; if (ls && !rs) return -1; if (rs && !ls) return 1; }
+        if (kl.prio > kr.prio) return -1;  // prioritizePrioritized :76-85
+        if (kl.prio < kr.prio) return 1;
+        { bool lv = kl.flags & QF_VIOL, rv = kr.flags & QF_VIOL; if (lv && !rv) return 1; if (!lv && rv) return -1; }
         if (kl.dom_with_job < kr.dom_with_job) return -1; if (kl.dom_with_job > kr.dom_with_job) return 1;
         if (kl.dom_no_job < kr.dom_no_job) return -1; if (kl.dom_no_job > kr.dom_no_job) return 1;
         {   // prioritizeBasedOnAllocatableShare :214-224
@@ -626,7 +686,7 @@ struct Engine {
         return c.q_created[lq] < c.q_created[rq];
     }
     KAI_HD bool over_limit(int j, const double* req) const {  // capacity_policy/max_allowed_check.go:20-66
-        for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
+        for (int q = c.j_queue[j]; q >= 0; q = qn[q].parent) for (int k = 0; k < 3; k++) {
             const QShare& s = c.q_share[(size_t)q * 3 + k];
             if (s.max_allowed == KAI_UNLIMITED) continue;
             if (req[k] == 0) continue;
@@ -636,7 +696,7 @@ struct Engine {
     }
     KAI_HD bool np_over_quota(int j, const double* req) const {  // capacity_policy/quota_check.go:27-77
         if (c.j_preempt[j]) return false;
-        for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
+        for (int q = c.j_queue[j]; q >= 0; q = qn[q].parent) for (int k = 0; k < 3; k++) {
             const QShare& s = c.q_share[(size_t)q * 3 + k];
             if (s.deserved == KAI_UNLIMITED) continue;
             if (req[k] == 0) continue;
@@ -663,8 +723,8 @@ struct Engine {
     // for jobs that come back with a changed key (allocate.go:69-72).  Inner nodes order their children with the proportion
     // comparator, which is not a total order in every corner, so they stay array heaps with container/heap's exact sift rules
     // (scheduler_util/priority_queue.go) and the lazy needsReorder protocol.
-    KAI_HD bool q_is_leaf(int q) const { return c.q_child_off[q + 1] == c.q_child_off[q]; }
-    KAI_HD int leaf_len(int q) const { return (c.lq_end[q] - c.lq_cur[q]) + c.lq_side_len[q]; }
+    KAI_HD bool q_is_leaf(int q) const { return qn[q].flags & QF_LEAF; }
+    KAI_HD int leaf_len_mem(int q) const { return (c.lq_end[q] - c.lq_cur[q]) + c.lq_side_len[q]; }
     KAI_HD int leaf_top(int q) const {
         int a = c.lq_cur[q] < c.lq_end[q] ? c.lq_sorted[c.q_job_off[q] + c.lq_cur[q]] : -1;
         int b = c.lq_side_len[q] > 0 ? c.lq_side[c.q_job_off[q]] : -1;
@@ -691,6 +751,7 @@ struct Engine {
     KAI_HD int leaf_pop(int q) {
         int a = c.lq_cur[q] < c.lq_end[q] ? c.lq_sorted[c.q_job_off[q] + c.lq_cur[q]] : -1;
         int b = c.lq_side_len[q] > 0 ? c.lq_side[c.q_job_off[q]] : -1;
+        qn[q].len--; qn[q].flags &= ~QF_TOP;
         if (b < 0 || (a >= 0 && !job_order(b, a))) { c.lq_cur[q]++; return a; }
         int32_t* h = c.lq_side + c.q_job_off[q]; int n = c.lq_side_len[q] - 1;
         int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); c.lq_side_len[q] = n;
@@ -700,26 +761,27 @@ struct Engine {
         int32_t* h = c.lq_side + c.q_job_off[q]; int n = c.lq_side_len[q];
         if (n >= c.q_job_off[q + 1] - c.q_job_off[q]) { fault(FAULT_HEAP); return; }
         h[n] = j; c.lq_side_len[q] = n + 1; heap_up(h, n, JobLess{this});
+        qn[q].len++; qn[q].flags &= ~QF_TOP;
     }
-    KAI_HD bool node_children_empty(int q) const { return q_is_leaf(q) ? leaf_len(q) == 0 : c.qheap_len[q] == 0; }
     KAI_HD bool node_less(int l, int r) {  // buildNodeOrderFn :280-305
-        if (node_children_empty(l)) return true;
-        if (node_children_empty(r)) return false;
+        if (qn[l].len == 0) return true;
+        if (qn[r].len == 0) return false;
         return queue_order_fn(l, r);
     }
-    KAI_HD int32_t* node_heap(int parent) { return parent < 0 ? c.root_heap : c.qheap + c.q_child_off[parent]; }
-    KAI_HD int32_t& node_heap_len(int parent) { return parent < 0 ? c.st->root_len : c.qheap_len[parent]; }
-    KAI_HD void node_heap_push(int parent, int q) { int32_t* h = node_heap(parent); int32_t& n = node_heap_len(parent); h[n++] = q; heap_up(h, n - 1, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
-    KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int32_t& n = node_heap_len(parent); n--; int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
+    KAI_HD int32_t* node_heap(int parent) { return parent < 0 ? root_heap : qheap + qn[parent].heap_off; }
+    KAI_HD int node_heap_len(int parent) const { return parent < 0 ? root_len : qn[parent].len; }
+    KAI_HD void set_heap_len(int parent, int n) { if (parent < 0) root_len = n; else qn[parent].len = n; }
+    KAI_HD void node_heap_push(int parent, int q) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); h[n] = q; set_heap_len(parent, n + 1); heap_up(h, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
+    KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent) - 1; set_heap_len(parent, n); int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
     KAI_HD void node_heap_fix0(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); if (!heap_down(h, 0, n, NodeLess{this})) heap_up(h, 0, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
 
     KAI_HD void ensure_ancestor_chain(int child) {  // :134-176
         for (;;) {
-            int parent = c.q_parent[child];
-            if (parent < 0) { if (!c.qn_linked[child]) { c.st->root_init = 1; c.qn_linked[child] = 1; node_heap_push(-1, child); } return; }
-            bool parent_new = !c.qn_exists[parent];
-            if (parent_new) { c.qn_exists[parent] = 1; c.qn_reorder[parent] = 0; c.qn_linked[parent] = 0; c.qheap_len[parent] = 0; }
-            if (!c.qn_linked[child]) { c.qn_linked[child] = 1; node_heap_push(parent, child); }
+            int parent = qn[child].parent;
+            if (parent < 0) { if (!(qn[child].flags & QF_LINKED)) { root_init = 1; qn[child].flags |= QF_LINKED; node_heap_push(-1, child); } return; }
+            bool parent_new = !(qn[parent].flags & QF_EXISTS);
+            if (parent_new) { qn[parent].flags = (qn[parent].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS; qn[parent].len = 0; }
+            if (!(qn[child].flags & QF_LINKED)) { qn[child].flags |= QF_LINKED; node_heap_push(parent, child); }
             if (!parent_new) return;
             child = parent;
         }
@@ -727,35 +789,34 @@ struct Engine {
     KAI_HD void push_job(int j) {  // :91-120
         int q = c.j_queue[j];
         if (!q_is_leaf(q)) return;
-        bool needs_linking = !c.qn_exists[q];
-        if (needs_linking) { c.qn_exists[q] = 1; c.qn_reorder[q] = 0; c.qn_linked[q] = 0; }
+        bool needs_linking = !(qn[q].flags & QF_EXISTS);
+        if (needs_linking) qn[q].flags = (qn[q].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS;
         leaf_push(q, j);
         invalidate_path(q);
         if (needs_linking) ensure_ancestor_chain(q);
-        for (int x = q; x >= 0; x = c.q_parent[x]) c.qn_reorder[x] = 1;  // markAncestorsForReorder: parent pointers follow the queue tree
+        for (int x = q; x >= 0; x = qn[x].parent) qn[x].flags |= QF_REORDER;  // markAncestorsForReorder: parent pointers follow the queue tree
     }
     KAI_HD int next_node(int parent) {  // getNextNode :194-217
         for (;;) {
             if (node_heap_len(parent) == 0) return -1;
             int q = node_heap(parent)[0];
-            if (c.qn_reorder[q]) { node_heap_fix0(parent); c.qn_reorder[q] = 0; continue; }
-            if (node_children_empty(q)) return -1;
+            if (qn[q].flags & QF_REORDER) { node_heap_fix0(parent); qn[q].flags &= ~QF_REORDER; continue; }
+            if (qn[q].len == 0) return -1;
             return q;
         }
     }
     KAI_HD void handle_pop_from_node(int q) {  // :221-245
         for (;;) {
-            int len = q_is_leaf(q) ? leaf_len(q) : c.qheap_len[q];
-            if (len != 0) { for (int x = q; x >= 0; x = c.q_parent[x]) c.qn_reorder[x] = 1; return; }
-            int parent = c.q_parent[q];
+            if (qn[q].len != 0) { for (int x = q; x >= 0; x = qn[x].parent) qn[x].flags |= QF_REORDER; return; }
+            int parent = qn[q].parent;
             node_heap_pop(parent);  // removeNodeFromParent: the node is at the top of its parent's heap
-            c.qn_exists[q] = 0; c.qn_linked[q] = 0;
+            qn[q].flags &= ~(QF_EXISTS | QF_LINKED);
             if (parent < 0) return;
             q = parent;
         }
     }
     KAI_HD int pop_next_job() {  // :61-89
-        if (!c.st->root_init || c.st->root_len == 0) return -1;
+        if (!root_init || root_len == 0) return -1;
         int parent = -1, q;
         for (;;) { q = next_node(parent); if (q < 0) return -1; if (q_is_leaf(q)) break; parent = q; }  // traverseToLeaf :179-191
         int job = leaf_pop(q);
@@ -771,23 +832,23 @@ struct Engine {
         int b0 = c.q_child_off[x], b1 = c.q_child_off[x + 1], best = -1, live = 0;
         for (int i = b0; i < b1; i++) {
             int k = c.q_children[i];
-            bool alive = q_is_leaf(k) ? leaf_len(k) > 0 : c.qheap_len[k] > 0;
-            if (!alive) continue;
+            if (qn[k].len == 0) continue;
             live++;
             if (best < 0 || node_less(k, best)) best = k;
         }
         if (!live) return;
-        if (parent >= 0) { c.qn_exists[parent] = 1; c.qn_reorder[parent] = 1; } else c.st->root_init = 1;
-        c.qn_exists[best] = 1; c.qn_linked[best] = 1; c.qn_reorder[best] = 1; node_heap_push(parent, best);
+        if (parent >= 0) qn[parent].flags |= QF_EXISTS | QF_REORDER; else root_init = 1;
+        qn[best].flags |= QF_EXISTS | QF_LINKED | QF_REORDER; node_heap_push(parent, best);
         for (int i = b0; i < b1; i++) {
             int k = c.q_children[i]; if (k == best) continue;
-            bool alive = q_is_leaf(k) ? leaf_len(k) > 0 : c.qheap_len[k] > 0;
-            if (!alive) continue;
-            c.qn_exists[k] = 1; c.qn_linked[k] = 1; c.qn_reorder[k] = 1; node_heap_push(parent, k);
+            if (qn[k].len == 0) continue;
+            qn[k].flags |= QF_EXISTS | QF_LINKED | QF_REORDER;
+            // the heap length of an inner node counts linked children only: children are appended as they are pushed
+            node_heap_push(parent, k);
         }
     }
     KAI_HD void truncate_leaf(int q, int depth) {  // PriorityQueue.Push with a finite maxQueueSize under sorted pushes keeps the best `depth` jobs
-        while (leaf_len(q) > depth) {
+        while (leaf_len_mem(q) > depth) {
             int a = c.lq_cur[q] < c.lq_end[q] ? c.lq_sorted[c.q_job_off[q] + c.lq_end[q] - 1] : -1;
             int32_t* h = c.lq_side + c.q_job_off[q]; int n = c.lq_side_len[q], wi = -1;
             for (int i = 0; i < n; i++) if (wi < 0 || job_order(h[wi], h[i])) wi = i;
@@ -795,10 +856,10 @@ struct Engine {
             h[wi] = h[n - 1]; c.lq_side_len[q] = n - 1;
             for (int i = (n - 1) / 2; i >= 0; i--) heap_down(h, i, n - 1, JobLess{this});
         }
+        qn[q].len = leaf_len_mem(q); qn[q].flags &= ~QF_TOP;
     }
-    KAI_HD void init_jobs_order() {
-        c.st->root_len = 0; c.st->root_init = 0;
-        for (int q = 0; q < c.Q; q++) { c.qn_exists[q] = 0; c.qn_reorder[q] = 0; c.qn_linked[q] = 0; c.qheap_len[q] = 0; c.qk_valid[q] = 0; }
+    KAI_HD void init_jobs_order() {  // qn[] comes from k_leaf_init: static fields, flags = QF_LEAF or 0, len = queued jobs of a leaf, 0 for inner nodes
+        root_len = 0; root_init = 0;
         if (c.queue_depth > 0) for (int q = 0; q < c.Q; q++) if (q_is_leaf(q)) truncate_leaf(q, c.queue_depth);
         for (int i = 0; i < c.Q; i++) { int x = c.q_depth_order[i]; if (!q_is_leaf(x)) link_children(x); }
         link_children(c.Q);
@@ -832,19 +893,28 @@ struct Engine {
     }
     KAI_HD bool allocate_task(int p, bool pipeline_only) {  // :121-163
         c.st->decisions++;
+        int64_t t0 = be.clock();
         // predicates step 1 is node independent on this path (capacity_policy.go:51-61): evaluate it once
-        if ((c.plugins & KAI_PLUGIN_PREDICATES) && task_over_capacity(p)) return false;
+        bool over = (c.plugins & KAI_PLUGIN_PREDICATES) && task_over_capacity(p);
+        int64_t t1 = be.clock(); c.st->prof[PF_TASKCAP] += t1 - t0;
+        if (over) return false;
         bool allocatable = false;
         int n = find_node(p, allocatable);
+        int64_t t2 = be.clock(); c.st->prof[PF_FIND] += t2 - t1;
         if (n < 0) { fail_no_node = true; return false; }
         // allocateTaskToNode :165-174
-        if (!pipeline_only && allocatable) return stmt_allocate(p, n);
-        return stmt_pipeline(p, n, !pipeline_only);
+        bool ok = (!pipeline_only && allocatable) ? stmt_allocate(p, n) : stmt_pipeline(p, n, !pipeline_only);
+        c.st->prof[PF_STMT] += be.clock() - t2;
+        return ok;
     }
     KAI_HD bool allocate_job(int j, bool pipeline_only) {  // AllocateJob :20-36 → allocateSubGroupSet :38-81 → allocatePodSet :83-119
         if (c.j_n_ps[j] > 64) { fault(FAULT_INTERNAL); return false; }  // engine limit: 64 pod-sets per job
+        int64_t t0 = be.clock();
         ensure_tta(j, !pipeline_only);
-        if (job_over_queue_capacity(j)) return false;
+        int64_t t1 = be.clock(); c.st->prof[PF_TTA] += t1 - t0;
+        bool gated = job_over_queue_capacity(j);
+        c.st->prof[PF_GATE] += be.clock() - t1;
+        if (gated) return false;
         int cp_root = checkpoint();
         int first = c.j_first_pod[j], nt = c.j_tta_n[j], nps = c.j_n_ps[j], ps0 = c.j_first_ps[j];
         // the cached chunk is consumed below while statuses change, so snapshot it (Go holds the slice it got)
@@ -861,7 +931,7 @@ struct Engine {
             int s = ps0 + best;
             int cp = checkpoint(); bool ok = true;
             for (int i = 0; i < nt; i++) { int p = chunk[i]; if (c.p_podset[p] != s) continue; if (!allocate_task(p, pipeline_only)) { ok = false; break; } }
-            if (!ok) { rollback(cp); rollback(cp_root); return false; }
+            if (!ok) { int64_t tr = be.clock(); rollback(cp); rollback(cp_root); c.st->prof[PF_ROLLBACK] += be.clock() - tr; return false; }
         }
         return true;
     }
@@ -876,6 +946,7 @@ struct Engine {
     }
     KAI_HD void execute_allocate() {  // actions/allocate/allocate.go:46-77
         int64_t t0 = be.clock(), t;
+        be.hot(c, qn, qheap, root_heap);
         be.begin(c);
         init_jobs_order();
         t = be.clock(); c.st->prof[5] += t - t0;
@@ -897,7 +968,7 @@ struct Engine {
             if (ok) {
                 c.st->jobs_committed++;
                 commit();
-                if (c.j_n_pending[j] > 0) push_job(j);  // HasTasksToAllocate(job, true)
+                if (c.j_n_pending[j] > 0) { int64_t tp = be.clock(); push_job(j); c.st->prof[PF_PUSH] += be.clock() - tp; }  // HasTasksToAllocate(job, true)
             } else {
                 discard();
             }
@@ -1033,6 +1104,14 @@ KAI_HD uint8_t job_init_state(const KaiCtx& c, int j) {
     }
     if (!(c.plugins & KAI_PLUGIN_ELASTIC)) return 0;                   // without the elastic plugin the state does not enter JobOrderFn
     return below ? 0 : exactly ? 1 : 2;
+}
+
+// job-order tree node of queue q at action start (k_leaf_init lane 0 / host_sim): static fields + queued jobs of a leaf
+KAI_HD void qnode_init(const KaiCtx& c, int q, int queued) {
+    QNode n; n.dom_with_job = 0; n.dom_no_job = 0; n.best_job = -1; n.prio = c.q_prio[q]; n.heap_off = c.q_child_off[q]; n.parent = c.q_parent[q];
+    bool leaf = c.q_child_off[q + 1] == c.q_child_off[q];
+    n.len = leaf ? queued : 0; n.flags = leaf ? QF_LEAF : 0;
+    c.qn[q] = n;
 }
 
 }  // namespace kai

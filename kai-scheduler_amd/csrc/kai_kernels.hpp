@@ -9,7 +9,7 @@
 //    node SoA (resource-major, so a wavefront reads 64 consecutive nodes of one resource = one 512-byte request);
 //  * the drain kernel: once no class has a fitting node, the jobs still queued are resolved chip-wide.
 //
-// wave = 64 lanes; workgroup = 1024 threads = 16 wavefronts (1 control + 15 service waves).
+// wave = 64 lanes; workgroup = 512 threads = 8 wavefronts (1 control + 7 service waves).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -17,7 +17,7 @@
 
 namespace kai {
 
-constexpr int WG = 1024;        // threads per workgroup of the action kernel
+constexpr int WG = 512;         // threads per workgroup of the action kernel (8 waves: the control lane's code wants > 128 VGPRs)
 constexpr int WAVES = WG / 64;  // 16
 constexpr int SCAN_LANES = WG - 64;
 constexpr int SVC = WAVES - 1;  // service waves
@@ -164,8 +164,9 @@ __global__ void k_index_build(KaiCtx c) {
     int b = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (b >= c.NB) return;
     int lane = threadIdx.x & 63, n = b * KAI_BLOCK + lane;
+    NodeRegs ns; load_node(c, n < c.N ? n : 0, ns);
     for (int k = 0; k < c.C; k++) {
-        uint64_t key = n < c.N ? class_key(c, c.cls[k], n) : 0; int bn = n;
+        uint64_t key = n < c.N ? class_key_regs(c, c.cls[k], ns) : 0; int bn = n;
         wave_argmax(key, bn);
         if (lane == 0) { c.sum1_key[(size_t)k * c.NB + b] = key; c.sum1_node[(size_t)k * c.NB + b] = bn; }
     }
@@ -178,15 +179,29 @@ struct NullBackend {  // kernels that only need the engine's pure helpers
     __device__ void minmax(const KaiCtx&, int, double&, double&) {}
     __device__ int best_node(const KaiCtx&, const ScanReq&) { return -1; }
     __device__ void begin(const KaiCtx&) {}
-    __device__ void refresh(const KaiCtx&, const int32_t*, int) {}
+    __device__ bool dirty_add(int) { return true; }
+    __device__ int dirty_count() { return 0; }
+    __device__ void refresh(const KaiCtx&) {}
     __device__ void class_top(const KaiCtx&, int, uint64_t& k, int& n) { k = 0; n = -1; }
     __device__ bool all_dead(const KaiCtx&) { return false; }
+    __device__ void hot(const KaiCtx&, QNode*&, int32_t*&, int32_t*&) {}
     __device__ int64_t clock() { return 0; }
 };
 
+// static fields of the job-order tree records (parent chain, priority, heap offsets): valid from session open on
+__global__ void k_qnode_static(KaiCtx c) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < c.Q) qnode_init(c, q, 0);
+}
 __global__ void k_job_init(KaiCtx c) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < c.J) c.j_state[j] = job_init_state(c, j);
+    if (j >= c.J) return;
+    uint8_t st = job_init_state(c, j);
+    c.j_state[j] = st;
+    // the tasks-to-allocate chunk of every queued job (allocation_info.go:27-113), which the queue comparator reads for the best
+    // job of each queue: computed here chip-wide instead of lazily by the control lane.  Nothing is virtual before the first
+    // statement of an action, so the chunk does not depend on isRealAllocation.
+    if (st != 3 && c.j_n_ps[j] <= 64) { NullBackend nb; Engine<NullBackend> eng(c, nb); eng.ensure_tta(j, true); }
 }
 // One wavefront per leaf queue: stable compaction of the eligible "below minAvailable" jobs (host order: priority desc,
 // creation, uid) into the leaf's sorted region; the few jobs in another elastic state go to the leaf's side heap.
@@ -207,6 +222,7 @@ __global__ void k_leaf_init(KaiCtx c) {
     __threadfence_block();
     if (lane == 0) {
         c.lq_cur[q] = 0; c.lq_end[q] = cnt; c.lq_side_len[q] = 0;
+        qnode_init(c, q, cnt + side);
         if (side) {
             NullBackend nb; Engine<NullBackend> eng(c, nb);
             int32_t* h = c.lq_side + b;
@@ -218,7 +234,12 @@ __global__ void k_leaf_init(KaiCtx c) {
 // ------------------------------------------------------------------------------------------------------
 // the persistent action kernel
 // ------------------------------------------------------------------------------------------------------
-enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5 };
+enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5, CMD_LOADTREE = 6 };
+
+// dynamic LDS of k_action / k_best_node: [s2_key C*NSB u64][s2_node C*NSB i32] and, when tree_in_lds, [QNode Q][qheap Q+1][root_heap Q+1]
+extern __shared__ __align__(16) unsigned char kai_dyn_lds[];
+__host__ __device__ inline size_t lds_index_bytes(int C, int NSB) { return (((size_t)C * NSB * 12) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t lds_tree_bytes(int Q) { return (size_t)Q * sizeof(QNode) + 2 * (size_t)(Q + 1) * 4 + 16; }
 
 struct ActShared {
     ScanReq req;
@@ -228,7 +249,9 @@ struct ActShared {
     unsigned long long part_key[WAVES];  // orderable score bits
     int32_t part_node[WAVES];
     unsigned long long top_key[KAI_CMAX]; int32_t top_node[KAI_CMAX];
-    unsigned long long s2_key[KAI_CMAX * KAI_NSB_MAX]; int32_t s2_node[KAI_CMAX * KAI_NSB_MAX];
+    unsigned long long* s2_key; int32_t* s2_node;  // [C][NSB] in dynamic LDS
+    QNode* qn; int32_t *qheap, *root_heap;          // job-order tree: dynamic LDS when it fits, else the HBM arrays
+    int32_t tree_in_lds, pad1;
 };
 
 // monotone map f64 → u64 (larger double ⇒ larger key); scores here are finite and ≥ 0 but keep it general
@@ -262,12 +285,21 @@ struct DevBackend {
         return best;
     }
     __device__ void begin(const KaiCtx& c) { if (c.use_index) call(CMD_BEGIN); }
-    __device__ void refresh(const KaiCtx&, const int32_t* blocks, int n) {
-        for (int i = 0; i < n; i++) sh->dirty[i] = blocks[i];
-        sh->n_dirty = n; call(CMD_REFRESH);
+    __device__ bool dirty_add(int b) {
+        int n = sh->n_dirty;
+        for (int i = 0; i < n; i++) if (sh->dirty[i] == b) return true;
+        if (n == KAI_MAXD) return false;
+        sh->dirty[n] = b; sh->n_dirty = n + 1;
+        return true;
     }
+    __device__ int dirty_count() { return sh->n_dirty; }
+    __device__ void refresh(const KaiCtx&) { call(CMD_REFRESH); sh->n_dirty = 0; }
     __device__ void class_top(const KaiCtx&, int k, uint64_t& key, int& node) { key = sh->top_key[k]; node = sh->top_node[k]; }
     __device__ bool all_dead(const KaiCtx& c) { for (int k = 0; k < c.C; k++) if (sh->top_key[k]) return false; return true; }
+    __device__ void hot(const KaiCtx&, QNode*& qn, int32_t*& qheap, int32_t*& root_heap) {
+        if (sh->tree_in_lds) call(CMD_LOADTREE);  // service waves copy the k_leaf_init records HBM → LDS
+        qn = sh->qn; qheap = sh->qheap; root_heap = sh->root_heap;
+    }
     __device__ int64_t clock() { return (int64_t)clock64(); }
     __device__ void finish() { sh->cmd = CMD_EXIT; __syncthreads(); }
 };
@@ -277,10 +309,10 @@ __device__ __forceinline__ void svc_l2(const KaiCtx& c, ActShared* sh, int k, in
     int e = sb * 64 + lane;
     uint64_t key = e < c.NB ? c.sum1_key[(size_t)k * c.NB + e] : 0; int n = e < c.NB ? c.sum1_node[(size_t)k * c.NB + e] : 0x7fffffff;
     wave_argmax(key, n);
-    if (lane == 0) { sh->s2_key[k * KAI_NSB_MAX + sb] = key; sh->s2_node[k * KAI_NSB_MAX + sb] = n; }
+    if (lane == 0) { sh->s2_key[k * c.NSB + sb] = key; sh->s2_node[k * c.NSB + sb] = n; }
 }
 __device__ __forceinline__ void svc_top(const KaiCtx& c, ActShared* sh, int k, int lane) {
-    uint64_t key = lane < c.NSB ? sh->s2_key[k * KAI_NSB_MAX + lane] : 0; int n = lane < c.NSB ? sh->s2_node[k * KAI_NSB_MAX + lane] : 0x7fffffff;
+    uint64_t key = lane < c.NSB ? sh->s2_key[k * c.NSB + lane] : 0; int n = lane < c.NSB ? sh->s2_node[k * c.NSB + lane] : 0x7fffffff;
     wave_argmax(key, n);
     if (lane == 0) { sh->top_key[k] = key; sh->top_node[k] = n; }
 }
@@ -293,7 +325,11 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
         __syncthreads();  // wait for a command
         int cmd = sh->cmd;
         if (cmd == CMD_EXIT) return;
-        if (cmd == CMD_BEGIN) {
+        if (cmd == CMD_LOADTREE) {
+            const int4* src = reinterpret_cast<const int4*>(c.qn); int4* dst = reinterpret_cast<int4*>(sh->qn);
+            int n16 = (int)(((size_t)c.Q * sizeof(QNode) + 15) / 16);
+            for (int i = slot; i < n16; i += SCAN_LANES) dst[i] = src[i];
+        } else if (cmd == CMD_BEGIN) {
             for (int k = hw; k < c.C; k += SVC) {
                 for (int sb = 0; sb < c.NSB; sb++) svc_l2(c, sh, k, sb, lane);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -301,24 +337,43 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
             }
         } else if (cmd == CMD_REFRESH) {
             const int nd = sh->n_dirty;
-            // L1: re-evaluate the dirty blocks for this wave's classes
-            for (int i = 0; i < nd; i++) {
-                int b = sh->dirty[i], n = b * KAI_BLOCK + lane;
+            if (nd == 1) {  // the common case (one placement): everything in one pass, upper levels patched in registers
+                const int b = sh->dirty[0], n = b * KAI_BLOCK + lane, sb = b / 64, e = sb * 64 + lane;
+                NodeRegs ns; load_node(c, n < c.N ? n : 0, ns);
                 for (int k = hw; k < c.C; k += SVC) {
-                    uint64_t key = n < c.N ? class_key(c, c.cls[k], n) : 0; int bn = n;
+                    uint64_t rk = e < c.NB ? c.sum1_key[(size_t)k * c.NB + e] : 0; int rn = e < c.NB ? c.sum1_node[(size_t)k * c.NB + e] : 0x7fffffff;  // L1 row, in flight with the node loads
+                    uint64_t tk = lane < c.NSB ? sh->s2_key[k * c.NSB + lane] : 0; int tn = lane < c.NSB ? sh->s2_node[k * c.NSB + lane] : 0x7fffffff;
+                    uint64_t key = n < c.N ? class_key_regs(c, c.cls[k], ns) : 0; int bn = n;
                     wave_argmax(key, bn);
                     if (lane == 0) { c.sum1_key[(size_t)k * c.NB + b] = key; c.sum1_node[(size_t)k * c.NB + b] = bn; }
+                    if (lane == (b & 63)) { rk = key; rn = bn; }
+                    wave_argmax(rk, rn);
+                    if (lane == 0) { sh->s2_key[k * c.NSB + sb] = rk; sh->s2_node[k * c.NSB + sb] = rn; }
+                    if (lane == sb) { tk = rk; tn = rn; }
+                    wave_argmax(tk, tn);
+                    if (lane == 0) { sh->top_key[k] = tk; sh->top_node[k] = tn; }
                 }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // this wave re-reads its own L1 rows
-            for (int k = hw; k < c.C; k += SVC) {
+            } else {
+                // L1: re-evaluate the dirty blocks for this wave's classes
                 for (int i = 0; i < nd; i++) {
-                    int sb = sh->dirty[i] / 64; bool seen = false;
-                    for (int x = 0; x < i; x++) if (sh->dirty[x] / 64 == sb) seen = true;
-                    if (!seen) svc_l2(c, sh, k, sb, lane);
+                    int b = sh->dirty[i], n = b * KAI_BLOCK + lane;
+                    NodeRegs ns; load_node(c, n < c.N ? n : 0, ns);
+                    for (int k = hw; k < c.C; k += SVC) {
+                        uint64_t key = n < c.N ? class_key_regs(c, c.cls[k], ns) : 0; int bn = n;
+                        wave_argmax(key, bn);
+                        if (lane == 0) { c.sum1_key[(size_t)k * c.NB + b] = key; c.sum1_node[(size_t)k * c.NB + b] = bn; }
+                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                svc_top(c, sh, k, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // this wave re-reads its own L1 rows
+                for (int k = hw; k < c.C; k += SVC) {
+                    for (int i = 0; i < nd; i++) {
+                        int sb = sh->dirty[i] / 64; bool seen = false;
+                        for (int x = 0; x < i; x++) if (sh->dirty[x] / 64 == sb) seen = true;
+                        if (!seen) svc_l2(c, sh, k, sb, lane);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    svc_top(c, sh, k, lane);
+                }
             }
         } else if (cmd == CMD_MINMAX) {  // getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86)
             int r = sh->r;
@@ -352,9 +407,17 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
 }
 
 // One workgroup; wave 0 lane 0 = control, waves 1..15 = service.
-__global__ void __launch_bounds__(WG) k_action(KaiCtx c, int action) {
+__global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, int action, int tree_in_lds) {
+    const KaiCtx& c = *cp;  // the context sits in HBM: uniform, read-only, no-alias loads → scalar loads, hoistable across the stores of the engine
     __shared__ ActShared sh;
-    if (threadIdx.x == 0) sh.cmd = CMD_NONE;
+    if (threadIdx.x == 0) {
+        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds;
+        size_t off = 0;
+        sh.s2_key = reinterpret_cast<unsigned long long*>(kai_dyn_lds); sh.s2_node = reinterpret_cast<int32_t*>(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
+        off = lds_index_bytes(c.C, c.NSB);
+        if (tree_in_lds) { sh.qn = reinterpret_cast<QNode*>(kai_dyn_lds + off); sh.qheap = reinterpret_cast<int32_t*>(kai_dyn_lds + off + (size_t)c.Q * sizeof(QNode)); sh.root_heap = sh.qheap + (c.Q + 1); }
+        else { sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
+    }
     __syncthreads();
     if (threadIdx.x >= 64) { service_loop(c, &sh); return; }
     if (threadIdx.x != 0) return;  // the rest of wave 0 idles: s_barrier counts wavefronts, not lanes
@@ -387,8 +450,16 @@ __global__ void k_drain(KaiCtx c, const int32_t* slot_queue) {
 
 // kai_best_node: one OrderedNodesByTask + FittingNode against the current session state (brute-force scan)
 __global__ void __launch_bounds__(WG) k_best_node(KaiCtx c, int pod, int pipeline_only, int32_t* out) {
+    const int tree_in_lds = 0;
     __shared__ ActShared sh;
-    if (threadIdx.x == 0) sh.cmd = CMD_NONE;
+    if (threadIdx.x == 0) {
+        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds;
+        size_t off = 0;
+        sh.s2_key = reinterpret_cast<unsigned long long*>(kai_dyn_lds); sh.s2_node = reinterpret_cast<int32_t*>(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
+        off = lds_index_bytes(c.C, c.NSB);
+        if (tree_in_lds) { sh.qn = reinterpret_cast<QNode*>(kai_dyn_lds + off); sh.qheap = reinterpret_cast<int32_t*>(kai_dyn_lds + off + (size_t)c.Q * sizeof(QNode)); sh.root_heap = sh.qheap + (c.Q + 1); }
+        else { sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
+    }
     __syncthreads();
     if (threadIdx.x >= 64) { service_loop(c, &sh); return; }
     if (threadIdx.x != 0) return;

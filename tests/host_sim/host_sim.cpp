@@ -42,11 +42,11 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     void l2(const KaiCtx& c, int k, int sb) {
         uint64_t bk = 0; int bn = 0x7fffffff;
         for (int e = sb * 64; e < std::min(c.NB, sb * 64 + 64); e++) { uint64_t key = c.sum1_key[(size_t)k * c.NB + e]; int n = c.sum1_node[(size_t)k * c.NB + e]; if (key_better(key, n, bk, bn)) { bk = key; bn = n; } }
-        s2_key[k * KAI_NSB_MAX + sb] = bk; s2_node[k * KAI_NSB_MAX + sb] = bn;
+        s2_key[k * c.NSB + sb] = bk; s2_node[k * c.NSB + sb] = bn;
     }
     void top(const KaiCtx& c, int k) {
         uint64_t bk = 0; int bn = 0x7fffffff;
-        for (int sb = 0; sb < c.NSB; sb++) { uint64_t key = s2_key[k * KAI_NSB_MAX + sb]; int n = s2_node[k * KAI_NSB_MAX + sb]; if (key_better(key, n, bk, bn)) { bk = key; bn = n; } }
+        for (int sb = 0; sb < c.NSB; sb++) { uint64_t key = s2_key[k * c.NSB + sb]; int n = s2_node[k * c.NSB + sb]; if (key_better(key, n, bk, bn)) { bk = key; bn = n; } }
         top_key[k] = bk; top_node[k] = bn;
     }
     void begin(const KaiCtx& c) {
@@ -59,12 +59,17 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
         for (int n = b * KAI_BLOCK; n < std::min(c.N, (b + 1) * KAI_BLOCK); n++) { uint64_t key = class_key(c, c.cls[k], n); if (key_better(key, n, bk, bn)) { bk = key; bn = n; } }
         c.sum1_key[(size_t)k * c.NB + b] = bk; c.sum1_node[(size_t)k * c.NB + b] = bn;
     }
-    void refresh(const KaiCtx& c, const int32_t* blocks, int n) {
+    int32_t blocks[KAI_MAXD]; int n = 0;
+    bool dirty_add(int b) { for (int i = 0; i < n; i++) if (blocks[i] == b) return true; if (n == KAI_MAXD) return false; blocks[n++] = b; return true; }
+    int dirty_count() { return n; }
+    void refresh(const KaiCtx& c) {
         for (int i = 0; i < n; i++) for (int k = 0; k < c.C; k++) build_block(c, k, blocks[i]);
         for (int k = 0; k < c.C; k++) { for (int i = 0; i < n; i++) l2(c, k, blocks[i] / 64); top(c, k); }
+        n = 0;
     }
     void class_top(const KaiCtx&, int k, uint64_t& key, int& node) { key = top_key[k]; node = top_node[k]; }
     bool all_dead(const KaiCtx& c) { for (int k = 0; k < c.C; k++) if (top_key[k]) return false; return true; }
+    void hot(const KaiCtx& c, QNode*& qn, int32_t*& qheap, int32_t*& root_heap) { qn = c.qn; qheap = c.qheap; root_heap = c.root_heap; }
     int64_t clock() { return 0; }
 };
 
@@ -119,9 +124,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.j_n_pending = own<int32_t>(pool, J); c.j_tta_valid = own<int32_t>(pool, J); c.j_tta_n = own<int32_t>(pool, J); c.tta = own<int32_t>(pool, P);
     c.j_tta_res = own<double>(pool, (size_t)3 * J); c.j_allocated = own<double>(pool, (size_t)3 * J);
     c.lq_sorted = own<int32_t>(pool, J); c.lq_side = own<int32_t>(pool, J); c.lq_cur = own<int32_t>(pool, Q); c.lq_end = own<int32_t>(pool, Q); c.lq_side_len = own<int32_t>(pool, Q); c.j_state = own<uint8_t>(pool, J);
-    c.qheap = own<int32_t>(pool, Q + 1); c.qheap_len = own<int32_t>(pool, Q + 1); c.root_heap = own<int32_t>(pool, Q + 1);
-    c.qn_exists = own<uint8_t>(pool, Q); c.qn_reorder = own<uint8_t>(pool, Q); c.qn_linked = own<uint8_t>(pool, Q);
-    c.qkey = own<QKey>(pool, Q); c.qk_valid = own<uint8_t>(pool, Q);
+    c.qheap = own<int32_t>(pool, Q + 1); c.root_heap = own<int32_t>(pool, Q + 1); c.qn = own<QNode>(pool, Q + 1);
     c.ops_cap = 4 * P + 64; c.ops = own<StmtOp>(pool, c.ops_cap); c.out_cap = (int64_t)2 * P + 64; c.out_ops = own<kai_op>(pool, c.out_cap);
     c.scratch = own<int32_t>(pool, (size_t)P + 64); c.st = own<EngineState>(pool, 1);
     c.q_share = const_cast<QShare*>(copy(pool, prep.shares.data(), prep.shares.size()));
@@ -195,11 +198,11 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     HostBackend be; Engine<HostBackend> eng(c, be);
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] != KAI_ACTION_ALLOCATE) return KAI_ERR_UNSUPPORTED;
-        for (int j = 0; j < J; j++) c.j_state[j] = job_init_state(c, j);  // k_job_init
+        for (int j = 0; j < J; j++) { c.j_state[j] = job_init_state(c, j); if (c.j_state[j] != 3 && c.j_n_ps[j] <= 64) eng.ensure_tta(j, true); }  // k_job_init
         for (int q = 0; q < Q; q++) {                                      // k_leaf_init
             int b = c.q_job_off[q], e = c.q_job_off[q + 1], cnt = 0; c.lq_side_len[q] = 0;
             for (int x = b; x < e; x++) { int j = c.jobs_static[x]; int st = c.j_state[j]; if (st == 0) c.lq_sorted[b + cnt++] = j; else if (st != 3) eng.leaf_push(q, j); }
-            c.lq_cur[q] = 0; c.lq_end[q] = cnt;
+            c.lq_cur[q] = 0; c.lq_end[q] = cnt; qnode_init(c, q, cnt + c.lq_side_len[q]);
         }
         eng.execute_allocate();
         if (c.st->drain_pending) {                                         // k_drain
