@@ -27,7 +27,8 @@ struct kai_core {
     bool open = false;
     KaiCtx ctx{};
     KaiCtx* d_ctx = nullptr;  // HBM copy of ctx for the persistent kernel
-    std::vector<void*> bufs;  // session HBM
+    std::vector<void*> bufs;  // session HBM: a few large slabs, sub-allocated (one contiguous range ⇒ few TLB entries for the latency-bound engine)
+    char* slab = nullptr; size_t slab_left = 0;
     // device-only helpers
     double* d_jsum = nullptr; int32_t* d_slot_queue = nullptr;
     int32_t *d_lvl_off = nullptr, *d_lvl_parents = nullptr; int n_levels = 0;
@@ -51,10 +52,16 @@ namespace {
 
 template <class T>
 int dalloc(kai_core* core, T** out, size_t n) {
-    void* p = nullptr;
-    HIP_TRY(core, hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
-    core->bufs.push_back(p);
-    *out = static_cast<T*>(p);
+    size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+    if (bytes > core->slab_left) {
+        size_t want = std::max<size_t>(bytes, (size_t)256 << 20);  // 256 MiB slabs (2 MiB-aligned by the driver)
+        void* p = nullptr;
+        HIP_TRY(core, hipMalloc(&p, want));
+        core->bufs.push_back(p);
+        core->slab = static_cast<char*>(p); core->slab_left = want;
+    }
+    *out = reinterpret_cast<T*>(core->slab);
+    core->slab += bytes; core->slab_left -= bytes;
     return KAI_OK;
 }
 template <class T>
@@ -75,7 +82,7 @@ int dzero(kai_core* core, T** out, size_t n) {
 }
 void free_session(kai_core* core) {
     for (void* p : core->bufs) (void)hipFree(p);
-    core->bufs.clear();
+    core->bufs.clear(); core->slab = nullptr; core->slab_left = 0;
     core->open = false;
 }
 int fail(kai_core* core, int code, const char* msg) { core->err = msg; return code; }

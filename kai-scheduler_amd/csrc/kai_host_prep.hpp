@@ -118,7 +118,7 @@ struct HostPrep {
     //     CPU resource every node has Allocatable > 0 (a zero-capacity node scores 0, not by its free amount);
     //   spread on r: the divisor (gpu.count label or Allocatable) is an integer in [Allocatable, 2^22] so the ratio stays in [0,1]
     //     and distinct ratios stay distinct after the sum.
-    // The KAI_CMAX most frequent admissible classes among pending pods are indexed; other pods use the brute-force scan.
+    // The KAI_CMAX most frequent admissible classes among PENDING pods are indexed; other pods use the brute-force scan.
     void build_classes(const kai_config& cfg, const kai_snapshot_soa* s) {
         const int N = s->n_nodes, P = s->n_pods, R = s->n_res;
         pod_scls.assign(P, -1); classes.clear(); all_tracked = 1;
@@ -159,7 +159,8 @@ struct HostPrep {
             const Key& k = keys[id];
             bool cpu_only = !(k.req[KAI_RES_GPU] > 0);
             bool admissible = !(cfg.plugins & KAI_PLUGIN_NODEPLACEMENT) || ok_res[cpu_only ? 0 : 1];
-            if (!admissible || (int)classes.size() >= KAI_CMAX) { if (freq[id] > 0) all_tracked = 0; continue; }
+            if (freq[id] == 0) continue;  // only classes that have pending pods are ever queried by the allocate action
+            if (!admissible || (int)classes.size() >= KAI_CMAX) { all_tracked = 0; continue; }
             ClassRec cr; std::memset(&cr, 0, sizeof cr);
             for (int r = 0; r < KAI_MAX_RES; r++) cr.req[r] = k.req[r];
             cr.pod_class = k.pc; cr.cpu_only = cpu_only;

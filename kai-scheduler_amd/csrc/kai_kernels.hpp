@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kai_engine.hpp"
+#include "kai_wave.hpp"
 
 namespace kai {
 
@@ -153,11 +154,9 @@ __global__ void k_fair_share(KaiCtx c, const int32_t* lvl_off, const int32_t* lv
 // ------------------------------------------------------------------------------------------------------
 // class index
 // ------------------------------------------------------------------------------------------------------
+// arg-max of (key, node) over a wavefront; lanes are in ascending node / block order, ties go to the lowest lane (kai_wave.hpp)
 __device__ __forceinline__ void wave_argmax(uint64_t& k, int& n) {
-    for (int o = 32; o > 0; o >>= 1) {
-        uint64_t ok = __shfl_xor((unsigned long long)k, o, 64); int on = __shfl_xor(n, o, 64);
-        if (key_better(ok, on, k, n)) { k = ok; n = on; }
-    }
+    unsigned long long kk = k; wave_argmax_first(kk, n); k = kk;
 }
 // L1 of the class index: one wavefront per 64-node block, every class (node state is read once per class from L1/L2)
 __global__ void k_index_build(KaiCtx c) {
@@ -252,6 +251,7 @@ struct ActShared {
     unsigned long long* s2_key; int32_t* s2_node;  // [C][NSB] in dynamic LDS
     QNode* qn; int32_t *qheap, *root_heap;          // job-order tree: dynamic LDS when it fits, else the HBM arrays
     int32_t tree_in_lds, pad1;
+    long long t_publish, t_wait, t_svc, t_seg[6];  // profiling: control lane through barrier 1 / barrier 2, service wave 1 busy time
 };
 
 // monotone map f64 → u64 (larger double ⇒ larger key); scores here are finite and ≥ 0 but keep it general
@@ -265,8 +265,11 @@ struct DevBackend {
     // control lane side -------------------------------------------------------------------------------
     __device__ void call(int cmd) {
         sh->cmd = cmd;
+        long long t0 = clock64();
         __syncthreads();  // publish the command
+        long long t1 = clock64();
         __syncthreads();  // results ready
+        if (cmd == CMD_REFRESH) { sh->t_publish += t1 - t0; sh->t_wait += clock64() - t1; }
     }
     __device__ void minmax(const KaiCtx&, int r, double& mn, double& mx) {
         sh->r = r; call(CMD_MINMAX);
@@ -325,6 +328,7 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
         __syncthreads();  // wait for a command
         int cmd = sh->cmd;
         if (cmd == CMD_EXIT) return;
+        long long ts = clock64();
         if (cmd == CMD_LOADTREE) {
             const int4* src = reinterpret_cast<const int4*>(c.qn); int4* dst = reinterpret_cast<int4*>(sh->qn);
             int n16 = (int)(((size_t)c.Q * sizeof(QNode) + 15) / 16);
@@ -339,11 +343,16 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
             const int nd = sh->n_dirty;
             if (nd == 1) {  // the common case (one placement): everything in one pass, upper levels patched in registers
                 const int b = sh->dirty[0], n = b * KAI_BLOCK + lane, sb = b / 64, e = sb * 64 + lane;
+                long long q0 = clock64();
                 NodeRegs ns; load_node(c, n < c.N ? n : 0, ns);
+                double fence_v = ns.idle[0] + ns.rel[0] + ns.alloc_cpu + (double)ns.flags + (double)ns.ncls;  // profiling: wait for the node loads
+                long long q1 = clock64() + (fence_v == -1.25 ? 1 : 0);
                 for (int k = hw; k < c.C; k += SVC) {
                     uint64_t rk = e < c.NB ? c.sum1_key[(size_t)k * c.NB + e] : 0; int rn = e < c.NB ? c.sum1_node[(size_t)k * c.NB + e] : 0x7fffffff;  // L1 row, in flight with the node loads
                     uint64_t tk = lane < c.NSB ? sh->s2_key[k * c.NSB + lane] : 0; int tn = lane < c.NSB ? sh->s2_node[k * c.NSB + lane] : 0x7fffffff;
+                    long long q2 = clock64();
                     uint64_t key = n < c.N ? class_key_regs(c, c.cls[k], ns) : 0; int bn = n;
+                    long long q3 = clock64() + (key == 0x123456789abcull ? 1 : 0);
                     wave_argmax(key, bn);
                     if (lane == 0) { c.sum1_key[(size_t)k * c.NB + b] = key; c.sum1_node[(size_t)k * c.NB + b] = bn; }
                     if (lane == (b & 63)) { rk = key; rn = bn; }
@@ -352,6 +361,8 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
                     if (lane == sb) { tk = rk; tn = rn; }
                     wave_argmax(tk, tn);
                     if (lane == 0) { sh->top_key[k] = tk; sh->top_node[k] = tn; }
+                    long long q4 = clock64() + (tk == 0x123456789abcull ? 1 : 0);
+                    if (threadIdx.x == 64) { sh->t_seg[0] += q1 - q0; sh->t_seg[1] += q2 - q1; sh->t_seg[2] += q3 - q2; sh->t_seg[3] += q4 - q3; }
                 }
             } else {
                 // L1: re-evaluate the dirty blocks for this wave's classes
@@ -402,6 +413,7 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
             }
             if (lane == 0) { sh->part_node[wave] = best; sh->part_key[wave] = bk; }
         }
+        if (cmd == CMD_REFRESH && threadIdx.x == 64) sh->t_svc += clock64() - ts;
         __syncthreads();  // results ready
     }
 }
@@ -411,7 +423,7 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     const KaiCtx& c = *cp;  // the context sits in HBM: uniform, read-only, no-alias loads → scalar loads, hoistable across the stores of the engine
     __shared__ ActShared sh;
     if (threadIdx.x == 0) {
-        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds;
+        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
         size_t off = 0;
         sh.s2_key = reinterpret_cast<unsigned long long*>(kai_dyn_lds); sh.s2_node = reinterpret_cast<int32_t*>(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
         off = lds_index_bytes(c.C, c.NSB);
@@ -424,6 +436,8 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     DevBackend be{&sh};
     Engine<DevBackend> eng(c, be);
     if (action == KAI_ACTION_ALLOCATE) eng.execute_allocate();
+    c.st->prof[1] = sh.t_publish; c.st->prof[6] = sh.t_wait; c.st->prof[PF_PUSH] = sh.t_svc;
+    c.st->prof[PF_TTA] = sh.t_seg[0]; c.st->prof[PF_GATE] = sh.t_seg[1]; c.st->prof[PF_TASKCAP] = sh.t_seg[2]; c.st->prof[PF_ROLLBACK] = sh.t_seg[3];
     be.finish();
 }
 
@@ -453,7 +467,7 @@ __global__ void __launch_bounds__(WG) k_best_node(KaiCtx c, int pod, int pipelin
     const int tree_in_lds = 0;
     __shared__ ActShared sh;
     if (threadIdx.x == 0) {
-        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds;
+        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
         size_t off = 0;
         sh.s2_key = reinterpret_cast<unsigned long long*>(kai_dyn_lds); sh.s2_node = reinterpret_cast<int32_t*>(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
         off = lds_index_bytes(c.C, c.NSB);
