@@ -136,7 +136,7 @@ typedef struct kai_config {
     int32_t full_hierarchy_fairness;
     int64_t min_node_gpu_memory;          /* ClusterInfo.MinNodeGPUMemory */
     int32_t queue_depth[4];               /* per kai_action; -1 = infinite (framework/session.go:398-404) */
-    int32_t engine_mode;                  /* 0 = default; 1 = force brute-force node scans (debug / A-B) */
+    int32_t engine_mode;                  /* 0 = default; 1 = force brute-force node scans; 2 = class index without the staged job path (debug / A-B) */
     int32_t reserved[7];
 } kai_config;
 

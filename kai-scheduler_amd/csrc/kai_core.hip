@@ -221,7 +221,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     core->n_levels = prep.n_levels;
     // ---- scan classes + class index
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64;
-    c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked;
+    c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok;
     { int d = core->cfg.queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
     TRY(dupload(core, &c.cls, prep.classes.data(), prep.classes.size()));
     TRY(dzero(core, &c.sum1_key, (size_t)std::max(c.C, 1) * std::max(c.NB, 1))); TRY(dzero(core, &c.sum1_node, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)));

@@ -88,6 +88,28 @@ struct QNode {
 enum : uint32_t { QF_OVER = 1, QF_STARVED = 2, QF_VIOL = 4, QF_VALID = 8, QF_REORDER = 16, QF_EXISTS = 32, QF_LINKED = 64, QF_LEAF = 128,
                   QF_TOP = 256 };  // leaf: best_job holds the top job of the leaf (kept across key invalidations, dropped on pop / push)
 
+// Working set of one job attempt on the staged ("fast") path: the chunk's pods with their request vectors and the shares of
+// the queues on the job's leaf→root chain, held in LDS for the duration of the attempt (kai_kernels.hpp) and written back once.
+constexpr int KAI_FMAX = 32;   // tasks per chunk the frame holds; larger gangs take the general path
+constexpr int KAI_FDEPTH = 8;  // queue levels
+struct FastFrame {
+    int32_t depth, np, pad0, pad1;
+    int32_t q[KAI_FDEPTH];
+    int32_t p[KAI_FMAX], cls[KAI_FMAX], node[KAI_FMAX];
+    double req[KAI_FMAX][KAI_MAX_RES];
+    double alloc[KAI_FDEPTH][3], alloc_np[KAI_FDEPTH][3], max_allowed[KAI_FDEPTH][3], deserved[KAI_FDEPTH][3];
+};
+
+// The frame is addressed directly (not through a generic pointer) so that the device code uses ds_read / ds_write, which the
+// compiler may batch and reorder against global memory traffic.
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ FastFrame kai_frame_lds;
+#define KAI_FRAME kai_frame_lds
+#else
+inline FastFrame& kai_frame_host() { static thread_local FastFrame f; return f; }
+#define KAI_FRAME kai_frame_host()
+#endif
+
 struct EngineState {  // mutable scalars of the running action
     int32_t ops_len, n_undo;
     int32_t fault;            // != 0: engine gave up (see FAULT_*)
@@ -106,7 +128,7 @@ enum { FAULT_NONE = 0, FAULT_OPS_CAP = 1, FAULT_OUT_CAP = 2, FAULT_HEAP = 3, FAU
 struct KaiCtx {
     int32_t N, P, S, J, Q, R, n_pod_classes, n_node_classes;
     uint32_t plugins; int32_t gpu_strategy, cpu_strategy, restrict_nodes; double k_value;
-    int32_t C, NB, NSB, use_index, all_tracked, queue_depth, pad0, pad1;
+    int32_t C, NB, NSB, use_index, all_tracked, queue_depth, fast_ok, pad1;
     // nodes
     const double* n_alloc; const uint32_t* n_flags; const int32_t* n_gpu_count; const int32_t* n_class;
     double *n_idle, *n_rel, *n_used;
@@ -298,28 +320,42 @@ KAI_HD bool key_better(uint64_t k, int n, uint64_t bk, int bn) { return k > bk |
 //    void class_top(const KaiCtx&, int cls, uint64_t& key, int& node)   — arg-max of class_key over all nodes
 //    bool all_dead(const KaiCtx&)                                       — no class has a fitting node
 //    void hot(const KaiCtx&, QNode*&, int32_t*& qheap, int32_t*& root_heap) — where the job-order tree lives (LDS if it fits, else HBM)
+//    const KaiCtx& ctx() / EngineLocal& local() / void bind(const KaiCtx&) — context and engine scalars (LDS objects on the device)
 //    int64_t clock()
 // ======================================================================================================
+// the engine's own scalars (one set per running action)
+struct EngineLocal {
+    QNode* qn; int32_t *qheap, *root_heap;  // where the job-order tree lives (LDS if it fits, else HBM)
+    int32_t root_len, root_init, fail_no_node, pad;
+    double total0, total1, total2;          // proportion totalResource (read-only during an action)
+};
+
 template <class Backend>
 struct Engine {
-    const KaiCtx& c; Backend& be;
-    bool fail_no_node = false;
-    QNode* qn; int32_t *qheap, *root_heap; int root_len = 0, root_init = 0;
-    double total0, total1, total2;  // proportion totalResource (read-only during an action)
-    KAI_HD Engine(const KaiCtx& ctx, Backend& b) : c(ctx), be(b) { qn = ctx.qn; qheap = ctx.qheap; root_heap = ctx.root_heap; total0 = ctx.st->total[0]; total1 = ctx.st->total[1]; total2 = ctx.st->total[2]; }
+    Backend& be;
+    // The context and the engine's own scalars are reached through the backend: on the device they are directly addressed LDS
+    // objects (static accessors, nothing goes through this object), on the host plain members of the backend.
+    KAI_HD const KaiCtx& cx() const { return be.ctx(); }
+    KAI_HD EngineLocal& el() const { return be.local(); }
+    KAI_HD Engine(const KaiCtx& ctx, Backend& b) : be(b) {
+        be.bind(ctx);
+        EngineLocal& e = el();
+        e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
+        e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
+    }
 
-    KAI_HD void fault(int code) { if (!c.st->fault) c.st->fault = code; }
-    KAI_HD double preq(int p, int r) const { return c.p_req[(size_t)r * c.P + p]; }
+    KAI_HD void fault(int code) { if (!cx().st->fault) cx().st->fault = code; }
+    KAI_HD double preq(int p, int r) const { return cx().p_req[(size_t)r * cx().P + p]; }
     KAI_HD bool pod_cpu_only(int p) const { return !(preq(p, KAI_RES_GPU) > 0); }  // pod_info.go:340-347
     KAI_HD bool pod_best_effort(int p) const {  // ResourceRequirements.IsEmpty (resource_requirment.go:99-104, base_resources.go:119-130)
         if (preq(p, KAI_RES_GPU) > 0.01) return false;
         if (preq(p, KAI_RES_CPU) >= 10.0 || preq(p, KAI_RES_MEM) >= 10.0 * 1024 * 1024) return false;
-        for (int r = KAI_RES_PODS; r < c.R; r++) if (preq(p, r) >= 10.0) return false;
+        for (int r = KAI_RES_PODS; r < cx().R; r++) if (preq(p, r) >= 10.0) return false;
         return true;
     }
     KAI_HD bool should_allocate(int p, bool real) const {  // pod_info.go:518-521
-        int s = c.p_status[p];
-        return s == KAI_POD_PENDING || (!real && s == KAI_POD_RELEASING && c.p_virtual[p]);
+        int s = cx().p_status[p];
+        return s == KAI_POD_PENDING || (!real && s == KAI_POD_RELEASING && cx().p_virtual[p]);
     }
     // quota triple of a pod: utils.QuantifyResourceRequirements (plugins/proportion/utils/utils.go:15-17)
     KAI_HD double pquota(int p, int k) const { return k == KAI_Q_CPU ? preq(p, KAI_RES_CPU) : k == KAI_Q_MEM ? preq(p, KAI_RES_MEM) : preq(p, KAI_RES_GPU); }
@@ -328,159 +364,159 @@ struct Engine {
     // the dirty-block list lives in the backend (LDS on the device) so that this object holds no dynamically indexed storage
     KAI_HD void flush_index() {
         int nd = be.dirty_count();
-        if (nd) { int64_t t = be.clock(); be.refresh(c); c.st->index_refreshes += nd; c.st->prof[PF_REFRESH] += be.clock() - t; }
+        if (nd) { int64_t t = be.clock(); be.refresh(cx()); cx().st->index_refreshes += nd; cx().st->prof[PF_REFRESH] += be.clock() - t; }
     }
     KAI_HD void mark_dirty(int n) {
-        if (!c.use_index) return;
+        if (!cx().use_index) return;
         int b = n / KAI_BLOCK;
         if (be.dirty_add(b)) return;
         flush_index();  // list full
         be.dirty_add(b);
     }
-    KAI_HD void invalidate_path(int q) { for (int x = q; x >= 0; x = qn[x].parent) qn[x].flags &= ~QF_VALID; }
+    KAI_HD void invalidate_path(int q) { for (int x = q; x >= 0; x = el().qn[x].parent) el().qn[x].flags &= ~QF_VALID; }
 
     // ------------------------------------------------------------------ status bookkeeping
     // PodGroupInfo.UpdateTaskStatus (api/podgroup_info/job_info.go:228-287) + PodSet.AssignTask (subgroup_info/podset.go:56-99)
     KAI_HD void update_task_status(int p, int status) {
-        int j = c.p_job[p], s = c.p_podset[p], old = c.p_status[p];
-        if (st_allocated(old)) for (int k = 0; k < 3; k++) c.j_allocated[(size_t)k * c.J + j] -= pquota(p, k);
-        if (st_active_allocated(old)) c.s_active_alloc[s]--;
-        if (st_active_used(old)) c.s_active_used[s]--;
-        if (st_alive(old)) c.s_alive[s]--;
-        if (old == KAI_POD_GATED) c.s_gated[s]--;
-        if (old == KAI_POD_PIPELINED) c.s_pipelined[s]--;
-        if (old == KAI_POD_PENDING) c.j_n_pending[j]--;
-        c.p_status[p] = status;
-        if (st_allocated(status)) for (int k = 0; k < 3; k++) c.j_allocated[(size_t)k * c.J + j] += pquota(p, k);
-        if (st_active_allocated(status)) c.s_active_alloc[s]++;
-        if (st_active_used(status)) c.s_active_used[s]++;
-        if (st_alive(status)) c.s_alive[s]++;
-        if (status == KAI_POD_GATED) c.s_gated[s]++;
-        if (status == KAI_POD_PIPELINED) c.s_pipelined[s]++;
-        if (status == KAI_POD_PENDING) c.j_n_pending[j]++;
-        c.j_tta_valid[j] = 0;  // invalidateTasksCache (job_info.go:253-256)
+        int j = cx().p_job[p], s = cx().p_podset[p], old = cx().p_status[p];
+        if (st_allocated(old)) for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)k * cx().J + j] -= pquota(p, k);
+        if (st_active_allocated(old)) cx().s_active_alloc[s]--;
+        if (st_active_used(old)) cx().s_active_used[s]--;
+        if (st_alive(old)) cx().s_alive[s]--;
+        if (old == KAI_POD_GATED) cx().s_gated[s]--;
+        if (old == KAI_POD_PIPELINED) cx().s_pipelined[s]--;
+        if (old == KAI_POD_PENDING) cx().j_n_pending[j]--;
+        cx().p_status[p] = status;
+        if (st_allocated(status)) for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)k * cx().J + j] += pquota(p, k);
+        if (st_active_allocated(status)) cx().s_active_alloc[s]++;
+        if (st_active_used(status)) cx().s_active_used[s]++;
+        if (st_alive(status)) cx().s_alive[s]++;
+        if (status == KAI_POD_GATED) cx().s_gated[s]++;
+        if (status == KAI_POD_PIPELINED) cx().s_pipelined[s]++;
+        if (status == KAI_POD_PENDING) cx().j_n_pending[j]++;
+        cx().j_tta_valid[j] = 0;  // invalidateTasksCache (job_info.go:253-256)
     }
 
     // ------------------------------------------------------------------ node accounting (api/node_info/node_info.go)
     KAI_HD void node_apply(int n, int p, int status, double sign) {  // addTaskResources :457-493 / removeTaskResources :515-551
-        for (int r = 0; r < c.R; r++) {
+        for (int r = 0; r < cx().R; r++) {
             double v = preq(p, r); if (v == 0) continue;
-            size_t i = (size_t)r * c.N + n;
-            c.n_used[i] += sign * v;
-            if (status == KAI_POD_RELEASING) { c.n_rel[i] += sign * v; c.n_idle[i] -= sign * v; }
-            else if (status == KAI_POD_PIPELINED) c.n_rel[i] -= sign * v;
-            else c.n_idle[i] -= sign * v;
+            size_t i = (size_t)r * cx().N + n;
+            cx().n_used[i] += sign * v;
+            if (status == KAI_POD_RELEASING) { cx().n_rel[i] += sign * v; cx().n_idle[i] -= sign * v; }
+            else if (status == KAI_POD_PIPELINED) cx().n_rel[i] -= sign * v;
+            else cx().n_idle[i] -= sign * v;
         }
         mark_dirty(n);
     }
     KAI_HD bool node_add_task(int n, int p) {  // AddTask :384-417
-        if (st_active_used(c.p_status[p])) c.p_accepted[p] = 1;  // setAcceptedResources :746-766
-        if (c.p_on_node[p] == n) return false;                    // "task already on node"
-        if (c.p_on_node[p] >= 0) { fault(FAULT_INTERNAL); return false; }  // a pod on two nodes only happens in reclaim scenarios (not built yet)
-        c.p_on_node[p] = n; c.p_on_node_status[p] = c.p_status[p];
-        node_apply(n, p, c.p_status[p], 1.0);
+        if (st_active_used(cx().p_status[p])) cx().p_accepted[p] = 1;  // setAcceptedResources :746-766
+        if (cx().p_on_node[p] == n) return false;                    // "task already on node"
+        if (cx().p_on_node[p] >= 0) { fault(FAULT_INTERNAL); return false; }  // a pod on two nodes only happens in reclaim scenarios (not built yet)
+        cx().p_on_node[p] = n; cx().p_on_node_status[p] = cx().p_status[p];
+        node_apply(n, p, cx().p_status[p], 1.0);
         return true;
     }
     KAI_HD bool node_remove_task(int n, int p) {  // RemoveTask :495-513 — with the status the node's copy was added with
-        if (c.p_on_node[p] != n) return false;
-        node_apply(n, p, c.p_on_node_status[p], -1.0);
-        c.p_on_node[p] = -1;
+        if (cx().p_on_node[p] != n) return false;
+        node_apply(n, p, cx().p_on_node_status[p], -1.0);
+        cx().p_on_node[p] = -1;
         return true;
     }
     KAI_HD bool node_update_task(int n, int p) { if (!node_remove_task(n, p)) return false; return node_add_task(n, p); }  // :571-576
 
     // ------------------------------------------------------------------ proportion event handlers (plugins/proportion/proportion.go:443-489)
     KAI_HD void queue_event(int p, double sign) {
-        if (!(c.plugins & KAI_PLUGIN_PROPORTION)) return;
-        if (!c.p_accepted[p]) return;  // AcceptedResource is empty until the task was added to a node
-        int j = c.p_job[p]; bool np = !c.j_preempt[j];
-        for (int q = c.j_queue[j]; q >= 0; q = qn[q].parent) {
+        if (!(cx().plugins & KAI_PLUGIN_PROPORTION)) return;
+        if (!cx().p_accepted[p]) return;  // AcceptedResource is empty until the task was added to a node
+        int j = cx().p_job[p]; bool np = !cx().j_preempt[j];
+        for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) {
             for (int k = 0; k < 3; k++) {
-                QShare& s = c.q_share[(size_t)q * 3 + k]; double v = pquota(p, k);
+                QShare& s = cx().q_share[(size_t)q * 3 + k]; double v = pquota(p, k);
                 s.allocated += sign * v;
                 if (np) s.allocated_np += sign * v;
             }
-            qn[q].flags &= ~QF_VALID;
+            el().qn[q].flags &= ~QF_VALID;
         }
     }
 
     // ------------------------------------------------------------------ Statement (framework/statement.go)
-    KAI_HD int checkpoint() const { return c.st->ops_len; }
-    KAI_HD bool push_op(const StmtOp& o) { if (c.st->ops_len >= c.ops_cap) { fault(FAULT_OPS_CAP); return false; } c.ops[c.st->ops_len++] = o; return true; }
+    KAI_HD int checkpoint() const { return cx().st->ops_len; }
+    KAI_HD bool push_op(const StmtOp& o) { if (cx().st->ops_len >= cx().ops_cap) { fault(FAULT_OPS_CAP); return false; } cx().ops[cx().st->ops_len++] = o; return true; }
     KAI_HD bool op_valid(int i) const {  // :652-663 — valid(i) = no undo of i, or that undo is itself undone (iterative form)
-        if (c.st->n_undo == 0) return true;
+        if (cx().st->n_undo == 0) return true;
         bool valid = true; int target = i;
         for (;;) {
             int u = -1;
-            for (int k = 0; k < c.st->ops_len; k++) if (c.ops[k].name == OP_UNDO && c.ops[k].op_index == target) { u = k; break; }
+            for (int k = 0; k < cx().st->ops_len; k++) if (cx().ops[k].name == OP_UNDO && cx().ops[k].op_index == target) { u = k; break; }
             if (u < 0) return valid;
             valid = !valid; target = u;
         }
     }
     KAI_HD bool stmt_allocate(int p, int n) {  // :297-358
         update_task_status(p, KAI_POD_ALLOCATED);
-        c.p_node[p] = n;
+        cx().p_node[p] = n;
         if (!node_add_task(n, p)) return false;
         queue_event(p, 1.0);
-        StmtOp o{}; o.name = OP_ALLOCATE; o.pod = p; o.next_node = n; o.prev_virtual = c.p_virtual[p]; o.op_index = -1;
+        StmtOp o{}; o.name = OP_ALLOCATE; o.pod = p; o.next_node = n; o.prev_virtual = cx().p_virtual[p]; o.op_index = -1;
         if (!push_op(o)) return false;
-        c.p_virtual[p] = 1;
+        cx().p_virtual[p] = 1;
         return true;
     }
     KAI_HD bool stmt_pipeline(int p, int n, bool update_if_exists) {  // :197-295
-        bool found_on_node = c.p_on_node[p] == n;
+        bool found_on_node = cx().p_on_node[p] == n;
         if (found_on_node && !update_if_exists) return stmt_unevict_earliest(p);
-        int prev_status = c.p_status[p];
+        int prev_status = cx().p_status[p];
         update_task_status(p, KAI_POD_PIPELINED);
-        int prev_node = c.p_node[p]; c.p_node[p] = n; int prev_virtual = c.p_virtual[p];
+        int prev_node = cx().p_node[p]; cx().p_node[p] = n; int prev_virtual = cx().p_virtual[p];
         if (found_on_node) node_update_task(n, p); else if (!node_add_task(n, p)) return false;
         queue_event(p, 1.0);
         StmtOp o{}; o.name = OP_PIPELINE; o.pod = p; o.prev_status = prev_status; o.prev_node = prev_node; o.next_node = n; o.prev_virtual = prev_virtual; o.op_index = -1;
         if (!push_op(o)) return false;
-        c.p_virtual[p] = 1;
+        cx().p_virtual[p] = 1;
         return true;
     }
     KAI_HD bool stmt_evict(int p) {  // :63-126
-        int n = c.p_node[p]; if (n < 0) return false;
-        int prev_status = c.p_status[p], prev_virtual = c.p_virtual[p];
+        int n = cx().p_node[p]; if (n < 0) return false;
+        int prev_status = cx().p_status[p], prev_virtual = cx().p_virtual[p];
         update_task_status(p, KAI_POD_RELEASING);
         if (!node_update_task(n, p)) return false;
         queue_event(p, -1.0);
         StmtOp o{}; o.name = OP_EVICT; o.pod = p; o.prev_status = prev_status; o.prev_node = n; o.prev_virtual = prev_virtual; o.op_index = -1;
         if (!push_op(o)) return false;
-        c.p_virtual[p] = 1;
+        cx().p_virtual[p] = 1;
         return true;
     }
     KAI_HD void unallocate(int p, int prev_virtual) {  // :391-425
         update_task_status(p, KAI_POD_PENDING);
-        int n = c.p_node[p];
+        int n = cx().p_node[p];
         if (n >= 0) node_remove_task(n, p);
-        c.p_node[p] = -1; c.p_virtual[p] = (uint8_t)prev_virtual;
+        cx().p_node[p] = -1; cx().p_virtual[p] = (uint8_t)prev_virtual;
         queue_event(p, -1.0);
     }
     KAI_HD void unpipeline(int p, int prev_node, int prev_status, int prev_virtual) {  // :431-476
         update_task_status(p, prev_status);
-        int host = c.p_node[p]; c.p_node[p] = prev_node; c.p_virtual[p] = (uint8_t)prev_virtual;
+        int host = cx().p_node[p]; cx().p_node[p] = prev_node; cx().p_virtual[p] = (uint8_t)prev_virtual;
         if (host >= 0) node_remove_task(host, p);
         queue_event(p, -1.0);
     }
     KAI_HD void unevict(int p, int prev_status, int n, int prev_virtual) {  // :152-195
         update_task_status(p, prev_status);
-        c.p_virtual[p] = (uint8_t)prev_virtual;
-        if (n >= 0) { if (c.p_on_node[p] == n) node_update_task(n, p); else node_add_task(n, p); }
+        cx().p_virtual[p] = (uint8_t)prev_virtual;
+        if (n >= 0) { if (cx().p_on_node[p] == n) node_update_task(n, p); else node_add_task(n, p); }
         queue_event(p, 1.0);
     }
     KAI_HD bool stmt_unevict_earliest(int p) {  // Unevict → undoEarliestValidOperation :478-481,578-600
-        for (int i = 0; i < c.st->ops_len; i++) {
+        for (int i = 0; i < cx().st->ops_len; i++) {
             if (!op_valid(i)) continue;
-            if (c.ops[i].name != OP_EVICT || c.ops[i].pod != p) continue;
+            if (cx().ops[i].name != OP_EVICT || cx().ops[i].pod != p) continue;
             undo_operation(i); return true;
         }
         return false;
     }
     KAI_HD void undo_operation(int index) {  // :602-643
         if (!op_valid(index)) return;
-        StmtOp op = c.ops[index];
+        StmtOp op = cx().ops[index];
         switch (op.name) {
             case OP_EVICT: unevict(op.pod, op.prev_status, op.prev_node, op.prev_virtual); break;
             case OP_PIPELINE: unpipeline(op.pod, op.prev_node, op.prev_status, op.prev_virtual); break;
@@ -488,45 +524,45 @@ struct Engine {
             default: fault(FAULT_INTERNAL); return;  // undo of an undo (= redo) only arises in victim scenarios; not on the allocate path
         }
         StmtOp u{}; u.name = OP_UNDO; u.pod = -1; u.op_index = index;
-        if (push_op(u)) c.st->n_undo++;
+        if (push_op(u)) cx().st->n_undo++;
     }
     KAI_HD void truncate_ops(int cp) {
-        for (int i = cp; i < c.st->ops_len; i++) if (c.ops[i].name == OP_UNDO) c.st->n_undo--;
-        c.st->ops_len = cp;
+        for (int i = cp; i < cx().st->ops_len; i++) if (cx().ops[i].name == OP_UNDO) cx().st->n_undo--;
+        cx().st->ops_len = cp;
     }
     KAI_HD void rollback(int cp) {  // :48-61
-        for (int i = c.st->ops_len - 1; i >= cp; i--) undo_operation(i);
-        truncate_ops(cp); c.st->rollbacks++;
+        for (int i = cx().st->ops_len - 1; i >= cp; i--) undo_operation(i);
+        truncate_ops(cp); cx().st->rollbacks++;
     }
-    KAI_HD void discard() { for (int i = c.st->ops_len - 1; i >= 0; i--) undo_operation(i); truncate_ops(0); }  // :522-534
+    KAI_HD void discard() { for (int i = cx().st->ops_len - 1; i >= 0; i--) undo_operation(i); truncate_ops(0); }  // :522-534
     KAI_HD bool convert_all_allocated_to_pipelined(int job) {  // :483-516
-        int n0 = c.st->ops_len;
+        int n0 = cx().st->ops_len;
         for (int i = 0; i < n0; i++) {
-            StmtOp op = c.ops[i];
-            if (op.name != OP_ALLOCATE || c.p_job[op.pod] != job) continue;
-            int node = c.p_node[op.pod];
+            StmtOp op = cx().ops[i];
+            if (op.name != OP_ALLOCATE || cx().p_job[op.pod] != job) continue;
+            int node = cx().p_node[op.pod];
             unallocate(op.pod, 1);
             if (!stmt_pipeline(op.pod, node, true)) return false;
         }
         int w = 0;
-        for (int i = 0; i < c.st->ops_len; i++) {
-            StmtOp op = c.ops[i];
-            if (op.name == OP_ALLOCATE && c.p_job[op.pod] == job) continue;
-            c.ops[w++] = op;
+        for (int i = 0; i < cx().st->ops_len; i++) {
+            StmtOp op = cx().ops[i];
+            if (op.name == OP_ALLOCATE && cx().p_job[op.pod] == job) continue;
+            cx().ops[w++] = op;
         }
-        c.st->ops_len = w;
+        cx().st->ops_len = w;
         return true;
     }
     KAI_HD void commit() {  // :536-575 — the cache side effects are replayed by the caller from out_ops
-        for (int i = 0; i < c.st->ops_len; i++) {
+        for (int i = 0; i < cx().st->ops_len; i++) {
             if (!op_valid(i)) continue;
-            StmtOp op = c.ops[i]; if (op.name == OP_UNDO) continue;
-            if (c.st->out_len >= c.out_cap) { fault(FAULT_OUT_CAP); break; }
-            kai_op o; o.seq = c.st->out_len; o.pod = op.pod; o.job = c.p_job[op.pod]; o.node = c.p_node[op.pod];
-            if (op.name == OP_EVICT) { o.kind = KAI_OP_EVICT; o.node = op.prev_node; c.p_virtual[op.pod] = 0; }
+            StmtOp op = cx().ops[i]; if (op.name == OP_UNDO) continue;
+            if (cx().st->out_len >= cx().out_cap) { fault(FAULT_OUT_CAP); break; }
+            kai_op o; o.seq = cx().st->out_len; o.pod = op.pod; o.job = cx().p_job[op.pod]; o.node = cx().p_node[op.pod];
+            if (op.name == OP_EVICT) { o.kind = KAI_OP_EVICT; o.node = op.prev_node; cx().p_virtual[op.pod] = 0; }
             else if (op.name == OP_PIPELINE) o.kind = KAI_OP_PIPELINE;
             else { o.kind = KAI_OP_ALLOCATE; update_task_status(op.pod, KAI_POD_BINDING); }  // ssn.BindPod (framework/session.go:111-126)
-            c.out_ops[c.st->out_len++] = o;
+            cx().out_ops[cx().st->out_len++] = o;
         }
         truncate_ops(0);
     }
@@ -534,89 +570,89 @@ struct Engine {
     // ------------------------------------------------------------------ order functions
     KAI_HD int min_available_state(int j) const {  // plugins/elastic/elastic.go:53-65 → 0 below, 1 exactly, 2 above
         bool exactly = true;
-        for (int k = 0; k < c.j_n_ps[j]; k++) {
-            int s = c.j_first_ps[j] + k; int n = c.s_active_alloc[s], m = c.s_min[s];
+        for (int k = 0; k < cx().j_n_ps[j]; k++) {
+            int s = cx().j_first_ps[j] + k; int n = cx().s_active_alloc[s], m = cx().s_min[s];
             if (n < m) return 0;
             if (n > m) exactly = false;
         }
         return exactly ? 1 : 2;
     }
     KAI_HD bool job_order(int l, int r) const {  // framework/session_plugins.go:227-242
-        if (c.plugins & KAI_PLUGIN_PRIORITY) {
-            if (c.j_prio[l] > c.j_prio[r]) return true;
-            if (c.j_prio[l] < c.j_prio[r]) return false;
+        if (cx().plugins & KAI_PLUGIN_PRIORITY) {
+            if (cx().j_prio[l] > cx().j_prio[r]) return true;
+            if (cx().j_prio[l] < cx().j_prio[r]) return false;
         }
-        if (c.plugins & KAI_PLUGIN_ELASTIC) {  // plugins/elastic/elastic.go:25-51 — an order on (below < exactly < above)
+        if (cx().plugins & KAI_PLUGIN_ELASTIC) {  // plugins/elastic/elastic.go:25-51 — an order on (below < exactly < above)
             int ls = min_available_state(l), rs = min_available_state(r);
             if (ls == 0 && rs != 0) return true;
             if (ls == 1 && rs == 2) return true;
             if (ls != 0 && rs == 0) return false;
             if (ls == 2 && rs == 1) return false;
         }
-        if (c.j_created[l] == c.j_created[r]) return c.j_uid_rank[l] < c.j_uid_rank[r];
-        return c.j_created[l] < c.j_created[r];
+        if (cx().j_created[l] == cx().j_created[r]) return cx().j_uid_rank[l] < cx().j_uid_rank[r];
+        return cx().j_created[l] < cx().j_created[r];
     }
     KAI_HD bool podset_order(int l, int r) const {  // session_plugins.go:262-271 + plugins/subgrouporder/subgroup_order.go:31-62
-        if (c.plugins & KAI_PLUGIN_SUBGROUPORDER) {
-            int ln = c.s_active_alloc[l], rn = c.s_active_alloc[r];
-            bool ls = ln >= c.s_min[l], rs = rn >= c.s_min[r];
-            if (!ls && !rs) return c.s_name_rank[l] < c.s_name_rank[r];
+        if (cx().plugins & KAI_PLUGIN_SUBGROUPORDER) {
+            int ln = cx().s_active_alloc[l], rn = cx().s_active_alloc[r];
+            bool ls = ln >= cx().s_min[l], rs = rn >= cx().s_min[r];
+            if (!ls && !rs) return cx().s_name_rank[l] < cx().s_name_rank[r];
             if (!ls) return true;
             if (!rs) return false;
-            double lr = (double)ln / (double)c.s_min[l], rr = (double)rn / (double)c.s_min[r];
+            double lr = (double)ln / (double)cx().s_min[l], rr = (double)rn / (double)cx().s_min[r];
             if (lr < rr) return true;
             if (rr < lr) return false;
         }
-        return c.s_name_rank[l] < c.s_name_rank[r];
+        return cx().s_name_rank[l] < cx().s_name_rank[r];
     }
 
     // ------------------------------------------------------------------ tasks to allocate (api/podgroup_info/allocation_info.go:27-177)
     KAI_HD void ensure_tta(int j, bool real) {
-        if (c.j_tta_valid[j]) return;
-        int first = c.j_first_pod[j], np = c.j_n_pods[j], nps = c.j_n_ps[j], ps0 = c.j_first_ps[j];
+        if (cx().j_tta_valid[j]) return;
+        int first = cx().j_first_pod[j], np = cx().j_n_pods[j], nps = cx().j_n_ps[j], ps0 = cx().j_first_ps[j];
         int out = 0;
         if (nps == 1) {  // one pod-set: the chunk is the first max_tasks allocatable pods in task order
-            int s = ps0, act = c.s_active_alloc[s], mn = c.s_min[s];
+            int s = ps0, act = cx().s_active_alloc[s], mn = cx().s_min[s];
             int max_tasks = act >= mn ? 1 : mn - act;  // getNumTasksToAllocate :145-153
-            for (int i = 0; i < np && out < max_tasks; i++) { int p = c.j_pods_sorted[first + i]; if (should_allocate(p, real)) c.tta[first + out++] = p; }
+            for (int i = 0; i < np && out < max_tasks; i++) { int p = cx().j_pods_sorted[first + i]; if (should_allocate(p, real)) cx().tta[first + out++] = p; }
         } else {
-            int unsat = 0; for (int k = 0; k < nps; k++) if (c.s_active_alloc[ps0 + k] < c.s_min[ps0 + k]) unsat++;
+            int unsat = 0; for (int k = 0; k < nps; k++) if (cx().s_active_alloc[ps0 + k] < cx().s_min[ps0 + k]) unsat++;
             int max_sg = unsat > 0 ? unsat : 1, n_sg = 0;
             // pod-sets leave the priority queue in PodSetOrderFn order: repeated arg-min, podsets per job are few
             uint64_t taken_lo = 0;  // bitmap for up to 64 pod-sets; larger jobs fall back to the scratch array
             for (int round = 0; round < nps && n_sg < max_sg; round++) {
                 int best = -1;
                 for (int k = 0; k < nps; k++) {
-                    bool taken = k < 64 ? ((taken_lo >> k) & 1) : (c.scratch[first + (k - 64)] != 0);
+                    bool taken = k < 64 ? ((taken_lo >> k) & 1) : (cx().scratch[first + (k - 64)] != 0);
                     if (taken) continue;
                     if (best < 0 || podset_order(ps0 + k, ps0 + best)) best = k;
                 }
                 if (best < 0) break;
-                if (best < 64) taken_lo |= (1ull << best); else c.scratch[first + (best - 64)] = 1;
+                if (best < 64) taken_lo |= (1ull << best); else cx().scratch[first + (best - 64)] = 1;
                 int s = ps0 + best;
-                int avail = 0; for (int i = 0; i < np; i++) { int p = c.j_pods_sorted[first + i]; if (c.p_podset[p] == s && should_allocate(p, real)) avail++; }
+                int avail = 0; for (int i = 0; i < np; i++) { int p = cx().j_pods_sorted[first + i]; if (cx().p_podset[p] == s && should_allocate(p, real)) avail++; }
                 if (avail == 0) continue;
-                int max_tasks = c.s_active_alloc[s] >= c.s_min[s] ? (avail < 1 ? avail : 1) : (c.s_min[s] - c.s_active_alloc[s]);  // getNumTasksToAllocate :145-153
+                int max_tasks = cx().s_active_alloc[s] >= cx().s_min[s] ? (avail < 1 ? avail : 1) : (cx().s_min[s] - cx().s_active_alloc[s]);  // getNumTasksToAllocate :145-153
                 int got = 0;
-                for (int i = 0; i < np && got < max_tasks; i++) { int p = c.j_pods_sorted[first + i]; if (c.p_podset[p] == s && should_allocate(p, real)) { c.tta[first + out++] = p; got++; } }
+                for (int i = 0; i < np && got < max_tasks; i++) { int p = cx().j_pods_sorted[first + i]; if (cx().p_podset[p] == s && should_allocate(p, real)) { cx().tta[first + out++] = p; got++; } }
                 n_sg++;
             }
-            if (nps > 64) for (int k = 64; k < nps; k++) c.scratch[first + (k - 64)] = 0;
+            if (nps > 64) for (int k = 64; k < nps; k++) cx().scratch[first + (k - 64)] = 0;
         }
-        c.j_tta_n[j] = out;
+        cx().j_tta_n[j] = out;
         double res[3] = {0, 0, 0};  // GetTasksToAllocateInitResource :88-113
-        for (int i = 0; i < out; i++) { int p = c.tta[first + i]; for (int k = 0; k < 3; k++) res[k] += pquota(p, k); }
-        for (int k = 0; k < 3; k++) c.j_tta_res[(size_t)k * c.J + j] = res[k];
-        c.j_tta_valid[j] = 1;
+        for (int i = 0; i < out; i++) { int p = cx().tta[first + i]; for (int k = 0; k < 3; k++) res[k] += pquota(p, k); }
+        for (int k = 0; k < 3; k++) cx().j_tta_res[(size_t)k * cx().J + j] = res[k];
+        cx().j_tta_valid[j] = 1;
     }
 
     // ------------------------------------------------------------------ proportion: queue order + capacity
     KAI_HD double dominant_share(int q, const double* add) const {  // resource_share/queue_resource_share.go:142-166
         double dom = 0.0;
         for (int k = 0; k < 3; k++) {
-            const QShare& s = c.q_share[(size_t)q * 3 + k];
+            const QShare& s = cx().q_share[(size_t)q * 3 + k];
             double allocatable = qs_allocatable(s);
-            if (allocatable == KAI_UNLIMITED) allocatable = k == 0 ? total0 : k == 1 ? total1 : total2;
+            if (allocatable == KAI_UNLIMITED) allocatable = k == 0 ? el().total0 : k == 1 ? el().total1 : el().total2;
             double allocated = s.allocated; if (add) allocated += add[k];
             double v = allocatable == 0 ? allocated * 1000 : allocated / allocatable;
             dom = kmax(dom, v);
@@ -631,20 +667,20 @@ struct Engine {
     // getBestJobFromNode :309-318 (pending ordering); a node whose key is valid already knows the best job of its subtree
     KAI_HD int best_job_from_node(int q) {
         for (;;) {
-            const QNode& n = qn[q];
+            const QNode& n = el().qn[q];
             if (n.flags & (QF_VALID | QF_TOP)) return n.best_job;
-            if (n.flags & QF_LEAF) { int t = leaf_top(q); qn[q].best_job = t; qn[q].flags |= QF_TOP; return t; }
+            if (n.flags & QF_LEAF) { int t = leaf_top(q); el().qn[q].best_job = t; el().qn[q].flags |= QF_TOP; return t; }
             if (n.len == 0) return -1;
-            q = qheap[n.heap_off];
+            q = el().qheap[n.heap_off];
         }
     }
     // operands of queue_order.GetQueueOrderResult for queue q with the best job of its subtree, cached until q's shares or best job change
     KAI_HD void queue_key(int q) {
-        if (qn[q].flags & QF_VALID) return;
-        const QShare* L = &c.q_share[(size_t)q * 3];
+        if (el().qn[q].flags & QF_VALID) return;
+        const QShare* L = &cx().q_share[(size_t)q * 3];
         int bj = best_job_from_node(q);
         double req[3] = {0, 0, 0};
-        if (bj >= 0) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = c.j_tta_res[(size_t)k * c.J + bj]; }
+        if (bj >= 0) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)k * cx().J + bj]; }
         uint32_t bits = 0;
         bool over = true, starved = true, viol = false;
         for (int k = 0; k < 3; k++) {
@@ -655,14 +691,14 @@ struct Engine {
         }
         if (over) bits |= QF_OVER; if (starved) bits |= QF_STARVED; if (viol) bits |= QF_VIOL;
         double dwj = dominant_share(q, req), dnj = dominant_share(q, nullptr);  // :178-196, 242-273 ; :198-212
-        QNode& n = qn[q];
+        QNode& n = el().qn[q];
         n.best_job = bj; n.dom_with_job = dwj; n.dom_no_job = dnj;
         n.flags = (n.flags & ~(QF_OVER | QF_STARVED | QF_VIOL)) | bits | QF_VALID;
     }
     // plugins/proportion/queue_order/queue_order.go:19-73 (allocate ordering: no victims)
     KAI_HD int queue_order(int lq, int rq) {
         queue_key(lq); queue_key(rq);
-        const QNode kl = qn[lq]; const QNode kr = qn[rq];
+        const QNode kl = el().qn[lq]; const QNode kr = el().qn[rq];
         { bool lo = kl.flags & QF_OVER, ro = kr.flags & QF_OVER; if (!lo && ro) return -1; if (lo && !ro) return 1; }
         { bool ls = kl.flags & QF_STARVED, rs = kr.flags & QF_STARVED; if (ls && !rs) return -1; if (rs && !ls) return 1; }
         if (kl.prio > kr.prio) return -1;  // prioritizePrioritized :76-85
@@ -671,23 +707,23 @@ struct Engine {
         if (kl.dom_with_job < kr.dom_with_job) return -1; if (kl.dom_with_job > kr.dom_with_job) return 1;
         if (kl.dom_no_job < kr.dom_no_job) return -1; if (kl.dom_no_job > kr.dom_no_job) return 1;
         {   // prioritizeBasedOnAllocatableShare :214-224
-            const QShare* L = &c.q_share[(size_t)lq * 3]; const QShare* Rr = &c.q_share[(size_t)rq * 3];
+            const QShare* L = &cx().q_share[(size_t)lq * 3]; const QShare* Rr = &cx().q_share[(size_t)rq * 3];
             bool l_le = true, r_le = true;
             for (int k = 0; k < 3; k++) { int cmp = cmp_q(qs_allocatable(L[k]), qs_allocatable(Rr[k])); if (cmp > 0) l_le = false; if (cmp < 0) r_le = false; }
             if (!r_le && l_le) return -1;  // l.LessInAtLeastOne(r) == !r.LessEqual(l)
             if (!l_le && r_le) return 1;
         }
-        if (c.q_created[lq] < c.q_created[rq]) return -1;  // :235-240
+        if (cx().q_created[lq] < cx().q_created[rq]) return -1;  // :235-240
         return 1;
     }
     KAI_HD bool queue_order_fn(int lq, int rq) {  // framework/session_plugins.go:283-299
-        if (c.plugins & KAI_PLUGIN_PROPORTION) { int v = queue_order(lq, rq); if (v != 0) return v < 0; }
-        if (c.q_created[lq] == c.q_created[rq]) return c.q_uid_rank[lq] < c.q_uid_rank[rq];
-        return c.q_created[lq] < c.q_created[rq];
+        if (cx().plugins & KAI_PLUGIN_PROPORTION) { int v = queue_order(lq, rq); if (v != 0) return v < 0; }
+        if (cx().q_created[lq] == cx().q_created[rq]) return cx().q_uid_rank[lq] < cx().q_uid_rank[rq];
+        return cx().q_created[lq] < cx().q_created[rq];
     }
     KAI_HD bool over_limit(int j, const double* req) const {  // capacity_policy/max_allowed_check.go:20-66
-        for (int q = c.j_queue[j]; q >= 0; q = qn[q].parent) for (int k = 0; k < 3; k++) {
-            const QShare& s = c.q_share[(size_t)q * 3 + k];
+        for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) for (int k = 0; k < 3; k++) {
+            const QShare& s = cx().q_share[(size_t)q * 3 + k];
             if (s.max_allowed == KAI_UNLIMITED) continue;
             if (req[k] == 0) continue;
             if (s.max_allowed < s.allocated + req[k]) return true;
@@ -695,9 +731,9 @@ struct Engine {
         return false;
     }
     KAI_HD bool np_over_quota(int j, const double* req) const {  // capacity_policy/quota_check.go:27-77
-        if (c.j_preempt[j]) return false;
-        for (int q = c.j_queue[j]; q >= 0; q = qn[q].parent) for (int k = 0; k < 3; k++) {
-            const QShare& s = c.q_share[(size_t)q * 3 + k];
+        if (cx().j_preempt[j]) return false;
+        for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) for (int k = 0; k < 3; k++) {
+            const QShare& s = cx().q_share[(size_t)q * 3 + k];
             if (s.deserved == KAI_UNLIMITED) continue;
             if (req[k] == 0) continue;
             if (s.deserved < s.allocated_np + req[k]) return true;
@@ -705,15 +741,15 @@ struct Engine {
         return false;
     }
     KAI_HD bool job_over_queue_capacity(int j) const {  // capacity_policy.go:26-36,76-84
-        if (!(c.plugins & KAI_PLUGIN_PROPORTION)) return false;
-        double req[3] = {0, 0, 0}; int first = c.j_first_pod[j];
-        for (int i = 0; i < c.j_tta_n[j]; i++) { int p = c.tta[first + i]; req[KAI_Q_GPU] += pquota(p, KAI_Q_GPU); req[KAI_Q_CPU] += pquota(p, KAI_Q_CPU); req[KAI_Q_MEM] += pquota(p, KAI_Q_MEM); }
+        if (!(cx().plugins & KAI_PLUGIN_PROPORTION)) return false;
+        double req[3] = {0, 0, 0}; int first = cx().j_first_pod[j];
+        for (int i = 0; i < cx().j_tta_n[j]; i++) { int p = cx().tta[first + i]; req[KAI_Q_GPU] += pquota(p, KAI_Q_GPU); req[KAI_Q_CPU] += pquota(p, KAI_Q_CPU); req[KAI_Q_MEM] += pquota(p, KAI_Q_MEM); }
         return over_limit(j, req) || np_over_quota(j, req);
     }
     KAI_HD bool task_over_capacity(int p) const {  // capacity_policy.go:51-61 with NodeInfo.GetRequiredInitQuota (node_info.go:734-744):
-        if (!(c.plugins & KAI_PLUGIN_PROPORTION)) return false;  // the GPU term is 1 for ANY whole-GPU request, 0 for CPU-only
+        if (!(cx().plugins & KAI_PLUGIN_PROPORTION)) return false;  // the GPU term is 1 for ANY whole-GPU request, 0 for CPU-only
         double req[3] = {preq(p, KAI_RES_CPU), preq(p, KAI_RES_MEM), preq(p, KAI_RES_GPU) >= 1 ? 1.0 : 0.0};
-        int j = c.p_job[p];
+        int j = cx().p_job[p];
         return over_limit(j, req) || np_over_quota(j, req);
     }
 
@@ -723,11 +759,11 @@ struct Engine {
     // for jobs that come back with a changed key (allocate.go:69-72).  Inner nodes order their children with the proportion
     // comparator, which is not a total order in every corner, so they stay array heaps with container/heap's exact sift rules
     // (scheduler_util/priority_queue.go) and the lazy needsReorder protocol.
-    KAI_HD bool q_is_leaf(int q) const { return qn[q].flags & QF_LEAF; }
-    KAI_HD int leaf_len_mem(int q) const { return (c.lq_end[q] - c.lq_cur[q]) + c.lq_side_len[q]; }
+    KAI_HD bool q_is_leaf(int q) const { return el().qn[q].flags & QF_LEAF; }
+    KAI_HD int leaf_len_mem(int q) const { return (cx().lq_end[q] - cx().lq_cur[q]) + cx().lq_side_len[q]; }
     KAI_HD int leaf_top(int q) const {
-        int a = c.lq_cur[q] < c.lq_end[q] ? c.lq_sorted[c.q_job_off[q] + c.lq_cur[q]] : -1;
-        int b = c.lq_side_len[q] > 0 ? c.lq_side[c.q_job_off[q]] : -1;
+        int a = cx().lq_cur[q] < cx().lq_end[q] ? cx().lq_sorted[cx().q_job_off[q] + cx().lq_cur[q]] : -1;
+        int b = cx().lq_side_len[q] > 0 ? cx().lq_side[cx().q_job_off[q]] : -1;
         if (a < 0) return b;
         if (b < 0) return a;
         return job_order(b, a) ? b : a;
@@ -749,74 +785,74 @@ struct Engine {
         return i > i0;
     }
     KAI_HD int leaf_pop(int q) {
-        int a = c.lq_cur[q] < c.lq_end[q] ? c.lq_sorted[c.q_job_off[q] + c.lq_cur[q]] : -1;
-        int b = c.lq_side_len[q] > 0 ? c.lq_side[c.q_job_off[q]] : -1;
-        qn[q].len--; qn[q].flags &= ~QF_TOP;
-        if (b < 0 || (a >= 0 && !job_order(b, a))) { c.lq_cur[q]++; return a; }
-        int32_t* h = c.lq_side + c.q_job_off[q]; int n = c.lq_side_len[q] - 1;
-        int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); c.lq_side_len[q] = n;
+        int a = cx().lq_cur[q] < cx().lq_end[q] ? cx().lq_sorted[cx().q_job_off[q] + cx().lq_cur[q]] : -1;
+        int b = cx().lq_side_len[q] > 0 ? cx().lq_side[cx().q_job_off[q]] : -1;
+        el().qn[q].len--; el().qn[q].flags &= ~QF_TOP;
+        if (b < 0 || (a >= 0 && !job_order(b, a))) { cx().lq_cur[q]++; return a; }
+        int32_t* h = cx().lq_side + cx().q_job_off[q]; int n = cx().lq_side_len[q] - 1;
+        int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); cx().lq_side_len[q] = n;
         return b;
     }
     KAI_HD void leaf_push(int q, int j) {
-        int32_t* h = c.lq_side + c.q_job_off[q]; int n = c.lq_side_len[q];
-        if (n >= c.q_job_off[q + 1] - c.q_job_off[q]) { fault(FAULT_HEAP); return; }
-        h[n] = j; c.lq_side_len[q] = n + 1; heap_up(h, n, JobLess{this});
-        qn[q].len++; qn[q].flags &= ~QF_TOP;
+        int32_t* h = cx().lq_side + cx().q_job_off[q]; int n = cx().lq_side_len[q];
+        if (n >= cx().q_job_off[q + 1] - cx().q_job_off[q]) { fault(FAULT_HEAP); return; }
+        h[n] = j; cx().lq_side_len[q] = n + 1; heap_up(h, n, JobLess{this});
+        el().qn[q].len++; el().qn[q].flags &= ~QF_TOP;
     }
     KAI_HD bool node_less(int l, int r) {  // buildNodeOrderFn :280-305
-        if (qn[l].len == 0) return true;
-        if (qn[r].len == 0) return false;
+        if (el().qn[l].len == 0) return true;
+        if (el().qn[r].len == 0) return false;
         return queue_order_fn(l, r);
     }
-    KAI_HD int32_t* node_heap(int parent) { return parent < 0 ? root_heap : qheap + qn[parent].heap_off; }
-    KAI_HD int node_heap_len(int parent) const { return parent < 0 ? root_len : qn[parent].len; }
-    KAI_HD void set_heap_len(int parent, int n) { if (parent < 0) root_len = n; else qn[parent].len = n; }
+    KAI_HD int32_t* node_heap(int parent) { return parent < 0 ? el().root_heap : el().qheap + el().qn[parent].heap_off; }
+    KAI_HD int node_heap_len(int parent) const { return parent < 0 ? el().root_len : el().qn[parent].len; }
+    KAI_HD void set_heap_len(int parent, int n) { if (parent < 0) el().root_len = n; else el().qn[parent].len = n; }
     KAI_HD void node_heap_push(int parent, int q) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); h[n] = q; set_heap_len(parent, n + 1); heap_up(h, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
     KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent) - 1; set_heap_len(parent, n); int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
     KAI_HD void node_heap_fix0(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); if (!heap_down(h, 0, n, NodeLess{this})) heap_up(h, 0, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
 
     KAI_HD void ensure_ancestor_chain(int child) {  // :134-176
         for (;;) {
-            int parent = qn[child].parent;
-            if (parent < 0) { if (!(qn[child].flags & QF_LINKED)) { root_init = 1; qn[child].flags |= QF_LINKED; node_heap_push(-1, child); } return; }
-            bool parent_new = !(qn[parent].flags & QF_EXISTS);
-            if (parent_new) { qn[parent].flags = (qn[parent].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS; qn[parent].len = 0; }
-            if (!(qn[child].flags & QF_LINKED)) { qn[child].flags |= QF_LINKED; node_heap_push(parent, child); }
+            int parent = el().qn[child].parent;
+            if (parent < 0) { if (!(el().qn[child].flags & QF_LINKED)) { el().root_init = 1; el().qn[child].flags |= QF_LINKED; node_heap_push(-1, child); } return; }
+            bool parent_new = !(el().qn[parent].flags & QF_EXISTS);
+            if (parent_new) { el().qn[parent].flags = (el().qn[parent].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS; el().qn[parent].len = 0; }
+            if (!(el().qn[child].flags & QF_LINKED)) { el().qn[child].flags |= QF_LINKED; node_heap_push(parent, child); }
             if (!parent_new) return;
             child = parent;
         }
     }
     KAI_HD void push_job(int j) {  // :91-120
-        int q = c.j_queue[j];
+        int q = cx().j_queue[j];
         if (!q_is_leaf(q)) return;
-        bool needs_linking = !(qn[q].flags & QF_EXISTS);
-        if (needs_linking) qn[q].flags = (qn[q].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS;
+        bool needs_linking = !(el().qn[q].flags & QF_EXISTS);
+        if (needs_linking) el().qn[q].flags = (el().qn[q].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS;
         leaf_push(q, j);
         invalidate_path(q);
         if (needs_linking) ensure_ancestor_chain(q);
-        for (int x = q; x >= 0; x = qn[x].parent) qn[x].flags |= QF_REORDER;  // markAncestorsForReorder: parent pointers follow the queue tree
+        for (int x = q; x >= 0; x = el().qn[x].parent) el().qn[x].flags |= QF_REORDER;  // markAncestorsForReorder: parent pointers follow the queue tree
     }
     KAI_HD int next_node(int parent) {  // getNextNode :194-217
         for (;;) {
             if (node_heap_len(parent) == 0) return -1;
             int q = node_heap(parent)[0];
-            if (qn[q].flags & QF_REORDER) { node_heap_fix0(parent); qn[q].flags &= ~QF_REORDER; continue; }
-            if (qn[q].len == 0) return -1;
+            if (el().qn[q].flags & QF_REORDER) { node_heap_fix0(parent); el().qn[q].flags &= ~QF_REORDER; continue; }
+            if (el().qn[q].len == 0) return -1;
             return q;
         }
     }
     KAI_HD void handle_pop_from_node(int q) {  // :221-245
         for (;;) {
-            if (qn[q].len != 0) { for (int x = q; x >= 0; x = qn[x].parent) qn[x].flags |= QF_REORDER; return; }
-            int parent = qn[q].parent;
+            if (el().qn[q].len != 0) { for (int x = q; x >= 0; x = el().qn[x].parent) el().qn[x].flags |= QF_REORDER; return; }
+            int parent = el().qn[q].parent;
             node_heap_pop(parent);  // removeNodeFromParent: the node is at the top of its parent's heap
-            qn[q].flags &= ~(QF_EXISTS | QF_LINKED);
+            el().qn[q].flags &= ~(QF_EXISTS | QF_LINKED);
             if (parent < 0) return;
             q = parent;
         }
     }
     KAI_HD int pop_next_job() {  // :61-89
-        if (!root_init || root_len == 0) return -1;
+        if (!el().root_init || el().root_len == 0) return -1;
         int parent = -1, q;
         for (;;) { q = next_node(parent); if (q < 0) return -1; if (q_is_leaf(q)) break; parent = q; }  // traverseToLeaf :179-191
         int job = leaf_pop(q);
@@ -828,98 +864,98 @@ struct Engine {
     // the leaves were filled by k_job_init / k_leaf_init; here every inner node links its best child first, then the others
     // in index order, deepest nodes first, so every node enters its parent's heap with its final key.
     KAI_HD void link_children(int x) {  // x = queue index, or Q for the virtual root
-        int parent = x == c.Q ? -1 : x;
-        int b0 = c.q_child_off[x], b1 = c.q_child_off[x + 1], best = -1, live = 0;
+        int parent = x == cx().Q ? -1 : x;
+        int b0 = cx().q_child_off[x], b1 = cx().q_child_off[x + 1], best = -1, live = 0;
         for (int i = b0; i < b1; i++) {
-            int k = c.q_children[i];
-            if (qn[k].len == 0) continue;
+            int k = cx().q_children[i];
+            if (el().qn[k].len == 0) continue;
             live++;
             if (best < 0 || node_less(k, best)) best = k;
         }
         if (!live) return;
-        if (parent >= 0) qn[parent].flags |= QF_EXISTS | QF_REORDER; else root_init = 1;
-        qn[best].flags |= QF_EXISTS | QF_LINKED | QF_REORDER; node_heap_push(parent, best);
+        if (parent >= 0) el().qn[parent].flags |= QF_EXISTS | QF_REORDER; else el().root_init = 1;
+        el().qn[best].flags |= QF_EXISTS | QF_LINKED | QF_REORDER; node_heap_push(parent, best);
         for (int i = b0; i < b1; i++) {
-            int k = c.q_children[i]; if (k == best) continue;
-            if (qn[k].len == 0) continue;
-            qn[k].flags |= QF_EXISTS | QF_LINKED | QF_REORDER;
+            int k = cx().q_children[i]; if (k == best) continue;
+            if (el().qn[k].len == 0) continue;
+            el().qn[k].flags |= QF_EXISTS | QF_LINKED | QF_REORDER;
             // the heap length of an inner node counts linked children only: children are appended as they are pushed
             node_heap_push(parent, k);
         }
     }
     KAI_HD void truncate_leaf(int q, int depth) {  // PriorityQueue.Push with a finite maxQueueSize under sorted pushes keeps the best `depth` jobs
         while (leaf_len_mem(q) > depth) {
-            int a = c.lq_cur[q] < c.lq_end[q] ? c.lq_sorted[c.q_job_off[q] + c.lq_end[q] - 1] : -1;
-            int32_t* h = c.lq_side + c.q_job_off[q]; int n = c.lq_side_len[q], wi = -1;
+            int a = cx().lq_cur[q] < cx().lq_end[q] ? cx().lq_sorted[cx().q_job_off[q] + cx().lq_end[q] - 1] : -1;
+            int32_t* h = cx().lq_side + cx().q_job_off[q]; int n = cx().lq_side_len[q], wi = -1;
             for (int i = 0; i < n; i++) if (wi < 0 || job_order(h[wi], h[i])) wi = i;
-            if (wi < 0 || (a >= 0 && job_order(h[wi], a))) { c.lq_end[q]--; continue; }
-            h[wi] = h[n - 1]; c.lq_side_len[q] = n - 1;
+            if (wi < 0 || (a >= 0 && job_order(h[wi], a))) { cx().lq_end[q]--; continue; }
+            h[wi] = h[n - 1]; cx().lq_side_len[q] = n - 1;
             for (int i = (n - 1) / 2; i >= 0; i--) heap_down(h, i, n - 1, JobLess{this});
         }
-        qn[q].len = leaf_len_mem(q); qn[q].flags &= ~QF_TOP;
+        el().qn[q].len = leaf_len_mem(q); el().qn[q].flags &= ~QF_TOP;
     }
-    KAI_HD void init_jobs_order() {  // qn[] comes from k_leaf_init: static fields, flags = QF_LEAF or 0, len = queued jobs of a leaf, 0 for inner nodes
-        root_len = 0; root_init = 0;
-        if (c.queue_depth > 0) for (int q = 0; q < c.Q; q++) if (q_is_leaf(q)) truncate_leaf(q, c.queue_depth);
-        for (int i = 0; i < c.Q; i++) { int x = c.q_depth_order[i]; if (!q_is_leaf(x)) link_children(x); }
-        link_children(c.Q);
+    KAI_HD void init_jobs_order() {  // el().qn[] comes from k_leaf_init: static fields, flags = QF_LEAF or 0, len = queued jobs of a leaf, 0 for inner nodes
+        el().root_len = 0; el().root_init = 0;
+        if (cx().queue_depth > 0) for (int q = 0; q < cx().Q; q++) if (q_is_leaf(q)) truncate_leaf(q, cx().queue_depth);
+        for (int i = 0; i < cx().Q; i++) { int x = cx().q_depth_order[i]; if (!q_is_leaf(x)) link_children(x); }
+        link_children(cx().Q);
     }
 
     // ------------------------------------------------------------------ actions/common/allocate.go
     KAI_HD void fill_req(ScanReq& q, int p) {
-        q.pod = p; q.cpu_only = pod_cpu_only(p); q.best_effort = pod_best_effort(p); q.pod_class = c.p_class[p]; q.nominated = c.p_nominated[p];
-        q.r_place = q.cpu_only ? KAI_RES_CPU : KAI_RES_GPU; q.strategy = q.cpu_only ? c.cpu_strategy : c.gpu_strategy;
-        for (int r = 0; r < KAI_MAX_RES; r++) q.req[r] = r < c.R ? preq(p, r) : 0.0;
+        q.pod = p; q.cpu_only = pod_cpu_only(p); q.best_effort = pod_best_effort(p); q.pod_class = cx().p_class[p]; q.nominated = cx().p_nominated[p];
+        q.r_place = q.cpu_only ? KAI_RES_CPU : KAI_RES_GPU; q.strategy = q.cpu_only ? cx().cpu_strategy : cx().gpu_strategy;
+        for (int r = 0; r < KAI_MAX_RES; r++) q.req[r] = r < cx().R ? preq(p, r) : 0.0;
         q.min_a = 0; q.max_a = 0;
     }
     // OrderedNodesByTask + FittingNode for one task (framework/session.go:201-264): the first fitting node in score order, or -1
     KAI_HD int find_node(int p, bool& allocatable) {
-        int k = c.use_index ? c.p_scls[p] : -1;
+        int k = cx().use_index ? cx().p_scls[p] : -1;
         if (k >= 0) {
-            const ClassRec& cr = c.cls[k];
+            const ClassRec& cr = cx().cls[k];
             int n = -1; uint64_t key = 0;
-            int nom = (c.plugins & KAI_PLUGIN_NOMINATEDNODE) ? c.p_nominated[p] : -1;
-            if (nom >= 0) { key = class_key(c, cr, nom); if (key) n = nom; }  // +1e6 outranks every other sum (plugins/nominatednode/nominatednode.go:29-41)
-            if (n < 0) { flush_index(); be.class_top(c, k, key, n); c.st->index_queries++; if (!key) n = -1; }
-            if (n >= 0) allocatable = (c.plugins & KAI_PLUGIN_NODEAVAILABILITY) ? (key >> 63) != 0 : (cr.best_effort || fits(c, cr.req, n, false));
+            int nom = (cx().plugins & KAI_PLUGIN_NOMINATEDNODE) ? cx().p_nominated[p] : -1;
+            if (nom >= 0) { key = class_key(cx(), cr, nom); if (key) n = nom; }  // +1e6 outranks every other sum (plugins/nominatednode/nominatednode.go:29-41)
+            if (n < 0) { flush_index(); be.class_top(cx(), k, key, n); cx().st->index_queries++; if (!key) n = -1; }
+            if (n >= 0) allocatable = (cx().plugins & KAI_PLUGIN_NODEAVAILABILITY) ? (key >> 63) != 0 : (cr.best_effort || fits(cx(), cr.req, n, false));
             return n;
         }
         ScanReq q; fill_req(q, p);
-        if ((c.plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) be.minmax(c, q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
-        int n = be.best_node(c, q);
-        c.st->node_scans++; c.st->nodes_scanned += c.N;
-        if (n >= 0) allocatable = q.best_effort || fits(c, q.req, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
+        if ((cx().plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) be.minmax(cx(), q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
+        int n = be.best_node(cx(), q);
+        cx().st->node_scans++; cx().st->nodes_scanned += cx().N;
+        if (n >= 0) allocatable = q.best_effort || fits(cx(), q.req, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
         return n;
     }
     KAI_HD bool allocate_task(int p, bool pipeline_only) {  // :121-163
-        c.st->decisions++;
+        cx().st->decisions++;
         int64_t t0 = be.clock();
         // predicates step 1 is node independent on this path (capacity_policy.go:51-61): evaluate it once
-        bool over = (c.plugins & KAI_PLUGIN_PREDICATES) && task_over_capacity(p);
-        int64_t t1 = be.clock(); c.st->prof[PF_TASKCAP] += t1 - t0;
+        bool over = (cx().plugins & KAI_PLUGIN_PREDICATES) && task_over_capacity(p);
+        int64_t t1 = be.clock(); cx().st->prof[PF_TASKCAP] += t1 - t0;
         if (over) return false;
         bool allocatable = false;
         int n = find_node(p, allocatable);
-        int64_t t2 = be.clock(); c.st->prof[PF_FIND] += t2 - t1;
-        if (n < 0) { fail_no_node = true; return false; }
+        int64_t t2 = be.clock(); cx().st->prof[PF_FIND] += t2 - t1;
+        if (n < 0) { el().fail_no_node = true; return false; }
         // allocateTaskToNode :165-174
         bool ok = (!pipeline_only && allocatable) ? stmt_allocate(p, n) : stmt_pipeline(p, n, !pipeline_only);
-        c.st->prof[PF_STMT] += be.clock() - t2;
+        cx().st->prof[PF_STMT] += be.clock() - t2;
         return ok;
     }
     KAI_HD bool allocate_job(int j, bool pipeline_only) {  // AllocateJob :20-36 → allocateSubGroupSet :38-81 → allocatePodSet :83-119
-        if (c.j_n_ps[j] > 64) { fault(FAULT_INTERNAL); return false; }  // engine limit: 64 pod-sets per job
+        if (cx().j_n_ps[j] > 64) { fault(FAULT_INTERNAL); return false; }  // engine limit: 64 pod-sets per job
         int64_t t0 = be.clock();
         ensure_tta(j, !pipeline_only);
-        int64_t t1 = be.clock(); c.st->prof[PF_TTA] += t1 - t0;
+        int64_t t1 = be.clock(); cx().st->prof[PF_TTA] += t1 - t0;
         bool gated = job_over_queue_capacity(j);
-        c.st->prof[PF_GATE] += be.clock() - t1;
+        cx().st->prof[PF_GATE] += be.clock() - t1;
         if (gated) return false;
         int cp_root = checkpoint();
-        int first = c.j_first_pod[j], nt = c.j_tta_n[j], nps = c.j_n_ps[j], ps0 = c.j_first_ps[j];
+        int first = cx().j_first_pod[j], nt = cx().j_tta_n[j], nps = cx().j_n_ps[j], ps0 = cx().j_first_ps[j];
         // the cached chunk is consumed below while statuses change, so snapshot it (Go holds the slice it got)
-        int32_t* chunk = c.scratch + first;
-        for (int i = 0; i < nt; i++) chunk[i] = c.tta[first + i];
+        int32_t* chunk = cx().scratch + first;
+        for (int i = 0; i < nt; i++) chunk[i] = cx().tta[first + i];
         // orderedPodSets :270-277 — sort.Slice by PodSetOrderFn; the order is re-read at every step because allocating
         // changes the counters only of pod-sets already visited
         uint64_t done = 0;
@@ -930,10 +966,134 @@ struct Engine {
             done |= 1ull << best;
             int s = ps0 + best;
             int cp = checkpoint(); bool ok = true;
-            for (int i = 0; i < nt; i++) { int p = chunk[i]; if (c.p_podset[p] != s) continue; if (!allocate_task(p, pipeline_only)) { ok = false; break; } }
-            if (!ok) { int64_t tr = be.clock(); rollback(cp); rollback(cp_root); c.st->prof[PF_ROLLBACK] += be.clock() - tr; return false; }
+            for (int i = 0; i < nt; i++) { int p = chunk[i]; if (cx().p_podset[p] != s) continue; if (!allocate_task(p, pipeline_only)) { ok = false; break; } }
+            if (!ok) { int64_t tr = be.clock(); rollback(cp); rollback(cp_root); cx().st->prof[PF_ROLLBACK] += be.clock() - tr; return false; }
         }
         return true;
+    }
+    // ------------------------------------------------------------------ staged job path
+    // The same AllocateJob → allocateTask → Statement.Allocate → Commit / Rollback sequence as above for the overwhelmingly common
+    // job shape — one pod-set, pending pods of indexed classes, nothing releasing or pipelined in the session (so every fitting
+    // node is allocatable now and nothing is pipelined) — with the job's working set staged in LDS: the shares of the queue chain
+    // and the chunk's request vectors are loaded once, every f64 operation of the reference is applied to the staged copy in the
+    // reference's order (allocate handlers :443-465, rollback = the same operations with the opposite sign, Allocated→Binding on
+    // commit), and the results are written back once.  Returns -1 when the job does not qualify (nothing touched).
+    KAI_HD bool frame_over_limit(const FastFrame& f, const double* req) const {  // capacity_policy/max_allowed_check.go:20-66
+        for (int l = 0; l < f.depth; l++) for (int k = 0; k < 3; k++) {
+            double mx = f.max_allowed[l][k];
+            if (mx == KAI_UNLIMITED) continue;
+            if (req[k] == 0) continue;
+            if (mx < f.alloc[l][k] + req[k]) return true;
+        }
+        return false;
+    }
+    KAI_HD bool frame_np_over_quota(const FastFrame& f, const double* req) const {  // capacity_policy/quota_check.go:27-77
+        if (!f.np) return false;
+        for (int l = 0; l < f.depth; l++) for (int k = 0; k < 3; k++) {
+            double ds = f.deserved[l][k];
+            if (ds == KAI_UNLIMITED) continue;
+            if (req[k] == 0) continue;
+            if (ds < f.alloc_np[l][k] + req[k]) return true;
+        }
+        return false;
+    }
+    KAI_HD static double frame_quota(const double* rq, int k) { return k == KAI_Q_CPU ? rq[KAI_RES_CPU] : k == KAI_Q_MEM ? rq[KAI_RES_MEM] : rq[KAI_RES_GPU]; }
+    KAI_HD int allocate_job_fast(int j) {
+        if (!cx().use_index || !cx().fast_ok) return -1;
+        if (cx().j_n_ps[j] != 1) return -1;
+        const int s = cx().j_first_ps[j];
+        if (cx().s_pipelined[s] != 0) return -1;
+        ensure_tta(j, true);
+        const int nt = cx().j_tta_n[j], first = cx().j_first_pod[j];
+        if (nt <= 0 || nt > KAI_FMAX) return -1;
+        FastFrame& f = KAI_FRAME;
+        const bool nominated = cx().plugins & KAI_PLUGIN_NOMINATEDNODE;
+        for (int i = 0; i < nt; i++) f.p[i] = cx().tta[first + i];
+        for (int i = 0; i < nt; i++) {
+            int p = f.p[i], k = cx().p_scls[p];
+            if (k < 0 || cx().p_status[p] != KAI_POD_PENDING || cx().p_on_node[p] >= 0 || (nominated && cx().p_nominated[p] >= 0)) return -1;
+            f.cls[i] = k;
+        }
+        for (int i = 0; i < nt; i++) for (int r = 0; r < KAI_MAX_RES; r++) f.req[i][r] = r < cx().R ? preq(f.p[i], r) : 0.0;
+        const bool prop = cx().plugins & KAI_PLUGIN_PROPORTION;
+        int d = 0;
+        for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
+        f.depth = d; f.np = !cx().j_preempt[j];
+        for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {
+            const QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k];
+            f.alloc[l][k] = sh.allocated; f.alloc_np[l][k] = sh.allocated_np; f.max_allowed[l][k] = sh.max_allowed; f.deserved[l][k] = sh.deserved;
+        }
+        if (prop) {  // IsJobOverQueueCapacityFn (capacity_policy.go:26-36,76-84)
+            double req[3] = {0, 0, 0};
+            for (int i = 0; i < nt; i++) { req[KAI_Q_GPU] += frame_quota(f.req[i], KAI_Q_GPU); req[KAI_Q_CPU] += frame_quota(f.req[i], KAI_Q_CPU); req[KAI_Q_MEM] += frame_quota(f.req[i], KAI_Q_MEM); }
+            if (frame_over_limit(f, req) || frame_np_over_quota(f, req)) return 0;
+        }
+        double ja[3] = {cx().j_allocated[(size_t)0 * cx().J + j], cx().j_allocated[(size_t)1 * cx().J + j], cx().j_allocated[(size_t)2 * cx().J + j]};
+        const bool preds = cx().plugins & KAI_PLUGIN_PREDICATES;
+        int done = 0; bool ok = true;
+        for (int i = 0; i < nt; i++) {  // allocateTask :121-163
+            cx().st->decisions++;
+            const double* rq = f.req[i];
+            if (preds && prop) {  // predicates step 1 (capacity_policy.go:51-61, node_info.go:734-744: 1 GPU for any whole-GPU request)
+                double r3[3] = {rq[KAI_RES_CPU], rq[KAI_RES_MEM], rq[KAI_RES_GPU] >= 1 ? 1.0 : 0.0};
+                if (frame_over_limit(f, r3) || frame_np_over_quota(f, r3)) { ok = false; break; }
+            }
+            flush_index();
+            uint64_t key; int n; be.class_top(cx(), f.cls[i], key, n); cx().st->index_queries++;
+            if (!key) { el().fail_no_node = true; ok = false; break; }
+            // Statement.Allocate :297-358 → NodeInfo.AddTask → addTaskResources (node_info.go:457-493)
+            for (int r = 0; r < cx().R; r++) {
+                double v = rq[r]; if (v == 0) continue;
+                size_t x = (size_t)r * cx().N + n;
+                cx().n_used[x] += v; cx().n_idle[x] -= v;
+            }
+            mark_dirty(n);
+            if (prop) for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {  // proportion allocate handler :443-465
+                double v = frame_quota(rq, k);
+                f.alloc[l][k] += v;
+                if (f.np) f.alloc_np[l][k] += v;
+            }
+            for (int k = 0; k < 3; k++) ja[k] += frame_quota(rq, k);  // PodGroupInfo.Allocated (job_info.go:208-226)
+            f.node[i] = n; done++;
+        }
+        if (ok) {  // Statement.Commit :536-575 + ssn.BindPod: nt Allocate operations in task order
+            for (int i = 0; i < nt; i++) {
+                int p = f.p[i], n = f.node[i];
+                if (cx().st->out_len >= cx().out_cap) { fault(FAULT_OUT_CAP); break; }
+                kai_op o; o.seq = cx().st->out_len; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j;
+                cx().out_ops[cx().st->out_len++] = o;
+                for (int k = 0; k < 3; k++) { double v = frame_quota(f.req[i], k); ja[k] -= v; ja[k] += v; }  // Allocated → Binding (job_info.go:228-287)
+                cx().p_status[p] = KAI_POD_BINDING; cx().p_node[p] = n; cx().p_on_node[p] = n; cx().p_on_node_status[p] = KAI_POD_ALLOCATED; cx().p_accepted[p] = 1; cx().p_virtual[p] = 1;
+            }
+            cx().s_active_alloc[s] += nt; cx().s_active_used[s] += nt; cx().j_n_pending[j] -= nt;
+        } else {  // Statement.Rollback :48-61: the undone operations in reverse order, same arithmetic with the opposite sign
+            for (int i = done - 1; i >= 0; i--) {
+                const double* rq = f.req[i]; int n = f.node[i];
+                for (int k = 0; k < 3; k++) ja[k] -= frame_quota(rq, k);
+                for (int r = 0; r < cx().R; r++) {
+                    double v = rq[r]; if (v == 0) continue;
+                    size_t x = (size_t)r * cx().N + n;
+                    cx().n_used[x] += -1.0 * v; cx().n_idle[x] -= -1.0 * v;
+                }
+                mark_dirty(n);
+                cx().p_accepted[f.p[i]] = 1;  // AcceptedResource stays set after unallocate (node_info.go:746-766)
+                if (prop) for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {
+                    double v = frame_quota(rq, k);
+                    f.alloc[l][k] += -1.0 * v;
+                    if (f.np) f.alloc_np[l][k] += -1.0 * v;
+                }
+            }
+            cx().st->rollbacks += 2;
+        }
+        if (done > 0) {
+            cx().j_tta_valid[j] = 0;
+            for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)k * cx().J + j] = ja[k];
+            if (prop) for (int l = 0; l < d; l++) {
+                for (int k = 0; k < 3; k++) { QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k]; sh.allocated = f.alloc[l][k]; sh.allocated_np = f.alloc_np[l][k]; }
+                el().qn[f.q[l]].flags &= ~QF_VALID;
+            }
+        }
+        return ok ? 1 : 0;
     }
     // What the allocate loop does with a job once no class has a fitting node (used by k_drain and the host twin): the job is
     // attempted, passes or fails the queue-capacity gate, and its first task finds no node.  Touches only job j's own cache.
@@ -941,45 +1101,46 @@ struct Engine {
         attempted++;
         ensure_tta(j, true);
         if (job_over_queue_capacity(j)) return;
-        if (c.j_tta_n[j] == 0) return;
+        if (cx().j_tta_n[j] == 0) return;
         decisions++; rollbacks += 2;
     }
     KAI_HD void execute_allocate() {  // actions/allocate/allocate.go:46-77
         int64_t t0 = be.clock(), t;
-        be.hot(c, qn, qheap, root_heap);
-        be.begin(c);
+        be.hot(cx(), el().qn, el().qheap, el().root_heap);
+        be.begin(cx());
         init_jobs_order();
-        t = be.clock(); c.st->prof[5] += t - t0;
+        t = be.clock(); cx().st->prof[5] += t - t0;
         for (;;) {
-            if (c.st->fault) break;
+            if (cx().st->fault) break;
             int64_t ta = be.clock();
             int j = pop_next_job(); if (j < 0) break;
-            int64_t tb = be.clock(); c.st->prof[0] += tb - ta;
-            c.st->ops_len = 0; c.st->n_undo = 0;
-            c.st->jobs_attempted++;
-            fail_no_node = false;
-            bool ok = allocate_job(j, false);
-            int64_t tc = be.clock(); c.st->prof[2] += tc - tb;
+            int64_t tb = be.clock(); cx().st->prof[0] += tb - ta;
+            cx().st->ops_len = 0; cx().st->n_undo = 0;
+            cx().st->jobs_attempted++;
+            el().fail_no_node = false;
+            int fr = allocate_job_fast(j);
+            bool ok = fr < 0 ? allocate_job(j, false) : fr == 1;
+            int64_t tc = be.clock(); cx().st->prof[2] += tc - tb;
             if (ok) {  // attemptToAllocateJob :79-111 — ShouldPipelineJob (job_info.go:443-464)
                 bool should_pipeline = false;
-                for (int k = 0; k < c.j_n_ps[j]; k++) { int s = c.j_first_ps[j] + k; if (c.s_pipelined[s] > 0 && (c.s_active_alloc[s] - c.s_pipelined[s]) < c.s_min[s]) should_pipeline = true; }
+                for (int k = 0; k < cx().j_n_ps[j]; k++) { int s = cx().j_first_ps[j] + k; if (cx().s_pipelined[s] > 0 && (cx().s_active_alloc[s] - cx().s_pipelined[s]) < cx().s_min[s]) should_pipeline = true; }
                 if (should_pipeline && !convert_all_allocated_to_pipelined(j)) ok = false;
             }
             if (ok) {
-                c.st->jobs_committed++;
+                cx().st->jobs_committed++;
                 commit();
-                if (c.j_n_pending[j] > 0) { int64_t tp = be.clock(); push_job(j); c.st->prof[PF_PUSH] += be.clock() - tp; }  // HasTasksToAllocate(job, true)
+                if (cx().j_n_pending[j] > 0) { int64_t tp = be.clock(); push_job(j); cx().st->prof[PF_PUSH] += be.clock() - tp; }  // HasTasksToAllocate(job, true)
             } else {
                 discard();
             }
-            int64_t td = be.clock(); c.st->prof[3] += td - tc;
-            if (!ok && fail_no_node && c.use_index && c.all_tracked) {  // nothing fits any class any more: the rest of the queue fails job by job
+            int64_t td = be.clock(); cx().st->prof[3] += td - tc;
+            if (!ok && el().fail_no_node && cx().use_index && cx().all_tracked) {  // nothing fits any class any more: the rest of the queue fails job by job
                 flush_index();
-                if (be.all_dead(c)) { c.st->drain_pending = 1; break; }
+                if (be.all_dead(cx())) { cx().st->drain_pending = 1; break; }
             }
-            c.st->prof[4] += be.clock() - td;
+            cx().st->prof[4] += be.clock() - td;
         }
-        c.st->prof[7] += be.clock() - t0;
+        cx().st->prof[7] += be.clock() - t0;
     }
 };
 

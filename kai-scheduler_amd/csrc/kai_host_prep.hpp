@@ -25,7 +25,7 @@ struct HostPrep {
     std::vector<int32_t> perm, node_gpu_count, node_class, pod_node, pod_nominated;
     std::vector<double> node_alloc; std::vector<uint32_t> node_flags;
     // scan classes
-    std::vector<ClassRec> classes; std::vector<int32_t> pod_scls; int all_tracked = 1;
+    std::vector<ClassRec> classes; std::vector<int32_t> pod_scls; int all_tracked = 1, fast_ok = 1;
 
     // returns 0 or KAI_ERR_INVALID_ARG with err set
     int build(const kai_config& cfg, const kai_snapshot_soa* s, std::string& err) {
@@ -122,6 +122,9 @@ struct HostPrep {
     void build_classes(const kai_config& cfg, const kai_snapshot_soa* s) {
         const int N = s->n_nodes, P = s->n_pods, R = s->n_res;
         pod_scls.assign(P, -1); classes.clear(); all_tracked = 1;
+        // the staged job path needs "fits on Idle+Releasing" == "fits on Idle" for every node: nothing releasing, nothing pipelined
+        fast_ok = cfg.engine_mode == 2 ? 0 : 1;
+        for (int p = 0; p < P; p++) if (s->pod_status[p] & (KAI_POD_RELEASING | KAI_POD_PIPELINED)) fast_ok = 0;
         auto integral = [](double v, double lim) { return v >= 0 && v <= lim && v == std::floor(v); };
         bool ok_res[2] = {true, true};  // [0] = CPU, [1] = GPU as placement resource
         const int rr[2] = {KAI_RES_CPU, KAI_RES_GPU};

@@ -175,6 +175,10 @@ __global__ void k_index_build(KaiCtx c) {
 // action init
 // ------------------------------------------------------------------------------------------------------
 struct NullBackend {  // kernels that only need the engine's pure helpers
+    const KaiCtx* cref = nullptr; EngineLocal loc;
+    __device__ void bind(const KaiCtx& c) { cref = &c; }
+    __device__ const KaiCtx& ctx() const { return *cref; }
+    __device__ EngineLocal& local() { return loc; }
     __device__ void minmax(const KaiCtx&, int, double&, double&) {}
     __device__ int best_node(const KaiCtx&, const ScanReq&) { return -1; }
     __device__ void begin(const KaiCtx&) {}
@@ -254,6 +258,12 @@ struct ActShared {
     long long t_publish, t_wait, t_svc, t_seg[6];  // profiling: control lane through barrier 1 / barrier 2, service wave 1 busy time
 };
 
+// the mailbox between the control lane and the service waves, the action's context and the engine's scalars: directly
+// addressed LDS objects of the (single) workgroup
+__shared__ ActShared g_sh;
+__shared__ KaiCtx g_ctx;
+__shared__ EngineLocal g_el;
+
 // monotone map f64 → u64 (larger double ⇒ larger key); scores here are finite and ≥ 0 but keep it general
 __device__ __forceinline__ unsigned long long orderable(double d) {
     unsigned long long b = (unsigned long long)__double_as_longlong(d);
@@ -261,7 +271,10 @@ __device__ __forceinline__ unsigned long long orderable(double d) {
 }
 
 struct DevBackend {
-    ActShared* sh;
+    ActShared* const sh = &g_sh;  // every use below folds to a direct LDS address
+    __device__ static void bind(const KaiCtx&) {}  // k_action copied the context into g_ctx before constructing the engine
+    __device__ static const KaiCtx& ctx() { return g_ctx; }
+    __device__ static EngineLocal& local() { return g_el; }
     // control lane side -------------------------------------------------------------------------------
     __device__ void call(int cmd) {
         sh->cmd = cmd;
@@ -420,8 +433,13 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
 
 // One workgroup; wave 0 lane 0 = control, waves 1..15 = service.
 __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, int action, int tree_in_lds) {
-    const KaiCtx& c = *cp;  // the context sits in HBM: uniform, read-only, no-alias loads → scalar loads, hoistable across the stores of the engine
-    __shared__ ActShared sh;
+    {   // the context into LDS: every pointer fetch of the engine is a ds_read the compiler can batch
+        const int* src = reinterpret_cast<const int*>(cp); int* dst = reinterpret_cast<int*>(&g_ctx);
+        for (int i = threadIdx.x; i < (int)(sizeof(KaiCtx) / 4); i += WG) dst[i] = src[i];
+    }
+    __syncthreads();
+    const KaiCtx& c = g_ctx;
+    ActShared& sh = g_sh;
     if (threadIdx.x == 0) {
         sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
         size_t off = 0;
@@ -431,9 +449,9 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
         else { sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
     }
     __syncthreads();
-    if (threadIdx.x >= 64) { service_loop(c, &sh); return; }
+    if (threadIdx.x >= 64) { service_loop(c, &g_sh); return; }
     if (threadIdx.x != 0) return;  // the rest of wave 0 idles: s_barrier counts wavefronts, not lanes
-    DevBackend be{&sh};
+    DevBackend be;
     Engine<DevBackend> eng(c, be);
     if (action == KAI_ACTION_ALLOCATE) eng.execute_allocate();
     c.st->prof[1] = sh.t_publish; c.st->prof[6] = sh.t_wait; c.st->prof[PF_PUSH] = sh.t_svc;
@@ -463,23 +481,17 @@ __global__ void k_drain(KaiCtx c, const int32_t* slot_queue) {
 }
 
 // kai_best_node: one OrderedNodesByTask + FittingNode against the current session state (brute-force scan)
-__global__ void __launch_bounds__(WG) k_best_node(KaiCtx c, int pod, int pipeline_only, int32_t* out) {
-    const int tree_in_lds = 0;
-    __shared__ ActShared sh;
-    if (threadIdx.x == 0) {
-        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
-        size_t off = 0;
-        sh.s2_key = reinterpret_cast<unsigned long long*>(kai_dyn_lds); sh.s2_node = reinterpret_cast<int32_t*>(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
-        off = lds_index_bytes(c.C, c.NSB);
-        if (tree_in_lds) { sh.qn = reinterpret_cast<QNode*>(kai_dyn_lds + off); sh.qheap = reinterpret_cast<int32_t*>(kai_dyn_lds + off + (size_t)c.Q * sizeof(QNode)); sh.root_heap = sh.qheap + (c.Q + 1); }
-        else { sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
-    }
+__global__ void __launch_bounds__(WG) k_best_node(KaiCtx cv, int pod, int pipeline_only, int32_t* out) {
+    if (threadIdx.x == 0) { g_ctx = cv; g_ctx.use_index = 0; }
     __syncthreads();
-    if (threadIdx.x >= 64) { service_loop(c, &sh); return; }
+    const KaiCtx& c = g_ctx;
+    ActShared& sh = g_sh;
+    if (threadIdx.x == 0) { sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = 0; sh.s2_key = nullptr; sh.s2_node = nullptr; sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
+    __syncthreads();
+    if (threadIdx.x >= 64) { service_loop(c, &g_sh); return; }
     if (threadIdx.x != 0) return;
-    DevBackend be{&sh};
-    KaiCtx cb = c; cb.use_index = 0;
-    Engine<DevBackend> eng(cb, be);
+    DevBackend be;
+    Engine<DevBackend> eng(c, be);
     int n = -1, pipe = 0;
     if (!((c.plugins & KAI_PLUGIN_PREDICATES) && eng.task_over_capacity(pod))) {
         bool allocatable = false;

@@ -127,3 +127,16 @@ def test_gpu_full_size_properties(gpu):
     cnt = np.bincount(a["pod_podset"][active], minlength=snap.n_podsets)
     assert ((cnt == 0) | (cnt >= a["podset_min_available"])).all()
     assert_same(res, T.Oracle.run(snap, cfg))
+
+
+@pytest.mark.parametrize("idx,scale", [(1, 0.3), (2, 0.03), (4, 0.01)])
+def test_gpu_engine_modes_agree(gpu, idx, scale):
+    """class index + staged job path (0), brute-force scans (1) and class index with the general job path (2): same results, same counters."""
+    snap, cfg, _ = T.pkg.synth.config(idx, scale)
+    ref = T.Oracle.run(snap, cfg)
+    want = (ref.stats.decisions, ref.stats.jobs_attempted, ref.stats.jobs_committed, ref.stats.rollbacks)
+    for mode in (0, 1, 2):
+        c = T.abi.KaiConfig.from_buffer_copy(cfg); c.engine_mode = mode
+        res = run_gpu(snap, c)
+        assert_same(res, ref)
+        assert (res.stats.decisions, res.stats.jobs_attempted, res.stats.jobs_committed, res.stats.rollbacks) == want, mode
