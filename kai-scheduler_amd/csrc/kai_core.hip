@@ -80,6 +80,31 @@ int dzero(kai_core* core, T** out, size_t n) {
     HIP_TRY(core, hipMemsetAsync(*out, 0, std::max<size_t>(n, 1) * sizeof(T), core->stream));
     return KAI_OK;
 }
+// KaiCtx fields are address-space-qualified pointers in the device pass (kai_engine.hpp KAI_GP): assign them through casts
+#define KAI_VP(x) ((void*)(x))
+template <class F>
+int dalloc_f(kai_core* core, F& field, size_t n) {
+    char* p = nullptr;
+    int rc = dalloc(core, &p, std::max<size_t>(n, 1) * sizeof(*field));
+    if (rc) return rc;
+    field = (F)p;
+    return KAI_OK;
+}
+template <class F>
+int dzero_f(kai_core* core, F& field, size_t n) {
+    int rc = dalloc_f(core, field, n);
+    if (rc) return rc;
+    HIP_TRY(core, hipMemsetAsync(KAI_VP(field), 0, std::max<size_t>(n, 1) * sizeof(*field), core->stream));
+    return KAI_OK;
+}
+template <class F, class T>
+int dupload_f(kai_core* core, F& field, const T* host, size_t n) {
+    static_assert(sizeof(*field) == sizeof(T), "element size");
+    int rc = dalloc_f(core, field, n);
+    if (rc) return rc;
+    if (n) HIP_TRY(core, hipMemcpyAsync(KAI_VP(field), host, n * sizeof(T), hipMemcpyHostToDevice, core->stream));
+    return KAI_OK;
+}
 void free_session(kai_core* core) {
     for (void* p : core->bufs) (void)hipFree(p);
     core->bufs.clear(); core->slab = nullptr; core->slab_left = 0;
@@ -180,41 +205,41 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     // ---- static arrays (optional ones get neutral defaults); nodes go up in name-rank order
     std::vector<int32_t> zerop(P, 0); std::vector<uint32_t> zeropu(P, 0);
     uint8_t one = 1;
-    TRY(dupload(core, &c.n_alloc, prep.node_alloc.data(), (size_t)R * N));
-    TRY(dupload(core, &c.n_flags, prep.node_flags.data(), (size_t)N));
-    TRY(dupload(core, &c.n_gpu_count, prep.node_gpu_count.data(), (size_t)N));
-    TRY(dupload(core, &c.n_class, prep.node_class.data(), (size_t)N));
-    TRY(dupload(core, &c.p_req, s->pod_req, (size_t)R * P));
-    TRY(dupload(core, &c.p_job, s->pod_job, (size_t)P));
-    TRY(dupload(core, &c.p_podset, s->pod_podset, (size_t)P));
-    TRY(dupload(core, &c.p_flags, s->pod_flags ? s->pod_flags : zeropu.data(), (size_t)P));
-    TRY(dupload(core, &c.p_class, s->pod_class ? s->pod_class : zerop.data(), (size_t)P));
-    TRY(dupload(core, &c.p_nominated, prep.pod_nominated.data(), (size_t)P));
-    TRY(dupload(core, &c.p_scls, prep.pod_scls.data(), (size_t)P));
-    TRY(dupload(core, &c.s_job, s->podset_job, (size_t)S));
-    TRY(dupload(core, &c.s_min, s->podset_min_available, (size_t)S));
-    TRY(dupload(core, &c.s_name_rank, s->podset_name_rank, (size_t)S));
-    TRY(dupload(core, &c.j_queue, s->job_queue, (size_t)J));
-    TRY(dupload(core, &c.j_prio, s->job_priority, (size_t)J));
-    TRY(dupload(core, &c.j_preempt, s->job_preemptible, (size_t)J));
-    TRY(dupload(core, &c.j_created, s->job_created_ns, (size_t)J));
-    TRY(dupload(core, &c.j_uid_rank, s->job_uid_rank, (size_t)J));
-    TRY(dupload(core, &c.j_first_pod, s->job_first_pod, (size_t)J));
-    TRY(dupload(core, &c.j_n_pods, s->job_n_pods, (size_t)J));
-    TRY(dupload(core, &c.j_first_ps, s->job_first_podset, (size_t)J));
-    TRY(dupload(core, &c.j_n_ps, s->job_n_podsets, (size_t)J));
-    TRY(dupload(core, &c.q_parent, s->queue_parent, (size_t)Q));
-    TRY(dupload(core, &c.q_prio, s->queue_priority, (size_t)Q));
-    TRY(dupload(core, &c.q_created, s->queue_created_ns, (size_t)Q));
-    TRY(dupload(core, &c.q_uid_rank, s->queue_uid_rank, (size_t)Q));
-    if (s->class_fit && s->n_pod_classes > 0 && s->n_node_classes > 0) TRY(dupload(core, &c.class_fit, s->class_fit, (size_t)s->n_pod_classes * s->n_node_classes));
-    else TRY(dupload(core, &c.class_fit, &one, (size_t)1));
-    TRY(dupload(core, &c.j_pods_sorted, prep.sorted.data(), (size_t)P));
-    TRY(dupload(core, &c.q_child_off, prep.child_off.data(), (size_t)Q + 2));
-    TRY(dupload(core, &c.q_children, prep.children.data(), (size_t)std::max(Q, 1)));
-    TRY(dupload(core, &c.q_job_off, prep.job_off.data(), (size_t)Q + 1));
-    TRY(dupload(core, &c.jobs_static, prep.jobs_static.data(), (size_t)std::max(J, 1)));
-    TRY(dupload(core, &c.q_depth_order, prep.depth_order.data(), (size_t)Q));
+    TRY(dupload_f(core, c.n_alloc, prep.node_alloc.data(), (size_t)R * N));
+    TRY(dupload_f(core, c.n_flags, prep.node_flags.data(), (size_t)N));
+    TRY(dupload_f(core, c.n_gpu_count, prep.node_gpu_count.data(), (size_t)N));
+    TRY(dupload_f(core, c.n_class, prep.node_class.data(), (size_t)N));
+    TRY(dupload_f(core, c.p_req, s->pod_req, (size_t)R * P));
+    TRY(dupload_f(core, c.p_job, s->pod_job, (size_t)P));
+    TRY(dupload_f(core, c.p_podset, s->pod_podset, (size_t)P));
+    TRY(dupload_f(core, c.p_flags, s->pod_flags ? s->pod_flags : zeropu.data(), (size_t)P));
+    TRY(dupload_f(core, c.p_class, s->pod_class ? s->pod_class : zerop.data(), (size_t)P));
+    TRY(dupload_f(core, c.p_nominated, prep.pod_nominated.data(), (size_t)P));
+    TRY(dupload_f(core, c.p_scls, prep.pod_scls.data(), (size_t)P));
+    TRY(dupload_f(core, c.s_job, s->podset_job, (size_t)S));
+    TRY(dupload_f(core, c.s_min, s->podset_min_available, (size_t)S));
+    TRY(dupload_f(core, c.s_name_rank, s->podset_name_rank, (size_t)S));
+    TRY(dupload_f(core, c.j_queue, s->job_queue, (size_t)J));
+    TRY(dupload_f(core, c.j_prio, s->job_priority, (size_t)J));
+    TRY(dupload_f(core, c.j_preempt, s->job_preemptible, (size_t)J));
+    TRY(dupload_f(core, c.j_created, s->job_created_ns, (size_t)J));
+    TRY(dupload_f(core, c.j_uid_rank, s->job_uid_rank, (size_t)J));
+    TRY(dupload_f(core, c.j_first_pod, s->job_first_pod, (size_t)J));
+    TRY(dupload_f(core, c.j_n_pods, s->job_n_pods, (size_t)J));
+    TRY(dupload_f(core, c.j_first_ps, s->job_first_podset, (size_t)J));
+    TRY(dupload_f(core, c.j_n_ps, s->job_n_podsets, (size_t)J));
+    TRY(dupload_f(core, c.q_parent, s->queue_parent, (size_t)Q));
+    TRY(dupload_f(core, c.q_prio, s->queue_priority, (size_t)Q));
+    TRY(dupload_f(core, c.q_created, s->queue_created_ns, (size_t)Q));
+    TRY(dupload_f(core, c.q_uid_rank, s->queue_uid_rank, (size_t)Q));
+    if (s->class_fit && s->n_pod_classes > 0 && s->n_node_classes > 0) TRY(dupload_f(core, c.class_fit, s->class_fit, (size_t)s->n_pod_classes * s->n_node_classes));
+    else TRY(dupload_f(core, c.class_fit, &one, (size_t)1));
+    TRY(dupload_f(core, c.j_pods_sorted, prep.sorted.data(), (size_t)P));
+    TRY(dupload_f(core, c.q_child_off, prep.child_off.data(), (size_t)Q + 2));
+    TRY(dupload_f(core, c.q_children, prep.children.data(), (size_t)std::max(Q, 1)));
+    TRY(dupload_f(core, c.q_job_off, prep.job_off.data(), (size_t)Q + 1));
+    TRY(dupload_f(core, c.jobs_static, prep.jobs_static.data(), (size_t)std::max(J, 1)));
+    TRY(dupload_f(core, c.q_depth_order, prep.depth_order.data(), (size_t)Q));
     { const int32_t* t; TRY(dupload(core, &t, prep.slot_queue.data(), (size_t)std::max(J, 1))); core->d_slot_queue = const_cast<int32_t*>(t);
       TRY(dupload(core, &t, prep.lvl_off.data(), prep.lvl_off.size())); core->d_lvl_off = const_cast<int32_t*>(t);
       TRY(dupload(core, &t, prep.lvl_parents.data(), prep.lvl_parents.size())); core->d_lvl_parents = const_cast<int32_t*>(t); }
@@ -223,37 +248,36 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64;
     c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok;
     { int d = core->cfg.queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
-    TRY(dupload(core, &c.cls, prep.classes.data(), prep.classes.size()));
-    TRY(dzero(core, &c.sum1_key, (size_t)std::max(c.C, 1) * std::max(c.NB, 1))); TRY(dzero(core, &c.sum1_node, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)));
+    TRY(dupload_f(core, c.cls, prep.classes.data(), prep.classes.size()));
+    TRY(dzero_f(core, c.sum1_key, (size_t)std::max(c.C, 1) * std::max(c.NB, 1))); TRY(dzero_f(core, c.sum1_node, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)));
 
     // ---- dynamic state
     double* d;
-    TRY(dalloc(core, &d, (size_t)R * N)); c.n_idle = d;
-    if ((size_t)R * N) HIP_TRY(core, hipMemcpyAsync(c.n_idle, c.n_alloc, (size_t)R * N * sizeof(double), hipMemcpyDeviceToDevice, core->stream));  // NewNodeInfo: Idle = Allocatable
-    TRY(dzero(core, &c.n_rel, (size_t)R * N)); TRY(dzero(core, &c.n_used, (size_t)R * N));
-    { int32_t* t; TRY(dalloc(core, &t, (size_t)P)); c.p_status = t; if (P) HIP_TRY(core, hipMemcpyAsync(t, s->pod_status, (size_t)P * 4, hipMemcpyHostToDevice, core->stream));
-      TRY(dalloc(core, &t, (size_t)P)); c.p_node = t; if (P) HIP_TRY(core, hipMemcpyAsync(t, prep.pod_node.data(), (size_t)P * 4, hipMemcpyHostToDevice, core->stream)); }
-    TRY(dzero(core, &c.p_on_node, (size_t)P)); TRY(dzero(core, &c.p_on_node_status, (size_t)P)); TRY(dzero(core, &c.p_virtual, (size_t)P)); TRY(dzero(core, &c.p_accepted, (size_t)P));
-    TRY(dzero(core, &c.s_active_alloc, (size_t)S)); TRY(dzero(core, &c.s_active_used, (size_t)S)); TRY(dzero(core, &c.s_alive, (size_t)S)); TRY(dzero(core, &c.s_gated, (size_t)S)); TRY(dzero(core, &c.s_pipelined, (size_t)S));
-    TRY(dzero(core, &c.j_n_pending, (size_t)J)); TRY(dzero(core, &c.j_tta_valid, (size_t)J)); TRY(dzero(core, &c.j_tta_n, (size_t)J)); TRY(dzero(core, &c.tta, (size_t)P));
-    TRY(dzero(core, &c.j_tta_res, (size_t)3 * J)); TRY(dzero(core, &c.j_allocated, (size_t)3 * J));
-    TRY(dzero(core, &c.lq_sorted, (size_t)J)); TRY(dzero(core, &c.lq_side, (size_t)J)); TRY(dzero(core, &c.lq_cur, (size_t)Q)); TRY(dzero(core, &c.lq_end, (size_t)Q)); TRY(dzero(core, &c.lq_side_len, (size_t)Q));
-    TRY(dzero(core, &c.j_state, (size_t)J));
-    TRY(dzero(core, &c.qheap, (size_t)Q + 1)); TRY(dzero(core, &c.root_heap, (size_t)Q + 1)); TRY(dzero(core, &c.qn, (size_t)Q + 1));
-    c.ops_cap = 4 * P + 64; TRY(dalloc(core, &c.ops, (size_t)c.ops_cap));
-    c.out_cap = (int64_t)2 * P + 64; TRY(dalloc(core, &c.out_ops, (size_t)c.out_cap));
-    TRY(dzero(core, &c.scratch, (size_t)P + 64));
-    TRY(dzero(core, &c.st, (size_t)1));
+    TRY(dalloc_f(core, c.n_idle, (size_t)R * N)); (void)d;
+    if ((size_t)R * N) HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.n_idle), KAI_VP(c.n_alloc), (size_t)R * N * sizeof(double), hipMemcpyDeviceToDevice, core->stream));  // NewNodeInfo: Idle = Allocatable
+    TRY(dzero_f(core, c.n_rel, (size_t)R * N)); TRY(dzero_f(core, c.n_used, (size_t)R * N));
+    TRY(dupload_f(core, c.p_status, s->pod_status, (size_t)P)); TRY(dupload_f(core, c.p_node, prep.pod_node.data(), (size_t)P));
+    TRY(dzero_f(core, c.p_on_node, (size_t)P)); TRY(dzero_f(core, c.p_on_node_status, (size_t)P)); TRY(dzero_f(core, c.p_virtual, (size_t)P)); TRY(dzero_f(core, c.p_accepted, (size_t)P));
+    TRY(dzero_f(core, c.s_active_alloc, (size_t)S)); TRY(dzero_f(core, c.s_active_used, (size_t)S)); TRY(dzero_f(core, c.s_alive, (size_t)S)); TRY(dzero_f(core, c.s_gated, (size_t)S)); TRY(dzero_f(core, c.s_pipelined, (size_t)S));
+    TRY(dzero_f(core, c.j_n_pending, (size_t)J)); TRY(dzero_f(core, c.j_tta_valid, (size_t)J)); TRY(dzero_f(core, c.j_tta_n, (size_t)J)); TRY(dzero_f(core, c.tta, (size_t)P));
+    TRY(dzero_f(core, c.j_tta_res, (size_t)4 * J)); TRY(dzero_f(core, c.j_allocated, (size_t)4 * J));
+    TRY(dzero_f(core, c.lq_sorted, (size_t)J)); TRY(dzero_f(core, c.lq_side, (size_t)J)); TRY(dzero_f(core, c.lq_cur, (size_t)Q)); TRY(dzero_f(core, c.lq_end, (size_t)Q)); TRY(dzero_f(core, c.lq_side_len, (size_t)Q));
+    TRY(dzero_f(core, c.j_state, (size_t)J));
+    TRY(dzero_f(core, c.qheap, (size_t)Q + 1)); TRY(dzero_f(core, c.root_heap, (size_t)Q + 1)); TRY(dzero_f(core, c.qn, (size_t)Q + 1));
+    c.ops_cap = 4 * P + 64; TRY(dalloc_f(core, c.ops, (size_t)c.ops_cap));
+    c.out_cap = (int64_t)2 * P + 64; TRY(dalloc_f(core, c.out_ops, (size_t)c.out_cap));
+    TRY(dzero_f(core, c.scratch, (size_t)P + 64));
+    TRY(dzero_f(core, c.st, (size_t)1));
     TRY(dzero(core, &core->d_jsum, (size_t)9 * J));
     TRY(dzero(core, &core->d_weight, (size_t)3 * Q)); TRY(dzero(core, &core->d_rem_amt, (size_t)3 * Q)); TRY(dzero(core, &core->d_rem_has, (size_t)3 * Q));
     TRY(dzero(core, &core->d_best_out, (size_t)2));
-    { const QShare* t; TRY(dupload(core, &t, prep.shares.data(), prep.shares.size())); c.q_share = const_cast<QShare*>(t); }
+    TRY(dupload_f(core, c.q_share, prep.shares.data(), prep.shares.size()));
     // keep the initial dynamic state in HBM so that kai_session_reset needs no host traffic
     TRY(dalloc(core, &core->d_status0, (size_t)P)); TRY(dalloc(core, &core->d_node0, (size_t)P)); TRY(dalloc(core, &core->d_shares0, (size_t)std::max(Q, 1) * 3));
 #undef TRY
-    if (P) { HIP_TRY(core, hipMemcpyAsync(core->d_status0, c.p_status, (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream));
-             HIP_TRY(core, hipMemcpyAsync(core->d_node0, c.p_node, (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream)); }
-    HIP_TRY(core, hipMemcpyAsync(core->d_shares0, c.q_share, (size_t)std::max(Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
+    if (P) { HIP_TRY(core, hipMemcpyAsync(core->d_status0, KAI_VP(c.p_status), (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream));
+             HIP_TRY(core, hipMemcpyAsync(core->d_node0, KAI_VP(c.p_node), (size_t)P * 4, hipMemcpyDeviceToDevice, core->stream)); }
+    HIP_TRY(core, hipMemcpyAsync(core->d_shares0, KAI_VP(c.q_share), (size_t)std::max(Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
     { KaiCtx* t = nullptr; int rc3 = dalloc(core, &t, (size_t)1); if (rc3) return rc3; core->d_ctx = t; }
     HIP_TRY(core, hipMemcpyAsync(core->d_ctx, &core->ctx, sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
     { int rc2 = launch_open_kernels(core); if (rc2) return rc2; }
@@ -273,12 +297,12 @@ int kai_session_reset(kai_core* core) {
     KaiCtx& c = core->ctx;
     const size_t RN = (size_t)c.R * c.N;
     HIP_TRY(core, hipEventRecord(core->ev0, core->stream));
-    if (RN) { HIP_TRY(core, hipMemcpyAsync(c.n_idle, c.n_alloc, RN * 8, hipMemcpyDeviceToDevice, core->stream));
-              HIP_TRY(core, hipMemsetAsync(c.n_rel, 0, RN * 8, core->stream)); HIP_TRY(core, hipMemsetAsync(c.n_used, 0, RN * 8, core->stream)); }
-    if (c.P) { HIP_TRY(core, hipMemcpyAsync(c.p_status, core->d_status0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream));
-               HIP_TRY(core, hipMemcpyAsync(c.p_node, core->d_node0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream)); }
-    HIP_TRY(core, hipMemcpyAsync(c.q_share, core->d_shares0, (size_t)std::max(c.Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
-    HIP_TRY(core, hipMemsetAsync(c.st, 0, sizeof(EngineState), core->stream));
+    if (RN) { HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.n_idle), KAI_VP(c.n_alloc), RN * 8, hipMemcpyDeviceToDevice, core->stream));
+              HIP_TRY(core, hipMemsetAsync(KAI_VP(c.n_rel), 0, RN * 8, core->stream)); HIP_TRY(core, hipMemsetAsync(KAI_VP(c.n_used), 0, RN * 8, core->stream)); }
+    if (c.P) { HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_status), core->d_status0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream));
+               HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_node), core->d_node0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream)); }
+    HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.q_share), core->d_shares0, (size_t)std::max(c.Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
+    HIP_TRY(core, hipMemsetAsync(KAI_VP(c.st), 0, sizeof(EngineState), core->stream));
     int rc = launch_open_kernels(core); if (rc) return rc;
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));
@@ -294,7 +318,7 @@ int kai_queue_shares(kai_core* core, kai_queue_share* out, int cap) {
     if (cap < Q) return fail(core, KAI_ERR_CAPACITY, "kai_queue_shares: cap < n_queues");
     HIP_TRY(core, hipSetDevice(core->device));
     std::vector<QShare> h((size_t)std::max(Q, 1) * 3);
-    HIP_TRY(core, hipMemcpyAsync(h.data(), core->ctx.q_share, (size_t)Q * 3 * sizeof(QShare), hipMemcpyDeviceToHost, core->stream));
+    HIP_TRY(core, hipMemcpyAsync(h.data(), KAI_VP(core->ctx.q_share), (size_t)Q * 3 * sizeof(QShare), hipMemcpyDeviceToHost, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));
     for (int q = 0; q < Q; q++) for (int k = 0; k < 3; k++) {
         const QShare& x = h[(size_t)q * 3 + k];
@@ -312,11 +336,11 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     KaiCtx& c = core->ctx;
     // reset the per-action scalars, keep the proportion totals
     EngineState st{};
-    HIP_TRY(core, hipMemcpyAsync(&st, c.st, sizeof(st), hipMemcpyDeviceToHost, core->stream));
+    HIP_TRY(core, hipMemcpyAsync(&st, KAI_VP(c.st), sizeof(st), hipMemcpyDeviceToHost, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));
     double total[3] = {st.total[0], st.total[1], st.total[2]};
     st = EngineState{}; st.total[0] = total[0]; st.total[1] = total[1]; st.total[2] = total[2];
-    HIP_TRY(core, hipMemcpyAsync(c.st, &st, sizeof(st), hipMemcpyHostToDevice, core->stream));
+    HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.st), &st, sizeof(st), hipMemcpyHostToDevice, core->stream));
     HIP_TRY(core, hipEventRecord(core->ev0, core->stream));
     const int TB = 256;
     if (c.J) hipLaunchKernelGGL(k_job_init, dim3((c.J + TB - 1) / TB), dim3(TB), 0, core->stream, c);
@@ -332,7 +356,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     if (c.J) hipLaunchKernelGGL(k_drain, dim3(std::min(2048, (c.J + TB - 1) / TB)), dim3(TB), 0, core->stream, c, core->d_slot_queue);
     HIP_TRY(core, hipGetLastError());
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
-    HIP_TRY(core, hipMemcpyAsync(&st, c.st, sizeof(st), hipMemcpyDeviceToHost, core->stream));
+    HIP_TRY(core, hipMemcpyAsync(&st, KAI_VP(c.st), sizeof(st), hipMemcpyDeviceToHost, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));
     float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));
     double upload = core->stats.upload_ms;
@@ -346,7 +370,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     *n_ops = st.out_len;
     if (ops_out) {
         if (st.out_len > ops_cap) return fail(core, KAI_ERR_CAPACITY, "kai_action_execute: ops_cap too small");
-        if (st.out_len) HIP_TRY(core, hipMemcpyAsync(ops_out, c.out_ops, (size_t)st.out_len * sizeof(kai_op), hipMemcpyDeviceToHost, core->stream));
+        if (st.out_len) HIP_TRY(core, hipMemcpyAsync(ops_out, KAI_VP(c.out_ops), (size_t)st.out_len * sizeof(kai_op), hipMemcpyDeviceToHost, core->stream));
         HIP_TRY(core, hipStreamSynchronize(core->stream));
         for (int64_t i = 0; i < st.out_len; i++) if (ops_out[i].node >= 0) ops_out[i].node = core->perm[ops_out[i].node];  // name rank → caller's index
     }
@@ -375,8 +399,8 @@ int kai_pod_states(kai_core* core, int32_t* status_out, int32_t* node_out, int c
     const int P = core->ctx.P;
     if (cap < P) return fail(core, KAI_ERR_CAPACITY, "kai_pod_states: cap < n_pods");
     HIP_TRY(core, hipSetDevice(core->device));
-    if (status_out && P) HIP_TRY(core, hipMemcpyAsync(status_out, core->ctx.p_status, (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
-    if (node_out && P) HIP_TRY(core, hipMemcpyAsync(node_out, core->ctx.p_node, (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
+    if (status_out && P) HIP_TRY(core, hipMemcpyAsync(status_out, KAI_VP(core->ctx.p_status), (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
+    if (node_out && P) HIP_TRY(core, hipMemcpyAsync(node_out, KAI_VP(core->ctx.p_node), (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));
     if (node_out) for (int p = 0; p < P; p++) if (node_out[p] >= 0) node_out[p] = core->perm[node_out[p]];
     return KAI_OK;
@@ -390,9 +414,9 @@ int kai_node_states(kai_core* core, kai_node_state* out, int cap) {
     HIP_TRY(core, hipSetDevice(core->device));
     std::vector<double> idle((size_t)R * N + 1), rel((size_t)R * N + 1), used((size_t)R * N + 1);
     if (N) {
-        HIP_TRY(core, hipMemcpyAsync(idle.data(), core->ctx.n_idle, (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
-        HIP_TRY(core, hipMemcpyAsync(rel.data(), core->ctx.n_rel, (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
-        HIP_TRY(core, hipMemcpyAsync(used.data(), core->ctx.n_used, (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
+        HIP_TRY(core, hipMemcpyAsync(idle.data(), KAI_VP(core->ctx.n_idle), (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
+        HIP_TRY(core, hipMemcpyAsync(rel.data(), KAI_VP(core->ctx.n_rel), (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
+        HIP_TRY(core, hipMemcpyAsync(used.data(), KAI_VP(core->ctx.n_used), (size_t)R * N * 8, hipMemcpyDeviceToHost, core->stream));
     }
     HIP_TRY(core, hipStreamSynchronize(core->stream));
     for (int i = 0; i < N; i++) {

@@ -85,7 +85,7 @@ struct QNode {
     int32_t parent;                   // parent queue or -1 (static)
     uint32_t flags;                   // QF_*
 };
-enum : uint32_t { QF_OVER = 1, QF_STARVED = 2, QF_VIOL = 4, QF_VALID = 8, QF_REORDER = 16, QF_EXISTS = 32, QF_LINKED = 64, QF_LEAF = 128,
+enum : uint32_t { QF_OVER = 1, QF_STARVED = 2, QF_VIOL = 4, QF_VALID = 8, QF_REORDER = 16, QF_EXISTS = 32, QF_LINKED = 64, QF_LEAF = 128, QF_DNJ = 512,
                   QF_TOP = 256 };  // leaf: best_job holds the top job of the leaf (kept across key invalidations, dropped on pop / push)
 
 // Working set of one job attempt on the staged ("fast") path: the chunk's pods with their request vectors and the shares of
@@ -379,7 +379,7 @@ struct Engine {
     // PodGroupInfo.UpdateTaskStatus (api/podgroup_info/job_info.go:228-287) + PodSet.AssignTask (subgroup_info/podset.go:56-99)
     KAI_HD void update_task_status(int p, int status) {
         int j = cx().p_job[p], s = cx().p_podset[p], old = cx().p_status[p];
-        if (st_allocated(old)) for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)k * cx().J + j] -= pquota(p, k);
+        if (st_allocated(old)) for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)j * 4 + k] -= pquota(p, k);
         if (st_active_allocated(old)) cx().s_active_alloc[s]--;
         if (st_active_used(old)) cx().s_active_used[s]--;
         if (st_alive(old)) cx().s_alive[s]--;
@@ -387,7 +387,7 @@ struct Engine {
         if (old == KAI_POD_PIPELINED) cx().s_pipelined[s]--;
         if (old == KAI_POD_PENDING) cx().j_n_pending[j]--;
         cx().p_status[p] = status;
-        if (st_allocated(status)) for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)k * cx().J + j] += pquota(p, k);
+        if (st_allocated(status)) for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)j * 4 + k] += pquota(p, k);
         if (st_active_allocated(status)) cx().s_active_alloc[s]++;
         if (st_active_used(status)) cx().s_active_used[s]++;
         if (st_alive(status)) cx().s_alive[s]++;
@@ -642,7 +642,7 @@ struct Engine {
         cx().j_tta_n[j] = out;
         double res[3] = {0, 0, 0};  // GetTasksToAllocateInitResource :88-113
         for (int i = 0; i < out; i++) { int p = cx().tta[first + i]; for (int k = 0; k < 3; k++) res[k] += pquota(p, k); }
-        for (int k = 0; k < 3; k++) cx().j_tta_res[(size_t)k * cx().J + j] = res[k];
+        for (int k = 0; k < 3; k++) cx().j_tta_res[(size_t)j * 4 + k] = res[k];
         cx().j_tta_valid[j] = 1;
     }
 
@@ -680,7 +680,7 @@ struct Engine {
         const QShare* L = &cx().q_share[(size_t)q * 3];
         int bj = best_job_from_node(q);
         double req[3] = {0, 0, 0};
-        if (bj >= 0) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)k * cx().J + bj]; }
+        if (bj >= 0) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)bj * 4 + k]; }
         uint32_t bits = 0;
         bool over = true, starved = true, viol = false;
         for (int k = 0; k < 3; k++) {
@@ -690,10 +690,15 @@ struct Engine {
             if (qs_allocatable(L[k]) == 0 && with_job > 0) viol = true;       // penalizeZeroShareWithJob :127-176
         }
         if (over) bits |= QF_OVER; if (starved) bits |= QF_STARVED; if (viol) bits |= QF_VIOL;
-        double dwj = dominant_share(q, req), dnj = dominant_share(q, nullptr);  // :178-196, 242-273 ; :198-212
+        double dwj = dominant_share(q, req);  // :178-196, 242-273; the share without the job (:198-212) is computed on demand
         QNode& n = el().qn[q];
-        n.best_job = bj; n.dom_with_job = dwj; n.dom_no_job = dnj;
-        n.flags = (n.flags & ~(QF_OVER | QF_STARVED | QF_VIOL)) | bits | QF_VALID;
+        n.best_job = bj; n.dom_with_job = dwj;
+        n.flags = (n.flags & ~(QF_OVER | QF_STARVED | QF_VIOL | QF_DNJ)) | bits | QF_VALID;
+    }
+    KAI_HD double dom_no_job(int q) {
+        QNode& n = el().qn[q];
+        if (!(n.flags & QF_DNJ)) { n.dom_no_job = dominant_share(q, nullptr); n.flags |= QF_DNJ; }
+        return n.dom_no_job;
     }
     // plugins/proportion/queue_order/queue_order.go:19-73 (allocate ordering: no victims)
     KAI_HD int queue_order(int lq, int rq) {
@@ -705,7 +710,10 @@ struct Engine {
         if (kl.prio < kr.prio) return 1;
         { bool lv = kl.flags & QF_VIOL, rv = kr.flags & QF_VIOL; if (lv && !rv) return 1; if (!lv && rv) return -1; }
         if (kl.dom_with_job < kr.dom_with_job) return -1; if (kl.dom_with_job > kr.dom_with_job) return 1;
-        if (kl.dom_no_job < kr.dom_no_job) return -1; if (kl.dom_no_job > kr.dom_no_job) return 1;
+        {   // prioritizeSmallerResourceShareWithoutTask :198-212 — only reached on an exact tie above
+            double l = dom_no_job(lq), r = dom_no_job(rq);
+            if (l < r) return -1; if (l > r) return 1;
+        }
         {   // prioritizeBasedOnAllocatableShare :214-224
             const QShare* L = &cx().q_share[(size_t)lq * 3]; const QShare* Rr = &cx().q_share[(size_t)rq * 3];
             bool l_le = true, r_le = true;
@@ -1009,12 +1017,15 @@ struct Engine {
         FastFrame& f = KAI_FRAME;
         const bool nominated = cx().plugins & KAI_PLUGIN_NOMINATEDNODE;
         for (int i = 0; i < nt; i++) f.p[i] = cx().tta[first + i];
-        for (int i = 0; i < nt; i++) {
-            int p = f.p[i], k = cx().p_scls[p];
-            if (k < 0 || cx().p_status[p] != KAI_POD_PENDING || cx().p_on_node[p] >= 0 || (nominated && cx().p_nominated[p] >= 0)) return -1;
+        int bad = 0;
+        for (int i = 0; i < nt; i++) {  // independent loads, checked afterwards: nothing here is conditional on an earlier load
+            int p = f.p[i];
+            int k = cx().p_scls[p], st = cx().p_status[p], on = cx().p_on_node[p], nom = cx().p_nominated[p];
             f.cls[i] = k;
+            bad |= (k < 0) | (st != KAI_POD_PENDING) | (on >= 0) | (nominated && nom >= 0);
+            for (int r = 0; r < KAI_MAX_RES; r++) f.req[i][r] = r < cx().R ? preq(p, r) : 0.0;
         }
-        for (int i = 0; i < nt; i++) for (int r = 0; r < KAI_MAX_RES; r++) f.req[i][r] = r < cx().R ? preq(f.p[i], r) : 0.0;
+        if (bad) return -1;
         const bool prop = cx().plugins & KAI_PLUGIN_PROPORTION;
         int d = 0;
         for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
@@ -1028,7 +1039,7 @@ struct Engine {
             for (int i = 0; i < nt; i++) { req[KAI_Q_GPU] += frame_quota(f.req[i], KAI_Q_GPU); req[KAI_Q_CPU] += frame_quota(f.req[i], KAI_Q_CPU); req[KAI_Q_MEM] += frame_quota(f.req[i], KAI_Q_MEM); }
             if (frame_over_limit(f, req) || frame_np_over_quota(f, req)) return 0;
         }
-        double ja[3] = {cx().j_allocated[(size_t)0 * cx().J + j], cx().j_allocated[(size_t)1 * cx().J + j], cx().j_allocated[(size_t)2 * cx().J + j]};
+        double ja[3] = {cx().j_allocated[(size_t)j * 4 + 0], cx().j_allocated[(size_t)j * 4 + 1], cx().j_allocated[(size_t)j * 4 + 2]};
         const bool preds = cx().plugins & KAI_PLUGIN_PREDICATES;
         int done = 0; bool ok = true;
         for (int i = 0; i < nt; i++) {  // allocateTask :121-163
@@ -1087,7 +1098,7 @@ struct Engine {
         }
         if (done > 0) {
             cx().j_tta_valid[j] = 0;
-            for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)k * cx().J + j] = ja[k];
+            for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)j * 4 + k] = ja[k];
             if (prop) for (int l = 0; l < d; l++) {
                 for (int k = 0; k < 3; k++) { QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k]; sh.allocated = f.alloc[l][k]; sh.allocated_np = f.alloc_np[l][k]; }
                 el().qn[f.q[l]].flags &= ~QF_VALID;

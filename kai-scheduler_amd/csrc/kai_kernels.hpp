@@ -104,7 +104,7 @@ __global__ void k_job_usage(KaiCtx c, double* jsum) {
     c.j_n_pending[j] = pending; c.j_tta_valid[j] = 0; c.j_tta_n[j] = 0;
     bool np = !c.j_preempt[j];
     for (int k = 0; k < 3; k++) {
-        c.j_allocated[(size_t)k * c.J + j] = ja[k];
+        c.j_allocated[(size_t)j * 4 + k] = ja[k];
         jsum[(size_t)(0 + k) * c.J + j] = al[k]; jsum[(size_t)(3 + k) * c.J + j] = np ? al[k] : 0.0; jsum[(size_t)(6 + k) * c.J + j] = rq[k];
     }
 }
@@ -356,16 +356,11 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
             const int nd = sh->n_dirty;
             if (nd == 1) {  // the common case (one placement): everything in one pass, upper levels patched in registers
                 const int b = sh->dirty[0], n = b * KAI_BLOCK + lane, sb = b / 64, e = sb * 64 + lane;
-                long long q0 = clock64();
                 NodeRegs ns; load_node(c, n < c.N ? n : 0, ns);
-                double fence_v = ns.idle[0] + ns.rel[0] + ns.alloc_cpu + (double)ns.flags + (double)ns.ncls;  // profiling: wait for the node loads
-                long long q1 = clock64() + (fence_v == -1.25 ? 1 : 0);
                 for (int k = hw; k < c.C; k += SVC) {
                     uint64_t rk = e < c.NB ? c.sum1_key[(size_t)k * c.NB + e] : 0; int rn = e < c.NB ? c.sum1_node[(size_t)k * c.NB + e] : 0x7fffffff;  // L1 row, in flight with the node loads
                     uint64_t tk = lane < c.NSB ? sh->s2_key[k * c.NSB + lane] : 0; int tn = lane < c.NSB ? sh->s2_node[k * c.NSB + lane] : 0x7fffffff;
-                    long long q2 = clock64();
                     uint64_t key = n < c.N ? class_key_regs(c, c.cls[k], ns) : 0; int bn = n;
-                    long long q3 = clock64() + (key == 0x123456789abcull ? 1 : 0);
                     wave_argmax(key, bn);
                     if (lane == 0) { c.sum1_key[(size_t)k * c.NB + b] = key; c.sum1_node[(size_t)k * c.NB + b] = bn; }
                     if (lane == (b & 63)) { rk = key; rn = bn; }
@@ -374,8 +369,6 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
                     if (lane == sb) { tk = rk; tn = rn; }
                     wave_argmax(tk, tn);
                     if (lane == 0) { sh->top_key[k] = tk; sh->top_node[k] = tn; }
-                    long long q4 = clock64() + (tk == 0x123456789abcull ? 1 : 0);
-                    if (threadIdx.x == 64) { sh->t_seg[0] += q1 - q0; sh->t_seg[1] += q2 - q1; sh->t_seg[2] += q3 - q2; sh->t_seg[3] += q4 - q3; }
                 }
             } else {
                 // L1: re-evaluate the dirty blocks for this wave's classes
@@ -455,7 +448,6 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     Engine<DevBackend> eng(c, be);
     if (action == KAI_ACTION_ALLOCATE) eng.execute_allocate();
     c.st->prof[1] = sh.t_publish; c.st->prof[6] = sh.t_wait; c.st->prof[PF_PUSH] = sh.t_svc;
-    c.st->prof[PF_TTA] = sh.t_seg[0]; c.st->prof[PF_GATE] = sh.t_seg[1]; c.st->prof[PF_TASKCAP] = sh.t_seg[2]; c.st->prof[PF_ROLLBACK] = sh.t_seg[3];
     be.finish();
 }
 

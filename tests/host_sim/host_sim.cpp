@@ -126,7 +126,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.p_on_node = own<int32_t>(pool, P); c.p_on_node_status = own<int32_t>(pool, P); c.p_virtual = own<uint8_t>(pool, P); c.p_accepted = own<uint8_t>(pool, P);
     c.s_active_alloc = own<int32_t>(pool, S); c.s_active_used = own<int32_t>(pool, S); c.s_alive = own<int32_t>(pool, S); c.s_gated = own<int32_t>(pool, S); c.s_pipelined = own<int32_t>(pool, S);
     c.j_n_pending = own<int32_t>(pool, J); c.j_tta_valid = own<int32_t>(pool, J); c.j_tta_n = own<int32_t>(pool, J); c.tta = own<int32_t>(pool, P);
-    c.j_tta_res = own<double>(pool, (size_t)3 * J); c.j_allocated = own<double>(pool, (size_t)3 * J);
+    c.j_tta_res = own<double>(pool, (size_t)4 * J); c.j_allocated = own<double>(pool, (size_t)4 * J);
     c.lq_sorted = own<int32_t>(pool, J); c.lq_side = own<int32_t>(pool, J); c.lq_cur = own<int32_t>(pool, Q); c.lq_end = own<int32_t>(pool, Q); c.lq_side_len = own<int32_t>(pool, Q); c.j_state = own<uint8_t>(pool, J);
     c.qheap = own<int32_t>(pool, Q + 1); c.root_heap = own<int32_t>(pool, Q + 1); c.qn = own<QNode>(pool, Q + 1);
     c.ops_cap = 4 * P + 64; c.ops = own<StmtOp>(pool, c.ops_cap); c.out_cap = (int64_t)2 * P + 64; c.out_ops = own<kai_op>(pool, c.out_cap);
@@ -174,7 +174,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             else if (st == KAI_POD_PENDING) for (int k = 0; k < 3; k++) rq[k] += q[k];
         }
         c.j_n_pending[j] = pending;
-        for (int k = 0; k < 3; k++) c.j_allocated[(size_t)k * J + j] = ja[k];
+        for (int k = 0; k < 3; k++) c.j_allocated[(size_t)j * 4 + k] = ja[k];
         if ((c.plugins & KAI_PLUGIN_PROPORTION) && c.j_queue[j] >= 0) for (int k = 0; k < 3; k++) {
             QShare& x = c.q_share[(size_t)c.j_queue[j] * 3 + k];
             x.allocated += al[k]; x.request += rq[k]; if (!c.j_preempt[j]) x.allocated_np += al[k];
