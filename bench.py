@@ -32,6 +32,16 @@ B_NODE, B_POD_OUT = 128, 80  # algorithmic bytes per node of the node set / per 
 CONFIGS = {"C1": 0, "C2": 1, "C3": 2, "C5": 4}
 
 
+def pmc_traffic(workload):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this workload (tools/gpu_prof.sh, tools/pmc_traffic.py), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[workload]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,7 +131,10 @@ def main():
                               "drained_jobs": int(st.reserved[2]), "drained_decisions": int(st.reserved[3]), "jobs_attempted": int(st.jobs_attempted),
                               "jobs_committed": int(st.jobs_committed), "control_cycles": {"pop": int(st.reserved[4]), "allocate": int(st.reserved[5]), "commit_discard": int(st.reserved[6]), "total": int(st.reserved[7])}}},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_action", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                     "traffic": pmc_traffic(desc), "kernel": "k_action (+ k_job_init, k_leaf_init, k_drain on the same stream)", "kernel_ms": k_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "achieved = decisions x (N x 128 B + 80 B) / action time (HIP events); the class index answers a decision from one 64-node block, "
+                             "so PMC traffic is far below the algorithmic bytes: frac is decision throughput against the streaming formulation's roofline"},
     }
 
     if rank == 0 and world == 1 and args.cpu_sample != 0:
