@@ -54,32 +54,24 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a MI355X: the scheduling-cycle core has no CPU path"
 
     import __graft_entry__ as G
     pkg = G._load_pkg()
+    rank, local_rank, world = pkg.dist.env_world()
+    assert torch.cuda.is_available(), "bench.py needs a MI355X: the scheduling-cycle core has no CPU path"
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        pkg.dist.init("nccl", device=torch.device("cuda", local_rank))
     pkg.load_library()
 
     idx = CONFIGS[args.config]
     t0 = time.time()
-    snap, cfg, desc = pkg.synth.config(idx, args.scale)
+    snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=pkg.dist.shard_seed(0, rank))  # every rank schedules its own shard
     gen_s = time.time() - t0
     N = snap.n_nodes
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        pkg.dist.barrier(torch.cuda.synchronize)
 
     core = pkg.KaiCore(cfg, gpu_ids=(local_rank,))
     t0 = time.time()
@@ -107,13 +99,10 @@ def main():
         st = step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pkg.dist.max_over_ranks(elapsed, device="cuda")
     ssn.close(); core.destroy()
 
-    total_decisions = decisions * args.steps * world  # every rank runs its own replica of the workload (see DESIGN.md "Multi-GPU")
+    total_decisions = pkg.dist.sum_over_ranks(decisions * args.steps, device="cuda")  # one scheduling shard per rank (DESIGN.md "Multi-GPU")
     value = total_decisions / elapsed
     k_ms = float(np.mean(kernel_ms))
     alg_bytes = decisions * (N * B_NODE + B_POD_OUT)
@@ -125,7 +114,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "nodes": N, "pods": snap.n_pods, "jobs": snap.n_jobs, "queues": snap.n_queues,
                    "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2],
-                   "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (node-axis sharding not built yet)",
+                   "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else f"{world} scheduling shards, one per GPU, no data-path collective",
                    "snapshot_gen_s": round(gen_s, 2), "host_to_hbm_s": round(upload_s, 3),
                    "engine": {"index_queries": int(st.reserved[0]), "block_refreshes": int(st.reserved[1]), "brute_force_scans": int(st.node_scans),
                               "drained_jobs": int(st.reserved[2]), "drained_decisions": int(st.reserved[3]), "jobs_attempted": int(st.jobs_attempted),
@@ -149,8 +138,7 @@ def main():
                                "sample": f"first {done} decisions of the same snapshot in {ref.elapsed_ms / 1e3:.1f} s (oracle/liboracle.so, single thread, incl. session open)"}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    pkg.dist.finish()
 
 
 if __name__ == "__main__":

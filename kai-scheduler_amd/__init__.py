@@ -5,7 +5,7 @@ include/kai_core.h), `abi` (ctypes mirror + structure-of-arrays snapshot), `core
 Session / Action interface re-exposed over the C ABI) and `synth` (synthetic cluster snapshots of
 BASELINE.json's configs).
 """
-from . import abi, core, synth  # noqa: F401
+from . import abi, core, dist, synth  # noqa: F401
 from .core import KaiCore, KaiError, Session, load_library  # noqa: F401
 
-__all__ = ["abi", "core", "synth", "KaiCore", "KaiError", "Session", "load_library"]
+__all__ = ["abi", "core", "dist", "synth", "KaiCore", "KaiError", "Session", "load_library"]

@@ -1,0 +1,73 @@
+"""Multi-GPU plumbing of the scheduling-cycle core: one process per GPU, one scheduling shard per process.
+
+The reference scales by SchedulingShards — node-pool partitions, each served by its own scheduler instance with its own
+session (conf/scheduler_conf.go:95-112 node-pool label filter; pkg/operator SchedulingShard).  Shards never exchange data on
+the placement path, so the only cross-rank operations are the timing barrier and the max-over-ranks of the elapsed time that
+bench.py's contract asks for.  No data-path collective exists (DESIGN.md "Multi-GPU").
+"""
+from __future__ import annotations
+
+import os
+
+
+def env_world():
+    """(rank, local_rank, world_size) as torch.distributed.run exports them; (0, 0, 1) when launched plainly."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_seed(base_seed: int, rank: int) -> int:
+    """Every rank schedules its own shard: same shape, different contents (weak scaling)."""
+    return base_seed + 1000003 * rank
+
+
+def init(backend: str, device=None):
+    """Join the process group (nccl = RCCL on the GPU box, gloo in the CPU tests).  No-op for a single process."""
+    import torch.distributed as dist
+
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": device} if (device is not None and backend == "nccl") else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def barrier(sync=None):
+    """Device sync + rank barrier + device sync (the bracket bench.py's contract prescribes)."""
+    import torch.distributed as dist
+
+    if sync:
+        sync()
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if sync:
+        sync()
+
+
+def max_over_ranks(value: float, device="cpu") -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device="cpu") -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def finish():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

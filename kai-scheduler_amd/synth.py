@@ -145,9 +145,9 @@ def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill
     return snap
 
 
-def config(idx: int, scale: float = 1.0) -> tuple[abi.Snapshot, abi.KaiConfig, str]:
+def config(idx: int, scale: float = 1.0, seed_offset: int = 0) -> tuple[abi.Snapshot, abi.KaiConfig, str]:
     """BASELINE.json configs[idx] (0-based) → (snapshot, config, description).  `scale` shrinks node and pod counts together."""
-    seed = SEED0 + idx
+    seed = SEED0 + idx + seed_offset
     n = lambda x: max(1, int(round(x * scale)))
     if idx == 0:   # C1: 16 nodes / 64 single-pod jobs, single queue, bin-pack (plumbing)
         s = make_snapshot(16, 64, seed, queue_levels=(1, 1), prefill=0.0, single_pod_jobs=True, uniform_nodes=True, cpu_per_gpu=1000.0, mem_per_gpu=1e9)
