@@ -884,5 +884,40 @@ int kai_oracle_set_resources_share(int Q, const double* total, double k_value, c
     return KAI_OK;
 }
 
+double kai_oracle_spread_score(double non_allocated, double count) {  // plugins/nodeplacement/spread.go:16-36
+    return count == 0 ? 0.0 : non_allocated / count;
+}
+// ONE resource of one sibling set, as the reference's unit tests drive it (resource_division_test.go):
+// mode 0 = setResourceShare (resource_division.go:33-42), mode 1 = divideOverQuotaResource (:111-162) on preset fair shares.
+int kai_oracle_divide_one(int mode, int Q, double total, double k_value, const double* deserved, const double* limit, const double* oqw, const double* request,
+                          const double* usage, const double* fair_in, const int* priority, const int64_t* created_ns, double* fair_out, double* remaining_out) {
+    std::vector<orc::QueueAttributes> qs(Q); std::vector<orc::QueueAttributes*> ptr;
+    for (int q = 0; q < Q; q++) {
+        qs[q].idx = q; qs[q].uidRank = q; qs[q].priority = priority ? priority[q] : 0; qs[q].createdNs = created_ns ? created_ns[q] : q;
+        auto& s = qs[q].share[2]; s.Deserved = deserved[q]; s.MaxAllowed = limit[q]; s.OverQuotaWeight = oqw[q]; s.Request = request[q]; s.Usage = usage ? usage[q] : 0; s.FairShare = fair_in ? fair_in[q] : 0;
+        ptr.push_back(&qs[q]);
+    }
+    double remaining;
+    if (mode == 0) { remaining = orc::resource_division::setDeservedResource(total, ptr, 2); remaining = remaining > 0 ? orc::resource_division::divideOverQuotaResource(remaining, k_value, ptr, 2) : 0; }
+    else remaining = orc::resource_division::divideOverQuotaResource(total, k_value, ptr, 2);
+    for (int q = 0; q < Q; q++) fair_out[q] = qs[q].share[2].FairShare;
+    if (remaining_out) *remaining_out = remaining;
+    return KAI_OK;
+}
+
+// queue_order.GetQueueOrderResult (plugins/proportion/queue_order/queue_order.go:19-73) for two queues without jobs or victims.
+// shares: [2 queues][3 resources CPU,Memory,GPU][7] = deserved, fair, max_allowed, oqw, allocated, allocated_np, request
+int kai_oracle_queue_order(const double* shares, const int* priority, const int64_t* created_ns, const double* total) {
+    orc::Session ssn; ssn.cfg = kai_config{}; ssn.cfg.plugins = KAI_PLUGIN_ALL;
+    ssn.qattrs.resize(2); ssn.queues.resize(2);
+    for (int q = 0; q < 2; q++) {
+        ssn.qattrs[q].idx = q; ssn.qattrs[q].uidRank = q; ssn.qattrs[q].priority = priority[q]; ssn.qattrs[q].createdNs = created_ns[q];
+        for (int r = 0; r < 3; r++) { const double* v = shares + (q * 3 + r) * 7; auto& s = ssn.qattrs[q].share[r];
+            s.Deserved = v[0]; s.FairShare = v[1]; s.MaxAllowed = v[2]; s.OverQuotaWeight = v[3]; s.Allocated = v[4]; s.AllocatedNotPreemptible = v[5]; s.Request = v[6]; }
+    }
+    ssn.totalResource = {total[0], total[1], total[2]};
+    return ssn.queueOrder(0, 1, nullptr, nullptr, {}, {});
+}
+
 const char* kai_oracle_version(void) { return "kai_oracle 1 (CPU restatement; test infrastructure)"; }
 }

@@ -1,0 +1,79 @@
+"""Known-answer tests of the reference's own unit tests, hand-transcribed into tests/golden/kat_*.json (source file and line in
+each entry): the oracle's pure functions must return exactly (==, float64) what the Go tests expect."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import kai_testlib as T
+
+
+def _load(name):
+    with open(os.path.join(T.GOLDEN, name)) as f:
+        return json.load(f)
+
+
+DIV = _load("kat_resource_division.json")
+NP = _load("kat_nodeplacement.json")
+
+
+def _lib():
+    lib = T.Oracle.lib()
+    lib.kai_oracle_spread_score.restype = C.c_double
+    lib.kai_oracle_spread_score.argtypes = [C.c_double, C.c_double]
+    lib.kai_oracle_divide_one.restype = C.c_int
+    return lib
+
+
+@pytest.mark.parametrize("case", DIV["cases"], ids=[f"L{c['line']}" for c in DIV["cases"]])
+def test_resource_division_kat(case):
+    lib = _lib()
+    qs = case["queues"]; Q = len(qs)
+    arr = lambda k: np.array([q[k] for q in qs], np.float64)
+    deserved, limit, oqw, request, fair = arr("deserved"), arr("max_allowed"), arr("oqw"), arr("request"), arr("fair")
+    prio = np.array([q["priority"] for q in qs], np.int32); created = np.array([q["created"] for q in qs], np.int64)
+    out = np.zeros(Q, np.float64); rem = C.c_double(0)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = lib.kai_oracle_divide_one(0 if case["fn"] == "setResourceShare" else 1, Q, C.c_double(case["total"]), C.c_double(case["k_value"]),
+                                   p(deserved, C.c_double), p(limit, C.c_double), p(oqw, C.c_double), p(request, C.c_double), None, p(fair, C.c_double),
+                                   p(prio, C.c_int), p(created, C.c_int64), p(out, C.c_double), C.byref(rem))
+    assert rc == 0
+    assert rem.value == case["remaining"], (case["name"], rem.value)
+    assert out.tolist() == [float(x) for x in case["fair"]], (case["name"], out.tolist())
+
+
+@pytest.mark.parametrize("case", NP["pack"], ids=[f"L{c['line']}" for c in NP["pack"]])
+def test_nodepack_kat(case):
+    lib = _lib()
+    # getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86): nodes without the resource are skipped, min starts at MaxFloat64, max at 0
+    lo, hi = np.finfo(np.float64).max, 0.0
+    for n in case["nodes"]:
+        if n["alloc"] == 0:
+            continue
+        lo, hi = min(lo, float(n["idle"])), max(hi, float(n["idle"]))
+    for n in case["nodes"]:
+        got = lib.kai_oracle_pack_score(lo, hi, float(n["idle"]), float(n["alloc"]))
+        assert got == n["score"], (case["name"], n, got)
+
+
+def test_nodespread_kat():
+    lib = _lib()
+    for c in NP["spread"]:
+        assert lib.kai_oracle_spread_score(float(c["non_allocated"]), float(c["count"])) == c["score"], c
+
+
+QO = _load("kat_queue_order.json")
+
+
+@pytest.mark.parametrize("case", QO["cases"], ids=[f"L{c['line']}" for c in QO["cases"]])
+def test_queue_order_kat(case):
+    lib = _lib()
+    lib.kai_oracle_queue_order.restype = C.c_int
+    f = ("deserved", "fair", "max_allowed", "oqw", "allocated", "allocated_np", "request")
+    shares = np.array([[[side[res][k] for k in f] for res in ("cpu", "memory", "gpu")] for side in (case["l"], case["r"])], np.float64)
+    prio = np.array([case["l"]["priority"], case["r"]["priority"]], np.int32); created = np.array([1, 2], np.int64); total = np.zeros(3, np.float64)
+    got = lib.kai_oracle_queue_order(shares.ctypes.data_as(C.POINTER(C.c_double)), prio.ctypes.data_as(C.POINTER(C.c_int)),
+                                     created.ctypes.data_as(C.POINTER(C.c_int64)), total.ctypes.data_as(C.POINTER(C.c_double)))
+    assert got == case["expected"], case["name"]
