@@ -129,7 +129,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         import kai_testlib as T
         # bounded sample: the oracle walks the SAME snapshot in the same fair order and stops after `sample` decisions
-        sample = args.cpu_sample if args.cpu_sample > 0 else max(50, int(6e7 / max(N, 1)))
+        sample = args.cpu_sample if args.cpu_sample > 0 else max(200, int(3e8 / max(N, 1)))  # about 10-20 s of single-thread oracle work
         c2 = T.abi.KaiConfig.from_buffer_copy(cfg)
         c2.reserved[0] = sample
         ref = T.Oracle.run(snap, c2, ("allocate",))

@@ -60,7 +60,7 @@ def _queue_tree(levels, rng, total_gpu, zipf=False, limits_frac=0.0, prios=(100,
 def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill=0.3, gpu_mix=((8, 1.0),), cpu_only_frac=0.0,
                   gang_sizes=(1, 2, 4, 8), gang_p=(0.4, 0.2, 0.2, 0.2), gpus_per_pod=(1, 2, 4, 8), zipf=False, limits_frac=0.0,
                   queue_prios=(100,), oqws=(1.0,), nonpreempt_frac=0.0, usage_max=0.0, lexi_names=False, single_pod_jobs=False,
-                  uniform_nodes=False, cpu_per_gpu=4000.0, mem_per_gpu=32 * GIB) -> abi.Snapshot:
+                  uniform_nodes=False, cpu_per_gpu=4000.0, mem_per_gpu=32 * GIB, elastic_frac=0.0, multi_podset_frac=0.0, task_prio_frac=0.0) -> abi.Snapshot:
     rng = np.random.default_rng(seed)
     R = 4
     N = n_nodes
@@ -129,13 +129,39 @@ def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill
     a["node_flags"] = np.zeros(N, np.uint32)
     a["node_gpu_count"] = gpus.astype(np.int32)
     a["node_name_rank"] = abi.rank_strings(node_names) if lexi_names else np.arange(N, dtype=np.uint32)
-    a["pod_req"] = pod_req; a["pod_job"] = pod_job; a["pod_podset"] = pod_job.copy()  # one pod-set ("default") per job
+    # ---- pod-sets: one ("default") per job, or — for a fraction of the pending gangs — two named sub-groups; a fraction of the
+    # single-pod-set gangs is elastic (minAvailable < pods: the job grows one pod per pop, allocate.go:69-72)
+    n_ps = np.ones(J, np.int32)
+    draw = lambda frac: (rng.random(J) < frac) if frac > 0 else np.zeros(J, bool)  # no RNG draw when the feature is off: the BASELINE configs stay as they were
+    multi = draw(multi_podset_frac) & (job_sizes >= 2) & (np.arange(J) < nj)
+    n_ps[multi] = 2
+    first_ps = np.concatenate([[0], np.cumsum(n_ps)[:-1]]).astype(np.int32) if J else np.zeros(0, np.int32)
+    S = int(n_ps.sum())
+    podset_job = np.repeat(np.arange(J, dtype=np.int32), n_ps)
+    podset_min = np.zeros(S, np.int32); podset_rank = np.zeros(S, np.uint32)
+    pod_podset = np.zeros(P, np.int32)
+    elastic = draw(elastic_frac) & (job_sizes >= 2) & ~multi & (np.arange(J) < nj)
+    for j in range(J):
+        b, n, s0 = int(first_pod[j]), int(job_sizes[j]), int(first_ps[j])
+        if n_ps[j] == 1:
+            podset_min[s0] = max(1, n // 2) if elastic[j] else n
+            pod_podset[b:b + n] = s0
+        else:
+            h = n // 2
+            podset_min[s0], podset_min[s0 + 1] = h, n - h
+            podset_rank[s0], podset_rank[s0 + 1] = 0, 1
+            pod_podset[b:b + h] = s0; pod_podset[b + h:b + n] = s0 + 1
+    a["pod_req"] = pod_req; a["pod_job"] = pod_job; a["pod_podset"] = pod_podset
     a["pod_status"] = pod_status; a["pod_node"] = pod_node
     a["pod_uid_rank"] = np.arange(P, dtype=np.uint32)  # pod UIDs are zero-padded by construction
-    a["podset_job"] = np.arange(J, dtype=np.int32); a["podset_min_available"] = job_sizes.copy(); a["podset_name_rank"] = np.zeros(J, np.uint32)
+    if task_prio_frac > 0:  # task-order label on some pods (plugins/taskorder/task_order.go:28-63)
+        has = rng.random(P) < task_prio_frac
+        a["pod_flags"] = np.where(has, abi.POD_HAS_TASK_PRIORITY, 0).astype(np.uint32)
+        a["pod_task_priority"] = rng.integers(0, 4, size=P).astype(np.int32)
+    a["podset_job"] = podset_job; a["podset_min_available"] = podset_min; a["podset_name_rank"] = podset_rank
     a["job_queue"] = job_queue; a["job_priority"] = job_prio; a["job_preemptible"] = (job_prio < 100).astype(np.int32)
     a["job_created_ns"] = created; a["job_uid_rank"] = np.arange(J, dtype=np.uint32)
-    a["job_first_pod"] = first_pod; a["job_n_pods"] = job_sizes; a["job_first_podset"] = np.arange(J, dtype=np.int32); a["job_n_podsets"] = np.ones(J, np.int32)
+    a["job_first_pod"] = first_pod; a["job_n_pods"] = job_sizes; a["job_first_podset"] = first_ps; a["job_n_podsets"] = n_ps
     a["queue_parent"] = qt["parent"]; a["queue_priority"] = qt["prio"]; a["queue_created_ns"] = qt["created"]
     a["queue_uid_rank"] = np.arange(len(qt["parent"]), dtype=np.uint32)
     a["queue_deserved"] = qt["deserved"]; a["queue_limit"] = qt["limit"]; a["queue_oqw"] = qt["oqw"]; a["queue_usage"] = qt["usage"]

@@ -42,3 +42,13 @@ def test_finite_queue_depth():
     for depth in (1, 3, 50):
         c = T.abi.KaiConfig.from_buffer_copy(cfg); c.queue_depth[0] = depth
         run_modes(HostSim.run, snap, c)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_modes_agree_elastic_and_subgroups(seed):
+    """elastic jobs (grow one pod per pop, re-pushed with a changed order key), two-pod-set gangs and task-order labels"""
+    rng = np.random.default_rng(300 + seed)
+    snap = T.pkg.synth.make_snapshot(int(rng.integers(4, 120)), int(rng.integers(20, 900)), 3000 + seed, queue_levels=(2, 2), prefill=float(rng.random()) * 0.6,
+                                     gpu_mix=((8, .6), (4, .4)), zipf=bool(seed % 2), limits_frac=0.2, queue_prios=(100, 200), oqws=(1.0, 2.0),
+                                     nonpreempt_frac=0.1, elastic_frac=0.4, multi_podset_frac=0.3, task_prio_frac=0.3, lexi_names=bool(seed % 3 == 0))
+    run_modes(HostSim.run, snap, T.abi.default_config(k_value=float(seed % 2)))

@@ -140,3 +140,17 @@ def test_gpu_engine_modes_agree(gpu, idx, scale):
         res = run_gpu(snap, c)
         assert_same(res, ref)
         assert (res.stats.decisions, res.stats.jobs_attempted, res.stats.jobs_committed, res.stats.rollbacks) == want, mode
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_gpu_elastic_and_subgroups(gpu, seed):
+    """elastic jobs (re-pushed with a changed order key), two-pod-set gangs and task-order labels through the C ABI, all engine modes"""
+    rng = np.random.default_rng(300 + seed)
+    snap = T.pkg.synth.make_snapshot(int(rng.integers(4, 120)), int(rng.integers(20, 900)), 3000 + seed, queue_levels=(2, 2), prefill=float(rng.random()) * 0.6,
+                                     gpu_mix=((8, .6), (4, .4)), zipf=bool(seed % 2), limits_frac=0.2, queue_prios=(100, 200), oqws=(1.0, 2.0),
+                                     nonpreempt_frac=0.1, elastic_frac=0.4, multi_podset_frac=0.3, task_prio_frac=0.3, lexi_names=bool(seed % 3 == 0))
+    cfg = T.abi.default_config(k_value=float(seed % 2))
+    ref = T.Oracle.run(snap, cfg)
+    for mode in (0, 1, 2):
+        c = T.abi.KaiConfig.from_buffer_copy(cfg); c.engine_mode = mode
+        assert_same(run_gpu(snap, c), ref)
