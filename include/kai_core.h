@@ -265,8 +265,8 @@ int kai_queue_shares(kai_core* core, kai_queue_share* out, int cap);
 int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_cap, int64_t* n_ops);
 
 /* replaces: Session.OrderedNodesByTask + FittingNode for one task (framework/session.go:201-264),
- * against the session's current node state.  nodeset_bitmap may be NULL (= all nodes).
- * node_idx_out = -1 when nothing fits. */
+ * against the session's current node state.  nodeset_bitmap (bit n of word n/32 = node index n, ceil(N/32) words) restricts the
+ * node set as SubsetNodesFn would (framework/session_plugins.go:345-366); NULL = all nodes.  node_idx_out = -1 when nothing fits. */
 int kai_best_node(kai_core* core, int32_t pod_idx, const uint32_t* nodeset_bitmap, int pipeline_only,
                   int32_t* node_idx_out, int* is_pipeline_out);
 

@@ -112,9 +112,16 @@ class Session:
         arr = np.frombuffer(ops, dtype=np.dtype([("seq", "<i8"), ("kind", "<i4"), ("pod", "<i4"), ("node", "<i4"), ("job", "<i4")]), count=n.value)
         return arr.copy()
 
-    def best_node(self, pod: int, pipeline_only: bool = False):
+    def best_node(self, pod: int, pipeline_only: bool = False, nodeset=None):
+        """Session.OrderedNodesByTask + FittingNode for one task; `nodeset` = iterable of node indices (None = all nodes)."""
         node, pipe = C.c_int32(-1), C.c_int(0)
-        self.core._check(self.core.lib.kai_best_node(self.core.handle, pod, None, int(pipeline_only), C.byref(node), C.byref(pipe)))
+        bits = None
+        if nodeset is not None:
+            words = np.zeros(max((self.snap.n_nodes + 31) // 32, 1), np.uint32)
+            for n in nodeset:
+                words[n >> 5] |= np.uint32(1 << (n & 31))
+            bits = words.ctypes.data_as(C.POINTER(C.c_uint32))
+        self.core._check(self.core.lib.kai_best_node(self.core.handle, pod, bits, int(pipeline_only), C.byref(node), C.byref(pipe)))
         return node.value, bool(pipe.value)
 
     def queue_shares(self):

@@ -380,14 +380,23 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
 int kai_best_node(kai_core* core, int32_t pod_idx, const uint32_t* nodeset_bitmap, int pipeline_only, int32_t* node_idx_out, int* is_pipeline_out) {
     if (!core || !node_idx_out) return KAI_ERR_INVALID_ARG;
     if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
-    if (nodeset_bitmap) return fail(core, KAI_ERR_UNSUPPORTED, "node-set bitmaps arrive with the topology plugin");
     if (pod_idx < 0 || pod_idx >= core->ctx.P) return fail(core, KAI_ERR_INVALID_ARG, "pod index out of range");
     HIP_TRY(core, hipSetDevice(core->device));
-    hipLaunchKernelGGL(k_best_node, dim3(1), dim3(WG), 16, core->stream, core->ctx, (int)pod_idx, pipeline_only, core->d_best_out);
+    uint32_t* d_bits = nullptr;
+    if (nodeset_bitmap) {  // caller's node indices → engine order (name rank), then to HBM for this call
+        const int N = core->ctx.N, W = (N + 31) / 32;
+        std::vector<uint32_t> bits((size_t)std::max(W, 1), 0u);
+        for (int i = 0; i < N; i++) { int o = core->perm[i]; if ((nodeset_bitmap[o >> 5] >> (o & 31)) & 1u) bits[i >> 5] |= 1u << (i & 31); }
+        HIP_TRY(core, hipMalloc(reinterpret_cast<void**>(&d_bits), bits.size() * 4));
+        HIP_TRY(core, hipMemcpyAsync(d_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, core->stream));
+        HIP_TRY(core, hipStreamSynchronize(core->stream));
+    }
+    hipLaunchKernelGGL(k_best_node, dim3(1), dim3(WG), 16, core->stream, core->ctx, (int)pod_idx, pipeline_only, core->d_best_out, (const uint32_t*)d_bits);
     HIP_TRY(core, hipGetLastError());
     int32_t h[2] = {-1, 0};
     HIP_TRY(core, hipMemcpyAsync(h, core->d_best_out, sizeof h, hipMemcpyDeviceToHost, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));
+    if (d_bits) (void)hipFree(d_bits);
     *node_idx_out = h[0] >= 0 ? core->perm[h[0]] : -1;
     if (is_pipeline_out) *is_pipeline_out = h[1];
     return KAI_OK;

@@ -252,9 +252,10 @@ struct ActShared {
     unsigned long long part_key[WAVES];  // orderable score bits
     int32_t part_node[WAVES];
     unsigned long long top_key[KAI_CMAX]; int32_t top_node[KAI_CMAX];
-    unsigned long long* s2_key; int32_t* s2_node;  // [C][NSB] in dynamic LDS
+    unsigned long long __attribute__((address_space(3)))* s2_key; int32_t __attribute__((address_space(3)))* s2_node;  // [C][NSB] in dynamic LDS (typed LDS pointers: ds_read / ds_write)
     QNode* qn; int32_t *qheap, *root_heap;          // job-order tree: dynamic LDS when it fits, else the HBM arrays
     int32_t tree_in_lds, pad1;
+    const uint32_t* nodeset;  // optional node-set bitmap for brute-force scans (bit n of word n/32; engine node order), nullptr = all nodes
     long long t_publish, t_wait, t_svc, t_seg[6];  // profiling: control lane through barrier 1 / barrier 2, service wave 1 busy time
 };
 
@@ -335,7 +336,8 @@ __device__ __forceinline__ void svc_top(const KaiCtx& c, ActShared* sh, int k, i
 
 // service-wave side: each of the 15 service waves owns the classes  k ≡ wave-1 (mod 15)  of the class index and the nodes
 // (wave-1)*64 + lane (mod 960) of a brute-force scan
-__device__ void service_loop(const KaiCtx& c, ActShared* sh) {
+__device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
+    const KaiCtx c = cref;  // loop-invariant: a register copy of the fields used below instead of an LDS read + wait in front of every access
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = threadIdx.x - 64, hw = wave - 1;
     for (;;) {
         __syncthreads();  // wait for a command
@@ -395,7 +397,9 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
         } else if (cmd == CMD_MINMAX) {  // getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86)
             int r = sh->r;
             double lo = 1.7976931348623157e308, hi = 0;
+            const uint32_t* ns_bits = sh->nodeset;
             for (int n = slot; n < c.N; n += SCAN_LANES) {
+                if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;  // the pre-order scan ranges the node set (pack.go:66-86)
                 if (c.n_alloc[(size_t)r * c.N + n] == 0) continue;
                 double cur = c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n];
                 if (cur < lo) lo = cur;
@@ -406,7 +410,9 @@ __device__ void service_loop(const KaiCtx& c, ActShared* sh) {
         } else if (cmd == CMD_BEST) {  // OrderedNodesByTask + FittingNode collapsed to an arg-max (framework/session.go:201-264, 466-485)
             const ScanReq& q = sh->req;
             int best = -1; unsigned long long bk = 0;
+            const uint32_t* ns_bits = sh->nodeset;
             for (int n = slot; n < c.N; n += SCAN_LANES) {
+                if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;
                 if (!fits(c, q.req, n, true)) continue;                              // IsTaskAllocatableOnReleasingOrIdle
                 if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;  // ssn.PredicateFn
                 bool fit_idle = q.best_effort || fits(c, q.req, n, false);
@@ -434,9 +440,9 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     const KaiCtx& c = g_ctx;
     ActShared& sh = g_sh;
     if (threadIdx.x == 0) {
-        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
+        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds; sh.nodeset = nullptr; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
         size_t off = 0;
-        sh.s2_key = reinterpret_cast<unsigned long long*>(kai_dyn_lds); sh.s2_node = reinterpret_cast<int32_t*>(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
+        sh.s2_key = (unsigned long long __attribute__((address_space(3)))*)(kai_dyn_lds); sh.s2_node = (int32_t __attribute__((address_space(3)))*)(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
         off = lds_index_bytes(c.C, c.NSB);
         if (tree_in_lds) { sh.qn = reinterpret_cast<QNode*>(kai_dyn_lds + off); sh.qheap = reinterpret_cast<int32_t*>(kai_dyn_lds + off + (size_t)c.Q * sizeof(QNode)); sh.root_heap = sh.qheap + (c.Q + 1); }
         else { sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
@@ -473,12 +479,12 @@ __global__ void k_drain(KaiCtx c, const int32_t* slot_queue) {
 }
 
 // kai_best_node: one OrderedNodesByTask + FittingNode against the current session state (brute-force scan)
-__global__ void __launch_bounds__(WG) k_best_node(KaiCtx cv, int pod, int pipeline_only, int32_t* out) {
+__global__ void __launch_bounds__(WG) k_best_node(KaiCtx cv, int pod, int pipeline_only, int32_t* out, const uint32_t* nodeset) {
     if (threadIdx.x == 0) { g_ctx = cv; g_ctx.use_index = 0; }
     __syncthreads();
     const KaiCtx& c = g_ctx;
     ActShared& sh = g_sh;
-    if (threadIdx.x == 0) { sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = 0; sh.s2_key = nullptr; sh.s2_node = nullptr; sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
+    if (threadIdx.x == 0) { sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = 0; sh.nodeset = nodeset; sh.s2_key = nullptr; sh.s2_node = nullptr; sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
     __syncthreads();
     if (threadIdx.x >= 64) { service_loop(c, &g_sh); return; }
     if (threadIdx.x != 0) return;

@@ -863,6 +863,35 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
     return KAI_OK;
 }
 
+// Session.OrderedNodesByTask + FittingNode for ONE task over a node subset of a freshly opened session (framework/session.go:201-264):
+// what kai_best_node answers.  nodeset_bitmap may be NULL (all nodes); bit n of word n/32 = caller's node index n.
+int kai_oracle_best_node(const kai_config* cfg, const kai_snapshot_soa* snap, int pod, const uint32_t* nodeset_bitmap, int pipeline_only, int* node_out, int* is_pipeline_out) {
+    if (!cfg || !snap || pod < 0 || pod >= snap->n_pods) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    const int Q = snap->n_queues; ssn.qattrs.resize(Q);
+    for (int q = 0; q < Q; q++) {
+        orc::QueueAttributes& a = ssn.qattrs[q]; a.idx = q; a.uidRank = ssn.queues[q].uidRank; a.parent = ssn.queues[q].parent; a.children = ssn.queues[q].children;
+        a.createdNs = ssn.queues[q].createdNs; a.priority = ssn.queues[q].priority;
+        for (int r = 0; r < 3; r++) {
+            double deserved = snap->queue_deserved[r * Q + q], limit = snap->queue_limit[r * Q + q];
+            if (r == KAI_Q_MEM) { deserved = std::fmax(KAI_UNLIMITED, deserved * 1000000.0); limit = std::fmax(KAI_UNLIMITED, limit * 1000000.0); }
+            a.share[r].Deserved = deserved; a.share[r].MaxAllowed = limit; a.share[r].OverQuotaWeight = snap->queue_oqw[r * Q + q]; a.share[r].Usage = snap->queue_usage ? snap->queue_usage[r * Q + q] : 0.0;
+        }
+    }
+    ssn.proportionOnSessionOpen();
+    std::vector<orc::NodeInfo*> nodeSet;
+    for (auto& n : ssn.nodes) if (!nodeset_bitmap || ((nodeset_bitmap[n.idx >> 5] >> (n.idx & 31)) & 1u)) nodeSet.push_back(&n);
+    orc::PodInfo* task = &ssn.pods[pod];
+    *node_out = -1; if (is_pipeline_out) *is_pipeline_out = 0;
+    for (auto* node : ssn.OrderedNodesByTask(nodeSet, task)) {
+        if (!ssn.FittingNode(task, node)) continue;
+        *node_out = node->idx;
+        if (is_pipeline_out) *is_pipeline_out = (pipeline_only || !node->IsTaskAllocatable(task)) ? 1 : 0;
+        break;
+    }
+    return KAI_OK;
+}
+
 // known-answer hooks for the reference's pure-function tests
 double kai_oracle_pack_score(double minA, double maxA, double cur, double overall) {  // plugins/nodeplacement/pack.go:45-64
     if (overall == 0) return 0.0;

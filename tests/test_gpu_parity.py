@@ -154,3 +154,30 @@ def test_gpu_elastic_and_subgroups(gpu, seed):
     for mode in (0, 1, 2):
         c = T.abi.KaiConfig.from_buffer_copy(cfg); c.engine_mode = mode
         assert_same(run_gpu(snap, c), ref)
+
+
+def test_gpu_best_node_with_node_sets(gpu):
+    """kai_best_node over node subsets (what SubsetNodesFn hands to OrderedNodesByTask) against the oracle, bin-pack and spread"""
+    import ctypes as C
+    lib = T.Oracle.lib(); lib.kai_oracle_best_node.restype = C.c_int
+    rng = np.random.default_rng(11)
+    snap = T.pkg.synth.make_snapshot(150, 400, 4242, queue_levels=(2, 2), prefill=0.5, gpu_mix=((8, .5), (4, .3), (0, .2)), cpu_only_frac=0.3, lexi_names=True)
+    pending = np.nonzero(snap.arrays["pod_status"] == T.abi.POD_STATUS["Pending"])[0]
+    for strat in (T.abi.BINPACK, T.abi.SPREAD):
+        cfg = T.abi.default_config(gpu_strategy=strat, cpu_strategy=strat)
+        s = snap.as_struct()
+        with T.pkg.KaiCore(cfg) as core:
+            ssn = core.open_session(snap)
+            for trial in range(24):
+                pod = int(rng.choice(pending))
+                subset = None if trial % 4 == 0 else np.nonzero(rng.random(snap.n_nodes) < rng.choice([0.02, 0.2, 0.7]))[0].tolist()
+                got = ssn.best_node(pod, pipeline_only=bool(trial % 3 == 0), nodeset=subset)
+                words = None
+                if subset is not None:
+                    w = np.zeros((snap.n_nodes + 31) // 32, np.uint32)
+                    for n in subset: w[n >> 5] |= np.uint32(1 << (n & 31))
+                    words = w.ctypes.data_as(C.POINTER(C.c_uint32))
+                node, pipe = C.c_int(-1), C.c_int(0)
+                assert lib.kai_oracle_best_node(C.byref(cfg), C.byref(s), pod, words, int(trial % 3 == 0), C.byref(node), C.byref(pipe)) == 0
+                assert got == (node.value, bool(pipe.value)), (strat, trial, pod, got, node.value, pipe.value)
+            ssn.close()
