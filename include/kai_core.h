@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KAI_ABI_VERSION 1u
+#define KAI_ABI_VERSION 2u
 
 /* resource vector layout: api/resource_info/resource_vector.go:23-36 (cpu, memory, gpu, pods, extras…) */
 #define KAI_RES_CPU 0
@@ -200,6 +200,37 @@ typedef struct kai_snapshot_soa {
     int32_t n_pod_classes;
     int32_t n_node_classes;
     const uint8_t* class_fit;         /* [n_pod_classes][n_node_classes] 1 = every static Filter passes */
+
+    /* ---- topologies (Topology CR: ordered spec.levels[].nodeLabel; plugins/topology/topology_plugin.go:57-110).
+     * Levels of topology t are the global level rows topo_level_off[t] .. topo_level_off[t+1]-1, top level first.  A domain is one
+     * distinct prefix of level label values (plugins/topology/topology_structs.go:94-101); the host builds the domain table.
+     * All of this may be absent (n_topologies = 0). ---- */
+    int32_t n_topologies;
+    const int32_t* topo_level_off;    /* [T+1] */
+    int32_t n_topo_levels;            /* = topo_level_off[T] */
+    const int32_t* node_domain;       /* [n_topo_levels][N] domain of the node at that level, -1 at every level of a topology the node is not
+                                         part of (a node joins a topology only if it has every level label: topology/common.go:70-77) */
+    int32_t n_domains;
+    const int32_t* domain_level;      /* [D] global level row */
+    const int32_t* domain_parent;     /* [D] domain at the level above, -1 for a top-level domain */
+    const uint32_t* domain_id_rank;   /* [D] rank of the domain ID string ("zone1.rack3") inside its topology, byte-wise ascending */
+
+    /* ---- sub-group tree of every job (api/podgroup_info/subgroup_info/subgroupset.go): groups = SubGroupSets incl. each job's root;
+     * pod-sets are the leaves.  Absent (n_groups = 0) ⇒ every job has a root group without constraint holding all its pod-sets.
+     * A topology constraint (api/topology_info) is {topology index or -1 (none) or -2 (named topology does not exist),
+     * required level, preferred level} with levels counted inside the topology (0 = top) or -1. ---- */
+    int32_t n_groups;
+    const int32_t* group_job;         /* [G] */
+    const int32_t* group_parent;      /* [G] parent group, -1 for the job's root */
+    const uint32_t* group_name_rank;  /* [G] rank of the SubGroupSet name inside its job (framework/session_plugins.go:273-282) */
+    const int32_t* group_topology;    /* [G] */
+    const int32_t* group_required_level;
+    const int32_t* group_preferred_level;
+    const int32_t* job_root_group;    /* [J] */
+    const int32_t* podset_group;      /* [S] parent group of the pod-set */
+    const int32_t* podset_topology;   /* [S] the pod-set's own constraint */
+    const int32_t* podset_required_level;
+    const int32_t* podset_preferred_level;
 } kai_snapshot_soa;
 
 typedef struct kai_op {

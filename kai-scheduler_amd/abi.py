@@ -12,7 +12,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-KAI_ABI_VERSION = 1
+KAI_ABI_VERSION = 2
 RES_CPU, RES_MEM, RES_GPU, RES_PODS = 0, 1, 2, 3
 MAX_RES = 8
 Q_CPU, Q_MEM, Q_GPU = 0, 1, 2
@@ -92,6 +92,12 @@ class KaiSnapshotSoA(C.Structure):
         ("queue_uid_rank", _P(C.c_uint32)), ("queue_deserved", _P(C.c_double)), ("queue_limit", _P(C.c_double)), ("queue_oqw", _P(C.c_double)),
         ("queue_usage", _P(C.c_double)),
         ("n_pod_classes", C.c_int32), ("n_node_classes", C.c_int32), ("class_fit", _P(C.c_uint8)),
+        ("n_topologies", C.c_int32), ("topo_level_off", _P(C.c_int32)), ("n_topo_levels", C.c_int32), ("node_domain", _P(C.c_int32)),
+        ("n_domains", C.c_int32), ("domain_level", _P(C.c_int32)), ("domain_parent", _P(C.c_int32)), ("domain_id_rank", _P(C.c_uint32)),
+        ("n_groups", C.c_int32), ("group_job", _P(C.c_int32)), ("group_parent", _P(C.c_int32)), ("group_name_rank", _P(C.c_uint32)),
+        ("group_topology", _P(C.c_int32)), ("group_required_level", _P(C.c_int32)), ("group_preferred_level", _P(C.c_int32)),
+        ("job_root_group", _P(C.c_int32)), ("podset_group", _P(C.c_int32)), ("podset_topology", _P(C.c_int32)),
+        ("podset_required_level", _P(C.c_int32)), ("podset_preferred_level", _P(C.c_int32)),
     ]
 
 
@@ -135,6 +141,13 @@ _SPEC = [  # (field, dtype, shape-kind)
     ("queue_parent", np.int32, "Q"), ("queue_priority", np.int32, "Q"), ("queue_created_ns", np.int64, "Q"), ("queue_uid_rank", np.uint32, "Q"),
     ("queue_deserved", np.float64, "3Q"), ("queue_limit", np.float64, "3Q"), ("queue_oqw", np.float64, "3Q"), ("queue_usage", np.float64, "3Q"),
     ("class_fit", np.uint8, "CF"),
+]
+# optional topology + sub-group-tree arrays (kai_core.h): present only when the snapshot carries them
+_SPEC_OPT = [
+    ("topo_level_off", np.int32), ("node_domain", np.int32), ("domain_level", np.int32), ("domain_parent", np.int32), ("domain_id_rank", np.uint32),
+    ("group_job", np.int32), ("group_parent", np.int32), ("group_name_rank", np.uint32), ("group_topology", np.int32),
+    ("group_required_level", np.int32), ("group_preferred_level", np.int32), ("job_root_group", np.int32), ("podset_group", np.int32),
+    ("podset_topology", np.int32), ("podset_required_level", np.int32), ("podset_preferred_level", np.int32),
 ]
 
 
@@ -186,6 +199,9 @@ class Snapshot:
         a.setdefault("queue_usage", np.zeros((3, self.n_queues), np.float64))
         for name, dt, _ in _SPEC:
             a[name] = np.ascontiguousarray(a[name], dtype=dt)
+        for name, dt in _SPEC_OPT:
+            if name in a:
+                a[name] = np.ascontiguousarray(a[name], dtype=dt)
         assert a["node_allocatable"].shape == (self.n_res, N), a["node_allocatable"].shape
         assert a["pod_req"].shape == (self.n_res, P), a["pod_req"].shape
         return self
@@ -202,5 +218,12 @@ class Snapshot:
         for name, dt, _ in _SPEC:
             arr = a[name]
             setattr(s, name, arr.ctypes.data_as(_P(ctype[np.dtype(dt)])))
+        for name, dt in _SPEC_OPT:
+            if name in a:
+                setattr(s, name, a[name].ctypes.data_as(_P(ctype[np.dtype(dt)])))
+        s.n_topologies = int(a["topo_level_off"].shape[0]) - 1 if "topo_level_off" in a else 0
+        s.n_topo_levels = int(a["topo_level_off"][-1]) if "topo_level_off" in a else 0
+        s.n_domains = int(a["domain_level"].shape[0]) if "domain_level" in a else 0
+        s.n_groups = int(a["group_job"].shape[0]) if "group_job" in a else 0
         s._keepalive = a  # the struct borrows the numpy buffers
         return s

@@ -42,10 +42,58 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
         qi.priority = s->queue_priority[q]; qi.createdNs = s->queue_created_ns[q];
     }
     for (int q = 0; q < Q; q++) if (queues[q].parent >= 0) queues[queues[q].parent].children.push_back(q);  // cache/cluster_info/queue.go:95-103
-    for (int k = 0; k < S; k++) { PodSet& ps = podsets[k]; ps.idx = k; ps.job = s->podset_job[k]; ps.minAvailable = s->podset_min_available[k]; ps.nameRank = s->podset_name_rank[k]; }
+    for (int k = 0; k < S; k++) {
+        PodSet& ps = podsets[k]; ps.idx = k; ps.job = s->podset_job[k]; ps.minAvailable = s->podset_min_available[k]; ps.nameRank = s->podset_name_rank[k];
+        if (s->n_groups > 0) { ps.group = s->podset_group[k]; ps.tc = {s->podset_topology[k], s->podset_required_level[k], s->podset_preferred_level[k]}; }
+    }
+    // sub-group tree (api/podgroup_info/subgroup_info/subgroupset.go); absent ⇒ one root SubGroupSet per job without constraint
+    if (s->n_groups > 0) {
+        groups.resize(s->n_groups);
+        for (int g = 0; g < s->n_groups; g++) {
+            SubGroupSet& sg = groups[g]; sg.idx = g; sg.job = s->group_job[g]; sg.parent = s->group_parent[g]; sg.nameRank = s->group_name_rank[g];
+            sg.tc = {s->group_topology[g], s->group_required_level[g], s->group_preferred_level[g]};
+        }
+        for (int g = 0; g < s->n_groups; g++) if (groups[g].parent >= 0) groups[groups[g].parent].groups.push_back(g);
+        for (int k = 0; k < S; k++) if (podsets[k].group >= 0) groups[podsets[k].group].podSets.push_back(k);
+    } else {
+        groups.resize(J);
+        for (int j = 0; j < J; j++) { groups[j].idx = j; groups[j].job = j; }
+        for (int k = 0; k < S; k++) { podsets[k].group = podsets[k].job; groups[podsets[k].job].podSets.push_back(k); }
+    }
+    // topology trees (plugins/topology/topology_plugin.go:57-110).  Children are appended in node-index order (the reference ranges a
+    // Go map of nodes; every use of the order below a sorted level is order-free).
+    nTopologies = s->n_topologies; nRealDomains = s->n_domains;
+    if (nTopologies > 0) {
+        topoLevelOff.assign(s->topo_level_off, s->topo_level_off + nTopologies + 1);
+        nodeDomain.assign(s->node_domain, s->node_domain + size_t(s->n_topo_levels) * N);
+        domains.resize(size_t(s->n_domains) + nTopologies);
+        auto topoOfLevel = [&](int gl) { for (int t = 0; t < nTopologies; t++) if (gl >= topoLevelOff[t] && gl < topoLevelOff[t + 1]) return t; return -1; };
+        for (int d = 0; d < s->n_domains; d++) {
+            DomainInfo& di = domains[d]; di.id = d; di.topo = topoOfLevel(s->domain_level[d]); di.level = s->domain_level[d] - topoLevelOff[di.topo];
+            di.parent = s->domain_parent[d] >= 0 ? s->domain_parent[d] : s->n_domains + di.topo; di.idRank = s->domain_id_rank[d];
+        }
+        for (int t = 0; t < nTopologies; t++) { DomainInfo& r = domains[s->n_domains + t]; r.id = s->n_domains + t; r.topo = t; r.level = -1; r.parent = -1; }
+        for (int t = 0; t < nTopologies; t++) {
+            int L = topoLevelOff[t + 1] - topoLevelOff[t];
+            for (int n = 0; n < N; n++) {
+                if (L == 0 || nodeDomain[size_t(topoLevelOff[t]) * N + n] < 0) continue;  // isNodePartOfTopology
+                int child = -1;
+                for (int l = L - 1; l >= 0; l--) {
+                    int d = nodeDomain[size_t(topoLevelOff[t] + l) * N + n];
+                    domains[d].nodes.push_back(n);
+                    if (child >= 0) { auto& ch = domains[d].children; if (std::find(ch.begin(), ch.end(), child) == ch.end()) ch.push_back(child); }
+                    child = d;
+                }
+                DomainInfo& root = domains[s->n_domains + t];
+                if (std::find(root.children.begin(), root.children.end(), child) == root.children.end()) root.children.push_back(child);
+                root.nodes.push_back(n);
+            }
+        }
+    }
     for (int j = 0; j < J; j++) {
         PodGroupInfo& g = jobs[j]; g.idx = j; g.uidRank = s->job_uid_rank[j]; g.queue = s->job_queue[j]; g.priority = s->job_priority[j];
         g.preemptible = s->job_preemptible[j] != 0; g.createdNs = s->job_created_ns[j];
+        g.rootGroup = s->n_groups > 0 ? s->job_root_group[j] : j;
         for (int k = 0; k < s->job_n_podsets[j]; k++) g.podSets.push_back(&podsets[s->job_first_podset[j] + k]);
         std::sort(g.podSets.begin(), g.podSets.end(), [](PodSet* a, PodSet* b) { return a->nameRank < b->nameRank; });
     }
@@ -449,14 +497,17 @@ double Session::NodeOrderFn(PodInfo* task, NodeInfo* node) {  // session_plugins
         else place = 9.0 * (1 - (cur - minA) / (maxA - minA));
     }
     if (cfg.plugins & KAI_PLUGIN_NODEPLACEMENT) score += place;
-    // topology (plugins/topology/node_scoring.go:17-35): no preferred level on this path
-    score += 0.0;
+    // topology (plugins/topology/node_scoring.go:17-35) is added by OrderedNodesByTask, where a lookup error drops the node
     return score;
 }
 std::vector<NodeInfo*> Session::OrderedNodesByTask(const std::vector<NodeInfo*>& nodeSet, PodInfo* task) {  // session.go:234-264, 466-485
     NodePreOrderFn(task, nodeSet);
     std::map<double, std::vector<NodeInfo*>, std::greater<double>> nodeScores;
-    for (auto* node : nodeSet) nodeScores[NodeOrderFn(task, node)].push_back(node);
+    for (auto* node : nodeSet) {
+        double score = NodeOrderFn(task, node);
+        if (cfg.plugins & KAI_PLUGIN_TOPOLOGY) { bool err = false; double ts = topologyNodeScore(task, node, err); if (err) continue; score += ts; }  // session.go:247-251
+        nodeScores[score].push_back(node);
+    }
     std::vector<NodeInfo*> ordered; ordered.reserve(nodeSet.size());
     for (auto& kv : nodeScores) {
         std::sort(kv.second.begin(), kv.second.end(), [](NodeInfo* a, NodeInfo* b) { return a->nameRank < b->nameRank; });
@@ -750,30 +801,227 @@ bool Session::allocateTask(Statement& stmt, const std::vector<NodeInfo*>& nodeSe
     }
     return success;
 }
-bool Session::allocatePodSet(Statement& stmt, const std::vector<NodeInfo*>& nodeSet, PodGroupInfo* job, PodSet*, const std::vector<PodInfo*>& tasks, bool isPipelineOnly) {  // :83-107
-    // SubsetNodesFn without a topology constraint returns the node set unchanged (plugins/topology/job_filtering.go:47-49)
-    int cp = stmt.Checkpoint();
-    bool ok = true;
-    for (auto* task : tasks) if (!allocateTask(stmt, nodeSet, task, isPipelineOnly)) { ok = false; break; }  // allocateTasksOnNodeSet :109-119
-    if (ok) return true;
-    stmt.Rollback(cp); stats.rollbacks++;
+// =====================================================================================================
+// plugins/topology
+// =====================================================================================================
+void Session::allPodSets(SubGroupSet* sgs, std::vector<PodSet*>& out) {  // SubGroupSet.GetAllPodSets (subgroupset.go:57-69)
+    for (int k : sgs->podSets) out.push_back(&podsets[k]);
+    for (int g : sgs->groups) allPodSets(&groups[g], out);
+}
+double Session::topologyNodeScore(PodInfo* task, NodeInfo* node, bool& err) {  // node_scoring.go:17-35, 88-99
+    int key = -(task->podset + 1);
+    for (;;) {
+        auto it = subGroupNodeScores.find(key);
+        if (it != subGroupNodeScores.end()) { auto sc = it->second.find(node->idx); if (sc == it->second.end()) { err = true; return 0; } return sc->second; }
+        int parent = key < 0 ? podsets[-key - 1].group : groups[key].parent;
+        if (parent < 0) return 0;
+        key = parent;
+    }
+}
+namespace topology {
+static double quantityValueMilli(double milli) { return std::ceil(milli / 1000.0); }  // resource.NewMilliQuantity(x).Value(): rounded up
+// getJobRatioToFreeResources (job_filtering.go:491-524)
+static double getJobRatioToFreeResources(const Resource& tasks, const DomainInfo& domain) {
+    double dominant = 0.0;
+    const Resource empty;
+    if (tasks.gpus <= empty.gpus && tasks.LessEqual(empty)) return dominant;
+    if (tasks.gpus > 0) dominant = std::fmax(dominant, tasks.gpus / domain.IdleOrReleasingResources.gpus);
+    auto ratio = [&](double taskV, double freeV) { if (taskV == 0) return; double r = freeV == 0 ? 1000.0 : taskV / freeV; dominant = std::fmax(dominant, r); };
+    ratio(quantityValueMilli(double(int64_t(tasks.milliCpu))), quantityValueMilli(double(int64_t(domain.IdleOrReleasingResources.milliCpu))));
+    ratio(double(int64_t(tasks.memory)), double(int64_t(domain.IdleOrReleasingResources.memory)));
+    for (auto& kv : tasks.scalars) {
+        if (kv.first == KAI_RES_PODS) continue;  // "Ignore pods resource for bin-packing behavior"
+        ratio(quantityValueMilli(double(kv.second)), quantityValueMilli(domain.IdleOrReleasingResources.GetScalar(kv.first)));
+    }
+    return dominant;
+}
+}  // namespace topology
+
+// subSetNodesFn (plugins/topology/job_filtering.go:34-112).  Returns false on an error (the caller gives up on the job).
+bool Session::SubsetNodesFn(PodGroupInfo* job, int key, const TopologyConstraint& tc, const std::vector<PodSet*>& podSetsIn, const std::vector<PodInfo*>& tasks,
+                            const std::vector<NodeInfo*>& nodeSet, std::vector<std::vector<NodeInfo*>>& out) {
+    out.clear();
+    if (!(cfg.plugins & KAI_PLUGIN_TOPOLOGY)) { out.push_back(nodeSet); return true; }  // session_plugins.go:345-366 without plugins
+    if (tc.topology == -2) return true;                                   // "Requested topology does not exist": no node sets
+    if (tc.topology < 0 || tasks.empty()) { out.push_back(nodeSet); return true; }
+    const int t = tc.topology, L = topoLevelOff[t + 1] - topoLevelOff[t], N = int(nodes.size());
+    const int rootId = nRealDomains + t;
+    auto domAt = [&](int n, int l) { return nodeDomain[size_t(topoLevelOff[t] + l) * N + n]; };
+    // lowestCommonDomainID (common.go:17-67)
+    std::vector<char> valid(N, 0); std::vector<NodeInfo*> validNodes;
+    for (auto* n : nodeSet) if (L > 0 && domAt(n->idx, 0) >= 0) { valid[n->idx] = 1; validNodes.push_back(n); }
+    int domainId = rootId;
+    for (int l = 0; l < L; l++) {
+        if (validNodes.empty()) break;
+        int v = domAt(validNodes[0]->idx, l); bool allMatch = true;
+        for (auto* n : validNodes) if (domAt(n->idx, l) != v) { allMatch = false; break; }
+        if (!allMatch) break;
+        domainId = v;
+        if (tc.preferred == l) break;  // no reason to look below the preferred level
+    }
+    DomainInfo* domain = &domains[domainId];
+    // treeAllocatableCleanup :438-445
+    for (auto& d : domains) if (d.topo == t) { d.AllocatablePods = -1; d.IdleOrReleasingResources = Resource(); }
+    // calcSubTreeFreeResources :192-211
+    std::function<Resource(DomainInfo*)> freeRes = [&](DomainInfo* d) {
+        if (d->children.empty()) { for (int n : d->nodes) { d->IdleOrReleasingResources.Add(nodes[n].Idle); d->IdleOrReleasingResources.Add(nodes[n].Releasing); } return d->IdleOrReleasingResources; }
+        for (int c : d->children) { Resource sub = freeRes(&domains[c]); d->IdleOrReleasingResources.Add(sub); }
+        return d->IdleOrReleasingResources;
+    };
+    freeRes(domain);
+    // useRepresentorPodsAccounting :550-571 → calcTreeAllocatable :138-190
+    bool homogeneous = true;
+    { std::map<int, int> ext; int podsUsingGpu = 0;
+      for (auto* task : tasks) { for (auto& kv : task->resReq.scalars) ext[kv.first]++; if (task->resReq.GPUs() > 0) podsUsingGpu++; }
+      if (podsUsingGpu != int(tasks.size()) && podsUsingGpu != 0) homogeneous = false;
+      for (auto& kv : ext) if (kv.second != int(tasks.size())) homogeneous = false; }
+    if (homogeneous) {
+        ResourceRequirements maxPod;  // initTasksRepresentorMetadataStruct :150-168
+        for (auto* task : tasks) {
+            const ResourceRequirements& rr = task->resReq;
+            if (rr.milliCpu > maxPod.milliCpu) maxPod.milliCpu = rr.milliCpu;
+            if (rr.memory > maxPod.memory) maxPod.memory = rr.memory;
+            for (auto& kv : rr.scalars) { auto it = maxPod.scalars.find(kv.first); if (it == maxPod.scalars.end() || kv.second > it->second) maxPod.scalars[kv.first] = kv.second; }
+            if (getExtendedResourceGpus(rr.portion, rr.count) > getExtendedResourceGpus(maxPod.portion, maxPod.count)) { maxPod.count = rr.count; maxPod.portion = rr.portion; }
+        }
+        std::vector<ResourceRequirements> testPods{maxPod};  // allocationTestPods: k-th = k x maxPod, grown on demand
+        auto accommodation = [&](NodeInfo& node) {  // calcNodeAccommodation :213-246
+            bool onePodOnly = maxPod.milliCpu <= 0 && maxPod.memory <= 0 && maxPod.count <= 0 && !(maxPod.portion > 0.01);
+            for (auto& kv : maxPod.scalars) if (kv.first != KAI_RES_PODS || kv.second > 1) onePodOnly = false;
+            if (onePodOnly) return int(tasks.size());
+            int count = 0;
+            for (auto& tp : testPods) { PodInfo rep; rep.resReq = tp; if (node.IsTaskAllocatableOnReleasingOrIdle(&rep)) count++; else break; }
+            if (count == int(testPods.size())) for (;;) {
+                ResourceRequirements next = testPods.back();  // calcNextAllocationTestPodResources :248-263
+                next.milliCpu += maxPod.milliCpu; next.memory += maxPod.memory;
+                for (auto& kv : maxPod.scalars) { next.scalars[kv.first] += kv.second; if (next.scalars[kv.first] == 0) next.scalars.erase(kv.first); }
+                next.count = next.count + maxPod.count;
+                testPods.push_back(next);
+                PodInfo rep; rep.resReq = next;
+                if (node.IsTaskAllocatableOnReleasingOrIdle(&rep)) count++; else break;
+            }
+            return count;
+        };
+        std::function<int(DomainInfo*)> alloc = [&](DomainInfo* d) {
+            d->AllocatablePods = 0;
+            if (d->children.empty()) { for (int n : d->nodes) d->AllocatablePods += accommodation(nodes[n]); return d->AllocatablePods; }
+            for (int c : d->children) d->AllocatablePods += alloc(&domains[c]);
+            return d->AllocatablePods;
+        };
+        alloc(domain);
+    }
+    // getTasksAllocationMetadata :114-121
+    Resource tasksResources; for (auto* task : tasks) tasksResources.Add(task->resReq.AsResource());
+    const int tasksCount = int(tasks.size());
+    auto fits = [&](DomainInfo* d) {  // checkJobDomainFit :362-379
+        if (d->AllocatablePods != -1) return d->AllocatablePods >= tasksCount;
+        return !(topology::getJobRatioToFreeResources(tasksResources, *d) > 1.0);
+    };
+    if (!fits(domain)) return true;  // no node sets
+    // sortTreeFromRoot :447-486 down to the preferred (else required) level
+    const int maxDepth = tc.preferred >= 0 ? tc.preferred : tc.required;
+    std::function<void(DomainInfo*)> sortTree = [&](DomainInfo* root) {
+        if (maxDepth < 0) return;
+        std::map<int, double> ratio; for (int c : root->children) ratio[c] = topology::getJobRatioToFreeResources(tasksResources, domains[c]);
+        std::stable_sort(root->children.begin(), root->children.end(), [&](int i, int j) {
+            if (ratio[j] != ratio[i]) return ratio[j] < ratio[i];  // cmp.Compare(jRatio, iRatio): higher ratio first
+            return domains[i].idRank < domains[j].idRank; });
+        if (root->level == maxDepth) return;
+        for (int c : root->children) sortTree(&domains[c]);
+    };
+    sortTree(domain);
+    if (tc.preferred >= 0) {  // calculateNodeScores (node_scoring.go:37-69)
+        std::vector<DomainInfo*> lvl;
+        std::function<void(DomainInfo*)> collect = [&](DomainInfo* d) { if (d->level == tc.preferred) { lvl.push_back(d); return; } for (int c : d->children) collect(&domains[c]); };
+        collect(domain);
+        std::map<int, double>& scoresMap = subGroupNodeScores[key]; scoresMap.clear();
+        for (size_t i = 0; i < lvl.size(); i++) for (int n : lvl[i]->nodes) {
+            double score = (double(i + 1) / double(lvl.size())) * 10;
+            scoresMap[n] = std::floor(score) * 10000.0;  // scores.Topology
+        }
+    }
+    // getJobAllocatableDomains :265-310 with calculateRelevantDomainLevels :381-425: from the preferred level up to the required one
+    if (tc.required < 0 && tc.preferred < 0) return false;
+    if (tc.required >= L || tc.preferred >= L) return false;  // a level name the topology does not have
+    std::vector<int> relevantLevels;  // inside-topology levels, lowest first; -1 = root
+    { bool foundPref = false, foundReq = false;
+      for (int l = L - 1; l >= -1; l--) {
+          if (l == tc.preferred && l >= 0) foundPref = true;
+          if (l == tc.required && l >= 0) foundReq = true;
+          if (foundPref || foundReq) relevantLevels.push_back(l);
+          if (foundReq) break;
+      } }
+    std::vector<char> relevant(domains.size(), 1);
+    { bool hasActive = false; for (auto* ps : podSetsIn) if (ps->numActiveAllocatedTasks > 0) hasActive = true;
+      if (hasActive && tc.required >= 0) {  // getRelevantDomainsWithAllocatedPods :321-332
+          std::fill(relevant.begin(), relevant.end(), 0);
+          std::function<void(DomainInfo*)> addSubTree = [&](DomainInfo* d) { relevant[d->id] = 1; for (int c : d->children) addSubTree(&domains[c]); };
+          for (auto& d : domains) {
+              if (d.topo != t || d.level != tc.required) continue;
+              bool has = false;
+              for (auto* ps : podSetsIn) for (auto& kv : ps->podInfos) if (IsActiveAllocatedStatus(kv.second->status) && kv.second->node >= 0 &&
+                  std::find(d.nodes.begin(), d.nodes.end(), kv.second->node) != d.nodes.end()) has = true;
+              if (has) addSubTree(&d);
+          }
+      } }
+    std::vector<char> chosen(domains.size(), 0); bool any = false;
+    for (int l : relevantLevels) for (auto& d : domains) if (d.topo == t && d.level == l && relevant[d.id] && fits(&d)) { chosen[d.id] = 1; any = true; }
+    if (!any) return true;
+    // sortDomainInfos :526-542: bottom-up level order of the (sorted) tree from the topology root
+    std::vector<std::vector<int>> levels; { std::vector<int> q{rootId};
+      while (!q.empty()) { levels.push_back(q); std::vector<int> nx; for (int d : q) for (int c : domains[d].children) nx.push_back(c); q = nx; } }
+    for (int i = int(levels.size()) - 1; i >= 0; i--) for (int d : levels[i]) {
+        if (!chosen[d]) continue;
+        std::vector<NodeInfo*> set; for (int n : domains[d].nodes) if (valid[n]) set.push_back(&nodes[n]);
+        out.push_back(set);
+    }
+    return true;
+}
+
+bool Session::allocatePodSet(Statement& stmt, const std::vector<NodeInfo*>& nodeSet, PodGroupInfo* job, PodSet* ps, const std::vector<PodInfo*>& tasks, bool isPipelineOnly) {  // :83-107
+    std::vector<std::vector<NodeInfo*>> nodeSets;
+    if (!SubsetNodesFn(job, -(ps->idx + 1), ps->tc, {ps}, tasks, nodeSet, nodeSets)) return false;
+    for (auto& set : nodeSets) {
+        int cp = stmt.Checkpoint();
+        bool ok = true;
+        for (auto* task : tasks) if (!allocateTask(stmt, set, task, isPipelineOnly)) { ok = false; break; }  // allocateTasksOnNodeSet :109-119
+        if (ok) return true;
+        stmt.Rollback(cp); stats.rollbacks++;
+    }
+    return false;
+}
+bool Session::allocateSubGroupSetOnNodes(Statement& stmt, const std::vector<NodeInfo*>& nodeSet, PodGroupInfo* job, SubGroupSet* sgs, const std::vector<PodInfo*>& tasks, bool isPipelineOnly) {  // :62-81
+    std::vector<SubGroupSet*> childGroups; for (int g : sgs->groups) childGroups.push_back(&groups[g]);
+    std::stable_sort(childGroups.begin(), childGroups.end(), [](SubGroupSet* a, SubGroupSet* b) { return a->nameRank < b->nameRank; });  // SubGroupSetOrderFn: by name
+    for (auto* child : childGroups) {
+        std::vector<PodSet*> under; allPodSets(child, under);
+        std::vector<PodInfo*> sub; for (auto* t : tasks) for (auto* ps : under) if (t->podset == ps->idx) { sub.push_back(t); break; }  // filterTasksForPodSets :246-258
+        if (!allocateSubGroupSet(stmt, nodeSet, job, child, sub, isPipelineOnly)) return false;
+    }
+    std::vector<PodSet*> ordered; for (int k : sgs->podSets) ordered.push_back(&podsets[k]);
+    std::stable_sort(ordered.begin(), ordered.end(), [this](PodSet* a, PodSet* b) { return PodSetOrderFn(a, b); });  // orderedPodSets :270-277
+    for (auto* ps : ordered) {
+        std::vector<PodInfo*> podSetTasks; for (auto* t : tasks) if (t->podset == ps->idx) podSetTasks.push_back(t);
+        if (!allocatePodSet(stmt, nodeSet, job, ps, podSetTasks, isPipelineOnly)) return false;
+    }
+    return true;
+}
+bool Session::allocateSubGroupSet(Statement& stmt, const std::vector<NodeInfo*>& nodeSet, PodGroupInfo* job, SubGroupSet* sgs, const std::vector<PodInfo*>& tasks, bool isPipelineOnly) {  // :38-60
+    std::vector<PodSet*> under; allPodSets(sgs, under);
+    std::vector<std::vector<NodeInfo*>> nodeSets;
+    if (!SubsetNodesFn(job, sgs->idx, sgs->tc, under, tasks, nodeSet, nodeSets)) return false;
+    for (auto& set : nodeSets) {
+        int cp = stmt.Checkpoint();
+        if (allocateSubGroupSetOnNodes(stmt, set, job, sgs, tasks, isPipelineOnly)) return true;
+        stmt.Rollback(cp); stats.rollbacks++;
+    }
     return false;
 }
 bool Session::AllocateJob(Statement& stmt, const std::vector<NodeInfo*>& nodeSet, PodGroupInfo* job, bool isPipelineOnly) {  // :20-36
+    subGroupNodeScores.clear();  // ssn.PreJobAllocation → topology.preJobAllocationFn (topology_plugin.go:52-55)
     std::vector<PodInfo*> tasksToAllocate = GetTasksToAllocate(job, !isPipelineOnly);
     if (IsJobOverQueueCapacity(job, tasksToAllocate)) return false;
-    // allocateSubGroupSet on the root (:38-60): one node set, then allocateSubGroupSetOnNodes (:62-81)
-    int cp = stmt.Checkpoint();
-    std::vector<PodSet*> ordered = job->podSets;  // root's child pod-sets, orderedPodSets :270-277
-    std::sort(ordered.begin(), ordered.end(), [this](PodSet* a, PodSet* b) { return PodSetOrderFn(a, b); });
-    bool ok = true;
-    for (auto* ps : ordered) {
-        std::vector<PodInfo*> podSetTasks; for (auto* t : tasksToAllocate) if (t->podset == ps->idx) podSetTasks.push_back(t);  // filterTasksForPodSet :241-257
-        if (!allocatePodSet(stmt, nodeSet, job, ps, podSetTasks, isPipelineOnly)) { ok = false; break; }
-    }
-    if (ok) return true;
-    stmt.Rollback(cp); stats.rollbacks++;
-    return false;
+    return allocateSubGroupSet(stmt, nodeSet, job, &groups[job->rootGroup], tasksToAllocate, isPipelineOnly);
 }
 
 // =====================================================================================================

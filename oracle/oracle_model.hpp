@@ -96,6 +96,9 @@ struct ResourceRequirements : BaseResource {
 
 struct PodGroupInfo; struct PodSet; struct NodeInfo;
 
+// api/topology_info: {Topology, RequiredLevel, PreferredLevel}; topology -1 = no constraint, -2 = the named topology does not exist
+struct TopologyConstraint { int topology = -1, required = -1, preferred = -1; };
+
 // ---------------------------------------------------------------- api/pod_info/pod_info.go:70-112
 struct PodInfo {
     int idx = -1;            // index in the snapshot (stands for UID; ordering uses uidRank)
@@ -120,6 +123,7 @@ struct PodInfo {
 // ---------------------------------------------------------------- api/podgroup_info/subgroup_info/podset.go
 struct PodSet {
     int idx = -1; uint32_t nameRank = 0; int job = -1;
+    int group = -1; TopologyConstraint tc;  // parent SubGroupSet, own constraint (subgroup_info.go)
     int32_t minAvailable = 1;
     std::map<int, PodInfo*> podInfos;  // keyed by pod idx (UID)
     std::map<int, int> podStatusMap;
@@ -146,10 +150,27 @@ struct PodSet {
     bool IsElastic() const { return minAvailable < int32_t(podInfos.size()); }
 };
 
+// ---------------------------------------------------------------- api/podgroup_info/subgroup_info/subgroupset.go
+struct SubGroupSet {
+    int idx = -1, job = -1, parent = -1; uint32_t nameRank = 0; TopologyConstraint tc;
+    std::vector<int> groups;   // child SubGroupSets (insertion order)
+    std::vector<int> podSets;  // child pod-sets (insertion order)
+};
+
+// ---------------------------------------------------------------- plugins/topology/topology_structs.go:41-59
+struct DomainInfo {
+    int id = -1, topo = -1, level = -1 /* inside the topology, 0 = top; -1 = the root domain */, parent = -1; uint32_t idRank = 0;
+    std::vector<int> children;  // ordered: sortTree re-orders them in place
+    std::vector<int> nodes;
+    int AllocatablePods = -1;   // allocatablePodsNotSet
+    Resource IdleOrReleasingResources;
+};
+
 // ---------------------------------------------------------------- api/podgroup_info/job_info.go:65-103
 struct PodGroupInfo {
     int idx = -1; uint32_t uidRank = 0;
     int queue = -1; int32_t priority = 0; bool preemptible = true; int64_t createdNs = 0;
+    int rootGroup = -1;            // RootSubGroupSet
     std::vector<PodSet*> podSets;  // GetSubGroups(); kept sorted by name rank (Go ranges a map; order-free uses only)
     Resource allocated;            // job_info.go:78 Allocated
     std::map<int, std::map<int, PodInfo*>> podStatusIndex;

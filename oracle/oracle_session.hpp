@@ -63,6 +63,11 @@ struct Session {
     kai_config cfg{};
     int R = 4;
     std::vector<NodeInfo> nodes; std::vector<PodInfo> pods; std::vector<PodSet> podsets; std::vector<PodGroupInfo> jobs; std::vector<QueueInfo> queues;
+    std::vector<SubGroupSet> groups;
+    // topology plugin state (plugins/topology/topology_plugin.go:22-28): domain trees + per-sub-group node scores of the current job
+    int nTopologies = 0; std::vector<int> topoLevelOff, nodeDomain; std::vector<DomainInfo> domains;  // domains[D + t] = root domain of topology t
+    int nRealDomains = 0;
+    std::map<int, std::map<int, double>> subGroupNodeScores;  // key: group idx, or -(podset idx + 1)
     std::vector<uint8_t> classFit; int nPodClasses = 0, nNodeClasses = 0;
     // proportion plugin state (plugins/proportion/proportion.go:52-65)
     ResourceQuantities totalResource{0, 0, 0};
@@ -105,7 +110,14 @@ struct Session {
 
     // ---- actions/common/allocate.go
     bool AllocateJob(Statement& stmt, const std::vector<NodeInfo*>& nodes, PodGroupInfo* job, bool isPipelineOnly);
+    bool allocateSubGroupSet(Statement& stmt, const std::vector<NodeInfo*>& nodes, PodGroupInfo* job, SubGroupSet* sgs, const std::vector<PodInfo*>& tasks, bool isPipelineOnly);
+    bool allocateSubGroupSetOnNodes(Statement& stmt, const std::vector<NodeInfo*>& nodes, PodGroupInfo* job, SubGroupSet* sgs, const std::vector<PodInfo*>& tasks, bool isPipelineOnly);
     bool allocatePodSet(Statement& stmt, const std::vector<NodeInfo*>& nodes, PodGroupInfo* job, PodSet* ps, const std::vector<PodInfo*>& tasks, bool isPipelineOnly);
+    // ---- plugins/topology
+    void allPodSets(SubGroupSet* sgs, std::vector<PodSet*>& out);
+    bool SubsetNodesFn(PodGroupInfo* job, int key, const TopologyConstraint& tc, const std::vector<PodSet*>& podSets, const std::vector<PodInfo*>& tasks,
+                       const std::vector<NodeInfo*>& nodeSet, std::vector<std::vector<NodeInfo*>>& out);
+    double topologyNodeScore(PodInfo* task, NodeInfo* node, bool& err);
     bool allocateTask(Statement& stmt, const std::vector<NodeInfo*>& nodes, PodInfo* task, bool isPipelineOnly);
     bool allocateTaskToNode(Statement& stmt, PodInfo* task, NodeInfo* node, bool isPipelineOnly);
 

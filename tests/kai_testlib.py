@@ -135,11 +135,29 @@ def _flatten_subgroups(root):
     return out
 
 
+def _expand_nodes(nodes):
+    """actions/allocate/allocateTopology_test.go:3162-3188 buildEvenlyDistributedTopologyNodes(zones, spines/zone, racks/spine, nodes/rack, gpus)"""
+    if not (isinstance(nodes, dict) and nodes.get("_call") == "buildEvenlyDistributedTopologyNodes"):
+        return nodes
+    nz, ns, nr, nn, gpus = [int(x) for x in nodes["args"]]
+    out, node_id = {}, 0
+    for z in range(1, nz + 1):
+        for sp in range(1, ns + 1):
+            for r in range(1, nr + 1):
+                for _ in range(nn):
+                    out[f"node{node_id}"] = {"GPUs": gpus, "Labels": {"k8s.io/zone": f"zone{z}", "k8s.io/spine": f"spine{sp + (z - 1) * ns}",
+                                                                      "k8s.io/rack": f"rack{r + (sp - 1) * nr + (z - 1) * ns * nr}"}}
+                    node_id += 1
+    return out
+
+
 def case_to_snapshot(case, actions=("allocate",)):
     """→ (Snapshot, KaiConfig, meta).  Raises Unsupported for features outside the built path."""
     S = abi.POD_STATUS
-    if case.get("Topologies"):
-        raise Unsupported("topology")
+    case = dict(case); case["Nodes"] = _expand_nodes(case.get("Nodes") or {})
+    topologies = case.get("Topologies") or []
+    topo_names = [t["ObjectMeta"]["Name"] for t in topologies]
+    topo_levels = [[lv["NodeLabel"] for lv in t["Spec"]["Levels"]] for t in topologies]
     mocks = case.get("Mocks") or {}
     cfg = abi.default_config(max_consolidation_preemptees=-1)  # test_utils_builder.go:78-79
     # addSessionPlugins (test_utils_builder.go:297-321): "predicates" is skipped unless a cache mock exists
@@ -236,8 +254,44 @@ def case_to_snapshot(case, actions=("allocate",)):
                 nflags[i] |= abi.NODE_MIG_MIXED
         if nd.get("GpuMemorySynced") is not None or nd.get("GPUMemory"):
             pass  # only read by gpu-memory requests (unsupported here)
-        if nd.get("Labels"):
-            pass  # topology / custom labels: only the topology plugin reads them
+
+    # ---- topology domain tables (plugins/topology/topology_plugin.go:57-110, topology_structs.go:94-101)
+    topo_level_off = [0]
+    for lv in topo_levels:
+        topo_level_off.append(topo_level_off[-1] + len(lv))
+    node_domain = np.full((topo_level_off[-1], N), -1, np.int32)
+    domain_level, domain_parent, domain_ids = [], [], []
+    for t, levels in enumerate(topo_levels):
+        ids = {}
+        for i, nm in enumerate(node_names):
+            labels = case["Nodes"][nm].get("Labels") or {}
+            if not all(lv in labels for lv in levels):  # isNodePartOfTopology (common.go:70-77)
+                continue
+            parent = -1
+            for l, lv in enumerate(levels):
+                did = ".".join(labels[x] for x in levels[: l + 1])
+                if (l, did) not in ids:
+                    ids[(l, did)] = len(domain_level)
+                    domain_level.append(topo_level_off[t] + l); domain_parent.append(parent); domain_ids.append((t, did))
+                node_domain[topo_level_off[t] + l, i] = ids[(l, did)]
+                parent = ids[(l, did)]
+    domain_id_rank = np.zeros(len(domain_ids), np.uint32)
+    for t in range(len(topo_levels)):
+        idxs = [k for k, (tt, _) in enumerate(domain_ids) if tt == t]
+        for k, r in zip(idxs, abi.rank_strings([domain_ids[k][1] for k in idxs])):
+            domain_id_rank[k] = r
+
+    def constraint(tc):
+        """api/topology_info.TopologyConstraintInfo → (topology index | -1 none | -2 missing, required level, preferred level)"""
+        if not tc or not tc.get("Topology"):
+            return (-1, -1, -1)
+        if tc["Topology"] not in topo_names:
+            return (-2, -1, -1)
+        t = topo_names.index(tc["Topology"])
+        lv = lambda name: (topo_levels[t].index(name) if name in topo_levels[t] else 10 ** 6) if name else -1  # unknown level name ⇒ beyond the last level
+        return (t, lv(tc.get("RequiredLevel")), lv(tc.get("PreferredLevel")))
+
+    group_job, group_parent, group_names, group_tc, job_root_group, podset_group, podset_tc = [], [], [], [], [], [], []
 
     # ---- jobs & tasks (jobs_fake/jobs.go:51-330)
     jobs = sorted(enumerate(case.get("Jobs", [])), key=lambda t: -int(t[1].get("Priority", 0)))  # SliceStable by priority desc
@@ -267,25 +321,31 @@ def case_to_snapshot(case, actions=("allocate",)):
         job_preempt.append(1 if pre == "preemptible" else 0 if pre == "non-preemptible" else (1 if prio < 100 else 0))
         age = int(job.get("JobAgeInMinutes", 0))
         job_created.append((-(age if age != 0 else (J - ji)) * 60_000_000_000) + ji)
-        # pod-sets
+        # sub-group tree: RootSubGroupSet (subgroup_info/subgroupset.go) or, by default, a root without constraint (jobs.go:116-123)
         root = job.get("RootSubGroupSet")
-        sets = []
+        sets = []  # (name, minAvailable, constraint, parent group)
+        root_g = len(group_job)
+        job_root_group.append(root_g)
+        group_job.append(ji); group_parent.append(-1); group_names.append((ji, "")); group_tc.append(constraint(root.get("TopologyConstraint") if root else None))
+
+        def walk(g, gi):
+            for ps in g.get("PodSets", []) or []:
+                sets.append((ps["Name"], int(ps["MinAvailable"]), constraint(ps.get("TopologyConstraint")), gi))
+            for sg in g.get("SubGroups", []) or []:
+                ci = len(group_job)
+                group_job.append(ji); group_parent.append(gi); group_names.append((ji, sg.get("Name", ""))); group_tc.append(constraint(sg.get("TopologyConstraint")))
+                walk(sg, ci)
         if root:
-            flat = _flatten_subgroups(root)
-            if root.get("SubGroups"):
-                raise Unsupported("nested sub-group sets")
-            if root.get("TopologyConstraint") or any(c for (_, _, c, _) in flat):
-                raise Unsupported("topology constraint")
-            sets = [(n, m) for (n, m, _, _) in flat]
+            walk(root, root_g)
             trees[job["Name"]] = root
-        names_in_sets = [n for n, _ in sets]
+        names_in_sets = [x[0] for x in sets]
         if any(not t.get("SubGroupName") for t in tasks) and "default" not in names_in_sets:
-            sets.append(("default", len(tasks)))  # jobs.go:116-123
+            sets.append(("default", len(tasks), (-1, -1, -1), root_g))  # jobs.go:116-123
         job_first_podset.append(len(podset_job)); job_n_podsets.append(len(sets))
         set_index = {}
-        for n, m in sets:
+        for n, m, tc, gi in sets:
             set_index[n] = len(podset_job)
-            podset_job.append(ji); podset_min.append(int(m)); podset_names_l.append((ji, n))
+            podset_job.append(ji); podset_min.append(int(m)); podset_names_l.append((ji, n)); podset_group.append(gi); podset_tc.append(tc)
         job_first_pod.append(len(pod_names)); job_n_pods.append(len(tasks))
         for ti, t in enumerate(tasks):
             if t.get("RequiredMigInstances") or t.get("IsLegacyMigTask"):
@@ -336,7 +396,8 @@ def case_to_snapshot(case, actions=("allocate",)):
         class_fit = np.zeros((len(aff_sets), max(N, 1)), np.uint8)
         for ci, names in enumerate(aff_sets):
             for i, nm in enumerate(node_names):
-                class_fit[ci, i] = 1 if (not names or nm in names) else 0
+                label = (case["Nodes"][nm].get("Labels") or {}).get("tasks_fake.NodeAffinityKey", nm)  # nodes_fake/nodes.go:187-191
+                class_fit[ci, i] = 1 if (not names or label in names) else 0
         pod_class = np.array([aff_sets.index(a) for a in pod_aff], np.int32)
         node_class = np.arange(N, dtype=np.int32)
 
@@ -373,6 +434,20 @@ def case_to_snapshot(case, actions=("allocate",)):
     a["queue_limit"] = np.array([[r["limit"][k] for r in qrec] for k in range(3)], np.float64).reshape(3, Q)
     a["queue_oqw"] = np.array([[r["oqw"][k] for r in qrec] for k in range(3)], np.float64).reshape(3, Q)
     a["class_fit"] = class_fit
+    # topology + sub-group tree (ABI v2)
+    G = len(group_job)
+    g_rank = np.zeros(G, np.uint32)
+    for ji in range(J):
+        idxs = [k for k in range(G) if group_job[k] == ji]
+        for k, r in zip(idxs, abi.rank_strings([group_names[k][1] for k in idxs])):
+            g_rank[k] = r
+    a["topo_level_off"] = np.array(topo_level_off, np.int32); a["node_domain"] = node_domain
+    a["domain_level"] = np.array(domain_level, np.int32); a["domain_parent"] = np.array(domain_parent, np.int32); a["domain_id_rank"] = domain_id_rank
+    a["group_job"] = np.array(group_job, np.int32); a["group_parent"] = np.array(group_parent, np.int32); a["group_name_rank"] = g_rank
+    a["group_topology"] = np.array([t[0] for t in group_tc], np.int32); a["group_required_level"] = np.array([t[1] for t in group_tc], np.int32)
+    a["group_preferred_level"] = np.array([t[2] for t in group_tc], np.int32); a["job_root_group"] = np.array(job_root_group, np.int32)
+    a["podset_group"] = np.array(podset_group, np.int32); a["podset_topology"] = np.array([t[0] for t in podset_tc], np.int32)
+    a["podset_required_level"] = np.array([t[1] for t in podset_tc], np.int32); a["podset_preferred_level"] = np.array([t[2] for t in podset_tc], np.int32)
     snap.finalize()
     meta = dict(name=case.get("Name"), line=case.get("_line"), expected_jobs=case.get("JobExpectedResults") or {},
                 expected_tasks=case.get("TaskExpectedResults") or {}, expected_nodes=case.get("ExpectedNodesResources") or {})

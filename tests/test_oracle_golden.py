@@ -3,7 +3,7 @@ import pytest
 
 import kai_testlib as T
 
-FILES = ["allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups",
+FILES = ["allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology",
          "integration_tests__allocate__allocate"]
 
 
@@ -12,7 +12,7 @@ def _cases(name):
     return [(name, i, c, doc["actions"]) for i, c in enumerate(doc["cases"])]
 
 
-ALL = [x for f in FILES[:4] for x in _cases(f)]
+ALL = [x for f in FILES[:5] for x in _cases(f)]
 
 
 @pytest.mark.parametrize("name,i,case,actions", ALL, ids=[f"{n}[{i}]" for n, i, _, _ in ALL])
@@ -35,4 +35,4 @@ def test_golden_coverage():
             ok += 1
         except T.Unsupported:
             pass
-    assert ok >= 43, ok
+    assert ok >= 64, ok
