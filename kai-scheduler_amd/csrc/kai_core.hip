@@ -251,6 +251,25 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dupload_f(core, c.cls, prep.classes.data(), prep.classes.size()));
     TRY(dzero_f(core, c.sum1_key, (size_t)std::max(c.C, 1) * std::max(c.NB, 1))); TRY(dzero_f(core, c.sum1_node, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)));
 
+    // ---- topologies + sub-group tree
+    c.T = prep.T; c.TL = prep.TL; c.D = prep.D; c.G = prep.G; c.W = (N + 31) / 32;
+    TRY(dupload_f(core, c.topo_level_off, prep.topo_level_off.data(), prep.topo_level_off.size())); TRY(dupload_f(core, c.node_domain, prep.node_domain.data(), prep.node_domain.size()));
+    TRY(dupload_f(core, c.dom_level, prep.dom_level.data(), prep.dom_level.size())); TRY(dupload_f(core, c.dom_topo, prep.dom_topo.data(), prep.dom_topo.size()));
+    TRY(dupload_f(core, c.dom_parent, prep.dom_parent.data(), prep.dom_parent.size())); TRY(dupload_f(core, c.dom_id_rank, prep.dom_id_rank.data(), prep.dom_id_rank.size()));
+    TRY(dupload_f(core, c.dom_child_off, prep.dom_child_off.data(), prep.dom_child_off.size())); TRY(dupload_f(core, c.dom_children, prep.dom_children.data(), prep.dom_children.size()));
+    { const size_t DT = (size_t)prep.D + prep.T;
+      TRY(dzero_f(core, c.dom_alloc_pods, DT)); TRY(dzero_f(core, c.dom_free, DT * KAI_MAX_RES)); TRY(dzero_f(core, c.dom_tmp, 3 * DT + 4)); TRY(dzero_f(core, c.dom_ratio, DT));
+      TRY(dzero_f(core, c.ns_bits, (size_t)KAI_TDEPTH * std::max(c.W, 1))); TRY(dzero_f(core, c.ns_sets, (size_t)KAI_TDEPTH * (DT + 1)));
+      TRY(dzero_f(core, c.sg_score, (size_t)KAI_TKEYS * std::max<size_t>(DT, 1))); TRY(dzero_f(core, c.sg_key, (size_t)KAI_TKEYS)); TRY(dzero_f(core, c.sg_row, (size_t)KAI_TKEYS)); }
+    TRY(dupload_f(core, c.g_job, prep.g_job.data(), prep.g_job.size())); TRY(dupload_f(core, c.g_parent, prep.g_parent.data(), prep.g_parent.size()));
+    TRY(dupload_f(core, c.g_name_rank, prep.g_name_rank.data(), prep.g_name_rank.size())); TRY(dupload_f(core, c.g_topo, prep.g_topo.data(), prep.g_topo.size()));
+    TRY(dupload_f(core, c.g_req, prep.g_req.data(), prep.g_req.size())); TRY(dupload_f(core, c.g_pref, prep.g_pref.data(), prep.g_pref.size()));
+    TRY(dupload_f(core, c.j_root_group, prep.j_root_group.data(), prep.j_root_group.size()));
+    TRY(dupload_f(core, c.g_child_off, prep.g_child_off.data(), prep.g_child_off.size())); TRY(dupload_f(core, c.g_children, prep.g_children.data(), prep.g_children.size()));
+    TRY(dupload_f(core, c.s_group, prep.s_group.data(), prep.s_group.size())); TRY(dupload_f(core, c.s_topo, prep.s_topo.data(), prep.s_topo.size()));
+    TRY(dupload_f(core, c.s_req, prep.s_req.data(), prep.s_req.size())); TRY(dupload_f(core, c.s_pref, prep.s_pref.data(), prep.s_pref.size()));
+    TRY(dupload_f(core, c.j_has_topology, prep.j_has_topology.data(), prep.j_has_topology.size()));
+
     // ---- dynamic state
     double* d;
     TRY(dalloc_f(core, c.n_idle, (size_t)R * N)); (void)d;

@@ -34,6 +34,16 @@
 #define KAI_HD_NOINLINE
 #endif
 
+// KAI_GP(T): pointer to T in HBM.  On the device it is an address-space-1 ("global") pointer so that every array access is a
+// global_load / global_store (vmcnt only); through generic pointers they would be flat_* operations, which also count on
+// lgkmcnt and so serialise against every LDS read of the engine.  Same size and layout on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> using kai_gptr = T __attribute__((address_space(1)))*;
+#else
+template <class T> using kai_gptr = T*;
+#endif
+#define KAI_GP(T) kai_gptr<T>
+
 namespace kai {
 
 // pod status groups: api/pod_status/pod_status.go:64-71
@@ -92,6 +102,8 @@ enum : uint32_t { QF_OVER = 1, QF_STARVED = 2, QF_VIOL = 4, QF_VALID = 8, QF_REO
 // the queues on the job's leaf→root chain, held in LDS for the duration of the attempt (kai_kernels.hpp) and written back once.
 constexpr int KAI_FMAX = 32;   // tasks per chunk the frame holds; larger gangs take the general path
 constexpr int KAI_FDEPTH = 8;  // queue levels
+constexpr int KAI_TDEPTH = 16;  // frames of the sub-group DFS (group depth + the pod-set level)
+constexpr int KAI_TKEYS = 32;   // sub-groups of one job that carry preferred-level node scores
 struct FastFrame {
     int32_t depth, np, pad0, pad1;
     int32_t q[KAI_FDEPTH];
@@ -130,37 +142,54 @@ struct KaiCtx {
     uint32_t plugins; int32_t gpu_strategy, cpu_strategy, restrict_nodes; double k_value;
     int32_t C, NB, NSB, use_index, all_tracked, queue_depth, fast_ok, pad1;
     // nodes
-    const double* n_alloc; const uint32_t* n_flags; const int32_t* n_gpu_count; const int32_t* n_class;
-    double *n_idle, *n_rel, *n_used;
+    KAI_GP(const double) n_alloc; KAI_GP(const uint32_t) n_flags; KAI_GP(const int32_t) n_gpu_count; KAI_GP(const int32_t) n_class;
+    KAI_GP(double) n_idle, n_rel, n_used;
     // pods
-    const double* p_req; const int32_t *p_job, *p_podset; const uint32_t* p_flags; const int32_t *p_class, *p_nominated, *p_scls;
-    int32_t *p_status, *p_node, *p_on_node, *p_on_node_status; uint8_t *p_virtual, *p_accepted;
+    KAI_GP(const double) p_req; KAI_GP(const int32_t) p_job, p_podset; KAI_GP(const uint32_t) p_flags; KAI_GP(const int32_t) p_class, p_nominated, p_scls;
+    KAI_GP(int32_t) p_status, p_node, p_on_node, p_on_node_status; KAI_GP(uint8_t) p_virtual, p_accepted;
     // pod-sets
-    const int32_t *s_job, *s_min; const uint32_t* s_name_rank;
-    int32_t *s_active_alloc, *s_active_used, *s_alive, *s_gated, *s_pipelined;
+    KAI_GP(const int32_t) s_job, s_min; KAI_GP(const uint32_t) s_name_rank;
+    KAI_GP(int32_t) s_active_alloc, s_active_used, s_alive, s_gated, s_pipelined;
     // jobs
-    const int32_t *j_queue, *j_prio, *j_preempt; const int64_t* j_created; const uint32_t* j_uid_rank;
-    const int32_t *j_first_pod, *j_n_pods, *j_first_ps, *j_n_ps;
-    const int32_t* j_pods_sorted;  // [P] each job's pods in TaskOrderFn order (session_plugins.go:244-260), same region as the job's pods
-    int32_t *j_n_pending, *j_tta_valid, *j_tta_n, *tta;  // tasks-to-allocate cache (allocation_info.go:31-33), region = job's pod range
-    double *j_tta_res;  // [3][J] init resource of the cached chunk (CPU, Memory, GPU)
-    double *j_allocated;  // [3][J] PodGroupInfo.Allocated
+    KAI_GP(const int32_t) j_queue, j_prio, j_preempt; KAI_GP(const int64_t) j_created; KAI_GP(const uint32_t) j_uid_rank;
+    KAI_GP(const int32_t) j_first_pod, j_n_pods, j_first_ps, j_n_ps;
+    KAI_GP(const int32_t) j_pods_sorted;  // [P] each job's pods in TaskOrderFn order (session_plugins.go:244-260), same region as the job's pods
+    KAI_GP(int32_t) j_n_pending, j_tta_valid, j_tta_n, tta;  // tasks-to-allocate cache (allocation_info.go:31-33), region = job's pod range
+    KAI_GP(double) j_tta_res;  // [3][J] init resource of the cached chunk (CPU, Memory, GPU)
+    KAI_GP(double) j_allocated;  // [3][J] PodGroupInfo.Allocated
     // queues
-    const int32_t *q_parent, *q_prio; const int64_t* q_created; const uint32_t* q_uid_rank;
-    const int32_t *q_child_off, *q_children, *q_job_off, *q_depth_order;  // CSR children (virtual root at Q); leaf job regions; deepest first
-    QShare* q_share;  // [Q][3]
-    QNode* qn;  // [Q] HBM home of the job-order tree (static fields + leaf lengths set by k_leaf_init)
-    const uint8_t* class_fit;
+    KAI_GP(const int32_t) q_parent, q_prio; KAI_GP(const int64_t) q_created; KAI_GP(const uint32_t) q_uid_rank;
+    KAI_GP(const int32_t) q_child_off, q_children, q_job_off, q_depth_order;  // CSR children (virtual root at Q); leaf job regions; deepest first
+    KAI_GP(QShare) q_share;  // [Q][3]
+    KAI_GP(QNode) qn;  // [Q] HBM home of the job-order tree (static fields + leaf lengths set by k_leaf_init)
+    KAI_GP(const uint8_t) class_fit;
     // scan classes + class index
-    const ClassRec* cls; uint64_t* sum1_key; int32_t* sum1_node;  // [C][NB]
+    KAI_GP(const ClassRec) cls; KAI_GP(uint64_t) sum1_key; KAI_GP(int32_t) sum1_node;  // [C][NB]
     // job-order tree (actions/utils/job_order_by_queue.go).  Leaves: a sorted region + a side heap; inner nodes: array heaps.
-    const int32_t* jobs_static;  // [J] CSR by q_job_off: each queue's jobs by (priority desc, creation, uid)
-    int32_t *lq_sorted, *lq_cur, *lq_end, *lq_side, *lq_side_len; uint8_t* j_state;
-    int32_t *qheap, *root_heap;
+    KAI_GP(const int32_t) jobs_static;  // [J] CSR by q_job_off: each queue's jobs by (priority desc, creation, uid)
+    KAI_GP(int32_t) lq_sorted, lq_cur, lq_end, lq_side, lq_side_len; KAI_GP(uint8_t) j_state;
+    KAI_GP(int32_t) qheap, root_heap;
     // statement + committed operations
-    StmtOp* ops; int32_t ops_cap; kai_op* out_ops; int64_t out_cap;
-    int32_t* scratch;  // [P] ints
-    EngineState* st;
+    KAI_GP(StmtOp) ops; int32_t ops_cap; KAI_GP(kai_op) out_ops; int64_t out_cap;
+    KAI_GP(int32_t) scratch;  // [P] ints
+    KAI_GP(EngineState) st;
+    // topologies (plugins/topology) — node_domain rows are in engine node order; index D + t = root domain of topology t
+    int32_t T, TL, D, G; int32_t W, pad2, pad3, pad4;               // topologies, level rows, domains, groups; words per node-set bitmap
+    KAI_GP(const int32_t) topo_level_off, node_domain, dom_level /* inside its topology, -1 root */, dom_topo, dom_parent; KAI_GP(const uint32_t) dom_id_rank;
+    KAI_GP(const int32_t) dom_child_off;                             // [D+T+1] CSR of children
+    KAI_GP(int32_t) dom_children;                                    // [..] current child order (sortTree re-orders in place, like the reference)
+    KAI_GP(int32_t) dom_alloc_pods; KAI_GP(double) dom_free;         // [D+T], [D+T][KAI_MAX_RES] AllocatablePods / IdleOrReleasingResources
+    KAI_GP(int32_t) dom_tmp;                                         // [3*(D+T)+4] scratch: chosen flags, BFS queue
+    KAI_GP(double) dom_ratio;                                        // [D+T] scratch of sortTree
+    // sub-group tree
+    KAI_GP(const int32_t) g_job, g_parent; KAI_GP(const uint32_t) g_name_rank; KAI_GP(const int32_t) g_topo, g_req, g_pref, j_root_group;
+    KAI_GP(const int32_t) g_child_off, g_children;                   // CSR of child groups
+    KAI_GP(const int32_t) s_group, s_topo, s_req, s_pref; KAI_GP(const uint8_t) j_has_topology;
+    // the general path's node sets (one bitmap per DFS level), set lists and preferred-level scores of the current job
+    KAI_GP(uint32_t) ns_bits;                                        // [KAI_TDEPTH][W]
+    KAI_GP(int32_t) ns_sets;                                         // [KAI_TDEPTH][D+T+1] domains of the node sets of a frame
+    KAI_GP(double) sg_score;                                         // [KAI_TKEYS][D+T] node score of a domain at the key's preferred level, <0 = not scored
+    KAI_GP(int32_t) sg_key, sg_row;                                  // [KAI_TKEYS] sub-group key and its preferred level row
 };
 
 // ======================================================================================================
@@ -319,6 +348,7 @@ KAI_HD bool key_better(uint64_t k, int n, uint64_t bk, int bn) { return k > bk |
 //    void refresh(const KaiCtx&)                                        — re-evaluate the listed blocks, clear the list
 //    void class_top(const KaiCtx&, int cls, uint64_t& key, int& node)   — arg-max of class_key over all nodes
 //    bool all_dead(const KaiCtx&)                                       — no class has a fitting node
+//    (brute-force scans honour local().scope_bits / scope_row / scope_score: node-set bitmap and preferred-level topology scores)
 //    void hot(const KaiCtx&, QNode*&, int32_t*& qheap, int32_t*& root_heap) — where the job-order tree lives (LDS if it fits, else HBM)
 //    const KaiCtx& ctx() / EngineLocal& local() / void bind(const KaiCtx&) — context and engine scalars (LDS objects on the device)
 //    int64_t clock()
@@ -328,6 +358,9 @@ struct EngineLocal {
     QNode* qn; int32_t *qheap, *root_heap;  // where the job-order tree lives (LDS if it fits, else HBM)
     int32_t root_len, root_init, fail_no_node, pad;
     double total0, total1, total2;          // proportion totalResource (read-only during an action)
+    // scope of the next node scans (general path): node-set bitmap (null = every node) and the preferred-level scores that apply
+    KAI_GP(const uint32_t) scope_bits; KAI_GP(const double) scope_score; int32_t scope_row, n_keys;
+    uint32_t restricted, pad5;               // bit d: the node set of DFS depth d is narrower than "every node"
 };
 
 template <class Backend>
@@ -342,6 +375,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0;
     }
 
     KAI_HD void fault(int code) { if (!cx().st->fault) cx().st->fault = code; }
@@ -625,7 +659,9 @@ struct Engine {
                 for (int k = 0; k < nps; k++) {
                     bool taken = k < 64 ? ((taken_lo >> k) & 1) : (cx().scratch[first + (k - 64)] != 0);
                     if (taken) continue;
-                    if (best < 0 || podset_order(ps0 + k, ps0 + best)) best = k;
+                    const int cur = best < 0 ? k : best;  // branch-free, see allocate_job
+                    const bool take = podset_order(ps0 + k, ps0 + cur) | (best < 0);
+                    best = take ? k : best;
                 }
                 if (best < 0) break;
                 if (best < 64) taken_lo |= (1ull << best); else cx().scratch[first + (best - 64)] = 1;
@@ -918,7 +954,7 @@ struct Engine {
     }
     // OrderedNodesByTask + FittingNode for one task (framework/session.go:201-264): the first fitting node in score order, or -1
     KAI_HD int find_node(int p, bool& allocatable) {
-        int k = cx().use_index ? cx().p_scls[p] : -1;
+        int k = (cx().use_index && !el().scope_bits && el().scope_row < 0) ? cx().p_scls[p] : -1;
         if (k >= 0) {
             const ClassRec& cr = cx().cls[k];
             int n = -1; uint64_t key = 0;
@@ -951,33 +987,321 @@ struct Engine {
         cx().st->prof[PF_STMT] += be.clock() - t2;
         return ok;
     }
-    KAI_HD bool allocate_job(int j, bool pipeline_only) {  // AllocateJob :20-36 → allocateSubGroupSet :38-81 → allocatePodSet :83-119
-        if (cx().j_n_ps[j] > 64) { fault(FAULT_INTERNAL); return false; }  // engine limit: 64 pod-sets per job
+    // ------------------------------------------------------------------ plugins/topology: SubsetNodesFn
+    KAI_HD bool podset_in_group(int ps, int g) const { for (int x = cx().s_group[ps]; x >= 0; x = cx().g_parent[x]) if (x == g) return true; return false; }
+    KAI_HD bool task_in_subgroup(int p, int grp, int ps) const { return ps >= 0 ? cx().p_podset[p] == ps : podset_in_group(cx().p_podset[p], grp); }
+    KAI_HD static bool bits_has(KAI_GP(const uint32_t) bits, int n) { return !bits || ((bits[n >> 5] >> (n & 31)) & 1u); }
+    KAI_HD int node_dom(int row, int n) const { return cx().node_domain[(size_t)row * cx().N + n]; }
+    KAI_HD bool dom_in_subtree(int d, int root_dom) const {  // is d inside the sub-tree of root_dom (same topology)?
+        int rl = cx().dom_level[root_dom];
+        while (d >= 0 && cx().dom_level[d] > rl) d = cx().dom_parent[d];
+        return d == root_dom;
+    }
+    KAI_HD double quantity_value_milli(double milli) const {  // resource.NewMilliQuantity(x).Value(): rounded up
+        double q = milli / 1000.0, f = rd_floor_any(q);
+        return f < q ? f + 1.0 : f;
+    }
+    KAI_HD static double rd_floor_any(double x) { double t = (double)(int64_t)x; return t > x ? t - 1.0 : t; }
+    // getJobRatioToFreeResources (plugins/topology/job_filtering.go:491-524); tr = summed request of the tasks
+    KAI_HD double job_ratio(const double* tr, int d) const {
+        double dominant = 0.0;
+        bool none = !(tr[KAI_RES_GPU] > 0) && !(tr[KAI_RES_CPU] > 0) && !(tr[KAI_RES_MEM] > 0);
+        for (int r = KAI_RES_PODS; r < cx().R; r++) if (tr[r] > 0) none = false;   // a scalar the empty resource does not have
+        if (none) return dominant;
+        KAI_GP(const double) fr = cx().dom_free + (size_t)d * KAI_MAX_RES;
+        if (tr[KAI_RES_GPU] > 0) dominant = kmax(dominant, tr[KAI_RES_GPU] / fr[KAI_RES_GPU]);
+        {   double tv = quantity_value_milli((double)(int64_t)tr[KAI_RES_CPU]), fv = quantity_value_milli((double)(int64_t)fr[KAI_RES_CPU]);
+            if (tv != 0) dominant = kmax(dominant, fv == 0 ? 1000.0 : tv / fv); }
+        {   double tv = (double)(int64_t)tr[KAI_RES_MEM], fv = (double)(int64_t)fr[KAI_RES_MEM];
+            if (tv != 0) dominant = kmax(dominant, fv == 0 ? 1000.0 : tv / fv); }
+        for (int r = KAI_RES_PODS + 1; r < cx().R; r++) {  // the pods resource is ignored for bin-packing
+            double tv = quantity_value_milli(tr[r]), fv = quantity_value_milli(fr[r]);
+            if (tv != 0) dominant = kmax(dominant, fv == 0 ? 1000.0 : tv / fv);
+        }
+        return dominant;
+    }
+    KAI_HD bool domain_fits(int d, const double* tr, int count) const {  // checkJobDomainFit :362-379
+        int ap = cx().dom_alloc_pods[d];
+        if (ap != -1) return ap >= count;
+        return !(job_ratio(tr, d) > 1.0);
+    }
+    // subSetNodesFn (plugins/topology/job_filtering.go:34-112) for a sub-group (grp = SubGroupSet, or ps = pod-set) of job j over the node set
+    // `parent`.  Writes the node sets in order to sets_out: a domain index, or -1 = "the parent set as it is".  Returns their number
+    // (0 = no node set / configuration error).  Control-lane code over the HBM domain tables.
+    KAI_HD int subset_nodes(int j, int key, int tc_topo, int tc_req, int tc_pref, int grp, int ps, const int32_t* chunk, int nt,
+                            KAI_GP(const uint32_t) parent, KAI_GP(int32_t) sets_out) {
+        const KaiCtx& c = cx();
+        if (!(c.plugins & KAI_PLUGIN_TOPOLOGY)) { sets_out[0] = -1; return 1; }
+        if (tc_topo == -2) return 0;  // "Requested topology does not exist"
+        int tasks = 0; for (int i = 0; i < nt; i++) if (task_in_subgroup(chunk[i], grp, ps)) tasks++;
+        if (tc_topo < 0 || tasks == 0) { sets_out[0] = -1; return 1; }
+        const int t = tc_topo, row0 = c.topo_level_off[t], L = c.topo_level_off[t + 1] - row0, N = c.N, DT = c.D + c.T, root = c.D + t, R = c.R;
+        // lowestCommonDomainID (common.go:17-67) over the nodes of `parent` that are part of the topology
+        int domain = root;
+        for (int l = 0; l < L; l++) {
+            int v = -2; bool all = true;
+            for (int n = 0; n < N && all; n++) {
+                if (!bits_has(parent, n) || node_dom(row0, n) < 0) continue;
+                int dd = node_dom(row0 + l, n);
+                if (v == -2) v = dd; else if (dd != v) all = false;
+            }
+            if (v == -2 || !all) break;
+            domain = v;
+            if (tc_pref == l) break;
+        }
+        const int dl = c.dom_level[domain];
+        // treeAllocatableCleanup :438-445 + calcSubTreeFreeResources :192-211 (leaf accumulation, then bottom-up inside the sub-tree)
+        for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t) { c.dom_alloc_pods[d] = -1; for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = 0.0; }
+        auto node_in_domain = [&](int n) { return L > 0 && (domain == root ? node_dom(row0, n) >= 0 : node_dom(row0 + dl, n) == domain); };
+        for (int n = 0; n < N; n++) {
+            if (!node_in_domain(n)) continue;
+            int leaf = node_dom(row0 + L - 1, n);
+            for (int r = 0; r < R; r++) { size_t x = (size_t)leaf * KAI_MAX_RES + r; c.dom_free[x] += c.n_idle[(size_t)r * N + n]; c.dom_free[x] += c.n_rel[(size_t)r * N + n]; }
+        }
+        for (int lvl = L - 1; lvl > dl; lvl--) for (int d = 0; d < c.D; d++) {
+            if (c.dom_topo[d] != t || c.dom_level[d] != lvl || !dom_in_subtree(d, domain)) continue;
+            int par = c.dom_parent[d];
+            for (int r = 0; r < R; r++) c.dom_free[(size_t)par * KAI_MAX_RES + r] += c.dom_free[(size_t)d * KAI_MAX_RES + r];
+        }
+        // tasks: summed request, element-wise maximum, homogeneity (useRepresentorPodsAccounting :550-571)
+        double tr[KAI_MAX_RES], mx[KAI_MAX_RES]; int scalar_users[KAI_MAX_RES], gpu_users = 0;
+        for (int r = 0; r < KAI_MAX_RES; r++) { tr[r] = 0; mx[r] = 0; scalar_users[r] = 0; }
+        for (int i = 0; i < nt; i++) {
+            int p = chunk[i]; if (!task_in_subgroup(p, grp, ps)) continue;
+            for (int r = 0; r < R; r++) { double v = preq(p, r); tr[r] += v; if (v > mx[r]) mx[r] = v; if (r >= KAI_RES_PODS && v != 0) scalar_users[r]++; }
+            if (preq(p, KAI_RES_GPU) > 0) gpu_users++;
+        }
+        bool homogeneous = !(gpu_users != tasks && gpu_users != 0);
+        for (int r = KAI_RES_PODS; r < R; r++) if (scalar_users[r] != 0 && scalar_users[r] != tasks) homogeneous = false;
+        if (homogeneous) {  // calcTreeAllocatable :138-190 with calcNodeAccommodation :213-246
+            bool one_pod_only = !(mx[KAI_RES_CPU] > 0) && !(mx[KAI_RES_MEM] > 0) && !(mx[KAI_RES_GPU] > 0) && mx[KAI_RES_PODS] <= 1;
+            for (int r = KAI_RES_PODS + 1; r < R; r++) if (mx[r] > 0) one_pod_only = false;
+            for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t && dom_in_subtree(d, domain)) c.dom_alloc_pods[d] = 0;
+            for (int n = 0; n < N; n++) {
+                if (!node_in_domain(n)) continue;
+                int count = 0;
+                if (one_pod_only) count = tasks;
+                else {
+                    double cur[KAI_MAX_RES]; for (int r = 0; r < KAI_MAX_RES; r++) cur[r] = mx[r];  // k-th test pod = k x the maximal pod, by repeated addition
+                    for (;;) {
+                        if (!fits(c, cur, n, true)) break;
+                        count++;
+                        for (int r = 0; r < R; r++) cur[r] += mx[r];
+                    }
+                }
+                c.dom_alloc_pods[node_dom(row0 + L - 1, n)] += count;
+            }
+            for (int lvl = L - 1; lvl > dl; lvl--) for (int d = 0; d < c.D; d++) {
+                if (c.dom_topo[d] != t || c.dom_level[d] != lvl || !dom_in_subtree(d, domain)) continue;
+                c.dom_alloc_pods[c.dom_parent[d]] += c.dom_alloc_pods[d];
+            }
+        }
+        if (!domain_fits(domain, tr, tasks)) return 0;
+        // sortTreeFromRoot :447-486: children by ratio descending, then by domain ID, down to the preferred (else required) level
+        const int max_depth = tc_pref >= 0 ? tc_pref : tc_req;
+        KAI_GP(int32_t) stack = c.dom_tmp;
+        if (max_depth >= 0) {
+            int sp = 0; stack[sp++] = domain;
+            while (sp > 0) {
+                int d = stack[--sp];
+                int b0 = c.dom_child_off[d], b1 = c.dom_child_off[d + 1];
+                for (int i = b0; i < b1; i++) c.dom_ratio[c.dom_children[i]] = job_ratio(tr, c.dom_children[i]);
+                for (int i = b0 + 1; i < b1; i++) {  // insertion sort: (ratio desc, ID asc) is a total order on siblings
+                    int x = c.dom_children[i]; int k = i - 1;
+                    while (k >= b0) {
+                        int y = c.dom_children[k];
+                        bool x_first = c.dom_ratio[x] > c.dom_ratio[y] || (c.dom_ratio[x] == c.dom_ratio[y] && c.dom_id_rank[x] < c.dom_id_rank[y]);
+                        if (!x_first) break;
+                        c.dom_children[k + 1] = y; k--;
+                    }
+                    c.dom_children[k + 1] = x;
+                }
+                if (c.dom_level[d] == max_depth) continue;
+                for (int i = b0; i < b1; i++) stack[sp++] = c.dom_children[i];
+            }
+        }
+        if (tc_pref >= 0) {  // calculateNodeScores (node_scoring.go:37-69): i-th preferred-level domain in tree order scores floor((i+1)/n*10)*10000
+            int slot = -1; for (int i = 0; i < el().n_keys; i++) if (c.sg_key[i] == key) slot = i;
+            if (slot < 0) { if (el().n_keys >= KAI_TKEYS) { fault(FAULT_INTERNAL); return 0; } slot = el().n_keys++; c.sg_key[slot] = key; }
+            c.sg_row[slot] = row0 + tc_pref;
+            KAI_GP(double) sc = c.sg_score + (size_t)slot * DT;
+            for (int d = 0; d < DT; d++) sc[d] = -1.0;
+            for (int pass = 0, total = 0; pass < 2; pass++) {
+                int sp = 0, idx = 0; stack[sp++] = domain;
+                while (sp > 0) {
+                    int d = stack[--sp];
+                    if (c.dom_level[d] == tc_pref) { if (pass == 0) total++; else { double score = ((double)(idx + 1) / (double)total) * 10; sc[d] = rd_floor_any(score) * 10000.0; idx++; } continue; }
+                    for (int i = c.dom_child_off[d + 1] - 1; i >= c.dom_child_off[d]; i--) stack[sp++] = c.dom_children[i];  // reverse push = in-order visit
+                }
+            }
+        }
+        // getJobAllocatableDomains :265-310 over calculateRelevantDomainLevels :381-425 (from the preferred level up to the required one)
+        if (tc_req < 0 && tc_pref < 0) return 0;
+        if (tc_req >= L || tc_pref >= L) return 0;  // a level the topology does not have
+        bool restrict_active = false;
+        if (tc_req >= 0) {  // hasActiveAllocatedTasks && required level: only sub-trees that already hold an active pod of these pod-sets (:321-347)
+            for (int k = 0; k < c.j_n_ps[j]; k++) { int s2 = c.j_first_ps[j] + k; if ((ps >= 0 ? s2 == ps : podset_in_group(s2, grp)) && c.s_active_alloc[s2] > 0) restrict_active = true; }
+        }
+        KAI_GP(int32_t) chosen = c.dom_tmp + DT;      // 1 = allocatable domain of a relevant level
+        for (int d = 0; d < DT; d++) chosen[d] = 0;
+        int n_chosen = 0;
+        bool found_pref = false, found_req = false;
+        for (int l = L - 1; l >= -1; l--) {
+            if (l == tc_pref && l >= 0) found_pref = true;
+            if (l == tc_req && l >= 0) found_req = true;
+            if (found_pref || found_req) for (int d = 0; d < DT; d++) {
+                if (c.dom_topo[d] != t || c.dom_level[d] != l) continue;
+                if (restrict_active) {
+                    int anc = d; while (anc >= 0 && c.dom_level[anc] > tc_req) anc = c.dom_parent[anc];
+                    bool has = false;
+                    if (anc >= 0 && c.dom_level[anc] == tc_req) for (int i = 0; i < c.j_n_pods[j] && !has; i++) {
+                        int p = c.j_first_pod[j] + i;
+                        if (!st_active_allocated(c.p_status[p]) || c.p_node[p] < 0 || !task_in_subgroup(p, grp, ps)) continue;
+                        if (node_dom(row0 + tc_req, c.p_node[p]) == anc) has = true;
+                    }
+                    if (!has) continue;
+                }
+                if (domain_fits(d, tr, tasks)) { chosen[d] = 1; n_chosen++; }
+            }
+            if (found_req) break;
+        }
+        if (!n_chosen) return 0;
+        // sortDomainInfos :526-542: bottom-up level order of the tree from the topology root
+        KAI_GP(int32_t) ord = c.dom_tmp + 2 * DT;
+        int n_ord = 0, lvl_start[KAI_MAX_RES * 4], n_lvls = 0;
+        ord[n_ord++] = root; lvl_start[n_lvls++] = 0;
+        for (int b = 0; b < n_ord;) {
+            int e = n_ord;
+            for (int i = b; i < e; i++) for (int k = c.dom_child_off[ord[i]]; k < c.dom_child_off[ord[i] + 1]; k++) ord[n_ord++] = c.dom_children[k];
+            b = e;
+            if (n_ord > e) { if (n_lvls >= KAI_MAX_RES * 4) { fault(FAULT_INTERNAL); return 0; } lvl_start[n_lvls++] = e; }
+        }
+        int n_sets = 0;
+        for (int lv = n_lvls - 1; lv >= 0; lv--) {
+            int b = lvl_start[lv], e = lv + 1 < n_lvls ? lvl_start[lv + 1] : n_ord;
+            for (int i = b; i < e; i++) if (chosen[ord[i]]) sets_out[n_sets++] = ord[i];
+        }
+        return n_sets;
+    }
+    // node set of a frame: parent ∩ nodes of the topology ∩ nodes of domain d   (d = -1: the parent set itself)
+    KAI_HD void build_node_set(KAI_GP(uint32_t) out, KAI_GP(const uint32_t) parent, int d) {
+        const KaiCtx& c = cx();
+        for (int w = 0; w < c.W; w++) out[w] = 0;
+        int row0 = 0, dl = -1;
+        if (d >= 0) { row0 = c.topo_level_off[c.dom_topo[d]]; dl = c.dom_level[d]; }
+        for (int n = 0; n < c.N; n++) {
+            bool in = bits_has(parent, n);
+            if (in && d >= 0) in = dl < 0 ? node_dom(row0, n) >= 0 : node_dom(row0 + dl, n) == d;
+            if (in) out[n >> 5] |= 1u << (n & 31);
+        }
+    }
+    // the preferred-level scores that apply to a task: its pod-set's, else the nearest ancestor's (node_scoring.go:88-99)
+    KAI_HD void set_scan_scope(int p, KAI_GP(const uint32_t) bits) {
+        const KaiCtx& c = cx();
+        el().scope_bits = bits; el().scope_row = -1; el().scope_score = nullptr;
+        if (!(c.plugins & KAI_PLUGIN_TOPOLOGY) || el().n_keys == 0) return;
+        int key = -(c.p_podset[p] + 1);
+        for (;;) {
+            for (int i = 0; i < el().n_keys; i++) if (c.sg_key[i] == key) { el().scope_row = c.sg_row[i]; el().scope_score = c.sg_score + (size_t)i * (c.D + c.T); return; }
+            int parent = key < 0 ? c.s_group[-key - 1] : c.g_parent[key];
+            if (parent < 0) return;
+            key = parent;
+        }
+    }
+
+    // ------------------------------------------------------------------ actions/common/allocate.go: the sub-group DFS
+    // AllocateJob :20-36 → allocateSubGroupSet :38-60 → allocateSubGroupSetOnNodes :62-81 → allocatePodSet :83-107 →
+    // allocateTasksOnNodeSet :109-119, as an explicit stack of frames (one per SubGroupSet / pod-set on the current path): each frame
+    // walks its node sets in order, under a checkpoint, and a failing child sends its parent to the parent's next node set.
+    struct Frame { int32_t kind /* 0 SubGroupSet, 1 pod-set */, id, n_sets, cur, cp, last_rank; uint64_t done; };
+    KAI_HD bool allocate_job(int j, bool pipeline_only) {
+        const KaiCtx& c = cx();
+        if (c.j_n_ps[j] > 64) { fault(FAULT_INTERNAL); return false; }  // engine limit: 64 pod-sets per job
+        el().n_keys = 0; el().restricted = 0;  // ssn.PreJobAllocation → topology.preJobAllocationFn (topology_plugin.go:52-55)
         int64_t t0 = be.clock();
         ensure_tta(j, !pipeline_only);
-        int64_t t1 = be.clock(); cx().st->prof[PF_TTA] += t1 - t0;
+        int64_t t1 = be.clock(); c.st->prof[PF_TTA] += t1 - t0;
         bool gated = job_over_queue_capacity(j);
-        cx().st->prof[PF_GATE] += be.clock() - t1;
+        c.st->prof[PF_GATE] += be.clock() - t1;
         if (gated) return false;
-        int cp_root = checkpoint();
-        int first = cx().j_first_pod[j], nt = cx().j_tta_n[j], nps = cx().j_n_ps[j], ps0 = cx().j_first_ps[j];
+        const int first = c.j_first_pod[j], nt = c.j_tta_n[j], nps = c.j_n_ps[j], ps0 = c.j_first_ps[j], DT1 = c.D + c.T + 1;
         // the cached chunk is consumed below while statuses change, so snapshot it (Go holds the slice it got)
-        int32_t* chunk = cx().scratch + first;
-        for (int i = 0; i < nt; i++) chunk[i] = cx().tta[first + i];
-        // orderedPodSets :270-277 — sort.Slice by PodSetOrderFn; the order is re-read at every step because allocating
-        // changes the counters only of pod-sets already visited
-        uint64_t done = 0;
-        for (int round = 0; round < nps; round++) {
-            int best = -1;
-            for (int k = 0; k < nps && k < 64; k++) { if ((done >> k) & 1) continue; if (best < 0 || podset_order(ps0 + k, ps0 + best)) best = k; }
-            if (best < 0) break;
-            done |= 1ull << best;
-            int s = ps0 + best;
-            int cp = checkpoint(); bool ok = true;
-            for (int i = 0; i < nt; i++) { int p = chunk[i]; if (cx().p_podset[p] != s) continue; if (!allocate_task(p, pipeline_only)) { ok = false; break; } }
-            if (!ok) { int64_t tr = be.clock(); rollback(cp); rollback(cp_root); cx().st->prof[PF_ROLLBACK] += be.clock() - tr; return false; }
+        int32_t* chunk = (int32_t*)(c.scratch + first);
+        for (int i = 0; i < nt; i++) chunk[i] = c.tta[first + i];
+        Frame fr[KAI_TDEPTH]; int depth = 0;
+        fr[0].kind = 0; fr[0].id = c.j_root_group[j]; fr[0].n_sets = -1; fr[0].cur = -1; fr[0].cp = 0; fr[0].last_rank = -1; fr[0].done = 0;
+        int ret = -1;  // result handed up by a finished child: -1 none, 0 failed, 1 succeeded
+        bool result = false;
+        for (;;) {
+            Frame& f = fr[depth];
+            KAI_GP(int32_t) sets = c.ns_sets + (size_t)depth * DT1;
+            if (f.n_sets < 0) {  // first visit: SubsetNodesFn for this sub-group
+                int topo = f.kind ? c.s_topo[f.id] : c.g_topo[f.id], req = f.kind ? c.s_req[f.id] : c.g_req[f.id], pref = f.kind ? c.s_pref[f.id] : c.g_pref[f.id];
+                f.n_sets = subset_nodes(j, f.kind ? -(f.id + 1) : f.id, topo, req, pref, f.kind ? -1 : f.id, f.kind ? f.id : -1, chunk, nt, el_parent_bits(depth), sets);
+                f.cur = -1; ret = -1;
+            }
+            if (ret == 1) { ret = -1; }                       // a child succeeded: continue with the next child of this frame
+            else {                                            // first visit, or a child failed: (roll back and) move to the next node set
+                if (f.cur >= 0) { rollback(f.cp); }
+                ret = -1;
+                f.cur++;
+                if (f.cur >= f.n_sets) { if (depth == 0) { result = false; break; } depth--; ret = 0; continue; }
+                f.cp = checkpoint(); f.last_rank = -1; f.done = 0;
+                set_frame_bits(depth, sets[f.cur]);
+            }
+            if (f.kind == 1) {  // allocateTasksOnNodeSet :109-119
+                bool ok = true;
+                for (int i = 0; i < nt; i++) {
+                    int p = chunk[i]; if (c.p_podset[p] != f.id) continue;
+                    set_scan_scope(p, frame_bits(depth));
+                    if (!allocate_task(p, pipeline_only)) { ok = false; break; }
+                }
+                el().scope_bits = nullptr; el().scope_row = -1; el().scope_score = nullptr;
+                if (ok) { if (depth == 0) { result = true; break; } depth--; ret = 1; }
+                else ret = 0;  // stay on this frame: next node set
+                continue;
+            }
+            // SubGroupSet: child SubGroupSets by name (SubGroupSetOrderFn, session_plugins.go:273-282), then child pod-sets by PodSetOrderFn
+            int next_kind = -1, next_id = -1;
+            {   int best = -1; uint32_t best_rank = 0;
+                for (int k = c.g_child_off[f.id]; k < c.g_child_off[f.id + 1]; k++) {
+                    int g = c.g_children[k]; uint32_t rk = c.g_name_rank[g];
+                    if ((int64_t)rk <= (int64_t)f.last_rank) continue;
+                    if (best < 0 || rk < best_rank) { best = g; best_rank = rk; }
+                }
+                if (best >= 0) { next_kind = 0; next_id = best; f.last_rank = (int32_t)best_rank; } }
+            if (next_kind < 0) {
+                f.last_rank = 0x7fffffff;
+                int best = -1;
+                // (branch-free selection: hipcc 7.2 dropped the conditional `best = k` of the short-circuit form on gfx950)
+                for (int k = 0; k < nps; k++) {
+                    if ((f.done >> k) & 1) continue;
+                    if (c.s_group[ps0 + k] != f.id) continue;
+                    const int cur = best < 0 ? k : best;
+                    const bool take = podset_order(ps0 + k, ps0 + cur) | (best < 0);
+                    best = take ? k : best;
+                }
+                if (best >= 0) { f.done |= 1ull << best; next_kind = 1; next_id = ps0 + best; }
+            }
+            if (next_kind < 0) { if (depth == 0) { result = true; break; } depth--; ret = 1; continue; }  // every child placed
+            if (depth + 1 >= KAI_TDEPTH) { fault(FAULT_INTERNAL); result = false; break; }
+            depth++;
+            fr[depth].kind = next_kind; fr[depth].id = next_id; fr[depth].n_sets = -1; fr[depth].cur = -1; fr[depth].cp = 0; fr[depth].last_rank = -1; fr[depth].done = 0;
+            ret = -1;
         }
-        return true;
+        el().scope_bits = nullptr; el().scope_row = -1; el().scope_score = nullptr;
+        return result;
+    }
+    // node-set bitmaps of the DFS: slot d holds the set the frame at depth d is currently trying; `restricted[d]` tells whether any frame
+    // up to depth d narrowed the set (otherwise the set is "every node" and scans may use the class index)
+    KAI_HD KAI_GP(const uint32_t) frame_bits(int depth) { return el_restricted(depth) ? (KAI_GP(const uint32_t))(cx().ns_bits + (size_t)depth * cx().W) : (KAI_GP(const uint32_t))nullptr; }
+    KAI_HD KAI_GP(const uint32_t) el_parent_bits(int depth) { return depth == 0 ? (KAI_GP(const uint32_t))nullptr : frame_bits(depth - 1); }
+    KAI_HD bool el_restricted(int depth) const { return (el().restricted >> depth) & 1u; }
+    KAI_HD void set_frame_bits(int depth, int dom) {
+        bool parent_restricted = depth > 0 && el_restricted(depth - 1);
+        if (dom < 0 && !parent_restricted) { el().restricted &= ~(1u << depth); return; }  // still every node
+        build_node_set(cx().ns_bits + (size_t)depth * cx().W, el_parent_bits(depth), dom);
+        el().restricted |= 1u << depth;
     }
     // ------------------------------------------------------------------ staged job path
     // The same AllocateJob → allocateTask → Statement.Allocate → Commit / Rollback sequence as above for the overwhelmingly common
@@ -1008,7 +1332,7 @@ struct Engine {
     KAI_HD static double frame_quota(const double* rq, int k) { return k == KAI_Q_CPU ? rq[KAI_RES_CPU] : k == KAI_Q_MEM ? rq[KAI_RES_MEM] : rq[KAI_RES_GPU]; }
     KAI_HD int allocate_job_fast(int j) {
         if (!cx().use_index || !cx().fast_ok) return -1;
-        if (cx().j_n_ps[j] != 1) return -1;
+        if (cx().j_n_ps[j] != 1 || cx().j_has_topology[j]) return -1;
         const int s = cx().j_first_ps[j];
         if (cx().s_pipelined[s] != 0) return -1;
         ensure_tta(j, true);

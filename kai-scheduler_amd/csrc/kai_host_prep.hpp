@@ -26,6 +26,12 @@ struct HostPrep {
     std::vector<double> node_alloc; std::vector<uint32_t> node_flags;
     // scan classes
     std::vector<ClassRec> classes; std::vector<int32_t> pod_scls; int all_tracked = 1, fast_ok = 1;
+    // topology + sub-group tree (defaults synthesised when the snapshot carries none)
+    int T = 0, TL = 0, D = 0, G = 0;
+    std::vector<int32_t> topo_level_off, node_domain, dom_level, dom_topo, dom_parent, dom_child_off, dom_children;
+    std::vector<uint32_t> dom_id_rank, g_name_rank;
+    std::vector<int32_t> g_job, g_parent, g_topo, g_req, g_pref, j_root_group, g_child_off, g_children, s_group, s_topo, s_req, s_pref;
+    std::vector<uint8_t> j_has_topology;
 
     // returns 0 or KAI_ERR_INVALID_ARG with err set
     int build(const kai_config& cfg, const kai_snapshot_soa* s, std::string& err) {
@@ -106,7 +112,78 @@ struct HostPrep {
             if (k == KAI_Q_MEM) { des = std::max(KAI_UNLIMITED, des * 1000000.0); lim = std::max(KAI_UNLIMITED, lim * 1000000.0); }
             x.deserved = des; x.max_allowed = lim; x.oqw = s->queue_oqw[(size_t)k * Q + q]; x.usage = s->queue_usage ? s->queue_usage[(size_t)k * Q + q] : 0.0;
         }
+        if (int rc = build_topology(s, err)) return rc;
         build_classes(cfg, s);
+        return 0;
+    }
+
+    // Topology domain tree and sub-group tree in the engine's indexing (plugins/topology/topology_plugin.go:57-110,
+    // api/podgroup_info/subgroup_info/subgroupset.go).  Children of a domain are appended in the caller's node-index order, as the
+    // oracle does (the reference ranges a Go map; the order only matters below a level that sortTree has sorted).
+    int build_topology(const kai_snapshot_soa* s, std::string& err) {
+        const int N = s->n_nodes, J = s->n_jobs, S = s->n_podsets;
+        auto fail = [&](const char* m) { err = m; return (int)KAI_ERR_INVALID_ARG; };
+        T = s->n_topologies; TL = s->n_topo_levels; D = s->n_domains;
+        if (T < 0 || TL < 0 || D < 0) return fail("negative topology dimension");
+        topo_level_off.assign(T + 1, 0);
+        for (int t = 0; t <= T && T > 0; t++) topo_level_off[t] = s->topo_level_off[t];
+        if (T > 0 && topo_level_off[T] != TL) return fail("topo_level_off / n_topo_levels mismatch");
+        node_domain.assign((size_t)std::max(TL, 1) * std::max(N, 1), -1);
+        for (int l = 0; l < TL; l++) for (int i = 0; i < N; i++) { int d = s->node_domain[(size_t)l * N + perm[i]]; if (d >= D) return fail("node_domain out of range"); node_domain[(size_t)l * N + i] = d; }
+        dom_level.assign(D + T, -1); dom_topo.assign(D + T, 0); dom_parent.assign(D + T, -1); dom_id_rank.assign(D + T, 0);
+        for (int d = 0; d < D; d++) {
+            int gl = s->domain_level[d], t = -1;
+            for (int x = 0; x < T; x++) if (gl >= topo_level_off[x] && gl < topo_level_off[x + 1]) t = x;
+            if (t < 0) return fail("domain_level out of range");
+            dom_topo[d] = t; dom_level[d] = gl - topo_level_off[t]; dom_parent[d] = s->domain_parent[d] >= 0 ? s->domain_parent[d] : D + t; dom_id_rank[d] = s->domain_id_rank[d];
+        }
+        for (int t = 0; t < T; t++) { dom_topo[D + t] = t; dom_level[D + t] = -1; dom_parent[D + t] = -1; }
+        std::vector<std::vector<int32_t>> kids(D + T);
+        for (int t = 0; t < T; t++) {
+            const int L = topo_level_off[t + 1] - topo_level_off[t];
+            for (int o = 0; o < N; o++) {  // caller's node order
+                if (L == 0 || s->node_domain[(size_t)topo_level_off[t] * N + o] < 0) continue;
+                int child = -1;
+                for (int l = L - 1; l >= 0; l--) {
+                    int d = s->node_domain[(size_t)(topo_level_off[t] + l) * N + o];
+                    if (d < 0) return fail("node_domain: a node of a topology must have a domain at every level");
+                    if (child >= 0 && std::find(kids[d].begin(), kids[d].end(), child) == kids[d].end()) kids[d].push_back(child);
+                    child = d;
+                }
+                if (std::find(kids[D + t].begin(), kids[D + t].end(), child) == kids[D + t].end()) kids[D + t].push_back(child);
+            }
+        }
+        dom_child_off.assign(D + T + 1, 0); dom_children.clear();
+        for (int d = 0; d < D + T; d++) { dom_child_off[d] = (int)dom_children.size(); dom_children.insert(dom_children.end(), kids[d].begin(), kids[d].end()); }
+        dom_child_off[D + T] = (int)dom_children.size();
+        if (dom_children.empty()) dom_children.push_back(0);
+        // sub-group tree
+        if (s->n_groups > 0) {
+            G = s->n_groups;
+            g_job.assign(s->group_job, s->group_job + G); g_parent.assign(s->group_parent, s->group_parent + G); g_name_rank.assign(s->group_name_rank, s->group_name_rank + G);
+            g_topo.assign(s->group_topology, s->group_topology + G); g_req.assign(s->group_required_level, s->group_required_level + G); g_pref.assign(s->group_preferred_level, s->group_preferred_level + G);
+            j_root_group.assign(s->job_root_group, s->job_root_group + J);
+            s_group.assign(s->podset_group, s->podset_group + S); s_topo.assign(s->podset_topology, s->podset_topology + S);
+            s_req.assign(s->podset_required_level, s->podset_required_level + S); s_pref.assign(s->podset_preferred_level, s->podset_preferred_level + S);
+        } else {
+            G = J;
+            g_job.resize(J); g_parent.assign(J, -1); g_name_rank.assign(J, 0); g_topo.assign(J, -1); g_req.assign(J, -1); g_pref.assign(J, -1); j_root_group.resize(J);
+            for (int j = 0; j < J; j++) { g_job[j] = j; j_root_group[j] = j; }
+            s_group.resize(S); s_topo.assign(S, -1); s_req.assign(S, -1); s_pref.assign(S, -1);
+            for (int k = 0; k < S; k++) s_group[k] = s->podset_job[k];
+        }
+        for (int g = 0; g < G; g++) { if (g_parent[g] >= G || g_job[g] < 0 || g_job[g] >= J) return fail("bad group table"); if (g_topo[g] >= T) return fail("group_topology out of range"); }
+        for (int k = 0; k < S; k++) { if (s_group[k] < 0 || s_group[k] >= G) return fail("bad podset_group"); if (s_topo[k] >= T) return fail("podset_topology out of range"); }
+        std::vector<std::vector<int32_t>> gk(G);
+        for (int g = 0; g < G; g++) if (g_parent[g] >= 0) gk[g_parent[g]].push_back(g);
+        g_child_off.assign(G + 1, 0); g_children.clear();
+        for (int g = 0; g < G; g++) { g_child_off[g] = (int)g_children.size(); g_children.insert(g_children.end(), gk[g].begin(), gk[g].end()); }
+        g_child_off[G] = (int)g_children.size();
+        if (g_children.empty()) g_children.push_back(0);
+        j_has_topology.assign(std::max(J, 1), 0);
+        for (int g = 0; g < G; g++) if (g_topo[g] != -1) j_has_topology[g_job[g]] = 1;
+        for (int k = 0; k < S; k++) if (s_topo[k] != -1) j_has_topology[s->podset_job[k]] = 1;
+        for (int g = 0; g < G; g++) if (g_parent[g] >= 0) j_has_topology[g_job[g]] = 1;  // nested sub-group sets also take the general path
         return 0;
     }
 

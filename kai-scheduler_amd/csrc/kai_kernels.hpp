@@ -255,7 +255,8 @@ struct ActShared {
     unsigned long long __attribute__((address_space(3)))* s2_key; int32_t __attribute__((address_space(3)))* s2_node;  // [C][NSB] in dynamic LDS (typed LDS pointers: ds_read / ds_write)
     QNode* qn; int32_t *qheap, *root_heap;          // job-order tree: dynamic LDS when it fits, else the HBM arrays
     int32_t tree_in_lds, pad1;
-    const uint32_t* nodeset;  // optional node-set bitmap for brute-force scans (bit n of word n/32; engine node order), nullptr = all nodes
+    KAI_GP(const uint32_t) nodeset;  // scope of brute-force scans: node-set bitmap (bit n of word n/32; engine node order), nullptr = all nodes,
+    KAI_GP(const double) topo_score; int32_t topo_row, pad2;  // … and preferred-level topology scores per domain of level row topo_row (-1 = none)
     long long t_publish, t_wait, t_svc, t_seg[6];  // profiling: control lane through barrier 1 / barrier 2, service wave 1 busy time
 };
 
@@ -285,14 +286,15 @@ struct DevBackend {
         __syncthreads();  // results ready
         if (cmd == CMD_REFRESH) { sh->t_publish += t1 - t0; sh->t_wait += clock64() - t1; }
     }
+    __device__ void scope() { sh->nodeset = g_el.scope_bits; sh->topo_row = g_el.scope_row; sh->topo_score = g_el.scope_score; }
     __device__ void minmax(const KaiCtx&, int r, double& mn, double& mx) {
-        sh->r = r; call(CMD_MINMAX);
+        scope(); sh->r = r; call(CMD_MINMAX);
         double lo = 1.7976931348623157e308, hi = 0;  // math.MaxFloat64, 0 (plugins/nodeplacement/pack.go:66-68)
         for (int w = 1; w < WAVES; w++) { if (sh->part_min[w] < lo) lo = sh->part_min[w]; if (sh->part_max[w] > hi) hi = sh->part_max[w]; }
         mn = lo; mx = hi;
     }
     __device__ int best_node(const KaiCtx&, const ScanReq& q) {
-        sh->req = q; call(CMD_BEST);
+        scope(); sh->req = q; call(CMD_BEST);
         int best = -1; unsigned long long bk = 0;
         for (int w = 1; w < WAVES; w++) {
             int n = sh->part_node[w]; if (n < 0) continue;
@@ -397,7 +399,7 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
         } else if (cmd == CMD_MINMAX) {  // getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86)
             int r = sh->r;
             double lo = 1.7976931348623157e308, hi = 0;
-            const uint32_t* ns_bits = sh->nodeset;
+            KAI_GP(const uint32_t) ns_bits = sh->nodeset;
             for (int n = slot; n < c.N; n += SCAN_LANES) {
                 if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;  // the pre-order scan ranges the node set (pack.go:66-86)
                 if (c.n_alloc[(size_t)r * c.N + n] == 0) continue;
@@ -410,13 +412,19 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
         } else if (cmd == CMD_BEST) {  // OrderedNodesByTask + FittingNode collapsed to an arg-max (framework/session.go:201-264, 466-485)
             const ScanReq& q = sh->req;
             int best = -1; unsigned long long bk = 0;
-            const uint32_t* ns_bits = sh->nodeset;
+            KAI_GP(const uint32_t) ns_bits = sh->nodeset; const int trow = sh->topo_row; KAI_GP(const double) tscore = sh->topo_score;
             for (int n = slot; n < c.N; n += SCAN_LANES) {
                 if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;
                 if (!fits(c, q.req, n, true)) continue;                              // IsTaskAllocatableOnReleasingOrIdle
                 if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;  // ssn.PredicateFn
                 bool fit_idle = q.best_effort || fits(c, q.req, n, false);
-                unsigned long long k = orderable(node_score(c, q, n, fit_idle));
+                double sc = node_score(c, q, n, fit_idle);
+                if (trow >= 0) {  // topology.nodeOrderFn (plugins/topology/node_scoring.go:17-35): a node without a score is dropped (session.go:247-251)
+                    int dd = c.node_domain[(size_t)trow * c.N + n]; double ts = dd >= 0 ? tscore[dd] : -1.0;
+                    if (ts < 0) continue;
+                    sc += ts;
+                }
+                unsigned long long k = orderable(sc);
                 if (best < 0 || k > bk) { best = n; bk = k; }                        // n ascends: the first of equal scores is the lowest name rank
             }
             for (int o = 32; o > 0; o >>= 1) {
@@ -440,7 +448,7 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     const KaiCtx& c = g_ctx;
     ActShared& sh = g_sh;
     if (threadIdx.x == 0) {
-        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds; sh.nodeset = nullptr; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
+        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
         size_t off = 0;
         sh.s2_key = (unsigned long long __attribute__((address_space(3)))*)(kai_dyn_lds); sh.s2_node = (int32_t __attribute__((address_space(3)))*)(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
         off = lds_index_bytes(c.C, c.NSB);
@@ -484,12 +492,13 @@ __global__ void __launch_bounds__(WG) k_best_node(KaiCtx cv, int pod, int pipeli
     __syncthreads();
     const KaiCtx& c = g_ctx;
     ActShared& sh = g_sh;
-    if (threadIdx.x == 0) { sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = 0; sh.nodeset = nodeset; sh.s2_key = nullptr; sh.s2_node = nullptr; sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
+    if (threadIdx.x == 0) { sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = 0; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.s2_key = nullptr; sh.s2_node = nullptr; sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
     __syncthreads();
     if (threadIdx.x >= 64) { service_loop(c, &g_sh); return; }
     if (threadIdx.x != 0) return;
     DevBackend be;
     Engine<DevBackend> eng(c, be);
+    g_el.scope_bits = (KAI_GP(const uint32_t))nodeset;  // the caller's node set (SubsetNodesFn result)
     int n = -1, pipe = 0;
     if (!((c.plugins & KAI_PLUGIN_PREDICATES) && eng.task_over_capacity(pod))) {
         bool allocatable = false;

@@ -149,7 +149,7 @@ def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill
         else:
             h = n // 2
             podset_min[s0], podset_min[s0 + 1] = h, n - h
-            podset_rank[s0], podset_rank[s0 + 1] = 0, 1
+            podset_rank[s0], podset_rank[s0 + 1] = (1, 0) if rng.random() < 0.5 else (0, 1)  # name order independent of index order
             pod_podset[b:b + h] = s0; pod_podset[b + h:b + n] = s0 + 1
     a["pod_req"] = pod_req; a["pod_job"] = pod_job; a["pod_podset"] = pod_podset
     a["pod_status"] = pod_status; a["pod_node"] = pod_node

@@ -25,6 +25,7 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     void minmax(const KaiCtx& c, int r, double& mn, double& mx) {
         double lo = 1.7976931348623157e308, hi = 0;
         for (int n = 0; n < c.N; n++) {
+            if (loc.scope_bits && !((loc.scope_bits[n >> 5] >> (n & 31)) & 1)) continue;
             if (c.n_alloc[(size_t)r * c.N + n] == 0) continue;
             double cur = c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n];
             if (cur < lo) lo = cur;
@@ -35,10 +36,12 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     int best_node(const KaiCtx& c, const ScanReq& q) {
         int best = -1; double bs = 0;
         for (int n = 0; n < c.N; n++) {
+            if (loc.scope_bits && !((loc.scope_bits[n >> 5] >> (n & 31)) & 1)) continue;
             if (!fits(c, q.req, n, true)) continue;
             if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;
             bool fit_idle = q.best_effort || fits(c, q.req, n, false);
             double sc = node_score(c, q, n, fit_idle);
+            if (loc.scope_row >= 0) { int dd = c.node_domain[(size_t)loc.scope_row * c.N + n]; double ts = dd >= 0 ? loc.scope_score[dd] : -1.0; if (ts < 0) continue; sc += ts; }
             if (best < 0 || sc > bs) { best = n; bs = sc; }
         }
         return best;
@@ -120,6 +123,20 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64; c.use_index = c.C > 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok;
     { int d = cfg->queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
     c.cls = copy(pool, prep.classes.data(), prep.classes.size());
+    c.T = prep.T; c.TL = prep.TL; c.D = prep.D; c.G = prep.G; c.W = (N + 31) / 32;
+    { const size_t DT = (size_t)prep.D + prep.T;
+      c.topo_level_off = copy(pool, prep.topo_level_off.data(), prep.topo_level_off.size()); c.node_domain = copy(pool, prep.node_domain.data(), prep.node_domain.size());
+      c.dom_level = copy(pool, prep.dom_level.data(), prep.dom_level.size()); c.dom_topo = copy(pool, prep.dom_topo.data(), prep.dom_topo.size());
+      c.dom_parent = copy(pool, prep.dom_parent.data(), prep.dom_parent.size()); c.dom_id_rank = copy(pool, prep.dom_id_rank.data(), prep.dom_id_rank.size());
+      c.dom_child_off = copy(pool, prep.dom_child_off.data(), prep.dom_child_off.size()); c.dom_children = const_cast<int32_t*>(copy(pool, prep.dom_children.data(), prep.dom_children.size()));
+      c.dom_alloc_pods = own<int32_t>(pool, DT); c.dom_free = own<double>(pool, DT * KAI_MAX_RES); c.dom_tmp = own<int32_t>(pool, 3 * DT + 4); c.dom_ratio = own<double>(pool, DT);
+      c.ns_bits = own<uint32_t>(pool, (size_t)KAI_TDEPTH * std::max(c.W, 1)); c.ns_sets = own<int32_t>(pool, (size_t)KAI_TDEPTH * (DT + 1));
+      c.sg_score = own<double>(pool, (size_t)KAI_TKEYS * std::max<size_t>(DT, 1)); c.sg_key = own<int32_t>(pool, KAI_TKEYS); c.sg_row = own<int32_t>(pool, KAI_TKEYS); }
+    c.g_job = copy(pool, prep.g_job.data(), prep.g_job.size()); c.g_parent = copy(pool, prep.g_parent.data(), prep.g_parent.size()); c.g_name_rank = copy(pool, prep.g_name_rank.data(), prep.g_name_rank.size());
+    c.g_topo = copy(pool, prep.g_topo.data(), prep.g_topo.size()); c.g_req = copy(pool, prep.g_req.data(), prep.g_req.size()); c.g_pref = copy(pool, prep.g_pref.data(), prep.g_pref.size());
+    c.j_root_group = copy(pool, prep.j_root_group.data(), prep.j_root_group.size()); c.g_child_off = copy(pool, prep.g_child_off.data(), prep.g_child_off.size()); c.g_children = copy(pool, prep.g_children.data(), prep.g_children.size());
+    c.s_group = copy(pool, prep.s_group.data(), prep.s_group.size()); c.s_topo = copy(pool, prep.s_topo.data(), prep.s_topo.size()); c.s_req = copy(pool, prep.s_req.data(), prep.s_req.size());
+    c.s_pref = copy(pool, prep.s_pref.data(), prep.s_pref.size()); c.j_has_topology = copy(pool, prep.j_has_topology.data(), prep.j_has_topology.size());
     c.sum1_key = own<uint64_t>(pool, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)); c.sum1_node = own<int32_t>(pool, (size_t)std::max(c.C, 1) * std::max(c.NB, 1));
     c.n_idle = const_cast<double*>(copy(pool, prep.node_alloc.data(), (size_t)R * N)); c.n_rel = own<double>(pool, (size_t)R * N); c.n_used = own<double>(pool, (size_t)R * N);
     c.p_status = const_cast<int32_t*>(copy(pool, s->pod_status, P)); c.p_node = const_cast<int32_t*>(copy(pool, prep.pod_node.data(), P));

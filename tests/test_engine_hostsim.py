@@ -43,7 +43,7 @@ def assert_same(res, ref):
         assert np.array_equal(res.nodes[k], ref.nodes[k]), k
 
 
-GOLD = [(n, i, c, T.load_golden(n)["actions"]) for n in ("allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups")
+GOLD = [(n, i, c, T.load_golden(n)["actions"]) for n in ("allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology")
         for i, c in enumerate(T.load_golden(n)["cases"])]
 
 
