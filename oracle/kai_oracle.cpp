@@ -804,9 +804,9 @@ bool Session::allocateTask(Statement& stmt, const std::vector<NodeInfo*>& nodeSe
 // =====================================================================================================
 // plugins/topology
 // =====================================================================================================
-void Session::allPodSets(SubGroupSet* sgs, std::vector<PodSet*>& out) {  // SubGroupSet.GetAllPodSets (subgroupset.go:57-69)
-    for (int k : sgs->podSets) out.push_back(&podsets[k]);
-    for (int g : sgs->groups) allPodSets(&groups[g], out);
+void Session::allPodSets(PodGroupInfo* job, SubGroupSet* sgs, std::vector<PodSet*>& out) {  // SubGroupSet.GetAllPodSets (subgroupset.go:57-69); a representative job has its own pod-sets
+    for (int k : sgs->podSets) out.push_back(job->podSetByIdx(k));
+    for (int g : sgs->groups) allPodSets(job, &groups[g], out);
 }
 double Session::topologyNodeScore(PodInfo* task, NodeInfo* node, bool& err) {  // node_scoring.go:17-35, 88-99
     int key = -(task->podset + 1);
@@ -994,11 +994,11 @@ bool Session::allocateSubGroupSetOnNodes(Statement& stmt, const std::vector<Node
     std::vector<SubGroupSet*> childGroups; for (int g : sgs->groups) childGroups.push_back(&groups[g]);
     std::stable_sort(childGroups.begin(), childGroups.end(), [](SubGroupSet* a, SubGroupSet* b) { return a->nameRank < b->nameRank; });  // SubGroupSetOrderFn: by name
     for (auto* child : childGroups) {
-        std::vector<PodSet*> under; allPodSets(child, under);
+        std::vector<PodSet*> under; allPodSets(job, child, under);
         std::vector<PodInfo*> sub; for (auto* t : tasks) for (auto* ps : under) if (t->podset == ps->idx) { sub.push_back(t); break; }  // filterTasksForPodSets :246-258
         if (!allocateSubGroupSet(stmt, nodeSet, job, child, sub, isPipelineOnly)) return false;
     }
-    std::vector<PodSet*> ordered; for (int k : sgs->podSets) ordered.push_back(&podsets[k]);
+    std::vector<PodSet*> ordered; for (int k : sgs->podSets) ordered.push_back(job->podSetByIdx(k));
     std::stable_sort(ordered.begin(), ordered.end(), [this](PodSet* a, PodSet* b) { return PodSetOrderFn(a, b); });  // orderedPodSets :270-277
     for (auto* ps : ordered) {
         std::vector<PodInfo*> podSetTasks; for (auto* t : tasks) if (t->podset == ps->idx) podSetTasks.push_back(t);
@@ -1007,7 +1007,7 @@ bool Session::allocateSubGroupSetOnNodes(Statement& stmt, const std::vector<Node
     return true;
 }
 bool Session::allocateSubGroupSet(Statement& stmt, const std::vector<NodeInfo*>& nodeSet, PodGroupInfo* job, SubGroupSet* sgs, const std::vector<PodInfo*>& tasks, bool isPipelineOnly) {  // :38-60
-    std::vector<PodSet*> under; allPodSets(sgs, under);
+    std::vector<PodSet*> under; allPodSets(job, sgs, under);
     std::vector<std::vector<NodeInfo*>> nodeSets;
     if (!SubsetNodesFn(job, sgs->idx, sgs->tc, under, tasks, nodeSet, nodeSets)) return false;
     for (auto& set : nodeSets) {
@@ -1053,6 +1053,9 @@ void Session::executeAllocate() {
 
 }  // namespace orc
 
+#include "oracle_solver.hpp"
+namespace orc { Session::~Session() = default; }
+
 // =====================================================================================================
 // C entry points (ctypes)
 // =====================================================================================================
@@ -1093,6 +1096,7 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
     for (int i = 0; i < n_actions; i++) {
         switch (actions[i]) {
             case KAI_ACTION_ALLOCATE: ssn.executeAllocate(); break;
+            case KAI_ACTION_CONSOLIDATION: case KAI_ACTION_RECLAIM: case KAI_ACTION_PREEMPT: ssn.executeVictimAction(actions[i]); break;
             default: return KAI_ERR_UNSUPPORTED;
         }
     }

@@ -10,7 +10,7 @@
 
 namespace orc {
 
-struct Session;
+struct Session; struct Scenario; struct JobClone; struct JobsOrderByQueues;
 
 // ---------------------------------------------------------------- framework/statement.go + operations.go
 enum OpName { opEvict, opPipeline, opAllocate, opUndo };
@@ -56,7 +56,7 @@ struct Statement {
     }
 };
 
-struct SessionStats { int64_t decisions = 0, nodeScans = 0, nodesScanned = 0, jobsAttempted = 0, jobsCommitted = 0, rollbacks = 0; };
+struct SessionStats { int64_t decisions = 0, nodeScans = 0, nodesScanned = 0, jobsAttempted = 0, jobsCommitted = 0, rollbacks = 0, scenarios = 0, simulations = 0, scenariosFiltered = 0; };
 
 // ---------------------------------------------------------------- framework/session.go:51-90 + the default tier
 struct Session {
@@ -114,7 +114,7 @@ struct Session {
     bool allocateSubGroupSetOnNodes(Statement& stmt, const std::vector<NodeInfo*>& nodes, PodGroupInfo* job, SubGroupSet* sgs, const std::vector<PodInfo*>& tasks, bool isPipelineOnly);
     bool allocatePodSet(Statement& stmt, const std::vector<NodeInfo*>& nodes, PodGroupInfo* job, PodSet* ps, const std::vector<PodInfo*>& tasks, bool isPipelineOnly);
     // ---- plugins/topology
-    void allPodSets(SubGroupSet* sgs, std::vector<PodSet*>& out);
+    void allPodSets(PodGroupInfo* job, SubGroupSet* sgs, std::vector<PodSet*>& out);
     bool SubsetNodesFn(PodGroupInfo* job, int key, const TopologyConstraint& tc, const std::vector<PodSet*>& podSets, const std::vector<PodInfo*>& tasks,
                        const std::vector<NodeInfo*>& nodeSet, std::vector<std::vector<NodeInfo*>>& out);
     double topologyNodeScore(PodInfo* task, NodeInfo* node, bool& err);
@@ -123,6 +123,17 @@ struct Session {
 
     // ---- actions
     void executeAllocate();  // actions/allocate/allocate.go:46-77
+    // ---- victim search (oracle_solver.hpp): actions/{reclaim,preempt,consolidation} + actions/common/solvers
+    std::vector<std::unique_ptr<JobClone>> clonePool;  // CloneWithTasks representatives of the job being solved
+    std::vector<QueueAttributes> jobSimulationQueues;  // proportion.OnJobSolutionStartFn (proportion.go:131-136)
+    PodGroupInfo* CloneWithTasks(PodGroupInfo* src, const std::vector<PodInfo*>& tasks);
+    std::vector<PodInfo*> GetTasksToEvict(PodGroupInfo* job, bool& hasMoreTasks);
+    std::vector<int> FeasibleNodesForJob(PodGroupInfo* job);
+    bool CanReclaimResources(PodGroupInfo* reclaimer);
+    bool reclaimableFn(Scenario* sc);
+    std::unique_ptr<JobsOrderByQueues> GetVictimsQueue(const std::function<bool(PodGroupInfo*)>& filter);
+    void executeVictimAction(int action);
+    ~Session();
 };
 
 // ---------------------------------------------------------------- actions/utils/job_order_by_queue.go

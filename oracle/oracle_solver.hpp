@@ -1,0 +1,584 @@
+// oracle_solver.hpp — TEST INFRASTRUCTURE (see oracle_model.hpp header).
+// Restates the victim search of the reference: actions/{reclaim,preempt,consolidation} on top of
+// actions/common/solvers (JobSolver → PodAccumulatedScenarioBuilder → byPodSolver), the AccumulatedIdleGpus scenario
+// filter, proportion's reclaimable validator and MinimalJobRepresentatives.  Included at the end of kai_oracle.cpp.
+//
+// Where the reference ranges over a Go map (random order) this restatement fixes ONE order — any order is a valid
+// execution of the reference; the device engine follows the same choices (DESIGN.md "canonical orders"):
+//   * jobs: ascending snapshot index;  nodes: ascending snapshot index, "" (no node) first;  queues: ascending index
+//   * pods of a job: pod-sets by name rank, pods by snapshot index inside a pod-set (PodGroupInfo::AllPods)
+// Not restated (pure pruning of scenarios that cannot succeed, no effect on results): the AccumulatedNodeAffinities and
+// TopologyAwareIdleGpus scenario filters (accumulated_scenario_filters/{node_affinities,idle_gpus/topology_aware_idle_gpus}.go);
+// the minruntime plugin's victim filters (default min-runtime 0s protects nothing, plugins/minruntime/minruntime.go:40-53).
+#pragma once
+#include <set>
+
+namespace orc {
+
+// ---------------------------------------------------------------- api/podgroup_info/job_info.go:477-510 CloneWithTasks
+struct JobClone { PodGroupInfo job; std::vector<std::unique_ptr<PodSet>> sets; };
+inline PodGroupInfo* Session::CloneWithTasks(PodGroupInfo* src, const std::vector<PodInfo*>& tasks) {
+    auto c = std::make_unique<JobClone>();
+    PodGroupInfo& j = c->job;
+    j.idx = src->idx; j.uidRank = src->uidRank; j.queue = src->queue; j.priority = src->priority; j.preemptible = src->preemptible; j.createdNs = src->createdNs;
+    j.rootGroup = src->rootGroup; j.isClone = true;
+    for (auto* ps : src->podSets) {  // RootSubGroupSet.Clone(): pod-sets without pods, same minAvailable / constraints
+        auto n = std::make_unique<PodSet>();
+        n->idx = ps->idx; n->nameRank = ps->nameRank; n->job = ps->job; n->group = ps->group; n->tc = ps->tc; n->minAvailable = ps->minAvailable;
+        j.podSets.push_back(n.get()); c->sets.push_back(std::move(n));
+    }
+    // the reference adds task.Clone(); statement operations mutate the object they are handed and re-index the ORIGINAL job with
+    // it (statement.go:63-126 → job.UpdateTaskStatus), so "the task with this UID" is one object here
+    for (auto* t : tasks) j.AddTaskInfo(t);
+    PodGroupInfo* out = &c->job; clonePool.push_back(std::move(c));
+    return out;
+}
+
+// ---------------------------------------------------------------- api/podgroup_info/eviction_info.go:14-97
+inline std::vector<PodInfo*> Session::GetTasksToEvict(PodGroupInfo* job, bool& hasMoreTasks) {
+    PriorityQueue<PodSet*> sgq; sgq.lessFn = [this](PodSet* const& l, PodSet* const& r) { return PodSetOrderFn(r, l); };
+    for (auto* ps : job->podSets) sgq.Push(ps);
+    int maxNumOfSubGroups = int(job->podSets.size());  // getNumOfSubGroupsToEvict :49-59
+    for (auto* ps : job->podSets) if (ps->numActiveAllocatedTasks > int(ps->minAvailable)) { maxNumOfSubGroups = 1; break; }
+    std::vector<PodInfo*> tasksToEvict; int numEvictedSubGroups = 0;
+    while (!sgq.Empty() && numEvictedSubGroups < maxNumOfSubGroups) {
+        PodSet* next = sgq.Pop();
+        PriorityQueue<PodInfo*> tq; tq.lessFn = [this](PodInfo* const& l, PodInfo* const& r) { return TaskOrderFn(r, l); };
+        for (auto& kv : next->podInfos) if (IsActiveAllocatedStatus(kv.second->status)) tq.Push(kv.second);
+        int maxTasksToEvict = next->numActiveAllocatedTasks > int(next->minAvailable) ? 1 : next->numActiveAllocatedTasks;  // :61-67
+        int n = 0; while (!tq.Empty() && n < maxTasksToEvict) { tasksToEvict.push_back(tq.Pop()); n++; }
+        numEvictedSubGroups += 1;
+    }
+    int numAllocatedTasks = 0; for (auto* t : job->AllPods()) if (IsActiveAllocatedStatus(t->status)) numAllocatedTasks++;  // GetActiveAllocatedTasksCount
+    hasMoreTasks = int(tasksToEvict.size()) < numAllocatedTasks;
+    return tasksToEvict;
+}
+
+// ---------------------------------------------------------------- solvers/scenario/{base_scenario,by_node_scenario}.go
+struct VictimInfo { PodGroupInfo* Job = nullptr; std::vector<PodInfo*> Tasks; };
+struct Scenario {
+    Session* ssn; PodGroupInfo* preemptor;
+    std::map<int, VictimInfo> victims;                                 // by job index
+    std::vector<PodInfo*> pendingTasks, potentialVictimsTasks, recordedVictimsTasks;
+    std::vector<PodGroupInfo*> recordedVictimsJobs;
+    std::map<int, std::vector<PodGroupInfo*>> victimsJobsTaskGroups;   // job index → representatives (clones)
+    std::map<int, std::vector<int>> potentialVictimsJobsByNode;        // node index (-1 = no node) → job indices, first-seen order
+
+    Scenario(Session* s, PodGroupInfo* pendingJob, const std::vector<PodGroupInfo*>& recorded) : ssn(s), preemptor(pendingJob) {  // base_scenario.go:35-71
+        pendingTasks = pendingJob->AllPods();
+        for (auto* rj : recorded) { recordedVictimsJobs.push_back(rj); appendTasksAsVictimJob(rj->AllPods()); }
+        for (auto* rj : recordedVictimsJobs) for (auto* t : rj->AllPods()) recordedVictimsTasks.push_back(t);
+    }
+    PodGroupInfo* LatestPotentialVictim() const { return potentialVictimsTasks.empty() ? nullptr : &ssn->jobs[potentialVictimsTasks.back()->job]; }  // :97-103
+    void appendTasksAsVictimJob(const std::vector<PodInfo*>& tasks) {  // :118-137
+        PodGroupInfo* originalJob = &ssn->jobs[tasks[0]->job];
+        PodGroupInfo* job = ssn->CloneWithTasks(originalJob, tasks);
+        victimsJobsTaskGroups[job->idx].push_back(job);
+        VictimInfo& v = victims[job->idx]; v.Job = originalJob;
+        v.Tasks.insert(v.Tasks.end(), tasks.begin(), tasks.end());
+    }
+    void AddPotentialVictimsTasks(const std::vector<PodInfo*>& tasks) {  // base :109-116 + by_node :47-53
+        if (tasks.empty()) return;
+        potentialVictimsTasks.insert(potentialVictimsTasks.end(), tasks.begin(), tasks.end());
+        appendTasksAsVictimJob(tasks);
+        for (auto* t : tasks) { auto& l = potentialVictimsJobsByNode[t->node]; if (std::find(l.begin(), l.end(), t->job) == l.end()) l.push_back(t->job); }
+    }
+    std::vector<PodInfo*> VictimsTasksFromNodes(int node) {  // by_node_scenario.go:55-80
+        std::vector<PodInfo*> tasks;
+        auto it = potentialVictimsJobsByNode.find(node); if (it == potentialVictimsJobsByNode.end()) return tasks;
+        for (int jobID : it->second) for (auto* group : victimsJobsTaskGroups[jobID]) for (auto* t : group->AllPods()) tasks.push_back(t);
+        return tasks;
+    }
+    PodGroupInfo* GetVictimJobRepresentativeById(PodInfo* victim) {  // base_scenario.go:139-149
+        for (auto* rep : victimsJobsTaskGroups[victim->job]) for (auto* t : rep->AllPods()) if (t->idx == victim->idx) return rep;
+        return nullptr;
+    }
+};
+
+// ---------------------------------------------------------------- accumulated_scenario_filters/idle_gpus/{idle_gpus,common}.go
+struct AccumulatedIdleGpus {
+    std::vector<double> requiredGpusSorted;
+    std::map<int, double> nodesNameToIdleGpus;
+    std::vector<int> maxFreeGpuNodesSorted;
+    std::set<int> pendingTasksInState, recordedVictimsInCache, potentialVictimsInCache;
+    bool valid = true;
+
+    static int cmpDesc(const std::map<int, double>& m, int elem, int target) {  // cmp.Compare(idle[target], idle[elem])
+        double a = m.at(target), b = m.at(elem); return a < b ? -1 : a > b ? 1 : 0;
+    }
+    void orderedInsert(int t, bool replace) {  // idle_gpus.go:198-247 (slices.BinarySearchFunc + in-place shifts)
+        auto& ts = maxFreeGpuNodesSorted;
+        int lo = 0, hi = int(ts.size());
+        while (lo < hi) { int h = (lo + hi) / 2; if (cmpDesc(nodesNameToIdleGpus, ts[h], t) < 0) lo = h + 1; else hi = h; }
+        int i = lo;
+        for (int j = 0; j < int(ts.size()); j++) if (ts[j] == t) {  // updateLocationIfTAlreadyExists
+            if (j == i) return;
+            if (i < j) { int elem = ts[j]; for (int k = j; k > i; k--) ts[k] = ts[k - 1]; ts[i] = elem; }  // shiftElementLeft
+            return;
+        }
+        if (replace) {  // insertWithoutIncreasingListSize
+            if (i == int(ts.size()) - 1) { ts[i] = t; return; }
+            for (int j = int(ts.size()) - 1; j > i; j--) ts[j] = ts[j - 1];
+            if (i < int(ts.size())) ts[i] = t;
+        } else ts.insert(ts.begin() + i, t);
+    }
+    AccumulatedIdleGpus(Session* ssn, Scenario* sc) {  // NewIdleGpusFilter :53-71 + createGpuMap :176-196
+        int relevantNodesLen = int(sc->pendingTasks.size()); double minRelevantValue = -1;
+        for (auto& ni : ssn->nodes) {
+            nodesNameToIdleGpus[ni.idx] = ni.Idle.gpus + ni.Releasing.gpus;
+            if (nodesNameToIdleGpus[ni.idx] > minRelevantValue || int(maxFreeGpuNodesSorted.size()) < relevantNodesLen) {
+                bool replace = relevantNodesLen <= int(maxFreeGpuNodesSorted.size());
+                orderedInsert(ni.idx, replace);
+                if (!maxFreeGpuNodesSorted.empty()) minRelevantValue = nodesNameToIdleGpus[maxFreeGpuNodesSorted.back()];
+            }
+        }
+        valid = updateStateWithScenario(sc, true);
+    }
+    bool Filter(Scenario* sc, bool& err) {  // :77-88
+        err = !updateStateWithScenario(sc, false);
+        if (err) return false;
+        std::map<int, double> virtuallyAllocated;  // greedyMatchRequirements common.go:34-64
+        for (double required : requiredGpusSorted) {
+            if (required == 0) return true;
+            bool matched = false;
+            for (int holder : maxFreeGpuNodesSorted) {
+                double total = nodesNameToIdleGpus[holder];
+                if (total < required) break;
+                double available = total - virtuallyAllocated[holder];
+                if (available >= required) { virtuallyAllocated[holder] += required; matched = true; break; }
+            }
+            if (!matched) return false;
+        }
+        return true;
+    }
+    int updateVictimList(const std::vector<PodInfo*>& victimTasks, std::set<int>& cache) {  // :111-122 + iterateNewVictims common.go:66-88
+        int minIdleGpusRelevant = maxFreeGpuNodesSorted.empty() ? -2 : maxFreeGpuNodesSorted.back(); int hits = 0;
+        for (auto* task : victimTasks) {
+            if (task->node < 0) continue;
+            if (cache.count(task->idx)) { hits++; continue; }
+            cache.insert(task->idx);
+            // updateWithVictim :160-174
+            if (nodesNameToIdleGpus.empty()) { minIdleGpusRelevant = -2; continue; }
+            double prevMinRelevantValue = minIdleGpusRelevant == -2 ? 0.0 : nodesNameToIdleGpus[minIdleGpusRelevant];
+            nodesNameToIdleGpus[task->node] += task->accepted.GPUs();
+            if (nodesNameToIdleGpus[task->node] > prevMinRelevantValue) {
+                orderedInsert(task->node, true);
+                minIdleGpusRelevant = maxFreeGpuNodesSorted.empty() ? -2 : maxFreeGpuNodesSorted.back();
+            }
+        }
+        return hits;
+    }
+    bool updateStateWithScenario(Scenario* sc, bool isFirstScenario) {  // :90-109, 124-158
+        if (!isFirstScenario) for (auto* pod : sc->pendingTasks) if (!pendingTasksInState.count(pod->idx)) return false;
+        std::vector<double> required;
+        for (auto* pod : sc->pendingTasks) { required.push_back(pod->resReq.GPUs()); pendingTasksInState.insert(pod->idx); }
+        std::sort(required.begin(), required.end(), [](double a, double b) { return a > b; });
+        requiredGpusSorted = required;
+        size_t pre = recordedVictimsInCache.size();
+        size_t hits = size_t(updateVictimList(sc->recordedVictimsTasks, recordedVictimsInCache));
+        if (!(isFirstScenario || (pre == hits && hits == recordedVictimsInCache.size()))) return false;
+        size_t preP = potentialVictimsInCache.size();
+        size_t hitsP = size_t(updateVictimList(sc->potentialVictimsTasks, potentialVictimsInCache));
+        if (preP != hitsP) return false;
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------- solvers/pod_scenario_builder.go
+struct ScenarioBuilder {
+    Session* ssn; std::unique_ptr<Scenario> lastScenario; std::unique_ptr<AccumulatedIdleGpus> idleGpus;
+    JobsOrderByQueues* victimsJobsQueue; std::set<int> recordedVictimsTasks;
+    ScenarioBuilder(Session* s, PodGroupInfo* pendingJob, const std::vector<PodGroupInfo*>& recordedVictimsJobs, JobsOrderByQueues* vq) : ssn(s), victimsJobsQueue(vq) {  // :32-76
+        if (!ssn->GetTasksToAllocate(pendingJob, false).empty()) {
+            lastScenario = std::make_unique<Scenario>(ssn, pendingJob, recordedVictimsJobs);
+            for (auto* job : recordedVictimsJobs) for (auto* t : job->AllPods()) recordedVictimsTasks.insert(t->idx);
+            idleGpus = std::make_unique<AccumulatedIdleGpus>(ssn, lastScenario.get());
+            if (!idleGpus->valid) idleGpus.reset();
+        }
+    }
+    bool addNextPotentialVictims() {  // :91-133
+        PodGroupInfo* nextVictimJob = victimsJobsQueue->PopNextJob();
+        bool jobHasMoreTasks = false;
+        std::vector<PodInfo*> potentialVictimTasks = ssn->GetTasksToEvict(nextVictimJob, jobHasMoreTasks);
+        for (auto* pv : potentialVictimTasks) if (recordedVictimsTasks.count(pv->idx)) {
+            std::vector<PodInfo*> remaining; for (auto* t : nextVictimJob->AllPods()) if (!recordedVictimsTasks.count(t->idx)) remaining.push_back(t);
+            if (!remaining.empty()) victimsJobsQueue->PushJob(ssn->CloneWithTasks(nextVictimJob, remaining));
+            return false;
+        }
+        if (jobHasMoreTasks) {
+            std::vector<PodInfo*> remaining;
+            for (auto* t : nextVictimJob->AllPods()) if (std::find(potentialVictimTasks.begin(), potentialVictimTasks.end(), t) == potentialVictimTasks.end()) remaining.push_back(t);
+            victimsJobsQueue->PushJob(ssn->CloneWithTasks(nextVictimJob, remaining));
+        }
+        if (lastScenario) lastScenario->AddPotentialVictimsTasks(potentialVictimTasks);
+        return true;
+    }
+    Scenario* GetNextScenario() {  // :78-89
+        for (;;) {
+            if (victimsJobsQueue->IsEmpty()) return nullptr;
+            if (!addNextPotentialVictims()) continue;
+            return GetValidScenario();
+        }
+    }
+    Scenario* GetValidScenario() {  // :135-161
+        bool valid = true;
+        if (idleGpus && lastScenario) { bool err = false; bool ok = idleGpus->Filter(lastScenario.get(), err); if (!err && !ok) valid = false; }
+        if (!valid) { ssn->stats.scenariosFiltered++; return GetNextScenario(); }
+        return lastScenario.get();
+    }
+};
+
+// ---------------------------------------------------------------- solvers/by_pod_solver.go + common/action.go
+struct SolutionResult { bool solved = false; std::vector<PodInfo*> victimsTasks; std::vector<PodGroupInfo*> victimJobs; std::unique_ptr<Statement> statement; };
+using SolutionValidator = std::function<bool(Scenario*)>;
+
+struct ByPodSolver {
+    Session* ssn; std::set<int>& feasibleNodes; SolutionValidator validator; bool allowVictimConsolidation;
+    enum Sim { simNone, simSolved, simRejected };
+
+    void EvictAllPreemptees(Statement& stmt, const std::vector<PodInfo*>& tasks) { for (auto* t : tasks) stmt.Evict(t); }  // common/action.go:27-52
+    // common/action.go:65-122 (GetJobsToAllocate + TryToVirtuallyAllocatePreemptorAndGetVictims)
+    bool tryScenarioWithEvictedVictims(Scenario* sc, Statement& stmt, const std::vector<PodInfo*>& victimTasks) {  // by_pod_solver.go:211-237
+        PodGroupInfo* pendingJob = sc->preemptor;
+        std::vector<NodeInfo*> nodes; for (int n : feasibleNodes) nodes.push_back(&ssn->nodes[n]);
+        std::map<int, PodGroupInfo*> all;  // keyed by job index: the preemptor's representative replaces the session's job of the same UID
+        for (auto& job : ssn->jobs) if (job.GetNumPendingTasks() > 0) all[job.idx] = &job;  // utils.GetAllPendingJobs
+        std::set<int> potentialVictims;
+        for (auto* t : victimTasks) { all[t->job] = &ssn->jobs[t->job]; potentialVictims.insert(t->job); }
+        all[pendingJob->idx] = pendingJob;
+        JobsOrderInitOptions o; o.MaxJobsQueueDepth = -1;
+        JobsOrderByQueues jobsToAllocate(ssn, o);
+        std::vector<PodGroupInfo*> v; for (auto& kv : all) v.push_back(kv.second);
+        jobsToAllocate.InitializeWithJobs(v);
+        bool preemptorAllocated = false;
+        while (!jobsToAllocate.IsEmpty()) {
+            PodGroupInfo* job = jobsToAllocate.PopNextJob();
+            if (!potentialVictims.count(job->idx) && job->idx != pendingJob->idx) continue;
+            ssn->GetTasksToAllocateInitResource(job, false);  // evaluated for a log line; fills the job's cache like the reference does
+            if (job->idx != pendingJob->idx) { ssn->AllocateJob(stmt, nodes, job, true); continue; }
+            if (!ssn->AllocateJob(stmt, nodes, job, true)) return false;
+            preemptorAllocated = true;
+        }
+        return preemptorAllocated;
+    }
+    Sim runSimulation(Scenario* sc, std::unique_ptr<Statement>& stmt, const std::vector<PodInfo*>& victimTasks, SolutionResult& out) {  // :100-116
+        ssn->stats.simulations++;
+        if (!tryScenarioWithEvictedVictims(sc, *stmt, victimTasks)) return simNone;
+        std::vector<PodInfo*> preempted, pipelined;
+        for (auto* t : victimTasks) { if (t->status == Releasing) preempted.push_back(t); else if (t->status == Pipelined) pipelined.push_back(t); }
+        // handleScenarioSolution :171-197
+        std::vector<PodInfo*> victimsTasks = preempted;
+        if (!allowVictimConsolidation) victimsTasks.insert(victimsTasks.end(), pipelined.begin(), pipelined.end());
+        std::vector<PodGroupInfo*> victimJobs = getVictimJobsFromVictimTasks(victimsTasks, sc);
+        if (validator && !validator(sc)) { stmt->Discard(); out = SolutionResult{}; return simRejected; }
+        if (allowVictimConsolidation) { victimsTasks.insert(victimsTasks.end(), pipelined.begin(), pipelined.end()); victimJobs = getVictimJobsFromVictimTasks(victimsTasks, sc); }
+        out.solved = true; out.victimsTasks = victimsTasks; out.victimJobs = victimJobs; out.statement = std::move(stmt);
+        return simSolved;
+    }
+    static std::vector<PodGroupInfo*> getVictimJobsFromVictimTasks(const std::vector<PodInfo*>& tasks, Scenario* sc) {  // :239-276
+        std::map<int, std::vector<PodGroupInfo*>> jobs;
+        for (auto* task : tasks) {
+            bool exists = false;
+            auto it = jobs.find(task->job);
+            if (it != jobs.end()) for (auto* dup : it->second) { for (auto* p : dup->AllPods()) if (p->idx == task->idx) { exists = true; break; } if (exists) break; }
+            if (!exists) { PodGroupInfo* m = sc->GetVictimJobRepresentativeById(task); if (m) jobs[m->idx].push_back(m); }
+        }
+        std::vector<PodGroupInfo*> out; for (auto& kv : jobs) out.insert(out.end(), kv.second.begin(), kv.second.end());
+        return out;
+    }
+    SolutionResult solve(Scenario* sc) {  // :61-98
+        auto stmt = std::make_unique<Statement>(ssn);
+        SolutionResult res;
+        EvictAllPreemptees(*stmt, sc->recordedVictimsTasks);
+        PodGroupInfo* latest = sc->LatestPotentialVictim();
+        if (!latest) {
+            if (!sc->recordedVictimsTasks.empty()) { Sim s = runSimulation(sc, stmt, sc->recordedVictimsTasks, res); if (s != simNone) return res; }
+        } else {
+            std::set<int> nodeNames; for (auto* t : latest->AllPods()) nodeNames.insert(t->node);  // getNodesOfJob :199-209 (every pod of the job, "" included)
+            for (int nodeToTest : nodeNames) {  // solveOnPotentialNodes :118-144
+                int cp = stmt->Checkpoint();
+                std::vector<PodInfo*> potential = sc->VictimsTasksFromNodes(nodeToTest);
+                EvictAllPreemptees(*stmt, potential);
+                std::vector<int> newFeasible;
+                for (auto* t : potential) if (t->node >= 0 && feasibleNodes.insert(t->node).second) newFeasible.push_back(t->node);
+                std::vector<PodInfo*> victimTasks = sc->recordedVictimsTasks; victimTasks.insert(victimTasks.end(), potential.begin(), potential.end());
+                Sim s = runSimulation(sc, stmt, victimTasks, res);
+                if (s != simNone) return res;
+                for (int n : newFeasible) feasibleNodes.erase(n);
+                stmt->Rollback(cp);
+            }
+        }
+        stmt->Discard();
+        return SolutionResult{};
+    }
+};
+
+// ---------------------------------------------------------------- solvers/job_solver.go
+struct JobSolver {
+    Session* ssn; std::vector<int> feasibleNodes; SolutionValidator validator; std::function<std::unique_ptr<JobsOrderByQueues>()> generateVictimsQueue;
+
+    static PodGroupInfo* getPartialJobRepresentative(Session* ssn, PodGroupInfo* job, const std::vector<PodInfo*>& pendingTasks) {  // :128-151
+        PodGroupInfo* rep = ssn->CloneWithTasks(job, pendingTasks);
+        std::map<int, int> minAvailable; for (auto* t : pendingTasks) minAvailable[t->podset] += 1;
+        for (auto& kv : minAvailable) for (auto* ps : rep->podSets) if (ps->idx == kv.first) ps->minAvailable = int32_t(kv.second);
+        return rep;
+    }
+    bool Solve(PodGroupInfo* pendingJob, std::unique_ptr<Statement>& statementOut) {  // :50-93
+        std::vector<PodGroupInfo*> recordedVictimsJobs; std::vector<PodInfo*> recordedVictimsTasks;
+        int originalNumActiveTasks = 0; for (auto* ps : pendingJob->podSets) originalNumActiveTasks += ps->numActiveUsedTasks;
+        std::vector<PodInfo*> tasksToAllocate = ssn->GetTasksToAllocate(pendingJob, false), pendingTasks;
+        for (auto* next : tasksToAllocate) {
+            pendingTasks.push_back(next);
+            bool satisfactory = pendingTasks.size() == tasksToAllocate.size();
+            PodGroupInfo* partial = getPartialJobRepresentative(ssn, pendingJob, pendingTasks);
+            SolutionResult result = solvePartialJob(recordedVictimsJobs, recordedVictimsTasks, partial);
+            if (!result.solved) break;
+            if (!satisfactory && result.statement) result.statement->Discard();
+            statementOut = std::move(result.statement);
+            recordedVictimsTasks = result.victimsTasks; recordedVictimsJobs = result.victimJobs;
+        }
+        int numActiveTasks = 0; for (auto* ps : pendingJob->podSets) numActiveTasks += ps->numActiveUsedTasks;
+        bool jobSolved = pendingJob->IsGangSatisfied();
+        if (originalNumActiveTasks >= numActiveTasks) jobSolved = false;
+        return jobSolved;
+    }
+    SolutionResult solvePartialJob(const std::vector<PodGroupInfo*>& recordedVictimsJobs, const std::vector<PodInfo*>& recordedVictimsTasks, PodGroupInfo* partial) {  // :95-126
+        std::set<int> feasibleNodeMap(feasibleNodes.begin(), feasibleNodes.end());
+        for (auto* t : recordedVictimsTasks) if (t->node >= 0) feasibleNodeMap.insert(t->node);
+        std::unique_ptr<JobsOrderByQueues> vq = generateVictimsQueue();
+        ScenarioBuilder builder(ssn, partial, recordedVictimsJobs, vq.get());
+        for (Scenario* sc = builder.GetValidScenario(); sc; sc = builder.GetNextScenario()) {
+            ByPodSolver solver{ssn, feasibleNodeMap, validator, ssn->cfg.allow_consolidating_reclaim != 0};
+            ssn->stats.scenarios++;
+            SolutionResult r = solver.solve(sc);
+            if (r.solved) return r;
+        }
+        return SolutionResult{};
+    }
+};
+
+// ---------------------------------------------------------------- common/feasible_nodes.go
+inline std::vector<int> Session::FeasibleNodesForJob(PodGroupInfo* job) {
+    std::vector<int> out;
+    bool allNeedGpu = true; for (auto* t : job->AllPods()) if (!(t->resReq.GPUs() > 0)) { allNeedGpu = false; break; }  // IsRequireAnyKindOfGPU, whole-GPU path
+    for (auto& n : nodes) if (!allNeedGpu || n.Idle.gpus > 0 || n.Releasing.gpus > 0) out.push_back(n.idx);
+    return out;
+}
+
+// ---------------------------------------------------------------- common/minimal_job_comparison.go
+struct MinimalJobRepresentatives {
+    std::map<int64_t, PodGroupInfo*> representatives;
+    static std::vector<const ResourceRequirements*> sortedRequests(PodGroupInfo* g) {  // :101-112 (sort.Slice with LessEqual as "less")
+        std::vector<const ResourceRequirements*> v; auto it = g->podStatusIndex.find(Pending);
+        if (it != g->podStatusIndex.end()) for (auto& kv : it->second) v.push_back(&kv.second->resReq);
+        std::stable_sort(v.begin(), v.end(), [](const ResourceRequirements* a, const ResourceRequirements* b) { return reqLessEqual(*a, *b) && !reqLessEqual(*b, *a); });
+        return v;
+    }
+    static bool reqLessEqual(const ResourceRequirements& a, const ResourceRequirements& b) {  // resource_requirment.go:106-124
+        if (!a.BaseResource::LessEqual(b)) return false;
+        return a.GPUs() <= b.GPUs();
+    }
+    static bool easier(PodGroupInfo* g1, PodGroupInfo* g2) {  // jobEasierToScheduleComparison :46-76
+        auto r1 = sortedRequests(g1), r2 = sortedRequests(g2);
+        if (r1.empty() || r2.empty()) return false;
+        if (r2.size() > r1.size()) return true;
+        for (size_t i = 0; i < r1.size(); i++) {
+            if (i >= r2.size()) return false;
+            if (reqLessEqual(*r1[i], *r2[i])) { if (reqLessEqual(*r2[i], *r1[i])) continue; return true; }
+        }
+        return false;
+    }
+    static bool footprintSmaller(PodGroupInfo* g1, PodGroupInfo* g2) {  // isPodGroupFootprintSmaller :78-99
+        auto r1 = sortedRequests(g1), r2 = sortedRequests(g2);
+        if (r1.empty() || r2.empty()) return false;
+        if (r1.size() > r2.size()) return false;
+        for (size_t i = 0; i < r1.size(); i++) if (!reqLessEqual(*r1[i], *r2[i])) return false;
+        return true;
+    }
+    bool IsEasierToSchedule(PodGroupInfo* other) { auto it = representatives.find(other->signature); if (it == representatives.end()) return true; return easier(other, it->second); }
+    void UpdateRepresentative(PodGroupInfo* job) { auto it = representatives.find(job->signature); if (it != representatives.end() && !footprintSmaller(job, it->second)) return; representatives[job->signature] = job; }
+};
+
+// ---------------------------------------------------------------- plugins/proportion/reclaimable/{reclaimable,strategies/strategies}.go
+inline bool Session::CanReclaimResources(PodGroupInfo* reclaimer) {  // reclaimable.go:29-54 via proportion.go:138-141
+    if (!(cfg.plugins & KAI_PLUGIN_PROPORTION)) return false;       // session_plugins.go:117-123: no registered fn → false
+    QueueAttributes& q = qattrs[reclaimer->queue];
+    ResourceQuantities requested = QuantifyResource(GetTasksToAllocateInitResource(reclaimer, false));
+    ResourceQuantities allocated = q.GetAllocatedShare(); for (int r = 0; r < 3; r++) allocated[r] += requested[r];
+    if (!rqLessEqual(allocated, q.GetFairShare())) return false;
+    if (reclaimer->IsPreemptibleJob()) return true;
+    ResourceQuantities np = q.get(&ResourceShare::AllocatedNotPreemptible); for (int r = 0; r < 3; r++) np[r] += requested[r];
+    return rqLessEqual(np, q.GetDeservedShare());
+}
+struct Involved { bool r[3] = {false, false, false}; void add(const Resource& x) { if (x.milliCpu > 0) r[0] = true; if (x.memory > 0) r[1] = true; if (x.gpus > 0) r[2] = true; } void merge(const Involved& o) { for (int i = 0; i < 3; i++) r[i] = r[i] || o.r[i]; } };
+inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 + reclaimable.go:56-232
+    const std::vector<QueueAttributes>& Q = jobSimulationQueues;
+    PodGroupInfo* reclaimer = sc->preemptor;
+    Resource required = GetTasksToAllocateInitResource(reclaimer, false);
+    const bool ignoreReallocated = cfg.allow_consolidating_reclaim != 0;
+    auto getResources = [&](const std::vector<PodInfo*>& pods, Resource& out) {  // proportion.go:222-240
+        int n = 0; out = Resource();
+        for (auto* t : pods) { if (ignoreReallocated && IsActiveAllocatedStatus(t->status)) continue; out.Add(t->accepted.AsResource()); n++; }
+        return n > 0;
+    };
+    std::map<int, std::vector<Resource>> totalVictimsResources;  // by queue
+    for (auto& kv : sc->victims) {  // scenario.GetVictims(): the tasks re-resolved by UID are the live objects here
+        const VictimInfo& victim = kv.second;
+        // splitVictimTasks :187-220 (sub-groups in name-rank order)
+        std::vector<PodInfo*> core, elastic;
+        for (auto* ps : victim.Job->podSets) {
+            std::vector<PodInfo*> sub; for (auto* t : victim.Tasks) if (t->podset == ps->idx) sub.push_back(t);
+            if (sub.empty()) continue;
+            if (ps->minAvailable >= int32_t(sub.size())) { core.insert(core.end(), sub.begin(), sub.end()); continue; }
+            core.insert(core.end(), sub.begin(), sub.begin() + ps->minAvailable); elastic.insert(elastic.end(), sub.begin() + ps->minAvailable, sub.end());
+        }
+        std::vector<Resource> res; Resource x;
+        for (auto* t : elastic) if (getResources({t}, x)) res.push_back(x);
+        if (getResources(core, x)) res.push_back(x);
+        if (res.empty()) continue;
+        auto& dst = totalVictimsResources[victim.Job->queue]; dst.insert(dst.end(), res.begin(), res.end());
+    }
+    auto path = [&](int q) { std::vector<int> p; for (; q >= 0; q = Q[q].parent) p.insert(p.begin(), q); return p; };  // getHierarchyPath :253-262
+    // reclaimResourcesFromReclaimees :69-108
+    std::map<int, ResourceQuantities> remaining; std::map<int, Involved> involved;
+    for (auto& kv : totalVictimsResources) {
+        int reclaimeeQueueID = kv.first;
+        std::vector<int> a = path(reclaimer->queue), b = path(reclaimeeQueueID);  // getLeveledQueues :234-251
+        int rq = -1, eq = -1; for (size_t i = 0; i < std::min(a.size(), b.size()); i++) { rq = a[i]; eq = b[i]; if (rq != eq) break; }
+        Involved inv; for (auto& r : kv.second) inv.add(r);
+        involved[reclaimeeQueueID] = inv;
+        if (!remaining.count(eq)) remaining[eq] = Q[eq].GetAllocatedShare();
+        for (auto& res : kv.second) {
+            ResourceQuantities& rem = remaining[eq];
+            // strategies.FitsReclaimStrategy :20-35: MaintainFairShare :45-60, GuaranteeDeservedQuota :62-91
+            bool fits = !rqLessEqual(rem, Q[eq].GetAllocatableShare());
+            if (!fits) {
+                ResourceQuantities want = Q[rq].GetAllocatedShare(), rr = QuantifyResource(required); for (int r = 0; r < 3; r++) want[r] += rr[r];
+                bool over = !rqLessEqual(want, Q[rq].GetDeservedShare());
+                fits = !over && !rqLessEqual(rem, Q[eq].GetDeservedShare());
+            }
+            if (!fits) return false;
+            // subtractReclaimedResources :110-133
+            for (int q = reclaimeeQueueID; q >= 0; q = Q[q].parent) {
+                if (!remaining.count(q)) remaining[q] = Q[q].GetAllocatedShare();
+                ResourceQuantities act = QuantifyResource(res); for (int r = 0; r < 3; r++) remaining[q][r] -= act[r];
+                if (involved.count(q)) involved[q].merge(involved[reclaimeeQueueID]); else involved[q] = involved[reclaimeeQueueID];
+            }
+        }
+    }
+    // reclaimingQueuesRemainWithinBoundaries :135-190
+    ResourceQuantities requestedQuota = QuantifyResource(required); Involved reclaimerInvolved; reclaimerInvolved.add(required);
+    for (int rq = reclaimer->queue; rq >= 0; rq = Q[rq].parent) {
+        ResourceQuantities rem = remaining.count(rq) ? remaining[rq] : Q[rq].GetAllocatedShare();
+        for (int r = 0; r < 3; r++) rem[r] += requestedQuota[r];
+        if (remaining.count(rq)) remaining[rq] = rem;  // the map holds the slice-backed value: Add mutates the stored entry
+        for (auto& kv : remaining) {
+            int sib = kv.first;
+            if (Q[sib].parent != Q[rq].parent || sib == rq) continue;
+            Involved inv = involved[sib]; inv.merge(reclaimerInvolved);
+            ResourceQuantities rf = Q[rq].GetFairShare(), sf = Q[sib].GetFairShare();
+            for (int r = 0; r < 3; r++) {  // isFairShareSaturationLowerPerResource :197-217
+                if (!inv.r[r]) continue;
+                if (rf[r] == KAI_UNLIMITED && sf[r] == KAI_UNLIMITED) continue;
+                auto ratio = [](double allocated, double fair) { if (fair == 0) return allocated > 0 ? INFINITY : 0.0; if (fair == KAI_UNLIMITED) return 0.0; return allocated / fair; };
+                double ratioReclaimer = ratio(rem[r], rf[r]), ratioSibling = ratio(kv.second[r], sf[r]);
+                if (ratioReclaimer > 1 && sf[r] > 0 && ratioReclaimer * cfg.reclaimer_saturation_multiplier >= ratioSibling) return false;
+            }
+        }
+        if (reclaimer->IsPreemptibleJob()) continue;
+        ResourceQuantities np = Q[rq].get(&ResourceShare::AllocatedNotPreemptible); for (int r = 0; r < 3; r++) np[r] += requestedQuota[r];
+        if (!rqLessEqual(np, Q[rq].GetDeservedShare())) return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- actions/utils/action.go:18-47
+inline std::unique_ptr<JobsOrderByQueues> Session::GetVictimsQueue(const std::function<bool(PodGroupInfo*)>& filter) {
+    std::vector<PodGroupInfo*> preemptees;
+    for (auto& job : jobs) {
+        bool alive = false; for (auto* t : job.AllPods()) if (IsAliveStatus(t->status)) alive = true;
+        if (alive && (!filter || filter(&job))) preemptees.push_back(&job);
+    }
+    JobsOrderInitOptions o; o.VictimQueue = true; o.MaxJobsQueueDepth = -1;
+    auto q = std::make_unique<JobsOrderByQueues>(this, o);
+    q->InitializeWithJobs(preemptees);
+    return q;
+}
+static inline int activeAllocatedCount(PodGroupInfo* job) { int n = 0; for (auto* t : job->AllPods()) if (IsActiveAllocatedStatus(t->status)) n++; return n; }
+
+// ---------------------------------------------------------------- actions/{reclaim,preempt,consolidation}
+inline void Session::executeVictimAction(int action) {
+    JobsOrderInitOptions o; o.FilterNonPending = true; o.FilterUnready = true;
+    if (action == KAI_ACTION_CONSOLIDATION) { if (cfg.max_consolidation_preemptees == 0) return; o.FilterNonPreemptible = true; }  // consolidation.go:36-46
+    o.MaxJobsQueueDepth = cfg.queue_depth[action] == 0 ? -1 : cfg.queue_depth[action];
+    JobsOrderByQueues jobsOrder(this, o);
+    std::vector<PodGroupInfo*> all; for (auto& j : jobs) all.push_back(&j);
+    jobsOrder.InitializeWithJobs(all);
+    std::map<int, MinimalJobRepresentatives> smallestFailedJobsByQueue;  // consolidation keeps ONE set (consolidation.go:52): key -1
+    while (!jobsOrder.IsEmpty()) {
+        PodGroupInfo* job = jobsOrder.PopNextJob(); if (!job) break;
+        if (action == KAI_ACTION_RECLAIM && !CanReclaimResources(job)) continue;  // reclaim.go:64-66
+        MinimalJobRepresentatives& smallest = smallestFailedJobsByQueue[action == KAI_ACTION_CONSOLIDATION ? -1 : job->queue];
+        if (cfg.use_scheduling_signatures && !smallest.IsEasierToSchedule(job)) continue;
+        stats.jobsAttempted++;
+        std::unique_ptr<Statement> stmt; bool ok = false;
+        clonePool.clear();
+        switch (action) {
+            case KAI_ACTION_RECLAIM: {  // reclaim.go:102-143
+                GetTasksToAllocateInitResource(job, false);
+                jobSimulationQueues = qattrs;  // ssn.OnJobSolutionStart → proportion.OnJobSolutionStartFn (proportion.go:131-136)
+                JobSolver solver{this, FeasibleNodesForJob(job), [this](Scenario* sc) { return (cfg.plugins & KAI_PLUGIN_PROPORTION) ? reclaimableFn(sc) : true; },
+                    [this, job]() {
+                        JobsOrderInitOptions vo; vo.FilterNonPreemptible = true; vo.FilterNonActiveAllocated = true; vo.VictimQueue = true; vo.MaxJobsQueueDepth = -1;
+                        auto q = std::make_unique<JobsOrderByQueues>(this, vo);
+                        std::vector<PodGroupInfo*> v; for (auto& other : jobs) if (other.queue != job->queue) v.push_back(&other);
+                        q->InitializeWithJobs(v); return q;
+                    }};
+                ok = solver.Solve(job, stmt);
+                break;
+            }
+            case KAI_ACTION_PREEMPT: {  // preempt.go:99-161
+                GetTasksToAllocateInitResource(job, false);
+                std::vector<PodInfo*> preemptorTasks = GetTasksToAllocate(job, false);
+                if (cfg.plugins & KAI_PLUGIN_PROPORTION) {  // IsNonPreemptibleJobOverQueueQuotaFn → capacity_policy.go:38-49
+                    ResourceQuantities q{0, 0, 0}; for (auto* pod : preemptorTasks) { q[2] += pod->resReq.GetGpusQuota(); q[0] += pod->resReq.milliCpu; q[1] += pod->resReq.memory; }
+                    if (resultsWithNonPreemptibleOverQuota(q, job)) break;
+                }
+                JobSolver solver{this, FeasibleNodesForJob(job), nullptr,
+                    [this, job]() { return GetVictimsQueue([job](PodGroupInfo* v) {  // buildFilterFuncForPreempt :122-152
+                        if (!v->IsPreemptibleJob()) return false;
+                        if (v->priority >= job->priority) return false;
+                        if (v->queue != job->queue) return false;
+                        if (v->idx == job->idx) return false;
+                        if (activeAllocatedCount(v) == 0) return false;
+                        return true; }); }};
+                ok = solver.Solve(job, stmt);
+                break;
+            }
+            case KAI_ACTION_CONSOLIDATION: {  // consolidation.go:80-157
+                GetTasksToAllocateInitResource(job, false);
+                double sumGpus = 0;  // utils.IsEnoughGPUsAllocatableForJob (action.go:119-160)
+                for (auto& n : nodes) { if (n.flags & KAI_NODE_NOT_READY) continue; sumGpus += n.Idle.gpus; sumGpus += n.Releasing.gpus; }
+                double requested = 0; for (auto* t : GetTasksToAllocate(job, false)) requested += t->resReq.GPUs();
+                if (!(sumGpus >= requested)) break;
+                JobSolver solver{this, FeasibleNodesForJob(job),
+                    [](Scenario* sc) { for (auto& kv : sc->victims) for (auto* t : kv.second.Tasks) if (t->status == Releasing) return false; return true; },  // allPodsReallocated :120-129
+                    [this, job]() {
+                        auto counter = std::make_shared<int>(0); int maxPreemptees = cfg.max_consolidation_preemptees;
+                        return GetVictimsQueue([job, counter, maxPreemptees](PodGroupInfo* v) {  // buildPreemptibleFilterFunc :136-157
+                            if (!v->IsPreemptibleJob()) return false;
+                            if (v->idx == job->idx) return false;
+                            if (maxPreemptees != -1 && *counter > maxPreemptees) return false;
+                            if (activeAllocatedCount(v) == 0) return false;
+                            *counter += 1; return true; }); }};
+                ok = solver.Solve(job, stmt);
+                break;
+            }
+        }
+        if (ok && stmt) { stats.jobsCommitted++; stmt->Commit(); }
+        else smallest.UpdateRepresentative(job);
+    }
+    clonePool.clear();
+}
+
+}  // namespace orc

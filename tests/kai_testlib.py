@@ -294,6 +294,8 @@ def case_to_snapshot(case, actions=("allocate",)):
     group_job, group_parent, group_names, group_tc, job_root_group, podset_group, podset_tc = [], [], [], [], [], [], []
 
     # ---- jobs & tasks (jobs_fake/jobs.go:51-330)
+    if not isinstance(case.get("Jobs", []), list) or any(not isinstance(j, dict) for j in case.get("Jobs", [])):
+        raise Unsupported("fixture built by Go code, not a literal")
     jobs = sorted(enumerate(case.get("Jobs", [])), key=lambda t: -int(t[1].get("Priority", 0)))  # SliceStable by priority desc
     jobs = [j for _, j in jobs]
     J = len(jobs)

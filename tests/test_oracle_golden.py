@@ -4,7 +4,9 @@ import pytest
 import kai_testlib as T
 
 FILES = ["allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology",
-         "integration_tests__allocate__allocate"]
+         "reclaim__reclaim", "reclaim__reclaimDepartments", "reclaim__reclaimGang", "reclaim__reclaim_elastic", "reclaim__reclaim_sub_group",
+         "preempt__preempt", "preempt__preemptGang", "preempt__preempt_elastic", "preempt__preempt_subgroups",
+         "consolidation__consolidation", "consolidation__consolidation_subgroups"]
 
 
 def _cases(name):
@@ -12,7 +14,7 @@ def _cases(name):
     return [(name, i, c, doc["actions"]) for i, c in enumerate(doc["cases"])]
 
 
-ALL = [x for f in FILES[:5] for x in _cases(f)]
+ALL = [x for f in FILES for x in _cases(f)]
 
 
 @pytest.mark.parametrize("name,i,case,actions", ALL, ids=[f"{n}[{i}]" for n, i, _, _ in ALL])
@@ -27,7 +29,7 @@ def test_oracle_reproduces_reference_expectations(name, i, case, actions):
 
 
 def test_golden_coverage():
-    """At least the 43 allocate scenarios that are inside the built path must be exercised (not silently skipped)."""
+    """The scenarios inside the built path must be exercised, not silently skipped: 64 allocate + 122 reclaim / preempt / consolidation."""
     ok = 0
     for name, i, case, actions in ALL:
         try:
@@ -35,4 +37,4 @@ def test_golden_coverage():
             ok += 1
         except T.Unsupported:
             pass
-    assert ok >= 64, ok
+    assert ok >= 186, ok
