@@ -27,6 +27,7 @@ struct kai_core {
     bool open = false;
     KaiCtx ctx{};
     KaiCtx* d_ctx = nullptr;  // HBM copy of ctx for the persistent kernel
+    bool solver_ready = false;  // scratch of the victim search allocated (first reclaim / preempt / consolidation of the session)
     std::vector<void*> bufs;  // session HBM: a few large slabs, sub-allocated (one contiguous range ⇒ few TLB entries for the latency-bound engine)
     char* slab = nullptr; size_t slab_left = 0;
     // device-only helpers
@@ -248,6 +249,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64;
     c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok;
     { int d = core->cfg.queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
+    c.action = KAI_ACTION_ALLOCATE; c.max_consolidation_preemptees = core->cfg.max_consolidation_preemptees; c.allow_consolidating_reclaim = core->cfg.allow_consolidating_reclaim;
+    c.saturation_multiplier = core->cfg.reclaimer_saturation_multiplier; c.sv = SolverCtx{}; core->solver_ready = false;
     TRY(dupload_f(core, c.cls, prep.classes.data(), prep.classes.size()));
     TRY(dzero_f(core, c.sum1_key, (size_t)std::max(c.C, 1) * std::max(c.NB, 1))); TRY(dzero_f(core, c.sum1_node, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)));
 
@@ -321,6 +324,7 @@ int kai_session_reset(kai_core* core) {
     if (c.P) { HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_status), core->d_status0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream));
                HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_node), core->d_node0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream)); }
     HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.q_share), core->d_shares0, (size_t)std::max(c.Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
+    if (core->solver_ready) HIP_TRY(core, hipMemsetAsync(c.sv.xr_key, 0xFF, sizeof(int64_t) * ((size_t)c.sv.xr_mask + 1), core->stream));
     HIP_TRY(core, hipMemsetAsync(KAI_VP(c.st), 0, sizeof(EngineState), core->stream));
     int rc = launch_open_kernels(core); if (rc) return rc;
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
@@ -350,9 +354,21 @@ int kai_queue_shares(kai_core* core, kai_queue_share* out, int cap) {
 int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_cap, int64_t* n_ops) {
     if (!core || !n_ops) return KAI_ERR_INVALID_ARG;
     if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
-    if (action != KAI_ACTION_ALLOCATE) return fail(core, KAI_ERR_UNSUPPORTED, "only the allocate action is built so far");
+    if (action < KAI_ACTION_ALLOCATE || action > KAI_ACTION_PREEMPT) return fail(core, KAI_ERR_INVALID_ARG, "unknown action");
+    const bool victim = action != KAI_ACTION_ALLOCATE;
+    if (victim && core->cfg.use_scheduling_signatures) return fail(core, KAI_ERR_UNSUPPORTED, "useSchedulingSignatures is not built (MinimalJobRepresentatives, actions/common/minimal_job_comparison.go)");
     HIP_TRY(core, hipSetDevice(core->device));
     KaiCtx& c = core->ctx;
+    if (victim && !core->solver_ready) {  // scratch of the victim search, kept for the rest of the session
+        char* base = nullptr; size_t bytes = solver_scratch_bytes(c.N, c.P, c.S, c.J, c.Q, c.W);
+        int rc0 = dalloc(core, &base, bytes); if (rc0) return rc0;
+        HIP_TRY(core, hipMemsetAsync(base, 0, bytes, core->stream));
+        solver_scratch_bind(c.sv, base, c.N, c.P, c.S, c.J, c.Q, c.W);
+        HIP_TRY(core, hipMemsetAsync(c.sv.xr_key, 0xFF, sizeof(int64_t) * ((size_t)c.sv.xr_mask + 1), core->stream));  // empty residency table
+        core->solver_ready = true;
+    }
+    { int d = core->cfg.queue_depth[action]; c.queue_depth = d > 0 ? d : 0; c.action = action; }
+    HIP_TRY(core, hipMemcpyAsync(core->d_ctx, &core->ctx, sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
     // reset the per-action scalars, keep the proportion totals
     EngineState st{};
     HIP_TRY(core, hipMemcpyAsync(&st, KAI_VP(c.st), sizeof(st), hipMemcpyDeviceToHost, core->stream));
@@ -369,10 +385,15 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         const size_t budget = 160 * 1024 - 4096;  // static ActShared + margin
         int tree_in_lds = (idx_b + tree_b <= budget && !std::getenv("KAI_TREE_IN_HBM")) ? 1 : 0;
         size_t dyn = idx_b + (tree_in_lds ? tree_b : 0);
-        HIP_TRY(core, hipFuncSetAttribute(reinterpret_cast<const void*>(k_action), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(k_action, dim3(1), dim3(WG), dyn, core->stream, (const KaiCtx*)core->d_ctx, action, tree_in_lds);
+        if (victim) {
+            HIP_TRY(core, hipFuncSetAttribute(reinterpret_cast<const void*>(k_action<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(k_action<true>, dim3(1), dim3(WG), dyn, core->stream, (const KaiCtx*)core->d_ctx, action, tree_in_lds);
+        } else {
+            HIP_TRY(core, hipFuncSetAttribute(reinterpret_cast<const void*>(k_action<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(k_action<false>, dim3(1), dim3(WG), dyn, core->stream, (const KaiCtx*)core->d_ctx, action, tree_in_lds);
+        }
     }
-    if (c.J) hipLaunchKernelGGL(k_drain, dim3(std::min(2048, (c.J + TB - 1) / TB)), dim3(TB), 0, core->stream, c, core->d_slot_queue);
+    if (c.J && !victim) hipLaunchKernelGGL(k_drain, dim3(std::min(2048, (c.J + TB - 1) / TB)), dim3(TB), 0, core->stream, c, core->d_slot_queue);
     HIP_TRY(core, hipGetLastError());
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
     HIP_TRY(core, hipMemcpyAsync(&st, KAI_VP(c.st), sizeof(st), hipMemcpyDeviceToHost, core->stream));
@@ -382,10 +403,10 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     std::memset(&core->stats, 0, sizeof(core->stats));
     core->stats.upload_ms = upload; core->stats.kernel_ms = ms; core->stats.decisions = st.decisions; core->stats.node_scans = st.node_scans;
     core->stats.nodes_scanned = st.nodes_scanned; core->stats.jobs_attempted = st.jobs_attempted; core->stats.jobs_committed = st.jobs_committed; core->stats.rollbacks = st.rollbacks;
-    core->stats.reserved[0] = st.index_queries; core->stats.reserved[1] = st.index_refreshes; core->stats.reserved[2] = st.drained_jobs; core->stats.reserved[3] = st.drained_decisions;
+    core->stats.reserved[0] = st.index_queries; core->stats.reserved[1] = st.index_refreshes; core->stats.reserved[2] = victim ? st.scenarios : st.drained_jobs; core->stats.reserved[3] = victim ? st.simulations : st.drained_decisions;
     for (int i = 0; i < 4; i++) core->stats.reserved[4 + i] = st.prof[i == 3 ? 7 : i == 2 ? 3 : i == 1 ? 2 : 0];  // control-lane cycles: pop, allocate, commit/discard, total
     if (std::getenv("KAI_PROF")) { std::fprintf(stderr, "kai prof:"); for (int i = 0; i < 16; i++) std::fprintf(stderr, " %lld", (long long)st.prof[i]); std::fprintf(stderr, "\n"); }
-    if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d", st.fault); core->err = buf; return KAI_ERR_DEVICE_FAULT; }
+    if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d (engine source line %d)", st.fault, st.fault_line); core->err = buf; return KAI_ERR_DEVICE_FAULT; }
     *n_ops = st.out_len;
     if (ops_out) {
         if (st.out_len > ops_cap) return fail(core, KAI_ERR_CAPACITY, "kai_action_execute: ops_cap too small");

@@ -29,9 +29,11 @@
 #if defined(__HIPCC__)
 #define KAI_HD __host__ __device__ __forceinline__
 #define KAI_HD_NOINLINE __host__ __device__
+#define KAI_HDS __host__ __device__ __attribute__((noinline))  // victim search: real calls, or the one persistent kernel inlines itself into hours of compile time
 #else
 #define KAI_HD inline
 #define KAI_HD_NOINLINE
+#define KAI_HDS inline
 #endif
 
 // KAI_GP(T): pointer to T in HBM.  On the device it is an address-space-1 ("global") pointer so that every array access is a
@@ -125,16 +127,78 @@ inline FastFrame& kai_frame_host() { static thread_local FastFrame f; return f; 
 struct EngineState {  // mutable scalars of the running action
     int32_t ops_len, n_undo;
     int32_t fault;            // != 0: engine gave up (see FAULT_*)
+    int32_t fault_line, pad_f; // source line of the fault() call (diagnostics)
     int32_t drain_pending;    // allocate: every class is dead at a committed state → the rest of the queue is counted by k_drain
     int64_t out_len;
     int64_t decisions, node_scans, nodes_scanned, jobs_attempted, jobs_committed, rollbacks;
     int64_t index_queries, index_refreshes, drained_jobs, drained_decisions;
+    int64_t scenarios, simulations, scenarios_filtered;  // victim search (actions/common/solvers)
     int64_t prof[16];         // control-lane cycles per phase, see PF_*
     double total[3];          // proportion totalResource (CPU, Memory, GPU)
 };
 enum { PF_POP = 0, PF_ALLOC = 2, PF_FINISH = 3, PF_DRAINCHK = 4, PF_INIT = 5, PF_TOTAL = 7, PF_TTA = 8, PF_GATE = 9, PF_TASKCAP = 10, PF_FIND = 11,
        PF_REFRESH = 12, PF_STMT = 13, PF_ROLLBACK = 14, PF_PUSH = 15 };
 enum { FAULT_NONE = 0, FAULT_OPS_CAP = 1, FAULT_OUT_CAP = 2, FAULT_HEAP = 3, FAULT_INTERNAL = 4, FAULT_SPIN = 5 };
+
+// Scratch of the victim search (reclaim / preempt / consolidation, kai_engine_solver.inc), all in HBM.  "View" of a victim job =
+// its pods that are not yet taken into a task group of the scenario (and, once the builder met a recorded victim of the job, not
+// recorded): what the reference holds as CloneWithTasks(remainingTasks) in the victims queue (solvers/pod_scenario_builder.go:91-133).
+struct SolverCtx {
+    uint8_t *vq_in, *vq_excl, *ja_in;                 // [J] victims-queue membership, "view excludes recorded tasks", jobsToAllocate membership (bit 1 = victim job)
+    uint8_t *p_taken, *p_recorded, *p_partial, *ig_cache;  // [P]
+    int32_t *p_grp;                                   // [P] task group (representative clone) of a victim pod in the current scenario
+    int64_t* xr_key; int32_t* xr_status; int32_t xr_mask, xr_pad;  // further node residencies of a pod, hash (pod, node) → status the node's copy was added with:
+                                                      // an evicted task stays on its node as Releasing while it is pipelined elsewhere (statement.go:197-295)
+    // the two solver-internal job-order instances (index 0 = victims queue, 1 = jobs to allocate): same records and heaps as the action's own
+    QNode* i_qn[2]; int32_t *i_qheap[2], *i_root[2], *i_cur[2], *i_end[2], *i_side[2], *i_side_len[2];  // [Q], [Q+1], [Q+1], [Q], [Q], [J], [Q]
+    double* vq_pop;                                   // [Q][3] Σ Allocated of the jobs popped from a leaf (poppedJobsByQueue, job_order_by_queue.go:80-82)
+    int32_t* s_ov_min;                                // [S] minAvailable of the partial preemptor representative (job_solver.go:128-151)
+    int32_t *grp_job, *grp_off, *grp_pods;            // task groups of the scenario: recorded first, then potential in the order they were added
+    int32_t *rec_job, *rec_off, *rec_pods;            // recorded victim jobs handed to the next partial job (result.victimJobs)
+    int32_t *res_tasks, *ev_tasks, *vt_tasks, *pend, *tmp, *tmp2, *tmp3;  // [P] result.victimsTasks, GetTasksToEvict output, victims of the running simulation, tasks of the job being solved, scratch
+    uint32_t *feas, *feas0;                           // [W] byPodSolver.feasibleNodes / JobSolver.feasibleNodes as node bitmaps
+    double* ig_idle; int32_t* ig_sorted;              // [N], [P] AccumulatedIdleGpus state
+    QShare* q_sim;                                    // [Q][3] proportion.jobSimulationQueues
+    double *rc_rem, *rc_ent; int32_t* rc_ent_q; uint8_t *rc_has, *rc_inv;  // reclaimable validator scratch
+    int32_t P_cap;
+};
+inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W) {
+    size_t b = 0; auto add = [&](size_t n) { b += (n + 15) & ~size_t(15); };
+    add(J); add(J); add(J); add(P); add(P); add(P); add(P);
+    add(sizeof(int32_t) * P); { size_t h = 16; while (h < 2 * (size_t)P + 16) h <<= 1; add(sizeof(int64_t) * h); add(sizeof(int32_t) * h); }
+    for (int i = 0; i < 2; i++) { add(sizeof(QNode) * (Q + 1)); add(sizeof(int32_t) * (Q + 2)); add(sizeof(int32_t) * (Q + 2)); add(sizeof(int32_t) * (Q + 1)); add(sizeof(int32_t) * (Q + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (Q + 1)); }
+    add(sizeof(double) * 3 * Q); add(sizeof(int32_t) * (S + 1));
+    for (int i = 0; i < 2; i++) { add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); }
+    for (int i = 0; i < 7; i++) add(sizeof(int32_t) * (P + 1));
+    add(sizeof(uint32_t) * (W + 1)); add(sizeof(uint32_t) * (W + 1));
+    add(sizeof(double) * (N + 1)); add(sizeof(int32_t) * (P + 1));
+    add(sizeof(QShare) * 3 * (Q + 1));
+    add(sizeof(double) * 3 * (Q + 1)); add(sizeof(double) * 3 * (2 * (size_t)P + J + 2)); add(sizeof(int32_t) * (2 * (size_t)P + J + 2)); add(Q + 1); add(Q + 1);
+    return b + 64;
+}
+inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, int J, int Q, int W) {
+    char* c = base; auto take = [&](size_t n) { char* r = c; c += (n + 15) & ~size_t(15); return r; };
+    v.vq_in = (uint8_t*)take(J); v.vq_excl = (uint8_t*)take(J); v.ja_in = (uint8_t*)take(J);
+    v.p_taken = (uint8_t*)take(P); v.p_recorded = (uint8_t*)take(P); v.p_partial = (uint8_t*)take(P); v.ig_cache = (uint8_t*)take(P);
+    v.p_grp = (int32_t*)take(sizeof(int32_t) * P);
+    { size_t h = 16; while (h < 2 * (size_t)P + 16) h <<= 1; v.xr_key = (int64_t*)take(sizeof(int64_t) * h); v.xr_status = (int32_t*)take(sizeof(int32_t) * h); v.xr_mask = (int32_t)(h - 1); }
+    for (int i = 0; i < 2; i++) {
+        v.i_qn[i] = (QNode*)take(sizeof(QNode) * (Q + 1)); v.i_qheap[i] = (int32_t*)take(sizeof(int32_t) * (Q + 2)); v.i_root[i] = (int32_t*)take(sizeof(int32_t) * (Q + 2));
+        v.i_cur[i] = (int32_t*)take(sizeof(int32_t) * (Q + 1)); v.i_end[i] = (int32_t*)take(sizeof(int32_t) * (Q + 1)); v.i_side[i] = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.i_side_len[i] = (int32_t*)take(sizeof(int32_t) * (Q + 1));
+    }
+    v.vq_pop = (double*)take(sizeof(double) * 3 * Q); v.s_ov_min = (int32_t*)take(sizeof(int32_t) * (S + 1));
+    v.grp_job = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.grp_off = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.grp_pods = (int32_t*)take(sizeof(int32_t) * (P + 1));
+    v.rec_job = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.rec_off = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.rec_pods = (int32_t*)take(sizeof(int32_t) * (P + 1));
+    v.res_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.ev_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vt_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1));
+    v.pend = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.tmp = (int32_t*)take(sizeof(int32_t) * (P + 1));
+    v.tmp2 = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.tmp3 = (int32_t*)take(sizeof(int32_t) * (P + 1));
+    v.feas = (uint32_t*)take(sizeof(uint32_t) * (W + 1)); v.feas0 = (uint32_t*)take(sizeof(uint32_t) * (W + 1));
+    v.ig_idle = (double*)take(sizeof(double) * (N + 1)); v.ig_sorted = (int32_t*)take(sizeof(int32_t) * (P + 1));
+    v.q_sim = (QShare*)take(sizeof(QShare) * 3 * (Q + 1));
+    v.rc_rem = (double*)take(sizeof(double) * 3 * (Q + 1)); v.rc_ent = (double*)take(sizeof(double) * 3 * (2 * (size_t)P + J + 2));
+    v.rc_ent_q = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)P + J + 2)); v.rc_has = (uint8_t*)take(Q + 1); v.rc_inv = (uint8_t*)take(Q + 1);
+    v.P_cap = P;
+}
 
 // All pointers are device memory (HBM).  [R][N] arrays are resource-major.  Node index = name rank.
 struct KaiCtx {
@@ -190,6 +254,9 @@ struct KaiCtx {
     KAI_GP(int32_t) ns_sets;                                         // [KAI_TDEPTH][D+T+1] domains of the node sets of a frame
     KAI_GP(double) sg_score;                                         // [KAI_TKEYS][D+T] node score of a domain at the key's preferred level, <0 = not scored
     KAI_GP(int32_t) sg_key, sg_row;                                  // [KAI_TKEYS] sub-group key and its preferred level row
+    // victim actions
+    int32_t action, max_consolidation_preemptees, allow_consolidating_reclaim, pad6; double saturation_multiplier;
+    SolverCtx sv;
 };
 
 // ======================================================================================================
@@ -361,6 +428,12 @@ struct EngineLocal {
     // scope of the next node scans (general path): node-set bitmap (null = every node) and the preferred-level scores that apply
     KAI_GP(const uint32_t) scope_bits; KAI_GP(const double) scope_score; int32_t scope_row, n_keys;
     uint32_t restricted, pad5;               // bit d: the node set of DFS depth d is narrower than "every node"
+    KAI_GP(const uint32_t) base_bits;        // node set every job attempt starts from (null = every node; a scenario's feasible nodes in the victim search)
+    int32_t ov_job, pad7;                    // job currently stood in for by its partial representative (job_solver.go:128-151), -1 = none
+    // victim search: the active job-order instance (0 = the action's, 1 = victims queue, 2 = jobs to allocate of a simulation)
+    int32_t *i_sorted, *i_cur, *i_end, *i_side, *i_side_len;  // leaf storage of the active instance
+    int32_t jo_kind, cur_inst;               // jo_kind 1 = victims ordering (reversed comparators, victims operands)
+    struct JoSave { QNode* qn; int32_t *qheap, *root_heap, *sorted, *cur, *end, *side, *side_len; int32_t root_len, root_init, kind, pad; } save[3];
 };
 
 template <class Backend>
@@ -370,15 +443,18 @@ struct Engine {
     // objects (static accessors, nothing goes through this object), on the host plain members of the backend.
     KAI_HD const KaiCtx& cx() const { return be.ctx(); }
     KAI_HD EngineLocal& el() const { return be.local(); }
+    static constexpr bool kVictim = Backend::kVictim;  // compiled with the victim search (reclaim / preempt / consolidation)
+    KAI_HD const SolverCtx& sx() const { return cx().sv; }
     KAI_HD Engine(const KaiCtx& ctx, Backend& b) : be(b) {
         be.bind(ctx);
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0;
+        e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 
-    KAI_HD void fault(int code) { if (!cx().st->fault) cx().st->fault = code; }
+    KAI_HD void fault(int code, int line = __builtin_LINE()) { if (!cx().st->fault) { cx().st->fault = code; cx().st->fault_line = line; } }
     KAI_HD double preq(int p, int r) const { return cx().p_req[(size_t)r * cx().P + p]; }
     KAI_HD bool pod_cpu_only(int p) const { return !(preq(p, KAI_RES_GPU) > 0); }  // pod_info.go:340-347
     KAI_HD bool pod_best_effort(int p) const {  // ResourceRequirements.IsEmpty (resource_requirment.go:99-104, base_resources.go:119-130)
@@ -428,7 +504,10 @@ struct Engine {
         if (status == KAI_POD_GATED) cx().s_gated[s]++;
         if (status == KAI_POD_PIPELINED) cx().s_pipelined[s]++;
         if (status == KAI_POD_PENDING) cx().j_n_pending[j]++;
-        cx().j_tta_valid[j] = 0;  // invalidateTasksCache (job_info.go:253-256)
+        // invalidateTasksCache (job_info.go:253-256) — of the SESSION's job: the partial representative the victim search stands in for
+        // it keeps the chunk it cached when it was made (statement operations re-index the original job, not the clone)
+        if constexpr (kVictim) { if (j == el().ov_job) return; }
+        cx().j_tta_valid[j] = 0;
     }
 
     // ------------------------------------------------------------------ node accounting (api/node_info/node_info.go)
@@ -443,19 +522,44 @@ struct Engine {
         }
         mark_dirty(n);
     }
+    // further residencies (victim search only): open addressing, key = pod << 32 | node, -1 empty, -2 deleted
+    KAI_HD int xr_find(int p, int n) const {
+        const int64_t key = ((int64_t)p << 32) | (uint32_t)n; uint32_t h = (uint32_t)(((uint64_t)key * 0x9E3779B97F4A7C15ull) >> 33) & (uint32_t)sx().xr_mask;
+        for (;;) { int64_t k = sx().xr_key[h]; if (k == key) return (int)h; if (k == -1) return -1; h = (h + 1) & (uint32_t)sx().xr_mask; }
+    }
+    KAI_HD void xr_insert(int p, int n, int status) {
+        const int64_t key = ((int64_t)p << 32) | (uint32_t)n; uint32_t h = (uint32_t)(((uint64_t)key * 0x9E3779B97F4A7C15ull) >> 33) & (uint32_t)sx().xr_mask;
+        for (;;) { int64_t k = sx().xr_key[h]; if (k < 0) { sx().xr_key[h] = key; sx().xr_status[h] = status; return; } h = (h + 1) & (uint32_t)sx().xr_mask; }
+    }
     KAI_HD bool node_add_task(int n, int p) {  // AddTask :384-417
         if (st_active_used(cx().p_status[p])) cx().p_accepted[p] = 1;  // setAcceptedResources :746-766
         if (cx().p_on_node[p] == n) return false;                    // "task already on node"
-        if (cx().p_on_node[p] >= 0) { fault(FAULT_INTERNAL); return false; }  // a pod on two nodes only happens in reclaim scenarios (not built yet)
+        if constexpr (kVictim) { if (xr_find(p, n) >= 0) return false; }
+        if (cx().p_on_node[p] >= 0) {
+            if constexpr (kVictim) {
+                xr_insert(p, n, cx().p_status[p]);
+                node_apply(n, p, cx().p_status[p], 1.0);
+                return true;
+            }
+            fault(FAULT_INTERNAL); return false;
+        }
         cx().p_on_node[p] = n; cx().p_on_node_status[p] = cx().p_status[p];
         node_apply(n, p, cx().p_status[p], 1.0);
         return true;
     }
+    KAI_HD bool on_node(int p, int n) const {
+        if (cx().p_on_node[p] == n) return true;
+        if constexpr (kVictim) return xr_find(p, n) >= 0;
+        return false;
+    }
     KAI_HD bool node_remove_task(int n, int p) {  // RemoveTask :495-513 — with the status the node's copy was added with
-        if (cx().p_on_node[p] != n) return false;
-        node_apply(n, p, cx().p_on_node_status[p], -1.0);
-        cx().p_on_node[p] = -1;
-        return true;
+        if (cx().p_on_node[p] == n) {
+            node_apply(n, p, cx().p_on_node_status[p], -1.0);
+            cx().p_on_node[p] = -1;
+            return true;
+        }
+        if constexpr (kVictim) { int h = xr_find(p, n); if (h >= 0) { node_apply(n, p, sx().xr_status[h], -1.0); sx().xr_key[h] = -2; return true; } }
+        return false;
     }
     KAI_HD bool node_update_task(int n, int p) { if (!node_remove_task(n, p)) return false; return node_add_task(n, p); }  // :571-576
 
@@ -498,7 +602,7 @@ struct Engine {
         return true;
     }
     KAI_HD bool stmt_pipeline(int p, int n, bool update_if_exists) {  // :197-295
-        bool found_on_node = cx().p_on_node[p] == n;
+        bool found_on_node = on_node(p, n);
         if (found_on_node && !update_if_exists) return stmt_unevict_earliest(p);
         int prev_status = cx().p_status[p];
         update_task_status(p, KAI_POD_PIPELINED);
@@ -537,7 +641,7 @@ struct Engine {
     KAI_HD void unevict(int p, int prev_status, int n, int prev_virtual) {  // :152-195
         update_task_status(p, prev_status);
         cx().p_virtual[p] = (uint8_t)prev_virtual;
-        if (n >= 0) { if (cx().p_on_node[p] == n) node_update_task(n, p); else node_add_task(n, p); }
+        if (n >= 0) { if (on_node(p, n)) node_update_task(n, p); else node_add_task(n, p); }
         queue_event(p, 1.0);
     }
     KAI_HD bool stmt_unevict_earliest(int p) {  // Unevict → undoEarliestValidOperation :478-481,578-600
@@ -555,7 +659,15 @@ struct Engine {
             case OP_EVICT: unevict(op.pod, op.prev_status, op.prev_node, op.prev_virtual); break;
             case OP_PIPELINE: unpipeline(op.pod, op.prev_node, op.prev_status, op.prev_virtual); break;
             case OP_ALLOCATE: unallocate(op.pod, op.prev_virtual); break;
-            default: fault(FAULT_INTERNAL); return;  // undo of an undo (= redo) only arises in victim scenarios; not on the allocate path
+            default: {  // undo of an undo = redo the original operation (:606-623)
+                if constexpr (kVictim) {
+                    StmtOp orig = cx().ops[op.op_index];
+                    if (orig.name == OP_EVICT) stmt_evict(orig.pod); else if (orig.name == OP_PIPELINE) stmt_pipeline(orig.pod, orig.next_node, true);
+                    else if (orig.name == OP_ALLOCATE) stmt_allocate(orig.pod, orig.next_node); else undo_operation(orig.op_index);
+                    break;
+                }
+                fault(FAULT_INTERNAL); return;
+            }
         }
         StmtOp u{}; u.name = OP_UNDO; u.pod = -1; u.op_index = index;
         if (push_op(u)) cx().st->n_undo++;
@@ -602,10 +714,16 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ order functions
+    // pod-set counters as the job object at hand holds them: the session's live counters, except for the job the victim search is
+    // solving, which is stood in for by its partial representative (CloneWithTasks of the pending tasks: nothing allocated yet,
+    // minAvailable = number of its tasks in the pod-set; job_solver.go:128-151)
+    KAI_HD int ps_min(int s) const { if constexpr (kVictim) { if (cx().s_job[s] == el().ov_job) return sx().s_ov_min[s]; } return cx().s_min[s]; }
+    KAI_HD int ps_act(int s) const { if constexpr (kVictim) { if (cx().s_job[s] == el().ov_job) return 0; } return cx().s_active_alloc[s]; }
+    KAI_HD bool job_has_pod(int j, int p) const { if constexpr (kVictim) { if (j == el().ov_job) return sx().p_partial[p] != 0; } return true; }
     KAI_HD int min_available_state(int j) const {  // plugins/elastic/elastic.go:53-65 → 0 below, 1 exactly, 2 above
         bool exactly = true;
         for (int k = 0; k < cx().j_n_ps[j]; k++) {
-            int s = cx().j_first_ps[j] + k; int n = cx().s_active_alloc[s], m = cx().s_min[s];
+            int s = cx().j_first_ps[j] + k; int n = ps_act(s), m = ps_min(s);
             if (n < m) return 0;
             if (n > m) exactly = false;
         }
@@ -626,14 +744,16 @@ struct Engine {
         if (cx().j_created[l] == cx().j_created[r]) return cx().j_uid_rank[l] < cx().j_uid_rank[r];
         return cx().j_created[l] < cx().j_created[r];
     }
+    // order of a leaf's job heap (job_order_by_queue.go:249-262): JobOrderFn, negated for a victims queue
+    KAI_HD bool job_less(int a, int b) const { if constexpr (kVictim) { if (el().jo_kind) return !job_order_view(a, b); } return job_order(a, b); }
     KAI_HD bool podset_order(int l, int r) const {  // session_plugins.go:262-271 + plugins/subgrouporder/subgroup_order.go:31-62
         if (cx().plugins & KAI_PLUGIN_SUBGROUPORDER) {
-            int ln = cx().s_active_alloc[l], rn = cx().s_active_alloc[r];
-            bool ls = ln >= cx().s_min[l], rs = rn >= cx().s_min[r];
+            int ln = ps_act(l), rn = ps_act(r), lm = ps_min(l), rm = ps_min(r);
+            bool ls = ln >= lm, rs = rn >= rm;
             if (!ls && !rs) return cx().s_name_rank[l] < cx().s_name_rank[r];
             if (!ls) return true;
             if (!rs) return false;
-            double lr = (double)ln / (double)cx().s_min[l], rr = (double)rn / (double)cx().s_min[r];
+            double lr = (double)ln / (double)lm, rr = (double)rn / (double)rm;
             if (lr < rr) return true;
             if (rr < lr) return false;
         }
@@ -646,11 +766,11 @@ struct Engine {
         int first = cx().j_first_pod[j], np = cx().j_n_pods[j], nps = cx().j_n_ps[j], ps0 = cx().j_first_ps[j];
         int out = 0;
         if (nps == 1) {  // one pod-set: the chunk is the first max_tasks allocatable pods in task order
-            int s = ps0, act = cx().s_active_alloc[s], mn = cx().s_min[s];
+            int s = ps0, act = ps_act(s), mn = ps_min(s);
             int max_tasks = act >= mn ? 1 : mn - act;  // getNumTasksToAllocate :145-153
-            for (int i = 0; i < np && out < max_tasks; i++) { int p = cx().j_pods_sorted[first + i]; if (should_allocate(p, real)) cx().tta[first + out++] = p; }
+            for (int i = 0; i < np && out < max_tasks; i++) { int p = cx().j_pods_sorted[first + i]; if (should_allocate(p, real) && job_has_pod(j, p)) cx().tta[first + out++] = p; }
         } else {
-            int unsat = 0; for (int k = 0; k < nps; k++) if (cx().s_active_alloc[ps0 + k] < cx().s_min[ps0 + k]) unsat++;
+            int unsat = 0; for (int k = 0; k < nps; k++) if (ps_act(ps0 + k) < ps_min(ps0 + k)) unsat++;
             int max_sg = unsat > 0 ? unsat : 1, n_sg = 0;
             // pod-sets leave the priority queue in PodSetOrderFn order: repeated arg-min, podsets per job are few
             uint64_t taken_lo = 0;  // bitmap for up to 64 pod-sets; larger jobs fall back to the scratch array
@@ -666,11 +786,11 @@ struct Engine {
                 if (best < 0) break;
                 if (best < 64) taken_lo |= (1ull << best); else cx().scratch[first + (best - 64)] = 1;
                 int s = ps0 + best;
-                int avail = 0; for (int i = 0; i < np; i++) { int p = cx().j_pods_sorted[first + i]; if (cx().p_podset[p] == s && should_allocate(p, real)) avail++; }
+                int avail = 0; for (int i = 0; i < np; i++) { int p = cx().j_pods_sorted[first + i]; if (cx().p_podset[p] == s && should_allocate(p, real) && job_has_pod(j, p)) avail++; }
                 if (avail == 0) continue;
-                int max_tasks = cx().s_active_alloc[s] >= cx().s_min[s] ? (avail < 1 ? avail : 1) : (cx().s_min[s] - cx().s_active_alloc[s]);  // getNumTasksToAllocate :145-153
+                int max_tasks = ps_act(s) >= ps_min(s) ? (avail < 1 ? avail : 1) : (ps_min(s) - ps_act(s));  // getNumTasksToAllocate :145-153
                 int got = 0;
-                for (int i = 0; i < np && got < max_tasks; i++) { int p = cx().j_pods_sorted[first + i]; if (cx().p_podset[p] == s && should_allocate(p, real)) { cx().tta[first + out++] = p; got++; } }
+                for (int i = 0; i < np && got < max_tasks; i++) { int p = cx().j_pods_sorted[first + i]; if (cx().p_podset[p] == s && should_allocate(p, real) && job_has_pod(j, p)) { cx().tta[first + out++] = p; got++; } }
                 n_sg++;
             }
             if (nps > 64) for (int k = 64; k < nps; k++) cx().scratch[first + (k - 64)] = 0;
@@ -716,7 +836,12 @@ struct Engine {
         const QShare* L = &cx().q_share[(size_t)q * 3];
         int bj = best_job_from_node(q);
         double req[3] = {0, 0, 0};
-        if (bj >= 0) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)bj * 4 + k]; }
+        double sub[3] = {0, 0, 0}; bool victims = false;
+        if constexpr (kVictim) if (el().jo_kind && bj >= 0) {  // getVictimsForQueue :336-346: the jobs popped from the leaf so far plus its next job
+            victims = true; int leaf = cx().j_queue[bj]; double a[3]; view_allocated(bj, a);
+            for (int k = 0; k < 3; k++) sub[k] = sx().vq_pop[leaf * 3 + k] + a[k];
+        }
+        if (bj >= 0 && !victims) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)bj * 4 + k]; }
         uint32_t bits = 0;
         bool over = true, starved = true, viol = false;
         for (int k = 0; k < 3; k++) {
@@ -727,6 +852,7 @@ struct Engine {
         }
         if (over) bits |= QF_OVER; if (starved) bits |= QF_STARVED; if (viol) bits |= QF_VIOL;
         double dwj = dominant_share(q, req);  // :178-196, 242-273; the share without the job (:198-212) is computed on demand
+        if constexpr (kVictim) if (victims) dwj = dominant_share_x(q, nullptr, sub);
         QNode& n = el().qn[q];
         n.best_job = bj; n.dom_with_job = dwj;
         n.flags = (n.flags & ~(QF_OVER | QF_STARVED | QF_VIOL | QF_DNJ)) | bits | QF_VALID;
@@ -803,16 +929,22 @@ struct Engine {
     // for jobs that come back with a changed key (allocate.go:69-72).  Inner nodes order their children with the proportion
     // comparator, which is not a total order in every corner, so they stay array heaps with container/heap's exact sift rules
     // (scheduler_util/priority_queue.go) and the lazy needsReorder protocol.
+    // leaf storage of the job-order tree: the context's arrays, or (victim search) those of the active instance
+    KAI_HD auto lq_sorted() const { if constexpr (kVictim) return el().i_sorted; else return cx().lq_sorted; }
+    KAI_HD auto lq_cur() const { if constexpr (kVictim) return el().i_cur; else return cx().lq_cur; }
+    KAI_HD auto lq_end() const { if constexpr (kVictim) return el().i_end; else return cx().lq_end; }
+    KAI_HD auto lq_side() const { if constexpr (kVictim) return el().i_side; else return cx().lq_side; }
+    KAI_HD auto lq_side_len() const { if constexpr (kVictim) return el().i_side_len; else return cx().lq_side_len; }
     KAI_HD bool q_is_leaf(int q) const { return el().qn[q].flags & QF_LEAF; }
-    KAI_HD int leaf_len_mem(int q) const { return (cx().lq_end[q] - cx().lq_cur[q]) + cx().lq_side_len[q]; }
+    KAI_HD int leaf_len_mem(int q) const { return (lq_end()[q] - lq_cur()[q]) + lq_side_len()[q]; }
     KAI_HD int leaf_top(int q) const {
-        int a = cx().lq_cur[q] < cx().lq_end[q] ? cx().lq_sorted[cx().q_job_off[q] + cx().lq_cur[q]] : -1;
-        int b = cx().lq_side_len[q] > 0 ? cx().lq_side[cx().q_job_off[q]] : -1;
+        int a = lq_cur()[q] < lq_end()[q] ? lq_sorted()[cx().q_job_off[q] + lq_cur()[q]] : -1;
+        int b = lq_side_len()[q] > 0 ? lq_side()[cx().q_job_off[q]] : -1;
         if (a < 0) return b;
         if (b < 0) return a;
-        return job_order(b, a) ? b : a;
+        return job_less(b, a) ? b : a;
     }
-    struct JobLess { const Engine* e; KAI_HD bool operator()(int a, int b) const { return e->job_order(a, b); } };
+    struct JobLess { const Engine* e; KAI_HD bool operator()(int a, int b) const { return e->job_less(a, b); } };
     struct NodeLess { Engine* e; KAI_HD bool operator()(int a, int b) const { return e->node_less(a, b); } };
     template <class Less> KAI_HD void heap_up(int32_t* h, int j, Less less) {
         for (;;) { int i = (j - 1) / 2; if (i == j || !less(h[j], h[i])) break; int t = h[i]; h[i] = h[j]; h[j] = t; j = i; }
@@ -829,21 +961,26 @@ struct Engine {
         return i > i0;
     }
     KAI_HD int leaf_pop(int q) {
-        int a = cx().lq_cur[q] < cx().lq_end[q] ? cx().lq_sorted[cx().q_job_off[q] + cx().lq_cur[q]] : -1;
-        int b = cx().lq_side_len[q] > 0 ? cx().lq_side[cx().q_job_off[q]] : -1;
+        int a = lq_cur()[q] < lq_end()[q] ? lq_sorted()[cx().q_job_off[q] + lq_cur()[q]] : -1;
+        int b = lq_side_len()[q] > 0 ? lq_side()[cx().q_job_off[q]] : -1;
         el().qn[q].len--; el().qn[q].flags &= ~QF_TOP;
-        if (b < 0 || (a >= 0 && !job_order(b, a))) { cx().lq_cur[q]++; return a; }
-        int32_t* h = cx().lq_side + cx().q_job_off[q]; int n = cx().lq_side_len[q] - 1;
-        int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); cx().lq_side_len[q] = n;
+        if (b < 0 || (a >= 0 && !job_less(b, a))) { lq_cur()[q]++; return a; }
+        int32_t* h = lq_side() + cx().q_job_off[q]; int n = lq_side_len()[q] - 1;
+        int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); lq_side_len()[q] = n;
         return b;
     }
     KAI_HD void leaf_push(int q, int j) {
-        int32_t* h = cx().lq_side + cx().q_job_off[q]; int n = cx().lq_side_len[q];
+        int32_t* h = lq_side() + cx().q_job_off[q]; int n = lq_side_len()[q];
         if (n >= cx().q_job_off[q + 1] - cx().q_job_off[q]) { fault(FAULT_HEAP); return; }
-        h[n] = j; cx().lq_side_len[q] = n + 1; heap_up(h, n, JobLess{this});
+        h[n] = j; lq_side_len()[q] = n + 1; heap_up(h, n, JobLess{this});
         el().qn[q].len++; el().qn[q].flags &= ~QF_TOP;
     }
     KAI_HD bool node_less(int l, int r) {  // buildNodeOrderFn :280-305
+        if constexpr (kVictim) if (el().jo_kind) {  // reverseOrder
+            if (el().qn[l].len == 0) return false;
+            if (el().qn[r].len == 0) return true;
+            return !queue_order_fn(l, r);
+        }
         if (el().qn[l].len == 0) return true;
         if (el().qn[r].len == 0) return false;
         return queue_order_fn(l, r);
@@ -929,11 +1066,11 @@ struct Engine {
     }
     KAI_HD void truncate_leaf(int q, int depth) {  // PriorityQueue.Push with a finite maxQueueSize under sorted pushes keeps the best `depth` jobs
         while (leaf_len_mem(q) > depth) {
-            int a = cx().lq_cur[q] < cx().lq_end[q] ? cx().lq_sorted[cx().q_job_off[q] + cx().lq_end[q] - 1] : -1;
-            int32_t* h = cx().lq_side + cx().q_job_off[q]; int n = cx().lq_side_len[q], wi = -1;
+            int a = lq_cur()[q] < lq_end()[q] ? lq_sorted()[cx().q_job_off[q] + lq_end()[q] - 1] : -1;
+            int32_t* h = lq_side() + cx().q_job_off[q]; int n = lq_side_len()[q], wi = -1;
             for (int i = 0; i < n; i++) if (wi < 0 || job_order(h[wi], h[i])) wi = i;
-            if (wi < 0 || (a >= 0 && job_order(h[wi], a))) { cx().lq_end[q]--; continue; }
-            h[wi] = h[n - 1]; cx().lq_side_len[q] = n - 1;
+            if (wi < 0 || (a >= 0 && job_order(h[wi], a))) { lq_end()[q]--; continue; }
+            h[wi] = h[n - 1]; lq_side_len()[q] = n - 1;
             for (int i = (n - 1) / 2; i >= 0; i--) heap_down(h, i, n - 1, JobLess{this});
         }
         el().qn[q].len = leaf_len_mem(q); el().qn[q].flags &= ~QF_TOP;
@@ -1140,7 +1277,7 @@ struct Engine {
         if (tc_req >= L || tc_pref >= L) return 0;  // a level the topology does not have
         bool restrict_active = false;
         if (tc_req >= 0) {  // hasActiveAllocatedTasks && required level: only sub-trees that already hold an active pod of these pod-sets (:321-347)
-            for (int k = 0; k < c.j_n_ps[j]; k++) { int s2 = c.j_first_ps[j] + k; if ((ps >= 0 ? s2 == ps : podset_in_group(s2, grp)) && c.s_active_alloc[s2] > 0) restrict_active = true; }
+            for (int k = 0; k < c.j_n_ps[j]; k++) { int s2 = c.j_first_ps[j] + k; if ((ps >= 0 ? s2 == ps : podset_in_group(s2, grp)) && ps_act(s2) > 0) restrict_active = true; }
         }
         KAI_GP(int32_t) chosen = c.dom_tmp + DT;      // 1 = allocatable domain of a relevant level
         for (int d = 0; d < DT; d++) chosen[d] = 0;
@@ -1295,10 +1432,10 @@ struct Engine {
     // node-set bitmaps of the DFS: slot d holds the set the frame at depth d is currently trying; `restricted[d]` tells whether any frame
     // up to depth d narrowed the set (otherwise the set is "every node" and scans may use the class index)
     KAI_HD KAI_GP(const uint32_t) frame_bits(int depth) { return el_restricted(depth) ? (KAI_GP(const uint32_t))(cx().ns_bits + (size_t)depth * cx().W) : (KAI_GP(const uint32_t))nullptr; }
-    KAI_HD KAI_GP(const uint32_t) el_parent_bits(int depth) { return depth == 0 ? (KAI_GP(const uint32_t))nullptr : frame_bits(depth - 1); }
+    KAI_HD KAI_GP(const uint32_t) el_parent_bits(int depth) { return depth == 0 ? el().base_bits : frame_bits(depth - 1); }
     KAI_HD bool el_restricted(int depth) const { return (el().restricted >> depth) & 1u; }
     KAI_HD void set_frame_bits(int depth, int dom) {
-        bool parent_restricted = depth > 0 && el_restricted(depth - 1);
+        bool parent_restricted = depth > 0 ? el_restricted(depth - 1) : (el().base_bits != nullptr);
         if (dom < 0 && !parent_restricted) { el().restricted &= ~(1u << depth); return; }  // still every node
         build_node_set(cx().ns_bits + (size_t)depth * cx().W, el_parent_bits(depth), dom);
         el().restricted |= 1u << depth;
@@ -1477,6 +1614,10 @@ struct Engine {
         }
         cx().st->prof[7] += be.clock() - t0;
     }
+
+    // ------------------------------------------------------------------ reclaim / preempt / consolidation
+#include "kai_engine_solver.inc"
+
 };
 
 // ======================================================================================================
@@ -1591,6 +1732,7 @@ KAI_HD uint8_t job_init_state(const KaiCtx& c, int j) {
     int q = c.j_queue[j];
     if (q < 0 || c.q_child_off[q + 1] != c.q_child_off[q]) return 3;  // queue missing or not a leaf
     if (c.j_n_pending[j] == 0) return 3;                               // FilterNonPending
+    if (c.action == KAI_ACTION_CONSOLIDATION && !c.j_preempt[j]) return 3;  // FilterNonPreemptible (consolidation.go:41-46)
     bool exactly = true, below = false;
     for (int k = 0; k < c.j_n_ps[j]; k++) {
         int s = c.j_first_ps[j] + k;

@@ -171,6 +171,63 @@ def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill
     return snap
 
 
+def make_crowded_snapshot(n_nodes, seed, *, fill=0.9, n_pending_jobs=12, queue_levels=(2, 2), hog_frac=0.6, elastic_frac=0.3,
+                          nonpreempt_frac=0.1, cpu_only_frac=0.0) -> abi.Snapshot:
+    """A nearly full cluster for the victim actions (reclaim / preempt / consolidation): ~`fill` of the GPUs are held by
+    Running gangs (1-4 pods x 1-4 GPUs, some elastic = more pods than minAvailable), `hog_frac` of them in the first leaf queue so that
+    it sits over its fair share; pending gangs wait in every queue with mixed priorities (train 50 / build 100 non-preemptible)."""
+    rng = np.random.default_rng(seed)
+    R, N = 4, n_nodes
+    alloc = np.zeros((R, N)); alloc[abi.RES_CPU] = 64000.0; alloc[abi.RES_MEM] = 512 * GIB; alloc[abi.RES_GPU] = 8.0; alloc[abi.RES_PODS] = 110
+    free = np.full(N, 8.0)
+    qt = _queue_tree(list(queue_levels), rng, 8.0 * N)
+    leaves = qt["leaves"]
+    jobs = []  # (queue, prio, preemptible, min_available, [(gpus, status, node)])
+    target = fill * 8.0 * N
+    while 8.0 * N - free.sum() < target:
+        size = int(rng.integers(1, 5)); g = float(rng.choice([1, 1, 2, 4]))
+        pods = []
+        for _ in range(size):
+            cand = np.nonzero(free >= g)[0]
+            if len(cand) == 0:
+                break
+            n = int(rng.choice(cand)); free[n] -= g; pods.append((g, "Running", n))
+        if not pods:
+            break
+        q = int(leaves[0]) if rng.random() < hog_frac else int(rng.choice(leaves))
+        nonpre = rng.random() < nonpreempt_frac
+        mn = len(pods) if (len(pods) < 2 or rng.random() >= elastic_frac) else max(1, len(pods) // 2)
+        jobs.append((q, int(rng.choice([100, 125])) if nonpre else int(rng.choice([50, 60, 75])), 0 if nonpre else 1, mn, pods))
+    for _ in range(n_pending_jobs):
+        size = int(rng.integers(1, 4)); g = 0.0 if rng.random() < cpu_only_frac else float(rng.choice([1, 2, 4, 8]))
+        nonpre = rng.random() < nonpreempt_frac
+        jobs.append((int(rng.choice(leaves)), int(rng.choice([100, 125])) if nonpre else int(rng.choice([50, 60, 75])), 0 if nonpre else 1, size,
+                     [(g, "Pending", -1)] * size))
+    order = rng.permutation(len(jobs)); jobs = [jobs[i] for i in order]
+    J = len(jobs); sizes = np.array([len(j[4]) for j in jobs], np.int32); P = int(sizes.sum())
+    first_pod = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
+    pod_req = np.zeros((R, P)); pod_status = np.zeros(P, np.int32); pod_node = np.full(P, -1, np.int32)
+    p = 0
+    for j in jobs:
+        for g, st, n in j[4]:
+            pod_req[abi.RES_GPU, p] = g; pod_req[abi.RES_CPU, p] = 4000.0 * g if g > 0 else 2000.0; pod_req[abi.RES_MEM, p] = 16 * GIB * max(g, 0.25); pod_req[abi.RES_PODS, p] = 1.0
+            pod_status[p] = abi.POD_STATUS[st]; pod_node[p] = n; p += 1
+    snap = abi.Snapshot(n_res=R); a = snap.arrays
+    a["node_allocatable"] = alloc; a["node_flags"] = np.zeros(N, np.uint32); a["node_gpu_count"] = np.full(N, 8, np.int32); a["node_name_rank"] = np.arange(N, dtype=np.uint32)
+    a["pod_req"] = pod_req; a["pod_job"] = np.repeat(np.arange(J, dtype=np.int32), sizes); a["pod_podset"] = np.repeat(np.arange(J, dtype=np.int32), sizes)
+    a["pod_status"] = pod_status; a["pod_node"] = pod_node; a["pod_uid_rank"] = np.arange(P, dtype=np.uint32)
+    a["podset_job"] = np.arange(J, dtype=np.int32); a["podset_min_available"] = np.array([j[3] for j in jobs], np.int32); a["podset_name_rank"] = np.zeros(J, np.uint32)
+    a["job_queue"] = np.array([j[0] for j in jobs], np.int32); a["job_priority"] = np.array([j[1] for j in jobs], np.int32)
+    a["job_preemptible"] = np.array([j[2] for j in jobs], np.int32)
+    a["job_created_ns"] = (rng.permutation(J).astype(np.int64) + 1) * 60_000_000_000; a["job_uid_rank"] = np.arange(J, dtype=np.uint32)
+    a["job_first_pod"] = first_pod; a["job_n_pods"] = sizes; a["job_first_podset"] = np.arange(J, dtype=np.int32); a["job_n_podsets"] = np.ones(J, np.int32)
+    a["queue_parent"] = qt["parent"]; a["queue_priority"] = qt["prio"]; a["queue_created_ns"] = qt["created"]; a["queue_uid_rank"] = np.arange(len(qt["parent"]), dtype=np.uint32)
+    a["queue_deserved"] = qt["deserved"]; a["queue_limit"] = qt["limit"]; a["queue_oqw"] = qt["oqw"]; a["queue_usage"] = qt["usage"]
+    snap.node_names = [f"node-{i:06d}" for i in range(N)]; snap.queue_names = qt["names"]
+    snap.finalize()
+    return snap
+
+
 def config(idx: int, scale: float = 1.0, seed_offset: int = 0) -> tuple[abi.Snapshot, abi.KaiConfig, str]:
     """BASELINE.json configs[idx] (0-based) → (snapshot, config, description).  `scale` shrinks node and pod counts together."""
     seed = SEED0 + idx + seed_offset

@@ -6,6 +6,8 @@
 // This is NOT a CPU fallback: libkai_core never contains it, the package never loads it, and every
 // parity claim is made by the `-m gpu` tests through the C ABI on a real MI355X.
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,6 +19,7 @@ using namespace kai;
 namespace {
 
 struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.hpp)
+    static constexpr bool kVictim = true;
     const KaiCtx* cref = nullptr; EngineLocal loc;
     void bind(const KaiCtx& c) { cref = &c; }
     const KaiCtx& ctx() const { return *cref; }
@@ -216,15 +219,20 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     };
     if (shares_open) fill(shares_open);
     if (c.use_index) for (int b = 0; b < c.NB; b++) for (int k = 0; k < c.C; k++) HostBackend::build_block(c, k, b);  // k_index_build
+    c.max_consolidation_preemptees = cfg->max_consolidation_preemptees; c.allow_consolidating_reclaim = cfg->allow_consolidating_reclaim; c.saturation_multiplier = cfg->reclaimer_saturation_multiplier;
+    { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; }
     HostBackend be; Engine<HostBackend> eng(c, be);
     for (int i = 0; i < n_actions; i++) {
-        if (actions[i] != KAI_ACTION_ALLOCATE) return KAI_ERR_UNSUPPORTED;
+        if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;
+        if (actions[i] != KAI_ACTION_ALLOCATE && cfg->use_scheduling_signatures) return KAI_ERR_UNSUPPORTED;
+        c.action = actions[i]; { int d = cfg->queue_depth[actions[i]]; c.queue_depth = d > 0 ? d : 0; }
         for (int j = 0; j < J; j++) { c.j_state[j] = job_init_state(c, j); if (c.j_state[j] != 3 && c.j_n_ps[j] <= 64) eng.ensure_tta(j, true); }  // k_job_init
         for (int q = 0; q < Q; q++) {                                      // k_leaf_init
             int b = c.q_job_off[q], e = c.q_job_off[q + 1], cnt = 0; c.lq_side_len[q] = 0;
             for (int x = b; x < e; x++) { int j = c.jobs_static[x]; int st = c.j_state[j]; if (st == 0) c.lq_sorted[b + cnt++] = j; else if (st != 3) eng.leaf_push(q, j); }
             c.lq_cur[q] = 0; c.lq_end[q] = cnt; qnode_init(c, q, cnt + c.lq_side_len[q]);
         }
+        if (actions[i] != KAI_ACTION_ALLOCATE) { eng.execute_victim_action(); continue; }
         eng.execute_allocate();
         if (c.st->drain_pending) {                                         // k_drain
             for (int x = 0; x < J; x++) {
@@ -239,7 +247,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     }
     auto t1 = std::chrono::steady_clock::now();
     if (elapsed_ms_out) *elapsed_ms_out = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    if (c.st->fault) return KAI_ERR_DEVICE_FAULT;
+    if (c.st->fault) { if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: engine fault %d at line %d\n", c.st->fault, c.st->fault_line); return KAI_ERR_DEVICE_FAULT; }
     if (n_ops) *n_ops = c.st->out_len;
     if (ops_out) { if (c.st->out_len > ops_cap) return KAI_ERR_CAPACITY; std::memcpy(ops_out, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)); for (int64_t i = 0; i < c.st->out_len; i++) if (ops_out[i].node >= 0) ops_out[i].node = prep.perm[ops_out[i].node]; }
     if (pod_status_out) std::memcpy(pod_status_out, c.p_status, (size_t)P * 4);

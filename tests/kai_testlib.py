@@ -49,7 +49,7 @@ class Oracle:
     def lib(cls):
         if cls._lib is None:
             so = os.path.join(ROOT, "oracle", "liboracle.so")
-            srcs = [os.path.join(ROOT, "oracle", f) for f in ("kai_oracle.cpp", "oracle_model.hpp", "oracle_session.hpp")]
+            srcs = [os.path.join(ROOT, "oracle", f) for f in ("kai_oracle.cpp", "oracle_model.hpp", "oracle_session.hpp", "oracle_solver.hpp")]
             if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
                 subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
             lib = C.CDLL(so)
@@ -159,7 +159,8 @@ def case_to_snapshot(case, actions=("allocate",)):
     topo_names = [t["ObjectMeta"]["Name"] for t in topologies]
     topo_levels = [[lv["NodeLabel"] for lv in t["Spec"]["Levels"]] for t in topologies]
     mocks = case.get("Mocks") or {}
-    cfg = abi.default_config(max_consolidation_preemptees=-1)  # test_utils_builder.go:78-79
+    cfg = abi.default_config(max_consolidation_preemptees=-1)  # test_utils_builder.go:73-79: SchedulerParams carries only the queue label key
+    cfg.use_scheduling_signatures = 0
     # addSessionPlugins (test_utils_builder.go:297-321): "predicates" is skipped unless a cache mock exists
     cache_mock = bool(mocks) and mocks.get("CacheRequirements") is not None and mocks.get("Cache") is None
     plugins = abi.PLUGIN_ALL

@@ -21,7 +21,7 @@ class HostSim(T.Oracle):
         if cls._sim is None:
             so = os.path.join(T.ROOT, "tests", "host_sim", "libhostsim.so")
             src = os.path.join(T.ROOT, "tests", "host_sim", "host_sim.cpp")
-            deps = [src] + [os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", f) for f in ("kai_engine.hpp", "kai_host_prep.hpp")]
+            deps = [src] + [os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", f) for f in ("kai_engine.hpp", "kai_engine_solver.inc", "kai_host_prep.hpp")]
             if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
                 subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", so, src])
             raw = C.CDLL(so)
@@ -43,7 +43,11 @@ def assert_same(res, ref):
         assert np.array_equal(res.nodes[k], ref.nodes[k]), k
 
 
-GOLD = [(n, i, c, T.load_golden(n)["actions"]) for n in ("allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology")
+GOLD_FILES = ("allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology",
+              "reclaim__reclaim", "reclaim__reclaimDepartments", "reclaim__reclaimGang", "reclaim__reclaim_elastic", "reclaim__reclaim_sub_group",
+              "preempt__preempt", "preempt__preemptGang", "preempt__preempt_elastic", "preempt__preempt_subgroups",
+              "consolidation__consolidation", "consolidation__consolidation_subgroups")
+GOLD = [(n, i, c, T.load_golden(n)["actions"]) for n in GOLD_FILES
         for i, c in enumerate(T.load_golden(n)["cases"])]
 
 
@@ -73,3 +77,17 @@ def test_hostsim_random_small(seed):
     for strat in (T.abi.BINPACK, T.abi.SPREAD):
         cfg = T.abi.default_config(gpu_strategy=strat, cpu_strategy=strat, k_value=float(seed % 3) * 0.5)
         assert_same(HostSim.run(snap, cfg), T.Oracle.run(snap, cfg))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_hostsim_victim_actions_crowded_cluster(seed):
+    snap = T.pkg.synth.make_crowded_snapshot(6 + seed % 17, 1000 + seed, fill=0.85 + 0.1 * (seed % 2), queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3],
+                                             cpu_only_frac=0.2 if seed % 5 == 0 else 0.0)
+    cfg = T.abi.default_config(max_consolidation_preemptees=-1 if seed % 2 else 16)
+    cfg.use_scheduling_signatures = 0; cfg.allow_consolidating_reclaim = int(seed % 3 != 0)
+    evictions = 0
+    for actions in (("reclaim",), ("preempt",), ("consolidation",), ("allocate", "consolidation", "reclaim", "preempt")):
+        ref = T.Oracle.run(snap, cfg, actions)
+        assert_same(HostSim.run(snap, cfg, actions), ref)
+        evictions += sum(1 for o in ref.ops if o[0] == 2)
+    assert evictions > 0 or seed % 17 < 2  # the generator must actually exercise the victim search

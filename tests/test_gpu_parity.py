@@ -42,7 +42,11 @@ def assert_same(res, ref):
         assert np.array_equal(res.nodes[k], ref.nodes[k]), k
 
 
-GOLD = [(n, i, c, T.load_golden(n)["actions"]) for n in ("allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology")
+GOLD_FILES = ("allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology",
+              "reclaim__reclaim", "reclaim__reclaimDepartments", "reclaim__reclaimGang", "reclaim__reclaim_elastic", "reclaim__reclaim_sub_group",
+              "preempt__preempt", "preempt__preemptGang", "preempt__preempt_elastic", "preempt__preempt_subgroups",
+              "consolidation__consolidation", "consolidation__consolidation_subgroups")
+GOLD = [(n, i, c, T.load_golden(n)["actions"]) for n in GOLD_FILES
         for i, c in enumerate(T.load_golden(n)["cases"])]
 
 
@@ -181,3 +185,20 @@ def test_gpu_best_node_with_node_sets(gpu):
                 assert lib.kai_oracle_best_node(C.byref(cfg), C.byref(s), pod, words, int(trial % 3 == 0), C.byref(node), C.byref(pipe)) == 0
                 assert got == (node.value, bool(pipe.value)), (strat, trial, pod, got, node.value, pipe.value)
             ssn.close()
+
+
+def crowded(seed):
+    snap = T.pkg.synth.make_crowded_snapshot(6 + seed % 17, 1000 + seed, fill=0.85 + 0.1 * (seed % 2), queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3],
+                                             cpu_only_frac=0.2 if seed % 5 == 0 else 0.0)
+    cfg = T.abi.default_config(max_consolidation_preemptees=-1 if seed % 2 else 16)
+    cfg.use_scheduling_signatures = 0; cfg.allow_consolidating_reclaim = int(seed % 3 != 0)
+    return snap, cfg
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("actions", [("reclaim",), ("preempt",), ("consolidation",), ("allocate", "consolidation", "reclaim", "preempt")], ids=lambda a: "+".join(a))
+def test_gpu_victim_actions_crowded_cluster(gpu, seed, actions):
+    """reclaim / preempt / consolidation (scenario solver) on a nearly full cluster: committed evictions, pipelines and allocations,
+    pod states, node accounting and queue shares identical to the oracle; the full action list runs in ONE session like a scheduling cycle."""
+    snap, cfg = crowded(seed)
+    assert_same(run_gpu(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
