@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 B_NODE, B_POD_OUT = 128, 80  # algorithmic bytes per node of the node set / per decision
 
-CONFIGS = {"C1": 0, "C2": 1, "C3": 2, "C5": 4}
+CONFIGS = {"C1": 0, "C2": 1, "C3": 2, "C4": 3, "C5": 4}
 
 
 def pmc_traffic(workload):
@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("KAI_BENCH_CONFIG", "C5"), choices=sorted(CONFIGS))
     ap.add_argument("--scale", type=float, default=float(os.environ.get("KAI_BENCH_SCALE", "1.0")))
+    ap.add_argument("--actions", default="", help="comma-separated actions of one cycle (default: allocate; C4: allocate,consolidation,reclaim)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="decisions the CPU oracle is timed on (-1 = auto, 0 = skip)")
     args = ap.parse_args()
 
@@ -65,6 +66,7 @@ def main():
     pkg.load_library()
 
     idx = CONFIGS[args.config]
+    actions = tuple(a for a in (args.actions or ("allocate,consolidation,reclaim" if args.config == "C4" else "allocate")).split(",") if a)
     t0 = time.time()
     snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=pkg.dist.shard_seed(0, rank))  # every rank schedules its own shard
     gen_s = time.time() - t0
@@ -84,11 +86,14 @@ def main():
         nonlocal decisions, placed
         ssn.reset()
         o_ms = ssn.stats().upload_ms
-        ops = ssn.execute("allocate")
-        st = ssn.stats()
+        n_ops, n_dec, k_ms_sum, st = 0, 0, 0.0, None
+        for a in actions:  # one scheduling cycle: the configured actions in order on the same session
+            n_ops += len(ssn.execute(a))
+            s_a = ssn.stats(); n_dec += int(s_a.decisions); k_ms_sum += s_a.kernel_ms
+            st = s_a if st is None else st  # the engine counters reported below are the allocate action's
         if record:
-            kernel_ms.append(st.kernel_ms); open_ms.append(o_ms)
-            decisions = int(st.decisions); placed = int(len(ops))
+            kernel_ms.append(k_ms_sum); open_ms.append(o_ms)
+            decisions = n_dec; placed = n_ops
         return st
 
     for _ in range(args.warmup):
@@ -109,7 +114,7 @@ def main():
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     lat = sorted((a + b) for a, b in zip(kernel_ms, open_ms))
     out = {
-        "metric": "pod placement decisions/sec (allocate action, synthetic snapshot)", "value": value, "unit": "decisions/s",
+        "metric": "pod placement decisions/sec (" + " + ".join(actions) + (" action" if len(actions) == 1 else " actions") + ", synthetic snapshot)", "value": value, "unit": "decisions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "nodes": N, "pods": snap.n_pods, "jobs": snap.n_jobs, "queues": snap.n_queues,
@@ -131,11 +136,11 @@ def main():
         # bounded sample: the oracle walks the SAME snapshot in the same fair order and stops after `sample` decisions
         sample = args.cpu_sample if args.cpu_sample > 0 else max(200, int(3e8 / max(N, 1)))  # about 10-20 s of single-thread oracle work
         c2 = T.abi.KaiConfig.from_buffer_copy(cfg)
-        c2.reserved[0] = sample
-        ref = T.Oracle.run(snap, c2, ("allocate",))
+        c2.reserved[0] = sample  # bounds the allocate action only; the victim actions of a C4 run are timed in full (keep --scale small)
+        ref = T.Oracle.run(snap, c2, actions)
         done = int(ref.stats.decisions)
         out["cpu_baseline"] = {"value": done / (ref.elapsed_ms * 1e-3), "unit": "decisions/s", "cores": 1, "kind": "port",
-                               "sample": f"first {done} decisions of the same snapshot in {ref.elapsed_ms / 1e3:.1f} s (oracle/liboracle.so, single thread, incl. session open)"}
+                               "sample": f"{'first ' if actions == ('allocate',) else ''}{done} decisions of the same snapshot in {ref.elapsed_ms / 1e3:.1f} s (oracle/liboracle.so, single thread, incl. session open; actions: {', '.join(actions)})"}
     if rank == 0:
         print(json.dumps(out))
     pkg.dist.finish()

@@ -228,6 +228,39 @@ def make_crowded_snapshot(n_nodes, seed, *, fill=0.9, n_pending_jobs=12, queue_l
     return snap
 
 
+def add_topology(snap: abi.Snapshot, seed: int, zones: int = 8, racks_per_zone: int = 40, req_rack_frac: float = 0.5, pref_rack_frac: float = 0.2) -> abi.Snapshot:
+    """Label the nodes `zone / rack` (one Topology CR with levels [zone, rack], plugins/topology/topology_plugin.go:57-110) and give a
+    fraction of the pending gangs a topology constraint on their root sub-group set: requiredLevel = rack, or preferredLevel = rack with
+    requiredLevel = zone (BASELINE config 4)."""
+    rng = np.random.default_rng(seed ^ 0x70B0)
+    a = snap.arrays
+    N, J, S = snap.n_nodes, snap.n_jobs, snap.n_podsets
+    racks = max(1, min(zones * racks_per_zone, N))
+    zones = max(1, min(zones, racks))
+    rack_of = (np.arange(N, dtype=np.int64) * racks // max(N, 1)).astype(np.int32)      # contiguous name ranges per rack
+    zone_of = (rack_of.astype(np.int64) * zones // racks).astype(np.int32)
+    # domains: zones first (level row 0), then racks (level row 1, parent = its zone); ids "z%03d" / "z%03d.r%04d" rank like their indices
+    a["topo_level_off"] = np.array([0, 2], np.int32)
+    a["node_domain"] = np.stack([zone_of, zones + rack_of]).astype(np.int32)
+    rack_zone = np.zeros(racks, np.int32); rack_zone[rack_of] = zone_of
+    a["domain_level"] = np.concatenate([np.zeros(zones, np.int32), np.ones(racks, np.int32)])
+    a["domain_parent"] = np.concatenate([np.full(zones, -1, np.int32), rack_zone])
+    a["domain_id_rank"] = np.concatenate([np.arange(zones), np.arange(racks)]).astype(np.uint32)
+    # one root sub-group set per job (jobs_fake/jobs.go:116-123), every pod-set directly under it
+    pending = np.zeros(J, bool); np.logical_or.at(pending, a["pod_job"], a["pod_status"] == abi.POD_STATUS["Pending"])
+    u = rng.random(J)
+    req_rack = pending & (a["job_n_pods"] >= 2) & (u < req_rack_frac)
+    pref_rack = pending & (a["job_n_pods"] >= 2) & ~req_rack & (u < req_rack_frac + pref_rack_frac)
+    a["group_job"] = np.arange(J, dtype=np.int32); a["group_parent"] = np.full(J, -1, np.int32); a["group_name_rank"] = np.zeros(J, np.uint32)
+    a["group_topology"] = np.where(req_rack | pref_rack, 0, -1).astype(np.int32)
+    a["group_required_level"] = np.where(req_rack, 1, np.where(pref_rack, 0, -1)).astype(np.int32)
+    a["group_preferred_level"] = np.where(pref_rack, 1, -1).astype(np.int32)
+    a["job_root_group"] = np.arange(J, dtype=np.int32)
+    a["podset_group"] = a["podset_job"].astype(np.int32)
+    a["podset_topology"] = np.full(S, -1, np.int32); a["podset_required_level"] = np.full(S, -1, np.int32); a["podset_preferred_level"] = np.full(S, -1, np.int32)
+    return snap.finalize()
+
+
 def config(idx: int, scale: float = 1.0, seed_offset: int = 0) -> tuple[abi.Snapshot, abi.KaiConfig, str]:
     """BASELINE.json configs[idx] (0-based) → (snapshot, config, description).  `scale` shrinks node and pod counts together."""
     seed = SEED0 + idx + seed_offset
@@ -246,4 +279,9 @@ def config(idx: int, scale: float = 1.0, seed_offset: int = 0) -> tuple[abi.Snap
         s = make_snapshot(n(65536), n(1000000), seed, queue_levels=(8, 16, 16), prefill=0.3, zipf=True, limits_frac=0.2, queue_prios=(100, 200),
                           oqws=(1.0, 2.0, 4.0), nonpreempt_frac=0.1, usage_max=0.3)
         return s, abi.default_config(k_value=0.5), f"C5 {n(65536)}n x {n(1000000)}p full chain + time-based fair-share"
-    raise ValueError("config 3 (topology + consolidation) needs the topology plugin — not built yet")
+    if idx == 3:   # C4: 10k x 100k, zone/rack topology, cluster 85 % full of preemptible Running jobs; actions allocate, consolidation, reclaim
+        s = make_snapshot(n(10000), n(100000), seed, queue_levels=(10, 10), prefill=0.85, zipf=True, limits_frac=0.2, queue_prios=(100, 200),
+                          oqws=(1.0, 2.0, 4.0), nonpreempt_frac=0.1)
+        add_topology(s, seed, zones=min(8, max(1, n(8))), racks_per_zone=max(1, min(40, n(10000) // (8 * 4))))
+        return s, abi.default_config(k_value=0.0, max_consolidation_preemptees=16), f"C4 {n(10000)}n x {n(100000)}p zone/rack topology + consolidation + reclaim"
+    raise ValueError(f"no BASELINE config {idx}")

@@ -91,3 +91,13 @@ def test_hostsim_victim_actions_crowded_cluster(seed):
         assert_same(HostSim.run(snap, cfg, actions), ref)
         evictions += sum(1 for o in ref.ops if o[0] == 2)
     assert evictions > 0 or seed % 17 < 2  # the generator must actually exercise the victim search
+
+
+@pytest.mark.parametrize("scale", [0.003, 0.01])
+def test_hostsim_config4_topology_consolidation_reclaim(scale):
+    """BASELINE config 4 (scaled): zone/rack topology constraints on the pending gangs, a cluster 85 % full of preemptible Running jobs,
+    one cycle = allocate, consolidation, reclaim."""
+    snap, cfg, _ = T.pkg.synth.config(3, scale)
+    cfg.use_scheduling_signatures = 0
+    acts = ("allocate", "consolidation", "reclaim")
+    assert_same(HostSim.run(snap, cfg, acts), T.Oracle.run(snap, cfg, acts))

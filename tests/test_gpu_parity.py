@@ -202,3 +202,14 @@ def test_gpu_victim_actions_crowded_cluster(gpu, seed, actions):
     pod states, node accounting and queue shares identical to the oracle; the full action list runs in ONE session like a scheduling cycle."""
     snap, cfg = crowded(seed)
     assert_same(run_gpu(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
+
+
+@pytest.mark.parametrize("scale", [0.003, 0.01])
+def test_gpu_config4_topology_consolidation_reclaim(gpu, scale):
+    """BASELINE config 4 (scaled): topology-constrained gangs on a cluster 85 % full of preemptible jobs; allocate, consolidation, reclaim in one session."""
+    snap, cfg, _ = T.pkg.synth.config(3, scale)
+    cfg.use_scheduling_signatures = 0
+    acts = ("allocate", "consolidation", "reclaim")
+    ref = T.Oracle.run(snap, cfg, acts)
+    assert any(o[0] == 2 for o in ref.ops)  # the cycle really evicts
+    assert_same(run_gpu(snap, cfg, acts), ref)
