@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KAI_ABI_VERSION 2u
+#define KAI_ABI_VERSION 3u
 
 /* resource vector layout: api/resource_info/resource_vector.go:23-36 (cpu, memory, gpu, pods, extras…) */
 #define KAI_RES_CPU 0
@@ -231,6 +231,12 @@ typedef struct kai_snapshot_soa {
     const int32_t* podset_topology;   /* [S] the pod-set's own constraint */
     const int32_t* podset_required_level;
     const int32_t* podset_preferred_level;
+
+    /* ---- scheduling-constraints signature (api/podgroup_info/job_info.go:547-570, api/pod_info/scheduling_constraints_signature.go) ----
+     * [J] any injective id of the job's signature (the reference hashes node selector, affinity, tolerations, priority class, ...).
+     * Only equality is used (actions/common/minimal_job_comparison.go:15-44).  NULL: the victim actions refuse to run with
+     * use_scheduling_signatures set. */
+    const int64_t* job_signature;
 } kai_snapshot_soa;
 
 typedef struct kai_op {

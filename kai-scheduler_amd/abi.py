@@ -12,7 +12,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-KAI_ABI_VERSION = 2
+KAI_ABI_VERSION = 3
 RES_CPU, RES_MEM, RES_GPU, RES_PODS = 0, 1, 2, 3
 MAX_RES = 8
 Q_CPU, Q_MEM, Q_GPU = 0, 1, 2
@@ -98,6 +98,7 @@ class KaiSnapshotSoA(C.Structure):
         ("group_topology", _P(C.c_int32)), ("group_required_level", _P(C.c_int32)), ("group_preferred_level", _P(C.c_int32)),
         ("job_root_group", _P(C.c_int32)), ("podset_group", _P(C.c_int32)), ("podset_topology", _P(C.c_int32)),
         ("podset_required_level", _P(C.c_int32)), ("podset_preferred_level", _P(C.c_int32)),
+        ("job_signature", _P(C.c_int64)),
     ]
 
 
@@ -148,6 +149,7 @@ _SPEC_OPT = [
     ("group_job", np.int32), ("group_parent", np.int32), ("group_name_rank", np.uint32), ("group_topology", np.int32),
     ("group_required_level", np.int32), ("group_preferred_level", np.int32), ("job_root_group", np.int32), ("podset_group", np.int32),
     ("podset_topology", np.int32), ("podset_required_level", np.int32), ("podset_preferred_level", np.int32),
+    ("job_signature", np.int64),
 ]
 
 

@@ -251,6 +251,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     { int d = core->cfg.queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
     c.action = KAI_ACTION_ALLOCATE; c.max_consolidation_preemptees = core->cfg.max_consolidation_preemptees; c.allow_consolidating_reclaim = core->cfg.allow_consolidating_reclaim;
     c.saturation_multiplier = core->cfg.reclaimer_saturation_multiplier; c.sv = SolverCtx{}; core->solver_ready = false;
+    c.use_signatures = core->cfg.use_scheduling_signatures ? 1 : 0; c.j_signature = nullptr;
+    if (s->job_signature) TRY(dupload_f(core, c.j_signature, s->job_signature, (size_t)J));
     TRY(dupload_f(core, c.cls, prep.classes.data(), prep.classes.size()));
     TRY(dzero_f(core, c.sum1_key, (size_t)std::max(c.C, 1) * std::max(c.NB, 1))); TRY(dzero_f(core, c.sum1_node, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)));
 
@@ -356,7 +358,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
     if (action < KAI_ACTION_ALLOCATE || action > KAI_ACTION_PREEMPT) return fail(core, KAI_ERR_INVALID_ARG, "unknown action");
     const bool victim = action != KAI_ACTION_ALLOCATE;
-    if (victim && core->cfg.use_scheduling_signatures) return fail(core, KAI_ERR_UNSUPPORTED, "useSchedulingSignatures is not built (MinimalJobRepresentatives, actions/common/minimal_job_comparison.go)");
+    if (victim && core->cfg.use_scheduling_signatures && !core->ctx.j_signature) return fail(core, KAI_ERR_UNSUPPORTED, "use_scheduling_signatures needs kai_snapshot_soa.job_signature (actions/common/minimal_job_comparison.go)");
     HIP_TRY(core, hipSetDevice(core->device));
     KaiCtx& c = core->ctx;
     if (victim && !core->solver_ready) {  // scratch of the victim search, kept for the rest of the session

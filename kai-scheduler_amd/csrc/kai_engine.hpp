@@ -159,6 +159,7 @@ struct SolverCtx {
     uint32_t *feas, *feas0;                           // [W] byPodSolver.feasibleNodes / JobSolver.feasibleNodes as node bitmaps
     double* ig_idle; int32_t* ig_sorted;              // [N], [P] AccumulatedIdleGpus state
     QShare* q_sim;                                    // [Q][3] proportion.jobSimulationQueues
+    int32_t *mjr_q, *mjr_job;                         // [J] MinimalJobRepresentatives: (queue or -1, representative job) per signature met so far
     double *rc_rem, *rc_ent; int32_t* rc_ent_q; uint8_t *rc_has, *rc_inv;  // reclaimable validator scratch
     int32_t P_cap;
 };
@@ -172,7 +173,7 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W) {
     for (int i = 0; i < 7; i++) add(sizeof(int32_t) * (P + 1));
     add(sizeof(uint32_t) * (W + 1)); add(sizeof(uint32_t) * (W + 1));
     add(sizeof(double) * (N + 1)); add(sizeof(int32_t) * (P + 1));
-    add(sizeof(QShare) * 3 * (Q + 1));
+    add(sizeof(QShare) * 3 * (Q + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (J + 1));
     add(sizeof(double) * 3 * (Q + 1)); add(sizeof(double) * 3 * (2 * (size_t)P + J + 2)); add(sizeof(int32_t) * (2 * (size_t)P + J + 2)); add(Q + 1); add(Q + 1);
     return b + 64;
 }
@@ -194,7 +195,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     v.tmp2 = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.tmp3 = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.feas = (uint32_t*)take(sizeof(uint32_t) * (W + 1)); v.feas0 = (uint32_t*)take(sizeof(uint32_t) * (W + 1));
     v.ig_idle = (double*)take(sizeof(double) * (N + 1)); v.ig_sorted = (int32_t*)take(sizeof(int32_t) * (P + 1));
-    v.q_sim = (QShare*)take(sizeof(QShare) * 3 * (Q + 1));
+    v.q_sim = (QShare*)take(sizeof(QShare) * 3 * (Q + 1)); v.mjr_q = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.mjr_job = (int32_t*)take(sizeof(int32_t) * (J + 1));
     v.rc_rem = (double*)take(sizeof(double) * 3 * (Q + 1)); v.rc_ent = (double*)take(sizeof(double) * 3 * (2 * (size_t)P + J + 2));
     v.rc_ent_q = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)P + J + 2)); v.rc_has = (uint8_t*)take(Q + 1); v.rc_inv = (uint8_t*)take(Q + 1);
     v.P_cap = P;
@@ -255,7 +256,8 @@ struct KaiCtx {
     KAI_GP(double) sg_score;                                         // [KAI_TKEYS][D+T] node score of a domain at the key's preferred level, <0 = not scored
     KAI_GP(int32_t) sg_key, sg_row;                                  // [KAI_TKEYS] sub-group key and its preferred level row
     // victim actions
-    int32_t action, max_consolidation_preemptees, allow_consolidating_reclaim, pad6; double saturation_multiplier;
+    int32_t action, max_consolidation_preemptees, allow_consolidating_reclaim, use_signatures; double saturation_multiplier;
+    KAI_GP(const int64_t) j_signature;  // [J] scheduling-constraints signature id (null when the snapshot has none)
     SolverCtx sv;
 };
 

@@ -161,6 +161,7 @@ def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill
     a["podset_job"] = podset_job; a["podset_min_available"] = podset_min; a["podset_name_rank"] = podset_rank
     a["job_queue"] = job_queue; a["job_priority"] = job_prio; a["job_preemptible"] = (job_prio < 100).astype(np.int32)
     a["job_created_ns"] = created; a["job_uid_rank"] = np.arange(J, dtype=np.uint32)
+    a["job_signature"] = job_prio.astype(np.int64)  # the synthetic pods carry no selector / affinity / toleration: the priority class is what distinguishes signatures
     a["job_first_pod"] = first_pod; a["job_n_pods"] = job_sizes; a["job_first_podset"] = first_ps; a["job_n_podsets"] = n_ps
     a["queue_parent"] = qt["parent"]; a["queue_priority"] = qt["prio"]; a["queue_created_ns"] = qt["created"]
     a["queue_uid_rank"] = np.arange(len(qt["parent"]), dtype=np.uint32)
@@ -219,6 +220,7 @@ def make_crowded_snapshot(n_nodes, seed, *, fill=0.9, n_pending_jobs=12, queue_l
     a["podset_job"] = np.arange(J, dtype=np.int32); a["podset_min_available"] = np.array([j[3] for j in jobs], np.int32); a["podset_name_rank"] = np.zeros(J, np.uint32)
     a["job_queue"] = np.array([j[0] for j in jobs], np.int32); a["job_priority"] = np.array([j[1] for j in jobs], np.int32)
     a["job_preemptible"] = np.array([j[2] for j in jobs], np.int32)
+    a["job_signature"] = a["job_priority"].astype(np.int64)
     a["job_created_ns"] = (rng.permutation(J).astype(np.int64) + 1) * 60_000_000_000; a["job_uid_rank"] = np.arange(J, dtype=np.uint32)
     a["job_first_pod"] = first_pod; a["job_n_pods"] = sizes; a["job_first_podset"] = np.arange(J, dtype=np.int32); a["job_n_podsets"] = np.ones(J, np.int32)
     a["queue_parent"] = qt["parent"]; a["queue_priority"] = qt["prio"]; a["queue_created_ns"] = qt["created"]; a["queue_uid_rank"] = np.arange(len(qt["parent"]), dtype=np.uint32)

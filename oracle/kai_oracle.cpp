@@ -93,6 +93,7 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
     for (int j = 0; j < J; j++) {
         PodGroupInfo& g = jobs[j]; g.idx = j; g.uidRank = s->job_uid_rank[j]; g.queue = s->job_queue[j]; g.priority = s->job_priority[j];
         g.preemptible = s->job_preemptible[j] != 0; g.createdNs = s->job_created_ns[j];
+        g.signature = s->job_signature ? s->job_signature[j] : 0; hasSignatures = s->job_signature != nullptr;
         g.rootGroup = s->n_groups > 0 ? s->job_root_group[j] : j;
         for (int k = 0; k < s->job_n_podsets[j]; k++) g.podSets.push_back(&podsets[s->job_first_podset[j] + k]);
         std::sort(g.podSets.begin(), g.podSets.end(), [](PodSet* a, PodSet* b) { return a->nameRank < b->nameRank; });
@@ -1096,7 +1097,9 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
     for (int i = 0; i < n_actions; i++) {
         switch (actions[i]) {
             case KAI_ACTION_ALLOCATE: ssn.executeAllocate(); break;
-            case KAI_ACTION_CONSOLIDATION: case KAI_ACTION_RECLAIM: case KAI_ACTION_PREEMPT: ssn.executeVictimAction(actions[i]); break;
+            case KAI_ACTION_CONSOLIDATION: case KAI_ACTION_RECLAIM: case KAI_ACTION_PREEMPT:
+                if (cfg->use_scheduling_signatures && !ssn.hasSignatures) return KAI_ERR_UNSUPPORTED;  // same rule as libkai_core
+                ssn.executeVictimAction(actions[i]); break;
             default: return KAI_ERR_UNSUPPORTED;
         }
     }

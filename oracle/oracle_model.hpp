@@ -181,6 +181,7 @@ struct PodGroupInfo {
     bool isClone = false;          // CloneWithTasks representative (job_info.go:477-510): same UID, own pod-sets over a subset of the tasks
     int64_t signature = 0;         // GetSchedulingConstraintsSignature (job_info.go:547-570): any injective id of the constraint set
     std::vector<PodInfo*> AllPods() const { std::vector<PodInfo*> v; for (auto* ps : podSets) for (auto& kv : ps->podInfos) v.push_back(kv.second); return v; }
+    std::vector<PodInfo*> AllPodsByIndex() const { std::map<int, PodInfo*> m; for (auto* ps : podSets) for (auto& kv : ps->podInfos) m[kv.first] = kv.second; std::vector<PodInfo*> v; for (auto& kv : m) v.push_back(kv.second); return v; }
     bool IsPreemptibleJob() const { return preemptible; }
     void invalidateTasksCache() { hasTasksToAllocate = false; tasksToAllocate.clear(); hasInitResource = false; }
     PodSet* podSetByIdx(int k) const { for (auto* ps : podSets) if (ps->idx == k) return ps; return nullptr; }

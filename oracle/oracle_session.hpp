@@ -69,6 +69,7 @@ struct Session {
     int nRealDomains = 0;
     std::map<int, std::map<int, double>> subGroupNodeScores;  // key: group idx, or -(podset idx + 1)
     std::vector<uint8_t> classFit; int nPodClasses = 0, nNodeClasses = 0;
+    bool hasSignatures = false;  // the snapshot carries job_signature
     // proportion plugin state (plugins/proportion/proportion.go:52-65)
     ResourceQuantities totalResource{0, 0, 0};
     std::vector<QueueAttributes> qattrs;

@@ -370,10 +370,17 @@ inline std::vector<int> Session::FeasibleNodesForJob(PodGroupInfo* job) {
 // ---------------------------------------------------------------- common/minimal_job_comparison.go
 struct MinimalJobRepresentatives {
     std::map<int64_t, PodGroupInfo*> representatives;
-    static std::vector<const ResourceRequirements*> sortedRequests(PodGroupInfo* g) {  // :101-112 (sort.Slice with LessEqual as "less")
-        std::vector<const ResourceRequirements*> v; auto it = g->podStatusIndex.find(Pending);
-        if (it != g->podStatusIndex.end()) for (auto& kv : it->second) v.push_back(&kv.second->resReq);
-        std::stable_sort(v.begin(), v.end(), [](const ResourceRequirements* a, const ResourceRequirements* b) { return reqLessEqual(*a, *b) && !reqLessEqual(*b, *a); });
+    // extractSortedResourceRequests :101-112: sort.Slice with the NON-strict LessEqual as "less" over GetPendingTasks(), which ranges a
+    // map — the reference's own order is not defined for incomparable requests.  Canonical choice (same in the engine): the pending
+    // pods in index order, stable insertion sort by the strict part of the comparator.
+    static std::vector<const ResourceRequirements*> sortedRequests(PodGroupInfo* g) {
+        std::vector<const ResourceRequirements*> v;
+        for (auto* t : g->AllPodsByIndex()) if (t->status == Pending) v.push_back(&t->resReq);
+        for (size_t i = 1; i < v.size(); i++) {
+            const ResourceRequirements* x = v[i]; size_t k = i;
+            while (k > 0 && reqLessEqual(*x, *v[k - 1]) && !reqLessEqual(*v[k - 1], *x)) { v[k] = v[k - 1]; k--; }
+            v[k] = x;
+        }
         return v;
     }
     static bool reqLessEqual(const ResourceRequirements& a, const ResourceRequirements& b) {  // resource_requirment.go:106-124

@@ -219,12 +219,13 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     };
     if (shares_open) fill(shares_open);
     if (c.use_index) for (int b = 0; b < c.NB; b++) for (int k = 0; k < c.C; k++) HostBackend::build_block(c, k, b);  // k_index_build
+    c.use_signatures = cfg->use_scheduling_signatures ? 1 : 0; c.j_signature = s->job_signature ? copy(pool, s->job_signature, J) : nullptr;
     c.max_consolidation_preemptees = cfg->max_consolidation_preemptees; c.allow_consolidating_reclaim = cfg->allow_consolidating_reclaim; c.saturation_multiplier = cfg->reclaimer_saturation_multiplier;
     { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; }
     HostBackend be; Engine<HostBackend> eng(c, be);
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;
-        if (actions[i] != KAI_ACTION_ALLOCATE && cfg->use_scheduling_signatures) return KAI_ERR_UNSUPPORTED;
+        if (actions[i] != KAI_ACTION_ALLOCATE && cfg->use_scheduling_signatures && !s->job_signature) return KAI_ERR_UNSUPPORTED;
         c.action = actions[i]; { int d = cfg->queue_depth[actions[i]]; c.queue_depth = d > 0 ? d : 0; }
         for (int j = 0; j < J; j++) { c.j_state[j] = job_init_state(c, j); if (c.j_state[j] != 3 && c.j_n_ps[j] <= 64) eng.ensure_tta(j, true); }  // k_job_init
         for (int q = 0; q < Q; q++) {                                      // k_leaf_init

@@ -84,7 +84,7 @@ def test_hostsim_victim_actions_crowded_cluster(seed):
     snap = T.pkg.synth.make_crowded_snapshot(6 + seed % 17, 1000 + seed, fill=0.85 + 0.1 * (seed % 2), queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3],
                                              cpu_only_frac=0.2 if seed % 5 == 0 else 0.0)
     cfg = T.abi.default_config(max_consolidation_preemptees=-1 if seed % 2 else 16)
-    cfg.use_scheduling_signatures = 0; cfg.allow_consolidating_reclaim = int(seed % 3 != 0)
+    cfg.use_scheduling_signatures = seed % 2; cfg.allow_consolidating_reclaim = int(seed % 3 != 0)  # MinimalJobRepresentatives on for odd seeds
     evictions = 0
     for actions in (("reclaim",), ("preempt",), ("consolidation",), ("allocate", "consolidation", "reclaim", "preempt")):
         ref = T.Oracle.run(snap, cfg, actions)
@@ -98,6 +98,5 @@ def test_hostsim_config4_topology_consolidation_reclaim(scale):
     """BASELINE config 4 (scaled): zone/rack topology constraints on the pending gangs, a cluster 85 % full of preemptible Running jobs,
     one cycle = allocate, consolidation, reclaim."""
     snap, cfg, _ = T.pkg.synth.config(3, scale)
-    cfg.use_scheduling_signatures = 0
     acts = ("allocate", "consolidation", "reclaim")
     assert_same(HostSim.run(snap, cfg, acts), T.Oracle.run(snap, cfg, acts))
