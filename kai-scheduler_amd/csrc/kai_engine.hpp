@@ -835,6 +835,9 @@ struct Engine {
     // operands of queue_order.GetQueueOrderResult for queue q with the best job of its subtree, cached until q's shares or best job change
     KAI_HD void queue_key(int q) {
         if (el().qn[q].flags & QF_VALID) return;
+#ifdef KAI_PROF_POP
+        int64_t tk0 = be.clock(); cx().st->prof[8]++;
+#endif
         const QShare* L = &cx().q_share[(size_t)q * 3];
         int bj = best_job_from_node(q);
         double req[3] = {0, 0, 0};
@@ -858,6 +861,9 @@ struct Engine {
         QNode& n = el().qn[q];
         n.best_job = bj; n.dom_with_job = dwj;
         n.flags = (n.flags & ~(QF_OVER | QF_STARVED | QF_VIOL | QF_DNJ)) | bits | QF_VALID;
+#ifdef KAI_PROF_POP
+        cx().st->prof[9] += be.clock() - tk0;
+#endif
     }
     KAI_HD double dom_no_job(int q) {
         QNode& n = el().qn[q];
@@ -992,7 +998,15 @@ struct Engine {
     KAI_HD void set_heap_len(int parent, int n) { if (parent < 0) el().root_len = n; else el().qn[parent].len = n; }
     KAI_HD void node_heap_push(int parent, int q) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); h[n] = q; set_heap_len(parent, n + 1); heap_up(h, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
     KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent) - 1; set_heap_len(parent, n); int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
-    KAI_HD void node_heap_fix0(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); if (!heap_down(h, 0, n, NodeLess{this})) heap_up(h, 0, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
+    KAI_HD void node_heap_fix0(int parent) {
+#ifdef KAI_PROF_POP
+        int64_t tf0 = be.clock(); cx().st->prof[11]++;
+#endif
+        int32_t* h = node_heap(parent); int n = node_heap_len(parent); if (!heap_down(h, 0, n, NodeLess{this})) heap_up(h, 0, NodeLess{this}); if (parent >= 0) invalidate_path(parent);
+#ifdef KAI_PROF_POP
+        cx().st->prof[10] += be.clock() - tf0;
+#endif
+    }
 
     KAI_HD void ensure_ancestor_chain(int child) {  // :134-176
         for (;;) {
@@ -1489,6 +1503,9 @@ struct Engine {
             for (int r = 0; r < KAI_MAX_RES; r++) f.req[i][r] = r < cx().R ? preq(p, r) : 0.0;
         }
         if (bad) return -1;
+#ifdef KAI_PROF_POP
+        int64_t ts0 = be.clock();
+#endif
         const bool prop = cx().plugins & KAI_PLUGIN_PROPORTION;
         int d = 0;
         for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
@@ -1502,6 +1519,10 @@ struct Engine {
             for (int i = 0; i < nt; i++) { req[KAI_Q_GPU] += frame_quota(f.req[i], KAI_Q_GPU); req[KAI_Q_CPU] += frame_quota(f.req[i], KAI_Q_CPU); req[KAI_Q_MEM] += frame_quota(f.req[i], KAI_Q_MEM); }
             if (frame_over_limit(f, req) || frame_np_over_quota(f, req)) return 0;
         }
+#ifdef KAI_PROF_POP
+        cx().st->prof[13] += be.clock() - ts0;  // frame: queue chain + gate
+        int64_t ts1 = be.clock();
+#endif
         double ja[3] = {cx().j_allocated[(size_t)j * 4 + 0], cx().j_allocated[(size_t)j * 4 + 1], cx().j_allocated[(size_t)j * 4 + 2]};
         const bool preds = cx().plugins & KAI_PLUGIN_PREDICATES;
         int done = 0; bool ok = true;
@@ -1516,12 +1537,17 @@ struct Engine {
             uint64_t key; int n; be.class_top(cx(), f.cls[i], key, n); cx().st->index_queries++;
             if (!key) { el().fail_no_node = true; ok = false; break; }
             // Statement.Allocate :297-358 → NodeInfo.AddTask → addTaskResources (node_info.go:457-493)
-            for (int r = 0; r < cx().R; r++) {
-                double v = rq[r]; if (v == 0) continue;
-                size_t x = (size_t)r * cx().N + n;
-                cx().n_used[x] += v; cx().n_idle[x] -= v;
+            {   // all loads first (independent, one latency), then the stores: same values, same operations
+                double u[KAI_MAX_RES], id[KAI_MAX_RES];
+                for (int r = 0; r < KAI_MAX_RES; r++) if (r < cx().R) { size_t x = (size_t)r * cx().N + n; u[r] = cx().n_used[x]; id[r] = cx().n_idle[x]; }
+                for (int r = 0; r < KAI_MAX_RES; r++) if (r < cx().R) {
+                    double v = rq[r]; if (v == 0) continue;
+                    size_t x = (size_t)r * cx().N + n;
+                    cx().n_used[x] = u[r] + v; cx().n_idle[x] = id[r] - v;
+                }
             }
             mark_dirty(n);
+            flush_index();  // published now, awaited by the next reader of the index: overlaps the bookkeeping below, the commit and the next pop
             if (prop) for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {  // proportion allocate handler :443-465
                 double v = frame_quota(rq, k);
                 f.alloc[l][k] += v;
@@ -1530,6 +1556,9 @@ struct Engine {
             for (int k = 0; k < 3; k++) ja[k] += frame_quota(rq, k);  // PodGroupInfo.Allocated (job_info.go:208-226)
             f.node[i] = n; done++;
         }
+#ifdef KAI_PROF_POP
+        cx().st->prof[14] += be.clock() - ts1;  // task loop
+#endif
         if (ok) {  // Statement.Commit :536-575 + ssn.BindPod: nt Allocate operations in task order
             for (int i = 0; i < nt; i++) {
                 int p = f.p[i], n = f.node[i];
@@ -1544,10 +1573,13 @@ struct Engine {
             for (int i = done - 1; i >= 0; i--) {
                 const double* rq = f.req[i]; int n = f.node[i];
                 for (int k = 0; k < 3; k++) ja[k] -= frame_quota(rq, k);
-                for (int r = 0; r < cx().R; r++) {
-                    double v = rq[r]; if (v == 0) continue;
-                    size_t x = (size_t)r * cx().N + n;
-                    cx().n_used[x] += -1.0 * v; cx().n_idle[x] -= -1.0 * v;
+                {   double u[KAI_MAX_RES], id[KAI_MAX_RES];
+                    for (int r = 0; r < KAI_MAX_RES; r++) if (r < cx().R) { size_t x = (size_t)r * cx().N + n; u[r] = cx().n_used[x]; id[r] = cx().n_idle[x]; }
+                    for (int r = 0; r < KAI_MAX_RES; r++) if (r < cx().R) {
+                        double v = rq[r]; if (v == 0) continue;
+                        size_t x = (size_t)r * cx().N + n;
+                        cx().n_used[x] = u[r] + -1.0 * v; cx().n_idle[x] = id[r] - -1.0 * v;
+                    }
                 }
                 mark_dirty(n);
                 cx().p_accepted[f.p[i]] = 1;  // AcceptedResource stays set after unallocate (node_info.go:746-766)

@@ -255,7 +255,7 @@ struct ActShared {
     unsigned long long top_key[KAI_CMAX]; int32_t top_node[KAI_CMAX];
     unsigned long long __attribute__((address_space(3)))* s2_key; int32_t __attribute__((address_space(3)))* s2_node;  // [C][NSB] in dynamic LDS (typed LDS pointers: ds_read / ds_write)
     QNode* qn; int32_t *qheap, *root_heap;          // job-order tree: dynamic LDS when it fits, else the HBM arrays
-    int32_t tree_in_lds, pad1;
+    int32_t tree_in_lds, in_flight;  // in_flight: a refresh was published and its results not yet awaited (the control lane overlaps it with its own work)
     KAI_GP(const uint32_t) nodeset;  // scope of brute-force scans: node-set bitmap (bit n of word n/32; engine node order), nullptr = all nodes,
     KAI_GP(const double) topo_score; int32_t topo_row, pad2;  // … and preferred-level topology scores per domain of level row topo_row (-1 = none)
     long long t_publish, t_wait, t_svc, t_seg[6];  // profiling: control lane through barrier 1 / barrier 2, service wave 1 busy time
@@ -281,13 +281,22 @@ struct DevBackendT {
     __device__ static const KaiCtx& ctx() { return g_ctx; }
     __device__ static EngineLocal& local() { return g_el; }
     // control lane side -------------------------------------------------------------------------------
-    __device__ void call(int cmd) {
-        sh->cmd = cmd;
-        long long t0 = clock64();
-        __syncthreads();  // publish the command
+    // A command is two workgroup barriers: publish, then results ready.  A refresh is split: refresh() publishes and returns, the
+    // control lane goes on with work that neither reads the index nor touches the dirty list (commit, next pop, frame load), and
+    // wait() passes the second barrier right before the next reader.  Node-state writes in between (a rollback) are followed by
+    // their own mark_dirty + refresh, so a block evaluated mid-update is evaluated again before anyone reads it.
+    __device__ void wait() {
+        if (!sh->in_flight) return;
         long long t1 = clock64();
         __syncthreads();  // results ready
-        if (cmd == CMD_REFRESH) { sh->t_publish += t1 - t0; sh->t_wait += clock64() - t1; }
+        sh->t_wait += clock64() - t1;
+        sh->in_flight = 0; sh->n_dirty = 0;
+    }
+    __device__ void call(int cmd) {
+        wait();
+        sh->cmd = cmd;
+        __syncthreads();  // publish the command
+        __syncthreads();  // results ready
     }
     __device__ void scope() { sh->nodeset = g_el.scope_bits; sh->topo_row = g_el.scope_row; sh->topo_score = g_el.scope_score; }
     __device__ void minmax(const KaiCtx&, int r, double& mn, double& mx) {
@@ -308,22 +317,28 @@ struct DevBackendT {
     }
     __device__ void begin(const KaiCtx& c) { if (c.use_index) call(CMD_BEGIN); }
     __device__ bool dirty_add(int b) {
+        wait();  // the service waves read the list while a refresh is in flight
         int n = sh->n_dirty;
         for (int i = 0; i < n; i++) if (sh->dirty[i] == b) return true;
         if (n == KAI_MAXD) return false;
         sh->dirty[n] = b; sh->n_dirty = n + 1;
         return true;
     }
-    __device__ int dirty_count() { return sh->n_dirty; }
-    __device__ void refresh(const KaiCtx&) { call(CMD_REFRESH); sh->n_dirty = 0; }
-    __device__ void class_top(const KaiCtx&, int k, uint64_t& key, int& node) { key = sh->top_key[k]; node = sh->top_node[k]; }
-    __device__ bool all_dead(const KaiCtx& c) { for (int k = 0; k < c.C; k++) if (sh->top_key[k]) return false; return true; }
+    __device__ int dirty_count() { return sh->in_flight ? 0 : sh->n_dirty; }
+    __device__ void refresh(const KaiCtx&) {  // publish only; see wait()
+        wait();
+        sh->cmd = CMD_REFRESH; long long t0 = clock64();
+        __syncthreads();
+        sh->t_publish += clock64() - t0; sh->in_flight = 1;
+    }
+    __device__ void class_top(const KaiCtx&, int k, uint64_t& key, int& node) { wait(); key = sh->top_key[k]; node = sh->top_node[k]; }
+    __device__ bool all_dead(const KaiCtx& c) { wait(); for (int k = 0; k < c.C; k++) if (sh->top_key[k]) return false; return true; }
     __device__ void hot(const KaiCtx&, QNode*& qn, int32_t*& qheap, int32_t*& root_heap) {
         if (sh->tree_in_lds) call(CMD_LOADTREE);  // service waves copy the k_leaf_init records HBM → LDS
         qn = sh->qn; qheap = sh->qheap; root_heap = sh->root_heap;
     }
     __device__ int64_t clock() { return (int64_t)clock64(); }
-    __device__ void finish() { sh->cmd = CMD_EXIT; __syncthreads(); }
+    __device__ void finish() { wait(); sh->cmd = CMD_EXIT; __syncthreads(); }
 };
 
 using DevBackend = DevBackendT<false>;
@@ -454,7 +469,7 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     const KaiCtx& c = g_ctx;
     ActShared& sh = g_sh;
     if (threadIdx.x == 0) {
-        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = tree_in_lds; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
+        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.in_flight = 0; sh.tree_in_lds = tree_in_lds; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
         size_t off = 0;
         sh.s2_key = (unsigned long long __attribute__((address_space(3)))*)(kai_dyn_lds); sh.s2_node = (int32_t __attribute__((address_space(3)))*)(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
         off = lds_index_bytes(c.C, c.NSB);
@@ -498,7 +513,7 @@ __global__ void __launch_bounds__(WG) k_best_node(KaiCtx cv, int pod, int pipeli
     __syncthreads();
     const KaiCtx& c = g_ctx;
     ActShared& sh = g_sh;
-    if (threadIdx.x == 0) { sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.tree_in_lds = 0; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.s2_key = nullptr; sh.s2_node = nullptr; sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
+    if (threadIdx.x == 0) { sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.in_flight = 0; sh.tree_in_lds = 0; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.s2_key = nullptr; sh.s2_node = nullptr; sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
     __syncthreads();
     if (threadIdx.x >= 64) { service_loop(c, &g_sh); return; }
     if (threadIdx.x != 0) return;
