@@ -817,6 +817,17 @@ struct Engine {
         }
         return dom;
     }
+    KAI_HD double dominant_share_l(const QShare* L, const double* add) const {  // the same on shares already in registers
+        double dom = 0.0;
+        for (int k = 0; k < 3; k++) {
+            double allocatable = qs_allocatable(L[k]);
+            if (allocatable == KAI_UNLIMITED) allocatable = k == 0 ? el().total0 : k == 1 ? el().total1 : el().total2;
+            double allocated = L[k].allocated; if (add) allocated += add[k];
+            double v = allocatable == 0 ? allocated * 1000 : allocated / allocatable;
+            dom = kmax(dom, v);
+        }
+        return dom;
+    }
     KAI_HD static int cmp_q(double a, double b) {  // resource_quantities.go:80-97
         if (a == KAI_UNLIMITED) return b == KAI_UNLIMITED ? 0 : 1;
         if (b == KAI_UNLIMITED) return -1;
@@ -838,7 +849,7 @@ struct Engine {
 #ifdef KAI_PROF_POP
         int64_t tk0 = be.clock(); cx().st->prof[8]++;
 #endif
-        const QShare* L = &cx().q_share[(size_t)q * 3];
+        const QShare L[3] = {cx().q_share[(size_t)q * 3], cx().q_share[(size_t)q * 3 + 1], cx().q_share[(size_t)q * 3 + 2]};  // loaded before the best-job chain: the two overlap
         int bj = best_job_from_node(q);
         double req[3] = {0, 0, 0};
         double sub[3] = {0, 0, 0}; bool victims = false;
@@ -856,7 +867,7 @@ struct Engine {
             if (qs_allocatable(L[k]) == 0 && with_job > 0) viol = true;       // penalizeZeroShareWithJob :127-176
         }
         if (over) bits |= QF_OVER; if (starved) bits |= QF_STARVED; if (viol) bits |= QF_VIOL;
-        double dwj = dominant_share(q, req);  // :178-196, 242-273; the share without the job (:198-212) is computed on demand
+        double dwj = dominant_share_l(L, req);  // :178-196, 242-273; the share without the job (:198-212) is computed on demand
         if constexpr (kVictim) if (victims) dwj = dominant_share_x(q, nullptr, sub);
         QNode& n = el().qn[q];
         n.best_job = bj; n.dom_with_job = dwj;
@@ -1485,11 +1496,14 @@ struct Engine {
     KAI_HD static double frame_quota(const double* rq, int k) { return k == KAI_Q_CPU ? rq[KAI_RES_CPU] : k == KAI_Q_MEM ? rq[KAI_RES_MEM] : rq[KAI_RES_GPU]; }
     KAI_HD int allocate_job_fast(int j) {
         if (!cx().use_index || !cx().fast_ok) return -1;
-        if (cx().j_n_ps[j] != 1 || cx().j_has_topology[j]) return -1;
-        const int s = cx().j_first_ps[j];
+        // every job-level field first: independent loads, one memory latency (the early exits below would serialise them)
+        const int n_ps = cx().j_n_ps[j], has_topo = cx().j_has_topology[j], s = cx().j_first_ps[j], first = cx().j_first_pod[j];
+        const int tta_valid = cx().j_tta_valid[j], tta_n = cx().j_tta_n[j], jq = cx().j_queue[j], jpre = cx().j_preempt[j];
+        const double ja0 = cx().j_allocated[(size_t)j * 4 + 0], ja1 = cx().j_allocated[(size_t)j * 4 + 1], ja2 = cx().j_allocated[(size_t)j * 4 + 2];
+        if (n_ps != 1 || has_topo) return -1;
         if (cx().s_pipelined[s] != 0) return -1;
-        ensure_tta(j, true);
-        const int nt = cx().j_tta_n[j], first = cx().j_first_pod[j];
+        if (!tta_valid) ensure_tta(j, true);
+        const int nt = tta_valid ? tta_n : cx().j_tta_n[j];
         if (nt <= 0 || nt > KAI_FMAX) return -1;
         FastFrame& f = KAI_FRAME;
         const bool nominated = cx().plugins & KAI_PLUGIN_NOMINATEDNODE;
@@ -1508,8 +1522,8 @@ struct Engine {
 #endif
         const bool prop = cx().plugins & KAI_PLUGIN_PROPORTION;
         int d = 0;
-        for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
-        f.depth = d; f.np = !cx().j_preempt[j];
+        for (int q = jq; q >= 0; q = el().qn[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
+        f.depth = d; f.np = !jpre;
         for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {
             const QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k];
             f.alloc[l][k] = sh.allocated; f.alloc_np[l][k] = sh.allocated_np; f.max_allowed[l][k] = sh.max_allowed; f.deserved[l][k] = sh.deserved;
@@ -1523,7 +1537,7 @@ struct Engine {
         cx().st->prof[13] += be.clock() - ts0;  // frame: queue chain + gate
         int64_t ts1 = be.clock();
 #endif
-        double ja[3] = {cx().j_allocated[(size_t)j * 4 + 0], cx().j_allocated[(size_t)j * 4 + 1], cx().j_allocated[(size_t)j * 4 + 2]};
+        double ja[3] = {ja0, ja1, ja2};
         const bool preds = cx().plugins & KAI_PLUGIN_PREDICATES;
         int done = 0; bool ok = true;
         for (int i = 0; i < nt; i++) {  // allocateTask :121-163
