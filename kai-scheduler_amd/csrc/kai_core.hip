@@ -387,13 +387,13 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         const size_t budget = 160 * 1024 - 4096;  // static ActShared + margin
         int tree_in_lds = (idx_b + tree_b <= budget && !std::getenv("KAI_TREE_IN_HBM")) ? 1 : 0;
         size_t dyn = idx_b + (tree_in_lds ? tree_b : 0);
-        if (victim) {
-            HIP_TRY(core, hipFuncSetAttribute(reinterpret_cast<const void*>(k_action<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(k_action<true>, dim3(1), dim3(WG), dyn, core->stream, (const KaiCtx*)core->d_ctx, action, tree_in_lds);
-        } else {
-            HIP_TRY(core, hipFuncSetAttribute(reinterpret_cast<const void*>(k_action<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(k_action<false>, dim3(1), dim3(WG), dyn, core->stream, (const KaiCtx*)core->d_ctx, action, tree_in_lds);
-        }
+        auto launch = [&](auto kernel) -> int {
+            HIP_TRY(core, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(kernel, dim3(1), dim3(WG), dyn, core->stream, (const KaiCtx*)core->d_ctx, action, tree_in_lds);
+            return KAI_OK;
+        };
+        int rcl = victim ? launch(k_action<true, false>) : tree_in_lds ? launch(k_action<false, true>) : launch(k_action<false, false>);
+        if (rcl) return rcl;
     }
     if (c.J && !victim) hipLaunchKernelGGL(k_drain, dim3(std::min(2048, (c.J + TB - 1) / TB)), dim3(TB), 0, core->stream, c, core->d_slot_queue);
     HIP_TRY(core, hipGetLastError());

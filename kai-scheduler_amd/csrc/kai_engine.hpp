@@ -447,6 +447,11 @@ struct Engine {
     KAI_HD EngineLocal& el() const { return be.local(); }
     static constexpr bool kVictim = Backend::kVictim;  // compiled with the victim search (reclaim / preempt / consolidation)
     KAI_HD const SolverCtx& sx() const { return cx().sv; }
+    // the job-order tree through pointers the compiler may treat as LDS pointers when the backend says the tree lives there
+    // (an assumption on a generic pointer: flat_load/flat_store become ds_read/ds_write, which do not wait on global traffic)
+    KAI_HD QNode* qnp() const { QNode* p = el().qn; Backend::assume_tree(p); return p; }
+    KAI_HD int32_t* qheapp() const { int32_t* p = el().qheap; Backend::assume_tree(p); return p; }
+    KAI_HD int32_t* rootheapp() const { int32_t* p = el().root_heap; Backend::assume_tree(p); return p; }
     KAI_HD Engine(const KaiCtx& ctx, Backend& b) : be(b) {
         be.bind(ctx);
         EngineLocal& e = el();
@@ -485,7 +490,7 @@ struct Engine {
         flush_index();  // list full
         be.dirty_add(b);
     }
-    KAI_HD void invalidate_path(int q) { for (int x = q; x >= 0; x = el().qn[x].parent) el().qn[x].flags &= ~QF_VALID; }
+    KAI_HD void invalidate_path(int q) { for (int x = q; x >= 0; x = qnp()[x].parent) qnp()[x].flags &= ~QF_VALID; }
 
     // ------------------------------------------------------------------ status bookkeeping
     // PodGroupInfo.UpdateTaskStatus (api/podgroup_info/job_info.go:228-287) + PodSet.AssignTask (subgroup_info/podset.go:56-99)
@@ -570,13 +575,13 @@ struct Engine {
         if (!(cx().plugins & KAI_PLUGIN_PROPORTION)) return;
         if (!cx().p_accepted[p]) return;  // AcceptedResource is empty until the task was added to a node
         int j = cx().p_job[p]; bool np = !cx().j_preempt[j];
-        for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) {
+        for (int q = cx().j_queue[j]; q >= 0; q = qnp()[q].parent) {
             for (int k = 0; k < 3; k++) {
                 QShare& s = cx().q_share[(size_t)q * 3 + k]; double v = pquota(p, k);
                 s.allocated += sign * v;
                 if (np) s.allocated_np += sign * v;
             }
-            el().qn[q].flags &= ~QF_VALID;
+            qnp()[q].flags &= ~QF_VALID;
         }
     }
 
@@ -836,16 +841,16 @@ struct Engine {
     // getBestJobFromNode :309-318 (pending ordering); a node whose key is valid already knows the best job of its subtree
     KAI_HD int best_job_from_node(int q) {
         for (;;) {
-            const QNode& n = el().qn[q];
+            const QNode& n = qnp()[q];
             if (n.flags & (QF_VALID | QF_TOP)) return n.best_job;
-            if (n.flags & QF_LEAF) { int t = leaf_top(q); el().qn[q].best_job = t; el().qn[q].flags |= QF_TOP; return t; }
+            if (n.flags & QF_LEAF) { int t = leaf_top(q); qnp()[q].best_job = t; qnp()[q].flags |= QF_TOP; return t; }
             if (n.len == 0) return -1;
-            q = el().qheap[n.heap_off];
+            q = qheapp()[n.heap_off];
         }
     }
     // operands of queue_order.GetQueueOrderResult for queue q with the best job of its subtree, cached until q's shares or best job change
     KAI_HD void queue_key(int q) {
-        if (el().qn[q].flags & QF_VALID) return;
+        if (qnp()[q].flags & QF_VALID) return;
 #ifdef KAI_PROF_POP
         int64_t tk0 = be.clock(); cx().st->prof[8]++;
 #endif
@@ -869,7 +874,7 @@ struct Engine {
         if (over) bits |= QF_OVER; if (starved) bits |= QF_STARVED; if (viol) bits |= QF_VIOL;
         double dwj = dominant_share_l(L, req);  // :178-196, 242-273; the share without the job (:198-212) is computed on demand
         if constexpr (kVictim) if (victims) dwj = dominant_share_x(q, nullptr, sub);
-        QNode& n = el().qn[q];
+        QNode& n = qnp()[q];
         n.best_job = bj; n.dom_with_job = dwj;
         n.flags = (n.flags & ~(QF_OVER | QF_STARVED | QF_VIOL | QF_DNJ)) | bits | QF_VALID;
 #ifdef KAI_PROF_POP
@@ -877,14 +882,14 @@ struct Engine {
 #endif
     }
     KAI_HD double dom_no_job(int q) {
-        QNode& n = el().qn[q];
+        QNode& n = qnp()[q];
         if (!(n.flags & QF_DNJ)) { n.dom_no_job = dominant_share(q, nullptr); n.flags |= QF_DNJ; }
         return n.dom_no_job;
     }
     // plugins/proportion/queue_order/queue_order.go:19-73 (allocate ordering: no victims)
     KAI_HD int queue_order(int lq, int rq) {
         queue_key(lq); queue_key(rq);
-        const QNode kl = el().qn[lq]; const QNode kr = el().qn[rq];
+        const QNode kl = qnp()[lq]; const QNode kr = qnp()[rq];
         { bool lo = kl.flags & QF_OVER, ro = kr.flags & QF_OVER; if (!lo && ro) return -1; if (lo && !ro) return 1; }
         { bool ls = kl.flags & QF_STARVED, rs = kr.flags & QF_STARVED; if (ls && !rs) return -1; if (rs && !ls) return 1; }
         if (kl.prio > kr.prio) return -1;  // prioritizePrioritized :76-85
@@ -911,7 +916,7 @@ struct Engine {
         return cx().q_created[lq] < cx().q_created[rq];
     }
     KAI_HD bool over_limit(int j, const double* req) const {  // capacity_policy/max_allowed_check.go:20-66
-        for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) for (int k = 0; k < 3; k++) {
+        for (int q = cx().j_queue[j]; q >= 0; q = qnp()[q].parent) for (int k = 0; k < 3; k++) {
             const QShare& s = cx().q_share[(size_t)q * 3 + k];
             if (s.max_allowed == KAI_UNLIMITED) continue;
             if (req[k] == 0) continue;
@@ -921,7 +926,7 @@ struct Engine {
     }
     KAI_HD bool np_over_quota(int j, const double* req) const {  // capacity_policy/quota_check.go:27-77
         if (cx().j_preempt[j]) return false;
-        for (int q = cx().j_queue[j]; q >= 0; q = el().qn[q].parent) for (int k = 0; k < 3; k++) {
+        for (int q = cx().j_queue[j]; q >= 0; q = qnp()[q].parent) for (int k = 0; k < 3; k++) {
             const QShare& s = cx().q_share[(size_t)q * 3 + k];
             if (s.deserved == KAI_UNLIMITED) continue;
             if (req[k] == 0) continue;
@@ -954,7 +959,7 @@ struct Engine {
     KAI_HD auto lq_end() const { if constexpr (kVictim) return el().i_end; else return cx().lq_end; }
     KAI_HD auto lq_side() const { if constexpr (kVictim) return el().i_side; else return cx().lq_side; }
     KAI_HD auto lq_side_len() const { if constexpr (kVictim) return el().i_side_len; else return cx().lq_side_len; }
-    KAI_HD bool q_is_leaf(int q) const { return el().qn[q].flags & QF_LEAF; }
+    KAI_HD bool q_is_leaf(int q) const { return qnp()[q].flags & QF_LEAF; }
     KAI_HD int leaf_len_mem(int q) const { return (lq_end()[q] - lq_cur()[q]) + lq_side_len()[q]; }
     KAI_HD int leaf_top(int q) const {
         int a = lq_cur()[q] < lq_end()[q] ? lq_sorted()[cx().q_job_off[q] + lq_cur()[q]] : -1;
@@ -982,7 +987,7 @@ struct Engine {
     KAI_HD int leaf_pop(int q) {
         int a = lq_cur()[q] < lq_end()[q] ? lq_sorted()[cx().q_job_off[q] + lq_cur()[q]] : -1;
         int b = lq_side_len()[q] > 0 ? lq_side()[cx().q_job_off[q]] : -1;
-        el().qn[q].len--; el().qn[q].flags &= ~QF_TOP;
+        qnp()[q].len--; qnp()[q].flags &= ~QF_TOP;
         if (b < 0 || (a >= 0 && !job_less(b, a))) { lq_cur()[q]++; return a; }
         int32_t* h = lq_side() + cx().q_job_off[q]; int n = lq_side_len()[q] - 1;
         int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); lq_side_len()[q] = n;
@@ -992,21 +997,21 @@ struct Engine {
         int32_t* h = lq_side() + cx().q_job_off[q]; int n = lq_side_len()[q];
         if (n >= cx().q_job_off[q + 1] - cx().q_job_off[q]) { fault(FAULT_HEAP); return; }
         h[n] = j; lq_side_len()[q] = n + 1; heap_up(h, n, JobLess{this});
-        el().qn[q].len++; el().qn[q].flags &= ~QF_TOP;
+        qnp()[q].len++; qnp()[q].flags &= ~QF_TOP;
     }
     KAI_HD bool node_less(int l, int r) {  // buildNodeOrderFn :280-305
         if constexpr (kVictim) if (el().jo_kind) {  // reverseOrder
-            if (el().qn[l].len == 0) return false;
-            if (el().qn[r].len == 0) return true;
+            if (qnp()[l].len == 0) return false;
+            if (qnp()[r].len == 0) return true;
             return !queue_order_fn(l, r);
         }
-        if (el().qn[l].len == 0) return true;
-        if (el().qn[r].len == 0) return false;
+        if (qnp()[l].len == 0) return true;
+        if (qnp()[r].len == 0) return false;
         return queue_order_fn(l, r);
     }
-    KAI_HD int32_t* node_heap(int parent) { return parent < 0 ? el().root_heap : el().qheap + el().qn[parent].heap_off; }
-    KAI_HD int node_heap_len(int parent) const { return parent < 0 ? el().root_len : el().qn[parent].len; }
-    KAI_HD void set_heap_len(int parent, int n) { if (parent < 0) el().root_len = n; else el().qn[parent].len = n; }
+    KAI_HD int32_t* node_heap(int parent) { return parent < 0 ? rootheapp() : qheapp() + qnp()[parent].heap_off; }
+    KAI_HD int node_heap_len(int parent) const { return parent < 0 ? el().root_len : qnp()[parent].len; }
+    KAI_HD void set_heap_len(int parent, int n) { if (parent < 0) el().root_len = n; else qnp()[parent].len = n; }
     KAI_HD void node_heap_push(int parent, int q) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); h[n] = q; set_heap_len(parent, n + 1); heap_up(h, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
     KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent) - 1; set_heap_len(parent, n); int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
     KAI_HD void node_heap_fix0(int parent) {
@@ -1021,11 +1026,11 @@ struct Engine {
 
     KAI_HD void ensure_ancestor_chain(int child) {  // :134-176
         for (;;) {
-            int parent = el().qn[child].parent;
-            if (parent < 0) { if (!(el().qn[child].flags & QF_LINKED)) { el().root_init = 1; el().qn[child].flags |= QF_LINKED; node_heap_push(-1, child); } return; }
-            bool parent_new = !(el().qn[parent].flags & QF_EXISTS);
-            if (parent_new) { el().qn[parent].flags = (el().qn[parent].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS; el().qn[parent].len = 0; }
-            if (!(el().qn[child].flags & QF_LINKED)) { el().qn[child].flags |= QF_LINKED; node_heap_push(parent, child); }
+            int parent = qnp()[child].parent;
+            if (parent < 0) { if (!(qnp()[child].flags & QF_LINKED)) { el().root_init = 1; qnp()[child].flags |= QF_LINKED; node_heap_push(-1, child); } return; }
+            bool parent_new = !(qnp()[parent].flags & QF_EXISTS);
+            if (parent_new) { qnp()[parent].flags = (qnp()[parent].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS; qnp()[parent].len = 0; }
+            if (!(qnp()[child].flags & QF_LINKED)) { qnp()[child].flags |= QF_LINKED; node_heap_push(parent, child); }
             if (!parent_new) return;
             child = parent;
         }
@@ -1033,28 +1038,28 @@ struct Engine {
     KAI_HD void push_job(int j) {  // :91-120
         int q = cx().j_queue[j];
         if (!q_is_leaf(q)) return;
-        bool needs_linking = !(el().qn[q].flags & QF_EXISTS);
-        if (needs_linking) el().qn[q].flags = (el().qn[q].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS;
+        bool needs_linking = !(qnp()[q].flags & QF_EXISTS);
+        if (needs_linking) qnp()[q].flags = (qnp()[q].flags & ~(QF_REORDER | QF_LINKED)) | QF_EXISTS;
         leaf_push(q, j);
         invalidate_path(q);
         if (needs_linking) ensure_ancestor_chain(q);
-        for (int x = q; x >= 0; x = el().qn[x].parent) el().qn[x].flags |= QF_REORDER;  // markAncestorsForReorder: parent pointers follow the queue tree
+        for (int x = q; x >= 0; x = qnp()[x].parent) qnp()[x].flags |= QF_REORDER;  // markAncestorsForReorder: parent pointers follow the queue tree
     }
     KAI_HD int next_node(int parent) {  // getNextNode :194-217
         for (;;) {
             if (node_heap_len(parent) == 0) return -1;
             int q = node_heap(parent)[0];
-            if (el().qn[q].flags & QF_REORDER) { node_heap_fix0(parent); el().qn[q].flags &= ~QF_REORDER; continue; }
-            if (el().qn[q].len == 0) return -1;
+            if (qnp()[q].flags & QF_REORDER) { node_heap_fix0(parent); qnp()[q].flags &= ~QF_REORDER; continue; }
+            if (qnp()[q].len == 0) return -1;
             return q;
         }
     }
     KAI_HD void handle_pop_from_node(int q) {  // :221-245
         for (;;) {
-            if (el().qn[q].len != 0) { for (int x = q; x >= 0; x = el().qn[x].parent) el().qn[x].flags |= QF_REORDER; return; }
-            int parent = el().qn[q].parent;
+            if (qnp()[q].len != 0) { for (int x = q; x >= 0; x = qnp()[x].parent) qnp()[x].flags |= QF_REORDER; return; }
+            int parent = qnp()[q].parent;
             node_heap_pop(parent);  // removeNodeFromParent: the node is at the top of its parent's heap
-            el().qn[q].flags &= ~(QF_EXISTS | QF_LINKED);
+            qnp()[q].flags &= ~(QF_EXISTS | QF_LINKED);
             if (parent < 0) return;
             q = parent;
         }
@@ -1076,17 +1081,17 @@ struct Engine {
         int b0 = cx().q_child_off[x], b1 = cx().q_child_off[x + 1], best = -1, live = 0;
         for (int i = b0; i < b1; i++) {
             int k = cx().q_children[i];
-            if (el().qn[k].len == 0) continue;
+            if (qnp()[k].len == 0) continue;
             live++;
             if (best < 0 || node_less(k, best)) best = k;
         }
         if (!live) return;
-        if (parent >= 0) el().qn[parent].flags |= QF_EXISTS | QF_REORDER; else el().root_init = 1;
-        el().qn[best].flags |= QF_EXISTS | QF_LINKED | QF_REORDER; node_heap_push(parent, best);
+        if (parent >= 0) qnp()[parent].flags |= QF_EXISTS | QF_REORDER; else el().root_init = 1;
+        qnp()[best].flags |= QF_EXISTS | QF_LINKED | QF_REORDER; node_heap_push(parent, best);
         for (int i = b0; i < b1; i++) {
             int k = cx().q_children[i]; if (k == best) continue;
-            if (el().qn[k].len == 0) continue;
-            el().qn[k].flags |= QF_EXISTS | QF_LINKED | QF_REORDER;
+            if (qnp()[k].len == 0) continue;
+            qnp()[k].flags |= QF_EXISTS | QF_LINKED | QF_REORDER;
             // the heap length of an inner node counts linked children only: children are appended as they are pushed
             node_heap_push(parent, k);
         }
@@ -1100,9 +1105,9 @@ struct Engine {
             h[wi] = h[n - 1]; lq_side_len()[q] = n - 1;
             for (int i = (n - 1) / 2; i >= 0; i--) heap_down(h, i, n - 1, JobLess{this});
         }
-        el().qn[q].len = leaf_len_mem(q); el().qn[q].flags &= ~QF_TOP;
+        qnp()[q].len = leaf_len_mem(q); qnp()[q].flags &= ~QF_TOP;
     }
-    KAI_HD void init_jobs_order() {  // el().qn[] comes from k_leaf_init: static fields, flags = QF_LEAF or 0, len = queued jobs of a leaf, 0 for inner nodes
+    KAI_HD void init_jobs_order() {  // qnp()[] comes from k_leaf_init: static fields, flags = QF_LEAF or 0, len = queued jobs of a leaf, 0 for inner nodes
         el().root_len = 0; el().root_init = 0;
         if (cx().queue_depth > 0) for (int q = 0; q < cx().Q; q++) if (q_is_leaf(q)) truncate_leaf(q, cx().queue_depth);
         for (int i = 0; i < cx().Q; i++) { int x = cx().q_depth_order[i]; if (!q_is_leaf(x)) link_children(x); }
@@ -1522,7 +1527,7 @@ struct Engine {
 #endif
         const bool prop = cx().plugins & KAI_PLUGIN_PROPORTION;
         int d = 0;
-        for (int q = jq; q >= 0; q = el().qn[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
+        for (int q = jq; q >= 0; q = qnp()[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
         f.depth = d; f.np = !jpre;
         for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {
             const QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k];
@@ -1610,7 +1615,7 @@ struct Engine {
             for (int k = 0; k < 3; k++) cx().j_allocated[(size_t)j * 4 + k] = ja[k];
             if (prop) for (int l = 0; l < d; l++) {
                 for (int k = 0; k < 3; k++) { QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k]; sh.allocated = f.alloc[l][k]; sh.allocated_np = f.alloc_np[l][k]; }
-                el().qn[f.q[l]].flags &= ~QF_VALID;
+                qnp()[f.q[l]].flags &= ~QF_VALID;
             }
         }
         return ok ? 1 : 0;

@@ -176,6 +176,7 @@ __global__ void k_index_build(KaiCtx c) {
 // ------------------------------------------------------------------------------------------------------
 struct NullBackend {  // kernels that only need the engine's pure helpers
     static constexpr bool kVictim = false;
+    template <class T> __device__ static void assume_tree(T*) {}
     const KaiCtx* cref = nullptr; EngineLocal loc;
     __device__ void bind(const KaiCtx& c) { cref = &c; }
     __device__ const KaiCtx& ctx() const { return *cref; }
@@ -273,9 +274,17 @@ __device__ __forceinline__ unsigned long long orderable(double d) {
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
-template <bool VICTIM>
+template <bool VICTIM, bool TREE_LDS = false>
 struct DevBackendT {
     static constexpr bool kVictim = VICTIM;  // the victim search (reclaim / preempt / consolidation) is compiled into its own kernel
+    // TREE_LDS: the job-order tree of this launch is in dynamic LDS (never assumed for the victim search, whose other instances are in HBM)
+    template <class T> __device__ static void assume_tree(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (TREE_LDS && !VICTIM) __builtin_assume(__builtin_amdgcn_is_shared((const void*)p));
+#else
+        (void)p;
+#endif
+    }
     ActShared* const sh = &g_sh;  // every use below folds to a direct LDS address
     __device__ static void bind(const KaiCtx&) {}  // k_action copied the context into g_ctx before constructing the engine
     __device__ static const KaiCtx& ctx() { return g_ctx; }
@@ -341,7 +350,7 @@ struct DevBackendT {
     __device__ void finish() { wait(); sh->cmd = CMD_EXIT; __syncthreads(); }
 };
 
-using DevBackend = DevBackendT<false>;
+using DevBackend = DevBackendT<false, false>;
 
 // L2 entry (class k, super-block sb) from the 64 L1 entries below it, then the class top from the L2 row
 __device__ __forceinline__ void svc_l2(const KaiCtx& c, ActShared* sh, int k, int sb, int lane) {
@@ -459,7 +468,7 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
 }
 
 // One workgroup; wave 0 lane 0 = control, waves 1..15 = service.
-template <bool VICTIM>
+template <bool VICTIM, bool TREE_LDS>
 __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, int action, int tree_in_lds) {
     {   // the context into LDS: every pointer fetch of the engine is a ds_read the compiler can batch
         const int* src = reinterpret_cast<const int*>(cp); int* dst = reinterpret_cast<int*>(&g_ctx);
@@ -479,8 +488,8 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     __syncthreads();
     if (threadIdx.x >= 64) { service_loop(c, &g_sh); return; }
     if (threadIdx.x != 0) return;  // the rest of wave 0 idles: s_barrier counts wavefronts, not lanes
-    DevBackendT<VICTIM> be;
-    Engine<DevBackendT<VICTIM>> eng(c, be);
+    DevBackendT<VICTIM, TREE_LDS> be;
+    Engine<DevBackendT<VICTIM, TREE_LDS>> eng(c, be);
     if constexpr (VICTIM) eng.execute_victim_action(); else if (action == KAI_ACTION_ALLOCATE) eng.execute_allocate();
     c.st->prof[1] = sh.t_publish; c.st->prof[6] = sh.t_wait; c.st->prof[PF_PUSH] = sh.t_svc;
     be.finish();

@@ -20,6 +20,7 @@ namespace {
 
 struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.hpp)
     static constexpr bool kVictim = true;
+    template <class T> static void assume_tree(T*) {}
     const KaiCtx* cref = nullptr; EngineLocal loc;
     void bind(const KaiCtx& c) { cref = &c; }
     const KaiCtx& ctx() const { return *cref; }
