@@ -498,3 +498,64 @@ def check_expectations(snap, meta, pod_status, pod_node, nodes=None):
             if nodes["idle"][i, abi.RES_GPU] != float(exp.get("IdleGPUs", 0)):
                 errs.append(f"{nname}: idle gpus {nodes['idle'][i, abi.RES_GPU]} want {exp.get('IdleGPUs', 0)}")
     return errs
+
+
+# ------------------------------------------------------------------------------------------------ integration tests (several rounds)
+CYCLE = ("allocate", "consolidation", "reclaim", "preempt")  # the default action list minus stalegangeviction (checked to be a no-op below)
+
+
+def _stale_gang(snap, pod_status):
+    """PodGroupInfo.IsStale (api/podgroup_info/job_info.go:417-432): some pods active, a pod-set below minAvailable, nothing Succeeded."""
+    S = abi.POD_STATUS
+    active = S["Allocated"] | S["Pipelined"] | S["Binding"] | S["Bound"] | S["Running"] | S["Releasing"]
+    for j in range(snap.n_jobs):
+        b, n = int(snap.job_first_pod[j]), int(snap.job_n_pods[j])
+        st = pod_status[b:b + n]
+        if (st == S["Succeeded"]).any() or not ((st & active) != 0).any():
+            continue
+        for k in range(int(snap.job_first_podset[j]), int(snap.job_first_podset[j] + snap.job_n_podsets[j])):
+            used = int((((st & active) != 0) & (snap.pod_podset[b:b + n] == k)).sum())
+            if used < int(snap.podset_min_available[k]):
+                return True
+    return False
+
+
+def run_integration(case, run_fn, rounds_after=None):
+    """actions/integration_tests/integration_tests_utils/integration_tests_utils.go:40-156: `RoundsUntilMatch` scheduling cycles, each on a
+    session rebuilt from the fixture with the previous cycle's outcome fed back (Binding -> Running, Pipelined / Releasing -> Pending),
+    then the expectations on a rebuilt session and after each of `RoundsAfterMatch` further cycles.  Returns the list of mismatches."""
+    import copy
+    case = copy.deepcopy(case)
+
+    def one_round():
+        snap, cfg, meta = case_to_snapshot(case)
+        res = run_fn(snap, cfg, CYCLE)
+        if _stale_gang(snap, res.pod_status):
+            raise Unsupported("stalegangeviction would act (not a placement action)")
+        for job in case["Jobs"]:
+            for ti, t in enumerate(job.get("Tasks", []) or []):
+                p = snap.pod_names.index(f"{job['Name']}-{ti}")
+                st = abi.POD_STATUS_NAME[int(res.pod_status[p])]
+                node = snap.node_names[res.pod_node[p]] if res.pod_node[p] >= 0 else ""
+                if st == "Releasing":
+                    if job.get("DeleteJobInTest"):
+                        t["NodeName"] = node; t["State"] = "Releasing"
+                    else:
+                        t["NodeName"] = ""; t["State"] = "Pending"
+                elif st == "Pipelined":
+                    t["NodeName"] = ""; t["State"] = "Pending"
+                elif st == "Binding":
+                    t["State"] = "Running"; t["NodeName"] = node
+                else:
+                    t["State"] = st; t["NodeName"] = node
+        return snap, meta, res
+
+    for _ in range(int(case.get("_RoundsUntilMatch", 2))):
+        one_round()
+    snap, cfg, meta = case_to_snapshot(case)  # prepareSessionForMatch: a rebuilt session, nothing run on it
+    res = run_fn(snap, cfg, ())
+    errs = check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes)
+    for _ in range(int(case.get("_RoundsAfterMatch", 5)) if rounds_after is None else rounds_after):
+        snap, meta, res = one_round()
+        errs += check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes)
+    return errs

@@ -100,3 +100,22 @@ def test_hostsim_config4_topology_consolidation_reclaim(scale):
     snap, cfg, _ = T.pkg.synth.config(3, scale)
     acts = ("allocate", "consolidation", "reclaim")
     assert_same(HostSim.run(snap, cfg, acts), T.Oracle.run(snap, cfg, acts))
+
+
+INTEG_FILES = ("integration_tests__allocate__allocate", "integration_tests__allocate__allocate_topology", "integration_tests__reclaim__reclaim",
+               "integration_tests__preempt__preempt", "integration_tests__preempt__preemptGang", "integration_tests__consolidation__consolidation",
+               "integration_tests__consolidation__consolidationGang", "integration_tests__consolidation_and_reclaim__consolidation_and_reclaim")
+INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["cases"])]
+
+
+@pytest.mark.parametrize("name,i,case", INTEG, ids=[f"{n}[{i}]" for n, i, _ in INTEG])
+def test_hostsim_integration_rounds(name, i, case):
+    def run_both(snap, cfg, actions):
+        res = HostSim.run(snap, cfg, actions)
+        assert_same(res, T.Oracle.run(snap, cfg, actions))
+        return res
+    try:
+        errs = T.run_integration(case, run_both, rounds_after=1)
+    except T.Unsupported as e:
+        pytest.skip(str(e))
+    assert not errs, errs[:4]

@@ -212,3 +212,24 @@ def test_gpu_config4_topology_consolidation_reclaim(gpu, scale):
     ref = T.Oracle.run(snap, cfg, acts)
     assert any(o[0] == 2 for o in ref.ops)  # the cycle really evicts
     assert_same(run_gpu(snap, cfg, acts), ref)
+
+
+INTEG_FILES = ("integration_tests__allocate__allocate", "integration_tests__allocate__allocate_topology", "integration_tests__reclaim__reclaim",
+               "integration_tests__preempt__preempt", "integration_tests__preempt__preemptGang", "integration_tests__consolidation__consolidation",
+               "integration_tests__consolidation__consolidationGang", "integration_tests__consolidation_and_reclaim__consolidation_and_reclaim")
+INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["cases"])]
+
+
+@pytest.mark.parametrize("name,i,case", INTEG, ids=[f"{n}[{i}]" for n, i, _ in INTEG])
+def test_gpu_integration_rounds(gpu, name, i, case):
+    """The reference's integration tests: full cycles (allocate, consolidation, reclaim, preempt) over several rounds with state fed back;
+    every round identical to the oracle and the final cluster state as the reference expects."""
+    def run_both(snap, cfg, actions):
+        res = run_gpu(snap, cfg, actions)
+        assert_same(res, T.Oracle.run(snap, cfg, actions))
+        return res
+    try:
+        errs = T.run_integration(case, run_both, rounds_after=1)
+    except T.Unsupported as e:
+        pytest.skip(str(e))
+    assert not errs, errs[:4]

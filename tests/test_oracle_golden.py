@@ -38,3 +38,30 @@ def test_golden_coverage():
         except T.Unsupported:
             pass
     assert ok >= 186, ok
+
+
+INTEG_FILES = ("integration_tests__allocate__allocate", "integration_tests__allocate__allocate_topology", "integration_tests__reclaim__reclaim",
+               "integration_tests__preempt__preempt", "integration_tests__preempt__preemptGang", "integration_tests__consolidation__consolidation",
+               "integration_tests__consolidation__consolidationGang", "integration_tests__consolidation_and_reclaim__consolidation_and_reclaim")
+INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["cases"])]
+
+
+@pytest.mark.parametrize("name,i,case", INTEG, ids=[f"{n}[{i}]" for n, i, _ in INTEG])
+def test_oracle_reproduces_integration_expectations(name, i, case):
+    """The reference's integration tests (actions/integration_tests/*): several scheduling cycles — allocate, consolidation, reclaim,
+    preempt on a session rebuilt each round with the outcome fed back — must end in the expected cluster state and stay there."""
+    try:
+        errs = T.run_integration(case, T.Oracle.run)
+    except T.Unsupported as e:
+        pytest.skip(f"outside the built path: {e}")
+    assert not errs, f"{case.get('Name')} ({name} line {case.get('_line')}): {errs[:4]}"
+
+
+def test_integration_coverage():
+    ok = 0
+    for name, i, case in INTEG:
+        try:
+            T.run_integration(case, T.Oracle.run, rounds_after=0); ok += 1
+        except T.Unsupported:
+            pass
+    assert ok >= 74, ok

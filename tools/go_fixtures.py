@@ -43,6 +43,13 @@ SOURCES = [
     ("actions/consolidation/consolidation_test.go", ["consolidation"]),
     ("actions/consolidation/consolidation_subgroups_test.go", ["consolidation"]),
     ("actions/integration_tests/allocate/allocate_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/allocate/allocate_topology_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/reclaim/reclaim_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/preempt/preempt_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/preempt/preemptGang_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/consolidation/consolidation_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/consolidation/consolidationGang_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/consolidation_and_reclaim/consolidation_and_reclaim_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
 ]
 
 
@@ -413,6 +420,17 @@ def extract(path: str):
             continue
         if isinstance(val, dict) and ("Jobs" in val or "Nodes" in val):
             val["_line"] = line
+            # RoundsUntilMatch / RoundsAfterMatch live on the wrapping TestTopologyMetadata literal (integration tests): the
+            # fields that follow this literal up to the wrapper's closing brace
+            end = p.peek()[2]
+            tail = src[end:end + 400]
+            nxt = tail.find("TestTopologyBasic")
+            if nxt >= 0:
+                tail = tail[:nxt]
+            for fld in ("RoundsUntilMatch", "RoundsAfterMatch"):
+                mm = re.search(fld + r":\s*(\d+)", tail)
+                if mm:
+                    val["_" + fld] = int(mm.group(1))
             out.append(val)
     # RoundsUntilMatch etc. live on the wrapping TestTopologyMetadata literal
     return out
