@@ -198,7 +198,6 @@ struct ScenarioBuilder {
     }
     bool addNextPotentialVictims() {  // :91-133
         PodGroupInfo* nextVictimJob = victimsJobsQueue->PopNextJob();
-        if (getenv("KAI_SOLVER_TRACE")) fprintf(stderr, "  [orc] victim pop job %d (preemptor %d)\n", nextVictimJob->idx, lastScenario ? lastScenario->preemptor->idx : -1);
         bool jobHasMoreTasks = false;
         std::vector<PodInfo*> potentialVictimTasks = ssn->GetTasksToEvict(nextVictimJob, jobHasMoreTasks);
         for (auto* pv : potentialVictimTasks) if (recordedVictimsTasks.count(pv->idx)) {
@@ -254,7 +253,6 @@ struct ByPodSolver {
         bool preemptorAllocated = false;
         while (!jobsToAllocate.IsEmpty()) {
             PodGroupInfo* job = jobsToAllocate.PopNextJob();
-            if (getenv("KAI_SOLVER_TRACE")) fprintf(stderr, "    [orc] ja pop %d\n", job->idx);
             if (!potentialVictims.count(job->idx) && job->idx != pendingJob->idx) continue;
             ssn->GetTasksToAllocateInitResource(job, false);  // evaluated for a log line; fills the job's cache like the reference does
             if (job->idx != pendingJob->idx) { ssn->AllocateJob(stmt, nodes, job, true); continue; }
@@ -265,14 +263,14 @@ struct ByPodSolver {
     }
     Sim runSimulation(Scenario* sc, std::unique_ptr<Statement>& stmt, const std::vector<PodInfo*>& victimTasks, SolutionResult& out) {  // :100-116
         ssn->stats.simulations++;
-        { bool okk = tryScenarioWithEvictedVictims(sc, *stmt, victimTasks); if (getenv("KAI_SOLVER_TRACE")) fprintf(stderr, "  [orc] sim preemptor %d nvt %d -> %d   ops_len %d\n", sc->preemptor->idx, (int)victimTasks.size(), (int)okk, (int)stmt->operations.size()); if (!okk) return simNone; }
+        if (!tryScenarioWithEvictedVictims(sc, *stmt, victimTasks)) return simNone;
         std::vector<PodInfo*> preempted, pipelined;
         for (auto* t : victimTasks) { if (t->status == Releasing) preempted.push_back(t); else if (t->status == Pipelined) pipelined.push_back(t); }
         // handleScenarioSolution :171-197
         std::vector<PodInfo*> victimsTasks = preempted;
         if (!allowVictimConsolidation) victimsTasks.insert(victimsTasks.end(), pipelined.begin(), pipelined.end());
         std::vector<PodGroupInfo*> victimJobs = getVictimJobsFromVictimTasks(victimsTasks, sc);
-        { bool v = !validator || validator(sc); if (getenv("KAI_SOLVER_TRACE")) fprintf(stderr, "  [orc] validator -> %d\n", (int)v); if (!v) { stmt->Discard(); out = SolutionResult{}; return simRejected; } }
+        if (validator && !validator(sc)) { stmt->Discard(); out = SolutionResult{}; return simRejected; }
         if (allowVictimConsolidation) { victimsTasks.insert(victimsTasks.end(), pipelined.begin(), pipelined.end()); victimJobs = getVictimJobsFromVictimTasks(victimsTasks, sc); }
         out.solved = true; out.victimsTasks = victimsTasks; out.victimJobs = victimJobs; out.statement = std::move(stmt);
         return simSolved;
@@ -447,7 +445,6 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 + r
         if (res.empty()) continue;
         auto& dst = totalVictimsResources[victim.Job->queue]; dst.insert(dst.end(), res.begin(), res.end());
     }
-    if (getenv("KAI_SOLVER_TRACE")) for (auto& kv : totalVictimsResources) for (auto& r : kv.second) fprintf(stderr, "      [orc] ent q%d %g %g %g\n", kv.first, r.milliCpu, r.memory, r.gpus);
     auto path = [&](int q) { std::vector<int> p; for (; q >= 0; q = Q[q].parent) p.insert(p.begin(), q); return p; };  // getHierarchyPath :253-262
     // reclaimResourcesFromReclaimees :69-108
     std::map<int, ResourceQuantities> remaining; std::map<int, Involved> involved;
