@@ -138,6 +138,12 @@ typedef struct kai_config {
     int32_t queue_depth[4];               /* per kai_action; -1 = infinite (framework/session.go:398-404) */
     int32_t engine_mode;                  /* 0 = default; 1 = force brute-force node scans; 2 = class index without the staged job path (debug / A-B) */
     int32_t reserved[7];
+    /* minruntime plugin (plugins/minruntime/minruntime.go:40-100): "now" of the cycle, plugin-argument defaults, reclaim resolve method */
+    int64_t now_ns;
+    int64_t default_preempt_min_runtime_ns;
+    int64_t default_reclaim_min_runtime_ns;
+    int32_t reclaim_resolve_method;       /* 0 = lca (default), 1 = queue */
+    int32_t pad0;
 } kai_config;
 
 /* Structure-of-arrays session snapshot.  [R][N] means resource-major: element (r, i) at r*N + i. */
@@ -237,6 +243,13 @@ typedef struct kai_snapshot_soa {
      * Only equality is used (actions/common/minimal_job_comparison.go:15-44).  NULL: the victim actions refuse to run with
      * use_scheduling_signatures set. */
     const int64_t* job_signature;
+
+    /* ---- minruntime plugin inputs (all optional; NULL = nothing is protected) ----
+     * PodGroupInfo.LastStartTimestamp (ns since the epoch, 0 = never started) and the queues' preemptMinRuntime / reclaimMinRuntime
+     * (ns, -1 = not set on that queue; resolved up the tree, plugins/minruntime/resolver.go:33-190) */
+    const int64_t* job_last_start_ns;            /* [J] */
+    const int64_t* queue_preempt_min_runtime_ns; /* [Q] */
+    const int64_t* queue_reclaim_min_runtime_ns; /* [Q] */
 } kai_snapshot_soa;
 
 typedef struct kai_op {

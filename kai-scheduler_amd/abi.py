@@ -48,6 +48,8 @@ class KaiConfig(C.Structure):
         ("max_consolidation_preemptees", C.c_int32), ("use_scheduling_signatures", C.c_int32), ("allow_consolidating_reclaim", C.c_int32),
         ("full_hierarchy_fairness", C.c_int32), ("min_node_gpu_memory", C.c_int64), ("queue_depth", C.c_int32 * 4),
         ("engine_mode", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("now_ns", C.c_int64), ("default_preempt_min_runtime_ns", C.c_int64), ("default_reclaim_min_runtime_ns", C.c_int64),
+        ("reclaim_resolve_method", C.c_int32), ("pad0", C.c_int32),
     ]
 
 
@@ -99,6 +101,7 @@ class KaiSnapshotSoA(C.Structure):
         ("job_root_group", _P(C.c_int32)), ("podset_group", _P(C.c_int32)), ("podset_topology", _P(C.c_int32)),
         ("podset_required_level", _P(C.c_int32)), ("podset_preferred_level", _P(C.c_int32)),
         ("job_signature", _P(C.c_int64)),
+        ("job_last_start_ns", _P(C.c_int64)), ("queue_preempt_min_runtime_ns", _P(C.c_int64)), ("queue_reclaim_min_runtime_ns", _P(C.c_int64)),
     ]
 
 
@@ -149,7 +152,7 @@ _SPEC_OPT = [
     ("group_job", np.int32), ("group_parent", np.int32), ("group_name_rank", np.uint32), ("group_topology", np.int32),
     ("group_required_level", np.int32), ("group_preferred_level", np.int32), ("job_root_group", np.int32), ("podset_group", np.int32),
     ("podset_topology", np.int32), ("podset_required_level", np.int32), ("podset_preferred_level", np.int32),
-    ("job_signature", np.int64),
+    ("job_signature", np.int64), ("job_last_start_ns", np.int64), ("queue_preempt_min_runtime_ns", np.int64), ("queue_reclaim_min_runtime_ns", np.int64),
 ]
 
 

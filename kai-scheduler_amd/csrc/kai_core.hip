@@ -253,6 +253,11 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     c.saturation_multiplier = core->cfg.reclaimer_saturation_multiplier; c.sv = SolverCtx{}; core->solver_ready = false;
     c.use_signatures = core->cfg.use_scheduling_signatures ? 1 : 0; c.j_signature = nullptr;
     if (s->job_signature) TRY(dupload_f(core, c.j_signature, s->job_signature, (size_t)J));
+    c.j_last_start = nullptr; c.q_preempt_mr = nullptr; c.q_reclaim_mr = nullptr;
+    if (s->job_last_start_ns) TRY(dupload_f(core, c.j_last_start, s->job_last_start_ns, (size_t)J));
+    if (s->queue_preempt_min_runtime_ns) TRY(dupload_f(core, c.q_preempt_mr, s->queue_preempt_min_runtime_ns, (size_t)Q));
+    if (s->queue_reclaim_min_runtime_ns) TRY(dupload_f(core, c.q_reclaim_mr, s->queue_reclaim_min_runtime_ns, (size_t)Q));
+    c.now_ns = core->cfg.now_ns; c.def_preempt_mr = core->cfg.default_preempt_min_runtime_ns; c.def_reclaim_mr = core->cfg.default_reclaim_min_runtime_ns; c.reclaim_method = core->cfg.reclaim_resolve_method;
     TRY(dupload_f(core, c.cls, prep.classes.data(), prep.classes.size()));
     TRY(dzero_f(core, c.sum1_key, (size_t)std::max(c.C, 1) * std::max(c.NB, 1))); TRY(dzero_f(core, c.sum1_node, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)));
 

@@ -258,6 +258,8 @@ struct KaiCtx {
     // victim actions
     int32_t action, max_consolidation_preemptees, allow_consolidating_reclaim, use_signatures; double saturation_multiplier;
     KAI_GP(const int64_t) j_signature;  // [J] scheduling-constraints signature id (null when the snapshot has none)
+    // minruntime plugin inputs (null = nothing is protected)
+    KAI_GP(const int64_t) j_last_start, q_preempt_mr, q_reclaim_mr; int64_t now_ns, def_preempt_mr, def_reclaim_mr; int32_t reclaim_method, pad8;
     SolverCtx sv;
 };
 

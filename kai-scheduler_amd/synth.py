@@ -11,6 +11,7 @@ import numpy as np
 from . import abi
 
 GIB = float(1 << 30)
+NOW_NS = 1_780_000_000 * 1_000_000_000  # "now" of the synthetic cycles (minruntime plugin)
 SEED0 = 0x4B4149
 
 
@@ -173,7 +174,7 @@ def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill
 
 
 def make_crowded_snapshot(n_nodes, seed, *, fill=0.9, n_pending_jobs=12, queue_levels=(2, 2), hog_frac=0.6, elastic_frac=0.3,
-                          nonpreempt_frac=0.1, cpu_only_frac=0.0) -> abi.Snapshot:
+                          nonpreempt_frac=0.1, cpu_only_frac=0.0, minruntime=False) -> abi.Snapshot:
     """A nearly full cluster for the victim actions (reclaim / preempt / consolidation): ~`fill` of the GPUs are held by
     Running gangs (1-4 pods x 1-4 GPUs, some elastic = more pods than minAvailable), `hog_frac` of them in the first leaf queue so that
     it sits over its fair share; pending gangs wait in every queue with mixed priorities (train 50 / build 100 non-preemptible)."""
@@ -225,6 +226,11 @@ def make_crowded_snapshot(n_nodes, seed, *, fill=0.9, n_pending_jobs=12, queue_l
     a["job_first_pod"] = first_pod; a["job_n_pods"] = sizes; a["job_first_podset"] = np.arange(J, dtype=np.int32); a["job_n_podsets"] = np.ones(J, np.int32)
     a["queue_parent"] = qt["parent"]; a["queue_priority"] = qt["prio"]; a["queue_created_ns"] = qt["created"]; a["queue_uid_rank"] = np.arange(len(qt["parent"]), dtype=np.uint32)
     a["queue_deserved"] = qt["deserved"]; a["queue_limit"] = qt["limit"]; a["queue_oqw"] = qt["oqw"]; a["queue_usage"] = qt["usage"]
+    if minruntime:  # minruntime plugin inputs: start times up to 2 h before NOW_NS, min-runtimes of 0 / 30 / 60 min on some queues
+        Qn = len(qt["parent"]); running = np.array([any(st == "Running" for _, st, _ in j[4]) for j in jobs])
+        a["job_last_start_ns"] = np.where(running, NOW_NS - rng.integers(0, 7200, size=J).astype(np.int64) * 1_000_000_000, 0).astype(np.int64)
+        pick = lambda: np.where(rng.random(Qn) < 0.5, -1, rng.choice(np.array([0, 1800, 3600]), size=Qn) * 1_000_000_000).astype(np.int64)
+        a["queue_preempt_min_runtime_ns"] = pick(); a["queue_reclaim_min_runtime_ns"] = pick()
     snap.node_names = [f"node-{i:06d}" for i in range(N)]; snap.queue_names = qt["names"]
     snap.finalize()
     return snap

@@ -40,6 +40,8 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
     for (int q = 0; q < Q; q++) {
         QueueInfo& qi = queues[q]; qi.idx = q; qi.uidRank = s->queue_uid_rank[q]; qi.parent = s->queue_parent[q];
         qi.priority = s->queue_priority[q]; qi.createdNs = s->queue_created_ns[q];
+        qi.preemptMinRuntimeNs = s->queue_preempt_min_runtime_ns ? s->queue_preempt_min_runtime_ns[q] : -1;
+        qi.reclaimMinRuntimeNs = s->queue_reclaim_min_runtime_ns ? s->queue_reclaim_min_runtime_ns[q] : -1;
     }
     for (int q = 0; q < Q; q++) if (queues[q].parent >= 0) queues[queues[q].parent].children.push_back(q);  // cache/cluster_info/queue.go:95-103
     for (int k = 0; k < S; k++) {
@@ -94,6 +96,7 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
         PodGroupInfo& g = jobs[j]; g.idx = j; g.uidRank = s->job_uid_rank[j]; g.queue = s->job_queue[j]; g.priority = s->job_priority[j];
         g.preemptible = s->job_preemptible[j] != 0; g.createdNs = s->job_created_ns[j];
         g.signature = s->job_signature ? s->job_signature[j] : 0; hasSignatures = s->job_signature != nullptr;
+        g.lastStartNs = s->job_last_start_ns ? s->job_last_start_ns[j] : 0;
         g.rootGroup = s->n_groups > 0 ? s->job_root_group[j] : j;
         for (int k = 0; k < s->job_n_podsets[j]; k++) g.podSets.push_back(&podsets[s->job_first_podset[j] + k]);
         std::sort(g.podSets.begin(), g.podSets.end(), [](PodSet* a, PodSet* b) { return a->nameRank < b->nameRank; });
@@ -1204,4 +1207,13 @@ int kai_oracle_queue_order(const double* shares, const int* priority, const int6
 }
 
 const char* kai_oracle_version(void) { return "kai_oracle 1 (CPU restatement; test infrastructure)"; }
+
+// KAT hook: plugins/minruntime/resolver.go on a bare queue tree.  kind 0 = preempt(victim queue), 1 = reclaim / queue method, 2 = reclaim / LCA method.
+int64_t kai_oracle_min_runtime(int n_queues, const int32_t* parent, const int64_t* preempt_ns, const int64_t* reclaim_ns, int64_t default_preempt_ns,
+                               int64_t default_reclaim_ns, int pending_queue, int victim_queue, int kind) {
+    orc::Session ssn; ssn.queues.resize(n_queues);
+    for (int q = 0; q < n_queues; q++) { ssn.queues[q].idx = q; ssn.queues[q].parent = parent[q]; ssn.queues[q].preemptMinRuntimeNs = preempt_ns[q]; ssn.queues[q].reclaimMinRuntimeNs = reclaim_ns[q]; }
+    ssn.cfg.default_preempt_min_runtime_ns = default_preempt_ns; ssn.cfg.default_reclaim_min_runtime_ns = default_reclaim_ns; ssn.cfg.reclaim_resolve_method = kind == 1 ? 1 : 0;
+    return kind == 0 ? ssn.preemptMinRuntime(victim_queue) : ssn.reclaimMinRuntime(pending_queue, victim_queue);
+}
 }

@@ -179,6 +179,7 @@ struct PodGroupInfo {
     bool hasInitResource = false; Resource tasksToAllocateInitResource;
     bool hasLastStart = false;
     bool isClone = false;          // CloneWithTasks representative (job_info.go:477-510): same UID, own pod-sets over a subset of the tasks
+    int64_t lastStartNs = 0;       // LastStartTimestamp (0 = nil / zero)
     int64_t signature = 0;         // GetSchedulingConstraintsSignature (job_info.go:547-570): any injective id of the constraint set
     std::vector<PodInfo*> AllPods() const { std::vector<PodInfo*> v; for (auto* ps : podSets) for (auto& kv : ps->podInfos) v.push_back(kv.second); return v; }
     std::vector<PodInfo*> AllPodsByIndex() const { std::map<int, PodInfo*> m; for (auto* ps : podSets) for (auto& kv : ps->podInfos) m[kv.first] = kv.second; std::vector<PodInfo*> v; for (auto& kv : m) v.push_back(kv.second); return v; }
@@ -316,7 +317,9 @@ inline bool rqLessEqual(const ResourceQuantities& a, const ResourceQuantities& b
 inline bool rqLessInAtLeastOneResource(const ResourceQuantities& a, const ResourceQuantities& b) { return !rqLessEqual(b, a); }
 
 // api/queue_info/queue_info.go:32-43
-struct QueueInfo { int idx = -1; uint32_t uidRank = 0; int parent = -1; std::vector<int> children; int priority = 0; int64_t createdNs = 0; bool IsLeafQueue() const { return children.empty(); } };
+struct QueueInfo { int idx = -1; uint32_t uidRank = 0; int parent = -1; std::vector<int> children; int priority = 0; int64_t createdNs = 0;
+                   int64_t preemptMinRuntimeNs = -1, reclaimMinRuntimeNs = -1;  // -1 = nil (queue_info.go PreemptMinRuntime / ReclaimMinRuntime)
+                   bool IsLeafQueue() const { return children.empty(); } };
 
 // ---------------------------------------------------------------- scheduler_util/priority_queue.go (container/heap semantics)
 template <class T>

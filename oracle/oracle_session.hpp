@@ -134,6 +134,12 @@ struct Session {
     bool reclaimableFn(Scenario* sc);
     std::unique_ptr<JobsOrderByQueues> GetVictimsQueue(const std::function<bool(PodGroupInfo*)>& filter);
     void executeVictimAction(int action);
+    // ---- plugins/minruntime
+    bool minruntimeOn() const { return (cfg.plugins & KAI_PLUGIN_MINRUNTIME) != 0; }
+    int64_t preemptMinRuntime(int queue) const;
+    int64_t reclaimMinRuntime(int preemptorQueue, int preempteeQueue) const;
+    bool isProtected(const PodGroupInfo* victim, int64_t minRuntime) const { return victim->lastStartNs != 0 && cfg.now_ns < victim->lastStartNs + minRuntime; }
+    bool minruntimeValidator(Scenario* sc, bool reclaim);
     ~Session();
 };
 

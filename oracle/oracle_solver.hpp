@@ -8,8 +8,7 @@
 //   * jobs: ascending snapshot index;  nodes: ascending snapshot index, "" (no node) first;  queues: ascending index
 //   * pods of a job: pod-sets by name rank, pods by snapshot index inside a pod-set (PodGroupInfo::AllPods)
 // Not restated (pure pruning of scenarios that cannot succeed, no effect on results): the AccumulatedNodeAffinities and
-// TopologyAwareIdleGpus scenario filters (accumulated_scenario_filters/{node_affinities,idle_gpus/topology_aware_idle_gpus}.go);
-// the minruntime plugin's victim filters (default min-runtime 0s protects nothing, plugins/minruntime/minruntime.go:40-53).
+// TopologyAwareIdleGpus scenario filters (accumulated_scenario_filters/{node_affinities,idle_gpus/topology_aware_idle_gpus}.go).
 #pragma once
 #include <set>
 
@@ -499,6 +498,42 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 + r
     return true;
 }
 
+// ---------------------------------------------------------------- plugins/minruntime/{minruntime,resolver}.go
+inline int64_t Session::preemptMinRuntime(int queue) const {  // resolvePreemptMinRuntime resolver.go:47-69: first value set from the leaf up
+    for (int q = queue; q >= 0; q = queues[q].parent) if (queues[q].preemptMinRuntimeNs >= 0) return queues[q].preemptMinRuntimeNs;
+    return cfg.default_preempt_min_runtime_ns;
+}
+inline int64_t Session::reclaimMinRuntime(int preemptorQueue, int preempteeQueue) const {
+    if (cfg.reclaim_resolve_method == 1) {  // resolveReclaimMinRuntimeQueue :96-117
+        for (int q = preempteeQueue; q >= 0; q = queues[q].parent) if (queues[q].reclaimMinRuntimeNs >= 0) return queues[q].reclaimMinRuntimeNs;
+        return cfg.default_reclaim_min_runtime_ns;
+    }
+    // resolveReclaimMinRuntimeLCA :119-190
+    auto path = [&](int q) { std::vector<int> p; for (; q >= 0; q = queues[q].parent) p.insert(p.begin(), q); return p; };
+    std::vector<int> a = path(preemptorQueue), b = path(preempteeQueue);
+    if (a[0] != b[0]) return queues[b[0]].reclaimMinRuntimeNs >= 0 ? queues[b[0]].reclaimMinRuntimeNs : cfg.default_reclaim_min_runtime_ns;
+    int lca = 0; for (size_t i = 0; i < std::min(a.size(), b.size()); i++) { if (a[i] != b[i]) break; lca = int(i); }
+    if (lca + 1 < int(b.size())) lca++;
+    for (int i = lca; i >= 0; i--) if (queues[b[i]].reclaimMinRuntimeNs >= 0) return queues[b[i]].reclaimMinRuntimeNs;
+    return cfg.default_reclaim_min_runtime_ns;
+}
+static inline bool jobIsElastic(const PodGroupInfo* j) { for (auto* ps : j->podSets) if (ps->IsElastic()) return true; return false; }  // job_info.go:408-415
+inline bool Session::minruntimeValidator(Scenario* sc, bool reclaim) {  // reclaimScenarioValidatorFn / preemptScenarioValidatorFn minruntime.go:112-142
+    for (auto& kv : sc->victims) {
+        const VictimInfo& v = kv.second;
+        if (!jobIsElastic(v.Job)) continue;
+        int64_t mr = reclaim ? reclaimMinRuntime(sc->preemptor->queue, v.Job->queue) : preemptMinRuntime(v.Job->queue);
+        if (!isProtected(v.Job, mr)) continue;
+        // validVictimForMinAvailable :198-222: the protected elastic job must keep minAvailable tasks in every touched sub-group
+        for (auto* ps : v.Job->podSets) {
+            int numVictims = 0; for (auto* t : v.Tasks) if (t->podset == ps->idx) numVictims++;
+            if (!numVictims) continue;
+            if (ps->minAvailable > int32_t(ps->numActiveUsedTasks) - int32_t(numVictims)) return false;
+        }
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------- actions/utils/action.go:18-47
 inline std::unique_ptr<JobsOrderByQueues> Session::GetVictimsQueue(const std::function<bool(PodGroupInfo*)>& filter) {
     std::vector<PodGroupInfo*> preemptees;
@@ -534,11 +569,17 @@ inline void Session::executeVictimAction(int action) {
             case KAI_ACTION_RECLAIM: {  // reclaim.go:102-143
                 GetTasksToAllocateInitResource(job, false);
                 jobSimulationQueues = qattrs;  // ssn.OnJobSolutionStart → proportion.OnJobSolutionStartFn (proportion.go:131-136)
-                JobSolver solver{this, FeasibleNodesForJob(job), [this](Scenario* sc) { return (cfg.plugins & KAI_PLUGIN_PROPORTION) ? reclaimableFn(sc) : true; },
+                JobSolver solver{this, FeasibleNodesForJob(job), [this](Scenario* sc) { if ((cfg.plugins & KAI_PLUGIN_PROPORTION) && !reclaimableFn(sc)) return false; return !minruntimeOn() || minruntimeValidator(sc, true); },
                     [this, job]() {
                         JobsOrderInitOptions vo; vo.FilterNonPreemptible = true; vo.FilterNonActiveAllocated = true; vo.VictimQueue = true; vo.MaxJobsQueueDepth = -1;
                         auto q = std::make_unique<JobsOrderByQueues>(this, vo);
-                        std::vector<PodGroupInfo*> v; for (auto& other : jobs) if (other.queue != job->queue) v.push_back(&other);
+                        std::vector<PodGroupInfo*> v;
+                        for (auto& other : jobs) {
+                            if (other.queue == job->queue) continue;
+                            // ssn.ReclaimVictimFilter → minruntime.reclaimFilterFn (minruntime.go:95-101): elastic jobs pass, they are checked per scenario
+                            if (minruntimeOn() && !jobIsElastic(&other) && isProtected(&other, reclaimMinRuntime(job->queue, other.queue))) continue;
+                            v.push_back(&other);
+                        }
                         q->InitializeWithJobs(v); return q;
                     }};
                 ok = solver.Solve(job, stmt);
@@ -551,13 +592,14 @@ inline void Session::executeVictimAction(int action) {
                     ResourceQuantities q{0, 0, 0}; for (auto* pod : preemptorTasks) { q[2] += pod->resReq.GetGpusQuota(); q[0] += pod->resReq.milliCpu; q[1] += pod->resReq.memory; }
                     if (resultsWithNonPreemptibleOverQuota(q, job)) break;
                 }
-                JobSolver solver{this, FeasibleNodesForJob(job), nullptr,
-                    [this, job]() { return GetVictimsQueue([job](PodGroupInfo* v) {  // buildFilterFuncForPreempt :122-152
+                JobSolver solver{this, FeasibleNodesForJob(job), [this](Scenario* sc) { return !minruntimeOn() || minruntimeValidator(sc, false); },
+                    [this, job]() { return GetVictimsQueue([this, job](PodGroupInfo* v) {  // buildFilterFuncForPreempt :122-152
                         if (!v->IsPreemptibleJob()) return false;
                         if (v->priority >= job->priority) return false;
                         if (v->queue != job->queue) return false;
                         if (v->idx == job->idx) return false;
                         if (activeAllocatedCount(v) == 0) return false;
+                        if (minruntimeOn() && !jobIsElastic(v) && isProtected(v, preemptMinRuntime(v->queue))) return false;  // PreemptVictimFilter → minruntime.preemptFilterFn :103-110
                         return true; }); }};
                 ok = solver.Solve(job, stmt);
                 break;

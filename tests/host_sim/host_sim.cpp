@@ -221,6 +221,9 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (shares_open) fill(shares_open);
     if (c.use_index) for (int b = 0; b < c.NB; b++) for (int k = 0; k < c.C; k++) HostBackend::build_block(c, k, b);  // k_index_build
     c.use_signatures = cfg->use_scheduling_signatures ? 1 : 0; c.j_signature = s->job_signature ? copy(pool, s->job_signature, J) : nullptr;
+    c.j_last_start = s->job_last_start_ns ? copy(pool, s->job_last_start_ns, J) : nullptr; c.q_preempt_mr = s->queue_preempt_min_runtime_ns ? copy(pool, s->queue_preempt_min_runtime_ns, Q) : nullptr;
+    c.q_reclaim_mr = s->queue_reclaim_min_runtime_ns ? copy(pool, s->queue_reclaim_min_runtime_ns, Q) : nullptr;
+    c.now_ns = cfg->now_ns; c.def_preempt_mr = cfg->default_preempt_min_runtime_ns; c.def_reclaim_mr = cfg->default_reclaim_min_runtime_ns; c.reclaim_method = cfg->reclaim_resolve_method;
     c.max_consolidation_preemptees = cfg->max_consolidation_preemptees; c.allow_consolidating_reclaim = cfg->allow_consolidating_reclaim; c.saturation_multiplier = cfg->reclaimer_saturation_multiplier;
     { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; }
     HostBackend be; Engine<HostBackend> eng(c, be);
@@ -247,6 +250,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             c.st->drain_pending = 0;
         }
     }
+    if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: scenarios %lld simulations %lld filtered %lld attempted %lld committed %lld decisions %lld\n", (long long)c.st->scenarios, (long long)c.st->simulations, (long long)c.st->scenarios_filtered, (long long)c.st->jobs_attempted, (long long)c.st->jobs_committed, (long long)c.st->decisions);
     auto t1 = std::chrono::steady_clock::now();
     if (elapsed_ms_out) *elapsed_ms_out = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (c.st->fault) { if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: engine fault %d at line %d\n", c.st->fault, c.st->fault_line); return KAI_ERR_DEVICE_FAULT; }

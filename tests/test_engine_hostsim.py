@@ -119,3 +119,15 @@ def test_hostsim_integration_rounds(name, i, case):
     except T.Unsupported as e:
         pytest.skip(str(e))
     assert not errs, errs[:4]
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_hostsim_minruntime_protection(seed):
+    """minruntime plugin (plugins/minruntime): start times up to 2 h before "now", min-runtimes of 0 / 30 / 60 min on half of the queues, both
+    reclaim resolve methods — victim filters and the elastic-victim scenario validators must match the oracle, and protection must matter."""
+    snap = T.pkg.synth.make_crowded_snapshot(6 + seed % 17, 1000 + seed, fill=0.9, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3], minruntime=True)
+    cfg = T.abi.default_config(max_consolidation_preemptees=-1); cfg.use_scheduling_signatures = seed % 2
+    cfg.now_ns = T.pkg.synth.NOW_NS; cfg.default_preempt_min_runtime_ns = 0 if seed % 4 else 900 * 10**9
+    cfg.default_reclaim_min_runtime_ns = 600 * 10**9 if seed % 3 == 0 else 0; cfg.reclaim_resolve_method = seed % 2
+    for actions in (("reclaim",), ("preempt",), ("allocate", "consolidation", "reclaim", "preempt")):
+        assert_same(HostSim.run(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))

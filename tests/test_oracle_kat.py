@@ -77,3 +77,20 @@ def test_queue_order_kat(case):
     got = lib.kai_oracle_queue_order(shares.ctypes.data_as(C.POINTER(C.c_double)), prio.ctypes.data_as(C.POINTER(C.c_int)),
                                      created.ctypes.data_as(C.POINTER(C.c_int64)), total.ctypes.data_as(C.POINTER(C.c_double)))
     assert got == case["expected"], case["name"]
+
+
+def test_minruntime_resolver_known_answers():
+    """plugins/minruntime/resolver_test.go:38-212 (queue tree of createTestQueues :345-430, defaults 2 s / 1 s): preempt and reclaim min-runtime
+    resolution — own value, inheritance, the queue method and the lowest-common-ancestor method incl. different top-level queues."""
+    import ctypes as C
+    lib = T.Oracle.lib(); f = lib.kai_oracle_min_runtime; f.restype = C.c_int64
+    S = 1_000_000_000
+    # dev, prod, research, dev-team1, dev-team2, prod-team1, prod-team2, research-project
+    parent = np.array([-1, -1, -1, 0, 0, 1, 1, 2], np.int32)
+    pre = np.array([5, 20, 4, -1, 3, -1, 15, 7], np.int64); rec = np.array([10, 30, 6, 8, -1, 25, 35, 9], np.int64)
+    pre = np.where(pre >= 0, pre * S, -1); rec = np.where(rec >= 0, rec * S, -1)
+    q = lambda pq, vq, kind: f(8, parent.ctypes.data_as(C.POINTER(C.c_int32)), pre.ctypes.data_as(C.POINTER(C.c_int64)), rec.ctypes.data_as(C.POINTER(C.c_int64)),
+                               C.c_int64(2 * S), C.c_int64(1 * S), pq, vq, kind) // S
+    assert [q(0, 6, 0), q(0, 5, 0), q(0, 3, 0), q(0, 1, 0), q(0, 2, 0)] == [15, 20, 5, 20, 4]     # getPreemptMinRuntime :38-77
+    assert [q(3, 6, 1), q(3, 4, 1)] == [35, 10]                                                    # queue method :97-120
+    assert [q(3, 6, 2), q(4, 3, 2), q(5, 6, 2), q(6, 6, 2), q(3, 7, 2)] == [30, 8, 35, 35, 6]      # LCA method :148-203
