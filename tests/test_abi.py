@@ -29,7 +29,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(T.abi.KaiQueueShare) == 6 * 3 * 8
     assert C.sizeof(T.abi.KaiNodeState) == 3 * 8 * 8
     assert C.sizeof(T.abi.KaiActionStats) == 6 * 8 + 2 * 8 + 8 * 8
-    assert C.sizeof(T.abi.KaiConfig) == 4 + 4 + 4 + 4 + 8 + 8 + 4 * 6 + 8 + 16 + 4 + 28  # incl. alignment padding after cpu_strategy
+    assert C.sizeof(T.abi.KaiConfig) == 4 + 4 + 4 + 4 + 8 + 8 + 4 * 6 + 8 + 16 + 4 + 28 + 3 * 8 + 4 + 4  # incl. alignment padding after cpu_strategy; minruntime fields last
 
 
 def test_no_device_fails_loudly():
