@@ -367,10 +367,10 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     HIP_TRY(core, hipSetDevice(core->device));
     KaiCtx& c = core->ctx;
     if (victim && !core->solver_ready) {  // scratch of the victim search, kept for the rest of the session
-        char* base = nullptr; size_t bytes = solver_scratch_bytes(c.N, c.P, c.S, c.J, c.Q, c.W);
+        char* base = nullptr; size_t bytes = solver_scratch_bytes(c.N, c.P, c.S, c.J, c.Q, c.W, c.D + c.T, c.TL, c.G);
         int rc0 = dalloc(core, &base, bytes); if (rc0) return rc0;
         HIP_TRY(core, hipMemsetAsync(base, 0, bytes, core->stream));
-        solver_scratch_bind(c.sv, base, c.N, c.P, c.S, c.J, c.Q, c.W);
+        solver_scratch_bind(c.sv, base, c.N, c.P, c.S, c.J, c.Q, c.W, c.D + c.T, c.TL, c.G);
         HIP_TRY(core, hipMemsetAsync(c.sv.xr_key, 0xFF, sizeof(int64_t) * ((size_t)c.sv.xr_mask + 1), core->stream));  // empty residency table
         core->solver_ready = true;
     }

@@ -159,11 +159,13 @@ struct SolverCtx {
     uint32_t *feas, *feas0;                           // [W] byPodSolver.feasibleNodes / JobSolver.feasibleNodes as node bitmaps
     double* ig_idle; int32_t* ig_sorted;              // [N], [P] AccumulatedIdleGpus state
     QShare* q_sim;                                    // [Q][3] proportion.jobSimulationQueues
+    double *ta_cap, *ta_req, *ta_virt; int32_t *ta_sorted, *ta_off, *ta_row, *ta_sg, *ta_sg_row;  // TopologyAwareIdleGpus: capacity per domain [D+T], per constraint key (level row) the domains by capacity
+                                                      // descending [D+T] with offsets [TL+1] and rows [TL], the preemptor's sub-groups with a required level [G+1] x 2
     int32_t *mjr_q, *mjr_job;                         // [J] MinimalJobRepresentatives: (queue or -1, representative job) per signature met so far
     double *rc_rem, *rc_ent; int32_t* rc_ent_q; uint8_t *rc_has, *rc_inv;  // reclaimable validator scratch
     int32_t P_cap;
 };
-inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W) {
+inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int DT = 0, int TL = 0, int G = 0) {
     size_t b = 0; auto add = [&](size_t n) { b += (n + 15) & ~size_t(15); };
     add(J); add(J); add(J); add(P); add(P); add(P); add(P);
     add(sizeof(int32_t) * P); { size_t h = 16; while (h < 2 * (size_t)P + 16) h <<= 1; add(sizeof(int64_t) * h); add(sizeof(int32_t) * h); }
@@ -174,10 +176,11 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W) {
     add(sizeof(uint32_t) * (W + 1)); add(sizeof(uint32_t) * (W + 1));
     add(sizeof(double) * (N + 1)); add(sizeof(int32_t) * (P + 1));
     add(sizeof(QShare) * 3 * (Q + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (J + 1));
+    add(sizeof(double) * (DT + 1)); add(sizeof(double) * (G + 1)); add(sizeof(double) * (DT + 1)); add(sizeof(int32_t) * (DT + 1)); add(sizeof(int32_t) * (TL + 2)); add(sizeof(int32_t) * (TL + 1)); add(sizeof(int32_t) * (G + 1)); add(sizeof(int32_t) * (G + 1));
     add(sizeof(double) * 3 * (Q + 1)); add(sizeof(double) * 3 * (2 * (size_t)P + J + 2)); add(sizeof(int32_t) * (2 * (size_t)P + J + 2)); add(Q + 1); add(Q + 1);
     return b + 64;
 }
-inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, int J, int Q, int W) {
+inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, int J, int Q, int W, int DT = 0, int TL = 0, int G = 0) {
     char* c = base; auto take = [&](size_t n) { char* r = c; c += (n + 15) & ~size_t(15); return r; };
     v.vq_in = (uint8_t*)take(J); v.vq_excl = (uint8_t*)take(J); v.ja_in = (uint8_t*)take(J);
     v.p_taken = (uint8_t*)take(P); v.p_recorded = (uint8_t*)take(P); v.p_partial = (uint8_t*)take(P); v.ig_cache = (uint8_t*)take(P);
@@ -196,6 +199,8 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     v.feas = (uint32_t*)take(sizeof(uint32_t) * (W + 1)); v.feas0 = (uint32_t*)take(sizeof(uint32_t) * (W + 1));
     v.ig_idle = (double*)take(sizeof(double) * (N + 1)); v.ig_sorted = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.q_sim = (QShare*)take(sizeof(QShare) * 3 * (Q + 1)); v.mjr_q = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.mjr_job = (int32_t*)take(sizeof(int32_t) * (J + 1));
+    v.ta_cap = (double*)take(sizeof(double) * (DT + 1)); v.ta_req = (double*)take(sizeof(double) * (G + 1)); v.ta_virt = (double*)take(sizeof(double) * (DT + 1)); v.ta_sorted = (int32_t*)take(sizeof(int32_t) * (DT + 1)); v.ta_off = (int32_t*)take(sizeof(int32_t) * (TL + 2));
+    v.ta_row = (int32_t*)take(sizeof(int32_t) * (TL + 1)); v.ta_sg = (int32_t*)take(sizeof(int32_t) * (G + 1)); v.ta_sg_row = (int32_t*)take(sizeof(int32_t) * (G + 1));
     v.rc_rem = (double*)take(sizeof(double) * 3 * (Q + 1)); v.rc_ent = (double*)take(sizeof(double) * 3 * (2 * (size_t)P + J + 2));
     v.rc_ent_q = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)P + J + 2)); v.rc_has = (uint8_t*)take(Q + 1); v.rc_inv = (uint8_t*)take(Q + 1);
     v.P_cap = P;
@@ -1155,6 +1160,9 @@ struct Engine {
         if (n < 0) { el().fail_no_node = true; return false; }
         // allocateTaskToNode :165-174
         bool ok = (!pipeline_only && allocatable) ? stmt_allocate(p, n) : stmt_pipeline(p, n, !pipeline_only);
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(KAI_SOLVER_TRACE)
+        std::fprintf(stderr, "[eng] task %d -> node %d pipe %d ok %d\n", p, n, (int)pipeline_only, (int)ok);
+#endif
         cx().st->prof[PF_STMT] += be.clock() - t2;
         return ok;
     }

@@ -174,7 +174,7 @@ def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill
 
 
 def make_crowded_snapshot(n_nodes, seed, *, fill=0.9, n_pending_jobs=12, queue_levels=(2, 2), hog_frac=0.6, elastic_frac=0.3,
-                          nonpreempt_frac=0.1, cpu_only_frac=0.0, minruntime=False) -> abi.Snapshot:
+                          nonpreempt_frac=0.1, cpu_only_frac=0.0, minruntime=False, two_podsets_frac=0.0) -> abi.Snapshot:
     """A nearly full cluster for the victim actions (reclaim / preempt / consolidation): ~`fill` of the GPUs are held by
     Running gangs (1-4 pods x 1-4 GPUs, some elastic = more pods than minAvailable), `hog_frac` of them in the first leaf queue so that
     it sits over its fair share; pending gangs wait in every queue with mixed priorities (train 50 / build 100 non-preemptible)."""
@@ -216,14 +216,27 @@ def make_crowded_snapshot(n_nodes, seed, *, fill=0.9, n_pending_jobs=12, queue_l
             pod_status[p] = abi.POD_STATUS[st]; pod_node[p] = n; p += 1
     snap = abi.Snapshot(n_res=R); a = snap.arrays
     a["node_allocatable"] = alloc; a["node_flags"] = np.zeros(N, np.uint32); a["node_gpu_count"] = np.full(N, 8, np.int32); a["node_name_rank"] = np.arange(N, dtype=np.uint32)
-    a["pod_req"] = pod_req; a["pod_job"] = np.repeat(np.arange(J, dtype=np.int32), sizes); a["pod_podset"] = np.repeat(np.arange(J, dtype=np.int32), sizes)
+    # pod-sets: one per job, or (a fraction of the pending gangs of >= 2 pods) two named ones of half the pods each
+    two = np.array([two_podsets_frac > 0 and len(j[4]) >= 2 and j[4][0][1] == "Pending" and rng.random() < two_podsets_frac for j in jobs], bool)
+    n_ps = np.where(two, 2, 1).astype(np.int32); first_ps = np.concatenate([[0], np.cumsum(n_ps)[:-1]]).astype(np.int32)
+    S = int(n_ps.sum()); podset_job = np.repeat(np.arange(J, dtype=np.int32), n_ps); podset_min = np.zeros(S, np.int32); podset_rank = np.zeros(S, np.uint32)
+    pod_podset = np.zeros(P, np.int32)
+    for ji, j in enumerate(jobs):
+        b, n, s0 = int(first_pod[ji]), len(j[4]), int(first_ps[ji])
+        if two[ji]:
+            h = n // 2; podset_min[s0], podset_min[s0 + 1] = h, n - h
+            podset_rank[s0], podset_rank[s0 + 1] = (1, 0) if rng.random() < 0.5 else (0, 1)
+            pod_podset[b:b + h] = s0; pod_podset[b + h:b + n] = s0 + 1
+        else:
+            podset_min[s0] = j[3]; pod_podset[b:b + n] = s0
+    a["pod_req"] = pod_req; a["pod_job"] = np.repeat(np.arange(J, dtype=np.int32), sizes); a["pod_podset"] = pod_podset
     a["pod_status"] = pod_status; a["pod_node"] = pod_node; a["pod_uid_rank"] = np.arange(P, dtype=np.uint32)
-    a["podset_job"] = np.arange(J, dtype=np.int32); a["podset_min_available"] = np.array([j[3] for j in jobs], np.int32); a["podset_name_rank"] = np.zeros(J, np.uint32)
+    a["podset_job"] = podset_job; a["podset_min_available"] = podset_min; a["podset_name_rank"] = podset_rank
     a["job_queue"] = np.array([j[0] for j in jobs], np.int32); a["job_priority"] = np.array([j[1] for j in jobs], np.int32)
     a["job_preemptible"] = np.array([j[2] for j in jobs], np.int32)
     a["job_signature"] = a["job_priority"].astype(np.int64)
     a["job_created_ns"] = (rng.permutation(J).astype(np.int64) + 1) * 60_000_000_000; a["job_uid_rank"] = np.arange(J, dtype=np.uint32)
-    a["job_first_pod"] = first_pod; a["job_n_pods"] = sizes; a["job_first_podset"] = np.arange(J, dtype=np.int32); a["job_n_podsets"] = np.ones(J, np.int32)
+    a["job_first_pod"] = first_pod; a["job_n_pods"] = sizes; a["job_first_podset"] = first_ps; a["job_n_podsets"] = n_ps
     a["queue_parent"] = qt["parent"]; a["queue_priority"] = qt["prio"]; a["queue_created_ns"] = qt["created"]; a["queue_uid_rank"] = np.arange(len(qt["parent"]), dtype=np.uint32)
     a["queue_deserved"] = qt["deserved"]; a["queue_limit"] = qt["limit"]; a["queue_oqw"] = qt["oqw"]; a["queue_usage"] = qt["usage"]
     if minruntime:  # minruntime plugin inputs: start times up to 2 h before NOW_NS, min-runtimes of 0 / 30 / 60 min on some queues
@@ -265,6 +278,43 @@ def add_topology(snap: abi.Snapshot, seed: int, zones: int = 8, racks_per_zone: 
     a["group_preferred_level"] = np.where(pref_rack, 1, -1).astype(np.int32)
     a["job_root_group"] = np.arange(J, dtype=np.int32)
     a["podset_group"] = a["podset_job"].astype(np.int32)
+    a["podset_topology"] = np.full(S, -1, np.int32); a["podset_required_level"] = np.full(S, -1, np.int32); a["podset_preferred_level"] = np.full(S, -1, np.int32)
+    return snap.finalize()
+
+
+def add_replica_topology(snap: abi.Snapshot, seed: int, zones: int = 2, nodes_per_rack: int = 3) -> abi.Snapshot:
+    """zone / rack labels plus, for every two-pod-set job, the sub-group tree of the reference's replica fixtures
+    (actions/allocate/allocateTopology_test.go): a root SubGroupSet (preferred level zone for half of them) with two child SubGroupSets,
+    one pod-set each, BOTH with requiredLevel = rack — two sub-groups on one constraint level, the case in which the
+    TopologyAwareIdleGpus scenario filter matters.  Some single-pod-set gangs get requiredLevel = rack on their root."""
+    rng = np.random.default_rng(seed ^ 0x7E91)
+    a = snap.arrays
+    N, J, S = snap.n_nodes, snap.n_jobs, snap.n_podsets
+    racks = max(1, (N + nodes_per_rack - 1) // nodes_per_rack); zones = max(1, min(zones, racks))
+    rack_of = (np.arange(N) // nodes_per_rack).astype(np.int32); zone_of = (rack_of.astype(np.int64) * zones // racks).astype(np.int32)
+    a["topo_level_off"] = np.array([0, 2], np.int32); a["node_domain"] = np.stack([zone_of, zones + rack_of]).astype(np.int32)
+    rack_zone = np.zeros(racks, np.int32); rack_zone[rack_of] = zone_of
+    a["domain_level"] = np.concatenate([np.zeros(zones, np.int32), np.ones(racks, np.int32)]); a["domain_parent"] = np.concatenate([np.full(zones, -1, np.int32), rack_zone])
+    a["domain_id_rank"] = np.concatenate([np.arange(zones), np.arange(racks)]).astype(np.uint32)
+    gj, gp, gr, gt, gq, gf, root = [], [], [], [], [], [], []
+    ps_group = np.zeros(S, np.int32)
+    pending = np.zeros(J, bool); np.logical_or.at(pending, a["pod_job"], a["pod_status"] == abi.POD_STATUS["Pending"])
+    for j in range(J):
+        r = len(gj); root.append(r)
+        s0, n = int(a["job_first_podset"][j]), int(a["job_n_podsets"][j])
+        if n == 2:
+            pref = rng.random() < 0.5
+            gj.append(j); gp.append(-1); gr.append(0); gt.append(0 if pref else -1); gq.append(-1); gf.append(0 if pref else -1)
+            for k in range(2):
+                gj.append(j); gp.append(r); gr.append(k); gt.append(0); gq.append(1); gf.append(-1)
+                ps_group[s0 + k] = r + 1 + k
+        else:
+            req = pending[j] and a["job_n_pods"][j] >= 2 and rng.random() < 0.4
+            gj.append(j); gp.append(-1); gr.append(0); gt.append(0 if req else -1); gq.append(1 if req else -1); gf.append(-1)
+            ps_group[s0] = r
+    a["group_job"] = np.array(gj, np.int32); a["group_parent"] = np.array(gp, np.int32); a["group_name_rank"] = np.array(gr, np.uint32)
+    a["group_topology"] = np.array(gt, np.int32); a["group_required_level"] = np.array(gq, np.int32); a["group_preferred_level"] = np.array(gf, np.int32)
+    a["job_root_group"] = np.array(root, np.int32); a["podset_group"] = ps_group
     a["podset_topology"] = np.full(S, -1, np.int32); a["podset_required_level"] = np.full(S, -1, np.int32); a["podset_preferred_level"] = np.full(S, -1, np.int32)
     return snap.finalize()
 

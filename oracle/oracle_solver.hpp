@@ -7,8 +7,9 @@
 // execution of the reference; the device engine follows the same choices (DESIGN.md "canonical orders"):
 //   * jobs: ascending snapshot index;  nodes: ascending snapshot index, "" (no node) first;  queues: ascending index
 //   * pods of a job: pod-sets by name rank, pods by snapshot index inside a pod-set (PodGroupInfo::AllPods)
-// Not restated (pure pruning of scenarios that cannot succeed, no effect on results): the AccumulatedNodeAffinities and
-// TopologyAwareIdleGpus scenario filters (accumulated_scenario_filters/{node_affinities,idle_gpus/topology_aware_idle_gpus}.go).
+// Not restated: the AccumulatedNodeAffinities scenario filter (accumulated_scenario_filters/node_affinities): it rejects a scenario only
+// when some pending pod's node affinity matches none of the nodes the simulation may use — an exact necessary condition, so it
+// prunes without changing results.
 #pragma once
 #include <set>
 
@@ -183,14 +184,95 @@ struct AccumulatedIdleGpus {
     }
 };
 
+// ---------------------------------------------------------------- accumulated_scenario_filters/idle_gpus/topology_aware_idle_gpus.go
+// Per (topology, required level) of the preemptor's SubGroupSets: the GPU totals of those sub-groups, largest first, are matched
+// greedily against the level's domains by idle + releasing + freed GPUs.  With two sub-groups on one level the greedy match can
+// reject a feasible scenario, so the filter is part of the result, not only a shortcut.  (The reference keys a domain by the node's
+// label VALUE at that level; here a domain is the snapshot's domain of that level row — the same thing when label values are unique
+// across parents.)
+struct TopologyAwareIdleGpus {
+    Session* ssn; bool active = false;
+    std::vector<std::pair<int, int>> subgroups;          // (SubGroupSet idx, level row) of the preemptor's groups with a required level
+    std::vector<int> rows;                                // distinct level rows (constraint keys)
+    std::map<int, double> domainCapacity;                 // domain → idle GPUs
+    std::map<int, std::vector<int>> domainsByRow;         // level row → domains, capacity descending
+    std::set<int> processedVictims;
+    TopologyAwareIdleGpus(Session* s, Scenario* sc) : ssn(s) {
+        if (ssn->nTopologies == 0) return;
+        std::function<void(int)> walk = [&](int g) {  // getSubgroupsWithRequiredConstraints :175-189 (SubGroupSets only)
+            const SubGroupSet& sg = ssn->groups[g];
+            if (sg.tc.topology >= 0 && sg.tc.required >= 0 && sg.tc.required < ssn->topoLevelOff[sg.tc.topology + 1] - ssn->topoLevelOff[sg.tc.topology])
+                subgroups.push_back({g, ssn->topoLevelOff[sg.tc.topology] + sg.tc.required});
+            for (int c : sg.groups) walk(c);
+        };
+        walk(sc->preemptor->rootGroup);
+        if (subgroups.empty()) return;
+        active = true;
+        for (auto& sr : subgroups) if (std::find(rows.begin(), rows.end(), sr.second) == rows.end()) rows.push_back(sr.second);
+        const int N = int(ssn->nodes.size());
+        for (auto& ni : ssn->nodes) {  // buildDomainCapacity :191-244
+            double total = ni.Idle.gpus + ni.Releasing.gpus;
+            for (int row : rows) { int d = ssn->nodeDomain[size_t(row) * N + ni.idx]; if (d < 0) continue; domainCapacity[d] += total; }
+        }
+        for (int row : rows) {
+            std::vector<int>& v = domainsByRow[row];
+            for (auto& kv : domainCapacity) if (ssn->domains[kv.first].level + ssn->topoLevelOff[ssn->domains[kv.first].topo] == row) v.push_back(kv.first);
+            std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return domainCapacity[a] > domainCapacity[b]; });
+        }
+    }
+    void applyVictimTasks(const std::vector<PodInfo*>& tasks) {  // :73-97
+        const int N = int(ssn->nodes.size());
+        for (auto* t : tasks) {
+            if (t->node < 0 || processedVictims.count(t->idx)) continue;
+            processedVictims.insert(t->idx);
+            double freed = t->accepted.GPUs();
+            for (int row : rows) {
+                int d = ssn->nodeDomain[size_t(row) * N + t->node]; if (d < 0) continue;
+                domainCapacity[d] += freed;
+                std::vector<int>& v = domainsByRow[row];  // repositionDomainAfterIncrease :99-128
+                int cur = -1; for (int i = 0; i < int(v.size()); i++) if (v[i] == d) { cur = i; break; }
+                if (cur <= 0) continue;
+                int np = cur; while (np > 0 && domainCapacity[v[np - 1]] < domainCapacity[d]) np--;
+                if (np != cur) { int e = v[cur]; for (int k = cur; k > np; k--) v[k] = v[k - 1]; v[np] = e; }
+            }
+        }
+    }
+    bool Filter(Scenario* sc) {  // :66-71 + requiredTopologyCapacityExists :130-147
+        applyVictimTasks(sc->recordedVictimsTasks); applyVictimTasks(sc->potentialVictimsTasks);
+        for (int row : rows) {
+            std::vector<double> req;
+            for (auto& sr : subgroups) if (sr.second == row) {  // sumGpuRequirements :246-257 over the representative's pods
+                std::vector<PodSet*> under; ssn->allPodSets(sc->preemptor, &ssn->groups[sr.first], under);
+                double sum = 0; for (auto* ps : under) for (auto& kv : ps->podInfos) sum += kv.second->resReq.GPUs();
+                req.push_back(sum);
+            }
+            std::sort(req.begin(), req.end(), [](double a, double b) { return a > b; });
+            std::map<int, double> virt;  // greedyMatchRequirements common.go:34-64
+            for (double required : req) {
+                if (required == 0) break;
+                bool matched = false;
+                for (int d : domainsByRow[row]) {
+                    double total = domainCapacity[d];
+                    if (total < required) break;
+                    if (total - virt[d] >= required) { virt[d] += required; matched = true; break; }
+                }
+                if (!matched) return false;
+            }
+        }
+        return true;
+    }
+};
+
 // ---------------------------------------------------------------- solvers/pod_scenario_builder.go
 struct ScenarioBuilder {
-    Session* ssn; std::unique_ptr<Scenario> lastScenario; std::unique_ptr<AccumulatedIdleGpus> idleGpus;
+    Session* ssn; std::unique_ptr<Scenario> lastScenario; std::unique_ptr<AccumulatedIdleGpus> idleGpus; std::unique_ptr<TopologyAwareIdleGpus> topoGpus;
     JobsOrderByQueues* victimsJobsQueue; std::set<int> recordedVictimsTasks;
     ScenarioBuilder(Session* s, PodGroupInfo* pendingJob, const std::vector<PodGroupInfo*>& recordedVictimsJobs, JobsOrderByQueues* vq) : ssn(s), victimsJobsQueue(vq) {  // :32-76
         if (!ssn->GetTasksToAllocate(pendingJob, false).empty()) {
             lastScenario = std::make_unique<Scenario>(ssn, pendingJob, recordedVictimsJobs);
             for (auto* job : recordedVictimsJobs) for (auto* t : job->AllPods()) recordedVictimsTasks.insert(t->idx);
+            topoGpus = std::make_unique<TopologyAwareIdleGpus>(ssn, lastScenario.get());
+            if (!topoGpus->active) topoGpus.reset();
             idleGpus = std::make_unique<AccumulatedIdleGpus>(ssn, lastScenario.get());
             if (!idleGpus->valid) idleGpus.reset();
         }
@@ -221,7 +303,8 @@ struct ScenarioBuilder {
     }
     Scenario* GetValidScenario() {  // :135-161
         bool valid = true;
-        if (idleGpus && lastScenario) { bool err = false; bool ok = idleGpus->Filter(lastScenario.get(), err); if (!err && !ok) valid = false; }
+        if (topoGpus && lastScenario && !topoGpus->Filter(lastScenario.get())) valid = false;
+        if (valid && idleGpus && lastScenario) { bool err = false; bool ok = idleGpus->Filter(lastScenario.get(), err); if (!err && !ok) valid = false; }
         if (!valid) { ssn->stats.scenariosFiltered++; return GetNextScenario(); }
         return lastScenario.get();
     }

@@ -225,7 +225,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.q_reclaim_mr = s->queue_reclaim_min_runtime_ns ? copy(pool, s->queue_reclaim_min_runtime_ns, Q) : nullptr;
     c.now_ns = cfg->now_ns; c.def_preempt_mr = cfg->default_preempt_min_runtime_ns; c.def_reclaim_mr = cfg->default_reclaim_min_runtime_ns; c.reclaim_method = cfg->reclaim_resolve_method;
     c.max_consolidation_preemptees = cfg->max_consolidation_preemptees; c.allow_consolidating_reclaim = cfg->allow_consolidating_reclaim; c.saturation_multiplier = cfg->reclaimer_saturation_multiplier;
-    { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; }
+    { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; }
     HostBackend be; Engine<HostBackend> eng(c, be);
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;

@@ -245,3 +245,15 @@ def test_gpu_minruntime_protection(gpu, seed):
     cfg.default_reclaim_min_runtime_ns = 600 * 10**9 if seed % 3 == 0 else 0; cfg.reclaim_resolve_method = seed % 2
     for actions in (("reclaim",), ("preempt",), ("allocate", "consolidation", "reclaim", "preempt")):
         assert_same(run_gpu(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_replica_groups_with_required_rack(gpu, seed):
+    """Two sub-groups of one job on the same required topology level (the replica fixtures of allocateTopology_test.go) in a crowded
+    cluster: allocation through the sub-group DFS and the victim actions with the TopologyAwareIdleGpus scenario filter in play."""
+    snap = T.pkg.synth.make_crowded_snapshot(6 + seed % 13, 3000 + seed, fill=0.8 + 0.1 * (seed % 2), queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3],
+                                             two_podsets_frac=0.6, n_pending_jobs=14)
+    T.pkg.synth.add_replica_topology(snap, seed, zones=2, nodes_per_rack=2 + seed % 2)
+    cfg = T.abi.default_config(max_consolidation_preemptees=-1); cfg.use_scheduling_signatures = seed % 2
+    for actions in (("allocate",), ("reclaim",), ("preempt",), ("consolidation",), ("allocate", "consolidation", "reclaim", "preempt")):
+        assert_same(run_gpu(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
