@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("KAI_BENCH_CONFIG", "C5"), choices=sorted(CONFIGS))
-    ap.add_argument("--scale", type=float, default=float(os.environ.get("KAI_BENCH_SCALE", "1.0")))
+    ap.add_argument("--scale", type=float, default=None, help="shrinks nodes and pods together (default 1.0; C4: 0.01 — its victim search is not engineered for full size yet, DESIGN.md section 9)")
     ap.add_argument("--actions", default="", help="comma-separated actions of one cycle (default: allocate; C4: allocate,consolidation,reclaim)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="decisions the CPU oracle is timed on (-1 = auto, 0 = skip)")
     args = ap.parse_args()
@@ -65,6 +65,8 @@ def main():
         pkg.dist.init("nccl", device=torch.device("cuda", local_rank))
     pkg.load_library()
 
+    if args.scale is None:
+        args.scale = float(os.environ.get("KAI_BENCH_SCALE", "0.01" if args.config == "C4" else "1.0"))
     idx = CONFIGS[args.config]
     actions = tuple(a for a in (args.actions or ("allocate,consolidation,reclaim" if args.config == "C4" else "allocate")).split(",") if a)
     t0 = time.time()
