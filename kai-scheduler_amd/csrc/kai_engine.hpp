@@ -161,6 +161,8 @@ struct SolverCtx {
     QShare* q_sim;                                    // [Q][3] proportion.jobSimulationQueues
     double *ta_cap, *ta_req, *ta_virt; int32_t *ta_sorted, *ta_off, *ta_row, *ta_sg, *ta_sg_row;  // TopologyAwareIdleGpus: capacity per domain [D+T], per constraint key (level row) the domains by capacity
                                                       // descending [D+T] with offsets [TL+1] and rows [TL], the preemptor's sub-groups with a required level [G+1] x 2
+    int32_t *tpl_sorted, *tpl_end; uint8_t* ja_skip;  // [J] (CSR by q_job_off), [Q], [J]: every leaf's pending jobs in JobOrderFn order at the committed state (the
+                                                      // simulation queues start from it), and the jobs a simulation takes out of it because their state is in flux
     int32_t *mjr_q, *mjr_job;                         // [J] MinimalJobRepresentatives: (queue or -1, representative job) per signature met so far
     double *rc_rem, *rc_ent; int32_t* rc_ent_q; uint8_t *rc_has, *rc_inv;  // reclaimable validator scratch
     int32_t P_cap;
@@ -176,6 +178,7 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     add(sizeof(uint32_t) * (W + 1)); add(sizeof(uint32_t) * (W + 1));
     add(sizeof(double) * (N + 1)); add(sizeof(int32_t) * (P + 1));
     add(sizeof(QShare) * 3 * (Q + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (J + 1));
+    add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (Q + 1)); add(J + 1);
     add(sizeof(double) * (DT + 1)); add(sizeof(double) * (G + 1)); add(sizeof(double) * (DT + 1)); add(sizeof(int32_t) * (DT + 1)); add(sizeof(int32_t) * (TL + 2)); add(sizeof(int32_t) * (TL + 1)); add(sizeof(int32_t) * (G + 1)); add(sizeof(int32_t) * (G + 1));
     add(sizeof(double) * 3 * (Q + 1)); add(sizeof(double) * 3 * (2 * (size_t)P + J + 2)); add(sizeof(int32_t) * (2 * (size_t)P + J + 2)); add(Q + 1); add(Q + 1);
     return b + 64;
@@ -199,6 +202,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     v.feas = (uint32_t*)take(sizeof(uint32_t) * (W + 1)); v.feas0 = (uint32_t*)take(sizeof(uint32_t) * (W + 1));
     v.ig_idle = (double*)take(sizeof(double) * (N + 1)); v.ig_sorted = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.q_sim = (QShare*)take(sizeof(QShare) * 3 * (Q + 1)); v.mjr_q = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.mjr_job = (int32_t*)take(sizeof(int32_t) * (J + 1));
+    v.tpl_sorted = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.tpl_end = (int32_t*)take(sizeof(int32_t) * (Q + 1)); v.ja_skip = (uint8_t*)take(J + 1);
     v.ta_cap = (double*)take(sizeof(double) * (DT + 1)); v.ta_req = (double*)take(sizeof(double) * (G + 1)); v.ta_virt = (double*)take(sizeof(double) * (DT + 1)); v.ta_sorted = (int32_t*)take(sizeof(int32_t) * (DT + 1)); v.ta_off = (int32_t*)take(sizeof(int32_t) * (TL + 2));
     v.ta_row = (int32_t*)take(sizeof(int32_t) * (TL + 1)); v.ta_sg = (int32_t*)take(sizeof(int32_t) * (G + 1)); v.ta_sg_row = (int32_t*)take(sizeof(int32_t) * (G + 1));
     v.rc_rem = (double*)take(sizeof(double) * 3 * (Q + 1)); v.rc_ent = (double*)take(sizeof(double) * 3 * (2 * (size_t)P + J + 2));
@@ -442,6 +446,7 @@ struct EngineLocal {
     // victim search: the active job-order instance (0 = the action's, 1 = victims queue, 2 = jobs to allocate of a simulation)
     int32_t *i_sorted, *i_cur, *i_end, *i_side, *i_side_len;  // leaf storage of the active instance
     int32_t jo_kind, cur_inst;               // jo_kind 1 = victims ordering (reversed comparators, victims operands)
+    int32_t tpl_valid, pad9;                 // the pending-job template of the simulation queues matches the committed state
     struct JoSave { QNode* qn; int32_t *qheap, *root_heap, *sorted, *cur, *end, *side, *side_len; int32_t root_len, root_init, kind, pad; } save[3];
 };
 
@@ -464,7 +469,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0;
         e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 
@@ -968,7 +973,12 @@ struct Engine {
     KAI_HD auto lq_side_len() const { if constexpr (kVictim) return el().i_side_len; else return cx().lq_side_len; }
     KAI_HD bool q_is_leaf(int q) const { return qnp()[q].flags & QF_LEAF; }
     KAI_HD int leaf_len_mem(int q) const { return (lq_end()[q] - lq_cur()[q]) + lq_side_len()[q]; }
+    // simulation queues (instance 2): a leaf's sorted region is the shared template; jobs taken out of it for this simulation are stepped over
+    KAI_HD void leaf_skip(int q) const {
+        if constexpr (kVictim) if (el().cur_inst == 2) { const int off = cx().q_job_off[q]; while (lq_cur()[q] < lq_end()[q] && sx().ja_skip[lq_sorted()[off + lq_cur()[q]]]) lq_cur()[q]++; }
+    }
     KAI_HD int leaf_top(int q) const {
+        leaf_skip(q);
         int a = lq_cur()[q] < lq_end()[q] ? lq_sorted()[cx().q_job_off[q] + lq_cur()[q]] : -1;
         int b = lq_side_len()[q] > 0 ? lq_side()[cx().q_job_off[q]] : -1;
         if (a < 0) return b;
@@ -992,6 +1002,7 @@ struct Engine {
         return i > i0;
     }
     KAI_HD int leaf_pop(int q) {
+        leaf_skip(q);
         int a = lq_cur()[q] < lq_end()[q] ? lq_sorted()[cx().q_job_off[q] + lq_cur()[q]] : -1;
         int b = lq_side_len()[q] > 0 ? lq_side()[cx().q_job_off[q]] : -1;
         qnp()[q].len--; qnp()[q].flags &= ~QF_TOP;
