@@ -190,6 +190,7 @@ struct NullBackend {  // kernels that only need the engine's pure helpers
     __device__ void class_top(const KaiCtx&, int, uint64_t& k, int& n) { k = 0; n = -1; }
     __device__ bool all_dead(const KaiCtx&) { return false; }
     __device__ void hot(const KaiCtx&, QNode*&, int32_t*&, int32_t*&) {}
+    __device__ bool sim_tree(QNode*&, int32_t*&, int32_t*&) { return false; }
     __device__ int64_t clock() { return 0; }
 };
 
@@ -342,10 +343,13 @@ struct DevBackendT {
     }
     __device__ void class_top(const KaiCtx&, int k, uint64_t& key, int& node) { wait(); key = sh->top_key[k]; node = sh->top_node[k]; }
     __device__ bool all_dead(const KaiCtx& c) { wait(); for (int k = 0; k < c.C; k++) if (sh->top_key[k]) return false; return true; }
-    __device__ void hot(const KaiCtx&, QNode*& qn, int32_t*& qheap, int32_t*& root_heap) {
+    __device__ void hot(const KaiCtx& c, QNode*& qn, int32_t*& qheap, int32_t*& root_heap) {
+        if constexpr (VICTIM) { qn = c.qn; qheap = c.qheap; root_heap = c.root_heap; return; }  // the LDS region goes to the simulation queue (sim_tree)
         if (sh->tree_in_lds) call(CMD_LOADTREE);  // service waves copy the k_leaf_init records HBM → LDS
         qn = sh->qn; qheap = sh->qheap; root_heap = sh->root_heap;
     }
+    // victim search: the job-order instance of the simulations (by far the hottest of the three) lives in the LDS tree region when it fits
+    __device__ bool sim_tree(QNode*& qn, int32_t*& qheap, int32_t*& root_heap) { if (!sh->tree_in_lds) return false; qn = sh->qn; qheap = sh->qheap; root_heap = sh->root_heap; return true; }
     __device__ int64_t clock() { return (int64_t)clock64(); }
     __device__ void finish() { wait(); sh->cmd = CMD_EXIT; __syncthreads(); }
 };

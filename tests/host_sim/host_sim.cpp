@@ -21,6 +21,7 @@ namespace {
 struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.hpp)
     static constexpr bool kVictim = true;
     template <class T> static void assume_tree(T*) {}
+    bool sim_tree(QNode*&, int32_t*&, int32_t*&) { return false; }
     const KaiCtx* cref = nullptr; EngineLocal loc;
     void bind(const KaiCtx& c) { cref = &c; }
     const KaiCtx& ctx() const { return *cref; }
