@@ -27,6 +27,7 @@ struct kai_core {
     bool open = false;
     KaiCtx ctx{};
     KaiCtx* d_ctx = nullptr;  // HBM copy of ctx for the persistent kernel
+    int fast_ok0 = 0;  // the snapshot's verdict on the staged job path (restored by kai_session_reset)
     bool solver_ready = false;  // scratch of the victim search allocated (first reclaim / preempt / consolidation of the session)
     std::vector<void*> bufs;  // session HBM: a few large slabs, sub-allocated (one contiguous range ⇒ few TLB entries for the latency-bound engine)
     char* slab = nullptr; size_t slab_left = 0;
@@ -247,7 +248,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     core->n_levels = prep.n_levels;
     // ---- scan classes + class index
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64;
-    c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok;
+    c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok; core->fast_ok0 = prep.fast_ok;
     { int d = core->cfg.queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
     c.action = KAI_ACTION_ALLOCATE; c.max_consolidation_preemptees = core->cfg.max_consolidation_preemptees; c.allow_consolidating_reclaim = core->cfg.allow_consolidating_reclaim;
     c.saturation_multiplier = core->cfg.reclaimer_saturation_multiplier; c.sv = SolverCtx{}; core->solver_ready = false;
@@ -331,6 +332,7 @@ int kai_session_reset(kai_core* core) {
     if (c.P) { HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_status), core->d_status0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream));
                HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_node), core->d_node0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream)); }
     HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.q_share), core->d_shares0, (size_t)std::max(c.Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
+    c.fast_ok = core->fast_ok0;
     if (core->solver_ready) HIP_TRY(core, hipMemsetAsync(c.sv.xr_key, 0xFF, sizeof(int64_t) * ((size_t)c.sv.xr_mask + 1), core->stream));
     HIP_TRY(core, hipMemsetAsync(KAI_VP(c.st), 0, sizeof(EngineState), core->stream));
     int rc = launch_open_kernels(core); if (rc) return rc;
@@ -413,6 +415,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     core->stats.reserved[0] = st.index_queries; core->stats.reserved[1] = st.index_refreshes; core->stats.reserved[2] = victim ? st.scenarios : st.drained_jobs; core->stats.reserved[3] = victim ? st.simulations : st.drained_decisions;
     for (int i = 0; i < 4; i++) core->stats.reserved[4 + i] = st.prof[i == 3 ? 7 : i == 2 ? 3 : i == 1 ? 2 : 0];  // control-lane cycles: pop, allocate, commit/discard, total
     if (std::getenv("KAI_PROF")) { std::fprintf(stderr, "kai prof:"); for (int i = 0; i < 16; i++) std::fprintf(stderr, " %lld", (long long)st.prof[i]); std::fprintf(stderr, "\n"); }
+    if (st.non_allocate_commits) c.fast_ok = 0;  // the staged job path assumes nothing releasing / pipelined in the session (kai_host_prep.hpp); until the next open / reset
     if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d (engine source line %d)", st.fault, st.fault_line); core->err = buf; return KAI_ERR_DEVICE_FAULT; }
     *n_ops = st.out_len;
     if (ops_out) {

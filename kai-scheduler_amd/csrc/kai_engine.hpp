@@ -133,6 +133,7 @@ struct EngineState {  // mutable scalars of the running action
     int64_t decisions, node_scans, nodes_scanned, jobs_attempted, jobs_committed, rollbacks;
     int64_t index_queries, index_refreshes, drained_jobs, drained_decisions;
     int64_t scenarios, simulations, scenarios_filtered;  // victim search (actions/common/solvers)
+    int64_t non_allocate_commits;  // evictions / pipelines committed by this action: from then on something is releasing or pipelined in the session
     int64_t prof[16];         // control-lane cycles per phase, see PF_*
     double total[3];          // proportion totalResource (CPU, Memory, GPU)
 };
@@ -442,7 +443,8 @@ struct EngineLocal {
     KAI_GP(const uint32_t) scope_bits; KAI_GP(const double) scope_score; int32_t scope_row, n_keys;
     uint32_t restricted, pad5;               // bit d: the node set of DFS depth d is narrower than "every node"
     KAI_GP(const uint32_t) base_bits;        // node set every job attempt starts from (null = every node; a scenario's feasible nodes in the victim search)
-    int32_t ov_job, pad7;                    // job currently stood in for by its partial representative (job_solver.go:128-151), -1 = none
+    int32_t ov_job, ov_orig_valid;           // job currently stood in for by its partial representative (job_solver.go:128-151), -1 = none;
+                                             // whether the SESSION job's own tasks-to-allocate cache (saved aside) is still valid
     // victim search: the active job-order instance (0 = the action's, 1 = victims queue, 2 = jobs to allocate of a simulation)
     int32_t *i_sorted, *i_cur, *i_end, *i_side, *i_side_len;  // leaf storage of the active instance
     int32_t jo_kind, cur_inst;               // jo_kind 1 = victims ordering (reversed comparators, victims operands)
@@ -525,7 +527,7 @@ struct Engine {
         if (status == KAI_POD_PENDING) cx().j_n_pending[j]++;
         // invalidateTasksCache (job_info.go:253-256) — of the SESSION's job: the partial representative the victim search stands in for
         // it keeps the chunk it cached when it was made (statement operations re-index the original job, not the clone)
-        if constexpr (kVictim) { if (j == el().ov_job) return; }
+        if constexpr (kVictim) { if (j == el().ov_job) { el().ov_orig_valid = 0; return; } }
         cx().j_tta_valid[j] = 0;
     }
 
@@ -724,8 +726,8 @@ struct Engine {
             StmtOp op = cx().ops[i]; if (op.name == OP_UNDO) continue;
             if (cx().st->out_len >= cx().out_cap) { fault(FAULT_OUT_CAP); break; }
             kai_op o; o.seq = cx().st->out_len; o.pod = op.pod; o.job = cx().p_job[op.pod]; o.node = cx().p_node[op.pod];
-            if (op.name == OP_EVICT) { o.kind = KAI_OP_EVICT; o.node = op.prev_node; cx().p_virtual[op.pod] = 0; }
-            else if (op.name == OP_PIPELINE) o.kind = KAI_OP_PIPELINE;
+            if (op.name == OP_EVICT) { o.kind = KAI_OP_EVICT; o.node = op.prev_node; cx().p_virtual[op.pod] = 0; cx().st->non_allocate_commits++; }
+            else if (op.name == OP_PIPELINE) { o.kind = KAI_OP_PIPELINE; cx().st->non_allocate_commits++; }
             else { o.kind = KAI_OP_ALLOCATE; update_task_status(op.pod, KAI_POD_BINDING); }  // ssn.BindPod (framework/session.go:111-126)
             cx().out_ops[cx().st->out_len++] = o;
         }

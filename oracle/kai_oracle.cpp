@@ -801,6 +801,9 @@ bool Session::allocateTask(Statement& stmt, const std::vector<NodeInfo*>& nodeSe
     for (auto* node : OrderedNodesByTask(nodeSet, task)) {
         if (!FittingNode(task, node)) continue;
         success = allocateTaskToNode(stmt, task, node, isPipelineOnly);
+#ifdef ORC_TRACE
+        fprintf(stderr, "[orc] task %d -> node %d pipe %d ok %d\n", task->idx, node->idx, (int)isPipelineOnly, (int)success);
+#endif
         if (success) break;
     }
     return success;

@@ -5,13 +5,18 @@
 //
 // Where the reference ranges over a Go map (random order) this restatement fixes ONE order — any order is a valid
 // execution of the reference; the device engine follows the same choices (DESIGN.md "canonical orders"):
-//   * jobs: ascending snapshot index;  nodes: ascending snapshot index, "" (no node) first;  queues: ascending index
+//   * jobs: ascending snapshot index;  nodes: ascending node name (name rank), "" (no node) first;  queues: ascending index
 //   * pods of a job: pod-sets by name rank, pods by snapshot index inside a pod-set (PodGroupInfo::AllPods)
 // Not restated: the AccumulatedNodeAffinities scenario filter (accumulated_scenario_filters/node_affinities): it rejects a scenario only
 // when some pending pod's node affinity matches none of the nodes the simulation may use — an exact necessary condition, so it
 // prunes without changing results.
 #pragma once
 #include <set>
+#ifdef ORC_TRACE
+#define ORC_T(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define ORC_T(...) ((void)0)
+#endif
 
 namespace orc {
 
@@ -279,6 +284,7 @@ struct ScenarioBuilder {
     }
     bool addNextPotentialVictims() {  // :91-133
         PodGroupInfo* nextVictimJob = victimsJobsQueue->PopNextJob();
+        ORC_T("[orc] victim pop %d (preemptor %d)\n", nextVictimJob->idx, lastScenario ? lastScenario->preemptor->idx : -1);
         bool jobHasMoreTasks = false;
         std::vector<PodInfo*> potentialVictimTasks = ssn->GetTasksToEvict(nextVictimJob, jobHasMoreTasks);
         for (auto* pv : potentialVictimTasks) if (recordedVictimsTasks.count(pv->idx)) {
@@ -335,6 +341,7 @@ struct ByPodSolver {
         bool preemptorAllocated = false;
         while (!jobsToAllocate.IsEmpty()) {
             PodGroupInfo* job = jobsToAllocate.PopNextJob();
+            ORC_T("[orc] ja pop %d\n", job->idx);
             if (!potentialVictims.count(job->idx) && job->idx != pendingJob->idx) continue;
             ssn->GetTasksToAllocateInitResource(job, false);  // evaluated for a log line; fills the job's cache like the reference does
             if (job->idx != pendingJob->idx) { ssn->AllocateJob(stmt, nodes, job, true); continue; }
@@ -345,14 +352,14 @@ struct ByPodSolver {
     }
     Sim runSimulation(Scenario* sc, std::unique_ptr<Statement>& stmt, const std::vector<PodInfo*>& victimTasks, SolutionResult& out) {  // :100-116
         ssn->stats.simulations++;
-        if (!tryScenarioWithEvictedVictims(sc, *stmt, victimTasks)) return simNone;
+        { bool okk = tryScenarioWithEvictedVictims(sc, *stmt, victimTasks); ORC_T("[orc] sim preemptor %d nvt %d -> %d   ops_len %d\n", sc->preemptor->idx, (int)victimTasks.size(), (int)okk, (int)stmt->operations.size()); if (!okk) return simNone; }
         std::vector<PodInfo*> preempted, pipelined;
         for (auto* t : victimTasks) { if (t->status == Releasing) preempted.push_back(t); else if (t->status == Pipelined) pipelined.push_back(t); }
         // handleScenarioSolution :171-197
         std::vector<PodInfo*> victimsTasks = preempted;
         if (!allowVictimConsolidation) victimsTasks.insert(victimsTasks.end(), pipelined.begin(), pipelined.end());
         std::vector<PodGroupInfo*> victimJobs = getVictimJobsFromVictimTasks(victimsTasks, sc);
-        if (validator && !validator(sc)) { stmt->Discard(); out = SolutionResult{}; return simRejected; }
+        { bool v = !validator || validator(sc); ORC_T("[orc] validator -> %d\n", (int)v); if (!v) { stmt->Discard(); out = SolutionResult{}; return simRejected; } }
         if (allowVictimConsolidation) { victimsTasks.insert(victimsTasks.end(), pipelined.begin(), pipelined.end()); victimJobs = getVictimJobsFromVictimTasks(victimsTasks, sc); }
         out.solved = true; out.victimsTasks = victimsTasks; out.victimJobs = victimJobs; out.statement = std::move(stmt);
         return simSolved;
@@ -376,7 +383,9 @@ struct ByPodSolver {
         if (!latest) {
             if (!sc->recordedVictimsTasks.empty()) { Sim s = runSimulation(sc, stmt, sc->recordedVictimsTasks, res); if (s != simNone) return res; }
         } else {
-            std::set<int> nodeNames; for (auto* t : latest->AllPods()) nodeNames.insert(t->node);  // getNodesOfJob :199-209 (every pod of the job, "" included)
+            // getNodesOfJob :199-209: the distinct NodeName of every pod of the job ("" included) — maps.Keys, random in the reference; canonical: by node name, "" first
+            std::vector<int> nodeNames; for (auto* t : latest->AllPods()) if (std::find(nodeNames.begin(), nodeNames.end(), t->node) == nodeNames.end()) nodeNames.push_back(t->node);
+            std::sort(nodeNames.begin(), nodeNames.end(), [&](int a, int b) { if (a < 0 || b < 0) return a < b; return ssn->nodes[a].nameRank < ssn->nodes[b].nameRank; });
             for (int nodeToTest : nodeNames) {  // solveOnPotentialNodes :118-144
                 int cp = stmt->Checkpoint();
                 std::vector<PodInfo*> potential = sc->VictimsTasksFromNodes(nodeToTest);
@@ -408,12 +417,15 @@ struct JobSolver {
     bool Solve(PodGroupInfo* pendingJob, std::unique_ptr<Statement>& statementOut) {  // :50-93
         std::vector<PodGroupInfo*> recordedVictimsJobs; std::vector<PodInfo*> recordedVictimsTasks;
         int originalNumActiveTasks = 0; for (auto* ps : pendingJob->podSets) originalNumActiveTasks += ps->numActiveUsedTasks;
+        ORC_T("[orc] solve job %d cached %d pending %d\n", pendingJob->idx, (int)pendingJob->hasTasksToAllocate, pendingJob->GetNumPendingTasks());
         std::vector<PodInfo*> tasksToAllocate = ssn->GetTasksToAllocate(pendingJob, false), pendingTasks;
+        ORC_T("[orc] solve job %d ntasks %d\n", pendingJob->idx, (int)tasksToAllocate.size()); for (auto* t : tasksToAllocate) ORC_T("[orc]    task %d status %d virtual %d\n", t->idx, t->status, (int)t->isVirtualStatus); for (auto* t : pendingJob->AllPodsByIndex()) ORC_T("[orc]    pod %d status %d virtual %d node %d\n", t->idx, t->status, (int)t->isVirtualStatus, t->node);
         for (auto* next : tasksToAllocate) {
             pendingTasks.push_back(next);
             bool satisfactory = pendingTasks.size() == tasksToAllocate.size();
             PodGroupInfo* partial = getPartialJobRepresentative(ssn, pendingJob, pendingTasks);
             SolutionResult result = solvePartialJob(recordedVictimsJobs, recordedVictimsTasks, partial);
+            ORC_T("[orc] partial result solved %d\n", (int)result.solved);
             if (!result.solved) break;
             if (!satisfactory && result.statement) result.statement->Discard();
             statementOut = std::move(result.statement);
@@ -429,6 +441,7 @@ struct JobSolver {
         for (auto* t : recordedVictimsTasks) if (t->node >= 0) feasibleNodeMap.insert(t->node);
         std::unique_ptr<JobsOrderByQueues> vq = generateVictimsQueue();
         ScenarioBuilder builder(ssn, partial, recordedVictimsJobs, vq.get());
+        ORC_T("[orc] partial job %d: victims queue len %d empty %d scenario %d feasible %d\n", partial->idx, vq->Len(), (int)vq->IsEmpty(), (int)(builder.lastScenario != nullptr), (int)feasibleNodeMap.size());
         for (Scenario* sc = builder.GetValidScenario(); sc; sc = builder.GetNextScenario()) {
             ByPodSolver solver{ssn, feasibleNodeMap, validator, ssn->cfg.allow_consolidating_reclaim != 0};
             ssn->stats.scenarios++;
@@ -644,7 +657,8 @@ inline void Session::executeVictimAction(int action) {
         PodGroupInfo* job = jobsOrder.PopNextJob(); if (!job) break;
         if (action == KAI_ACTION_RECLAIM && !CanReclaimResources(job)) continue;  // reclaim.go:64-66
         MinimalJobRepresentatives& smallest = smallestFailedJobsByQueue[action == KAI_ACTION_CONSOLIDATION ? -1 : job->queue];
-        if (cfg.use_scheduling_signatures && !smallest.IsEasierToSchedule(job)) continue;
+        if (cfg.use_scheduling_signatures && !smallest.IsEasierToSchedule(job)) { ORC_T("[orc] mjr skip job %d\n", job->idx); continue; }
+        ORC_T("[orc] attempt job %d\n", job->idx);
         stats.jobsAttempted++;
         std::unique_ptr<Statement> stmt; bool ok = false;
         clonePool.clear();
@@ -673,10 +687,11 @@ inline void Session::executeVictimAction(int action) {
                 std::vector<PodInfo*> preemptorTasks = GetTasksToAllocate(job, false);
                 if (cfg.plugins & KAI_PLUGIN_PROPORTION) {  // IsNonPreemptibleJobOverQueueQuotaFn → capacity_policy.go:38-49
                     ResourceQuantities q{0, 0, 0}; for (auto* pod : preemptorTasks) { q[2] += pod->resReq.GetGpusQuota(); q[0] += pod->resReq.milliCpu; q[1] += pod->resReq.memory; }
-                    if (resultsWithNonPreemptibleOverQuota(q, job)) break;
+                    if (resultsWithNonPreemptibleOverQuota(q, job)) { ORC_T("[orc] np over quota job %d req %g %g %g ntasks %d\n", job->idx, q[0], q[1], q[2], (int)preemptorTasks.size()); break; }
                 }
                 JobSolver solver{this, FeasibleNodesForJob(job), [this](Scenario* sc) { return !minruntimeOn() || minruntimeValidator(sc, false); },
                     [this, job]() { return GetVictimsQueue([this, job](PodGroupInfo* v) {  // buildFilterFuncForPreempt :122-152
+                        if (v->idx == 76 && job->idx == 3) ORC_T("[orc] filter v76: preemptible %d prio %d vs %d queue %d vs %d active %d elastic %d last %lld\n", (int)v->IsPreemptibleJob(), v->priority, job->priority, v->queue, job->queue, activeAllocatedCount(v), (int)jobIsElastic(v), (long long)v->lastStartNs);
                         if (!v->IsPreemptibleJob()) return false;
                         if (v->priority >= job->priority) return false;
                         if (v->queue != job->queue) return false;

@@ -238,6 +238,8 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             for (int x = b; x < e; x++) { int j = c.jobs_static[x]; int st = c.j_state[j]; if (st == 0) c.lq_sorted[b + cnt++] = j; else if (st != 3) eng.leaf_push(q, j); }
             c.lq_cur[q] = 0; c.lq_end[q] = cnt; qnode_init(c, q, cnt + c.lq_side_len[q]);
         }
+        if (std::getenv("KAI_HOSTSIM_PS")) { int ps = std::atoi(std::getenv("KAI_HOSTSIM_PS")); std::fprintf(stderr, "host_sim: before action %d podset %d active_alloc %d used %d alive %d pipelined %d\n", actions[i], ps, c.s_active_alloc[ps], c.s_active_used[ps], c.s_alive[ps], c.s_pipelined[ps]); }
+        if (c.st->non_allocate_commits) c.fast_ok = 0;  // as kai_action_execute does after every action
         if (actions[i] != KAI_ACTION_ALLOCATE) { eng.execute_victim_action(); continue; }
         eng.execute_allocate();
         if (c.st->drain_pending) {                                         // k_drain

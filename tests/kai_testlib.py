@@ -559,3 +559,30 @@ def run_integration(case, run_fn, rounds_after=None):
         snap, meta, res = one_round()
         errs += check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes)
     return errs
+
+
+def broad_case(seed):
+    """One seed of the broad randomized campaign (the one that found the staged-path / canonical-node-order / stale-cache / leaf-heap
+    divergences): a crowded cluster with every optional feature drawn at random, and a baseline-style snapshot, each under several action orders."""
+    synth = pkg.synth
+    rng = np.random.default_rng(seed)
+    cases = []
+    s1 = synth.make_crowded_snapshot(4 + seed % 29, 5000 + seed, fill=0.7 + 0.25 * rng.random(), queue_levels=((2, 2), (3,), (2, 2, 2), (4, 3))[seed % 4], hog_frac=rng.random(),
+                                     elastic_frac=rng.random() * 0.6, nonpreempt_frac=rng.random() * 0.3, cpu_only_frac=0.3 if seed % 4 == 0 else 0.0, n_pending_jobs=5 + seed % 25,
+                                     minruntime=seed % 3 == 0, two_podsets_frac=0.5 if seed % 2 else 0.0)
+    if seed % 2:
+        synth.add_replica_topology(s1, seed, zones=1 + seed % 3, nodes_per_rack=2 + seed % 3)
+    c1 = abi.default_config(max_consolidation_preemptees=(-1, 16, 2, 0)[seed % 4], gpu_strategy=(abi.BINPACK, abi.SPREAD)[seed % 2], cpu_strategy=(abi.BINPACK, abi.SPREAD)[(seed // 2) % 2],
+                            k_value=(0.0, 0.5, 1.0)[seed % 3])
+    c1.use_scheduling_signatures = seed % 2; c1.allow_consolidating_reclaim = int(seed % 3 != 0); c1.reclaimer_saturation_multiplier = (1.0, 1.2, 2.0)[seed % 3]
+    c1.now_ns = synth.NOW_NS; c1.default_preempt_min_runtime_ns = (0, 900 * 10**9)[seed % 2]; c1.default_reclaim_min_runtime_ns = (0, 600 * 10**9)[(seed // 2) % 2]; c1.reclaim_resolve_method = seed % 2
+    for acts in (("allocate", "consolidation", "reclaim", "preempt"), ("reclaim", "preempt", "consolidation", "allocate"), ("preempt",), ("consolidation",)):
+        cases.append((s1, c1, acts))
+    s2 = synth.make_snapshot(int(rng.integers(2, 60)), int(rng.integers(0, 400)), 7000 + seed, queue_levels=((2, 3), (3, 2, 2), (1, 4))[seed % 3], prefill=float(rng.random()) * 0.9,
+                             gpu_mix=((8, .5), (4, .3), (0, .2)), cpu_only_frac=0.3, zipf=True, limits_frac=0.3, queue_prios=(100, 200), oqws=(1.0, 2.0), nonpreempt_frac=0.2,
+                             usage_max=0.2, lexi_names=bool(seed % 2), elastic_frac=0.3, multi_podset_frac=0.3, task_prio_frac=0.2)
+    if seed % 2 == 0:
+        synth.add_topology(s2, seed, zones=1 + seed % 4, racks_per_zone=1 + seed % 5, req_rack_frac=0.4, pref_rack_frac=0.3)
+    c2 = abi.default_config(gpu_strategy=(abi.BINPACK, abi.SPREAD)[seed % 2], k_value=float(seed % 3) * 0.5, max_consolidation_preemptees=8)
+    cases.append((s2, c2, ("allocate",))); cases.append((s2, c2, ("allocate", "consolidation", "reclaim", "preempt")))
+    return cases

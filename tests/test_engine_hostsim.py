@@ -143,3 +143,12 @@ def test_hostsim_replica_groups_with_required_rack(seed):
     cfg = T.abi.default_config(max_consolidation_preemptees=-1); cfg.use_scheduling_signatures = seed % 2
     for actions in (("allocate",), ("reclaim",), ("preempt",), ("consolidation",), ("allocate", "consolidation", "reclaim", "preempt")):
         assert_same(HostSim.run(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
+
+
+@pytest.mark.parametrize("seed", [9, 31, 36, 43, 123, 234, 1623] + list(range(2000, 2060)))
+def test_hostsim_broad_random_cycles(seed):
+    """Seeds of the broad randomized campaign (tests/kai_testlib.py::broad_case), incl. the ones that exposed real divergences: staged job
+    path after a victim action, candidate-node order under lexicographic node names, the session job's own tasks cache, leaf heaps
+    whose keys change while a job waits.  Every case: operations, pod states, node accounting and queue shares identical to the oracle."""
+    for snap, cfg, actions in T.broad_case(seed):
+        assert_same(HostSim.run(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
