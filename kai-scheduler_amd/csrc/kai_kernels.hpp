@@ -351,7 +351,12 @@ struct DevBackendT {
     // victim search: the job-order instance of the simulations (by far the hottest of the three) lives in the LDS tree region when it fits
     __device__ bool sim_tree(QNode*& qn, int32_t*& qheap, int32_t*& root_heap) { if (!sh->tree_in_lds) return false; qn = sh->qn; qheap = sh->qheap; root_heap = sh->root_heap; return true; }
     __device__ int64_t clock() { return (int64_t)clock64(); }
-    __device__ void finish() { wait(); sh->cmd = CMD_EXIT; __syncthreads(); }
+    __device__ void finish() {
+        wait();
+        // blocks still on the dirty list: bring the HBM level of the index up to date, the next action of the session starts from it
+        if (sh->n_dirty) { sh->cmd = CMD_REFRESH; __syncthreads(); sh->in_flight = 1; wait(); }
+        sh->cmd = CMD_EXIT; __syncthreads();
+    }
 };
 
 using DevBackend = DevBackendT<false, false>;
