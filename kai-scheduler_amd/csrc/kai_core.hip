@@ -365,7 +365,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
     if (action < KAI_ACTION_ALLOCATE || action > KAI_ACTION_PREEMPT) return fail(core, KAI_ERR_INVALID_ARG, "unknown action");
     const bool victim = action != KAI_ACTION_ALLOCATE;
-    if (victim && core->cfg.use_scheduling_signatures && !core->ctx.j_signature) return fail(core, KAI_ERR_UNSUPPORTED, "use_scheduling_signatures needs kai_snapshot_soa.job_signature (actions/common/minimal_job_comparison.go)");
+    if (victim && core->cfg.use_scheduling_signatures && !core->ctx.j_signature && core->ctx.J > 0) return fail(core, KAI_ERR_UNSUPPORTED, "use_scheduling_signatures needs kai_snapshot_soa.job_signature (actions/common/minimal_job_comparison.go)");
     HIP_TRY(core, hipSetDevice(core->device));
     KaiCtx& c = core->ctx;
     if (victim && !core->solver_ready) {  // scratch of the victim search, kept for the rest of the session

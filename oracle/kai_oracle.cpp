@@ -92,10 +92,11 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
             }
         }
     }
+    hasSignatures = s->job_signature != nullptr || J == 0;
     for (int j = 0; j < J; j++) {
         PodGroupInfo& g = jobs[j]; g.idx = j; g.uidRank = s->job_uid_rank[j]; g.queue = s->job_queue[j]; g.priority = s->job_priority[j];
         g.preemptible = s->job_preemptible[j] != 0; g.createdNs = s->job_created_ns[j];
-        g.signature = s->job_signature ? s->job_signature[j] : 0; hasSignatures = s->job_signature != nullptr;
+        g.signature = s->job_signature ? s->job_signature[j] : 0;
         g.lastStartNs = s->job_last_start_ns ? s->job_last_start_ns[j] : 0;
         g.rootGroup = s->n_groups > 0 ? s->job_root_group[j] : j;
         for (int k = 0; k < s->job_n_podsets[j]; k++) g.podSets.push_back(&podsets[s->job_first_podset[j] + k]);

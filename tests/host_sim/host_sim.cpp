@@ -230,7 +230,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     HostBackend be; Engine<HostBackend> eng(c, be);
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;
-        if (actions[i] != KAI_ACTION_ALLOCATE && cfg->use_scheduling_signatures && !s->job_signature) return KAI_ERR_UNSUPPORTED;
+        if (actions[i] != KAI_ACTION_ALLOCATE && cfg->use_scheduling_signatures && !s->job_signature && J > 0) return KAI_ERR_UNSUPPORTED;
         c.action = actions[i]; { int d = cfg->queue_depth[actions[i]]; c.queue_depth = d > 0 ? d : 0; }
         for (int j = 0; j < J; j++) { c.j_state[j] = job_init_state(c, j); if (c.j_state[j] != 3 && c.j_n_ps[j] <= 64) eng.ensure_tta(j, true); }  // k_job_init
         for (int q = 0; q < Q; q++) {                                      // k_leaf_init
