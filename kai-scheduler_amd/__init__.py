@@ -3,9 +3,9 @@
 Holds only what the hot path needs: `csrc/` (HIP kernels + the C ABI of
 include/kai_core.h), `abi` (ctypes mirror + structure-of-arrays snapshot), `core` (the reference's
 Session / Action interface re-exposed over the C ABI) and `synth` (synthetic cluster snapshots of
-BASELINE.json's configs).
+BASELINE.json's configs) and `ingest` (reference-schema snapshot.json / snapshot.zip -> structure-of-arrays snapshot).
 """
-from . import abi, core, dist, synth  # noqa: F401
+from . import abi, core, dist, ingest, synth  # noqa: F401
 from .core import KaiCore, KaiError, Session, load_library  # noqa: F401
 
-__all__ = ["abi", "core", "dist", "synth", "KaiCore", "KaiError", "Session", "load_library"]
+__all__ = ["abi", "core", "dist", "ingest", "synth", "KaiCore", "KaiError", "Session", "load_library"]

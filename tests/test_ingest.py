@@ -1,0 +1,549 @@
+"""Snapshot ingest (SURVEY.md §8f n1 + n4): snapshot.json / snapshot.zip → kai_snapshot_soa.
+
+Pinned on the reference's own tests where they exist (transcribed by hand, source lines cited), on known answers of
+k8s.io/apimachinery's resource.Quantity, and on round trips: every synthetic snapshot written as reference-schema objects and ingested
+again must give back the same arrays and the same scheduling result.
+"""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import kai_testlib as T
+
+pkg = T.pkg
+ing = pkg.ingest
+abi = pkg.abi
+E = ing._EPOCH_NS
+ST = abi.POD_STATUS
+
+
+# ------------------------------------------------------------------------------------------------ ABI
+def test_ingest_library_exports_header_symbols():
+    hdr = open(os.path.join(T.ROOT, "include", "kai_ingest.h")).read()
+    syms = sorted(set(re.findall(r"^(?:int|void|const char\*|const kai_[a-z_]+\*)\s+(kai_[a-z_]+)\s*\(", hdr, flags=re.M)))
+    lib = ing.load_ingest_library()
+    assert set(syms) == set(ing.EXPORTS), (syms, ing.EXPORTS)
+    for s in syms:
+        assert hasattr(lib, s), s
+
+
+# ------------------------------------------------------------------------------------------------ resource.Quantity
+# k8s.io/apimachinery pkg/api/resource: MilliValue() / Value() round up (quantity.go); suffix table of suffix.go
+QUANTITIES = [
+    ("0", 0, 0), ("1", 1000, 1), ("100m", 100, 1), ("1500m", 1500, 2), ("0.1", 100, 1), ("2.5", 2500, 3), ("1k", 1_000_000, 1000),
+    ("20000m", 20000, 20), ("1G", 10**12, 10**9), ("20G", 2 * 10**13, 2 * 10**10), ("1Gi", 2**30 * 1000, 2**30), ("1.5Gi", 1610612736000, 1610612736),
+    ("128974848", 128974848000, 128974848), ("129e6", 129 * 10**9, 129 * 10**6), ("123Mi", 123 * 2**20 * 1000, 123 * 2**20), ("1e3", 10**6, 1000),
+    ("1E3", 10**6, 1000), ("5Ki", 5120000, 5120), ("1u", 1, 1), ("1n", 1, 1), ("999u", 1, 1), ("1001u", 2, 1), ("0.0005", 1, 1), ("1T", 10**15, 10**12),
+    ("1Ti", 2**40 * 1000, 2**40), ("12e-1", 1200, 2), ("+3", 3000, 3), ("1.000", 1000, 1), ("110", 110000, 110),
+]
+
+
+@pytest.mark.parametrize("text,milli,value", QUANTITIES)
+def test_quantity_known_answers(text, milli, value):
+    lib = ing.load_ingest_library()
+    out = C.c_int64()
+    assert lib.kai_quantity_milli(text.encode(), C.byref(out)) == 0 and out.value == milli
+    assert lib.kai_quantity_value(text.encode(), C.byref(out)) == 0 and out.value == value
+
+
+@pytest.mark.parametrize("text", ["", "abc", "1.2.3", "1Zi", "1e", "--1", "1 Gi"])
+def test_quantity_rejects_malformed(text):
+    lib = ing.load_ingest_library()
+    out = C.c_int64()
+    assert lib.kai_quantity_milli(text.encode(), C.byref(out)) == -1
+
+
+# ------------------------------------------------------------------------------------------------ document helpers
+def doc(pods=(), nodes=(), queues=(), pod_groups=(), params=None, config=None, **raw):
+    p = {"schedulerName": "kai-scheduler", "fullHierarchyFairness": True, "useSchedulingSignatures": True}
+    p.update(params or {})
+    r = {"pods": list(pods), "nodes": list(nodes), "queues": list(queues), "podGroups": list(pod_groups)}
+    r.update(raw)
+    return {"config": config if config is not None else {"actions": "allocate"}, "schedulerParams": p, "rawObjects": r}
+
+
+def node(name, cpu="10", mem="64Gi", gpu="8", pods="110", labels=None, taints=None, **extra):
+    alloc = {"cpu": cpu, "memory": mem, "pods": pods}
+    if gpu is not None: alloc["nvidia.com/gpu"] = gpu
+    alloc.update(extra.pop("alloc", {}))
+    n = {"metadata": {"name": name, "labels": labels or {}}, "spec": {}, "status": {"allocatable": alloc}}
+    if taints: n["spec"]["taints"] = taints
+    n["spec"].update(extra.pop("spec", {}))
+    n["status"].update(extra.pop("status", {}))
+    return n
+
+
+def queue(name, parent=None, gpu_quota=-1, labels=None, **spec):
+    s = {"resources": {k: {"quota": -1, "limit": -1, "overQuotaWeight": 1} for k in ("cpu", "memory", "gpu")}}
+    s["resources"]["gpu"]["quota"] = gpu_quota
+    if parent: s["parentQueue"] = parent
+    s.update(spec)
+    return {"metadata": {"name": name, "labels": labels or {}, "creationTimestamp": "2024-01-01T00:00:00Z"}, "spec": s}
+
+
+def pod_group(name, queue_name="q", min_member=1, **spec):
+    s = {"queue": queue_name, "minMember": min_member}
+    s.update(spec)
+    return {"metadata": {"name": name, "namespace": "ns", "creationTimestamp": "2024-01-01T00:00:00Z"}, "spec": s}
+
+
+def pod(name, group=None, requests=None, phase="Pending", node_name=None, **over):
+    md = {"name": name, "namespace": "ns", "uid": "uid-" + name, "creationTimestamp": "2024-01-01T00:00:00Z", "labels": {}, "annotations": {}}
+    if group: md["annotations"]["pod-group-name"] = group
+    spec = {"schedulerName": "kai-scheduler", "containers": [{"name": "c", "resources": {"requests": requests if requests is not None else {"cpu": "1", "memory": "1Gi", "nvidia.com/gpu": "1"}}}]}
+    if node_name: spec["nodeName"] = node_name
+    md["labels"].update(over.pop("labels", {})); md["annotations"].update(over.pop("annotations", {}))
+    md.update(over.pop("metadata", {})); spec.update(over.pop("spec", {}))
+    return {"metadata": md, "spec": spec, "status": dict({"phase": phase}, **over.pop("status", {}))}
+
+
+def ingest(d, **kw):
+    return ing.ingest_json(json.dumps(d), **kw)
+
+
+def rl(cpu, mem, gpu=None):
+    r = {"cpu": cpu, "memory": mem}
+    if gpu is not None: r["nvidia.com/gpu"] = gpu
+    return r
+
+
+# ------------------------------------------------------------------------------------------------ reference known answers
+def test_pod_resource_request_reference_cases():
+    """api/pod_info/pod_info_test.go:42-165 TestGetPodResourceRequest (4 cases): sum of containers, max with each init container,
+    + overhead; expected (gpu, milli-cpu, memory bytes) as the test states them."""
+    cases = [
+        (dict(containers=[rl("1000m", "1G"), rl("2000m", "1G")]), (0, 3000, 2e9)),
+        (dict(init=[rl("2000m", "5G"), rl("2000m", "1G")], containers=[rl("1000m", "1G"), rl("2000m", "1G")]), (0, 3000, 5e9)),
+        (dict(init=[rl("2000m", "5G"), rl("2000m", "1G")], containers=[rl("1000m", "1G", "1"), rl("2000m", "1G")]), (1, 3000, 5e9)),
+        (dict(containers=[rl("1000m", "1G", "1"), rl("2000m", "1G")], overhead=rl("1000m", "1G")), (1, 4000, 3e9)),
+    ]
+    pods = []
+    for i, (c, _) in enumerate(cases):
+        spec = {"containers": [{"name": f"c{k}", "resources": {"requests": r}} for k, r in enumerate(c["containers"])]}
+        if "init" in c: spec["initContainers"] = [{"name": f"i{k}", "resources": {"requests": r}} for k, r in enumerate(c["init"])]
+        if "overhead" in c: spec["overhead"] = c["overhead"]
+        pods.append(pod(f"p{i}", spec=spec))
+    got = ingest(doc(pods=pods)).snapshot
+    for i, (_, (gpu, cpu, mem)) in enumerate(cases):
+        assert tuple(got.pod_req[:, i]) == (cpu, mem, gpu, 1.0), i  # pods := 1 (pod_info.go:390)
+
+
+def test_queue_hierarchy_reference_case():
+    """cache/cluster_info/queue_test.go:15-54 TestUpdateQueueHierarchySetChildQueues: the orphan goes, six queues stay."""
+    qs = [queue("queue1", "dep1"), queue("dep1"), queue("queue2", "dep2"), queue("queue3", "dep2"), queue("dep2"), queue("dep3"), queue("orphan", "unexisting")]
+    got = ingest(doc(queues=qs))
+    s = got.snapshot
+    assert s.n_queues == 6 and "orphan" not in s.queue_names
+    par = {n: (s.queue_names[p] if p >= 0 else None) for n, p in zip(s.queue_names, s.queue_parent)}
+    assert par == {"queue1": "dep1", "dep1": None, "queue2": "dep2", "queue3": "dep2", "dep2": None, "dep3": None}
+    assert any("orphan" in w for w in got.warnings)
+    # an orphan's whole subtree goes with it (queue.go:117-129)
+    got = ingest(doc(queues=[queue("a", "missing"), queue("b", "a"), queue("c", "b"), queue("d")]))
+    assert got.snapshot.queue_names == ["d"]
+
+
+def test_flat_hierarchy_reference_case():
+    """cache/cluster_info/cluster_info_test.go:1392-1481 TestSnapshotFlatHierarchy: without full-hierarchy fairness the parents are replaced by
+    one unlimited "default" queue; partition label filter on the queues."""
+    lab = {"pool": "nodepool-a"}
+    dep = lambda n: dict(queue(n, labels=lab), spec={"resources": {"gpu": {"quota": 4, "overQuotaWeight": 2, "limit": 10}}})
+    qs = [dep("department0"), dep("department1"), queue("queue0", "department0", labels=lab), queue("queue1", "department1", labels=lab),
+          queue("elsewhere", "department0", labels={"pool": "nodepool-b"})]
+    got = ingest(doc(queues=qs, params={"fullHierarchyFairness": False, "partitionParams": {"NodePoolLabelKey": "pool", "NodePoolLabelValue": "nodepool-a"}}))
+    s = got.snapshot
+    assert sorted(s.queue_names) == ["default", "queue0", "queue1"]
+    d = s.queue_names.index("default")
+    assert s.queue_parent[d] == -1 and all(s.queue_parent[i] == d for i in range(3) if i != d)
+    assert list(s.queue_deserved[:, d]) == [-1, -1, -1] and list(s.queue_limit[:, d]) == [-1, -1, -1] and list(s.queue_oqw[:, d]) == [1, 1, 1]
+
+
+def test_node_accounting_reference_case():
+    """cache/cluster_info/cluster_info_test.go:244-310 TestSnapshotNodes "BasicUsage": 10 cpu / 110 pods, one Running 2-cpu pod →
+    idle 8 cpu / 109 pods, used 2 cpu / 1 pod.  The accounting itself is the oracle's; the ingest supplies the quantities."""
+    d = doc(nodes=[node("node-1", cpu="10", mem="0", gpu=None)], pods=[pod("p", requests={"cpu": "2"}, phase="Running", node_name="node-1")])
+    got = ingest(d)
+    s = got.snapshot
+    assert s.pod_status[0] == ST["Running"] and s.pod_node[0] == 0 and s.pod_job[0] == -1
+    res = T.Oracle.run(s, got.config, ())
+    assert res.nodes["idle"][0, 0] == 8000 and res.nodes["idle"][0, 3] == 109 and res.nodes["used"][0, 0] == 2000 and res.nodes["used"][0, 3] == 1
+
+
+def test_priority_and_preemptibility_rules():
+    """cluster_info.go:495-531 (priority class by name, else the globalDefault class, else 50) and pkg/common/podgroup/preemptible.go:10-26."""
+    pcs = [{"metadata": {"name": "train"}, "value": 50}, {"metadata": {"name": "build"}, "value": 100}, {"metadata": {"name": "dflt"}, "value": 75, "globalDefault": True}]
+    pgs = [pod_group("a", priorityClassName="train"), pod_group("b", priorityClassName="build"), pod_group("c", priorityClassName="nope"), pod_group("d"),
+           pod_group("e", priorityClassName="build", preemptibility="preemptible"), pod_group("f", priorityClassName="train", preemptibility="non-preemptible"),
+           pod_group("g", queue_name="missing", priorityClassName="build")]
+    s = ingest(doc(queues=[queue("q")], pod_groups=pgs, priorityClasses=pcs)).snapshot
+    assert list(s.job_priority) == [50, 100, 75, 75, 100, 50, 0]
+    assert list(s.job_preemptible) == [1, 0, 1, 1, 1, 0, 0]
+    assert list(s.job_queue) == [0] * 6 + [-1]
+    s = ingest(doc(queues=[queue("q")], pod_groups=[pod_group("a")])).snapshot
+    assert list(s.job_priority) == [50]  # DefaultPodGroupPriority
+
+
+def test_pod_status_rules():
+    """api/pod_info/pod_info.go:410-445 getTaskStatus + NodeName from the bind request (:176-179); failed bind requests are ignored
+    (bindrequest_info.go:84-92) and so are those for unknown nodes (cluster_info.go:337-345)."""
+    del_ts = {"deletionTimestamp": "2024-01-02T00:00:00Z"}
+    pods = [pod("running", phase="Running", node_name="n0"), pod("releasing", phase="Running", node_name="n0", metadata=del_ts),
+            pod("pend-del", metadata=del_ts), pod("bound", node_name="n0"), pod("binding"), pod("bind-failed"), pod("bind-retry"), pod("bind-nonode"),
+            pod("gated", spec={"schedulingGates": [{"name": "g"}]}), pod("pending"), pod("succeeded", phase="Succeeded", node_name="n0"),
+            pod("failed", phase="Failed"), pod("unknown", phase="Unknown"), pod("weird", phase="")]
+    brs = [{"metadata": {"namespace": "ns"}, "spec": {"podName": "binding", "selectedNode": "n0"}},
+           {"metadata": {"namespace": "ns"}, "spec": {"podName": "bind-failed", "selectedNode": "n0"}, "status": {"phase": "Failed"}},
+           {"metadata": {"namespace": "ns"}, "spec": {"podName": "bind-retry", "selectedNode": "n0", "backoffLimit": 3}, "status": {"phase": "Failed", "failedAttempts": 1}},
+           {"metadata": {"namespace": "ns"}, "spec": {"podName": "bind-nonode", "selectedNode": "gone"}}]
+    s = ingest(doc(nodes=[node("n0")], pods=pods, bindRequests=brs)).snapshot
+    names = [n.split("/")[1] for n in s.pod_names]
+    st = {n: (int(s.pod_status[i]), int(s.pod_node[i])) for i, n in enumerate(names)}
+    assert st == {"running": (ST["Running"], 0), "releasing": (ST["Releasing"], 0), "pend-del": (ST["Releasing"], -1), "bound": (ST["Bound"], 0),
+                  "binding": (ST["Binding"], 0), "bind-failed": (ST["Pending"], -1), "bind-retry": (ST["Binding"], 0), "bind-nonode": (ST["Pending"], -1),
+                  "gated": (ST["Gated"], -1), "pending": (ST["Pending"], -1), "succeeded": (ST["Succeeded"], 0), "failed": (ST["Failed"], -1),
+                  "unknown": (ST["Unknown"], -1), "weird": (ST["Unknown"], -1)}
+
+
+def test_node_rules():
+    """scheduler_util/scheduler_utils.go:12-40 (conditions), node_info.go:619-640 (gpu.count), :704-732 (MIG), resource_info.go:53-79 (units),
+    cluster_info.go:533-549 (restrictSchedulingNodes keeps labelled nodes only)."""
+    cond = lambda t, s: {"type": t, "status": s}
+    nodes = [node("a", cpu="64", mem="512Gi", gpu="8", labels={"nvidia.com/gpu.count": "8", "node-role.kubernetes.io/gpu-worker": ""}, status={"conditions": [cond("Ready", "True"), cond("MemoryPressure", "False")]}),
+             node("b", cpu="1500m", mem="1G", gpu=None, labels={"node-role.kubernetes.io/cpu-worker": "x"}, status={"conditions": [cond("Ready", "False")]}),
+             node("c", spec={"unschedulable": True}), node("d", status={"conditions": [cond("Ready", "True"), cond("DiskPressure", "Unknown")]}),
+             node("e", labels={"node-role.kubernetes.io/mig-enabled": "true", "nvidia.com/mig.strategy": "mixed", "nvidia.com/gpu.count": "x"}),
+             node("f", alloc={"nvidia.com/mig-1g.5gb": "7"}), node("g", gpu=None, alloc={"amd.com/gpu": "4", "example.com/foo": "3", "ephemeral-storage": "10Gi"})]
+    s = ingest(doc(nodes=nodes, pods=[pod("p", requests={"example.com/foo": "2", "ephemeral-storage": "1Gi", "cpu": "1"})])).snapshot
+    f = dict(zip(s.node_names, (int(x) for x in s.node_flags)))
+    assert f["a"] == abi.NODE_GPU_WORKER and f["b"] == abi.NODE_NOT_READY | abi.NODE_CPU_WORKER and f["c"] == abi.NODE_NOT_READY and f["d"] == abi.NODE_NOT_READY
+    assert f["e"] == abi.NODE_MIG_ENABLED | abi.NODE_MIG_MIXED and f["f"] == abi.NODE_MIG_ENABLED and f["g"] == 0
+    assert list(s.node_gpu_count) == [8, -1, -1, -1, -1, -1, -1]
+    assert list(s.node_allocatable[:4, 0]) == [64000, 512 * 2**30, 8, 110] and list(s.node_allocatable[:4, 1]) == [1500, 1e9, 0, 110]
+    assert s.node_allocatable[2, 6] == 4  # amd.com/gpu counts as gpu (resource_requirment.go:17-18)
+    # scalar columns appear only for resources some pod requests, alphabetical: ephemeral-storage → Value, extended → MilliValue, on both sides
+    got = ingest(doc(nodes=nodes, pods=[pod("p", requests={"example.com/foo": "2", "ephemeral-storage": "1Gi", "cpu": "1"})]))
+    assert got.resource_names == ["cpu", "memory", "gpu", "pods", "ephemeral-storage", "example.com/foo"] and got.snapshot.n_res == 6
+    assert list(got.snapshot.node_allocatable[4:, 6]) == [10 * 2**30, 3000] and list(got.snapshot.pod_req[:, 0]) == [1000, 0, 0, 1, 2**30, 2000]
+    kept = ingest(doc(nodes=nodes, params={"restrictSchedulingNodes": True})).snapshot
+    assert kept.node_names == ["a", "b"]
+
+
+def test_subgroup_tree_rules():
+    """subgroup_info/factory.go:16-135: entries with children become SubGroupSets, leaves PodSets (minAvailable = max(minMember, 1)), parents are
+    lower-cased, the root carries spec.topologyConstraint; job_info.go:231-251: a pod whose sub-group is unknown stays out of the job."""
+    topo = {"metadata": {"name": "t"}, "spec": {"levels": [{"nodeLabel": "zone"}, {"nodeLabel": "rack"}]}}
+    sgs = [{"name": "workers", "topologyConstraint": {"topology": "t", "requiredTopologyLevel": "rack"}}, {"name": "w-a", "parent": "Workers", "minMember": 2},
+           {"name": "w-b", "parent": "workers", "minMember": 0, "topologyConstraint": {"topology": "t", "preferredTopologyLevel": "rack"}}, {"name": "leader", "minMember": 1}]
+    pg = pod_group("job", subGroups=sgs, topologyConstraint={"topology": "t", "requiredTopologyLevel": "zone", "preferredTopologyLevel": "nope"})
+    pods = [pod("l0", "job", labels={"kai.scheduler/subgroup-name": "leader"}), pod("a0", "job", labels={"kai.scheduler/subgroup-name": "w-a"}),
+            pod("a1", "job", labels={"kai.scheduler/subgroup-name": "w-a"}), pod("b0", "job", labels={"kai.scheduler/subgroup-name": "w-b"}),
+            pod("stray", "job"), pod("lost", "job", labels={"kai.scheduler/subgroup-name": "ghost"}), pod("solo", "other"), pod("free")]
+    nodes = [node("n0", labels={"zone": "z0", "rack": "r0"}), node("n1", labels={"zone": "z0", "rack": "r1"}), node("n2", labels={"zone": "z1"}), node("n3")]
+    got = ingest(doc(nodes=nodes, queues=[queue("q")], pods=pods, pod_groups=[pg, pod_group("other", min_member=3)], topologies=[topo]))
+    s = got.snapshot
+    assert s.job_names == ["job", "other"] and list(s.job_n_podsets) == [3, 1] and list(s.job_n_pods) == [4, 1]
+    assert s.podset_names == ["w-a", "w-b", "leader", "default"] and list(s.podset_min_available) == [2, 1, 1, 3]
+    assert list(s.podset_name_rank) == [1, 2, 0, 0]  # leader < w-a < w-b inside the job
+    # groups: job root (zone required, unknown preferred level lies beyond the last level), "workers" (rack required), root of "other"
+    assert list(s.group_job) == [0, 0, 1] and list(s.group_parent) == [-1, 0, -1] and list(s.job_root_group) == [0, 2]
+    assert list(s.group_topology) == [0, 0, -1] and list(s.group_required_level) == [0, 1, -1] and list(s.group_preferred_level) == [10**6, -1, -1]
+    assert list(s.podset_group) == [1, 1, 0, 2] and list(s.podset_topology) == [-1, 0, -1, -1] and list(s.podset_preferred_level) == [-1, 1, -1, -1]
+    names = [n.split("/")[1] for n in s.pod_names]
+    assert names[:5] == ["l0", "a0", "a1", "b0", "solo"] and sorted(names[5:]) == ["free", "lost", "stray"]
+    assert list(s.pod_job) == [0, 0, 0, 0, 1, -1, -1, -1] and list(s.pod_podset[:5]) == [2, 0, 0, 1, 3]
+    assert sum("left out of the job" in w for w in got.warnings) == 2
+    # topology tables: a node joins only with every level label (topology/common.go:70-77); domain ids "z0", "z0.r0", "z0.r1"
+    assert list(s.topo_level_off) == [0, 2] and s.node_domain.tolist() == [[0, 0, -1, -1], [1, 2, -1, -1]]
+    assert list(s.domain_level) == [0, 1, 1] and list(s.domain_parent) == [-1, 0, 0] and list(s.domain_id_rank) == [0, 1, 2]
+
+
+def test_static_predicate_classes():
+    """n4: NodeAffinity (nodeSelector + required terms: In, NotIn, Exists, DoesNotExist, Gt, Lt, matchFields) and TaintToleration
+    (NoSchedule / NoExecute only; Equal / Exists, empty key, effect match) — k8s.io/kubernetes v1.34.2 semantics."""
+    taint = lambda k, v, e: {"key": k, "value": v, "effect": e}
+    nodes = [node("plain"), node("a100", labels={"gpu": "a100", "mem": "80"}), node("h100", labels={"gpu": "h100", "mem": "94"}),
+             node("tainted", labels={"gpu": "a100", "mem": "40"}, taints=[taint("dedicated", "ml", "NoSchedule")]),
+             node("soft", taints=[taint("x", "y", "PreferNoSchedule")]), node("evict", taints=[taint("down", "", "NoExecute")])]
+    term = lambda *ex: {"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [{"matchExpressions": list(ex)}]}}}}
+    ex = lambda k, op, *v: dict({"key": k, "operator": op}, **({"values": list(v)} if v else {}))
+    cases = {
+        "any": ({}, {"plain", "a100", "h100", "soft"}),
+        "selector": ({"nodeSelector": {"gpu": "a100"}}, {"a100"}),
+        "in": (term(ex("gpu", "In", "a100", "h100")), {"a100", "h100"}),
+        "notin": (term(ex("gpu", "NotIn", "a100")), {"plain", "h100", "soft"}),
+        "exists": (term(ex("gpu", "Exists")), {"a100", "h100"}),
+        "absent": (term(ex("gpu", "DoesNotExist")), {"plain", "soft"}),
+        "gt": (term(ex("mem", "Gt", "79")), {"a100", "h100"}),
+        "lt": (term(ex("mem", "Lt", "90")), {"a100"}),
+        "and": (term(ex("gpu", "Exists"), ex("mem", "Gt", "90")), {"h100"}),
+        "or": ({"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [
+            {"matchExpressions": [ex("gpu", "In", "h100")]}, {"matchFields": [ex("metadata.name", "In", "plain")]}]}}}}, {"h100", "plain"}),
+        "emptyterms": ({"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": []}}}}, set()),
+        "emptyterm": ({"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [{}]}}}}, set()),
+        "tol-equal": ({"tolerations": [{"key": "dedicated", "operator": "Equal", "value": "ml", "effect": "NoSchedule"}]}, {"plain", "a100", "h100", "soft", "tainted"}),
+        "tol-wrongvalue": ({"tolerations": [{"key": "dedicated", "value": "web"}]}, {"plain", "a100", "h100", "soft"}),
+        "tol-exists": ({"tolerations": [{"key": "dedicated", "operator": "Exists"}]}, {"plain", "a100", "h100", "soft", "tainted"}),
+        "tol-all": ({"tolerations": [{"operator": "Exists"}]}, {"plain", "a100", "h100", "soft", "tainted", "evict"}),
+        "tol-effect": ({"tolerations": [{"operator": "Exists", "effect": "NoExecute"}]}, {"plain", "a100", "h100", "soft", "evict"}),
+        "both": ({"nodeSelector": {"gpu": "a100"}, "tolerations": [{"key": "dedicated", "operator": "Exists"}]}, {"a100", "tainted"}),
+    }
+    pods = [pod(n, spec=spec) for n, (spec, _) in cases.items()]
+    s = ingest(doc(nodes=nodes, pods=pods)).snapshot
+    for i, (n, (_, want)) in enumerate(cases.items()):
+        fit = {s.node_names[k] for k in range(s.n_nodes) if s.class_fit[s.pod_class[i], s.node_class[k]]}
+        assert fit == want, (n, fit, want)
+    assert s.n_node_classes <= 6 and s.n_pod_classes <= len(cases)
+    # nodes that no constraint can tell apart share a class
+    s2 = ingest(doc(nodes=nodes, pods=[pod("p")])).snapshot
+    assert s2.n_pod_classes == 1 and s2.n_node_classes == 3  # untainted / dedicated:NoSchedule / down:NoExecute
+
+
+def test_fallback_flags_and_config_maps():
+    """SURVEY §8b fallback rule + k8s_internal/predicates/config_maps.go (a missing non-optional config map fits no node)."""
+    cm_vol = {"volumes": [{"name": "v", "configMap": {"name": "cm1"}}], "containers": [{"name": "c", "volumeMounts": [{"name": "v"}], "resources": {}}]}
+    pods = [pod("frac", annotations={"gpu-fraction": "0.5"}), pod("mem", annotations={"gpu-memory": "2000"}), pod("mig", requests={"nvidia.com/mig-1g.5gb": "1"}),
+            pod("port", spec={"containers": [{"name": "c", "ports": [{"hostPort": 80}]}]}), pod("pvc", spec={"volumes": [{"name": "d", "persistentVolumeClaim": {"claimName": "x"}}]}),
+            pod("dra", spec={"resourceClaims": [{"name": "c"}]}), pod("aff", spec={"affinity": {"podAffinity": {}}}), pod("ok"),
+            pod("cm-ok", spec=cm_vol), pod("cm-missing", spec=dict(cm_vol, volumes=[{"name": "v", "configMap": {"name": "nope"}}])),
+            pod("cm-optional", spec=dict(cm_vol, volumes=[{"name": "v", "configMap": {"name": "nope", "optional": True}}])),
+            pod("cm-unmounted", spec={"volumes": [{"name": "v", "configMap": {"name": "nope"}}]}),
+            pod("cm-env", spec={"containers": [{"name": "c", "env": [{"name": "E", "valueFrom": {"configMapKeyRef": {"name": "nope", "key": "k"}}}]}]}),
+            pod("foreign", spec={"schedulerName": "default-scheduler"}), pod("prio", labels={"kai.scheduler/task-priority": "7"})]
+    s = ingest(doc(nodes=[node("n")], pods=pods, configMaps=[{"metadata": {"name": "cm1", "namespace": "ns"}}])).snapshot
+    names = [n.split("/")[1] for n in s.pod_names]
+    fl = {n: int(s.pod_flags[i]) for i, n in enumerate(names)}
+    for n in ("frac", "mem", "mig", "port", "pvc", "dra", "aff"):
+        assert fl[n] & abi.POD_CPU_FALLBACK, n
+    for n in ("ok", "cm-ok", "cm-missing", "foreign", "prio"):
+        assert not fl[n] & abi.POD_CPU_FALLBACK, n
+    assert fl["foreign"] & abi.POD_FOREIGN_SCHEDULER and not fl["ok"] & abi.POD_FOREIGN_SCHEDULER
+    assert fl["prio"] & abi.POD_HAS_TASK_PRIORITY and s.pod_task_priority[names.index("prio")] == 7
+    fits = {n: bool(s.class_fit[s.pod_class[i], s.node_class[0]]) for i, n in enumerate(names)}
+    assert fits["cm-ok"] and fits["cm-optional"] and fits["cm-unmounted"] and fits["ok"] and not fits["cm-missing"] and not fits["cm-env"]
+
+
+def test_config_and_actions():
+    """conf/scheduler_conf.go:31-88, conf_util/scheduler_conf_util.go:36-107, plugin arguments (nodeplacement.go:59-70, proportion.go:67-93,
+    minruntime.go:40-70)."""
+    got = ingest(doc(config={}))
+    assert got.actions == ["allocate", "consolidation", "reclaim", "preempt"] and got.config.plugins == abi.PLUGIN_ALL  # defaults; stalegangeviction is skipped
+    assert got.config.k_value == 1.0 and got.config.gpu_strategy == abi.BINPACK and list(got.config.queue_depth) == [-1] * 4 and got.config.min_node_gpu_memory == 100
+    tiers = [{"plugins": [{"name": "predicates"}, {"name": "proportion", "arguments": {"kValue": "0.5", "relcaimerSaturationMultiplier": "1.5"}}, {"name": "gpupack"},
+                          {"name": "nodeplacement", "arguments": {"gpu": "spread", "cpu": "binpack"}},
+                          {"name": "minruntime", "arguments": {"defaultPreemptMinRuntime": "5m", "defaultReclaimMinRuntime": "1h30m", "reclaimResolveMethod": "queue"}}]}]
+    got = ingest(doc(config={"actions": "reclaim, allocate", "tiers": tiers, "queueDepthPerAction": {"reclaim": 10, "preempt": 3}},
+                     params={"maxNumberConsolidationPreemptees": 16, "allowConsolidatingReclaim": True, "restrictSchedulingNodes": True}), now_ns=123)
+    c = got.config
+    assert got.actions == ["reclaim", "allocate"]
+    assert c.plugins == abi.PLUGINS["predicates"] | abi.PLUGINS["proportion"] | abi.PLUGINS["nodeplacement"] | abi.PLUGINS["minruntime"]
+    assert (c.k_value, c.reclaimer_saturation_multiplier, c.gpu_strategy, c.cpu_strategy) == (0.5, 1.5, abi.SPREAD, abi.BINPACK)
+    assert (c.default_preempt_min_runtime_ns, c.default_reclaim_min_runtime_ns, c.reclaim_resolve_method) == (300 * 10**9, 5400 * 10**9, 1)
+    assert list(c.queue_depth) == [-1, -1, 10, 3] and c.max_consolidation_preemptees == 16 and c.allow_consolidating_reclaim == 1 and c.restrict_node_scheduling == 1
+    assert c.now_ns == 123 and any("gpupack" in w for w in got.warnings)
+    with pytest.raises(ing.IngestError, match="failed to find Action bogus"):
+        ingest(doc(config={"actions": "allocate, bogus"}))
+
+
+def test_queue_fields_and_minruntime_inputs():
+    q = queue("q", gpu_quota=8, priority=200, preemptMinRuntime="10m", reclaimMinRuntime="1m30s")
+    q["spec"]["resources"]["cpu"] = {"quota": 16000, "limit": 32000, "overQuotaWeight": 2}
+    pg = pod_group("j"); pg["metadata"]["annotations"] = {"kai.scheduler/last-start-timestamp": "2024-03-01T12:00:00+02:00"}
+    got = ingest(doc(queues=[q, queue("plain")], pod_groups=[pg, pod_group("k")]))
+    s = got.snapshot
+    assert list(s.queue_priority) == [200, 100] and list(s.queue_deserved[:, 0]) == [16000, -1, 8] and list(s.queue_limit[:, 0]) == [32000, -1, -1] and list(s.queue_oqw[:, 0]) == [2, 1, 1]
+    assert list(s.queue_preempt_min_runtime_ns) == [600 * 10**9, -1] and list(s.queue_reclaim_min_runtime_ns) == [90 * 10**9, -1]
+    assert list(s.job_last_start_ns) == [1709287200 * 10**9, 0]  # 2024-03-01T10:00:00Z
+    assert got.config.now_ns == 1709287200 * 10**9  # default "now": the latest timestamp in the snapshot
+    assert s.queue_created_ns[0] == 1704067200 * 10**9
+
+
+def test_scheduling_signatures():
+    """job_info.go:547-570 / podset.go:167-196 / scheduling_constraints_signature.go: equal constraint sets ⇔ equal ids; resource requests,
+    names and placed pods do not enter."""
+    sel = {"nodeSelector": {"gpu": "a100", "zone": "z"}}
+    sel_reordered = {"nodeSelector": {"zone": "z", "gpu": "a100"}}
+    pods = [pod("a0", "a", spec=sel), pod("a1", "a", spec=sel), pod("b0", "b", spec=sel_reordered, requests={"cpu": "9"}), pod("b1", "b", spec=sel),
+            pod("c0", "c", spec=sel), pod("d0", "d"), pod("e0", "e"), pod("e1", "e", phase="Running", node_name="n", spec=sel),
+            pod("f0", "f", spec=dict(sel, tolerations=[{"operator": "Exists"}]))]
+    s = ingest(doc(nodes=[node("n", labels={"gpu": "a100", "zone": "z"})], queues=[queue("q")], pods=pods, pod_groups=[pod_group(x) for x in "abcdef"])).snapshot
+    sig = dict(zip(s.job_names, (int(x) for x in s.job_signature)))
+    assert sig["a"] == sig["b"] and sig["d"] == sig["e"] and len({sig["a"], sig["c"], sig["d"], sig["f"]}) == 4
+
+
+def test_malformed_input_is_rejected():
+    for text in ("", "{", "[1,2", '{"a":}', '{"a":1}x', "nul"):
+        with pytest.raises(ing.IngestError):
+            ing.ingest_json(text)
+    with pytest.raises(ing.IngestError, match="bad quantity"):
+        ingest(doc(nodes=[node("n", cpu="lots")]))
+    with pytest.raises(ing.IngestError, match="cannot open"):
+        ing.ingest_file("/nonexistent/snapshot.zip")
+    assert ingest({"rawObjects": {}}).snapshot.n_nodes == 0  # an empty cluster is a valid snapshot
+
+
+def test_json_escapes_and_unicode_names():
+    raw = json.dumps(doc(nodes=[node("n")])).replace('"n"', '"n\\u00e9\\ud83d\\ude00\\t\\"q\\""', 1)
+    s = ing.ingest_json(raw).snapshot
+    assert s.node_names == ['né\U0001F600\t"q"']
+
+
+# ------------------------------------------------------------------------------------------------ round trips
+def _assert_same_arrays(snap, got):
+    a, b = snap.arrays, got.arrays
+    for k, x in a.items():
+        if k in ("job_signature", "class_fit", "pod_class", "node_class", "queue_usage", "domain_id_rank", "node_domain", "domain_level", "domain_parent", "group_name_rank"):
+            continue
+        y = b[k]
+        if k in ("pod_created_ns", "job_created_ns", "queue_created_ns"): y = y - E
+        if k == "job_last_start_ns": y = np.where(y != 0, y - E, 0)
+        if k == "pod_task_priority": x = np.where(a["pod_flags"] & abi.POD_HAS_TASK_PRIORITY, x, 0)  # only read under the flag
+        assert x.shape == y.shape and np.array_equal(x, y), k
+    if snap.n_pods and snap.n_nodes:  # the class tables may be factored differently; the pod × node fit relation must be the same
+        assert np.array_equal(a["class_fit"][a["pod_class"]][:, a["node_class"]], b["class_fit"][b["pod_class"]][:, b["node_class"]])
+    if "group_name_rank" in a:  # only siblings are ever compared (framework/session_plugins.go:273-282): same order under every parent
+        sib = lambda arr, g: sum(1 for h in range(len(arr)) if a["group_job"][h] == a["group_job"][g] and a["group_parent"][h] == a["group_parent"][g] and arr[h] < arr[g])
+        for g in range(len(a["group_job"])):
+            assert sib(a["group_name_rank"], g) == sib(b["group_name_rank"], g)
+    if "domain_id_rank" in a:  # domain numbering is free: the tables must be the same up to the renumbering the node rows induce
+        m = {-1: -1}
+        for x, y in zip(a["node_domain"].ravel().tolist(), b["node_domain"].ravel().tolist()):
+            assert m.setdefault(x, y) == y
+        assert len(set(m.values())) == len(m) and len(m) - 1 == len(b["domain_level"]) == len(a["domain_level"])
+        for d in range(len(a["domain_level"])):
+            assert a["domain_level"][d] == b["domain_level"][m[d]] and m[int(a["domain_parent"][d])] == b["domain_parent"][m[d]]
+        for lv in np.unique(a["domain_level"]):  # ranks are order-isomorphic inside a level
+            ds = [d for d in range(len(a["domain_level"])) if a["domain_level"][d] == lv]
+            assert sorted(ds, key=lambda d: a["domain_id_rank"][d]) == sorted(ds, key=lambda d: b["domain_id_rank"][m[d]])
+    # job_signature is not compared: a synthetic snapshot carries arbitrary ids, the ingest derives them from the pods' constraints
+    # (test_scheduling_signatures); the round-trip tests hand the derived ids to both runs.
+
+
+def _roundtrip(snap, cfg, actions):
+    d = ing.export_snapshot_json(snap, cfg, actions)
+    got = ing.ingest_json(json.dumps(d))
+    _assert_same_arrays(snap, got.snapshot)
+    assert got.actions == list(actions) and not got.warnings
+    for f, _ in abi.KaiConfig._fields_:
+        if f in ("now_ns", "engine_mode", "reserved", "queue_depth", "full_hierarchy_fairness", "pad0", "min_node_gpu_memory"):
+            continue
+        assert getattr(got.config, f) == getattr(cfg, f), f
+    assert list(got.config.queue_depth) == list(cfg.queue_depth)
+    return got
+
+
+@pytest.mark.parametrize("idx,scale", [(0, 1.0), (1, 0.05), (2, 0.01), (3, 0.01)])
+def test_roundtrip_baseline_configs(idx, scale):
+    snap, cfg, _ = pkg.synth.config(idx, scale=scale)
+    acts = ("allocate",) if idx < 3 else ("allocate", "consolidation", "reclaim")
+    got = _roundtrip(snap, cfg, acts)
+    snap.arrays["job_signature"] = got.snapshot.arrays["job_signature"]
+    ref, res = T.Oracle.run(snap, cfg, acts), T.Oracle.run(got.snapshot, got.config, tuple(got.actions))
+    assert ref.ops == res.ops and len(ref.ops) > 0
+    assert np.array_equal(ref.pod_status, res.pod_status) and np.array_equal(ref.pod_node, res.pod_node)
+    assert np.array_equal(ref.shares_final["fair_share"], res.shares_final["fair_share"])
+
+
+@pytest.mark.parametrize("seed", range(1000, 1010))
+def test_roundtrip_randomized_cycles(seed):
+    """Seeds of the broad campaign (full cycles incl. the victim actions: signatures, minruntime inputs, elastic gangs, two pod-sets, replica / rack
+    topology, lexicographic node names) through the file format: same arrays, same scheduling result."""
+    seen = set()
+    for snap, cfg, acts in T.broad_case(seed):
+        if id(snap) not in seen:  # one snapshot serves several action orders: shift it to absolute time once
+            seen.add(id(snap))
+            a = snap.arrays
+            if "queue_usage" in a: a["queue_usage"][:] = 0  # usage history is not part of the snapshot schema
+            got = ing.ingest_json(json.dumps(ing.export_snapshot_json(snap, cfg, acts)), now_ns=E + int(cfg.now_ns))
+            _assert_same_arrays(snap, got.snapshot)
+            if "job_last_start_ns" in a: a["job_last_start_ns"] = np.where(a["job_last_start_ns"] != 0, a["job_last_start_ns"] + E, 0)
+            a["job_signature"] = got.snapshot.arrays["job_signature"]
+            ingested = got.snapshot
+        cfg2 = ing.ingest_json(json.dumps(ing.export_snapshot_json(ingested, cfg, acts)), now_ns=E + int(cfg.now_ns)).config
+        ref_cfg = abi.KaiConfig.from_buffer_copy(cfg); ref_cfg.now_ns = E + int(cfg.now_ns)
+        ref, res = T.Oracle.run(snap, ref_cfg, acts), T.Oracle.run(ingested, cfg2, acts)
+        assert ref.ops == res.ops
+        assert np.array_equal(ref.pod_status, res.pod_status) and np.array_equal(ref.pod_node, res.pod_node)
+
+
+def test_snapshot_zip(tmp_path):
+    """BASELINE config 1 as an actual snapshot.zip (plugins/snapshot/snapshot.go:33, cmd/snapshot-tool/main.go:118-147): deflated and stored members."""
+    import zipfile
+    snap, cfg, _ = pkg.synth.config(0)
+    d = ing.export_snapshot_json(snap, cfg, ("allocate",))
+    z = tmp_path / "snapshot.zip"
+    ing.write_snapshot_zip(str(z), d)
+    got = ing.ingest_file(str(z))
+    _assert_same_arrays(snap, got.snapshot)
+    with zipfile.ZipFile(tmp_path / "stored.zip", "w", zipfile.ZIP_STORED) as f:
+        f.writestr("readme.txt", "x"); f.writestr("snapshot.json", json.dumps(d))
+    _assert_same_arrays(snap, ing.ingest_file(str(tmp_path / "stored.zip")).snapshot)
+    (tmp_path / "plain.json").write_text(json.dumps(d))
+    _assert_same_arrays(snap, ing.ingest_file(str(tmp_path / "plain.json")).snapshot)
+    with zipfile.ZipFile(tmp_path / "empty.zip", "w") as f:
+        f.writestr("other.json", "{}")
+    with pytest.raises(ing.IngestError, match="snapshot.json"):
+        ing.ingest_file(str(tmp_path / "empty.zip"))
+    ref, res = T.Oracle.run(snap, cfg, ("allocate",)), T.Oracle.run(got.snapshot, got.config, tuple(got.actions))
+    assert ref.ops == res.ops and len(res.ops) == 64
+
+
+def _rich_document():
+    """A small cluster using what only the file format carries: taints / selectors, pods of no job, extended resources, sub-groups."""
+    nodes = [node(f"gpu-{i}", labels={"pool": "gpu", "zone": f"z{i // 2}"}, alloc={"example.com/nic": "2"}) for i in range(4)]
+    nodes += [node(f"cpu-{i}", gpu=None, cpu="32", labels={"pool": "cpu"}, taints=[{"key": "cpu-only", "value": "", "effect": "NoSchedule"}]) for i in range(2)]
+    qs = [queue("dep"), queue("team-a", "dep", gpu_quota=8), queue("team-b", "dep", gpu_quota=8)]
+    pods, pgs = [pod("daemon", requests={"cpu": "500m"}, phase="Running", node_name="gpu-0", spec={"schedulerName": "default-scheduler"})], []
+    for j in range(10):
+        team = "team-a" if j % 2 else "team-b"
+        pgs.append(pod_group(f"job-{j}", team, min_member=2 if j % 3 == 0 else 1, priorityClassName="train"))
+        pgs[-1]["metadata"]["creationTimestamp"] = f"2024-01-01T00:{j:02d}:00Z"
+        for k in range(2 if j % 3 == 0 else 1):
+            spec = {}
+            if j % 4 == 0: spec = {"nodeSelector": {"zone": "z1"}}
+            if j % 5 == 1: spec = {"tolerations": [{"key": "cpu-only", "operator": "Exists"}], "nodeSelector": {"pool": "cpu"}}
+            req = {"cpu": "2", "memory": "4Gi"} if j % 5 == 1 else {"cpu": "4", "memory": "8Gi", "nvidia.com/gpu": str(1 + j % 3)}
+            if j == 7: req["example.com/nic"] = "2"
+            pods.append(pod(f"job-{j}-{k}", f"job-{j}", requests=req, spec=spec, metadata={"creationTimestamp": f"2024-01-01T00:{j:02d}:0{k}Z"}))
+    pods.append(pod("run-0", "job-running", phase="Running", node_name="gpu-1", requests={"cpu": "4", "memory": "8Gi", "nvidia.com/gpu": "6"}))
+    pgs.append(pod_group("job-running", "team-a", priorityClassName="train"))
+    return doc(nodes=nodes, queues=qs, pods=pods, pod_groups=pgs, priorityClasses=[{"metadata": {"name": "train"}, "value": 50}],
+               config={"actions": "allocate, reclaim"}, params={"maxNumberConsolidationPreemptees": 16, "allowConsolidatingReclaim": True})
+
+
+def test_rich_document_schedules_identically_in_oracle_and_engine():
+    """Ingest → the engine's control flow (host-compiled) and the oracle agree on a snapshot with predicate classes, pods of no job and an extra
+    resource column; placements honour selectors and taints."""
+    import test_engine_hostsim as H
+    got = ingest(_rich_document())
+    s = got.snapshot
+    assert got.resource_names[4:] == ["example.com/nic"] and s.n_pod_classes == 3 and s.n_node_classes == 3 and not got.warnings
+    ref = T.Oracle.run(s, got.config, tuple(got.actions))
+    sim = H.HostSim.run(s, got.config, tuple(got.actions))
+    assert sim.ops == ref.ops and np.array_equal(sim.pod_status, ref.pod_status) and np.array_equal(sim.pod_node, ref.pod_node)
+    placed = {s.pod_names[p].split("/")[1]: s.node_names[n] for kind, p, n, _ in ref.ops if kind in (0, 1)}
+    assert placed and all(v.startswith("cpu-") for k, v in placed.items() if k.startswith(("job-1-", "job-6-")))
+    assert all(v in ("gpu-2", "gpu-3") for k, v in placed.items() if k.startswith(("job-0-", "job-4-", "job-8-")))
+    assert all(not v.startswith("cpu-") for k, v in placed.items() if not k.startswith(("job-1-", "job-6-")))
+
+
+@pytest.mark.gpu
+def test_gpu_ingested_snapshots_match_oracle(tmp_path):
+    """snapshot.zip → ingest → MI355X engine through the C ABI → bit-identical to the oracle (config 1 from the file, and the rich document)."""
+    snap, cfg, _ = pkg.synth.config(0)
+    z = tmp_path / "snapshot.zip"
+    ing.write_snapshot_zip(str(z), ing.export_snapshot_json(snap, cfg, ("allocate",)))
+    for got in (ing.ingest_file(str(z)), ingest(_rich_document())):
+        s, acts = got.snapshot, tuple(got.actions)
+        ref = T.Oracle.run(s, got.config, acts)
+        ops = []
+        with pkg.KaiCore(got.config) as core:
+            ssn = core.open_session(s)
+            for a in acts:
+                ops += [(int(o["kind"]), int(o["pod"]), int(o["node"]), int(o["job"])) for o in ssn.execute(a)]
+            st, nd = ssn.pod_states()
+            ssn.close()
+        assert ops == ref.ops and len(ops) > 0
+        assert np.array_equal(st, ref.pod_status) and np.array_equal(nd, ref.pod_node)
