@@ -57,6 +57,14 @@ int kai_ingest_actions(const kai_ingest* h, int32_t* out, int cap);
 const char* kai_ingest_name(const kai_ingest* h, int kind, int idx);
 /* newline-separated notes: objects dropped, features routed to the CPU fallback, ignored plugins (never NULL) */
 const char* kai_ingest_warnings(const kai_ingest* h);
+/* The committed operations of kai_action_execute written as what the reference's cache creates for them — SURVEY §8f n3, the data format
+ * AFTER the path: {"bindRequests": [scheduling.run.ai/v1alpha2 BindRequest, one per Allocate, in commit order — cache/cache.go:290-330
+ * createBindRequest: name / namespace / owner reference of the pod, label selected-node (+ the node-pool label), spec.podName, selectedNode,
+ * receivedResourceType "Regular", receivedGPU{count, portion "%.2f"} per node_info.go:746-768], "evictions": [pods handed to cache.Evict,
+ * cache.go:216-252, with their pod group], "pipelined": [pod → node; no cluster side effect, framework/statement.go:197-295]}.
+ * One call hands over the whole batch: 10^6 placements are one document, not 10^6 API creates.  Writes a NUL-terminated string; *len = its
+ * length.  KAI_ERR_CAPACITY (with *len set) when cap < *len + 1; out may be NULL to size the buffer. */
+int kai_ingest_decisions_json(const kai_ingest* h, const kai_op* ops, int64_t n_ops, char* out, size_t cap, size_t* len);
 void kai_ingest_free(kai_ingest* h);
 /* detail of the last failed parse/load on this thread (never NULL) */
 const char* kai_ingest_last_error(void);

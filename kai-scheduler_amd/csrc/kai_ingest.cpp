@@ -330,6 +330,10 @@ struct kai_ingest {
         podset_group, podset_topology, podset_req, podset_pref;
     std::vector<int64_t> pod_created, job_created, queue_created, job_signature, job_last_start, q_preempt_mrt, q_reclaim_mrt;
     std::vector<uint8_t> class_fit;
+    // what the decision writer needs of each pod / job (cache/cache.go:216-330)
+    std::vector<std::string> pod_ns, pod_name, pod_uid, job_ns;
+    std::vector<double> pod_gpus;
+    std::string np_key, np_val;
     void warn(const std::string& m) { if (warnings.size() < 16384) { warnings += m; warnings += '\n'; } }
     int build(const JV& root, const kai_ingest_options* opt);
 };
@@ -388,6 +392,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
 
     // partition selector (conf/scheduler_conf.go:95-112): applied to nodes, queues and pod groups by the lister
     const std::string np_key = params["partitionParams"]["NodePoolLabelKey"].str(), np_val = params["partitionParams"]["NodePoolLabelValue"].str();
+    this->np_key = np_key; this->np_val = np_val;
     auto in_partition = [&](const JV& obj) { if (np_key.empty()) return true; if (np_val.empty()) return !has_label(obj, np_key); return label_of(obj, np_key.c_str()).str() == np_val && has_label(obj, np_key); };
 
     // ---------------------------------------------------------------- nodes (cluster_info.go:229-257, node_info.go:105-156, scheduler_utils.go:12-40)
@@ -603,7 +608,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
             const std::string& pre = spec["preemptibility"].str(); preempt = pre == "preemptible" ? true : pre == "non-preemptible" ? false : prio < 100;  // pkg/common/podgroup/preemptible.go:10-26
         } else warn("pod group " + pg_name + ": queue '" + spec["queue"].str() + "' does not exist");
         job_priority.push_back(prio); job_preempt.push_back(preempt); job_created.push_back(seen_ts(time_of(pg["metadata"]["creationTimestamp"])));
-        names[KAI_NAME_JOB].push_back(pg_name); job_uids.push_back(pg_name);  // PodGroupInfo.UID = PodGroupID(podGroup.Name) (cluster_info.go:379)
+        names[KAI_NAME_JOB].push_back(pg_name); job_uids.push_back(pg_name); job_ns.push_back(pg["metadata"]["namespace"].str());  // PodGroupInfo.UID = PodGroupID(podGroup.Name) (cluster_info.go:379)
         { int64_t ls = 0; const std::string& a = pg["metadata"]["annotations"]["kai.scheduler/last-start-timestamp"].str(); if (!a.empty() && parse_rfc3339(a, ls)) seen_ts(ls); else ls = 0; job_last_start.push_back(ls); }
         // sub-group tree: root = spec.topologyConstraint; entries with children are SubGroupSets, the others PodSets; parents are lower-cased
         const int root_g = (int)group_job.size(); job_root_group.push_back(root_g);
@@ -718,6 +723,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         for (int c = 4; c < R; c++) { auto it = r.req.scalars.find(names[KAI_NAME_RESOURCE][c]); if (it != r.req.scalars.end()) pod_req[(size_t)c * P + k] = (double)it->second; }
         pod_job[k] = r.job; pod_podset[k] = r.podset; pod_status[k] = r.status; pod_node[k] = r.node; pod_flags[k] = r.flags; pod_task_priority[k] = r.task_prio; pod_created[k] = r.created;
         pod_class[k] = pclass_of[pod_order[k]]; pod_nominated[k] = r.nominated; uids[k] = r.uid; names[KAI_NAME_POD].push_back(r.key);
+        { const JV& md = (*r.pod)["metadata"]; pod_ns.push_back(md["namespace"].str()); pod_name.push_back(md["name"].str()); pod_uid.push_back(md["uid"].str()); pod_gpus.push_back(r.req.gpu); }
     }
     // ranks: the reference's tie-breaks are string compares (framework/session.go:480-485 node name; session_plugins.go:227-260 UID)
     node_name_rank = rank_strings(names[KAI_NAME_NODE]); pod_uid_rank = rank_strings(uids); job_uid_rank = rank_strings(job_uids); queue_uid_rank = rank_strings(names[KAI_NAME_QUEUE]);
@@ -821,6 +827,41 @@ const char* kai_ingest_name(const kai_ingest* h, int kind, int idx) { if (!h || 
 const char* kai_ingest_warnings(const kai_ingest* h) { return h ? h->warnings.c_str() : ""; }
 void kai_ingest_free(kai_ingest* h) { delete h; }
 const char* kai_ingest_last_error(void) { return g_err.c_str(); }
+// The committed operations as the objects the reference's cache would create for them (cache/cache.go:266-330 createBindRequest for
+// Allocate, :216-252 Evict; Pipeline has no cluster side effect, framework/statement.go:197-295) — the data format AFTER the path.
+int kai_ingest_decisions_json(const kai_ingest* h, const kai_op* ops, int64_t n_ops, char* out, size_t cap, size_t* len) {
+    if (!h || (!ops && n_ops > 0) || !len) return KAI_ERR_INVALID_ARG;
+    auto esc = [](const std::string& v) { std::string o = "\""; for (unsigned char c : v) { if (c == '"' || c == '\\') { o += '\\'; o += (char)c; } else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; } else o += (char)c; } o += '"'; return o; };
+    const int P = h->snap.n_pods, N = h->snap.n_nodes, J = h->snap.n_jobs;
+    std::string binds, evicts, pipes;
+    for (int64_t i = 0; i < n_ops; i++) {
+        const kai_op& o = ops[i];
+        if (o.pod < 0 || o.pod >= P || ((o.kind == KAI_OP_ALLOCATE || o.kind == KAI_OP_PIPELINE) && (o.node < 0 || o.node >= N))) { g_err = "operation " + std::to_string(i) + " is out of range for this snapshot"; return KAI_ERR_INVALID_ARG; }
+        const std::string &ns = h->pod_ns[o.pod], &nm = h->pod_name[o.pod];
+        if (o.kind == KAI_OP_ALLOCATE) {
+            const std::string& node = h->names[KAI_NAME_NODE][o.node]; double g = h->pod_gpus[o.pod];
+            if (!binds.empty()) binds += ',';
+            binds += "{\"apiVersion\":\"scheduling.run.ai/v1alpha2\",\"kind\":\"BindRequest\",\"metadata\":{\"name\":" + esc(nm) + ",\"namespace\":" + esc(ns) +
+                     ",\"ownerReferences\":[{\"apiVersion\":\"v1\",\"kind\":\"Pod\",\"name\":" + esc(nm) + ",\"uid\":" + esc(h->pod_uid[o.pod]) + "}],\"labels\":{\"selected-node\":" + esc(node);
+            if (!h->np_key.empty() && !h->np_val.empty()) binds += "," + esc(h->np_key) + ":" + esc(h->np_val);  // SchedulingNodePoolParams.GetLabels
+            binds += "}},\"spec\":{\"podName\":" + esc(nm) + ",\"selectedNode\":" + esc(node) + ",\"receivedResourceType\":\"Regular\",\"receivedGPU\":{";  // node_info.go:746-768 setAcceptedResources
+            if (g >= 1) binds += "\"count\":" + std::to_string((long long)g) + ",\"portion\":\"1.00\"}}}"; else binds += "\"portion\":\"0.00\"}}}";
+        } else if (o.kind == KAI_OP_EVICT) {
+            if (!evicts.empty()) evicts += ',';
+            evicts += "{\"namespace\":" + esc(ns) + ",\"name\":" + esc(nm) + ",\"uid\":" + esc(h->pod_uid[o.pod]);
+            if (o.job >= 0 && o.job < J) evicts += ",\"podGroup\":{\"namespace\":" + esc(h->job_ns[o.job]) + ",\"name\":" + esc(h->names[KAI_NAME_JOB][o.job]) + "}";
+            evicts += "}";
+        } else if (o.kind == KAI_OP_PIPELINE) {
+            if (!pipes.empty()) pipes += ',';
+            pipes += "{\"namespace\":" + esc(ns) + ",\"name\":" + esc(nm) + ",\"node\":" + esc(h->names[KAI_NAME_NODE][o.node]) + "}";
+        } else { g_err = "operation " + std::to_string(i) + " has an unknown kind"; return KAI_ERR_INVALID_ARG; }
+    }
+    std::string doc = "{\"bindRequests\":[" + binds + "],\"evictions\":[" + evicts + "],\"pipelined\":[" + pipes + "]}";
+    *len = doc.size();
+    if (!out || cap < doc.size() + 1) return KAI_ERR_CAPACITY;
+    memcpy(out, doc.c_str(), doc.size() + 1);
+    return KAI_OK;
+}
 int kai_quantity_milli(const char* s, int64_t* out) { if (!s || !out) return KAI_ERR_INVALID_ARG; Qty q = parse_qty(s); if (!q.ok) return KAI_ERR_INVALID_ARG; *out = qty_milli(q); return KAI_OK; }
 int kai_quantity_value(const char* s, int64_t* out) { if (!s || !out) return KAI_ERR_INVALID_ARG; Qty q = parse_qty(s); if (!q.ok) return KAI_ERR_INVALID_ARG; *out = qty_value(q); return KAI_OK; }
 

@@ -19,7 +19,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkai_ingest.so")
 EXPORTS = ["kai_ingest_parse", "kai_ingest_load", "kai_ingest_snapshot", "kai_ingest_config", "kai_ingest_actions", "kai_ingest_name",
-           "kai_ingest_warnings", "kai_ingest_free", "kai_ingest_last_error", "kai_quantity_milli", "kai_quantity_value"]
+           "kai_ingest_warnings", "kai_ingest_decisions_json", "kai_ingest_free", "kai_ingest_last_error", "kai_quantity_milli", "kai_quantity_value"]
 ACTION_NAMES = ["allocate", "consolidation", "reclaim", "preempt"]
 
 
@@ -45,6 +45,7 @@ def load_ingest_library(path: str = LIB_PATH):
     lib.kai_ingest_name.argtypes = [C.c_void_p, C.c_int, C.c_int]; lib.kai_ingest_name.restype = C.c_char_p
     lib.kai_ingest_warnings.argtypes = [C.c_void_p]; lib.kai_ingest_warnings.restype = C.c_char_p
     lib.kai_ingest_free.argtypes = [C.c_void_p]; lib.kai_ingest_free.restype = None
+    lib.kai_ingest_decisions_json.argtypes = [C.c_void_p, C.POINTER(abi.KaiOp), C.c_int64, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.kai_ingest_last_error.restype = C.c_char_p
     lib.kai_quantity_milli.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
     lib.kai_quantity_value.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
@@ -63,6 +64,33 @@ class Ingested:
     actions: list
     warnings: list
     resource_names: list = field(default_factory=list)
+    _handle: object = None  # the native handle: keeps the name tables the decision writer needs
+
+    def decisions_json(self, ops) -> str:
+        """The committed operations (records of `Session.execute`, or (kind, pod, node, job) tuples) as the BindRequests / evictions the
+        reference's cache would create (cache/cache.go:216-330) — one document for the whole batch."""
+        lib = load_ingest_library()
+        n = len(ops)
+        arr = (abi.KaiOp * max(n, 1))()
+        for i, o in enumerate(ops):
+            kind, pod, node, job = (int(o["kind"]), int(o["pod"]), int(o["node"]), int(o["job"])) if not isinstance(o, tuple) else o
+            arr[i].seq, arr[i].kind, arr[i].pod, arr[i].node, arr[i].job = i, kind, pod, node, job
+        need = C.c_size_t(0)
+        rc = lib.kai_ingest_decisions_json(self._handle, arr, n, None, 0, C.byref(need))
+        if rc != -4:
+            raise IngestError(lib.kai_ingest_last_error().decode())
+        buf = C.create_string_buffer(need.value + 1)
+        if lib.kai_ingest_decisions_json(self._handle, arr, n, buf, need.value + 1, C.byref(need)) != 0:
+            raise IngestError(lib.kai_ingest_last_error().decode())
+        return buf.value.decode()
+
+    def close(self):
+        if self._handle is not None:
+            load_ingest_library().kai_ingest_free(self._handle); self._handle = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
 
 
 def _copy(ptr, n, dtype):
@@ -103,7 +131,7 @@ def _from_handle(lib, h) -> Ingested:
     if n < 0:
         raise IngestError(lib.kai_ingest_last_error().decode())
     warnings = [w for w in lib.kai_ingest_warnings(h).decode().split("\n") if w]
-    return Ingested(snap, cfg, [ACTION_NAMES[buf[i]] for i in range(min(n, 16))], warnings, names(5, R))
+    return Ingested(snap, cfg, [ACTION_NAMES[buf[i]] for i in range(min(n, 16))], warnings, names(5, R), h)
 
 
 def _options(scheduler_name, now_ns):
@@ -119,8 +147,9 @@ def ingest_json(text, scheduler_name: str | None = None, now_ns: int = 0) -> Ing
         raise IngestError(lib.kai_ingest_last_error().decode())
     try:
         return _from_handle(lib, h)
-    finally:
+    except Exception:
         lib.kai_ingest_free(h)
+        raise
 
 
 def ingest_file(path: str, scheduler_name: str | None = None, now_ns: int = 0) -> Ingested:
@@ -130,8 +159,9 @@ def ingest_file(path: str, scheduler_name: str | None = None, now_ns: int = 0) -
         raise IngestError(lib.kai_ingest_last_error().decode())
     try:
         return _from_handle(lib, h)
-    finally:
+    except Exception:
         lib.kai_ingest_free(h)
+        raise
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

@@ -547,3 +547,48 @@ def test_gpu_ingested_snapshots_match_oracle(tmp_path):
             ssn.close()
         assert ops == ref.ops and len(ops) > 0
         assert np.array_equal(st, ref.pod_status) and np.array_equal(nd, ref.pod_node)
+
+
+# ------------------------------------------------------------------------------------------------ decisions out (n3)
+def test_decisions_document():
+    """cache/cache.go:290-330 createBindRequest (name, namespace, owner reference, selected-node + node-pool labels, podName, selectedNode,
+    receivedResourceType, receivedGPU{count, portion "%.2f"}) for Allocate; evictions carry the pod group (cache.go:216-252); one batch."""
+    d = doc(nodes=[node("n0", labels={"pool": "a"}), node("n1", labels={"pool": "a"})], queues=[queue("q", labels={"pool": "a"})],
+            pods=[pod("gpu", "j", requests={"cpu": "1", "nvidia.com/gpu": "2"}), pod('c"pu', "j", requests={"cpu": "1"}), pod("victim", "k", phase="Running", node_name="n1")],
+            pod_groups=[dict(pod_group("j"), metadata={"name": "j", "namespace": "ns", "labels": {"pool": "a"}}), dict(pod_group("k"), metadata={"name": "k", "namespace": "team", "labels": {"pool": "a"}})],
+            params={"partitionParams": {"NodePoolLabelKey": "pool", "NodePoolLabelValue": "a"}})
+    got = ingest(d)
+    s = got.snapshot
+    idx = {n.split("/")[1]: i for i, n in enumerate(s.pod_names)}
+    out = json.loads(got.decisions_json([(0, idx["gpu"], 0, 0), (2, idx["victim"], 1, 1), (0, idx['c"pu'], 1, 0), (1, idx["gpu"], 1, 0)]))
+    assert [b["spec"] for b in out["bindRequests"]] == [
+        {"podName": "gpu", "selectedNode": "n0", "receivedResourceType": "Regular", "receivedGPU": {"count": 2, "portion": "1.00"}},
+        {"podName": 'c"pu', "selectedNode": "n1", "receivedResourceType": "Regular", "receivedGPU": {"portion": "0.00"}}]
+    b = out["bindRequests"][0]
+    assert b["apiVersion"] == "scheduling.run.ai/v1alpha2" and b["kind"] == "BindRequest"
+    assert b["metadata"] == {"name": "gpu", "namespace": "ns", "ownerReferences": [{"apiVersion": "v1", "kind": "Pod", "name": "gpu", "uid": "uid-gpu"}],
+                             "labels": {"selected-node": "n0", "pool": "a"}}
+    assert out["evictions"] == [{"namespace": "ns", "name": "victim", "uid": "uid-victim", "podGroup": {"namespace": "team", "name": "k"}}]
+    assert out["pipelined"] == [{"namespace": "ns", "name": "gpu", "node": "n1"}]
+    assert json.loads(got.decisions_json([])) == {"bindRequests": [], "evictions": [], "pipelined": []}
+    with pytest.raises(ing.IngestError, match="out of range"):
+        got.decisions_json([(0, 99, 0, 0)])
+
+
+def test_replay_closes_the_loop():
+    """snapshot → ingest → schedule (oracle here; the GPU test does the same through the C ABI) → BindRequests → fed back as the next snapshot's
+    bind requests: the pods come back Binding on the chosen nodes and nothing is left to place (cmd/snapshot-tool's loop through both formats)."""
+    d = _rich_document()
+    got = ingest(d)
+    res = T.Oracle.run(got.snapshot, got.config, tuple(got.actions))
+    out = json.loads(got.decisions_json(res.ops))
+    assert len(out["bindRequests"]) == sum(1 for o in res.ops if o[0] == 0) > 0
+    d["rawObjects"]["bindRequests"] = out["bindRequests"]
+    nxt = ingest(d)
+    s = nxt.snapshot
+    placed = {b["spec"]["podName"]: b["spec"]["selectedNode"] for b in out["bindRequests"]}
+    for i, n in enumerate(s.pod_names):
+        if n.split("/")[1] in placed:
+            assert s.pod_status[i] == ST["Binding"] and s.node_names[s.pod_node[i]] == placed[n.split("/")[1]]
+    res2 = T.Oracle.run(s, nxt.config, ("allocate",))
+    assert all(o[0] != 0 or s.pod_names[o[1]].split("/")[1] not in placed for o in res2.ops)
