@@ -151,7 +151,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.j_tta_res = own<double>(pool, (size_t)4 * J); c.j_allocated = own<double>(pool, (size_t)4 * J);
     c.lq_sorted = own<int32_t>(pool, J); c.lq_side = own<int32_t>(pool, J); c.lq_cur = own<int32_t>(pool, Q); c.lq_end = own<int32_t>(pool, Q); c.lq_side_len = own<int32_t>(pool, Q); c.j_state = own<uint8_t>(pool, J);
     c.qheap = own<int32_t>(pool, Q + 1); c.root_heap = own<int32_t>(pool, Q + 1); c.qn = own<QNode>(pool, Q + 1);
-    c.ops_cap = 4 * P + 64; c.ops = own<StmtOp>(pool, c.ops_cap); c.out_cap = (int64_t)2 * P + 64; c.out_ops = own<kai_op>(pool, c.out_cap);
+    c.ops_cap = 4 * P + 64; c.ops = own<StmtOp>(pool, c.ops_cap); c.out_cap = ((int64_t)2 * P + 64) * (n_actions > 0 ? n_actions : 1); c.out_ops = own<kai_op>(pool, c.out_cap);  // the library gives every action its own 2P + 64; this harness keeps one list for the whole cycle
     c.scratch = own<int32_t>(pool, (size_t)P + 64); c.st = own<EngineState>(pool, 1);
     c.q_share = const_cast<QShare*>(copy(pool, prep.shares.data(), prep.shares.size()));
     auto t0 = std::chrono::steady_clock::now();
