@@ -12,9 +12,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <set>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -122,6 +124,71 @@ struct JParser {
     }
 };
 
+// Structural skip of one value (strings with escapes, nesting by depth): finds the element boundaries of rawObjects.pods so that the pods —
+// nearly all of a snapshot's bytes — are parsed on every host core.
+bool skip_value(const char*& p, const char* e) {
+    auto ws = [&] { while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; };
+    ws(); if (p >= e) return false;
+    if (*p == '"') { p++; while (p < e && *p != '"') { if (*p == '\\') p++; p++; } if (p >= e) return false; p++; return true; }
+    if (*p == '{' || *p == '[') {
+        int depth = 0;
+        while (p < e) {
+            char c = *p;
+            if (c == '"') { p++; while (p < e && *p != '"') { if (*p == '\\') p++; p++; } if (p >= e) return false; p++; continue; }
+            if (c == '{' || c == '[') depth++;
+            else if (c == '}' || c == ']') { depth--; if (depth == 0) { p++; return true; } }
+            p++;
+        }
+        return false;
+    }
+    while (p < e && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n' && *p != '\r' && *p != '\t') p++;
+    return true;
+}
+template <class F> void parallel_for(size_t n, F f);
+// the document: {"config":…, "schedulerParams":…, "rawObjects":{"pods":[…], …}, …} — everything through JParser, the pods element-wise in parallel
+bool parse_document(const char* json, size_t len, JV& root, std::string& err, size_t& err_at) {
+    JParser ps{json, json + len, {}, 0};
+    auto fail = [&](const char* m) { err = ps.err.empty() ? m : ps.err; err_at = (size_t)(ps.p - json); return false; };
+    ps.ws(); if (ps.p >= ps.e || *ps.p != '{') { if (!ps.value(root)) return fail("bad document"); ps.ws(); if (ps.p != ps.e) return fail("trailing data"); return true; }
+    root.t = JV::Obj; ps.p++; ps.ws();
+    std::vector<std::pair<const char*, const char*>> spans; JV* pods_arr = nullptr;
+    if (ps.p < ps.e && *ps.p == '}') ps.p++;
+    else for (;;) {
+        ps.ws(); std::string k; if (!ps.string(k)) return fail("expected string"); ps.ws(); if (ps.p >= ps.e || *ps.p != ':') return fail("expected ':'"); ps.p++; ps.ws();
+        root.o.emplace_back(k, JV()); JV& v = root.o.back().second;
+        if (k == "rawObjects" && ps.p < ps.e && *ps.p == '{') {
+            v.t = JV::Obj; ps.p++; ps.ws();
+            if (ps.p < ps.e && *ps.p == '}') ps.p++;
+            else for (;;) {
+                ps.ws(); std::string k2; if (!ps.string(k2)) return fail("expected string"); ps.ws(); if (ps.p >= ps.e || *ps.p != ':') return fail("expected ':'"); ps.p++; ps.ws();
+                v.o.emplace_back(k2, JV()); JV& v2 = v.o.back().second;
+                if (k2 == "pods" && ps.p < ps.e && *ps.p == '[' && !pods_arr) {
+                    v2.t = JV::Arr; ps.p++; ps.ws(); spans.clear();
+                    if (ps.p < ps.e && *ps.p == ']') ps.p++;
+                    else for (;;) {
+                        ps.ws(); const char* b = ps.p; if (!skip_value(ps.p, ps.e)) return fail("unterminated pods array"); spans.emplace_back(b, ps.p);
+                        ps.ws(); if (ps.p < ps.e && *ps.p == ',') { ps.p++; continue; } if (ps.p < ps.e && *ps.p == ']') { ps.p++; break; } return fail("expected ',' or ']'");
+                    }
+                } else if (!ps.value(v2)) return fail("bad value");
+                ps.ws(); if (ps.p < ps.e && *ps.p == ',') { ps.p++; continue; } if (ps.p < ps.e && *ps.p == '}') { ps.p++; break; } return fail("expected ',' or '}'");
+            }
+        } else if (!ps.value(v)) return fail("bad value");
+        ps.ws(); if (ps.p < ps.e && *ps.p == ',') { ps.p++; continue; } if (ps.p < ps.e && *ps.p == '}') { ps.p++; break; } return fail("expected ',' or '}'");
+    }
+    ps.ws(); if (ps.p != ps.e) return fail("trailing data");
+    for (auto& kv : root.o) if (kv.first == "rawObjects") for (auto& kv2 : kv.second.o) if (kv2.first == "pods" && kv2.second.t == JV::Arr && kv2.second.a.empty() && !pods_arr) pods_arr = &kv2.second;  // addresses are final now
+    if (pods_arr && !spans.empty()) {
+        pods_arr->a.resize(spans.size()); std::vector<std::string> errs(spans.size()); std::vector<size_t> at(spans.size());
+        parallel_for(spans.size(), [&](size_t i) {
+            JParser q{spans[i].first, spans[i].second, {}, 0};
+            if (!q.value(pods_arr->a[i])) { errs[i] = q.err.empty() ? "bad value" : q.err; at[i] = (size_t)(q.p - json); return; }
+            q.ws(); if (q.p != q.e) { errs[i] = "unexpected character"; at[i] = (size_t)(q.p - json); }
+        });
+        for (size_t i = 0; i < errs.size(); i++) if (!errs[i].empty()) { err = errs[i]; err_at = at[i]; return false; }
+    }
+    return true;
+}
+
 // ===================================================================================================== resource.Quantity
 // k8s.io/apimachinery v0.34.3 pkg/api/resource: <sign><digits>[.<digits>]<suffix>, suffix = Ki Mi Gi Ti Pi Ei | n u m "" k M G T P E |
 // e<exp> E<exp>.  Held exactly as num / 10^dexp; Value() and MilliValue() round UP (quantity.go ScaledValue → infScale / int64Amount).
@@ -202,6 +269,15 @@ bool parse_duration(const std::string& s, int64_t& out) {
 }
 
 // ===================================================================================================== helpers
+// static partition over the host cores; pods are independent of each other until the signatures are interned
+template <class F> void parallel_for(size_t n, F f) {
+    unsigned hw = std::thread::hardware_concurrency(); if (const char* e = std::getenv("KAI_INGEST_THREADS")) hw = (unsigned)atoi(e);
+    size_t T = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 32), n / 512 + 1);
+    if (T <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++) th.emplace_back([=, &f] { for (size_t i = n * t / T, e = n * (t + 1) / T; i < e; i++) f(i); });
+    for (auto& x : th) x.join();
+}
 std::vector<uint32_t> rank_strings(const std::vector<std::string>& names) {  // byte-wise ascending like Go's string <; ties keep first-seen order
     std::vector<uint32_t> order(names.size()), rank(names.size());
     for (size_t i = 0; i < names.size(); i++) order[i] = (uint32_t)i;
@@ -341,6 +417,9 @@ struct kai_ingest {
 int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     if (!root.is_obj()) { g_err = "snapshot.json: top level is not an object"; return KAI_ERR_INVALID_ARG; }
     const JV& conf = root["config"]; const JV& params = root["schedulerParams"]; const JV& raw = root["rawObjects"];
+    const bool timing = std::getenv("KAI_INGEST_TIMING") != nullptr;
+    auto tnow = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+    double tl = tnow(); auto lap = [&](const char* what) { if (timing) { double t = tnow(); std::fprintf(stderr, "kai_ingest:   %-28s %.3f s\n", what, t - tl); tl = t; } };
     int64_t latest_ts = 0; auto seen_ts = [&](int64_t t) { if (t > latest_ts) latest_ts = t; return t; };
 
     // ---------------------------------------------------------------- configuration (conf/scheduler_conf.go:31-88, conf_util/scheduler_conf_util.go:36-107)
@@ -439,6 +518,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     }
     if (raw["resourceSlices"].is_arr() && !raw["resourceSlices"].a.empty()) warn("resourceSlices present: DRA GPUs are not counted (KAI_NODE_HAS_DRA_GPUS is never set by the ingest)");
 
+    lap("config + nodes");
     // ---------------------------------------------------------------- bind requests (cluster_info.go:328-349, bindrequest_info: key = namespace/podName, failed ones ignored)
     std::map<std::string, std::string> bind_node;
     if (raw["bindRequests"].is_arr()) for (auto& br : raw["bindRequests"].a) {
@@ -451,15 +531,15 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     std::set<std::string> config_maps; if (raw["configMaps"].is_arr()) for (auto& cm : raw["configMaps"].a) config_maps.insert(cm["metadata"]["namespace"].str() + "/" + cm["metadata"]["name"].str());
 
     // ---------------------------------------------------------------- pods (pod_info.go:172-214, 365-445)
-    struct PodRec { const JV* pod; std::string key, uid, group, subgroup; Req req; int32_t status, node, nominated; uint32_t flags; int32_t task_prio; int64_t created; bool unschedulable; int job = -1, podset = -1; };
+    struct PodRec { const JV* pod; std::string key, uid, group, subgroup, class_sig, sched_sig; Req req; int32_t status, node, nominated; uint32_t flags; int32_t task_prio; int64_t created; bool unschedulable, placed_anti_affinity; int job = -1, podset = -1; };
     std::vector<PodRec> pods; std::set<std::string> extra_names;
     bool any_existing_anti_affinity = false;
-    if (raw["pods"].is_arr()) for (auto& p : raw["pods"].a) {
-        if (!p.is_obj()) continue;
-        PodRec r{}; r.pod = &p; const JV& md = p["metadata"]; const JV& spec = p["spec"];
+    // one pod → its record; reads only what was built above (node / bind-request / config-map tables), so pods are converted in parallel
+    auto make_pod = [&](const JV& p, PodRec& r) -> std::string {
+        r = PodRec{}; r.pod = &p; const JV& md = p["metadata"]; const JV& spec = p["spec"];
         r.key = md["namespace"].str() + "/" + md["name"].str(); r.uid = md["uid"].str(); if (r.uid.empty()) r.uid = r.key;
         r.group = md["annotations"]["pod-group-name"].str(); r.subgroup = md["labels"]["kai.scheduler/subgroup-name"].str();
-        r.created = seen_ts(time_of(md["creationTimestamp"]));
+        r.created = time_of(md["creationTimestamp"]);
         // getPodResourceRequest :373-393: exact sum over containers, max with every init container, + overhead (base resources only), pods := 1
         std::map<std::string, Qty> sum;
         if (spec["containers"].is_arr()) for (auto& c : spec["containers"].a) { const JV& rq = c["resources"]["requests"]; if (rq.is_obj()) for (auto& kv : rq.o) { auto it = sum.find(kv.first); Qty q = qty_of(kv.second); if (it == sum.end()) sum[kv.first] = q; else it->second = qty_add(it->second, q); } }
@@ -470,8 +550,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
             for (auto& kv : ir.scalars) { auto it = r.req.scalars.find(kv.first); if (it == r.req.scalars.end() || kv.second > it->second) r.req.scalars[kv.first] = kv.second; }
         }
         if (spec["overhead"].is_obj()) { Req o = req_from_list(list_of(spec["overhead"])); r.req.cpu += o.cpu; r.req.mem += o.mem; for (auto& kv : o.scalars) r.req.scalars[kv.first] += kv.second; }
-        if (r.req.bad) { g_err = "pod " + r.key + ": bad resource quantity"; return KAI_ERR_INVALID_ARG; }
-        for (auto& kv : r.req.scalars) if (kv.second != 0) extra_names.insert(kv.first);
+        if (r.req.bad) return "pod " + r.key + ": bad resource quantity";
         // node + status (getTaskStatus :410-445)
         std::string node_name = spec["nodeName"].str(); auto bit = bind_node.find(r.key); bool has_bind = bit != bind_node.end();
         if (node_name.empty() && has_bind) node_name = bit->second;
@@ -487,7 +566,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         const JV& ann = md["annotations"]; bool fb = r.req.mig;
         if (!ann["gpu-fraction"].str().empty() || !ann["gpu-memory"].str().empty() || !ann["gpu-fraction-num-devices"].str().empty()) fb = true;
         if (spec["resourceClaims"].is_arr() && !spec["resourceClaims"].a.empty()) fb = true;
-        if (spec["affinity"]["podAffinity"].is_obj() || spec["affinity"]["podAntiAffinity"].is_obj()) { fb = true; if (spec["affinity"]["podAntiAffinity"]["requiredDuringSchedulingIgnoredDuringExecution"].is_arr() && r.node >= 0) any_existing_anti_affinity = true; }
+        if (spec["affinity"]["podAffinity"].is_obj() || spec["affinity"]["podAntiAffinity"].is_obj()) { fb = true; if (spec["affinity"]["podAntiAffinity"]["requiredDuringSchedulingIgnoredDuringExecution"].is_arr() && r.node >= 0) r.placed_anti_affinity = true; }
         if (spec["volumes"].is_arr()) for (auto& v : spec["volumes"].a) if (v["persistentVolumeClaim"].is_obj() || v["ephemeral"].is_obj()) fb = true;
         for (const char* cs : {"containers", "initContainers"}) if (spec[cs].is_arr()) for (auto& c : spec[cs].a) if (c["ports"].is_arr()) for (auto& port : c["ports"].a) if (port["hostPort"].inum() > 0) fb = true;
         if (fb) r.flags |= KAI_POD_CPU_FALLBACK;
@@ -507,10 +586,29 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
             }
             for (auto& cmn : need) { if (has_shared && starts_with(cmn, shared_cm.c_str())) continue; if (!config_maps.count(md["namespace"].str() + "/" + cmn)) r.unschedulable = true; }
         }
-        pods.push_back(std::move(r));
+        {   // constraint signatures, compared for equality further down: predicate class (node selector, required node affinity, tolerations,
+            // schedulability) and the scheduling-constraints signature of api/pod_info/scheduling_constraints_signature.go
+            std::string& sig = r.class_sig;
+            canon(spec["nodeSelector"], sig); sig += '|'; canon(spec["affinity"]["nodeAffinity"]["requiredDuringSchedulingIgnoredDuringExecution"], sig); sig += '|'; canon(spec["tolerations"], sig); sig += r.unschedulable ? "|U" : "|S";
+            std::string& sg = r.sched_sig;
+            if (spec["volumes"].is_arr()) for (auto& v : spec["volumes"].a) if (v["persistentVolumeClaim"].is_obj()) { canon(v["persistentVolumeClaim"], sg); }
+            sg += '|'; canon(spec["nodeSelector"], sg); sg += '|'; canon(spec["affinity"], sg); sg += '|';
+            if (spec["tolerations"].is_arr()) for (auto& t : spec["tolerations"].a) sg += t["key"].str() + "\x03" + t["operator"].str() + "\x03" + t["value"].str() + "\x03" + t["effect"].str() + "\x04";
+            sg += '|'; sg += spec["priorityClassName"].str(); sg += '|'; canon(spec["priority"], sg); sg += '|'; canon(spec["topologySpreadConstraints"], sg); sg += '|';
+            for (const char* cs : {"containers", "initContainers"}) if (spec[cs].is_arr()) for (auto& c : spec[cs].a) if (c["ports"].is_arr()) for (auto& port : c["ports"].a) { sg += std::to_string(port["hostPort"].inum()); sg += ','; }
+        }
+        return std::string();
+    };
+    {
+        std::vector<const JV*> pv; if (raw["pods"].is_arr()) for (auto& p : raw["pods"].a) if (p.is_obj()) pv.push_back(&p);
+        pods.resize(pv.size()); std::vector<std::string> errs(pv.size());
+        parallel_for(pv.size(), [&](size_t i) { errs[i] = make_pod(*pv[i], pods[i]); });
+        for (auto& e : errs) if (!e.empty()) { g_err = e; return KAI_ERR_INVALID_ARG; }
+        for (auto& r : pods) { seen_ts(r.created); if (r.placed_anti_affinity) any_existing_anti_affinity = true; for (auto& kv : r.req.scalars) if (kv.second != 0) extra_names.insert(kv.first); }
     }
     if (any_existing_anti_affinity) { warn("a placed pod carries required pod anti-affinity: every pending pod is routed to the CPU fallback"); for (auto& r : pods) if (r.status == KAI_POD_PENDING) r.flags |= KAI_POD_CPU_FALLBACK; }
 
+    lap("pods");
     // resource columns: cpu, memory, gpu, pods + the scalar resources pods actually request (BaseResource.LessEqual ranges the request's scalars)
     names[KAI_NAME_RESOURCE] = {"cpu", "memory", "gpu", "pods"};
     for (auto& n : extra_names) { if ((int)names[KAI_NAME_RESOURCE].size() < KAI_MAX_RES) names[KAI_NAME_RESOURCE].push_back(n); else { warn("more than " + std::to_string(KAI_MAX_RES - 4) + " scalar resources requested: pods asking for '" + n + "' go to the CPU fallback"); for (auto& r : pods) { auto it = r.req.scalars.find(n); if (it != r.req.scalars.end() && it->second != 0) r.flags |= KAI_POD_CPU_FALLBACK; } } }
@@ -589,6 +687,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         c.topo = t; c.req = lv(tc["requiredTopologyLevel"].str()); c.pref = lv(tc["preferredTopologyLevel"].str()); return c;
     };
 
+    lap("queues + topologies");
     // ---------------------------------------------------------------- pod groups (cluster_info.go:351-400, 495-542; job_info.go:160-251; subgroup_info/factory.go:16-135)
     int32_t default_priority = 50;  // DefaultPodGroupPriority; the first globalDefault PriorityClass overrides it
     std::map<std::string, int32_t> pc_value;
@@ -647,14 +746,14 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     for (int i = 0; i < (int)pods.size(); i++) if (pods[i].job < 0) pod_order.push_back(i);  // pods of no job: node accounting only
     const int P = (int)pod_order.size();
 
+    lap("pod groups");
     // ---------------------------------------------------------------- static predicate classes (n4): pods by constraint, nodes by what those constraints can see
     std::vector<int> pclass_of(pods.size(), 0); std::vector<const JV*> pclass_rep; std::vector<bool> pclass_unsched;
     std::set<std::string> used_keys; bool uses_name_field = false;
     {
         std::unordered_map<std::string, int> ids;
         for (size_t i = 0; i < pods.size(); i++) {
-            const JV& spec = (*pods[i].pod)["spec"]; std::string sig;
-            canon(spec["nodeSelector"], sig); sig += '|'; canon(spec["affinity"]["nodeAffinity"]["requiredDuringSchedulingIgnoredDuringExecution"], sig); sig += '|'; canon(spec["tolerations"], sig); sig += pods[i].unschedulable ? "|U" : "|S";
+            const JV& spec = (*pods[i].pod)["spec"]; const std::string& sig = pods[i].class_sig;
             auto it = ids.find(sig);
             if (it == ids.end()) {
                 it = ids.emplace(sig, (int)pclass_rep.size()).first; pclass_rep.push_back(pods[i].pod); pclass_unsched.push_back(pods[i].unschedulable);
@@ -683,17 +782,13 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         class_fit[a * NC + b] = !pclass_unsched[a] && node_affinity_fits(*pclass_rep[a], nv) && taints_tolerated(*pclass_rep[a], *nv.node);
     }
 
+    lap("predicate classes");
     // ---------------------------------------------------------------- scheduling-constraints signatures (job_info.go:547-570, podset.go:167-196, scheduling_constraints_signature.go)
     std::vector<int64_t> pod_sig(pods.size(), 0);
     {
         std::unordered_map<std::string, int64_t> ids;
         for (size_t i = 0; i < pods.size(); i++) {
-            const JV& spec = (*pods[i].pod)["spec"]; std::string sig;
-            if (spec["volumes"].is_arr()) for (auto& v : spec["volumes"].a) if (v["persistentVolumeClaim"].is_obj()) { canon(v["persistentVolumeClaim"], sig); }
-            sig += '|'; canon(spec["nodeSelector"], sig); sig += '|'; canon(spec["affinity"], sig); sig += '|';
-            if (spec["tolerations"].is_arr()) for (auto& t : spec["tolerations"].a) sig += t["key"].str() + "\x03" + t["operator"].str() + "\x03" + t["value"].str() + "\x03" + t["effect"].str() + "\x04";
-            sig += '|'; sig += spec["priorityClassName"].str(); sig += '|'; canon(spec["priority"], sig); sig += '|'; canon(spec["topologySpreadConstraints"], sig); sig += '|';
-            for (const char* cs : {"containers", "initContainers"}) if (spec[cs].is_arr()) for (auto& c : spec[cs].a) if (c["ports"].is_arr()) for (auto& port : c["ports"].a) { sig += std::to_string(port["hostPort"].inum()); sig += ','; }
+            const std::string& sig = pods[i].sched_sig;
             pod_sig[i] = ids.emplace(sig, (int64_t)ids.size()).first->second;
         }
     }
@@ -714,6 +809,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         }
     }
 
+    lap("signatures");
     // ---------------------------------------------------------------- pods in their final order: pods of a job contiguous, pods of no job last
     pod_req.assign((size_t)R * P, 0.0); pod_job.resize(P); pod_podset.resize(P); pod_status.resize(P); pod_node.resize(P); pod_flags.resize(P); pod_task_priority.resize(P); pod_created.resize(P); pod_class.resize(P); pod_nominated.resize(P);
     std::vector<std::string> uids(P);
@@ -736,6 +832,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     podset_topology.resize(S); podset_req.resize(S); podset_pref.resize(S); for (int s = 0; s < S; s++) { podset_topology[s] = podset_tc_v[s].topo; podset_req[s] = podset_tc_v[s].req; podset_pref[s] = podset_tc_v[s].pref; }
     cfg.now_ns = opt && opt->now_ns ? opt->now_ns : latest_ts;
 
+    lap("final arrays + ranks");
     // ---------------------------------------------------------------- the struct
     auto ptr = [](auto& v) { typedef typename std::remove_reference<decltype(v)>::type::value_type E; static E dummy{}; return v.empty() ? (const E*)&dummy : (const E*)v.data(); };
     kai_snapshot_soa& s = snap; s.abi_version = KAI_ABI_VERSION; s.n_res = R;
@@ -794,11 +891,15 @@ extern "C" {
 int kai_ingest_parse(const char* json, size_t len, const kai_ingest_options* opt, kai_ingest** out) {
     if (!json || !out) { g_err = "null argument"; return KAI_ERR_INVALID_ARG; }
     *out = nullptr; g_err.clear();
-    JV root; JParser ps{json, json + len, {}, 0};
-    if (!ps.value(root)) { g_err = "snapshot.json: " + ps.err + " at byte " + std::to_string(ps.p - json); return KAI_ERR_INVALID_ARG; }
-    ps.ws(); if (ps.p != ps.e) { g_err = "snapshot.json: trailing data at byte " + std::to_string(ps.p - json); return KAI_ERR_INVALID_ARG; }
+    double t_start; { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); t_start = ts.tv_sec + ts.tv_nsec * 1e-9; }
+    JV root; std::string perr; size_t perr_at = 0;
+    if (!parse_document(json, len, root, perr, perr_at)) { g_err = "snapshot.json: " + perr + " at byte " + std::to_string(perr_at); return KAI_ERR_INVALID_ARG; }
+    const bool timing = std::getenv("KAI_INGEST_TIMING") != nullptr;
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+    double t_parsed = now();
     kai_ingest* h = new kai_ingest();
     int rc = h->build(root, opt);
+    if (timing) std::fprintf(stderr, "kai_ingest: parse %.3f s, build %.3f s (%zu bytes)\n", t_parsed - t_start, now() - t_parsed, len);
     if (rc != KAI_OK) { delete h; return rc; }
     *out = h; return KAI_OK;
 }
