@@ -116,12 +116,32 @@ struct FastFrame {
 
 // The frame is addressed directly (not through a generic pointer) so that the device code uses ds_read / ds_write, which the
 // compiler may batch and reorder against global memory traffic.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIPCC__)
 __shared__ FastFrame kai_frame_lds;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 #define KAI_FRAME kai_frame_lds
 #else
 inline FastFrame& kai_frame_host() { static thread_local FastFrame f; return f; }
 #define KAI_FRAME kai_frame_host()
+#endif
+
+// Job-level fields of the staged path, gathered ahead of the attempt (Backend::stage_async): on the device a service wave loads them, the
+// chunk's pods, classes and request vectors straight into the frame — one wide gather per dependent level instead of ~40 loads issued one by
+// one by the control lane — while the control lane finishes the pop (heap fixes, key recomputation).
+struct JobPf {
+    int32_t job, ok;      // ok: the frame (p, cls, req) and the fields below are staged for `job` and the job has the staged path's shape
+    int32_t shape, n_ps, has_topo, s, first, tta_valid, tta_n, jq, jpre, s_pipelined;
+    double ja[3];
+};
+#if defined(__HIPCC__)
+__shared__ JobPf kai_pf_lds;  // declared in both passes of hipcc: the device-only code of kai_kernels.hpp names it directly
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KAI_JOBPF kai_pf_lds
+#else
+inline JobPf& kai_pf_host() { static thread_local JobPf f; return f; }
+#define KAI_JOBPF kai_pf_host()
 #endif
 
 struct EngineState {  // mutable scalars of the running action
@@ -420,6 +440,29 @@ KAI_HD uint64_t class_key_regs(const KaiCtx& c, const ClassRec& k, const NodeReg
 KAI_HD uint64_t class_key(const KaiCtx& c, const ClassRec& k, int n) { NodeRegs s; load_node(c, n, s); return class_key_regs(c, k, s); }
 KAI_HD bool key_better(uint64_t k, int n, uint64_t bk, int bn) { return k > bk || (k == bk && k != 0 && n < bn); }
 
+// Stage job j (see JobPf): cooperative over nl lanes, lane handles the chunk's pods lane, lane + nl, …  Returns this lane's "some pod does not
+// qualify" bit; lane 0 writes the job-level fields.  Reads exactly what allocate_job_fast reads when it loads the job itself.
+KAI_HD int stage_job_lane(const KaiCtx& c, int j, FastFrame& f, JobPf& out, int lane, int nl) {
+    JobPf v;
+    v.job = j; v.ok = 0;
+    v.n_ps = c.j_n_ps[j]; v.has_topo = c.j_has_topology[j]; v.s = c.j_first_ps[j]; v.first = c.j_first_pod[j];
+    v.tta_valid = c.j_tta_valid[j]; v.tta_n = c.j_tta_n[j]; v.jq = c.j_queue[j]; v.jpre = c.j_preempt[j];
+    v.ja[0] = c.j_allocated[(size_t)j * 4 + 0]; v.ja[1] = c.j_allocated[(size_t)j * 4 + 1]; v.ja[2] = c.j_allocated[(size_t)j * 4 + 2];
+    v.s_pipelined = (v.n_ps == 1) ? c.s_pipelined[v.s] : 1;
+    v.shape = v.n_ps == 1 && !v.has_topo && v.s_pipelined == 0 && v.tta_valid && v.tta_n > 0 && v.tta_n <= KAI_FMAX;
+    int bad = 0;
+    const bool nominated = c.plugins & KAI_PLUGIN_NOMINATEDNODE;
+    if (v.shape) for (int i = lane; i < v.tta_n; i += nl) {
+        int p = c.tta[v.first + i];
+        int k = c.p_scls[p], st = c.p_status[p], on = c.p_on_node[p], nom = c.p_nominated[p];
+        f.p[i] = p; f.cls[i] = k;
+        bad |= (k < 0) | (st != KAI_POD_PENDING) | (on >= 0) | (nominated && nom >= 0);
+        for (int r = 0; r < KAI_MAX_RES; r++) f.req[i][r] = r < c.R ? c.p_req[(size_t)r * c.P + p] : 0.0;
+    }
+    if (lane == 0) out = v;
+    return bad;
+}
+
 // ======================================================================================================
 // Engine<Backend>: the control flow.  Backend provides
 //    void minmax(const KaiCtx&, int r, double& mn, double& mx)          — pack.go:66-86 over the node set (brute force)
@@ -435,9 +478,16 @@ KAI_HD bool key_better(uint64_t k, int n, uint64_t bk, int bn) { return k > bk |
 //    int64_t clock()
 // ======================================================================================================
 // the engine's own scalars (one set per running action)
+// Counters the control lane bumps on every pop / decision / committed operation: kept with the engine's scalars (LDS on the device, a dependent
+// global read-modify-write each otherwise) and written to EngineState once, when the action ends.
+struct EngineHot {
+    int64_t decisions, index_queries, index_refreshes, rollbacks, jobs_attempted, jobs_committed, out_len;
+    int64_t prof[16];
+};
 struct EngineLocal {
+    EngineHot h;
     QNode* qn; int32_t *qheap, *root_heap;  // where the job-order tree lives (LDS if it fits, else HBM)
-    int32_t root_len, root_init, fail_no_node, pad;
+    int32_t root_len, root_init, fail_no_node, pop_leaf;  // pop_leaf: leaf queue the last job was popped from (= its queue)
     double total0, total1, total2;          // proportion totalResource (read-only during an action)
     // scope of the next node scans (general path): node-set bitmap (null = every node) and the preferred-level scores that apply
     KAI_GP(const uint32_t) scope_bits; KAI_GP(const double) scope_score; int32_t scope_row, n_keys;
@@ -495,7 +545,7 @@ struct Engine {
     // the dirty-block list lives in the backend (LDS on the device) so that this object holds no dynamically indexed storage
     KAI_HD void flush_index() {
         int nd = be.dirty_count();
-        if (nd) { int64_t t = be.clock(); be.refresh(cx()); cx().st->index_refreshes += nd; cx().st->prof[PF_REFRESH] += be.clock() - t; }
+        if (nd) { int64_t t = be.clock(); be.refresh(cx()); el().h.index_refreshes += nd; el().h.prof[PF_REFRESH] += be.clock() - t; }
     }
     KAI_HD void mark_dirty(int n) {
         if (!cx().use_index) return;
@@ -699,7 +749,7 @@ struct Engine {
     }
     KAI_HD void rollback(int cp) {  // :48-61
         for (int i = cx().st->ops_len - 1; i >= cp; i--) undo_operation(i);
-        truncate_ops(cp); cx().st->rollbacks++;
+        truncate_ops(cp); el().h.rollbacks++;
     }
     KAI_HD void discard() { for (int i = cx().st->ops_len - 1; i >= 0; i--) undo_operation(i); truncate_ops(0); }  // :522-534
     KAI_HD bool convert_all_allocated_to_pipelined(int job) {  // :483-516
@@ -724,12 +774,12 @@ struct Engine {
         for (int i = 0; i < cx().st->ops_len; i++) {
             if (!op_valid(i)) continue;
             StmtOp op = cx().ops[i]; if (op.name == OP_UNDO) continue;
-            if (cx().st->out_len >= cx().out_cap) { fault(FAULT_OUT_CAP); break; }
-            kai_op o; o.seq = cx().st->out_len; o.pod = op.pod; o.job = cx().p_job[op.pod]; o.node = cx().p_node[op.pod];
+            if (el().h.out_len >= cx().out_cap) { fault(FAULT_OUT_CAP); break; }
+            kai_op o; o.seq = el().h.out_len; o.pod = op.pod; o.job = cx().p_job[op.pod]; o.node = cx().p_node[op.pod];
             if (op.name == OP_EVICT) { o.kind = KAI_OP_EVICT; o.node = op.prev_node; cx().p_virtual[op.pod] = 0; cx().st->non_allocate_commits++; }
             else if (op.name == OP_PIPELINE) { o.kind = KAI_OP_PIPELINE; cx().st->non_allocate_commits++; }
             else { o.kind = KAI_OP_ALLOCATE; update_task_status(op.pod, KAI_POD_BINDING); }  // ssn.BindPod (framework/session.go:111-126)
-            cx().out_ops[cx().st->out_len++] = o;
+            cx().out_ops[el().h.out_len++] = o;
         }
         truncate_ops(0);
     }
@@ -866,7 +916,7 @@ struct Engine {
     KAI_HD void queue_key(int q) {
         if (qnp()[q].flags & QF_VALID) return;
 #ifdef KAI_PROF_POP
-        int64_t tk0 = be.clock(); cx().st->prof[8]++;
+        int64_t tk0 = be.clock(); el().h.prof[8]++;
 #endif
         const QShare L[3] = {cx().q_share[(size_t)q * 3], cx().q_share[(size_t)q * 3 + 1], cx().q_share[(size_t)q * 3 + 2]};  // loaded before the best-job chain: the two overlap
         int bj = best_job_from_node(q);
@@ -892,7 +942,7 @@ struct Engine {
         n.best_job = bj; n.dom_with_job = dwj;
         n.flags = (n.flags & ~(QF_OVER | QF_STARVED | QF_VIOL | QF_DNJ)) | bits | QF_VALID;
 #ifdef KAI_PROF_POP
-        cx().st->prof[9] += be.clock() - tk0;
+        el().h.prof[9] += be.clock() - tk0;
 #endif
     }
     KAI_HD double dom_no_job(int q) {
@@ -1025,9 +1075,23 @@ struct Engine {
             if (qnp()[r].len == 0) return true;
             return !queue_order_fn(l, r);
         }
-        if (qnp()[l].len == 0) return true;
-        if (qnp()[r].len == 0) return false;
+        // both records in one batch of LDS reads; with both keys cached (the usual case inside a sift: only the node whose subtree was popped is
+        // recomputed) the first five rules of queue_order.go:19-73 — over fair share, starved, priority, zero-share violation, dominant share with
+        // the job — are one integer and one f64 compare on registers.  Ties, and keys still to be computed, take the full comparator.
+        const QNode a = qnp()[l], b = qnp()[r];
+        if (a.len == 0) return true;
+        if (b.len == 0) return false;
+        if ((cx().plugins & KAI_PLUGIN_PROPORTION) && (a.flags & b.flags & QF_VALID)) {
+            const uint64_t ka = order_bits(a), kb = order_bits(b);
+            if (ka != kb) return ka < kb;
+            if (a.dom_with_job < b.dom_with_job) return true;
+            if (a.dom_with_job > b.dom_with_job) return false;
+        }
         return queue_order_fn(l, r);
+    }
+    KAI_HD static uint64_t order_bits(const QNode& n) {  // smaller sorts first: not over fair share, starved, higher priority, no violation
+        return ((uint64_t)((n.flags & QF_OVER) != 0) << 34) | ((uint64_t)((n.flags & QF_STARVED) == 0) << 33) |
+               ((uint64_t)(uint32_t)((int64_t)0x7fffffff - (int64_t)n.prio) << 1) | (uint64_t)((n.flags & QF_VIOL) != 0);
     }
     KAI_HD int32_t* node_heap(int parent) { return parent < 0 ? rootheapp() : qheapp() + qnp()[parent].heap_off; }
     KAI_HD int node_heap_len(int parent) const { return parent < 0 ? el().root_len : qnp()[parent].len; }
@@ -1036,11 +1100,11 @@ struct Engine {
     KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent) - 1; set_heap_len(parent, n); int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
     KAI_HD void node_heap_fix0(int parent) {
 #ifdef KAI_PROF_POP
-        int64_t tf0 = be.clock(); cx().st->prof[11]++;
+        int64_t tf0 = be.clock(); el().h.prof[11]++;
 #endif
         int32_t* h = node_heap(parent); int n = node_heap_len(parent); if (!heap_down(h, 0, n, NodeLess{this})) heap_up(h, 0, NodeLess{this}); if (parent >= 0) invalidate_path(parent);
 #ifdef KAI_PROF_POP
-        cx().st->prof[10] += be.clock() - tf0;
+        el().h.prof[10] += be.clock() - tf0;
 #endif
     }
 
@@ -1089,6 +1153,8 @@ struct Engine {
         int parent = -1, q;
         for (;;) { q = next_node(parent); if (q < 0) return -1; if (q_is_leaf(q)) break; parent = q; }  // traverseToLeaf :179-191
         int job = leaf_pop(q);
+        el().pop_leaf = q;
+        if constexpr (!kVictim) { if (cx().use_index && cx().fast_ok) be.stage_async(cx(), job); }  // gathered by a service wave while the pop is finished
         invalidate_path(q);
         handle_pop_from_node(q);
         return job;
@@ -1149,7 +1215,7 @@ struct Engine {
             int n = -1; uint64_t key = 0;
             int nom = (cx().plugins & KAI_PLUGIN_NOMINATEDNODE) ? cx().p_nominated[p] : -1;
             if (nom >= 0) { key = class_key(cx(), cr, nom); if (key) n = nom; }  // +1e6 outranks every other sum (plugins/nominatednode/nominatednode.go:29-41)
-            if (n < 0) { flush_index(); be.class_top(cx(), k, key, n); cx().st->index_queries++; if (!key) n = -1; }
+            if (n < 0) { flush_index(); be.class_top(cx(), k, key, n); el().h.index_queries++; if (!key) n = -1; }
             if (n >= 0) allocatable = (cx().plugins & KAI_PLUGIN_NODEAVAILABILITY) ? (key >> 63) != 0 : (cr.best_effort || fits(cx(), cr.req, n, false));
             return n;
         }
@@ -1161,22 +1227,22 @@ struct Engine {
         return n;
     }
     KAI_HD bool allocate_task(int p, bool pipeline_only) {  // :121-163
-        cx().st->decisions++;
+        el().h.decisions++;
         int64_t t0 = be.clock();
         // predicates step 1 is node independent on this path (capacity_policy.go:51-61): evaluate it once
         bool over = (cx().plugins & KAI_PLUGIN_PREDICATES) && task_over_capacity(p);
-        int64_t t1 = be.clock(); cx().st->prof[PF_TASKCAP] += t1 - t0;
+        int64_t t1 = be.clock(); el().h.prof[PF_TASKCAP] += t1 - t0;
         if (over) return false;
         bool allocatable = false;
         int n = find_node(p, allocatable);
-        int64_t t2 = be.clock(); cx().st->prof[PF_FIND] += t2 - t1;
+        int64_t t2 = be.clock(); el().h.prof[PF_FIND] += t2 - t1;
         if (n < 0) { el().fail_no_node = true; return false; }
         // allocateTaskToNode :165-174
         bool ok = (!pipeline_only && allocatable) ? stmt_allocate(p, n) : stmt_pipeline(p, n, !pipeline_only);
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(KAI_SOLVER_TRACE)
         std::fprintf(stderr, "[eng] task %d -> node %d pipe %d ok %d\n", p, n, (int)pipeline_only, (int)ok);
 #endif
-        cx().st->prof[PF_STMT] += be.clock() - t2;
+        el().h.prof[PF_STMT] += be.clock() - t2;
         return ok;
     }
     // ------------------------------------------------------------------ plugins/topology: SubsetNodesFn
@@ -1412,9 +1478,9 @@ struct Engine {
         el().n_keys = 0; el().restricted = 0;  // ssn.PreJobAllocation → topology.preJobAllocationFn (topology_plugin.go:52-55)
         int64_t t0 = be.clock();
         ensure_tta(j, !pipeline_only);
-        int64_t t1 = be.clock(); c.st->prof[PF_TTA] += t1 - t0;
+        int64_t t1 = be.clock(); el().h.prof[PF_TTA] += t1 - t0;
         bool gated = job_over_queue_capacity(j);
-        c.st->prof[PF_GATE] += be.clock() - t1;
+        el().h.prof[PF_GATE] += be.clock() - t1;
         if (gated) return false;
         const int first = c.j_first_pod[j], nt = c.j_tta_n[j], nps = c.j_n_ps[j], ps0 = c.j_first_ps[j], DT1 = c.D + c.T + 1;
         // the cached chunk is consumed below while statuses change, so snapshot it (Go holds the slice it got)
@@ -1524,59 +1590,77 @@ struct Engine {
     KAI_HD static double frame_quota(const double* rq, int k) { return k == KAI_Q_CPU ? rq[KAI_RES_CPU] : k == KAI_Q_MEM ? rq[KAI_RES_MEM] : rq[KAI_RES_GPU]; }
     KAI_HD int allocate_job_fast(int j) {
         if (!cx().use_index || !cx().fast_ok) return -1;
-        // every job-level field first: independent loads, one memory latency (the early exits below would serialise them)
-        const int n_ps = cx().j_n_ps[j], has_topo = cx().j_has_topology[j], s = cx().j_first_ps[j], first = cx().j_first_pod[j];
-        const int tta_valid = cx().j_tta_valid[j], tta_n = cx().j_tta_n[j], jq = cx().j_queue[j], jpre = cx().j_preempt[j];
-        const double ja0 = cx().j_allocated[(size_t)j * 4 + 0], ja1 = cx().j_allocated[(size_t)j * 4 + 1], ja2 = cx().j_allocated[(size_t)j * 4 + 2];
-        if (n_ps != 1 || has_topo) return -1;
-        if (cx().s_pipelined[s] != 0) return -1;
-        if (!tta_valid) ensure_tta(j, true);
-        const int nt = tta_valid ? tta_n : cx().j_tta_n[j];
-        if (nt <= 0 || nt > KAI_FMAX) return -1;
+        int s, first, jq, jpre, nt; double ja0, ja1, ja2;
         FastFrame& f = KAI_FRAME;
-        const bool nominated = cx().plugins & KAI_PLUGIN_NOMINATEDNODE;
-        for (int i = 0; i < nt; i++) f.p[i] = cx().tta[first + i];
-        int bad = 0;
-        for (int i = 0; i < nt; i++) {  // independent loads, checked afterwards: nothing here is conditional on an earlier load
-            int p = f.p[i];
-            int k = cx().p_scls[p], st = cx().p_status[p], on = cx().p_on_node[p], nom = cx().p_nominated[p];
-            f.cls[i] = k;
-            bad |= (k < 0) | (st != KAI_POD_PENDING) | (on >= 0) | (nominated && nom >= 0);
-            for (int r = 0; r < KAI_MAX_RES; r++) f.req[i][r] = r < cx().R ? preq(p, r) : 0.0;
-        }
-        if (bad) return -1;
-#ifdef KAI_PROF_POP
-        int64_t ts0 = be.clock();
-#endif
-        const bool prop = cx().plugins & KAI_PLUGIN_PROPORTION;
-        int d = 0;
-        for (int q = jq; q >= 0; q = qnp()[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
-        f.depth = d; f.np = !jpre;
+        // the shares of the queue chain first: they hang off the leaf the job was popped from, not off anything of the job, so their loads overlap the
+        // staging of the job by the service wave (and, on the sequential path, the job's own first loads)
+        const int chain_leaf = el().pop_leaf; int d = 0;
+        for (int q = chain_leaf; q >= 0; q = qnp()[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
         for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {
             const QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k];
             f.alloc[l][k] = sh.allocated; f.alloc_np[l][k] = sh.allocated_np; f.max_allowed[l][k] = sh.max_allowed; f.deserved[l][k] = sh.deserved;
         }
+        if (be.staged(j)) {  // a service wave gathered the job while the pop was being finished (JobPf)
+            const JobPf& pf = KAI_JOBPF;
+            s = pf.s; first = pf.first; jq = pf.jq; jpre = pf.jpre; nt = pf.tta_n; ja0 = pf.ja[0]; ja1 = pf.ja[1]; ja2 = pf.ja[2];
+        } else {
+            // every job-level field first: independent loads, one memory latency (the early exits below would serialise them)
+            const int n_ps = cx().j_n_ps[j], has_topo = cx().j_has_topology[j];
+            s = cx().j_first_ps[j]; first = cx().j_first_pod[j];
+            const int tta_valid = cx().j_tta_valid[j], tta_n = cx().j_tta_n[j];
+            jq = cx().j_queue[j]; jpre = cx().j_preempt[j];
+            ja0 = cx().j_allocated[(size_t)j * 4 + 0]; ja1 = cx().j_allocated[(size_t)j * 4 + 1]; ja2 = cx().j_allocated[(size_t)j * 4 + 2];
+            if (n_ps != 1 || has_topo) return -1;
+            if (cx().s_pipelined[s] != 0) return -1;
+            if (!tta_valid) ensure_tta(j, true);
+            nt = tta_valid ? tta_n : cx().j_tta_n[j];
+            if (nt <= 0 || nt > KAI_FMAX) return -1;
+            const bool nominated = cx().plugins & KAI_PLUGIN_NOMINATEDNODE;
+            for (int i = 0; i < nt; i++) f.p[i] = cx().tta[first + i];
+            int bad = 0;
+            for (int i = 0; i < nt; i++) {  // independent loads, checked afterwards: nothing here is conditional on an earlier load
+                int p = f.p[i];
+                int k = cx().p_scls[p], st = cx().p_status[p], on = cx().p_on_node[p], nom = cx().p_nominated[p];
+                f.cls[i] = k;
+                bad |= (k < 0) | (st != KAI_POD_PENDING) | (on >= 0) | (nominated && nom >= 0);
+                for (int r = 0; r < KAI_MAX_RES; r++) f.req[i][r] = r < cx().R ? preq(p, r) : 0.0;
+            }
+            if (bad) return -1;
+        }
+#ifdef KAI_PROF_POP
+        int64_t ts0 = be.clock();
+#endif
+        const bool prop = cx().plugins & KAI_PLUGIN_PROPORTION;
+        if (jq != chain_leaf) {  // not reached from the allocate loop (a job is popped from its own queue); kept for any other caller
+            d = 0;
+            for (int q = jq; q >= 0; q = qnp()[q].parent) { if (d == KAI_FDEPTH) return -1; f.q[d++] = q; }
+            for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {
+                const QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k];
+                f.alloc[l][k] = sh.allocated; f.alloc_np[l][k] = sh.allocated_np; f.max_allowed[l][k] = sh.max_allowed; f.deserved[l][k] = sh.deserved;
+            }
+        }
+        f.depth = d; f.np = !jpre;
         if (prop) {  // IsJobOverQueueCapacityFn (capacity_policy.go:26-36,76-84)
             double req[3] = {0, 0, 0};
             for (int i = 0; i < nt; i++) { req[KAI_Q_GPU] += frame_quota(f.req[i], KAI_Q_GPU); req[KAI_Q_CPU] += frame_quota(f.req[i], KAI_Q_CPU); req[KAI_Q_MEM] += frame_quota(f.req[i], KAI_Q_MEM); }
             if (frame_over_limit(f, req) || frame_np_over_quota(f, req)) return 0;
         }
 #ifdef KAI_PROF_POP
-        cx().st->prof[13] += be.clock() - ts0;  // frame: queue chain + gate
+        el().h.prof[13] += be.clock() - ts0;  // frame: queue chain + gate
         int64_t ts1 = be.clock();
 #endif
         double ja[3] = {ja0, ja1, ja2};
         const bool preds = cx().plugins & KAI_PLUGIN_PREDICATES;
         int done = 0; bool ok = true;
         for (int i = 0; i < nt; i++) {  // allocateTask :121-163
-            cx().st->decisions++;
+            el().h.decisions++;
             const double* rq = f.req[i];
             if (preds && prop) {  // predicates step 1 (capacity_policy.go:51-61, node_info.go:734-744: 1 GPU for any whole-GPU request)
                 double r3[3] = {rq[KAI_RES_CPU], rq[KAI_RES_MEM], rq[KAI_RES_GPU] >= 1 ? 1.0 : 0.0};
                 if (frame_over_limit(f, r3) || frame_np_over_quota(f, r3)) { ok = false; break; }
             }
             flush_index();
-            uint64_t key; int n; be.class_top(cx(), f.cls[i], key, n); cx().st->index_queries++;
+            uint64_t key; int n; be.class_top(cx(), f.cls[i], key, n); el().h.index_queries++;
             if (!key) { el().fail_no_node = true; ok = false; break; }
             // Statement.Allocate :297-358 → NodeInfo.AddTask → addTaskResources (node_info.go:457-493)
             {   // all loads first (independent, one latency), then the stores: same values, same operations
@@ -1599,14 +1683,14 @@ struct Engine {
             f.node[i] = n; done++;
         }
 #ifdef KAI_PROF_POP
-        cx().st->prof[14] += be.clock() - ts1;  // task loop
+        el().h.prof[14] += be.clock() - ts1;  // task loop
 #endif
         if (ok) {  // Statement.Commit :536-575 + ssn.BindPod: nt Allocate operations in task order
             for (int i = 0; i < nt; i++) {
                 int p = f.p[i], n = f.node[i];
-                if (cx().st->out_len >= cx().out_cap) { fault(FAULT_OUT_CAP); break; }
-                kai_op o; o.seq = cx().st->out_len; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j;
-                cx().out_ops[cx().st->out_len++] = o;
+                if (el().h.out_len >= cx().out_cap) { fault(FAULT_OUT_CAP); break; }
+                kai_op o; o.seq = el().h.out_len; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j;
+                cx().out_ops[el().h.out_len++] = o;
                 for (int k = 0; k < 3; k++) { double v = frame_quota(f.req[i], k); ja[k] -= v; ja[k] += v; }  // Allocated → Binding (job_info.go:228-287)
                 cx().p_status[p] = KAI_POD_BINDING; cx().p_node[p] = n; cx().p_on_node[p] = n; cx().p_on_node_status[p] = KAI_POD_ALLOCATED; cx().p_accepted[p] = 1; cx().p_virtual[p] = 1;
             }
@@ -1631,7 +1715,7 @@ struct Engine {
                     if (f.np) f.alloc_np[l][k] += -1.0 * v;
                 }
             }
-            cx().st->rollbacks += 2;
+            el().h.rollbacks += 2;
         }
         if (done > 0) {
             cx().j_tta_valid[j] = 0;
@@ -1652,43 +1736,56 @@ struct Engine {
         if (cx().j_tta_n[j] == 0) return;
         decisions++; rollbacks += 2;
     }
-    KAI_HD void execute_allocate() {  // actions/allocate/allocate.go:46-77
+    KAI_HD void hot_begin() {
+        EngineHot& h = el().h; const EngineState& st = *cx().st;
+        h.decisions = st.decisions; h.index_queries = st.index_queries; h.index_refreshes = st.index_refreshes; h.rollbacks = st.rollbacks;
+        h.jobs_attempted = st.jobs_attempted; h.jobs_committed = st.jobs_committed; h.out_len = st.out_len;
+        for (int i = 0; i < 16; i++) h.prof[i] = st.prof[i];
+    }
+    KAI_HD void hot_end() {
+        const EngineHot& h = el().h; EngineState& st = *cx().st;
+        st.decisions = h.decisions; st.index_queries = h.index_queries; st.index_refreshes = h.index_refreshes; st.rollbacks = h.rollbacks;
+        st.jobs_attempted = h.jobs_attempted; st.jobs_committed = h.jobs_committed; st.out_len = h.out_len;
+        for (int i = 0; i < 16; i++) st.prof[i] = h.prof[i];
+    }
+    KAI_HD void execute_allocate() { hot_begin(); execute_allocate_impl(); hot_end(); }
+    KAI_HD void execute_allocate_impl() {  // actions/allocate/allocate.go:46-77
         int64_t t0 = be.clock(), t;
         be.hot(cx(), el().qn, el().qheap, el().root_heap);
         be.begin(cx());
         init_jobs_order();
-        t = be.clock(); cx().st->prof[5] += t - t0;
+        t = be.clock(); el().h.prof[5] += t - t0;
         for (;;) {
             if (cx().st->fault) break;
             int64_t ta = be.clock();
             int j = pop_next_job(); if (j < 0) break;
-            int64_t tb = be.clock(); cx().st->prof[0] += tb - ta;
+            int64_t tb = be.clock(); el().h.prof[0] += tb - ta;
             cx().st->ops_len = 0; cx().st->n_undo = 0;
-            cx().st->jobs_attempted++;
+            el().h.jobs_attempted++;
             el().fail_no_node = false;
             int fr = allocate_job_fast(j);
             bool ok = fr < 0 ? allocate_job(j, false) : fr == 1;
-            int64_t tc = be.clock(); cx().st->prof[2] += tc - tb;
+            int64_t tc = be.clock(); el().h.prof[2] += tc - tb;
             if (ok) {  // attemptToAllocateJob :79-111 — ShouldPipelineJob (job_info.go:443-464)
                 bool should_pipeline = false;
                 for (int k = 0; k < cx().j_n_ps[j]; k++) { int s = cx().j_first_ps[j] + k; if (cx().s_pipelined[s] > 0 && (cx().s_active_alloc[s] - cx().s_pipelined[s]) < cx().s_min[s]) should_pipeline = true; }
                 if (should_pipeline && !convert_all_allocated_to_pipelined(j)) ok = false;
             }
             if (ok) {
-                cx().st->jobs_committed++;
+                el().h.jobs_committed++;
                 commit();
-                if (cx().j_n_pending[j] > 0) { int64_t tp = be.clock(); push_job(j); cx().st->prof[PF_PUSH] += be.clock() - tp; }  // HasTasksToAllocate(job, true)
+                if (cx().j_n_pending[j] > 0) { int64_t tp = be.clock(); push_job(j); el().h.prof[PF_PUSH] += be.clock() - tp; }  // HasTasksToAllocate(job, true)
             } else {
                 discard();
             }
-            int64_t td = be.clock(); cx().st->prof[3] += td - tc;
+            int64_t td = be.clock(); el().h.prof[3] += td - tc;
             if (!ok && el().fail_no_node && cx().use_index && cx().all_tracked) {  // nothing fits any class any more: the rest of the queue fails job by job
                 flush_index();
                 if (be.all_dead(cx())) { cx().st->drain_pending = 1; break; }
             }
-            cx().st->prof[4] += be.clock() - td;
+            el().h.prof[4] += be.clock() - td;
         }
-        cx().st->prof[7] += be.clock() - t0;
+        el().h.prof[7] += be.clock() - t0;
     }
 
     // ------------------------------------------------------------------ reclaim / preempt / consolidation

@@ -189,6 +189,8 @@ struct NullBackend {  // kernels that only need the engine's pure helpers
     __device__ void refresh(const KaiCtx&) {}
     __device__ void class_top(const KaiCtx&, int, uint64_t& k, int& n) { k = 0; n = -1; }
     __device__ bool all_dead(const KaiCtx&) { return false; }
+    __device__ void stage_async(const KaiCtx&, int) {}
+    __device__ bool staged(int) { return false; }
     __device__ void hot(const KaiCtx&, QNode*&, int32_t*&, int32_t*&) {}
     __device__ bool sim_tree(QNode*&, int32_t*&, int32_t*&) { return false; }
     __device__ int64_t clock() { return 0; }
@@ -240,7 +242,7 @@ __global__ void k_leaf_init(KaiCtx c) {
 // ------------------------------------------------------------------------------------------------------
 // the persistent action kernel
 // ------------------------------------------------------------------------------------------------------
-enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5, CMD_LOADTREE = 6 };
+enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5, CMD_LOADTREE = 6, CMD_STAGE = 7 };
 
 // dynamic LDS of k_action / k_best_node: [s2_key C*NSB u64][s2_node C*NSB i32] and, when tree_in_lds, [QNode Q][qheap Q+1][root_heap Q+1]
 extern __shared__ __align__(16) unsigned char kai_dyn_lds[];
@@ -257,7 +259,8 @@ struct ActShared {
     unsigned long long top_key[KAI_CMAX]; int32_t top_node[KAI_CMAX];
     unsigned long long __attribute__((address_space(3)))* s2_key; int32_t __attribute__((address_space(3)))* s2_node;  // [C][NSB] in dynamic LDS (typed LDS pointers: ds_read / ds_write)
     QNode* qn; int32_t *qheap, *root_heap;          // job-order tree: dynamic LDS when it fits, else the HBM arrays
-    int32_t tree_in_lds, in_flight;  // in_flight: a refresh was published and its results not yet awaited (the control lane overlaps it with its own work)
+    int32_t tree_in_lds, in_flight;  // in_flight: 1 = a refresh, 2 = a job staging was published and its results not yet awaited (the control lane overlaps it with its own work)
+    int32_t stage_job, pad3;
     KAI_GP(const uint32_t) nodeset;  // scope of brute-force scans: node-set bitmap (bit n of word n/32; engine node order), nullptr = all nodes,
     KAI_GP(const double) topo_score; int32_t topo_row, pad2;  // … and preferred-level topology scores per domain of level row topo_row (-1 = none)
     long long t_publish, t_wait, t_svc, t_seg[6];  // profiling: control lane through barrier 1 / barrier 2, service wave 1 busy time
@@ -300,7 +303,8 @@ struct DevBackendT {
         long long t1 = clock64();
         __syncthreads();  // results ready
         sh->t_wait += clock64() - t1;
-        sh->in_flight = 0; sh->n_dirty = 0;
+        if (sh->in_flight == 1) sh->n_dirty = 0;
+        sh->in_flight = 0;
     }
     __device__ void call(int cmd) {
         wait();
@@ -342,6 +346,16 @@ struct DevBackendT {
         sh->t_publish += clock64() - t0; sh->in_flight = 1;
     }
     __device__ void class_top(const KaiCtx&, int k, uint64_t& key, int& node) { wait(); key = sh->top_key[k]; node = sh->top_node[k]; }
+    // job staging: published like a refresh, awaited by allocate_job_fast; skipped while blocks wait on the dirty list (the list belongs to the
+    // next refresh)
+    __device__ void stage_async(const KaiCtx&, int j) {
+        wait();
+        if (sh->n_dirty) { kai_pf_lds.job = -1; return; }
+        sh->stage_job = j; sh->cmd = CMD_STAGE;
+        __syncthreads();
+        sh->in_flight = 2;
+    }
+    __device__ bool staged(int j) { if (sh->in_flight == 2) wait(); bool r = kai_pf_lds.job == j && kai_pf_lds.ok; kai_pf_lds.job = -1; return r; }
     __device__ bool all_dead(const KaiCtx& c) { wait(); for (int k = 0; k < c.C; k++) if (sh->top_key[k]) return false; return true; }
     __device__ void hot(const KaiCtx& c, QNode*& qn, int32_t*& qheap, int32_t*& root_heap) {
         if constexpr (VICTIM) { qn = c.qn; qheap = c.qheap; root_heap = c.root_heap; return; }  // the LDS region goes to the simulation queue (sim_tree)
@@ -434,6 +448,12 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
                     svc_top(c, sh, k, lane);
                 }
             }
+        } else if (cmd == CMD_STAGE) {  // gather one job for the staged path (JobPf, stage_job_lane): one wave, a lane per pod of the chunk
+            if (hw == 0) {
+                int bad = stage_job_lane(c, sh->stage_job, kai_frame_lds, kai_pf_lds, lane, 64);
+                bad = __any(bad);
+                if (lane == 0) kai_pf_lds.ok = kai_pf_lds.shape && !bad;
+            }
         } else if (cmd == CMD_MINMAX) {  // getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86)
             int r = sh->r;
             double lo = 1.7976931348623157e308, hi = 0;
@@ -487,6 +507,7 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     const KaiCtx& c = g_ctx;
     ActShared& sh = g_sh;
     if (threadIdx.x == 0) {
+        kai_pf_lds.job = -1; kai_pf_lds.ok = 0;
         sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.in_flight = 0; sh.tree_in_lds = tree_in_lds; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
         size_t off = 0;
         sh.s2_key = (unsigned long long __attribute__((address_space(3)))*)(kai_dyn_lds); sh.s2_node = (int32_t __attribute__((address_space(3)))*)(kai_dyn_lds + (size_t)c.C * c.NSB * 8);

@@ -81,6 +81,14 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     }
     void class_top(const KaiCtx&, int k, uint64_t& key, int& node) { key = top_key[k]; node = top_node[k]; }
     bool all_dead(const KaiCtx& c) { for (int k = 0; k < c.C; k++) if (top_key[k]) return false; return true; }
+    // job staging (kai_engine.hpp JobPf): the device hands it to a service wave and overlaps it with the rest of the pop; here it runs in place,
+    // with several "lanes" so that the strided pod assignment is exercised
+    void stage_async(const KaiCtx& c, int j) {
+        if (n) { KAI_JOBPF.job = -1; KAI_JOBPF.ok = 0; return; }
+        int bad = 0; for (int lane = 3; lane >= 0; lane--) bad |= stage_job_lane(c, j, KAI_FRAME, KAI_JOBPF, lane, 4);
+        KAI_JOBPF.ok = KAI_JOBPF.shape && !bad;
+    }
+    bool staged(int j) { bool r = KAI_JOBPF.job == j && KAI_JOBPF.ok; KAI_JOBPF.job = -1; return r; }
     void hot(const KaiCtx& c, QNode*& qn, int32_t*& qheap, int32_t*& root_heap) { qn = c.qn; qheap = c.qheap; root_heap = c.root_heap; }
     int64_t clock() { return 0; }
 };
