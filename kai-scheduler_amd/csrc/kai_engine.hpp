@@ -107,7 +107,8 @@ constexpr int KAI_FDEPTH = 8;  // queue levels
 constexpr int KAI_TDEPTH = 16;  // frames of the sub-group DFS (group depth + the pod-set level)
 constexpr int KAI_TKEYS = 32;   // sub-groups of one job that carry preferred-level node scores
 struct FastFrame {
-    int32_t depth, np, pad0, pad1;
+    int32_t depth, np, n_lim, n_dsv;   // n_lim / n_dsv: entries of lim_idx / dsv_idx
+    uint8_t lim_idx[KAI_FDEPTH * 3], dsv_idx[KAI_FDEPTH * 3];  // (level * 3 + resource) of the finite limits / finite quotas on the chain: the only entries the capacity checks can trip on
     int32_t q[KAI_FDEPTH];
     int32_t p[KAI_FMAX], cls[KAI_FMAX], node[KAI_FMAX];
     double req[KAI_FMAX][KAI_MAX_RES];
@@ -926,7 +927,13 @@ struct Engine {
             victims = true; int leaf = cx().j_queue[bj]; double a[3]; view_allocated(bj, a);
             for (int k = 0; k < 3; k++) sub[k] = sx().vq_pop[leaf * 3 + k] + a[k];
         }
-        if (bj >= 0 && !victims) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)bj * 4 + k]; }
+        if (bj >= 0 && !victims) {
+            if constexpr (!kVictim) {  // cached chunk: flag and sums in one batch of loads (the sums are re-read only if the chunk had to be rebuilt)
+                const int tv = cx().j_tta_valid[bj];
+                req[0] = cx().j_tta_res[(size_t)bj * 4 + 0]; req[1] = cx().j_tta_res[(size_t)bj * 4 + 1]; req[2] = cx().j_tta_res[(size_t)bj * 4 + 2];
+                if (!tv) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)bj * 4 + k]; }
+            } else { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)bj * 4 + k]; }
+        }
         uint32_t bits = 0;
         bool over = true, starved = true, viol = false;
         for (int k = 0; k < 3; k++) {
@@ -1055,10 +1062,16 @@ struct Engine {
     }
     KAI_HD int leaf_pop(int q) {
         leaf_skip(q);
-        int a = lq_cur()[q] < lq_end()[q] ? lq_sorted()[cx().q_job_off[q] + lq_cur()[q]] : -1;
-        int b = lq_side_len()[q] > 0 ? lq_side()[cx().q_job_off[q]] : -1;
+        const int cur = lq_cur()[q], end = lq_end()[q], off = cx().q_job_off[q], nside = lq_side_len()[q];
+        int a = cur < end ? lq_sorted()[off + cur] : -1;
+        int a2 = cur + 1 < end ? lq_sorted()[off + cur + 1] : -1;  // the job behind it: same latency (usually the same line) as the head itself
+        int b = nside > 0 ? lq_side()[off] : -1;
         qnp()[q].len--; qnp()[q].flags &= ~QF_TOP;
-        if (b < 0 || (a >= 0 && !job_less(b, a))) { lq_cur()[q]++; return a; }
+        if (b < 0 || (a >= 0 && !job_less(b, a))) {
+            lq_cur()[q] = cur + 1;
+            if constexpr (!kVictim) { if (b < 0) { qnp()[q].best_job = a2; qnp()[q].flags |= QF_TOP; } }  // no side heap: the next head is known now (leaf_top would fetch exactly this)
+            return a;
+        }
         int32_t* h = lq_side() + cx().q_job_off[q]; int n = lq_side_len()[q] - 1;
         int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, JobLess{this}); lq_side_len()[q] = n;
         return b;
@@ -1569,23 +1582,29 @@ struct Engine {
     // reference's order (allocate handlers :443-465, rollback = the same operations with the opposite sign, Allocated→Binding on
     // commit), and the results are written back once.  Returns -1 when the job does not qualify (nothing touched).
     KAI_HD bool frame_over_limit(const FastFrame& f, const double* req) const {  // capacity_policy/max_allowed_check.go:20-66
-        for (int l = 0; l < f.depth; l++) for (int k = 0; k < 3; k++) {
-            double mx = f.max_allowed[l][k];
-            if (mx == KAI_UNLIMITED) continue;
+        for (int i = 0; i < f.n_lim; i++) {  // an unlimited entry never trips (:38-40): only the finite ones were listed when the chain was loaded
+            int l = f.lim_idx[i] / 3, k = f.lim_idx[i] % 3;
             if (req[k] == 0) continue;
-            if (mx < f.alloc[l][k] + req[k]) return true;
+            if (f.max_allowed[l][k] < f.alloc[l][k] + req[k]) return true;
         }
         return false;
     }
     KAI_HD bool frame_np_over_quota(const FastFrame& f, const double* req) const {  // capacity_policy/quota_check.go:27-77
         if (!f.np) return false;
-        for (int l = 0; l < f.depth; l++) for (int k = 0; k < 3; k++) {
-            double ds = f.deserved[l][k];
-            if (ds == KAI_UNLIMITED) continue;
+        for (int i = 0; i < f.n_dsv; i++) {
+            int l = f.dsv_idx[i] / 3, k = f.dsv_idx[i] % 3;
             if (req[k] == 0) continue;
-            if (ds < f.alloc_np[l][k] + req[k]) return true;
+            if (f.deserved[l][k] < f.alloc_np[l][k] + req[k]) return true;
         }
         return false;
+    }
+    KAI_HD void frame_list_constraints(FastFrame& f, int d) const {
+        int nl = 0, nd = 0;
+        for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {
+            if (f.max_allowed[l][k] != KAI_UNLIMITED) f.lim_idx[nl++] = (uint8_t)(l * 3 + k);
+            if (f.deserved[l][k] != KAI_UNLIMITED) f.dsv_idx[nd++] = (uint8_t)(l * 3 + k);
+        }
+        f.n_lim = nl; f.n_dsv = nd;
     }
     KAI_HD static double frame_quota(const double* rq, int k) { return k == KAI_Q_CPU ? rq[KAI_RES_CPU] : k == KAI_Q_MEM ? rq[KAI_RES_MEM] : rq[KAI_RES_GPU]; }
     KAI_HD int allocate_job_fast(int j) {
@@ -1600,6 +1619,7 @@ struct Engine {
             const QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k];
             f.alloc[l][k] = sh.allocated; f.alloc_np[l][k] = sh.allocated_np; f.max_allowed[l][k] = sh.max_allowed; f.deserved[l][k] = sh.deserved;
         }
+        frame_list_constraints(f, d);
         if (be.staged(j)) {  // a service wave gathered the job while the pop was being finished (JobPf)
             const JobPf& pf = KAI_JOBPF;
             s = pf.s; first = pf.first; jq = pf.jq; jpre = pf.jpre; nt = pf.tta_n; ja0 = pf.ja[0]; ja1 = pf.ja[1]; ja2 = pf.ja[2];
@@ -1638,6 +1658,7 @@ struct Engine {
                 const QShare& sh = cx().q_share[(size_t)f.q[l] * 3 + k];
                 f.alloc[l][k] = sh.allocated; f.alloc_np[l][k] = sh.allocated_np; f.max_allowed[l][k] = sh.max_allowed; f.deserved[l][k] = sh.deserved;
             }
+            frame_list_constraints(f, d);
         }
         f.depth = d; f.np = !jpre;
         if (prop) {  // IsJobOverQueueCapacityFn (capacity_policy.go:26-36,76-84)
@@ -1653,14 +1674,23 @@ struct Engine {
         const bool preds = cx().plugins & KAI_PLUGIN_PREDICATES;
         int done = 0; bool ok = true;
         for (int i = 0; i < nt; i++) {  // allocateTask :121-163
+#ifdef KAI_PROF_LOOP
+            int64_t L0 = be.clock();
+#endif
             el().h.decisions++;
             const double* rq = f.req[i];
             if (preds && prop) {  // predicates step 1 (capacity_policy.go:51-61, node_info.go:734-744: 1 GPU for any whole-GPU request)
                 double r3[3] = {rq[KAI_RES_CPU], rq[KAI_RES_MEM], rq[KAI_RES_GPU] >= 1 ? 1.0 : 0.0};
                 if (frame_over_limit(f, r3) || frame_np_over_quota(f, r3)) { ok = false; break; }
             }
+#ifdef KAI_PROF_LOOP
+            int64_t L1 = be.clock(); el().h.prof[8] += L1 - L0;
+#endif
             flush_index();
             uint64_t key; int n; be.class_top(cx(), f.cls[i], key, n); el().h.index_queries++;
+#ifdef KAI_PROF_LOOP
+            int64_t L2 = be.clock(); el().h.prof[9] += L2 - L1;
+#endif
             if (!key) { el().fail_no_node = true; ok = false; break; }
             // Statement.Allocate :297-358 → NodeInfo.AddTask → addTaskResources (node_info.go:457-493)
             {   // all loads first (independent, one latency), then the stores: same values, same operations
@@ -1672,15 +1702,30 @@ struct Engine {
                     cx().n_used[x] = u[r] + v; cx().n_idle[x] = id[r] - v;
                 }
             }
+#ifdef KAI_PROF_LOOP
+            int64_t L3 = be.clock(); el().h.prof[10] += L3 - L2;
+#endif
             mark_dirty(n);
             flush_index();  // published now, awaited by the next reader of the index: overlaps the bookkeeping below, the commit and the next pop
-            if (prop) for (int l = 0; l < d; l++) for (int k = 0; k < 3; k++) {  // proportion allocate handler :443-465
-                double v = frame_quota(rq, k);
-                f.alloc[l][k] += v;
-                if (f.np) f.alloc_np[l][k] += v;
+#ifdef KAI_PROF_LOOP
+            int64_t L4 = be.clock(); el().h.prof[11] += L4 - L3;
+#endif
+            if (prop) {  // proportion allocate handler :443-465 — unrolled over the levels: the LDS reads of one pass go out together
+                const double v0 = frame_quota(rq, 0), v1 = frame_quota(rq, 1), v2 = frame_quota(rq, 2); const bool np = f.np;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+                for (int l = 0; l < KAI_FDEPTH; l++) {
+                    if (l >= d) break;
+                    f.alloc[l][0] += v0; f.alloc[l][1] += v1; f.alloc[l][2] += v2;
+                    if (np) { f.alloc_np[l][0] += v0; f.alloc_np[l][1] += v1; f.alloc_np[l][2] += v2; }
+                }
             }
             for (int k = 0; k < 3; k++) ja[k] += frame_quota(rq, k);  // PodGroupInfo.Allocated (job_info.go:208-226)
             f.node[i] = n; done++;
+#ifdef KAI_PROF_LOOP
+            el().h.prof[13] += be.clock() - L4;
+#endif
         }
 #ifdef KAI_PROF_POP
         el().h.prof[14] += be.clock() - ts1;  // task loop
