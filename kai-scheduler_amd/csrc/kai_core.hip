@@ -391,7 +391,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     if (c.Q) hipLaunchKernelGGL(k_leaf_init, dim3((c.Q + 3) / 4), dim3(TB), 0, core->stream, c);
     {   // dynamic LDS: upper levels of the class index, plus the job-order tree when it fits beside them (160 KiB per CU)
         size_t idx_b = lds_index_bytes(c.C, c.NSB), tree_b = lds_tree_bytes(c.Q);
-        const size_t budget = 160 * 1024 - 4096;  // static ActShared + margin
+        const size_t budget = 160 * 1024 - 16384;  // static LDS of the kernel (mailbox, context, engine scalars, frame: 6.8 KB, llvm-readelf .group_segment_fixed_size) + margin
         int tree_in_lds = (idx_b + tree_b <= budget && !std::getenv("KAI_TREE_IN_HBM")) ? 1 : 0;
         size_t dyn = idx_b + (tree_in_lds ? tree_b : 0);
         auto launch = [&](auto kernel) -> int {
