@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KAI_ABI_VERSION 3u
+#define KAI_ABI_VERSION 4u
 
 /* resource vector layout: api/resource_info/resource_vector.go:23-36 (cpu, memory, gpu, pods, extras…) */
 #define KAI_RES_CPU 0
@@ -81,6 +81,7 @@ typedef enum kai_pod_status {
 #define KAI_NODE_HAS_DRA_GPUS 0x8u   /* node_info.go:95 HasDRAGPUs */
 #define KAI_NODE_GPU_WORKER 0x10u    /* has conf GPUWorkerNodeLabelKey (plugins/predicates/predicates.go:243-259) */
 #define KAI_NODE_CPU_WORKER 0x20u    /* has conf CPUWorkerNodeLabelKey */
+#define KAI_NODE_MIG_SINGLE 0x40u    /* MigStrategy == single (node_info.go:720-732): only whole-GPU tasks may run there (:349-352) */
 
 /* pod flag bits */
 #define KAI_POD_FOREIGN_SCHEDULER 0x1u /* spec.schedulerName != ours: plugins/proportion/proportion.go:276-285 */
@@ -117,7 +118,12 @@ typedef enum kai_placement_strategy { KAI_BINPACK = 0, KAI_SPREAD = 1 } kai_plac
 #define KAI_PLUGIN_NODEPLACEMENT 0x200u
 #define KAI_PLUGIN_MINRUNTIME 0x400u
 #define KAI_PLUGIN_TOPOLOGY 0x800u
-#define KAI_PLUGIN_ALL 0xFFFu
+/* shared-GPU plugins (fractional requests, ABI v4; restated by the oracle, not yet by the device engine — pods with a fraction still carry
+ * KAI_POD_CPU_FALLBACK): plugins/gpusharingorder (node order), plugins/gpupack and plugins/gpuspread (GPU order inside a node) */
+#define KAI_PLUGIN_GPUSHARINGORDER 0x1000u
+#define KAI_PLUGIN_GPUPACK 0x2000u
+#define KAI_PLUGIN_GPUSPREAD 0x4000u
+#define KAI_PLUGIN_ALL 0x3FFFu /* the default tier list: everything above except gpuspread */
 
 /* knobs of conf.SchedulerParams / plugin arguments that the path reads
  * (conf/scheduler_conf.go:31-61, plugins/proportion/proportion.go:67-93,
@@ -250,6 +256,19 @@ typedef struct kai_snapshot_soa {
     const int64_t* job_last_start_ns;            /* [J] */
     const int64_t* queue_preempt_min_runtime_ns; /* [Q] */
     const int64_t* queue_reclaim_min_runtime_ns; /* [Q] */
+
+    /* ---- fractional GPU requests (ABI v4; all optional, NULL = no pod asks for a fraction) ----
+     * pod_gpu_portion: 0 = a whole-GPU or CPU-only pod; in (0, 1) = a fraction of ONE device (annotation gpu-fraction,
+     *   api/pod_info/pod_info.go:472-477); pod_req's gpu column then holds the same portion (ResourceRequirements.GPUs()).
+     * pod_gpu_group: the shared-GPU group an ACTIVE fraction pod runs in (label runai-gpu-group; PodInfo.GPUGroups), as an id >= 0 that is
+     *   unique on its node; -1 = none.  Equality on one node is what the accounting uses (api/node_info/gpu_sharing_node_info.go); in addition
+     *   ids below 2^20 stand for numeric group names and ids from 2^20 on for any other name, because the predicates plugin takes a
+     *   non-numeric name for a group that is being created (plugins/predicates/predicates.go:320-330).
+     * node_gpu_memory: NodeInfo.MemoryOfEveryGpuOnNode in MiB (label nvidia.com/gpu.memory floored to a multiple of 100, node_info.go:673-687);
+     *   NULL = 100 on every node (DefaultGpuMemory). */
+    const double* pod_gpu_portion;   /* [P] */
+    const int32_t* pod_gpu_group;    /* [P] */
+    const int64_t* node_gpu_memory;  /* [N] */
 } kai_snapshot_soa;
 
 typedef struct kai_op {

@@ -12,7 +12,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-KAI_ABI_VERSION = 3
+KAI_ABI_VERSION = 4
 RES_CPU, RES_MEM, RES_GPU, RES_PODS = 0, 1, 2, 3
 MAX_RES = 8
 Q_CPU, Q_MEM, Q_GPU = 0, 1, 2
@@ -26,7 +26,7 @@ POD_STATUS = {
 POD_STATUS_NAME = {v: k for k, v in POD_STATUS.items()}
 ACTIVE_USED = sum(POD_STATUS[s] for s in ("Allocated", "Pipelined", "Binding", "Bound", "Running", "Releasing"))
 
-NODE_NOT_READY, NODE_MIG_ENABLED, NODE_MIG_MIXED, NODE_HAS_DRA_GPUS, NODE_GPU_WORKER, NODE_CPU_WORKER = 1, 2, 4, 8, 16, 32
+NODE_NOT_READY, NODE_MIG_ENABLED, NODE_MIG_MIXED, NODE_HAS_DRA_GPUS, NODE_GPU_WORKER, NODE_CPU_WORKER, NODE_MIG_SINGLE = 1, 2, 4, 8, 16, 32, 64
 POD_FOREIGN_SCHEDULER, POD_HAS_TASK_PRIORITY, POD_CPU_FALLBACK = 1, 2, 4
 
 ACTIONS = {"allocate": 0, "consolidation": 1, "reclaim": 2, "preempt": 3}
@@ -34,8 +34,8 @@ OP_KIND = {0: "allocate", 1: "pipeline", 2: "evict"}
 BINPACK, SPREAD = 0, 1
 PLUGINS = {"predicates": 0x001, "proportion": 0x002, "priority": 0x004, "elastic": 0x008, "nodeavailability": 0x010,
            "resourcetype": 0x020, "subgrouporder": 0x040, "taskorder": 0x080, "nominatednode": 0x100, "nodeplacement": 0x200,
-           "minruntime": 0x400, "topology": 0x800}
-PLUGIN_ALL = 0xFFF
+           "minruntime": 0x400, "topology": 0x800, "gpusharingorder": 0x1000, "gpupack": 0x2000, "gpuspread": 0x4000}
+PLUGIN_ALL = 0x3FFF  # the default tier list (conf_util/scheduler_conf_util.go:36-61): everything except gpuspread
 
 STATUS_TEXT = {0: "ok", -1: "invalid argument", -2: "no HIP device", -3: "HIP runtime error", -4: "output capacity",
                -5: "unsupported snapshot feature", -6: "call order", -7: "device engine fault", -8: "multi-GPU exchange"}
@@ -102,6 +102,7 @@ class KaiSnapshotSoA(C.Structure):
         ("podset_required_level", _P(C.c_int32)), ("podset_preferred_level", _P(C.c_int32)),
         ("job_signature", _P(C.c_int64)),
         ("job_last_start_ns", _P(C.c_int64)), ("queue_preempt_min_runtime_ns", _P(C.c_int64)), ("queue_reclaim_min_runtime_ns", _P(C.c_int64)),
+        ("pod_gpu_portion", _P(C.c_double)), ("pod_gpu_group", _P(C.c_int32)), ("node_gpu_memory", _P(C.c_int64)),
     ]
 
 
@@ -153,6 +154,7 @@ _SPEC_OPT = [
     ("group_required_level", np.int32), ("group_preferred_level", np.int32), ("job_root_group", np.int32), ("podset_group", np.int32),
     ("podset_topology", np.int32), ("podset_required_level", np.int32), ("podset_preferred_level", np.int32),
     ("job_signature", np.int64), ("job_last_start_ns", np.int64), ("queue_preempt_min_runtime_ns", np.int64), ("queue_reclaim_min_runtime_ns", np.int64),
+    ("pod_gpu_portion", np.float64), ("pod_gpu_group", np.int32), ("node_gpu_memory", np.int64),
 ]
 
 

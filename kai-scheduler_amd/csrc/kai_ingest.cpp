@@ -404,7 +404,8 @@ struct kai_ingest {
         podset_job, podset_min, job_queue, job_priority, job_preempt, job_first_pod, job_n_pods, job_first_podset, job_n_podsets, queue_parent, queue_priority,
         topo_level_off, node_domain, domain_level, domain_parent, group_job, group_parent, group_topology, group_req, group_pref, job_root_group,
         podset_group, podset_topology, podset_req, podset_pref;
-    std::vector<int64_t> pod_created, job_created, queue_created, job_signature, job_last_start, q_preempt_mrt, q_reclaim_mrt;
+    std::vector<int64_t> pod_created, job_created, queue_created, job_signature, job_last_start, q_preempt_mrt, q_reclaim_mrt, node_gpu_memory;
+    std::vector<double> pod_gpu_portion; std::vector<int32_t> pod_gpu_group; bool any_fraction = false;
     std::vector<uint8_t> class_fit;
     // what the decision writer needs of each pod / job (cache/cache.go:216-330)
     std::vector<std::string> pod_ns, pod_name, pod_uid, job_ns;
@@ -448,7 +449,8 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     {
         static const std::pair<const char*, uint32_t> kPlugins[] = {{"predicates", KAI_PLUGIN_PREDICATES}, {"proportion", KAI_PLUGIN_PROPORTION}, {"priority", KAI_PLUGIN_PRIORITY},
             {"elastic", KAI_PLUGIN_ELASTIC}, {"nodeavailability", KAI_PLUGIN_NODEAVAILABILITY}, {"resourcetype", KAI_PLUGIN_RESOURCETYPE}, {"subgrouporder", KAI_PLUGIN_SUBGROUPORDER},
-            {"taskorder", KAI_PLUGIN_TASKORDER}, {"nominatednode", KAI_PLUGIN_NOMINATEDNODE}, {"nodeplacement", KAI_PLUGIN_NODEPLACEMENT}, {"minruntime", KAI_PLUGIN_MINRUNTIME}, {"topology", KAI_PLUGIN_TOPOLOGY}};
+            {"taskorder", KAI_PLUGIN_TASKORDER}, {"nominatednode", KAI_PLUGIN_NOMINATEDNODE}, {"nodeplacement", KAI_PLUGIN_NODEPLACEMENT}, {"minruntime", KAI_PLUGIN_MINRUNTIME}, {"topology", KAI_PLUGIN_TOPOLOGY},
+            {"gpusharingorder", KAI_PLUGIN_GPUSHARINGORDER}, {"gpupack", KAI_PLUGIN_GPUPACK}, {"gpuspread", KAI_PLUGIN_GPUSPREAD}};
         const JV& tiers = conf["tiers"];
         if (!tiers.is_arr() || tiers.a.empty()) cfg.plugins = KAI_PLUGIN_ALL;  // the default tier list (scheduler_conf_util.go:36-61)
         else for (auto& tier : tiers.a) if (tier["plugins"].is_arr()) for (auto& pl : tier["plugins"].a) {
@@ -465,7 +467,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
                 if (args["defaultReclaimMinRuntime"].t == JV::Str && parse_duration(args["defaultReclaimMinRuntime"].s, d) && d >= 0) cfg.default_reclaim_min_runtime_ns = d;
                 cfg.reclaim_resolve_method = args["reclaimResolveMethod"].str() == "queue" ? 1 : 0;
             }
-            if (!known && n != "kubeflow" && n != "ray" && n != "snapshot") warn("plugin '" + n + "' is not on the device path (fractional GPU / DRA / pod-affinity scoring): ignored");
+            if (!known && n != "kubeflow" && n != "ray" && n != "snapshot") warn("plugin '" + n + "' is not on the path (DRA / pod-affinity scoring): ignored");
         }
     }
 
@@ -509,12 +511,17 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         {   // IsMIGEnabled (node_info.go:704-718): the label decides when present (strconv.ParseBool), else any MIG resource
             auto it = nodes[i].labels.find("node-role.kubernetes.io/mig-enabled"); bool mig;
             if (it != nodes[i].labels.end()) { const std::string& v = it->second; mig = v == "1" || v == "t" || v == "T" || v == "true" || v == "TRUE" || v == "True"; } else mig = mig_res;
-            if (mig) { f |= KAI_NODE_MIG_ENABLED; auto ms = nodes[i].labels.find("nvidia.com/mig.strategy"); if (ms != nodes[i].labels.end() && ms->second == "mixed") f |= KAI_NODE_MIG_MIXED; }
+            if (mig) { f |= KAI_NODE_MIG_ENABLED; auto ms = nodes[i].labels.find("nvidia.com/mig.strategy"); if (ms != nodes[i].labels.end() && ms->second == "mixed") f |= KAI_NODE_MIG_MIXED; if (ms != nodes[i].labels.end() && ms->second == "single") f |= KAI_NODE_MIG_SINGLE; }
         }
         if (nodes[i].labels.count("node-role.kubernetes.io/gpu-worker")) f |= KAI_NODE_GPU_WORKER;
         if (nodes[i].labels.count("node-role.kubernetes.io/cpu-worker")) f |= KAI_NODE_CPU_WORKER;
         { auto it = nodes[i].labels.find("nvidia.com/gpu.count"); if (it != nodes[i].labels.end()) { char* e = nullptr; long v = strtol(it->second.c_str(), &e, 10); if (!it->second.empty() && !*e) node_gpu_count[i] = (int32_t)v; } }  // node_info.go:619-640
         node_flags[i] = f;
+        {   // getNodeGpuMemory (node_info.go:673-687): label nvidia.com/gpu.memory in MiB (bytes when >= 1 TiB-in-MiB: gpu-feature-discovery issue 26), floored to a multiple of 100; 100 when absent
+            int64_t mem = 100; auto it = nodes[i].labels.find("nvidia.com/gpu.memory");
+            if (it != nodes[i].labels.end() && !it->second.empty()) { char* e = nullptr; long long v = strtoll(it->second.c_str(), &e, 10); if (!*e) { if (v >= 1048576) v /= 1048576; mem = v - v % 100; } }
+            node_gpu_memory.push_back(mem);
+        }
     }
     if (raw["resourceSlices"].is_arr() && !raw["resourceSlices"].a.empty()) warn("resourceSlices present: DRA GPUs are not counted (KAI_NODE_HAS_DRA_GPUS is never set by the ingest)");
 
@@ -531,7 +538,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     std::set<std::string> config_maps; if (raw["configMaps"].is_arr()) for (auto& cm : raw["configMaps"].a) config_maps.insert(cm["metadata"]["namespace"].str() + "/" + cm["metadata"]["name"].str());
 
     // ---------------------------------------------------------------- pods (pod_info.go:172-214, 365-445)
-    struct PodRec { const JV* pod; std::string key, uid, group, subgroup, class_sig, sched_sig; Req req; int32_t status, node, nominated; uint32_t flags; int32_t task_prio; int64_t created; bool unschedulable, placed_anti_affinity; int job = -1, podset = -1; };
+    struct PodRec { const JV* pod; std::string key, uid, group, subgroup, class_sig, sched_sig; Req req; int32_t status, node, nominated; uint32_t flags; int32_t task_prio; int64_t created; bool unschedulable, placed_anti_affinity; int job = -1, podset = -1; double gpu_portion = 0; std::string gpu_group; };
     std::vector<PodRec> pods; std::set<std::string> extra_names;
     bool any_existing_anti_affinity = false;
     // one pod → its record; reads only what was built above (node / bind-request / config-map tables), so pods are converted in parallel
@@ -565,6 +572,12 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         // features outside the device path (SURVEY §8b fallback rule)
         const JV& ann = md["annotations"]; bool fb = r.req.mig;
         if (!ann["gpu-fraction"].str().empty() || !ann["gpu-memory"].str().empty() || !ann["gpu-fraction-num-devices"].str().empty()) fb = true;
+        {   // a fraction of ONE device (pod_info.go:472-477) is described to the ABI (v4); the pod still goes to the CPU fallback until the device models shared GPUs
+            char* e = nullptr; const std::string& fs = ann["gpu-fraction"].str(); double fv = fs.empty() ? 0.0 : strtod(fs.c_str(), &e);
+            if (!fs.empty() && !*e && fv > 0 && fv < 1 && ann["gpu-memory"].str().empty() && ann["gpu-fraction-num-devices"].str().empty()) {
+                r.gpu_portion = fv; r.req.gpu = fv; r.gpu_group = md["labels"]["runai-gpu-group"].str();  // common/resources/gpu_sharing.go:87-100
+            }
+        }
         if (spec["resourceClaims"].is_arr() && !spec["resourceClaims"].a.empty()) fb = true;
         if (spec["affinity"]["podAffinity"].is_obj() || spec["affinity"]["podAntiAffinity"].is_obj()) { fb = true; if (spec["affinity"]["podAntiAffinity"]["requiredDuringSchedulingIgnoredDuringExecution"].is_arr() && r.node >= 0) r.placed_anti_affinity = true; }
         if (spec["volumes"].is_arr()) for (auto& v : spec["volumes"].a) if (v["persistentVolumeClaim"].is_obj() || v["ephemeral"].is_obj()) fb = true;
@@ -812,13 +825,20 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     lap("signatures");
     // ---------------------------------------------------------------- pods in their final order: pods of a job contiguous, pods of no job last
     pod_req.assign((size_t)R * P, 0.0); pod_job.resize(P); pod_podset.resize(P); pod_status.resize(P); pod_node.resize(P); pod_flags.resize(P); pod_task_priority.resize(P); pod_created.resize(P); pod_class.resize(P); pod_nominated.resize(P);
-    std::vector<std::string> uids(P);
+    std::vector<std::string> uids(P); std::map<std::string, int> gpu_group_ids;
     for (int k = 0; k < P; k++) {
         const PodRec& r = pods[pod_order[k]];
         pod_req[(size_t)KAI_RES_CPU * P + k] = r.req.cpu; pod_req[(size_t)KAI_RES_MEM * P + k] = r.req.mem; pod_req[(size_t)KAI_RES_GPU * P + k] = r.req.gpu; pod_req[(size_t)KAI_RES_PODS * P + k] = 1.0;
         for (int c = 4; c < R; c++) { auto it = r.req.scalars.find(names[KAI_NAME_RESOURCE][c]); if (it != r.req.scalars.end()) pod_req[(size_t)c * P + k] = (double)it->second; }
         pod_job[k] = r.job; pod_podset[k] = r.podset; pod_status[k] = r.status; pod_node[k] = r.node; pod_flags[k] = r.flags; pod_task_priority[k] = r.task_prio; pod_created[k] = r.created;
         pod_class[k] = pclass_of[pod_order[k]]; pod_nominated[k] = r.nominated; uids[k] = r.uid; names[KAI_NAME_POD].push_back(r.key);
+        {   // shared-GPU group id: the numeric name itself, or 2^20 + an interned index for any other name (a UUID)
+            int32_t gid = -1;
+            if (r.gpu_portion > 0) { any_fraction = true; if (!r.gpu_group.empty() && (r.status & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) {
+                char* e = nullptr; long v = strtol(r.gpu_group.c_str(), &e, 10);
+                if (!*e && v >= 0 && v < (1 << 20)) gid = (int32_t)v; else gid = (1 << 20) + (int32_t)gpu_group_ids.emplace(r.gpu_group, (int)gpu_group_ids.size()).first->second; } }
+            pod_gpu_portion.push_back(r.gpu_portion); pod_gpu_group.push_back(gid);
+        }
         { const JV& md = (*r.pod)["metadata"]; pod_ns.push_back(md["namespace"].str()); pod_name.push_back(md["name"].str()); pod_uid.push_back(md["uid"].str()); pod_gpus.push_back(r.req.gpu); }
     }
     // ranks: the reference's tie-breaks are string compares (framework/session.go:480-485 node name; session_plugins.go:227-260 UID)
@@ -848,6 +868,8 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     s.n_topologies = T; s.topo_level_off = ptr(topo_level_off); s.n_topo_levels = TL; s.node_domain = ptr(node_domain); s.n_domains = D; s.domain_level = ptr(domain_level); s.domain_parent = ptr(domain_parent); s.domain_id_rank = ptr(domain_id_rank);
     s.n_groups = G; s.group_job = ptr(group_job); s.group_parent = ptr(group_parent); s.group_name_rank = ptr(group_name_rank); s.group_topology = ptr(group_topology); s.group_required_level = ptr(group_req); s.group_preferred_level = ptr(group_pref);
     s.job_root_group = ptr(job_root_group); s.podset_group = ptr(podset_group); s.podset_topology = ptr(podset_topology); s.podset_required_level = ptr(podset_req); s.podset_preferred_level = ptr(podset_pref);
+    if (any_fraction) { s.pod_gpu_portion = ptr(pod_gpu_portion); s.pod_gpu_group = ptr(pod_gpu_group); }
+    s.node_gpu_memory = ptr(node_gpu_memory);
     s.job_signature = ptr(job_signature); s.job_last_start_ns = ptr(job_last_start); s.queue_preempt_min_runtime_ns = ptr(q_preempt_mrt); s.queue_reclaim_min_runtime_ns = ptr(q_reclaim_mrt);
     return KAI_OK;
 }

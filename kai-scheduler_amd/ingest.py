@@ -122,6 +122,10 @@ def _from_handle(lib, h) -> Ingested:
             a[name] = _copy(getattr(s, name), n, dict(abi._SPEC_OPT)[name])
     a["job_signature"] = _copy(s.job_signature, J, np.int64); a["job_last_start_ns"] = _copy(s.job_last_start_ns, J, np.int64)
     a["queue_preempt_min_runtime_ns"] = _copy(s.queue_preempt_min_runtime_ns, Q, np.int64); a["queue_reclaim_min_runtime_ns"] = _copy(s.queue_reclaim_min_runtime_ns, Q, np.int64)
+    if s.pod_gpu_portion:
+        a["pod_gpu_portion"] = _copy(s.pod_gpu_portion, P, np.float64); a["pod_gpu_group"] = _copy(s.pod_gpu_group, P, np.int32)
+    if s.node_gpu_memory and N:
+        a["node_gpu_memory"] = _copy(s.node_gpu_memory, N, np.int64)
     snap = abi.Snapshot(n_res=R, arrays=a)
     names = lambda kind, n: [lib.kai_ingest_name(h, kind, i).decode() for i in range(n)]
     snap.node_names, snap.pod_names, snap.job_names, snap.queue_names, snap.podset_names = names(0, N), names(1, P), names(2, J), names(3, Q), names(4, S)

@@ -35,6 +35,7 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
     for (int i = 0; i < N; i++) {  // api/node_info/node_info.go:107-155 NewNodeInfo
         NodeInfo& n = nodes[i]; n.idx = i; n.nameRank = s->node_name_rank[i]; n.flags = s->node_flags[i];
         n.gpuCountLabel = s->node_gpu_count ? s->node_gpu_count[i] : -1; n.nodeClass = s->node_class ? s->node_class[i] : 0;
+        n.MemoryOfEveryGpuOnNode = s->node_gpu_memory ? s->node_gpu_memory[i] : 100;
         n.Allocatable = toResource(s->node_allocatable, N, i); n.Idle = n.Allocatable;
     }
     for (int q = 0; q < Q; q++) {
@@ -110,6 +111,12 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
         t.resReq.milliCpu = s->pod_req[size_t(KAI_RES_CPU) * P + p]; t.resReq.memory = s->pod_req[size_t(KAI_RES_MEM) * P + p];
         double g = s->pod_req[size_t(KAI_RES_GPU) * P + p];
         if (g >= 1) { t.resReq.count = int64_t(g); t.resReq.portion = 1; }  // resource_requirment.go:52-58
+        const double frac = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0;
+        if (frac > 0 && frac < 1) {  // pod_info.go:472-477: NewGpuResourceRequirementWithGpus(fraction, 0) → one device, that portion
+            t.resReq.count = 1; t.resReq.portion = frac; t.isFractionRequest = true; hasFractions = true;
+            const int grp = s->pod_gpu_group ? s->pod_gpu_group[p] : -1;
+            if (grp >= 0) { t.gpuGroups.push_back(grp); if (grp >= nextNewGpuGroup) nextNewGpuGroup = grp + 1; }
+        }
         for (int k = KAI_RES_PODS; k < R; k++) { double v = s->pod_req[size_t(k) * P + p]; if (v != 0) t.resReq.scalars[k] = int64_t(v); }
     }
     // jobs own their tasks (job_info.go AddTaskInfo), nodes hold the active-used ones (node_info.go:419-437 AddTasksToNode;
@@ -360,11 +367,12 @@ bool Session::IsJobOverQueueCapacity(PodGroupInfo* job, const std::vector<PodInf
     for (auto* pod : tasks) { q[2] += pod->resReq.GetGpusQuota(); q[0] += pod->resReq.milliCpu; q[1] += pod->resReq.memory; }
     return resultsOverLimit(q, job) || resultsWithNonPreemptibleOverQuota(q, job);
 }
-bool Session::IsTaskAllocationOnNodeOverCapacity(PodInfo* task, PodGroupInfo* job, NodeInfo*) {  // capacity_policy.go:51-61
+bool Session::IsTaskAllocationOnNodeOverCapacity(PodInfo* task, PodGroupInfo* job, NodeInfo* node) {  // capacity_policy.go:51-61
     if (!(cfg.plugins & KAI_PLUGIN_PROPORTION)) return false;
-    // NodeInfo.GetRequiredInitQuota (api/node_info/node_info.go:734-744): for a whole-GPU request the GPU term is
-    // ceil(portion*mem/mem*100)/100 = 1 for any count >= 1, 0 for a CPU-only request.
-    ResourceQuantities q{task->resReq.milliCpu, task->resReq.memory, task->resReq.count >= 1 ? std::ceil(task->resReq.portion * 100.0) / 100.0 : 0.0};
+    // NodeInfo.GetRequiredInitQuota (api/node_info/node_info.go:734-744): the GPU term is the request's GPU memory on this node as a fraction of
+    // a device, rounded up to 1/100 — 1 for a whole-GPU request of any count, 0 for a CPU-only one, and for a fraction
+    // ceil(int64(portion * mem) / mem * 100) / 100 (so 0.3 of a 100 MiB device counts as 0.31: 0.3 * 100 is 30.000000000000004 in float64)
+    ResourceQuantities q{task->resReq.milliCpu, task->resReq.memory, node->getGpuMemoryFractionalOnNode(node->GetResourceGpuMemory(task->resReq))};
     return resultsOverLimit(q, job) || resultsWithNonPreemptibleOverQuota(q, job);
 }
 
@@ -480,8 +488,8 @@ double Session::NodeOrderFn(PodInfo* task, NodeInfo* node) {  // session_plugins
     double score = 0;
     // nodeavailability (plugins/nodeavailability/nodeavailability.go:29-40)
     if (cfg.plugins & KAI_PLUGIN_NODEAVAILABILITY) score += node->IsTaskAllocatable(task) ? 100.0 : 0.0;
-    // gpusharingorder (plugins/gpusharingorder/gpusharingorder.go:29-44): no shared-GPU groups on the path
-    score += 0.0;
+    // gpusharingorder (plugins/gpusharingorder/gpusharingorder.go:29-44): 1000 when some used shared GPU of the node can take the task
+    if (cfg.plugins & KAI_PLUGIN_GPUSHARINGORDER) { double sc = 0.0; for (auto& kv : node->UsedSharedGPUsMemory) if (node->IsTaskFitOnGpuGroup(task->resReq, kv.first)) sc = 1000.0; score += sc; }
     // resourcetype (plugins/resourcetype/resourcetype.go:29-41)
     if (cfg.plugins & KAI_PLUGIN_RESOURCETYPE) score += (task->IsCPUOnlyRequest() && node->IsCPUOnlyNode()) ? 10.0 : 0.0;
     // nominatednode (plugins/nominatednode/nominatednode.go:29-41)
@@ -528,9 +536,14 @@ bool Session::PredicateFn(PodInfo* task, PodGroupInfo* job, NodeInfo* node) {  /
     if (!task->IsCPUOnlyRequest()) {
         if (task->resReq.GPUs() > 0 && (node->flags & KAI_NODE_HAS_DRA_GPUS)) return false;
         if ((node->flags & KAI_NODE_MIG_ENABLED) && (node->flags & KAI_NODE_MIG_MIXED)) return false;
+        if ((node->flags & KAI_NODE_MIG_ENABLED) && (node->flags & KAI_NODE_MIG_SINGLE) && !task->IsRegularGPURequest()) return false;  // :349-352
     }
-    // checkMaxPodsWithGpuGroupReservation :264-285
-    if (!(node->Idle.GetScalar(KAI_RES_PODS) + node->Releasing.GetScalar(KAI_RES_PODS) > 0)) return false;
+    // checkMaxPodsWithGpuGroupReservation :264-285: a shared-GPU task that opens a new GPU group also needs room for the reservation pod
+    {
+        double availablePods = node->Idle.GetScalar(KAI_RES_PODS) + node->Releasing.GetScalar(KAI_RES_PODS);
+        if (!task->IsSharedGPURequest()) { if (!(availablePods > 0)) return false; }
+        else if (willCreateNewGpuGroup(task, node) && availablePods < 2) return false;
+    }
     // CheckNodeConditionPredicate (scheduler_util/scheduler_utils.go:12-40)
     if (node->flags & KAI_NODE_NOT_READY) return false;
     // upstream kube-scheduler Filters, pre-evaluated per (pod class, node class)
@@ -789,7 +802,60 @@ void JobsOrderByQueues::InitializeWithJobs(const std::vector<PodGroupInfo*>& job
 // =====================================================================================================
 // actions/common/allocate.go
 // =====================================================================================================
+// ---- shared GPUs
+double Session::GpuOrderFn(PodInfo*, NodeInfo* node, int gpu) {  // session_plugins.go:405-416 over plugins/gpupack/gpupack.go:31-45 and plugins/gpuspread/gpuspread.go:31-46
+    double score = 0;
+    if (cfg.plugins & KAI_PLUGIN_GPUPACK) score += gpu == kWholeGpuIndicator ? 0.0 : node->GetUsedGpuPortion(gpu);
+    if (cfg.plugins & KAI_PLUGIN_GPUSPREAD) score += gpu == kWholeGpuIndicator ? 1.0 : 1 - node->GetUsedGpuPortion(gpu);
+    return score;
+}
+std::vector<int> Session::FittingGPUs(NodeInfo* node, PodInfo* pod) {  // session.go:163-199, 487-498
+    // filterGpusByEnoughResources ranges a Go map of groups; canonical order: ascending group id (groups of the snapshot first, then the
+    // groups of this session in creation order), then one entry per idle-or-releasing whole GPU
+    std::vector<int> filtered;
+    for (auto& kv : node->UsedSharedGPUsMemory) if (node->IsTaskFitOnGpuGroup(pod->resReq, kv.first)) filtered.push_back(kv.first);
+    if (node->Idle.gpus > 0 || node->Releasing.gpus > 0) for (int i = 0, n = int(node->Idle.gpus) + int(node->Releasing.gpus); i < n; i++) filtered.push_back(kWholeGpuIndicator);
+    std::map<double, std::vector<int>, std::greater<double>> byScore;  // sortGPUs: scores descending, each bucket in the order it was filled
+    for (int g : filtered) byScore[GpuOrderFn(pod, node, g)].push_back(g);
+    std::vector<int> sorted; for (auto& kv : byScore) for (int g : kv.second) sorted.push_back(g);
+    return sorted;
+}
+Session::NodeGpuForSharing Session::GetNodePreferableGpuForSharing(const std::vector<int>& fittingGPUs, NodeInfo* node, PodInfo* pod, bool isPipelineOnly) {  // gpuSharing.go:39-71
+    NodeGpuForSharing r;
+    const int64_t deviceCounts = pod->resReq.count;
+    for (int gpu : fittingGPUs) {
+        if (gpu == kWholeGpuIndicator) {  // findGpuForSharingOnNode :73-83: a new group; releasing unless the task is allocatable now
+            bool isReleasing = true;
+            if (!isPipelineOnly && node->IsTaskAllocatable(pod)) isReleasing = false;
+            r.IsReleasing = r.IsReleasing || isReleasing; r.Groups.push_back(nextNewGpuGroup++);
+        } else {
+            r.IsReleasing = r.IsReleasing || !node->EnoughIdleResourcesOnGpu(pod->resReq, gpu) || !node->IsTaskAllocatable(pod);
+            r.Groups.push_back(gpu);
+        }
+        if (int64_t(r.Groups.size()) == deviceCounts) { r.ok = true; return r; }
+    }
+    return NodeGpuForSharing{};
+}
+bool Session::AllocateFractionalGPUTaskToNode(Statement& stmt, PodInfo* pod, NodeInfo* node, bool isPipelineOnly) {  // gpuSharing.go:20-37, 85-103
+    NodeGpuForSharing g = GetNodePreferableGpuForSharing(FittingGPUs(node, pod), node, pod, isPipelineOnly);
+    if (!g.ok) return false;
+    pod->gpuGroups = g.Groups;
+    isPipelineOnly = isPipelineOnly || g.IsReleasing;
+    bool success = isPipelineOnly ? stmt.Pipeline(pod, node->idx, !isPipelineOnly) : stmt.Allocate(pod, node->idx);
+    if (!success) pod->gpuGroups.clear();
+    return success;
+}
+bool Session::willCreateNewGpuGroup(PodInfo* task, NodeInfo* node) {  // plugins/predicates/predicates.go:286-330: a UUID, i.e. non-numeric, group is new
+    auto containsNew = [](const std::vector<int>& gs) { for (int g : gs) if (g >= kNewGpuGroup) return true; return false; };
+    std::vector<int> fitting = FittingGPUs(node, task);
+    NodeGpuForSharing now = GetNodePreferableGpuForSharing(fitting, node, task, false);
+    if (now.ok && !now.IsReleasing) return containsNew(now.Groups);
+    NodeGpuForSharing later = GetNodePreferableGpuForSharing(fitting, node, task, true);
+    if (later.ok) return containsNew(later.Groups);
+    return true;
+}
 bool Session::allocateTaskToNode(Statement& stmt, PodInfo* task, NodeInfo* node, bool isPipelineOnly) {  // :165-174
+    if (task->isFractionRequest) return AllocateFractionalGPUTaskToNode(stmt, task, node, isPipelineOnly);
     bool taskAllocatable = node->IsTaskAllocatable(task);
     if (!isPipelineOnly && taskAllocatable) return stmt.Allocate(task, node->idx);
     return stmt.Pipeline(task, node->idx, !isPipelineOnly);
@@ -1067,6 +1133,7 @@ namespace orc { Session::~Session() = default; }
 // =====================================================================================================
 // C entry points (ctypes)
 // =====================================================================================================
+static std::vector<int32_t> g_last_gpu_groups;  // of the last kai_oracle_run on this thread of the test process
 extern "C" {
 
 static void fill_shares(const orc::Session& ssn, kai_queue_share* out) {
@@ -1106,6 +1173,7 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
             case KAI_ACTION_ALLOCATE: ssn.executeAllocate(); break;
             case KAI_ACTION_CONSOLIDATION: case KAI_ACTION_RECLAIM: case KAI_ACTION_PREEMPT:
                 if (cfg->use_scheduling_signatures && !ssn.hasSignatures) return KAI_ERR_UNSUPPORTED;  // same rule as libkai_core
+                if (ssn.hasFractions) return KAI_ERR_UNSUPPORTED;  // shared GPUs are restated for the allocate action only so far (GetTasksToEvict, idle-GPU filter, moving a task between GPUs: not yet)
                 ssn.executeVictimAction(actions[i]); break;
             default: return KAI_ERR_UNSUPPORTED;
         }
@@ -1116,6 +1184,8 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
     if (ops_out) { if (int64_t(ssn.committed.size()) > ops_cap) return KAI_ERR_CAPACITY; std::memcpy(ops_out, ssn.committed.data(), ssn.committed.size() * sizeof(kai_op)); }
     if (pod_status_out) for (size_t p = 0; p < ssn.pods.size(); p++) pod_status_out[p] = ssn.pods[p].status;
     if (pod_node_out) for (size_t p = 0; p < ssn.pods.size(); p++) pod_node_out[p] = ssn.pods[p].node;
+    g_last_gpu_groups.assign(ssn.pods.size(), -1);  // PodInfo.GPUGroups of the active fraction pods (what BindRequest.SelectedGPUGroups would carry)
+    for (size_t p = 0; p < ssn.pods.size(); p++) if (orc::IsActiveUsedStatus(ssn.pods[p].status) && ssn.pods[p].receivedFraction && !ssn.pods[p].gpuGroups.empty()) g_last_gpu_groups[p] = ssn.pods[p].gpuGroups[0];
     if (shares_final) fill_shares(ssn, shares_final);
     if (nodes_out) for (size_t n = 0; n < ssn.nodes.size(); n++) for (int r = 0; r < ssn.R; r++) {
         nodes_out[n].idle[r] = ssn.nodes[n].Idle.Get(r); nodes_out[n].releasing[r] = ssn.nodes[n].Releasing.Get(r); nodes_out[n].used[r] = ssn.nodes[n].Used.Get(r);
@@ -1124,6 +1194,9 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
                  stats->jobs_attempted = ssn.stats.jobsAttempted; stats->jobs_committed = ssn.stats.jobsCommitted; stats->rollbacks = ssn.stats.rollbacks; }
     return KAI_OK;
 }
+
+// shared-GPU group of every pod after the last kai_oracle_run: id < 2^20 = a group of the snapshot, >= 2^20 = created by the run, -1 = none
+int kai_oracle_last_gpu_groups(int32_t* out, int cap) { int n = int(g_last_gpu_groups.size()); for (int i = 0; i < n && i < cap; i++) out[i] = g_last_gpu_groups[i]; return n; }
 
 // Session.OrderedNodesByTask + FittingNode for ONE task over a node subset of a freshly opened session (framework/session.go:201-264):
 // what kai_best_node answers.  nodeset_bitmap may be NULL (all nodes); bit n of word n/32 = caller's node index n.

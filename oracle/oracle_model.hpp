@@ -15,6 +15,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -114,6 +115,14 @@ struct PodInfo {
     int nominatedNode = -1;
     ResourceRequirements resReq;
     ResourceRequirements accepted;  // AcceptedResource, set by NodeInfo.setAcceptedResources
+    // shared GPUs (ABI v4): a fraction of one device (pod_info.go:472-477 RequestTypeFraction); the groups it holds (PodInfo.GPUGroups; ids are
+    // unique per node, ids >= kNewGpuGroup were created in this session — the reference draws a UUID there, gpu_sharing/gpuSharing.go:94)
+    bool isFractionRequest = false;   // ResourceRequestType == RequestTypeFraction
+    bool receivedFraction = false;    // ResourceReceivedType == ReceivedTypeFraction (node_info.go:755-758)
+    std::vector<int> gpuGroups;
+    bool IsSharedGPURequest() const { return isFractionRequest; }       // pod_info.go:326-328 (no gpu-memory requests on the path)
+    bool IsSharedGPUAllocation() const { return receivedFraction; }    // :330-332
+    bool IsRegularGPURequest() const { return !isFractionRequest; }    // :322-324
     bool IsCPUOnlyRequest() const { return !(resReq.GPUs() > 0); }  // pod_info.go:340-347
     bool ShouldAllocate(bool isRealAllocation) const {               // pod_info.go:518-521
         return status == Pending || (!isRealAllocation && status == Releasing && isVirtualStatus);
@@ -218,17 +227,56 @@ struct PodGroupInfo {
 };
 
 // ---------------------------------------------------------------- api/node_info/node_info.go:68-105
+constexpr int kNewGpuGroup = 1 << 20;  // group ids from here on were created by this session (a UUID in the reference); below: groups of the snapshot ("0", "1", …)
+constexpr int kWholeGpuIndicator = -1; // pod_info.WholeGpuIndicator
+
 struct NodeInfo {
     int idx = -1; uint32_t nameRank = 0; uint32_t flags = 0; int gpuCountLabel = -1; int nodeClass = 0;
     Resource Idle, Used, Releasing, Allocatable;
-    struct OnNode { int status; Resource tracked; };
-    std::map<int, OnNode> podInfos;  // the node's own copy of the task (status at add time)
+    int64_t MemoryOfEveryGpuOnNode = 100;  // node_info.go:48 DefaultGpuMemory
+    // GpuSharingNodeInfo (api/node_info/gpu_sharing_node_info.go:17-27), keyed by group id
+    std::set<int> ReleasingSharedGPUs;
+    std::map<int, int64_t> UsedSharedGPUsMemory, ReleasingSharedGPUsMemory, AllocatedSharedGPUsMemory;
+    struct OnNode { int status; Resource tracked; bool shared; std::vector<int> groups; int64_t gpuMemory; };
+    std::map<int, OnNode> podInfos;  // the node's own copy of the task (status, groups and amounts at add time)
     double NonAllocatedResource(int r) const { return Idle.Get(r) + Releasing.Get(r); }  // node_info.go:164-166
     Resource NonAllocatedResources() const { Resource x; x.Add(Idle); x.Add(Releasing); return x; }  // :157-162
     bool IsCPUOnlyNode() const { if (flags & KAI_NODE_MIG_ENABLED) return false; return Allocatable.gpus <= 0 && !(flags & KAI_NODE_HAS_DRA_GPUS); }  // :697-702
     int64_t GetNumberOfGPUsInNode() const { return gpuCountLabel >= 0 ? gpuCountLabel : int64_t(Allocatable.gpus); }  // :630-637
-    bool isTaskAllocatableOnNonAllocatedResources(const PodInfo* task, const Resource& avail) const {  // :361-382 (regular GPU request)
-        return task->resReq.LessEqualResource(avail);  // isValidGpuPortion is vacuous for whole GPUs (:668-671)
+    // ---- shared-GPU helpers (gpu_sharing_node_info.go)
+    static int64_t get(const std::map<int, int64_t>& m, int g) { auto it = m.find(g); return it == m.end() ? 0 : it->second; }
+    int64_t GetResourceGpuMemory(const ResourceRequirements& r) const { return int64_t(r.portion * double(MemoryOfEveryGpuOnNode)); }  // node_info.go:653-659 (no gpu-memory requests)
+    double getGpuMemoryFractionalOnNode(int64_t memory) const { return std::ceil(double(memory) / double(MemoryOfEveryGpuOnNode) * 100) / 100; }  // :329-332
+    int getNumberOfUsedSharedGPUs() const { int n = 0; for (auto& kv : UsedSharedGPUsMemory) if (kv.second > 0) n++; return n; }  // :265-273
+    int getNumberOfUsedGPUs() const { return int(Used.gpus) + getNumberOfUsedSharedGPUs(); }                                     // :275-277
+    bool isSharedGpuMarkedAsReleasing(int g) const { return ReleasingSharedGPUs.count(g) != 0; }
+    bool isGpuReleasingFromSharedTasks(int g) const {  // :253-263
+        int64_t used = get(UsedSharedGPUsMemory, g); if (used == 0) return false;
+        return ReleasingSharedGPUsMemory.count(g) && get(ReleasingSharedGPUsMemory, g) == used;
+    }
+    bool enoughResourcesOnGpu(const ResourceRequirements& r, int g) const {  // :365-371
+        return MemoryOfEveryGpuOnNode - get(AllocatedSharedGPUsMemory, g) + get(ReleasingSharedGPUsMemory, g) - GetResourceGpuMemory(r) >= 0;
+    }
+    bool isAllGpuReleased(int g) const { return get(AllocatedSharedGPUsMemory, g) == get(ReleasingSharedGPUsMemory, g); }  // :373-375
+    bool IsTaskFitOnGpuGroup(const ResourceRequirements& r, int g) const {  // :350-354
+        return get(UsedSharedGPUsMemory, g) != 0 && enoughResourcesOnGpu(r, g) && !isAllGpuReleased(g);
+    }
+    bool EnoughIdleResourcesOnGpu(const ResourceRequirements& r, int g) const {  // :356-363
+        if (!AllocatedSharedGPUsMemory.count(g)) return false;
+        return MemoryOfEveryGpuOnNode - get(AllocatedSharedGPUsMemory, g) - GetResourceGpuMemory(r) >= 0;
+    }
+    double GetUsedGpuPortion(int g) const { return double(get(UsedSharedGPUsMemory, g)) / double(MemoryOfEveryGpuOnNode); }  // :377-383
+    int64_t fractionTaskGpusAllocatableDeviceCount(const PodInfo* pod) const {  // :334-348
+        int64_t n = 0;
+        for (auto& kv : UsedSharedGPUsMemory) if (IsTaskFitOnGpuGroup(pod->resReq, kv.first)) { n++; if (n >= pod->resReq.count) return n; }
+        return n;
+    }
+    bool isTaskAllocatableOnNonAllocatedResources(const PodInfo* task, const Resource& avail) const {  // :361-382
+        if (task->IsRegularGPURequest()) return task->resReq.LessEqualResource(avail);
+        if (!static_cast<const BaseResource&>(task->resReq).LessEqual(avail)) return false;
+        // isValidGpuPortion (:668-671): a portion of at most one device always is
+        int64_t wholeGpus = int64_t(std::floor(avail.gpus));
+        return wholeGpus + fractionTaskGpusAllocatableDeviceCount(task) >= task->resReq.count;
     }
     bool IsTaskAllocatable(const PodInfo* task) const {  // :168-188 (no storage claims on the path)
         if (task->resReq.IsEmpty()) return true;
@@ -237,7 +285,11 @@ struct NodeInfo {
     bool IsTaskAllocatableOnReleasingOrIdle(const PodInfo* task) const {  // :190-206
         return isTaskAllocatableOnNonAllocatedResources(task, NonAllocatedResources());
     }
-    void setAcceptedResources(PodInfo* pi) const { if (!IsActiveUsedStatus(pi->status)) return; pi->accepted = pi->resReq; }  // :746-766
+    void setAcceptedResources(PodInfo* pi) const {  // :746-766
+        if (!IsActiveUsedStatus(pi->status)) return;
+        pi->accepted = pi->resReq;
+        pi->receivedFraction = pi->isFractionRequest;  // ReceivedTypeFraction for a fraction candidate, ReceivedTypeRegular otherwise
+    }
     void addTaskResources(const Resource& r, int status) {  // :457-493
         Used.Add(r);
         switch (status) {
@@ -254,18 +306,68 @@ struct NodeInfo {
             default: Idle.Add(r);
         }
     }
+    void addSharedTaskResourcesPerPodGroup(int status, int64_t mem, int g) {  // gpu_sharing_node_info.go:83-136
+        UsedSharedGPUsMemory[g] += mem;
+        switch (status) {
+            case KAI_POD_RELEASING:
+                ReleasingSharedGPUsMemory[g] += mem; AllocatedSharedGPUsMemory[g] += mem;
+                if (UsedSharedGPUsMemory[g] == ReleasingSharedGPUsMemory[g]) {
+                    if (!isSharedGpuMarkedAsReleasing(g)) { Releasing.gpus += 1; ReleasingSharedGPUs.insert(g); }
+                    if (int(GetNumberOfGPUsInNode()) < int(Idle.gpus) + getNumberOfUsedGPUs()) Idle.gpus -= 1;
+                }
+                break;
+            case KAI_POD_PIPELINED:
+                ReleasingSharedGPUsMemory[g] -= mem;
+                if (UsedSharedGPUsMemory[g] - mem == ReleasingSharedGPUsMemory[g] + mem) Releasing.gpus -= 1;
+                break;
+            default:
+                AllocatedSharedGPUsMemory[g] += mem;
+                if (UsedSharedGPUsMemory[g] <= mem) { if (int(GetNumberOfGPUsInNode()) < int(Idle.gpus) + getNumberOfUsedGPUs()) Idle.gpus -= 1; }
+                if (isSharedGpuMarkedAsReleasing(g)) { Releasing.gpus -= 1; ReleasingSharedGPUs.erase(g); }
+        }
+    }
+    bool isPipelinedToReleasingGpu(int64_t mem, int g) const {  // :237-245
+        int64_t usedBefore = get(UsedSharedGPUsMemory, g) + mem, releasingBefore = get(ReleasingSharedGPUsMemory, g) - mem;
+        bool usedOriginally0 = get(UsedSharedGPUsMemory, g) == 0, releasingOriginally0 = get(ReleasingSharedGPUsMemory, g) == 0;
+        return usedBefore == releasingBefore || (usedOriginally0 && releasingOriginally0);
+    }
+    void removeSharedTaskResourcesPerPodGroup(int status, int64_t mem, int g) {  // :153-235
+        UsedSharedGPUsMemory[g] -= mem;
+        switch (status) {
+            case KAI_POD_RELEASING:
+                ReleasingSharedGPUsMemory[g] -= mem; AllocatedSharedGPUsMemory[g] -= mem;
+                if (UsedSharedGPUsMemory[g] <= 0) {
+                    if (int(GetNumberOfGPUsInNode()) >= int(Idle.gpus) + getNumberOfUsedGPUs()) Idle.gpus += 1;
+                    if (isSharedGpuMarkedAsReleasing(g)) { Releasing.gpus -= 1; ReleasingSharedGPUs.erase(g); }
+                }
+                break;
+            case KAI_POD_PIPELINED:
+                ReleasingSharedGPUsMemory[g] += mem;
+                if (isPipelinedToReleasingGpu(mem, g)) Releasing.gpus += 1;
+                break;
+            default:
+                AllocatedSharedGPUsMemory[g] -= mem;
+                if (UsedSharedGPUsMemory[g] <= 0) { if (int(GetNumberOfGPUsInNode()) >= int(Idle.gpus) + getNumberOfUsedGPUs()) Idle.gpus += 1; }
+                if (isGpuReleasingFromSharedTasks(g) && !isSharedGpuMarkedAsReleasing(g)) { Releasing.gpus += 1; ReleasingSharedGPUs.insert(g); }
+        }
+    }
     bool AddTask(PodInfo* task) {  // :384-417
         setAcceptedResources(task);
         if (podInfos.count(task->idx)) return false;  // "task already on node"
-        Resource r = task->accepted.AsResource();     // getAcceptedTaskResourceWithoutSharedGPU for a regular task
-        podInfos[task->idx] = OnNode{task->status, r};
+        Resource r = task->accepted.AsResource();     // getAcceptedTaskResourceWithoutSharedGPU (gpu_sharing_node_info.go:52-66): no GPUs for a shared allocation
+        const bool shared = task->IsSharedGPUAllocation();
+        if (shared) r.gpus = 0;
+        OnNode c{task->status, r, shared, task->gpuGroups, shared ? GetResourceGpuMemory(task->resReq) : 0};
+        podInfos[task->idx] = c;
         addTaskResources(r, task->status);
+        if (shared) for (int g : c.groups) addSharedTaskResourcesPerPodGroup(c.status, c.gpuMemory, g);  // addSharedTaskResources :68-81
         return true;
     }
-    bool RemoveTask(PodInfo* ti) {  // :495-513 — uses the node's copy, i.e. the status at add time
+    bool RemoveTask(PodInfo* ti) {  // :495-513 — uses the node's copy, i.e. the status and groups at add time
         auto it = podInfos.find(ti->idx); if (it == podInfos.end()) return false;
         OnNode c = it->second; podInfos.erase(it);
         removeTaskResources(c.tracked, c.status);
+        if (c.shared) for (int g : c.groups) removeSharedTaskResourcesPerPodGroup(c.status, c.gpuMemory, g);  // removeSharedTaskResources :138-151
         return true;
     }
     bool UpdateTask(PodInfo* ti) { if (!RemoveTask(ti)) return false; return AddTask(ti); }  // :571-576

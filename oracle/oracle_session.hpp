@@ -121,6 +121,15 @@ struct Session {
     double topologyNodeScore(PodInfo* task, NodeInfo* node, bool& err);
     bool allocateTask(Statement& stmt, const std::vector<NodeInfo*>& nodes, PodInfo* task, bool isPipelineOnly);
     bool allocateTaskToNode(Statement& stmt, PodInfo* task, NodeInfo* node, bool isPipelineOnly);
+    // shared GPUs: framework/session.go:163-199, gpu_sharing/gpuSharing.go, plugins/{gpupack,gpuspread,gpusharingorder}
+    struct NodeGpuForSharing { std::vector<int> Groups; bool IsReleasing = false; bool ok = false; };
+    int nextNewGpuGroup = kNewGpuGroup;  // uuid.NewUUID() of findGpuForSharingOnNode
+    bool hasFractions = false;
+    double GpuOrderFn(PodInfo* task, NodeInfo* node, int gpu);
+    std::vector<int> FittingGPUs(NodeInfo* node, PodInfo* pod);
+    NodeGpuForSharing GetNodePreferableGpuForSharing(const std::vector<int>& fittingGPUs, NodeInfo* node, PodInfo* pod, bool isPipelineOnly);
+    bool AllocateFractionalGPUTaskToNode(Statement& stmt, PodInfo* pod, NodeInfo* node, bool isPipelineOnly);
+    bool willCreateNewGpuGroup(PodInfo* task, NodeInfo* node);
 
     // ---- actions
     void executeAllocate();  // actions/allocate/allocate.go:46-77

@@ -110,6 +110,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
                                kai_queue_share* shares_open, kai_queue_share* shares_final, kai_node_state* nodes_out,
                                kai_action_stats* stats, double* elapsed_ms_out) {
     if (!cfg || !s || s->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
+    if (s->pod_gpu_portion) for (int p = 0; p < s->n_pods; p++) if (s->pod_gpu_portion[p] > 0) return KAI_ERR_UNSUPPORTED;  // shared GPUs: oracle only for now
     const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
     std::vector<std::vector<char>> pool;
     HostPrep prep; std::string err;

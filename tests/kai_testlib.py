@@ -79,7 +79,10 @@ class Oracle:
                                 sh_open, sh_fin, nodes, C.byref(stats), C.byref(ms))
         if rc != 0:
             raise RuntimeError(f"oracle rc={rc}")
-        return Result(ops=[(o.kind, o.pod, o.node, o.job) for o in ops[: n_ops.value]], pod_status=status, pod_node=node,
+        groups = np.full(P, -1, np.int32)
+        if hasattr(lib, "kai_oracle_last_gpu_groups") and cls is Oracle:
+            lib.kai_oracle_last_gpu_groups(groups.ctypes.data_as(C.POINTER(C.c_int32)), P)
+        return Result(gpu_groups=groups, ops=[(o.kind, o.pod, o.node, o.job) for o in ops[: n_ops.value]], pod_status=status, pod_node=node,
                       shares_open=shares_to_np(sh_open, Q), shares_final=shares_to_np(sh_fin, Q), nodes=nodes_to_np(nodes, N, snap.n_res),
                       stats=stats, elapsed_ms=ms.value)
 
@@ -151,8 +154,9 @@ def _expand_nodes(nodes):
     return out
 
 
-def case_to_snapshot(case, actions=("allocate",)):
-    """→ (Snapshot, KaiConfig, meta).  Raises Unsupported for features outside the built path."""
+def case_to_snapshot(case, actions=("allocate",), fractions=False):
+    """→ (Snapshot, KaiConfig, meta).  Raises Unsupported for features outside the built path.  `fractions`: accept tasks that ask for a fraction of
+    one GPU (ABI v4 arrays) — restated by the oracle for the allocate action only, so only its golden test asks for them."""
     S = abi.POD_STATUS
     case = dict(case); case["Nodes"] = _expand_nodes(case.get("Nodes") or {})
     topologies = case.get("Topologies") or []
@@ -253,6 +257,8 @@ def case_to_snapshot(case, actions=("allocate",)):
             nflags[i] |= abi.NODE_MIG_ENABLED
             if mig == "mixed":
                 nflags[i] |= abi.NODE_MIG_MIXED
+            if mig == "single":
+                nflags[i] |= abi.NODE_MIG_SINGLE
         if nd.get("GpuMemorySynced") is not None or nd.get("GPUMemory"):
             pass  # only read by gpu-memory requests (unsupported here)
 
@@ -301,6 +307,7 @@ def case_to_snapshot(case, actions=("allocate",)):
     jobs = [j for _, j in jobs]
     J = len(jobs)
     pod_names, pod_job, pod_podset, pod_status, pod_node, pod_flags, pod_prio, pod_aff = [], [], [], [], [], [], [], []
+    pod_gpu_portion, pod_gpu_group = [], []
     req_rows = []
     podset_job, podset_min, podset_names_l, job_first_podset, job_n_podsets, job_first_pod, job_n_pods = [], [], [], [], [], [], []
     job_names, job_queue, job_priority, job_preempt, job_created = [], [], [], [], []
@@ -312,8 +319,11 @@ def case_to_snapshot(case, actions=("allocate",)):
         if job.get("RequiredMultiFractionDevicesPerTask") is not None:
             raise Unsupported("multi-fraction")
         g = float(job.get("RequiredGPUsPerTask", 0))
-        if g != int(g):
-            raise Unsupported("fractional gpu")
+        frac = 0.0 < g < 1.0  # a fraction of one device (jobs.go:278-283 → annotation gpu-fraction)
+        if g != int(g) and not frac:
+            raise Unsupported("fractional gpu above one device")
+        if frac and not fractions:
+            raise Unsupported("fractional gpu (oracle only, allocate action)")
         job_names.append(job["Name"])
         job_queue.append(qidx.get(job.get("QueueName", ""), -1))
         if job_queue[-1] >= 0:  # input_jobs.go:53-59: the queue's parent must exist too (already pruned above)
@@ -357,8 +367,11 @@ def case_to_snapshot(case, actions=("allocate",)):
                 raise Unsupported("inter-pod affinity")
             if t.get("ResourceClaimNames") or t.get("ResourceClaimTemplates"):
                 raise Unsupported("DRA")
-            if t.get("GPUGroups"):
-                raise Unsupported("shared gpu groups")
+            groups = t.get("GPUGroups") or []
+            if len(groups) > 1 or (groups and not frac) or any(not str(x).lstrip("-").isdigit() for x in groups):
+                raise Unsupported("shared gpu groups beyond one numeric group of a fraction task")
+            pod_gpu_portion.append(g if frac else 0.0)
+            pod_gpu_group.append(int(groups[0]) if groups and t.get("State", "Pending") != "Pending" else -1)
             pod_names.append(f"{job['Name']}-{ti}")
             pod_job.append(ji)
             sg = t.get("SubGroupName") or "default"
@@ -380,7 +393,7 @@ def case_to_snapshot(case, actions=("allocate",)):
             else:
                 cpu = _milli(job["RequiredCPUsPerTask"]) if job.get("RequiredCPUsPerTask", 0) != 0 else 1000.0
                 mem = _value(job["RequiredMemoryPerTask"]) if job.get("RequiredMemoryPerTask", 0) != 0 else 1e9
-                gp = float(int(g))
+                gp = g if frac else float(int(g))
             if t.get("RequiredGPUs") is not None:
                 gp = float(int(t["RequiredGPUs"]))  # jobs.go:309-312
             req_rows.append((cpu, mem, gp, 1.0))
@@ -423,6 +436,12 @@ def case_to_snapshot(case, actions=("allocate",)):
     a["pod_flags"] = np.array(pod_flags, np.uint32); a["pod_task_priority"] = np.array(pod_prio, np.int32)
     a["pod_created_ns"] = np.zeros(P, np.int64); a["pod_uid_rank"] = abi.rank_strings(pod_names); a["pod_class"] = pod_class
     a["pod_nominated_node"] = np.full(P, -1, np.int32)
+    if any(x > 0 for x in pod_gpu_portion):  # shared GPUs (ABI v4)
+        a["pod_gpu_portion"] = np.array(pod_gpu_portion, np.float64); a["pod_gpu_group"] = np.array(pod_gpu_group, np.int32)
+        gm = []
+        for nm in node_names:  # nodes_fake/nodes.go:184-194 + getNodeGpuMemory (node_info.go:673-687): MiB, floored to a multiple of 100
+            v = int(case["Nodes"][nm].get("GPUMemory") or 100); gm.append(v - v % 100)
+        a["node_gpu_memory"] = np.array(gm, np.int64)
     a["podset_job"] = np.array(podset_job, np.int32); a["podset_min_available"] = np.array(podset_min, np.int32); a["podset_name_rank"] = ps_rank
     a["job_queue"] = np.array(job_queue, np.int32); a["job_priority"] = np.array(job_priority, np.int32)
     a["job_preemptible"] = np.array(job_preempt, np.int32); a["job_created_ns"] = np.array(job_created, np.int64)
@@ -457,10 +476,22 @@ def case_to_snapshot(case, actions=("allocate",)):
     return snap, cfg, meta
 
 
-def check_expectations(snap, meta, pod_status, pod_node, nodes=None):
-    """test_utils.MatchExpectedAndRealTasks (test_utils/test_utils.go:121-314): status + node per task. → list of mismatches."""
+NEW_GPU_GROUP = 1 << 20  # oracle: ids from here on are groups created by the run (a UUID in the reference)
+
+
+def check_expectations(snap, meta, pod_status, pod_node, nodes=None, gpu_groups=None):
+    """test_utils.MatchExpectedAndRealTasks (test_utils/test_utils.go:121-314): status + node per task. → list of mismatches.
+    GPU groups (:150-175): the reference maps every expected group name of a node to the actual group the first time it sees it and requires
+    consistency afterwards — and only looks at all when expected and actual names are literally equal, which a freshly drawn UUID never is.
+    Checked here a little more strictly: a task that lands on a group of the fixture must be on the one named; new groups must map to the
+    expected names consistently per node."""
     S = abi.POD_STATUS
     errs = []
+    seen = {}  # (node, expected name) → actual id
+    if gpu_groups is not None and "pod_gpu_group" in snap.arrays:
+        for p in range(snap.n_pods):
+            g = int(snap.pod_gpu_group[p])
+            if g >= 0 and snap.pod_node[p] >= 0: seen[(int(snap.pod_node[p]), str(g))] = g
     for jname, exp in meta["expected_jobs"].items():
         if jname not in snap.job_names:
             errs.append(f"job {jname} missing"); continue
@@ -476,6 +507,13 @@ def check_expectations(snap, meta, pod_status, pod_node, nodes=None):
                 if got != exp["NodeName"]:
                     errs.append(f"{snap.pod_names[p]}: node {got!r} want {exp['NodeName']!r}")
             gsum += snap.pod_req[abi.RES_GPU, p]
+            if gpu_groups is not None and exp.get("GPUGroups") and not exp.get("DontValidateGPUGroup") and (int(pod_status[p]) & abi.ACTIVE_USED) and "pod_gpu_portion" in snap.arrays and snap.pod_gpu_portion[p] > 0:
+                name, actual, key = str(exp["GPUGroups"][0]), int(gpu_groups[p]), (int(pod_node[p]), str(exp["GPUGroups"][0]))
+                if actual < NEW_GPU_GROUP:  # landed on a group of the fixture: it must be the one named
+                    if str(actual) != name: errs.append(f"{snap.pod_names[p]}: gpu group {actual} want {name!r}")
+                elif key not in seen: seen[key] = actual  # a new group: the same one every time this name appears on the node …
+                elif seen[key] >= NEW_GPU_GROUP and seen[key] != actual: errs.append(f"{snap.pod_names[p]}: gpu group {actual} want {name!r} = {seen[key]}")
+                # … unless the name is a group of the fixture: the reference's check compares literal names only, so a fresh group passes it (e.g. line 1369)
         if abs(gsum - float(exp.get("GPUsRequired", 0))) > 1e-9:
             errs.append(f"{jname}: GPUsRequired {gsum} want {exp.get('GPUsRequired', 0)}")
     for tname, exp in meta["expected_tasks"].items():

@@ -331,18 +331,18 @@ def test_config_and_actions():
     got = ingest(doc(config={}))
     assert got.actions == ["allocate", "consolidation", "reclaim", "preempt"] and got.config.plugins == abi.PLUGIN_ALL  # defaults; stalegangeviction is skipped
     assert got.config.k_value == 1.0 and got.config.gpu_strategy == abi.BINPACK and list(got.config.queue_depth) == [-1] * 4 and got.config.min_node_gpu_memory == 100
-    tiers = [{"plugins": [{"name": "predicates"}, {"name": "proportion", "arguments": {"kValue": "0.5", "relcaimerSaturationMultiplier": "1.5"}}, {"name": "gpupack"},
+    tiers = [{"plugins": [{"name": "predicates"}, {"name": "proportion", "arguments": {"kValue": "0.5", "relcaimerSaturationMultiplier": "1.5"}}, {"name": "gpupack"}, {"name": "podaffinity"},
                           {"name": "nodeplacement", "arguments": {"gpu": "spread", "cpu": "binpack"}},
                           {"name": "minruntime", "arguments": {"defaultPreemptMinRuntime": "5m", "defaultReclaimMinRuntime": "1h30m", "reclaimResolveMethod": "queue"}}]}]
     got = ingest(doc(config={"actions": "reclaim, allocate", "tiers": tiers, "queueDepthPerAction": {"reclaim": 10, "preempt": 3}},
                      params={"maxNumberConsolidationPreemptees": 16, "allowConsolidatingReclaim": True, "restrictSchedulingNodes": True}), now_ns=123)
     c = got.config
     assert got.actions == ["reclaim", "allocate"]
-    assert c.plugins == abi.PLUGINS["predicates"] | abi.PLUGINS["proportion"] | abi.PLUGINS["nodeplacement"] | abi.PLUGINS["minruntime"]
+    assert c.plugins == abi.PLUGINS["predicates"] | abi.PLUGINS["proportion"] | abi.PLUGINS["nodeplacement"] | abi.PLUGINS["minruntime"] | abi.PLUGINS["gpupack"]
     assert (c.k_value, c.reclaimer_saturation_multiplier, c.gpu_strategy, c.cpu_strategy) == (0.5, 1.5, abi.SPREAD, abi.BINPACK)
     assert (c.default_preempt_min_runtime_ns, c.default_reclaim_min_runtime_ns, c.reclaim_resolve_method) == (300 * 10**9, 5400 * 10**9, 1)
     assert list(c.queue_depth) == [-1, -1, 10, 3] and c.max_consolidation_preemptees == 16 and c.allow_consolidating_reclaim == 1 and c.restrict_node_scheduling == 1
-    assert c.now_ns == 123 and any("gpupack" in w for w in got.warnings)
+    assert c.now_ns == 123 and any("podaffinity" in w for w in got.warnings)
     with pytest.raises(ing.IngestError, match="failed to find Action bogus"):
         ingest(doc(config={"actions": "allocate, bogus"}))
 
@@ -592,3 +592,38 @@ def test_replay_closes_the_loop():
             assert s.pod_status[i] == ST["Binding"] and s.node_names[s.pod_node[i]] == placed[n.split("/")[1]]
     res2 = T.Oracle.run(s, nxt.config, ("allocate",))
     assert all(o[0] != 0 or s.pod_names[o[1]].split("/")[1] not in placed for o in res2.ops)
+
+
+# ------------------------------------------------------------------------------------------------ shared GPUs (ABI v4)
+def test_fraction_fields_and_oracle_placement():
+    """gpu-fraction annotation → pod_gpu_portion (pod_info.go:472-477), runai-gpu-group label → pod_gpu_group (numeric names keep their value,
+    any other name is numbered from 2^20: plugins/predicates/predicates.go:320-330 takes it for a group being created), nvidia.com/gpu.memory →
+    node_gpu_memory floored to 100 (node_info.go:673-687).  The scenario of allocateFractionalGpu_test.go:155-214 through the file format:
+    the pending half-GPU pod joins the running half on the same shared GPU (oracle; such pods still carry KAI_POD_CPU_FALLBACK for the device)."""
+    frac = lambda v: {"annotations": {"gpu-fraction": v}}
+    pods = [pod("run", "j0", requests={"cpu": "1"}, phase="Running", node_name="node0", labels={"runai-gpu-group": "1"}, **frac("0.5")),
+            pod("uuid", "j2", requests={"cpu": "1"}, phase="Running", node_name="node1", labels={"runai-gpu-group": "6c3e-uuid"}, **frac("0.25")),
+            pod("pend", "j1", requests={"cpu": "1"}, **frac("0.5")), pod("whole", "j3"), pod("multi", "j4", annotations={"gpu-fraction": "0.5", "gpu-fraction-num-devices": "2"})]
+    nodes = [node("node0", gpu="2", labels={"nvidia.com/gpu.memory": "40537"}), node("node1", gpu="2")]
+    got = ingest(doc(nodes=nodes, queues=[queue("q")], pods=pods, pod_groups=[pod_group(f"j{i}", priorityClassName="p") for i in range(5)],
+                     priorityClasses=[{"metadata": {"name": "p"}, "value": 100}]))
+    s = got.snapshot
+    idx = {n.split("/")[1]: i for i, n in enumerate(s.pod_names)}
+    assert [float(s.pod_gpu_portion[idx[n]]) for n in ("run", "uuid", "pend", "whole", "multi")] == [0.5, 0.25, 0.5, 0.0, 0.0]
+    assert [int(s.pod_gpu_group[idx[n]]) for n in ("run", "uuid", "pend", "whole", "multi")] == [1, 1 << 20, -1, -1, -1]
+    assert float(s.pod_req[abi.RES_GPU, idx["pend"]]) == 0.5 and float(s.pod_req[abi.RES_GPU, idx["whole"]]) == 1.0
+    assert list(s.node_gpu_memory) == [40500, 100]
+    for n in ("run", "uuid", "pend", "multi"):
+        assert s.pod_flags[idx[n]] & abi.POD_CPU_FALLBACK
+    # drop the pods the oracle does not model (several devices per pod) and let it place the rest
+    keep = doc(nodes=nodes, queues=[queue("q")], pods=[p for p in pods if p["metadata"]["name"] != "multi"], pod_groups=[pod_group(f"j{i}", priorityClassName="p") for i in range(4)],
+               priorityClasses=[{"metadata": {"name": "p"}, "value": 100}])
+    g2 = ingest(keep); s2 = g2.snapshot
+    res = T.Oracle.run(s2, g2.config, ("allocate",))
+    i2 = {n.split("/")[1]: i for i, n in enumerate(s2.pod_names)}
+    assert res.pod_status[i2["pend"]] == ST["Binding"] and s2.node_names[res.pod_node[i2["pend"]]] == "node0" and res.gpu_groups[i2["pend"]] == 1
+    assert res.pod_status[i2["whole"]] == ST["Binding"]
+    # the device path refuses the snapshot loudly instead of mis-accounting the shared GPU (host-compiled engine: same rule as libkai_core)
+    import test_engine_hostsim as H
+    with pytest.raises(RuntimeError):
+        H.HostSim.run(s2, g2.config, ("allocate",))

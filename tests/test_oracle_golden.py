@@ -3,7 +3,7 @@ import pytest
 
 import kai_testlib as T
 
-FILES = ["allocate__allocate", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology",
+FILES = ["allocate__allocate", "allocate__allocateFractionalGpu", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology",
          "reclaim__reclaim", "reclaim__reclaimDepartments", "reclaim__reclaimGang", "reclaim__reclaim_elastic", "reclaim__reclaim_sub_group",
          "preempt__preempt", "preempt__preemptGang", "preempt__preempt_elastic", "preempt__preempt_subgroups",
          "consolidation__consolidation", "consolidation__consolidation_subgroups"]
@@ -20,24 +20,25 @@ ALL = [x for f in FILES for x in _cases(f)]
 @pytest.mark.parametrize("name,i,case,actions", ALL, ids=[f"{n}[{i}]" for n, i, _, _ in ALL])
 def test_oracle_reproduces_reference_expectations(name, i, case, actions):
     try:
-        snap, cfg, meta = T.case_to_snapshot(case)
+        snap, cfg, meta = T.case_to_snapshot(case, fractions=list(actions) == ["allocate"])
     except T.Unsupported as e:
         pytest.skip(f"outside the built path: {e}")
     res = T.Oracle.run(snap, cfg, actions)
-    errs = T.check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes)
+    errs = T.check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes, res.gpu_groups)
     assert not errs, f"{meta['name']} ({name} line {meta['line']}): {errs}"
 
 
 def test_golden_coverage():
-    """The scenarios inside the built path must be exercised, not silently skipped: 64 allocate + 122 reclaim / preempt / consolidation."""
+    """The scenarios inside the built path must be exercised, not silently skipped: 64 allocate + 22 allocate with fractional GPUs (oracle) +
+    122 reclaim / preempt / consolidation."""
     ok = 0
     for name, i, case, actions in ALL:
         try:
-            T.case_to_snapshot(case)
+            T.case_to_snapshot(case, fractions=list(actions) == ["allocate"])
             ok += 1
         except T.Unsupported:
             pass
-    assert ok >= 186, ok
+    assert ok >= 208, ok
 
 
 INTEG_FILES = ("integration_tests__allocate__allocate", "integration_tests__allocate__allocate_topology", "integration_tests__reclaim__reclaim",
