@@ -568,27 +568,32 @@ bool Statement::Evict(PodInfo* task) {
     job.UpdateTaskStatus(task, Releasing);
     if (!node.UpdateTask(task)) return false;
     ssn->deallocateHandler(task);
-    Operation op; op.name = opEvict; op.task = task; op.previousStatus = previousStatus; op.previousNode = node.idx; op.previousIsVirtual = previousIsVirtual;
+    Operation op; op.name = opEvict; op.task = task; op.previousStatus = previousStatus; op.previousNode = node.idx; op.previousIsVirtual = previousIsVirtual; op.previousGpuGroups = task->gpuGroups;
     operations.push_back(op); task->isVirtualStatus = true;
     return true;
 }
-bool Statement::unevict(PodInfo* task, int previousStatus, int nodeIdx, bool previousIsVirtual) {
+bool Statement::unevict(PodInfo* task, int previousStatus, int nodeIdx, bool previousIsVirtual, const std::vector<int>& previousGpuGroups) {
     ssn->jobs[task->job].UpdateTaskStatus(task, previousStatus);
-    task->isVirtualStatus = previousIsVirtual;
+    task->gpuGroups = previousGpuGroups; task->isVirtualStatus = previousIsVirtual;  // :167-168
     if (nodeIdx >= 0) { NodeInfo& node = ssn->nodes[nodeIdx]; if (node.podInfos.count(task->idx)) node.UpdateTask(task); else node.AddTask(task); }
     ssn->allocateHandler(task);
     return true;
 }
 bool Statement::Pipeline(PodInfo* task, int nodeIdx, bool updateTaskIfExistsOnNode) {
     PodGroupInfo& job = ssn->jobs[task->job]; NodeInfo& node = ssn->nodes[nodeIdx];
-    bool foundOnNode = node.podInfos.count(task->idx) > 0;
-    if (foundOnNode && !updateTaskIfExistsOnNode) return Unevict(task);  // :216-227
+    auto on = node.podInfos.find(task->idx); bool foundOnNode = on != node.podInfos.end();
+    // a shared-GPU task that was evicted from this node and now comes back on ANOTHER GPU of it (:208-213); GPUGroups == {"-1"} is the whole-GPU indicator
+    bool isSharedAndMoveToDifferentGPU = foundOnNode && !task->gpuGroups.empty() && task->IsSharedGPUAllocation() &&
+                                         !(task->gpuGroups.size() == 1 && task->gpuGroups[0] == kWholeGpuIndicator) && task->gpuGroups != on->second.groups;
+    if (foundOnNode && !updateTaskIfExistsOnNode && !isSharedAndMoveToDifferentGPU) { task->gpuGroups = on->second.groups; return Unevict(task); }  // :216-227
     int previousStatus = task->status;
     job.UpdateTaskStatus(task, Pipelined);
     int previousNode = task->node; task->node = nodeIdx; bool previousIsVirtual = task->isVirtualStatus;
-    if (foundOnNode) node.UpdateTask(task); else if (!node.AddTask(task)) return false;
+    std::vector<int> previousGpuGroups = task->gpuGroups;
+    if (isSharedAndMoveToDifferentGPU) { previousGpuGroups = on->second.groups; if (!node.ConsolidateSharedPodInfoToDifferentGPU(task)) return false; }
+    else if (foundOnNode) node.UpdateTask(task); else if (!node.AddTask(task)) return false;
     ssn->allocateHandler(task);
-    Operation op; op.name = opPipeline; op.task = task; op.previousStatus = previousStatus; op.previousNode = previousNode; op.nextNode = nodeIdx; op.previousIsVirtual = previousIsVirtual;
+    Operation op; op.name = opPipeline; op.task = task; op.previousStatus = previousStatus; op.previousNode = previousNode; op.nextNode = nodeIdx; op.previousIsVirtual = previousIsVirtual; op.previousGpuGroups = previousGpuGroups;
     operations.push_back(op); task->isVirtualStatus = true;
     return true;
 }
@@ -610,9 +615,9 @@ bool Statement::unallocate(PodInfo* task, bool previousIsVirtual) {
     ssn->deallocateHandler(task);
     return true;
 }
-bool Statement::unpipeline(PodInfo* task, int previousNode, int previousStatus, bool previousIsVirtual) {
+bool Statement::unpipeline(PodInfo* task, int previousNode, int previousStatus, bool previousIsVirtual, const std::vector<int>& previousGpuGroups) {
     ssn->jobs[task->job].UpdateTaskStatus(task, previousStatus);
-    int hostname = task->node; task->node = previousNode; task->isVirtualStatus = previousIsVirtual;
+    int hostname = task->node; task->node = previousNode; task->gpuGroups = previousGpuGroups; task->isVirtualStatus = previousIsVirtual;  // :450-454
     if (hostname < 0) return false;
     ssn->nodes[hostname].RemoveTask(task);
     ssn->deallocateHandler(task);
@@ -636,8 +641,8 @@ void Statement::undoOperation(int index) {
     if (!operationValid(index)) return;
     Operation op = operations[index];
     switch (op.name) {
-        case opEvict: unevict(op.task, op.previousStatus, op.previousNode, op.previousIsVirtual); break;
-        case opPipeline: unpipeline(op.task, op.previousNode, op.previousStatus, op.previousIsVirtual); break;
+        case opEvict: unevict(op.task, op.previousStatus, op.previousNode, op.previousIsVirtual, op.previousGpuGroups); break;
+        case opPipeline: unpipeline(op.task, op.previousNode, op.previousStatus, op.previousIsVirtual, op.previousGpuGroups); break;
         case opAllocate: unallocate(op.task, op.previousIsVirtual); break;
         case opUndo: {  // reverse of an undo = redo the original operation (:606-623)
             Operation orig = operations[op.operationIndex];
@@ -1173,7 +1178,6 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
             case KAI_ACTION_ALLOCATE: ssn.executeAllocate(); break;
             case KAI_ACTION_CONSOLIDATION: case KAI_ACTION_RECLAIM: case KAI_ACTION_PREEMPT:
                 if (cfg->use_scheduling_signatures && !ssn.hasSignatures) return KAI_ERR_UNSUPPORTED;  // same rule as libkai_core
-                if (ssn.hasFractions) return KAI_ERR_UNSUPPORTED;  // shared GPUs are restated for the allocate action only so far (GetTasksToEvict, idle-GPU filter, moving a task between GPUs: not yet)
                 ssn.executeVictimAction(actions[i]); break;
             default: return KAI_ERR_UNSUPPORTED;
         }

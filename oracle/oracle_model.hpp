@@ -266,6 +266,14 @@ struct NodeInfo {
         return MemoryOfEveryGpuOnNode - get(AllocatedSharedGPUsMemory, g) - GetResourceGpuMemory(r) >= 0;
     }
     double GetUsedGpuPortion(int g) const { return double(get(UsedSharedGPUsMemory, g)) / double(MemoryOfEveryGpuOnNode); }  // :377-383
+    double getSumOfAvailableSharedGPUs() const {  // :289-300: the free portion of every shared GPU that has something allocated
+        double sum = 0; for (auto& kv : AllocatedSharedGPUsMemory) if (kv.second > 0) sum += 1 - getGpuMemoryFractionalOnNode(kv.second); return sum;
+    }
+    double getSumOfReleasingSharedGPUs() const {  // :302-313: portions being released on shared GPUs that are not released as a whole
+        double sum = 0; for (auto& kv : ReleasingSharedGPUsMemory) if (kv.second > 0 && !isGpuReleasingFromSharedTasks(kv.first)) sum += getGpuMemoryFractionalOnNode(kv.second); return sum;
+    }
+    double GetSumOfIdleGPUs() const { return getSumOfAvailableSharedGPUs() + Idle.gpus; }            // node_info.go:592-609 (no MIG resources on the path)
+    double GetSumOfReleasingGPUs() const { return getSumOfReleasingSharedGPUs() + Releasing.gpus; }  // :611-628
     int64_t fractionTaskGpusAllocatableDeviceCount(const PodInfo* pod) const {  // :334-348
         int64_t n = 0;
         for (auto& kv : UsedSharedGPUsMemory) if (IsTaskFitOnGpuGroup(pod->resReq, kv.first)) { n++; if (n >= pod->resReq.count) return n; }
@@ -361,6 +369,21 @@ struct NodeInfo {
         podInfos[task->idx] = c;
         addTaskResources(r, task->status);
         if (shared) for (int g : c.groups) addSharedTaskResourcesPerPodGroup(c.status, c.gpuMemory, g);  // addSharedTaskResources :68-81
+        return true;
+    }
+    // ConsolidateSharedPodInfoToDifferentGPU (gpu_sharing_node_info.go:247-249 → addTask(ti, true), node_info.go:388-417): the node's copy of the
+    // task (releasing on its old GPU group) is dropped from PodInfos WITHOUT taking its amounts back — they stay "being released" — and the
+    // task is added again on its new group
+    bool ConsolidateSharedPodInfoToDifferentGPU(PodInfo* task) {
+        setAcceptedResources(task);
+        if (task->IsSharedGPUAllocation()) podInfos.erase(task->idx); else if (podInfos.count(task->idx)) return false;
+        Resource r = task->accepted.AsResource();
+        const bool shared = task->IsSharedGPUAllocation();
+        if (shared) r.gpus = 0;
+        OnNode c{task->status, r, shared, task->gpuGroups, shared ? GetResourceGpuMemory(task->resReq) : 0};
+        podInfos[task->idx] = c;
+        addTaskResources(r, task->status);
+        if (shared) for (int g : c.groups) addSharedTaskResourcesPerPodGroup(c.status, c.gpuMemory, g);
         return true;
     }
     bool RemoveTask(PodInfo* ti) {  // :495-513 — uses the node's copy, i.e. the status and groups at add time

@@ -18,6 +18,7 @@ struct Operation {
     OpName name; PodInfo* task = nullptr;
     int previousStatus = 0; int previousNode = -1; int nextNode = -1; bool previousIsVirtual = false;
     int operationIndex = -1;  // undo: index of the undone op
+    std::vector<int> previousGpuGroups;  // evictOperation / pipelineOperation.previousGpuGroups (operations.go)
 };
 
 struct Statement {
@@ -29,11 +30,11 @@ struct Statement {
         operations.resize(cp);
     }
     bool Evict(PodInfo* task);                                             // statement.go:63-126
-    bool unevict(PodInfo* task, int previousStatus, int node, bool previousIsVirtual);  // :152-195
+    bool unevict(PodInfo* task, int previousStatus, int node, bool previousIsVirtual, const std::vector<int>& previousGpuGroups);  // :152-195
     bool Pipeline(PodInfo* task, int node, bool updateTaskIfExistsOnNode); // :197-295
     bool Allocate(PodInfo* task, int node);                                // :297-358
     bool unallocate(PodInfo* task, bool previousIsVirtual);                // :391-425
-    bool unpipeline(PodInfo* task, int previousNode, int previousStatus, bool previousIsVirtual);  // :431-476
+    bool unpipeline(PodInfo* task, int previousNode, int previousStatus, bool previousIsVirtual, const std::vector<int>& previousGpuGroups);  // :431-476
     bool Unevict(PodInfo* task) { return undoEarliestValidOperation(task, opEvict); }              // :478-481
     bool ConvertAllAllocatedToPipelined(int jobIdx);                       // :483-516
     void Discard() { for (int i = int(operations.size()) - 1; i >= 0; i--) undoOperation(i); operations.clear(); }  // :522-534

@@ -130,7 +130,7 @@ struct AccumulatedIdleGpus {
     AccumulatedIdleGpus(Session* ssn, Scenario* sc) {  // NewIdleGpusFilter :53-71 + createGpuMap :176-196
         int relevantNodesLen = int(sc->pendingTasks.size()); double minRelevantValue = -1;
         for (auto& ni : ssn->nodes) {
-            nodesNameToIdleGpus[ni.idx] = ni.Idle.gpus + ni.Releasing.gpus;
+            nodesNameToIdleGpus[ni.idx] = ni.GetSumOfIdleGPUs() + ni.GetSumOfReleasingGPUs();  // nodeIdleOrReleasingGpuCapacity (idle_gpus/common.go:12-16)
             if (nodesNameToIdleGpus[ni.idx] > minRelevantValue || int(maxFreeGpuNodesSorted.size()) < relevantNodesLen) {
                 bool replace = relevantNodesLen <= int(maxFreeGpuNodesSorted.size());
                 orderedInsert(ni.idx, replace);
@@ -216,7 +216,7 @@ struct TopologyAwareIdleGpus {
         for (auto& sr : subgroups) if (std::find(rows.begin(), rows.end(), sr.second) == rows.end()) rows.push_back(sr.second);
         const int N = int(ssn->nodes.size());
         for (auto& ni : ssn->nodes) {  // buildDomainCapacity :191-244
-            double total = ni.Idle.gpus + ni.Releasing.gpus;
+            double total = ni.GetSumOfIdleGPUs() + ni.GetSumOfReleasingGPUs();
             for (int row : rows) { int d = ssn->nodeDomain[size_t(row) * N + ni.idx]; if (d < 0) continue; domainCapacity[d] += total; }
         }
         for (int row : rows) {
@@ -456,7 +456,7 @@ struct JobSolver {
 inline std::vector<int> Session::FeasibleNodesForJob(PodGroupInfo* job) {
     std::vector<int> out;
     bool allNeedGpu = true; for (auto* t : job->AllPods()) if (!(t->resReq.GPUs() > 0)) { allNeedGpu = false; break; }  // IsRequireAnyKindOfGPU, whole-GPU path
-    for (auto& n : nodes) if (!allNeedGpu || n.Idle.gpus > 0 || n.Releasing.gpus > 0) out.push_back(n.idx);
+    for (auto& n : nodes) if (!allNeedGpu || n.GetSumOfIdleGPUs() > 0 || n.GetSumOfReleasingGPUs() > 0) out.push_back(n.idx);
     return out;
 }
 
@@ -705,7 +705,7 @@ inline void Session::executeVictimAction(int action) {
             case KAI_ACTION_CONSOLIDATION: {  // consolidation.go:80-157
                 GetTasksToAllocateInitResource(job, false);
                 double sumGpus = 0;  // utils.IsEnoughGPUsAllocatableForJob (action.go:119-160)
-                for (auto& n : nodes) { if (n.flags & KAI_NODE_NOT_READY) continue; sumGpus += n.Idle.gpus; sumGpus += n.Releasing.gpus; }
+                for (auto& n : nodes) { if (n.flags & KAI_NODE_NOT_READY) continue; sumGpus += n.GetSumOfIdleGPUs(); sumGpus += n.GetSumOfReleasingGPUs(); }
                 double requested = 0; for (auto* t : GetTasksToAllocate(job, false)) requested += t->resReq.GPUs();
                 if (!(sumGpus >= requested)) break;
                 JobSolver solver{this, FeasibleNodesForJob(job),

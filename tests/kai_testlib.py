@@ -371,7 +371,10 @@ def case_to_snapshot(case, actions=("allocate",), fractions=False):
             if len(groups) > 1 or (groups and not frac) or any(not str(x).lstrip("-").isdigit() for x in groups):
                 raise Unsupported("shared gpu groups beyond one numeric group of a fraction task")
             pod_gpu_portion.append(g if frac else 0.0)
-            pod_gpu_group.append(int(groups[0]) if groups and t.get("State", "Pending") != "Pending" else -1)
+            if frac and t.get("NodeName"):  # resourceFractionCalc (jobs.go:318-330): a placed fraction task without a group gets one of its own, named by a fresh UUID
+                pod_gpu_group.append(int(groups[0]) if groups else NEW_GPU_GROUP + len(pod_gpu_group))
+            else:
+                pod_gpu_group.append(-1)
             pod_names.append(f"{job['Name']}-{ti}")
             pod_job.append(ji)
             sg = t.get("SubGroupName") or "default"
@@ -558,7 +561,7 @@ def _stale_gang(snap, pod_status):
     return False
 
 
-def run_integration(case, run_fn, rounds_after=None):
+def run_integration(case, run_fn, rounds_after=None, fractions=False):
     """actions/integration_tests/integration_tests_utils/integration_tests_utils.go:40-156: `RoundsUntilMatch` scheduling cycles, each on a
     session rebuilt from the fixture with the previous cycle's outcome fed back (Binding -> Running, Pipelined / Releasing -> Pending),
     then the expectations on a rebuilt session and after each of `RoundsAfterMatch` further cycles.  Returns the list of mismatches."""
@@ -566,7 +569,7 @@ def run_integration(case, run_fn, rounds_after=None):
     case = copy.deepcopy(case)
 
     def one_round():
-        snap, cfg, meta = case_to_snapshot(case)
+        snap, cfg, meta = case_to_snapshot(case, CYCLE, fractions)
         res = run_fn(snap, cfg, CYCLE)
         if _stale_gang(snap, res.pod_status):
             raise Unsupported("stalegangeviction would act (not a placement action)")
@@ -586,11 +589,15 @@ def run_integration(case, run_fn, rounds_after=None):
                     t["State"] = "Running"; t["NodeName"] = node
                 else:
                     t["State"] = st; t["NodeName"] = node
+                if "pod_gpu_portion" in snap.arrays and snap.pod_gpu_portion[p] > 0:  # the shared-GPU group travels with the placed pod (label runai-gpu-group)
+                    g = int(getattr(res, "gpu_groups", np.full(snap.n_pods, -1))[p])
+                    if t["NodeName"] and g >= 0: t["GPUGroups"] = [str(g)]
+                    else: t.pop("GPUGroups", None)
         return snap, meta, res
 
     for _ in range(int(case.get("_RoundsUntilMatch", 2))):
         one_round()
-    snap, cfg, meta = case_to_snapshot(case)  # prepareSessionForMatch: a rebuilt session, nothing run on it
+    snap, cfg, meta = case_to_snapshot(case, CYCLE, fractions)  # prepareSessionForMatch: a rebuilt session, nothing run on it
     res = run_fn(snap, cfg, ())
     errs = check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes)
     for _ in range(int(case.get("_RoundsAfterMatch", 5)) if rounds_after is None else rounds_after):
