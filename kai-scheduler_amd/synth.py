@@ -343,3 +343,33 @@ def config(idx: int, scale: float = 1.0, seed_offset: int = 0) -> tuple[abi.Snap
         add_topology(s, seed, zones=min(8, max(1, n(8))), racks_per_zone=max(1, min(40, n(10000) // (8 * 4))))
         return s, abi.default_config(k_value=0.0, max_consolidation_preemptees=16), f"C4 {n(10000)}n x {n(100000)}p zone/rack topology + consolidation + reclaim"
     raise ValueError(f"no BASELINE config {idx}")
+
+
+def add_fractions(snap: abi.Snapshot, seed: int, frac: float = 0.4, portions=(0.2, 0.25, 0.5, 0.75), gpu_memory: int = 100) -> abi.Snapshot:
+    """Turn a share of the one-GPU pods into requests for a fraction of one device (ABI v4: pod_gpu_portion / pod_gpu_group / node_gpu_memory).
+    Placed ones are packed first-fit into shared-GPU groups of their node (numeric group names 0, 1, …; every group takes one of the GPUs the
+    original pods held, so the node accounting of the reference — api/node_info/gpu_sharing_node_info.go — stays within the node's devices);
+    pending ones ask for their portion.  The oracle restates the shared-GPU model; the device engine refuses such snapshots for now."""
+    rng = np.random.default_rng(seed ^ 0xF2AC)
+    a = snap.arrays
+    P, N = snap.n_pods, snap.n_nodes
+    S = abi.POD_STATUS
+    active = S["Running"] | S["Bound"] | S["Binding"] | S["Allocated"]
+    portion = np.zeros(P, np.float64); group = np.full(P, -1, np.int32)
+    fill = [[] for _ in range(N)]  # per node: used portion (in 1/100) of every group
+    for p in range(P):
+        if a["pod_req"][abi.RES_GPU, p] != 1.0 or rng.random() >= frac:
+            continue
+        st = int(a["pod_status"][p])
+        if st != S["Pending"] and not (st & active):
+            continue
+        v = float(rng.choice(portions)); portion[p] = v; a["pod_req"][abi.RES_GPU, p] = v
+        if st & active:
+            n = int(a["pod_node"][p]); need = int(round(v * 100))
+            for g, used in enumerate(fill[n]):
+                if used + need <= 100:
+                    fill[n][g] += need; group[p] = g; break
+            else:
+                fill[n].append(need); group[p] = len(fill[n]) - 1
+    a["pod_gpu_portion"] = portion; a["pod_gpu_group"] = group; a["node_gpu_memory"] = np.full(N, gpu_memory, np.int64)
+    return snap.finalize()

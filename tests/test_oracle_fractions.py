@@ -1,0 +1,63 @@
+"""Shared GPUs in the oracle beyond the reference's golden tables: invariants of the reference's own accounting
+(api/node_info/gpu_sharing_node_info.go) on randomized clusters, full scheduling cycles incl. the victim actions."""
+import numpy as np
+import pytest
+
+import kai_testlib as T
+
+pkg, abi = T.pkg, T.abi
+S = abi.POD_STATUS
+HOLDS = S["Allocated"] | S["Binding"] | S["Bound"] | S["Running"] | S["Pipelined"] | S["Releasing"]
+
+
+def _check(snap, res, label, allocate_only):
+    """What must hold whatever the path taken: no shared GPU is handed out beyond one device to pods that keep running on it; after an allocate
+    action alone (nothing releasing, nothing pipelined) every GPU of a node is held by whole-GPU pods, is a shared GPU in use, or is idle."""
+    a = snap.arrays
+    N = snap.n_nodes
+    por = a["pod_gpu_portion"]
+    whole = np.zeros(N); groups = [dict() for _ in range(N)]
+    keeps = S["Allocated"] | S["Binding"] | S["Bound"] | S["Running"]
+    for p in range(snap.n_pods):
+        st, n = int(res.pod_status[p]), int(res.pod_node[p])
+        if not (st & keeps) or n < 0:
+            continue
+        if por[p] > 0:
+            g = int(res.gpu_groups[p])
+            assert g >= 0, f"{label}: pod {p} holds a fraction without a GPU group"
+            groups[n][g] = groups[n].get(g, 0) + int(por[p] * 100)
+        else:
+            whole[n] += a["pod_req"][abi.RES_GPU, p]
+    for n in range(N):
+        for g, used in groups[n].items():
+            assert used <= 100, f"{label}: node {n} GPU group {g} holds {used} % of a device"  # enoughResourcesOnGpu: memory of one device
+        if allocate_only:
+            total = a["node_allocatable"][abi.RES_GPU, n]
+            assert res.nodes["idle"][n, abi.RES_GPU] == total - whole[n] - len(groups[n]), f"{label}: node {n} idle {res.nodes['idle'][n, abi.RES_GPU]}"
+            assert res.nodes["releasing"][n, abi.RES_GPU] == 0
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fraction_cycles_keep_the_accounting_invariants(seed):
+    snap = pkg.synth.make_crowded_snapshot(3 + seed % 7, 9100 + seed, fill=0.6 + 0.3 * (seed % 4) / 3, n_pending_jobs=6 + seed % 9, elastic_frac=0.2,
+                                           hog_frac=0.5, queue_levels=((2, 2), (3,))[seed % 2])
+    pkg.synth.add_fractions(snap, seed, frac=0.5)
+    if not (snap.arrays["pod_gpu_portion"] > 0).any():
+        pytest.skip("no fraction pod drawn")
+    cfg = abi.default_config(max_consolidation_preemptees=-1, gpu_strategy=(abi.BINPACK, abi.SPREAD)[seed % 2])
+    if seed % 3 == 0: cfg.plugins = (cfg.plugins & ~abi.PLUGINS["gpupack"]) | abi.PLUGINS["gpuspread"]
+    cfg.use_scheduling_signatures = 0
+    for acts in (("allocate",), ("allocate", "consolidation", "reclaim", "preempt")):
+        res = T.Oracle.run(snap, cfg, acts)
+        _check(snap, res, f"seed {seed} {acts}", acts == ("allocate",))
+        again = T.Oracle.run(snap, cfg, acts)  # the restatement is deterministic (the reference's map orders are fixed canonically)
+        assert again.ops == res.ops and np.array_equal(again.gpu_groups < (1 << 20), res.gpu_groups < (1 << 20))
+
+
+def test_fraction_snapshots_are_refused_by_the_engine():
+    """libkai_core (here: its host-compiled twin) must not schedule a snapshot with shared GPUs it does not model."""
+    import test_engine_hostsim as H
+    snap = pkg.synth.make_crowded_snapshot(4, 9000)
+    pkg.synth.add_fractions(snap, 1, frac=1.0)
+    with pytest.raises(RuntimeError):
+        H.HostSim.run(snap, abi.default_config(), ("allocate",))
