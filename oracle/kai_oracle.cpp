@@ -11,6 +11,7 @@
 //
 // Go-map iteration orders that leak into results are fixed to index order.
 #include <chrono>
+#include <cstddef>
 #include <cstring>
 
 #include "oracle_session.hpp"
@@ -1197,6 +1198,21 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
     if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = ssn.stats.decisions; stats->node_scans = ssn.stats.nodeScans; stats->nodes_scanned = ssn.stats.nodesScanned;
                  stats->jobs_attempted = ssn.stats.jobsAttempted; stats->jobs_committed = ssn.stats.jobsCommitted; stats->rollbacks = ssn.stats.rollbacks; }
     return KAI_OK;
+}
+
+// layout probes for tests/test_abi.py: the ctypes mirror (kai-scheduler_amd/abi.py) must describe the same structs as include/kai_core.h
+int kai_oracle_layout(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(kai_snapshot_soa);
+        case 1: return (int)offsetof(kai_snapshot_soa, node_gpu_memory);
+        case 2: return (int)offsetof(kai_snapshot_soa, job_signature);
+        case 3: return (int)offsetof(kai_snapshot_soa, class_fit);
+        case 4: return (int)sizeof(kai_config);
+        case 5: return (int)offsetof(kai_config, now_ns);
+        case 6: return (int)sizeof(kai_action_stats);
+        case 7: return (int)offsetof(kai_snapshot_soa, n_groups);
+        default: return -1;
+    }
 }
 
 // shared-GPU group of every pod after the last kai_oracle_run: id < 2^20 = a group of the snapshot, >= 2^20 = created by the run, -1 = none

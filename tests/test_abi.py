@@ -45,3 +45,18 @@ def test_no_device_fails_loudly():
     assert rc == -2, rc
     with pytest.raises(T.pkg.KaiError):
         T.pkg.KaiCore(cfg)
+
+
+def test_ctypes_mirror_matches_the_header_layout():
+    """sizeof / offsetof as the C compiler sees include/kai_core.h (probed through the oracle library, which includes the header) against
+    the ctypes structures of kai-scheduler_amd/abi.py: a drifted mirror would hand the device library garbage pointers."""
+    lib = T.Oracle.lib()
+    S, Cf = T.abi.KaiSnapshotSoA, T.abi.KaiConfig
+    assert lib.kai_oracle_layout(0) == C.sizeof(S)
+    assert lib.kai_oracle_layout(1) == S.node_gpu_memory.offset
+    assert lib.kai_oracle_layout(2) == S.job_signature.offset
+    assert lib.kai_oracle_layout(3) == S.class_fit.offset
+    assert lib.kai_oracle_layout(7) == S.n_groups.offset
+    assert lib.kai_oracle_layout(4) == C.sizeof(Cf)
+    assert lib.kai_oracle_layout(5) == Cf.now_ns.offset
+    assert lib.kai_oracle_layout(6) == C.sizeof(T.abi.KaiActionStats)
