@@ -292,6 +292,17 @@ struct KaiCtx {
     // minruntime plugin inputs (null = nothing is protected)
     KAI_GP(const int64_t) j_last_start, q_preempt_mr, q_reclaim_mr; int64_t now_ns, def_preempt_mr, def_reclaim_mr; int32_t reclaim_method, pad8;
     SolverCtx sv;
+#ifdef KAI_SHARED_GPUS
+    // shared GPUs (ABI v4; compiled into the host twin only until the device path is verified on the MI355X): fractions of one device
+    KAI_GP(const double) p_portion;       // [P] 0 = a whole-GPU / CPU-only pod
+    KAI_GP(int32_t) p_group, p_on_group;  // [P] PodInfo.GPUGroups[0]; the group in the node's own copy of the pod (node_info.go:397-398)
+    KAI_GP(const int64_t) n_gpu_mem;      // [N] MemoryOfEveryGpuOnNode
+    KAI_GP(int32_t) ng_id;                // [N][KAI_GMAX] GpuSharingNodeInfo: group id of the slot, -1 = free
+    KAI_GP(int64_t) ng_used, ng_rel, ng_alloc;  // [N][KAI_GMAX] UsedSharedGPUsMemory / ReleasingSharedGPUsMemory / AllocatedSharedGPUsMemory
+    KAI_GP(uint32_t) ng_mark, ng_has_alloc;     // [N] bit per slot: ReleasingSharedGPUs; the group has an entry in AllocatedSharedGPUsMemory
+    KAI_GP(int32_t) next_new_group;       // [1] uuid.NewUUID() of findGpuForSharingOnNode
+    int32_t shared_on, pad_sh;
+#endif
 };
 
 // ======================================================================================================
@@ -301,6 +312,9 @@ struct ScanReq {
     int32_t pod, cpu_only, best_effort, pod_class, nominated, r_place, strategy, pad;
     double req[KAI_MAX_RES];
     double min_a, max_a;  // nodeplacement.setBinpackPreOrder range (plugins/nodeplacement/pack.go:35-43)
+#ifdef KAI_SHARED_GPUS
+    double portion;       // > 0: the task asks for this fraction of one device
+#endif
 };
 
 KAI_HD bool fits(const KaiCtx& c, const double* req, int n, bool with_releasing) {
@@ -315,6 +329,125 @@ KAI_HD bool fits(const KaiCtx& c, const double* req, int n, bool with_releasing)
     }
     return true;
 }
+
+#ifdef KAI_SHARED_GPUS
+// ------------------------------------------------------------------------------------------------------
+// Shared GPUs: api/node_info/gpu_sharing_node_info.go on fixed tables — KAI_GMAX group slots per node.  A Go map entry exists once it was
+// written, whatever its value; a slot is that entry for the three maps together (ng_has_alloc tells whether AllocatedSharedGPUsMemory has
+// the key).  Maps are ranged in ascending group id (the oracle's canonical order).
+// ------------------------------------------------------------------------------------------------------
+constexpr int KAI_GMAX = 16;
+constexpr int KAI_NEW_GROUP = 1 << 20;  // ids from here on: non-numeric group names (UUIDs) — "new" for predicates.go:320-330
+constexpr int KAI_WHOLE_GPU = -1;       // pod_info.WholeGpuIndicator
+struct SgNode {
+    const KaiCtx& c; int n;
+    KAI_HD int32_t& id(int s) const { return c.ng_id[(size_t)n * KAI_GMAX + s]; }
+    KAI_HD int64_t& used(int s) const { return c.ng_used[(size_t)n * KAI_GMAX + s]; }
+    KAI_HD int64_t& rel(int s) const { return c.ng_rel[(size_t)n * KAI_GMAX + s]; }
+    KAI_HD int64_t& alloc(int s) const { return c.ng_alloc[(size_t)n * KAI_GMAX + s]; }
+    KAI_HD double& idle_gpu() const { return c.n_idle[(size_t)KAI_RES_GPU * c.N + n]; }
+    KAI_HD double& rel_gpu() const { return c.n_rel[(size_t)KAI_RES_GPU * c.N + n]; }
+    KAI_HD double used_gpu() const { return c.n_used[(size_t)KAI_RES_GPU * c.N + n]; }
+    KAI_HD int64_t gpu_mem() const { return c.n_gpu_mem[n]; }
+    KAI_HD int64_t mem_of(double portion) const { return (int64_t)(portion * (double)gpu_mem()); }  // GetResourceGpuMemory (node_info.go:653-659)
+    KAI_HD double frac_of(int64_t mem) const { double x = (double)mem / (double)gpu_mem() * 100; double f = (double)(int64_t)x; if (f < x) f += 1; return f / 100; }  // getGpuMemoryFractionalOnNode :329-332 (x >= 0)
+    KAI_HD int find(int g) const { for (int s = 0; s < KAI_GMAX; s++) if (id(s) == g) return s; return -1; }
+    KAI_HD int slot(int g) const {  // the map entry of group g, created on first write; -1 = table full
+        int s = find(g); if (s >= 0) return s;
+        for (s = 0; s < KAI_GMAX; s++) if (id(s) < 0) { id(s) = g; used(s) = 0; rel(s) = 0; alloc(s) = 0; c.ng_mark[n] &= ~(1u << s); c.ng_has_alloc[n] &= ~(1u << s); return s; }
+        return -1;
+    }
+    KAI_HD bool marked(int s) const { return (c.ng_mark[n] >> s) & 1u; }
+    KAI_HD int64_t n_gpus() const { int lbl = c.n_gpu_count[n]; return lbl >= 0 ? lbl : (int64_t)c.n_alloc[(size_t)KAI_RES_GPU * c.N + n]; }  // GetNumberOfGPUsInNode
+    KAI_HD int used_shared() const { int k = 0; for (int s = 0; s < KAI_GMAX; s++) if (id(s) >= 0 && used(s) > 0) k++; return k; }     // :265-273
+    KAI_HD int used_gpus() const { return (int)used_gpu() + used_shared(); }                                                            // :275-277
+    KAI_HD bool releasing_from_shared(int s) const { return used(s) != 0 && rel(s) == used(s); }                                        // :253-263 (a found key with value 0 != used)
+    KAI_HD bool fit_on_group(int s, int64_t mem) const { return used(s) != 0 && gpu_mem() - alloc(s) + rel(s) - mem >= 0 && alloc(s) != rel(s); }  // IsTaskFitOnGpuGroup :350-354
+    KAI_HD bool enough_idle(int s, int64_t mem) const { return ((c.ng_has_alloc[n] >> s) & 1u) && gpu_mem() - alloc(s) - mem >= 0; }              // EnoughIdleResourcesOnGpu :356-363
+    KAI_HD int count_fit(int64_t mem) const { int k = 0; for (int s = 0; s < KAI_GMAX; s++) if (id(s) >= 0 && fit_on_group(s, mem)) k++; return k; }  // fractionTaskGpusAllocatableDeviceCount (count = 1)
+    // addSharedTaskResourcesPerPodGroup :83-136 / removeSharedTaskResourcesPerPodGroup :153-235; false = table full
+    KAI_HD bool add(int status, int64_t mem, int g) const {
+        int s = slot(g); if (s < 0) return false;
+        used(s) += mem;
+        if (status == KAI_POD_RELEASING) {
+            rel(s) += mem; alloc(s) += mem; c.ng_has_alloc[n] |= 1u << s;
+            if (used(s) == rel(s)) {
+                if (!marked(s)) { rel_gpu() += 1; c.ng_mark[n] |= 1u << s; }
+                if ((int)n_gpus() < (int)idle_gpu() + used_gpus()) idle_gpu() -= 1;
+            }
+        } else if (status == KAI_POD_PIPELINED) {
+            rel(s) -= mem;
+            if (used(s) - mem == rel(s) + mem) rel_gpu() -= 1;
+        } else {
+            alloc(s) += mem; c.ng_has_alloc[n] |= 1u << s;
+            if (used(s) <= mem) { if ((int)n_gpus() < (int)idle_gpu() + used_gpus()) idle_gpu() -= 1; }
+            if (marked(s)) { rel_gpu() -= 1; c.ng_mark[n] &= ~(1u << s); }
+        }
+        return true;
+    }
+    KAI_HD bool remove(int status, int64_t mem, int g) const {
+        int s = slot(g); if (s < 0) return false;
+        used(s) -= mem;
+        if (status == KAI_POD_RELEASING) {
+            rel(s) -= mem; alloc(s) -= mem; c.ng_has_alloc[n] |= 1u << s;
+            if (used(s) <= 0) {
+                if ((int)n_gpus() >= (int)idle_gpu() + used_gpus()) idle_gpu() += 1;
+                if (marked(s)) { rel_gpu() -= 1; c.ng_mark[n] &= ~(1u << s); }
+            }
+        } else if (status == KAI_POD_PIPELINED) {
+            rel(s) += mem;
+            const bool to_releasing = (used(s) + mem == rel(s) - mem) || (used(s) == 0 && rel(s) == 0);  // isPipelinedToReleasingGpu :237-245
+            if (to_releasing) rel_gpu() += 1;
+        } else {
+            alloc(s) -= mem; c.ng_has_alloc[n] |= 1u << s;
+            if (used(s) <= 0) { if ((int)n_gpus() >= (int)idle_gpu() + used_gpus()) idle_gpu() += 1; }
+            if (releasing_from_shared(s) && !marked(s)) { rel_gpu() += 1; c.ng_mark[n] |= 1u << s; }
+        }
+        return true;
+    }
+    // FittingGPUs (framework/session.go:163-199): groups that can take the task in ascending id, then one entry per idle-or-releasing whole GPU,
+    // stably ordered by the GPU order score (gpupack: used portion; gpuspread: 1 - used portion, 1 for a whole GPU).  out[] holds slots, or
+    // KAI_WHOLE_GPU entries; returns the count (at most KAI_GMAX + whole GPUs, capped).
+    KAI_HD double gpu_score(int s) const {
+        double sc = 0, usedp = s == KAI_WHOLE_GPU ? 0.0 : (double)used(s) / (double)gpu_mem();
+        if (c.plugins & KAI_PLUGIN_GPUPACK) sc += s == KAI_WHOLE_GPU ? 0.0 : usedp;
+        if (c.plugins & KAI_PLUGIN_GPUSPREAD) sc += s == KAI_WHOLE_GPU ? 1.0 : 1 - usedp;
+        return sc;
+    }
+    // GetNodePreferableGpuForSharing (gpu_sharing/gpuSharing.go:39-71) for one device: the first entry of FittingGPUs.  Returns false when none;
+    // slot = the group's slot or KAI_WHOLE_GPU (a new group), releasing = the task has to be pipelined there
+    KAI_HD bool preferable(int64_t mem, bool pipeline_only, bool allocatable_now, int& slot_out, bool& releasing) const {
+        int best = -2; double bs = 0; int best_id = 0;
+        for (int s = 0; s < KAI_GMAX; s++) {  // stable order: ascending group id among equal scores; groups come before whole GPUs
+            if (id(s) < 0 || !fit_on_group(s, mem)) continue;
+            double sc = gpu_score(s);
+            if (best == -2 || sc > bs || (sc == bs && id(s) < best_id)) { best = s; bs = sc; best_id = id(s); }
+        }
+        const int whole = (idle_gpu() > 0 || rel_gpu() > 0) ? (int)idle_gpu() + (int)rel_gpu() : 0;
+        if (whole > 0) { double sc = gpu_score(KAI_WHOLE_GPU); if (best == -2 || sc > bs) { best = KAI_WHOLE_GPU; bs = sc; } }
+        if (best == -2) return false;
+        slot_out = best;
+        if (best == KAI_WHOLE_GPU) releasing = pipeline_only ? true : !allocatable_now;              // findGpuForSharingOnNode :73-83
+        else releasing = !enough_idle(best, mem) || !allocatable_now;
+        return true;
+    }
+};
+// isTaskAllocatableOnNonAllocatedResources for a fraction of one device (node_info.go:361-382)
+KAI_HD bool fits_shared(const KaiCtx& c, const ScanReq& q, int n, bool with_releasing) {
+    for (int r = 0; r < c.R; r++) {
+        if (r == KAI_RES_GPU) continue;
+        double rq = q.req[r];
+        if (r >= KAI_RES_PODS && !(rq > 0)) continue;
+        double avail = c.n_idle[(size_t)r * c.N + n];
+        if (with_releasing) avail = avail + c.n_rel[(size_t)r * c.N + n];
+        if (rq > avail) return false;
+    }
+    SgNode g{c, n};
+    double ag = g.idle_gpu(); if (with_releasing) ag = ag + g.rel_gpu();
+    double fl = (double)(int64_t)ag; if (fl > ag) fl -= 1;  // math.Floor
+    return (int64_t)fl + g.count_fit(g.mem_of(q.portion)) >= 1;
+}
+#endif
 
 // plugins/predicates/predicates.go:173-262 minus the queue-capacity step (node independent, done by the control lane)
 KAI_HD bool node_predicates(const KaiCtx& c, bool cpu_only, int pod_class, int n) {
@@ -334,6 +467,27 @@ KAI_HD bool node_predicates(const KaiCtx& c, bool cpu_only, int pod_class, int n
     }
     return true;
 }
+#ifdef KAI_SHARED_GPUS
+// the same for a task that asks for a fraction of one device: MigStrategy single admits whole-GPU tasks only (node_info.go:349-352) and the pod
+// count check becomes checkMaxPodsWithGpuGroupReservation + willCreateNewGpuGroup (plugins/predicates/predicates.go:264-330): two free pod slots
+// when the task would open a new GPU group (the reservation pod), none asked for when it joins a group of the snapshot
+KAI_HD bool node_predicates_shared(const KaiCtx& c, const ScanReq& q, int n) {
+    if (!(c.plugins & KAI_PLUGIN_PREDICATES)) return true;
+    uint32_t f = c.n_flags[n];
+    if (f & KAI_NODE_HAS_DRA_GPUS) return false;
+    if ((f & KAI_NODE_MIG_ENABLED) && (f & (KAI_NODE_MIG_MIXED | KAI_NODE_MIG_SINGLE))) return false;
+    SgNode g{c, n}; const int64_t mem = g.mem_of(q.portion);
+    const bool alloc_now = q.best_effort || fits_shared(c, q, n, false);
+    int slot = 0; bool releasing = false; bool needs_new = true;
+    if (g.preferable(mem, false, alloc_now, slot, releasing)) needs_new = slot == KAI_WHOLE_GPU || g.id(slot) >= KAI_NEW_GROUP;
+    double pods = c.n_idle[(size_t)KAI_RES_PODS * c.N + n] + c.n_rel[(size_t)KAI_RES_PODS * c.N + n];
+    if (needs_new && pods < 2) return false;
+    if (f & KAI_NODE_NOT_READY) return false;
+    if (!c.class_fit[(size_t)q.pod_class * c.n_node_classes + c.n_class[n]]) return false;
+    if (c.restrict_nodes && !(f & KAI_NODE_GPU_WORKER)) return false;
+    return true;
+}
+#endif
 KAI_HD bool cpu_only_node(const KaiCtx& c, int n) {  // node_info.go:697-702
     uint32_t f = c.n_flags[n];
     return !(f & KAI_NODE_MIG_ENABLED) && c.n_alloc[(size_t)KAI_RES_GPU * c.N + n] <= 0 && !(f & KAI_NODE_HAS_DRA_GPUS);
@@ -343,6 +497,13 @@ KAI_HD bool cpu_only_node(const KaiCtx& c, int n) {  // node_info.go:697-702
 KAI_HD double node_score(const KaiCtx& c, const ScanReq& q, int n, bool fit_idle) {
     double score = 0.0;
     if (c.plugins & KAI_PLUGIN_NODEAVAILABILITY) score += fit_idle ? 100.0 : 0.0;  // plugins/nodeavailability/nodeavailability.go:29-40
+#ifdef KAI_SHARED_GPUS
+    if (c.shared_on && (c.plugins & KAI_PLUGIN_GPUSHARINGORDER)) {  // plugins/gpusharingorder/gpusharingorder.go:29-44: 1000 when a used shared GPU of the node can take the task
+        SgNode g{c, n}; const int64_t mem = g.mem_of(q.portion);  // GetResourceGpuMemory: portion 1 for whole GPUs, 0 for a CPU-only task (which therefore "fits" every active shared GPU)
+        double sc = 0.0; for (int s2 = 0; s2 < KAI_GMAX; s2++) if (g.id(s2) >= 0 && g.fit_on_group(s2, mem)) sc = 1000.0;
+        score += sc;
+    }
+#endif
     if (c.plugins & KAI_PLUGIN_RESOURCETYPE) score += (q.cpu_only && cpu_only_node(c, n)) ? 10.0 : 0.0;  // plugins/resourcetype/resourcetype.go:29-41
     if (c.plugins & KAI_PLUGIN_NOMINATEDNODE) score += (q.nominated >= 0 && q.nominated == n) ? 1000000.0 : 0.0;
     if (c.plugins & KAI_PLUGIN_NODEPLACEMENT) {
@@ -586,12 +747,21 @@ struct Engine {
     KAI_HD void node_apply(int n, int p, int status, double sign) {  // addTaskResources :457-493 / removeTaskResources :515-551
         for (int r = 0; r < cx().R; r++) {
             double v = preq(p, r); if (v == 0) continue;
+#ifdef KAI_SHARED_GPUS
+            if (r == KAI_RES_GPU && cx().shared_on && cx().p_portion[p] > 0) continue;  // getAcceptedTaskResourceWithoutSharedGPU (gpu_sharing_node_info.go:52-66)
+#endif
             size_t i = (size_t)r * cx().N + n;
             cx().n_used[i] += sign * v;
             if (status == KAI_POD_RELEASING) { cx().n_rel[i] += sign * v; cx().n_idle[i] -= sign * v; }
             else if (status == KAI_POD_PIPELINED) cx().n_rel[i] -= sign * v;
             else cx().n_idle[i] -= sign * v;
         }
+#ifdef KAI_SHARED_GPUS
+        if (cx().shared_on && cx().p_portion[p] > 0) {  // addSharedTaskResources / removeSharedTaskResources with the group of the node's own copy
+            SgNode g{cx(), n}; const int grp = cx().p_on_group[p];
+            if (grp >= 0) { bool ok = sign > 0 ? g.add(status, g.mem_of(cx().p_portion[p]), grp) : g.remove(status, g.mem_of(cx().p_portion[p]), grp); if (!ok) fault(FAULT_INTERNAL); }
+        }
+#endif
         mark_dirty(n);
     }
     // further residencies (victim search only): open addressing, key = pod << 32 | node, -1 empty, -2 deleted
@@ -616,6 +786,9 @@ struct Engine {
             fault(FAULT_INTERNAL); return false;
         }
         cx().p_on_node[p] = n; cx().p_on_node_status[p] = cx().p_status[p];
+#ifdef KAI_SHARED_GPUS
+        if (cx().shared_on) cx().p_on_group[p] = cx().p_group[p];
+#endif
         node_apply(n, p, cx().p_status[p], 1.0);
         return true;
     }
@@ -1014,6 +1187,11 @@ struct Engine {
     KAI_HD bool task_over_capacity(int p) const {  // capacity_policy.go:51-61 with NodeInfo.GetRequiredInitQuota (node_info.go:734-744):
         if (!(cx().plugins & KAI_PLUGIN_PROPORTION)) return false;  // the GPU term is 1 for ANY whole-GPU request, 0 for CPU-only
         double req[3] = {preq(p, KAI_RES_CPU), preq(p, KAI_RES_MEM), preq(p, KAI_RES_GPU) >= 1 ? 1.0 : 0.0};
+#ifdef KAI_SHARED_GPUS
+        // a fraction: ceil(int64(portion * mem) / mem * 100) / 100 of a device; node independent because the host admits shared GPUs only when
+        // every node has the same MemoryOfEveryGpuOnNode
+        if (cx().shared_on && cx().p_portion[p] > 0 && cx().N > 0) { SgNode g{cx(), 0}; req[2] = g.frac_of(g.mem_of(cx().p_portion[p])); }
+#endif
         int j = cx().p_job[p];
         return over_limit(j, req) || np_over_quota(j, req);
     }
@@ -1219,6 +1397,9 @@ struct Engine {
         q.r_place = q.cpu_only ? KAI_RES_CPU : KAI_RES_GPU; q.strategy = q.cpu_only ? cx().cpu_strategy : cx().gpu_strategy;
         for (int r = 0; r < KAI_MAX_RES; r++) q.req[r] = r < cx().R ? preq(p, r) : 0.0;
         q.min_a = 0; q.max_a = 0;
+#ifdef KAI_SHARED_GPUS
+        q.portion = cx().shared_on ? (cx().p_portion[p] > 0 ? cx().p_portion[p] : (preq(p, KAI_RES_GPU) >= 1 ? 1.0 : 0.0)) : 0.0;  // GpuFractionalPortion()
+#endif
     }
     // OrderedNodesByTask + FittingNode for one task (framework/session.go:201-264): the first fitting node in score order, or -1
     KAI_HD int find_node(int p, bool& allocatable) {
@@ -1237,6 +1418,9 @@ struct Engine {
         int n = be.best_node(cx(), q);
         cx().st->node_scans++; cx().st->nodes_scanned += cx().N;
         if (n >= 0) allocatable = q.best_effort || fits(cx(), q.req, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
+#ifdef KAI_SHARED_GPUS
+        if (n >= 0 && cx().shared_on && cx().p_portion[p] > 0) allocatable = q.best_effort || fits_shared(cx(), q, n, false);
+#endif
         return n;
     }
     KAI_HD bool allocate_task(int p, bool pipeline_only) {  // :121-163
@@ -1251,7 +1435,18 @@ struct Engine {
         int64_t t2 = be.clock(); el().h.prof[PF_FIND] += t2 - t1;
         if (n < 0) { el().fail_no_node = true; return false; }
         // allocateTaskToNode :165-174
-        bool ok = (!pipeline_only && allocatable) ? stmt_allocate(p, n) : stmt_pipeline(p, n, !pipeline_only);
+        bool ok;
+#ifdef KAI_SHARED_GPUS
+        if (cx().shared_on && cx().p_portion[p] > 0) {  // gpu_sharing.AllocateFractionalGPUTaskToNode (gpuSharing.go:20-37, 85-103)
+            SgNode g{cx(), n}; int slot = 0; bool releasing = false;
+            if (!g.preferable(g.mem_of(cx().p_portion[p]), pipeline_only, allocatable, slot, releasing)) { fault(FAULT_INTERNAL); return false; }
+            cx().p_group[p] = slot == KAI_WHOLE_GPU ? cx().next_new_group[0]++ : g.id(slot);
+            const bool pipe = pipeline_only || releasing;
+            ok = pipe ? stmt_pipeline(p, n, false) : stmt_allocate(p, n);
+            if (!ok) cx().p_group[p] = -1;
+        } else
+#endif
+        ok = (!pipeline_only && allocatable) ? stmt_allocate(p, n) : stmt_pipeline(p, n, !pipeline_only);
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(KAI_SOLVER_TRACE)
         std::fprintf(stderr, "[eng] task %d -> node %d pipe %d ok %d\n", p, n, (int)pipeline_only, (int)ok);
 #endif

@@ -5,6 +5,7 @@
 // plain g++ and a serial node scanner, to debug it against the oracle in the `-m "not gpu"` suite.
 // This is NOT a CPU fallback: libkai_core never contains it, the package never loads it, and every
 // parity claim is made by the `-m gpu` tests through the C ABI on a real MI355X.
+#define KAI_SHARED_GPUS 1  // the host twin carries the shared-GPU engine code (ABI v4); the device library is built without it until it is verified on the MI355X
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -42,9 +43,10 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
         int best = -1; double bs = 0;
         for (int n = 0; n < c.N; n++) {
             if (loc.scope_bits && !((loc.scope_bits[n >> 5] >> (n & 31)) & 1)) continue;
-            if (!fits(c, q.req, n, true)) continue;
-            if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;
-            bool fit_idle = q.best_effort || fits(c, q.req, n, false);
+            const bool frac = c.shared_on && q.portion > 0 && q.portion < 1;
+            if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
+            if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n))) continue;
+            bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
             double sc = node_score(c, q, n, fit_idle);
             if (loc.scope_row >= 0) { int dd = c.node_domain[(size_t)loc.scope_row * c.N + n]; double ts = dd >= 0 ? loc.scope_score[dd] : -1.0; if (ts < 0) continue; sc += ts; }
             if (best < 0 || sc > bs) { best = n; bs = sc; }
@@ -105,12 +107,19 @@ template <class T> const T* copy(std::vector<std::vector<char>>& pool, const T* 
 
 }  // namespace
 
+static std::vector<int32_t> g_last_groups;  // PodInfo.GPUGroups[0] of the active fraction pods after the last run
+extern "C" int kai_hostsim_last_gpu_groups(int32_t* out, int cap) { int n = (int)g_last_groups.size(); for (int i = 0; i < n && i < cap; i++) out[i] = g_last_groups[i]; return n; }
 extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s, const int* actions, int n_actions,
                                kai_op* ops_out, int64_t ops_cap, int64_t* n_ops, int32_t* pod_status_out, int32_t* pod_node_out,
                                kai_queue_share* shares_open, kai_queue_share* shares_final, kai_node_state* nodes_out,
                                kai_action_stats* stats, double* elapsed_ms_out) {
     if (!cfg || !s || s->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
-    if (s->pod_gpu_portion) for (int p = 0; p < s->n_pods; p++) if (s->pod_gpu_portion[p] > 0) return KAI_ERR_UNSUPPORTED;  // shared GPUs: oracle only for now
+    bool shared = false;
+    if (s->pod_gpu_portion) for (int p = 0; p < s->n_pods; p++) if (s->pod_gpu_portion[p] > 0) shared = true;
+    if (shared) {  // shared GPUs in the engine: the allocate action, one GPU memory size for the whole cluster (the queue-capacity step stays node independent)
+        for (int i = 0; i < n_actions; i++) if (actions[i] != KAI_ACTION_ALLOCATE) return KAI_ERR_UNSUPPORTED;
+        if (s->node_gpu_memory) for (int n = 1; n < s->n_nodes; n++) if (s->node_gpu_memory[n] != s->node_gpu_memory[0]) return KAI_ERR_UNSUPPORTED;
+    }
     const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
     std::vector<std::vector<char>> pool;
     HostPrep prep; std::string err;
@@ -135,6 +144,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.j_pods_sorted = copy(pool, prep.sorted.data(), P); c.q_child_off = copy(pool, prep.child_off.data(), Q + 2); c.q_children = copy(pool, prep.children.data(), std::max(Q, 1));
     c.q_job_off = copy(pool, prep.job_off.data(), Q + 1); c.jobs_static = copy(pool, prep.jobs_static.data(), std::max(J, 1)); c.q_depth_order = copy(pool, prep.depth_order.data(), Q);
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64; c.use_index = c.C > 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok;
+    if (shared) { c.use_index = 0; c.all_tracked = 0; c.fast_ok = 0; }  // every scan by brute force: the class keys know neither fractions nor the gpusharingorder score
     { int d = cfg->queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
     c.cls = copy(pool, prep.classes.data(), prep.classes.size());
     c.T = prep.T; c.TL = prep.TL; c.D = prep.D; c.G = prep.G; c.W = (N + 31) / 32;
@@ -155,6 +165,18 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.n_idle = const_cast<double*>(copy(pool, prep.node_alloc.data(), (size_t)R * N)); c.n_rel = own<double>(pool, (size_t)R * N); c.n_used = own<double>(pool, (size_t)R * N);
     c.p_status = const_cast<int32_t*>(copy(pool, s->pod_status, P)); c.p_node = const_cast<int32_t*>(copy(pool, prep.pod_node.data(), P));
     c.p_on_node = own<int32_t>(pool, P); c.p_on_node_status = own<int32_t>(pool, P); c.p_virtual = own<uint8_t>(pool, P); c.p_accepted = own<uint8_t>(pool, P);
+    {   // shared-GPU tables (KaiCtx, KAI_SHARED_GPUS): nodes in name-rank order like every other node array
+        c.shared_on = shared ? 1 : 0;
+        double* por = own<double>(pool, P); int32_t* grp = own<int32_t>(pool, P); int32_t* ogrp = own<int32_t>(pool, P); int64_t* gm = own<int64_t>(pool, N);
+        int32_t next_new = KAI_NEW_GROUP;
+        for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && por[p] > 0) ? s->pod_gpu_group[p] : -1; ogrp[p] = -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
+        for (int n = 0; n < N; n++) gm[n] = s->node_gpu_memory ? s->node_gpu_memory[prep.perm[n]] : 100;
+        c.p_portion = por; c.p_group = grp; c.p_on_group = ogrp; c.n_gpu_mem = gm;
+        c.ng_id = own<int32_t>(pool, (size_t)N * KAI_GMAX); for (size_t i = 0; i < (size_t)N * KAI_GMAX; i++) c.ng_id[i] = -1;
+        c.ng_used = own<int64_t>(pool, (size_t)N * KAI_GMAX); c.ng_rel = own<int64_t>(pool, (size_t)N * KAI_GMAX); c.ng_alloc = own<int64_t>(pool, (size_t)N * KAI_GMAX);
+        c.ng_mark = own<uint32_t>(pool, N); c.ng_has_alloc = own<uint32_t>(pool, N);
+        c.next_new_group = own<int32_t>(pool, 1); c.next_new_group[0] = next_new;
+    }
     c.s_active_alloc = own<int32_t>(pool, S); c.s_active_used = own<int32_t>(pool, S); c.s_alive = own<int32_t>(pool, S); c.s_gated = own<int32_t>(pool, S); c.s_pipelined = own<int32_t>(pool, S);
     c.j_n_pending = own<int32_t>(pool, J); c.j_tta_valid = own<int32_t>(pool, J); c.j_tta_n = own<int32_t>(pool, J); c.tta = own<int32_t>(pool, P);
     c.j_tta_res = own<double>(pool, (size_t)4 * J); c.j_allocated = own<double>(pool, (size_t)4 * J);
@@ -166,16 +188,22 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     auto t0 = std::chrono::steady_clock::now();
 
     // ---- serial twins of the session-open kernels (kai_kernels.hpp)
-    for (int p = 0; p < P; p++) {  // k_node_accounting
+    std::vector<int> acct(P); for (int p = 0; p < P; p++) acct[p] = p;
+    if (shared) std::sort(acct.begin(), acct.end(), [&](int a, int b) { return s->pod_uid_rank[a] < s->pod_uid_rank[b]; });  // AddTasksToNode order of the fixtures (nodes_fake/nodes.go:289-302): the shared-GPU guards are order sensitive
+    for (int p = 0; p < P; p++) c.p_on_node[p] = -1;
+    for (int pi = 0; pi < P; pi++) {  // k_node_accounting
+        const int p = acct[pi];
         int st = c.p_status[p], n = c.p_node[p];
-        c.p_on_node[p] = -1;
         if (!st_active_used(st) || n < 0 || n >= N) continue;
         c.p_on_node[p] = n; c.p_on_node_status[p] = st; c.p_accepted[p] = 1;
+        if (shared && c.p_portion[p] > 0 && c.p_group[p] >= 0) { c.p_on_group[p] = c.p_group[p]; }
         for (int r = 0; r < R; r++) {
+            if (shared && r == KAI_RES_GPU && c.p_portion[p] > 0) continue;
             double v = c.p_req[(size_t)r * P + p]; if (v == 0) continue; size_t i = (size_t)r * N + n;
             c.n_used[i] += v;
             if (st == KAI_POD_RELEASING) { c.n_rel[i] += v; c.n_idle[i] -= v; } else if (st == KAI_POD_PIPELINED) c.n_rel[i] -= v; else c.n_idle[i] -= v;
         }
+        if (shared && c.p_portion[p] > 0 && c.p_on_group[p] >= 0) { SgNode g{c, n}; if (!g.add(st, g.mem_of(c.p_portion[p]), c.p_on_group[p])) return KAI_ERR_UNSUPPORTED; }
     }
     if (c.plugins & KAI_PLUGIN_PROPORTION) {  // k_total_nodes + k_total_foreign
         for (int n = 0; n < N; n++) {
@@ -268,6 +296,8 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (c.st->fault) { if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: engine fault %d at line %d\n", c.st->fault, c.st->fault_line); return KAI_ERR_DEVICE_FAULT; }
     if (n_ops) *n_ops = c.st->out_len;
     if (ops_out) { if (c.st->out_len > ops_cap) return KAI_ERR_CAPACITY; std::memcpy(ops_out, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)); for (int64_t i = 0; i < c.st->out_len; i++) if (ops_out[i].node >= 0) ops_out[i].node = prep.perm[ops_out[i].node]; }
+    g_last_groups.assign(P, -1);
+    for (int p = 0; p < P; p++) if (shared && c.p_portion[p] > 0 && st_active_used(c.p_status[p])) g_last_groups[p] = c.p_group[p];
     if (pod_status_out) std::memcpy(pod_status_out, c.p_status, (size_t)P * 4);
     if (pod_node_out) for (int p = 0; p < P; p++) pod_node_out[p] = c.p_node[p] >= 0 ? prep.perm[c.p_node[p]] : -1;
     if (shares_final) fill(shares_final);

@@ -80,7 +80,7 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"oracle rc={rc}")
         groups = np.full(P, -1, np.int32)
-        if hasattr(lib, "kai_oracle_last_gpu_groups") and cls is Oracle:
+        if hasattr(lib, "kai_oracle_last_gpu_groups"):
             lib.kai_oracle_last_gpu_groups(groups.ctypes.data_as(C.POINTER(C.c_int32)), P)
         return Result(gpu_groups=groups, ops=[(o.kind, o.pod, o.node, o.job) for o in ops[: n_ops.value]], pod_status=status, pod_node=node,
                       shares_open=shares_to_np(sh_open, Q), shares_final=shares_to_np(sh_fin, Q), nodes=nodes_to_np(nodes, N, snap.n_res),
