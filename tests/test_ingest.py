@@ -623,7 +623,7 @@ def test_fraction_fields_and_oracle_placement():
     i2 = {n.split("/")[1]: i for i, n in enumerate(s2.pod_names)}
     assert res.pod_status[i2["pend"]] == ST["Binding"] and s2.node_names[res.pod_node[i2["pend"]]] == "node0" and res.gpu_groups[i2["pend"]] == 1
     assert res.pod_status[i2["whole"]] == ST["Binding"]
-    # the device path refuses the snapshot loudly instead of mis-accounting the shared GPU (host-compiled engine: same rule as libkai_core)
+    # the host-compiled engine (shared-GPU code compiled in) places the same; libkai_core, built without it, refuses such a snapshot
     import test_engine_hostsim as H
-    with pytest.raises(RuntimeError):
-        H.HostSim.run(s2, g2.config, ("allocate",))
+    sim = H.HostSim.run(s2, g2.config, ("allocate",))
+    assert sim.ops == res.ops and sim.gpu_groups[i2["pend"]] == 1
