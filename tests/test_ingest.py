@@ -616,6 +616,7 @@ def test_fraction_fields_and_oracle_placement():
     for n in ("run", "uuid", "pend", "multi"):
         assert s.pod_flags[idx[n]] & abi.POD_CPU_FALLBACK
     # drop the pods the oracle does not model (several devices per pod) and let it place the rest
+    nodes[1]["metadata"]["labels"]["nvidia.com/gpu.memory"] = "40537"  # one GPU memory size for the cluster: what the engine twin admits
     keep = doc(nodes=nodes, queues=[queue("q")], pods=[p for p in pods if p["metadata"]["name"] != "multi"], pod_groups=[pod_group(f"j{i}", priorityClassName="p") for i in range(4)],
                priorityClasses=[{"metadata": {"name": "p"}, "value": 100}])
     g2 = ingest(keep); s2 = g2.snapshot
