@@ -259,7 +259,8 @@ typedef struct kai_snapshot_soa {
 
     /* ---- fractional GPU requests (ABI v4; all optional, NULL = no pod asks for a fraction) ----
      * pod_gpu_portion: 0 = a whole-GPU or CPU-only pod; in (0, 1) = a fraction of ONE device (annotation gpu-fraction,
-     *   api/pod_info/pod_info.go:472-477); pod_req's gpu column then holds the same portion (ResourceRequirements.GPUs()).
+     *   api/pod_info/pod_info.go:472-477); pod_req's gpu column then holds ResourceRequirements.GPUs() of it: the portion rounded to 1/100
+     *   (fixed point, api/resource_info/gpu_resource_requirment.go:230-234) — 0.125 counts as 0.13 against quota, and as int64(0.125 * memory) on the device.
      * pod_gpu_group: the shared-GPU group an ACTIVE fraction pod runs in (label runai-gpu-group; PodInfo.GPUGroups), as an id >= 0 that is
      *   unique on its node; -1 = none.  Equality on one node is what the accounting uses (api/node_info/gpu_sharing_node_info.go); in addition
      *   ids below 2^20 stand for numeric group names and ids from 2^20 on for any other name, because the predicates plugin takes a

@@ -169,6 +169,9 @@ struct SolverCtx {
     uint8_t *vq_in, *vq_excl, *ja_in;                 // [J] victims-queue membership, "view excludes recorded tasks", jobsToAllocate membership (bit 1 = victim job)
     uint8_t *p_taken, *p_recorded, *p_partial, *ig_cache;  // [P]
     int32_t *p_grp;                                   // [P] task group (representative clone) of a victim pod in the current scenario
+#ifdef KAI_SHARED_GPUS
+    int32_t* xr_group;  // shared-GPU group of that further copy
+#endif
     int64_t* xr_key; int32_t* xr_status; int32_t xr_mask, xr_pad;  // further node residencies of a pod, hash (pod, node) → status the node's copy was added with:
                                                       // an evicted task stays on its node as Releasing while it is pipelined elsewhere (statement.go:197-295)
     // the two solver-internal job-order instances (index 0 = victims queue, 1 = jobs to allocate): same records and heaps as the action's own
@@ -355,6 +358,9 @@ struct SgNode {
     KAI_HD int slot(int g) const {  // the map entry of group g, created on first write; -1 = table full
         int s = find(g); if (s >= 0) return s;
         for (s = 0; s < KAI_GMAX; s++) if (id(s) < 0) { id(s) = g; used(s) = 0; rel(s) = 0; alloc(s) = 0; c.ng_mark[n] &= ~(1u << s); c.ng_has_alloc[n] &= ~(1u << s); return s; }
+        // table full: take over the entry of a group that was opened inside a rolled-back simulation and is empty again.  Its id came from the
+        // new-group counter, so nothing can name it any more, and an all-zero unmarked entry takes part in no sum, fit or count of the node.
+        for (s = 0; s < KAI_GMAX; s++) if (id(s) >= KAI_NEW_GROUP && used(s) == 0 && rel(s) == 0 && alloc(s) == 0 && !marked(s)) { id(s) = g; c.ng_has_alloc[n] &= ~(1u << s); return s; }
         return -1;
     }
     KAI_HD bool marked(int s) const { return (c.ng_mark[n] >> s) & 1u; }
@@ -364,7 +370,7 @@ struct SgNode {
     KAI_HD bool releasing_from_shared(int s) const { return used(s) != 0 && rel(s) == used(s); }                                        // :253-263 (a found key with value 0 != used)
     KAI_HD bool fit_on_group(int s, int64_t mem) const { return used(s) != 0 && gpu_mem() - alloc(s) + rel(s) - mem >= 0 && alloc(s) != rel(s); }  // IsTaskFitOnGpuGroup :350-354
     KAI_HD bool enough_idle(int s, int64_t mem) const { return ((c.ng_has_alloc[n] >> s) & 1u) && gpu_mem() - alloc(s) - mem >= 0; }              // EnoughIdleResourcesOnGpu :356-363
-    KAI_HD int count_fit(int64_t mem) const { int k = 0; for (int s = 0; s < KAI_GMAX; s++) if (id(s) >= 0 && fit_on_group(s, mem)) k++; return k; }  // fractionTaskGpusAllocatableDeviceCount (count = 1)
+    KAI_HD int count_fit(int64_t mem) const { for (int s = 0; s < KAI_GMAX; s++) if (id(s) >= 0 && fit_on_group(s, mem)) return 1; return 0; }  // fractionTaskGpusAllocatableDeviceCount: stops at the device count of the task, 1
     // addSharedTaskResourcesPerPodGroup :83-136 / removeSharedTaskResourcesPerPodGroup :153-235; false = table full
     KAI_HD bool add(int status, int64_t mem, int g) const {
         int s = slot(g); if (s < 0) return false;
@@ -404,6 +410,13 @@ struct SgNode {
             if (releasing_from_shared(s) && !marked(s)) { rel_gpu() += 1; c.ng_mark[n] |= 1u << s; }
         }
         return true;
+    }
+    KAI_HD int next_slot_by_id(int prev_id) const { int best = -1; for (int s = 0; s < KAI_GMAX; s++) if (id(s) > prev_id && (best < 0 || id(s) < id(best))) best = s; return best; }  // ranges the maps in ascending group id
+    KAI_HD double sum_available_shared() const {  // getSumOfAvailableSharedGPUs :289-300
+        double sum = 0; for (int s = next_slot_by_id(-1); s >= 0; s = next_slot_by_id(id(s))) if (((c.ng_has_alloc[n] >> s) & 1u) && alloc(s) > 0) sum += 1 - frac_of(alloc(s)); return sum;
+    }
+    KAI_HD double sum_releasing_shared() const {  // getSumOfReleasingSharedGPUs :302-313
+        double sum = 0; for (int s = next_slot_by_id(-1); s >= 0; s = next_slot_by_id(id(s))) if (rel(s) > 0 && !releasing_from_shared(s)) sum += frac_of(rel(s)); return sum;
     }
     // FittingGPUs (framework/session.go:163-199): groups that can take the task in ascending id, then one entry per idle-or-releasing whole GPU,
     // stably ordered by the GPU order score (gpupack: used portion; gpuspread: 1 - used portion, 1 for a whole GPU).  out[] holds slots, or
@@ -743,8 +756,21 @@ struct Engine {
         cx().j_tta_valid[j] = 0;
     }
 
+    // NodeInfo.GetSumOfIdleGPUs / GetSumOfReleasingGPUs (node_info.go:592-628): whole GPUs plus, with shared GPUs, the free / releasing portions on them
+    KAI_HD double gpus_idle_sum(int n) const {
+#ifdef KAI_SHARED_GPUS
+        if (cx().shared_on) { SgNode g{cx(), n}; return g.sum_available_shared() + cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n]; }
+#endif
+        return cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n];
+    }
+    KAI_HD double gpus_rel_sum(int n) const {
+#ifdef KAI_SHARED_GPUS
+        if (cx().shared_on) { SgNode g{cx(), n}; return g.sum_releasing_shared() + cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n]; }
+#endif
+        return cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n];
+    }
     // ------------------------------------------------------------------ node accounting (api/node_info/node_info.go)
-    KAI_HD void node_apply(int n, int p, int status, double sign) {  // addTaskResources :457-493 / removeTaskResources :515-551
+    KAI_HD void node_apply(int n, int p, int status, double sign, int grp_of_copy = -2) {  // addTaskResources :457-493 / removeTaskResources :515-551
         for (int r = 0; r < cx().R; r++) {
             double v = preq(p, r); if (v == 0) continue;
 #ifdef KAI_SHARED_GPUS
@@ -758,7 +784,7 @@ struct Engine {
         }
 #ifdef KAI_SHARED_GPUS
         if (cx().shared_on && cx().p_portion[p] > 0) {  // addSharedTaskResources / removeSharedTaskResources with the group of the node's own copy
-            SgNode g{cx(), n}; const int grp = cx().p_on_group[p];
+            SgNode g{cx(), n}; const int grp = grp_of_copy != -2 ? grp_of_copy : cx().p_on_group[p];
             if (grp >= 0) { bool ok = sign > 0 ? g.add(status, g.mem_of(cx().p_portion[p]), grp) : g.remove(status, g.mem_of(cx().p_portion[p]), grp); if (!ok) fault(FAULT_INTERNAL); }
         }
 #endif
@@ -780,6 +806,9 @@ struct Engine {
         if (cx().p_on_node[p] >= 0) {
             if constexpr (kVictim) {
                 xr_insert(p, n, cx().p_status[p]);
+#ifdef KAI_SHARED_GPUS
+                if (cx().shared_on) { sx().xr_group[xr_find(p, n)] = cx().p_group[p]; node_apply(n, p, cx().p_status[p], 1.0, cx().p_group[p]); return true; }
+#endif
                 node_apply(n, p, cx().p_status[p], 1.0);
                 return true;
             }
@@ -803,9 +832,28 @@ struct Engine {
             cx().p_on_node[p] = -1;
             return true;
         }
-        if constexpr (kVictim) { int h = xr_find(p, n); if (h >= 0) { node_apply(n, p, sx().xr_status[h], -1.0); sx().xr_key[h] = -2; return true; } }
+        if constexpr (kVictim) { int h = xr_find(p, n); if (h >= 0) {
+#ifdef KAI_SHARED_GPUS
+            if (cx().shared_on) { node_apply(n, p, sx().xr_status[h], -1.0, sx().xr_group[h]); sx().xr_key[h] = -2; return true; }
+#endif
+            node_apply(n, p, sx().xr_status[h], -1.0); sx().xr_key[h] = -2; return true; } }
         return false;
     }
+#ifdef KAI_SHARED_GPUS
+    KAI_HD int group_on_node(int p, int n) const {  // GPUGroups of the node's own copy of the task
+        if (cx().p_on_node[p] == n) return cx().p_on_group[p];
+        if constexpr (kVictim) { int h = xr_find(p, n); if (h >= 0) return sx().xr_group[h]; }
+        return -1;
+    }
+    // ConsolidateSharedPodInfoToDifferentGPU (gpu_sharing_node_info.go:247-249 → addTask(ti, true)): the node's copy of the task is REPLACED — its
+    // amounts on the old GPU group stay booked as they are — and the task is added on its new group
+    KAI_HD void node_consolidate_shared(int n, int p) {
+        if (st_active_used(cx().p_status[p])) cx().p_accepted[p] = 1;
+        if (cx().p_on_node[p] == n) { cx().p_on_node_status[p] = cx().p_status[p]; cx().p_on_group[p] = cx().p_group[p]; node_apply(n, p, cx().p_status[p], 1.0); return; }
+        if constexpr (kVictim) { int h = xr_find(p, n); if (h >= 0) { sx().xr_status[h] = cx().p_status[p]; sx().xr_group[h] = cx().p_group[p]; node_apply(n, p, cx().p_status[p], 1.0, cx().p_group[p]); return; } }
+        fault(FAULT_INTERNAL);
+    }
+#endif
     KAI_HD bool node_update_task(int n, int p) { if (!node_remove_task(n, p)) return false; return node_add_task(n, p); }  // :571-576
 
     // ------------------------------------------------------------------ proportion event handlers (plugins/proportion/proportion.go:443-489)
@@ -848,13 +896,28 @@ struct Engine {
     }
     KAI_HD bool stmt_pipeline(int p, int n, bool update_if_exists) {  // :197-295
         bool found_on_node = on_node(p, n);
+#ifdef KAI_SHARED_GPUS
+        // a shared-GPU task that was evicted from this node and comes back on ANOTHER GPU of it (:208-213)
+        const bool shared_task = cx().shared_on && cx().p_portion[p] > 0;
+        const int grp_there = (shared_task && found_on_node) ? group_on_node(p, n) : -1;
+        const bool is_move = shared_task && found_on_node && cx().p_group[p] >= 0 && cx().p_group[p] != grp_there;
+        if (found_on_node && !update_if_exists && !is_move) { if (shared_task) cx().p_group[p] = grp_there; return stmt_unevict_earliest(p); }
+        int prev_group = shared_task ? cx().p_group[p] : -1;
+#else
         if (found_on_node && !update_if_exists) return stmt_unevict_earliest(p);
+#endif
         int prev_status = cx().p_status[p];
         update_task_status(p, KAI_POD_PIPELINED);
         int prev_node = cx().p_node[p]; cx().p_node[p] = n; int prev_virtual = cx().p_virtual[p];
+#ifdef KAI_SHARED_GPUS
+        if (is_move) { prev_group = grp_there; node_consolidate_shared(n, p); } else
+#endif
         if (found_on_node) node_update_task(n, p); else if (!node_add_task(n, p)) return false;
         queue_event(p, 1.0);
         StmtOp o{}; o.name = OP_PIPELINE; o.pod = p; o.prev_status = prev_status; o.prev_node = prev_node; o.next_node = n; o.prev_virtual = prev_virtual; o.op_index = -1;
+#ifdef KAI_SHARED_GPUS
+        o.pad = prev_group;
+#endif
         if (!push_op(o)) return false;
         cx().p_virtual[p] = 1;
         return true;
@@ -866,6 +929,9 @@ struct Engine {
         if (!node_update_task(n, p)) return false;
         queue_event(p, -1.0);
         StmtOp o{}; o.name = OP_EVICT; o.pod = p; o.prev_status = prev_status; o.prev_node = n; o.prev_virtual = prev_virtual; o.op_index = -1;
+#ifdef KAI_SHARED_GPUS
+        o.pad = cx().shared_on ? cx().p_group[p] : -1;
+#endif
         if (!push_op(o)) return false;
         cx().p_virtual[p] = 1;
         return true;
@@ -877,14 +943,24 @@ struct Engine {
         cx().p_node[p] = -1; cx().p_virtual[p] = (uint8_t)prev_virtual;
         queue_event(p, -1.0);
     }
-    KAI_HD void unpipeline(int p, int prev_node, int prev_status, int prev_virtual) {  // :431-476
+    KAI_HD void unpipeline(int p, int prev_node, int prev_status, int prev_virtual, int prev_group = -1) {  // :431-476
         update_task_status(p, prev_status);
+#ifdef KAI_SHARED_GPUS
+        if (cx().shared_on && cx().p_portion[p] > 0) cx().p_group[p] = prev_group;  // :452
+#else
+        (void)prev_group;
+#endif
         int host = cx().p_node[p]; cx().p_node[p] = prev_node; cx().p_virtual[p] = (uint8_t)prev_virtual;
         if (host >= 0) node_remove_task(host, p);
         queue_event(p, -1.0);
     }
-    KAI_HD void unevict(int p, int prev_status, int n, int prev_virtual) {  // :152-195
+    KAI_HD void unevict(int p, int prev_status, int n, int prev_virtual, int prev_group = -1) {  // :152-195
         update_task_status(p, prev_status);
+#ifdef KAI_SHARED_GPUS
+        if (cx().shared_on && cx().p_portion[p] > 0) cx().p_group[p] = prev_group;  // :167
+#else
+        (void)prev_group;
+#endif
         cx().p_virtual[p] = (uint8_t)prev_virtual;
         if (n >= 0) { if (on_node(p, n)) node_update_task(n, p); else node_add_task(n, p); }
         queue_event(p, 1.0);
@@ -901,8 +977,8 @@ struct Engine {
         if (!op_valid(index)) return;
         StmtOp op = cx().ops[index];
         switch (op.name) {
-            case OP_EVICT: unevict(op.pod, op.prev_status, op.prev_node, op.prev_virtual); break;
-            case OP_PIPELINE: unpipeline(op.pod, op.prev_node, op.prev_status, op.prev_virtual); break;
+            case OP_EVICT: unevict(op.pod, op.prev_status, op.prev_node, op.prev_virtual, op.pad); break;
+            case OP_PIPELINE: unpipeline(op.pod, op.prev_node, op.prev_status, op.prev_virtual, op.pad); break;
             case OP_ALLOCATE: unallocate(op.pod, op.prev_virtual); break;
             default: {  // undo of an undo = redo the original operation (:606-623)
                 if constexpr (kVictim) {

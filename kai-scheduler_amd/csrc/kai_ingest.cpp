@@ -575,7 +575,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         {   // a fraction of ONE device (pod_info.go:472-477) is described to the ABI (v4); the pod still goes to the CPU fallback until the device models shared GPUs
             char* e = nullptr; const std::string& fs = ann["gpu-fraction"].str(); double fv = fs.empty() ? 0.0 : strtod(fs.c_str(), &e);
             if (!fs.empty() && !*e && fv > 0 && fv < 1 && ann["gpu-memory"].str().empty() && ann["gpu-fraction-num-devices"].str().empty()) {
-                r.gpu_portion = fv; r.req.gpu = fv; r.gpu_group = md["labels"]["runai-gpu-group"].str();  // common/resources/gpu_sharing.go:87-100
+                r.gpu_portion = fv; r.req.gpu = (double)std::llround(fv * 100.0) / 100.0;  /* GPUs() is fixed point, 1/100 (gpu_resource_requirment.go:230-234) */ r.gpu_group = md["labels"]["runai-gpu-group"].str();  // common/resources/gpu_sharing.go:87-100
             }
         }
         if (spec["resourceClaims"].is_arr() && !spec["resourceClaims"].a.empty()) fb = true;

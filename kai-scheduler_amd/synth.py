@@ -363,7 +363,7 @@ def add_fractions(snap: abi.Snapshot, seed: int, frac: float = 0.4, portions=(0.
         st = int(a["pod_status"][p])
         if st != S["Pending"] and not (st & active):
             continue
-        v = float(rng.choice(portions)); portion[p] = v; a["pod_req"][abi.RES_GPU, p] = v
+        v = float(rng.choice(portions)); portion[p] = v; a["pod_req"][abi.RES_GPU, p] = np.floor(v * 100.0 + 0.5) / 100.0  # GPUs(): 1/100 fixed point
         if st & active:
             n = int(a["pod_node"][p]); need = int(round(v * 100))
             for g, used in enumerate(fill[n]):

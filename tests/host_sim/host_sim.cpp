@@ -116,8 +116,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (!cfg || !s || s->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
     bool shared = false;
     if (s->pod_gpu_portion) for (int p = 0; p < s->n_pods; p++) if (s->pod_gpu_portion[p] > 0) shared = true;
-    if (shared) {  // shared GPUs in the engine: the allocate action, one GPU memory size for the whole cluster (the queue-capacity step stays node independent)
-        for (int i = 0; i < n_actions; i++) if (actions[i] != KAI_ACTION_ALLOCATE) return KAI_ERR_UNSUPPORTED;
+    if (shared) {  // shared GPUs in the engine: one GPU memory size for the whole cluster (the queue-capacity step stays node independent)
         if (s->node_gpu_memory) for (int n = 1; n < s->n_nodes; n++) if (s->node_gpu_memory[n] != s->node_gpu_memory[0]) return KAI_ERR_UNSUPPORTED;
     }
     const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
@@ -263,7 +262,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.q_reclaim_mr = s->queue_reclaim_min_runtime_ns ? copy(pool, s->queue_reclaim_min_runtime_ns, Q) : nullptr;
     c.now_ns = cfg->now_ns; c.def_preempt_mr = cfg->default_preempt_min_runtime_ns; c.def_reclaim_mr = cfg->default_reclaim_min_runtime_ns; c.reclaim_method = cfg->reclaim_resolve_method;
     c.max_consolidation_preemptees = cfg->max_consolidation_preemptees; c.allow_consolidating_reclaim = cfg->allow_consolidating_reclaim; c.saturation_multiplier = cfg->reclaimer_saturation_multiplier;
-    { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; }
+    { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; c.sv.xr_group = own<int32_t>(pool, (size_t)c.sv.xr_mask + 1); }
     HostBackend be; Engine<HostBackend> eng(c, be);
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;

@@ -199,3 +199,53 @@ def test_hostsim_fraction_fuzz(seed):
     res = HostSim.run(snap, cfg, ("allocate",))
     assert_same(res, ref, share_tol=1e-9)
     _same_groups(snap, res, ref)
+
+
+def _fraction_victim_goldens():
+    """Golden cases outside allocateFractionalGpu_test.go that hold fraction pods (reclaim / preempt / consolidation / integration tables)."""
+    import test_oracle_golden as G
+    out = []
+    for name, i, case, actions in G.ALL:
+        if name == "allocate__allocateFractionalGpu": continue
+        try:
+            T.case_to_snapshot(case)
+        except T.Unsupported as e:
+            if "fractional gpu (oracle" in str(e): out.append((name, i, case, actions))
+    return out
+
+
+FRAC_VICTIM_GOLD = _fraction_victim_goldens()
+
+
+@pytest.mark.parametrize("name,i,case,actions", FRAC_VICTIM_GOLD, ids=[f"{n}[{i}]" for n, i, _, _ in FRAC_VICTIM_GOLD])
+def test_hostsim_fractional_victim_goldens(name, i, case, actions):
+    """Victim actions over shared GPUs: eviction of fraction pods, their re-placement on another GPU group of the same node
+    (ConsolidateSharedPodInfoToDifferentGPU), statement undo with the previous groups — engine twin against the oracle and the reference's tables."""
+    snap, cfg, meta = T.case_to_snapshot(case, fractions=True)
+    ref = T.Oracle.run(snap, cfg, actions)
+    res = HostSim.run(snap, cfg, actions)
+    assert_same(res, ref, share_tol=1e-9)
+    _same_groups(snap, res, ref)
+    assert not T.check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes, res.gpu_groups)
+
+
+FRAC_ACTS = (("reclaim",), ("preempt",), ("consolidation",), ("allocate", "consolidation", "reclaim", "preempt"), ("allocate", "reclaim"), ("allocate", "preempt"), ("reclaim", "preempt"))
+
+
+@pytest.mark.parametrize("seed", range(70))
+def test_hostsim_fraction_victim_fuzz(seed):
+    """Crowded clusters with fraction pods under every victim action.  The portions are multiples of 1/4: quota sums stay exact in float64, so the
+    exact comparisons of the proportion plugin (resource_quantities.go:59-97) cannot flip on the order of addition (the reference ranges Go maps
+    there, so with portions like 0.2 its own outcome at an exact tie is not defined).  Node accounting is compared bit for bit — including what a
+    rolled-back simulation leaves behind on a node whose victim was re-placed on another GPU group (the first copy stays booked in the reference)."""
+    snap = T.pkg.synth.make_crowded_snapshot(2 + seed % 7, 9500 + seed, fill=0.6 + 0.35 * (seed % 5) / 4, n_pending_jobs=4 + seed % 11, elastic_frac=0.2 * (seed % 2),
+                                             hog_frac=0.5, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3])
+    T.pkg.synth.add_fractions(snap, seed, frac=(0.3, 0.6, 0.9)[seed % 3], portions=((0.25, 0.25, 0.5, 0.75), (0.25, 0.5, 0.5, 0.75), (0.5,))[seed % 3])
+    cfg = T.abi.default_config(max_consolidation_preemptees=(-1, 16, 2)[seed % 3], gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=(0.0, 0.5, 1.0)[seed % 3])
+    cfg.use_scheduling_signatures = seed % 2
+    if seed % 3 == 0: cfg.plugins = (cfg.plugins & ~T.abi.PLUGINS["gpupack"]) | T.abi.PLUGINS["gpuspread"]
+    for acts in (FRAC_ACTS[seed % len(FRAC_ACTS)], FRAC_ACTS[3]):
+        ref = T.Oracle.run(snap, cfg, acts)
+        res = HostSim.run(snap, cfg, acts)
+        assert_same(res, ref, share_tol=1e-9)
+        _same_groups(snap, res, ref)

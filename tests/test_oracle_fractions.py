@@ -54,14 +54,13 @@ def test_fraction_cycles_keep_the_accounting_invariants(seed):
         assert again.ops == res.ops and np.array_equal(again.gpu_groups < (1 << 20), res.gpu_groups < (1 << 20))
 
 
-def test_engine_twin_takes_fractions_for_allocate_only():
-    """The host-compiled engine carries the shared-GPU code (KAI_SHARED_GPUS): allocate runs and matches the oracle; the victim actions are
-    refused until GPU groups travel through its solver.  libkai_core itself is built without the flag and refuses such snapshots outright."""
+def test_engine_twin_takes_fractions():
+    """The host-compiled engine carries the shared-GPU code (KAI_SHARED_GPUS) for every action and matches the oracle (test_engine_hostsim.py holds
+    the goldens and the fuzz).  libkai_core itself is built without the flag and refuses such snapshots outright."""
     import test_engine_hostsim as H
     snap = pkg.synth.make_crowded_snapshot(4, 9000)
-    pkg.synth.add_fractions(snap, 1, frac=1.0)
+    pkg.synth.add_fractions(snap, 1, frac=1.0, portions=(0.25, 0.5, 0.75))
     cfg = abi.default_config()
-    ref, res = T.Oracle.run(snap, cfg, ("allocate",)), H.HostSim.run(snap, cfg, ("allocate",))
-    assert res.ops == ref.ops and np.array_equal(res.pod_status, ref.pod_status)
-    with pytest.raises(RuntimeError):
-        H.HostSim.run(snap, cfg, ("allocate", "reclaim"))
+    for acts in (("allocate",), ("allocate", "reclaim"), ("allocate", "consolidation", "reclaim", "preempt")):
+        ref, res = T.Oracle.run(snap, cfg, acts), H.HostSim.run(snap, cfg, acts)
+        assert res.ops == ref.ops and np.array_equal(res.pod_status, ref.pod_status) and np.array_equal(res.pod_node, ref.pod_node)
