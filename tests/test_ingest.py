@@ -628,3 +628,18 @@ def test_fraction_fields_and_oracle_placement():
     import test_engine_hostsim as H
     sim = H.HostSim.run(s2, g2.config, ("allocate",))
     assert sim.ops == res.ops and sim.gpu_groups[i2["pend"]] == 1
+
+
+def test_fraction_request_is_fixed_point():
+    """ResourceRequirements.GPUs() of a fraction is fixed point, 1/100 (api/resource_info/gpu_resource_requirment.go:230-234: math.Round(portion * 100)):
+    a gpu-fraction of 0.125 counts as 0.13 against the queue, 0.374 as 0.37 — while the memory it takes on the device stays int64(portion * memory)."""
+    frac = lambda v: {"annotations": {"gpu-fraction": v}}
+    got = ingest(doc(nodes=[node("node0", gpu="2")], queues=[queue("q")], pod_groups=[pod_group(f"j{i}") for i in range(3)],
+                     pods=[pod("a", "j0", requests={"cpu": "1"}, **frac("0.125")), pod("b", "j1", requests={"cpu": "1"}, **frac("0.374")), pod("c", "j2", requests={"cpu": "1"}, **frac("0.5"))]))
+    s = got.snapshot
+    idx = {n.split("/")[1]: i for i, n in enumerate(s.pod_names)}
+    assert [float(s.pod_gpu_portion[idx[n]]) for n in "abc"] == [0.125, 0.374, 0.5]
+    assert [float(s.pod_req[abi.RES_GPU, idx[n]]) for n in "abc"] == [0.13, 0.37, 0.5]
+    res = T.Oracle.run(s, got.config, ("allocate",))
+    q = int(s.job_queue[s.pod_job[idx["a"]]])
+    assert abs(res.shares_final["allocated"][q][2] - 1.0) < 1e-12  # 0.13 + 0.37 + 0.5
