@@ -249,3 +249,15 @@ def test_hostsim_fraction_victim_fuzz(seed):
         res = HostSim.run(snap, cfg, acts)
         assert_same(res, ref, share_tol=1e-9)
         _same_groups(snap, res, ref)
+
+
+@pytest.mark.parametrize("seed", range(3000, 3040))
+def test_hostsim_broad_random_cycles_with_fractions(seed):
+    """The broad campaign (topology, sub-groups, minruntime, signatures, every action order) with a share of the one-GPU pods turned into fraction
+    pods on shared GPUs — tools/host_campaign.py with CAMPAIGN_FRACTIONS=1 ran 9 000 such cycles identical to the oracle."""
+    for ci in range(len(T.broad_case(seed))):
+        snap, cfg, actions = T.broad_case(seed)[ci]  # the cases of one seed share snapshot objects: take a fresh one before changing it
+        T.pkg.synth.add_fractions(snap, seed * 7 + ci, frac=(0.3, 0.6, 0.9)[(seed + ci) % 3], portions=((0.25, 0.5, 0.75), (0.5,), (0.25, 0.25, 0.5))[seed % 3])
+        ref, res = T.Oracle.run(snap, cfg, actions), HostSim.run(snap, cfg, actions)
+        assert_same(res, ref, share_tol=1e-9)
+        _same_groups(snap, res, ref)
