@@ -238,8 +238,30 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             x.allocated += al[k]; x.request += rq[k]; if (!c.j_preempt[j]) x.allocated_np += al[k];
         }
     }
+    // With fraction pods the queue sums are sums of non-integers and their last bit depends on the order of addition.  The device kernels roll pods
+    // up job by job and queue by queue; the reference walks pod by pod up the ancestry in Go-map order (proportion.go:347-401), the oracle in (job,
+    // status, pod) order.  KAI_HOSTSIM_POD_ORDER_SUMS=1 makes this harness add in the oracle's order, which takes the order of addition out of a
+    // comparison with arbitrary portions (0.2, 0.3 ...): what then still differs is control flow.
+    const bool pod_order_sums = shared && (c.plugins & KAI_PLUGIN_PROPORTION) && std::getenv("KAI_HOSTSIM_POD_ORDER_SUMS");
+    if (pod_order_sums) {
+        for (int q = 0; q < Q; q++) for (int k = 0; k < 3; k++) { QShare& x = c.q_share[(size_t)q * 3 + k]; x.allocated = 0; x.allocated_np = 0; x.request = 0; }
+        std::vector<int> ord;
+        for (int j = 0; j < J; j++) {
+            if (c.j_queue[j] < 0) continue;
+            ord.clear(); for (int i = 0; i < c.j_n_pods[j]; i++) ord.push_back(c.j_first_pod[j] + i);
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return c.p_status[a] < c.p_status[b]; });
+            for (int p : ord) {
+                const int st = c.p_status[p]; const bool al = st_allocated(st) && c.p_accepted[p], pe = st == KAI_POD_PENDING;
+                if (!al && !pe) continue;
+                for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
+                    QShare& x = c.q_share[(size_t)q * 3 + k]; const double v = c.p_req[(size_t)(k == 0 ? KAI_RES_CPU : k == 1 ? KAI_RES_MEM : KAI_RES_GPU) * P + p];
+                    x.request += v; if (al) { x.allocated += v; if (!c.j_preempt[j]) x.allocated_np += v; }
+                }
+            }
+        }
+    }
     if (c.plugins & KAI_PLUGIN_PROPORTION) {
-        for (int i = 0; i < Q; i++) {  // k_tree_usage
+        if (!pod_order_sums) for (int i = 0; i < Q; i++) {  // k_tree_usage
             int q = prep.depth_order[i], par = c.q_parent[q]; if (par < 0) continue;
             for (int k = 0; k < 3; k++) { QShare& x = c.q_share[(size_t)q * 3 + k]; QShare& d = c.q_share[(size_t)par * 3 + k]; d.allocated += x.allocated; d.allocated_np += x.allocated_np; d.request += x.request; }
         }
