@@ -1,0 +1,111 @@
+// kai_batch_driver.hpp — host side of the batch path: buffers, qualification and the round loop (plan → fill → apply), written once against
+// a Launcher (kai_core.hip: HIP launches on the session's stream; tests/host_sim: the lock-step emulator of kai_simt.hpp).
+//
+// Launcher interface:  void <kernel>(grid, block, args...)  for every kernel of kai_batch_kernels.hpp,
+//                      int read(void* host_dst, const void* dev_src, size_t bytes)   (synchronises),
+//                      int write(void* dev_dst, const void* host_src, size_t bytes).
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "kai_host_prep.hpp"
+
+namespace kai {
+
+struct BatchStats {
+    int64_t rounds = 0, mismatches = 0, planned = 0;
+    int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0;
+    int64_t fill_cycles = 0, fill_load = 0, fill_update = 0, fill_rescan = 0, block_loads = 0, rescans1 = 0, rescans2 = 0, rescans3 = 0;
+    int32_t drain = 0, ran = 0, max_h = 0, pad = 0;
+};
+
+// pools: every queued job can be an element of its leaf and of every ancestor (incl. the virtual root)
+inline size_t batch_pool_e(const HostPrep& prep, int J, int Q) { return (size_t)J * (size_t)prep.n_heights + 2 * (size_t)Q + 64; }
+inline size_t batch_pool_k(const HostPrep& prep, int J, int Q) { return (size_t)J * (size_t)prep.n_heights + 2 * (size_t)Q + 64; }
+
+// zalloc(bytes) -> zero-filled memory the kernels can address; upload(dst, src, bytes)
+template <class ZAlloc, class Upload>
+int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload) {
+    BatchCtx& b = c.bt;
+    b = BatchCtx{};
+    b.enabled = prep.batch_ok && c.use_index && c.all_tracked && c.fast_ok && c.R <= 4 && (c.plugins & KAI_PLUGIN_PROPORTION) ? 1 : 0;
+    if (!b.enabled) return 0;
+    const int Q = c.Q, J = c.J, P = c.P;
+    b.n_h = prep.n_heights; b.pool_e = (int32_t)batch_pool_e(prep, J, Q); b.pool_k = (int32_t)batch_pool_k(prep, J, Q);
+#define KB_Z(field, n) do { void* p_ = zalloc(std::max<size_t>((size_t)(n), 1) * sizeof(*b.field)); if (!p_) return KAI_ERR_HIP; b.field = (decltype(b.field))p_; } while (0)
+    KB_Z(q_height, Q + 1); KB_Z(h_off, b.n_h + 1); KB_Z(h_nodes, Q + 1); KB_Z(q_srank, Q + 1);
+    KB_Z(j_clsmask, J); KB_Z(cur_sp, Q + 1); KB_Z(qual, 4);
+    KB_Z(q_cnt, Q + 1); KB_Z(q_ebase, Q + 1); KB_Z(q_kbase, Q + 1); KB_Z(q_valid, Q + 1); KB_Z(q_nk, Q + 1); KB_Z(q_sent, Q + 1); KB_Z(q_taken, Q + 1); KB_Z(q_complete, Q + 1);
+    KB_Z(pk, b.pool_k); KB_Z(sp, b.pool_k); KB_Z(k_owner, b.pool_k);
+    KB_Z(el_leaf, b.pool_e); KB_Z(el_ck, b.pool_e); KB_Z(el_next, b.pool_e); KB_Z(e_job, b.pool_e); KB_Z(e_grank, b.pool_e); KB_Z(e_flag, b.pool_e);
+    KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
+    KB_Z(t_cls, P); KB_Z(t_node, P);
+    KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1);
+#undef KB_Z
+    if (int rc = upload((void*)b.q_height, prep.q_height.data(), prep.q_height.size() * 4)) return rc;
+    if (int rc = upload((void*)b.h_off, prep.h_off.data(), prep.h_off.size() * 4)) return rc;
+    if (int rc = upload((void*)b.h_nodes, prep.h_nodes.data(), prep.h_nodes.size() * 4)) return rc;
+    return 0;
+}
+
+// LDS of the fill kernel: super-block level always, block level when it fits beside it
+inline size_t batch_fill_lds(const KaiCtx& c, int& l1_in_lds) {
+    const size_t l2 = ((size_t)c.C * c.NSB * 12 + 15) & ~(size_t)15, l1 = (size_t)c.C * c.NB * 12 + 16;
+    const size_t budget = 160 * 1024 - 24 * 1024;  // static LDS of the kernel (class table, tops, rollback list) + margin
+    l1_in_lds = (l2 + l1 <= budget) ? 1 : 0;
+    return l2 + (l1_in_lds ? l1 : 0);
+}
+
+// Runs the allocate action on the batch path.  ran = false: the action does not qualify, nothing was touched (run the sequential engine).
+// On return with ran: out_len / counters are in bs; drain = the remaining queue is to be resolved by k_drain (no class fits anywhere).
+template <class L>
+int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStats& bs, int64_t ops_base0 = 0) {
+    bs = BatchStats{};
+    if (!c.bt.enabled || c.action != KAI_ACTION_ALLOCATE || c.queue_depth > 0 || !c.fast_ok) return 0;
+    const int TB = 256, Q = c.Q, J = c.J;
+    int32_t qual[4] = {0, 0, 0, 0};
+    if (int rc = l.write((void*)c.bt.qual, qual, sizeof qual)) return rc;
+    if (Q) { l.static_rank((Q + TB - 1) / TB, TB, c); l.static_check((Q + TB - 1) / TB, TB, c); }
+    if (J) l.qualify((J + TB - 1) / TB, TB, c);
+    if (int rc = l.read(qual, (const void*)c.bt.qual, sizeof qual)) return rc;
+    if (qual[0] || qual[1]) return 0;
+    bs.ran = 1;
+    int remaining = qual[2];
+    l.nrec((c.NB * KAI_BLOCK + TB - 1) / TB, TB, c);
+    int l1_in_lds = 0; const size_t dyn = batch_fill_lds(c, l1_in_lds);
+    RoundParams rp{}; rp.mode = 1;
+    l.fill(1, 64, dyn, c, rp, l1_in_lds);
+    FillStatus fs{};
+    if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc;
+    int H = 16; int64_t ops_base = ops_base0;
+    while (remaining > 0) {
+        if (fs.all_dead) { bs.drain = 1; break; }
+        rp = RoundParams{}; rp.h_leaf = H; rp.mode = 0;
+        const int64_t e_bound = std::min<int64_t>(remaining, (int64_t)shape.n_leaves * H);
+        const int64_t slots = std::min<int64_t>(c.bt.pool_k, e_bound * shape.n_heights + Q + 1);
+        rp.n_slots = (int32_t)slots;
+        l.plan_setup(1, 256, c, rp);
+        l.plan_leaf(std::max(Q, 1), 64, c, rp);
+        for (int h = 1; h < shape.n_heights; h++) {
+            rp.height = h;
+            l.plan_rank((int)((slots + TB - 1) / TB), TB, c, rp);
+            l.plan_scan(std::max(shape.h_count[h], 1), 64, c, rp);
+        }
+        l.plan_emit((int)((e_bound + TB - 1) / TB), TB, c);
+        l.fill(1, 64, dyn, c, rp, l1_in_lds);
+        l.apply_jobs((int)((e_bound + TB - 1) / TB), TB, c, ops_base);
+        if (Q) l.apply_nodes((Q + TB - 1) / TB, TB, c);
+        if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc;
+        if (fs.n_done <= 0) return KAI_ERR_DEVICE_FAULT;  // a round always executes at least one job
+        bs.rounds++; bs.mismatches += fs.mismatch; bs.planned += fs.planned; bs.max_h = std::max(bs.max_h, H);
+        bs.decisions += fs.decisions; bs.attempted += fs.attempted; bs.committed += fs.committed; bs.rollbacks += fs.rollbacks; bs.ops += fs.ops;
+        bs.fill_cycles += fs.cycles_total; bs.fill_load += fs.cycles_load; bs.fill_update += fs.cycles_update; bs.fill_rescan += fs.cycles_rescan;
+        bs.block_loads += fs.block_loads; bs.rescans1 += fs.rescans1; bs.rescans2 += fs.rescans2; bs.rescans3 += fs.rescans3;
+        ops_base += fs.ops; remaining -= fs.n_done;
+        if (!fs.mismatch) H = std::min(H * 2, 1 << 20);                       // the plan ran out before anything surprising happened: look further ahead
+        else if ((int64_t)fs.n_done * 4 < fs.planned) H = std::max(H / 2, 8);  // most of the plan was thrown away
+    }
+    return 0;
+}
+
+}  // namespace kai

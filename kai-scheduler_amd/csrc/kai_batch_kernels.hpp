@@ -1,0 +1,524 @@
+// kai_batch_kernels.hpp — kernel bodies of the batch path (see kai_batch.hpp for the algorithm), written against kai_simt.hpp.
+// Under hipcc every body gets a __global__ entry point; tests/host_sim runs the same bodies on the lock-step emulator.
+#pragma once
+#include "kai_batch.hpp"
+
+namespace kai {
+
+constexpr int KB_INF = 0x7fffffff;
+constexpr int KB_PLACED_MAX = 1024;  // tasks of one gang the fill kernel can roll back (larger chunks do not qualify)
+
+KW_BODY bool kb_is_leaf(const KaiCtx& c, int q) { return q < c.Q && c.q_child_off[q + 1] == c.q_child_off[q]; }
+KW_BODY int kb_parent(const KaiCtx& c, int q) { int p = c.q_parent[q]; return p < 0 ? c.Q : p; }
+
+// ------------------------------------------------------------------------------------------------------ per action
+// static sibling order (queue_order.go:214-240): rank = number of siblings that sort before q; flagged when the relation is not a strict
+// total order on the sibling set (a tournament is transitive iff its scores are all different)
+KW_BODY void kb_static_rank(const KaiCtx& c) {
+    const int q = kw::bid() * kw::bdim() + kw::tid();
+    if (q >= c.Q) return;
+    const BatchCtx& b = c.bt;
+    const int par = kb_parent(c, q), b0 = c.q_child_off[par], b1 = c.q_child_off[par + 1];
+    int wins = 0; bool bad = false;
+    for (int i = b0; i < b1; i++) { int s = c.q_children[i]; if (s == q) continue; bool sq = plan_static_before(c, s, q), qs = plan_static_before(c, q, s); if (sq == qs) bad = true; if (sq) wins++; }
+    b.q_srank[q] = wins;
+    if (bad) kw::atomic_add((int32_t*)&b.qual[1], 1);
+}
+KW_BODY void kb_static_check(const KaiCtx& c) {
+    const int q = kw::bid() * kw::bdim() + kw::tid();
+    if (q >= c.Q) return;
+    const BatchCtx& b = c.bt;
+    const int par = kb_parent(c, q), b0 = c.q_child_off[par], b1 = c.q_child_off[par + 1], mine = b.q_srank[q];
+    for (int i = b0; i < b1; i++) { int s = c.q_children[i]; if (s != q && b.q_srank[s] == mine) { kw::atomic_add((int32_t*)&b.qual[1], 1); break; } }
+    b.cur_sp[q] = -1;
+}
+// per queued job: is it "regular" (see kai_batch.hpp)?  + the scan classes of its chunk, + class of every task in chunk order
+KW_BODY void kb_qualify(const KaiCtx& c) {
+    const int j = kw::bid() * kw::bdim() + kw::tid();
+    if (j >= c.J) return;
+    const BatchCtx& b = c.bt;
+    b.j_clsmask[j] = 0;
+    const int st = c.j_state[j];
+    if (st == 3) return;  // not queued
+    kw::atomic_add((int32_t*)&b.qual[2], 1);
+    bool ok = st == 0 && c.j_n_ps[j] == 1 && !c.j_has_topology[j] && c.j_tta_valid[j] && c.j_tta_n[j] == c.j_n_pending[j] && c.j_tta_n[j] >= 1 && c.j_tta_n[j] <= KB_PLACED_MAX;
+    if (ok && c.s_pipelined[c.j_first_ps[j]] != 0) ok = false;
+    uint64_t mask = 0;
+    if (ok) {
+        const int first = c.j_first_pod[j], nt = c.j_tta_n[j]; const bool nominated = c.plugins & KAI_PLUGIN_NOMINATEDNODE;
+        for (int i = 0; i < nt; i++) {
+            const int p = c.tta[first + i], k = c.p_scls[p];
+            if (k < 0 || c.p_status[p] != KAI_POD_PENDING || c.p_on_node[p] >= 0 || (nominated && c.p_nominated[p] >= 0)) { ok = false; break; }
+            mask |= 1ull << k; b.t_cls[first + i] = k;
+        }
+    }
+    if (!ok) { kw::atomic_add((int32_t*)&b.qual[0], 1); return; }
+    b.j_clsmask[j] = mask;
+}
+// node records of the fill kernel from the session's node arrays (nothing is releasing on this path: the host checked)
+KW_BODY void kb_build_nrec(const KaiCtx& c) {
+    const int n = kw::bid() * kw::bdim() + kw::tid();
+    if (n >= c.NB * KAI_BLOCK) return;
+    NodeRec r; r.idle[0] = r.idle[1] = r.idle[2] = r.idle[3] = 0; r.alloc_cpu = 0; r.alloc_gpu = 0; r.flags = KAI_NODE_NOT_READY; r.gpu_count = -1; r.okmask = 0;
+    if (n < c.N) {
+        for (int k = 0; k < 4; k++) r.idle[k] = k < c.R ? c.n_idle[(size_t)k * c.N + n] : 0.0;
+        r.alloc_cpu = c.n_alloc[(size_t)KAI_RES_CPU * c.N + n]; r.alloc_gpu = c.n_alloc[(size_t)KAI_RES_GPU * c.N + n];
+        r.flags = c.n_flags[n]; r.gpu_count = c.n_gpu_count[n];
+        const int nc = c.n_class[n];
+        for (int k = 0; k < c.C; k++) if (c.class_fit[(size_t)c.cls[k].pod_class * c.n_node_classes + nc]) r.okmask |= 1ull << k;
+    }
+    c.bt.nrec[n] = r;
+}
+
+// ------------------------------------------------------------------------------------------------------ plan: setup
+// candidate counts (a leaf offers its next h_leaf jobs), stream regions of every node in the pools.  One workgroup.
+KW_BODY void kb_plan_setup(const KaiCtx& c, RoundParams rp) {
+    const BatchCtx& b = c.bt;
+    const int T = kw::bdim(), t = kw::tid(), Q = c.Q;
+    for (int q = t; q <= Q; q += T) {
+        int cnt = 0;
+        if (kb_is_leaf(c, q)) { int rem = c.lq_end[q] - c.lq_cur[q]; cnt = rem < rp.h_leaf ? rem : rp.h_leaf; if (cnt < 0) cnt = 0; }
+        b.q_cnt[q] = cnt; b.q_sent[q] = KB_INF; b.q_valid[q] = 0; b.q_nk[q] = 0; b.q_complete[q] = 1; b.q_taken[q] = 0;
+    }
+    kw::sync();
+    for (int h = 1; h < b.n_h; h++) {
+        for (int i = b.h_off[h] + t; i < b.h_off[h + 1]; i += T) {
+            const int x = b.h_nodes[i]; int cnt = 0;
+            for (int k = c.q_child_off[x]; k < c.q_child_off[x + 1]; k++) cnt += b.q_cnt[c.q_children[k]];
+            b.q_cnt[x] = cnt;
+        }
+        kw::sync();
+    }
+    // exclusive scan over h_nodes order: element region = cnt + children (room for the sentinels), key region = cnt + 1
+    KW_SHARED int s_part[64]; KW_SHARED int s_carry[2];
+    if (t == 0) { s_carry[0] = 0; s_carry[1] = 0; }
+    kw::sync();
+    const int lane = kw::lane(), wave = t >> 6, nw = (T + 63) >> 6;
+    for (int base = 0; base <= Q; base += T) {
+        const int i = base + t; int ve = 0, vk = 0, x = -1;
+        if (i <= Q) { x = b.h_nodes[i]; ve = b.q_cnt[x] + (c.q_child_off[x + 1] - c.q_child_off[x]); vk = b.q_cnt[x] + 1; }
+        int se = kw::wave_scan_add(ve), sk = kw::wave_scan_add(vk);
+        if (lane == 63) { s_part[wave] = se; s_part[32 + wave] = sk; }
+        kw::sync();
+        int oe = s_carry[0], ok = s_carry[1];
+        for (int w = 0; w < wave; w++) { oe += s_part[w]; ok += s_part[32 + w]; }
+        if (x >= 0) { b.q_ebase[x] = oe + se - ve; b.q_kbase[x] = ok + sk - vk; }
+        kw::sync();
+        if (t == T - 1) { int te = 0, tk = 0; for (int w = 0; w < nw; w++) { te += s_part[w]; tk += s_part[32 + w]; } s_carry[0] += te; s_carry[1] += tk; }
+        kw::sync();
+    }
+}
+
+// inclusive running maximum of a PlanKey over the lanes, seeded with `carry` (valid when have_carry)
+KW_BODY PlanKey kb_wave_scan_max(PlanKey v, bool valid, PlanKey carry, bool have_carry) {
+    if (have_carry && (!valid || pk_less(v, carry))) { v = carry; valid = true; }
+    const int lane = kw::lane();
+    for (int d = 1; d < 64; d <<= 1) {
+        PlanKey o; o.w0 = kw::shfl_up(v.w0, d); o.w1 = kw::shfl_up(v.w1, d); o.w2 = kw::shfl_up(v.w2, d); o.w3 = kw::shfl_up(v.w3, d);
+        const int ov = kw::shfl_up((int)valid, d);
+        if (lane >= d && ov && (!valid || pk_less(v, o))) { v = o; valid = true; }
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------ plan: leaves
+// One wavefront per leaf queue: walks the leaf's next candidates in JobOrderFn order, decides the leaf's own capacity gate exactly
+// (sequential in effect: a gate failure changes the shares every later job sees — resolved per 64-job chunk by re-scanning from the first
+// failure), predicts node fit from the dead classes, and emits the key the leaf competes with before each pop.
+KW_BODY void kb_plan_leaf(const KaiCtx& c, RoundParams rp) {
+    const BatchCtx& b = c.bt;
+    const int q = kw::bid() * (kw::bdim() >> 6) + (kw::tid() >> 6), lane = kw::lane();
+    if (q >= c.Q || !kb_is_leaf(c, q)) return;
+    const int V = b.q_cnt[q], rem = c.lq_end[q] - c.lq_cur[q];
+    const bool complete = V == rem;
+    const int nk = V + (complete ? 0 : 1);
+    const int off = c.q_job_off[q] + c.lq_cur[q], eb = b.q_ebase[q], kb = b.q_kbase[q], srank = b.q_srank[q];
+    double alloc[3], anp[3];
+    for (int k = 0; k < 3; k++) { alloc[k] = c.q_share[(size_t)q * 3 + k].allocated; anp[k] = c.q_share[(size_t)q * 3 + k].allocated_np; }
+    const uint64_t dead_mask = b.dead_mask[0];
+    const double t0 = c.st->total[0], t1 = c.st->total[1], t2 = c.st->total[2];
+    PlanKey run; run.w0 = run.w1 = run.w2 = run.w3 = 0; bool have_run = false;
+    for (int base = 0; base < nk; base += 64) {
+        const int i = base + lane;
+        const bool is_elem = i < V, is_key = i < nk;
+        const int job = is_key ? c.lq_sorted[off + i] : -1;
+        double res[3] = {0, 0, 0}; bool np = false, dead = false;
+        if (job >= 0) { for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k]; np = !c.j_preempt[job]; dead = (b.j_clsmask[job] & dead_mask) != 0; }
+        bool assumed = is_elem && !dead, gate = false;
+        double ab[3], abn[3], tot[3], totn[3];
+        for (;;) {
+            for (int k = 0; k < 3; k++) {
+                const double d = assumed ? res[k] : 0.0, dn = (assumed && np) ? res[k] : 0.0;
+                const double s = kw::wave_scan_add(d), sn = kw::wave_scan_add(dn);
+                ab[k] = alloc[k] + (s - d); abn[k] = anp[k] + (sn - dn);
+                tot[k] = kw::shfl(s, 63); totn[k] = kw::shfl(sn, 63);
+            }
+            gate = is_elem && plan_gate_fails(c, q, ab, abn, res, np);
+            const uint64_t bad = kw::ballot(assumed && gate);
+            if (!bad) break;
+            if (lane == __builtin_ctzll(bad)) assumed = false;  // exact: every job before it is settled
+        }
+        if (is_elem) { b.e_job[eb + i] = job; b.e_flag[eb + i] = gate ? BF_GATE : dead ? BF_DEAD : BF_OK; b.e_grank[eb + i] = KB_INF; }
+        PlanKey key; key.w0 = key.w1 = key.w2 = key.w3 = 0;
+        if (is_key) key = plan_key(c, q, ab, res, t0, t1, t2, srank);
+        key = kb_wave_scan_max(key, is_key, run, have_run);
+        if (is_key) { b.pk[kb + i] = key; b.sp[kb + i] = job; b.k_owner[kb + i] = q; }
+        run.w0 = kw::shfl(key.w0, 63); run.w1 = kw::shfl(key.w1, 63); run.w2 = kw::shfl(key.w2, 63); run.w3 = kw::shfl(key.w3, 63); have_run = true;
+        for (int k = 0; k < 3; k++) { alloc[k] += tot[k]; anp[k] += totn[k]; }
+    }
+    if (lane == 0) { b.q_valid[q] = V; b.q_nk[q] = nk; b.q_complete[q] = complete ? 1 : 0; }
+}
+
+// ------------------------------------------------------------------------------------------------------ plan: merge
+// One thread per key slot of a child whose parent has height rp.height: its rank in the parent's merged stream = its index in its own stream
+// + the number of smaller running-maximum keys in every sibling stream (keys of different siblings never tie: w3 is the sibling rank).
+KW_BODY void kb_plan_rank(const KaiCtx& c, RoundParams rp) {
+    const BatchCtx& b = c.bt;
+    const int g = kw::bid() * kw::bdim() + kw::tid();
+    if (g >= rp.n_slots) return;  // key slots in use this round (upper bound)
+    const int cq = b.k_owner[g];
+    if (cq < 0 || cq >= c.Q) return;
+    const int i = g - b.q_kbase[cq];
+    if (i < 0 || i >= b.q_nk[cq]) return;
+    const int x = kb_parent(c, cq);
+    if (b.q_height[x] != rp.height) return;
+    const PlanKey key = b.pk[g];
+    int rank = i;
+    for (int k = c.q_child_off[x]; k < c.q_child_off[x + 1]; k++) {
+        const int s = c.q_children[k]; if (s == cq) continue;
+        const int n = b.q_nk[s]; if (n == 0) continue;
+        rank += plan_lower_bound(b.pk + b.q_kbase[s], n, key);
+    }
+    const int V = b.q_valid[cq], cap = b.q_cnt[x] + (c.q_child_off[x + 1] - c.q_child_off[x]);
+    if (rank >= cap) return;  // beyond a sentinel: never used
+    const int pos = b.q_ebase[x] + rank;
+    if (i < V) {
+        b.el_leaf[pos] = kb_is_leaf(c, cq) ? b.q_ebase[cq] + i : b.el_leaf[b.q_ebase[cq] + i];
+        b.el_ck[pos] = g + 1; b.el_next[pos] = (i + 1 < b.q_nk[cq]) ? 1 : 0;
+    } else {  // the key after the child's last planned element: the parent's stream is valid up to here
+        b.el_leaf[pos] = -1; b.el_ck[pos] = g + 1; b.el_next[pos] = 0;
+        kw::atomic_min((int32_t*)&b.q_sent[x], rank);
+    }
+}
+
+// One wavefront per inner node of height rp.height (the virtual root included): shares along its merged stream (segmented scan), its own
+// capacity gate (the first job it turns away ends the node's valid stream: everything after it would be ordered under wrong shares), the
+// stale-path job and the key of the node before each of its pops, as a running maximum.
+KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
+    const BatchCtx& b = c.bt;
+    const int idx = b.h_off[rp.height] + kw::bid() * (kw::bdim() >> 6) + (kw::tid() >> 6), lane = kw::lane();
+    if (idx >= b.h_off[rp.height + 1]) return;
+    const int x = b.h_nodes[idx];
+    int sumV = 0, compl_all = 1;
+    for (int k = c.q_child_off[x] + lane; k < c.q_child_off[x + 1]; k += 64) { const int s = c.q_children[k]; sumV += b.q_valid[s]; if (!b.q_complete[s]) compl_all = 0; }
+    sumV = kw::shfl(kw::wave_scan_add(sumV), 63);
+    compl_all = kw::ballot(!compl_all) ? 0 : 1;
+    int V = b.q_sent[x] < sumV ? b.q_sent[x] : sumV;
+    const int eb = b.q_ebase[x], kb = b.q_kbase[x];
+    if (x == c.Q) { if (lane == 0) { b.q_valid[x] = V; b.q_complete[x] = (compl_all && V == sumV) ? 1 : 0; b.q_nk[x] = 0; } return; }
+    double alloc0[3], anp0[3];
+    for (int k = 0; k < 3; k++) { alloc0[k] = c.q_share[(size_t)x * 3 + k].allocated; anp0[k] = c.q_share[(size_t)x * 3 + k].allocated_np; }
+    // pass 1: the node's own gate along the stream; stops at the first job it turns away
+    {
+        double alloc[3] = {alloc0[0], alloc0[1], alloc0[2]}, anp[3] = {anp0[0], anp0[1], anp0[2]};
+        for (int base = 0; base < V; base += 64) {
+            const int t = base + lane; const bool is_elem = t < V;
+            const int e = is_elem ? b.el_leaf[eb + t] : -1, job = e >= 0 ? b.e_job[e] : -1; const int flag = e >= 0 ? b.e_flag[e] : BF_GATE;
+            double res[3] = {0, 0, 0}; bool np = false;
+            if (job >= 0) { for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k]; np = !c.j_preempt[job]; }
+            double ab[3], abn[3], tot[3], totn[3];
+            for (int k = 0; k < 3; k++) {
+                const double d = flag == BF_OK ? res[k] : 0.0, dn = (flag == BF_OK && np) ? res[k] : 0.0;
+                const double s = kw::wave_scan_add(d), sn = kw::wave_scan_add(dn);
+                ab[k] = alloc[k] + (s - d); abn[k] = anp[k] + (sn - dn); tot[k] = kw::shfl(s, 63); totn[k] = kw::shfl(sn, 63);
+            }
+            const bool gate = is_elem && flag != BF_GATE && plan_gate_fails(c, x, ab, abn, res, np);
+            const uint64_t bad = kw::ballot(gate && flag == BF_OK);
+            const int f = bad ? __builtin_ctzll(bad) : 64;
+            if (gate && lane <= f) b.e_flag[e] = BF_GATE;  // lanes before f hold exact shares: a dead job turned away here counts as a gate failure
+            if (bad) { V = base + f + 1; break; }
+            for (int k = 0; k < 3; k++) { alloc[k] += tot[k]; anp[k] += totn[k]; }
+        }
+    }
+    kw::fence();
+    const bool complete = compl_all && V == sumV;
+    const int nk = complete ? V : V + 1;
+    const int srank = b.q_srank[x], cs = b.cur_sp[x];
+    const double t0 = c.st->total[0], t1 = c.st->total[1], t2 = c.st->total[2];
+    // pass 2: shares with the final flags, stale-path job and key before each pop
+    {
+        double alloc[3] = {alloc0[0], alloc0[1], alloc0[2]};
+        PlanKey run; run.w0 = run.w1 = run.w2 = run.w3 = 0; bool have_run = false;
+        for (int base = 0; base < nk; base += 64) {
+            const int t = base + lane; const bool is_elem = t < V, is_key = t < nk;
+            const int e = is_elem ? b.el_leaf[eb + t] : -1, job = e >= 0 ? b.e_job[e] : -1; const int flag = e >= 0 ? b.e_flag[e] : BF_GATE;
+            double res[3] = {0, 0, 0};
+            if (job >= 0) for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k];
+            double ab[3], tot[3];
+            for (int k = 0; k < 3; k++) { const double d = flag == BF_OK ? res[k] : 0.0; const double s = kw::wave_scan_add(d); ab[k] = alloc[k] + (s - d); tot[k] = kw::shfl(s, 63); }
+            int spj = -1;
+            if (is_key) {
+                if (t == 0) spj = cs >= 0 ? cs : b.sp[b.el_ck[eb] - 1];
+                else if (b.el_next[eb + t - 1]) spj = b.sp[b.el_ck[eb + t - 1]];
+                else spj = b.sp[b.el_ck[eb + t] - 1];  // the child popped from is gone: the node's heap top is now its best remaining child
+            }
+            double rq[3] = {0, 0, 0};
+            if (spj >= 0) for (int k = 0; k < 3; k++) rq[k] = c.j_tta_res[(size_t)spj * 4 + k];
+            PlanKey key; key.w0 = key.w1 = key.w2 = key.w3 = 0;
+            if (is_key) key = plan_key(c, x, ab, rq, t0, t1, t2, srank);
+            key = kb_wave_scan_max(key, is_key, run, have_run);
+            if (is_key) { b.pk[kb + t] = key; b.sp[kb + t] = spj; b.k_owner[kb + t] = x; }
+            run.w0 = kw::shfl(key.w0, 63); run.w1 = kw::shfl(key.w1, 63); run.w2 = kw::shfl(key.w2, 63); run.w3 = kw::shfl(key.w3, 63); have_run = true;
+            for (int k = 0; k < 3; k++) alloc[k] += tot[k];
+        }
+    }
+    if (lane == 0) { b.q_valid[x] = V; b.q_nk[x] = nk; b.q_complete[x] = complete ? 1 : 0; }
+}
+
+// the planned global order: one thread per position of the virtual root's valid stream
+KW_BODY void kb_plan_emit(const KaiCtx& c) {
+    const BatchCtx& b = c.bt;
+    const int t = kw::bid() * kw::bdim() + kw::tid();
+    if (t >= b.q_valid[c.Q]) return;
+    const int e = b.el_leaf[b.q_ebase[c.Q] + t], job = b.e_job[e];
+    b.e_grank[e] = t; b.g_job[t] = job; b.g_flag[t] = b.e_flag[e];
+}
+
+// ------------------------------------------------------------------------------------------------------ fill
+// ONE wavefront walks the planned order and places every task: arg-max node of the task's scan class out of the three-level class
+// index (block maxima [C][NB] in HBM or LDS, super-block maxima and class tops in LDS), node update, index maintenance — all inside this
+// wave: lane = node of the current 64-node block (its records stay in registers) for the block level, lane = class for the upper levels.
+struct FillLds {
+    ClassRec cls[KAI_CMAX];
+    uint64_t top_key[KAI_CMAX]; int32_t top_node[KAI_CMAX];
+    int32_t placed_node[KB_PLACED_MAX]; int32_t placed_cls[KB_PLACED_MAX];
+};
+struct FillState {
+    int bcur; NodeRec rec;
+    uint64_t* l1k; int32_t* l1n; uint64_t* l2k; int32_t* l2n;
+    int64_t n_loads, n_r1, n_r2, n_r3, cy_load, cy_upd, cy_rescan;
+};
+KW_BODY void kb_fill_load_block(const KaiCtx& c, FillState& fsx, int blk) {
+    if (blk == fsx.bcur) return;
+    const int64_t t0 = kw::clock();
+    kw::fence_wg();  // the record stores of this wave to the block it may be coming back to
+    fsx.rec = c.bt.nrec[(size_t)blk * KAI_BLOCK + kw::lane()]; fsx.bcur = blk; fsx.n_loads++;
+    fsx.cy_load += kw::clock() - t0;
+}
+// node n (in the current block) changed: bring the three index levels up to date for every class
+KW_BODY void kb_fill_node_changed(const KaiCtx& c, FillLds& L, FillState& fsx, int n) {
+    const int64_t t0 = kw::clock();
+    const int lane = kw::lane(), blk = n >> 6, ln = n & 63, sb = blk >> 6, NB = c.NB, NSB = c.NSB, C = c.C;
+    NodeRec rn;
+    for (int r = 0; r < 4; r++) rn.idle[r] = kw::shfl(fsx.rec.idle[r], ln);
+    rn.alloc_cpu = kw::shfl(fsx.rec.alloc_cpu, ln); rn.alloc_gpu = kw::shfl(fsx.rec.alloc_gpu, ln);
+    rn.flags = (uint32_t)kw::shfl((int)fsx.rec.flags, ln); rn.gpu_count = kw::shfl(fsx.rec.gpu_count, ln); rn.okmask = kw::shfl(fsx.rec.okmask, ln);
+    const bool act = lane < C; const int k = act ? lane : 0;
+    // ---- level 1 (block)
+    const uint64_t kap = act ? class_key_rec(c, L.cls[k], k, rn) : 0;
+    const uint64_t o1k = act ? fsx.l1k[(size_t)k * NB + blk] : 0; const int o1n = act ? fsx.l1n[(size_t)k * NB + blk] : 0;
+    uint64_t n1k = o1k; int n1n = o1n; bool need = false;
+    if (act) {
+        if (o1k != 0 && o1n == n) { if (kap >= o1k) n1k = kap; else need = true; }
+        else if (key_better(kap, n, o1k, o1n)) { n1k = kap; n1n = n; }
+    }
+    uint64_t todo = kw::ballot(need);
+    while (todo) {
+        const int kk = __builtin_ctzll(todo); todo &= todo - 1;
+        const int64_t tr = kw::clock();
+        uint64_t key = class_key_rec(c, L.cls[kk], kk, fsx.rec); int bn = blk * KAI_BLOCK + lane;
+        kw::wave_argmax_first(key, bn);
+        if (lane == kk) { n1k = key; n1n = bn; }
+        fsx.n_r1++; fsx.cy_rescan += kw::clock() - tr;
+    }
+    const bool ch1 = act && (n1k != o1k || n1n != o1n);
+    if (ch1) { fsx.l1k[(size_t)k * NB + blk] = n1k; fsx.l1n[(size_t)k * NB + blk] = n1n; }
+    // ---- level 2 (super-block of 64 blocks)
+    const uint64_t o2k = act ? fsx.l2k[k * NSB + sb] : 0; const int o2n = act ? fsx.l2n[k * NSB + sb] : 0;
+    uint64_t n2k = o2k; int n2n = o2n; need = false;
+    if (ch1) {
+        if (o2k != 0 && (o2n >> 6) == blk) { if (n1k != 0 && n1k >= o2k) { n2k = n1k; n2n = n1n; } else need = true; }
+        else if (key_better(n1k, n1n, o2k, o2n)) { n2k = n1k; n2n = n1n; }
+    }
+    todo = kw::ballot(need);
+    while (todo) {
+        const int kk = __builtin_ctzll(todo); todo &= todo - 1;
+        const int64_t tr = kw::clock();
+        const int e = sb * 64 + lane;
+        uint64_t key = e < NB ? fsx.l1k[(size_t)kk * NB + e] : 0; int bn = e < NB ? fsx.l1n[(size_t)kk * NB + e] : KB_INF;
+        const uint64_t pk1 = kw::shfl(n1k, kk); const int pn1 = kw::shfl(n1n, kk);
+        if (e == blk) { key = pk1; bn = pn1; }  // the entry lane kk has just decided, from registers
+        kw::wave_argmax_first(key, bn);
+        if (lane == kk) { n2k = key; n2n = bn; }
+        fsx.n_r2++; fsx.cy_rescan += kw::clock() - tr;
+    }
+    const bool ch2 = act && (n2k != o2k || n2n != o2n);
+    if (ch2) { fsx.l2k[k * NSB + sb] = n2k; fsx.l2n[k * NSB + sb] = n2n; }
+    // ---- level 3 (class top)
+    const uint64_t o3k = act ? L.top_key[k] : 0; const int o3n = act ? L.top_node[k] : 0;
+    uint64_t n3k = o3k; int n3n = o3n; need = false;
+    if (ch2) {
+        if (o3k != 0 && (o3n >> 12) == sb) { if (n2k != 0 && n2k >= o3k) { n3k = n2k; n3n = n2n; } else need = true; }
+        else if (key_better(n2k, n2n, o3k, o3n)) { n3k = n2k; n3n = n2n; }
+    }
+    todo = kw::ballot(need);
+    while (todo) {
+        const int kk = __builtin_ctzll(todo); todo &= todo - 1;
+        const int64_t tr = kw::clock();
+        uint64_t key = lane < NSB ? fsx.l2k[kk * NSB + lane] : 0; int bn = lane < NSB ? fsx.l2n[kk * NSB + lane] : KB_INF;
+        const uint64_t pk2 = kw::shfl(n2k, kk); const int pn2 = kw::shfl(n2n, kk);
+        if (lane == sb) { key = pk2; bn = pn2; }
+        kw::wave_argmax_first(key, bn);
+        if (lane == kk) { n3k = key; n3n = bn; }
+        fsx.n_r3++; fsx.cy_rescan += kw::clock() - tr;
+    }
+    if (act && (n3k != o3k || n3n != o3n)) { L.top_key[k] = n3k; L.top_node[k] = n3n; }
+    kw::fence_wg();  // index entries written by one lane are read by other lanes of this wave later on
+    fsx.cy_upd += kw::clock() - t0;
+}
+// Statement.Allocate's node side (NodeInfo.addTaskResources, node_info.go:457-493) / its undo, on the node record
+KW_BODY void kb_fill_apply(const KaiCtx& c, FillLds& L, FillState& fsx, int n, int kcls, double sign) {
+    kb_fill_load_block(c, fsx, n >> 6);
+    if (kw::lane() == (n & 63)) {
+        for (int r = 0; r < 4; r++) { if (r >= c.R) continue; const double v = L.cls[kcls].req[r]; if (v == 0) continue; fsx.rec.idle[r] = fsx.rec.idle[r] - sign * v; }
+        for (int r = 0; r < 4; r++) c.bt.nrec[n].idle[r] = fsx.rec.idle[r];
+    }
+    kb_fill_node_changed(c, L, fsx, n);
+}
+KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {
+    const BatchCtx& b = c.bt;
+    KW_SHARED FillLds L;
+    const int lane = kw::lane(), C = c.C, NB = c.NB, NSB = c.NSB;
+    FillState fsx; fsx.bcur = -1; fsx.n_loads = fsx.n_r1 = fsx.n_r2 = fsx.n_r3 = 0; fsx.cy_load = fsx.cy_upd = fsx.cy_rescan = 0;
+    const int64_t tstart = kw::clock();
+    unsigned char* dyn = kw::dyn_lds();
+    fsx.l2k = reinterpret_cast<uint64_t*>(dyn); fsx.l2n = reinterpret_cast<int32_t*>(dyn + (size_t)C * NSB * 8);
+    size_t off = ((size_t)C * NSB * 12 + 15) & ~(size_t)15;
+    if (l1_in_lds) {
+        fsx.l1k = reinterpret_cast<uint64_t*>(dyn + off); fsx.l1n = reinterpret_cast<int32_t*>(dyn + off + (size_t)C * NB * 8);
+        for (int i = lane; i < C * NB; i += 64) { fsx.l1k[i] = c.sum1_key[i]; fsx.l1n[i] = c.sum1_node[i]; }
+    } else { fsx.l1k = (uint64_t*)c.sum1_key; fsx.l1n = (int32_t*)c.sum1_node; }
+    for (int k = lane; k < C; k += 64) L.cls[k] = c.cls[k];
+    kw::sync();
+    for (int k = 0; k < C; k++) {  // upper levels from the block level
+        for (int sb = 0; sb < NSB; sb++) {
+            const int e = sb * 64 + lane;
+            uint64_t key = e < NB ? fsx.l1k[(size_t)k * NB + e] : 0; int bn = e < NB ? fsx.l1n[(size_t)k * NB + e] : KB_INF;
+            kw::wave_argmax_first(key, bn);
+            if (lane == 0) { fsx.l2k[k * NSB + sb] = key; fsx.l2n[k * NSB + sb] = bn; }
+        }
+        kw::sync();
+        uint64_t key = lane < NSB ? fsx.l2k[k * NSB + lane] : 0; int bn = lane < NSB ? fsx.l2n[k * NSB + lane] : KB_INF;
+        kw::wave_argmax_first(key, bn);
+        if (lane == 0) { L.top_key[k] = key; L.top_node[k] = bn; }
+    }
+    kw::sync();
+    const int V = rp.mode == 0 ? b.q_valid[c.Q] : 0;  // mode 1: index levels and dead classes only (before the first plan)
+    int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0; int n_done = 0, mismatch = 0;
+    for (int base = 0; base < V && !mismatch; base += 64) {
+        const int gi = base + lane;
+        const int my_job = gi < V ? b.g_job[gi] : -1; const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE;
+        const int my_first = my_job >= 0 ? c.j_first_pod[my_job] : 0, my_nt = my_job >= 0 ? c.j_tta_n[my_job] : 0;
+        const int cnt = V - base < 64 ? V - base : 64;
+        for (int jj = 0; jj < cnt; jj++) {
+            const int flag = kw::shfl(my_flag, jj), first = kw::shfl(my_first, jj), nt = kw::shfl(my_nt, jj);
+            attempted++; n_done = base + jj + 1;
+            const int opoff = (int)ops;
+            bool ok = flag != BF_GATE; int placed = 0;
+            if (flag != BF_GATE) {
+                for (int tb = 0; tb < nt && ok; tb += 64) {
+                    const int my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;
+                    const int tc = nt - tb < 64 ? nt - tb : 64;
+                    for (int ti = 0; ti < tc; ti++) {
+                        const int kcls = kw::shfl(my_cls, ti);
+                        decisions++;
+                        const uint64_t tk = L.top_key[kcls]; const int tn = L.top_node[kcls];
+                        if (tk == 0) { ok = false; break; }
+                        kb_fill_apply(c, L, fsx, tn, kcls, 1.0);
+                        if (lane == 0) { L.placed_node[placed] = tn; L.placed_cls[placed] = kcls; b.t_node[first + placed] = tn; }
+                        placed++;
+                    }
+                }
+                if (!ok) {  // Statement.Rollback: the undone operations in reverse order
+                    kw::sync();
+                    for (int i = placed - 1; i >= 0; i--) kb_fill_apply(c, L, fsx, L.placed_node[i], L.placed_cls[i], -1.0);
+                    rollbacks += 2;
+                } else { committed++; ops += nt; }
+            }
+            if (lane == 0) { b.g_out[base + jj] = ok ? BF_OK : BF_DEAD; b.g_opoff[base + jj] = opoff; }
+            if ((flag == BF_OK) != ok) { mismatch = 1; break; }
+        }
+    }
+    kw::sync();
+    if (l1_in_lds) for (int i = lane; i < C * NB; i += 64) { c.sum1_key[i] = fsx.l1k[i]; c.sum1_node[i] = fsx.l1n[i]; }
+    uint64_t dead = kw::ballot(lane < C && L.top_key[lane < C ? lane : 0] == 0);
+    if (lane == 0) {
+        FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V;
+        s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
+        s.cycles_total = kw::clock() - tstart; s.cycles_load = fsx.cy_load; s.cycles_update = fsx.cy_upd; s.cycles_rescan = fsx.cy_rescan;
+        s.block_loads = fsx.n_loads; s.rescans1 = fsx.n_r1; s.rescans2 = fsx.n_r2; s.rescans3 = fsx.n_r3;
+        b.fs[0] = s; b.dead_mask[0] = dead;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------ apply
+// Statement.Commit of every committed job of the executed prefix (framework/statement.go:536-575): pod state, committed operations in
+// commit order, pod-set / job counters, node accounting, proportion event handlers up the queue chain (proportion.go:443-465).
+// Quantities add exactly in any order (HostPrep::batch_units), so f64 atomics reproduce the sequential sums bit for bit.
+KW_BODY void kb_apply_jobs(const KaiCtx& c, int64_t ops_base) {
+    const BatchCtx& b = c.bt;
+    const int t = kw::bid() * kw::bdim() + kw::tid();
+    if (t >= b.fs[0].n_done) return;
+    if (b.g_out[t] != BF_OK || b.g_flag[t] == BF_GATE) return;
+    const int j = b.g_job[t], first = c.j_first_pod[j], nt = c.j_tta_n[j], s = c.j_first_ps[j];
+    double sum[3] = {0, 0, 0};
+    for (int i = 0; i < nt; i++) {
+        const int p = c.tta[first + i], n = b.t_node[first + i];
+        kai_op o; o.seq = ops_base + b.g_opoff[t] + i; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j;
+        c.out_ops[o.seq] = o;
+        c.p_status[p] = KAI_POD_BINDING; c.p_node[p] = n; c.p_on_node[p] = n; c.p_on_node_status[p] = KAI_POD_ALLOCATED; c.p_accepted[p] = 1; c.p_virtual[p] = 1;
+        for (int r = 0; r < c.R; r++) {
+            const double v = c.p_req[(size_t)r * c.P + p]; if (v == 0) continue;
+            kw::atomic_add((double*)&c.n_used[(size_t)r * c.N + n], v); kw::atomic_add((double*)&c.n_idle[(size_t)r * c.N + n], -v);
+        }
+        sum[0] += c.p_req[(size_t)KAI_RES_CPU * c.P + p]; sum[1] += c.p_req[(size_t)KAI_RES_MEM * c.P + p]; sum[2] += c.p_req[(size_t)KAI_RES_GPU * c.P + p];
+    }
+    c.s_active_alloc[s] += nt; c.s_active_used[s] += nt; c.j_n_pending[j] -= nt; c.j_tta_valid[j] = 0;
+    for (int k = 0; k < 3; k++) c.j_allocated[(size_t)j * 4 + k] += sum[k];
+    const bool np = !c.j_preempt[j];
+    for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
+        if (sum[k] == 0) continue;
+        kw::atomic_add((double*)&c.q_share[(size_t)q * 3 + k].allocated, sum[k]);
+        if (np) kw::atomic_add((double*)&c.q_share[(size_t)q * 3 + k].allocated_np, sum[k]);
+    }
+}
+// how far every queue node got inside the executed prefix: leaf cursors, stale-path jobs of the inner nodes
+KW_BODY void kb_apply_nodes(const KaiCtx& c) {
+    const BatchCtx& b = c.bt;
+    const int x = kw::bid() * kw::bdim() + kw::tid();
+    if (x >= c.Q) return;
+    const int A = b.fs[0].n_done, V = b.q_valid[x], eb = b.q_ebase[x];
+    const bool leaf = kb_is_leaf(c, x);
+    int lo = 0, hi = V;  // elements of the node's stream inside the executed prefix: a prefix of the stream
+    while (lo < hi) { const int mid = (lo + hi) >> 1; const int e = leaf ? eb + mid : b.el_leaf[eb + mid]; if (b.e_grank[e] < A) lo = mid + 1; else hi = mid; }
+    if (lo == 0) return;
+    if (leaf) c.lq_cur[x] += lo;
+    else b.cur_sp[x] = lo < b.q_nk[x] ? b.sp[b.q_kbase[x] + lo] : -1;
+}
+
+#if defined(__HIPCC__)
+__global__ void k_batch_static_rank(KaiCtx c) { kb_static_rank(c); }
+__global__ void k_batch_static_check(KaiCtx c) { kb_static_check(c); }
+__global__ void k_batch_qualify(KaiCtx c) { kb_qualify(c); }
+__global__ void k_batch_nrec(KaiCtx c) { kb_build_nrec(c); }
+__global__ void k_plan_setup(KaiCtx c, RoundParams rp) { kb_plan_setup(c, rp); }
+__global__ void k_plan_leaf(KaiCtx c, RoundParams rp) { kb_plan_leaf(c, rp); }
+__global__ void k_plan_rank(KaiCtx c, RoundParams rp) { kb_plan_rank(c, rp); }
+__global__ void k_plan_scan(KaiCtx c, RoundParams rp) { kb_plan_scan(c, rp); }
+__global__ void k_plan_emit(KaiCtx c) { kb_plan_emit(c); }
+__global__ void __launch_bounds__(64) k_fill(KaiCtx c, RoundParams rp, int l1_in_lds) { kb_fill(c, rp, l1_in_lds); }
+__global__ void k_apply_jobs(KaiCtx c, long long ops_base) { kb_apply_jobs(c, (int64_t)ops_base); }
+__global__ void k_apply_nodes(KaiCtx c) { kb_apply_nodes(c); }
+#endif
+
+}  // namespace kai

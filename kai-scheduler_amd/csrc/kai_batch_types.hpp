@@ -1,0 +1,61 @@
+// kai_batch_types.hpp — data of the batch path (kai_batch.hpp explains the algorithm); included by kai_engine.hpp because the context carries it.
+#pragma once
+#include <stdint.h>
+
+namespace kai {
+
+struct PlanKey { uint64_t w0, w1, w2, w3; };  // ascending = popped first
+enum : uint8_t { BF_OK = 0, BF_GATE = 1, BF_DEAD = 2 };  // predicted outcome of an attempt: committed / fails the capacity gate / finds no node
+
+struct FillStatus {  // written by the fill kernel, read by the host between rounds
+    int32_t n_done;        // jobs of the planned order that were executed (the last one may be the mismatch)
+    int32_t mismatch;      // 1 = job n_done-1 ended differently from its prediction
+    int32_t all_dead;      // no class has a fitting node at the committed state
+    int32_t planned;       // length of the planned order of this round
+    int64_t decisions, attempted, committed, rollbacks, ops;  // of this round
+    uint64_t dead_mask;    // classes without a fitting node at the committed state
+    int64_t cycles_total, cycles_load, cycles_update, cycles_rescan;  // fill-wave clocks (profiling)
+    int64_t block_loads, rescans1, rescans2, rescans3;
+};
+
+// per-node record of the fill kernel: everything class_key reads of one node, 64 bytes, node-major (one wave loads a 64-node block as 4 KB)
+struct NodeRec {
+    double idle[4];
+    double alloc_cpu, alloc_gpu;
+    uint32_t flags; int32_t gpu_count;
+    uint64_t okmask;  // bit k: the static predicates of scan class k pass on this node (class_fit table)
+};
+
+struct BatchCtx {
+    int32_t enabled, n_h, pool_e, pool_k;  // n_h: heights incl. the virtual root's
+    // static per session
+    KAI_GP(int32_t) q_height;    // [Q+1] leaf = 0; index Q = virtual root
+    KAI_GP(int32_t) h_off;       // [n_h+1]
+    KAI_GP(int32_t) h_nodes;     // [Q+1] queue nodes by ascending height
+    KAI_GP(int32_t) q_srank;     // [Q] static rank among siblings: allocatable-share dominance, creation time (queue_order.go:214-240)
+    // per action
+    KAI_GP(uint64_t) j_clsmask;  // [J] scan classes of the job's chunk
+    KAI_GP(int32_t) cur_sp;      // [Q] stale-path job of an inner node (-1 = its true best job: nothing popped from it yet)
+    KAI_GP(int32_t) qual;        // [4] 0: irregular jobs, 1: sibling sets without a strict static order, 2: queued jobs, 3: pad
+    // per round
+    KAI_GP(int32_t) q_cnt, q_ebase, q_kbase, q_valid, q_nk, q_sent, q_taken;  // [Q+1]
+    KAI_GP(uint8_t) q_complete;  // [Q+1]
+    KAI_GP(PlanKey) pk;          // [pool_k] running maximum of the node's keys
+    KAI_GP(int32_t) sp;          // [pool_k] stale-path job after t selections
+    KAI_GP(int32_t) k_owner;     // [pool_k] queue node that wrote the key slot
+    KAI_GP(int32_t) el_leaf, el_ck;  // [pool_e] leaf element of a merged element; key slot of its child stream AFTER the extraction
+    KAI_GP(uint8_t) el_next;     // [pool_e] the child still has a key after this extraction
+    KAI_GP(int32_t) e_job, e_grank;  // [pool_e] leaf regions: job, rank in the global order (INT_MAX = not in its valid prefix)
+    KAI_GP(uint8_t) e_flag;      // [pool_e] leaf regions: BF_*
+    // global order + task stream
+    KAI_GP(int32_t) g_job, g_opoff;  // [J+1] planned global order: job, offset of its operations among the round's committed ones
+    KAI_GP(uint8_t) g_flag, g_out;           // [J] predicted / actual outcome
+    KAI_GP(int32_t) t_cls, t_node;           // [P] (a job's pod range) scan class of the i-th task of its chunk; node the fill kernel gave it
+    KAI_GP(NodeRec) nrec;        // [NB*64]
+    KAI_GP(FillStatus) fs;       // [1]
+    KAI_GP(uint64_t) dead_mask;  // [1]
+};
+
+struct RoundParams { int32_t h_leaf, height, mode, n_slots; };  // mode 1 (fill): build the index levels and the dead-class mask only
+
+}  // namespace kai

@@ -46,6 +46,8 @@ template <class T> using kai_gptr = T*;
 #endif
 #define KAI_GP(T) kai_gptr<T>
 
+#include "kai_batch_types.hpp"
+
 namespace kai {
 
 // pod status groups: api/pod_status/pod_status.go:64-71
@@ -295,6 +297,7 @@ struct KaiCtx {
     // minruntime plugin inputs (null = nothing is protected)
     KAI_GP(const int64_t) j_last_start, q_preempt_mr, q_reclaim_mr; int64_t now_ns, def_preempt_mr, def_reclaim_mr; int32_t reclaim_method, pad8;
     SolverCtx sv;
+    BatchCtx bt;  // batch path of the allocate action (kai_batch.hpp)
 #ifdef KAI_SHARED_GPUS
     // shared GPUs (ABI v4; compiled into the host twin only until the device path is verified on the MI355X): fractions of one device
     KAI_GP(const double) p_portion;       // [P] 0 = a whole-GPU / CPU-only pod
@@ -2081,6 +2084,10 @@ struct Engine {
             el().fail_no_node = false;
             int fr = allocate_job_fast(j);
             bool ok = fr < 0 ? allocate_job(j, false) : fr == 1;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(KAI_ALLOC_TRACE)
+            { static FILE* tf = std::getenv("KAI_ALLOC_TRACE") ? std::fopen(std::getenv("KAI_ALLOC_TRACE"), "w") : nullptr;
+              if (tf) { int first = cx().j_first_pod[j]; int p0 = cx().j_pods_sorted[first]; std::fprintf(tf, "%d %d %d %d %d %d %lld\n", j, cx().j_queue[j], fr, (int)ok, (int)el().fail_no_node, cx().p_scls[p0], (long long)el().h.decisions); } }
+#endif
             int64_t tc = be.clock(); el().h.prof[2] += tc - tb;
             if (ok) {  // attemptToAllocateJob :79-111 — ShouldPipelineJob (job_info.go:443-464)
                 bool should_pipeline = false;

@@ -32,6 +32,10 @@ struct HostPrep {
     std::vector<uint32_t> dom_id_rank, g_name_rank;
     std::vector<int32_t> g_job, g_parent, g_topo, g_req, g_pref, j_root_group, g_child_off, g_children, s_group, s_topo, s_req, s_pref;
     std::vector<uint8_t> j_has_topology;
+    // batch path (kai_batch.hpp): queue nodes by height (leaf = 0, the virtual root at index Q on top), and whether the snapshot's quantities add
+    // exactly in any order (the batch path sums shares and node accounting in parallel)
+    struct BatchShape { int n_leaves = 0, n_heights = 0; std::vector<int> h_count; };
+    std::vector<int32_t> q_height, h_off, h_nodes; int n_heights = 0, batch_ok = 0; BatchShape shape;
 
     // returns 0 or KAI_ERR_INVALID_ARG with err set
     int build(const kai_config& cfg, const kai_snapshot_soa* s, std::string& err) {
@@ -114,7 +118,37 @@ struct HostPrep {
         }
         if (int rc = build_topology(s, err)) return rc;
         build_classes(cfg, s);
+        build_batch(cfg, s);
         return 0;
+    }
+
+    void build_batch(const kai_config& cfg, const kai_snapshot_soa* s) {
+        const int N = s->n_nodes, P = s->n_pods, Q = s->n_queues, R = s->n_res;
+        q_height.assign(Q + 1, 0);
+        for (int i = 0; i < Q; i++) { int q = depth_order[i], par = s->queue_parent[q] < 0 ? Q : s->queue_parent[q]; q_height[par] = std::max(q_height[par], q_height[q] + 1); }  // deepest first
+        if (Q == 0) q_height[Q] = 1;
+        n_heights = q_height[Q] + 1;
+        h_off.assign(n_heights + 1, 0); h_nodes.assign(Q + 1, 0); shape = BatchShape{}; shape.n_heights = n_heights; shape.h_count.assign(n_heights, 0);
+        for (int q = 0; q <= Q; q++) { h_off[q_height[q] + 1]++; shape.h_count[q_height[q]]++; }
+        for (int h = 0; h < n_heights; h++) h_off[h + 1] += h_off[h];
+        { std::vector<int32_t> fill(h_off.begin(), h_off.end() - 1); for (int q = 0; q <= Q; q++) h_nodes[fill[q_height[q]]++] = q; }
+        for (int q = 0; q < Q; q++) if (child_off[q + 1] == child_off[q]) shape.n_leaves++;
+        // exact sums: per resource every quantity is a non-negative integer multiple of one power of two, and the totals stay below 2^53 units
+        batch_ok = (cfg.engine_mode == 0 || cfg.engine_mode == 4) && R <= 4 && n_heights <= 16;
+        for (int r = 0; r < R && batch_ok; r++) {
+            uint64_t bits = 0; bool ok = true;
+            auto take = [&](double v) { if (!(v >= 0) || v != std::floor(v) || v >= 9.2e18) { ok = false; return; } bits |= (uint64_t)v; };
+            for (int n = 0; n < N && ok; n++) take(s->node_allocatable[(size_t)r * N + n]);
+            for (int p = 0; p < P && ok; p++) take(s->pod_req[(size_t)r * P + p]);
+            if (!ok) { batch_ok = 0; break; }
+            if (!bits) continue;
+            const int tz = __builtin_ctzll(bits);
+            unsigned __int128 sum_nodes = 0, sum_pods = 0;
+            for (int n = 0; n < N; n++) sum_nodes += (uint64_t)s->node_allocatable[(size_t)r * N + n] >> tz;
+            for (int p = 0; p < P; p++) sum_pods += (uint64_t)s->pod_req[(size_t)r * P + p] >> tz;
+            const unsigned __int128 lim = (unsigned __int128)1 << 52;
+            if (sum_nodes >= lim || sum_pods >= lim) batch_ok = 0;
+        }
     }
 
     // Topology domain tree and sub-group tree in the engine's indexing (plugins/topology/topology_plugin.go:57-110,

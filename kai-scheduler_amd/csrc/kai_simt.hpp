@@ -1,0 +1,203 @@
+// kai_simt.hpp — the few SIMT primitives the batch-path kernels (kai_plan_kernels.hpp) are written against.
+//
+// Device pass (hipcc, gfx950): thin wrappers over the hardware — threadIdx / blockIdx, s_barrier, ballot, ds_bpermute shuffles, the DPP
+// max-scan of kai_wave.hpp, global atomics.  That is the product.
+//
+// Plain g++ (tests/host_sim only): the same names are backed by a small lock-step emulator — every thread of a workgroup is a fiber with its
+// own stack, a collective (barrier, ballot, shuffle) parks the fiber until all live lanes of its wave / workgroup have arrived — so that the
+// kernels' bodies, scans and index arithmetic can be debugged against the oracle in the `-m "not gpu"` suite of a container without a GPU.
+// It is TEST INFRASTRUCTURE: libkai_core.so never contains it (hipcc defines __HIPCC__ in both of its passes) and nothing in the package
+// loads it; every parity claim is made by the `-m gpu` tests through the C ABI on a real MI355X.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+
+#include "kai_wave.hpp"
+#define KW_DEV __device__ __forceinline__
+#define KW_BODY __device__ __forceinline__  // kernel bodies and their helpers: device code only in the product library
+#define KW_SHARED __shared__
+namespace kw {
+KW_DEV int tid() { return (int)threadIdx.x; }
+KW_DEV int bid() { return (int)blockIdx.x; }
+KW_DEV int bdim() { return (int)blockDim.x; }
+KW_DEV int gdim() { return (int)gridDim.x; }
+KW_DEV int lane() { return (int)(threadIdx.x & 63); }
+KW_DEV void sync() { __syncthreads(); }
+KW_DEV uint64_t ballot(bool p) { return (uint64_t)__ballot(p); }
+template <class T> KW_DEV T shfl(T v, int src) { return __shfl(v, src, 64); }
+KW_DEV uint64_t shfl(uint64_t v, int src) { return (uint64_t)__shfl((unsigned long long)v, src, 64); }
+KW_DEV int64_t shfl(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
+template <class T> KW_DEV T shfl_up(T v, int d) { return __shfl_up(v, d, 64); }  // lanes < d keep their own value
+KW_DEV uint64_t wave_max_u64(uint64_t v) { return (uint64_t)kai::wave_max_u64((unsigned long long)v); }
+KW_DEV int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
+KW_DEV int atomic_min(int32_t* p, int v) { return atomicMin(p, v); }
+KW_DEV int atomic_max(int32_t* p, int v) { return atomicMax(p, v); }
+KW_DEV unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
+KW_DEV unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
+KW_DEV double atomic_add(double* p, double v) { return atomicAdd(p, v); }
+KW_DEV int64_t clock() { return (int64_t)clock64(); }
+KW_DEV unsigned char* dyn_lds() { extern __shared__ __align__(16) unsigned char kw_dyn_lds_[]; return kw_dyn_lds_; }
+KW_DEV void fence() { __threadfence(); }
+KW_DEV void fence_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+}  // namespace kw
+
+#else  // ---------------------------------------------------------------------------------------------- host emulator (tests only)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+#define KW_DEV inline
+#define KW_BODY inline
+#define KW_SHARED static  // workgroups run one after the other, so one static object per declaration is "the LDS of the running workgroup"
+namespace kw {
+
+extern "C" void kw_switch_ctx(void** save_sp, void* load_sp);
+#if defined(__x86_64__)
+asm(R"(
+.text
+.globl kw_switch_ctx
+.type kw_switch_ctx,@function
+kw_switch_ctx:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size kw_switch_ctx,.-kw_switch_ctx
+)");
+#else
+#error "the host emulator's context switch is written for x86-64"
+#endif
+
+enum FiberState : int { F_RUN = 0, F_WAIT_BLOCK = 1, F_WAIT_WAVE = 2, F_DONE = 3 };
+struct Fiber { void* sp = nullptr; int state = F_DONE; char* stack = nullptr; };
+struct Emu {
+    std::vector<Fiber> fibers; std::vector<char*> stacks;
+    void* sched_sp = nullptr;
+    int cur = -1, block = 0, bdim = 0, gdim = 0;
+    const std::function<void()>* body = nullptr;
+    uint64_t xchg[64 * 64];       // per wave: 64 slots of 8 bytes (up to 64 waves per workgroup)
+    std::vector<unsigned char> lds;
+    static constexpr size_t STACK = 128 * 1024;
+};
+inline Emu& emu() { static Emu e; return e; }
+inline void fiber_yield() { Emu& e = emu(); kw_switch_ctx(&e.fibers[e.cur].sp, e.sched_sp); }
+inline void fiber_entry() {
+    Emu& e = emu();
+    (*e.body)();
+    e.fibers[e.cur].state = F_DONE;
+    fiber_yield();
+    std::abort();  // never resumed
+}
+// Runs `grid` workgroups of `block` threads, one workgroup at a time, its threads as fibers in lock-step at collectives.
+inline void launch(int grid, int block, size_t dyn_lds_bytes, const std::function<void()>& body) {
+    Emu& e = emu();
+    if (grid <= 0 || block <= 0) return;
+    if (block > 64 * 64) { std::fprintf(stderr, "kw::launch: workgroup too large\n"); std::abort(); }
+    e.lds.assign(dyn_lds_bytes + 64, 0);
+    e.body = &body; e.bdim = block; e.gdim = grid;
+    if ((int)e.fibers.size() < block) e.fibers.resize(block);
+    while ((int)e.stacks.size() < block) e.stacks.push_back(static_cast<char*>(std::malloc(Emu::STACK)));
+    for (int b = 0; b < grid; b++) {
+        e.block = b;
+        for (int t = 0; t < block; t++) {
+            Fiber& f = e.fibers[t]; f.stack = e.stacks[t]; f.state = F_RUN;
+            // initial frame: six callee-saved registers, then the return address = fiber_entry; at its first instruction rsp % 16 == 8
+            uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + Emu::STACK) & ~uintptr_t(15);
+            void** sp = reinterpret_cast<void**>(top) - 2;  // keeps the alignment rule after `ret`
+            *sp = reinterpret_cast<void*>(&fiber_entry);
+            for (int i = 0; i < 6; i++) *--sp = nullptr;
+            f.sp = sp;
+        }
+        int live = block;
+        while (live > 0) {
+            bool progress = false;
+            for (int t = 0; t < block; t++) {
+                if (e.fibers[t].state != F_RUN) continue;
+                e.cur = t; kw_switch_ctx(&e.sched_sp, e.fibers[t].sp);
+                progress = true;
+                if (e.fibers[t].state == F_DONE) live--;
+            }
+            // release the barriers every live participant has reached
+            bool all_block = true; int waiting = 0;
+            for (int t = 0; t < block; t++) { int s = e.fibers[t].state; if (s == F_RUN || s == F_WAIT_WAVE) all_block = false; if (s == F_WAIT_BLOCK) waiting++; }
+            if (all_block && waiting) { for (int t = 0; t < block; t++) if (e.fibers[t].state == F_WAIT_BLOCK) e.fibers[t].state = F_RUN; progress = true; }
+            for (int w = 0; w * 64 < block; w++) {
+                bool all = true; int nw = 0;
+                for (int t = w * 64; t < block && t < w * 64 + 64; t++) { int s = e.fibers[t].state; if (s == F_RUN || s == F_WAIT_BLOCK) all = false; if (s == F_WAIT_WAVE) nw++; }
+                if (all && nw) { for (int t = w * 64; t < block && t < w * 64 + 64; t++) if (e.fibers[t].state == F_WAIT_WAVE) e.fibers[t].state = F_RUN; progress = true; }
+            }
+            if (!progress && live > 0) { std::fprintf(stderr, "kw::launch: deadlock (a collective not reached by every live lane)\n"); std::abort(); }
+        }
+    }
+    e.body = nullptr;
+}
+inline int tid() { return emu().cur; }
+inline int bid() { return emu().block; }
+inline int bdim() { return emu().bdim; }
+inline int gdim() { return emu().gdim; }
+inline int lane() { return emu().cur & 63; }
+inline void sync() { Emu& e = emu(); e.fibers[e.cur].state = F_WAIT_BLOCK; fiber_yield(); }
+inline void wave_bar() { Emu& e = emu(); e.fibers[e.cur].state = F_WAIT_WAVE; fiber_yield(); }
+inline uint64_t* wave_slots() { Emu& e = emu(); return e.xchg + (size_t)(e.cur >> 6) * 64; }
+inline bool lane_live(int l) { Emu& e = emu(); int t = (e.cur & ~63) + l; return t < e.bdim && e.fibers[t].state != F_DONE; }
+template <class T> inline T shfl(T v, int src) {
+    static_assert(sizeof(T) <= 8, "shfl: 8 bytes at most");
+    uint64_t raw = 0; std::memcpy(&raw, &v, sizeof(T));
+    wave_slots()[lane()] = raw; wave_bar();
+    uint64_t got = wave_slots()[src & 63]; wave_bar();
+    T r; std::memcpy(&r, &got, sizeof(T)); return r;
+}
+template <class T> inline T shfl_up(T v, int d) { int l = lane(); T r = shfl(v, l >= d ? l - d : l); return l >= d ? r : v; }
+inline uint64_t ballot(bool p) {
+    wave_slots()[lane()] = p ? 1 : 0; wave_bar();
+    uint64_t m = 0; for (int l = 0; l < 64; l++) if (lane_live(l) && wave_slots()[l]) m |= 1ull << l;
+    wave_bar(); return m;
+}
+inline uint64_t wave_max_u64(uint64_t v) {
+    wave_slots()[lane()] = v; wave_bar();
+    uint64_t m = 0; for (int l = 0; l < 64; l++) if (lane_live(l) && wave_slots()[l] > m) m = wave_slots()[l];
+    wave_bar(); return m;
+}
+inline int atomic_add(int32_t* p, int v) { int o = *p; *p = o + v; return o; }
+inline int atomic_min(int32_t* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+inline int atomic_max(int32_t* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+inline unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+inline unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
+inline double atomic_add(double* p, double v) { double o = *p; *p = o + v; return o; }
+inline int64_t clock() { return 0; }
+inline unsigned char* dyn_lds() { Emu& e = emu(); return reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(e.lds.data()) + 15) & ~uintptr_t(15)); }
+inline void fence() {}
+inline void fence_wg() {}
+}  // namespace kw
+#endif
+
+namespace kw {
+// arg-max of (key, n) over the wave, ties to the lowest lane; every lane returns the winner (key 0 = none).  Same contract as
+// kai::wave_argmax_first (kai_wave.hpp), which it is on the device.
+KW_DEV void wave_argmax_first(uint64_t& key, int& n) {
+    const uint64_t m = wave_max_u64(key);
+    const uint64_t win = ballot(key == m);
+    const int l = __builtin_ctzll(win);
+    n = shfl(n, l);
+    key = m;
+}
+// inclusive prefix sums over the 64 lanes (Hillis-Steele with shfl_up)
+template <class T> KW_DEV T wave_scan_add(T v) {
+    for (int d = 1; d < 64; d <<= 1) { T o = shfl_up(v, d); if (lane() >= d) v = v + o; }
+    return v;
+}
+}  // namespace kw

@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "../../kai-scheduler_amd/csrc/kai_host_prep.hpp"
+#include "../../kai-scheduler_amd/csrc/kai_batch_kernels.hpp"
+#include "../../kai-scheduler_amd/csrc/kai_batch_driver.hpp"
 
 using namespace kai;
 
@@ -93,6 +95,24 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     bool staged(int j) { bool r = KAI_JOBPF.job == j && KAI_JOBPF.ok; KAI_JOBPF.job = -1; return r; }
     void hot(const KaiCtx& c, QNode*& qn, int32_t*& qheap, int32_t*& root_heap) { qn = c.qn; qheap = c.qheap; root_heap = c.root_heap; }
     int64_t clock() { return 0; }
+};
+
+// the batch path's kernels on the lock-step emulator (kai_simt.hpp)
+struct HostLauncher {
+    void static_rank(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_static_rank(c); }); }
+    void static_check(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_static_check(c); }); }
+    void qualify(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_qualify(c); }); }
+    void nrec(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_build_nrec(c); }); }
+    void plan_setup(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_setup(c, rp); }); }
+    void plan_leaf(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_leaf(c, rp); }); }
+    void plan_rank(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_rank(c, rp); }); }
+    void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_scan(c, rp); }); }
+    void plan_emit(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_plan_emit(c); }); }
+    void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) { kw::launch(g, b, dyn, [&] { kb_fill(c, rp, l1); }); }
+    void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base) { kw::launch(g, b, 0, [&] { kb_apply_jobs(c, ops_base); }); }
+    void apply_nodes(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_apply_nodes(c); }); }
+    int read(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); return 0; }
+    int write(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); return 0; }
 };
 
 template <class T> T* own(std::vector<std::vector<char>>& pool, size_t n) {
@@ -285,7 +305,10 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.now_ns = cfg->now_ns; c.def_preempt_mr = cfg->default_preempt_min_runtime_ns; c.def_reclaim_mr = cfg->default_reclaim_min_runtime_ns; c.reclaim_method = cfg->reclaim_resolve_method;
     c.max_consolidation_preemptees = cfg->max_consolidation_preemptees; c.allow_consolidating_reclaim = cfg->allow_consolidating_reclaim; c.saturation_multiplier = cfg->reclaimer_saturation_multiplier;
     { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; c.sv.xr_group = own<int32_t>(pool, (size_t)c.sv.xr_mask + 1); }
+    if (int rc = batch_bind(c, prep, [&](size_t bytes) { return (void*)own<char>(pool, bytes); }, [&](void* d, const void* h, size_t n) { std::memcpy(d, h, n); return 0; })) return rc;
+    if (shared || std::getenv("KAI_HOSTSIM_NO_BATCH")) c.bt.enabled = 0;
     HostBackend be; Engine<HostBackend> eng(c, be);
+    int64_t batch_rounds = 0, batch_actions = 0;
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;
         if (actions[i] != KAI_ACTION_ALLOCATE && cfg->use_scheduling_signatures && !s->job_signature && J > 0) return KAI_ERR_UNSUPPORTED;
@@ -299,7 +322,14 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         if (std::getenv("KAI_HOSTSIM_PS")) { int ps = std::atoi(std::getenv("KAI_HOSTSIM_PS")); std::fprintf(stderr, "host_sim: before action %d podset %d active_alloc %d used %d alive %d pipelined %d\n", actions[i], ps, c.s_active_alloc[ps], c.s_active_used[ps], c.s_alive[ps], c.s_pipelined[ps]); }
         if (c.st->non_allocate_commits) c.fast_ok = 0;  // as kai_action_execute does after every action
         if (actions[i] != KAI_ACTION_ALLOCATE) { eng.execute_victim_action(); continue; }
-        eng.execute_allocate();
+        {   // the batch path when the action qualifies (kai_batch.hpp), else the sequential engine — as kai_action_execute does
+            HostLauncher hl; BatchStats bs;
+            if (int rc = batch_allocate(hl, c, prep.shape, bs, c.st->out_len)) return rc;
+            if (bs.ran) {
+                c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops;
+                c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++;
+            } else eng.execute_allocate();
+        }
         if (c.st->drain_pending) {                                         // k_drain
             for (int x = 0; x < J; x++) {
                 int q = prep.slot_queue[x]; if (q < 0) continue; int pos = x - c.q_job_off[q];
@@ -323,6 +353,6 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (pod_node_out) for (int p = 0; p < P; p++) pod_node_out[p] = c.p_node[p] >= 0 ? prep.perm[c.p_node[p]] : -1;
     if (shares_final) fill(shares_final);
     if (nodes_out) for (int n = 0; n < N; n++) { kai_node_state& o = nodes_out[prep.perm[n]]; std::memset(&o, 0, sizeof(kai_node_state)); for (int r = 0; r < R; r++) { o.idle[r] = c.n_idle[(size_t)r * N + n]; o.releasing[r] = c.n_rel[(size_t)r * N + n]; o.used[r] = c.n_used[(size_t)r * N + n]; } }
-    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; }
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; stats->reserved[4] = batch_actions; stats->reserved[5] = batch_rounds; }
     return KAI_OK;
 }
