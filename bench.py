@@ -73,6 +73,8 @@ def main():
     snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=pkg.dist.shard_seed(0, rank))  # every rank schedules its own shard
     gen_s = time.time() - t0
     N = snap.n_nodes
+    if os.environ.get("KAI_BENCH_ENGINE_MODE"):
+        cfg.engine_mode = int(os.environ["KAI_BENCH_ENGINE_MODE"])  # 3 = sequential engine only (A/B against the batch path)
 
     def barrier():
         pkg.dist.barrier(torch.cuda.synchronize)
@@ -125,7 +127,11 @@ def main():
                    "snapshot_gen_s": round(gen_s, 2), "host_to_hbm_s": round(upload_s, 3),
                    "engine": {"index_queries": int(st.reserved[0]), "block_refreshes": int(st.reserved[1]), "brute_force_scans": int(st.node_scans),
                               "drained_jobs": int(st.reserved[2]), "drained_decisions": int(st.reserved[3]), "jobs_attempted": int(st.jobs_attempted),
-                              "jobs_committed": int(st.jobs_committed), "control_cycles": {"pop": int(st.reserved[4]), "allocate": int(st.reserved[5]), "commit_discard": int(st.reserved[6]), "total": int(st.reserved[7])}}},
+                              "jobs_committed": int(st.jobs_committed),
+                              **({"path": "batch (plan / fill / apply rounds)", "rounds": int(st.reserved[4]), "fill_wave_cycles": int(st.reserved[5]), "mispredicted_jobs": int(st.reserved[6]),
+                                  "plan_ms": (int(st.reserved[7]) >> 42) / 1e3, "fill_ms": ((int(st.reserved[7]) >> 21) & 0x1fffff) / 1e3, "apply_ms": (int(st.reserved[7]) & 0x1fffff) / 1e3}
+                                 if int(st.reserved[4]) > 0 else
+                                 {"path": "sequential engine", "control_cycles": {"allocate": int(st.reserved[5]), "commit_discard": int(st.reserved[6]), "total": int(st.reserved[7])}})}},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(desc), "kernel": "k_action (+ k_job_init, k_leaf_init, k_drain on the same stream)", "kernel_ms": k_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,

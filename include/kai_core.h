@@ -142,7 +142,8 @@ typedef struct kai_config {
     int32_t full_hierarchy_fairness;
     int64_t min_node_gpu_memory;          /* ClusterInfo.MinNodeGPUMemory */
     int32_t queue_depth[4];               /* per kai_action; -1 = infinite (framework/session.go:398-404) */
-    int32_t engine_mode;                  /* 0 = default; 1 = force brute-force node scans; 2 = class index without the staged job path (debug / A-B) */
+    int32_t engine_mode;                  /* 0 = default (allocate: batch plan/fill/apply path when the action qualifies, else the sequential engine);
+                                             1 = force brute-force node scans; 2 = class index without the staged job path; 3 = sequential engine only (debug / A-B) */
     int32_t reserved[7];
     /* minruntime plugin (plugins/minruntime/minruntime.go:40-100): "now" of the cycle, plugin-argument defaults, reclaim resolve method */
     int64_t now_ns;
@@ -306,7 +307,8 @@ typedef struct kai_action_stats {
     int64_t rollbacks;
     double kernel_ms;           /* HIP-event time of the action kernel on its stream */
     double upload_ms;           /* snapshot → HBM (session_open only) */
-    int64_t reserved[8];
+    int64_t reserved[8];        /* [0] index queries, [1] block refreshes / loads, [2] drained jobs | scenarios, [3] drained decisions | simulations,
+                                   [4] rounds of the batch path (0 = sequential engine), [5..7] cycle / time counters of the path that ran (kai_core.hip) */
 } kai_action_stats;
 
 typedef struct kai_core kai_core; /* opaque */

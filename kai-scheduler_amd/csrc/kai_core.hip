@@ -15,6 +15,8 @@
 
 #include "kai_host_prep.hpp"
 #include "kai_kernels.hpp"
+#include "kai_batch_kernels.hpp"
+#include "kai_batch_driver.hpp"
 
 using namespace kai;
 
@@ -39,6 +41,9 @@ struct kai_core {
     int32_t *d_status0 = nullptr, *d_node0 = nullptr; QShare* d_shares0 = nullptr;  // HBM-resident initial state for kai_session_reset
     std::vector<int32_t> perm;  // engine node index (= name rank) → caller's node index
     kai_action_stats stats{};
+    HostPrep::BatchShape shape;  // batch path of the allocate action (kai_batch.hpp)
+    hipEvent_t bev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double batch_plan_ms = 0, batch_fill_ms = 0, batch_apply_ms = 0;
 };
 
 #define HIP_TRY(core, expr)                                                                                        \
@@ -136,11 +141,46 @@ int launch_open_kernels(kai_core* core) {
     HIP_TRY(core, hipGetLastError());
     return KAI_OK;
 }
+// the batch path's kernels on the session's stream (kai_batch_driver.hpp's Launcher)
+struct DevLauncher {
+    kai_core* core; int rc = 0; bool fill_attr_set = false;
+    void static_rank(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_static_rank, dim3(g), dim3(b), 0, core->stream, c); }
+    void static_check(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_static_check, dim3(g), dim3(b), 0, core->stream, c); }
+    void qualify(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_qualify, dim3(g), dim3(b), 0, core->stream, c); }
+    void nrec(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_nrec, dim3(g), dim3(b), 0, core->stream, c); }
+    void plan_setup(int g, int b, const KaiCtx& c, RoundParams rp) { (void)hipEventRecord(core->bev[0], core->stream); hipLaunchKernelGGL(k_plan_setup, dim3(g), dim3(b), 0, core->stream, c, rp); }
+    void plan_leaf(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_leaf, dim3(g), dim3(b), 0, core->stream, c, rp); }
+    void plan_rank(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_rank, dim3(g), dim3(b), 0, core->stream, c, rp); }
+    void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_scan, dim3(g), dim3(b), 0, core->stream, c, rp); }
+    void plan_emit(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_plan_emit, dim3(g), dim3(b), 0, core->stream, c); }
+    void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) {
+        if (!fill_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_attr_set = true; }
+        if (rp.mode == 0) (void)hipEventRecord(core->bev[1], core->stream);
+        hipLaunchKernelGGL(k_fill, dim3(g), dim3(b), dyn, core->stream, c, rp, l1);
+        if (rp.mode == 0) (void)hipEventRecord(core->bev[2], core->stream);
+    }
+    void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base) { hipLaunchKernelGGL(k_apply_jobs, dim3(g), dim3(b), 0, core->stream, c, (long long)ops_base); }
+    void apply_nodes(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_apply_nodes, dim3(g), dim3(b), 0, core->stream, c); (void)hipEventRecord(core->bev[3], core->stream); timed = true; }
+    bool timed = false;
+    int read(void* dst, const void* src, size_t n) {
+        if (hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, core->stream) != hipSuccess || hipStreamSynchronize(core->stream) != hipSuccess || hipGetLastError() != hipSuccess) { core->err = "batch path: device error"; return KAI_ERR_HIP; }
+        if (rc) return rc;
+        if (timed) {  // the round's phases, from the events recorded around them
+            float a = 0, f = 0, p = 0;
+            if (hipEventElapsedTime(&p, core->bev[0], core->bev[1]) == hipSuccess && hipEventElapsedTime(&f, core->bev[1], core->bev[2]) == hipSuccess && hipEventElapsedTime(&a, core->bev[2], core->bev[3]) == hipSuccess) {
+                core->batch_plan_ms += p; core->batch_fill_ms += f; core->batch_apply_ms += a;
+            }
+            timed = false;
+        }
+        return KAI_OK;
+    }
+    int write(void* dst, const void* src, size_t n) { return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, core->stream) == hipSuccess ? KAI_OK : KAI_ERR_HIP; }
+};
 }  // namespace
 
 extern "C" {
 
-const char* kai_version(void) { return "kai_core abi 1 gfx950 (HIP, device-resident engine, class index)"; }
+const char* kai_version(void) { return "kai_core abi 4 gfx950 (HIP; batch plan/fill/apply path + device-resident sequential engine, class index)"; }
 
 const char* kai_last_error(kai_core* core) { return core ? core->err.c_str() : "null handle"; }
 
@@ -154,7 +194,8 @@ int kai_core_create(const kai_config* cfg, int n_gpus, const int* gpu_ids, kai_c
     kai_core* core = new kai_core();
     core->cfg = *cfg; core->device = dev;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&core->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&core->ev0) != hipSuccess || hipEventCreate(&core->ev1) != hipSuccess) {
+        hipEventCreate(&core->ev0) != hipSuccess || hipEventCreate(&core->ev1) != hipSuccess || hipEventCreate(&core->bev[0]) != hipSuccess ||
+        hipEventCreate(&core->bev[1]) != hipSuccess || hipEventCreate(&core->bev[2]) != hipSuccess || hipEventCreate(&core->bev[3]) != hipSuccess) {
         delete core;
         return KAI_ERR_HIP;
     }
@@ -168,6 +209,7 @@ int kai_core_destroy(kai_core* core) {
     free_session(core);
     if (core->ev0) (void)hipEventDestroy(core->ev0);
     if (core->ev1) (void)hipEventDestroy(core->ev1);
+    for (hipEvent_t e : core->bev) if (e) (void)hipEventDestroy(e);
     if (core->stream) (void)hipStreamDestroy(core->stream);
     delete core;
     return KAI_OK;
@@ -305,6 +347,12 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dzero(core, &core->d_weight, (size_t)3 * Q)); TRY(dzero(core, &core->d_rem_amt, (size_t)3 * Q)); TRY(dzero(core, &core->d_rem_has, (size_t)3 * Q));
     TRY(dzero(core, &core->d_best_out, (size_t)2));
     TRY(dupload_f(core, c.q_share, prep.shares.data(), prep.shares.size()));
+    // batch path of the allocate action (kai_batch.hpp): its pools and tables, when the snapshot admits it
+    core->shape = prep.shape;
+    {   int rcb = batch_bind(c, prep,
+            [&](size_t bytes) -> void* { char* p = nullptr; if (dalloc(core, &p, bytes)) return nullptr; if (hipMemsetAsync(p, 0, bytes, core->stream) != hipSuccess) return nullptr; return p; },
+            [&](void* d, const void* h, size_t n) -> int { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, core->stream) == hipSuccess ? 0 : (int)KAI_ERR_HIP; });
+        if (rcb) return fail(core, rcb, "batch path buffers"); }
     // keep the initial dynamic state in HBM so that kai_session_reset needs no host traffic
     TRY(dalloc(core, &core->d_status0, (size_t)P)); TRY(dalloc(core, &core->d_node0, (size_t)P)); TRY(dalloc(core, &core->d_shares0, (size_t)std::max(Q, 1) * 3));
 #undef TRY
@@ -392,7 +440,21 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     const int TB = 256;
     if (c.J) hipLaunchKernelGGL(k_job_init, dim3((c.J + TB - 1) / TB), dim3(TB), 0, core->stream, c);
     if (c.Q) hipLaunchKernelGGL(k_leaf_init, dim3((c.Q + 3) / 4), dim3(TB), 0, core->stream, c);
-    {   // dynamic LDS: upper levels of the class index, plus the job-order tree when it fits beside them (160 KiB per CU)
+    BatchStats bs; core->batch_plan_ms = core->batch_fill_ms = core->batch_apply_ms = 0;
+    if (!victim) {  // the batch path (plan / fill / apply rounds, kai_batch.hpp) when the action qualifies
+        DevLauncher dl{core};
+        int rcb = batch_allocate(dl, c, core->shape, bs);
+        if (rcb) { if (core->err == "ok") core->err = "batch path failed"; return rcb; }
+        if (bs.ran) {
+            EngineState sb{};
+            HIP_TRY(core, hipMemcpyAsync(&sb, KAI_VP(c.st), sizeof(sb), hipMemcpyDeviceToHost, core->stream));
+            HIP_TRY(core, hipStreamSynchronize(core->stream));
+            sb.decisions += bs.decisions; sb.jobs_attempted += bs.attempted; sb.jobs_committed += bs.committed; sb.rollbacks += bs.rollbacks; sb.out_len += bs.ops;
+            sb.index_queries += bs.decisions; sb.drain_pending = bs.drain;
+            HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.st), &sb, sizeof(sb), hipMemcpyHostToDevice, core->stream));
+        }
+    }
+    if (!bs.ran) {  // dynamic LDS: upper levels of the class index, plus the job-order tree when it fits beside them (160 KiB per CU)
         size_t idx_b = lds_index_bytes(c.C, c.NSB), tree_b = lds_tree_bytes(c.Q);
         const size_t budget = 160 * 1024 - 16384;  // static LDS of the kernel (mailbox, context, engine scalars, frame: 6.8 KB, llvm-readelf .group_segment_fixed_size) + margin
         int tree_in_lds = (idx_b + tree_b <= budget && !std::getenv("KAI_TREE_IN_HBM")) ? 1 : 0;
@@ -416,7 +478,17 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     core->stats.upload_ms = upload; core->stats.kernel_ms = ms; core->stats.decisions = st.decisions; core->stats.node_scans = st.node_scans;
     core->stats.nodes_scanned = st.nodes_scanned; core->stats.jobs_attempted = st.jobs_attempted; core->stats.jobs_committed = st.jobs_committed; core->stats.rollbacks = st.rollbacks;
     core->stats.reserved[0] = st.index_queries; core->stats.reserved[1] = st.index_refreshes; core->stats.reserved[2] = victim ? st.scenarios : st.drained_jobs; core->stats.reserved[3] = victim ? st.simulations : st.drained_decisions;
-    for (int i = 0; i < 4; i++) core->stats.reserved[4 + i] = st.prof[i == 3 ? 7 : i == 2 ? 3 : i == 1 ? 2 : 0];  // control-lane cycles: pop, allocate, commit/discard, total
+    // reserved[4] = plan/fill rounds of the batch path (0 = the sequential engine ran the action); batch path: [5] fill-wave cycles, [6] mispredicted jobs,
+    // [7] plan / fill / apply time in microseconds, 21 bits each; sequential engine: [5..7] control-lane cycles allocate / commit+discard / total
+    if (bs.ran) {
+        core->stats.reserved[4] = bs.rounds; core->stats.reserved[5] = bs.fill_cycles; core->stats.reserved[6] = bs.mismatches;
+        auto us = [](double ms) { int64_t v = (int64_t)(ms * 1000.0); return v < 0 ? (int64_t)0 : v > 0x1fffff ? (int64_t)0x1fffff : v; };
+        core->stats.reserved[7] = (us(core->batch_plan_ms) << 42) | (us(core->batch_fill_ms) << 21) | us(core->batch_apply_ms);
+        core->stats.reserved[1] = bs.block_loads;
+        if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai batch: rounds %lld mismatches %lld planned %lld max_h %d | fill cycles %lld load %lld update %lld rescan %lld | block loads %lld rescans %lld %lld %lld | plan %.3f ms fill %.3f ms apply %.3f ms\n",
+            (long long)bs.rounds, (long long)bs.mismatches, (long long)bs.planned, bs.max_h, (long long)bs.fill_cycles, (long long)bs.fill_load, (long long)bs.fill_update, (long long)bs.fill_rescan,
+            (long long)bs.block_loads, (long long)bs.rescans1, (long long)bs.rescans2, (long long)bs.rescans3, core->batch_plan_ms, core->batch_fill_ms, core->batch_apply_ms);
+    } else { core->stats.reserved[4] = 0; core->stats.reserved[5] = st.prof[2]; core->stats.reserved[6] = st.prof[3]; core->stats.reserved[7] = st.prof[7]; }
     if (std::getenv("KAI_PROF")) { std::fprintf(stderr, "kai prof:"); for (int i = 0; i < 16; i++) std::fprintf(stderr, " %lld", (long long)st.prof[i]); std::fprintf(stderr, "\n"); }
     if (st.non_allocate_commits) c.fast_ok = 0;  // the staged job path assumes nothing releasing / pipelined in the session (kai_host_prep.hpp); until the next open / reset
     if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d (engine source line %d)", st.fault, st.fault_line); core->err = buf; return KAI_ERR_DEVICE_FAULT; }

@@ -134,7 +134,7 @@ struct HostPrep {
         { std::vector<int32_t> fill(h_off.begin(), h_off.end() - 1); for (int q = 0; q <= Q; q++) h_nodes[fill[q_height[q]]++] = q; }
         for (int q = 0; q < Q; q++) if (child_off[q + 1] == child_off[q]) shape.n_leaves++;
         // exact sums: per resource every quantity is a non-negative integer multiple of one power of two, and the totals stay below 2^53 units
-        batch_ok = (cfg.engine_mode == 0 || cfg.engine_mode == 4) && R <= 4 && n_heights <= 16;
+        batch_ok = cfg.engine_mode == 0 && R <= 4 && n_heights <= 16;
         for (int r = 0; r < R && batch_ok; r++) {
             uint64_t bits = 0; bool ok = true;
             auto take = [&](double v) { if (!(v >= 0) || v != std::floor(v) || v >= 9.2e18) { ok = false; return; } bits |= (uint64_t)v; };

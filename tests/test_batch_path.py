@@ -1,0 +1,78 @@
+"""The batch path of the allocate action (kai-scheduler_amd/csrc/kai_batch.hpp: plan / fill / apply) against the oracle.
+
+CPU part: the kernels' bodies run on the lock-step SIMT emulator of kai_simt.hpp inside tests/host_sim (debug aid, see its header);
+`stats.reserved[4]` = allocate actions that took the batch path, `reserved[5]` = plan/fill rounds.  The `-m gpu` twin of these tests is in
+tests/test_gpu_parity.py (same snapshots through the C ABI on the MI355X)."""
+import numpy as np
+import pytest
+
+import kai_testlib as T
+from test_engine_hostsim import HostSim, assert_same
+
+abi = T.abi
+synth = T.pkg.synth
+
+
+def stats_tuple(s):
+    return (s.decisions, s.jobs_attempted, s.jobs_committed, s.rollbacks)
+
+
+def regular_snapshot(seed):
+    """Clusters whose queued jobs are all 'regular' (plain gangs, one pod-set): what the batch path takes.  Everything else varies:
+    queue tree shape (1-4 levels, ragged fan-out), quotas (zipf), limits, queue priorities, over-quota weights, historical usage,
+    non-preemptible jobs, CPU-only jobs and nodes, node mix, pre-filled nodes, lexicographic node names."""
+    rng = np.random.default_rng(9000 + seed)
+    levels = [(1,), (3,), (2, 2), (3, 4), (2, 2, 2), (1, 5), (4, 1, 3), (2, 3, 2, 2)][seed % 8]
+    n_nodes = int(rng.integers(1, 150)); n_pods = int(rng.integers(1, 1200))
+    snap = synth.make_snapshot(n_nodes, n_pods, 9000 + seed, queue_levels=levels, prefill=float(rng.random()) * 0.9,
+                               gpu_mix=((8, .5), (4, .3), (0, .2)) if seed % 3 else ((8, 1.0),), cpu_only_frac=0.3 if seed % 2 else 0.0,
+                               zipf=bool(seed % 2), limits_frac=0.4 if seed % 3 == 0 else 0.0, queue_prios=(100, 200) if seed % 4 < 2 else (100,),
+                               oqws=(1.0, 2.0, 4.0), nonpreempt_frac=0.25 if seed % 5 < 3 else 0.0, usage_max=0.3 if seed % 2 else 0.0,
+                               lexi_names=bool(seed % 7 == 0), single_pod_jobs=bool(seed % 11 == 0))
+    return snap
+
+
+def run_both(snap, cfg, need_batch=True):
+    ref = T.Oracle.run(snap, cfg)
+    res = HostSim.run(snap, cfg)
+    assert_same(res, ref)
+    assert stats_tuple(res.stats) == stats_tuple(ref.stats)
+    if need_batch:
+        assert res.stats.reserved[4] == 1, "the allocate action did not take the batch path"
+    seq = abi.KaiConfig.from_buffer_copy(cfg); seq.engine_mode = 3  # the sequential engine on the same snapshot
+    res3 = HostSim.run(snap, seq)
+    assert res3.stats.reserved[4] == 0
+    assert_same(res3, ref)
+    return res
+
+
+@pytest.mark.parametrize("idx,scale", [(0, 1.0), (1, 0.2), (2, 0.03), (4, 0.006)])
+def test_batch_baseline_configs(idx, scale):
+    snap, cfg, _ = synth.config(idx, scale)
+    res = run_both(snap, cfg)
+    assert res.stats.reserved[5] >= 1
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_batch_random_regular(seed):
+    snap = regular_snapshot(seed)
+    strat = (abi.BINPACK, abi.SPREAD)[seed % 2]
+    cfg = abi.default_config(gpu_strategy=strat, cpu_strategy=(abi.BINPACK, abi.SPREAD)[(seed // 2) % 2], k_value=float(seed % 3) * 0.5)
+    run_both(snap, cfg)
+
+
+def test_batch_declines_irregular_jobs():
+    """elastic gangs / two pod-sets are pushed back or walk the sub-group tree: the sequential engine takes the action"""
+    snap = synth.make_snapshot(30, 300, 77, queue_levels=(2, 2), elastic_frac=0.4, multi_podset_frac=0.3)
+    res = HostSim.run(snap, abi.default_config())
+    assert res.stats.reserved[4] == 0
+    assert_same(res, T.Oracle.run(snap, abi.default_config()))
+
+
+def test_batch_after_victim_actions_is_sequential():
+    """once something is releasing in the session the batch path (Idle == Idle+Releasing) is off"""
+    snap = synth.make_crowded_snapshot(8, 1003, elastic_frac=0.0)
+    cfg = abi.default_config(max_consolidation_preemptees=-1)
+    acts = ("reclaim", "allocate")
+    ref = T.Oracle.run(snap, cfg, acts); res = HostSim.run(snap, cfg, acts)
+    assert_same(res, ref)

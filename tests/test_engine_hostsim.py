@@ -21,7 +21,8 @@ class HostSim(T.Oracle):
         if cls._sim is None:
             so = os.path.join(T.ROOT, "tests", "host_sim", "libhostsim.so")
             src = os.path.join(T.ROOT, "tests", "host_sim", "host_sim.cpp")
-            deps = [src] + [os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", f) for f in ("kai_engine.hpp", "kai_engine_solver.inc", "kai_host_prep.hpp")]
+            import glob
+            deps = [src] + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.inc")) + glob.glob(os.path.join(T.ROOT, "include", "*.h"))
             if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
                 subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", so, src])
             raw = C.CDLL(so)

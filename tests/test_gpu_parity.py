@@ -266,3 +266,89 @@ def test_gpu_broad_random_cycles(gpu, seed):
     whose keys change while a job waits.  Every case: operations, pod states, node accounting and queue shares identical to the oracle."""
     for snap, cfg, actions in T.broad_case(seed):
         assert_same(run_gpu(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
+
+
+# ------------------------------------------------------------------------------------------------ batch path (kai_batch.hpp) on the MI355X
+def stats_tuple(s):
+    return (s.decisions, s.jobs_attempted, s.jobs_committed, s.rollbacks)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_gpu_batch_random_regular(gpu, seed):
+    """plain-gang clusters over every queue-tree shape: the allocate action must take the batch path and equal the oracle and the sequential engine"""
+    from test_batch_path import regular_snapshot
+    snap = regular_snapshot(seed)
+    cfg = T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], cpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[(seed // 2) % 2], k_value=float(seed % 3) * 0.5)
+    ref = T.Oracle.run(snap, cfg)
+    res = run_gpu(snap, cfg)
+    assert_same(res, ref)
+    assert stats_tuple(res.stats) == stats_tuple(ref.stats)
+    assert res.stats.reserved[4] >= 1 or snap.n_jobs == 0 or ref.stats.jobs_attempted == 0, "the allocate action did not take the batch path"
+    seq = T.abi.KaiConfig.from_buffer_copy(cfg); seq.engine_mode = 3
+    res3 = run_gpu(snap, seq)
+    assert res3.stats.reserved[4] == 0
+    assert_same(res3, ref)
+
+
+@pytest.mark.parametrize("idx,scale", [(1, 1.0), (2, 0.1), (4, 0.02)])
+def test_gpu_batch_and_sequential_engine_agree(gpu, idx, scale):
+    snap, cfg, _ = T.pkg.synth.config(idx, scale)
+    res = run_gpu(snap, cfg)
+    assert res.stats.reserved[4] >= 1
+    seq = T.abi.KaiConfig.from_buffer_copy(cfg); seq.engine_mode = 3
+    res3 = run_gpu(snap, seq)
+    assert res3.stats.reserved[4] == 0
+    assert res.ops == res3.ops and (res.pod_node == res3.pod_node).all() and stats_tuple(res.stats) == stats_tuple(res3.stats)
+    for k in res.shares_final:
+        assert np.array_equal(res.shares_final[k], res3.shares_final[k])
+    for k in res.nodes:
+        assert np.array_equal(res.nodes[k], res3.nodes[k])
+
+
+def test_gpu_three_level_index_against_the_oracle(gpu):
+    """8 192 nodes: the class index has two super-blocks (NSB > 1), the level the small cases never reach; oracle = 40 s of CPU"""
+    snap, cfg, _ = T.pkg.synth.config(4, 0.125)
+    ref = T.Oracle.run(snap, cfg)
+    for mode in (0, 3):
+        c = T.abi.KaiConfig.from_buffer_copy(cfg); c.engine_mode = mode
+        res = run_gpu(snap, c)
+        assert_same(res, ref)
+        assert stats_tuple(res.stats) == stats_tuple(ref.stats)
+        assert (res.stats.reserved[4] >= 1) == (mode == 0)
+
+
+def test_gpu_quarter_scale_modes_agree(gpu):
+    """BASELINE config 5 at a quarter of its size (16 384 nodes x 250 000 pods): batch path vs sequential engine on the device"""
+    snap, cfg, _ = T.pkg.synth.config(4, 0.25)
+    res = run_gpu(snap, cfg)
+    seq = T.abi.KaiConfig.from_buffer_copy(cfg); seq.engine_mode = 3
+    res3 = run_gpu(snap, seq)
+    assert res.stats.reserved[4] >= 1 and res3.stats.reserved[4] == 0
+    assert res.ops == res3.ops and (res.pod_status == res3.pod_status).all() and (res.pod_node == res3.pod_node).all()
+    assert stats_tuple(res.stats) == stats_tuple(res3.stats)
+    for k in res.nodes:
+        assert np.array_equal(res.nodes[k], res3.nodes[k])
+    for k in res.shares_final:
+        assert np.array_equal(res.shares_final[k], res3.shares_final[k])
+
+
+def test_gpu_full_size_against_the_host_compiled_engine(gpu):
+    """BASELINE config 5 at FULL size (65 536 nodes x 1 000 000 pending pods, the benched workload): every committed operation, pod state, node
+    and queue share of the MI355X's batch path against the host-compiled sequential engine (tests/host_sim, 1.2 s of CPU; itself held to the
+    oracle at every size the oracle finishes) and against the oracle's first decisions."""
+    from test_engine_hostsim import HostSim
+    snap, cfg, _ = T.pkg.synth.config(4, 1.0)
+    res = run_gpu(snap, cfg)
+    assert res.stats.reserved[4] >= 1
+    seq = T.abi.KaiConfig.from_buffer_copy(cfg); seq.engine_mode = 3
+    twin = HostSim.run(snap, seq)
+    assert res.ops == twin.ops
+    assert (res.pod_status == twin.pod_status).all() and (res.pod_node == twin.pod_node).all()
+    assert stats_tuple(res.stats) == stats_tuple(twin.stats)
+    for k in twin.nodes:
+        assert np.array_equal(res.nodes[k], twin.nodes[k])
+    for k in twin.shares_final:
+        assert np.array_equal(res.shares_final[k], twin.shares_final[k])
+    bounded = T.abi.KaiConfig.from_buffer_copy(cfg); bounded.reserved[0] = 3000  # the oracle stops after its first 3 000 decisions
+    ref = T.Oracle.run(snap, bounded)
+    assert len(ref.ops) > 500 and res.ops[:len(ref.ops)] == ref.ops
