@@ -35,6 +35,8 @@ BINPACK, SPREAD = 0, 1
 PLUGINS = {"predicates": 0x001, "proportion": 0x002, "priority": 0x004, "elastic": 0x008, "nodeavailability": 0x010,
            "resourcetype": 0x020, "subgrouporder": 0x040, "taskorder": 0x080, "nominatednode": 0x100, "nodeplacement": 0x200,
            "minruntime": 0x400, "topology": 0x800, "gpusharingorder": 0x1000, "gpupack": 0x2000, "gpuspread": 0x4000}
+PLUGIN_PREDICATES, PLUGIN_PROPORTION, PLUGIN_PRIORITY, PLUGIN_ELASTIC, PLUGIN_NODEAVAILABILITY, PLUGIN_RESOURCETYPE = 0x001, 0x002, 0x004, 0x008, 0x010, 0x020
+PLUGIN_SUBGROUPORDER, PLUGIN_TASKORDER, PLUGIN_NOMINATEDNODE, PLUGIN_NODEPLACEMENT, PLUGIN_MINRUNTIME, PLUGIN_TOPOLOGY = 0x040, 0x080, 0x100, 0x200, 0x400, 0x800
 PLUGIN_ALL = 0x3FFF  # the default tier list (conf_util/scheduler_conf_util.go:36-61): everything except gpuspread
 
 STATUS_TEXT = {0: "ok", -1: "invalid argument", -2: "no HIP device", -3: "HIP runtime error", -4: "output capacity",

@@ -19,7 +19,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libkai_core.so")
+LIB_PATH = os.environ.get("KAI_CORE_LIB") or os.path.join(_HERE, "csrc", "libkai_core.so")  # KAI_CORE_LIB: another BUILD of the same HIP library (profiling variants)
 
 EXPORTS = ["kai_core_create", "kai_core_destroy", "kai_session_open", "kai_queue_shares", "kai_action_execute", "kai_best_node",
            "kai_pod_states", "kai_node_states", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]

@@ -33,6 +33,12 @@
 #include "kai_engine.hpp"
 #include "kai_simt.hpp"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KAI_OPAQUE_F64(x) asm volatile("" : "+v"(x))
+#else
+#define KAI_OPAQUE_F64(x) (void)0
+#endif
+
 namespace kai {
 
 // ------------------------------------------------------------------------------------------------------ keys
@@ -100,51 +106,65 @@ KAI_HD int plan_lower_bound(KAI_GP(const PlanKey) keys, int n, const PlanKey& k)
     return lo;
 }
 
-// class key from a node record: kai_engine.hpp class_key_regs with Releasing = 0 and the class_fit lookup folded into okmask
-KAI_HD uint64_t class_key_rec(const KaiCtx& c, const ClassRec& k, int kidx, const NodeRec& s) {
+// The class key (kai_engine.hpp class_key_regs) from a node record, with Releasing = 0 and the static predicates read from okmask.
+// creq / cflags: the class's request vector and bits (1 = CPU-only request, 2 = placement resource is the GPU, 4 = spread strategy).
+KAI_HD uint64_t class_key_rec(uint32_t plugins, int R, const double* creq, uint32_t cflags, int kidx, const NodeRec& s) {
     bool fit = true;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int r = 0; r < 4; r++) {
-        if (r >= c.R) continue;
-        double rq = k.req[r];
+        if (r >= R) continue;
+        const double rq = creq[r];
         if (r >= KAI_RES_PODS && !(rq > 0)) continue;
-        if (rq > s.idle[r] + 0.0) fit = false;
+        if (rq > s.idle[r]) fit = false;
     }
     if (!fit) return 0;
-    const bool cpu_node = !(s.flags & KAI_NODE_MIG_ENABLED) && s.alloc_gpu <= 0 && !(s.flags & KAI_NODE_HAS_DRA_GPUS);
-    if (c.plugins & KAI_PLUGIN_PREDICATES) {
-        if (!k.cpu_only) {
-            if (s.flags & KAI_NODE_HAS_DRA_GPUS) return 0;
-            if ((s.flags & KAI_NODE_MIG_ENABLED) && (s.flags & KAI_NODE_MIG_MIXED)) return 0;
-        }
-        if (!(s.idle[KAI_RES_PODS] + 0.0 > 0)) return 0;
-        if (s.flags & KAI_NODE_NOT_READY) return 0;
-        if (!((s.okmask >> kidx) & 1ull)) return 0;
-        if (c.restrict_nodes) {
-            if (!k.cpu_only) { if (!(s.flags & KAI_NODE_GPU_WORKER)) return 0; }
-            else if (!(s.flags & KAI_NODE_CPU_WORKER)) return 0;
-        }
-    }
+    if ((plugins & KAI_PLUGIN_PREDICATES) && !(s.idle[KAI_RES_PODS] > 0)) return 0;
+    if (!((s.okmask >> kidx) & 1ull)) return 0;
     uint64_t key = 0;
-    if (c.plugins & KAI_PLUGIN_NODEAVAILABILITY) key |= 1ull << 63;  // fits on Idle alone: nothing is releasing on this path
-    if ((c.plugins & KAI_PLUGIN_RESOURCETYPE) && k.cpu_only && cpu_node) key |= 1ull << 62;
+    if (plugins & KAI_PLUGIN_NODEAVAILABILITY) key |= 1ull << 63;  // fits on Idle alone: nothing is releasing on this path
+    if ((plugins & KAI_PLUGIN_RESOURCETYPE) && (cflags & 1u) && s.cpu_node) key |= 1ull << 62;
     uint64_t v = 1;
-    if (c.plugins & KAI_PLUGIN_NODEPLACEMENT) {
-        const bool gpu = k.r_place == KAI_RES_GPU;
-        double cur = gpu ? s.idle[KAI_RES_GPU] + 0.0 : s.idle[KAI_RES_CPU] + 0.0;
-        if (k.strategy == KAI_SPREAD) {
-            double overall = gpu ? s.alloc_gpu : s.alloc_cpu, count = overall;
-            if (gpu) count = s.gpu_count >= 0 ? (double)s.gpu_count : (double)(int64_t)overall;
-            double place = count == 0 ? 0.0 : cur / count;
+    if (plugins & KAI_PLUGIN_NODEPLACEMENT) {
+        const bool gpu = cflags & 2u;
+        // the two candidates as opaque register values: left visible, the compiler folds "select of two loads" into one load at a selected
+        // address, which takes the whole record out of registers into scratch memory (a memory round trip per key)
+        double ig = s.idle[KAI_RES_GPU], ic = s.idle[KAI_RES_CPU]; KAI_OPAQUE_F64(ig); KAI_OPAQUE_F64(ic);
+        const double cur = gpu ? ig : ic;
+        if (cflags & 4u) {
+            double cg = s.cnt_gpu, cc = s.cnt_cpu; KAI_OPAQUE_F64(cg); KAI_OPAQUE_F64(cc);
+            const double count = gpu ? cg : cc;
+            const double place = count == 0 ? 0.0 : cur / count;
             union { double d; uint64_t u; } cv; cv.d = place;
             v = cv.u + 1;
         } else {
-            v = (uint64_t)((((int64_t)1 << 53) - 1) - (int64_t)cur);
+            v = (uint64_t)((((int64_t)1 << 53) - 1) - (int64_t)(int32_t)cur);  // a bin-pack class is indexed only with integer quantities <= 2^30 (HostPrep::build_classes): one v_cvt_i32_f64
         }
     }
     return key | v;
+}
+KAI_HD uint32_t class_flags(const ClassRec& k) { return (k.cpu_only ? 1u : 0u) | (k.r_place == KAI_RES_GPU ? 2u : 0u) | (k.strategy == KAI_SPREAD ? 4u : 0u); }
+// the node record of node n from the session's node arrays (the static predicates of every scan class folded into okmask)
+KAI_HD NodeRec make_node_rec(const KaiCtx& c, int n) {
+    NodeRec r; r.idle[0] = r.idle[1] = r.idle[2] = r.idle[3] = 0; r.cnt_gpu = 0; r.cnt_cpu = 0; r.okmask = 0; r.cpu_node = 0; r.pad = 0;
+    if (n >= c.N) return r;
+    for (int k = 0; k < 4; k++) r.idle[k] = k < c.R ? c.n_idle[(size_t)k * c.N + n] : 0.0;
+    const uint32_t f = c.n_flags[n]; const int nc = c.n_class[n], lbl = c.n_gpu_count[n];
+    const double ag = c.n_alloc[(size_t)KAI_RES_GPU * c.N + n], ac = c.n_alloc[(size_t)KAI_RES_CPU * c.N + n];
+    r.cnt_gpu = lbl >= 0 ? (double)lbl : (double)(int64_t)ag; r.cnt_cpu = ac;
+    r.cpu_node = (!(f & KAI_NODE_MIG_ENABLED) && ag <= 0 && !(f & KAI_NODE_HAS_DRA_GPUS)) ? 1u : 0u;
+    for (int k = 0; k < c.C; k++) {
+        const ClassRec& cr = c.cls[k]; bool ok = true;
+        if (c.plugins & KAI_PLUGIN_PREDICATES) {
+            if (!cr.cpu_only) { if (f & KAI_NODE_HAS_DRA_GPUS) ok = false; if ((f & KAI_NODE_MIG_ENABLED) && (f & KAI_NODE_MIG_MIXED)) ok = false; }
+            if (f & KAI_NODE_NOT_READY) ok = false;
+            if (!c.class_fit[(size_t)cr.pod_class * c.n_node_classes + nc]) ok = false;
+            if (c.restrict_nodes) { if (!cr.cpu_only) { if (!(f & KAI_NODE_GPU_WORKER)) ok = false; } else if (!(f & KAI_NODE_CPU_WORKER)) ok = false; }
+        }
+        if (ok) r.okmask |= 1ull << k;
+    }
+    return r;
 }
 
 }  // namespace kai

@@ -6,6 +6,7 @@
 //                      int write(void* dev_dst, const void* host_src, size_t bytes).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "kai_host_prep.hpp"
@@ -34,11 +35,11 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     b.n_h = prep.n_heights; b.pool_e = (int32_t)batch_pool_e(prep, J, Q); b.pool_k = (int32_t)batch_pool_k(prep, J, Q);
 #define KB_Z(field, n) do { void* p_ = zalloc(std::max<size_t>((size_t)(n), 1) * sizeof(*b.field)); if (!p_) return KAI_ERR_HIP; b.field = (decltype(b.field))p_; } while (0)
     KB_Z(q_height, Q + 1); KB_Z(h_off, b.n_h + 1); KB_Z(h_nodes, Q + 1); KB_Z(q_srank, Q + 1);
-    KB_Z(j_clsmask, J); KB_Z(cur_sp, Q + 1); KB_Z(qual, 4);
+    KB_Z(j_clsmask, J); KB_Z(j_ucls, J); KB_Z(cur_sp, Q + 1); KB_Z(qual, 4);
     KB_Z(q_cnt, Q + 1); KB_Z(q_ebase, Q + 1); KB_Z(q_kbase, Q + 1); KB_Z(q_valid, Q + 1); KB_Z(q_nk, Q + 1); KB_Z(q_sent, Q + 1); KB_Z(q_taken, Q + 1); KB_Z(q_complete, Q + 1);
     KB_Z(pk, b.pool_k); KB_Z(sp, b.pool_k); KB_Z(k_owner, b.pool_k);
     KB_Z(el_leaf, b.pool_e); KB_Z(el_ck, b.pool_e); KB_Z(el_next, b.pool_e); KB_Z(e_job, b.pool_e); KB_Z(e_grank, b.pool_e); KB_Z(e_flag, b.pool_e);
-    KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
+    KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_first, J + 1); KB_Z(g_nt, J + 1); KB_Z(g_ucls, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
     KB_Z(t_cls, P); KB_Z(t_node, P);
     KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1);
 #undef KB_Z
@@ -50,10 +51,10 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
 
 // LDS of the fill kernel: super-block level always, block level when it fits beside it
 inline size_t batch_fill_lds(const KaiCtx& c, int& l1_in_lds) {
-    const size_t l2 = ((size_t)c.C * c.NSB * 12 + 15) & ~(size_t)15, l1 = (size_t)c.C * c.NB * 12 + 16;
-    const size_t budget = 160 * 1024 - 24 * 1024;  // static LDS of the kernel (class table, tops, rollback list) + margin
-    l1_in_lds = (l2 + l1 <= budget) ? 1 : 0;
-    return l2 + (l1_in_lds ? l1 : 0);
+    const size_t l2 = (size_t)c.C * c.NSB * sizeof(IdxE), l1 = (size_t)c.C * c.NB * sizeof(IdxE);
+    const size_t budget = 160 * 1024 - 16 * 1024;  // static LDS of the kernel (class tops, rollback list: 9 KB) + margin
+    l1_in_lds = (l2 + l1 <= budget && !std::getenv("KAI_BATCH_L1_HBM")) ? 1 : 0;  // the variable forces the HBM variant (tests)
+    return l2 + (l1_in_lds ? l1 : 0) + 16;
 }
 
 // Runs the allocate action on the batch path.  ran = false: the action does not qualify, nothing was touched (run the sequential engine).
@@ -71,7 +72,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     if (qual[0] || qual[1]) return 0;
     bs.ran = 1;
     int remaining = qual[2];
-    l.nrec((c.NB * KAI_BLOCK + TB - 1) / TB, TB, c);
+    l.nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
     int l1_in_lds = 0; const size_t dyn = batch_fill_lds(c, l1_in_lds);
     RoundParams rp{}; rp.mode = 1;
     l.fill(1, 64, dyn, c, rp, l1_in_lds);
@@ -88,12 +89,12 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         l.plan_leaf(std::max(Q, 1), 64, c, rp);
         for (int h = 1; h < shape.n_heights; h++) {
             rp.height = h;
-            l.plan_rank((int)((slots + TB - 1) / TB), TB, c, rp);
+            l.plan_rank(std::max(1, (int)((slots + TB - 1) / TB)), TB, c, rp);
             l.plan_scan(std::max(shape.h_count[h], 1), 64, c, rp);
         }
-        l.plan_emit((int)((e_bound + TB - 1) / TB), TB, c);
+        l.plan_emit(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c);
         l.fill(1, 64, dyn, c, rp, l1_in_lds);
-        l.apply_jobs((int)((e_bound + TB - 1) / TB), TB, c, ops_base);
+        l.apply_jobs(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c, ops_base);
         if (Q) l.apply_nodes((Q + TB - 1) / TB, TB, c);
         if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc;
         if (fs.n_done <= 0) return KAI_ERR_DEVICE_FAULT;  // a round always executes at least one job

@@ -6,6 +6,13 @@
 namespace kai {
 
 constexpr int KB_INF = 0x7fffffff;
+#ifdef KAI_FILL_PROF  // section clocks of the fill wave (diagnostic build only: every read of the clock stalls the wave)
+#define KB_T(var) const int64_t var = kw::clock()
+#define KB_ACC(slot, t0) f.cy[slot] += kw::clock() - (t0)
+#else
+#define KB_T(var)
+#define KB_ACC(slot, t0)
+#endif
 constexpr int KB_PLACED_MAX = 1024;  // tasks of one gang the fill kernel can roll back (larger chunks do not qualify)
 
 KW_BODY bool kb_is_leaf(const KaiCtx& c, int q) { return q < c.Q && c.q_child_off[q + 1] == c.q_child_off[q]; }
@@ -37,7 +44,7 @@ KW_BODY void kb_qualify(const KaiCtx& c) {
     const int j = kw::bid() * kw::bdim() + kw::tid();
     if (j >= c.J) return;
     const BatchCtx& b = c.bt;
-    b.j_clsmask[j] = 0;
+    b.j_clsmask[j] = 0; b.j_ucls[j] = -1;
     const int st = c.j_state[j];
     if (st == 3) return;  // not queued
     kw::atomic_add((int32_t*)&b.qual[2], 1);
@@ -53,21 +60,13 @@ KW_BODY void kb_qualify(const KaiCtx& c) {
         }
     }
     if (!ok) { kw::atomic_add((int32_t*)&b.qual[0], 1); return; }
-    b.j_clsmask[j] = mask;
+    b.j_clsmask[j] = mask; b.j_ucls[j] = (mask & (mask - 1)) == 0 ? __builtin_ctzll(mask) : -1;
 }
 // node records of the fill kernel from the session's node arrays (nothing is releasing on this path: the host checked)
 KW_BODY void kb_build_nrec(const KaiCtx& c) {
     const int n = kw::bid() * kw::bdim() + kw::tid();
     if (n >= c.NB * KAI_BLOCK) return;
-    NodeRec r; r.idle[0] = r.idle[1] = r.idle[2] = r.idle[3] = 0; r.alloc_cpu = 0; r.alloc_gpu = 0; r.flags = KAI_NODE_NOT_READY; r.gpu_count = -1; r.okmask = 0;
-    if (n < c.N) {
-        for (int k = 0; k < 4; k++) r.idle[k] = k < c.R ? c.n_idle[(size_t)k * c.N + n] : 0.0;
-        r.alloc_cpu = c.n_alloc[(size_t)KAI_RES_CPU * c.N + n]; r.alloc_gpu = c.n_alloc[(size_t)KAI_RES_GPU * c.N + n];
-        r.flags = c.n_flags[n]; r.gpu_count = c.n_gpu_count[n];
-        const int nc = c.n_class[n];
-        for (int k = 0; k < c.C; k++) if (c.class_fit[(size_t)c.cls[k].pod_class * c.n_node_classes + nc]) r.okmask |= 1ull << k;
-    }
-    c.bt.nrec[n] = r;
+    c.bt.nrec[n] = make_node_rec(c, n);
 }
 
 // ------------------------------------------------------------------------------------------------------ plan: setup
@@ -281,60 +280,113 @@ KW_BODY void kb_plan_emit(const KaiCtx& c) {
     const int t = kw::bid() * kw::bdim() + kw::tid();
     if (t >= b.q_valid[c.Q]) return;
     const int e = b.el_leaf[b.q_ebase[c.Q] + t], job = b.e_job[e];
-    b.e_grank[e] = t; b.g_job[t] = job; b.g_flag[t] = b.e_flag[e];
+    const int flag = b.e_flag[e];
+    b.e_grank[e] = t; b.g_job[t] = job; b.g_flag[t] = (uint8_t)flag;
+    b.g_first[t] = c.j_first_pod[job]; b.g_nt[t] = flag == BF_GATE ? 0 : c.j_tta_n[job]; b.g_ucls[t] = b.j_ucls[job];
 }
 
 // ------------------------------------------------------------------------------------------------------ fill
 // ONE wavefront walks the planned order and places every task: arg-max node of the task's scan class out of the three-level class
-// index (block maxima [C][NB] in HBM or LDS, super-block maxima and class tops in LDS), node update, index maintenance — all inside this
-// wave: lane = node of the current 64-node block (its records stay in registers) for the block level, lane = class for the upper levels.
+// index (block maxima [C][NB] in LDS — or in HBM when they do not fit —, super-block maxima and class tops in LDS), node update, index
+// maintenance, all inside this wave: lane = node of the current 64-node block (its records stay in registers) for the block level,
+// lane = class for the upper levels.  What bounds it is the number of instructions one wave issues per decision, so the hot path keeps its
+// operands in registers (class table: lane k holds class k; broadcasts are v_readlane, not LDS round trips) and touches memory only for the
+// 16-byte index entries and the 32-byte node update.
 struct FillLds {
-    ClassRec cls[KAI_CMAX];
-    uint64_t top_key[KAI_CMAX]; int32_t top_node[KAI_CMAX];
     int32_t placed_node[KB_PLACED_MAX]; int32_t placed_cls[KB_PLACED_MAX];
 };
-struct FillState {
-    int bcur; NodeRec rec;
-    uint64_t* l1k; int32_t* l1n; uint64_t* l2k; int32_t* l2n;
-    int64_t n_loads, n_r1, n_r2, n_r3, cy_load, cy_upd, cy_rescan;
+// block level of the index: 16-byte entries in LDS, or the session's HBM arrays (sum1_key / sum1_node) when C x NB entries do not fit
+KW_BODY void idx_get(KW_LDS_PTR(IdxE) p, int i, uint64_t& key, int& node) { key = p[i].key; node = p[i].node; }  // member-wise: no struct copies across address spaces
+KW_BODY void idx_set(KW_LDS_PTR(IdxE) p, int i, uint64_t key, int node) { p[i].key = key; p[i].node = node; }
+struct L1Lds {
+    KW_LDS_PTR(IdxE) e; int NB;
+    KW_BODY void get(int k, int blk, uint64_t& key, int& node) const { idx_get(e, k * NB + blk, key, node); }
+    KW_BODY void set(int k, int blk, uint64_t key, int node) const { idx_set(e, k * NB + blk, key, node); }
+    KW_BODY void done() const {}
 };
-KW_BODY void kb_fill_load_block(const KaiCtx& c, FillState& fsx, int blk) {
-    if (blk == fsx.bcur) return;
-    const int64_t t0 = kw::clock();
-    kw::fence_wg();  // the record stores of this wave to the block it may be coming back to
-    fsx.rec = c.bt.nrec[(size_t)blk * KAI_BLOCK + kw::lane()]; fsx.bcur = blk; fsx.n_loads++;
-    fsx.cy_load += kw::clock() - t0;
+struct L1Hbm {
+    KAI_GP(uint64_t) key; KAI_GP(int32_t) node; int NB;
+    KW_BODY void get(int k, int blk, uint64_t& ky, int& nd) const { ky = key[(size_t)k * NB + blk]; nd = node[(size_t)k * NB + blk]; }
+    KW_BODY void set(int k, int blk, uint64_t ky, int nd) const { key[(size_t)k * NB + blk] = ky; node[(size_t)k * NB + blk] = nd; }
+    KW_BODY void done() const { kw::fence_wg(); }  // entries written by one lane are read by other lanes of this wave later on
+};
+// plugin bits the class key reads; SPEC instantiations of the fill kernel have them all set and R == 4 as compile-time facts
+constexpr uint32_t KB_KEY_PLUGINS = KAI_PLUGIN_PREDICATES | KAI_PLUGIN_NODEAVAILABILITY | KAI_PLUGIN_RESOURCETYPE | KAI_PLUGIN_NODEPLACEMENT;
+struct FillState {
+    int bcur, sbcur; NodeRec rec;          // the current block: lane i holds node bcur*64 + i
+    double creq[4]; uint32_t cflags;       // lane k: scan class k
+    uint64_t topk; int topn;               // lane k: arg-max key of class k over the cluster and its node
+    uint64_t c1k, c2k; int c1n, c2n; bool c1_dirty, c2_dirty;  // lane k: class k's index entry of the current block / super-block (written back when the wave moves on)
+    int pend_n, pend_cls; uint64_t pend_key;  // node whose index entries are behind its record (see kb_fill_place), the class that is filling it, that class's top key
+    KW_LDS_PTR(IdxE) l2;
+    uint32_t plugins; int R, C, NB, NSB;
+    int64_t n_loads, n_r1, n_r2, n_r3;
+    int64_t cy[4];  // KAI_FILL_PROF: place (top, block, record) / block level / super-block level / class tops
+};
+template <bool SPEC> KW_BODY uint32_t kb_plugins(const FillState& f) { return SPEC ? KB_KEY_PLUGINS : f.plugins; }
+template <bool SPEC> KW_BODY int kb_nres(const FillState& f) { return SPEC ? 4 : f.R; }
+template <bool SPEC>
+KW_BODY uint64_t kb_lane_key(const FillState& f, int kk) {  // key of this lane's node for class kk (kk the same in every lane)
+    double rq[4]; for (int r = 0; r < 4; r++) rq[r] = kw::bcast(f.creq[r], kk);
+    return class_key_rec(kb_plugins<SPEC>(f), kb_nres<SPEC>(f), rq, kw::bcast(f.cflags, kk), kk, f.rec);
+}
+template <class L1>
+KW_BODY void kb_fill_writeback(FillState& f, const L1& l1) {
+    const int lane = kw::lane();
+    if (f.bcur >= 0 && f.c1_dirty && lane < f.C) l1.set(lane, f.bcur, f.c1k, f.c1n);
+    if (f.sbcur >= 0 && f.c2_dirty && lane < f.C) idx_set(f.l2, lane * f.NSB + f.sbcur, f.c2k, f.c2n);
+    f.c1_dirty = false; f.c2_dirty = false;
+    l1.done();
+}
+template <class L1>
+KW_BODY void kb_fill_load_block(const KaiCtx& c, FillState& f, const L1& l1, int blk) {
+    if (blk == f.bcur) return;
+    const int lane = kw::lane(), sb = blk >> 6;
+    if (f.bcur >= 0 && f.c1_dirty && lane < f.C) l1.set(lane, f.bcur, f.c1k, f.c1n);
+    f.c1_dirty = false;
+    kw::fence_wg();  // the record stores of this wave to a block it may be coming back to (and, in HBM, its index entries)
+    f.rec = c.bt.nrec[(size_t)blk * KAI_BLOCK + lane]; f.bcur = blk; f.n_loads++;
+    f.c1k = 0; f.c1n = 0;
+    if (lane < f.C) l1.get(lane, blk, f.c1k, f.c1n);
+    if (sb != f.sbcur) {
+        if (f.sbcur >= 0 && f.c2_dirty && lane < f.C) idx_set(f.l2, lane * f.NSB + f.sbcur, f.c2k, f.c2n);
+        f.c2_dirty = false; f.c2k = 0; f.c2n = 0;
+        if (lane < f.C) idx_get(f.l2, lane * f.NSB + sb, f.c2k, f.c2n);
+        f.sbcur = sb;
+    }
 }
 // node n (in the current block) changed: bring the three index levels up to date for every class
-KW_BODY void kb_fill_node_changed(const KaiCtx& c, FillLds& L, FillState& fsx, int n) {
-    const int64_t t0 = kw::clock();
-    const int lane = kw::lane(), blk = n >> 6, ln = n & 63, sb = blk >> 6, NB = c.NB, NSB = c.NSB, C = c.C;
+template <bool SPEC, class L1>
+KW_BODY void kb_fill_node_changed(FillState& f, const L1& l1, int n) {
+    const int lane = kw::lane(), blk = n >> 6, ln = n & 63, sb = blk >> 6;
+    KB_T(t_l1);
     NodeRec rn;
-    for (int r = 0; r < 4; r++) rn.idle[r] = kw::shfl(fsx.rec.idle[r], ln);
-    rn.alloc_cpu = kw::shfl(fsx.rec.alloc_cpu, ln); rn.alloc_gpu = kw::shfl(fsx.rec.alloc_gpu, ln);
-    rn.flags = (uint32_t)kw::shfl((int)fsx.rec.flags, ln); rn.gpu_count = kw::shfl(fsx.rec.gpu_count, ln); rn.okmask = kw::shfl(fsx.rec.okmask, ln);
-    const bool act = lane < C; const int k = act ? lane : 0;
-    // ---- level 1 (block)
-    const uint64_t kap = act ? class_key_rec(c, L.cls[k], k, rn) : 0;
-    const uint64_t o1k = act ? fsx.l1k[(size_t)k * NB + blk] : 0; const int o1n = act ? fsx.l1n[(size_t)k * NB + blk] : 0;
+    for (int r = 0; r < 4; r++) rn.idle[r] = kw::bcast(f.rec.idle[r], ln);
+    rn.cnt_gpu = kw::bcast(f.rec.cnt_gpu, ln); rn.cnt_cpu = kw::bcast(f.rec.cnt_cpu, ln); rn.okmask = kw::bcast(f.rec.okmask, ln); rn.cpu_node = kw::bcast(f.rec.cpu_node, ln); rn.pad = 0;
+    const bool act = lane < f.C; const int k = act ? lane : 0;
+    // ---- level 1 (block): lane k holds class k's entry of this block
+    const uint64_t kap = act ? class_key_rec(kb_plugins<SPEC>(f), kb_nres<SPEC>(f), f.creq, f.cflags, k, rn) : 0;
+    const uint64_t o1k = f.c1k; const int o1n = f.c1n;
     uint64_t n1k = o1k; int n1n = o1n; bool need = false;
     if (act) {
-        if (o1k != 0 && o1n == n) { if (kap >= o1k) n1k = kap; else need = true; }
+        if (o1k != 0 && o1n == n) { if (kap >= o1k) n1k = kap; else need = true; }  // n was the block's best: a raised key keeps it there, a lowered one needs the others
         else if (key_better(kap, n, o1k, o1n)) { n1k = kap; n1n = n; }
     }
     uint64_t todo = kw::ballot(need);
     while (todo) {
         const int kk = __builtin_ctzll(todo); todo &= todo - 1;
-        const int64_t tr = kw::clock();
-        uint64_t key = class_key_rec(c, L.cls[kk], kk, fsx.rec); int bn = blk * KAI_BLOCK + lane;
+        uint64_t key = kb_lane_key<SPEC>(f, kk); int bn = blk * KAI_BLOCK + lane;
         kw::wave_argmax_first(key, bn);
         if (lane == kk) { n1k = key; n1n = bn; }
-        fsx.n_r1++; fsx.cy_rescan += kw::clock() - tr;
+        f.n_r1++;
     }
     const bool ch1 = act && (n1k != o1k || n1n != o1n);
-    if (ch1) { fsx.l1k[(size_t)k * NB + blk] = n1k; fsx.l1n[(size_t)k * NB + blk] = n1n; }
-    // ---- level 2 (super-block of 64 blocks)
-    const uint64_t o2k = act ? fsx.l2k[k * NSB + sb] : 0; const int o2n = act ? fsx.l2n[k * NSB + sb] : 0;
+    if (ch1) { f.c1k = n1k; f.c1n = n1n; f.c1_dirty = true; }
+    KB_ACC(1, t_l1);
+    if (!kw::ballot(ch1)) return;  // no block maximum moved: the upper levels stand
+    KB_T(t_l2);
+    // ---- level 2 (super-block of 64 blocks): lane k holds class k's entry of this super-block
+    const uint64_t o2k = f.c2k; const int o2n = f.c2n;
     uint64_t n2k = o2k; int n2n = o2n; need = false;
     if (ch1) {
         if (o2k != 0 && (o2n >> 6) == blk) { if (n1k != 0 && n1k >= o2k) { n2k = n1k; n2n = n1n; } else need = true; }
@@ -343,19 +395,22 @@ KW_BODY void kb_fill_node_changed(const KaiCtx& c, FillLds& L, FillState& fsx, i
     todo = kw::ballot(need);
     while (todo) {
         const int kk = __builtin_ctzll(todo); todo &= todo - 1;
-        const int64_t tr = kw::clock();
         const int e = sb * 64 + lane;
-        uint64_t key = e < NB ? fsx.l1k[(size_t)kk * NB + e] : 0; int bn = e < NB ? fsx.l1n[(size_t)kk * NB + e] : KB_INF;
-        const uint64_t pk1 = kw::shfl(n1k, kk); const int pn1 = kw::shfl(n1n, kk);
-        if (e == blk) { key = pk1; bn = pn1; }  // the entry lane kk has just decided, from registers
+        uint64_t key = 0; int bn = KB_INF;
+        if (e < f.NB) l1.get(kk, e, key, bn);
+        const uint64_t pk1 = kw::bcast(n1k, kk); const int pn1 = kw::bcast(n1n, kk);
+        if (e == blk) { key = pk1; bn = pn1; }  // this block's entry lives in lane kk's registers
         kw::wave_argmax_first(key, bn);
         if (lane == kk) { n2k = key; n2n = bn; }
-        fsx.n_r2++; fsx.cy_rescan += kw::clock() - tr;
+        f.n_r2++;
     }
     const bool ch2 = act && (n2k != o2k || n2n != o2n);
-    if (ch2) { fsx.l2k[k * NSB + sb] = n2k; fsx.l2n[k * NSB + sb] = n2n; }
-    // ---- level 3 (class top)
-    const uint64_t o3k = act ? L.top_key[k] : 0; const int o3n = act ? L.top_node[k] : 0;
+    if (ch2) { f.c2k = n2k; f.c2n = n2n; f.c2_dirty = true; }
+    KB_ACC(2, t_l2);
+    if (!kw::ballot(ch2)) return;
+    KB_T(t_l3);
+    // ---- level 3 (class top, in registers)
+    const uint64_t o3k = f.topk; const int o3n = f.topn;
     uint64_t n3k = o3k; int n3n = o3n; need = false;
     if (ch2) {
         if (o3k != 0 && (o3n >> 12) == sb) { if (n2k != 0 && n2k >= o3k) { n3k = n2k; n3n = n2n; } else need = true; }
@@ -364,84 +419,106 @@ KW_BODY void kb_fill_node_changed(const KaiCtx& c, FillLds& L, FillState& fsx, i
     todo = kw::ballot(need);
     while (todo) {
         const int kk = __builtin_ctzll(todo); todo &= todo - 1;
-        const int64_t tr = kw::clock();
-        uint64_t key = lane < NSB ? fsx.l2k[kk * NSB + lane] : 0; int bn = lane < NSB ? fsx.l2n[kk * NSB + lane] : KB_INF;
-        const uint64_t pk2 = kw::shfl(n2k, kk); const int pn2 = kw::shfl(n2n, kk);
-        if (lane == sb) { key = pk2; bn = pn2; }
+        uint64_t key = 0; int bn = KB_INF;
+        if (lane < f.NSB) idx_get(f.l2, kk * f.NSB + lane, key, bn);
+        const uint64_t pk2 = kw::bcast(n2k, kk); const int pn2 = kw::bcast(n2n, kk);
+        if (lane == sb) { key = pk2; bn = pn2; }  // this super-block's entry lives in lane kk's registers
         kw::wave_argmax_first(key, bn);
         if (lane == kk) { n3k = key; n3n = bn; }
-        fsx.n_r3++; fsx.cy_rescan += kw::clock() - tr;
+        f.n_r3++;
     }
-    if (act && (n3k != o3k || n3n != o3n)) { L.top_key[k] = n3k; L.top_node[k] = n3n; }
-    kw::fence_wg();  // index entries written by one lane are read by other lanes of this wave later on
-    fsx.cy_upd += kw::clock() - t0;
+    f.topk = n3k; f.topn = n3n;
+    KB_ACC(3, t_l3);
 }
-// Statement.Allocate's node side (NodeInfo.addTaskResources, node_info.go:457-493) / its undo, on the node record
-KW_BODY void kb_fill_apply(const KaiCtx& c, FillLds& L, FillState& fsx, int n, int kcls, double sign) {
-    kb_fill_load_block(c, fsx, n >> 6);
+// Statement.Allocate's node side (NodeInfo.addTaskResources, node_info.go:457-493) / its undo, on the record of node n (current block)
+KW_BODY void kb_fill_update_rec(const KaiCtx& c, FillState& f, int n, int kcls, double sign) {
+    double rq[4]; for (int r = 0; r < 4; r++) rq[r] = kw::bcast(f.creq[r], kcls);
     if (kw::lane() == (n & 63)) {
-        for (int r = 0; r < 4; r++) { if (r >= c.R) continue; const double v = L.cls[kcls].req[r]; if (v == 0) continue; fsx.rec.idle[r] = fsx.rec.idle[r] - sign * v; }
-        for (int r = 0; r < 4; r++) c.bt.nrec[n].idle[r] = fsx.rec.idle[r];
+        for (int r = 0; r < 4; r++) { if (r >= f.R) continue; const double v = rq[r]; if (v == 0) continue; f.rec.idle[r] = f.rec.idle[r] - sign * v; }
+        for (int r = 0; r < 4; r++) c.bt.nrec[n].idle[r] = f.rec.idle[r];
     }
-    kb_fill_node_changed(c, L, fsx, n);
 }
-KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {
+template <bool SPEC, class L1>
+KW_BODY void kb_fill_flush(FillState& f, const L1& l1) { if (f.pend_n >= 0) { kb_fill_node_changed<SPEC>(f, l1, f.pend_n); f.pend_n = -1; } }
+// One task of scan class kcls: the node it goes to, or -1.  The index is brought up to date LAZILY: while consecutive tasks of one class keep
+// landing on the node that class's top pointed to — its key for the class did not drop below the top key the index holds, so no other node can
+// have overtaken it — only the node's record changes; the index entries of every class follow in one step when another class is asked for,
+// when the node stops being the class's best, or when the round ends.
+template <bool SPEC, class L1>
+KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls) {
+    if (f.pend_n >= 0) {
+        if (kcls == f.pend_cls) {
+            const int ln = f.pend_n & 63;
+            const uint64_t mine = kb_lane_key<SPEC>(f, kcls);
+            const uint64_t kap = kw::bcast(mine, ln);
+            if (kap != 0 && kap >= f.pend_key) { kb_fill_update_rec(c, f, f.pend_n, kcls, 1.0); return f.pend_n; }
+        }
+        kb_fill_flush<SPEC>(f, l1);
+    }
+    KB_T(t_p);
+    const uint64_t tk = kw::bcast(f.topk, kcls); const int tn = kw::bcast(f.topn, kcls);
+    if (tk == 0) return -1;
+    kb_fill_load_block(c, f, l1, tn >> 6);
+    kb_fill_update_rec(c, f, tn, kcls, 1.0);
+    f.pend_n = tn; f.pend_cls = kcls; f.pend_key = tk;
+    KB_ACC(0, t_p);
+    return tn;
+}
+template <bool SPEC, class L1>
+KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState& f, const L1& l1, bool l1_in_lds) {
     const BatchCtx& b = c.bt;
-    KW_SHARED FillLds L;
-    const int lane = kw::lane(), C = c.C, NB = c.NB, NSB = c.NSB;
-    FillState fsx; fsx.bcur = -1; fsx.n_loads = fsx.n_r1 = fsx.n_r2 = fsx.n_r3 = 0; fsx.cy_load = fsx.cy_upd = fsx.cy_rescan = 0;
+    const int lane = kw::lane(), C = f.C, NB = f.NB, NSB = f.NSB;
     const int64_t tstart = kw::clock();
-    unsigned char* dyn = kw::dyn_lds();
-    fsx.l2k = reinterpret_cast<uint64_t*>(dyn); fsx.l2n = reinterpret_cast<int32_t*>(dyn + (size_t)C * NSB * 8);
-    size_t off = ((size_t)C * NSB * 12 + 15) & ~(size_t)15;
-    if (l1_in_lds) {
-        fsx.l1k = reinterpret_cast<uint64_t*>(dyn + off); fsx.l1n = reinterpret_cast<int32_t*>(dyn + off + (size_t)C * NB * 8);
-        for (int i = lane; i < C * NB; i += 64) { fsx.l1k[i] = c.sum1_key[i]; fsx.l1n[i] = c.sum1_node[i]; }
-    } else { fsx.l1k = (uint64_t*)c.sum1_key; fsx.l1n = (int32_t*)c.sum1_node; }
-    for (int k = lane; k < C; k += 64) L.cls[k] = c.cls[k];
+    if (l1_in_lds) for (int i = lane; i < C * NB; i += 64) l1.set(i / NB, i % NB, c.sum1_key[i], c.sum1_node[i]);
     kw::sync();
+    f.topk = 0; f.topn = KB_INF;
     for (int k = 0; k < C; k++) {  // upper levels from the block level
         for (int sb = 0; sb < NSB; sb++) {
             const int e = sb * 64 + lane;
-            uint64_t key = e < NB ? fsx.l1k[(size_t)k * NB + e] : 0; int bn = e < NB ? fsx.l1n[(size_t)k * NB + e] : KB_INF;
+            uint64_t key = 0; int bn = KB_INF;
+            if (e < NB) l1.get(k, e, key, bn);
             kw::wave_argmax_first(key, bn);
-            if (lane == 0) { fsx.l2k[k * NSB + sb] = key; fsx.l2n[k * NSB + sb] = bn; }
+            if (lane == 0) idx_set(f.l2, k * NSB + sb, key, bn);
         }
         kw::sync();
-        uint64_t key = lane < NSB ? fsx.l2k[k * NSB + lane] : 0; int bn = lane < NSB ? fsx.l2n[k * NSB + lane] : KB_INF;
+        uint64_t key = 0; int bn = KB_INF;
+        if (lane < NSB) idx_get(f.l2, k * NSB + lane, key, bn);
         kw::wave_argmax_first(key, bn);
-        if (lane == 0) { L.top_key[k] = key; L.top_node[k] = bn; }
+        if (lane == k) { f.topk = key; f.topn = bn; }
     }
     kw::sync();
     const int V = rp.mode == 0 ? b.q_valid[c.Q] : 0;  // mode 1: index levels and dead classes only (before the first plan)
     int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0; int n_done = 0, mismatch = 0;
     for (int base = 0; base < V && !mismatch; base += 64) {
         const int gi = base + lane;
-        const int my_job = gi < V ? b.g_job[gi] : -1; const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE;
-        const int my_first = my_job >= 0 ? c.j_first_pod[my_job] : 0, my_nt = my_job >= 0 ? c.j_tta_n[my_job] : 0;
+        const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE, my_first = gi < V ? b.g_first[gi] : 0, my_nt = gi < V ? b.g_nt[gi] : 0, my_ucls = gi < V ? b.g_ucls[gi] : 0;
         const int cnt = V - base < 64 ? V - base : 64;
         for (int jj = 0; jj < cnt; jj++) {
-            const int flag = kw::shfl(my_flag, jj), first = kw::shfl(my_first, jj), nt = kw::shfl(my_nt, jj);
+            const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
             attempted++; n_done = base + jj + 1;
             const int opoff = (int)ops;
             bool ok = flag != BF_GATE; int placed = 0;
             if (flag != BF_GATE) {
                 for (int tb = 0; tb < nt && ok; tb += 64) {
-                    const int my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;
+                    int my_cls = ucls;
+                    if (ucls < 0) my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;  // a gang of several scan classes: its task list
                     const int tc = nt - tb < 64 ? nt - tb : 64;
                     for (int ti = 0; ti < tc; ti++) {
-                        const int kcls = kw::shfl(my_cls, ti);
+                        const int kcls = ucls >= 0 ? ucls : kw::bcast(my_cls, ti);
                         decisions++;
-                        const uint64_t tk = L.top_key[kcls]; const int tn = L.top_node[kcls];
-                        if (tk == 0) { ok = false; break; }
-                        kb_fill_apply(c, L, fsx, tn, kcls, 1.0);
+                        const int tn = kb_fill_place<SPEC>(c, f, l1, kcls);
+                        if (tn < 0) { ok = false; break; }
                         if (lane == 0) { L.placed_node[placed] = tn; L.placed_cls[placed] = kcls; b.t_node[first + placed] = tn; }
                         placed++;
                     }
                 }
                 if (!ok) {  // Statement.Rollback: the undone operations in reverse order
+                    kb_fill_flush<SPEC>(f, l1);
                     kw::sync();
-                    for (int i = placed - 1; i >= 0; i--) kb_fill_apply(c, L, fsx, L.placed_node[i], L.placed_cls[i], -1.0);
+                    for (int i = placed - 1; i >= 0; i--) {
+                        const int n = L.placed_node[i];
+                        kb_fill_load_block(c, f, l1, n >> 6); kb_fill_update_rec(c, f, n, L.placed_cls[i], -1.0); kb_fill_node_changed<SPEC>(f, l1, n);
+                    }
                     rollbacks += 2;
                 } else { committed++; ops += nt; }
             }
@@ -449,16 +526,33 @@ KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {
             if ((flag == BF_OK) != ok) { mismatch = 1; break; }
         }
     }
+    kb_fill_flush<SPEC>(f, l1);
+    kb_fill_writeback(f, l1);
     kw::sync();
-    if (l1_in_lds) for (int i = lane; i < C * NB; i += 64) { c.sum1_key[i] = fsx.l1k[i]; c.sum1_node[i] = fsx.l1n[i]; }
-    uint64_t dead = kw::ballot(lane < C && L.top_key[lane < C ? lane : 0] == 0);
+    if (l1_in_lds) for (int i = lane; i < C * NB; i += 64) { uint64_t ky; int nd; l1.get(i / NB, i % NB, ky, nd); c.sum1_key[i] = ky; c.sum1_node[i] = nd; }
+    const uint64_t dead = kw::ballot(lane < C && f.topk == 0);
     if (lane == 0) {
         FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V;
         s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
-        s.cycles_total = kw::clock() - tstart; s.cycles_load = fsx.cy_load; s.cycles_update = fsx.cy_upd; s.cycles_rescan = fsx.cy_rescan;
-        s.block_loads = fsx.n_loads; s.rescans1 = fsx.n_r1; s.rescans2 = fsx.n_r2; s.rescans3 = fsx.n_r3;
+        s.cycles_total = kw::clock() - tstart; s.cycles_load = f.cy[0]; s.cycles_update = f.cy[1]; s.cycles_rescan = f.cy[2] + f.cy[3];
+        s.block_loads = f.n_loads; s.rescans1 = f.n_r1; s.rescans2 = f.n_r2; s.rescans3 = f.n_r3;
         b.fs[0] = s; b.dead_mask[0] = dead;
     }
+}
+KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {
+    KW_SHARED FillLds L;
+    const int lane = kw::lane();
+    FillState f; f.bcur = -1; f.sbcur = -1; f.c1k = f.c2k = 0; f.c1n = f.c2n = 0; f.c1_dirty = f.c2_dirty = false; f.n_loads = f.n_r1 = f.n_r2 = f.n_r3 = 0; f.pend_n = -1; f.pend_cls = 0; f.pend_key = 0; f.topk = 0; f.topn = KB_INF; for (int i = 0; i < 4; i++) f.cy[i] = 0;
+    f.plugins = c.plugins; f.R = c.R; f.C = c.C; f.NB = c.NB; f.NSB = c.NSB;
+    for (int r = 0; r < 4; r++) f.creq[r] = 0; f.cflags = 0;
+    if (lane < c.C) { const ClassRec cr = c.cls[lane]; for (int r = 0; r < 4; r++) f.creq[r] = cr.req[r]; f.cflags = class_flags(cr); }
+    f.rec = make_node_rec(c, c.N);  // an empty record until the first block is loaded
+    unsigned char* dyn = kw::dyn_lds();
+    f.l2 = (KW_LDS_PTR(IdxE))(dyn);
+    const size_t off = (size_t)c.C * c.NSB * sizeof(IdxE);
+    const bool spec = (c.plugins & KB_KEY_PLUGINS) == KB_KEY_PLUGINS && c.R == 4;  // the default plugin tier: the class key folds to its shortest form
+    if (l1_in_lds) { L1Lds l1; l1.e = (KW_LDS_PTR(IdxE))(dyn + off); l1.NB = c.NB; if (spec) kb_fill_run<true>(c, rp, L, f, l1, true); else kb_fill_run<false>(c, rp, L, f, l1, true); }
+    else { L1Hbm l1; l1.key = c.sum1_key; l1.node = c.sum1_node; l1.NB = c.NB; if (spec) kb_fill_run<true>(c, rp, L, f, l1, false); else kb_fill_run<false>(c, rp, L, f, l1, false); }
 }
 
 // ------------------------------------------------------------------------------------------------------ apply

@@ -18,13 +18,17 @@ struct FillStatus {  // written by the fill kernel, read by the host between rou
     int64_t block_loads, rescans1, rescans2, rescans3;
 };
 
-// per-node record of the fill kernel: everything class_key reads of one node, 64 bytes, node-major (one wave loads a 64-node block as 4 KB)
+// per-node record of the fill kernel: everything the class key reads of one node, 64 bytes, node-major (one wave loads a 64-node block as 4 KB).
+// The static predicates (class_fit table, DRA / MIG rules, readiness, worker labels: plugins/predicates/predicates.go:173-262 minus the resource
+// and pod-count checks) are folded into okmask when the records are built.
 struct NodeRec {
     double idle[4];
-    double alloc_cpu, alloc_gpu;
-    uint32_t flags; int32_t gpu_count;
-    uint64_t okmask;  // bit k: the static predicates of scan class k pass on this node (class_fit table)
+    double cnt_gpu, cnt_cpu;  // divisors of the spread score (plugins/nodeplacement/spread.go:16-36)
+    uint64_t okmask;          // bit k: every static predicate of scan class k passes on this node
+    uint32_t cpu_node, pad;   // NodeInfo.IsCPUOnlyNode (node_info.go:697-702)
 };
+// one entry of the class index: arg-max key of a block / super-block / the cluster and the node that holds it (key 0 = no fitting node)
+struct IdxE { uint64_t key; int32_t node, pad; };
 
 struct BatchCtx {
     int32_t enabled, n_h, pool_e, pool_k;  // n_h: heights incl. the virtual root's
@@ -35,6 +39,7 @@ struct BatchCtx {
     KAI_GP(int32_t) q_srank;     // [Q] static rank among siblings: allocatable-share dominance, creation time (queue_order.go:214-240)
     // per action
     KAI_GP(uint64_t) j_clsmask;  // [J] scan classes of the job's chunk
+    KAI_GP(int32_t) j_ucls;      // [J] the one scan class of the job's chunk, -1 = mixed
     KAI_GP(int32_t) cur_sp;      // [Q] stale-path job of an inner node (-1 = its true best job: nothing popped from it yet)
     KAI_GP(int32_t) qual;        // [4] 0: irregular jobs, 1: sibling sets without a strict static order, 2: queued jobs, 3: pad
     // per round
@@ -49,6 +54,7 @@ struct BatchCtx {
     KAI_GP(uint8_t) e_flag;      // [pool_e] leaf regions: BF_*
     // global order + task stream
     KAI_GP(int32_t) g_job, g_opoff;  // [J+1] planned global order: job, offset of its operations among the round's committed ones
+    KAI_GP(int32_t) g_first, g_nt, g_ucls;   // [J+1] the job's pod range start, tasks in its chunk, its one scan class or -1 (what the fill kernel needs, coalesced)
     KAI_GP(uint8_t) g_flag, g_out;           // [J] predicted / actual outcome
     KAI_GP(int32_t) t_cls, t_node;           // [P] (a job's pod range) scan class of the i-th task of its chunk; node the fill kernel gave it
     KAI_GP(NodeRec) nrec;        // [NB*64]

@@ -163,7 +163,8 @@ struct DevLauncher {
     void apply_nodes(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_apply_nodes, dim3(g), dim3(b), 0, core->stream, c); (void)hipEventRecord(core->bev[3], core->stream); timed = true; }
     bool timed = false;
     int read(void* dst, const void* src, size_t n) {
-        if (hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, core->stream) != hipSuccess || hipStreamSynchronize(core->stream) != hipSuccess || hipGetLastError() != hipSuccess) { core->err = "batch path: device error"; return KAI_ERR_HIP; }
+        hipError_t e1 = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, core->stream), e2 = hipStreamSynchronize(core->stream), e3 = hipGetLastError();
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { core->err = std::string("batch path: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3); return KAI_ERR_HIP; }
         if (rc) return rc;
         if (timed) {  // the round's phases, from the events recorded around them
             float a = 0, f = 0, p = 0;

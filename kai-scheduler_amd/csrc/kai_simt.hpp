@@ -18,6 +18,7 @@
 #define KW_DEV __device__ __forceinline__
 #define KW_BODY __device__ __forceinline__  // kernel bodies and their helpers: device code only in the product library
 #define KW_SHARED __shared__
+#define KW_LDS_PTR(T) T __attribute__((address_space(3)))*  // pointer into LDS: ds_read / ds_write instead of flat accesses
 namespace kw {
 KW_DEV int tid() { return (int)threadIdx.x; }
 KW_DEV int bid() { return (int)blockIdx.x; }
@@ -31,6 +32,11 @@ KW_DEV uint64_t shfl(uint64_t v, int src) { return (uint64_t)__shfl((unsigned lo
 KW_DEV int64_t shfl(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
 template <class T> KW_DEV T shfl_up(T v, int d) { return __shfl_up(v, d, 64); }  // lanes < d keep their own value
 KW_DEV uint64_t wave_max_u64(uint64_t v) { return (uint64_t)kai::wave_max_u64((unsigned long long)v); }
+// value of lane `src` in every lane, `src` being the same in all lanes: v_readlane_b32 per dword (no LDS round trip)
+KW_DEV int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+KW_DEV uint32_t bcast(uint32_t v, int src) { return (uint32_t)bcast((int)v, src); }
+KW_DEV uint64_t bcast(uint64_t v, int src) { const int s = __builtin_amdgcn_readfirstlane(src); return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), s) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, s); }
+KW_DEV double bcast(double v, int src) { return __longlong_as_double((long long)bcast((uint64_t)__double_as_longlong(v), src)); }
 KW_DEV int atomic_add(int32_t* p, int v) { return atomicAdd(p, v); }
 KW_DEV int atomic_min(int32_t* p, int v) { return atomicMin(p, v); }
 KW_DEV int atomic_max(int32_t* p, int v) { return atomicMax(p, v); }
@@ -51,6 +57,7 @@ KW_DEV void fence_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); 
 #include <vector>
 #define KW_DEV inline
 #define KW_BODY inline
+#define KW_LDS_PTR(T) T*
 #define KW_SHARED static  // workgroups run one after the other, so one static object per declaration is "the LDS of the running workgroup"
 namespace kw {
 
@@ -172,6 +179,7 @@ inline uint64_t wave_max_u64(uint64_t v) {
     uint64_t m = 0; for (int l = 0; l < 64; l++) if (lane_live(l) && wave_slots()[l] > m) m = wave_slots()[l];
     wave_bar(); return m;
 }
+template <class T> inline T bcast(T v, int src) { return shfl(v, src); }
 inline int atomic_add(int32_t* p, int v) { int o = *p; *p = o + v; return o; }
 inline int atomic_min(int32_t* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 inline int atomic_max(int32_t* p, int v) { int o = *p; if (v > o) *p = v; return o; }

@@ -76,3 +76,21 @@ def test_batch_after_victim_actions_is_sequential():
     acts = ("reclaim", "allocate")
     ref = T.Oracle.run(snap, cfg, acts); res = HostSim.run(snap, cfg, acts)
     assert_same(res, ref)
+
+
+def test_batch_block_level_in_hbm(monkeypatch):
+    """the fill kernel's variant for clusters whose block level does not fit the LDS (KAI_BATCH_L1_HBM forces it)"""
+    monkeypatch.setenv("KAI_BATCH_L1_HBM", "1")
+    for seed in (3, 8, 13):
+        snap = regular_snapshot(seed)
+        run_both(snap, abi.default_config(k_value=0.5))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_batch_plugin_subsets(seed):
+    """without some of the node-order / predicate plugins the fill kernel runs its general (not constant-folded) class key"""
+    snap = regular_snapshot(100 + seed)
+    cfg = abi.default_config(gpu_strategy=(abi.BINPACK, abi.SPREAD)[seed % 2], k_value=0.5)
+    drop = (abi.PLUGIN_RESOURCETYPE, abi.PLUGIN_NODEAVAILABILITY, abi.PLUGIN_NODEPLACEMENT, abi.PLUGIN_RESOURCETYPE | abi.PLUGIN_NODEAVAILABILITY)[seed % 4]
+    cfg.plugins &= ~drop
+    run_both(snap, cfg)
