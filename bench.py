@@ -32,13 +32,14 @@ B_NODE, B_POD_OUT = 128, 80  # algorithmic bytes per node of the node set / per 
 CONFIGS = {"C1": 0, "C2": 1, "C3": 2, "C4": 3, "C5": 4}
 
 
-def pmc_traffic(workload):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this workload (tools/gpu_prof.sh, tools/pmc_traffic.py), or None."""
+def pmc_traffic(workload, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this command (tools/gpu_prof.sh + tools/pmc_traffic.py write
+    profiles/pmc_traffic.json; counters need their own passes, so this is not measured inside the timed run), or None when no pass is on file."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)[workload]["bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+            return json.load(f)[workload][kernel]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
@@ -85,19 +86,23 @@ def main():
     upload_s = time.time() - t0
 
     kernel_ms, open_ms, decisions, placed = [], [], 0, 0
+    first_ops = []
 
     def step(record):
         nonlocal decisions, placed
         ssn.reset()
         o_ms = ssn.stats().upload_ms
         n_ops, n_dec, k_ms_sum, st = 0, 0, 0.0, None
+        ops_step = []
         for a in actions:  # one scheduling cycle: the configured actions in order on the same session
-            n_ops += len(ssn.execute(a))
+            o = ssn.execute(a); n_ops += len(o)
+            ops_step.append(o)  # kept as returned (numpy view of the C ABI's kai_op array): converting is left for after the timed region
             s_a = ssn.stats(); n_dec += int(s_a.decisions); k_ms_sum += s_a.kernel_ms
             st = s_a if st is None else st  # the engine counters reported below are the allocate action's
         if record:
             kernel_ms.append(k_ms_sum); open_ms.append(o_ms)
             decisions = n_dec; placed = n_ops
+            first_ops[:] = ops_step
         return st
 
     for _ in range(args.warmup):
@@ -111,37 +116,54 @@ def main():
     elapsed = pkg.dist.max_over_ranks(elapsed, device="cuda")
     ssn.close(); core.destroy()
 
+    first_ops = [(int(x["kind"]), int(x["pod"]), int(x["node"]), int(x["job"])) for o in first_ops for x in o]  # the last step's committed operations
     total_decisions = pkg.dist.sum_over_ranks(decisions * args.steps, device="cuda")  # one scheduling shard per rank (DESIGN.md "Multi-GPU")
+    total_placed = pkg.dist.sum_over_ranks(placed * args.steps, device="cuda")
     value = total_decisions / elapsed
     k_ms = float(np.mean(kernel_ms))
-    alg_bytes = decisions * (N * B_NODE + B_POD_OUT)
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    b_dec = N * B_NODE + B_POD_OUT
+    batch = int(st.reserved[4]) > 0
     lat = sorted((a + b) for a, b in zip(kernel_ms, open_ms))
+    drained = int(st.reserved[3])
+    engine = {"index_queries": int(st.reserved[0]), "brute_force_scans": int(st.node_scans), "drained_jobs": int(st.reserved[2]), "drained_decisions": drained,
+              "jobs_attempted": int(st.jobs_attempted), "jobs_committed": int(st.jobs_committed)}
+    if batch:
+        plan_ms, fill_ms, apply_ms = (int(st.reserved[7]) >> 42) / 1e3, ((int(st.reserved[7]) >> 21) & 0x1fffff) / 1e3, (int(st.reserved[7]) & 0x1fffff) / 1e3
+        rounds = int(st.reserved[4]); fill_dec = decisions - drained
+        engine.update({"path": "batch (plan / fill / apply rounds)", "rounds": rounds, "mispredicted_jobs": int(st.reserved[6]), "fill_wave_cycles": int(st.reserved[5]),
+                       "fill_block_loads": int(st.reserved[1]), "plan_ms": plan_ms, "fill_ms": fill_ms, "apply_ms": apply_ms,
+                       "fill_cycles_per_decision": int(st.reserved[5]) / max(fill_dec, 1)})
+        # the dominant kernel: k_fill, `rounds` launches per step, timed with HIP events on its stream around every launch (kai_core.hip DevLauncher)
+        alg_bytes_launch = fill_dec * b_dec / max(rounds, 1); avg_launch_ms = fill_ms / max(rounds, 1)
+        achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(desc, "k_fill"),
+                "kernel": "k_fill", "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,
+                "other_kernels": {"plan (k_plan_leaf / rank / scan / emit)": {"ms_per_step": plan_ms}, "apply (k_apply_jobs / nodes)": {"ms_per_step": apply_ms},
+                                  "k_drain": {"decisions": drained, "note": "jobs popped after no class fits anywhere: resolved chip-wide without touching a node; NOT counted in this roofline"}},
+                "note": "achieved = decisions placed by k_fill x (N x 128 B + 80 B) / k_fill time: decision throughput against the roofline of the STREAMING formulation (SURVEY 8d). "
+                        "The class index answers a decision from one 64-node block, so the measured traffic is far below the algorithmic bytes; the kernel is one wavefront "
+                        "bound by instruction issue / dependent latency (fill_cycles_per_decision), not by HBM bandwidth."}
+    else:
+        engine.update({"path": "sequential engine", "control_cycles": {"allocate": int(st.reserved[5]), "commit_discard": int(st.reserved[6]), "total": int(st.reserved[7])}})
+        alg = (decisions - drained) * b_dec; achieved = alg / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(desc, "k_action"), "kernel": "k_action",
+                "launches_per_step": 1, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg, "note": "decisions of k_action x (N x 128 B + 80 B) / action time; latency bound (one control lane)"}
     out = {
         "metric": "pod placement decisions/sec (" + " + ".join(actions) + (" action" if len(actions) == 1 else " actions") + ", synthetic snapshot)", "value": value, "unit": "decisions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "placements_per_s": total_placed / elapsed,
         "config": {"workload": desc, "nodes": N, "pods": snap.n_pods, "jobs": snap.n_jobs, "queues": snap.n_queues,
-                   "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2],
+                   "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2], "action_ms": k_ms,
                    "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else f"{world} scheduling shards, one per GPU, no data-path collective",
-                   "snapshot_gen_s": round(gen_s, 2), "host_to_hbm_s": round(upload_s, 3),
-                   "engine": {"index_queries": int(st.reserved[0]), "block_refreshes": int(st.reserved[1]), "brute_force_scans": int(st.node_scans),
-                              "drained_jobs": int(st.reserved[2]), "drained_decisions": int(st.reserved[3]), "jobs_attempted": int(st.jobs_attempted),
-                              "jobs_committed": int(st.jobs_committed),
-                              **({"path": "batch (plan / fill / apply rounds)", "rounds": int(st.reserved[4]), "fill_wave_cycles": int(st.reserved[5]), "mispredicted_jobs": int(st.reserved[6]),
-                                  "plan_ms": (int(st.reserved[7]) >> 42) / 1e3, "fill_ms": ((int(st.reserved[7]) >> 21) & 0x1fffff) / 1e3, "apply_ms": (int(st.reserved[7]) & 0x1fffff) / 1e3}
-                                 if int(st.reserved[4]) > 0 else
-                                 {"path": "sequential engine", "control_cycles": {"allocate": int(st.reserved[5]), "commit_discard": int(st.reserved[6]), "total": int(st.reserved[7])}})}},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(desc), "kernel": "k_action (+ k_job_init, k_leaf_init, k_drain on the same stream)", "kernel_ms": k_ms,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "achieved = decisions x (N x 128 B + 80 B) / action time (HIP events); the class index answers a decision from one 64-node block, "
-                             "so PMC traffic is far below the algorithmic bytes: frac is decision throughput against the streaming formulation's roofline"},
+                   "snapshot_gen_s": round(gen_s, 2), "host_to_hbm_s": round(upload_s, 3), "engine": engine},
+        "roofline": roof,
     }
 
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         import kai_testlib as T
-        # bounded sample: the oracle walks the SAME snapshot in the same fair order and stops after `sample` decisions
+        # (1) contract baseline: the oracle (faithful single-thread restatement of the reference path) on a bounded sample of the SAME snapshot:
+        #     it walks the same fair order and stops after `sample` decisions; its operations must be the first operations of the GPU's
         sample = args.cpu_sample if args.cpu_sample > 0 else max(200, int(3e8 / max(N, 1)))  # about 10-20 s of single-thread oracle work
         c2 = T.abi.KaiConfig.from_buffer_copy(cfg)
         c2.reserved[0] = sample  # bounds the allocate action only; the victim actions of a C4 run are timed in full (keep --scale small)
@@ -149,6 +171,22 @@ def main():
         done = int(ref.stats.decisions)
         out["cpu_baseline"] = {"value": done / (ref.elapsed_ms * 1e-3), "unit": "decisions/s", "cores": 1, "kind": "port",
                                "sample": f"{'first ' if actions == ('allocate',) else ''}{done} decisions of the same snapshot in {ref.elapsed_ms / 1e3:.1f} s (oracle/liboracle.so, single thread, incl. session open; actions: {', '.join(actions)})"}
+        if actions == ("allocate",):
+            n_eq = 0
+            for a, b in zip(ref.ops, first_ops):
+                if tuple(a) != tuple(b):
+                    break
+                n_eq += 1
+            out["parity_prefix"] = {"oracle_ops": len(ref.ops), "equal_to_gpu": n_eq}
+        # (2) the same ALGORITHM on one CPU thread: the host-compiled sequential engine of tests/host_sim (test infrastructure) on the full step
+        try:
+            from test_engine_hostsim import HostSim
+            c3 = T.abi.KaiConfig.from_buffer_copy(cfg); c3.engine_mode = 3
+            tw = HostSim.run(snap, c3, actions)
+            out["cpu_same_algorithm"] = {"value": int(tw.stats.decisions) / (tw.elapsed_ms * 1e-3), "unit": "decisions/s", "cores": 1, "kind": "host-compiled sequential engine (tests/host_sim, g++ -O2)",
+                                         "ms_per_step": tw.elapsed_ms, "sample": "the full step", "ops_equal_to_gpu": [tuple(o) for o in tw.ops] == [tuple(o) for o in first_ops]}
+        except Exception as e:  # the twin is optional evidence
+            out["cpu_same_algorithm"] = {"error": str(e)[:200]}
     if rank == 0:
         print(json.dumps(out))
     pkg.dist.finish()

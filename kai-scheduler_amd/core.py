@@ -106,7 +106,9 @@ class Session:
         lib, h = self.core.lib, self.core.handle
         act = abi.ACTIONS[action] if isinstance(action, str) else int(action)
         cap = 2 * self.snap.n_pods + 64
-        ops = (abi.KaiOp * cap)()
+        if getattr(self, "_ops_buf", None) is None:  # the caller-owned output buffer of the C ABI, allocated once per session
+            self._ops_buf = (abi.KaiOp * cap)()
+        ops = self._ops_buf
         n = C.c_int64(0)
         self.core._check(lib.kai_action_execute(h, act, ops, cap, C.byref(n)))
         arr = np.frombuffer(ops, dtype=np.dtype([("seq", "<i8"), ("kind", "<i4"), ("pod", "<i4"), ("node", "<i4"), ("job", "<i4")]), count=n.value)

@@ -27,10 +27,12 @@ def main():
     w, nw = per_launch(write, kernel)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     doc = json.load(open(out)) if os.path.exists(out) else {}
-    doc[workload] = {"kernel": kernel, "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "launches": [nf, nw],
-                     "bytes_per_launch": (f + w) * 1024.0, "note": "raw rocprofv3 counters, separate --pmc passes; scattered 8-byte accesses (uncalibrated)"}
+    if not isinstance(doc.get(workload), dict) or "bytes_per_launch" in doc.get(workload, {}):
+        doc[workload] = {}  # round-1 layout (one kernel per workload) is replaced by {workload: {kernel: ...}}
+    doc[workload][kernel] = {"fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "launches": [nf, nw],
+                             "bytes_per_launch": (f + w) * 1024.0, "note": "raw rocprofv3 counters, separate --pmc passes of bench.py; scattered small accesses (uncalibrated, MI355X_MICROARCH.md)"}
     json.dump(doc, open(out, "w"), indent=1, sort_keys=True)
-    print(json.dumps(doc[workload]))
+    print(json.dumps(doc[workload][kernel]))
 
 
 if __name__ == "__main__":
