@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KAI_ABI_VERSION 4u
+#define KAI_ABI_VERSION 5u
 
 /* resource vector layout: api/resource_info/resource_vector.go:23-36 (cpu, memory, gpu, pods, extras…) */
 #define KAI_RES_CPU 0
@@ -278,7 +278,10 @@ typedef struct kai_op {
     int32_t kind;  /* kai_op_kind */
     int32_t pod;
     int32_t node;
-    int32_t job;
+    int32_t job;   /* the pod's own job */
+    int32_t stmt;  /* Statement the operation was committed by (framework/statement.go:536-575), numbered from 0 per action in commit order:
+                      the shim replays the operations of one id through ONE Statement — a reclaim statement is "evict A, evict B, pipeline C" */
+    int32_t pad;
 } kai_op;
 
 /* per queue, in KAI_Q_* order: plugins/proportion/resource_share/resource_share.go:12-21 */

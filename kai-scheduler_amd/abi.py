@@ -12,7 +12,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-KAI_ABI_VERSION = 4
+KAI_ABI_VERSION = 5
 RES_CPU, RES_MEM, RES_GPU, RES_PODS = 0, 1, 2, 3
 MAX_RES = 8
 Q_CPU, Q_MEM, Q_GPU = 0, 1, 2
@@ -109,7 +109,7 @@ class KaiSnapshotSoA(C.Structure):
 
 
 class KaiOp(C.Structure):
-    _fields_ = [("seq", C.c_int64), ("kind", C.c_int32), ("pod", C.c_int32), ("node", C.c_int32), ("job", C.c_int32)]
+    _fields_ = [("seq", C.c_int64), ("kind", C.c_int32), ("pod", C.c_int32), ("node", C.c_int32), ("job", C.c_int32), ("stmt", C.c_int32), ("pad", C.c_int32)]
 
 
 class KaiQueueShare(C.Structure):

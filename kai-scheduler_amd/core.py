@@ -111,7 +111,7 @@ class Session:
         ops = self._ops_buf
         n = C.c_int64(0)
         self.core._check(lib.kai_action_execute(h, act, ops, cap, C.byref(n)))
-        arr = np.frombuffer(ops, dtype=np.dtype([("seq", "<i8"), ("kind", "<i4"), ("pod", "<i4"), ("node", "<i4"), ("job", "<i4")]), count=n.value)
+        arr = np.frombuffer(ops, dtype=np.dtype([("seq", "<i8"), ("kind", "<i4"), ("pod", "<i4"), ("node", "<i4"), ("job", "<i4"), ("stmt", "<i4"), ("pad", "<i4")]), count=n.value)
         return arr.copy()
 
     def best_node(self, pod: int, pipeline_only: bool = False, nodeset=None):

@@ -39,7 +39,7 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     KB_Z(q_cnt, Q + 1); KB_Z(q_ebase, Q + 1); KB_Z(q_kbase, Q + 1); KB_Z(q_valid, Q + 1); KB_Z(q_nk, Q + 1); KB_Z(q_sent, Q + 1); KB_Z(q_taken, Q + 1); KB_Z(q_complete, Q + 1);
     KB_Z(pk, b.pool_k); KB_Z(sp, b.pool_k); KB_Z(k_owner, b.pool_k);
     KB_Z(el_leaf, b.pool_e); KB_Z(el_ck, b.pool_e); KB_Z(el_next, b.pool_e); KB_Z(e_job, b.pool_e); KB_Z(e_grank, b.pool_e); KB_Z(e_flag, b.pool_e);
-    KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_first, J + 1); KB_Z(g_nt, J + 1); KB_Z(g_ucls, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
+    KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_stmt, J + 1); KB_Z(g_first, J + 1); KB_Z(g_nt, J + 1); KB_Z(g_ucls, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
     KB_Z(t_cls, P); KB_Z(t_node, P);
     KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1);
 #undef KB_Z
@@ -60,7 +60,7 @@ inline size_t batch_fill_lds(const KaiCtx& c, int& l1_in_lds) {
 // Runs the allocate action on the batch path.  ran = false: the action does not qualify, nothing was touched (run the sequential engine).
 // On return with ran: out_len / counters are in bs; drain = the remaining queue is to be resolved by k_drain (no class fits anywhere).
 template <class L>
-int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStats& bs, int64_t ops_base0 = 0) {
+int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStats& bs, int64_t ops_base0 = 0, int64_t stmt_base0 = 0) {
     bs = BatchStats{};
     if (!c.bt.enabled || c.action != KAI_ACTION_ALLOCATE || c.queue_depth > 0 || !c.fast_ok) return 0;
     const int TB = 256, Q = c.Q, J = c.J;
@@ -78,7 +78,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     l.fill(1, 64, dyn, c, rp, l1_in_lds);
     FillStatus fs{};
     if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc;
-    int H = 16; int64_t ops_base = ops_base0;
+    int H = 16; int64_t ops_base = ops_base0, stmt_base = stmt_base0;
     while (remaining > 0) {
         if (fs.all_dead) { bs.drain = 1; break; }
         rp = RoundParams{}; rp.h_leaf = H; rp.mode = 0;
@@ -94,7 +94,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         }
         l.plan_emit(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c);
         l.fill(1, 64, dyn, c, rp, l1_in_lds);
-        l.apply_jobs(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c, ops_base);
+        l.apply_jobs(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c, ops_base, stmt_base);
         if (Q) l.apply_nodes((Q + TB - 1) / TB, TB, c);
         if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc;
         if (fs.n_done <= 0) return KAI_ERR_DEVICE_FAULT;  // a round always executes at least one job
@@ -102,7 +102,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         bs.decisions += fs.decisions; bs.attempted += fs.attempted; bs.committed += fs.committed; bs.rollbacks += fs.rollbacks; bs.ops += fs.ops;
         bs.fill_cycles += fs.cycles_total; bs.fill_load += fs.cycles_load; bs.fill_update += fs.cycles_update; bs.fill_rescan += fs.cycles_rescan;
         bs.block_loads += fs.block_loads; bs.rescans1 += fs.rescans1; bs.rescans2 += fs.rescans2; bs.rescans3 += fs.rescans3;
-        ops_base += fs.ops; remaining -= fs.n_done;
+        ops_base += fs.ops; stmt_base += fs.committed; remaining -= fs.n_done;
         if (!fs.mismatch) H = std::min(H * 2, 1 << 20);                       // the plan ran out before anything surprising happened: look further ahead
         else if ((int64_t)fs.n_done * 4 < fs.planned) H = std::max(H / 2, 8);  // most of the plan was thrown away
     }

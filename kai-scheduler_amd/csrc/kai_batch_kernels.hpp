@@ -496,7 +496,7 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
         for (int jj = 0; jj < cnt; jj++) {
             const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
             attempted++; n_done = base + jj + 1;
-            const int opoff = (int)ops;
+            const int opoff = (int)ops, stmtoff = (int)committed;
             bool ok = flag != BF_GATE; int placed = 0;
             if (flag != BF_GATE) {
                 for (int tb = 0; tb < nt && ok; tb += 64) {
@@ -522,7 +522,7 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
                     rollbacks += 2;
                 } else { committed++; ops += nt; }
             }
-            if (lane == 0) { b.g_out[base + jj] = ok ? BF_OK : BF_DEAD; b.g_opoff[base + jj] = opoff; }
+            if (lane == 0) { b.g_out[base + jj] = ok ? BF_OK : BF_DEAD; b.g_opoff[base + jj] = opoff; b.g_stmt[base + jj] = stmtoff; }
             if ((flag == BF_OK) != ok) { mismatch = 1; break; }
         }
     }
@@ -559,7 +559,7 @@ KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {
 // Statement.Commit of every committed job of the executed prefix (framework/statement.go:536-575): pod state, committed operations in
 // commit order, pod-set / job counters, node accounting, proportion event handlers up the queue chain (proportion.go:443-465).
 // Quantities add exactly in any order (HostPrep::batch_units), so f64 atomics reproduce the sequential sums bit for bit.
-KW_BODY void kb_apply_jobs(const KaiCtx& c, int64_t ops_base) {
+KW_BODY void kb_apply_jobs(const KaiCtx& c, int64_t ops_base, int64_t stmt_base) {
     const BatchCtx& b = c.bt;
     const int t = kw::bid() * kw::bdim() + kw::tid();
     if (t >= b.fs[0].n_done) return;
@@ -568,7 +568,7 @@ KW_BODY void kb_apply_jobs(const KaiCtx& c, int64_t ops_base) {
     double sum[3] = {0, 0, 0};
     for (int i = 0; i < nt; i++) {
         const int p = c.tta[first + i], n = b.t_node[first + i];
-        kai_op o; o.seq = ops_base + b.g_opoff[t] + i; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j;
+        kai_op o; o.seq = ops_base + b.g_opoff[t] + i; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j; o.stmt = (int32_t)(stmt_base + b.g_stmt[t]); o.pad = 0;
         c.out_ops[o.seq] = o;
         c.p_status[p] = KAI_POD_BINDING; c.p_node[p] = n; c.p_on_node[p] = n; c.p_on_node_status[p] = KAI_POD_ALLOCATED; c.p_accepted[p] = 1; c.p_virtual[p] = 1;
         for (int r = 0; r < c.R; r++) {
@@ -611,7 +611,7 @@ __global__ void k_plan_rank(KaiCtx c, RoundParams rp) { kb_plan_rank(c, rp); }
 __global__ void k_plan_scan(KaiCtx c, RoundParams rp) { kb_plan_scan(c, rp); }
 __global__ void k_plan_emit(KaiCtx c) { kb_plan_emit(c); }
 __global__ void __launch_bounds__(64) k_fill(KaiCtx c, RoundParams rp, int l1_in_lds) { kb_fill(c, rp, l1_in_lds); }
-__global__ void k_apply_jobs(KaiCtx c, long long ops_base) { kb_apply_jobs(c, (int64_t)ops_base); }
+__global__ void k_apply_jobs(KaiCtx c, long long ops_base, long long stmt_base) { kb_apply_jobs(c, (int64_t)ops_base, (int64_t)stmt_base); }
 __global__ void k_apply_nodes(KaiCtx c) { kb_apply_nodes(c); }
 #endif
 

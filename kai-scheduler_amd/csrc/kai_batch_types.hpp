@@ -12,7 +12,7 @@ struct FillStatus {  // written by the fill kernel, read by the host between rou
     int32_t mismatch;      // 1 = job n_done-1 ended differently from its prediction
     int32_t all_dead;      // no class has a fitting node at the committed state
     int32_t planned;       // length of the planned order of this round
-    int64_t decisions, attempted, committed, rollbacks, ops;  // of this round
+    int64_t decisions, attempted, committed, rollbacks, ops;  // of this round (committed = Statements of the round: every committed job has operations)
     uint64_t dead_mask;    // classes without a fitting node at the committed state
     int64_t cycles_total, cycles_load, cycles_update, cycles_rescan;  // fill-wave clocks (profiling)
     int64_t block_loads, rescans1, rescans2, rescans3;
@@ -53,6 +53,7 @@ struct BatchCtx {
     KAI_GP(int32_t) e_job, e_grank;  // [pool_e] leaf regions: job, rank in the global order (INT_MAX = not in its valid prefix)
     KAI_GP(uint8_t) e_flag;      // [pool_e] leaf regions: BF_*
     // global order + task stream
+    KAI_GP(int32_t) g_stmt;      // [J+1] committed jobs before this one in the round (its Statement number minus the round's base)
     KAI_GP(int32_t) g_job, g_opoff;  // [J+1] planned global order: job, offset of its operations among the round's committed ones
     KAI_GP(int32_t) g_first, g_nt, g_ucls;   // [J+1] the job's pod range start, tasks in its chunk, its one scan class or -1 (what the fill kernel needs, coalesced)
     KAI_GP(uint8_t) g_flag, g_out;           // [J] predicted / actual outcome

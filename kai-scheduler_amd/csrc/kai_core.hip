@@ -159,7 +159,7 @@ struct DevLauncher {
         hipLaunchKernelGGL(k_fill, dim3(g), dim3(b), dyn, core->stream, c, rp, l1);
         if (rp.mode == 0) (void)hipEventRecord(core->bev[2], core->stream);
     }
-    void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base) { hipLaunchKernelGGL(k_apply_jobs, dim3(g), dim3(b), 0, core->stream, c, (long long)ops_base); }
+    void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { hipLaunchKernelGGL(k_apply_jobs, dim3(g), dim3(b), 0, core->stream, c, (long long)ops_base, (long long)stmt_base); }
     void apply_nodes(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_apply_nodes, dim3(g), dim3(b), 0, core->stream, c); (void)hipEventRecord(core->bev[3], core->stream); timed = true; }
     bool timed = false;
     int read(void* dst, const void* src, size_t n) {
@@ -450,7 +450,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
             EngineState sb{};
             HIP_TRY(core, hipMemcpyAsync(&sb, KAI_VP(c.st), sizeof(sb), hipMemcpyDeviceToHost, core->stream));
             HIP_TRY(core, hipStreamSynchronize(core->stream));
-            sb.decisions += bs.decisions; sb.jobs_attempted += bs.attempted; sb.jobs_committed += bs.committed; sb.rollbacks += bs.rollbacks; sb.out_len += bs.ops;
+            sb.decisions += bs.decisions; sb.jobs_attempted += bs.attempted; sb.jobs_committed += bs.committed; sb.rollbacks += bs.rollbacks; sb.out_len += bs.ops; sb.stmts += bs.committed;
             sb.index_queries += bs.decisions; sb.drain_pending = bs.drain;
             HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.st), &sb, sizeof(sb), hipMemcpyHostToDevice, core->stream));
         }

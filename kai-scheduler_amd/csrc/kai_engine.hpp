@@ -152,7 +152,7 @@ struct EngineState {  // mutable scalars of the running action
     int32_t fault;            // != 0: engine gave up (see FAULT_*)
     int32_t fault_line, pad_f; // source line of the fault() call (diagnostics)
     int32_t drain_pending;    // allocate: every class is dead at a committed state → the rest of the queue is counted by k_drain
-    int64_t out_len;
+    int64_t out_len, stmts;   // committed operations / Statements that committed at least one operation, of this action
     int64_t decisions, node_scans, nodes_scanned, jobs_attempted, jobs_committed, rollbacks;
     int64_t index_queries, index_refreshes, drained_jobs, drained_decisions;
     int64_t scenarios, simulations, scenarios_filtered;  // victim search (actions/common/solvers)
@@ -659,7 +659,7 @@ KAI_HD int stage_job_lane(const KaiCtx& c, int j, FastFrame& f, JobPf& out, int 
 // Counters the control lane bumps on every pop / decision / committed operation: kept with the engine's scalars (LDS on the device, a dependent
 // global read-modify-write each otherwise) and written to EngineState once, when the action ends.
 struct EngineHot {
-    int64_t decisions, index_queries, index_refreshes, rollbacks, jobs_attempted, jobs_committed, out_len;
+    int64_t decisions, index_queries, index_refreshes, rollbacks, jobs_attempted, jobs_committed, out_len, stmts;
     int64_t prof[16];
 };
 struct EngineLocal {
@@ -1024,16 +1024,18 @@ struct Engine {
         return true;
     }
     KAI_HD void commit() {  // :536-575 — the cache side effects are replayed by the caller from out_ops
+        const int64_t len0 = el().h.out_len;
         for (int i = 0; i < cx().st->ops_len; i++) {
             if (!op_valid(i)) continue;
             StmtOp op = cx().ops[i]; if (op.name == OP_UNDO) continue;
             if (el().h.out_len >= cx().out_cap) { fault(FAULT_OUT_CAP); break; }
-            kai_op o; o.seq = el().h.out_len; o.pod = op.pod; o.job = cx().p_job[op.pod]; o.node = cx().p_node[op.pod];
+            kai_op o; o.seq = el().h.out_len; o.pod = op.pod; o.job = cx().p_job[op.pod]; o.node = cx().p_node[op.pod]; o.stmt = (int32_t)el().h.stmts; o.pad = 0;
             if (op.name == OP_EVICT) { o.kind = KAI_OP_EVICT; o.node = op.prev_node; cx().p_virtual[op.pod] = 0; cx().st->non_allocate_commits++; }
             else if (op.name == OP_PIPELINE) { o.kind = KAI_OP_PIPELINE; cx().st->non_allocate_commits++; }
             else { o.kind = KAI_OP_ALLOCATE; update_task_status(op.pod, KAI_POD_BINDING); }  // ssn.BindPod (framework/session.go:111-126)
             cx().out_ops[el().h.out_len++] = o;
         }
+        if (el().h.out_len > len0) el().h.stmts++;
         truncate_ops(0);
     }
 
@@ -2008,12 +2010,13 @@ struct Engine {
             for (int i = 0; i < nt; i++) {
                 int p = f.p[i], n = f.node[i];
                 if (el().h.out_len >= cx().out_cap) { fault(FAULT_OUT_CAP); break; }
-                kai_op o; o.seq = el().h.out_len; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j;
+                kai_op o; o.seq = el().h.out_len; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j; o.stmt = (int32_t)el().h.stmts; o.pad = 0;
                 cx().out_ops[el().h.out_len++] = o;
                 for (int k = 0; k < 3; k++) { double v = frame_quota(f.req[i], k); ja[k] -= v; ja[k] += v; }  // Allocated → Binding (job_info.go:228-287)
                 cx().p_status[p] = KAI_POD_BINDING; cx().p_node[p] = n; cx().p_on_node[p] = n; cx().p_on_node_status[p] = KAI_POD_ALLOCATED; cx().p_accepted[p] = 1; cx().p_virtual[p] = 1;
             }
             cx().s_active_alloc[s] += nt; cx().s_active_used[s] += nt; cx().j_n_pending[j] -= nt;
+            if (nt > 0) el().h.stmts++;
         } else {  // Statement.Rollback :48-61: the undone operations in reverse order, same arithmetic with the opposite sign
             for (int i = done - 1; i >= 0; i--) {
                 const double* rq = f.req[i]; int n = f.node[i];
@@ -2058,13 +2061,13 @@ struct Engine {
     KAI_HD void hot_begin() {
         EngineHot& h = el().h; const EngineState& st = *cx().st;
         h.decisions = st.decisions; h.index_queries = st.index_queries; h.index_refreshes = st.index_refreshes; h.rollbacks = st.rollbacks;
-        h.jobs_attempted = st.jobs_attempted; h.jobs_committed = st.jobs_committed; h.out_len = st.out_len;
+        h.jobs_attempted = st.jobs_attempted; h.jobs_committed = st.jobs_committed; h.out_len = st.out_len; h.stmts = st.stmts;
         for (int i = 0; i < 16; i++) h.prof[i] = st.prof[i];
     }
     KAI_HD void hot_end() {
         const EngineHot& h = el().h; EngineState& st = *cx().st;
         st.decisions = h.decisions; st.index_queries = h.index_queries; st.index_refreshes = h.index_refreshes; st.rollbacks = h.rollbacks;
-        st.jobs_attempted = h.jobs_attempted; st.jobs_committed = h.jobs_committed; st.out_len = h.out_len;
+        st.jobs_attempted = h.jobs_attempted; st.jobs_committed = h.jobs_committed; st.out_len = h.out_len; st.stmts = h.stmts;
         for (int i = 0; i < 16; i++) st.prof[i] = h.prof[i];
     }
     KAI_HD void execute_allocate() { hot_begin(); execute_allocate_impl(); hot_end(); }

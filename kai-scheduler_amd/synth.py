@@ -373,3 +373,39 @@ def add_fractions(snap: abi.Snapshot, seed: int, frac: float = 0.4, portions=(0.
                 fill[n].append(need); group[p] = len(fill[n]) - 1
     a["pod_gpu_portion"] = portion; a["pod_gpu_group"] = group; a["node_gpu_memory"] = np.full(N, gpu_memory, np.int64)
     return snap.finalize()
+
+
+def add_predicate_features(snap: abi.Snapshot, seed: int, *, nominated_frac=0.15, not_ready_frac=0.1, worker_label_frac=0.8, foreign_frac=0.2,
+                           oversized_frac=0.05) -> abi.Snapshot:
+    """Exercise the predicate / node-order corners the BASELINE configs leave untouched:
+      * status.nominatedNodeName on some pending pods (plugins/nominatednode/nominatednode.go:29-41: +1e6 for that node),
+      * nodes that fail CheckNodeConditionPredicate (scheduler_util/scheduler_utils.go:12-40 → KAI_NODE_NOT_READY),
+      * GPU / CPU worker labels on most nodes, for restrictSchedulingNodes (plugins/predicates/predicates.go:243-259),
+      * Running pods of another scheduler (subtracted from the proportion totals, plugins/proportion/proportion.go:276-285),
+      * pending pods that ask for more than any node has (what MaxNodeResourcesPredicate.PreFilter turns away up front,
+        k8s_internal/predicates/maxNodeResources.go:59-96; the engine reaches the same verdict node by node)."""
+    rng = np.random.default_rng(seed ^ 0x9E37)
+    a = snap.arrays
+    N, P = snap.n_nodes, snap.n_pods
+    S = abi.POD_STATUS
+    flags = a["node_flags"].copy()
+    flags[rng.random(N) < not_ready_frac] |= abi.NODE_NOT_READY
+    gpu_nodes = a["node_allocatable"][abi.RES_GPU] > 0
+    lab = rng.random(N) < worker_label_frac
+    flags[lab & gpu_nodes] |= abi.NODE_GPU_WORKER
+    flags[lab & ~gpu_nodes] |= abi.NODE_CPU_WORKER
+    flags[rng.random(N) < 0.1] |= abi.NODE_CPU_WORKER  # some GPU nodes also take CPU-only work
+    a["node_flags"] = flags
+    nom = np.full(P, -1, np.int32)
+    pending = a["pod_status"] == S["Pending"]
+    pick = pending & (rng.random(P) < nominated_frac)
+    if N:
+        nom[pick] = rng.integers(0, N, size=int(pick.sum()))
+    a["pod_nominated_node"] = nom
+    pf = a["pod_flags"].copy() if "pod_flags" in a else np.zeros(P, np.uint32)
+    running = a["pod_status"] == S["Running"]
+    pf[running & (rng.random(P) < foreign_frac)] |= abi.POD_FOREIGN_SCHEDULER
+    a["pod_flags"] = pf
+    big = pending & (rng.random(P) < oversized_frac)
+    a["pod_req"][abi.RES_CPU, big] = a["node_allocatable"][abi.RES_CPU].max(initial=0.0) + 1000.0
+    return snap.finalize()

@@ -659,10 +659,11 @@ void Statement::undoOperation(int index) {
     Operation u; u.name = opUndo; u.operationIndex = index; operations.push_back(u);
 }
 void Statement::Commit() {
+    const size_t len0 = ssn->committed.size();
     for (int i = 0; i < int(operations.size()); i++) {
         if (!operationValid(i)) continue;
         Operation& op = operations[i]; if (op.name == opUndo) continue;
-        kai_op out; out.seq = int64_t(ssn->committed.size()); out.pod = op.task->idx; out.job = op.task->job; out.node = op.task->node;
+        kai_op out; out.seq = int64_t(ssn->committed.size()); out.pod = op.task->idx; out.job = op.task->job; out.node = op.task->node; out.stmt = ssn->n_statements; out.pad = 0;
         switch (op.name) {
             case opEvict: out.kind = KAI_OP_EVICT; out.node = op.previousNode; op.task->isVirtualStatus = false; break;  // commitEvict :128-150
             case opPipeline: out.kind = KAI_OP_PIPELINE; break;                                                      // commitPipeline :427-429
@@ -671,6 +672,7 @@ void Statement::Commit() {
         }
         ssn->committed.push_back(out);
     }
+    if (ssn->committed.size() > len0) ssn->n_statements++;  // one id per Statement that committed something
     operations.clear();
 }
 

@@ -78,6 +78,7 @@ struct Session {
     std::map<int, std::pair<double, double>> podAllocatableRange;
     // committed operations in commit order (what cache.Bind / Evict / TaskPipelined would receive)
     std::vector<kai_op> committed;
+    int32_t n_statements = 0;  // Statements that committed at least one operation so far (kai_op.stmt)
     SessionStats stats;
 
     void load(const kai_config* c, const kai_snapshot_soa* s);

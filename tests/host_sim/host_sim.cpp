@@ -109,7 +109,7 @@ struct HostLauncher {
     void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_scan(c, rp); }); }
     void plan_emit(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_plan_emit(c); }); }
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) { kw::launch(g, b, dyn, [&] { kb_fill(c, rp, l1); }); }
-    void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base) { kw::launch(g, b, 0, [&] { kb_apply_jobs(c, ops_base); }); }
+    void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { kw::launch(g, b, 0, [&] { kb_apply_jobs(c, ops_base, stmt_base); }); }
     void apply_nodes(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_apply_nodes(c); }); }
     int read(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); return 0; }
     int write(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); return 0; }
@@ -324,9 +324,9 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         if (actions[i] != KAI_ACTION_ALLOCATE) { eng.execute_victim_action(); continue; }
         {   // the batch path when the action qualifies (kai_batch.hpp), else the sequential engine — as kai_action_execute does
             HostLauncher hl; BatchStats bs;
-            if (int rc = batch_allocate(hl, c, prep.shape, bs, c.st->out_len)) return rc;
+            if (int rc = batch_allocate(hl, c, prep.shape, bs, c.st->out_len, c.st->stmts)) return rc;
             if (bs.ran) {
-                c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops;
+                c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops; c.st->stmts += bs.committed;
                 c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++;
             } else eng.execute_allocate();
         }

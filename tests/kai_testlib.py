@@ -82,7 +82,7 @@ class Oracle:
         groups = np.full(P, -1, np.int32)
         if hasattr(lib, "kai_oracle_last_gpu_groups"):
             lib.kai_oracle_last_gpu_groups(groups.ctypes.data_as(C.POINTER(C.c_int32)), P)
-        return Result(gpu_groups=groups, ops=[(o.kind, o.pod, o.node, o.job) for o in ops[: n_ops.value]], pod_status=status, pod_node=node,
+        return Result(gpu_groups=groups, ops=[(o.kind, o.pod, o.node, o.job) for o in ops[: n_ops.value]], stmts=[o.stmt for o in ops[: n_ops.value]], pod_status=status, pod_node=node,
                       shares_open=shares_to_np(sh_open, Q), shares_final=shares_to_np(sh_fin, Q), nodes=nodes_to_np(nodes, N, snap.n_res),
                       stats=stats, elapsed_ms=ms.value)
 

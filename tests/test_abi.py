@@ -25,7 +25,7 @@ def test_library_exports_header_symbols():
 
 def test_struct_layouts_match_header():
     # sizes computed by hand from include/kai_core.h (LP64)
-    assert C.sizeof(T.abi.KaiOp) == 24
+    assert C.sizeof(T.abi.KaiOp) == 32  # ABI v5: + stmt, pad
     assert C.sizeof(T.abi.KaiQueueShare) == 6 * 3 * 8
     assert C.sizeof(T.abi.KaiNodeState) == 3 * 8 * 8
     assert C.sizeof(T.abi.KaiActionStats) == 6 * 8 + 2 * 8 + 8 * 8

@@ -40,6 +40,8 @@ def assert_same(res, ref, share_tol=0.0):
     addition — the reference itself ranges Go maps there (proportion.go:347-401); the engine rolls pods up job by job, the oracle pod by pod.
     Placements stay exact; the shares are held to the task's 1e-6 (here 1e-9)."""
     assert res.ops == ref.ops
+    if getattr(res, "stmts", None) is not None and getattr(ref, "stmts", None) is not None:
+        assert res.stmts == ref.stmts  # Statement boundaries (kai_op.stmt)
     assert (res.pod_status == ref.pod_status).all() and (res.pod_node == ref.pod_node).all()
     same = (lambda a, b: np.array_equal(a, b)) if share_tol == 0.0 else (lambda a, b: np.allclose(a, b, rtol=0.0, atol=share_tol))
     for k in ref.shares_open:

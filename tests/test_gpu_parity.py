@@ -22,11 +22,14 @@ def run_gpu(snap, cfg, actions=("allocate",)):
     with T.pkg.KaiCore(cfg) as core:
         ssn = core.open_session(snap)
         shares_open = ssn.queue_shares()
-        ops = []
+        ops, stmts = [], []
         for a in actions:
-            ops += [(int(o["kind"]), int(o["pod"]), int(o["node"]), int(o["job"])) for o in ssn.execute(a)]
+            arr = ssn.execute(a)
+            base = (stmts[-1] + 1) if stmts else 0  # kai_op.stmt counts from 0 in every action; the oracle numbers a whole cycle
+            ops += [(int(o["kind"]), int(o["pod"]), int(o["node"]), int(o["job"])) for o in arr]
+            stmts += [int(o["stmt"]) + base for o in arr]
         st, nd = ssn.pod_states()
-        res = T.Result(ops=ops, pod_status=st, pod_node=nd, shares_open=shares_open, shares_final=ssn.queue_shares(), nodes=ssn.node_states(), stats=ssn.stats())
+        res = T.Result(ops=ops, stmts=stmts, pod_status=st, pod_node=nd, shares_open=shares_open, shares_final=ssn.queue_shares(), nodes=ssn.node_states(), stats=ssn.stats())
         ssn.close()
     return res
 
@@ -34,6 +37,8 @@ def run_gpu(snap, cfg, actions=("allocate",)):
 def assert_same(res, ref):
     assert len(res.ops) == len(ref.ops)
     assert res.ops == ref.ops
+    if getattr(res, "stmts", None) is not None and getattr(ref, "stmts", None) is not None:
+        assert res.stmts == ref.stmts  # Statement boundaries (kai_op.stmt)
     assert (res.pod_status == ref.pod_status).all() and (res.pod_node == ref.pod_node).all()
     for k in ref.shares_open:
         assert np.array_equal(res.shares_open[k], ref.shares_open[k]), f"open {k}"
