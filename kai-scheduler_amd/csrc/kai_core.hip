@@ -35,7 +35,8 @@ struct kai_core {
     char* slab = nullptr; size_t slab_left = 0;
     // device-only helpers
     double* d_jsum = nullptr; int32_t* d_slot_queue = nullptr;
-    int32_t *d_lvl_off = nullptr, *d_lvl_parents = nullptr; int n_levels = 0;
+    int32_t *d_lvl_off = nullptr, *d_lvl_parents = nullptr; int n_levels = 0; std::vector<int32_t> h_lvl_off;
+    int32_t *d_h_off = nullptr, *d_h_nodes = nullptr; int n_heights = 0;  // queues by height (leaf = 0), for the usage roll-up
     double *d_weight = nullptr, *d_rem_amt = nullptr; uint8_t* d_rem_has = nullptr;
     int32_t* d_best_out = nullptr;
     int32_t *d_status0 = nullptr, *d_node0 = nullptr; QShare* d_shares0 = nullptr;  // HBM-resident initial state for kai_session_reset
@@ -132,9 +133,12 @@ int launch_open_kernels(kai_core* core) {
     if (J) hipLaunchKernelGGL(k_job_usage, dim3((J + TB - 1) / TB), dim3(TB), 0, core->stream, c, core->d_jsum);
     if (core->cfg.plugins & KAI_PLUGIN_PROPORTION) {
         if (Q) hipLaunchKernelGGL(k_leaf_usage, dim3((Q + 3) / 4), dim3(TB), 0, core->stream, c, core->d_jsum);
-        if (Q) hipLaunchKernelGGL(k_tree_usage, dim3(1), dim3(64), 0, core->stream, c);
-        if (Q) hipLaunchKernelGGL(k_fair_share, dim3(1), dim3(256), 0, core->stream, c, core->d_lvl_off, core->d_lvl_parents, core->n_levels,
-                                  core->d_weight, core->d_rem_amt, core->d_rem_has);
+        if (Q) hipLaunchKernelGGL(k_tree_usage, dim3(1), dim3(1024), 0, core->stream, c, (const int32_t*)core->d_h_off, (const int32_t*)core->d_h_nodes, core->n_heights);
+        for (int l = 0; Q && l < core->n_levels; l++) {  // a level's totals are the fair shares of the level above: one launch per level
+            const int first = core->h_lvl_off[l], count = core->h_lvl_off[l + 1] - first;
+            if (count > 0) hipLaunchKernelGGL(k_fair_share_level, dim3((count * 3 + FS_WAVES - 1) / FS_WAVES), dim3(FS_WAVES * 64), 0, core->stream, c, (const int32_t*)core->d_lvl_parents, first, count,
+                                              core->d_weight, core->d_rem_amt, core->d_rem_has);
+        }
     }
     if (Q) hipLaunchKernelGGL(k_qnode_static, dim3((Q + TB - 1) / TB), dim3(TB), 0, core->stream, c);
     if (c.use_index && c.NB) hipLaunchKernelGGL(k_index_build, dim3((c.NB + 3) / 4), dim3(TB), 0, core->stream, c);
@@ -291,7 +295,9 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     { const int32_t* t; TRY(dupload(core, &t, prep.slot_queue.data(), (size_t)std::max(J, 1))); core->d_slot_queue = const_cast<int32_t*>(t);
       TRY(dupload(core, &t, prep.lvl_off.data(), prep.lvl_off.size())); core->d_lvl_off = const_cast<int32_t*>(t);
       TRY(dupload(core, &t, prep.lvl_parents.data(), prep.lvl_parents.size())); core->d_lvl_parents = const_cast<int32_t*>(t); }
-    core->n_levels = prep.n_levels;
+    core->n_levels = prep.n_levels; core->h_lvl_off = prep.lvl_off; core->n_heights = prep.n_heights;
+    { const int32_t* t; TRY(dupload(core, &t, prep.h_off.data(), prep.h_off.size())); core->d_h_off = const_cast<int32_t*>(t);
+      TRY(dupload(core, &t, prep.h_nodes.data(), prep.h_nodes.size())); core->d_h_nodes = const_cast<int32_t*>(t); }
     // ---- scan classes + class index
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64;
     c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok; core->fast_ok0 = prep.fast_ok;

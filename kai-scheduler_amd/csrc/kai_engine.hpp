@@ -2138,16 +2138,17 @@ KAI_HD double rd_floor(double x) {  // math.Floor for the non-negative finite va
     double t = (double)(int64_t)x;
     return t > x ? t - 1.0 : t;
 }
-KAI_HD void divide_sibling_set(const KaiCtx& c, const int32_t* kids, int nk, int k, double total, double k_value,
-                               double* weight, double* rem_amt, uint8_t* rem_has) {
+// V: the sibling set as seen by the caller — share(i) = QShare of child i for the resource, prio / created / uid of child i, and three scratch slots per child
+template <class V>
+KAI_HD void divide_sibling_view(V& v, int nk, double total, double k_value) {
     // setDeservedResource :92-109
     double remaining = total;
     for (int i = 0; i < nk; i++) {
-        QShare& s = c.q_share[(size_t)kids[i] * 3 + k];
+        QShare& s = v.share(i);
         double deserved = s.deserved; if (deserved == KAI_UNLIMITED) deserved = total;
         double amount = kmin(deserved, qs_requestable(s));
         s.fair += amount; remaining -= amount;
-        rem_has[kids[i]] = 0;
+        v.rem_has(i) = 0;
     }
     if (!(remaining > 0)) return;
     // divideOverQuotaResource :111-144 — priorities descending
@@ -2155,7 +2156,7 @@ KAI_HD void divide_sibling_set(const KaiCtx& c, const int32_t* kids, int nk, int
     int64_t bound = NO_PRIO;
     for (;;) {
         int64_t p = -NO_PRIO;
-        for (int i = 0; i < nk; i++) { int64_t qp = c.q_prio[kids[i]]; if (qp < bound && qp > p) p = qp; }
+        for (int i = 0; i < nk; i++) { int64_t qp = v.prio(i); if (qp < bound && qp > p) p = qp; }
         if (p == -NO_PRIO) break;
         bound = p;
         // divideUpToFairShare :164-222 on the queues of priority p
@@ -2163,29 +2164,29 @@ KAI_HD void divide_sibling_set(const KaiCtx& c, const int32_t* kids, int nk, int
         for (;;) {
             bool another = false; double give_round = amount_left;
             double total_w = 0;  // getTotalWeightsForUnsatisfied :307-315
-            for (int i = 0; i < nk; i++) { int q = kids[i]; if (c.q_prio[q] != p) continue; const QShare& s = c.q_share[(size_t)q * 3 + k]; if (rd_remaining_requested(s) > 0) total_w += s.oqw; }
+            for (int i = 0; i < nk; i++) { if (v.prio(i) != p) continue; const QShare& s = v.share(i); if (rd_remaining_requested(s) > 0) total_w += s.oqw; }
             double w_sum = 0.0;  // calcShareWeights :224-251
             if (total_w != 0) for (int i = 0; i < nk; i++) {
-                int q = kids[i]; if (c.q_prio[q] != p) continue; const QShare& s = c.q_share[(size_t)q * 3 + k];
+                if (v.prio(i) != p) continue; const QShare& s = v.share(i);
                 if (rd_satisfied(s)) continue;
                 double n_w = s.oqw / total_w;
                 double w = kmax(0, n_w + k_value * (n_w - s.usage));
-                weight[q] = w; w_sum += w;
+                v.weight(i) = w; w_sum += w;
             }
             if (w_sum == 0) break;
             for (int i = 0; i < nk; i++) {
-                int q = kids[i]; if (c.q_prio[q] != p) continue; QShare& s = c.q_share[(size_t)q * 3 + k];
+                if (v.prio(i) != p) continue; QShare& s = v.share(i);
                 if (amount_left == 0) break;
                 if (rd_satisfied(s)) continue;
                 double requested = rd_remaining_requested(s);
                 if (s.oqw == 0) continue;
-                double fair = give_round * (weight[q] / w_sum);
+                double fair = give_round * (v.weight(i) / w_sum);
                 double to_give = 0;  // getResourceToGiveInCurrentRound :283-305
-                if (requested <= fair) { to_give = requested; rem_has[q] = 0; }
+                if (requested <= fair) { to_give = requested; v.rem_has(i) = 0; }
                 else {
                     double rf = rd_floor(fair);
                     if (rf > 0) to_give = rf;
-                    if (fair - to_give > 0) { rem_has[q] = 1; rem_amt[q] = fair - to_give; }
+                    if (fair - to_give > 0) { v.rem_has(i) = 1; v.rem_amt(i) = fair - to_give; }
                 }
                 if (to_give == 0) continue;
                 s.fair += to_give; amount_left -= to_give;
@@ -2200,26 +2201,43 @@ KAI_HD void divide_sibling_set(const KaiCtx& c, const int32_t* kids, int nk, int
     for (;;) {
         if (remaining <= 0) break;
         int64_t p = -NO_PRIO;
-        for (int i = 0; i < nk; i++) { int64_t qp = c.q_prio[kids[i]]; if (qp < bound && qp > p) p = qp; }
+        for (int i = 0; i < nk; i++) { int64_t qp = v.prio(i); if (qp < bound && qp > p) p = qp; }
         if (p == -NO_PRIO) break;
         bound = p;
         for (;;) {
             if (remaining == 0) break;
             int best = -1;  // remainingRequestedOrderFn :337-357
             for (int i = 0; i < nk; i++) {
-                int q = kids[i]; if (c.q_prio[q] != p || !rem_has[q]) continue;
-                if (best < 0) { best = q; continue; }
-                if (rem_amt[q] > rem_amt[best]) { best = q; continue; }
-                if (rem_amt[q] < rem_amt[best]) continue;
-                if (c.q_created[q] != c.q_created[best]) { if (c.q_created[q] < c.q_created[best]) best = q; continue; }
-                if (c.q_uid_rank[q] < c.q_uid_rank[best]) best = q;
+                if (v.prio(i) != p || !v.rem_has(i)) continue;
+                if (best < 0) { best = i; continue; }
+                if (v.rem_amt(i) > v.rem_amt(best)) { best = i; continue; }
+                if (v.rem_amt(i) < v.rem_amt(best)) continue;
+                if (v.created(i) != v.created(best)) { if (v.created(i) < v.created(best)) best = i; continue; }
+                if (v.uid(i) < v.uid(best)) best = i;
             }
             if (best < 0) break;
-            rem_has[best] = 0;
+            v.rem_has(best) = 0;
             double give = kmin(1, remaining);
-            c.q_share[(size_t)best * 3 + k].fair += give; remaining -= give;
+            v.share(best).fair += give; remaining -= give;
         }
     }
+}
+
+// the sibling set straight out of the session arrays (host twin; sets too large for the staged kernel)
+struct SiblingsGlobal {
+    const KaiCtx& c; const int32_t* kids; int k; double* w; double* ra; uint8_t* rh;
+    KAI_HD QShare& share(int i) const { return c.q_share[(size_t)kids[i] * 3 + k]; }
+    KAI_HD int64_t prio(int i) const { return c.q_prio[kids[i]]; }
+    KAI_HD int64_t created(int i) const { return c.q_created[kids[i]]; }
+    KAI_HD uint32_t uid(int i) const { return c.q_uid_rank[kids[i]]; }
+    KAI_HD double& weight(int i) const { return w[kids[i]]; }
+    KAI_HD double& rem_amt(int i) const { return ra[kids[i]]; }
+    KAI_HD uint8_t& rem_has(int i) const { return rh[kids[i]]; }
+};
+KAI_HD void divide_sibling_set(const KaiCtx& c, const int32_t* kids, int nk, int k, double total, double k_value,
+                               double* weight, double* rem_amt, uint8_t* rem_has) {
+    SiblingsGlobal v{c, kids, k, weight, rem_amt, rem_has};
+    divide_sibling_view(v, nk, total, k_value);
 }
 
 // ======================================================================================================

@@ -122,33 +122,55 @@ __global__ void k_leaf_usage(KaiCtx c, const double* jsum) {
         s.allocated = acc[k]; s.allocated_np = acc[3 + k]; s.request = acc[6 + k]; s.fair = 0;
     }
 }
-// ancestors: queues in decreasing depth push their sums to the parent (Q is small)
-__global__ void k_tree_usage(KaiCtx c) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (int i = 0; i < c.Q; i++) {
-        int q = c.q_depth_order[i], par = c.q_parent[q]; if (par < 0) continue;
-        for (int k = 0; k < 3; k++) {
-            QShare& s = c.q_share[(size_t)q * 3 + k]; QShare& d = c.q_share[(size_t)par * 3 + k];
-            d.allocated += s.allocated; d.allocated_np += s.allocated_np; d.request += s.request;
-        }
-    }
-}
-// proportion.setFairShareForQueues (plugins/proportion/proportion.go:410-423): level by level, one lane per
-// (sibling set, resource); a level's totals are the parents' fair shares of the previous level.
-// child_off / children carry a virtual root at index Q whose children are the top queues.
-__global__ void k_fair_share(KaiCtx c, const int32_t* lvl_off, const int32_t* lvl_parents, int n_levels,
-                             double* weight, double* rem_amt, uint8_t* rem_has) {
-    for (int l = 0; l < n_levels; l++) {
-        int b = lvl_off[l], e = lvl_off[l + 1];
-        for (int t = threadIdx.x; t < (e - b) * 3; t += blockDim.x) {
-            int par = lvl_parents[b + t / 3], k = t % 3;
-            double total = par == c.Q ? c.st->total[k] : c.q_share[(size_t)par * 3 + k].fair;
-            const int32_t* kids = c.q_children + c.q_child_off[par];
-            int nk = c.q_child_off[par + 1] - c.q_child_off[par];
-            divide_sibling_set(c, kids, nk, k, total, c.k_value, weight + (size_t)k * c.Q, rem_amt + (size_t)k * c.Q, rem_has + (size_t)k * c.Q);
+// ancestors: level by level up the tree (leaf = height 0), one lane per (inner queue, field): a segmented reduction over the queue's children,
+// added in child-index order like the sequential roll-up.  One workgroup; h_nodes / h_off list the queues by height (HostPrep::build_batch).
+__global__ void k_tree_usage(KaiCtx c, const int32_t* h_off, const int32_t* h_nodes, int n_h) {
+    for (int h = 1; h < n_h - 1; h++) {  // the virtual root (last height) holds no shares
+        const int b = h_off[h], e = h_off[h + 1];
+        for (int t = threadIdx.x; t < (e - b) * 9; t += blockDim.x) {
+            const int x = h_nodes[b + t / 9], f = (t % 9) / 3, k = t % 3;
+            if (x >= c.Q) continue;
+            double acc = 0.0;
+            for (int i = c.q_child_off[x]; i < c.q_child_off[x + 1]; i++) {
+                const QShare& s = c.q_share[(size_t)c.q_children[i] * 3 + k];
+                acc += f == 0 ? s.allocated : f == 1 ? s.allocated_np : s.request;
+            }
+            QShare& d = c.q_share[(size_t)x * 3 + k];
+            if (f == 0) d.allocated += acc; else if (f == 1) d.allocated_np += acc; else d.request += acc;
         }
         __threadfence(); __syncthreads();
     }
+}
+// proportion.setFairShareForQueues (plugins/proportion/proportion.go:410-423), one tree level per launch (a level's totals are the parents' fair
+// shares of the level above).  One wavefront per (sibling set, resource): the lanes stage the set — shares, priorities, creation times — into LDS,
+// lane 0 runs the division (resource_division.go:26-357: rounds whose outcome feeds the next, sequential by construction) on the staged copy, the
+// lanes write the fair shares back.  Sets of more than 64 queues run on the session arrays directly.
+struct SiblingsLds {
+    QShare* sh; int64_t* pr; int64_t* cr; uint32_t* ui; double* w; double* ra; uint8_t* rh;
+    __device__ QShare& share(int i) const { return sh[i]; }
+    __device__ int64_t prio(int i) const { return pr[i]; }
+    __device__ int64_t created(int i) const { return cr[i]; }
+    __device__ uint32_t uid(int i) const { return ui[i]; }
+    __device__ double& weight(int i) const { return w[i]; }
+    __device__ double& rem_amt(int i) const { return ra[i]; }
+    __device__ uint8_t& rem_has(int i) const { return rh[i]; }
+};
+constexpr int FS_WAVES = 4, FS_MAX = 64;
+__global__ void __launch_bounds__(FS_WAVES * 64) k_fair_share_level(KaiCtx c, const int32_t* lvl_parents, int first, int count, double* weight, double* rem_amt, uint8_t* rem_has) {
+    __shared__ QShare s_sh[FS_WAVES][FS_MAX]; __shared__ int64_t s_pr[FS_WAVES][FS_MAX], s_cr[FS_WAVES][FS_MAX];
+    __shared__ uint32_t s_ui[FS_WAVES][FS_MAX]; __shared__ double s_w[FS_WAVES][FS_MAX], s_ra[FS_WAVES][FS_MAX]; __shared__ uint8_t s_rh[FS_WAVES][FS_MAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, t = blockIdx.x * FS_WAVES + wave;
+    if (t >= count * 3) return;
+    const int par = lvl_parents[first + t / 3], k = t % 3;
+    const double total = par == c.Q ? c.st->total[k] : c.q_share[(size_t)par * 3 + k].fair;
+    const int32_t* kids = c.q_children + c.q_child_off[par];
+    const int nk = c.q_child_off[par + 1] - c.q_child_off[par];
+    if (nk > FS_MAX) { if (lane == 0) divide_sibling_set(c, kids, nk, k, total, c.k_value, weight + (size_t)k * c.Q, rem_amt + (size_t)k * c.Q, rem_has + (size_t)k * c.Q); return; }
+    if (lane < nk) { const int q = kids[lane]; s_sh[wave][lane] = c.q_share[(size_t)q * 3 + k]; s_pr[wave][lane] = c.q_prio[q]; s_cr[wave][lane] = c.q_created[q]; s_ui[wave][lane] = c.q_uid_rank[q]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) { SiblingsLds v{s_sh[wave], s_pr[wave], s_cr[wave], s_ui[wave], s_w[wave], s_ra[wave], s_rh[wave]}; divide_sibling_view(v, nk, total, c.k_value); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < nk) c.q_share[(size_t)kids[lane] * 3 + k].fair = s_sh[wave][lane].fair;
 }
 
 // ------------------------------------------------------------------------------------------------------
