@@ -88,6 +88,9 @@ typedef enum kai_pod_status {
 #define KAI_POD_HAS_TASK_PRIORITY 0x2u /* carries the task-order label: plugins/taskorder/task_order.go:28-63 */
 #define KAI_POD_CPU_FALLBACK 0x4u      /* needs a state-dependent upstream predicate, fractional GPU, MIG, DRA …:
                                           not placed by the device path (SURVEY §8b fallback rule) */
+#define KAI_POD_GPU_UNMODELLED 0x8u    /* holds / asks for GPU state the device's node accounting does not carry (gpu-memory request, several fractional
+                                          devices, MIG profile, DRA claim): an ACTIVE pod of that kind would leave its node's idle GPUs overstated
+                                          (api/node_info/node_info.go:457-493 addSharedTaskResources), so kai_session_open refuses the snapshot */
 
 typedef enum kai_action {
     KAI_ACTION_ALLOCATE = 0,      /* actions/allocate/allocate.go:46-77 */

@@ -27,7 +27,7 @@ POD_STATUS_NAME = {v: k for k, v in POD_STATUS.items()}
 ACTIVE_USED = sum(POD_STATUS[s] for s in ("Allocated", "Pipelined", "Binding", "Bound", "Running", "Releasing"))
 
 NODE_NOT_READY, NODE_MIG_ENABLED, NODE_MIG_MIXED, NODE_HAS_DRA_GPUS, NODE_GPU_WORKER, NODE_CPU_WORKER, NODE_MIG_SINGLE = 1, 2, 4, 8, 16, 32, 64
-POD_FOREIGN_SCHEDULER, POD_HAS_TASK_PRIORITY, POD_CPU_FALLBACK = 1, 2, 4
+POD_FOREIGN_SCHEDULER, POD_HAS_TASK_PRIORITY, POD_CPU_FALLBACK, POD_GPU_UNMODELLED = 1, 2, 4, 8
 
 ACTIONS = {"allocate": 0, "consolidation": 1, "reclaim": 2, "preempt": 3}
 OP_KIND = {0: "allocate", 1: "pipeline", 2: "evict"}

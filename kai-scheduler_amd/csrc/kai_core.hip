@@ -236,6 +236,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     if (N < 0 || P < 0 || S < 0 || J < 0 || Q < 0) return fail(core, KAI_ERR_INVALID_ARG, "negative dimension");
     for (int p = 0; p < P; p++) if (s->pod_flags && (s->pod_flags[p] & KAI_POD_CPU_FALLBACK) && s->pod_status[p] == KAI_POD_PENDING)
         return fail(core, KAI_ERR_UNSUPPORTED, "a pending pod is flagged KAI_POD_CPU_FALLBACK: leave its job to the host path");
+    for (int p = 0; p < P; p++) if (s->pod_flags && (s->pod_flags[p] & KAI_POD_GPU_UNMODELLED) && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING)))
+        return fail(core, KAI_ERR_UNSUPPORTED, "an active pod holds GPU state the device does not model (gpu-memory / several fractional devices / MIG / DRA): its node's idle GPUs would be overstated");
     // shared-GPU state (ABI v4) is not modelled on the device yet: any pod holding or asking for a fraction of a GPU sends the cycle to the host path
     if (s->pod_gpu_portion) for (int p = 0; p < P; p++) if (s->pod_gpu_portion[p] > 0 && (s->pod_status[p] & (KAI_POD_PENDING | KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING)))
         return fail(core, KAI_ERR_UNSUPPORTED, "a pod requests or holds a fraction of a GPU (pod_gpu_portion): shared-GPU placement is not on the device path yet");

@@ -41,6 +41,27 @@ struct HostPrep {
     int build(const kai_config& cfg, const kai_snapshot_soa* s, std::string& err) {
         const int N = s->n_nodes, P = s->n_pods, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
         auto fail = [&](const char* m) { err = m; return (int)KAI_ERR_INVALID_ARG; };
+        // ---- the snapshot indexes device arrays directly: every index is range-checked here, every required array must be present
+        const int S = s->n_podsets;
+        if (N > 0 && (!s->node_allocatable || !s->node_flags || !s->node_name_rank)) return fail("a required node array is NULL");
+        if (P > 0 && (!s->pod_req || !s->pod_job || !s->pod_podset || !s->pod_status || !s->pod_node || !s->pod_uid_rank)) return fail("a required pod array is NULL");
+        if (S > 0 && (!s->podset_job || !s->podset_min_available || !s->podset_name_rank)) return fail("a required pod-set array is NULL");
+        if (J > 0 && (!s->job_queue || !s->job_priority || !s->job_preemptible || !s->job_created_ns || !s->job_uid_rank || !s->job_first_pod || !s->job_n_pods || !s->job_first_podset || !s->job_n_podsets)) return fail("a required job array is NULL");
+        if (Q > 0 && (!s->queue_parent || !s->queue_priority || !s->queue_created_ns || !s->queue_uid_rank || !s->queue_deserved || !s->queue_limit || !s->queue_oqw)) return fail("a required queue array is NULL");
+        for (int k = 0; k < S; k++) if (s->podset_job[k] < 0 || s->podset_job[k] >= J) return fail("podset_job out of range");
+        for (int j = 0; j < J; j++) {
+            const int b = s->job_first_podset[j], n = s->job_n_podsets[j];
+            if (b < 0 || n < 0 || b + n > S) return fail("job pod-set range out of bounds");
+            if (s->job_queue[j] < -1) return fail("bad job_queue");
+        }
+        for (int p = 0; p < P; p++) {
+            const int j = s->pod_job[p];
+            if (j < -1 || j >= J) return fail("pod_job out of range");
+            if (j >= 0) { const int ps = s->pod_podset[p]; if (ps < s->job_first_podset[j] || ps >= s->job_first_podset[j] + s->job_n_podsets[j]) return fail("pod_podset outside its job's pod-sets"); }
+            else if (s->pod_podset[p] < -1 || s->pod_podset[p] >= S) return fail("pod_podset out of range");
+        }
+        for (int d = 0; d < s->n_domains; d++) if (s->domain_parent && (s->domain_parent[d] < -1 || s->domain_parent[d] >= s->n_domains)) return fail("domain_parent out of range");
+        for (int g = 0; g < s->n_groups; g++) if (s->group_parent && s->group_parent[g] < -1) return fail("group_parent out of range");
         // ---- nodes: permute into name-rank order (framework/session.go:480-485 breaks score ties by node name)
         perm.assign(N, -1);
         for (int i = 0; i < N; i++) { uint32_t rk = s->node_name_rank[i]; if (rk >= (uint32_t)N || perm[rk] >= 0) return fail("node_name_rank must be a permutation of 0..N-1"); perm[rk] = i; }

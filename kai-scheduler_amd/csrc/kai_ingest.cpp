@@ -583,6 +583,15 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         if (spec["volumes"].is_arr()) for (auto& v : spec["volumes"].a) if (v["persistentVolumeClaim"].is_obj() || v["ephemeral"].is_obj()) fb = true;
         for (const char* cs : {"containers", "initContainers"}) if (spec[cs].is_arr()) for (auto& c : spec[cs].a) if (c["ports"].is_arr()) for (auto& port : c["ports"].a) if (port["hostPort"].inum() > 0) fb = true;
         if (fb) r.flags |= KAI_POD_CPU_FALLBACK;
+        if (r.req.mig || !ann["gpu-memory"].str().empty() || !ann["gpu-fraction-num-devices"].str().empty() || (spec["resourceClaims"].is_arr() && !spec["resourceClaims"].a.empty()))
+            r.flags |= KAI_POD_GPU_UNMODELLED;  // GPU state beyond whole devices and one fraction: the device refuses such a pod when it is active
+        {   // kai utility pods (api/pod_info/utility_pods.go:13-33, conf/global_config.go:25-26): never "another scheduler's" (proportion.go:276-285);
+            // a reservation pod holds its GPU on behalf of the fraction pods of its group, so its own devices are not booked (node_info.go:465)
+            const std::string& app = md["labels"]["app"].str();
+            const bool reservation = app == "kai-resource-reservation", scaling = app == "scaling-pod";
+            if (reservation || scaling) r.flags &= ~(uint32_t)KAI_POD_FOREIGN_SCHEDULER;
+            if (reservation) r.req.gpu = 0;
+        }
         // ConfigMap pre-filter (config_maps.go): a missing non-optional config map makes the pod unschedulable everywhere
         {
             std::set<std::string> mounted; std::vector<std::string> need;
@@ -888,14 +897,16 @@ bool unzip_member(const std::string& z, const char* member, std::string& out) {
     for (int k = 0; k < entries && cd + 46 <= n; k++) {
         if (rd32(b + cd) != 0x02014b50) return false;
         uint16_t method = rd16(b + cd + 10); uint32_t csize = rd32(b + cd + 20), usize = rd32(b + cd + 24); uint16_t fl = rd16(b + cd + 28), xl = rd16(b + cd + 30), cl = rd16(b + cd + 32); uint32_t lho = rd32(b + cd + 42);
+        if (cd + 46 + (size_t)fl + xl + cl > n) return false;  // every offset below in size_t: header fields are untrusted
         std::string name((const char*)b + cd + 46, fl);
         if (name == member) {
             if (csize == 0xFFFFFFFFu || usize == 0xFFFFFFFFu) { g_err = "zip64 members are not supported"; return false; }
-            if (lho + 30 > n || rd32(b + lho) != 0x04034b50) return false;
-            size_t data = lho + 30 + rd16(b + lho + 26) + rd16(b + lho + 28);
-            if (data + csize > n) return false;
+            if ((size_t)lho + 30 > n || rd32(b + lho) != 0x04034b50) return false;
+            size_t data = (size_t)lho + 30 + rd16(b + lho + 26) + rd16(b + lho + 28);
+            if (data > n || (size_t)csize > n - data) return false;
             if (method == 0) { out.assign((const char*)b + data, csize); return true; }
             if (method != 8) { g_err = "unsupported zip compression method"; return false; }
+            if ((size_t)usize > ((size_t)1 << 31) || (usize > 1032 && (size_t)usize / 1032 > (size_t)csize + 1)) { g_err = "zip member: implausible uncompressed size"; return false; }  // deflate expands at most 1032:1
             out.resize(usize); z_stream zs{}; if (inflateInit2(&zs, -MAX_WBITS) != Z_OK) return false;
             zs.next_in = (Bytef*)(b + data); zs.avail_in = csize; zs.next_out = (Bytef*)&out[0]; zs.avail_out = usize;
             int rc = inflate(&zs, Z_FINISH); inflateEnd(&zs);

@@ -325,6 +325,28 @@ def test_fallback_flags_and_config_maps():
     assert fits["cm-ok"] and fits["cm-optional"] and fits["cm-unmounted"] and fits["ok"] and not fits["cm-missing"] and not fits["cm-env"]
 
 
+def test_active_gpu_state_and_utility_pods():
+    """(1) a RUNNING gpu-memory / MIG / DRA pod holds GPU state the device's node accounting does not carry — flagged
+    KAI_POD_GPU_UNMODELLED so that kai_session_open can refuse it (api/node_info/node_info.go:457-493 takes a device out of Idle for it);
+    (2) kai utility pods (api/pod_info/utility_pods.go:13-33): a reservation pod's own GPU is not booked on its node (node_info.go:465) and neither
+    it nor a scale-adjust pod counts as another scheduler's pod (plugins/proportion/proportion.go:276-285)."""
+    pods = [pod("mem", annotations={"gpu-memory": "2000"}, phase="Running", node_name="n"), pod("mig", requests={"nvidia.com/mig-1g.5gb": "1"}, phase="Running", node_name="n"),
+            pod("frac", annotations={"gpu-fraction": "0.5"}, phase="Running", node_name="n", labels={"runai-gpu-group": "0"}),
+            pod("plain", phase="Running", node_name="n"),
+            pod("reservation", phase="Running", node_name="n", labels={"app": "kai-resource-reservation"}, spec={"schedulerName": "default-scheduler"}),
+            pod("scaler", phase="Running", node_name="n", labels={"app": "scaling-pod"}, spec={"schedulerName": "default-scheduler"}),
+            pod("foreign", phase="Running", node_name="n", spec={"schedulerName": "default-scheduler"})]
+    s = ingest(doc(nodes=[node("n")], pods=pods)).snapshot
+    names = [n.split("/")[1] for n in s.pod_names]
+    fl = {n: int(s.pod_flags[i]) for i, n in enumerate(names)}
+    assert fl["mem"] & abi.POD_GPU_UNMODELLED and fl["mig"] & abi.POD_GPU_UNMODELLED
+    assert not fl["frac"] & abi.POD_GPU_UNMODELLED and not fl["plain"] & abi.POD_GPU_UNMODELLED  # one fraction of one device is described to the ABI (v4)
+    assert fl["foreign"] & abi.POD_FOREIGN_SCHEDULER
+    assert not fl["reservation"] & abi.POD_FOREIGN_SCHEDULER and not fl["scaler"] & abi.POD_FOREIGN_SCHEDULER
+    gpu = {n: float(s.pod_req[abi.RES_GPU, i]) for i, n in enumerate(names)}
+    assert gpu["reservation"] == 0.0 and gpu["scaler"] == 1.0 and gpu["plain"] == 1.0
+
+
 def test_config_and_actions():
     """conf/scheduler_conf.go:31-88, conf_util/scheduler_conf_util.go:36-107, plugin arguments (nodeplacement.go:59-70, proportion.go:67-93,
     minruntime.go:40-70)."""
