@@ -121,8 +121,7 @@ typedef enum kai_placement_strategy { KAI_BINPACK = 0, KAI_SPREAD = 1 } kai_plac
 #define KAI_PLUGIN_NODEPLACEMENT 0x200u
 #define KAI_PLUGIN_MINRUNTIME 0x400u
 #define KAI_PLUGIN_TOPOLOGY 0x800u
-/* shared-GPU plugins (fractional requests, ABI v4; restated by the oracle, not yet by the device engine — pods with a fraction still carry
- * KAI_POD_CPU_FALLBACK): plugins/gpusharingorder (node order), plugins/gpupack and plugins/gpuspread (GPU order inside a node) */
+/* shared-GPU plugins (fractions of one device, ABI v4): plugins/gpusharingorder (node order), plugins/gpupack and plugins/gpuspread (GPU order inside a node) */
 #define KAI_PLUGIN_GPUSHARINGORDER 0x1000u
 #define KAI_PLUGIN_GPUPACK 0x2000u
 #define KAI_PLUGIN_GPUSPREAD 0x4000u
@@ -351,6 +350,10 @@ int kai_best_node(kai_core* core, int32_t pod_idx, const uint32_t* nodeset_bitma
 /* session-state read-back (what the shim mirrors into PodInfo.Status/NodeName and NodeInfo.Idle/Releasing) */
 int kai_pod_states(kai_core* core, int32_t* status_out, int32_t* node_out, int cap);
 int kai_node_states(kai_core* core, kai_node_state* out, int cap);
+
+/* PodInfo.GPUGroups[0] of every active fraction pod after the actions run so far (what a BindRequest carries as SelectedGPUGroups,
+ * cache/cache.go:290-330): the snapshot's group id, or an id >= 2^20 for a group the cycle opened (gpu_sharing/gpuSharing.go:73-83); -1 otherwise */
+int kai_pod_gpu_groups(kai_core* core, int32_t* groups_out, int cap);
 
 int kai_action_stats_get(kai_core* core, kai_action_stats* out);
 

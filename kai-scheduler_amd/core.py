@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KAI_CORE_LIB") or os.path.join(_HERE, "csrc", "libkai_core.so")  # KAI_CORE_LIB: another BUILD of the same HIP library (profiling variants)
 
 EXPORTS = ["kai_core_create", "kai_core_destroy", "kai_session_open", "kai_queue_shares", "kai_action_execute", "kai_best_node",
-           "kai_pod_states", "kai_node_states", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]
+           "kai_pod_states", "kai_node_states", "kai_pod_gpu_groups", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]
 
 
 class KaiError(RuntimeError):
@@ -125,6 +125,13 @@ class Session:
             bits = words.ctypes.data_as(C.POINTER(C.c_uint32))
         self.core._check(self.core.lib.kai_best_node(self.core.handle, pod, bits, int(pipeline_only), C.byref(node), C.byref(pipe)))
         return node.value, bool(pipe.value)
+
+    def gpu_groups(self):
+        """PodInfo.GPUGroups[0] of the active fraction pods (-1 elsewhere): kai_pod_gpu_groups."""
+        P = self.snap.n_pods
+        out = np.full(max(P, 1), -1, np.int32)
+        self.core._check(self.core.lib.kai_pod_gpu_groups(self.core.handle, out.ctypes.data_as(C.POINTER(C.c_int32)), max(P, 1)))
+        return out[:P]
 
     def queue_shares(self):
         Q = self.snap.n_queues

@@ -4,6 +4,7 @@
 // of the input (kai_host_prep.hpp: nodes in name-rank order, CSR children, per-queue job lists, each job's pods in
 // TaskOrderFn order, scan classes), launches the kernels and copies results back.  There is NO CPU implementation of
 // the path in this library: without a HIP device every entry point fails with KAI_ERR_NO_DEVICE.
+#define KAI_SHARED_GPUS 1  // fractions of one device (ABI v4): group tables per node, gpusharingorder score, FittingGPUs (kai_engine.hpp)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -43,6 +44,7 @@ struct kai_core {
     std::vector<int32_t> perm;  // engine node index (= name rank) → caller's node index
     kai_action_stats stats{};
     HostPrep::BatchShape shape;  // batch path of the allocate action (kai_batch.hpp)
+    bool shared = false; int32_t* d_group0 = nullptr; int32_t next_group0 = 0; int32_t *d_np_off = nullptr, *d_np_pods = nullptr;  // shared GPUs: initial groups, each node's active pods in UID order
     hipEvent_t bev[4] = {nullptr, nullptr, nullptr, nullptr};
     double batch_plan_ms = 0, batch_fill_ms = 0, batch_apply_ms = 0;
 };
@@ -125,7 +127,11 @@ int launch_open_kernels(kai_core* core) {
     KaiCtx& c = core->ctx;
     const int N = c.N, P = c.P, J = c.J, Q = c.Q;
     const int TB = 256;
-    if (P) hipLaunchKernelGGL(k_node_accounting, dim3((P + TB - 1) / TB), dim3(TB), 0, core->stream, c);
+    if (core->shared) {  // shared GPUs: group tables reset, then every node adds its pods in UID order (one lane per node)
+        HIP_TRY(core, hipMemsetAsync(KAI_VP(c.ng_id), 0xFF, sizeof(int32_t) * (size_t)std::max(N, 1) * KAI_GMAX, core->stream));
+        if (P) hipLaunchKernelGGL(k_pod_accounting_reset, dim3((P + TB - 1) / TB), dim3(TB), 0, core->stream, c);
+        if (N) hipLaunchKernelGGL(k_node_accounting_shared, dim3((N + TB - 1) / TB), dim3(TB), 0, core->stream, c, (const int32_t*)core->d_np_off, (const int32_t*)core->d_np_pods);
+    } else if (P) hipLaunchKernelGGL(k_node_accounting, dim3((P + TB - 1) / TB), dim3(TB), 0, core->stream, c);
     if (core->cfg.plugins & KAI_PLUGIN_PROPORTION) {
         if (N) hipLaunchKernelGGL(k_total_nodes, dim3(std::min(1024, (N + TB - 1) / TB)), dim3(TB), 0, core->stream, c);
         if (P) hipLaunchKernelGGL(k_total_foreign, dim3((P + TB - 1) / TB), dim3(TB), 0, core->stream, c);
@@ -238,9 +244,11 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
         return fail(core, KAI_ERR_UNSUPPORTED, "a pending pod is flagged KAI_POD_CPU_FALLBACK: leave its job to the host path");
     for (int p = 0; p < P; p++) if (s->pod_flags && (s->pod_flags[p] & KAI_POD_GPU_UNMODELLED) && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING)))
         return fail(core, KAI_ERR_UNSUPPORTED, "an active pod holds GPU state the device does not model (gpu-memory / several fractional devices / MIG / DRA): its node's idle GPUs would be overstated");
-    // shared-GPU state (ABI v4) is not modelled on the device yet: any pod holding or asking for a fraction of a GPU sends the cycle to the host path
-    if (s->pod_gpu_portion) for (int p = 0; p < P; p++) if (s->pod_gpu_portion[p] > 0 && (s->pod_status[p] & (KAI_POD_PENDING | KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING)))
-        return fail(core, KAI_ERR_UNSUPPORTED, "a pod requests or holds a fraction of a GPU (pod_gpu_portion): shared-GPU placement is not on the device path yet");
+    // shared GPUs (ABI v4): fractions of one device.  One GPU memory size for the whole cluster keeps the queue-capacity step node independent.
+    bool shared = false;
+    if (s->pod_gpu_portion) for (int p = 0; p < P; p++) if (s->pod_gpu_portion[p] > 0) shared = true;
+    if (shared && s->node_gpu_memory) for (int n = 1; n < N; n++) if (s->node_gpu_memory[n] != s->node_gpu_memory[0]) return fail(core, KAI_ERR_UNSUPPORTED, "shared GPUs with different node_gpu_memory values: leave the cycle to the host path");
+    core->shared = shared;
 
     HIP_TRY(core, hipEventRecord(core->ev0, core->stream));
     KaiCtx& c = core->ctx;
@@ -316,6 +324,32 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dupload_f(core, c.cls, prep.classes.data(), prep.classes.size()));
     TRY(dzero_f(core, c.sum1_key, (size_t)std::max(c.C, 1) * std::max(c.NB, 1))); TRY(dzero_f(core, c.sum1_node, (size_t)std::max(c.C, 1) * std::max(c.NB, 1)));
 
+    // ---- shared GPUs: per-pod portion / group, per-node GPU memory and group tables (api/node_info/gpu_sharing_node_info.go)
+    {
+        std::vector<double> por((size_t)std::max(P, 1), 0.0); std::vector<int32_t> grp((size_t)std::max(P, 1), -1), minus1((size_t)std::max(P, 1), -1); std::vector<int64_t> gm((size_t)std::max(N, 1), 100);
+        int32_t next_new = KAI_NEW_GROUP;
+        for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && por[p] > 0) ? s->pod_gpu_group[p] : -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
+        for (int n = 0; n < N; n++) gm[n] = s->node_gpu_memory ? s->node_gpu_memory[prep.perm[n]] : 100;
+        TRY(dupload_f(core, c.p_portion, por.data(), (size_t)P)); TRY(dupload_f(core, c.p_group, grp.data(), (size_t)P)); TRY(dupload_f(core, c.p_on_group, minus1.data(), (size_t)P));
+        TRY(dupload_f(core, c.n_gpu_mem, gm.data(), (size_t)N));
+        { const int32_t* t; TRY(dupload(core, &t, grp.data(), (size_t)std::max(P, 1))); core->d_group0 = const_cast<int32_t*>(t); }
+        TRY(dalloc_f(core, c.ng_id, (size_t)N * KAI_GMAX)); TRY(dzero_f(core, c.ng_used, (size_t)N * KAI_GMAX)); TRY(dzero_f(core, c.ng_rel, (size_t)N * KAI_GMAX)); TRY(dzero_f(core, c.ng_alloc, (size_t)N * KAI_GMAX));
+        TRY(dzero_f(core, c.ng_mark, (size_t)N)); TRY(dzero_f(core, c.ng_has_alloc, (size_t)N));
+        TRY(dupload_f(core, c.next_new_group, &next_new, (size_t)1)); core->next_group0 = next_new;
+        c.shared_on = shared ? 1 : 0;
+        if (shared) { c.use_index = 0; c.all_tracked = 0; c.fast_ok = 0; core->fast_ok0 = 0; }  // every scan by brute force: the class keys know neither fractions nor the gpusharingorder score
+        // each node's active pods in UID order: the shared-GPU guards of addTaskResources are order sensitive (nodes_fake/nodes.go:289-302 adds tasks by UID)
+        std::vector<int32_t> np_off((size_t)N + 1, 0), np_pods;
+        if (shared) {
+            std::vector<int> order; for (int p = 0; p < P; p++) { const int st = s->pod_status[p], n = prep.pod_node[p]; if (n >= 0 && (st & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) { order.push_back(p); np_off[n + 1]++; } }
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return s->pod_uid_rank[a] < s->pod_uid_rank[b]; });
+            for (int n = 0; n < N; n++) np_off[n + 1] += np_off[n];
+            np_pods.resize(order.size()); std::vector<int32_t> fillp(np_off.begin(), np_off.end() - 1);
+            for (int p : order) np_pods[fillp[prep.pod_node[p]]++] = p;
+        }
+        { const int32_t* t; TRY(dupload(core, &t, np_off.data(), np_off.size())); core->d_np_off = const_cast<int32_t*>(t);
+          TRY(dupload(core, &t, np_pods.data(), np_pods.size())); core->d_np_pods = const_cast<int32_t*>(t); }
+    }
     // ---- topologies + sub-group tree
     c.T = prep.T; c.TL = prep.TL; c.D = prep.D; c.G = prep.G; c.W = (N + 31) / 32;
     TRY(dupload_f(core, c.topo_level_off, prep.topo_level_off.data(), prep.topo_level_off.size())); TRY(dupload_f(core, c.node_domain, prep.node_domain.data(), prep.node_domain.size()));
@@ -361,7 +395,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     {   int rcb = batch_bind(c, prep,
             [&](size_t bytes) -> void* { char* p = nullptr; if (dalloc(core, &p, bytes)) return nullptr; if (hipMemsetAsync(p, 0, bytes, core->stream) != hipSuccess) return nullptr; return p; },
             [&](void* d, const void* h, size_t n) -> int { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, core->stream) == hipSuccess ? 0 : (int)KAI_ERR_HIP; });
-        if (rcb) return fail(core, rcb, "batch path buffers"); }
+        if (rcb) return fail(core, rcb, "batch path buffers");
+        if (shared) c.bt.enabled = 0; }
     // keep the initial dynamic state in HBM so that kai_session_reset needs no host traffic
     TRY(dalloc(core, &core->d_status0, (size_t)P)); TRY(dalloc(core, &core->d_node0, (size_t)P)); TRY(dalloc(core, &core->d_shares0, (size_t)std::max(Q, 1) * 3));
 #undef TRY
@@ -393,6 +428,11 @@ int kai_session_reset(kai_core* core) {
                HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_node), core->d_node0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream)); }
     HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.q_share), core->d_shares0, (size_t)std::max(c.Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
     c.fast_ok = core->fast_ok0;
+    if (c.P) HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_group), core->d_group0, (size_t)c.P * 4, hipMemcpyDeviceToDevice, core->stream));
+    HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.next_new_group), &core->next_group0, 4, hipMemcpyHostToDevice, core->stream));
+    { const size_t NG = (size_t)std::max(c.N, 1) * KAI_GMAX;
+      HIP_TRY(core, hipMemsetAsync(KAI_VP(c.ng_used), 0, NG * 8, core->stream)); HIP_TRY(core, hipMemsetAsync(KAI_VP(c.ng_rel), 0, NG * 8, core->stream)); HIP_TRY(core, hipMemsetAsync(KAI_VP(c.ng_alloc), 0, NG * 8, core->stream));
+      HIP_TRY(core, hipMemsetAsync(KAI_VP(c.ng_mark), 0, (size_t)std::max(c.N, 1) * 4, core->stream)); HIP_TRY(core, hipMemsetAsync(KAI_VP(c.ng_has_alloc), 0, (size_t)std::max(c.N, 1) * 4, core->stream)); }
     if (core->solver_ready) HIP_TRY(core, hipMemsetAsync(c.sv.xr_key, 0xFF, sizeof(int64_t) * ((size_t)c.sv.xr_mask + 1), core->stream));
     HIP_TRY(core, hipMemsetAsync(KAI_VP(c.st), 0, sizeof(EngineState), core->stream));
     int rc = launch_open_kernels(core); if (rc) return rc;
@@ -434,6 +474,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         HIP_TRY(core, hipMemsetAsync(base, 0, bytes, core->stream));
         solver_scratch_bind(c.sv, base, c.N, c.P, c.S, c.J, c.Q, c.W, c.D + c.T, c.TL, c.G);
         HIP_TRY(core, hipMemsetAsync(c.sv.xr_key, 0xFF, sizeof(int64_t) * ((size_t)c.sv.xr_mask + 1), core->stream));  // empty residency table
+        { int32_t* xg = nullptr; int rcx = dalloc(core, &xg, (size_t)c.sv.xr_mask + 1); if (rcx) return rcx; c.sv.xr_group = xg; }
         core->solver_ready = true;
     }
     { int d = core->cfg.queue_depth[action]; c.queue_depth = d > 0 ? d : 0; c.action = action; }
@@ -567,6 +608,21 @@ int kai_node_states(kai_core* core, kai_node_state* out, int cap) {
         std::memset(&o, 0, sizeof(kai_node_state));
         for (int r = 0; r < R; r++) { o.idle[r] = idle[(size_t)r * N + i]; o.releasing[r] = rel[(size_t)r * N + i]; o.used[r] = used[(size_t)r * N + i]; }
     }
+    return KAI_OK;
+}
+
+int kai_pod_gpu_groups(kai_core* core, int32_t* out, int cap) {
+    if (!core || !out) return KAI_ERR_INVALID_ARG;
+    if (!core->open) return fail(core, KAI_ERR_STATE, "no open session");
+    const int P = core->ctx.P;
+    if (cap < P) return fail(core, KAI_ERR_CAPACITY, "kai_pod_gpu_groups: cap < n_pods");
+    HIP_TRY(core, hipSetDevice(core->device));
+    std::vector<int32_t> st((size_t)std::max(P, 1)); std::vector<double> por((size_t)std::max(P, 1));
+    if (P) { HIP_TRY(core, hipMemcpyAsync(out, KAI_VP(core->ctx.p_group), (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
+             HIP_TRY(core, hipMemcpyAsync(st.data(), KAI_VP(core->ctx.p_status), (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
+             HIP_TRY(core, hipMemcpyAsync(por.data(), KAI_VP(core->ctx.p_portion), (size_t)P * 8, hipMemcpyDeviceToHost, core->stream)); }
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
+    for (int p = 0; p < P; p++) if (!(core->shared && por[p] > 0 && (st[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING)))) out[p] = -1;
     return KAI_OK;
 }
 

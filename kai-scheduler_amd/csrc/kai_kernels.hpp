@@ -46,6 +46,34 @@ __global__ void k_node_accounting(KaiCtx c) {
     }
 }
 
+#ifdef KAI_SHARED_GPUS
+// shared GPUs: NodeInfo.AddTask of a node's active pods in UID order by ONE lane per node — addSharedTaskResources' guards read what the
+// pods before them left behind (api/node_info/gpu_sharing_node_info.go:83-136), so the order inside a node is part of the result
+__global__ void k_pod_accounting_reset(KaiCtx c) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= c.P) return;
+    c.p_on_node[p] = -1; c.p_on_node_status[p] = 0; c.p_accepted[p] = 0; c.p_virtual[p] = 0; c.p_on_group[p] = -1;
+}
+__global__ void k_node_accounting_shared(KaiCtx c, const int32_t* np_off, const int32_t* np_pods) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= c.N) return;
+    for (int i = np_off[n]; i < np_off[n + 1]; i++) {
+        const int p = np_pods[i], st = c.p_status[p];
+        c.p_on_node[p] = n; c.p_on_node_status[p] = st; c.p_accepted[p] = 1;
+        const bool frac = c.p_portion[p] > 0;
+        if (frac && c.p_group[p] >= 0) c.p_on_group[p] = c.p_group[p];
+        for (int r = 0; r < c.R; r++) {
+            if (r == KAI_RES_GPU && frac) continue;  // getAcceptedTaskResourceWithoutSharedGPU :52-66
+            const double v = c.p_req[(size_t)r * c.P + p]; if (v == 0) continue;
+            const size_t x = (size_t)r * c.N + n;
+            c.n_used[x] += v;
+            if (st == KAI_POD_RELEASING) { c.n_rel[x] += v; c.n_idle[x] -= v; } else if (st == KAI_POD_PIPELINED) c.n_rel[x] -= v; else c.n_idle[x] -= v;
+        }
+        if (frac && c.p_on_group[p] >= 0) { SgNode g{c, n}; if (!g.add(st, g.mem_of(c.p_portion[p]), c.p_on_group[p])) { c.st->fault = FAULT_INTERNAL; c.st->fault_line = __LINE__; } }
+    }
+}
+#endif
+
 __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
@@ -495,9 +523,16 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
             KAI_GP(const uint32_t) ns_bits = sh->nodeset; const int trow = sh->topo_row; KAI_GP(const double) tscore = sh->topo_score;
             for (int n = slot; n < c.N; n += SCAN_LANES) {
                 if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;
+#ifdef KAI_SHARED_GPUS
+                const bool frac = c.shared_on && q.portion > 0 && q.portion < 1;  // a fraction of one device: fit / predicates over the node's GPU groups
+                if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
+                if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n))) continue;
+                bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
+#else
                 if (!fits(c, q.req, n, true)) continue;                              // IsTaskAllocatableOnReleasingOrIdle
                 if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;  // ssn.PredicateFn
                 bool fit_idle = q.best_effort || fits(c, q.req, n, false);
+#endif
                 double sc = node_score(c, q, n, fit_idle);
                 if (trow >= 0) {  // topology.nodeOrderFn (plugins/topology/node_scoring.go:17-35): a node without a score is dropped (session.go:247-251)
                     int dd = c.node_domain[(size_t)trow * c.N + n]; double ts = dd >= 0 ? tscore[dd] : -1.0;

@@ -29,7 +29,8 @@ def run_gpu(snap, cfg, actions=("allocate",)):
             ops += [(int(o["kind"]), int(o["pod"]), int(o["node"]), int(o["job"])) for o in arr]
             stmts += [int(o["stmt"]) + base for o in arr]
         st, nd = ssn.pod_states()
-        res = T.Result(ops=ops, stmts=stmts, pod_status=st, pod_node=nd, shares_open=shares_open, shares_final=ssn.queue_shares(), nodes=ssn.node_states(), stats=ssn.stats())
+        groups = ssn.gpu_groups()
+        res = T.Result(gpu_groups=groups, ops=ops, stmts=stmts, pod_status=st, pod_node=nd, shares_open=shares_open, shares_final=ssn.queue_shares(), nodes=ssn.node_states(), stats=ssn.stats())
         ssn.close()
     return res
 
@@ -357,3 +358,52 @@ def test_gpu_full_size_against_the_host_compiled_engine(gpu):
     bounded = T.abi.KaiConfig.from_buffer_copy(cfg); bounded.reserved[0] = 3000  # the oracle stops after its first 3 000 decisions
     ref = T.Oracle.run(snap, bounded)
     assert len(ref.ops) > 500 and res.ops[:len(ref.ops)] == ref.ops
+
+
+# ------------------------------------------------------------------------------------------------ shared GPUs (fractions of one device) on the MI355X
+def assert_same_tol(res, ref, tol=1e-9):
+    """with fractional quantities the queue sums are no longer sums of integers: the reference itself adds them in Go-map order, so shares are held to
+    1e-9 (north_star: 1e-6); placements, pod states and node accounting stay exact"""
+    assert res.ops == ref.ops and res.stmts == ref.stmts
+    assert (res.pod_status == ref.pod_status).all() and (res.pod_node == ref.pod_node).all()
+    for k in ref.shares_open:
+        assert np.allclose(res.shares_open[k], ref.shares_open[k], rtol=0.0, atol=tol), k
+        assert np.allclose(res.shares_final[k], ref.shares_final[k], rtol=0.0, atol=tol), k
+    for k in ref.nodes:
+        assert np.array_equal(res.nodes[k], ref.nodes[k]), k
+
+
+def _frac_cases():
+    from test_engine_hostsim import FRAC_GOLD, FRAC_VICTIM_GOLD
+    out = [("allocate__allocateFractionalGpu", i, c, ("allocate",)) for i, c in FRAC_GOLD]
+    return out + [(n, i, c, a) for n, i, c, a in FRAC_VICTIM_GOLD]
+
+
+@pytest.mark.parametrize("name,i,case,actions", _frac_cases(), ids=[f"{n}[{i}]" for n, i, _, _ in _frac_cases()])
+def test_gpu_fractional_goldens(gpu, name, i, case, actions):
+    """the reference's 35 golden scenarios with fraction pods (allocateFractionalGpu_test.go and the victim-action tables): expectations of the
+    reference, and operations / states / node accounting / GPU groups of the oracle"""
+    from test_engine_hostsim import _same_groups
+    snap, cfg, meta = T.case_to_snapshot(case, fractions=True)
+    ref = T.Oracle.run(snap, cfg, actions)
+    res = run_gpu(snap, cfg, actions)
+    assert_same_tol(res, ref)
+    _same_groups(snap, res, ref)
+    assert not T.check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes, res.gpu_groups)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_gpu_fraction_fuzz(gpu, seed):
+    from test_engine_hostsim import _same_groups, FRAC_ACTS
+    snap = T.pkg.synth.make_crowded_snapshot(2 + seed % 9, 9300 + seed, fill=0.3 + 0.5 * (seed % 5) / 4, n_pending_jobs=6 + seed % 13, elastic_frac=0.2,
+                                             hog_frac=0.5, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3], cpu_only_frac=0.3 if seed % 4 == 0 else 0.0)
+    T.pkg.synth.add_fractions(snap, seed, frac=0.6, portions=(0.25, 0.5, 0.75))
+    cfg = T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], cpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[(seed // 2) % 2], k_value=(0.0, 0.5, 1.0)[seed % 3],
+                               max_consolidation_preemptees=(-1, 16, 2)[seed % 3])
+    if seed % 3 == 0: cfg.plugins = (cfg.plugins & ~T.abi.PLUGINS["gpupack"]) | T.abi.PLUGINS["gpuspread"]
+    if seed % 7 == 0: cfg.plugins &= ~T.abi.PLUGINS["gpusharingorder"]
+    for acts in (("allocate",), FRAC_ACTS[seed % len(FRAC_ACTS)]):
+        ref = T.Oracle.run(snap, cfg, acts)
+        res = run_gpu(snap, cfg, acts)
+        assert_same_tol(res, ref)
+        _same_groups(snap, res, ref)
