@@ -71,7 +71,10 @@ def main():
     idx = CONFIGS[args.config]
     actions = tuple(a for a in (args.actions or ("allocate,consolidation,reclaim" if args.config == "C4" else "allocate")).split(",") if a)
     t0 = time.time()
-    snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=pkg.dist.shard_seed(0, rank))  # every rank schedules its own shard
+    # N > 1: the ranks shard the NODE axis of ONE snapshot (strong scaling: total work fixed) — every rank builds the same snapshot.
+    # KAI_BENCH_MULTI=replicas runs one independent scheduling shard per GPU instead (weak scaling, no data-path collective).
+    sharded = world > 1 and os.environ.get("KAI_BENCH_MULTI", "shard") != "replicas"
+    snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=0 if (sharded or world == 1) else pkg.dist.shard_seed(0, rank))
     gen_s = time.time() - t0
     N = snap.n_nodes
     if os.environ.get("KAI_BENCH_ENGINE_MODE"):
@@ -80,7 +83,7 @@ def main():
     def barrier():
         pkg.dist.barrier(torch.cuda.synchronize)
 
-    core = pkg.KaiCore(cfg, gpu_ids=(local_rank,))
+    core = pkg.KaiCore(cfg, gpu_ids=(local_rank,), world=world, rank=rank) if sharded else pkg.KaiCore(cfg, gpu_ids=(local_rank,))
     t0 = time.time()
     ssn = core.open_session(snap)  # host → HBM once; the timed steps replay from the resident copy
     upload_s = time.time() - t0
@@ -117,8 +120,11 @@ def main():
     ssn.close(); core.destroy()
 
     first_ops = [(int(x["kind"]), int(x["pod"]), int(x["node"]), int(x["job"])) for o in first_ops for x in o]  # the last step's committed operations
-    total_decisions = pkg.dist.sum_over_ranks(decisions * args.steps, device="cuda")  # one scheduling shard per rank (DESIGN.md "Multi-GPU")
-    total_placed = pkg.dist.sum_over_ranks(placed * args.steps, device="cuda")
+    if sharded:  # one job: every rank committed the same operations
+        total_decisions, total_placed = decisions * args.steps, placed * args.steps
+    else:        # replicas: one scheduling shard per rank
+        total_decisions = pkg.dist.sum_over_ranks(decisions * args.steps, device="cuda")
+        total_placed = pkg.dist.sum_over_ranks(placed * args.steps, device="cuda")
     value = total_decisions / elapsed
     k_ms = float(np.mean(kernel_ms))
     b_dec = N * B_NODE + B_POD_OUT
@@ -130,6 +136,8 @@ def main():
     if batch:
         plan_ms, fill_ms, apply_ms = (int(st.reserved[7]) >> 42) / 1e3, ((int(st.reserved[7]) >> 21) & 0x1fffff) / 1e3, (int(st.reserved[7]) & 0x1fffff) / 1e3
         rounds = int(st.reserved[4]); fill_dec = decisions - drained
+        if sharded:
+            engine["exchanges_per_step"] = int(st.reserved[0])
         engine.update({"path": "batch (plan / fill / apply rounds)", "rounds": rounds, "mispredicted_jobs": int(st.reserved[6]), "fill_wave_cycles": int(st.reserved[5]),
                        "fill_block_loads": int(st.reserved[1]), "plan_ms": plan_ms, "fill_ms": fill_ms, "apply_ms": apply_ms,
                        "fill_cycles_per_decision": int(st.reserved[5]) / max(fill_dec, 1)})
@@ -151,11 +159,12 @@ def main():
     out = {
         "metric": "pod placement decisions/sec (" + " + ".join(actions) + (" action" if len(actions) == 1 else " actions") + ", synthetic snapshot)", "value": value, "unit": "decisions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "placements_per_s": total_placed / elapsed,
         "config": {"workload": desc, "nodes": N, "pods": snap.n_pods, "jobs": snap.n_jobs, "queues": snap.n_queues,
                    "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2], "action_ms": k_ms,
-                   "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else f"{world} scheduling shards, one per GPU, no data-path collective",
+                   "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else (f"node axis of one snapshot sharded over {world} GPUs: per exchange every rank offers its 128 best nodes per scan class, all-gather over RCCL / xGMI, the same virtual fill on every rank"
+                                                                      if sharded else f"{world} scheduling shards, one per GPU, no data-path collective"),
                    "snapshot_gen_s": round(gen_s, 2), "host_to_hbm_s": round(upload_s, 3), "engine": engine},
         "roofline": roof,
     }

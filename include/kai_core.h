@@ -318,8 +318,18 @@ typedef struct kai_action_stats {
 
 typedef struct kai_core kai_core; /* opaque */
 
-/* replaces: scheduler.NewScheduler wiring (pkg/scheduler/scheduler.go:53-101); gpu_ids = HIP device ordinals */
+/* replaces: scheduler.NewScheduler wiring (pkg/scheduler/scheduler.go:53-101); gpu_ids = HIP device ordinals.
+ * n_gpus == 1: the whole session on gpu_ids[0].  n_gpus > 1: ONE PROCESS PER GPU — this handle is one rank of a group of n_gpus handles that
+ * shard the NODE axis of one session (contiguous name-rank ranges; pods, jobs, queues replicated) on the GPUs of one node; gpu_ids[0] is this
+ * rank's device and kai_shard_attach names the rank and the group's all-gather.  Every rank opens the same snapshot and makes the same calls. */
 int kai_core_create(const kai_config* cfg, int n_gpus, const int* gpu_ids, kai_core** out);
+
+/* The group's exchange step: an all-gather of `bytes_per_rank` bytes from every rank's `send` into `recv` (rank-major), on DEVICE
+ * memory of the library.  The library has no communicator of its own: the caller supplies the collective (the Python mirror:
+ * torch.distributed.all_gather_into_tensor over RCCL / xGMI) and the library calls it between kernels, with its stream synchronised.
+ * offers_per_class: nodes a rank offers per scan class and exchange (0 = default 128).  Returns 0 / a kai_status. */
+typedef int (*kai_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes_per_rank);
+int kai_shard_attach(kai_core* core, int rank, int world, int offers_per_class, kai_allgather_fn fn, void* user);
 int kai_core_destroy(kai_core* core);
 
 /* replaces: framework.OpenSession + every OnSessionOpen on the path (framework/framework.go:32-65):

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KAI_CORE_LIB") or os.path.join(_HERE, "csrc", "libkai_core.so")  # KAI_CORE_LIB: another BUILD of the same HIP library (profiling variants)
 
 EXPORTS = ["kai_core_create", "kai_core_destroy", "kai_session_open", "kai_queue_shares", "kai_action_execute", "kai_best_node",
-           "kai_pod_states", "kai_node_states", "kai_pod_gpu_groups", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]
+           "kai_pod_states", "kai_node_states", "kai_pod_gpu_groups", "kai_shard_attach", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]
 
 
 class KaiError(RuntimeError):
@@ -31,7 +31,19 @@ class KaiError(RuntimeError):
         super().__init__(f"kai_core status {code} ({abi.STATUS_TEXT.get(code, '?')}): {detail}")
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)  # kai_allgather_fn (include/kai_core.h)
 _lib = None
+_hip = None
+
+
+def _hip_runtime():
+    """libamdhip64 through ctypes: device-to-device copies between the library's exchange buffers and torch's tensors."""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpy.restype = C.c_int
+    return _hip
 
 
 def load_library(path: str = LIB_PATH):
@@ -50,6 +62,8 @@ def load_library(path: str = LIB_PATH):
     lib.kai_core_destroy.argtypes = [C.c_void_p]
     lib.kai_session_open.argtypes = [C.c_void_p, C.POINTER(abi.KaiSnapshotSoA)]
     lib.kai_session_close.argtypes = [C.c_void_p]
+    lib.kai_shard_attach.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]
+    lib.kai_pod_gpu_groups.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
     lib.kai_session_reset.argtypes = [C.c_void_p]
     lib.kai_queue_shares.argtypes = [C.c_void_p, C.POINTER(abi.KaiQueueShare), C.c_int]
     lib.kai_action_execute.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.KaiOp), C.c_int64, C.POINTER(C.c_int64)]
@@ -65,14 +79,47 @@ def load_library(path: str = LIB_PATH):
 
 
 class KaiCore:
-    def __init__(self, cfg: abi.KaiConfig | None = None, gpu_ids=(0,)):
+    """One handle = one GPU.  `world` > 1: this process is rank `rank` of a group that shards the NODE axis of one session over the GPUs of one
+    node (one process per GPU, every rank opens the same snapshot and makes the same calls).  The group's exchange step is an
+    all-gather of a few KB per rank: `allgather(send_ptr, recv_ptr, nbytes_per_rank)` on the library's device buffers, by default
+    torch.distributed.all_gather_into_tensor on the default process group (backend "nccl" = RCCL over xGMI on the GPU box)."""
+
+    def __init__(self, cfg: abi.KaiConfig | None = None, gpu_ids=(0,), world: int = 1, rank: int = 0, offers_per_class: int = 0, allgather=None):
         self.lib = load_library()
         self.cfg = cfg or abi.default_config()
         self.handle = C.c_void_p()
-        ids = (C.c_int * len(gpu_ids))(*gpu_ids)
-        rc = self.lib.kai_core_create(C.byref(self.cfg), len(gpu_ids), ids, C.byref(self.handle))
+        self.world, self.rank = int(world), int(rank)
+        ids = (C.c_int * 1)(gpu_ids[0])
+        rc = self.lib.kai_core_create(C.byref(self.cfg), self.world, ids, C.byref(self.handle))
         if rc != 0:
             raise KaiError(rc, "kai_core_create")
+        if self.world > 1:
+            self._user_allgather = allgather
+            self._stage = None
+            self._cb = ALLGATHER_FN(self._allgather)  # kept alive with the handle
+            rc = self.lib.kai_shard_attach(self.handle, self.rank, self.world, int(offers_per_class), self._cb, None)
+            if rc != 0:
+                raise KaiError(rc, "kai_shard_attach")
+
+    def _allgather(self, user, send, recv, nbytes):
+        try:
+            if self._user_allgather is not None:
+                return int(self._user_allgather(send, recv, nbytes) or 0)
+            import torch
+            import torch.distributed as dist
+            hip = _hip_runtime()
+            if self._stage is None or self._stage[0].numel() != nbytes:  # torch-owned staging tensors: the collective runs on memory torch knows
+                self._stage = (torch.empty(nbytes, dtype=torch.uint8, device="cuda"), torch.empty(nbytes * self.world, dtype=torch.uint8, device="cuda"))
+            s, r = self._stage
+            if hip.hipMemcpy(C.c_void_p(s.data_ptr()), C.c_void_p(send), C.c_size_t(nbytes), 3) != 0:  # hipMemcpyDeviceToDevice
+                return 1
+            dist.all_gather_into_tensor(r, s)
+            torch.cuda.synchronize()
+            return 0 if hip.hipMemcpy(C.c_void_p(recv), C.c_void_p(r.data_ptr()), C.c_size_t(nbytes * self.world), 3) == 0 else 1
+        except Exception:  # a ctypes callback must not raise
+            import traceback
+            traceback.print_exc()
+            return 1
 
     def _check(self, rc):
         if rc != 0:

@@ -6,6 +6,7 @@
 //                      int write(void* dev_dst, const void* host_src, size_t bytes).
 #pragma once
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -18,6 +19,7 @@ struct BatchStats {
     int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0;
     int64_t fill_cycles = 0, fill_load = 0, fill_update = 0, fill_rescan = 0, block_loads = 0, rescans1 = 0, rescans2 = 0, rescans3 = 0;
     int32_t drain = 0, ran = 0, max_h = 0, pad = 0;
+    int64_t exchanges = 0;  // node-sharded group: all-gathers of the action
 };
 
 // pools: every queued job can be an element of its leaf and of every ancestor (incl. the virtual root)
@@ -26,13 +28,14 @@ inline size_t batch_pool_k(const HostPrep& prep, int J, int Q) { return (size_t)
 
 // zalloc(bytes) -> zero-filled memory the kernels can address; upload(dst, src, bytes)
 template <class ZAlloc, class Upload>
-int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload) {
+int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload, int world = 1, int rank = 0, int shard_k = 0) {
     BatchCtx& b = c.bt;
     b = BatchCtx{};
     b.enabled = prep.batch_ok && c.use_index && c.all_tracked && c.fast_ok && c.R <= 4 && (c.plugins & KAI_PLUGIN_PROPORTION) ? 1 : 0;
     if (!b.enabled) return 0;
     const int Q = c.Q, J = c.J, P = c.P;
     b.n_h = prep.n_heights; b.pool_e = (int32_t)batch_pool_e(prep, J, Q); b.pool_k = (int32_t)batch_pool_k(prep, J, Q);
+#define KB_Z2(field, n) do { void* p_ = zalloc(std::max<size_t>((size_t)(n), 1) * sizeof(*b.field)); if (!p_) return KAI_ERR_HIP; b.field = (decltype(b.field))p_; } while (0)
 #define KB_Z(field, n) do { void* p_ = zalloc(std::max<size_t>((size_t)(n), 1) * sizeof(*b.field)); if (!p_) return KAI_ERR_HIP; b.field = (decltype(b.field))p_; } while (0)
     KB_Z(q_height, Q + 1); KB_Z(h_off, b.n_h + 1); KB_Z(h_nodes, Q + 1); KB_Z(q_srank, Q + 1);
     KB_Z(j_clsmask, J); KB_Z(j_ucls, J); KB_Z(cur_sp, Q + 1); KB_Z(qual, 4);
@@ -42,10 +45,25 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_stmt, J + 1); KB_Z(g_first, J + 1); KB_Z(g_nt, J + 1); KB_Z(g_ucls, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
     KB_Z(t_cls, P); KB_Z(t_node, P);
     KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1);
-#undef KB_Z
+    if (world > 1) {  // node-axis sharding: contiguous 64-node-block ranges in name-rank order, offers of K nodes per class and rank
+        b.world = world; b.rank = rank;
+        const int per = (c.NB + world - 1) / world;  // blocks per rank
+        b.n_lo = std::min(c.N, rank * per * KAI_BLOCK); b.n_hi = std::min(c.N, (rank + 1) * per * KAI_BLOCK);
+        b.shard_k = shard_k > 0 ? shard_k : 128;
+        b.shard_mmax = std::max(1, std::min(std::max(c.C, 1) * b.shard_k, std::max(per * KAI_BLOCK, 1)));  // the same on every rank: the messages of an all-gather have one size
+        b.msg_bytes = (int64_t)((sizeof(ShardHdr) + (size_t)b.shard_mmax * 4 + (size_t)b.shard_mmax * sizeof(NodeRec) + 63) & ~(size_t)63);
+        b.vcap = ((b.shard_mmax * world + KAI_BLOCK - 1) / KAI_BLOCK + 1) * KAI_BLOCK;
+        KB_Z2(sh_keys, (size_t)std::max(c.C, 1) * std::max(c.N, 1)); KB_Z2(cand_bits, (size_t)(c.N + 31) / 32 + 1);
+        KB_Z2(send, (size_t)b.msg_bytes); KB_Z2(recv, (size_t)b.msg_bytes * world);
+        KB_Z2(vrec, (size_t)b.vcap); KB_Z2(vmap, (size_t)b.vcap); KB_Z2(v1k, (size_t)std::max(c.C, 1) * (b.vcap / KAI_BLOCK)); KB_Z2(v1n, (size_t)std::max(c.C, 1) * (b.vcap / KAI_BLOCK));
+        KB_Z2(floors, 64); KB_Z2(vstate, 4);
+        b.nrec_home = b.nrec;
+    } else { b.world = 1; b.rank = 0; b.n_lo = 0; b.n_hi = c.N; }
     if (int rc = upload((void*)b.q_height, prep.q_height.data(), prep.q_height.size() * 4)) return rc;
     if (int rc = upload((void*)b.h_off, prep.h_off.data(), prep.h_off.size() * 4)) return rc;
     if (int rc = upload((void*)b.h_nodes, prep.h_nodes.data(), prep.h_nodes.size() * 4)) return rc;
+#undef KB_Z
+#undef KB_Z2
     return 0;
 }
 
@@ -55,6 +73,46 @@ inline size_t batch_fill_lds(const KaiCtx& c, int& l1_in_lds) {
     const size_t budget = 160 * 1024 - 16 * 1024;  // static LDS of the kernel (class tops, rollback list: 9 KB) + margin
     l1_in_lds = (l2 + l1 <= budget && !std::getenv("KAI_BATCH_L1_HBM")) ? 1 : 0;  // the variable forces the HBM variant (tests)
     return l2 + (l1_in_lds ? l1 : 0) + 16;
+}
+
+// The fill of one planned round on a node-sharded group: offers -> all-gather -> the same virtual fill on every rank -> own records
+// back, until the round's order is used up, a job ends differently from its prediction, or — the usual case — a class runs out of offered
+// nodes that beat what the ranks hold back, which starts the next exchange.  fs ends up describing the whole round (like a single fill).
+template <class L>
+int batch_fill_sharded(L& l, KaiCtx& c, RoundParams rp, FillStatus& fs, int64_t& exchanges) {
+    const int TB = 256; BatchCtx& b = c.bt;
+    KaiCtx cv = c;  // the virtual cluster: same classes and plugins, its own records / block index; its size lives on the device (vstate)
+    cv.bt.nrec = b.vrec; cv.sum1_key = b.v1k; cv.sum1_node = b.v1n; cv.N = 0x7fffffff; cv.NB = b.vcap / KAI_BLOCK; cv.NSB = (cv.NB + 63) / 64;
+    int l1v = 0; size_t dynv = batch_fill_lds(cv, l1v); l1v = 0; dynv = (size_t)cv.C * cv.NSB * sizeof(IdxE) + 16;  // block level of the virtual index stays in HBM
+    const int nloc = b.n_hi - b.n_lo, blk0 = b.n_lo / KAI_BLOCK, blk1 = (b.n_hi + KAI_BLOCK - 1) / KAI_BLOCK;
+    FillStatus acc{}; acc.n_done = rp.start; int start = rp.start, stalled = 0;
+    for (;;) {
+        l.shard_keys(std::max(1, (int)(((int64_t)std::max(nloc, 1) * std::max(c.C, 1) + TB - 1) / TB)), TB, c);
+        if (c.C) l.shard_select(c.C, TB, c);
+        l.shard_compact(1, TB, c);
+        if (int rc = l.allgather((const void*)b.send, (void*)b.recv, b.msg_bytes)) return rc;
+        exchanges++;
+        l.shard_vbuild(b.world + 1, TB, c);
+        l.index_from_recs(std::max(1, cv.NB), 64, cv, (const NodeRec*)b.vrec, -1, (uint64_t*)b.v1k, (int32_t*)b.v1n, cv.NB, 0, cv.NB);
+        RoundParams r2 = rp; r2.start = start; r2.ops0 = (int32_t)acc.ops; r2.stmt0 = (int32_t)acc.committed; if (rp.mode == 0) r2.mode = 2;
+        l.fill(1, 64, dynv, cv, r2, l1v);
+        FillStatus f1{};
+        if (int rc = l.read(&f1, (const void*)b.fs, sizeof f1)) return rc;
+        if (std::getenv("KAI_SHARD_DEBUG")) { int32_t vs[4] = {0, 0, 0, 0}; IdxE fl[4]; (void)l.read(vs, (const void*)b.vstate, sizeof vs); (void)l.read(fl, (const void*)b.floors, sizeof fl);
+            std::fprintf(stderr, "[shard r%d] exchange %lld mode %d start %d -> n_done %d planned %d floor_stop %d mismatch %d decisions %lld | virtual nodes %d floor0 %llx/%d\n", b.rank, (long long)exchanges, r2.mode, start, f1.n_done, f1.planned, f1.floor_stop, f1.mismatch, (long long)f1.decisions, vs[0], (unsigned long long)fl[0].key, fl[0].node); }
+        l.shard_scatter(std::max(1, (b.vcap + TB - 1) / TB), TB, c, b.vcap);
+        if (blk1 > blk0) l.index_from_recs(blk1 - blk0, 64, c, (const NodeRec*)b.nrec, c.N, (uint64_t*)c.sum1_key, (int32_t*)c.sum1_node, c.NB, blk0, blk1);
+        acc.decisions += f1.decisions; acc.attempted += f1.attempted; acc.committed += f1.committed; acc.rollbacks += f1.rollbacks; acc.ops += f1.ops;
+        acc.cycles_total += f1.cycles_total; acc.block_loads += f1.block_loads; acc.rescans1 += f1.rescans1; acc.rescans2 += f1.rescans2; acc.rescans3 += f1.rescans3;
+        acc.mismatch = f1.mismatch; acc.all_dead = f1.all_dead; acc.dead_mask = f1.dead_mask; acc.planned = f1.planned; acc.floor_stop = f1.floor_stop;
+        if (rp.mode == 1) break;
+        stalled = f1.n_done == start ? stalled + 1 : 0;
+        start = f1.n_done; acc.n_done = start;
+        if (f1.mismatch || !f1.floor_stop || start >= f1.planned) break;
+        if (stalled >= 2) return KAI_ERR_COMM;  // a gang larger than the ranks' offers can hold: does not qualify for the sharded path
+    }
+    fs = acc;
+    return l.write((void*)b.fs, &acc, sizeof acc);  // the apply kernels read the round's totals
 }
 
 // Runs the allocate action on the batch path.  ran = false: the action does not qualify, nothing was touched (run the sequential engine).
@@ -75,9 +133,13 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     l.nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
     int l1_in_lds = 0; const size_t dyn = batch_fill_lds(c, l1_in_lds);
     RoundParams rp{}; rp.mode = 1;
-    l.fill(1, 64, dyn, c, rp, l1_in_lds);
     FillStatus fs{};
-    if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc;
+    const bool sharded = c.bt.world > 1;
+    if (sharded) { l.shard_mask_nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
+                   const int b0 = c.bt.n_lo / KAI_BLOCK, b1 = (c.bt.n_hi + KAI_BLOCK - 1) / KAI_BLOCK; (void)b0; (void)b1;
+                   l.index_from_recs(std::max(1, c.NB), 64, c, (const NodeRec*)c.bt.nrec, c.N, (uint64_t*)c.sum1_key, (int32_t*)c.sum1_node, c.NB, 0, c.NB);
+                   if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }
+    else { l.fill(1, 64, dyn, c, rp, l1_in_lds); if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; }
     int H = 16; int64_t ops_base = ops_base0, stmt_base = stmt_base0;
     while (remaining > 0) {
         if (fs.all_dead) { bs.drain = 1; break; }
@@ -93,10 +155,11 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
             l.plan_scan(std::max(shape.h_count[h], 1), 64, c, rp);
         }
         l.plan_emit(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c);
-        l.fill(1, 64, dyn, c, rp, l1_in_lds);
+        if (sharded) { rp.start = 0; if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }
+        else l.fill(1, 64, dyn, c, rp, l1_in_lds);
         l.apply_jobs(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c, ops_base, stmt_base);
         if (Q) l.apply_nodes((Q + TB - 1) / TB, TB, c);
-        if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc;
+        if (!sharded) { if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; } else if (int rc = l.read(nullptr, nullptr, 0)) return rc;
         if (fs.n_done <= 0) return KAI_ERR_DEVICE_FAULT;  // a round always executes at least one job
         bs.rounds++; bs.mismatches += fs.mismatch; bs.planned += fs.planned; bs.max_h = std::max(bs.max_h, H);
         bs.decisions += fs.decisions; bs.attempted += fs.attempted; bs.committed += fs.committed; bs.rollbacks += fs.rollbacks; bs.ops += fs.ops;

@@ -444,19 +444,34 @@ KW_BODY void kb_fill_flush(FillState& f, const L1& l1) { if (f.pend_n >= 0) { kb
 // landing on the node that class's top pointed to — its key for the class did not drop below the top key the index holds, so no other node can
 // have overtaken it — only the node's record changes; the index entries of every class follow in one step when another class is asked for,
 // when the node stops being the class's best, or when the round ends.
+// node-sharded fill (mode 2): may the class's best candidate (tk, tn) be used?  Only while it beats the best node the ranks did NOT offer.
+KW_BODY bool kb_beats_floor(const KaiCtx& c, int kcls, uint64_t tk, int tn) {
+    const BatchCtx& b = c.bt;
+    const uint64_t fk = b.floors[kcls].key; const int fn = b.floors[kcls].node;
+    return fk == 0 || key_better(tk, b.vmap[tn], fk, fn);
+}
 template <bool SPEC, class L1>
-KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls) {
+KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls, bool sharded) {
     if (f.pend_n >= 0) {
         if (kcls == f.pend_cls) {
             const int ln = f.pend_n & 63;
             const uint64_t mine = kb_lane_key<SPEC>(f, kcls);
             const uint64_t kap = kw::bcast(mine, ln);
-            if (kap != 0 && kap >= f.pend_key) { kb_fill_update_rec(c, f, f.pend_n, kcls, 1.0); return f.pend_n; }
+            if (kap != 0 && kap >= f.pend_key && (!sharded || kb_beats_floor(c, kcls, kap, f.pend_n))) { kb_fill_update_rec(c, f, f.pend_n, kcls, 1.0); return f.pend_n; }
         }
         kb_fill_flush<SPEC>(f, l1);
     }
     KB_T(t_p);
     const uint64_t tk = kw::bcast(f.topk, kcls); const int tn = kw::bcast(f.topn, kcls);
+    if (sharded) {  // no candidate at all is an answer only when no rank holds anything back for the class
+        if (tk == 0) return c.bt.floors[kcls].key == 0 ? -1 : -2;
+        if (!kb_beats_floor(c, kcls, tk, tn)) {
+#if !defined(__HIPCC__)
+            if (kw::lane() == 0 && std::getenv("KAI_SHARD_TRACE")) std::fprintf(stderr, "[shard r%d] floor stop: class %d top %llx / node %d (virtual %d) vs floor %llx / %d\n", c.bt.rank, kcls, (unsigned long long)tk, c.bt.vmap[tn], tn, (unsigned long long)c.bt.floors[kcls].key, c.bt.floors[kcls].node);
+#endif
+            return -2;
+        }
+    }
     if (tk == 0) return -1;
     kb_fill_load_block(c, f, l1, tn >> 6);
     kb_fill_update_rec(c, f, tn, kcls, 1.0);
@@ -487,16 +502,16 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
         if (lane == k) { f.topk = key; f.topn = bn; }
     }
     kw::sync();
-    const int V = rp.mode == 0 ? b.q_valid[c.Q] : 0;  // mode 1: index levels and dead classes only (before the first plan)
-    int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0; int n_done = 0, mismatch = 0;
-    for (int base = 0; base < V && !mismatch; base += 64) {
+    const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: index levels and dead classes only (before the first plan)
+    const bool sharded = rp.mode == 2;
+    int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0; int n_done = rp.start, mismatch = 0, floor_stop = 0;
+    for (int base = rp.start; base < V && !mismatch && !floor_stop; base += 64) {
         const int gi = base + lane;
         const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE, my_first = gi < V ? b.g_first[gi] : 0, my_nt = gi < V ? b.g_nt[gi] : 0, my_ucls = gi < V ? b.g_ucls[gi] : 0;
         const int cnt = V - base < 64 ? V - base : 64;
         for (int jj = 0; jj < cnt; jj++) {
             const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
-            attempted++; n_done = base + jj + 1;
-            const int opoff = (int)ops, stmtoff = (int)committed;
+            const int opoff = (int)ops + rp.ops0, stmtoff = (int)committed + rp.stmt0; const int64_t dec0 = decisions;  // ops0 / stmt0: what earlier launches of this round committed
             bool ok = flag != BF_GATE; int placed = 0;
             if (flag != BF_GATE) {
                 for (int tb = 0; tb < nt && ok; tb += 64) {
@@ -506,9 +521,10 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
                     for (int ti = 0; ti < tc; ti++) {
                         const int kcls = ucls >= 0 ? ucls : kw::bcast(my_cls, ti);
                         decisions++;
-                        const int tn = kb_fill_place<SPEC>(c, f, l1, kcls);
+                        const int tn = kb_fill_place<SPEC>(c, f, l1, kcls, sharded);
+                        if (tn == -2) { floor_stop = 1; ok = false; break; }
                         if (tn < 0) { ok = false; break; }
-                        if (lane == 0) { L.placed_node[placed] = tn; L.placed_cls[placed] = kcls; b.t_node[first + placed] = tn; }
+                        if (lane == 0) { L.placed_node[placed] = tn; L.placed_cls[placed] = kcls; b.t_node[first + placed] = sharded ? b.vmap[tn] : tn; }
                         placed++;
                     }
                 }
@@ -519,9 +535,11 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
                         const int n = L.placed_node[i];
                         kb_fill_load_block(c, f, l1, n >> 6); kb_fill_update_rec(c, f, n, L.placed_cls[i], -1.0); kb_fill_node_changed<SPEC>(f, l1, n);
                     }
+                    if (floor_stop) { decisions = dec0; break; }  // the gang is taken back untouched: the next exchange starts with it
                     rollbacks += 2;
                 } else { committed++; ops += nt; }
             }
+            attempted++; n_done = base + jj + 1;
             if (lane == 0) { b.g_out[base + jj] = ok ? BF_OK : BF_DEAD; b.g_opoff[base + jj] = opoff; b.g_stmt[base + jj] = stmtoff; }
             if ((flag == BF_OK) != ok) { mismatch = 1; break; }
         }
@@ -530,9 +548,9 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
     kb_fill_writeback(f, l1);
     kw::sync();
     if (l1_in_lds) for (int i = lane; i < C * NB; i += 64) { uint64_t ky; int nd; l1.get(i / NB, i % NB, ky, nd); c.sum1_key[i] = ky; c.sum1_node[i] = nd; }
-    const uint64_t dead = kw::ballot(lane < C && f.topk == 0);
+    const uint64_t dead = kw::ballot(lane < C && f.topk == 0 && (!sharded || b.floors[lane < C ? lane : 0].key == 0));  // sharded: out of candidates is not out of nodes
     if (lane == 0) {
-        FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V;
+        FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V; s.floor_stop = floor_stop; s.pad = 0;
         s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
         s.cycles_total = kw::clock() - tstart; s.cycles_load = f.cy[0]; s.cycles_update = f.cy[1]; s.cycles_rescan = f.cy[2] + f.cy[3];
         s.block_loads = f.n_loads; s.rescans1 = f.n_r1; s.rescans2 = f.n_r2; s.rescans3 = f.n_r3;
@@ -544,15 +562,140 @@ KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {
     const int lane = kw::lane();
     FillState f; f.bcur = -1; f.sbcur = -1; f.c1k = f.c2k = 0; f.c1n = f.c2n = 0; f.c1_dirty = f.c2_dirty = false; f.n_loads = f.n_r1 = f.n_r2 = f.n_r3 = 0; f.pend_n = -1; f.pend_cls = 0; f.pend_key = 0; f.topk = 0; f.topn = KB_INF; for (int i = 0; i < 4; i++) f.cy[i] = 0;
     f.plugins = c.plugins; f.R = c.R; f.C = c.C; f.NB = c.NB; f.NSB = c.NSB;
+    if (rp.mode == 2 || (rp.mode == 1 && c.bt.world > 1)) { f.NB = (c.bt.vstate[0] + KAI_BLOCK - 1) / KAI_BLOCK; f.NSB = (f.NB + 63) / 64; if (f.NSB < 1) f.NSB = 1; }  // the virtual cluster of a node-sharded group
     for (int r = 0; r < 4; r++) f.creq[r] = 0; f.cflags = 0;
     if (lane < c.C) { const ClassRec cr = c.cls[lane]; for (int r = 0; r < 4; r++) f.creq[r] = cr.req[r]; f.cflags = class_flags(cr); }
     f.rec = make_node_rec(c, c.N);  // an empty record until the first block is loaded
     unsigned char* dyn = kw::dyn_lds();
     f.l2 = (KW_LDS_PTR(IdxE))(dyn);
-    const size_t off = (size_t)c.C * c.NSB * sizeof(IdxE);
+    const size_t off = (size_t)c.C * f.NSB * sizeof(IdxE);
     const bool spec = (c.plugins & KB_KEY_PLUGINS) == KB_KEY_PLUGINS && c.R == 4;  // the default plugin tier: the class key folds to its shortest form
-    if (l1_in_lds) { L1Lds l1; l1.e = (KW_LDS_PTR(IdxE))(dyn + off); l1.NB = c.NB; if (spec) kb_fill_run<true>(c, rp, L, f, l1, true); else kb_fill_run<false>(c, rp, L, f, l1, true); }
-    else { L1Hbm l1; l1.key = c.sum1_key; l1.node = c.sum1_node; l1.NB = c.NB; if (spec) kb_fill_run<true>(c, rp, L, f, l1, false); else kb_fill_run<false>(c, rp, L, f, l1, false); }
+    if (l1_in_lds) { L1Lds l1; l1.e = (KW_LDS_PTR(IdxE))(dyn + off); l1.NB = f.NB; if (spec) kb_fill_run<true>(c, rp, L, f, l1, true); else kb_fill_run<false>(c, rp, L, f, l1, true); }
+    else { L1Hbm l1; l1.key = c.sum1_key; l1.node = c.sum1_node; l1.NB = f.NB; if (spec) kb_fill_run<true>(c, rp, L, f, l1, false); else kb_fill_run<false>(c, rp, L, f, l1, false); }
+}
+
+// ------------------------------------------------------------------------------------------------------ node-axis sharding
+// Class index of a record array, block level only: one wavefront per 64-record block, every class (k_index_build on node records).
+KW_BODY void kb_index_from_recs(const KaiCtx& c, KAI_GP(const NodeRec) recs, int n_recs, KAI_GP(uint64_t) l1k, KAI_GP(int32_t) l1n, int nb, int blk0, int blk1) {
+    const int blk = blk0 + kw::bid() * (kw::bdim() >> 6) + (kw::tid() >> 6), lane = kw::lane();
+    if (n_recs < 0) { n_recs = c.bt.vstate[0]; nb = (n_recs + KAI_BLOCK - 1) / KAI_BLOCK; blk1 = nb; }  // the virtual cluster: its size is on the device
+    if (blk >= blk1) return;
+    const int n = blk * KAI_BLOCK + lane;
+    NodeRec rec = make_node_rec(c, c.N);
+    if (n < n_recs) rec = recs[n];
+    for (int k = 0; k < c.C; k++) {
+        const ClassRec cr = c.cls[k]; double rq[4]; for (int r = 0; r < 4; r++) rq[r] = cr.req[r];
+        uint64_t key = n < n_recs ? class_key_rec(c.plugins, c.R, rq, class_flags(cr), k, rec) : 0; int bn = n;
+        kw::wave_argmax_first(key, bn);
+        if (lane == 0) { l1k[(size_t)k * nb + blk] = key; l1n[(size_t)k * nb + blk] = bn; }
+    }
+}
+// records of the nodes this rank does not own are dead (no class fits): its index and its offers then cover exactly its own slice
+KW_BODY void kb_shard_mask_nrec(const KaiCtx& c) {
+    const int n = kw::bid() * kw::bdim() + kw::tid();
+    if (n >= c.NB * KAI_BLOCK) return;
+    if (n < c.bt.n_lo || n >= c.bt.n_hi) c.bt.nrec[n].okmask = 0;
+}
+// class keys of the own nodes
+KW_BODY void kb_shard_keys(const KaiCtx& c) {
+    const BatchCtx& b = c.bt;
+    const int i = kw::bid() * kw::bdim() + kw::tid(), nloc = b.n_hi - b.n_lo;
+    if (i < (c.N + 31) / 32) b.cand_bits[i] = 0;
+    if (i >= nloc * c.C) return;
+    const int k = i / nloc, n = b.n_lo + i % nloc;
+    const ClassRec cr = c.cls[k]; double rq[4]; for (int r = 0; r < 4; r++) rq[r] = cr.req[r];
+    const NodeRec rec = b.nrec[n];
+    b.sh_keys[(size_t)k * c.N + n] = class_key_rec(c.plugins, c.R, rq, class_flags(cr), k, rec);
+}
+// One workgroup per scan class: the K best own nodes in (key desc, node asc) order are marked as offered, the K+1st is the class's floor.
+// Every thread owns the nodes n_lo + tid, + T, …; a round takes the workgroup's best of the threads' current bests, the thread it came from
+// moves on to its next best (its nodes worse than the one just taken).
+KW_BODY void kb_shard_select(const KaiCtx& c) {
+    const BatchCtx& b = c.bt;
+    const int k = kw::bid(), T = kw::bdim(), t = kw::tid(), lane = kw::lane(), wave = t >> 6, nw = (T + 63) >> 6;
+    KW_SHARED uint64_t s_key[16]; KW_SHARED int s_node[16]; KW_SHARED uint64_t s_wk; KW_SHARED int s_wn;
+    KAI_GP(const uint64_t) keys = b.sh_keys + (size_t)k * c.N;
+    uint64_t myk = 0; int myn = KB_INF;
+    for (int n = b.n_lo + t; n < b.n_hi; n += T) { const uint64_t ky = keys[n]; if (key_better(ky, n, myk, myn)) { myk = ky; myn = n; } }
+    ShardHdr* hdr = (ShardHdr*)(unsigned char*)b.send;
+    for (int round = 0; round <= b.shard_k; round++) {
+        // best of the wave by (key desc, NODE asc): lanes do not hold ascending nodes here (a thread's current best may be its second node)
+        uint64_t wk = kw::wave_max_u64(myk);
+        const uint64_t inv = kw::wave_max_u64((myk == wk && wk != 0) ? (uint64_t)(0x7fffffff - myn) + 1 : 0);
+        int wn = inv ? 0x7fffffff - (int)(inv - 1) : KB_INF;
+        if (lane == 0) { s_key[wave] = wk; s_node[wave] = wn; }
+        kw::sync();
+        if (t == 0) { uint64_t bk = 0; int bn = KB_INF; for (int w = 0; w < nw; w++) if (key_better(s_key[w], s_node[w], bk, bn)) { bk = s_key[w]; bn = s_node[w]; } s_wk = bk; s_wn = bn; }
+        kw::sync();
+        const uint64_t bk = s_wk; const int bn = s_wn;
+        if (round == b.shard_k || bk == 0) { if (t == 0) { hdr->floor[k].key = bk; hdr->floor[k].node = bk ? bn : KB_INF; hdr->floor[k].pad = 0; } break; }
+        if (t == 0) { uint32_t* w = (uint32_t*)&b.cand_bits[bn >> 5]; kw::atomic_or32(w, 1u << (bn & 31)); }
+        if (myn == bn) {  // mine was taken: my next best is my best node that sorts after it
+            myk = 0; myn = KB_INF;
+            for (int n = b.n_lo + t; n < b.n_hi; n += T) { const uint64_t ky = keys[n]; if (!key_better(bk, bn, ky, n)) continue; if (key_better(ky, n, myk, myn)) { myk = ky; myn = n; } }
+        }
+        kw::sync();
+    }
+}
+// the offered nodes in ascending node order with their records (one workgroup: prefix sums over the bitmap words of the own range)
+KW_BODY void kb_shard_compact(const KaiCtx& c) {
+    const BatchCtx& b = c.bt;
+    const int T = kw::bdim(), t = kw::tid(), lane = kw::lane(), wave = t >> 6, nw = (T + 63) >> 6;
+    KW_SHARED int s_part[16]; KW_SHARED int s_carry;
+    ShardHdr* hdr = (ShardHdr*)(unsigned char*)b.send;
+    int32_t* out_node = (int32_t*)((unsigned char*)b.send + sizeof(ShardHdr));
+    NodeRec* out_rec = (NodeRec*)((unsigned char*)b.send + sizeof(ShardHdr) + (size_t)b.shard_mmax * 4);
+    if (t == 0) s_carry = 0;
+    kw::sync();
+    const int w0 = b.n_lo >> 5, w1 = (b.n_hi + 31) >> 5;
+    for (int base = w0; base < w1; base += T) {
+        const int wi = base + t; const uint32_t word = wi < w1 ? b.cand_bits[wi] : 0u; const int cnt = __builtin_popcount(word);
+        const int incl = kw::wave_scan_add(cnt);
+        if (lane == 63) s_part[wave] = incl;
+        kw::sync();
+        int off = s_carry; for (int w = 0; w < wave; w++) off += s_part[w];
+        off += incl - cnt;
+        uint32_t m = word;
+        while (m) { const int bit = __builtin_ctz(m); m &= m - 1; const int n = wi * 32 + bit; if (off < b.shard_mmax) { out_node[off] = n; out_rec[off] = b.nrec[n]; } off++; }
+        kw::sync();
+        if (t == T - 1) { int tot = 0; for (int w = 0; w < nw; w++) tot += s_part[w]; s_carry += tot; }
+        kw::sync();
+    }
+    if (t == 0) { hdr->count = s_carry < b.shard_mmax ? s_carry : b.shard_mmax; hdr->pad = 0; }
+    for (int k = c.C + t; k < 64; k += T) { hdr->floor[k].key = 0; hdr->floor[k].node = KB_INF; hdr->floor[k].pad = 0; }
+}
+// after the all-gather: the virtual cluster = the ranks' offers one after the other (rank ranges ascend, offers ascend: global node order),
+// padded with dead records to a multiple of 64, and the best floor per class.  One workgroup per rank message + one for the floors.
+KW_BODY void kb_shard_vbuild(const KaiCtx& c) {
+    const BatchCtx& b = c.bt;
+    const int r = kw::bid(), T = kw::bdim(), t = kw::tid();
+    int base = 0, total = 0;
+    for (int q = 0; q < b.world; q++) { const ShardHdr* h = (const ShardHdr*)((const unsigned char*)b.recv + (size_t)q * b.msg_bytes); if (q < r) base += h->count; total += h->count; }
+    if (r < b.world) {
+        const unsigned char* msg = (const unsigned char*)b.recv + (size_t)r * b.msg_bytes;
+        const ShardHdr* h = (const ShardHdr*)msg; const int32_t* nodes = (const int32_t*)(msg + sizeof(ShardHdr)); const NodeRec* recs = (const NodeRec*)(msg + sizeof(ShardHdr) + (size_t)b.shard_mmax * 4);
+        for (int i = t; i < h->count; i += T) { b.vrec[base + i] = recs[i]; b.vmap[base + i] = nodes[i]; }
+    } else {  // floors + padding
+        for (int k = t; k < c.C; k += T) {
+            uint64_t fk = 0; int fn = KB_INF;
+            for (int q = 0; q < b.world; q++) { const ShardHdr* h = (const ShardHdr*)((const unsigned char*)b.recv + (size_t)q * b.msg_bytes); if (key_better(h->floor[k].key, h->floor[k].node, fk, fn)) { fk = h->floor[k].key; fn = h->floor[k].node; } }
+            b.floors[k].key = fk; b.floors[k].node = fn; b.floors[k].pad = 0;
+        }
+        const int padded = (total + KAI_BLOCK - 1) / KAI_BLOCK * KAI_BLOCK;
+        for (int i = total + t; i < padded; i += T) { b.vrec[i] = make_node_rec(c, c.N); b.vmap[i] = KB_INF; }
+        if (t == 0) b.vstate[0] = total;
+#if !defined(__HIPCC__)
+        if (t == 0 && std::getenv("KAI_SHARD_TRACE")) { std::fprintf(stderr, "[shard r%d] total %d nodes:", b.rank, total); for (int i = 0; i < total && i < 12; i++) std::fprintf(stderr, " %d(gpu %.0f)", b.vmap[i], b.vrec[i].idle[2]); std::fprintf(stderr, " floor0 %llx/%d\n", (unsigned long long)b.floors[0].key, b.floors[0].node); }
+#endif
+    }
+}
+// what the virtual fill left on the nodes this rank owns goes back into its own records
+KW_BODY void kb_shard_scatter(const KaiCtx& c, int total) {
+    const BatchCtx& b = c.bt;
+    const int i = kw::bid() * kw::bdim() + kw::tid();
+    if (i >= total || i >= b.vstate[0]) return;  // the virtual cluster's size is on the device
+    const int n = b.vmap[i];
+    if (n >= b.n_lo && n < b.n_hi) b.nrec_home[n] = b.vrec[i];
 }
 
 // ------------------------------------------------------------------------------------------------------ apply
@@ -613,6 +756,13 @@ __global__ void k_plan_emit(KaiCtx c) { kb_plan_emit(c); }
 __global__ void __launch_bounds__(64) k_fill(KaiCtx c, RoundParams rp, int l1_in_lds) { kb_fill(c, rp, l1_in_lds); }
 __global__ void k_apply_jobs(KaiCtx c, long long ops_base, long long stmt_base) { kb_apply_jobs(c, (int64_t)ops_base, (int64_t)stmt_base); }
 __global__ void k_apply_nodes(KaiCtx c) { kb_apply_nodes(c); }
+__global__ void k_index_from_recs(KaiCtx c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { kb_index_from_recs(c, (KAI_GP(const NodeRec))recs, n_recs, (KAI_GP(uint64_t))l1k, (KAI_GP(int32_t))l1n, nb, blk0, blk1); }
+__global__ void k_shard_mask_nrec(KaiCtx c) { kb_shard_mask_nrec(c); }
+__global__ void k_shard_keys(KaiCtx c) { kb_shard_keys(c); }
+__global__ void k_shard_select(KaiCtx c) { kb_shard_select(c); }
+__global__ void k_shard_compact(KaiCtx c) { kb_shard_compact(c); }
+__global__ void k_shard_vbuild(KaiCtx c) { kb_shard_vbuild(c); }
+__global__ void k_shard_scatter(KaiCtx c, int total) { kb_shard_scatter(c, total); }
 #endif
 
 }  // namespace kai

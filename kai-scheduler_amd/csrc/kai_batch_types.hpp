@@ -12,6 +12,7 @@ struct FillStatus {  // written by the fill kernel, read by the host between rou
     int32_t mismatch;      // 1 = job n_done-1 ended differently from its prediction
     int32_t all_dead;      // no class has a fitting node at the committed state
     int32_t planned;       // length of the planned order of this round
+    int32_t floor_stop, pad;  // node-sharded fill: stopped because a class's best candidate no longer beats what the ranks hold back
     int64_t decisions, attempted, committed, rollbacks, ops;  // of this round (committed = Statements of the round: every committed job has operations)
     uint64_t dead_mask;    // classes without a fitting node at the committed state
     int64_t cycles_total, cycles_load, cycles_update, cycles_rescan;  // fill-wave clocks (profiling)
@@ -61,8 +62,24 @@ struct BatchCtx {
     KAI_GP(NodeRec) nrec;        // [NB*64]
     KAI_GP(FillStatus) fs;       // [1]
     KAI_GP(uint64_t) dead_mask;  // [1]
+    // node-axis sharding over the GPUs of one node: this rank owns the nodes [n_lo, n_hi); everything else is replicated.
+    // Per exchange every rank offers, per scan class, its K best nodes (records) and the key it holds back (its K+1st: the floor); the
+    // all-gathered offers form a small VIRTUAL cluster on which every rank runs the same fill until a class's best candidate no longer
+    // beats the best floor — only then can a node nobody offered matter, and the ranks exchange again.
+    int32_t world, rank, n_lo, n_hi, shard_k, shard_mmax, vcap, pad_s;
+    int64_t msg_bytes;
+    KAI_GP(uint64_t) sh_keys;    // [C][N] class keys of the own nodes (selection scratch)
+    KAI_GP(uint32_t) cand_bits;  // [ceil(N/32)] union of the offered nodes
+    KAI_GP(unsigned char) send, recv;  // exchange buffers: ShardHdr, node ids [mmax], records [mmax]; recv = world messages
+    KAI_GP(NodeRec) vrec; KAI_GP(int32_t) vmap;  // [vcap] virtual cluster: records and global node ids, ascending
+    KAI_GP(uint64_t) v1k; KAI_GP(int32_t) v1n;   // [C][vcap/64] block level of the virtual cluster's class index
+    KAI_GP(IdxE) floors;         // [C] best held-back (key, node) over the ranks
+    KAI_GP(int32_t) vstate;      // [4] nodes of the virtual cluster (written by k_shard_vbuild, read by the kernels that follow: no host round trip)
+    KAI_GP(NodeRec) nrec_home;   // the rank's own records (nrec points at vrec while the virtual fill runs)
 };
+struct ShardHdr { int32_t count, pad; IdxE floor[64]; };
 
-struct RoundParams { int32_t h_leaf, height, mode, n_slots; };  // mode 1 (fill): build the index levels and the dead-class mask only
+struct RoundParams { int32_t h_leaf, height, mode, n_slots, start, ops0, stmt0, pad2; };  // mode (fill): 0 = run the planned order from job `start`, 1 = index levels and
+                                                                                        // dead-class mask only, 2 = like 0 on the virtual cluster of a node-sharded group (stops at a floor)
 
 }  // namespace kai

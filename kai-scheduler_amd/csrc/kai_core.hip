@@ -44,6 +44,7 @@ struct kai_core {
     std::vector<int32_t> perm;  // engine node index (= name rank) → caller's node index
     kai_action_stats stats{};
     HostPrep::BatchShape shape;  // batch path of the allocate action (kai_batch.hpp)
+    int world = 1, rank = 0, shard_k = 0; kai_allgather_fn ag_fn = nullptr; void* ag_user = nullptr;  // node-axis sharding over the GPUs of one node (kai_shard_attach)
     bool shared = false; int32_t* d_group0 = nullptr; int32_t next_group0 = 0; int32_t *d_np_off = nullptr, *d_np_pods = nullptr;  // shared GPUs: initial groups, each node's active pods in UID order
     hipEvent_t bev[4] = {nullptr, nullptr, nullptr, nullptr};
     double batch_plan_ms = 0, batch_fill_ms = 0, batch_apply_ms = 0;
@@ -165,22 +166,36 @@ struct DevLauncher {
     void plan_emit(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_plan_emit, dim3(g), dim3(b), 0, core->stream, c); }
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) {
         if (!fill_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_attr_set = true; }
-        if (rp.mode == 0) (void)hipEventRecord(core->bev[1], core->stream);
+        if (rp.mode == 0 || (rp.mode == 2 && rp.start == 0)) (void)hipEventRecord(core->bev[1], core->stream);  // a sharded round: from its first virtual fill …
         hipLaunchKernelGGL(k_fill, dim3(g), dim3(b), dyn, core->stream, c, rp, l1);
-        if (rp.mode == 0) (void)hipEventRecord(core->bev[2], core->stream);
+        if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);                                       // … to its last (exchanges included)
     }
     void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { hipLaunchKernelGGL(k_apply_jobs, dim3(g), dim3(b), 0, core->stream, c, (long long)ops_base, (long long)stmt_base); }
     void apply_nodes(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_apply_nodes, dim3(g), dim3(b), 0, core->stream, c); (void)hipEventRecord(core->bev[3], core->stream); timed = true; }
     bool timed = false;
+    void index_from_recs(int g, int b, const KaiCtx& c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { hipLaunchKernelGGL(k_index_from_recs, dim3(g), dim3(b), 0, core->stream, c, recs, n_recs, l1k, l1n, nb, blk0, blk1); }
+    void shard_mask_nrec(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_shard_mask_nrec, dim3(g), dim3(b), 0, core->stream, c); }
+    void shard_keys(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_shard_keys, dim3(g), dim3(b), 0, core->stream, c); }
+    void shard_select(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_shard_select, dim3(g), dim3(b), 0, core->stream, c); }
+    void shard_compact(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_shard_compact, dim3(g), dim3(b), 0, core->stream, c); }
+    void shard_vbuild(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_shard_vbuild, dim3(g), dim3(b), 0, core->stream, c); }
+    void shard_scatter(int g, int b, const KaiCtx& c, int total) { hipLaunchKernelGGL(k_shard_scatter, dim3(g), dim3(b), 0, core->stream, c, total); }
+    // the group's all-gather is the caller's (torch.distributed over RCCL / xGMI in the Python mirror): the library hands over its device buffers
+    int allgather(const void* send, void* recv, int64_t bytes) {
+        if (!core->ag_fn) { core->err = "node-sharded group without kai_shard_attach"; return KAI_ERR_COMM; }
+        if (hipStreamSynchronize(core->stream) != hipSuccess) return KAI_ERR_HIP;
+        if (core->ag_fn(core->ag_user, send, recv, bytes) != 0) { core->err = "the caller's all-gather failed"; return KAI_ERR_COMM; }
+        return KAI_OK;
+    }
     int read(void* dst, const void* src, size_t n) {
-        hipError_t e1 = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, core->stream), e2 = hipStreamSynchronize(core->stream), e3 = hipGetLastError();
+        hipError_t e1 = n ? hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, core->stream) : hipSuccess, e2 = hipStreamSynchronize(core->stream), e3 = hipGetLastError();
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { core->err = std::string("batch path: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3); return KAI_ERR_HIP; }
         if (rc) return rc;
         if (timed) {  // the round's phases, from the events recorded around them
             float a = 0, f = 0, p = 0;
             if (hipEventElapsedTime(&p, core->bev[0], core->bev[1]) == hipSuccess && hipEventElapsedTime(&f, core->bev[1], core->bev[2]) == hipSuccess && hipEventElapsedTime(&a, core->bev[2], core->bev[3]) == hipSuccess) {
                 core->batch_plan_ms += p; core->batch_fill_ms += f; core->batch_apply_ms += a;
-            }
+            } else (void)hipGetLastError();  // an event that was not recorded this round: not an error of the path
             timed = false;
         }
         return KAI_OK;
@@ -199,11 +214,10 @@ int kai_core_create(const kai_config* cfg, int n_gpus, const int* gpu_ids, kai_c
     if (!cfg || !out || cfg->abi_version != KAI_ABI_VERSION || n_gpus < 1) return KAI_ERR_INVALID_ARG;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return KAI_ERR_NO_DEVICE;
-    if (n_gpus != 1) return KAI_ERR_UNSUPPORTED;  // one handle = one scheduling shard on one GPU: see DESIGN.md "Multi-GPU"
     int dev = gpu_ids ? gpu_ids[0] : 0;
     if (dev < 0 || dev >= count) return KAI_ERR_INVALID_ARG;
     kai_core* core = new kai_core();
-    core->cfg = *cfg; core->device = dev;
+    core->cfg = *cfg; core->device = dev; core->world = n_gpus;  // n_gpus > 1: this handle is ONE rank of a node-sharded group (kai_shard_attach names the rank)
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&core->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&core->ev0) != hipSuccess || hipEventCreate(&core->ev1) != hipSuccess || hipEventCreate(&core->bev[0]) != hipSuccess ||
         hipEventCreate(&core->bev[1]) != hipSuccess || hipEventCreate(&core->bev[2]) != hipSuccess || hipEventCreate(&core->bev[3]) != hipSuccess) {
@@ -394,7 +408,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     core->shape = prep.shape;
     {   int rcb = batch_bind(c, prep,
             [&](size_t bytes) -> void* { char* p = nullptr; if (dalloc(core, &p, bytes)) return nullptr; if (hipMemsetAsync(p, 0, bytes, core->stream) != hipSuccess) return nullptr; return p; },
-            [&](void* d, const void* h, size_t n) -> int { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, core->stream) == hipSuccess ? 0 : (int)KAI_ERR_HIP; });
+            [&](void* d, const void* h, size_t n) -> int { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, core->stream) == hipSuccess ? 0 : (int)KAI_ERR_HIP; },
+            core->world, core->rank, core->shard_k);
         if (rcb) return fail(core, rcb, "batch path buffers");
         if (shared) c.bt.enabled = 0; }
     // keep the initial dynamic state in HBM so that kai_session_reset needs no host traffic
@@ -504,6 +519,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
             HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.st), &sb, sizeof(sb), hipMemcpyHostToDevice, core->stream));
         }
     }
+    if (!bs.ran && core->world > 1) return fail(core, KAI_ERR_UNSUPPORTED, "a node-sharded group runs the allocate action on the batch path only (this action or snapshot does not qualify)");
     if (!bs.ran) {  // dynamic LDS: upper levels of the class index, plus the job-order tree when it fits beside them (160 KiB per CU)
         size_t idx_b = lds_index_bytes(c.C, c.NSB), tree_b = lds_tree_bytes(c.Q);
         const size_t budget = 160 * 1024 - 16384;  // static LDS of the kernel (mailbox, context, engine scalars, frame: 6.8 KB, llvm-readelf .group_segment_fixed_size) + margin
@@ -534,7 +550,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         core->stats.reserved[4] = bs.rounds; core->stats.reserved[5] = bs.fill_cycles; core->stats.reserved[6] = bs.mismatches;
         auto us = [](double ms) { int64_t v = (int64_t)(ms * 1000.0); return v < 0 ? (int64_t)0 : v > 0x1fffff ? (int64_t)0x1fffff : v; };
         core->stats.reserved[7] = (us(core->batch_plan_ms) << 42) | (us(core->batch_fill_ms) << 21) | us(core->batch_apply_ms);
-        core->stats.reserved[1] = bs.block_loads;
+        core->stats.reserved[1] = bs.block_loads; core->stats.reserved[0] = core->world > 1 ? bs.exchanges : core->stats.reserved[0];
         if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai batch: rounds %lld mismatches %lld planned %lld max_h %d | fill cycles %lld load %lld update %lld rescan %lld | block loads %lld rescans %lld %lld %lld | plan %.3f ms fill %.3f ms apply %.3f ms\n",
             (long long)bs.rounds, (long long)bs.mismatches, (long long)bs.planned, bs.max_h, (long long)bs.fill_cycles, (long long)bs.fill_load, (long long)bs.fill_update, (long long)bs.fill_rescan,
             (long long)bs.block_loads, (long long)bs.rescans1, (long long)bs.rescans2, (long long)bs.rescans3, core->batch_plan_ms, core->batch_fill_ms, core->batch_apply_ms);
@@ -608,6 +624,13 @@ int kai_node_states(kai_core* core, kai_node_state* out, int cap) {
         std::memset(&o, 0, sizeof(kai_node_state));
         for (int r = 0; r < R; r++) { o.idle[r] = idle[(size_t)r * N + i]; o.releasing[r] = rel[(size_t)r * N + i]; o.used[r] = used[(size_t)r * N + i]; }
     }
+    return KAI_OK;
+}
+
+int kai_shard_attach(kai_core* core, int rank, int world, int offers_per_class, kai_allgather_fn fn, void* user) {
+    if (!core || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return KAI_ERR_INVALID_ARG;
+    if (core->open) return fail(core, KAI_ERR_STATE, "kai_shard_attach: before kai_session_open");
+    core->world = world; core->rank = rank; core->shard_k = offers_per_class; core->ag_fn = fn; core->ag_user = user;
     return KAI_OK;
 }
 

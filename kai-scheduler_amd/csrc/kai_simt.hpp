@@ -43,6 +43,7 @@ KW_DEV int atomic_max(int32_t* p, int v) { return atomicMax(p, v); }
 KW_DEV unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 KW_DEV unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
 KW_DEV double atomic_add(double* p, double v) { return atomicAdd(p, v); }
+KW_DEV uint32_t atomic_or32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 KW_DEV int64_t clock() { return (int64_t)clock64(); }
 KW_DEV unsigned char* dyn_lds() { extern __shared__ __align__(16) unsigned char kw_dyn_lds_[]; return kw_dyn_lds_; }
 KW_DEV void fence() { __threadfence(); }
@@ -186,6 +187,7 @@ inline int atomic_max(int32_t* p, int v) { int o = *p; if (v > o) *p = v; return
 inline unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline unsigned long long atomic_or(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
 inline double atomic_add(double* p, double v) { double o = *p; *p = o + v; return o; }
+inline uint32_t atomic_or32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 inline int64_t clock() { return 0; }
 inline unsigned char* dyn_lds() { Emu& e = emu(); return reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(e.lds.data()) + 15) & ~uintptr_t(15)); }
 inline void fence() {}

@@ -111,7 +111,16 @@ struct HostLauncher {
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) { kw::launch(g, b, dyn, [&] { kb_fill(c, rp, l1); }); }
     void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { kw::launch(g, b, 0, [&] { kb_apply_jobs(c, ops_base, stmt_base); }); }
     void apply_nodes(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_apply_nodes(c); }); }
-    int read(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); return 0; }
+    void index_from_recs(int g, int b, const KaiCtx& c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { kw::launch(g, b, 0, [&] { kb_index_from_recs(c, recs, n_recs, l1k, l1n, nb, blk0, blk1); }); }
+    void shard_mask_nrec(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_shard_mask_nrec(c); }); }
+    void shard_keys(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_shard_keys(c); }); }
+    void shard_select(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_shard_select(c); }); }
+    void shard_compact(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_shard_compact(c); }); }
+    void shard_vbuild(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_shard_vbuild(c); }); }
+    void shard_scatter(int g, int b, const KaiCtx& c, int total) { kw::launch(g, b, 0, [&] { kb_shard_scatter(c, total); }); }
+    int (*ag_fn)(void*, const void*, void*, int64_t) = nullptr; void* ag_user = nullptr;
+    int allgather(const void* send, void* recv, int64_t bytes) { return ag_fn ? ag_fn(ag_user, send, recv, bytes) : (int)KAI_ERR_COMM; }  // the test's gloo all-gather
+    int read(void* dst, const void* src, size_t n) { if (n) std::memcpy(dst, src, n); return 0; }
     int write(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); return 0; }
 };
 
@@ -127,6 +136,10 @@ template <class T> const T* copy(std::vector<std::vector<char>>& pool, const T* 
 
 }  // namespace
 
+// node-sharded run (tests/test_dist_gloo.py): rank / world / offers per class and the all-gather of the test's process group, for the next run
+static int g_sh_rank = 0, g_sh_world = 1, g_sh_k = 0; static int (*g_sh_fn)(void*, const void*, void*, int64_t) = nullptr; static void* g_sh_user = nullptr; static int64_t g_sh_exchanges = 0;
+extern "C" void kai_hostsim_set_shard(int rank, int world, int k, int (*fn)(void*, const void*, void*, int64_t), void* user) { g_sh_rank = rank; g_sh_world = world; g_sh_k = k; g_sh_fn = fn; g_sh_user = user; }
+extern "C" int64_t kai_hostsim_last_exchanges() { return g_sh_exchanges; }
 static std::vector<int32_t> g_last_groups;  // PodInfo.GPUGroups[0] of the active fraction pods after the last run
 extern "C" int kai_hostsim_last_gpu_groups(int32_t* out, int cap) { int n = (int)g_last_groups.size(); for (int i = 0; i < n && i < cap; i++) out[i] = g_last_groups[i]; return n; }
 extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s, const int* actions, int n_actions,
@@ -305,7 +318,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.now_ns = cfg->now_ns; c.def_preempt_mr = cfg->default_preempt_min_runtime_ns; c.def_reclaim_mr = cfg->default_reclaim_min_runtime_ns; c.reclaim_method = cfg->reclaim_resolve_method;
     c.max_consolidation_preemptees = cfg->max_consolidation_preemptees; c.allow_consolidating_reclaim = cfg->allow_consolidating_reclaim; c.saturation_multiplier = cfg->reclaimer_saturation_multiplier;
     { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; c.sv.xr_group = own<int32_t>(pool, (size_t)c.sv.xr_mask + 1); }
-    if (int rc = batch_bind(c, prep, [&](size_t bytes) { return (void*)own<char>(pool, bytes); }, [&](void* d, const void* h, size_t n) { std::memcpy(d, h, n); return 0; })) return rc;
+    if (int rc = batch_bind(c, prep, [&](size_t bytes) { return (void*)own<char>(pool, bytes); }, [&](void* d, const void* h, size_t n) { std::memcpy(d, h, n); return 0; }, g_sh_world, g_sh_rank, g_sh_k)) return rc;
     if (shared || std::getenv("KAI_HOSTSIM_NO_BATCH")) c.bt.enabled = 0;
     HostBackend be; Engine<HostBackend> eng(c, be);
     int64_t batch_rounds = 0, batch_actions = 0;
@@ -323,12 +336,14 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         if (c.st->non_allocate_commits) c.fast_ok = 0;  // as kai_action_execute does after every action
         if (actions[i] != KAI_ACTION_ALLOCATE) { eng.execute_victim_action(); continue; }
         {   // the batch path when the action qualifies (kai_batch.hpp), else the sequential engine — as kai_action_execute does
-            HostLauncher hl; BatchStats bs;
+            HostLauncher hl; BatchStats bs; hl.ag_fn = g_sh_fn; hl.ag_user = g_sh_user;
             if (int rc = batch_allocate(hl, c, prep.shape, bs, c.st->out_len, c.st->stmts)) return rc;
             if (bs.ran) {
                 c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops; c.st->stmts += bs.committed;
                 c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++;
-            } else eng.execute_allocate();
+                g_sh_exchanges = bs.exchanges;
+            } else if (g_sh_world > 1) return KAI_ERR_UNSUPPORTED;  // a node-sharded group runs the batch path only
+            else eng.execute_allocate();
         }
         if (c.st->drain_pending) {                                         // k_drain
             for (int x = 0; x < J; x++) {

@@ -1,6 +1,9 @@
-"""N > 1 plumbing on CPU: two processes over gloo exercise what bench.py does across GPUs — every rank builds and
-schedules its own shard (different contents, same shape), a barrier brackets the timed region, the elapsed time is the
-max over ranks and the work is summed.  No data-path collective exists (one scheduling shard per GPU)."""
+"""Node-axis sharding over several ranks on CPU: world-size-2 and -3 gloo groups run the REAL exchange protocol of the batch
+path — every rank owns a contiguous name-rank range of the nodes, offers its K best nodes per scan class, the offers are all-gathered
+(torch.distributed, gloo here / RCCL on the GPU box) into a virtual cluster on which every rank runs the same fill until a class runs out of
+offers that beat the held-back floors — with the kernels on the lock-step emulator (tests/host_sim).  The committed operations, pod states,
+node accounting and queue shares of EVERY rank must equal the single-rank run and the oracle bit for bit."""
+import ctypes as C
 import os
 import socket
 import sys
@@ -16,35 +19,75 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _cases():
     sys.path.insert(0, HERE)
     import kai_testlib as T
+    from test_batch_path import regular_snapshot
+    out = []
+    for idx, scale in ((1, 0.1), (2, 0.02), (4, 0.004)):
+        snap, cfg, _ = T.pkg.synth.config(idx, scale)
+        out.append((snap, cfg))
+    for seed in (1, 2, 5, 9, 12):
+        out.append((regular_snapshot(seed), T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=0.5)))
+    return out
+
+
+def _worker(rank, world, port, k_offers, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    import kai_testlib as T
+    from test_engine_hostsim import HostSim
     d = T.pkg.dist
-    r, lr, w = d.init("gloo")
-    assert (r, lr, w) == (rank, rank, world)
-    snap, cfg, _ = T.pkg.synth.config(1, 0.05, seed_offset=d.shard_seed(0, rank))
-    d.barrier()
-    res = T.Oracle.run(snap, cfg)  # the shard's cycle (CPU oracle here; the HIP path on the GPU box)
-    d.barrier()
-    elapsed = d.max_over_ranks(1.0 + rank)          # rank 1 is "slower"
-    total = d.sum_over_ranks(float(res.stats.decisions))
-    out.put((rank, elapsed, total, int(res.stats.decisions), int(snap.arrays["pod_req"].sum())))
+    d.init("gloo")
+    HostSim.lib()
+    raw = HostSim._raw
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+    def allgather(user, send, recv, nbytes):  # the group's exchange step: the library's buffers, the caller's collective
+        s = torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,)))
+        r = torch.from_numpy(np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,)))
+        dist.all_gather_into_tensor(r, s)
+        return 0
+
+    rows = []
+    for snap, cfg in _cases():
+        raw.kai_hostsim_set_shard(rank, world, k_offers, allgather, None)
+        res = HostSim.run(snap, cfg)
+        rows.append((res.ops, res.stmts, res.pod_status.tolist(), res.pod_node.tolist(), {k: v.tolist() for k, v in res.nodes.items()},
+                     {k: v.tolist() for k, v in res.shares_final.items()}, int(res.stats.reserved[4]), int(raw.kai_hostsim_last_exchanges()),
+                     (int(res.stats.decisions), int(res.stats.jobs_attempted), int(res.stats.jobs_committed), int(res.stats.rollbacks))))
+    raw.kai_hostsim_set_shard(0, 1, 0, None, None)
+    out.put((rank, rows))
     d.finish()
 
 
-def test_two_rank_shards_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world,k_offers", [(2, 0), (2, 16), (3, 16)])
+def test_node_sharded_group_equals_one_rank(world, k_offers):
+    sys.path.insert(0, HERE)
+    import kai_testlib as T
+    from test_engine_hostsim import HostSim
+    port = _free_port()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k_offers, out)) for r in range(world)]
     for p in procs: p.start()
-    rows = sorted(out.get(timeout=120) for _ in range(world))
+    got = dict(out.get(timeout=600) for _ in range(world))
     for p in procs: p.join(timeout=60); assert p.exitcode == 0
-    (r0, e0, t0, d0, c0), (r1, e1, t1, d1, c1) = rows
-    assert e0 == e1 == 2.0                     # max over ranks
-    assert t0 == t1 == float(d0 + d1)          # whole-job work = sum of the shards
-    assert c0 != c1                            # the shards differ
+    for ci, (snap, cfg) in enumerate(_cases()):
+        ref = T.Oracle.run(snap, cfg)
+        one = HostSim.run(snap, cfg)
+        assert one.ops == ref.ops
+        for rank in range(world):
+            ops, stmts, st, nd, nodes, shares, batch, exchanges, stats = got[rank][ci]
+            assert batch == 1, "the sharded group did not take the batch path"
+            assert exchanges >= 1 or len(ref.ops) == 0
+            assert [tuple(o) for o in ops] == ref.ops and stmts == ref.stmts
+            assert st == ref.pod_status.tolist() and nd == ref.pod_node.tolist()
+            for k in ref.nodes: assert nodes[k] == ref.nodes[k].tolist(), k
+            for k in ref.shares_final: assert shares[k] == ref.shares_final[k].tolist(), k
+            assert stats == (ref.stats.decisions, ref.stats.jobs_attempted, ref.stats.jobs_committed, ref.stats.rollbacks)
 
 
 def test_single_process_is_a_noop():

@@ -27,6 +27,8 @@ class HostSim(T.Oracle):
                 subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", so, src])
             raw = C.CDLL(so)
             raw.kai_hostsim_run.restype = C.c_int
+            raw.kai_hostsim_last_exchanges.restype = C.c_int64
+            cls._raw = raw
 
             class L:
                 kai_oracle_run = raw.kai_hostsim_run

@@ -407,3 +407,78 @@ def test_gpu_fraction_fuzz(gpu, seed):
         res = run_gpu(snap, cfg, acts)
         assert_same_tol(res, ref)
         _same_groups(snap, res, ref)
+
+
+# ------------------------------------------------------------------------------------------------ node-axis sharding on the device
+@pytest.mark.parametrize("world,offers", [(2, 0), (3, 16)])
+def test_gpu_node_sharded_group_on_one_device(gpu, world, offers):
+    """The device code of the node-sharded batch path (offers, virtual cluster, virtual fill, scatter-back: SURVEY 8e) with `world` handles — one
+    per rank, each on its own thread — on THIS box's single GPU; the group's all-gather is done by the test with device-to-device copies, where
+    the product uses torch.distributed over RCCL.  (The multi-process form of the same protocol runs over gloo in tests/test_dist_gloo.py.)
+    Every rank must commit exactly the one-rank operations."""
+    import ctypes as C
+    import threading
+    from test_batch_path import regular_snapshot
+    hip = T.pkg.core._hip_runtime()
+    cases = [T.pkg.synth.config(1, 0.3)[:2], T.pkg.synth.config(2, 0.05)[:2], T.pkg.synth.config(4, 0.01)[:2],
+             (regular_snapshot(5), T.abi.default_config(gpu_strategy=T.abi.SPREAD, k_value=0.5))]
+    for snap, cfg in cases:
+        ref = T.Oracle.run(snap, cfg)
+        barrier = threading.Barrier(world)
+        sends, recvs = [None] * world, [None] * world
+        results, errors = [None] * world, []
+
+        def make_allgather(rank):
+            def allgather(send, recv, nbytes):
+                sends[rank], recvs[rank] = send, recv
+                barrier.wait()
+                for q in range(world):  # this rank's message into every rank's receive buffer
+                    assert hip.hipMemcpy(C.c_void_p(recvs[q] + rank * nbytes), C.c_void_p(send), C.c_size_t(nbytes), 3) == 0
+                import torch; torch.cuda.synchronize()
+                barrier.wait()
+                return 0
+            return allgather
+
+        def run(rank):
+            try:
+                with T.pkg.KaiCore(cfg, world=world, rank=rank, offers_per_class=offers, allgather=make_allgather(rank)) as core:
+                    ssn = core.open_session(snap)
+                    ops = [(int(o["kind"]), int(o["pod"]), int(o["node"]), int(o["job"])) for o in ssn.execute("allocate")]
+                    st, nd = ssn.pod_states()
+                    results[rank] = (ops, st, nd, ssn.node_states(), ssn.queue_shares(), ssn.stats())
+                    ssn.close()
+            except Exception as e:  # noqa: BLE001 — reported below; the other threads are released
+                errors.append((rank, repr(e))); barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads: t.start()
+        for t in threads: t.join(timeout=300)
+        assert not errors, errors
+        for rank in range(world):
+            ops, st, nd, nodes, shares, stats = results[rank]
+            assert ops == ref.ops
+            assert (st == ref.pod_status).all() and (nd == ref.pod_node).all()
+            for k in ref.nodes: assert np.array_equal(nodes[k], ref.nodes[k]), k
+            for k in ref.shares_final: assert np.array_equal(shares[k], ref.shares_final[k]), k
+            assert stats.reserved[4] >= 1 and stats.reserved[0] >= 1  # batch rounds, exchanges
+
+
+def test_gpu_default_allgather_plumbing(gpu):
+    """KaiCore's default exchange step — stage into torch tensors, torch.distributed.all_gather_into_tensor (backend nccl = RCCL), stage back — on
+    this box's one GPU with a one-rank group: what a node-sharded group calls between kernels, minus the second GPU."""
+    import torch
+    import torch.distributed as dist
+    os_env = __import__("os").environ
+    os_env.setdefault("MASTER_ADDR", "127.0.0.1"); os_env.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        core = T.pkg.KaiCore(T.abi.default_config())
+        core.world, core._user_allgather, core._stage = 1, None, None
+        a = torch.arange(4096, dtype=torch.uint8, device="cuda"); b = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+        assert core._allgather(None, a.data_ptr(), b.data_ptr(), 4096) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        core.destroy()
+    finally:
+        dist.destroy_process_group()
