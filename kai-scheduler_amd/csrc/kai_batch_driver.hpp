@@ -70,7 +70,7 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
 // LDS of the fill kernel: super-block level always, block level when it fits beside it
 inline size_t batch_fill_lds(const KaiCtx& c, int& l1_in_lds) {
     const size_t l2 = (size_t)c.C * c.NSB * sizeof(IdxE), l1 = (size_t)c.C * c.NB * sizeof(IdxE);
-    const size_t budget = 160 * 1024 - 16 * 1024;  // static LDS of the kernel (class tops, rollback list: 9 KB) + margin
+    const size_t budget = 160 * 1024 - 16 * 1024;  // static LDS of the kernel (rollback list: 8 KB) + margin
     l1_in_lds = (l2 + l1 <= budget && !std::getenv("KAI_BATCH_L1_HBM")) ? 1 : 0;  // the variable forces the HBM variant (tests)
     return l2 + (l1_in_lds ? l1 : 0) + 16;
 }
@@ -131,10 +131,10 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     bs.ran = 1;
     int remaining = qual[2];
     l.nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
+    const bool sharded = c.bt.world > 1;
     int l1_in_lds = 0; const size_t dyn = batch_fill_lds(c, l1_in_lds);
     RoundParams rp{}; rp.mode = 1;
     FillStatus fs{};
-    const bool sharded = c.bt.world > 1;
     if (sharded) { l.shard_mask_nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
                    const int b0 = c.bt.n_lo / KAI_BLOCK, b1 = (c.bt.n_hi + KAI_BLOCK - 1) / KAI_BLOCK; (void)b0; (void)b1;
                    l.index_from_recs(std::max(1, c.NB), 64, c, (const NodeRec*)c.bt.nrec, c.N, (uint64_t*)c.sum1_key, (int32_t*)c.sum1_node, c.NB, 0, c.NB);

@@ -295,6 +295,7 @@ KW_BODY void kb_plan_emit(const KaiCtx& c) {
 struct FillLds {
     int32_t placed_node[KB_PLACED_MAX]; int32_t placed_cls[KB_PLACED_MAX];
 };
+enum { FM_PLAIN = 0, FM_SHARDED = 2 };  // compile-time modes of the fill kernel: the session's own nodes / the virtual cluster of a node-sharded group (floors)
 // block level of the index: 16-byte entries in LDS, or the session's HBM arrays (sum1_key / sum1_node) when C x NB entries do not fit
 KW_BODY void idx_get(KW_LDS_PTR(IdxE) p, int i, uint64_t& key, int& node) { key = p[i].key; node = p[i].node; }  // member-wise: no struct copies across address spaces
 KW_BODY void idx_set(KW_LDS_PTR(IdxE) p, int i, uint64_t key, int node) { p[i].key = key; p[i].node = node; }
@@ -325,7 +326,7 @@ struct FillState {
 };
 template <bool SPEC> KW_BODY uint32_t kb_plugins(const FillState& f) { return SPEC ? KB_KEY_PLUGINS : f.plugins; }
 template <bool SPEC> KW_BODY int kb_nres(const FillState& f) { return SPEC ? 4 : f.R; }
-template <bool SPEC>
+template <int MODE, bool SPEC>
 KW_BODY uint64_t kb_lane_key(const FillState& f, int kk) {  // key of this lane's node for class kk (kk the same in every lane)
     double rq[4]; for (int r = 0; r < 4; r++) rq[r] = kw::bcast(f.creq[r], kk);
     return class_key_rec(kb_plugins<SPEC>(f), kb_nres<SPEC>(f), rq, kw::bcast(f.cflags, kk), kk, f.rec);
@@ -356,7 +357,7 @@ KW_BODY void kb_fill_load_block(const KaiCtx& c, FillState& f, const L1& l1, int
     }
 }
 // node n (in the current block) changed: bring the three index levels up to date for every class
-template <bool SPEC, class L1>
+template <int MODE, bool SPEC, class L1>
 KW_BODY void kb_fill_node_changed(FillState& f, const L1& l1, int n) {
     const int lane = kw::lane(), blk = n >> 6, ln = n & 63, sb = blk >> 6;
     KB_T(t_l1);
@@ -375,7 +376,7 @@ KW_BODY void kb_fill_node_changed(FillState& f, const L1& l1, int n) {
     uint64_t todo = kw::ballot(need);
     while (todo) {
         const int kk = __builtin_ctzll(todo); todo &= todo - 1;
-        uint64_t key = kb_lane_key<SPEC>(f, kk); int bn = blk * KAI_BLOCK + lane;
+        uint64_t key = kb_lane_key<MODE, SPEC>(f, kk); int bn = blk * KAI_BLOCK + lane;
         kw::wave_argmax_first(key, bn);
         if (lane == kk) { n1k = key; n1n = bn; }
         f.n_r1++;
@@ -438,8 +439,8 @@ KW_BODY void kb_fill_update_rec(const KaiCtx& c, FillState& f, int n, int kcls, 
         for (int r = 0; r < 4; r++) c.bt.nrec[n].idle[r] = f.rec.idle[r];
     }
 }
-template <bool SPEC, class L1>
-KW_BODY void kb_fill_flush(FillState& f, const L1& l1) { if (f.pend_n >= 0) { kb_fill_node_changed<SPEC>(f, l1, f.pend_n); f.pend_n = -1; } }
+template <int MODE, bool SPEC, class L1>
+KW_BODY void kb_fill_flush(FillState& f, const L1& l1) { if (f.pend_n >= 0) { kb_fill_node_changed<MODE, SPEC>(f, l1, f.pend_n); f.pend_n = -1; } }
 // One task of scan class kcls: the node it goes to, or -1.  The index is brought up to date LAZILY: while consecutive tasks of one class keep
 // landing on the node that class's top pointed to — its key for the class did not drop below the top key the index holds, so no other node can
 // have overtaken it — only the node's record changes; the index entries of every class follow in one step when another class is asked for,
@@ -450,27 +451,28 @@ KW_BODY bool kb_beats_floor(const KaiCtx& c, int kcls, uint64_t tk, int tn) {
     const uint64_t fk = b.floors[kcls].key; const int fn = b.floors[kcls].node;
     return fk == 0 || key_better(tk, b.vmap[tn], fk, fn);
 }
-template <bool SPEC, class L1>
-KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls, bool sharded) {
+// One task of scan class kcls: the node it goes to, -1 = no node fits, -2 (node-sharded group) = ask the ranks again.  The index is brought up to date
+// LAZILY: while consecutive tasks of one class keep landing on the node that class's top pointed to — its key for the class did not drop below the top key
+// the index holds, so no other node can have overtaken it — only the node's record changes; the index entries of every class follow in one step when
+// another class is asked for, when the node stops being the class's best, or when the round ends.
+template <int MODE, bool SPEC, class L1>
+KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls) {
     if (f.pend_n >= 0) {
         if (kcls == f.pend_cls) {
             const int ln = f.pend_n & 63;
-            const uint64_t mine = kb_lane_key<SPEC>(f, kcls);
+            const uint64_t mine = kb_lane_key<MODE, SPEC>(f, kcls);
             const uint64_t kap = kw::bcast(mine, ln);
-            if (kap != 0 && kap >= f.pend_key && (!sharded || kb_beats_floor(c, kcls, kap, f.pend_n))) { kb_fill_update_rec(c, f, f.pend_n, kcls, 1.0); return f.pend_n; }
+            bool stay = kap != 0 && kap >= f.pend_key;
+            if (MODE == FM_SHARDED) stay = stay && kb_beats_floor(c, kcls, kap, f.pend_n);
+            if (stay) { kb_fill_update_rec(c, f, f.pend_n, kcls, 1.0); return f.pend_n; }
         }
-        kb_fill_flush<SPEC>(f, l1);
+        kb_fill_flush<MODE, SPEC>(f, l1);
     }
     KB_T(t_p);
     const uint64_t tk = kw::bcast(f.topk, kcls); const int tn = kw::bcast(f.topn, kcls);
-    if (sharded) {  // no candidate at all is an answer only when no rank holds anything back for the class
+    if (MODE == FM_SHARDED) {  // no candidate at all is an answer only when no rank holds anything back for the class
         if (tk == 0) return c.bt.floors[kcls].key == 0 ? -1 : -2;
-        if (!kb_beats_floor(c, kcls, tk, tn)) {
-#if !defined(__HIPCC__)
-            if (kw::lane() == 0 && std::getenv("KAI_SHARD_TRACE")) std::fprintf(stderr, "[shard r%d] floor stop: class %d top %llx / node %d (virtual %d) vs floor %llx / %d\n", c.bt.rank, kcls, (unsigned long long)tk, c.bt.vmap[tn], tn, (unsigned long long)c.bt.floors[kcls].key, c.bt.floors[kcls].node);
-#endif
-            return -2;
-        }
+        if (!kb_beats_floor(c, kcls, tk, tn)) return -2;
     }
     if (tk == 0) return -1;
     kb_fill_load_block(c, f, l1, tn >> 6);
@@ -479,12 +481,14 @@ KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls,
     KB_ACC(0, t_p);
     return tn;
 }
-template <bool SPEC, class L1>
+template <int MODE, bool SPEC, class L1>
 KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState& f, const L1& l1, bool l1_in_lds) {
     const BatchCtx& b = c.bt;
     const int lane = kw::lane(), C = f.C, NB = f.NB, NSB = f.NSB;
+    const bool sharded = MODE == FM_SHARDED;
     const int64_t tstart = kw::clock();
-    if (l1_in_lds) for (int i = lane; i < C * NB; i += 64) l1.set(i / NB, i % NB, c.sum1_key[i], c.sum1_node[i]);
+    KAI_GP(uint64_t) home_k = c.sum1_key; KAI_GP(int32_t) home_n = c.sum1_node;  // HBM home of the block level (the virtual cluster's in a node-sharded group)
+    if (l1_in_lds) for (int i = lane; i < C * NB; i += 64) l1.set(i / NB, i % NB, home_k[i], home_n[i]);
     kw::sync();
     f.topk = 0; f.topn = KB_INF;
     for (int k = 0; k < C; k++) {  // upper levels from the block level
@@ -503,7 +507,6 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
     }
     kw::sync();
     const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: index levels and dead classes only (before the first plan)
-    const bool sharded = rp.mode == 2;
     int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0; int n_done = rp.start, mismatch = 0, floor_stop = 0;
     for (int base = rp.start; base < V && !mismatch && !floor_stop; base += 64) {
         const int gi = base + lane;
@@ -521,7 +524,7 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
                     for (int ti = 0; ti < tc; ti++) {
                         const int kcls = ucls >= 0 ? ucls : kw::bcast(my_cls, ti);
                         decisions++;
-                        const int tn = kb_fill_place<SPEC>(c, f, l1, kcls, sharded);
+                        const int tn = kb_fill_place<MODE, SPEC>(c, f, l1, kcls);
                         if (tn == -2) { floor_stop = 1; ok = false; break; }
                         if (tn < 0) { ok = false; break; }
                         if (lane == 0) { L.placed_node[placed] = tn; L.placed_cls[placed] = kcls; b.t_node[first + placed] = sharded ? b.vmap[tn] : tn; }
@@ -529,11 +532,11 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
                     }
                 }
                 if (!ok) {  // Statement.Rollback: the undone operations in reverse order
-                    kb_fill_flush<SPEC>(f, l1);
+                    kb_fill_flush<MODE, SPEC>(f, l1);
                     kw::sync();
                     for (int i = placed - 1; i >= 0; i--) {
                         const int n = L.placed_node[i];
-                        kb_fill_load_block(c, f, l1, n >> 6); kb_fill_update_rec(c, f, n, L.placed_cls[i], -1.0); kb_fill_node_changed<SPEC>(f, l1, n);
+                        kb_fill_load_block(c, f, l1, n >> 6); kb_fill_update_rec(c, f, n, L.placed_cls[i], -1.0); kb_fill_node_changed<MODE, SPEC>(f, l1, n);
                     }
                     if (floor_stop) { decisions = dec0; break; }  // the gang is taken back untouched: the next exchange starts with it
                     rollbacks += 2;
@@ -544,10 +547,10 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
             if ((flag == BF_OK) != ok) { mismatch = 1; break; }
         }
     }
-    kb_fill_flush<SPEC>(f, l1);
+    kb_fill_flush<MODE, SPEC>(f, l1);
     kb_fill_writeback(f, l1);
     kw::sync();
-    if (l1_in_lds) for (int i = lane; i < C * NB; i += 64) { uint64_t ky; int nd; l1.get(i / NB, i % NB, ky, nd); c.sum1_key[i] = ky; c.sum1_node[i] = nd; }
+    if (l1_in_lds) for (int i = lane; i < C * NB; i += 64) { uint64_t ky; int nd; l1.get(i / NB, i % NB, ky, nd); home_k[i] = ky; home_n[i] = nd; }
     const uint64_t dead = kw::ballot(lane < C && f.topk == 0 && (!sharded || b.floors[lane < C ? lane : 0].key == 0));  // sharded: out of candidates is not out of nodes
     if (lane == 0) {
         FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V; s.floor_stop = floor_stop; s.pad = 0;
@@ -557,21 +560,29 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
         b.fs[0] = s; b.dead_mask[0] = dead;
     }
 }
+template <int MODE>
+KW_BODY void kb_fill_mode(const KaiCtx& c, RoundParams rp, int l1_in_lds, FillLds& L, FillState& f, unsigned char* dyn, size_t off) {
+    const bool spec = (c.plugins & KB_KEY_PLUGINS) == KB_KEY_PLUGINS && c.R == 4;  // the default plugin tier: the class key folds to its shortest form
+    if (l1_in_lds) { L1Lds l1; l1.e = (KW_LDS_PTR(IdxE))(dyn + off); l1.NB = f.NB; if (spec) kb_fill_run<MODE, true>(c, rp, L, f, l1, true); else kb_fill_run<MODE, false>(c, rp, L, f, l1, true); }
+    else { L1Hbm l1; l1.key = c.sum1_key; l1.node = c.sum1_node; l1.NB = f.NB;
+           if (spec) kb_fill_run<MODE, true>(c, rp, L, f, l1, false); else kb_fill_run<MODE, false>(c, rp, L, f, l1, false); }
+}
+// dynamic LDS: [super-block level C x NSB][block level C x NB when it fits]
 KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {
     KW_SHARED FillLds L;
     const int lane = kw::lane();
     FillState f; f.bcur = -1; f.sbcur = -1; f.c1k = f.c2k = 0; f.c1n = f.c2n = 0; f.c1_dirty = f.c2_dirty = false; f.n_loads = f.n_r1 = f.n_r2 = f.n_r3 = 0; f.pend_n = -1; f.pend_cls = 0; f.pend_key = 0; f.topk = 0; f.topn = KB_INF; for (int i = 0; i < 4; i++) f.cy[i] = 0;
     f.plugins = c.plugins; f.R = c.R; f.C = c.C; f.NB = c.NB; f.NSB = c.NSB;
-    if (rp.mode == 2 || (rp.mode == 1 && c.bt.world > 1)) { f.NB = (c.bt.vstate[0] + KAI_BLOCK - 1) / KAI_BLOCK; f.NSB = (f.NB + 63) / 64; if (f.NSB < 1) f.NSB = 1; }  // the virtual cluster of a node-sharded group
+    const bool virt = rp.mode == 2 || (rp.mode == 1 && c.bt.world > 1);
+    if (virt) { f.NB = (c.bt.vstate[0] + KAI_BLOCK - 1) / KAI_BLOCK; f.NSB = (f.NB + 63) / 64; if (f.NSB < 1) f.NSB = 1; }  // the virtual cluster of a node-sharded group
     for (int r = 0; r < 4; r++) f.creq[r] = 0; f.cflags = 0;
     if (lane < c.C) { const ClassRec cr = c.cls[lane]; for (int r = 0; r < 4; r++) f.creq[r] = cr.req[r]; f.cflags = class_flags(cr); }
     f.rec = make_node_rec(c, c.N);  // an empty record until the first block is loaded
     unsigned char* dyn = kw::dyn_lds();
     f.l2 = (KW_LDS_PTR(IdxE))(dyn);
     const size_t off = (size_t)c.C * f.NSB * sizeof(IdxE);
-    const bool spec = (c.plugins & KB_KEY_PLUGINS) == KB_KEY_PLUGINS && c.R == 4;  // the default plugin tier: the class key folds to its shortest form
-    if (l1_in_lds) { L1Lds l1; l1.e = (KW_LDS_PTR(IdxE))(dyn + off); l1.NB = f.NB; if (spec) kb_fill_run<true>(c, rp, L, f, l1, true); else kb_fill_run<false>(c, rp, L, f, l1, true); }
-    else { L1Hbm l1; l1.key = c.sum1_key; l1.node = c.sum1_node; l1.NB = f.NB; if (spec) kb_fill_run<true>(c, rp, L, f, l1, false); else kb_fill_run<false>(c, rp, L, f, l1, false); }
+    if (rp.mode == 2) kb_fill_mode<FM_SHARDED>(c, rp, l1_in_lds, L, f, dyn, off);
+    else kb_fill_mode<FM_PLAIN>(c, rp, l1_in_lds, L, f, dyn, off);
 }
 
 // ------------------------------------------------------------------------------------------------------ node-axis sharding

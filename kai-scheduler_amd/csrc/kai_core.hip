@@ -206,7 +206,7 @@ struct DevLauncher {
 
 extern "C" {
 
-const char* kai_version(void) { return "kai_core abi 4 gfx950 (HIP; batch plan/fill/apply path + device-resident sequential engine, class index)"; }
+const char* kai_version(void) { return "kai_core abi 5 gfx950 (HIP; batch plan/fill/apply path, node-axis sharding, device-resident sequential engine, class index)"; }
 
 const char* kai_last_error(kai_core* core) { return core ? core->err.c_str() : "null handle"; }
 

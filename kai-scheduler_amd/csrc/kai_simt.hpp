@@ -47,6 +47,9 @@ KW_DEV uint32_t atomic_or32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 KW_DEV int64_t clock() { return (int64_t)clock64(); }
 KW_DEV unsigned char* dyn_lds() { extern __shared__ __align__(16) unsigned char kw_dyn_lds_[]; return kw_dyn_lds_; }
 KW_DEV void fence() { __threadfence(); }
+// lanes of one wave exchange data through LDS / memory: on the hardware they run in lock-step, so ordering the accesses is enough
+KW_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+KW_DEV void expect_uniform(long long) {}
 KW_DEV void fence_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 }  // namespace kw
 
@@ -91,7 +94,7 @@ kw_switch_ctx:
 #endif
 
 enum FiberState : int { F_RUN = 0, F_WAIT_BLOCK = 1, F_WAIT_WAVE = 2, F_DONE = 3 };
-struct Fiber { void* sp = nullptr; int state = F_DONE; char* stack = nullptr; };
+struct Fiber { void* sp = nullptr; int state = F_DONE; char* stack = nullptr; int line = 0; };  // line: source line of the collective the fiber is parked in (deadlock report)
 struct Emu {
     std::vector<Fiber> fibers; std::vector<char*> stacks;
     void* sched_sp = nullptr;
@@ -148,7 +151,11 @@ inline void launch(int grid, int block, size_t dyn_lds_bytes, const std::functio
                 for (int t = w * 64; t < block && t < w * 64 + 64; t++) { int s = e.fibers[t].state; if (s == F_RUN || s == F_WAIT_BLOCK) all = false; if (s == F_WAIT_WAVE) nw++; }
                 if (all && nw) { for (int t = w * 64; t < block && t < w * 64 + 64; t++) if (e.fibers[t].state == F_WAIT_WAVE) e.fibers[t].state = F_RUN; progress = true; }
             }
-            if (!progress && live > 0) { std::fprintf(stderr, "kw::launch: deadlock (a collective not reached by every live lane)\n"); std::abort(); }
+            if (!progress && live > 0) {
+                std::fprintf(stderr, "kw::launch: deadlock (a collective not reached by every live lane); block %d, lanes parked at source lines:", b);
+                for (int t = 0; t < block && t < 64; t++) std::fprintf(stderr, " %d:%s%d", t, e.fibers[t].state == F_WAIT_BLOCK ? "B" : e.fibers[t].state == F_WAIT_WAVE ? "W" : e.fibers[t].state == F_DONE ? "done" : "run", e.fibers[t].line);
+                std::fprintf(stderr, "\n"); std::abort();
+            }
         }
     }
     e.body = nullptr;
@@ -158,29 +165,29 @@ inline int bid() { return emu().block; }
 inline int bdim() { return emu().bdim; }
 inline int gdim() { return emu().gdim; }
 inline int lane() { return emu().cur & 63; }
-inline void sync() { Emu& e = emu(); e.fibers[e.cur].state = F_WAIT_BLOCK; fiber_yield(); }
-inline void wave_bar() { Emu& e = emu(); e.fibers[e.cur].state = F_WAIT_WAVE; fiber_yield(); }
+inline void sync(int line = __builtin_LINE()) { Emu& e = emu(); e.fibers[e.cur].line = line; e.fibers[e.cur].state = F_WAIT_BLOCK; fiber_yield(); }
+inline void wave_bar(int line = 0) { Emu& e = emu(); if (line) e.fibers[e.cur].line = line; e.fibers[e.cur].state = F_WAIT_WAVE; fiber_yield(); }
 inline uint64_t* wave_slots() { Emu& e = emu(); return e.xchg + (size_t)(e.cur >> 6) * 64; }
 inline bool lane_live(int l) { Emu& e = emu(); int t = (e.cur & ~63) + l; return t < e.bdim && e.fibers[t].state != F_DONE; }
-template <class T> inline T shfl(T v, int src) {
+template <class T> inline T shfl(T v, int src, int line = __builtin_LINE()) {
     static_assert(sizeof(T) <= 8, "shfl: 8 bytes at most");
     uint64_t raw = 0; std::memcpy(&raw, &v, sizeof(T));
-    wave_slots()[lane()] = raw; wave_bar();
+    wave_slots()[lane()] = raw; wave_bar(line);
     uint64_t got = wave_slots()[src & 63]; wave_bar();
     T r; std::memcpy(&r, &got, sizeof(T)); return r;
 }
 template <class T> inline T shfl_up(T v, int d) { int l = lane(); T r = shfl(v, l >= d ? l - d : l); return l >= d ? r : v; }
-inline uint64_t ballot(bool p) {
-    wave_slots()[lane()] = p ? 1 : 0; wave_bar();
+inline uint64_t ballot(bool p, int line = __builtin_LINE()) {
+    wave_slots()[lane()] = p ? 1 : 0; wave_bar(line);
     uint64_t m = 0; for (int l = 0; l < 64; l++) if (lane_live(l) && wave_slots()[l]) m |= 1ull << l;
     wave_bar(); return m;
 }
-inline uint64_t wave_max_u64(uint64_t v) {
-    wave_slots()[lane()] = v; wave_bar();
+inline uint64_t wave_max_u64(uint64_t v, int line = __builtin_LINE()) {
+    wave_slots()[lane()] = v; wave_bar(line);
     uint64_t m = 0; for (int l = 0; l < 64; l++) if (lane_live(l) && wave_slots()[l] > m) m = wave_slots()[l];
     wave_bar(); return m;
 }
-template <class T> inline T bcast(T v, int src) { return shfl(v, src); }
+template <class T> inline T bcast(T v, int src, int line = __builtin_LINE()) { return shfl(v, src, line); }
 inline int atomic_add(int32_t* p, int v) { int o = *p; *p = o + v; return o; }
 inline int atomic_min(int32_t* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 inline int atomic_max(int32_t* p, int v) { int o = *p; if (v > o) *p = v; return o; }
@@ -192,6 +199,9 @@ inline int64_t clock() { return 0; }
 inline unsigned char* dyn_lds() { Emu& e = emu(); return reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(e.lds.data()) + 15) & ~uintptr_t(15)); }
 inline void fence() {}
 inline void fence_wg() {}
+inline void wave_sync(int line = __builtin_LINE()) { wave_bar(line); }
+// debug aid: every lane must hold the same value here (a branch on it is meant to be uniform)
+inline void expect_uniform(long long v, int line = __builtin_LINE()) { const long long v0 = shfl(v, 0, line); if (v != v0) { std::fprintf(stderr, "kw: value not uniform at line %d: lane %d has %lld, lane 0 has %lld\n", line, lane(), v, v0); std::abort(); } }  // the emulator's lanes are fibers: they meet here
 }  // namespace kw
 #endif
 
