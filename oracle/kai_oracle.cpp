@@ -10,7 +10,11 @@
 // from the Go test files) — see tests/test_oracle_golden.py.
 //
 // Go-map iteration orders that leak into results are fixed to index order.
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstddef>
 #include <cstring>
 
@@ -514,13 +518,55 @@ double Session::NodeOrderFn(PodInfo* task, NodeInfo* node) {  // session_plugins
     // topology (plugins/topology/node_scoring.go:17-35) is added by OrderedNodesByTask, where a lookup error drops the node
     return score;
 }
+// Node scoring on several threads: the reference scores every node on its own goroutine (session.go:243-261) and collects the scores under a mutex;
+// kai_oracle_set_threads(n) gives this restatement n workers for the same fan-out (contiguous node ranges, scores into an array, the map built in
+// node order afterwards — the map's content does not depend on who computed a score).  n = 1 (default): the plain loop.
+namespace {
+struct ScorePool {
+    std::vector<std::thread> workers; std::mutex m; std::condition_variable cv_go, cv_done;
+    std::function<void(size_t, size_t)> job; size_t n_items = 0; std::atomic<size_t> next{0}; int gen = 0, running = 0; bool stop = false;
+    static constexpr size_t CHUNK = 512;
+    void work() { for (;;) { size_t b = next.fetch_add(CHUNK); if (b >= n_items) return; job(b, std::min(n_items, b + CHUNK)); } }
+    void loop() {
+        int seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> l(m); cv_go.wait(l, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+            work();
+            { std::lock_guard<std::mutex> l(m); if (--running == 0) cv_done.notify_one(); }
+        }
+    }
+    void resize(int n) {  // n - 1 helpers beside the caller
+        { std::lock_guard<std::mutex> l(m); stop = true; } cv_go.notify_all();
+        for (auto& t : workers) t.join();
+        workers.clear(); stop = false; gen = 0;
+        for (int i = 1; i < n; i++) workers.emplace_back([this] { loop(); });
+    }
+    void run(size_t n, std::function<void(size_t, size_t)> f) {
+        job = std::move(f); n_items = n; next = 0;
+        { std::lock_guard<std::mutex> l(m); running = (int)workers.size(); gen++; } cv_go.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(m); cv_done.wait(l, [&] { return running == 0; });
+    }
+    ~ScorePool() { resize(1); }
+};
+ScorePool g_pool; int g_threads = 1;
+}  // namespace
+int set_score_threads(int n) { int prev = g_threads; if (n < 1) n = 1; if (n != g_threads) { g_pool.resize(n); g_threads = n; } return prev; }
 std::vector<NodeInfo*> Session::OrderedNodesByTask(const std::vector<NodeInfo*>& nodeSet, PodInfo* task) {  // session.go:234-264, 466-485
     NodePreOrderFn(task, nodeSet);
     std::map<double, std::vector<NodeInfo*>, std::greater<double>> nodeScores;
-    for (auto* node : nodeSet) {
+    auto score_of = [&](NodeInfo* node, bool& err) {
         double score = NodeOrderFn(task, node);
-        if (cfg.plugins & KAI_PLUGIN_TOPOLOGY) { bool err = false; double ts = topologyNodeScore(task, node, err); if (err) continue; score += ts; }  // session.go:247-251
-        nodeScores[score].push_back(node);
+        if (cfg.plugins & KAI_PLUGIN_TOPOLOGY) { double ts = topologyNodeScore(task, node, err); if (!err) score += ts; }  // session.go:247-251: an error drops the node
+        return score;
+    };
+    if (g_threads > 1 && nodeSet.size() >= 2048) {
+        (void)podAllocatableRange[task->idx];  // NodeOrderFn reads it through operator[]: no insertion from a worker
+        std::vector<double> sc(nodeSet.size()); std::vector<uint8_t> bad(nodeSet.size(), 0);
+        g_pool.run(nodeSet.size(), [&](size_t b, size_t e) { for (size_t i = b; i < e; i++) { bool err = false; sc[i] = score_of(nodeSet[i], err); bad[i] = err; } });
+        for (size_t i = 0; i < nodeSet.size(); i++) if (!bad[i]) nodeScores[sc[i]].push_back(nodeSet[i]);
+    } else {
+        for (auto* node : nodeSet) { bool err = false; double score = score_of(node, err); if (err) continue; nodeScores[score].push_back(node); }
     }
     std::vector<NodeInfo*> ordered; ordered.reserve(nodeSet.size());
     for (auto& kv : nodeScores) {
@@ -1143,6 +1189,9 @@ namespace orc { Session::~Session() = default; }
 // =====================================================================================================
 static std::vector<int32_t> g_last_gpu_groups;  // of the last kai_oracle_run on this thread of the test process
 extern "C" {
+
+// worker threads of the node-scoring fan-out (see OrderedNodesByTask); returns the previous value
+int kai_oracle_set_threads(int n) { return orc::set_score_threads(n); }
 
 static void fill_shares(const orc::Session& ssn, kai_queue_share* out) {
     for (size_t q = 0; q < ssn.qattrs.size(); q++) for (int r = 0; r < 3; r++) {

@@ -356,7 +356,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             c.st->drain_pending = 0;
         }
     }
-    if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: scenarios %lld simulations %lld filtered %lld attempted %lld committed %lld decisions %lld\n", (long long)c.st->scenarios, (long long)c.st->simulations, (long long)c.st->scenarios_filtered, (long long)c.st->jobs_attempted, (long long)c.st->jobs_committed, (long long)c.st->decisions);
+    if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: scenarios %lld simulations %lld filtered %lld attempted %lld committed %lld decisions %lld sim-queue pops %lld | N %d C %d NB %d NSB %d R %d plugins 0x%x\n", (long long)c.st->scenarios, (long long)c.st->simulations, (long long)c.st->scenarios_filtered, (long long)c.st->jobs_attempted, (long long)c.st->jobs_committed, (long long)c.st->decisions, (long long)c.st->prof[4], c.N, c.C, c.NB, c.NSB, c.R, (unsigned)c.plugins);
     auto t1 = std::chrono::steady_clock::now();
     if (elapsed_ms_out) *elapsed_ms_out = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (c.st->fault) { if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: engine fault %d at line %d\n", c.st->fault, c.st->fault_line); return KAI_ERR_DEVICE_FAULT; }

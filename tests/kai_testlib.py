@@ -61,8 +61,10 @@ class Oracle:
         return cls._lib
 
     @classmethod
-    def run(cls, snap, cfg=None, actions=("allocate",)):
+    def run(cls, snap, cfg=None, actions=("allocate",), threads=1):
+        """threads > 1: the node-scoring fan-out of OrderedNodesByTask on that many threads (the reference scores nodes on goroutines); same results."""
         lib = cls.lib()
+        if hasattr(lib, "kai_oracle_set_threads"): lib.kai_oracle_set_threads(int(threads))  # (the host twin shares this wrapper and has no such knob)
         cfg = cfg or abi.default_config()
         s = snap.as_struct()
         acts = (C.c_int * len(actions))(*[abi.ACTIONS[a] for a in actions])
