@@ -134,14 +134,25 @@ inline void launch(int grid, int block, size_t dyn_lds_bytes, const std::functio
             f.sp = sp;
         }
         int live = block;
+        // KW_EMU_ORDER: how the waves of a workgroup take turns between their collectives — unset / 0: in order; 1: in reverse; 2: every wave sits
+        // out a pass with probability 1/2 (seeded), so the waves drift apart as far as the barriers allow.  Races between waves show up as
+        // results that depend on this setting.
+        static const int order = [] { const char* v = std::getenv("KW_EMU_ORDER"); return v ? std::atoi(v) : 0; }();
+        static uint64_t rng = [] { const char* v = std::getenv("KW_EMU_SEED"); return 0x9e3779b97f4a7c15ull + (v ? (uint64_t)std::atoll(v) * 0x100000001b3ull : 0); }();
         while (live > 0) {
             bool progress = false;
-            for (int t = 0; t < block; t++) {
-                if (e.fibers[t].state != F_RUN) continue;
-                e.cur = t; kw_switch_ctx(&e.sched_sp, e.fibers[t].sp);
-                progress = true;
-                if (e.fibers[t].state == F_DONE) live--;
+            const int nwv = (block + 63) / 64;
+            for (int wi = 0; wi < nwv; wi++) {
+                const int w = order == 1 ? nwv - 1 - wi : wi;
+                if (order == 2) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; if ((rng >> 40) & 1) continue; }
+                for (int t = w * 64; t < block && t < w * 64 + 64; t++) {
+                    if (e.fibers[t].state != F_RUN) continue;
+                    e.cur = t; kw_switch_ctx(&e.sched_sp, e.fibers[t].sp);
+                    progress = true;
+                    if (e.fibers[t].state == F_DONE) live--;
+                }
             }
+            if (order == 2 && !progress) { bool any = false; for (int t = 0; t < block; t++) if (e.fibers[t].state == F_RUN) any = true; if (any) continue; }  // every wave sat out
             // release the barriers every live participant has reached
             bool all_block = true; int waiting = 0;
             for (int t = 0; t < block; t++) { int s = e.fibers[t].state; if (s == F_RUN || s == F_WAIT_WAVE) all_block = false; if (s == F_WAIT_BLOCK) waiting++; }

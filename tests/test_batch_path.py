@@ -94,3 +94,21 @@ def test_batch_plugin_subsets(seed):
     drop = (abi.PLUGIN_RESOURCETYPE, abi.PLUGIN_NODEAVAILABILITY, abi.PLUGIN_NODEPLACEMENT, abi.PLUGIN_RESOURCETYPE | abi.PLUGIN_NODEAVAILABILITY)[seed % 4]
     cfg.plugins &= ~drop
     run_both(snap, cfg)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_batch_under_other_wave_schedules(order):
+    """The emulator lets the waves of a workgroup take turns in reverse or drift apart at random (kai_simt.hpp KW_EMU_ORDER): results that depend
+    on it are races between waves (plan, apply and exchange kernels run several waves per workgroup).  The setting is read once per process."""
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import kai_testlib as T\nfrom test_engine_hostsim import HostSim\nfrom test_batch_path import regular_snapshot\n"
+            "for seed in (0, 3, 7, 11, 29, 41):\n"
+            "    snap = regular_snapshot(seed); cfg = T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed %% 2], k_value=0.5)\n"
+            "    ref = T.Oracle.run(snap, cfg); res = HostSim.run(snap, cfg)\n"
+            "    assert res.ops == ref.ops and res.stats.reserved[4] == 1, seed\n"
+            "snap, cfg, _ = T.pkg.synth.config(2, 0.03)\n"
+            "assert HostSim.run(snap, cfg).ops == T.Oracle.run(snap, cfg).ops\n") % os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, KW_EMU_ORDER=str(order), KW_EMU_SEED="5")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
