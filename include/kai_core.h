@@ -269,10 +269,16 @@ typedef struct kai_snapshot_soa {
      *   ids below 2^20 stand for numeric group names and ids from 2^20 on for any other name, because the predicates plugin takes a
      *   non-numeric name for a group that is being created (plugins/predicates/predicates.go:320-330).
      * node_gpu_memory: NodeInfo.MemoryOfEveryGpuOnNode in MiB (label nvidia.com/gpu.memory floored to a multiple of 100, node_info.go:673-687);
-     *   NULL = 100 on every node (DefaultGpuMemory). */
+     *   NULL = 100 on every node (DefaultGpuMemory).
+     * pod_gpu_memory (ABI v5): > 0 = the pod asks for that many MiB of ONE device (annotation gpu-memory, pod_info.go:463-468): its gpu
+     *   column in pod_req and its pod_gpu_portion are 0 (ResourceRequirements.GPUs() of such a request is 0); on a node it takes that memory of a
+     *   shared device and counts as ceil(memory / node_gpu_memory * 100) / 100 of a device (node_info.go:329-332, 661-666, 734-744); while pending it
+     *   weighs memory / kai_config.min_node_gpu_memory in its queue's request and in its job's resources (proportion.go:360-366,
+     *   allocation_info.go:103-107).  NULL = no such pod. */
     const double* pod_gpu_portion;   /* [P] */
     const int32_t* pod_gpu_group;    /* [P] */
     const int64_t* node_gpu_memory;  /* [N] */
+    const int64_t* pod_gpu_memory;   /* [P] */
 } kai_snapshot_soa;
 
 typedef struct kai_op {

@@ -104,7 +104,7 @@ class KaiSnapshotSoA(C.Structure):
         ("podset_required_level", _P(C.c_int32)), ("podset_preferred_level", _P(C.c_int32)),
         ("job_signature", _P(C.c_int64)),
         ("job_last_start_ns", _P(C.c_int64)), ("queue_preempt_min_runtime_ns", _P(C.c_int64)), ("queue_reclaim_min_runtime_ns", _P(C.c_int64)),
-        ("pod_gpu_portion", _P(C.c_double)), ("pod_gpu_group", _P(C.c_int32)), ("node_gpu_memory", _P(C.c_int64)),
+        ("pod_gpu_portion", _P(C.c_double)), ("pod_gpu_group", _P(C.c_int32)), ("node_gpu_memory", _P(C.c_int64)), ("pod_gpu_memory", _P(C.c_int64)),
     ]
 
 
@@ -156,7 +156,7 @@ _SPEC_OPT = [
     ("group_required_level", np.int32), ("group_preferred_level", np.int32), ("job_root_group", np.int32), ("podset_group", np.int32),
     ("podset_topology", np.int32), ("podset_required_level", np.int32), ("podset_preferred_level", np.int32),
     ("job_signature", np.int64), ("job_last_start_ns", np.int64), ("queue_preempt_min_runtime_ns", np.int64), ("queue_reclaim_min_runtime_ns", np.int64),
-    ("pod_gpu_portion", np.float64), ("pod_gpu_group", np.int32), ("node_gpu_memory", np.int64),
+    ("pod_gpu_portion", np.float64), ("pod_gpu_group", np.int32), ("node_gpu_memory", np.int64), ("pod_gpu_memory", np.int64),
 ]
 
 

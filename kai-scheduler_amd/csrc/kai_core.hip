@@ -259,9 +259,9 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     for (int p = 0; p < P; p++) if (s->pod_flags && (s->pod_flags[p] & KAI_POD_GPU_UNMODELLED) && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING)))
         return fail(core, KAI_ERR_UNSUPPORTED, "an active pod holds GPU state the device does not model (gpu-memory / several fractional devices / MIG / DRA): its node's idle GPUs would be overstated");
     // shared GPUs (ABI v4): fractions of one device.  One GPU memory size for the whole cluster keeps the queue-capacity step node independent.
-    bool shared = false;
-    if (s->pod_gpu_portion) for (int p = 0; p < P; p++) if (s->pod_gpu_portion[p] > 0) shared = true;
-    if (shared && s->node_gpu_memory) for (int n = 1; n < N; n++) if (s->node_gpu_memory[n] != s->node_gpu_memory[0]) return fail(core, KAI_ERR_UNSUPPORTED, "shared GPUs with different node_gpu_memory values: leave the cycle to the host path");
+    SharedPods sp;
+    if (!sp.build(core->cfg, s)) return fail(core, KAI_ERR_UNSUPPORTED, sp.err.c_str());
+    const bool shared = sp.any;
     core->shared = shared;
 
     HIP_TRY(core, hipEventRecord(core->ev0, core->stream));
@@ -342,8 +342,10 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     {
         std::vector<double> por((size_t)std::max(P, 1), 0.0); std::vector<int32_t> grp((size_t)std::max(P, 1), -1), minus1((size_t)std::max(P, 1), -1); std::vector<int64_t> gm((size_t)std::max(N, 1), 100);
         int32_t next_new = KAI_NEW_GROUP;
-        for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && por[p] > 0) ? s->pod_gpu_group[p] : -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
+        for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && sp.shared[p]) ? s->pod_gpu_group[p] : -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
         for (int n = 0; n < N; n++) gm[n] = s->node_gpu_memory ? s->node_gpu_memory[prep.perm[n]] : 100;
+        TRY(dupload_f(core, c.p_shared, sp.shared.data(), (size_t)P)); TRY(dupload_f(core, c.p_mem, sp.mem.data(), (size_t)P)); TRY(dupload_f(core, c.p_gmem, sp.gmem.data(), (size_t)P));
+        TRY(dupload_f(core, c.p_acc_gpu, sp.acc_gpu.data(), (size_t)P)); TRY(dupload_f(core, c.p_pend_gpu, sp.pend_gpu.data(), (size_t)P));
         TRY(dupload_f(core, c.p_portion, por.data(), (size_t)P)); TRY(dupload_f(core, c.p_group, grp.data(), (size_t)P)); TRY(dupload_f(core, c.p_on_group, minus1.data(), (size_t)P));
         TRY(dupload_f(core, c.n_gpu_mem, gm.data(), (size_t)N));
         { const int32_t* t; TRY(dupload(core, &t, grp.data(), (size_t)std::max(P, 1))); core->d_group0 = const_cast<int32_t*>(t); }
@@ -640,12 +642,12 @@ int kai_pod_gpu_groups(kai_core* core, int32_t* out, int cap) {
     const int P = core->ctx.P;
     if (cap < P) return fail(core, KAI_ERR_CAPACITY, "kai_pod_gpu_groups: cap < n_pods");
     HIP_TRY(core, hipSetDevice(core->device));
-    std::vector<int32_t> st((size_t)std::max(P, 1)); std::vector<double> por((size_t)std::max(P, 1));
+    std::vector<int32_t> st((size_t)std::max(P, 1)); std::vector<uint8_t> por((size_t)std::max(P, 1));
     if (P) { HIP_TRY(core, hipMemcpyAsync(out, KAI_VP(core->ctx.p_group), (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
              HIP_TRY(core, hipMemcpyAsync(st.data(), KAI_VP(core->ctx.p_status), (size_t)P * 4, hipMemcpyDeviceToHost, core->stream));
-             HIP_TRY(core, hipMemcpyAsync(por.data(), KAI_VP(core->ctx.p_portion), (size_t)P * 8, hipMemcpyDeviceToHost, core->stream)); }
+             HIP_TRY(core, hipMemcpyAsync(por.data(), KAI_VP(core->ctx.p_shared), (size_t)P, hipMemcpyDeviceToHost, core->stream)); }
     HIP_TRY(core, hipStreamSynchronize(core->stream));
-    for (int p = 0; p < P; p++) if (!(core->shared && por[p] > 0 && (st[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING)))) out[p] = -1;
+    for (int p = 0; p < P; p++) if (!(core->shared && por[p] && (st[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING)))) out[p] = -1;
     return KAI_OK;
 }
 

@@ -301,6 +301,12 @@ struct KaiCtx {
 #ifdef KAI_SHARED_GPUS
     // shared GPUs (ABI v4; compiled into the host twin only until the device path is verified on the MI355X): fractions of one device
     KAI_GP(const double) p_portion;       // [P] 0 = a whole-GPU / CPU-only pod
+    // derived per pod on the host (HostPrep::SharedPods; one GPU memory size M for the whole cluster):
+    KAI_GP(const uint8_t) p_shared;       // [P] IsSharedGPURequest: a fraction of one device, or MiB of one device (pod_info.go:332-334)
+    KAI_GP(const int64_t) p_mem;          // [P] NodeInfo.GetResourceGpuMemory of the request (node_info.go:653-659): the MiB it takes on its device
+    KAI_GP(const int64_t) p_gmem;         // [P] ResReq.GpuMemory(): > 0 = a gpu-memory request
+    KAI_GP(const double) p_acc_gpu;       // [P] AcceptedResource.GetGpusQuota() once a node holds the pod (node_info.go:746-766)
+    KAI_GP(const double) p_pend_gpu;      // [P] GPU weight while pending: ResReq.GPUs() + memory / MinNodeGPUMemory (proportion.go:360-366, allocation_info.go:103-107)
     KAI_GP(int32_t) p_group, p_on_group;  // [P] PodInfo.GPUGroups[0]; the group in the node's own copy of the pod (node_info.go:397-398)
     KAI_GP(const int64_t) n_gpu_mem;      // [N] MemoryOfEveryGpuOnNode
     KAI_GP(int32_t) ng_id;                // [N][KAI_GMAX] GpuSharingNodeInfo: group id of the slot, -1 = free
@@ -320,6 +326,8 @@ struct ScanReq {
     double min_a, max_a;  // nodeplacement.setBinpackPreOrder range (plugins/nodeplacement/pack.go:35-43)
 #ifdef KAI_SHARED_GPUS
     double portion;       // > 0: the task asks for this fraction of one device
+    int64_t gmem;         // >= 0: GetResourceGpuMemory of a shared request (fraction or gpu-memory), -1: derive it from the portion
+    int32_t shared, pad_s;  // IsSharedGPURequest
 #endif
 };
 
@@ -421,6 +429,8 @@ struct SgNode {
     KAI_HD double sum_releasing_shared() const {  // getSumOfReleasingSharedGPUs :302-313
         double sum = 0; for (int s = next_slot_by_id(-1); s >= 0; s = next_slot_by_id(id(s))) if (rel(s) > 0 && !releasing_from_shared(s)) sum += frac_of(rel(s)); return sum;
     }
+    KAI_HD int64_t mem_available_shared() const { int64_t m = 0; for (int s = 0; s < KAI_GMAX; s++) if (id(s) >= 0 && ((c.ng_has_alloc[n] >> s) & 1u) && alloc(s) > 0) m += gpu_mem() - alloc(s); return m; }  // second result of :314-326
+    KAI_HD int64_t mem_releasing_shared() const { int64_t m = 0; for (int s = 0; s < KAI_GMAX; s++) if (id(s) >= 0 && rel(s) > 0 && !releasing_from_shared(s)) m += rel(s); return m; }       // … of :328-339
     // FittingGPUs (framework/session.go:163-199): groups that can take the task in ascending id, then one entry per idle-or-releasing whole GPU,
     // stably ordered by the GPU order score (gpupack: used portion; gpuspread: 1 - used portion, 1 for a whole GPU).  out[] holds slots, or
     // KAI_WHOLE_GPU entries; returns the count (at most KAI_GMAX + whole GPUs, capped).
@@ -449,6 +459,7 @@ struct SgNode {
     }
 };
 // isTaskAllocatableOnNonAllocatedResources for a fraction of one device (node_info.go:361-382)
+KAI_HD int64_t req_gpu_mem(const SgNode& g, const ScanReq& q) { return q.gmem >= 0 ? q.gmem : g.mem_of(q.portion); }  // NodeInfo.GetResourceGpuMemory (node_info.go:653-659)
 KAI_HD bool fits_shared(const KaiCtx& c, const ScanReq& q, int n, bool with_releasing) {
     for (int r = 0; r < c.R; r++) {
         if (r == KAI_RES_GPU) continue;
@@ -461,7 +472,7 @@ KAI_HD bool fits_shared(const KaiCtx& c, const ScanReq& q, int n, bool with_rele
     SgNode g{c, n};
     double ag = g.idle_gpu(); if (with_releasing) ag = ag + g.rel_gpu();
     double fl = (double)(int64_t)ag; if (fl > ag) fl -= 1;  // math.Floor
-    return (int64_t)fl + g.count_fit(g.mem_of(q.portion)) >= 1;
+    return (int64_t)fl + g.count_fit(req_gpu_mem(g, q)) >= 1;  // (isValidGpuPortion :668-671: the host admits gpu-memory requests of at most one device)
 }
 #endif
 
@@ -492,7 +503,7 @@ KAI_HD bool node_predicates_shared(const KaiCtx& c, const ScanReq& q, int n) {
     uint32_t f = c.n_flags[n];
     if (f & KAI_NODE_HAS_DRA_GPUS) return false;
     if ((f & KAI_NODE_MIG_ENABLED) && (f & (KAI_NODE_MIG_MIXED | KAI_NODE_MIG_SINGLE))) return false;
-    SgNode g{c, n}; const int64_t mem = g.mem_of(q.portion);
+    SgNode g{c, n}; const int64_t mem = req_gpu_mem(g, q);
     const bool alloc_now = q.best_effort || fits_shared(c, q, n, false);
     int slot = 0; bool releasing = false; bool needs_new = true;
     if (g.preferable(mem, false, alloc_now, slot, releasing)) needs_new = slot == KAI_WHOLE_GPU || g.id(slot) >= KAI_NEW_GROUP;
@@ -515,7 +526,7 @@ KAI_HD double node_score(const KaiCtx& c, const ScanReq& q, int n, bool fit_idle
     if (c.plugins & KAI_PLUGIN_NODEAVAILABILITY) score += fit_idle ? 100.0 : 0.0;  // plugins/nodeavailability/nodeavailability.go:29-40
 #ifdef KAI_SHARED_GPUS
     if (c.shared_on && (c.plugins & KAI_PLUGIN_GPUSHARINGORDER)) {  // plugins/gpusharingorder/gpusharingorder.go:29-44: 1000 when a used shared GPU of the node can take the task
-        SgNode g{c, n}; const int64_t mem = g.mem_of(q.portion);  // GetResourceGpuMemory: portion 1 for whole GPUs, 0 for a CPU-only task (which therefore "fits" every active shared GPU)
+        SgNode g{c, n}; const int64_t mem = req_gpu_mem(g, q);  // GetResourceGpuMemory: portion 1 for whole GPUs, 0 for a CPU-only task (which therefore "fits" every active shared GPU)
         double sc = 0.0; for (int s2 = 0; s2 < KAI_GMAX; s2++) if (g.id(s2) >= 0 && g.fit_on_group(s2, mem)) sc = 1000.0;
         score += sc;
     }
@@ -705,9 +716,20 @@ struct Engine {
 
     KAI_HD void fault(int code, int line = __builtin_LINE()) { if (!cx().st->fault) { cx().st->fault = code; cx().st->fault_line = line; } }
     KAI_HD double preq(int p, int r) const { return cx().p_req[(size_t)r * cx().P + p]; }
-    KAI_HD bool pod_cpu_only(int p) const { return !(preq(p, KAI_RES_GPU) > 0); }  // pod_info.go:340-347
+#ifdef KAI_SHARED_GPUS
+    KAI_HD bool pod_shared(int p) const { return cx().shared_on && cx().p_shared[p]; }
+    KAI_HD int64_t pod_gmem(int p) const { return cx().shared_on ? cx().p_gmem[p] : 0; }
+    KAI_HD double pacc_gpu(int p) const { return cx().shared_on ? cx().p_acc_gpu[p] : preq(p, KAI_RES_GPU); }
+    KAI_HD double ppend_gpu(int p) const { return cx().shared_on ? cx().p_pend_gpu[p] : preq(p, KAI_RES_GPU); }
+#else
+    KAI_HD bool pod_shared(int) const { return false; }
+    KAI_HD int64_t pod_gmem(int) const { return 0; }
+    KAI_HD double pacc_gpu(int p) const { return preq(p, KAI_RES_GPU); }
+    KAI_HD double ppend_gpu(int p) const { return preq(p, KAI_RES_GPU); }
+#endif
+    KAI_HD bool pod_cpu_only(int p) const { return !(preq(p, KAI_RES_GPU) > 0 || pod_gmem(p) > 0); }  // pod_info.go:340-347 IsRequireAnyKindOfGPU
     KAI_HD bool pod_best_effort(int p) const {  // ResourceRequirements.IsEmpty (resource_requirment.go:99-104, base_resources.go:119-130)
-        if (preq(p, KAI_RES_GPU) > 0.01) return false;
+        if (preq(p, KAI_RES_GPU) > 0.01 || pod_gmem(p) > 0) return false;  // (node_info.go:169-170: a gpu-memory request is never best effort)
         if (preq(p, KAI_RES_CPU) >= 10.0 || preq(p, KAI_RES_MEM) >= 10.0 * 1024 * 1024) return false;
         for (int r = KAI_RES_PODS; r < cx().R; r++) if (preq(p, r) >= 10.0) return false;
         return true;
@@ -766,6 +788,12 @@ struct Engine {
 #endif
         return cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n];
     }
+    KAI_HD int64_t gpus_free_mem(int n) const {  // GPU memory behind GetSumOfIdleGPUs + GetSumOfReleasingGPUs (node_info.go:592-628): whole devices count in full
+#ifdef KAI_SHARED_GPUS
+        if (cx().shared_on) { SgNode g{cx(), n}; return g.mem_available_shared() + (int64_t)cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n] * g.gpu_mem() + g.mem_releasing_shared() + (int64_t)cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n] * g.gpu_mem(); }
+#endif
+        return 0;
+    }
     KAI_HD double gpus_rel_sum(int n) const {
 #ifdef KAI_SHARED_GPUS
         if (cx().shared_on) { SgNode g{cx(), n}; return g.sum_releasing_shared() + cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n]; }
@@ -777,7 +805,7 @@ struct Engine {
         for (int r = 0; r < cx().R; r++) {
             double v = preq(p, r); if (v == 0) continue;
 #ifdef KAI_SHARED_GPUS
-            if (r == KAI_RES_GPU && cx().shared_on && cx().p_portion[p] > 0) continue;  // getAcceptedTaskResourceWithoutSharedGPU (gpu_sharing_node_info.go:52-66)
+            if (r == KAI_RES_GPU && pod_shared(p)) continue;  // getAcceptedTaskResourceWithoutSharedGPU (gpu_sharing_node_info.go:52-66)
 #endif
             size_t i = (size_t)r * cx().N + n;
             cx().n_used[i] += sign * v;
@@ -786,9 +814,9 @@ struct Engine {
             else cx().n_idle[i] -= sign * v;
         }
 #ifdef KAI_SHARED_GPUS
-        if (cx().shared_on && cx().p_portion[p] > 0) {  // addSharedTaskResources / removeSharedTaskResources with the group of the node's own copy
+        if (pod_shared(p)) {  // addSharedTaskResources / removeSharedTaskResources with the group of the node's own copy
             SgNode g{cx(), n}; const int grp = grp_of_copy != -2 ? grp_of_copy : cx().p_on_group[p];
-            if (grp >= 0) { bool ok = sign > 0 ? g.add(status, g.mem_of(cx().p_portion[p]), grp) : g.remove(status, g.mem_of(cx().p_portion[p]), grp); if (!ok) fault(FAULT_INTERNAL); }
+            if (grp >= 0) { bool ok = sign > 0 ? g.add(status, cx().p_mem[p], grp) : g.remove(status, cx().p_mem[p], grp); if (!ok) fault(FAULT_INTERNAL); }
         }
 #endif
         mark_dirty(n);
@@ -866,7 +894,7 @@ struct Engine {
         int j = cx().p_job[p]; bool np = !cx().j_preempt[j];
         for (int q = cx().j_queue[j]; q >= 0; q = qnp()[q].parent) {
             for (int k = 0; k < 3; k++) {
-                QShare& s = cx().q_share[(size_t)q * 3 + k]; double v = pquota(p, k);
+                QShare& s = cx().q_share[(size_t)q * 3 + k]; double v = k == KAI_Q_GPU ? pacc_gpu(p) : pquota(p, k);  // QuantifyResourceRequirements(AcceptedResource)
                 s.allocated += sign * v;
                 if (np) s.allocated_np += sign * v;
             }
@@ -901,7 +929,7 @@ struct Engine {
         bool found_on_node = on_node(p, n);
 #ifdef KAI_SHARED_GPUS
         // a shared-GPU task that was evicted from this node and comes back on ANOTHER GPU of it (:208-213)
-        const bool shared_task = cx().shared_on && cx().p_portion[p] > 0;
+        const bool shared_task = pod_shared(p);
         const int grp_there = (shared_task && found_on_node) ? group_on_node(p, n) : -1;
         const bool is_move = shared_task && found_on_node && cx().p_group[p] >= 0 && cx().p_group[p] != grp_there;
         if (found_on_node && !update_if_exists && !is_move) { if (shared_task) cx().p_group[p] = grp_there; return stmt_unevict_earliest(p); }
@@ -949,7 +977,7 @@ struct Engine {
     KAI_HD void unpipeline(int p, int prev_node, int prev_status, int prev_virtual, int prev_group = -1) {  // :431-476
         update_task_status(p, prev_status);
 #ifdef KAI_SHARED_GPUS
-        if (cx().shared_on && cx().p_portion[p] > 0) cx().p_group[p] = prev_group;  // :452
+        if (pod_shared(p)) cx().p_group[p] = prev_group;  // :452
 #else
         (void)prev_group;
 #endif
@@ -960,7 +988,7 @@ struct Engine {
     KAI_HD void unevict(int p, int prev_status, int n, int prev_virtual, int prev_group = -1) {  // :152-195
         update_task_status(p, prev_status);
 #ifdef KAI_SHARED_GPUS
-        if (cx().shared_on && cx().p_portion[p] > 0) cx().p_group[p] = prev_group;  // :167
+        if (pod_shared(p)) cx().p_group[p] = prev_group;  // :167
 #else
         (void)prev_group;
 #endif
@@ -1123,7 +1151,7 @@ struct Engine {
         }
         cx().j_tta_n[j] = out;
         double res[3] = {0, 0, 0};  // GetTasksToAllocateInitResource :88-113
-        for (int i = 0; i < out; i++) { int p = cx().tta[first + i]; for (int k = 0; k < 3; k++) res[k] += pquota(p, k); }
+        for (int i = 0; i < out; i++) { int p = cx().tta[first + i]; for (int k = 0; k < 3; k++) res[k] += k == KAI_Q_GPU ? ppend_gpu(p) : pquota(p, k); }  // GetTasksToAllocateInitResource :88-113
         for (int k = 0; k < 3; k++) cx().j_tta_res[(size_t)j * 4 + k] = res[k];
         cx().j_tta_valid[j] = 1;
     }
@@ -1271,7 +1299,7 @@ struct Engine {
 #ifdef KAI_SHARED_GPUS
         // a fraction: ceil(int64(portion * mem) / mem * 100) / 100 of a device; node independent because the host admits shared GPUs only when
         // every node has the same MemoryOfEveryGpuOnNode
-        if (cx().shared_on && cx().p_portion[p] > 0 && cx().N > 0) { SgNode g{cx(), 0}; req[2] = g.frac_of(g.mem_of(cx().p_portion[p])); }
+        if (pod_shared(p) && cx().N > 0) { SgNode g{cx(), 0}; req[2] = g.frac_of(cx().p_mem[p]); }
 #endif
         int j = cx().p_job[p];
         return over_limit(j, req) || np_over_quota(j, req);
@@ -1480,6 +1508,7 @@ struct Engine {
         q.min_a = 0; q.max_a = 0;
 #ifdef KAI_SHARED_GPUS
         q.portion = cx().shared_on ? (cx().p_portion[p] > 0 ? cx().p_portion[p] : (preq(p, KAI_RES_GPU) >= 1 ? 1.0 : 0.0)) : 0.0;  // GpuFractionalPortion()
+        q.shared = pod_shared(p) ? 1 : 0; q.gmem = q.shared ? cx().p_mem[p] : -1;  // GetResourceGpuMemory of a shared request (a gpu-memory request: portion 0, its own MiB)
 #endif
     }
     // OrderedNodesByTask + FittingNode for one task (framework/session.go:201-264): the first fitting node in score order, or -1
@@ -1500,7 +1529,7 @@ struct Engine {
         cx().st->node_scans++; cx().st->nodes_scanned += cx().N;
         if (n >= 0) allocatable = q.best_effort || fits(cx(), q.req, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
 #ifdef KAI_SHARED_GPUS
-        if (n >= 0 && cx().shared_on && cx().p_portion[p] > 0) allocatable = q.best_effort || fits_shared(cx(), q, n, false);
+        if (n >= 0 && pod_shared(p)) allocatable = q.best_effort || fits_shared(cx(), q, n, false);
 #endif
         return n;
     }
@@ -1518,9 +1547,9 @@ struct Engine {
         // allocateTaskToNode :165-174
         bool ok;
 #ifdef KAI_SHARED_GPUS
-        if (cx().shared_on && cx().p_portion[p] > 0) {  // gpu_sharing.AllocateFractionalGPUTaskToNode (gpuSharing.go:20-37, 85-103)
+        if (pod_shared(p)) {  // gpu_sharing.AllocateFractionalGPUTaskToNode (gpuSharing.go:20-37, 85-103)
             SgNode g{cx(), n}; int slot = 0; bool releasing = false;
-            if (!g.preferable(g.mem_of(cx().p_portion[p]), pipeline_only, allocatable, slot, releasing)) { fault(FAULT_INTERNAL); return false; }
+            if (!g.preferable(cx().p_mem[p], pipeline_only, allocatable, slot, releasing)) { fault(FAULT_INTERNAL); return false; }
             cx().p_group[p] = slot == KAI_WHOLE_GPU ? cx().next_new_group[0]++ : g.id(slot);
             const bool pipe = pipeline_only || releasing;
             ok = pipe ? stmt_pipeline(p, n, false) : stmt_allocate(p, n);

@@ -17,6 +17,43 @@
 
 namespace kai {
 
+// Shared-GPU requests (a fraction of one device: pod_gpu_portion; MiB of one device: pod_gpu_memory) as the per-pod quantities the engine reads.  The
+// engine admits them only with ONE GPU memory size M for the whole cluster, so what a request takes on "its node" is known here.
+struct SharedPods {
+    bool any = false; std::string err;
+    std::vector<uint8_t> shared; std::vector<int64_t> mem, gmem; std::vector<double> acc_gpu, pend_gpu;
+    static bool has(const kai_snapshot_soa* s) {
+        for (int p = 0; p < s->n_pods; p++) if ((s->pod_gpu_portion && s->pod_gpu_portion[p] > 0) || (s->pod_gpu_memory && s->pod_gpu_memory[p] > 0)) return true;
+        return false;
+    }
+    bool build(const kai_config& cfg, const kai_snapshot_soa* s) {  // false: refused, err says why
+        const int P = s->n_pods, N = s->n_nodes;
+        any = has(s);
+        const size_t n = (size_t)std::max(P, 1);
+        shared.assign(n, 0); mem.assign(n, 0); gmem.assign(n, 0); acc_gpu.assign(n, 0.0); pend_gpu.assign(n, 0.0);
+        if (any && s->node_gpu_memory) for (int i = 1; i < N; i++) if (s->node_gpu_memory[i] != s->node_gpu_memory[0]) { err = "shared GPUs with different node_gpu_memory values: leave the cycle to the host path"; return false; }
+        const int64_t M = (s->node_gpu_memory && N > 0) ? s->node_gpu_memory[0] : 100;
+        for (int p = 0; p < P; p++) {
+            const double g = s->pod_req[(size_t)KAI_RES_GPU * P + p];
+            const double por = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0;
+            const int64_t gm = (s->pod_gpu_memory && !(por > 0)) ? s->pod_gpu_memory[p] : 0;
+            acc_gpu[p] = g; pend_gpu[p] = g;
+            if (por > 0) { shared[p] = 1; mem[p] = (int64_t)(por * (double)M); }  // GetResourceGpuMemory (node_info.go:653-659); AcceptedResource keeps the portion
+            else if (gm > 0) {
+                if (gm > M || M <= 0) { err = "a gpu-memory request above one device's memory: leave the cycle to the host path"; return false; }  // isValidGpuPortion :668-671
+                if (g != 0) { err = "a gpu-memory request beside a GPU count"; return false; }
+                if (cfg.min_node_gpu_memory <= 0) { err = "gpu-memory requests need kai_config.min_node_gpu_memory > 0"; return false; }
+                shared[p] = 1; mem[p] = gm; gmem[p] = gm;
+                double x = (double)gm / (double)M * 100; double f = (double)(int64_t)x; if (f < x) f += 1;  // getGpuMemoryFractionalOnNode :329-332 (ceil to 1/100)
+                const double frac = f / 100;
+                acc_gpu[p] = (double)(int64_t)(frac * 100.0 + 0.5) / 100.0;  // GPUs() of NewGpuResourceRequirementWithMultiFraction(1, that portion, …): fixed point 1/100
+                pend_gpu[p] = cfg.min_node_gpu_memory > 0 ? (double)gm / (double)cfg.min_node_gpu_memory : 0.0;  // proportion.go:360-366, allocation_info.go:103-107
+            }
+        }
+        return true;
+    }
+};
+
 struct HostPrep {
     std::vector<int32_t> sorted, child_off, children, depth, job_off, jobs_static, slot_queue, depth_order, lvl_off, lvl_parents;
     std::vector<QShare> shares;

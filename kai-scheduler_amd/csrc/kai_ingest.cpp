@@ -405,7 +405,7 @@ struct kai_ingest {
         topo_level_off, node_domain, domain_level, domain_parent, group_job, group_parent, group_topology, group_req, group_pref, job_root_group,
         podset_group, podset_topology, podset_req, podset_pref;
     std::vector<int64_t> pod_created, job_created, queue_created, job_signature, job_last_start, q_preempt_mrt, q_reclaim_mrt, node_gpu_memory;
-    std::vector<double> pod_gpu_portion; std::vector<int32_t> pod_gpu_group; bool any_fraction = false;
+    std::vector<double> pod_gpu_portion; std::vector<int32_t> pod_gpu_group; std::vector<int64_t> pod_gpu_memory; bool any_fraction = false, any_gpu_memory = false;
     std::vector<uint8_t> class_fit;
     // what the decision writer needs of each pod / job (cache/cache.go:216-330)
     std::vector<std::string> pod_ns, pod_name, pod_uid, job_ns;
@@ -538,7 +538,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     std::set<std::string> config_maps; if (raw["configMaps"].is_arr()) for (auto& cm : raw["configMaps"].a) config_maps.insert(cm["metadata"]["namespace"].str() + "/" + cm["metadata"]["name"].str());
 
     // ---------------------------------------------------------------- pods (pod_info.go:172-214, 365-445)
-    struct PodRec { const JV* pod; std::string key, uid, group, subgroup, class_sig, sched_sig; Req req; int32_t status, node, nominated; uint32_t flags; int32_t task_prio; int64_t created; bool unschedulable, placed_anti_affinity; int job = -1, podset = -1; double gpu_portion = 0; std::string gpu_group; };
+    struct PodRec { const JV* pod; std::string key, uid, group, subgroup, class_sig, sched_sig; Req req; int32_t status, node, nominated; uint32_t flags; int32_t task_prio; int64_t created; bool unschedulable, placed_anti_affinity; int job = -1, podset = -1; double gpu_portion = 0; int64_t gpu_memory = 0; std::string gpu_group; };
     std::vector<PodRec> pods; std::set<std::string> extra_names;
     bool any_existing_anti_affinity = false;
     // one pod → its record; reads only what was built above (node / bind-request / config-map tables), so pods are converted in parallel
@@ -571,20 +571,26 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         { const JV& tp = md["labels"]["kai.scheduler/task-priority"]; if (tp.t == JV::Str) { char* e = nullptr; long v = strtol(tp.s.c_str(), &e, 10); if (!tp.s.empty() && !*e) { r.flags |= KAI_POD_HAS_TASK_PRIORITY; r.task_prio = (int32_t)v; } } }  // task_order.go:28-63
         // features outside the device path (SURVEY §8b fallback rule)
         const JV& ann = md["annotations"]; bool fb = r.req.mig;
-        if (!ann["gpu-fraction"].str().empty() || !ann["gpu-memory"].str().empty() || !ann["gpu-fraction-num-devices"].str().empty()) fb = true;
-        {   // a fraction of ONE device (pod_info.go:472-477) is described to the ABI (v4); the pod still goes to the CPU fallback until the device models shared GPUs
-            char* e = nullptr; const std::string& fs = ann["gpu-fraction"].str(); double fv = fs.empty() ? 0.0 : strtod(fs.c_str(), &e);
-            if (!fs.empty() && !*e && fv > 0 && fv < 1 && ann["gpu-memory"].str().empty() && ann["gpu-fraction-num-devices"].str().empty()) {
+        bool gpu_unmodelled = false;
+        {   // shared-GPU requests (pod_info.go:463-486): a fraction of ONE device (annotation gpu-fraction; ABI v4 pod_gpu_portion) and MiB of ONE device
+            // (annotation gpu-memory; ABI v5 pod_gpu_memory) are described to the device; several devices per pod (gpu-fraction-num-devices), both
+            // annotations at once or a value that does not parse leave the pod to the host path
+            const std::string& fs = ann["gpu-fraction"].str(); const std::string& ms = ann["gpu-memory"].str(); const bool multi = !ann["gpu-fraction-num-devices"].str().empty();
+            char* e = nullptr; const double fv = fs.empty() ? 0.0 : strtod(fs.c_str(), &e); const bool f_ok = !fs.empty() && !*e && fv > 0 && fv < 1;
+            char* e2 = nullptr; const long long mv = ms.empty() ? 0 : strtoll(ms.c_str(), &e2, 10); const bool m_ok = !ms.empty() && !*e2 && mv > 0;
+            if (f_ok && ms.empty() && !multi) {
                 r.gpu_portion = fv; r.req.gpu = (double)std::llround(fv * 100.0) / 100.0;  /* GPUs() is fixed point, 1/100 (gpu_resource_requirment.go:230-234) */ r.gpu_group = md["labels"]["runai-gpu-group"].str();  // common/resources/gpu_sharing.go:87-100
-            }
+            } else if (m_ok && fs.empty() && !multi) {
+                r.gpu_memory = mv; r.req.gpu = 0;  /* NewGpuResourceRequirementWithGpus(0, memory): one device, portion 0 */ r.gpu_group = md["labels"]["runai-gpu-group"].str();
+            } else if (!fs.empty() || !ms.empty() || multi) { fb = true; gpu_unmodelled = true; }
         }
         if (spec["resourceClaims"].is_arr() && !spec["resourceClaims"].a.empty()) fb = true;
         if (spec["affinity"]["podAffinity"].is_obj() || spec["affinity"]["podAntiAffinity"].is_obj()) { fb = true; if (spec["affinity"]["podAntiAffinity"]["requiredDuringSchedulingIgnoredDuringExecution"].is_arr() && r.node >= 0) r.placed_anti_affinity = true; }
         if (spec["volumes"].is_arr()) for (auto& v : spec["volumes"].a) if (v["persistentVolumeClaim"].is_obj() || v["ephemeral"].is_obj()) fb = true;
         for (const char* cs : {"containers", "initContainers"}) if (spec[cs].is_arr()) for (auto& c : spec[cs].a) if (c["ports"].is_arr()) for (auto& port : c["ports"].a) if (port["hostPort"].inum() > 0) fb = true;
         if (fb) r.flags |= KAI_POD_CPU_FALLBACK;
-        if (r.req.mig || !ann["gpu-memory"].str().empty() || !ann["gpu-fraction-num-devices"].str().empty() || (spec["resourceClaims"].is_arr() && !spec["resourceClaims"].a.empty()))
-            r.flags |= KAI_POD_GPU_UNMODELLED;  // GPU state beyond whole devices and one fraction: the device refuses such a pod when it is active
+        if (r.req.mig || gpu_unmodelled || (spec["resourceClaims"].is_arr() && !spec["resourceClaims"].a.empty()))
+            r.flags |= KAI_POD_GPU_UNMODELLED;  // GPU state beyond whole devices and one shared device: the device refuses such a pod when it is active
         {   // kai utility pods (api/pod_info/utility_pods.go:13-33, conf/global_config.go:25-26): never "another scheduler's" (proportion.go:276-285);
             // a reservation pod holds its GPU on behalf of the fraction pods of its group, so its own devices are not booked (node_info.go:465)
             const std::string& app = md["labels"]["app"].str();
@@ -843,10 +849,10 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         pod_class[k] = pclass_of[pod_order[k]]; pod_nominated[k] = r.nominated; uids[k] = r.uid; names[KAI_NAME_POD].push_back(r.key);
         {   // shared-GPU group id: the numeric name itself, or 2^20 + an interned index for any other name (a UUID)
             int32_t gid = -1;
-            if (r.gpu_portion > 0) { any_fraction = true; if (!r.gpu_group.empty() && (r.status & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) {
+            if (r.gpu_portion > 0 || r.gpu_memory > 0) { any_fraction = true; if (r.gpu_memory > 0) any_gpu_memory = true; if (!r.gpu_group.empty() && (r.status & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) {
                 char* e = nullptr; long v = strtol(r.gpu_group.c_str(), &e, 10);
                 if (!*e && v >= 0 && v < (1 << 20)) gid = (int32_t)v; else gid = (1 << 20) + (int32_t)gpu_group_ids.emplace(r.gpu_group, (int)gpu_group_ids.size()).first->second; } }
-            pod_gpu_portion.push_back(r.gpu_portion); pod_gpu_group.push_back(gid);
+            pod_gpu_portion.push_back(r.gpu_portion); pod_gpu_group.push_back(gid); pod_gpu_memory.push_back(r.gpu_memory);
         }
         { const JV& md = (*r.pod)["metadata"]; pod_ns.push_back(md["namespace"].str()); pod_name.push_back(md["name"].str()); pod_uid.push_back(md["uid"].str()); pod_gpus.push_back(r.req.gpu); }
     }
@@ -878,6 +884,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     s.n_groups = G; s.group_job = ptr(group_job); s.group_parent = ptr(group_parent); s.group_name_rank = ptr(group_name_rank); s.group_topology = ptr(group_topology); s.group_required_level = ptr(group_req); s.group_preferred_level = ptr(group_pref);
     s.job_root_group = ptr(job_root_group); s.podset_group = ptr(podset_group); s.podset_topology = ptr(podset_topology); s.podset_required_level = ptr(podset_req); s.podset_preferred_level = ptr(podset_pref);
     if (any_fraction) { s.pod_gpu_portion = ptr(pod_gpu_portion); s.pod_gpu_group = ptr(pod_gpu_group); }
+    if (any_gpu_memory) s.pod_gpu_memory = ptr(pod_gpu_memory);
     s.node_gpu_memory = ptr(node_gpu_memory);
     s.job_signature = ptr(job_signature); s.job_last_start_ns = ptr(job_last_start); s.queue_preempt_min_runtime_ns = ptr(q_preempt_mrt); s.queue_reclaim_min_runtime_ns = ptr(q_reclaim_mrt);
     return KAI_OK;

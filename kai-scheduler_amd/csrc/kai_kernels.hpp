@@ -60,7 +60,7 @@ __global__ void k_node_accounting_shared(KaiCtx c, const int32_t* np_off, const 
     for (int i = np_off[n]; i < np_off[n + 1]; i++) {
         const int p = np_pods[i], st = c.p_status[p];
         c.p_on_node[p] = n; c.p_on_node_status[p] = st; c.p_accepted[p] = 1;
-        const bool frac = c.p_portion[p] > 0;
+        const bool frac = c.p_shared[p] != 0;
         if (frac && c.p_group[p] >= 0) c.p_on_group[p] = c.p_group[p];
         for (int r = 0; r < c.R; r++) {
             if (r == KAI_RES_GPU && frac) continue;  // getAcceptedTaskResourceWithoutSharedGPU :52-66
@@ -69,7 +69,7 @@ __global__ void k_node_accounting_shared(KaiCtx c, const int32_t* np_off, const 
             c.n_used[x] += v;
             if (st == KAI_POD_RELEASING) { c.n_rel[x] += v; c.n_idle[x] -= v; } else if (st == KAI_POD_PIPELINED) c.n_rel[x] -= v; else c.n_idle[x] -= v;
         }
-        if (frac && c.p_on_group[p] >= 0) { SgNode g{c, n}; if (!g.add(st, g.mem_of(c.p_portion[p]), c.p_on_group[p])) { c.st->fault = FAULT_INTERNAL; c.st->fault_line = __LINE__; } }
+        if (frac && c.p_on_group[p] >= 0) { SgNode g{c, n}; if (!g.add(st, c.p_mem[p], c.p_on_group[p])) { c.st->fault = FAULT_INTERNAL; c.st->fault_line = __LINE__; } }
     }
 }
 #endif
@@ -122,11 +122,15 @@ __global__ void k_job_usage(KaiCtx c, double* jsum) {
         if (s == KAI_POD_PIPELINED) c.s_pipelined[ps]++;
         if (s == KAI_POD_PENDING) pending++;
         double q[3] = {c.p_req[(size_t)KAI_RES_CPU * c.P + p], c.p_req[(size_t)KAI_RES_MEM * c.P + p], c.p_req[(size_t)KAI_RES_GPU * c.P + p]};
+        double qa = q[2], qp = q[2];  // GPU quota of AcceptedResource / GPU weight of a pending request: they differ from ResReq.GPUs() for a gpu-memory request
+#ifdef KAI_SHARED_GPUS
+        if (c.shared_on) { qa = c.p_acc_gpu[p]; qp = c.p_pend_gpu[p]; }
+#endif
         if (st_allocated(s)) {
             for (int k = 0; k < 3; k++) ja[k] += q[k];
-            if (c.p_accepted[p]) for (int k = 0; k < 3; k++) { al[k] += q[k]; rq[k] += q[k]; }  // AcceptedResource is empty for a pod no node holds
+            if (c.p_accepted[p]) for (int k = 0; k < 3; k++) { const double v = k == 2 ? qa : q[k]; al[k] += v; rq[k] += v; }  // AcceptedResource is empty for a pod no node holds
         } else if (s == KAI_POD_PENDING) {
-            for (int k = 0; k < 3; k++) rq[k] += q[k];
+            for (int k = 0; k < 3; k++) rq[k] += k == 2 ? qp : q[k];
         }
     }
     c.j_n_pending[j] = pending; c.j_tta_valid[j] = 0; c.j_tta_n[j] = 0;
@@ -524,7 +528,7 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
             for (int n = slot; n < c.N; n += SCAN_LANES) {
                 if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;
 #ifdef KAI_SHARED_GPUS
-                const bool frac = c.shared_on && q.portion > 0 && q.portion < 1;  // a fraction of one device: fit / predicates over the node's GPU groups
+                const bool frac = c.shared_on && q.shared;  // a fraction (or MiB) of one device: fit / predicates over the node's GPU groups
                 if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
                 if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n))) continue;
                 bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));

@@ -124,6 +124,8 @@ def _from_handle(lib, h) -> Ingested:
     a["queue_preempt_min_runtime_ns"] = _copy(s.queue_preempt_min_runtime_ns, Q, np.int64); a["queue_reclaim_min_runtime_ns"] = _copy(s.queue_reclaim_min_runtime_ns, Q, np.int64)
     if s.pod_gpu_portion:
         a["pod_gpu_portion"] = _copy(s.pod_gpu_portion, P, np.float64); a["pod_gpu_group"] = _copy(s.pod_gpu_group, P, np.int32)
+    if s.pod_gpu_memory:
+        a["pod_gpu_memory"] = _copy(s.pod_gpu_memory, P, np.int64)
     if s.node_gpu_memory and N:
         a["node_gpu_memory"] = _copy(s.node_gpu_memory, N, np.int64)
     snap = abi.Snapshot(n_res=R, arrays=a)

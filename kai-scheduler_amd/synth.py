@@ -345,17 +345,18 @@ def config(idx: int, scale: float = 1.0, seed_offset: int = 0) -> tuple[abi.Snap
     raise ValueError(f"no BASELINE config {idx}")
 
 
-def add_fractions(snap: abi.Snapshot, seed: int, frac: float = 0.4, portions=(0.2, 0.25, 0.5, 0.75), gpu_memory: int = 100) -> abi.Snapshot:
+def add_fractions(snap: abi.Snapshot, seed: int, frac: float = 0.4, portions=(0.2, 0.25, 0.5, 0.75), gpu_memory: int = 100, memory_requests: float = 0.0) -> abi.Snapshot:
     """Turn a share of the one-GPU pods into requests for a fraction of one device (ABI v4: pod_gpu_portion / pod_gpu_group / node_gpu_memory).
     Placed ones are packed first-fit into shared-GPU groups of their node (numeric group names 0, 1, …; every group takes one of the GPUs the
     original pods held, so the node accounting of the reference — api/node_info/gpu_sharing_node_info.go — stays within the node's devices);
-    pending ones ask for their portion.  The oracle restates the shared-GPU model; the device engine refuses such snapshots for now."""
+    pending ones ask for their portion.  memory_requests: that share of them asks for MiB of one device instead (annotation gpu-memory, ABI v5
+    pod_gpu_memory: the GPU column and the portion are 0, the request is portion x gpu_memory MiB)."""
     rng = np.random.default_rng(seed ^ 0xF2AC)
     a = snap.arrays
     P, N = snap.n_pods, snap.n_nodes
     S = abi.POD_STATUS
     active = S["Running"] | S["Bound"] | S["Binding"] | S["Allocated"]
-    portion = np.zeros(P, np.float64); group = np.full(P, -1, np.int32)
+    portion = np.zeros(P, np.float64); group = np.full(P, -1, np.int32); gmem = np.zeros(P, np.int64)
     fill = [[] for _ in range(N)]  # per node: used portion (in 1/100) of every group
     for p in range(P):
         if a["pod_req"][abi.RES_GPU, p] != 1.0 or rng.random() >= frac:
@@ -371,7 +372,10 @@ def add_fractions(snap: abi.Snapshot, seed: int, frac: float = 0.4, portions=(0.
                     fill[n][g] += need; group[p] = g; break
             else:
                 fill[n].append(need); group[p] = len(fill[n]) - 1
+        if memory_requests > 0 and rng.random() < memory_requests:
+            gmem[p] = int(round(v * gpu_memory)); portion[p] = 0.0; a["pod_req"][abi.RES_GPU, p] = 0.0
     a["pod_gpu_portion"] = portion; a["pod_gpu_group"] = group; a["node_gpu_memory"] = np.full(N, gpu_memory, np.int64)
+    if memory_requests > 0: a["pod_gpu_memory"] = gmem
     return snap.finalize()
 
 

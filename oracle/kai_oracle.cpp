@@ -122,6 +122,12 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
             const int grp = s->pod_gpu_group ? s->pod_gpu_group[p] : -1;
             if (grp >= 0) { t.gpuGroups.push_back(grp); if (grp >= nextNewGpuGroup) nextNewGpuGroup = grp + 1; }
         }
+        const int64_t gmem = s->pod_gpu_memory ? s->pod_gpu_memory[p] : 0;
+        if (gmem > 0 && !t.isFractionRequest) {  // pod_info.go:463-468: NewGpuResourceRequirementWithGpus(0, memory) → one device, portion 0, that memory
+            t.resReq.count = 1; t.resReq.portion = 0; t.resReq.gpuMemory = gmem; t.isMemoryRequest = true; hasFractions = true;
+            const int grp = s->pod_gpu_group ? s->pod_gpu_group[p] : -1;
+            if (grp >= 0) { t.gpuGroups.push_back(grp); if (grp >= nextNewGpuGroup) nextNewGpuGroup = grp + 1; }
+        }
         for (int k = KAI_RES_PODS; k < R; k++) { double v = s->pod_req[size_t(k) * P + p]; if (v != 0) t.resReq.scalars[k] = int64_t(v); }
     }
     // jobs own their tasks (job_info.go AddTaskInfo), nodes hold the active-used ones (node_info.go:419-437 AddTasksToNode;
@@ -277,6 +283,7 @@ void Session::proportionOnSessionOpen() {  // proportion.go:99-124, 242-423
             } else if (status == Pending) {
                 for (auto& kv : byStatus.second) {
                     ResourceQuantities res = QuantifyResourceRequirements(kv.second->resReq);
+                    if (kv.second->IsMemoryRequest()) res[2] += double(kv.second->resReq.count) * (double(kv.second->resReq.gpuMemory) / double(cfg.min_node_gpu_memory));  // :360-366
                     for (int q = job.queue; q >= 0; q = qattrs[q].parent) for (int r = 0; r < 3; r++) qattrs[q].share[r].Request += res[r];
                 }
             }
@@ -466,7 +473,11 @@ const std::vector<PodInfo*>& Session::GetTasksToAllocate(PodGroupInfo* job, bool
 const Resource& Session::GetTasksToAllocateInitResource(PodGroupInfo* job, bool isRealAllocation) {  // :88-113
     if (job->hasInitResource) return job->tasksToAllocateInitResource;
     Resource total;
-    for (auto* task : GetTasksToAllocate(job, isRealAllocation)) if (task->ShouldAllocate(isRealAllocation)) total.Add(task->resReq.AsResource());
+    for (auto* task : GetTasksToAllocate(job, isRealAllocation)) if (task->ShouldAllocate(isRealAllocation)) {
+        total.Add(task->resReq.AsResource());
+        if (task->IsMemoryRequest() && cfg.min_node_gpu_memory > 0)  // :103-107: a memory request weighs its share of the smallest device of the cluster
+            total.gpus += double(task->resReq.count) * (double(task->resReq.gpuMemory) / double(cfg.min_node_gpu_memory));
+    }
     job->tasksToAllocateInitResource = total; job->hasInitResource = true;
     return job->tasksToAllocateInitResource;
 }
@@ -909,7 +920,7 @@ bool Session::willCreateNewGpuGroup(PodInfo* task, NodeInfo* node) {  // plugins
     return true;
 }
 bool Session::allocateTaskToNode(Statement& stmt, PodInfo* task, NodeInfo* node, bool isPipelineOnly) {  // :165-174
-    if (task->isFractionRequest) return AllocateFractionalGPUTaskToNode(stmt, task, node, isPipelineOnly);
+    if (task->isFractionRequest || task->IsMemoryRequest()) return AllocateFractionalGPUTaskToNode(stmt, task, node, isPipelineOnly);  // allocate.go:166
     bool taskAllocatable = node->IsTaskAllocatable(task);
     if (!isPipelineOnly && taskAllocatable) return stmt.Allocate(task, node->idx);
     return stmt.Pipeline(task, node->idx, !isPipelineOnly);

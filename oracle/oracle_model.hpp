@@ -75,10 +75,11 @@ inline double getExtendedResourceGpus(double portion, int64_t count) {
     return double(portionAsDecimals * count) / 100.0;
 }
 
-// api/resource_info/resource_requirment.go:17-20 (+ gpu_resource_requirment.go:26-32; whole-GPU requests only:
-// fractional / gpu-memory / MIG / DRA pods are flagged KAI_POD_CPU_FALLBACK and never reach the path)
+// api/resource_info/resource_requirment.go:17-20 (+ gpu_resource_requirment.go:26-32; whole GPUs, a fraction of one device, MiB of one device:
+// MIG / DRA pods are flagged KAI_POD_CPU_FALLBACK and never reach the path)
 struct ResourceRequirements : BaseResource {
     int64_t count = 0; double portion = 0;
+    int64_t gpuMemory = 0;  // a request for that many MiB of one device (annotation gpu-memory, pod_info.go:463-468): count 1, portion 0
     double GPUs() const { return getExtendedResourceGpus(portion, count); }
     double GetGpusQuota() const { return GPUs(); }  // gpu_resource_requirment.go:163-178 without mig/dra
     bool IsEmpty() const {                          // resource_requirment.go:99-104, gpu_resource_requirment.go:89-104
@@ -120,10 +121,13 @@ struct PodInfo {
     bool isFractionRequest = false;   // ResourceRequestType == RequestTypeFraction
     bool receivedFraction = false;    // ResourceReceivedType == ReceivedTypeFraction (node_info.go:755-758)
     std::vector<int> gpuGroups;
-    bool IsSharedGPURequest() const { return isFractionRequest; }       // pod_info.go:326-328 (no gpu-memory requests on the path)
-    bool IsSharedGPUAllocation() const { return receivedFraction; }    // :330-332
-    bool IsRegularGPURequest() const { return !isFractionRequest; }    // :322-324
-    bool IsCPUOnlyRequest() const { return !(resReq.GPUs() > 0); }  // pod_info.go:340-347
+    bool isMemoryRequest = false;     // ResourceRequestType == RequestTypeGpuMemory (pod_info.go:463-468)
+    bool IsMemoryRequest() const { return isMemoryRequest; }                                  // pod_info.go:324-326
+    bool IsFractionCandidate() const { return isFractionRequest || isMemoryRequest; }        // :316-318
+    bool IsSharedGPURequest() const { return isFractionRequest || isMemoryRequest; }         // :332-334
+    bool IsSharedGPUAllocation() const { return receivedFraction; }    // :336-338
+    bool IsRegularGPURequest() const { return !isFractionRequest && !isMemoryRequest; }     // :328-330 (RequestTypeRegular)
+    bool IsCPUOnlyRequest() const { return !(resReq.GPUs() > 0 || isMemoryRequest); }  // pod_info.go:340-347 IsRequireAnyKindOfGPU
     bool ShouldAllocate(bool isRealAllocation) const {               // pod_info.go:518-521
         return status == Pending || (!isRealAllocation && status == Releasing && isVirtualStatus);
     }
@@ -245,7 +249,9 @@ struct NodeInfo {
     int64_t GetNumberOfGPUsInNode() const { return gpuCountLabel >= 0 ? gpuCountLabel : int64_t(Allocatable.gpus); }  // :630-637
     // ---- shared-GPU helpers (gpu_sharing_node_info.go)
     static int64_t get(const std::map<int, int64_t>& m, int g) { auto it = m.find(g); return it == m.end() ? 0 : it->second; }
-    int64_t GetResourceGpuMemory(const ResourceRequirements& r) const { return int64_t(r.portion * double(MemoryOfEveryGpuOnNode)); }  // node_info.go:653-659 (no gpu-memory requests)
+    int64_t GetResourceGpuMemory(const ResourceRequirements& r) const { return r.gpuMemory > 0 ? r.gpuMemory : int64_t(r.portion * double(MemoryOfEveryGpuOnNode)); }  // node_info.go:653-659
+    double getResourceGpuPortion(const ResourceRequirements& r) const { return r.gpuMemory > 0 ? getGpuMemoryFractionalOnNode(r.gpuMemory) : r.portion; }  // :661-666
+    bool isValidGpuPortion(const ResourceRequirements& r) const { double p = getResourceGpuPortion(r); return p <= 1 || p == double(int(p)); }  // :668-671
     double getGpuMemoryFractionalOnNode(int64_t memory) const { return std::ceil(double(memory) / double(MemoryOfEveryGpuOnNode) * 100) / 100; }  // :329-332
     int getNumberOfUsedSharedGPUs() const { int n = 0; for (auto& kv : UsedSharedGPUsMemory) if (kv.second > 0) n++; return n; }  // :265-273
     int getNumberOfUsedGPUs() const { return int(Used.gpus) + getNumberOfUsedSharedGPUs(); }                                     // :275-277
@@ -273,6 +279,14 @@ struct NodeInfo {
         double sum = 0; for (auto& kv : ReleasingSharedGPUsMemory) if (kv.second > 0 && !isGpuReleasingFromSharedTasks(kv.first)) sum += getGpuMemoryFractionalOnNode(kv.second); return sum;
     }
     double GetSumOfIdleGPUs() const { return getSumOfAvailableSharedGPUs() + Idle.gpus; }            // node_info.go:592-609 (no MIG resources on the path)
+    int64_t GetSumOfIdleGPUsMemory() const {  // the second result of :592-609 and gpu_sharing_node_info.go:314-326
+        int64_t m = 0; for (auto& kv : AllocatedSharedGPUsMemory) if (kv.second > 0) m += MemoryOfEveryGpuOnNode - kv.second;
+        return m + int64_t(Idle.gpus) * MemoryOfEveryGpuOnNode;
+    }
+    int64_t GetSumOfReleasingGPUsMemory() const {  // :611-628, :328-339
+        int64_t m = 0; for (auto& kv : ReleasingSharedGPUsMemory) if (kv.second > 0 && !isGpuReleasingFromSharedTasks(kv.first)) m += kv.second;
+        return m + int64_t(Releasing.gpus) * MemoryOfEveryGpuOnNode;
+    }
     double GetSumOfReleasingGPUs() const { return getSumOfReleasingSharedGPUs() + Releasing.gpus; }  // :611-628
     int64_t fractionTaskGpusAllocatableDeviceCount(const PodInfo* pod) const {  // :334-348
         int64_t n = 0;
@@ -282,12 +296,12 @@ struct NodeInfo {
     bool isTaskAllocatableOnNonAllocatedResources(const PodInfo* task, const Resource& avail) const {  // :361-382
         if (task->IsRegularGPURequest()) return task->resReq.LessEqualResource(avail);
         if (!static_cast<const BaseResource&>(task->resReq).LessEqual(avail)) return false;
-        // isValidGpuPortion (:668-671): a portion of at most one device always is
+        if (!isValidGpuPortion(task->resReq)) return false;
         int64_t wholeGpus = int64_t(std::floor(avail.gpus));
         return wholeGpus + fractionTaskGpusAllocatableDeviceCount(task) >= task->resReq.count;
     }
     bool IsTaskAllocatable(const PodInfo* task) const {  // :168-188 (no storage claims on the path)
-        if (task->resReq.IsEmpty()) return true;
+        if (task->resReq.IsEmpty() && !task->IsMemoryRequest()) return true;
         return isTaskAllocatableOnNonAllocatedResources(task, Idle);
     }
     bool IsTaskAllocatableOnReleasingOrIdle(const PodInfo* task) const {  // :190-206
@@ -296,7 +310,10 @@ struct NodeInfo {
     void setAcceptedResources(PodInfo* pi) const {  // :746-766
         if (!IsActiveUsedStatus(pi->status)) return;
         pi->accepted = pi->resReq;
-        pi->receivedFraction = pi->isFractionRequest;  // ReceivedTypeFraction for a fraction candidate, ReceivedTypeRegular otherwise
+        pi->receivedFraction = pi->IsFractionCandidate();  // ReceivedTypeFraction for a fraction candidate, ReceivedTypeRegular otherwise
+        if (pi->IsFractionCandidate()) {  // NewGpuResourceRequirementWithMultiFraction(devices, this node's portion, this node's memory) :756-759
+            pi->accepted.portion = getResourceGpuPortion(pi->resReq); pi->accepted.gpuMemory = GetResourceGpuMemory(pi->resReq);
+        }
     }
     void addTaskResources(const Resource& r, int status) {  // :457-493
         Used.Add(r);

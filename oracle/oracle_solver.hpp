@@ -455,7 +455,7 @@ struct JobSolver {
 // ---------------------------------------------------------------- common/feasible_nodes.go
 inline std::vector<int> Session::FeasibleNodesForJob(PodGroupInfo* job) {
     std::vector<int> out;
-    bool allNeedGpu = true; for (auto* t : job->AllPods()) if (!(t->resReq.GPUs() > 0)) { allNeedGpu = false; break; }  // IsRequireAnyKindOfGPU, whole-GPU path
+    bool allNeedGpu = true; for (auto* t : job->AllPods()) if (t->IsCPUOnlyRequest()) { allNeedGpu = false; break; }  // !IsRequireAnyKindOfGPU
     for (auto& n : nodes) if (!allNeedGpu || n.GetSumOfIdleGPUs() > 0 || n.GetSumOfReleasingGPUs() > 0) out.push_back(n.idx);
     return out;
 }
@@ -706,8 +706,10 @@ inline void Session::executeVictimAction(int action) {
                 GetTasksToAllocateInitResource(job, false);
                 double sumGpus = 0;  // utils.IsEnoughGPUsAllocatableForJob (action.go:119-160)
                 for (auto& n : nodes) { if (n.flags & KAI_NODE_NOT_READY) continue; sumGpus += n.GetSumOfIdleGPUs(); sumGpus += n.GetSumOfReleasingGPUs(); }
-                double requested = 0; for (auto* t : GetTasksToAllocate(job, false)) requested += t->resReq.GPUs();
-                if (!(sumGpus >= requested)) break;
+                int64_t sumMem = 0; for (auto& n : nodes) { if (n.flags & KAI_NODE_NOT_READY) continue; sumMem += n.GetSumOfIdleGPUsMemory(); sumMem += n.GetSumOfReleasingGPUsMemory(); }
+                double requested = 0; int64_t requestedMem = 0;  // GetTasksToAllocateRequestedGPUs (allocation_info.go:55-86)
+                for (auto* t : GetTasksToAllocate(job, false)) { requested += t->resReq.GPUs(); requestedMem += t->resReq.gpuMemory; }
+                if (!(sumGpus >= requested && sumMem >= requestedMem)) break;
                 JobSolver solver{this, FeasibleNodesForJob(job),
                     [](Scenario* sc) { for (auto& kv : sc->victims) for (auto* t : kv.second.Tasks) if (t->status == Releasing) return false; return true; },  // allPodsReallocated :120-129
                     [this, job]() {

@@ -128,7 +128,7 @@ func statusBit(s pod_status.PodStatus) C.int32_t { // api/pod_status/pod_status.
 
 // needsFallback: the task needs a predicate or a resource model the device path does not carry — SURVEY §8b fallback rule
 func needsFallback(t *pod_info.PodInfo) bool {
-	if t.IsLegacyMIGtask || len(t.ResReq.MigResources()) > 0 || t.ResReq.GpuMemory() > 0 || t.ResReq.GetDraGpusCount() > 0 {
+	if t.IsLegacyMIGtask || len(t.ResReq.MigResources()) > 0 || t.ResReq.GetDraGpusCount() > 0 {
 		return true
 	}
 	if t.ResReq.GetNumOfGpuDevices() > 1 && t.ResReq.IsFractionalRequest() {
@@ -295,6 +295,7 @@ func packSnapshot(ssn *framework.Session, params packParams) *packedSnapshot {
 	pClass := carray[C.int32_t](p, P)
 	pNominated := carray[C.int32_t](p, P)
 	pPortion := carray[C.double](p, P)
+	pGpuMem := carray[C.int64_t](p, P)
 	pGroup := carray[C.int32_t](p, P)
 	copy(jUID, rankStrings(jids))
 	sigIDs := map[string]int64{}
@@ -367,8 +368,12 @@ func packSnapshot(ssn *framework.Session, params packParams) *packedSnapshot {
 			if needsFallback(t) {
 				pFlags[pi] |= C.KAI_POD_CPU_FALLBACK
 			}
-			if t.ResReq.IsFractionalRequest() && t.ResReq.GetNumOfGpuDevices() == 1 { // ABI v4: a fraction of ONE device
-				pPortion[pi] = C.double(t.ResReq.GpuFractionalPortion())
+			if t.ResReq.IsFractionalRequest() && t.ResReq.GetNumOfGpuDevices() == 1 { // ABI v4 / v5: a fraction, or MiB, of ONE device
+				if t.IsMemoryRequest() { // pod_info.go:463-468: GPUs() and the portion are 0, the request is the memory
+					pGpuMem[pi] = C.int64_t(t.ResReq.GpuMemory())
+				} else {
+					pPortion[pi] = C.double(t.ResReq.GpuFractionalPortion())
+				}
 				if len(t.GPUGroups) > 0 {
 					pGroup[pi] = C.int32_t(classes.groupID(t.NodeName, t.GPUGroups[0]))
 				}
@@ -394,7 +399,7 @@ func packSnapshot(ssn *framework.Session, params packParams) *packedSnapshot {
 	s.queue_deserved, s.queue_limit, s.queue_oqw, s.queue_usage = ptr(qDeserved), ptr(qLimit), ptr(qOqw), ptr(qUsage)
 	s.n_pod_classes, s.n_node_classes, s.class_fit = C.int32_t(classes.nPod()), C.int32_t(classes.nNode()), ptr(fit)
 	s.job_signature, s.job_last_start_ns, s.queue_preempt_min_runtime_ns, s.queue_reclaim_min_runtime_ns = ptr(jSig), ptr(jLastStart), ptr(qPreMR), ptr(qRecMR)
-	s.pod_gpu_portion, s.pod_gpu_group, s.node_gpu_memory = ptr(pPortion), ptr(pGroup), ptr(gpuMem)
+	s.pod_gpu_portion, s.pod_gpu_group, s.node_gpu_memory, s.pod_gpu_memory = ptr(pPortion), ptr(pGroup), ptr(gpuMem), ptr(pGpuMem)
 	packTopologies(p, ssn, nodeIdx) // Topology CRs -> node_domain / domain tables; RootSubGroupSet -> group tables (plugins/topology/topology_plugin.go:57-110)
 	return p
 }

@@ -45,7 +45,7 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
         int best = -1; double bs = 0;
         for (int n = 0; n < c.N; n++) {
             if (loc.scope_bits && !((loc.scope_bits[n >> 5] >> (n & 31)) & 1)) continue;
-            const bool frac = c.shared_on && q.portion > 0 && q.portion < 1;
+            const bool frac = c.shared_on && q.shared;
             if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
             if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n))) continue;
             bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
@@ -147,11 +147,9 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
                                kai_queue_share* shares_open, kai_queue_share* shares_final, kai_node_state* nodes_out,
                                kai_action_stats* stats, double* elapsed_ms_out) {
     if (!cfg || !s || s->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
-    bool shared = false;
-    if (s->pod_gpu_portion) for (int p = 0; p < s->n_pods; p++) if (s->pod_gpu_portion[p] > 0) shared = true;
-    if (shared) {  // shared GPUs in the engine: one GPU memory size for the whole cluster (the queue-capacity step stays node independent)
-        if (s->node_gpu_memory) for (int n = 1; n < s->n_nodes; n++) if (s->node_gpu_memory[n] != s->node_gpu_memory[0]) return KAI_ERR_UNSUPPORTED;
-    }
+    SharedPods sp;  // shared GPUs in the engine: one GPU memory size for the whole cluster (the queue-capacity step stays node independent)
+    if (!sp.build(*cfg, s)) return KAI_ERR_UNSUPPORTED;
+    const bool shared = sp.any;
     const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
     std::vector<std::vector<char>> pool;
     HostPrep prep; std::string err;
@@ -201,7 +199,8 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         c.shared_on = shared ? 1 : 0;
         double* por = own<double>(pool, P); int32_t* grp = own<int32_t>(pool, P); int32_t* ogrp = own<int32_t>(pool, P); int64_t* gm = own<int64_t>(pool, N);
         int32_t next_new = KAI_NEW_GROUP;
-        for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && por[p] > 0) ? s->pod_gpu_group[p] : -1; ogrp[p] = -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
+        for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && sp.shared[p]) ? s->pod_gpu_group[p] : -1; ogrp[p] = -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
+        c.p_shared = copy(pool, sp.shared.data(), P); c.p_mem = copy(pool, sp.mem.data(), P); c.p_gmem = copy(pool, sp.gmem.data(), P); c.p_acc_gpu = copy(pool, sp.acc_gpu.data(), P); c.p_pend_gpu = copy(pool, sp.pend_gpu.data(), P);
         for (int n = 0; n < N; n++) gm[n] = s->node_gpu_memory ? s->node_gpu_memory[prep.perm[n]] : 100;
         c.p_portion = por; c.p_group = grp; c.p_on_group = ogrp; c.n_gpu_mem = gm;
         c.ng_id = own<int32_t>(pool, (size_t)N * KAI_GMAX); for (size_t i = 0; i < (size_t)N * KAI_GMAX; i++) c.ng_id[i] = -1;
@@ -228,14 +227,14 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         int st = c.p_status[p], n = c.p_node[p];
         if (!st_active_used(st) || n < 0 || n >= N) continue;
         c.p_on_node[p] = n; c.p_on_node_status[p] = st; c.p_accepted[p] = 1;
-        if (shared && c.p_portion[p] > 0 && c.p_group[p] >= 0) { c.p_on_group[p] = c.p_group[p]; }
+        if (shared && c.p_shared[p] && c.p_group[p] >= 0) { c.p_on_group[p] = c.p_group[p]; }
         for (int r = 0; r < R; r++) {
-            if (shared && r == KAI_RES_GPU && c.p_portion[p] > 0) continue;
+            if (shared && r == KAI_RES_GPU && c.p_shared[p]) continue;
             double v = c.p_req[(size_t)r * P + p]; if (v == 0) continue; size_t i = (size_t)r * N + n;
             c.n_used[i] += v;
             if (st == KAI_POD_RELEASING) { c.n_rel[i] += v; c.n_idle[i] -= v; } else if (st == KAI_POD_PIPELINED) c.n_rel[i] -= v; else c.n_idle[i] -= v;
         }
-        if (shared && c.p_portion[p] > 0 && c.p_on_group[p] >= 0) { SgNode g{c, n}; if (!g.add(st, g.mem_of(c.p_portion[p]), c.p_on_group[p])) return KAI_ERR_UNSUPPORTED; }
+        if (shared && c.p_shared[p] && c.p_on_group[p] >= 0) { SgNode g{c, n}; if (!g.add(st, c.p_mem[p], c.p_on_group[p])) return KAI_ERR_UNSUPPORTED; }
     }
     if (c.plugins & KAI_PLUGIN_PROPORTION) {  // k_total_nodes + k_total_foreign
         for (int n = 0; n < N; n++) {
@@ -261,8 +260,9 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             if (st == KAI_POD_PIPELINED) c.s_pipelined[ps]++;
             if (st == KAI_POD_PENDING) pending++;
             double q[3] = {c.p_req[(size_t)KAI_RES_CPU * P + p], c.p_req[(size_t)KAI_RES_MEM * P + p], c.p_req[(size_t)KAI_RES_GPU * P + p]};
-            if (st_allocated(st)) { for (int k = 0; k < 3; k++) ja[k] += q[k]; if (c.p_accepted[p]) for (int k = 0; k < 3; k++) { al[k] += q[k]; rq[k] += q[k]; } }
-            else if (st == KAI_POD_PENDING) for (int k = 0; k < 3; k++) rq[k] += q[k];
+            const double qa = shared ? c.p_acc_gpu[p] : q[2], qp = shared ? c.p_pend_gpu[p] : q[2];  // accepted quota / pending weight of a gpu-memory request
+            if (st_allocated(st)) { for (int k = 0; k < 3; k++) ja[k] += q[k]; if (c.p_accepted[p]) for (int k = 0; k < 3; k++) { const double v = k == 2 ? qa : q[k]; al[k] += v; rq[k] += v; } }
+            else if (st == KAI_POD_PENDING) for (int k = 0; k < 3; k++) rq[k] += k == 2 ? qp : q[k];
         }
         c.j_n_pending[j] = pending;
         for (int k = 0; k < 3; k++) c.j_allocated[(size_t)j * 4 + k] = ja[k];
@@ -287,7 +287,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
                 const int st = c.p_status[p]; const bool al = st_allocated(st) && c.p_accepted[p], pe = st == KAI_POD_PENDING;
                 if (!al && !pe) continue;
                 for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
-                    QShare& x = c.q_share[(size_t)q * 3 + k]; const double v = c.p_req[(size_t)(k == 0 ? KAI_RES_CPU : k == 1 ? KAI_RES_MEM : KAI_RES_GPU) * P + p];
+                    QShare& x = c.q_share[(size_t)q * 3 + k]; const double v = k == 2 ? (al ? c.p_acc_gpu[p] : c.p_pend_gpu[p]) : c.p_req[(size_t)(k == 0 ? KAI_RES_CPU : KAI_RES_MEM) * P + p];
                     x.request += v; if (al) { x.allocated += v; if (!c.j_preempt[j]) x.allocated_np += v; }
                 }
             }
@@ -363,7 +363,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (n_ops) *n_ops = c.st->out_len;
     if (ops_out) { if (c.st->out_len > ops_cap) return KAI_ERR_CAPACITY; std::memcpy(ops_out, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)); for (int64_t i = 0; i < c.st->out_len; i++) if (ops_out[i].node >= 0) ops_out[i].node = prep.perm[ops_out[i].node]; }
     g_last_groups.assign(P, -1);
-    for (int p = 0; p < P; p++) if (shared && c.p_portion[p] > 0 && st_active_used(c.p_status[p])) g_last_groups[p] = c.p_group[p];
+    for (int p = 0; p < P; p++) if (shared && c.p_shared[p] && st_active_used(c.p_status[p])) g_last_groups[p] = c.p_group[p];
     if (pod_status_out) std::memcpy(pod_status_out, c.p_status, (size_t)P * 4);
     if (pod_node_out) for (int p = 0; p < P; p++) pod_node_out[p] = c.p_node[p] >= 0 ? prep.perm[c.p_node[p]] : -1;
     if (shares_final) fill(shares_final);

@@ -309,19 +309,22 @@ def case_to_snapshot(case, actions=("allocate",), fractions=False):
     jobs = [j for _, j in jobs]
     J = len(jobs)
     pod_names, pod_job, pod_podset, pod_status, pod_node, pod_flags, pod_prio, pod_aff = [], [], [], [], [], [], [], []
-    pod_gpu_portion, pod_gpu_group = [], []
+    pod_gpu_portion, pod_gpu_group, pod_gpu_memory = [], [], []
     req_rows = []
     podset_job, podset_min, podset_names_l, job_first_podset, job_n_podsets, job_first_pod, job_n_pods = [], [], [], [], [], [], []
     job_names, job_queue, job_priority, job_preempt, job_created = [], [], [], [], []
     trees = {}
     for ji, job in enumerate(jobs):
         tasks = job.get("Tasks", []) or []
-        if job.get("RequiredGpuMemory", 0):
-            raise Unsupported("gpu memory request")
+        gmem = int(job.get("RequiredGpuMemory", 0) or 0)  # annotation gpu-memory (jobs.go:277): MiB of one device
+        if gmem and not fractions:
+            raise Unsupported("gpu memory request (oracle only, allocate action)")
         if job.get("RequiredMultiFractionDevicesPerTask") is not None:
             raise Unsupported("multi-fraction")
         g = float(job.get("RequiredGPUsPerTask", 0))
         frac = 0.0 < g < 1.0  # a fraction of one device (jobs.go:278-283 → annotation gpu-fraction)
+        if gmem and g != 0:
+            raise Unsupported("gpu memory request beside a GPU count")
         if g != int(g) and not frac:
             raise Unsupported("fractional gpu above one device")
         if frac and not fractions:
@@ -370,11 +373,17 @@ def case_to_snapshot(case, actions=("allocate",), fractions=False):
             if t.get("ResourceClaimNames") or t.get("ResourceClaimTemplates"):
                 raise Unsupported("DRA")
             groups = t.get("GPUGroups") or []
-            if len(groups) > 1 or (groups and not frac) or any(not str(x).lstrip("-").isdigit() for x in groups):
+            shared = frac or gmem > 0
+            if groups and not shared and g == 0:
+                groups = []  # a group label on a task that asks for no GPU: nothing reads it
+            if len(groups) > 1 or (groups and not shared) or any(not str(x).lstrip("-").isdigit() for x in groups):
                 raise Unsupported("shared gpu groups beyond one numeric group of a fraction task")
-            pod_gpu_portion.append(g if frac else 0.0)
+            pod_gpu_portion.append(g if frac else 0.0); pod_gpu_memory.append(gmem)
             if frac and t.get("NodeName"):  # resourceFractionCalc (jobs.go:318-330): a placed fraction task without a group gets one of its own, named by a fresh UUID
                 pod_gpu_group.append(int(groups[0]) if groups else NEW_GPU_GROUP + len(pod_gpu_group))
+            elif gmem and t.get("NodeName"):  # a gpu-memory task keeps the groups its fixture names (jobs.go:277: the whole-GPU branch, no UUID)
+                if not groups: raise Unsupported("placed gpu-memory task without a group")
+                pod_gpu_group.append(int(groups[0]))
             else:
                 pod_gpu_group.append(-1)
             pod_names.append(f"{job['Name']}-{ti}")
@@ -441,8 +450,9 @@ def case_to_snapshot(case, actions=("allocate",), fractions=False):
     a["pod_flags"] = np.array(pod_flags, np.uint32); a["pod_task_priority"] = np.array(pod_prio, np.int32)
     a["pod_created_ns"] = np.zeros(P, np.int64); a["pod_uid_rank"] = abi.rank_strings(pod_names); a["pod_class"] = pod_class
     a["pod_nominated_node"] = np.full(P, -1, np.int32)
-    if any(x > 0 for x in pod_gpu_portion):  # shared GPUs (ABI v4)
+    if any(x > 0 for x in pod_gpu_portion) or any(pod_gpu_memory):  # shared GPUs (ABI v4; gpu-memory requests: v5)
         a["pod_gpu_portion"] = np.array(pod_gpu_portion, np.float64); a["pod_gpu_group"] = np.array(pod_gpu_group, np.int32)
+        if any(pod_gpu_memory): a["pod_gpu_memory"] = np.array(pod_gpu_memory, np.int64)
         gm = []
         for nm in node_names:  # nodes_fake/nodes.go:184-194 + getNodeGpuMemory (node_info.go:673-687): MiB, floored to a multiple of 100
             v = int(case["Nodes"][nm].get("GPUMemory") or 100); gm.append(v - v % 100)
@@ -512,7 +522,7 @@ def check_expectations(snap, meta, pod_status, pod_node, nodes=None, gpu_groups=
                 if got != exp["NodeName"]:
                     errs.append(f"{snap.pod_names[p]}: node {got!r} want {exp['NodeName']!r}")
             gsum += snap.pod_req[abi.RES_GPU, p]
-            if gpu_groups is not None and exp.get("GPUGroups") and not exp.get("DontValidateGPUGroup") and (int(pod_status[p]) & abi.ACTIVE_USED) and "pod_gpu_portion" in snap.arrays and snap.pod_gpu_portion[p] > 0:
+            if gpu_groups is not None and exp.get("GPUGroups") and not exp.get("DontValidateGPUGroup") and (int(pod_status[p]) & abi.ACTIVE_USED) and "pod_gpu_portion" in snap.arrays and (snap.pod_gpu_portion[p] > 0 or ("pod_gpu_memory" in snap.arrays and snap.pod_gpu_memory[p] > 0)):
                 name, actual, key = str(exp["GPUGroups"][0]), int(gpu_groups[p]), (int(pod_node[p]), str(exp["GPUGroups"][0]))
                 if actual < NEW_GPU_GROUP:  # landed on a group of the fixture: it must be the one named
                     if str(actual) != name: errs.append(f"{snap.pod_names[p]}: gpu group {actual} want {name!r}")
@@ -591,7 +601,7 @@ def run_integration(case, run_fn, rounds_after=None, fractions=False):
                     t["State"] = "Running"; t["NodeName"] = node
                 else:
                     t["State"] = st; t["NodeName"] = node
-                if "pod_gpu_portion" in snap.arrays and snap.pod_gpu_portion[p] > 0:  # the shared-GPU group travels with the placed pod (label runai-gpu-group)
+                if "pod_gpu_portion" in snap.arrays and (snap.pod_gpu_portion[p] > 0 or ("pod_gpu_memory" in snap.arrays and snap.pod_gpu_memory[p] > 0)):  # the shared-GPU group travels with the placed pod (label runai-gpu-group)
                     g = int(getattr(res, "gpu_groups", np.full(snap.n_pods, -1))[p])
                     if t["NodeName"] and g >= 0: t["GPUGroups"] = [str(g)]
                     else: t.pop("GPUGroups", None)

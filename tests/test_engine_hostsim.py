@@ -178,9 +178,10 @@ def _same_groups(snap, res, ref):
 
 
 FRAC_GOLD = [(i, c) for i, c in enumerate(T.load_golden("allocate__allocateFractionalGpu")["cases"])]
+MEM_GOLD = [(i, c) for i, c in enumerate(T.load_golden("allocate__allocateGpuMemory")["cases"])]  # allocateGpuMemory_test.go: requests for MiB of one device
 
 
-@pytest.mark.parametrize("i,case", FRAC_GOLD, ids=[f"allocateFractionalGpu[{i}]" for i, _ in FRAC_GOLD])
+@pytest.mark.parametrize("i,case", FRAC_GOLD + MEM_GOLD, ids=[f"allocateFractionalGpu[{i}]" for i, _ in FRAC_GOLD] + [f"allocateGpuMemory[{i}]" for i, _ in MEM_GOLD])
 def test_hostsim_fractional_goldens(i, case):
     """The engine's control flow with the shared-GPU code compiled in (KAI_SHARED_GPUS, host twin) against the oracle and the reference's
     expectations on allocateFractionalGpu_test.go."""
@@ -202,6 +203,26 @@ def test_hostsim_fraction_fuzz(seed):
     if seed % 7 == 0: cfg.plugins &= ~T.abi.PLUGINS["gpusharingorder"]
     ref = T.Oracle.run(snap, cfg, ("allocate",))
     res = HostSim.run(snap, cfg, ("allocate",))
+    assert_same(res, ref, share_tol=1e-9)
+    _same_groups(snap, res, ref)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_hostsim_gpu_memory_fuzz(seed, monkeypatch):
+    """Requests for MiB of one device beside fractions (ABI v5 pod_gpu_memory): what they take on a shared device, their accepted quota
+    (ceil to 1/100 of the device), their weight while pending (memory / MinNodeGPUMemory) — every action, engine twin against the oracle.
+    Even seeds use portions whose quantities are exact in binary; odd seeds use arbitrary ones (0.2, 0.3: 0.3 of a device counts as 0.31) with the
+    harness adding the queue sums in the oracle's order, so that the last bit of a sum of non-integers is not what is compared."""
+    if seed % 2: monkeypatch.setenv("KAI_HOSTSIM_POD_ORDER_SUMS", "1")
+    snap = T.pkg.synth.make_crowded_snapshot(2 + seed % 9, 9900 + seed, fill=0.3 + 0.5 * (seed % 5) / 4, n_pending_jobs=6 + seed % 13, elastic_frac=0.2,
+                                             hog_frac=0.5, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3], cpu_only_frac=0.3 if seed % 4 == 0 else 0.0)
+    T.pkg.synth.add_fractions(snap, seed, frac=0.7, memory_requests=0.5, gpu_memory=(100, 200, 16300)[seed % 3], portions=(0.2, 0.25, 0.3, 0.5, 0.75) if seed % 2 else (0.25, 0.5, 0.75))
+    cfg = T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=(0.0, 0.5, 1.0)[seed % 3])
+    cfg.min_node_gpu_memory = (100, 200, 16300)[seed % 3] if seed % 5 else 100
+    if seed % 3 == 0: cfg.plugins = (cfg.plugins & ~T.abi.PLUGINS["gpupack"]) | T.abi.PLUGINS["gpuspread"]
+    actions = FRAC_ACTS[seed % len(FRAC_ACTS)] if seed % 2 else ("allocate",)
+    ref = T.Oracle.run(snap, cfg, actions)
+    res = HostSim.run(snap, cfg, actions)
     assert_same(res, ref, share_tol=1e-9)
     _same_groups(snap, res, ref)
 

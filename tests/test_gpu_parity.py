@@ -374,8 +374,8 @@ def assert_same_tol(res, ref, tol=1e-9):
 
 
 def _frac_cases():
-    from test_engine_hostsim import FRAC_GOLD, FRAC_VICTIM_GOLD
-    out = [("allocate__allocateFractionalGpu", i, c, ("allocate",)) for i, c in FRAC_GOLD]
+    from test_engine_hostsim import FRAC_GOLD, MEM_GOLD, FRAC_VICTIM_GOLD
+    out = [("allocate__allocateFractionalGpu", i, c, ("allocate",)) for i, c in FRAC_GOLD] + [("allocate__allocateGpuMemory", i, c, ("allocate",)) for i, c in MEM_GOLD]
     return out + [(n, i, c, a) for n, i, c, a in FRAC_VICTIM_GOLD]
 
 
@@ -402,6 +402,24 @@ def test_gpu_fraction_fuzz(gpu, seed):
                                max_consolidation_preemptees=(-1, 16, 2)[seed % 3])
     if seed % 3 == 0: cfg.plugins = (cfg.plugins & ~T.abi.PLUGINS["gpupack"]) | T.abi.PLUGINS["gpuspread"]
     if seed % 7 == 0: cfg.plugins &= ~T.abi.PLUGINS["gpusharingorder"]
+    for acts in (("allocate",), FRAC_ACTS[seed % len(FRAC_ACTS)]):
+        ref = T.Oracle.run(snap, cfg, acts)
+        res = run_gpu(snap, cfg, acts)
+        assert_same_tol(res, ref)
+        _same_groups(snap, res, ref)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_gpu_gpu_memory_fuzz(gpu, seed):
+    """Requests for MiB of one device (ABI v5 pod_gpu_memory) beside fractions and whole GPUs on the device: the memory they take on a shared GPU, their
+    accepted quota (ceil to 1/100 of a device), their weight while pending (memory / MinNodeGPUMemory), the memory term of consolidation's gate."""
+    from test_engine_hostsim import _same_groups, FRAC_ACTS
+    snap = T.pkg.synth.make_crowded_snapshot(2 + seed % 9, 9900 + seed, fill=0.3 + 0.5 * (seed % 5) / 4, n_pending_jobs=6 + seed % 13, elastic_frac=0.2,
+                                             hog_frac=0.5, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3], cpu_only_frac=0.3 if seed % 4 == 0 else 0.0)
+    T.pkg.synth.add_fractions(snap, seed, frac=0.7, memory_requests=(0.5, 1.0)[seed % 2], gpu_memory=(100, 200, 16300)[seed % 3], portions=(0.25, 0.5, 0.75))
+    cfg = T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=(0.0, 0.5, 1.0)[seed % 3])
+    cfg.min_node_gpu_memory = (100, 200, 16300)[seed % 3] if seed % 5 else 100
+    if seed % 3 == 0: cfg.plugins = (cfg.plugins & ~T.abi.PLUGINS["gpupack"]) | T.abi.PLUGINS["gpuspread"]
     for acts in (("allocate",), FRAC_ACTS[seed % len(FRAC_ACTS)]):
         ref = T.Oracle.run(snap, cfg, acts)
         res = run_gpu(snap, cfg, acts)

@@ -305,6 +305,7 @@ def test_fallback_flags_and_config_maps():
     """SURVEY §8b fallback rule + k8s_internal/predicates/config_maps.go (a missing non-optional config map fits no node)."""
     cm_vol = {"volumes": [{"name": "v", "configMap": {"name": "cm1"}}], "containers": [{"name": "c", "volumeMounts": [{"name": "v"}], "resources": {}}]}
     pods = [pod("frac", annotations={"gpu-fraction": "0.5"}), pod("mem", annotations={"gpu-memory": "2000"}), pod("mig", requests={"nvidia.com/mig-1g.5gb": "1"}),
+            pod("multi", annotations={"gpu-fraction": "0.5", "gpu-fraction-num-devices": "2"}), pod("both", annotations={"gpu-fraction": "0.5", "gpu-memory": "2000"}),
             pod("port", spec={"containers": [{"name": "c", "ports": [{"hostPort": 80}]}]}), pod("pvc", spec={"volumes": [{"name": "d", "persistentVolumeClaim": {"claimName": "x"}}]}),
             pod("dra", spec={"resourceClaims": [{"name": "c"}]}), pod("aff", spec={"affinity": {"podAffinity": {}}}), pod("ok"),
             pod("cm-ok", spec=cm_vol), pod("cm-missing", spec=dict(cm_vol, volumes=[{"name": "v", "configMap": {"name": "nope"}}])),
@@ -315,10 +316,13 @@ def test_fallback_flags_and_config_maps():
     s = ingest(doc(nodes=[node("n")], pods=pods, configMaps=[{"metadata": {"name": "cm1", "namespace": "ns"}}])).snapshot
     names = [n.split("/")[1] for n in s.pod_names]
     fl = {n: int(s.pod_flags[i]) for i, n in enumerate(names)}
-    for n in ("frac", "mem", "mig", "port", "pvc", "dra", "aff"):
+    for n in ("multi", "both", "mig", "port", "pvc", "dra", "aff"):
         assert fl[n] & abi.POD_CPU_FALLBACK, n
-    for n in ("ok", "cm-ok", "cm-missing", "foreign", "prio"):
+    for n in ("ok", "cm-ok", "cm-missing", "foreign", "prio", "frac", "mem"):  # a fraction / MiB of ONE device is described to the device (ABI v4 / v5)
         assert not fl[n] & abi.POD_CPU_FALLBACK, n
+    i_mem, i_frac = names.index("mem"), names.index("frac")
+    assert s.pod_gpu_memory[i_mem] == 2000 and s.pod_req[abi.RES_GPU, i_mem] == 0 and s.pod_gpu_portion[i_mem] == 0  # NewGpuResourceRequirementWithGpus(0, memory): GPUs() == 0
+    assert s.pod_gpu_portion[i_frac] == 0.5 and s.pod_gpu_memory[i_frac] == 0
     assert fl["foreign"] & abi.POD_FOREIGN_SCHEDULER and not fl["ok"] & abi.POD_FOREIGN_SCHEDULER
     assert fl["prio"] & abi.POD_HAS_TASK_PRIORITY and s.pod_task_priority[names.index("prio")] == 7
     fits = {n: bool(s.class_fit[s.pod_class[i], s.node_class[0]]) for i, n in enumerate(names)}
@@ -330,7 +334,8 @@ def test_active_gpu_state_and_utility_pods():
     KAI_POD_GPU_UNMODELLED so that kai_session_open can refuse it (api/node_info/node_info.go:457-493 takes a device out of Idle for it);
     (2) kai utility pods (api/pod_info/utility_pods.go:13-33): a reservation pod's own GPU is not booked on its node (node_info.go:465) and neither
     it nor a scale-adjust pod counts as another scheduler's pod (plugins/proportion/proportion.go:276-285)."""
-    pods = [pod("mem", annotations={"gpu-memory": "2000"}, phase="Running", node_name="n"), pod("mig", requests={"nvidia.com/mig-1g.5gb": "1"}, phase="Running", node_name="n"),
+    pods = [pod("mem", annotations={"gpu-memory": "2000"}, phase="Running", node_name="n", labels={"runai-gpu-group": "1"}), pod("mig", requests={"nvidia.com/mig-1g.5gb": "1"}, phase="Running", node_name="n"),
+            pod("multi", annotations={"gpu-fraction": "0.5", "gpu-fraction-num-devices": "2"}, phase="Running", node_name="n"),
             pod("frac", annotations={"gpu-fraction": "0.5"}, phase="Running", node_name="n", labels={"runai-gpu-group": "0"}),
             pod("plain", phase="Running", node_name="n"),
             pod("reservation", phase="Running", node_name="n", labels={"app": "kai-resource-reservation"}, spec={"schedulerName": "default-scheduler"}),
@@ -339,8 +344,9 @@ def test_active_gpu_state_and_utility_pods():
     s = ingest(doc(nodes=[node("n")], pods=pods)).snapshot
     names = [n.split("/")[1] for n in s.pod_names]
     fl = {n: int(s.pod_flags[i]) for i, n in enumerate(names)}
-    assert fl["mem"] & abi.POD_GPU_UNMODELLED and fl["mig"] & abi.POD_GPU_UNMODELLED
-    assert not fl["frac"] & abi.POD_GPU_UNMODELLED and not fl["plain"] & abi.POD_GPU_UNMODELLED  # one fraction of one device is described to the ABI (v4)
+    assert fl["multi"] & abi.POD_GPU_UNMODELLED and fl["mig"] & abi.POD_GPU_UNMODELLED
+    assert not fl["frac"] & abi.POD_GPU_UNMODELLED and not fl["mem"] & abi.POD_GPU_UNMODELLED and not fl["plain"] & abi.POD_GPU_UNMODELLED  # a fraction / MiB of one device is described to the ABI (v4 / v5)
+    assert s.pod_gpu_group[names.index("mem")] == 1 and s.pod_gpu_memory[names.index("mem")] == 2000
     assert fl["foreign"] & abi.POD_FOREIGN_SCHEDULER
     assert not fl["reservation"] & abi.POD_FOREIGN_SCHEDULER and not fl["scaler"] & abi.POD_FOREIGN_SCHEDULER
     gpu = {n: float(s.pod_req[abi.RES_GPU, i]) for i, n in enumerate(names)}
@@ -621,7 +627,7 @@ def test_fraction_fields_and_oracle_placement():
     """gpu-fraction annotation → pod_gpu_portion (pod_info.go:472-477), runai-gpu-group label → pod_gpu_group (numeric names keep their value,
     any other name is numbered from 2^20: plugins/predicates/predicates.go:320-330 takes it for a group being created), nvidia.com/gpu.memory →
     node_gpu_memory floored to 100 (node_info.go:673-687).  The scenario of allocateFractionalGpu_test.go:155-214 through the file format:
-    the pending half-GPU pod joins the running half on the same shared GPU (oracle; such pods still carry KAI_POD_CPU_FALLBACK for the device)."""
+    the pending half-GPU pod joins the running half on the same shared GPU."""
     frac = lambda v: {"annotations": {"gpu-fraction": v}}
     pods = [pod("run", "j0", requests={"cpu": "1"}, phase="Running", node_name="node0", labels={"runai-gpu-group": "1"}, **frac("0.5")),
             pod("uuid", "j2", requests={"cpu": "1"}, phase="Running", node_name="node1", labels={"runai-gpu-group": "6c3e-uuid"}, **frac("0.25")),
@@ -635,8 +641,9 @@ def test_fraction_fields_and_oracle_placement():
     assert [int(s.pod_gpu_group[idx[n]]) for n in ("run", "uuid", "pend", "whole", "multi")] == [1, 1 << 20, -1, -1, -1]
     assert float(s.pod_req[abi.RES_GPU, idx["pend"]]) == 0.5 and float(s.pod_req[abi.RES_GPU, idx["whole"]]) == 1.0
     assert list(s.node_gpu_memory) == [40500, 100]
-    for n in ("run", "uuid", "pend", "multi"):
-        assert s.pod_flags[idx[n]] & abi.POD_CPU_FALLBACK
+    assert s.pod_flags[idx["multi"]] & abi.POD_CPU_FALLBACK  # several devices per pod: the host path's
+    for n in ("run", "uuid", "pend"):
+        assert not s.pod_flags[idx[n]] & abi.POD_CPU_FALLBACK  # a fraction of one device is the device's (shared GPUs, ABI v4)
     # drop the pods the oracle does not model (several devices per pod) and let it place the rest
     nodes[1]["metadata"]["labels"]["nvidia.com/gpu.memory"] = "40537"  # one GPU memory size for the cluster: what the engine twin admits
     keep = doc(nodes=nodes, queues=[queue("q")], pods=[p for p in pods if p["metadata"]["name"] != "multi"], pod_groups=[pod_group(f"j{i}", priorityClassName="p") for i in range(4)],
@@ -646,7 +653,7 @@ def test_fraction_fields_and_oracle_placement():
     i2 = {n.split("/")[1]: i for i, n in enumerate(s2.pod_names)}
     assert res.pod_status[i2["pend"]] == ST["Binding"] and s2.node_names[res.pod_node[i2["pend"]]] == "node0" and res.gpu_groups[i2["pend"]] == 1
     assert res.pod_status[i2["whole"]] == ST["Binding"]
-    # the host-compiled engine (shared-GPU code compiled in) places the same; libkai_core, built without it, refuses such a snapshot
+    # the host-compiled engine places the same (the device: tests/test_gpu_parity.py)
     import test_engine_hostsim as H
     sim = H.HostSim.run(s2, g2.config, ("allocate",))
     assert sim.ops == res.ops and sim.gpu_groups[i2["pend"]] == 1
