@@ -152,7 +152,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         for (int h = 1; h < shape.n_heights; h++) {
             rp.height = h;
             l.plan_rank(std::max(1, (int)((slots + TB - 1) / TB)), TB, c, rp);
-            l.plan_scan(std::max(shape.h_count[h], 1), 64, c, rp);
+            l.plan_scan(std::max(shape.h_count[h], 1), KB_PLAN_SCAN_THREADS, c, rp);  // one workgroup per queue node of this height
         }
         l.plan_emit(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c);
         if (sharded) { rp.start = 0; if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }

@@ -13,6 +13,11 @@ constexpr int KB_INF = 0x7fffffff;
 #define KB_T(var)
 #define KB_ACC(slot, t0)
 #endif
+#if defined(__HIPCC__)
+constexpr int KB_PLAN_SCAN_THREADS = 512;  // workgroup of k_plan_scan (a multiple of 64, at most 1024)
+#else
+constexpr int KB_PLAN_SCAN_THREADS = 128;  // the emulator runs every thread as a fiber: two waves exercise the same code
+#endif
 constexpr int KB_PLACED_MAX = 1024;  // tasks of one gang the fill kernel can roll back (larger chunks do not qualify)
 
 KW_BODY bool kb_is_leaf(const KaiCtx& c, int q) { return q < c.Q && c.q_child_off[q + 1] == c.q_child_off[q]; }
@@ -203,43 +208,79 @@ KW_BODY void kb_plan_rank(const KaiCtx& c, RoundParams rp) {
 // One wavefront per inner node of height rp.height (the virtual root included): shares along its merged stream (segmented scan), its own
 // capacity gate (the first job it turns away ends the node's valid stream: everything after it would be ordered under wrong shares), the
 // stale-path job and the key of the node before each of its pops, as a running maximum.
+// Workgroup-wide scans of the stream of one queue node: thread t of the workgroup holds element base + t.  Per-wave scans, the waves' totals (or last
+// keys) through LDS, one barrier pair per batch of scans.
+struct PlanScanLds { double tot[6][16]; PlanKey wkey[16]; int32_t wvalid[16]; int32_t wbad[16]; };
+template <int NV>
+KW_BODY void kb_block_scan_add(PlanScanLds& L, const double* d, double* incl, double* total) {  // NV independent inclusive sums over the workgroup's threads
+    const int w = kw::tid() >> 6, nw = kw::bdim() >> 6, lane = kw::lane();
+    for (int k = 0; k < NV; k++) { incl[k] = kw::wave_scan_add(d[k]); if (lane == 63) L.tot[k][w] = incl[k]; }
+    kw::sync();
+    for (int k = 0; k < NV; k++) { double pre = 0, tot = 0; for (int i = 0; i < nw; i++) { const double v = L.tot[k][i]; if (i < w) pre += v; tot += v; } incl[k] += pre; total[k] = tot; }
+    kw::sync();  // the totals are read: the next batch may overwrite them
+}
+KW_BODY PlanKey kb_block_scan_max(PlanScanLds& L, PlanKey v, bool valid, PlanKey carry, bool have_carry, PlanKey& last) {  // inclusive running maximum, seeded with carry; last = its value at the last thread
+    const int w = kw::tid() >> 6, nw = kw::bdim() >> 6, lane = kw::lane();
+    PlanKey none; none.w0 = none.w1 = none.w2 = none.w3 = 0;
+    v = kb_wave_scan_max(v, valid, none, false);
+    const uint64_t anyv = kw::ballot(valid);
+    const bool mine = anyv && lane >= __builtin_ctzll(anyv ? anyv : 1);  // lanes from the wave's first valid element on hold a maximum
+    if (lane == 63) { L.wkey[w] = v; L.wvalid[w] = anyv ? 1 : 0; }
+    kw::sync();
+    PlanKey pre = carry; bool have = have_carry;
+    for (int i = 0; i < w; i++) if (L.wvalid[i]) { const PlanKey o = L.wkey[i]; if (!have || pk_less(pre, o)) { pre = o; have = true; } }
+    PlanKey out = v; bool ov = mine;
+    if (have && (!ov || pk_less(out, pre))) { out = pre; ov = true; }
+    PlanKey fin = carry; bool hf = have_carry;
+    for (int i = 0; i < nw; i++) if (L.wvalid[i]) { const PlanKey o = L.wkey[i]; if (!hf || pk_less(fin, o)) { fin = o; hf = true; } }
+    last = fin;
+    kw::sync();
+    return out;
+}
+// One WORKGROUP per queue node of height rp.height (the streams of the top levels hold tens of thousands of elements).
 KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
     const BatchCtx& b = c.bt;
-    const int idx = b.h_off[rp.height] + kw::bid() * (kw::bdim() >> 6) + (kw::tid() >> 6), lane = kw::lane();
-    if (idx >= b.h_off[rp.height + 1]) return;
+    KW_SHARED PlanScanLds L; KW_SHARED int32_t s_sum; KW_SHARED int32_t s_incomplete;
+    const int idx = b.h_off[rp.height] + kw::bid(), lane = kw::lane(), tid = kw::tid(), T = kw::bdim(), w = tid >> 6, nw = T >> 6;
+    if (idx >= b.h_off[rp.height + 1]) return;  // the same for the whole workgroup
     const int x = b.h_nodes[idx];
-    int sumV = 0, compl_all = 1;
-    for (int k = c.q_child_off[x] + lane; k < c.q_child_off[x + 1]; k += 64) { const int s = c.q_children[k]; sumV += b.q_valid[s]; if (!b.q_complete[s]) compl_all = 0; }
-    sumV = kw::shfl(kw::wave_scan_add(sumV), 63);
-    compl_all = kw::ballot(!compl_all) ? 0 : 1;
+    if (tid == 0) { s_sum = 0; s_incomplete = 0; }
+    kw::sync();
+    { int sv = 0, inc = 0;
+      for (int k = c.q_child_off[x] + tid; k < c.q_child_off[x + 1]; k += T) { const int s = c.q_children[k]; sv += b.q_valid[s]; if (!b.q_complete[s]) inc = 1; }
+      if (sv) kw::atomic_add(&s_sum, sv); if (inc) kw::atomic_add(&s_incomplete, 1); }
+    kw::sync();
+    const int sumV = s_sum; const int compl_all = s_incomplete ? 0 : 1;
     int V = b.q_sent[x] < sumV ? b.q_sent[x] : sumV;
     const int eb = b.q_ebase[x], kb = b.q_kbase[x];
-    if (x == c.Q) { if (lane == 0) { b.q_valid[x] = V; b.q_complete[x] = (compl_all && V == sumV) ? 1 : 0; b.q_nk[x] = 0; } return; }
+    if (x == c.Q) { if (tid == 0) { b.q_valid[x] = V; b.q_complete[x] = (compl_all && V == sumV) ? 1 : 0; b.q_nk[x] = 0; } return; }
     double alloc0[3], anp0[3];
     for (int k = 0; k < 3; k++) { alloc0[k] = c.q_share[(size_t)x * 3 + k].allocated; anp0[k] = c.q_share[(size_t)x * 3 + k].allocated_np; }
     // pass 1: the node's own gate along the stream; stops at the first job it turns away
     {
         double alloc[3] = {alloc0[0], alloc0[1], alloc0[2]}, anp[3] = {anp0[0], anp0[1], anp0[2]};
-        for (int base = 0; base < V; base += 64) {
-            const int t = base + lane; const bool is_elem = t < V;
+        for (int base = 0; base < V; base += T) {
+            const int t = base + tid; const bool is_elem = t < V;
             const int e = is_elem ? b.el_leaf[eb + t] : -1, job = e >= 0 ? b.e_job[e] : -1; const int flag = e >= 0 ? b.e_flag[e] : BF_GATE;
             double res[3] = {0, 0, 0}; bool np = false;
             if (job >= 0) { for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k]; np = !c.j_preempt[job]; }
-            double ab[3], abn[3], tot[3], totn[3];
-            for (int k = 0; k < 3; k++) {
-                const double d = flag == BF_OK ? res[k] : 0.0, dn = (flag == BF_OK && np) ? res[k] : 0.0;
-                const double s = kw::wave_scan_add(d), sn = kw::wave_scan_add(dn);
-                ab[k] = alloc[k] + (s - d); abn[k] = anp[k] + (sn - dn); tot[k] = kw::shfl(s, 63); totn[k] = kw::shfl(sn, 63);
-            }
+            double d[6], incl[6], tot[6];
+            for (int k = 0; k < 3; k++) { d[k] = flag == BF_OK ? res[k] : 0.0; d[3 + k] = (flag == BF_OK && np) ? res[k] : 0.0; }
+            kb_block_scan_add<6>(L, d, incl, tot);
+            double ab[3], abn[3];
+            for (int k = 0; k < 3; k++) { ab[k] = alloc[k] + (incl[k] - d[k]); abn[k] = anp[k] + (incl[3 + k] - d[3 + k]); }
             const bool gate = is_elem && flag != BF_GATE && plan_gate_fails(c, x, ab, abn, res, np);
-            const uint64_t bad = kw::ballot(gate && flag == BF_OK);
-            const int f = bad ? __builtin_ctzll(bad) : 64;
-            if (gate && lane <= f) b.e_flag[e] = BF_GATE;  // lanes before f hold exact shares: a dead job turned away here counts as a gate failure
-            if (bad) { V = base + f + 1; break; }
-            for (int k = 0; k < 3; k++) { alloc[k] += tot[k]; anp[k] += totn[k]; }
+            const uint64_t badw = kw::ballot(gate && flag == BF_OK);
+            if (lane == 0) L.wbad[w] = badw ? (w << 6) + __builtin_ctzll(badw) : 0x7fffffff;
+            kw::sync();
+            int f = 0x7fffffff; for (int i = 0; i < nw; i++) if (L.wbad[i] < f) f = L.wbad[i];
+            kw::sync();
+            if (gate && tid <= f) b.e_flag[e] = BF_GATE;  // threads before f hold exact shares: a dead job turned away here counts as a gate failure
+            if (f != 0x7fffffff) { V = base + f + 1; break; }
+            for (int k = 0; k < 3; k++) { alloc[k] += tot[k]; anp[k] += tot[3 + k]; }
         }
     }
-    kw::fence();
+    kw::fence(); kw::sync();
     const bool complete = compl_all && V == sumV;
     const int nk = complete ? V : V + 1;
     const int srank = b.q_srank[x], cs = b.cur_sp[x];
@@ -248,13 +289,15 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
     {
         double alloc[3] = {alloc0[0], alloc0[1], alloc0[2]};
         PlanKey run; run.w0 = run.w1 = run.w2 = run.w3 = 0; bool have_run = false;
-        for (int base = 0; base < nk; base += 64) {
-            const int t = base + lane; const bool is_elem = t < V, is_key = t < nk;
+        for (int base = 0; base < nk; base += T) {
+            const int t = base + tid; const bool is_elem = t < V, is_key = t < nk;
             const int e = is_elem ? b.el_leaf[eb + t] : -1, job = e >= 0 ? b.e_job[e] : -1; const int flag = e >= 0 ? b.e_flag[e] : BF_GATE;
             double res[3] = {0, 0, 0};
             if (job >= 0) for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k];
-            double ab[3], tot[3];
-            for (int k = 0; k < 3; k++) { const double d = flag == BF_OK ? res[k] : 0.0; const double s = kw::wave_scan_add(d); ab[k] = alloc[k] + (s - d); tot[k] = kw::shfl(s, 63); }
+            double d[3], incl[3], tot[3];
+            for (int k = 0; k < 3; k++) d[k] = flag == BF_OK ? res[k] : 0.0;
+            kb_block_scan_add<3>(L, d, incl, tot);
+            double ab[3]; for (int k = 0; k < 3; k++) ab[k] = alloc[k] + (incl[k] - d[k]);
             int spj = -1;
             if (is_key) {
                 if (t == 0) spj = cs >= 0 ? cs : b.sp[b.el_ck[eb] - 1];
@@ -265,15 +308,15 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
             if (spj >= 0) for (int k = 0; k < 3; k++) rq[k] = c.j_tta_res[(size_t)spj * 4 + k];
             PlanKey key; key.w0 = key.w1 = key.w2 = key.w3 = 0;
             if (is_key) key = plan_key(c, x, ab, rq, t0, t1, t2, srank);
-            key = kb_wave_scan_max(key, is_key, run, have_run);
+            PlanKey last;
+            key = kb_block_scan_max(L, key, is_key, run, have_run, last);
             if (is_key) { b.pk[kb + t] = key; b.sp[kb + t] = spj; b.k_owner[kb + t] = x; }
-            run.w0 = kw::shfl(key.w0, 63); run.w1 = kw::shfl(key.w1, 63); run.w2 = kw::shfl(key.w2, 63); run.w3 = kw::shfl(key.w3, 63); have_run = true;
+            run = last; have_run = true;
             for (int k = 0; k < 3; k++) alloc[k] += tot[k];
         }
     }
-    if (lane == 0) { b.q_valid[x] = V; b.q_nk[x] = nk; b.q_complete[x] = complete ? 1 : 0; }
+    if (tid == 0) { b.q_valid[x] = V; b.q_nk[x] = nk; b.q_complete[x] = complete ? 1 : 0; }
 }
-
 // the planned global order: one thread per position of the virtual root's valid stream
 KW_BODY void kb_plan_emit(const KaiCtx& c) {
     const BatchCtx& b = c.bt;
@@ -762,7 +805,7 @@ __global__ void k_batch_nrec(KaiCtx c) { kb_build_nrec(c); }
 __global__ void k_plan_setup(KaiCtx c, RoundParams rp) { kb_plan_setup(c, rp); }
 __global__ void k_plan_leaf(KaiCtx c, RoundParams rp) { kb_plan_leaf(c, rp); }
 __global__ void k_plan_rank(KaiCtx c, RoundParams rp) { kb_plan_rank(c, rp); }
-__global__ void k_plan_scan(KaiCtx c, RoundParams rp) { kb_plan_scan(c, rp); }
+__global__ void __launch_bounds__(1024) k_plan_scan(KaiCtx c, RoundParams rp) { kb_plan_scan(c, rp); }
 __global__ void k_plan_emit(KaiCtx c) { kb_plan_emit(c); }
 __global__ void __launch_bounds__(64) k_fill(KaiCtx c, RoundParams rp, int l1_in_lds) { kb_fill(c, rp, l1_in_lds); }
 __global__ void k_apply_jobs(KaiCtx c, long long ops_base, long long stmt_base) { kb_apply_jobs(c, (int64_t)ops_base, (int64_t)stmt_base); }
