@@ -145,6 +145,7 @@ def main():
         alg_bytes_launch = fill_dec * b_dec / max(rounds, 1); avg_launch_ms = fill_ms / max(rounds, 1)
         achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(desc, "k_fill"),
+                "traffic_source": "static: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE of k_fill from committed rocprofv3 --pmc passes of this command (counters need their own passes; not collected in this run)",
                 "kernel": "k_fill", "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "other_kernels": {"plan (k_plan_leaf / rank / scan / emit)": {"ms_per_step": plan_ms}, "apply (k_apply_jobs / nodes)": {"ms_per_step": apply_ms},
                                   "k_drain": {"decisions": drained, "note": "jobs popped after no class fits anywhere: resolved chip-wide without touching a node; NOT counted in this roofline"}},
