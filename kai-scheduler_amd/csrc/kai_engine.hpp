@@ -157,7 +157,7 @@ struct EngineState {  // mutable scalars of the running action
     int64_t index_queries, index_refreshes, drained_jobs, drained_decisions;
     int64_t scenarios, simulations, scenarios_filtered;  // victim search (actions/common/solvers)
     int64_t non_allocate_commits;  // evictions / pipelines committed by this action: from then on something is releasing or pipelined in the session
-    int64_t prof[16];         // control-lane cycles per phase, see PF_*
+    int64_t prof[24];         // control-lane cycles per phase, see PF_* (16..23: victim search, -DKAI_PROF_VICTIM)
     double total[3];          // proportion totalResource (CPU, Memory, GPU)
 };
 enum { PF_POP = 0, PF_ALLOC = 2, PF_FINISH = 3, PF_DRAINCHK = 4, PF_INIT = 5, PF_TOTAL = 7, PF_TTA = 8, PF_GATE = 9, PF_TASKCAP = 10, PF_FIND = 11,
@@ -675,7 +675,7 @@ KAI_HD int stage_job_lane(const KaiCtx& c, int j, FastFrame& f, JobPf& out, int 
 // global read-modify-write each otherwise) and written to EngineState once, when the action ends.
 struct EngineHot {
     int64_t decisions, index_queries, index_refreshes, rollbacks, jobs_attempted, jobs_committed, out_len, stmts;
-    int64_t prof[16];
+    int64_t prof[24];
 };
 struct EngineLocal {
     EngineHot h;
@@ -1817,7 +1817,13 @@ struct Engine {
             KAI_GP(int32_t) sets = c.ns_sets + (size_t)depth * DT1;
             if (f.n_sets < 0) {  // first visit: SubsetNodesFn for this sub-group
                 int topo = f.kind ? c.s_topo[f.id] : c.g_topo[f.id], req = f.kind ? c.s_req[f.id] : c.g_req[f.id], pref = f.kind ? c.s_pref[f.id] : c.g_pref[f.id];
+#ifdef KAI_PROF_VICTIM
+                const int64_t tsn0 = be.clock();
+#endif
                 f.n_sets = subset_nodes(j, f.kind ? -(f.id + 1) : f.id, topo, req, pref, f.kind ? -1 : f.id, f.kind ? f.id : -1, chunk, nt, el_parent_bits(depth), sets);
+#ifdef KAI_PROF_VICTIM
+                el().h.prof[20] += be.clock() - tsn0;
+#endif
                 f.cur = -1; ret = -1;
             }
             if (ret == 1) { ret = -1; }                       // a child succeeded: continue with the next child of this frame
@@ -2095,13 +2101,13 @@ struct Engine {
         EngineHot& h = el().h; const EngineState& st = *cx().st;
         h.decisions = st.decisions; h.index_queries = st.index_queries; h.index_refreshes = st.index_refreshes; h.rollbacks = st.rollbacks;
         h.jobs_attempted = st.jobs_attempted; h.jobs_committed = st.jobs_committed; h.out_len = st.out_len; h.stmts = st.stmts;
-        for (int i = 0; i < 16; i++) h.prof[i] = st.prof[i];
+        for (int i = 0; i < 24; i++) h.prof[i] = st.prof[i];
     }
     KAI_HD void hot_end() {
         const EngineHot& h = el().h; EngineState& st = *cx().st;
         st.decisions = h.decisions; st.index_queries = h.index_queries; st.index_refreshes = h.index_refreshes; st.rollbacks = h.rollbacks;
         st.jobs_attempted = h.jobs_attempted; st.jobs_committed = h.jobs_committed; st.out_len = h.out_len; st.stmts = h.stmts;
-        for (int i = 0; i < 16; i++) st.prof[i] = h.prof[i];
+        for (int i = 0; i < 24; i++) st.prof[i] = h.prof[i];
     }
     KAI_HD void execute_allocate() { hot_begin(); execute_allocate_impl(); hot_end(); }
     KAI_HD void execute_allocate_impl() {  // actions/allocate/allocate.go:46-77
