@@ -324,7 +324,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
       TRY(dupload(core, &t, prep.h_nodes.data(), prep.h_nodes.size())); core->d_h_nodes = const_cast<int32_t*>(t); }
     // ---- scan classes + class index
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64;
-    c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok; core->fast_ok0 = prep.fast_ok;
+    c.use_index = c.C > 0 ? 1 : 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok; core->fast_ok0 = prep.fast_ok; c.exact_sums = prep.exact_sums;
     { int d = core->cfg.queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
     c.action = KAI_ACTION_ALLOCATE; c.max_consolidation_preemptees = core->cfg.max_consolidation_preemptees; c.allow_consolidating_reclaim = core->cfg.allow_consolidating_reclaim;
     c.saturation_multiplier = core->cfg.reclaimer_saturation_multiplier; c.sv = SolverCtx{}; core->solver_ready = false;

@@ -319,11 +319,28 @@ struct KaiCtx {
     KAI_GP(int32_t) next_new_group;       // [1] uuid.NewUUID() of findGpuForSharingOnNode
     int32_t shared_on, pad_sh;
 #endif
+    int32_t exact_sums, pad_es;  // HostPrep::exact_sums: integral quantities with totals below 2^52 units — parallel sums of them are exact
 };
 
 // ======================================================================================================
 // per-node arithmetic shared by every scanner
 // ======================================================================================================
+// The node loops of the topology plugin's subSetNodesFn (plugins/topology/job_filtering.go) as one request to the backend's scan lanes: Backend::topo_scan
+// returns false when it has none (the engine then walks the nodes itself).
+constexpr int KAI_TOPO_SCAN_LEVELS = 8;
+struct TopoScan {
+    int32_t op;          // 1 = per level the smallest / largest domain id over the nodes of `parent` that are part of the topology (lowestCommonDomainID, common.go:17-67)
+                         // 2 = Idle + Releasing of the nodes of `domain` summed into their leaf domains (calcSubTreeFreeResources :192-211; integral quantities: the order
+                         //     of addition does not show)   3 = pods of the maximal request every node of `domain` takes, summed per leaf domain (calcNodeAccommodation :213-246)
+    int32_t row0, L, domain, root, dl, R, tasks, one_pod, any;
+    double mx[KAI_MAX_RES];
+    KAI_GP(const uint32_t) parent;
+    int32_t lvl_min[KAI_TOPO_SCAN_LEVELS], lvl_max[KAI_TOPO_SCAN_LEVELS];  // results of op 1 (any = some node qualified)
+};
+KAI_HD bool topo_node_in_domain(const KaiCtx& c, const TopoScan& t, int n) {
+    if (t.L <= 0) return false;
+    return t.domain == t.root ? c.node_domain[(size_t)t.row0 * c.N + n] >= 0 : c.node_domain[(size_t)(t.row0 + t.dl) * c.N + n] == t.domain;
+}
 struct ScanReq {
     int32_t pod, cpu_only, best_effort, pod_class, nominated, r_place, strategy, pad;
     double req[KAI_MAX_RES];
@@ -659,6 +676,7 @@ KAI_HD int stage_job_lane(const KaiCtx& c, int j, FastFrame& f, JobPf& out, int 
 // ======================================================================================================
 // Engine<Backend>: the control flow.  Backend provides
 //    void minmax(const KaiCtx&, int r, double& mn, double& mx)          — pack.go:66-86 over the node set (brute force)
+//    bool topo_scan(const KaiCtx&, TopoScan&)                           — the node loops of subSetNodesFn on the scan lanes; false = the backend has none
 //    int  best_node(const KaiCtx&, const ScanReq&)                      — arg-max of (score, -index) over fitting nodes (brute force)
 //    void begin(const KaiCtx&)                                          — build the in-LDS levels of the class index
 //    bool dirty_add(int block) / int dirty_count()                      — list of 64-node blocks whose node state changed
@@ -1618,7 +1636,16 @@ struct Engine {
         const int t = tc_topo, row0 = c.topo_level_off[t], L = c.topo_level_off[t + 1] - row0, N = c.N, DT = c.D + c.T, root = c.D + t, R = c.R;
         // lowestCommonDomainID (common.go:17-67) over the nodes of `parent` that are part of the topology
         int domain = root;
-        for (int l = 0; l < L; l++) {
+        TopoScan ts; ts.op = 1; ts.row0 = row0; ts.L = L; ts.domain = root; ts.root = root; ts.dl = 0; ts.R = R; ts.tasks = tasks; ts.one_pod = 0; ts.any = 0; ts.parent = parent;
+        for (int r = 0; r < KAI_MAX_RES; r++) ts.mx[r] = 0;
+        const bool scan_lanes = L <= KAI_TOPO_SCAN_LEVELS && c.exact_sums && be.topo_scan(c, ts);
+        if (scan_lanes) {
+            for (int l = 0; l < L; l++) {
+                if (!ts.any || ts.lvl_min[l] != ts.lvl_max[l]) break;
+                domain = ts.lvl_min[l];
+                if (tc_pref == l) break;
+            }
+        } else for (int l = 0; l < L; l++) {
             int v = -2; bool all = true;
             for (int n = 0; n < N && all; n++) {
                 if (!bits_has(parent, n) || node_dom(row0, n) < 0) continue;
@@ -1633,7 +1660,8 @@ struct Engine {
         // treeAllocatableCleanup :438-445 + calcSubTreeFreeResources :192-211 (leaf accumulation, then bottom-up inside the sub-tree)
         for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t) { c.dom_alloc_pods[d] = -1; for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = 0.0; }
         auto node_in_domain = [&](int n) { return L > 0 && (domain == root ? node_dom(row0, n) >= 0 : node_dom(row0 + dl, n) == domain); };
-        for (int n = 0; n < N; n++) {
+        ts.op = 2; ts.domain = domain; ts.dl = dl;
+        if (!(scan_lanes && be.topo_scan(c, ts))) for (int n = 0; n < N; n++) {
             if (!node_in_domain(n)) continue;
             int leaf = node_dom(row0 + L - 1, n);
             for (int r = 0; r < R; r++) { size_t x = (size_t)leaf * KAI_MAX_RES + r; c.dom_free[x] += c.n_idle[(size_t)r * N + n]; c.dom_free[x] += c.n_rel[(size_t)r * N + n]; }
@@ -1657,7 +1685,8 @@ struct Engine {
             bool one_pod_only = !(mx[KAI_RES_CPU] > 0) && !(mx[KAI_RES_MEM] > 0) && !(mx[KAI_RES_GPU] > 0) && mx[KAI_RES_PODS] <= 1;
             for (int r = KAI_RES_PODS + 1; r < R; r++) if (mx[r] > 0) one_pod_only = false;
             for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t && dom_in_subtree(d, domain)) c.dom_alloc_pods[d] = 0;
-            for (int n = 0; n < N; n++) {
+            ts.op = 3; ts.one_pod = one_pod_only ? 1 : 0; for (int r = 0; r < KAI_MAX_RES; r++) ts.mx[r] = mx[r];
+            if (!(scan_lanes && be.topo_scan(c, ts))) for (int n = 0; n < N; n++) {
                 if (!node_in_domain(n)) continue;
                 int count = 0;
                 if (one_pod_only) count = tasks;

@@ -72,7 +72,7 @@ struct HostPrep {
     // batch path (kai_batch.hpp): queue nodes by height (leaf = 0, the virtual root at index Q on top), and whether the snapshot's quantities add
     // exactly in any order (the batch path sums shares and node accounting in parallel)
     struct BatchShape { int n_leaves = 0, n_heights = 0; std::vector<int> h_count; };
-    std::vector<int32_t> q_height, h_off, h_nodes; int n_heights = 0, batch_ok = 0; BatchShape shape;
+    std::vector<int32_t> q_height, h_off, h_nodes; int n_heights = 0, batch_ok = 0, exact_sums = 0; BatchShape shape;  // exact_sums: sums of node / pod quantities do not depend on the order of addition
 
     // returns 0 or KAI_ERR_INVALID_ARG with err set
     int build(const kai_config& cfg, const kai_snapshot_soa* s, std::string& err) {
@@ -192,21 +192,22 @@ struct HostPrep {
         { std::vector<int32_t> fill(h_off.begin(), h_off.end() - 1); for (int q = 0; q <= Q; q++) h_nodes[fill[q_height[q]]++] = q; }
         for (int q = 0; q < Q; q++) if (child_off[q + 1] == child_off[q]) shape.n_leaves++;
         // exact sums: per resource every quantity is a non-negative integer multiple of one power of two, and the totals stay below 2^53 units
-        batch_ok = cfg.engine_mode == 0 && R <= 4 && n_heights <= 16;
-        for (int r = 0; r < R && batch_ok; r++) {
+        exact_sums = 1;
+        for (int r = 0; r < R && exact_sums; r++) {
             uint64_t bits = 0; bool ok = true;
             auto take = [&](double v) { if (!(v >= 0) || v != std::floor(v) || v >= 9.2e18) { ok = false; return; } bits |= (uint64_t)v; };
             for (int n = 0; n < N && ok; n++) take(s->node_allocatable[(size_t)r * N + n]);
             for (int p = 0; p < P && ok; p++) take(s->pod_req[(size_t)r * P + p]);
-            if (!ok) { batch_ok = 0; break; }
+            if (!ok) { exact_sums = 0; break; }
             if (!bits) continue;
             const int tz = __builtin_ctzll(bits);
             unsigned __int128 sum_nodes = 0, sum_pods = 0;
             for (int n = 0; n < N; n++) sum_nodes += (uint64_t)s->node_allocatable[(size_t)r * N + n] >> tz;
             for (int p = 0; p < P; p++) sum_pods += (uint64_t)s->pod_req[(size_t)r * P + p] >> tz;
             const unsigned __int128 lim = (unsigned __int128)1 << 52;
-            if (sum_nodes >= lim || sum_pods >= lim) batch_ok = 0;
+            if (sum_nodes >= lim || sum_pods >= lim) exact_sums = 0;
         }
+        batch_ok = cfg.engine_mode == 0 && R <= 4 && n_heights <= 16 && exact_sums;
     }
 
     // Topology domain tree and sub-group tree in the engine's indexing (plugins/topology/topology_plugin.go:57-110,

@@ -236,6 +236,7 @@ struct NullBackend {  // kernels that only need the engine's pure helpers
     __device__ const KaiCtx& ctx() const { return *cref; }
     __device__ EngineLocal& local() { return loc; }
     __device__ void minmax(const KaiCtx&, int, double&, double&) {}
+    __device__ bool topo_scan(const KaiCtx&, TopoScan&) { return false; }
     __device__ int best_node(const KaiCtx&, const ScanReq&) { return -1; }
     __device__ void begin(const KaiCtx&) {}
     __device__ bool dirty_add(int) { return true; }
@@ -296,7 +297,7 @@ __global__ void k_leaf_init(KaiCtx c) {
 // ------------------------------------------------------------------------------------------------------
 // the persistent action kernel
 // ------------------------------------------------------------------------------------------------------
-enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5, CMD_LOADTREE = 6, CMD_STAGE = 7 };
+enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5, CMD_LOADTREE = 6, CMD_STAGE = 7, CMD_TOPO = 8 };
 
 // dynamic LDS of k_action / k_best_node: [s2_key C*NSB u64][s2_node C*NSB i32] and, when tree_in_lds, [QNode Q][qheap Q+1][root_heap Q+1]
 extern __shared__ __align__(16) unsigned char kai_dyn_lds[];
@@ -305,6 +306,7 @@ __host__ __device__ inline size_t lds_tree_bytes(int Q) { return (size_t)Q * siz
 
 struct ActShared {
     ScanReq req;
+    TopoScan topo; int32_t topo_min[WAVES][KAI_TOPO_SCAN_LEVELS], topo_max[WAVES][KAI_TOPO_SCAN_LEVELS], topo_any[WAVES];  // CMD_TOPO request and the waves' partial results
     int32_t cmd, r, n_dirty, pad0;
     int32_t dirty[KAI_MAXD];
     double part_min[WAVES], part_max[WAVES];
@@ -372,6 +374,16 @@ struct DevBackendT {
         double lo = 1.7976931348623157e308, hi = 0;  // math.MaxFloat64, 0 (plugins/nodeplacement/pack.go:66-68)
         for (int w = 1; w < WAVES; w++) { if (sh->part_min[w] < lo) lo = sh->part_min[w]; if (sh->part_max[w] > hi) hi = sh->part_max[w]; }
         mn = lo; mx = hi;
+    }
+    __device__ bool topo_scan(const KaiCtx&, TopoScan& t) {
+        sh->topo = t; call(CMD_TOPO);
+        if (t.op == 1) {
+            int any = 0;
+            for (int l = 0; l < t.L; l++) { int mn = 0x7fffffff, mx = -0x7fffffff - 1; for (int w = 1; w < WAVES; w++) { if (sh->topo_min[w][l] < mn) mn = sh->topo_min[w][l]; if (sh->topo_max[w][l] > mx) mx = sh->topo_max[w][l]; } t.lvl_min[l] = mn; t.lvl_max[l] = mx; }
+            for (int w = 1; w < WAVES; w++) any |= sh->topo_any[w];
+            t.any = any;
+        }
+        return true;
     }
     __device__ int best_node(const KaiCtx&, const ScanReq& q) {
         scope(); sh->req = q; call(CMD_BEST);
@@ -521,6 +533,40 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
             }
             for (int o = 32; o > 0; o >>= 1) { double a = __shfl_xor(lo, o, 64), b = __shfl_xor(hi, o, 64); if (a < lo) lo = a; if (b > hi) hi = b; }
             if (lane == 0) { sh->part_min[wave] = lo; sh->part_max[wave] = hi; }
+        } else if (cmd == CMD_TOPO) {  // the node loops of subSetNodesFn (kai_engine.hpp subset_nodes)
+            const TopoScan t = sh->topo;
+            if (t.op == 1) {
+                int mn[KAI_TOPO_SCAN_LEVELS], mx[KAI_TOPO_SCAN_LEVELS]; int any = 0;
+                for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { mn[l] = 0x7fffffff; mx[l] = -0x7fffffff - 1; }
+                for (int n = slot; n < c.N; n += SCAN_LANES) {
+                    if (t.parent && !((t.parent[n >> 5] >> (n & 31)) & 1)) continue;
+                    if (c.node_domain[(size_t)t.row0 * c.N + n] < 0) continue;
+                    any = 1;
+                    for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) if (l < t.L) { const int dd = c.node_domain[(size_t)(t.row0 + l) * c.N + n]; if (dd < mn[l]) mn[l] = dd; if (dd > mx[l]) mx[l] = dd; }
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    any |= __shfl_xor(any, o, 64);
+                    for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { const int a = __shfl_xor(mn[l], o, 64), b = __shfl_xor(mx[l], o, 64); if (a < mn[l]) mn[l] = a; if (b > mx[l]) mx[l] = b; }
+                }
+                if (lane == 0) { for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { sh->topo_min[wave][l] = mn[l]; sh->topo_max[wave][l] = mx[l]; } sh->topo_any[wave] = any; }
+            } else {
+                for (int n = slot; n < c.N; n += SCAN_LANES) {
+                    if (!topo_node_in_domain(c, t, n)) continue;
+                    const int leaf = c.node_domain[(size_t)(t.row0 + t.L - 1) * c.N + n];
+                    if (t.op == 2) {
+                        for (int r = 0; r < t.R; r++) { double* x = (double*)&c.dom_free[(size_t)leaf * KAI_MAX_RES + r]; atomicAdd(x, c.n_idle[(size_t)r * c.N + n]); atomicAdd(x, c.n_rel[(size_t)r * c.N + n]); }
+                    } else {
+                        int count = 0;
+                        if (t.one_pod) count = t.tasks;
+                        else {
+                            double cur[KAI_MAX_RES]; for (int r = 0; r < KAI_MAX_RES; r++) cur[r] = t.mx[r];  // k-th test pod = k x the maximal pod, by repeated addition
+                            for (;;) { if (!fits(c, cur, n, true)) break; count++; for (int r = 0; r < t.R; r++) cur[r] += t.mx[r]; }
+                        }
+                        if (count) atomicAdd((int*)&c.dom_alloc_pods[leaf], count);
+                    }
+                }
+                __threadfence();
+            }
         } else if (cmd == CMD_BEST) {  // OrderedNodesByTask + FittingNode collapsed to an arg-max (framework/session.go:201-264, 466-485)
             const ScanReq& q = sh->req;
             int best = -1; unsigned long long bk = 0;

@@ -30,6 +30,7 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     const KaiCtx& ctx() const { return *cref; }
     EngineLocal& local() { return loc; }
     std::vector<uint64_t> s2_key, top_key; std::vector<int32_t> s2_node, top_node;
+    bool topo_scan(const KaiCtx&, TopoScan&) { return false; }
     void minmax(const KaiCtx& c, int r, double& mn, double& mx) {
         double lo = 1.7976931348623157e308, hi = 0;
         for (int n = 0; n < c.N; n++) {
@@ -173,7 +174,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     else c.class_fit = copy(pool, &one, 1);
     c.j_pods_sorted = copy(pool, prep.sorted.data(), P); c.q_child_off = copy(pool, prep.child_off.data(), Q + 2); c.q_children = copy(pool, prep.children.data(), std::max(Q, 1));
     c.q_job_off = copy(pool, prep.job_off.data(), Q + 1); c.jobs_static = copy(pool, prep.jobs_static.data(), std::max(J, 1)); c.q_depth_order = copy(pool, prep.depth_order.data(), Q);
-    c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64; c.use_index = c.C > 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok;
+    c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64; c.use_index = c.C > 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok; c.exact_sums = prep.exact_sums;
     if (shared) { c.use_index = 0; c.all_tracked = 0; c.fast_ok = 0; }  // every scan by brute force: the class keys know neither fractions nor the gpusharingorder score
     { int d = cfg->queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
     c.cls = copy(pool, prep.classes.data(), prep.classes.size());
