@@ -192,6 +192,8 @@ struct SolverCtx {
                                                       // simulation queues start from it), and the jobs a simulation takes out of it because their state is in flux
     int32_t *mjr_q, *mjr_job;                         // [J] MinimalJobRepresentatives: (queue or -1, representative job) per signature met so far
     double *rc_rem, *rc_ent; int32_t* rc_ent_q; uint8_t *rc_has, *rc_inv;  // reclaimable validator scratch
+    int32_t *job_head, *job_tail, *grp_link, *sc_jobs, *sc_jobs_n;  // [J+1] x 2, [P+2], [P+1], [1]: the scenario's task groups chained per job in the order they were added, and its distinct
+                                                      // victim jobs in ascending index (what the validators range: kai_engine_solver.inc grp_add / scenario_jobs)
     uint8_t *q_total, *q_relc, *q_pruned;             // [Q+1] simulation queues without bystander subtrees (kai_engine_solver.inc sim_prune): the sibling order below this node is a strict total order /
                                                       // children with relevant jobs below them in this simulation / subtree left out of this simulation's queue
     int32_t P_cap;
@@ -211,6 +213,7 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     add(sizeof(double) * (DT + 1)); add(sizeof(double) * (G + 1)); add(sizeof(double) * (DT + 1)); add(sizeof(int32_t) * (DT + 1)); add(sizeof(int32_t) * (TL + 2)); add(sizeof(int32_t) * (TL + 1)); add(sizeof(int32_t) * (G + 1)); add(sizeof(int32_t) * (G + 1));
     add(sizeof(double) * 3 * (Q + 1)); add(sizeof(double) * 3 * (2 * (size_t)P + J + 2)); add(sizeof(int32_t) * (2 * (size_t)P + J + 2)); add(Q + 1); add(Q + 1);
     add(Q + 2); add(Q + 2); add(Q + 2);
+    add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * 4);
     return b + 64;
 }
 inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, int J, int Q, int W, int DT = 0, int TL = 0, int G = 0) {
@@ -238,6 +241,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     v.rc_rem = (double*)take(sizeof(double) * 3 * (Q + 1)); v.rc_ent = (double*)take(sizeof(double) * 3 * (2 * (size_t)P + J + 2));
     v.rc_ent_q = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)P + J + 2)); v.rc_has = (uint8_t*)take(Q + 1); v.rc_inv = (uint8_t*)take(Q + 1);
     v.q_total = (uint8_t*)take(Q + 2); v.q_relc = (uint8_t*)take(Q + 2); v.q_pruned = (uint8_t*)take(Q + 2);
+    v.job_head = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.job_tail = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.grp_link = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.sc_jobs = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.sc_jobs_n = (int32_t*)take(sizeof(int32_t) * 4);
     v.P_cap = P;
 }
 
