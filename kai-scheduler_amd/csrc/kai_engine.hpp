@@ -341,6 +341,10 @@ struct TopoScan {
     KAI_GP(const uint32_t) parent;
     int32_t lvl_min[KAI_TOPO_SCAN_LEVELS], lvl_max[KAI_TOPO_SCAN_LEVELS];  // results of op 1 (any = some node qualified)
 };
+// Index loops of the victim search (resets, the victims-queue filter, feasible nodes, idle GPUs per node) as one request to the backend's scan lanes:
+// Backend::pfor returns false when it has none (the engine then runs the loop itself); the bodies are Engine::pfor_body (kai_engine_solver.inc).
+enum PforOp : int32_t { PFO_PARTIAL_RESET = 1, PFO_VICTIM_FILTER = 2, PFO_FEASIBLE = 3, PFO_IG_IDLE = 4 };
+struct PforReq { int32_t op, n, a, b; };
 KAI_HD bool topo_node_in_domain(const KaiCtx& c, const TopoScan& t, int n) {
     if (t.L <= 0) return false;
     return t.domain == t.root ? c.node_domain[(size_t)t.row0 * c.N + n] >= 0 : c.node_domain[(size_t)(t.row0 + t.dl) * c.N + n] == t.domain;
@@ -681,6 +685,8 @@ KAI_HD int stage_job_lane(const KaiCtx& c, int j, FastFrame& f, JobPf& out, int 
 // Engine<Backend>: the control flow.  Backend provides
 //    void minmax(const KaiCtx&, int r, double& mn, double& mx)          — pack.go:66-86 over the node set (brute force)
 //    bool topo_scan(const KaiCtx&, TopoScan&)                           — the node loops of subSetNodesFn on the scan lanes; false = the backend has none
+//    bool pfor(const KaiCtx&, const PforReq&)                           — an index loop of the victim search on the scan lanes; false = none
+//    void or32(uint32_t* word, uint32_t bits)                           — *word |= bits (atomic where lanes share words)
 //    int  best_node(const KaiCtx&, const ScanReq&)                      — arg-max of (score, -index) over fitting nodes (brute force)
 //    void begin(const KaiCtx&)                                          — build the in-LDS levels of the class index
 //    bool dirty_add(int block) / int dirty_count()                      — list of 64-node blocks whose node state changed

@@ -237,6 +237,8 @@ struct NullBackend {  // kernels that only need the engine's pure helpers
     __device__ EngineLocal& local() { return loc; }
     __device__ void minmax(const KaiCtx&, int, double&, double&) {}
     __device__ bool topo_scan(const KaiCtx&, TopoScan&) { return false; }
+    __device__ bool pfor(const KaiCtx&, const PforReq&) { return false; }
+    __device__ void or32(uint32_t* w, uint32_t bits) { atomicOr(w, bits); }
     __device__ int best_node(const KaiCtx&, const ScanReq&) { return -1; }
     __device__ void begin(const KaiCtx&) {}
     __device__ bool dirty_add(int) { return true; }
@@ -297,7 +299,7 @@ __global__ void k_leaf_init(KaiCtx c) {
 // ------------------------------------------------------------------------------------------------------
 // the persistent action kernel
 // ------------------------------------------------------------------------------------------------------
-enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5, CMD_LOADTREE = 6, CMD_STAGE = 7, CMD_TOPO = 8 };
+enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5, CMD_LOADTREE = 6, CMD_STAGE = 7, CMD_TOPO = 8, CMD_PFOR = 9 };
 
 // dynamic LDS of k_action / k_best_node: [s2_key C*NSB u64][s2_node C*NSB i32] and, when tree_in_lds, [QNode Q][qheap Q+1][root_heap Q+1]
 extern __shared__ __align__(16) unsigned char kai_dyn_lds[];
@@ -306,6 +308,7 @@ __host__ __device__ inline size_t lds_tree_bytes(int Q) { return (size_t)Q * siz
 
 struct ActShared {
     ScanReq req;
+    PforReq pfor;
     TopoScan topo; int32_t topo_min[WAVES][KAI_TOPO_SCAN_LEVELS], topo_max[WAVES][KAI_TOPO_SCAN_LEVELS], topo_any[WAVES];  // CMD_TOPO request and the waves' partial results
     int32_t cmd, r, n_dirty, pad0;
     int32_t dirty[KAI_MAXD];
@@ -375,6 +378,8 @@ struct DevBackendT {
         for (int w = 1; w < WAVES; w++) { if (sh->part_min[w] < lo) lo = sh->part_min[w]; if (sh->part_max[w] > hi) hi = sh->part_max[w]; }
         mn = lo; mx = hi;
     }
+    __device__ bool pfor(const KaiCtx&, const PforReq& r) { if (r.n < 256) return false; sh->pfor = r; call(CMD_PFOR); return true; }  // short loops stay on the control lane (two barriers cost more)
+    __device__ void or32(uint32_t* w, uint32_t bits) { *w |= bits; }
     __device__ bool topo_scan(const KaiCtx&, TopoScan& t) {
         sh->topo = t; call(CMD_TOPO);
         if (t.op == 1) {
@@ -533,6 +538,11 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
             }
             for (int o = 32; o > 0; o >>= 1) { double a = __shfl_xor(lo, o, 64), b = __shfl_xor(hi, o, 64); if (a < lo) lo = a; if (b > hi) hi = b; }
             if (lane == 0) { sh->part_min[wave] = lo; sh->part_max[wave] = hi; }
+        } else if (cmd == CMD_PFOR) {  // an index loop of the victim search (Engine::pfor_body)
+            const PforReq r = sh->pfor;
+            NullBackend nb; Engine<NullBackend> eng(c, nb);
+            for (int i = slot; i < r.n; i += SCAN_LANES) eng.pfor_body(r, i);
+            __threadfence();
         } else if (cmd == CMD_TOPO) {  // the node loops of subSetNodesFn (kai_engine.hpp subset_nodes)
             const TopoScan t = sh->topo;
             if (t.op == 1) {

@@ -31,6 +31,8 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     EngineLocal& local() { return loc; }
     std::vector<uint64_t> s2_key, top_key; std::vector<int32_t> s2_node, top_node;
     bool topo_scan(const KaiCtx&, TopoScan&) { return false; }
+    bool pfor(const KaiCtx&, const PforReq&) { return false; }
+    void or32(uint32_t* w, uint32_t bits) { *w |= bits; }
     void minmax(const KaiCtx& c, int r, double& mn, double& mx) {
         double lo = 1.7976931348623157e308, hi = 0;
         for (int n = 0; n < c.N; n++) {
