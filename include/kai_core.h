@@ -86,6 +86,7 @@ typedef enum kai_pod_status {
 /* pod flag bits */
 #define KAI_POD_FOREIGN_SCHEDULER 0x1u /* spec.schedulerName != ours: plugins/proportion/proportion.go:276-285 */
 #define KAI_POD_HAS_TASK_PRIORITY 0x2u /* carries the task-order label: plugins/taskorder/task_order.go:28-63 */
+#define KAI_POD_LEGACY_MIG 0x10u       /* PodInfo.IsLegacyMIGtask (pod_info.go:500-516): never schedulable (node_info.go:317-320); a node that holds one takes no MIG request (:342-346) */
 #define KAI_POD_CPU_FALLBACK 0x4u      /* needs a state-dependent upstream predicate, fractional GPU, MIG, DRA …:
                                           not placed by the device path (SURVEY §8b fallback rule) */
 #define KAI_POD_GPU_UNMODELLED 0x8u    /* holds / asks for GPU state the device's node accounting does not carry (gpu-memory request, several fractional
@@ -279,6 +280,15 @@ typedef struct kai_snapshot_soa {
     const int32_t* pod_gpu_group;    /* [P] */
     const int64_t* node_gpu_memory;  /* [N] */
     const int64_t* pod_gpu_memory;   /* [P] */
+
+    /* ---- MIG profiles (ABI v5; optional, NULL = no resource row is a MIG profile) ----
+     * A MIG instance type (nvidia.com/mig-<g>g.<m>gb) is a resource row >= 4 of node_allocatable / pod_req, counted in instances.  res_mig_gpus[r] = g (its GPU
+     * weight, api/common_info/resources/mig.go:13-33), 0 for every other row; res_mig_memory[r] = m.  A pod that requests such a row is a MIG request
+     * (RequestTypeMigInstance, pod_info.go:493-497): its GPU quota is sum(g x instances) while ResourceRequirements.GPUs() stays 0
+     * (gpu_resource_requirment.go:163-178); nodes count idle instances by their weight (resource_info.go:177-194, node_info.go:592-628); the predicates
+     * of api/node_info/node_info.go:315-359 apply (KAI_NODE_MIG_* flags, KAI_POD_LEGACY_MIG). */
+    const int32_t* res_mig_gpus;     /* [R] */
+    const int64_t* res_mig_memory;   /* [R] */
 } kai_snapshot_soa;
 
 typedef struct kai_op {

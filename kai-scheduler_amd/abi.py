@@ -27,7 +27,7 @@ POD_STATUS_NAME = {v: k for k, v in POD_STATUS.items()}
 ACTIVE_USED = sum(POD_STATUS[s] for s in ("Allocated", "Pipelined", "Binding", "Bound", "Running", "Releasing"))
 
 NODE_NOT_READY, NODE_MIG_ENABLED, NODE_MIG_MIXED, NODE_HAS_DRA_GPUS, NODE_GPU_WORKER, NODE_CPU_WORKER, NODE_MIG_SINGLE = 1, 2, 4, 8, 16, 32, 64
-POD_FOREIGN_SCHEDULER, POD_HAS_TASK_PRIORITY, POD_CPU_FALLBACK, POD_GPU_UNMODELLED = 1, 2, 4, 8
+POD_FOREIGN_SCHEDULER, POD_HAS_TASK_PRIORITY, POD_CPU_FALLBACK, POD_GPU_UNMODELLED, POD_LEGACY_MIG = 1, 2, 4, 8, 16
 
 ACTIONS = {"allocate": 0, "consolidation": 1, "reclaim": 2, "preempt": 3}
 OP_KIND = {0: "allocate", 1: "pipeline", 2: "evict"}
@@ -105,6 +105,7 @@ class KaiSnapshotSoA(C.Structure):
         ("job_signature", _P(C.c_int64)),
         ("job_last_start_ns", _P(C.c_int64)), ("queue_preempt_min_runtime_ns", _P(C.c_int64)), ("queue_reclaim_min_runtime_ns", _P(C.c_int64)),
         ("pod_gpu_portion", _P(C.c_double)), ("pod_gpu_group", _P(C.c_int32)), ("node_gpu_memory", _P(C.c_int64)), ("pod_gpu_memory", _P(C.c_int64)),
+        ("res_mig_gpus", _P(C.c_int32)), ("res_mig_memory", _P(C.c_int64)),
     ]
 
 
@@ -156,7 +157,7 @@ _SPEC_OPT = [
     ("group_required_level", np.int32), ("group_preferred_level", np.int32), ("job_root_group", np.int32), ("podset_group", np.int32),
     ("podset_topology", np.int32), ("podset_required_level", np.int32), ("podset_preferred_level", np.int32),
     ("job_signature", np.int64), ("job_last_start_ns", np.int64), ("queue_preempt_min_runtime_ns", np.int64), ("queue_reclaim_min_runtime_ns", np.int64),
-    ("pod_gpu_portion", np.float64), ("pod_gpu_group", np.int32), ("node_gpu_memory", np.int64), ("pod_gpu_memory", np.int64),
+    ("pod_gpu_portion", np.float64), ("pod_gpu_group", np.int32), ("node_gpu_memory", np.int64), ("pod_gpu_memory", np.int64), ("res_mig_gpus", np.int32), ("res_mig_memory", np.int64),
 ]
 
 

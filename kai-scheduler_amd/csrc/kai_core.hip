@@ -274,6 +274,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     // ---- index structures (pure re-orderings / groupings of the input; kai_host_prep.hpp)
     HostPrep prep;
     if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG;
+    for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
+        if (s->pod_flags && (s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
     core->perm = prep.perm;
 
     int rc;
@@ -346,6 +348,9 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
         for (int n = 0; n < N; n++) gm[n] = s->node_gpu_memory ? s->node_gpu_memory[prep.perm[n]] : 100;
         TRY(dupload_f(core, c.p_shared, sp.shared.data(), (size_t)P)); TRY(dupload_f(core, c.p_mem, sp.mem.data(), (size_t)P)); TRY(dupload_f(core, c.p_gmem, sp.gmem.data(), (size_t)P));
         TRY(dupload_f(core, c.p_acc_gpu, sp.acc_gpu.data(), (size_t)P)); TRY(dupload_f(core, c.p_pend_gpu, sp.pend_gpu.data(), (size_t)P));
+        TRY(dupload_f(core, c.p_quota_gpu, sp.quota_gpu.data(), (size_t)P)); TRY(dupload_f(core, c.p_mig_q, sp.mig_q.data(), (size_t)P)); TRY(dupload_f(core, c.p_kind, sp.kind.data(), (size_t)P));
+        c.quota_on = sp.on ? 1 : 0; c.mig_on = sp.mig ? 1 : 0;
+        for (int r = 0; r < KAI_MAX_RES; r++) { c.res_mig_g[r] = sp.mig_g[r]; c.res_mig_m[r] = sp.mig_m[r]; }
         TRY(dupload_f(core, c.p_portion, por.data(), (size_t)P)); TRY(dupload_f(core, c.p_group, grp.data(), (size_t)P)); TRY(dupload_f(core, c.p_on_group, minus1.data(), (size_t)P));
         TRY(dupload_f(core, c.n_gpu_mem, gm.data(), (size_t)N));
         { const int32_t* t; TRY(dupload(core, &t, grp.data(), (size_t)std::max(P, 1))); core->d_group0 = const_cast<int32_t*>(t); }
@@ -353,7 +358,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
         TRY(dzero_f(core, c.ng_mark, (size_t)N)); TRY(dzero_f(core, c.ng_has_alloc, (size_t)N));
         TRY(dupload_f(core, c.next_new_group, &next_new, (size_t)1)); core->next_group0 = next_new;
         c.shared_on = shared ? 1 : 0;
-        if (shared) { c.use_index = 0; c.all_tracked = 0; c.fast_ok = 0; core->fast_ok0 = 0; }  // every scan by brute force: the class keys know neither fractions nor the gpusharingorder score
+        if (shared || sp.mig) { c.use_index = 0; c.all_tracked = 0; c.fast_ok = 0; core->fast_ok0 = 0; }  // every scan by brute force: the class keys know neither fractions, the gpusharingorder score nor the MIG predicates
         // each node's active pods in UID order: the shared-GPU guards of addTaskResources are order sensitive (nodes_fake/nodes.go:289-302 adds tasks by UID)
         std::vector<int32_t> np_off((size_t)N + 1, 0), np_pods;
         if (shared) {

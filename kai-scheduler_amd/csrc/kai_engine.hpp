@@ -191,7 +191,7 @@ struct SolverCtx {
     int32_t *tpl_sorted, *tpl_end; uint8_t* ja_skip;  // [J] (CSR by q_job_off), [Q], [J]: every leaf's pending jobs in JobOrderFn order at the committed state (the
                                                       // simulation queues start from it), and the jobs a simulation takes out of it because their state is in flux
     int32_t *mjr_q, *mjr_job;                         // [J] MinimalJobRepresentatives: (queue or -1, representative job) per signature met so far
-    double *rc_rem, *rc_ent; int32_t* rc_ent_q; uint8_t *rc_has, *rc_inv;  // reclaimable validator scratch
+    double *rc_rem, *rc_ent; int32_t* rc_ent_q; uint8_t *rc_has, *rc_inv, *rc_ent_g;  // reclaimable validator scratch (rc_ent_g: the entry frees whole / shared GPUs, Resource.GPUs() > 0 — MIG instances do not count there)
     int32_t *job_head, *job_tail, *grp_link, *sc_jobs, *sc_jobs_n;  // [J+1] x 2, [P+2], [P+1], [1]: the scenario's task groups chained per job in the order they were added, and its distinct
                                                       // victim jobs in ascending index (what the validators range: kai_engine_solver.inc grp_add / scenario_jobs)
     uint8_t *q_total, *q_relc, *q_pruned;             // [Q+1] simulation queues without bystander subtrees (kai_engine_solver.inc sim_prune): the sibling order below this node is a strict total order /
@@ -214,6 +214,7 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     add(sizeof(double) * 3 * (Q + 1)); add(sizeof(double) * 3 * (2 * (size_t)P + J + 2)); add(sizeof(int32_t) * (2 * (size_t)P + J + 2)); add(Q + 1); add(Q + 1);
     add(Q + 2); add(Q + 2); add(Q + 2);
     add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * 4);
+    add(2 * (size_t)P + J + 2);
     return b + 64;
 }
 inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, int J, int Q, int W, int DT = 0, int TL = 0, int G = 0) {
@@ -242,6 +243,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     v.rc_ent_q = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)P + J + 2)); v.rc_has = (uint8_t*)take(Q + 1); v.rc_inv = (uint8_t*)take(Q + 1);
     v.q_total = (uint8_t*)take(Q + 2); v.q_relc = (uint8_t*)take(Q + 2); v.q_pruned = (uint8_t*)take(Q + 2);
     v.job_head = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.job_tail = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.grp_link = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.sc_jobs = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.sc_jobs_n = (int32_t*)take(sizeof(int32_t) * 4);
+    v.rc_ent_g = (uint8_t*)take(2 * (size_t)P + J + 2);
     v.P_cap = P;
 }
 
@@ -315,6 +317,11 @@ struct KaiCtx {
     KAI_GP(const int64_t) p_gmem;         // [P] ResReq.GpuMemory(): > 0 = a gpu-memory request
     KAI_GP(const double) p_acc_gpu;       // [P] AcceptedResource.GetGpusQuota() once a node holds the pod (node_info.go:746-766)
     KAI_GP(const double) p_pend_gpu;      // [P] GPU weight while pending: ResReq.GPUs() + memory / MinNodeGPUMemory (proportion.go:360-366, allocation_info.go:103-107)
+    KAI_GP(const double) p_quota_gpu;     // [P] ResReq.GetGpusQuota(): GPUs() + MIG instances by weight (gpu_resource_requirment.go:163-178)
+    KAI_GP(const double) p_mig_q;         // [P] the MIG part of the three quantities above (AcceptedResource.GPUs() = p_acc_gpu - p_mig_q)
+    KAI_GP(const uint8_t) p_kind;         // [P] SharedPods::K_*: MIG candidate / legacy MIG task / regular GPU request / GPUs() > 0
+    int32_t quota_on, mig_on;             // the per-pod arrays above are valid (shared GPUs or MIG rows in the snapshot) / some resource row is a MIG profile
+    int32_t res_mig_g[KAI_MAX_RES]; int64_t res_mig_m[KAI_MAX_RES];  // per resource row: GPU weight and memory of a MIG profile, 0 otherwise (mig.go:13-33)
     KAI_GP(int32_t) p_group, p_on_group;  // [P] PodInfo.GPUGroups[0]; the group in the node's own copy of the pod (node_info.go:397-398)
     KAI_GP(const int64_t) n_gpu_mem;      // [N] MemoryOfEveryGpuOnNode
     KAI_GP(int32_t) ng_id;                // [N][KAI_GMAX] GpuSharingNodeInfo: group id of the slot, -1 = free
@@ -356,7 +363,7 @@ struct ScanReq {
 #ifdef KAI_SHARED_GPUS
     double portion;       // > 0: the task asks for this fraction of one device
     int64_t gmem;         // >= 0: GetResourceGpuMemory of a shared request (fraction or gpu-memory), -1: derive it from the portion
-    int32_t shared, pad_s;  // IsSharedGPURequest
+    int32_t shared, kind;   // IsSharedGPURequest; SharedPods::K_* of the pod (MIG candidate / legacy MIG / regular / GPUs() > 0)
 #endif
 };
 
@@ -506,12 +513,21 @@ KAI_HD bool fits_shared(const KaiCtx& c, const ScanReq& q, int n, bool with_rele
 #endif
 
 // plugins/predicates/predicates.go:173-262 minus the queue-capacity step (node independent, done by the control lane)
-KAI_HD bool node_predicates(const KaiCtx& c, bool cpu_only, int pod_class, int n) {
+constexpr uint32_t KAI_NODE_LEGACY_MIG_I = 0x40000000u;  // internal: the node holds a legacy MIG task (NodeInfo.LegacyMIGTasks is not empty; set by the host at session open)
+constexpr int KAI_KIND_MIG = 1, KAI_KIND_LEGACY = 2, KAI_KIND_REGULAR = 4, KAI_KIND_GPUS = 8;  // = SharedPods::K_*
+KAI_HD bool node_predicates(const KaiCtx& c, bool cpu_only, int pod_class, int n, int kind = KAI_KIND_REGULAR | KAI_KIND_GPUS) {
     if (!(c.plugins & KAI_PLUGIN_PREDICATES)) return true;
     uint32_t f = c.n_flags[n];
-    if (!cpu_only) {  // NodeInfo.PredicateByNodeResourcesType (api/node_info/node_info.go:315-359)
-        if (f & KAI_NODE_HAS_DRA_GPUS) return false;
-        if ((f & KAI_NODE_MIG_ENABLED) && (f & KAI_NODE_MIG_MIXED)) return false;
+    if (kind & KAI_KIND_LEGACY) return false;  // NodeInfo.PredicateByNodeResourcesType (api/node_info/node_info.go:315-359): "Legacy MIG jobs cannot be scheduled"
+    if (!cpu_only) {
+        if ((kind & KAI_KIND_GPUS) && (f & KAI_NODE_HAS_DRA_GPUS)) return false;
+        const bool mig_node = f & KAI_NODE_MIG_ENABLED, mig_task = kind & KAI_KIND_MIG;
+        if (!mig_node && mig_task) return false;                                   // :336-340
+        if (mig_node) {
+            if (mig_task && (f & KAI_NODE_LEGACY_MIG_I)) return false;             // :342-346
+            if ((f & KAI_NODE_MIG_SINGLE) && !(kind & KAI_KIND_REGULAR)) return false;  // :349-352
+            if ((f & KAI_NODE_MIG_MIXED) && !mig_task) return false;               // :353-356
+        }
     }
     double pods = c.n_idle[(size_t)KAI_RES_PODS * c.N + n] + c.n_rel[(size_t)KAI_RES_PODS * c.N + n];  // :264-285
     if (!(pods > 0)) return false;
@@ -750,20 +766,29 @@ struct Engine {
     KAI_HD double preq(int p, int r) const { return cx().p_req[(size_t)r * cx().P + p]; }
 #ifdef KAI_SHARED_GPUS
     KAI_HD bool pod_shared(int p) const { return cx().shared_on && cx().p_shared[p]; }
-    KAI_HD int64_t pod_gmem(int p) const { return cx().shared_on ? cx().p_gmem[p] : 0; }
-    KAI_HD double pacc_gpu(int p) const { return cx().shared_on ? cx().p_acc_gpu[p] : preq(p, KAI_RES_GPU); }
-    KAI_HD double ppend_gpu(int p) const { return cx().shared_on ? cx().p_pend_gpu[p] : preq(p, KAI_RES_GPU); }
+    KAI_HD int64_t pod_gmem(int p) const { return cx().quota_on ? cx().p_gmem[p] : 0; }
+    KAI_HD double pacc_gpu(int p) const { return cx().quota_on ? cx().p_acc_gpu[p] : preq(p, KAI_RES_GPU); }   // AcceptedResource.GetGpusQuota()
+    KAI_HD double pacc_gpus(int p) const { return cx().quota_on ? cx().p_acc_gpu[p] - cx().p_mig_q[p] : preq(p, KAI_RES_GPU); }  // AcceptedResource.GPUs(): no MIG instances
+    KAI_HD double ppend_gpu(int p) const { return cx().quota_on ? cx().p_pend_gpu[p] : preq(p, KAI_RES_GPU); }
+    KAI_HD double pquota_gpu(int p) const { return cx().quota_on ? cx().p_quota_gpu[p] : preq(p, KAI_RES_GPU); }  // ResReq.GetGpusQuota()
+    KAI_HD int pod_kind(int p) const { return cx().quota_on ? cx().p_kind[p] : (KAI_KIND_REGULAR | (preq(p, KAI_RES_GPU) > 0 ? KAI_KIND_GPUS : 0)); }
+    KAI_HD bool mig_row(int r) const { return cx().mig_on && cx().res_mig_g[r] > 0; }
 #else
     KAI_HD bool pod_shared(int) const { return false; }
     KAI_HD int64_t pod_gmem(int) const { return 0; }
     KAI_HD double pacc_gpu(int p) const { return preq(p, KAI_RES_GPU); }
+    KAI_HD double pacc_gpus(int p) const { return preq(p, KAI_RES_GPU); }
     KAI_HD double ppend_gpu(int p) const { return preq(p, KAI_RES_GPU); }
+    KAI_HD double pquota_gpu(int p) const { return preq(p, KAI_RES_GPU); }
+    KAI_HD int pod_kind(int p) const { return KAI_KIND_REGULAR | (preq(p, KAI_RES_GPU) > 0 ? KAI_KIND_GPUS : 0); }
+    KAI_HD bool mig_row(int) const { return false; }
 #endif
-    KAI_HD bool pod_cpu_only(int p) const { return !(preq(p, KAI_RES_GPU) > 0 || pod_gmem(p) > 0); }  // pod_info.go:340-347 IsRequireAnyKindOfGPU
+    KAI_HD bool pod_cpu_only(int p) const { return !(preq(p, KAI_RES_GPU) > 0 || pod_gmem(p) > 0 || (pod_kind(p) & KAI_KIND_MIG)); }  // pod_info.go:340-347 IsRequireAnyKindOfGPU
     KAI_HD bool pod_best_effort(int p) const {  // ResourceRequirements.IsEmpty (resource_requirment.go:99-104, base_resources.go:119-130)
         if (preq(p, KAI_RES_GPU) > 0.01 || pod_gmem(p) > 0) return false;  // (node_info.go:169-170: a gpu-memory request is never best effort)
+        if (pod_kind(p) & KAI_KIND_MIG) return false;                      // gpu_resource_requirment.go:89-104: MIG instances make the request non-empty
         if (preq(p, KAI_RES_CPU) >= 10.0 || preq(p, KAI_RES_MEM) >= 10.0 * 1024 * 1024) return false;
-        for (int r = KAI_RES_PODS; r < cx().R; r++) if (preq(p, r) >= 10.0) return false;
+        for (int r = KAI_RES_PODS; r < cx().R; r++) if (!mig_row(r) && preq(p, r) >= 10.0) return false;
         return true;
     }
     KAI_HD bool should_allocate(int p, bool real) const {  // pod_info.go:518-521
@@ -771,7 +796,7 @@ struct Engine {
         return s == KAI_POD_PENDING || (!real && s == KAI_POD_RELEASING && cx().p_virtual[p]);
     }
     // quota triple of a pod: utils.QuantifyResourceRequirements (plugins/proportion/utils/utils.go:15-17)
-    KAI_HD double pquota(int p, int k) const { return k == KAI_Q_CPU ? preq(p, KAI_RES_CPU) : k == KAI_Q_MEM ? preq(p, KAI_RES_MEM) : preq(p, KAI_RES_GPU); }
+    KAI_HD double pquota(int p, int k) const { return k == KAI_Q_CPU ? preq(p, KAI_RES_CPU) : k == KAI_Q_MEM ? preq(p, KAI_RES_MEM) : pquota_gpu(p); }  // QuantifyResourceRequirements(ResReq)
 
     // ------------------------------------------------------------------ class index bookkeeping
     // the dirty-block list lives in the backend (LDS on the device) so that this object holds no dynamically indexed storage
@@ -814,23 +839,30 @@ struct Engine {
     }
 
     // NodeInfo.GetSumOfIdleGPUs / GetSumOfReleasingGPUs (node_info.go:592-628): whole GPUs plus, with shared GPUs, the free / releasing portions on them
+    template <class A> KAI_HD double mig_sum(A arr, int n) const {  // idle / releasing MIG instances by their GPU weight (node_info.go:596-606, 615-625)
+        double q = 0;
+#ifdef KAI_SHARED_GPUS
+        if (cx().mig_on) for (int r = KAI_RES_PODS + 1; r < cx().R; r++) if (cx().res_mig_g[r] > 0) q += (double)((int64_t)cx().res_mig_g[r] * (int64_t)arr[(size_t)r * cx().N + n]);
+#endif
+        return q;
+    }
     KAI_HD double gpus_idle_sum(int n) const {
 #ifdef KAI_SHARED_GPUS
-        if (cx().shared_on) { SgNode g{cx(), n}; return g.sum_available_shared() + cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n]; }
+        if (cx().shared_on) { SgNode g{cx(), n}; return g.sum_available_shared() + cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n] + mig_sum(cx().n_idle, n); }
 #endif
-        return cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n];
+        return cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n] + mig_sum(cx().n_idle, n);
     }
     KAI_HD int64_t gpus_free_mem(int n) const {  // GPU memory behind GetSumOfIdleGPUs + GetSumOfReleasingGPUs (node_info.go:592-628): whole devices count in full
 #ifdef KAI_SHARED_GPUS
-        if (cx().shared_on) { SgNode g{cx(), n}; return g.mem_available_shared() + (int64_t)cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n] * g.gpu_mem() + g.mem_releasing_shared() + (int64_t)cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n] * g.gpu_mem(); }
+        if (cx().quota_on) { SgNode g{cx(), n}; return (cx().shared_on ? g.mem_available_shared() + g.mem_releasing_shared() : 0) + (int64_t)(cx().n_idle[(size_t)KAI_RES_GPU * cx().N + n] + mig_sum(cx().n_idle, n)) * g.gpu_mem() + (int64_t)(cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n] + mig_sum(cx().n_rel, n)) * g.gpu_mem(); }
 #endif
         return 0;
     }
     KAI_HD double gpus_rel_sum(int n) const {
 #ifdef KAI_SHARED_GPUS
-        if (cx().shared_on) { SgNode g{cx(), n}; return g.sum_releasing_shared() + cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n]; }
+        if (cx().shared_on) { SgNode g{cx(), n}; return g.sum_releasing_shared() + cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n] + mig_sum(cx().n_rel, n); }
 #endif
-        return cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n];
+        return cx().n_rel[(size_t)KAI_RES_GPU * cx().N + n] + mig_sum(cx().n_rel, n);
     }
     // ------------------------------------------------------------------ node accounting (api/node_info/node_info.go)
     KAI_HD void node_apply(int n, int p, int status, double sign, int grp_of_copy = -2) {  // addTaskResources :457-493 / removeTaskResources :515-551
@@ -1332,6 +1364,7 @@ struct Engine {
         // a fraction: ceil(int64(portion * mem) / mem * 100) / 100 of a device; node independent because the host admits shared GPUs only when
         // every node has the same MemoryOfEveryGpuOnNode
         if (pod_shared(p) && cx().N > 0) { SgNode g{cx(), 0}; req[2] = g.frac_of(cx().p_mem[p]); }
+        if (pod_kind(p) & KAI_KIND_MIG) req[2] = pquota_gpu(p);  // node_info.go:736-737
 #endif
         int j = cx().p_job[p];
         return over_limit(j, req) || np_over_quota(j, req);
@@ -1540,7 +1573,7 @@ struct Engine {
         q.min_a = 0; q.max_a = 0;
 #ifdef KAI_SHARED_GPUS
         q.portion = cx().shared_on ? (cx().p_portion[p] > 0 ? cx().p_portion[p] : (preq(p, KAI_RES_GPU) >= 1 ? 1.0 : 0.0)) : 0.0;  // GpuFractionalPortion()
-        q.shared = pod_shared(p) ? 1 : 0; q.gmem = q.shared ? cx().p_mem[p] : -1;  // GetResourceGpuMemory of a shared request (a gpu-memory request: portion 0, its own MiB)
+        q.shared = pod_shared(p) ? 1 : 0; q.kind = pod_kind(p); q.gmem = q.shared ? cx().p_mem[p] : -1;  // GetResourceGpuMemory of a shared request (a gpu-memory request: portion 0, its own MiB)
 #endif
     }
     // OrderedNodesByTask + FittingNode for one task (framework/session.go:201-264): the first fitting node in score order, or -1

@@ -20,8 +20,10 @@ namespace kai {
 // Shared-GPU requests (a fraction of one device: pod_gpu_portion; MiB of one device: pod_gpu_memory) as the per-pod quantities the engine reads.  The
 // engine admits them only with ONE GPU memory size M for the whole cluster, so what a request takes on "its node" is known here.
 struct SharedPods {
-    bool any = false; std::string err;
-    std::vector<uint8_t> shared; std::vector<int64_t> mem, gmem; std::vector<double> acc_gpu, pend_gpu;
+    bool any = false, mig = false, on = false; std::string err;  // any: shared-GPU requests; mig: some resource row is a MIG profile; on = any || mig: the arrays below are in use
+    std::vector<uint8_t> shared, kind; std::vector<int64_t> mem, gmem; std::vector<double> acc_gpu, pend_gpu, quota_gpu, mig_q;
+    int32_t mig_g[KAI_MAX_RES] = {0}; int64_t mig_m[KAI_MAX_RES] = {0};
+    enum { K_MIG = 1, K_LEGACY = 2, K_REGULAR = 4, K_GPUS = 8 };  // PodInfo: IsMigCandidate / IsLegacyMIGtask / IsRegularGPURequest / ResReq.GPUs() > 0
     static bool has(const kai_snapshot_soa* s) {
         for (int p = 0; p < s->n_pods; p++) if ((s->pod_gpu_portion && s->pod_gpu_portion[p] > 0) || (s->pod_gpu_memory && s->pod_gpu_memory[p] > 0)) return true;
         return false;
@@ -30,14 +32,16 @@ struct SharedPods {
         const int P = s->n_pods, N = s->n_nodes;
         any = has(s);
         const size_t n = (size_t)std::max(P, 1);
-        shared.assign(n, 0); mem.assign(n, 0); gmem.assign(n, 0); acc_gpu.assign(n, 0.0); pend_gpu.assign(n, 0.0);
+        shared.assign(n, 0); kind.assign(n, 0); mem.assign(n, 0); gmem.assign(n, 0); acc_gpu.assign(n, 0.0); pend_gpu.assign(n, 0.0); quota_gpu.assign(n, 0.0); mig_q.assign(n, 0.0);
+        for (int r = KAI_RES_PODS + 1; r < s->n_res && r < KAI_MAX_RES; r++) { mig_g[r] = s->res_mig_gpus ? s->res_mig_gpus[r] : 0; mig_m[r] = s->res_mig_memory ? s->res_mig_memory[r] : 0; if (mig_g[r] > 0) mig = true; }
+        on = any || mig;
         if (any && s->node_gpu_memory) for (int i = 1; i < N; i++) if (s->node_gpu_memory[i] != s->node_gpu_memory[0]) { err = "shared GPUs with different node_gpu_memory values: leave the cycle to the host path"; return false; }
         const int64_t M = (s->node_gpu_memory && N > 0) ? s->node_gpu_memory[0] : 100;
         for (int p = 0; p < P; p++) {
             const double g = s->pod_req[(size_t)KAI_RES_GPU * P + p];
             const double por = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0;
             const int64_t gm = (s->pod_gpu_memory && !(por > 0)) ? s->pod_gpu_memory[p] : 0;
-            acc_gpu[p] = g; pend_gpu[p] = g;
+            acc_gpu[p] = g; pend_gpu[p] = g; quota_gpu[p] = g;
             if (por > 0) { shared[p] = 1; mem[p] = (int64_t)(por * (double)M); }  // GetResourceGpuMemory (node_info.go:653-659); AcceptedResource keeps the portion
             else if (gm > 0) {
                 if (gm > M || M <= 0) { err = "a gpu-memory request above one device's memory: leave the cycle to the host path"; return false; }  // isValidGpuPortion :668-671
@@ -49,6 +53,15 @@ struct SharedPods {
                 acc_gpu[p] = (double)(int64_t)(frac * 100.0 + 0.5) / 100.0;  // GPUs() of NewGpuResourceRequirementWithMultiFraction(1, that portion, …): fixed point 1/100
                 pend_gpu[p] = cfg.min_node_gpu_memory > 0 ? (double)gm / (double)cfg.min_node_gpu_memory : 0.0;  // proportion.go:360-366, allocation_info.go:103-107
             }
+            // MIG instances: GetGpusQuota adds weight x count to every GPU quantity of the request except GPUs() itself (gpu_resource_requirment.go:163-178)
+            double mq = 0; if (mig) for (int r = KAI_RES_PODS + 1; r < s->n_res && r < KAI_MAX_RES; r++) if (mig_g[r] > 0) mq += (double)mig_g[r] * s->pod_req[(size_t)r * P + p];
+            mig_q[p] = mq; acc_gpu[p] += mq; pend_gpu[p] += mq; quota_gpu[p] += mq;
+            uint8_t k = 0;
+            if (mq > 0) k |= K_MIG;
+            if (s->pod_flags && (s->pod_flags[p] & KAI_POD_LEGACY_MIG)) k |= K_LEGACY;
+            if (!(k & K_MIG) && !shared[p]) k |= K_REGULAR;
+            if (g > 0) k |= K_GPUS;
+            kind[p] = k;
         }
         return true;
     }

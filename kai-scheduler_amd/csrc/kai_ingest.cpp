@@ -304,6 +304,16 @@ void canon(const JV& v, std::string& out) {
 // resource names (api/resource_info/resource_requirment.go:17-18,45-71, resource_info.go:53-79, k8s_internal/kubernetes_helpers.go:12-15)
 bool is_gpu_name(const std::string& n) { return n == "nvidia.com/gpu" || n == "amd.com/gpu"; }
 bool is_mig_name(const std::string& n) { return starts_with(n, "nvidia.com/mig-"); }
+// ^nvidia.com/mig-(\d+)g\.(\d+)gb$ (api/common_info/resources/mig.go:13-33): GPU weight and memory of the profile; false when the name does not parse
+bool parse_mig_name(const std::string& n, int& g, int64_t& m) {
+    const std::string pre = "nvidia.com/mig-"; if (!starts_with(n, pre.c_str())) return false;
+    size_t i = pre.size(), j = i; while (j < n.size() && isdigit((unsigned char)n[j])) j++;
+    if (j == i || j - i > 6 || n.compare(j, 2, "g.") != 0) return false;
+    size_t k = j + 2, l = k; while (l < n.size() && isdigit((unsigned char)n[l])) l++;
+    if (l == k || l - k > 9 || n.compare(l, std::string::npos, "gb") != 0) return false;
+    g = atoi(n.substr(i, j - i).c_str()); m = atoll(n.substr(k, l - k).c_str());
+    return true;
+}
 bool is_scalar_name(const std::string& n) {  // v1helper.IsExtendedResourceName || IsHugePageResourceName || IsPrefixedNativeResource || IsAttachableVolumeResourceName
     bool native = n.find('/') == std::string::npos || n.find("kubernetes.io/") != std::string::npos;
     if (!native && !starts_with(n, "requests.")) return true;
@@ -322,7 +332,7 @@ Req req_from_list(const std::map<std::string, Qty>& rl) {
         if (n == "cpu") r.cpu += (double)qty_milli(q);
         else if (n == "memory") r.mem += (double)qty_value(q);
         else if (is_gpu_name(n)) { int64_t v = qty_value(q); if (v >= 1) r.gpu += (double)v; }  // Value() is an integer: below 1 means 0 devices
-        else if (is_mig_name(n)) r.mig = true;
+        else if (is_mig_name(n)) { r.mig = true; r.scalars[n] += qty_value(q); }  // instances (Value): a resource row of its own, described by res_mig_* (ABI v5)
         else if (is_scalar_name(n)) r.scalars[n] += qty_milli(q);
         else if (is_storage_name(n)) r.scalars[n] += qty_value(q);
     }
@@ -404,7 +414,8 @@ struct kai_ingest {
         podset_job, podset_min, job_queue, job_priority, job_preempt, job_first_pod, job_n_pods, job_first_podset, job_n_podsets, queue_parent, queue_priority,
         topo_level_off, node_domain, domain_level, domain_parent, group_job, group_parent, group_topology, group_req, group_pref, job_root_group,
         podset_group, podset_topology, podset_req, podset_pref;
-    std::vector<int64_t> pod_created, job_created, queue_created, job_signature, job_last_start, q_preempt_mrt, q_reclaim_mrt, node_gpu_memory;
+    std::vector<int64_t> pod_created, job_created, queue_created, job_signature, job_last_start, q_preempt_mrt, q_reclaim_mrt, node_gpu_memory, res_mig_memory;
+    std::vector<int32_t> res_mig_gpus;
     std::vector<double> pod_gpu_portion; std::vector<int32_t> pod_gpu_group; std::vector<int64_t> pod_gpu_memory; bool any_fraction = false, any_gpu_memory = false;
     std::vector<uint8_t> class_fit;
     // what the decision writer needs of each pod / job (cache/cache.go:216-330)
@@ -498,7 +509,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
             if (qty_zero(q)) continue;
             const std::string& rn = kv.first;
             if (rn == "cpu") ncpu[i] += (double)qty_milli(q); else if (rn == "memory") nmem[i] += (double)qty_value(q); else if (is_gpu_name(rn)) ngpu[i] += (double)qty_value(q);
-            else if (rn == "pods") npods[i] += (double)qty_value(q); else if (is_mig_name(rn)) mig_res = true;
+            else if (rn == "pods") npods[i] += (double)qty_value(q); else if (is_mig_name(rn)) { mig_res = true; node_scalars[i][rn] += qty_value(q); }
             else if (is_storage_name(rn)) node_scalars[i][rn] += qty_value(q); else if (is_scalar_name(rn)) node_scalars[i][rn] += qty_milli(q);
         }
         if (n["spec"]["unschedulable"].truthy()) f |= KAI_NODE_NOT_READY;
@@ -570,7 +581,14 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         if (!spec["schedulerName"].str().empty() ? spec["schedulerName"].str() != scheduler_name : true) r.flags |= KAI_POD_FOREIGN_SCHEDULER;  // proportion.go:276-285
         { const JV& tp = md["labels"]["kai.scheduler/task-priority"]; if (tp.t == JV::Str) { char* e = nullptr; long v = strtol(tp.s.c_str(), &e, 10); if (!tp.s.empty() && !*e) { r.flags |= KAI_POD_HAS_TASK_PRIORITY; r.task_prio = (int32_t)v; } } }  // task_order.go:28-63
         // features outside the device path (SURVEY §8b fallback rule)
-        const JV& ann = md["annotations"]; bool fb = r.req.mig;
+        const JV& ann = md["annotations"]; bool fb = false;
+        for (auto& kv : r.req.scalars) { int g; int64_t m; if (is_mig_name(kv.first) && !parse_mig_name(kv.first, g, m)) fb = true; }  // a MIG profile the device cannot weigh
+        if (ann.is_obj()) for (auto& kv : ann.o) if (is_mig_name(kv.first)) {  // updateLegacyMigResourceRequestFromAnnotations (pod_info.go:500-516): the request becomes that profile, the task is legacy
+            char* e = nullptr; const std::string& vs = kv.second.str(); long long v = strtoll(vs.c_str(), &e, 10);
+            if (vs.empty() || *e) continue;
+            for (auto it = r.req.scalars.begin(); it != r.req.scalars.end();) { if (is_mig_name(it->first)) it = r.req.scalars.erase(it); else ++it; }
+            r.req.scalars[kv.first] = v; r.req.gpu = 0; r.req.mig = true; r.flags |= KAI_POD_LEGACY_MIG;
+        }
         bool gpu_unmodelled = false;
         {   // shared-GPU requests (pod_info.go:463-486): a fraction of ONE device (annotation gpu-fraction; ABI v4 pod_gpu_portion) and MiB of ONE device
             // (annotation gpu-memory; ABI v5 pod_gpu_memory) are described to the device; several devices per pod (gpu-fraction-num-devices), both
@@ -589,7 +607,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         if (spec["volumes"].is_arr()) for (auto& v : spec["volumes"].a) if (v["persistentVolumeClaim"].is_obj() || v["ephemeral"].is_obj()) fb = true;
         for (const char* cs : {"containers", "initContainers"}) if (spec[cs].is_arr()) for (auto& c : spec[cs].a) if (c["ports"].is_arr()) for (auto& port : c["ports"].a) if (port["hostPort"].inum() > 0) fb = true;
         if (fb) r.flags |= KAI_POD_CPU_FALLBACK;
-        if (r.req.mig || gpu_unmodelled || (spec["resourceClaims"].is_arr() && !spec["resourceClaims"].a.empty()))
+        if (gpu_unmodelled || (spec["resourceClaims"].is_arr() && !spec["resourceClaims"].a.empty()))
             r.flags |= KAI_POD_GPU_UNMODELLED;  // GPU state beyond whole devices and one shared device: the device refuses such a pod when it is active
         {   // kai utility pods (api/pod_info/utility_pods.go:13-33, conf/global_config.go:25-26): never "another scheduler's" (proportion.go:276-285);
             // a reservation pod holds its GPU on behalf of the fraction pods of its group, so its own devices are not booked (node_info.go:465)
@@ -886,6 +904,11 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     if (any_fraction) { s.pod_gpu_portion = ptr(pod_gpu_portion); s.pod_gpu_group = ptr(pod_gpu_group); }
     if (any_gpu_memory) s.pod_gpu_memory = ptr(pod_gpu_memory);
     s.node_gpu_memory = ptr(node_gpu_memory);
+    {   // MIG profiles among the resource rows (ABI v5)
+        bool any = false; res_mig_gpus.assign((size_t)R, 0); res_mig_memory.assign((size_t)R, 0);
+        for (int k = 4; k < R; k++) { int g; int64_t m; if (parse_mig_name(names[KAI_NAME_RESOURCE][k], g, m)) { res_mig_gpus[k] = g; res_mig_memory[k] = m; any = true; } }
+        if (any) { s.res_mig_gpus = ptr(res_mig_gpus); s.res_mig_memory = ptr(res_mig_memory); }
+    }
     s.job_signature = ptr(job_signature); s.job_last_start_ns = ptr(job_last_start); s.queue_preempt_min_runtime_ns = ptr(q_preempt_mrt); s.queue_reclaim_min_runtime_ns = ptr(q_reclaim_mrt);
     return KAI_OK;
 }

@@ -88,7 +88,12 @@ __global__ void k_total_nodes(KaiCtx c) {
         bool ignore_gpus = c.restrict_nodes && !(f & KAI_NODE_GPU_WORKER);
         acc[KAI_Q_CPU] += c.n_alloc[(size_t)KAI_RES_CPU * c.N + n];
         acc[KAI_Q_MEM] += c.n_alloc[(size_t)KAI_RES_MEM * c.N + n];
-        if (!ignore_gpus) acc[KAI_Q_GPU] += c.n_alloc[(size_t)KAI_RES_GPU * c.N + n];
+        if (!ignore_gpus) {  // QuantifyResource(Allocatable): GPUs + MIG instances by weight (resource_info.go:177-194)
+            acc[KAI_Q_GPU] += c.n_alloc[(size_t)KAI_RES_GPU * c.N + n];
+#ifdef KAI_SHARED_GPUS
+            if (c.mig_on) for (int r = KAI_RES_PODS + 1; r < c.R; r++) if (c.res_mig_g[r] > 0) acc[KAI_Q_GPU] += (double)c.res_mig_g[r] * c.n_alloc[(size_t)r * c.N + n];
+#endif
+        }
     }
     for (int k = 0; k < 3; k++) { double v = wave_sum(acc[k]); if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(&c.st->total[k], v); }
 }
@@ -102,7 +107,11 @@ __global__ void k_total_foreign(KaiCtx c) {
     if (c.n_flags[n] & KAI_NODE_NOT_READY) return;
     atomicAdd(&c.st->total[KAI_Q_CPU], -c.p_req[(size_t)KAI_RES_CPU * c.P + p]);
     atomicAdd(&c.st->total[KAI_Q_MEM], -c.p_req[(size_t)KAI_RES_MEM * c.P + p]);
+#ifdef KAI_SHARED_GPUS
+    atomicAdd(&c.st->total[KAI_Q_GPU], -(c.quota_on ? c.p_quota_gpu[p] : c.p_req[(size_t)KAI_RES_GPU * c.P + p]));  // QuantifyResourceRequirements(ResReq)
+#else
     atomicAdd(&c.st->total[KAI_Q_GPU], -c.p_req[(size_t)KAI_RES_GPU * c.P + p]);
+#endif
 }
 
 // per-job sums + pod-set / job counters (api/podgroup_info/job_info.go:208-226, subgroup_info/podset.go:56-77).
@@ -122,12 +131,12 @@ __global__ void k_job_usage(KaiCtx c, double* jsum) {
         if (s == KAI_POD_PIPELINED) c.s_pipelined[ps]++;
         if (s == KAI_POD_PENDING) pending++;
         double q[3] = {c.p_req[(size_t)KAI_RES_CPU * c.P + p], c.p_req[(size_t)KAI_RES_MEM * c.P + p], c.p_req[(size_t)KAI_RES_GPU * c.P + p]};
-        double qa = q[2], qp = q[2];  // GPU quota of AcceptedResource / GPU weight of a pending request: they differ from ResReq.GPUs() for a gpu-memory request
+        double qa = q[2], qp = q[2], qq = q[2];  // GPU quota of AcceptedResource / GPU weight of a pending request / quota of ResReq: they differ from ResReq.GPUs() for gpu-memory and MIG requests
 #ifdef KAI_SHARED_GPUS
-        if (c.shared_on) { qa = c.p_acc_gpu[p]; qp = c.p_pend_gpu[p]; }
+        if (c.quota_on) { qa = c.p_acc_gpu[p]; qp = c.p_pend_gpu[p]; qq = c.p_quota_gpu[p]; }
 #endif
         if (st_allocated(s)) {
-            for (int k = 0; k < 3; k++) ja[k] += q[k];
+            for (int k = 0; k < 3; k++) ja[k] += k == 2 ? qq : q[k];  // PodGroupInfo.Allocated carries the MIG instances (job_info.go:231-251): QuantifyResource of it
             if (c.p_accepted[p]) for (int k = 0; k < 3; k++) { const double v = k == 2 ? qa : q[k]; al[k] += v; rq[k] += v; }  // AcceptedResource is empty for a pod no node holds
         } else if (s == KAI_POD_PENDING) {
             for (int k = 0; k < 3; k++) rq[k] += k == 2 ? qp : q[k];
@@ -586,7 +595,7 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
 #ifdef KAI_SHARED_GPUS
                 const bool frac = c.shared_on && q.shared;  // a fraction (or MiB) of one device: fit / predicates over the node's GPU groups
                 if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
-                if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n))) continue;
+                if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n, q.kind))) continue;
                 bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
 #else
                 if (!fits(c, q.req, n, true)) continue;                              // IsTaskAllocatableOnReleasingOrIdle

@@ -126,6 +126,8 @@ def _from_handle(lib, h) -> Ingested:
         a["pod_gpu_portion"] = _copy(s.pod_gpu_portion, P, np.float64); a["pod_gpu_group"] = _copy(s.pod_gpu_group, P, np.int32)
     if s.pod_gpu_memory:
         a["pod_gpu_memory"] = _copy(s.pod_gpu_memory, P, np.int64)
+    if s.res_mig_gpus:
+        a["res_mig_gpus"] = _copy(s.res_mig_gpus, int(s.n_res), np.int32); a["res_mig_memory"] = _copy(s.res_mig_memory, int(s.n_res), np.int64)
     if s.node_gpu_memory and N:
         a["node_gpu_memory"] = _copy(s.node_gpu_memory, N, np.int64)
     snap = abi.Snapshot(n_res=R, arrays=a)

@@ -379,6 +379,50 @@ def add_fractions(snap: abi.Snapshot, seed: int, frac: float = 0.4, portions=(0.
     return snap.finalize()
 
 
+def add_mig(snap: abi.Snapshot, seed: int, node_frac: float = 0.3, pod_frac: float = 0.5, legacy_frac: float = 0.05) -> abi.Snapshot:
+    """Turn a share of the GPU nodes into MIG nodes with MigStrategy "mixed" (ABI v5 res_mig_*): two more resource rows, nvidia.com/mig-1g.10gb and
+    nvidia.com/mig-2g.20gb, hold their instances (as many 1g instances as the node had GPUs plus half as many 2g ones), their whole-GPU count becomes 0
+    (nodes_fake/nodes.go:71-73), and the whole-GPU pods that run there ask for 1g instances instead (same GPU quota: weight 1).  A share of the pending
+    GPU pods ask for MIG instances as well (2g ones for even counts); a few pods are legacy MIG tasks (never schedulable; the node of a running one takes
+    no MIG request, api/node_info/node_info.go:315-359)."""
+    rng = np.random.default_rng(seed ^ 0x316)
+    a = snap.arrays
+    P, N, R0 = snap.n_pods, snap.n_nodes, snap.n_res
+    if R0 + 2 > 8:
+        raise ValueError("no free resource rows for MIG profiles")
+    S = abi.POD_STATUS
+    active = S["Running"] | S["Bound"] | S["Binding"] | S["Allocated"] | S["Pipelined"] | S["Releasing"]
+    alloc = np.vstack([a["node_allocatable"], np.zeros((2, N))]); req = np.vstack([a["pod_req"], np.zeros((2, P))])
+    r1, r2 = R0, R0 + 1
+    mig_node = np.zeros(N, bool)
+    for n in range(N):
+        g = alloc[abi.RES_GPU, n]
+        if g > 0 and g == int(g) and rng.random() < node_frac:
+            mig_node[n] = True
+            alloc[r1, n] = g; alloc[r2, n] = int(g) // 2; alloc[abi.RES_GPU, n] = 0
+            a["node_flags"][n] |= abi.NODE_MIG_ENABLED | abi.NODE_MIG_MIXED
+    flags = a["pod_flags"].copy() if "pod_flags" in a else np.zeros(P, np.uint32)
+    for p in range(P):
+        g = req[abi.RES_GPU, p]
+        if not (g > 0 and g == int(g)):
+            continue
+        st = int(a["pod_status"][p]); n = int(a["pod_node"][p])
+        if st & active and n >= 0:
+            if mig_node[n]:
+                req[r1, p] = g; req[abi.RES_GPU, p] = 0
+                if rng.random() < legacy_frac: flags[p] |= abi.POD_LEGACY_MIG
+        elif st == S["Pending"] and rng.random() < pod_frac:
+            if int(g) % 2 == 0 and rng.random() < 0.5: req[r2, p] = int(g) // 2
+            else: req[r1, p] = g
+            req[abi.RES_GPU, p] = 0
+            if rng.random() < legacy_frac: flags[p] |= abi.POD_LEGACY_MIG
+    a["node_allocatable"] = alloc; a["pod_req"] = req; a["pod_flags"] = flags
+    mg = np.zeros(R0 + 2, np.int32); mm = np.zeros(R0 + 2, np.int64); mg[r1], mm[r1], mg[r2], mm[r2] = 1, 10, 2, 20
+    a["res_mig_gpus"] = mg; a["res_mig_memory"] = mm
+    snap.n_res = R0 + 2
+    return snap.finalize()
+
+
 def add_predicate_features(snap: abi.Snapshot, seed: int, *, nominated_frac=0.15, not_ready_frac=0.1, worker_label_frac=0.8, foreign_frac=0.2,
                            oversized_frac=0.05) -> abi.Snapshot:
     """Exercise the predicate / node-order corners the BASELINE configs leave untouched:

@@ -108,6 +108,7 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
         for (int k = 0; k < s->job_n_podsets[j]; k++) g.podSets.push_back(&podsets[s->job_first_podset[j] + k]);
         std::sort(g.podSets.begin(), g.podSets.end(), [](PodSet* a, PodSet* b) { return a->nameRank < b->nameRank; });
     }
+    { MigRows& m = migRows(); m = MigRows(); for (int r = KAI_RES_PODS + 1; r < R && r < KAI_MAX_RES; r++) { m.gpus[r] = s->res_mig_gpus ? s->res_mig_gpus[r] : 0; m.mem[r] = s->res_mig_memory ? s->res_mig_memory[r] : 0; if (m.gpus[r] > 0) m.any = true; } }
     for (int p = 0; p < P; p++) {  // api/pod_info/pod_info.go:172-214 NewTaskInfo
         PodInfo& t = pods[p]; t.idx = p; t.uidRank = s->pod_uid_rank[p]; t.job = s->pod_job[p]; t.podset = s->pod_podset[p];
         t.status = s->pod_status[p]; t.node = s->pod_node[p]; t.flags = s->pod_flags ? s->pod_flags[p] : 0;
@@ -129,6 +130,8 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
             if (grp >= 0) { t.gpuGroups.push_back(grp); if (grp >= nextNewGpuGroup) nextNewGpuGroup = grp + 1; }
         }
         for (int k = KAI_RES_PODS; k < R; k++) { double v = s->pod_req[size_t(k) * P + p]; if (v != 0) t.resReq.scalars[k] = int64_t(v); }
+        t.isMigRequest = t.resReq.HasMig();                       // pod_info.go:493-497
+        t.isLegacyMig = (t.flags & KAI_POD_LEGACY_MIG) != 0;      // :500-516
     }
     // jobs own their tasks (job_info.go AddTaskInfo), nodes hold the active-used ones (node_info.go:419-437 AddTasksToNode;
     // test fixtures add them in sorted-UID order, nodes_fake/nodes.go:289-302 — order-free for whole-GPU pods)
@@ -142,7 +145,7 @@ void Session::load(const kai_config* c, const kai_snapshot_soa* s) {
 // plugins/proportion
 // =====================================================================================================
 static ResourceQuantities QuantifyResourceRequirements(const ResourceRequirements& r) { return {r.milliCpu, r.memory, r.GetGpusQuota()}; }  // utils/utils.go:15-17
-static ResourceQuantities QuantifyResource(const Resource& r) { return {r.milliCpu, r.memory, r.gpus}; }                                   // utils/utils.go:11-13 (no MIG)
+static ResourceQuantities QuantifyResource(const Resource& r) { return {r.milliCpu, r.memory, r.GetTotalGPURequest()}; }                  // utils/utils.go:11-13
 
 // resource_division.go — all functions below operate on one sibling set, in index order
 namespace resource_division {
@@ -384,7 +387,8 @@ bool Session::IsTaskAllocationOnNodeOverCapacity(PodInfo* task, PodGroupInfo* jo
     // NodeInfo.GetRequiredInitQuota (api/node_info/node_info.go:734-744): the GPU term is the request's GPU memory on this node as a fraction of
     // a device, rounded up to 1/100 — 1 for a whole-GPU request of any count, 0 for a CPU-only one, and for a fraction
     // ceil(int64(portion * mem) / mem * 100) / 100 (so 0.3 of a 100 MiB device counts as 0.31: 0.3 * 100 is 30.000000000000004 in float64)
-    ResourceQuantities q{task->resReq.milliCpu, task->resReq.memory, node->getGpuMemoryFractionalOnNode(node->GetResourceGpuMemory(task->resReq))};
+    ResourceQuantities q{task->resReq.milliCpu, task->resReq.memory, task->resReq.HasMig() ? task->resReq.GetGpusQuota()  // :736-737: a MIG request counts its instances' weights
+                                                                                             : node->getGpuMemoryFractionalOnNode(node->GetResourceGpuMemory(task->resReq))};
     return resultsOverLimit(q, job) || resultsWithNonPreemptibleOverQuota(q, job);
 }
 
@@ -591,10 +595,16 @@ bool Session::PredicateFn(PodInfo* task, PodGroupInfo* job, NodeInfo* node) {  /
     if (!(cfg.plugins & KAI_PLUGIN_PREDICATES)) return true;
     if (IsTaskAllocationOnNodeOverCapacity(task, job, node)) return false;
     // PredicateByNodeResourcesType (api/node_info/node_info.go:315-359) for regular / CPU-only requests
+    if (task->isLegacyMig) return false;  // :317-320 "Legacy MIG jobs cannot be scheduled"
     if (!task->IsCPUOnlyRequest()) {
         if (task->resReq.GPUs() > 0 && (node->flags & KAI_NODE_HAS_DRA_GPUS)) return false;
-        if ((node->flags & KAI_NODE_MIG_ENABLED) && (node->flags & KAI_NODE_MIG_MIXED)) return false;
-        if ((node->flags & KAI_NODE_MIG_ENABLED) && (node->flags & KAI_NODE_MIG_SINGLE) && !task->IsRegularGPURequest()) return false;  // :349-352
+        const bool migNode = node->flags & KAI_NODE_MIG_ENABLED;
+        if (!migNode && task->IsMigCandidate()) return false;                                      // :336-340
+        if (migNode) {
+            if (task->IsMigCandidate() && node->hasLegacyMigTasks) return false;                  // :342-346
+            if ((node->flags & KAI_NODE_MIG_SINGLE) && !task->IsRegularGPURequest()) return false;  // :349-352
+            if ((node->flags & KAI_NODE_MIG_MIXED) && !task->IsMigCandidate()) return false;       // :353-356
+        }
     }
     // checkMaxPodsWithGpuGroupReservation :264-285: a shared-GPU task that opens a new GPU group also needs room for the reservation pod
     {

@@ -61,9 +61,15 @@ struct BaseResource {
     }
 };
 
+// MIG profiles (api/common_info/resources/mig.go:13-33): a resource row >= 4 that stands for nvidia.com/mig-<g>g.<m>gb carries its GPU weight g and its memory m
+struct MigRows { int gpus[KAI_MAX_RES] = {0}; int64_t mem[KAI_MAX_RES] = {0}; bool any = false; };
+inline MigRows& migRows() { static MigRows m; return m; }
+inline double migGpus(const std::map<int, int64_t>& scalars) { double q = 0; if (migRows().any) for (auto& kv : scalars) if (kv.first < KAI_MAX_RES && migRows().gpus[kv.first] > 0) q += double(migRows().gpus[kv.first]) * double(kv.second); return q; }
+
 // api/resource_info/resource_info.go:16-19
 struct Resource : BaseResource {
     double gpus = 0;
+    double GetTotalGPURequest() const { return migGpus(scalars) + gpus; }  // resource_info.go:177-194
     void Add(const Resource& o) { BaseResource::Add(o); gpus += o.gpus; }
     void Sub(const Resource& o) { BaseResource::Sub(o); gpus -= o.gpus; }
     double Get(int r) const { return r == KAI_RES_CPU ? milliCpu : r == KAI_RES_MEM ? memory : r == KAI_RES_GPU ? gpus : GetScalar(r); }
@@ -81,10 +87,15 @@ struct ResourceRequirements : BaseResource {
     int64_t count = 0; double portion = 0;
     int64_t gpuMemory = 0;  // a request for that many MiB of one device (annotation gpu-memory, pod_info.go:463-468): count 1, portion 0
     double GPUs() const { return getExtendedResourceGpus(portion, count); }
-    double GetGpusQuota() const { return GPUs(); }  // gpu_resource_requirment.go:163-178 without mig/dra
+    // MIG instances: the reference keeps them in GpuResourceRequirement.migResources; here they are the scalar rows the MIG table names
+    bool HasMig() const { if (migRows().any) for (auto& kv : scalars) if (kv.first < KAI_MAX_RES && migRows().gpus[kv.first] > 0 && kv.second > 0) return true; return false; }
+    double GetGpusQuota() const { return migGpus(scalars) + GPUs(); }  // gpu_resource_requirment.go:163-178 (no DRA claims on the path)
     bool IsEmpty() const {                          // resource_requirment.go:99-104, gpu_resource_requirment.go:89-104
         if (GPUs() > 0.01) return false;
-        return BaseResource::IsEmpty();
+        if (HasMig()) return false;
+        if (milliCpu >= 10.0 || memory >= 10.0 * 1024 * 1024) return false;  // base_resources.go:119-130 over the scalars that are not MIG instances
+        for (auto& kv : scalars) { if (migRows().any && kv.first < KAI_MAX_RES && migRows().gpus[kv.first] > 0) continue; if (kv.second >= 10) return false; }
+        return true;
     }
     bool LessEqualResource(const Resource& rr) const {  // resource_requirment.go:126-140
         if (!BaseResource::LessEqual(rr)) return false;
@@ -122,12 +133,16 @@ struct PodInfo {
     bool receivedFraction = false;    // ResourceReceivedType == ReceivedTypeFraction (node_info.go:755-758)
     std::vector<int> gpuGroups;
     bool isMemoryRequest = false;     // ResourceRequestType == RequestTypeGpuMemory (pod_info.go:463-468)
+    bool isMigRequest = false;        // RequestTypeMigInstance: the request holds MIG instances (pod_info.go:493-497)
+    bool isLegacyMig = false;         // IsLegacyMIGtask (pod_info.go:500-516)
+    bool IsMigCandidate() const { return isMigRequest; }        // pod_info.go:320-322
+    bool IsMigProfileRequest() const { return isMigRequest; }   // :300-302
     bool IsMemoryRequest() const { return isMemoryRequest; }                                  // pod_info.go:324-326
     bool IsFractionCandidate() const { return isFractionRequest || isMemoryRequest; }        // :316-318
     bool IsSharedGPURequest() const { return isFractionRequest || isMemoryRequest; }         // :332-334
     bool IsSharedGPUAllocation() const { return receivedFraction; }    // :336-338
-    bool IsRegularGPURequest() const { return !isFractionRequest && !isMemoryRequest; }     // :328-330 (RequestTypeRegular)
-    bool IsCPUOnlyRequest() const { return !(resReq.GPUs() > 0 || isMemoryRequest); }  // pod_info.go:340-347 IsRequireAnyKindOfGPU
+    bool IsRegularGPURequest() const { return !isFractionRequest && !isMemoryRequest && !isMigRequest; }     // :328-330 (RequestTypeRegular)
+    bool IsCPUOnlyRequest() const { return !(resReq.GPUs() > 0 || isMemoryRequest || isMigRequest); }  // pod_info.go:340-347 IsRequireAnyKindOfGPU
     bool ShouldAllocate(bool isRealAllocation) const {               // pod_info.go:518-521
         return status == Pending || (!isRealAllocation && status == Releasing && isVirtualStatus);
     }
@@ -278,23 +293,24 @@ struct NodeInfo {
     double getSumOfReleasingSharedGPUs() const {  // :302-313: portions being released on shared GPUs that are not released as a whole
         double sum = 0; for (auto& kv : ReleasingSharedGPUsMemory) if (kv.second > 0 && !isGpuReleasingFromSharedTasks(kv.first)) sum += getGpuMemoryFractionalOnNode(kv.second); return sum;
     }
-    double GetSumOfIdleGPUs() const { return getSumOfAvailableSharedGPUs() + Idle.gpus; }            // node_info.go:592-609 (no MIG resources on the path)
+    bool hasLegacyMigTasks = false;  // len(LegacyMIGTasks) > 0: entries are added with the task and never removed (node_info.go:407-409)
+    double GetSumOfIdleGPUs() const { return getSumOfAvailableSharedGPUs() + Idle.gpus + migGpus(Idle.scalars); }            // node_info.go:592-609
     int64_t GetSumOfIdleGPUsMemory() const {  // the second result of :592-609 and gpu_sharing_node_info.go:314-326
         int64_t m = 0; for (auto& kv : AllocatedSharedGPUsMemory) if (kv.second > 0) m += MemoryOfEveryGpuOnNode - kv.second;
-        return m + int64_t(Idle.gpus) * MemoryOfEveryGpuOnNode;
+        return m + int64_t(Idle.gpus + migGpus(Idle.scalars)) * MemoryOfEveryGpuOnNode;
     }
     int64_t GetSumOfReleasingGPUsMemory() const {  // :611-628, :328-339
         int64_t m = 0; for (auto& kv : ReleasingSharedGPUsMemory) if (kv.second > 0 && !isGpuReleasingFromSharedTasks(kv.first)) m += kv.second;
-        return m + int64_t(Releasing.gpus) * MemoryOfEveryGpuOnNode;
+        return m + int64_t(Releasing.gpus + migGpus(Releasing.scalars)) * MemoryOfEveryGpuOnNode;
     }
-    double GetSumOfReleasingGPUs() const { return getSumOfReleasingSharedGPUs() + Releasing.gpus; }  // :611-628
+    double GetSumOfReleasingGPUs() const { return getSumOfReleasingSharedGPUs() + Releasing.gpus + migGpus(Releasing.scalars); }  // :611-628
     int64_t fractionTaskGpusAllocatableDeviceCount(const PodInfo* pod) const {  // :334-348
         int64_t n = 0;
         for (auto& kv : UsedSharedGPUsMemory) if (IsTaskFitOnGpuGroup(pod->resReq, kv.first)) { n++; if (n >= pod->resReq.count) return n; }
         return n;
     }
     bool isTaskAllocatableOnNonAllocatedResources(const PodInfo* task, const Resource& avail) const {  // :361-382
-        if (task->IsRegularGPURequest()) return task->resReq.LessEqualResource(avail);
+        if (task->IsRegularGPURequest() || task->IsMigProfileRequest()) return task->resReq.LessEqualResource(avail);
         if (!static_cast<const BaseResource&>(task->resReq).LessEqual(avail)) return false;
         if (!isValidGpuPortion(task->resReq)) return false;
         int64_t wholeGpus = int64_t(std::floor(avail.gpus));
@@ -379,6 +395,7 @@ struct NodeInfo {
     bool AddTask(PodInfo* task) {  // :384-417
         setAcceptedResources(task);
         if (podInfos.count(task->idx)) return false;  // "task already on node"
+        if (task->isLegacyMig) hasLegacyMigTasks = true;  // :407-409
         Resource r = task->accepted.AsResource();     // getAcceptedTaskResourceWithoutSharedGPU (gpu_sharing_node_info.go:52-66): no GPUs for a shared allocation
         const bool shared = task->IsSharedGPUAllocation();
         if (shared) r.gpus = 0;

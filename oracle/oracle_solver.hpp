@@ -708,7 +708,10 @@ inline void Session::executeVictimAction(int action) {
                 for (auto& n : nodes) { if (n.flags & KAI_NODE_NOT_READY) continue; sumGpus += n.GetSumOfIdleGPUs(); sumGpus += n.GetSumOfReleasingGPUs(); }
                 int64_t sumMem = 0; for (auto& n : nodes) { if (n.flags & KAI_NODE_NOT_READY) continue; sumMem += n.GetSumOfIdleGPUsMemory(); sumMem += n.GetSumOfReleasingGPUsMemory(); }
                 double requested = 0; int64_t requestedMem = 0;  // GetTasksToAllocateRequestedGPUs (allocation_info.go:55-86)
-                for (auto* t : GetTasksToAllocate(job, false)) { requested += t->resReq.GPUs(); requestedMem += t->resReq.gpuMemory; }
+                for (auto* t : GetTasksToAllocate(job, false)) {
+                    requested += t->resReq.GPUs(); requestedMem += t->resReq.gpuMemory;
+                    if (migRows().any) for (auto& kv : t->resReq.scalars) if (kv.first < KAI_MAX_RES && migRows().gpus[kv.first] > 0) { requested += double(int64_t(migRows().gpus[kv.first]) * kv.second); requestedMem += migRows().mem[kv.first] * kv.second; }  // :73-81
+                }
                 if (!(sumGpus >= requested && sumMem >= requestedMem)) break;
                 JobSolver solver{this, FeasibleNodesForJob(job),
                     [](Scenario* sc) { for (auto& kv : sc->victims) for (auto* t : kv.second.Tasks) if (t->status == Releasing) return false; return true; },  // allPodsReallocated :120-129

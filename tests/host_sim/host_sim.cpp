@@ -50,7 +50,7 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
             if (loc.scope_bits && !((loc.scope_bits[n >> 5] >> (n & 31)) & 1)) continue;
             const bool frac = c.shared_on && q.shared;
             if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
-            if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n))) continue;
+            if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n, q.kind))) continue;
             bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
             double sc = node_score(c, q, n, fit_idle);
             if (loc.scope_row >= 0) { int dd = c.node_domain[(size_t)loc.scope_row * c.N + n]; double ts = dd >= 0 ? loc.scope_score[dd] : -1.0; if (ts < 0) continue; sc += ts; }
@@ -157,6 +157,8 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     std::vector<std::vector<char>> pool;
     HostPrep prep; std::string err;
     if (prep.build(*cfg, s, err)) return KAI_ERR_INVALID_ARG;
+    for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
+        if (s->pod_flags && (s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
     KaiCtx c{};
     c.N = N; c.P = P; c.S = S; c.J = J; c.Q = Q; c.R = R; c.n_pod_classes = std::max(1, s->n_pod_classes); c.n_node_classes = std::max(1, s->n_node_classes);
     c.plugins = cfg->plugins; c.gpu_strategy = cfg->gpu_strategy; c.cpu_strategy = cfg->cpu_strategy; c.restrict_nodes = cfg->restrict_node_scheduling;
@@ -177,7 +179,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.j_pods_sorted = copy(pool, prep.sorted.data(), P); c.q_child_off = copy(pool, prep.child_off.data(), Q + 2); c.q_children = copy(pool, prep.children.data(), std::max(Q, 1));
     c.q_job_off = copy(pool, prep.job_off.data(), Q + 1); c.jobs_static = copy(pool, prep.jobs_static.data(), std::max(J, 1)); c.q_depth_order = copy(pool, prep.depth_order.data(), Q);
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64; c.use_index = c.C > 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok; c.exact_sums = prep.exact_sums;
-    if (shared) { c.use_index = 0; c.all_tracked = 0; c.fast_ok = 0; }  // every scan by brute force: the class keys know neither fractions nor the gpusharingorder score
+    if (shared || sp.mig) { c.use_index = 0; c.all_tracked = 0; c.fast_ok = 0; }  // every scan by brute force: the class keys know neither fractions nor the gpusharingorder score
     { int d = cfg->queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
     c.cls = copy(pool, prep.classes.data(), prep.classes.size());
     c.T = prep.T; c.TL = prep.TL; c.D = prep.D; c.G = prep.G; c.W = (N + 31) / 32;
@@ -204,6 +206,8 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         int32_t next_new = KAI_NEW_GROUP;
         for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && sp.shared[p]) ? s->pod_gpu_group[p] : -1; ogrp[p] = -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
         c.p_shared = copy(pool, sp.shared.data(), P); c.p_mem = copy(pool, sp.mem.data(), P); c.p_gmem = copy(pool, sp.gmem.data(), P); c.p_acc_gpu = copy(pool, sp.acc_gpu.data(), P); c.p_pend_gpu = copy(pool, sp.pend_gpu.data(), P);
+        c.p_quota_gpu = copy(pool, sp.quota_gpu.data(), P); c.p_mig_q = copy(pool, sp.mig_q.data(), P); c.p_kind = copy(pool, sp.kind.data(), P); c.quota_on = sp.on ? 1 : 0; c.mig_on = sp.mig ? 1 : 0;
+        for (int r = 0; r < KAI_MAX_RES; r++) { c.res_mig_g[r] = sp.mig_g[r]; c.res_mig_m[r] = sp.mig_m[r]; }
         for (int n = 0; n < N; n++) gm[n] = s->node_gpu_memory ? s->node_gpu_memory[prep.perm[n]] : 100;
         c.p_portion = por; c.p_group = grp; c.p_on_group = ogrp; c.n_gpu_mem = gm;
         c.ng_id = own<int32_t>(pool, (size_t)N * KAI_GMAX); for (size_t i = 0; i < (size_t)N * KAI_GMAX; i++) c.ng_id[i] = -1;
@@ -244,12 +248,12 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             uint32_t f = c.n_flags[n]; if (f & KAI_NODE_NOT_READY) continue;
             bool ignore = c.restrict_nodes && !(f & KAI_NODE_GPU_WORKER);
             c.st->total[0] += c.n_alloc[(size_t)KAI_RES_CPU * N + n]; c.st->total[1] += c.n_alloc[(size_t)KAI_RES_MEM * N + n];
-            if (!ignore) c.st->total[2] += c.n_alloc[(size_t)KAI_RES_GPU * N + n];
+            if (!ignore) { c.st->total[2] += c.n_alloc[(size_t)KAI_RES_GPU * N + n]; if (c.mig_on) for (int r = KAI_RES_PODS + 1; r < R; r++) if (c.res_mig_g[r] > 0) c.st->total[2] += (double)c.res_mig_g[r] * c.n_alloc[(size_t)r * N + n]; }
         }
         for (int p = 0; p < P; p++) {
             if (!(c.p_flags[p] & KAI_POD_FOREIGN_SCHEDULER)) continue;
             int n = c.p_on_node[p]; if (n < 0 || !st_active_used(c.p_on_node_status[p]) || (c.n_flags[n] & KAI_NODE_NOT_READY)) continue;
-            c.st->total[0] -= c.p_req[(size_t)KAI_RES_CPU * P + p]; c.st->total[1] -= c.p_req[(size_t)KAI_RES_MEM * P + p]; c.st->total[2] -= c.p_req[(size_t)KAI_RES_GPU * P + p];
+            c.st->total[0] -= c.p_req[(size_t)KAI_RES_CPU * P + p]; c.st->total[1] -= c.p_req[(size_t)KAI_RES_MEM * P + p]; c.st->total[2] -= c.quota_on ? c.p_quota_gpu[p] : c.p_req[(size_t)KAI_RES_GPU * P + p];
         }
     }
     for (int j = 0; j < J; j++) {  // k_job_usage + k_leaf_usage
@@ -263,8 +267,8 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             if (st == KAI_POD_PIPELINED) c.s_pipelined[ps]++;
             if (st == KAI_POD_PENDING) pending++;
             double q[3] = {c.p_req[(size_t)KAI_RES_CPU * P + p], c.p_req[(size_t)KAI_RES_MEM * P + p], c.p_req[(size_t)KAI_RES_GPU * P + p]};
-            const double qa = shared ? c.p_acc_gpu[p] : q[2], qp = shared ? c.p_pend_gpu[p] : q[2];  // accepted quota / pending weight of a gpu-memory request
-            if (st_allocated(st)) { for (int k = 0; k < 3; k++) ja[k] += q[k]; if (c.p_accepted[p]) for (int k = 0; k < 3; k++) { const double v = k == 2 ? qa : q[k]; al[k] += v; rq[k] += v; } }
+            const double qa = c.quota_on ? c.p_acc_gpu[p] : q[2], qp = c.quota_on ? c.p_pend_gpu[p] : q[2], qq = c.quota_on ? c.p_quota_gpu[p] : q[2];  // accepted quota / pending weight / request quota (gpu-memory, MIG)
+            if (st_allocated(st)) { for (int k = 0; k < 3; k++) ja[k] += k == 2 ? qq : q[k]; if (c.p_accepted[p]) for (int k = 0; k < 3; k++) { const double v = k == 2 ? qa : q[k]; al[k] += v; rq[k] += v; } }
             else if (st == KAI_POD_PENDING) for (int k = 0; k < 3; k++) rq[k] += k == 2 ? qp : q[k];
         }
         c.j_n_pending[j] = pending;

@@ -242,12 +242,21 @@ def case_to_snapshot(case, actions=("allocate",), fractions=False):
     node_names = sorted(case.get("Nodes", {}).keys())
     nidx = {n: i for i, n in enumerate(node_names)}
     N = len(node_names)
-    R = 4
+    # MIG instance types of the case (nodes' MigInstances, tasks' RequiredMigInstances): one resource row each, after the four base rows (ABI v5 res_mig_*)
+    mig_names = sorted({k for nd in case.get("Nodes", {}).values() if isinstance(nd, dict) for k in (nd.get("MigInstances") or {})} |
+                       {k for job in case.get("Jobs", []) if isinstance(job, dict) for t in (job.get("Tasks") or []) if isinstance(t, dict) for k in (t.get("RequiredMigInstances") or {})})
+    if mig_names and not fractions:
+        raise Unsupported("MIG instances (oracle only, allocate action)")
+    if len(mig_names) > 4:
+        raise Unsupported("more MIG profiles than resource rows")
+    import re as _re
+    mig_row = {k: 4 + i for i, k in enumerate(mig_names)}
+    R = 4 + len(mig_names)
     alloc = np.zeros((R, N)); nflags = np.zeros(N, np.uint32); gpu_count = np.zeros(N, np.int32)
     for i, nm in enumerate(node_names):
         nd = case["Nodes"][nm]
-        if nd.get("MigInstances"):
-            raise Unsupported("MIG instances")
+        for k, v in (nd.get("MigInstances") or {}).items():
+            alloc[mig_row[k], i] = int(v)  # BuildResourceList (resources_fake/resources.go:37-81): the instance count
         gpus = int(nd.get("GPUs", 0))
         mig = nd.get("MigStrategy", "")
         alloc[abi.RES_CPU, i] = _milli(nd["CPUMillis"]) if nd.get("CPUMillis", 0) > 0 else 20000.0 * 1000.0
@@ -366,8 +375,8 @@ def case_to_snapshot(case, actions=("allocate",), fractions=False):
             podset_job.append(ji); podset_min.append(int(m)); podset_names_l.append((ji, n)); podset_group.append(gi); podset_tc.append(tc)
         job_first_pod.append(len(pod_names)); job_n_pods.append(len(tasks))
         for ti, t in enumerate(tasks):
-            if t.get("RequiredMigInstances") or t.get("IsLegacyMigTask"):
-                raise Unsupported("MIG task")
+            if (t.get("RequiredMigInstances") or t.get("IsLegacyMigTask")) and not fractions:
+                raise Unsupported("MIG task (oracle only, allocate action)")
             if t.get("PodAffinityLabels") or t.get("PodAffinityTopologyKey") or t.get("PodAntiAffinityTopologyKey"):
                 raise Unsupported("inter-pod affinity")
             if t.get("ResourceClaimNames") or t.get("ResourceClaimTemplates"):
@@ -397,6 +406,8 @@ def case_to_snapshot(case, actions=("allocate",), fractions=False):
             nn = t.get("NodeName", "")
             pod_node.append(nidx.get(nn, -1) if nn else -1)
             fl = 0
+            if t.get("IsLegacyMigTask"):
+                fl |= abi.POD_LEGACY_MIG  # jobs_fake/jobs.go:213
             if t.get("Priority") is not None:
                 fl |= abi.POD_HAS_TASK_PRIORITY
             pod_flags.append(fl); pod_prio.append(int(t["Priority"]) if t.get("Priority") is not None else 0)
@@ -410,7 +421,7 @@ def case_to_snapshot(case, actions=("allocate",), fractions=False):
                 gp = g if frac else float(int(g))
             if t.get("RequiredGPUs") is not None:
                 gp = float(int(t["RequiredGPUs"]))  # jobs.go:309-312
-            req_rows.append((cpu, mem, gp, 1.0))
+            req_rows.append((cpu, mem, gp, 1.0) + tuple(float((t.get("RequiredMigInstances") or {}).get(k, 0)) for k in mig_names))
     P = len(pod_names)
     pod_req = np.zeros((R, P))
     for p, row in enumerate(req_rows):
@@ -450,6 +461,13 @@ def case_to_snapshot(case, actions=("allocate",), fractions=False):
     a["pod_flags"] = np.array(pod_flags, np.uint32); a["pod_task_priority"] = np.array(pod_prio, np.int32)
     a["pod_created_ns"] = np.zeros(P, np.int64); a["pod_uid_rank"] = abi.rank_strings(pod_names); a["pod_class"] = pod_class
     a["pod_nominated_node"] = np.full(P, -1, np.int32)
+    if mig_names:  # nvidia.com/mig-<g>g.<m>gb (api/common_info/resources/mig.go:13-33)
+        mg = np.zeros(R, np.int32); mm = np.zeros(R, np.int64)
+        for k, r in mig_row.items():
+            m = _re.match(r"^nvidia.com/mig-(\d+)g\.(\d+)gb$", k)
+            if not m: raise Unsupported("MIG profile name")
+            mg[r], mm[r] = int(m.group(1)), int(m.group(2))
+        a["res_mig_gpus"] = mg; a["res_mig_memory"] = mm
     if any(x > 0 for x in pod_gpu_portion) or any(pod_gpu_memory):  # shared GPUs (ABI v4; gpu-memory requests: v5)
         a["pod_gpu_portion"] = np.array(pod_gpu_portion, np.float64); a["pod_gpu_group"] = np.array(pod_gpu_group, np.int32)
         if any(pod_gpu_memory): a["pod_gpu_memory"] = np.array(pod_gpu_memory, np.int64)

@@ -179,9 +179,10 @@ def _same_groups(snap, res, ref):
 
 FRAC_GOLD = [(i, c) for i, c in enumerate(T.load_golden("allocate__allocateFractionalGpu")["cases"])]
 MEM_GOLD = [(i, c) for i, c in enumerate(T.load_golden("allocate__allocateGpuMemory")["cases"])]  # allocateGpuMemory_test.go: requests for MiB of one device
+MIG_GOLD = [(i, c) for i, c in enumerate(T.load_golden("allocate__allocateMIG")["cases"])]        # allocateMIG_test.go: MIG instances, legacy MIG tasks
 
 
-@pytest.mark.parametrize("i,case", FRAC_GOLD + MEM_GOLD, ids=[f"allocateFractionalGpu[{i}]" for i, _ in FRAC_GOLD] + [f"allocateGpuMemory[{i}]" for i, _ in MEM_GOLD])
+@pytest.mark.parametrize("i,case", FRAC_GOLD + MEM_GOLD + MIG_GOLD, ids=[f"allocateFractionalGpu[{i}]" for i, _ in FRAC_GOLD] + [f"allocateGpuMemory[{i}]" for i, _ in MEM_GOLD] + [f"allocateMIG[{i}]" for i, _ in MIG_GOLD])
 def test_hostsim_fractional_goldens(i, case):
     """The engine's control flow with the shared-GPU code compiled in (KAI_SHARED_GPUS, host twin) against the oracle and the reference's
     expectations on allocateFractionalGpu_test.go."""
@@ -225,6 +226,20 @@ def test_hostsim_gpu_memory_fuzz(seed, monkeypatch):
     res = HostSim.run(snap, cfg, actions)
     assert_same(res, ref, share_tol=1e-9)
     _same_groups(snap, res, ref)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_hostsim_mig_fuzz(seed):
+    """MIG nodes (MigStrategy mixed) and MIG requests (ABI v5 res_mig_*): instances as resource rows, GPU quota by weight while GPUs() stays 0, idle
+    instances in the nodes' GPU sums, the predicates of node_info.go:315-359 with legacy MIG tasks — every action, engine twin against the oracle."""
+    snap = T.pkg.synth.make_crowded_snapshot(3 + seed % 9, 4400 + seed, fill=0.3 + 0.5 * (seed % 5) / 4, n_pending_jobs=6 + seed % 13, elastic_frac=0.2,
+                                             hog_frac=0.5, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3], cpu_only_frac=0.3 if seed % 4 == 0 else 0.0)
+    T.pkg.synth.add_mig(snap, seed, node_frac=(0.3, 0.6, 1.0)[seed % 3], pod_frac=(0.5, 0.9)[seed % 2], legacy_frac=(0.0, 0.05, 0.2)[seed % 3])
+    cfg = T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=(0.0, 0.5, 1.0)[seed % 3], max_consolidation_preemptees=(-1, 16, 2)[seed % 3])
+    actions = FRAC_ACTS[seed % len(FRAC_ACTS)] if seed % 2 else ("allocate",)
+    ref = T.Oracle.run(snap, cfg, actions)
+    res = HostSim.run(snap, cfg, actions)
+    assert_same(res, ref)
 
 
 def _fraction_victim_goldens():

@@ -374,8 +374,8 @@ def assert_same_tol(res, ref, tol=1e-9):
 
 
 def _frac_cases():
-    from test_engine_hostsim import FRAC_GOLD, MEM_GOLD, FRAC_VICTIM_GOLD
-    out = [("allocate__allocateFractionalGpu", i, c, ("allocate",)) for i, c in FRAC_GOLD] + [("allocate__allocateGpuMemory", i, c, ("allocate",)) for i, c in MEM_GOLD]
+    from test_engine_hostsim import FRAC_GOLD, MEM_GOLD, MIG_GOLD, FRAC_VICTIM_GOLD
+    out = [("allocate__allocateFractionalGpu", i, c, ("allocate",)) for i, c in FRAC_GOLD] + [("allocate__allocateGpuMemory", i, c, ("allocate",)) for i, c in MEM_GOLD] + [("allocate__allocateMIG", i, c, ("allocate",)) for i, c in MIG_GOLD]
     return out + [(n, i, c, a) for n, i, c, a in FRAC_VICTIM_GOLD]
 
 
@@ -425,6 +425,20 @@ def test_gpu_gpu_memory_fuzz(gpu, seed):
         res = run_gpu(snap, cfg, acts)
         assert_same_tol(res, ref)
         _same_groups(snap, res, ref)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_gpu_mig_fuzz(gpu, seed):
+    """MIG nodes and MIG requests on the device (ABI v5 res_mig_*), see test_hostsim_mig_fuzz."""
+    from test_engine_hostsim import FRAC_ACTS
+    snap = T.pkg.synth.make_crowded_snapshot(3 + seed % 9, 4400 + seed, fill=0.3 + 0.5 * (seed % 5) / 4, n_pending_jobs=6 + seed % 13, elastic_frac=0.2,
+                                             hog_frac=0.5, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3], cpu_only_frac=0.3 if seed % 4 == 0 else 0.0)
+    T.pkg.synth.add_mig(snap, seed, node_frac=(0.3, 0.6, 1.0)[seed % 3], pod_frac=(0.5, 0.9)[seed % 2], legacy_frac=(0.0, 0.05, 0.2)[seed % 3])
+    cfg = T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=(0.0, 0.5, 1.0)[seed % 3], max_consolidation_preemptees=(-1, 16, 2)[seed % 3])
+    for acts in (("allocate",), FRAC_ACTS[seed % len(FRAC_ACTS)]):
+        ref = T.Oracle.run(snap, cfg, acts)
+        res = run_gpu(snap, cfg, acts)
+        assert_same_tol(res, ref)
 
 
 # ------------------------------------------------------------------------------------------------ node-axis sharding on the device

@@ -316,10 +316,13 @@ def test_fallback_flags_and_config_maps():
     s = ingest(doc(nodes=[node("n")], pods=pods, configMaps=[{"metadata": {"name": "cm1", "namespace": "ns"}}])).snapshot
     names = [n.split("/")[1] for n in s.pod_names]
     fl = {n: int(s.pod_flags[i]) for i, n in enumerate(names)}
-    for n in ("multi", "both", "mig", "port", "pvc", "dra", "aff"):
+    for n in ("multi", "both", "port", "pvc", "dra", "aff"):
         assert fl[n] & abi.POD_CPU_FALLBACK, n
-    for n in ("ok", "cm-ok", "cm-missing", "foreign", "prio", "frac", "mem"):  # a fraction / MiB of ONE device is described to the device (ABI v4 / v5)
+    for n in ("ok", "cm-ok", "cm-missing", "foreign", "prio", "frac", "mem", "mig"):  # a fraction / MiB of ONE device and MIG instances are described to the device (ABI v4 / v5)
         assert not fl[n] & abi.POD_CPU_FALLBACK, n
+    # the MIG profile is a resource row of its own, counted in instances, with its GPU weight and memory beside it (mig.go:13-33)
+    rows = [k for k in range(4, s.n_res) if s.res_mig_gpus[k] > 0]
+    assert len(rows) == 1 and (int(s.res_mig_gpus[rows[0]]), int(s.res_mig_memory[rows[0]])) == (1, 5) and s.pod_req[rows[0], names.index("mig")] == 1 and s.pod_req[abi.RES_GPU, names.index("mig")] == 0
     i_mem, i_frac = names.index("mem"), names.index("frac")
     assert s.pod_gpu_memory[i_mem] == 2000 and s.pod_req[abi.RES_GPU, i_mem] == 0 and s.pod_gpu_portion[i_mem] == 0  # NewGpuResourceRequirementWithGpus(0, memory): GPUs() == 0
     assert s.pod_gpu_portion[i_frac] == 0.5 and s.pod_gpu_memory[i_frac] == 0
@@ -344,7 +347,7 @@ def test_active_gpu_state_and_utility_pods():
     s = ingest(doc(nodes=[node("n")], pods=pods)).snapshot
     names = [n.split("/")[1] for n in s.pod_names]
     fl = {n: int(s.pod_flags[i]) for i, n in enumerate(names)}
-    assert fl["multi"] & abi.POD_GPU_UNMODELLED and fl["mig"] & abi.POD_GPU_UNMODELLED
+    assert fl["multi"] & abi.POD_GPU_UNMODELLED and not fl["mig"] & abi.POD_GPU_UNMODELLED  # MIG instances are resource rows (ABI v5 res_mig_*)
     assert not fl["frac"] & abi.POD_GPU_UNMODELLED and not fl["mem"] & abi.POD_GPU_UNMODELLED and not fl["plain"] & abi.POD_GPU_UNMODELLED  # a fraction / MiB of one device is described to the ABI (v4 / v5)
     assert s.pod_gpu_group[names.index("mem")] == 1 and s.pod_gpu_memory[names.index("mem")] == 2000
     assert fl["foreign"] & abi.POD_FOREIGN_SCHEDULER
@@ -672,3 +675,18 @@ def test_fraction_request_is_fixed_point():
     res = T.Oracle.run(s, got.config, ("allocate",))
     q = int(s.job_queue[s.pod_job[idx["a"]]])
     assert abs(res.shares_final["allocated"][q][2] - 1.0) < 1e-12  # 0.13 + 0.37 + 0.5
+
+
+def test_mig_node_and_legacy_mig_pod():
+    """MIG instances on the node side (ResourceFromResourceList, resource_info.go:53-79: instances by Value) and a legacy MIG pod: an annotation named like a
+    MIG profile replaces the request by that profile and marks the task (pod_info.go:500-516) — the device never schedules it (node_info.go:317-320)."""
+    nodes = [node("n", labels={"nvidia.com/mig.strategy": "mixed", "node-role.kubernetes.io/mig-enabled": "true"})]
+    nodes[0]["status"]["allocatable"]["nvidia.com/mig-2g.20gb"] = "3"
+    pods = [pod("new", requests={"nvidia.com/mig-2g.20gb": "2"}), pod("legacy", annotations={"nvidia.com/mig-2g.20gb": "1"})]
+    s = ingest(doc(nodes=nodes, pods=pods)).snapshot
+    names = [n.split("/")[1] for n in s.pod_names]
+    row = [k for k in range(4, s.n_res) if s.res_mig_gpus[k] == 2]
+    assert len(row) == 1 and s.res_mig_memory[row[0]] == 20 and s.node_allocatable[row[0], 0] == 3
+    assert s.pod_req[row[0], names.index("new")] == 2 and s.pod_req[row[0], names.index("legacy")] == 1
+    assert s.pod_flags[names.index("legacy")] & abi.POD_LEGACY_MIG and not s.pod_flags[names.index("new")] & abi.POD_LEGACY_MIG
+    assert not s.pod_flags[names.index("new")] & abi.POD_CPU_FALLBACK

@@ -3,7 +3,7 @@ import pytest
 
 import kai_testlib as T
 
-FILES = ["allocate__allocate", "allocate__allocateFractionalGpu", "allocate__allocateGpuMemory", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology",
+FILES = ["allocate__allocate", "allocate__allocateFractionalGpu", "allocate__allocateGpuMemory", "allocate__allocateMIG", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology",
          "reclaim__reclaim", "reclaim__reclaimDepartments", "reclaim__reclaimGang", "reclaim__reclaim_elastic", "reclaim__reclaim_sub_group",
          "preempt__preempt", "preempt__preemptGang", "preempt__preempt_elastic", "preempt__preempt_subgroups",
          "consolidation__consolidation", "consolidation__consolidation_subgroups"]
