@@ -37,7 +37,9 @@ import (
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/scheduler_util"
 )
 
-const nRes = 4 // cpu (milli), memory (bytes), gpu (devices), pods — api/resource_info/resource_vector.go:23-36
+const nRes = 4 // cpu (milli), memory (bytes), gpu (devices), pods — api/resource_info/resource_vector.go:23-36.  Rows >= 4 (other scalar resources; MIG instance
+// types with res_mig_gpus / res_mig_memory beside them, ABI v5) are laid out as kai_ingest.cpp does from the snapshot file; this shim packs the four base rows and leaves
+// tasks with MIG instances to the fallback rule below.
 
 var core *C.kai_core // one handle per scheduler process (= per scheduling shard)
 
