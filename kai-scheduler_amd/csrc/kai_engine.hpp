@@ -194,6 +194,7 @@ struct SolverCtx {
     double *rc_rem, *rc_ent; int32_t* rc_ent_q; uint8_t *rc_has, *rc_inv, *rc_ent_g;  // reclaimable validator scratch (rc_ent_g: the entry frees whole / shared GPUs, Resource.GPUs() > 0 — MIG instances do not count there)
     int32_t *job_head, *job_tail, *grp_link, *sc_jobs, *sc_jobs_n;  // [J+1] x 2, [P+2], [P+1], [1]: the scenario's task groups chained per job in the order they were added, and its distinct
                                                       // victim jobs in ascending index (what the validators range: kai_engine_solver.inc grp_add / scenario_jobs)
+    int32_t *q_live, *q_dead, *q_stack, *q_markl, *q_live_n;  // [Q+2] x 4, [4]: the nodes of a simulation's queue (parents before children), the children left out, scratch, the marked nodes; counts
     uint8_t *q_total, *q_relc, *q_pruned;             // [Q+1] simulation queues without bystander subtrees (kai_engine_solver.inc sim_prune): the sibling order below this node is a strict total order /
                                                       // children with relevant jobs below them in this simulation / subtree left out of this simulation's queue
     int32_t P_cap;
@@ -215,6 +216,7 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     add(Q + 2); add(Q + 2); add(Q + 2);
     add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * 4);
     add(2 * (size_t)P + J + 2);
+    for (int i = 0; i < 4; i++) add(sizeof(int32_t) * (2 * (size_t)Q + 4)); add(sizeof(int32_t) * 4);
     return b + 64;
 }
 inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, int J, int Q, int W, int DT = 0, int TL = 0, int G = 0) {
@@ -244,6 +246,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     v.q_total = (uint8_t*)take(Q + 2); v.q_relc = (uint8_t*)take(Q + 2); v.q_pruned = (uint8_t*)take(Q + 2);
     v.job_head = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.job_tail = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.grp_link = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.sc_jobs = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.sc_jobs_n = (int32_t*)take(sizeof(int32_t) * 4);
     v.rc_ent_g = (uint8_t*)take(2 * (size_t)P + J + 2);
+    v.q_live = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_dead = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_stack = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_markl = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_live_n = (int32_t*)take(sizeof(int32_t) * 4);
     v.P_cap = P;
 }
 
