@@ -112,9 +112,8 @@ def test_hostsim_config4_topology_consolidation_reclaim(scale):
     assert_same(HostSim.run(snap, cfg, acts), T.Oracle.run(snap, cfg, acts))
 
 
-INTEG_FILES = ("integration_tests__allocate__allocate", "integration_tests__allocate__allocate_topology", "integration_tests__reclaim__reclaim",
-               "integration_tests__preempt__preempt", "integration_tests__preempt__preemptGang", "integration_tests__consolidation__consolidation",
-               "integration_tests__consolidation__consolidationGang", "integration_tests__consolidation_and_reclaim__consolidation_and_reclaim")
+import test_oracle_golden as _G
+INTEG_FILES = _G.INTEG_FILES  # incl. the fraction, GPU-memory and MIG tables (allocateFractionalGpu, allocateMIG, consolidationFractional, preempt/reclaim Fractional and MIG)
 INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["cases"])]
 
 
@@ -122,10 +121,12 @@ INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["
 def test_hostsim_integration_rounds(name, i, case):
     def run_both(snap, cfg, actions):
         res = HostSim.run(snap, cfg, actions)
-        assert_same(res, T.Oracle.run(snap, cfg, actions))
+        ref = T.Oracle.run(snap, cfg, actions)
+        assert_same(res, ref, share_tol=1e-9)
+        if "pod_gpu_portion" in snap.arrays: _same_groups(snap, res, ref)
         return res
     try:
-        errs = T.run_integration(case, run_both, rounds_after=1)
+        errs = T.run_integration(case, run_both, rounds_after=1, fractions=True)
     except T.Unsupported as e:
         pytest.skip(str(e))
     assert not errs, errs[:4]
@@ -247,11 +248,13 @@ def _fraction_victim_goldens():
     import test_oracle_golden as G
     out = []
     for name, i, case, actions in G.ALL:
-        if name == "allocate__allocateFractionalGpu": continue
+        if name in ("allocate__allocateFractionalGpu", "allocate__allocateGpuMemory", "allocate__allocateMIG"): continue  # FRAC_GOLD, MEM_GOLD, MIG_GOLD
         try:
             T.case_to_snapshot(case)
-        except T.Unsupported as e:
-            if "fractional gpu (oracle" in str(e): out.append((name, i, case, actions))
+        except T.Unsupported:
+            try: T.case_to_snapshot(case, fractions=True)
+            except T.Unsupported: continue
+            out.append((name, i, case, actions))  # shared devices, GPU-memory requests or MIG: reclaim / preempt / consolidation (GpuMemory, MIG) tables
     return out
 
 

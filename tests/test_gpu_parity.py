@@ -220,9 +220,8 @@ def test_gpu_config4_topology_consolidation_reclaim(gpu, scale):
     assert_same(run_gpu(snap, cfg, acts), ref)
 
 
-INTEG_FILES = ("integration_tests__allocate__allocate", "integration_tests__allocate__allocate_topology", "integration_tests__reclaim__reclaim",
-               "integration_tests__preempt__preempt", "integration_tests__preempt__preemptGang", "integration_tests__consolidation__consolidation",
-               "integration_tests__consolidation__consolidationGang", "integration_tests__consolidation_and_reclaim__consolidation_and_reclaim")
+import test_oracle_golden as _G
+INTEG_FILES = _G.INTEG_FILES  # all 113 scenarios, incl. the fraction, GPU-memory and MIG tables
 INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["cases"])]
 
 
@@ -230,12 +229,17 @@ INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["
 def test_gpu_integration_rounds(gpu, name, i, case):
     """The reference's integration tests: full cycles (allocate, consolidation, reclaim, preempt) over several rounds with state fed back;
     every round identical to the oracle and the final cluster state as the reference expects."""
+    from test_engine_hostsim import _same_groups
     def run_both(snap, cfg, actions):
         res = run_gpu(snap, cfg, actions)
-        assert_same(res, T.Oracle.run(snap, cfg, actions))
+        ref = T.Oracle.run(snap, cfg, actions)
+        if "pod_gpu_portion" in snap.arrays:
+            assert_same_tol(res, ref); _same_groups(snap, res, ref)
+        else:
+            assert_same(res, ref)
         return res
     try:
-        errs = T.run_integration(case, run_both, rounds_after=1)
+        errs = T.run_integration(case, run_both, rounds_after=1, fractions=True)
     except T.Unsupported as e:
         pytest.skip(str(e))
     assert not errs, errs[:4]
@@ -381,7 +385,8 @@ def _frac_cases():
 
 @pytest.mark.parametrize("name,i,case,actions", _frac_cases(), ids=[f"{n}[{i}]" for n, i, _, _ in _frac_cases()])
 def test_gpu_fractional_goldens(gpu, name, i, case, actions):
-    """the reference's 35 golden scenarios with fraction pods (allocateFractionalGpu_test.go and the victim-action tables): expectations of the
+    """the reference's golden scenarios with shared devices, GPU-memory requests and MIG (allocateFractionalGpu / GpuMemory / MIG _test.go, the reclaim /
+    preempt / consolidation GpuMemory and MIG tables and the fraction cases inside the other victim-action tables): expectations of the
     reference, and operations / states / node accounting / GPU groups of the oracle"""
     from test_engine_hostsim import _same_groups
     snap, cfg, meta = T.case_to_snapshot(case, fractions=True)

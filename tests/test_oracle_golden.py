@@ -4,6 +4,7 @@ import pytest
 import kai_testlib as T
 
 FILES = ["allocate__allocate", "allocate__allocateFractionalGpu", "allocate__allocateGpuMemory", "allocate__allocateMIG", "allocate__allocateGang", "allocate__allocateElastic", "allocate__allocate_subgroups", "allocate__allocateTopology",
+         "reclaim__reclaimGpuMemory", "reclaim__reclaimMIG", "preempt__preemptGpuMemory", "preempt__preemptMIG", "consolidation__consolidationGpuMemory",
          "reclaim__reclaim", "reclaim__reclaimDepartments", "reclaim__reclaimGang", "reclaim__reclaim_elastic", "reclaim__reclaim_sub_group",
          "preempt__preempt", "preempt__preemptGang", "preempt__preempt_elastic", "preempt__preempt_subgroups",
          "consolidation__consolidation", "consolidation__consolidation_subgroups"]
@@ -29,8 +30,9 @@ def test_oracle_reproduces_reference_expectations(name, i, case, actions):
 
 
 def test_golden_coverage():
-    """The scenarios must be exercised, not silently skipped: 217 of the 218 action-test scenarios (65 allocate + 22 allocate with fractional GPUs +
-    130 reclaim / preempt / consolidation, 7 of them with shared GPUs); the one left out is a fixture built by Go code instead of a literal."""
+    """The scenarios must be exercised, not silently skipped: 250 of the 251 action-test scenarios (99 allocate, 22 of them with fractional GPUs, 6 with
+    GPU-memory requests, 6 with MIG; 151 reclaim / preempt / consolidation, 7 of them with shared GPUs, 14 with GPU-memory requests, 7 with MIG); the one
+    left out is a fixture built by Go code instead of a literal."""
     ok = 0
     for name, i, case, actions in ALL:
         try:
@@ -38,12 +40,15 @@ def test_golden_coverage():
             ok += 1
         except T.Unsupported:
             pass
-    assert ok >= 217, ok
+    assert ok >= 250, ok
 
 
 INTEG_FILES = ("integration_tests__allocate__allocate", "integration_tests__allocate__allocate_topology", "integration_tests__reclaim__reclaim",
                "integration_tests__preempt__preempt", "integration_tests__preempt__preemptGang", "integration_tests__consolidation__consolidation",
-               "integration_tests__consolidation__consolidationGang", "integration_tests__consolidation_and_reclaim__consolidation_and_reclaim")
+               "integration_tests__consolidation__consolidationGang", "integration_tests__consolidation_and_reclaim__consolidation_and_reclaim",
+               "integration_tests__allocate__allocateFractionalGpu", "integration_tests__allocate__allocateMIG", "integration_tests__consolidation__consolidationFractional",
+               "integration_tests__preempt__preemptFractional", "integration_tests__preempt__preemptMIG", "integration_tests__reclaim__reclaimFractional",
+               "integration_tests__reclaim__reclaimMIG")
 INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["cases"])]
 
 
@@ -65,4 +70,4 @@ def test_integration_coverage():
             T.run_integration(case, T.Oracle.run, rounds_after=0, fractions=True); ok += 1
         except T.Unsupported:
             pass
-    assert ok >= 80, ok
+    assert ok >= 113, ok

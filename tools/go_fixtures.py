@@ -42,6 +42,11 @@ SOURCES = [
     ("actions/preempt/preempt_subgroups_test.go", ["preempt"]),
     ("actions/consolidation/consolidation_test.go", ["consolidation"]),
     ("actions/consolidation/consolidation_subgroups_test.go", ["consolidation"]),
+    ("actions/reclaim/reclaimGpuMemory_test.go", ["reclaim"]),
+    ("actions/reclaim/reclaimMIG_test.go", ["reclaim"]),
+    ("actions/preempt/preemptGpuMemory_test.go", ["preempt"]),
+    ("actions/preempt/preemptMIG_test.go", ["preempt"]),
+    ("actions/consolidation/consolidationGpuMemory_test.go", ["consolidation"]),
     ("actions/integration_tests/allocate/allocate_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
     ("actions/integration_tests/allocate/allocate_topology_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
     ("actions/integration_tests/reclaim/reclaim_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
@@ -50,6 +55,13 @@ SOURCES = [
     ("actions/integration_tests/consolidation/consolidation_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
     ("actions/integration_tests/consolidation/consolidationGang_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
     ("actions/integration_tests/consolidation_and_reclaim/consolidation_and_reclaim_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/allocate/allocateFractionalGpu_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/allocate/allocateMIG_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/consolidation/consolidationFractional_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/preempt/preemptFractional_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/preempt/preemptMIG_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/reclaim/reclaimFractional_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
+    ("actions/integration_tests/reclaim/reclaimMIG_test.go", ["allocate", "consolidation", "reclaim", "preempt", "stalegangeviction"]),
 ]
 
 
