@@ -1290,6 +1290,40 @@ int kai_oracle_layout(int which) {
 // shared-GPU group of every pod after the last kai_oracle_run: id < 2^20 = a group of the snapshot, >= 2^20 = created by the run, -1 = none
 int kai_oracle_last_gpu_groups(int32_t* out, int cap) { int n = int(g_last_gpu_groups.size()); for (int i = 0; i < n && i < cap; i++) out[i] = g_last_gpu_groups[i]; return n; }
 
+// JobsOrderByQueues on a freshly opened session (actions/utils/job_order_by_queue.go:28-346): InitializeWithJobs over the jobs of init_mask (NULL = all of
+// them), then a script of PopNextJob (-1) and PushJob (a job index); every pop appends the job's index (-1 for nil) to out.  flags: 1 VictimQueue,
+// 2 FilterNonPending, 4 FilterUnready; depth <= 0 = QueueCapacityInfinite.  What the reference's job_order_by_queue_test.go drives directly.
+int kai_oracle_jobs_order(const kai_config* cfg, const kai_snapshot_soa* snap, int flags, int depth, const uint8_t* init_mask, const int32_t* script, int n_script,
+                          int32_t* out, int cap, int* len_after_init) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    const int Q = snap->n_queues; ssn.qattrs.resize(Q);
+    for (int q = 0; q < Q; q++) {
+        orc::QueueAttributes& a = ssn.qattrs[q]; a.idx = q; a.uidRank = ssn.queues[q].uidRank; a.parent = ssn.queues[q].parent; a.children = ssn.queues[q].children;
+        a.createdNs = ssn.queues[q].createdNs; a.priority = ssn.queues[q].priority;
+        for (int r = 0; r < 3; r++) {
+            double deserved = snap->queue_deserved[r * Q + q], limit = snap->queue_limit[r * Q + q];
+            if (r == KAI_Q_MEM) { deserved = std::fmax(KAI_UNLIMITED, deserved * 1000000.0); limit = std::fmax(KAI_UNLIMITED, limit * 1000000.0); }
+            a.share[r].Deserved = deserved; a.share[r].MaxAllowed = limit; a.share[r].OverQuotaWeight = snap->queue_oqw[r * Q + q];
+            a.share[r].Usage = snap->queue_usage ? snap->queue_usage[r * Q + q] : 0.0;
+        }
+    }
+    ssn.proportionOnSessionOpen();
+    orc::JobsOrderInitOptions o; o.VictimQueue = flags & 1; o.FilterNonPending = flags & 2; o.FilterUnready = flags & 4; o.MaxJobsQueueDepth = depth <= 0 ? -1 : depth;
+    orc::JobsOrderByQueues jobsOrder(&ssn, o);
+    std::vector<orc::PodGroupInfo*> init; for (size_t j = 0; j < ssn.jobs.size(); j++) if (!init_mask || init_mask[j]) init.push_back(&ssn.jobs[j]);
+    jobsOrder.InitializeWithJobs(init);
+    if (len_after_init) *len_after_init = jobsOrder.Len();
+    int n = 0;
+    for (int i = 0; i < n_script; i++) {
+        if (script[i] >= 0) { if (script[i] >= int(ssn.jobs.size())) return KAI_ERR_INVALID_ARG; jobsOrder.PushJob(&ssn.jobs[script[i]]); continue; }
+        if (n >= cap) return KAI_ERR_CAPACITY;
+        orc::PodGroupInfo* job = jobsOrder.IsEmpty() ? nullptr : jobsOrder.PopNextJob();
+        out[n++] = job ? job->idx : -1;
+    }
+    return n;
+}
+
 // Session.OrderedNodesByTask + FittingNode for ONE task over a node subset of a freshly opened session (framework/session.go:201-264):
 // what kai_best_node answers.  nodeset_bitmap may be NULL (all nodes); bit n of word n/32 = caller's node index n.
 int kai_oracle_best_node(const kai_config* cfg, const kai_snapshot_soa* snap, int pod, const uint32_t* nodeset_bitmap, int pipeline_only, int* node_out, int* is_pipeline_out) {
