@@ -1324,6 +1324,28 @@ int kai_oracle_jobs_order(const kai_config* cfg, const kai_snapshot_soa* snap, i
     return n;
 }
 
+// plugins/proportion/reclaimable on hand-set queue attributes (what reclaimable_test.go drives): shares = Q x 3 (cpu, memory, gpu) x 5 (Deserved, FairShare,
+// MaxAllowed, Allocated, AllocatedNotPreemptible); required / res rows = (milli-cpu, memory, gpus).  mode 0 = Reclaimable (reclaimable.go:56-232),
+// mode 1 = CanReclaimResources (:29-54).  → 1 / 0, < 0 on bad arguments.
+int kai_oracle_reclaimable(int mode, int Q, const int32_t* parent, const double* shares, int reclaimer_queue, const double* required, int preemptible,
+                           int n_res, const int32_t* res_queue, const double* res, double saturation_multiplier) {
+    if (Q <= 0 || !parent || !shares || !required || reclaimer_queue < 0 || reclaimer_queue >= Q) return KAI_ERR_INVALID_ARG;
+    std::vector<orc::QueueAttributes> qa(Q);
+    for (int q = 0; q < Q; q++) {
+        qa[q].idx = q; qa[q].parent = parent[q];
+        for (int r = 0; r < 3; r++) {
+            const double* v = shares + (size_t(q) * 3 + r) * 5; orc::ResourceShare& sh = qa[q].share[r];
+            sh.Deserved = v[0]; sh.FairShare = v[1]; sh.MaxAllowed = v[2]; sh.Allocated = v[3]; sh.AllocatedNotPreemptible = v[4];
+        }
+    }
+    for (int q = 0; q < Q; q++) if (parent[q] >= 0) qa[parent[q]].children.push_back(q);
+    orc::Resource req; req.milliCpu = required[0]; req.memory = required[1]; req.gpus = required[2];
+    if (mode == 1) return orc::canReclaimResourcesCore(qa[reclaimer_queue], orc::QuantifyResource(req), preemptible != 0) ? 1 : 0;
+    std::map<int, std::vector<orc::Resource>> by_queue;
+    for (int i = 0; i < n_res; i++) { if (res_queue[i] < 0 || res_queue[i] >= Q) return KAI_ERR_INVALID_ARG; orc::Resource x; x.milliCpu = res[i * 3]; x.memory = res[i * 3 + 1]; x.gpus = res[i * 3 + 2]; by_queue[res_queue[i]].push_back(x); }
+    return orc::reclaimableCore(qa, reclaimer_queue, req, preemptible != 0, by_queue, saturation_multiplier) ? 1 : 0;
+}
+
 // Session.OrderedNodesByTask + FittingNode for ONE task over a node subset of a freshly opened session (framework/session.go:201-264):
 // what kai_best_node answers.  nodeset_bitmap may be NULL (all nodes); bit n of word n/32 = caller's node index n.
 int kai_oracle_best_node(const kai_config* cfg, const kai_snapshot_soa* snap, int pod, const uint32_t* nodeset_bitmap, int pipeline_only, int* node_out, int* is_pipeline_out) {

@@ -502,18 +502,22 @@ struct MinimalJobRepresentatives {
 };
 
 // ---------------------------------------------------------------- plugins/proportion/reclaimable/{reclaimable,strategies/strategies}.go
-inline bool Session::CanReclaimResources(PodGroupInfo* reclaimer) {  // reclaimable.go:29-54 via proportion.go:138-141
-    if (!(cfg.plugins & KAI_PLUGIN_PROPORTION)) return false;       // session_plugins.go:117-123: no registered fn → false
-    QueueAttributes& q = qattrs[reclaimer->queue];
-    ResourceQuantities requested = QuantifyResource(GetTasksToAllocateInitResource(reclaimer, false));
+// Reclaimable.CanReclaimResources (reclaimable.go:29-54) on one queue's attributes: what the reference's reclaimable_test.go drives directly
+inline bool canReclaimResourcesCore(const QueueAttributes& q, const ResourceQuantities& requested, bool isPreemptible) {
     ResourceQuantities allocated = q.GetAllocatedShare(); for (int r = 0; r < 3; r++) allocated[r] += requested[r];
     if (!rqLessEqual(allocated, q.GetFairShare())) return false;
-    if (reclaimer->IsPreemptibleJob()) return true;
+    if (isPreemptible) return true;
     ResourceQuantities np = q.get(&ResourceShare::AllocatedNotPreemptible); for (int r = 0; r < 3; r++) np[r] += requested[r];
     return rqLessEqual(np, q.GetDeservedShare());
 }
+inline bool Session::CanReclaimResources(PodGroupInfo* reclaimer) {  // reclaimable.go:29-54 via proportion.go:138-141
+    if (!(cfg.plugins & KAI_PLUGIN_PROPORTION)) return false;       // session_plugins.go:117-123: no registered fn → false
+    return canReclaimResourcesCore(qattrs[reclaimer->queue], QuantifyResource(GetTasksToAllocateInitResource(reclaimer, false)), reclaimer->IsPreemptibleJob());
+}
 struct Involved { bool r[3] = {false, false, false}; void add(const Resource& x) { if (x.milliCpu > 0) r[0] = true; if (x.memory > 0) r[1] = true; if (x.gpus > 0) r[2] = true; } void merge(const Involved& o) { for (int i = 0; i < 3; i++) r[i] = r[i] || o.r[i]; } };
-inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 + reclaimable.go:56-232
+inline bool reclaimableCore(const std::vector<QueueAttributes>& Q, int reclaimerQueue, const Resource& required, bool reclaimerPreemptible,
+                            const std::map<int, std::vector<Resource>>& totalVictimsResources, double saturationMultiplier);
+inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 (the victims' resources by queue), then reclaimable.go:56-232
     const std::vector<QueueAttributes>& Q = jobSimulationQueues;
     PodGroupInfo* reclaimer = sc->preemptor;
     Resource required = GetTasksToAllocateInitResource(reclaimer, false);
@@ -540,12 +544,18 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 + r
         if (res.empty()) continue;
         auto& dst = totalVictimsResources[victim.Job->queue]; dst.insert(dst.end(), res.begin(), res.end());
     }
+    return reclaimableCore(Q, reclaimer->queue, required, reclaimer->IsPreemptibleJob(), totalVictimsResources, cfg.reclaimer_saturation_multiplier);
+}
+// Reclaimable.Reclaimable (reclaimable.go:56-232) on queue attributes, the reclaimer's queue / required resources and the reclaimees' resources by queue — the
+// signature the reference's reclaimable_test.go drives
+inline bool reclaimableCore(const std::vector<QueueAttributes>& Q, int reclaimerQueue, const Resource& required, bool reclaimerPreemptible,
+                            const std::map<int, std::vector<Resource>>& totalVictimsResources, double saturationMultiplier) {
     auto path = [&](int q) { std::vector<int> p; for (; q >= 0; q = Q[q].parent) p.insert(p.begin(), q); return p; };  // getHierarchyPath :253-262
     // reclaimResourcesFromReclaimees :69-108
     std::map<int, ResourceQuantities> remaining; std::map<int, Involved> involved;
     for (auto& kv : totalVictimsResources) {
         int reclaimeeQueueID = kv.first;
-        std::vector<int> a = path(reclaimer->queue), b = path(reclaimeeQueueID);  // getLeveledQueues :234-251
+        std::vector<int> a = path(reclaimerQueue), b = path(reclaimeeQueueID);  // getLeveledQueues :234-251
         int rq = -1, eq = -1; for (size_t i = 0; i < std::min(a.size(), b.size()); i++) { rq = a[i]; eq = b[i]; if (rq != eq) break; }
         Involved inv; for (auto& r : kv.second) inv.add(r);
         involved[reclaimeeQueueID] = inv;
@@ -570,7 +580,7 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 + r
     }
     // reclaimingQueuesRemainWithinBoundaries :135-190
     ResourceQuantities requestedQuota = QuantifyResource(required); Involved reclaimerInvolved; reclaimerInvolved.add(required);
-    for (int rq = reclaimer->queue; rq >= 0; rq = Q[rq].parent) {
+    for (int rq = reclaimerQueue; rq >= 0; rq = Q[rq].parent) {
         ResourceQuantities rem = remaining.count(rq) ? remaining[rq] : Q[rq].GetAllocatedShare();
         for (int r = 0; r < 3; r++) rem[r] += requestedQuota[r];
         if (remaining.count(rq)) remaining[rq] = rem;  // the map holds the slice-backed value: Add mutates the stored entry
@@ -584,10 +594,10 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 + r
                 if (rf[r] == KAI_UNLIMITED && sf[r] == KAI_UNLIMITED) continue;
                 auto ratio = [](double allocated, double fair) { if (fair == 0) return allocated > 0 ? INFINITY : 0.0; if (fair == KAI_UNLIMITED) return 0.0; return allocated / fair; };
                 double ratioReclaimer = ratio(rem[r], rf[r]), ratioSibling = ratio(kv.second[r], sf[r]);
-                if (ratioReclaimer > 1 && sf[r] > 0 && ratioReclaimer * cfg.reclaimer_saturation_multiplier >= ratioSibling) return false;
+                if (ratioReclaimer > 1 && sf[r] > 0 && ratioReclaimer * saturationMultiplier >= ratioSibling) return false;
             }
         }
-        if (reclaimer->IsPreemptibleJob()) continue;
+        if (reclaimerPreemptible) continue;
         ResourceQuantities np = Q[rq].get(&ResourceShare::AllocatedNotPreemptible); for (int r = 0; r < 3; r++) np[r] += requestedQuota[r];
         if (!rqLessEqual(np, Q[rq].GetDeservedShare())) return false;
     }

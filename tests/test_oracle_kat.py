@@ -94,3 +94,29 @@ def test_minruntime_resolver_known_answers():
     assert [q(0, 6, 0), q(0, 5, 0), q(0, 3, 0), q(0, 1, 0), q(0, 2, 0)] == [15, 20, 5, 20, 4]     # getPreemptMinRuntime :38-77
     assert [q(3, 6, 1), q(3, 4, 1)] == [35, 10]                                                    # queue method :97-120
     assert [q(3, 6, 2), q(4, 3, 2), q(5, 6, 2), q(6, 6, 2), q(3, 7, 2)] == [30, 8, 35, 35, 6]      # LCA method :148-203
+
+
+# ------------------------------------------------------------------------------------------------ plugins/proportion/reclaimable
+RECLAIMABLE = T.load_golden("kat_reclaimable")
+
+
+@pytest.mark.parametrize("case", RECLAIMABLE["cases"], ids=[f"{c['mode']}:{c['line']}" for c in RECLAIMABLE["cases"]])
+def test_reclaimable_known_answers(case):
+    """plugins/proportion/reclaimable/reclaimable_test.go: CanReclaimResources (:34-531: the reclaimer's queue stays within its fair share, a non-preemptible
+    reclaimer within its quota) and Reclaimable (:533-1163: strategies per reclaimee chunk, saturation ratios between siblings on every level, non-preemptible
+    quota up the reclaimer's chain) on hand-set queue attributes — through kai_oracle_reclaimable, the same core the oracle's scenario validator calls."""
+    import ctypes as C
+    lib = T.Oracle.lib(); lib.kai_oracle_reclaimable.restype = C.c_int
+    names = list(case["queues"])
+    Q = len(names)
+    parent = np.array([names.index(case["queues"][n][0]) if case["queues"][n][0] else -1 for n in names], np.int32)
+    shares = np.array([[case["queues"][n][1][r] for r in ("cpu", "memory", "gpu")] for n in names], np.float64)  # Q x 3 x 5
+    rq, req, preemptible = case["reclaimer"]
+    req = np.array(req, np.float64)
+    res_q = np.array([names.index(q) for q, _ in case["reclaimees"]], np.int32)
+    res = np.array([r for _, r in case["reclaimees"]], np.float64).reshape(-1, 3)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)); ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    got = lib.kai_oracle_reclaimable(1 if case["mode"] == "can_reclaim" else 0, Q, ip(parent), dp(shares), names.index(rq), dp(req), int(preemptible),
+                                     len(res_q), ip(res_q), dp(res), C.c_double(RECLAIMABLE["saturation_multiplier"]))
+    assert got in (0, 1), got
+    assert bool(got) == case["want"], f"{case['name']} (reclaimable_test.go:{case['line']})"
