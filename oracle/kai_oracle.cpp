@@ -1324,6 +1324,45 @@ int kai_oracle_jobs_order(const kai_config* cfg, const kai_snapshot_soa* snap, i
     return n;
 }
 
+// The order plugins as three-way comparisons on hand-built operands (elastic_test.go, subgroup_order_test.go, task_order_test.go).  The oracle's session
+// functions are strict orders that end in creation time / UID; evaluated with that tie-break in l's favour and then in r's, a result that follows the tie-break is the
+// plugin's 0.  which 0 = elastic.JobOrderFn: l / r = pod-sets x (minAvailable, active allocated tasks) of each job; 1 = subgrouporder.PodSetOrderFn: (minAvailable,
+// allocated); 2 = taskorder.TaskOrderFn: (has label, priority).  → -1 / 0 / 1
+int kai_oracle_order_fn(int which, const int32_t* l, int nl, const int32_t* r, int nr) {
+    kai_config cfg{}; cfg.plugins = which == 0 ? KAI_PLUGIN_ELASTIC : which == 1 ? KAI_PLUGIN_SUBGROUPORDER : KAI_PLUGIN_TASKORDER;
+    orc::Session ssn; ssn.cfg = cfg;
+    bool res[2];
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t lr = pass == 0 ? 0 : 1, rr = 1 - lr;  // pass 0: every tie-break says l first
+        if (which == 0) {
+            std::vector<orc::PodSet> ls(nl), rs(nr); orc::PodGroupInfo lj, rj;
+            for (int i = 0; i < nl; i++) { ls[i].minAvailable = l[2 * i]; ls[i].numActiveAllocatedTasks = l[2 * i + 1]; lj.podSets.push_back(&ls[i]); }
+            for (int i = 0; i < nr; i++) { rs[i].minAvailable = r[2 * i]; rs[i].numActiveAllocatedTasks = r[2 * i + 1]; rj.podSets.push_back(&rs[i]); }
+            lj.uidRank = lr; rj.uidRank = rr;
+            res[pass] = ssn.JobOrderFn(&lj, &rj);
+        } else if (which == 1) {
+            orc::PodSet a, b; a.minAvailable = l[0]; a.numActiveAllocatedTasks = l[1]; b.minAvailable = r[0]; b.numActiveAllocatedTasks = r[1]; a.nameRank = lr; b.nameRank = rr;
+            res[pass] = ssn.PodSetOrderFn(&a, &b);
+        } else {
+            orc::PodInfo a, b; a.flags = l[0] ? KAI_POD_HAS_TASK_PRIORITY : 0; a.taskPriority = l[1]; b.flags = r[0] ? KAI_POD_HAS_TASK_PRIORITY : 0; b.taskPriority = r[1]; a.uidRank = lr; b.uidRank = rr;
+            res[pass] = ssn.TaskOrderFn(&a, &b);
+        }
+    }
+    return res[0] && res[1] ? -1 : (!res[0] && !res[1]) ? 1 : 0;
+}
+
+// plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
+// FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
+int kai_oracle_resource_share(const double* rs, const double* total, double* out) {
+    if (!rs || !total || !out) return KAI_ERR_INVALID_ARG;
+    orc::QueueAttributes qa;
+    for (int r = 0; r < 3; r++) { const double* v = rs + r * 7; orc::ResourceShare& sh = qa.share[r];
+        sh.Deserved = v[0]; sh.FairShare = v[1]; sh.MaxAllowed = v[2]; sh.OverQuotaWeight = v[3]; sh.Allocated = v[4]; sh.AllocatedNotPreemptible = v[5]; sh.Request = v[6]; }
+    for (int r = 0; r < 3; r++) { out[r] = qa.share[r].GetRequestableShare(); out[3 + r] = qa.share[r].GetAllocatableShare(); }
+    out[6] = qa.GetDominantResourceShare({total[0], total[1], total[2]});
+    return KAI_OK;
+}
+
 // plugins/proportion/reclaimable on hand-set queue attributes (what reclaimable_test.go drives): shares = Q x 3 (cpu, memory, gpu) x 5 (Deserved, FairShare,
 // MaxAllowed, Allocated, AllocatedNotPreemptible); required / res rows = (milli-cpu, memory, gpus).  mode 0 = Reclaimable (reclaimable.go:56-232),
 // mode 1 = CanReclaimResources (:29-54).  → 1 / 0, < 0 on bad arguments.

@@ -120,3 +120,61 @@ def test_reclaimable_known_answers(case):
                                      len(res_q), ip(res_q), dp(res), C.c_double(RECLAIMABLE["saturation_multiplier"]))
     assert got in (0, 1), got
     assert bool(got) == case["want"], f"{case['name']} (reclaimable_test.go:{case['line']})"
+
+
+def _resource_share(rs, total=(0.0, 0.0, 0.0)):
+    lib = T.Oracle.lib(); lib.kai_oracle_resource_share.restype = C.c_int
+    a = np.array(rs, np.float64); t = np.array(total, np.float64); out = np.zeros(7)
+    assert lib.kai_oracle_resource_share(a.ctypes.data_as(C.POINTER(C.c_double)), t.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    return out
+
+
+def test_resource_share_known_answers():
+    """plugins/proportion/resource_share: queue_resource_share_test.go:81-105 (requestable share 3 / 10 / 17, dominant share 2.5 of createQueueResourceShare :120-151)
+    and resource_share_test.go:46-80 (requestable = min(MaxAllowed, Request), allocatable = min(MaxAllowed, max(Deserved, FairShare)), both with an unlimited MaxAllowed)."""
+    q = [[1, 2, 3, 4, 5, 6, 7], [8, 9, 10, 11, 12, 13, 14], [15, 16, 17, 18, 19, 20, 21]]
+    out = _resource_share(q)
+    assert list(out[:3]) == [3.0, 10.0, 17.0] and out[6] == 2.5
+    r = [21, 22, 10, 2, 5, 4, 17]  # createResourceShare
+    out = _resource_share([r, r, r]); assert out[0] == 10.0 and out[3] == 10.0
+    r[2] = -1.0
+    out = _resource_share([r, r, r]); assert out[0] == 17.0 and out[3] == 22.0
+
+
+# ------------------------------------------------------------------------------------------------ plugins/elastic, subgrouporder, taskorder
+def _order_fn(which, l, r):
+    lib = T.Oracle.lib(); lib.kai_oracle_order_fn.restype = C.c_int
+    a = np.array(l, np.int32).reshape(-1); b = np.array(r, np.int32).reshape(-1)
+    n = 2 if which == 0 else 1
+    return lib.kai_oracle_order_fn(which, a.ctypes.data_as(C.POINTER(C.c_int32)), len(a) // n if which == 0 else 1, b.ctypes.data_as(C.POINTER(C.c_int32)), len(b) // n if which == 0 else 1)
+
+
+ACTIVE_ALLOCATED = ("Allocated", "Binding", "Bound", "Running", "Pipelined")  # pod_status.IsActiveAllocatedStatus: a releasing pod is not
+ELASTIC = [  # plugins/elastic/elastic_test.go:24-482 (line, minAvailable of l / r, pod states of l / r, JobOrderFn)
+    (31, 0, 0, [], [], 0), (55, 1, 1, ["Running"], ["Running"], 0), (91, 1, 1, ["Allocated"], ["Running"], 0), (127, 1, 1, ["Bound"], ["Running"], 0),
+    (163, 1, 1, ["Releasing"], ["Running"], -1), (199, 1, 1, ["Running"], [], 1), (226, 2, 2, ["Running"], ["Running"] * 2, -1), (268, 2, 2, ["Running"], ["Running"] * 3, -1),
+    (316, 1, 1, ["Running"], ["Running"] * 2, -1), (358, 1, 3, ["Running"], ["Running"] * 2, 1), (400, 1, 1, ["Running"] * 2, ["Running"], 1), (442, 1, 1, ["Running"] * 2, ["Running"], 1),
+]
+
+
+@pytest.mark.parametrize("line,lmin,rmin,lp,rp,want", ELASTIC, ids=[f"elastic:{c[0]}" for c in ELASTIC])
+def test_elastic_job_order_known_answers(line, lmin, rmin, lp, rp, want):
+    """elastic.JobOrderFn (plugins/elastic/elastic.go:25-65): below minAvailable first, then exactly at it, then above — by the active ALLOCATED pods of every pod-set"""
+    n = lambda pods: sum(1 for s in pods if s in ACTIVE_ALLOCATED)
+    assert _order_fn(0, [lmin, n(lp)], [rmin, n(rp)]) == want, f"elastic_test.go:{line}"
+
+
+SUBGROUP_ORDER = [(3, 1, 4, 2, 0), (3, 1, 3, 5, -1), (3, 5, 3, 1, 1), (2, 4, 4, 9, -1), (2, 10, 4, 9, 1), (2, 4, 4, 8, 0)]  # subgroup_order_test.go:40-89
+
+
+@pytest.mark.parametrize("lmin,lalloc,rmin,ralloc,want", SUBGROUP_ORDER)
+def test_subgroup_order_known_answers(lmin, lalloc, rmin, ralloc, want):
+    """subgrouporder.PodSetOrderFn (subgroup_order.go:31-62): a pod-set below its minAvailable first, above it the smaller allocated / minAvailable ratio"""
+    assert _order_fn(1, [lmin, lalloc], [rmin, ralloc]) == want
+
+
+def test_task_order_known_answers():
+    """taskorder.TaskOrderFn (task_order_test.go:17-53): the higher kai.scheduler/task-priority label first, a pod with the label before one without"""
+    L = lambda p: [1, p]; NONE = [0, 0]
+    assert _order_fn(2, L(1), L(2)) == 1 and _order_fn(2, L(2), L(2)) == 0 and _order_fn(2, L(2), L(1)) == -1
+    assert _order_fn(2, NONE, L(1)) == 1 and _order_fn(2, L(1), NONE) == -1 and _order_fn(2, NONE, NONE) == 0
