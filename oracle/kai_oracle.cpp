@@ -1351,6 +1351,25 @@ int kai_oracle_order_fn(int which, const int32_t* l, int nl, const int32_t* r, i
     return res[0] && res[1] ? -1 : (!res[0] && !res[1]) ? 1 : 0;
 }
 
+// scheduler_util.PriorityQueue over ints under "<" (priority_queue_test.go): script of (op, value): 0 Push(value), 1 Pop → out, 2 Peek → out (-1 when empty),
+// 3 set the top item's value and Fix(0), 4 Len → out.  max_size <= 0 = QueueCapacityInfinite.  → number of outputs
+int kai_oracle_priority_queue(int max_size, const int32_t* script, int n_ops, int32_t* out, int cap) {
+    std::vector<std::unique_ptr<int>> store; orc::PriorityQueue<int*> q; q.maxQueueSize = max_size <= 0 ? -1 : max_size;
+    q.lessFn = [](int* const& l, int* const& r) { return *l < *r; };
+    int n = 0;
+    for (int i = 0; i < n_ops; i++) {
+        const int op = script[2 * i], v = script[2 * i + 1];
+        if (op == 0) { store.emplace_back(new int(v)); q.Push(store.back().get()); continue; }
+        if (op == 3) { if (q.Empty()) return KAI_ERR_INVALID_ARG; *q.items[0] = v; q.Fix(0); continue; }
+        if (n >= cap) return KAI_ERR_CAPACITY;
+        if (op == 1) out[n++] = q.Empty() ? -1 : *q.Pop();
+        else if (op == 2) out[n++] = q.Empty() ? -1 : *q.Peek();
+        else if (op == 4) out[n++] = q.Len();
+        else return KAI_ERR_INVALID_ARG;
+    }
+    return n;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

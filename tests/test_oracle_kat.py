@@ -178,3 +178,24 @@ def test_task_order_known_answers():
     L = lambda p: [1, p]; NONE = [0, 0]
     assert _order_fn(2, L(1), L(2)) == 1 and _order_fn(2, L(2), L(2)) == 0 and _order_fn(2, L(2), L(1)) == -1
     assert _order_fn(2, NONE, L(1)) == 1 and _order_fn(2, L(1), NONE) == -1 and _order_fn(2, NONE, NONE) == 0
+
+
+# ------------------------------------------------------------------------------------------------ scheduler_util/priority_queue.go
+def _pq(max_size, ops):
+    lib = T.Oracle.lib(); lib.kai_oracle_priority_queue.restype = C.c_int
+    sc = np.array(ops, np.int32).reshape(-1); out = (C.c_int32 * 32)()
+    n = lib.kai_oracle_priority_queue(max_size, sc.ctypes.data_as(C.POINTER(C.c_int32)), len(ops), out, 32)
+    assert n >= 0, n
+    return [out[i] for i in range(n)]
+
+
+def test_priority_queue_known_answers():
+    """scheduler_util/priority_queue_test.go: Push / Pop with and without a capacity (:13-108: a full queue drops an item — the one the heap holds at index
+    maxQueueSize after the push), Peek (:110-186), Fix after the top item's key changed (:188-245), Empty / Len (:247-305)"""
+    PUSH, POP, PEEK, FIX, LEN = 0, 1, 2, 3, 4
+    assert _pq(0, [(PUSH, 2), (PUSH, 3), (PUSH, 1), (LEN, 0), (POP, 0)]) == [3, 1]
+    assert _pq(0, [(PUSH, 1), (PUSH, 3), (PUSH, 2), (LEN, 0), (POP, 0)]) == [3, 1]
+    assert _pq(2, [(PUSH, 2), (PUSH, 3), (PUSH, 4), (PUSH, 1), (LEN, 0), (POP, 0)]) == [2, 1]
+    assert _pq(0, [(PUSH, 2), (PUSH, 3), (PEEK, 0), (LEN, 0)]) == [2, 2] and _pq(0, [(PEEK, 0)]) == [-1]
+    assert _pq(0, [(PUSH, 2), (PUSH, 3), (FIX, 4), (PEEK, 0)]) == [3]
+    assert _pq(0, [(LEN, 0)]) == [0] and _pq(0, [(PUSH, 5), (LEN, 0)]) == [1] and _pq(0, [(PUSH, 5), (PUSH, 1), (PUSH, 9), (LEN, 0)]) == [3]
