@@ -1370,6 +1370,18 @@ int kai_oracle_priority_queue(int max_size, const int32_t* script, int n_ops, in
     return n;
 }
 
+// reclaimable/strategies on hand-set attributes (strategies_test.go): shares rows as in kai_oracle_reclaimable (3 x 5 per queue); which 0 = MaintainFairShare,
+// 1 = GuaranteeDeservedQuota → 1 / 0
+int kai_oracle_reclaim_strategy(int which, const double* reclaimer, const double* reclaimee, const double* required, const double* remaining) {
+    if (!reclaimer || !reclaimee || !required || !remaining) return KAI_ERR_INVALID_ARG;
+    orc::QueueAttributes a, b;
+    for (int r = 0; r < 3; r++) for (int side = 0; side < 2; side++) { const double* v = (side ? reclaimee : reclaimer) + r * 5; orc::ResourceShare& sh = (side ? b : a).share[r];
+        sh.Deserved = v[0]; sh.FairShare = v[1]; sh.MaxAllowed = v[2]; sh.Allocated = v[3]; sh.AllocatedNotPreemptible = v[4]; }
+    orc::Resource req; req.milliCpu = required[0]; req.memory = required[1]; req.gpus = required[2];
+    const orc::ResourceQuantities rem{remaining[0], remaining[1], remaining[2]};
+    return (which == 0 ? orc::maintainFairShareStrategy(b, rem) : orc::guaranteeDeservedQuotaStrategy(req, a, b, rem)) ? 1 : 0;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

@@ -546,6 +546,16 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 (th
     }
     return reclaimableCore(Q, reclaimer->queue, required, reclaimer->IsPreemptibleJob(), totalVictimsResources, cfg.reclaimer_saturation_multiplier);
 }
+// reclaimable/strategies/strategies.go: MaintainFairShareStrategy :45-60 — the reclaimee is over what it may hold; GuaranteeDeservedQuotaStrategy :62-91 — the
+// reclaimer stays within its deserved quota with the job and the reclaimee is over its own
+inline bool maintainFairShareStrategy(const QueueAttributes& reclaimee, const ResourceQuantities& reclaimeeRemainingShare) {
+    return !rqLessEqual(reclaimeeRemainingShare, reclaimee.GetAllocatableShare());
+}
+inline bool guaranteeDeservedQuotaStrategy(const Resource& reclaimerResources, const QueueAttributes& reclaimer, const QueueAttributes& reclaimee, const ResourceQuantities& reclaimeeRemainingShare) {
+    ResourceQuantities want = reclaimer.GetAllocatedShare(), rr = QuantifyResource(reclaimerResources); for (int r = 0; r < 3; r++) want[r] += rr[r];
+    if (!rqLessEqual(want, reclaimer.GetDeservedShare())) return false;  // reclaimerWillGoOverQuota :93-98
+    return !rqLessEqual(reclaimeeRemainingShare, reclaimee.GetDeservedShare());
+}
 // Reclaimable.Reclaimable (reclaimable.go:56-232) on queue attributes, the reclaimer's queue / required resources and the reclaimees' resources by queue — the
 // signature the reference's reclaimable_test.go drives
 inline bool reclaimableCore(const std::vector<QueueAttributes>& Q, int reclaimerQueue, const Resource& required, bool reclaimerPreemptible,
@@ -562,14 +572,8 @@ inline bool reclaimableCore(const std::vector<QueueAttributes>& Q, int reclaimer
         if (!remaining.count(eq)) remaining[eq] = Q[eq].GetAllocatedShare();
         for (auto& res : kv.second) {
             ResourceQuantities& rem = remaining[eq];
-            // strategies.FitsReclaimStrategy :20-35: MaintainFairShare :45-60, GuaranteeDeservedQuota :62-91
-            bool fits = !rqLessEqual(rem, Q[eq].GetAllocatableShare());
-            if (!fits) {
-                ResourceQuantities want = Q[rq].GetAllocatedShare(), rr = QuantifyResource(required); for (int r = 0; r < 3; r++) want[r] += rr[r];
-                bool over = !rqLessEqual(want, Q[rq].GetDeservedShare());
-                fits = !over && !rqLessEqual(rem, Q[eq].GetDeservedShare());
-            }
-            if (!fits) return false;
+            // strategies.FitsReclaimStrategy :20-35
+            if (!maintainFairShareStrategy(Q[eq], rem) && !guaranteeDeservedQuotaStrategy(required, Q[rq], Q[eq], rem)) return false;
             // subtractReclaimedResources :110-133
             for (int q = reclaimeeQueueID; q >= 0; q = Q[q].parent) {
                 if (!remaining.count(q)) remaining[q] = Q[q].GetAllocatedShare();

@@ -199,3 +199,18 @@ def test_priority_queue_known_answers():
     assert _pq(0, [(PUSH, 2), (PUSH, 3), (PEEK, 0), (LEN, 0)]) == [2, 2] and _pq(0, [(PEEK, 0)]) == [-1]
     assert _pq(0, [(PUSH, 2), (PUSH, 3), (FIX, 4), (PEEK, 0)]) == [3]
     assert _pq(0, [(LEN, 0)]) == [0] and _pq(0, [(PUSH, 5), (LEN, 0)]) == [1] and _pq(0, [(PUSH, 5), (PUSH, 1), (PUSH, 9), (LEN, 0)]) == [3]
+
+
+STRATEGIES = T.load_golden("kat_reclaim_strategies")
+
+
+@pytest.mark.parametrize("case", STRATEGIES["cases"], ids=[f"{c['strategy']}:{c['line']}" for c in STRATEGIES["cases"]])
+def test_reclaim_strategies_known_answers(case):
+    """plugins/proportion/reclaimable/strategies/strategies_test.go: MaintainFairShareStrategy (the reclaimee's remaining share is not within what it may hold,
+    one resource and several, MaxAllowed below the fair share) and GuaranteeDeservedQuotaStrategy (the reclaimer stays within its quota, the reclaimee is over its own)."""
+    lib = T.Oracle.lib(); lib.kai_oracle_reclaim_strategy.restype = C.c_int
+    arr = lambda q: np.array([q[r] for r in ("cpu", "memory", "gpu")], np.float64)
+    a, b = arr(case["reclaimer"]), arr(case["reclaimee"]); req = np.array(case["required"], np.float64); rem = np.array(case["remaining"], np.float64)
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    got = lib.kai_oracle_reclaim_strategy(0 if case["strategy"] == "maintain_fair_share" else 1, dp(a), dp(b), dp(req), dp(rem))
+    assert got in (0, 1) and bool(got) == case["want"], f"{case['name']} (strategies_test.go:{case['line']})"
