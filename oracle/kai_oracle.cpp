@@ -1382,6 +1382,19 @@ int kai_oracle_reclaim_strategy(int which, const double* reclaimer, const double
     return (which == 0 ? orc::maintainFairShareStrategy(b, rem) : orc::guaranteeDeservedQuotaStrategy(req, a, b, rem)) ? 1 : 0;
 }
 
+// capacity_policy on ONE hand-set queue (max_allowed_check_test.go, quota_check_test.go): which 0 = isOverLimit (limit = MaxAllowed, allocated = Allocated),
+// 1 = isAllocatedNonPreemptibleOverQuota (limit = Deserved, allocated = AllocatedNotPreemptible, a non-preemptible job) — through the session functions the
+// actions call (resultsOverLimit / resultsWithNonPreemptibleOverQuota walk the job's queue chain: here a chain of one) → 1 / 0
+int kai_oracle_capacity_check(int which, const double* limit, const double* allocated, const double* requested) {
+    if (!limit || !allocated || !requested) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.qattrs.resize(1); ssn.qattrs[0].idx = 0; ssn.qattrs[0].parent = -1;
+    for (int r = 0; r < 3; r++) { orc::ResourceShare& sh = ssn.qattrs[0].share[r]; sh.MaxAllowed = KAI_UNLIMITED; sh.Deserved = KAI_UNLIMITED;
+        if (which == 0) { sh.MaxAllowed = limit[r]; sh.Allocated = allocated[r]; } else { sh.Deserved = limit[r]; sh.AllocatedNotPreemptible = allocated[r]; } }
+    orc::PodGroupInfo job; job.queue = 0; job.preemptible = false;
+    const orc::ResourceQuantities req{requested[0], requested[1], requested[2]};
+    return (which == 0 ? ssn.resultsOverLimit(req, &job) : ssn.resultsWithNonPreemptibleOverQuota(req, &job)) ? 1 : 0;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

@@ -214,3 +214,17 @@ def test_reclaim_strategies_known_answers(case):
     dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
     got = lib.kai_oracle_reclaim_strategy(0 if case["strategy"] == "maintain_fair_share" else 1, dp(a), dp(b), dp(req), dp(rem))
     assert got in (0, 1) and bool(got) == case["want"], f"{case['name']} (strategies_test.go:{case['line']})"
+
+
+CAPACITY = T.load_golden("kat_capacity_policy")
+
+
+@pytest.mark.parametrize("case", CAPACITY["cases"], ids=[f"{c['fn']}:{c['line']}" for c in CAPACITY["cases"]])
+def test_capacity_policy_known_answers(case):
+    """plugins/proportion/capacity_policy: isOverLimit (max_allowed_check_test.go:38-208 — MaxAllowed < Allocated + requested in a resource that is requested and
+    limited) and isAllocatedNonPreemptibleOverQuota (quota_check_test.go:32-130 — the same against Deserved with the non-preemptible allocation)"""
+    lib = T.Oracle.lib(); lib.kai_oracle_capacity_check.restype = C.c_int
+    dp = lambda x: np.array(x, np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    lim, al, rq = (np.array(case[k], np.float64) for k in ("limit", "allocated", "requested"))
+    got = lib.kai_oracle_capacity_check(0 if case["fn"] == "isOverLimit" else 1, lim.ctypes.data_as(C.POINTER(C.c_double)), al.ctypes.data_as(C.POINTER(C.c_double)), rq.ctypes.data_as(C.POINTER(C.c_double)))
+    assert got in (0, 1) and bool(got) == case["want"], f"{case['name']} ({case['file']}:{case['line']})"
