@@ -1395,6 +1395,12 @@ int kai_oracle_capacity_check(int which, const double* limit, const double* allo
     return (which == 0 ? ssn.resultsOverLimit(req, &job) : ssn.resultsWithNonPreemptibleOverQuota(req, &job)) ? 1 : 0;
 }
 
+// idle_gpus.greedyMatchRequirements (idle_gpus_test.go:106-199): holders by index in the given order, capacity[i] of holder i → 1 / 0
+int kai_oracle_greedy_match(const double* requirements, int n_req, const int32_t* holders, int n_holders, const double* capacity) {
+    std::vector<double> req(requirements, requirements + n_req); std::vector<int> h(holders, holders + n_holders);
+    return orc::greedyMatchRequirements(req, h, [&](int x) { return capacity[x]; }) ? 1 : 0;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

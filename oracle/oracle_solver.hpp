@@ -101,6 +101,24 @@ struct Scenario {
 };
 
 // ---------------------------------------------------------------- accumulated_scenario_filters/idle_gpus/{idle_gpus,common}.go
+// accumulated_scenario_filters/idle_gpus/common.go:34-64: every requirement (sorted descending) is matched to the first holder (sorted descending by capacity) that
+// still has room after what earlier requirements took from it; a zero requirement ends the list
+template <class Reqs, class Holders, class Cap>
+inline bool greedyMatchRequirements(const Reqs& requirements, const Holders& holders, Cap capacity) {
+    std::map<int, double> virtuallyAllocated;
+    for (double required : requirements) {
+        if (required == 0) return true;
+        bool matched = false;
+        for (int holder : holders) {
+            const double totalCapacity = capacity(holder);
+            if (totalCapacity < required) break;  // holders are sorted: nobody behind this one can take it either
+            if (totalCapacity - virtuallyAllocated[holder] >= required) { virtuallyAllocated[holder] += required; matched = true; break; }
+        }
+        if (!matched) return false;
+    }
+    return true;
+}
+
 struct AccumulatedIdleGpus {
     std::vector<double> requiredGpusSorted;
     std::map<int, double> nodesNameToIdleGpus;
@@ -142,19 +160,7 @@ struct AccumulatedIdleGpus {
     bool Filter(Scenario* sc, bool& err) {  // :77-88
         err = !updateStateWithScenario(sc, false);
         if (err) return false;
-        std::map<int, double> virtuallyAllocated;  // greedyMatchRequirements common.go:34-64
-        for (double required : requiredGpusSorted) {
-            if (required == 0) return true;
-            bool matched = false;
-            for (int holder : maxFreeGpuNodesSorted) {
-                double total = nodesNameToIdleGpus[holder];
-                if (total < required) break;
-                double available = total - virtuallyAllocated[holder];
-                if (available >= required) { virtuallyAllocated[holder] += required; matched = true; break; }
-            }
-            if (!matched) return false;
-        }
-        return true;
+        return greedyMatchRequirements(requiredGpusSorted, maxFreeGpuNodesSorted, [&](int holder) { return nodesNameToIdleGpus[holder]; });
     }
     int updateVictimList(const std::vector<PodInfo*>& victimTasks, std::set<int>& cache) {  // :111-122 + iterateNewVictims common.go:66-88
         int minIdleGpusRelevant = maxFreeGpuNodesSorted.empty() ? -2 : maxFreeGpuNodesSorted.back(); int hits = 0;
@@ -252,17 +258,7 @@ struct TopologyAwareIdleGpus {
                 req.push_back(sum);
             }
             std::sort(req.begin(), req.end(), [](double a, double b) { return a > b; });
-            std::map<int, double> virt;  // greedyMatchRequirements common.go:34-64
-            for (double required : req) {
-                if (required == 0) break;
-                bool matched = false;
-                for (int d : domainsByRow[row]) {
-                    double total = domainCapacity[d];
-                    if (total < required) break;
-                    if (total - virt[d] >= required) { virt[d] += required; matched = true; break; }
-                }
-                if (!matched) return false;
-            }
+            if (!greedyMatchRequirements(req, domainsByRow[row], [&](int d) { return domainCapacity[d]; })) return false;
         }
         return true;
     }

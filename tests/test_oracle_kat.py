@@ -228,3 +228,19 @@ def test_capacity_policy_known_answers(case):
     lim, al, rq = (np.array(case[k], np.float64) for k in ("limit", "allocated", "requested"))
     got = lib.kai_oracle_capacity_check(0 if case["fn"] == "isOverLimit" else 1, lim.ctypes.data_as(C.POINTER(C.c_double)), al.ctypes.data_as(C.POINTER(C.c_double)), rq.ctypes.data_as(C.POINTER(C.c_double)))
     assert got in (0, 1) and bool(got) == case["want"], f"{case['name']} ({case['file']}:{case['line']})"
+
+
+GREEDY = [  # idle_gpus_test.go:117-189: (requirements, holders in order, capacity by holder, want)
+    ([], ["n1"], {"n1": 1.0}, True), ([0, 0], [], {}, True), ([0.5], ["n1"], {"n1": 1.0}, True), ([0.5], ["n1"], {"n1": 0.0}, False),
+    ([1.0, 0.5], ["n1"], {"n1": 1.0}, False), ([1.0, 0.5], ["n1"], {"n1": 1.5}, True), ([1.0, 1.0], ["n2", "n1"], {"n1": 1.0, "n2": 2.0}, True), ([2.0], ["n1"], {"n1": 1.0}, False),
+]
+
+
+@pytest.mark.parametrize("req,holders,cap,want", GREEDY)
+def test_greedy_match_requirements_known_answers(req, holders, cap, want):
+    """accumulated_scenario_filters/idle_gpus/common.go:34-64 (the idle-GPU scenario filters' feasibility test) against idle_gpus_test.go:106-199"""
+    lib = T.Oracle.lib(); lib.kai_oracle_greedy_match.restype = C.c_int
+    names = sorted(cap)
+    r = np.array(req, np.float64); h = np.array([names.index(x) for x in holders], np.int32); c = np.array([cap[n] for n in names] or [0.0], np.float64)
+    got = lib.kai_oracle_greedy_match(r.ctypes.data_as(C.POINTER(C.c_double)), len(r), h.ctypes.data_as(C.POINTER(C.c_int32)), len(h), c.ctypes.data_as(C.POINTER(C.c_double)))
+    assert bool(got) == want
