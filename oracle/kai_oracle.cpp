@@ -1401,6 +1401,29 @@ int kai_oracle_greedy_match(const double* requirements, int n_req, const int32_t
     return orc::greedyMatchRequirements(req, h, [&](int x) { return capacity[x]; }) ? 1 : 0;
 }
 
+// actions/common/minimal_job_comparison.go on hand-built jobs of ONE scheduling signature (minimal_job_comparison_test.go): pods = rows of (pending 0/1, milli-cpu,
+// memory, gpus).  mode 0: UpdateRepresentative(rep), → IsEasierToSchedule(job); mode 1: UpdateRepresentative(rep), UpdateRepresentative(job) → job is the representative
+int kai_oracle_minimal_job(int mode, const double* rep, int n_rep, const double* job, int n_job) {
+    auto build = [](const double* rows, int n, std::vector<orc::PodInfo>& pods, orc::PodSet& ps, orc::PodGroupInfo& g) {
+        pods.resize(n);
+        for (int i = 0; i < n; i++) {
+            orc::PodInfo& p = pods[i]; p.idx = i; p.status = rows[i * 4] != 0 ? orc::Pending : orc::Running;
+            p.resReq.milliCpu = rows[i * 4 + 1]; p.resReq.memory = rows[i * 4 + 2];
+            const double gpus = rows[i * 4 + 3];  // NewGpuResourceRequirementWithGpus (gpu_resource_requirment.go): whole devices, or a fraction of one
+            if (gpus >= 1) { p.resReq.count = int64_t(gpus); p.resReq.portion = 1; } else if (gpus > 0) { p.resReq.count = 1; p.resReq.portion = gpus; }
+            ps.podInfos[i] = &p;
+        }
+        g.podSets.push_back(&ps); g.signature = 7;
+    };
+    std::vector<orc::PodInfo> rp, jp; orc::PodSet rs, js; orc::PodGroupInfo rg, jg;
+    build(rep, n_rep, rp, rs, rg); build(job, n_job, jp, js, jg);
+    orc::MinimalJobRepresentatives m;
+    m.UpdateRepresentative(&rg);
+    if (mode == 0) return m.IsEasierToSchedule(&jg) ? 1 : 0;
+    m.UpdateRepresentative(&jg);
+    return m.representatives[7] == &jg ? 1 : 0;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

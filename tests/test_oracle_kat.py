@@ -244,3 +244,29 @@ def test_greedy_match_requirements_known_answers(req, holders, cap, want):
     r = np.array(req, np.float64); h = np.array([names.index(x) for x in holders], np.int32); c = np.array([cap[n] for n in names] or [0.0], np.float64)
     got = lib.kai_oracle_greedy_match(r.ctypes.data_as(C.POINTER(C.c_double)), len(r), h.ctypes.data_as(C.POINTER(C.c_int32)), len(h), c.ctypes.data_as(C.POINTER(C.c_double)))
     assert bool(got) == want
+
+
+MI = 1048576.0
+def _pods(*rows): return [list(r) if isinstance(r, (list, tuple)) else r for r in rows]
+P = lambda cpu=0.0, mem=0.0, gpu=0.0, pending=1: [float(pending), float(cpu), float(mem), float(gpu)]
+MINIMAL_JOB = [  # actions/common/minimal_job_comparison_test.go: (mode, representative's pods, job's pods, want)
+    # IsEasierToSchedule, single pod :43-140
+    (0, [P(100)], [P()], True), (0, [P()], [P(100)], False), (0, [P(100)], [P(100)], False), (0, [P(100)], [P(200)], False), (0, [P(100)], [P(50)], True),
+    (0, [P(mem=100 * MI)], [P(mem=200 * MI)], False), (0, [P(mem=100 * MI)], [P(mem=50 * MI)], True), (0, [P(100, 100 * MI)], [P(200, 50 * MI)], False), (0, [P(100, 100 * MI)], [P(50, 200 * MI)], False),
+    (0, [P(gpu=1)], [P(gpu=2)], False), (0, [P(gpu=2)], [P(gpu=1)], True), (0, [P(gpu=0.25)], [P(gpu=0.5)], False), (0, [P(gpu=0.5)], [P(gpu=0.25)], True),
+    # multiple pods :143-190
+    (0, [P(), P()], [P(100), P(100)], False), (0, [P(100), P(100)], [P(), P()], True), (0, [P(100), P(100)], [P(100), P(50)], True), (0, [P(1000), P(100), P(100)], [P(500)] * 3, True),
+    # multiple pods, different pod statuses :192-260 — only pending pods are compared
+    (0, [P(100), P(100, pending=0)], [P(100), P(100)], False), (0, [P(100), P(100)], [P(100), P(100, pending=0)], True), (0, [P(100), P(100)], [P(100), P(150, pending=0)], True),
+    # UpdateRepresentative :263-305 — the job replaces the representative only if every sorted request is no larger
+    (1, [P(100), P(100)], [P(100), P(50)], True), (1, [P(1000), P(100), P(100)], [P(500)] * 3, False),
+]
+
+
+@pytest.mark.parametrize("mode,rep,job,want", MINIMAL_JOB)
+def test_minimal_job_comparison_known_answers(mode, rep, job, want):
+    """MinimalJobRepresentatives (actions/common/minimal_job_comparison.go:15-112): a job is skipped when a job of its signature with no larger sorted requests already failed"""
+    lib = T.Oracle.lib(); lib.kai_oracle_minimal_job.restype = C.c_int
+    a, b = np.array(rep, np.float64).reshape(-1, 4), np.array(job, np.float64).reshape(-1, 4)
+    got = lib.kai_oracle_minimal_job(mode, a.ctypes.data_as(C.POINTER(C.c_double)), len(a), b.ctypes.data_as(C.POINTER(C.c_double)), len(b))
+    assert bool(got) == want
