@@ -246,7 +246,7 @@ static void SetResourcesShare(const ResourceQuantities& total, double kValue, st
 }
 }  // namespace resource_division
 
-static void setFairShareForQueues(Session* ssn, const ResourceQuantities& total, double kValue, std::vector<QueueAttributes*>& queues) {  // proportion.go:410-423
+void setFairShareForQueues(Session* ssn, const ResourceQuantities& total, double kValue, std::vector<QueueAttributes*>& queues) {  // proportion.go:410-423
     if (queues.empty()) return;
     resource_division::SetResourcesShare(total, kValue, queues);
     for (auto* q : queues) {
@@ -1505,6 +1505,23 @@ int kai_oracle_set_resources_share(int Q, const double* total, double k_value, c
     }
     orc::resource_division::SetResourcesShare({total[0], total[1], total[2]}, k_value, ptr);
     for (int q = 0; q < Q; q++) for (int r = 0; r < 3; r++) fair_share_out[r * Q + q] = qs[q].share[r].FairShare;
+    return KAI_OK;
+}
+
+// proportionPlugin.setFairShare (proportion.go:403-423) on a hand-set queue TREE (proportion_test.go:43-524): SetResourcesShare on the top queues, then on every
+// queue's children with the parent's fair share as the total.  Arrays are [resource * Q + queue] like kai_oracle_set_resources_share.
+int kai_oracle_set_fair_share_tree(int Q, const int32_t* parent, const double* total, double k_value, const double* deserved, const double* limit, const double* oqw,
+                                   const double* request, const int* priority, const int64_t* created_ns, double* fair_share_out) {
+    if (Q <= 0 || !parent) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.qattrs.resize(Q);
+    for (int q = 0; q < Q; q++) {
+        orc::QueueAttributes& a = ssn.qattrs[q]; a.idx = q; a.uidRank = q; a.parent = parent[q]; a.priority = priority ? priority[q] : 0; a.createdNs = created_ns ? created_ns[q] : 0;
+        for (int r = 0; r < 3; r++) { auto& sh = a.share[r]; sh.Deserved = deserved[r * Q + q]; sh.MaxAllowed = limit[r * Q + q]; sh.OverQuotaWeight = oqw[r * Q + q]; sh.Request = request[r * Q + q]; }
+    }
+    for (int q = 0; q < Q; q++) if (parent[q] >= 0) ssn.qattrs[parent[q]].children.push_back(q);
+    std::vector<orc::QueueAttributes*> top; for (auto& q : ssn.qattrs) if (q.parent < 0) top.push_back(&q);
+    orc::setFairShareForQueues(&ssn, {total[0], total[1], total[2]}, k_value, top);
+    for (int q = 0; q < Q; q++) for (int r = 0; r < 3; r++) fair_share_out[r * Q + q] = ssn.qattrs[q].share[r].FairShare;
     return KAI_OK;
 }
 

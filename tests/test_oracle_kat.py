@@ -270,3 +270,25 @@ def test_minimal_job_comparison_known_answers(mode, rep, job, want):
     a, b = np.array(rep, np.float64).reshape(-1, 4), np.array(job, np.float64).reshape(-1, 4)
     got = lib.kai_oracle_minimal_job(mode, a.ctypes.data_as(C.POINTER(C.c_double)), len(a), b.ctypes.data_as(C.POINTER(C.c_double)), len(b))
     assert bool(got) == want
+
+
+FAIR_TREE = T.load_golden("kat_fair_share_tree")
+
+
+@pytest.mark.parametrize("case", FAIR_TREE["cases"], ids=[f"fair_share_tree:{c['line']}" for c in FAIR_TREE["cases"]])
+def test_fair_share_tree_known_answers(case):
+    """proportion_test.go:43-524 — setFairShare over a queue hierarchy (proportion.go:403-423): the top queues divide the cluster, every queue's children divide the
+    parent's fair share; deserved quota first, then over-quota by priority and weight.  GPU fair share of every queue, exact."""
+    lib = T.Oracle.lib(); lib.kai_oracle_set_fair_share_tree.restype = C.c_int
+    names = list(case["queues"]); Q = len(names)
+    parent = np.array([names.index(case["queues"][n]["parent"]) if case["queues"][n]["parent"] else -1 for n in names], np.int32)
+    z = np.zeros((3, Q)); des, lim, oqw, req = z.copy(), z.copy(), z.copy(), z.copy()  # CPU / Memory are zero-valued ResourceShare{} in the fixtures
+    for i, n in enumerate(names): des[2, i], lim[2, i], oqw[2, i], req[2, i] = case["queues"][n]["gpu"]
+    prio = np.array([case["queues"][n]["priority"] for n in names], np.int32); created = np.zeros(Q, np.int64)
+    total = np.array(case["total"], np.float64); out = np.zeros((3, Q))
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    rc = lib.kai_oracle_set_fair_share_tree(Q, parent.ctypes.data_as(C.POINTER(C.c_int32)), dp(total), C.c_double(0.0), dp(des), dp(lim), dp(oqw), dp(req),
+                                            prio.ctypes.data_as(C.POINTER(C.c_int)), created.ctypes.data_as(C.POINTER(C.c_int64)), dp(out))
+    assert rc == 0
+    got = {n: out[2, i] for i, n in enumerate(names)}
+    assert got == case["want"], f"{case['name']} (proportion_test.go:{case['line']})"
