@@ -61,9 +61,14 @@ def main():
     pkg = G._load_pkg()
     rank, local_rank, world = pkg.dist.env_world()
     assert torch.cuda.is_available(), "bench.py needs a MI355X: the scheduling-cycle core has no CPU path"
+    # KAI_BENCH_BACKEND=gloo KAI_BENCH_ONE_DEVICE=1: rehearsal of the multi-process path on a box with ONE GPU (every rank on device 0, the exchange staged through
+    # host memory over gloo) — RCCL refuses two ranks on one device.  The driver's runs use neither.
+    backend = os.environ.get("KAI_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("KAI_BENCH_ONE_DEVICE") == "1" else local_rank
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        pkg.dist.init("nccl", device=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        pkg.dist.init(backend, device=torch.device("cuda", dev_index))
     pkg.load_library()
 
     if args.scale is None:
@@ -83,7 +88,7 @@ def main():
     def barrier():
         pkg.dist.barrier(torch.cuda.synchronize)
 
-    core = pkg.KaiCore(cfg, gpu_ids=(local_rank,), world=world, rank=rank) if sharded else pkg.KaiCore(cfg, gpu_ids=(local_rank,))
+    core = pkg.KaiCore(cfg, gpu_ids=(dev_index,), world=world, rank=rank) if sharded else pkg.KaiCore(cfg, gpu_ids=(dev_index,))
     t0 = time.time()
     ssn = core.open_session(snap)  # host → HBM once; the timed steps replay from the resident copy
     upload_s = time.time() - t0
@@ -116,15 +121,15 @@ def main():
         st = step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = pkg.dist.max_over_ranks(elapsed, device="cuda")
+    elapsed = pkg.dist.max_over_ranks(elapsed, device=red_dev)
     ssn.close(); core.destroy()
 
     first_ops = [(int(x["kind"]), int(x["pod"]), int(x["node"]), int(x["job"])) for o in first_ops for x in o]  # the last step's committed operations
     if sharded:  # one job: every rank committed the same operations
         total_decisions, total_placed = decisions * args.steps, placed * args.steps
     else:        # replicas: one scheduling shard per rank
-        total_decisions = pkg.dist.sum_over_ranks(decisions * args.steps, device="cuda")
-        total_placed = pkg.dist.sum_over_ranks(placed * args.steps, device="cuda")
+        total_decisions = pkg.dist.sum_over_ranks(decisions * args.steps, device=red_dev)
+        total_placed = pkg.dist.sum_over_ranks(placed * args.steps, device=red_dev)
     value = total_decisions / elapsed
     k_ms = float(np.mean(kernel_ms))
     b_dec = N * B_NODE + B_POD_OUT
@@ -209,6 +214,30 @@ def main():
                                          "ms_per_step": tw.elapsed_ms, "sample": "the full step", "ops_equal_to_gpu": [tuple(o) for o in tw.ops] == [tuple(o) for o in first_ops]}
         except Exception as e:  # the twin is optional evidence
             out["cpu_same_algorithm"] = {"error": str(e)[:200]}
+    if sharded and os.environ.get("KAI_BENCH_REPLICAS_LEG", "1") != "0":
+        # second leg, every rank: the same GPUs as independent scheduling shards (how KAI itself scales out: one scheduler instance per node pool,
+        # conf/scheduler_conf.go:95-112) — one snapshot of the same shape per rank, no data-path collective, same bracket; reported beside the sharded value
+        snap2, cfg2, _ = pkg.synth.config(idx, args.scale, seed_offset=pkg.dist.shard_seed(0, rank))
+        core2 = pkg.KaiCore(cfg2, gpu_ids=(dev_index,)); ssn2 = core2.open_session(snap2)
+
+        def step2():
+            ssn2.reset(); n = 0
+            for a in actions:
+                ssn2.execute(a); n += int(ssn2.stats().decisions)
+            return n
+        d2 = 0
+        for _ in range(args.warmup):
+            step2()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d2 = step2()
+        barrier()
+        el2 = pkg.dist.max_over_ranks(time.perf_counter() - t0, device=red_dev)
+        tot2 = pkg.dist.sum_over_ranks(d2 * args.steps, device=red_dev)
+        ssn2.close(); core2.destroy()
+        out["replicas"] = {"value": tot2 / el2, "unit": "decisions/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "weak",
+                           "note": f"{world} independent scheduling shards of the same shape, one per GPU, no data-path collective (KAI_BENCH_MULTI=replicas makes this the reported value)"}
     if rank == 0:
         print(json.dumps(out))
     pkg.dist.finish()

@@ -108,14 +108,16 @@ class KaiCore:
             import torch
             import torch.distributed as dist
             hip = _hip_runtime()
+            on_host = dist.get_backend() != "nccl"  # a gloo group (rehearsal of the multi-process path without RCCL): staged through host memory
             if self._stage is None or self._stage[0].numel() != nbytes:  # torch-owned staging tensors: the collective runs on memory torch knows
-                self._stage = (torch.empty(nbytes, dtype=torch.uint8, device="cuda"), torch.empty(nbytes * self.world, dtype=torch.uint8, device="cuda"))
+                dev = "cpu" if on_host else "cuda"
+                self._stage = (torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev))
             s, r = self._stage
-            if hip.hipMemcpy(C.c_void_p(s.data_ptr()), C.c_void_p(send), C.c_size_t(nbytes), 3) != 0:  # hipMemcpyDeviceToDevice
+            if hip.hipMemcpy(C.c_void_p(s.data_ptr()), C.c_void_p(send), C.c_size_t(nbytes), 2 if on_host else 3) != 0:  # hipMemcpyDeviceToHost / DeviceToDevice
                 return 1
             dist.all_gather_into_tensor(r, s)
-            torch.cuda.synchronize()
-            return 0 if hip.hipMemcpy(C.c_void_p(recv), C.c_void_p(r.data_ptr()), C.c_size_t(nbytes * self.world), 3) == 0 else 1
+            if not on_host: torch.cuda.synchronize()
+            return 0 if hip.hipMemcpy(C.c_void_p(recv), C.c_void_p(r.data_ptr()), C.c_size_t(nbytes * self.world), 1 if on_host else 3) == 0 else 1
         except Exception:  # a ctypes callback must not raise
             import traceback
             traceback.print_exc()

@@ -1,9 +1,10 @@
-"""Multi-GPU plumbing of the scheduling-cycle core: one process per GPU, one scheduling shard per process.
+"""Multi-GPU plumbing of the scheduling-cycle core: one process per GPU.
 
-The reference scales by SchedulingShards — node-pool partitions, each served by its own scheduler instance with its own
-session (conf/scheduler_conf.go:95-112 node-pool label filter; pkg/operator SchedulingShard).  Shards never exchange data on
-the placement path, so the only cross-rank operations are the timing barrier and the max-over-ranks of the elapsed time that
-bench.py's contract asks for.  No data-path collective exists (DESIGN.md "Multi-GPU").
+Two ways to use the GPUs of one node.  (1) Node-sharded group: `KaiCore(world=G, rank=g)` shards the NODE axis of one session; the
+group's exchange step (offers + floors, an all-gather of a few KB per rank) goes through `torch.distributed` — backend "nccl" = RCCL over xGMI — from a
+callback in core.py.  (2) Scheduling shards, the way the reference scales out (conf/scheduler_conf.go:95-112 node-pool label filter; pkg/operator
+SchedulingShard): one independent session per GPU, no data-path collective.  This module holds what both need around the timed region: the process group, the
+barrier and the max / sum over ranks that bench.py's contract asks for.
 """
 from __future__ import annotations
 
