@@ -519,3 +519,37 @@ def test_gpu_default_allgather_plumbing(gpu):
         core.destroy()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,nodes,pods", [("fractions", 1500, 9000), ("gpu_memory", 700, 5000), ("mig", 1500, 9000)])
+def test_gpu_shared_devices_and_mig_at_scale(gpu, kind, nodes, pods):
+    """Shared devices, GPU-memory requests and MIG rows beyond the few-node fuzz cases: such snapshots scan every decision by brute force over all node blocks (no
+    class index), so this is the scanner's block reduction with the shared-GPU fit, the gpusharingorder score and the MIG predicates on hundreds of blocks."""
+    from test_engine_hostsim import _same_groups
+    snap = T.pkg.synth.make_snapshot(nodes, pods, 7700 + nodes, queue_levels=(2, 3), prefill=0.4, gpu_mix=((8, .6), (4, .3), (0, .1)), gpus_per_pod=(1, 1, 2, 4), cpu_only_frac=0.1,
+                                     limits_frac=0.2, queue_prios=(100, 200), oqws=(1.0, 2.0), nonpreempt_frac=0.1)
+    if kind == "mig": T.pkg.synth.add_mig(snap, 5, node_frac=0.4, pod_frac=0.6, legacy_frac=0.02)
+    else: T.pkg.synth.add_fractions(snap, 5, frac=0.7, portions=(0.25, 0.5, 0.75), memory_requests=0.6 if kind == "gpu_memory" else 0.0)
+    cfg = T.abi.default_config(k_value=0.5)
+    ref = T.Oracle.run(snap, cfg, ("allocate",), threads=8)
+    res = run_gpu(snap, cfg, ("allocate",))
+    assert len(ref.ops) > 500
+    assert_same_tol(res, ref)
+    if kind != "mig": _same_groups(snap, res, ref)
+
+
+@pytest.mark.parametrize("kind,n", [("fractions", 100), ("mig", 100), ("gpu_memory", 60)])
+def test_gpu_victim_actions_with_shared_devices_and_mig_on_crowded_clusters(gpu, kind, n):
+    """A full cycle (allocate, consolidation, reclaim, preempt) on a crowded cluster of 60–100 nodes with fraction pods, GPU-memory requests or MIG: hundreds of
+    operations, > 100 evictions; everything identical to the oracle (shares to 1e-9 where the quantities are not integers)."""
+    from test_engine_hostsim import _same_groups
+    snap = T.pkg.synth.make_crowded_snapshot(n, 4100 + n, fill=0.85, n_pending_jobs=60, elastic_frac=0.2, hog_frac=0.5, queue_levels=(2, 2, 2))
+    if kind == "mig": T.pkg.synth.add_mig(snap, 9, node_frac=0.5, pod_frac=0.6, legacy_frac=0.02)
+    else: T.pkg.synth.add_fractions(snap, 9, frac=0.6, portions=(0.25, 0.5, 0.75), memory_requests=0.5 if kind == "gpu_memory" else 0.0)
+    cfg = T.abi.default_config(max_consolidation_preemptees=16, k_value=0.5)
+    acts = ("allocate", "consolidation", "reclaim", "preempt")
+    ref = T.Oracle.run(snap, cfg, acts)
+    assert sum(1 for o in ref.ops if o[0] == 2) > 100
+    res = run_gpu(snap, cfg, acts)
+    assert_same_tol(res, ref)
+    if kind != "mig": _same_groups(snap, res, ref)
