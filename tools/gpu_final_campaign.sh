@@ -3,10 +3,10 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; OUT=gpurun_out/${1:-r02k}_gpu_campaign.txt
 {
 echo "# tools/gpu_final_campaign.sh on one MI355X, library of the last commit: operations, pod states, node accounting, shares against the oracle"
-echo "## tools/gpu_campaign.py 300000.. (broad cases, every action, engine modes)"
-CAMPAIGN_SECONDS=${CAMPAIGN_SECONDS:-270} timeout 400 python tools/gpu_campaign.py 300000 400000 2>&1 | tail -3
-echo "## tools/gpu_campaign_mig.py 3000.. (fractions, gpu-memory requests, MIG)"
-CAMPAIGN_SECONDS=${CAMPAIGN_SECONDS_MIG:-120} timeout 300 python tools/gpu_campaign_mig.py 3000 20000 2>&1 | tail -3
+echo "## tools/gpu_campaign.py ${SEED_BROAD:-300000}.. (broad cases, every action, engine modes)"
+CAMPAIGN_SECONDS=${CAMPAIGN_SECONDS:-270} timeout 400 python tools/gpu_campaign.py ${SEED_BROAD:-300000} $(( ${SEED_BROAD:-300000} + 100000 )) 2>&1 | tail -3
+echo "## tools/gpu_campaign_mig.py ${SEED_MIG:-3000}.. (fractions, gpu-memory requests, MIG)"
+CAMPAIGN_SECONDS=${CAMPAIGN_SECONDS_MIG:-120} timeout 300 python tools/gpu_campaign_mig.py ${SEED_MIG:-3000} $(( ${SEED_MIG:-3000} + 17000 )) 2>&1 | tail -3
 echo "## BASELINE config 4 (allocate, consolidation, reclaim in one session) at 2 % and 3 %"
 timeout 300 python - <<'PY'
 import sys, os, time
