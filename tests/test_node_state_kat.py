@@ -1,0 +1,50 @@
+"""Node accounting at session open against the reference's own expectations (api/node_info/node_info_test.go TestAddRemovePods :393-676): what adding
+releasing, running and pipelined fraction pods to a node leaves in Idle / Used / Releasing (NodeInfo.addTaskResources :457-493 with the shared-GPU rules of
+gpu_sharing_node_info.go).  Checked on the oracle, on the host-compiled engine and (-m gpu) on the MI355X: the snapshot is opened and nothing is run."""
+import numpy as np
+import pytest
+
+import kai_testlib as T
+
+G = 1e9
+# (name, pods = (milli-cpu cores, memory bytes, fraction of the device, status, gpu group), expected Idle / Used / Releasing as (milli-cpu, memory, gpus, pods))
+CASES = [
+    ("releasing pod", [(1.0, 1 * G, 0.5, "Releasing", "1")],
+     (7000, 9 * G, 0, 109), (1000, 1 * G, 0, 1), (1000, 1 * G, 1, 1)),                                   # :410-455
+    ("pipelined pod - different gpus", [(1.0, 1 * G, 0.5, "Releasing", "1"), (0.5, 1 * G, 0.5, "Pipelined", "2")],
+     (7000, 9 * G, 0, 109), (1500, 2 * G, 0, 2), (500, 0, 0, 0)),                                        # :457-531
+    ("pipelined pod - same gpus", [(1.0, 1 * G, 0.5, "Releasing", "1"), (1.0, 1 * G, 0.2, "Running", "1"), (0.5, 1 * G, 0.5, "Pipelined", "1")],
+     (6000, 8 * G, 0, 108), (2500, 3 * G, 0, 3), (500, 0, 0, 0)),                                        # :532-610
+]
+
+
+def build(pods):
+    case = {"Name": "node state", "Nodes": {"n1": {"GPUs": 1, "CPUMillis": 8, "CPUMemory": 10 * G, "MaxTaskNum": 110}},
+            "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": f"j{i}", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": frac, "RequiredCPUsPerTask": cpu, "RequiredMemoryPerTask": mem,
+                      "Tasks": [{"State": st, "NodeName": "n1", "GPUGroups": [grp]}]} for i, (cpu, mem, frac, st, grp) in enumerate(pods)],
+            "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case, fractions=True)
+    return snap, cfg
+
+
+def check(res, idle, used, releasing, who):
+    for name, want in (("idle", idle), ("used", used), ("releasing", releasing)):
+        got = res.nodes[name][0]
+        assert np.array_equal(got[:4], np.array(want, np.float64)), f"{who}: {name} {got[:4].tolist()} want {list(want)}"
+
+
+@pytest.mark.parametrize("name,pods,idle,used,releasing", CASES, ids=[c[0].replace(" ", "_") for c in CASES])
+def test_add_pods_node_state(name, pods, idle, used, releasing):
+    from test_engine_hostsim import HostSim
+    snap, cfg = build(pods)
+    check(T.Oracle.run(snap, cfg, ()), idle, used, releasing, "oracle")
+    check(HostSim.run(snap, cfg, ()), idle, used, releasing, "host-compiled engine")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,pods,idle,used,releasing", CASES, ids=[c[0].replace(" ", "_") for c in CASES])
+def test_gpu_add_pods_node_state(gpu, name, pods, idle, used, releasing):
+    from test_gpu_parity import run_gpu
+    snap, cfg = build(pods)
+    check(run_gpu(snap, cfg, ()), idle, used, releasing, "MI355X")
