@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import kai_testlib as T
+from test_gpu_parity import gpu  # noqa: F401 — the fixture that skips without a device
 
 G = 1e9
 # (name, pods = (milli-cpu cores, memory bytes, fraction of the device, status, gpu group), expected Idle / Used / Releasing as (milli-cpu, memory, gpus, pods))
