@@ -49,3 +49,60 @@ def test_gpu_add_pods_node_state(gpu, name, pods, idle, used, releasing):
     from test_gpu_parity import run_gpu
     snap, cfg = build(pods)
     check(run_gpu(snap, cfg, ()), idle, used, releasing, "MI355X")
+
+
+# ------------------------------------------------------------------------------------------------ NodeInfo.IsTaskAllocatable (node_info_test.go:677-794)
+M = 1e6
+# (name, node (cores, memory, gpus), pods running there (cores, memory, gpus), the task (cores, memory, gpus; a pod's overhead is part of its request,
+#  pod_info.go:373-393), allocatable)
+FIT = [
+    ("not enough cpu and memory", (2, 2 * G, 0), [(1, 1 * G, 0)], (2, 2 * G, 0), False),
+    ("not enough cpu - 1 millicpu", (2, 2 * G, 0), [(1, 1 * G, 0)], (1.001, 1 * G, 0), False),
+    ("not enough memory - 1 Kb", (2, 2 * G, 0), [(1, 2 * G, 0)], (1, 1024, 0), False),
+    ("enough cpu and memory", (2, 2 * G, 0), [(1, 1 * G, 0)], (1, 1 * G, 0), True),
+    ("missing gpu", (2, 2 * G, 0), [], (1, 1 * G, 1), False),
+    ("missing gpu - requesting a fraction", (2, 2 * G, 0), [], (1, 1 * G, 0.5), False),
+    ("already used gpu so missing gpu", (2, 2 * G, 1), [(1, 1 * G, 1)], (1, 1 * G, 1), False),
+    ("enough cpu memory and gpu", (2, 2 * G, 2), [(1, 1 * G, 1)], (1, 1 * G, 1), True),
+    ("overhead: fits without it, not with it", (2, 2 * G, 0), [(1, 1 * G, 0)], (0.5 + 0.6, 500 * M + 600 * M, 0), False),
+    ("overhead: does not fit even without it", (2, 2 * G, 0), [(1, 1 * G, 0)], (1.5 + 0.1, 1500 * M + 100 * M, 0), False),
+    ("without overhead, does not fit", (2, 2 * G, 0), [(1, 1 * G, 0)], (1.5, 1500 * M, 0), False),
+    ("overhead: fits with it", (2, 2 * G, 0), [(1, 1 * G, 0)], (0.5 + 0.1, 500 * M + 100 * M, 0), True),
+]
+
+
+def build_fit(node, running, task):
+    def job(name, r, state):
+        return {"Name": name, "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": r[2], "RequiredCPUsPerTask": r[0], "RequiredMemoryPerTask": r[1],
+                "Tasks": [{"State": state, **({"NodeName": "n1"} if state != "Pending" else {})}]}
+    case = {"Name": "fit", "Nodes": {"n1": {"GPUs": node[2], "CPUMillis": node[0], "CPUMemory": node[1], "MaxTaskNum": 110}},
+            "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [job(f"run{i}", r, "Running") for i, r in enumerate(running)] + [job("task", task, "Pending")], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case, fractions=True)
+    return snap, cfg, snap.pod_names.index("task-0")
+
+
+def oracle_fits(snap, cfg, pod):
+    import ctypes as C
+    lib = T.Oracle.lib(); lib.kai_oracle_best_node.restype = C.c_int
+    s = snap.as_struct(); node, pipe = C.c_int(-1), C.c_int(0)
+    assert lib.kai_oracle_best_node(C.byref(cfg), C.byref(s), pod, None, 0, C.byref(node), C.byref(pipe)) == 0
+    return node.value == 0
+
+
+@pytest.mark.parametrize("name,node,running,task,want", FIT, ids=[c[0].replace(" ", "_") for c in FIT])
+def test_is_task_allocatable(name, node, running, task, want):
+    """the resource fit of FittingNode on a one-node cluster without releasing pods = NodeInfo.IsTaskAllocatable (node_info.go:168-188), against node_info_test.go:677-794"""
+    snap, cfg, pod = build_fit(node, running, task)
+    assert oracle_fits(snap, cfg, pod) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,node,running,task,want", FIT, ids=[c[0].replace(" ", "_") for c in FIT])
+def test_gpu_is_task_allocatable(gpu, name, node, running, task, want):
+    snap, cfg, pod = build_fit(node, running, task)
+    with T.pkg.KaiCore(cfg) as core:
+        ssn = core.open_session(snap)
+        got = ssn.best_node(pod)
+        ssn.close()
+    assert (got[0] == 0) == want
