@@ -68,6 +68,9 @@ FIT = [
     ("overhead: does not fit even without it", (2, 2 * G, 0), [(1, 1 * G, 0)], (1.5 + 0.1, 1500 * M + 100 * M, 0), False),
     ("without overhead, does not fit", (2, 2 * G, 0), [(1, 1 * G, 0)], (1.5, 1500 * M, 0), False),
     ("overhead: fits with it", (2, 2 * G, 0), [(1, 1 * G, 0)], (0.5 + 0.1, 500 * M + 100 * M, 0), True),
+    # TestIsTaskAllocatableOnReleasingOrIdle :796-833: a CPU-only task on MIG-enabled nodes (MigStrategy single / mixed)
+    ("cpu only job on single mig node", (2, 2 * G, 8, "single"), [(0.2, 1, 0)], (0.2, 1, 0), True),
+    ("cpu only job on mixed mig node", (2, 2 * G, 8, "mixed"), [(0.2, 1, 0)], (0.2, 1, 0), True),
 ]
 
 
@@ -75,7 +78,7 @@ def build_fit(node, running, task):
     def job(name, r, state):
         return {"Name": name, "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": r[2], "RequiredCPUsPerTask": r[0], "RequiredMemoryPerTask": r[1],
                 "Tasks": [{"State": state, **({"NodeName": "n1"} if state != "Pending" else {})}]}
-    case = {"Name": "fit", "Nodes": {"n1": {"GPUs": node[2], "CPUMillis": node[0], "CPUMemory": node[1], "MaxTaskNum": 110}},
+    case = {"Name": "fit", "Nodes": {"n1": {"GPUs": node[2], "CPUMillis": node[0], "CPUMemory": node[1], "MaxTaskNum": 110, **({"MigStrategy": node[3]} if len(node) > 3 else {})}},
             "Queues": [{"Name": "q", "DeservedGPUs": 1}],
             "Jobs": [job(f"run{i}", r, "Running") for i, r in enumerate(running)] + [job("task", task, "Pending")], "JobExpectedResults": {}}
     snap, cfg, _ = T.case_to_snapshot(case, fractions=True)
