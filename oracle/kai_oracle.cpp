@@ -1424,6 +1424,18 @@ int kai_oracle_minimal_job(int mode, const double* rep, int n_rep, const double*
     return m.representatives[7] == &jg ? 1 : 0;
 }
 
+// NodeInfo.GetSumOfIdleGPUs / GetSumOfReleasingGPUs (node_info.go:592-628) of every node of a freshly loaded session: out[n * 4 + 0..3] = idle GPUs, idle GPU
+// memory, releasing GPUs, releasing GPU memory (node_info_test.go:1052-1283)
+int kai_oracle_node_gpu_sums(const kai_config* cfg, const kai_snapshot_soa* snap, double* out) {
+    if (!cfg || !snap || !out || snap->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    for (size_t n = 0; n < ssn.nodes.size(); n++) {
+        out[n * 4 + 0] = ssn.nodes[n].GetSumOfIdleGPUs(); out[n * 4 + 1] = double(ssn.nodes[n].GetSumOfIdleGPUsMemory());
+        out[n * 4 + 2] = ssn.nodes[n].GetSumOfReleasingGPUs(); out[n * 4 + 3] = double(ssn.nodes[n].GetSumOfReleasingGPUsMemory());
+    }
+    return KAI_OK;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

@@ -109,3 +109,29 @@ def test_gpu_is_task_allocatable(gpu, name, node, running, task, want):
         got = ssn.best_node(pod)
         ssn.close()
     assert (got[0] == 0) == want
+
+
+# ------------------------------------------------------------------------------------------------ GetSumOfIdleGPUs / GetSumOfReleasingGPUs (node_info_test.go:1052-1283)
+# (node GPUs, pods (gpus or fraction, group), releasing, expected sum of GPUs, expected GPU memory at 100 MiB per device)
+GPU_SUMS = [
+    (2, [], False, 2, 200), (8, [(2, None), (1, None)], False, 5, 500), (8, [(0.5, "1"), (0.1, "2")], False, 7.4, 740), (8, [(0.5, "1"), (0.1, "1")], False, 7.4, 740),
+    (8, [(2, None), (0.5, "1"), (1, None), (0.1, "2")], False, 4.4, 440),
+    (2, [], True, 0, 0), (8, [(2, None), (1, None)], True, 3, 300), (8, [(0.5, "1"), (0.1, "2")], True, 2, 200), (8, [(0.5, "1"), (0.1, "1")], True, 1, 100),
+    (8, [(2, None), (0.5, "1"), (1, None)], True, 4, 400),
+]
+
+
+@pytest.mark.parametrize("gpus,pods,releasing,want,want_mem", GPU_SUMS)
+def test_sum_of_idle_and_releasing_gpus(gpus, pods, releasing, want, want_mem):
+    """whole devices plus what is free (or being released) on shared ones — what the idle-GPU scenario filters and FeasibleNodes read"""
+    import ctypes as C
+    case = {"Name": "sums", "Nodes": {"n1": {"GPUs": gpus, "CPUMillis": 8, "CPUMemory": 10 * G}}, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": f"j{i}", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": g,
+                      "Tasks": [{"State": "Releasing" if releasing else "Running", "NodeName": "n1", **({"GPUGroups": [grp]} if grp else {})}]} for i, (g, grp) in enumerate(pods)],
+            "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case, fractions=True)
+    lib = T.Oracle.lib(); lib.kai_oracle_node_gpu_sums.restype = C.c_int
+    out = np.zeros(4); s = snap.as_struct()
+    assert lib.kai_oracle_node_gpu_sums(C.byref(cfg), C.byref(s), out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    got, got_mem = (out[2], out[3]) if releasing else (out[0], out[1])
+    assert got == want and got_mem == want_mem, out.tolist()
