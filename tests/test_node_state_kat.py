@@ -135,3 +135,14 @@ def test_sum_of_idle_and_releasing_gpus(gpus, pods, releasing, want, want_mem):
     assert lib.kai_oracle_node_gpu_sums(C.byref(cfg), C.byref(s), out.ctypes.data_as(C.POINTER(C.c_double))) == 0
     got, got_mem = (out[2], out[3]) if releasing else (out[0], out[1])
     assert got == want and got_mem == want_mem, out.tolist()
+
+
+# ------------------------------------------------------------------------------------------------ isTaskAllocatableOnNonAllocatedResources with a GPU-memory request (node_info_test.go:911-1050)
+@pytest.mark.parametrize("mib,want", [(1500, False), (1000, True)])
+def test_gpu_memory_request_against_device_size(mib, want):
+    """a request for more MiB than one device has is an invalid portion (isValidGpuPortion, node_info.go:668-671); exactly one device's worth fits on an idle GPU"""
+    case = {"Name": "gm", "Nodes": {"n1": {"GPUs": 2, "GPUMemory": 1000, "CPUMillis": 8, "CPUMemory": 10 * G, "MaxTaskNum": 10}}, "Queues": [{"Name": "q", "DeservedGPUs": 2}],
+            "Jobs": [{"Name": "task", "Priority": 50, "QueueName": "q", "RequiredGpuMemory": mib, "Tasks": [{"State": "Pending"}]}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case, fractions=True)
+    cfg.min_node_gpu_memory = 1000
+    assert oracle_fits(snap, cfg, snap.pod_names.index("task-0")) == want
