@@ -1436,6 +1436,36 @@ int kai_oracle_node_gpu_sums(const kai_config* cfg, const kai_snapshot_soa* snap
     return KAI_OK;
 }
 
+// framework.Statement on a freshly loaded session (statement_checkpoint_test.go): script rows (op, pod, node, flag) with op 0 = Checkpoint, 1 = Evict(pod),
+// 2 = Allocate(pod, node), 3 = Pipeline(pod, node, updateTaskIfExistsOnNode = flag), 4 = Rollback(last checkpoint), 5 = Discard.  results[i] = 1 / 0 of the call
+// (Checkpoint: the length).  Then the state: pod status / node, and Idle / Releasing / Used of every node.
+int kai_oracle_statement_script(const kai_config* cfg, const kai_snapshot_soa* snap, const int32_t* script, int n_ops, int32_t* results,
+                                int32_t* pod_status_out, int32_t* pod_node_out, kai_node_state* nodes_out) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    orc::Statement stmt(&ssn); int cp = 0;
+    for (int i = 0; i < n_ops; i++) {
+        const int op = script[4 * i], pod = script[4 * i + 1], node = script[4 * i + 2], flag = script[4 * i + 3]; int r = 0;
+        if (op != 0 && op != 4 && op != 5 && (pod < 0 || pod >= int(ssn.pods.size()))) return KAI_ERR_INVALID_ARG;
+        switch (op) {
+            case 0: cp = stmt.Checkpoint(); r = cp; break;
+            case 1: r = stmt.Evict(&ssn.pods[pod]); break;
+            case 2: r = stmt.Allocate(&ssn.pods[pod], node); break;
+            case 3: r = stmt.Pipeline(&ssn.pods[pod], node, flag != 0); break;
+            case 4: stmt.Rollback(cp); r = 1; break;
+            case 5: stmt.Discard(); r = 1; break;
+            default: return KAI_ERR_INVALID_ARG;
+        }
+        if (results) results[i] = r;
+    }
+    if (pod_status_out) for (size_t p = 0; p < ssn.pods.size(); p++) pod_status_out[p] = ssn.pods[p].status;
+    if (pod_node_out) for (size_t p = 0; p < ssn.pods.size(); p++) pod_node_out[p] = ssn.pods[p].node;
+    if (nodes_out) for (size_t n = 0; n < ssn.nodes.size(); n++) for (int r = 0; r < ssn.R; r++) {
+        nodes_out[n].idle[r] = ssn.nodes[n].Idle.Get(r); nodes_out[n].releasing[r] = ssn.nodes[n].Releasing.Get(r); nodes_out[n].used[r] = ssn.nodes[n].Used.Get(r);
+    }
+    return KAI_OK;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {
