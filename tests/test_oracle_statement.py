@@ -59,3 +59,25 @@ def test_statement_operations_change_the_state_before_the_rollback():
     S = T.abi.POD_STATUS
     assert st[snap.pod_names.index(RUN)] == S["Releasing"] and st[snap.pod_names.index(PEND)] == S["Allocated"] and nd[snap.pod_names.index(PEND)] == 0
     assert nodes["releasing"][0, T.abi.RES_GPU] == 1 and nodes["idle"][0, T.abi.RES_GPU] == 0 and nodes["used"][0, T.abi.RES_GPU] == 2
+
+
+def test_evicting_a_pending_task_is_an_error():
+    """statement_test.go:156-210 (TestStatement_Evict "Pending job eviction") and :307-360: a task without a node cannot be evicted ("node doesn't exist in session")"""
+    snap, cfg = session()
+    _, st0, nd0, nodes0 = run_script(snap, cfg, [])
+    res, st, nd, nodes = run_script(snap, cfg, [(EVICT, snap.pod_names.index(PEND), 0, 0)])
+    assert res == [0] and st == st0 and nd == nd0 and all(np.array_equal(nodes[k], nodes0[k]) for k in nodes0)
+
+
+def test_pipeline_unpipeline_on_a_full_node():
+    """statement_test.go:462-560 (TestStatement_Pipeline_Unpipeline "basic pipeline/unpipeline"): a pending task pipelined onto a node whose two GPUs are in use, then
+    undone: the job holds no GPU again and the node's used GPUs are the two of the running job"""
+    case = {"Name": "statement", "Nodes": {"node0": {"GPUs": 2}}, "Queues": [{"Name": "queue0", "DeservedGPUs": 2}],
+            "Jobs": [{"Name": "pending_job0", "RequiredGPUsPerTask": 1, "QueueName": "queue0", "Priority": 50, "Tasks": [{"State": "Pending"}]},
+                     {"Name": "running_job0", "RequiredGPUsPerTask": 1, "QueueName": "queue0", "Priority": 50, "Tasks": [{"State": "Running", "NodeName": "node0"}] * 2}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case); cfg.plugins = 0
+    p = snap.pod_names.index(PEND)
+    res, st, nd, nodes = run_script(snap, cfg, [(PIPELINE, p, 0, 1)])
+    assert res == [1] and st[p] == T.abi.POD_STATUS["Pipelined"] and nd[p] == 0 and nodes["used"][0, T.abi.RES_GPU] == 3
+    res, st, nd, nodes = run_script(snap, cfg, [(CP, 0, 0, 0), (PIPELINE, p, 0, 1), (ROLLBACK, 0, 0, 0)])
+    assert st[p] == T.abi.POD_STATUS["Pending"] and nd[p] == -1 and nodes["used"][0, T.abi.RES_GPU] == 2
