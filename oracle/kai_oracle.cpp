@@ -1466,6 +1466,19 @@ int kai_oracle_statement_script(const kai_config* cfg, const kai_snapshot_soa* s
     return KAI_OK;
 }
 
+// resource_share.ResourceQuantities comparisons (resource_quantities.go:50-97; resource_quantities_test.go): which 0 = Less, 1 = LessEqual, 2 = LessInAtLeastOneResource
+// on (cpu, memory, gpu) triples, 3 = compareQuantities(a[0], b[0]) + 1
+int kai_oracle_quantities_cmp(int which, const double* a, const double* b) {
+    const orc::ResourceQuantities x{a[0], a[1], a[2]}, y{b[0], b[1], b[2]};
+    switch (which) {
+        case 0: return orc::rqLess(x, y) ? 1 : 0;
+        case 1: return orc::rqLessEqual(x, y) ? 1 : 0;
+        case 2: return orc::rqLessInAtLeastOneResource(x, y) ? 1 : 0;
+        case 3: return orc::compareQuantities(a[0], b[0]) + 1;
+        default: return KAI_ERR_INVALID_ARG;
+    }
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

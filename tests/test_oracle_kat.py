@@ -292,3 +292,19 @@ def test_fair_share_tree_known_answers(case):
     assert rc == 0
     got = {n: out[2, i] for i, n in enumerate(names)}
     assert got == case["want"], f"{case['name']} (proportion_test.go:{case['line']})"
+
+
+def test_resource_quantities_comparisons_known_answers():
+    """plugins/proportion/resource_share/resource_quantities_test.go:60-147: Less (strict in every resource), LessEqual, LessInAtLeastOneResource, and compareQuantities with
+    the unlimited quantity (-1) above every number"""
+    lib = T.Oracle.lib(); lib.kai_oracle_quantities_cmp.restype = C.c_int
+    def cmp(which, a, b):
+        x, y = np.array(a, np.float64), np.array(b, np.float64)
+        return lib.kai_oracle_quantities_cmp(which, x.ctypes.data_as(C.POINTER(C.c_double)), y.ctypes.data_as(C.POINTER(C.c_double)))
+    cpu, mem, gpu = 111.0, 22.0, 0.5; rq = [cpu, mem, gpu]
+    assert cmp(0, rq, [cpu + 1, mem + 1, gpu + 0.1]) == 1 and cmp(0, rq, [cpu + 1, mem, gpu + 0.1]) == 0
+    assert cmp(1, rq, [cpu + 1, mem + 1, gpu]) == 1 and cmp(1, rq, [cpu + 1, mem + 1, gpu - 0.1]) == 0
+    assert cmp(2, rq, [cpu + 1, mem, gpu - 0.1]) == 1 and cmp(2, rq, [cpu, mem - 1, gpu - 0.1]) == 0
+    U = -1.0
+    for a, b, want in ((1.5, 2.5, -1), (2.5, 1.5, 1), (2.5, 2.5, 0), (U, 2.5, 1), (2.5, U, -1), (U, U, 0)):
+        assert cmp(3, [a, 0, 0], [b, 0, 0]) - 1 == want
