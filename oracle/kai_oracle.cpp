@@ -1479,6 +1479,14 @@ int kai_oracle_quantities_cmp(int which, const double* a, const double* b) {
     }
 }
 
+// Session.NodeOrderFn (session_plugins.go:427-437) of one task on one node of a freshly loaded session: the sum of the node-order plugins cfg.plugins enables
+// (nodeavailability_test.go, resourcetype_test.go, nominatednode_test.go pin one plugin at a time)
+double kai_oracle_node_score(const kai_config* cfg, const kai_snapshot_soa* snap, int pod, int node) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || pod < 0 || pod >= snap->n_pods || node < 0 || node >= snap->n_nodes) return -1.0;
+    orc::Session ssn; ssn.load(cfg, snap);
+    return ssn.NodeOrderFn(&ssn.pods[pod], &ssn.nodes[node]);
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

@@ -146,3 +146,43 @@ def test_gpu_memory_request_against_device_size(mib, want):
     snap, cfg, _ = T.case_to_snapshot(case, fractions=True)
     cfg.min_node_gpu_memory = 1000
     assert oracle_fits(snap, cfg, snap.pod_names.index("task-0")) == want
+
+
+# ------------------------------------------------------------------------------------------------ the node-order plugins one at a time (plugins/*/…_test.go)
+def _score(case, plugin, task="task-0", node="n1", nominated=None):
+    import ctypes as C
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins = T.abi.PLUGINS[plugin]
+    if nominated is not None: snap.arrays["pod_nominated_node"][snap.pod_names.index(task)] = snap.node_names.index(nominated)
+    lib = T.Oracle.lib(); lib.kai_oracle_node_score.restype = C.c_double
+    s = snap.as_struct()
+    return lib.kai_oracle_node_score(C.byref(cfg), C.byref(s), snap.pod_names.index(task), snap.node_names.index(node))
+
+
+def _one_task(gpus, nodes, running=()):
+    return {"Name": "score", "Nodes": nodes, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": "task", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": gpus, "Tasks": [{"State": "Pending"}]}] +
+                    [{"Name": f"run{i}", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": g, "Tasks": [{"State": "Running", "NodeName": "n1"}]} for i, g in enumerate(running)],
+            "JobExpectedResults": {}}
+
+
+def test_node_availability_score():
+    """nodeavailability_test.go:51-66: scores.Availability (100) when the task fits the node's idle resources (one GPU idle of two), 0 when it does not"""
+    assert _score(_one_task(1, {"n1": {"GPUs": 2}}, running=(1,)), "nodeavailability") == 100.0
+    assert _score(_one_task(2, {"n1": {"GPUs": 2}}, running=(1,)), "nodeavailability") == 0.0
+
+
+def test_resource_type_score():
+    """resourcetype_test.go:52-84: scores.ResourceType (10) only for a CPU-only task on a node without GPUs — not for a GPU task there, not on a GPU or MIG node"""
+    assert _score(_one_task(0, {"n1": {"GPUs": 0}}), "resourcetype") == 10.0
+    assert _score(_one_task(1, {"n1": {"GPUs": 0}}), "resourcetype") == 0.0
+    assert _score(_one_task(0, {"n1": {"GPUs": 2}}), "resourcetype") == 0.0
+    assert _score(_one_task(1, {"n1": {"GPUs": 2}}), "resourcetype") == 0.0
+
+
+def test_nominated_node_score():
+    """nominatednode_test.go:25-83: scores.NominatedNode (1e6) iff the pod's nominated node is this node"""
+    nodes = {"n1": {"GPUs": 2}, "other-node": {"GPUs": 2}}
+    assert _score(_one_task(1, nodes), "nominatednode") == 0.0
+    assert _score(_one_task(1, nodes), "nominatednode", nominated="other-node") == 0.0
+    assert _score(_one_task(1, nodes), "nominatednode", nominated="n1") == 1000000.0
