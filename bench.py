@@ -215,29 +215,32 @@ def main():
         except Exception as e:  # the twin is optional evidence
             out["cpu_same_algorithm"] = {"error": str(e)[:200]}
     if sharded and os.environ.get("KAI_BENCH_REPLICAS_LEG", "1") != "0":
-        # second leg, every rank: the same GPUs as independent scheduling shards (how KAI itself scales out: one scheduler instance per node pool,
-        # conf/scheduler_conf.go:95-112) — one snapshot of the same shape per rank, no data-path collective, same bracket; reported beside the sharded value
-        snap2, cfg2, _ = pkg.synth.config(idx, args.scale, seed_offset=pkg.dist.shard_seed(0, rank))
-        core2 = pkg.KaiCore(cfg2, gpu_ids=(dev_index,)); ssn2 = core2.open_session(snap2)
+        try:
+            # second leg, every rank: the same GPUs as independent scheduling shards (how KAI itself scales out: one scheduler instance per node pool,
+            # conf/scheduler_conf.go:95-112) — one snapshot of the same shape per rank, no data-path collective, same bracket; reported beside the sharded value
+            snap2, cfg2, _ = pkg.synth.config(idx, args.scale, seed_offset=pkg.dist.shard_seed(0, rank))
+            core2 = pkg.KaiCore(cfg2, gpu_ids=(dev_index,)); ssn2 = core2.open_session(snap2)
 
-        def step2():
-            ssn2.reset(); n = 0
-            for a in actions:
-                ssn2.execute(a); n += int(ssn2.stats().decisions)
-            return n
-        d2 = 0
-        for _ in range(args.warmup):
-            step2()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            d2 = step2()
-        barrier()
-        el2 = pkg.dist.max_over_ranks(time.perf_counter() - t0, device=red_dev)
-        tot2 = pkg.dist.sum_over_ranks(d2 * args.steps, device=red_dev)
-        ssn2.close(); core2.destroy()
-        out["replicas"] = {"value": tot2 / el2, "unit": "decisions/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "weak",
-                           "note": f"{world} independent scheduling shards of the same shape, one per GPU, no data-path collective (KAI_BENCH_MULTI=replicas makes this the reported value)"}
+            def step2():
+                ssn2.reset(); n = 0
+                for a in actions:
+                    ssn2.execute(a); n += int(ssn2.stats().decisions)
+                return n
+            d2 = 0
+            for _ in range(args.warmup):
+                step2()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                d2 = step2()
+            barrier()
+            el2 = pkg.dist.max_over_ranks(time.perf_counter() - t0, device=red_dev)
+            tot2 = pkg.dist.sum_over_ranks(d2 * args.steps, device=red_dev)
+            ssn2.close(); core2.destroy()
+            out["replicas"] = {"value": tot2 / el2, "unit": "decisions/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "weak",
+                               "note": f"{world} independent scheduling shards of the same shape, one per GPU, no data-path collective (KAI_BENCH_MULTI=replicas makes this the reported value)"}
+        except Exception as e:  # the second leg is additional evidence: it must not take the sharded result down with it (every rank runs the same code, so a failure is common to all)
+            out["replicas"] = {"error": str(e)[:200]}
     if rank == 0:
         print(json.dumps(out))
     pkg.dist.finish()
