@@ -1487,6 +1487,26 @@ double kai_oracle_node_score(const kai_config* cfg, const kai_snapshot_soa* snap
     return ssn.NodeOrderFn(&ssn.pods[pod], &ssn.nodes[node]);
 }
 
+// topology.subSetNodesFn (plugins/topology/job_filtering.go:34-112) for a job's root sub-group set over all nodes of a freshly loaded session, with the tasks
+// the allocate action would hand it (GetTasksToAllocate).  out = the nodes of the FIRST node set; → its size, -1 when the function reports an error (the job is
+// given up), -2 when it returns no node set at all; *n_sets = the number of node sets.  What job_filtering_test.go TestTopologyPlugin_subsetNodesFn drives.
+int kai_oracle_subset_nodes(const kai_config* cfg, const kai_snapshot_soa* snap, int job, int32_t* out, int cap, int* n_sets) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    orc::PodGroupInfo* j = &ssn.jobs[job];
+    orc::SubGroupSet* sgs = &ssn.groups[j->rootGroup];
+    std::vector<orc::PodSet*> under; ssn.allPodSets(j, sgs, under);
+    std::vector<orc::PodInfo*> tasks = ssn.GetTasksToAllocate(j, true);
+    std::vector<orc::NodeInfo*> all; for (auto& n : ssn.nodes) all.push_back(&n);
+    std::vector<std::vector<orc::NodeInfo*>> sets;
+    const bool ok = ssn.SubsetNodesFn(j, sgs->idx, sgs->tc, under, tasks, all, sets);
+    if (n_sets) *n_sets = int(sets.size());
+    if (!ok) return -1;
+    if (sets.empty()) return -2;
+    int n = 0; for (auto* nd : sets[0]) { if (n < cap) out[n] = nd->idx; n++; }
+    return n;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

@@ -1,0 +1,39 @@
+"""The oracle's topology.subSetNodesFn against plugins/topology/job_filtering_test.go TestTopologyPlugin_subsetNodesFn (:31-643): the first node set a job with a
+topology constraint is offered.  The Go cases build the domain tree by hand; here it comes from the nodes' labels and the Topology object, as in the plugin
+(topology_plugin.go:57-110).  CPU quantities are cores: the fixtures' "CPUMillis: 1000" is parsed as the quantity "1000" (nodes_fake/nodes.go:78-80)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import kai_testlib as T
+
+TOPO = [{"ObjectMeta": {"Name": "test-topology"}, "Spec": {"Levels": [{"NodeLabel": "zone"}, {"NodeLabel": "rack"}]}}]
+N = lambda cpu, zone=None, rack=None: {"CPUMillis": cpu, "GPUs": 6, "MaxTaskNum": 100, "Labels": {k: v for k, v in (("zone", zone), ("rack", rack)) if v}}
+TWO = {"node-1": N(1000, "zone1", "rack1"), "node-2": N(400, "zone1", "rack2")}
+CASES = [  # (line, name, cpu cores per task, tasks (RequiredGPUs or None), constraint, nodes, expected first node set | "error" | "none" | "all")
+    (47, "right nodes", 500, [None, None], ("test-topology", "zone", "rack"), TWO, {"node-1"}),
+    (149, "required equal preferred", 500, [None, None], ("test-topology", "rack", "rack"), TWO, {"node-1"}),
+    (251, "no topology constraint - early return", 500, [None], None, {"node-1": N(1000, "zone1")}, "all"),
+    (284, "topology not found", 500, [None], ("nonexistent-topology", "", ""), {"node-1": N(1000, "zone1")}, "none"),
+    (320, "insufficient allocatable pods - no domains found", 2000, [None], ("test-topology", "zone", ""), {"node-1": N(1000, "zone1")}, "none"),
+    (378, "mixed GPU tasks", 2000, [1, 0], ("test-topology", "zone", "rack"), {"node-1": N(2000, "zone1", "rack1"), "node-2": N(2000, "zone1", "rack2")}, {"node-1", "node-2"}),
+    (484, "constraint names a level the topology does not have", 500, [None], ("test-topology", "nonexistent-level", "rack"), {"node-1": N(1000, "zone1", "rack1")}, "error"),
+]
+
+
+@pytest.mark.parametrize("line,name,cpu,tasks,tc,nodes,want", CASES, ids=[f"{c[0]}:{c[1].replace(' ', '_')}" for c in CASES])
+def test_subset_nodes_first_set(line, name, cpu, tasks, tc, nodes, want):
+    root = {"Name": "", "PodSets": [], "SubGroups": [], "TopologyConstraint": {"Topology": tc[0], "RequiredLevel": tc[1], "PreferredLevel": tc[2]} if tc else None}
+    case = {"Name": name, "Nodes": nodes, "Topologies": TOPO, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": cpu, "RootSubGroupSet": root,
+                      "Tasks": [{"State": "Pending", **({"RequiredGPUs": g} if g is not None else {})} for g in tasks]}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    lib = T.Oracle.lib(); lib.kai_oracle_subset_nodes.restype = C.c_int
+    out = np.zeros(16, np.int32); n_sets = C.c_int(0); s = snap.as_struct()
+    n = lib.kai_oracle_subset_nodes(C.byref(cfg), C.byref(s), snap.job_names.index("test-job"), out.ctypes.data_as(C.POINTER(C.c_int32)), 16, C.byref(n_sets))
+    if want == "error": assert n == -1, n
+    elif want == "none": assert n == -2 and n_sets.value == 0, n  # no error, and no node set is offered: a fit error on the job (the Go test reads its message)
+    elif want == "all": assert n == len(nodes) and n_sets.value == 1
+    else: assert {snap.node_names[out[i]] for i in range(n)} == want, (n, n_sets.value)
