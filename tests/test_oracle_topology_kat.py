@@ -37,3 +37,21 @@ def test_subset_nodes_first_set(line, name, cpu, tasks, tc, nodes, want):
     elif want == "none": assert n == -2 and n_sets.value == 0, n  # no error, and no node set is offered: a fit error on the job (the Go test reads its message)
     elif want == "all": assert n == len(nodes) and n_sets.value == 1
     else: assert {snap.node_names[out[i]] for i in range(n)} == want, (n, n_sets.value)
+
+
+def test_required_level_follows_the_pods_that_already_run():
+    """job_filtering_test.go:1860-1928 (getJobAllocatableDomains "mixed task statuses with required constraint - choose zone with existing pods"): a gang with one pod
+    running in zone2 and two pending, required level zone — both zones have room for two pods, only zone2 is offered"""
+    topo = [{"ObjectMeta": {"Name": "test-topology"}, "Spec": {"Levels": [{"NodeLabel": "zone"}]}}]
+    nodes = {"node1": {"CPUMillis": 2, "GPUs": 0, "MaxTaskNum": 100, "Labels": {"zone": "zone1"}}, "node2": {"CPUMillis": 3, "GPUs": 0, "MaxTaskNum": 100, "Labels": {"zone": "zone2"}}}
+    root = {"Name": "", "PodSets": [{"Name": "default", "MinAvailable": 2, "TopologyConstraint": None}], "SubGroups": [],
+            "TopologyConstraint": {"Topology": "test-topology", "RequiredLevel": "zone", "PreferredLevel": ""}}
+    case = {"Name": "existing pods", "Nodes": nodes, "Topologies": topo, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 1, "RootSubGroupSet": root,
+                      "Tasks": [{"State": "Running", "NodeName": "node2"}, {"State": "Pending"}, {"State": "Pending"}]}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    lib = T.Oracle.lib(); lib.kai_oracle_subset_nodes.restype = C.c_int
+    out = np.zeros(16, np.int32); n_sets = C.c_int(0); s = snap.as_struct()
+    n = lib.kai_oracle_subset_nodes(C.byref(cfg), C.byref(s), 0, out.ctypes.data_as(C.POINTER(C.c_int32)), 16, C.byref(n_sets))
+    assert n == 1 and snap.node_names[out[0]] == "node2" and n_sets.value == 1
