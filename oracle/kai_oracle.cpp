@@ -1506,6 +1506,21 @@ int kai_oracle_subset_nodes(const kai_config* cfg, const kai_snapshot_soa* snap,
     int n = 0; for (auto* nd : sets[0]) { if (n < cap) out[n] = nd->idx; n++; }
     return n;
 }
+// the same call, every node set in the order the action would try them: node indices with -1 after each set → the number of entries written
+int kai_oracle_subset_nodes_all(const kai_config* cfg, const kai_snapshot_soa* snap, int job, int32_t* out, int cap) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    orc::PodGroupInfo* j = &ssn.jobs[job];
+    orc::SubGroupSet* sgs = &ssn.groups[j->rootGroup];
+    std::vector<orc::PodSet*> under; ssn.allPodSets(j, sgs, under);
+    std::vector<orc::PodInfo*> tasks = ssn.GetTasksToAllocate(j, true);
+    std::vector<orc::NodeInfo*> all; for (auto& n : ssn.nodes) all.push_back(&n);
+    std::vector<std::vector<orc::NodeInfo*>> sets;
+    if (!ssn.SubsetNodesFn(j, sgs->idx, sgs->tc, under, tasks, all, sets)) return -1;
+    int n = 0;
+    for (auto& set : sets) { for (auto* nd : set) { if (n >= cap) return KAI_ERR_CAPACITY; out[n++] = nd->idx; } if (n >= cap) return KAI_ERR_CAPACITY; out[n++] = -1; }
+    return n;
+}
 
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`

@@ -55,3 +55,30 @@ def test_required_level_follows_the_pods_that_already_run():
     out = np.zeros(16, np.int32); n_sets = C.c_int(0); s = snap.as_struct()
     n = lib.kai_oracle_subset_nodes(C.byref(cfg), C.byref(s), 0, out.ctypes.data_as(C.POINTER(C.c_int32)), 16, C.byref(n_sets))
     assert n == 1 and snap.node_names[out[0]] == "node2" and n_sets.value == 1
+
+
+def _node_sets(racks, cpu, gpus):
+    """one node per rack of zone1 with the given idle (cores, GPUs); a one-task job with required zone / preferred rack → the node sets in the order they are tried"""
+    nodes = {f"node-{r}": {"CPUMillis": c, "GPUs": g, "MaxTaskNum": 100, "Labels": {"zone": "zone1", "rack": r}} for r, (c, g) in racks.items()}
+    root = {"Name": "", "PodSets": [], "SubGroups": [], "TopologyConstraint": {"Topology": "test-topology", "RequiredLevel": "zone", "PreferredLevel": "rack"}}
+    case = {"Name": "sort", "Nodes": nodes, "Topologies": TOPO, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": cpu, "RequiredGPUsPerTask": gpus, "RootSubGroupSet": root, "Tasks": [{"State": "Pending"}]}],
+            "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    lib = T.Oracle.lib(); lib.kai_oracle_subset_nodes_all.restype = C.c_int
+    out = np.zeros(64, np.int32); s = snap.as_struct()
+    n = lib.kai_oracle_subset_nodes_all(C.byref(cfg), C.byref(s), 0, out.ctypes.data_as(C.POINTER(C.c_int32)), 64)
+    assert n > 0
+    sets, cur = [], []
+    for v in out[:n]:
+        if v < 0: sets.append(cur); cur = []
+        else: cur.append(snap.node_names[v].replace("node-", ""))
+    return sets
+
+
+def test_sort_tree_orders_racks_by_job_to_free_ratio():
+    """node_scoring_test.go:294-345 (TestSortTree): the children of a domain are tried fullest first — descending ratio of the job's request to the domain's idle-or-releasing
+    resources in the job's dominant resource (job_filtering.go:460-524), GPUs or CPU — so racks with 2 / 5 / 8 free come in that order; the zone itself comes last"""
+    assert _node_sets({"rack3": (100, 5), "rack1": (100, 2), "rack2": (100, 8)}, cpu=0.001, gpus=1)[:3] == [["rack1"], ["rack3"], ["rack2"]]
+    assert _node_sets({"rack3": (5, 0), "rack1": (2, 0), "rack2": (8, 0)}, cpu=1, gpus=0)[:3] == [["rack1"], ["rack3"], ["rack2"]]
