@@ -1506,6 +1506,22 @@ int kai_oracle_subset_nodes(const kai_config* cfg, const kai_snapshot_soa* snap,
     int n = 0; for (auto* nd : sets[0]) { if (n < cap) out[n] = nd->idx; n++; }
     return n;
 }
+// … and the preferred-level node scores the call leaves behind for the node order (node_scoring.go:37-69): out[n] = score of node n, -1 = no score recorded
+int kai_oracle_topology_scores(const kai_config* cfg, const kai_snapshot_soa* snap, int job, double* out) {
+    if (!cfg || !snap || !out || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    orc::PodGroupInfo* j = &ssn.jobs[job];
+    orc::SubGroupSet* sgs = &ssn.groups[j->rootGroup];
+    std::vector<orc::PodSet*> under; ssn.allPodSets(j, sgs, under);
+    std::vector<orc::PodInfo*> tasks = ssn.GetTasksToAllocate(j, true);
+    std::vector<orc::NodeInfo*> all; for (auto& n : ssn.nodes) all.push_back(&n);
+    std::vector<std::vector<orc::NodeInfo*>> sets;
+    if (!ssn.SubsetNodesFn(j, sgs->idx, sgs->tc, under, tasks, all, sets)) return -1;
+    for (size_t n = 0; n < ssn.nodes.size(); n++) out[n] = -1.0;
+    auto it = ssn.subGroupNodeScores.find(sgs->idx);
+    if (it != ssn.subGroupNodeScores.end()) for (auto& kv : it->second) out[kv.first] = kv.second;
+    return KAI_OK;
+}
 // the same call, every node set in the order the action would try them: node indices with -1 after each set → the number of entries written
 int kai_oracle_subset_nodes_all(const kai_config* cfg, const kai_snapshot_soa* snap, int job, int32_t* out, int cap) {
     if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;

@@ -82,3 +82,26 @@ def test_sort_tree_orders_racks_by_job_to_free_ratio():
     resources in the job's dominant resource (job_filtering.go:460-524), GPUs or CPU — so racks with 2 / 5 / 8 free come in that order; the zone itself comes last"""
     assert _node_sets({"rack3": (100, 5), "rack1": (100, 2), "rack2": (100, 8)}, cpu=0.001, gpus=1)[:3] == [["rack1"], ["rack3"], ["rack2"]]
     assert _node_sets({"rack3": (5, 0), "rack1": (2, 0), "rack2": (8, 0)}, cpu=1, gpus=0)[:3] == [["rack1"], ["rack3"], ["rack2"]]
+
+
+def _topology_scores(racks, n_tasks, cpu):
+    """racks: {rack: [cores of each of its nodes]}; a gang of n_tasks x cpu cores, required zone, preferred rack → {node: topology score}"""
+    nodes = {f"{r}-n{i}": {"CPUMillis": c, "GPUs": 0, "MaxTaskNum": 100, "Labels": {"zone": "zone1", "rack": r}} for r, cs in racks.items() for i, c in enumerate(cs)}
+    root = {"Name": "", "PodSets": [], "SubGroups": [], "TopologyConstraint": {"Topology": "test-topology", "RequiredLevel": "zone", "PreferredLevel": "rack"}}
+    case = {"Name": "scores", "Nodes": nodes, "Topologies": TOPO, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": cpu, "RootSubGroupSet": root, "Tasks": [{"State": "Pending"}] * n_tasks}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    lib = T.Oracle.lib(); lib.kai_oracle_topology_scores.restype = C.c_int
+    out = np.zeros(snap.n_nodes); s = snap.as_struct()
+    assert lib.kai_oracle_topology_scores(C.byref(cfg), C.byref(s), 0, out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    return {snap.node_names[i]: out[i] for i in range(snap.n_nodes)}
+
+
+def test_preferred_level_node_scores():
+    """node_scoring_test.go:106-257 (TestCalculateNodeScores): the domains of the preferred level in tree order get floor((i + 1) / D * 10) x scores.Topology (10 000) — one
+    rack: 10 for its nodes; three racks that can take 1 / 2 / 3 pods (fullest first in the sorted tree): 3, 6, 10; four racks: 2, 5, 7, 10"""
+    K = 10000.0
+    assert _topology_scores({"rack1": [1, 1]}, 1, 1) == {"rack1-n0": 10 * K, "rack1-n1": 10 * K}
+    assert _topology_scores({"rack3": [1], "rack2": [2], "rack1": [3]}, 1, 1) == {"rack1-n0": 10 * K, "rack2-n0": 6 * K, "rack3-n0": 3 * K}
+    assert _topology_scores({"rack4": [1], "rack3": [2], "rack2": [3], "rack1": [4]}, 1, 1) == {"rack1-n0": 10 * K, "rack2-n0": 7 * K, "rack3-n0": 5 * K, "rack4-n0": 2 * K}
