@@ -105,3 +105,21 @@ def test_preferred_level_node_scores():
     assert _topology_scores({"rack1": [1, 1]}, 1, 1) == {"rack1-n0": 10 * K, "rack1-n1": 10 * K}
     assert _topology_scores({"rack3": [1], "rack2": [2], "rack1": [3]}, 1, 1) == {"rack1-n0": 10 * K, "rack2-n0": 6 * K, "rack3-n0": 3 * K}
     assert _topology_scores({"rack4": [1], "rack3": [2], "rack2": [3], "rack1": [4]}, 1, 1) == {"rack1-n0": 10 * K, "rack2-n0": 7 * K, "rack3-n0": 5 * K, "rack4-n0": 2 * K}
+
+
+def test_releasing_resources_count_towards_a_domain():
+    """job_filtering_test.go:1260-1327 (calcTreeAllocatable "Can pipeline on domain with releasing pods"): each rack's node has 500 cores idle and 500 being released; a gang
+    of 2 x 500 with the rack REQUIRED fits a rack only if releasing resources count (AllocatablePods 2 per rack) — both racks are offered, fullest-first ties by ID"""
+    nodes = {"node-1": {"CPUMillis": 1000, "GPUs": 6, "MaxTaskNum": 100, "Labels": {"zone": "zone1", "rack": "rack1"}},
+             "node-2": {"CPUMillis": 1000, "GPUs": 6, "MaxTaskNum": 100, "Labels": {"zone": "zone1", "rack": "rack2"}}}
+    root = {"Name": "", "PodSets": [], "SubGroups": [], "TopologyConstraint": {"Topology": "test-topology", "RequiredLevel": "rack", "PreferredLevel": ""}}
+    case = {"Name": "releasing", "Nodes": nodes, "Topologies": TOPO, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 500, "RootSubGroupSet": root, "Tasks": [{"State": "Pending"}] * 2},
+                     {"Name": "running-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 500,
+                      "Tasks": [{"State": "Releasing", "NodeName": "node-1"}, {"State": "Releasing", "NodeName": "node-2"}]}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    lib = T.Oracle.lib(); lib.kai_oracle_subset_nodes_all.restype = C.c_int
+    out = np.zeros(16, np.int32); s = snap.as_struct()
+    n = lib.kai_oracle_subset_nodes_all(C.byref(cfg), C.byref(s), snap.job_names.index("test-job"), out.ctypes.data_as(C.POINTER(C.c_int32)), 16)
+    assert [snap.node_names[v] if v >= 0 else None for v in out[:n]] == ["node-1", None, "node-2", None]
