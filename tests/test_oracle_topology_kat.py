@@ -123,3 +123,19 @@ def test_releasing_resources_count_towards_a_domain():
     out = np.zeros(16, np.int32); s = snap.as_struct()
     n = lib.kai_oracle_subset_nodes_all(C.byref(cfg), C.byref(s), snap.job_names.index("test-job"), out.ctypes.data_as(C.POINTER(C.c_int32)), 16)
     assert [snap.node_names[v] if v >= 0 else None for v in out[:n]] == ["node-1", None, "node-2", None]
+
+
+def test_a_job_that_requests_nothing_fits_every_domain():
+    """job_filtering_test.go:1329-1380 ("Job requests 0 resources - set maximal amount of pods on each node"): a best-effort gang of four with the rack required — every
+    node can take all of its tasks, so both racks are offered"""
+    nodes = {"node-1": {"CPUMillis": 1000, "GPUs": 6, "MaxTaskNum": 100, "Labels": {"zone": "zone1", "rack": "rack1"}},
+             "node-2": {"CPUMillis": 1000, "GPUs": 6, "MaxTaskNum": 100, "Labels": {"zone": "zone1", "rack": "rack2"}}}
+    root = {"Name": "", "PodSets": [], "SubGroups": [], "TopologyConstraint": {"Topology": "test-topology", "RequiredLevel": "rack", "PreferredLevel": ""}}
+    case = {"Name": "zero", "Nodes": nodes, "Topologies": TOPO, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": "test-job", "Priority": 50, "QueueName": "q", "IsBestEffortJob": True, "RootSubGroupSet": root, "Tasks": [{"State": "Pending"}] * 4}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    lib = T.Oracle.lib(); lib.kai_oracle_subset_nodes_all.restype = C.c_int
+    out = np.zeros(16, np.int32); s = snap.as_struct()
+    n = lib.kai_oracle_subset_nodes_all(C.byref(cfg), C.byref(s), 0, out.ctypes.data_as(C.POINTER(C.c_int32)), 16)
+    assert [snap.node_names[v] if v >= 0 else None for v in out[:n]] == ["node-1", None, "node-2", None]
