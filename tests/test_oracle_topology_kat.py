@@ -139,3 +139,59 @@ def test_a_job_that_requests_nothing_fits_every_domain():
     out = np.zeros(16, np.int32); s = snap.as_struct()
     n = lib.kai_oracle_subset_nodes_all(C.byref(cfg), C.byref(s), 0, out.ctypes.data_as(C.POINTER(C.c_int32)), 16)
     assert [snap.node_names[v] if v >= 0 else None for v in out[:n]] == ["node-1", None, "node-2", None]
+
+
+# ------------------------------------------------------------------------------------------------ the same scenes through the allocate action: engine against oracle
+def _scene(nodes, jobs, topo=TOPO):
+    case = {"Name": "scene", "Nodes": nodes, "Topologies": topo, "Queues": [{"Name": "q", "DeservedGPUs": 1}], "Jobs": jobs, "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    return snap, cfg
+
+
+def _root(required, preferred=""):
+    return {"Name": "", "PodSets": [], "SubGroups": [], "TopologyConstraint": {"Topology": "test-topology", "RequiredLevel": required, "PreferredLevel": preferred}}
+
+
+def _rack_node(cpu, rack, gpus=6):
+    return {"CPUMillis": cpu, "GPUs": gpus, "MaxTaskNum": 100, "Labels": {"zone": "zone1", "rack": rack}}
+
+
+SCENES = {
+    "right nodes": lambda: _scene(TWO, [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 500, "RootSubGroupSet": _root("zone", "rack"), "Tasks": [{"State": "Pending"}] * 2}]),
+    "mixed GPU tasks": lambda: _scene({"node-1": _rack_node(2000, "rack1"), "node-2": _rack_node(2000, "rack2")},
+                                      [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 2000, "RootSubGroupSet": _root("zone", "rack"),
+                                        "Tasks": [{"State": "Pending", "RequiredGPUs": 1}, {"State": "Pending", "RequiredGPUs": 0}]}]),
+    "releasing counts": lambda: _scene({"node-1": _rack_node(1000, "rack1"), "node-2": _rack_node(1000, "rack2")},
+                                       [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 500, "RootSubGroupSet": _root("rack"), "Tasks": [{"State": "Pending"}] * 2},
+                                        {"Name": "running-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 500,
+                                         "Tasks": [{"State": "Releasing", "NodeName": "node-1"}, {"State": "Releasing", "NodeName": "node-2"}]}]),
+    "requests nothing": lambda: _scene({"node-1": _rack_node(1000, "rack1"), "node-2": _rack_node(1000, "rack2")},
+                                       [{"Name": "test-job", "Priority": 50, "QueueName": "q", "IsBestEffortJob": True, "RootSubGroupSet": _root("rack"), "Tasks": [{"State": "Pending"}] * 4}]),
+    "racks fullest first": lambda: _scene({"node-rack3": _rack_node(100, "rack3", 5), "node-rack1": _rack_node(100, "rack1", 2), "node-rack2": _rack_node(100, "rack2", 8)},
+                                          [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": 1, "RootSubGroupSet": _root("zone", "rack"), "Tasks": [{"State": "Pending"}] * 2}]),
+    "no room in the zone": lambda: _scene({"node-1": {"CPUMillis": 1000, "GPUs": 6, "MaxTaskNum": 100, "Labels": {"zone": "zone1"}}},
+                                          [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 2000, "RootSubGroupSet": _root("zone"), "Tasks": [{"State": "Pending"}]}]),
+}
+
+
+def _same(res, ref):
+    assert res.ops == ref.ops and np.array_equal(res.pod_status, ref.pod_status) and np.array_equal(res.pod_node, ref.pod_node)
+    for k in ref.nodes: assert np.array_equal(res.nodes[k], ref.nodes[k]), k
+
+
+@pytest.mark.parametrize("scene", sorted(SCENES))
+def test_scenes_allocate_on_the_host_compiled_engine(scene):
+    from test_engine_hostsim import HostSim
+    snap, cfg = SCENES[scene]()
+    _same(HostSim.run(snap, cfg, ("allocate",)), T.Oracle.run(snap, cfg, ("allocate",)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", sorted(SCENES))
+def test_gpu_scenes_allocate(scene):
+    import torch
+    assert torch.cuda.is_available()
+    from test_gpu_parity import run_gpu
+    snap, cfg = SCENES[scene]()
+    _same(run_gpu(snap, cfg, ("allocate",)), T.Oracle.run(snap, cfg, ("allocate",)))
