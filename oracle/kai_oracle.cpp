@@ -1538,6 +1538,16 @@ int kai_oracle_subset_nodes_all(const kai_config* cfg, const kai_snapshot_soa* s
     return n;
 }
 
+// common.FeasibleNodesForJob (actions/common/feasible_nodes.go; feasible_nodes_test.go): out[n] = 1 when node n is feasible for the job → the number of feasible nodes
+int kai_oracle_feasible_nodes(const kai_config* cfg, const kai_snapshot_soa* snap, int job, uint8_t* out) {
+    if (!cfg || !snap || !out || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    for (int n = 0; n < snap->n_nodes; n++) out[n] = 0;
+    std::vector<int> f = ssn.FeasibleNodesForJob(&ssn.jobs[job]);
+    for (int n : f) out[n] = 1;
+    return int(f.size());
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

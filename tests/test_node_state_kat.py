@@ -186,3 +186,32 @@ def test_nominated_node_score():
     assert _score(_one_task(1, nodes), "nominatednode") == 0.0
     assert _score(_one_task(1, nodes), "nominatednode", nominated="other-node") == 0.0
     assert _score(_one_task(1, nodes), "nominatednode", nominated="n1") == 1000000.0
+
+
+# ------------------------------------------------------------------------------------------------ common.FeasibleNodesForJob (actions/common/feasible_nodes_test.go:20-277)
+def test_feasible_nodes_for_job():
+    """a job whose every pod needs some kind of GPU looks only at nodes with idle or releasing GPUs — whole devices, room on a shared device, MIG instances; any other
+    job looks at all nodes.  The seven nodes of the reference's test: CPU only, idle GPU, releasing GPU, idle fraction, releasing fraction, idle MIG, releasing MIG."""
+    import ctypes as C
+    MIG = "nvidia.com/mig-1g.10gb"
+    nodes = {"cpu-node": {"GPUs": 0}, "idle-gpu-node": {"GPUs": 1}, "releasing-gpu-node": {"GPUs": 1}, "idle-fraction-node": {"GPUs": 1}, "releasing-fraction-node": {"GPUs": 1},
+             "idle-mig-node": {"GPUs": 0, "MigStrategy": "mixed", "MigInstances": {MIG: 1}}, "releasing-mig-node": {"GPUs": 0, "MigStrategy": "mixed", "MigInstances": {MIG: 1}}}
+    J = lambda name, tasks, **kw: {"Name": name, "Priority": 50, "QueueName": "q", "Tasks": tasks, **kw}
+    P = {"State": "Pending"}
+    jobs = [J("hold-gpu", [{"State": "Releasing", "NodeName": "releasing-gpu-node"}], RequiredGPUsPerTask=1),
+            J("half-a", [{"State": "Running", "NodeName": "idle-fraction-node", "GPUGroups": ["0"]}], RequiredGPUsPerTask=0.5),
+            J("half-b", [{"State": "Running", "NodeName": "releasing-fraction-node", "GPUGroups": ["0"]}], RequiredGPUsPerTask=0.5),
+            J("half-c", [{"State": "Releasing", "NodeName": "releasing-fraction-node", "GPUGroups": ["0"]}], RequiredGPUsPerTask=0.5),
+            J("hold-mig", [{"State": "Releasing", "NodeName": "releasing-mig-node", "RequiredMigInstances": {MIG: 1}}]),
+            J("cpu only", [P]), J("whole gpu", [P], RequiredGPUsPerTask=1), J("distributed whole gpu", [P, P], RequiredGPUsPerTask=1),
+            J("mixed", [{"State": "Pending", "RequiredGPUs": 1}, {"State": "Pending", "RequiredGPUs": 0}], RequiredGPUsPerTask=1),
+            J("fraction", [P], RequiredGPUsPerTask=0.5), J("gpu memory", [P], RequiredGpuMemory=50), J("mig", [{"State": "Pending", "RequiredMigInstances": {MIG: 1}}])]
+    case = {"Name": "feasible", "Nodes": nodes, "Queues": [{"Name": "q", "DeservedGPUs": 4}], "Jobs": jobs, "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case, fractions=True)
+    lib = T.Oracle.lib(); lib.kai_oracle_feasible_nodes.restype = C.c_int
+    s = snap.as_struct()
+    gpu_nodes = set(nodes) - {"cpu-node"}
+    for job, want in (("cpu only", set(nodes)), ("whole gpu", gpu_nodes), ("distributed whole gpu", gpu_nodes), ("mixed", set(nodes)), ("fraction", gpu_nodes), ("gpu memory", gpu_nodes), ("mig", gpu_nodes)):
+        out = np.zeros(snap.n_nodes, np.uint8)
+        n = lib.kai_oracle_feasible_nodes(C.byref(cfg), C.byref(s), snap.job_names.index(job), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        assert {snap.node_names[i] for i in range(snap.n_nodes) if out[i]} == want and n == len(want), job
