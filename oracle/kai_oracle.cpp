@@ -1548,6 +1548,17 @@ int kai_oracle_feasible_nodes(const kai_config* cfg, const kai_snapshot_soa* sna
     return int(f.size());
 }
 
+// podgroup_info.GetTasksToEvict (api/podgroup_info/eviction_info.go:14-97; eviction_info_test.go) of one job of a freshly loaded session: out = the tasks (pod
+// indices) in the order they are taken, *has_more = the second result → the number of tasks
+int kai_oracle_tasks_to_evict(const kai_config* cfg, const kai_snapshot_soa* snap, int job, int32_t* out, int cap, int* has_more) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    bool more = false; std::vector<orc::PodInfo*> v = ssn.GetTasksToEvict(&ssn.jobs[job], more);
+    if (has_more) *has_more = more ? 1 : 0;
+    int n = 0; for (auto* t : v) { if (out && n < cap) out[n] = t->idx; n++; }
+    return n;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

@@ -215,3 +215,28 @@ def test_feasible_nodes_for_job():
         out = np.zeros(snap.n_nodes, np.uint8)
         n = lib.kai_oracle_feasible_nodes(C.byref(cfg), C.byref(s), snap.job_names.index(job), out.ctypes.data_as(C.POINTER(C.c_uint8)))
         assert {snap.node_names[i] for i in range(snap.n_nodes) if out[i]} == want and n == len(want), job
+
+
+# ------------------------------------------------------------------------------------------------ GetTasksToEvict (api/podgroup_info/eviction_info_test.go:16-106)
+EVICT = [  # (name, pod-sets (name, minAvailable), running pods by pod-set, tasks expected, has more)
+    ("WithoutSubGroups_EvictOne", [("default", 1)], ["default"] * 3, 1, True),
+    ("WithoutSubGroups_EmptyQueue", [("default", 1)], [], 0, False),
+    ("WithoutSubGroups_MultipleEvict", [("default", 2)], ["default"] * 2, 2, False),
+    ("WithSubGroups_SingleEvict", [("default", 2), ("sg1", 1), ("sg2", 1)], ["sg1", "sg1", "sg2"], 1, True),
+    ("WithSubGroups_EvictAll", [("default", 2), ("sg1", 1), ("sg2", 1)], ["sg1", "sg2"], 2, False),
+]
+
+
+@pytest.mark.parametrize("name,podsets,pods,want,more", EVICT, ids=[c[0] for c in EVICT])
+def test_tasks_to_evict(name, podsets, pods, want, more):
+    """one elastic pod above the gang's minimum at a time, the whole gang once it is down to its minimum — per pod-set, and whether anything is left afterwards"""
+    import ctypes as C
+    root = {"Name": "", "PodSets": [{"Name": n, "MinAvailable": m, "TopologyConstraint": None} for n, m in podsets], "SubGroups": [], "TopologyConstraint": None}
+    case = {"Name": name, "Nodes": {"n1": {"GPUs": 8}}, "Queues": [{"Name": "q", "DeservedGPUs": 8}],
+            "Jobs": [{"Name": "pg1", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": 1, "RootSubGroupSet": root,
+                      "Tasks": [{"State": "Running", "NodeName": "n1", **({"SubGroupName": p} if p != "default" else {})} for p in pods]}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    lib = T.Oracle.lib(); lib.kai_oracle_tasks_to_evict.restype = C.c_int
+    out = np.zeros(8, np.int32); hm = C.c_int(0); s = snap.as_struct()
+    n = lib.kai_oracle_tasks_to_evict(C.byref(cfg), C.byref(s), 0, out.ctypes.data_as(C.POINTER(C.c_int32)), 8, C.byref(hm))
+    assert (n, bool(hm.value)) == (want, more)
