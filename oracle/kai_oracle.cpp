@@ -1559,6 +1559,16 @@ int kai_oracle_tasks_to_evict(const kai_config* cfg, const kai_snapshot_soa* sna
     return n;
 }
 
+// podgroup_info.GetTasksToAllocate (api/podgroup_info/allocation_info.go:27-54, 145-177; allocation_info_test.go) of one job of a freshly loaded session →
+// the number of tasks of the next chunk (out = their pod indices in order)
+int kai_oracle_tasks_to_allocate(const kai_config* cfg, const kai_snapshot_soa* snap, int job, int real_allocation, int32_t* out, int cap) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    std::vector<orc::PodInfo*> v = ssn.GetTasksToAllocate(&ssn.jobs[job], real_allocation != 0);
+    int n = 0; for (auto* t : v) { if (out && n < cap) out[n] = t->idx; n++; }
+    return n;
+}
+
 // plugins/proportion/resource_share on hand-set values (resource_share_test.go, queue_resource_share_test.go): rs = 3 (cpu, memory, gpu) x 7 (Deserved,
 // FairShare, MaxAllowed, OverQuotaWeight, Allocated, AllocatedNotPreemptible, Request) → out = requestable[3], allocatable[3], dominant share over `total`
 int kai_oracle_resource_share(const double* rs, const double* total, double* out) {

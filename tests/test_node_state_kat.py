@@ -240,3 +240,23 @@ def test_tasks_to_evict(name, podsets, pods, want, more):
     out = np.zeros(8, np.int32); hm = C.c_int(0); s = snap.as_struct()
     n = lib.kai_oracle_tasks_to_evict(C.byref(cfg), C.byref(s), 0, out.ctypes.data_as(C.POINTER(C.c_int32)), 8, C.byref(hm))
     assert (n, bool(hm.value)) == (want, more)
+
+
+# ------------------------------------------------------------------------------------------------ getNumTasksToAllocate (api/podgroup_info/allocation_info_test.go:396-461)
+TO_ALLOCATE = [("pending equal to minAvailable", 3, ["Pending"] * 3, 3), ("allocated equal to minAvailable, plus pending", 2, ["Allocated", "Allocated", "Pending"], 1),
+               ("allocated above minAvailable, extra pending", 2, ["Allocated"] * 3 + ["Pending"], 1), ("allocated less than minAvailable, rest pending", 4, ["Allocated"] * 2 + ["Pending"] * 2, 2),
+               ("all allocated, at minAvailable", 3, ["Allocated"] * 3, 0)]
+
+
+@pytest.mark.parametrize("name,min_available,statuses,want", TO_ALLOCATE, ids=[c[0].replace(" ", "_").replace(",", "") for c in TO_ALLOCATE])
+def test_num_tasks_to_allocate(name, min_available, statuses, want):
+    """the gang's missing tasks up to minAvailable in one chunk, then one elastic task at a time"""
+    import ctypes as C
+    root = {"Name": "", "PodSets": [{"Name": "default", "MinAvailable": min_available, "TopologyConstraint": None}], "SubGroups": [], "TopologyConstraint": None}
+    case = {"Name": name, "Nodes": {"n1": {"GPUs": 8}}, "Queues": [{"Name": "q", "DeservedGPUs": 8}],
+            "Jobs": [{"Name": "pg", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": 1, "RootSubGroupSet": root,
+                      "Tasks": [{"State": st, **({"NodeName": "n1"} if st != "Pending" else {})} for st in statuses]}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    lib = T.Oracle.lib(); lib.kai_oracle_tasks_to_allocate.restype = C.c_int
+    s = snap.as_struct()
+    assert lib.kai_oracle_tasks_to_allocate(C.byref(cfg), C.byref(s), 0, 1, None, 0) == want
