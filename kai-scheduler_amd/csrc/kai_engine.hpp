@@ -180,7 +180,8 @@ struct SolverCtx {
     QNode* i_qn[2]; int32_t *i_qheap[2], *i_root[2], *i_cur[2], *i_end[2], *i_side[2], *i_side_len[2];  // [Q], [Q+1], [Q+1], [Q], [Q], [J], [Q]
     double* vq_pop;                                   // [Q][3] Σ Allocated of the jobs popped from a leaf (poppedJobsByQueue, job_order_by_queue.go:80-82)
     int32_t* s_ov_min;                                // [S] minAvailable of the partial preemptor representative (job_solver.go:128-151)
-    int32_t *grp_job, *grp_off, *grp_pods;            // task groups of the scenario: recorded first, then potential in the order they were added
+    int32_t *grp_job, *grp_off, *grp_pods, *grp_ord;  // task groups of the scenario: recorded first, then potential in the order they were added; grp_pods = a group's pods in canonical order
+                                                      // (what ranging the representative's pod map stands for), grp_ord = in the order they were handed over (VictimInfo.Tasks, potentialVictimsTasks: slices)
     int32_t *rec_job, *rec_off, *rec_pods;            // recorded victim jobs handed to the next partial job (result.victimJobs)
     int32_t *res_tasks, *ev_tasks, *vt_tasks, *pend, *tmp, *tmp2, *tmp3;  // [P] result.victimsTasks, GetTasksToEvict output, victims of the running simulation, tasks of the job being solved, scratch
     uint32_t *feas, *feas0;                           // [W] byPodSolver.feasibleNodes / JobSolver.feasibleNodes as node bitmaps
@@ -206,6 +207,7 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     for (int i = 0; i < 2; i++) { add(sizeof(QNode) * (Q + 1)); add(sizeof(int32_t) * (Q + 2)); add(sizeof(int32_t) * (Q + 2)); add(sizeof(int32_t) * (Q + 1)); add(sizeof(int32_t) * (Q + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (Q + 1)); }
     add(sizeof(double) * 3 * Q); add(sizeof(int32_t) * (S + 1));
     for (int i = 0; i < 2; i++) { add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); }
+    add(sizeof(int32_t) * (P + 1));  // grp_ord
     for (int i = 0; i < 7; i++) add(sizeof(int32_t) * (P + 1));
     add(sizeof(uint32_t) * (W + 1)); add(sizeof(uint32_t) * (W + 1));
     add(sizeof(double) * (N + 1)); add(sizeof(int32_t) * (P + 1));
@@ -230,7 +232,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
         v.i_cur[i] = (int32_t*)take(sizeof(int32_t) * (Q + 1)); v.i_end[i] = (int32_t*)take(sizeof(int32_t) * (Q + 1)); v.i_side[i] = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.i_side_len[i] = (int32_t*)take(sizeof(int32_t) * (Q + 1));
     }
     v.vq_pop = (double*)take(sizeof(double) * 3 * Q); v.s_ov_min = (int32_t*)take(sizeof(int32_t) * (S + 1));
-    v.grp_job = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.grp_off = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.grp_pods = (int32_t*)take(sizeof(int32_t) * (P + 1));
+    v.grp_job = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.grp_off = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.grp_pods = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.grp_ord = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.rec_job = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.rec_off = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.rec_pods = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.res_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.ev_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vt_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.pend = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.tmp = (int32_t*)take(sizeof(int32_t) * (P + 1));

@@ -528,6 +528,7 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 (th
         const VictimInfo& victim = kv.second;
         // splitVictimTasks :187-220 (sub-groups in name-rank order)
         std::vector<PodInfo*> core, elastic;
+        ORC_T("[orc] victim job %d tasks:", victim.Job->idx); for (auto* t : victim.Tasks) ORC_T(" %d", t->idx); ORC_T("\n");
         for (auto* ps : victim.Job->podSets) {
             std::vector<PodInfo*> sub; for (auto* t : victim.Tasks) if (t->podset == ps->idx) sub.push_back(t);
             if (sub.empty()) continue;
@@ -540,6 +541,7 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 (th
         if (res.empty()) continue;
         auto& dst = totalVictimsResources[victim.Job->queue]; dst.insert(dst.end(), res.begin(), res.end());
     }
+    for (auto& kv : totalVictimsResources) for (auto& r : kv.second) ORC_T("[orc] ent q%d %g %g %g\n", kv.first, r.milliCpu, r.memory, r.gpus);
     return reclaimableCore(Q, reclaimer->queue, required, reclaimer->IsPreemptibleJob(), totalVictimsResources, cfg.reclaimer_saturation_multiplier);
 }
 // reclaimable/strategies/strategies.go: MaintainFairShareStrategy :45-60 — the reclaimee is over what it may hold; GuaranteeDeservedQuotaStrategy :62-91 — the

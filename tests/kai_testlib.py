@@ -48,7 +48,7 @@ class Oracle:
     @classmethod
     def lib(cls):
         if cls._lib is None:
-            so = os.path.join(ROOT, "oracle", "liboracle.so")
+            so = os.environ.get("KAI_ORACLE_SO") or os.path.join(ROOT, "oracle", "liboracle.so")  # override: a -DORC_TRACE build while debugging
             srcs = [os.path.join(ROOT, "oracle", f) for f in ("kai_oracle.cpp", "oracle_model.hpp", "oracle_session.hpp", "oracle_solver.hpp")]
             if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
                 subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)

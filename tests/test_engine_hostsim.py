@@ -19,7 +19,7 @@ class HostSim(T.Oracle):
     @classmethod
     def lib(cls):
         if cls._sim is None:
-            so = os.path.join(T.ROOT, "tests", "host_sim", "libhostsim.so")
+            so = os.environ.get("KAI_HOSTSIM_SO") or os.path.join(T.ROOT, "tests", "host_sim", "libhostsim.so")  # override: a -DKAI_SOLVER_TRACE build
             src = os.path.join(T.ROOT, "tests", "host_sim", "host_sim.cpp")
             import glob
             deps = [src] + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.inc")) + glob.glob(os.path.join(T.ROOT, "include", "*.h"))
@@ -305,3 +305,25 @@ def test_hostsim_broad_random_cycles_with_fractions(seed):
         ref, res = T.Oracle.run(snap, cfg, actions), HostSim.run(snap, cfg, actions)
         assert_same(res, ref, share_tol=1e-9)
         _same_groups(snap, res, ref)
+
+
+FRACTION_VICTIM_ORDER_SEEDS = ((5592, 5), (8881176, 5))  # tools/host_campaign.py CAMPAIGN_FRACTIONS=1: the two cycles of rounds 1-2 that differed from the oracle
+
+
+def fraction_campaign_case(seed, ci):
+    snap, cfg, actions = T.broad_case(seed)[ci]
+    cfg.engine_mode = seed % 3 if ci % 2 else 0
+    T.pkg.synth.add_fractions(snap, seed * 7 + ci, frac=(0.3, 0.6, 0.9)[(seed + ci) % 3], portions=((0.25, 0.5, 0.75), (0.5,), (0.25, 0.25, 0.5))[seed % 3])
+    return snap, cfg, actions
+
+
+@pytest.mark.parametrize("seed,ci", FRACTION_VICTIM_ORDER_SEEDS)
+def test_hostsim_victim_tasks_keep_their_eviction_order(seed, ci):
+    """VictimInfo.Tasks and potentialVictimsTasks are SLICES in the order GetTasksToEvict handed the tasks over (base_scenario.go:109-137): proportion's
+    splitVictimTasks (proportion.go:187-220) takes the first minAvailable of them as the core tasks, so with pods of different sizes (fractions) the
+    reclaim validator's amounts depend on that order.  The engine kept every task group in the canonical pod order only (what ranging the clone's pod
+    MAP stands for) and so validated another split: seed 8881176 took another solution, seed 5592 the same operations in another order."""
+    snap, cfg, actions = fraction_campaign_case(seed, ci)
+    ref, res = T.Oracle.run(snap, cfg, actions), HostSim.run(snap, cfg, actions)
+    assert_same(res, ref, share_tol=1e-9)
+    _same_groups(snap, res, ref)

@@ -414,6 +414,18 @@ def test_gpu_fraction_fuzz(gpu, seed):
         _same_groups(snap, res, ref)
 
 
+@pytest.mark.parametrize("seed,ci", ((5592, 5), (8881176, 5)))
+def test_gpu_victim_tasks_keep_their_eviction_order(gpu, seed, ci):
+    """The two campaign cycles with fractions under allocate + consolidation + reclaim + preempt that differed from the oracle in rounds 1-2
+    (tests/test_engine_hostsim.py::test_hostsim_victim_tasks_keep_their_eviction_order has the story)."""
+    from test_engine_hostsim import _same_groups, fraction_campaign_case
+    snap, cfg, acts = fraction_campaign_case(seed, ci)
+    ref = T.Oracle.run(snap, cfg, acts)
+    res = run_gpu(snap, cfg, acts)
+    assert_same_tol(res, ref)
+    _same_groups(snap, res, ref)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_gpu_gpu_memory_fuzz(gpu, seed):
     """Requests for MiB of one device (ABI v5 pod_gpu_memory) beside fractions and whole GPUs on the device: the memory they take on a shared GPU, their
