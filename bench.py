@@ -175,6 +175,18 @@ def main():
         "roofline": roof,
     }
 
+    if rank == 0 and actions == ("allocate",):
+        # end-to-end pin: SHA-256 of this run's committed operations against the oracle's full-size run of the same workload (tools/pin_full_sizes.py wrote
+        # profiles/full_size_pins.json on the CPU: oracle vs host-compiled engine, every operation / pod / node / share equal)
+        import kai_testlib as T
+        sha = T.ops_sha256(first_ops); pin = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "full_size_pins.json")) as f:
+                pin = next((v for v in json.load(f).values() if v["workload"] == desc and v["nodes"] == N and v["pods"] == snap.n_pods), None)
+        except (OSError, ValueError, KeyError):
+            pin = None
+        out["parity_full"] = {"ops": len(first_ops), "ops_sha256": sha, "oracle_ops_sha256": pin["ops_sha256"] if pin else None, "equal_to_oracle": (sha == pin["ops_sha256"]) if pin else None,
+                              "oracle_pin": "profiles/full_size_pins.json (oracle end to end on the CPU, %s s)" % pin["oracle_s"] if pin else "no pin on file for this workload"}
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         import kai_testlib as T
         # (1) contract baseline: the oracle (faithful single-thread restatement of the reference path) on a bounded sample of the SAME snapshot:

@@ -94,6 +94,23 @@ class Result:
         self.__dict__.update(kw)
 
 
+def ops_sha256(ops):
+    """SHA-256 of a committed operation stream [(kind, pod, node, job), ...] as little-endian int32 quadruples in commit order — what profiles/full_size_pins.json
+    holds for the oracle's full-size runs (tools/pin_full_sizes.py) and bench.py prints for the MI355X's."""
+    import hashlib
+    return hashlib.sha256(np.asarray([tuple(o)[:4] for o in ops], dtype="<i4").reshape(-1, 4).tobytes()).hexdigest()
+
+
+def state_sha256(res):
+    """SHA-256 of the final pod statuses and nodes plus the node accounting and the final queue shares of a result."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(res.pod_status, dtype="<i4").tobytes()); h.update(np.ascontiguousarray(res.pod_node, dtype="<i4").tobytes())
+    for k in ("idle", "releasing", "used"): h.update(np.ascontiguousarray(res.nodes[k], dtype="<f8").tobytes())
+    for k in ("fair_share", "allocated", "allocated_non_preemptible", "request"): h.update(np.ascontiguousarray(res.shares_final[k], dtype="<f8").tobytes())
+    return h.hexdigest()
+
+
 def shares_to_np(sh, Q):
     out = {}
     for f in ("fair_share", "allocated", "allocated_non_preemptible", "request", "deserved", "max_allowed"):

@@ -301,6 +301,49 @@ def test_static_predicate_classes():
     assert s2.n_pod_classes == 1 and s2.n_node_classes == 3  # untainted / dedicated:NoSchedule / down:NoExecute
 
 
+# The reference's own (pod constraint, node) cases for the NodeAffinity Filter of k8s.io/kubernetes v1.34.2 (absent from /root/reference): the ten rows of
+# accumulated_scenario_filters/node_affinities/node_affinities_test.go:248-400 (TestNodeAffinitiesFilter_Filter), transcribed by hand:
+# (name, all nodes {name: labels}, feasible node names, pending pod specs, victim node names, wantFilterResult)
+_SEL = lambda v: {"nodeSelector": {"gpu-type": v}}
+_AFF = lambda k, v: {"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [{"matchExpressions": [{"key": k, "operator": "In", "values": [v]}]}]}}}}
+_FIELD = lambda n: {"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [{"matchFields": [{"key": "metadata.name", "operator": "In", "values": [n]}]}]}}}}
+_PREF = lambda k, v, w: {"affinity": {"nodeAffinity": {"preferredDuringSchedulingIgnoredDuringExecution": [{"weight": w, "preference": {"matchExpressions": [{"key": k, "operator": "In", "values": [v]}]}}]}}}
+_A, _V = {"node-a100": {"gpu-type": "A100"}}, {"node-v100": {"gpu-type": "V100"}}
+NODE_AFFINITY_FILTER_CASES = [
+    ("pending pod matches node selector - filter passes", _A, ["node-a100"], [_SEL("A100")], [], True),
+    ("pending pod node selector has no matching node - filter fails", _V, ["node-v100"], [_SEL("A100")], [], False),
+    ("pending pod with NodeAffinity matches node - filter passes", _A, ["node-a100"], [_AFF("gpu-type", "A100")], [], True),
+    ("mixed pending pods: affinity pod matches, pod without affinity is skipped - filter passes", _A, ["node-a100"], [_SEL("A100"), {}], [], True),
+    ("mixed pending pods: affinity pod has no matching node - filter fails", _V, ["node-v100"], [_SEL("A100"), {}], [], False),
+    ("victim running on matching node expands feasible set - filter passes", dict(_A, **_V), ["node-v100"], [_SEL("A100")], ["node-a100"], True),
+    ("MatchFields targets node that exists in cluster but is not feasible - filter passes", {"node-specific": {}, "node-other": {}}, ["node-other"], [_FIELD("node-specific")], [], True),
+    ("MatchFields targets node absent from the cluster - filter fails", {"node-other": {}}, ["node-other"], [_FIELD("node-specific")], [], False),
+    ("victim on non-matching node does not satisfy affinity - filter fails", dict(_A, **_V), ["node-v100"], [_SEL("A100")], ["node-v100"], False),
+    ("mixed pending pods: required affinity matches, preferred-only pod present - filter passes", _A, ["node-a100"], [_AFF("gpu-type", "A100"), _PREF("gpu-type", "A100", 100)], [], True),
+]
+
+
+@pytest.mark.parametrize("name,all_nodes,feasible,pending,victim_nodes,want", NODE_AFFINITY_FILTER_CASES, ids=[c[0][:60] for c in NODE_AFFINITY_FILTER_CASES])
+def test_static_predicate_matcher_on_reference_node_affinity_cases(name, all_nodes, feasible, pending, victim_nodes, want):
+    """n4 pinned on the reference: the compiled class_fit table (NodeAffinity Filter semantics restated in kai_ingest.cpp) must give the reference's expectation
+    in each of its ten AccumulatedNodeAffinities cases.  The filter itself is restated here over the table as the reference wires it
+    (node_affinities.go:83-176): victims' nodes join the feasible set; a pod with a nodeSelector or required terms needs ONE node that passes the Filter among
+    the PreFilter's node names (terms of matchFields metadata.name In [...] only) looked up in the WHOLE cluster, else among the feasible nodes."""
+    s = ingest(doc(nodes=[node(n, labels=l) for n, l in all_nodes.items()], pods=[pod("p%d" % i, spec=sp) for i, sp in enumerate(pending)])).snapshot
+    names = list(s.node_names); idx = {n: k for k, n in enumerate(names)}
+    feas = set(feasible) | {n for n in victim_nodes if n in idx}
+    ok = True
+    for i, sp in enumerate(pending):
+        req = (sp.get("affinity", {}).get("nodeAffinity", {}) or {}).get("requiredDuringSchedulingIgnoredDuringExecution")
+        if "nodeSelector" not in sp and req is None: continue  # hasRequiredNodeAffinity :124-135
+        terms = (req or {}).get("nodeSelectorTerms", [])
+        field_only = bool(terms) and all(t.get("matchFields") and not t.get("matchExpressions") and all(f["key"] == "metadata.name" and f["operator"] == "In" for f in t["matchFields"]) for t in terms)
+        cand = {v for t in terms for f in t["matchFields"] for v in f["values"]} if field_only else feas  # NodeAffinity.PreFilter's NodeNames
+        pi = [k for k, n in enumerate(s.pod_names) if n.endswith("/p%d" % i)][0]
+        if not any(n in idx and s.class_fit[s.pod_class[pi], s.node_class[idx[n]]] for n in cand): ok = False
+    assert ok == want, name
+
+
 def test_fallback_flags_and_config_maps():
     """SURVEY §8b fallback rule + k8s_internal/predicates/config_maps.go (a missing non-optional config map fits no node)."""
     cm_vol = {"volumes": [{"name": "v", "configMap": {"name": "cm1"}}], "containers": [{"name": "c", "volumeMounts": [{"name": "v"}], "resources": {}}]}
