@@ -562,7 +562,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
             (long long)bs.rounds, (long long)bs.mismatches, (long long)bs.planned, bs.max_h, (long long)bs.fill_cycles, (long long)bs.fill_load, (long long)bs.fill_update, (long long)bs.fill_rescan,
             (long long)bs.block_loads, (long long)bs.rescans1, (long long)bs.rescans2, (long long)bs.rescans3, core->batch_plan_ms, core->batch_fill_ms, core->batch_apply_ms);
     } else { core->stats.reserved[4] = 0; core->stats.reserved[5] = st.prof[2]; core->stats.reserved[6] = st.prof[3]; core->stats.reserved[7] = st.prof[7]; }
-    if (std::getenv("KAI_PROF")) { std::fprintf(stderr, "kai prof:"); for (int i = 0; i < 24; i++) std::fprintf(stderr, " %lld", (long long)st.prof[i]); std::fprintf(stderr, "\n"); }
+    if (std::getenv("KAI_PROF")) { std::fprintf(stderr, "kai prof:"); for (int i = 0; i < KAI_NPROF; i++) std::fprintf(stderr, " %lld", (long long)st.prof[i]); std::fprintf(stderr, "\n"); }
     if (st.non_allocate_commits) c.fast_ok = 0;  // the staged job path assumes nothing releasing / pipelined in the session (kai_host_prep.hpp); until the next open / reset
     if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d (engine source line %d)", st.fault, st.fault_line); core->err = buf; return KAI_ERR_DEVICE_FAULT; }
     *n_ops = st.out_len;

@@ -147,6 +147,7 @@ inline JobPf& kai_pf_host() { static thread_local JobPf f; return f; }
 #define KAI_JOBPF kai_pf_host()
 #endif
 
+constexpr int KAI_NPROF = 40;
 struct EngineState {  // mutable scalars of the running action
     int32_t ops_len, n_undo;
     int32_t fault;            // != 0: engine gave up (see FAULT_*)
@@ -157,12 +158,24 @@ struct EngineState {  // mutable scalars of the running action
     int64_t index_queries, index_refreshes, drained_jobs, drained_decisions;
     int64_t scenarios, simulations, scenarios_filtered;  // victim search (actions/common/solvers)
     int64_t non_allocate_commits;  // evictions / pipelines committed by this action: from then on something is releasing or pipelined in the session
-    int64_t prof[24];         // control-lane cycles per phase, see PF_* (16..23: victim search, -DKAI_PROF_VICTIM)
+    int64_t prof[KAI_NPROF];  // control-lane cycles per phase, see PF_* (16..39: victim search, -DKAI_PROF_VICTIM)
     double total[3];          // proportion totalResource (CPU, Memory, GPU)
 };
 enum { PF_POP = 0, PF_ALLOC = 2, PF_FINISH = 3, PF_DRAINCHK = 4, PF_INIT = 5, PF_TOTAL = 7, PF_TTA = 8, PF_GATE = 9, PF_TASKCAP = 10, PF_FIND = 11,
        PF_REFRESH = 12, PF_STMT = 13, PF_ROLLBACK = 14, PF_PUSH = 15 };
 enum { FAULT_NONE = 0, FAULT_OPS_CAP = 1, FAULT_OUT_CAP = 2, FAULT_HEAP = 3, FAULT_INTERNAL = 4, FAULT_SPIN = 5 };
+
+// Victim search on several workgroups (kai_engine_solver.inc solve_partial_multi): every workgroup runs the SAME control flow on its own replica of the session
+// state (KaiCtx pointers rebased into the replica); the simulations of one partial job are dealt out to them in waves, and this block — the only memory they share —
+// carries each wave's outcomes and the grid barrier.  One instance per victim action, zeroed by the host before the launch.
+constexpr int KAI_MW_MAX = 256;   // workgroups of one victim action at most (one per compute unit)
+constexpr int KAI_MW_CNT = 8;     // counter deltas a simulation reports (see Engine::mw_counters)
+struct MultiCtx {
+    int32_t world, fault, bar_count, bar_gen;
+    int32_t res[2][KAI_MW_MAX];                 // per wave (double buffered) and rank: SIM_* status | MW_TOUCHED_PREEMPTOR
+    int64_t cnt[2][KAI_MW_MAX][KAI_MW_CNT];     // … and the counters that simulation bumped
+    int64_t waves, sims_run, sims_used, replays;  // diagnostics (rank 0 writes)
+};
 
 // Scratch of the victim search (reclaim / preempt / consolidation, kai_engine_solver.inc), all in HBM.  "View" of a victim job =
 // its pods that are not yet taken into a task group of the scenario (and, once the builder met a recorded victim of the job, not
@@ -180,6 +193,9 @@ struct SolverCtx {
     QNode* i_qn[2]; int32_t *i_qheap[2], *i_root[2], *i_cur[2], *i_end[2], *i_side[2], *i_side_len[2];  // [Q], [Q+1], [Q+1], [Q], [Q], [J], [Q]
     double* vq_pop;                                   // [Q][3] Σ Allocated of the jobs popped from a leaf (poppedJobsByQueue, job_order_by_queue.go:80-82)
     int32_t* s_ov_min;                                // [S] minAvailable of the partial preemptor representative (job_solver.go:128-151)
+    int32_t *mw_end, *mw_filt;                        // [P+J+2] scenarios the builder has produced for the running partial job: group count of scenario k, scenarios the filters dropped before it
+    uint32_t* mw_feas; int32_t *mw_nstamp, *mw_nmaxk, *mw_wk, *mw_wn, *mw_ctr;  // [W+1] feasible nodes a wave starts from; [N+1] x 2 per node: wave stamp and the last scenario of the wave's consumed simulations on it; [KAI_MW_MAX] x 2 the wave's simulations
+    int32_t *mw_sj, *mw_sv, *mw_sn, *mw_stta; double* mw_sres;  // [J+1] x 3, [P+1], [4(J+1)]: tasks-to-allocate caches of the jobs a speculative simulation touches, saved aside
     int32_t *grp_job, *grp_off, *grp_pods, *grp_ord;  // task groups of the scenario: recorded first, then potential in the order they were added; grp_pods = a group's pods in canonical order
                                                       // (what ranging the representative's pod map stands for), grp_ord = in the order they were handed over (VictimInfo.Tasks, potentialVictimsTasks: slices)
     int32_t *rec_job, *rec_off, *rec_pods;            // recorded victim jobs handed to the next partial job (result.victimJobs)
@@ -208,6 +224,8 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     add(sizeof(double) * 3 * Q); add(sizeof(int32_t) * (S + 1));
     for (int i = 0; i < 2; i++) { add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); }
     add(sizeof(int32_t) * (P + 1));  // grp_ord
+    add(sizeof(int32_t) * ((size_t)P + J + 2)); add(sizeof(int32_t) * ((size_t)P + J + 2)); for (int i = 0; i < 3; i++) add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (P + 1)); add(sizeof(double) * 4 * (J + 1));  // mw_*
+    add(sizeof(uint32_t) * (W + 1)); add(sizeof(int32_t) * (N + 1)); add(sizeof(int32_t) * (N + 1)); add(sizeof(int32_t) * KAI_MW_MAX); add(sizeof(int32_t) * KAI_MW_MAX); add(sizeof(int32_t) * 4);
     for (int i = 0; i < 7; i++) add(sizeof(int32_t) * (P + 1));
     add(sizeof(uint32_t) * (W + 1)); add(sizeof(uint32_t) * (W + 1));
     add(sizeof(double) * (N + 1)); add(sizeof(int32_t) * (P + 1));
@@ -233,6 +251,9 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     }
     v.vq_pop = (double*)take(sizeof(double) * 3 * Q); v.s_ov_min = (int32_t*)take(sizeof(int32_t) * (S + 1));
     v.grp_job = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.grp_off = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.grp_pods = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.grp_ord = (int32_t*)take(sizeof(int32_t) * (P + 1));
+    v.mw_end = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 2)); v.mw_filt = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 2)); v.mw_sj = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.mw_sv = (int32_t*)take(sizeof(int32_t) * (J + 1));
+    v.mw_sn = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.mw_stta = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.mw_sres = (double*)take(sizeof(double) * 4 * (J + 1));
+    v.mw_feas = (uint32_t*)take(sizeof(uint32_t) * (W + 1)); v.mw_nstamp = (int32_t*)take(sizeof(int32_t) * (N + 1)); v.mw_nmaxk = (int32_t*)take(sizeof(int32_t) * (N + 1)); v.mw_wk = (int32_t*)take(sizeof(int32_t) * KAI_MW_MAX); v.mw_wn = (int32_t*)take(sizeof(int32_t) * KAI_MW_MAX); v.mw_ctr = (int32_t*)take(sizeof(int32_t) * 4);
     v.rec_job = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.rec_off = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.rec_pods = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.res_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.ev_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vt_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.pend = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.tmp = (int32_t*)take(sizeof(int32_t) * (P + 1));
@@ -335,6 +356,7 @@ struct KaiCtx {
     KAI_GP(int32_t) next_new_group;       // [1] uuid.NewUUID() of findGpuForSharingOnNode
     int32_t shared_on, pad_sh;
 #endif
+    MultiCtx* mw; int32_t mw_rank, mw_world;  // victim search on several workgroups: the block they share (null / world 1 = one workgroup), this replica's rank
     int32_t exact_sums, pad_es;  // HostPrep::exact_sums: integral quantities with totals below 2^52 units — parallel sums of them are exact
 };
 
@@ -391,7 +413,8 @@ KAI_HD bool fits(const KaiCtx& c, const double* req, int n, bool with_releasing)
 // written, whatever its value; a slot is that entry for the three maps together (ng_has_alloc tells whether AllocatedSharedGPUsMemory has
 // the key).  Maps are ranged in ascending group id (the oracle's canonical order).
 // ------------------------------------------------------------------------------------------------------
-constexpr int KAI_GMAX = 16;
+constexpr int KAI_GMAX = 32;  // (the slot masks ng_mark / ng_has_alloc are 32 bits; 16 slots overflowed once in 6·10^5 campaign cycles: entries that rolled-back simulations leave
+                              // booked — the reference's own residue, gpu_sharing_node_info.go:102-105 — cannot be taken over)
 constexpr int KAI_NEW_GROUP = 1 << 20;  // ids from here on: non-numeric group names (UUIDs) — "new" for predicates.go:320-330
 constexpr int KAI_WHOLE_GPU = -1;       // pod_info.WholeGpuIndicator
 struct SgNode {
@@ -724,7 +747,7 @@ KAI_HD int stage_job_lane(const KaiCtx& c, int j, FastFrame& f, JobPf& out, int 
 // global read-modify-write each otherwise) and written to EngineState once, when the action ends.
 struct EngineHot {
     int64_t decisions, index_queries, index_refreshes, rollbacks, jobs_attempted, jobs_committed, out_len, stmts;
-    int64_t prof[24];
+    int64_t prof[KAI_NPROF];
 };
 struct EngineLocal {
     EngineHot h;
@@ -2178,13 +2201,13 @@ struct Engine {
         EngineHot& h = el().h; const EngineState& st = *cx().st;
         h.decisions = st.decisions; h.index_queries = st.index_queries; h.index_refreshes = st.index_refreshes; h.rollbacks = st.rollbacks;
         h.jobs_attempted = st.jobs_attempted; h.jobs_committed = st.jobs_committed; h.out_len = st.out_len; h.stmts = st.stmts;
-        for (int i = 0; i < 24; i++) h.prof[i] = st.prof[i];
+        for (int i = 0; i < KAI_NPROF; i++) h.prof[i] = st.prof[i];
     }
     KAI_HD void hot_end() {
         const EngineHot& h = el().h; EngineState& st = *cx().st;
         st.decisions = h.decisions; st.index_queries = h.index_queries; st.index_refreshes = h.index_refreshes; st.rollbacks = h.rollbacks;
         st.jobs_attempted = h.jobs_attempted; st.jobs_committed = h.jobs_committed; st.out_len = h.out_len; st.stmts = h.stmts;
-        for (int i = 0; i < 24; i++) st.prof[i] = h.prof[i];
+        for (int i = 0; i < KAI_NPROF; i++) st.prof[i] = h.prof[i];
     }
     KAI_HD void execute_allocate() { hot_begin(); execute_allocate_impl(); hot_end(); }
     KAI_HD void execute_allocate_impl() {  // actions/allocate/allocate.go:46-77

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../kai-scheduler_amd/csrc/kai_host_prep.hpp"
@@ -97,7 +98,23 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     }
     bool staged(int j) { bool r = KAI_JOBPF.job == j && KAI_JOBPF.ok; KAI_JOBPF.job = -1; return r; }
     void hot(const KaiCtx& c, QNode*& qn, int32_t*& qheap, int32_t*& root_heap) { qn = c.qn; qheap = c.qheap; root_heap = c.root_heap; }
-    int64_t clock() { return 0; }
+    // several engines of one victim action (MultiCtx): here they are threads of this process
+    static void mw_store32(int32_t* p, int32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+    static int32_t mw_load32(const int32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+    static void mw_store64(int64_t* p, int64_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+    static int64_t mw_load64(const int64_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+    static void grid_sync(MultiCtx* m) {
+        const int gen = __atomic_load_n(&m->bar_gen, __ATOMIC_ACQUIRE);
+        if (__atomic_add_fetch(&m->bar_count, 1, __ATOMIC_ACQ_REL) == m->world) { __atomic_store_n(&m->bar_count, 0, __ATOMIC_RELAXED); __atomic_add_fetch(&m->bar_gen, 1, __ATOMIC_RELEASE); }
+        else { long spins = 0; while (__atomic_load_n(&m->bar_gen, __ATOMIC_ACQUIRE) == gen) { if (++spins > 64) std::this_thread::yield(); if (spins > 400000000L) { __atomic_store_n(&m->fault, 1, __ATOMIC_RELEASE); break; } } }
+    }
+    int64_t clock() {
+#if defined(KAI_PROF_VICTIM) && defined(__x86_64__)
+        return (int64_t)__builtin_ia32_rdtsc();  // phase clocks of the host-compiled engine (debug builds only)
+#else
+        return 0;
+#endif
+    }
 };
 
 // the batch path's kernels on the lock-step emulator (kai_simt.hpp)
@@ -143,6 +160,9 @@ template <class T> const T* copy(std::vector<std::vector<char>>& pool, const T* 
 static int g_sh_rank = 0, g_sh_world = 1, g_sh_k = 0; static int (*g_sh_fn)(void*, const void*, void*, int64_t) = nullptr; static void* g_sh_user = nullptr; static int64_t g_sh_exchanges = 0;
 extern "C" void kai_hostsim_set_shard(int rank, int world, int k, int (*fn)(void*, const void*, void*, int64_t), void* user) { g_sh_rank = rank; g_sh_world = world; g_sh_k = k; g_sh_fn = fn; g_sh_user = user; }
 extern "C" int64_t kai_hostsim_last_exchanges() { return g_sh_exchanges; }
+static int g_mw_world = 1; static int64_t g_mw_waves = 0, g_mw_sims_run = 0, g_mw_sims_used = 0, g_mw_replays = 0;
+extern "C" void kai_hostsim_set_multi(int engines) { g_mw_world = engines < 1 ? 1 : engines > KAI_MW_MAX ? KAI_MW_MAX : engines; g_mw_waves = g_mw_sims_run = g_mw_sims_used = g_mw_replays = 0; }  // victim actions of the next runs on that many engines
+extern "C" void kai_hostsim_multi_stats(int64_t* out) { out[0] = g_mw_waves; out[1] = g_mw_sims_run; out[2] = g_mw_sims_used; out[3] = g_mw_replays; }
 static std::vector<int32_t> g_last_groups;  // PodInfo.GPUGroups[0] of the active fraction pods after the last run
 extern "C" int kai_hostsim_last_gpu_groups(int32_t* out, int cap) { int n = (int)g_last_groups.size(); for (int i = 0; i < n && i < cap; i++) out[i] = g_last_groups[i]; return n; }
 extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s, const int* actions, int n_actions,
@@ -150,6 +170,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
                                kai_queue_share* shares_open, kai_queue_share* shares_final, kai_node_state* nodes_out,
                                kai_action_stats* stats, double* elapsed_ms_out) {
     if (!cfg || !s || s->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
+    if (const char* e = std::getenv("KAI_HOSTSIM_MW")) { const int v = std::atoi(e); if (v > 0) g_mw_world = v > KAI_MW_MAX ? KAI_MW_MAX : v; }
     SharedPods sp;  // shared GPUs in the engine: one GPU memory size for the whole cluster (the queue-capacity step stays node independent)
     if (!sp.build(*cfg, s)) return KAI_ERR_UNSUPPORTED;
     const bool shared = sp.any;
@@ -160,6 +181,8 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
         if (s->pod_flags && (s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
     KaiCtx c{};
+    // every array of the context (part 1: what the session-open math below works on); a lambda so that further engines of a victim action get replicas of identical layout
+    auto alloc1 = [&](std::vector<std::vector<char>>& pool, KaiCtx& c) {
     c.N = N; c.P = P; c.S = S; c.J = J; c.Q = Q; c.R = R; c.n_pod_classes = std::max(1, s->n_pod_classes); c.n_node_classes = std::max(1, s->n_node_classes);
     c.plugins = cfg->plugins; c.gpu_strategy = cfg->gpu_strategy; c.cpu_strategy = cfg->cpu_strategy; c.restrict_nodes = cfg->restrict_node_scheduling;
     c.k_value = cfg->k_value <= 0.0 ? 0.0 : cfg->k_value;
@@ -223,6 +246,8 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.ops_cap = 4 * P + 64; c.ops = own<StmtOp>(pool, c.ops_cap); c.out_cap = ((int64_t)2 * P + 64) * (n_actions > 0 ? n_actions : 1); c.out_ops = own<kai_op>(pool, c.out_cap);  // the library gives every action its own 2P + 64; this harness keeps one list for the whole cycle
     c.scratch = own<int32_t>(pool, (size_t)P + 64); c.st = own<EngineState>(pool, 1);
     c.q_share = const_cast<QShare*>(copy(pool, prep.shares.data(), prep.shares.size()));
+    };
+    alloc1(pool, c);
     auto t0 = std::chrono::steady_clock::now();
 
     // ---- serial twins of the session-open kernels (kai_kernels.hpp)
@@ -319,6 +344,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     };
     if (shares_open) fill(shares_open);
     if (c.use_index) for (int b = 0; b < c.NB; b++) for (int k = 0; k < c.C; k++) HostBackend::build_block(c, k, b);  // k_index_build
+    auto alloc2 = [&](std::vector<std::vector<char>>& pool, KaiCtx& c) -> int {
     c.use_signatures = cfg->use_scheduling_signatures ? 1 : 0; c.j_signature = s->job_signature ? copy(pool, s->job_signature, J) : nullptr;
     c.j_last_start = s->job_last_start_ns ? copy(pool, s->job_last_start_ns, J) : nullptr; c.q_preempt_mr = s->queue_preempt_min_runtime_ns ? copy(pool, s->queue_preempt_min_runtime_ns, Q) : nullptr;
     c.q_reclaim_mr = s->queue_reclaim_min_runtime_ns ? copy(pool, s->queue_reclaim_min_runtime_ns, Q) : nullptr;
@@ -327,6 +353,11 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     { size_t bytes = solver_scratch_bytes(N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); char* base = own<char>(pool, bytes); solver_scratch_bind(c.sv, base, N, P, S, J, Q, c.W, c.D + c.T, c.TL, c.G); for (int i = 0; i <= c.sv.xr_mask; i++) c.sv.xr_key[i] = -1; c.sv.xr_group = own<int32_t>(pool, (size_t)c.sv.xr_mask + 1); }
     if (int rc = batch_bind(c, prep, [&](size_t bytes) { return (void*)own<char>(pool, bytes); }, [&](void* d, const void* h, size_t n) { std::memcpy(d, h, n); return 0; }, g_sh_world, g_sh_rank, g_sh_k)) return rc;
     if (shared || std::getenv("KAI_HOSTSIM_NO_BATCH")) c.bt.enabled = 0;
+        return 0;
+    };
+    if (int rc = alloc2(pool, c)) return rc;
+    struct Rep { std::vector<std::vector<char>> pool; KaiCtx c{}; };
+    std::vector<Rep> reps;
     HostBackend be; Engine<HostBackend> eng(c, be);
     int64_t batch_rounds = 0, batch_actions = 0;
     for (int i = 0; i < n_actions; i++) {
@@ -341,7 +372,36 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         }
         if (std::getenv("KAI_HOSTSIM_PS")) { int ps = std::atoi(std::getenv("KAI_HOSTSIM_PS")); std::fprintf(stderr, "host_sim: before action %d podset %d active_alloc %d used %d alive %d pipelined %d\n", actions[i], ps, c.s_active_alloc[ps], c.s_active_used[ps], c.s_alive[ps], c.s_pipelined[ps]); }
         if (c.st->non_allocate_commits) c.fast_ok = 0;  // as kai_action_execute does after every action
-        if (actions[i] != KAI_ACTION_ALLOCATE) { eng.execute_victim_action(); continue; }
+        if (actions[i] != KAI_ACTION_ALLOCATE) {
+            // victim actions on several engines (kai_engine_solver.inc solve_partial_multi): every engine a thread on its own replica of the context; what must
+            // hold afterwards — every replica committed the same operations and ended in the same state — is checked here on every run
+            const int G = shared ? 1 : g_mw_world;
+            if (G <= 1) { c.mw = nullptr; c.mw_rank = 0; c.mw_world = 1; eng.execute_victim_action(); continue; }
+            if (reps.empty()) { reps.resize(G - 1); for (auto& r : reps) { alloc1(r.pool, r.c); if (int rc = alloc2(r.pool, r.c)) return rc; if (r.pool.size() != pool.size()) return KAI_ERR_DEVICE_FAULT; } }
+            static MultiCtx M; std::memset(&M, 0, sizeof M); M.world = G;
+            c.mw = &M; c.mw_rank = 0; c.mw_world = G;
+            for (int w = 1; w < G; w++) {
+                Rep& r = reps[w - 1];
+                for (size_t k = 0; k < pool.size(); k++) { if (r.pool[k].size() != pool[k].size()) return KAI_ERR_DEVICE_FAULT; std::memcpy(r.pool[k].data(), pool[k].data(), pool[k].size()); }
+                r.c.action = c.action; r.c.queue_depth = c.queue_depth; r.c.fast_ok = c.fast_ok; r.c.use_index = c.use_index; r.c.all_tracked = c.all_tracked; r.c.bt.enabled = 0;
+                r.c.mw = &M; r.c.mw_rank = w; r.c.mw_world = G;
+            }
+            std::vector<std::thread> th;
+            for (int w = 1; w < G; w++) th.emplace_back([&, w] { HostBackend bw; Engine<HostBackend> ew(reps[w - 1].c, bw); ew.execute_victim_action(); });
+            { HostBackend b0; Engine<HostBackend> e0(c, b0); e0.execute_victim_action(); }
+            for (auto& t : th) t.join();
+            g_mw_waves += M.waves; g_mw_sims_run += M.sims_run; g_mw_sims_used += M.sims_used; g_mw_replays += M.replays;
+            for (int w = 1; w < G; w++) {  // the engines must agree bit for bit
+                const KaiCtx& r = reps[w - 1].c;
+                bool same = r.st->out_len == c.st->out_len && r.st->fault == c.st->fault && std::memcmp(r.out_ops, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)) == 0 && std::memcmp(r.p_status, c.p_status, (size_t)P * 4) == 0 &&
+                            std::memcmp(r.p_node, c.p_node, (size_t)P * 4) == 0 && std::memcmp(r.n_idle, c.n_idle, (size_t)R * N * 8) == 0 && std::memcmp(r.n_rel, c.n_rel, (size_t)R * N * 8) == 0 &&
+                            std::memcmp(r.q_share, c.q_share, (size_t)Q * 3 * sizeof(QShare)) == 0 && std::memcmp(r.j_tta_valid, c.j_tta_valid, (size_t)J * 4) == 0 &&
+                            r.st->decisions == c.st->decisions && r.st->simulations == c.st->simulations && r.st->scenarios == c.st->scenarios && r.st->scenarios_filtered == c.st->scenarios_filtered;
+                if (!same) { if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: engine %d of %d ended in another state than engine 0 (ops %lld vs %lld, fault %d vs %d)\n", w, G, (long long)r.st->out_len, (long long)c.st->out_len, r.st->fault, c.st->fault); return KAI_ERR_DEVICE_FAULT; }
+            }
+            c.mw = nullptr; c.mw_world = 1;
+            continue;
+        }
         {   // the batch path when the action qualifies (kai_batch.hpp), else the sequential engine — as kai_action_execute does
             HostLauncher hl; BatchStats bs; hl.ag_fn = g_sh_fn; hl.ag_user = g_sh_user;
             if (int rc = batch_allocate(hl, c, prep.shape, bs, c.st->out_len, c.st->stmts)) return rc;
@@ -364,6 +424,9 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         }
     }
     if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: scenarios %lld simulations %lld filtered %lld attempted %lld committed %lld decisions %lld sim-queue pops %lld | N %d C %d NB %d NSB %d R %d plugins 0x%x\n", (long long)c.st->scenarios, (long long)c.st->simulations, (long long)c.st->scenarios_filtered, (long long)c.st->jobs_attempted, (long long)c.st->jobs_committed, (long long)c.st->decisions, (long long)c.st->prof[4], c.N, c.C, c.NB, c.NSB, c.R, (unsigned)c.plugins);
+#ifdef KAI_PROF_VICTIM
+    if (std::getenv("KAI_HOSTSIM_DEBUG")) { std::fprintf(stderr, "host_sim prof:"); for (int i = 0; i < KAI_NPROF; i++) std::fprintf(stderr, " %lld", (long long)c.st->prof[i]); std::fprintf(stderr, "\n"); }
+#endif
     auto t1 = std::chrono::steady_clock::now();
     if (elapsed_ms_out) *elapsed_ms_out = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (c.st->fault) { if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: engine fault %d at line %d\n", c.st->fault, c.st->fault_line); return KAI_ERR_DEVICE_FAULT; }

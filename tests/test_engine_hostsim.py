@@ -307,7 +307,8 @@ def test_hostsim_broad_random_cycles_with_fractions(seed):
         _same_groups(snap, res, ref)
 
 
-FRACTION_VICTIM_ORDER_SEEDS = ((5592, 5), (8881176, 5))  # tools/host_campaign.py CAMPAIGN_FRACTIONS=1: the two cycles of rounds 1-2 that differed from the oracle
+FRACTION_VICTIM_ORDER_SEEDS = ((5592, 5), (8881176, 5),  # tools/host_campaign.py CAMPAIGN_FRACTIONS=1: the two cycles of rounds 1-2 that differed from the oracle
+                               (31415658, 5))            # round 3: a node's GPU-group table (then 16 slots) overflowed on entries that rolled-back simulations leave booked
 
 
 def fraction_campaign_case(seed, ci):

@@ -414,7 +414,7 @@ def test_gpu_fraction_fuzz(gpu, seed):
         _same_groups(snap, res, ref)
 
 
-@pytest.mark.parametrize("seed,ci", ((5592, 5), (8881176, 5)))
+@pytest.mark.parametrize("seed,ci", ((5592, 5), (8881176, 5), (31415658, 5)))
 def test_gpu_victim_tasks_keep_their_eviction_order(gpu, seed, ci):
     """The two campaign cycles with fractions under allocate + consolidation + reclaim + preempt that differed from the oracle in rounds 1-2
     (tests/test_engine_hostsim.py::test_hostsim_victim_tasks_keep_their_eviction_order has the story)."""
