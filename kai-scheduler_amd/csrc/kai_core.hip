@@ -48,6 +48,10 @@ struct kai_core {
     bool shared = false; int32_t* d_group0 = nullptr; int32_t next_group0 = 0; int32_t *d_np_off = nullptr, *d_np_pods = nullptr;  // shared GPUs: initial groups, each node's active pods in UID order
     hipEvent_t bev[4] = {nullptr, nullptr, nullptr, nullptr};
     double batch_plan_ms = 0, batch_fill_ms = 0, batch_apply_ms = 0;
+    // victim actions on several workgroups (kai_engine_solver.inc solve_partial_multi): every array a KaiCtx field points to, so that each workgroup gets a replica
+    struct AllocRec { size_t field_off; char* base; size_t bytes; };
+    std::vector<AllocRec> allocs; char* sv_base = nullptr; size_t sv_bytes = 0; char* xr_base = nullptr; size_t xr_bytes = 0;
+    int mw_world = 0; char* rep_mem = nullptr; size_t rep_stride = 0; KaiCtx* d_ctxs = nullptr; MultiCtx* d_mw = nullptr; void* d_segs = nullptr; int n_segs = 0;
 };
 
 #define HIP_TRY(core, expr)                                                                                        \
@@ -99,6 +103,8 @@ int dalloc_f(kai_core* core, F& field, size_t n) {
     int rc = dalloc(core, &p, std::max<size_t>(n, 1) * sizeof(*field));
     if (rc) return rc;
     field = (F)p;
+    { const char* fp = reinterpret_cast<const char*>(&field); const char* c0 = reinterpret_cast<const char*>(&core->ctx);  // a field of the session context: its array is part of every replica
+      if (fp >= c0 && fp + sizeof(void*) <= c0 + sizeof(KaiCtx)) core->allocs.push_back({(size_t)(fp - c0), p, std::max<size_t>(n, 1) * sizeof(*field)}); }
     return KAI_OK;
 }
 template <class F>
@@ -119,6 +125,7 @@ int dupload_f(kai_core* core, F& field, const T* host, size_t n) {
 void free_session(kai_core* core) {
     for (void* p : core->bufs) (void)hipFree(p);
     core->bufs.clear(); core->slab = nullptr; core->slab_left = 0;
+    core->allocs.clear(); core->sv_base = nullptr; core->xr_base = nullptr; core->mw_world = 0; core->rep_mem = nullptr; core->d_ctxs = nullptr; core->d_mw = nullptr; core->d_segs = nullptr;
     core->open = false;
 }
 int fail(kai_core* core, int code, const char* msg) { core->err = msg; return code; }
@@ -202,6 +209,60 @@ struct DevLauncher {
     }
     int write(void* dst, const void* src, size_t n) { return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, core->stream) == hipSuccess ? KAI_OK : KAI_ERR_HIP; }
 };
+// ---- victim actions on several workgroups: replicas of the session arrays, one per further workgroup
+struct RepSeg { const char* src; unsigned long long dst_off, bytes; };
+constexpr size_t REP_CHUNK = (size_t)256 << 10;
+__global__ void __launch_bounds__(256) k_replicate(const RepSeg* segs, char* rep_mem, unsigned long long stride) {
+    const RepSeg sg = segs[blockIdx.x];
+    const uint4* s = reinterpret_cast<const uint4*>(sg.src); uint4* d = reinterpret_cast<uint4*>(rep_mem + (size_t)blockIdx.y * stride + sg.dst_off);
+    const size_t n16 = (size_t)sg.bytes / 16;  // (every allocation is a multiple of 256 bytes)
+    for (size_t i = threadIdx.x; i < n16; i += blockDim.x) d[i] = s[i];
+}
+// Builds (first call of a session) and refreshes (every call) the replicas for a victim action on `G` workgroups; G <= 1 or no memory: one workgroup.
+int prepare_multi(kai_core* core, int G, int* g_out) {
+    *g_out = 1;
+    KaiCtx& c = core->ctx;
+    c.mw = nullptr; c.mw_rank = 0; c.mw_world = 1;
+    if (G <= 1 || core->shared || !core->sv_base) return KAI_OK;  // (with shared GPUs a rolled-back simulation is observable on its node: the simulations of a partial job are not independent)
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    if (core->mw_world != G) {  // the layout of a replica: the registered arrays, the solver's scratch, the shared-GPU residency groups
+        if (core->mw_world != 0) return KAI_OK;  // (replicas of another width exist already: keep to one workgroup rather than rebuild)
+        size_t total = 0; std::vector<RepSeg> segs;
+        auto add = [&](const char* src, size_t bytes) { bytes = up(bytes); for (size_t o = 0; o < bytes; o += REP_CHUNK) segs.push_back({src + o, (unsigned long long)(total + o), (unsigned long long)std::min(REP_CHUNK, bytes - o)}); total += bytes; };
+        for (const auto& a : core->allocs) add(a.base, a.bytes);
+        add(core->sv_base, core->sv_bytes); add(core->xr_base, core->xr_bytes);
+        void* mem = nullptr;
+        if (hipMalloc(&mem, total * (size_t)(G - 1)) != hipSuccess) { (void)hipGetLastError(); return KAI_OK; }
+        core->bufs.push_back(mem); core->rep_mem = static_cast<char*>(mem); core->rep_stride = total;
+        RepSeg* dsegs = nullptr; KaiCtx* dctx = nullptr; MultiCtx* dmw = nullptr;
+        int rc = dalloc(core, &dsegs, segs.size()); if (rc) return rc;
+        rc = dalloc(core, &dctx, (size_t)G); if (rc) return rc;
+        rc = dalloc(core, &dmw, (size_t)1); if (rc) return rc;
+        HIP_TRY(core, hipMemcpyAsync(dsegs, segs.data(), segs.size() * sizeof(RepSeg), hipMemcpyHostToDevice, core->stream));
+        HIP_TRY(core, hipStreamSynchronize(core->stream));  // segs dies with this scope
+        core->d_segs = dsegs; core->n_segs = (int)segs.size(); core->d_ctxs = dctx; core->d_mw = dmw; core->mw_world = G;
+    }
+    // this action's contexts: replica w = the session's context with every array pointer moved into replica w's memory
+    std::vector<KaiCtx> ctxs((size_t)G, c);
+    for (int w = 0; w < G; w++) {
+        KaiCtx& cw = ctxs[w];
+        cw.mw = core->d_mw; cw.mw_rank = w; cw.mw_world = G;
+        if (w == 0) continue;
+        char* rb = core->rep_mem + (size_t)(w - 1) * core->rep_stride; size_t off = 0;
+        for (const auto& a : core->allocs) { *reinterpret_cast<char**>(reinterpret_cast<char*>(&cw) + a.field_off) = rb + off; off += up(a.bytes); }
+        solver_scratch_bind(cw.sv, rb + off, c.N, c.P, c.S, c.J, c.Q, c.W, c.D + c.T, c.TL, c.G); off += up(core->sv_bytes);
+        cw.sv.xr_group = reinterpret_cast<int32_t*>(rb + off); off += up(core->xr_bytes);
+        cw.bt.enabled = 0;  // (the batch path's pools are not replicated; a victim action never reads them)
+    }
+    HIP_TRY(core, hipMemcpyAsync(core->d_ctxs, ctxs.data(), (size_t)G * sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
+    MultiCtx m0{}; m0.world = G;
+    HIP_TRY(core, hipMemcpyAsync(core->d_mw, &m0, sizeof(MultiCtx), hipMemcpyHostToDevice, core->stream));
+    hipLaunchKernelGGL(k_replicate, dim3(core->n_segs, G - 1), dim3(256), 0, core->stream, (const RepSeg*)core->d_segs, core->rep_mem, (unsigned long long)core->rep_stride);
+    HIP_TRY(core, hipGetLastError());
+    HIP_TRY(core, hipStreamSynchronize(core->stream));  // ctxs / m0 die with this scope
+    *g_out = G;
+    return KAI_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -495,8 +556,9 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         int rc0 = dalloc(core, &base, bytes); if (rc0) return rc0;
         HIP_TRY(core, hipMemsetAsync(base, 0, bytes, core->stream));
         solver_scratch_bind(c.sv, base, c.N, c.P, c.S, c.J, c.Q, c.W, c.D + c.T, c.TL, c.G);
+        core->sv_base = base; core->sv_bytes = bytes;
         HIP_TRY(core, hipMemsetAsync(c.sv.xr_key, 0xFF, sizeof(int64_t) * ((size_t)c.sv.xr_mask + 1), core->stream));  // empty residency table
-        { int32_t* xg = nullptr; int rcx = dalloc(core, &xg, (size_t)c.sv.xr_mask + 1); if (rcx) return rcx; c.sv.xr_group = xg; }
+        { int32_t* xg = nullptr; int rcx = dalloc(core, &xg, (size_t)c.sv.xr_mask + 1); if (rcx) return rcx; c.sv.xr_group = xg; core->xr_base = (char*)xg; core->xr_bytes = ((size_t)c.sv.xr_mask + 1) * 4; }
         core->solver_ready = true;
     }
     { int d = core->cfg.queue_depth[action]; c.queue_depth = d > 0 ? d : 0; c.action = action; }
@@ -512,7 +574,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     const int TB = 256;
     if (c.J) hipLaunchKernelGGL(k_job_init, dim3((c.J + TB - 1) / TB), dim3(TB), 0, core->stream, c);
     if (c.Q) hipLaunchKernelGGL(k_leaf_init, dim3((c.Q + 3) / 4), dim3(TB), 0, core->stream, c);
-    BatchStats bs; core->batch_plan_ms = core->batch_fill_ms = core->batch_apply_ms = 0;
+    BatchStats bs; core->batch_plan_ms = core->batch_fill_ms = core->batch_apply_ms = 0; int g_run = 1;
     if (!victim) {  // the batch path (plan / fill / apply rounds, kai_batch.hpp) when the action qualifies
         DevLauncher dl{core};
         int rcb = batch_allocate(dl, c, core->shape, bs);
@@ -532,9 +594,16 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         const size_t budget = 160 * 1024 - 16384;  // static LDS of the kernel (mailbox, context, engine scalars, frame: 6.8 KB, llvm-readelf .group_segment_fixed_size) + margin
         int tree_in_lds = (idx_b + tree_b <= budget && !std::getenv("KAI_TREE_IN_HBM")) ? 1 : 0;
         size_t dyn = idx_b + (tree_in_lds ? tree_b : 0);
+        // a victim action runs on several workgroups, each on a replica of the session arrays made right here (after k_job_init / k_leaf_init on the stream)
+        if (victim) {
+            int want = 64; if (const char* e = std::getenv("KAI_VICTIM_WGS")) want = std::atoi(e);
+            int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, core->device) != hipSuccess || cus <= 0) cus = 64;
+            want = std::max(1, std::min(std::min(want, (int)KAI_MW_MAX), cus));  // every workgroup must be resident: they meet at a grid barrier
+            int rcm = prepare_multi(core, want, &g_run); if (rcm) return rcm;
+        }
         auto launch = [&](auto kernel) -> int {
             HIP_TRY(core, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(kernel, dim3(1), dim3(WG), dyn, core->stream, (const KaiCtx*)core->d_ctx, action, tree_in_lds);
+            hipLaunchKernelGGL(kernel, dim3(g_run), dim3(WG), dyn, core->stream, g_run > 1 ? (const KaiCtx*)core->d_ctxs : (const KaiCtx*)core->d_ctx, action, tree_in_lds);
             return KAI_OK;
         };
         int rcl = victim ? launch(k_action<true, false>) : tree_in_lds ? launch(k_action<false, true>) : launch(k_action<false, false>);
@@ -562,6 +631,14 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
             (long long)bs.rounds, (long long)bs.mismatches, (long long)bs.planned, bs.max_h, (long long)bs.fill_cycles, (long long)bs.fill_load, (long long)bs.fill_update, (long long)bs.fill_rescan,
             (long long)bs.block_loads, (long long)bs.rescans1, (long long)bs.rescans2, (long long)bs.rescans3, core->batch_plan_ms, core->batch_fill_ms, core->batch_apply_ms);
     } else { core->stats.reserved[4] = 0; core->stats.reserved[5] = st.prof[2]; core->stats.reserved[6] = st.prof[3]; core->stats.reserved[7] = st.prof[7]; }
+    if (victim) {  // victim actions: [1] workgroups the action ran on, [5] waves, [6] simulations run (speculative ones included) << 32 | simulations the reference's order reached
+        core->stats.reserved[1] = g_run;
+        if (g_run > 1) {
+            MultiCtx m{}; HIP_TRY(core, hipMemcpyAsync(&m, core->d_mw, sizeof(MultiCtx), hipMemcpyDeviceToHost, core->stream)); HIP_TRY(core, hipStreamSynchronize(core->stream));
+            core->stats.reserved[5] = m.waves; core->stats.reserved[6] = (m.sims_run << 32) | (m.sims_used & 0xffffffffll);
+            if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai victim: %d workgroups, waves %lld, simulations run %lld / counted %lld, replays %lld, fault %d\n", g_run, (long long)m.waves, (long long)m.sims_run, (long long)m.sims_used, (long long)m.replays, m.fault);
+        }
+    }
     if (std::getenv("KAI_PROF")) { std::fprintf(stderr, "kai prof:"); for (int i = 0; i < KAI_NPROF; i++) std::fprintf(stderr, " %lld", (long long)st.prof[i]); std::fprintf(stderr, "\n"); }
     if (st.non_allocate_commits) c.fast_ok = 0;  // the staged job path assumes nothing releasing / pipelined in the session (kai_host_prep.hpp); until the next open / reset
     if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d (engine source line %d)", st.fault, st.fault_line); core->err = buf; return KAI_ERR_DEVICE_FAULT; }

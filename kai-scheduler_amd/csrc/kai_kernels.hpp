@@ -445,6 +445,27 @@ struct DevBackendT {
     // victim search: the job-order instance of the simulations (by far the hottest of the three) lives in the LDS tree region when it fits
     __device__ bool sim_tree(QNode*& qn, int32_t*& qheap, int32_t*& root_heap) { if (!sh->tree_in_lds) return false; qn = sh->qn; qheap = sh->qheap; root_heap = sh->root_heap; return true; }
     __device__ int64_t clock() { return (int64_t)clock64(); }
+    // several engines of one victim action (MultiCtx, kai_engine_solver.inc solve_partial_multi): one workgroup each, on its own replica; MultiCtx is the only memory
+    // they share.  Agent-scope atomics: the workgroups sit on different XCDs, whose L2s are only coherent through such accesses and the fences of the barrier.
+    __device__ static void mw_store32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static int32_t mw_load32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static void mw_store64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static int64_t mw_load64(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static void grid_sync(MultiCtx* m) {  // the control lanes of the action's workgroups (all resident: one per compute unit at most, kai_core.hip)
+        const int gen = __hip_atomic_load(&m->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        if (__hip_atomic_fetch_add(&m->bar_count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1 == m->world) {
+            __hip_atomic_store(&m->bar_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&m->bar_gen, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            long long spins = 0;
+            while (__hip_atomic_load(&m->bar_gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1ll << 27)) { __hip_atomic_store(&m->fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }  // ≈ a minute: an engine left the protocol; every engine gives up
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     __device__ void finish() {
         wait();
         // blocks still on the dirty list: bring the HBM level of the index up to date, the next action of the session starts from it
@@ -626,7 +647,7 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
 template <bool VICTIM, bool TREE_LDS>
 __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, int action, int tree_in_lds) {
     {   // the context into LDS: every pointer fetch of the engine is a ds_read the compiler can batch
-        const int* src = reinterpret_cast<const int*>(cp); int* dst = reinterpret_cast<int*>(&g_ctx);
+        const int* src = reinterpret_cast<const int*>(cp + blockIdx.x); int* dst = reinterpret_cast<int*>(&g_ctx);  // (a victim action on several workgroups: one context — one replica of the session state — each)
         for (int i = threadIdx.x; i < (int)(sizeof(KaiCtx) / 4); i += WG) dst[i] = src[i];
     }
     __syncthreads();

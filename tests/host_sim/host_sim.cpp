@@ -376,7 +376,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             // victim actions on several engines (kai_engine_solver.inc solve_partial_multi): every engine a thread on its own replica of the context; what must
             // hold afterwards — every replica committed the same operations and ended in the same state — is checked here on every run
             const int G = shared ? 1 : g_mw_world;
-            if (G <= 1) { c.mw = nullptr; c.mw_rank = 0; c.mw_world = 1; eng.execute_victim_action(); continue; }
+            if (G <= 1) { c.mw = nullptr; c.mw_rank = 0; c.mw_world = 1; if (std::getenv("KAI_HOSTSIM_FRESH")) { HostBackend bf; Engine<HostBackend> ef(c, bf); ef.execute_victim_action(); ef.flush_index(); } else eng.execute_victim_action(); continue; }
             if (reps.empty()) { reps.resize(G - 1); for (auto& r : reps) { alloc1(r.pool, r.c); if (int rc = alloc2(r.pool, r.c)) return rc; if (r.pool.size() != pool.size()) return KAI_ERR_DEVICE_FAULT; } }
             static MultiCtx M; std::memset(&M, 0, sizeof M); M.world = G;
             c.mw = &M; c.mw_rank = 0; c.mw_world = G;
@@ -387,16 +387,25 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
                 r.c.mw = &M; r.c.mw_rank = w; r.c.mw_world = G;
             }
             std::vector<std::thread> th;
-            for (int w = 1; w < G; w++) th.emplace_back([&, w] { HostBackend bw; Engine<HostBackend> ew(reps[w - 1].c, bw); ew.execute_victim_action(); });
-            { HostBackend b0; Engine<HostBackend> e0(c, b0); e0.execute_victim_action(); }
+            for (int w = 1; w < G; w++) th.emplace_back([&, w] { HostBackend bw; Engine<HostBackend> ew(reps[w - 1].c, bw); ew.execute_victim_action(); ew.flush_index(); });  // (flush_index: what DevBackend::finish does when the kernel ends)
+            { HostBackend b0; Engine<HostBackend> e0(c, b0); e0.execute_victim_action(); e0.flush_index(); }
             for (auto& t : th) t.join();
             g_mw_waves += M.waves; g_mw_sims_run += M.sims_run; g_mw_sims_used += M.sims_used; g_mw_replays += M.replays;
+            // (tasks-to-allocate caches: an engine may have filled the cache of a bystander job while another has not — the same content whenever it is computed,
+            // job_info.go:253-256 invalidates it with every status change of the job's tasks — so: where both hold one, the same one)
+            auto tta_same = [&](const KaiCtx& r) { for (int j = 0; j < J; j++) { if (!r.j_tta_valid[j] || !c.j_tta_valid[j]) continue; if (r.j_tta_n[j] != c.j_tta_n[j] || std::memcmp(r.tta + c.j_first_pod[j], c.tta + c.j_first_pod[j], (size_t)c.j_tta_n[j] * 4) != 0 || std::memcmp(r.j_tta_res + (size_t)j * 4, c.j_tta_res + (size_t)j * 4, 24) != 0) return false; } return true; };
             for (int w = 1; w < G; w++) {  // the engines must agree bit for bit
                 const KaiCtx& r = reps[w - 1].c;
                 bool same = r.st->out_len == c.st->out_len && r.st->fault == c.st->fault && std::memcmp(r.out_ops, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)) == 0 && std::memcmp(r.p_status, c.p_status, (size_t)P * 4) == 0 &&
                             std::memcmp(r.p_node, c.p_node, (size_t)P * 4) == 0 && std::memcmp(r.n_idle, c.n_idle, (size_t)R * N * 8) == 0 && std::memcmp(r.n_rel, c.n_rel, (size_t)R * N * 8) == 0 &&
-                            std::memcmp(r.q_share, c.q_share, (size_t)Q * 3 * sizeof(QShare)) == 0 && std::memcmp(r.j_tta_valid, c.j_tta_valid, (size_t)J * 4) == 0 &&
+                            std::memcmp(r.q_share, c.q_share, (size_t)Q * 3 * sizeof(QShare)) == 0 && tta_same(r) &&
                             r.st->decisions == c.st->decisions && r.st->simulations == c.st->simulations && r.st->scenarios == c.st->scenarios && r.st->scenarios_filtered == c.st->scenarios_filtered;
+                if (!same && std::getenv("KAI_HOSTSIM_DEBUG")) {
+                    std::fprintf(stderr, "host_sim: differs: ops %d status %d node %d idle %d rel %d shares %d tta_valid %d | decisions %lld/%lld sims %lld/%lld scen %lld/%lld filt %lld/%lld\n", std::memcmp(r.out_ops, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)) != 0, std::memcmp(r.p_status, c.p_status, (size_t)P * 4) != 0, std::memcmp(r.p_node, c.p_node, (size_t)P * 4) != 0,
+                                 std::memcmp(r.n_idle, c.n_idle, (size_t)R * N * 8) != 0, std::memcmp(r.n_rel, c.n_rel, (size_t)R * N * 8) != 0, std::memcmp(r.q_share, c.q_share, (size_t)Q * 3 * sizeof(QShare)) != 0, std::memcmp(r.j_tta_valid, c.j_tta_valid, (size_t)J * 4) != 0,
+                                 (long long)r.st->decisions, (long long)c.st->decisions, (long long)r.st->simulations, (long long)c.st->simulations, (long long)r.st->scenarios, (long long)c.st->scenarios, (long long)r.st->scenarios_filtered, (long long)c.st->scenarios_filtered);
+                    for (int j = 0; j < J; j++) if (r.j_tta_valid[j] != c.j_tta_valid[j]) std::fprintf(stderr, "   job %d tta_valid %d vs %d (pending %d)\n", j, r.j_tta_valid[j], c.j_tta_valid[j], c.j_n_pending[j]);
+                }
                 if (!same) { if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: engine %d of %d ended in another state than engine 0 (ops %lld vs %lld, fault %d vs %d)\n", w, G, (long long)r.st->out_len, (long long)c.st->out_len, r.st->fault, c.st->fault); return KAI_ERR_DEVICE_FAULT; }
             }
             c.mw = nullptr; c.mw_world = 1;

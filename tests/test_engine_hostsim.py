@@ -24,7 +24,7 @@ class HostSim(T.Oracle):
             import glob
             deps = [src] + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.inc")) + glob.glob(os.path.join(T.ROOT, "include", "*.h"))
             if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-                subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", so, src])
+                subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-pthread", "-o", so, src])
             raw = C.CDLL(so)
             raw.kai_hostsim_run.restype = C.c_int
             raw.kai_hostsim_last_exchanges.restype = C.c_int64
@@ -328,3 +328,49 @@ def test_hostsim_victim_tasks_keep_their_eviction_order(seed, ci):
     ref, res = T.Oracle.run(snap, cfg, actions), HostSim.run(snap, cfg, actions)
     assert_same(res, ref, share_tol=1e-9)
     _same_groups(snap, res, ref)
+
+
+@pytest.fixture
+def engines():
+    """Victim actions of the host-compiled engine on several engines (threads over replicas of the context, kai_engine_solver.inc solve_partial_multi); back to one afterwards.
+    The harness itself checks on every run that all engines committed the same operations and ended in the same state."""
+    HostSim.lib()
+    yield HostSim._raw.kai_hostsim_set_multi
+    HostSim._raw.kai_hostsim_set_multi(1)
+
+
+@pytest.mark.parametrize("seed", range(5200, 5260))
+def test_hostsim_victim_search_on_several_engines_broad(engines, seed):
+    """The simulations of a partial job dealt out in waves over 2 .. 9 engines: operations, Statement numbers, states, node accounting and shares of the oracle —
+    the broad campaign's cases (topology, sub-groups, elastic gangs, minruntime, signatures, every action order)."""
+    engines(2 + seed % 8)
+    for snap, cfg, actions in T.broad_case(seed):
+        ref, res = T.Oracle.run(snap, cfg, actions), HostSim.run(snap, cfg, actions)
+        assert_same(res, ref)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_hostsim_victim_search_on_several_engines_crowded(engines, seed):
+    """Crowded clusters (long victim queues: many scenarios per partial job, rejections by the reclaim validator that leave nodes feasible) on 3 .. 16 engines, and the
+    same cycle on one engine: identical operations and the identical statistics (scenarios, simulations, filtered scenarios count what the reference's order reaches)."""
+    snap = T.pkg.synth.make_crowded_snapshot(6 + seed % 20, 7700 + seed, fill=0.7 + 0.25 * (seed % 4) / 3, n_pending_jobs=6 + seed % 17, elastic_frac=0.25 * (seed % 3), hog_frac=0.5,
+                                             queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3])
+    cfg = T.abi.default_config(max_consolidation_preemptees=(-1, 16, 2)[seed % 3], gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=(0.0, 0.5, 1.0)[seed % 3])
+    cfg.use_scheduling_signatures = seed % 2
+    acts = FRAC_ACTS[seed % len(FRAC_ACTS)]
+    ref = T.Oracle.run(snap, cfg, acts)
+    engines(1); one = HostSim.run(snap, cfg, acts)
+    engines(3 + seed % 14); res = HostSim.run(snap, cfg, acts)
+    assert_same(res, ref); assert_same(one, ref)
+    assert (int(res.stats.decisions), int(res.stats.jobs_attempted), int(res.stats.jobs_committed)) == (int(one.stats.decisions), int(one.stats.jobs_attempted), int(one.stats.jobs_committed))
+
+
+def test_hostsim_config4_on_several_engines(engines):
+    """BASELINE config 4 (zone / rack topology, consolidation + reclaim) at 2 %: one engine, eight engines, the oracle."""
+    snap, cfg, _ = T.pkg.synth.config(3, 0.02)
+    acts = ("allocate", "consolidation", "reclaim")
+    ref = T.Oracle.run(snap, cfg, acts)
+    engines(8); res = HostSim.run(snap, cfg, acts)
+    assert_same(res, ref)
+    st = (C.c_int64 * 4)(); HostSim._raw.kai_hostsim_multi_stats(st)
+    assert st[0] > 0 and st[2] <= st[1], list(st)  # waves ran; simulations counted <= simulations run

@@ -426,6 +426,25 @@ def test_gpu_victim_tasks_keep_their_eviction_order(gpu, seed, ci):
     _same_groups(snap, res, ref)
 
 
+@pytest.mark.parametrize("wgs", (1, 2, 7, 64, 200))
+def test_gpu_victim_search_on_several_workgroups(gpu, wgs, monkeypatch):
+    """The victim actions on 1 / 2 / 7 / 64 / 200 workgroups of the MI355X (one replica of the session arrays each, the simulations of a partial job dealt out in waves,
+    kai_engine_solver.inc solve_partial_multi): BASELINE config 4 at 2 % and two crowded clusters — the oracle's operations, Statement numbers, states and shares whatever
+    the width; stats.reserved[1] says how many workgroups ran the action."""
+    monkeypatch.setenv("KAI_VICTIM_WGS", str(wgs))
+    snap, cfg, _ = T.pkg.synth.config(3, 0.02)
+    acts = ("allocate", "consolidation", "reclaim")
+    ref = T.Oracle.run(snap, cfg, acts)
+    res = run_gpu(snap, cfg, acts)
+    assert_same(res, ref)
+    assert int(res.stats.reserved[1]) == wgs, int(res.stats.reserved[1])  # the last action (reclaim) ran on that many workgroups
+    for seed in (3, 10):
+        snap = T.pkg.synth.make_crowded_snapshot(6 + seed, 7700 + seed, fill=0.9, n_pending_jobs=6 + seed, elastic_frac=0.25, hog_frac=0.5, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3])
+        cfg = T.abi.default_config(max_consolidation_preemptees=-1, k_value=0.5)
+        acts = ("allocate", "consolidation", "reclaim", "preempt")
+        assert_same(run_gpu(snap, cfg, acts), T.Oracle.run(snap, cfg, acts))
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_gpu_gpu_memory_fuzz(gpu, seed):
     """Requests for MiB of one device (ABI v5 pod_gpu_memory) beside fractions and whole GPUs on the device: the memory they take on a shared GPU, their

@@ -8,6 +8,8 @@ import kai_testlib as T
 from test_engine_hostsim import HostSim
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 FRAC = os.environ.get("CAMPAIGN_FRACTIONS", "0") == "1"
+MW = int(os.environ.get("CAMPAIGN_MW", "1"))  # > 1: the victim actions of the host-compiled engine on that many engines (threads over replicas, kai_engine_solver.inc solve_partial_multi)
+HostSim.lib(); HostSim._raw.kai_hostsim_set_multi(MW)
 same = (lambda a, b: np.allclose(a, b, rtol=0.0, atol=1e-9)) if FRAC else np.array_equal
 bad = tot = 0; t0 = time.time()
 for seed in range(lo, hi):
