@@ -94,6 +94,7 @@ def main():
     upload_s = time.time() - t0
 
     kernel_ms, open_ms, decisions, placed = [], [], 0, 0
+    last_stats = [None]  # statistics of the cycle's last action
     first_ops = []
 
     def step(record):
@@ -107,6 +108,7 @@ def main():
             ops_step.append(o)  # kept as returned (numpy view of the C ABI's kai_op array): converting is left for after the timed region
             s_a = ssn.stats(); n_dec += int(s_a.decisions); k_ms_sum += s_a.kernel_ms
             st = s_a if st is None else st  # the engine counters reported below are the allocate action's
+            last_stats[0] = s_a
         if record:
             kernel_ms.append(k_ms_sum); open_ms.append(o_ms)
             decisions = n_dec; placed = n_ops
@@ -130,7 +132,7 @@ def main():
     else:        # replicas: one scheduling shard per rank
         total_decisions = pkg.dist.sum_over_ranks(decisions * args.steps, device=red_dev)
         total_placed = pkg.dist.sum_over_ranks(placed * args.steps, device=red_dev)
-    value = total_decisions / elapsed
+    value = total_placed / elapsed  # BASELINE's metric: pod placements per second (committed allocate / pipeline operations; evictions of the victim actions are operations too)
     k_ms = float(np.mean(kernel_ms))
     b_dec = N * B_NODE + B_POD_OUT
     batch = int(st.reserved[4]) > 0
@@ -149,7 +151,10 @@ def main():
         # the dominant kernel: k_fill, `rounds` launches per step, timed with HIP events on its stream around every launch (kai_core.hip DevLauncher)
         alg_bytes_launch = fill_dec * b_dec / max(rounds, 1); avg_launch_ms = fill_ms / max(rounds, 1)
         achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(desc, "k_fill"),
+        traffic = pmc_traffic(desc, "k_fill")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "limiter": "instruction issue of ONE wavefront (k_fill runs as 1 workgroup x 64 lanes on one of the 256 CUs; fill_cycles_per_decision below), not HBM",
+                "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 1,
                 "traffic_source": "static: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE of k_fill from committed rocprofv3 --pmc passes of this command (counters need their own passes; not collected in this run)",
                 "kernel": "k_fill", "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "other_kernels": {"plan (k_plan_leaf / rank / scan / emit)": {"ms_per_step": plan_ms}, "apply (k_apply_jobs / nodes)": {"ms_per_step": apply_ms},
@@ -158,15 +163,22 @@ def main():
                         "The class index answers a decision from one 64-node block, so the measured traffic is far below the algorithmic bytes; the kernel is one wavefront "
                         "bound by instruction issue / dependent latency (fill_cycles_per_decision), not by HBM bandwidth."}
     else:
+        if any(a != "allocate" for a in actions):
+            s_a = last_stats[0]
+            engine["victim_search"] = {"workgroups": int(s_a.reserved[1]), "waves": int(s_a.reserved[5]), "simulations_run": int(s_a.reserved[6]) >> 32, "simulations_counted": int(s_a.reserved[6]) & 0xffffffff,
+                                       "scenarios": int(s_a.reserved[2]), "simulations": int(s_a.reserved[3]), "note": "last victim action of the cycle; one replica of the session arrays per workgroup, simulations of a partial job handed out in waves (DESIGN.md)"}
         engine.update({"path": "sequential engine", "control_cycles": {"allocate": int(st.reserved[5]), "commit_discard": int(st.reserved[6]), "total": int(st.reserved[7])}})
         alg = (decisions - drained) * b_dec; achieved = alg / (k_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(desc, "k_action"), "kernel": "k_action",
                 "launches_per_step": 1, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg, "note": "decisions of k_action x (N x 128 B + 80 B) / action time; latency bound (one control lane)"}
     out = {
-        "metric": "pod placement decisions/sec (" + " + ".join(actions) + (" action" if len(actions) == 1 else " actions") + ", synthetic snapshot)", "value": value, "unit": "decisions/s",
+        "metric": "pod placements/sec (" + " + ".join(actions) + (" action" if len(actions) == 1 else " actions") + ", synthetic snapshot)", "value": value, "unit": "placements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if (sharded or world == 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "placements_per_s": total_placed / elapsed,
+        # every allocateTask execution is a decision; the ones k_drain resolves — jobs popped once no class fits anywhere, turned away without touching a node — are split out
+        "decisions_per_s": {"all": total_decisions / elapsed, "fill": (total_decisions - drained * args.steps * (1 if sharded or world == 1 else world)) / elapsed if batch else None,
+                            "drained": (drained * args.steps * (1 if sharded or world == 1 else world)) / elapsed if batch else None},
         "config": {"workload": desc, "nodes": N, "pods": snap.n_pods, "jobs": snap.n_jobs, "queues": snap.n_queues,
                    "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2], "action_ms": k_ms,
                    "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else (f"node axis of one snapshot sharded over {world} GPUs: per exchange every rank offers its 128 best nodes per scan class, all-gather over RCCL / xGMI, the same virtual fill on every rank"

@@ -255,7 +255,7 @@ int prepare_multi(kai_core* core, int G, int* g_out) {
         cw.bt.enabled = 0;  // (the batch path's pools are not replicated; a victim action never reads them)
     }
     HIP_TRY(core, hipMemcpyAsync(core->d_ctxs, ctxs.data(), (size_t)G * sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
-    MultiCtx m0{}; m0.world = G;
+    static MultiCtx m0; std::memset(&m0, 0, sizeof m0); m0.world = G; m0.hit[0] = m0.hit[1] = 0x7fffffff;  // (static: 150 KB)
     HIP_TRY(core, hipMemcpyAsync(core->d_mw, &m0, sizeof(MultiCtx), hipMemcpyHostToDevice, core->stream));
     hipLaunchKernelGGL(k_replicate, dim3(core->n_segs, G - 1), dim3(256), 0, core->stream, (const RepSeg*)core->d_segs, core->rep_mem, (unsigned long long)core->rep_stride);
     HIP_TRY(core, hipGetLastError());
@@ -596,7 +596,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         size_t dyn = idx_b + (tree_in_lds ? tree_b : 0);
         // a victim action runs on several workgroups, each on a replica of the session arrays made right here (after k_job_init / k_leaf_init on the stream)
         if (victim) {
-            int want = 64; if (const char* e = std::getenv("KAI_VICTIM_WGS")) want = std::atoi(e);
+            int want = 32; if (const char* e = std::getenv("KAI_VICTIM_WGS")) want = std::atoi(e);  // (measured on C4: 32 workgroups — four replicas per XCD, hot in its L2 — beat 64 and more, whose waves are no shorter)
             int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, core->device) != hipSuccess || cus <= 0) cus = 64;
             want = std::max(1, std::min(std::min(want, (int)KAI_MW_MAX), cus));  // every workgroup must be resident: they meet at a grid barrier
             int rcm = prepare_multi(core, want, &g_run); if (rcm) return rcm;
@@ -634,7 +634,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     if (victim) {  // victim actions: [1] workgroups the action ran on, [5] waves, [6] simulations run (speculative ones included) << 32 | simulations the reference's order reached
         core->stats.reserved[1] = g_run;
         if (g_run > 1) {
-            MultiCtx m{}; HIP_TRY(core, hipMemcpyAsync(&m, core->d_mw, sizeof(MultiCtx), hipMemcpyDeviceToHost, core->stream)); HIP_TRY(core, hipStreamSynchronize(core->stream));
+            static MultiCtx m; HIP_TRY(core, hipMemcpyAsync(&m, core->d_mw, sizeof(MultiCtx), hipMemcpyDeviceToHost, core->stream)); HIP_TRY(core, hipStreamSynchronize(core->stream));
             core->stats.reserved[5] = m.waves; core->stats.reserved[6] = (m.sims_run << 32) | (m.sims_used & 0xffffffffll);
             if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai victim: %d workgroups, waves %lld, simulations run %lld / counted %lld, replays %lld, fault %d\n", g_run, (long long)m.waves, (long long)m.sims_run, (long long)m.sims_used, (long long)m.replays, m.fault);
         }

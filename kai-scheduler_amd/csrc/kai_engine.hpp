@@ -168,19 +168,22 @@ enum { FAULT_NONE = 0, FAULT_OPS_CAP = 1, FAULT_OUT_CAP = 2, FAULT_HEAP = 3, FAU
 // Victim search on several workgroups (kai_engine_solver.inc solve_partial_multi): every workgroup runs the SAME control flow on its own replica of the session
 // state (KaiCtx pointers rebased into the replica); the simulations of one partial job are dealt out to them in waves, and this block — the only memory they share —
 // carries each wave's outcomes and the grid barrier.  One instance per victim action, zeroed by the host before the launch.
-constexpr int KAI_MW_MAX = 256;   // workgroups of one victim action at most (one per compute unit)
-constexpr int KAI_MW_CNT = 8;     // counter deltas a simulation reports (see Engine::mw_counters)
+constexpr int KAI_MW_MAX = 256;    // workgroups of one victim action at most (one per compute unit)
+constexpr int KAI_MW_WAVE = 1024;  // simulations of one wave at most
+constexpr int KAI_MW_CNT = 8;      // counter deltas a simulation reports (see Engine::mw_cnt_get)
 struct MultiCtx {
     int32_t world, fault, bar_count, bar_gen;
-    int32_t res[2][KAI_MW_MAX];                 // per wave (double buffered) and rank: SIM_* status | MW_TOUCHED_PREEMPTOR
-    int64_t cnt[2][KAI_MW_MAX][KAI_MW_CNT];     // … and the counters that simulation bumped
-    int64_t waves, sims_run, sims_used, replays;  // diagnostics (rank 0 writes)
+    int32_t next[2], hit[2];                     // per wave (double buffered): the next simulation to hand out; the lowest simulation so far that did not simply fail (INT_MAX: none)
+    int32_t res[2][KAI_MW_WAVE];                 // … SIM_* status | MW_TOUCHED of simulation i
+    int64_t cnt[2][KAI_MW_WAVE][KAI_MW_CNT];     // … and the counters it bumped
+    int64_t waves, sims_run, sims_used, replays;  // diagnostics (rank 0 adds what it sees)
 };
 
 // Scratch of the victim search (reclaim / preempt / consolidation, kai_engine_solver.inc), all in HBM.  "View" of a victim job =
 // its pods that are not yet taken into a task group of the scenario (and, once the builder met a recorded victim of the job, not
 // recorded): what the reference holds as CloneWithTasks(remainingTasks) in the victims queue (solvers/pod_scenario_builder.go:91-133).
 struct SolverCtx {
+    uint8_t *vq_state, *tpl_state;                    // [J+1] elastic state of a victim job's view, cached while the view stands (255 = not known); state of a pending job for the template (255 = not pending)
     uint8_t *vq_in, *vq_excl, *ja_in;                 // [J] victims-queue membership, "view excludes recorded tasks", jobsToAllocate membership (bit 1 = victim job)
     uint8_t *p_taken, *p_recorded, *p_partial, *ig_cache;  // [P]
     int32_t *p_grp;                                   // [P] task group (representative clone) of a victim pod in the current scenario
@@ -194,7 +197,7 @@ struct SolverCtx {
     double* vq_pop;                                   // [Q][3] Σ Allocated of the jobs popped from a leaf (poppedJobsByQueue, job_order_by_queue.go:80-82)
     int32_t* s_ov_min;                                // [S] minAvailable of the partial preemptor representative (job_solver.go:128-151)
     int32_t *mw_end, *mw_filt;                        // [P+J+2] scenarios the builder has produced for the running partial job: group count of scenario k, scenarios the filters dropped before it
-    uint32_t* mw_feas; int32_t *mw_nstamp, *mw_nmaxk, *mw_wk, *mw_wn, *mw_ctr;  // [W+1] feasible nodes a wave starts from; [N+1] x 2 per node: wave stamp and the last scenario of the wave's consumed simulations on it; [KAI_MW_MAX] x 2 the wave's simulations
+    uint32_t* mw_feas; int32_t *mw_nstamp, *mw_nmaxk, *mw_wk, *mw_wn, *mw_ctr;  // [W+1] feasible nodes a wave starts from; [N+1] x 2 per node: wave stamp and the last scenario of the wave's consumed simulations on it; [KAI_MW_WAVE] x 2 the wave's simulations
     int32_t *mw_sj, *mw_sv, *mw_sn, *mw_stta; double* mw_sres;  // [J+1] x 3, [P+1], [4(J+1)]: tasks-to-allocate caches of the jobs a speculative simulation touches, saved aside
     int32_t *grp_job, *grp_off, *grp_pods, *grp_ord;  // task groups of the scenario: recorded first, then potential in the order they were added; grp_pods = a group's pods in canonical order
                                                       // (what ranging the representative's pod map stands for), grp_ord = in the order they were handed over (VictimInfo.Tasks, potentialVictimsTasks: slices)
@@ -224,8 +227,9 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     add(sizeof(double) * 3 * Q); add(sizeof(int32_t) * (S + 1));
     for (int i = 0; i < 2; i++) { add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); }
     add(sizeof(int32_t) * (P + 1));  // grp_ord
+    add(J + 1); add(J + 1);  // vq_state, tpl_state
     add(sizeof(int32_t) * ((size_t)P + J + 2)); add(sizeof(int32_t) * ((size_t)P + J + 2)); for (int i = 0; i < 3; i++) add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (P + 1)); add(sizeof(double) * 4 * (J + 1));  // mw_*
-    add(sizeof(uint32_t) * (W + 1)); add(sizeof(int32_t) * (N + 1)); add(sizeof(int32_t) * (N + 1)); add(sizeof(int32_t) * KAI_MW_MAX); add(sizeof(int32_t) * KAI_MW_MAX); add(sizeof(int32_t) * 4);
+    add(sizeof(uint32_t) * (W + 1)); add(sizeof(int32_t) * (N + 1)); add(sizeof(int32_t) * (N + 1)); add(sizeof(int32_t) * KAI_MW_WAVE); add(sizeof(int32_t) * KAI_MW_WAVE); add(sizeof(int32_t) * 4);
     for (int i = 0; i < 7; i++) add(sizeof(int32_t) * (P + 1));
     add(sizeof(uint32_t) * (W + 1)); add(sizeof(uint32_t) * (W + 1));
     add(sizeof(double) * (N + 1)); add(sizeof(int32_t) * (P + 1));
@@ -251,9 +255,10 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     }
     v.vq_pop = (double*)take(sizeof(double) * 3 * Q); v.s_ov_min = (int32_t*)take(sizeof(int32_t) * (S + 1));
     v.grp_job = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.grp_off = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.grp_pods = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.grp_ord = (int32_t*)take(sizeof(int32_t) * (P + 1));
+    v.vq_state = (uint8_t*)take(J + 1); v.tpl_state = (uint8_t*)take(J + 1);
     v.mw_end = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 2)); v.mw_filt = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 2)); v.mw_sj = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.mw_sv = (int32_t*)take(sizeof(int32_t) * (J + 1));
     v.mw_sn = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.mw_stta = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.mw_sres = (double*)take(sizeof(double) * 4 * (J + 1));
-    v.mw_feas = (uint32_t*)take(sizeof(uint32_t) * (W + 1)); v.mw_nstamp = (int32_t*)take(sizeof(int32_t) * (N + 1)); v.mw_nmaxk = (int32_t*)take(sizeof(int32_t) * (N + 1)); v.mw_wk = (int32_t*)take(sizeof(int32_t) * KAI_MW_MAX); v.mw_wn = (int32_t*)take(sizeof(int32_t) * KAI_MW_MAX); v.mw_ctr = (int32_t*)take(sizeof(int32_t) * 4);
+    v.mw_feas = (uint32_t*)take(sizeof(uint32_t) * (W + 1)); v.mw_nstamp = (int32_t*)take(sizeof(int32_t) * (N + 1)); v.mw_nmaxk = (int32_t*)take(sizeof(int32_t) * (N + 1)); v.mw_wk = (int32_t*)take(sizeof(int32_t) * KAI_MW_WAVE); v.mw_wn = (int32_t*)take(sizeof(int32_t) * KAI_MW_WAVE); v.mw_ctr = (int32_t*)take(sizeof(int32_t) * 4);
     v.rec_job = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.rec_off = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.rec_pods = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.res_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.ev_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vt_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1));
     v.pend = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.tmp = (int32_t*)take(sizeof(int32_t) * (P + 1));
@@ -377,7 +382,7 @@ struct TopoScan {
 };
 // Index loops of the victim search (resets, the victims-queue filter, feasible nodes, idle GPUs per node) as one request to the backend's scan lanes:
 // Backend::pfor returns false when it has none (the engine then runs the loop itself); the bodies are Engine::pfor_body (kai_engine_solver.inc).
-enum PforOp : int32_t { PFO_PARTIAL_RESET = 1, PFO_VICTIM_FILTER = 2, PFO_FEASIBLE = 3, PFO_IG_IDLE = 4 };
+enum PforOp : int32_t { PFO_PARTIAL_RESET = 1, PFO_VICTIM_FILTER = 2, PFO_FEASIBLE = 3, PFO_IG_IDLE = 4, PFO_TPL_STATE = 5 };
 struct PforReq { int32_t op, n, a, b; };
 KAI_HD bool topo_node_in_domain(const KaiCtx& c, const TopoScan& t, int n) {
     if (t.L <= 0) return false;
@@ -763,7 +768,9 @@ struct EngineLocal {
     // victim search: the active job-order instance (0 = the action's, 1 = victims queue, 2 = jobs to allocate of a simulation)
     int32_t *i_sorted, *i_cur, *i_end, *i_side, *i_side_len;  // leaf storage of the active instance
     int32_t jo_kind, cur_inst;               // jo_kind 1 = victims ordering (reversed comparators, victims operands)
-    int32_t tpl_valid, pad9;                 // the pending-job template of the simulation queues matches the committed state
+    int32_t tpl_valid, mw_poll;              // the pending-job template of the simulation queues matches the committed state; >= 0: this simulation's index in its wave — it is
+                                             // given up as soon as an earlier simulation of the wave is known not to have simply failed (MultiCtx::hit), buffer mw_buf
+    int32_t mw_buf, pad10;
     struct JoSave { QNode* qn; int32_t *qheap, *root_heap, *sorted, *cur, *end, *side, *side_len; int32_t root_len, root_init, kind, pad; } save[3];
 };
 
@@ -786,7 +793,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0;
         e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 

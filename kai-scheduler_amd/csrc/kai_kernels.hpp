@@ -451,10 +451,13 @@ struct DevBackendT {
     __device__ static int32_t mw_load32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static void mw_store64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static int64_t mw_load64(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ static void grid_sync(MultiCtx* m) {  // the control lanes of the action's workgroups (all resident: one per compute unit at most, kai_core.hip)
+    __device__ static int32_t mw_fetch_add32(int32_t* p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static void mw_fetch_min32(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static void grid_sync(MultiCtx* m, int clear) {  // the control lanes of the action's workgroups (all resident: one per compute unit at most, kai_core.hip)
         const int gen = __hip_atomic_load(&m->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __atomic_thread_fence(__ATOMIC_RELEASE);
         if (__hip_atomic_fetch_add(&m->bar_count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1 == m->world) {
+            __hip_atomic_store(&m->next[clear], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&m->hit[clear], 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&m->bar_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&m->bar_gen, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {

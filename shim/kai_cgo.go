@@ -28,6 +28,9 @@ import (
 	v1 "k8s.io/api/core/v1"
 
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/allocate"
+	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/consolidation"
+	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/preempt"
+	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/reclaim"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/node_info"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/pod_info"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/pod_status"
@@ -60,7 +63,8 @@ type packedSnapshot struct {
 	pods     []*pod_info.PodInfo           // ABI pod index  -> task
 	nodes    []*node_info.NodeInfo         // ABI node index -> node
 	jobs     []*podgroup_info.PodGroupInfo // ABI job index  -> pod group
-	fallback bool
+	classes  *staticClasses                // pod / node classes of the static Filters, shared-GPU group ids
+	fallback bool                          // the rest of this cycle runs on the Go actions
 }
 
 func (p *packedSnapshot) free() {
@@ -128,26 +132,41 @@ func statusBit(s pod_status.PodStatus) C.int32_t { // api/pod_status/pod_status.
 	return C.KAI_POD_UNKNOWN
 }
 
-// needsFallback: the task needs a predicate or a resource model the device path does not carry — SURVEY §8b fallback rule
-func needsFallback(t *pod_info.PodInfo) bool {
-	if t.IsLegacyMIGtask || len(t.ResReq.MigResources()) > 0 || t.ResReq.GetDraGpusCount() > 0 {
-		return true
+// podModelFlags: what the device path does not carry for this task (SURVEY §8b fallback rule; kai_ingest.cpp:592-611 sets the same bits from snapshot.json).
+//   KAI_POD_CPU_FALLBACK   a state-dependent upstream predicate or a request kind without a device model: a PENDING pod with it makes kai_session_open decline
+//   KAI_POD_GPU_UNMODELLED several fractional devices / DRA claims: an ACTIVE pod with it holds GPU state the node accounting would overstate, the session is declined
+//   KAI_POD_LEGACY_MIG     a legacy MIG task (annotation-named instances): never scheduled, and its node takes no MIG request (node_info.go:315-359, 407-409)
+// A fraction or MiB of ONE device (ABI v4 / v5) and MIG instance requests (resource rows >= 4) are described to the device and need no flag.
+func podModelFlags(t *pod_info.PodInfo) C.uint32_t {
+	var f C.uint32_t
+	if t.IsLegacyMIGtask {
+		f |= C.KAI_POD_LEGACY_MIG
 	}
-	if t.ResReq.GetNumOfGpuDevices() > 1 && t.ResReq.IsFractionalRequest() {
-		return true
+	multiFraction := t.ResReq.GetNumOfGpuDevices() > 1 && t.ResReq.IsFractionalRequest()
+	dra := t.ResReq.GetDraGpusCount() > 0 || len(t.Pod.Spec.ResourceClaims) > 0
+	if multiFraction || dra {
+		f |= C.KAI_POD_CPU_FALLBACK | C.KAI_POD_GPU_UNMODELLED
+	}
+	if len(t.ResReq.MigResources()) > 0 {
+		f |= C.KAI_POD_CPU_FALLBACK // this shim packs the four base resource rows only (nRes): MIG instance rows are laid out by the snapshot-file path
 	}
 	spec := t.Pod.Spec
 	if spec.Affinity != nil && (spec.Affinity.PodAffinity != nil || spec.Affinity.PodAntiAffinity != nil) {
-		return true
+		f |= C.KAI_POD_CPU_FALLBACK
 	}
-	for _, c := range spec.Containers {
-		for _, port := range c.Ports {
-			if port.HostPort != 0 {
-				return true
+	for _, cs := range [][]v1.Container{spec.Containers, spec.InitContainers} {
+		for _, c := range cs {
+			for _, port := range c.Ports {
+				if port.HostPort != 0 {
+					f |= C.KAI_POD_CPU_FALLBACK
+				}
 			}
 		}
 	}
-	return len(t.GetAllStorageClaims()) > 0 || len(spec.ResourceClaims) > 0
+	if len(t.GetAllStorageClaims()) > 0 {
+		f |= C.KAI_POD_CPU_FALLBACK
+	}
+	return f
 }
 
 // packSnapshot: ssn.ClusterInfo (api/cluster_info.go:43-64, built by cache/cluster_info/cluster_info.go:118-228) ->
@@ -303,6 +322,7 @@ func packSnapshot(ssn *framework.Session, params packParams) *packedSnapshot {
 	sigIDs := map[string]int64{}
 	podUIDs := make([]string, 0, P)
 	classes := newStaticClasses(p.nodes) // pod classes by constraint sub-tree, node classes by the labels / taints those constraints see
+	p.classes = classes
 	pi, si := 0, 0
 	for j, id := range jids {
 		job := ci.PodGroupInfos[podgroup_info.PodGroupID(id)]
@@ -367,9 +387,7 @@ func packSnapshot(ssn *framework.Session, params packParams) *packedSnapshot {
 				pFlags[pi] |= C.KAI_POD_HAS_TASK_PRIORITY
 				pTaskPrio[pi] = C.int32_t(prio)
 			}
-			if needsFallback(t) {
-				pFlags[pi] |= C.KAI_POD_CPU_FALLBACK
-			}
+			pFlags[pi] |= podModelFlags(t)
 			if t.ResReq.IsFractionalRequest() && t.ResReq.GetNumOfGpuDevices() == 1 { // ABI v4 / v5: a fraction, or MiB, of ONE device
 				if t.IsMemoryRequest() { // pod_info.go:463-468: GPUs() and the portion are 0, the request is the memory
 					pGpuMem[pi] = C.int64_t(t.ResReq.GpuMemory())
@@ -452,39 +470,67 @@ func (a *action) Execute(ssn *framework.Session) { // framework/interface.go:41-
 	defer C.free(unsafe.Pointer(ops))
 	var n C.int64_t
 	if rc := C.kai_action_execute(core, a.kind, ops, capOps, &n); rc != 0 {
+		// The device may have applied part of the action before it failed (e.g. KAI_ERR_CAPACITY after some rounds), and in any case it will not see what
+		// the Go action does now: the rest of this cycle stays on the Go actions.
+		pack.fallback = true
 		a.goAction.Execute(ssn)
 		return
 	}
-	replay(ssn, pack, unsafe.Slice(ops, int(n)))
+	if !replay(ssn, pack, unsafe.Slice(ops, int(n))) {
+		pack.fallback = true // the live session and the device state have parted: nothing more from the device in this cycle
+	}
 }
 
 // replay: the committed operations through the real Statement.  kai_op.stmt numbers the Statements of the action in
 // commit order; one id = one Statement, e.g. a reclaim "evict A, evict B, pipeline C" (framework/statement.go:536-575).
-func replay(ssn *framework.Session, pack *packedSnapshot, ops []C.kai_op) {
+// An operation the live session refuses (the cache moved on since the snapshot, a bind conflict) discards its whole Statement —
+// a gang is committed entirely or not at all — and ends the replay: false.
+func replay(ssn *framework.Session, pack *packedSnapshot, ops []C.kai_op) bool {
+	groups := carray[C.int32_t](pack, len(pack.pods)) // PodInfo.GPUGroups[0] of the fraction pods after the action (freed with the snapshot)
+	haveGroups := len(pack.pods) > 0 && C.kai_pod_gpu_groups(core, ptr(groups), C.int(len(pack.pods))) == 0
 	for i := 0; i < len(ops); {
 		stmt := ssn.Statement()
 		id := ops[i].stmt
+		var err error
 		for ; i < len(ops) && ops[i].stmt == id; i++ {
+			if err != nil {
+				continue // skip the rest of a Statement that is going to be discarded
+			}
 			task := pack.pods[ops[i].pod]
 			switch ops[i].kind {
-			case C.KAI_OP_ALLOCATE:
-				_ = stmt.Allocate(task, pack.nodes[ops[i].node].Name)
-			case C.KAI_OP_PIPELINE:
-				_ = stmt.Pipeline(task, pack.nodes[ops[i].node].Name, task.Status != pod_status.Pending)
+			case C.KAI_OP_ALLOCATE, C.KAI_OP_PIPELINE:
+				node := pack.nodes[ops[i].node]
+				if haveGroups && task.IsSharedGPURequest() && groups[ops[i].pod] >= 0 {
+					// SelectedGPUGroups of the BindRequest (cache/cache.go:290-330) come from PodInfo.GPUGroups: the group the device chose
+					task.GPUGroups = []string{pack.classes.groupName(node.Name, int32(groups[ops[i].pod]))}
+				}
+				if ops[i].kind == C.KAI_OP_ALLOCATE {
+					err = stmt.Allocate(task, node.Name)
+				} else {
+					err = stmt.Pipeline(task, node.Name, task.Status != pod_status.Pending)
+				}
 			case C.KAI_OP_EVICT:
-				_ = stmt.Evict(task, "gpucore", nil)
+				err = stmt.Evict(task, "gpucore", nil)
 			}
 		}
-		_ = stmt.Commit()
+		if err != nil {
+			stmt.Discard()
+			return false
+		}
+		if err = stmt.Commit(); err != nil {
+			return false
+		}
 	}
+	return true
 }
 
 func init() {
-	framework.RegisterPluginBuilder("gpucore", New)                                                                     // framework/plugins.go:31-47
-	framework.RegisterAction(&action{kind: C.KAI_ACTION_ALLOCATE, name: framework.Allocate, goAction: allocate.New()}) // framework/plugins.go:49-54: takes the name of the original
-	// consolidation / reclaim / preempt: the same wrapper with C.KAI_ACTION_CONSOLIDATION / _RECLAIM / _PREEMPT and the package's New()
+	framework.RegisterPluginBuilder("gpucore", New) // framework/plugins.go:31-47
+	// framework/plugins.go:49-54: an action registered under the name of the original takes its place in the configured `actions:` list
+	framework.RegisterAction(&action{kind: C.KAI_ACTION_ALLOCATE, name: framework.Allocate, goAction: allocate.New()})
+	framework.RegisterAction(&action{kind: C.KAI_ACTION_CONSOLIDATION, name: framework.Consolidation, goAction: consolidation.New()})
+	framework.RegisterAction(&action{kind: C.KAI_ACTION_RECLAIM, name: framework.Reclaim, goAction: reclaim.New()})
+	framework.RegisterAction(&action{kind: C.KAI_ACTION_PREEMPT, name: framework.Preempt, goAction: preempt.New()})
 }
 
-// taskPriority, newStaticClasses (podClass / nodeClass / fitTable / groupID) and packTopologies are in kai_cgo_classes.go of the same
-// package: they restate, for live API objects, exactly what kai_ingest.cpp does for snapshot.json (node_affinity_fits, taints_tolerated,
-// the Topology CR walk) — that C++ is the executable specification the tests pin (tests/test_ingest.py).
+// taskPriority, newStaticClasses (podClass / nodeClass / fitTable / groupID / groupName) and packTopologies: kai_cgo_classes.go.

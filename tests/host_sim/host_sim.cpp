@@ -103,9 +103,11 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     static int32_t mw_load32(const int32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
     static void mw_store64(int64_t* p, int64_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
     static int64_t mw_load64(const int64_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-    static void grid_sync(MultiCtx* m) {
+    static int32_t mw_fetch_add32(int32_t* p, int32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+    static void mw_fetch_min32(int32_t* p, int32_t v) { int32_t o = __atomic_load_n(p, __ATOMIC_ACQUIRE); while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {} }
+    static void grid_sync(MultiCtx* m, int clear) {
         const int gen = __atomic_load_n(&m->bar_gen, __ATOMIC_ACQUIRE);
-        if (__atomic_add_fetch(&m->bar_count, 1, __ATOMIC_ACQ_REL) == m->world) { __atomic_store_n(&m->bar_count, 0, __ATOMIC_RELAXED); __atomic_add_fetch(&m->bar_gen, 1, __ATOMIC_RELEASE); }
+        if (__atomic_add_fetch(&m->bar_count, 1, __ATOMIC_ACQ_REL) == m->world) { __atomic_store_n(&m->next[clear], 0, __ATOMIC_RELAXED); __atomic_store_n(&m->hit[clear], 0x7fffffff, __ATOMIC_RELAXED); __atomic_store_n(&m->bar_count, 0, __ATOMIC_RELAXED); __atomic_add_fetch(&m->bar_gen, 1, __ATOMIC_RELEASE); }
         else { long spins = 0; while (__atomic_load_n(&m->bar_gen, __ATOMIC_ACQUIRE) == gen) { if (++spins > 64) std::this_thread::yield(); if (spins > 400000000L) { __atomic_store_n(&m->fault, 1, __ATOMIC_RELEASE); break; } } }
     }
     int64_t clock() {
@@ -378,7 +380,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             const int G = shared ? 1 : g_mw_world;
             if (G <= 1) { c.mw = nullptr; c.mw_rank = 0; c.mw_world = 1; if (std::getenv("KAI_HOSTSIM_FRESH")) { HostBackend bf; Engine<HostBackend> ef(c, bf); ef.execute_victim_action(); ef.flush_index(); } else eng.execute_victim_action(); continue; }
             if (reps.empty()) { reps.resize(G - 1); for (auto& r : reps) { alloc1(r.pool, r.c); if (int rc = alloc2(r.pool, r.c)) return rc; if (r.pool.size() != pool.size()) return KAI_ERR_DEVICE_FAULT; } }
-            static MultiCtx M; std::memset(&M, 0, sizeof M); M.world = G;
+            static MultiCtx M; std::memset(&M, 0, sizeof M); M.world = G; M.hit[0] = M.hit[1] = 0x7fffffff;
             c.mw = &M; c.mw_rank = 0; c.mw_world = G;
             for (int w = 1; w < G; w++) {
                 Rep& r = reps[w - 1];

@@ -374,3 +374,16 @@ def test_hostsim_config4_on_several_engines(engines):
     assert_same(res, ref)
     st = (C.c_int64 * 4)(); HostSim._raw.kai_hostsim_multi_stats(st)
     assert st[0] > 0 and st[2] <= st[1], list(st)  # waves ran; simulations counted <= simulations run
+
+
+def test_hostsim_config3_full_size_hashes_to_the_oracles_pin():
+    """profiles/full_size_pins.json (tools/pin_full_sizes.py: the oracle's full-size runs): BASELINE config 3 at full size on the host-compiled engine gives the pinned
+    operation and state hashes (the GPU twin of this test also covers config 5)."""
+    import json
+    with open(os.path.join(T.ROOT, "profiles", "full_size_pins.json")) as f:
+        pin = json.load(f)["C3"]
+    snap, cfg, desc = T.pkg.synth.config(2, 1.0)
+    assert (desc, snap.n_nodes, snap.n_pods) == (pin["workload"], pin["nodes"], pin["pods"])
+    cfg.engine_mode = 3
+    res = HostSim.run(snap, cfg)
+    assert T.ops_sha256(res.ops) == pin["ops_sha256"] and T.state_sha256(res) == pin["state_sha256"]

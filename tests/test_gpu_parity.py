@@ -67,10 +67,26 @@ def test_gpu_reference_goldens(gpu, name, i, case, actions):
     assert_same(res, T.Oracle.run(snap, cfg, actions))
 
 
-@pytest.mark.parametrize("idx,scale", [(0, 1.0), (1, 0.1), (1, 1.0), (2, 0.05), (4, 0.005)])
+@pytest.mark.parametrize("idx,scale", [(0, 1.0), (1, 0.1), (1, 1.0), (2, 0.05), (2, 1.0), (4, 0.005)])
 def test_gpu_synthetic_configs(gpu, idx, scale):
+    """(2, 1.0) = BASELINE config 3 at full size end to end against the oracle (node scoring on 8 threads: about a minute)."""
     snap, cfg, _ = T.pkg.synth.config(idx, scale)
-    assert_same(run_gpu(snap, cfg), T.Oracle.run(snap, cfg))
+    assert_same(run_gpu(snap, cfg), T.Oracle.run(snap, cfg, threads=8 if snap.n_nodes >= 2048 else 1))
+
+
+@pytest.mark.parametrize("name,idx", [("C3", 2), ("C5", 4)])
+def test_gpu_full_size_operations_hash_to_the_oracles(gpu, name, idx):
+    """The benched sizes pinned END TO END: profiles/full_size_pins.json holds the SHA-256 of the operation stream and of the final state (pod statuses and nodes, node accounting,
+    queue shares) of the ORACLE's full-size run (tools/pin_full_sizes.py; C5: 37 minutes of oracle time on 8 cores, where the host-compiled engine agreed on every
+    operation, pod, node and share) — the MI355X must produce the same two hashes."""
+    import json, os
+    with open(os.path.join(T.ROOT, "profiles", "full_size_pins.json")) as f:
+        pin = json.load(f)[name]
+    snap, cfg, desc = T.pkg.synth.config(idx, 1.0)
+    assert (desc, snap.n_nodes, snap.n_pods) == (pin["workload"], pin["nodes"], pin["pods"])
+    res = run_gpu(snap, cfg)
+    assert len(res.ops) == pin["ops"] and T.ops_sha256(res.ops) == pin["ops_sha256"]
+    assert T.state_sha256(res) == pin["state_sha256"]
 
 
 @pytest.mark.parametrize("seed", range(8))

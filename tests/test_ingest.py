@@ -668,6 +668,40 @@ def test_replay_closes_the_loop():
     assert all(o[0] != 0 or s.pod_names[o[1]].split("/")[1] not in placed for o in res2.ops)
 
 
+@pytest.mark.gpu
+def test_gpu_decisions_close_the_loop():
+    """n3 on the device: snapshot → ingest → the configured actions on the MI355X through the C ABI → kai_ingest_decisions_json (one document: a BindRequest per
+    Allocate as cache.createBindRequest fills it, cache/cache.go:290-330; evictions with their pod group, :216-252) → fed back as the next snapshot's bind requests →
+    the pods come back Binding on the chosen nodes and a second cycle on the device places none of them again; the oracle agrees with both cycles."""
+    d = _rich_document()
+    got = ingest(d)
+
+    def cycle(g, acts):
+        ops = []
+        with pkg.KaiCore(g.config) as core:
+            ssn = core.open_session(g.snapshot)
+            for a in acts:
+                ops += [(int(o["kind"]), int(o["pod"]), int(o["node"]), int(o["job"])) for o in ssn.execute(a)]
+            ssn.close()
+        return ops
+
+    ops = cycle(got, tuple(got.actions))
+    assert ops == T.Oracle.run(got.snapshot, got.config, tuple(got.actions)).ops and any(o[0] == 0 for o in ops)
+    out = json.loads(got.decisions_json(ops))
+    assert len(out["bindRequests"]) == sum(1 for o in ops if o[0] == 0) and len(out["evictions"]) == sum(1 for o in ops if o[0] == 2)
+    for b, o in zip(out["bindRequests"], [o for o in ops if o[0] == 0]):
+        assert b["spec"]["podName"] == got.snapshot.pod_names[o[1]].split("/")[1] and b["spec"]["selectedNode"] == got.snapshot.node_names[o[2]] == b["metadata"]["labels"]["selected-node"]
+    d["rawObjects"]["bindRequests"] = out["bindRequests"]
+    nxt = ingest(d); s = nxt.snapshot
+    placed = {b["spec"]["podName"]: b["spec"]["selectedNode"] for b in out["bindRequests"]}
+    for i, n in enumerate(s.pod_names):
+        if n.split("/")[1] in placed:
+            assert s.pod_status[i] == ST["Binding"] and s.node_names[s.pod_node[i]] == placed[n.split("/")[1]]
+    ops2 = cycle(nxt, ("allocate",))
+    assert ops2 == T.Oracle.run(s, nxt.config, ("allocate",)).ops
+    assert all(o[0] != 0 or s.pod_names[o[1]].split("/")[1] not in placed for o in ops2)
+
+
 # ------------------------------------------------------------------------------------------------ shared GPUs (ABI v4)
 def test_fraction_fields_and_oracle_placement():
     """gpu-fraction annotation → pod_gpu_portion (pod_info.go:472-477), runai-gpu-group label → pod_gpu_group (numeric names keep their value,
