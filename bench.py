@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--config", default=os.environ.get("KAI_BENCH_CONFIG", "C5"), choices=sorted(CONFIGS))
     ap.add_argument("--scale", type=float, default=None, help="shrinks nodes and pods together (default 1.0; C4: 0.01 — its victim search is not engineered for full size yet, DESIGN.md section 9)")
     ap.add_argument("--actions", default="", help="comma-separated actions of one cycle (default: allocate; C4: allocate,consolidation,reclaim)")
+    ap.add_argument("--mixed", action="store_true", help="config C5 in the shape SURVEY 8d gives it: zone/rack labels, 5 %% topology gangs, 5 %% elastic gangs, minruntime — jobs the batch path leaves to the sequential engine")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="decisions the CPU oracle is timed on (-1 = auto, 0 = skip)")
     args = ap.parse_args()
 
@@ -76,10 +77,11 @@ def main():
     idx = CONFIGS[args.config]
     actions = tuple(a for a in (args.actions or ("allocate,consolidation,reclaim" if args.config == "C4" else "allocate")).split(",") if a)
     t0 = time.time()
-    # N > 1: the ranks shard the NODE axis of ONE snapshot (strong scaling: total work fixed) — every rank builds the same snapshot.
-    # KAI_BENCH_MULTI=replicas runs one independent scheduling shard per GPU instead (weak scaling, no data-path collective).
-    sharded = world > 1 and os.environ.get("KAI_BENCH_MULTI", "shard") != "replicas"
-    snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=0 if (sharded or world == 1) else pkg.dist.shard_seed(0, rank))
+    # N > 1, default: one independent scheduling shard per GPU (how KAI scales out: a scheduler instance per node pool, conf/scheduler_conf.go:95-112) — weak scaling, no data-path
+    # collective.  KAI_BENCH_MULTI=shard: the ranks shard the NODE axis of ONE snapshot instead (strong scaling; DESIGN.md section 7 explains why that cannot beat one GPU:
+    # the fill is one dependency chain, the exchange only adds to it) and the replicas run as a second leg beside it.
+    sharded = world > 1 and os.environ.get("KAI_BENCH_MULTI", "replicas") == "shard"
+    snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=0 if (sharded or world == 1) else pkg.dist.shard_seed(0, rank), mixed=args.mixed)
     gen_s = time.time() - t0
     N = snap.n_nodes
     if os.environ.get("KAI_BENCH_ENGINE_MODE"):
@@ -174,11 +176,11 @@ def main():
     out = {
         "metric": "pod placements/sec (" + " + ".join(actions) + (" action" if len(actions) == 1 else " actions") + ", synthetic snapshot)", "value": value, "unit": "placements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong" if (sharded or world == 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "placements_per_s": total_placed / elapsed,
         # every allocateTask execution is a decision; the ones k_drain resolves — jobs popped once no class fits anywhere, turned away without touching a node — are split out
-        "decisions_per_s": {"all": total_decisions / elapsed, "fill": (total_decisions - drained * args.steps * (1 if sharded or world == 1 else world)) / elapsed if batch else None,
-                            "drained": (drained * args.steps * (1 if sharded or world == 1 else world)) / elapsed if batch else None},
+        "decisions_per_s": {"all": total_decisions / elapsed, "fill": (total_decisions - drained * args.steps * (1 if sharded else world)) / elapsed if batch else None,
+                            "drained": (drained * args.steps * (1 if sharded else world)) / elapsed if batch else None},
         "config": {"workload": desc, "nodes": N, "pods": snap.n_pods, "jobs": snap.n_jobs, "queues": snap.n_queues,
                    "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2], "action_ms": k_ms,
                    "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else (f"node axis of one snapshot sharded over {world} GPUs: per exchange every rank offers its 128 best nodes per scan class, all-gather over RCCL / xGMI, the same virtual fill on every rank"
@@ -248,7 +250,7 @@ def main():
             def step2():
                 ssn2.reset(); n = 0
                 for a in actions:
-                    ssn2.execute(a); n += int(ssn2.stats().decisions)
+                    n += len(ssn2.execute(a))
                 return n
             d2 = 0
             for _ in range(args.warmup):
@@ -261,7 +263,7 @@ def main():
             el2 = pkg.dist.max_over_ranks(time.perf_counter() - t0, device=red_dev)
             tot2 = pkg.dist.sum_over_ranks(d2 * args.steps, device=red_dev)
             ssn2.close(); core2.destroy()
-            out["replicas"] = {"value": tot2 / el2, "unit": "decisions/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "weak",
+            out["replicas"] = {"value": tot2 / el2, "unit": "placements/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "weak",
                                "note": f"{world} independent scheduling shards of the same shape, one per GPU, no data-path collective (KAI_BENCH_MULTI=replicas makes this the reported value)"}
         except Exception as e:  # the second leg is additional evidence: it must not take the sharded result down with it (every rank runs the same code, so a failure is common to all)
             out["replicas"] = {"error": str(e)[:200]}

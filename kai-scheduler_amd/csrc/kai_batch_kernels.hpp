@@ -475,29 +475,12 @@ KW_BODY void kb_fill_node_changed(FillState& f, const L1& l1, int n) {
     KB_ACC(3, t_l3);
 }
 // Statement.Allocate's node side (NodeInfo.addTaskResources, node_info.go:457-493) / its undo, on the record of node n (current block)
-// `times` tasks at once: the amounts are integer multiples of one power of two with totals below 2^52 units (HostPrep::build_batch), so idle - times * v IS idle - v - v … - v
-KW_BODY void kb_fill_update_rec(const KaiCtx& c, FillState& f, int n, int kcls, double sign, int times = 1) {
+KW_BODY void kb_fill_update_rec(const KaiCtx& c, FillState& f, int n, int kcls, double sign) {
     double rq[4]; for (int r = 0; r < 4; r++) rq[r] = kw::bcast(f.creq[r], kcls);
     if (kw::lane() == (n & 63)) {
-        for (int r = 0; r < 4; r++) { if (r >= f.R) continue; const double v = rq[r]; if (v == 0) continue; f.rec.idle[r] = f.rec.idle[r] - sign * (times == 1 ? v : (double)times * v); }
+        for (int r = 0; r < 4; r++) { if (r >= f.R) continue; const double v = rq[r]; if (v == 0) continue; f.rec.idle[r] = f.rec.idle[r] - sign * v; }
         for (int r = 0; r < 4; r++) c.bt.nrec[n].idle[r] = f.rec.idle[r];
     }
-}
-// How many CONSECUTIVE tasks of scan class kcls node n (in the current block, fitting one now) takes before it stops fitting, at most `left` and at most 16 per step
-// (a longer run continues with the next step): counted up with exact products (integers below 2^53) on values every lane holds alike — no f64 division, no divergence.
-KW_BODY int kb_fill_capacity(const FillState& f, int n, int kcls, int left) {
-    const int ln = n & 63;
-    int m = left < 16 ? left : 16;
-    for (int r = 0; r < 4; r++) {
-        if (r >= f.R) continue;
-        const double v = kw::bcast(f.creq[r], kcls);
-        if (!(v > 0)) continue;
-        const double idle = kw::bcast(f.rec.idle[r], ln);
-        int t = 1; double need = v + v;
-        while (t < m && need <= idle) { t++; need += v; }  // (t + 1) * v as a sum of integers: exact
-        m = t;
-    }
-    return m;
 }
 template <int MODE, bool SPEC, class L1>
 KW_BODY void kb_fill_flush(FillState& f, const L1& l1) { if (f.pend_n >= 0) { kb_fill_node_changed<MODE, SPEC>(f, l1, f.pend_n); f.pend_n = -1; } }
@@ -515,17 +498,8 @@ KW_BODY bool kb_beats_floor(const KaiCtx& c, int kcls, uint64_t tk, int tn) {
 // LAZILY: while consecutive tasks of one class keep landing on the node that class's top pointed to — its key for the class did not drop below the top key
 // the index holds, so no other node can have overtaken it — only the node's record changes; the index entries of every class follow in one step when
 // another class is asked for, when the node stops being the class's best, or when the round ends.
-// `left` tasks of the class follow one another (a gang of one scan class): `cnt` of them go to the returned node in one step when the class key cannot fall while the
-// node fills — bin-pack (the key grows with every task, plugins/nodeplacement/pack.go:45-64) or no placement plugin (a constant) — because then every one of them would
-// find the node still on top: min(left, what the node takes).  A spread class (the key falls) and a node-sharded group (the floors) go task by task.
 template <int MODE, bool SPEC, class L1>
-KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls, int left, int& cnt) {
-    cnt = 1;
-#ifdef KAI_FILL_NO_RUNS  // A/B builds: every task on its own
-    const bool run = false; (void)left;
-#else
-    const bool run = MODE != FM_SHARDED && left > 1 && (!(kw::bcast(f.cflags, kcls) & 4u) || !(kb_plugins<SPEC>(f) & KAI_PLUGIN_NODEPLACEMENT));
-#endif
+KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls) {
     if (f.pend_n >= 0) {
         if (kcls == f.pend_cls) {
             const int ln = f.pend_n & 63;
@@ -533,7 +507,7 @@ KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls,
             const uint64_t kap = kw::bcast(mine, ln);
             bool stay = kap != 0 && kap >= f.pend_key;
             if (MODE == FM_SHARDED) stay = stay && kb_beats_floor(c, kcls, kap, f.pend_n);
-            if (stay) { if (run) cnt = kb_fill_capacity(f, f.pend_n, kcls, left); kb_fill_update_rec(c, f, f.pend_n, kcls, 1.0, cnt); return f.pend_n; }
+            if (stay) { kb_fill_update_rec(c, f, f.pend_n, kcls, 1.0); return f.pend_n; }
         }
         kb_fill_flush<MODE, SPEC>(f, l1);
     }
@@ -545,8 +519,7 @@ KW_BODY int kb_fill_place(const KaiCtx& c, FillState& f, const L1& l1, int kcls,
     }
     if (tk == 0) return -1;
     kb_fill_load_block(c, f, l1, tn >> 6);
-    if (run) cnt = kb_fill_capacity(f, tn, kcls, left);
-    kb_fill_update_rec(c, f, tn, kcls, 1.0, cnt);
+    kb_fill_update_rec(c, f, tn, kcls, 1.0);
     f.pend_n = tn; f.pend_cls = kcls; f.pend_key = tk;
     KB_ACC(0, t_p);
     return tn;
@@ -587,24 +560,14 @@ KW_BODY void kb_fill_run(const KaiCtx& c, RoundParams rp, FillLds& L, FillState&
             const int opoff = (int)ops + rp.ops0, stmtoff = (int)committed + rp.stmt0; const int64_t dec0 = decisions;  // ops0 / stmt0: what earlier launches of this round committed
             bool ok = flag != BF_GATE; int placed = 0;
             if (flag != BF_GATE) {
-                if (ucls >= 0) {  // a gang of one scan class: runs of tasks per node (kb_fill_place)
-                    while (placed < nt) {
-                        int cnt = 1;
-                        const int tn = kb_fill_place<MODE, SPEC>(c, f, l1, ucls, nt - placed, cnt);
-                        if (tn == -2) { decisions++; floor_stop = 1; ok = false; break; }
-                        if (tn < 0) { decisions++; ok = false; break; }
-                        decisions += cnt;
-                        for (int i = lane; i < cnt; i += 64) { L.placed_node[placed + i] = tn; L.placed_cls[placed + i] = ucls; b.t_node[first + placed + i] = sharded ? b.vmap[tn] : tn; }
-                        placed += cnt;
-                    }
-                } else for (int tb = 0; tb < nt && ok; tb += 64) {
-                    const int my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;  // a gang of several scan classes: its task list
+                for (int tb = 0; tb < nt && ok; tb += 64) {
+                    int my_cls = ucls;
+                    if (ucls < 0) my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;  // a gang of several scan classes: its task list
                     const int tc = nt - tb < 64 ? nt - tb : 64;
                     for (int ti = 0; ti < tc; ti++) {
-                        const int kcls = kw::bcast(my_cls, ti);
+                        const int kcls = ucls >= 0 ? ucls : kw::bcast(my_cls, ti);
                         decisions++;
-                        int cnt = 1;
-                        const int tn = kb_fill_place<MODE, SPEC>(c, f, l1, kcls, 1, cnt);
+                        const int tn = kb_fill_place<MODE, SPEC>(c, f, l1, kcls);
                         if (tn == -2) { floor_stop = 1; ok = false; break; }
                         if (tn < 0) { ok = false; break; }
                         if (lane == 0) { L.placed_node[placed] = tn; L.placed_cls[placed] = kcls; b.t_node[first + placed] = sharded ? b.vmap[tn] : tn; }

@@ -378,6 +378,7 @@ struct TopoScan {
     int32_t row0, L, domain, root, dl, R, tasks, one_pod, any;
     double mx[KAI_MAX_RES];
     KAI_GP(const uint32_t) parent;
+    KAI_GP(uint32_t) out;  // op 4: the node-set bitmap parent ∩ nodes of `domain` (domain < 0: the parent set itself; dl < 0: every node of the topology) — build_node_set
     int32_t lvl_min[KAI_TOPO_SCAN_LEVELS], lvl_max[KAI_TOPO_SCAN_LEVELS];  // results of op 1 (any = some node qualified)
 };
 // Index loops of the victim search (resets, the victims-queue filter, feasible nodes, idle GPUs per node) as one request to the backend's scan lanes:
@@ -1714,7 +1715,7 @@ struct Engine {
         const int t = tc_topo, row0 = c.topo_level_off[t], L = c.topo_level_off[t + 1] - row0, N = c.N, DT = c.D + c.T, root = c.D + t, R = c.R;
         // lowestCommonDomainID (common.go:17-67) over the nodes of `parent` that are part of the topology
         int domain = root;
-        TopoScan ts; ts.op = 1; ts.row0 = row0; ts.L = L; ts.domain = root; ts.root = root; ts.dl = 0; ts.R = R; ts.tasks = tasks; ts.one_pod = 0; ts.any = 0; ts.parent = parent;
+        TopoScan ts; ts.op = 1; ts.row0 = row0; ts.L = L; ts.domain = root; ts.root = root; ts.dl = 0; ts.R = R; ts.tasks = tasks; ts.one_pod = 0; ts.any = 0; ts.parent = parent; ts.out = nullptr;
         for (int r = 0; r < KAI_MAX_RES; r++) ts.mx[r] = 0;
         const bool scan_lanes = L <= KAI_TOPO_SCAN_LEVELS && c.exact_sums && be.topo_scan(c, ts);
         if (scan_lanes) {
@@ -1873,9 +1874,14 @@ struct Engine {
     // node set of a frame: parent ∩ nodes of the topology ∩ nodes of domain d   (d = -1: the parent set itself)
     KAI_HD void build_node_set(KAI_GP(uint32_t) out, KAI_GP(const uint32_t) parent, int d) {
         const KaiCtx& c = cx();
-        for (int w = 0; w < c.W; w++) out[w] = 0;
         int row0 = 0, dl = -1;
         if (d >= 0) { row0 = c.topo_level_off[c.dom_topo[d]]; dl = c.dom_level[d]; }
+        {   // N iterations on the control lane cost milliseconds at 64k nodes: the scan lanes build the words
+            TopoScan ts; ts.op = 4; ts.row0 = row0; ts.L = 1; ts.domain = d; ts.root = -1; ts.dl = dl; ts.R = 0; ts.tasks = 0; ts.one_pod = 0; ts.any = 0; ts.parent = parent; ts.out = out;
+            for (int r = 0; r < KAI_MAX_RES; r++) ts.mx[r] = 0;
+            if (c.N >= 64 && be.topo_scan(c, ts)) return;
+        }
+        for (int w = 0; w < c.W; w++) out[w] = 0;
         for (int n = 0; n < c.N; n++) {
             bool in = bits_has(parent, n);
             if (in && d >= 0) in = dl < 0 ? node_dom(row0, n) >= 0 : node_dom(row0 + dl, n) == d;

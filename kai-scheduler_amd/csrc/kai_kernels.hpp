@@ -592,6 +592,18 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
                     for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { const int a = __shfl_xor(mn[l], o, 64), b = __shfl_xor(mx[l], o, 64); if (a < mn[l]) mn[l] = a; if (b > mx[l]) mx[l] = b; }
                 }
                 if (lane == 0) { for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { sh->topo_min[wave][l] = mn[l]; sh->topo_max[wave][l] = mx[l]; } sh->topo_any[wave] = any; }
+            } else if (t.op == 4) {  // build_node_set: one 32-node word of the bitmap per step
+                for (int w = slot; w < c.W; w += SCAN_LANES) {
+                    uint32_t word = 0; const uint32_t pw = t.parent ? t.parent[w] : 0xffffffffu;
+                    for (int b = 0; b < 32; b++) {
+                        const int n = w * 32 + b; if (n >= c.N) break;
+                        bool in = (pw >> b) & 1u;
+                        if (in && t.domain >= 0) in = t.dl < 0 ? c.node_domain[(size_t)t.row0 * c.N + n] >= 0 : c.node_domain[(size_t)(t.row0 + t.dl) * c.N + n] == t.domain;
+                        if (in) word |= 1u << b;
+                    }
+                    t.out[w] = word;
+                }
+                __threadfence();
             } else {
                 for (int n = slot; n < c.N; n += SCAN_LANES) {
                     if (!topo_node_in_domain(c, t, n)) continue;

@@ -319,10 +319,19 @@ def add_replica_topology(snap: abi.Snapshot, seed: int, zones: int = 2, nodes_pe
     return snap.finalize()
 
 
-def config(idx: int, scale: float = 1.0, seed_offset: int = 0) -> tuple[abi.Snapshot, abi.KaiConfig, str]:
-    """BASELINE.json configs[idx] (0-based) → (snapshot, config, description).  `scale` shrinks node and pod counts together."""
+def config(idx: int, scale: float = 1.0, seed_offset: int = 0, mixed: bool = False) -> tuple[abi.Snapshot, abi.KaiConfig, str]:
+    """BASELINE.json configs[idx] (0-based) → (snapshot, config, description).  `scale` shrinks node and pod counts together.
+    mixed (config 5 only): the shape SURVEY.md section 8d writes down for it — nodes labelled 8 zones x 64 racks, 5 % of the gangs with a required rack, 5 % elastic
+    gangs (minMember below their pod count), the cluster half full of running pods, the minruntime plugin on: jobs the batch path of the allocate action does not take."""
     seed = SEED0 + idx + seed_offset
     n = lambda x: max(1, int(round(x * scale)))
+    if idx == 4 and mixed:
+        s = make_snapshot(n(65536), n(1000000), seed, queue_levels=(8, 16, 16), prefill=0.5, zipf=True, limits_frac=0.2, queue_prios=(100, 200),
+                          oqws=(1.0, 2.0, 4.0), nonpreempt_frac=0.1, usage_max=0.3, elastic_frac=0.05)
+        add_topology(s, seed, zones=min(8, max(1, n(8))), racks_per_zone=max(1, min(64, n(65536) // (8 * 4))), req_rack_frac=0.05, pref_rack_frac=0.0)
+        cfg = abi.default_config(k_value=0.5)
+        cfg.plugins |= abi.PLUGINS.get("minruntime", 0)
+        return s, cfg, f"C5-mixed {n(65536)}n x {n(1000000)}p zone/rack labels, 5% topology gangs, 5% elastic gangs, minruntime"
     if idx == 0:   # C1: 16 nodes / 64 single-pod jobs, single queue, bin-pack (plumbing)
         s = make_snapshot(16, 64, seed, queue_levels=(1, 1), prefill=0.0, single_pod_jobs=True, uniform_nodes=True, cpu_per_gpu=1000.0, mem_per_gpu=1e9)
         return s, abi.default_config(), "C1 16n x 64p single-queue bin-pack"

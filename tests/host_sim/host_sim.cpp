@@ -31,7 +31,20 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     const KaiCtx& ctx() const { return *cref; }
     EngineLocal& local() { return loc; }
     std::vector<uint64_t> s2_key, top_key; std::vector<int32_t> s2_node, top_node;
-    bool topo_scan(const KaiCtx&, TopoScan&) { return false; }
+    bool topo_scan(const KaiCtx& c, TopoScan& t) {  // the node loops of subset_nodes stay serial here; op 4 (build_node_set) word by word as the scan lanes do it
+        if (t.op != 4) return false;
+        for (int w = 0; w < c.W; w++) {
+            uint32_t word = 0; const uint32_t pw = t.parent ? t.parent[w] : 0xffffffffu;
+            for (int b = 0; b < 32; b++) {
+                const int n = w * 32 + b; if (n >= c.N) break;
+                bool in = (pw >> b) & 1u;
+                if (in && t.domain >= 0) in = t.dl < 0 ? c.node_domain[(size_t)t.row0 * c.N + n] >= 0 : c.node_domain[(size_t)(t.row0 + t.dl) * c.N + n] == t.domain;
+                if (in) word |= 1u << b;
+            }
+            t.out[w] = word;
+        }
+        return true;
+    }
     bool pfor(const KaiCtx&, const PforReq&) { return false; }
     void or32(uint32_t* w, uint32_t bits) { *w |= bits; }
     void minmax(const KaiCtx& c, int r, double& mn, double& mx) {
