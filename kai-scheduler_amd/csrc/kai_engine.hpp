@@ -376,6 +376,11 @@ struct TopoScan {
                          // 2 = Idle + Releasing of the nodes of `domain` summed into their leaf domains (calcSubTreeFreeResources :192-211; integral quantities: the order
                          //     of addition does not show)   3 = pods of the maximal request every node of `domain` takes, summed per leaf domain (calcNodeAccommodation :213-246)
     int32_t row0, L, domain, root, dl, R, tasks, one_pod, any;
+    // ops over the DOMAINS of topology `topo` (Engine::topo_dom_body, one domain per lane step): 5 = treeAllocatableCleanup (:438-445)   6 = one level of the bottom-up roll-up inside the
+    // sub-tree of `domain` (what & 1: IdleOrReleasingResources, what & 2: AllocatablePods) — level `lvl` into its parents   7 = AllocatablePods := 0 inside the sub-tree
+    // 8 = getJobRatioToFreeResources of every domain (sortTree's keys)   9 = checkJobDomainFit of the domains whose level is in `what` (bit l + 1) → chosen flags, `any` = their number
+    int32_t topo, lvl, what, pad_t;
+    double tr[KAI_MAX_RES];  // summed request of the sub-group's tasks (ops 8, 9)
     double mx[KAI_MAX_RES];
     KAI_GP(const uint32_t) parent;
     KAI_GP(uint32_t) out;  // op 4: the node-set bitmap parent ∩ nodes of `domain` (domain < 0: the parent set itself; dl < 0: every node of the topology) — build_node_set
@@ -771,7 +776,7 @@ struct EngineLocal {
     int32_t jo_kind, cur_inst;               // jo_kind 1 = victims ordering (reversed comparators, victims operands)
     int32_t tpl_valid, mw_poll;              // the pending-job template of the simulation queues matches the committed state; >= 0: this simulation's index in its wave — it is
                                              // given up as soon as an earlier simulation of the wave is known not to have simply failed (MultiCtx::hit), buffer mw_buf
-    int32_t mw_buf, pad10;
+    int32_t mw_buf, rc_early;                // rc_early: the running simulation stopped right after placing the preemptor because the reclaim validator's verdict (known then) is "no"
     struct JoSave { QNode* qn; int32_t *qheap, *root_heap, *sorted, *cur, *end, *side, *side_len; int32_t root_len, root_init, kind, pad; } save[3];
 };
 
@@ -794,7 +799,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.rc_early = 0;
         e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 
@@ -1702,6 +1707,29 @@ struct Engine {
         if (ap != -1) return ap >= count;
         return !(job_ratio(tr, d) > 1.0);
     }
+    // one domain of a TopoScan op 5..9 (the scan lanes of the action kernel run these; tests/host_sim runs them in a plain loop); returns what op 9 counts
+    KAI_HD int topo_dom_body(const TopoScan& t, int d) const {
+        const KaiCtx& c = cx();
+        if (c.dom_topo[d] != t.topo) return 0;
+        switch (t.op) {
+        case 5: c.dom_alloc_pods[d] = -1; for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = 0.0; return 0;
+        case 6: {
+            if (d >= c.D || c.dom_level[d] != t.lvl || !dom_in_subtree(d, t.domain)) return 0;
+            const int par = c.dom_parent[d];
+            if (t.what & 1) for (int r = 0; r < t.R; r++) be.add_f64((double*)&c.dom_free[(size_t)par * KAI_MAX_RES + r], c.dom_free[(size_t)d * KAI_MAX_RES + r]);  // integral amounts (exact_sums): any order of addition
+            if (t.what & 2) be.add_i32((int32_t*)&c.dom_alloc_pods[par], c.dom_alloc_pods[d]);
+            return 0; }
+        case 7: if (dom_in_subtree(d, t.domain)) c.dom_alloc_pods[d] = 0; return 0;
+        case 8: c.dom_ratio[d] = job_ratio(t.tr, d); return 0;
+        case 9: {
+            const int l = c.dom_level[d];
+            c.dom_tmp[(c.D + c.T) + d] = 0;
+            if (!((t.what >> (l + 1)) & 1)) return 0;
+            if (!domain_fits(d, t.tr, t.tasks)) return 0;
+            c.dom_tmp[(c.D + c.T) + d] = 1; return 1; }
+        }
+        return 0;
+    }
     // subSetNodesFn (plugins/topology/job_filtering.go:34-112) for a sub-group (grp = SubGroupSet, or ps = pod-set) of job j over the node set
     // `parent`.  Writes the node sets in order to sets_out: a domain index, or -1 = "the parent set as it is".  Returns their number
     // (0 = no node set / configuration error).  Control-lane code over the HBM domain tables.
@@ -1737,7 +1765,11 @@ struct Engine {
         }
         const int dl = c.dom_level[domain];
         // treeAllocatableCleanup :438-445 + calcSubTreeFreeResources :192-211 (leaf accumulation, then bottom-up inside the sub-tree)
-        for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t) { c.dom_alloc_pods[d] = -1; for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = 0.0; }
+        // the loops over the DOMAINS go to the scan lanes as well once there are enough of them (TopoScan ops 5..9, topo_dom_body); `dom_lanes` = they took the first one
+        ts.topo = t; ts.lvl = 0; ts.what = 0; for (int r = 0; r < KAI_MAX_RES; r++) ts.tr[r] = 0;
+        bool dom_lanes = false;
+        if (c.exact_sums && DT >= 16) { ts.op = 5; dom_lanes = be.topo_scan(c, ts); }
+        if (!dom_lanes) for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t) { c.dom_alloc_pods[d] = -1; for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = 0.0; }
         auto node_in_domain = [&](int n) { return L > 0 && (domain == root ? node_dom(row0, n) >= 0 : node_dom(row0 + dl, n) == domain); };
         ts.op = 2; ts.domain = domain; ts.dl = dl;
         if (!(scan_lanes && be.topo_scan(c, ts))) for (int n = 0; n < N; n++) {
@@ -1745,10 +1777,13 @@ struct Engine {
             int leaf = node_dom(row0 + L - 1, n);
             for (int r = 0; r < R; r++) { size_t x = (size_t)leaf * KAI_MAX_RES + r; c.dom_free[x] += c.n_idle[(size_t)r * N + n]; c.dom_free[x] += c.n_rel[(size_t)r * N + n]; }
         }
-        for (int lvl = L - 1; lvl > dl; lvl--) for (int d = 0; d < c.D; d++) {
-            if (c.dom_topo[d] != t || c.dom_level[d] != lvl || !dom_in_subtree(d, domain)) continue;
-            int par = c.dom_parent[d];
-            for (int r = 0; r < R; r++) c.dom_free[(size_t)par * KAI_MAX_RES + r] += c.dom_free[(size_t)d * KAI_MAX_RES + r];
+        for (int lvl = L - 1; lvl > dl; lvl--) {
+            if (dom_lanes) { ts.op = 6; ts.lvl = lvl; ts.what = 1; be.topo_scan(c, ts); continue; }
+            for (int d = 0; d < c.D; d++) {
+                if (c.dom_topo[d] != t || c.dom_level[d] != lvl || !dom_in_subtree(d, domain)) continue;
+                int par = c.dom_parent[d];
+                for (int r = 0; r < R; r++) c.dom_free[(size_t)par * KAI_MAX_RES + r] += c.dom_free[(size_t)d * KAI_MAX_RES + r];
+            }
         }
         // tasks: summed request, element-wise maximum, homogeneity (useRepresentorPodsAccounting :550-571)
         double tr[KAI_MAX_RES], mx[KAI_MAX_RES]; int scalar_users[KAI_MAX_RES], gpu_users = 0;
@@ -1763,7 +1798,8 @@ struct Engine {
         if (homogeneous) {  // calcTreeAllocatable :138-190 with calcNodeAccommodation :213-246
             bool one_pod_only = !(mx[KAI_RES_CPU] > 0) && !(mx[KAI_RES_MEM] > 0) && !(mx[KAI_RES_GPU] > 0) && mx[KAI_RES_PODS] <= 1;
             for (int r = KAI_RES_PODS + 1; r < R; r++) if (mx[r] > 0) one_pod_only = false;
-            for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t && dom_in_subtree(d, domain)) c.dom_alloc_pods[d] = 0;
+            if (dom_lanes) { ts.op = 7; be.topo_scan(c, ts); }
+            else for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t && dom_in_subtree(d, domain)) c.dom_alloc_pods[d] = 0;
             ts.op = 3; ts.one_pod = one_pod_only ? 1 : 0; for (int r = 0; r < KAI_MAX_RES; r++) ts.mx[r] = mx[r];
             if (!(scan_lanes && be.topo_scan(c, ts))) for (int n = 0; n < N; n++) {
                 if (!node_in_domain(n)) continue;
@@ -1779,9 +1815,12 @@ struct Engine {
                 }
                 c.dom_alloc_pods[node_dom(row0 + L - 1, n)] += count;
             }
-            for (int lvl = L - 1; lvl > dl; lvl--) for (int d = 0; d < c.D; d++) {
-                if (c.dom_topo[d] != t || c.dom_level[d] != lvl || !dom_in_subtree(d, domain)) continue;
-                c.dom_alloc_pods[c.dom_parent[d]] += c.dom_alloc_pods[d];
+            for (int lvl = L - 1; lvl > dl; lvl--) {
+                if (dom_lanes) { ts.op = 6; ts.lvl = lvl; ts.what = 2; be.topo_scan(c, ts); continue; }
+                for (int d = 0; d < c.D; d++) {
+                    if (c.dom_topo[d] != t || c.dom_level[d] != lvl || !dom_in_subtree(d, domain)) continue;
+                    c.dom_alloc_pods[c.dom_parent[d]] += c.dom_alloc_pods[d];
+                }
             }
         }
         if (!domain_fits(domain, tr, tasks)) return 0;
@@ -1789,11 +1828,13 @@ struct Engine {
         const int max_depth = tc_pref >= 0 ? tc_pref : tc_req;
         KAI_GP(int32_t) stack = c.dom_tmp;
         if (max_depth >= 0) {
+            bool ratios_ready = false;
+            if (dom_lanes) { ts.op = 8; for (int r = 0; r < KAI_MAX_RES; r++) ts.tr[r] = tr[r]; ratios_ready = be.topo_scan(c, ts); }  // the ratio of every domain of the topology at once
             int sp = 0; stack[sp++] = domain;
             while (sp > 0) {
                 int d = stack[--sp];
                 int b0 = c.dom_child_off[d], b1 = c.dom_child_off[d + 1];
-                for (int i = b0; i < b1; i++) c.dom_ratio[c.dom_children[i]] = job_ratio(tr, c.dom_children[i]);
+                if (!ratios_ready) for (int i = b0; i < b1; i++) c.dom_ratio[c.dom_children[i]] = job_ratio(tr, c.dom_children[i]);
                 for (int i = b0 + 1; i < b1; i++) {  // insertion sort: (ratio desc, ID asc) is a total order on siblings
                     int x = c.dom_children[i]; int k = i - 1;
                     while (k >= b0) {
@@ -1831,10 +1872,17 @@ struct Engine {
             for (int k = 0; k < c.j_n_ps[j]; k++) { int s2 = c.j_first_ps[j] + k; if ((ps >= 0 ? s2 == ps : podset_in_group(s2, grp)) && ps_act(s2) > 0) restrict_active = true; }
         }
         KAI_GP(int32_t) chosen = c.dom_tmp + DT;      // 1 = allocatable domain of a relevant level
-        for (int d = 0; d < DT; d++) chosen[d] = 0;
         int n_chosen = 0;
         bool found_pref = false, found_req = false;
-        for (int l = L - 1; l >= -1; l--) {
+        bool chosen_done = false;
+        if (dom_lanes && !restrict_active) {  // the relevant levels as a mask, every domain of them judged on the scan lanes
+            int mask = 0; bool fp = false, fq = false;
+            for (int l = L - 1; l >= -1; l--) { if (l == tc_pref && l >= 0) fp = true; if (l == tc_req && l >= 0) fq = true; if (fp || fq) mask |= 1 << (l + 1); if (fq) break; }
+            ts.op = 9; ts.what = mask; ts.any = 0; for (int r = 0; r < KAI_MAX_RES; r++) ts.tr[r] = tr[r];
+            if (be.topo_scan(c, ts)) { n_chosen = ts.any; chosen_done = true; }
+        }
+        if (!chosen_done) for (int d = 0; d < DT; d++) chosen[d] = 0;
+        if (!chosen_done) for (int l = L - 1; l >= -1; l--) {
             if (l == tc_pref && l >= 0) found_pref = true;
             if (l == tc_req && l >= 0) found_req = true;
             if (found_pref || found_req) for (int d = 0; d < DT; d++) {

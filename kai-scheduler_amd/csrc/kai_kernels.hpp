@@ -248,6 +248,8 @@ struct NullBackend {  // kernels that only need the engine's pure helpers
     __device__ bool topo_scan(const KaiCtx&, TopoScan&) { return false; }
     __device__ bool pfor(const KaiCtx&, const PforReq&) { return false; }
     __device__ void or32(uint32_t* w, uint32_t bits) { atomicOr(w, bits); }
+    __device__ static void add_f64(double* p, double v) { atomicAdd(p, v); }
+    __device__ static void add_i32(int32_t* p, int32_t v) { atomicAdd(p, v); }
     __device__ int best_node(const KaiCtx&, const ScanReq&) { return -1; }
     __device__ void begin(const KaiCtx&) {}
     __device__ bool dirty_add(int) { return true; }
@@ -397,6 +399,7 @@ struct DevBackendT {
             for (int w = 1; w < WAVES; w++) any |= sh->topo_any[w];
             t.any = any;
         }
+        if (t.op == 9) { int n = 0; for (int w = 1; w < WAVES; w++) n += sh->topo_any[w]; t.any = n; }  // chosen domains
         return true;
     }
     __device__ int best_node(const KaiCtx&, const ScanReq& q) {
@@ -592,6 +595,12 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
                     for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { const int a = __shfl_xor(mn[l], o, 64), b = __shfl_xor(mx[l], o, 64); if (a < mn[l]) mn[l] = a; if (b > mx[l]) mx[l] = b; }
                 }
                 if (lane == 0) { for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { sh->topo_min[wave][l] = mn[l]; sh->topo_max[wave][l] = mx[l]; } sh->topo_any[wave] = any; }
+            } else if (t.op >= 5) {  // loops over the domains of a topology (Engine::topo_dom_body)
+                NullBackend nb; Engine<NullBackend> eng(c, nb);
+                int cnt = 0;
+                for (int d = slot; d < c.D + c.T; d += SCAN_LANES) cnt += eng.topo_dom_body(t, d);
+                if (t.op == 9) { for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64); if (lane == 0) sh->topo_any[wave] = cnt; }
+                __threadfence();
             } else if (t.op == 4) {  // build_node_set: one 32-node word of the bitmap per step
                 for (int w = slot; w < c.W; w += SCAN_LANES) {
                     uint32_t word = 0; const uint32_t pw = t.parent ? t.parent[w] : 0xffffffffu;

@@ -31,7 +31,10 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     const KaiCtx& ctx() const { return *cref; }
     EngineLocal& local() { return loc; }
     std::vector<uint64_t> s2_key, top_key; std::vector<int32_t> s2_node, top_node;
-    bool topo_scan(const KaiCtx& c, TopoScan& t) {  // the node loops of subset_nodes stay serial here; op 4 (build_node_set) word by word as the scan lanes do it
+    static void add_f64(double* p, double v) { *p += v; }
+    static void add_i32(int32_t* p, int32_t v) { *p += v; }
+    bool topo_scan(const KaiCtx& c, TopoScan& t);  // (below: needs Engine<HostBackend>)
+    bool topo_scan_nodes(const KaiCtx& c, TopoScan& t) {  // the node loops of subset_nodes stay serial here; op 4 (build_node_set) word by word as the scan lanes do it
         if (t.op != 4) return false;
         for (int w = 0; w < c.W; w++) {
             uint32_t word = 0; const uint32_t pw = t.parent ? t.parent[w] : 0xffffffffu;
@@ -131,6 +134,16 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
 #endif
     }
 };
+
+// TopoScan ops over domains (5..9): the same per-domain bodies the scan lanes of the action kernel run (Engine::topo_dom_body), in a plain loop
+bool HostBackend::topo_scan(const KaiCtx& c, TopoScan& t) {
+    if (t.op < 5) return topo_scan_nodes(c, t);
+    HostBackend tmp; Engine<HostBackend> e(c, tmp);
+    int cnt = 0;
+    for (int d = 0; d < c.D + c.T; d++) cnt += e.topo_dom_body(t, d);
+    if (t.op == 9) t.any = cnt;
+    return true;
+}
 
 // the batch path's kernels on the lock-step emulator (kai_simt.hpp)
 struct HostLauncher {
