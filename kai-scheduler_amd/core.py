@@ -43,6 +43,8 @@ def _hip_runtime():
         _hip = C.CDLL("libamdhip64.so")
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _hip.hipMemcpy.restype = C.c_int
+        _hip.hipDeviceSynchronize.argtypes = []
+        _hip.hipDeviceSynchronize.restype = C.c_int
     return _hip
 
 
@@ -117,7 +119,10 @@ class KaiCore:
                 return 1
             dist.all_gather_into_tensor(r, s)
             if not on_host: torch.cuda.synchronize()
-            return 0 if hip.hipMemcpy(C.c_void_p(recv), C.c_void_p(r.data_ptr()), C.c_size_t(nbytes * self.world), 1 if on_host else 3) == 0 else 1
+            if hip.hipMemcpy(C.c_void_p(recv), C.c_void_p(r.data_ptr()), C.c_size_t(nbytes * self.world), 1 if on_host else 3) != 0:
+                return 1
+            # the library goes on with kernels on its own non-blocking stream, which has no implicit order with the null stream this copy ran on
+            return 0 if hip.hipDeviceSynchronize() == 0 else 1
         except Exception:  # a ctypes callback must not raise
             import traceback
             traceback.print_exc()

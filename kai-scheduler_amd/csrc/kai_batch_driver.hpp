@@ -128,6 +128,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     if (J) l.qualify((J + TB - 1) / TB, TB, c);
     if (int rc = l.read(qual, (const void*)c.bt.qual, sizeof qual)) return rc;
     if (qual[0] || qual[1]) return 0;
+    if (c.bt.world > 1 && qual[3] > c.bt.shard_k) return 0;  // a gang that needs more nodes of one rank than a rank offers per exchange would stall mid-action: this group does not take the action
     bs.ran = 1;
     int remaining = qual[2];
     l.nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);

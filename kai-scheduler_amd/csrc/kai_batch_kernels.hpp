@@ -65,6 +65,7 @@ KW_BODY void kb_qualify(const KaiCtx& c) {
         }
     }
     if (!ok) { kw::atomic_add((int32_t*)&b.qual[0], 1); return; }
+    kw::atomic_max((int32_t*)&b.qual[3], c.j_tta_n[j]);  // the largest gang (a node-sharded group compares it with the offers per class)
     b.j_clsmask[j] = mask; b.j_ucls[j] = (mask & (mask - 1)) == 0 ? __builtin_ctzll(mask) : -1;
 }
 // node records of the fill kernel from the session's node arrays (nothing is releasing on this path: the host checked)

@@ -35,8 +35,12 @@ struct SharedPods {
         shared.assign(n, 0); kind.assign(n, 0); mem.assign(n, 0); gmem.assign(n, 0); acc_gpu.assign(n, 0.0); pend_gpu.assign(n, 0.0); quota_gpu.assign(n, 0.0); mig_q.assign(n, 0.0);
         for (int r = KAI_RES_PODS + 1; r < s->n_res && r < KAI_MAX_RES; r++) { mig_g[r] = s->res_mig_gpus ? s->res_mig_gpus[r] : 0; mig_m[r] = s->res_mig_memory ? s->res_mig_memory[r] : 0; if (mig_g[r] > 0) mig = true; }
         on = any || mig;
-        if (any && s->node_gpu_memory) for (int i = 1; i < N; i++) if (s->node_gpu_memory[i] != s->node_gpu_memory[0]) { err = "shared GPUs with different node_gpu_memory values: leave the cycle to the host path"; return false; }
-        const int64_t M = (s->node_gpu_memory && N > 0) ? s->node_gpu_memory[0] : 100;
+        // one GPU memory size for the cluster — among the nodes that HAVE devices: a node without the gpu.memory label carries DefaultGpuMemory = 100 (node_info.go:673-687),
+        // which on a CPU-only node is never read
+        auto has_gpus = [&](int i) { if (s->node_allocatable[(size_t)KAI_RES_GPU * N + i] > 0) return true; for (int r = KAI_RES_PODS + 1; r < s->n_res && r < KAI_MAX_RES; r++) if (mig_g[r] > 0 && s->node_allocatable[(size_t)r * N + i] > 0) return true; return false; };
+        int first_gpu = -1;
+        if (s->node_gpu_memory) for (int i = 0; i < N; i++) if (has_gpus(i)) { if (first_gpu < 0) first_gpu = i; else if (any && s->node_gpu_memory[i] != s->node_gpu_memory[first_gpu]) { err = "shared GPUs with different node_gpu_memory values: leave the cycle to the host path"; return false; } }
+        const int64_t M = (s->node_gpu_memory && N > 0) ? s->node_gpu_memory[first_gpu >= 0 ? first_gpu : 0] : 100;
         for (int p = 0; p < P; p++) {
             const double g = s->pod_req[(size_t)KAI_RES_GPU * P + p];
             const double por = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0;

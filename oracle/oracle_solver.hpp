@@ -415,7 +415,9 @@ struct JobSolver {
         int originalNumActiveTasks = 0; for (auto* ps : pendingJob->podSets) originalNumActiveTasks += ps->numActiveUsedTasks;
         ORC_T("[orc] solve job %d cached %d pending %d\n", pendingJob->idx, (int)pendingJob->hasTasksToAllocate, pendingJob->GetNumPendingTasks());
         std::vector<PodInfo*> tasksToAllocate = ssn->GetTasksToAllocate(pendingJob, false), pendingTasks;
+#ifdef ORC_TRACE
         ORC_T("[orc] solve job %d ntasks %d\n", pendingJob->idx, (int)tasksToAllocate.size()); for (auto* t : tasksToAllocate) ORC_T("[orc]    task %d status %d virtual %d\n", t->idx, t->status, (int)t->isVirtualStatus); for (auto* t : pendingJob->AllPodsByIndex()) ORC_T("[orc]    pod %d status %d virtual %d node %d\n", t->idx, t->status, (int)t->isVirtualStatus, t->node);
+#endif
         for (auto* next : tasksToAllocate) {
             pendingTasks.push_back(next);
             bool satisfactory = pendingTasks.size() == tasksToAllocate.size();
@@ -528,7 +530,9 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 (th
         const VictimInfo& victim = kv.second;
         // splitVictimTasks :187-220 (sub-groups in name-rank order)
         std::vector<PodInfo*> core, elastic;
+#ifdef ORC_TRACE
         ORC_T("[orc] victim job %d tasks:", victim.Job->idx); for (auto* t : victim.Tasks) ORC_T(" %d", t->idx); ORC_T("\n");
+#endif
         for (auto* ps : victim.Job->podSets) {
             std::vector<PodInfo*> sub; for (auto* t : victim.Tasks) if (t->podset == ps->idx) sub.push_back(t);
             if (sub.empty()) continue;
@@ -541,7 +545,9 @@ inline bool Session::reclaimableFn(Scenario* sc) {  // proportion.go:143-220 (th
         if (res.empty()) continue;
         auto& dst = totalVictimsResources[victim.Job->queue]; dst.insert(dst.end(), res.begin(), res.end());
     }
+#ifdef ORC_TRACE
     for (auto& kv : totalVictimsResources) for (auto& r : kv.second) ORC_T("[orc] ent q%d %g %g %g\n", kv.first, r.milliCpu, r.memory, r.gpus);
+#endif
     return reclaimableCore(Q, reclaimer->queue, required, reclaimer->IsPreemptibleJob(), totalVictimsResources, cfg.reclaimer_saturation_multiplier);
 }
 // reclaimable/strategies/strategies.go: MaintainFairShareStrategy :45-60 — the reclaimee is over what it may hold; GuaranteeDeservedQuotaStrategy :62-91 — the
@@ -703,7 +709,6 @@ inline void Session::executeVictimAction(int action) {
                 }
                 JobSolver solver{this, FeasibleNodesForJob(job), [this](Scenario* sc) { return !minruntimeOn() || minruntimeValidator(sc, false); },
                     [this, job]() { return GetVictimsQueue([this, job](PodGroupInfo* v) {  // buildFilterFuncForPreempt :122-152
-                        if (v->idx == 76 && job->idx == 3) ORC_T("[orc] filter v76: preemptible %d prio %d vs %d queue %d vs %d active %d elastic %d last %lld\n", (int)v->IsPreemptibleJob(), v->priority, job->priority, v->queue, job->queue, activeAllocatedCount(v), (int)jobIsElastic(v), (long long)v->lastStartNs);
                         if (!v->IsPreemptibleJob()) return false;
                         if (v->priority >= job->priority) return false;
                         if (v->queue != job->queue) return false;

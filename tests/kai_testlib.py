@@ -557,6 +557,9 @@ def check_expectations(snap, meta, pod_status, pod_node, nodes=None, gpu_groups=
                 if "pod_gpu_memory" in snap.arrays and snap.pod_gpu_memory[p] > 0 and snap.node_gpu_memory[ni] > 0: f = float(snap.pod_gpu_memory[p]) / float(snap.node_gpu_memory[ni])
                 if f > 0: load[(ni, str(exp["GPUGroups"][0]))] = load.get((ni, str(exp["GPUGroups"][0])), 0.0) + f
         labels_ok = all(v <= 1.0 + 1e-9 for v in load.values())
+        # … the one scenario named above, nothing else: an overbooked expectation anywhere else is a broken fixture
+        if not labels_ok and meta.get("name") != "consolidate two memory jobs to free gpu":
+            errs.append("the expectations book more than one device's worth on a shared GPU group: " + ", ".join(f"{k}: {v:.2f}" for k, v in load.items() if v > 1.0 + 1e-9))
     for jname, exp in meta["expected_jobs"].items():
         if jname not in snap.job_names:
             errs.append(f"job {jname} missing"); continue
