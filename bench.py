@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--scale", type=float, default=None, help="shrinks nodes and pods together (default 1.0; C4: 0.01 — its victim search is not engineered for full size yet, DESIGN.md section 9)")
     ap.add_argument("--actions", default="", help="comma-separated actions of one cycle (default: allocate; C4: allocate,consolidation,reclaim)")
     ap.add_argument("--mixed", action="store_true", help="config C5 in the shape SURVEY 8d gives it: zone/rack labels, 5 %% topology gangs, 5 %% elastic gangs, minruntime — jobs the batch path leaves to the sequential engine")
+    ap.add_argument("--fractions", type=float, default=0.0, help="that share of the one-GPU pods asks for a fraction of one device (shared GPUs: every decision is a brute-force scan of the nodes' GPU groups — the streaming kernel of SURVEY 8d)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="decisions the CPU oracle is timed on (-1 = auto, 0 = skip)")
     args = ap.parse_args()
 
@@ -82,6 +83,9 @@ def main():
     # the fill is one dependency chain, the exchange only adds to it) and the replicas run as a second leg beside it.
     sharded = world > 1 and os.environ.get("KAI_BENCH_MULTI", "replicas") == "shard"
     snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=0 if (sharded or world == 1) else pkg.dist.shard_seed(0, rank), mixed=args.mixed)
+    if args.fractions > 0:
+        pkg.synth.add_fractions(snap, 7, frac=args.fractions)
+        desc += f" + {round(args.fractions * 100)} % of the one-GPU pods as fractions of one device"
     gen_s = time.time() - t0
     N = snap.n_nodes
     if os.environ.get("KAI_BENCH_ENGINE_MODE"):
@@ -171,8 +175,13 @@ def main():
                                        "scenarios": int(s_a.reserved[2]), "simulations": int(s_a.reserved[3]), "note": "last victim action of the cycle; one replica of the session arrays per workgroup, simulations of a partial job handed out in waves (DESIGN.md)"}
         engine.update({"path": "sequential engine", "control_cycles": {"allocate": int(st.reserved[5]), "commit_discard": int(st.reserved[6]), "total": int(st.reserved[7])}})
         alg = (decisions - drained) * b_dec; achieved = alg / (k_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(desc, "k_action"), "kernel": "k_action",
+        traffic = pmc_traffic(desc, "k_action")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_action",
                 "launches_per_step": 1, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg, "note": "decisions of k_action x (N x 128 B + 80 B) / action time; latency bound (one control lane)"}
+        if int(st.node_scans) > 0:  # decisions answered by a pass over the nodes (no class index: shared GPUs, node sets of the topology DFS): the scanner of SURVEY 8d as it runs
+            roof["scanner"] = {"scans": int(st.node_scans), "nodes_scanned": int(st.nodes_scanned), "nodes_per_s": int(st.nodes_scanned) / (k_ms * 1e-3),
+                               "workgroups": max(1, int(st.reserved[1]) >> 48), "lanes_per_workgroup": "448 (engine's) / 512 (helpers)", "achieved_physical_GBs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                               "note": "the engine's workgroup (7 scan wavefronts beside the control lane) plus the helper workgroups of the scan grid, one CU each (kai_kernels.hpp ScanGrid); physical rate = PMC FETCH_SIZE + WRITE_SIZE of k_action / its time when a pass is on file"}
     out = {
         "metric": "pod placements/sec (" + " + ".join(actions) + (" action" if len(actions) == 1 else " actions") + ", synthetic snapshot)", "value": value, "unit": "placements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

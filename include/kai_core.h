@@ -331,7 +331,9 @@ typedef struct kai_action_stats {
     int64_t reserved[8];        /* [0] index queries, [1] block refreshes / loads, [2] drained jobs | scenarios, [3] drained decisions | simulations,
                                    [4] rounds of the batch path (0 = sequential engine), [5..7] cycle / time counters of the path that ran (kai_core.hip).
                                    Victim actions (consolidation / reclaim / preempt): [1] workgroups the action ran on (default 32, environment KAI_VICTIM_WGS;
-                                   1 with shared GPUs in the session), [5] waves of simulations, [6] simulations run << 32 | simulations the reference's order reaches */
+                                   1 with shared GPUs in the session), [5] waves of simulations, [6] simulations run << 32 | simulations the reference's order reaches.
+                                   Allocate on the sequential engine of a cluster of >= 4096 nodes: bits 48.. of [1] = workgroups that took the passes over the nodes
+                                   (scan grid: the engine's own + the helpers; default 32 launched, environment KAI_SCAN_WGS, 1 = off) */
 } kai_action_stats;
 
 typedef struct kai_core kai_core; /* opaque */

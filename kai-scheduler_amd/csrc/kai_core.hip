@@ -52,6 +52,7 @@ struct kai_core {
     struct AllocRec { size_t field_off; char* base; size_t bytes; };
     std::vector<AllocRec> allocs; char* sv_base = nullptr; size_t sv_bytes = 0; char* xr_base = nullptr; size_t xr_bytes = 0;
     int mw_world = 0; char* rep_mem = nullptr; size_t rep_stride = 0; KaiCtx* d_ctxs = nullptr; MultiCtx* d_mw = nullptr; void* d_segs = nullptr; int n_segs = 0;
+    ScanGrid* d_sg = nullptr;  // the scan grid's table (allocate action on the sequential engine, kai_kernels.hpp)
 };
 
 #define HIP_TRY(core, expr)                                                                                        \
@@ -125,7 +126,7 @@ int dupload_f(kai_core* core, F& field, const T* host, size_t n) {
 void free_session(kai_core* core) {
     for (void* p : core->bufs) (void)hipFree(p);
     core->bufs.clear(); core->slab = nullptr; core->slab_left = 0;
-    core->allocs.clear(); core->sv_base = nullptr; core->xr_base = nullptr; core->mw_world = 0; core->rep_mem = nullptr; core->d_ctxs = nullptr; core->d_mw = nullptr; core->d_segs = nullptr;
+    core->allocs.clear(); core->sv_base = nullptr; core->xr_base = nullptr; core->mw_world = 0; core->rep_mem = nullptr; core->d_ctxs = nullptr; core->d_mw = nullptr; core->d_segs = nullptr; core->d_sg = nullptr;
     core->open = false;
 }
 int fail(kai_core* core, int code, const char* msg) { core->err = msg; return code; }
@@ -439,7 +440,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dupload_f(core, c.dom_parent, prep.dom_parent.data(), prep.dom_parent.size())); TRY(dupload_f(core, c.dom_id_rank, prep.dom_id_rank.data(), prep.dom_id_rank.size()));
     TRY(dupload_f(core, c.dom_child_off, prep.dom_child_off.data(), prep.dom_child_off.size())); TRY(dupload_f(core, c.dom_children, prep.dom_children.data(), prep.dom_children.size()));
     { const size_t DT = (size_t)prep.D + prep.T;
-      TRY(dzero_f(core, c.dom_alloc_pods, DT)); TRY(dzero_f(core, c.dom_free, DT * KAI_MAX_RES)); TRY(dzero_f(core, c.dom_tmp, 3 * DT + 4)); TRY(dzero_f(core, c.dom_ratio, DT));
+      TRY(dzero_f(core, c.dom_alloc_pods, DT)); TRY(dzero_f(core, c.dom_free, DT * KAI_MAX_RES)); TRY(dzero_f(core, c.dom_tmp, 3 * DT + 4)); TRY(dzero_f(core, c.dom_ratio, DT)); TRY(dzero_f(core, c.dom_key, 2 * DT));
       TRY(dzero_f(core, c.ns_bits, (size_t)KAI_TDEPTH * std::max(c.W, 1))); TRY(dzero_f(core, c.ns_sets, (size_t)KAI_TDEPTH * (DT + 1)));
       TRY(dzero_f(core, c.sg_score, (size_t)KAI_TKEYS * std::max<size_t>(DT, 1))); TRY(dzero_f(core, c.sg_key, (size_t)KAI_TKEYS)); TRY(dzero_f(core, c.sg_row, (size_t)KAI_TKEYS)); }
     TRY(dupload_f(core, c.g_job, prep.g_job.data(), prep.g_job.size())); TRY(dupload_f(core, c.g_parent, prep.g_parent.data(), prep.g_parent.size()));
@@ -574,7 +575,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     const int TB = 256;
     if (c.J) hipLaunchKernelGGL(k_job_init, dim3((c.J + TB - 1) / TB), dim3(TB), 0, core->stream, c);
     if (c.Q) hipLaunchKernelGGL(k_leaf_init, dim3((c.Q + 3) / 4), dim3(TB), 0, core->stream, c);
-    BatchStats bs; core->batch_plan_ms = core->batch_fill_ms = core->batch_apply_ms = 0; int g_run = 1;
+    BatchStats bs; core->batch_plan_ms = core->batch_fill_ms = core->batch_apply_ms = 0; int g_run = 1, scan_wgs_used = 1;
     if (!victim) {  // the batch path (plan / fill / apply rounds, kai_batch.hpp) when the action qualifies
         DevLauncher dl{core};
         int rcb = batch_allocate(dl, c, core->shape, bs);
@@ -601,13 +602,30 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
             want = std::max(1, std::min(std::min(want, (int)KAI_MW_MAX), cus));  // every workgroup must be resident: they meet at a grid barrier
             int rcm = prepare_multi(core, want, &g_run); if (rcm) return rcm;
         }
+        // the allocate action of a large cluster: helper workgroups beside the engine's take the passes over the nodes (ScanGrid, kai_kernels.hpp)
+        int scan_wgs = 1;
+        if (!victim) {
+            int want = c.N >= 4096 ? 32 : 1; if (const char* e = std::getenv("KAI_SCAN_WGS")) want = std::atoi(e);  // (measured on the mixed config 5 and on config 3 with fractions: 16 .. 32 workgroups are the fastest, 64 and more pay for the table they all watch)
+            int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, core->device) != hipSuccess || cus <= 0) cus = 64;
+            want = std::max(1, std::min(std::min(want, (int)KAI_SG_MAX), cus / 2));  // every workgroup must be resident (the control lane waits for the helpers); half the chip leaves room for a neighbour
+            if (want > 1 && !core->d_sg) { ScanGrid* g = nullptr; int rcg = dalloc(core, &g, (size_t)1); if (rcg) return rcg; core->d_sg = g; }
+            if (want > 1) {
+                HIP_TRY(core, hipMemsetAsync(core->d_sg, 0, sizeof(ScanGrid), core->stream));
+                c.sg = core->d_sg; c.sg_wgs = want; c.sg_per = (((c.N + want - 1) / want + 63) / 64) * 64;
+                HIP_TRY(core, hipMemcpyAsync(core->d_ctx, &core->ctx, sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
+                HIP_TRY(core, hipStreamSynchronize(core->stream));
+                c.sg = nullptr; c.sg_wgs = 0; c.sg_per = 0;  // (the host copy is what every other kernel of the session gets by value)
+                scan_wgs = want;
+            }
+        }
         auto launch = [&](auto kernel) -> int {
             HIP_TRY(core, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(kernel, dim3(g_run), dim3(WG), dyn, core->stream, g_run > 1 ? (const KaiCtx*)core->d_ctxs : (const KaiCtx*)core->d_ctx, action, tree_in_lds);
+            hipLaunchKernelGGL(kernel, dim3(victim ? g_run : scan_wgs), dim3(WG), dyn, core->stream, g_run > 1 ? (const KaiCtx*)core->d_ctxs : (const KaiCtx*)core->d_ctx, action, tree_in_lds, victim ? 1 : scan_wgs);
             return KAI_OK;
         };
         int rcl = victim ? launch(k_action<true, false>) : tree_in_lds ? launch(k_action<false, true>) : launch(k_action<false, false>);
         if (rcl) return rcl;
+        scan_wgs_used = scan_wgs;
     }
     if (c.J && !victim) hipLaunchKernelGGL(k_drain, dim3(std::min(2048, (c.J + TB - 1) / TB)), dim3(TB), 0, core->stream, c, core->d_slot_queue);
     HIP_TRY(core, hipGetLastError());
@@ -631,6 +649,11 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
             (long long)bs.rounds, (long long)bs.mismatches, (long long)bs.planned, bs.max_h, (long long)bs.fill_cycles, (long long)bs.fill_load, (long long)bs.fill_update, (long long)bs.fill_rescan,
             (long long)bs.block_loads, (long long)bs.rescans1, (long long)bs.rescans2, (long long)bs.rescans3, core->batch_plan_ms, core->batch_fill_ms, core->batch_apply_ms);
     } else { core->stats.reserved[4] = 0; core->stats.reserved[5] = st.prof[2]; core->stats.reserved[6] = st.prof[3]; core->stats.reserved[7] = st.prof[7]; }
+    if (!victim && !bs.ran && scan_wgs_used > 1) {  // sequential allocate with a scan grid: bits 48.. of [1] = workgroups that took the passes over the nodes (the engine's + the helpers that signed on)
+        int32_t nreg = 0; HIP_TRY(core, hipMemcpyAsync(&nreg, &core->d_sg->n_reg, sizeof nreg, hipMemcpyDeviceToHost, core->stream)); HIP_TRY(core, hipStreamSynchronize(core->stream));
+        core->stats.reserved[1] |= (int64_t)(nreg + 1) << 48;
+        if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai scan grid: %d workgroups launched, %d helpers signed on\n", scan_wgs_used, nreg);
+    }
     if (victim) {  // victim actions: [1] workgroups the action ran on, [5] waves, [6] simulations run (speculative ones included) << 32 | simulations the reference's order reached
         core->stats.reserved[1] = g_run;
         if (g_run > 1) {

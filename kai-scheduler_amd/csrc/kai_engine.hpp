@@ -279,6 +279,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
 }
 
 // All pointers are device memory (HBM).  [R][N] arrays are resource-major.  Node index = name rank.
+struct ScanGrid;
 struct KaiCtx {
     int32_t N, P, S, J, Q, R, n_pod_classes, n_node_classes;
     uint32_t plugins; int32_t gpu_strategy, cpu_strategy, restrict_nodes; double k_value;
@@ -323,6 +324,7 @@ struct KaiCtx {
     KAI_GP(int32_t) dom_alloc_pods; KAI_GP(double) dom_free;         // [D+T], [D+T][KAI_MAX_RES] AllocatablePods / IdleOrReleasingResources
     KAI_GP(int32_t) dom_tmp;                                         // [3*(D+T)+4] scratch: chosen flags, BFS queue
     KAI_GP(double) dom_ratio;                                        // [D+T] scratch of sortTree
+    KAI_GP(int64_t) dom_key;                                         // [2 (D+T)] scratch of sortDomainInfos on the scan lanes: a domain's path from the root as one number
     // sub-group tree
     KAI_GP(const int32_t) g_job, g_parent; KAI_GP(const uint32_t) g_name_rank; KAI_GP(const int32_t) g_topo, g_req, g_pref, j_root_group;
     KAI_GP(const int32_t) g_child_off, g_children;                   // CSR of child groups
@@ -361,6 +363,7 @@ struct KaiCtx {
     KAI_GP(int32_t) next_new_group;       // [1] uuid.NewUUID() of findGpuForSharingOnNode
     int32_t shared_on, pad_sh;
 #endif
+    struct ScanGrid* sg; int32_t sg_wgs, sg_per;  // allocate action on the sequential engine: node scans spread over sg_wgs workgroups (0 / 1: this workgroup only), sg_per nodes each (kai_kernels.hpp)
     MultiCtx* mw; int32_t mw_rank, mw_world;  // victim search on several workgroups: the block they share (null / world 1 = one workgroup), this replica's rank
     int32_t exact_sums, pad_es;  // HostPrep::exact_sums: integral quantities with totals below 2^52 units — parallel sums of them are exact
 };
@@ -368,6 +371,16 @@ struct KaiCtx {
 // ======================================================================================================
 // per-node arithmetic shared by every scanner
 // ======================================================================================================
+#ifndef KAI_DOM_LANES_MIN
+#define KAI_DOM_LANES_MIN 16  // domains of a topology from which the loops over them go to the scan lanes (tests/host_sim overrides it to cover the path on small trees)
+#endif
+#ifdef KAI_PROF_VICTIM
+#define KAI_TCLK(slot) { int64_t tnow_ = be.clock(); el().h.prof[slot] += tnow_ - tclk_; tclk_ = tnow_; }
+#define KAI_TCLK0 int64_t tclk_ = be.clock();
+#else
+#define KAI_TCLK(slot)
+#define KAI_TCLK0
+#endif
 // The node loops of the topology plugin's subSetNodesFn (plugins/topology/job_filtering.go) as one request to the backend's scan lanes: Backend::topo_scan
 // returns false when it has none (the engine then walks the nodes itself).
 constexpr int KAI_TOPO_SCAN_LEVELS = 8;
@@ -379,6 +392,9 @@ struct TopoScan {
     // ops over the DOMAINS of topology `topo` (Engine::topo_dom_body, one domain per lane step): 5 = treeAllocatableCleanup (:438-445)   6 = one level of the bottom-up roll-up inside the
     // sub-tree of `domain` (what & 1: IdleOrReleasingResources, what & 2: AllocatablePods) — level `lvl` into its parents   7 = AllocatablePods := 0 inside the sub-tree
     // 8 = getJobRatioToFreeResources of every domain (sortTree's keys)   9 = checkJobDomainFit of the domains whose level is in `what` (bit l + 1) → chosen flags, `any` = their number
+    // 10 / 11 = sortTreeFromRoot: every child's place among its siblings, the new order back   12 / 13 / 14 = sortDomainInfos: positions, paths as numbers, the chosen domains in order → out
+    // 15 = the SURVEY: ops 1, 2 and 3 in ONE pass over the nodes (level minima / maxima over `parent`; Idle + Releasing and — what & 2 — the pod counts of EVERY node of the
+    // topology into its leaf domain, counts in dom_tmp[2 DT ..])   16 = what the survey gathered outside the sub-tree of `domain` is dropped, the counts inside become AllocatablePods
     int32_t topo, lvl, what, pad_t;
     double tr[KAI_MAX_RES];  // summed request of the sub-group's tasks (ops 8, 9)
     double mx[KAI_MAX_RES];
@@ -393,6 +409,21 @@ struct PforReq { int32_t op, n, a, b; };
 KAI_HD bool topo_node_in_domain(const KaiCtx& c, const TopoScan& t, int n) {
     if (t.L <= 0) return false;
     return t.domain == t.root ? c.node_domain[(size_t)t.row0 * c.N + n] >= 0 : c.node_domain[(size_t)(t.row0 + t.dl) * c.N + n] == t.domain;
+}
+// calcNodeAccommodation (plugins/topology/job_filtering.go:213-246) against av = Idle + Releasing of one node: how many pods of the maximal request fit, the k-th test pod
+// being k x that request by repeated addition (the comparisons of fits(), on values held in registers)
+KAI_HD int topo_node_count(const TopoScan& t, const double* av) {
+    if (t.one_pod) return t.tasks;
+    double cur[KAI_MAX_RES]; for (int r = 0; r < KAI_MAX_RES; r++) cur[r] = t.mx[r];
+    int count = 0;
+    for (;;) {
+        bool ok = true;
+        for (int r = 0; r < KAI_MAX_RES; r++) if (r < t.R) { const double rq = cur[r]; if (r >= KAI_RES_PODS && !(rq > 0)) continue; if (rq > av[r]) ok = false; }
+        if (!ok) break;
+        count++;
+        for (int r = 0; r < KAI_MAX_RES; r++) if (r < t.R) cur[r] += t.mx[r];
+    }
+    return count;
 }
 struct ScanReq {
     int32_t pod, cpu_only, best_effort, pod_class, nominated, r_place, strategy, pad;
@@ -776,6 +807,7 @@ struct EngineLocal {
     int32_t jo_kind, cur_inst;               // jo_kind 1 = victims ordering (reversed comparators, victims operands)
     int32_t tpl_valid, mw_poll;              // the pending-job template of the simulation queues matches the committed state; >= 0: this simulation's index in its wave — it is
                                              // given up as soon as an earlier simulation of the wave is known not to have simply failed (MultiCtx::hit), buffer mw_buf
+    int32_t sg_gen, pad_sg;                  // scan grid: number of the last command the control lane put on the table (kai_kernels.hpp)
     int32_t mw_buf, rc_early;                // rc_early: the running simulation stopped right after placing the preemptor because the reclaim validator's verdict (known then) is "no"
     struct JoSave { QNode* qn; int32_t *qheap, *root_heap, *sorted, *cur, *end, *side, *side_len; int32_t root_len, root_init, kind, pad; } save[3];
 };
@@ -1708,11 +1740,32 @@ struct Engine {
         return !(job_ratio(tr, d) > 1.0);
     }
     // one domain of a TopoScan op 5..9 (the scan lanes of the action kernel run these; tests/host_sim runs them in a plain loop); returns what op 9 counts
+    // is `p` a domain whose children sortTreeFromRoot re-orders?  The walk starts at t.domain (level t.dl) and does not descend below level t.lvl
+    KAI_HD bool sort_visits(const TopoScan& t, int p) const {
+        if (!dom_in_subtree(p, t.domain)) return false;
+        return !(t.dl <= t.lvl && t.lvl < cx().dom_level[p]);
+    }
     KAI_HD int topo_dom_body(const TopoScan& t, int d) const {
         const KaiCtx& c = cx();
-        if (c.dom_topo[d] != t.topo) return 0;
+        const int DT = c.D + c.T;
+        if (t.op == 11 || t.op == 12) {  // d = a slot of the children table
+            if (d >= c.dom_child_off[DT]) return 0;
+            const int x = c.dom_children[d];
+            if (c.dom_topo[x] != t.topo) return 0;
+            const int p = c.dom_parent[x];
+            if (t.op == 11) { if (sort_visits(t, p)) c.dom_children[d] = c.dom_tmp[d]; }  // the sorted order back (a slot only ever holds children of one parent)
+            else c.dom_tmp[x] = d - c.dom_child_off[p];                                  // position among the siblings
+            return 0;
+        }
+        if (c.dom_topo[d] != t.topo) { if (t.op == 13) c.dom_key[2 * (size_t)d + 1] = -100; return 0; }  // (op 14 counts over every entry of the table)
         switch (t.op) {
-        case 5: c.dom_alloc_pods[d] = -1; for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = 0.0; return 0;
+        case 5: c.dom_alloc_pods[d] = -1; c.dom_tmp[2 * DT + d] = 0; for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = 0.0; return 0;
+        case 16: {
+            if (!dom_in_subtree(d, t.domain)) { for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = 0.0; return 0; }
+            // what the survey gathered is read coherently (other workgroups of a scan grid added to it behind this one's L2) and, for the sums, stored again for the plain loads that follow
+            if (c.dom_level[d] == t.L - 1) for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = be.coh_f64(&c.dom_free[(size_t)d * KAI_MAX_RES + r]);
+            if (t.what & 2) c.dom_alloc_pods[d] = c.dom_level[d] == t.L - 1 ? be.coh_i32(&c.dom_tmp[2 * DT + d]) : 0;
+            return 0; }
         case 6: {
             if (d >= c.D || c.dom_level[d] != t.lvl || !dom_in_subtree(d, t.domain)) return 0;
             const int par = c.dom_parent[d];
@@ -1727,6 +1780,25 @@ struct Engine {
             if (!((t.what >> (l + 1)) & 1)) return 0;
             if (!domain_fits(d, t.tr, t.tasks)) return 0;
             c.dom_tmp[(c.D + c.T) + d] = 1; return 1; }
+        case 10: {  // sortTreeFromRoot: (ratio descending, ID ascending) is a total order on siblings, so a child's place is the number of siblings in front of it
+            if (d >= c.D) return 0;
+            const int p = c.dom_parent[d];
+            if (!sort_visits(t, p)) return 0;
+            const int b0 = c.dom_child_off[p], b1 = c.dom_child_off[p + 1];
+            const double rx = c.dom_ratio[d]; const uint32_t ix = c.dom_id_rank[d];
+            int r = 0;
+            for (int i = b0; i < b1; i++) { const int y = c.dom_children[i]; if (y == d) continue; const double ry = c.dom_ratio[y]; if (ry > rx || (ry == rx && c.dom_id_rank[y] < ix)) r++; }
+            c.dom_tmp[b0 + r] = d; return 0; }
+        case 13: {  // the path from the root as a number with base DT digits: the order of the level-order walk inside one level; beside it the level of a chosen domain (else a level nothing has)
+            int64_t key = 0, mul = 1;
+            for (int a = d; a >= 0 && c.dom_level[a] >= 0; a = c.dom_parent[a]) { key += (int64_t)c.dom_tmp[a] * mul; mul *= DT; }
+            c.dom_key[2 * (size_t)d] = key; c.dom_key[2 * (size_t)d + 1] = c.dom_tmp[DT + d] ? c.dom_level[d] : -100; return 0; }
+        case 14: {  // sortDomainInfos: deepest level first, level-order inside a level — a chosen domain's place is the number of chosen ones in front of it
+            if (!c.dom_tmp[DT + d]) return 0;
+            const int64_t l = c.dom_level[d], k = c.dom_key[2 * (size_t)d];
+            int r = 0;
+            for (int e = 0; e < DT; e++) { const int64_t ke = c.dom_key[2 * (size_t)e], le = c.dom_key[2 * (size_t)e + 1]; r += (int)((le > l) | ((le == l) & (ke < k))); }
+            ((KAI_GP(int32_t))t.out)[r] = d; return 0; }
         }
         return 0;
     }
@@ -1741,10 +1813,46 @@ struct Engine {
         int tasks = 0; for (int i = 0; i < nt; i++) if (task_in_subgroup(chunk[i], grp, ps)) tasks++;
         if (tc_topo < 0 || tasks == 0) { sets_out[0] = -1; return 1; }
         const int t = tc_topo, row0 = c.topo_level_off[t], L = c.topo_level_off[t + 1] - row0, N = c.N, DT = c.D + c.T, root = c.D + t, R = c.R;
+        // tasks: summed request, element-wise maximum, homogeneity (useRepresentorPodsAccounting :550-571)
+        double tr[KAI_MAX_RES], mx[KAI_MAX_RES]; int scalar_users[KAI_MAX_RES], gpu_users = 0;
+        for (int r = 0; r < KAI_MAX_RES; r++) { tr[r] = 0; mx[r] = 0; scalar_users[r] = 0; }
+        for (int i = 0; i < nt; i++) {
+            int p = chunk[i]; if (!task_in_subgroup(p, grp, ps)) continue;
+            for (int r = 0; r < R; r++) { double v = preq(p, r); tr[r] += v; if (v > mx[r]) mx[r] = v; if (r >= KAI_RES_PODS && v != 0) scalar_users[r]++; }
+            if (preq(p, KAI_RES_GPU) > 0) gpu_users++;
+        }
+        bool homogeneous = !(gpu_users != tasks && gpu_users != 0);
+        for (int r = KAI_RES_PODS; r < R; r++) if (scalar_users[r] != 0 && scalar_users[r] != tasks) homogeneous = false;
+        bool one_pod_only = !(mx[KAI_RES_CPU] > 0) && !(mx[KAI_RES_MEM] > 0) && !(mx[KAI_RES_GPU] > 0) && mx[KAI_RES_PODS] <= 1;
+        for (int r = KAI_RES_PODS + 1; r < R; r++) if (mx[r] > 0) one_pod_only = false;
         // lowestCommonDomainID (common.go:17-67) over the nodes of `parent` that are part of the topology
-        int domain = root;
+        int domain = root, dl = -1;
+        KAI_TCLK0
         TopoScan ts; ts.op = 1; ts.row0 = row0; ts.L = L; ts.domain = root; ts.root = root; ts.dl = 0; ts.R = R; ts.tasks = tasks; ts.one_pod = 0; ts.any = 0; ts.parent = parent; ts.out = nullptr;
         for (int r = 0; r < KAI_MAX_RES; r++) ts.mx[r] = 0;
+        ts.topo = t; ts.lvl = 0; ts.what = 0; for (int r = 0; r < KAI_MAX_RES; r++) ts.tr[r] = 0;
+        bool dom_lanes = false, surveyed = false;
+        // the loops over the DOMAINS go to the scan lanes once there are enough of them (TopoScan ops 5..16, topo_dom_body); `dom_lanes` = they took the first one
+        if (c.exact_sums && DT >= KAI_DOM_LANES_MIN) { ts.op = 5; dom_lanes = be.topo_scan(c, ts); }  // treeAllocatableCleanup :438-445
+        if (dom_lanes && L > 0 && L <= KAI_TOPO_SCAN_LEVELS) {
+            // one pass over the nodes for the three node loops of the function: the common domain of `parent`, Idle + Releasing per leaf domain, and (homogeneous tasks) the
+            // pods every node accommodates per leaf domain — gathered for the whole topology, then cut down to the sub-tree of the common domain
+            ts.op = 15; ts.what = homogeneous ? 2 : 0; ts.one_pod = one_pod_only ? 1 : 0; for (int r = 0; r < KAI_MAX_RES; r++) ts.mx[r] = mx[r];
+            surveyed = be.topo_scan(c, ts);
+        }
+        if (surveyed) {
+            for (int l = 0; l < L; l++) {
+                if (!ts.any || ts.lvl_min[l] != ts.lvl_max[l]) break;
+                domain = ts.lvl_min[l];
+                if (tc_pref == l) break;
+            }
+            dl = c.dom_level[domain];
+            KAI_TCLK(21)
+            ts.op = 16; ts.domain = domain; ts.dl = dl; be.topo_scan(c, ts);
+            for (int lvl = L - 1; lvl > dl; lvl--) { ts.op = 6; ts.lvl = lvl; ts.what = homogeneous ? 3 : 1; be.topo_scan(c, ts); }  // calcSubTreeFreeResources :192-211 + calcTreeAllocatable :138-190, one level at a time
+            KAI_TCLK(22)
+        } else {
+        ts.op = 1;
         const bool scan_lanes = L <= KAI_TOPO_SCAN_LEVELS && c.exact_sums && be.topo_scan(c, ts);
         if (scan_lanes) {
             for (int l = 0; l < L; l++) {
@@ -1763,12 +1871,9 @@ struct Engine {
             domain = v;
             if (tc_pref == l) break;
         }
-        const int dl = c.dom_level[domain];
+        dl = c.dom_level[domain];
+        KAI_TCLK(21)
         // treeAllocatableCleanup :438-445 + calcSubTreeFreeResources :192-211 (leaf accumulation, then bottom-up inside the sub-tree)
-        // the loops over the DOMAINS go to the scan lanes as well once there are enough of them (TopoScan ops 5..9, topo_dom_body); `dom_lanes` = they took the first one
-        ts.topo = t; ts.lvl = 0; ts.what = 0; for (int r = 0; r < KAI_MAX_RES; r++) ts.tr[r] = 0;
-        bool dom_lanes = false;
-        if (c.exact_sums && DT >= 16) { ts.op = 5; dom_lanes = be.topo_scan(c, ts); }
         if (!dom_lanes) for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t) { c.dom_alloc_pods[d] = -1; for (int r = 0; r < KAI_MAX_RES; r++) c.dom_free[(size_t)d * KAI_MAX_RES + r] = 0.0; }
         auto node_in_domain = [&](int n) { return L > 0 && (domain == root ? node_dom(row0, n) >= 0 : node_dom(row0 + dl, n) == domain); };
         ts.op = 2; ts.domain = domain; ts.dl = dl;
@@ -1785,19 +1890,8 @@ struct Engine {
                 for (int r = 0; r < R; r++) c.dom_free[(size_t)par * KAI_MAX_RES + r] += c.dom_free[(size_t)d * KAI_MAX_RES + r];
             }
         }
-        // tasks: summed request, element-wise maximum, homogeneity (useRepresentorPodsAccounting :550-571)
-        double tr[KAI_MAX_RES], mx[KAI_MAX_RES]; int scalar_users[KAI_MAX_RES], gpu_users = 0;
-        for (int r = 0; r < KAI_MAX_RES; r++) { tr[r] = 0; mx[r] = 0; scalar_users[r] = 0; }
-        for (int i = 0; i < nt; i++) {
-            int p = chunk[i]; if (!task_in_subgroup(p, grp, ps)) continue;
-            for (int r = 0; r < R; r++) { double v = preq(p, r); tr[r] += v; if (v > mx[r]) mx[r] = v; if (r >= KAI_RES_PODS && v != 0) scalar_users[r]++; }
-            if (preq(p, KAI_RES_GPU) > 0) gpu_users++;
-        }
-        bool homogeneous = !(gpu_users != tasks && gpu_users != 0);
-        for (int r = KAI_RES_PODS; r < R; r++) if (scalar_users[r] != 0 && scalar_users[r] != tasks) homogeneous = false;
+        KAI_TCLK(22)
         if (homogeneous) {  // calcTreeAllocatable :138-190 with calcNodeAccommodation :213-246
-            bool one_pod_only = !(mx[KAI_RES_CPU] > 0) && !(mx[KAI_RES_MEM] > 0) && !(mx[KAI_RES_GPU] > 0) && mx[KAI_RES_PODS] <= 1;
-            for (int r = KAI_RES_PODS + 1; r < R; r++) if (mx[r] > 0) one_pod_only = false;
             if (dom_lanes) { ts.op = 7; be.topo_scan(c, ts); }
             else for (int d = 0; d < DT; d++) if (c.dom_topo[d] == t && dom_in_subtree(d, domain)) c.dom_alloc_pods[d] = 0;
             ts.op = 3; ts.one_pod = one_pod_only ? 1 : 0; for (int r = 0; r < KAI_MAX_RES; r++) ts.mx[r] = mx[r];
@@ -1823,6 +1917,9 @@ struct Engine {
                 }
             }
         }
+        }
+        ts.domain = domain; ts.dl = dl;
+        KAI_TCLK(23)
         if (!domain_fits(domain, tr, tasks)) return 0;
         // sortTreeFromRoot :447-486: children by ratio descending, then by domain ID, down to the preferred (else required) level
         const int max_depth = tc_pref >= 0 ? tc_pref : tc_req;
@@ -1830,7 +1927,12 @@ struct Engine {
         if (max_depth >= 0) {
             bool ratios_ready = false;
             if (dom_lanes) { ts.op = 8; for (int r = 0; r < KAI_MAX_RES; r++) ts.tr[r] = tr[r]; ratios_ready = be.topo_scan(c, ts); }  // the ratio of every domain of the topology at once
-            int sp = 0; stack[sp++] = domain;
+            bool sorted = false;
+            if (ratios_ready) {  // every child's place among its siblings at once, then the new order back into the table
+                ts.op = 10; ts.lvl = max_depth;
+                if (be.topo_scan(c, ts)) { ts.op = 11; be.topo_scan(c, ts); sorted = true; }
+            }
+            int sp = 0; if (!sorted) stack[sp++] = domain;
             while (sp > 0) {
                 int d = stack[--sp];
                 int b0 = c.dom_child_off[d], b1 = c.dom_child_off[d + 1];
@@ -1849,6 +1951,7 @@ struct Engine {
                 for (int i = b0; i < b1; i++) stack[sp++] = c.dom_children[i];
             }
         }
+        KAI_TCLK(24)
         if (tc_pref >= 0) {  // calculateNodeScores (node_scoring.go:37-69): i-th preferred-level domain in tree order scores floor((i+1)/n*10)*10000
             int slot = -1; for (int i = 0; i < el().n_keys; i++) if (c.sg_key[i] == key) slot = i;
             if (slot < 0) { if (el().n_keys >= KAI_TKEYS) { fault(FAULT_INTERNAL); return 0; } slot = el().n_keys++; c.sg_key[slot] = key; }
@@ -1864,6 +1967,7 @@ struct Engine {
                 }
             }
         }
+        KAI_TCLK(25)
         // getJobAllocatableDomains :265-310 over calculateRelevantDomainLevels :381-425 (from the preferred level up to the required one)
         if (tc_req < 0 && tc_pref < 0) return 0;
         if (tc_req >= L || tc_pref >= L) return 0;  // a level the topology does not have
@@ -1901,8 +2005,20 @@ struct Engine {
             }
             if (found_req) break;
         }
+        KAI_TCLK(26)
         if (!n_chosen) return 0;
         // sortDomainInfos :526-542: bottom-up level order of the tree from the topology root
+        if (chosen_done && DT <= 4096) {  // on the scan lanes: positions among siblings, paths as numbers, a chosen domain's place = the chosen ones in front of it
+            bool fits64 = true; int64_t m = 1;
+            for (int l = 0; l < L; l++) { if (m > (int64_t)0x7fffffffffffffffll / DT) { fits64 = false; break; } m *= DT; }
+            if (fits64) {
+                ts.op = 12; be.topo_scan(c, ts);
+                ts.op = 13; be.topo_scan(c, ts);
+                ts.op = 14; ts.out = (KAI_GP(uint32_t))sets_out; be.topo_scan(c, ts);
+                KAI_TCLK(27)
+                return n_chosen;
+            }
+        }
         KAI_GP(int32_t) ord = c.dom_tmp + 2 * DT;
         int n_ord = 0, lvl_start[KAI_MAX_RES * 4], n_lvls = 0;
         ord[n_ord++] = root; lvl_start[n_lvls++] = 0;
@@ -1917,6 +2033,7 @@ struct Engine {
             int b = lvl_start[lv], e = lv + 1 < n_lvls ? lvl_start[lv + 1] : n_ord;
             for (int i = b; i < e; i++) if (chosen[ord[i]]) sets_out[n_sets++] = ord[i];
         }
+        KAI_TCLK(27)
         return n_sets;
     }
     // node set of a frame: parent ∩ nodes of the topology ∩ nodes of domain d   (d = -1: the parent set itself)
@@ -1994,16 +2111,18 @@ struct Engine {
                 f.cur++;
                 if (f.cur >= f.n_sets) { if (depth == 0) { result = false; break; } depth--; ret = 0; continue; }
                 f.cp = checkpoint(); f.last_rank = -1; f.done = 0;
-                set_frame_bits(depth, sets[f.cur]);
+                { KAI_TCLK0 set_frame_bits(depth, sets[f.cur]); KAI_TCLK(28) }
             }
             if (f.kind == 1) {  // allocateTasksOnNodeSet :109-119
                 bool ok = true;
+                KAI_TCLK0
                 for (int i = 0; i < nt; i++) {
                     int p = chunk[i]; if (c.p_podset[p] != f.id) continue;
                     set_scan_scope(p, frame_bits(depth));
                     if (!allocate_task(p, pipeline_only)) { ok = false; break; }
                 }
                 el().scope_bits = nullptr; el().scope_row = -1; el().scope_score = nullptr;
+                KAI_TCLK(el_restricted(depth) ? 29 : 30)
                 if (ok) { if (depth == 0) { result = true; break; } depth--; ret = 1; }
                 else ret = 0;  // stay on this frame: next node set
                 continue;

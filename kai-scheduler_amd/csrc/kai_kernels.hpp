@@ -248,8 +248,10 @@ struct NullBackend {  // kernels that only need the engine's pure helpers
     __device__ bool topo_scan(const KaiCtx&, TopoScan&) { return false; }
     __device__ bool pfor(const KaiCtx&, const PforReq&) { return false; }
     __device__ void or32(uint32_t* w, uint32_t bits) { atomicOr(w, bits); }
-    __device__ static void add_f64(double* p, double v) { atomicAdd(p, v); }
-    __device__ static void add_i32(int32_t* p, int32_t v) { atomicAdd(p, v); }
+    __device__ static void add_f64(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }  // the roll-ups of subSetNodesFn: one workgroup, one L2
+    __device__ static void add_i32(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ static double coh_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // coherent with the atomics of workgroups on other XCDs
+    __device__ static int32_t coh_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ int best_node(const KaiCtx&, const ScanReq&) { return -1; }
     __device__ void begin(const KaiCtx&) {}
     __device__ bool dirty_add(int) { return true; }
@@ -321,7 +323,7 @@ struct ActShared {
     ScanReq req;
     PforReq pfor;
     TopoScan topo; int32_t topo_min[WAVES][KAI_TOPO_SCAN_LEVELS], topo_max[WAVES][KAI_TOPO_SCAN_LEVELS], topo_any[WAVES];  // CMD_TOPO request and the waves' partial results
-    int32_t cmd, r, n_dirty, pad0;
+    int32_t cmd, r, n_dirty, slice_hi;  // slice_hi: the node passes of the current command cover [0, slice_hi) here (N without a scan grid)
     int32_t dirty[KAI_MAXD];
     double part_min[WAVES], part_max[WAVES];
     unsigned long long part_key[WAVES];  // orderable score bits
@@ -335,6 +337,25 @@ struct ActShared {
     KAI_GP(const double) topo_score; int32_t topo_row, pad2;  // … and preferred-level topology scores per domain of level row topo_row (-1 = none)
     long long t_publish, t_wait, t_svc, t_seg[6];  // profiling: control lane through barrier 1 / barrier 2, service wave 1 busy time
 };
+
+// The scan grid of an allocate action on the sequential engine: beside the engine's workgroup, helper workgroups that take the passes over the NODES (pre-order range, best
+// node of a decision without a class index — shared GPUs, node sets of the topology DFS —, the node loops of subSetNodesFn).  Workgroup g owns the nodes
+// [g * sg_per, (g + 1) * sg_per); the control lane publishes a command here (payload, then seq with release at agent scope: the workgroups sit on different XCDs, whose L2s
+// meet only through such accesses and fences), runs slice 0 on its own scan waves, waits for `done` and folds the helpers' partial results into its own.  One 64-node
+// step of a 65 536-node pass per lane instead of 146.
+constexpr int KAI_SG_MAX = 256;
+struct ScanGridPart { unsigned long long key; int32_t node, any; double mn, mx; int32_t tmin[KAI_TOPO_SCAN_LEVELS], tmax[KAI_TOPO_SCAN_LEVELS]; int32_t pad[8]; };  // 128 bytes
+struct ScanGrid {
+    int32_t seq, done, cmd, r;  // seq: number of the command on the table (0 = none yet); done: helpers finished, summed over all commands
+    int32_t topo_row, fault, ready, per;  // ready: number of the last command whose folded result is in `res`; per: nodes per slice
+    int32_t xcc0, n_reg, checked, pad0;   // start-up: the engine's XCD + 1, helpers that signed on, workgroups that answered
+    KAI_GP(const uint32_t) nodeset; KAI_GP(const double) topo_score;
+    ScanReq req; TopoScan topo;
+    ScanGridPart res;
+    ScanGridPart part[KAI_SG_MAX];
+};
+__device__ __forceinline__ int sg_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // coherent across the XCDs without touching the reader's L2
+__device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg(20 | (3 << 11)); }  // HW_REG_XCC_ID, bits 3:0
 
 // the mailbox between the control lane and the service waves, the action's context and the engine's scalars: directly
 // addressed LDS objects of the (single) workgroup
@@ -383,32 +404,64 @@ struct DevBackendT {
         __syncthreads();  // results ready
     }
     __device__ void scope() { sh->nodeset = g_el.scope_bits; sh->topo_row = g_el.scope_row; sh->topo_score = g_el.scope_score; }
+    // scan grid, control-lane side (never in the victim-search kernel, whose engines sit on replicas)
+    __device__ static bool grid_on() { if constexpr (VICTIM) return false; else return g_ctx.sg_wgs > 1; }
+    __device__ void node_pass(int cmd) {  // a command whose work is a pass over the nodes: on every workgroup of the grid at once
+        if (!grid_on()) { sh->slice_hi = g_ctx.N; call(cmd); return; }
+        wait();
+        ScanGrid* g = g_ctx.sg;
+        g->cmd = cmd; g->r = sh->r; g->nodeset = sh->nodeset; g->topo_row = sh->topo_row; g->topo_score = sh->topo_score;
+        if (cmd == CMD_BEST) g->req = sh->req; else if (cmd == CMD_TOPO) g->topo = sh->topo;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the node state this lane changed since the last pass, and the payload: written back for the other XCDs
+        __hip_atomic_store(&g->seq, ++g_el.sg_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh->slice_hi = g_ctx.sg_per < g_ctx.N ? g_ctx.sg_per : g_ctx.N;
+        call(cmd);
+        // the helpers' folded result: read with coherent loads only — an acquire fence here would empty this XCD's L2 under the control lane after every pass.  What the
+        // helpers wrote elsewhere is never read here through a plain load first: bitmap words are read by the slice that wrote them, the survey's sums by op 16's coherent loads
+        long long spins = 0;
+        while (sg_ld(&g->ready) != g_el.sg_gen) {
+            if (++spins > (1ll << 28)) { g_ctx.st->fault = FAULT_INTERNAL; g_ctx.st->fault_line = __LINE__; break; }  // a helper left the protocol
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     __device__ void minmax(const KaiCtx&, int r, double& mn, double& mx) {
-        scope(); sh->r = r; call(CMD_MINMAX);
+        scope(); sh->r = r; node_pass(CMD_MINMAX);
         double lo = 1.7976931348623157e308, hi = 0;  // math.MaxFloat64, 0 (plugins/nodeplacement/pack.go:66-68)
         for (int w = 1; w < WAVES; w++) { if (sh->part_min[w] < lo) lo = sh->part_min[w]; if (sh->part_max[w] > hi) hi = sh->part_max[w]; }
+        if (grid_on()) { const ScanGridPart& p = g_ctx.sg->res; const double a = __hip_atomic_load(&p.mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(&p.mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (a < lo) lo = a; if (b > hi) hi = b; }
         mn = lo; mx = hi;
     }
     __device__ bool pfor(const KaiCtx&, const PforReq& r) { if (r.n < 256) return false; sh->pfor = r; call(CMD_PFOR); return true; }  // short loops stay on the control lane (two barriers cost more)
     __device__ void or32(uint32_t* w, uint32_t bits) { *w |= bits; }
     __device__ bool topo_scan(const KaiCtx&, TopoScan& t) {
-        sh->topo = t; call(CMD_TOPO);
-        if (t.op == 1) {
+        const bool grid = t.op == 1 || t.op == 4 || t.op == 15;  // passes over the nodes that go to the whole grid (ops 2 / 3 — only used without the survey — and the loops over domains: this workgroup's scan waves)
+        sh->topo = t; if (grid) node_pass(CMD_TOPO); else { sh->slice_hi = g_ctx.N; call(CMD_TOPO); }
+        if (t.op == 1 || t.op == 15) {
             int any = 0;
             for (int l = 0; l < t.L; l++) { int mn = 0x7fffffff, mx = -0x7fffffff - 1; for (int w = 1; w < WAVES; w++) { if (sh->topo_min[w][l] < mn) mn = sh->topo_min[w][l]; if (sh->topo_max[w][l] > mx) mx = sh->topo_max[w][l]; } t.lvl_min[l] = mn; t.lvl_max[l] = mx; }
             for (int w = 1; w < WAVES; w++) any |= sh->topo_any[w];
+            if (grid_on()) {
+                const ScanGridPart& p = g_ctx.sg->res;
+                any |= sg_ld(&p.any);
+                for (int l = 0; l < t.L; l++) { const int a = sg_ld(&p.tmin[l]), b = sg_ld(&p.tmax[l]); if (a < t.lvl_min[l]) t.lvl_min[l] = a; if (b > t.lvl_max[l]) t.lvl_max[l] = b; }
+            }
             t.any = any;
         }
         if (t.op == 9) { int n = 0; for (int w = 1; w < WAVES; w++) n += sh->topo_any[w]; t.any = n; }  // chosen domains
         return true;
     }
     __device__ int best_node(const KaiCtx&, const ScanReq& q) {
-        scope(); sh->req = q; call(CMD_BEST);
+        scope(); sh->req = q; node_pass(CMD_BEST);
         int best = -1; unsigned long long bk = 0;
         for (int w = 1; w < WAVES; w++) {
             int n = sh->part_node[w]; if (n < 0) continue;
             unsigned long long k = sh->part_key[w];
             if (best < 0 || k > bk || (k == bk && n < best)) { best = n; bk = k; }
+        }
+        if (grid_on()) {
+            const ScanGridPart& p = g_ctx.sg->res;
+            const int n = sg_ld(&p.node); const unsigned long long k = __hip_atomic_load(&p.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n >= 0 && (best < 0 || k > bk || (k == bk && n < best))) { best = n; bk = k; }
         }
         return best;
     }
@@ -456,6 +509,8 @@ struct DevBackendT {
     __device__ static int64_t mw_load64(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static int32_t mw_fetch_add32(int32_t* p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static void mw_fetch_min32(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static double coh_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static int32_t coh_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ static void grid_sync(MultiCtx* m, int clear) {  // the control lanes of the action's workgroups (all resident: one per compute unit at most, kai_core.hip)
         const int gen = __hip_atomic_load(&m->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __atomic_thread_fence(__ATOMIC_RELEASE);
@@ -476,6 +531,7 @@ struct DevBackendT {
         wait();
         // blocks still on the dirty list: bring the HBM level of the index up to date, the next action of the session starts from it
         if (sh->n_dirty) { sh->cmd = CMD_REFRESH; __syncthreads(); sh->in_flight = 1; wait(); }
+        if (!VICTIM && g_ctx.sg) { g_ctx.sg->cmd = CMD_EXIT; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __hip_atomic_store(&g_ctx.sg->seq, ++g_el.sg_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         sh->cmd = CMD_EXIT; __syncthreads();
     }
 };
@@ -493,6 +549,170 @@ __device__ __forceinline__ void svc_top(const KaiCtx& c, ActShared* sh, int k, i
     uint64_t key = lane < c.NSB ? sh->s2_key[k * c.NSB + lane] : 0; int n = lane < c.NSB ? sh->s2_node[k * c.NSB + lane] : 0x7fffffff;
     wave_argmax(key, n);
     if (lane == 0) { sh->top_key[k] = key; sh->top_node[k] = n; }
+}
+
+// The passes over the NODES a command asks for (pre-order range, best node, the node loops of subSetNodesFn), over the slice [n_lo, n_hi) with `lanes` lanes of this
+// workgroup (`slot` = this lane's number among them); per-wave partial results go to the workgroup's ActShared.  The control lane's own workgroup runs it on its scan
+// waves; with a scan grid (ScanGrid below) the helper workgroups run it on theirs at the same time.
+__device__ __forceinline__ void scan_cmd(const KaiCtx& c, ActShared* sh, int cmd, int n_lo, int n_hi, int slot, int lanes) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (cmd == CMD_MINMAX) {  // getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86)
+        int r = sh->r;
+        double lo = 1.7976931348623157e308, hi = 0;
+        KAI_GP(const uint32_t) ns_bits = sh->nodeset;
+        for (int n = n_lo + slot; n < n_hi; n += lanes) {
+            if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;  // the pre-order scan ranges the node set (pack.go:66-86)
+            if (c.n_alloc[(size_t)r * c.N + n] == 0) continue;
+            double cur = c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n];
+            if (cur < lo) lo = cur;
+            if (cur > hi) hi = cur;
+        }
+        for (int o = 32; o > 0; o >>= 1) { double a = __shfl_xor(lo, o, 64), b = __shfl_xor(hi, o, 64); if (a < lo) lo = a; if (b > hi) hi = b; }
+        if (lane == 0) { sh->part_min[wave] = lo; sh->part_max[wave] = hi; }
+    } else if (cmd == CMD_TOPO) {  // the node loops of subSetNodesFn (kai_engine.hpp subset_nodes)
+        const TopoScan t = sh->topo;
+        if (t.op == 1) {
+            int mn[KAI_TOPO_SCAN_LEVELS], mx[KAI_TOPO_SCAN_LEVELS]; int any = 0;
+            for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { mn[l] = 0x7fffffff; mx[l] = -0x7fffffff - 1; }
+            for (int n = n_lo + slot; n < n_hi; n += lanes) {
+                if (t.parent && !((t.parent[n >> 5] >> (n & 31)) & 1)) continue;
+                if (c.node_domain[(size_t)t.row0 * c.N + n] < 0) continue;
+                any = 1;
+                for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) if (l < t.L) { const int dd = c.node_domain[(size_t)(t.row0 + l) * c.N + n]; if (dd < mn[l]) mn[l] = dd; if (dd > mx[l]) mx[l] = dd; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                any |= __shfl_xor(any, o, 64);
+                for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { const int a = __shfl_xor(mn[l], o, 64), b = __shfl_xor(mx[l], o, 64); if (a < mn[l]) mn[l] = a; if (b > mx[l]) mx[l] = b; }
+            }
+            if (lane == 0) { for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { sh->topo_min[wave][l] = mn[l]; sh->topo_max[wave][l] = mx[l]; } sh->topo_any[wave] = any; }
+        } else if (t.op == 15) {  // the survey: ops 1, 2 and 3 in one pass, two 64-node steps of a wave in flight at a time (their loads go out together)
+            int mn[KAI_TOPO_SCAN_LEVELS], mx[KAI_TOPO_SCAN_LEVELS]; int any = 0;
+            for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { mn[l] = 0x7fffffff; mx[l] = -0x7fffffff - 1; }
+            const int DT = c.D + c.T;
+            constexpr int U = 2;
+            for (int nb = n_lo + slot - lane; nb < n_hi; nb += lanes * U) {
+                int n[U], top[U], leaf[U], dlv[U][KAI_TOPO_SCAN_LEVELS]; uint32_t pw[U]; double av[U][KAI_MAX_RES];
+                for (int u = 0; u < U; u++) {  // every load unconditional, on a clamped index
+                    const int nn = nb + u * lanes + lane; n[u] = nn;
+                    const int x = nn < n_hi ? nn : n_hi - 1;
+                    top[u] = c.node_domain[(size_t)t.row0 * c.N + x];
+                    leaf[u] = c.node_domain[(size_t)(t.row0 + t.L - 1) * c.N + x];
+                    pw[u] = t.parent ? t.parent[x >> 5] : 0xffffffffu;
+                    for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) dlv[u][l] = l < t.L ? c.node_domain[(size_t)(t.row0 + l) * c.N + x] : 0;
+                    for (int r = 0; r < KAI_MAX_RES; r++) av[u][r] = r < t.R ? c.n_idle[(size_t)r * c.N + x] + c.n_rel[(size_t)r * c.N + x] : 0.0;
+                }
+                for (int u = 0; u < U; u++) {
+                    const bool act = n[u] < n_hi && top[u] >= 0 && leaf[u] >= 0;  // a node of the topology
+                    if (act && ((pw[u] >> (n[u] & 31)) & 1u)) {
+                        any = 1;
+                        for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) if (l < t.L) { if (dlv[u][l] < mn[l]) mn[l] = dlv[u][l]; if (dlv[u][l] > mx[l]) mx[l] = dlv[u][l]; }
+                    }
+                    const unsigned long long am = __ballot(act);
+                    if (!am) continue;
+                    const int l0 = __shfl(leaf[u], __ffsll((long long)am) - 1, 64);
+                    const bool uni = __ballot(act && leaf[u] != l0) == 0;
+                    for (int r = 0; r < KAI_MAX_RES; r++) if (r < t.R) {
+                        double v = act ? av[u][r] : 0.0;
+                        if (uni) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); if (lane == 0 && v != 0.0) atomicAdd((double*)&c.dom_free[(size_t)l0 * KAI_MAX_RES + r], v); }
+                        else if (act) atomicAdd((double*)&c.dom_free[(size_t)leaf[u] * KAI_MAX_RES + r], v);
+                    }
+                    if (t.what & 2) {
+                        int count = act ? topo_node_count(t, av[u]) : 0;
+                        if (uni) { for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64); if (lane == 0 && count) atomicAdd((int*)&c.dom_tmp[2 * DT + l0], count); }
+                        else if (count) atomicAdd((int*)&c.dom_tmp[2 * DT + leaf[u]], count);
+                    }
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                any |= __shfl_xor(any, o, 64);
+                for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { const int a = __shfl_xor(mn[l], o, 64), b = __shfl_xor(mx[l], o, 64); if (a < mn[l]) mn[l] = a; if (b > mx[l]) mx[l] = b; }
+            }
+            if (lane == 0) { for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { sh->topo_min[wave][l] = mn[l]; sh->topo_max[wave][l] = mx[l]; } sh->topo_any[wave] = any; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the sums are in memory (agent-scope atomics) before op 16 reads them coherently; no acquire: nothing here is read back through a plain load
+        } else if (t.op >= 5) {  // loops over the domains of a topology (Engine::topo_dom_body)
+            NullBackend nb; Engine<NullBackend> eng(c, nb);
+            int cnt = 0;
+            for (int d = slot; d < c.D + c.T; d += lanes) cnt += eng.topo_dom_body(t, d);
+            if (t.op == 9) { for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64); if (lane == 0) sh->topo_any[wave] = cnt; }
+            // a loop over domains stays inside this workgroup: its atomics (NullBackend::add_*) and its fence have workgroup scope, so this XCD's L2 is neither written back nor emptied —
+            // except after ops 5 and 7, whose stores must be in memory before the agent-scope atomics of the survey (ops 2 / 3) add to them
+            if (t.op == 5 || t.op == 7) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        } else if (t.op == 4) {  // build_node_set: one 32-node word of the bitmap per step
+            for (int w = (n_lo >> 5) + slot; w < ((n_hi + 31) >> 5); w += lanes) {  // (slices begin on multiples of 64 nodes)
+                uint32_t word = 0; const uint32_t pw = t.parent ? t.parent[w] : 0xffffffffu;
+                for (int b = 0; b < 32; b++) {
+                    const int n = w * 32 + b; if (n >= c.N) break;
+                    bool in = (pw >> b) & 1u;
+                    if (in && t.domain >= 0) in = t.dl < 0 ? c.node_domain[(size_t)t.row0 * c.N + n] >= 0 : c.node_domain[(size_t)(t.row0 + t.dl) * c.N + n] == t.domain;
+                    if (in) word |= 1u << b;
+                }
+                t.out[w] = word;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (a slice reads only the words it wrote itself)
+        } else {
+            // ops 2 / 3: a wave takes 64 consecutive nodes per step — normally the nodes of ONE leaf domain, whose contributions are then summed
+            // across the wave and added to the domain once (the amounts are integral under exact_sums, counts are integers: the grouping of the
+            // additions does not show); a step that straddles leaf domains falls back to one atomic per node
+            for (int nb = n_lo + slot - lane; nb < n_hi; nb += lanes) {
+                const int n = nb + lane;
+                const bool act = n < n_hi && topo_node_in_domain(c, t, n);
+                const int leaf = act ? c.node_domain[(size_t)(t.row0 + t.L - 1) * c.N + n] : -1;
+                const unsigned long long am = __ballot(act);
+                if (!am) continue;
+                const int l0 = __shfl(leaf, __ffsll((long long)am) - 1, 64);
+                const bool uni = __ballot(act && leaf != l0) == 0;
+                if (t.op == 2) {
+                    for (int r = 0; r < t.R; r++) {
+                        double v = act ? c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n] : 0.0;
+                        if (uni) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); if (lane == 0 && v != 0.0) atomicAdd((double*)&c.dom_free[(size_t)l0 * KAI_MAX_RES + r], v); }
+                        else if (act) atomicAdd((double*)&c.dom_free[(size_t)leaf * KAI_MAX_RES + r], v);
+                    }
+                } else {
+                    int count = 0;
+                    if (act) {
+                        if (t.one_pod) count = t.tasks;
+                        else {
+                            double cur[KAI_MAX_RES]; for (int r = 0; r < KAI_MAX_RES; r++) cur[r] = t.mx[r];  // k-th test pod = k x the maximal pod, by repeated addition
+                            for (;;) { if (!fits(c, cur, n, true)) break; count++; for (int r = 0; r < t.R; r++) cur[r] += t.mx[r]; }
+                        }
+                    }
+                    if (uni) { for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64); if (lane == 0 && count) atomicAdd((int*)&c.dom_alloc_pods[l0], count); }
+                    else if (count) atomicAdd((int*)&c.dom_alloc_pods[leaf], count);
+                }
+            }
+            __threadfence();
+        }
+    } else if (cmd == CMD_BEST) {  // OrderedNodesByTask + FittingNode collapsed to an arg-max (framework/session.go:201-264, 466-485)
+        const ScanReq& q = sh->req;
+        int best = -1; unsigned long long bk = 0;
+        KAI_GP(const uint32_t) ns_bits = sh->nodeset; const int trow = sh->topo_row; KAI_GP(const double) tscore = sh->topo_score;
+        for (int n = n_lo + slot; n < n_hi; n += lanes) {
+            if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;
+#ifdef KAI_SHARED_GPUS
+            const bool frac = c.shared_on && q.shared;  // a fraction (or MiB) of one device: fit / predicates over the node's GPU groups
+            if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
+            if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n, q.kind))) continue;
+            bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
+#else
+            if (!fits(c, q.req, n, true)) continue;                              // IsTaskAllocatableOnReleasingOrIdle
+            if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;  // ssn.PredicateFn
+            bool fit_idle = q.best_effort || fits(c, q.req, n, false);
+#endif
+            double sc = node_score(c, q, n, fit_idle);
+            if (trow >= 0) {  // topology.nodeOrderFn (plugins/topology/node_scoring.go:17-35): a node without a score is dropped (session.go:247-251)
+                int dd = c.node_domain[(size_t)trow * c.N + n]; double ts = dd >= 0 ? tscore[dd] : -1.0;
+                if (ts < 0) continue;
+                sc += ts;
+            }
+            unsigned long long k = orderable(sc);
+            if (best < 0 || k > bk) { best = n; bk = k; }                        // n ascends: the first of equal scores is the lowest name rank
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            int on = __shfl_xor(best, o, 64); unsigned long long ok = __shfl_xor(bk, o, 64);
+            if (on >= 0 && (best < 0 || ok > bk || (ok == bk && on < best))) { best = on; bk = ok; }
+        }
+        if (lane == 0) { sh->part_node[wave] = best; sh->part_key[wave] = bk; }
+    }
 }
 
 // service-wave side: each of the 15 service waves owns the classes  k ≡ wave-1 (mod 15)  of the class index and the nodes
@@ -561,125 +781,134 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
                 bad = __any(bad);
                 if (lane == 0) kai_pf_lds.ok = kai_pf_lds.shape && !bad;
             }
-        } else if (cmd == CMD_MINMAX) {  // getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86)
-            int r = sh->r;
-            double lo = 1.7976931348623157e308, hi = 0;
-            KAI_GP(const uint32_t) ns_bits = sh->nodeset;
-            for (int n = slot; n < c.N; n += SCAN_LANES) {
-                if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;  // the pre-order scan ranges the node set (pack.go:66-86)
-                if (c.n_alloc[(size_t)r * c.N + n] == 0) continue;
-                double cur = c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n];
-                if (cur < lo) lo = cur;
-                if (cur > hi) hi = cur;
-            }
-            for (int o = 32; o > 0; o >>= 1) { double a = __shfl_xor(lo, o, 64), b = __shfl_xor(hi, o, 64); if (a < lo) lo = a; if (b > hi) hi = b; }
-            if (lane == 0) { sh->part_min[wave] = lo; sh->part_max[wave] = hi; }
         } else if (cmd == CMD_PFOR) {  // an index loop of the victim search (Engine::pfor_body)
             const PforReq r = sh->pfor;
             NullBackend nb; Engine<NullBackend> eng(c, nb);
             for (int i = slot; i < r.n; i += SCAN_LANES) eng.pfor_body(r, i);
             __threadfence();
-        } else if (cmd == CMD_TOPO) {  // the node loops of subSetNodesFn (kai_engine.hpp subset_nodes)
-            const TopoScan t = sh->topo;
-            if (t.op == 1) {
-                int mn[KAI_TOPO_SCAN_LEVELS], mx[KAI_TOPO_SCAN_LEVELS]; int any = 0;
-                for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { mn[l] = 0x7fffffff; mx[l] = -0x7fffffff - 1; }
-                for (int n = slot; n < c.N; n += SCAN_LANES) {
-                    if (t.parent && !((t.parent[n >> 5] >> (n & 31)) & 1)) continue;
-                    if (c.node_domain[(size_t)t.row0 * c.N + n] < 0) continue;
-                    any = 1;
-                    for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) if (l < t.L) { const int dd = c.node_domain[(size_t)(t.row0 + l) * c.N + n]; if (dd < mn[l]) mn[l] = dd; if (dd > mx[l]) mx[l] = dd; }
-                }
-                for (int o = 32; o > 0; o >>= 1) {
-                    any |= __shfl_xor(any, o, 64);
-                    for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { const int a = __shfl_xor(mn[l], o, 64), b = __shfl_xor(mx[l], o, 64); if (a < mn[l]) mn[l] = a; if (b > mx[l]) mx[l] = b; }
-                }
-                if (lane == 0) { for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { sh->topo_min[wave][l] = mn[l]; sh->topo_max[wave][l] = mx[l]; } sh->topo_any[wave] = any; }
-            } else if (t.op >= 5) {  // loops over the domains of a topology (Engine::topo_dom_body)
-                NullBackend nb; Engine<NullBackend> eng(c, nb);
-                int cnt = 0;
-                for (int d = slot; d < c.D + c.T; d += SCAN_LANES) cnt += eng.topo_dom_body(t, d);
-                if (t.op == 9) { for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64); if (lane == 0) sh->topo_any[wave] = cnt; }
-                __threadfence();
-            } else if (t.op == 4) {  // build_node_set: one 32-node word of the bitmap per step
-                for (int w = slot; w < c.W; w += SCAN_LANES) {
-                    uint32_t word = 0; const uint32_t pw = t.parent ? t.parent[w] : 0xffffffffu;
-                    for (int b = 0; b < 32; b++) {
-                        const int n = w * 32 + b; if (n >= c.N) break;
-                        bool in = (pw >> b) & 1u;
-                        if (in && t.domain >= 0) in = t.dl < 0 ? c.node_domain[(size_t)t.row0 * c.N + n] >= 0 : c.node_domain[(size_t)(t.row0 + t.dl) * c.N + n] == t.domain;
-                        if (in) word |= 1u << b;
-                    }
-                    t.out[w] = word;
-                }
-                __threadfence();
-            } else {
-                for (int n = slot; n < c.N; n += SCAN_LANES) {
-                    if (!topo_node_in_domain(c, t, n)) continue;
-                    const int leaf = c.node_domain[(size_t)(t.row0 + t.L - 1) * c.N + n];
-                    if (t.op == 2) {
-                        for (int r = 0; r < t.R; r++) { double* x = (double*)&c.dom_free[(size_t)leaf * KAI_MAX_RES + r]; atomicAdd(x, c.n_idle[(size_t)r * c.N + n]); atomicAdd(x, c.n_rel[(size_t)r * c.N + n]); }
-                    } else {
-                        int count = 0;
-                        if (t.one_pod) count = t.tasks;
-                        else {
-                            double cur[KAI_MAX_RES]; for (int r = 0; r < KAI_MAX_RES; r++) cur[r] = t.mx[r];  // k-th test pod = k x the maximal pod, by repeated addition
-                            for (;;) { if (!fits(c, cur, n, true)) break; count++; for (int r = 0; r < t.R; r++) cur[r] += t.mx[r]; }
-                        }
-                        if (count) atomicAdd((int*)&c.dom_alloc_pods[leaf], count);
-                    }
-                }
-                __threadfence();
-            }
-        } else if (cmd == CMD_BEST) {  // OrderedNodesByTask + FittingNode collapsed to an arg-max (framework/session.go:201-264, 466-485)
-            const ScanReq& q = sh->req;
-            int best = -1; unsigned long long bk = 0;
-            KAI_GP(const uint32_t) ns_bits = sh->nodeset; const int trow = sh->topo_row; KAI_GP(const double) tscore = sh->topo_score;
-            for (int n = slot; n < c.N; n += SCAN_LANES) {
-                if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;
-#ifdef KAI_SHARED_GPUS
-                const bool frac = c.shared_on && q.shared;  // a fraction (or MiB) of one device: fit / predicates over the node's GPU groups
-                if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
-                if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n, q.kind))) continue;
-                bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
-#else
-                if (!fits(c, q.req, n, true)) continue;                              // IsTaskAllocatableOnReleasingOrIdle
-                if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;  // ssn.PredicateFn
-                bool fit_idle = q.best_effort || fits(c, q.req, n, false);
-#endif
-                double sc = node_score(c, q, n, fit_idle);
-                if (trow >= 0) {  // topology.nodeOrderFn (plugins/topology/node_scoring.go:17-35): a node without a score is dropped (session.go:247-251)
-                    int dd = c.node_domain[(size_t)trow * c.N + n]; double ts = dd >= 0 ? tscore[dd] : -1.0;
-                    if (ts < 0) continue;
-                    sc += ts;
-                }
-                unsigned long long k = orderable(sc);
-                if (best < 0 || k > bk) { best = n; bk = k; }                        // n ascends: the first of equal scores is the lowest name rank
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                int on = __shfl_xor(best, o, 64); unsigned long long ok = __shfl_xor(bk, o, 64);
-                if (on >= 0 && (best < 0 || ok > bk || (ok == bk && on < best))) { best = on; bk = ok; }
-            }
-            if (lane == 0) { sh->part_node[wave] = best; sh->part_key[wave] = bk; }
+        } else if (cmd == CMD_MINMAX || cmd == CMD_TOPO || cmd == CMD_BEST) {
+            scan_cmd(c, sh, cmd, 0, sh->slice_hi, slot, SCAN_LANES);
         }
         if (cmd == CMD_REFRESH && threadIdx.x == 64) sh->t_svc += clock64() - ts;
         __syncthreads();  // results ready
     }
 }
 
-// One workgroup; wave 0 lane 0 = control, waves 1..15 = service.
+// A helper workgroup of the scan grid: all eight waves scan; wave 0 watches the table, and the helper that finishes a command last folds everybody's partial results.
+__device__ void helper_loop(const KaiCtx& cref, ActShared* sh, int wgs) {
+    const KaiCtx c = cref;
+    ScanGrid* g = c.sg;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // sign on — unless this workgroup sits on the engine's XCD: its acquire fences would empty the L2 the control lane lives in
+    if (threadIdx.x == 0) {
+        int x0; long long spins = 0;
+        while ((x0 = sg_ld(&g->xcc0)) == 0) { __builtin_amdgcn_s_sleep(8); if (++spins > (1ll << 28)) break; }
+        int h = -1;
+        if (x0 != 0 && xcc_id() + 1 != x0) h = __hip_atomic_fetch_add(&g->n_reg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        __hip_atomic_fetch_add(&g->checked, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        sh->r = h;
+    }
+    __syncthreads();
+    const int h = sh->r;
+    __syncthreads();
+    if (h < 0) return;
+    (void)wgs;
+    int gen = 0, n_lo = 0, n_hi = 0, H = 0;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            long long spins = 0; bool lost = false;
+            while (sg_ld(&g->seq) == gen) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1ll << 30)) { lost = true; break; }  // minutes without a command: the engine is gone
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lost) { __hip_atomic_store(&g->fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sh->cmd = CMD_EXIT; }
+            else {
+                sh->cmd = g->cmd; sh->r = g->r; sh->nodeset = g->nodeset; sh->topo_row = g->topo_row; sh->topo_score = g->topo_score;
+                if (sh->cmd == CMD_BEST) sh->req = g->req; else if (sh->cmd == CMD_TOPO) sh->topo = g->topo;
+                sh->slice_hi = g->per; sh->n_dirty = g->n_reg;
+            }
+        }
+        gen++;
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int cmd = sh->cmd;
+        if (cmd == CMD_EXIT) return;
+        if (gen == 1) { const int per = sh->slice_hi; H = sh->n_dirty; n_lo = h * per < c.N ? h * per : c.N; n_hi = (h + 1) * per < c.N ? (h + 1) * per : c.N; }
+        scan_cmd(c, sh, cmd, n_lo, n_hi, threadIdx.x, WG);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (wave != 0) continue;
+        const int top = cmd == CMD_TOPO ? sh->topo.op : 0;
+        int last = 0;
+        if (lane == 0) {
+            ScanGridPart& p = g->part[h];
+            if (cmd == CMD_MINMAX) { double lo = 1.7976931348623157e308, hi = 0; for (int w = 0; w < WAVES; w++) { if (sh->part_min[w] < lo) lo = sh->part_min[w]; if (sh->part_max[w] > hi) hi = sh->part_max[w]; } p.mn = lo; p.mx = hi; }
+            else if (cmd == CMD_BEST) {
+                int best = -1; unsigned long long bk = 0;
+                for (int w = 0; w < WAVES; w++) { int n = sh->part_node[w]; if (n < 0) continue; unsigned long long k = sh->part_key[w]; if (best < 0 || k > bk || (k == bk && n < best)) { best = n; bk = k; } }
+                p.node = best; p.key = bk;
+            } else if (top == 1 || top == 15) {
+                int any = 0;
+                for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { int mn = 0x7fffffff, mx = -0x7fffffff - 1; for (int w = 0; w < WAVES; w++) { if (sh->topo_min[w][l] < mn) mn = sh->topo_min[w][l]; if (sh->topo_max[w][l] > mx) mx = sh->topo_max[w][l]; } p.tmin[l] = mn; p.tmax[l] = mx; }
+                for (int w = 0; w < WAVES; w++) any |= sh->topo_any[w];
+                p.any = any;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            last = __hip_atomic_fetch_add(&g->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == gen * H;
+        }
+        last = __shfl(last, 0, 64);
+        if (!last) continue;
+        // every helper's partial result is on the table: fold them, a lane per helper
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        ScanGridPart& res = g->res;
+        if (cmd == CMD_MINMAX) {
+            double lo = 1.7976931348623157e308, hi = 0;
+            for (int x = 1 + lane; x <= H; x += 64) { const ScanGridPart& p = g->part[x]; if (p.mn < lo) lo = p.mn; if (p.mx > hi) hi = p.mx; }
+            for (int o = 32; o > 0; o >>= 1) { double a = __shfl_xor(lo, o, 64), b = __shfl_xor(hi, o, 64); if (a < lo) lo = a; if (b > hi) hi = b; }
+            if (lane == 0) { res.mn = lo; res.mx = hi; }
+        } else if (cmd == CMD_BEST) {
+            int best = -1; unsigned long long bk = 0;
+            for (int x = 1 + lane; x <= H; x += 64) { const ScanGridPart& p = g->part[x]; const int n = p.node; const unsigned long long k = p.key; if (n >= 0 && (best < 0 || k > bk || (k == bk && n < best))) { best = n; bk = k; } }
+            for (int o = 32; o > 0; o >>= 1) {
+                int on = __shfl_xor(best, o, 64); unsigned long long ok = __shfl_xor(bk, o, 64);
+                if (on >= 0 && (best < 0 || ok > bk || (ok == bk && on < best))) { best = on; bk = ok; }
+            }
+            if (lane == 0) { res.node = best; res.key = bk; }
+        } else if (top == 1 || top == 15) {
+            int any = 0, mn[KAI_TOPO_SCAN_LEVELS], mx[KAI_TOPO_SCAN_LEVELS];
+            for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { mn[l] = 0x7fffffff; mx[l] = -0x7fffffff - 1; }
+            for (int x = 1 + lane; x <= H; x += 64) { const ScanGridPart& p = g->part[x]; any |= p.any; for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { if (p.tmin[l] < mn[l]) mn[l] = p.tmin[l]; if (p.tmax[l] > mx[l]) mx[l] = p.tmax[l]; } }
+            for (int o = 32; o > 0; o >>= 1) {
+                any |= __shfl_xor(any, o, 64);
+                for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { const int a = __shfl_xor(mn[l], o, 64), b = __shfl_xor(mx[l], o, 64); if (a < mn[l]) mn[l] = a; if (b > mx[l]) mx[l] = b; }
+            }
+            if (lane == 0) { res.any = any; for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { res.tmin[l] = mn[l]; res.tmax[l] = mx[l]; } }
+        }
+        if (lane == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __hip_atomic_store(&g->ready, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+}
+
+// The engine's workgroup: wave 0 lane 0 = control, waves 1..7 = service.  scan_wgs > 1: workgroups 1.. are the helpers of the scan grid (same context).
 template <bool VICTIM, bool TREE_LDS>
-__global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, int action, int tree_in_lds) {
+__global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, int action, int tree_in_lds, int scan_wgs) {
     {   // the context into LDS: every pointer fetch of the engine is a ds_read the compiler can batch
-        const int* src = reinterpret_cast<const int*>(cp + blockIdx.x); int* dst = reinterpret_cast<int*>(&g_ctx);  // (a victim action on several workgroups: one context — one replica of the session state — each)
+        const int* src = reinterpret_cast<const int*>(cp + (scan_wgs > 1 ? 0 : blockIdx.x)); int* dst = reinterpret_cast<int*>(&g_ctx);  // (a victim action on several workgroups: one context — one replica of the session state — each)
         for (int i = threadIdx.x; i < (int)(sizeof(KaiCtx) / 4); i += WG) dst[i] = src[i];
+    }
+    if (scan_wgs > 1 && blockIdx.x > 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) { g_sh.cmd = CMD_NONE; g_sh.nodeset = nullptr; g_sh.topo_row = -1; g_sh.topo_score = nullptr; }
+        __syncthreads();
+        helper_loop(g_ctx, &g_sh, scan_wgs);
+        return;
     }
     __syncthreads();
     const KaiCtx& c = g_ctx;
     ActShared& sh = g_sh;
     if (threadIdx.x == 0) {
         kai_pf_lds.job = -1; kai_pf_lds.ok = 0;
-        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.in_flight = 0; sh.tree_in_lds = tree_in_lds; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
+        sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.in_flight = 0; sh.slice_hi = c.N; g_el.sg_gen = 0; sh.tree_in_lds = tree_in_lds; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.t_publish = 0; sh.t_wait = 0; sh.t_svc = 0; for (int i = 0; i < 6; i++) sh.t_seg[i] = 0;
         size_t off = 0;
         sh.s2_key = (unsigned long long __attribute__((address_space(3)))*)(kai_dyn_lds); sh.s2_node = (int32_t __attribute__((address_space(3)))*)(kai_dyn_lds + (size_t)c.C * c.NSB * 8);
         off = lds_index_bytes(c.C, c.NSB);
@@ -689,6 +918,16 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     __syncthreads();
     if (threadIdx.x >= 64) { service_loop(c, &g_sh); return; }
     if (threadIdx.x != 0) return;  // the rest of wave 0 idles: s_barrier counts wavefronts, not lanes
+    if constexpr (!VICTIM) if (scan_wgs > 1) {  // the scan grid signs on: the helpers that do not share this XCD (their fences would empty its L2)
+        ScanGrid* g = g_ctx.sg;
+        __hip_atomic_store(&g->xcc0, xcc_id() + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long spins = 0;
+        while (sg_ld(&g->checked) != scan_wgs - 1) { if (++spins > (1ll << 28)) break; }
+        const int H = sg_ld(&g->checked) == scan_wgs - 1 ? sg_ld(&g->n_reg) : 0;
+        g_ctx.sg_wgs = H + 1; g_ctx.sg_per = (((c.N + H) / (H + 1) + 63) / 64) * 64;
+        g->per = g_ctx.sg_per;
+        if (H == 0) g_ctx.sg_wgs = 1;  // (helpers that never answered would wait for a command forever: they get their EXIT from finish() below only when the grid is on — so keep it on if any signed on)
+    }
     DevBackendT<VICTIM, TREE_LDS> be;
     Engine<DevBackendT<VICTIM, TREE_LDS>> eng(c, be);
     if constexpr (VICTIM) eng.execute_victim_action(); else if (action == KAI_ACTION_ALLOCATE) eng.execute_allocate();
@@ -723,7 +962,7 @@ __global__ void __launch_bounds__(WG) k_best_node(KaiCtx cv, int pod, int pipeli
     __syncthreads();
     const KaiCtx& c = g_ctx;
     ActShared& sh = g_sh;
-    if (threadIdx.x == 0) { sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.in_flight = 0; sh.tree_in_lds = 0; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.s2_key = nullptr; sh.s2_node = nullptr; sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
+    if (threadIdx.x == 0) { sh.cmd = CMD_NONE; sh.n_dirty = 0; sh.in_flight = 0; sh.slice_hi = c.N; g_ctx.sg_wgs = 0; sh.tree_in_lds = 0; sh.nodeset = nullptr; sh.topo_row = -1; sh.topo_score = nullptr; sh.s2_key = nullptr; sh.s2_node = nullptr; sh.qn = c.qn; sh.qheap = c.qheap; sh.root_heap = c.root_heap; }
     __syncthreads();
     if (threadIdx.x >= 64) { service_loop(c, &g_sh); return; }
     if (threadIdx.x != 0) return;

@@ -6,6 +6,8 @@
 // This is NOT a CPU fallback: libkai_core never contains it, the package never loads it, and every
 // parity claim is made by the `-m gpu` tests through the C ABI on a real MI355X.
 #define KAI_SHARED_GPUS 1  // the host twin carries the shared-GPU engine code (ABI v4); the device library is built without it until it is verified on the MI355X
+static int g_dom_lanes_min = 16;  // kai_hostsim_set_dom_lanes_min: tests lower it so that small topologies take the scan-lane forms of the domain loops
+#define KAI_DOM_LANES_MIN g_dom_lanes_min
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,8 +35,27 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     std::vector<uint64_t> s2_key, top_key; std::vector<int32_t> s2_node, top_node;
     static void add_f64(double* p, double v) { *p += v; }
     static void add_i32(int32_t* p, int32_t v) { *p += v; }
+    static double coh_f64(const double* p) { return *p; }
+    static int32_t coh_i32(const int32_t* p) { return *p; }
     bool topo_scan(const KaiCtx& c, TopoScan& t);  // (below: needs Engine<HostBackend>)
     bool topo_scan_nodes(const KaiCtx& c, TopoScan& t) {  // the node loops of subset_nodes stay serial here; op 4 (build_node_set) word by word as the scan lanes do it
+        if (t.op == 15) {  // the survey in a plain loop: what the scan lanes gather (level minima / maxima over `parent`, Idle + Releasing and pod counts per leaf domain)
+            const int DT = c.D + c.T;
+            t.any = 0; for (int l = 0; l < KAI_TOPO_SCAN_LEVELS; l++) { t.lvl_min[l] = 0x7fffffff; t.lvl_max[l] = -0x7fffffff - 1; }
+            for (int n = 0; n < c.N; n++) {
+                const int top = c.node_domain[(size_t)t.row0 * c.N + n], leaf = c.node_domain[(size_t)(t.row0 + t.L - 1) * c.N + n];
+                if (top < 0 || leaf < 0) continue;
+                if (!t.parent || ((t.parent[n >> 5] >> (n & 31)) & 1u)) {
+                    t.any = 1;
+                    for (int l = 0; l < t.L; l++) { const int dd = c.node_domain[(size_t)(t.row0 + l) * c.N + n]; if (dd < t.lvl_min[l]) t.lvl_min[l] = dd; if (dd > t.lvl_max[l]) t.lvl_max[l] = dd; }
+                }
+                double av[KAI_MAX_RES];
+                for (int r = 0; r < KAI_MAX_RES; r++) av[r] = r < t.R ? c.n_idle[(size_t)r * c.N + n] + c.n_rel[(size_t)r * c.N + n] : 0.0;
+                for (int r = 0; r < t.R; r++) c.dom_free[(size_t)leaf * KAI_MAX_RES + r] += av[r];
+                if (t.what & 2) c.dom_tmp[2 * DT + leaf] += topo_node_count(t, av);
+            }
+            return true;
+        }
         if (t.op != 4) return false;
         for (int w = 0; w < c.W; w++) {
             uint32_t word = 0; const uint32_t pw = t.parent ? t.parent[w] : 0xffffffffu;
@@ -137,7 +158,7 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
 
 // TopoScan ops over domains (5..9): the same per-domain bodies the scan lanes of the action kernel run (Engine::topo_dom_body), in a plain loop
 bool HostBackend::topo_scan(const KaiCtx& c, TopoScan& t) {
-    if (t.op < 5) return topo_scan_nodes(c, t);
+    if (t.op < 5 || t.op == 15) return topo_scan_nodes(c, t);
     HostBackend tmp; Engine<HostBackend> e(c, tmp);
     int cnt = 0;
     for (int d = 0; d < c.D + c.T; d++) cnt += e.topo_dom_body(t, d);
@@ -189,6 +210,7 @@ static int g_sh_rank = 0, g_sh_world = 1, g_sh_k = 0; static int (*g_sh_fn)(void
 extern "C" void kai_hostsim_set_shard(int rank, int world, int k, int (*fn)(void*, const void*, void*, int64_t), void* user) { g_sh_rank = rank; g_sh_world = world; g_sh_k = k; g_sh_fn = fn; g_sh_user = user; }
 extern "C" int64_t kai_hostsim_last_exchanges() { return g_sh_exchanges; }
 static int g_mw_world = 1; static int64_t g_mw_waves = 0, g_mw_sims_run = 0, g_mw_sims_used = 0, g_mw_replays = 0;
+extern "C" void kai_hostsim_set_dom_lanes_min(int n) { g_dom_lanes_min = n < 1 ? 1 : n; }
 extern "C" void kai_hostsim_set_multi(int engines) { g_mw_world = engines < 1 ? 1 : engines > KAI_MW_MAX ? KAI_MW_MAX : engines; g_mw_waves = g_mw_sims_run = g_mw_sims_used = g_mw_replays = 0; }  // victim actions of the next runs on that many engines
 extern "C" void kai_hostsim_multi_stats(int64_t* out) { out[0] = g_mw_waves; out[1] = g_mw_sims_run; out[2] = g_mw_sims_used; out[3] = g_mw_replays; }
 static std::vector<int32_t> g_last_groups;  // PodInfo.GPUGroups[0] of the active fraction pods after the last run
@@ -239,7 +261,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
       c.dom_level = copy(pool, prep.dom_level.data(), prep.dom_level.size()); c.dom_topo = copy(pool, prep.dom_topo.data(), prep.dom_topo.size());
       c.dom_parent = copy(pool, prep.dom_parent.data(), prep.dom_parent.size()); c.dom_id_rank = copy(pool, prep.dom_id_rank.data(), prep.dom_id_rank.size());
       c.dom_child_off = copy(pool, prep.dom_child_off.data(), prep.dom_child_off.size()); c.dom_children = const_cast<int32_t*>(copy(pool, prep.dom_children.data(), prep.dom_children.size()));
-      c.dom_alloc_pods = own<int32_t>(pool, DT); c.dom_free = own<double>(pool, DT * KAI_MAX_RES); c.dom_tmp = own<int32_t>(pool, 3 * DT + 4); c.dom_ratio = own<double>(pool, DT);
+      c.dom_alloc_pods = own<int32_t>(pool, DT); c.dom_free = own<double>(pool, DT * KAI_MAX_RES); c.dom_tmp = own<int32_t>(pool, 3 * DT + 4); c.dom_ratio = own<double>(pool, DT); c.dom_key = own<int64_t>(pool, 2 * DT);
       c.ns_bits = own<uint32_t>(pool, (size_t)KAI_TDEPTH * std::max(c.W, 1)); c.ns_sets = own<int32_t>(pool, (size_t)KAI_TDEPTH * (DT + 1));
       c.sg_score = own<double>(pool, (size_t)KAI_TKEYS * std::max<size_t>(DT, 1)); c.sg_key = own<int32_t>(pool, KAI_TKEYS); c.sg_row = own<int32_t>(pool, KAI_TKEYS); }
     c.g_job = copy(pool, prep.g_job.data(), prep.g_job.size()); c.g_parent = copy(pool, prep.g_parent.data(), prep.g_parent.size()); c.g_name_rank = copy(pool, prep.g_name_rank.data(), prep.g_name_rank.size());

@@ -165,6 +165,56 @@ def test_hostsim_broad_random_cycles(seed):
         assert_same(HostSim.run(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
 
 
+@pytest.mark.parametrize("scale", [0.02, 0.05])
+def test_hostsim_config5_in_the_mixed_shape(scale):
+    """BASELINE config 5 as SURVEY 8d writes it down (bench.py --config C5 --mixed), scaled: zone / rack labels (8 x 64 racks: 521 domains, so subSetNodesFn's domain
+    loops take their scan-lane forms), 5 % of the gangs with a required rack, 5 % elastic, half the cluster running, minruntime on."""
+    snap, cfg, _ = T.pkg.synth.config(4, scale, mixed=True)
+    assert_same(HostSim.run(snap, cfg, ("allocate",)), T.Oracle.run(snap, cfg, ("allocate",), threads=8 if snap.n_nodes >= 2048 else 1))
+
+
+@pytest.fixture
+def domain_loops_on_lanes():
+    """subSetNodesFn's loops over the DOMAINS of a topology in the forms the scan lanes of the action kernel run (TopoScan ops 5 .. 14, Engine::topo_dom_body: roll-ups,
+    ratios, every child's place among its siblings, paths as numbers, a chosen domain's place in the level order) for every topology, however small; the default
+    sends trees of fewer than 16 domains through the control lane's loops."""
+    HostSim.lib()
+    HostSim._raw.kai_hostsim_set_dom_lanes_min(1)
+    yield
+    HostSim._raw.kai_hostsim_set_dom_lanes_min(16)
+
+
+TOPO_GOLD = [g for g in GOLD if g[0] in ("allocate__allocateTopology", "allocate__allocate_subgroups", "consolidation__consolidation_subgroups", "reclaim__reclaim_sub_group")]
+
+
+@pytest.mark.parametrize("name,i,case,actions", TOPO_GOLD, ids=[f"{n}[{i}]" for n, i, _, _ in TOPO_GOLD])
+def test_hostsim_golden_topology_domain_loops_on_lanes(domain_loops_on_lanes, name, i, case, actions):
+    """The reference's topology / sub-group tables (allocateTopology_test.go and the sub-group action tests) with the domain loops in their scan-lane forms."""
+    try:
+        snap, cfg, meta = T.case_to_snapshot(case)
+    except T.Unsupported as e:
+        pytest.skip(str(e))
+    res = HostSim.run(snap, cfg, actions)
+    assert not T.check_expectations(snap, meta, res.pod_status, res.pod_node, res.nodes)
+    assert_same(res, T.Oracle.run(snap, cfg, actions))
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_hostsim_replica_groups_domain_loops_on_lanes(domain_loops_on_lanes, seed):
+    snap = T.pkg.synth.make_crowded_snapshot(6 + seed % 13, 3000 + seed, fill=0.8 + 0.1 * (seed % 2), queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3],
+                                             two_podsets_frac=0.6, n_pending_jobs=14)
+    T.pkg.synth.add_replica_topology(snap, seed, zones=2, nodes_per_rack=2 + seed % 2)
+    cfg = T.abi.default_config(max_consolidation_preemptees=-1); cfg.use_scheduling_signatures = seed % 2
+    for actions in (("allocate",), ("allocate", "consolidation", "reclaim", "preempt")):
+        assert_same(HostSim.run(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
+
+
+@pytest.mark.parametrize("seed", list(range(2100, 2140)))
+def test_hostsim_broad_random_cycles_domain_loops_on_lanes(domain_loops_on_lanes, seed):
+    for snap, cfg, actions in T.broad_case(seed):
+        assert_same(HostSim.run(snap, cfg, actions), T.Oracle.run(snap, cfg, actions))
+
+
 # ------------------------------------------------------------------------------------------------ shared GPUs (host twin only so far)
 def _same_groups(snap, res, ref):
     """GPU groups up to the naming of the groups created by the run (the reference draws UUIDs): groups of the snapshot by id, new ones by who shares them."""

@@ -236,6 +236,57 @@ def test_gpu_config4_topology_consolidation_reclaim(gpu, scale):
     assert_same(run_gpu(snap, cfg, acts), ref)
 
 
+@pytest.mark.parametrize("scale", [0.02, 0.1])
+def test_gpu_config5_in_the_mixed_shape(gpu, scale):
+    """BASELINE config 5 as SURVEY 8d writes it down (bench.py --config C5 --mixed), scaled: 521 topology domains (the domain loops of subSetNodesFn run on the scan
+    lanes: TopoScan ops 5 .. 14), 5 % of the gangs with a required rack, 5 % elastic gangs, half the cluster running — the sequential engine against the oracle."""
+    snap, cfg, _ = T.pkg.synth.config(4, scale, mixed=True)
+    assert_same(run_gpu(snap, cfg, ("allocate",)), T.Oracle.run(snap, cfg, ("allocate",), threads=8 if snap.n_nodes >= 2048 else 1))
+
+
+@pytest.mark.parametrize("wgs", (2, 7, 64, 128))
+def test_gpu_scan_grid_on_several_workgroups(gpu, wgs, monkeypatch):
+    """The allocate action of the sequential engine with its passes over the nodes spread over 2 / 7 / 64 / 128 workgroups (ScanGrid, kai_kernels.hpp: pre-order range, best
+    node of a decision that has no class index — fractions of a device, node sets of the topology DFS —, the node loops of subSetNodesFn): shared-GPU clusters, replica
+    groups with a required rack, the mixed config 5 at 2 % (521 topology domains) and sub-group jobs, each against the oracle."""
+    from test_engine_hostsim import _same_groups
+    monkeypatch.setenv("KAI_SCAN_WGS", str(wgs))
+    for seed in (1, 4, 12, 23):
+        snap = T.pkg.synth.make_crowded_snapshot(2 + seed % 9, 9300 + seed, fill=0.3 + 0.5 * (seed % 5) / 4, n_pending_jobs=6 + seed % 13, elastic_frac=0.2,
+                                                 hog_frac=0.5, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3], cpu_only_frac=0.3 if seed % 4 == 0 else 0.0)
+        T.pkg.synth.add_fractions(snap, seed, frac=0.6, portions=(0.25, 0.5, 0.75))
+        cfg = T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=(0.0, 0.5, 1.0)[seed % 3])
+        ref = T.Oracle.run(snap, cfg, ("allocate",)); res = run_gpu(snap, cfg, ("allocate",))
+        assert_same_tol(res, ref); _same_groups(snap, res, ref)
+    for seed in (2, 7, 19):
+        snap = T.pkg.synth.make_crowded_snapshot(6 + seed % 13, 3000 + seed, fill=0.8 + 0.1 * (seed % 2), queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3], two_podsets_frac=0.6, n_pending_jobs=14)
+        T.pkg.synth.add_replica_topology(snap, seed, zones=2, nodes_per_rack=2 + seed % 2)
+        cfg = T.abi.default_config(max_consolidation_preemptees=-1)
+        for acts in (("allocate",), ("allocate", "consolidation", "reclaim", "preempt")):
+            assert_same(run_gpu(snap, cfg, acts), T.Oracle.run(snap, cfg, acts))
+    snap, cfg, _ = T.pkg.synth.config(4, 0.02, mixed=True)
+    res = run_gpu(snap, cfg, ("allocate",))
+    assert_same(res, T.Oracle.run(snap, cfg, ("allocate",)))
+    assert 2 <= (int(res.stats.reserved[1]) >> 48) <= wgs  # the engine's workgroup + the helpers that signed on (those on the engine's own XCD stay out)
+    snap, cfg, _ = T.pkg.synth.config(2, 0.05)
+    T.pkg.synth.add_fractions(snap, 7, frac=0.3)
+    ref = T.Oracle.run(snap, cfg, ("allocate",)); res = run_gpu(snap, cfg, ("allocate",))
+    assert_same_tol(res, ref); _same_groups(snap, res, ref)
+
+
+def test_gpu_scan_grid_at_full_size_against_the_host_compiled_engine(gpu):
+    """The two workloads the scan grid is for, at the benched sizes, against the host-compiled engine (same source, g++, passes over the nodes as plain loops): config 5 in the
+    mixed shape (65 536 nodes, 521 topology domains) and config 3 with 30 % of the one-GPU pods as fractions of a device (every decision a pass over 10 000 nodes' GPU groups)."""
+    from test_engine_hostsim import HostSim, _same_groups
+    snap, cfg, _ = T.pkg.synth.config(4, 1.0, mixed=True)
+    res, ref = run_gpu(snap, cfg, ("allocate",)), HostSim.run(snap, cfg, ("allocate",))
+    assert_same(res, ref)
+    snap, cfg, _ = T.pkg.synth.config(2, 1.0)
+    T.pkg.synth.add_fractions(snap, 7, frac=0.3)
+    res, ref = run_gpu(snap, cfg, ("allocate",)), HostSim.run(snap, cfg, ("allocate",))
+    assert_same_tol(res, ref); _same_groups(snap, res, ref)
+
+
 import test_oracle_golden as _G
 INTEG_FILES = _G.INTEG_FILES  # all 113 scenarios, incl. the fraction, GPU-memory and MIG tables
 INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["cases"])]
