@@ -94,7 +94,9 @@ def main():
     def barrier():
         pkg.dist.barrier(torch.cuda.synchronize)
 
-    core = pkg.KaiCore(cfg, gpu_ids=(dev_index,), world=world, rank=rank) if sharded else pkg.KaiCore(cfg, gpu_ids=(dev_index,))
+    # KAI_BENCH_RCCL=1: the node-sharded group's exchange from the library's own RCCL communicator (kai_shard_attach_rccl: ncclAllGather on its stream) instead of the
+    # caller-supplied collective (the Python mirror's torch.distributed.all_gather_into_tensor with a host round trip per exchange)
+    core = pkg.KaiCore(cfg, gpu_ids=(dev_index,), world=world, rank=rank, allgather="rccl" if os.environ.get("KAI_BENCH_RCCL") == "1" else None) if sharded else pkg.KaiCore(cfg, gpu_ids=(dev_index,))
     t0 = time.time()
     ssn = core.open_session(snap)  # host → HBM once; the timed steps replay from the resident copy
     upload_s = time.time() - t0

@@ -350,6 +350,14 @@ int kai_core_create(const kai_config* cfg, int n_gpus, const int* gpu_ids, kai_c
  * offers_per_class: nodes a rank offers per scan class and exchange (0 = default 128).  Returns 0 / a kai_status. */
 typedef int (*kai_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes_per_rank);
 int kai_shard_attach(kai_core* core, int rank, int world, int offers_per_class, kai_allgather_fn fn, void* user);
+/* The same exchange from the library itself: its own RCCL communicator (librccl is resolved at run time), the all-gather issued on the library's stream between the
+ * kernels it separates — no host round trip, no staging.  Rank 0 draws the 128-byte id (ncclGetUniqueId), the caller carries it to the other ranks by whatever it has
+ * (the Python mirror: torch.distributed.broadcast), every rank attaches with it (ncclCommInitRank: collective over the group, one device per rank).
+ * kai_shard_allgather_probe runs the group's exchange step once on caller-provided device buffers (diagnostics; what the fill calls between kernels). */
+#define KAI_RCCL_ID_BYTES 128
+int kai_shard_rccl_id(kai_core* core, void* id_out /* KAI_RCCL_ID_BYTES */);
+int kai_shard_attach_rccl(kai_core* core, int rank, int world, int offers_per_class, const void* id /* KAI_RCCL_ID_BYTES, the same on every rank */);
+int kai_shard_allgather_probe(kai_core* core, const void* send, void* recv, int64_t bytes_per_rank);
 int kai_core_destroy(kai_core* core);
 
 /* replaces: framework.OpenSession + every OnSessionOpen on the path (framework/framework.go:32-65):

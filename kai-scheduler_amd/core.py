@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KAI_CORE_LIB") or os.path.join(_HERE, "csrc", "libkai_core.so")  # KAI_CORE_LIB: another BUILD of the same HIP library (profiling variants)
 
 EXPORTS = ["kai_core_create", "kai_core_destroy", "kai_session_open", "kai_queue_shares", "kai_action_execute", "kai_best_node",
-           "kai_pod_states", "kai_node_states", "kai_pod_gpu_groups", "kai_shard_attach", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]
+           "kai_pod_states", "kai_node_states", "kai_pod_gpu_groups", "kai_shard_attach", "kai_shard_rccl_id", "kai_shard_attach_rccl", "kai_shard_allgather_probe", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]
 
 
 class KaiError(RuntimeError):
@@ -65,6 +65,9 @@ def load_library(path: str = LIB_PATH):
     lib.kai_session_open.argtypes = [C.c_void_p, C.POINTER(abi.KaiSnapshotSoA)]
     lib.kai_session_close.argtypes = [C.c_void_p]
     lib.kai_shard_attach.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]
+    lib.kai_shard_rccl_id.argtypes = [C.c_void_p, C.c_void_p]
+    lib.kai_shard_attach_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.kai_shard_allgather_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.kai_pod_gpu_groups.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
     lib.kai_session_reset.argtypes = [C.c_void_p]
     lib.kai_queue_shares.argtypes = [C.c_void_p, C.POINTER(abi.KaiQueueShare), C.c_int]
@@ -95,13 +98,33 @@ class KaiCore:
         rc = self.lib.kai_core_create(C.byref(self.cfg), self.world, ids, C.byref(self.handle))
         if rc != 0:
             raise KaiError(rc, "kai_core_create")
-        if self.world > 1:
+        if isinstance(allgather, str) and allgather == "rccl":
+            # the library's own communicator (kai_shard_attach_rccl): rank 0 draws the id, the default process group carries it to the others, the exchange itself
+            # is an ncclAllGather the library issues on its stream between its kernels
+            self._attach_rccl(int(offers_per_class))
+        elif self.world > 1:
             self._user_allgather = allgather
             self._stage = None
             self._cb = ALLGATHER_FN(self._allgather)  # kept alive with the handle
             rc = self.lib.kai_shard_attach(self.handle, self.rank, self.world, int(offers_per_class), self._cb, None)
             if rc != 0:
                 raise KaiError(rc, "kai_shard_attach")
+
+    def _attach_rccl(self, offers_per_class):
+        idbuf = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            rc = self.lib.kai_shard_rccl_id(self.handle, idbuf)
+            if rc != 0:
+                raise KaiError(rc, self.lib.kai_last_error(self.handle).decode())
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(t, 0)
+            idbuf = (C.c_ubyte * 128)(*t.cpu().tolist())
+        rc = self.lib.kai_shard_attach_rccl(self.handle, self.rank, self.world, offers_per_class, idbuf)
+        if rc != 0:
+            raise KaiError(rc, self.lib.kai_last_error(self.handle).decode())
 
     def _allgather(self, user, send, recv, nbytes):
         try:

@@ -6,6 +6,7 @@
 // the path in this library: without a HIP device every entry point fails with KAI_ERR_NO_DEVICE.
 #define KAI_SHARED_GPUS 1  // fractions of one device (ABI v4): group tables per node, gpusharingorder score, FittingGPUs (kai_engine.hpp)
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -45,6 +46,7 @@ struct kai_core {
     kai_action_stats stats{};
     HostPrep::BatchShape shape;  // batch path of the allocate action (kai_batch.hpp)
     int world = 1, rank = 0, shard_k = 0; kai_allgather_fn ag_fn = nullptr; void* ag_user = nullptr;  // node-axis sharding over the GPUs of one node (kai_shard_attach)
+    void* rccl_comm = nullptr;  // the library's own communicator (kai_shard_attach_rccl): the exchange is an ncclAllGather on `stream`, no host round trip
     bool shared = false; int32_t* d_group0 = nullptr; int32_t next_group0 = 0; int32_t *d_np_off = nullptr, *d_np_pods = nullptr;  // shared GPUs: initial groups, each node's active pods in UID order
     hipEvent_t bev[4] = {nullptr, nullptr, nullptr, nullptr};
     double batch_plan_ms = 0, batch_fill_ms = 0, batch_apply_ms = 0;
@@ -123,6 +125,38 @@ int dupload_f(kai_core* core, F& field, const T* host, size_t n) {
     if (n) HIP_TRY(core, hipMemcpyAsync(KAI_VP(field), host, n * sizeof(T), hipMemcpyHostToDevice, core->stream));
     return KAI_OK;
 }
+// RCCL, resolved at run time (the library loads without it; only kai_shard_attach_rccl needs it).  Prototypes as in rccl/rccl.h: ncclUniqueId is 128 opaque bytes passed BY VALUE,
+// ncclUint8 = 1, ncclSuccess = 0.
+struct RcclId { char internal[128]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl_api() {
+    static RcclApi a; static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (a.lib) break; }
+        if (a.lib) {
+            a.GetUniqueId = reinterpret_cast<int (*)(RcclId*)>(dlsym(a.lib, "ncclGetUniqueId"));
+            a.CommInitRank = reinterpret_cast<int (*)(void**, int, RcclId, int)>(dlsym(a.lib, "ncclCommInitRank"));
+            a.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(a.lib, "ncclAllGather"));
+            a.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(a.lib, "ncclCommDestroy"));
+            a.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(a.lib, "ncclGetErrorString"));
+        }
+    }
+    return (a.lib && a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy) ? &a : nullptr;
+}
+int rccl_fail(kai_core* core, const char* what, int rc) {
+    RcclApi* a = rccl_api();
+    core->err = std::string(what) + ": " + ((a && a->GetErrorString) ? a->GetErrorString(rc) : "RCCL error");
+    return KAI_ERR_COMM;
+}
+
 void free_session(kai_core* core) {
     for (void* p : core->bufs) (void)hipFree(p);
     core->bufs.clear(); core->slab = nullptr; core->slab_left = 0;
@@ -190,6 +224,10 @@ struct DevLauncher {
     void shard_scatter(int g, int b, const KaiCtx& c, int total) { hipLaunchKernelGGL(k_shard_scatter, dim3(g), dim3(b), 0, core->stream, c, total); }
     // the group's all-gather is the caller's (torch.distributed over RCCL / xGMI in the Python mirror): the library hands over its device buffers
     int allgather(const void* send, void* recv, int64_t bytes) {
+        if (core->rccl_comm) {  // the library's own communicator: stream-ordered with the kernels on either side, nothing to wait for on the host
+            const int rc = rccl_api()->AllGather(send, recv, (size_t)bytes, /*ncclUint8*/ 1, core->rccl_comm, core->stream);
+            return rc ? rccl_fail(core, "ncclAllGather", rc) : KAI_OK;
+        }
         if (!core->ag_fn) { core->err = "node-sharded group without kai_shard_attach"; return KAI_ERR_COMM; }
         if (hipStreamSynchronize(core->stream) != hipSuccess) return KAI_ERR_HIP;
         if (core->ag_fn(core->ag_user, send, recv, bytes) != 0) { core->err = "the caller's all-gather failed"; return KAI_ERR_COMM; }
@@ -294,6 +332,7 @@ int kai_core_destroy(kai_core* core) {
     if (!core) return KAI_ERR_INVALID_ARG;
     (void)hipSetDevice(core->device);
     free_session(core);
+    if (core->rccl_comm) { (void)hipStreamSynchronize(core->stream); if (RcclApi* a = rccl_api()) (void)a->CommDestroy(core->rccl_comm); core->rccl_comm = nullptr; }
     if (core->ev0) (void)hipEventDestroy(core->ev0);
     if (core->ev1) (void)hipEventDestroy(core->ev1);
     for (hipEvent_t e : core->bev) if (e) (void)hipEventDestroy(e);
@@ -738,6 +777,39 @@ int kai_shard_attach(kai_core* core, int rank, int world, int offers_per_class, 
     if (!core || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return KAI_ERR_INVALID_ARG;
     if (core->open) return fail(core, KAI_ERR_STATE, "kai_shard_attach: before kai_session_open");
     core->world = world; core->rank = rank; core->shard_k = offers_per_class; core->ag_fn = fn; core->ag_user = user;
+    return KAI_OK;
+}
+
+int kai_shard_rccl_id(kai_core* core, void* id_out) {
+    if (!core || !id_out) return KAI_ERR_INVALID_ARG;
+    RcclApi* a = rccl_api();
+    if (!a) return fail(core, KAI_ERR_COMM, "kai_shard_rccl_id: librccl could not be loaded");
+    RcclId id; const int rc = a->GetUniqueId(&id);
+    if (rc) return rccl_fail(core, "ncclGetUniqueId", rc);
+    std::memcpy(id_out, id.internal, sizeof id.internal);
+    return KAI_OK;
+}
+
+int kai_shard_attach_rccl(kai_core* core, int rank, int world, int offers_per_class, const void* id) {
+    if (!core || !id || world < 1 || rank < 0 || rank >= world) return KAI_ERR_INVALID_ARG;
+    if (core->open) return fail(core, KAI_ERR_STATE, "kai_shard_attach_rccl: before kai_session_open");
+    RcclApi* a = rccl_api();
+    if (!a) return fail(core, KAI_ERR_COMM, "kai_shard_attach_rccl: librccl could not be loaded");
+    HIP_TRY(core, hipSetDevice(core->device));
+    if (core->rccl_comm) { (void)a->CommDestroy(core->rccl_comm); core->rccl_comm = nullptr; }
+    RcclId uid; std::memcpy(uid.internal, id, sizeof uid.internal);
+    void* comm = nullptr; const int rc = a->CommInitRank(&comm, world, uid, rank);
+    if (rc) return rccl_fail(core, "ncclCommInitRank", rc);
+    core->rccl_comm = comm; core->world = world; core->rank = rank; core->shard_k = offers_per_class; core->ag_fn = nullptr; core->ag_user = nullptr;
+    return KAI_OK;
+}
+
+int kai_shard_allgather_probe(kai_core* core, const void* send, void* recv, int64_t bytes_per_rank) {
+    if (!core || !send || !recv || bytes_per_rank <= 0) return KAI_ERR_INVALID_ARG;
+    HIP_TRY(core, hipSetDevice(core->device));
+    DevLauncher dl{core};
+    if (int rc = dl.allgather(send, recv, bytes_per_rank)) return rc;
+    HIP_TRY(core, hipStreamSynchronize(core->stream));
     return KAI_OK;
 }
 

@@ -619,6 +619,26 @@ def test_gpu_default_allgather_plumbing(gpu):
         dist.destroy_process_group()
 
 
+def test_gpu_exchange_from_the_library_over_rccl(gpu):
+    """kai_shard_attach_rccl: the library's own RCCL communicator (librccl resolved at run time, ncclGetUniqueId → ncclCommInitRank) and the group's exchange step as an
+    ncclAllGather on the library's stream (kai_shard_allgather_probe = what the sharded fill calls between kernels) — on this box's one GPU as a group of one rank.
+    The session behind such a handle runs as usual."""
+    import ctypes as C
+    import torch
+    core = T.pkg.KaiCore(T.abi.default_config(), allgather="rccl")
+    try:
+        a = torch.arange(8192, dtype=torch.uint8, device="cuda") ; b = torch.zeros(8192, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        assert core.lib.kai_shard_allgather_probe(core.handle, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), 8192) == 0, core.lib.kai_last_error(core.handle)
+        assert torch.equal(a, b)
+        snap, cfg, _ = T.pkg.synth.config(0, 1.0)
+        ssn = core.open_session(snap)
+        ops = ssn.execute("allocate")
+        assert len(ops) == len(T.Oracle.run(snap, cfg).ops)
+    finally:
+        core.destroy()
+
+
 @pytest.mark.parametrize("kind,nodes,pods", [("fractions", 1500, 9000), ("gpu_memory", 700, 5000), ("mig", 1500, 9000)])
 def test_gpu_shared_devices_and_mig_at_scale(gpu, kind, nodes, pods):
     """Shared devices, GPU-memory requests and MIG rows beyond the few-node fuzz cases: such snapshots scan every decision by brute force over all node blocks (no
