@@ -807,6 +807,8 @@ struct EngineLocal {
     int32_t jo_kind, cur_inst;               // jo_kind 1 = victims ordering (reversed comparators, victims operands)
     int32_t tpl_valid, mw_poll;              // the pending-job template of the simulation queues matches the committed state; >= 0: this simulation's index in its wave — it is
                                              // given up as soon as an earlier simulation of the wave is known not to have simply failed (MultiCtx::hit), buffer mw_buf
+    int32_t mm_valid[2], mm_nchg, mm_pend;   // NodePreOrderFn's range over ALL nodes, kept between decisions (preorder_range): valid per placement resource (0 CPU, 1 GPU), nodes changed since, the node whose old amounts mm_before holds
+    int32_t mm_cn[8]; double mm_lo[2], mm_hi[2], mm_old[8][2];
     int32_t sg_gen, pad_sg;                  // scan grid: number of the last command the control lane put on the table (kai_kernels.hpp)
     int32_t mw_buf, rc_early;                // rc_early: the running simulation stopped right after placing the preemptor because the reclaim validator's verdict (known then) is "no"
     struct JoSave { QNode* qn; int32_t *qheap, *root_heap, *sorted, *cur, *end, *side, *side_len; int32_t root_len, root_init, kind, pad; } save[3];
@@ -831,7 +833,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.rc_early = 0;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1;
         e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 
@@ -877,7 +879,44 @@ struct Engine {
         int nd = be.dirty_count();
         if (nd) { int64_t t = be.clock(); be.refresh(cx()); el().h.index_refreshes += nd; el().h.prof[PF_REFRESH] += be.clock() - t; }
     }
+    // getMinMaxPerNode (plugins/nodeplacement/pack.go:66-86) over all nodes is a pass per decision when decisions have no class index (shared GPUs).  Between two decisions one or
+    // two nodes change, so the range is kept and patched: a node that was strictly inside the range can only widen it; one that sat ON a bound and moves outward takes the bound
+    // along; one that sat on a bound and moves inward may or may not have been alone there — then the next decision makes the pass again.  Same minima / maxima of the same
+    // amounts, so the same doubles.  mm_before(n) holds the amounts before a change (node_apply); a change that did not announce itself (the staged job path) drops the range.
+    KAI_HD double mm_cur(int r, int n) const { return cx().n_idle[(size_t)r * cx().N + n] + cx().n_rel[(size_t)r * cx().N + n]; }
+    KAI_HD void mm_drop() { el().mm_valid[0] = el().mm_valid[1] = 0; el().mm_nchg = 0; el().mm_pend = -1; }
+    KAI_HD void mm_before(int n) {
+        if (!(el().mm_valid[0] | el().mm_valid[1])) return;
+        el().mm_pend = n;
+        for (int i = 0; i < el().mm_nchg; i++) if (el().mm_cn[i] == n) return;  // already listed: its first amounts are the ones the kept range knows
+        if (el().mm_nchg >= 8) { mm_drop(); return; }
+        const int i = el().mm_nchg++;
+        el().mm_cn[i] = n; el().mm_old[i][0] = mm_cur(KAI_RES_CPU, n); el().mm_old[i][1] = mm_cur(KAI_RES_GPU, n);
+    }
+    KAI_HD void mm_apply() {
+        for (int i = 0; i < el().mm_nchg; i++) {
+            const int n = el().mm_cn[i];
+            for (int k = 0; k < 2; k++) {
+                if (!el().mm_valid[k]) continue;
+                const int r = k ? KAI_RES_GPU : KAI_RES_CPU;
+                if (cx().n_alloc[(size_t)r * cx().N + n] == 0) continue;  // not part of the range (pack.go:70-73)
+                const double o = el().mm_old[i][k], v = mm_cur(r, n);
+                double& lo = el().mm_lo[k]; double& hi = el().mm_hi[k];
+                if (o > lo) { if (v < lo) lo = v; } else if (v <= lo) lo = v; else { el().mm_valid[k] = 0; continue; }
+                if (o < hi) { if (v > hi) hi = v; } else if (v >= hi) hi = v; else el().mm_valid[k] = 0;
+            }
+        }
+        el().mm_nchg = 0;
+    }
+    KAI_HD void preorder_range(int r, double& mn, double& mx) {
+        if (el().scope_bits || (r != KAI_RES_CPU && r != KAI_RES_GPU)) { be.minmax(cx(), r, mn, mx); return; }  // a node set: not kept
+        const int k = r == KAI_RES_GPU ? 1 : 0;
+        mm_apply();
+        if (!el().mm_valid[k]) { be.minmax(cx(), r, el().mm_lo[k], el().mm_hi[k]); el().mm_valid[k] = 1; }
+        mn = el().mm_lo[k]; mx = el().mm_hi[k];
+    }
     KAI_HD void mark_dirty(int n) {
+        if (el().mm_valid[0] | el().mm_valid[1]) { if (el().mm_pend != n) mm_drop(); el().mm_pend = -1; }
         if (!cx().use_index) return;
         int b = n / KAI_BLOCK;
         if (be.dirty_add(b)) return;
@@ -939,6 +978,7 @@ struct Engine {
     }
     // ------------------------------------------------------------------ node accounting (api/node_info/node_info.go)
     KAI_HD void node_apply(int n, int p, int status, double sign, int grp_of_copy = -2) {  // addTaskResources :457-493 / removeTaskResources :515-551
+        mm_before(n);
         for (int r = 0; r < cx().R; r++) {
             double v = preq(p, r); if (v == 0) continue;
 #ifdef KAI_SHARED_GPUS
@@ -1662,7 +1702,7 @@ struct Engine {
             return n;
         }
         ScanReq q; fill_req(q, p);
-        if ((cx().plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) be.minmax(cx(), q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
+        if ((cx().plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) preorder_range(q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
         int n = be.best_node(cx(), q);
         cx().st->node_scans++; cx().st->nodes_scanned += cx().N;
         if (n >= 0) allocatable = q.best_effort || fits(cx(), q.req, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
