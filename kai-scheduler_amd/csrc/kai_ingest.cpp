@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <deque>
 #include <map>
 #include <set>
 #include <string>
@@ -146,7 +147,10 @@ bool skip_value(const char*& p, const char* e) {
 }
 template <class F> void parallel_for(size_t n, F f);
 // the document: {"config":…, "schedulerParams":…, "rawObjects":{"pods":[…], …}, …} — everything through JParser, the pods element-wise in parallel
-bool parse_document(const char* json, size_t len, JV& root, std::string& err, size_t& err_at) {
+// rawObjects.pods is by far the largest part of a snapshot (10^6 objects at BASELINE config 5): its elements are only located here (spans) and converted one at a time,
+// in parallel, each through a DOM of its own that lives for that one conversion (kai_ingest::build) — the document tree holds everything else
+struct PodSpans { std::vector<std::pair<const char*, const char*>> spans; const char* base = nullptr; };
+bool parse_document(const char* json, size_t len, JV& root, std::string& err, size_t& err_at, PodSpans* lazy = nullptr) {
     JParser ps{json, json + len, {}, 0};
     auto fail = [&](const char* m) { err = ps.err.empty() ? m : ps.err; err_at = (size_t)(ps.p - json); return false; };
     ps.ws(); if (ps.p >= ps.e || *ps.p != '{') { if (!ps.value(root)) return fail("bad document"); ps.ws(); if (ps.p != ps.e) return fail("trailing data"); return true; }
@@ -177,6 +181,7 @@ bool parse_document(const char* json, size_t len, JV& root, std::string& err, si
     }
     ps.ws(); if (ps.p != ps.e) return fail("trailing data");
     for (auto& kv : root.o) if (kv.first == "rawObjects") for (auto& kv2 : kv.second.o) if (kv2.first == "pods" && kv2.second.t == JV::Arr && kv2.second.a.empty() && !pods_arr) pods_arr = &kv2.second;  // addresses are final now
+    if (pods_arr && !spans.empty() && lazy) { lazy->spans.swap(spans); lazy->base = json; return true; }
     if (pods_arr && !spans.empty()) {
         pods_arr->a.resize(spans.size()); std::vector<std::string> errs(spans.size()); std::vector<size_t> at(spans.size());
         parallel_for(spans.size(), [&](size_t i) {
@@ -279,10 +284,28 @@ template <class F> void parallel_for(size_t n, F f) {
     for (auto& x : th) x.join();
 }
 std::vector<uint32_t> rank_strings(const std::vector<std::string>& names) {  // byte-wise ascending like Go's string <; ties keep first-seen order
-    std::vector<uint32_t> order(names.size()), rank(names.size());
-    for (size_t i = 0; i < names.size(); i++) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
-    for (size_t r = 0; r < order.size(); r++) rank[order[r]] = (uint32_t)r;
+    const size_t n = names.size();
+    std::vector<uint32_t> order(n), rank(n);
+    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+    auto less = [&](uint32_t a, uint32_t b) { const int c = names[a].compare(names[b]); return c < 0 || (c == 0 && a < b); };  // a strict total order: any sort gives the stable result
+    size_t T = 1;
+    if (n >= 131072) { unsigned hw = std::thread::hardware_concurrency(); if (const char* e = std::getenv("KAI_INGEST_THREADS")) hw = (unsigned)atoi(e); T = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 65536); }  // (called per job as well, on a handful of names)
+    if (T <= 1) std::stable_sort(order.begin(), order.end(), less);  // (merge sort: names that arrive in order — the usual export — cost one pass)
+    else {  // sorted runs on the host cores, then pairwise merges (each level in parallel)
+        std::vector<size_t> cut(T + 1); for (size_t t = 0; t <= T; t++) cut[t] = n * t / T;
+        { std::vector<std::thread> th; for (size_t t = 0; t < T; t++) th.emplace_back([&, t] { std::stable_sort(order.begin() + cut[t], order.begin() + cut[t + 1], less); }); for (auto& x : th) x.join(); }
+        std::vector<uint32_t> tmp(n);
+        while (cut.size() > 2) {
+            std::vector<size_t> next; std::vector<std::thread> th;
+            for (size_t t = 0; t + 1 < cut.size(); t += 2) {
+                if (t + 2 < cut.size()) { th.emplace_back([&, t] { std::merge(order.begin() + cut[t], order.begin() + cut[t + 1], order.begin() + cut[t + 1], order.begin() + cut[t + 2], tmp.begin() + cut[t], less); }); next.push_back(cut[t]); }
+                else { std::copy(order.begin() + cut[t], order.begin() + cut[t + 1], tmp.begin() + cut[t]); next.push_back(cut[t]); }
+            }
+            for (auto& x : th) x.join();
+            next.push_back(n); cut.swap(next); order.swap(tmp);
+        }
+    }
+    for (size_t r = 0; r < n; r++) rank[order[r]] = (uint32_t)r;
     return rank;
 }
 const JV& label_of(const JV& obj, const char* key) { return obj["metadata"]["labels"][key]; }
@@ -423,10 +446,10 @@ struct kai_ingest {
     std::vector<double> pod_gpus;
     std::string np_key, np_val;
     void warn(const std::string& m) { if (warnings.size() < 16384) { warnings += m; warnings += '\n'; } }
-    int build(const JV& root, const kai_ingest_options* opt);
+    int build(const JV& root, const kai_ingest_options* opt, const PodSpans* lazy_pods = nullptr);
 };
 
-int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
+int kai_ingest::build(const JV& root, const kai_ingest_options* opt, const PodSpans* lazy_pods) {
     if (!root.is_obj()) { g_err = "snapshot.json: top level is not an object"; return KAI_ERR_INVALID_ARG; }
     const JV& conf = root["config"]; const JV& params = root["schedulerParams"]; const JV& raw = root["rawObjects"];
     const bool timing = std::getenv("KAI_INGEST_TIMING") != nullptr;
@@ -549,13 +572,14 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     std::set<std::string> config_maps; if (raw["configMaps"].is_arr()) for (auto& cm : raw["configMaps"].a) config_maps.insert(cm["metadata"]["namespace"].str() + "/" + cm["metadata"]["name"].str());
 
     // ---------------------------------------------------------------- pods (pod_info.go:172-214, 365-445)
-    struct PodRec { const JV* pod; std::string key, uid, group, subgroup, class_sig, sched_sig; Req req; int32_t status, node, nominated; uint32_t flags; int32_t task_prio; int64_t created; bool unschedulable, placed_anti_affinity; int job = -1, podset = -1; double gpu_portion = 0; int64_t gpu_memory = 0; std::string gpu_group; };
+    struct PodRec { const JV* pod; int64_t span = -1; std::string ns, name, uid_raw; std::string key, uid, group, subgroup, class_sig, sched_sig; Req req; int32_t status, node, nominated; uint32_t flags; int32_t task_prio; int64_t created; bool unschedulable, placed_anti_affinity; int job = -1, podset = -1; double gpu_portion = 0; int64_t gpu_memory = 0; std::string gpu_group; };
     std::vector<PodRec> pods; std::set<std::string> extra_names;
     bool any_existing_anti_affinity = false;
     // one pod → its record; reads only what was built above (node / bind-request / config-map tables), so pods are converted in parallel
     auto make_pod = [&](const JV& p, PodRec& r) -> std::string {
         r = PodRec{}; r.pod = &p; const JV& md = p["metadata"]; const JV& spec = p["spec"];
-        r.key = md["namespace"].str() + "/" + md["name"].str(); r.uid = md["uid"].str(); if (r.uid.empty()) r.uid = r.key;
+        r.ns = md["namespace"].str(); r.name = md["name"].str(); r.uid_raw = md["uid"].str();
+        r.key = r.ns + "/" + r.name; r.uid = r.uid_raw; if (r.uid.empty()) r.uid = r.key;
         r.group = md["annotations"]["pod-group-name"].str(); r.subgroup = md["labels"]["kai.scheduler/subgroup-name"].str();
         r.created = time_of(md["creationTimestamp"]);
         // getPodResourceRequest :373-393: exact sum over containers, max with every init container, + overhead (base resources only), pods := 1
@@ -645,11 +669,32 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
         }
         return std::string();
     };
-    {
+    auto parse_span = [&](int64_t i, JV& out, std::string& perr, size_t& at) -> bool {  // one element of rawObjects.pods into a DOM of its own
+        JParser q{lazy_pods->spans[(size_t)i].first, lazy_pods->spans[(size_t)i].second, {}, 0};
+        if (!q.value(out)) { perr = q.err.empty() ? "bad value" : q.err; at = (size_t)(q.p - lazy_pods->base); return false; }
+        q.ws(); if (q.p != q.e) { perr = "unexpected character"; at = (size_t)(q.p - lazy_pods->base); return false; }
+        return true;
+    };
+    if (lazy_pods && !lazy_pods->spans.empty()) {
+        const size_t n = lazy_pods->spans.size();
+        pods.resize(n); std::vector<std::string> errs(n), perrs(n); std::vector<size_t> at(n); std::vector<uint8_t> skip(n, 0);
+        parallel_for(n, [&](size_t i) {
+            JV tmp;  // lives for this one conversion
+            if (!parse_span((int64_t)i, tmp, perrs[i], at[i])) return;
+            if (!tmp.is_obj()) { skip[i] = 1; return; }
+            errs[i] = make_pod(tmp, pods[i]); pods[i].pod = nullptr; pods[i].span = (int64_t)i;
+        });
+        for (size_t i = 0; i < n; i++) if (!perrs[i].empty()) { g_err = "snapshot.json: " + perrs[i] + " at byte " + std::to_string(at[i]); return KAI_ERR_INVALID_ARG; }
+        for (auto& e : errs) if (!e.empty()) { g_err = e; return KAI_ERR_INVALID_ARG; }
+        size_t w = 0; for (size_t i = 0; i < n; i++) if (!skip[i]) { if (w != i) pods[w] = std::move(pods[i]); w++; }
+        pods.resize(w);
+    } else {
         std::vector<const JV*> pv; if (raw["pods"].is_arr()) for (auto& p : raw["pods"].a) if (p.is_obj()) pv.push_back(&p);
         pods.resize(pv.size()); std::vector<std::string> errs(pv.size());
         parallel_for(pv.size(), [&](size_t i) { errs[i] = make_pod(*pv[i], pods[i]); });
         for (auto& e : errs) if (!e.empty()) { g_err = e; return KAI_ERR_INVALID_ARG; }
+    }
+    {
         for (auto& r : pods) { seen_ts(r.created); if (r.placed_anti_affinity) any_existing_anti_affinity = true; for (auto& kv : r.req.scalars) if (kv.second != 0) extra_names.insert(kv.first); }
     }
     if (any_existing_anti_affinity) { warn("a placed pod carries required pod anti-affinity: every pending pod is routed to the CPU fallback"); for (auto& r : pods) if (r.status == KAI_POD_PENDING) r.flags |= KAI_POD_CPU_FALLBACK; }
@@ -738,7 +783,8 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     int32_t default_priority = 50;  // DefaultPodGroupPriority; the first globalDefault PriorityClass overrides it
     std::map<std::string, int32_t> pc_value;
     if (raw["priorityClasses"].is_arr()) { bool found = false; for (auto& pc : raw["priorityClasses"].a) { pc_value[pc["metadata"]["name"].str()] = (int32_t)pc["value"].inum(); if (!found && pc["globalDefault"].truthy()) { default_priority = (int32_t)pc["value"].inum(); found = true; } } }
-    std::map<std::string, std::vector<int>> pods_by_group; for (int i = 0; i < (int)pods.size(); i++) if (!pods[i].group.empty()) pods_by_group[pods[i].group].push_back(i);
+    std::unordered_map<std::string, std::vector<int>> pods_by_group; pods_by_group.reserve(pods.size() / 2 + 16);  // (only looked up by name below: no order needed)
+    for (int i = 0; i < (int)pods.size(); i++) if (!pods[i].group.empty()) pods_by_group[pods[i].group].push_back(i);
     struct PSRec { std::string name; int32_t min; TC tc; int parent_group; };
     std::vector<int> pod_order; std::vector<std::string> job_uids; std::vector<TC> group_tc_v, podset_tc_v; std::vector<std::string> group_names_v;
     std::vector<std::vector<int>> job_podset_ids;
@@ -795,14 +841,18 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
     lap("pod groups");
     // ---------------------------------------------------------------- static predicate classes (n4): pods by constraint, nodes by what those constraints can see
     std::vector<int> pclass_of(pods.size(), 0); std::vector<const JV*> pclass_rep; std::vector<bool> pclass_unsched;
+    std::deque<JV> pclass_store;  // representatives of a snapshot whose pods were converted from spans: parsed once more, kept
     std::set<std::string> used_keys; bool uses_name_field = false;
     {
         std::unordered_map<std::string, int> ids;
         for (size_t i = 0; i < pods.size(); i++) {
-            const JV& spec = (*pods[i].pod)["spec"]; const std::string& sig = pods[i].class_sig;
+            const std::string& sig = pods[i].class_sig;
             auto it = ids.find(sig);
             if (it == ids.end()) {
-                it = ids.emplace(sig, (int)pclass_rep.size()).first; pclass_rep.push_back(pods[i].pod); pclass_unsched.push_back(pods[i].unschedulable);
+                const JV* rep = pods[i].pod;
+                if (!rep) { pclass_store.emplace_back(); std::string pe; size_t at = 0; if (!parse_span(pods[i].span, pclass_store.back(), pe, at)) { g_err = "snapshot.json: " + pe + " at byte " + std::to_string(at); return KAI_ERR_INVALID_ARG; } rep = &pclass_store.back(); }
+                const JV& spec = (*rep)["spec"];
+                it = ids.emplace(sig, (int)pclass_rep.size()).first; pclass_rep.push_back(rep); pclass_unsched.push_back(pods[i].unschedulable);
                 if (spec["nodeSelector"].is_obj()) for (auto& kv : spec["nodeSelector"].o) used_keys.insert(kv.first);
                 const JV& terms = spec["affinity"]["nodeAffinity"]["requiredDuringSchedulingIgnoredDuringExecution"]["nodeSelectorTerms"];
                 if (terms.is_arr()) for (auto& t : terms.a) { if (t["matchExpressions"].is_arr()) for (auto& ex : t["matchExpressions"].a) used_keys.insert(ex["key"].str()); if (t["matchFields"].is_arr() && !t["matchFields"].a.empty()) uses_name_field = true; }
@@ -872,7 +922,7 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt) {
                 if (!*e && v >= 0 && v < (1 << 20)) gid = (int32_t)v; else gid = (1 << 20) + (int32_t)gpu_group_ids.emplace(r.gpu_group, (int)gpu_group_ids.size()).first->second; } }
             pod_gpu_portion.push_back(r.gpu_portion); pod_gpu_group.push_back(gid); pod_gpu_memory.push_back(r.gpu_memory);
         }
-        { const JV& md = (*r.pod)["metadata"]; pod_ns.push_back(md["namespace"].str()); pod_name.push_back(md["name"].str()); pod_uid.push_back(md["uid"].str()); pod_gpus.push_back(r.req.gpu); }
+        { pod_ns.push_back(r.ns); pod_name.push_back(r.name); pod_uid.push_back(r.uid_raw); pod_gpus.push_back(r.req.gpu); }
     }
     // ranks: the reference's tie-breaks are string compares (framework/session.go:480-485 node name; session_plugins.go:227-260 UID)
     node_name_rank = rank_strings(names[KAI_NAME_NODE]); pod_uid_rank = rank_strings(uids); job_uid_rank = rank_strings(job_uids); queue_uid_rank = rank_strings(names[KAI_NAME_QUEUE]);
@@ -955,13 +1005,13 @@ int kai_ingest_parse(const char* json, size_t len, const kai_ingest_options* opt
     if (!json || !out) { g_err = "null argument"; return KAI_ERR_INVALID_ARG; }
     *out = nullptr; g_err.clear();
     double t_start; { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); t_start = ts.tv_sec + ts.tv_nsec * 1e-9; }
-    JV root; std::string perr; size_t perr_at = 0;
-    if (!parse_document(json, len, root, perr, perr_at)) { g_err = "snapshot.json: " + perr + " at byte " + std::to_string(perr_at); return KAI_ERR_INVALID_ARG; }
+    JV root; std::string perr; size_t perr_at = 0; PodSpans pod_spans;
+    if (!parse_document(json, len, root, perr, perr_at, &pod_spans)) { g_err = "snapshot.json: " + perr + " at byte " + std::to_string(perr_at); return KAI_ERR_INVALID_ARG; }
     const bool timing = std::getenv("KAI_INGEST_TIMING") != nullptr;
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
     double t_parsed = now();
     kai_ingest* h = new kai_ingest();
-    int rc = h->build(root, opt);
+    int rc = h->build(root, opt, &pod_spans);
     if (timing) std::fprintf(stderr, "kai_ingest: parse %.3f s, build %.3f s (%zu bytes)\n", t_parsed - t_start, now() - t_parsed, len);
     if (rc != KAI_OK) { delete h; return rc; }
     *out = h; return KAI_OK;
