@@ -278,6 +278,28 @@ def main():
                                "note": f"{world} independent scheduling shards of the same shape, one per GPU, no data-path collective (KAI_BENCH_MULTI=replicas makes this the reported value)"}
         except Exception as e:  # the second leg is additional evidence: it must not take the sharded result down with it (every rank runs the same code, so a failure is common to all)
             out["replicas"] = {"error": str(e)[:200]}
+    if rank == 0 and world == 1 and args.config == "C5" and args.scale == 1.0 and not args.mixed and args.fractions == 0 and actions == ("allocate",) and os.environ.get("KAI_BENCH_OTHER_SHAPES", "1") != "0":
+        # beside the headline (plain gangs: every job on the batch path): the same cluster in the shape SURVEY 8d writes down — zone / rack labels, 5 % of the gangs with a
+        # required rack, 5 % elastic, minruntime on — and config 3 with 30 % of its one-GPU pods as fractions of a device; both run on the sequential engine with its passes
+        # over the nodes on the scan grid.  One warm-up + one timed cycle each; additional evidence, never part of `value`.
+        shapes = {}
+        for key, (i2, kw, frac) in {"c5_mixed": (4, {"mixed": True}, 0.0), "c3_fractions_30": (2, {}, 0.3)}.items():
+            try:
+                s2, c2, d2 = pkg.synth.config(i2, 1.0, **kw)
+                if frac > 0:
+                    pkg.synth.add_fractions(s2, 7, frac=frac)
+                core2 = pkg.KaiCore(c2, gpu_ids=(dev_index,)); ssn2 = core2.open_session(s2)
+                n2 = 0
+                for it in range(2):
+                    ssn2.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
+                    n2 = len(ssn2.execute("allocate")); torch.cuda.synchronize(); el = time.perf_counter() - t0
+                st2 = ssn2.stats()
+                shapes[key] = {"workload": d2 + (" + 30 % of the one-GPU pods as fractions of one device" if frac > 0 else ""), "ms_per_step": el * 1e3, "placements_per_s": n2 / el, "placements": n2,
+                               "decisions": int(st2.decisions), "path": "batch" if int(st2.reserved[4]) > 0 else "sequential engine", "scan_grid_workgroups": max(1, int(st2.reserved[1]) >> 48) if int(st2.reserved[4]) == 0 else None}
+                ssn2.close(); core2.destroy()
+            except Exception as e:  # additional evidence: it must not take the headline down
+                shapes[key] = {"error": str(e)[:200]}
+        out["other_shapes"] = shapes
     if rank == 0:
         print(json.dumps(out))
     pkg.dist.finish()
