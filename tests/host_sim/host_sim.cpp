@@ -6,7 +6,8 @@
 // This is NOT a CPU fallback: libkai_core never contains it, the package never loads it, and every
 // parity claim is made by the `-m gpu` tests through the C ABI on a real MI355X.
 #define KAI_SHARED_GPUS 1  // the host twin carries the shared-GPU engine code (ABI v4); the device library is built without it until it is verified on the MI355X
-static int g_dom_lanes_min = 16;  // kai_hostsim_set_dom_lanes_min: tests lower it so that small topologies take the scan-lane forms of the domain loops
+#include <cstdlib>
+static int g_dom_lanes_min = std::getenv("KAI_HOSTSIM_DOM_MIN") ? std::atoi(std::getenv("KAI_HOSTSIM_DOM_MIN")) : 16;  // kai_hostsim_set_dom_lanes_min: tests lower it so that small topologies take the scan-lane forms of the domain loops
 #define KAI_DOM_LANES_MIN g_dom_lanes_min
 #include <chrono>
 #include <cstdio>
