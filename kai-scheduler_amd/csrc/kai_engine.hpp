@@ -667,6 +667,22 @@ KAI_HD double node_score(const KaiCtx& c, const ScanReq& q, int n, bool fit_idle
     }
     return score;
 }
+// What a brute-force decision over ALL nodes evaluates per node (no node set, no topology scores): is the node a candidate, and its score.  The passes of the scan
+// lanes, the single-node re-evaluations of Engine::best_node_kept and tests/host_sim share it.
+KAI_HD bool scan_node_score(const KaiCtx& c, const ScanReq& q, int n, double& sc) {
+#ifdef KAI_SHARED_GPUS
+    const bool frac = c.shared_on && q.shared;  // a fraction (or MiB) of one device: fit / predicates over the node's GPU groups
+    if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) return false;                                      // IsTaskAllocatableOnReleasingOrIdle
+    if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n, q.kind))) return false;  // ssn.PredicateFn
+    const bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
+#else
+    if (!fits(c, q.req, n, true)) return false;
+    if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) return false;
+    const bool fit_idle = q.best_effort || fits(c, q.req, n, false);
+#endif
+    sc = node_score(c, q, n, fit_idle);
+    return true;
+}
 
 // The class key: 0 = the node does not pass FittingNode for this class; otherwise a 64-bit value whose order over nodes is the
 // order of the reference's f64 score sum for every task of the class:
@@ -773,7 +789,8 @@ KAI_HD int stage_job_lane(const KaiCtx& c, int j, FastFrame& f, JobPf& out, int 
 //    bool topo_scan(const KaiCtx&, TopoScan&)                           — the node loops of subSetNodesFn on the scan lanes; false = the backend has none
 //    bool pfor(const KaiCtx&, const PforReq&)                           — an index loop of the victim search on the scan lanes; false = none
 //    void or32(uint32_t* word, uint32_t bits)                           — *word |= bits (atomic where lanes share words)
-//    int  best_node(const KaiCtx&, const ScanReq&)                      — arg-max of (score, -index) over fitting nodes (brute force)
+//    int  best_node(const KaiCtx&, const ScanReq&, double* score)       — arg-max of (score, -index) over fitting nodes (brute force); its score when asked for
+//    bool eval_nodes(const KaiCtx&, const ScanReq&, const int32_t* n, int m, double* sc, uint8_t* ok) — scan_node_score of m <= 32 nodes; false = the backend has no lanes for it (unscoped requests only)
 //    void begin(const KaiCtx&)                                          — build the in-LDS levels of the class index
 //    bool dirty_add(int block) / int dirty_count()                      — list of 64-node blocks whose node state changed
 //    void refresh(const KaiCtx&)                                        — re-evaluate the listed blocks, clear the list
@@ -791,6 +808,10 @@ struct EngineHot {
     int64_t decisions, index_queries, index_refreshes, rollbacks, jobs_attempted, jobs_committed, out_len, stmts;
     int64_t prof[KAI_NPROF];
 };
+// A brute-force decision over all nodes whose answer is kept: the request (everything but the pod), its best node and that node's score, and how far into the log of changed
+// nodes the answer is up to date (Engine::best_node_kept)
+constexpr int KAI_BN_ENT = 16, KAI_BN_LOG = 32;
+struct BnEnt { ScanReq q; uint64_t h; double score; int32_t node, valid; uint32_t sync, used; };  // h: bn_hash(q), compared first
 struct EngineLocal {
     EngineHot h;
     QNode* qn; int32_t *qheap, *root_heap;  // where the job-order tree lives (LDS if it fits, else HBM)
@@ -807,6 +828,9 @@ struct EngineLocal {
     int32_t jo_kind, cur_inst;               // jo_kind 1 = victims ordering (reversed comparators, victims operands)
     int32_t tpl_valid, mw_poll;              // the pending-job template of the simulation queues matches the committed state; >= 0: this simulation's index in its wave — it is
                                              // given up as soon as an earlier simulation of the wave is known not to have simply failed (MultiCtx::hit), buffer mw_buf
+    BnEnt bn[KAI_BN_ENT]; int32_t bn_log[KAI_BN_LOG]; uint32_t bn_seq, bn_tick; int32_t bn_last;
+    int32_t bn_m[KAI_BN_LOG]; double bn_sc[KAI_BN_LOG]; uint8_t bn_ok[KAI_BN_LOG];  // work lists of best_node_kept (here rather than on the control lane's stack: that is scratch memory)
+  // best nodes of recent brute-force decisions, kept and patched (best_node_kept); the nodes changed since, in order
     int32_t mm_valid[2], mm_nchg, mm_pend;   // NodePreOrderFn's range over ALL nodes, kept between decisions (preorder_range): valid per placement resource (0 CPU, 1 GPU), nodes changed since, the node whose old amounts mm_before holds
     int32_t mm_cn[8]; double mm_lo[2], mm_hi[2], mm_old[8][2];
     int32_t sg_gen, pad_sg;                  // scan grid: number of the last command the control lane put on the table (kai_kernels.hpp)
@@ -833,7 +857,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1; for (int i = 0; i < KAI_BN_ENT; i++) e.bn[i].valid = 0; e.bn_seq = 0; e.bn_tick = 0; e.bn_last = 0;
         e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 
@@ -916,6 +940,7 @@ struct Engine {
         mn = el().mm_lo[k]; mx = el().mm_hi[k];
     }
     KAI_HD void mark_dirty(int n) {
+        el().bn_log[el().bn_seq % KAI_BN_LOG] = n; el().bn_seq++;  // every change of a node's amounts or GPU groups passes here
         if (el().mm_valid[0] | el().mm_valid[1]) { if (el().mm_pend != n) mm_drop(); el().mm_pend = -1; }
         if (!cx().use_index) return;
         int b = n / KAI_BLOCK;
@@ -1689,6 +1714,59 @@ struct Engine {
         q.shared = pod_shared(p) ? 1 : 0; q.kind = pod_kind(p); q.gmem = q.shared ? cx().p_mem[p] : -1;  // GetResourceGpuMemory of a shared request (a gpu-memory request: portion 0, its own MiB)
 #endif
     }
+    // A decision without a class index (shared GPUs) is a pass over every node.  Between two decisions with the same request only a node or two changed, so the answer is kept
+    // and patched: the arg-max over the UNCHANGED nodes is still the kept node (if it is unchanged) — or the kept node itself when it changed but its score did not drop, the
+    // bin-packing case: a fuller node scores higher — and the changed nodes are evaluated one by one against it (score descending, index ascending, as the pass breaks ties).
+    // A kept node whose score dropped leaves the others unknown: then the pass runs.  Same scores from the same function (scan_node_score), so the same node.
+    KAI_HD static bool bn_same(const ScanReq& a, const ScanReq& b) {
+        if (a.cpu_only != b.cpu_only || a.best_effort != b.best_effort || a.pod_class != b.pod_class || a.nominated != b.nominated || a.r_place != b.r_place || a.strategy != b.strategy) return false;
+        for (int r = 0; r < KAI_MAX_RES; r++) if (a.req[r] != b.req[r]) return false;
+        if (a.min_a != b.min_a || a.max_a != b.max_a) return false;
+#ifdef KAI_SHARED_GPUS
+        if (a.portion != b.portion || a.gmem != b.gmem || a.shared != b.shared || a.kind != b.kind) return false;
+#endif
+        return true;
+    }
+    KAI_HD static uint64_t bn_hash(const ScanReq& q) {  // any mix will do: equal requests have equal hashes, bn_same decides
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        auto mix = [&](uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); };
+        mix((uint64_t)(uint32_t)q.cpu_only | ((uint64_t)(uint32_t)q.best_effort << 1) | ((uint64_t)(uint32_t)q.r_place << 2) | ((uint64_t)(uint32_t)q.strategy << 6) | ((uint64_t)(uint32_t)q.pod_class << 16) | ((uint64_t)(uint32_t)q.nominated << 40));
+        for (int r = 0; r < KAI_MAX_RES; r++) { uint64_t b; const double v = q.req[r]; __builtin_memcpy(&b, &v, 8); mix(b); }
+        { uint64_t b; double v = q.min_a; __builtin_memcpy(&b, &v, 8); mix(b); v = q.max_a; __builtin_memcpy(&b, &v, 8); mix(b); }
+#ifdef KAI_SHARED_GPUS
+        { uint64_t b; const double v = q.portion; __builtin_memcpy(&b, &v, 8); mix(b); mix((uint64_t)q.gmem); mix((uint64_t)(uint32_t)q.shared | ((uint64_t)(uint32_t)q.kind << 8)); }
+#endif
+        return h;
+    }
+    KAI_HD int best_node_kept(const ScanReq& q) {
+        const uint64_t h = bn_hash(q);
+        BnEnt* e = nullptr; int lru = 0;
+        { BnEnt& x = el().bn[el().bn_last]; if (x.valid && x.h == h && bn_same(x.q, q)) e = &x; }  // the tasks of a gang ask one after the other
+        if (!e) for (int i = 0; i < KAI_BN_ENT; i++) {
+            BnEnt& x = el().bn[i];
+            if (x.valid && x.h == h && bn_same(x.q, q)) { e = &x; el().bn_last = i; break; }
+            if (!x.valid || (el().bn[lru].valid && x.used < el().bn[lru].used)) lru = i;
+        }
+        if (e && el().bn_seq - e->sync <= (uint32_t)KAI_BN_LOG) {
+            int32_t* m = el().bn_m; double* sc = el().bn_sc; uint8_t* ok = el().bn_ok; int nm = 0;
+            for (uint32_t i = e->sync; i != el().bn_seq; i++) { const int x = el().bn_log[i % KAI_BN_LOG]; bool seen = false; for (int k = 0; k < nm; k++) if (m[k] == x) seen = true; if (!seen) m[nm++] = x; }
+            if (nm == 0 || be.eval_nodes(cx(), q, m, nm, sc, ok)) {
+                int best = e->node; double bs = e->score; bool keep = true;
+                for (int k = 0; k < nm; k++) if (m[k] == e->node) { if (ok[k] && sc[k] >= e->score) bs = sc[k]; else keep = false; }
+                if (keep) {
+                    for (int k = 0; k < nm; k++) if (m[k] != e->node && ok[k] && (best < 0 || sc[k] > bs || (sc[k] == bs && m[k] < best))) { best = m[k]; bs = sc[k]; }
+                    e->node = best; e->score = bs; e->sync = el().bn_seq; e->used = ++el().bn_tick;
+                    el().h.index_queries++;
+                    return best;
+                }
+            }
+        }
+        if (!e) { e = &el().bn[lru]; el().bn_last = lru; }
+        double s = 0; const int n = be.best_node(cx(), q, &s);
+        cx().st->node_scans++; cx().st->nodes_scanned += cx().N;
+        e->q = q; e->h = h; e->node = n; e->score = s; e->valid = 1; e->sync = el().bn_seq; e->used = ++el().bn_tick;
+        return n;
+    }
     // OrderedNodesByTask + FittingNode for one task (framework/session.go:201-264): the first fitting node in score order, or -1
     KAI_HD int find_node(int p, bool& allocatable) {
         int k = (cx().use_index && !el().scope_bits && el().scope_row < 0) ? cx().p_scls[p] : -1;
@@ -1703,8 +1781,9 @@ struct Engine {
         }
         ScanReq q; fill_req(q, p);
         if ((cx().plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) preorder_range(q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
-        int n = be.best_node(cx(), q);
-        cx().st->node_scans++; cx().st->nodes_scanned += cx().N;
+        int n;
+        if (cx().action == KAI_ACTION_ALLOCATE && !el().scope_bits && el().scope_row < 0) n = best_node_kept(q);  // over all nodes: the answer of the last decision with this request, patched
+        else { n = be.best_node(cx(), q, nullptr); cx().st->node_scans++; cx().st->nodes_scanned += cx().N; }
         if (n >= 0) allocatable = q.best_effort || fits(cx(), q.req, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
 #ifdef KAI_SHARED_GPUS
         if (n >= 0 && pod_shared(p)) allocatable = q.best_effort || fits_shared(cx(), q, n, false);

@@ -252,7 +252,8 @@ struct NullBackend {  // kernels that only need the engine's pure helpers
     __device__ static void add_i32(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ static double coh_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // coherent with the atomics of workgroups on other XCDs
     __device__ static int32_t coh_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ int best_node(const KaiCtx&, const ScanReq&) { return -1; }
+    __device__ int best_node(const KaiCtx&, const ScanReq&, double* = nullptr) { return -1; }
+    __device__ bool eval_nodes(const KaiCtx&, const ScanReq&, const int32_t*, int, double*, uint8_t*) { return false; }
     __device__ void begin(const KaiCtx&) {}
     __device__ bool dirty_add(int) { return true; }
     __device__ int dirty_count() { return 0; }
@@ -312,7 +313,7 @@ __global__ void k_leaf_init(KaiCtx c) {
 // ------------------------------------------------------------------------------------------------------
 // the persistent action kernel
 // ------------------------------------------------------------------------------------------------------
-enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5, CMD_LOADTREE = 6, CMD_STAGE = 7, CMD_TOPO = 8, CMD_PFOR = 9 };
+enum SvcCmd : int32_t { CMD_NONE = 0, CMD_MINMAX = 1, CMD_BEST = 2, CMD_EXIT = 3, CMD_BEGIN = 4, CMD_REFRESH = 5, CMD_LOADTREE = 6, CMD_STAGE = 7, CMD_TOPO = 8, CMD_PFOR = 9, CMD_EVAL = 10 };
 
 // dynamic LDS of k_action / k_best_node: [s2_key C*NSB u64][s2_node C*NSB i32] and, when tree_in_lds, [QNode Q][qheap Q+1][root_heap Q+1]
 extern __shared__ __align__(16) unsigned char kai_dyn_lds[];
@@ -323,6 +324,7 @@ struct ActShared {
     ScanReq req;
     PforReq pfor;
     TopoScan topo; int32_t topo_min[WAVES][KAI_TOPO_SCAN_LEVELS], topo_max[WAVES][KAI_TOPO_SCAN_LEVELS], topo_any[WAVES];  // CMD_TOPO request and the waves' partial results
+    int32_t eval_n, eval_nodes[KAI_BN_LOG]; uint8_t eval_ok[KAI_BN_LOG]; double eval_sc[KAI_BN_LOG];  // CMD_EVAL: scan_node_score of a few nodes for the request in `req` (Engine::best_node_kept)
     int32_t cmd, r, n_dirty, slice_hi;  // slice_hi: the node passes of the current command cover [0, slice_hi) here (N without a scan grid)
     int32_t dirty[KAI_MAXD];
     double part_min[WAVES], part_max[WAVES];
@@ -367,6 +369,11 @@ __shared__ EngineLocal g_el;
 __device__ __forceinline__ unsigned long long orderable(double d) {
     unsigned long long b = (unsigned long long)__double_as_longlong(d);
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ double unorderable(unsigned long long k) {  // the inverse of orderable()
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
 }
 
 template <bool VICTIM, bool TREE_LDS = false>
@@ -450,7 +457,14 @@ struct DevBackendT {
         if (t.op == 9) { int n = 0; for (int w = 1; w < WAVES; w++) n += sh->topo_any[w]; t.any = n; }  // chosen domains
         return true;
     }
-    __device__ int best_node(const KaiCtx&, const ScanReq& q) {
+    __device__ bool eval_nodes(const KaiCtx&, const ScanReq& q, const int32_t* nodes, int m, double* sc, uint8_t* ok) {  // a lane per node on this workgroup's scan waves
+        wait();
+        sh->req = q; sh->eval_n = m; for (int i = 0; i < m; i++) sh->eval_nodes[i] = nodes[i];
+        call(CMD_EVAL);
+        for (int i = 0; i < m; i++) { sc[i] = sh->eval_sc[i]; ok[i] = sh->eval_ok[i]; }
+        return true;
+    }
+    __device__ int best_node(const KaiCtx&, const ScanReq& q, double* score_out = nullptr) {
         scope(); sh->req = q; node_pass(CMD_BEST);
         int best = -1; unsigned long long bk = 0;
         for (int w = 1; w < WAVES; w++) {
@@ -463,6 +477,7 @@ struct DevBackendT {
             const int n = sg_ld(&p.node); const unsigned long long k = __hip_atomic_load(&p.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (n >= 0 && (best < 0 || k > bk || (k == bk && n < best))) { best = n; bk = k; }
         }
+        if (score_out) *score_out = best >= 0 ? unorderable(bk) : 0.0;
         return best;
     }
     __device__ void begin(const KaiCtx& c) { if (c.use_index) call(CMD_BEGIN); }
@@ -688,17 +703,8 @@ __device__ __forceinline__ void scan_cmd(const KaiCtx& c, ActShared* sh, int cmd
         KAI_GP(const uint32_t) ns_bits = sh->nodeset; const int trow = sh->topo_row; KAI_GP(const double) tscore = sh->topo_score;
         for (int n = n_lo + slot; n < n_hi; n += lanes) {
             if (ns_bits && !((ns_bits[n >> 5] >> (n & 31)) & 1)) continue;
-#ifdef KAI_SHARED_GPUS
-            const bool frac = c.shared_on && q.shared;  // a fraction (or MiB) of one device: fit / predicates over the node's GPU groups
-            if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
-            if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n, q.kind))) continue;
-            bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
-#else
-            if (!fits(c, q.req, n, true)) continue;                              // IsTaskAllocatableOnReleasingOrIdle
-            if (!node_predicates(c, q.cpu_only != 0, q.pod_class, n)) continue;  // ssn.PredicateFn
-            bool fit_idle = q.best_effort || fits(c, q.req, n, false);
-#endif
-            double sc = node_score(c, q, n, fit_idle);
+            double sc = 0;
+            if (!scan_node_score(c, q, n, sc)) continue;
             if (trow >= 0) {  // topology.nodeOrderFn (plugins/topology/node_scoring.go:17-35): a node without a score is dropped (session.go:247-251)
                 int dd = c.node_domain[(size_t)trow * c.N + n]; double ts = dd >= 0 ? tscore[dd] : -1.0;
                 if (ts < 0) continue;
@@ -788,6 +794,8 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
             __threadfence();
         } else if (cmd == CMD_MINMAX || cmd == CMD_TOPO || cmd == CMD_BEST) {
             scan_cmd(c, sh, cmd, 0, sh->slice_hi, slot, SCAN_LANES);
+        } else if (cmd == CMD_EVAL) {
+            if (slot < sh->eval_n) { double sc = 0; const bool ok = scan_node_score(c, sh->req, sh->eval_nodes[slot], sc); sh->eval_ok[slot] = ok ? 1 : 0; sh->eval_sc[slot] = sc; }
         }
         if (cmd == CMD_REFRESH && threadIdx.x == 64) sh->t_svc += clock64() - ts;
         __syncthreads();  // results ready

@@ -83,18 +83,20 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
         }
         mn = lo; mx = hi;
     }
-    int best_node(const KaiCtx& c, const ScanReq& q) {
+    bool eval_nodes(const KaiCtx& c, const ScanReq& q, const int32_t* nodes, int m, double* sc, uint8_t* ok) {  // the single-node re-evaluations of Engine::best_node_kept
+        for (int i = 0; i < m; i++) { double s = 0; ok[i] = scan_node_score(c, q, nodes[i], s) ? 1 : 0; sc[i] = s; }
+        return true;
+    }
+    int best_node(const KaiCtx& c, const ScanReq& q, double* score_out = nullptr) {
         int best = -1; double bs = 0;
         for (int n = 0; n < c.N; n++) {
             if (loc.scope_bits && !((loc.scope_bits[n >> 5] >> (n & 31)) & 1)) continue;
-            const bool frac = c.shared_on && q.shared;
-            if (!(frac ? fits_shared(c, q, n, true) : fits(c, q.req, n, true))) continue;
-            if (!(frac ? node_predicates_shared(c, q, n) : node_predicates(c, q.cpu_only != 0, q.pod_class, n, q.kind))) continue;
-            bool fit_idle = q.best_effort || (frac ? fits_shared(c, q, n, false) : fits(c, q.req, n, false));
-            double sc = node_score(c, q, n, fit_idle);
+            double sc = 0;
+            if (!scan_node_score(c, q, n, sc)) continue;
             if (loc.scope_row >= 0) { int dd = c.node_domain[(size_t)loc.scope_row * c.N + n]; double ts = dd >= 0 ? loc.scope_score[dd] : -1.0; if (ts < 0) continue; sc += ts; }
             if (best < 0 || sc > bs) { best = n; bs = sc; }
         }
+        if (score_out) *score_out = bs;
         return best;
     }
     void l2(const KaiCtx& c, int k, int sb) {
