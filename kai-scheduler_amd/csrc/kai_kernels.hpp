@@ -19,7 +19,7 @@
 namespace kai {
 
 constexpr int WG = 512;         // threads per workgroup of the action kernel (8 waves: the control lane's code wants > 128 VGPRs)
-constexpr int WAVES = WG / 64;  // 16
+constexpr int WAVES = WG / 64;  // 8
 constexpr int SCAN_LANES = WG - 64;
 constexpr int SVC = WAVES - 1;  // service waves
 
@@ -721,8 +721,8 @@ __device__ __forceinline__ void scan_cmd(const KaiCtx& c, ActShared* sh, int cmd
     }
 }
 
-// service-wave side: each of the 15 service waves owns the classes  k ≡ wave-1 (mod 15)  of the class index and the nodes
-// (wave-1)*64 + lane (mod 960) of a brute-force scan
+// service-wave side: each of the 7 service waves owns the classes  k ≡ wave-1 (mod 7)  of the class index and the nodes
+// (wave-1)*64 + lane (mod 448) of this workgroup's slice of a pass over the nodes
 __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
     const KaiCtx c = cref;  // loop-invariant: a register copy of the fields used below instead of an LDS read + wait in front of every access
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = threadIdx.x - 64, hw = wave - 1;
