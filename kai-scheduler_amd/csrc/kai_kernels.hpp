@@ -419,10 +419,19 @@ struct DevBackendT {
         ScanGrid* g = g_ctx.sg;
         g->cmd = cmd; g->r = sh->r; g->nodeset = sh->nodeset; g->topo_row = sh->topo_row; g->topo_score = sh->topo_score;
         if (cmd == CMD_BEST) g->req = sh->req; else if (cmd == CMD_TOPO) g->topo = sh->topo;
+#ifdef KAI_PROF_VICTIM
+        const long long tg0 = clock64();
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the node state this lane changed since the last pass, and the payload: written back for the other XCDs
         __hip_atomic_store(&g->seq, ++g_el.sg_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef KAI_PROF_VICTIM
+        const long long tg1 = clock64(); sh->t_seg[0] += tg1 - tg0; sh->t_seg[3]++;
+#endif
         sh->slice_hi = g_ctx.sg_per < g_ctx.N ? g_ctx.sg_per : g_ctx.N;
         call(cmd);
+#ifdef KAI_PROF_VICTIM
+        const long long tg2 = clock64(); sh->t_seg[1] += tg2 - tg1;
+#endif
         // the helpers' folded result: read with coherent loads only — an acquire fence here would empty this XCD's L2 under the control lane after every pass.  What the
         // helpers wrote elsewhere is never read here through a plain load first: bitmap words are read by the slice that wrote them, the survey's sums by op 16's coherent loads
         long long spins = 0;
@@ -430,6 +439,9 @@ struct DevBackendT {
             if (++spins > (1ll << 28)) { g_ctx.st->fault = FAULT_INTERNAL; g_ctx.st->fault_line = __LINE__; break; }  // a helper left the protocol
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef KAI_PROF_VICTIM
+        sh->t_seg[2] += clock64() - tg2;
+#endif
     }
     __device__ void minmax(const KaiCtx&, int r, double& mn, double& mx) {
         scope(); sh->r = r; node_pass(CMD_MINMAX);
@@ -940,6 +952,9 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
     Engine<DevBackendT<VICTIM, TREE_LDS>> eng(c, be);
     if constexpr (VICTIM) eng.execute_victim_action(); else if (action == KAI_ACTION_ALLOCATE) eng.execute_allocate();
     c.st->prof[1] = sh.t_publish; c.st->prof[6] = sh.t_wait; c.st->prof[PF_PUSH] = sh.t_svc;
+#ifdef KAI_PROF_VICTIM
+    if constexpr (!VICTIM) { c.st->prof[36] = sh.t_seg[0]; c.st->prof[37] = sh.t_seg[1]; c.st->prof[38] = sh.t_seg[2]; c.st->prof[39] = sh.t_seg[3]; }  // scan grid: publish (release fence), own slice, wait for the fold, commands
+#endif
     be.finish();
 }
 
