@@ -815,7 +815,7 @@ __device__ void service_loop(const KaiCtx& cref, ActShared* sh) {
 }
 
 // A helper workgroup of the scan grid: all eight waves scan; wave 0 watches the table, and the helper that finishes a command last folds everybody's partial results.
-__device__ void helper_loop(const KaiCtx& cref, ActShared* sh, int wgs) {
+__device__ void helper_loop(const KaiCtx& cref, ActShared* sh) {
     const KaiCtx c = cref;
     ScanGrid* g = c.sg;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -832,7 +832,6 @@ __device__ void helper_loop(const KaiCtx& cref, ActShared* sh, int wgs) {
     const int h = sh->r;
     __syncthreads();
     if (h < 0) return;
-    (void)wgs;
     int gen = 0, n_lo = 0, n_hi = 0, H = 0;
     for (;;) {
         if (threadIdx.x == 0) {
@@ -920,7 +919,7 @@ __global__ void __launch_bounds__(WG) k_action(const KaiCtx* __restrict__ cp, in
         __syncthreads();
         if (threadIdx.x == 0) { g_sh.cmd = CMD_NONE; g_sh.nodeset = nullptr; g_sh.topo_row = -1; g_sh.topo_score = nullptr; }
         __syncthreads();
-        helper_loop(g_ctx, &g_sh, scan_wgs);
+        helper_loop(g_ctx, &g_sh);
         return;
     }
     __syncthreads();
