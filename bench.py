@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--actions", default="", help="comma-separated actions of one cycle (default: allocate; C4: allocate,consolidation,reclaim)")
     ap.add_argument("--mixed", action="store_true", help="config C5 in the shape SURVEY 8d gives it: zone/rack labels, 5 %% topology gangs, 5 %% elastic gangs, minruntime — jobs the batch path leaves to the sequential engine")
     ap.add_argument("--fractions", type=float, default=0.0, help="that share of the one-GPU pods asks for a fraction of one device (shared GPUs: every decision is a brute-force scan of the nodes' GPU groups — the streaming kernel of SURVEY 8d)")
+    ap.add_argument("--queue-depth", type=int, default=0, help="queueDepthPerAction for reclaim / preempt / consolidation (jobs tried per queue and action; 0 = the default: unlimited).  The reference's operator docs configure 5 .. 15 (docs/operator/README.md:64-66, scheduling-shards.md:51-54)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="decisions the CPU oracle is timed on (-1 = auto, 0 = skip)")
     args = ap.parse_args()
 
@@ -83,6 +84,10 @@ def main():
     # the fill is one dependency chain, the exchange only adds to it) and the replicas run as a second leg beside it.
     sharded = world > 1 and os.environ.get("KAI_BENCH_MULTI", "replicas") == "shard"
     snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=0 if (sharded or world == 1) else pkg.dist.shard_seed(0, rank), mixed=args.mixed)
+    if args.queue_depth > 0:
+        for a in ("consolidation", "reclaim", "preempt"):
+            cfg.queue_depth[pkg.abi.ACTIONS[a]] = args.queue_depth
+        desc += f", queueDepthPerAction {args.queue_depth} for the victim actions"
     if args.fractions > 0:
         pkg.synth.add_fractions(snap, 7, frac=args.fractions)
         desc += f" + {round(args.fractions * 100)} % of the one-GPU pods as fractions of one device"
@@ -200,7 +205,7 @@ def main():
         "roofline": roof,
     }
 
-    if rank == 0 and actions == ("allocate",):
+    if rank == 0:
         # end-to-end pin: SHA-256 of this run's committed operations against the oracle's full-size run of the same workload (tools/pin_full_sizes.py wrote
         # profiles/full_size_pins.json on the CPU: oracle vs host-compiled engine, every operation / pod / node / share equal)
         import kai_testlib as T
