@@ -173,6 +173,19 @@ def test_hostsim_config5_in_the_mixed_shape(scale):
     assert_same(HostSim.run(snap, cfg, ("allocate",)), T.Oracle.run(snap, cfg, ("allocate",), threads=8 if snap.n_nodes >= 2048 else 1))
 
 
+@pytest.mark.parametrize("scale,depth", [(0.02, 3), (0.05, 8)])
+def test_hostsim_config4_with_queue_depth(scale, depth):
+    """BASELINE config 4 with queueDepthPerAction for the victim actions (framework/session.go:398-404: jobs tried per queue and action; the reference's operator docs configure
+    5 .. 15): allocate, consolidation, reclaim against the oracle.  The same shape at 30 % is pinned in profiles/full_size_pins.json (tools/pin_c4_depth.py)."""
+    snap, cfg, _ = T.pkg.synth.config(3, scale)
+    for a in ("consolidation", "reclaim", "preempt"):
+        cfg.queue_depth[T.abi.ACTIONS[a]] = depth
+    acts = ("allocate", "consolidation", "reclaim")
+    ref = T.Oracle.run(snap, cfg, acts)
+    assert any(o[0] == 2 for o in ref.ops)
+    assert_same(HostSim.run(snap, cfg, acts), ref)
+
+
 @pytest.fixture
 def domain_loops_on_lanes():
     """subSetNodesFn's loops over the DOMAINS of a topology in the forms the scan lanes of the action kernel run (TopoScan ops 5 .. 14, Engine::topo_dom_body: roll-ups,

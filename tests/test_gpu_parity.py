@@ -287,6 +287,19 @@ def test_gpu_scan_grid_at_full_size_against_the_host_compiled_engine(gpu):
     assert_same_tol(res, ref); _same_groups(snap, res, ref)
 
 
+@pytest.mark.parametrize("scale,depth", [(0.02, 3), (0.05, 8)])
+def test_gpu_config4_with_queue_depth(gpu, scale, depth):
+    """BASELINE config 4 with queueDepthPerAction for the victim actions (the reference's operator docs configure 5 .. 15): allocate, consolidation, reclaim on the device
+    (victim actions on 32 workgroups) against the oracle.  bench.py --config C4 --scale 0.3 --queue-depth 8 is the benched form (profiles/full_size_pins.json holds the oracle's hash)."""
+    snap, cfg, _ = T.pkg.synth.config(3, scale)
+    for a in ("consolidation", "reclaim", "preempt"):
+        cfg.queue_depth[T.abi.ACTIONS[a]] = depth
+    acts = ("allocate", "consolidation", "reclaim")
+    ref = T.Oracle.run(snap, cfg, acts)
+    assert any(o[0] == 2 for o in ref.ops)
+    assert_same(run_gpu(snap, cfg, acts), ref)
+
+
 import test_oracle_golden as _G
 INTEG_FILES = _G.INTEG_FILES  # all 113 scenarios, incl. the fraction, GPU-memory and MIG tables
 INTEG = [(n, i, c) for n in INTEG_FILES for i, c in enumerate(T.load_golden(n)["cases"])]
