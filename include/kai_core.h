@@ -332,8 +332,8 @@ typedef struct kai_action_stats {
                                    [4] rounds of the batch path (0 = sequential engine), [5..7] cycle / time counters of the path that ran (kai_core.hip).
                                    Victim actions (consolidation / reclaim / preempt): [1] workgroups the action ran on (default 32, environment KAI_VICTIM_WGS;
                                    1 with shared GPUs in the session), [5] waves of simulations, [6] simulations run << 32 | simulations the reference's order reaches.
-                                   Allocate on the sequential engine of a cluster of >= 4096 nodes: bits 48.. of [1] = workgroups that took the passes over the nodes
-                                   (scan grid: the engine's own + the helpers; default 32 launched, environment KAI_SCAN_WGS, 1 = off) */
+                                   Allocate on the sequential engine of a cluster of >= 1024 nodes: bits 48.. of [1] = workgroups that took the passes over the nodes
+                                   (scan grid: the engine's own + the helpers; default 16 launched, 32 from 4096 nodes, environment KAI_SCAN_WGS, 1 = off) */
 } kai_action_stats;
 
 typedef struct kai_core kai_core; /* opaque */

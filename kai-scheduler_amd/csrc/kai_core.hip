@@ -644,7 +644,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         // the allocate action of a large cluster: helper workgroups beside the engine's take the passes over the nodes (ScanGrid, kai_kernels.hpp)
         int scan_wgs = 1;
         if (!victim) {
-            int want = c.N >= 4096 ? 32 : 1; if (const char* e = std::getenv("KAI_SCAN_WGS")) want = std::atoi(e);  // (measured on the mixed config 5 and on config 3 with fractions: 16 .. 32 workgroups are the fastest, 64 and more pay for the table they all watch)
+            int want = c.N >= 4096 ? 32 : c.N >= 1024 ? 16 : 1; if (const char* e = std::getenv("KAI_SCAN_WGS")) want = std::atoi(e);  // (measured on the mixed config 5 and on config 3 with fractions: 16 .. 32 workgroups are the fastest, 64 and more pay for the table they all watch; from about a thousand nodes a pass on the grid beats one on this workgroup alone: 1 500 nodes 355 -> 303 ms, 2 500: 707 -> 517, 3 500: 1 143 -> 725 per cycle of config 3 with fractions)
             int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, core->device) != hipSuccess || cus <= 0) cus = 64;
             want = std::max(1, std::min(std::min(want, (int)KAI_SG_MAX), cus / 2));  // every workgroup must be resident (the control lane waits for the helpers); half the chip leaves room for a neighbour
             if (want > 1 && !core->d_sg) { ScanGrid* g = nullptr; int rcg = dalloc(core, &g, (size_t)1); if (rcg) return rcg; core->d_sg = g; }
