@@ -447,6 +447,28 @@ def test_scheduling_signatures():
     assert sig["a"] == sig["b"] and sig["d"] == sig["e"] and len({sig["a"], sig["c"], sig["d"], sig["f"]}) == 4
 
 
+def test_pods_are_converted_from_spans_one_at_a_time():
+    """rawObjects.pods is only LOCATED by the document parser; every element is parsed on its own when it is converted (kai_ingest.cpp PodSpans): a syntax error inside one pod
+    is reported with its byte offset in the document, an element that is not an object is skipped like encoding/json would leave it zero-valued, and the result equals what
+    the same document gives when its pods are few."""
+    d = doc(nodes=[node("n")], queues=[queue("q")], pods=[pod("a0", "a"), pod("a1", "a"), pod("b0", "b")], pod_groups=[pod_group("a"), pod_group("b")])
+    text = json.dumps(d)
+    good = ing.ingest_json(text).snapshot
+    assert good.n_pods == 3
+    # a broken element: the offset points into that element
+    i = text.index('"name": "a1"')
+    bad = text[:i] + '"name": @' + text[i + len('"name": "a1"'):]
+    with pytest.raises(ing.IngestError, match=r"snapshot.json: .* at byte (\d+)") as e:
+        ing.ingest_json(bad)
+    at = int(str(e.value).rsplit("at byte ", 1)[1].split()[0].rstrip(")"))
+    assert abs(at - i) < 40
+    # elements that are not objects are passed over
+    j = text.index('"pods": [') + len('"pods": [')
+    odd = text[:j] + "null, 7, " + text[j:]
+    assert ing.ingest_json(odd).snapshot.n_pods == 3
+    assert list(ing.ingest_json(odd).snapshot.pod_names) == list(good.pod_names)
+
+
 def test_malformed_input_is_rejected():
     for text in ("", "{", "[1,2", '{"a":}', '{"a":1}x', "nul"):
         with pytest.raises(ing.IngestError):
