@@ -294,12 +294,22 @@ def main():
                 if frac > 0:
                     pkg.synth.add_fractions(s2, 7, frac=frac)
                 core2 = pkg.KaiCore(c2, gpu_ids=(dev_index,)); ssn2 = core2.open_session(s2)
-                n2 = 0
+                n2 = 0; ops2 = None
                 for it in range(2):
                     ssn2.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
-                    n2 = len(ssn2.execute("allocate")); torch.cuda.synchronize(); el = time.perf_counter() - t0
+                    ops2 = ssn2.execute("allocate"); n2 = len(ops2); torch.cuda.synchronize(); el = time.perf_counter() - t0
                 st2 = ssn2.stats()
-                shapes[key] = {"workload": d2 + (" + 30 % of the one-GPU pods as fractions of one device" if frac > 0 else ""), "ms_per_step": el * 1e3, "placements_per_s": n2 / el, "placements": n2,
+                w2 = d2 + (" + 30 % of the one-GPU pods as fractions of one device" if frac > 0 else "")
+                import hashlib
+                sha2 = hashlib.sha256(np.stack([ops2["kind"], ops2["pod"], ops2["node"], ops2["job"]], 1).astype("<i4").tobytes()).hexdigest()  # = kai_testlib.ops_sha256
+                pin2 = None
+                try:
+                    with open(os.path.join(ROOT, "profiles", "full_size_pins.json")) as f:
+                        pin2 = next((v for v in json.load(f).values() if v.get("workload") == w2 and v.get("nodes") == s2.n_nodes and v.get("pods") == s2.n_pods), None)
+                except (OSError, ValueError):
+                    pin2 = None
+                shapes[key] = {"workload": w2, "ms_per_step": el * 1e3, "placements_per_s": n2 / el, "placements": n2,
+                               "ops_sha256": sha2, "equal_to_oracle": (sha2 == pin2["ops_sha256"]) if pin2 else None,
                                "decisions": int(st2.decisions), "path": "batch" if int(st2.reserved[4]) > 0 else "sequential engine", "scan_grid_workgroups": max(1, int(st2.reserved[1]) >> 48) if int(st2.reserved[4]) == 0 else None}
                 ssn2.close(); core2.destroy()
             except Exception as e:  # additional evidence: it must not take the headline down
