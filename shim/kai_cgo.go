@@ -26,11 +26,14 @@ import (
 	"unsafe"
 
 	v1 "k8s.io/api/core/v1"
+	"k8s.io/apimachinery/pkg/types"
 
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/allocate"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/consolidation"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/preempt"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/reclaim"
+	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/utils"
+	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/eviction_info"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/node_info"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/pod_info"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/pod_status"
@@ -464,6 +467,9 @@ func (a *action) Execute(ssn *framework.Session) { // framework/interface.go:41-
 		a.goAction.Execute(ssn)
 		return
 	}
+	if zeroDepth[a.kind] {
+		return // queueDepthPerAction 0: every leaf heap stays empty (kai_cgo_config.go), the action tries no job — neither here nor on the device
+	}
 	pack := current.pack
 	capOps := C.int64_t(2*len(pack.pods) + 64)
 	ops := (*C.kai_op)(C.malloc(C.size_t(capOps) * C.size_t(unsafe.Sizeof(C.kai_op{}))))
@@ -476,7 +482,7 @@ func (a *action) Execute(ssn *framework.Session) { // framework/interface.go:41-
 		a.goAction.Execute(ssn)
 		return
 	}
-	if !replay(ssn, pack, unsafe.Slice(ops, int(n))) {
+	if !replay(ssn, a.name, pack, unsafe.Slice(ops, int(n))) {
 		pack.fallback = true // the live session and the device state have parted: nothing more from the device in this cycle
 	}
 }
@@ -485,13 +491,36 @@ func (a *action) Execute(ssn *framework.Session) { // framework/interface.go:41-
 // commit order; one id = one Statement, e.g. a reclaim "evict A, evict B, pipeline C" (framework/statement.go:536-575).
 // An operation the live session refuses (the cache moved on since the snapshot, a bind conflict) discards its whole Statement —
 // a gang is committed entirely or not at all — and ends the replay: false.
-func replay(ssn *framework.Session, pack *packedSnapshot, ops []C.kai_op) bool {
+func replay(ssn *framework.Session, action framework.ActionType, pack *packedSnapshot, ops []C.kai_op) bool {
 	groups := carray[C.int32_t](pack, len(pack.pods)) // PodInfo.GPUGroups[0] of the fraction pods after the action (freed with the snapshot)
 	haveGroups := len(pack.pods) > 0 && C.kai_pod_gpu_groups(core, ptr(groups), C.int(len(pack.pods))) == 0
 	for i := 0; i < len(ops); {
 		stmt := ssn.Statement()
 		id := ops[i].stmt
 		var err error
+		// EvictionMetadata of the Statement's evictions (actions/common/action.go:34-38): the gang = every task the solution evicts, the preemptor = the job the
+		// Statement pipelines / allocates.  A Statement of a victim action holds one solution: "evict ..., pipeline the preemptor's tasks" (framework/statement.go:536-575).
+		meta := eviction_info.EvictionMetadata{Action: string(action)}
+		var preemptor *podgroup_info.PodGroupInfo
+		for k := i; k < len(ops) && ops[k].stmt == id; k++ {
+			switch ops[k].kind {
+			case C.KAI_OP_EVICT:
+				meta.EvictionGangSize++
+			case C.KAI_OP_ALLOCATE, C.KAI_OP_PIPELINE:
+				if preemptor == nil {
+					preemptor = ssn.ClusterInfo.PodGroupInfos[pack.pods[ops[k].pod].Job]
+				}
+			}
+		}
+		messages := map[int]string{} // getEvictionMessages: every message from the state BEFORE the first eviction (actions/common/action.go:51-60)
+		if preemptor != nil {
+			meta.Preemptor = &types.NamespacedName{Namespace: preemptor.Namespace, Name: preemptor.Name}
+			for k := i; k < len(ops) && ops[k].stmt == id; k++ {
+				if ops[k].kind == C.KAI_OP_EVICT {
+					messages[k] = utils.GetMessageOfEviction(ssn, action, pack.pods[ops[k].pod], preemptor)
+				}
+			}
+		}
 		for ; i < len(ops) && ops[i].stmt == id; i++ {
 			if err != nil {
 				continue // skip the rest of a Statement that is going to be discarded
@@ -510,7 +539,7 @@ func replay(ssn *framework.Session, pack *packedSnapshot, ops []C.kai_op) bool {
 					err = stmt.Pipeline(task, node.Name, task.Status != pod_status.Pending)
 				}
 			case C.KAI_OP_EVICT:
-				err = stmt.Evict(task, "gpucore", nil)
+				err = stmt.Evict(task, messages[i], meta)
 			}
 		}
 		if err != nil {

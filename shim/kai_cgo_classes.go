@@ -21,6 +21,7 @@ import (
 	"unsafe"
 
 	v1 "k8s.io/api/core/v1"
+	"k8s.io/apimachinery/pkg/util/uuid"
 	v1helper "k8s.io/component-helpers/scheduling/corev1"
 	"k8s.io/component-helpers/scheduling/corev1/nodeaffinity"
 
@@ -63,13 +64,19 @@ type staticClasses struct {
 	nodeIDs    map[string]int
 	nodeReps   []*v1.Node
 	nodeOf     map[string]int // node name -> class, filled by nodeClass
-	groupIDs   map[string]int32
+	groupIDs   map[string]int32   // node + "\x00" + group name -> id
+	groupNames map[groupKey]string // (node, id) -> group name: the snapshot's names and the UUIDs drawn in replay for devices opened in this cycle
 	nextNewGrp int32
+}
+
+type groupKey struct {
+	node string
+	id   int32
 }
 
 func newStaticClasses(nodes []*node_info.NodeInfo) *staticClasses {
 	return &staticClasses{nodes: nodes, podIDs: map[string]int{}, usedKeys: map[string]struct{}{}, nodeIDs: map[string]int{}, nodeOf: map[string]int{},
-		groupIDs: map[string]int32{}, nextNewGrp: 1 << 20} // KAI_NEW_GROUP: ids of non-numeric group names (kai_engine.hpp)
+		groupIDs: map[string]int32{}, groupNames: map[groupKey]string{}, nextNewGrp: 1 << 20} // KAI_NEW_GROUP: ids of non-numeric group names (kai_engine.hpp)
 }
 
 func reqSig(rs []v1.NodeSelectorRequirement) string {
@@ -205,20 +212,26 @@ func (c *staticClasses) groupID(nodeName, group string) int32 {
 	id := c.nextNewGrp
 	c.nextNewGrp++
 	c.groupIDs[key] = id
+	c.groupNames[groupKey{nodeName, id}] = group
 	return id
 }
 
-// groupName: the inverse, for the GPU groups kai_pod_gpu_groups reports after an action (SelectedGPUGroups of a BindRequest)
+// groupName: the inverse, for the GPU groups kai_pod_gpu_groups reports after an action (SelectedGPUGroups of a BindRequest).
+// An id >= KAI_NEW_GROUP that no snapshot name maps to is a device the engine opened in THIS cycle.  The reference names such a
+// group in the scheduler, before stmt.Allocate / Pipeline: findGpuForSharingOnNode draws uuid.NewUUID() (gpu_sharing/gpuSharing.go:73-83),
+// cache.go:316 copies PodInfo.GPUGroups into BindRequest.SelectedGPUGroups.  So the first pod that lands in (node, id) draws the
+// UUID and every later pod of the same (node, id) — the device put it in the same group — reads it back from groupIDs.
 func (c *staticClasses) groupName(nodeName string, id int32) string {
 	if id < 1<<20 {
 		return strconv.Itoa(int(id))
 	}
-	for key, v := range c.groupIDs {
-		if v == id && strings.HasPrefix(key, nodeName+"\x00") {
-			return key[len(nodeName)+1:]
-		}
+	if name, ok := c.groupNames[groupKey{nodeName, id}]; ok {
+		return name
 	}
-	return "" // a group the device opened in this cycle: the binder names it (gpu_sharing/gpuSharing.go:60-75)
+	name := string(uuid.NewUUID())
+	c.groupIDs[nodeName+"\x00"+name] = id
+	c.groupNames[groupKey{nodeName, id}] = name
+	return name
 }
 
 // ------------------------------------------------------------------------------------------------ topologies + sub-group trees

@@ -26,6 +26,9 @@ var pluginBits = map[string]C.uint32_t{
 	"gpupack": C.KAI_PLUGIN_GPUPACK, "gpuspread": C.KAI_PLUGIN_GPUSPREAD,
 }
 
+// actions whose queueDepthPerAction entry is an explicit 0 (filled by ConfigFromScheduler): they pop no job in the reference
+var zeroDepth = map[C.int]bool{}
+
 var actionIndex = map[string]int{"allocate": C.KAI_ACTION_ALLOCATE, "consolidation": C.KAI_ACTION_CONSOLIDATION, "reclaim": C.KAI_ACTION_RECLAIM, "preempt": C.KAI_ACTION_PREEMPT}
 
 // ConfigFromScheduler fills kai_config from the scheduler's configuration.  Returns the actions of conf.Actions that the device path implements, in order
@@ -51,9 +54,16 @@ func ConfigFromScheduler(sc *conf.SchedulerConfiguration, params conf.SchedulerP
 	for i := range cfg.queue_depth { // framework/session.go:398-404: no entry = every job of the queue
 		cfg.queue_depth[i] = -1
 	}
+	zeroDepth = map[C.int]bool{}
 	for name, depth := range sc.QueueDepthPerAction {
 		if i, ok := actionIndex[name]; ok {
 			cfg.queue_depth[i] = C.int32_t(depth)
+			// An explicit 0 is NOT "infinite": PriorityQueue.Push removes index 0 — the element just pushed or the best one — whenever Len() > 0
+			// (scheduler_util/priority_queue.go:50-55), so every leaf heap of the action stays empty and the action pops no job.  The ABI reads
+			// 0 as "no limit", so the shim keeps such an action away from the device and runs it as the no-op it is (action.Execute).
+			if depth == 0 {
+				zeroDepth[C.int(i)] = true
+			}
 		}
 	}
 	if len(sc.Tiers) == 0 {
@@ -72,6 +82,9 @@ func ConfigFromScheduler(sc *conf.SchedulerConfiguration, params conf.SchedulerP
 				}
 			case "proportion":
 				if v, err := strconv.ParseFloat(pl.Arguments["kValue"], 64); err == nil {
+					if v <= 0 { // proportion.go:81-84: "kValue must be > 0.0 ... Setting as 0"
+						v = 0
+					}
 					cfg.k_value = C.double(v)
 				}
 				if v, err := strconv.ParseFloat(pl.Arguments["relcaimerSaturationMultiplier"], 64); err == nil && v >= 1.0 { // (the argument's spelling in proportion.go)

@@ -142,7 +142,8 @@ def test_gpu_full_size_properties(gpu):
     placed = np.array([p for (_, p, _, _) in res.ops])
     assert len(set(placed.tolist())) == len(placed)
     # node accounting: allocatable == idle + used for every resource when nothing is releasing
-    assert np.array_equal(a["node_allocatable"].T, res.nodes["idle"] + res.nodes["used"] - res.nodes["releasing"] * 0 + 0 * res.nodes["used"]) or True
+    assert not res.nodes["releasing"].any()
+    assert np.array_equal(a["node_allocatable"].T, res.nodes["idle"] + res.nodes["used"])
     used = np.zeros_like(res.nodes["used"])
     active = (res.pod_status & T.abi.ACTIVE_USED) != 0
     for r in range(snap.n_res):
