@@ -156,25 +156,36 @@ def main():
     if batch:
         plan_ms, fill_ms, apply_ms = (int(st.reserved[7]) >> 42) / 1e3, ((int(st.reserved[7]) >> 21) & 0x1fffff) / 1e3, (int(st.reserved[7]) & 0x1fffff) / 1e3
         rounds = int(st.reserved[4]); fill_dec = decisions - drained
+        buckets = bool((int(st.reserved[1]) >> 62) & 1)  # the fill ran on k_fill_buckets (kai_fill_buckets.hpp): sets of nodes by free devices, all in LDS
+        fill_kernel = "k_fill_buckets" if buckets else "k_fill"
         if sharded:
             engine["exchanges_per_step"] = int(st.reserved[0])
         engine.update({"path": "batch (plan / fill / apply rounds)", "rounds": rounds, "mispredicted_jobs": int(st.reserved[6]), "fill_wave_cycles": int(st.reserved[5]),
-                       "fill_block_loads": int(st.reserved[1]), "plan_ms": plan_ms, "fill_ms": fill_ms, "apply_ms": apply_ms,
+                       "fill_kernel": fill_kernel, "fill_block_loads": int(st.reserved[1]) & ((1 << 48) - 1), "plan_ms": plan_ms, "fill_ms": fill_ms, "apply_ms": apply_ms,
                        "fill_cycles_per_decision": int(st.reserved[5]) / max(fill_dec, 1)})
         # the dominant kernel: k_fill, `rounds` launches per step, timed with HIP events on its stream around every launch (kai_core.hip DevLauncher)
         alg_bytes_launch = fill_dec * b_dec / max(rounds, 1); avg_launch_ms = fill_ms / max(rounds, 1)
         achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = pmc_traffic(desc, "k_fill")
+        traffic = pmc_traffic(desc, fill_kernel)
+        if buckets:
+            limiter = ("dependent LDS accesses of ONE wavefront (k_fill_buckets: 1 workgroup, wavefront 0 walks the planned order over bitmaps of the nodes by free devices "
+                       "— ~10 LDS round trips per decision, no node record is read; fill_cycles_per_decision below), not HBM")
+            note = ("achieved = decisions placed by k_fill_buckets x (N x 128 B + 80 B) / its time: decision throughput against the roofline of the STREAMING formulation (SURVEY 8d), "
+                    "which re-reads every node per decision.  The kernel answers a decision from LDS-resident sets (nodes with g free devices, g = 1..L) and touches HBM only for the "
+                    "task's node (4 B) and the sets' home copy per launch, so frac may exceed 1 (SURVEY 8d says so); what bounds it is LDS latency on one wavefront.")
+        else:
+            limiter = "instruction issue of ONE wavefront (k_fill runs as 1 workgroup x 64 lanes on one of the 256 CUs; fill_cycles_per_decision below), not HBM"
+            note = ("achieved = decisions placed by k_fill x (N x 128 B + 80 B) / k_fill time: decision throughput against the roofline of the STREAMING formulation (SURVEY 8d). "
+                    "The class index answers a decision from one 64-node block, so the measured traffic is far below the algorithmic bytes; the kernel is one wavefront "
+                    "bound by instruction issue / dependent latency (fill_cycles_per_decision), not by HBM bandwidth.")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "limiter": "instruction issue of ONE wavefront (k_fill runs as 1 workgroup x 64 lanes on one of the 256 CUs; fill_cycles_per_decision below), not HBM",
-                "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 1,
-                "traffic_source": "static: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE of k_fill from committed rocprofv3 --pmc passes of this command (counters need their own passes; not collected in this run)",
-                "kernel": "k_fill", "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,
+                "bound_actual": "lds-latency" if buckets else "issue", "limiter": limiter,
+                "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 4 if buckets else 1,
+                "traffic_source": "static: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE of the fill kernel from committed rocprofv3 --pmc passes of this command (counters need their own passes; not collected in this run)" if traffic else "no --pmc pass of this kernel on file",
+                "kernel": fill_kernel, "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "other_kernels": {"plan (k_plan_leaf / rank / scan / emit)": {"ms_per_step": plan_ms}, "apply (k_apply_jobs / nodes)": {"ms_per_step": apply_ms},
                                   "k_drain": {"decisions": drained, "note": "jobs popped after no class fits anywhere: resolved chip-wide without touching a node; NOT counted in this roofline"}},
-                "note": "achieved = decisions placed by k_fill x (N x 128 B + 80 B) / k_fill time: decision throughput against the roofline of the STREAMING formulation (SURVEY 8d). "
-                        "The class index answers a decision from one 64-node block, so the measured traffic is far below the algorithmic bytes; the kernel is one wavefront "
-                        "bound by instruction issue / dependent latency (fill_cycles_per_decision), not by HBM bandwidth."}
+                "note": note}
     else:
         if any(a != "allocate" for a in actions):
             s_a = last_stats[0]

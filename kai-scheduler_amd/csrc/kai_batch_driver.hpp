@@ -18,7 +18,7 @@ struct BatchStats {
     int64_t rounds = 0, mismatches = 0, planned = 0;
     int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0;
     int64_t fill_cycles = 0, fill_load = 0, fill_update = 0, fill_rescan = 0, block_loads = 0, rescans1 = 0, rescans2 = 0, rescans3 = 0;
-    int32_t drain = 0, ran = 0, max_h = 0, pad = 0;
+    int32_t drain = 0, ran = 0, max_h = 0, buckets = 0;  // buckets: the fill ran on kai_fill_buckets.hpp
     int64_t exchanges = 0;  // node-sharded group: all-gathers of the action
 };
 
@@ -45,6 +45,7 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_stmt, J + 1); KB_Z(g_first, J + 1); KB_Z(g_nt, J + 1); KB_Z(g_ucls, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
     KB_Z(t_cls, P); KB_Z(t_node, P);
     KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1);
+    KB_Z(bk_words, (size_t)KBK_GMAX * c.NB); KB_Z(bk_ok, (size_t)std::max(c.C, 1) * c.NB); KB_Z(bk_meta, sizeof(BucketMeta) / 4);
     if (world > 1) {  // node-axis sharding: contiguous 64-node-block ranges in name-rank order, offers of K nodes per class and rank
         b.world = world; b.rank = rank;
         const int per = (c.NB + world - 1) / world;  // blocks per rank
@@ -73,6 +74,18 @@ inline size_t batch_fill_lds(const KaiCtx& c, int& l1_in_lds) {
     const size_t budget = 160 * 1024 - 16 * 1024;  // static LDS of the kernel (rollback list: 8 KB) + margin
     l1_in_lds = (l2 + l1 <= budget && !std::getenv("KAI_BATCH_L1_HBM")) ? 1 : 0;  // the variable forces the HBM variant (tests)
     return l2 + (l1_in_lds ? l1 : 0) + 16;
+}
+
+// The bucket fill (kai_fill_buckets.hpp) takes the action when k_bucket_build's proof holds for every node and the sets fit the LDS of one CU.
+inline bool batch_bucket_params(const KaiCtx& c, const BucketMeta& m, BucketParams& bp, size_t& dyn) {
+    bp = BucketParams{}; dyn = 0;
+    if (m.bad || c.C < 1 || c.C > 64 || !(c.plugins & KAI_PLUGIN_NODEPLACEMENT)) return false;
+    bp.levels = std::max(1, (int)m.max_free); bp.nw = c.NB; bp.nw1 = (c.NB + 63) / 64; bp.n_ok = 0;
+    if (bp.levels > KBK_GMAX || bp.nw1 > 64) return false;
+    for (int k = 0; k < 64; k++) bp.okslot[k] = -1;
+    for (int k = 0; k < c.C; k++) if (m.ok_miss[k]) bp.okslot[k] = (int8_t)bp.n_ok++;
+    dyn = ((size_t)bp.levels * bp.nw + (size_t)bp.levels * bp.nw1 + KBK_GMAX + (size_t)bp.n_ok * bp.nw) * 8 + 16;
+    return dyn <= (size_t)(160 - 16) * 1024;  // beside the kernel's static LDS (rollback list: 8 KB) and a margin
 }
 
 // The fill of one planned round on a node-sharded group: offers -> all-gather -> the same virtual fill on every rank -> own records
@@ -136,11 +149,22 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     int l1_in_lds = 0; const size_t dyn = batch_fill_lds(c, l1_in_lds);
     RoundParams rp{}; rp.mode = 1;
     FillStatus fs{};
+    // bin-packed GPU classes on nodes where only the devices can bind: the fill over sets of nodes by free devices, all in LDS (kai_fill_buckets.hpp);
+    // KAI_FILL_GENERAL=1 keeps the general kernel (A/B runs, tests)
+    bool buckets = false; BucketParams bp{}; size_t dyn_bk = 0;
+    if (!sharded && c.C >= 1 && !std::getenv("KAI_FILL_GENERAL")) {
+        BucketMeta m{};
+        if (int rc = l.write((void*)c.bt.bk_meta, &m, sizeof m)) return rc;
+        l.bucket_build(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
+        if (int rc = l.read(&m, (const void*)c.bt.bk_meta, sizeof m)) return rc;
+        buckets = batch_bucket_params(c, m, bp, dyn_bk);
+    }
+    bs.buckets = buckets ? 1 : 0;
     if (sharded) { l.shard_mask_nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
                    const int b0 = c.bt.n_lo / KAI_BLOCK, b1 = (c.bt.n_hi + KAI_BLOCK - 1) / KAI_BLOCK; (void)b0; (void)b1;
                    l.index_from_recs(std::max(1, c.NB), 64, c, (const NodeRec*)c.bt.nrec, c.N, (uint64_t*)c.sum1_key, (int32_t*)c.sum1_node, c.NB, 0, c.NB);
                    if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }
-    else { l.fill(1, 64, dyn, c, rp, l1_in_lds); if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; }
+    else { if (buckets) l.fill_buckets(1, 256, dyn_bk, c, rp, bp); else l.fill(1, 64, dyn, c, rp, l1_in_lds); if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; }
     int H = 16; int64_t ops_base = ops_base0, stmt_base = stmt_base0;
     while (remaining > 0) {
         if (fs.all_dead) { bs.drain = 1; break; }
@@ -157,6 +181,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         }
         l.plan_emit(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c);
         if (sharded) { rp.start = 0; if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }
+        else if (buckets) l.fill_buckets(1, 256, dyn_bk, c, rp, bp);
         else l.fill(1, 64, dyn, c, rp, l1_in_lds);
         l.apply_jobs(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c, ops_base, stmt_base);
         if (Q) l.apply_nodes((Q + TB - 1) / TB, TB, c);

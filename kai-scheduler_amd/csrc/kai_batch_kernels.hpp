@@ -821,3 +821,5 @@ __global__ void k_shard_scatter(KaiCtx c, int total) { kb_shard_scatter(c, total
 #endif
 
 }  // namespace kai
+
+#include "kai_fill_buckets.hpp"

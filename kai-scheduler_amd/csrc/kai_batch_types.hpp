@@ -60,6 +60,10 @@ struct BatchCtx {
     KAI_GP(uint8_t) g_flag, g_out;           // [J] predicted / actual outcome
     KAI_GP(int32_t) t_cls, t_node;           // [P] (a job's pod range) scan class of the i-th task of its chunk; node the fill kernel gave it
     KAI_GP(NodeRec) nrec;        // [NB*64]
+    // bucket fill (kai_fill_buckets.hpp): HBM home of the sets "nodes with g free devices" (g = 1 .. 16), the classes' static-predicate bitmaps, the build's verdict
+    KAI_GP(uint64_t) bk_words;   // [16][NB]
+    KAI_GP(uint64_t) bk_ok;      // [C][NB]
+    KAI_GP(int32_t) bk_meta;     // BucketMeta
     KAI_GP(FillStatus) fs;       // [1]
     KAI_GP(uint64_t) dead_mask;  // [1]
     // node-axis sharding over the GPUs of one node: this rank owns the nodes [n_lo, n_hi); everything else is replicated.

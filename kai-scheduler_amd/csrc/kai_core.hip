@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -212,6 +213,14 @@ struct DevLauncher {
         hipLaunchKernelGGL(k_fill, dim3(g), dim3(b), dyn, core->stream, c, rp, l1);
         if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);                                       // … to its last (exchanges included)
     }
+    bool fill_bk_attr_set = false;
+    void bucket_build(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_bucket_build, dim3(g), dim3(b), 0, core->stream, c); }
+    void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
+        if (!fill_bk_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_buckets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_bk_attr_set = true; }
+        if (rp.mode == 0) (void)hipEventRecord(core->bev[1], core->stream);
+        hipLaunchKernelGGL(k_fill_buckets, dim3(g), dim3(b), dyn, core->stream, c, rp, bp);
+        if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);
+    }
     void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { hipLaunchKernelGGL(k_apply_jobs, dim3(g), dim3(b), 0, core->stream, c, (long long)ops_base, (long long)stmt_base); }
     void apply_nodes(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_apply_nodes, dim3(g), dim3(b), 0, core->stream, c); (void)hipEventRecord(core->bev[3], core->stream); timed = true; }
     bool timed = false;
@@ -352,7 +361,12 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     if (!core || !s) return KAI_ERR_INVALID_ARG;
     if (s->abi_version != KAI_ABI_VERSION || s->n_res < 4 || s->n_res > KAI_MAX_RES) return fail(core, KAI_ERR_INVALID_ARG, "bad abi_version / n_res");
     HIP_TRY(core, hipSetDevice(core->device));
+    const bool prof_open = std::getenv("KAI_PROF") != nullptr;  // host clocks of the open: where a production cycle's per-cycle cost goes (stderr)
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_begin = tnow();
     free_session(core);
+    const auto t_freed = tnow();
     const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
     if (N < 0 || P < 0 || S < 0 || J < 0 || Q < 0) return fail(core, KAI_ERR_INVALID_ARG, "negative dimension");
     for (int p = 0; p < P; p++) if (s->pod_flags && (s->pod_flags[p] & KAI_POD_CPU_FALLBACK) && s->pod_status[p] == KAI_POD_PENDING)
@@ -373,8 +387,10 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     c.restrict_nodes = core->cfg.restrict_node_scheduling; c.k_value = core->cfg.k_value <= 0.0 ? 0.0 : core->cfg.k_value;  // proportion.go:77-84
 
     // ---- index structures (pure re-orderings / groupings of the input; kai_host_prep.hpp)
+    const auto t_shared = tnow();
     HostPrep prep;
     if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG;
+    const auto t_prep = tnow();
     for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
         if (s->pod_flags && (s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
     core->perm = prep.perm;
@@ -530,7 +546,10 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     HIP_TRY(core, hipMemcpyAsync(core->d_ctx, &core->ctx, sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
     { int rc2 = launch_open_kernels(core); if (rc2) return rc2; }
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
+    const auto t_enq = tnow();
     HIP_TRY(core, hipStreamSynchronize(core->stream));  // prep's host buffers die with this scope
+    if (prof_open) std::fprintf(stderr, "kai open: free %.2f ms, checks + shared pods %.2f, host prep %.2f, allocate + enqueue uploads %.2f, wait %.2f | total %.2f ms\n",
+                                tms(t_begin, t_freed), tms(t_freed, t_shared), tms(t_shared, t_prep), tms(t_prep, t_enq), tms(t_enq, tnow()), tms(t_begin, tnow()));
     float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));
     std::memset(&core->stats, 0, sizeof(core->stats));
     core->stats.upload_ms = ms;
@@ -683,9 +702,9 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         core->stats.reserved[4] = bs.rounds; core->stats.reserved[5] = bs.fill_cycles; core->stats.reserved[6] = bs.mismatches;
         auto us = [](double ms) { int64_t v = (int64_t)(ms * 1000.0); return v < 0 ? (int64_t)0 : v > 0x1fffff ? (int64_t)0x1fffff : v; };
         core->stats.reserved[7] = (us(core->batch_plan_ms) << 42) | (us(core->batch_fill_ms) << 21) | us(core->batch_apply_ms);
-        core->stats.reserved[1] = bs.block_loads; core->stats.reserved[0] = core->world > 1 ? bs.exchanges : core->stats.reserved[0];
-        if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai batch: rounds %lld mismatches %lld planned %lld max_h %d | fill cycles %lld load %lld update %lld rescan %lld | block loads %lld rescans %lld %lld %lld | plan %.3f ms fill %.3f ms apply %.3f ms\n",
-            (long long)bs.rounds, (long long)bs.mismatches, (long long)bs.planned, bs.max_h, (long long)bs.fill_cycles, (long long)bs.fill_load, (long long)bs.fill_update, (long long)bs.fill_rescan,
+        core->stats.reserved[1] = bs.block_loads | ((int64_t)bs.buckets << 62); /* bit 62: the fill ran on the bucket kernel (kai_fill_buckets.hpp) */ core->stats.reserved[0] = core->world > 1 ? bs.exchanges : core->stats.reserved[0];
+        if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai batch%s: rounds %lld mismatches %lld planned %lld max_h %d | fill cycles %lld load %lld update %lld rescan %lld | block loads %lld rescans %lld %lld %lld | plan %.3f ms fill %.3f ms apply %.3f ms\n",
+            bs.buckets ? " (bucket fill)" : "", (long long)bs.rounds, (long long)bs.mismatches, (long long)bs.planned, bs.max_h, (long long)bs.fill_cycles, (long long)bs.fill_load, (long long)bs.fill_update, (long long)bs.fill_rescan,
             (long long)bs.block_loads, (long long)bs.rescans1, (long long)bs.rescans2, (long long)bs.rescans3, core->batch_plan_ms, core->batch_fill_ms, core->batch_apply_ms);
     } else { core->stats.reserved[4] = 0; core->stats.reserved[5] = st.prof[2]; core->stats.reserved[6] = st.prof[3]; core->stats.reserved[7] = st.prof[7]; }
     if (!victim && !bs.ran && scan_wgs_used > 1) {  // sequential allocate with a scan grid: bits 48.. of [1] = workgroups that took the passes over the nodes (the engine's + the helpers that signed on)

@@ -1,0 +1,236 @@
+// kai_fill_buckets.hpp — the fill of the batch path for bin-packed GPU classes: nodes bucketed by free devices, all of it in LDS.
+//
+// What the fill has to answer per task is OrderedNodesByTask + FittingNode (framework/session.go:201-283) for the task's scan class: the fitting node
+// with the largest Σ NodeOrderFn, ties to the lowest name.  With the default plugin tier and the bin-pack strategy on the GPU (plugins/nodeplacement/
+// pack.go:45-64: 9·(1 − (free − min)/(max − min)), strictly decreasing in the node's free devices) every fitting node carries the same nodeavailability
+// and resourcetype points (a GPU class never earns the CPU-only bonus, resourcetype.go:29-41), so the order of the fitting nodes of a class is
+//     (free devices ascending, name rank ascending)
+// — what kai_batch.hpp::class_key_rec encodes as a 64-bit key.  Free devices are small integers, so instead of keys this kernel keeps, per number of
+// free devices g = 1 .. L, the SET of nodes with exactly g free devices as a bitmap over the name ranks with two summary levels (64 words / 64·64 words
+// per bit), all in LDS: 8 levels x 65 536 nodes = 64 KB.  The best node of a class that asks for q devices is the first set bit of the lowest non-empty
+// level g >= q; placing a task moves one bit from level g to level g − q.  Per class the current best is cached (lane = class) and patched in O(1) after
+// every placement (the node that changed is the only one whose key moved); only a class whose best node stops fitting looks its next one up — one lane per
+// level walks summary → word, the lowest level that finds a node wins.  No node record is loaded, no key is computed, nothing goes to HBM but the task's
+// node: ~10 LDS accesses per decision instead of the general kernel's ≈ 530 instructions.
+//
+// When is "fits ⇔ free devices >= q" exact?  The fit of FittingNode also compares CPU, memory, pods and every other tracked resource
+// (resource_requirment.go:126-140) and predicates.go:264-285 wants a free pod slot.  k_bucket_build proves per node, before the action, that none of those
+// can bind before the devices do: for every class c that may use the node and every resource r != GPU, req_c[r]·free0 <= idle0[r]·q_c (exact 128-bit
+// integer products).  Then whatever sequence of tasks lands on the node consumes at most idle0[r]·(devices consumed)/free0 of r, and a task that still finds
+// its devices finds its share of r (DESIGN.md §5.2b has the two-line proof).  Static predicates (class_fit, node readiness, worker labels, MIG / DRA rules)
+// are the okmask of the node records: a per-class bitmap ANDed into the lookup, dropped for classes it would not change.  Anything else — a node that fails
+// the proof, a spread or CPU-placed class, fractional or > 16 free devices, a node-sharded group — and the action runs on the general kernel (k_fill), with
+// identical results (tests/test_batch_path.py runs both against the oracle).
+#pragma once
+#include "kai_batch.hpp"
+
+namespace kai {
+
+constexpr int KBK_GMAX = 16;  // levels the home arrays hold: free devices 1 .. 16
+
+struct BucketMeta {        // written by k_bucket_build (zeroed by the host before it)
+    int32_t bad;           // != 0: the action does not qualify for the bucket fill (bit 0 class shape, 1 free amount, 2 a resource may bind first)
+    int32_t max_free;      // largest free amount of a live node
+    int32_t live, pad;     // nodes some class may use
+    int32_t ok_miss[64];   // class k: live nodes its static predicates turn away (0 = the class needs no bitmap of its own)
+};
+struct BucketParams { int32_t levels, nw, nw1, n_ok; int8_t okslot[64]; };  // okslot[k]: LDS slot of class k's static bitmap, -1 = none needed
+
+// per 64-node block: bucket words, static-predicate words, the proof that only the devices can bind
+KW_BODY void kb_bucket_build(const KaiCtx& c) {
+    const BatchCtx& b = c.bt;
+    const int w = kw::bid() * (kw::bdim() >> 6) + (kw::tid() >> 6), lane = kw::lane(), NW = c.NB;
+    if (w >= NW) return;
+    BucketMeta* meta = (BucketMeta*)b.bk_meta;
+    int bad = 0;
+    if (w == 0 && lane < c.C) {  // class shape: bin-packed on the GPU, a whole number of 1 .. 16 devices, one pod slot
+        const ClassRec cr = c.cls[lane];
+        const double qd = cr.req[KAI_RES_GPU];
+        if (cr.cpu_only || cr.r_place != KAI_RES_GPU || cr.strategy != KAI_BINPACK || !(qd >= 1) || qd > KBK_GMAX || qd != (double)(int)qd) bad |= 1;
+        if (c.R > KAI_RES_PODS && !(cr.req[KAI_RES_PODS] >= 1)) bad |= 1;  // the free-pod-slot predicate is implied only for classes that take a slot
+    }
+    const NodeRec rec = b.nrec[(size_t)w * KAI_BLOCK + lane];
+    const bool live = rec.okmask != 0;
+    int fr = 0;
+    if (live) {
+        const double f = rec.idle[KAI_RES_GPU];
+        if (!(f >= 0) || f > KBK_GMAX || f != (double)(int)f) bad |= 2; else fr = (int)f;
+        for (int r = 0; r < c.R && r < 4; r++) if (!(rec.idle[r] >= 0) || rec.idle[r] >= 9.2e18) bad |= 4;
+    }
+    if (live && fr >= 1 && !bad) {
+        for (int k = 0; k < c.C; k++) {
+            if (!((rec.okmask >> k) & 1ull)) continue;
+            const int q = (int)c.cls[k].req[KAI_RES_GPU];
+            if (q < 1) continue;  // (flagged above)
+            for (int r = 0; r < c.R && r < 4; r++) {
+                if (r == KAI_RES_GPU) continue;
+                const double rq = c.cls[k].req[r];
+                if (!(rq > 0)) continue;
+                if (rq >= 9.2e18) { bad |= 4; continue; }
+                const unsigned __int128 lhs = (unsigned __int128)(uint64_t)rq * (unsigned)fr, rhs = (unsigned __int128)(uint64_t)rec.idle[r] * (unsigned)q;
+                if (lhs > rhs) bad |= 4;
+            }
+        }
+    }
+    const uint64_t livew = kw::ballot(live);
+    int top = 0;
+    for (int g = 1; g <= KBK_GMAX; g++) {
+        const uint64_t word = kw::ballot(live && fr == g);
+        if (word) top = g;
+        if (lane == 0) b.bk_words[(size_t)(g - 1) * NW + w] = word;
+    }
+    for (int k = 0; k < c.C; k++) {
+        const uint64_t okw = kw::ballot(live && ((rec.okmask >> k) & 1ull));
+        if (lane == 0) { b.bk_ok[(size_t)k * NW + w] = okw; const int miss = __builtin_popcountll(livew & ~okw); if (miss) kw::atomic_add((int32_t*)&meta->ok_miss[k], miss); }
+    }
+    const uint64_t anybad = kw::ballot(bad != 0);
+    if (anybad) { int all = 0; for (int l = 0; l < 64; l++) all |= kw::shfl(bad, l); if (lane == 0) kw::atomic_max((int32_t*)&meta->bad, all); }
+    if (lane == 0) { if (top) kw::atomic_max((int32_t*)&meta->max_free, top); if (livew) kw::atomic_add((int32_t*)&meta->live, __builtin_popcountll(livew)); }
+}
+
+struct BkLds { int32_t placed_node[KB_PLACED_MAX]; int32_t placed_info[KB_PLACED_MAX]; };  // info: class | level before the placement << 8
+struct BkView {
+    KW_LDS_PTR(uint64_t) gw; KW_LDS_PTR(uint64_t) s1; KW_LDS_PTR(uint64_t) s2; KW_LDS_PTR(uint64_t) ok;
+    int NW, NW1, LV;
+};
+// the first node (lowest name rank) of the lowest level >= from_g that class (q, slot) may use: one lane per level, the lowest level that finds one wins
+KW_BODY void bk_find(const BkView& v, int slot, int from_g, int& og, int& on) {
+    const int lane = kw::lane();
+    int n = KB_INF;
+    if (lane < v.LV && lane + 1 >= from_g) {
+        uint64_t s2 = v.s2[lane];
+        while (s2 && n == KB_INF) {
+            const int w1 = __builtin_ctzll(s2); s2 &= s2 - 1;
+            uint64_t s1 = v.s1[lane * v.NW1 + w1];
+            while (s1) {
+                const int w = w1 * 64 + __builtin_ctzll(s1); s1 &= s1 - 1;
+                uint64_t word = v.gw[lane * v.NW + w];
+                if (slot >= 0) word &= v.ok[slot * v.NW + w];
+                if (word) { n = w * 64 + __builtin_ctzll(word); break; }
+            }
+        }
+    }
+    const uint64_t m = kw::ballot(n != KB_INF);
+    if (!m) { og = 0; on = -1; return; }
+    const int l = __builtin_ctzll(m);
+    og = l + 1; on = kw::bcast(n, l);
+}
+// node n leaves level `from` and enters level `to` (0 = no level: a node without a free device fits no class)
+KW_BODY void bk_move(const BkView& v, int n, int from, int to) {
+    const int w = n >> 6, w1 = w >> 6; const uint64_t bit = 1ull << (n & 63), bit1 = 1ull << (w & 63), bit2 = 1ull << w1;
+    if (kw::lane() == 0) {
+        if (from >= 1) {
+            const int l = from - 1;
+            const uint64_t x = v.gw[l * v.NW + w] & ~bit; v.gw[l * v.NW + w] = x;
+            if (!x) { const uint64_t y = v.s1[l * v.NW1 + w1] & ~bit1; v.s1[l * v.NW1 + w1] = y; if (!y) v.s2[l] = v.s2[l] & ~bit2; }
+        }
+        if (to >= 1) {
+            const int l = to - 1;
+            v.gw[l * v.NW + w] = v.gw[l * v.NW + w] | bit; v.s1[l * v.NW1 + w1] = v.s1[l * v.NW1 + w1] | bit1; v.s2[l] = v.s2[l] | bit2;
+        }
+    }
+    kw::lds_order();
+}
+
+// workgroup of 256: all four wavefronts move the state between its HBM home and LDS, wavefront 0 walks the planned order
+KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
+    KW_SHARED BkLds L;
+    const BatchCtx& b = c.bt;
+    const int tid = kw::tid(), T = kw::bdim(), lane = kw::lane(), C = c.C;
+    BkView v; v.NW = bp.nw; v.NW1 = bp.nw1; v.LV = bp.levels;
+    unsigned char* dyn = kw::dyn_lds();
+    v.gw = (KW_LDS_PTR(uint64_t))dyn; v.s1 = v.gw + (size_t)v.LV * v.NW; v.s2 = v.s1 + (size_t)v.LV * v.NW1; v.ok = v.s2 + KBK_GMAX;
+    const int64_t tstart = kw::clock();
+    for (int i = tid; i < v.LV * v.NW; i += T) v.gw[i] = b.bk_words[i];
+    for (int k = 0; k < C; k++) { const int s = bp.okslot[k]; if (s < 0) continue; for (int i = tid; i < v.NW; i += T) v.ok[s * v.NW + i] = b.bk_ok[(size_t)k * v.NW + i]; }
+    kw::sync();
+    for (int i = tid; i < v.LV * v.NW1; i += T) {
+        const int l = i / v.NW1, w1 = i % v.NW1; uint64_t m = 0;
+        for (int j = 0; j < 64 && w1 * 64 + j < v.NW; j++) if (v.gw[l * v.NW + w1 * 64 + j]) m |= 1ull << j;
+        v.s1[i] = m;
+    }
+    kw::sync();
+    for (int l = tid; l < v.LV; l += T) { uint64_t m = 0; for (int j = 0; j < v.NW1; j++) if (v.s1[l * v.NW1 + j]) m |= 1ull << j; v.s2[l] = m; }
+    kw::sync();
+    if (tid < 64) {
+        // lane k: class k — devices asked for, slot of its static bitmap, its best node and that node's level
+        const bool act = lane < C;
+        int q = 0, okslot = -1, topg = 0, topn = -1;
+        if (act) { q = (int)c.cls[lane].req[KAI_RES_GPU]; okslot = bp.okslot[lane]; }
+        for (int k = 0; k < C; k++) { int g, n; bk_find(v, kw::bcast(okslot, k), kw::bcast(q, k), g, n); if (lane == k) { topg = g; topn = n; } }
+        const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: dead classes only (before the first plan)
+        int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, finds = 0; int n_done = rp.start, mismatch = 0;
+        for (int base = rp.start; base < V && !mismatch; base += 64) {
+            const int gi = base + lane;
+            const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE, my_first = gi < V ? b.g_first[gi] : 0, my_nt = gi < V ? b.g_nt[gi] : 0, my_ucls = gi < V ? b.g_ucls[gi] : 0;
+            const int cnt = V - base < 64 ? V - base : 64;
+            for (int jj = 0; jj < cnt; jj++) {
+                const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
+                const int opoff = (int)ops + rp.ops0, stmtoff = (int)committed + rp.stmt0;
+                bool ok = flag != BF_GATE; int placed = 0;
+                if (flag != BF_GATE) {
+                    for (int tb = 0; tb < nt && ok; tb += 64) {
+                        int my_cls = ucls;
+                        if (ucls < 0) my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;  // a gang of several scan classes: its task list
+                        const int tc = nt - tb < 64 ? nt - tb : 64;
+                        for (int ti = 0; ti < tc; ti++) {
+                            const int kcls = ucls >= 0 ? ucls : kw::bcast(my_cls, ti);
+                            decisions++;
+                            const int n = kw::bcast(topn, kcls);
+                            if (n < 0) { ok = false; break; }
+                            const int g = kw::bcast(topg, kcls), g2 = g - kw::bcast(q, kcls);
+                            if (lane == 0) { L.placed_node[placed] = n; L.placed_info[placed] = kcls | (g << 8); b.t_node[first + placed] = n; }
+                            placed++;
+                            bk_move(v, n, g, g2);
+                            // the only node whose key moved is n: a class that had it on top keeps it while it still fits (fewer free devices = a better key),
+                            // any other class takes it if it now beats that class's best
+                            bool need = false;
+                            if (act) {
+                                if (topn == n) { if (g2 >= q) topg = g2; else need = true; }
+                                else if (g2 >= q) {
+                                    const bool okn = okslot < 0 || ((v.ok[okslot * v.NW + (n >> 6)] >> (n & 63)) & 1ull);
+                                    if (okn && (topn < 0 || g2 < topg || (g2 == topg && n < topn))) { topg = g2; topn = n; }
+                                }
+                            }
+                            uint64_t todo = kw::ballot(need);
+                            while (todo) {  // the class's next best sorts behind (g, n): nothing with fewer free devices exists, or it would have been on top
+                                const int kk = __builtin_ctzll(todo); todo &= todo - 1;
+                                int fg, fn; bk_find(v, kw::bcast(okslot, kk), g, fg, fn); finds++;
+                                if (lane == kk) { topg = fg; topn = fn; }
+                            }
+                        }
+                    }
+                    if (!ok) {  // Statement.Rollback: the undone operations in reverse order, then every class's best from the restored sets
+                        kw::lds_order();
+                        for (int i = placed - 1; i >= 0; i--) {
+                            const int n = L.placed_node[i], info = L.placed_info[i], gb = info >> 8;
+                            bk_move(v, n, gb - kw::bcast(q, info & 0xff), gb);
+                        }
+                        if (placed) for (int k = 0; k < C; k++) { int g, n; bk_find(v, kw::bcast(okslot, k), kw::bcast(q, k), g, n); finds++; if (lane == k) { topg = g; topn = n; } }
+                        rollbacks += 2;
+                    } else { committed++; ops += nt; }
+                }
+                attempted++; n_done = base + jj + 1;
+                if (lane == 0) { b.g_out[base + jj] = ok ? BF_OK : BF_DEAD; b.g_opoff[base + jj] = opoff; b.g_stmt[base + jj] = stmtoff; }
+                if ((flag == BF_OK) != ok) { mismatch = 1; break; }
+            }
+        }
+        const uint64_t dead = kw::ballot(act && topn < 0);
+        if (lane == 0) {
+            FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V; s.floor_stop = 0; s.pad = 0;
+            s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
+            s.cycles_total = kw::clock() - tstart; s.cycles_load = 0; s.cycles_update = 0; s.cycles_rescan = 0;
+            s.block_loads = 0; s.rescans1 = finds; s.rescans2 = 0; s.rescans3 = 0;
+            b.fs[0] = s; b.dead_mask[0] = dead;
+        }
+    }
+    kw::sync();
+    for (int i = tid; i < v.LV * v.NW; i += T) b.bk_words[i] = v.gw[i];
+}
+
+#if defined(__HIPCC__)
+__global__ void k_bucket_build(KaiCtx c) { kb_bucket_build(c); }
+__global__ void __launch_bounds__(256) k_fill_buckets(KaiCtx c, RoundParams rp, BucketParams bp) { kb_fill_buckets(c, rp, bp); }
+#endif
+
+}  // namespace kai

@@ -7,6 +7,7 @@
 // Shared by kai_core.hip (uploads them to HBM) and by tests/host_sim (which debugs the engine's control flow without a GPU).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -41,16 +42,20 @@ struct SharedPods {
         int first_gpu = -1;
         if (s->node_gpu_memory) for (int i = 0; i < N; i++) if (has_gpus(i)) { if (first_gpu < 0) first_gpu = i; else if (any && s->node_gpu_memory[i] != s->node_gpu_memory[first_gpu]) { err = "shared GPUs with different node_gpu_memory values: leave the cycle to the host path"; return false; } }
         const int64_t M = (s->node_gpu_memory && N > 0) ? s->node_gpu_memory[first_gpu >= 0 ? first_gpu : 0] : 100;
-        for (int p = 0; p < P; p++) {
+        // per pod, independent of the others: chunks of the pod range on the host's cores; the error reported is the one of the lowest pod
+        const int K = chunk_count((size_t)P);
+        std::vector<std::string> cerr((size_t)K);
+        parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) {
+        for (size_t p = p0; p < p1; p++) {
             const double g = s->pod_req[(size_t)KAI_RES_GPU * P + p];
             const double por = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0;
             const int64_t gm = (s->pod_gpu_memory && !(por > 0)) ? s->pod_gpu_memory[p] : 0;
             acc_gpu[p] = g; pend_gpu[p] = g; quota_gpu[p] = g;
             if (por > 0) { shared[p] = 1; mem[p] = (int64_t)(por * (double)M); }  // GetResourceGpuMemory (node_info.go:653-659); AcceptedResource keeps the portion
             else if (gm > 0) {
-                if (gm > M || M <= 0) { err = "a gpu-memory request above one device's memory: leave the cycle to the host path"; return false; }  // isValidGpuPortion :668-671
-                if (g != 0) { err = "a gpu-memory request beside a GPU count"; return false; }
-                if (cfg.min_node_gpu_memory <= 0) { err = "gpu-memory requests need kai_config.min_node_gpu_memory > 0"; return false; }
+                if (gm > M || M <= 0) { cerr[(size_t)ci] = "a gpu-memory request above one device's memory: leave the cycle to the host path"; return; }  // isValidGpuPortion :668-671
+                if (g != 0) { cerr[(size_t)ci] = "a gpu-memory request beside a GPU count"; return; }
+                if (cfg.min_node_gpu_memory <= 0) { cerr[(size_t)ci] = "gpu-memory requests need kai_config.min_node_gpu_memory > 0"; return; }
                 shared[p] = 1; mem[p] = gm; gmem[p] = gm;
                 double x = (double)gm / (double)M * 100; double f = (double)(int64_t)x; if (f < x) f += 1;  // getGpuMemoryFractionalOnNode :329-332 (ceil to 1/100)
                 const double frac = f / 100;
@@ -67,6 +72,8 @@ struct SharedPods {
             if (g > 0) k |= K_GPUS;
             kind[p] = k;
         }
+        });
+        for (int ci = 0; ci < K; ci++) if (!cerr[(size_t)ci].empty()) { err = cerr[(size_t)ci]; return false; }
         return true;
     }
 };
@@ -91,10 +98,13 @@ struct HostPrep {
     struct BatchShape { int n_leaves = 0, n_heights = 0; std::vector<int> h_count; };
     std::vector<int32_t> q_height, h_off, h_nodes; int n_heights = 0, batch_ok = 0, exact_sums = 0; BatchShape shape;  // exact_sums: sums of node / pod quantities do not depend on the order of addition
 
+    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host clocks of build(): range checks / nodes / pods / task order / queues + job lists / shares + topology / classes / batch shape
     // returns 0 or KAI_ERR_INVALID_ARG with err set
     int build(const kai_config& cfg, const kai_snapshot_soa* s, std::string& err) {
         const int N = s->n_nodes, P = s->n_pods, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
         auto fail = [&](const char* m) { err = m; return (int)KAI_ERR_INVALID_ARG; };
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](int i) { const auto t = std::chrono::steady_clock::now(); phase_ms[i] += std::chrono::duration<double, std::milli>(t - t_last).count(); t_last = t; };
         // ---- the snapshot indexes device arrays directly: every index is range-checked here, every required array must be present
         const int S = s->n_podsets;
         if (N > 0 && (!s->node_allocatable || !s->node_flags || !s->node_name_rank)) return fail("a required node array is NULL");
@@ -116,6 +126,7 @@ struct HostPrep {
         }
         for (int d = 0; d < s->n_domains; d++) if (s->domain_parent && (s->domain_parent[d] < -1 || s->domain_parent[d] >= s->n_domains)) return fail("domain_parent out of range");
         for (int g = 0; g < s->n_groups; g++) if (s->group_parent && s->group_parent[g] < -1) return fail("group_parent out of range");
+        lap(0);
         // ---- nodes: permute into name-rank order (framework/session.go:480-485 breaks score ties by node name)
         perm.assign(N, -1);
         for (int i = 0; i < N; i++) { uint32_t rk = s->node_name_rank[i]; if (rk >= (uint32_t)N || perm[rk] >= 0) return fail("node_name_rank must be a permutation of 0..N-1"); perm[rk] = i; }
@@ -126,30 +137,39 @@ struct HostPrep {
             node_flags[i] = s->node_flags[o]; node_gpu_count[i] = s->node_gpu_count ? s->node_gpu_count[o] : -1; node_class[i] = s->node_class ? s->node_class[o] : 0;
             if (node_class[i] < 0 || node_class[i] >= std::max(1, s->n_node_classes)) return fail("node_class out of range");
         }
+        lap(1);
         pod_node.resize(P); pod_nominated.resize(P);
-        for (int p = 0; p < P; p++) {
-            int n = s->pod_node[p]; pod_node[p] = (n >= 0 && n < N) ? (int32_t)s->node_name_rank[n] : -1;
-            int m = s->pod_nominated_node ? s->pod_nominated_node[p] : -1; pod_nominated[p] = (m >= 0 && m < N) ? (int32_t)s->node_name_rank[m] : -1;
-            int pc = s->pod_class ? s->pod_class[p] : 0; if (pc < 0 || pc >= std::max(1, s->n_pod_classes)) return fail("pod_class out of range");
-        }
+        { std::vector<char> bad((size_t)chunk_count((size_t)P), 0);
+          parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) {
+              for (size_t p = p0; p < p1; p++) {
+                  int n = s->pod_node[p]; pod_node[p] = (n >= 0 && n < N) ? (int32_t)s->node_name_rank[n] : -1;
+                  int m = s->pod_nominated_node ? s->pod_nominated_node[p] : -1; pod_nominated[p] = (m >= 0 && m < N) ? (int32_t)s->node_name_rank[m] : -1;
+                  int pc = s->pod_class ? s->pod_class[p] : 0; if (pc < 0 || pc >= std::max(1, s->n_pod_classes)) bad[(size_t)ci] = 1;
+              }
+          });
+          for (char b : bad) if (b) return fail("pod_class out of range"); }
+        lap(2);
         // each job's pods in TaskOrderFn order (framework/session_plugins.go:244-260 + plugins/taskorder/task_order.go:28-63)
         sorted.resize(P);
-        for (int p = 0; p < P; p++) sorted[p] = p;
         const bool taskorder = cfg.plugins & KAI_PLUGIN_TASKORDER;
-        for (int j = 0; j < J; j++) {
-            int b = s->job_first_pod[j], n = s->job_n_pods[j];
-            if (b < 0 || n < 0 || b + n > P) return fail("job pod range out of bounds");
-            if (n > 1) std::sort(sorted.begin() + b, sorted.begin() + b + n, [&](int l, int r) {
-                if (taskorder) {
-                    bool ll = s->pod_flags && (s->pod_flags[l] & KAI_POD_HAS_TASK_PRIORITY), rl = s->pod_flags && (s->pod_flags[r] & KAI_POD_HAS_TASK_PRIORITY);
-                    if (ll != rl) return ll;
-                    if (ll && rl && s->pod_task_priority[l] != s->pod_task_priority[r]) return s->pod_task_priority[l] > s->pod_task_priority[r];
-                }
-                int64_t lc = s->pod_created_ns ? s->pod_created_ns[l] : 0, rc2 = s->pod_created_ns ? s->pod_created_ns[r] : 0;
-                if (lc != rc2) return lc < rc2;
-                return s->pod_uid_rank[l] < s->pod_uid_rank[r];
-            });
-        }
+        for (int j = 0; j < J; j++) { int b = s->job_first_pod[j], n = s->job_n_pods[j]; if (b < 0 || n < 0 || b + n > P) return fail("job pod range out of bounds"); }
+        parallel_chunks((size_t)P, [&](int, size_t p0, size_t p1) { for (size_t p = p0; p < p1; p++) sorted[p] = (int32_t)p; });
+        parallel_chunks((size_t)J, [&](int, size_t j0, size_t j1) {
+            for (size_t j = j0; j < j1; j++) {
+                int b = s->job_first_pod[j], n = s->job_n_pods[j];
+                if (n > 1) std::sort(sorted.begin() + b, sorted.begin() + b + n, [&](int l, int r) {
+                    if (taskorder) {
+                        bool ll = s->pod_flags && (s->pod_flags[l] & KAI_POD_HAS_TASK_PRIORITY), rl = s->pod_flags && (s->pod_flags[r] & KAI_POD_HAS_TASK_PRIORITY);
+                        if (ll != rl) return ll;
+                        if (ll && rl && s->pod_task_priority[l] != s->pod_task_priority[r]) return s->pod_task_priority[l] > s->pod_task_priority[r];
+                    }
+                    int64_t lc = s->pod_created_ns ? s->pod_created_ns[l] : 0, rc2 = s->pod_created_ns ? s->pod_created_ns[r] : 0;
+                    if (lc != rc2) return lc < rc2;
+                    return s->pod_uid_rank[l] < s->pod_uid_rank[r];
+                });
+            }
+        }, 2048);
+        lap(3);
         // queue children CSR with a virtual root at index Q (cache/cluster_info/queue.go:95-103)
         child_off.assign(Q + 2, 0); children.assign(std::max(Q, 1), 0); depth.assign(Q, 0);
         for (int q = 0; q < Q; q++) { int par = s->queue_parent[q]; if (par < -1 || par >= Q || par == q) return fail("bad queue_parent"); child_off[(par < 0 ? Q : par) + 1]++; }
@@ -163,14 +183,16 @@ struct HostPrep {
         for (int q = 0; q < Q; q++) job_off[q + 1] += job_off[q];
         { std::vector<int32_t> fill(job_off.begin(), job_off.end() - 1); for (int j = 0; j < J; j++) { int q = s->job_queue[j]; if (q >= 0) jobs_static[fill[q]++] = j; } }
         const bool use_prio = cfg.plugins & KAI_PLUGIN_PRIORITY;
-        for (int q = 0; q < Q; q++) {
-            std::sort(jobs_static.begin() + job_off[q], jobs_static.begin() + job_off[q + 1], [&](int l, int r) {
-                if (use_prio && s->job_priority[l] != s->job_priority[r]) return s->job_priority[l] > s->job_priority[r];
-                if (s->job_created_ns[l] != s->job_created_ns[r]) return s->job_created_ns[l] < s->job_created_ns[r];
-                return s->job_uid_rank[l] < s->job_uid_rank[r];
-            });
-            for (int i = job_off[q]; i < job_off[q + 1]; i++) slot_queue[i] = q;
-        }
+        parallel_chunks((size_t)Q, [&](int, size_t q0, size_t q1) {
+            for (size_t q = q0; q < q1; q++) {
+                std::sort(jobs_static.begin() + job_off[q], jobs_static.begin() + job_off[q + 1], [&](int l, int r) {
+                    if (use_prio && s->job_priority[l] != s->job_priority[r]) return s->job_priority[l] > s->job_priority[r];
+                    if (s->job_created_ns[l] != s->job_created_ns[r]) return s->job_created_ns[l] < s->job_created_ns[r];
+                    return s->job_uid_rank[l] < s->job_uid_rank[r];
+                });
+                for (int i = job_off[q]; i < job_off[q + 1]; i++) slot_queue[i] = (int32_t)q;
+            }
+        }, 4);
         depth_order.resize(Q);
         for (int q = 0; q < Q; q++) depth_order[q] = q;
         std::stable_sort(depth_order.begin(), depth_order.end(), [&](int a, int b) { return depth[a] > depth[b]; });
@@ -183,6 +205,7 @@ struct HostPrep {
             if ((int)lvl_parents.size() > lvl_off.back()) lvl_off.push_back((int)lvl_parents.size());
         }
         n_levels = (int)lvl_off.size() - 1;
+        lap(4);
         // proportion.createQueueResourceAttrs (plugins/proportion/proportion.go:307-345)
         shares.assign((size_t)std::max(Q, 1) * 3, QShare{});
         for (int q = 0; q < Q; q++) for (int k = 0; k < 3; k++) {
@@ -192,8 +215,11 @@ struct HostPrep {
             x.deserved = des; x.max_allowed = lim; x.oqw = s->queue_oqw[(size_t)k * Q + q]; x.usage = s->queue_usage ? s->queue_usage[(size_t)k * Q + q] : 0.0;
         }
         if (int rc = build_topology(s, err)) return rc;
+        lap(5);
         build_classes(cfg, s);
+        lap(6);
         build_batch(cfg, s);
+        lap(7);
         return 0;
     }
 
@@ -284,12 +310,11 @@ struct HostPrep {
         }
         for (int g = 0; g < G; g++) { if (g_parent[g] >= G || g_job[g] < 0 || g_job[g] >= J) return fail("bad group table"); if (g_topo[g] >= T) return fail("group_topology out of range"); }
         for (int k = 0; k < S; k++) { if (s_group[k] < 0 || s_group[k] >= G) return fail("bad podset_group"); if (s_topo[k] >= T) return fail("podset_topology out of range"); }
-        std::vector<std::vector<int32_t>> gk(G);
-        for (int g = 0; g < G; g++) if (g_parent[g] >= 0) gk[g_parent[g]].push_back(g);
-        g_child_off.assign(G + 1, 0); g_children.clear();
-        for (int g = 0; g < G; g++) { g_child_off[g] = (int)g_children.size(); g_children.insert(g_children.end(), gk[g].begin(), gk[g].end()); }
-        g_child_off[G] = (int)g_children.size();
-        if (g_children.empty()) g_children.push_back(0);
+        g_child_off.assign(G + 1, 0);  // children of a group in ascending group index (counting sort: no vector per group — G = J for a snapshot without sub-group trees)
+        for (int g = 0; g < G; g++) if (g_parent[g] >= 0) g_child_off[g_parent[g] + 1]++;
+        for (int g = 0; g < G; g++) g_child_off[g + 1] += g_child_off[g];
+        g_children.assign((size_t)std::max(g_child_off[G], 1), 0);
+        if (g_child_off[G] > 0) { std::vector<int32_t> fillg(g_child_off.begin(), g_child_off.end() - 1); for (int g = 0; g < G; g++) if (g_parent[g] >= 0) g_children[fillg[g_parent[g]]++] = g; }
         j_has_topology.assign(std::max(J, 1), 0);
         for (int g = 0; g < G; g++) if (g_topo[g] != -1) j_has_topology[g_job[g]] = 1;
         for (int k = 0; k < S; k++) if (s_topo[k] != -1) j_has_topology[s->podset_job[k]] = 1;
@@ -332,15 +357,35 @@ struct HostPrep {
         }
         if (cfg.engine_mode == 1) { all_tracked = 0; return; }
         struct Key { double req[KAI_MAX_RES]; int32_t pc; bool operator<(const Key& o) const { int c = std::memcmp(req, o.req, sizeof req); return c ? c < 0 : pc < o.pc; } };
+        // class ids in order of first appearance over the pods.  Chunks of the pod range are classified on the host's cores (a chunk's keys in ITS order of first
+        // appearance; a pod usually repeats the key of the pod before it, so that one is compared first), then merged chunk by chunk: the ids come out as in one pass
         std::map<Key, int> ids; std::vector<Key> keys; std::vector<int64_t> freq; std::vector<int32_t> pod_cls(P, -1);
-        for (int p = 0; p < P; p++) {
-            Key k; std::memset(&k, 0, sizeof k);
-            for (int r = 0; r < R; r++) { double v = s->pod_req[(size_t)r * P + p]; k.req[r] = v == 0 ? 0.0 : v; }  // fold -0.0
-            k.pc = s->pod_class ? s->pod_class[p] : 0;
-            auto it = ids.find(k);
-            int id; if (it == ids.end()) { id = (int)keys.size(); ids[k] = id; keys.push_back(k); freq.push_back(0); } else id = it->second;
-            pod_cls[p] = id;
-            if (s->pod_status[p] == KAI_POD_PENDING) freq[id]++;
+        {
+            const int K = chunk_count((size_t)P);
+            struct Local { std::vector<Key> keys; std::vector<int64_t> freq; };
+            std::vector<Local> loc((size_t)K);
+            auto make_key = [&](size_t p, Key& k) { std::memset(&k, 0, sizeof k); for (int r = 0; r < R; r++) { double v = s->pod_req[(size_t)r * P + p]; k.req[r] = v == 0 ? 0.0 : v; } k.pc = s->pod_class ? s->pod_class[p] : 0; };  // folds -0.0
+            parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) {
+                Local& L = loc[(size_t)ci]; std::map<Key, int> lid; int last = -1;
+                for (size_t p = p0; p < p1; p++) {
+                    Key k; make_key(p, k);
+                    int id;
+                    if (last >= 0 && std::memcmp(&L.keys[(size_t)last], &k, sizeof(Key)) == 0) id = last;
+                    else { auto it = lid.find(k); if (it == lid.end()) { id = (int)L.keys.size(); lid[k] = id; L.keys.push_back(k); L.freq.push_back(0); } else id = it->second; }
+                    last = id; pod_cls[p] = id;  // chunk-local id for now
+                    if (s->pod_status[p] == KAI_POD_PENDING) L.freq[(size_t)id]++;
+                }
+            });
+            std::vector<std::vector<int>> to_global((size_t)K);
+            for (int ci = 0; ci < K; ci++) {
+                Local& L = loc[(size_t)ci]; to_global[(size_t)ci].resize(L.keys.size());
+                for (size_t i = 0; i < L.keys.size(); i++) {
+                    auto it = ids.find(L.keys[i]);
+                    int id; if (it == ids.end()) { id = (int)keys.size(); ids[L.keys[i]] = id; keys.push_back(L.keys[i]); freq.push_back(0); } else id = it->second;
+                    to_global[(size_t)ci][i] = id; freq[(size_t)id] += L.freq[i];
+                }
+            }
+            parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) { const std::vector<int>& g = to_global[(size_t)ci]; for (size_t p = p0; p < p1; p++) pod_cls[p] = g[(size_t)pod_cls[p]]; });
         }
         std::vector<int> order(keys.size()); for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return freq[a] > freq[b]; });
@@ -359,7 +404,7 @@ struct HostPrep {
             cr.best_effort = be; cr.r_place = cpu_only ? KAI_RES_CPU : KAI_RES_GPU; cr.strategy = cpu_only ? cfg.cpu_strategy : cfg.gpu_strategy;
             remap[id] = (int)classes.size(); classes.push_back(cr);
         }
-        for (int p = 0; p < P; p++) pod_scls[p] = remap[pod_cls[p]];
+        parallel_chunks((size_t)P, [&](int, size_t p0, size_t p1) { for (size_t p = p0; p < p1; p++) pod_scls[p] = remap[(size_t)pod_cls[p]]; });
         int NB = (N + KAI_BLOCK - 1) / KAI_BLOCK, NSB = (NB + 63) / 64;
         if (NSB > KAI_NSB_MAX) { classes.clear(); std::fill(pod_scls.begin(), pod_scls.end(), -1); all_tracked = 0; }  // beyond the LDS level: brute force
     }

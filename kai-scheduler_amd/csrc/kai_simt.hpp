@@ -49,6 +49,9 @@ KW_DEV unsigned char* dyn_lds() { extern __shared__ __align__(16) unsigned char 
 KW_DEV void fence() { __threadfence(); }
 // lanes of one wave exchange data through LDS / memory: on the hardware they run in lock-step, so ordering the accesses is enough
 KW_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// lanes of ONE wave exchange data through LDS only: the LDS serves a wave's accesses in issue order, so keeping the compiler from reordering is enough
+// (no s_waitcnt on the vector-memory counter: stores to HBM stay in flight)
+KW_DEV void lds_order() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 KW_DEV void expect_uniform(long long) {}
 KW_DEV void fence_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 }  // namespace kw
@@ -211,6 +214,7 @@ inline unsigned char* dyn_lds() { Emu& e = emu(); return reinterpret_cast<unsign
 inline void fence() {}
 inline void fence_wg() {}
 inline void wave_sync(int line = __builtin_LINE()) { wave_bar(line); }
+inline void lds_order(int line = __builtin_LINE()) { wave_bar(line); }
 // debug aid: every lane must hold the same value here (a branch on it is meant to be uniform)
 inline void expect_uniform(long long v, int line = __builtin_LINE()) { const long long v0 = shfl(v, 0, line); if (v != v0) { std::fprintf(stderr, "kw: value not uniform at line %d: lane %d has %lld, lane 0 has %lld\n", line, lane(), v, v0); std::abort(); } }  // the emulator's lanes are fibers: they meet here
 }  // namespace kw

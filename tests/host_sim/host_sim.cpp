@@ -181,6 +181,8 @@ struct HostLauncher {
     void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_scan(c, rp); }); }
     void plan_emit(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_plan_emit(c); }); }
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) { kw::launch(g, b, dyn, [&] { kb_fill(c, rp, l1); }); }
+    void bucket_build(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_bucket_build(c); }); }
+    void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); }); }
     void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { kw::launch(g, b, 0, [&] { kb_apply_jobs(c, ops_base, stmt_base); }); }
     void apply_nodes(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_apply_nodes(c); }); }
     void index_from_recs(int g, int b, const KaiCtx& c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { kw::launch(g, b, 0, [&] { kb_index_from_recs(c, recs, n_recs, l1k, l1n, nb, blk0, blk1); }); }
@@ -218,6 +220,19 @@ extern "C" void kai_hostsim_set_multi(int engines) { g_mw_world = engines < 1 ? 
 extern "C" void kai_hostsim_multi_stats(int64_t* out) { out[0] = g_mw_waves; out[1] = g_mw_sims_run; out[2] = g_mw_sims_used; out[3] = g_mw_replays; }
 static std::vector<int32_t> g_last_groups;  // PodInfo.GPUGroups[0] of the active fraction pods after the last run
 extern "C" int kai_hostsim_last_gpu_groups(int32_t* out, int cap) { int n = (int)g_last_groups.size(); for (int i = 0; i < n && i < cap; i++) out[i] = g_last_groups[i]; return n; }
+// host clocks of the per-cycle host preparation (HostPrep + SharedPods: what kai_session_open does before the first upload), phase by phase — timing aid
+extern "C" int kai_hostsim_prep_ms(const kai_config* cfg, const kai_snapshot_soa* s, double* out, int cap) {
+    auto t0 = std::chrono::steady_clock::now();
+    SharedPods sp; if (!sp.build(*cfg, s)) return KAI_ERR_UNSUPPORTED;
+    auto t1 = std::chrono::steady_clock::now();
+    HostPrep prep; std::string err;
+    if (prep.build(*cfg, s, err)) return KAI_ERR_INVALID_ARG;
+    auto t2 = std::chrono::steady_clock::now();
+    if (cap > 0) out[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (cap > 1) out[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    for (int i = 0; i < 8 && i + 2 < cap; i++) out[i + 2] = prep.phase_ms[i];
+    return 0;
+}
 extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s, const int* actions, int n_actions,
                                kai_op* ops_out, int64_t ops_cap, int64_t* n_ops, int32_t* pod_status_out, int32_t* pod_node_out,
                                kai_queue_share* shares_open, kai_queue_share* shares_final, kai_node_state* nodes_out,
@@ -412,7 +427,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     struct Rep { std::vector<std::vector<char>> pool; KaiCtx c{}; };
     std::vector<Rep> reps;
     HostBackend be; Engine<HostBackend> eng(c, be);
-    int64_t batch_rounds = 0, batch_actions = 0;
+    int64_t batch_rounds = 0, batch_actions = 0, bucket_actions = 0;
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;
         if (actions[i] != KAI_ACTION_ALLOCATE && cfg->use_scheduling_signatures && !s->job_signature && J > 0) return KAI_ERR_UNSUPPORTED;
@@ -469,7 +484,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             if (int rc = batch_allocate(hl, c, prep.shape, bs, c.st->out_len, c.st->stmts)) return rc;
             if (bs.ran) {
                 c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops; c.st->stmts += bs.committed;
-                c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++;
+                c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++; bucket_actions += bs.buckets;
                 g_sh_exchanges = bs.exchanges;
             } else if (g_sh_world > 1) return KAI_ERR_UNSUPPORTED;  // a node-sharded group runs the batch path only
             else eng.execute_allocate();
@@ -500,6 +515,6 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (pod_node_out) for (int p = 0; p < P; p++) pod_node_out[p] = c.p_node[p] >= 0 ? prep.perm[c.p_node[p]] : -1;
     if (shares_final) fill(shares_final);
     if (nodes_out) for (int n = 0; n < N; n++) { kai_node_state& o = nodes_out[prep.perm[n]]; std::memset(&o, 0, sizeof(kai_node_state)); for (int r = 0; r < R; r++) { o.idle[r] = c.n_idle[(size_t)r * N + n]; o.releasing[r] = c.n_rel[(size_t)r * N + n]; o.used[r] = c.n_used[(size_t)r * N + n]; } }
-    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; stats->reserved[4] = batch_actions; stats->reserved[5] = batch_rounds; }
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; stats->reserved[4] = batch_actions; stats->reserved[5] = batch_rounds; stats->reserved[6] = bucket_actions; }
     return KAI_OK;
 }

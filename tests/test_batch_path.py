@@ -112,3 +112,72 @@ def test_batch_under_other_wave_schedules(order):
     env = dict(os.environ, KW_EMU_ORDER=str(order), KW_EMU_SEED="5")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------- the bucket fill (kai_fill_buckets.hpp)
+# stats.reserved[6] of the host simulation = allocate actions whose fill ran on the bucket kernel (sets of nodes by free devices in LDS)
+def _buckets(res):
+    return int(res.stats.reserved[6])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_bucket_fill_takes_binpacked_gpu_classes(seed, monkeypatch):
+    """bin-packed GPU classes on nodes where only the devices can bind: the bucket kernel and the general kernel against the oracle, and against each other"""
+    rng = np.random.default_rng(5100 + seed)
+    snap = synth.make_snapshot(int(rng.integers(1, 400)), int(rng.integers(1, 1500)), 5100 + seed, queue_levels=[(1,), (2, 2), (3, 4), (2, 2, 2)][seed % 4],
+                               prefill=float(rng.random()) * 0.9, gpu_mix=((8, .6), (4, .4)) if seed % 2 else ((8, 1.0),), zipf=bool(seed % 2),
+                               limits_frac=0.3 if seed % 3 == 0 else 0.0, lexi_names=bool(seed % 5 == 0), gpus_per_pod=(1, 2, 4, 8) if seed % 4 else (1, 3, 5))
+    cfg = abi.default_config(k_value=0.5)
+    res = run_both(snap, cfg)
+    assert _buckets(res) == 1
+    monkeypatch.setenv("KAI_FILL_GENERAL", "1")
+    gen = HostSim.run(snap, cfg)
+    assert _buckets(gen) == 0 and gen.stats.reserved[4] == 1
+    assert_same(gen, res)
+    assert stats_tuple(gen.stats) == stats_tuple(res.stats)
+
+
+def test_bucket_fill_declines_when_another_resource_may_bind():
+    """20 000 mCPU per device on nodes of 64 000 - 192 000 mCPU: the CPU runs out before the devices do on most nodes, k_bucket_build's proof fails and
+    the general kernel takes the fill — same results"""
+    for seed in (1, 2, 3):
+        snap = synth.make_snapshot(60, 500, 5200 + seed, prefill=0.2, cpu_per_gpu=20000.0)
+        res = run_both(snap, abi.default_config(k_value=0.5))
+        assert _buckets(res) == 0
+    # memory: 96 GiB per device on nodes of 256 - 1024 GiB
+    snap = synth.make_snapshot(60, 500, 5210, prefill=0.2, mem_per_gpu=96 * synth.GIB)
+    assert _buckets(run_both(snap, abi.default_config())) == 0
+    # pod slots: 3 slots on a node of 8 devices
+    snap = synth.make_snapshot(40, 400, 5211, prefill=0.0)
+    snap.arrays["node_allocatable"][abi.RES_PODS, ::3] = 3; snap.finalize()
+    assert _buckets(run_both(snap, abi.default_config())) == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bucket_fill_with_static_predicates(seed):
+    """pod classes x node classes (the compiled NodeAffinity / TaintToleration table), nodes that are not ready, worker labels under restrictSchedulingNodes: every
+    class looks its nodes up through its own bitmap"""
+    rng = np.random.default_rng(5300 + seed)
+    snap = synth.make_snapshot(int(rng.integers(20, 300)), int(rng.integers(100, 1200)), 5300 + seed, queue_levels=(2, 3), prefill=0.3)
+    synth.add_predicate_features(snap, 5300 + seed, nominated_frac=0.0, oversized_frac=0.02 if seed % 2 else 0.0)
+    a = snap.arrays
+    a["node_class"] = rng.integers(0, 3, size=snap.n_nodes).astype(np.int32)
+    a["pod_class"] = np.repeat(rng.integers(0, 2, size=snap.n_jobs), a["job_n_pods"]).astype(np.int32)
+    a["class_fit"] = np.array([[1, 1, 0], [1, 0, 1]], np.uint8)
+    snap.finalize()
+    cfg = abi.default_config(k_value=0.5)
+    cfg.restrict_node_scheduling = seed % 2
+    res = run_both(snap, cfg)
+    assert _buckets(res) == (0 if seed % 2 else 1)  # (an oversized request asks for more CPU than any node has: the proof cannot hold for its class)
+
+
+def test_bucket_fill_levels():
+    """16 devices per node are the most the sets hold; 32 go to the general kernel; requests of 16 devices; one node; no pending pod"""
+    snap = synth.make_snapshot(50, 600, 5400, gpu_mix=((16, .5), (8, .5)), gpus_per_pod=(1, 2, 4, 8, 16), mem_per_gpu=8 * synth.GIB, cpu_per_gpu=2000.0, prefill=0.4)
+    assert _buckets(run_both(snap, abi.default_config())) == 1
+    snap = synth.make_snapshot(50, 600, 5401, gpu_mix=((32, .5), (8, .5)), gpus_per_pod=(1, 2, 4, 8), mem_per_gpu=4 * synth.GIB, cpu_per_gpu=1000.0, prefill=0.4)
+    assert _buckets(run_both(snap, abi.default_config())) == 0
+    snap = synth.make_snapshot(1, 40, 5402, prefill=0.0)
+    assert _buckets(run_both(snap, abi.default_config())) == 1
+    snap = synth.make_snapshot(130, 900, 5403, prefill=0.97)  # nearly full: most classes are dead from the start, gangs roll back
+    assert _buckets(run_both(snap, abi.default_config())) == 1

@@ -381,6 +381,59 @@ def test_gpu_batch_random_regular(gpu, seed):
     assert_same(res3, ref)
 
 
+def on_buckets(stats):
+    """the fill of the batch path ran on k_fill_buckets (sets of nodes by free devices in LDS; kai_core.hip puts bit 62 of reserved[1])"""
+    return bool((int(stats.reserved[1]) >> 62) & 1)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_gpu_bucket_fill_against_oracle_and_general_kernel(gpu, seed, monkeypatch):
+    """bin-packed GPU classes on nodes where only the devices can bind: k_fill_buckets against the oracle, then the general k_fill on the same snapshot"""
+    rng = np.random.default_rng(5100 + seed)
+    snap = T.pkg.synth.make_snapshot(int(rng.integers(1, 400)), int(rng.integers(1, 1500)), 5100 + seed, queue_levels=[(1,), (2, 2), (3, 4), (2, 2, 2)][seed % 4],
+                                     prefill=float(rng.random()) * 0.9, gpu_mix=((8, .6), (4, .4)) if seed % 2 else ((8, 1.0),), zipf=bool(seed % 2),
+                                     limits_frac=0.3 if seed % 3 == 0 else 0.0, lexi_names=bool(seed % 5 == 0), gpus_per_pod=(1, 2, 4, 8) if seed % 4 else (1, 3, 5))
+    cfg = T.abi.default_config(k_value=0.5)
+    ref = T.Oracle.run(snap, cfg)
+    res = run_gpu(snap, cfg)
+    assert_same(res, ref)
+    assert stats_tuple(res.stats) == stats_tuple(ref.stats)
+    assert res.stats.reserved[4] >= 1 and on_buckets(res.stats)
+    monkeypatch.setenv("KAI_FILL_GENERAL", "1")
+    gen = run_gpu(snap, cfg)
+    assert gen.stats.reserved[4] >= 1 and not on_buckets(gen.stats)
+    assert_same(gen, ref)
+
+
+def test_gpu_bucket_fill_corners(gpu):
+    """what k_bucket_build turns away (another resource may bind first, 32 devices per node) runs on the general kernel; static predicates per class, 16
+    devices per node, a nearly full cluster run on the bucket kernel — all equal to the oracle"""
+    S = T.pkg.synth
+    cases = []
+    cases.append((S.make_snapshot(60, 500, 5201, prefill=0.2, cpu_per_gpu=20000.0), False))
+    cases.append((S.make_snapshot(60, 500, 5210, prefill=0.2, mem_per_gpu=96 * S.GIB), False))
+    cases.append((S.make_snapshot(50, 600, 5401, gpu_mix=((32, .5), (8, .5)), mem_per_gpu=4 * S.GIB, cpu_per_gpu=1000.0, prefill=0.4), False))
+    cases.append((S.make_snapshot(50, 600, 5400, gpu_mix=((16, .5), (8, .5)), gpus_per_pod=(1, 2, 4, 8, 16), mem_per_gpu=8 * S.GIB, cpu_per_gpu=2000.0, prefill=0.4), True))
+    cases.append((S.make_snapshot(130, 900, 5403, prefill=0.97), True))
+    for seed in (0, 2, 4):
+        rng = np.random.default_rng(5300 + seed)
+        snap = S.make_snapshot(int(rng.integers(20, 300)), int(rng.integers(100, 1200)), 5300 + seed, queue_levels=(2, 3), prefill=0.3)
+        S.add_predicate_features(snap, 5300 + seed, nominated_frac=0.0, oversized_frac=0.0)
+        a = snap.arrays
+        a["node_class"] = rng.integers(0, 3, size=snap.n_nodes).astype(np.int32)
+        a["pod_class"] = np.repeat(rng.integers(0, 2, size=snap.n_jobs), a["job_n_pods"]).astype(np.int32)
+        a["class_fit"] = np.array([[1, 1, 0], [1, 0, 1]], np.uint8)
+        snap.finalize()
+        cases.append((snap, True))
+    for snap, want in cases:
+        cfg = T.abi.default_config(k_value=0.5)
+        ref = T.Oracle.run(snap, cfg)
+        res = run_gpu(snap, cfg)
+        assert_same(res, ref)
+        assert stats_tuple(res.stats) == stats_tuple(ref.stats)
+        assert res.stats.reserved[4] >= 1 and on_buckets(res.stats) == want
+
+
 @pytest.mark.parametrize("idx,scale", [(1, 1.0), (2, 0.1), (4, 0.02)])
 def test_gpu_batch_and_sequential_engine_agree(gpu, idx, scale):
     snap, cfg, _ = T.pkg.synth.config(idx, scale)
