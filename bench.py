@@ -79,10 +79,11 @@ def main():
     idx = CONFIGS[args.config]
     actions = tuple(a for a in (args.actions or ("allocate,consolidation,reclaim" if args.config == "C4" else "allocate")).split(",") if a)
     t0 = time.time()
-    # N > 1, default: one independent scheduling shard per GPU (how KAI scales out: a scheduler instance per node pool, conf/scheduler_conf.go:95-112) — weak scaling, no data-path
-    # collective.  KAI_BENCH_MULTI=shard: the ranks shard the NODE axis of ONE snapshot instead (strong scaling; DESIGN.md section 7 explains why that cannot beat one GPU:
-    # the fill is one dependency chain, the exchange only adds to it) and the replicas run as a second leg beside it.
-    sharded = world > 1 and os.environ.get("KAI_BENCH_MULTI", "replicas") == "shard"
+    # N > 1, default (SURVEY 8e / north_star's split): the ranks shard the NODE axis of ONE snapshot — strong scaling; per exchange every rank offers its best nodes
+    # per scan class, one all-gather over RCCL / xGMI, the same virtual fill on every rank (DESIGN.md section 7 says why this cannot beat one GPU: the fill is one
+    # dependency chain and an exchange only adds to it).  The same GPUs as independent scheduling shards (how KAI itself scales out: a scheduler instance per node pool,
+    # conf/scheduler_conf.go:95-112; weak scaling, no data-path collective) run as a second leg beside it (`replicas`).  KAI_BENCH_MULTI=replicas swaps the two.
+    sharded = world > 1 and os.environ.get("KAI_BENCH_MULTI", "shard") == "shard"
     snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=0 if (sharded or world == 1) else pkg.dist.shard_seed(0, rank), mixed=args.mixed)
     if args.queue_depth > 0:
         for a in ("consolidation", "reclaim", "preempt"):
@@ -203,7 +204,7 @@ def main():
     out = {
         "metric": "pod placements/sec (" + " + ".join(actions) + (" action" if len(actions) == 1 else " actions") + ", synthetic snapshot)", "value": value, "unit": "placements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if (sharded or world == 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "placements_per_s": total_placed / elapsed,
         # every allocateTask execution is a decision; the ones k_drain resolves — jobs popped once no class fits anywhere, turned away without touching a node — are split out
         "decisions_per_s": {"all": total_decisions / elapsed, "fill": (total_decisions - drained * args.steps * (1 if sharded else world)) / elapsed if batch else None,
@@ -267,6 +268,51 @@ def main():
                                          "ms_per_step": tw.elapsed_ms, "sample": "the full step", "ops_equal_to_gpu": [tuple(o) for o in tw.ops] == [tuple(o) for o in first_ops]}
         except Exception as e:  # the twin is optional evidence
             out["cpu_same_algorithm"] = {"error": str(e)[:200]}
+    if rank == 0 and world == 1 and os.environ.get("KAI_BENCH_OPEN_LEG", "1") != "0":
+        # What a production scheduler pays per cycle: every cycle opens a session on a NEW snapshot (scheduler.go:112-138, framework/framework.go:32-65), so
+        # kai_session_open — host preparation (node permutation, task / job orders, scan classes: on the host's cores), ~80 MB over PCIe, the OnSessionOpen
+        # kernels — belongs to the cycle.  `value` above keeps the contract's definition (inputs resident in HBM); these two legs are reported beside it:
+        #   serial    : open + actions, one after the other, on one handle;
+        #   pipelined : two handles — while cycle k's actions run on one, cycle k+1's snapshot is opened on the other (host thread + its own stream).  A
+        #               scheduler can only do this if snapshot k+1 is taken before cycle k's decisions are committed to its cache, so it is an upper bound of
+        #               what overlap buys, not a drop-in mode.
+        try:
+            import threading
+            n_cyc = max(3, min(args.steps, 7))
+            ser, ser_open = [], []
+            core2 = pkg.KaiCore(cfg, gpu_ids=(dev_index,))
+            for i in range(n_cyc + 1):
+                t0 = time.perf_counter(); s2 = core2.open_session(snap); t1 = time.perf_counter()
+                for a in actions:
+                    s2.execute(a)
+                t2 = time.perf_counter(); s2.close()
+                if i > 0:
+                    ser.append((t2 - t0) * 1e3); ser_open.append((t1 - t0) * 1e3)
+            cores = [core2, pkg.KaiCore(cfg, gpu_ids=(dev_index,))]
+            pipe = []
+            cur = cores[0].open_session(snap)
+            for i in range(n_cyc + 1):
+                box = {}
+                def opener(k=(i + 1) % 2):
+                    box["s"] = cores[k].open_session(snap)
+                t0 = time.perf_counter(); th = threading.Thread(target=opener); th.start()
+                for a in actions:
+                    cur.execute(a)
+                th.join(); t1 = time.perf_counter()
+                cur.close(); cur = box["s"]
+                if i > 0:
+                    pipe.append((t1 - t0) * 1e3)
+            cur.close()
+            for c2 in cores:
+                c2.destroy()
+            med = lambda v: sorted(v)[len(v) // 2]
+            out["cycle_with_open_ms"] = {"p50": med(ser), "open_p50": med(ser_open), "cycles": n_cyc, "over_ms_per_step": med(ser) / (elapsed / args.steps * 1e3) - 1.0,
+                                         "note": "kai_session_open (host prep + PCIe + OnSessionOpen kernels) + the actions, serial, one handle: the cycle a scheduler pays"}
+            out["cycle_pipelined_ms"] = {"p50": med(pipe), "cycles": n_cyc, "over_ms_per_step": med(pipe) / (elapsed / args.steps * 1e3) - 1.0,
+                                         "note": "two handles: cycle k+1's open overlaps cycle k's actions (valid only if the next snapshot does not wait for this cycle's commits)"}
+            out["config"]["p50_cycle_latency_ms_note"] = "reset of the HBM-resident snapshot + actions; with the per-cycle open: cycle_with_open_ms"
+        except Exception as e:  # additional evidence
+            out["cycle_with_open_ms"] = {"error": str(e)[:200]}
     if sharded and os.environ.get("KAI_BENCH_REPLICAS_LEG", "1") != "0":
         try:
             # second leg, every rank: the same GPUs as independent scheduling shards (how KAI itself scales out: one scheduler instance per node pool,

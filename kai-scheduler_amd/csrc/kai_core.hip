@@ -34,7 +34,8 @@ struct kai_core {
     KaiCtx* d_ctx = nullptr;  // HBM copy of ctx for the persistent kernel
     int fast_ok0 = 0;  // the snapshot's verdict on the staged job path (restored by kai_session_reset)
     bool solver_ready = false;  // scratch of the victim search allocated (first reclaim / preempt / consolidation of the session)
-    std::vector<void*> bufs;  // session HBM: a few large slabs, sub-allocated (one contiguous range ⇒ few TLB entries for the latency-bound engine)
+    std::vector<void*> bufs; std::vector<size_t> buf_bytes;  // session HBM: a few large slabs, sub-allocated (one contiguous range ⇒ few TLB entries for the latency-bound engine)
+    std::vector<std::pair<void*, size_t>> spare;  // slabs of closed sessions, reused by the next open
     char* slab = nullptr; size_t slab_left = 0;
     // device-only helpers
     double* d_jsum = nullptr; int32_t* d_slot_queue = nullptr;
@@ -75,8 +76,11 @@ int dalloc(kai_core* core, T** out, size_t n) {
     if (bytes > core->slab_left) {
         size_t want = std::max<size_t>(bytes, (size_t)256 << 20);  // 256 MiB slabs (2 MiB-aligned by the driver)
         void* p = nullptr;
-        HIP_TRY(core, hipMalloc(&p, want));
-        core->bufs.push_back(p);
+        // a slab of the previous session first: a scheduler opens a session per cycle (scheduler.go:112-138), and hipFree + hipMalloc of a few 256 MiB
+        // slabs per cycle would be milliseconds of every one of them
+        for (size_t i = 0; i < core->spare.size(); i++) if (core->spare[i].second >= want) { p = core->spare[i].first; want = core->spare[i].second; core->spare.erase(core->spare.begin() + (long)i); break; }
+        if (!p) HIP_TRY(core, hipMalloc(&p, want));
+        core->bufs.push_back(p); core->buf_bytes.push_back(want);
         core->slab = static_cast<char*>(p); core->slab_left = want;
     }
     *out = reinterpret_cast<T*>(core->slab);
@@ -158,9 +162,11 @@ int rccl_fail(kai_core* core, const char* what, int rc) {
     return KAI_ERR_COMM;
 }
 
-void free_session(kai_core* core) {
-    for (void* p : core->bufs) (void)hipFree(p);
-    core->bufs.clear(); core->slab = nullptr; core->slab_left = 0;
+void free_session(kai_core* core, bool release = false) {
+    // the slabs stay with the handle for the next session (dalloc takes them back); kai_core_destroy releases them
+    for (size_t i = 0; i < core->bufs.size(); i++) core->spare.push_back({core->bufs[i], core->buf_bytes[i]});
+    core->bufs.clear(); core->buf_bytes.clear(); core->slab = nullptr; core->slab_left = 0;
+    if (release) { for (auto& sp : core->spare) (void)hipFree(sp.first); core->spare.clear(); }
     core->allocs.clear(); core->sv_base = nullptr; core->xr_base = nullptr; core->mw_world = 0; core->rep_mem = nullptr; core->d_ctxs = nullptr; core->d_mw = nullptr; core->d_segs = nullptr; core->d_sg = nullptr;
     core->open = false;
 }
@@ -340,7 +346,7 @@ int kai_core_create(const kai_config* cfg, int n_gpus, const int* gpu_ids, kai_c
 int kai_core_destroy(kai_core* core) {
     if (!core) return KAI_ERR_INVALID_ARG;
     (void)hipSetDevice(core->device);
-    free_session(core);
+    free_session(core, true);
     if (core->rccl_comm) { (void)hipStreamSynchronize(core->stream); if (RcclApi* a = rccl_api()) (void)a->CommDestroy(core->rccl_comm); core->rccl_comm = nullptr; }
     if (core->ev0) (void)hipEventDestroy(core->ev0);
     if (core->ev1) (void)hipEventDestroy(core->ev1);
@@ -609,6 +615,8 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     const bool victim = action != KAI_ACTION_ALLOCATE;
     if (victim && core->cfg.use_scheduling_signatures && !core->ctx.j_signature && core->ctx.J > 0) return fail(core, KAI_ERR_UNSUPPORTED, "use_scheduling_signatures needs kai_snapshot_soa.job_signature (actions/common/minimal_job_comparison.go)");
     HIP_TRY(core, hipSetDevice(core->device));
+    const auto ta0 = std::chrono::steady_clock::now();
+    auto ta_ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     KaiCtx& c = core->ctx;
     if (victim && !core->solver_ready) {  // scratch of the victim search, kept for the rest of the session
         char* base = nullptr; size_t bytes = solver_scratch_bytes(c.N, c.P, c.S, c.J, c.Q, c.W, c.D + c.T, c.TL, c.G);
@@ -647,7 +655,14 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
             HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.st), &sb, sizeof(sb), hipMemcpyHostToDevice, core->stream));
         }
     }
-    if (!bs.ran && core->world > 1) return fail(core, KAI_ERR_UNSUPPORTED, "a node-sharded group runs the allocate action on the batch path only (this action or snapshot does not qualify)");
+    const auto ta1 = std::chrono::steady_clock::now();
+    if (!bs.ran && core->world > 1) {
+        // A node-sharded group shards the batch path's fill.  Every other action — sub-group trees, topology, elastic jobs, the victim actions — runs REPLICATED: every rank
+        // holds the whole session (only the fill's index is sharded), runs the same engine on it and commits the same operations; nothing is exchanged and nothing gets
+        // faster, but a cycle that mixes both kinds of action (BASELINE config 4: allocate, consolidation, reclaim) runs on the group with the one-rank results.
+        // The sharded fill left a class index of the own slice only: rebuild it over all nodes first.
+        if (c.use_index && c.NB) hipLaunchKernelGGL(k_index_build, dim3((c.NB + 3) / 4), dim3(TB), 0, core->stream, c);
+    }
     if (!bs.ran) {  // dynamic LDS: upper levels of the class index, plus the job-order tree when it fits beside them (160 KiB per CU)
         size_t idx_b = lds_index_bytes(c.C, c.NSB), tree_b = lds_tree_bytes(c.Q);
         const size_t budget = 160 * 1024 - 16384;  // static LDS of the kernel (mailbox, context, engine scalars, frame: 6.8 KB, llvm-readelf .group_segment_fixed_size) + margin
@@ -724,12 +739,14 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     if (st.non_allocate_commits) c.fast_ok = 0;  // the staged job path assumes nothing releasing / pipelined in the session (kai_host_prep.hpp); until the next open / reset
     if (st.fault) { char buf[96]; std::snprintf(buf, sizeof buf, "device engine fault code %d (engine source line %d)", st.fault, st.fault_line); core->err = buf; return KAI_ERR_DEVICE_FAULT; }
     *n_ops = st.out_len;
+    const auto ta2 = std::chrono::steady_clock::now();
     if (ops_out) {
         if (st.out_len > ops_cap) return fail(core, KAI_ERR_CAPACITY, "kai_action_execute: ops_cap too small");
         if (st.out_len) HIP_TRY(core, hipMemcpyAsync(ops_out, KAI_VP(c.out_ops), (size_t)st.out_len * sizeof(kai_op), hipMemcpyDeviceToHost, core->stream));
         HIP_TRY(core, hipStreamSynchronize(core->stream));
         for (int64_t i = 0; i < st.out_len; i++) if (ops_out[i].node >= 0) ops_out[i].node = core->perm[ops_out[i].node];  // name rank → caller's index
     }
+    if (std::getenv("KAI_PROF")) { const auto ta3 = std::chrono::steady_clock::now(); std::fprintf(stderr, "kai action host clocks: setup + batch path %.2f ms, engine / drain / stats %.2f, operations to the caller %.2f | total %.2f ms\n", ta_ms(ta0, ta1), ta_ms(ta1, ta2), ta_ms(ta2, ta3), ta_ms(ta0, ta3)); }
     return KAI_OK;
 }
 

@@ -90,20 +90,24 @@ KW_BODY void kb_bucket_build(const KaiCtx& c) {
 
 struct BkLds { int32_t placed_node[KB_PLACED_MAX]; int32_t placed_info[KB_PLACED_MAX]; };  // info: class | level before the placement << 8
 struct BkView {
-    KW_LDS_PTR(uint64_t) gw; KW_LDS_PTR(uint64_t) s1; KW_LDS_PTR(uint64_t) s2; KW_LDS_PTR(uint64_t) ok;
+    KW_LDS_PTR(uint64_t) gw; KW_LDS_PTR(uint64_t) s1; KW_LDS_PTR(uint64_t) ok;
     int NW, NW1, LV;
 };
-// the first node (lowest name rank) of the lowest level >= from_g that class (q, slot) may use: one lane per level, the lowest level that finds one wins
-KW_BODY void bk_find(const BkView& v, int slot, int from_g, int& og, int& on) {
+// LANE l OWNS LEVEL l + 1: its words gw[l][·], its first summary s1[l][·] (LDS) and its second summary s2 (a register of that lane).  No lane ever
+// touches another lane's level, so the levels need no ordering between lanes at all.
+//
+// The first node (lowest name rank) of the lowest level >= from_g that a class with static bitmap `slot` may use: every lane walks its own level
+// (summary register -> summary word -> node word: two dependent LDS reads), the lowest level that finds one wins.
+KW_BODY void bk_find(const BkView& v, uint64_t s2, int slot, int from_g, int& og, int& on) {
     const int lane = kw::lane();
     int n = KB_INF;
     if (lane < v.LV && lane + 1 >= from_g) {
-        uint64_t s2 = v.s2[lane];
-        while (s2 && n == KB_INF) {
-            const int w1 = __builtin_ctzll(s2); s2 &= s2 - 1;
-            uint64_t s1 = v.s1[lane * v.NW1 + w1];
-            while (s1) {
-                const int w = w1 * 64 + __builtin_ctzll(s1); s1 &= s1 - 1;
+        uint64_t m2 = s2;
+        while (m2 && n == KB_INF) {
+            const int w1 = __builtin_ctzll(m2); m2 &= m2 - 1;
+            uint64_t m1 = v.s1[lane * v.NW1 + w1];
+            while (m1) {
+                const int w = w1 * 64 + __builtin_ctzll(m1); m1 &= m1 - 1;
                 uint64_t word = v.gw[lane * v.NW + w];
                 if (slot >= 0) word &= v.ok[slot * v.NW + w];
                 if (word) { n = w * 64 + __builtin_ctzll(word); break; }
@@ -115,21 +119,23 @@ KW_BODY void bk_find(const BkView& v, int slot, int from_g, int& og, int& on) {
     const int l = __builtin_ctzll(m);
     og = l + 1; on = kw::bcast(n, l);
 }
-// node n leaves level `from` and enters level `to` (0 = no level: a node without a free device fits no class)
-KW_BODY void bk_move(const BkView& v, int n, int from, int to) {
-    const int w = n >> 6, w1 = w >> 6; const uint64_t bit = 1ull << (n & 63), bit1 = 1ull << (w & 63), bit2 = 1ull << w1;
-    if (kw::lane() == 0) {
-        if (from >= 1) {
-            const int l = from - 1;
-            const uint64_t x = v.gw[l * v.NW + w] & ~bit; v.gw[l * v.NW + w] = x;
-            if (!x) { const uint64_t y = v.s1[l * v.NW1 + w1] & ~bit1; v.s1[l * v.NW1 + w1] = y; if (!y) v.s2[l] = v.s2[l] & ~bit2; }
-        }
-        if (to >= 1) {
-            const int l = to - 1;
-            v.gw[l * v.NW + w] = v.gw[l * v.NW + w] | bit; v.s1[l * v.NW1 + w1] = v.s1[l * v.NW1 + w1] | bit1; v.s2[l] = v.s2[l] | bit2;
+// Node n leaves level `from` and enters level `to` (0 = no level: a node without a free device fits no class).  Both are the same operation on the owning
+// lane's word — toggle bit n (ds_xor_rtn_b64, one LDS round trip for both levels) — and a summary bit toggles exactly when the word below it became
+// empty or stopped being empty.  Returns, in the lane of level `from`, that level's word after the removal.
+KW_BODY uint64_t bk_move(const BkView& v, uint64_t& s2, int n, int from, int to) {
+    const int lane = kw::lane(), w = n >> 6, w1 = w >> 6;
+    const uint64_t bit = 1ull << (n & 63), bit1 = 1ull << (w & 63), bit2 = 1ull << w1;
+    const bool isfrom = lane == from - 1, isto = lane == to - 1;
+    uint64_t neww = 0;
+    if (isfrom || isto) {
+        const uint64_t old = kw::lds_xor(&v.gw[lane * v.NW + w], bit);
+        neww = old ^ bit;
+        if (isfrom ? neww == 0 : old == 0) {
+            const uint64_t o1 = kw::lds_xor(&v.s1[lane * v.NW1 + w1], bit1);
+            if (isfrom ? (o1 ^ bit1) == 0 : o1 == 0) s2 ^= bit2;
         }
     }
-    kw::lds_order();
+    return neww;
 }
 
 // workgroup of 256: all four wavefronts move the state between its HBM home and LDS, wavefront 0 walks the planned order
@@ -139,7 +145,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
     const int tid = kw::tid(), T = kw::bdim(), lane = kw::lane(), C = c.C;
     BkView v; v.NW = bp.nw; v.NW1 = bp.nw1; v.LV = bp.levels;
     unsigned char* dyn = kw::dyn_lds();
-    v.gw = (KW_LDS_PTR(uint64_t))dyn; v.s1 = v.gw + (size_t)v.LV * v.NW; v.s2 = v.s1 + (size_t)v.LV * v.NW1; v.ok = v.s2 + KBK_GMAX;
+    v.gw = (KW_LDS_PTR(uint64_t))dyn; v.s1 = v.gw + (size_t)v.LV * v.NW; v.ok = v.s1 + (size_t)v.LV * v.NW1 + KBK_GMAX;
     const int64_t tstart = kw::clock();
     for (int i = tid; i < v.LV * v.NW; i += T) v.gw[i] = b.bk_words[i];
     for (int k = 0; k < C; k++) { const int s = bp.okslot[k]; if (s < 0) continue; for (int i = tid; i < v.NW; i += T) v.ok[s * v.NW + i] = b.bk_ok[(size_t)k * v.NW + i]; }
@@ -150,14 +156,15 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         v.s1[i] = m;
     }
     kw::sync();
-    for (int l = tid; l < v.LV; l += T) { uint64_t m = 0; for (int j = 0; j < v.NW1; j++) if (v.s1[l * v.NW1 + j]) m |= 1ull << j; v.s2[l] = m; }
-    kw::sync();
     if (tid < 64) {
+        uint64_t s2 = 0;  // lane l: second summary of level l + 1
+        if (lane < v.LV) for (int j = 0; j < v.NW1; j++) if (v.s1[lane * v.NW1 + j]) s2 |= 1ull << j;
         // lane k: class k — devices asked for, slot of its static bitmap, its best node and that node's level
         const bool act = lane < C;
         int q = 0, okslot = -1, topg = 0, topn = -1;
         if (act) { q = (int)c.cls[lane].req[KAI_RES_GPU]; okslot = bp.okslot[lane]; }
-        for (int k = 0; k < C; k++) { int g, n; bk_find(v, kw::bcast(okslot, k), kw::bcast(q, k), g, n); if (lane == k) { topg = g; topn = n; } }
+        const bool plain = kw::ballot(act && okslot >= 0) == 0;  // no class carries a static bitmap of its own: one lookup answers every class that lost the same node
+        for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); if (lane == k) { topg = g; topn = n; } }
         const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: dead classes only (before the first plan)
         int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, finds = 0; int n_done = rp.start, mismatch = 0;
         for (int base = rp.start; base < V && !mismatch; base += 64) {
@@ -181,7 +188,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                             const int g = kw::bcast(topg, kcls), g2 = g - kw::bcast(q, kcls);
                             if (lane == 0) { L.placed_node[placed] = n; L.placed_info[placed] = kcls | (g << 8); b.t_node[first + placed] = n; }
                             placed++;
-                            bk_move(v, n, g, g2);
+                            const uint64_t neww = bk_move(v, s2, n, g, g2);
                             // the only node whose key moved is n: a class that had it on top keeps it while it still fits (fewer free devices = a better key),
                             // any other class takes it if it now beats that class's best
                             bool need = false;
@@ -193,10 +200,20 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                                 }
                             }
                             uint64_t todo = kw::ballot(need);
-                            while (todo) {  // the class's next best sorts behind (g, n): nothing with fewer free devices exists, or it would have been on top
-                                const int kk = __builtin_ctzll(todo); todo &= todo - 1;
-                                int fg, fn; bk_find(v, kw::bcast(okslot, kk), g, fg, fn); finds++;
-                                if (lane == kk) { topg = fg; topn = fn; }
+                            if (todo) {
+                                // A class that lost n had it at level g as the FIRST node of the lowest level it can use, and n went below what it asks for: its
+                                // next best is the first node at level >= g.  Without static bitmaps that is one answer for all of them — and usually the next
+                                // bit of the word n just left, which the move already returned.
+                                if (plain) {
+                                    const uint64_t rest = kw::bcast(neww, g - 1);
+                                    int fg = g, fn = (n & ~63) + (rest ? __builtin_ctzll(rest) : 0);
+                                    if (!rest) { bk_find(v, s2, -1, g, fg, fn); finds++; }
+                                    if (need) { topg = fg; topn = fn; }
+                                } else while (todo) {
+                                    const int kk = __builtin_ctzll(todo); todo &= todo - 1;
+                                    int fg, fn; bk_find(v, s2, kw::bcast(okslot, kk), g, fg, fn); finds++;
+                                    if (lane == kk) { topg = fg; topn = fn; }
+                                }
                             }
                         }
                     }
@@ -204,9 +221,9 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                         kw::lds_order();
                         for (int i = placed - 1; i >= 0; i--) {
                             const int n = L.placed_node[i], info = L.placed_info[i], gb = info >> 8;
-                            bk_move(v, n, gb - kw::bcast(q, info & 0xff), gb);
+                            (void)bk_move(v, s2, n, gb - kw::bcast(q, info & 0xff), gb);
                         }
-                        if (placed) for (int k = 0; k < C; k++) { int g, n; bk_find(v, kw::bcast(okslot, k), kw::bcast(q, k), g, n); finds++; if (lane == k) { topg = g; topn = n; } }
+                        if (placed) for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); finds++; if (lane == k) { topg = g; topn = n; } }
                         rollbacks += 2;
                     } else { committed++; ops += nt; }
                 }

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "kai_engine.hpp"
+#include "kai_parallel.hpp"
 
 namespace kai {
 
@@ -22,7 +23,7 @@ namespace kai {
 // engine admits them only with ONE GPU memory size M for the whole cluster, so what a request takes on "its node" is known here.
 struct SharedPods {
     bool any = false, mig = false, on = false; std::string err;  // any: shared-GPU requests; mig: some resource row is a MIG profile; on = any || mig: the arrays below are in use
-    std::vector<uint8_t> shared, kind; std::vector<int64_t> mem, gmem; std::vector<double> acc_gpu, pend_gpu, quota_gpu, mig_q;
+    raw_vector<uint8_t> shared, kind; raw_vector<int64_t> mem, gmem; raw_vector<double> acc_gpu, pend_gpu, quota_gpu, mig_q;  // every element is written by build()'s parallel loop
     int32_t mig_g[KAI_MAX_RES] = {0}; int64_t mig_m[KAI_MAX_RES] = {0};
     enum { K_MIG = 1, K_LEGACY = 2, K_REGULAR = 4, K_GPUS = 8 };  // PodInfo: IsMigCandidate / IsLegacyMIGtask / IsRegularGPURequest / ResReq.GPUs() > 0
     static bool has(const kai_snapshot_soa* s) {
@@ -33,7 +34,8 @@ struct SharedPods {
         const int P = s->n_pods, N = s->n_nodes;
         any = has(s);
         const size_t n = (size_t)std::max(P, 1);
-        shared.assign(n, 0); kind.assign(n, 0); mem.assign(n, 0); gmem.assign(n, 0); acc_gpu.assign(n, 0.0); pend_gpu.assign(n, 0.0); quota_gpu.assign(n, 0.0); mig_q.assign(n, 0.0);
+        shared.resize(n); kind.resize(n); mem.resize(n); gmem.resize(n); acc_gpu.resize(n); pend_gpu.resize(n); quota_gpu.resize(n); mig_q.resize(n);
+        if (P == 0) { shared[0] = 0; kind[0] = 0; mem[0] = 0; gmem[0] = 0; acc_gpu[0] = pend_gpu[0] = quota_gpu[0] = mig_q[0] = 0.0; }
         for (int r = KAI_RES_PODS + 1; r < s->n_res && r < KAI_MAX_RES; r++) { mig_g[r] = s->res_mig_gpus ? s->res_mig_gpus[r] : 0; mig_m[r] = s->res_mig_memory ? s->res_mig_memory[r] : 0; if (mig_g[r] > 0) mig = true; }
         on = any || mig;
         // one GPU memory size for the cluster — among the nodes that HAVE devices: a node without the gpu.memory label carries DefaultGpuMemory = 100 (node_info.go:673-687),
@@ -50,7 +52,7 @@ struct SharedPods {
             const double g = s->pod_req[(size_t)KAI_RES_GPU * P + p];
             const double por = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0;
             const int64_t gm = (s->pod_gpu_memory && !(por > 0)) ? s->pod_gpu_memory[p] : 0;
-            acc_gpu[p] = g; pend_gpu[p] = g; quota_gpu[p] = g;
+            acc_gpu[p] = g; pend_gpu[p] = g; quota_gpu[p] = g; shared[p] = 0; mem[p] = 0; gmem[p] = 0;
             if (por > 0) { shared[p] = 1; mem[p] = (int64_t)(por * (double)M); }  // GetResourceGpuMemory (node_info.go:653-659); AcceptedResource keeps the portion
             else if (gm > 0) {
                 if (gm > M || M <= 0) { cerr[(size_t)ci] = "a gpu-memory request above one device's memory: leave the cycle to the host path"; return; }  // isValidGpuPortion :668-671
@@ -237,18 +239,26 @@ struct HostPrep {
         // exact sums: per resource every quantity is a non-negative integer multiple of one power of two, and the totals stay below 2^53 units
         exact_sums = 1;
         for (int r = 0; r < R && exact_sums; r++) {
-            uint64_t bits = 0; bool ok = true;
-            auto take = [&](double v) { if (!(v >= 0) || v != std::floor(v) || v >= 9.2e18) { ok = false; return; } bits |= (uint64_t)v; };
-            for (int n = 0; n < N && ok; n++) take(s->node_allocatable[(size_t)r * N + n]);
-            for (int p = 0; p < P && ok; p++) take(s->pod_req[(size_t)r * P + p]);
-            if (!ok) { exact_sums = 0; break; }
+            // one pass per array on the host's cores: every value a non-negative integer below 2^63, the OR of all values (its trailing zeros = the common
+            // power-of-two unit) and the 128-bit sums of the raw values (sum / unit = the sum of the units: every value is a multiple of the unit)
+            struct Acc { bool ok = true; uint64_t bits = 0; unsigned __int128 sum = 0; };
+            auto pass = [&](const double* v, size_t n) {
+                std::vector<Acc> acc((size_t)chunk_count(n));
+                parallel_chunks(n, [&](int ci, size_t i0, size_t i1) {
+                    Acc a;
+                    for (size_t i = i0; i < i1 && a.ok; i++) { const double x = v[i]; if (!(x >= 0) || x != std::floor(x) || x >= 9.2e18) { a.ok = false; break; } a.bits |= (uint64_t)x; a.sum += (uint64_t)x; }
+                    acc[(size_t)ci] = a;
+                });
+                Acc t; for (const Acc& a : acc) { t.ok = t.ok && a.ok; t.bits |= a.bits; t.sum += a.sum; }
+                return t;
+            };
+            const Acc an = pass(s->node_allocatable + (size_t)r * N, (size_t)N), ap = pass(s->pod_req + (size_t)r * P, (size_t)P);
+            if (!an.ok || !ap.ok) { exact_sums = 0; break; }
+            const uint64_t bits = an.bits | ap.bits;
             if (!bits) continue;
             const int tz = __builtin_ctzll(bits);
-            unsigned __int128 sum_nodes = 0, sum_pods = 0;
-            for (int n = 0; n < N; n++) sum_nodes += (uint64_t)s->node_allocatable[(size_t)r * N + n] >> tz;
-            for (int p = 0; p < P; p++) sum_pods += (uint64_t)s->pod_req[(size_t)r * P + p] >> tz;
             const unsigned __int128 lim = (unsigned __int128)1 << 52;
-            if (sum_nodes >= lim || sum_pods >= lim) exact_sums = 0;
+            if ((an.sum >> tz) >= lim || (ap.sum >> tz) >= lim) exact_sums = 0;
         }
         batch_ok = cfg.engine_mode == 0 && R <= 4 && n_heights <= 16 && exact_sums;
     }

@@ -4,6 +4,8 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -32,5 +34,14 @@ inline void parallel_chunks(size_t n, F&& f, size_t min_chunk = 16384) {
     f(0, bound(0), bound(1));
     for (auto& t : th) t.join();
 }
+
+// std::vector whose resize() leaves new elements uninitialised (trivial types only): the parallel loop that follows writes every element, so the
+// zero fill of a plain vector — a serial pass of page faults over tens of megabytes — is not paid first
+template <class T> struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <class T> using raw_vector = std::vector<T, DefaultInitAlloc<T>>;
 
 }  // namespace kai

@@ -52,6 +52,8 @@ KW_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 // lanes of ONE wave exchange data through LDS only: the LDS serves a wave's accesses in issue order, so keeping the compiler from reordering is enough
 // (no s_waitcnt on the vector-memory counter: stores to HBM stay in flight)
 KW_DEV void lds_order() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+// read-modify-write of one LDS word in ONE ds instruction (ds_xor_rtn_b64); returns the old value.  Wavefront scope: the word belongs to the calling lane
+KW_DEV uint64_t lds_xor(KW_LDS_PTR(uint64_t) p, uint64_t v) { return __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 KW_DEV void expect_uniform(long long) {}
 KW_DEV void fence_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 }  // namespace kw
@@ -215,6 +217,7 @@ inline void fence() {}
 inline void fence_wg() {}
 inline void wave_sync(int line = __builtin_LINE()) { wave_bar(line); }
 inline void lds_order(int line = __builtin_LINE()) { wave_bar(line); }
+inline uint64_t lds_xor(uint64_t* p, uint64_t v) { const uint64_t o = *p; *p = o ^ v; return o; }
 // debug aid: every lane must hold the same value here (a branch on it is meant to be uniform)
 inline void expect_uniform(long long v, int line = __builtin_LINE()) { const long long v0 = shfl(v, 0, line); if (v != v0) { std::fprintf(stderr, "kw: value not uniform at line %d: lane %d has %lld, lane 0 has %lld\n", line, lane(), v, v0); std::abort(); } }  // the emulator's lanes are fibers: they meet here
 }  // namespace kw

@@ -441,6 +441,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         if (std::getenv("KAI_HOSTSIM_PS")) { int ps = std::atoi(std::getenv("KAI_HOSTSIM_PS")); std::fprintf(stderr, "host_sim: before action %d podset %d active_alloc %d used %d alive %d pipelined %d\n", actions[i], ps, c.s_active_alloc[ps], c.s_active_used[ps], c.s_alive[ps], c.s_pipelined[ps]); }
         if (c.st->non_allocate_commits) c.fast_ok = 0;  // as kai_action_execute does after every action
         if (actions[i] != KAI_ACTION_ALLOCATE) {
+            if (g_sh_world > 1 && c.use_index) for (int b = 0; b < c.NB; b++) for (int k = 0; k < c.C; k++) HostBackend::build_block(c, k, b);  // node-sharded group: replicated action on the whole index
             // victim actions on several engines (kai_engine_solver.inc solve_partial_multi): every engine a thread on its own replica of the context; what must
             // hold afterwards — every replica committed the same operations and ended in the same state — is checked here on every run
             const int G = shared ? 1 : g_mw_world;
@@ -486,8 +487,11 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
                 c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops; c.st->stmts += bs.committed;
                 c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++; bucket_actions += bs.buckets;
                 g_sh_exchanges = bs.exchanges;
-            } else if (g_sh_world > 1) return KAI_ERR_UNSUPPORTED;  // a node-sharded group runs the batch path only
-            else eng.execute_allocate();
+            } else {
+                // a node-sharded group shards the batch path's fill; every other action runs replicated on every rank (kai_core.hip kai_action_execute)
+                if (g_sh_world > 1 && c.use_index) for (int b = 0; b < c.NB; b++) for (int k = 0; k < c.C; k++) HostBackend::build_block(c, k, b);  // the sharded fill left an index of the own slice only
+                eng.execute_allocate();
+            }
         }
         if (c.st->drain_pending) {                                         // k_drain
             for (int x = 0; x < J; x++) {

@@ -23,12 +23,18 @@ def _cases():
     sys.path.insert(0, HERE)
     import kai_testlib as T
     from test_batch_path import regular_snapshot
-    out = []
+    out = []  # (snapshot, config, actions of the cycle, does the allocate action take the (sharded) batch path)
     for idx, scale in ((1, 0.1), (2, 0.02), (4, 0.004)):
         snap, cfg, _ = T.pkg.synth.config(idx, scale)
-        out.append((snap, cfg))
+        out.append((snap, cfg, ("allocate",), True))
     for seed in (1, 2, 5, 9, 12):
-        out.append((regular_snapshot(seed), T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=0.5)))
+        out.append((regular_snapshot(seed), T.abi.default_config(gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[seed % 2], k_value=0.5), ("allocate",), True))
+    # actions the group does not shard run replicated on every rank: BASELINE config 4 (zone / rack topology gangs; allocate, consolidation, reclaim),
+    # elastic gangs and two pod-sets, a crowded cluster under all four actions with an allocate after the victim actions (sharded fill, then replicated engine, ...)
+    snap, cfg, _ = T.pkg.synth.config(3, 0.004)
+    out.append((snap, cfg, ("allocate", "consolidation", "reclaim"), False))
+    out.append((T.pkg.synth.make_snapshot(30, 300, 77, queue_levels=(2, 2), elastic_frac=0.4, multi_podset_frac=0.3), T.abi.default_config(), ("allocate",), False))
+    out.append((T.pkg.synth.make_crowded_snapshot(8, 1003, elastic_frac=0.0), T.abi.default_config(max_consolidation_preemptees=-1), ("allocate", "reclaim", "preempt", "allocate"), None))
     return out
 
 
@@ -52,9 +58,9 @@ def _worker(rank, world, port, k_offers, out):
         return 0
 
     rows = []
-    for snap, cfg in _cases():
+    for snap, cfg, actions, _ in _cases():
         raw.kai_hostsim_set_shard(rank, world, k_offers, allgather, None)
-        res = HostSim.run(snap, cfg)
+        res = HostSim.run(snap, cfg, actions)
         rows.append((res.ops, res.stmts, res.pod_status.tolist(), res.pod_node.tolist(), {k: v.tolist() for k, v in res.nodes.items()},
                      {k: v.tolist() for k, v in res.shares_final.items()}, int(res.stats.reserved[4]), int(raw.kai_hostsim_last_exchanges()),
                      (int(res.stats.decisions), int(res.stats.jobs_attempted), int(res.stats.jobs_committed), int(res.stats.rollbacks))))
@@ -75,19 +81,23 @@ def test_node_sharded_group_equals_one_rank(world, k_offers):
     for p in procs: p.start()
     got = dict(out.get(timeout=600) for _ in range(world))
     for p in procs: p.join(timeout=60); assert p.exitcode == 0
-    for ci, (snap, cfg) in enumerate(_cases()):
-        ref = T.Oracle.run(snap, cfg)
-        one = HostSim.run(snap, cfg)
+    for ci, (snap, cfg, actions, want_batch) in enumerate(_cases()):
+        ref = T.Oracle.run(snap, cfg, actions)
+        one = HostSim.run(snap, cfg, actions)
         assert one.ops == ref.ops
         for rank in range(world):
             ops, stmts, st, nd, nodes, shares, batch, exchanges, stats = got[rank][ci]
-            assert batch == 1, "the sharded group did not take the batch path"
-            assert exchanges >= 1 or len(ref.ops) == 0
+            if want_batch is True:
+                assert batch == 1, "the sharded group did not take the batch path"
+                assert exchanges >= 1 or len(ref.ops) == 0
+            elif want_batch is False:
+                assert batch == 0  # replicated: the same engine on every rank, no exchange
             assert [tuple(o) for o in ops] == ref.ops and stmts == ref.stmts
             assert st == ref.pod_status.tolist() and nd == ref.pod_node.tolist()
             for k in ref.nodes: assert nodes[k] == ref.nodes[k].tolist(), k
             for k in ref.shares_final: assert shares[k] == ref.shares_final[k].tolist(), k
-            assert stats == (ref.stats.decisions, ref.stats.jobs_attempted, ref.stats.jobs_committed, ref.stats.rollbacks)
+            if len(actions) == 1:  # (statistics are those of the cycle's last action)
+                assert stats == (ref.stats.decisions, ref.stats.jobs_attempted, ref.stats.jobs_committed, ref.stats.rollbacks)
 
 
 def test_single_process_is_a_noop():
