@@ -111,9 +111,13 @@ def main():
     last_stats = [None]  # statistics of the cycle's last action
     first_ops = []
 
+    trace_steps = os.environ.get("KAI_BENCH_TRACE") == "1"  # host clocks of a step's parts on stderr (diagnostic)
+
     def step(record):
         nonlocal decisions, placed
+        t_s0 = time.perf_counter()
         ssn.reset()
+        t_s1 = time.perf_counter()
         o_ms = ssn.stats().upload_ms
         n_ops, n_dec, k_ms_sum, st = 0, 0, 0.0, None
         ops_step = []
@@ -123,6 +127,8 @@ def main():
             s_a = ssn.stats(); n_dec += int(s_a.decisions); k_ms_sum += s_a.kernel_ms
             st = s_a if st is None else st  # the engine counters reported below are the allocate action's
             last_stats[0] = s_a
+        if trace_steps:
+            print(f"bench step: reset {1e3 * (t_s1 - t_s0):.2f} ms, actions {1e3 * (time.perf_counter() - t_s1):.2f} ms", file=sys.stderr)
         if record:
             kernel_ms.append(k_ms_sum); open_ms.append(o_ms)
             decisions = n_dec; placed = n_ops

@@ -612,7 +612,29 @@ KW_BODY void kb_fill_mode(const KaiCtx& c, RoundParams rp, int l1_in_lds, FillLd
            if (spec) kb_fill_run<MODE, true>(c, rp, L, f, l1, false); else kb_fill_run<MODE, false>(c, rp, L, f, l1, false); }
 }
 // dynamic LDS: [super-block level C x NSB][block level C x NB when it fits]
-KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {
+KW_BODY void kb_fill_state(const KaiCtx& c, RoundParams rp, FillState& f) {
+    const int lane = kw::lane();
+    f.bcur = -1; f.sbcur = -1; f.c1k = f.c2k = 0; f.c1n = f.c2n = 0; f.c1_dirty = f.c2_dirty = false; f.n_loads = f.n_r1 = f.n_r2 = f.n_r3 = 0; f.pend_n = -1; f.pend_cls = 0; f.pend_key = 0; f.topk = 0; f.topn = KB_INF; for (int i = 0; i < 4; i++) f.cy[i] = 0;
+    f.plugins = c.plugins; f.R = c.R; f.C = c.C; f.NB = c.NB; f.NSB = c.NSB;
+    const bool virt = rp.mode == 2 || (rp.mode == 1 && c.bt.world > 1);
+    if (virt) { f.NB = (c.bt.vstate[0] + KAI_BLOCK - 1) / KAI_BLOCK; f.NSB = (f.NB + 63) / 64; if (f.NSB < 1) f.NSB = 1; }  // the virtual cluster of a node-sharded group
+    for (int r = 0; r < 4; r++) f.creq[r] = 0; f.cflags = 0;
+    if (lane < c.C) { const ClassRec cr = c.cls[lane]; for (int r = 0; r < 4; r++) f.creq[r] = cr.req[r]; f.cflags = class_flags(cr); }
+    f.rec = make_node_rec(c, c.N);  // an empty record until the first block is loaded
+    f.l2 = (KW_LDS_PTR(IdxE))(kw::dyn_lds());
+}
+// ONE variant of the fill per kernel (device): compiled together into one kernel the eight variants cost ~800 SGPR spills and a 35 000-instruction body; apart, 72 - 110
+// spills each (profiles/r04_fill_kernels_resource_usage.txt).  MODE: the session's own nodes / the virtual cluster of a node-sharded group; SPEC: the default plugin tier
+// with R = 4 (the class key folds to its shortest form); L1L: block level of the index in LDS / in HBM.
+template <int MODE, bool SPEC, bool L1L>
+KW_BODY void kb_fill_variant(const KaiCtx& c, RoundParams rp) {
+    KW_SHARED FillLds L;
+    FillState f; kb_fill_state(c, rp, f);
+    if (L1L) { L1Lds l1; l1.e = (KW_LDS_PTR(IdxE))(kw::dyn_lds() + (size_t)c.C * f.NSB * sizeof(IdxE)); l1.NB = f.NB; kb_fill_run<MODE, SPEC>(c, rp, L, f, l1, true); }
+    else { L1Hbm l1; l1.key = c.sum1_key; l1.node = c.sum1_node; l1.NB = f.NB; kb_fill_run<MODE, SPEC>(c, rp, L, f, l1, false); }
+}
+KW_BODY bool kb_fill_spec(const KaiCtx& c) { return (c.plugins & KB_KEY_PLUGINS) == KB_KEY_PLUGINS && c.R == 4; }
+KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {  // every variant behind one entry: the emulator's form (tests/host_sim)
     KW_SHARED FillLds L;
     const int lane = kw::lane();
     FillState f; f.bcur = -1; f.sbcur = -1; f.c1k = f.c2k = 0; f.c1n = f.c2n = 0; f.c1_dirty = f.c2_dirty = false; f.n_loads = f.n_r1 = f.n_r2 = f.n_r3 = 0; f.pend_n = -1; f.pend_cls = 0; f.pend_key = 0; f.topk = 0; f.topn = KB_INF; for (int i = 0; i < 4; i++) f.cy[i] = 0;
@@ -808,7 +830,7 @@ __global__ void k_plan_leaf(KaiCtx c, RoundParams rp) { kb_plan_leaf(c, rp); }
 __global__ void k_plan_rank(KaiCtx c, RoundParams rp) { kb_plan_rank(c, rp); }
 __global__ void __launch_bounds__(1024) k_plan_scan(KaiCtx c, RoundParams rp) { kb_plan_scan(c, rp); }
 __global__ void k_plan_emit(KaiCtx c) { kb_plan_emit(c); }
-__global__ void __launch_bounds__(64) k_fill(KaiCtx c, RoundParams rp, int l1_in_lds) { kb_fill(c, rp, l1_in_lds); }
+template <int MODE, bool SPEC, bool L1L> __global__ void __launch_bounds__(64) k_fill(KaiCtx c, RoundParams rp) { kb_fill_variant<MODE, SPEC, L1L>(c, rp); }
 __global__ void k_apply_jobs(KaiCtx c, long long ops_base, long long stmt_base) { kb_apply_jobs(c, (int64_t)ops_base, (int64_t)stmt_base); }
 __global__ void k_apply_nodes(KaiCtx c) { kb_apply_nodes(c); }
 __global__ void k_index_from_recs(KaiCtx c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { kb_index_from_recs(c, (KAI_GP(const NodeRec))recs, n_recs, (KAI_GP(uint64_t))l1k, (KAI_GP(int32_t))l1n, nb, blk0, blk1); }

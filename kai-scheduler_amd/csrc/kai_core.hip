@@ -203,7 +203,7 @@ int launch_open_kernels(kai_core* core) {
 }
 // the batch path's kernels on the session's stream (kai_batch_driver.hpp's Launcher)
 struct DevLauncher {
-    kai_core* core; int rc = 0; bool fill_attr_set = false;
+    kai_core* core; int rc = 0; unsigned fill_attr_mask = 0; size_t fill_attr_dyn = 0;
     void static_rank(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_static_rank, dim3(g), dim3(b), 0, core->stream, c); }
     void static_check(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_static_check, dim3(g), dim3(b), 0, core->stream, c); }
     void qualify(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_qualify, dim3(g), dim3(b), 0, core->stream, c); }
@@ -213,10 +213,18 @@ struct DevLauncher {
     void plan_rank(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_rank, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_scan, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_emit(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_plan_emit, dim3(g), dim3(b), 0, core->stream, c); }
+    template <int MODE, bool SPEC, bool L1L> void fill_launch(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp) {
+        const unsigned vbit = 1u << ((MODE == FM_SHARDED ? 4 : 0) + (SPEC ? 2 : 0) + (L1L ? 1 : 0));  // once per variant and action: the dynamic-LDS ceiling of the kernel
+        if (!(fill_attr_mask & vbit) || dyn > fill_attr_dyn) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<MODE, SPEC, L1L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_attr_mask |= vbit; fill_attr_dyn = std::max(fill_attr_dyn, dyn); }
+        hipLaunchKernelGGL((k_fill<MODE, SPEC, L1L>), dim3(g), dim3(b), dyn, core->stream, c, rp);
+    }
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) {
-        if (!fill_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_attr_set = true; }
         if (rp.mode == 0 || (rp.mode == 2 && rp.start == 0)) (void)hipEventRecord(core->bev[1], core->stream);  // a sharded round: from its first virtual fill …
-        hipLaunchKernelGGL(k_fill, dim3(g), dim3(b), dyn, core->stream, c, rp, l1);
+        const bool spec = (c.plugins & KB_KEY_PLUGINS) == KB_KEY_PLUGINS && c.R == 4, sh = rp.mode == 2;
+        if (sh) { if (spec) { if (l1) fill_launch<FM_SHARDED, true, true>(g, b, dyn, c, rp); else fill_launch<FM_SHARDED, true, false>(g, b, dyn, c, rp); }
+                  else { if (l1) fill_launch<FM_SHARDED, false, true>(g, b, dyn, c, rp); else fill_launch<FM_SHARDED, false, false>(g, b, dyn, c, rp); } }
+        else { if (spec) { if (l1) fill_launch<FM_PLAIN, true, true>(g, b, dyn, c, rp); else fill_launch<FM_PLAIN, true, false>(g, b, dyn, c, rp); }
+               else { if (l1) fill_launch<FM_PLAIN, false, true>(g, b, dyn, c, rp); else fill_launch<FM_PLAIN, false, false>(g, b, dyn, c, rp); } }
         if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);                                       // … to its last (exchanges included)
     }
     bool fill_bk_attr_set = false;

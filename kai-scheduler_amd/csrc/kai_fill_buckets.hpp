@@ -124,15 +124,16 @@ KW_BODY void bk_find(const BkView& v, uint64_t s2, int slot, int from_g, int& og
 // empty or stopped being empty.  Returns, in the lane of level `from`, that level's word after the removal.
 KW_BODY uint64_t bk_move(const BkView& v, uint64_t& s2, int n, int from, int to) {
     const int lane = kw::lane(), w = n >> 6, w1 = w >> 6;
-    const uint64_t bit = 1ull << (n & 63), bit1 = 1ull << (w & 63), bit2 = 1ull << w1;
-    const bool isfrom = lane == from - 1, isto = lane == to - 1;
-    uint64_t neww = 0;
-    if (isfrom || isto) {
-        const uint64_t old = kw::lds_xor(&v.gw[lane * v.NW + w], bit);
-        neww = old ^ bit;
-        if (isfrom ? neww == 0 : old == 0) {
-            const uint64_t o1 = kw::lds_xor(&v.s1[lane * v.NW1 + w1], bit1);
-            if (isfrom ? (o1 ^ bit1) == 0 : o1 == 0) s2 ^= bit2;
+    const uint64_t bit = 1ull << (n & 63);
+    const bool isfrom = lane == from - 1, part = isfrom || lane == to - 1;
+    uint64_t old = 0;
+    if (part) old = kw::lds_xor(&v.gw[lane * v.NW + w], bit);
+    const uint64_t neww = old ^ bit;
+    const bool flip1 = part && (isfrom ? neww == 0 : old == 0);
+    if (kw::ballot(flip1)) {  // (uniform) a word became empty or stopped being empty: its bit in the first summary toggles, and so on upwards
+        if (flip1) {
+            const uint64_t bit1 = 1ull << (w & 63), o1 = kw::lds_xor(&v.s1[lane * v.NW1 + w1], bit1);
+            if (isfrom ? (o1 ^ bit1) == 0 : o1 == 0) s2 ^= 1ull << w1;
         }
     }
     return neww;
@@ -180,25 +181,26 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                         int my_cls = ucls;
                         if (ucls < 0) my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;  // a gang of several scan classes: its task list
                         const int tc = nt - tb < 64 ? nt - tb : 64;
+                        int my_node = 0, my_info = 0, done = 0;  // lane i: the i-th placement of this stretch of (at most 64) tasks
                         for (int ti = 0; ti < tc; ti++) {
                             const int kcls = ucls >= 0 ? ucls : kw::bcast(my_cls, ti);
                             decisions++;
                             const int n = kw::bcast(topn, kcls);
                             if (n < 0) { ok = false; break; }
                             const int g = kw::bcast(topg, kcls), g2 = g - kw::bcast(q, kcls);
-                            if (lane == 0) { L.placed_node[placed] = n; L.placed_info[placed] = kcls | (g << 8); b.t_node[first + placed] = n; }
-                            placed++;
+                            const bool me = lane == ti;
+                            my_node = me ? n : my_node; my_info = me ? (kcls | (g << 8)) : my_info;
+                            done++;
                             const uint64_t neww = bk_move(v, s2, n, g, g2);
                             // the only node whose key moved is n: a class that had it on top keeps it while it still fits (fewer free devices = a better key),
                             // any other class takes it if it now beats that class's best
-                            bool need = false;
-                            if (act) {
-                                if (topn == n) { if (g2 >= q) topg = g2; else need = true; }
-                                else if (g2 >= q) {
-                                    const bool okn = okslot < 0 || ((v.ok[okslot * v.NW + (n >> 6)] >> (n & 63)) & 1ull);
-                                    if (okn && (topn < 0 || g2 < topg || (g2 == topg && n < topn))) { topg = g2; topn = n; }
-                                }
-                            }
+                            bool okn = true;
+                            if (!plain) okn = okslot < 0 || ((v.ok[(okslot < 0 ? 0 : okslot) * v.NW + (n >> 6)] >> (n & 63)) & 1ull);
+                            const bool mine = topn == n, fits2 = g2 >= q;
+                            const bool take = act && !mine && fits2 && okn && (topn < 0 || g2 < topg || (g2 == topg && n < topn));
+                            const bool need = act && mine && !fits2;
+                            topg = (take || (act && mine && fits2)) ? g2 : topg;
+                            topn = take ? n : topn;
                             uint64_t todo = kw::ballot(need);
                             if (todo) {
                                 // A class that lost n had it at level g as the FIRST node of the lowest level it can use, and n went below what it asks for: its
@@ -208,7 +210,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                                     const uint64_t rest = kw::bcast(neww, g - 1);
                                     int fg = g, fn = (n & ~63) + (rest ? __builtin_ctzll(rest) : 0);
                                     if (!rest) { bk_find(v, s2, -1, g, fg, fn); finds++; }
-                                    if (need) { topg = fg; topn = fn; }
+                                    topg = need ? fg : topg; topn = need ? fn : topn;
                                 } else while (todo) {
                                     const int kk = __builtin_ctzll(todo); todo &= todo - 1;
                                     int fg, fn; bk_find(v, s2, kw::bcast(okslot, kk), g, fg, fn); finds++;
@@ -216,6 +218,9 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                                 }
                             }
                         }
+                        // the stretch's placements: the tasks' nodes for the apply kernels (one coalesced store) and the rollback list
+                        if (lane < done) { b.t_node[first + tb + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
+                        placed += done;
                     }
                     if (!ok) {  // Statement.Rollback: the undone operations in reverse order, then every class's best from the restored sets
                         kw::lds_order();
