@@ -36,6 +36,7 @@ struct kai_core {
     bool solver_ready = false;  // scratch of the victim search allocated (first reclaim / preempt / consolidation of the session)
     std::vector<void*> bufs; std::vector<size_t> buf_bytes;  // session HBM: a few large slabs, sub-allocated (one contiguous range ⇒ few TLB entries for the latency-bound engine)
     std::vector<std::pair<void*, size_t>> spare;  // slabs of closed sessions, reused by the next open
+    void* pin_buf = nullptr; size_t pin_bytes = 0;  // pinned host staging for the operations handed to the caller (grows, lives with the handle)
     char* slab = nullptr; size_t slab_left = 0;
     // device-only helpers
     double* d_jsum = nullptr; int32_t* d_slot_queue = nullptr;
@@ -355,6 +356,7 @@ int kai_core_destroy(kai_core* core) {
     if (!core) return KAI_ERR_INVALID_ARG;
     (void)hipSetDevice(core->device);
     free_session(core, true);
+    if (core->pin_buf) { (void)hipHostFree(core->pin_buf); core->pin_buf = nullptr; core->pin_bytes = 0; }
     if (core->rccl_comm) { (void)hipStreamSynchronize(core->stream); if (RcclApi* a = rccl_api()) (void)a->CommDestroy(core->rccl_comm); core->rccl_comm = nullptr; }
     if (core->ev0) (void)hipEventDestroy(core->ev0);
     if (core->ev1) (void)hipEventDestroy(core->ev1);
@@ -750,9 +752,20 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     const auto ta2 = std::chrono::steady_clock::now();
     if (ops_out) {
         if (st.out_len > ops_cap) return fail(core, KAI_ERR_CAPACITY, "kai_action_execute: ops_cap too small");
-        if (st.out_len) HIP_TRY(core, hipMemcpyAsync(ops_out, KAI_VP(c.out_ops), (size_t)st.out_len * sizeof(kai_op), hipMemcpyDeviceToHost, core->stream));
+        // through the handle's own pinned buffer: a copy of some MB straight into the caller's pageable memory makes the runtime pin and unpin that memory around
+        // the transfer, and the unpinning lands in a later call (measured: 22 ms in every other kai_session_reset of the C5 bench, profiles/r04e_*)
+        const size_t bytes = (size_t)st.out_len * sizeof(kai_op);
+        if (bytes > core->pin_bytes) {
+            if (core->pin_buf) (void)hipHostFree(core->pin_buf);
+            core->pin_buf = nullptr; core->pin_bytes = 0;
+            const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+            HIP_TRY(core, hipHostMalloc(&core->pin_buf, want, hipHostMallocDefault));
+            core->pin_bytes = want;
+        }
+        if (st.out_len) HIP_TRY(core, hipMemcpyAsync(core->pin_buf, KAI_VP(c.out_ops), bytes, hipMemcpyDeviceToHost, core->stream));
         HIP_TRY(core, hipStreamSynchronize(core->stream));
-        for (int64_t i = 0; i < st.out_len; i++) if (ops_out[i].node >= 0) ops_out[i].node = core->perm[ops_out[i].node];  // name rank → caller's index
+        const kai_op* src = static_cast<const kai_op*>(core->pin_buf);
+        for (int64_t i = 0; i < st.out_len; i++) { kai_op o = src[i]; if (o.node >= 0) o.node = core->perm[o.node]; ops_out[i] = o; }  // name rank → caller's index
     }
     if (std::getenv("KAI_PROF")) { const auto ta3 = std::chrono::steady_clock::now(); std::fprintf(stderr, "kai action host clocks: setup + batch path %.2f ms, engine / drain / stats %.2f, operations to the caller %.2f | total %.2f ms\n", ta_ms(ta0, ta1), ta_ms(ta1, ta2), ta_ms(ta2, ta3), ta_ms(ta0, ta3)); }
     return KAI_OK;

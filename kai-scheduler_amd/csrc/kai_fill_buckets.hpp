@@ -89,6 +89,8 @@ KW_BODY void kb_bucket_build(const KaiCtx& c) {
 }
 
 struct BkLds { int32_t placed_node[KB_PLACED_MAX]; int32_t placed_info[KB_PLACED_MAX]; };  // info: class | level before the placement << 8
+constexpr uint32_t BK_DEAD = 0xffffffffu;  // a class's best node as one ascending key, level << 20 | node (N <= 2^18 nodes: the summaries' reach); BK_DEAD: none
+KW_BODY uint32_t bk_key(int g, int n) { return n < 0 ? BK_DEAD : ((uint32_t)g << 20) | (uint32_t)n; }
 struct BkView {
     KW_LDS_PTR(uint64_t) gw; KW_LDS_PTR(uint64_t) s1; KW_LDS_PTR(uint64_t) ok;
     int NW, NW1, LV;
@@ -160,21 +162,22 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
     if (tid < 64) {
         uint64_t s2 = 0;  // lane l: second summary of level l + 1
         if (lane < v.LV) for (int j = 0; j < v.NW1; j++) if (v.s1[lane * v.NW1 + j]) s2 |= 1ull << j;
-        // lane k: class k — devices asked for, slot of its static bitmap, its best node and that node's level
+        // lane k: class k — devices asked for, slot of its static bitmap, and its best node as ONE ascending key: level << 20 | node (a class's order over the nodes
+        // it may use is (free devices, name rank) ascending; BK_DEAD = no node fits).  Lanes beyond the classes hold BK_DEAD and ask for "infinitely many" devices.
         const bool act = lane < C;
-        int q = 0, okslot = -1, topg = 0, topn = -1;
+        int q = 0x7fffffff, okslot = -1; uint32_t top = BK_DEAD;
         if (act) { q = (int)c.cls[lane].req[KAI_RES_GPU]; okslot = bp.okslot[lane]; }
         const bool plain = kw::ballot(act && okslot >= 0) == 0;  // no class carries a static bitmap of its own: one lookup answers every class that lost the same node
-        for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); if (lane == k) { topg = g; topn = n; } }
+        for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); if (lane == k) top = bk_key(g, n); }
         const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: dead classes only (before the first plan)
-        int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, finds = 0; int n_done = rp.start, mismatch = 0;
+        int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, finds = 0, n_done = rp.start, mismatch = 0;  // (of one launch: far below 2^31)
         for (int base = rp.start; base < V && !mismatch; base += 64) {
             const int gi = base + lane;
             const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE, my_first = gi < V ? b.g_first[gi] : 0, my_nt = gi < V ? b.g_nt[gi] : 0, my_ucls = gi < V ? b.g_ucls[gi] : 0;
             const int cnt = V - base < 64 ? V - base : 64;
             for (int jj = 0; jj < cnt; jj++) {
                 const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
-                const int opoff = (int)ops + rp.ops0, stmtoff = (int)committed + rp.stmt0;
+                const int opoff = ops + rp.ops0, stmtoff = committed + rp.stmt0;
                 bool ok = flag != BF_GATE; int placed = 0;
                 if (flag != BF_GATE) {
                     for (int tb = 0; tb < nt && ok; tb += 64) {
@@ -185,22 +188,21 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                         for (int ti = 0; ti < tc; ti++) {
                             const int kcls = ucls >= 0 ? ucls : kw::bcast(my_cls, ti);
                             decisions++;
-                            const int n = kw::bcast(topn, kcls);
-                            if (n < 0) { ok = false; break; }
-                            const int g = kw::bcast(topg, kcls), g2 = g - kw::bcast(q, kcls);
+                            const uint32_t tk = kw::bcast(top, kcls);
+                            if (tk == BK_DEAD) { ok = false; break; }
+                            const int n = (int)(tk & 0xfffffu), g = (int)(tk >> 20), g2 = g - kw::bcast(q, kcls);
                             const bool me = lane == ti;
                             my_node = me ? n : my_node; my_info = me ? (kcls | (g << 8)) : my_info;
                             done++;
                             const uint64_t neww = bk_move(v, s2, n, g, g2);
-                            // the only node whose key moved is n: a class that had it on top keeps it while it still fits (fewer free devices = a better key),
-                            // any other class takes it if it now beats that class's best
+                            // the only node whose key moved is n (to cand): a class that had it on top keeps it while it still fits (fewer free devices = a better
+                            // key), any other class takes it if it now beats that class's best
+                            const uint32_t cand = ((uint32_t)g2 << 20) | (uint32_t)n;
                             bool okn = true;
                             if (!plain) okn = okslot < 0 || ((v.ok[(okslot < 0 ? 0 : okslot) * v.NW + (n >> 6)] >> (n & 63)) & 1ull);
-                            const bool mine = topn == n, fits2 = g2 >= q;
-                            const bool take = act && !mine && fits2 && okn && (topn < 0 || g2 < topg || (g2 == topg && n < topn));
-                            const bool need = act && mine && !fits2;
-                            topg = (take || (act && mine && fits2)) ? g2 : topg;
-                            topn = take ? n : topn;
+                            const bool mine = top == tk, fits2 = g2 >= q;
+                            const bool need = mine && !fits2;
+                            top = (fits2 && (mine || (okn && cand < top))) ? cand : top;
                             uint64_t todo = kw::ballot(need);
                             if (todo) {
                                 // A class that lost n had it at level g as the FIRST node of the lowest level it can use, and n went below what it asks for: its
@@ -208,13 +210,13 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                                 // bit of the word n just left, which the move already returned.
                                 if (plain) {
                                     const uint64_t rest = kw::bcast(neww, g - 1);
-                                    int fg = g, fn = (n & ~63) + (rest ? __builtin_ctzll(rest) : 0);
-                                    if (!rest) { bk_find(v, s2, -1, g, fg, fn); finds++; }
-                                    topg = need ? fg : topg; topn = need ? fn : topn;
+                                    uint32_t fk = ((uint32_t)g << 20) | (uint32_t)((n & ~63) + (rest ? __builtin_ctzll(rest) : 0));
+                                    if (!rest) { int fg, fn; bk_find(v, s2, -1, g, fg, fn); fk = bk_key(fg, fn); finds++; }
+                                    top = need ? fk : top;
                                 } else while (todo) {
                                     const int kk = __builtin_ctzll(todo); todo &= todo - 1;
                                     int fg, fn; bk_find(v, s2, kw::bcast(okslot, kk), g, fg, fn); finds++;
-                                    if (lane == kk) { topg = fg; topn = fn; }
+                                    if (lane == kk) top = bk_key(fg, fn);
                                 }
                             }
                         }
@@ -228,7 +230,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                             const int n = L.placed_node[i], info = L.placed_info[i], gb = info >> 8;
                             (void)bk_move(v, s2, n, gb - kw::bcast(q, info & 0xff), gb);
                         }
-                        if (placed) for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); finds++; if (lane == k) { topg = g; topn = n; } }
+                        if (placed) for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); finds++; if (lane == k) top = bk_key(g, n); }
                         rollbacks += 2;
                     } else { committed++; ops += nt; }
                 }
@@ -237,7 +239,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                 if ((flag == BF_OK) != ok) { mismatch = 1; break; }
             }
         }
-        const uint64_t dead = kw::ballot(act && topn < 0);
+        const uint64_t dead = kw::ballot(act && top == BK_DEAD);
         if (lane == 0) {
             FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V; s.floor_stop = 0; s.pad = 0;
             s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
