@@ -171,9 +171,17 @@ class Parser:
         raise SyntaxError(f"type? {t}")
 
     # expressions ---------------------------------------------------------------------------------
-    def parse_expr(self, elem_type=None):
+    def parse_expr(self, elem_type=None):  # Go's precedence for the arithmetic the fixtures use: * / bind tighter than + -, both left-associative
+        lhs = self.parse_term(elem_type)
+        while self.peek()[1] in ("+", "-") and self.peek()[0] == "op":
+            op = self.next()[1]
+            rhs = self.parse_term(None)
+            lhs = {"_bin": op, "l": lhs, "r": rhs}
+        return lhs
+
+    def parse_term(self, elem_type=None):
         lhs = self.parse_unary(elem_type)
-        while self.peek()[1] in ("*", "/", "+", "-") and self.peek()[0] == "op":
+        while self.peek()[1] in ("*", "/") and self.peek()[0] == "op":
             op = self.next()[1]
             rhs = self.parse_unary(None)
             lhs = {"_bin": op, "l": lhs, "r": rhs}
