@@ -177,6 +177,10 @@ struct MultiCtx {
     int32_t res[2][KAI_MW_WAVE];                 // … SIM_* status | MW_TOUCHED of simulation i
     int64_t cnt[2][KAI_MW_WAVE][KAI_MW_CNT];     // … and the counters it bumped
     int64_t waves, sims_run, sims_used, replays;  // diagnostics (rank 0 adds what it sees)
+    // the same waves dealt out over the GPUs of a node-sharded group (kai_victim_shard.hpp): written between the two barriers of a wave's end by whoever carries the
+    // exchange (the host behind the mailbox on the device, engine 0 itself on the emulator); res / cnt / hit of buffer b then describe the wave of the whole group
+    int32_t xrun[2];                              // per wave: simulations 0 .. xrun-1 were run by the ranks that own them (the counted prefix when nothing hit)
+    int32_t xdone, xpad;                          // a rank left the protocol (fault): every engine of every rank gives up
 };
 
 // Scratch of the victim search (reclaim / preempt / consolidation, kai_engine_solver.inc), all in HBM.  "View" of a victim job =
@@ -365,6 +369,8 @@ struct KaiCtx {
 #endif
     struct ScanGrid* sg; int32_t sg_wgs, sg_per;  // allocate action on the sequential engine: node scans spread over sg_wgs workgroups (0 / 1: this workgroup only), sg_per nodes each (kai_kernels.hpp)
     MultiCtx* mw; int32_t mw_rank, mw_world;  // victim search on several workgroups: the block they share (null / world 1 = one workgroup), this replica's rank
+    int32_t mw_xworld, mw_xrank, mw_xcap, mw_xpad;  // ... and over the GPUs of a node-sharded group: ranks of the group (0 / 1 = this GPU alone), this GPU's rank, simulations of one wave at most
+    struct XMail* mw_mail;                    // the mailbox the exchange of a wave's outcomes goes through on the device (pinned host memory, kai_victim_shard.hpp)
     int32_t exact_sums, pad_es;  // HostPrep::exact_sums: integral quantities with totals below 2^52 units — parallel sums of them are exact
 };
 

@@ -20,9 +20,25 @@ static int g_dom_lanes_min = std::getenv("KAI_HOSTSIM_DOM_MIN") ? std::atoi(std:
 #include "../../kai-scheduler_amd/csrc/kai_host_prep.hpp"
 #include "../../kai-scheduler_amd/csrc/kai_batch_kernels.hpp"
 #include "../../kai-scheduler_amd/csrc/kai_batch_driver.hpp"
+#include "../../kai-scheduler_amd/csrc/kai_victim_shard.hpp"
 
 using namespace kai;
 
+// the victim search's waves over the ranks of a node-sharded group (kai_victim_shard.hpp): the test's all-gather on host memory, the exchange state of the running action
+static int (*g_x_fn)(void*, const void*, void*, int64_t) = nullptr; static void* g_x_user = nullptr; static int g_x_on = 0, g_x_cap = 0; static int64_t g_x_exchanges = 0;
+static kai::XShardHost g_xs;
+struct HostXIo {  // MultiCtx lives in this process: the "copies" of the device path are plain reads and writes between the wave's two barriers
+    kai::MultiCtx* M;
+    int pull(int32_t* hdr, int32_t* res, int64_t* cnt, int b, int cap) {
+        hdr[0] = M->world; hdr[1] = __atomic_load_n(&M->fault, __ATOMIC_ACQUIRE); hdr[2] = 0; hdr[3] = 0; for (int k = 0; k < 2; k++) { hdr[4 + k] = __atomic_load_n(&M->next[k], __ATOMIC_ACQUIRE); hdr[6 + k] = __atomic_load_n(&M->hit[k], __ATOMIC_ACQUIRE); }
+        std::memcpy(res, M->res[b], sizeof(int32_t) * (size_t)cap); std::memcpy(cnt, M->cnt[b], sizeof(int64_t) * kai::KAI_MW_CNT * (size_t)cap); return 0;
+    }
+    int push(int b, const int32_t* res, const int64_t* cnt, int cap, int hit, int xrun, int fault) {
+        std::memcpy(M->res[b], res, sizeof(int32_t) * (size_t)cap); std::memcpy(M->cnt[b], cnt, sizeof(int64_t) * kai::KAI_MW_CNT * (size_t)cap);
+        __atomic_store_n(&M->hit[b], hit, __ATOMIC_RELEASE); __atomic_store_n(&M->xrun[b], xrun, __ATOMIC_RELEASE); if (fault) __atomic_store_n(&M->fault, 1, __ATOMIC_RELEASE); return 0;
+    }
+    int allgather(const void* s, void* r, int64_t n) { return g_x_fn ? g_x_fn(g_x_user, s, r, n) : (int)KAI_ERR_COMM; }
+};
 namespace {
 
 struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.hpp)
@@ -145,6 +161,7 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     static int64_t mw_load64(const int64_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
     static int32_t mw_fetch_add32(int32_t* p, int32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
     static void mw_fetch_min32(int32_t* p, int32_t v) { int32_t o = __atomic_load_n(p, __ATOMIC_ACQUIRE); while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {} }
+    static void mw_exchange(const KaiCtx&, MultiCtx* m, int b) { HostXIo io{m}; if (g_xs.wave(io, b)) __atomic_store_n(&m->fault, 1, __ATOMIC_RELEASE); }  // engine 0, between the wave's two barriers
     static void grid_sync(MultiCtx* m, int clear) {
         const int gen = __atomic_load_n(&m->bar_gen, __ATOMIC_ACQUIRE);
         if (__atomic_add_fetch(&m->bar_count, 1, __ATOMIC_ACQ_REL) == m->world) { __atomic_store_n(&m->next[clear], 0, __ATOMIC_RELAXED); __atomic_store_n(&m->hit[clear], 0x7fffffff, __ATOMIC_RELAXED); __atomic_store_n(&m->bar_count, 0, __ATOMIC_RELAXED); __atomic_add_fetch(&m->bar_gen, 1, __ATOMIC_RELEASE); }
@@ -214,6 +231,10 @@ template <class T> const T* copy(std::vector<std::vector<char>>& pool, const T* 
 static int g_sh_rank = 0, g_sh_world = 1, g_sh_k = 0; static int (*g_sh_fn)(void*, const void*, void*, int64_t) = nullptr; static void* g_sh_user = nullptr; static int64_t g_sh_exchanges = 0;
 extern "C" void kai_hostsim_set_shard(int rank, int world, int k, int (*fn)(void*, const void*, void*, int64_t), void* user) { g_sh_rank = rank; g_sh_world = world; g_sh_k = k; g_sh_fn = fn; g_sh_user = user; }
 extern "C" int64_t kai_hostsim_last_exchanges() { return g_sh_exchanges; }
+// victim actions of a node-sharded run: on = their simulation waves are dealt out over the ranks (kai_victim_shard.hpp) through fn, an all-gather on host memory;
+// cap = simulations per wave (0 = the default: two per engine of the group).  Off = every rank runs the whole action (replicated).
+extern "C" void kai_hostsim_set_victim_shard(int on, int cap, int (*fn)(void*, const void*, void*, int64_t), void* user) { g_x_on = on; g_x_cap = cap; g_x_fn = fn; g_x_user = user; g_x_exchanges = 0; }
+extern "C" int64_t kai_hostsim_victim_exchanges() { return g_x_exchanges; }
 static int g_mw_world = 1; static int64_t g_mw_waves = 0, g_mw_sims_run = 0, g_mw_sims_used = 0, g_mw_replays = 0;
 extern "C" void kai_hostsim_set_dom_lanes_min(int n) { g_dom_lanes_min = n < 1 ? 1 : n; }
 extern "C" void kai_hostsim_set_multi(int engines) { g_mw_world = engines < 1 ? 1 : engines > KAI_MW_MAX ? KAI_MW_MAX : engines; g_mw_waves = g_mw_sims_run = g_mw_sims_used = g_mw_replays = 0; }  // victim actions of the next runs on that many engines
@@ -445,8 +466,12 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             // victim actions on several engines (kai_engine_solver.inc solve_partial_multi): every engine a thread on its own replica of the context; what must
             // hold afterwards — every replica committed the same operations and ended in the same state — is checked here on every run
             const int G = shared ? 1 : g_mw_world;
-            if (G <= 1) { c.mw = nullptr; c.mw_rank = 0; c.mw_world = 1; if (std::getenv("KAI_HOSTSIM_FRESH")) { HostBackend bf; Engine<HostBackend> ef(c, bf); ef.execute_victim_action(); ef.flush_index(); } else eng.execute_victim_action(); continue; }
-            if (reps.empty()) { reps.resize(G - 1); for (auto& r : reps) { alloc1(r.pool, r.c); if (int rc = alloc2(r.pool, r.c)) return rc; if (r.pool.size() != pool.size()) return KAI_ERR_DEVICE_FAULT; } }
+            const bool xsh = !shared && g_sh_world > 1 && g_x_on && g_x_fn;  // the waves of this action over the ranks of the group
+            const int xcap = xsh ? (g_x_cap > 0 ? g_x_cap : xw_default_cap(g_sh_world, G)) : 0;
+            c.mw_xworld = xsh ? g_sh_world : 0; c.mw_xrank = xsh ? g_sh_rank : 0; c.mw_xcap = xcap; c.mw_mail = nullptr;
+            if (xsh) g_xs.begin(g_sh_world, g_sh_rank, xcap);
+            if (G <= 1 && !xsh) { c.mw = nullptr; c.mw_rank = 0; c.mw_world = 1; if (std::getenv("KAI_HOSTSIM_FRESH")) { HostBackend bf; Engine<HostBackend> ef(c, bf); ef.execute_victim_action(); ef.flush_index(); } else eng.execute_victim_action(); continue; }
+            if (reps.empty() && G > 1) { reps.resize(G - 1); for (auto& r : reps) { alloc1(r.pool, r.c); if (int rc = alloc2(r.pool, r.c)) return rc; if (r.pool.size() != pool.size()) return KAI_ERR_DEVICE_FAULT; } }
             static MultiCtx M; std::memset(&M, 0, sizeof M); M.world = G; M.hit[0] = M.hit[1] = 0x7fffffff;
             c.mw = &M; c.mw_rank = 0; c.mw_world = G;
             for (int w = 1; w < G; w++) {
@@ -454,11 +479,13 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
                 for (size_t k = 0; k < pool.size(); k++) { if (r.pool[k].size() != pool[k].size()) return KAI_ERR_DEVICE_FAULT; std::memcpy(r.pool[k].data(), pool[k].data(), pool[k].size()); }
                 r.c.action = c.action; r.c.queue_depth = c.queue_depth; r.c.fast_ok = c.fast_ok; r.c.use_index = c.use_index; r.c.all_tracked = c.all_tracked; r.c.bt.enabled = 0;
                 r.c.mw = &M; r.c.mw_rank = w; r.c.mw_world = G;
+                r.c.mw_xworld = c.mw_xworld; r.c.mw_xrank = c.mw_xrank; r.c.mw_xcap = c.mw_xcap; r.c.mw_mail = nullptr;
             }
             std::vector<std::thread> th;
             for (int w = 1; w < G; w++) th.emplace_back([&, w] { HostBackend bw; Engine<HostBackend> ew(reps[w - 1].c, bw); ew.execute_victim_action(); ew.flush_index(); });  // (flush_index: what DevBackend::finish does when the kernel ends)
             { HostBackend b0; Engine<HostBackend> e0(c, b0); e0.execute_victim_action(); e0.flush_index(); }
             for (auto& t : th) t.join();
+            if (xsh) { HostXIo io{&M}; const int rcx = g_xs.finish(io, (c.st->fault || M.fault) ? 1 : 0); g_x_exchanges += g_xs.exchanges; c.mw_xworld = 0; if (rcx && !c.st->fault) return rcx; }
             g_mw_waves += M.waves; g_mw_sims_run += M.sims_run; g_mw_sims_used += M.sims_used; g_mw_replays += M.replays;
             // (tasks-to-allocate caches: an engine may have filled the cache of a bystander job while another has not — the same content whenever it is computed,
             // job_info.go:253-256 invalidates it with every status change of the job's tasks — so: where both hold one, the same one)
