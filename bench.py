@@ -102,7 +102,13 @@ def main():
 
     # KAI_BENCH_RCCL=1: the node-sharded group's exchange from the library's own RCCL communicator (kai_shard_attach_rccl: ncclAllGather on its stream) instead of the
     # caller-supplied collective (the Python mirror's torch.distributed.all_gather_into_tensor with a host round trip per exchange)
-    core = pkg.KaiCore(cfg, gpu_ids=(dev_index,), world=world, rank=rank, allgather="rccl" if os.environ.get("KAI_BENCH_RCCL") == "1" else None) if sharded else pkg.KaiCore(cfg, gpu_ids=(dev_index,))
+    # victim actions of the cycle on a group: their simulation waves dealt out over the ranks (kai_victim_shard.hpp) — the exchange on host memory over a gloo group
+    # beside the nccl one, or the library's own communicator with KAI_BENCH_RCCL=1
+    rccl = os.environ.get("KAI_BENCH_RCCL") == "1"
+    host_ag = True if (sharded and not rccl and any(a != "allocate" for a in actions)) else None
+    if host_ag:
+        pkg.KaiCore.host_group = pkg.dist.host_group()
+    core = pkg.KaiCore(cfg, gpu_ids=(dev_index,), world=world, rank=rank, allgather="rccl" if rccl else None, host_allgather=host_ag) if sharded else pkg.KaiCore(cfg, gpu_ids=(dev_index,))
     t0 = time.time()
     ssn = core.open_session(snap)  # host → HBM once; the timed steps replay from the resident copy
     upload_s = time.time() - t0
@@ -196,7 +202,7 @@ def main():
     else:
         if any(a != "allocate" for a in actions):
             s_a = last_stats[0]
-            engine["victim_search"] = {"workgroups": int(s_a.reserved[1]), "waves": int(s_a.reserved[5]), "simulations_run": int(s_a.reserved[6]) >> 32, "simulations_counted": int(s_a.reserved[6]) & 0xffffffff,
+            engine["victim_search"] = {"workgroups": int(s_a.reserved[1]), "ranks": world if (sharded and (host_ag or rccl)) else 1, "collectives": int(s_a.reserved[7]) if (sharded and (host_ag or rccl)) else 0, "waves": int(s_a.reserved[5]), "simulations_run": int(s_a.reserved[6]) >> 32, "simulations_counted": int(s_a.reserved[6]) & 0xffffffff,
                                        "scenarios": int(s_a.reserved[2]), "simulations": int(s_a.reserved[3]), "note": "last victim action of the cycle; one replica of the session arrays per workgroup, simulations of a partial job handed out in waves (DESIGN.md)"}
         engine.update({"path": "sequential engine", "control_cycles": {"allocate": int(st.reserved[5]), "commit_discard": int(st.reserved[6]), "total": int(st.reserved[7])}})
         alg = (decisions - drained) * b_dec; achieved = alg / (k_ms * 1e-3) / 1e9

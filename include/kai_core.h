@@ -350,6 +350,12 @@ int kai_core_create(const kai_config* cfg, int n_gpus, const int* gpu_ids, kai_c
  * offers_per_class: nodes a rank offers per scan class and exchange (0 = default 128).  Returns 0 / a kai_status. */
 typedef int (*kai_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes_per_rank);
 int kai_shard_attach(kai_core* core, int rank, int world, int offers_per_class, kai_allgather_fn fn, void* user);
+/* Victim actions (reclaim, preempt, consolidation) on a group: every rank holds the whole session, the SIMULATIONS of a partial job are dealt out over the ranks
+ * (simulation i of a wave to rank i mod n_gpus; the reference's loop: actions/common/solvers/job_solver.go:95-126, by_pod_solver.go:61-144) and a wave ends with one
+ * all-gather of its outcomes (68 bytes per simulation).  That exchange happens while the action's kernel is running and waits for it, so it is the host's: `fn` is
+ * called from inside kai_action_execute with HOST memory of the library and must not synchronise the device (the kernel only goes on when fn has returned).
+ * Without it — and without the library's own communicator below — a group runs its victim actions replicated (same results, nothing shortened). */
+int kai_shard_attach_host(kai_core* core, kai_allgather_fn fn, void* user);
 /* The same exchange from the library itself: its own RCCL communicator (librccl is resolved at run time), the all-gather issued on the library's stream between the
  * kernels it separates — no host round trip, no staging.  Rank 0 draws the 128-byte id (ncclGetUniqueId), the caller carries it to the other ranks by whatever it has
  * (the Python mirror: torch.distributed.broadcast), every rank attaches with it (ncclCommInitRank: collective over the group, one device per rank).

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KAI_CORE_LIB") or os.path.join(_HERE, "csrc", "libkai_core.so")  # KAI_CORE_LIB: another BUILD of the same HIP library (profiling variants)
 
 EXPORTS = ["kai_core_create", "kai_core_destroy", "kai_session_open", "kai_queue_shares", "kai_action_execute", "kai_best_node",
-           "kai_pod_states", "kai_node_states", "kai_pod_gpu_groups", "kai_shard_attach", "kai_shard_rccl_id", "kai_shard_attach_rccl", "kai_shard_allgather_probe", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]
+           "kai_pod_states", "kai_node_states", "kai_pod_gpu_groups", "kai_shard_attach", "kai_shard_attach_host", "kai_shard_rccl_id", "kai_shard_attach_rccl", "kai_shard_allgather_probe", "kai_action_stats_get", "kai_session_reset", "kai_session_close", "kai_last_error", "kai_version"]
 
 
 class KaiError(RuntimeError):
@@ -65,6 +65,7 @@ def load_library(path: str = LIB_PATH):
     lib.kai_session_open.argtypes = [C.c_void_p, C.POINTER(abi.KaiSnapshotSoA)]
     lib.kai_session_close.argtypes = [C.c_void_p]
     lib.kai_shard_attach.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]
+    lib.kai_shard_attach_host.argtypes = [C.c_void_p, ALLGATHER_FN, C.c_void_p]
     lib.kai_shard_rccl_id.argtypes = [C.c_void_p, C.c_void_p]
     lib.kai_shard_attach_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.kai_shard_allgather_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
@@ -89,7 +90,7 @@ class KaiCore:
     all-gather of a few KB per rank: `allgather(send_ptr, recv_ptr, nbytes_per_rank)` on the library's device buffers, by default
     torch.distributed.all_gather_into_tensor on the default process group (backend "nccl" = RCCL over xGMI on the GPU box)."""
 
-    def __init__(self, cfg: abi.KaiConfig | None = None, gpu_ids=(0,), world: int = 1, rank: int = 0, offers_per_class: int = 0, allgather=None):
+    def __init__(self, cfg: abi.KaiConfig | None = None, gpu_ids=(0,), world: int = 1, rank: int = 0, offers_per_class: int = 0, allgather=None, host_allgather=None):
         self.lib = load_library()
         self.cfg = cfg or abi.default_config()
         self.handle = C.c_void_p()
@@ -109,6 +110,33 @@ class KaiCore:
             rc = self.lib.kai_shard_attach(self.handle, self.rank, self.world, int(offers_per_class), self._cb, None)
             if rc != 0:
                 raise KaiError(rc, "kai_shard_attach")
+
+        if self.world > 1 and host_allgather is not None:
+            # the victim actions' waves over the ranks (kai_shard_attach_host): host_allgather(send_ptr, recv_ptr, nbytes_per_rank) on HOST memory, called while the
+            # action's kernel runs (it must not synchronise the device); True = torch.distributed on CPU tensors of a gloo group `host_group` (default group if gloo)
+            self._host_ag = host_allgather
+            self._hcb = ALLGATHER_FN(self._host_allgather)
+            rc = self.lib.kai_shard_attach_host(self.handle, self._hcb, None)
+            if rc != 0:
+                raise KaiError(rc, "kai_shard_attach_host")
+
+    host_group = None  # the process group host_allgather=True uses (a gloo group beside an nccl default group)
+
+    def _host_allgather(self, user, send, recv, nbytes):
+        try:
+            if callable(self._host_ag):
+                return int(self._host_ag(send, recv, nbytes) or 0)
+            import numpy as np
+            import torch
+            import torch.distributed as dist
+            s = torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,)))
+            r = torch.from_numpy(np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * self.world,)))
+            dist.all_gather_into_tensor(r, s, group=self.host_group)
+            return 0
+        except Exception:  # a ctypes callback must not raise
+            import traceback
+            traceback.print_exc()
+            return 1
 
     def _attach_rccl(self, offers_per_class):
         idbuf = (C.c_ubyte * 128)()

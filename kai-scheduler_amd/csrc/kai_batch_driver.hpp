@@ -44,7 +44,7 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     KB_Z(el_leaf, b.pool_e); KB_Z(el_ck, b.pool_e); KB_Z(el_next, b.pool_e); KB_Z(e_job, b.pool_e); KB_Z(e_grank, b.pool_e); KB_Z(e_flag, b.pool_e);
     KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_stmt, J + 1); KB_Z(g_first, J + 1); KB_Z(g_nt, J + 1); KB_Z(g_ucls, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
     KB_Z(t_cls, P); KB_Z(t_node, P);
-    KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1);
+    KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1); KB_Z(cls_cap, 64);
     KB_Z(bk_words, (size_t)KBK_GMAX * c.NB); KB_Z(bk_ok, (size_t)std::max(c.C, 1) * c.NB); KB_Z(bk_meta, sizeof(BucketMeta) / 4);
     if (world > 1) {  // node-axis sharding: contiguous 64-node-block ranges in name-rank order, offers of K nodes per class and rank
         b.world = world; b.rank = rank;
@@ -165,9 +165,18 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
                    l.index_from_recs(std::max(1, c.NB), 64, c, (const NodeRec*)c.bt.nrec, c.N, (uint64_t*)c.sum1_key, (int32_t*)c.sum1_node, c.NB, 0, c.NB);
                    if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }
     else { if (buckets) l.fill_buckets(1, 256, dyn_bk, c, rp, bp); else l.fill(1, 64, dyn, c, rp, l1_in_lds); if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; }
-    int H = 16; int64_t ops_base = ops_base0, stmt_base = stmt_base0;
+    int H = 256;  // jobs a leaf offers per round: everything a usual leaf holds (a plan is cheap next to the rounds a short one costs); halved while most of a plan is thrown away
+    if (const char* e = std::getenv("KAI_BATCH_H0")) { const int v = std::atoi(e); if (v >= 8) H = v; }
+    int64_t ops_base = ops_base0, stmt_base = stmt_base0;
+    const bool capacity = !sharded && !std::getenv("KAI_BATCH_NO_CAPACITY");  // (a rank of a node-sharded group sees its own nodes only: no capacity prediction there)
+    c.bt.cap_on = capacity ? 1 : 0;
+    { int32_t z[64]; for (int k = 0; k < 64; k++) z[k] = 0; if (capacity) if (int rc = l.write((void*)c.bt.cls_cap, z, sizeof z)) return rc; }
+    if (!capacity) { int32_t inf[64]; for (int k = 0; k < 64; k++) inf[k] = 0x7fffffff; if (int rc = l.write((void*)c.bt.cls_cap, inf, sizeof inf)) return rc; }
     while (remaining > 0) {
         if (fs.all_dead) { bs.drain = 1; break; }
+        // tasks of every scan class the cluster still holds (for the plan's prediction of gangs that no longer fit; the fill verifies every prediction, so this only
+        // saves rounds): summed here, read by k_plan_leaf, zeroed again by k_plan_emit
+        if (capacity && c.C >= 1) l.class_capacity(std::max(1, c.NB), 64, c, buckets ? 1 : 0, bp.levels);
         rp = RoundParams{}; rp.h_leaf = H; rp.mode = 0;
         const int64_t e_bound = std::min<int64_t>(remaining, (int64_t)shape.n_leaves * H);
         const int64_t slots = std::min<int64_t>(c.bt.pool_k, e_bound * shape.n_heights + Q + 1);

@@ -148,7 +148,8 @@ KW_BODY void kb_plan_leaf(const KaiCtx& c, RoundParams rp) {
         const bool is_elem = i < V, is_key = i < nk;
         const int job = is_key ? c.lq_sorted[off + i] : -1;
         double res[3] = {0, 0, 0}; bool np = false, dead = false;
-        if (job >= 0) { for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k]; np = !c.j_preempt[job]; dead = (b.j_clsmask[job] & dead_mask) != 0; }
+        if (job >= 0) { for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k]; np = !c.j_preempt[job]; dead = (b.j_clsmask[job] & dead_mask) != 0;
+                        const int uc = b.j_ucls[job]; if (uc >= 0 && b.cls_cap[uc] < c.j_tta_n[job]) dead = true; }  // a gang of one class larger than what the cluster holds of it
         bool assumed = is_elem && !dead, gate = false;
         double ab[3], abn[3], tot[3], totn[3];
         for (;;) {
@@ -322,6 +323,7 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
 KW_BODY void kb_plan_emit(const KaiCtx& c) {
     const BatchCtx& b = c.bt;
     const int t = kw::bid() * kw::bdim() + kw::tid();
+    if (t < 64 && b.cap_on) b.cls_cap[t] = 0;  // (the plan's leaves have read it: ready for the next round's sum)
     if (t >= b.q_valid[c.Q]) return;
     const int e = b.el_leaf[b.q_ebase[c.Q] + t], job = b.e_job[e];
     const int flag = b.e_flag[e];

@@ -66,11 +66,12 @@ struct BatchCtx {
     KAI_GP(int32_t) bk_meta;     // BucketMeta
     KAI_GP(FillStatus) fs;       // [1]
     KAI_GP(uint64_t) dead_mask;  // [1]
+    KAI_GP(int32_t) cls_cap;     // [64] tasks of scan class k the cluster still holds at the round's start (k_class_capacity): a gang of one class that asks for more is predicted BF_DEAD
     // node-axis sharding over the GPUs of one node: this rank owns the nodes [n_lo, n_hi); everything else is replicated.
     // Per exchange every rank offers, per scan class, its K best nodes (records) and the key it holds back (its K+1st: the floor); the
     // all-gathered offers form a small VIRTUAL cluster on which every rank runs the same fill until a class's best candidate no longer
     // beats the best floor — only then can a node nobody offered matter, and the ranks exchange again.
-    int32_t world, rank, n_lo, n_hi, shard_k, shard_mmax, vcap, pad_s;
+    int32_t world, rank, n_lo, n_hi, shard_k, shard_mmax, vcap, cap_on;  // cap_on: cls_cap is summed every round (else it holds INT_MAX)
     int64_t msg_bytes;
     KAI_GP(uint64_t) sh_keys;    // [C][N] class keys of the own nodes (selection scratch)
     KAI_GP(uint32_t) cand_bits;  // [ceil(N/32)] union of the offered nodes

@@ -20,6 +20,8 @@
 #include "kai_kernels.hpp"
 #include "kai_batch_kernels.hpp"
 #include "kai_batch_driver.hpp"
+#include "kai_victim_shard.hpp"
+#include <thread>
 
 using namespace kai;
 
@@ -58,6 +60,12 @@ struct kai_core {
     std::vector<AllocRec> allocs; char* sv_base = nullptr; size_t sv_bytes = 0; char* xr_base = nullptr; size_t xr_bytes = 0;
     int mw_world = 0; char* rep_mem = nullptr; size_t rep_stride = 0; KaiCtx* d_ctxs = nullptr; MultiCtx* d_mw = nullptr; void* d_segs = nullptr; int n_segs = 0;
     ScanGrid* d_sg = nullptr;  // the scan grid's table (allocate action on the sequential engine, kai_kernels.hpp)
+    // victim actions of a node-sharded group: the waves' outcomes exchanged over the ranks (kai_victim_shard.hpp) — the caller's all-gather on HOST memory (kai_shard_attach_host)
+    // or the library's own RCCL communicator on xstream; the mailbox the running kernel rings, pinned staging for the copies in and out of MultiCtx
+    kai_allgather_fn xag_fn = nullptr; void* xag_user = nullptr;
+    XMail* mail = nullptr; XMail* d_mail = nullptr; hipStream_t xstream = nullptr;
+    unsigned char* xpin = nullptr; size_t xpin_bytes = 0; unsigned char *xd_send = nullptr, *xd_recv = nullptr; size_t xd_bytes = 0;
+    XShardHost xs;
 };
 
 #define HIP_TRY(core, expr)                                                                                        \
@@ -214,6 +222,7 @@ struct DevLauncher {
     void plan_rank(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_rank, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_scan, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_emit(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_plan_emit, dim3(g), dim3(b), 0, core->stream, c); }
+    void class_capacity(int g, int b, const KaiCtx& c, int buckets, int levels) { hipLaunchKernelGGL(k_class_capacity, dim3(g), dim3(b), 0, core->stream, c, buckets, levels); }
     template <int MODE, bool SPEC, bool L1L> void fill_launch(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp) {
         const unsigned vbit = 1u << ((MODE == FM_SHARDED ? 4 : 0) + (SPEC ? 2 : 0) + (L1L ? 1 : 0));  // once per variant and action: the dynamic-LDS ceiling of the kernel
         if (!(fill_attr_mask & vbit) || dyn > fill_attr_dyn) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill<MODE, SPEC, L1L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_attr_mask |= vbit; fill_attr_dyn = std::max(fill_attr_dyn, dyn); }
@@ -272,6 +281,77 @@ struct DevLauncher {
     }
     int write(void* dst, const void* src, size_t n) { return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, core->stream) == hipSuccess ? KAI_OK : KAI_ERR_HIP; }
 };
+// ---- victim actions of a node-sharded group: the host side of a wave's exchange (kai_victim_shard.hpp XShardHost) against the device
+struct DevXIo {
+    kai_core* core;
+    // pinned layout: [0,32) MultiCtx header | res (cap x 4) | cnt (cap x 64) | scalars
+    int pull(int32_t* hdr, int32_t* res, int64_t* cnt, int b, int cap) {
+        MultiCtx* M = core->d_mw; unsigned char* p = core->xpin;
+        if (hipMemcpyAsync(p, M, 32, hipMemcpyDeviceToHost, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        if (hipMemcpyAsync(p + 64, &M->res[b][0], (size_t)cap * 4, hipMemcpyDeviceToHost, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        if (hipMemcpyAsync(p + 64 + (size_t)KAI_MW_WAVE * 4, &M->cnt[b][0][0], (size_t)cap * 8 * KAI_MW_CNT, hipMemcpyDeviceToHost, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        if (hipStreamSynchronize(core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        std::memcpy(hdr, p, 32); std::memcpy(res, p + 64, (size_t)cap * 4); std::memcpy(cnt, p + 64 + (size_t)KAI_MW_WAVE * 4, (size_t)cap * 8 * KAI_MW_CNT);
+        return 0;
+    }
+    int push(int b, const int32_t* res, const int64_t* cnt, int cap, int hit, int xrun, int fault) {
+        MultiCtx* M = core->d_mw; unsigned char* p = core->xpin;
+        std::memcpy(p + 64, res, (size_t)cap * 4); std::memcpy(p + 64 + (size_t)KAI_MW_WAVE * 4, cnt, (size_t)cap * 8 * KAI_MW_CNT);
+        int32_t* sc = reinterpret_cast<int32_t*>(p + 32); sc[0] = hit; sc[1] = xrun; sc[2] = 1;
+        if (hipMemcpyAsync(&M->res[b][0], p + 64, (size_t)cap * 4, hipMemcpyHostToDevice, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        if (hipMemcpyAsync(&M->cnt[b][0][0], p + 64 + (size_t)KAI_MW_WAVE * 4, (size_t)cap * 8 * KAI_MW_CNT, hipMemcpyHostToDevice, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        if (hipMemcpyAsync(&M->hit[b], &sc[0], 4, hipMemcpyHostToDevice, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        if (hipMemcpyAsync(&M->xrun[b], &sc[1], 4, hipMemcpyHostToDevice, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        if (fault && hipMemcpyAsync(&M->fault, &sc[2], 4, hipMemcpyHostToDevice, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        return hipStreamSynchronize(core->xstream) == hipSuccess ? 0 : (int)KAI_ERR_HIP;
+    }
+    int raise_fault() { int32_t* sc = reinterpret_cast<int32_t*>(core->xpin + 32); sc[2] = 1; (void)hipMemcpyAsync(&core->d_mw->fault, &sc[2], 4, hipMemcpyHostToDevice, core->xstream); return hipStreamSynchronize(core->xstream) == hipSuccess ? 0 : (int)KAI_ERR_HIP; }
+    int allgather(const void* send, void* recv, int64_t bytes) {
+        if (core->xag_fn) return core->xag_fn(core->xag_user, send, recv, bytes) == 0 ? 0 : (int)KAI_ERR_COMM;
+        if (!core->rccl_comm || (size_t)bytes * core->world > core->xd_bytes) return KAI_ERR_COMM;
+        if (hipMemcpyAsync(core->xd_send, send, (size_t)bytes, hipMemcpyHostToDevice, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        if (rccl_api()->AllGather(core->xd_send, core->xd_recv, (size_t)bytes, /*ncclUint8*/ 1, core->rccl_comm, core->xstream)) return KAI_ERR_COMM;
+        if (hipMemcpyAsync(recv, core->xd_recv, (size_t)bytes * core->world, hipMemcpyDeviceToHost, core->xstream) != hipSuccess) return KAI_ERR_HIP;
+        return hipStreamSynchronize(core->xstream) == hipSuccess ? 0 : (int)KAI_ERR_HIP;
+    }
+};
+// mailbox, second stream, staging: once per handle
+int xshard_setup(kai_core* core) {
+    if (!core->xstream) HIP_TRY(core, hipStreamCreateWithFlags(&core->xstream, hipStreamNonBlocking));
+    if (!core->mail) {
+        void* m = nullptr; HIP_TRY(core, hipHostMalloc(&m, 4096, hipHostMallocCoherent | hipHostMallocMapped));
+        core->mail = static_cast<XMail*>(m); std::memset(m, 0, 4096);
+        void* d = nullptr; HIP_TRY(core, hipHostGetDevicePointer(&d, m, 0)); core->d_mail = static_cast<XMail*>(d);
+    }
+    if (!core->xpin) { const size_t want = 64 + (size_t)KAI_MW_WAVE * 4 + (size_t)KAI_MW_WAVE * 8 * KAI_MW_CNT; void* p = nullptr; HIP_TRY(core, hipHostMalloc(&p, want, hipHostMallocDefault)); core->xpin = static_cast<unsigned char*>(p); core->xpin_bytes = want; }
+    if (core->rccl_comm && !core->xag_fn && !core->xd_send) {
+        const size_t one = xw_msg_bytes(KAI_MW_WAVE, 1); void* a = nullptr; void* b = nullptr;
+        HIP_TRY(core, hipMalloc(&a, one)); HIP_TRY(core, hipMalloc(&b, one * (size_t)core->world));
+        core->xd_send = static_cast<unsigned char*>(a); core->xd_recv = static_cast<unsigned char*>(b); core->xd_bytes = one * (size_t)core->world;
+    }
+    return KAI_OK;
+}
+// while the action's kernel runs: answer the mailbox (one exchange per wave) until the stream is idle
+int xshard_serve(kai_core* core) {
+    DevXIo io{core}; int32_t served = 0; long idle = 0;
+    for (;;) {
+        const int32_t req = __atomic_load_n(&core->mail->req, __ATOMIC_ACQUIRE);
+        if (req != served) {
+            const int b = __atomic_load_n(&core->mail->buf, __ATOMIC_ACQUIRE) & 1;
+            if (core->xs.wave(io, b)) (void)io.raise_fault();  // the engines give up at the barrier behind the answer
+            served = req; __atomic_store_n(&core->mail->resp, served, __ATOMIC_RELEASE); idle = 0;
+            continue;
+        }
+        if ((++idle & 63) == 0) {
+            const hipError_t q = hipStreamQuery(core->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { core->err = std::string("victim action: ") + hipGetErrorString(q); return KAI_ERR_HIP; }
+            if (idle > 4096) std::this_thread::yield();
+        }
+    }
+    return KAI_OK;
+}
+
 // ---- victim actions on several workgroups: replicas of the session arrays, one per further workgroup
 struct RepSeg { const char* src; unsigned long long dst_off, bytes; };
 constexpr size_t REP_CHUNK = (size_t)256 << 10;
@@ -295,7 +375,7 @@ int prepare_multi(kai_core* core, int G, int* g_out) {
         for (const auto& a : core->allocs) add(a.base, a.bytes);
         add(core->sv_base, core->sv_bytes); add(core->xr_base, core->xr_bytes);
         void* mem = nullptr;
-        if (hipMalloc(&mem, total * (size_t)(G - 1)) != hipSuccess) { (void)hipGetLastError(); return KAI_OK; }
+        if (hipMalloc(&mem, total * (size_t)(G - 1)) != hipSuccess) { (void)hipGetLastError(); if (c.mw_xworld > 1) { core->err = "victim action of a node-sharded group: no memory for the replicas (every rank must run the same number of engines)"; return KAI_ERR_HIP; } return KAI_OK; }
         core->bufs.push_back(mem); core->rep_mem = static_cast<char*>(mem); core->rep_stride = total;
         RepSeg* dsegs = nullptr; KaiCtx* dctx = nullptr; MultiCtx* dmw = nullptr;
         int rc = dalloc(core, &dsegs, segs.size()); if (rc) return rc;
@@ -358,6 +438,11 @@ int kai_core_destroy(kai_core* core) {
     free_session(core, true);
     if (core->pin_buf) { (void)hipHostFree(core->pin_buf); core->pin_buf = nullptr; core->pin_bytes = 0; }
     if (core->rccl_comm) { (void)hipStreamSynchronize(core->stream); if (RcclApi* a = rccl_api()) (void)a->CommDestroy(core->rccl_comm); core->rccl_comm = nullptr; }
+    if (core->mail) (void)hipHostFree(core->mail);
+    if (core->xpin) (void)hipHostFree(core->xpin);
+    if (core->xd_send) (void)hipFree(core->xd_send);
+    if (core->xd_recv) (void)hipFree(core->xd_recv);
+    if (core->xstream) (void)hipStreamDestroy(core->xstream);
     if (core->ev0) (void)hipEventDestroy(core->ev0);
     if (core->ev1) (void)hipEventDestroy(core->ev1);
     for (hipEvent_t e : core->bev) if (e) (void)hipEventDestroy(e);
@@ -651,7 +736,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     const int TB = 256;
     if (c.J) hipLaunchKernelGGL(k_job_init, dim3((c.J + TB - 1) / TB), dim3(TB), 0, core->stream, c);
     if (c.Q) hipLaunchKernelGGL(k_leaf_init, dim3((c.Q + 3) / 4), dim3(TB), 0, core->stream, c);
-    BatchStats bs; core->batch_plan_ms = core->batch_fill_ms = core->batch_apply_ms = 0; int g_run = 1, scan_wgs_used = 1;
+    BatchStats bs; core->batch_plan_ms = core->batch_fill_ms = core->batch_apply_ms = 0; int g_run = 1, scan_wgs_used = 1; bool xsh = false;
     if (!victim) {  // the batch path (plan / fill / apply rounds, kai_batch.hpp) when the action qualifies
         DevLauncher dl{core};
         int rcb = batch_allocate(dl, c, core->shape, bs);
@@ -683,7 +768,19 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
             int want = 32; if (const char* e = std::getenv("KAI_VICTIM_WGS")) want = std::atoi(e);  // (measured on C4: 32 workgroups — four replicas per XCD, hot in its L2 — beat 64 and more, whose waves are no shorter)
             int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, core->device) != hipSuccess || cus <= 0) cus = 64;
             want = std::max(1, std::min(std::min(want, (int)KAI_MW_MAX), cus));  // every workgroup must be resident: they meet at a grid barrier
-            int rcm = prepare_multi(core, want, &g_run); if (rcm) return rcm;
+            // a node-sharded group with an exchange for it deals the waves out over its ranks (kai_victim_shard.hpp); every rank takes the same decision here
+            xsh = core->world > 1 && (core->xag_fn || core->rccl_comm) && !core->shared && want > 1 && (core->mw_world == 0 || core->mw_world == want) && !std::getenv("KAI_VICTIM_REPLICATED");
+            if (xsh) {
+                if (int rcx = xshard_setup(core)) return rcx;
+                int cap = xw_default_cap(core->world, want); if (const char* e = std::getenv("KAI_VICTIM_XCAP")) { const int v = std::atoi(e); if (v > 0) cap = std::max(core->world, std::min(v, (int)KAI_MW_WAVE)); }
+                c.mw_xworld = core->world; c.mw_xrank = core->rank; c.mw_xcap = cap; c.mw_mail = core->d_mail;
+                core->xs.begin(core->world, core->rank, cap);
+                __atomic_store_n(&core->mail->req, 0, __ATOMIC_RELEASE); __atomic_store_n(&core->mail->resp, 0, __ATOMIC_RELEASE);
+            }
+            int rcm = prepare_multi(core, want, &g_run);
+            c.mw_xworld = 0; c.mw_xrank = 0; c.mw_xcap = 0; c.mw_mail = nullptr;  // (the host copy is what every other kernel of the session gets by value)
+            if (rcm) return rcm;
+            if (xsh && g_run <= 1) xsh = false;  // (one engine: the action runs replicated; the conditions are the same on every rank — a failed allocation is an error above)
         }
         // the allocate action of a large cluster: helper workgroups beside the engine's take the passes over the nodes (ScanGrid, kai_kernels.hpp)
         int scan_wgs = 1;
@@ -709,6 +806,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         int rcl = victim ? launch(k_action<true, false>) : tree_in_lds ? launch(k_action<false, true>) : launch(k_action<false, false>);
         if (rcl) return rcl;
         scan_wgs_used = scan_wgs;
+        if (xsh) { HIP_TRY(core, hipGetLastError()); if (int rcs = xshard_serve(core)) return rcs; }  // the kernel is running: carry its waves' exchanges until it ends
     }
     if (c.J && !victim) hipLaunchKernelGGL(k_drain, dim3(std::min(2048, (c.J + TB - 1) / TB)), dim3(TB), 0, core->stream, c, core->d_slot_queue);
     HIP_TRY(core, hipGetLastError());
@@ -737,7 +835,14 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         core->stats.reserved[1] |= (int64_t)(nreg + 1) << 48;
         if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai scan grid: %d workgroups launched, %d helpers signed on\n", scan_wgs_used, nreg);
     }
-    if (victim) {  // victim actions: [1] workgroups the action ran on, [5] waves, [6] simulations run (speculative ones included) << 32 | simulations the reference's order reached
+    if (xsh) {  // the action's closing message (every rank sends exactly one; skipped once another rank's was seen): a fault anywhere is everybody's
+        DevXIo io{core}; int32_t mfault = 0;
+        HIP_TRY(core, hipMemcpyAsync(&mfault, &core->d_mw->fault, 4, hipMemcpyDeviceToHost, core->stream)); HIP_TRY(core, hipStreamSynchronize(core->stream));
+        const int rcf = core->xs.finish(io, (st.fault || mfault) ? 1 : 0);
+        core->stats.reserved[7] = core->xs.exchanges;  // collectives of this action
+        if (rcf && !st.fault) return fail(core, rcf, "victim action of a node-sharded group: another rank ended it with a fault");
+    }
+    if (victim) {  // victim actions: [1] workgroups the action ran on, [5] waves, [6] simulations run (speculative ones included) << 32 | simulations the reference's order reached; a group that dealt the waves out over its ranks: [7] collectives
         core->stats.reserved[1] = g_run;
         if (g_run > 1) {
             static MultiCtx m; HIP_TRY(core, hipMemcpyAsync(&m, core->d_mw, sizeof(MultiCtx), hipMemcpyDeviceToHost, core->stream)); HIP_TRY(core, hipStreamSynchronize(core->stream));
@@ -834,6 +939,12 @@ int kai_shard_attach(kai_core* core, int rank, int world, int offers_per_class, 
     if (!core || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return KAI_ERR_INVALID_ARG;
     if (core->open) return fail(core, KAI_ERR_STATE, "kai_shard_attach: before kai_session_open");
     core->world = world; core->rank = rank; core->shard_k = offers_per_class; core->ag_fn = fn; core->ag_user = user;
+    return KAI_OK;
+}
+
+int kai_shard_attach_host(kai_core* core, kai_allgather_fn fn, void* user) {
+    if (!core) return KAI_ERR_INVALID_ARG;
+    core->xag_fn = fn; core->xag_user = user;
     return KAI_OK;
 }
 

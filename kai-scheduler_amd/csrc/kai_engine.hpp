@@ -168,6 +168,8 @@ enum { FAULT_NONE = 0, FAULT_OPS_CAP = 1, FAULT_OUT_CAP = 2, FAULT_HEAP = 3, FAU
 // Victim search on several workgroups (kai_engine_solver.inc solve_partial_multi): every workgroup runs the SAME control flow on its own replica of the session
 // state (KaiCtx pointers rebased into the replica); the simulations of one partial job are dealt out to them in waves, and this block — the only memory they share —
 // carries each wave's outcomes and the grid barrier.  One instance per victim action, zeroed by the host before the launch.
+struct XMail { int32_t req, resp, buf, pad; };  // mailbox of a wave's exchange over the GPUs of a group (kai_victim_shard.hpp), pinned host memory: device → host req = number of the
+                                                // exchange asked for, buf = the wave's buffer; host → device resp = req once the merged wave is in MultiCtx
 constexpr int KAI_MW_MAX = 256;    // workgroups of one victim action at most (one per compute unit)
 constexpr int KAI_MW_WAVE = 1024;  // simulations of one wave at most
 constexpr int KAI_MW_CNT = 8;      // counter deltas a simulation reports (see Engine::mw_cnt_get)
@@ -370,7 +372,7 @@ struct KaiCtx {
     struct ScanGrid* sg; int32_t sg_wgs, sg_per;  // allocate action on the sequential engine: node scans spread over sg_wgs workgroups (0 / 1: this workgroup only), sg_per nodes each (kai_kernels.hpp)
     MultiCtx* mw; int32_t mw_rank, mw_world;  // victim search on several workgroups: the block they share (null / world 1 = one workgroup), this replica's rank
     int32_t mw_xworld, mw_xrank, mw_xcap, mw_xpad;  // ... and over the GPUs of a node-sharded group: ranks of the group (0 / 1 = this GPU alone), this GPU's rank, simulations of one wave at most
-    struct XMail* mw_mail;                    // the mailbox the exchange of a wave's outcomes goes through on the device (pinned host memory, kai_victim_shard.hpp)
+    XMail* mw_mail;                    // the mailbox the exchange of a wave's outcomes goes through on the device (pinned host memory, kai_victim_shard.hpp)
     int32_t exact_sums, pad_es;  // HostPrep::exact_sums: integral quantities with totals below 2^52 units — parallel sums of them are exact
 };
 

@@ -252,7 +252,39 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
     for (int i = tid; i < v.LV * v.NW; i += T) b.bk_words[i] = v.gw[i];
 }
 
+// Tasks of every scan class the cluster holds at the committed state, summed into cls_cap: per node the pods of the class that fit it one after the other (the smallest
+// quotient idle / request over the class's resources; the sets by free devices give it as free / q), capped at 4096 per node.  It feeds a PREDICTION of the plan (a gang of one
+// class that asks for more tasks than the cluster holds cannot fit — and stays unfit, free resources only shrink during allocate); the fill verifies every prediction.
+// One wavefront per 64-node block.
+KW_BODY void kb_class_capacity(const KaiCtx& c, int buckets, int levels) {
+    const BatchCtx& b = c.bt;
+    const int w = kw::bid() * (kw::bdim() >> 6) + (kw::tid() >> 6), lane = kw::lane(), NW = c.NB;
+    if (w >= NW) return;
+    if (buckets) {  // lane = class: the block's word of every level against the class's static bitmap
+        if (lane >= c.C) return;
+        const int q = (int)c.cls[lane].req[KAI_RES_GPU]; if (q < 1) return;
+        const uint64_t okw = b.bk_ok[(size_t)lane * NW + w];
+        int sum = 0;
+        for (int g = q; g <= levels; g++) sum += (g / q) * __builtin_popcountll(b.bk_words[(size_t)(g - 1) * NW + w] & okw);
+        if (sum) kw::atomic_add((int32_t*)&b.cls_cap[lane], sum);
+        return;
+    }
+    const NodeRec rec = b.nrec[(size_t)w * KAI_BLOCK + lane];
+    for (int k = 0; k < c.C; k++) {
+        int m = 0;
+        if ((rec.okmask >> k) & 1ull) {
+            double best = 4096.0;
+            for (int r = 0; r < c.R && r < 4; r++) { const double rq = c.cls[k].req[r]; if (!(rq > 0)) continue; const double f = rec.idle[r] >= rq ? rec.idle[r] / rq : 0.0; if (f < best) best = f; }
+            if ((c.plugins & KAI_PLUGIN_PREDICATES) && !(rec.idle[KAI_RES_PODS] > 0)) best = 0.0;
+            m = (int)best;
+        }
+        const int s = kw::wave_scan_add(m), tot = kw::shfl(s, 63);
+        if (lane == 0 && tot) kw::atomic_add((int32_t*)&b.cls_cap[k], tot);
+    }
+}
+
 #if defined(__HIPCC__)
+__global__ void k_class_capacity(KaiCtx c, int buckets, int levels) { kb_class_capacity(c, buckets, levels); }
 __global__ void k_bucket_build(KaiCtx c) { kb_bucket_build(c); }
 __global__ void __launch_bounds__(256) k_fill_buckets(KaiCtx c, RoundParams rp, BucketParams bp) { kb_fill_buckets(c, rp, bp); }
 #endif

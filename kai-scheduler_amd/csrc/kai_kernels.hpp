@@ -554,6 +554,23 @@ struct DevBackendT {
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
+    // the wave's outcomes over the GPUs of a node-sharded group (kai_victim_shard.hpp): the host carries the exchange.  Everything the engines wrote into MultiCtx went
+    // there with agent-scope atomics before the barrier this lane just left; ring the mailbox (pinned host memory, system scope) and wait for the answer — the merged
+    // wave is in MultiCtx by then (written by copies the host waited for), read by every engine with agent-scope loads after the next barrier.
+    __device__ static void mw_exchange(const KaiCtx& c, MultiCtx* m, int b) {
+        XMail* mail = c.mw_mail;
+        if (!mail) { __hip_atomic_store(&m->fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        const int seq = __hip_atomic_load(&mail->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
+        __hip_atomic_store(&mail->buf, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        __hip_atomic_store(&mail->req, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        long long spins = 0;
+        while (__hip_atomic_load(&mail->resp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(127);
+            if (++spins > (1ll << 24)) { __hip_atomic_store(&m->fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }  // about a minute: the host (or another rank) is gone; every engine gives up
+        }
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    }
     __device__ void finish() {
         wait();
         // blocks still on the dirty list: bring the HBM level of the index up to date, the next action of the session starts from it

@@ -25,8 +25,6 @@
 
 namespace kai {
 
-struct XMail { int32_t req, resp, buf, pad; };  // device → host: req = sequence number of the exchange asked for, buf = the wave's buffer; host → device: resp = req when it is done
-
 constexpr int32_t XW_MAGIC = 0x4b584d57;
 struct XWaveHdr { int32_t magic, seq, done, fault, hit, next, n_own, pad; };  // hit: lowest own simulation that did not simply fail (INT_MAX: none); next: own simulations handed out
 

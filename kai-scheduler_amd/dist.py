@@ -33,6 +33,24 @@ def init(backend: str, device=None):
     return rank, local_rank, world
 
 
+_HOST_GROUP = None
+
+
+def host_group():
+    """A gloo group over all ranks for collectives on HOST memory (the victim actions' wave exchange, core.py host_allgather=True): the default group when that is
+    gloo already, else a second group beside the nccl one.  Collective: every rank calls it."""
+    import torch.distributed as dist
+
+    global _HOST_GROUP
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_backend() == "gloo":
+        return None  # (None = the default group)
+    if _HOST_GROUP is None:
+        _HOST_GROUP = dist.new_group(backend="gloo")
+    return _HOST_GROUP
+
+
 def barrier(sync=None):
     """Device sync + rank barrier + device sync (the bracket bench.py's contract prescribes)."""
     import torch.distributed as dist

@@ -197,6 +197,7 @@ struct HostLauncher {
     void plan_rank(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_rank(c, rp); }); }
     void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_scan(c, rp); }); }
     void plan_emit(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_plan_emit(c); }); }
+    void class_capacity(int g, int b, const KaiCtx& c, int buckets, int levels) { kw::launch(g, b, 0, [&] { kb_class_capacity(c, buckets, levels); }); }
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) { kw::launch(g, b, dyn, [&] { kb_fill(c, rp, l1); }); }
     void bucket_build(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_bucket_build(c); }); }
     void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); }); }

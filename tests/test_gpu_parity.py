@@ -670,6 +670,75 @@ def test_gpu_node_sharded_group_on_one_device(gpu, world, offers):
                 assert stats.reserved[4] >= 1 and stats.reserved[0] >= 1  # batch rounds, exchanges
 
 
+@pytest.mark.parametrize("world,wgs,cap", [(2, 32, 0), (3, 8, 7), (2, 2, 1024)])
+def test_gpu_victim_waves_over_the_ranks_of_a_group_on_one_device(gpu, world, wgs, cap, monkeypatch):
+    """The victim actions of a node-sharded group with their simulation waves dealt out over the ranks (kai_victim_shard.hpp): `world` handles, one per rank and thread, on THIS
+    box's single GPU — each action's kernel runs on `wgs` workgroups per rank and rings its mailbox at every wave's end; the host thread inside kai_action_execute copies the
+    wave out of HBM, all-gathers (here: a barrier and memmove between the threads, host memory; the product: kai_shard_attach_host's collective or the library's RCCL
+    communicator), merges and answers.  Every rank must commit exactly the oracle's operations, and collectives must have happened.  (The multi-process form of the same
+    protocol runs over gloo on the emulator: tests/test_dist_gloo.py.)"""
+    import ctypes as C
+    import threading
+    monkeypatch.setenv("KAI_VICTIM_WGS", str(wgs))
+    if cap: monkeypatch.setenv("KAI_VICTIM_XCAP", str(cap))
+    cases = [T.pkg.synth.config(3, 0.01)[:2] + (("allocate", "consolidation", "reclaim"),),
+             (T.pkg.synth.make_crowded_snapshot(8, 1003, elastic_frac=0.0), T.abi.default_config(max_consolidation_preemptees=-1), ("allocate", "reclaim", "preempt", "allocate")),
+             (T.pkg.synth.make_crowded_snapshot(15, 7703, fill=0.9, n_pending_jobs=12, elastic_frac=0.25, hog_frac=0.5, queue_levels=(2, 2)), T.abi.default_config(max_consolidation_preemptees=16), ("consolidation", "reclaim", "preempt"))]
+    for snap, cfg, actions in cases:
+        ref = T.Oracle.run(snap, cfg, actions)
+        barrier = threading.Barrier(world)
+        sends, recvs = [None] * world, [None] * world
+        results, errors = [None] * world, []
+
+        def make_host_allgather(rank):
+            def allgather(send, recv, nbytes):  # host memory of the library; must not touch the device (the action's kernel waits for this to return)
+                sends[rank], recvs[rank] = send, recv
+                barrier.wait(timeout=120)
+                for q in range(world): C.memmove(recvs[q] + rank * nbytes, send, nbytes)
+                barrier.wait(timeout=120)
+                return 0
+            return allgather
+
+        def make_allgather(rank):  # the sharded fill's exchange (device memory), as in test_gpu_node_sharded_group_on_one_device
+            hip = T.pkg.core._hip_runtime()
+            def allgather(send, recv, nbytes):
+                sends[rank], recvs[rank] = send, recv
+                barrier.wait(timeout=120)
+                for q in range(world): assert hip.hipMemcpy(C.c_void_p(recvs[q] + rank * nbytes), C.c_void_p(send), C.c_size_t(nbytes), 3) == 0
+                import torch; torch.cuda.synchronize()
+                barrier.wait(timeout=120)
+                return 0
+            return allgather
+
+        def run(rank):
+            try:
+                with T.pkg.KaiCore(cfg, world=world, rank=rank, offers_per_class=16, allgather=make_allgather(rank), host_allgather=make_host_allgather(rank)) as core:
+                    ssn = core.open_session(snap)
+                    ops, exchanges = [], 0
+                    for a in actions:
+                        ops += [(int(o["kind"]), int(o["pod"]), int(o["node"]), int(o["job"])) for o in ssn.execute(a)]
+                        if a != "allocate": exchanges += int(ssn.stats().reserved[7])
+                    st, nd = ssn.pod_states()
+                    results[rank] = (ops, st, nd, ssn.node_states(), ssn.queue_shares(), exchanges)
+                    ssn.close()
+            except Exception as e:  # noqa: BLE001 — reported below; the other threads are released
+                errors.append((rank, repr(e))); barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads: t.start()
+        for t in threads: t.join(timeout=600)
+        assert not errors, errors
+        n_victim = sum(1 for a in actions if a != "allocate")
+        for rank in range(world):
+            ops, st, nd, nodes, shares, exchanges = results[rank]
+            assert ops == ref.ops
+            assert (st == ref.pod_status).all() and (nd == ref.pod_node).all()
+            for k in ref.nodes: assert np.array_equal(nodes[k], ref.nodes[k]), k
+            for k in ref.shares_final: assert np.array_equal(shares[k], ref.shares_final[k]), k
+            assert exchanges == results[0][5] and exchanges >= n_victim  # the same collectives on every rank; at least every action's closing message
+        assert results[0][5] > n_victim or not ref.ops  # waves were exchanged
+
+
 def test_gpu_default_allgather_plumbing(gpu):
     """KaiCore's default exchange step — stage into torch tensors, torch.distributed.all_gather_into_tensor (backend nccl = RCCL), stage back — on
     this box's one GPU with a one-rank group: what a node-sharded group calls between kernels, minus the second GPU."""
