@@ -177,7 +177,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         // tasks of every scan class the cluster still holds (for the plan's prediction of gangs that no longer fit; the fill verifies every prediction, so this only
         // saves rounds): summed here, read by k_plan_leaf, zeroed again by k_plan_emit
         if (capacity && c.C >= 1) l.class_capacity(std::max(1, c.NB), 64, c, buckets ? 1 : 0, bp.levels);
-        rp = RoundParams{}; rp.h_leaf = H; rp.mode = 0;
+        rp = RoundParams{}; rp.h_leaf = H; rp.mode = 0; rp.pad2 = std::getenv("KAI_FILL_UNBATCHED") ? 1 : 0;
         const int64_t e_bound = std::min<int64_t>(remaining, (int64_t)shape.n_leaves * H);
         const int64_t slots = std::min<int64_t>(c.bt.pool_k, e_bound * shape.n_heights + Q + 1);
         rp.n_slots = (int32_t)slots;
@@ -200,7 +200,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         bs.decisions += fs.decisions; bs.attempted += fs.attempted; bs.committed += fs.committed; bs.rollbacks += fs.rollbacks; bs.ops += fs.ops;
         bs.fill_cycles += fs.cycles_total; bs.fill_load += fs.cycles_load; bs.fill_update += fs.cycles_update; bs.fill_rescan += fs.cycles_rescan;
         bs.block_loads += fs.block_loads; bs.rescans1 += fs.rescans1; bs.rescans2 += fs.rescans2; bs.rescans3 += fs.rescans3;
-        if (std::getenv("KAI_BATCH_TRACE")) std::fprintf(stderr, "kai batch round %lld: H %d planned %d executed %d mismatch %d decisions %lld committed %lld remaining %d\n", (long long)bs.rounds, H, fs.planned, fs.n_done, fs.mismatch, (long long)fs.decisions, (long long)fs.committed, remaining - fs.n_done);
+        if (std::getenv("KAI_BATCH_TRACE")) std::fprintf(stderr, "kai batch round %lld: H %d planned %d executed %d mismatch %d decisions %lld steps %lld committed %lld remaining %d\n", (long long)bs.rounds, H, fs.planned, fs.n_done, fs.mismatch, (long long)fs.decisions, (long long)fs.rescans2, (long long)fs.committed, remaining - fs.n_done);
         ops_base += fs.ops; stmt_base += fs.committed; remaining -= fs.n_done;
         if (!fs.mismatch) H = std::min(H * 2, 1 << 20);                       // the plan ran out before anything surprising happened: look further ahead
         else if ((int64_t)fs.n_done * 4 < fs.planned) H = std::max(H / 2, 8);  // most of the plan was thrown away

@@ -88,6 +88,15 @@ KW_BODY void kb_bucket_build(const KaiCtx& c) {
     if (lane == 0) { if (top) kw::atomic_max((int32_t*)&meta->max_free, top); if (livew) kw::atomic_add((int32_t*)&meta->live, __builtin_popcountll(livew)); }
 }
 
+// a / b for 0 <= a <= 1024, 1 <= b <= 64 without the integer-division sequence (the fill wave's steps divide small counts): (a + 1/2) / b lies at least 1 / (2b) from an
+// integer, far more than a float reciprocal is off by
+KW_BODY int bk_div_small(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
+#else
+    return (int)(((float)a + 0.5f) * (1.0f / (float)b));  // (the same arithmetic on the emulator, so that the CPU tests exercise it)
+#endif
+}
 struct BkLds { int32_t placed_node[KB_PLACED_MAX]; int32_t placed_info[KB_PLACED_MAX]; };  // info: class | level before the placement << 8
 constexpr uint32_t BK_DEAD = 0xffffffffu;  // a class's best node as one ascending key, level << 20 | node (N <= 2^18 nodes: the summaries' reach); BK_DEAD: none
 KW_BODY uint32_t bk_key(int g, int n) { return n < 0 ? BK_DEAD : ((uint32_t)g << 20) | (uint32_t)n; }
@@ -124,12 +133,28 @@ KW_BODY void bk_find(const BkView& v, uint64_t s2, int slot, int from_g, int& og
 // Node n leaves level `from` and enters level `to` (0 = no level: a node without a free device fits no class).  Both are the same operation on the owning
 // lane's word — toggle bit n (ds_xor_rtn_b64, one LDS round trip for both levels) — and a summary bit toggles exactly when the word below it became
 // empty or stopped being empty.  Returns, in the lane of level `from`, that level's word after the removal.
-KW_BODY uint64_t bk_move(const BkView& v, uint64_t& s2, int n, int from, int to) {
+// (bk_move_mask: the same for several nodes of ONE word at once — `bit` holds their bits; they all leave `from` and enter `to`)
+KW_BODY uint64_t bk_move_mask(const BkView& v, uint64_t& s2, int& cnt, int w, uint64_t bit, int from, int to) {
+    const int lane = kw::lane(), w1 = w >> 6;
+    const bool isfrom = lane == from - 1, part = isfrom || lane == to - 1;
+    uint64_t old = 0;
+    if (part) { old = kw::lds_xor(&v.gw[lane * v.NW + w], bit); const int kb = __builtin_popcountll(bit); cnt += isfrom ? -kb : kb; }
+    const uint64_t neww = old ^ bit;
+    const bool flip1 = part && (isfrom ? neww == 0 : old == 0);
+    if (kw::ballot(flip1)) {
+        if (flip1) {
+            const uint64_t bit1 = 1ull << (w & 63), o1 = kw::lds_xor(&v.s1[lane * v.NW1 + w1], bit1);
+            if (isfrom ? (o1 ^ bit1) == 0 : o1 == 0) s2 ^= 1ull << w1;
+        }
+    }
+    return neww;
+}
+KW_BODY uint64_t bk_move(const BkView& v, uint64_t& s2, int& cnt, int n, int from, int to) {
     const int lane = kw::lane(), w = n >> 6, w1 = w >> 6;
     const uint64_t bit = 1ull << (n & 63);
     const bool isfrom = lane == from - 1, part = isfrom || lane == to - 1;
     uint64_t old = 0;
-    if (part) old = kw::lds_xor(&v.gw[lane * v.NW + w], bit);
+    if (part) { old = kw::lds_xor(&v.gw[lane * v.NW + w], bit); cnt += isfrom ? -1 : 1; }
     const uint64_t neww = old ^ bit;
     const bool flip1 = part && (isfrom ? neww == 0 : old == 0);
     if (kw::ballot(flip1)) {  // (uniform) a word became empty or stopped being empty: its bit in the first summary toggles, and so on upwards
@@ -162,39 +187,111 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
     if (tid < 64) {
         uint64_t s2 = 0;  // lane l: second summary of level l + 1
         if (lane < v.LV) for (int j = 0; j < v.NW1; j++) if (v.s1[lane * v.NW1 + j]) s2 |= 1ull << j;
+        int lvl_n = 0;    // lane l: nodes of level l + 1 (kept by every move; what a class's capacity is summed from)
+        if (lane < v.LV) for (int j = 0; j < v.NW; j++) lvl_n += __builtin_popcountll(v.gw[lane * v.NW + j]);
         // lane k: class k — devices asked for, slot of its static bitmap, and its best node as ONE ascending key: level << 20 | node (a class's order over the nodes
         // it may use is (free devices, name rank) ascending; BK_DEAD = no node fits).  Lanes beyond the classes hold BK_DEAD and ask for "infinitely many" devices.
         const bool act = lane < C;
         int q = 0x7fffffff, okslot = -1; uint32_t top = BK_DEAD;
         if (act) { q = (int)c.cls[lane].req[KAI_RES_GPU]; okslot = bp.okslot[lane]; }
+        const bool batched = rp.pad2 == 0;  // (RoundParams::pad2 = 1: one placement per step for every gang — A/B runs, tests)
         const bool plain = kw::ballot(act && okslot >= 0) == 0;  // no class carries a static bitmap of its own: one lookup answers every class that lost the same node
         for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); if (lane == k) top = bk_key(g, n); }
         const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: dead classes only (before the first plan)
-        int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, finds = 0, n_done = rp.start, mismatch = 0;  // (of one launch: far below 2^31)
+        int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, finds = 0, steps = 0, n_done = rp.start, mismatch = 0;  // (of one launch: far below 2^31)
+#ifdef KAI_FILL_PROF
+        int64_t pcy[4] = {0, 0, 0, 0};  // per job: before its tasks / its steps incl. the stretch stores / after them (rollback, outputs); [3] the stretch stores alone
+#endif
         for (int base = rp.start; base < V && !mismatch; base += 64) {
             const int gi = base + lane;
             const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE, my_first = gi < V ? b.g_first[gi] : 0, my_nt = gi < V ? b.g_nt[gi] : 0, my_ucls = gi < V ? b.g_ucls[gi] : 0;
             const int cnt = V - base < 64 ? V - base : 64;
+            int my_out = 0, my_opoff = 0, my_stmt = 0, n_out = 0;  // lane jj: what job jj of this stretch ended with (stored once per stretch, coalesced)
             for (int jj = 0; jj < cnt; jj++) {
+#ifdef KAI_FILL_PROF
+                const int64_t pt0 = kw::clock();
+#endif
                 const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
                 const int opoff = ops + rp.ops0, stmtoff = committed + rp.stmt0;
                 bool ok = flag != BF_GATE; int placed = 0;
+#ifdef KAI_FILL_PROF
+                const int64_t pt1 = kw::clock(); int64_t pt2 = pt1;
+#endif
                 if (flag != BF_GATE) {
                     for (int tb = 0; tb < nt && ok; tb += 64) {
+                        if (ucls >= 0 && plain && batched) {
+                            // A gang of ONE class, no static bitmaps: whole nodes per step.  The class's best node n holds g free devices, so it takes r = g / q of the gang's
+                            // tasks one after the other (fewer free devices is a better key: it stays on top while it fits); then it holds g mod q < q and the class's next best is the
+                            // next node of the same level — levels q .. g-1 were empty and still are — which again takes r tasks, and so on.  So a step moves the first k nodes of
+                            // n's word at level g to level g mod q at once (one ds_xor per level with the k bits) and hands out k·r tasks; a remainder of fewer than r tasks goes to one
+                            // node, which then stays at level g - rem·q.  Every other class sees exactly what k·r single placements would have left: the only new candidates are the
+                            // moved nodes, all at one level, the first of them the best.
+                            const int tc = nt - tb < 64 ? nt - tb : 64, qc = kw::bcast(q, ucls);
+                            if (tb == 0 && nt > 1 && flag == BF_DEAD) {  // (the plan's predictions of "dead" are exact: free resources only shrink)
+                                // Does the gang fit at all?  A node with g free devices holds g / q of its tasks and every placement takes exactly one such place away (g - q holds
+                                // g / q - 1), so the placements above succeed exactly while Σ_levels (g / q) · nodes(g) lasts: a gang that asks for more than that places `cap`
+                                // tasks, finds no node for the next one and is rolled back — the state it started from, cap + 1 decisions.  Decided here without placing anything.
+                                int term = 0;
+                                if (lane < v.LV && lane + 1 >= qc) term = bk_div_small(lane + 1, qc) * lvl_n;
+                                int cap = 0;
+                                for (int l = qc - 1; l < v.LV; l++) cap += kw::bcast(term, l);
+                                if (cap < nt) { decisions += cap + 1; steps++; ok = false; break; }
+                            }
+                            int my_node = 0, my_info = 0, done = 0;
+                            while (done < tc) {
+                                const uint32_t tk = kw::bcast(top, ucls);
+                                if (tk == BK_DEAD) { decisions++; ok = false; break; }
+                                const int n = (int)(tk & 0xfffffu), g = (int)(tk >> 20), r = bk_div_small(g, qc), rem = tc - done, w = n >> 6;
+                                int k = 1, per = rem < r ? rem : r;
+                                uint64_t mask = 1ull << (n & 63);
+                                if (rem >= 2 * r) {  // more than one whole node: the set bits of n's word at its level, from n upwards (n is the level's first node)
+                                    uint64_t word = v.gw[(g - 1) * v.NW + w];
+                                    kw::lds_order();  // (every lane has read the word before its owner toggles it below; lock-step on the device, an order the emulator needs told)
+                                    const int want = bk_div_small(rem, r); mask = 0;
+                                    for (k = 0; k < want && word; k++) { mask |= word & (0 - word); word &= word - 1; }
+                                }
+                                const int g2 = g - per * qc, step = k * per;
+                                {   // lane done + t: task t of the step, on the (t / per)-th node of the mask, found at level g - (t mod per)·q (what the rollback needs)
+                                    uint64_t m = mask; int x = lane - done;  // (x: this lane's task counted from the node the loop is at)
+                                    for (int j = 0; j < k; j++, x -= per) { const int nj = (w << 6) + __builtin_ctzll(m); m &= m - 1; if (x >= 0 && x < per) { my_node = nj; my_info = ucls | ((g - x * qc) << 8); } }
+                                }
+                                decisions += step; done += step; steps++;
+                                const uint64_t neww = bk_move_mask(v, s2, lvl_n, w, mask, g, g2);
+                                const uint32_t cand = ((uint32_t)g2 << 20) | (uint32_t)n;
+                                const bool mine = top == tk, fits2 = g2 >= q;
+                                const bool need = mine && !fits2;
+                                top = (fits2 && (mine || cand < top)) ? cand : top;
+                                if (kw::ballot(need)) {
+                                    const uint64_t rest = kw::bcast(neww, g - 1);
+                                    uint32_t fk = ((uint32_t)g << 20) | (uint32_t)((n & ~63) + (rest ? __builtin_ctzll(rest) : 0));
+                                    if (!rest) { int fg, fn; bk_find(v, s2, -1, g, fg, fn); fk = bk_key(fg, fn); finds++; }
+                                    top = need ? fk : top;
+                                }
+                            }
+#ifdef KAI_FILL_PROF
+                            const int64_t ps0 = kw::clock();
+#endif
+                            if (lane < done) { b.t_node[first + tb + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
+#ifdef KAI_FILL_PROF
+                            pcy[3] += kw::clock() - ps0;
+#endif
+                            placed += done;
+                            continue;
+                        }
                         int my_cls = ucls;
                         if (ucls < 0) my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;  // a gang of several scan classes: its task list
                         const int tc = nt - tb < 64 ? nt - tb : 64;
                         int my_node = 0, my_info = 0, done = 0;  // lane i: the i-th placement of this stretch of (at most 64) tasks
                         for (int ti = 0; ti < tc; ti++) {
                             const int kcls = ucls >= 0 ? ucls : kw::bcast(my_cls, ti);
-                            decisions++;
+                            decisions++; steps++;
                             const uint32_t tk = kw::bcast(top, kcls);
                             if (tk == BK_DEAD) { ok = false; break; }
                             const int n = (int)(tk & 0xfffffu), g = (int)(tk >> 20), g2 = g - kw::bcast(q, kcls);
                             const bool me = lane == ti;
                             my_node = me ? n : my_node; my_info = me ? (kcls | (g << 8)) : my_info;
                             done++;
-                            const uint64_t neww = bk_move(v, s2, n, g, g2);
+                            const uint64_t neww = bk_move(v, s2, lvl_n, n, g, g2);
                             // the only node whose key moved is n (to cand): a class that had it on top keeps it while it still fits (fewer free devices = a better
                             // key), any other class takes it if it now beats that class's best
                             const uint32_t cand = ((uint32_t)g2 << 20) | (uint32_t)n;
@@ -224,27 +321,38 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                         if (lane < done) { b.t_node[first + tb + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
                         placed += done;
                     }
+#ifdef KAI_FILL_PROF
+                    pt2 = kw::clock();
+#endif
                     if (!ok) {  // Statement.Rollback: the undone operations in reverse order, then every class's best from the restored sets
                         kw::lds_order();
                         for (int i = placed - 1; i >= 0; i--) {
                             const int n = L.placed_node[i], info = L.placed_info[i], gb = info >> 8;
-                            (void)bk_move(v, s2, n, gb - kw::bcast(q, info & 0xff), gb);
+                            (void)bk_move(v, s2, lvl_n, n, gb - kw::bcast(q, info & 0xff), gb);
                         }
                         if (placed) for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); finds++; if (lane == k) top = bk_key(g, n); }
                         rollbacks += 2;
                     } else { committed++; ops += nt; }
                 }
+#ifdef KAI_FILL_PROF
+                { const int64_t pt3 = kw::clock(); pcy[0] += pt1 - pt0; pcy[1] += pt2 - pt1; pcy[2] += pt3 - pt2; }
+#endif
                 attempted++; n_done = base + jj + 1;
-                if (lane == 0) { b.g_out[base + jj] = ok ? BF_OK : BF_DEAD; b.g_opoff[base + jj] = opoff; b.g_stmt[base + jj] = stmtoff; }
+                { const bool me = lane == jj; my_out = me ? (ok ? BF_OK : BF_DEAD) : my_out; my_opoff = me ? opoff : my_opoff; my_stmt = me ? stmtoff : my_stmt; n_out = jj + 1; }
                 if ((flag == BF_OK) != ok) { mismatch = 1; break; }
             }
+            if (lane < n_out) { b.g_out[base + lane] = (uint8_t)my_out; b.g_opoff[base + lane] = my_opoff; b.g_stmt[base + lane] = my_stmt; }
         }
         const uint64_t dead = kw::ballot(act && top == BK_DEAD);
         if (lane == 0) {
             FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V; s.floor_stop = 0; s.pad = 0;
             s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
             s.cycles_total = kw::clock() - tstart; s.cycles_load = 0; s.cycles_update = 0; s.cycles_rescan = 0;
-            s.block_loads = 0; s.rescans1 = finds; s.rescans2 = 0; s.rescans3 = 0;
+            s.block_loads = 0;
+#ifdef KAI_FILL_PROF
+            s.cycles_load = pcy[0]; s.cycles_update = pcy[1]; s.cycles_rescan = pcy[2]; s.block_loads = pcy[3];
+#endif
+            s.rescans1 = finds; s.rescans2 = steps; s.rescans3 = 0;  // rescans2: steps of the fill wave (a step places whole nodes of a one-class gang, or one task)
             b.fs[0] = s; b.dead_mask[0] = dead;
         }
     }

@@ -137,6 +137,30 @@ def test_bucket_fill_takes_binpacked_gpu_classes(seed, monkeypatch):
     assert stats_tuple(gen.stats) == stats_tuple(res.stats)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_bucket_fill_whole_nodes_per_step(seed, monkeypatch):
+    """A gang of one class is placed in steps of whole nodes (the class's best node takes g / q tasks, the next nodes of its level follow in one ds_xor): large gangs of
+    small requests on 16-device nodes, 3- and 5-device requests (a node is left at g mod q and becomes another class's best), nearly full and nearly empty clusters —
+    against the oracle, against one placement per step (KAI_FILL_UNBATCHED) and against the general kernel"""
+    rng = np.random.default_rng(5600 + seed)
+    sizes, probs = ((1, 4, 8, 16, 64, 100), (.1, .2, .3, .2, .1, .1)) if seed % 2 else ((1, 2, 3, 24), (.3, .2, .2, .3))
+    snap = synth.make_snapshot(int(rng.integers(3, 300)), int(rng.integers(50, 2500)), 5600 + seed, queue_levels=[(1,), (2, 2), (3, 4)][seed % 3], prefill=(0.0, 0.3, 0.6, 0.9)[seed % 4],
+                               gpu_mix=((16, .5), (8, .5)) if seed % 3 == 0 else ((8, .7), (4, .3)), gpus_per_pod=(1, 2, 4, 8) if seed % 4 else (1, 3, 5), gang_sizes=sizes, gang_p=probs,
+                               mem_per_gpu=8 * synth.GIB, cpu_per_gpu=2000.0, lexi_names=bool(seed % 5 == 0))
+    cfg = abi.default_config(k_value=0.5)
+    res = run_both(snap, cfg)
+    if _buckets(res) != 1:
+        pytest.skip("this cluster does not qualify for the bucket fill (a resource other than the devices may bind first)")
+    monkeypatch.setenv("KAI_FILL_UNBATCHED", "1")
+    one = HostSim.run(snap, cfg)
+    assert _buckets(one) == 1
+    assert_same(one, res); assert stats_tuple(one.stats) == stats_tuple(res.stats)
+    monkeypatch.delenv("KAI_FILL_UNBATCHED"); monkeypatch.setenv("KAI_FILL_GENERAL", "1")
+    gen = HostSim.run(snap, cfg)
+    assert _buckets(gen) == 0
+    assert_same(gen, res); assert stats_tuple(gen.stats) == stats_tuple(res.stats)
+
+
 def test_bucket_fill_declines_when_another_resource_may_bind():
     """20 000 mCPU per device on nodes of 64 000 - 192 000 mCPU: the CPU runs out before the devices do on most nodes, k_bucket_build's proof fails and
     the general kernel takes the fill — same results"""

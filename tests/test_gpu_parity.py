@@ -405,6 +405,28 @@ def test_gpu_bucket_fill_against_oracle_and_general_kernel(gpu, seed, monkeypatc
     assert_same(gen, ref)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_bucket_fill_whole_nodes_per_step(gpu, seed, monkeypatch):
+    """k_fill_buckets places a gang of one class in steps of whole nodes (kai_fill_buckets.hpp): large gangs of small requests on 16-device nodes, 3- and 5-device requests,
+    nearly full and empty clusters — against the oracle and against one placement per step (KAI_FILL_UNBATCHED); the CPU twin of this test also runs the general kernel"""
+    rng = np.random.default_rng(5600 + seed)
+    sizes, probs = ((1, 4, 8, 16, 64, 100), (.1, .2, .3, .2, .1, .1)) if seed % 2 else ((1, 2, 3, 24), (.3, .2, .2, .3))
+    snap = T.pkg.synth.make_snapshot(int(rng.integers(3, 300)), int(rng.integers(50, 2500)), 5600 + seed, queue_levels=[(1,), (2, 2), (3, 4)][seed % 3], prefill=(0.0, 0.3, 0.6, 0.9)[seed % 4],
+                                     gpu_mix=((16, .5), (8, .5)) if seed % 3 == 0 else ((8, .7), (4, .3)), gpus_per_pod=(1, 2, 4, 8) if seed % 4 else (1, 3, 5), gang_sizes=sizes, gang_p=probs,
+                                     mem_per_gpu=8 * T.pkg.synth.GIB, cpu_per_gpu=2000.0, lexi_names=bool(seed % 5 == 0))
+    cfg = T.abi.default_config(k_value=0.5)
+    ref = T.Oracle.run(snap, cfg)
+    res = run_gpu(snap, cfg)
+    assert_same(res, ref)
+    assert stats_tuple(res.stats) == stats_tuple(ref.stats)
+    if not on_buckets(res.stats):
+        pytest.skip("this cluster does not qualify for the bucket fill")
+    monkeypatch.setenv("KAI_FILL_UNBATCHED", "1")
+    one = run_gpu(snap, cfg)
+    assert on_buckets(one.stats)
+    assert_same(one, ref); assert stats_tuple(one.stats) == stats_tuple(ref.stats)
+
+
 def test_gpu_bucket_fill_corners(gpu):
     """what k_bucket_build turns away (another resource may bind first, 32 devices per node) runs on the general kernel; static predicates per class, 16
     devices per node, a nearly full cluster run on the bucket kernel — all equal to the oracle"""
