@@ -33,7 +33,7 @@ CONFIGS = {"C1": 0, "C2": 1, "C3": 2, "C4": 3, "C5": 4}
 
 
 def pmc_traffic(workload, kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this command (tools/gpu_prof.sh + tools/pmc_traffic.py write
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this command (tools/runs/gpu_prof.sh + tools/pmc_traffic.py write
     profiles/pmc_traffic.json; counters need their own passes, so this is not measured inside the timed run), or None when no pass is on file."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:

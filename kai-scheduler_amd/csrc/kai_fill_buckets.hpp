@@ -97,7 +97,11 @@ KW_BODY int bk_div_small(int a, int b) {
     return (int)(((float)a + 0.5f) * (1.0f / (float)b));  // (the same arithmetic on the emulator, so that the CPU tests exercise it)
 #endif
 }
-struct BkLds { int32_t placed_node[KB_PLACED_MAX]; int32_t placed_info[KB_PLACED_MAX]; };  // info: class | level before the placement << 8
+constexpr int BK_SCAP = 1024;  // placements staged in LDS before they go to t_node in one burst
+// placed_*: the running gang, for its rollback (info: class | level before the placement << 8).  stage_*: (pod slot, node) of the placements of the running stretch of 64
+// jobs — the fill wave's loop over jobs issues NO global store: on gfx9 stores count on vmcnt like loads, and every s_waitcnt vmcnt(0) the compiler leaves in the loop
+// would wait for the previous job's stores to be acknowledged (measured: ≈ 1 700 cycles per job before, profiles/r04k → r04l)
+struct BkLds { int32_t placed_node[KB_PLACED_MAX]; int32_t placed_info[KB_PLACED_MAX]; int32_t stage_idx[BK_SCAP]; int32_t stage_node[BK_SCAP]; };
 constexpr uint32_t BK_DEAD = 0xffffffffu;  // a class's best node as one ascending key, level << 20 | node (N <= 2^18 nodes: the summaries' reach); BK_DEAD: none
 KW_BODY uint32_t bk_key(int g, int n) { return n < 0 ? BK_DEAD : ((uint32_t)g << 20) | (uint32_t)n; }
 struct BkView {
@@ -199,7 +203,10 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); if (lane == k) top = bk_key(g, n); }
         const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: dead classes only (before the first plan)
         int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, finds = 0, steps = 0, n_done = rp.start, mismatch = 0;  // (of one launch: far below 2^31)
+        int n_stage = 0, job_stage0 = 0;  // staged placements; where the running job's begin (0 after a flush)
+        auto flush_stage = [&]() { kw::lds_order(); for (int i = lane; i < n_stage; i += 64) b.t_node[L.stage_idx[i]] = L.stage_node[i]; kw::lds_order(); n_stage = 0; job_stage0 = 0; };
 #ifdef KAI_FILL_PROF
+        int64_t qcy[4] = {0, 0, 0, 0};  // per step: best node + mask / task records / the move / tops
         int64_t pcy[4] = {0, 0, 0, 0};  // per job: before its tasks / its steps incl. the stretch stores / after them (rollback, outputs); [3] the stretch stores alone
 #endif
         for (int base = rp.start; base < V && !mismatch; base += 64) {
@@ -214,6 +221,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                 const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
                 const int opoff = ops + rp.ops0, stmtoff = committed + rp.stmt0;
                 bool ok = flag != BF_GATE; int placed = 0;
+                job_stage0 = n_stage;
 #ifdef KAI_FILL_PROF
                 const int64_t pt1 = kw::clock(); int64_t pt2 = pt1;
 #endif
@@ -239,6 +247,9 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                             }
                             int my_node = 0, my_info = 0, done = 0;
                             while (done < tc) {
+#ifdef KAI_FILL_PROF
+                                const int64_t q0 = kw::clock();
+#endif
                                 const uint32_t tk = kw::bcast(top, ucls);
                                 if (tk == BK_DEAD) { decisions++; ok = false; break; }
                                 const int n = (int)(tk & 0xfffffu), g = (int)(tk >> 20), r = bk_div_small(g, qc), rem = tc - done, w = n >> 6;
@@ -250,13 +261,22 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                                     const int want = bk_div_small(rem, r); mask = 0;
                                     for (k = 0; k < want && word; k++) { mask |= word & (0 - word); word &= word - 1; }
                                 }
+#ifdef KAI_FILL_PROF
+                                const int64_t q1 = kw::clock();
+#endif
                                 const int g2 = g - per * qc, step = k * per;
                                 {   // lane done + t: task t of the step, on the (t / per)-th node of the mask, found at level g - (t mod per)·q (what the rollback needs)
                                     uint64_t m = mask; int x = lane - done;  // (x: this lane's task counted from the node the loop is at)
                                     for (int j = 0; j < k; j++, x -= per) { const int nj = (w << 6) + __builtin_ctzll(m); m &= m - 1; if (x >= 0 && x < per) { my_node = nj; my_info = ucls | ((g - x * qc) << 8); } }
                                 }
                                 decisions += step; done += step; steps++;
+#ifdef KAI_FILL_PROF
+                                const int64_t q2 = kw::clock();
+#endif
                                 const uint64_t neww = bk_move_mask(v, s2, lvl_n, w, mask, g, g2);
+#ifdef KAI_FILL_PROF
+                                const int64_t q3 = kw::clock();
+#endif
                                 const uint32_t cand = ((uint32_t)g2 << 20) | (uint32_t)n;
                                 const bool mine = top == tk, fits2 = g2 >= q;
                                 const bool need = mine && !fits2;
@@ -267,11 +287,16 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                                     if (!rest) { int fg, fn; bk_find(v, s2, -1, g, fg, fn); fk = bk_key(fg, fn); finds++; }
                                     top = need ? fk : top;
                                 }
+#ifdef KAI_FILL_PROF
+                                { const int64_t q4 = kw::clock(); qcy[0] += q1 - q0; qcy[1] += q2 - q1; qcy[2] += q3 - q2; qcy[3] += q4 - q3; }
+#endif
                             }
 #ifdef KAI_FILL_PROF
                             const int64_t ps0 = kw::clock();
 #endif
-                            if (lane < done) { b.t_node[first + tb + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
+                            if (n_stage + 64 > BK_SCAP) flush_stage();
+                            if (lane < done) { L.stage_idx[n_stage + lane] = first + tb + lane; L.stage_node[n_stage + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
+                            n_stage += done;
 #ifdef KAI_FILL_PROF
                             pcy[3] += kw::clock() - ps0;
 #endif
@@ -318,7 +343,9 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                             }
                         }
                         // the stretch's placements: the tasks' nodes for the apply kernels (one coalesced store) and the rollback list
-                        if (lane < done) { b.t_node[first + tb + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
+                        if (n_stage + 64 > BK_SCAP) flush_stage();
+                        if (lane < done) { L.stage_idx[n_stage + lane] = first + tb + lane; L.stage_node[n_stage + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
+                        n_stage += done;
                         placed += done;
                     }
 #ifdef KAI_FILL_PROF
@@ -332,6 +359,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                         }
                         if (placed) for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); finds++; if (lane == k) top = bk_key(g, n); }
                         rollbacks += 2;
+                        n_stage = job_stage0;  // (what a flush in the middle of the gang already wrote belongs to a job that failed: never read)
                     } else { committed++; ops += nt; }
                 }
 #ifdef KAI_FILL_PROF
@@ -341,6 +369,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                 { const bool me = lane == jj; my_out = me ? (ok ? BF_OK : BF_DEAD) : my_out; my_opoff = me ? opoff : my_opoff; my_stmt = me ? stmtoff : my_stmt; n_out = jj + 1; }
                 if ((flag == BF_OK) != ok) { mismatch = 1; break; }
             }
+            flush_stage();
             if (lane < n_out) { b.g_out[base + lane] = (uint8_t)my_out; b.g_opoff[base + lane] = my_opoff; b.g_stmt[base + lane] = my_stmt; }
         }
         const uint64_t dead = kw::ballot(act && top == BK_DEAD);
@@ -350,7 +379,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
             s.cycles_total = kw::clock() - tstart; s.cycles_load = 0; s.cycles_update = 0; s.cycles_rescan = 0;
             s.block_loads = 0;
 #ifdef KAI_FILL_PROF
-            s.cycles_load = pcy[0]; s.cycles_update = pcy[1]; s.cycles_rescan = pcy[2]; s.block_loads = pcy[3];
+            s.cycles_load = qcy[0]; s.cycles_update = qcy[1]; s.cycles_rescan = qcy[2]; s.block_loads = qcy[3]; (void)pcy;
 #endif
             s.rescans1 = finds; s.rescans2 = steps; s.rescans3 = 0;  // rescans2: steps of the fill wave (a step places whole nodes of a one-class gang, or one task)
             b.fs[0] = s; b.dead_mask[0] = dead;

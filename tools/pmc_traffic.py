@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fold the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_prof.sh into profiles/pmc_traffic.json (what bench.py reports as roofline.traffic).
+"""Fold the FETCH_SIZE / WRITE_SIZE passes of tools/runs/gpu_prof.sh into profiles/pmc_traffic.json (what bench.py reports as roofline.traffic).
 
     python tools/pmc_traffic.py <workload string> <FETCH counter_collection.csv> <WRITE counter_collection.csv> [kernel substring]
 Bytes = (FETCH_SIZE + WRITE_SIZE) x 1024 per launch of the kernel, raw counters (MI355X_MICROARCH.md: FETCH_SIZE under-reads wide
