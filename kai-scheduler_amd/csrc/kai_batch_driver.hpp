@@ -85,7 +85,7 @@ inline bool batch_bucket_params(const KaiCtx& c, const BucketMeta& m, BucketPara
     for (int k = 0; k < 64; k++) bp.okslot[k] = -1;
     for (int k = 0; k < c.C; k++) if (m.ok_miss[k]) bp.okslot[k] = (int8_t)bp.n_ok++;
     dyn = ((size_t)bp.levels * bp.nw + (size_t)bp.levels * bp.nw1 + KBK_GMAX + (size_t)bp.n_ok * bp.nw) * 8 + 16;
-    return dyn <= (size_t)(160 - 24) * 1024;  // beside the kernel's static LDS (rollback list 8 KB, staged placements 8 KB) and a margin
+    return dyn <= (size_t)(160 - 16) * 1024;  // beside the kernel's static LDS (rollback list: 8 KB) and a margin
 }
 
 // The fill of one planned round on a node-sharded group: offers -> all-gather -> the same virtual fill on every rank -> own records

@@ -66,6 +66,7 @@ struct kai_core {
     XMail* mail = nullptr; XMail* d_mail = nullptr; hipStream_t xstream = nullptr;
     unsigned char* xpin = nullptr; size_t xpin_bytes = 0; unsigned char *xd_send = nullptr, *xd_recv = nullptr; size_t xd_bytes = 0;
     XShardHost xs;
+    std::vector<MultiCtx> mw_host;  // staging of the victim actions' shared block (one per handle: handles of several ranks may run on threads of one process)
 };
 
 #define HIP_TRY(core, expr)                                                                                        \
@@ -398,7 +399,8 @@ int prepare_multi(kai_core* core, int G, int* g_out) {
         cw.bt.enabled = 0;  // (the batch path's pools are not replicated; a victim action never reads them)
     }
     HIP_TRY(core, hipMemcpyAsync(core->d_ctxs, ctxs.data(), (size_t)G * sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
-    static MultiCtx m0; std::memset(&m0, 0, sizeof m0); m0.world = G; m0.hit[0] = m0.hit[1] = 0x7fffffff;  // (static: 150 KB)
+    if (core->mw_host.empty()) core->mw_host.resize(1);
+    MultiCtx& m0 = core->mw_host[0]; std::memset(&m0, 0, sizeof m0); m0.world = G; m0.hit[0] = m0.hit[1] = 0x7fffffff;
     HIP_TRY(core, hipMemcpyAsync(core->d_mw, &m0, sizeof(MultiCtx), hipMemcpyHostToDevice, core->stream));
     hipLaunchKernelGGL(k_replicate, dim3(core->n_segs, G - 1), dim3(256), 0, core->stream, (const RepSeg*)core->d_segs, core->rep_mem, (unsigned long long)core->rep_stride);
     HIP_TRY(core, hipGetLastError());
@@ -768,6 +770,9 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
             int want = 32; if (const char* e = std::getenv("KAI_VICTIM_WGS")) want = std::atoi(e);  // (measured on C4: 32 workgroups — four replicas per XCD, hot in its L2 — beat 64 and more, whose waves are no shorter)
             int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, core->device) != hipSuccess || cus <= 0) cus = 64;
             want = std::max(1, std::min(std::min(want, (int)KAI_MW_MAX), cus));  // every workgroup must be resident: they meet at a grid barrier
+            { int per_cu = 0;  // ... as the runtime's occupancy calculation sees it for this kernel, its workgroup size and its dynamic LDS (not only one per compute unit)
+              if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_action<true, false>), WG, dyn) == hipSuccess && per_cu > 0) want = std::min(want, per_cu * cus);
+              else (void)hipGetLastError(); }
             // a node-sharded group with an exchange for it deals the waves out over its ranks (kai_victim_shard.hpp); every rank takes the same decision here
             xsh = core->world > 1 && (core->xag_fn || core->rccl_comm) && !core->shared && want > 1 && (core->mw_world == 0 || core->mw_world == want) && !std::getenv("KAI_VICTIM_REPLICATED");
             if (xsh) {
@@ -845,7 +850,8 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     if (victim) {  // victim actions: [1] workgroups the action ran on, [5] waves, [6] simulations run (speculative ones included) << 32 | simulations the reference's order reached; a group that dealt the waves out over its ranks: [7] collectives
         core->stats.reserved[1] = g_run;
         if (g_run > 1) {
-            static MultiCtx m; HIP_TRY(core, hipMemcpyAsync(&m, core->d_mw, sizeof(MultiCtx), hipMemcpyDeviceToHost, core->stream)); HIP_TRY(core, hipStreamSynchronize(core->stream));
+            if (core->mw_host.empty()) core->mw_host.resize(1);
+            MultiCtx& m = core->mw_host[0]; HIP_TRY(core, hipMemcpyAsync(&m, core->d_mw, sizeof(MultiCtx), hipMemcpyDeviceToHost, core->stream)); HIP_TRY(core, hipStreamSynchronize(core->stream));
             core->stats.reserved[5] = m.waves; core->stats.reserved[6] = (m.sims_run << 32) | (m.sims_used & 0xffffffffll);
             if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai victim: %d workgroups, waves %lld, simulations run %lld / counted %lld, replays %lld, fault %d\n", g_run, (long long)m.waves, (long long)m.sims_run, (long long)m.sims_used, (long long)m.replays, m.fault);
         }

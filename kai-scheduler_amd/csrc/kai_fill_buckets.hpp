@@ -97,11 +97,9 @@ KW_BODY int bk_div_small(int a, int b) {
     return (int)(((float)a + 0.5f) * (1.0f / (float)b));  // (the same arithmetic on the emulator, so that the CPU tests exercise it)
 #endif
 }
-constexpr int BK_SCAP = 1024;  // placements staged in LDS before they go to t_node in one burst
-// placed_*: the running gang, for its rollback (info: class | level before the placement << 8).  stage_*: (pod slot, node) of the placements of the running stretch of 64
-// jobs — the fill wave's loop over jobs issues NO global store: on gfx9 stores count on vmcnt like loads, and every s_waitcnt vmcnt(0) the compiler leaves in the loop
-// would wait for the previous job's stores to be acknowledged (measured: ≈ 1 700 cycles per job before, profiles/r04k → r04l)
-struct BkLds { int32_t placed_node[KB_PLACED_MAX]; int32_t placed_info[KB_PLACED_MAX]; int32_t stage_idx[BK_SCAP]; int32_t stage_node[BK_SCAP]; };
+struct BkLds { int32_t placed_node[KB_PLACED_MAX]; int32_t placed_info[KB_PLACED_MAX]; };  // the running gang, for its rollback (info: class | level before the placement << 8)
+// (Measured and dropped, r04l: the placements staged in LDS and written to t_node once per 64 jobs, so that the loop over jobs issues no global store — the fill was no
+// faster: the wave does not wait on its stores.  r04m, clocks around the four parts of a step: best node + mask 360, task records 250, the move 310, tops + lookups 430 cycles.)
 constexpr uint32_t BK_DEAD = 0xffffffffu;  // a class's best node as one ascending key, level << 20 | node (N <= 2^18 nodes: the summaries' reach); BK_DEAD: none
 KW_BODY uint32_t bk_key(int g, int n) { return n < 0 ? BK_DEAD : ((uint32_t)g << 20) | (uint32_t)n; }
 struct BkView {
@@ -203,8 +201,6 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); if (lane == k) top = bk_key(g, n); }
         const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: dead classes only (before the first plan)
         int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, finds = 0, steps = 0, n_done = rp.start, mismatch = 0;  // (of one launch: far below 2^31)
-        int n_stage = 0, job_stage0 = 0;  // staged placements; where the running job's begin (0 after a flush)
-        auto flush_stage = [&]() { kw::lds_order(); for (int i = lane; i < n_stage; i += 64) b.t_node[L.stage_idx[i]] = L.stage_node[i]; kw::lds_order(); n_stage = 0; job_stage0 = 0; };
 #ifdef KAI_FILL_PROF
         int64_t qcy[4] = {0, 0, 0, 0};  // per step: best node + mask / task records / the move / tops
         int64_t pcy[4] = {0, 0, 0, 0};  // per job: before its tasks / its steps incl. the stretch stores / after them (rollback, outputs); [3] the stretch stores alone
@@ -221,7 +217,6 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                 const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
                 const int opoff = ops + rp.ops0, stmtoff = committed + rp.stmt0;
                 bool ok = flag != BF_GATE; int placed = 0;
-                job_stage0 = n_stage;
 #ifdef KAI_FILL_PROF
                 const int64_t pt1 = kw::clock(); int64_t pt2 = pt1;
 #endif
@@ -294,9 +289,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
 #ifdef KAI_FILL_PROF
                             const int64_t ps0 = kw::clock();
 #endif
-                            if (n_stage + 64 > BK_SCAP) flush_stage();
-                            if (lane < done) { L.stage_idx[n_stage + lane] = first + tb + lane; L.stage_node[n_stage + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
-                            n_stage += done;
+                            if (lane < done) { b.t_node[first + tb + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
 #ifdef KAI_FILL_PROF
                             pcy[3] += kw::clock() - ps0;
 #endif
@@ -343,9 +336,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                             }
                         }
                         // the stretch's placements: the tasks' nodes for the apply kernels (one coalesced store) and the rollback list
-                        if (n_stage + 64 > BK_SCAP) flush_stage();
-                        if (lane < done) { L.stage_idx[n_stage + lane] = first + tb + lane; L.stage_node[n_stage + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
-                        n_stage += done;
+                        if (lane < done) { b.t_node[first + tb + lane] = my_node; L.placed_node[tb + lane] = my_node; L.placed_info[tb + lane] = my_info; }
                         placed += done;
                     }
 #ifdef KAI_FILL_PROF
@@ -359,7 +350,6 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                         }
                         if (placed) for (int k = 0; k < C; k++) { int g, n; bk_find(v, s2, kw::bcast(okslot, k), kw::bcast(q, k), g, n); finds++; if (lane == k) top = bk_key(g, n); }
                         rollbacks += 2;
-                        n_stage = job_stage0;  // (what a flush in the middle of the gang already wrote belongs to a job that failed: never read)
                     } else { committed++; ops += nt; }
                 }
 #ifdef KAI_FILL_PROF
@@ -369,7 +359,6 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                 { const bool me = lane == jj; my_out = me ? (ok ? BF_OK : BF_DEAD) : my_out; my_opoff = me ? opoff : my_opoff; my_stmt = me ? stmtoff : my_stmt; n_out = jj + 1; }
                 if ((flag == BF_OK) != ok) { mismatch = 1; break; }
             }
-            flush_stage();
             if (lane < n_out) { b.g_out[base + lane] = (uint8_t)my_out; b.g_opoff[base + lane] = my_opoff; b.g_stmt[base + lane] = my_stmt; }
         }
         const uint64_t dead = kw::ballot(act && top == BK_DEAD);

@@ -41,7 +41,8 @@ def test_resource_division_kat(case):
                                    p(prio, C.c_int), p(created, C.c_int64), p(out, C.c_double), C.byref(rem))
     assert rc == 0
     assert rem.value == case["remaining"], (case["name"], rem.value)
-    assert out.tolist() == [float(x) for x in case["fair"]], (case["name"], out.tolist())
+    for got, want in zip(out.tolist(), case["fair"]):  # (null: the reference's It does not look at that queue)
+        assert want is None or got == float(want), (case["name"], out.tolist())
 
 
 @pytest.mark.parametrize("case", NP["pack"], ids=[f"L{c['line']}" for c in NP["pack"]])
