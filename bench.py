@@ -46,8 +46,8 @@ def pmc_traffic(workload, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=os.environ.get("KAI_BENCH_CONFIG", "C5"), choices=sorted(CONFIGS))
     ap.add_argument("--scale", type=float, default=None, help="shrinks nodes and pods together (default 1.0; C4: 0.01 — measured on one MI355X: 10 %% of config 4 in 40 s, 30 %% with --queue-depth 8 in 55 s; full size is pinned against the oracle but not run on the device yet, DESIGN.md section 10.3)")
     ap.add_argument("--actions", default="", help="comma-separated actions of one cycle (default: allocate; C4: allocate,consolidation,reclaim)")
