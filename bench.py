@@ -280,7 +280,7 @@ def main():
                                          "ms_per_step": tw.elapsed_ms, "sample": "the full step", "ops_equal_to_gpu": [tuple(o) for o in tw.ops] == [tuple(o) for o in first_ops]}
         except Exception as e:  # the twin is optional evidence
             out["cpu_same_algorithm"] = {"error": str(e)[:200]}
-    if rank == 0 and world == 1 and os.environ.get("KAI_BENCH_OPEN_LEG", "1") != "0":
+    if rank == 0 and world == 1 and os.environ.get("KAI_BENCH_OPEN_LEG", "1" if elapsed / args.steps < 5.0 else "0") != "0":  # (not for cycles of many seconds: the leg repeats the cycle several times)
         # What a production scheduler pays per cycle: every cycle opens a session on a NEW snapshot (scheduler.go:112-138, framework/framework.go:32-65), so
         # kai_session_open — host preparation (node permutation, task / job orders, scan classes: on the host's cores), ~80 MB over PCIe, the OnSessionOpen
         # kernels — belongs to the cycle.  `value` above keeps the contract's definition (inputs resident in HBM); these two legs are reported beside it:
