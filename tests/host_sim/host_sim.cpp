@@ -550,3 +550,72 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; stats->reserved[4] = batch_actions; stats->reserved[5] = batch_rounds; stats->reserved[6] = bucket_actions; }
     return KAI_OK;
 }
+
+// ---- kai_victim_shard.hpp on its own (tests/test_dist_gloo.py::test_wave_exchange_protocol): R ranks in one process, the "all-gather" a memcpy between their send buffers.
+// mode 0: random waves — every rank must end with the identical merged wave, equal to what one rank running every simulation would hold (returns 0, or the failing check).
+// mode 1: rank `arg` leaves the protocol (its closing message with the fault flag) while the others are in a wave — they must see the fault, skip their own closing
+//         message, and every rank must have issued the same number of collectives.
+extern "C" int kai_hostsim_xw_selftest(int R, int cap_in, int mode, int arg, uint64_t seed) {
+    using namespace kai;
+    if (R < 1 || R > 16) return -1;
+    const int cap = xw_cap(cap_in);
+    auto rnd = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(seed >> 33); };
+    struct Rank { XShardHost xs; std::vector<int32_t> res; std::vector<int64_t> cnt; int32_t hdr[8]; int hit = 0, xrun = 0, fault = 0, rc = 0; const unsigned char* gathered = nullptr; };
+    std::vector<Rank> rk((size_t)R);
+    for (int r = 0; r < R; r++) { rk[r].xs.begin(R, r, cap_in); rk[r].res.assign(KAI_MW_WAVE, 0); rk[r].cnt.assign((size_t)KAI_MW_WAVE * KAI_MW_CNT, 0); }
+    // the exchange step for all ranks at once: phase 1 every rank packs (wave or closing message), phase 2 every rank merges the same R messages
+    std::vector<unsigned char> all(xw_msg_bytes(cap, R) * (size_t)R);
+    struct Io { Rank* me; std::vector<unsigned char>* all; int R; int phase;  // phase 0: publish the send buffer, report "not yet"; the driver below re-runs with phase 1
+        int pull(int32_t* hdr, int32_t* res, int64_t* cnt, int b, int cap) { std::memcpy(hdr, me->hdr, sizeof me->hdr); std::memcpy(res, me->res.data(), 4 * (size_t)cap); std::memcpy(cnt, me->cnt.data(), 8 * KAI_MW_CNT * (size_t)cap); (void)b; return 0; }
+        int push(int b, const int32_t* res, const int64_t* cnt, int cap, int hit, int xrun, int fault) { (void)b; std::memcpy(me->res.data(), res, 4 * (size_t)cap); std::memcpy(me->cnt.data(), cnt, 8 * KAI_MW_CNT * (size_t)cap); me->hit = hit; me->xrun = xrun; me->fault = fault; return 0; }
+        int allgather(const void* s, void* r, int64_t n) { if (phase == 0) { std::memcpy(all->data() + (size_t)me->xs.r * (size_t)n, s, (size_t)n); return 1; } std::memcpy(r, all->data(), (size_t)n * R); return 0; } };
+    auto exchange = [&](int b, const std::vector<int>& closing) {  // closing[r] = -1: rank r is in a wave; else its closing message with that fault flag; -2: takes no part (already gone)
+        for (int phase = 0; phase < 2; phase++) for (int r = 0; r < R; r++) {
+            if (closing[r] == -2) continue;
+            Io io{&rk[r], &all, R, phase};
+            XShardHost snap = rk[r].xs;  // phase 0 only publishes: run it on a copy so that the sequence number advances once
+            XShardHost& x = phase == 0 ? snap : rk[r].xs;
+            rk[r].rc = closing[r] == -1 ? x.wave(io, b) : x.finish(io, closing[r]);
+        }
+    };
+    if (mode == 0) {
+        for (int wave = 0; wave < 50; wave++) {
+            const int b = wave & 1, n_run = (int)(rnd() % (uint32_t)(cap + 1));  // simulations 0 .. n_run-1 of this wave were run by their owners
+            const int hit = (rnd() % 3) ? (int)(rnd() % (uint32_t)(n_run + 1)) : 0x7fffffff; const int true_hit = (hit < n_run) ? hit : 0x7fffffff;
+            std::vector<int32_t> ref_res(KAI_MW_WAVE, 0); std::vector<int64_t> ref_cnt((size_t)KAI_MW_WAVE * KAI_MW_CNT, 0);
+            for (int i = 0; i < n_run; i++) { ref_res[i] = (int32_t)(rnd() & 0x1ff); for (int k = 0; k < KAI_MW_CNT; k++) ref_cnt[(size_t)i * KAI_MW_CNT + k] = (int64_t)rnd() - 1000; }
+            for (int r = 0; r < R; r++) {
+                Rank& me = rk[r]; std::fill(me.res.begin(), me.res.end(), -7); std::fill(me.cnt.begin(), me.cnt.end(), -7);
+                int next = 0, own_hit = 0x7fffffff;
+                for (int i = r; i < n_run; i += R) { me.res[i] = ref_res[i]; for (int k = 0; k < KAI_MW_CNT; k++) me.cnt[(size_t)i * KAI_MW_CNT + k] = ref_cnt[(size_t)i * KAI_MW_CNT + k]; next++; if (i == true_hit) own_hit = i; }
+                next += (int)(rnd() % 3);  // engines whose last fetch found nothing to run
+                me.hdr[0] = 1; me.hdr[1] = 0; me.hdr[2] = me.hdr[3] = 0; me.hdr[4] = me.hdr[5] = next; me.hdr[6] = me.hdr[7] = own_hit;
+            }
+            exchange(b, std::vector<int>((size_t)R, -1));
+            for (int r = 0; r < R; r++) {
+                const Rank& me = rk[r];
+                if (me.rc) return 10 + r;
+                if (me.hit != true_hit || me.fault) return 100 + r;
+                if (true_hit == 0x7fffffff && me.xrun < std::min(n_run, cap)) return 200 + r;  // everything that was run counts when nothing hit
+                const int upto = true_hit != 0x7fffffff ? true_hit + 1 : std::min(std::min(me.xrun, n_run), cap);
+                for (int i = 0; i < upto; i++) { if (me.res[i] != ref_res[i]) return 300 + r; for (int k = 0; k < KAI_MW_CNT; k++) if (me.cnt[(size_t)i * KAI_MW_CNT + k] != ref_cnt[(size_t)i * KAI_MW_CNT + k]) return 400 + r; }
+            }
+        }
+        exchange(0, std::vector<int>((size_t)R, 0));
+        for (int r = 0; r < R; r++) { if (rk[r].rc) return 500 + r; if (rk[r].xs.exchanges != 51) return 600 + r; }
+        return 0;
+    }
+    // mode 1: two good waves, then rank `arg` is gone
+    for (int r = 0; r < R; r++) { Rank& me = rk[r]; me.hdr[0] = 1; me.hdr[1] = 0; me.hdr[4] = me.hdr[5] = 1; me.hdr[6] = me.hdr[7] = 0x7fffffff; }
+    exchange(0, std::vector<int>((size_t)R, -1)); exchange(1, std::vector<int>((size_t)R, -1));
+    std::vector<int> closing((size_t)R, -1); closing[arg % R] = 1;
+    exchange(0, closing);
+    for (int r = 0; r < R; r++) {
+        if (r == arg % R) { if (rk[r].rc != 0 && R > 1) return 700 + r; continue; }   // the rank that left: its closing message went out
+        if (rk[r].rc != 0 || !rk[r].fault) return 800 + r;                            // the others: the wave came back with the fault flag (their engines give up)
+        Io io{&rk[r], &all, R, 1};
+        if (rk[r].xs.finish(io, 1) != 0) return 900 + r;                              // ... and their own closing message is NOT sent any more
+    }
+    for (int r = 0; r < R; r++) if (rk[r].xs.exchanges != 3) return 1000 + r;          // the same number of collectives everywhere
+    return 0;
+}

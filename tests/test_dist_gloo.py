@@ -195,3 +195,21 @@ def test_victim_waves_over_the_ranks_of_a_group(world, engines, cap):
             assert exchanges == got[0][ci][6]     # the same number of collectives on every rank
             total_exchanges += exchanges
     assert total_exchanges > world * sum(sum(1 for a in acts if a != "allocate") for _, _, acts in _victim_cases())  # waves were exchanged, not only closing messages
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 3, 4, 8, 16])
+def test_wave_exchange_protocol(ranks):
+    """kai_victim_shard.hpp on its own (pack / merge / closing message), R ranks in one process: 50 random waves per seed — every rank ends with the identical merged wave,
+    equal to what one rank that ran every simulation would hold (hit = the lowest simulation that did not simply fail, every counted simulation's status and counters) —
+    and the fault path: a rank that leaves the protocol during the others' wave takes them out (fault flag in the merged wave, no further collective, the same number
+    of collectives on every rank)."""
+    sys.path.insert(0, HERE)
+    from test_engine_hostsim import HostSim
+    HostSim.lib()
+    fn = HostSim._raw.kai_hostsim_xw_selftest
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
+    for cap in (0, 1, 5, 64, 128, 1024, 5000):
+        for seed in range(1, 9):
+            assert fn(ranks, cap, 0, 0, seed) == 0, (ranks, cap, seed)
+        for gone in range(min(ranks, 4)):
+            assert fn(ranks, cap, 1, gone, 7) == 0, (ranks, cap, gone)
