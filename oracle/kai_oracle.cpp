@@ -1401,6 +1401,40 @@ int kai_oracle_greedy_match(const double* requirements, int n_req, const int32_t
     return orc::greedyMatchRequirements(req, h, [&](int x) { return capacity[x]; }) ? 1 : 0;
 }
 
+// The AccumulatedIdleGpus filter with its fields set by hand (idle_gpus_test.go: Test_orderedInsert :28-104, TestAccumulatedIdleGpus_updateWithVictim :201-305,
+// _updateStateWithScenario :307-945, _Filter :947-1384).  Nodes and pods are small integers; idle[n] = nodesNameToIdleGpus (NaN = the map has no such key).
+// mode 0: orderedInsert(sorted, value = v_node[0], replace = is_first) under the filter's comparator (idle descending); mode 1: updateWithVictim through
+// updateVictimList for the one victim (v_id[0], v_node[0], v_gpus[0]) — returns the new last node of the list; mode 2: updateStateWithScenario(scenario, is_first) →
+// 1 ok / 0 the reference's error; mode 3: Filter(scenario) → 1 valid / 0 not, *err = the update failed.  The scenario: pending (id, gpus), then n_pot potential and
+// n_rec recorded victims as (id, node, accepted gpus) in v_*.  The state afterwards comes back in the *_out arrays.
+int kai_oracle_idle_gpus_kat(int mode, int n_nodes, const double* idle, const int32_t* sorted, int n_sorted, const double* required, int n_required,
+                             const int32_t* pend_state, int n_ps, const int32_t* rec_cache, int n_rc, const int32_t* pot_cache, int n_pc,
+                             const int32_t* p_id, const double* p_gpus, int n_p, const int32_t* v_id, const int32_t* v_node, const double* v_gpus, int n_pot, int n_rec, int is_first,
+                             double* idle_out, int32_t* sorted_out, int32_t* n_sorted_out, int32_t* ps_out, int32_t* n_ps_out, int32_t* rc_out, int32_t* n_rc_out, int32_t* pc_out,
+                             int32_t* n_pc_out, int32_t* err) {
+    orc::AccumulatedIdleGpus ig;
+    for (int n = 0; n < n_nodes; n++) if (idle[n] == idle[n]) ig.nodesNameToIdleGpus[n] = idle[n];
+    ig.maxFreeGpuNodesSorted.assign(sorted, sorted + n_sorted); ig.requiredGpusSorted.assign(required, required + n_required);
+    ig.pendingTasksInState.insert(pend_state, pend_state + n_ps); ig.recordedVictimsInCache.insert(rec_cache, rec_cache + n_rc); ig.potentialVictimsInCache.insert(pot_cache, pot_cache + n_pc);
+    std::vector<orc::PodInfo> pods((size_t)(n_p + n_pot + n_rec));
+    orc::Scenario sc;
+    for (int i = 0; i < n_p; i++) { orc::PodInfo& p = pods[(size_t)i]; p.idx = p_id[i]; p.resReq.count = 1; p.resReq.portion = p_gpus[i]; sc.pendingTasks.push_back(&p); }
+    for (int i = 0; i < n_pot + n_rec; i++) {
+        orc::PodInfo& p = pods[(size_t)(n_p + i)]; p.idx = v_id[i]; p.node = v_node[i]; p.accepted.count = 1; p.accepted.portion = v_gpus[i]; p.resReq = p.accepted;
+        (i < n_pot ? sc.potentialVictimsTasks : sc.recordedVictimsTasks).push_back(&p);
+    }
+    int result = 0; if (err) *err = 0;
+    if (mode == 0) { ig.orderedInsert(v_node[0], is_first != 0); result = 1; }
+    else if (mode == 1) { std::set<int> cache; std::vector<orc::PodInfo*> one{&pods[(size_t)n_p]}; (void)ig.updateVictimList(one, cache); result = ig.maxFreeGpuNodesSorted.empty() ? -1 : ig.maxFreeGpuNodesSorted.back(); }
+    else if (mode == 2) result = ig.updateStateWithScenario(&sc, is_first != 0) ? 1 : 0;
+    else { bool e = false; result = ig.Filter(&sc, e) ? 1 : 0; if (err) *err = e ? 1 : 0; }
+    for (int n = 0; n < n_nodes; n++) { auto it = ig.nodesNameToIdleGpus.find(n); idle_out[n] = it == ig.nodesNameToIdleGpus.end() ? std::nan("") : it->second; }
+    *n_sorted_out = (int32_t)ig.maxFreeGpuNodesSorted.size(); for (size_t i = 0; i < ig.maxFreeGpuNodesSorted.size(); i++) sorted_out[i] = ig.maxFreeGpuNodesSorted[i];
+    auto dump = [](const std::set<int>& s, int32_t* out, int32_t* n) { *n = (int32_t)s.size(); int i = 0; for (int x : s) out[i++] = x; };
+    dump(ig.pendingTasksInState, ps_out, n_ps_out); dump(ig.recordedVictimsInCache, rc_out, n_rc_out); dump(ig.potentialVictimsInCache, pc_out, n_pc_out);
+    return result;
+}
+
 // actions/common/minimal_job_comparison.go on hand-built jobs of ONE scheduling signature (minimal_job_comparison_test.go): pods = rows of (pending 0/1, milli-cpu,
 // memory, gpus).  mode 0: UpdateRepresentative(rep), → IsEasierToSchedule(job); mode 1: UpdateRepresentative(rep), UpdateRepresentative(job) → job is the representative
 int kai_oracle_minimal_job(int mode, const double* rep, int n_rep, const double* job, int n_job) {

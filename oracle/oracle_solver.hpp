@@ -69,6 +69,7 @@ struct Scenario {
     std::map<int, std::vector<PodGroupInfo*>> victimsJobsTaskGroups;   // job index → representatives (clones)
     std::map<int, std::vector<int>> potentialVictimsJobsByNode;        // node index (-1 = no node) → job indices, first-seen order
 
+    Scenario() : ssn(nullptr), preemptor(nullptr) {}  // (task lists filled by hand: kai_oracle_idle_gpus_kat)
     Scenario(Session* s, PodGroupInfo* pendingJob, const std::vector<PodGroupInfo*>& recorded) : ssn(s), preemptor(pendingJob) {  // base_scenario.go:35-71
         pendingTasks = pendingJob->AllPods();
         for (auto* rj : recorded) { recordedVictimsJobs.push_back(rj); appendTasksAsVictimJob(rj->AllPods()); }
@@ -145,6 +146,7 @@ struct AccumulatedIdleGpus {
             if (i < int(ts.size())) ts[i] = t;
         } else ts.insert(ts.begin() + i, t);
     }
+    AccumulatedIdleGpus() = default;  // (the filter's fields set by hand: kai_oracle_idle_gpus_kat, the cases of idle_gpus_test.go)
     AccumulatedIdleGpus(Session* ssn, Scenario* sc) {  // NewIdleGpusFilter :53-71 + createGpuMap :176-196
         int relevantNodesLen = int(sc->pendingTasks.size()); double minRelevantValue = -1;
         for (auto& ni : ssn->nodes) {

@@ -309,3 +309,69 @@ def test_resource_quantities_comparisons_known_answers():
     U = -1.0
     for a, b, want in ((1.5, 2.5, -1), (2.5, 1.5, 1), (2.5, 2.5, 0), (U, 2.5, 1), (2.5, U, -1), (U, U, 0)):
         assert cmp(3, [a, 0, 0], [b, 0, 0]) - 1 == want
+
+
+# ------------------------------------------------------------------------------------------------ AccumulatedIdleGpus (idle_gpus_test.go), tools/go_kat_idle_gpus.py
+IG = _load("kat_idle_gpus.json")
+
+
+def _idle_gpus_run(mode, idle, sorted_nodes, required=(), pend_state=(), rec_cache=(), pot_cache=(), pending=(), potential=(), recorded=(), first=False, node_mem=None):
+    """names → small integers, one call of kai_oracle_idle_gpus_kat, the state afterwards back as names"""
+    lib = T.Oracle.lib(); lib.kai_oracle_idle_gpus_kat.restype = C.c_int
+    nodes = sorted(set(idle) | set(sorted_nodes) | {t["node"] for t in list(potential) + list(recorded) if t.get("node")})
+    pods = sorted(set(pend_state) | set(rec_cache) | set(pot_cache) | {t["uid"] for t in list(pending) + list(potential) + list(recorded)})
+    ni, pi = {n: i for i, n in enumerate(nodes)}, {p: i for i, p in enumerate(pods)}
+    N = max(len(nodes), 1)
+    idle_a = np.full(N, np.nan); [idle_a.__setitem__(ni[n], float(v)) for n, v in idle.items()]
+    i32 = lambda xs: np.array(list(xs) or [0], np.int32); f64 = lambda xs: np.array(list(xs) or [0.0], np.float64)
+    def accepted(t):  # a victim's AcceptedResource: its whole-device request, or its share of one device for a gpu-memory request (node_info.go setAcceptedResources)
+        return float(t["gpus"]) if "gpu_memory_mib" not in t else t["gpu_memory_mib"] / float(node_mem[t["node"]])
+    victims = list(potential) + list(recorded)
+    a_sorted, a_req = i32(ni[n] for n in sorted_nodes), f64(required)
+    a_ps, a_rc, a_pc = i32(pi[p] for p in pend_state), i32(pi[p] for p in rec_cache), i32(pi[p] for p in pot_cache)
+    a_pid, a_pg = i32(pi[t["uid"]] for t in pending), f64(t["gpus"] for t in pending)
+    a_vid, a_vn, a_vg = i32(pi[t["uid"]] for t in victims), i32(ni[t["node"]] if t.get("node") else -1 for t in victims), f64(accepted(t) for t in victims)
+    idle_o = np.zeros(N); sorted_o = np.zeros(N + 8, np.int32); ps_o = np.zeros(len(pods) + 8, np.int32); rc_o = np.zeros(len(pods) + 8, np.int32); pc_o = np.zeros(len(pods) + 8, np.int32)
+    n_s, n_ps, n_rc, n_pc, err = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    r = lib.kai_oracle_idle_gpus_kat(mode, len(nodes), p(idle_a, C.c_double), p(a_sorted, C.c_int32), len(sorted_nodes), p(a_req, C.c_double), len(required),
+                                     p(a_ps, C.c_int32), len(pend_state), p(a_rc, C.c_int32), len(rec_cache), p(a_pc, C.c_int32), len(pot_cache),
+                                     p(a_pid, C.c_int32), p(a_pg, C.c_double), len(pending), p(a_vid, C.c_int32), p(a_vn, C.c_int32), p(a_vg, C.c_double), len(potential), len(recorded), int(first),
+                                     p(idle_o, C.c_double), p(sorted_o, C.c_int32), C.byref(n_s), p(ps_o, C.c_int32), C.byref(n_ps), p(rc_o, C.c_int32), C.byref(n_rc), p(pc_o, C.c_int32), C.byref(n_pc), C.byref(err))
+    state = {"idle": {nodes[i]: float(idle_o[i]) for i in range(len(nodes)) if not np.isnan(idle_o[i])}, "sorted": [nodes[i] for i in sorted_o[:n_s.value]],
+             "pending_in_state": sorted(pods[i] for i in ps_o[:n_ps.value]), "recorded_in_cache": sorted(pods[i] for i in rc_o[:n_rc.value]), "potential_in_cache": sorted(pods[i] for i in pc_o[:n_pc.value])}
+    return r, bool(err.value), state, nodes
+
+
+@pytest.mark.parametrize("case", IG["ordered_insert"], ids=[f"L{c['line']}" for c in IG["ordered_insert"]])
+def test_idle_gpus_ordered_insert(case):
+    """orderedInsert under cmp.Compare[string] = the filter's comparator (idle descending) with idle = minus the string's rank"""
+    names = sorted(set(case["array"]) | {case["value"]})
+    idle = {n: -float(i) for i, n in enumerate(names)}
+    _, _, st, _ = _idle_gpus_run(0, idle, case["array"], potential=[{"uid": "v", "node": case["value"], "gpus": 0}], first=case["replace"])
+    assert st["sorted"] == case["want"]
+
+
+@pytest.mark.parametrize("case", IG["update_with_victim"], ids=[f"L{c['line']}" for c in IG["update_with_victim"]])
+def test_idle_gpus_update_with_victim(case):
+    r, _, st, nodes = _idle_gpus_run(1, case["idle"], case["sorted"], potential=[case["victim"]])
+    assert nodes[r] == case["want_min_relevant"] and st["sorted"] == case["want_sorted"]
+
+
+@pytest.mark.parametrize("case", IG["update_state"], ids=[f"L{c['line']}" for c in IG["update_state"]])
+def test_idle_gpus_update_state_with_scenario(case):
+    f, sc, w = case["fields"], case["scenario"], case["want"]
+    r, _, st, _ = _idle_gpus_run(2, f["idle"], f["sorted"], f["required"], f["pending_in_state"], f["recorded_in_cache"], f["potential_in_cache"],
+                                 sc["pending"], sc["potential_victims"], sc["recorded_victims"], first=case["first"])
+    assert (r == 0) == w["err"], case["name"]
+    for k in ("idle", "sorted", "pending_in_state", "recorded_in_cache", "potential_in_cache"):  # (the reference's test compares the fields its `want` names)
+        if k in w:
+            assert st[k] == w[k], (case["name"], k, st[k])
+
+
+@pytest.mark.parametrize("case", IG["filter"], ids=[f"L{c['line']}" for c in IG["filter"]])
+def test_idle_gpus_filter(case):
+    f, sc, w = case["fields"], case["scenario"], case["want"]
+    r, err, _, _ = _idle_gpus_run(3, f["idle"], f["sorted"], f["required"], f["pending_in_state"], f["recorded_in_cache"], f["potential_in_cache"],
+                                  sc["pending"], sc["potential_victims"], sc["recorded_victims"], node_mem=sc.get("node_gpu_memory_mib"))
+    assert err == w["err"] and bool(r) == w["valid"], case["name"]
