@@ -1540,6 +1540,28 @@ int kai_oracle_subset_nodes(const kai_config* cfg, const kai_snapshot_soa* snap,
     int n = 0; for (auto* nd : sets[0]) { if (n < cap) out[n] = nd->idx; n++; }
     return n;
 }
+// … and what calcTreeAllocatable left in the tree (job_filtering_test.go TestTopologyPlugin_calcTreeAllocatable :979-1448): per domain of the job's topology its
+// AllocatablePods (-1 = allocatablePodsNotSet) and its nodes as a 0/1 row of `member` [cap_domains][n_nodes] → the number of domains written (root domain included)
+int kai_oracle_tree_allocatable(const kai_config* cfg, const kai_snapshot_soa* snap, int job, int32_t* pods_out, uint8_t* member, int cap_domains) {
+    if (!cfg || !snap || !pods_out || !member || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    orc::PodGroupInfo* j = &ssn.jobs[job];
+    orc::SubGroupSet* sgs = &ssn.groups[j->rootGroup];
+    std::vector<orc::PodSet*> under; ssn.allPodSets(j, sgs, under);
+    std::vector<orc::PodInfo*> tasks = ssn.GetTasksToAllocate(j, true);
+    std::vector<orc::NodeInfo*> all; for (auto& n : ssn.nodes) all.push_back(&n);
+    std::vector<std::vector<orc::NodeInfo*>> sets;
+    (void)ssn.SubsetNodesFn(j, sgs->idx, sgs->tc, under, tasks, all, sets);
+    const int N = int(ssn.nodes.size()); int n = 0;
+    for (auto& d : ssn.domains) {
+        if (n >= cap_domains) return KAI_ERR_CAPACITY;
+        pods_out[n] = d.AllocatablePods;
+        for (int k = 0; k < N; k++) member[size_t(n) * N + k] = 0;
+        for (int k : d.nodes) member[size_t(n) * N + k] = 1;
+        n++;
+    }
+    return n;
+}
 // … and the preferred-level node scores the call leaves behind for the node order (node_scoring.go:37-69): out[n] = score of node n, -1 = no score recorded
 int kai_oracle_topology_scores(const kai_config* cfg, const kai_snapshot_soa* snap, int job, double* out) {
     if (!cfg || !snap || !out || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;

@@ -195,3 +195,37 @@ def test_gpu_scenes_allocate(scene):
     from test_gpu_parity import run_gpu
     snap, cfg = SCENES[scene]()
     _same(run_gpu(snap, cfg, ("allocate",)), T.Oracle.run(snap, cfg, ("allocate",)))
+
+
+# job_filtering_test.go TestTopologyPlugin_calcTreeAllocatable (:979-1448): AllocatablePods of every domain after the roll-up.  The Go cases hand a hand-built tree to
+# calcTreeAllocatable; here the tree comes from the nodes' labels and the job asks for the zone (the tree's top level), so the same roll-up runs inside subSetNodesFn.
+TREE_CASES = [  # (line, name, cores per task, tasks, nodes {name: (cores, zone, rack)}, expected {frozenset of node names: AllocatablePods})
+    (1043, "parent takes child values when children can allocate full job", 500, 2, {"node-1": (1000, "zone1", "rack1"), "node-2": (1000, "zone1", "rack2")},
+     {("node-1",): 2, ("node-2",): 2, ("node-1", "node-2"): 4}),
+    (1096, "children cannot allocate full job individually - parent sums allocations", 800, 2, {"node-1": (1000, "zone1", "rack1"), "node-2": (1000, "zone1", "rack2")},
+     {("node-1",): 1, ("node-2",): 1, ("node-1", "node-2"): 2}),
+    (1149, "mixed distances - parent takes minimum distance", 500, 2, {"node-1": (500, "zone1", "rack1"), "node-2": (500, "zone1", "rack1"), "node-3": (1000, "zone1", "rack2")},
+     {("node-1", "node-2"): 2, ("node-3",): 2, ("node-1", "node-2", "node-3"): 4}),
+    (1208, "no leaf domains - no allocatable domains", 2000, 1, {"node-1": (1000, "zone1", None)}, {("node-1",): 0}),
+]
+
+
+@pytest.mark.parametrize("line,name,cpu,n_tasks,nodes,want", TREE_CASES, ids=[f"{c[0]}" for c in TREE_CASES])
+def test_calc_tree_allocatable(line, name, cpu, n_tasks, nodes, want):
+    two_levels = any(r for _, _, r in nodes.values())
+    topo = TOPO if two_levels else [{"ObjectMeta": {"Name": "test-topology"}, "Spec": {"Levels": [{"NodeLabel": "zone"}]}}]
+    root = {"Name": "", "PodSets": [], "SubGroups": [], "TopologyConstraint": {"Topology": "test-topology", "RequiredLevel": "zone", "PreferredLevel": ""}}
+    case = {"Name": name, "Nodes": {k: N(c, z, r) for k, (c, z, r) in nodes.items()}, "Topologies": topo, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": cpu, "RootSubGroupSet": root, "Tasks": [{"State": "Pending"}] * n_tasks}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    lib = T.Oracle.lib(); lib.kai_oracle_tree_allocatable.restype = C.c_int
+    nn = snap.n_nodes; pods = np.zeros(32, np.int32); member = np.zeros(32 * nn, np.uint8); s = snap.as_struct()
+    nd = lib.kai_oracle_tree_allocatable(C.byref(cfg), C.byref(s), snap.job_names.index("test-job"), pods.ctypes.data_as(C.POINTER(C.c_int32)), member.ctypes.data_as(C.POINTER(C.c_uint8)), 32)
+    assert nd > 0, nd
+    got = {}
+    for d in range(nd):
+        names = tuple(sorted(snap.node_names[k] for k in range(nn) if member[d * nn + k]))
+        if names and int(pods[d]) != -1: got.setdefault(names, set()).add(int(pods[d]))  # (-1 = allocatablePodsNotSet: the root domain above the zone the roll-up started at)
+    for names, n in want.items():
+        assert got.get(tuple(sorted(names))) == {n}, (name, names, got)
