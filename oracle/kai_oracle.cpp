@@ -1009,6 +1009,7 @@ bool Session::SubsetNodesFn(PodGroupInfo* job, int key, const TopologyConstraint
         if (tc.preferred == l) break;  // no reason to look below the preferred level
     }
     DomainInfo* domain = &domains[domainId];
+    lastCommonDomain = domainId; lastValidNodes.clear(); for (auto* n : validNodes) lastValidNodes.push_back(n->idx);
     // treeAllocatableCleanup :438-445
     for (auto& d : domains) if (d.topo == t) { d.AllocatablePods = -1; d.IdleOrReleasingResources = Resource(); }
     // calcSubTreeFreeResources :192-211
@@ -1539,6 +1540,26 @@ int kai_oracle_subset_nodes(const kai_config* cfg, const kai_snapshot_soa* snap,
     if (sets.empty()) return -2;
     int n = 0; for (auto* nd : sets[0]) { if (n < cap) out[n] = nd->idx; n++; }
     return n;
+}
+// … and what lowestCommonDomainID returned (plugins/topology/common.go:17-67; common_test.go TestLowestCommonDomainID): the domain's level inside the topology (-1 = the
+// root domain), its nodes as 0/1 in member_out[n], the valid nodes as 0/1 in valid_out[n] → 0, or -1 when the call never got there
+int kai_oracle_lowest_common_domain(const kai_config* cfg, const kai_snapshot_soa* snap, int job, int32_t* level_out, uint8_t* member_out, uint8_t* valid_out) {
+    if (!cfg || !snap || !level_out || !member_out || !valid_out || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    orc::PodGroupInfo* j = &ssn.jobs[job];
+    orc::SubGroupSet* sgs = &ssn.groups[j->rootGroup];
+    std::vector<orc::PodSet*> under; ssn.allPodSets(j, sgs, under);
+    std::vector<orc::PodInfo*> tasks = ssn.GetTasksToAllocate(j, true);
+    std::vector<orc::NodeInfo*> all; for (auto& n : ssn.nodes) all.push_back(&n);
+    std::vector<std::vector<orc::NodeInfo*>> sets;
+    (void)ssn.SubsetNodesFn(j, sgs->idx, sgs->tc, under, tasks, all, sets);
+    if (ssn.lastCommonDomain < 0) return -1;
+    const orc::DomainInfo& d = ssn.domains[ssn.lastCommonDomain];
+    *level_out = d.level;
+    for (size_t n = 0; n < ssn.nodes.size(); n++) { member_out[n] = 0; valid_out[n] = 0; }
+    for (int n : d.nodes) member_out[n] = 1;
+    for (int n : ssn.lastValidNodes) valid_out[n] = 1;
+    return 0;
 }
 // … and what calcTreeAllocatable left in the tree (job_filtering_test.go TestTopologyPlugin_calcTreeAllocatable :979-1448): per domain of the job's topology its
 // AllocatablePods (-1 = allocatablePodsNotSet) and its nodes as a 0/1 row of `member` [cap_domains][n_nodes] → the number of domains written (root domain included)

@@ -69,6 +69,7 @@ struct Session {
     int nTopologies = 0; std::vector<int> topoLevelOff, nodeDomain; std::vector<DomainInfo> domains;  // domains[D + t] = root domain of topology t
     int nRealDomains = 0;
     std::map<int, std::map<int, double>> subGroupNodeScores;  // key: group idx, or -(podset idx + 1)
+    int lastCommonDomain = -2; std::vector<int> lastValidNodes;  // what lowestCommonDomainID returned in the last SubsetNodesFn (read by kai_oracle_lowest_common_domain: common_test.go)
     std::vector<uint8_t> classFit; int nPodClasses = 0, nNodeClasses = 0;
     bool hasSignatures = false;  // the snapshot carries job_signature
     // proportion plugin state (plugins/proportion/proportion.go:52-65)

@@ -229,3 +229,34 @@ def test_calc_tree_allocatable(line, name, cpu, n_tasks, nodes, want):
         if names and int(pods[d]) != -1: got.setdefault(names, set()).add(int(pods[d]))  # (-1 = allocatablePodsNotSet: the root domain above the zone the roll-up started at)
     for names, n in want.items():
         assert got.get(tuple(sorted(names))) == {n}, (name, names, got)
+
+
+# plugins/topology/common_test.go TestLowestCommonDomainID (:66-166) and TestIsNodePartOfTopology (:25-64): levels zone, rack; a node that misses a level label is outside the
+# topology (the packers apply that rule when they build node_domain: kai_testlib.py, kai_ingest.cpp, shim/kai_cgo_classes.go).  Expected: the level of the common domain
+# ("rack" / "zone" / root), the nodes that share it (what the ID z1.r1 stands for) and the valid nodes.
+LCD_CASES = [  # (line, name, nodes {name: labels}, preferred level, expected level, expected ID parts, expected valid nodes)
+    (81, "all nodes share full topology", {"node-1": {"zone": "z1", "rack": "r1"}, "node-2": {"zone": "z1", "rack": "r1"}}, "", "rack", ("z1", "r1"), ["node-1", "node-2"]),
+    (92, "all nodes share full topology - but the preferred level is zone", {"node-1": {"zone": "z1", "rack": "r1"}, "node-2": {"zone": "z1", "rack": "r1"}}, "zone", "zone", ("z1",), ["node-1", "node-2"]),
+    (105, "mismatch at deeper level returns common prefix", {"node-1": {"zone": "z1", "rack": "r1"}, "node-2": {"zone": "z1", "rack": "r2"}}, "", "zone", ("z1",), ["node-1", "node-2"]),
+    (116, "mismatch at first level returns root", {"node-1": {"zone": "z1", "rack": "r1"}, "node-2": {"zone": "z2", "rack": "r1"}}, "", "root", (), ["node-1", "node-2"]),
+    (127, "invalid nodes are filtered out", {"node-1": {"zone": "z1", "rack": "r1"}, "node-2": {"zone": "z1"}}, "", "rack", ("z1", "r1"), ["node-1"]),
+    (138, "no valid nodes returns root and empty map", {"node-1": {"zone": "z1"}}, "", "root", (), []),
+]
+
+
+@pytest.mark.parametrize("line,name,nodes,pref,want_level,want_id,want_valid", LCD_CASES, ids=[f"{c[0]}" for c in LCD_CASES])
+def test_lowest_common_domain(line, name, nodes, pref, want_level, want_id, want_valid):
+    root = {"Name": "", "PodSets": [], "SubGroups": [], "TopologyConstraint": {"Topology": "test-topology", "RequiredLevel": "", "PreferredLevel": pref}}
+    case = {"Name": name, "Nodes": {k: {"CPUMillis": 1000, "GPUs": 6, "MaxTaskNum": 100, "Labels": lb} for k, lb in nodes.items()}, "Topologies": TOPO, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+            "Jobs": [{"Name": "test-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 100, "RootSubGroupSet": root, "Tasks": [{"State": "Pending"}]}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(case)
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    lib = T.Oracle.lib(); lib.kai_oracle_lowest_common_domain.restype = C.c_int
+    nn = snap.n_nodes; level = C.c_int32(-7); member = np.zeros(nn, np.uint8); valid = np.zeros(nn, np.uint8); s = snap.as_struct()
+    rc = lib.kai_oracle_lowest_common_domain(C.byref(cfg), C.byref(s), snap.job_names.index("test-job"), C.byref(level), member.ctypes.data_as(C.POINTER(C.c_uint8)), valid.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert rc == 0, rc
+    assert {snap.node_names[k] for k in range(nn) if valid[k]} == set(want_valid)
+    assert level.value == {"root": -1, "zone": 0, "rack": 1}[want_level]
+    if want_id:  # the domain z1(.r1) = the nodes that carry those label values on every level
+        in_domain = {k for k, lb in nodes.items() if len(lb) == 2 and tuple(lb[l] for l in ("zone", "rack"))[:len(want_id)] == want_id}
+        assert {snap.node_names[k] for k in range(nn) if member[k]} == in_domain
