@@ -57,6 +57,19 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="decisions the CPU oracle is timed on (-1 = auto, 0 = skip)")
     args = ap.parse_args()
 
+    # `--gpus N` launched plainly (no WORLD_SIZE): one rank per GPU is the contract, so the script starts itself under torch.distributed.run — a line that says
+    # n_gpus N always comes from N ranks; a mismatch between --gpus and the launcher's world size is refused instead of reported
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and env_world == 0:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+    if env_world and env_world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {env_world} rank(s): refusing to report a line for another world size")
+
     import numpy as np
     import torch
 

@@ -38,6 +38,8 @@ struct kai_core {
     bool solver_ready = false;  // scratch of the victim search allocated (first reclaim / preempt / consolidation of the session)
     std::vector<void*> bufs; std::vector<size_t> buf_bytes;  // session HBM: a few large slabs, sub-allocated (one contiguous range ⇒ few TLB entries for the latency-bound engine)
     std::vector<std::pair<void*, size_t>> spare;  // slabs of closed sessions, reused by the next open
+    bool index_stale = false;  // the last action ran on the bucket fill, which keeps the sets current but not the class index (sum1_key / sum1_node): rebuilt before the next action reads it
+    void* rep_buf = nullptr; size_t rep_buf_bytes = 0;  // the victim actions' replica memory: its own allocation (never part of the slab bookkeeping), kept between sessions while it is large enough
     void* pin_buf = nullptr; size_t pin_bytes = 0;  // pinned host staging for the operations handed to the caller (grows, lives with the handle)
     char* slab = nullptr; size_t slab_left = 0;
     // device-only helpers
@@ -88,7 +90,10 @@ int dalloc(kai_core* core, T** out, size_t n) {
         void* p = nullptr;
         // a slab of the previous session first: a scheduler opens a session per cycle (scheduler.go:112-138), and hipFree + hipMalloc of a few 256 MiB
         // slabs per cycle would be milliseconds of every one of them
-        for (size_t i = 0; i < core->spare.size(); i++) if (core->spare[i].second >= want) { p = core->spare[i].first; want = core->spare[i].second; core->spare.erase(core->spare.begin() + (long)i); break; }
+        // (the smallest one that is large enough; what an open leaves unused is released at its end, trim_spare)
+        { size_t best = core->spare.size();
+          for (size_t i = 0; i < core->spare.size(); i++) if (core->spare[i].second >= want && (best == core->spare.size() || core->spare[i].second < core->spare[best].second)) best = i;
+          if (best != core->spare.size()) { p = core->spare[best].first; want = core->spare[best].second; core->spare.erase(core->spare.begin() + (long)best); } }
         if (!p) HIP_TRY(core, hipMalloc(&p, want));
         core->bufs.push_back(p); core->buf_bytes.push_back(want);
         core->slab = static_cast<char*>(p); core->slab_left = want;
@@ -176,7 +181,7 @@ void free_session(kai_core* core, bool release = false) {
     // the slabs stay with the handle for the next session (dalloc takes them back); kai_core_destroy releases them
     for (size_t i = 0; i < core->bufs.size(); i++) core->spare.push_back({core->bufs[i], core->buf_bytes[i]});
     core->bufs.clear(); core->buf_bytes.clear(); core->slab = nullptr; core->slab_left = 0;
-    if (release) { for (auto& sp : core->spare) (void)hipFree(sp.first); core->spare.clear(); }
+    if (release) { for (auto& sp : core->spare) (void)hipFree(sp.first); core->spare.clear(); if (core->rep_buf) (void)hipFree(core->rep_buf); core->rep_buf = nullptr; core->rep_buf_bytes = 0; }
     core->allocs.clear(); core->sv_base = nullptr; core->xr_base = nullptr; core->mw_world = 0; core->rep_mem = nullptr; core->d_ctxs = nullptr; core->d_mw = nullptr; core->d_segs = nullptr; core->d_sg = nullptr;
     core->open = false;
 }
@@ -375,9 +380,15 @@ int prepare_multi(kai_core* core, int G, int* g_out) {
         auto add = [&](const char* src, size_t bytes) { bytes = up(bytes); for (size_t o = 0; o < bytes; o += REP_CHUNK) segs.push_back({src + o, (unsigned long long)(total + o), (unsigned long long)std::min(REP_CHUNK, bytes - o)}); total += bytes; };
         for (const auto& a : core->allocs) add(a.base, a.bytes);
         add(core->sv_base, core->sv_bytes); add(core->xr_base, core->xr_bytes);
-        void* mem = nullptr;
-        if (hipMalloc(&mem, total * (size_t)(G - 1)) != hipSuccess) { (void)hipGetLastError(); if (c.mw_xworld > 1) { core->err = "victim action of a node-sharded group: no memory for the replicas (every rank must run the same number of engines)"; return KAI_ERR_HIP; } return KAI_OK; }
-        core->bufs.push_back(mem); core->rep_mem = static_cast<char*>(mem); core->rep_stride = total;
+        const size_t need = total * (size_t)(G - 1);
+        if (core->rep_buf_bytes < need) {  // the replicas of the previous session serve again while they are large enough
+            if (core->rep_buf) (void)hipFree(core->rep_buf);
+            core->rep_buf = nullptr; core->rep_buf_bytes = 0;
+            void* mem = nullptr;
+            if (hipMalloc(&mem, need) != hipSuccess) { (void)hipGetLastError(); if (c.mw_xworld > 1) { core->err = "victim action of a node-sharded group: no memory for the replicas (every rank must run the same number of engines)"; return KAI_ERR_HIP; } return KAI_OK; }
+            core->rep_buf = mem; core->rep_buf_bytes = need;
+        }
+        core->rep_mem = static_cast<char*>(core->rep_buf); core->rep_stride = total;
         RepSeg* dsegs = nullptr; KaiCtx* dctx = nullptr; MultiCtx* dmw = nullptr;
         int rc = dalloc(core, &dsegs, segs.size()); if (rc) return rc;
         rc = dalloc(core, &dctx, (size_t)G); if (rc) return rc;
@@ -492,7 +503,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     // ---- index structures (pure re-orderings / groupings of the input; kai_host_prep.hpp)
     const auto t_shared = tnow();
     HostPrep prep;
-    if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG;
+    try { if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG; }
+    catch (const std::exception& e) { core->err = std::string("host preparation: ") + e.what(); return KAI_ERR_INVALID_ARG; }  // (std::bad_alloc of a worker thread included: kai_parallel.hpp carries it here)
     const auto t_prep = tnow();
     for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
         if (s->pod_flags && (s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
@@ -647,7 +659,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     HIP_TRY(core, hipMemcpyAsync(core->d_shares0, KAI_VP(c.q_share), (size_t)std::max(Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
     { KaiCtx* t = nullptr; int rc3 = dalloc(core, &t, (size_t)1); if (rc3) return rc3; core->d_ctx = t; }
     HIP_TRY(core, hipMemcpyAsync(core->d_ctx, &core->ctx, sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
-    { int rc2 = launch_open_kernels(core); if (rc2) return rc2; }
+    { int rc2 = launch_open_kernels(core); if (rc2) return rc2; core->index_stale = false; }
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
     const auto t_enq = tnow();
     HIP_TRY(core, hipStreamSynchronize(core->stream));  // prep's host buffers die with this scope
@@ -656,6 +668,11 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));
     std::memset(&core->stats, 0, sizeof(core->stats));
     core->stats.upload_ms = ms;
+    // slabs of earlier (larger) sessions this open did not take: keep two for what the session's actions still allocate (solver scratch, batch pools), release the rest
+    if (core->spare.size() > 2) {
+        std::sort(core->spare.begin(), core->spare.end(), [](const std::pair<void*, size_t>& a, const std::pair<void*, size_t>& b) { return a.second < b.second; });
+        while (core->spare.size() > 2) { (void)hipFree(core->spare.back().first); core->spare.pop_back(); }
+    }
     core->open = true; core->err = "ok";
     return KAI_OK;
 }
@@ -681,6 +698,7 @@ int kai_session_reset(kai_core* core) {
     if (core->solver_ready) HIP_TRY(core, hipMemsetAsync(c.sv.xr_key, 0xFF, sizeof(int64_t) * ((size_t)c.sv.xr_mask + 1), core->stream));
     HIP_TRY(core, hipMemsetAsync(KAI_VP(c.st), 0, sizeof(EngineState), core->stream));
     int rc = launch_open_kernels(core); if (rc) return rc;
+    core->index_stale = false;
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
     HIP_TRY(core, hipStreamSynchronize(core->stream));
     float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));
@@ -736,6 +754,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
     HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.st), &st, sizeof(st), hipMemcpyHostToDevice, core->stream));
     HIP_TRY(core, hipEventRecord(core->ev0, core->stream));
     const int TB = 256;
+    if (core->index_stale) { if (c.use_index && c.NB) hipLaunchKernelGGL(k_index_build, dim3((c.NB + 3) / 4), dim3(TB), 0, core->stream, c); core->index_stale = false; }
     if (c.J) hipLaunchKernelGGL(k_job_init, dim3((c.J + TB - 1) / TB), dim3(TB), 0, core->stream, c);
     if (c.Q) hipLaunchKernelGGL(k_leaf_init, dim3((c.Q + 3) / 4), dim3(TB), 0, core->stream, c);
     BatchStats bs; core->batch_plan_ms = core->batch_fill_ms = core->batch_apply_ms = 0; int g_run = 1, scan_wgs_used = 1; bool xsh = false;
@@ -743,6 +762,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         DevLauncher dl{core};
         int rcb = batch_allocate(dl, c, core->shape, bs);
         if (rcb) { if (core->err == "ok") core->err = "batch path failed"; return rcb; }
+        if (bs.ran && bs.buckets) core->index_stale = true;
         if (bs.ran) {
             EngineState sb{};
             HIP_TRY(core, hipMemcpyAsync(&sb, KAI_VP(c.st), sizeof(sb), hipMemcpyDeviceToHost, core->stream));

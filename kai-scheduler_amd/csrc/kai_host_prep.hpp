@@ -155,6 +155,14 @@ struct HostPrep {
         sorted.resize(P);
         const bool taskorder = cfg.plugins & KAI_PLUGIN_TASKORDER;
         for (int j = 0; j < J; j++) { int b = s->job_first_pod[j], n = s->job_n_pods[j]; if (b < 0 || n < 0 || b + n > P) return fail("job pod range out of bounds"); }
+        {   // … and disjoint: the per-job sorts below run on the host's cores, two jobs over one slice of `sorted` would race (jobs in pod order is the usual case, checked in O(J))
+            bool mono = true; int end = 0;
+            for (int j = 0; j < J && mono; j++) { const int b = s->job_first_pod[j], n = s->job_n_pods[j]; if (n == 0) continue; if (b < end) mono = false; end = b + n; }
+            if (!mono) {
+                std::vector<char> own((size_t)P, 0);
+                for (int j = 0; j < J; j++) for (int b = s->job_first_pod[j], i = 0; i < s->job_n_pods[j]; i++) { if (own[(size_t)b + i]) return fail("job pod ranges overlap"); own[(size_t)b + i] = 1; }
+            }
+        }
         parallel_chunks((size_t)P, [&](int, size_t p0, size_t p1) { for (size_t p = p0; p < p1; p++) sorted[p] = (int32_t)p; });
         parallel_chunks((size_t)J, [&](int, size_t j0, size_t j1) {
             for (size_t j = j0; j < j1; j++) {

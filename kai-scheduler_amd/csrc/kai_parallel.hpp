@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <exception>
 #include <memory>
 #include <new>
 #include <thread>
@@ -30,9 +31,13 @@ inline void parallel_chunks(size_t n, F&& f, size_t min_chunk = 16384) {
     if (k <= 1) { f(0, (size_t)0, n); return; }
     std::vector<std::thread> th; th.reserve((size_t)k - 1);
     auto bound = [&](int i) { return (size_t)((unsigned __int128)n * (unsigned)i / (unsigned)k); };
-    for (int i = 1; i < k; i++) th.emplace_back([&, i] { f(i, bound(i), bound(i + 1)); });
-    f(0, bound(0), bound(1));
+    // an exception in a worker (std::bad_alloc) would end the process there: it is carried to the calling thread and rethrown after the join
+    std::vector<std::exception_ptr> err((size_t)k);
+    auto run = [&](int i) { try { f(i, bound(i), bound(i + 1)); } catch (...) { err[(size_t)i] = std::current_exception(); } };
+    for (int i = 1; i < k; i++) th.emplace_back([&, i] { run(i); });
+    run(0);
     for (auto& t : th) t.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 // std::vector whose resize() leaves new elements uninitialised (trivial types only): the parallel loop that follows writes every element, so the

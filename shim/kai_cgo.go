@@ -501,15 +501,19 @@ func replay(ssn *framework.Session, action framework.ActionType, pack *packedSna
 		// EvictionMetadata of the Statement's evictions (actions/common/action.go:34-38): the gang = every task the solution evicts, the preemptor = the job the
 		// Statement pipelines / allocates.  A Statement of a victim action holds one solution: "evict ..., pipeline the preemptor's tasks" (framework/statement.go:536-575).
 		meta := eviction_info.EvictionMetadata{Action: string(action)}
+		// The jobs re-placed behind the evictions are the victims' jobs AND the preemptor, in job order (actions/common/action.go:65-122), so the first pipelined task can be
+		// a victim's: the preemptor is the job of a placed task that was Pending when the Statement began and that this Statement does not evict.
 		var preemptor *podgroup_info.PodGroupInfo
+		evicted := map[C.int32_t]bool{}
 		for k := i; k < len(ops) && ops[k].stmt == id; k++ {
-			switch ops[k].kind {
-			case C.KAI_OP_EVICT:
+			if ops[k].kind == C.KAI_OP_EVICT {
 				meta.EvictionGangSize++
-			case C.KAI_OP_ALLOCATE, C.KAI_OP_PIPELINE:
-				if preemptor == nil {
-					preemptor = ssn.ClusterInfo.PodGroupInfos[pack.pods[ops[k].pod].Job]
-				}
+				evicted[ops[k].pod] = true
+			}
+		}
+		for k := i; k < len(ops) && ops[k].stmt == id && preemptor == nil; k++ {
+			if (ops[k].kind == C.KAI_OP_ALLOCATE || ops[k].kind == C.KAI_OP_PIPELINE) && !evicted[ops[k].pod] && pack.pods[ops[k].pod].Status == pod_status.Pending {
+				preemptor = ssn.ClusterInfo.PodGroupInfos[pack.pods[ops[k].pod].Job]
 			}
 		}
 		messages := map[int]string{} // getEvictionMessages: every message from the state BEFORE the first eviction (actions/common/action.go:51-60)

@@ -450,10 +450,12 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     std::vector<Rep> reps;
     HostBackend be; Engine<HostBackend> eng(c, be);
     int64_t batch_rounds = 0, batch_actions = 0, bucket_actions = 0;
+    bool index_stale = false;
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;
         if (actions[i] != KAI_ACTION_ALLOCATE && cfg->use_scheduling_signatures && !s->job_signature && J > 0) return KAI_ERR_UNSUPPORTED;
         c.action = actions[i]; { int d = cfg->queue_depth[actions[i]]; c.queue_depth = d > 0 ? d : 0; }
+        if (index_stale) { if (c.use_index) for (int b = 0; b < c.NB; b++) for (int k = 0; k < c.C; k++) HostBackend::build_block(c, k, b); index_stale = false; }  // as kai_action_execute: the bucket fill keeps the sets current, not the class index
         for (int j = 0; j < J; j++) { c.j_state[j] = job_init_state(c, j); if (c.j_state[j] != 3 && c.j_n_ps[j] <= 64) eng.ensure_tta(j, true); }  // k_job_init
         for (int q = 0; q < Q; q++) {                                      // k_leaf_init
             int b = c.q_job_off[q], e = c.q_job_off[q + 1], cnt = 0; c.lq_side_len[q] = 0;
@@ -514,6 +516,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             if (bs.ran) {
                 c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops; c.st->stmts += bs.committed;
                 c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++; bucket_actions += bs.buckets;
+                if (bs.buckets) index_stale = true;
                 g_sh_exchanges = bs.exchanges;
             } else {
                 // a node-sharded group shards the batch path's fill; every other action runs replicated on every rank (kai_core.hip kai_action_execute)
