@@ -223,6 +223,9 @@ struct SolverCtx {
     int32_t *q_live, *q_dead, *q_stack, *q_markl, *q_live_n;  // [Q+2] x 4, [4]: the nodes of a simulation's queue (parents before children), the children left out, scratch, the marked nodes; counts
     uint8_t *q_total, *q_relc, *q_pruned;             // [Q+1] simulation queues without bystander subtrees (kai_engine_solver.inc sim_prune): the sibling order below this node is a strict total order /
                                                       // children with relevant jobs below them in this simulation / subtree left out of this simulation's queue
+    // The victims log (kai_engine_solver.inc vl_*): the pops of the victims queue of the job being solved, once per pending job — every partial job walks the same sequence.
+    // Entry e = the job popped, its GetTasksToEvict slice (vl_tasks[vl_off[e] .. vl_off[e+1])) and whether the job was pushed back; p_vl[p] = the entry that took pod p (INT_MAX: none yet)
+    int32_t *vl_job, *vl_off, *vl_tasks, *vl_canon, *p_vl; uint8_t* vl_more;  // [P+J+2], [P+J+3], [P+1], [P+1] (an entry's tasks in canonical pod order), [P], [P+J+2]
     int32_t P_cap;
 };
 inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int DT = 0, int TL = 0, int G = 0) {
@@ -247,6 +250,7 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * 4);
     add(2 * (size_t)P + J + 2);
     for (int i = 0; i < 4; i++) add(sizeof(int32_t) * (2 * (size_t)Q + 4)); add(sizeof(int32_t) * 4);
+    add(sizeof(int32_t) * ((size_t)P + J + 2)); add(sizeof(int32_t) * ((size_t)P + J + 3)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add((size_t)P + J + 2);  // vl_*
     return b + 64;
 }
 inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, int J, int Q, int W, int DT = 0, int TL = 0, int G = 0) {
@@ -281,6 +285,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     v.job_head = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.job_tail = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.grp_link = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.sc_jobs = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.sc_jobs_n = (int32_t*)take(sizeof(int32_t) * 4);
     v.rc_ent_g = (uint8_t*)take(2 * (size_t)P + J + 2);
     v.q_live = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_dead = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_stack = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_markl = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_live_n = (int32_t*)take(sizeof(int32_t) * 4);
+    v.vl_job = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 2)); v.vl_off = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 3)); v.vl_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_canon = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.p_vl = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_more = (uint8_t*)take((size_t)P + J + 2);
     v.P_cap = P;
 }
 
@@ -843,6 +848,11 @@ struct EngineLocal {
     int32_t mm_cn[8]; double mm_lo[2], mm_hi[2], mm_old[8][2];
     int32_t sg_gen, pad_sg;                  // scan grid: number of the last command the control lane put on the table (kai_kernels.hpp)
     int32_t mw_buf, rc_early;                // rc_early: the running simulation stopped right after placing the preemptor because the reclaim validator's verdict (known then) is "no"
+    // the victims log of the job being solved (kai_engine_solver.inc): vl_job0 = that job (-1: none), vl_n entries, vl_done = the base queue ran empty behind them, vl_live = the
+    // victims-queue instance stands at the log's end in base mode (it can be extended), vl_cur = the running partial job's cursor, vl_mode 1 = this partial job left the log
+    // (a recorded victim changed the pop sequence) and pops the queue itself
+    int32_t vl_job0, vl_n, vl_done, vl_live, vl_cur, vl_mode;
+    int32_t vl_mat, vl_div_grp;  // entries below vl_mat have their task groups in the scenario (materialised lazily: a scenario the filters drop never needs them); groups the scenario held when the partial job left the log
     struct JoSave { QNode* qn; int32_t *qheap, *root_heap, *sorted, *cur, *end, *side, *side_len; int32_t root_len, root_init, kind, pad; } save[3];
 };
 
@@ -865,7 +875,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1; for (int i = 0; i < KAI_BN_ENT; i++) e.bn[i].valid = 0; e.bn_seq = 0; e.bn_tick = 0; e.bn_last = 0;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.vl_job0 = -1; e.vl_n = 0; e.vl_done = 0; e.vl_live = 0; e.vl_cur = 0; e.vl_mode = 0; e.vl_mat = 0; e.vl_div_grp = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1; for (int i = 0; i < KAI_BN_ENT; i++) e.bn[i].valid = 0; e.bn_seq = 0; e.bn_tick = 0; e.bn_last = 0;
         e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 
