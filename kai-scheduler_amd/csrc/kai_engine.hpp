@@ -225,6 +225,7 @@ struct SolverCtx {
                                                       // children with relevant jobs below them in this simulation / subtree left out of this simulation's queue
     // The victims log (kai_engine_solver.inc vl_*): the pops of the victims queue of the job being solved, once per pending job — every partial job walks the same sequence.
     // Entry e = the job popped, its GetTasksToEvict slice (vl_tasks[vl_off[e] .. vl_off[e+1])) and whether the job was pushed back; p_vl[p] = the entry that took pod p (INT_MAX: none yet)
+    int32_t *vl_node; double* vl_free;  // [P+1] x 2: a logged task's node and the devices its eviction frees there (AcceptedResource.GPUs(); the log is written and read at the committed state)
     int32_t *vl_job, *vl_off, *vl_tasks, *vl_canon, *p_vl; uint8_t* vl_more;  // [P+J+2], [P+J+3], [P+1], [P+1] (an entry's tasks in canonical pod order), [P], [P+J+2]
     int32_t P_cap;
 };
@@ -250,7 +251,7 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * 4);
     add(2 * (size_t)P + J + 2);
     for (int i = 0; i < 4; i++) add(sizeof(int32_t) * (2 * (size_t)Q + 4)); add(sizeof(int32_t) * 4);
-    add(sizeof(int32_t) * ((size_t)P + J + 2)); add(sizeof(int32_t) * ((size_t)P + J + 3)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add((size_t)P + J + 2);  // vl_*
+    add(sizeof(int32_t) * ((size_t)P + J + 2)); add(sizeof(int32_t) * ((size_t)P + J + 3)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add((size_t)P + J + 2); add(sizeof(int32_t) * (P + 1)); add(sizeof(double) * (P + 1));  // vl_*
     return b + 64;
 }
 inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, int J, int Q, int W, int DT = 0, int TL = 0, int G = 0) {
@@ -285,7 +286,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     v.job_head = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.job_tail = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.grp_link = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.sc_jobs = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.sc_jobs_n = (int32_t*)take(sizeof(int32_t) * 4);
     v.rc_ent_g = (uint8_t*)take(2 * (size_t)P + J + 2);
     v.q_live = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_dead = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_stack = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_markl = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_live_n = (int32_t*)take(sizeof(int32_t) * 4);
-    v.vl_job = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 2)); v.vl_off = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 3)); v.vl_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_canon = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.p_vl = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_more = (uint8_t*)take((size_t)P + J + 2);
+    v.vl_job = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 2)); v.vl_off = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 3)); v.vl_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_canon = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.p_vl = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_more = (uint8_t*)take((size_t)P + J + 2); v.vl_node = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_free = (double*)take(sizeof(double) * (P + 1));
     v.P_cap = P;
 }
 

@@ -89,6 +89,22 @@ def test_gpu_full_size_operations_hash_to_the_oracles(gpu, name, idx):
     assert T.state_sha256(res) == pin["state_sha256"]
 
 
+@pytest.mark.parametrize("key,scale,depth", [("C4_10pct_depth0", 0.1, 0), ("C4_30pct_depth8", 0.3, 8), ("C4_100pct_depth8", 1.0, 8)])
+def test_gpu_config4_cycle_hashes_to_the_oracles(gpu, key, scale, depth):
+    """BASELINE config 4 (allocate + consolidation + reclaim on one session: the victim search) pinned END TO END against the oracle's run of the same cycle
+    (tools/pin_c4_depth.py → profiles/full_size_pins.json): 10 % with the reference's default queue depth (unlimited, conf_util/scheduler_conf_util.go:89-90), 30 % and the FULL
+    size (10 000 nodes x 110 000 pods) with queueDepthPerAction 8 for the victim actions (framework/session.go:398-404; the operator docs configure 5 .. 15)."""
+    import json, os
+    with open(os.path.join(T.ROOT, "profiles", "full_size_pins.json")) as f:
+        pin = json.load(f)[key]
+    snap, cfg, desc = T.pkg.synth.config(3, scale)
+    for a in ("consolidation", "reclaim", "preempt"):
+        cfg.queue_depth[T.abi.ACTIONS[a]] = depth
+    assert (snap.n_nodes, snap.n_pods, snap.n_jobs) == (pin["nodes"], pin["pods"], pin["jobs"])
+    res = run_gpu(snap, cfg, tuple(pin["actions"]))
+    assert len(res.ops) == pin["ops"] and T.ops_sha256(res.ops) == pin["ops_sha256"]
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_gpu_random_small(gpu, seed):
     rng = np.random.default_rng(seed)
