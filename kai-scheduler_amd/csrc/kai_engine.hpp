@@ -75,6 +75,7 @@ enum OpName : int32_t { OP_EVICT = 0, OP_PIPELINE = 1, OP_ALLOCATE = 2, OP_UNDO 
 // framework/operations.go
 struct StmtOp {
     int32_t name, pod, prev_status, prev_node, next_node, prev_virtual, op_index, pad;
+    int32_t undo_link, pad2;  // undo_link: 1 + index of the FIRST OP_UNDO on the log that names this operation (0 = none was ever pushed; a link into a truncated part of the log is checked before use)
 };
 
 // scan class: every pod with the same request vector and static-predicate class (host: kai_host_prep.hpp)
@@ -225,6 +226,8 @@ struct SolverCtx {
                                                       // children with relevant jobs below them in this simulation / subtree left out of this simulation's queue
     // The victims log (kai_engine_solver.inc vl_*): the pops of the victims queue of the job being solved, once per pending job — every partial job walks the same sequence.
     // Entry e = the job popped, its GetTasksToEvict slice (vl_tasks[vl_off[e] .. vl_off[e+1])) and whether the job was pushed back; p_vl[p] = the entry that took pod p (INT_MAX: none yet)
+    int32_t* grp_mark;  // [P+2] stamp per task group (victim_groups: first-seen order without a search per task; the running stamp is mw_ctr[3])
+    uint32_t* sc_bits;  // [(J + 31) / 32 + 1] the scenario's distinct victim jobs as a bitmap (scenario_jobs puts them in ascending index from it); sc_jobs_n[2], [3] = its lowest / highest word in use
     int32_t *vl_node; double* vl_free;  // [P+1] x 2: a logged task's node and the devices its eviction frees there (AcceptedResource.GPUs(); the log is written and read at the committed state)
     int32_t *vl_job, *vl_off, *vl_tasks, *vl_canon, *p_vl; uint8_t* vl_more;  // [P+J+2], [P+J+3], [P+1], [P+1] (an entry's tasks in canonical pod order), [P], [P+J+2]
     int32_t P_cap;
@@ -251,7 +254,7 @@ inline size_t solver_scratch_bytes(int N, int P, int S, int J, int Q, int W, int
     add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (J + 1)); add(sizeof(int32_t) * (P + 2)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * 4);
     add(2 * (size_t)P + J + 2);
     for (int i = 0; i < 4; i++) add(sizeof(int32_t) * (2 * (size_t)Q + 4)); add(sizeof(int32_t) * 4);
-    add(sizeof(int32_t) * ((size_t)P + J + 2)); add(sizeof(int32_t) * ((size_t)P + J + 3)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add((size_t)P + J + 2); add(sizeof(int32_t) * (P + 1)); add(sizeof(double) * (P + 1));  // vl_*
+    add(sizeof(int32_t) * ((size_t)P + J + 2)); add(sizeof(int32_t) * ((size_t)P + J + 3)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add(sizeof(int32_t) * (P + 1)); add((size_t)P + J + 2); add(sizeof(int32_t) * (P + 1)); add(sizeof(double) * (P + 1)); add(sizeof(uint32_t) * ((size_t)J / 32 + 2)); add(sizeof(int32_t) * (P + 2));  // vl_*, sc_bits, grp_mark
     return b + 64;
 }
 inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, int J, int Q, int W, int DT = 0, int TL = 0, int G = 0) {
@@ -286,7 +289,7 @@ inline void solver_scratch_bind(SolverCtx& v, char* base, int N, int P, int S, i
     v.job_head = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.job_tail = (int32_t*)take(sizeof(int32_t) * (J + 1)); v.grp_link = (int32_t*)take(sizeof(int32_t) * (P + 2)); v.sc_jobs = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.sc_jobs_n = (int32_t*)take(sizeof(int32_t) * 4);
     v.rc_ent_g = (uint8_t*)take(2 * (size_t)P + J + 2);
     v.q_live = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_dead = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_stack = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_markl = (int32_t*)take(sizeof(int32_t) * (2 * (size_t)Q + 4)); v.q_live_n = (int32_t*)take(sizeof(int32_t) * 4);
-    v.vl_job = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 2)); v.vl_off = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 3)); v.vl_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_canon = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.p_vl = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_more = (uint8_t*)take((size_t)P + J + 2); v.vl_node = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_free = (double*)take(sizeof(double) * (P + 1));
+    v.vl_job = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 2)); v.vl_off = (int32_t*)take(sizeof(int32_t) * ((size_t)P + J + 3)); v.vl_tasks = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_canon = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.p_vl = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_more = (uint8_t*)take((size_t)P + J + 2); v.vl_node = (int32_t*)take(sizeof(int32_t) * (P + 1)); v.vl_free = (double*)take(sizeof(double) * (P + 1)); v.sc_bits = (uint32_t*)take(sizeof(uint32_t) * ((size_t)J / 32 + 2)); v.grp_mark = (int32_t*)take(sizeof(int32_t) * (P + 2));
     v.P_cap = P;
 }
 
@@ -1126,12 +1129,15 @@ struct Engine {
     // ------------------------------------------------------------------ Statement (framework/statement.go)
     KAI_HD int checkpoint() const { return cx().st->ops_len; }
     KAI_HD bool push_op(const StmtOp& o) { if (cx().st->ops_len >= cx().ops_cap) { fault(FAULT_OPS_CAP); return false; } cx().ops[cx().st->ops_len++] = o; return true; }
+    KAI_HD int op_undo_of(int target) const {  // the first OP_UNDO on the log that names `target` (the reference scans for it, statement.go:652-663), -1 = none: through the link undo_operation left
+        const int u = cx().ops[target].undo_link - 1;
+        return (u > target && u < cx().st->ops_len && cx().ops[u].name == OP_UNDO && cx().ops[u].op_index == target) ? u : -1;
+    }
     KAI_HD bool op_valid(int i) const {  // :652-663 — valid(i) = no undo of i, or that undo is itself undone (iterative form)
         if (cx().st->n_undo == 0) return true;
         bool valid = true; int target = i;
         for (;;) {
-            int u = -1;
-            for (int k = 0; k < cx().st->ops_len; k++) if (cx().ops[k].name == OP_UNDO && cx().ops[k].op_index == target) { u = k; break; }
+            const int u = op_undo_of(target);
             if (u < 0) return valid;
             valid = !valid; target = u;
         }
@@ -1243,7 +1249,8 @@ struct Engine {
             }
         }
         StmtOp u{}; u.name = OP_UNDO; u.pod = -1; u.op_index = index;
-        if (push_op(u)) cx().st->n_undo++;
+        const bool linked = op_undo_of(index) >= 0;  // (an operation undone, redone and undone again: the scan of the reference stops at its FIRST undo, so that link stays)
+        if (push_op(u)) { cx().st->n_undo++; if (!linked) cx().ops[index].undo_link = cx().st->ops_len; }
     }
     KAI_HD void truncate_ops(int cp) {
         for (int i = cp; i < cx().st->ops_len; i++) if (cx().ops[i].name == OP_UNDO) cx().st->n_undo--;
@@ -1431,11 +1438,11 @@ struct Engine {
             for (int k = 0; k < 3; k++) sub[k] = sx().vq_pop[leaf * 3 + k] + a[k];
         }
         if (bj >= 0 && !victims) {
-            if constexpr (!kVictim) {  // cached chunk: flag and sums in one batch of loads (the sums are re-read only if the chunk had to be rebuilt)
-                const int tv = cx().j_tta_valid[bj];
-                req[0] = cx().j_tta_res[(size_t)bj * 4 + 0]; req[1] = cx().j_tta_res[(size_t)bj * 4 + 1]; req[2] = cx().j_tta_res[(size_t)bj * 4 + 2];
-                if (!tv) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)bj * 4 + k]; }
-            } else { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)bj * 4 + k]; }
+            // cached chunk: flag and sums in one batch of loads (the sums are re-read only if the chunk had to be rebuilt; the victim search's queues pop hundreds of bystander
+            // jobs per simulation, all with a valid chunk — the out-of-line ensure_tta only for the few that were touched)
+            const int tv = cx().j_tta_valid[bj];
+            req[0] = cx().j_tta_res[(size_t)bj * 4 + 0]; req[1] = cx().j_tta_res[(size_t)bj * 4 + 1]; req[2] = cx().j_tta_res[(size_t)bj * 4 + 2];
+            if (!tv) { ensure_tta(bj, false); for (int k = 0; k < 3; k++) req[k] = cx().j_tta_res[(size_t)bj * 4 + k]; }
         }
         uint32_t bits = 0;
         bool over = true, starved = true, viol = false;

@@ -1210,6 +1210,7 @@ namespace orc { Session::~Session() = default; }
 // C entry points (ctypes)
 // =====================================================================================================
 static std::vector<int32_t> g_last_gpu_groups;  // of the last kai_oracle_run on this thread of the test process
+static int64_t g_last_victim_stats[3] = {0, 0, 0};
 extern "C" {
 
 // worker threads of the node-scoring fan-out (see OrderedNodesByTask); returns the previous value
@@ -1268,6 +1269,7 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
     if (nodes_out) for (size_t n = 0; n < ssn.nodes.size(); n++) for (int r = 0; r < ssn.R; r++) {
         nodes_out[n].idle[r] = ssn.nodes[n].Idle.Get(r); nodes_out[n].releasing[r] = ssn.nodes[n].Releasing.Get(r); nodes_out[n].used[r] = ssn.nodes[n].Used.Get(r);
     }
+    g_last_victim_stats[0] = ssn.stats.scenarios; g_last_victim_stats[1] = ssn.stats.simulations; g_last_victim_stats[2] = ssn.stats.scenariosFiltered;
     if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = ssn.stats.decisions; stats->node_scans = ssn.stats.nodeScans; stats->nodes_scanned = ssn.stats.nodesScanned;
                  stats->jobs_attempted = ssn.stats.jobsAttempted; stats->jobs_committed = ssn.stats.jobsCommitted; stats->rollbacks = ssn.stats.rollbacks; }
     return KAI_OK;
@@ -1287,6 +1289,10 @@ int kai_oracle_layout(int which) {
         default: return -1;
     }
 }
+
+// the victim search's counters of the last kai_oracle_run, summed over its actions: scenarios simulated (metrics.IncScenarioSimulatedByAction, job_solver.go:110), simulations run
+// (by_pod_solver.go:100-116), scenarios the accumulated filters dropped (IncScenarioFilteredByAction, pod_scenario_builder.go:140)
+int kai_oracle_last_victim_stats(int64_t* out3) { for (int i = 0; i < 3; i++) out3[i] = g_last_victim_stats[i]; return 0; }
 
 // shared-GPU group of every pod after the last kai_oracle_run: id < 2^20 = a group of the snapshot, >= 2^20 = created by the run, -1 = none
 int kai_oracle_last_gpu_groups(int32_t* out, int cap) { int n = int(g_last_gpu_groups.size()); for (int i = 0; i < n && i < cap; i++) out[i] = g_last_gpu_groups[i]; return n; }

@@ -241,6 +241,8 @@ extern "C" void kai_hostsim_set_dom_lanes_min(int n) { g_dom_lanes_min = n < 1 ?
 extern "C" void kai_hostsim_set_multi(int engines) { g_mw_world = engines < 1 ? 1 : engines > KAI_MW_MAX ? KAI_MW_MAX : engines; g_mw_waves = g_mw_sims_run = g_mw_sims_used = g_mw_replays = 0; }  // victim actions of the next runs on that many engines
 extern "C" void kai_hostsim_multi_stats(int64_t* out) { out[0] = g_mw_waves; out[1] = g_mw_sims_run; out[2] = g_mw_sims_used; out[3] = g_mw_replays; }
 static std::vector<int32_t> g_last_groups;  // PodInfo.GPUGroups[0] of the active fraction pods after the last run
+static int64_t g_last_victim_stats[3] = {0, 0, 0};  // scenarios, simulations, filtered scenarios of the last run, summed over its actions (the oracle exports the same: kai_oracle_last_victim_stats)
+extern "C" int kai_hostsim_last_victim_stats(int64_t* out3) { for (int i = 0; i < 3; i++) out3[i] = g_last_victim_stats[i]; return 0; }
 extern "C" int kai_hostsim_last_gpu_groups(int32_t* out, int cap) { int n = (int)g_last_groups.size(); for (int i = 0; i < n && i < cap; i++) out[i] = g_last_groups[i]; return n; }
 // host clocks of the per-cycle host preparation (HostPrep + SharedPods: what kai_session_open does before the first upload), phase by phase — timing aid
 extern "C" int kai_hostsim_prep_ms(const kai_config* cfg, const kai_snapshot_soa* s, double* out, int cap) {
@@ -544,6 +546,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (c.st->fault) { if (std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "host_sim: engine fault %d at line %d\n", c.st->fault, c.st->fault_line); return KAI_ERR_DEVICE_FAULT; }
     if (n_ops) *n_ops = c.st->out_len;
     if (ops_out) { if (c.st->out_len > ops_cap) return KAI_ERR_CAPACITY; std::memcpy(ops_out, c.out_ops, (size_t)c.st->out_len * sizeof(kai_op)); for (int64_t i = 0; i < c.st->out_len; i++) if (ops_out[i].node >= 0) ops_out[i].node = prep.perm[ops_out[i].node]; }
+    g_last_victim_stats[0] = c.st->scenarios; g_last_victim_stats[1] = c.st->simulations; g_last_victim_stats[2] = c.st->scenarios_filtered;
     g_last_groups.assign(P, -1);
     for (int p = 0; p < P; p++) if (shared && c.p_shared[p] && st_active_used(c.p_status[p])) g_last_groups[p] = c.p_group[p];
     if (pod_status_out) std::memcpy(pod_status_out, c.p_status, (size_t)P * 4);

@@ -450,3 +450,37 @@ def test_hostsim_config3_full_size_hashes_to_the_oracles_pin():
     cfg.engine_mode = 3
     res = HostSim.run(snap, cfg)
     assert T.ops_sha256(res.ops) == pin["ops_sha256"] and T.state_sha256(res) == pin["state_sha256"]
+
+
+def _victim_stats(raw_fn):
+    out = (C.c_int64 * 3)()
+    raw_fn(out)
+    return tuple(int(x) for x in out)
+
+
+@pytest.mark.parametrize("nodes", [10, 30, 60])
+def test_hostsim_reclaim_large_jobs_walks_the_victims_log(nodes):
+    """The reference's BenchmarkReclaimLargeJobs shape (integration_tests/reclaim/reclaim_benchmark_test.go:62-160, restated by tools/ref_benchmarks.py): one pending gang of
+    nodes/10 x 8-GPU tasks against 8 running one-GPU jobs per node — per partial job hundreds of scenarios that end at the AccumulatedIdleGpus filter, recorded victims in front
+    of them.  The engine pops the victims queue once per pending job (kai_engine_solver.inc vl_*), walks the log per partial job, keeps the filter as a running sum and builds the
+    task groups only for the scenario that gets through: operations, scenarios simulated, simulations run and scenarios dropped must be the oracle's."""
+    import sys
+    sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+    import ref_benchmarks as RB
+    snap, cfg, _ = T.case_to_snapshot(RB.reclaim_large(nodes), ("reclaim",))
+    ref = T.Oracle.run(snap, cfg, ("reclaim",)); o_stats = _victim_stats(T.Oracle.lib().kai_oracle_last_victim_stats)
+    res = HostSim.run(snap, cfg, ("reclaim",)); e_stats = _victim_stats(HostSim._raw.kai_hostsim_last_victim_stats)
+    assert_same(res, ref)
+    assert e_stats[:2] == o_stats[:2] and e_stats[2] >= o_stats[2]  # (the engine also books a simulation its pre-check turns away as a dropped scenario)
+    assert o_stats[2] > 5 * nodes
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_hostsim_victims_log_with_recorded_victims_of_elastic_jobs(seed):
+    """Crowded clusters of elastic running jobs (more pods than minAvailable) under reclaim and preempt: GetTasksToEvict hands an elastic job over one task at a time and pushes it
+    back, so a partial job's recorded victims meet log entries whose job still has tasks in the queue — the walk has to tell an entry it may pass over from one that changes the
+    pop sequence (vl_diverge: the queue rebuilt, the entries so far replayed as the real builder)."""
+    snap = T.pkg.synth.make_crowded_snapshot(6 + seed % 5, 7000 + seed)
+    cfg = T.abi.default_config(max_consolidation_preemptees=-1)
+    acts = ("allocate", "reclaim", "preempt") if seed % 2 else ("allocate", "consolidation", "reclaim")
+    assert_same(HostSim.run(snap, cfg, acts), T.Oracle.run(snap, cfg, acts))
