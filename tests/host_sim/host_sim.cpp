@@ -21,6 +21,7 @@ static int g_dom_lanes_min = std::getenv("KAI_HOSTSIM_DOM_MIN") ? std::atoi(std:
 #include "../../kai-scheduler_amd/csrc/kai_batch_kernels.hpp"
 #include "../../kai-scheduler_amd/csrc/kai_batch_driver.hpp"
 #include "../../kai-scheduler_amd/csrc/kai_victim_shard.hpp"
+#include "native_bucket_fill.hpp"
 
 using namespace kai;
 
@@ -186,6 +187,11 @@ bool HostBackend::topo_scan(const KaiCtx& c, TopoScan& t) {
     return true;
 }
 
+static double g_native_fill_ms = 0; static int64_t g_native_fill_launches = 0, g_native_fill_decisions = 0, g_native_fill_diffs = 0;  // the native shadow of the bucket fill, summed since the last read
+extern "C" int kai_hostsim_native_fill(double* ms, int64_t* launches, int64_t* decisions, int64_t* diffs) {
+    *ms = g_native_fill_ms; *launches = g_native_fill_launches; *decisions = g_native_fill_decisions; *diffs = g_native_fill_diffs;
+    g_native_fill_ms = 0; g_native_fill_launches = g_native_fill_decisions = g_native_fill_diffs = 0; return 0;
+}
 // the batch path's kernels on the lock-step emulator (kai_simt.hpp)
 struct HostLauncher {
     void static_rank(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_static_rank(c); }); }
@@ -200,7 +206,24 @@ struct HostLauncher {
     void class_capacity(int g, int b, const KaiCtx& c, int buckets, int levels) { kw::launch(g, b, 0, [&] { kb_class_capacity(c, buckets, levels); }); }
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) { kw::launch(g, b, dyn, [&] { kb_fill(c, rp, l1); }); }
     void bucket_build(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_bucket_build(c); }); }
-    void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); }); }
+    void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
+        // KAI_HOSTSIM_NATIVE_FILL=1: the same algorithm as plain scalar C++ (native_bucket_fill.hpp) on a copy of the sets first — timed, and every output checked against the emulated kernel's
+        static const bool shadow = std::getenv("KAI_HOSTSIM_NATIVE_FILL") != nullptr;
+        kai_native::NativeFillOut nat;
+        if (shadow) kai_native::native_fill_buckets(c, rp, bp, nat);
+        kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); });
+        if (!shadow) return;
+        const BatchCtx& bt = c.bt; const FillStatus& f = bt.fs[0]; bool same = true;
+        same = same && f.n_done == nat.fs.n_done && f.mismatch == nat.fs.mismatch && f.all_dead == nat.fs.all_dead && f.planned == nat.fs.planned && f.decisions == nat.fs.decisions && f.attempted == nat.fs.attempted &&
+               f.committed == nat.fs.committed && f.rollbacks == nat.fs.rollbacks && f.ops == nat.fs.ops && f.dead_mask == nat.fs.dead_mask;
+        for (size_t i = 0; i < nat.words.size() && same; i++) same = bt.bk_words[i] == nat.words[i];
+        for (int gi = rp.start; gi < f.n_done && same; gi++) {
+            const int x = gi - rp.start;
+            same = bt.g_out[gi] == nat.g_out[x] && bt.g_opoff[gi] == nat.g_opoff[x] && bt.g_stmt[gi] == nat.g_stmt[x];
+            if (same && nat.g_out[x] == BF_OK && bt.g_flag[gi] != BF_GATE) for (int t = 0; t < bt.g_nt[gi] && same; t++) same = bt.t_node[bt.g_first[gi] + t] == nat.t_node[(size_t)bt.g_first[gi] + t];
+        }
+        g_native_fill_ms += nat.ms; g_native_fill_launches++; g_native_fill_decisions += nat.fs.decisions; if (!same) g_native_fill_diffs++;
+    }
     void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { kw::launch(g, b, 0, [&] { kb_apply_jobs(c, ops_base, stmt_base); }); }
     void apply_nodes(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_apply_nodes(c); }); }
     void index_from_recs(int g, int b, const KaiCtx& c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { kw::launch(g, b, 0, [&] { kb_index_from_recs(c, recs, n_recs, l1k, l1n, nb, blk0, blk1); }); }
