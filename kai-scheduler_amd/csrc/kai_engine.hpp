@@ -855,6 +855,10 @@ struct EngineLocal {
     // the victims log of the job being solved (kai_engine_solver.inc): vl_job0 = that job (-1: none), vl_n entries, vl_done = the base queue ran empty behind them, vl_live = the
     // victims-queue instance stands at the log's end in base mode (it can be extended), vl_cur = the running partial job's cursor, vl_mode 1 = this partial job left the log
     // (a recorded victim changed the pop sequence) and pops the queue itself
+    // requests that found NO fitting node among a simulation's feasible nodes (victim search): inside one simulation resources are only taken — until a rollback hands some
+    // back, which empties the list — so the same request finds none again (a simulation re-places hundreds of evicted one-device tasks of one shape)
+    ScanReq sim_dead[4]; int32_t sim_dead_n, sim_dead_on;
+    KAI_GP(const uint32_t) fbits[KAI_TDEPTH];  // node set of the DFS frame at each depth (frame_bits)
     int32_t vl_job0, vl_n, vl_done, vl_live, vl_cur, vl_mode;
     int32_t vl_mat, vl_div_grp;  // entries below vl_mat have their task groups in the scenario (materialised lazily: a scenario the filters drop never needs them); groups the scenario held when the partial job left the log
     struct JoSave { QNode* qn; int32_t *qheap, *root_heap, *sorted, *cur, *end, *side, *side_len; int32_t root_len, root_init, kind, pad; } save[3];
@@ -879,7 +883,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.vl_job0 = -1; e.vl_n = 0; e.vl_done = 0; e.vl_live = 0; e.vl_cur = 0; e.vl_mode = 0; e.vl_mat = 0; e.vl_div_grp = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1; for (int i = 0; i < KAI_BN_ENT; i++) e.bn[i].valid = 0; e.bn_seq = 0; e.bn_tick = 0; e.bn_last = 0;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.sim_dead_n = 0; e.sim_dead_on = 0; e.vl_job0 = -1; e.vl_n = 0; e.vl_done = 0; e.vl_live = 0; e.vl_cur = 0; e.vl_mode = 0; e.vl_mat = 0; e.vl_div_grp = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1; for (int i = 0; i < KAI_BN_ENT; i++) e.bn[i].valid = 0; e.bn_seq = 0; e.bn_tick = 0; e.bn_last = 0;
         e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 
@@ -1233,6 +1237,7 @@ struct Engine {
     }
     KAI_HD void undo_operation(int index) {  // :602-643
         if (!op_valid(index)) return;
+        if constexpr (kVictim) el().sim_dead_n = 0;  // resources come back: a request that found no node may find one again
         StmtOp op = cx().ops[index];
         switch (op.name) {
             case OP_EVICT: unevict(op.pod, op.prev_status, op.prev_node, op.prev_virtual, op.pad); break;
@@ -1744,6 +1749,14 @@ struct Engine {
     // and patched: the arg-max over the UNCHANGED nodes is still the kept node (if it is unchanged) — or the kept node itself when it changed but its score did not drop, the
     // bin-packing case: a fuller node scores higher — and the changed nodes are evaluated one by one against it (score descending, index ascending, as the pass breaks ties).
     // A kept node whose score dropped leaves the others unknown: then the pass runs.  Same scores from the same function (scan_node_score), so the same node.
+    KAI_HD static bool sim_dead_same(const ScanReq& a, const ScanReq& b) {  // everything the FILTERS of a pass read (the pre-order range only scales scores)
+        if (a.cpu_only != b.cpu_only || a.best_effort != b.best_effort || a.pod_class != b.pod_class || a.nominated != b.nominated || a.r_place != b.r_place || a.strategy != b.strategy) return false;
+        for (int r = 0; r < KAI_MAX_RES; r++) if (a.req[r] != b.req[r]) return false;
+#ifdef KAI_SHARED_GPUS
+        if (a.portion != b.portion || a.gmem != b.gmem || a.shared != b.shared || a.kind != b.kind) return false;
+#endif
+        return true;
+    }
     KAI_HD static bool bn_same(const ScanReq& a, const ScanReq& b) {
         if (a.cpu_only != b.cpu_only || a.best_effort != b.best_effort || a.pod_class != b.pod_class || a.nominated != b.nominated || a.r_place != b.r_place || a.strategy != b.strategy) return false;
         for (int r = 0; r < KAI_MAX_RES; r++) if (a.req[r] != b.req[r]) return false;
@@ -1806,10 +1819,16 @@ struct Engine {
             return n;
         }
         ScanReq q; fill_req(q, p);
+        bool sim_scope = false;
+        if constexpr (kVictim) {  // a simulation's feasible nodes, no narrower node set on top: has this request already found nothing since the last rollback?
+            sim_scope = el().sim_dead_on && el().scope_bits && el().scope_bits == el().base_bits && el().scope_row < 0;
+            if (sim_scope) for (int i = 0; i < el().sim_dead_n; i++) if (sim_dead_same(el().sim_dead[i], q)) { cx().st->node_scans++; cx().st->nodes_scanned += cx().N; return -1; }  // (counted like the pass it stands for)
+        }
         if ((cx().plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) preorder_range(q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
         int n;
         if (cx().action == KAI_ACTION_ALLOCATE && !el().scope_bits && el().scope_row < 0) n = best_node_kept(q);  // over all nodes: the answer of the last decision with this request, patched
         else { n = be.best_node(cx(), q, nullptr); cx().st->node_scans++; cx().st->nodes_scanned += cx().N; }
+        if constexpr (kVictim) if (sim_scope && n < 0) { const int k = el().sim_dead_n < 4 ? el().sim_dead_n++ : 3; el().sim_dead[k] = q; }
         if (n >= 0) allocatable = q.best_effort || fits(cx(), q.req, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
 #ifdef KAI_SHARED_GPUS
         if (n >= 0 && pod_shared(p)) allocatable = q.best_effort || fits_shared(cx(), q, n, false);
@@ -2305,13 +2324,15 @@ struct Engine {
     }
     // node-set bitmaps of the DFS: slot d holds the set the frame at depth d is currently trying; `restricted[d]` tells whether any frame
     // up to depth d narrowed the set (otherwise the set is "every node" and scans may use the class index)
-    KAI_HD KAI_GP(const uint32_t) frame_bits(int depth) { return el_restricted(depth) ? (KAI_GP(const uint32_t))(cx().ns_bits + (size_t)depth * cx().W) : (KAI_GP(const uint32_t))nullptr; }
+    KAI_HD KAI_GP(const uint32_t) frame_bits(int depth) { return el_restricted(depth) ? el().fbits[depth] : (KAI_GP(const uint32_t))nullptr; }  // (the frame's own slot of ns_bits, or — a frame that narrows nothing — the set of the frame above it)
     KAI_HD KAI_GP(const uint32_t) el_parent_bits(int depth) { return depth == 0 ? el().base_bits : frame_bits(depth - 1); }
     KAI_HD bool el_restricted(int depth) const { return (el().restricted >> depth) & 1u; }
     KAI_HD void set_frame_bits(int depth, int dom) {
         bool parent_restricted = depth > 0 ? el_restricted(depth - 1) : (el().base_bits != nullptr);
         if (dom < 0 && !parent_restricted) { el().restricted &= ~(1u << depth); return; }  // still every node
+        if (dom < 0) { el().fbits[depth] = el_parent_bits(depth); el().restricted |= 1u << depth; return; }  // the parent's set as it is (a simulation's feasible nodes under every frame of every job it re-places): no copy
         build_node_set(cx().ns_bits + (size_t)depth * cx().W, el_parent_bits(depth), dom);
+        el().fbits[depth] = (KAI_GP(const uint32_t))(cx().ns_bits + (size_t)depth * cx().W);
         el().restricted |= 1u << depth;
     }
     // ------------------------------------------------------------------ staged job path
