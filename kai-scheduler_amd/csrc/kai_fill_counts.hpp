@@ -1,0 +1,177 @@
+// kai_fill_counts.hpp — the bucket fill (kai_fill_buckets.hpp) taken apart into two wavefronts that run side by side.
+//
+// kai_fill_buckets.hpp walks the planned order on ONE wavefront: per step it looks the best node up in the sets, moves its bit, patches every class's best, writes the
+// tasks' nodes — ≈ 1 000 cycles per decision, all of it one dependency chain (profiles/r04q_*: 134 instructions per decision at 7.7 cycles each; one host core runs the same
+// loop ≈ 7x faster, tests/host_sim/native_bucket_fill.hpp).  Most of that chain is not needed to DECIDE anything.  When no class carries a static bitmap of its own
+// ("plain": every class may use every live node — BASELINE configs 2 and 5), which node a task lands on never feeds back into a decision: a class that asks for q devices takes
+// the lowest non-empty level g >= q, and whether a gang fits, where its tasks go by LEVEL, what every later gang finds — all of it is a function of the levels'
+// POPULATIONS alone.  So:
+//
+//   * wavefront 0, the counting machine: the planned order over cnt[g] = nodes with g free devices, 8 .. 16 integers in registers.  A gang of one class is decided before
+//     anything moves (it fits iff Σ_g (g / q)·cnt[g] >= its tasks — the argument of kai_fill_buckets.hpp's capacity check, now the rule for every such gang), a gang of several
+//     classes is simulated on a copy of the counts; job outcomes, decision counts and operation offsets come out exactly as the one-wave kernel produces them.  What it emits is a
+//     stream of commands "the first k nodes of level g take `per` tasks each and move to level g2; their tasks are t_node[tbase ..)" through a ring in LDS.  It never touches a
+//     bitmap and never rolls anything back: only commands of gangs that fit are published.
+//   * wavefront 1, the set worker: executes the commands on the sets (lane = level as before: ds_xor moves, two summary levels, the first node of each level cached in its lane)
+//     and writes the tasks' nodes.  No class state, no outcomes, no rollback.
+//
+// The chain that bounds the action is now the longer of the two, and each is a fraction of the old one.  Results are identical to k_fill_buckets (and through it to the oracle):
+// tests/test_batch_path.py and tests/test_gpu_parity.py run the three fills against each other.  Everything that is not plain — static class bitmaps — and the
+// one-placement-per-step debug mode stay on k_fill_buckets.
+#pragma once
+#include "kai_fill_buckets.hpp"
+
+namespace kai {
+
+constexpr int KFC_RING = 2048;  // commands the ring holds; a gang (<= KB_PLACED_MAX tasks) is written in full before it is published
+struct FcCmd { int32_t lv, k, per, tbase; };  // lv = g | g2 << 8: the first k nodes of level g move to level g2 (0: no level), `per` tasks each; t_node[tbase ..) receives the nodes
+struct FcLds { FcCmd ring[KFC_RING]; int32_t cnt0[KBK_GMAX]; int32_t head, tail, done, pad; };
+
+KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
+    KW_SHARED FcLds L;
+    const BatchCtx& b = c.bt;
+    const int tid = kw::tid(), T = kw::bdim(), lane = kw::lane(), C = c.C;
+    BkView v; v.NW = bp.nw; v.NW1 = bp.nw1; v.LV = bp.levels;
+    unsigned char* dyn = kw::dyn_lds();
+    v.gw = (KW_LDS_PTR(uint64_t))dyn; v.s1 = v.gw + (size_t)v.LV * v.NW; v.ok = v.s1 + (size_t)v.LV * v.NW1 + KBK_GMAX;
+    const int64_t tstart = kw::clock();
+    if (tid < KBK_GMAX) L.cnt0[tid] = 0;
+    if (tid == 0) { L.head = 0; L.tail = 0; L.done = 0; }
+    for (int i = tid; i < v.LV * v.NW; i += T) v.gw[i] = b.bk_words[i];
+    kw::sync();
+    for (int i = tid; i < v.LV * v.NW1; i += T) {  // first summary level, and the levels' populations on the way
+        const int l = i / v.NW1, w1 = i % v.NW1; uint64_t m = 0; int pop = 0;
+        for (int j = 0; j < 64 && w1 * 64 + j < v.NW; j++) { const uint64_t x = v.gw[l * v.NW + w1 * 64 + j]; if (x) { m |= 1ull << j; pop += __builtin_popcountll(x); } }
+        v.s1[i] = m;
+        if (pop) kw::atomic_add((int32_t*)&L.cnt0[l], pop);
+    }
+    kw::sync();
+    const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: dead classes only (before the first plan)
+    if (tid < 64) {
+        // ------------------------------------------------------------------ wavefront 0: the counting machine.  lane l: nodes of level l + 1; lane k: class k's request
+        int cnt = lane < v.LV ? L.cnt0[lane] : 0;
+        const bool act = lane < C;
+        const int q = act ? (int)c.cls[lane].req[KAI_RES_GPU] : 0x7fffffff;
+        uint32_t nz = (uint32_t)kw::ballot(cnt > 0);  // bit l: level l + 1 holds a node
+        int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, steps = 0, n_done = rp.start, mismatch = 0;
+        int wp = 0, tail_seen = 0;  // commands written / the worker's progress as last read
+        // the lowest non-empty level >= qc, 0 = none
+        #define KFC_LEVEL_FOR(qc) ((nz >> ((qc) - 1)) ? (qc) + __builtin_ctz(nz >> ((qc) - 1)) : 0)
+        // k nodes leave level g for level g2 (0: none): the counts and the non-empty mask, from values this lane already holds
+        #define KFC_MOVE(g, g2, k, cg) do { if (lane == (g) - 1) cnt -= (k); if ((cg) == (k)) nz &= ~(1u << ((g) - 1)); if ((g2) >= 1) { if (lane == (g2) - 1) cnt += (k); nz |= 1u << ((g2) - 1); } } while (0)
+        for (int base = rp.start; base < V && !mismatch; base += 64) {
+            const int gi = base + lane;
+            const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE, my_first = gi < V ? b.g_first[gi] : 0, my_nt = gi < V ? b.g_nt[gi] : 0, my_ucls = gi < V ? b.g_ucls[gi] : 0;
+            const int jn = V - base < 64 ? V - base : 64;
+            int my_out = 0, my_opoff = 0, my_stmt = 0, n_out = 0;  // lane jj: what job jj of this stretch ended with (stored once per stretch, coalesced)
+            for (int jj = 0; jj < jn; jj++) {
+                const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
+                const int opoff = ops + rp.ops0, stmtoff = committed + rp.stmt0;
+                bool ok = flag != BF_GATE;
+                if (ok && ucls >= 0) {
+                    // a gang of ONE class: it fits iff the levels hold enough places for it (a node of level g holds g / q of its tasks, every placement takes exactly one
+                    // place away) — else it places `cap` tasks, finds no node for the next one and is rolled back: cap + 1 decisions, the state it started from
+                    const int qc = kw::bcast(q, ucls);
+                    int cap;
+                    if (nt == 1) cap = (nz >> (qc - 1)) ? 1 : 0;
+                    else { int term = 0; if (lane < v.LV && lane + 1 >= qc) term = bk_div_small(lane + 1, qc) * cnt; cap = 0; for (int l = qc - 1; l < v.LV && cap < nt; l++) cap += kw::bcast(term, l); }
+                    if (cap < nt) { decisions += cap + 1; ok = false; if (nt > 1 || cap) { /* (what the one-wave kernel books for a gang it started and undid) */ } }
+                    else {
+                        int done = 0;
+                        while (done < nt) {
+                            while (wp - tail_seen >= KFC_RING) { tail_seen = kw::lds_load_acq(&L.tail); if (wp - tail_seen >= KFC_RING) kw::relax(); }
+                            const int g = KFC_LEVEL_FOR(qc), r = bk_div_small(g, qc), rem = nt - done, cg = kw::bcast(cnt, g - 1);
+                            int k = 1, per = rem;
+                            if (rem >= r) { per = r; k = bk_div_small(rem, r); if (k > cg) k = cg; }
+                            const int g2 = g - per * qc;
+                            if (lane == 0) { FcCmd cm; cm.lv = g | (g2 << 8); cm.k = k; cm.per = per; cm.tbase = first + done; L.ring[wp & (KFC_RING - 1)] = cm; }
+                            wp++; steps++;
+                            KFC_MOVE(g, g2, k, cg);
+                            done += k * per;
+                        }
+                        decisions += nt;
+                        kw::lds_store_rel(&L.head, wp);
+                    }
+                } else if (ok) {
+                    // a gang of several scan classes: task by task on a copy of the counts; its commands stay unpublished until the last task has found its level
+                    while (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { tail_seen = kw::lds_load_acq(&L.tail); if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) kw::relax(); }
+                    const int cnt_s = cnt; const uint32_t nz_s = nz; const int wp_s = wp;
+                    for (int tb = 0; tb < nt && ok; tb += 64) {
+                        const int my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;
+                        const int tc = nt - tb < 64 ? nt - tb : 64;
+                        for (int ti = 0; ti < tc; ti++) {
+                            const int qc = kw::bcast(q, kw::bcast(my_cls, ti));
+                            decisions++;
+                            const int g = KFC_LEVEL_FOR(qc);
+                            if (!g) { ok = false; break; }
+                            const int cg = kw::bcast(cnt, g - 1), g2 = g - qc;
+                            if (lane == 0) { FcCmd cm; cm.lv = g | (g2 << 8); cm.k = 1; cm.per = 1; cm.tbase = first + tb + ti; L.ring[wp & (KFC_RING - 1)] = cm; }
+                            wp++; steps++;
+                            KFC_MOVE(g, g2, 1, cg);
+                        }
+                    }
+                    if (ok) kw::lds_store_rel(&L.head, wp);
+                    else { cnt = cnt_s; nz = nz_s; wp = wp_s; }  // Statement.Rollback: nothing was published
+                }
+                if (flag != BF_GATE) { if (ok) { committed++; ops += nt; } else rollbacks += 2; }
+                attempted++; n_done = base + jj + 1;
+                { const bool me = lane == jj; my_out = me ? (ok ? BF_OK : BF_DEAD) : my_out; my_opoff = me ? opoff : my_opoff; my_stmt = me ? stmtoff : my_stmt; n_out = jj + 1; }
+                if ((flag == BF_OK) != ok) { mismatch = 1; break; }
+            }
+            if (lane < n_out) { b.g_out[base + lane] = (uint8_t)my_out; b.g_opoff[base + lane] = my_opoff; b.g_stmt[base + lane] = my_stmt; }
+        }
+        #undef KFC_LEVEL_FOR
+        #undef KFC_MOVE
+        kw::lds_store_rel(&L.head, wp);
+        kw::lds_store_rel(&L.done, 1);
+        const uint64_t dead = kw::ballot(act && (q > 32 || (nz >> (q - 1)) == 0));
+        if (lane == 0) {
+            FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V; s.floor_stop = 0; s.pad = 0;
+            s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
+            s.cycles_total = kw::clock() - tstart; s.cycles_load = 0; s.cycles_update = 0; s.cycles_rescan = 0; s.block_loads = 0;
+            s.rescans1 = 0; s.rescans2 = steps; s.rescans3 = 0;  // rescans2: commands (a command moves the first k nodes of a level)
+            b.fs[0] = s; b.dead_mask[0] = dead;
+        }
+    } else if (tid < 128) {
+        // ------------------------------------------------------------------ wavefront 1: the set worker.  lane l owns level l + 1: its words, its summaries, its first node
+        uint64_t s2 = 0;
+        if (lane < v.LV) for (int j = 0; j < v.NW1; j++) if (v.s1[lane * v.NW1 + j]) s2 |= 1ull << j;
+        int dummy = 0, firstn = KB_INF;  // firstn: the lowest name rank of this lane's level (KB_INF: the level is empty)
+        auto own_first = [&]() { if (!s2) return KB_INF; const int w1 = __builtin_ctzll(s2); const uint64_t m1 = v.s1[lane * v.NW1 + w1]; const int w = w1 * 64 + __builtin_ctzll(m1); return w * 64 + __builtin_ctzll(v.gw[lane * v.NW + w]); };
+        if (lane < v.LV) firstn = own_first();
+        int tail = 0, finds = 0;
+        for (;;) {
+            const int head = kw::lds_load_acq(&L.head);
+            if (tail == head) { if (kw::lds_load_acq(&L.done) && tail == kw::lds_load_acq(&L.head)) break; kw::relax(); continue; }
+            for (; tail < head; tail++) {
+                const FcCmd cm = L.ring[tail & (KFC_RING - 1)];
+                const int g = cm.lv & 0xff, g2 = cm.lv >> 8, per = cm.per; int left = cm.k, tb = cm.tbase;
+                while (left > 0) {
+                    const int n = kw::bcast(firstn, g - 1), w = n >> 6;
+                    uint64_t word = v.gw[(g - 1) * v.NW + w];
+                    kw::lds_order();  // (every lane has read the word before its owner toggles it below)
+                    int m = __builtin_popcountll(word); uint64_t mask = word;
+                    if (m > left) { m = left; mask = 0; for (int j = 0; j < m; j++) { mask |= word & (0 - word); word &= word - 1; } }
+                    for (int t0 = 0; t0 < m * per; t0 += 64) {  // task t of this word's share sits on the (t / per)-th node of the mask
+                        const int t = t0 + lane;
+                        if (t < m * per) { uint64_t mm = mask; for (int j = bk_div_small(t, per); j > 0; j--) mm &= mm - 1; b.t_node[tb + t] = (w << 6) + __builtin_ctzll(mm); }
+                    }
+                    const uint64_t neww = bk_move_mask(v, s2, dummy, w, mask, g, g2);
+                    if (lane == g - 1) { if (neww) firstn = (w << 6) + __builtin_ctzll(neww); else { firstn = own_first(); finds++; } }
+                    if (lane == g2 - 1 && n < firstn) firstn = n;
+                    tb += m * per; left -= m;
+                }
+            }
+            kw::lds_store_rel(&L.tail, tail);
+        }
+        (void)finds;
+    }
+    kw::sync();
+    for (int i = tid; i < v.LV * v.NW; i += T) b.bk_words[i] = v.gw[i];
+}
+
+#if defined(__HIPCC__)
+__global__ void __launch_bounds__(256) k_fill_counts(KaiCtx c, RoundParams rp, BucketParams bp) { kb_fill_counts(c, rp, bp); }
+#endif
+
+}  // namespace kai

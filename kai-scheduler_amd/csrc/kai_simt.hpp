@@ -56,6 +56,11 @@ KW_DEV void lds_order() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 KW_DEV uint64_t lds_xor(KW_LDS_PTR(uint64_t) p, uint64_t v) { return __hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 KW_DEV void expect_uniform(long long) {}
 KW_DEV void fence_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// two wavefronts of one workgroup hand data over through LDS (kai_fill_counts.hpp: a command ring): the producer's stores, then its release store of the counter; the consumer's
+// acquire load of the counter, then its loads.  relax(): the polling wavefront steps aside for a few cycles
+KW_DEV int lds_load_acq(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+KW_DEV void lds_store_rel(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+KW_DEV void relax() { __builtin_amdgcn_s_sleep(1); }
 }  // namespace kw
 
 #else  // ---------------------------------------------------------------------------------------------- host emulator (tests only)
@@ -215,6 +220,9 @@ inline int64_t clock() { return 0; }
 inline unsigned char* dyn_lds() { Emu& e = emu(); return reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(e.lds.data()) + 15) & ~uintptr_t(15)); }
 inline void fence() {}
 inline void fence_wg() {}
+inline int lds_load_acq(const int32_t* p) { return *p; }
+inline void lds_store_rel(int32_t* p, int v) { *p = v; }
+inline void relax(int line = __builtin_LINE()) { wave_bar(line); }  // the whole wave parks: the scheduler lets the other wavefronts of the workgroup run
 inline void wave_sync(int line = __builtin_LINE()) { wave_bar(line); }
 inline void lds_order(int line = __builtin_LINE()) { wave_bar(line); }
 inline uint64_t lds_xor(uint64_t* p, uint64_t v) { const uint64_t o = *p; *p = o ^ v; return o; }

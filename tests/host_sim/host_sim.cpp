@@ -206,12 +206,12 @@ struct HostLauncher {
     void class_capacity(int g, int b, const KaiCtx& c, int buckets, int levels) { kw::launch(g, b, 0, [&] { kb_class_capacity(c, buckets, levels); }); }
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) { kw::launch(g, b, dyn, [&] { kb_fill(c, rp, l1); }); }
     void bucket_build(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_bucket_build(c); }); }
-    void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
-        // KAI_HOSTSIM_NATIVE_FILL=1: the same algorithm as plain scalar C++ (native_bucket_fill.hpp) on a copy of the sets first — timed, and every output checked against the emulated kernel's
-        static const bool shadow = std::getenv("KAI_HOSTSIM_NATIVE_FILL") != nullptr;
+    // KAI_HOSTSIM_NATIVE_FILL=1: the same algorithm as plain scalar C++ (native_bucket_fill.hpp) on a copy of the sets first — timed, and every output checked against the emulated kernel's
+    template <class F> void with_native_shadow(const KaiCtx& c, RoundParams rp, BucketParams bp, F&& run) {
+        const bool shadow = std::getenv("KAI_HOSTSIM_NATIVE_FILL") != nullptr;  // (read per launch: a test process sets it for single tests)
         kai_native::NativeFillOut nat;
         if (shadow) kai_native::native_fill_buckets(c, rp, bp, nat);
-        kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); });
+        run();
         if (!shadow) return;
         const BatchCtx& bt = c.bt; const FillStatus& f = bt.fs[0]; bool same = true;
         same = same && f.n_done == nat.fs.n_done && f.mismatch == nat.fs.mismatch && f.all_dead == nat.fs.all_dead && f.planned == nat.fs.planned && f.decisions == nat.fs.decisions && f.attempted == nat.fs.attempted &&
@@ -224,6 +224,8 @@ struct HostLauncher {
         }
         g_native_fill_ms += nat.ms; g_native_fill_launches++; g_native_fill_decisions += nat.fs.decisions; if (!same) g_native_fill_diffs++;
     }
+    void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); }); }); }
+    void fill_counts(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_counts(c, rp, bp); }); }); }
     void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { kw::launch(g, b, 0, [&] { kb_apply_jobs(c, ops_base, stmt_base); }); }
     void apply_nodes(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_apply_nodes(c); }); }
     void index_from_recs(int g, int b, const KaiCtx& c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { kw::launch(g, b, 0, [&] { kb_index_from_recs(c, recs, n_recs, l1k, l1n, nb, blk0, blk1); }); }
@@ -474,7 +476,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     struct Rep { std::vector<std::vector<char>> pool; KaiCtx c{}; };
     std::vector<Rep> reps;
     HostBackend be; Engine<HostBackend> eng(c, be);
-    int64_t batch_rounds = 0, batch_actions = 0, bucket_actions = 0;
+    int64_t batch_rounds = 0, batch_actions = 0, bucket_actions = 0, counts_actions = 0;
     bool index_stale = false;
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;
@@ -540,7 +542,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             if (int rc = batch_allocate(hl, c, prep.shape, bs, c.st->out_len, c.st->stmts)) return rc;
             if (bs.ran) {
                 c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops; c.st->stmts += bs.committed;
-                c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++; bucket_actions += bs.buckets;
+                c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++; bucket_actions += bs.buckets ? 1 : 0; counts_actions += bs.buckets == 2 ? 1 : 0;
                 if (bs.buckets) index_stale = true;
                 g_sh_exchanges = bs.exchanges;
             } else {
@@ -576,7 +578,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (pod_node_out) for (int p = 0; p < P; p++) pod_node_out[p] = c.p_node[p] >= 0 ? prep.perm[c.p_node[p]] : -1;
     if (shares_final) fill(shares_final);
     if (nodes_out) for (int n = 0; n < N; n++) { kai_node_state& o = nodes_out[prep.perm[n]]; std::memset(&o, 0, sizeof(kai_node_state)); for (int r = 0; r < R; r++) { o.idle[r] = c.n_idle[(size_t)r * N + n]; o.releasing[r] = c.n_rel[(size_t)r * N + n]; o.used[r] = c.n_used[(size_t)r * N + n]; } }
-    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; stats->reserved[4] = batch_actions; stats->reserved[5] = batch_rounds; stats->reserved[6] = bucket_actions; }
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; stats->reserved[4] = batch_actions; stats->reserved[5] = batch_rounds; stats->reserved[6] = bucket_actions; stats->reserved[7] = counts_actions; }
     return KAI_OK;
 }
 

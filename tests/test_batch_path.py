@@ -161,6 +161,59 @@ def test_bucket_fill_whole_nodes_per_step(seed, monkeypatch):
     assert_same(gen, res); assert stats_tuple(gen.stats) == stats_tuple(res.stats)
 
 
+def _counts(res):
+    """allocate actions whose fill ran as two wavefronts (kai_fill_counts.hpp: the planned order over the levels' populations, the sets behind a command ring)"""
+    return int(res.stats.reserved[7])
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_counts_fill_against_the_one_wave_kernel_the_general_kernel_and_the_oracle(seed, monkeypatch):
+    """The fill split in two (kai_fill_counts.hpp) takes the plain clusters — no class with a static bitmap of its own: gangs of one class decided from the levels' populations,
+    gangs of several classes simulated on a copy of the counts, the tasks' nodes resolved by the set worker behind the ring.  Against the oracle, the one-wave bucket kernel
+    (KAI_FILL_ONE_WAVE) and the general kernel; the native scalar shadow of tests/host_sim checks every launch's outputs on the way (KAI_HOSTSIM_NATIVE_FILL)."""
+    rng = np.random.default_rng(5900 + seed)
+    sizes, probs = [((1, 4, 8, 16, 64, 100), (.1, .2, .3, .2, .1, .1)), ((1, 2, 3, 24), (.3, .2, .2, .3)), ((1, 2, 700), (.6, .3, .1)), ((1,), (1.0,))][seed % 4]
+    snap = synth.make_snapshot(int(rng.integers(1, 500)), int(rng.integers(1, 3000)), 5900 + seed, queue_levels=[(1,), (2, 2), (3, 4), (2, 2, 2)][seed % 4], prefill=(0.0, 0.3, 0.6, 0.95)[seed % 4],
+                               gpu_mix=((16, .5), (8, .5)) if seed % 3 == 0 else ((8, .7), (4, .3)), gpus_per_pod=(1, 2, 4, 8) if seed % 5 else (1, 3, 5), gang_sizes=sizes, gang_p=probs,
+                               mem_per_gpu=8 * synth.GIB, cpu_per_gpu=2000.0, zipf=bool(seed % 2), limits_frac=0.3 if seed % 3 == 1 else 0.0, lexi_names=bool(seed % 7 == 0))
+    cfg = abi.default_config(k_value=0.5)
+    monkeypatch.setenv("KAI_HOSTSIM_NATIVE_FILL", "1")
+    res = run_both(snap, cfg)
+    if _buckets(res) != 1:
+        pytest.skip("this cluster does not qualify for the sets by free devices")
+    assert _counts(res) == 1
+    import ctypes as C
+    ms, a, b, d = C.c_double(), C.c_int64(), C.c_int64(), C.c_int64()
+    HostSim._raw.kai_hostsim_native_fill(C.byref(ms), C.byref(a), C.byref(b), C.byref(d))
+    assert a.value >= 1 and d.value == 0, "the native shadow of a launch ended with other outputs than the emulated kernel"
+    monkeypatch.setenv("KAI_FILL_ONE_WAVE", "1")
+    one = HostSim.run(snap, cfg)
+    assert _buckets(one) == 1 and _counts(one) == 0
+    assert_same(one, res); assert stats_tuple(one.stats) == stats_tuple(res.stats)
+    monkeypatch.delenv("KAI_FILL_ONE_WAVE"); monkeypatch.setenv("KAI_FILL_GENERAL", "1")
+    gen = HostSim.run(snap, cfg)
+    assert _buckets(gen) == 0
+    assert_same(gen, res); assert stats_tuple(gen.stats) == stats_tuple(res.stats)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_counts_fill_does_not_depend_on_how_the_two_wavefronts_interleave(order):
+    """The counting machine and the set worker only meet at the command ring: the emulator runs the waves of the workgroup in reverse order and with random passes sat out
+    (KW_EMU_ORDER), the results stay the oracle's."""
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import kai_testlib as T\nfrom test_engine_hostsim import HostSim\nfrom test_batch_path import assert_same\n"
+            "for seed in (1, 2, 3):\n"
+            "    snap = T.pkg.synth.make_snapshot(150, 1500, 6100 + seed, queue_levels=(2, 3), prefill=0.4, gang_sizes=(1, 4, 40), gang_p=(.5, .3, .2), mem_per_gpu=8 * T.pkg.synth.GIB, cpu_per_gpu=2000.0)\n"
+            "    cfg = T.abi.default_config(k_value=0.5)\n"
+            "    res = HostSim.run(snap, cfg)\n"
+            "    assert res.stats.reserved[7] == 1, seed\n"
+            "    assert_same(res, T.Oracle.run(snap, cfg))\n") % (T.ROOT, os.path.join(T.ROOT, "tests"))
+    env = dict(os.environ, KW_EMU_ORDER=str(order), KW_EMU_SEED="11")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_bucket_fill_declines_when_another_resource_may_bind():
     """20 000 mCPU per device on nodes of 64 000 - 192 000 mCPU: the CPU runs out before the devices do on most nodes, k_bucket_build's proof fails and
     the general kernel takes the fill — same results"""
