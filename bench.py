@@ -183,7 +183,8 @@ def main():
         plan_ms, fill_ms, apply_ms = (int(st.reserved[7]) >> 42) / 1e3, ((int(st.reserved[7]) >> 21) & 0x1fffff) / 1e3, (int(st.reserved[7]) & 0x1fffff) / 1e3
         rounds = int(st.reserved[4]); fill_dec = decisions - drained
         buckets = bool((int(st.reserved[1]) >> 62) & 1)  # the fill ran on k_fill_buckets (kai_fill_buckets.hpp): sets of nodes by free devices, all in LDS
-        fill_kernel = "k_fill_buckets" if buckets else "k_fill"
+        counts = bool((int(st.reserved[1]) >> 61) & 1)   # ... as two wavefronts side by side (kai_fill_counts.hpp): the planned order over the levels' populations, the sets behind a command ring
+        fill_kernel = "k_fill_counts" if counts else "k_fill_buckets" if buckets else "k_fill"
         if sharded:
             engine["exchanges_per_step"] = int(st.reserved[0])
         engine.update({"path": "batch (plan / fill / apply rounds)", "rounds": rounds, "mispredicted_jobs": int(st.reserved[6]), "fill_wave_cycles": int(st.reserved[5]),
@@ -193,20 +194,31 @@ def main():
         alg_bytes_launch = fill_dec * b_dec / max(rounds, 1); avg_launch_ms = fill_ms / max(rounds, 1)
         achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         traffic = pmc_traffic(desc, fill_kernel)
-        if buckets:
-            limiter = ("dependent LDS accesses of ONE wavefront (k_fill_buckets: 1 workgroup, wavefront 0 walks the planned order over bitmaps of the nodes by free devices "
-                       "— ~10 LDS round trips per decision, no node record is read; fill_cycles_per_decision below), not HBM")
-            note = ("achieved = decisions placed by k_fill_buckets x (N x 128 B + 80 B) / its time: decision throughput against the roofline of the STREAMING formulation (SURVEY 8d), "
-                    "which re-reads every node per decision.  The kernel answers a decision from LDS-resident sets (nodes with g free devices, g = 1..L) and touches HBM only for the "
-                    "task's node (4 B) and the sets' home copy per launch, so frac may exceed 1 (SURVEY 8d says so); what bounds it is LDS latency on one wavefront.")
+        cyc_dec = int(st.reserved[5]) / max(fill_dec, 1)
+        if counts:
+            limiter = ("instruction issue of TWO wavefronts on one compute unit (k_fill_counts: wavefront 0 walks the planned order over the levels' populations — a handful of integers in "
+                       "registers —, wavefront 1 executes its commands on the LDS-resident sets and writes the tasks' nodes; each is one dependency chain of mostly scalar instructions), not HBM and not LDS")
+            bound_actual = "single-wave issue (two chains side by side)"
+        elif buckets:
+            limiter = ("instruction issue of ONE wavefront (k_fill_buckets: 1 workgroup, wavefront 0 walks the planned order over bitmaps of the nodes by free devices: ~134 instructions per decision, "
+                       "most of them scalar, 1.4 LDS instructions — profiles/r04q_fill_pmc_instruction_mix.txt), not HBM and not LDS")
+            bound_actual = "single-wave issue"
         else:
             limiter = "instruction issue of ONE wavefront (k_fill runs as 1 workgroup x 64 lanes on one of the 256 CUs; fill_cycles_per_decision below), not HBM"
-            note = ("achieved = decisions placed by k_fill x (N x 128 B + 80 B) / k_fill time: decision throughput against the roofline of the STREAMING formulation (SURVEY 8d). "
-                    "The class index answers a decision from one 64-node block, so the measured traffic is far below the algorithmic bytes; the kernel is one wavefront "
-                    "bound by instruction issue / dependent latency (fill_cycles_per_decision), not by HBM bandwidth.")
+            bound_actual = "single-wave issue"
+        note = (f"achieved = decisions placed by {fill_kernel} x (N x 128 B + 80 B) / its time: decision throughput against the roofline of the STREAMING formulation (SURVEY 8d), which re-reads every "
+                "node per decision.  The kernel does not stream the nodes (it answers a decision from sets of nodes by free devices / a class index), so `frac` can exceed 1 and is NOT a statement about "
+                "HBM use: `own_roofline` is the kernel's own bound — the issue rate of the wavefronts that carry its dependency chain.")
+        # the kernel's OWN roofline: one wavefront issues one instruction per issue slot at best; r04q measured 7.7 cycles per instruction for this kind of dependent scalar / vector mix.  Floor taken
+        # here: 4 cycles per instruction (a wave64 VALU instruction occupies its SIMD for 4 cycles; dependent SALU instructions are no faster in practice) x the instructions per decision on file.
+        ipd = {"k_fill_buckets": 133.7, "k_fill": 530.0}.get(fill_kernel)  # profiles/r04q_fill_pmc_instruction_mix.txt, DESIGN.md section 5.2
+        own = {"bound": "single-wave instruction issue", "cycles_per_decision": cyc_dec, "clock_GHz": 2.4,
+               "instructions_per_decision": ipd, "issue_floor_cycles_per_instruction": 4.0,
+               "frac_of_issue_floor": (ipd * 4.0 / cyc_dec) if (ipd and cyc_dec > 0) else None,
+               "note": "cycles_per_decision = the fill wavefront's clock / decisions; instructions per decision from the committed SQ_INSTS_* passes of the same workload (None: no pass of this kernel on file yet)"}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "bound_actual": "lds-latency" if buckets else "issue", "limiter": limiter,
-                "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 4 if buckets else 1,
+                "bound_actual": bound_actual, "limiter": limiter, "own_roofline": own,
+                "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 4 if buckets else 1, "waves_working": 2 if counts else 1,
                 "traffic_source": "static: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE of the fill kernel from committed rocprofv3 --pmc passes of this command (counters need their own passes; not collected in this run)" if traffic else "no --pmc pass of this kernel on file",
                 "kernel": fill_kernel, "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "other_kernels": {"plan (k_plan_leaf / rank / scan / emit)": {"ms_per_step": plan_ms}, "apply (k_apply_jobs / nodes)": {"ms_per_step": apply_ms},
@@ -284,15 +296,39 @@ def main():
                     break
                 n_eq += 1
             out["parity_prefix"] = {"oracle_ops": len(ref.ops), "equal_to_gpu": n_eq}
-        # (2) the same ALGORITHM on one CPU thread: the host-compiled sequential engine of tests/host_sim (test infrastructure) on the full step
+        # (2) one CPU thread on the full step, two ways (both test infrastructure, tests/host_sim):
+        #   cpu_sequential_engine : the host-compiled SEQUENTIAL engine (engine_mode 3: the class-index walk of round 1, literal heaps) — another algorithm than the batch path's;
+        #   cpu_same_algorithm    : the batch path's FILL as it is — sets of nodes by free devices, whole nodes per step — in plain scalar C++ (native_bucket_fill.hpp), run as a shadow of
+        #                           every emulated fill launch with its outputs compared.  Live here on a scaled copy of the workload (the emulated plan kernels make a full-size run a matter
+        #                           of minutes); the full-size figure is the committed profiles/r05_native_fill_c5.json (tools/native_fill_timing.py on a GPU box's host).
         try:
             from test_engine_hostsim import HostSim
             c3 = T.abi.KaiConfig.from_buffer_copy(cfg); c3.engine_mode = 3
             tw = HostSim.run(snap, c3, actions)
-            out["cpu_same_algorithm"] = {"value": int(tw.stats.decisions) / (tw.elapsed_ms * 1e-3), "unit": "decisions/s", "cores": 1, "kind": "host-compiled sequential engine (tests/host_sim, g++ -O2)",
-                                         "ms_per_step": tw.elapsed_ms, "sample": "the full step", "ops_equal_to_gpu": [tuple(o) for o in tw.ops] == [tuple(o) for o in first_ops]}
+            out["cpu_sequential_engine"] = {"value": int(tw.stats.decisions) / (tw.elapsed_ms * 1e-3), "unit": "decisions/s", "cores": 1, "kind": "host-compiled sequential engine (tests/host_sim, g++ -O2): NOT the batch path's algorithm",
+                                            "ms_per_step": tw.elapsed_ms, "sample": "the full step", "ops_equal_to_gpu": [tuple(o) for o in tw.ops] == [tuple(o) for o in first_ops]}
         except Exception as e:  # the twin is optional evidence
-            out["cpu_same_algorithm"] = {"error": str(e)[:200]}
+            out["cpu_sequential_engine"] = {"error": str(e)[:200]}
+        if batch and actions == ("allocate",) and not args.mixed and args.fractions == 0 and os.environ.get("KAI_BENCH_NATIVE_FILL", "1") != "0":
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import native_fill_timing as NF
+                live_scale = min(args.scale, 0.1 if args.config == "C5" else 1.0)
+                live = NF.measure(idx, live_scale)
+                gpu_ns = fill_ms * 1e6 / max(fill_dec, 1)
+                same = {"kind": "the batch path's fill (sets of nodes by free devices) as scalar C++ on ONE host core, tests/host_sim/native_bucket_fill.hpp; outputs compared with the emulated kernel's at every launch",
+                        "cores": 1, "live": live, "gpu_fill_ns_per_decision": gpu_ns, "gpu_fill_kernel": fill_kernel,
+                        "host_core_over_gpu_fill": gpu_ns / live["ns_per_decision"] if live["ns_per_decision"] > 0 else None,
+                        "note": "fill only: the plan (data-parallel segmented scans / merges over the queue tree) and apply kernels have no single-core twin that is not the emulator; "
+                                "a ratio above 1 says one host core walks this chain faster than the MI355X's fill wavefronts"}
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r05_native_fill_c5.json")) as f:
+                        same["full_size_on_file"] = json.load(f)
+                except (OSError, ValueError):
+                    pass
+                out["cpu_same_algorithm"] = same
+            except Exception as e:
+                out["cpu_same_algorithm"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and os.environ.get("KAI_BENCH_OPEN_LEG", "1" if elapsed / args.steps < 5.0 else "0") != "0":  # (not for cycles of many seconds: the leg repeats the cycle several times)
         # What a production scheduler pays per cycle: every cycle opens a session on a NEW snapshot (scheduler.go:112-138, framework/framework.go:32-65), so
         # kai_session_open — host preparation (node permutation, task / job orders, scan classes: on the host's cores), ~80 MB over PCIe, the OnSessionOpen

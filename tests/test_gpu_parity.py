@@ -443,6 +443,35 @@ def test_gpu_bucket_fill_whole_nodes_per_step(gpu, seed, monkeypatch):
     assert_same(one, ref); assert stats_tuple(one.stats) == stats_tuple(ref.stats)
 
 
+def on_counts(stats):
+    """... as two wavefronts: the planned order over the levels' populations, the sets behind a command ring (kai_fill_counts.hpp; bit 61 of reserved[1])"""
+    return bool((int(stats.reserved[1]) >> 61) & 1)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_gpu_counts_fill_against_the_one_wave_kernel_and_the_oracle(gpu, seed, monkeypatch):
+    """k_fill_counts (kai_fill_counts.hpp) takes the clusters where no class carries a static bitmap of its own: gangs of one class decided from the levels' populations, gangs of
+    several classes on a copy of the counts, the tasks' nodes written by the set worker behind the ring — against the oracle and the one-wave k_fill_buckets (KAI_FILL_ONE_WAVE)
+    on the same snapshot (the CPU twin of this test also runs the general kernel and the native scalar shadow)."""
+    rng = np.random.default_rng(5900 + seed)
+    sizes, probs = [((1, 4, 8, 16, 64, 100), (.1, .2, .3, .2, .1, .1)), ((1, 2, 3, 24), (.3, .2, .2, .3)), ((1, 2, 700), (.6, .3, .1)), ((1,), (1.0,))][seed % 4]
+    snap = T.pkg.synth.make_snapshot(int(rng.integers(1, 500)), int(rng.integers(1, 3000)), 5900 + seed, queue_levels=[(1,), (2, 2), (3, 4), (2, 2, 2)][seed % 4], prefill=(0.0, 0.3, 0.6, 0.95)[seed % 4],
+                                     gpu_mix=((16, .5), (8, .5)) if seed % 3 == 0 else ((8, .7), (4, .3)), gpus_per_pod=(1, 2, 4, 8) if seed % 5 else (1, 3, 5), gang_sizes=sizes, gang_p=probs,
+                                     mem_per_gpu=8 * T.pkg.synth.GIB, cpu_per_gpu=2000.0, zipf=bool(seed % 2), limits_frac=0.3 if seed % 3 == 1 else 0.0, lexi_names=bool(seed % 7 == 0))
+    cfg = T.abi.default_config(k_value=0.5)
+    ref = T.Oracle.run(snap, cfg)
+    res = run_gpu(snap, cfg)
+    assert_same(res, ref)
+    assert stats_tuple(res.stats) == stats_tuple(ref.stats)
+    if not on_buckets(res.stats):
+        pytest.skip("this cluster does not qualify for the sets by free devices")
+    assert on_counts(res.stats)
+    monkeypatch.setenv("KAI_FILL_ONE_WAVE", "1")
+    one = run_gpu(snap, cfg)
+    assert on_buckets(one.stats) and not on_counts(one.stats)
+    assert_same(one, ref); assert stats_tuple(one.stats) == stats_tuple(ref.stats)
+
+
 def test_gpu_bucket_fill_corners(gpu):
     """what k_bucket_build turns away (another resource may bind first, 32 devices per node) runs on the general kernel; static predicates per class, 16
     devices per node, a nearly full cluster run on the bucket kernel — all equal to the oracle"""
