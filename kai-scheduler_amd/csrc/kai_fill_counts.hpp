@@ -25,7 +25,7 @@ namespace kai {
 
 constexpr int KFC_RING = 2048;  // commands the ring holds; a gang (<= KB_PLACED_MAX tasks) is written in full before it is published
 struct FcCmd { int32_t lv, k, per, tbase; };  // lv = g | g2 << 8: the first k nodes of level g move to level g2 (0: no level), `per` tasks each; t_node[tbase ..) receives the nodes
-struct FcLds { FcCmd ring[KFC_RING]; int32_t cnt0[KBK_GMAX]; int32_t head, tail, done, pad; };
+struct FcLds { FcCmd ring[KFC_RING]; int32_t cnt0[KBK_GMAX]; int32_t head, tail, done, pad; int64_t a_wait, b_idle, b_total; };  // (the three clocks: profiling)
 
 KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
     KW_SHARED FcLds L;
@@ -55,6 +55,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         uint32_t nz = (uint32_t)kw::ballot(cnt > 0);  // bit l: level l + 1 holds a node
         int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, steps = 0, n_done = rp.start, mismatch = 0;
         int wp = 0, tail_seen = 0;  // commands written / the worker's progress as last read
+        int64_t a_wait = 0;         // cycles this wavefront waited for room in the ring
         // the lowest non-empty level >= qc, 0 = none
         #define KFC_LEVEL_FOR(qc) ((nz >> ((qc) - 1)) ? (qc) + __builtin_ctz(nz >> ((qc) - 1)) : 0)
         // k nodes leave level g for level g2 (0: none): the counts and the non-empty mask, from values this lane already holds
@@ -62,24 +63,30 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         for (int base = rp.start; base < V && !mismatch; base += 64) {
             const int gi = base + lane;
             const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE, my_first = gi < V ? b.g_first[gi] : 0, my_nt = gi < V ? b.g_nt[gi] : 0, my_ucls = gi < V ? b.g_ucls[gi] : 0;
+            const int my_pack = my_flag | ((my_ucls + 1) << 2) | (my_nt << 12);  // (flag: 2 bits, class + 1: up to 64, tasks: up to KB_PLACED_MAX) — one readlane per job instead of three
             const int jn = V - base < 64 ? V - base : 64;
-            int my_out = 0, my_opoff = 0, my_stmt = 0, n_out = 0;  // lane jj: what job jj of this stretch ended with (stored once per stretch, coalesced)
-            for (int jj = 0; jj < jn; jj++) {
-                const int flag = kw::bcast(my_flag, jj), first = kw::bcast(my_first, jj), nt = kw::bcast(my_nt, jj), ucls = kw::bcast(my_ucls, jj);
+            // jobs the plan turned away at a capacity gate take no part in the fill: their outcome is written here, the walk below steps over them
+            uint64_t todo = kw::ballot(gi < V && my_flag != BF_GATE);
+            int my_out = BF_DEAD, my_opoff = 0, my_stmt = 0, n_out = jn;  // lane jj: what job jj of this stretch ended with (stored once per stretch, coalesced)
+            attempted += jn; n_done = base + jn;
+            while (todo) {
+                const int jj = __builtin_ctzll(todo); todo &= todo - 1;
+                const int pack = kw::bcast(my_pack, jj), first = kw::bcast(my_first, jj);
+                const int flag = pack & 3, ucls = ((pack >> 2) & 0x3ff) - 1, nt = pack >> 12;
                 const int opoff = ops + rp.ops0, stmtoff = committed + rp.stmt0;
-                bool ok = flag != BF_GATE;
-                if (ok && ucls >= 0) {
+                bool ok = true;
+                if (ucls >= 0) {
                     // a gang of ONE class: it fits iff the levels hold enough places for it (a node of level g holds g / q of its tasks, every placement takes exactly one
                     // place away) — else it places `cap` tasks, finds no node for the next one and is rolled back: cap + 1 decisions, the state it started from
                     const int qc = kw::bcast(q, ucls);
                     int cap;
                     if (nt == 1) cap = (nz >> (qc - 1)) ? 1 : 0;
                     else { int term = 0; if (lane < v.LV && lane + 1 >= qc) term = bk_div_small(lane + 1, qc) * cnt; cap = 0; for (int l = qc - 1; l < v.LV && cap < nt; l++) cap += kw::bcast(term, l); }
-                    if (cap < nt) { decisions += cap + 1; ok = false; if (nt > 1 || cap) { /* (what the one-wave kernel books for a gang it started and undid) */ } }
+                    if (cap < nt) { decisions += cap + 1; ok = false; }
                     else {
                         int done = 0;
                         while (done < nt) {
-                            while (wp - tail_seen >= KFC_RING) { tail_seen = kw::lds_load_acq(&L.tail); if (wp - tail_seen >= KFC_RING) kw::relax(); }
+                            if (wp - tail_seen >= KFC_RING) { const int64_t w0 = kw::clock(); while (wp - tail_seen >= KFC_RING) { tail_seen = kw::lds_load_acq(&L.tail); if (wp - tail_seen >= KFC_RING) kw::relax(); } a_wait += kw::clock() - w0; }
                             const int g = KFC_LEVEL_FOR(qc), r = bk_div_small(g, qc), rem = nt - done, cg = kw::bcast(cnt, g - 1);
                             int k = 1, per = rem;
                             if (rem >= r) { per = r; k = bk_div_small(rem, r); if (k > cg) k = cg; }
@@ -92,9 +99,9 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                         decisions += nt;
                         kw::lds_store_rel(&L.head, wp);
                     }
-                } else if (ok) {
+                } else {
                     // a gang of several scan classes: task by task on a copy of the counts; its commands stay unpublished until the last task has found its level
-                    while (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { tail_seen = kw::lds_load_acq(&L.tail); if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) kw::relax(); }
+                    if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { const int64_t w0 = kw::clock(); while (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { tail_seen = kw::lds_load_acq(&L.tail); if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) kw::relax(); } a_wait += kw::clock() - w0; }
                     const int cnt_s = cnt; const uint32_t nz_s = nz; const int wp_s = wp;
                     for (int tb = 0; tb < nt && ok; tb += 64) {
                         const int my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;
@@ -113,10 +120,9 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                     if (ok) kw::lds_store_rel(&L.head, wp);
                     else { cnt = cnt_s; nz = nz_s; wp = wp_s; }  // Statement.Rollback: nothing was published
                 }
-                if (flag != BF_GATE) { if (ok) { committed++; ops += nt; } else rollbacks += 2; }
-                attempted++; n_done = base + jj + 1;
-                { const bool me = lane == jj; my_out = me ? (ok ? BF_OK : BF_DEAD) : my_out; my_opoff = me ? opoff : my_opoff; my_stmt = me ? stmtoff : my_stmt; n_out = jj + 1; }
-                if ((flag == BF_OK) != ok) { mismatch = 1; break; }
+                if (ok) { committed++; ops += nt; } else rollbacks += 2;
+                { const bool me = lane == jj; my_out = me ? (ok ? BF_OK : BF_DEAD) : my_out; my_opoff = me ? opoff : my_opoff; my_stmt = me ? stmtoff : my_stmt; }
+                if ((flag == BF_OK) != ok) { mismatch = 1; n_done = base + jj + 1; n_out = jj + 1; attempted -= jn - (jj + 1); break; }
             }
             if (lane < n_out) { b.g_out[base + lane] = (uint8_t)my_out; b.g_opoff[base + lane] = my_opoff; b.g_stmt[base + lane] = my_stmt; }
         }
@@ -128,7 +134,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         if (lane == 0) {
             FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V; s.floor_stop = 0; s.pad = 0;
             s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
-            s.cycles_total = kw::clock() - tstart; s.cycles_load = 0; s.cycles_update = 0; s.cycles_rescan = 0; s.block_loads = 0;
+            s.cycles_total = kw::clock() - tstart; s.cycles_load = a_wait; s.cycles_update = 0; s.cycles_rescan = 0; s.block_loads = 0;  // (cycles_update / cycles_rescan: the worker's idle and total clocks, added below)
             s.rescans1 = 0; s.rescans2 = steps; s.rescans3 = 0;  // rescans2: commands (a command moves the first k nodes of a level)
             b.fs[0] = s; b.dead_mask[0] = dead;
         }
@@ -139,23 +145,31 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         int dummy = 0, firstn = KB_INF;  // firstn: the lowest name rank of this lane's level (KB_INF: the level is empty)
         auto own_first = [&]() { if (!s2) return KB_INF; const int w1 = __builtin_ctzll(s2); const uint64_t m1 = v.s1[lane * v.NW1 + w1]; const int w = w1 * 64 + __builtin_ctzll(m1); return w * 64 + __builtin_ctzll(v.gw[lane * v.NW + w]); };
         if (lane < v.LV) firstn = own_first();
-        int tail = 0, finds = 0;
+        int tail = 0, finds = 0; int64_t b_idle = 0; const int64_t b_start = kw::clock();
         for (;;) {
             const int head = kw::lds_load_acq(&L.head);
-            if (tail == head) { if (kw::lds_load_acq(&L.done) && tail == kw::lds_load_acq(&L.head)) break; kw::relax(); continue; }
+            if (tail == head) {
+                if (kw::lds_load_acq(&L.done) && tail == kw::lds_load_acq(&L.head)) break;
+                const int64_t i0 = kw::clock(); while (kw::lds_load_acq(&L.head) == tail && !kw::lds_load_acq(&L.done)) kw::relax(); b_idle += kw::clock() - i0;
+                continue;
+            }
+            FcCmd nxt = L.ring[tail & (KFC_RING - 1)];
             for (; tail < head; tail++) {
-                const FcCmd cm = L.ring[tail & (KFC_RING - 1)];
+                const FcCmd cm = nxt; nxt = L.ring[(tail + 1) & (KFC_RING - 1)];  // (the next command's read is in flight while this one runs; a slot beyond `head` is read and not used)
                 const int g = cm.lv & 0xff, g2 = cm.lv >> 8, per = cm.per; int left = cm.k, tb = cm.tbase;
                 while (left > 0) {
                     const int n = kw::bcast(firstn, g - 1), w = n >> 6;
-                    uint64_t word = v.gw[(g - 1) * v.NW + w];
-                    kw::lds_order();  // (every lane has read the word before its owner toggles it below)
-                    int m = __builtin_popcountll(word); uint64_t mask = word;
-                    if (m > left) { m = left; mask = 0; for (int j = 0; j < m; j++) { mask |= word & (0 - word); word &= word - 1; } }
-                    for (int t0 = 0; t0 < m * per; t0 += 64) {  // task t of this word's share sits on the (t / per)-th node of the mask
-                        const int t = t0 + lane;
-                        if (t < m * per) { uint64_t mm = mask; for (int j = bk_div_small(t, per); j > 0; j--) mm &= mm - 1; b.t_node[tb + t] = (w << 6) + __builtin_ctzll(mm); }
-                    }
+                    int m = 1; uint64_t mask = 1ull << (n & 63);
+                    if (left > 1) {  // several nodes: the set bits of n's word at its level, from n upwards (n is the level's first node)
+                        uint64_t word = v.gw[(g - 1) * v.NW + w];
+                        kw::lds_order();  // (every lane has read the word before its owner toggles it below)
+                        m = __builtin_popcountll(word); mask = word;
+                        if (m > left) { m = left; mask = 0; for (int j = 0; j < m; j++) { mask |= word & (0 - word); word &= word - 1; } }
+                        for (int t0 = 0; t0 < m * per; t0 += 64) {  // task t of this word's share sits on the (t / per)-th node of the mask
+                            const int t = t0 + lane;
+                            if (t < m * per) { uint64_t mm = mask; for (int j = bk_div_small(t, per); j > 0; j--) mm &= mm - 1; b.t_node[tb + t] = (w << 6) + __builtin_ctzll(mm); }
+                        }
+                    } else if (lane < per) b.t_node[tb + lane] = n;  // one node (the usual command): its tasks all sit on n (per <= 16)
                     const uint64_t neww = bk_move_mask(v, s2, dummy, w, mask, g, g2);
                     if (lane == g - 1) { if (neww) firstn = (w << 6) + __builtin_ctzll(neww); else { firstn = own_first(); finds++; } }
                     if (lane == g2 - 1 && n < firstn) firstn = n;
@@ -165,8 +179,10 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
             kw::lds_store_rel(&L.tail, tail);
         }
         (void)finds;
+        if (lane == 0) { L.b_idle = b_idle; L.b_total = kw::clock() - b_start; }
     }
     kw::sync();
+    if (tid == 0) { b.fs[0].cycles_update = L.b_idle; b.fs[0].cycles_rescan = L.b_total; }
     for (int i = tid; i < v.LV * v.NW; i += T) b.bk_words[i] = v.gw[i];
 }
 

@@ -217,11 +217,16 @@ struct HostLauncher {
         same = same && f.n_done == nat.fs.n_done && f.mismatch == nat.fs.mismatch && f.all_dead == nat.fs.all_dead && f.planned == nat.fs.planned && f.decisions == nat.fs.decisions && f.attempted == nat.fs.attempted &&
                f.committed == nat.fs.committed && f.rollbacks == nat.fs.rollbacks && f.ops == nat.fs.ops && f.dead_mask == nat.fs.dead_mask;
         for (size_t i = 0; i < nat.words.size() && same; i++) same = bt.bk_words[i] == nat.words[i];
+        if (!same && std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "native shadow: counters or sets differ\n");
         for (int gi = rp.start; gi < f.n_done && same; gi++) {
             const int x = gi - rp.start;
-            same = bt.g_out[gi] == nat.g_out[x] && bt.g_opoff[gi] == nat.g_opoff[x] && bt.g_stmt[gi] == nat.g_stmt[x];
+            same = bt.g_out[gi] == nat.g_out[x] && (nat.g_out[x] != BF_OK || (bt.g_opoff[gi] == nat.g_opoff[x] && bt.g_stmt[gi] == nat.g_stmt[x]));  // (offsets: what the apply kernels read, committed jobs only)
+            if (!same && std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "native shadow: job %d (start %d) flag %d out %d/%d opoff %d/%d stmt %d/%d\n", gi, rp.start, (int)bt.g_flag[gi], (int)bt.g_out[gi], (int)nat.g_out[x], bt.g_opoff[gi], nat.g_opoff[x], bt.g_stmt[gi], nat.g_stmt[x]);
             if (same && nat.g_out[x] == BF_OK && bt.g_flag[gi] != BF_GATE) for (int t = 0; t < bt.g_nt[gi] && same; t++) same = bt.t_node[bt.g_first[gi] + t] == nat.t_node[(size_t)bt.g_first[gi] + t];
         }
+        if (!same && std::getenv("KAI_HOSTSIM_DEBUG")) std::fprintf(stderr, "native shadow differs: n_done %d/%d mismatch %d/%d all_dead %d/%d planned %d/%d decisions %lld/%lld attempted %lld/%lld committed %lld/%lld rollbacks %lld/%lld ops %lld/%lld dead %llx/%llx\n",
+            f.n_done, nat.fs.n_done, f.mismatch, nat.fs.mismatch, f.all_dead, nat.fs.all_dead, f.planned, nat.fs.planned, (long long)f.decisions, (long long)nat.fs.decisions, (long long)f.attempted, (long long)nat.fs.attempted,
+            (long long)f.committed, (long long)nat.fs.committed, (long long)f.rollbacks, (long long)nat.fs.rollbacks, (long long)f.ops, (long long)nat.fs.ops, (unsigned long long)f.dead_mask, (unsigned long long)nat.fs.dead_mask);
         g_native_fill_ms += nat.ms; g_native_fill_launches++; g_native_fill_decisions += nat.fs.decisions; if (!same) g_native_fill_diffs++;
     }
     void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); }); }); }
