@@ -1434,6 +1434,10 @@ struct Engine {
 #ifdef KAI_PROF_POP
         int64_t tk0 = be.clock(); el().h.prof[8]++;
 #endif
+#ifdef KAI_PROF_VPOP
+        const int64_t tvk0 = be.clock(); el().h.prof[1]++;  // (victim-search profile of the queue pops: keys recomputed / their cycles in slot 6)
+        struct TVK { Engine* e; int64_t t0; KAI_HD ~TVK() { e->el().h.prof[6] += e->be.clock() - t0; } } tvk{this, tvk0};
+#endif
         const QShare L[3] = {cx().q_share[(size_t)q * 3], cx().q_share[(size_t)q * 3 + 1], cx().q_share[(size_t)q * 3 + 2]};  // loaded before the best-job chain: the two overlap
         int bj = best_job_from_node(q);
         double req[3] = {0, 0, 0};
@@ -1582,6 +1586,9 @@ struct Engine {
         return i > i0;
     }
     KAI_HD int leaf_pop(int q) {
+#ifdef KAI_PROF_VPOP
+        struct TVL { Engine* e; int64_t t0; KAI_HD ~TVL() { e->el().h.prof[23] += e->be.clock() - t0; } } tvl{this, be.clock()};
+#endif
         leaf_skip(q);
         const int cur = lq_cur()[q], end = lq_end()[q], off = cx().q_job_off[q], nside = lq_side_len()[q];
         int a = cur < end ? lq_sorted()[off + cur] : -1;
@@ -1633,6 +1640,9 @@ struct Engine {
     KAI_HD void node_heap_push(int parent, int q) { int32_t* h = node_heap(parent); int n = node_heap_len(parent); h[n] = q; set_heap_len(parent, n + 1); heap_up(h, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
     KAI_HD void node_heap_pop(int parent) { int32_t* h = node_heap(parent); int n = node_heap_len(parent) - 1; set_heap_len(parent, n); int t = h[0]; h[0] = h[n]; h[n] = t; heap_down(h, 0, n, NodeLess{this}); if (parent >= 0) invalidate_path(parent); }
     KAI_HD void node_heap_fix0(int parent) {
+#ifdef KAI_PROF_VPOP
+        struct TVF { Engine* e; int64_t t0; KAI_HD ~TVF() { e->el().h.prof[12] += e->be.clock() - t0; e->el().h.prof[15]++; } } tvf{this, be.clock()};  // (heap fixes: cycles incl. the keys computed inside / count)
+#endif
 #ifdef KAI_PROF_POP
         int64_t tf0 = be.clock(); el().h.prof[11]++;
 #endif
