@@ -211,11 +211,13 @@ def main():
                 "HBM use: `own_roofline` is the kernel's own bound — the issue rate of the wavefronts that carry its dependency chain.")
         # the kernel's OWN roofline: one wavefront issues one instruction per issue slot at best; r04q measured 7.7 cycles per instruction for this kind of dependent scalar / vector mix.  Floor taken
         # here: 4 cycles per instruction (a wave64 VALU instruction occupies its SIMD for 4 cycles; dependent SALU instructions are no faster in practice) x the instructions per decision on file.
-        ipd = {"k_fill_buckets": 133.7, "k_fill": 530.0}.get(fill_kernel)  # profiles/r04q_fill_pmc_instruction_mix.txt, DESIGN.md section 5.2
-        own = {"bound": "single-wave instruction issue", "cycles_per_decision": cyc_dec, "clock_GHz": 2.4,
+        ipd = {"k_fill_counts": 115.9, "k_fill_buckets": 133.7, "k_fill": 530.0}.get(fill_kernel)  # profiles/r05f_fill_pmc_instruction_mix.txt, r04q_fill_pmc_instruction_mix.txt, DESIGN.md section 5.2
+        chains = 2 if counts else 1  # wavefronts that carry the kernel's dependency chains side by side
+        own = {"bound": "single-wave instruction issue", "cycles_per_decision": cyc_dec, "clock_GHz": 2.4, "wavefronts_working": chains,
                "instructions_per_decision": ipd, "issue_floor_cycles_per_instruction": 4.0,
-               "frac_of_issue_floor": (ipd * 4.0 / cyc_dec) if (ipd and cyc_dec > 0) else None,
-               "note": "cycles_per_decision = the fill wavefront's clock / decisions; instructions per decision from the committed SQ_INSTS_* passes of the same workload (None: no pass of this kernel on file yet)"}
+               "frac_of_issue_floor": (ipd / chains * 4.0 / cyc_dec) if (ipd and cyc_dec > 0) else None,
+               "note": "cycles_per_decision = the fill wavefront's clock / decisions; instructions per decision (all working wavefronts together) from the committed SQ_INSTS_* passes of the same workload; "
+                       "floor = a wavefront issues at most one instruction per 4 cycles (a wave64 VALU instruction occupies its SIMD for 4 cycles); measured: one per 7.7 - 8.5 cycles (dependent scalar <-> vector chains)"}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bound_actual": bound_actual, "limiter": limiter, "own_roofline": own,
                 "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 4 if buckets else 1, "waves_working": 2 if counts else 1,
