@@ -263,7 +263,7 @@ def main():
         sha = T.ops_sha256(first_ops); pin = None
         try:
             with open(os.path.join(ROOT, "profiles", "full_size_pins.json")) as f:
-                pin = next((v for v in json.load(f).values() if v["workload"] == desc and v["nodes"] == N and v["pods"] == snap.n_pods), None)
+                pin = next((v for v in json.load(f).values() if v["workload"] == desc and v["nodes"] == N and v["pods"] == snap.n_pods and v.get("actions", list(actions)) == list(actions)), None)
         except (OSError, ValueError, KeyError):
             pin = None
         out["parity_full"] = {"ops": len(first_ops), "ops_sha256": sha, "oracle_ops_sha256": pin["ops_sha256"] if pin else None, "equal_to_oracle": (sha == pin["ops_sha256"]) if pin else None,

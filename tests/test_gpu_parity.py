@@ -105,6 +105,21 @@ def test_gpu_config4_cycle_hashes_to_the_oracles(gpu, key, scale, depth):
     assert len(res.ops) == pin["ops"] and T.ops_sha256(res.ops) == pin["ops_sha256"]
 
 
+def test_gpu_default_cycle_on_config5_hashes_to_the_oracles(gpu):
+    """The cycle the reference runs by default — allocate, consolidation, reclaim, preempt on one session (conf_util/scheduler_conf_util.go:37, without stalegangeviction) — on
+    BASELINE config 5's shape at 0.5 % (328 nodes x 5 000 pods; queueDepthPerAction 8 for the victim actions): after allocate most pods are still pending and the three victim
+    actions search victims for them.  Operations pinned by the oracle's run (tools/pin_full_cycle.py)."""
+    import json, os
+    with open(os.path.join(T.ROOT, "profiles", "full_size_pins.json")) as f:
+        pin = json.load(f)["C5_0.5pct_cycle_depth8"]
+    snap, cfg, _ = T.pkg.synth.config(4, pin["scale"])
+    for a in ("consolidation", "reclaim", "preempt"):
+        cfg.queue_depth[T.abi.ACTIONS[a]] = pin["queue_depth"]
+    assert (snap.n_nodes, snap.n_pods, snap.n_jobs) == (pin["nodes"], pin["pods"], pin["jobs"])
+    res = run_gpu(snap, cfg, tuple(pin["actions"]))
+    assert len(res.ops) == pin["ops"] and T.ops_sha256(res.ops) == pin["ops_sha256"]
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_gpu_random_small(gpu, seed):
     rng = np.random.default_rng(seed)
