@@ -25,7 +25,8 @@ namespace kai {
 
 constexpr int KFC_RING = 2048;  // commands the ring holds; a gang (<= KB_PLACED_MAX tasks) is written in full before it is published
 struct FcCmd { int32_t lv, k, per, tbase; };  // lv = g | g2 << 8: the first k nodes of level g move to level g2 (0: no level), `per` tasks each; t_node[tbase ..) receives the nodes
-struct FcLds { FcCmd ring[KFC_RING]; int32_t cnt0[KBK_GMAX]; int32_t head, tail, done, pad; int64_t a_wait, b_idle, b_total; };  // (the three clocks: profiling)
+struct FcMove { int32_t w, cmd; uint64_t mask; };  // hand-over from the worker of the upper levels to the worker of the lower ones: the nodes `mask` of word w enter command cmd's target level (cmd bit 30: its last entry)
+struct FcLds { FcCmd ring[KFC_RING]; FcMove xring[KFC_RING]; int32_t cnt0[KBK_GMAX]; int32_t head, tail0, tail1, done, xhead, xtail, pad0, pad1; int64_t a_wait, b_idle[2], b_total[2]; };  // (the clocks: profiling)
 
 KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
     KW_SHARED FcLds L;
@@ -36,7 +37,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
     v.gw = (KW_LDS_PTR(uint64_t))dyn; v.s1 = v.gw + (size_t)v.LV * v.NW; v.ok = v.s1 + (size_t)v.LV * v.NW1 + KBK_GMAX;
     const int64_t tstart = kw::clock();
     if (tid < KBK_GMAX) L.cnt0[tid] = 0;
-    if (tid == 0) { L.head = 0; L.tail = 0; L.done = 0; }
+    if (tid == 0) { L.head = 0; L.tail0 = 0; L.tail1 = 0; L.done = 0; L.xhead = 0; L.xtail = 0; L.b_idle[0] = L.b_idle[1] = 0; L.b_total[0] = L.b_total[1] = 0; }
     for (int i = tid; i < v.LV * v.NW; i += T) v.gw[i] = b.bk_words[i];
     kw::sync();
     for (int i = tid; i < v.LV * v.NW1; i += T) {  // first summary level, and the levels' populations on the way
@@ -47,6 +48,9 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
     }
     kw::sync();
     const int V = rp.mode != 1 ? b.q_valid[c.Q] : 0;  // mode 1: dead classes only (before the first plan)
+    // two set workers from four levels on: wavefront 1 owns the levels 1 .. SPLIT, wavefront 2 the levels above (nodes only move DOWN the levels, so the upper worker never waits for the lower one)
+    const int SPLIT = v.LV >= 4 ? (v.LV >= 8 ? v.LV / 2 - 1 : v.LV / 2) : v.LV;
+    const bool two_workers = SPLIT < v.LV;
     if (tid < 64) {
         // ------------------------------------------------------------------ wavefront 0: the counting machine.  lane l: nodes of level l + 1; lane k: class k's request
         int cnt = lane < v.LV ? L.cnt0[lane] : 0;
@@ -56,6 +60,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, steps = 0, n_done = rp.start, mismatch = 0;
         int wp = 0, tail_seen = 0;  // commands written / the worker's progress as last read
         int64_t a_wait = 0;         // cycles this wavefront waited for room in the ring
+        auto tails_min = [&]() { const int t0 = kw::lds_load_acq(&L.tail0); if (!two_workers) return t0; const int t1 = kw::lds_load_acq(&L.tail1); return t0 < t1 ? t0 : t1; };  // a slot is free once BOTH workers have read it
         // the lowest non-empty level >= qc, 0 = none
         #define KFC_LEVEL_FOR(qc) ((nz >> ((qc) - 1)) ? (qc) + __builtin_ctz(nz >> ((qc) - 1)) : 0)
         // k nodes leave level g for level g2 (0: none): the counts and the non-empty mask, from values this lane already holds
@@ -86,7 +91,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                     else {
                         int done = 0;
                         while (done < nt) {
-                            if (wp - tail_seen >= KFC_RING) { const int64_t w0 = kw::clock(); while (wp - tail_seen >= KFC_RING) { tail_seen = kw::lds_load_acq(&L.tail); if (wp - tail_seen >= KFC_RING) kw::relax(); } a_wait += kw::clock() - w0; }
+                            if (wp - tail_seen >= KFC_RING) { const int64_t w0 = kw::clock(); while (wp - tail_seen >= KFC_RING) { tail_seen = tails_min(); if (wp - tail_seen >= KFC_RING) kw::relax(); } a_wait += kw::clock() - w0; }
                             const int g = KFC_LEVEL_FOR(qc), r = bk_div_small(g, qc), rem = nt - done, cg = kw::bcast(cnt, g - 1);
                             int k = 1, per = rem;
                             if (rem >= r) { per = r; k = bk_div_small(rem, r); if (k > cg) k = cg; }
@@ -101,7 +106,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                     }
                 } else {
                     // a gang of several scan classes: task by task on a copy of the counts; its commands stay unpublished until the last task has found its level
-                    if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { const int64_t w0 = kw::clock(); while (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { tail_seen = kw::lds_load_acq(&L.tail); if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) kw::relax(); } a_wait += kw::clock() - w0; }
+                    if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { const int64_t w0 = kw::clock(); while (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { tail_seen = tails_min(); if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) kw::relax(); } a_wait += kw::clock() - w0; }
                     const int cnt_s = cnt; const uint32_t nz_s = nz; const int wp_s = wp;
                     for (int tb = 0; tb < nt && ok; tb += 64) {
                         const int my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;
@@ -134,18 +139,23 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         if (lane == 0) {
             FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V; s.floor_stop = 0; s.pad = 0;
             s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
-            s.cycles_total = kw::clock() - tstart; s.cycles_load = a_wait; s.cycles_update = 0; s.cycles_rescan = 0; s.block_loads = 0;  // (cycles_update / cycles_rescan: the worker's idle and total clocks, added below)
+            s.cycles_total = kw::clock() - tstart; s.cycles_load = a_wait; s.cycles_update = 0; s.cycles_rescan = 0; s.block_loads = 0;  // (cycles_update / cycles_rescan, block_loads / rescans1: the workers' idle and total clocks, added below)
             s.rescans1 = 0; s.rescans2 = steps; s.rescans3 = 0;  // rescans2: commands (a command moves the first k nodes of a level)
             b.fs[0] = s; b.dead_mask[0] = dead;
         }
-    } else if (tid < 128) {
-        // ------------------------------------------------------------------ wavefront 1: the set worker.  lane l owns level l + 1: its words, its summaries, its first node
+    } else if (tid < 128 || (tid < 192 && two_workers)) {
+        // ------------------------------------------------------------------ wavefronts 1 and 2: the set workers.  lane l owns level l + 1 — its words, its summaries, its first node — in
+        // the worker that owns that level.  Both read every command.  The worker that owns a command's SOURCE level removes the nodes and writes the tasks' nodes; if it also owns the
+        // target level it inserts them in the same ds_xor, else (source above SPLIT, target at or below) it hands (word, mask) over through xring and the lower worker inserts them when it
+        // reaches that command — every level sees its removals and insertions in command order.
+        const int me = tid < 128 ? 0 : 1, own_lo = me == 0 ? 1 : SPLIT + 1, own_hi = me == 0 ? SPLIT : v.LV;
+        const bool mine = lane + 1 >= own_lo && lane + 1 <= own_hi;
         uint64_t s2 = 0;
-        if (lane < v.LV) for (int j = 0; j < v.NW1; j++) if (v.s1[lane * v.NW1 + j]) s2 |= 1ull << j;
+        if (mine) for (int j = 0; j < v.NW1; j++) if (v.s1[lane * v.NW1 + j]) s2 |= 1ull << j;
         int dummy = 0, firstn = KB_INF;  // firstn: the lowest name rank of this lane's level (KB_INF: the level is empty)
         auto own_first = [&]() { if (!s2) return KB_INF; const int w1 = __builtin_ctzll(s2); const uint64_t m1 = v.s1[lane * v.NW1 + w1]; const int w = w1 * 64 + __builtin_ctzll(m1); return w * 64 + __builtin_ctzll(v.gw[lane * v.NW + w]); };
-        if (lane < v.LV) firstn = own_first();
-        int tail = 0, finds = 0; int64_t b_idle = 0; const int64_t b_start = kw::clock();
+        if (mine) firstn = own_first();
+        int tail = 0, finds = 0, xp = 0, xseen = 0; int64_t b_idle = 0; const int64_t b_start = kw::clock();  // xp: hand-over entries written (upper worker) / read (lower worker)
         for (;;) {
             const int head = kw::lds_load_acq(&L.head);
             if (tail == head) {
@@ -157,32 +167,52 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
             for (; tail < head; tail++) {
                 const FcCmd cm = nxt; nxt = L.ring[(tail + 1) & (KFC_RING - 1)];  // (the next command's read is in flight while this one runs; a slot beyond `head` is read and not used)
                 const int g = cm.lv & 0xff, g2 = cm.lv >> 8, per = cm.per; int left = cm.k, tb = cm.tbase;
-                while (left > 0) {
-                    const int n = kw::bcast(firstn, g - 1), w = n >> 6;
-                    int m = 1; uint64_t mask = 1ull << (n & 63);
-                    if (left > 1) {  // several nodes: the set bits of n's word at its level, from n upwards (n is the level's first node)
-                        uint64_t word = v.gw[(g - 1) * v.NW + w];
-                        kw::lds_order();  // (every lane has read the word before its owner toggles it below)
-                        m = __builtin_popcountll(word); mask = word;
-                        if (m > left) { m = left; mask = 0; for (int j = 0; j < m; j++) { mask |= word & (0 - word); word &= word - 1; } }
-                        for (int t0 = 0; t0 < m * per; t0 += 64) {  // task t of this word's share sits on the (t / per)-th node of the mask
-                            const int t = t0 + lane;
-                            if (t < m * per) { uint64_t mm = mask; for (int j = bk_div_small(t, per); j > 0; j--) mm &= mm - 1; b.t_node[tb + t] = (w << 6) + __builtin_ctzll(mm); }
+                const bool own_g = g >= own_lo && g <= own_hi, own_g2 = g2 >= own_lo && g2 <= own_hi;
+                if (own_g) {
+                    const int to = own_g2 ? g2 : 0;  // (a target level of the other worker: removed here, inserted there)
+                    while (left > 0) {
+                        const int n = kw::bcast(firstn, g - 1), w = n >> 6;
+                        int m = 1; uint64_t mask = 1ull << (n & 63);
+                        if (left > 1) {  // several nodes: the set bits of n's word at its level, from n upwards (n is the level's first node)
+                            uint64_t word = v.gw[(g - 1) * v.NW + w];
+                            kw::lds_order();  // (every lane has read the word before its owner toggles it below)
+                            m = __builtin_popcountll(word); mask = word;
+                            if (m > left) { m = left; mask = 0; for (int j = 0; j < m; j++) { mask |= word & (0 - word); word &= word - 1; } }
+                            for (int t0 = 0; t0 < m * per; t0 += 64) {  // task t of this word's share sits on the (t / per)-th node of the mask
+                                const int t = t0 + lane;
+                                if (t < m * per) { uint64_t mm = mask; for (int j = bk_div_small(t, per); j > 0; j--) mm &= mm - 1; b.t_node[tb + t] = (w << 6) + __builtin_ctzll(mm); }
+                            }
+                        } else if (lane < per) b.t_node[tb + lane] = n;  // one node (the usual command): its tasks all sit on n (per <= 16)
+                        const uint64_t neww = bk_move_mask(v, s2, dummy, w, mask, g, to);
+                        if (lane == g - 1) { if (neww) firstn = (w << 6) + __builtin_ctzll(neww); else { firstn = own_first(); finds++; } }
+                        if (lane == to - 1 && n < firstn) firstn = n;
+                        tb += m * per; left -= m;
+                        if (!own_g2 && g2 >= 1) {  // hand the nodes over to the worker of the lower levels
+                            if (xp - xseen >= KFC_RING) { while (xp - xseen >= KFC_RING) { xseen = kw::lds_load_acq(&L.xtail); if (xp - xseen >= KFC_RING) kw::relax(); } }
+                            if (lane == 0) { FcMove mv; mv.w = w; mv.cmd = tail | (left == 0 ? 1 << 30 : 0); mv.mask = mask; L.xring[xp & (KFC_RING - 1)] = mv; }
+                            xp++;
+                            kw::lds_store_rel(&L.xhead, xp);
                         }
-                    } else if (lane < per) b.t_node[tb + lane] = n;  // one node (the usual command): its tasks all sit on n (per <= 16)
-                    const uint64_t neww = bk_move_mask(v, s2, dummy, w, mask, g, g2);
-                    if (lane == g - 1) { if (neww) firstn = (w << 6) + __builtin_ctzll(neww); else { firstn = own_first(); finds++; } }
-                    if (lane == g2 - 1 && n < firstn) firstn = n;
-                    tb += m * per; left -= m;
+                    }
+                } else if (own_g2) {  // the upper worker removes this command's nodes: take them in as they arrive
+                    for (bool last = false; !last;) {
+                        if (xp == xseen) { const int64_t i0 = kw::clock(); while ((xseen = kw::lds_load_acq(&L.xhead)) == xp) kw::relax(); b_idle += kw::clock() - i0; }
+                        const FcMove mv = L.xring[xp & (KFC_RING - 1)]; xp++;
+                        last = (mv.cmd >> 30) & 1;
+                        (void)bk_move_mask(v, s2, dummy, mv.w, mv.mask, 0, g2);
+                        const int n = (mv.w << 6) + __builtin_ctzll(mv.mask);
+                        if (lane == g2 - 1 && n < firstn) firstn = n;
+                        kw::lds_store_rel(&L.xtail, xp);
+                    }
                 }
             }
-            kw::lds_store_rel(&L.tail, tail);
+            kw::lds_store_rel(me == 0 ? &L.tail0 : &L.tail1, tail);
         }
         (void)finds;
-        if (lane == 0) { L.b_idle = b_idle; L.b_total = kw::clock() - b_start; }
+        if (lane == 0) { L.b_idle[me] = b_idle; L.b_total[me] = kw::clock() - b_start; }
     }
     kw::sync();
-    if (tid == 0) { b.fs[0].cycles_update = L.b_idle; b.fs[0].cycles_rescan = L.b_total; }
+    if (tid == 0) { b.fs[0].cycles_update = L.b_idle[0]; b.fs[0].cycles_rescan = L.b_total[0]; b.fs[0].block_loads = L.b_idle[1]; b.fs[0].rescans1 = L.b_total[1]; }  // the lower / the upper worker: idle and total clocks
     for (int i = tid; i < v.LV * v.NW; i += T) b.bk_words[i] = v.gw[i];
 }
 
