@@ -84,6 +84,17 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                     // a gang of ONE class: it fits iff the levels hold enough places for it (a node of level g holds g / q of its tasks, every placement takes exactly one
                     // place away) — else it places `cap` tasks, finds no node for the next one and is rolled back: cap + 1 decisions, the state it started from
                     const int qc = kw::bcast(q, ucls);
+                    // the usual gang: all of it fits on the class's best node (its lowest non-empty level g holds nt·q devices) — one command, no capacity sum, no divisions
+                    const int g0 = KFC_LEVEL_FOR(qc), need0 = nt * qc;
+                    if (g0 && need0 <= g0) {
+                        if (wp - tail_seen >= KFC_RING) { const int64_t w0 = kw::clock(); while (wp - tail_seen >= KFC_RING) { tail_seen = tails_min(); if (wp - tail_seen >= KFC_RING) kw::relax(); } a_wait += kw::clock() - w0; }
+                        const int cg = kw::bcast(cnt, g0 - 1), g2 = g0 - need0;
+                        if (lane == 0) { FcCmd cm; cm.lv = g0 | (g2 << 8); cm.k = 1; cm.per = nt; cm.tbase = first; L.ring[wp & (KFC_RING - 1)] = cm; }
+                        wp++; steps++;
+                        KFC_MOVE(g0, g2, 1, cg);
+                        decisions += nt;
+                        kw::lds_store_rel(&L.head, wp);
+                    } else {
                     int cap;
                     if (nt == 1) cap = (nz >> (qc - 1)) ? 1 : 0;
                     else { int term = 0; if (lane < v.LV && lane + 1 >= qc) term = bk_div_small(lane + 1, qc) * cnt; cap = 0; for (int l = qc - 1; l < v.LV && cap < nt; l++) cap += kw::bcast(term, l); }
@@ -103,6 +114,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                         }
                         decisions += nt;
                         kw::lds_store_rel(&L.head, wp);
+                    }
                     }
                 } else {
                     // a gang of several scan classes: task by task on a copy of the counts; its commands stay unpublished until the last task has found its level
