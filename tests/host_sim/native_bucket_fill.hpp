@@ -7,8 +7,6 @@
 // of the sets, every output compared with the emulated kernel's (outcomes, operation offsets, the tasks' nodes, the counters, the sets afterwards), its time summed up.
 #pragma once
 #include <chrono>
-#include <cstdio>
-#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -114,7 +112,6 @@ inline void native_fill_buckets(const KaiCtx& c, RoundParams rp, const BucketPar
                     const int g2 = g - per * qc;
                     { uint64_t m = mask; int t = done; for (int j = 0; j < k; j++) { const int nj = (w << 6) + __builtin_ctzll(m); m &= m - 1; for (int x = 0; x < per; x++, t++) { placed_node[t] = nj; placed_info[t] = ucls | ((g - x * qc) << 8); } } }
                     decisions += (int64_t)k * per; done += k * per;
-                    if (const char* hp = std::getenv("KAI_NATIVE_FILL_HIST")) { static long hist[17][17]; static long cnt = 0; hist[g][g2]++; if (++cnt % atol(hp) == 0) { std::fprintf(stderr, "native fill commands by (from level -> to level):"); for (int a2 = 1; a2 <= 16; a2++) for (int b2 = 0; b2 <= 16; b2++) if (hist[a2][b2]) std::fprintf(stderr, " %d->%d:%ld", a2, b2, hist[a2][b2]); std::fprintf(stderr, "\n"); } }
                     const uint64_t rest = S.move_mask(w, mask, g, g2);
                     patch_tops(n, g, g2, rest, false);
                 }
