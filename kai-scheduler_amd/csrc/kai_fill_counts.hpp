@@ -58,7 +58,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         const int q = act ? (int)c.cls[lane].req[KAI_RES_GPU] : 0x7fffffff;
         uint32_t nz = (uint32_t)kw::ballot(cnt > 0);  // bit l: level l + 1 holds a node
         int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, steps = 0, n_done = rp.start, mismatch = 0;
-        int wp = 0, tail_seen = 0;  // commands written / the worker's progress as last read
+        int wp = 0, tail_seen = 0, pub = 0;  // commands written / the workers' progress as last read / commands published (per 64 commands, at the end of a stretch of jobs and before every wait: a release store per gang is a wait per gang)
         int64_t a_wait = 0;         // cycles this wavefront waited for room in the ring
         auto tails_min = [&]() { const int t0 = kw::lds_load_acq(&L.tail0); if (!two_workers) return t0; const int t1 = kw::lds_load_acq(&L.tail1); return t0 < t1 ? t0 : t1; };  // a slot is free once BOTH workers have read it
         // the lowest non-empty level >= qc, 0 = none
@@ -87,13 +87,13 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                     // the usual gang: all of it fits on the class's best node (its lowest non-empty level g holds nt·q devices) — one command, no capacity sum, no divisions
                     const int g0 = KFC_LEVEL_FOR(qc), need0 = nt * qc;
                     if (g0 && need0 <= g0) {
-                        if (wp - tail_seen >= KFC_RING) { const int64_t w0 = kw::clock(); while (wp - tail_seen >= KFC_RING) { tail_seen = tails_min(); if (wp - tail_seen >= KFC_RING) kw::relax(); } a_wait += kw::clock() - w0; }
+                        if (wp - tail_seen >= KFC_RING) { kw::lds_store_rel(&L.head, wp); pub = wp; const int64_t w0 = kw::clock(); while (wp - tail_seen >= KFC_RING) { tail_seen = tails_min(); if (wp - tail_seen >= KFC_RING) kw::relax(); } a_wait += kw::clock() - w0; }
                         const int cg = kw::bcast(cnt, g0 - 1), g2 = g0 - need0;
                         if (lane == 0) { FcCmd cm; cm.lv = g0 | (g2 << 8); cm.k = 1; cm.per = nt; cm.tbase = first; L.ring[wp & (KFC_RING - 1)] = cm; }
                         wp++; steps++;
                         KFC_MOVE(g0, g2, 1, cg);
                         decisions += nt;
-                        kw::lds_store_rel(&L.head, wp);
+                        if (wp - pub >= 64) { kw::lds_store_rel(&L.head, wp); pub = wp; }
                     } else {
                     int cap;
                     if (nt == 1) cap = (nz >> (qc - 1)) ? 1 : 0;
@@ -102,7 +102,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                     else {
                         int done = 0;
                         while (done < nt) {
-                            if (wp - tail_seen >= KFC_RING) { const int64_t w0 = kw::clock(); while (wp - tail_seen >= KFC_RING) { tail_seen = tails_min(); if (wp - tail_seen >= KFC_RING) kw::relax(); } a_wait += kw::clock() - w0; }
+                            if (wp - tail_seen >= KFC_RING) { kw::lds_store_rel(&L.head, wp); pub = wp; const int64_t w0 = kw::clock(); while (wp - tail_seen >= KFC_RING) { tail_seen = tails_min(); if (wp - tail_seen >= KFC_RING) kw::relax(); } a_wait += kw::clock() - w0; }
                             const int g = KFC_LEVEL_FOR(qc), r = bk_div_small(g, qc), rem = nt - done, cg = kw::bcast(cnt, g - 1);
                             int k = 1, per = rem;
                             if (rem >= r) { per = r; k = bk_div_small(rem, r); if (k > cg) k = cg; }
@@ -113,12 +113,12 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                             done += k * per;
                         }
                         decisions += nt;
-                        kw::lds_store_rel(&L.head, wp);
+                        if (wp - pub >= 64) { kw::lds_store_rel(&L.head, wp); pub = wp; }
                     }
                     }
                 } else {
                     // a gang of several scan classes: task by task on a copy of the counts; its commands stay unpublished until the last task has found its level
-                    if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { const int64_t w0 = kw::clock(); while (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { tail_seen = tails_min(); if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) kw::relax(); } a_wait += kw::clock() - w0; }
+                    if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { kw::lds_store_rel(&L.head, wp); pub = wp; const int64_t w0 = kw::clock(); while (wp - tail_seen > KFC_RING - KB_PLACED_MAX) { tail_seen = tails_min(); if (wp - tail_seen > KFC_RING - KB_PLACED_MAX) kw::relax(); } a_wait += kw::clock() - w0; }
                     const int cnt_s = cnt; const uint32_t nz_s = nz; const int wp_s = wp;
                     for (int tb = 0; tb < nt && ok; tb += 64) {
                         const int my_cls = tb + lane < nt ? b.t_cls[first + tb + lane] : 0;
@@ -134,7 +134,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                             KFC_MOVE(g, g2, 1, cg);
                         }
                     }
-                    if (ok) kw::lds_store_rel(&L.head, wp);
+                    if (ok) { if (wp - pub >= 64) { kw::lds_store_rel(&L.head, wp); pub = wp; } }
                     else { cnt = cnt_s; nz = nz_s; wp = wp_s; }  // Statement.Rollback: nothing was published
                 }
                 if (ok) { committed++; ops += nt; } else rollbacks += 2;
@@ -142,6 +142,7 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                 if ((flag == BF_OK) != ok) { mismatch = 1; n_done = base + jj + 1; n_out = jj + 1; attempted -= jn - (jj + 1); break; }
             }
             if (lane < n_out) { b.g_out[base + lane] = (uint8_t)my_out; b.g_opoff[base + lane] = my_opoff; b.g_stmt[base + lane] = my_stmt; }
+            if (wp != pub) { kw::lds_store_rel(&L.head, wp); pub = wp; }
         }
         #undef KFC_LEVEL_FOR
         #undef KFC_MOVE
