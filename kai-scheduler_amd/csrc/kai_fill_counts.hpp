@@ -65,9 +65,14 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         #define KFC_LEVEL_FOR(qc) ((nz >> ((qc) - 1)) ? (qc) + __builtin_ctz(nz >> ((qc) - 1)) : 0)
         // k nodes leave level g for level g2 (0: none): the counts and the non-empty mask, from values this lane already holds
         #define KFC_MOVE(g, g2, k, cg) do { if (lane == (g) - 1) cnt -= (k); if ((cg) == (k)) nz &= ~(1u << ((g) - 1)); if ((g2) >= 1) { if (lane == (g2) - 1) cnt += (k); nz |= 1u << ((g2) - 1); } } while (0)
+        // the 64 jobs of a stretch: one per lane; the NEXT stretch's loads are issued before this stretch is walked (a wavefront that waits out four HBM loads per 64 jobs waits ~3 ms per C5 cycle)
+        // (unconditional loads on a clamped index; the bound is applied when the values are used, so nothing waits for them before the walk)
+        int nx_flag = 0, nx_first = 0, nx_nt = 0, nx_ucls = 0;
+        if (V > rp.start) { const int gc = rp.start + lane < V ? rp.start + lane : V - 1; nx_flag = b.g_flag[gc]; nx_first = b.g_first[gc]; nx_nt = b.g_nt[gc]; nx_ucls = b.g_ucls[gc]; }
         for (int base = rp.start; base < V && !mismatch; base += 64) {
             const int gi = base + lane;
-            const int my_flag = gi < V ? b.g_flag[gi] : BF_GATE, my_first = gi < V ? b.g_first[gi] : 0, my_nt = gi < V ? b.g_nt[gi] : 0, my_ucls = gi < V ? b.g_ucls[gi] : 0;
+            const int my_flag = gi < V ? nx_flag : BF_GATE, my_first = gi < V ? nx_first : 0, my_nt = gi < V ? nx_nt : 0, my_ucls = gi < V ? nx_ucls : 0;
+            { const int gc = gi + 64 < V ? gi + 64 : V - 1; nx_flag = b.g_flag[gc]; nx_first = b.g_first[gc]; nx_nt = b.g_nt[gc]; nx_ucls = b.g_ucls[gc]; }
             const int my_pack = my_flag | ((my_ucls + 1) << 2) | (my_nt << 12);  // (flag: 2 bits, class + 1: up to 64, tasks: up to KB_PLACED_MAX) — one readlane per job instead of three
             const int jn = V - base < 64 ? V - base : 64;
             // jobs the plan turned away at a capacity gate take no part in the fill: their outcome is written here, the walk below steps over them
