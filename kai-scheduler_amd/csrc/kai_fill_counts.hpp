@@ -60,6 +60,9 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         int decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0, steps = 0, n_done = rp.start, mismatch = 0;
         int wp = 0, tail_seen = 0, pub = 0;  // commands written / the workers' progress as last read / commands published (per 64 commands, at the end of a stretch of jobs and before every wait: a release store per gang is a wait per gang)
         int64_t a_wait = 0;         // cycles this wavefront waited for room in the ring
+#ifdef KAI_FILL_PROF
+        int64_t pcy[4] = {0, 0, 0, 0};  // per job: decoding its parameters / deciding it and emitting its commands / its outcome; jobs
+#endif
         auto tails_min = [&]() { const int t0 = kw::lds_load_acq(&L.tail0); if (!two_workers) return t0; const int t1 = kw::lds_load_acq(&L.tail1); return t0 < t1 ? t0 : t1; };  // a slot is free once BOTH workers have read it
         // the lowest non-empty level >= qc, 0 = none
         #define KFC_LEVEL_FOR(qc) ((nz >> ((qc) - 1)) ? (qc) + __builtin_ctz(nz >> ((qc) - 1)) : 0)
@@ -80,11 +83,17 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
             int my_out = BF_DEAD, my_opoff = 0, my_stmt = 0, n_out = jn;  // lane jj: what job jj of this stretch ended with (stored once per stretch, coalesced)
             attempted += jn; n_done = base + jn;
             while (todo) {
+#ifdef KAI_FILL_PROF
+                const int64_t pj0 = kw::clock();
+#endif
                 const int jj = __builtin_ctzll(todo); todo &= todo - 1;
                 const int pack = kw::bcast(my_pack, jj), first = kw::bcast(my_first, jj);
                 const int flag = pack & 3, ucls = ((pack >> 2) & 0x3ff) - 1, nt = pack >> 12;
                 const int opoff = ops + rp.ops0, stmtoff = committed + rp.stmt0;
                 bool ok = true;
+#ifdef KAI_FILL_PROF
+                const int64_t pj1 = kw::clock();
+#endif
                 if (ucls >= 0) {
                     // a gang of ONE class: it fits iff the levels hold enough places for it (a node of level g holds g / q of its tasks, every placement takes exactly one
                     // place away) — else it places `cap` tasks, finds no node for the next one and is rolled back: cap + 1 decisions, the state it started from
@@ -142,9 +151,15 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                     if (ok) { if (wp - pub >= 64) { kw::lds_store_rel(&L.head, wp); pub = wp; } }
                     else { cnt = cnt_s; nz = nz_s; wp = wp_s; }  // Statement.Rollback: nothing was published
                 }
+#ifdef KAI_FILL_PROF
+                const int64_t pj2 = kw::clock();
+#endif
                 if (ok) { committed++; ops += nt; } else rollbacks += 2;
                 { const bool me = lane == jj; my_out = me ? (ok ? BF_OK : BF_DEAD) : my_out; my_opoff = me ? opoff : my_opoff; my_stmt = me ? stmtoff : my_stmt; }
                 if ((flag == BF_OK) != ok) { mismatch = 1; n_done = base + jj + 1; n_out = jj + 1; attempted -= jn - (jj + 1); break; }
+#ifdef KAI_FILL_PROF
+                { const int64_t pj3 = kw::clock(); pcy[0] += pj1 - pj0; pcy[1] += pj2 - pj1; pcy[2] += pj3 - pj2; pcy[3]++; }
+#endif
             }
             if (lane < n_out) { b.g_out[base + lane] = (uint8_t)my_out; b.g_opoff[base + lane] = my_opoff; b.g_stmt[base + lane] = my_stmt; }
             if (wp != pub) { kw::lds_store_rel(&L.head, wp); pub = wp; }
@@ -158,7 +173,11 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
             FillStatus s; s.n_done = n_done; s.mismatch = mismatch; s.all_dead = (C > 0 && dead == (C >= 64 ? ~0ull : ((1ull << C) - 1))) ? 1 : 0; s.planned = V; s.floor_stop = 0; s.pad = 0;
             s.decisions = decisions; s.attempted = attempted; s.committed = committed; s.rollbacks = rollbacks; s.ops = ops; s.dead_mask = dead;
             s.cycles_total = kw::clock() - tstart; s.cycles_load = a_wait; s.cycles_update = 0; s.cycles_rescan = 0; s.block_loads = 0;  // (cycles_update / cycles_rescan, block_loads / rescans1: the workers' idle and total clocks, added below)
-            s.rescans1 = 0; s.rescans2 = steps; s.rescans3 = 0;  // rescans2: commands (a command moves the first k nodes of a level)
+            s.rescans1 = 0; s.rescans2 = steps; s.rescans3 = 0;
+#ifdef KAI_FILL_PROF
+            s.cycles_load = pcy[0]; s.cycles_update = pcy[1]; s.cycles_rescan = pcy[2]; s.rescans3 = pcy[3];
+#endif
+  // rescans2: commands (a command moves the first k nodes of a level)
             b.fs[0] = s; b.dead_mask[0] = dead;
         }
     } else if (tid < 128 || (tid < 192 && two_workers)) {
@@ -230,7 +249,9 @@ KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
         if (lane == 0) { L.b_idle[me] = b_idle; L.b_total[me] = kw::clock() - b_start; }
     }
     kw::sync();
+#ifndef KAI_FILL_PROF
     if (tid == 0) { b.fs[0].cycles_update = L.b_idle[0]; b.fs[0].cycles_rescan = L.b_total[0]; b.fs[0].block_loads = L.b_idle[1]; b.fs[0].rescans1 = L.b_total[1]; }  // the lower / the upper worker: idle and total clocks
+#endif
     for (int i = tid; i < v.LV * v.NW; i += T) b.bk_words[i] = v.gw[i];
 }
 
