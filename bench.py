@@ -196,9 +196,10 @@ def main():
         traffic = pmc_traffic(desc, fill_kernel)
         cyc_dec = int(st.reserved[5]) / max(fill_dec, 1)
         if counts:
-            limiter = ("instruction issue of TWO wavefronts on one compute unit (k_fill_counts: wavefront 0 walks the planned order over the levels' populations — a handful of integers in "
-                       "registers —, wavefront 1 executes its commands on the LDS-resident sets and writes the tasks' nodes; each is one dependency chain of mostly scalar instructions), not HBM and not LDS")
-            bound_actual = "single-wave issue (two chains side by side)"
+            limiter = ("instruction issue of ONE wavefront, the counting machine of k_fill_counts: it walks the planned order over the levels' populations (a handful of integers in registers), ~1 000 cycles "
+                       "per gang of dependent, mostly scalar instructions (profiles/r05j: section clocks); two more wavefronts execute its commands on the LDS-resident sets and write the tasks' nodes and "
+                       "keep up with it (10 - 35 % idle) — not HBM and not LDS")
+            bound_actual = "single-wave issue (the counting machine; the set workers run beside it)"
         elif buckets:
             limiter = ("instruction issue of ONE wavefront (k_fill_buckets: 1 workgroup, wavefront 0 walks the planned order over bitmaps of the nodes by free devices: ~134 instructions per decision, "
                        "most of them scalar, 1.4 LDS instructions — profiles/r04q_fill_pmc_instruction_mix.txt), not HBM and not LDS")
@@ -212,7 +213,7 @@ def main():
         # the kernel's OWN roofline: one wavefront issues one instruction per issue slot at best; r04q measured 7.7 cycles per instruction for this kind of dependent scalar / vector mix.  Floor taken
         # here: 4 cycles per instruction (a wave64 VALU instruction occupies its SIMD for 4 cycles; dependent SALU instructions are no faster in practice) x the instructions per decision on file.
         ipd = {"k_fill_counts": 115.9, "k_fill_buckets": 133.7, "k_fill": 530.0}.get(fill_kernel)  # profiles/r05f_fill_pmc_instruction_mix.txt, r04q_fill_pmc_instruction_mix.txt, DESIGN.md section 5.2
-        chains = 2 if counts else 1  # wavefronts that carry the kernel's dependency chains side by side
+        chains = 3 if counts else 1  # wavefronts that carry the kernel's dependency chains side by side (k_fill_counts: the counting machine + two set workers)
         own = {"bound": "single-wave instruction issue", "cycles_per_decision": cyc_dec, "clock_GHz": 2.4, "wavefronts_working": chains,
                "instructions_per_decision": ipd, "issue_floor_cycles_per_instruction": 4.0,
                "frac_of_issue_floor": (ipd / chains * 4.0 / cyc_dec) if (ipd and cyc_dec > 0) else None,
@@ -220,7 +221,7 @@ def main():
                        "floor = a wavefront issues at most one instruction per 4 cycles (a wave64 VALU instruction occupies its SIMD for 4 cycles); measured: one per 7.7 - 8.5 cycles (dependent scalar <-> vector chains)"}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bound_actual": bound_actual, "limiter": limiter, "own_roofline": own,
-                "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 4 if buckets else 1, "waves_working": 2 if counts else 1,
+                "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 4 if buckets else 1, "waves_working": 3 if counts else 1,
                 "traffic_source": "static: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE of the fill kernel from committed rocprofv3 --pmc passes of this command (counters need their own passes; not collected in this run)" if traffic else "no --pmc pass of this kernel on file",
                 "kernel": fill_kernel, "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "other_kernels": {"plan (k_plan_leaf / rank / scan / emit)": {"ms_per_step": plan_ms}, "apply (k_apply_jobs / nodes)": {"ms_per_step": apply_ms},

@@ -857,6 +857,7 @@ struct EngineLocal {
     // (a recorded victim changed the pop sequence) and pops the queue itself
     // requests that found NO fitting node among a simulation's feasible nodes (victim search): inside one simulation resources are only taken — until a rollback hands some
     // back, which empties the list — so the same request finds none again (a simulation re-places hundreds of evicted one-device tasks of one shape)
+    int32_t mw_cow, mw_nsaved;  // victim search on several engines: != 0 = the wave's stamp while a speculative simulation runs — a job's tasks-to-allocate cache is set aside the first time the wave touches it (mw_touch); jobs set aside so far
     ScanReq sim_dead[4]; int32_t sim_dead_n, sim_dead_on;
     KAI_GP(const uint32_t) fbits[KAI_TDEPTH];  // node set of the DFS frame at each depth (frame_bits)
     int32_t vl_job0, vl_n, vl_done, vl_live, vl_cur, vl_mode;
@@ -883,7 +884,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.sim_dead_n = 0; e.sim_dead_on = 0; e.vl_job0 = -1; e.vl_n = 0; e.vl_done = 0; e.vl_live = 0; e.vl_cur = 0; e.vl_mode = 0; e.vl_mat = 0; e.vl_div_grp = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1; for (int i = 0; i < KAI_BN_ENT; i++) e.bn[i].valid = 0; e.bn_seq = 0; e.bn_tick = 0; e.bn_last = 0;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.sim_dead_n = 0; e.sim_dead_on = 0; e.mw_cow = 0; e.mw_nsaved = 0; e.vl_job0 = -1; e.vl_n = 0; e.vl_done = 0; e.vl_live = 0; e.vl_cur = 0; e.vl_mode = 0; e.vl_mat = 0; e.vl_div_grp = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1; for (int i = 0; i < KAI_BN_ENT; i++) e.bn[i].valid = 0; e.bn_seq = 0; e.bn_tick = 0; e.bn_last = 0;
         e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 
@@ -997,7 +998,7 @@ struct Engine {
         if (status == KAI_POD_PENDING) cx().j_n_pending[j]++;
         // invalidateTasksCache (job_info.go:253-256) — of the SESSION's job: the partial representative the victim search stands in for
         // it keeps the chunk it cached when it was made (statement operations re-index the original job, not the clone)
-        if constexpr (kVictim) { if (j == el().ov_job) { el().ov_orig_valid = 0; return; } }
+        if constexpr (kVictim) { if (j == el().ov_job) { el().ov_orig_valid = 0; return; } mw_touch(j); }
         cx().j_tta_valid[j] = 0;
     }
 
@@ -1348,8 +1349,21 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ tasks to allocate (api/podgroup_info/allocation_info.go:27-177)
+    // The tasks-to-allocate cache of job j is about to change (invalidated by a statement operation, rebuilt by ensure_tta) inside a SPECULATIVE simulation of a wave
+    // (kai_engine_solver.inc solve_partial_multi): set aside, once per wave, what it held when the wave started — mw_caches_restore puts it back after the simulation.
+    KAI_HD void mw_touch(int j) {
+        if constexpr (kVictim) {
+            const int st = el().mw_cow;
+            if (!st || (sx().mw_sv[j] >> 1) == st) return;
+            const int first = cx().j_first_pod[j], cnt = cx().j_tta_valid[j] ? cx().j_tta_n[j] : 0;
+            sx().mw_sv[j] = (st << 1) | (cx().j_tta_valid[j] ? 1 : 0); sx().mw_sn[j] = cx().j_tta_n[j]; sx().mw_sj[el().mw_nsaved++] = j;
+            for (int k = 0; k < 4; k++) sx().mw_sres[(size_t)j * 4 + k] = cx().j_tta_res[(size_t)j * 4 + k];
+            for (int k = 0; k < cnt; k++) sx().mw_stta[first + k] = cx().tta[first + k];
+        } else (void)j;
+    }
     KAI_HD void ensure_tta(int j, bool real) {
         if (cx().j_tta_valid[j]) return;
+        mw_touch(j);
         int first = cx().j_first_pod[j], np = cx().j_n_pods[j], nps = cx().j_n_ps[j], ps0 = cx().j_first_ps[j];
         int out = 0;
         if (nps == 1) {  // one pod-set: the chunk is the first max_tasks allocatable pods in task order

@@ -14,7 +14,7 @@ else:
     from test_engine_hostsim import HostSim
     HostSim.lib(); run = HostSim.run
 S = T.pkg.synth
-bad = tot = buckets = 0; t0 = time.time()
+bad = tot = buckets = counts = 0; t0 = time.time()
 for seed in range(lo, hi):
     rng = np.random.default_rng(910000 + seed)
     sizes, probs = [((1, 2, 4, 8), (.4, .2, .2, .2)), ((1, 4, 8, 16, 64, 100), (.1, .2, .3, .2, .1, .1)), ((1, 2, 3, 24), (.3, .2, .2, .3)), ((1,), (1.0,))][seed % 4]
@@ -27,7 +27,8 @@ for seed in range(lo, hi):
     if seed % 2: os.environ["KAI_FILL_UNBATCHED"] = "1"
     if seed % 5 == 0: os.environ["KAI_FILL_GENERAL"] = "1"
     o = T.Oracle.run(snap, cfg); g = run(snap, cfg); tot += 1
-    buckets += int((int(g.stats.reserved[1]) >> 62) & 1) if GPU else int(g.stats.reserved[5] == 1 if False else 0)
+    buckets += int((int(g.stats.reserved[1]) >> 62) & 1) if GPU else int(g.stats.reserved[6])
+    counts += int((int(g.stats.reserved[1]) >> 61) & 1) if GPU else int(g.stats.reserved[7])  # the fill as two / three wavefronts (kai_fill_counts.hpp)
     ok = o.ops == g.ops and getattr(g, "stmts", o.stmts) == o.stmts and (o.pod_status == g.pod_status).all() and (o.pod_node == g.pod_node).all() and all(np.array_equal(o.nodes[k], g.nodes[k]) for k in o.nodes) \
         and all(np.array_equal(o.shares_final[k], g.shares_final[k]) for k in o.shares_final) \
         and (int(o.stats.decisions), int(o.stats.jobs_attempted), int(o.stats.jobs_committed), int(o.stats.rollbacks)) == (int(g.stats.decisions), int(g.stats.jobs_attempted), int(g.stats.jobs_committed), int(g.stats.rollbacks))
@@ -35,4 +36,4 @@ for seed in range(lo, hi):
         bad += 1; print("MISMATCH seed", seed, dict(os.environ).get("KAI_FILL_UNBATCHED"), dict(os.environ).get("KAI_FILL_GENERAL"), flush=True)
     if time.time() - t0 > float(os.environ.get("CAMPAIGN_SECONDS", "150")):
         print("time budget reached at seed", seed); break
-print("batch campaign", "(device)" if GPU else "(host twin)", "runs", tot, "mismatch", bad, ("on the bucket kernel %d" % buckets) if GPU else "", f"{time.time()-t0:.0f}s")
+print("batch campaign", "(device)" if GPU else "(host twin)", "runs", tot, "mismatch", bad, "on the sets by free devices %d, of which on k_fill_counts %d" % (buckets, counts), f"{time.time()-t0:.0f}s")
