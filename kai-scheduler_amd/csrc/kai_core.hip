@@ -179,6 +179,7 @@ int rccl_fail(kai_core* core, const char* what, int rc) {
 
 void free_session(kai_core* core, bool release = false) {
     // the slabs stay with the handle for the next session (dalloc takes them back); kai_core_destroy releases them
+    if (core->bufs.size() != core->buf_bytes.size()) { for (void* p : core->bufs) (void)hipFree(p); core->bufs.clear(); core->buf_bytes.clear(); }  // (every slab carries its size: dalloc is the only writer of both; anything else is a bug — release rather than recycle under a wrong size)
     for (size_t i = 0; i < core->bufs.size(); i++) core->spare.push_back({core->bufs[i], core->buf_bytes[i]});
     core->bufs.clear(); core->buf_bytes.clear(); core->slab = nullptr; core->slab_left = 0;
     if (release) { for (auto& sp : core->spare) (void)hipFree(sp.first); core->spare.clear(); if (core->rep_buf) (void)hipFree(core->rep_buf); core->rep_buf = nullptr; core->rep_buf_bytes = 0; }

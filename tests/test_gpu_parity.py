@@ -105,6 +105,43 @@ def test_gpu_config4_cycle_hashes_to_the_oracles(gpu, key, scale, depth):
     assert len(res.ops) == pin["ops"] and T.ops_sha256(res.ops) == pin["ops_sha256"]
 
 
+@pytest.mark.parametrize("nodes", [30, 60, 200])
+def test_gpu_reclaim_large_jobs_walks_the_victims_log(gpu, nodes):
+    """The reference's BenchmarkReclaimLargeJobs shape (integration_tests/reclaim/reclaim_benchmark_test.go:62-160; tools/ref_benchmarks.py): hundreds of scenarios per partial job
+    that end at the AccumulatedIdleGpus filter, recorded victims in front of them — the victims log, the filter as a running sum, task groups only for the scenario that gets
+    through (kai_engine_solver.inc vl_*), on 32 workgroups.  Operations, scenarios simulated and simulations run must be the oracle's (200 nodes: 26 690 dropped scenarios)."""
+    import sys, os, ctypes as C
+    sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+    import ref_benchmarks as RB
+    snap, cfg, _ = T.case_to_snapshot(RB.reclaim_large(nodes), ("reclaim",))
+    ref = T.Oracle.run(snap, cfg, ("reclaim",))
+    out = (C.c_int64 * 3)(); T.Oracle.lib().kai_oracle_last_victim_stats(out)
+    res = run_gpu(snap, cfg, ("reclaim",))
+    assert_same(res, ref)
+    assert (int(res.stats.reserved[2]), int(res.stats.reserved[3])) == (int(out[0]), int(out[1]))  # scenarios, simulations of the (last) victim action
+
+
+def test_gpu_sessions_with_victim_actions_keep_device_memory_flat(gpu):
+    """One handle, a scheduling cycle per session (scheduler.go:112-138): the slabs of a closed session serve the next one and the victim actions' replica memory (32 workgroups, a
+    replica of the session arrays each) is its own allocation kept between sessions — device memory in use must not grow from the second session on (round 4's advisor finding: the
+    replica buffer was pushed into the slab list without its size)."""
+    import torch
+    snap, cfg, _ = T.pkg.synth.config(3, 0.02)
+    acts = ("allocate", "consolidation", "reclaim")
+    free = []
+    with T.pkg.KaiCore(cfg) as core:
+        first = None
+        for i in range(5):
+            ssn = core.open_session(snap)
+            ops = [tuple(int(o[k]) for k in ("kind", "pod", "node", "job")) for a in acts for o in ssn.execute(a)]
+            ssn.close()
+            torch.cuda.synchronize()
+            free.append(torch.cuda.mem_get_info()[0])
+            first = first or ops
+            assert ops == first
+    assert max(free[1:]) - min(free[1:]) <= 8 << 20, f"device memory in use moved between sessions: {[f >> 20 for f in free]} MiB free"
+
+
 def test_gpu_default_cycle_on_config5_hashes_to_the_oracles(gpu):
     """The cycle the reference runs by default — allocate, consolidation, reclaim, preempt on one session (conf_util/scheduler_conf_util.go:37, without stalegangeviction) — on
     BASELINE config 5's shape at 0.5 % (328 nodes x 5 000 pods; queueDepthPerAction 8 for the victim actions): after allocate most pods are still pending and the three victim
