@@ -212,7 +212,7 @@ def main():
                 "HBM use: `own_roofline` is the kernel's own bound — the issue rate of the wavefronts that carry its dependency chain.")
         # the kernel's OWN roofline: one wavefront issues one instruction per issue slot at best; r04q measured 7.7 cycles per instruction for this kind of dependent scalar / vector mix.  Floor taken
         # here: 4 cycles per instruction (a wave64 VALU instruction occupies its SIMD for 4 cycles; dependent SALU instructions are no faster in practice) x the instructions per decision on file.
-        ipd = {"k_fill_counts": 115.9, "k_fill_buckets": 133.7, "k_fill": 530.0}.get(fill_kernel)  # profiles/r05f_fill_pmc_instruction_mix.txt, r04q_fill_pmc_instruction_mix.txt, DESIGN.md section 5.2
+        ipd = {"k_fill_counts": 147.1, "k_fill_buckets": 133.7, "k_fill": 530.0}.get(fill_kernel)  # profiles/r05z_fill_pmc_instruction_mix.txt (all three wavefronts), r04q_fill_pmc_instruction_mix.txt, DESIGN.md section 5.2
         chains = 3 if counts else 1  # wavefronts that carry the kernel's dependency chains side by side (k_fill_counts: the counting machine + two set workers)
         own = {"bound": "single-wave instruction issue", "cycles_per_decision": cyc_dec, "clock_GHz": 2.4, "wavefronts_working": chains,
                "instructions_per_decision": ipd, "issue_floor_cycles_per_instruction": 4.0,
