@@ -450,7 +450,7 @@ struct DevBackendT {
         if (grid_on()) { const ScanGridPart& p = g_ctx.sg->res; const double a = __hip_atomic_load(&p.mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(&p.mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (a < lo) lo = a; if (b > hi) hi = b; }
         mn = lo; mx = hi;
     }
-    __device__ bool pfor(const KaiCtx&, const PforReq& r) { if (r.n < 256) return false; sh->pfor = r; call(CMD_PFOR); return true; }  // short loops stay on the control lane (two barriers cost more)
+    __device__ bool pfor(const KaiCtx&, const PforReq& r) { if (r.n < 48) return false; sh->pfor = r; call(CMD_PFOR); return true; }  // only short loops stay on the control lane: two barriers cost ~2 k cycles, a body (victim filter, view state: a few dependent loads) ~300 per index on the lane
     __device__ void or32(uint32_t* w, uint32_t bits) { *w |= bits; }
     __device__ bool topo_scan(const KaiCtx&, TopoScan& t) {
         const bool grid = t.op == 1 || t.op == 4 || t.op == 15;  // passes over the nodes that go to the whole grid (ops 2 / 3 — only used without the survey — and the loops over domains: this workgroup's scan waves)
