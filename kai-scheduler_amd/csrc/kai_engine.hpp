@@ -845,8 +845,7 @@ struct EngineLocal {
     int32_t jo_kind, cur_inst;               // jo_kind 1 = victims ordering (reversed comparators, victims operands)
     int32_t tpl_valid, mw_poll;              // the pending-job template of the simulation queues matches the committed state; >= 0: this simulation's index in its wave — it is
                                              // given up as soon as an earlier simulation of the wave is known not to have simply failed (MultiCtx::hit), buffer mw_buf
-    BnEnt bn[KAI_BN_ENT]; int32_t bn_log[KAI_BN_LOG]; uint32_t bn_seq, bn_tick; int32_t bn_last;
-    int32_t bn_m[KAI_BN_LOG]; double bn_sc[KAI_BN_LOG]; uint8_t bn_ok[KAI_BN_LOG];  // work lists of best_node_kept (here rather than on the control lane's stack: that is scratch memory)
+    uint32_t bn_seq, bn_tick; int32_t bn_last;  // (the kept best nodes themselves and their work lists: EngineBig)
   // best nodes of recent brute-force decisions, kept and patched (best_node_kept); the nodes changed since, in order
     int32_t mm_valid[2], mm_nchg, mm_pend;   // NodePreOrderFn's range over ALL nodes, kept between decisions (preorder_range): valid per placement resource (0 CPU, 1 GPU), nodes changed since, the node whose old amounts mm_before holds
     int32_t mm_cn[8]; double mm_lo[2], mm_hi[2], mm_old[8][2];
@@ -858,11 +857,20 @@ struct EngineLocal {
     // requests that found NO fitting node among a simulation's feasible nodes (victim search): inside one simulation resources are only taken — until a rollback hands some
     // back, which empties the list — so the same request finds none again (a simulation re-places hundreds of evicted one-device tasks of one shape)
     int32_t mw_cow, mw_nsaved;  // victim search on several engines: != 0 = the wave's stamp while a speculative simulation runs — a job's tasks-to-allocate cache is set aside the first time the wave touches it (mw_touch); jobs set aside so far
-    ScanReq sim_dead[4]; int32_t sim_dead_n, sim_dead_on;
-    KAI_GP(const uint32_t) fbits[KAI_TDEPTH];  // node set of the DFS frame at each depth (frame_bits)
+    int32_t sim_dead_n, sim_dead_on;  // (the requests: EngineBig::sim_dead; so are the DFS frames' node sets, EngineBig::fbits)
     int32_t vl_job0, vl_n, vl_done, vl_live, vl_cur, vl_mode;
     int32_t vl_mat, vl_div_grp;  // entries below vl_mat have their task groups in the scenario (materialised lazily: a scenario the filters drop never needs them); groups the scenario held when the partial job left the log
     struct JoSave { QNode* qn; int32_t *qheap, *root_heap, *sorted, *cur, *end, *side, *side_len; int32_t root_len, root_init, kind, pad; } save[3];
+};
+
+// The control lane's larger working data.  Not part of EngineLocal: every scan lane that borrows the engine's pure helpers (Engine<NullBackend>: index loops of the victim search, the
+// domain loops of subSetNodesFn) carries an EngineLocal in scratch memory, and the action kernels' private segment — 8 KB per lane times every wave slot of the chip per queue — is what a
+// node-sharded group of three ranks on one device ran out of (HSA_STATUS_ERROR_OUT_OF_RESOURCES) when these arrays grew.  Backend::big(): LDS on the device, a member on the host.
+struct EngineBig {
+    BnEnt bn[KAI_BN_ENT]; int32_t bn_log[KAI_BN_LOG];  // best nodes of recent brute-force decisions, kept and patched (best_node_kept); the nodes changed since, in order
+    int32_t bn_m[KAI_BN_LOG]; double bn_sc[KAI_BN_LOG]; uint8_t bn_ok[KAI_BN_LOG];  // work lists of best_node_kept
+    ScanReq sim_dead[4];                       // requests that found no fitting node among the running simulation's feasible nodes (EngineLocal::sim_dead_n of them)
+    KAI_GP(const uint32_t) fbits[KAI_TDEPTH];  // node set of the DFS frame at each depth (frame_bits)
 };
 
 template <class Backend>
@@ -872,6 +880,7 @@ struct Engine {
     // objects (static accessors, nothing goes through this object), on the host plain members of the backend.
     KAI_HD const KaiCtx& cx() const { return be.ctx(); }
     KAI_HD EngineLocal& el() const { return be.local(); }
+    KAI_HD EngineBig& eb() const { return be.big(); }
     static constexpr bool kVictim = Backend::kVictim;  // compiled with the victim search (reclaim / preempt / consolidation)
     KAI_HD const SolverCtx& sx() const { return cx().sv; }
     // the job-order tree through pointers the compiler may treat as LDS pointers when the backend says the tree lives there
@@ -884,7 +893,7 @@ struct Engine {
         EngineLocal& e = el();
         e.qn = ctx.qn; e.qheap = ctx.qheap; e.root_heap = ctx.root_heap; e.root_len = 0; e.root_init = 0; e.fail_no_node = 0;
         e.total0 = ctx.st->total[0]; e.total1 = ctx.st->total[1]; e.total2 = ctx.st->total[2];
-        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.sim_dead_n = 0; e.sim_dead_on = 0; e.mw_cow = 0; e.mw_nsaved = 0; e.vl_job0 = -1; e.vl_n = 0; e.vl_done = 0; e.vl_live = 0; e.vl_cur = 0; e.vl_mode = 0; e.vl_mat = 0; e.vl_div_grp = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1; for (int i = 0; i < KAI_BN_ENT; i++) e.bn[i].valid = 0; e.bn_seq = 0; e.bn_tick = 0; e.bn_last = 0;
+        e.scope_bits = nullptr; e.scope_score = nullptr; e.scope_row = -1; e.n_keys = 0; e.restricted = 0; e.base_bits = nullptr; e.ov_job = -1; e.jo_kind = 0; e.cur_inst = 0; e.tpl_valid = 0; e.mw_poll = -1; e.mw_buf = 0; e.sim_dead_n = 0; e.sim_dead_on = 0; e.mw_cow = 0; e.mw_nsaved = 0; e.vl_job0 = -1; e.vl_n = 0; e.vl_done = 0; e.vl_live = 0; e.vl_cur = 0; e.vl_mode = 0; e.vl_mat = 0; e.vl_div_grp = 0; e.rc_early = 0; e.mm_valid[0] = e.mm_valid[1] = 0; e.mm_nchg = 0; e.mm_pend = -1; for (int i = 0; i < KAI_BN_ENT; i++) { if constexpr (Backend::kBig) be.big().bn[i].valid = 0; } e.bn_seq = 0; e.bn_tick = 0; e.bn_last = 0;
         e.i_sorted = (int32_t*)ctx.lq_sorted; e.i_cur = (int32_t*)ctx.lq_cur; e.i_end = (int32_t*)ctx.lq_end; e.i_side = (int32_t*)ctx.lq_side; e.i_side_len = (int32_t*)ctx.lq_side_len;
     }
 
@@ -967,7 +976,7 @@ struct Engine {
         mn = el().mm_lo[k]; mx = el().mm_hi[k];
     }
     KAI_HD void mark_dirty(int n) {
-        el().bn_log[el().bn_seq % KAI_BN_LOG] = n; el().bn_seq++;  // every change of a node's amounts or GPU groups passes here
+        eb().bn_log[el().bn_seq % KAI_BN_LOG] = n; el().bn_seq++;  // every change of a node's amounts or GPU groups passes here
         if (el().mm_valid[0] | el().mm_valid[1]) { if (el().mm_pend != n) mm_drop(); el().mm_pend = -1; }
         if (!cx().use_index) return;
         int b = n / KAI_BLOCK;
@@ -1804,15 +1813,15 @@ struct Engine {
     KAI_HD int best_node_kept(const ScanReq& q) {
         const uint64_t h = bn_hash(q);
         BnEnt* e = nullptr; int lru = 0;
-        { BnEnt& x = el().bn[el().bn_last]; if (x.valid && x.h == h && bn_same(x.q, q)) e = &x; }  // the tasks of a gang ask one after the other
+        { BnEnt& x = eb().bn[el().bn_last]; if (x.valid && x.h == h && bn_same(x.q, q)) e = &x; }  // the tasks of a gang ask one after the other
         if (!e) for (int i = 0; i < KAI_BN_ENT; i++) {
-            BnEnt& x = el().bn[i];
+            BnEnt& x = eb().bn[i];
             if (x.valid && x.h == h && bn_same(x.q, q)) { e = &x; el().bn_last = i; break; }
-            if (!x.valid || (el().bn[lru].valid && x.used < el().bn[lru].used)) lru = i;
+            if (!x.valid || (eb().bn[lru].valid && x.used < eb().bn[lru].used)) lru = i;
         }
         if (e && el().bn_seq - e->sync <= (uint32_t)KAI_BN_LOG) {
-            int32_t* m = el().bn_m; double* sc = el().bn_sc; uint8_t* ok = el().bn_ok; int nm = 0;
-            for (uint32_t i = e->sync; i != el().bn_seq; i++) { const int x = el().bn_log[i % KAI_BN_LOG]; bool seen = false; for (int k = 0; k < nm; k++) if (m[k] == x) seen = true; if (!seen) m[nm++] = x; }
+            int32_t* m = eb().bn_m; double* sc = eb().bn_sc; uint8_t* ok = eb().bn_ok; int nm = 0;
+            for (uint32_t i = e->sync; i != el().bn_seq; i++) { const int x = eb().bn_log[i % KAI_BN_LOG]; bool seen = false; for (int k = 0; k < nm; k++) if (m[k] == x) seen = true; if (!seen) m[nm++] = x; }
             if (nm == 0 || be.eval_nodes(cx(), q, m, nm, sc, ok)) {
                 int best = e->node; double bs = e->score; bool keep = true;
                 for (int k = 0; k < nm; k++) if (m[k] == e->node) { if (ok[k] && sc[k] >= e->score) bs = sc[k]; else keep = false; }
@@ -1824,7 +1833,7 @@ struct Engine {
                 }
             }
         }
-        if (!e) { e = &el().bn[lru]; el().bn_last = lru; }
+        if (!e) { e = &eb().bn[lru]; el().bn_last = lru; }
         double s = 0; const int n = be.best_node(cx(), q, &s);
         cx().st->node_scans++; cx().st->nodes_scanned += cx().N;
         e->q = q; e->h = h; e->node = n; e->score = s; e->valid = 1; e->sync = el().bn_seq; e->used = ++el().bn_tick;
@@ -1846,13 +1855,13 @@ struct Engine {
         bool sim_scope = false;
         if constexpr (kVictim) {  // a simulation's feasible nodes, no narrower node set on top: has this request already found nothing since the last rollback?
             sim_scope = el().sim_dead_on && el().scope_bits && el().scope_bits == el().base_bits && el().scope_row < 0;
-            if (sim_scope) for (int i = 0; i < el().sim_dead_n; i++) if (sim_dead_same(el().sim_dead[i], q)) { cx().st->node_scans++; cx().st->nodes_scanned += cx().N; return -1; }  // (counted like the pass it stands for)
+            if (sim_scope) for (int i = 0; i < el().sim_dead_n; i++) if (sim_dead_same(eb().sim_dead[i], q)) { cx().st->node_scans++; cx().st->nodes_scanned += cx().N; return -1; }  // (counted like the pass it stands for)
         }
         if ((cx().plugins & KAI_PLUGIN_NODEPLACEMENT) && q.strategy == KAI_BINPACK) preorder_range(q.r_place, q.min_a, q.max_a);  // NodePreOrderFn
         int n;
         if (cx().action == KAI_ACTION_ALLOCATE && !el().scope_bits && el().scope_row < 0) n = best_node_kept(q);  // over all nodes: the answer of the last decision with this request, patched
         else { n = be.best_node(cx(), q, nullptr); cx().st->node_scans++; cx().st->nodes_scanned += cx().N; }
-        if constexpr (kVictim) if (sim_scope && n < 0) { const int k = el().sim_dead_n < 4 ? el().sim_dead_n++ : 3; el().sim_dead[k] = q; }
+        if constexpr (kVictim) if (sim_scope && n < 0) { const int k = el().sim_dead_n < 4 ? el().sim_dead_n++ : 3; eb().sim_dead[k] = q; }
         if (n >= 0) allocatable = q.best_effort || fits(cx(), q.req, n, false);  // NodeInfo.IsTaskAllocatable (node_info.go:168-188)
 #ifdef KAI_SHARED_GPUS
         if (n >= 0 && pod_shared(p)) allocatable = q.best_effort || fits_shared(cx(), q, n, false);
@@ -2348,15 +2357,15 @@ struct Engine {
     }
     // node-set bitmaps of the DFS: slot d holds the set the frame at depth d is currently trying; `restricted[d]` tells whether any frame
     // up to depth d narrowed the set (otherwise the set is "every node" and scans may use the class index)
-    KAI_HD KAI_GP(const uint32_t) frame_bits(int depth) { return el_restricted(depth) ? el().fbits[depth] : (KAI_GP(const uint32_t))nullptr; }  // (the frame's own slot of ns_bits, or — a frame that narrows nothing — the set of the frame above it)
+    KAI_HD KAI_GP(const uint32_t) frame_bits(int depth) { return el_restricted(depth) ? eb().fbits[depth] : (KAI_GP(const uint32_t))nullptr; }  // (the frame's own slot of ns_bits, or — a frame that narrows nothing — the set of the frame above it)
     KAI_HD KAI_GP(const uint32_t) el_parent_bits(int depth) { return depth == 0 ? el().base_bits : frame_bits(depth - 1); }
     KAI_HD bool el_restricted(int depth) const { return (el().restricted >> depth) & 1u; }
     KAI_HD void set_frame_bits(int depth, int dom) {
         bool parent_restricted = depth > 0 ? el_restricted(depth - 1) : (el().base_bits != nullptr);
         if (dom < 0 && !parent_restricted) { el().restricted &= ~(1u << depth); return; }  // still every node
-        if (dom < 0) { el().fbits[depth] = el_parent_bits(depth); el().restricted |= 1u << depth; return; }  // the parent's set as it is (a simulation's feasible nodes under every frame of every job it re-places): no copy
+        if (dom < 0) { eb().fbits[depth] = el_parent_bits(depth); el().restricted |= 1u << depth; return; }  // the parent's set as it is (a simulation's feasible nodes under every frame of every job it re-places): no copy
         build_node_set(cx().ns_bits + (size_t)depth * cx().W, el_parent_bits(depth), dom);
-        el().fbits[depth] = (KAI_GP(const uint32_t))(cx().ns_bits + (size_t)depth * cx().W);
+        eb().fbits[depth] = (KAI_GP(const uint32_t))(cx().ns_bits + (size_t)depth * cx().W);
         el().restricted |= 1u << depth;
     }
     // ------------------------------------------------------------------ staged job path

@@ -241,6 +241,8 @@ struct NullBackend {  // kernels that only need the engine's pure helpers
     static constexpr bool kVictim = false;
     template <class T> __device__ static void assume_tree(T*) {}
     const KaiCtx* cref = nullptr; EngineLocal loc;
+    static constexpr bool kBig = false;  // (no scan lane ever reads the control lane's larger data; big() only has to exist)
+    __device__ static EngineBig& big();
     __device__ void bind(const KaiCtx& c) { cref = &c; }
     __device__ const KaiCtx& ctx() const { return *cref; }
     __device__ EngineLocal& local() { return loc; }
@@ -364,6 +366,8 @@ __device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg(
 __shared__ ActShared g_sh;
 __shared__ KaiCtx g_ctx;
 __shared__ EngineLocal g_el;
+__shared__ EngineBig g_eb;
+__device__ inline EngineBig& NullBackend::big() { return g_eb; }  // (never dereferenced: kBig is false)
 
 // monotone map f64 → u64 (larger double ⇒ larger key); scores here are finite and ≥ 0 but keep it general
 __device__ __forceinline__ unsigned long long orderable(double d) {
@@ -391,6 +395,8 @@ struct DevBackendT {
     __device__ static void bind(const KaiCtx&) {}  // k_action copied the context into g_ctx before constructing the engine
     __device__ static const KaiCtx& ctx() { return g_ctx; }
     __device__ static EngineLocal& local() { return g_el; }
+    static constexpr bool kBig = true;
+    __device__ static EngineBig& big() { return g_eb; }
     // control lane side -------------------------------------------------------------------------------
     // A command is two workgroup barriers: publish, then results ready.  A refresh is split: refresh() publishes and returns, the
     // control lane goes on with work that neither reads the index nor touches the dirty list (commit, next pop, frame load), and

@@ -50,6 +50,7 @@ struct HostBackend {  // serial twin of DevBackend / service_loop (kai_kernels.h
     void bind(const KaiCtx& c) { cref = &c; }
     const KaiCtx& ctx() const { return *cref; }
     EngineLocal& local() { return loc; }
+    static constexpr bool kBig = true; EngineBig bigv; EngineBig& big() { return bigv; }
     std::vector<uint64_t> s2_key, top_key; std::vector<int32_t> s2_node, top_node;
     static void add_f64(double* p, double v) { *p += v; }
     static void add_i32(int32_t* p, int32_t v) { *p += v; }

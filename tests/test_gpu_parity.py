@@ -832,6 +832,7 @@ def test_gpu_victim_waves_over_the_ranks_of_a_group_on_one_device(gpu, world, wg
         def run(rank):
             try:
                 with T.pkg.KaiCore(cfg, world=world, rank=rank, offers_per_class=16, allgather=make_allgather(rank), host_allgather=make_host_allgather(rank)) as core:
+                  try:
                     ssn = core.open_session(snap)
                     ops, exchanges = [], 0
                     for a in actions:
@@ -840,7 +841,10 @@ def test_gpu_victim_waves_over_the_ranks_of_a_group_on_one_device(gpu, world, wg
                     st, nd = ssn.pod_states()
                     results[rank] = (ops, st, nd, ssn.node_states(), ssn.queue_shares(), exchanges)
                     ssn.close()
-            except Exception as e:  # noqa: BLE001 — reported below; the other threads are released
+                  except BaseException as e:  # (said before the handle is destroyed: a failing rank used to take the process down there without a word)
+                    import sys; print(f"rank {rank} failed inside the session: {e!r}", file=sys.stderr, flush=True); barrier.abort(); raise
+            except BaseException as e:  # noqa: BLE001 — reported below; the other threads are released
+                import sys; print(f"rank {rank}: {e!r}", file=sys.stderr, flush=True)
                 errors.append((rank, repr(e))); barrier.abort()
 
         threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
