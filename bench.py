@@ -140,14 +140,19 @@ def main():
         o_ms = ssn.stats().upload_ms
         n_ops, n_dec, k_ms_sum, st = 0, 0, 0.0, None
         ops_step = []
+        view = len(actions) == 1  # one action per step: its operations stay where the C ABI wrote them (the session's ops_out buffer) instead of being copied once more
         for a in actions:  # one scheduling cycle: the configured actions in order on the same session
-            o = ssn.execute(a); n_ops += len(o)
-            ops_step.append(o)  # kept as returned (numpy view of the C ABI's kai_op array): converting is left for after the timed region
+            t_a0 = time.perf_counter()
+            o = ssn.execute(a, copy=not view); n_ops += len(o)
+            t_a1 = time.perf_counter()
+            ops_step.append(o)  # kept as returned (numpy over the C ABI's kai_op array): converting is left for after the timed region
             s_a = ssn.stats(); n_dec += int(s_a.decisions); k_ms_sum += s_a.kernel_ms
             st = s_a if st is None else st  # the engine counters reported below are the allocate action's
             last_stats[0] = s_a
+            if trace_steps:
+                print(f"bench step: {a}: execute {1e3 * (t_a1 - t_a0):.2f} ms (device {s_a.kernel_ms:.2f}), statistics {1e3 * (time.perf_counter() - t_a1):.3f} ms", file=sys.stderr)
         if trace_steps:
-            print(f"bench step: reset {1e3 * (t_s1 - t_s0):.2f} ms, actions {1e3 * (time.perf_counter() - t_s1):.2f} ms", file=sys.stderr)
+            print(f"bench step: reset {1e3 * (t_s1 - t_s0):.2f} ms (device {o_ms:.2f}), actions {1e3 * (time.perf_counter() - t_s1):.2f} ms", file=sys.stderr)
         if record:
             kernel_ms.append(k_ms_sum); open_ms.append(o_ms)
             decisions = n_dec; placed = n_ops
@@ -348,7 +353,7 @@ def main():
             for i in range(n_cyc + 1):
                 t0 = time.perf_counter(); s2 = core2.open_session(snap); t1 = time.perf_counter()
                 for a in actions:
-                    s2.execute(a)
+                    s2.execute(a, copy=False)
                 t2 = time.perf_counter(); s2.close()
                 if i > 0:
                     ser.append((t2 - t0) * 1e3); ser_open.append((t1 - t0) * 1e3)
@@ -361,7 +366,7 @@ def main():
                     box["s"] = cores[k].open_session(snap)
                 t0 = time.perf_counter(); th = threading.Thread(target=opener); th.start()
                 for a in actions:
-                    cur.execute(a)
+                    cur.execute(a, copy=False)
                 th.join(); t1 = time.perf_counter()
                 cur.close(); cur = box["s"]
                 if i > 0:
