@@ -1442,6 +1442,30 @@ int kai_oracle_idle_gpus_kat(int mode, int n_nodes, const double* idle, const in
     return result;
 }
 
+// The AccumulatedNodeAffinities filter on the cases of node_affinities_test.go (:220-246 the three cases without a filter, :248-424 the table of ten): nodes and
+// pods are small integers.  required[i] = the pending pod has a node selector or required terms; match[i * n_nodes + n] = the upstream NodeAffinity Filter of pod i
+// on node n; pre_status[i] / pre_names[pre_off[i] ..) = what its PreFilter answers (0 no narrowing, 1 these node names — cluster indices, names the cluster does
+// not hold left out —, -1 unschedulable).  The filter is created on the scenario without victims (with_scenario = 0: on no scenario at all) and the feasible nodes,
+// then asked about the scenario with the victims (their nodes, -1 = none) as potential victims.  Returns -1 = no filter was created, else Filter: 1 valid / 0 not.
+int kai_oracle_node_affinities_kat(int n_nodes, const int32_t* feasible, int n_feasible, int n_pending, const uint8_t* required, const uint8_t* match,
+                                   const int32_t* pre_status, const int32_t* pre_off, const int32_t* pre_names, const int32_t* victim_node, int n_victims, int with_scenario) {
+    std::vector<orc::PodInfo> pods((size_t)(n_pending + n_victims));
+    orc::Scenario initial, asked;
+    for (int i = 0; i < n_pending; i++) { pods[(size_t)i].idx = i; initial.pendingTasks.push_back(&pods[(size_t)i]); asked.pendingTasks.push_back(&pods[(size_t)i]); }
+    for (int i = 0; i < n_victims; i++) { orc::PodInfo& p = pods[(size_t)(n_pending + i)]; p.idx = n_pending + i; p.node = victim_node[i]; asked.potentialVictimsTasks.push_back(&p); }
+    std::set<int> feas(feasible, feasible + n_feasible);
+    auto f = orc::AccumulatedNodeAffinities::create(with_scenario ? &initial : nullptr, feas,
+        [&](const orc::PodInfo* t) { return required[t->idx] != 0; },
+        [&](const orc::PodInfo* t, std::vector<int>& names) { if (pre_status[t->idx] == 1) names.assign(pre_names + pre_off[t->idx], pre_names + pre_off[t->idx + 1]); return (int)pre_status[t->idx]; },
+        [&](const orc::PodInfo* t, int n) { return n >= 0 && n < n_nodes && match[(size_t)t->idx * n_nodes + n] != 0; });
+    if (!f) return -1;
+    return f->Filter(&asked) ? 1 : 0;
+}
+
+// sessions of kai_oracle_run apply the AccumulatedNodeAffinities filter on the static class table (oracle_solver.hpp) from now on (1) / no longer (0); returns the
+// scenarios the filter dropped since the previous call
+int64_t kai_oracle_node_affinities_filter(int on) { const int64_t d = orc::g_node_affinities_dropped; orc::g_node_affinities_dropped = 0; orc::g_node_affinities_filter = on ? 1 : 0; return d; }
+
 // actions/common/minimal_job_comparison.go on hand-built jobs of ONE scheduling signature (minimal_job_comparison_test.go): pods = rows of (pending 0/1, milli-cpu,
 // memory, gpus).  mode 0: UpdateRepresentative(rep), → IsEasierToSchedule(job); mode 1: UpdateRepresentative(rep), UpdateRepresentative(job) → job is the representative
 int kai_oracle_minimal_job(int mode, const double* rep, int n_rep, const double* job, int n_job) {

@@ -7,9 +7,10 @@
 // execution of the reference; the device engine follows the same choices (DESIGN.md "canonical orders"):
 //   * jobs: ascending snapshot index;  nodes: ascending node name (name rank), "" (no node) first;  queues: ascending index
 //   * pods of a job: pod-sets by name rank, pods by snapshot index inside a pod-set (PodGroupInfo::AllPods)
-// Not restated: the AccumulatedNodeAffinities scenario filter (accumulated_scenario_filters/node_affinities): it rejects a scenario only
-// when some pending pod's node affinity matches none of the nodes the simulation may use — an exact necessary condition, so it
-// prunes without changing results.
+// The AccumulatedNodeAffinities scenario filter (accumulated_scenario_filters/node_affinities) is restated below and pinned on its own test table; it rejects a
+// scenario only when some pending pod's node affinity matches none of the nodes the simulation may use — a necessary condition, so it prunes without changing
+// results.  A session runs it only on request (kai_oracle_node_affinities_filter(1)): the snapshot carries the static Filters of a pod as ONE class table, not the
+// node affinity by itself, see the struct's header.
 #pragma once
 #include <set>
 #ifdef ORC_TRACE
@@ -266,14 +267,73 @@ struct TopologyAwareIdleGpus {
     }
 };
 
+// ---------------------------------------------------------------- accumulated_scenario_filters/node_affinities/node_affinities.go
+// The filter keeps the set of nodes a simulation may use — the feasible nodes it was created with plus the node of every victim it has seen (:100-121) — and
+// rejects a scenario when a pending pod with a REQUIRED node affinity (a node selector or requiredDuringScheduling terms, :134-145) has no node there that
+// its affinity matches (:123-132).  "Matches" is the upstream NodeAffinity plugin (k8s.io/kubernetes v1.34.2, pkg/scheduler/framework/plugins/nodeaffinity —
+// a go.mod dependency, not under /root/reference), asked in two steps (:147-166): PreFilter may narrow the candidates to the node NAMES the pod's terms list
+// (every term carries a metadata.name matchFields requirement; these are looked up among ALL nodes of the cluster, feasible or not, :157-160), no narrowing =
+// the filter's own node set (:168-188); Filter then decides per node.  The three questions come in as callbacks: the known-answer entry
+// (kai_oracle_node_affinities_kat) answers them from the test table's labels and pod specs; a session answers them from the static class table
+// (class_fit: every static Filter of the pod, the node affinity among them — a pod can only land on a node of its class row, so the condition stays a necessary
+// one; it prunes at least what the reference's filter prunes and changes no result: tests/test_oracle_kat.py runs the victim actions with and without it).
+struct AccumulatedNodeAffinities {
+    std::set<int> feasibleNodes, processedVictims;   // node indices; pod indices (:32-36; allNodes / allNodeInfos = the callbacks' business)
+    std::function<bool(const PodInfo*)> hasRequiredNodeAffinity;                              // :134-145
+    std::function<int(const PodInfo*, std::vector<int>&)> preFilter;                          // 0 = no narrowing (nil result or Skip), 1 = names (cluster node indices; absent nodes left out), -1 = unschedulable
+    std::function<bool(const PodInfo*, int)> filter;                                          // NodeAffinity.Filter(pod, node)
+
+    // NewNodeAffinitiesFilter :38-59: nullptr without a scenario or without a pending pod that has a required affinity
+    static std::unique_ptr<AccumulatedNodeAffinities> create(Scenario* sc, const std::set<int>& feasible, std::function<bool(const PodInfo*)> hasRequired,
+                                                             std::function<int(const PodInfo*, std::vector<int>&)> pre, std::function<bool(const PodInfo*, int)> flt) {
+        if (!sc) return nullptr;
+        bool any = false; for (auto* t : sc->pendingTasks) if (hasRequired(t)) { any = true; break; }  // preemptorHasPodsWithNodeAffinities :72-79
+        if (!any) return nullptr;
+        auto f = std::make_unique<AccumulatedNodeAffinities>();
+        f->feasibleNodes = feasible; f->hasRequiredNodeAffinity = std::move(hasRequired); f->preFilter = std::move(pre); f->filter = std::move(flt);
+        f->updateStateWithScenario(sc);
+        return f;
+    }
+    void updateVictimNodesFromTask(const PodInfo* task) {  // :100-112
+        if (!processedVictims.insert(task->idx).second) return;
+        if (task->node < 0) return;
+        feasibleNodes.insert(task->node);
+    }
+    void updateStateWithScenario(Scenario* sc) {  // :91-98
+        for (auto* t : sc->potentialVictimsTasks) updateVictimNodesFromTask(t);
+        for (auto* t : sc->recordedVictimsTasks) updateVictimNodesFromTask(t);
+    }
+    bool hasNodeMatchingPodInSet(const PodInfo* task) {  // :147-166 + preFilteredNodeNames :168-188
+        std::vector<int> names; const int st = preFilter(task, names);
+        if (st < 0) return false;
+        if (st == 0) names.assign(feasibleNodes.begin(), feasibleNodes.end());
+        for (int n : names) if (filter(task, n)) return true;
+        return false;
+    }
+    bool Filter(Scenario* sc) {  // :85-89
+        updateStateWithScenario(sc);
+        for (auto* t : sc->pendingTasks) { if (!hasRequiredNodeAffinity(t)) continue; if (!hasNodeMatchingPodInSet(t)) return false; }  // allPendingPodsHaveMatchingNodes :114-123
+        return true;
+    }
+};
+inline int g_node_affinities_filter = 0;   // kai_oracle_node_affinities_filter: sessions run the filter on the class table (0 = as before: not at all)
+inline int64_t g_node_affinities_dropped = 0;  // scenarios it dropped since the switch was last set
+
 // ---------------------------------------------------------------- solvers/pod_scenario_builder.go
 struct ScenarioBuilder {
     Session* ssn; std::unique_ptr<Scenario> lastScenario; std::unique_ptr<AccumulatedIdleGpus> idleGpus; std::unique_ptr<TopologyAwareIdleGpus> topoGpus;
+    std::unique_ptr<AccumulatedNodeAffinities> nodeAffinities;
     JobsOrderByQueues* victimsJobsQueue; std::set<int> recordedVictimsTasks;
-    ScenarioBuilder(Session* s, PodGroupInfo* pendingJob, const std::vector<PodGroupInfo*>& recordedVictimsJobs, JobsOrderByQueues* vq) : ssn(s), victimsJobsQueue(vq) {  // :32-76
+    ScenarioBuilder(Session* s, PodGroupInfo* pendingJob, const std::vector<PodGroupInfo*>& recordedVictimsJobs, JobsOrderByQueues* vq, const std::set<int>& feasibleNodes) : ssn(s), victimsJobsQueue(vq) {  // :32-76
         if (!ssn->GetTasksToAllocate(pendingJob, false).empty()) {
             lastScenario = std::make_unique<Scenario>(ssn, pendingJob, recordedVictimsJobs);
             for (auto* job : recordedVictimsJobs) for (auto* t : job->AllPods()) recordedVictimsTasks.insert(t->idx);
+            if (g_node_affinities_filter && !ssn->classFit.empty()) {  // :52-56, on the class table (see AccumulatedNodeAffinities)
+                Session* S = ssn;
+                auto fits = [S](const PodInfo* t, int n) { return S->classFit[size_t(t->podClass) * S->nNodeClasses + S->nodes[n].nodeClass] != 0; };
+                auto required = [S, fits](const PodInfo* t) { for (int n = 0; n < (int)S->nodes.size(); n++) if (!fits(t, n)) return true; return false; };
+                nodeAffinities = AccumulatedNodeAffinities::create(lastScenario.get(), feasibleNodes, required, [](const PodInfo*, std::vector<int>&) { return 0; }, fits);
+            }
             topoGpus = std::make_unique<TopologyAwareIdleGpus>(ssn, lastScenario.get());
             if (!topoGpus->active) topoGpus.reset();
             idleGpus = std::make_unique<AccumulatedIdleGpus>(ssn, lastScenario.get());
@@ -307,7 +367,8 @@ struct ScenarioBuilder {
     }
     Scenario* GetValidScenario() {  // :135-161
         bool valid = true;
-        if (topoGpus && lastScenario && !topoGpus->Filter(lastScenario.get())) valid = false;
+        if (nodeAffinities && lastScenario && !nodeAffinities->Filter(lastScenario.get())) { valid = false; g_node_affinities_dropped++; }
+        if (valid && topoGpus && lastScenario && !topoGpus->Filter(lastScenario.get())) valid = false;
         if (valid && idleGpus && lastScenario) { bool err = false; bool ok = idleGpus->Filter(lastScenario.get(), err); if (!err && !ok) valid = false; }
         if (!valid) { ssn->stats.scenariosFiltered++; return GetNextScenario(); }
         return lastScenario.get();
@@ -440,7 +501,7 @@ struct JobSolver {
         std::set<int> feasibleNodeMap(feasibleNodes.begin(), feasibleNodes.end());
         for (auto* t : recordedVictimsTasks) if (t->node >= 0) feasibleNodeMap.insert(t->node);
         std::unique_ptr<JobsOrderByQueues> vq = generateVictimsQueue();
-        ScenarioBuilder builder(ssn, partial, recordedVictimsJobs, vq.get());
+        ScenarioBuilder builder(ssn, partial, recordedVictimsJobs, vq.get(), feasibleNodeMap);
         ORC_T("[orc] partial job %d: victims queue len %d empty %d scenario %d feasible %d\n", partial->idx, vq->Len(), (int)vq->IsEmpty(), (int)(builder.lastScenario != nullptr), (int)feasibleNodeMap.size());
         for (Scenario* sc = builder.GetValidScenario(); sc; sc = builder.GetNextScenario()) {
             ByPodSolver solver{ssn, feasibleNodeMap, validator, ssn->cfg.allow_consolidating_reclaim != 0};

@@ -301,47 +301,79 @@ def test_static_predicate_classes():
     assert s2.n_pod_classes == 1 and s2.n_node_classes == 3  # untainted / dedicated:NoSchedule / down:NoExecute
 
 
-# The reference's own (pod constraint, node) cases for the NodeAffinity Filter of k8s.io/kubernetes v1.34.2 (absent from /root/reference): the ten rows of
-# accumulated_scenario_filters/node_affinities/node_affinities_test.go:248-400 (TestNodeAffinitiesFilter_Filter), transcribed by hand:
-# (name, all nodes {name: labels}, feasible node names, pending pod specs, victim node names, wantFilterResult)
-_SEL = lambda v: {"nodeSelector": {"gpu-type": v}}
-_AFF = lambda k, v: {"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [{"matchExpressions": [{"key": k, "operator": "In", "values": [v]}]}]}}}}
-_FIELD = lambda n: {"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [{"matchFields": [{"key": "metadata.name", "operator": "In", "values": [n]}]}]}}}}
-_PREF = lambda k, v, w: {"affinity": {"nodeAffinity": {"preferredDuringSchedulingIgnoredDuringExecution": [{"weight": w, "preference": {"matchExpressions": [{"key": k, "operator": "In", "values": [v]}]}}]}}}
-_A, _V = {"node-a100": {"gpu-type": "A100"}}, {"node-v100": {"gpu-type": "V100"}}
-NODE_AFFINITY_FILTER_CASES = [
-    ("pending pod matches node selector - filter passes", _A, ["node-a100"], [_SEL("A100")], [], True),
-    ("pending pod node selector has no matching node - filter fails", _V, ["node-v100"], [_SEL("A100")], [], False),
-    ("pending pod with NodeAffinity matches node - filter passes", _A, ["node-a100"], [_AFF("gpu-type", "A100")], [], True),
-    ("mixed pending pods: affinity pod matches, pod without affinity is skipped - filter passes", _A, ["node-a100"], [_SEL("A100"), {}], [], True),
-    ("mixed pending pods: affinity pod has no matching node - filter fails", _V, ["node-v100"], [_SEL("A100"), {}], [], False),
-    ("victim running on matching node expands feasible set - filter passes", dict(_A, **_V), ["node-v100"], [_SEL("A100")], ["node-a100"], True),
-    ("MatchFields targets node that exists in cluster but is not feasible - filter passes", {"node-specific": {}, "node-other": {}}, ["node-other"], [_FIELD("node-specific")], [], True),
-    ("MatchFields targets node absent from the cluster - filter fails", {"node-other": {}}, ["node-other"], [_FIELD("node-specific")], [], False),
-    ("victim on non-matching node does not satisfy affinity - filter fails", dict(_A, **_V), ["node-v100"], [_SEL("A100")], ["node-v100"], False),
-    ("mixed pending pods: required affinity matches, preferred-only pod present - filter passes", _A, ["node-a100"], [_AFF("gpu-type", "A100"), _PREF("gpu-type", "A100", 100)], [], True),
-]
+# The reference's own (pod constraint, node) cases for the NodeAffinity Filter of k8s.io/kubernetes v1.34.2 (absent from /root/reference): the table of
+# accumulated_scenario_filters/node_affinities/node_affinities_test.go:248-424 (TestNodeAffinitiesFilter_Filter, ten rows) and the three tests before it in which no
+# filter is created (:220-246) — tests/golden/kat_node_affinities.json, generated from the Go source by tools/go_kat_node_affinities.py.
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_node_affinities.json")) as _fh:
+    NODE_AFFINITIES = json.load(_fh)
+_TERMS = lambda *terms: {"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": list(terms)}}}}
 
 
-@pytest.mark.parametrize("name,all_nodes,feasible,pending,victim_nodes,want", NODE_AFFINITY_FILTER_CASES, ids=[c[0][:60] for c in NODE_AFFINITY_FILTER_CASES])
-def test_static_predicate_matcher_on_reference_node_affinity_cases(name, all_nodes, feasible, pending, victim_nodes, want):
-    """n4 pinned on the reference: the compiled class_fit table (NodeAffinity Filter semantics restated in kai_ingest.cpp) must give the reference's expectation
-    in each of its ten AccumulatedNodeAffinities cases.  The filter itself is restated here over the table as the reference wires it
-    (node_affinities.go:83-176): victims' nodes join the feasible set; a pod with a nodeSelector or required terms needs ONE node that passes the Filter among
-    the PreFilter's node names (terms of matchFields metadata.name In [...] only) looked up in the WHOLE cluster, else among the feasible nodes."""
-    s = ingest(doc(nodes=[node(n, labels=l) for n, l in all_nodes.items()], pods=[pod("p%d" % i, spec=sp) for i, sp in enumerate(pending)])).snapshot
-    names = list(s.node_names); idx = {n: k for k, n in enumerate(names)}
-    feas = set(feasible) | {n for n in victim_nodes if n in idx}
-    ok = True
-    for i, sp in enumerate(pending):
+def _pod_spec(p):
+    """a fixture pod (kind + arguments of the test file's helper, node_affinities_test.go:79-218) as a pod spec"""
+    if p["kind"] == "selector": return {"nodeSelector": p["selector"]}
+    if p["kind"] == "required_in": return _TERMS({"matchExpressions": [{"key": p["key"], "operator": "In", "values": p["values"]}]})
+    if p["kind"] == "required_match_fields": return _TERMS({"matchFields": [{"key": "metadata.name", "operator": "In", "values": p["node_names"]}]})
+    if p["kind"] == "preferred_only":
+        return {"affinity": {"nodeAffinity": {"preferredDuringSchedulingIgnoredDuringExecution": [{"weight": p["weight"], "preference": {"matchExpressions": [{"key": p["key"], "operator": "In", "values": p["values"]}]}}]}}}
+    assert p["kind"] == "none"
+    return {}
+
+
+def _node_affinity_answers(all_nodes, pending):
+    """What the upstream NodeAffinity plugin answers for each pending pod, from the COMPILED class table of kai_ingest.cpp: required (hasRequiredNodeAffinity,
+    node_affinities.go:134-145), match per node (Filter), PreFilter's node names (terms of matchFields metadata.name In [...] only; names the cluster does not
+    hold left out, :157-160)."""
+    specs = [_pod_spec(p) for p in pending]
+    s = ingest(doc(nodes=[node(n, labels=l) for n, l in all_nodes.items()] or [node("placeholder")], pods=[pod("p%d" % i, spec=sp) for i, sp in enumerate(specs)])).snapshot
+    names = list(s.node_names) if all_nodes else []; idx = {n: k for k, n in enumerate(names)}
+    required, match, pre = [], [], []
+    for i, sp in enumerate(specs):
         req = (sp.get("affinity", {}).get("nodeAffinity", {}) or {}).get("requiredDuringSchedulingIgnoredDuringExecution")
-        if "nodeSelector" not in sp and req is None: continue  # hasRequiredNodeAffinity :124-135
+        required.append("nodeSelector" in sp or req is not None)
         terms = (req or {}).get("nodeSelectorTerms", [])
         field_only = bool(terms) and all(t.get("matchFields") and not t.get("matchExpressions") and all(f["key"] == "metadata.name" and f["operator"] == "In" for f in t["matchFields"]) for t in terms)
-        cand = {v for t in terms for f in t["matchFields"] for v in f["values"]} if field_only else feas  # NodeAffinity.PreFilter's NodeNames
+        pre.append(sorted(idx[v] for t in terms for f in t["matchFields"] for v in f["values"] if v in idx) if field_only else None)
         pi = [k for k, n in enumerate(s.pod_names) if n.endswith("/p%d" % i)][0]
-        if not any(n in idx and s.class_fit[s.pod_class[pi], s.node_class[idx[n]]] for n in cand): ok = False
-    assert ok == want, name
+        match.append([bool(s.class_fit[s.pod_class[pi], s.node_class[idx[n]]]) for n in names])
+    return names, idx, required, match, pre
+
+
+def _oracle_node_affinities(n_nodes, feasible, required, match, pre, victim_nodes, with_scenario=True):
+    """one call of kai_oracle_node_affinities_kat (oracle_solver.hpp AccumulatedNodeAffinities): -1 no filter, else Filter"""
+    lib = T.Oracle.lib(); lib.kai_oracle_node_affinities_kat.restype = C.c_int
+    i32 = lambda v: (C.c_int32 * max(len(v), 1))(*v); u8 = lambda v: (C.c_uint8 * max(len(v), 1))(*[int(x) for x in v])
+    off = [0]; flat = []
+    for p in pre: flat += p or []; off.append(len(flat))
+    return lib.kai_oracle_node_affinities_kat(n_nodes, i32(feasible), len(feasible), len(required), u8(required), u8([x for row in match for x in row]),
+                                              i32([0 if p is None else 1 for p in pre]), i32(off), i32(flat), i32(victim_nodes), len(victim_nodes), int(with_scenario))
+
+
+@pytest.mark.parametrize("case", NODE_AFFINITIES["filter_cases"], ids=[c["name"][:60] for c in NODE_AFFINITIES["filter_cases"]])
+def test_static_predicate_matcher_on_reference_node_affinity_cases(case):
+    """n4 and a29 pinned on the reference: the compiled class_fit table (NodeAffinity Filter semantics restated in kai_ingest.cpp) must give the reference's
+    expectation in each of its ten AccumulatedNodeAffinities cases — through the filter as the reference wires it (node_affinities.go:83-188), once restated here
+    over the table (victims' nodes join the feasible set; a pod with a nodeSelector or required terms needs ONE node that passes the Filter among the PreFilter's
+    node names looked up in the WHOLE cluster, else among the feasible nodes), once as the oracle's AccumulatedNodeAffinities (oracle_solver.hpp) fed with the
+    table's answers."""
+    names, idx, required, match, pre = _node_affinity_answers(case["all_nodes"], case["pending"])
+    feas = set(case["feasible"]) | {n for n in case["victims"] if n in idx}
+    ok = True
+    for i in range(len(case["pending"])):
+        if not required[i]: continue
+        cand = pre[i] if pre[i] is not None else [idx[n] for n in feas if n in idx]
+        if not any(match[i][k] for k in cand): ok = False
+    assert ok == case["want"], case["name"]
+    got = _oracle_node_affinities(len(names), [idx[n] for n in case["feasible"]], required, match, pre, [idx.get(n, -1) for n in case["victims"]])
+    assert got == int(case["want"]), (case["name"], got)
+
+
+@pytest.mark.parametrize("case", NODE_AFFINITIES["no_filter_cases"], ids=[c["name"] for c in NODE_AFFINITIES["no_filter_cases"]])
+def test_node_affinities_filter_is_not_created_without_a_required_affinity(case):
+    """node_affinities_test.go:220-246: no scenario, no pending pod with a node affinity, a preferred-only affinity → NewNodeAffinitiesFilter returns nil"""
+    names, idx, required, match, pre = _node_affinity_answers({}, case["pending"])
+    assert not any(required)
+    assert _oracle_node_affinities(0, [], required, match, pre, [], with_scenario=case["scenario"]) == -1
 
 
 def test_fallback_flags_and_config_maps():

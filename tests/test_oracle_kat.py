@@ -375,3 +375,54 @@ def test_idle_gpus_filter(case):
     r, err, _, _ = _idle_gpus_run(3, f["idle"], f["sorted"], f["required"], f["pending_in_state"], f["recorded_in_cache"], f["potential_in_cache"],
                                   sc["pending"], sc["potential_victims"], sc["recorded_victims"], node_mem=sc.get("node_gpu_memory_mib"))
     assert err == w["err"] and bool(r) == w["valid"], case["name"]
+
+
+# ------------------------------------------------------------------------------------------------ AccumulatedNodeAffinities in a session (oracle_solver.hpp)
+def _with_predicate_classes(snap, seed):
+    """random static predicate classes on a crowded snapshot: a few node classes, pod classes that fit some of them (class 0 fits every node)"""
+    rng = np.random.default_rng(seed ^ 0xAFF1)
+    a = snap.arrays; N, P = snap.n_nodes, snap.n_pods
+    n_nc, n_pc = int(rng.integers(2, 5)), int(rng.integers(2, 5))
+    a["node_class"] = rng.integers(0, n_nc, N).astype(np.int32)
+    fit = (rng.random((n_pc, n_nc)) < 0.5).astype(np.uint8); fit[0, :] = 1
+    a["class_fit"] = fit
+    pc = np.zeros(P, np.int32)
+    pending = a["pod_status"] == T.abi.POD_STATUS["Pending"]
+    pc[pending] = rng.integers(0, n_pc, int(pending.sum()))  # running pods keep class 0: where they run already is not in question
+    a["pod_class"] = pc
+    return snap.finalize()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_node_affinities_filter_prunes_without_changing_a_result(seed):
+    """DESIGN.md §1 "not built": the AccumulatedNodeAffinities filter (node_affinities.go) is a necessary condition of a simulation's success, so a victim search
+    with it and one without it commit the same operations.  The oracle runs the victim actions on crowded snapshots with static predicate classes both ways — the
+    filter on the class table, oracle_solver.hpp — and must return the same operations, states and shares; over the seeds the filter must have dropped scenarios
+    (it is exercised) and the filtered run must have simulated no more scenarios than the other."""
+    synth = T.pkg.synth
+    snap = synth.make_crowded_snapshot(6 + seed % 11, 9100 + seed, fill=0.85, queue_levels=((2, 2), (3,), (2, 2, 2))[seed % 3], hog_frac=0.5, elastic_frac=0.3 if seed % 2 else 0.0,
+                                       nonpreempt_frac=0.1, n_pending_jobs=6 + seed % 9)
+    _with_predicate_classes(snap, seed)
+    cfg = T.abi.default_config(max_consolidation_preemptees=8); cfg.allow_consolidating_reclaim = seed % 2
+    acts = (("reclaim", "preempt"), ("allocate", "consolidation", "reclaim", "preempt"), ("preempt", "reclaim"))[seed % 3]
+    lib = T.Oracle.lib(); lib.kai_oracle_node_affinities_filter.restype = C.c_int64
+    stats = lambda: (lambda v: (lib.kai_oracle_last_victim_stats(v), list(v))[1])((C.c_int64 * 3)())
+    try:
+        lib.kai_oracle_node_affinities_filter(0)
+        plain = T.Oracle.run(snap, cfg, acts); st_plain = stats()
+        lib.kai_oracle_node_affinities_filter(1)
+        filtered = T.Oracle.run(snap, cfg, acts); st_filtered = stats()
+    finally:
+        dropped = lib.kai_oracle_node_affinities_filter(0)
+    assert plain.ops == filtered.ops and (plain.pod_status == filtered.pod_status).all() and (plain.pod_node == filtered.pod_node).all()
+    assert all(np.array_equal(plain.shares_final[k], filtered.shares_final[k]) for k in plain.shares_final)
+    assert st_filtered[0] <= st_plain[0] <= st_filtered[0] + dropped, (st_plain, st_filtered, dropped)  # scenarios simulated: every one it saved is one it dropped
+    test_node_affinities_filter_prunes_without_changing_a_result.dropped = getattr(test_node_affinities_filter_prunes_without_changing_a_result, "dropped", 0) + dropped
+
+
+def test_node_affinities_filter_was_exercised():
+    """(runs after the seeds above in file order; alone it has nothing to check)"""
+    d = getattr(test_node_affinities_filter_prunes_without_changing_a_result, "dropped", None)
+    if d is None:
+        pytest.skip("the parametrized test did not run in this process")
+    assert d > 0
