@@ -1462,6 +1462,27 @@ int kai_oracle_node_affinities_kat(int n_nodes, const int32_t* feasible, int n_f
     return f->Filter(&asked) ? 1 : 0;
 }
 
+// The TopologyAwareIdleGpus filter on a freshly loaded session (topology_aware_idle_gpus_test.go): the preemptor is job `pending_job` itself; call c asks about the
+// scenario whose potential victims are the pods pot_pods[pot_off[c] .. pot_off[c + 1]) and whose recorded victim jobs are rec_jobs[rec_off[c] ..) — each scenario is built
+// anew (NewByNodeScenario), the filter is created on the first one (NewTopologyAwareIdleGpusFilter) and keeps its state over the calls.  valid_out[c] = Filter's
+// answer.  Returns the number of calls, or -1 when no filter is created (no sub-group of the preemptor carries a required topology level).
+int kai_oracle_topo_idle_gpus_kat(const kai_config* cfg, const kai_snapshot_soa* snap, int pending_job, int n_calls, const int32_t* pot_off, const int32_t* pot_pods,
+                                  const int32_t* rec_off, const int32_t* rec_jobs, int32_t* valid_out) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || pending_job < 0 || pending_job >= snap->n_jobs || n_calls < 1) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    std::vector<std::unique_ptr<orc::Scenario>> scs;
+    for (int c = 0; c < n_calls; c++) {
+        std::vector<orc::PodGroupInfo*> rec; for (int i = rec_off[c]; i < rec_off[c + 1]; i++) rec.push_back(&ssn.jobs[rec_jobs[i]]);
+        scs.push_back(std::make_unique<orc::Scenario>(&ssn, &ssn.jobs[pending_job], rec));
+        std::vector<orc::PodInfo*> pot; for (int i = pot_off[c]; i < pot_off[c + 1]; i++) pot.push_back(&ssn.pods[pot_pods[i]]);
+        scs.back()->AddPotentialVictimsTasks(pot);
+    }
+    orc::TopologyAwareIdleGpus f(&ssn, scs[0].get());
+    if (!f.active) return -1;
+    for (int c = 0; c < n_calls; c++) valid_out[c] = f.Filter(scs[(size_t)c].get()) ? 1 : 0;
+    return n_calls;
+}
+
 // sessions of kai_oracle_run apply the AccumulatedNodeAffinities filter on the static class table (oracle_solver.hpp) from now on (1) / no longer (0); returns the
 // scenarios the filter dropped since the previous call
 int64_t kai_oracle_node_affinities_filter(int on) { const int64_t d = orc::g_node_affinities_dropped; orc::g_node_affinities_dropped = 0; orc::g_node_affinities_filter = on ? 1 : 0; return d; }

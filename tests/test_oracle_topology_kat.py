@@ -260,3 +260,55 @@ def test_lowest_common_domain(line, name, nodes, pref, want_level, want_id, want
     if want_id:  # the domain z1(.r1) = the nodes that carry those label values on every level
         in_domain = {k for k, lb in nodes.items() if len(lb) == 2 and tuple(lb[l] for l in ("zone", "rack"))[:len(want_id)] == want_id}
         assert {snap.node_names[k] for k in range(nn) if member[k]} == in_domain
+
+
+# ------------------------------------------------------------------------------------------------ TopologyAwareIdleGpus (topology_aware_idle_gpus_test.go), tools/go_kat_topo_idle_gpus.py
+import json, os  # noqa: E402
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_topo_idle_gpus.json")) as _fh:
+    TOPO_IDLE = json.load(_fh)["cases"]
+
+
+def _topo_idle_case(case):
+    """a fixture case as a scene of the reference's test framework: the Topology object lists the label keys the case's constraints name (top level first — the
+    test file's filter reads the labels directly, a session needs the object), the pending job carries one SubGroupSet per newConstrainedSubGroup, every victim is a
+    Running pod of a job of its own"""
+    levels = []
+    for sg in case["subgroups"]:
+        if sg["required_level"] not in levels: levels.append(sg["required_level"])
+    levels.sort(key=lambda k: (not k.endswith("zone"), k))  # zone above rack where a case has both (TestTopologyAwareIdleGpus_MultipleLevels)
+    topo = [{"ObjectMeta": {"Name": "cluster-topology"}, "Spec": {"Levels": [{"NodeLabel": k} for k in levels]}}] if levels else []
+    nodes = {n: {"CPUMillis": 1000, "GPUs": v["gpus"], "MaxTaskNum": 100, "Labels": v["labels"]} for n, v in case["nodes"].items()}
+    root = {"Name": "", "PodSets": [], "TopologyConstraint": None,
+            "SubGroups": [{"Name": sg["name"], "PodSets": [{"Name": sg["name"], "MinAvailable": sg["pods"], "TopologyConstraint": None}], "SubGroups": [],
+                           "TopologyConstraint": {"Topology": sg["topology"], "RequiredLevel": sg["required_level"], "PreferredLevel": ""}} for sg in case["subgroups"]]}
+    jobs = [{"Name": "pending-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 0, **({"RootSubGroupSet": root} if case["subgroups"] else {}),
+             "Tasks": [{"State": "Pending", "RequiredGPUs": t["gpus"], **({"SubGroupName": t["subgroup"]} if case["subgroups"] else {})} for t in case["tasks"]]}]
+    for v in case["victims"]:
+        jobs.append({"Name": v["name"] + "-job", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 0, "Tasks": [{"State": "Running", "NodeName": v["node"], "RequiredGPUs": v["gpus"]}]})
+    return {"Name": case["name"], "Nodes": nodes, "Topologies": topo, "Queues": [{"Name": "q", "DeservedGPUs": 1}], "Jobs": jobs, "JobExpectedResults": {}}
+
+
+@pytest.mark.parametrize("case", TOPO_IDLE, ids=[f"{c['line']}:{c['name'].split('_', 1)[1]}" for c in TOPO_IDLE])
+def test_topology_aware_idle_gpus_filter(case):
+    """accumulated_scenario_filters/idle_gpus/topology_aware_idle_gpus.go against its own twelve tests: whether a filter is created, and what it answers to every
+    scenario it is asked about, in the test's order (a victim counted once over two calls; recorded victims counted; a domain that moves two places up the
+    capacity order; the greedy match over several sub-groups of one level, fragmentation included)."""
+    snap, cfg, _ = T.case_to_snapshot(_topo_idle_case(case))
+    cfg.plugins |= T.abi.PLUGINS["topology"]
+    pod_of = {}
+    for v in case["victims"]:
+        j = snap.job_names.index(v["name"] + "-job")
+        pod_of[v["name"]] = (int(np.nonzero(snap.arrays["pod_job"] == j)[0][0]), j)
+    pot_off, pot, rec_off, rec = [0], [], [0], []
+    for c in case["calls"]:
+        pot += [pod_of[v][0] for v in c["potential"]]; pot_off.append(len(pot))
+        rec += [pod_of[v][1] for v in c["recorded"]]; rec_off.append(len(rec))
+    i32 = lambda v: (C.c_int32 * max(len(v), 1))(*v)
+    lib = T.Oracle.lib(); lib.kai_oracle_topo_idle_gpus_kat.restype = C.c_int
+    out = (C.c_int32 * len(case["calls"]))(); s = snap.as_struct()
+    r = lib.kai_oracle_topo_idle_gpus_kat(C.byref(cfg), C.byref(s), snap.job_names.index("pending-job"), len(case["calls"]), i32(pot_off), i32(pot), i32(rec_off), i32(rec), out)
+    if not case["want_filter"]:
+        assert r == -1, r
+        return
+    assert r == len(case["calls"]), r
+    assert [bool(x) for x in out] == [c["want"] for c in case["calls"]], (case["name"], list(out))
