@@ -1224,17 +1224,8 @@ static void fill_shares(const orc::Session& ssn, kai_queue_share* out) {
     }
 }
 
-// One full cycle: open session, run the listed actions in order, report.
-// shares_open / shares_final / nodes_out / stats may be NULL.  elapsed_ms_out excludes the snapshot load.
-int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const int* actions, int n_actions,
-                   kai_op* ops_out, int64_t ops_cap, int64_t* n_ops, int32_t* pod_status_out, int32_t* pod_node_out,
-                   kai_queue_share* shares_open, kai_queue_share* shares_final, kai_node_state* nodes_out,
-                   kai_action_stats* stats, double* elapsed_ms_out) {
-    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || snap->n_res < 4 || snap->n_res > KAI_MAX_RES) return KAI_ERR_INVALID_ARG;
-    orc::Session ssn;
-    ssn.load(cfg, snap);
-    auto t0 = std::chrono::steady_clock::now();
-    // createQueueResourceAttrs (plugins/proportion/proportion.go:307-345)
+// createQueueResourceAttrs (plugins/proportion/proportion.go:307-345) for every queue of a freshly loaded session, then proportion's OnSessionOpen
+static void open_queues(orc::Session& ssn, const kai_snapshot_soa* snap) {
     const int Q = snap->n_queues; ssn.qattrs.resize(Q);
     for (int q = 0; q < Q; q++) {
         orc::QueueAttributes& a = ssn.qattrs[q]; a.idx = q; a.uidRank = ssn.queues[q].uidRank; a.parent = ssn.queues[q].parent; a.children = ssn.queues[q].children;
@@ -1247,6 +1238,19 @@ int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const in
         }
     }
     ssn.proportionOnSessionOpen();
+}
+
+// One full cycle: open session, run the listed actions in order, report.
+// shares_open / shares_final / nodes_out / stats may be NULL.  elapsed_ms_out excludes the snapshot load.
+int kai_oracle_run(const kai_config* cfg, const kai_snapshot_soa* snap, const int* actions, int n_actions,
+                   kai_op* ops_out, int64_t ops_cap, int64_t* n_ops, int32_t* pod_status_out, int32_t* pod_node_out,
+                   kai_queue_share* shares_open, kai_queue_share* shares_final, kai_node_state* nodes_out,
+                   kai_action_stats* stats, double* elapsed_ms_out) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || snap->n_res < 4 || snap->n_res > KAI_MAX_RES) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn;
+    ssn.load(cfg, snap);
+    auto t0 = std::chrono::steady_clock::now();
+    open_queues(ssn, snap);
     if (shares_open) fill_shares(ssn, shares_open);
     for (int i = 0; i < n_actions; i++) {
         switch (actions[i]) {
@@ -1304,18 +1308,8 @@ int kai_oracle_jobs_order(const kai_config* cfg, const kai_snapshot_soa* snap, i
                           int32_t* out, int cap, int* len_after_init) {
     if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION) return KAI_ERR_INVALID_ARG;
     orc::Session ssn; ssn.load(cfg, snap);
-    const int Q = snap->n_queues; ssn.qattrs.resize(Q);
-    for (int q = 0; q < Q; q++) {
-        orc::QueueAttributes& a = ssn.qattrs[q]; a.idx = q; a.uidRank = ssn.queues[q].uidRank; a.parent = ssn.queues[q].parent; a.children = ssn.queues[q].children;
-        a.createdNs = ssn.queues[q].createdNs; a.priority = ssn.queues[q].priority;
-        for (int r = 0; r < 3; r++) {
-            double deserved = snap->queue_deserved[r * Q + q], limit = snap->queue_limit[r * Q + q];
-            if (r == KAI_Q_MEM) { deserved = std::fmax(KAI_UNLIMITED, deserved * 1000000.0); limit = std::fmax(KAI_UNLIMITED, limit * 1000000.0); }
-            a.share[r].Deserved = deserved; a.share[r].MaxAllowed = limit; a.share[r].OverQuotaWeight = snap->queue_oqw[r * Q + q];
-            a.share[r].Usage = snap->queue_usage ? snap->queue_usage[r * Q + q] : 0.0;
-        }
-    }
-    ssn.proportionOnSessionOpen();
+    const int Q = snap->n_queues; (void)Q;
+    open_queues(ssn, snap);
     orc::JobsOrderInitOptions o; o.VictimQueue = flags & 1; o.FilterNonPending = flags & 2; o.FilterUnready = flags & 4; o.MaxJobsQueueDepth = depth <= 0 ? -1 : depth;
     orc::JobsOrderByQueues jobsOrder(&ssn, o);
     std::vector<orc::PodGroupInfo*> init; for (size_t j = 0; j < ssn.jobs.size(); j++) if (!init_mask || init_mask[j]) init.push_back(&ssn.jobs[j]);
@@ -1481,6 +1475,39 @@ int kai_oracle_topo_idle_gpus_kat(const kai_config* cfg, const kai_snapshot_soa*
     if (!f.active) return -1;
     for (int c = 0; c < n_calls; c++) valid_out[c] = f.Filter(scs[(size_t)c].get()) ? 1 : 0;
     return n_calls;
+}
+
+// PodAccumulatedScenarioBuilder on a freshly opened session (pod_scenario_builder_test.go): the builder for the pending job `reclaimer`, the recorded victim jobs
+// rec_job[i] — as CloneWithTasks of the pods rec_pods[rec_off[i] .. rec_off[i + 1]) where that range is not empty (a recorded part of an elastic job), whole otherwise —
+// and the victims queue over every OTHER job that holds an alive pod (utils.GetVictimsQueue(ssn, nil); the test file's reclaimer is not part of its ClusterInfo).
+// The scenarios of GetValidScenario, GetNextScenario, … in order: out = [S, (potential victim tasks, recorded victim jobs) x S, K, sizes x K] with K = the potential
+// victims of the LAST scenario and, for each, the pods of the job representative it belongs to (GetVictimJobRepresentativeById).  Returns the length written.
+int kai_oracle_scenario_builder_kat(const kai_config* cfg, const kai_snapshot_soa* snap, int reclaimer, int n_rec, const int32_t* rec_job, const int32_t* rec_off,
+                                    const int32_t* rec_pods, int32_t* out, int cap) {
+    if (!cfg || !snap || !out || snap->abi_version != KAI_ABI_VERSION || reclaimer < 0 || reclaimer >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    open_queues(ssn, snap);
+    std::vector<orc::PodGroupInfo*> recorded;
+    for (int i = 0; i < n_rec; i++) {
+        orc::PodGroupInfo* j = &ssn.jobs[rec_job[i]];
+        if (rec_off[i + 1] > rec_off[i]) { std::vector<orc::PodInfo*> part; for (int k = rec_off[i]; k < rec_off[i + 1]; k++) part.push_back(&ssn.pods[rec_pods[k]]); j = ssn.CloneWithTasks(j, part); }
+        recorded.push_back(j);
+    }
+    orc::PodGroupInfo* pending = &ssn.jobs[reclaimer];
+    std::unique_ptr<orc::JobsOrderByQueues> vq = ssn.GetVictimsQueue([pending](orc::PodGroupInfo* v) { return v->idx != pending->idx; });
+    std::set<int> feasible; for (auto& n : ssn.nodes) feasible.insert(n.idx);
+    orc::ScenarioBuilder builder(&ssn, pending, recorded, vq.get(), feasible);
+    std::vector<int32_t> rows; orc::Scenario* last = nullptr;
+    for (orc::Scenario* sc = builder.GetValidScenario(); sc; sc = builder.GetNextScenario()) {
+        rows.push_back((int32_t)sc->potentialVictimsTasks.size()); rows.push_back((int32_t)sc->recordedVictimsJobs.size()); last = sc;
+        if (rows.size() > 4096) return KAI_ERR_CAPACITY;
+    }
+    std::vector<int32_t> sizes;
+    if (last) for (auto* t : last->potentialVictimsTasks) { orc::PodGroupInfo* rep = last->GetVictimJobRepresentativeById(t); sizes.push_back(rep ? (int32_t)rep->AllPods().size() : -1); }
+    const int need = 1 + (int)rows.size() + 1 + (int)sizes.size();
+    if (need > cap) return KAI_ERR_CAPACITY;
+    int n = 0; out[n++] = (int32_t)(rows.size() / 2); for (int32_t v : rows) out[n++] = v; out[n++] = (int32_t)sizes.size(); for (int32_t v : sizes) out[n++] = v;
+    return n;
 }
 
 // sessions of kai_oracle_run apply the AccumulatedNodeAffinities filter on the static class table (oracle_solver.hpp) from now on (1) / no longer (0); returns the
@@ -1736,17 +1763,8 @@ int kai_oracle_reclaimable(int mode, int Q, const int32_t* parent, const double*
 int kai_oracle_best_node(const kai_config* cfg, const kai_snapshot_soa* snap, int pod, const uint32_t* nodeset_bitmap, int pipeline_only, int* node_out, int* is_pipeline_out) {
     if (!cfg || !snap || pod < 0 || pod >= snap->n_pods) return KAI_ERR_INVALID_ARG;
     orc::Session ssn; ssn.load(cfg, snap);
-    const int Q = snap->n_queues; ssn.qattrs.resize(Q);
-    for (int q = 0; q < Q; q++) {
-        orc::QueueAttributes& a = ssn.qattrs[q]; a.idx = q; a.uidRank = ssn.queues[q].uidRank; a.parent = ssn.queues[q].parent; a.children = ssn.queues[q].children;
-        a.createdNs = ssn.queues[q].createdNs; a.priority = ssn.queues[q].priority;
-        for (int r = 0; r < 3; r++) {
-            double deserved = snap->queue_deserved[r * Q + q], limit = snap->queue_limit[r * Q + q];
-            if (r == KAI_Q_MEM) { deserved = std::fmax(KAI_UNLIMITED, deserved * 1000000.0); limit = std::fmax(KAI_UNLIMITED, limit * 1000000.0); }
-            a.share[r].Deserved = deserved; a.share[r].MaxAllowed = limit; a.share[r].OverQuotaWeight = snap->queue_oqw[r * Q + q]; a.share[r].Usage = snap->queue_usage ? snap->queue_usage[r * Q + q] : 0.0;
-        }
-    }
-    ssn.proportionOnSessionOpen();
+    const int Q = snap->n_queues; (void)Q;
+    open_queues(ssn, snap);
     std::vector<orc::NodeInfo*> nodeSet;
     for (auto& n : ssn.nodes) if (!nodeset_bitmap || ((nodeset_bitmap[n.idx >> 5] >> (n.idx & 31)) & 1u)) nodeSet.push_back(&n);
     orc::PodInfo* task = &ssn.pods[pod];

@@ -426,3 +426,52 @@ def test_node_affinities_filter_was_exercised():
     if d is None:
         pytest.skip("the parametrized test did not run in this process")
     assert d > 0
+
+
+# ------------------------------------------------------------------------------------------------ PodAccumulatedScenarioBuilder (pod_scenario_builder_test.go), tools/go_kat_scenario_builder.py
+SB = _load("kat_scenario_builder.json")["specs"]
+
+
+def _scenario_builder_case(spec):
+    """initializeSession + createJobWithTasks of the test file (:287-395) as a scene: one node exactly full of the running jobs' one-GPU pods, a queue per job under
+    "default", the pending reclaimer in team-a"""
+    J, K = spec["jobs"], spec["tasks_per_job"]
+    root = lambda m: {"Name": "", "TopologyConstraint": None, "SubGroups": [], "PodSets": [{"Name": "default", "MinAvailable": m, "TopologyConstraint": None}]}
+    m = K if spec["min_available"] == "all" else spec["min_available"]
+    jobs = [{"Name": f"job{j}", "Priority": 50, "QueueName": f"team-{j}", "RequiredCPUsPerTask": 0, "RootSubGroupSet": root(m),
+             "Tasks": [{"State": "Running", "NodeName": "node-1", "RequiredGPUs": 1} for _ in range(K)]} for j in range(J)]
+    jobs.append({"Name": "reclaimer", "Priority": 50, "QueueName": "team-a", "RequiredCPUsPerTask": 0, "RootSubGroupSet": root(1),
+                 "Tasks": [{"State": "Pending", **({"RequiredGPUs": spec["reclaimer_gpus_per_task"]} if spec["reclaimer_gpus_per_task"] else {})} for _ in range(spec["reclaimer_tasks"])]})
+    queues = [{"Name": f"team-{j}", "DeservedGPUs": 1} for j in range(J)] + [{"Name": "team-a", "DeservedGPUs": 1}]
+    return {"Name": spec["name"], "Nodes": {"node-1": {"CPUMillis": 1000, "GPUs": J * K, "MaxTaskNum": 100}}, "Queues": queues, "Jobs": jobs, "JobExpectedResults": {}}
+
+
+@pytest.mark.parametrize("spec", SB, ids=[f"{s['line']}" for s in SB])
+def test_scenario_builder(spec):
+    """actions/common/solvers/pod_scenario_builder.go against the nine specs of its Ginkgo suite: the scenarios GetValidScenario / GetNextScenario produce — how many,
+    the potential victims of each (an elastic job gives up one pod at a time down to its minAvailable, then the rest; recorded victims are stepped over and the rest of
+    their job is queued again), the recorded victim jobs of each, the job representatives of the last scenario's victims — with the AccumulatedIdleGpus filter
+    deciding whether the scenario without victims counts."""
+    snap, cfg, _ = T.case_to_snapshot(_scenario_builder_case(spec))
+    a = snap.arrays
+    pods_of = lambda j: [int(p) for p in np.nonzero(a["pod_job"] == snap.job_names.index(j))[0]]
+    rec_job, rec_off, rec_pods = [], [0], []
+    r = spec["recorded"]
+    if r and "whole_jobs" in r:
+        for j in range(r["whole_jobs"]):  # "indexes" of a Go map range: any two of the three alike jobs
+            rec_job.append(snap.job_names.index(f"job{(0, 2)[j]}")); rec_off.append(len(rec_pods))
+    elif r:
+        rec_job.append(snap.job_names.index("job0")); rec_pods.append(pods_of("job0")[r["pod_of_first_job"]]); rec_off.append(len(rec_pods))
+    i32 = lambda v: (C.c_int32 * max(len(v), 1))(*v)
+    lib = T.Oracle.lib(); lib.kai_oracle_scenario_builder_kat.restype = C.c_int
+    out = (C.c_int32 * 256)(); s = snap.as_struct()
+    n = lib.kai_oracle_scenario_builder_kat(C.byref(cfg), C.byref(s), snap.job_names.index("reclaimer"), len(rec_job), i32(rec_job), i32(rec_off), i32(rec_pods), out, 256)
+    assert n > 0, n
+    S = out[0]; rows = [(out[1 + 2 * i], out[2 + 2 * i]) for i in range(S)]; K = out[1 + 2 * S]; sizes = list(out[2 + 2 * S:2 + 2 * S + K])
+    w = spec["want"]
+    if "first_scenario" in w: assert (S > 0) == w["first_scenario"], rows
+    if w.get("next_of_empty_queue_is_nil"): assert S <= 1, rows
+    if "scenarios" in w: assert S == w["scenarios"], rows
+    if "potential_per_scenario" in w: assert [p for p, _ in rows] == w["potential_per_scenario"], rows
+    if w.get("recorded_jobs_in_every_scenario"): assert all(rj == len(rec_job) for _, rj in rows), rows
+    if "last_potential" in w: assert S > 0 and rows[-1][0] == w["last_potential"] == K and sizes == [w["last_representative_size"]] * K, (rows, sizes)
