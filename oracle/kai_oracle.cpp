@@ -1510,6 +1510,49 @@ int kai_oracle_scenario_builder_kat(const kai_config* cfg, const kai_snapshot_so
     return n;
 }
 
+// The scenario object of the victim search on a freshly loaded session (scenario/base_scenario_test.go, by_node_scenario_test.go): NewByNodeScenario(session,
+// pending, pending, the potential victims ctor_pods — added one task at a time, base_scenario.go:49-51 —, the recorded victim jobs rec_job[i], as CloneWithTasks of
+// rec_pods[rec_off[i] ..) where that range is not empty), then ONE AddPotentialVictimsTasks(add_pods) when n_add > 0, then the question:
+//   mode 0: the state — out = [P, potential victim pods x P, G, (job, task groups under its id) x G];
+//   mode 1: GetVictimJobRepresentativeById(pod arg[0]) — out = [-1] (nil) or [T, the representative's pods x T];
+//   mode 2: LatestPotentialVictim() — out = [job index, or -1 for nil];
+//   mode 3: VictimsTasksFromNodes(nodes arg[0 .. n_arg)) — out = [T, pods x T].
+// Returns the length written.
+int kai_oracle_scenario_kat(const kai_config* cfg, const kai_snapshot_soa* snap, int pending_job, const int32_t* ctor_pods, int n_ctor, int n_rec, const int32_t* rec_job,
+                            const int32_t* rec_off, const int32_t* rec_pods, const int32_t* add_pods, int n_add, int mode, const int32_t* arg, int n_arg, int32_t* out, int cap) {
+    if (!cfg || !snap || !out || snap->abi_version != KAI_ABI_VERSION || pending_job < 0 || pending_job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    std::vector<orc::PodGroupInfo*> recorded;
+    for (int i = 0; i < n_rec; i++) {
+        orc::PodGroupInfo* j = &ssn.jobs[rec_job[i]];
+        if (rec_off[i + 1] > rec_off[i]) { std::vector<orc::PodInfo*> part; for (int k = rec_off[i]; k < rec_off[i + 1]; k++) part.push_back(&ssn.pods[rec_pods[k]]); j = ssn.CloneWithTasks(j, part); }
+        recorded.push_back(j);
+    }
+    // (the reference's constructor adds the potential victims before the recorded jobs; the two touch different fields except victimsJobsTaskGroups, whose per-job lists
+    // the tests only count — the order of the two loops is kept anyway by building the scenario without recorded jobs first when there are constructor victims)
+    orc::Scenario sc(&ssn, &ssn.jobs[pending_job], n_ctor ? std::vector<orc::PodGroupInfo*>{} : recorded);
+    for (int i = 0; i < n_ctor; i++) sc.AddPotentialVictimsTasks({&ssn.pods[ctor_pods[i]]});
+    if (n_ctor) for (auto* rj : recorded) { sc.recordedVictimsJobs.push_back(rj); sc.appendTasksAsVictimJob(rj->AllPods()); for (auto* t : rj->AllPods()) sc.recordedVictimsTasks.push_back(t); }
+    if (n_add > 0) { std::vector<orc::PodInfo*> add; for (int i = 0; i < n_add; i++) add.push_back(&ssn.pods[add_pods[i]]); sc.AddPotentialVictimsTasks(add); }
+    std::vector<int32_t> r;
+    if (mode == 0) {
+        r.push_back((int32_t)sc.potentialVictimsTasks.size()); for (auto* t : sc.potentialVictimsTasks) r.push_back(t->idx);
+        int g = 0; for (auto& kv : sc.victimsJobsTaskGroups) if (!kv.second.empty()) g++;
+        r.push_back(g); for (auto& kv : sc.victimsJobsTaskGroups) if (!kv.second.empty()) { r.push_back(kv.first); r.push_back((int32_t)kv.second.size()); }
+    } else if (mode == 1) {
+        orc::PodGroupInfo* rep = sc.GetVictimJobRepresentativeById(&ssn.pods[arg[0]]);
+        if (!rep) r.push_back(-1); else { auto pods = rep->AllPods(); r.push_back((int32_t)pods.size()); for (auto* t : pods) r.push_back(t->idx); }
+    } else if (mode == 2) {
+        orc::PodGroupInfo* j = sc.LatestPotentialVictim(); r.push_back(j ? j->idx : -1);
+    } else {
+        std::vector<orc::PodInfo*> tasks = sc.VictimsTasksFromNodes(std::vector<int>(arg, arg + n_arg));
+        r.push_back((int32_t)tasks.size()); for (auto* t : tasks) r.push_back(t->idx);
+    }
+    if ((int)r.size() > cap) return KAI_ERR_CAPACITY;
+    for (size_t i = 0; i < r.size(); i++) out[i] = r[i];
+    return (int)r.size();
+}
+
 // sessions of kai_oracle_run apply the AccumulatedNodeAffinities filter on the static class table (oracle_solver.hpp) from now on (1) / no longer (0); returns the
 // scenarios the filter dropped since the previous call
 int64_t kai_oracle_node_affinities_filter(int on) { const int64_t d = orc::g_node_affinities_dropped; orc::g_node_affinities_dropped = 0; orc::g_node_affinities_filter = on ? 1 : 0; return d; }

@@ -90,12 +90,16 @@ struct Scenario {
         appendTasksAsVictimJob(tasks);
         for (auto* t : tasks) { auto& l = potentialVictimsJobsByNode[t->node]; if (std::find(l.begin(), l.end(), t->job) == l.end()) l.push_back(t->job); }
     }
-    std::vector<PodInfo*> VictimsTasksFromNodes(int node) {  // by_node_scenario.go:55-80
-        std::vector<PodInfo*> tasks;
-        auto it = potentialVictimsJobsByNode.find(node); if (it == potentialVictimsJobsByNode.end()) return tasks;
-        for (int jobID : it->second) for (auto* group : victimsJobsTaskGroups[jobID]) for (auto* t : group->AllPods()) tasks.push_back(t);
+    std::vector<PodInfo*> VictimsTasksFromNodes(const std::vector<int>& nodes) {  // by_node_scenario.go:58-80 (the reference collects the jobs in a Go map: any order; here first seen)
+        std::vector<PodInfo*> tasks; std::vector<int> victimsJobs;
+        for (int node : nodes) {
+            auto it = potentialVictimsJobsByNode.find(node); if (it == potentialVictimsJobsByNode.end()) continue;
+            for (int jobID : it->second) if (std::find(victimsJobs.begin(), victimsJobs.end(), jobID) == victimsJobs.end()) victimsJobs.push_back(jobID);
+        }
+        for (int jobID : victimsJobs) for (auto* group : victimsJobsTaskGroups[jobID]) for (auto* t : group->AllPods()) tasks.push_back(t);
         return tasks;
     }
+    std::vector<PodInfo*> VictimsTasksFromNodes(int node) { return VictimsTasksFromNodes(std::vector<int>{node}); }  // by_pod_solver.go:169 asks about one node
     PodGroupInfo* GetVictimJobRepresentativeById(PodInfo* victim) {  // base_scenario.go:139-149
         for (auto* rep : victimsJobsTaskGroups[victim->job]) for (auto* t : rep->AllPods()) if (t->idx == victim->idx) return rep;
         return nullptr;

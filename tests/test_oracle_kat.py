@@ -475,3 +475,52 @@ def test_scenario_builder(spec):
     if "potential_per_scenario" in w: assert [p for p, _ in rows] == w["potential_per_scenario"], rows
     if w.get("recorded_jobs_in_every_scenario"): assert all(rj == len(rec_job) for _, rj in rows), rows
     if "last_potential" in w: assert S > 0 and rows[-1][0] == w["last_potential"] == K and sizes == [w["last_representative_size"]] * K, (rows, sizes)
+
+
+# ------------------------------------------------------------------------------------------------ the scenario objects (scenario/base_scenario_test.go, by_node_scenario_test.go), tools/go_kat_scenarios.py
+SCN = _load("kat_scenarios.json")["cases"]
+
+
+@pytest.mark.parametrize("case", SCN, ids=[f"{c['file'].split('_')[0]}:{c['line']}" for c in SCN])
+def test_scenario_objects(case):
+    """solvers/scenario/{base_scenario,by_node_scenario}.go against their four test tables: the potential victims and the task groups per job after the constructor and one
+    AddPotentialVictimsTasks, the job representative a victim belongs to (one per call that added it: an elastic job's tasks sit in representatives of their own),
+    the job of the latest potential victim, the victims a node's jobs bring along (all task groups of a job that has ANY potential victim there)."""
+    by_job = {}
+    for p in case["pods"]: by_job.setdefault(p["job"], []).append(p)
+    jobs = [{"Name": j, "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 0, "RootSubGroupSet": {"Name": "", "TopologyConstraint": None, "SubGroups": [],
+             "PodSets": [{"Name": "default", "MinAvailable": 1, "TopologyConstraint": None}]},
+             "Tasks": [({"State": "Running", "NodeName": p["node"]} if p["node"] else {"State": "Pending"}) for p in ps]} for j, ps in sorted(by_job.items())]
+    jobs.append({"Name": "123", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 0, "Tasks": [{"State": "Pending"}]})  # pendingTasksAsJob (the tests' one has no task; nothing asks about it)
+    scene = {"Name": case["name"], "Nodes": {n: {"CPUMillis": 1000, "GPUs": 8, "MaxTaskNum": 100} for n in ("node1", "node2")}, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+             "Jobs": jobs, "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(scene)
+    pod = {}
+    for j, ps in by_job.items():
+        for i, p in enumerate(ps): pod[(j, p["name"])] = snap.pod_names.index(f"{j}-{i}")
+    name_of = {v: list(k) for k, v in pod.items()}
+    P = lambda ids: [pod[tuple(x)] for x in ids]
+    rec_job, rec_off, rec_pods = [], [0], []
+    for rj in case["recorded_jobs"]:
+        rec_job.append(snap.job_names.index(rj["name"])); rec_pods += P(rj["tasks"]); rec_off.append(len(rec_pods))
+    mode = {"AddPotentialVictimsTasks": 0, "GetVictimJobRepresentativeById": 1, "LatestPotentialVictim": 2, "VictimsTasksFromNodes": 3}[case["func"].split("_")[-1]]
+    arg = P([case["victim"]]) if mode == 1 else [snap.node_names.index(n) for n in case["node_names"]] if mode == 3 else []
+    i32 = lambda v: (C.c_int32 * max(len(v), 1))(*v)
+    lib = T.Oracle.lib(); lib.kai_oracle_scenario_kat.restype = C.c_int
+    out = (C.c_int32 * 128)(); s = snap.as_struct()
+    n = lib.kai_oracle_scenario_kat(C.byref(cfg), C.byref(s), snap.job_names.index("123"), i32(P(case["ctor_potential"])), len(case["ctor_potential"]), len(rec_job), i32(rec_job), i32(rec_off),
+                                    i32(rec_pods), i32(P(case["added"])), len(case["added"]), mode, i32(arg), len(arg), out, 128)
+    assert n > 0, n
+    r = list(out[:n]); w = case["want"]
+    if mode == 0:
+        np_ = r[0]; assert [name_of[x] for x in r[1:1 + np_]] == w["potential"]
+        g = r[1 + np_]; groups = {snap.job_names[r[2 + np_ + 2 * i]]: r[3 + np_ + 2 * i] for i in range(g)}
+        assert groups == w["groups_per_job"], groups
+    elif mode == 1:
+        if w is None: assert r == [-1], r
+        else: assert r[0] == len(w["tasks"]) and sorted(name_of[x] for x in r[1:]) == sorted(w["tasks"]), r
+    elif mode == 2:
+        assert (None if r[0] < 0 else snap.job_names[r[0]]) == (w and w["job"]), r
+        if w: assert sorted([j, p["name"]] for j, ps in by_job.items() if j == w["job"] for p in ps) == sorted(w["tasks"])  # the session's whole job (getJobForTask), as the table spells it out
+    else:
+        assert sorted(name_of[x] for x in r[1:1 + r[0]]) == sorted(w), r  # (map order in the reference: compared as sets; the tables' cases have one job each)
