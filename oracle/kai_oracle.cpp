@@ -878,7 +878,10 @@ void JobsOrderByQueues::InitializeWithJobs(const std::vector<PodGroupInfo*>& job
 // actions/common/allocate.go
 // =====================================================================================================
 // ---- shared GPUs
-double Session::GpuOrderFn(PodInfo*, NodeInfo* node, int gpu) {  // session_plugins.go:405-416 over plugins/gpupack/gpupack.go:31-45 and plugins/gpuspread/gpuspread.go:31-46
+double Session::GpuOrderFn(PodInfo*, NodeInfo* node, int gpu, bool* err) {  // session_plugins.go:405-416 over plugins/gpupack/gpupack.go:31-45 and plugins/gpuspread/gpuspread.go:31-46
+    if (err) *err = false;
+    // GetUsedGpuPortion (gpu_sharing_node_info.go:384-390) refuses a node whose GPU memory is below DefaultGpuMemory (node_info.go:48): the plugin's error is the session's (score 0)
+    if ((cfg.plugins & (KAI_PLUGIN_GPUPACK | KAI_PLUGIN_GPUSPREAD)) && gpu != kWholeGpuIndicator && node->MemoryOfEveryGpuOnNode < 100) { if (err) *err = true; return 0.0; }
     double score = 0;
     if (cfg.plugins & KAI_PLUGIN_GPUPACK) score += gpu == kWholeGpuIndicator ? 0.0 : node->GetUsedGpuPortion(gpu);
     if (cfg.plugins & KAI_PLUGIN_GPUSPREAD) score += gpu == kWholeGpuIndicator ? 1.0 : 1 - node->GetUsedGpuPortion(gpu);
@@ -891,7 +894,7 @@ std::vector<int> Session::FittingGPUs(NodeInfo* node, PodInfo* pod) {  // sessio
     for (auto& kv : node->UsedSharedGPUsMemory) if (node->IsTaskFitOnGpuGroup(pod->resReq, kv.first)) filtered.push_back(kv.first);
     if (node->Idle.gpus > 0 || node->Releasing.gpus > 0) for (int i = 0, n = int(node->Idle.gpus) + int(node->Releasing.gpus); i < n; i++) filtered.push_back(kWholeGpuIndicator);
     std::map<double, std::vector<int>, std::greater<double>> byScore;  // sortGPUs: scores descending, each bucket in the order it was filled
-    for (int g : filtered) byScore[GpuOrderFn(pod, node, g)].push_back(g);
+    for (int g : filtered) { bool err = false; const double sc = GpuOrderFn(pod, node, g, &err); if (err) continue; byScore[sc].push_back(g); }  // session.go:185-199: a GPU whose score fails is left out
     std::vector<int> sorted; for (auto& kv : byScore) for (int g : kv.second) sorted.push_back(g);
     return sorted;
 }
@@ -1551,6 +1554,32 @@ int kai_oracle_scenario_kat(const kai_config* cfg, const kai_snapshot_soa* snap,
     if ((int)r.size() > cap) return KAI_ERR_CAPACITY;
     for (size_t i = 0; i < r.size(); i++) out[i] = r[i];
     return (int)r.size();
+}
+
+// The GPU-order plugins on one device group (plugins/gpupack/gpupack_test.go, plugins/gpuspread/gpuspread_test.go): a node whose GPUs have total_mem MiB and whose group 0
+// has used_mem MiB in use; the score of that group, or of a whole free GPU (whole != 0), under the plugin bits of `plugins`.  *err = the reference's "invalid GPU memory".
+double kai_oracle_gpu_order_kat(uint32_t plugins, int64_t total_mem, int64_t used_mem, int whole, int* err) {
+    orc::Session ssn; ssn.cfg.plugins = plugins;
+    orc::NodeInfo n; n.MemoryOfEveryGpuOnNode = total_mem; n.UsedSharedGPUsMemory[0] = used_mem;
+    bool e = false; const double s = ssn.GpuOrderFn(nullptr, &n, whole ? orc::kWholeGpuIndicator : 0, &e);
+    if (err) *err = e ? 1 : 0;
+    return s;
+}
+
+// gpu_sharing.GetNodePreferableGpuForSharing on a freshly loaded session (gpuSharing_test.go): pod `pod` (asking for `device_count` devices where > 0: the
+// gpu-fraction-num-devices annotation, which the snapshot format does not carry) on node `node`, given the fitting GPUs (group ids, -1 = a whole GPU).  Returns 0 for
+// nil, else the number of groups; groups_out = the ids (>= 2^20: a group created by the call), *releasing = IsReleasing.
+int kai_oracle_gpu_sharing_kat(const kai_config* cfg, const kai_snapshot_soa* snap, int pod, int node, int device_count, const int32_t* fitting, int n_fitting, int pipeline_only,
+                               int32_t* groups_out, int cap, int* releasing) {
+    if (!cfg || !snap || snap->abi_version != KAI_ABI_VERSION || pod < 0 || pod >= snap->n_pods || node < 0 || node >= snap->n_nodes) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.load(cfg, snap);
+    if (device_count > 0) ssn.pods[pod].resReq.count = device_count;
+    orc::Session::NodeGpuForSharing r = ssn.GetNodePreferableGpuForSharing(std::vector<int>(fitting, fitting + n_fitting), &ssn.nodes[node], &ssn.pods[pod], pipeline_only != 0);
+    if (!r.ok) return 0;
+    if ((int)r.Groups.size() > cap) return KAI_ERR_CAPACITY;
+    for (size_t i = 0; i < r.Groups.size(); i++) groups_out[i] = r.Groups[i];
+    if (releasing) *releasing = r.IsReleasing ? 1 : 0;
+    return (int)r.Groups.size();
 }
 
 // sessions of kai_oracle_run apply the AccumulatedNodeAffinities filter on the static class table (oracle_solver.hpp) from now on (1) / no longer (0); returns the

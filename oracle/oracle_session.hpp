@@ -128,7 +128,7 @@ struct Session {
     struct NodeGpuForSharing { std::vector<int> Groups; bool IsReleasing = false; bool ok = false; };
     int nextNewGpuGroup = kNewGpuGroup;  // uuid.NewUUID() of findGpuForSharingOnNode
     bool hasFractions = false;
-    double GpuOrderFn(PodInfo* task, NodeInfo* node, int gpu);
+    double GpuOrderFn(PodInfo* task, NodeInfo* node, int gpu, bool* err = nullptr);
     std::vector<int> FittingGPUs(NodeInfo* node, PodInfo* pod);
     NodeGpuForSharing GetNodePreferableGpuForSharing(const std::vector<int>& fittingGPUs, NodeInfo* node, PodInfo* pod, bool isPipelineOnly);
     bool AllocateFractionalGPUTaskToNode(Statement& stmt, PodInfo* pod, NodeInfo* node, bool isPipelineOnly);

@@ -64,3 +64,38 @@ def test_engine_twin_takes_fractions():
     for acts in (("allocate",), ("allocate", "reclaim"), ("allocate", "consolidation", "reclaim", "preempt")):
         ref, res = T.Oracle.run(snap, cfg, acts), H.HostSim.run(snap, cfg, acts)
         assert res.ops == ref.ops and np.array_equal(res.pod_status, ref.pod_status) and np.array_equal(res.pod_node, ref.pod_node)
+
+
+# ------------------------------------------------------------------------------------------------ gpupack / gpuspread / GetNodePreferableGpuForSharing (tools/go_kat_gpu_sharing.py)
+import ctypes as C, json, os  # noqa: E402
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_gpu_sharing.json")) as _fh:
+    GS = json.load(_fh)
+
+
+@pytest.mark.parametrize("case", GS["gpu_order"], ids=[f"{c['plugin']}:{c['line']}" for c in GS["gpu_order"]])
+def test_gpu_order_plugins(case):
+    """plugins/gpupack/gpupack.go:31-45 and plugins/gpuspread/gpuspread.go:31-46 against their six cases each: the score of a device group (or of a whole free GPU)
+    from the memory in use on it; a node whose GPU memory is below DefaultGpuMemory is an error, score 0"""
+    lib = T.Oracle.lib(); lib.kai_oracle_gpu_order_kat.restype = C.c_double
+    lib.kai_oracle_gpu_order_kat.argtypes = [C.c_uint32, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int)]
+    err = C.c_int(0)
+    score = lib.kai_oracle_gpu_order_kat(abi.PLUGINS[case["plugin"]], case["total_mem"], case["used_mem"], int(case["whole_gpu"]), C.byref(err))
+    assert bool(err.value) == case["want_error"] and score == case["want_score"], (score, err.value)
+
+
+@pytest.mark.parametrize("case", GS["preferable_gpu_for_sharing"], ids=[f"{c['line']}" for c in GS["preferable_gpu_for_sharing"]])
+def test_node_preferable_gpu_for_sharing(case):
+    """gpu_sharing/gpuSharing.go:39-83 against Test_getNodePreferableGpuForSharing: how many groups the pod takes out of the fitting GPUs, which numbered groups are among
+    them, whether the placement waits for something releasing (a numbered group the node holds no allocation for counts as pipelined; the last case asks for two devices)"""
+    al = case["node_allocatable"]; pod = case["pod"]
+    g = float(pod["gpu_fraction"]) if pod["gpu_fraction"] else float(pod["gpu_request"])
+    scene = {"Name": case["name"], "Nodes": {"n1": {"CPUMillis": int(al["cpu"]) * 1000, "GPUs": int(al["nvidia.com/gpu"]), "MaxTaskNum": int(al["pods"])}}, "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+             "Jobs": [{"Name": "pg1", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": g, "Tasks": [{"State": "Pending"}]}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(scene, fractions=True)
+    fitting = [-1 if x == "whole" else int(x) for x in case["fitting"]]
+    lib = T.Oracle.lib(); lib.kai_oracle_gpu_sharing_kat.restype = C.c_int
+    out = (C.c_int32 * 8)(); rel = C.c_int(0); s = snap.as_struct()
+    n = lib.kai_oracle_gpu_sharing_kat(C.byref(cfg), C.byref(s), 0, 0, int(pod["num_devices"] or 0), (C.c_int32 * len(fitting))(*fitting), len(fitting), int(case["pipeline_only"]), out, 8, C.byref(rel))
+    w = case["want"]
+    assert n == w["groups"] and bool(rel.value) == w["releasing"], (n, rel.value)
+    assert all(int(x) in list(out[:n]) for x in w["includes"]), list(out[:n])
