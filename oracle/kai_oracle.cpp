@@ -1399,6 +1399,25 @@ int kai_oracle_capacity_check(int which, const double* limit, const double* allo
     return (which == 0 ? ssn.resultsOverLimit(req, &job) : ssn.resultsWithNonPreemptibleOverQuota(req, &job)) ? 1 : 0;
 }
 
+// capacity_policy over a CHAIN of hand-set queues (capacity_policy_test.go): parent[q] = the parent's index or -1; max_allowed / deserved / allocated /
+// allocated_np[q * 3 + r] in the order cpu, memory, gpu (a field the Go literal leaves out is 0).  A job of queue job_queue asks for `requested`; mode 0 =
+// IsJobOverQueueCapacity and 2 = IsTaskAllocationOnNodeOverCapacity (both checks, capacity_policy.go:26-36, 51-61), 1 = IsNonPreemptibleJobOverQuota (:38-49)
+// → IsSchedulable 1 / 0
+int kai_oracle_capacity_chain(int mode, int n_queues, const int32_t* parent, const double* max_allowed, const double* deserved, const double* allocated, const double* allocated_np,
+                              int job_queue, int preemptible, const double* requested) {
+    if (n_queues < 1 || !parent || !max_allowed || !deserved || !allocated || !allocated_np || !requested || job_queue < 0 || job_queue >= n_queues) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.qattrs.resize((size_t)n_queues);
+    for (int q = 0; q < n_queues; q++) {
+        ssn.qattrs[q].idx = q; ssn.qattrs[q].parent = parent[q];
+        for (int r = 0; r < 3; r++) { orc::ResourceShare& sh = ssn.qattrs[q].share[r]; sh.MaxAllowed = max_allowed[q * 3 + r]; sh.Deserved = deserved[q * 3 + r];
+                                      sh.Allocated = allocated[q * 3 + r]; sh.AllocatedNotPreemptible = allocated_np[q * 3 + r]; }
+    }
+    orc::PodGroupInfo job; job.queue = job_queue; job.preemptible = preemptible != 0;
+    const orc::ResourceQuantities req{requested[0], requested[1], requested[2]};
+    const bool over = mode == 1 ? ssn.resultsWithNonPreemptibleOverQuota(req, &job) : (ssn.resultsOverLimit(req, &job) || ssn.resultsWithNonPreemptibleOverQuota(req, &job));
+    return over ? 0 : 1;
+}
+
 // idle_gpus.greedyMatchRequirements (idle_gpus_test.go:106-199): holders by index in the given order, capacity[i] of holder i → 1 / 0
 int kai_oracle_greedy_match(const double* requirements, int n_req, const int32_t* holders, int n_holders, const double* capacity) {
     std::vector<double> req(requirements, requirements + n_req); std::vector<int> h(holders, holders + n_holders);

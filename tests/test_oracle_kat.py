@@ -231,6 +231,26 @@ def test_capacity_policy_known_answers(case):
     assert got in (0, 1) and bool(got) == case["want"], f"{case['name']} ({case['file']}:{case['line']})"
 
 
+CAP_CHAIN = _load("kat_capacity_chain.json")["cases"]
+
+
+@pytest.mark.parametrize("case", CAP_CHAIN, ids=[f"{c['fn']}:{c['line']}" for c in CAP_CHAIN])
+def test_capacity_policy_over_a_queue_chain(case):
+    """plugins/proportion/capacity_policy/capacity_policy.go against the fourteen cases of capacity_policy_test.go: the limit check and the non-preemptible quota check
+    walked from the job's leaf queue up to the top (a violation at ANY level, the top one in the cases, makes the job unschedulable; a preemptible job skips the quota
+    check) — tools/go_kat_capacity_chain.py"""
+    names = sorted(case["queues"]); idx = {n: i for i, n in enumerate(names)}
+    parent = [idx.get(case["queues"][n]["parent"], -1) for n in names]
+    col = lambda f: np.array([[case["queues"][n]["shares"].get(r, {}).get(f, 0.0) for r in ("CPU", "Memory", "GPU")] for n in names], np.float64)
+    d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ma, de, al, anp = col("MaxAllowed"), col("Deserved"), col("Allocated"), col("AllocatedNotPreemptible")
+    rq = np.array(case["requested"], np.float64)
+    mode = {"IsJobOverQueueCapacity": 0, "IsNonPreemptibleJobOverQuota": 1, "IsTaskAllocationOnNodeOverCapacity": 2}[case["fn"]]
+    lib = T.Oracle.lib(); lib.kai_oracle_capacity_chain.restype = C.c_int
+    got = lib.kai_oracle_capacity_chain(mode, len(names), (C.c_int32 * len(names))(*parent), d(ma), d(de), d(al), d(anp), idx[case["job_queue"]], int(case["preemptible"]), d(rq))
+    assert got == int(case["want_schedulable"]), (case["name"], got)
+
+
 GREEDY = [  # idle_gpus_test.go:117-189: (requirements, holders in order, capacity by holder, want)
     ([], ["n1"], {"n1": 1.0}, True), ([0, 0], [], {}, True), ([0.5], ["n1"], {"n1": 1.0}, True), ([0.5], ["n1"], {"n1": 0.0}, False),
     ([1.0, 0.5], ["n1"], {"n1": 1.0}, False), ([1.0, 0.5], ["n1"], {"n1": 1.5}, True), ([1.0, 1.0], ["n2", "n1"], {"n1": 1.0, "n2": 2.0}, True), ([2.0], ["n1"], {"n1": 1.0}, False),
