@@ -142,6 +142,25 @@ def test_resource_share_known_answers():
     out = _resource_share([r, r, r]); assert out[0] == 17.0 and out[3] == 22.0
 
 
+QA = _load("kat_queue_attributes.json")
+
+
+def test_queue_attributes_known_answers():
+    """plugins/proportion/resource_share/queue_attributes_test.go (tools/go_kat_queue_attributes.py): GetRequestableShare per resource (12 cases), GetDominantResourceShare over
+    a total capacity — what prioritizeSmallerResourceShare compares; a resource that is allocated but neither deserved nor a fair share counts 1000-fold, an unlimited
+    deserved amount is measured against the cluster's total — (6, exact), GetAllocatableShare (5)"""
+    row = lambda deserved=0, fair=0, max_allowed=0, allocated=0, request=0: [deserved, fair, max_allowed, 0, allocated, 0, request]
+    for c in QA["requestable_share"]:
+        rs = [row(), row(), row()]; rs[c["resource"]] = row(max_allowed=c["max_allowed"], request=c["request"])
+        assert _resource_share(rs)[c["resource"]] == c["want"], c
+    for c in QA["dominant_share"]:
+        rs = [row(deserved=c["deserved"][r], fair=c["fair_share"][r], max_allowed=-1.0, allocated=c["allocated"][r]) for r in range(3)]
+        assert _resource_share(rs, c["total"])[6] == c["want"], c
+    for c in QA["allocatable_share"]:
+        rs = [row(deserved=c["deserved"][r], fair=c["fair_share"][r], max_allowed=c["max_allowed"][r]) for r in range(3)]
+        assert list(_resource_share(rs)[3:6]) == c["want"], c
+
+
 # ------------------------------------------------------------------------------------------------ plugins/elastic, subgrouporder, taskorder
 def _order_fn(which, l, r):
     lib = T.Oracle.lib(); lib.kai_oracle_order_fn.restype = C.c_int
