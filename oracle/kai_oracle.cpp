@@ -1601,6 +1601,28 @@ int kai_oracle_gpu_sharing_kat(const kai_config* cfg, const kai_snapshot_soa* sn
     return (int)r.Groups.size();
 }
 
+// plugins/minruntime on a bare queue tree and ONE victim job of one pod-set (minruntime_test.go): the victim — min_available of its `pods` running pods — started
+// started_ago_ns before now (< 0: it has no start time); mode 0 = preemptFilterFn(pending, victim), 1 = reclaimFilterFn, 2 / 3 = preemptScenarioValidatorFn /
+// reclaimScenarioValidatorFn on a scenario that takes n_victim_tasks of its pods.  resolve_method 1 = queue, 0 = LCA.  → 1 / 0
+int kai_oracle_minruntime_kat(int mode, int n_queues, const int32_t* parent, const int64_t* preempt_ns, const int64_t* reclaim_ns, int64_t default_preempt_ns, int64_t default_reclaim_ns,
+                              int resolve_method, int pending_queue, int victim_queue, int64_t started_ago_ns, int min_available, int pods, int n_victim_tasks) {
+    if (n_queues < 1 || pods < 0 || n_victim_tasks > pods) return KAI_ERR_INVALID_ARG;
+    orc::Session ssn; ssn.queues.resize((size_t)n_queues);
+    for (int q = 0; q < n_queues; q++) { ssn.queues[q].idx = q; ssn.queues[q].parent = parent[q]; ssn.queues[q].preemptMinRuntimeNs = preempt_ns[q]; ssn.queues[q].reclaimMinRuntimeNs = reclaim_ns[q]; }
+    ssn.cfg.plugins = KAI_PLUGIN_MINRUNTIME; ssn.cfg.default_preempt_min_runtime_ns = default_preempt_ns; ssn.cfg.default_reclaim_min_runtime_ns = default_reclaim_ns;
+    ssn.cfg.reclaim_resolve_method = resolve_method; ssn.cfg.now_ns = int64_t(1) << 50;
+    orc::PodGroupInfo pending, victim; pending.idx = 0; pending.queue = pending_queue; victim.idx = 1; victim.queue = victim_queue;
+    victim.lastStartNs = started_ago_ns < 0 ? 0 : ssn.cfg.now_ns - started_ago_ns;
+    orc::PodSet ps; ps.idx = 0; ps.job = 1; ps.minAvailable = min_available; ps.numActiveUsedTasks = pods; ps.numActiveAllocatedTasks = pods; ps.numAliveTasks = pods;
+    std::vector<orc::PodInfo> tasks((size_t)pods);
+    for (int i = 0; i < pods; i++) { tasks[(size_t)i].idx = i; tasks[(size_t)i].job = 1; tasks[(size_t)i].podset = 0; tasks[(size_t)i].status = orc::Running; ps.podInfos[i] = &tasks[(size_t)i]; ps.podStatusMap[i] = orc::Running; }
+    victim.podSets.push_back(&ps);
+    if (mode < 2) return ssn.minruntimeVictimFilter(&pending, &victim, mode == 1) ? 1 : 0;
+    orc::Scenario sc; sc.ssn = &ssn; sc.preemptor = &pending;
+    orc::VictimInfo& v = sc.victims[1]; v.Job = &victim; for (int i = 0; i < n_victim_tasks; i++) v.Tasks.push_back(&tasks[(size_t)i]);
+    return ssn.minruntimeValidator(&sc, mode == 3) ? 1 : 0;
+}
+
 // sessions of kai_oracle_run apply the AccumulatedNodeAffinities filter on the static class table (oracle_solver.hpp) from now on (1) / no longer (0); returns the
 // scenarios the filter dropped since the previous call
 int64_t kai_oracle_node_affinities_filter(int on) { const int64_t d = orc::g_node_affinities_dropped; orc::g_node_affinities_dropped = 0; orc::g_node_affinities_filter = on ? 1 : 0; return d; }

@@ -152,6 +152,7 @@ struct Session {
     int64_t reclaimMinRuntime(int preemptorQueue, int preempteeQueue) const;
     bool isProtected(const PodGroupInfo* victim, int64_t minRuntime) const { return victim->lastStartNs != 0 && cfg.now_ns < victim->lastStartNs + minRuntime; }
     bool minruntimeValidator(Scenario* sc, bool reclaim);
+    bool minruntimeVictimFilter(const PodGroupInfo* pending, const PodGroupInfo* victim, bool reclaim) const;  // reclaimFilterFn / preemptFilterFn: true = the victim may be taken
     ~Session();
 };
 

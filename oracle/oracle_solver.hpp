@@ -699,6 +699,12 @@ inline int64_t Session::reclaimMinRuntime(int preemptorQueue, int preempteeQueue
     return cfg.default_reclaim_min_runtime_ns;
 }
 static inline bool jobIsElastic(const PodGroupInfo* j) { for (auto* ps : j->podSets) if (ps->IsElastic()) return true; return false; }  // job_info.go:408-415
+// reclaimFilterFn / preemptFilterFn (minruntime.go:95-110): a victim still inside its min-runtime is off limits — unless it is elastic: those pass here and are checked per
+// scenario by the validator below
+inline bool Session::minruntimeVictimFilter(const PodGroupInfo* pending, const PodGroupInfo* victim, bool reclaim) const {
+    if (!minruntimeOn() || jobIsElastic(victim)) return true;
+    return !isProtected(victim, reclaim ? reclaimMinRuntime(pending->queue, victim->queue) : preemptMinRuntime(victim->queue));
+}
 inline bool Session::minruntimeValidator(Scenario* sc, bool reclaim) {  // reclaimScenarioValidatorFn / preemptScenarioValidatorFn minruntime.go:112-142
     for (auto& kv : sc->victims) {
         const VictimInfo& v = kv.second;
@@ -759,7 +765,7 @@ inline void Session::executeVictimAction(int action) {
                         for (auto& other : jobs) {
                             if (other.queue == job->queue) continue;
                             // ssn.ReclaimVictimFilter → minruntime.reclaimFilterFn (minruntime.go:95-101): elastic jobs pass, they are checked per scenario
-                            if (minruntimeOn() && !jobIsElastic(&other) && isProtected(&other, reclaimMinRuntime(job->queue, other.queue))) continue;
+                            if (!minruntimeVictimFilter(job, &other, true)) continue;
                             v.push_back(&other);
                         }
                         q->InitializeWithJobs(v); return q;
@@ -781,7 +787,7 @@ inline void Session::executeVictimAction(int action) {
                         if (v->queue != job->queue) return false;
                         if (v->idx == job->idx) return false;
                         if (activeAllocatedCount(v) == 0) return false;
-                        if (minruntimeOn() && !jobIsElastic(v) && isProtected(v, preemptMinRuntime(v->queue))) return false;  // PreemptVictimFilter → minruntime.preemptFilterFn :103-110
+                        if (!minruntimeVictimFilter(job, v, false)) return false;  // PreemptVictimFilter → minruntime.preemptFilterFn :103-110
                         return true; }); }};
                 ok = solver.Solve(job, stmt);
                 break;

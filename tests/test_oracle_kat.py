@@ -97,6 +97,29 @@ def test_minruntime_resolver_known_answers():
     assert [q(3, 6, 2), q(4, 3, 2), q(5, 6, 2), q(6, 6, 2), q(3, 7, 2)] == [30, 8, 35, 35, 6]      # LCA method :148-203
 
 
+MR = _load("kat_minruntime.json")
+
+
+@pytest.mark.parametrize("spec", MR["specs"], ids=[f"{c['fn']}:{c['line']}" for c in MR["specs"]])
+def test_minruntime_filters_and_validators(spec):
+    """plugins/minruntime/minruntime.go against the eleven specs of minruntime_test.go (tools/go_kat_minruntime.py): a non-elastic victim inside its min-runtime is
+    filtered out of preemption / reclaim (resolved per queue: the victim's chain for preempt, the LCA or queue method for reclaim), a victim without a start time is
+    not; an elastic victim passes the filter and the scenario validator keeps minAvailable of its pods"""
+    import ctypes as C
+    names = sorted(MR["queues"]); idx = {n: i for i, n in enumerate(names)}
+    S = 1_000_000_000
+    ns = lambda v: -1 if v is None else v * S
+    parent = np.array([idx.get(MR["queues"][n]["parent"], -1) for n in names], np.int32)
+    pre = np.array([ns(MR["queues"][n]["preempt_s"]) for n in names], np.int64); rec = np.array([ns(MR["queues"][n]["reclaim_s"]) for n in names], np.int64)
+    lib = T.Oracle.lib(); f = lib.kai_oracle_minruntime_kat; f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]
+    mode = ("preemptFilterFn", "reclaimFilterFn", "preemptScenarioValidatorFn", "reclaimScenarioValidatorFn").index(spec["fn"])
+    got = f(mode, len(names), parent.ctypes.data_as(C.POINTER(C.c_int32)), pre.ctypes.data_as(C.POINTER(C.c_int64)), rec.ctypes.data_as(C.POINTER(C.c_int64)),
+            MR["default_preempt_s"] * S, MR["default_reclaim_s"] * S, 1 if spec["resolve_method"] == "queue" else 0, idx[spec["pending_queue"]], idx[spec["victim_queue"]],
+            ns(spec["victim_started_ago_s"]), spec["victim_min_available"], spec["victim_pods"], spec["scenario_victim_tasks"])
+    assert got == int(spec["want"]), (spec["name"], got)
+
+
 # ------------------------------------------------------------------------------------------------ plugins/proportion/reclaimable
 RECLAIMABLE = T.load_golden("kat_reclaimable")
 
