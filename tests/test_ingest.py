@@ -260,6 +260,31 @@ def test_subgroup_tree_rules():
     assert list(s.domain_level) == [0, 1, 1] and list(s.domain_parent) == [-1, 0, 0] and list(s.domain_id_rank) == [0, 1, 2]
 
 
+def test_topology_tree_of_the_reference_plugin_test():
+    """plugins/topology/topology_plugin_test.go:29-206 (TestTopologyPlugin_initializeTopologyTree): three nodes under two levels — the same rack label VALUE under two
+    blocks gives two rack domains ("test-block-1.test-rack-1" and "test-block-2.test-rack-1": a domain is a prefix of label values, topology_structs.go:94-101); block 1
+    has two children, block 2 one, racks none.  The domain table is the host's job (include/kai_core.h): checked for kai_ingest.cpp and for the scene builder of the tests."""
+    labels = [("test-block-1", "test-rack-1"), ("test-block-1", "test-rack-2"), ("test-block-2", "test-rack-1")]  # :33-90
+    lv = ("test-topology-label/block", "test-topology-label/rack")                                                 # :92-107
+    topo = {"metadata": {"name": "test-topology"}, "spec": {"levels": [{"nodeLabel": k} for k in lv]}}
+    s = ingest(doc(nodes=[node(f"test-node-{i}", labels=dict(zip(lv, l))) for i, l in enumerate(labels)], queues=[queue("q")], pods=[pod("p")], topologies=[topo])).snapshot
+    scene = {"Name": "tree", "Nodes": {f"test-node-{i}": {"CPUMillis": 1000, "GPUs": 1, "MaxTaskNum": 100, "Labels": dict(zip(lv, l))} for i, l in enumerate(labels)},
+             "Topologies": [{"ObjectMeta": {"Name": "test-topology"}, "Spec": {"Levels": [{"NodeLabel": k} for k in lv]}}], "Queues": [{"Name": "q", "DeservedGPUs": 1}],
+             "Jobs": [{"Name": "j", "Priority": 50, "QueueName": "q", "RequiredCPUsPerTask": 0, "Tasks": [{"State": "Pending"}]}], "JobExpectedResults": {}}
+    s2, _, _ = T.case_to_snapshot(scene)
+    for snap in (s, s2):
+        assert list(snap.topo_level_off) == [0, 2] and len(snap.domain_level) == 5                    # :188-191: root + two levels; 2 blocks + 3 racks
+        level, parent = list(snap.domain_level), list(snap.domain_parent)
+        blocks = [d for d in range(5) if level[d] == 0]; racks = [d for d in range(5) if level[d] == 1]
+        assert len(blocks) == 2 and len(racks) == 3 and all(parent[d] == -1 for d in blocks)
+        nd = np.asarray(snap.node_domain).reshape(2, 3); order = [list(snap.node_names).index(f"test-node-{i}") for i in range(3)]
+        b = [int(nd[0, n]) for n in order]; r = [int(nd[1, n]) for n in order]
+        assert b[0] == b[1] != b[2] and len(set(r)) == 3                                         # the two "test-rack-1" are different domains
+        children = lambda d: sum(1 for x in racks if parent[x] == d)
+        assert children(b[0]) == 2 and children(b[2]) == 1                                       # :196-203
+        assert [parent[x] for x in r] == [b[0], b[1], b[2]] and all(children(x) == 0 for x in racks)
+
+
 def test_static_predicate_classes():
     """n4: NodeAffinity (nodeSelector + required terms: In, NotIn, Exists, DoesNotExist, Gt, Lt, matchFields) and TaintToleration
     (NoSchedule / NoExecute only; Equal / Exists, empty key, effect match) — k8s.io/kubernetes v1.34.2 semantics."""
