@@ -95,7 +95,6 @@ inline void native_fill_buckets(const KaiCtx& c, RoundParams rp, const BucketPar
         const int flag = b.g_flag[gi], first = b.g_first[gi], nt = b.g_nt[gi], ucls = b.g_ucls[gi];
         const int opoff = (int)ops + rp.ops0, stmtoff = (int)committed + rp.stmt0;
         bool ok = flag != BF_GATE; int placed = 0;
-        if (std::getenv("KAI_NATIVE_FILL_STATS")) { static long n_gate = 0, n_multi = 0, n_single = 0, n_fit1 = 0, n_tasks_multi = 0, n_all = 0; n_all++; if (flag == BF_GATE) n_gate++; else if (ucls < 0) { n_multi++; n_tasks_multi += nt; } else { n_single++; int g0 = 0; for (int g = q[ucls]; g <= S.LV; g++) if (S.cnt[g - 1]) { g0 = g; break; } if (g0 && nt * q[ucls] <= g0) n_fit1++; } if (n_all % 5000 == 0) std::fprintf(stderr, "native fill jobs %ld: gated %ld, several classes %ld (%ld tasks), one class %ld (of which fit their class's best node: %ld)\n", n_all, n_gate, n_multi, n_tasks_multi, n_single, n_fit1); }
         if (flag != BF_GATE) {
             if (ucls >= 0 && plain && batched) {
                 const int qc = q[ucls];

@@ -22,7 +22,7 @@ class HostSim(T.Oracle):
             so = os.environ.get("KAI_HOSTSIM_SO") or os.path.join(T.ROOT, "tests", "host_sim", "libhostsim.so")  # override: a -DKAI_SOLVER_TRACE build
             src = os.path.join(T.ROOT, "tests", "host_sim", "host_sim.cpp")
             import glob
-            deps = [src] + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.inc")) + glob.glob(os.path.join(T.ROOT, "include", "*.h"))
+            deps = [src] + glob.glob(os.path.join(T.ROOT, "tests", "host_sim", "*.hpp")) + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(T.ROOT, "kai-scheduler_amd", "csrc", "*.inc")) + glob.glob(os.path.join(T.ROOT, "include", "*.h"))
             if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
                 subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-pthread", "-o", so, src])
             raw = C.CDLL(so)
