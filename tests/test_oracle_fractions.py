@@ -73,7 +73,7 @@ with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ka
 
 
 @pytest.mark.parametrize("case", GS["gpu_order"], ids=[f"{c['plugin']}:{c['line']}" for c in GS["gpu_order"]])
-def test_gpu_order_plugins(case):
+def test_device_group_order_plugins(case):
     """plugins/gpupack/gpupack.go:31-45 and plugins/gpuspread/gpuspread.go:31-46 against their six cases each: the score of a device group (or of a whole free GPU)
     from the memory in use on it; a node whose GPU memory is below DefaultGpuMemory is an error, score 0"""
     lib = T.Oracle.lib(); lib.kai_oracle_gpu_order_kat.restype = C.c_double
