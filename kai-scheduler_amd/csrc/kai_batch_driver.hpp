@@ -130,6 +130,7 @@ int batch_fill_sharded(L& l, KaiCtx& c, RoundParams rp, FillStatus& fs, int64_t&
 
 // Runs the allocate action on the batch path.  ran = false: the action does not qualify, nothing was touched (run the sequential engine).
 // On return with ran: out_len / counters are in bs; drain = the remaining queue is to be resolved by k_drain (no class fits anywhere).
+inline int batch_policy() { const char* e = std::getenv("KAI_BATCH_POLICY"); const int v = e ? std::atoi(e) : 4; return v >= 0 && v <= 4 ? v : 4; }
 template <class L>
 int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStats& bs, int64_t ops_base0 = 0, int64_t stmt_base0 = 0) {
     bs = BatchStats{};
@@ -206,8 +207,14 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         bs.block_loads += fs.block_loads; bs.rescans1 += fs.rescans1; bs.rescans2 += fs.rescans2; bs.rescans3 += fs.rescans3;
         if (std::getenv("KAI_BATCH_TRACE")) std::fprintf(stderr, "kai batch round %lld: H %d planned %d executed %d mismatch %d decisions %lld steps %lld committed %lld remaining %d\n", (long long)bs.rounds, H, fs.planned, fs.n_done, fs.mismatch, (long long)fs.decisions, (long long)fs.rescans2, (long long)fs.committed, remaining - fs.n_done);
         ops_base += fs.ops; stmt_base += fs.committed; remaining -= fs.n_done;
-        if (!fs.mismatch) H = std::min(H * 2, 1 << 20);                       // the plan ran out before anything surprising happened: look further ahead
-        else if ((int64_t)fs.n_done * 4 < fs.planned) H = std::max(H / 2, 8);  // most of the plan was thrown away
+        // How far the next plan looks.  A round without a surprise: back to the full depth at once (a leaf rarely holds more than 256 queued jobs, so that plan covers the whole
+        // queue; climbing back by doubling cost config 5 two rounds of ~0.6 ms each); a plan mostly thrown away: a QUARTER as far (the next surprise is usually close: the short
+        // plans in between are the cheaper the shorter they are).  Measured against the rule of rounds 1-4 (x2 up, /2 down): config 5 45.1 -> 42.9 ms, config 3 100.2 -> 99.0,
+        // config 2 2.13 -> 1.89 (`profiles/r05s_*`).  KAI_BATCH_POLICY selects the other rules of that A/B run (0: x2 up, /2 down; 1: x4 up; 2: full depth at once, /2 down;
+        // 3: x4 up, /4 down).
+        const int policy = batch_policy();
+        if (!fs.mismatch) H = std::min(policy == 0 ? H * 2 : (policy == 1 || policy == 3) ? H * 4 : std::max(H * 2, 256), 1 << 20);
+        else if ((int64_t)fs.n_done * 4 < fs.planned) H = std::max((policy == 3 || policy == 4) ? H / 4 : H / 2, 8);  // most of the plan was thrown away
     }
     return 0;
 }
