@@ -440,6 +440,46 @@ def main():
                 ssn2.close(); core2.destroy()
             except Exception as e:  # additional evidence: it must not take the headline down
                 shapes[key] = {"error": str(e)[:200]}
+        # the reference's OWN benchmark shapes (generators restated in tools/ref_benchmarks.py): `kai_session_open` + the benchmark's actions per
+        # iteration — what one b.N iteration of the Go benchmark times minus its fixture construction —, the operations' hash against the oracle's pin
+        # (profiles/reference_benchmark_pins.json, tools/pin_ref_benchmarks.py).  The victim search's hardware figures for the round; never part of `value`.
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import hashlib
+            import kai_testlib as T
+            import ref_benchmarks as RB
+            with open(os.path.join(ROOT, "profiles", "reference_benchmark_pins.json")) as f:
+                pins = json.load(f)["pins"]
+            rows, t_leg = {}, time.perf_counter()
+            for name, build, acts, published in RB.BENCHES:
+                if name not in pins or time.perf_counter() - t_leg > 40.0:  # the leg is bounded: a slow box drops the later shapes instead of the line
+                    continue
+                try:
+                    s3, c3, _m = T.case_to_snapshot(build(), acts)
+                    times, sha3, n3 = [], None, 0
+                    with pkg.KaiCore(c3, gpu_ids=(dev_index,)) as core3:
+                        for it in range(4):
+                            t0 = time.perf_counter()
+                            ssn3 = core3.open_session(s3)
+                            parts = [ssn3.execute(a) for a in acts]
+                            dt = (time.perf_counter() - t0) * 1e3
+                            if it == 0:
+                                quad = np.concatenate([np.stack([o["kind"], o["pod"], o["node"], o["job"]], 1).astype("<i4") for o in parts]) if parts else np.zeros((0, 4), "<i4")
+                                sha3, n3 = hashlib.sha256(quad.tobytes()).hexdigest(), int(quad.shape[0])
+                            ssn3.close()
+                            if it:
+                                times.append(dt)
+                            if dt > 3000 and it >= 1:
+                                break
+                    times.sort()
+                    rows[name] = {"nodes": s3.n_nodes, "pods": s3.n_pods, "actions": list(acts), "open_plus_actions_ms": times[len(times) // 2], "iterations": len(times),
+                                  "operations": n3, "ops_sha256": sha3, "equal_to_oracle": sha3 == pins[name]["ops_sha256"],
+                                  "reference_published": published, "host_compiled_engine_ms_one_core": pins[name].get("host_compiled_engine_ms")}
+                except Exception as e:
+                    rows[name] = {"error": str(e)[:200]}
+            shapes["reference_benchmarks"] = rows
+        except Exception as e:  # additional evidence: it must not take the headline down
+            shapes["reference_benchmarks"] = {"error": str(e)[:200]}
         out["other_shapes"] = shapes
     if rank == 0:
         print(json.dumps(out))
