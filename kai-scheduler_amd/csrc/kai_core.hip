@@ -69,6 +69,9 @@ struct kai_core {
     unsigned char* xpin = nullptr; size_t xpin_bytes = 0; unsigned char *xd_send = nullptr, *xd_recv = nullptr; size_t xd_bytes = 0;
     XShardHost xs;
     std::vector<MultiCtx> mw_host;  // staging of the victim actions' shared block (one per handle: handles of several ranks may run on threads of one process)
+    // kai_session_open's host preparation, kept with the handle: a scheduler opens a session per cycle, and arrays that keep their memory are not mapped and page-faulted
+    // in again every cycle (config 5: ~150 MB of host memory stays with the handle; build() rewrites every element it hands out)
+    HostPrep prep; SharedPods sp;
 };
 
 #define HIP_TRY(core, expr)                                                                                        \
@@ -491,13 +494,31 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     const auto t_freed = tnow();
     const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
     if (N < 0 || P < 0 || S < 0 || J < 0 || Q < 0) return fail(core, KAI_ERR_INVALID_ARG, "negative dimension");
-    for (int p = 0; p < P; p++) if (s->pod_flags && (s->pod_flags[p] & KAI_POD_CPU_FALLBACK) && s->pod_status[p] == KAI_POD_PENDING)
-        return fail(core, KAI_ERR_UNSUPPORTED, "a pending pod is flagged KAI_POD_CPU_FALLBACK: leave its job to the host path");
-    for (int p = 0; p < P; p++) if (s->pod_flags && (s->pod_flags[p] & KAI_POD_GPU_UNMODELLED) && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING)))
-        return fail(core, KAI_ERR_UNSUPPORTED, "an active pod holds GPU state the device does not model (gpu-memory / several fractional devices / MIG / DRA): its node's idle GPUs would be overstated");
+    if (P > 0 && !s->pod_status) return fail(core, KAI_ERR_INVALID_ARG, "a required pod array is NULL");
+    bool any_legacy_mig = false;
+    if (s->pod_flags) {  // one pass over the pods' flags on the host's cores: the two fallback rules (the first one wins, as when checked one after the other) and whether any pod is a legacy MIG task
+        const int K = chunk_count((size_t)P);
+        std::vector<unsigned char> seen((size_t)K, 0);
+        parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) {
+            unsigned char f = 0;
+            for (size_t p = p0; p < p1; p++) {
+                const uint32_t fl = s->pod_flags[p];
+                if (!(fl & (KAI_POD_CPU_FALLBACK | KAI_POD_GPU_UNMODELLED | KAI_POD_LEGACY_MIG))) continue;
+                if ((fl & KAI_POD_CPU_FALLBACK) && s->pod_status[p] == KAI_POD_PENDING) f |= 1;
+                if ((fl & KAI_POD_GPU_UNMODELLED) && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) f |= 2;
+                if (fl & KAI_POD_LEGACY_MIG) f |= 4;
+            }
+            seen[(size_t)ci] = f;
+        });
+        unsigned char all = 0; for (unsigned char f : seen) all |= f;
+        if (all & 1) return fail(core, KAI_ERR_UNSUPPORTED, "a pending pod is flagged KAI_POD_CPU_FALLBACK: leave its job to the host path");
+        if (all & 2) return fail(core, KAI_ERR_UNSUPPORTED, "an active pod holds GPU state the device does not model (gpu-memory / several fractional devices / MIG / DRA): its node's idle GPUs would be overstated");
+        any_legacy_mig = all & 4;
+    }
     // shared GPUs (ABI v4): fractions of one device.  One GPU memory size for the whole cluster keeps the queue-capacity step node independent.
-    SharedPods sp;
-    if (!sp.build(core->cfg, s)) return fail(core, KAI_ERR_UNSUPPORTED, sp.err.c_str());
+    SharedPods& sp = core->sp;
+    try { if (!sp.build(core->cfg, s)) return fail(core, KAI_ERR_UNSUPPORTED, sp.err.c_str()); }
+    catch (const std::exception& e) { core->err = std::string("host preparation: ") + e.what(); return KAI_ERR_INVALID_ARG; }
     const bool shared = sp.any;
     core->shared = shared;
 
@@ -510,18 +531,17 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
 
     // ---- index structures (pure re-orderings / groupings of the input; kai_host_prep.hpp)
     const auto t_shared = tnow();
-    HostPrep prep;
+    HostPrep& prep = core->prep;
     try { if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG; }
     catch (const std::exception& e) { core->err = std::string("host preparation: ") + e.what(); return KAI_ERR_INVALID_ARG; }  // (std::bad_alloc of a worker thread included: kai_parallel.hpp carries it here)
     const auto t_prep = tnow();
-    for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
-        if (s->pod_flags && (s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
+    if (any_legacy_mig) for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
+        if ((s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
     core->perm = prep.perm;
 
     int rc;
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
     // ---- static arrays (optional ones get neutral defaults); nodes go up in name-rank order
-    std::vector<int32_t> zerop(P, 0); std::vector<uint32_t> zeropu(P, 0);
     uint8_t one = 1;
     TRY(dupload_f(core, c.n_alloc, prep.node_alloc.data(), (size_t)R * N));
     TRY(dupload_f(core, c.n_flags, prep.node_flags.data(), (size_t)N));
@@ -530,9 +550,11 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dupload_f(core, c.p_req, s->pod_req, (size_t)R * P));
     TRY(dupload_f(core, c.p_job, s->pod_job, (size_t)P));
     TRY(dupload_f(core, c.p_podset, s->pod_podset, (size_t)P));
-    TRY(dupload_f(core, c.p_flags, s->pod_flags ? s->pod_flags : zeropu.data(), (size_t)P));
-    TRY(dupload_f(core, c.p_class, s->pod_class ? s->pod_class : zerop.data(), (size_t)P));
-    TRY(dupload_f(core, c.p_nominated, prep.pod_nominated.data(), (size_t)P));
+    if (s->pod_flags) TRY(dupload_f(core, c.p_flags, s->pod_flags, (size_t)P)); else TRY(dzero_f(core, c.p_flags, (size_t)P));  // (an optional array that is absent: zeros written on the device, not 4 MB of host zeros sent over)
+    if (s->pod_class) TRY(dupload_f(core, c.p_class, s->pod_class, (size_t)P)); else TRY(dzero_f(core, c.p_class, (size_t)P));
+    const bool full_uploads = std::getenv("KAI_OPEN_FULL_UPLOADS") != nullptr;  // (diagnostic: every array sent from the host, none of the constants below written on the device)
+    if (prep.any_nominated || full_uploads) TRY(dupload_f(core, c.p_nominated, prep.pod_nominated.data(), (size_t)P));
+    else { TRY(dalloc_f(core, c.p_nominated, (size_t)P)); HIP_TRY(core, hipMemsetAsync(KAI_VP(c.p_nominated), 0xFF, (size_t)std::max(P, 1) * sizeof(int32_t), core->stream)); }  // no nominated node anywhere: -1 in every element
     TRY(dupload_f(core, c.p_scls, prep.pod_scls.data(), (size_t)P));
     TRY(dupload_f(core, c.s_job, s->podset_job, (size_t)S));
     TRY(dupload_f(core, c.s_min, s->podset_min_available, (size_t)S));
@@ -582,18 +604,46 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
 
     // ---- shared GPUs: per-pod portion / group, per-node GPU memory and group tables (api/node_info/gpu_sharing_node_info.go)
     {
-        std::vector<double> por((size_t)std::max(P, 1), 0.0); std::vector<int32_t> grp((size_t)std::max(P, 1), -1), minus1((size_t)std::max(P, 1), -1); std::vector<int64_t> gm((size_t)std::max(N, 1), 100);
+        std::vector<int64_t> gm((size_t)std::max(N, 1), 100);
         int32_t next_new = KAI_NEW_GROUP;
-        for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && sp.shared[p]) ? s->pod_gpu_group[p] : -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
         for (int n = 0; n < N; n++) gm[n] = s->node_gpu_memory ? s->node_gpu_memory[prep.perm[n]] : 100;
-        TRY(dupload_f(core, c.p_shared, sp.shared.data(), (size_t)P)); TRY(dupload_f(core, c.p_mem, sp.mem.data(), (size_t)P)); TRY(dupload_f(core, c.p_gmem, sp.gmem.data(), (size_t)P));
-        TRY(dupload_f(core, c.p_acc_gpu, sp.acc_gpu.data(), (size_t)P)); TRY(dupload_f(core, c.p_pend_gpu, sp.pend_gpu.data(), (size_t)P));
-        TRY(dupload_f(core, c.p_quota_gpu, sp.quota_gpu.data(), (size_t)P)); TRY(dupload_f(core, c.p_mig_q, sp.mig_q.data(), (size_t)P)); TRY(dupload_f(core, c.p_kind, sp.kind.data(), (size_t)P));
         c.quota_on = sp.on ? 1 : 0; c.mig_on = sp.mig ? 1 : 0;
         for (int r = 0; r < KAI_MAX_RES; r++) { c.res_mig_g[r] = sp.mig_g[r]; c.res_mig_m[r] = sp.mig_m[r]; }
-        TRY(dupload_f(core, c.p_portion, por.data(), (size_t)P)); TRY(dupload_f(core, c.p_group, grp.data(), (size_t)P)); TRY(dupload_f(core, c.p_on_group, minus1.data(), (size_t)P));
+        TRY(dupload_f(core, c.p_shared, sp.shared.data(), (size_t)P)); TRY(dupload_f(core, c.p_kind, sp.kind.data(), (size_t)P));
+        const size_t P1 = (size_t)std::max(P, 1);
+        bool por_zero = true;  // pod_gpu_portion absent, or +0.0 in every element (what a packer that always fills the array sends for a cluster without fractions)
+        if (!sp.on && s->pod_gpu_portion) {
+            std::vector<char> nz((size_t)chunk_count((size_t)P), 0);
+            parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) { for (size_t p = p0; p < p1; p++) { uint64_t b; std::memcpy(&b, &s->pod_gpu_portion[p], 8); if (b) { nz[(size_t)ci] = 1; return; } } });
+            for (char x : nz) if (x) por_zero = false;
+        }
+        if (!sp.on && por_zero && !full_uploads) {
+            // A snapshot without shared-GPU requests and without MIG rows (SharedPods: neither `any` nor `mig`): the per-pod quantities of the shared-GPU model are constants —
+            // no memory of a device asked for, no MIG quota, every GPU quantity the pod's GPU request (the row of p_req that is in HBM already), no group anywhere.  They are
+            // written where they are read instead of being sent: at config 5 these twelve arrays are 73 of the open's 190 MB over PCIe.  (kai_hostsim_run checks the same
+            // statement about SharedPods on every snapshot the CPU suite runs: tests/host_sim/host_sim.cpp lean_shared_pods_hold.)
+            TRY(dzero_f(core, c.p_mem, (size_t)P)); TRY(dzero_f(core, c.p_gmem, (size_t)P)); TRY(dzero_f(core, c.p_mig_q, (size_t)P)); TRY(dzero_f(core, c.p_portion, (size_t)P));
+            TRY(dalloc_f(core, c.p_acc_gpu, (size_t)P)); TRY(dalloc_f(core, c.p_pend_gpu, (size_t)P)); TRY(dalloc_f(core, c.p_quota_gpu, (size_t)P));
+            if (P) {
+                const double* gpu_row = (const double*)KAI_VP(c.p_req) + (size_t)KAI_RES_GPU * P;
+                HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_acc_gpu), gpu_row, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, core->stream));
+                HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_pend_gpu), gpu_row, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, core->stream));
+                HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_quota_gpu), gpu_row, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, core->stream));
+            }
+            TRY(dalloc_f(core, c.p_group, (size_t)P)); TRY(dalloc_f(core, c.p_on_group, (size_t)P));
+            HIP_TRY(core, hipMemsetAsync(KAI_VP(c.p_group), 0xFF, P1 * sizeof(int32_t), core->stream));     // -1 in every element
+            HIP_TRY(core, hipMemsetAsync(KAI_VP(c.p_on_group), 0xFF, P1 * sizeof(int32_t), core->stream));
+            { int32_t* t = nullptr; TRY(dalloc(core, &t, P1)); HIP_TRY(core, hipMemsetAsync(t, 0xFF, P1 * sizeof(int32_t), core->stream)); core->d_group0 = t; }
+        } else {
+            std::vector<double> por(P1, 0.0); std::vector<int32_t> grp(P1, -1), minus1(P1, -1);
+            for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && sp.shared[p]) ? s->pod_gpu_group[p] : -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
+            TRY(dupload_f(core, c.p_mem, sp.mem.data(), (size_t)P)); TRY(dupload_f(core, c.p_gmem, sp.gmem.data(), (size_t)P));
+            TRY(dupload_f(core, c.p_acc_gpu, sp.acc_gpu.data(), (size_t)P)); TRY(dupload_f(core, c.p_pend_gpu, sp.pend_gpu.data(), (size_t)P));
+            TRY(dupload_f(core, c.p_quota_gpu, sp.quota_gpu.data(), (size_t)P)); TRY(dupload_f(core, c.p_mig_q, sp.mig_q.data(), (size_t)P));
+            TRY(dupload_f(core, c.p_portion, por.data(), (size_t)P)); TRY(dupload_f(core, c.p_group, grp.data(), (size_t)P)); TRY(dupload_f(core, c.p_on_group, minus1.data(), (size_t)P));
+            { const int32_t* t; TRY(dupload(core, &t, grp.data(), P1)); core->d_group0 = const_cast<int32_t*>(t); }
+        }
         TRY(dupload_f(core, c.n_gpu_mem, gm.data(), (size_t)N));
-        { const int32_t* t; TRY(dupload(core, &t, grp.data(), (size_t)std::max(P, 1))); core->d_group0 = const_cast<int32_t*>(t); }
         TRY(dalloc_f(core, c.ng_id, (size_t)N * KAI_GMAX)); TRY(dzero_f(core, c.ng_used, (size_t)N * KAI_GMAX)); TRY(dzero_f(core, c.ng_rel, (size_t)N * KAI_GMAX)); TRY(dzero_f(core, c.ng_alloc, (size_t)N * KAI_GMAX));
         TRY(dzero_f(core, c.ng_mark, (size_t)N)); TRY(dzero_f(core, c.ng_has_alloc, (size_t)N));
         TRY(dupload_f(core, c.next_new_group, &next_new, (size_t)1)); core->next_group0 = next_new;
@@ -621,14 +671,26 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
       TRY(dzero_f(core, c.dom_alloc_pods, DT)); TRY(dzero_f(core, c.dom_free, DT * KAI_MAX_RES)); TRY(dzero_f(core, c.dom_tmp, 3 * DT + 4)); TRY(dzero_f(core, c.dom_ratio, DT)); TRY(dzero_f(core, c.dom_key, 2 * DT));
       TRY(dzero_f(core, c.ns_bits, (size_t)KAI_TDEPTH * std::max(c.W, 1))); TRY(dzero_f(core, c.ns_sets, (size_t)KAI_TDEPTH * (DT + 1)));
       TRY(dzero_f(core, c.sg_score, (size_t)KAI_TKEYS * std::max<size_t>(DT, 1))); TRY(dzero_f(core, c.sg_key, (size_t)KAI_TKEYS)); TRY(dzero_f(core, c.sg_row, (size_t)KAI_TKEYS)); }
-    TRY(dupload_f(core, c.g_job, prep.g_job.data(), prep.g_job.size())); TRY(dupload_f(core, c.g_parent, prep.g_parent.data(), prep.g_parent.size()));
-    TRY(dupload_f(core, c.g_name_rank, prep.g_name_rank.data(), prep.g_name_rank.size())); TRY(dupload_f(core, c.g_topo, prep.g_topo.data(), prep.g_topo.size()));
-    TRY(dupload_f(core, c.g_req, prep.g_req.data(), prep.g_req.size())); TRY(dupload_f(core, c.g_pref, prep.g_pref.data(), prep.g_pref.size()));
-    TRY(dupload_f(core, c.j_root_group, prep.j_root_group.data(), prep.j_root_group.size()));
-    TRY(dupload_f(core, c.g_child_off, prep.g_child_off.data(), prep.g_child_off.size())); TRY(dupload_f(core, c.g_children, prep.g_children.data(), prep.g_children.size()));
-    TRY(dupload_f(core, c.s_group, prep.s_group.data(), prep.s_group.size())); TRY(dupload_f(core, c.s_topo, prep.s_topo.data(), prep.s_topo.size()));
-    TRY(dupload_f(core, c.s_req, prep.s_req.data(), prep.s_req.size())); TRY(dupload_f(core, c.s_pref, prep.s_pref.data(), prep.s_pref.size()));
-    TRY(dupload_f(core, c.j_has_topology, prep.j_has_topology.data(), prep.j_has_topology.size()));
+    TRY(dupload_f(core, c.g_job, prep.g_job.data(), prep.g_job.size())); TRY(dupload_f(core, c.j_root_group, prep.j_root_group.data(), prep.j_root_group.size()));
+    TRY(dupload_f(core, c.g_children, prep.g_children.data(), prep.g_children.size()));
+    if (prep.groups_default && !full_uploads) {
+        // no sub-group tree in the snapshot (HostPrep::build_topology's identity tables: one root group per job, G = J): no parent, no topology, no required / preferred level
+        // anywhere (-1), name rank 0, no children, and a pod-set's group is its job — constants written on the device, the pod-sets' groups copied from s_job (in HBM already)
+        auto minus_one = [&](auto& field, size_t n) -> int { int rc2 = dalloc_f(core, field, n); if (rc2) return rc2; HIP_TRY(core, hipMemsetAsync(KAI_VP(field), 0xFF, std::max<size_t>(n, 1) * sizeof(*field), core->stream)); return KAI_OK; };
+        TRY(minus_one(c.g_parent, (size_t)J)); TRY(minus_one(c.g_topo, (size_t)J)); TRY(minus_one(c.g_req, (size_t)J)); TRY(minus_one(c.g_pref, (size_t)J));
+        TRY(minus_one(c.s_topo, (size_t)S)); TRY(minus_one(c.s_req, (size_t)S)); TRY(minus_one(c.s_pref, (size_t)S));
+        TRY(dzero_f(core, c.g_name_rank, (size_t)J)); TRY(dzero_f(core, c.g_child_off, (size_t)J + 1)); TRY(dzero_f(core, c.j_has_topology, (size_t)std::max(J, 1)));
+        TRY(dalloc_f(core, c.s_group, (size_t)S));
+        if (S) HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.s_group), KAI_VP(c.s_job), (size_t)S * sizeof(int32_t), hipMemcpyDeviceToDevice, core->stream));
+    } else {
+        TRY(dupload_f(core, c.g_parent, prep.g_parent.data(), prep.g_parent.size()));
+        TRY(dupload_f(core, c.g_name_rank, prep.g_name_rank.data(), prep.g_name_rank.size())); TRY(dupload_f(core, c.g_topo, prep.g_topo.data(), prep.g_topo.size()));
+        TRY(dupload_f(core, c.g_req, prep.g_req.data(), prep.g_req.size())); TRY(dupload_f(core, c.g_pref, prep.g_pref.data(), prep.g_pref.size()));
+        TRY(dupload_f(core, c.g_child_off, prep.g_child_off.data(), prep.g_child_off.size()));
+        TRY(dupload_f(core, c.s_group, prep.s_group.data(), prep.s_group.size())); TRY(dupload_f(core, c.s_topo, prep.s_topo.data(), prep.s_topo.size()));
+        TRY(dupload_f(core, c.s_req, prep.s_req.data(), prep.s_req.size())); TRY(dupload_f(core, c.s_pref, prep.s_pref.data(), prep.s_pref.size()));
+        TRY(dupload_f(core, c.j_has_topology, prep.j_has_topology.data(), prep.j_has_topology.size()));
+    }
 
     // ---- dynamic state
     double* d;
@@ -673,6 +735,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     HIP_TRY(core, hipStreamSynchronize(core->stream));  // prep's host buffers die with this scope
     if (prof_open) std::fprintf(stderr, "kai open: free %.2f ms, checks + shared pods %.2f, host prep %.2f, allocate + enqueue uploads %.2f, wait %.2f | total %.2f ms\n",
                                 tms(t_begin, t_freed), tms(t_freed, t_shared), tms(t_shared, t_prep), tms(t_prep, t_enq), tms(t_enq, tnow()), tms(t_begin, tnow()));
+    if (prof_open) std::fprintf(stderr, "kai open: host prep by phase: range checks %.2f, nodes %.2f, pods %.2f, task order %.2f, queues + job lists %.2f, shares + topology %.2f, classes %.2f, batch shape %.2f ms on %d host threads\n",
+                                prep.phase_ms[0], prep.phase_ms[1], prep.phase_ms[2], prep.phase_ms[3], prep.phase_ms[4], prep.phase_ms[5], prep.phase_ms[6], prep.phase_ms[7], host_threads());
     float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));
     std::memset(&core->stats, 0, sizeof(core->stats));
     core->stats.upload_ms = ms;

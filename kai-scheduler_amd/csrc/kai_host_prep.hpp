@@ -27,11 +27,18 @@ struct SharedPods {
     int32_t mig_g[KAI_MAX_RES] = {0}; int64_t mig_m[KAI_MAX_RES] = {0};
     enum { K_MIG = 1, K_LEGACY = 2, K_REGULAR = 4, K_GPUS = 8 };  // PodInfo: IsMigCandidate / IsLegacyMIGtask / IsRegularGPURequest / ResReq.GPUs() > 0
     static bool has(const kai_snapshot_soa* s) {
-        for (int p = 0; p < s->n_pods; p++) if ((s->pod_gpu_portion && s->pod_gpu_portion[p] > 0) || (s->pod_gpu_memory && s->pod_gpu_memory[p] > 0)) return true;
+        if (!s->pod_gpu_portion && !s->pod_gpu_memory) return false;
+        const size_t P = (size_t)std::max(s->n_pods, 0);
+        std::vector<char> found((size_t)chunk_count(P), 0);
+        parallel_chunks(P, [&](int ci, size_t p0, size_t p1) {
+            for (size_t p = p0; p < p1; p++) if ((s->pod_gpu_portion && s->pod_gpu_portion[p] > 0) || (s->pod_gpu_memory && s->pod_gpu_memory[p] > 0)) { found[(size_t)ci] = 1; return; }
+        });
+        for (char f : found) if (f) return true;
         return false;
     }
     bool build(const kai_config& cfg, const kai_snapshot_soa* s) {  // false: refused, err says why
         const int P = s->n_pods, N = s->n_nodes;
+        mig = false; on = false; err.clear(); for (int r = 0; r < KAI_MAX_RES; r++) { mig_g[r] = 0; mig_m[r] = 0; }  // (the object may be one a handle keeps between sessions)
         any = has(s);
         const size_t n = (size_t)std::max(P, 1);
         shared.resize(n); kind.resize(n); mem.resize(n); gmem.resize(n); acc_gpu.resize(n); pend_gpu.resize(n); quota_gpu.resize(n); mig_q.resize(n);
@@ -66,7 +73,7 @@ struct SharedPods {
             }
             // MIG instances: GetGpusQuota adds weight x count to every GPU quantity of the request except GPUs() itself (gpu_resource_requirment.go:163-178)
             double mq = 0; if (mig) for (int r = KAI_RES_PODS + 1; r < s->n_res && r < KAI_MAX_RES; r++) if (mig_g[r] > 0) mq += (double)mig_g[r] * s->pod_req[(size_t)r * P + p];
-            mig_q[p] = mq; acc_gpu[p] += mq; pend_gpu[p] += mq; quota_gpu[p] += mq;
+            mig_q[p] = mq; if (mig) { acc_gpu[p] += mq; pend_gpu[p] += mq; quota_gpu[p] += mq; }  // (without MIG rows the three stay the request bit for bit: kai_session_open copies that row on the device)
             uint8_t k = 0;
             if (mq > 0) k |= K_MIG;
             if (s->pod_flags && (s->pod_flags[p] & KAI_POD_LEGACY_MIG)) k |= K_LEGACY;
@@ -81,20 +88,39 @@ struct SharedPods {
 };
 
 struct HostPrep {
-    std::vector<int32_t> sorted, child_off, children, depth, job_off, jobs_static, slot_queue, depth_order, lvl_off, lvl_parents;
+    // (the arrays with an element per pod / job / pod-set are raw_vectors: the parallel loop that fills them is their first touch — a plain vector's resize would
+    // zero tens of megabytes, page by page, on one core first)
+    std::vector<int32_t> child_off, children, depth, job_off, depth_order, lvl_off, lvl_parents;
+    raw_vector<int32_t> sorted, jobs_static, slot_queue;
     std::vector<QShare> shares;
     int n_levels = 0;
     // nodes in name-rank order: perm[i] = caller's index of the node with rank i
-    std::vector<int32_t> perm, node_gpu_count, node_class, pod_node, pod_nominated;
+    std::vector<int32_t> perm, node_gpu_count, node_class;
+    raw_vector<int32_t> pod_node, pod_nominated;
     std::vector<double> node_alloc; std::vector<uint32_t> node_flags;
     // scan classes
-    std::vector<ClassRec> classes; std::vector<int32_t> pod_scls; int all_tracked = 1, fast_ok = 1;
+    std::vector<ClassRec> classes; raw_vector<int32_t> pod_scls; int all_tracked = 1, fast_ok = 1;
     // topology + sub-group tree (defaults synthesised when the snapshot carries none)
     int T = 0, TL = 0, D = 0, G = 0;
+    bool groups_default = false;   // no sub-group tree in the snapshot: the group / pod-set tables below are the synthesised identity tables (kai_session_open writes their constants on the device)
+    bool any_nominated = false;    // some pod names a nominated node (pod_nominated is -1 everywhere otherwise)
     std::vector<int32_t> topo_level_off, node_domain, dom_level, dom_topo, dom_parent, dom_child_off, dom_children;
-    std::vector<uint32_t> dom_id_rank, g_name_rank;
-    std::vector<int32_t> g_job, g_parent, g_topo, g_req, g_pref, j_root_group, g_child_off, g_children, s_group, s_topo, s_req, s_pref;
-    std::vector<uint8_t> j_has_topology;
+    std::vector<uint32_t> dom_id_rank; raw_vector<uint32_t> g_name_rank;
+    raw_vector<int32_t> g_job, g_parent, g_topo, g_req, g_pref, j_root_group, g_child_off, g_children, s_group, s_topo, s_req, s_pref;
+    raw_vector<uint8_t> j_has_topology;
+    // v[0 .. n) = val on the host's cores (v: a raw_vector — resize leaves the elements to this loop)
+    template <class V, class X> static void par_fill(V& v, size_t n, X val) {
+        v.resize(n);
+        parallel_chunks(n, [&](int, size_t a, size_t b) { std::fill(v.begin() + (ptrdiff_t)a, v.begin() + (ptrdiff_t)b, (typename V::value_type)val); }, 65536);
+    }
+    // the message of the lowest index i in [0, n) for which check(i) returns one (nullptr: none fails) — what a sequential loop that stops at its first failure reports
+    template <class F> static const char* first_failure(size_t n, F&& check) {
+        const int K = chunk_count(n);
+        std::vector<const char*> e((size_t)K, nullptr);
+        parallel_chunks(n, [&](int ci, size_t a, size_t b) { for (size_t i = a; i < b; i++) if (const char* m = check(i)) { e[(size_t)ci] = m; return; } });
+        for (const char* m : e) if (m) return m;
+        return nullptr;
+    }
     // batch path (kai_batch.hpp): queue nodes by height (leaf = 0, the virtual root at index Q on top), and whether the snapshot's quantities add
     // exactly in any order (the batch path sums shares and node accounting in parallel)
     struct BatchShape { int n_leaves = 0, n_heights = 0; std::vector<int> h_count; };
@@ -105,6 +131,7 @@ struct HostPrep {
     int build(const kai_config& cfg, const kai_snapshot_soa* s, std::string& err) {
         const int N = s->n_nodes, P = s->n_pods, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
         auto fail = [&](const char* m) { err = m; return (int)KAI_ERR_INVALID_ARG; };
+        for (double& x : phase_ms) x = 0;  // (the object may be one a handle keeps between sessions: everything build() hands out is rewritten below)
         auto t_last = std::chrono::steady_clock::now();
         auto lap = [&](int i) { const auto t = std::chrono::steady_clock::now(); phase_ms[i] += std::chrono::duration<double, std::milli>(t - t_last).count(); t_last = t; };
         // ---- the snapshot indexes device arrays directly: every index is range-checked here, every required array must be present
@@ -114,18 +141,19 @@ struct HostPrep {
         if (S > 0 && (!s->podset_job || !s->podset_min_available || !s->podset_name_rank)) return fail("a required pod-set array is NULL");
         if (J > 0 && (!s->job_queue || !s->job_priority || !s->job_preemptible || !s->job_created_ns || !s->job_uid_rank || !s->job_first_pod || !s->job_n_pods || !s->job_first_podset || !s->job_n_podsets)) return fail("a required job array is NULL");
         if (Q > 0 && (!s->queue_parent || !s->queue_priority || !s->queue_created_ns || !s->queue_uid_rank || !s->queue_deserved || !s->queue_limit || !s->queue_oqw)) return fail("a required queue array is NULL");
-        for (int k = 0; k < S; k++) if (s->podset_job[k] < 0 || s->podset_job[k] >= J) return fail("podset_job out of range");
-        for (int j = 0; j < J; j++) {
-            const int b = s->job_first_podset[j], n = s->job_n_podsets[j];
-            if (b < 0 || n < 0 || b + n > S) return fail("job pod-set range out of bounds");
-            if (s->job_queue[j] < -1) return fail("bad job_queue");
-        }
-        for (int p = 0; p < P; p++) {
-            const int j = s->pod_job[p];
-            if (j < -1 || j >= J) return fail("pod_job out of range");
-            if (j >= 0) { const int ps = s->pod_podset[p]; if (ps < s->job_first_podset[j] || ps >= s->job_first_podset[j] + s->job_n_podsets[j]) return fail("pod_podset outside its job's pod-sets"); }
-            else if (s->pod_podset[p] < -1 || s->pod_podset[p] >= S) return fail("pod_podset out of range");
-        }
+        // (each loop on the host's cores; the failure reported is the one a sequential pass would stop at)
+        if (const char* m = first_failure((size_t)S, [&](size_t k) -> const char* { return (s->podset_job[k] < 0 || s->podset_job[k] >= J) ? "podset_job out of range" : nullptr; })) return fail(m);
+        if (const char* m = first_failure((size_t)J, [&](size_t j) -> const char* {
+                const int b = s->job_first_podset[j], n = s->job_n_podsets[j];
+                if (b < 0 || n < 0 || b + n > S) return "job pod-set range out of bounds";
+                if (s->job_queue[j] < -1) return "bad job_queue";
+                return nullptr; })) return fail(m);
+        if (const char* m = first_failure((size_t)P, [&](size_t p) -> const char* {
+                const int j = s->pod_job[p];
+                if (j < -1 || j >= J) return "pod_job out of range";
+                if (j >= 0) { const int ps = s->pod_podset[p]; if (ps < s->job_first_podset[j] || ps >= s->job_first_podset[j] + s->job_n_podsets[j]) return "pod_podset outside its job's pod-sets"; }
+                else if (s->pod_podset[p] < -1 || s->pod_podset[p] >= S) return "pod_podset out of range";
+                return nullptr; })) return fail(m);
         for (int d = 0; d < s->n_domains; d++) if (s->domain_parent && (s->domain_parent[d] < -1 || s->domain_parent[d] >= s->n_domains)) return fail("domain_parent out of range");
         for (int g = 0; g < s->n_groups; g++) if (s->group_parent && s->group_parent[g] < -1) return fail("group_parent out of range");
         lap(0);
@@ -143,18 +171,22 @@ struct HostPrep {
         pod_node.resize(P); pod_nominated.resize(P);
         { std::vector<char> bad((size_t)chunk_count((size_t)P), 0);
           parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) {
+              char f = 0;
               for (size_t p = p0; p < p1; p++) {
                   int n = s->pod_node[p]; pod_node[p] = (n >= 0 && n < N) ? (int32_t)s->node_name_rank[n] : -1;
                   int m = s->pod_nominated_node ? s->pod_nominated_node[p] : -1; pod_nominated[p] = (m >= 0 && m < N) ? (int32_t)s->node_name_rank[m] : -1;
-                  int pc = s->pod_class ? s->pod_class[p] : 0; if (pc < 0 || pc >= std::max(1, s->n_pod_classes)) bad[(size_t)ci] = 1;
+                  if (pod_nominated[p] != -1) f |= 2;
+                  int pc = s->pod_class ? s->pod_class[p] : 0; if (pc < 0 || pc >= std::max(1, s->n_pod_classes)) f |= 1;
               }
+              bad[(size_t)ci] = f;
           });
-          for (char b : bad) if (b) return fail("pod_class out of range"); }
+          any_nominated = false;
+          for (char b : bad) { if (b & 1) return fail("pod_class out of range"); if (b & 2) any_nominated = true; } }
         lap(2);
         // each job's pods in TaskOrderFn order (framework/session_plugins.go:244-260 + plugins/taskorder/task_order.go:28-63)
         sorted.resize(P);
         const bool taskorder = cfg.plugins & KAI_PLUGIN_TASKORDER;
-        for (int j = 0; j < J; j++) { int b = s->job_first_pod[j], n = s->job_n_pods[j]; if (b < 0 || n < 0 || b + n > P) return fail("job pod range out of bounds"); }
+        if (const char* m = first_failure((size_t)J, [&](size_t j) -> const char* { const int b = s->job_first_pod[j], n = s->job_n_pods[j]; return (b < 0 || n < 0 || b + n > P) ? "job pod range out of bounds" : nullptr; })) return fail(m);
         {   // … and disjoint: the per-job sorts below run on the host's cores, two jobs over one slice of `sorted` would race (jobs in pod order is the usual case, checked in O(J))
             bool mono = true; int end = 0;
             for (int j = 0; j < J && mono; j++) { const int b = s->job_first_pod[j], n = s->job_n_pods[j]; if (n == 0) continue; if (b < end) mono = false; end = b + n; }
@@ -188,10 +220,26 @@ struct HostPrep {
         for (int q = 0; q < Q; q++) { int d = 0; for (int x = s->queue_parent[q]; x >= 0; x = s->queue_parent[x]) { if (++d > Q) return fail("queue cycle"); } depth[q] = d; }
         // per-queue job lists in the static part of JobOrderFn (session_plugins.go:227-242): priority desc, creation, uid.
         // The elastic state, the only dynamic operand, is applied on the device (k_leaf_init).
-        job_off.assign(Q + 1, 0); jobs_static.assign(std::max(J, 1), 0); slot_queue.assign(std::max(J, 1), -1);
-        for (int j = 0; j < J; j++) { int q = s->job_queue[j]; if (q >= Q) return fail("bad job_queue"); if (q >= 0) job_off[q + 1]++; }
-        for (int q = 0; q < Q; q++) job_off[q + 1] += job_off[q];
-        { std::vector<int32_t> fill(job_off.begin(), job_off.end() - 1); for (int j = 0; j < J; j++) { int q = s->job_queue[j]; if (q >= 0) jobs_static[fill[q]++] = j; } }
+        // (a counting sort by queue over chunks of the job range: per chunk a histogram, the chunks' write positions from the histograms of the chunks before them —
+        // every queue's jobs come out in ascending job index, as one pass over the jobs leaves them)
+        job_off.assign(Q + 1, 0); jobs_static.resize((size_t)std::max(J, 1)); slot_queue.resize((size_t)std::max(J, 1));
+        {
+            const int K = chunk_count((size_t)J);
+            std::vector<std::vector<int32_t>> hist((size_t)K); std::vector<char> badq((size_t)K, 0);
+            parallel_chunks((size_t)J, [&](int ci, size_t j0, size_t j1) {
+                std::vector<int32_t>& h = hist[(size_t)ci]; h.assign((size_t)Q + 1, 0);
+                for (size_t j = j0; j < j1; j++) { const int q = s->job_queue[j]; if (q >= Q) { badq[(size_t)ci] = 1; return; } if (q >= 0) h[(size_t)q]++; }
+            });
+            for (char b : badq) if (b) return fail("bad job_queue");
+            for (int q = 0; q < Q; q++) { int32_t n = 0; for (int ci = 0; ci < K; ci++) n += hist[(size_t)ci].empty() ? 0 : hist[(size_t)ci][(size_t)q]; job_off[q + 1] = job_off[q] + n; }
+            for (int q = 0; q < Q; q++) { int32_t at = job_off[q]; for (int ci = 0; ci < K; ci++) { if (hist[(size_t)ci].empty()) continue; const int32_t n = hist[(size_t)ci][(size_t)q]; hist[(size_t)ci][(size_t)q] = at; at += n; } }  // histogram -> write position
+            parallel_chunks((size_t)J, [&](int ci, size_t j0, size_t j1) {
+                std::vector<int32_t>& at = hist[(size_t)ci];
+                for (size_t j = j0; j < j1; j++) { const int q = s->job_queue[j]; if (q >= 0) jobs_static[(size_t)at[(size_t)q]++] = (int32_t)j; }
+            });
+            // slots past the queued jobs (jobs without a queue leave the lists shorter than J): the values a zeroed / -1-filled array would hold there
+            std::fill(jobs_static.begin() + (J > 0 ? job_off[Q] : 0), jobs_static.end(), 0); std::fill(slot_queue.begin() + (J > 0 ? job_off[Q] : 0), slot_queue.end(), -1);
+        }
         const bool use_prio = cfg.plugins & KAI_PLUGIN_PRIORITY;
         parallel_chunks((size_t)Q, [&](int, size_t q0, size_t q1) {
             for (size_t q = q0; q < q1; q++) {
@@ -254,7 +302,7 @@ struct HostPrep {
                 std::vector<Acc> acc((size_t)chunk_count(n));
                 parallel_chunks(n, [&](int ci, size_t i0, size_t i1) {
                     Acc a;
-                    for (size_t i = i0; i < i1 && a.ok; i++) { const double x = v[i]; if (!(x >= 0) || x != std::floor(x) || x >= 9.2e18) { a.ok = false; break; } a.bits |= (uint64_t)x; a.sum += (uint64_t)x; }
+                    for (size_t i = i0; i < i1 && a.ok; i++) { const double x = v[i]; if (!(x >= 0) || x >= 9.2e18 || x != (double)(uint64_t)x) { a.ok = false; break; } a.bits |= (uint64_t)x; a.sum += (uint64_t)x; }  // (0 <= x < 2^63: the truncation is floor)
                     acc[(size_t)ci] = a;
                 });
                 Acc t; for (const Acc& a : acc) { t.ok = t.ok && a.ok; t.bits |= a.bits; t.sum += a.sum; }
@@ -312,6 +360,7 @@ struct HostPrep {
         dom_child_off[D + T] = (int)dom_children.size();
         if (dom_children.empty()) dom_children.push_back(0);
         // sub-group tree
+        groups_default = !(s->n_groups > 0);
         if (s->n_groups > 0) {
             G = s->n_groups;
             g_job.assign(s->group_job, s->group_job + G); g_parent.assign(s->group_parent, s->group_parent + G); g_name_rank.assign(s->group_name_rank, s->group_name_rank + G);
@@ -320,15 +369,23 @@ struct HostPrep {
             s_group.assign(s->podset_group, s->podset_group + S); s_topo.assign(s->podset_topology, s->podset_topology + S);
             s_req.assign(s->podset_required_level, s->podset_required_level + S); s_pref.assign(s->podset_preferred_level, s->podset_preferred_level + S);
         } else {
+            // no sub-group tree in the snapshot: one root group per job, no topology anywhere — identity tables, written on the host's cores (J and S are ~4·10^5 at config 5);
+            // the checks and the child lists below have nothing to find in them (every parent -1, every topology -1, podset_job range-checked by build())
             G = J;
-            g_job.resize(J); g_parent.assign(J, -1); g_name_rank.assign(J, 0); g_topo.assign(J, -1); g_req.assign(J, -1); g_pref.assign(J, -1); j_root_group.resize(J);
-            for (int j = 0; j < J; j++) { g_job[j] = j; j_root_group[j] = j; }
-            s_group.resize(S); s_topo.assign(S, -1); s_req.assign(S, -1); s_pref.assign(S, -1);
-            for (int k = 0; k < S; k++) s_group[k] = s->podset_job[k];
+            g_job.resize((size_t)J); g_parent.resize((size_t)J); g_name_rank.resize((size_t)J); g_topo.resize((size_t)J); g_req.resize((size_t)J); g_pref.resize((size_t)J); j_root_group.resize((size_t)J);
+            g_child_off.resize((size_t)G + 1); j_has_topology.resize((size_t)std::max(J, 1));
+            parallel_chunks((size_t)J, [&](int, size_t j0, size_t j1) {
+                for (size_t j = j0; j < j1; j++) { g_job[j] = (int32_t)j; j_root_group[j] = (int32_t)j; g_parent[j] = -1; g_name_rank[j] = 0; g_topo[j] = -1; g_req[j] = -1; g_pref[j] = -1; g_child_off[j] = 0; j_has_topology[j] = 0; }
+            }, 65536);
+            g_child_off[(size_t)G] = 0; if (J == 0) j_has_topology[0] = 0;
+            s_group.resize((size_t)S); s_topo.resize((size_t)S); s_req.resize((size_t)S); s_pref.resize((size_t)S);
+            parallel_chunks((size_t)S, [&](int, size_t k0, size_t k1) { for (size_t k = k0; k < k1; k++) { s_group[k] = s->podset_job[k]; s_topo[k] = -1; s_req[k] = -1; s_pref[k] = -1; } }, 65536);
+            g_children.assign(1, 0);
+            return 0;
         }
         for (int g = 0; g < G; g++) { if (g_parent[g] >= G || g_job[g] < 0 || g_job[g] >= J) return fail("bad group table"); if (g_topo[g] >= T) return fail("group_topology out of range"); }
         for (int k = 0; k < S; k++) { if (s_group[k] < 0 || s_group[k] >= G) return fail("bad podset_group"); if (s_topo[k] >= T) return fail("podset_topology out of range"); }
-        g_child_off.assign(G + 1, 0);  // children of a group in ascending group index (counting sort: no vector per group — G = J for a snapshot without sub-group trees)
+        g_child_off.assign(G + 1, 0);  // children of a group in ascending group index (counting sort: no vector per group)
         for (int g = 0; g < G; g++) if (g_parent[g] >= 0) g_child_off[g_parent[g] + 1]++;
         for (int g = 0; g < G; g++) g_child_off[g + 1] += g_child_off[g];
         g_children.assign((size_t)std::max(g_child_off[G], 1), 0);
@@ -351,11 +408,10 @@ struct HostPrep {
     // The KAI_CMAX most frequent admissible classes among PENDING pods are indexed; other pods use the brute-force scan.
     void build_classes(const kai_config& cfg, const kai_snapshot_soa* s) {
         const int N = s->n_nodes, P = s->n_pods, R = s->n_res;
-        pod_scls.assign(P, -1); classes.clear(); all_tracked = 1;
+        par_fill(pod_scls, (size_t)P, -1); classes.clear(); all_tracked = 1;
         // the staged job path needs "fits on Idle+Releasing" == "fits on Idle" for every node: nothing releasing, nothing pipelined
         fast_ok = cfg.engine_mode == 2 ? 0 : 1;
-        for (int p = 0; p < P; p++) if (s->pod_status[p] & (KAI_POD_RELEASING | KAI_POD_PIPELINED)) fast_ok = 0;
-        auto integral = [](double v, double lim) { return v >= 0 && v <= lim && v == std::floor(v); };
+        auto integral = [](double v, double lim) { return v >= 0 && v <= lim && v == (double)(int64_t)v; };  // (v <= lim < 2^63: the truncation is floor for v >= 0)
         bool ok_res[2] = {true, true};  // [0] = CPU, [1] = GPU as placement resource
         const int rr[2] = {KAI_RES_CPU, KAI_RES_GPU};
         for (int t = 0; t < 2; t++) {
@@ -371,13 +427,27 @@ struct HostPrep {
                     if (r == KAI_RES_CPU && a == 0) ok_res[t] = false;
                 }
             }
-            for (int p = 0; p < P && ok_res[t]; p++) if (!integral(s->pod_req[(size_t)r * P + p], 1073741824.0)) ok_res[t] = false;
+        }
+        {   // per pod, one pass on the host's cores: a releasing / pipelined pod anywhere, a CPU or GPU request that is no integer <= 2^30
+            const int K = chunk_count((size_t)P);
+            std::vector<unsigned char> flags((size_t)K, 0);
+            const double* cpu = s->pod_req + (size_t)KAI_RES_CPU * P; const double* gpu = s->pod_req + (size_t)KAI_RES_GPU * P;
+            parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) {
+                unsigned char f = 0;
+                for (size_t p = p0; p < p1; p++) {
+                    if (s->pod_status[p] & (KAI_POD_RELEASING | KAI_POD_PIPELINED)) f |= 1;
+                    if (!integral(cpu[p], 1073741824.0)) f |= 2;
+                    if (!integral(gpu[p], 1073741824.0)) f |= 4;
+                }
+                flags[(size_t)ci] = f;
+            });
+            for (unsigned char f : flags) { if (f & 1) fast_ok = 0; if (f & 2) ok_res[0] = false; if (f & 4) ok_res[1] = false; }
         }
         if (cfg.engine_mode == 1) { all_tracked = 0; return; }
         struct Key { double req[KAI_MAX_RES]; int32_t pc; bool operator<(const Key& o) const { int c = std::memcmp(req, o.req, sizeof req); return c ? c < 0 : pc < o.pc; } };
         // class ids in order of first appearance over the pods.  Chunks of the pod range are classified on the host's cores (a chunk's keys in ITS order of first
         // appearance; a pod usually repeats the key of the pod before it, so that one is compared first), then merged chunk by chunk: the ids come out as in one pass
-        std::map<Key, int> ids; std::vector<Key> keys; std::vector<int64_t> freq; std::vector<int32_t> pod_cls(P, -1);
+        std::map<Key, int> ids; std::vector<Key> keys; std::vector<int64_t> freq; raw_vector<int32_t> pod_cls((size_t)P);  // (every element is written by the classification below)
         {
             const int K = chunk_count((size_t)P);
             struct Local { std::vector<Key> keys; std::vector<int64_t> freq; };
@@ -424,7 +494,7 @@ struct HostPrep {
         }
         parallel_chunks((size_t)P, [&](int, size_t p0, size_t p1) { for (size_t p = p0; p < p1; p++) pod_scls[p] = remap[(size_t)pod_cls[p]]; });
         int NB = (N + KAI_BLOCK - 1) / KAI_BLOCK, NSB = (NB + 63) / 64;
-        if (NSB > KAI_NSB_MAX) { classes.clear(); std::fill(pod_scls.begin(), pod_scls.end(), -1); all_tracked = 0; }  // beyond the LDS level: brute force
+        if (NSB > KAI_NSB_MAX) { classes.clear(); par_fill(pod_scls, (size_t)P, -1); all_tracked = 0; }  // beyond the LDS level: brute force
     }
 };
 

@@ -278,15 +278,23 @@ extern "C" int kai_hostsim_last_gpu_groups(int32_t* out, int cap) { int n = (int
 // host clocks of the per-cycle host preparation (HostPrep + SharedPods: what kai_session_open does before the first upload), phase by phase — timing aid
 extern "C" int kai_hostsim_prep_ms(const kai_config* cfg, const kai_snapshot_soa* s, double* out, int cap) {
     auto t0 = std::chrono::steady_clock::now();
-    SharedPods sp; if (!sp.build(*cfg, s)) return KAI_ERR_UNSUPPORTED;
+    // (kept between calls, as kai_core keeps them between sessions: after the first call the arrays are touched memory)
+    static SharedPods sp; if (!sp.build(*cfg, s)) return KAI_ERR_UNSUPPORTED;
     auto t1 = std::chrono::steady_clock::now();
-    HostPrep prep; std::string err;
+    static HostPrep prep; std::string err;
     if (prep.build(*cfg, s, err)) return KAI_ERR_INVALID_ARG;
     auto t2 = std::chrono::steady_clock::now();
     if (cap > 0) out[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (cap > 1) out[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
     for (int i = 0; i < 8 && i + 2 < cap; i++) out[i + 2] = prep.phase_ms[i];
     return 0;
+}
+// HostPrep::build's verdict on a snapshot: its return code and, for a refused one, the message (what kai_session_open hands to kai_last_error)
+extern "C" int kai_hostsim_prep_error(const kai_config* cfg, const kai_snapshot_soa* s, char* msg, int cap) {
+    HostPrep prep; std::string err;
+    const int rc = prep.build(*cfg, s, err);
+    if (msg && cap > 0) { std::snprintf(msg, (size_t)cap, "%s", err.c_str()); }
+    return rc;
 }
 extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s, const int* actions, int n_actions,
                                kai_op* ops_out, int64_t ops_cap, int64_t* n_ops, int32_t* pod_status_out, int32_t* pod_node_out,
@@ -298,9 +306,29 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (!sp.build(*cfg, s)) return KAI_ERR_UNSUPPORTED;
     const bool shared = sp.any;
     const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
+    // lean_shared_pods_hold: kai_session_open (kai_core.hip) does not SEND the per-pod arrays of the shared-GPU model for a snapshot without shared-GPU requests and MIG rows — it
+    // writes the constants they hold on the device.  That they hold exactly those constants is checked here, on every snapshot the CPU suite runs.
+    if (!sp.on) for (int p = 0; p < P; p++) {
+        const double g = s->pod_req[(size_t)KAI_RES_GPU * P + p];
+        const bool same = std::memcmp(&sp.acc_gpu[p], &g, 8) == 0 && std::memcmp(&sp.pend_gpu[p], &g, 8) == 0 && std::memcmp(&sp.quota_gpu[p], &g, 8) == 0;
+        const double z = 0.0;
+        if (!same || sp.shared[p] != 0 || sp.mem[p] != 0 || sp.gmem[p] != 0 || std::memcmp(&sp.mig_q[p], &z, 8) != 0) { std::fprintf(stderr, "lean_shared_pods_hold: pod %d breaks the constants kai_session_open writes on the device\n", p); return KAI_ERR_STATE; }
+    }
     std::vector<std::vector<char>> pool;
     HostPrep prep; std::string err;
     if (prep.build(*cfg, s, err)) return KAI_ERR_INVALID_ARG;
+    {   // the other constants kai_session_open writes on the device instead of sending them (kai_core.hip: prep.groups_default, !prep.any_nominated) — checked on every snapshot the CPU suite runs
+        bool ok = true;
+        if (!prep.any_nominated) for (int p = 0; p < P; p++) ok = ok && prep.pod_nominated[p] == -1;
+        if (prep.groups_default) {
+            ok = ok && prep.G == J && (int)prep.g_job.size() == J && (int)prep.g_parent.size() == J && (int)prep.g_topo.size() == J && (int)prep.g_req.size() == J && (int)prep.g_pref.size() == J && (int)prep.g_name_rank.size() == J
+                    && (int)prep.g_child_off.size() == J + 1 && (int)prep.j_has_topology.size() == std::max(J, 1) && (int)prep.s_group.size() == S && (int)prep.s_topo.size() == S && (int)prep.s_req.size() == S && (int)prep.s_pref.size() == S;
+            for (int j = 0; j < J && ok; j++) ok = prep.g_parent[j] == -1 && prep.g_topo[j] == -1 && prep.g_req[j] == -1 && prep.g_pref[j] == -1 && prep.g_name_rank[j] == 0 && prep.g_child_off[j] == 0 && prep.j_has_topology[j] == 0;
+            ok = ok && prep.g_child_off[J] == 0 && prep.j_has_topology[0] == 0;
+            for (int k = 0; k < S && ok; k++) ok = prep.s_group[k] == s->podset_job[k] && prep.s_topo[k] == -1 && prep.s_req[k] == -1 && prep.s_pref[k] == -1;
+        }
+        if (!ok) { std::fprintf(stderr, "host_sim: HostPrep's default tables differ from the constants kai_session_open writes on the device\n"); return KAI_ERR_STATE; }
+    }
     for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
         if (s->pod_flags && (s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
     KaiCtx c{};

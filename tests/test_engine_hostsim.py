@@ -484,3 +484,44 @@ def test_hostsim_victims_log_with_recorded_victims_of_elastic_jobs(seed):
     cfg = T.abi.default_config(max_consolidation_preemptees=-1)
     acts = ("allocate", "reclaim", "preempt") if seed % 2 else ("allocate", "consolidation", "reclaim")
     assert_same(HostSim.run(snap, cfg, acts), T.Oracle.run(snap, cfg, acts))
+
+
+def test_hostprep_refuses_malformed_snapshots_like_a_sequential_pass():
+    """kai_session_open's host preparation (kai_host_prep.hpp) checks every index of the snapshot on the host's cores, chunk by chunk; the failure it reports must be the one
+    a sequential pass stops at: the checks in their order (pod-sets, jobs, pods, …), and within one loop the lowest index.  A snapshot large enough for several chunks."""
+    import ctypes as C
+    HostSim.lib(); raw = HostSim._raw
+    raw.kai_hostsim_prep_error.restype = C.c_int
+
+    def verdict(snap, cfg):
+        st = snap.as_struct(); buf = C.create_string_buffer(256)
+        rc = raw.kai_hostsim_prep_error(C.byref(cfg), C.byref(st), buf, 256)
+        return rc, buf.value.decode()
+
+    def fresh():
+        snap, cfg, _ = T.pkg.synth.config(1, 8.0)   # 8 000 nodes x ~88 000 pods
+        for k in list(snap.arrays):                 # own copies: the cases below write into them
+            snap.arrays[k] = snap.arrays[k].copy()
+        return snap, cfg
+    snap, cfg = fresh()
+    P, J, S, Q = snap.n_pods, snap.n_jobs, snap.n_podsets, snap.n_queues
+    assert P >= 65536 and verdict(snap, cfg) == (0, "")
+    cases = [
+        (lambda a: a["pod_job"].__setitem__(P - 3, J), "pod_job out of range"),
+        (lambda a: (a["pod_job"].__setitem__(P - 3, J), a["podset_job"].__setitem__(S - 1, -1)), "podset_job out of range"),          # the pod-set loop runs first
+        (lambda a: (a["pod_job"].__setitem__(5, -7), a["pod_podset"].__setitem__(P - 1, S + 9)), "pod_job out of range"),            # lowest pod wins inside the pod loop
+        (lambda a: (a["pod_podset"].__setitem__(P - 1, S + 9), a["job_n_podsets"].__setitem__(J - 1, -1)), "job pod-set range out of bounds"),
+        (lambda a: a["job_queue"].__setitem__(J - 2, Q), "bad job_queue"),
+        (lambda a: a["job_queue"].__setitem__(J // 2, -5), "bad job_queue"),
+        (lambda a: a["job_first_pod"].__setitem__(J - 1, P), "job pod range out of bounds"),
+        (lambda a: a["job_first_pod"].__setitem__(J - 1, int(a["job_first_pod"][J - 2])), "job pod ranges overlap"),
+        (lambda a: a["node_name_rank"].__setitem__(7, int(a["node_name_rank"][8])), "node_name_rank must be a permutation of 0..N-1"),
+        (lambda a: a["queue_parent"].__setitem__(0, 0), "bad queue_parent"),
+    ]
+    for corrupt, want in cases:
+        snap, cfg = fresh()
+        if want == "job pod ranges overlap" and int(snap.arrays["job_n_pods"][J - 1]) == 0:
+            snap.arrays["job_n_pods"][J - 1] = 1
+        corrupt(snap.arrays)
+        rc, msg = verdict(snap, cfg)
+        assert rc != 0 and msg == want, (want, rc, msg)
