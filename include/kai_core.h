@@ -368,7 +368,10 @@ int kai_core_destroy(kai_core* core);
 
 /* replaces: framework.OpenSession + every OnSessionOpen on the path (framework/framework.go:32-65):
  * node accounting from the pods (api/node_info/node_info.go:457-493), proportion totals / queue usage /
- * fair-share division (plugins/proportion/proportion.go:242-423). */
+ * fair-share division (plugins/proportion/proportion.go:242-423).
+ * The snapshot's arrays are read during the call only.  The handle keeps what it derives from them on the host (name-rank permutation, job lists, scan
+ * classes: about 150 bytes per pod) and its device slabs for the next open, as a scheduler opens a session per cycle (scheduler.go:112-138); kai_core_destroy
+ * releases both.  The loops of the preparation run on a process-wide pool of worker threads (KAI_HOST_THREADS, KAI_HOST_POOL: INTEGRATION.md). */
 int kai_session_open(kai_core* core, const kai_snapshot_soa* snap);
 
 /* Re-opens the session from the snapshot copy that is already resident in HBM (no host traffic): same math as

@@ -960,6 +960,15 @@ void Session::allPodSets(PodGroupInfo* job, SubGroupSet* sgs, std::vector<PodSet
     for (int k : sgs->podSets) out.push_back(job->podSetByIdx(k));
     for (int g : sgs->groups) allPodSets(job, &groups[g], out);
 }
+// reverseLevelOrder (plugins/topology/topology_utils.go:20-55): the tree's levels from the root down (every level left to right, children in list order), emitted from the
+// deepest level up — pinned on TestReverseLevelOrder (tests/golden/kat_level_order.json)
+template <class ChildrenOf> static std::vector<int> reverseLevelOrder(int root, ChildrenOf&& childrenOf) {
+    std::vector<int> result; if (root < 0) return result;
+    std::vector<std::vector<int>> levels; std::vector<int> queue{root};
+    while (!queue.empty()) { levels.push_back(queue); std::vector<int> next; for (int d : queue) for (int c : childrenOf(d)) next.push_back(c); queue = next; }
+    for (int i = int(levels.size()) - 1; i >= 0; i--) result.insert(result.end(), levels[i].begin(), levels[i].end());
+    return result;
+}
 double Session::topologyNodeScore(PodInfo* task, NodeInfo* node, bool& err) {  // node_scoring.go:17-35, 88-99
     int key = -(task->podset + 1);
     for (;;) {
@@ -1121,9 +1130,7 @@ bool Session::SubsetNodesFn(PodGroupInfo* job, int key, const TopologyConstraint
     for (int l : relevantLevels) for (auto& d : domains) if (d.topo == t && d.level == l && relevant[d.id] && fits(&d)) { chosen[d.id] = 1; any = true; }
     if (!any) return true;
     // sortDomainInfos :526-542: bottom-up level order of the (sorted) tree from the topology root
-    std::vector<std::vector<int>> levels; { std::vector<int> q{rootId};
-      while (!q.empty()) { levels.push_back(q); std::vector<int> nx; for (int d : q) for (int c : domains[d].children) nx.push_back(c); q = nx; } }
-    for (int i = int(levels.size()) - 1; i >= 0; i--) for (int d : levels[i]) {
+    for (int d : reverseLevelOrder(rootId, [&](int x) -> const std::vector<int>& { return domains[x].children; })) {
         if (!chosen[d]) continue;
         std::vector<NodeInfo*> set; for (int n : domains[d].nodes) if (valid[n]) set.push_back(&nodes[n]);
         out.push_back(set);
@@ -1734,6 +1741,14 @@ int kai_oracle_subset_nodes(const kai_config* cfg, const kai_snapshot_soa* snap,
 }
 // … and what lowestCommonDomainID returned (plugins/topology/common.go:17-67; common_test.go TestLowestCommonDomainID): the domain's level inside the topology (-1 = the
 // root domain), its nodes as 0/1 in member_out[n], the valid nodes as 0/1 in valid_out[n] → 0, or -1 when the call never got there
+// reverseLevelOrder on a tree given as child lists (child_off[n + 1] offsets into children); root < 0 = the nil root.  Returns the number of ids written.
+int kai_oracle_reverse_level_order(int n, const int32_t* child_off, const int32_t* children, int root, int32_t* out, int cap) {
+    std::vector<std::vector<int>> kids((size_t)std::max(n, 0));
+    for (int d = 0; d < n; d++) kids[(size_t)d].assign(children + child_off[d], children + child_off[d + 1]);
+    const std::vector<int> order = orc::reverseLevelOrder(root < n ? root : -1, [&](int x) -> const std::vector<int>& { return kids[(size_t)x]; });
+    for (size_t i = 0; i < order.size() && (int)i < cap; i++) out[i] = order[i];
+    return (int)order.size();
+}
 int kai_oracle_lowest_common_domain(const kai_config* cfg, const kai_snapshot_soa* snap, int job, int32_t* level_out, uint8_t* member_out, uint8_t* valid_out) {
     if (!cfg || !snap || !level_out || !member_out || !valid_out || snap->abi_version != KAI_ABI_VERSION || job < 0 || job >= snap->n_jobs) return KAI_ERR_INVALID_ARG;
     orc::Session ssn; ssn.load(cfg, snap);

@@ -312,3 +312,23 @@ def test_topology_aware_idle_gpus_filter(case):
         return
     assert r == len(case["calls"]), r
     assert [bool(x) for x in out] == [c["want"] for c in case["calls"]], (case["name"], list(out))
+
+
+LEVEL_ORDER = T.load_golden("kat_level_order")
+
+
+@pytest.mark.parametrize("case", LEVEL_ORDER["cases"], ids=[f"{c['line']}:{c['name']}" for c in LEVEL_ORDER["cases"]])
+def test_reverse_level_order(case):
+    """reverseLevelOrder (plugins/topology/topology_utils.go:20-55) on the five trees of TestReverseLevelOrder (topology_utils_test.go:12-140; tools/go_kat_level_order.py): the order in
+    which the domains that can hold a job are tried (job_filtering.go:526-542) — the oracle's SubsetNodesFn walks the sorted domain tree with the same function."""
+    lib = T.Oracle.lib(); lib.kai_oracle_reverse_level_order.restype = C.c_int
+    n = len(case["ids"])
+    off = np.zeros(n + 1, np.int32); flat = []
+    for d, kids in enumerate(case["children"]):
+        off[d + 1] = off[d] + len(kids); flat += kids
+    flat = np.asarray(flat + [0], np.int32); out = np.full(max(n, 1), -1, np.int32)
+    got = lib.kai_oracle_reverse_level_order(n, off.ctypes.data_as(C.POINTER(C.c_int32)), flat.ctypes.data_as(C.POINTER(C.c_int32)), 0 if n else -1, out.ctypes.data_as(C.POINTER(C.c_int32)), max(n, 1))
+    if case["expected"] is None:
+        assert got == 0
+    else:
+        assert got == len(case["expected"]) and [case["ids"][i] for i in out[:got]] == case["expected"]
