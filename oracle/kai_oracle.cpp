@@ -1741,6 +1741,16 @@ int kai_oracle_subset_nodes(const kai_config* cfg, const kai_snapshot_soa* snap,
 }
 // … and what lowestCommonDomainID returned (plugins/topology/common.go:17-67; common_test.go TestLowestCommonDomainID): the domain's level inside the topology (-1 = the
 // root domain), its nodes as 0/1 in member_out[n], the valid nodes as 0/1 in valid_out[n] → 0, or -1 when the call never got there
+// api/podgroup_info/subgroup_info/podset.go on podset_test.go's cases: NewPodSet(min_available), AssignTask for pods (uid, status) in order; out[8] = IsReadyForScheduling, IsGangSatisfied,
+// IsElastic, GetNumActiveAllocatedTasks, GetNumActiveUsedTasks, GetNumAliveTasks, GetNumGatedTasks, GetNumPendingTasks
+int kai_oracle_podset_kat(int min_available, const int32_t* uid, const int32_t* status, int n, int32_t* out) {
+    orc::PodSet ps; ps.minAvailable = min_available;
+    std::vector<orc::PodInfo> pods((size_t)std::max(n, 0));
+    for (int i = 0; i < n; i++) { pods[(size_t)i].idx = uid[i]; pods[(size_t)i].status = status[i]; ps.AssignTask(&pods[(size_t)i]); }
+    out[0] = ps.IsReadyForScheduling(); out[1] = ps.IsGangSatisfied(); out[2] = ps.IsElastic(); out[3] = ps.numActiveAllocatedTasks; out[4] = ps.numActiveUsedTasks;
+    out[5] = ps.numAliveTasks; out[6] = ps.numGated; out[7] = ps.GetNumPendingTasks();
+    return 0;
+}
 // reverseLevelOrder on a tree given as child lists (child_off[n + 1] offsets into children); root < 0 = the nil root.  Returns the number of ids written.
 int kai_oracle_reverse_level_order(int n, const int32_t* child_off, const int32_t* children, int root, int32_t* out, int cap) {
     std::vector<std::vector<int>> kids((size_t)std::max(n, 0));

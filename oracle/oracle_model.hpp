@@ -176,6 +176,7 @@ struct PodSet {
     bool IsReadyForScheduling() const { return int32_t(numAliveTasks - numGated) >= minAvailable; }  // podset.go:114-120
     bool IsGangSatisfied() const { return numActiveUsedTasks >= int(minAvailable); }                 // podset.go:122-125
     bool IsElastic() const { return minAvailable < int32_t(podInfos.size()); }
+    int GetNumPendingTasks() const { int n = 0; for (auto& kv : podStatusMap) if (kv.second == Pending) n++; return n; }  // podset.go:147-149 (len of the status index's Pending entry)
 };
 
 // ---------------------------------------------------------------- api/podgroup_info/subgroup_info/subgroupset.go

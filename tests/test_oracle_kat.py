@@ -586,3 +586,20 @@ def test_scenario_objects(case):
         if w: assert sorted([j, p["name"]] for j, ps in by_job.items() if j == w["job"] for p in ps) == sorted(w["tasks"])  # the session's whole job (getJobForTask), as the table spells it out
     else:
         assert sorted(name_of[x] for x in r[1:1 + r[0]]) == sorted(w), r  # (map order in the reference: compared as sets; the tables' cases have one job each)
+
+
+PODSET = T.load_golden("kat_podset")
+
+
+@pytest.mark.parametrize("case", PODSET["cases"], ids=[f"{c['line']}:{c['question']}:{c['name']}" for c in PODSET["cases"]])
+def test_podset_gang_counters(case):
+    """PodSet.AssignTask and the questions the gang logic asks of a pod-set (podset.go:56-149) on the sixteen cases of podset_test.go (tools/go_kat_podset.py): ready for scheduling,
+    gang satisfied, elastic, and the active-allocated / active-used / alive / gated / pending counts by pod status (pod_status.go:25-71)."""
+    import ctypes as C
+    lib = T.Oracle.lib(); lib.kai_oracle_podset_kat.restype = C.c_int
+    uid = np.asarray([int(u) for u, _ in case["pods"]] + [0], np.int32); st = np.asarray([T.abi.POD_STATUS[s] for _, s in case["pods"]] + [0], np.int32)
+    out = np.zeros(8, np.int32)
+    assert lib.kai_oracle_podset_kat(case["minAvailable"], uid.ctypes.data_as(C.POINTER(C.c_int32)), st.ctypes.data_as(C.POINTER(C.c_int32)), len(case["pods"]), out.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    which = ("IsReadyForScheduling", "IsGangSatisfied", "IsElastic", "GetNumActiveAllocatedTasks", "GetNumActiveUsedTasks", "GetNumAliveTasks", "GetNumGatedTasks", "GetNumPendingTasks").index(case["question"])
+    want = case["expected"]
+    assert (bool(out[which]) == want) if isinstance(want, bool) else (int(out[which]) == want)
