@@ -846,3 +846,15 @@ def test_mig_node_and_legacy_mig_pod():
     assert s.pod_req[row[0], names.index("new")] == 2 and s.pod_req[row[0], names.index("legacy")] == 1
     assert s.pod_flags[names.index("legacy")] & abi.POD_LEGACY_MIG and not s.pod_flags[names.index("new")] & abi.POD_LEGACY_MIG
     assert not s.pod_flags[names.index("new")] & abi.POD_CPU_FALLBACK
+
+
+NODE_CONDITIONS = T.load_golden("kat_node_conditions")
+
+
+@pytest.mark.parametrize("case", NODE_CONDITIONS["cases"], ids=[f"{c['line']}:{c['test']}" for c in NODE_CONDITIONS["cases"]])
+def test_node_condition_predicate_reference_cases(case):
+    """CheckNodeConditionPredicate (scheduler_util/scheduler_utils.go:12-40; predicates.go's node-readiness Filter) on the nine cases of scheduler_utils_test.go
+    (tools/go_kat_node_conditions.py): the ingest turns a node's conditions and spec.unschedulable into KAI_NODE_NOT_READY, the flag the device path's static predicate reads."""
+    n = node("n", spec={"unschedulable": True} if case["unschedulable"] else {}, status={"conditions": [{"type": t, "status": s} for t, s in case["conditions"]]})
+    s = ingest(doc(nodes=[n])).snapshot
+    assert bool(int(s.node_flags[0]) & abi.NODE_NOT_READY) == (not case["ready"])
