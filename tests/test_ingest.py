@@ -858,3 +858,34 @@ def test_node_condition_predicate_reference_cases(case):
     n = node("n", spec={"unschedulable": True} if case["unschedulable"] else {}, status={"conditions": [{"type": t, "status": s} for t, s in case["conditions"]]})
     s = ingest(doc(nodes=[n])).snapshot
     assert bool(int(s.node_flags[0]) & abi.NODE_NOT_READY) == (not case["ready"])
+
+
+MAX_NODE = T.load_golden("kat_max_node_resources")
+
+
+@pytest.mark.parametrize("case", MAX_NODE["cases"], ids=[f"{c['line']}:{c['name']}" for c in MAX_NODE["cases"]])
+def test_max_node_resources_reference_cases(case):
+    """MaxNodeResourcesPredicate.PreFilter (k8s_internal/predicates/maxNodeResources.go:59-96: a pod that asks for more of a resource than any ONE node has allocatable is unschedulable)
+    on the six non-DRA cases of Test_podToMaxNodeResourcesFiltering (tools/go_kat_max_node_resources.py).  The path does not restate the pre-predicate — the per-node fit reaches the same
+    verdict (actions/common/allocate.go:121-163) — so the cases are run END TO END: ingest (quantities, the pod's request over its containers, the extra resource column for ephemeral
+    storage, the fraction annotation), then the allocate action in the oracle and on the host-compiled engine: the pod is placed exactly when the reference's PreFilter lets it through
+    (the one schedulable case also fits a single node).  For whole-quantity requests the element-wise-maximum statement itself is checked on the ingested arrays."""
+    from test_engine_hostsim import HostSim
+    nodes = []
+    for name, al in case["nodes"].items():
+        extra = {k: v for k, v in al.items() if k not in ("cpu", "memory", "pods", "nvidia.com/gpu")}
+        nodes.append(node(name, cpu=al["cpu"], mem=al["memory"], gpu=al.get("nvidia.com/gpu"), pods=al["pods"], alloc=extra))
+    ann = {k: v for k, v in case["annotations"].items() if k != "pod-group-name"}
+    p = pod("name1", group="pg", requests=case["containers"][0], annotations=ann)
+    p["spec"]["containers"] = [{"name": f"c{i + 1}", "resources": {"requests": r}} for i, r in enumerate(case["containers"])]
+    got = ingest(doc(nodes=nodes, pods=[p], queues=[queue("q")], pod_groups=[pod_group("pg")]))
+    s, cfg = got.snapshot, got.config
+    assert s.n_pods == 1 and int(s.pod_status[0]) == ST["Pending"] and int(s.pod_job[0]) == 0
+    ref = T.Oracle.run(s, cfg, ("allocate",))
+    placed = any(o[0] in (0, 1) and o[1] == 0 for o in ref.ops)
+    assert placed == case["schedulable"], (case["name"], ref.ops)
+    res = HostSim.run(s, cfg, ("allocate",))
+    assert [tuple(o) for o in res.ops] == ref.ops
+    if "gpu-fraction" not in case["annotations"]:
+        fits_max = all(float(s.pod_req[r, 0]) <= float(s.node_allocatable[r].max()) for r in range(s.n_res))
+        assert fits_max == case["schedulable"]
