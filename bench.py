@@ -414,14 +414,15 @@ def main():
         # required rack, 5 % elastic, minruntime on — and config 3 with 30 % of its one-GPU pods as fractions of a device; both run on the sequential engine with its passes
         # over the nodes on the scan grid.  One warm-up + one timed cycle each; additional evidence, never part of `value`.
         shapes = {}
-        for key, (i2, kw, frac) in {"c5_mixed": (4, {"mixed": True}, 0.0), "c3_fractions_30": (2, {}, 0.3)}.items():
+        # (+ BASELINE configs 2 and 3 as they are — batch path, plan / fill / apply rounds —, so that the driver-run line holds every single-GPU configuration of BASELINE.json)
+        for key, (i2, kw, frac) in {"c5_mixed": (4, {"mixed": True}, 0.0), "c3_fractions_30": (2, {}, 0.3), "c3": (2, {}, 0.0), "c2": (1, {}, 0.0)}.items():
             try:
                 s2, c2, d2 = pkg.synth.config(i2, 1.0, **kw)
                 if frac > 0:
                     pkg.synth.add_fractions(s2, 7, frac=frac)
                 core2 = pkg.KaiCore(c2, gpu_ids=(dev_index,)); ssn2 = core2.open_session(s2)
                 n2 = 0; ops2 = None
-                for it in range(2):
+                for it in range(2 if key in ("c5_mixed", "c3_fractions_30") else 4):  # (the last cycle is the one reported)
                     ssn2.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
                     ops2 = ssn2.execute("allocate"); n2 = len(ops2); torch.cuda.synchronize(); el = time.perf_counter() - t0
                 st2 = ssn2.stats()
