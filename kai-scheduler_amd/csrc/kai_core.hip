@@ -609,7 +609,8 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
         for (int n = 0; n < N; n++) gm[n] = s->node_gpu_memory ? s->node_gpu_memory[prep.perm[n]] : 100;
         c.quota_on = sp.on ? 1 : 0; c.mig_on = sp.mig ? 1 : 0;
         for (int r = 0; r < KAI_MAX_RES; r++) { c.res_mig_g[r] = sp.mig_g[r]; c.res_mig_m[r] = sp.mig_m[r]; }
-        TRY(dupload_f(core, c.p_shared, sp.shared.data(), (size_t)P)); TRY(dupload_f(core, c.p_kind, sp.kind.data(), (size_t)P));
+        // (both ways allocate the arrays in ONE order — the session's layout in HBM does not depend on what is sent; tests/test_open_uploads.py compares the images)
+        TRY(dupload_f(core, c.p_shared, sp.shared.data(), (size_t)P));
         const size_t P1 = (size_t)std::max(P, 1);
         bool por_zero = true;  // pod_gpu_portion absent, or +0.0 in every element (what a packer that always fills the array sends for a cluster without fractions)
         if (!sp.on && s->pod_gpu_portion) {
@@ -617,33 +618,36 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
             parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) { for (size_t p = p0; p < p1; p++) { uint64_t b; std::memcpy(&b, &s->pod_gpu_portion[p], 8); if (b) { nz[(size_t)ci] = 1; return; } } });
             for (char x : nz) if (x) por_zero = false;
         }
-        if (!sp.on && por_zero && !full_uploads) {
-            // A snapshot without shared-GPU requests and without MIG rows (SharedPods: neither `any` nor `mig`): the per-pod quantities of the shared-GPU model are constants —
-            // no memory of a device asked for, no MIG quota, every GPU quantity the pod's GPU request (the row of p_req that is in HBM already), no group anywhere.  They are
-            // written where they are read instead of being sent: at config 5 these twelve arrays are 73 of the open's 190 MB over PCIe.  (kai_hostsim_run checks the same
-            // statement about SharedPods on every snapshot the CPU suite runs: tests/host_sim/host_sim.cpp lean_shared_pods_hold.)
-            TRY(dzero_f(core, c.p_mem, (size_t)P)); TRY(dzero_f(core, c.p_gmem, (size_t)P)); TRY(dzero_f(core, c.p_mig_q, (size_t)P)); TRY(dzero_f(core, c.p_portion, (size_t)P));
-            TRY(dalloc_f(core, c.p_acc_gpu, (size_t)P)); TRY(dalloc_f(core, c.p_pend_gpu, (size_t)P)); TRY(dalloc_f(core, c.p_quota_gpu, (size_t)P));
-            if (P) {
-                const double* gpu_row = (const double*)KAI_VP(c.p_req) + (size_t)KAI_RES_GPU * P;
-                HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_acc_gpu), gpu_row, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, core->stream));
-                HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_pend_gpu), gpu_row, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, core->stream));
-                HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.p_quota_gpu), gpu_row, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, core->stream));
-            }
-            TRY(dalloc_f(core, c.p_group, (size_t)P)); TRY(dalloc_f(core, c.p_on_group, (size_t)P));
-            HIP_TRY(core, hipMemsetAsync(KAI_VP(c.p_group), 0xFF, P1 * sizeof(int32_t), core->stream));     // -1 in every element
-            HIP_TRY(core, hipMemsetAsync(KAI_VP(c.p_on_group), 0xFF, P1 * sizeof(int32_t), core->stream));
-            { int32_t* t = nullptr; TRY(dalloc(core, &t, P1)); HIP_TRY(core, hipMemsetAsync(t, 0xFF, P1 * sizeof(int32_t), core->stream)); core->d_group0 = t; }
-        } else {
-            std::vector<double> por(P1, 0.0); std::vector<int32_t> grp(P1, -1), minus1(P1, -1);
+        // A snapshot without shared-GPU requests and without MIG rows (SharedPods: neither `any` nor `mig`): the per-pod quantities of the shared-GPU model are constants —
+        // no memory of a device asked for, no MIG quota, every GPU quantity the pod's GPU request (the row of p_req that is in HBM already), no group anywhere.  They are
+        // written where they are read instead of being sent: at config 5 these arrays are 73 of the open's 190 MB over PCIe.  (kai_hostsim_run checks the same statement
+        // about SharedPods on every snapshot the CPU suite runs: tests/host_sim/host_sim.cpp lean_shared_pods_hold.)
+        const bool lean_pods = !sp.on && por_zero && !full_uploads;
+        std::vector<double> por; std::vector<int32_t> grp, minus1;
+        if (!lean_pods) {
+            por.assign(P1, 0.0); grp.assign(P1, -1); minus1.assign(P1, -1);
             for (int p = 0; p < P; p++) { por[p] = s->pod_gpu_portion ? s->pod_gpu_portion[p] : 0.0; grp[p] = (s->pod_gpu_group && sp.shared[p]) ? s->pod_gpu_group[p] : -1; if (grp[p] >= next_new) next_new = grp[p] + 1; }
+        }
+        auto ones = [&](auto& field, size_t n) -> int { int rc2 = dalloc_f(core, field, n); if (rc2) return rc2; HIP_TRY(core, hipMemsetAsync(KAI_VP(field), 0xFF, std::max<size_t>(n, 1) * sizeof(*field), core->stream)); return KAI_OK; };  // -1 in every element
+        auto gpu_row = [&](auto& field) -> int {  // the pods' GPU requests: a device-to-device copy of that row of p_req
+            int rc2 = dalloc_f(core, field, (size_t)P); if (rc2) return rc2;
+            if (P) HIP_TRY(core, hipMemcpyAsync(KAI_VP(field), (const double*)KAI_VP(c.p_req) + (size_t)KAI_RES_GPU * P, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, core->stream));
+            return KAI_OK; };
+        if (lean_pods) {
+            TRY(dzero_f(core, c.p_mem, (size_t)P)); TRY(dzero_f(core, c.p_gmem, (size_t)P));
+            TRY(gpu_row(c.p_acc_gpu)); TRY(gpu_row(c.p_pend_gpu)); TRY(gpu_row(c.p_quota_gpu));
+            TRY(dzero_f(core, c.p_mig_q, (size_t)P));
+        } else {
             TRY(dupload_f(core, c.p_mem, sp.mem.data(), (size_t)P)); TRY(dupload_f(core, c.p_gmem, sp.gmem.data(), (size_t)P));
             TRY(dupload_f(core, c.p_acc_gpu, sp.acc_gpu.data(), (size_t)P)); TRY(dupload_f(core, c.p_pend_gpu, sp.pend_gpu.data(), (size_t)P));
             TRY(dupload_f(core, c.p_quota_gpu, sp.quota_gpu.data(), (size_t)P)); TRY(dupload_f(core, c.p_mig_q, sp.mig_q.data(), (size_t)P));
-            TRY(dupload_f(core, c.p_portion, por.data(), (size_t)P)); TRY(dupload_f(core, c.p_group, grp.data(), (size_t)P)); TRY(dupload_f(core, c.p_on_group, minus1.data(), (size_t)P));
-            { const int32_t* t; TRY(dupload(core, &t, grp.data(), P1)); core->d_group0 = const_cast<int32_t*>(t); }
         }
+        TRY(dupload_f(core, c.p_kind, sp.kind.data(), (size_t)P));
+        if (lean_pods) { TRY(dzero_f(core, c.p_portion, (size_t)P)); TRY(ones(c.p_group, (size_t)P)); TRY(ones(c.p_on_group, (size_t)P)); }
+        else { TRY(dupload_f(core, c.p_portion, por.data(), (size_t)P)); TRY(dupload_f(core, c.p_group, grp.data(), (size_t)P)); TRY(dupload_f(core, c.p_on_group, minus1.data(), (size_t)P)); }
         TRY(dupload_f(core, c.n_gpu_mem, gm.data(), (size_t)N));
+        if (lean_pods) { int32_t* t = nullptr; TRY(dalloc(core, &t, P1)); HIP_TRY(core, hipMemsetAsync(t, 0xFF, P1 * sizeof(int32_t), core->stream)); core->d_group0 = t; }
+        else { const int32_t* t; TRY(dupload(core, &t, grp.data(), P1)); core->d_group0 = const_cast<int32_t*>(t); }
         TRY(dalloc_f(core, c.ng_id, (size_t)N * KAI_GMAX)); TRY(dzero_f(core, c.ng_used, (size_t)N * KAI_GMAX)); TRY(dzero_f(core, c.ng_rel, (size_t)N * KAI_GMAX)); TRY(dzero_f(core, c.ng_alloc, (size_t)N * KAI_GMAX));
         TRY(dzero_f(core, c.ng_mark, (size_t)N)); TRY(dzero_f(core, c.ng_has_alloc, (size_t)N));
         TRY(dupload_f(core, c.next_new_group, &next_new, (size_t)1)); core->next_group0 = next_new;
@@ -671,25 +675,28 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
       TRY(dzero_f(core, c.dom_alloc_pods, DT)); TRY(dzero_f(core, c.dom_free, DT * KAI_MAX_RES)); TRY(dzero_f(core, c.dom_tmp, 3 * DT + 4)); TRY(dzero_f(core, c.dom_ratio, DT)); TRY(dzero_f(core, c.dom_key, 2 * DT));
       TRY(dzero_f(core, c.ns_bits, (size_t)KAI_TDEPTH * std::max(c.W, 1))); TRY(dzero_f(core, c.ns_sets, (size_t)KAI_TDEPTH * (DT + 1)));
       TRY(dzero_f(core, c.sg_score, (size_t)KAI_TKEYS * std::max<size_t>(DT, 1))); TRY(dzero_f(core, c.sg_key, (size_t)KAI_TKEYS)); TRY(dzero_f(core, c.sg_row, (size_t)KAI_TKEYS)); }
-    TRY(dupload_f(core, c.g_job, prep.g_job.data(), prep.g_job.size())); TRY(dupload_f(core, c.j_root_group, prep.j_root_group.data(), prep.j_root_group.size()));
-    TRY(dupload_f(core, c.g_children, prep.g_children.data(), prep.g_children.size()));
-    if (prep.groups_default && !full_uploads) {
-        // no sub-group tree in the snapshot (HostPrep::build_topology's identity tables: one root group per job, G = J): no parent, no topology, no required / preferred level
-        // anywhere (-1), name rank 0, no children, and a pod-set's group is its job — constants written on the device, the pod-sets' groups copied from s_job (in HBM already)
+    {   // no sub-group tree in the snapshot (HostPrep::build_topology's identity tables: one root group per job, G = J): no parent, no topology, no required / preferred level
+        // anywhere (-1), name rank 0, no children, and a pod-set's group is its job — constants written on the device, the pod-sets' groups copied from s_job (in HBM already).
+        // (One allocation order either way: the session's layout in HBM does not depend on what is sent.)
+        const bool lean_groups = prep.groups_default && !full_uploads;
         auto minus_one = [&](auto& field, size_t n) -> int { int rc2 = dalloc_f(core, field, n); if (rc2) return rc2; HIP_TRY(core, hipMemsetAsync(KAI_VP(field), 0xFF, std::max<size_t>(n, 1) * sizeof(*field), core->stream)); return KAI_OK; };
-        TRY(minus_one(c.g_parent, (size_t)J)); TRY(minus_one(c.g_topo, (size_t)J)); TRY(minus_one(c.g_req, (size_t)J)); TRY(minus_one(c.g_pref, (size_t)J));
-        TRY(minus_one(c.s_topo, (size_t)S)); TRY(minus_one(c.s_req, (size_t)S)); TRY(minus_one(c.s_pref, (size_t)S));
-        TRY(dzero_f(core, c.g_name_rank, (size_t)J)); TRY(dzero_f(core, c.g_child_off, (size_t)J + 1)); TRY(dzero_f(core, c.j_has_topology, (size_t)std::max(J, 1)));
-        TRY(dalloc_f(core, c.s_group, (size_t)S));
-        if (S) HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.s_group), KAI_VP(c.s_job), (size_t)S * sizeof(int32_t), hipMemcpyDeviceToDevice, core->stream));
-    } else {
-        TRY(dupload_f(core, c.g_parent, prep.g_parent.data(), prep.g_parent.size()));
-        TRY(dupload_f(core, c.g_name_rank, prep.g_name_rank.data(), prep.g_name_rank.size())); TRY(dupload_f(core, c.g_topo, prep.g_topo.data(), prep.g_topo.size()));
-        TRY(dupload_f(core, c.g_req, prep.g_req.data(), prep.g_req.size())); TRY(dupload_f(core, c.g_pref, prep.g_pref.data(), prep.g_pref.size()));
-        TRY(dupload_f(core, c.g_child_off, prep.g_child_off.data(), prep.g_child_off.size()));
-        TRY(dupload_f(core, c.s_group, prep.s_group.data(), prep.s_group.size())); TRY(dupload_f(core, c.s_topo, prep.s_topo.data(), prep.s_topo.size()));
-        TRY(dupload_f(core, c.s_req, prep.s_req.data(), prep.s_req.size())); TRY(dupload_f(core, c.s_pref, prep.s_pref.data(), prep.s_pref.size()));
-        TRY(dupload_f(core, c.j_has_topology, prep.j_has_topology.data(), prep.j_has_topology.size()));
+        TRY(dupload_f(core, c.g_job, prep.g_job.data(), prep.g_job.size()));
+        if (lean_groups) { TRY(minus_one(c.g_parent, (size_t)J)); TRY(dzero_f(core, c.g_name_rank, (size_t)J)); TRY(minus_one(c.g_topo, (size_t)J)); TRY(minus_one(c.g_req, (size_t)J)); TRY(minus_one(c.g_pref, (size_t)J)); }
+        else { TRY(dupload_f(core, c.g_parent, prep.g_parent.data(), prep.g_parent.size())); TRY(dupload_f(core, c.g_name_rank, prep.g_name_rank.data(), prep.g_name_rank.size())); TRY(dupload_f(core, c.g_topo, prep.g_topo.data(), prep.g_topo.size()));
+               TRY(dupload_f(core, c.g_req, prep.g_req.data(), prep.g_req.size())); TRY(dupload_f(core, c.g_pref, prep.g_pref.data(), prep.g_pref.size())); }
+        TRY(dupload_f(core, c.j_root_group, prep.j_root_group.data(), prep.j_root_group.size()));
+        if (lean_groups) TRY(dzero_f(core, c.g_child_off, (size_t)J + 1)); else TRY(dupload_f(core, c.g_child_off, prep.g_child_off.data(), prep.g_child_off.size()));
+        TRY(dupload_f(core, c.g_children, prep.g_children.data(), prep.g_children.size()));
+        if (lean_groups) {
+            TRY(dalloc_f(core, c.s_group, (size_t)S));
+            if (S) HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.s_group), KAI_VP(c.s_job), (size_t)S * sizeof(int32_t), hipMemcpyDeviceToDevice, core->stream));
+            TRY(minus_one(c.s_topo, (size_t)S)); TRY(minus_one(c.s_req, (size_t)S)); TRY(minus_one(c.s_pref, (size_t)S));
+            TRY(dzero_f(core, c.j_has_topology, (size_t)std::max(J, 1)));
+        } else {
+            TRY(dupload_f(core, c.s_group, prep.s_group.data(), prep.s_group.size())); TRY(dupload_f(core, c.s_topo, prep.s_topo.data(), prep.s_topo.size()));
+            TRY(dupload_f(core, c.s_req, prep.s_req.data(), prep.s_req.size())); TRY(dupload_f(core, c.s_pref, prep.s_pref.data(), prep.s_pref.size()));
+            TRY(dupload_f(core, c.j_has_topology, prep.j_has_topology.data(), prep.j_has_topology.size()));
+        }
     }
 
     // ---- dynamic state

@@ -1,0 +1,92 @@
+"""What kai_session_open leaves in device memory, on a machine without a GPU.
+
+kai_session_open does not SEND every array of the session: constants of the snapshot (the shared-GPU model's per-pod arrays when nothing asks for a shared GPU, the identity tables
+of a snapshot without sub-group trees, "no nominated node", absent optional arrays) are written on the device by memsets and device-to-device copies.  This test runs the library's
+HOST side for real — kai_core.hip compiled host-only (hipcc --cuda-host-only, seconds) and linked with tests/host_sim/fake_hip.cpp instead of libamdhip64: device memory is host
+memory, copies and memsets happen at the call, kernels do nothing — and compares the image a default open leaves in "device" memory with the image of KAI_OPEN_FULL_UPLOADS=1
+(every array sent from the host, as the library did before): byte for byte the same on every shape, with fewer bytes over the bus."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+DRIVER = r'''
+import ctypes as C, json, sys
+sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0, ROOT)
+import kai_testlib as T
+lib = C.CDLL(LIB)
+lib.kai_last_error.restype = C.c_char_p; lib.kai_last_error.argtypes = [C.c_void_p]
+syn = T.pkg.synth
+def shapes():
+    yield "C1", syn.config(0)[:2]
+    yield "C2", syn.config(1, 1.0)[:2]
+    yield "C3 at 30 %", syn.config(2, 0.3)[:2]
+    yield "C5 at 5 %", syn.config(4, 0.05)[:2]
+    yield "C5-mixed at 3 %", syn.config(4, 0.03, mixed=True)[:2]
+    s, c, _ = syn.config(1, 0.5); syn.add_fractions(s, 7, frac=0.3); yield "C2 at 50 % with fractions", (s, c)
+    s, c, _ = syn.config(1, 0.2); import numpy as np; s.arrays["pod_gpu_portion"] = np.zeros(s.n_pods); yield "C2 at 20 %, a portion array of zeros", (s, c)
+    for seed in (11, 12):
+        for ci, (snap, cfg, acts) in enumerate(T.broad_case(seed)):
+            yield f"broad {seed}/{ci}", (snap, cfg)
+out = {}
+for name, (snap, cfg) in shapes():
+    h = C.c_void_p()
+    assert lib.kai_core_create(C.byref(cfg), 1, None, C.byref(h)) == 0
+    st = snap.as_struct()
+    rc = lib.kai_session_open(h, C.byref(st))
+    assert rc == 0, (name, rc, lib.kai_last_error(h))
+    img = (C.c_uint64 * 8)(); lib.fakehip_image(img)
+    out[name] = [int(x) for x in img]
+    lib.kai_core_destroy(h)
+print(json.dumps(out))
+'''
+
+
+@pytest.fixture(scope="module")
+def fake_lib(tmp_path_factory):
+    if not os.path.exists(HIPCC) or shutil.which("g++") is None:
+        pytest.skip("hipcc / g++ not available")
+    d = tmp_path_factory.mktemp("fakehip")
+    obj, shim, stub, lib = str(d / "kai_core_host.o"), str(d / "fake_hip.o"), str(d / "fatbin_stub.c"), str(d / "libkai_core_fakehip.so")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "--cuda-host-only", "-O1", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", "-o", obj,
+                           os.path.join(ROOT, "kai-scheduler_amd", "csrc", "kai_core.hip")], stderr=subprocess.DEVNULL)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-I/opt/rocm/include", "-c", "-o", shim, os.path.join(ROOT, "tests", "host_sim", "fake_hip.cpp")])
+    undefined = subprocess.check_output(["nm", obj], text=True)
+    fat = [ln.split()[-1] for ln in undefined.splitlines() if " U __hip_fatbin" in ln]
+    with open(stub, "w") as f:
+        f.write("".join(f"const char {name}[16] = {{0}};\n" for name in fat))
+    subprocess.check_call(["g++", "-shared", "-o", lib, obj, shim, "-x", "c", stub, "-lpthread", "-ldl"])
+    return lib
+
+
+def _images(lib, env):
+    e = dict(os.environ); e.pop("KAI_OPEN_FULL_UPLOADS", None); e.update(env)
+    code = f"ROOT = {ROOT!r}\nLIB = {lib!r}\n" + DRIVER
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_device_image_of_an_open_does_not_depend_on_what_is_sent(fake_lib):
+    lean = _images(fake_lib, {})
+    full = _images(fake_lib, {"KAI_OPEN_FULL_UPLOADS": "1"})
+    assert lean.keys() == full.keys() and len(lean) >= 9
+    saved = 0
+    for name in lean:
+        h, n_alloc, n_bytes, launches, h2d, h2d_bytes, d2d, memsets = lean[name]
+        fh, fn_alloc, fn_bytes, flaunches, fh2d, fh2d_bytes, fd2d, fmemsets = full[name]
+        assert (h, n_alloc, n_bytes, launches) == (fh, fn_alloc, fn_bytes, flaunches), name   # the same image, the same allocations, the same kernels
+        assert h2d_bytes <= fh2d_bytes, name
+        saved += fh2d_bytes - h2d_bytes
+    assert saved > 0  # some shape has constants the default open does not send
+    # a snapshot without shared GPUs and sub-group trees sends markedly less
+    assert lean["C5 at 5 %"][5] < 0.7 * full["C5 at 5 %"][5]
+    # KAI_HOST_POOL=0 / one host thread: the same images (the preparation's outputs do not depend on how its loops run)
+    assert _images(fake_lib, {"KAI_HOST_THREADS": "1"}) == lean
+    assert _images(fake_lib, {"KAI_HOST_POOL": "0", "KAI_HOST_THREADS": "5"}) == lean
