@@ -72,6 +72,8 @@ struct kai_core {
     // kai_session_open's host preparation, kept with the handle: a scheduler opens a session per cycle, and arrays that keep their memory are not mapped and page-faulted
     // in again every cycle (config 5: ~150 MB of host memory stays with the handle; build() rewrites every element it hands out)
     HostPrep prep; SharedPods sp;
+    // pinned host staging for the snapshot's own arrays (kai_session_open, UploadStage): grows, lives with the handle
+    void* up_pin = nullptr; size_t up_pin_bytes = 0;
 };
 
 #define HIP_TRY(core, expr)                                                                                        \
@@ -148,6 +150,39 @@ int dupload_f(kai_core* core, F& field, const T* host, size_t n) {
     if (n) HIP_TRY(core, hipMemcpyAsync(KAI_VP(field), host, n * sizeof(T), hipMemcpyHostToDevice, core->stream));
     return KAI_OK;
 }
+// The snapshot's own arrays (nothing the host preparation derives) go up FIRST and from pinned memory: add() allocates the device array, flush() copies the host arrays into the
+// handle's pinned staging buffer on the host's cores and enqueues one DMA per array — which then runs while kai_session_open's host preparation (milliseconds of loops over the same
+// pods and jobs) keeps the cores busy.  hipMemcpyAsync from the caller's pageable arrays, as every other upload of the open is made, stages through the runtime's own bounce buffers on
+// the calling thread and returns when the data has left the host: ~27 GB/s and nothing else happens meanwhile.  Below 4 MB (nearly every session of the test suites) and with
+// KAI_OPEN_NO_STAGING the arrays are sent that way, in the same order to the same places.
+struct UploadStage {
+    kai_core* core; struct Seg { void* dst; const void* src; size_t bytes, off; }; std::vector<Seg> segs; size_t total = 0;
+    template <class F, class T> int add(F& field, const T* host, size_t n) {
+        static_assert(sizeof(*field) == sizeof(T), "element size");
+        int rc = dalloc_f(core, field, n); if (rc) return rc;
+        if (n) { segs.push_back({KAI_VP(field), host, n * sizeof(T), total}); total += (n * sizeof(T) + 255) & ~(size_t)255; }
+        return KAI_OK;
+    }
+    int flush() {
+        bool pinned = total >= ((size_t)4 << 20) && !std::getenv("KAI_OPEN_NO_STAGING");
+        if (pinned && total > core->up_pin_bytes) {
+            if (core->up_pin) { (void)hipHostFree(core->up_pin); core->up_pin = nullptr; core->up_pin_bytes = 0; }
+            const size_t want = total + total / 4;
+            if (hipHostMalloc(&core->up_pin, want, hipHostMallocDefault) == hipSuccess) core->up_pin_bytes = want; else { core->up_pin = nullptr; pinned = false; (void)hipGetLastError(); }  // (no pinned memory to be had: the plain way)
+        }
+        if (pinned) {
+            char* pin = static_cast<char*>(core->up_pin);
+            parallel_chunks(total, [&](int, size_t a, size_t b) {  // byte range [a, b) of the staging buffer: the pieces of the arrays that fall into it
+                for (const Seg& g : segs) { const size_t lo = std::max(a, g.off), hi = std::min(b, g.off + g.bytes); if (lo < hi) std::memcpy(pin + lo, static_cast<const char*>(g.src) + (lo - g.off), hi - lo); }
+            }, (size_t)1 << 20);
+            for (const Seg& g : segs) HIP_TRY(core, hipMemcpyAsync(g.dst, pin + g.off, g.bytes, hipMemcpyHostToDevice, core->stream));
+        } else {
+            for (const Seg& g : segs) HIP_TRY(core, hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, core->stream));
+        }
+        segs.clear(); total = 0;
+        return KAI_OK;
+    }
+};
 // RCCL, resolved at run time (the library loads without it; only kai_shard_attach_rccl needs it).  Prototypes as in rccl/rccl.h: ncclUniqueId is 128 opaque bytes passed BY VALUE,
 // ncclUint8 = 1, ncclSuccess = 0.
 struct RcclId { char internal[128]; };
@@ -461,6 +496,7 @@ int kai_core_destroy(kai_core* core) {
     (void)hipSetDevice(core->device);
     free_session(core, true);
     if (core->pin_buf) { (void)hipHostFree(core->pin_buf); core->pin_buf = nullptr; core->pin_bytes = 0; }
+    if (core->up_pin) { (void)hipStreamSynchronize(core->stream); (void)hipHostFree(core->up_pin); core->up_pin = nullptr; core->up_pin_bytes = 0; }
     if (core->rccl_comm) { (void)hipStreamSynchronize(core->stream); if (RcclApi* a = rccl_api()) (void)a->CommDestroy(core->rccl_comm); core->rccl_comm = nullptr; }
     if (core->mail) (void)hipHostFree(core->mail);
     if (core->xpin) (void)hipHostFree(core->xpin);
@@ -494,7 +530,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     const auto t_freed = tnow();
     const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues, R = s->n_res;
     if (N < 0 || P < 0 || S < 0 || J < 0 || Q < 0) return fail(core, KAI_ERR_INVALID_ARG, "negative dimension");
-    if (P > 0 && !s->pod_status) return fail(core, KAI_ERR_INVALID_ARG, "a required pod array is NULL");
+    if (const char* m = HostPrep::missing_array(s)) return fail(core, KAI_ERR_INVALID_ARG, m);  // (before anything reads the snapshot's arrays; HostPrep::build reports the same)
     bool any_legacy_mig = false;
     if (s->pod_flags) {  // one pass over the pods' flags on the host's cores: the two fallback rules (the first one wins, as when checked one after the other) and whether any pod is a legacy MIG task
         const int K = chunk_count((size_t)P);
@@ -529,11 +565,28 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     c.plugins = core->cfg.plugins; c.gpu_strategy = core->cfg.gpu_strategy; c.cpu_strategy = core->cfg.cpu_strategy;
     c.restrict_nodes = core->cfg.restrict_node_scheduling; c.k_value = core->cfg.k_value <= 0.0 ? 0.0 : core->cfg.k_value;  // proportion.go:77-84
 
-    // ---- index structures (pure re-orderings / groupings of the input; kai_host_prep.hpp)
+    // ---- the snapshot's own arrays: allocated first, sent from pinned staging while the host preparation below runs (UploadStage)
     const auto t_shared = tnow();
+    {
+        UploadStage up{core};
+        int rcu = 0;
+#define UP(field, host, n) do { if (!rcu) rcu = up.add(field, host, (size_t)(n)); } while (0)
+        UP(c.p_req, s->pod_req, (size_t)R * P); UP(c.p_job, s->pod_job, P); UP(c.p_podset, s->pod_podset, P);
+        if (s->pod_flags) UP(c.p_flags, s->pod_flags, P); else if (!rcu) rcu = dzero_f(core, c.p_flags, (size_t)P);  // (an optional array that is absent: zeros written on the device, not 4 MB of host zeros sent over)
+        if (s->pod_class) UP(c.p_class, s->pod_class, P); else if (!rcu) rcu = dzero_f(core, c.p_class, (size_t)P);
+        UP(c.p_status, s->pod_status, P);
+        UP(c.s_job, s->podset_job, S); UP(c.s_min, s->podset_min_available, S); UP(c.s_name_rank, s->podset_name_rank, S);
+        UP(c.j_queue, s->job_queue, J); UP(c.j_prio, s->job_priority, J); UP(c.j_preempt, s->job_preemptible, J); UP(c.j_created, s->job_created_ns, J); UP(c.j_uid_rank, s->job_uid_rank, J);
+        UP(c.j_first_pod, s->job_first_pod, J); UP(c.j_n_pods, s->job_n_pods, J); UP(c.j_first_ps, s->job_first_podset, J); UP(c.j_n_ps, s->job_n_podsets, J);
+#undef UP
+        if (!rcu) rcu = up.flush();
+        if (rcu) return rcu;
+    }
+    // ---- index structures (pure re-orderings / groupings of the input; kai_host_prep.hpp)
+    const auto t_staged = tnow();
     HostPrep& prep = core->prep;
-    try { if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG; }
-    catch (const std::exception& e) { core->err = std::string("host preparation: ") + e.what(); return KAI_ERR_INVALID_ARG; }  // (std::bad_alloc of a worker thread included: kai_parallel.hpp carries it here)
+    try { if (prep.build(core->cfg, s, core->err)) { (void)hipStreamSynchronize(core->stream); return KAI_ERR_INVALID_ARG; } }  // (the staged copies read the handle's pinned buffer: done before anyone reuses it)
+    catch (const std::exception& e) { (void)hipStreamSynchronize(core->stream); core->err = std::string("host preparation: ") + e.what(); return KAI_ERR_INVALID_ARG; }  // (std::bad_alloc of a worker thread included: kai_parallel.hpp carries it here)
     const auto t_prep = tnow();
     if (any_legacy_mig) for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
         if ((s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
@@ -547,27 +600,10 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dupload_f(core, c.n_flags, prep.node_flags.data(), (size_t)N));
     TRY(dupload_f(core, c.n_gpu_count, prep.node_gpu_count.data(), (size_t)N));
     TRY(dupload_f(core, c.n_class, prep.node_class.data(), (size_t)N));
-    TRY(dupload_f(core, c.p_req, s->pod_req, (size_t)R * P));
-    TRY(dupload_f(core, c.p_job, s->pod_job, (size_t)P));
-    TRY(dupload_f(core, c.p_podset, s->pod_podset, (size_t)P));
-    if (s->pod_flags) TRY(dupload_f(core, c.p_flags, s->pod_flags, (size_t)P)); else TRY(dzero_f(core, c.p_flags, (size_t)P));  // (an optional array that is absent: zeros written on the device, not 4 MB of host zeros sent over)
-    if (s->pod_class) TRY(dupload_f(core, c.p_class, s->pod_class, (size_t)P)); else TRY(dzero_f(core, c.p_class, (size_t)P));
     const bool full_uploads = std::getenv("KAI_OPEN_FULL_UPLOADS") != nullptr;  // (diagnostic: every array sent from the host, none of the constants below written on the device)
     if (prep.any_nominated || full_uploads) TRY(dupload_f(core, c.p_nominated, prep.pod_nominated.data(), (size_t)P));
     else { TRY(dalloc_f(core, c.p_nominated, (size_t)P)); HIP_TRY(core, hipMemsetAsync(KAI_VP(c.p_nominated), 0xFF, (size_t)std::max(P, 1) * sizeof(int32_t), core->stream)); }  // no nominated node anywhere: -1 in every element
     TRY(dupload_f(core, c.p_scls, prep.pod_scls.data(), (size_t)P));
-    TRY(dupload_f(core, c.s_job, s->podset_job, (size_t)S));
-    TRY(dupload_f(core, c.s_min, s->podset_min_available, (size_t)S));
-    TRY(dupload_f(core, c.s_name_rank, s->podset_name_rank, (size_t)S));
-    TRY(dupload_f(core, c.j_queue, s->job_queue, (size_t)J));
-    TRY(dupload_f(core, c.j_prio, s->job_priority, (size_t)J));
-    TRY(dupload_f(core, c.j_preempt, s->job_preemptible, (size_t)J));
-    TRY(dupload_f(core, c.j_created, s->job_created_ns, (size_t)J));
-    TRY(dupload_f(core, c.j_uid_rank, s->job_uid_rank, (size_t)J));
-    TRY(dupload_f(core, c.j_first_pod, s->job_first_pod, (size_t)J));
-    TRY(dupload_f(core, c.j_n_pods, s->job_n_pods, (size_t)J));
-    TRY(dupload_f(core, c.j_first_ps, s->job_first_podset, (size_t)J));
-    TRY(dupload_f(core, c.j_n_ps, s->job_n_podsets, (size_t)J));
     TRY(dupload_f(core, c.q_parent, s->queue_parent, (size_t)Q));
     TRY(dupload_f(core, c.q_prio, s->queue_priority, (size_t)Q));
     TRY(dupload_f(core, c.q_created, s->queue_created_ns, (size_t)Q));
@@ -704,7 +740,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     TRY(dalloc_f(core, c.n_idle, (size_t)R * N)); (void)d;
     if ((size_t)R * N) HIP_TRY(core, hipMemcpyAsync(KAI_VP(c.n_idle), KAI_VP(c.n_alloc), (size_t)R * N * sizeof(double), hipMemcpyDeviceToDevice, core->stream));  // NewNodeInfo: Idle = Allocatable
     TRY(dzero_f(core, c.n_rel, (size_t)R * N)); TRY(dzero_f(core, c.n_used, (size_t)R * N));
-    TRY(dupload_f(core, c.p_status, s->pod_status, (size_t)P)); TRY(dupload_f(core, c.p_node, prep.pod_node.data(), (size_t)P));
+    TRY(dupload_f(core, c.p_node, prep.pod_node.data(), (size_t)P));
     TRY(dzero_f(core, c.p_on_node, (size_t)P)); TRY(dzero_f(core, c.p_on_node_status, (size_t)P)); TRY(dzero_f(core, c.p_virtual, (size_t)P)); TRY(dzero_f(core, c.p_accepted, (size_t)P));
     TRY(dzero_f(core, c.s_active_alloc, (size_t)S)); TRY(dzero_f(core, c.s_active_used, (size_t)S)); TRY(dzero_f(core, c.s_alive, (size_t)S)); TRY(dzero_f(core, c.s_gated, (size_t)S)); TRY(dzero_f(core, c.s_pipelined, (size_t)S));
     TRY(dzero_f(core, c.j_n_pending, (size_t)J)); TRY(dzero_f(core, c.j_tta_valid, (size_t)J)); TRY(dzero_f(core, c.j_tta_n, (size_t)J)); TRY(dzero_f(core, c.tta, (size_t)P));
@@ -736,12 +772,21 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     HIP_TRY(core, hipMemcpyAsync(core->d_shares0, KAI_VP(c.q_share), (size_t)std::max(Q, 1) * 3 * sizeof(QShare), hipMemcpyDeviceToDevice, core->stream));
     { KaiCtx* t = nullptr; int rc3 = dalloc(core, &t, (size_t)1); if (rc3) return rc3; core->d_ctx = t; }
     HIP_TRY(core, hipMemcpyAsync(core->d_ctx, &core->ctx, sizeof(KaiCtx), hipMemcpyHostToDevice, core->stream));
+    if (std::getenv("KAI_OPEN_DIGEST")) {  // diagnostic: what the open put into every array of the session context, before its first kernel (FNV-1a per KaiCtx field; tests/test_open_uploads.py)
+        HIP_TRY(core, hipStreamSynchronize(core->stream));
+        for (const kai_core::AllocRec& a : core->allocs) {
+            std::vector<unsigned char> h(a.bytes);
+            HIP_TRY(core, hipMemcpyAsync(h.data(), a.base, a.bytes, hipMemcpyDeviceToHost, core->stream)); HIP_TRY(core, hipStreamSynchronize(core->stream));
+            uint64_t f = 1469598103934665603ull; for (unsigned char x : h) { f ^= x; f *= 1099511628211ull; }
+            std::fprintf(stderr, "kai open digest: field %zu bytes %zu fnv %016llx\n", a.field_off, a.bytes, (unsigned long long)f);
+        }
+    }
     { int rc2 = launch_open_kernels(core); if (rc2) return rc2; core->index_stale = false; }
     HIP_TRY(core, hipEventRecord(core->ev1, core->stream));
     const auto t_enq = tnow();
     HIP_TRY(core, hipStreamSynchronize(core->stream));  // prep's host buffers die with this scope
-    if (prof_open) std::fprintf(stderr, "kai open: free %.2f ms, checks + shared pods %.2f, host prep %.2f, allocate + enqueue uploads %.2f, wait %.2f | total %.2f ms\n",
-                                tms(t_begin, t_freed), tms(t_freed, t_shared), tms(t_shared, t_prep), tms(t_prep, t_enq), tms(t_enq, tnow()), tms(t_begin, tnow()));
+    if (prof_open) std::fprintf(stderr, "kai open: free %.2f ms, checks + shared pods %.2f, the snapshot's arrays staged %.2f, host prep %.2f, allocate + enqueue uploads %.2f, wait %.2f | total %.2f ms\n",
+                                tms(t_begin, t_freed), tms(t_freed, t_shared), tms(t_shared, t_staged), tms(t_staged, t_prep), tms(t_prep, t_enq), tms(t_enq, tnow()), tms(t_begin, tnow()));
     if (prof_open) std::fprintf(stderr, "kai open: host prep by phase: range checks %.2f, nodes %.2f, pods %.2f, task order %.2f, queues + job lists %.2f, shares + topology %.2f, classes %.2f, batch shape %.2f ms on %d host threads\n",
                                 prep.phase_ms[0], prep.phase_ms[1], prep.phase_ms[2], prep.phase_ms[3], prep.phase_ms[4], prep.phase_ms[5], prep.phase_ms[6], prep.phase_ms[7], host_threads());
     float ms = 0; HIP_TRY(core, hipEventElapsedTime(&ms, core->ev0, core->ev1));

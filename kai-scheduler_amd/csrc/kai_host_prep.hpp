@@ -126,6 +126,16 @@ struct HostPrep {
     struct BatchShape { int n_leaves = 0, n_heights = 0; std::vector<int> h_count; };
     std::vector<int32_t> q_height, h_off, h_nodes; int n_heights = 0, batch_ok = 0, exact_sums = 0; BatchShape shape;  // exact_sums: sums of node / pod quantities do not depend on the order of addition
 
+    // the required arrays of a snapshot with that many nodes / pods / pod-sets / jobs / queues: the first one that is missing, as a message (nullptr: all there)
+    static const char* missing_array(const kai_snapshot_soa* s) {
+        const int N = s->n_nodes, P = s->n_pods, S = s->n_podsets, J = s->n_jobs, Q = s->n_queues;
+        if (N > 0 && (!s->node_allocatable || !s->node_flags || !s->node_name_rank)) return "a required node array is NULL";
+        if (P > 0 && (!s->pod_req || !s->pod_job || !s->pod_podset || !s->pod_status || !s->pod_node || !s->pod_uid_rank)) return "a required pod array is NULL";
+        if (S > 0 && (!s->podset_job || !s->podset_min_available || !s->podset_name_rank)) return "a required pod-set array is NULL";
+        if (J > 0 && (!s->job_queue || !s->job_priority || !s->job_preemptible || !s->job_created_ns || !s->job_uid_rank || !s->job_first_pod || !s->job_n_pods || !s->job_first_podset || !s->job_n_podsets)) return "a required job array is NULL";
+        if (Q > 0 && (!s->queue_parent || !s->queue_priority || !s->queue_created_ns || !s->queue_uid_rank || !s->queue_deserved || !s->queue_limit || !s->queue_oqw)) return "a required queue array is NULL";
+        return nullptr;
+    }
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host clocks of build(): range checks / nodes / pods / task order / queues + job lists / shares + topology / classes / batch shape
     // returns 0 or KAI_ERR_INVALID_ARG with err set
     int build(const kai_config& cfg, const kai_snapshot_soa* s, std::string& err) {
@@ -136,11 +146,7 @@ struct HostPrep {
         auto lap = [&](int i) { const auto t = std::chrono::steady_clock::now(); phase_ms[i] += std::chrono::duration<double, std::milli>(t - t_last).count(); t_last = t; };
         // ---- the snapshot indexes device arrays directly: every index is range-checked here, every required array must be present
         const int S = s->n_podsets;
-        if (N > 0 && (!s->node_allocatable || !s->node_flags || !s->node_name_rank)) return fail("a required node array is NULL");
-        if (P > 0 && (!s->pod_req || !s->pod_job || !s->pod_podset || !s->pod_status || !s->pod_node || !s->pod_uid_rank)) return fail("a required pod array is NULL");
-        if (S > 0 && (!s->podset_job || !s->podset_min_available || !s->podset_name_rank)) return fail("a required pod-set array is NULL");
-        if (J > 0 && (!s->job_queue || !s->job_priority || !s->job_preemptible || !s->job_created_ns || !s->job_uid_rank || !s->job_first_pod || !s->job_n_pods || !s->job_first_podset || !s->job_n_podsets)) return fail("a required job array is NULL");
-        if (Q > 0 && (!s->queue_parent || !s->queue_priority || !s->queue_created_ns || !s->queue_uid_rank || !s->queue_deserved || !s->queue_limit || !s->queue_oqw)) return fail("a required queue array is NULL");
+        if (const char* m = missing_array(s)) return fail(m);
         // (each loop on the host's cores; the failure reported is the one a sequential pass would stop at)
         if (const char* m = first_failure((size_t)S, [&](size_t k) -> const char* { return (s->podset_job[k] < 0 || s->podset_job[k] >= J) ? "podset_job out of range" : nullptr; })) return fail(m);
         if (const char* m = first_failure((size_t)J, [&](size_t j) -> const char* {

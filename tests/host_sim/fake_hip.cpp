@@ -17,7 +17,7 @@
 
 namespace {
 struct Block { void* p; size_t n; };
-std::mutex g_m; std::vector<Block> g_live; uint64_t g_tok = 0x1000; int64_t g_launches = 0, g_h2d = 0, g_d2d = 0, g_memset = 0, g_h2d_bytes = 0;
+std::mutex g_m; std::vector<Block> g_live; uint64_t g_tok = 0x1000; int64_t g_launches = 0, g_h2d = 0, g_d2d = 0, g_memset = 0, g_h2d_bytes = 0, g_pinned_bytes = 0;
 thread_local struct { dim3 g, b; size_t sh; hipStream_t s; } g_cfg;
 }
 
@@ -46,7 +46,7 @@ hipError_t hipMalloc(void** p, size_t n) {
     g_live.push_back({m, n}); *p = m; return hipSuccess;
 }
 hipError_t hipFree(void* p) { std::lock_guard<std::mutex> lk(g_m); for (size_t i = 0; i < g_live.size(); i++) if (g_live[i].p == p) { g_live.erase(g_live.begin() + (long)i); break; } return hipSuccess; }
-hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(n ? n : 1, 1); { std::lock_guard<std::mutex> lk(g_m); g_pinned_bytes += (int64_t)n; } return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) {
@@ -67,12 +67,12 @@ void __hipUnregisterFatBinary(void**) {}
 void __hipRegisterFunction(void**, const void*, char*, const char*, unsigned, void*, void*, void*, void*, int*) {}
 void __hipRegisterVar(void**, void*, char*, const char*, int, size_t, int, int) {}
 
-// the image: FNV-1a over the live device allocations in allocation order; out = {hash, allocations, bytes, kernel launches, H2D copies, H2D bytes, D2D copies, memsets}
+// the image: FNV-1a over the live device allocations in allocation order; out[9] = {hash, allocations, bytes, kernel launches, H2D copies, H2D bytes, D2D copies, memsets, pinned host bytes ever allocated}
 int fakehip_image(uint64_t* out) {
     std::lock_guard<std::mutex> lk(g_m);
     uint64_t h = 1469598103934665603ull, bytes = 0;
     for (const Block& b : g_live) { const unsigned char* p = (const unsigned char*)b.p; for (size_t i = 0; i < b.n; i++) { h ^= p[i]; h *= 1099511628211ull; } bytes += b.n; h ^= b.n; h *= 1099511628211ull; }
-    out[0] = h; out[1] = g_live.size(); out[2] = bytes; out[3] = (uint64_t)g_launches; out[4] = (uint64_t)g_h2d; out[5] = (uint64_t)g_h2d_bytes; out[6] = (uint64_t)g_d2d; out[7] = (uint64_t)g_memset;
+    out[0] = h; out[1] = g_live.size(); out[2] = bytes; out[3] = (uint64_t)g_launches; out[4] = (uint64_t)g_h2d; out[5] = (uint64_t)g_h2d_bytes; out[6] = (uint64_t)g_d2d; out[7] = (uint64_t)g_memset; out[8] = (uint64_t)g_pinned_bytes;
     return 0;
 }
 }

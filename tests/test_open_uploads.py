@@ -4,7 +4,8 @@ kai_session_open does not SEND every array of the session: constants of the snap
 of a snapshot without sub-group trees, "no nominated node", absent optional arrays) are written on the device by memsets and device-to-device copies.  This test runs the library's
 HOST side for real — kai_core.hip compiled host-only (hipcc --cuda-host-only, seconds) and linked with tests/host_sim/fake_hip.cpp instead of libamdhip64: device memory is host
 memory, copies and memsets happen at the call, kernels do nothing — and compares the image a default open leaves in "device" memory with the image of KAI_OPEN_FULL_UPLOADS=1
-(every array sent from the host, as the library did before): byte for byte the same on every shape, with fewer bytes over the bus."""
+(every array sent from the host, as the library did before) and with the image of KAI_OPEN_NO_STAGING=1 (no pinned staging of the snapshot's own arrays): byte for byte the same on
+every shape, with fewer bytes over the bus."""
 import json
 import os
 import shutil
@@ -28,6 +29,7 @@ def shapes():
     yield "C2", syn.config(1, 1.0)[:2]
     yield "C3 at 30 %", syn.config(2, 0.3)[:2]
     yield "C5 at 5 %", syn.config(4, 0.05)[:2]
+    yield "C5 at 20 %", syn.config(4, 0.2)[:2]   # (its own arrays exceed 4 MB: sent from pinned staging)
     yield "C5-mixed at 3 %", syn.config(4, 0.03, mixed=True)[:2]
     s, c, _ = syn.config(1, 0.5); syn.add_fractions(s, 7, frac=0.3); yield "C2 at 50 % with fractions", (s, c)
     s, c, _ = syn.config(1, 0.2); import numpy as np; s.arrays["pod_gpu_portion"] = np.zeros(s.n_pods); yield "C2 at 20 %, a portion array of zeros", (s, c)
@@ -41,7 +43,7 @@ for name, (snap, cfg) in shapes():
     st = snap.as_struct()
     rc = lib.kai_session_open(h, C.byref(st))
     assert rc == 0, (name, rc, lib.kai_last_error(h))
-    img = (C.c_uint64 * 8)(); lib.fakehip_image(img)
+    img = (C.c_uint64 * 9)(); lib.fakehip_image(img)
     out[name] = [int(x) for x in img]
     lib.kai_core_destroy(h)
 print(json.dumps(out))
@@ -79,14 +81,48 @@ def test_device_image_of_an_open_does_not_depend_on_what_is_sent(fake_lib):
     assert lean.keys() == full.keys() and len(lean) >= 9
     saved = 0
     for name in lean:
-        h, n_alloc, n_bytes, launches, h2d, h2d_bytes, d2d, memsets = lean[name]
-        fh, fn_alloc, fn_bytes, flaunches, fh2d, fh2d_bytes, fd2d, fmemsets = full[name]
+        h, n_alloc, n_bytes, launches, h2d, h2d_bytes, d2d, memsets, pinned = lean[name]
+        fh, fn_alloc, fn_bytes, flaunches, fh2d, fh2d_bytes, fd2d, fmemsets, fpinned = full[name]
         assert (h, n_alloc, n_bytes, launches) == (fh, fn_alloc, fn_bytes, flaunches), name   # the same image, the same allocations, the same kernels
         assert h2d_bytes <= fh2d_bytes, name
         saved += fh2d_bytes - h2d_bytes
     assert saved > 0  # some shape has constants the default open does not send
     # a snapshot without shared GPUs and sub-group trees sends markedly less
     assert lean["C5 at 5 %"][5] < 0.7 * full["C5 at 5 %"][5]
+    # the snapshot's own arrays go up from pinned staging when they are large (UploadStage): the same image as sending them from where they lie
+    assert lean["C5 at 20 %"][8] > (4 << 20)  # (the staging buffer was allocated: the pinned way ran)
+    plain = _images(fake_lib, {"KAI_OPEN_NO_STAGING": "1"})
+    assert all(plain[k][:4] == lean[k][:4] for k in lean) and plain["C5 at 20 %"][8] == 0
     # KAI_HOST_POOL=0 / one host thread: the same images (the preparation's outputs do not depend on how its loops run)
     assert _images(fake_lib, {"KAI_HOST_THREADS": "1"}) == lean
     assert _images(fake_lib, {"KAI_HOST_POOL": "0", "KAI_HOST_THREADS": "5"}) == lean
+
+
+REFUSAL = r'''
+import ctypes as C, sys
+sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0, ROOT)
+import kai_testlib as T
+lib = C.CDLL(LIB)
+lib.kai_last_error.restype = C.c_char_p; lib.kai_last_error.argtypes = [C.c_void_p]
+snap, cfg, _ = T.pkg.synth.config(4, 0.2)
+h = C.c_void_p(); assert lib.kai_core_create(C.byref(cfg), 1, None, C.byref(h)) == 0
+good = snap.as_struct()
+assert lib.kai_session_open(h, C.byref(good)) == 0
+bad_job = snap.arrays["pod_job"].copy(); bad_job[-3] = snap.n_jobs + 5
+keep = snap.arrays["pod_job"]; snap.arrays["pod_job"] = bad_job
+st = snap.as_struct(); rc = lib.kai_session_open(h, C.byref(st)); msg = lib.kai_last_error(h).decode()
+assert rc != 0 and "pod_job out of range" in msg, (rc, msg)          # refused by the preparation, after the snapshot's arrays were staged
+snap.arrays["pod_job"] = keep
+st = snap.as_struct(); st.pod_req = None
+rc = lib.kai_session_open(h, C.byref(st)); msg = lib.kai_last_error(h).decode()
+assert rc != 0 and "a required pod array is NULL" in msg, (rc, msg)  # refused before anything reads the arrays
+assert lib.kai_session_open(h, C.byref(good)) == 0                    # and the handle opens the next session
+assert lib.kai_core_destroy(h) == 0
+print("refusals ok")
+'''
+
+
+def test_a_refused_snapshot_leaves_the_handle_usable(fake_lib):
+    code = f"ROOT = {ROOT!r}\nLIB = {fake_lib!r}\n" + REFUSAL
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "refusals ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
