@@ -113,6 +113,7 @@ int dupload(kai_core* core, const T** out, const T* host, size_t n) {
     int rc = dalloc(core, &p, n);
     if (rc) return rc;
     if (n) HIP_TRY(core, hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, core->stream));
+    else HIP_TRY(core, hipMemsetAsync(p, 0, sizeof(T), core->stream));  // (an empty array is one element nobody reads: zeros rather than what the slab held before)
     *out = p;
     return KAI_OK;
 }
@@ -148,6 +149,7 @@ int dupload_f(kai_core* core, F& field, const T* host, size_t n) {
     int rc = dalloc_f(core, field, n);
     if (rc) return rc;
     if (n) HIP_TRY(core, hipMemcpyAsync(KAI_VP(field), host, n * sizeof(T), hipMemcpyHostToDevice, core->stream));
+    else HIP_TRY(core, hipMemsetAsync(KAI_VP(field), 0, sizeof(T), core->stream));  // (an empty array is one element nobody reads: zeros rather than what the slab held before)
     return KAI_OK;
 }
 // The snapshot's own arrays (nothing the host preparation derives) go up FIRST and from pinned memory: add() allocates the device array, flush() copies the host arrays into the
@@ -161,6 +163,7 @@ struct UploadStage {
         static_assert(sizeof(*field) == sizeof(T), "element size");
         int rc = dalloc_f(core, field, n); if (rc) return rc;
         if (n) { segs.push_back({KAI_VP(field), host, n * sizeof(T), total}); total += (n * sizeof(T) + 255) & ~(size_t)255; }
+        else HIP_TRY(core, hipMemsetAsync(KAI_VP(field), 0, sizeof(T), core->stream));
         return KAI_OK;
     }
     int flush() {

@@ -126,3 +126,56 @@ def test_a_refused_snapshot_leaves_the_handle_usable(fake_lib):
     code = f"ROOT = {ROOT!r}\nLIB = {fake_lib!r}\n" + REFUSAL
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "refusals ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+SEQUENCE = r'''
+import ctypes as C, sys, os
+sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0, ROOT)
+import kai_testlib as T
+lib = C.CDLL(LIB)
+syn = T.pkg.synth
+shapes = [("C5 at 10 %", syn.config(4, 0.1)[:2]), ("C1", syn.config(0)[:2]), ("C5 at 20 %", syn.config(4, 0.2)[:2]), ("C2", syn.config(1, 1.0)[:2]), ("C5-mixed at 3 %", syn.config(4, 0.03, mixed=True)[:2])]
+s, c, _ = syn.config(1, 0.5); syn.add_fractions(s, 7, frac=0.3); shapes.append(("C2 at 50 % with fractions", (s, c)))
+shapes += [(f"broad 12/{ci}", (snap, cfg)) for ci, (snap, cfg, acts) in enumerate(T.broad_case(12))] + [shapes[0], shapes[2]]
+one = MODE == "one handle"
+h = C.c_void_p()
+for i, (name, (snap, cfg)) in enumerate(shapes):
+    if not one or i == 0:
+        h = C.c_void_p(); assert lib.kai_core_create(C.byref(cfg), 1, None, C.byref(h)) == 0
+    st = snap.as_struct()
+    assert lib.kai_session_open(h, C.byref(st)) == 0, name
+    sys.stderr.write("== %d %s\n" % (i, name)); sys.stderr.flush()
+    if not one: assert lib.kai_core_destroy(h) == 0
+'''
+
+
+def test_a_handle_that_opens_session_after_session_fills_the_context_like_a_fresh_one(fake_lib):
+    """One handle over a sequence of sessions of very different sizes (its kept preparation objects, its device slabs and its pinned staging buffer all reused and regrown) against a
+    fresh handle per session: every array of the session context holds the same bytes after the open (KAI_OPEN_DIGEST).  (The broad-campaign cases share one kai_config shape; the
+    handle's configuration is the first session's — as a scheduler's handle keeps its configuration over the cycles.)"""
+    import re
+
+    def digests(mode):
+        e = dict(os.environ); e["KAI_OPEN_DIGEST"] = "1"
+        code = f"ROOT = {ROOT!r}\nLIB = {fake_lib!r}\nMODE = {mode!r}\n" + SEQUENCE
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out, cur = {}, {}
+        for ln in r.stderr.splitlines():
+            m = re.match(r"kai open digest: field (\d+) bytes (\d+) fnv (\w+)", ln)
+            if m: cur[int(m.group(1))] = (int(m.group(2)), m.group(3))
+            elif ln.startswith("== "): out[ln[3:]] = cur; cur = {}
+        return out
+    # arrays the open allocates WITHOUT writing them (the operation log, the output staging, the GPU-group ids a kernel of the open resets): whatever the slab held — not part of the statement
+    probe = os.path.join(os.path.dirname(fake_lib), "ctx_offsets")
+    with open(probe + ".cpp", "w") as f:
+        f.write('#include <cmath>\n#include <math.h>\n#include <cstddef>\n#include <cstdio>\n#define KAI_SHARED_GPUS 1\n#include "%s"\nint main() { std::printf("%%zu %%zu %%zu\\n", offsetof(kai::KaiCtx, ops), offsetof(kai::KaiCtx, out_ops), offsetof(kai::KaiCtx, ng_id)); }\n'
+                % os.path.join(ROOT, "kai-scheduler_amd", "csrc", "kai_engine.hpp"))
+    subprocess.check_call(["g++", "-std=c++17", "-Wno-invalid-offsetof", "-o", probe, probe + ".cpp"])
+    scratch = {int(x) for x in subprocess.check_output([probe], text=True).split()}
+    one, fresh = digests("one handle"), digests("fresh handles")
+    assert one.keys() == fresh.keys() and len(one) >= 12
+    for k in one:
+        assert len(one[k]) > 100 and one[k].keys() == fresh[k].keys(), k
+        differing = {f for f in one[k] if one[k][f] != fresh[k][f]}
+        assert differing <= scratch, (k, differing, scratch)
