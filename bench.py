@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=os.environ.get("KAI_BENCH_CONFIG", "C5"), choices=sorted(CONFIGS))
-    ap.add_argument("--scale", type=float, default=None, help="shrinks nodes and pods together (default 1.0; C4: 0.01 — measured on one MI355X: 10 %% of config 4 in 40 s, 30 %% with --queue-depth 8 in 55 s; full size is pinned against the oracle but not run on the device yet, DESIGN.md section 10.3)")
+    ap.add_argument("--scale", type=float, default=None, help="shrinks nodes and pods together (default 1.0; C4: 0.01 — measured on one MI355X: 10 %% of config 4 in 34 s, 30 %% with --queue-depth 8 in 55 s, the FULL size with --queue-depth 8 in about 273 s, operations equal to the oracle's: a hash test of the -m gpu suite, DESIGN.md section 6)")
     ap.add_argument("--actions", default="", help="comma-separated actions of one cycle (default: allocate; C4: allocate,consolidation,reclaim)")
     ap.add_argument("--mixed", action="store_true", help="config C5 in the shape SURVEY 8d gives it: zone/rack labels, 5 %% topology gangs, 5 %% elastic gangs, minruntime — jobs the batch path leaves to the sequential engine")
     ap.add_argument("--fractions", type=float, default=0.0, help="that share of the one-GPU pods asks for a fraction of one device (shared GPUs: every decision is a brute-force scan of the nodes' GPU groups — the streaming kernel of SURVEY 8d)")
