@@ -179,3 +179,38 @@ def test_a_handle_that_opens_session_after_session_fills_the_context_like_a_fres
         assert len(one[k]) > 100 and one[k].keys() == fresh[k].keys(), k
         differing = {f for f in one[k] if one[k][f] != fresh[k][f]}
         assert differing <= scratch, (k, differing, scratch)
+
+
+def test_the_shipped_library_under_the_stand_in_runtime(fake_lib):
+    """The library as it ships (kai-scheduler_amd/csrc/libkai_core.so: hipcc -O3, device code embedded, linked against libamdhip64) with its HIP calls bound to the stand-in runtime
+    by LD_PRELOAD: the open fills every array of the session context with the same bytes as the host-only build of this test, and what it leaves in device memory does not depend on
+    KAI_OPEN_FULL_UPLOADS either.  (The binary that goes to the GPU box, not a rebuild of its source.)"""
+    import re
+    shipped = os.path.join(ROOT, "kai-scheduler_amd", "csrc", "libkai_core.so")
+    if not os.path.exists(shipped):
+        pytest.skip("libkai_core.so is not built")
+    shim = os.path.join(os.path.dirname(fake_lib), "libfakehip.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-I/opt/rocm/include", "-o", shim, os.path.join(ROOT, "tests", "host_sim", "fake_hip.cpp"), "-lpthread"])
+
+    def run(lib, preload, env):
+        e = dict(os.environ); e.pop("KAI_OPEN_FULL_UPLOADS", None); e["KAI_OPEN_DIGEST"] = "1"; e.update(env)
+        d = DRIVER.replace("out[name] = [int(x) for x in img]", "out[name] = [int(x) for x in img]; sys.stderr.write('== ' + name + chr(10)); sys.stderr.flush()")
+        if preload:
+            e["LD_PRELOAD"] = shim
+            d = d.replace("lib = C.CDLL(LIB)", f"lib = C.CDLL(LIB); shim = C.CDLL({shim!r})").replace("lib.fakehip_image(img)", "shim.fakehip_image(img)")
+        r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\nLIB = {lib!r}\n" + d], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        fields, cur = {}, {}
+        for ln in r.stderr.splitlines():
+            m = re.match(r"kai open digest: field (\d+) bytes (\d+) fnv (\w+)", ln)
+            if m: cur[int(m.group(1))] = (int(m.group(2)), m.group(3))
+            elif ln.startswith("== "): fields[ln[3:]] = cur; cur = {}
+        return fields, json.loads(r.stdout.strip().splitlines()[-1])
+    ship_fields, ship_img = run(shipped, True, {})
+    host_fields, _ = run(fake_lib, False, {})
+    assert ship_fields.keys() == host_fields.keys() and len(ship_fields) >= 9
+    for k in ship_fields:
+        assert len(ship_fields[k]) > 100 and ship_fields[k] == host_fields[k], k
+    _, full_img = run(shipped, True, {"KAI_OPEN_FULL_UPLOADS": "1"})
+    assert all(ship_img[k][:4] == full_img[k][:4] for k in ship_img)
+    assert sum(full_img[k][5] for k in full_img) > sum(ship_img[k][5] for k in ship_img)
