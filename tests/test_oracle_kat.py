@@ -603,3 +603,17 @@ def test_podset_gang_counters(case):
     which = ("IsReadyForScheduling", "IsGangSatisfied", "IsElastic", "GetNumActiveAllocatedTasks", "GetNumActiveUsedTasks", "GetNumAliveTasks", "GetNumGatedTasks", "GetNumPendingTasks").index(case["question"])
     want = case["expected"]
     assert (bool(out[which]) == want) if isinstance(want, bool) else (int(out[which]) == want)
+
+
+POD_STATUS_KAT = T.load_golden("kat_pod_status")
+
+
+@pytest.mark.parametrize("case", POD_STATUS_KAT["cases"], ids=[f"{c['line']}:{c['status']}" for c in POD_STATUS_KAT["cases"]])
+def test_alive_statuses(case):
+    """IsAliveStatus (api/pod_status/pod_status.go:59-71) on the eleven statuses of TestIsAliveStatus (tools/go_kat_pod_status.py), through the pod-set counter that uses it
+    (PodSet.GetNumAliveTasks, podset.go:56-77); the host mirror's status bit-set (abi.POD_STATUS) is the ABI's."""
+    import ctypes as C
+    lib = T.Oracle.lib(); lib.kai_oracle_podset_kat.restype = C.c_int
+    uid = np.asarray([1, 0], np.int32); st = np.asarray([T.abi.POD_STATUS[case["status"]], 0], np.int32); out = np.zeros(8, np.int32)
+    assert lib.kai_oracle_podset_kat(1, uid.ctypes.data_as(C.POINTER(C.c_int32)), st.ctypes.data_as(C.POINTER(C.c_int32)), 1, out.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    assert bool(out[5]) == case["expected"]
