@@ -896,6 +896,9 @@ int kai_ingest::build(const JV& root, const kai_ingest_options* opt, const PodSp
         for (int j = 0; j < J; j++) {
             std::vector<std::string> sigs;
             for (int s : job_podset_ids[j]) {
+                // a pod-set whose pods are all active-allocated (or that has none) has the EMPTY signature, whatever its constraints (podset.go:150-154 isAllPodsActiveAllocated):
+                // it adds nothing to the job's hash (job_info.go:555-569 writes the sorted signatures one after the other)
+                if (ps_pods[s].empty()) continue;
                 std::string x = podset_tc_v[s].sig; for (int g = podset_group[s]; g >= 0; g = group_parent[g]) { x += '|'; x += group_tc_v[g].sig; }
                 std::sort(ps_pods[s].begin(), ps_pods[s].end()); x += '#'; for (int64_t v : ps_pods[s]) { x += std::to_string(v); x += ','; }
                 sigs.push_back(std::move(x));

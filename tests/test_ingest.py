@@ -889,3 +889,19 @@ def test_max_node_resources_reference_cases(case):
     if "gpu-fraction" not in case["annotations"]:
         fits_max = all(float(s.pod_req[r, 0]) <= float(s.node_allocatable[r].max()) for r in range(s.n_res))
         assert fits_max == case["schedulable"]
+
+
+def test_a_pod_set_that_is_all_placed_does_not_enter_the_job_signature():
+    """podset.go:150-154: a pod-set whose pods are all active-allocated (or that has none) has the EMPTY scheduling-constraints signature, whatever its topology constraint; the job's
+    hash (job_info.go:555-569) is over the sorted pod-set signatures written one after the other, so such a pod-set adds nothing to it.  Jobs a / b / c: the same pending `workers`;
+    b also has a `servers` pod-set (own rack constraint) whose only pod runs, c has it with that pod still pending."""
+    topo = {"metadata": {"name": "t"}, "spec": {"levels": [{"nodeLabel": "zone"}, {"nodeLabel": "rack"}]}}
+    servers = {"name": "servers", "minMember": 1, "topologyConstraint": {"topology": "t", "requiredTopologyLevel": "rack"}}
+    pgs = [pod_group("a", subGroups=[{"name": "workers", "minMember": 1}]), pod_group("b", subGroups=[{"name": "workers", "minMember": 1}, servers]),
+           pod_group("c", subGroups=[{"name": "workers", "minMember": 1}, servers])]
+    lab = lambda n: {"kai.scheduler/subgroup-name": n}
+    pods = [pod("a-w", "a", labels=lab("workers")), pod("b-w", "b", labels=lab("workers")), pod("b-s", "b", labels=lab("servers"), phase="Running", node_name="n0"),
+            pod("c-w", "c", labels=lab("workers")), pod("c-s", "c", labels=lab("servers"))]
+    s = ingest(doc(nodes=[node("n0", labels={"zone": "z", "rack": "r"})], queues=[queue("q")], pods=pods, pod_groups=pgs, topologies=[topo])).snapshot
+    sig = dict(zip(s.job_names, (int(x) for x in s.job_signature)))
+    assert sig["a"] == sig["b"] and sig["c"] != sig["a"]
