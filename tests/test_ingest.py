@@ -905,3 +905,46 @@ def test_a_pod_set_that_is_all_placed_does_not_enter_the_job_signature():
     s = ingest(doc(nodes=[node("n0", labels={"zone": "z", "rack": "r"})], queues=[queue("q")], pods=pods, pod_groups=pgs, topologies=[topo])).snapshot
     sig = dict(zip(s.job_names, (int(x) for x in s.job_signature)))
     assert sig["a"] == sig["b"] and sig["c"] != sig["a"]
+
+
+JOB_SIGNATURE = T.load_golden("kat_job_signature")
+
+
+def _pod_group_objects(job, tree):
+    """a pod group of kat_job_signature.json (the tree the reference's test builds by hand) as snapshot objects: the PodGroup with its sub-group list, its pods"""
+    tc = lambda c: {k: v for k, v in (("topology", (c or {}).get("topology")), ("requiredTopologyLevel", (c or {}).get("required")), ("preferredTopologyLevel", (c or {}).get("preferred"))) if v}
+    subgroups, pods = [], []
+    flat = len(tree["children"]) == 1 and tree["children"][0]["kind"] == "PodSet" and tree["children"][0]["name"] == "default"
+
+    def walk(node, parent):
+        for ch in node["children"]:
+            e = {"name": ch["name"]}
+            if parent: e["parent"] = parent
+            if tc(ch["constraint"]): e["topologyConstraint"] = tc(ch["constraint"])
+            if ch["kind"] == "PodSet":
+                e["minMember"] = ch["minAvailable"]
+                for name, state in ch["pods"]:
+                    pods.append(pod(f"{job}-{ch['name']}-{name}", job, labels={} if flat else {"kai.scheduler/subgroup-name": ch["name"]},
+                                    **({"phase": "Running", "node_name": "n0"} if state == "Running" else {})))
+                if not flat: subgroups.append(e)
+            else:
+                subgroups.append(e); walk(ch, ch["name"])
+    walk(tree, None)
+    spec = {}
+    if tc(tree["constraint"]): spec["topologyConstraint"] = tc(tree["constraint"])
+    if subgroups: spec["subGroups"] = subgroups
+    return pod_group(job, min_member=tree["children"][0]["minAvailable"] if flat else 1, **spec), pods
+
+
+@pytest.mark.parametrize("case", JOB_SIGNATURE["cases"], ids=[f"{c['line']}:{c['name']}" for c in JOB_SIGNATURE["cases"]])
+def test_job_signature_reference_cases(case):
+    """PodGroupInfo.GetSchedulingConstraintsSignature (job_info.go:547-570; podset.go:150-196) on the eleven pairs of TestPodGroupInfo_GetSchedulingConstraintsSignature
+    (tools/go_kat_job_signature.py interprets the closures that build them): both pod groups of a pair go into ONE snapshot document as the objects the reference's cache would
+    hold, and the ids the ingest gives their jobs (kai_snapshot_soa.job_signature: equal exactly when the reference's hashes are) are equal exactly when the test expects it."""
+    levels = [{"nodeLabel": l} for l in ("zone", "rack", "node")]
+    topos = [{"metadata": {"name": n}, "spec": {"levels": levels}} for n in ("topo", "topology")]
+    pga, pa = _pod_group_objects("a", case["a"]); pgb, pb = _pod_group_objects("b", case["b"])
+    s = ingest(doc(nodes=[node("n0", labels={"zone": "z", "rack": "r", "node": "n0"})], queues=[queue("q")], pods=pa + pb, pod_groups=[pga, pgb], topologies=topos)).snapshot
+    assert s.n_pods == len(pa) + len(pb) and all(int(j) >= 0 for j in s.pod_job) and all(int(k) >= 0 for k in s.pod_podset)  # every pod found its pod-set
+    sig = dict(zip(s.job_names, (int(x) for x in s.job_signature)))
+    assert (sig["a"] == sig["b"]) == case["equal"], (sig, s.podset_names, list(s.pod_podset))
