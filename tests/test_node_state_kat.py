@@ -242,21 +242,29 @@ def test_tasks_to_evict(name, podsets, pods, want, more):
     assert (n, bool(hm.value)) == (want, more)
 
 
-# ------------------------------------------------------------------------------------------------ getNumTasksToAllocate (api/podgroup_info/allocation_info_test.go:396-461)
-TO_ALLOCATE = [("pending equal to minAvailable", 3, ["Pending"] * 3, 3), ("allocated equal to minAvailable, plus pending", 2, ["Allocated", "Allocated", "Pending"], 1),
-               ("allocated above minAvailable, extra pending", 2, ["Allocated"] * 3 + ["Pending"], 1), ("allocated less than minAvailable, rest pending", 4, ["Allocated"] * 2 + ["Pending"] * 2, 2),
-               ("all allocated, at minAvailable", 3, ["Allocated"] * 3, 0)]
+# ------------------------------------------------------------------------------------------------ GetTasksToAllocate / getNumTasksToAllocate (api/podgroup_info/allocation_info_test.go)
+TO_ALLOCATE = T.load_golden("kat_tasks_to_allocate")["cases"]  # tools/go_kat_tasks_to_allocate.py: Test_GetTasksToAllocate :62-217 (8), Test_getNumTasksToAllocate :396-461 (5)
 
 
-@pytest.mark.parametrize("name,min_available,statuses,want", TO_ALLOCATE, ids=[c[0].replace(" ", "_").replace(",", "") for c in TO_ALLOCATE])
-def test_num_tasks_to_allocate(name, min_available, statuses, want):
-    """the gang's missing tasks up to minAvailable in one chunk, then one elastic task at a time"""
+@pytest.mark.parametrize("case", TO_ALLOCATE, ids=[f"{c['line']}:{c['fn']}:{c['name']}".replace(" ", "_").replace(",", "") for c in TO_ALLOCATE])
+def test_tasks_to_allocate_reference_cases(case):
+    """GetTasksToAllocate (allocation_info.go:27-54): pod-sets in PodSetOrderFn order, of each the gang's missing tasks up to minAvailable — in one chunk — or, once every pod-set has its
+    gang, one elastic task of the first pod-set that has one; getNumTasksToAllocate (:145-177) is the chunk's size.  The test's order functions (pod-sets by name, tasks by UID) order its
+    cases like the default plugins do (its names rise with creation order)."""
     import ctypes as C
-    root = {"Name": "", "PodSets": [{"Name": "default", "MinAvailable": min_available, "TopologyConstraint": None}], "SubGroups": [], "TopologyConstraint": None}
-    case = {"Name": name, "Nodes": {"n1": {"GPUs": 8}}, "Queues": [{"Name": "q", "DeservedGPUs": 8}],
-            "Jobs": [{"Name": "pg", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": 1, "RootSubGroupSet": root,
-                      "Tasks": [{"State": st, **({"NodeName": "n1"} if st != "Pending" else {})} for st in statuses]}], "JobExpectedResults": {}}
-    snap, cfg, _ = T.case_to_snapshot(case)
+    if case["fn"] == "GetTasksToAllocate":
+        sets = sorted(case["minAvailable"]); tasks = case["tasks"]
+    else:
+        sets = ["default"]; tasks = [{"name": f"task{i}", "subGroup": "default", "status": st} for i, st in enumerate(case["statuses"])]
+    root = {"Name": "", "PodSets": [{"Name": n, "MinAvailable": case["minAvailable"][n] if case["fn"] == "GetTasksToAllocate" else case["minAvailable"], "TopologyConstraint": None} for n in sets], "SubGroups": [], "TopologyConstraint": None}
+    tc = {"Name": case["name"], "Nodes": {"n1": {"GPUs": 8}}, "Queues": [{"Name": "q", "DeservedGPUs": 8}],
+          "Jobs": [{"Name": "pg", "Priority": 50, "QueueName": "q", "RequiredGPUsPerTask": 1, "RootSubGroupSet": root,
+                    "Tasks": [{"State": t["status"], "SubGroupName": t["subGroup"], **({"NodeName": "n1"} if t["status"] != "Pending" else {})} for t in tasks]}], "JobExpectedResults": {}}
+    snap, cfg, _ = T.case_to_snapshot(tc)
     lib = T.Oracle.lib(); lib.kai_oracle_tasks_to_allocate.restype = C.c_int
-    s = snap.as_struct()
-    assert lib.kai_oracle_tasks_to_allocate(C.byref(cfg), C.byref(s), 0, 1, None, 0) == want
+    s = snap.as_struct(); out = np.full(8, -1, np.int32)
+    n = lib.kai_oracle_tasks_to_allocate(C.byref(cfg), C.byref(s), 0, 1 if case.get("realAllocation", True) else 0, out.ctypes.data_as(C.POINTER(C.c_int32)), 8)
+    if case["fn"] == "GetTasksToAllocate":
+        assert n == case["wantNumTasks"] and [tasks[int(p)]["name"] for p in out[:n]] == case["wantTasks"]   # (pod index = position in the job's task list)
+    else:
+        assert n == case["want"]
