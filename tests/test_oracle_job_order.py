@@ -125,21 +125,12 @@ def test_victim_queue_two_queues_with_running_jobs():  # :1047-1121 — two pops
     assert n == 2 and sorted(got[:2]) == ["job0", "job1"] and got[2] is None
 
 
-READY = [  # api/podgroup_info/job_info_test.go:397-779 (TestPodGroupInfo_IsReadyForScheduling): pod-sets (name, minAvailable, pod states) → ready
-    ("pending task", [("default", 1, ["Pending"])], True),
-    ("gated task", [("default", 1, ["Gated"])], False),
-    ("pending task, minAvailable 2", [("default", 2, ["Pending"])], False),
-    ("pending and gated tasks, minAvailable 1", [("default", 1, ["Pending", "Gated"])], True),
-    ("pending and gated tasks, minAvailable 2", [("default", 2, ["Pending", "Gated"])], False),
-    ("subgroups - all ready", [("sb-1", 2, ["Pending", "Pending"]), ("sb-2", 1, ["Pending"])], True),
-    ("subgroups - some already running", [("sb-1", 2, ["Running", "Pending"]), ("sb-2", 1, ["Pending"])], True),
-    ("subgroups - more than minAvailable", [("sb-1", 2, ["Pending"] * 3), ("sb-2", 1, ["Pending"])], True),
-    ("subgroups - one is not ready", [("sb-1", 2, ["Pending"]), ("sb-2", 1, ["Pending"])], False),
-]
+READY = [(c["name"], [(ps["name"], ps["minAvailable"], ps["statuses"]) for ps in c["podSets"]], c["ready"], c["line"])  # api/podgroup_info/job_info_test.go:397-779 (TestPodGroupInfo_IsReadyForScheduling):
+         for c in T.load_golden("kat_job_ready")["cases"]]                                                                   # pod-sets (name, minAvailable, pod states) → ready; tools/go_kat_job_ready.py
 
 
-@pytest.mark.parametrize("name,podsets,ready", READY, ids=[c[0].replace(" ", "_").replace(",", "") for c in READY])
-def test_is_ready_for_scheduling(name, podsets, ready):
+@pytest.mark.parametrize("name,podsets,ready,line", READY, ids=[f"{c[3]}:{c[0]}".replace(" ", "_").replace(",", "") for c in READY])
+def test_is_ready_for_scheduling(name, podsets, ready, line):
     """a job enters a FilterUnready queue iff every pod-set has minAvailable alive tasks that are not scheduling-gated (job_info.go:399-406, podset.go:114-120)"""
     root = {"Name": "", "PodSets": [{"Name": n, "MinAvailable": m, "TopologyConstraint": None} for n, m, _ in podsets], "SubGroups": [], "TopologyConstraint": None}
     tasks = [{"State": st, **({"SubGroupName": n} if n != "default" else {}), **({"NodeName": "n1"} if st == "Running" else {})} for n, _, sts in podsets for st in sts]
