@@ -207,7 +207,7 @@ def test_elastic_job_order_known_answers(line, lmin, rmin, lp, rp, want):
     assert _order_fn(0, [lmin, n(lp)], [rmin, n(rp)]) == want, f"elastic_test.go:{line}"
 
 
-SUBGROUP_ORDER = [(3, 1, 4, 2, 0), (3, 1, 3, 5, -1), (3, 5, 3, 1, 1), (2, 4, 4, 9, -1), (2, 10, 4, 9, 1), (2, 4, 4, 8, 0)]  # subgroup_order_test.go:40-89
+SUBGROUP_ORDER = [(c["lMinAvailable"], c["lAllocated"], c["rMinAvailable"], c["rAllocated"], c["want"]) for c in T.load_golden("kat_subgroup_order")["cases"]]  # subgroup_order_test.go:33-102 (tools/go_kat_subgroup_order.py)
 
 
 @pytest.mark.parametrize("lmin,lalloc,rmin,ralloc,want", SUBGROUP_ORDER)
@@ -293,10 +293,7 @@ def test_capacity_policy_over_a_queue_chain(case):
     assert got == int(case["want_schedulable"]), (case["name"], got)
 
 
-GREEDY = [  # idle_gpus_test.go:117-189: (requirements, holders in order, capacity by holder, want)
-    ([], ["n1"], {"n1": 1.0}, True), ([0, 0], [], {}, True), ([0.5], ["n1"], {"n1": 1.0}, True), ([0.5], ["n1"], {"n1": 0.0}, False),
-    ([1.0, 0.5], ["n1"], {"n1": 1.0}, False), ([1.0, 0.5], ["n1"], {"n1": 1.5}, True), ([1.0, 1.0], ["n2", "n1"], {"n1": 1.0, "n2": 2.0}, True), ([2.0], ["n1"], {"n1": 1.0}, False),
-]
+GREEDY = [(c["requirements"], c["holders"], c["capacity"], c["want"]) for c in T.load_golden("kat_greedy_match")["cases"]]  # idle_gpus_test.go:106-199 (tools/go_kat_greedy_match.py): requirements, holders in order, capacity by holder, want
 
 
 @pytest.mark.parametrize("req,holders,cap,want", GREEDY)
