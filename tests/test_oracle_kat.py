@@ -193,11 +193,7 @@ def _order_fn(which, l, r):
 
 
 ACTIVE_ALLOCATED = ("Allocated", "Binding", "Bound", "Running", "Pipelined")  # pod_status.IsActiveAllocatedStatus: a releasing pod is not
-ELASTIC = [  # plugins/elastic/elastic_test.go:24-482 (line, minAvailable of l / r, pod states of l / r, JobOrderFn)
-    (31, 0, 0, [], [], 0), (55, 1, 1, ["Running"], ["Running"], 0), (91, 1, 1, ["Allocated"], ["Running"], 0), (127, 1, 1, ["Bound"], ["Running"], 0),
-    (163, 1, 1, ["Releasing"], ["Running"], -1), (199, 1, 1, ["Running"], [], 1), (226, 2, 2, ["Running"], ["Running"] * 2, -1), (268, 2, 2, ["Running"], ["Running"] * 3, -1),
-    (316, 1, 1, ["Running"], ["Running"] * 2, -1), (358, 1, 3, ["Running"], ["Running"] * 2, 1), (400, 1, 1, ["Running"] * 2, ["Running"], 1), (442, 1, 1, ["Running"] * 2, ["Running"], 1),
-]
+ELASTIC = [(c["line"], c["lMinAvailable"], c["rMinAvailable"], c["lPods"], c["rPods"], c["want"]) for c in T.load_golden("kat_elastic")["cases"]]  # plugins/elastic/elastic_test.go:17-533 (tools/go_kat_elastic.py): minAvailable of l / r, pod states of l / r, JobOrderFn
 
 
 @pytest.mark.parametrize("line,lmin,rmin,lp,rp,want", ELASTIC, ids=[f"elastic:{c[0]}" for c in ELASTIC])
