@@ -302,25 +302,11 @@ def test_greedy_match_requirements_known_answers(req, holders, cap, want):
     assert bool(got) == want
 
 
-MI = 1048576.0
-def _pods(*rows): return [list(r) if isinstance(r, (list, tuple)) else r for r in rows]
-P = lambda cpu=0.0, mem=0.0, gpu=0.0, pending=1: [float(pending), float(cpu), float(mem), float(gpu)]
-MINIMAL_JOB = [  # actions/common/minimal_job_comparison_test.go: (mode, representative's pods, job's pods, want)
-    # IsEasierToSchedule, single pod :43-140
-    (0, [P(100)], [P()], True), (0, [P()], [P(100)], False), (0, [P(100)], [P(100)], False), (0, [P(100)], [P(200)], False), (0, [P(100)], [P(50)], True),
-    (0, [P(mem=100 * MI)], [P(mem=200 * MI)], False), (0, [P(mem=100 * MI)], [P(mem=50 * MI)], True), (0, [P(100, 100 * MI)], [P(200, 50 * MI)], False), (0, [P(100, 100 * MI)], [P(50, 200 * MI)], False),
-    (0, [P(gpu=1)], [P(gpu=2)], False), (0, [P(gpu=2)], [P(gpu=1)], True), (0, [P(gpu=0.25)], [P(gpu=0.5)], False), (0, [P(gpu=0.5)], [P(gpu=0.25)], True),
-    # multiple pods :143-190
-    (0, [P(), P()], [P(100), P(100)], False), (0, [P(100), P(100)], [P(), P()], True), (0, [P(100), P(100)], [P(100), P(50)], True), (0, [P(1000), P(100), P(100)], [P(500)] * 3, True),
-    # multiple pods, different pod statuses :192-260 — only pending pods are compared
-    (0, [P(100), P(100, pending=0)], [P(100), P(100)], False), (0, [P(100), P(100)], [P(100), P(100, pending=0)], True), (0, [P(100), P(100)], [P(100), P(150, pending=0)], True),
-    # UpdateRepresentative :263-305 — the job replaces the representative only if every sorted request is no larger
-    (1, [P(100), P(100)], [P(100), P(50)], True), (1, [P(1000), P(100), P(100)], [P(500)] * 3, False),
-]
+MINIMAL_JOB = [(1 if c["fn"] == "UpdateRepresentative" else 0, c["representative"], c["job"], c["want"], c["line"]) for c in T.load_golden("kat_minimal_job")["cases"]]  # actions/common/minimal_job_comparison_test.go (tools/go_kat_minimal_job.py): mode, the representative's pods, the job's pods [pending, milli-CPU, memory, GPUs], want
 
 
-@pytest.mark.parametrize("mode,rep,job,want", MINIMAL_JOB)
-def test_minimal_job_comparison_known_answers(mode, rep, job, want):
+@pytest.mark.parametrize("mode,rep,job,want,line", MINIMAL_JOB, ids=[f"minimal_job:{c[4]}" for c in MINIMAL_JOB])
+def test_minimal_job_comparison_known_answers(mode, rep, job, want, line):
     """MinimalJobRepresentatives (actions/common/minimal_job_comparison.go:15-112): a job is skipped when a job of its signature with no larger sorted requests already failed"""
     lib = T.Oracle.lib(); lib.kai_oracle_minimal_job.restype = C.c_int
     a, b = np.array(rep, np.float64).reshape(-1, 4), np.array(job, np.float64).reshape(-1, 4)
