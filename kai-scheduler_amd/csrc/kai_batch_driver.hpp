@@ -163,12 +163,15 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     // ... and, when no class carries a static bitmap of its own, as two wavefronts side by side: the planned order over the levels' populations, the sets behind a command ring
     // (kai_fill_counts.hpp); KAI_FILL_ONE_WAVE=1 keeps the one-wave kernel (A/B runs, tests)
     const bool counts = buckets && bp.n_ok == 0 && !std::getenv("KAI_FILL_UNBATCHED") && !std::getenv("KAI_FILL_ONE_WAVE") && dyn_bk + sizeof(FcLds) <= (size_t)(160 - 16) * 1024;
-    bs.buckets = buckets ? (counts ? 2 : 1) : 0;
+    // ... and, up to eight levels, with a wavefront per level behind the counting machine (kai_fill_levels.hpp); KAI_FILL_TWO_WORKERS=1 keeps the kernel of kai_fill_counts.hpp (A/B runs, tests)
+    const bool levels = counts && bp.levels <= KFL_LMAX && !std::getenv("KAI_FILL_TWO_WORKERS") && dyn_bk + sizeof(FlLds) <= (size_t)(160 - 16) * 1024;
+    const int fill_tb = levels ? 64 * (bp.levels + 1) : 256;
+    bs.buckets = buckets ? (levels ? 3 : counts ? 2 : 1) : 0;
     if (sharded) { l.shard_mask_nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
                    const int b0 = c.bt.n_lo / KAI_BLOCK, b1 = (c.bt.n_hi + KAI_BLOCK - 1) / KAI_BLOCK; (void)b0; (void)b1;
                    l.index_from_recs(std::max(1, c.NB), 64, c, (const NodeRec*)c.bt.nrec, c.N, (uint64_t*)c.sum1_key, (int32_t*)c.sum1_node, c.NB, 0, c.NB);
                    if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }
-    else { if (counts) l.fill_counts(1, 256, dyn_bk, c, rp, bp); else if (buckets) l.fill_buckets(1, 256, dyn_bk, c, rp, bp); else l.fill(1, 64, dyn, c, rp, l1_in_lds); if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; }
+    else { if (levels) l.fill_levels(1, fill_tb, dyn_bk, c, rp, bp); else if (counts) l.fill_counts(1, 256, dyn_bk, c, rp, bp); else if (buckets) l.fill_buckets(1, 256, dyn_bk, c, rp, bp); else l.fill(1, 64, dyn, c, rp, l1_in_lds); if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; }
     int H = 256;  // jobs a leaf offers per round: everything a usual leaf holds (a plan is cheap next to the rounds a short one costs); halved while most of a plan is thrown away
     if (const char* e = std::getenv("KAI_BATCH_H0")) { const int v = std::atoi(e); if (v >= 8) H = v; }
     int64_t ops_base = ops_base0, stmt_base = stmt_base0;
@@ -194,6 +197,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         }
         l.plan_emit(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c);
         if (sharded) { rp.start = 0; if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }
+        else if (levels) l.fill_levels(1, fill_tb, dyn_bk, c, rp, bp);
         else if (counts) l.fill_counts(1, 256, dyn_bk, c, rp, bp);
         else if (buckets) l.fill_buckets(1, 256, dyn_bk, c, rp, bp);
         else l.fill(1, 64, dyn, c, rp, l1_in_lds);

@@ -294,6 +294,13 @@ struct DevLauncher {
         hipLaunchKernelGGL(k_fill_counts, dim3(g), dim3(b), dyn, core->stream, c, rp, bp);
         if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);
     }
+    bool fill_lv_attr_set = false;
+    void fill_levels(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
+        if (!fill_lv_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_levels), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_lv_attr_set = true; }
+        if (rp.mode == 0) (void)hipEventRecord(core->bev[1], core->stream);
+        hipLaunchKernelGGL(k_fill_levels, dim3(g), dim3(b), dyn, core->stream, c, rp, bp);
+        if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);
+    }
     void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
         if (!fill_bk_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_buckets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_bk_attr_set = true; }
         if (rp.mode == 0) (void)hipEventRecord(core->bev[1], core->stream);
@@ -977,7 +984,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         core->stats.reserved[4] = bs.rounds; core->stats.reserved[5] = bs.fill_cycles; core->stats.reserved[6] = bs.mismatches;
         auto us = [](double ms) { int64_t v = (int64_t)(ms * 1000.0); return v < 0 ? (int64_t)0 : v > 0x1fffff ? (int64_t)0x1fffff : v; };
         core->stats.reserved[7] = (us(core->batch_plan_ms) << 42) | (us(core->batch_fill_ms) << 21) | us(core->batch_apply_ms);
-        core->stats.reserved[1] = (bs.block_loads & ((1ll << 48) - 1)) | ((int64_t)(bs.buckets ? 1 : 0) << 62) | ((int64_t)(bs.buckets == 2 ? 1 : 0) << 61); /* bit 62: the fill ran on the sets by free devices (kai_fill_buckets.hpp), bit 61: as two wavefronts (kai_fill_counts.hpp) */ core->stats.reserved[0] = core->world > 1 ? bs.exchanges : core->stats.reserved[0];
+        core->stats.reserved[1] = (bs.block_loads & ((1ll << 48) - 1)) | ((int64_t)(bs.buckets ? 1 : 0) << 62) | ((int64_t)(bs.buckets >= 2 ? 1 : 0) << 61) | ((int64_t)(bs.buckets == 3 ? 1 : 0) << 60); /* bit 62: the fill ran on the sets by free devices (kai_fill_buckets.hpp), bit 61: behind a counting machine (kai_fill_counts.hpp), bit 60: with a wavefront per level (kai_fill_levels.hpp) */ core->stats.reserved[0] = core->world > 1 ? bs.exchanges : core->stats.reserved[0];
         if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai batch%s: rounds %lld mismatches %lld planned %lld max_h %d | fill cycles %lld load %lld update %lld rescan %lld | block loads %lld rescans %lld %lld %lld | plan %.3f ms fill %.3f ms apply %.3f ms\n",
             bs.buckets ? " (bucket fill)" : "", (long long)bs.rounds, (long long)bs.mismatches, (long long)bs.planned, bs.max_h, (long long)bs.fill_cycles, (long long)bs.fill_load, (long long)bs.fill_update, (long long)bs.fill_rescan,
             (long long)bs.block_loads, (long long)bs.rescans1, (long long)bs.rescans2, (long long)bs.rescans3, core->batch_plan_ms, core->batch_fill_ms, core->batch_apply_ms);

@@ -231,6 +231,26 @@ struct HostLauncher {
         g_native_fill_ms += nat.ms; g_native_fill_launches++; g_native_fill_decisions += nat.fs.decisions; if (!same) g_native_fill_diffs++;
     }
     void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); }); }); }
+    // KAI_HOSTSIM_FILL_DUMP=<prefix>: inputs and outputs of every fill launch over >= 1 000 planned jobs as <prefix>_<n>.bin (what tools/micro/fill_bench.hip replays on the MI355X)
+    static void fill_dump(const KaiCtx& c, RoundParams rp, BucketParams bp, bool outputs) {
+        const char* pre = std::getenv("KAI_HOSTSIM_FILL_DUMP"); if (!pre || rp.mode == 1) return;
+        const BatchCtx& bt = c.bt; const int V = bt.q_valid[c.Q]; if (V - rp.start < 1000) return;
+        static int seq = 0; if (!outputs) seq++;
+        char path[512]; std::snprintf(path, sizeof path, "%s_%d.%s", pre, seq, outputs ? "out" : "in");
+        FILE* f = std::fopen(path, "wb"); if (!f) return;
+        auto w = [&](const void* p, size_t n) { std::fwrite(p, 1, n, f); };
+        if (!outputs) {
+            int32_t hdr[16] = {0x4b464c31, c.C, c.Q, c.P, V, bp.levels, bp.nw, bp.nw1, bp.n_ok, c.NB, 0, 0, 0, 0, 0, 0}; w(hdr, sizeof hdr); w(&rp, sizeof rp); w(&bp, sizeof bp);
+            for (int k = 0; k < 64; k++) { const double q = k < c.C ? c.cls[k].req[KAI_RES_GPU] : 0.0; w(&q, 8); }
+            w((const void*)bt.g_flag, (size_t)V); w((const void*)bt.g_first, (size_t)V * 4); w((const void*)bt.g_nt, (size_t)V * 4); w((const void*)bt.g_ucls, (size_t)V * 4);
+            w((const void*)bt.t_cls, (size_t)c.P * 4); w((const void*)bt.bk_words, (size_t)bp.levels * bp.nw * 8);
+        } else {
+            w((const void*)bt.fs, sizeof(FillStatus)); w((const void*)bt.g_out, (size_t)V); w((const void*)bt.g_opoff, (size_t)V * 4); w((const void*)bt.g_stmt, (size_t)V * 4);
+            w((const void*)bt.t_node, (size_t)c.P * 4); w((const void*)bt.bk_words, (size_t)bp.levels * bp.nw * 8);
+        }
+        std::fclose(f);
+    }
+    void fill_levels(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { fill_dump(c, rp, bp, false); with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_levels(c, rp, bp); }); }); fill_dump(c, rp, bp, true); }
     void fill_counts(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_counts(c, rp, bp); }); }); }
     void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { kw::launch(g, b, 0, [&] { kb_apply_jobs(c, ops_base, stmt_base); }); }
     void apply_nodes(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_apply_nodes(c); }); }
@@ -510,7 +530,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     struct Rep { std::vector<std::vector<char>> pool; KaiCtx c{}; };
     std::vector<Rep> reps;
     HostBackend be; Engine<HostBackend> eng(c, be);
-    int64_t batch_rounds = 0, batch_actions = 0, bucket_actions = 0, counts_actions = 0;
+    int64_t batch_rounds = 0, batch_actions = 0, bucket_actions = 0, counts_actions = 0, levels_actions = 0;
     bool index_stale = false;
     for (int i = 0; i < n_actions; i++) {
         if (actions[i] < KAI_ACTION_ALLOCATE || actions[i] > KAI_ACTION_PREEMPT) return KAI_ERR_UNSUPPORTED;
@@ -576,7 +596,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             if (int rc = batch_allocate(hl, c, prep.shape, bs, c.st->out_len, c.st->stmts)) return rc;
             if (bs.ran) {
                 c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops; c.st->stmts += bs.committed;
-                c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++; bucket_actions += bs.buckets ? 1 : 0; counts_actions += bs.buckets == 2 ? 1 : 0;
+                c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++; bucket_actions += bs.buckets ? 1 : 0; counts_actions += bs.buckets >= 2 ? 1 : 0; levels_actions += bs.buckets == 3 ? 1 : 0;
                 if (bs.buckets) index_stale = true;
                 g_sh_exchanges = bs.exchanges;
             } else {
@@ -612,7 +632,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     if (pod_node_out) for (int p = 0; p < P; p++) pod_node_out[p] = c.p_node[p] >= 0 ? prep.perm[c.p_node[p]] : -1;
     if (shares_final) fill(shares_final);
     if (nodes_out) for (int n = 0; n < N; n++) { kai_node_state& o = nodes_out[prep.perm[n]]; std::memset(&o, 0, sizeof(kai_node_state)); for (int r = 0; r < R; r++) { o.idle[r] = c.n_idle[(size_t)r * N + n]; o.releasing[r] = c.n_rel[(size_t)r * N + n]; o.used[r] = c.n_used[(size_t)r * N + n]; } }
-    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; stats->reserved[4] = batch_actions; stats->reserved[5] = batch_rounds; stats->reserved[6] = bucket_actions; stats->reserved[7] = counts_actions; }
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->decisions = c.st->decisions; stats->node_scans = c.st->node_scans; stats->nodes_scanned = c.st->nodes_scanned; stats->jobs_attempted = c.st->jobs_attempted; stats->jobs_committed = c.st->jobs_committed; stats->rollbacks = c.st->rollbacks; stats->reserved[0] = c.st->index_queries; stats->reserved[1] = c.st->index_refreshes; stats->reserved[2] = c.st->drained_jobs; stats->reserved[3] = c.st->drained_decisions; stats->reserved[4] = batch_actions; stats->reserved[5] = batch_rounds; stats->reserved[6] = bucket_actions; stats->reserved[7] = counts_actions | (levels_actions << 32); }
     return KAI_OK;
 }
 

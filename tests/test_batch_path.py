@@ -163,7 +163,12 @@ def test_bucket_fill_whole_nodes_per_step(seed, monkeypatch):
 
 def _counts(res):
     """allocate actions whose fill ran as two wavefronts (kai_fill_counts.hpp: the planned order over the levels' populations, the sets behind a command ring)"""
-    return int(res.stats.reserved[7])
+    return int(res.stats.reserved[7]) & 0xffffffff
+
+
+def _levels(res):
+    """... with a wavefront per level behind the counting machine (kai_fill_levels.hpp)"""
+    return int(res.stats.reserved[7]) >> 32
 
 
 @pytest.mark.parametrize("seed", range(20))
@@ -186,6 +191,14 @@ def test_counts_fill_against_the_one_wave_kernel_the_general_kernel_and_the_orac
     ms, a, b, d = C.c_double(), C.c_int64(), C.c_int64(), C.c_int64()
     HostSim._raw.kai_hostsim_native_fill(C.byref(ms), C.byref(a), C.byref(b), C.byref(d))
     assert a.value >= 1 and d.value == 0, "the native shadow of a launch ended with other outputs than the emulated kernel"
+    assert _levels(res) == (0 if seed % 3 == 0 else 1)  # (16-device nodes: more levels than kai_fill_levels.hpp has wavefronts for)
+    if _levels(res):  # the kernel of kai_fill_counts.hpp (two set workers) on the same snapshot
+        monkeypatch.setenv("KAI_FILL_TWO_WORKERS", "1")
+        two = HostSim.run(snap, cfg)
+        HostSim._raw.kai_hostsim_native_fill(C.byref(ms), C.byref(a), C.byref(b), C.byref(d))
+        assert _counts(two) == 1 and _levels(two) == 0 and a.value >= 1 and d.value == 0
+        assert_same(two, res); assert stats_tuple(two.stats) == stats_tuple(res.stats)
+        monkeypatch.delenv("KAI_FILL_TWO_WORKERS")
     monkeypatch.setenv("KAI_FILL_ONE_WAVE", "1")
     one = HostSim.run(snap, cfg)
     assert _buckets(one) == 1 and _counts(one) == 0
@@ -196,10 +209,11 @@ def test_counts_fill_against_the_one_wave_kernel_the_general_kernel_and_the_orac
     assert_same(gen, res); assert stats_tuple(gen.stats) == stats_tuple(res.stats)
 
 
+@pytest.mark.parametrize("two_workers", [0, 1])
 @pytest.mark.parametrize("order", [1, 2])
-def test_counts_fill_does_not_depend_on_how_the_two_wavefronts_interleave(order):
-    """The counting machine and the set worker only meet at the command ring: the emulator runs the waves of the workgroup in reverse order and with random passes sat out
-    (KW_EMU_ORDER), the results stay the oracle's."""
+def test_counts_fill_does_not_depend_on_how_the_two_wavefronts_interleave(order, two_workers):
+    """The counting machine and the set workers only meet at the command ring (and the workers of kai_fill_levels.hpp at their hand-over rings): the emulator runs the waves of
+    the workgroup in reverse order and with random passes sat out (KW_EMU_ORDER), the results stay the oracle's."""
     import subprocess, sys, os
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import kai_testlib as T\nfrom test_engine_hostsim import HostSim\nfrom test_batch_path import assert_same\n"
@@ -207,9 +221,10 @@ def test_counts_fill_does_not_depend_on_how_the_two_wavefronts_interleave(order)
             "    snap = T.pkg.synth.make_snapshot(150, 1500, 6100 + seed, queue_levels=(2, 3), prefill=0.4, gang_sizes=(1, 4, 40), gang_p=(.5, .3, .2), mem_per_gpu=8 * T.pkg.synth.GIB, cpu_per_gpu=2000.0)\n"
             "    cfg = T.abi.default_config(k_value=0.5)\n"
             "    res = HostSim.run(snap, cfg)\n"
-            "    assert res.stats.reserved[7] == 1, seed\n"
-            "    assert_same(res, T.Oracle.run(snap, cfg))\n") % (T.ROOT, os.path.join(T.ROOT, "tests"))
+            "    assert res.stats.reserved[7] == (1 if %d else 1 | 1 << 32), seed\n"
+            "    assert_same(res, T.Oracle.run(snap, cfg))\n") % (T.ROOT, os.path.join(T.ROOT, "tests"), two_workers)
     env = dict(os.environ, KW_EMU_ORDER=str(order), KW_EMU_SEED="11")
+    if two_workers: env["KAI_FILL_TWO_WORKERS"] = "1"
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
 
