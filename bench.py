@@ -189,7 +189,8 @@ def main():
         rounds = int(st.reserved[4]); fill_dec = decisions - drained
         buckets = bool((int(st.reserved[1]) >> 62) & 1)  # the fill ran on k_fill_buckets (kai_fill_buckets.hpp): sets of nodes by free devices, all in LDS
         counts = bool((int(st.reserved[1]) >> 61) & 1)   # ... as two wavefronts side by side (kai_fill_counts.hpp): the planned order over the levels' populations, the sets behind a command ring
-        fill_kernel = "k_fill_counts" if counts else "k_fill_buckets" if buckets else "k_fill"
+        levels = bool((int(st.reserved[1]) >> 60) & 1)   # ... with a wavefront per level behind a counting machine that only decides, and a bookkeeper for the dead gangs (kai_fill_levels.hpp)
+        fill_kernel = "k_fill_levels" if levels else "k_fill_counts" if counts else "k_fill_buckets" if buckets else "k_fill"
         if sharded:
             engine["exchanges_per_step"] = int(st.reserved[0])
         engine.update({"path": "batch (plan / fill / apply rounds)", "rounds": rounds, "mispredicted_jobs": int(st.reserved[6]), "fill_wave_cycles": int(st.reserved[5]),
@@ -200,7 +201,12 @@ def main():
         achieved = alg_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         traffic = pmc_traffic(desc, fill_kernel)
         cyc_dec = int(st.reserved[5]) / max(fill_dec, 1)
-        if counts:
+        if levels:
+            limiter = ("instruction issue of ONE wavefront, the counting machine of k_fill_levels: it walks the planned order over the levels' populations (a handful of integers in registers) and does nothing but "
+                       "decide and emit 8-byte commands; a wavefront per level executes them on the LDS-resident sets, a bookkeeper wavefront books the dead gangs' decisions; a conditional branch costs a lone "
+                       "wavefront ~20 cycles, a scalar instruction ~5 (tools/micro/issue_rate.hip) — not HBM and not LDS")
+            bound_actual = "single-wave issue (the counting machine; the level workers and the bookkeeper run beside it)"
+        elif counts:
             limiter = ("instruction issue of ONE wavefront, the counting machine of k_fill_counts: it walks the planned order over the levels' populations (a handful of integers in registers), ~1 000 cycles "
                        "per gang of dependent, mostly scalar instructions (profiles/r05j: section clocks); two more wavefronts execute its commands on the LDS-resident sets and write the tasks' nodes and "
                        "keep up with it (10 - 35 % idle) — not HBM and not LDS")
@@ -219,6 +225,7 @@ def main():
         # here: 4 cycles per instruction (a wave64 VALU instruction occupies its SIMD for 4 cycles; dependent SALU instructions are no faster in practice) x the instructions per decision on file.
         ipd = {"k_fill_counts": 147.1, "k_fill_buckets": 133.7, "k_fill": 530.0}.get(fill_kernel)  # profiles/r05z_fill_pmc_instruction_mix.txt (all three wavefronts), r04q_fill_pmc_instruction_mix.txt, DESIGN.md section 5.2
         chains = 3 if counts else 1  # wavefronts that carry the kernel's dependency chains side by side (k_fill_counts: the counting machine + two set workers)
+        if levels: chains = 10     # (k_fill_levels: the counting machine, a worker per level, the bookkeeper)
         own = {"bound": "single-wave instruction issue", "cycles_per_decision": cyc_dec, "clock_GHz": 2.4, "wavefronts_working": chains,
                "instructions_per_decision": ipd, "issue_floor_cycles_per_instruction": 4.0,
                "frac_of_issue_floor": (ipd / chains * 4.0 / cyc_dec) if (ipd and cyc_dec > 0) else None,
@@ -226,7 +233,7 @@ def main():
                        "floor = a wavefront issues at most one instruction per 4 cycles (a wave64 VALU instruction occupies its SIMD for 4 cycles); measured: one per 7.7 - 8.5 cycles (dependent scalar <-> vector chains)"}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bound_actual": bound_actual, "limiter": limiter, "own_roofline": own,
-                "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 4 if buckets else 1, "waves_working": 3 if counts else 1,
+                "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 10 if levels else 4 if buckets else 1, "waves_working": 10 if levels else 3 if counts else 1,
                 "traffic_source": "static: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE of the fill kernel from committed rocprofv3 --pmc passes of this command (counters need their own passes; not collected in this run)" if traffic else "no --pmc pass of this kernel on file",
                 "kernel": fill_kernel, "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "other_kernels": {"plan (k_plan_leaf / rank / scan / emit)": {"ms_per_step": plan_ms}, "apply (k_apply_jobs / nodes)": {"ms_per_step": apply_ms},

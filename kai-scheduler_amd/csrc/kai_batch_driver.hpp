@@ -165,7 +165,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     const bool counts = buckets && bp.n_ok == 0 && !std::getenv("KAI_FILL_UNBATCHED") && !std::getenv("KAI_FILL_ONE_WAVE") && dyn_bk + sizeof(FcLds) <= (size_t)(160 - 16) * 1024;
     // ... and, up to eight levels, with a wavefront per level behind the counting machine (kai_fill_levels.hpp); KAI_FILL_TWO_WORKERS=1 keeps the kernel of kai_fill_counts.hpp (A/B runs, tests)
     const bool levels = counts && bp.levels <= KFL_LMAX && !std::getenv("KAI_FILL_TWO_WORKERS") && dyn_bk + sizeof(FlLds) <= (size_t)(160 - 16) * 1024;
-    const int fill_tb = levels ? 64 * (bp.levels + 1) : 256;
+    const int fill_tb = levels ? 64 * (bp.levels + 2) : 256;  // the counting machine, a worker per level, the bookkeeper
     bs.buckets = buckets ? (levels ? 3 : counts ? 2 : 1) : 0;
     if (sharded) { l.shard_mask_nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
                    const int b0 = c.bt.n_lo / KAI_BLOCK, b1 = (c.bt.n_hi + KAI_BLOCK - 1) / KAI_BLOCK; (void)b0; (void)b1;

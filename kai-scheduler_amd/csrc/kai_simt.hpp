@@ -61,6 +61,9 @@ KW_DEV void fence_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); 
 KW_DEV int lds_load_acq(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 KW_DEV void lds_store_rel(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 KW_DEV void relax() { __builtin_amdgcn_s_sleep(1); }
+// ... the same hand-over without waiting for the producer's own stores to land: the LDS executes one wavefront's instructions in issue order, so a payload stored before the counter is
+// in place before it; all the producer must do is keep the compiler from reordering the two stores (kai_fill_levels.hpp: a worker's hand-over entries)
+KW_DEV void lds_store_ordered(int32_t* p, int v) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 }  // namespace kw
 
 #else  // ---------------------------------------------------------------------------------------------- host emulator (tests only)
@@ -222,6 +225,7 @@ inline void fence() {}
 inline void fence_wg() {}
 inline int lds_load_acq(const int32_t* p) { return *p; }
 inline void lds_store_rel(int32_t* p, int v) { *p = v; }
+inline void lds_store_ordered(int32_t* p, int v) { *p = v; }
 inline void relax(int line = __builtin_LINE()) { wave_bar(line); }  // the whole wave parks: the scheduler lets the other wavefronts of the workgroup run
 inline void wave_sync(int line = __builtin_LINE()) { wave_bar(line); }
 inline void lds_order(int line = __builtin_LINE()) { wave_bar(line); }

@@ -500,6 +500,11 @@ def on_counts(stats):
     return bool((int(stats.reserved[1]) >> 61) & 1)
 
 
+def on_levels(stats):
+    """... with a wavefront per level behind the counting machine and a bookkeeper for the dead gangs (kai_fill_levels.hpp; bit 60 of reserved[1])"""
+    return bool((int(stats.reserved[1]) >> 60) & 1)
+
+
 @pytest.mark.parametrize("seed", range(20))
 def test_gpu_counts_fill_against_the_one_wave_kernel_and_the_oracle(gpu, seed, monkeypatch):
     """k_fill_counts (kai_fill_counts.hpp) takes the clusters where no class carries a static bitmap of its own: gangs of one class decided from the levels' populations, gangs of
@@ -518,6 +523,13 @@ def test_gpu_counts_fill_against_the_one_wave_kernel_and_the_oracle(gpu, seed, m
     if not on_buckets(res.stats):
         pytest.skip("this cluster does not qualify for the sets by free devices")
     assert on_counts(res.stats)
+    assert on_levels(res.stats) == (seed % 3 != 0)  # (16-device nodes: more levels than kai_fill_levels.hpp has wavefronts for)
+    if on_levels(res.stats):  # the kernel of kai_fill_counts.hpp (two set workers) on the same snapshot
+        monkeypatch.setenv("KAI_FILL_TWO_WORKERS", "1")
+        two = run_gpu(snap, cfg)
+        assert on_counts(two.stats) and not on_levels(two.stats)
+        assert_same(two, ref); assert stats_tuple(two.stats) == stats_tuple(ref.stats)
+        monkeypatch.delenv("KAI_FILL_TWO_WORKERS")
     monkeypatch.setenv("KAI_FILL_ONE_WAVE", "1")
     one = run_gpu(snap, cfg)
     assert on_buckets(one.stats) and not on_counts(one.stats)

@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
             CK(hipMemset(d_node, 0xff, (size_t)P * 4)); CK(hipMemset(d_fs, 0, sizeof(FillStatus)));
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, 0));
-            if (kern == 0) hipLaunchKernelGGL(k_fill_levels, dim3(1), dim3(64 * (LV + 1)), dyn, 0, c, rp, bp);
+            if (kern == 0) hipLaunchKernelGGL(k_fill_levels, dim3(1), dim3(64 * (LV + 2)), dyn, 0, c, rp, bp);
             else if (kern == 1) hipLaunchKernelGGL(k_fill_counts, dim3(1), dim3(256), dyn, 0, c, rp, bp);
             else hipLaunchKernelGGL(k_fill_buckets, dim3(1), dim3(256), dyn, 0, c, rp, bp);
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
