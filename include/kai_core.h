@@ -55,7 +55,8 @@ typedef enum kai_status {
     KAI_ERR_UNSUPPORTED = -5,   /* snapshot needs a feature outside the device path (see kai_pod_flags) */
     KAI_ERR_STATE = -6,         /* call order violated (e.g. action before session_open) */
     KAI_ERR_DEVICE_FAULT = -7,  /* the device engine reported an internal fault / spin timeout */
-    KAI_ERR_COMM = -8           /* multi-GPU exchange failed */
+    KAI_ERR_COMM = -8,          /* multi-GPU exchange failed */
+    KAI_ERR_NO_MEMORY = -9      /* host memory ran out while a session was prepared (std::bad_alloc): not a malformed snapshot */
 } kai_status;
 
 /* pod status bit-set: api/pod_status/pod_status.go:25-71 */

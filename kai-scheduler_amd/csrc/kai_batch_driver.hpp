@@ -42,6 +42,7 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     KB_Z(q_cnt, Q + 1); KB_Z(q_ebase, Q + 1); KB_Z(q_kbase, Q + 1); KB_Z(q_valid, Q + 1); KB_Z(q_nk, Q + 1); KB_Z(q_sent, Q + 1); KB_Z(q_taken, Q + 1); KB_Z(q_complete, Q + 1);
     KB_Z(pk, b.pool_k); KB_Z(sp, b.pool_k); KB_Z(k_owner, b.pool_k);
     KB_Z(el_leaf, b.pool_e); KB_Z(el_ck, b.pool_e); KB_Z(el_next, b.pool_e); KB_Z(e_job, b.pool_e); KB_Z(e_grank, b.pool_e); KB_Z(e_flag, b.pool_e);
+    KB_Z(d_res, (size_t)b.pool_e * 3); KB_Z(d_meta, b.pool_e); KB_Z(d_spres, (size_t)b.pool_k * 3); KB_Z(d_spj, b.pool_k);
     KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_stmt, J + 1); KB_Z(g_first, J + 1); KB_Z(g_nt, J + 1); KB_Z(g_ucls, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
     KB_Z(t_cls, P); KB_Z(t_node, P);
     KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1); KB_Z(cls_cap, 64);
@@ -193,6 +194,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         for (int h = 1; h < shape.n_heights; h++) {
             rp.height = h;
             l.plan_rank(std::max(1, (int)((slots + TB - 1) / TB)), TB, c, rp);
+            if (h + 1 < shape.n_heights) l.plan_gather(std::max(1, (int)((slots + TB - 1) / TB)), TB, c, rp);  // (the virtual root's stream is not scanned)
             l.plan_scan(std::max(shape.h_count[h], 1), KB_PLAN_SCAN_THREADS, c, rp);  // one workgroup per queue node of this height
         }
         l.plan_emit(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c);

@@ -15,8 +15,10 @@ constexpr int KB_INF = 0x7fffffff;
 #endif
 #if defined(__HIPCC__)
 constexpr int KB_PLAN_SCAN_THREADS = 512;  // workgroup of k_plan_scan (a multiple of 64, at most 1024)
+constexpr int KB_PLAN_SCAN_ELEMS = 4;      // positions of a stream per thread and step
 #else
 constexpr int KB_PLAN_SCAN_THREADS = 128;  // the emulator runs every thread as a fiber: two waves exercise the same code
+constexpr int KB_PLAN_SCAN_ELEMS = 3;      // (an odd count: positions, threads and waves fall out of step)
 #endif
 constexpr int KB_PLACED_MAX = 1024;  // tasks of one gang the fill kernel can roll back (larger chunks do not qualify)
 
@@ -207,6 +209,38 @@ KW_BODY void kb_plan_rank(const KaiCtx& c, RoundParams rp) {
     }
 }
 
+// One thread per position of the merged streams of the nodes of height rp.height: what the node's scan reads of the position — the element's job resources and flag, and the
+// resources of the stale-path job the node's key before that pop is read through — gathered here chip-wide, so that the scan (ONE workgroup per node, walking its stream chunk by
+// chunk) reads coalesced arrays instead of waiting out three dependent loads per element and chunk (r05u: 1.4 of the 1.9 ms of a 300 k-element plan were k_plan_scan).
+KW_BODY void kb_plan_gather(const KaiCtx& c, RoundParams rp) {
+    const BatchCtx& b = c.bt;
+    const int p = kw::bid() * kw::bdim() + kw::tid();
+    int lo = b.h_off[rp.height], hi = b.h_off[rp.height + 1];  // nodes of this height, their regions ascending in the pools (k_plan_setup lays them out in h_nodes order)
+    if (lo >= hi || p < b.q_ebase[b.h_nodes[lo]]) return;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.q_ebase[b.h_nodes[mid]] <= p) lo = mid; else hi = mid; }
+    const int x = b.h_nodes[lo], eb = b.q_ebase[x], kb = b.q_kbase[x], t = p - eb;
+    if (x == c.Q) return;
+    int tot = 0;  // keys the children's streams hold = positions of the merged stream the rank kernel has written
+    for (int k = c.q_child_off[x]; k < c.q_child_off[x + 1]; k++) tot += b.q_nk[c.q_children[k]];
+    const int cap = b.q_cnt[x] + (c.q_child_off[x + 1] - c.q_child_off[x]);
+    if (t >= tot || t >= cap) return;
+    const int e = b.el_leaf[p], job = e >= 0 ? b.e_job[e] : -1; const int flag = e >= 0 ? (int)b.e_flag[e] : (int)BF_GATE;
+    double res[3] = {0, 0, 0}; int np = 0;
+    if (job >= 0) { for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k]; np = c.j_preempt[job] ? 0 : 1; }
+    for (int k = 0; k < 3; k++) b.d_res[(size_t)p * 3 + k] = res[k];
+    b.d_meta[p] = (uint8_t)(flag | (np << 2));
+    if (t > b.q_cnt[x]) return;  // the node's key region holds q_cnt + 1 slots (its element region one per child more): no key beyond
+    int spj;  // (kb_plan_scan pass 2 explains the three cases)
+    if (t == 0) { const int cs = b.cur_sp[x]; spj = cs >= 0 ? cs : b.sp[b.el_ck[eb] - 1]; }
+    else if (b.el_next[p - 1]) spj = b.sp[b.el_ck[p - 1]];
+    else spj = b.sp[b.el_ck[p] - 1];
+    b.d_spj[kb + t] = spj;
+#if !defined(__HIPCC__) && defined(KAI_PLAN_DEBUG)
+    if (std::getenv("KAI_PLAN_DEBUG_X") && x == std::atoi(std::getenv("KAI_PLAN_DEBUG_X"))) std::fprintf(stderr, "gather h %d x %d p %d eb %d kb %d t %d tot %d cap %d: el_ck[p] %d el_next[p-1] %d -> spj %d\n", rp.height, x, p, eb, kb, t, tot, cap, b.el_ck[p], t ? (int)b.el_next[p - 1] : -1, spj);
+#endif
+    for (int k = 0; k < 3; k++) b.d_spres[(size_t)(kb + t) * 3 + k] = spj >= 0 ? c.j_tta_res[(size_t)spj * 4 + k] : 0.0;
+}
+
 // One wavefront per inner node of height rp.height (the virtual root included): shares along its merged stream (segmented scan), its own
 // capacity gate (the first job it turns away ends the node's valid stream: everything after it would be ordered under wrong shares), the
 // stale-path job and the key of the node before each of its pops, as a running maximum.
@@ -239,10 +273,32 @@ KW_BODY PlanKey kb_block_scan_max(PlanScanLds& L, PlanKey v, bool valid, PlanKey
     kw::sync();
     return out;
 }
-// One WORKGROUP per queue node of height rp.height (the streams of the top levels hold tens of thousands of elements).
+// EXCLUSIVE running maximum over the workgroup's threads, seeded with carry: pre = the maximum of carry and the values of the threads before this one (have_pre: there is one);
+// last = the maximum over carry and every thread's value (valid when any of them is)
+KW_BODY void kb_block_excl_max(PlanScanLds& L, PlanKey v, bool valid, PlanKey carry, bool have_carry, PlanKey& pre, bool& have_pre, PlanKey& last, bool& have_last) {
+    const int w = kw::tid() >> 6, nw = kw::bdim() >> 6, lane = kw::lane();
+    PlanKey none; none.w0 = none.w1 = none.w2 = none.w3 = 0;
+    const PlanKey inc = kb_wave_scan_max(v, valid, none, false);  // inclusive, meaningful from the wave's first valid lane on
+    const uint64_t anyv = kw::ballot(valid);
+    if (lane == 63) { L.wkey[w] = inc; L.wvalid[w] = anyv ? 1 : 0; }
+    PlanKey ex; ex.w0 = kw::shfl_up(inc.w0, 1); ex.w1 = kw::shfl_up(inc.w1, 1); ex.w2 = kw::shfl_up(inc.w2, 1); ex.w3 = kw::shfl_up(inc.w3, 1);
+    const bool ex_valid = (anyv & ((1ull << lane) - 1)) != 0;  // a valid lane in front of this one in its wave
+    kw::sync();
+    pre = carry; have_pre = have_carry;
+    for (int i = 0; i < w; i++) if (L.wvalid[i]) { const PlanKey o = L.wkey[i]; if (!have_pre || pk_less(pre, o)) { pre = o; have_pre = true; } }
+    last = pre; have_last = have_pre;
+    for (int i = w; i < nw; i++) if (L.wvalid[i]) { const PlanKey o = L.wkey[i]; if (!have_last || pk_less(last, o)) { last = o; have_last = true; } }
+    if (ex_valid && (!have_pre || pk_less(pre, ex))) { pre = ex; have_pre = true; }
+    kw::sync();
+}
+// One WORKGROUP per queue node of height rp.height (the streams of the top levels hold tens of thousands of elements), KB_PLAN_SCAN_ELEMS consecutive positions of the stream per
+// thread and step: a thread sums its own positions serially and the workgroup scans the threads' totals, so a step of T·E positions costs the shuffles and barriers of ONE scan over T
+// values (r06c: the 38 k-position streams of config 5's eight top-level queues took 1.03 ms of a 1.9 ms plan at one position per thread).  Sums in another order are exact on this
+// path (HostPrep::batch_units).
 KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
     const BatchCtx& b = c.bt;
     KW_SHARED PlanScanLds L; KW_SHARED int32_t s_sum; KW_SHARED int32_t s_incomplete;
+    constexpr int E = KB_PLAN_SCAN_ELEMS;
     const int idx = b.h_off[rp.height] + kw::bid(), lane = kw::lane(), tid = kw::tid(), T = kw::bdim(), w = tid >> 6, nw = T >> 6;
     if (idx >= b.h_off[rp.height + 1]) return;  // the same for the whole workgroup
     const int x = b.h_nodes[idx];
@@ -261,23 +317,33 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
     // pass 1: the node's own gate along the stream; stops at the first job it turns away
     {
         double alloc[3] = {alloc0[0], alloc0[1], alloc0[2]}, anp[3] = {anp0[0], anp0[1], anp0[2]};
-        for (int base = 0; base < V; base += T) {
-            const int t = base + tid; const bool is_elem = t < V;
-            const int e = is_elem ? b.el_leaf[eb + t] : -1, job = e >= 0 ? b.e_job[e] : -1; const int flag = e >= 0 ? b.e_flag[e] : BF_GATE;
-            double res[3] = {0, 0, 0}; bool np = false;
-            if (job >= 0) { for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k]; np = !c.j_preempt[job]; }
-            double d[6], incl[6], tot[6];
-            for (int k = 0; k < 3; k++) { d[k] = flag == BF_OK ? res[k] : 0.0; d[3 + k] = (flag == BF_OK && np) ? res[k] : 0.0; }
-            kb_block_scan_add<6>(L, d, incl, tot);
-            double ab[3], abn[3];
-            for (int k = 0; k < 3; k++) { ab[k] = alloc[k] + (incl[k] - d[k]); abn[k] = anp[k] + (incl[3 + k] - d[3 + k]); }
-            const bool gate = is_elem && flag != BF_GATE && plan_gate_fails(c, x, ab, abn, res, np);
-            const uint64_t badw = kw::ballot(gate && flag == BF_OK);
-            if (lane == 0) L.wbad[w] = badw ? (w << 6) + __builtin_ctzll(badw) : 0x7fffffff;
+        for (int base = 0; base < V; base += T * E) {
+            const int t0 = base + tid * E;
+            int meta[E]; double res[E][3], pre[E][6], tsum[6] = {0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < E; j++) {  // (gathered by k_plan_gather) — the thread's own positions, each with the sums of the ones before it
+                const int t = t0 + j; const bool is_elem = t < V;
+                meta[j] = is_elem ? (int)b.d_meta[eb + t] : (int)BF_GATE;
+                for (int k = 0; k < 3; k++) res[j][k] = is_elem ? b.d_res[(size_t)(eb + t) * 3 + k] : 0.0;
+                const bool ok = (meta[j] & 3) == BF_OK, np = (meta[j] >> 2) & 1;
+                for (int k = 0; k < 6; k++) pre[j][k] = tsum[k];
+                for (int k = 0; k < 3; k++) { tsum[k] += ok ? res[j][k] : 0.0; tsum[3 + k] += (ok && np) ? res[j][k] : 0.0; }
+            }
+            double incl[6], tot[6];
+            kb_block_scan_add<6>(L, tsum, incl, tot);
+            bool gate[E]; int fb = 0x7fffffff;  // this thread's first position the node turns away (a job that would have been placed)
+            for (int j = 0; j < E; j++) {
+                const int t = t0 + j, flag = meta[j] & 3; const bool np = (meta[j] >> 2) & 1;
+                double ab[3], abn[3];
+                for (int k = 0; k < 3; k++) { ab[k] = alloc[k] + (incl[k] - tsum[k]) + pre[j][k]; abn[k] = anp[k] + (incl[3 + k] - tsum[3 + k]) + pre[j][3 + k]; }
+                gate[j] = t < V && flag != BF_GATE && plan_gate_fails(c, x, ab, abn, res[j], np);
+                if (gate[j] && flag == BF_OK && fb == 0x7fffffff) fb = tid * E + j;
+            }
+            const uint64_t wm = kw::wave_max_u64(fb == 0x7fffffff ? 0ull : (uint64_t)(0x7fffffff - fb));  // the wave's smallest fb
+            if (lane == 0) L.wbad[w] = wm ? 0x7fffffff - (int)wm : 0x7fffffff;
             kw::sync();
             int f = 0x7fffffff; for (int i = 0; i < nw; i++) if (L.wbad[i] < f) f = L.wbad[i];
             kw::sync();
-            if (gate && tid <= f) b.e_flag[e] = BF_GATE;  // threads before f hold exact shares: a dead job turned away here counts as a gate failure
+            for (int j = 0; j < E; j++) if (gate[j] && tid * E + j <= f) { const int t = t0 + j; b.e_flag[b.el_leaf[eb + t]] = BF_GATE; b.d_meta[eb + t] = (uint8_t)(BF_GATE | (meta[j] & 4)); }  // positions before f hold exact shares: a dead job turned away here counts as a gate failure
             if (f != 0x7fffffff) { V = base + f + 1; break; }
             for (int k = 0; k < 3; k++) { alloc[k] += tot[k]; anp[k] += tot[3 + k]; }
         }
@@ -285,35 +351,47 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
     kw::fence(); kw::sync();
     const bool complete = compl_all && V == sumV;
     const int nk = complete ? V : V + 1;
-    const int srank = b.q_srank[x], cs = b.cur_sp[x];
-    const double t0 = c.st->total[0], t1 = c.st->total[1], t2 = c.st->total[2];
+    const int srank = b.q_srank[x];
+    const double t0s = c.st->total[0], t1s = c.st->total[1], t2s = c.st->total[2];
     // pass 2: shares with the final flags, stale-path job and key before each pop
     {
         double alloc[3] = {alloc0[0], alloc0[1], alloc0[2]};
         PlanKey run; run.w0 = run.w1 = run.w2 = run.w3 = 0; bool have_run = false;
-        for (int base = 0; base < nk; base += T) {
-            const int t = base + tid; const bool is_elem = t < V, is_key = t < nk;
-            const int e = is_elem ? b.el_leaf[eb + t] : -1, job = e >= 0 ? b.e_job[e] : -1; const int flag = e >= 0 ? b.e_flag[e] : BF_GATE;
-            double res[3] = {0, 0, 0};
-            if (job >= 0) for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k];
-            double d[3], incl[3], tot[3];
-            for (int k = 0; k < 3; k++) d[k] = flag == BF_OK ? res[k] : 0.0;
-            kb_block_scan_add<3>(L, d, incl, tot);
-            double ab[3]; for (int k = 0; k < 3; k++) ab[k] = alloc[k] + (incl[k] - d[k]);
-            int spj = -1;
-            if (is_key) {
-                if (t == 0) spj = cs >= 0 ? cs : b.sp[b.el_ck[eb] - 1];
-                else if (b.el_next[eb + t - 1]) spj = b.sp[b.el_ck[eb + t - 1]];
-                else spj = b.sp[b.el_ck[eb + t] - 1];  // the child popped from is gone: the node's heap top is now its best remaining child
+        for (int base = 0; base < nk; base += T * E) {
+            const int t0 = base + tid * E;
+            double res[E][3], pre[E][3], tsum[3] = {0, 0, 0};
+            for (int j = 0; j < E; j++) {
+                const int t = t0 + j; const bool is_elem = t < V;
+                const int flag = is_elem ? (int)b.d_meta[eb + t] & 3 : (int)BF_GATE;
+                for (int k = 0; k < 3; k++) { res[j][k] = (is_elem && flag == BF_OK) ? b.d_res[(size_t)(eb + t) * 3 + k] : 0.0; pre[j][k] = tsum[k]; tsum[k] += res[j][k]; }
             }
-            double rq[3] = {0, 0, 0};
-            if (spj >= 0) for (int k = 0; k < 3; k++) rq[k] = c.j_tta_res[(size_t)spj * 4 + k];
-            PlanKey key; key.w0 = key.w1 = key.w2 = key.w3 = 0;
-            if (is_key) key = plan_key(c, x, ab, rq, t0, t1, t2, srank);
-            PlanKey last;
-            key = kb_block_scan_max(L, key, is_key, run, have_run, last);
-            if (is_key) { b.pk[kb + t] = key; b.sp[kb + t] = spj; b.k_owner[kb + t] = x; }
-            run = last; have_run = true;
+            double incl[3], tot[3];
+            kb_block_scan_add<3>(L, tsum, incl, tot);
+            // the keys of the thread's positions and their running maximum inside the thread.  The stale-path job (gathered by k_plan_gather): before the node's first pop its job of
+            // the last round (cur_sp) or its first child's; after a pop from a child that still has a key, that child's next stale-path job; else the child popped from is gone and the
+            // node's heap top is its best remaining child
+            PlanKey key[E]; bool kv[E]; int spj[E];
+            PlanKey tm; tm.w0 = tm.w1 = tm.w2 = tm.w3 = 0; bool tmv = false;
+            for (int j = 0; j < E; j++) {
+                const int t = t0 + j; const bool is_key = t < nk;
+                kv[j] = is_key; spj[j] = is_key ? b.d_spj[kb + t] : -1;
+                key[j].w0 = key[j].w1 = key[j].w2 = key[j].w3 = 0;
+                if (is_key) {
+                    double ab[3], rq[3];
+                    for (int k = 0; k < 3; k++) { ab[k] = alloc[k] + (incl[k] - tsum[k]) + pre[j][k]; rq[k] = b.d_spres[(size_t)(kb + t) * 3 + k]; }
+                    key[j] = plan_key(c, x, ab, rq, t0s, t1s, t2s, srank);
+                    if (tmv && pk_less(key[j], tm)) key[j] = tm;  // running maximum inside the thread
+                    tm = key[j]; tmv = true;
+                }
+            }
+            PlanKey pm, last; bool have_pm, have_last;
+            kb_block_excl_max(L, tm, tmv, run, have_run, pm, have_pm, last, have_last);
+            for (int j = 0; j < E; j++) if (kv[j]) {
+                const int t = t0 + j;
+                PlanKey out = key[j]; if (have_pm && pk_less(out, pm)) out = pm;
+                b.pk[kb + t] = out; b.sp[kb + t] = spj[j]; b.k_owner[kb + t] = x;
+            }
+            run = last; have_run = have_last;
             for (int k = 0; k < 3; k++) alloc[k] += tot[k];
         }
     }
@@ -830,6 +908,7 @@ __global__ void k_batch_nrec(KaiCtx c) { kb_build_nrec(c); }
 __global__ void k_plan_setup(KaiCtx c, RoundParams rp) { kb_plan_setup(c, rp); }
 __global__ void k_plan_leaf(KaiCtx c, RoundParams rp) { kb_plan_leaf(c, rp); }
 __global__ void k_plan_rank(KaiCtx c, RoundParams rp) { kb_plan_rank(c, rp); }
+__global__ void k_plan_gather(KaiCtx c, RoundParams rp) { kb_plan_gather(c, rp); }
 __global__ void __launch_bounds__(1024) k_plan_scan(KaiCtx c, RoundParams rp) { kb_plan_scan(c, rp); }
 __global__ void k_plan_emit(KaiCtx c) { kb_plan_emit(c); }
 template <int MODE, bool SPEC, bool L1L> __global__ void __launch_bounds__(64) k_fill(KaiCtx c, RoundParams rp) { kb_fill_variant<MODE, SPEC, L1L>(c, rp); }

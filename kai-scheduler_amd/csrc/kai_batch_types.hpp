@@ -53,6 +53,11 @@ struct BatchCtx {
     KAI_GP(uint8_t) el_next;     // [pool_e] the child still has a key after this extraction
     KAI_GP(int32_t) e_job, e_grank;  // [pool_e] leaf regions: job, rank in the global order (INT_MAX = not in its valid prefix)
     KAI_GP(uint8_t) e_flag;      // [pool_e] leaf regions: BF_*
+    // per position of an inner node's merged stream, gathered chip-wide before the node's scan (k_plan_gather): what the scan would otherwise fetch through three dependent loads per element
+    KAI_GP(double) d_res;        // [pool_e][3] the element's job: resources of its tasks-to-allocate chunk
+    KAI_GP(uint8_t) d_meta;      // [pool_e] its flag (BF_*) | non-preemptible << 2
+    KAI_GP(double) d_spres;      // [pool_k][3] resources of the stale-path job the node's key is read through before pop t
+    KAI_GP(int32_t) d_spj;       // [pool_k] that job
     // global order + task stream
     KAI_GP(int32_t) g_stmt;      // [J+1] committed jobs before this one in the round (its Statement number minus the round's base)
     KAI_GP(int32_t) g_job, g_opoff;  // [J+1] planned global order: job, offset of its operations among the round's committed ones

@@ -42,6 +42,7 @@ struct kai_core {
     void* rep_buf = nullptr; size_t rep_buf_bytes = 0;  // the victim actions' replica memory: its own allocation (never part of the slab bookkeeping), kept between sessions while it is large enough
     void* pin_buf = nullptr; size_t pin_bytes = 0;  // pinned host staging for the operations handed to the caller (grows, lives with the handle)
     char* slab = nullptr; size_t slab_left = 0;
+    size_t post_open_max = 0;  // largest slab a request made after kai_session_open needed in this session (trim rule of the next open)
     // device-only helpers
     double* d_jsum = nullptr; int32_t* d_slot_queue = nullptr;
     int32_t *d_lvl_off = nullptr, *d_lvl_parents = nullptr; int n_levels = 0; std::vector<int32_t> h_lvl_off;
@@ -92,6 +93,7 @@ int dalloc(kai_core* core, T** out, size_t n) {
     size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
     if (bytes > core->slab_left) {
         size_t want = std::max<size_t>(bytes, (size_t)256 << 20);  // 256 MiB slabs (2 MiB-aligned by the driver)
+        if (core->open && want > core->post_open_max) core->post_open_max = want;  // (what the end-of-open trim of the NEXT session keeps a slab for)
         void* p = nullptr;
         // a slab of the previous session first: a scheduler opens a session per cycle (scheduler.go:112-138), and hipFree + hipMalloc of a few 256 MiB
         // slabs per cycle would be milliseconds of every one of them
@@ -268,6 +270,7 @@ struct DevLauncher {
     void plan_setup(int g, int b, const KaiCtx& c, RoundParams rp) { (void)hipEventRecord(core->bev[0], core->stream); hipLaunchKernelGGL(k_plan_setup, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_leaf(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_leaf, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_rank(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_rank, dim3(g), dim3(b), 0, core->stream, c, rp); }
+    void plan_gather(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_gather, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_scan, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_emit(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_plan_emit, dim3(g), dim3(b), 0, core->stream, c); }
     void class_capacity(int g, int b, const KaiCtx& c, int buckets, int levels) { hipLaunchKernelGGL(k_class_capacity, dim3(g), dim3(b), 0, core->stream, c, buckets, levels); }
@@ -528,8 +531,7 @@ int kai_session_close(kai_core* core) {
     return KAI_OK;
 }
 
-int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
-    if (!core || !s) return KAI_ERR_INVALID_ARG;
+static int session_open_impl(kai_core* core, const kai_snapshot_soa* s) {
     if (s->abi_version != KAI_ABI_VERSION || s->n_res < 4 || s->n_res > KAI_MAX_RES) return fail(core, KAI_ERR_INVALID_ARG, "bad abi_version / n_res");
     HIP_TRY(core, hipSetDevice(core->device));
     const bool prof_open = std::getenv("KAI_PROF") != nullptr;  // host clocks of the open: where a production cycle's per-cycle cost goes (stderr)
@@ -564,6 +566,7 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     // shared GPUs (ABI v4): fractions of one device.  One GPU memory size for the whole cluster keeps the queue-capacity step node independent.
     SharedPods& sp = core->sp;
     try { if (!sp.build(core->cfg, s)) return fail(core, KAI_ERR_UNSUPPORTED, sp.err.c_str()); }
+    catch (const std::bad_alloc&) { throw; }  // (kai_session_open reports it as what it is)
     catch (const std::exception& e) { core->err = std::string("host preparation: ") + e.what(); return KAI_ERR_INVALID_ARG; }
     const bool shared = sp.any;
     core->shared = shared;
@@ -595,8 +598,9 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     // ---- index structures (pure re-orderings / groupings of the input; kai_host_prep.hpp)
     const auto t_staged = tnow();
     HostPrep& prep = core->prep;
-    try { if (prep.build(core->cfg, s, core->err)) { (void)hipStreamSynchronize(core->stream); return KAI_ERR_INVALID_ARG; } }  // (the staged copies read the handle's pinned buffer: done before anyone reuses it)
-    catch (const std::exception& e) { (void)hipStreamSynchronize(core->stream); core->err = std::string("host preparation: ") + e.what(); return KAI_ERR_INVALID_ARG; }  // (std::bad_alloc of a worker thread included: kai_parallel.hpp carries it here)
+    try { if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG; }  // (the staged copies read the handle's pinned buffer: kai_session_open drains the stream on every failure)
+    catch (const std::bad_alloc&) { throw; }  // (a worker thread's included: kai_parallel.hpp carries it here)
+    catch (const std::exception& e) { core->err = std::string("host preparation: ") + e.what(); return KAI_ERR_INVALID_ARG; }
     const auto t_prep = tnow();
     if (any_legacy_mig) for (int p = 0; p < P; p++)  // NodeInfo.LegacyMIGTasks (node_info.go:407-409): a node that holds a legacy MIG task takes no MIG request
         if ((s->pod_flags[p] & KAI_POD_LEGACY_MIG) && prep.pod_node[p] >= 0 && (s->pod_status[p] & (KAI_POD_ALLOCATED | KAI_POD_PIPELINED | KAI_POD_BINDING | KAI_POD_BOUND | KAI_POD_RUNNING | KAI_POD_RELEASING))) prep.node_flags[prep.pod_node[p]] |= KAI_NODE_LEGACY_MIG_I;
@@ -803,12 +807,38 @@ int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
     std::memset(&core->stats, 0, sizeof(core->stats));
     core->stats.upload_ms = ms;
     // slabs of earlier (larger) sessions this open did not take: keep two for what the session's actions still allocate (solver scratch, batch pools), release the rest
+    // ... and the smallest one that holds the LARGEST request the last session made after its open (post_open_max: a victim action's replicas, the batch pools) — or that request
+    // would pay a hipMalloc every cycle and a hipFree at the next trim, which is what keeping slabs is there to avoid
     if (core->spare.size() > 2) {
         std::sort(core->spare.begin(), core->spare.end(), [](const std::pair<void*, size_t>& a, const std::pair<void*, size_t>& b) { return a.second < b.second; });
-        while (core->spare.size() > 2) { (void)hipFree(core->spare.back().first); core->spare.pop_back(); }
+        size_t keep_big = core->spare.size();
+        for (size_t i = 2; i < core->spare.size(); i++) if (core->post_open_max > 0 && core->spare[i].second >= core->post_open_max) { keep_big = i; break; }
+        if (core->post_open_max > 0 && (core->spare[0].second >= core->post_open_max || core->spare[1].second >= core->post_open_max)) keep_big = core->spare.size();  // (one of the two small ones already holds it)
+        std::vector<std::pair<void*, size_t>> kept;
+        for (size_t i = 0; i < core->spare.size(); i++) { if (i < 2 || i == keep_big) kept.push_back(core->spare[i]); else (void)hipFree(core->spare[i].first); }
+        core->spare.swap(kept);
     }
+    core->post_open_max = 0;  // (counted from here on: dalloc)
     core->open = true; core->err = "ok";
     return KAI_OK;
+}
+// Nothing leaves this function by an exception (the host preparation's loops allocate: std::bad_alloc, also from a worker thread — kai_parallel.hpp carries it here — and
+// std::system_error from thread creation), and every failure takes ONE way out: the stream is drained — the staged copies read the handle's pinned buffer, which the next open
+// writes again — and the slabs this open took go back to the handle, so that a failed open leaves the handle as a closed session does.
+int kai_session_open(kai_core* core, const kai_snapshot_soa* s) {
+    if (!core || !s) return KAI_ERR_INVALID_ARG;
+    int rc;
+    try { rc = session_open_impl(core, s); }
+    catch (const std::bad_alloc&) { core->err = "kai_session_open: out of host memory"; rc = KAI_ERR_NO_MEMORY; }
+    catch (const std::exception& e) { core->err = std::string("kai_session_open: ") + e.what(); rc = KAI_ERR_INVALID_ARG; }
+    catch (...) { core->err = "kai_session_open: unknown exception"; rc = KAI_ERR_INVALID_ARG; }
+    if (rc != KAI_OK) {
+        const std::string why = core->err;
+        if (core->stream) (void)hipStreamSynchronize(core->stream);
+        free_session(core);
+        core->err = why;
+    }
+    return rc;
 }
 
 int kai_session_reset(kai_core* core) {

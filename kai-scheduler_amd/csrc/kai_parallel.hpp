@@ -1,6 +1,7 @@
 // kai_parallel.hpp — the host side's one parallel primitive: a range cut into contiguous chunks, one thread per chunk, chunk i handed to f(i, begin, end).
 // kai_session_open's host preparation (kai_host_prep.hpp) is loops over 10^6 pods and 10^5 jobs; every result that depends on the order of the input is
-// combined over the chunks in chunk order, so the output does not depend on the number of threads (KAI_HOST_THREADS, default: the machine's cores, at most 16).
+// combined over the chunks in chunk order, so the output does not depend on the number of threads (KAI_HOST_THREADS, 1 .. 64; default: the CPUs this process may run on —
+// its affinity mask and its cgroup's CPU quota, not the machine's core count —, at most 16).
 //
 // The chunks run on a pool of worker threads that is started on first use and kept (HostPool): the preparation is ~30 such loops per session and a scheduler opens
 // a session per cycle, so starting and joining 15 threads per loop (100 - 300 us each time) was a third of what was left of it.  A loop that finds the pool taken —
@@ -9,6 +10,8 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <exception>
 #include <memory>
@@ -17,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
 #include <unistd.h>
 
 namespace kai {
@@ -24,7 +28,15 @@ namespace kai {
 inline int host_threads() {
     static const int n = [] {
         if (const char* e = std::getenv("KAI_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1) return std::min(v, 64); }
-        const unsigned hc = std::thread::hardware_concurrency();
+        // the CPUs this process may use: the affinity mask (a container pinned to 2 CPUs of a 128-core host gets 2 threads, not 15) and the cgroup's quota where one is set
+        unsigned hc = std::thread::hardware_concurrency();
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a >= 1) hc = hc ? std::min<unsigned>(hc, (unsigned)a) : (unsigned)a; }
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+            long long quota = 0, period = 0;
+            if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) hc = std::min<unsigned>(hc ? hc : 1u, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+            std::fclose(f);
+        }
         return (int)std::max(1u, std::min(hc ? hc : 1u, 16u));
     }();
     return n;
@@ -119,9 +131,12 @@ inline void parallel_chunks(size_t n, F&& f, size_t min_chunk = 16384) {
     bool done = false;
     if (HostPool* pool = HostPool::get()) done = pool->run(k, [](void* c, int i) { (*static_cast<decltype(run)*>(c))(i); }, &run);
     if (!done) {
+        // own threads; a machine that refuses one (std::system_error) has this thread run the chunks that got none — never an unwinding vector of joinable threads (std::terminate)
         std::vector<std::thread> th; th.reserve((size_t)k - 1);
-        for (int i = 1; i < k; i++) th.emplace_back([&, i] { run(i); });
+        int started = 1;
+        try { for (; started < k; started++) th.emplace_back([&run, i = started] { run(i); }); } catch (...) {}
         run(0);
+        for (int i = started; i < k; i++) run(i);
         for (auto& t : th) t.join();
     }
     for (auto& e : err) if (e) std::rethrow_exception(e);

@@ -33,6 +33,7 @@ import (
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/preempt"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/reclaim"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/actions/utils"
+	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/common_info"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/eviction_info"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/node_info"
 	"github.com/NVIDIA/KAI-scheduler/pkg/scheduler/api/pod_info"
@@ -503,17 +504,22 @@ func replay(ssn *framework.Session, action framework.ActionType, pack *packedSna
 		meta := eviction_info.EvictionMetadata{Action: string(action)}
 		// The jobs re-placed behind the evictions are the victims' jobs AND the preemptor, in job order (actions/common/action.go:65-122), so the first pipelined task can be
 		// a victim's: the preemptor is the job of a placed task that was Pending when the Statement began and that this Statement does not evict.
+		// An elastic victim job may also place a pod of its own that was Pending in the same Statement (it is re-placed like any job of the scenario), and it can sort in front
+		// of the preemptor: the preemptor is a job NONE of whose pods this Statement evicts.
 		var preemptor *podgroup_info.PodGroupInfo
 		evicted := map[C.int32_t]bool{}
+		victimJob := map[common_info.PodGroupID]bool{}
 		for k := i; k < len(ops) && ops[k].stmt == id; k++ {
 			if ops[k].kind == C.KAI_OP_EVICT {
 				meta.EvictionGangSize++
 				evicted[ops[k].pod] = true
+				victimJob[pack.pods[ops[k].pod].Job] = true
 			}
 		}
 		for k := i; k < len(ops) && ops[k].stmt == id && preemptor == nil; k++ {
-			if (ops[k].kind == C.KAI_OP_ALLOCATE || ops[k].kind == C.KAI_OP_PIPELINE) && !evicted[ops[k].pod] && pack.pods[ops[k].pod].Status == pod_status.Pending {
-				preemptor = ssn.ClusterInfo.PodGroupInfos[pack.pods[ops[k].pod].Job]
+			task := pack.pods[ops[k].pod]
+			if (ops[k].kind == C.KAI_OP_ALLOCATE || ops[k].kind == C.KAI_OP_PIPELINE) && !evicted[ops[k].pod] && !victimJob[task.Job] && task.Status == pod_status.Pending {
+				preemptor = ssn.ClusterInfo.PodGroupInfos[task.Job]
 			}
 		}
 		messages := map[int]string{} // getEvictionMessages: every message from the state BEFORE the first eviction (actions/common/action.go:51-60)

@@ -202,6 +202,7 @@ struct HostLauncher {
     void plan_setup(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_setup(c, rp); }); }
     void plan_leaf(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_leaf(c, rp); }); }
     void plan_rank(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_rank(c, rp); }); }
+    void plan_gather(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_gather(c, rp); }); }
     void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_scan(c, rp); }); }
     void plan_emit(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_plan_emit(c); }); }
     void class_capacity(int g, int b, const KaiCtx& c, int buckets, int levels) { kw::launch(g, b, 0, [&] { kb_class_capacity(c, buckets, levels); }); }
