@@ -9,7 +9,9 @@ the allocate Action.  The unit of work is one placement decision = one allocateT
 set, picks the best fitting one, ends in allocate / pipeline / fail — SURVEY.md section 8d).
 
 Prints ONE JSON line with the contract's fields plus
-  roofline     — the dominant kernel (k_action) against the HBM roofline, algorithmic bytes = decisions x (N x 128 B + 80 B)
+  roofline     — the dominant kernel against the resource it saturates: on the batch path the fill kernel against instruction issue of its working wavefronts (with the decision
+                 throughput against HBM — algorithmic bytes = decisions x (N x 128 B + 80 B), SURVEY 8d — beside it as `algorithmic_vs_streaming`); on the sequential engine k_action
+                 against HBM
   cpu_baseline — the CPU oracle (a faithful single-thread restatement of the reference path, kind "port") timed on a
                  bounded sample of the same workload on this box's host cores.
 """
@@ -218,12 +220,12 @@ def main():
         else:
             limiter = "instruction issue of ONE wavefront (k_fill runs as 1 workgroup x 64 lanes on one of the 256 CUs; fill_cycles_per_decision below), not HBM"
             bound_actual = "single-wave issue"
-        note = (f"achieved = decisions placed by {fill_kernel} x (N x 128 B + 80 B) / its time: decision throughput against the roofline of the STREAMING formulation (SURVEY 8d), which re-reads every "
-                "node per decision.  The kernel does not stream the nodes (it answers a decision from sets of nodes by free devices / a class index), so `frac` can exceed 1 and is NOT a statement about "
-                "HBM use: `own_roofline` is the kernel's own bound — the issue rate of the wavefronts that carry its dependency chain.")
+        note = (f"{fill_kernel} answers a decision from sets of nodes by free devices / a class index kept on chip: it moves five orders of magnitude less than the streaming formulation of SURVEY 8d "
+                "(`traffic` = FETCH_SIZE + WRITE_SIZE per launch) and is bound by how fast its wavefronts issue dependent instructions.  achieved / peak: instructions per second over its working "
+                "wavefronts against one instruction per 4 cycles and wavefront; `own_roofline` has the cycles per decision, `algorithmic_vs_streaming` the decision throughput against HBM.")
         # the kernel's OWN roofline: one wavefront issues one instruction per issue slot at best; r04q measured 7.7 cycles per instruction for this kind of dependent scalar / vector mix.  Floor taken
         # here: 4 cycles per instruction (a wave64 VALU instruction occupies its SIMD for 4 cycles; dependent SALU instructions are no faster in practice) x the instructions per decision on file.
-        ipd = {"k_fill_counts": 147.1, "k_fill_buckets": 133.7, "k_fill": 530.0}.get(fill_kernel)  # profiles/r05z_fill_pmc_instruction_mix.txt (all three wavefronts), r04q_fill_pmc_instruction_mix.txt, DESIGN.md section 5.2
+        ipd = {"k_fill_levels": 170.3, "k_fill_counts": 147.1, "k_fill_buckets": 133.7, "k_fill": 530.0}.get(fill_kernel)  # profiles/r06c_fill_pmc_instruction_mix.txt (all ten wavefronts), r05z_fill_pmc_instruction_mix.txt (all three), r04q_fill_pmc_instruction_mix.txt, DESIGN.md section 5.2
         chains = 3 if counts else 1  # wavefronts that carry the kernel's dependency chains side by side (k_fill_counts: the counting machine + two set workers)
         if levels: chains = 10     # (k_fill_levels: the counting machine, a worker per level, the bookkeeper)
         own = {"bound": "single-wave instruction issue", "cycles_per_decision": cyc_dec, "clock_GHz": 2.4, "wavefronts_working": chains,
@@ -231,8 +233,15 @@ def main():
                "frac_of_issue_floor": (ipd / chains * 4.0 / cyc_dec) if (ipd and cyc_dec > 0) else None,
                "note": "cycles_per_decision = the fill wavefront's clock / decisions; instructions per decision (all working wavefronts together) from the committed SQ_INSTS_* passes of the same workload; "
                        "floor = a wavefront issues at most one instruction per 4 cycles (a wave64 VALU instruction occupies its SIMD for 4 cycles); measured: one per 7.7 - 8.5 cycles (dependent scalar <-> vector chains)"}
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        # `roofline` names the resource the kernel saturates: instruction ISSUE of the wavefronts that carry its dependency chains (one instruction per 4 cycles and wavefront at best).
+        # achieved = instructions the kernel issues per second (instructions per decision from the committed SQ_INSTS_* passes x the decisions of this run / the kernel's time, HIP events),
+        # peak = working wavefronts x clock / 4.  The figure SURVEY 8d prescribes — decisions x (N x 128 B + 80 B) against HBM — is kept beside it as `algorithmic_vs_streaming`.
+        issue_peak = chains * 2.4 / 4.0  # G instructions / s
+        issue_ach = (ipd * fill_dec / (fill_ms * 1e-3) / 1e9) if (ipd and fill_ms > 0) else 0.0
+        roof = {"bound": "issue", "achieved": issue_ach, "peak": issue_peak, "unit": "Ginstr/s", "frac": issue_ach / issue_peak if issue_peak else None, "traffic": traffic,
                 "bound_actual": bound_actual, "limiter": limiter, "own_roofline": own,
+                "algorithmic_vs_streaming": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                             "note": "SURVEY 8d's figure: decision throughput against a formulation that re-reads every node per decision; this kernel does not stream the nodes, so the fraction exceeds 1 and says nothing about HBM use"},
                 "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 10 if levels else 4 if buckets else 1, "waves_working": 10 if levels else 3 if counts else 1,
                 "traffic_source": "static: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE of the fill kernel from committed rocprofv3 --pmc passes of this command (counters need their own passes; not collected in this run)" if traffic else "no --pmc pass of this kernel on file",
                 "kernel": fill_kernel, "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,

@@ -58,35 +58,44 @@ KAI_HD int plan_cmp_q(double a, double b) {  // resource_quantities.go:80-97
     return a > b ? 1 : a < b ? -1 : 0;
 }
 
-// operands of queue_order.GetQueueOrderResult (plugins/proportion/queue_order/queue_order.go:19-73) for queue q holding `alloc` and
-// looking at a job that asks for `req`, as one ascending key.  Same f64 expressions as Engine::queue_key / dominant_share_l.
-KAI_HD PlanKey plan_key(const KaiCtx& c, int q, const double* alloc, const double* req, double t0, double t1, double t2, int32_t srank) {
-    const QShare L[3] = {c.q_share[(size_t)q * 3], c.q_share[(size_t)q * 3 + 1], c.q_share[(size_t)q * 3 + 2]};
+// Operands of queue_order.GetQueueOrderResult (plugins/proportion/queue_order/queue_order.go:19-73) for a queue holding `alloc` and looking at a job that asks for `req`, as one
+// ascending key, and the capacity gates of ONE queue of the chain (capacity_policy/max_allowed_check.go:20-66, quota_check.go:27-77) — same f64 expressions as Engine::queue_key /
+// dominant_share_l.  The plan computes MANY keys of ONE queue node: what they read of the node (its three QShare records, its priority) is loaded once into a PlanNodeConst — through
+// the context's pointers the compiler could not hoist those loads over the scans' stores.
+struct PlanNodeConst { double fair[3], deserved[3], max_allowed[3], allocatable[3], alloc_eff[3]; int32_t prio, pad; };  // allocatable: qs_allocatable; alloc_eff: ... with "unlimited" replaced by the cluster total
+KAI_HD PlanNodeConst plan_node_const(const KaiCtx& c, int q, double t0, double t1, double t2) {
+    PlanNodeConst n; n.prio = c.q_prio[q]; n.pad = 0;
+    for (int k = 0; k < 3; k++) {
+        const QShare s = c.q_share[(size_t)q * 3 + k];
+        n.fair[k] = s.fair; n.deserved[k] = s.deserved; n.max_allowed[k] = s.max_allowed;
+        const double a = qs_allocatable(s);
+        n.allocatable[k] = a; n.alloc_eff[k] = a == KAI_UNLIMITED ? (k == 0 ? t0 : k == 1 ? t1 : t2) : a;
+    }
+    return n;
+}
+KAI_HD PlanKey plan_key_c(const PlanNodeConst& n, const double* alloc, const double* req, int32_t srank) {
     bool over = true, starved = true, viol = false;
     double dwj = 0.0, dnj = 0.0;
     for (int k = 0; k < 3; k++) {
-        if (L[k].fair >= alloc[k]) over = false;                       // prioritizeUnderUtilized :87-98
+        if (n.fair[k] >= alloc[k]) over = false;
         const double with_job = alloc[k] + req[k];
-        if (plan_cmp_q(with_job, L[k].deserved) > 0) starved = false;  // prioritizeUnderQuotaWithJob :100-125
-        double allocatable = qs_allocatable(L[k]);
-        if (allocatable == 0 && with_job > 0) viol = true;             // penalizeZeroShareWithJob :127-176
-        if (allocatable == KAI_UNLIMITED) allocatable = k == 0 ? t0 : k == 1 ? t1 : t2;
-        const double vw = allocatable == 0 ? with_job * 1000 : with_job / allocatable;  // queue_resource_share.go:142-166
+        if (plan_cmp_q(with_job, n.deserved[k]) > 0) starved = false;
+        if (n.allocatable[k] == 0 && with_job > 0) viol = true;
+        const double allocatable = n.alloc_eff[k];
+        const double vw = allocatable == 0 ? with_job * 1000 : with_job / allocatable;
         const double vn = allocatable == 0 ? alloc[k] * 1000 : alloc[k] / allocatable;
         dwj = kmax(dwj, vw); dnj = kmax(dnj, vn);
     }
     PlanKey r;
-    r.w0 = ((uint64_t)over << 34) | ((uint64_t)!starved << 33) | ((uint64_t)(uint32_t)((int64_t)0x7fffffff - (int64_t)c.q_prio[q]) << 1) | (uint64_t)viol;
+    r.w0 = ((uint64_t)over << 34) | ((uint64_t)!starved << 33) | ((uint64_t)(uint32_t)((int64_t)0x7fffffff - (int64_t)n.prio) << 1) | (uint64_t)viol;
     r.w1 = pk_orderable(dwj); r.w2 = pk_orderable(dnj); r.w3 = (uint64_t)(uint32_t)srank;
     return r;
 }
-// capacity gates of ONE queue of the chain (capacity_policy/max_allowed_check.go:20-66, quota_check.go:27-77)
-KAI_HD bool plan_gate_fails(const KaiCtx& c, int q, const double* alloc, const double* alloc_np, const double* req, bool np) {
+KAI_HD bool plan_gate_fails_c(const PlanNodeConst& n, const double* alloc, const double* alloc_np, const double* req, bool np) {
     for (int k = 0; k < 3; k++) {
-        const QShare& s = c.q_share[(size_t)q * 3 + k];
         if (req[k] == 0) continue;
-        if (s.max_allowed != KAI_UNLIMITED && s.max_allowed < alloc[k] + req[k]) return true;
-        if (np && s.deserved != KAI_UNLIMITED && s.deserved < alloc_np[k] + req[k]) return true;
+        if (n.max_allowed[k] != KAI_UNLIMITED && n.max_allowed[k] < alloc[k] + req[k]) return true;
+        if (np && n.deserved[k] != KAI_UNLIMITED && n.deserved[k] < alloc_np[k] + req[k]) return true;
     }
     return false;
 }

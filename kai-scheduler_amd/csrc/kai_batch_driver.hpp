@@ -195,7 +195,11 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
             rp.height = h;
             l.plan_rank(std::max(1, (int)((slots + TB - 1) / TB)), TB, c, rp);
             if (h + 1 < shape.n_heights) l.plan_gather(std::max(1, (int)((slots + TB - 1) / TB)), TB, c, rp);  // (the virtual root's stream is not scanned)
-            l.plan_scan(std::max(shape.h_count[h], 1), KB_PLAN_SCAN_THREADS, c, rp);  // one workgroup per queue node of this height
+            // one workgroup per queue node of this height, sized by what a node's stream can hold this round: a long stream is bound by the keys' f64 divisions (more wavefronts
+            // hide more of them: r06g, 38 k positions per node: 1.03 ms at 512 threads x 1 position, 0.48 ms at 1 024 x 4), a short one by the barriers of its few steps
+            const int64_t per_node = e_bound / std::max(shape.h_count[h], 1);
+            const int scan_tb = std::min(KB_PLAN_SCAN_THREADS, per_node >= 8192 ? 1024 : per_node >= 1024 ? 512 : per_node >= 192 ? 128 : 64);
+            l.plan_scan(std::max(shape.h_count[h], 1), scan_tb, c, rp);
         }
         l.plan_emit(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c);
         if (sharded) { rp.start = 0; if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }

@@ -14,7 +14,7 @@ constexpr int KB_INF = 0x7fffffff;
 #define KB_ACC(slot, t0)
 #endif
 #if defined(__HIPCC__)
-constexpr int KB_PLAN_SCAN_THREADS = 512;  // workgroup of k_plan_scan (a multiple of 64, at most 1024)
+constexpr int KB_PLAN_SCAN_THREADS = 1024; // workgroup of k_plan_scan (a multiple of 64, at most 1024): the scan is latency bound (f64 divisions of the keys), more wavefronts hide more of it
 constexpr int KB_PLAN_SCAN_ELEMS = 4;      // positions of a stream per thread and step
 #else
 constexpr int KB_PLAN_SCAN_THREADS = 128;  // the emulator runs every thread as a fiber: two waves exercise the same code
@@ -143,7 +143,7 @@ KW_BODY void kb_plan_leaf(const KaiCtx& c, RoundParams rp) {
     double alloc[3], anp[3];
     for (int k = 0; k < 3; k++) { alloc[k] = c.q_share[(size_t)q * 3 + k].allocated; anp[k] = c.q_share[(size_t)q * 3 + k].allocated_np; }
     const uint64_t dead_mask = b.dead_mask[0];
-    const double t0 = c.st->total[0], t1 = c.st->total[1], t2 = c.st->total[2];
+    const PlanNodeConst nc = plan_node_const(c, q, c.st->total[0], c.st->total[1], c.st->total[2]);  // what the gate and the keys read of the leaf, loaded once
     PlanKey run; run.w0 = run.w1 = run.w2 = run.w3 = 0; bool have_run = false;
     for (int base = 0; base < nk; base += 64) {
         const int i = base + lane;
@@ -161,14 +161,14 @@ KW_BODY void kb_plan_leaf(const KaiCtx& c, RoundParams rp) {
                 ab[k] = alloc[k] + (s - d); abn[k] = anp[k] + (sn - dn);
                 tot[k] = kw::shfl(s, 63); totn[k] = kw::shfl(sn, 63);
             }
-            gate = is_elem && plan_gate_fails(c, q, ab, abn, res, np);
+            gate = is_elem && plan_gate_fails_c(nc, ab, abn, res, np);
             const uint64_t bad = kw::ballot(assumed && gate);
             if (!bad) break;
             if (lane == __builtin_ctzll(bad)) assumed = false;  // exact: every job before it is settled
         }
         if (is_elem) { b.e_job[eb + i] = job; b.e_flag[eb + i] = gate ? BF_GATE : dead ? BF_DEAD : BF_OK; b.e_grank[eb + i] = KB_INF; }
         PlanKey key; key.w0 = key.w1 = key.w2 = key.w3 = 0;
-        if (is_key) key = plan_key(c, q, ab, res, t0, t1, t2, srank);
+        if (is_key) key = plan_key_c(nc, ab, res, srank);
         key = kb_wave_scan_max(key, is_key, run, have_run);
         if (is_key) { b.pk[kb + i] = key; b.sp[kb + i] = job; b.k_owner[kb + i] = q; }
         run.w0 = kw::shfl(key.w0, 63); run.w1 = kw::shfl(key.w1, 63); run.w2 = kw::shfl(key.w2, 63); run.w3 = kw::shfl(key.w3, 63); have_run = true;
@@ -314,6 +314,7 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
     if (x == c.Q) { if (tid == 0) { b.q_valid[x] = V; b.q_complete[x] = (compl_all && V == sumV) ? 1 : 0; b.q_nk[x] = 0; } return; }
     double alloc0[3], anp0[3];
     for (int k = 0; k < 3; k++) { alloc0[k] = c.q_share[(size_t)x * 3 + k].allocated; anp0[k] = c.q_share[(size_t)x * 3 + k].allocated_np; }
+    const PlanNodeConst nc = plan_node_const(c, x, c.st->total[0], c.st->total[1], c.st->total[2]);  // what the gate and the keys read of the node, loaded once
     // pass 1: the node's own gate along the stream; stops at the first job it turns away
     {
         double alloc[3] = {alloc0[0], alloc0[1], alloc0[2]}, anp[3] = {anp0[0], anp0[1], anp0[2]};
@@ -335,7 +336,7 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
                 const int t = t0 + j, flag = meta[j] & 3; const bool np = (meta[j] >> 2) & 1;
                 double ab[3], abn[3];
                 for (int k = 0; k < 3; k++) { ab[k] = alloc[k] + (incl[k] - tsum[k]) + pre[j][k]; abn[k] = anp[k] + (incl[3 + k] - tsum[3 + k]) + pre[j][3 + k]; }
-                gate[j] = t < V && flag != BF_GATE && plan_gate_fails(c, x, ab, abn, res[j], np);
+                gate[j] = t < V && flag != BF_GATE && plan_gate_fails_c(nc, ab, abn, res[j], np);
                 if (gate[j] && flag == BF_OK && fb == 0x7fffffff) fb = tid * E + j;
             }
             const uint64_t wm = kw::wave_max_u64(fb == 0x7fffffff ? 0ull : (uint64_t)(0x7fffffff - fb));  // the wave's smallest fb
@@ -352,7 +353,6 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
     const bool complete = compl_all && V == sumV;
     const int nk = complete ? V : V + 1;
     const int srank = b.q_srank[x];
-    const double t0s = c.st->total[0], t1s = c.st->total[1], t2s = c.st->total[2];
     // pass 2: shares with the final flags, stale-path job and key before each pop
     {
         double alloc[3] = {alloc0[0], alloc0[1], alloc0[2]};
@@ -379,7 +379,7 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
                 if (is_key) {
                     double ab[3], rq[3];
                     for (int k = 0; k < 3; k++) { ab[k] = alloc[k] + (incl[k] - tsum[k]) + pre[j][k]; rq[k] = b.d_spres[(size_t)(kb + t) * 3 + k]; }
-                    key[j] = plan_key(c, x, ab, rq, t0s, t1s, t2s, srank);
+                    key[j] = plan_key_c(nc, ab, rq, srank);
                     if (tmv && pk_less(key[j], tm)) key[j] = tm;  // running maximum inside the thread
                     tm = key[j]; tmv = true;
                 }

@@ -280,6 +280,15 @@ template <class T> const T* copy(std::vector<std::vector<char>>& pool, const T* 
 
 }  // namespace
 
+// exhaustive checks of the small arithmetic helpers of kai_fill_levels.hpp (tests/test_batch_path.py): 0 = all hold, else the first failing case as a << 8 | b
+extern "C" int kai_hostsim_fill_levels_selfcheck() {
+    for (int b = 1; b <= 8; b++) for (int a = 0; a <= 1024; a++) if (kfl_div(a, b) != a / b) return (a << 8) | b;
+    for (int lv = 1; lv <= KFL_LMAX; lv++) for (int lane = 0; lane < 64; lane++) { const uint32_t t = kfl_tab(lane, lv); for (int g = 0; g <= lv; g++) if (kfl_quot(t, g) != g / (lane + 1)) return (g << 8) | (lane + 1) | (1 << 30); }
+    for (int g = 2; g <= KFL_LMAX; g++) for (int g2 = 1; g2 < g; g2++) { const int p = kfl_pair(g, g2); if (p < 0 || p >= KFL_PAIRS) return (g << 8) | g2 | (1 << 29); for (int h = 2; h <= KFL_LMAX; h++) for (int h2 = 1; h2 < h; h2++) if ((h != g || h2 != g2) && kfl_pair(h, h2) == p) return (g << 8) | g2 | (1 << 28); }
+    for (int g = 0; g <= 8; g++) for (int g2 = 0; g2 <= 8; g2++) for (int per = 0; per <= 8; per++) for (int k : {0, 1, 7, 1024}) { const uint64_t c = kfl_cmd(g, g2, k, per, 0x7ffffff0); const int a = (int)(uint32_t)c;
+        if ((a & 15) != g || ((a >> 4) & 15) != g2 || ((a >> 8) & 15) != per || ((a >> 12) & 0x7ff) != k || (int)(uint32_t)(c >> 32) != 0x7ffffff0) return (g << 8) | g2 | (1 << 27); }
+    return 0;
+}
 // node-sharded run (tests/test_dist_gloo.py): rank / world / offers per class and the all-gather of the test's process group, for the next run
 static int g_sh_rank = 0, g_sh_world = 1, g_sh_k = 0; static int (*g_sh_fn)(void*, const void*, void*, int64_t) = nullptr; static void* g_sh_user = nullptr; static int64_t g_sh_exchanges = 0;
 extern "C" void kai_hostsim_set_shard(int rank, int world, int k, int (*fn)(void*, const void*, void*, int64_t), void* user) { g_sh_rank = rank; g_sh_world = world; g_sh_k = k; g_sh_fn = fn; g_sh_user = user; }

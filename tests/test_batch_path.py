@@ -209,6 +209,12 @@ def test_counts_fill_against_the_one_wave_kernel_the_general_kernel_and_the_orac
     assert_same(gen, res); assert stats_tuple(gen.stats) == stats_tuple(res.stats)
 
 
+def test_fill_levels_small_arithmetic():
+    """kai_fill_levels.hpp: the scalar division by multiplication (every a <= 1024, b <= 8), the packed quotient tables, the (source, target) ring numbering, the 8-byte command's fields"""
+    HostSim.lib()
+    assert HostSim._raw.kai_hostsim_fill_levels_selfcheck() == 0
+
+
 @pytest.mark.parametrize("two_workers", [0, 1])
 @pytest.mark.parametrize("order", [1, 2])
 def test_counts_fill_does_not_depend_on_how_the_two_wavefronts_interleave(order, two_workers):
