@@ -152,19 +152,33 @@ KW_BODY void kb_plan_leaf(const KaiCtx& c, RoundParams rp) {
         double res[3] = {0, 0, 0}; bool np = false, dead = false;
         if (job >= 0) { for (int k = 0; k < 3; k++) res[k] = c.j_tta_res[(size_t)job * 4 + k]; np = !c.j_preempt[job]; dead = (b.j_clsmask[job] & dead_mask) != 0;
                         const int uc = b.j_ucls[job]; if (uc >= 0 && b.cls_cap[uc] < c.j_tta_n[job]) dead = true; }  // a gang of one class larger than what the cluster holds of it
-        bool assumed = is_elem && !dead, gate = false;
+        const bool assumed = is_elem && !dead; bool gate = false;
         double ab[3], abn[3], tot[3], totn[3];
-        for (;;) {
-            for (int k = 0; k < 3; k++) {
-                const double d = assumed ? res[k] : 0.0, dn = (assumed && np) ? res[k] : 0.0;
-                const double s = kw::wave_scan_add(d), sn = kw::wave_scan_add(dn);
-                ab[k] = alloc[k] + (s - d); abn[k] = anp[k] + (sn - dn);
-                tot[k] = kw::shfl(s, 63); totn[k] = kw::shfl(sn, 63);
+        for (int k = 0; k < 3; k++) {  // every job assumed placed unless its classes are dead: exact up to the first job the leaf's own gate turns away
+            const double d = assumed ? res[k] : 0.0, dn = (assumed && np) ? res[k] : 0.0;
+            const double s = kw::wave_scan_add(d), sn = kw::wave_scan_add(dn);
+            ab[k] = alloc[k] + (s - d); abn[k] = anp[k] + (sn - dn);
+            tot[k] = kw::shfl(s, 63); totn[k] = kw::shfl(sn, 63);
+        }
+        gate = is_elem && plan_gate_fails_c(nc, ab, abn, res, np);
+        const uint64_t bad = kw::ballot(assumed && gate);
+        if (bad) {
+            // A gate failure changes the shares every later job of the chunk sees.  From the first one on the chunk is settled job by job on uniform values (every lane computes the same
+            // running sums; lane l keeps what job l met): ~40 instructions per job, where re-scanning the chunk once per failure — what this loop did until round 6 — cost six wave scans
+            // per failure, and a leaf at its limit fails on every job (config 5: 70 k of 307 k planned jobs are gated, in the leaves with limits; k_plan_leaf was 0.3 ms of a 1.9 ms plan)
+            const int f = __builtin_ctzll(bad);
+            double ra[3], rn[3];
+            for (int k = 0; k < 3; k++) { ra[k] = kw::bcast(ab[k], f); rn[k] = kw::bcast(abn[k], f); }
+            const uint64_t em = kw::ballot(is_elem), dm = kw::ballot(dead), npm = kw::ballot(np);
+            for (int l = f; l < 64 && ((em >> l) & 1ull); l++) {
+                double r[3]; for (int k = 0; k < 3; k++) r[k] = kw::bcast(res[k], l);
+                const bool npl = (npm >> l) & 1ull, dl = (dm >> l) & 1ull;
+                const bool g = plan_gate_fails_c(nc, ra, rn, r, npl);
+                if (lane == l) { for (int k = 0; k < 3; k++) { ab[k] = ra[k]; abn[k] = rn[k]; } gate = g; }
+                if (!dl && !g) for (int k = 0; k < 3; k++) { ra[k] += r[k]; if (npl) rn[k] += r[k]; }
             }
-            gate = is_elem && plan_gate_fails_c(nc, ab, abn, res, np);
-            const uint64_t bad = kw::ballot(assumed && gate);
-            if (!bad) break;
-            if (lane == __builtin_ctzll(bad)) assumed = false;  // exact: every job before it is settled
+            if (!is_elem) for (int k = 0; k < 3; k++) { ab[k] = ra[k]; abn[k] = rn[k]; }  // (the key behind the chunk's last job)
+            for (int k = 0; k < 3; k++) { tot[k] = ra[k] - alloc[k]; totn[k] = rn[k] - anp[k]; }  // (exact: HostPrep::batch_units)
         }
         if (is_elem) { b.e_job[eb + i] = job; b.e_flag[eb + i] = gate ? BF_GATE : dead ? BF_DEAD : BF_OK; b.e_grank[eb + i] = KB_INF; }
         PlanKey key; key.w0 = key.w1 = key.w2 = key.w3 = 0;
