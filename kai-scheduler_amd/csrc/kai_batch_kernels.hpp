@@ -119,12 +119,20 @@ KW_BODY void kb_plan_setup(const KaiCtx& c, RoundParams rp) {
 // inclusive running maximum of a PlanKey over the lanes, seeded with `carry` (valid when have_carry)
 KW_BODY PlanKey kb_wave_scan_max(PlanKey v, bool valid, PlanKey carry, bool have_carry) {
     if (have_carry && (!valid || pk_less(v, carry))) { v = carry; valid = true; }
+#if defined(__HIPCC__)
+    // the DPP scan of kai_wave.hpp (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31) over (valid, key): nine DPP moves per step instead of nine ds_bpermute round trips
+#define KB_MAX_STEP(CTRL, RM) { PlanKey o; o.w0 = kw::dpp_mov64<CTRL, RM>(v.w0); o.w1 = kw::dpp_mov64<CTRL, RM>(v.w1); o.w2 = kw::dpp_mov64<CTRL, RM>(v.w2); o.w3 = kw::dpp_mov64<CTRL, RM>(v.w3); \
+                                const int ov = kw::dpp_mov32<CTRL, RM>((int)valid); if (ov && (!valid || pk_less(v, o))) { v = o; valid = true; } }
+    KB_MAX_STEP(0x111, 0xf) KB_MAX_STEP(0x112, 0xf) KB_MAX_STEP(0x114, 0xf) KB_MAX_STEP(0x118, 0xf) KB_MAX_STEP(0x142, 0xa) KB_MAX_STEP(0x143, 0xc)
+#undef KB_MAX_STEP
+#else
     const int lane = kw::lane();
     for (int d = 1; d < 64; d <<= 1) {
         PlanKey o; o.w0 = kw::shfl_up(v.w0, d); o.w1 = kw::shfl_up(v.w1, d); o.w2 = kw::shfl_up(v.w2, d); o.w3 = kw::shfl_up(v.w3, d);
         const int ov = kw::shfl_up((int)valid, d);
         if (lane >= d && ov && (!valid || pk_less(v, o))) { v = o; valid = true; }
     }
+#endif
     return v;
 }
 

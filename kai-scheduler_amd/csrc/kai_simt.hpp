@@ -250,4 +250,25 @@ template <class T> KW_DEV T wave_scan_add(T v) {
     for (int d = 1; d < 64; d <<= 1) { T o = shfl_up(v, d); if (lane() >= d) v = v + o; }
     return v;
 }
+#if defined(__HIPCC__)
+// ... on the device with DPP instead of ds_bpermute round trips (six dependent LDS-crossbar trips per scan, ~100 cycles each, against six DPP moves): row_shr 1 / 2 / 4 / 8 inside
+// the rows of 16 lanes, then row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3 — the scan of kai_wave.hpp's wave_max_u64.  A lane without a source adds 0.  The
+// additions are grouped differently from the shuffle form: integers always, and the f64 sums of the plan kernels are exact in any order (HostPrep::batch_units).
+#define KW_DPP_MOV(x, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rmask, 0xf, false)
+template <> KW_DEV int wave_scan_add<int>(int v) {
+    v += KW_DPP_MOV(v, 0x111, 0xf); v += KW_DPP_MOV(v, 0x112, 0xf); v += KW_DPP_MOV(v, 0x114, 0xf); v += KW_DPP_MOV(v, 0x118, 0xf);
+    v += KW_DPP_MOV(v, 0x142, 0xa); v += KW_DPP_MOV(v, 0x143, 0xc);
+    return v;
+}
+// the DPP move of one scan step for 32- and 64-bit values (CTRL / RMASK are instruction immediates); a lane without a source, or outside the row mask, reads 0
+template <int CTRL, int RMASK> KW_DEV int dpp_mov32(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, RMASK, 0xf, false); }
+template <int CTRL, int RMASK> KW_DEV uint64_t dpp_mov64(uint64_t x) { return ((uint64_t)(unsigned)dpp_mov32<CTRL, RMASK>((int)(x >> 32)) << 32) | (unsigned)dpp_mov32<CTRL, RMASK>((int)x); }
+template <> KW_DEV double wave_scan_add<double>(double v) {
+#define KW_DPP_ADD_F64(ctrl, rmask) { const long long b_ = __double_as_longlong(v); const unsigned lo_ = (unsigned)KW_DPP_MOV((unsigned)b_, ctrl, rmask), hi_ = (unsigned)KW_DPP_MOV((unsigned)((unsigned long long)b_ >> 32), ctrl, rmask); v = v + __longlong_as_double((long long)(((unsigned long long)hi_ << 32) | lo_)); }
+    KW_DPP_ADD_F64(0x111, 0xf) KW_DPP_ADD_F64(0x112, 0xf) KW_DPP_ADD_F64(0x114, 0xf) KW_DPP_ADD_F64(0x118, 0xf) KW_DPP_ADD_F64(0x142, 0xa) KW_DPP_ADD_F64(0x143, 0xc)
+#undef KW_DPP_ADD_F64
+    return v;
+}
+// one step of an inclusive scan over 64-bit words: the word of the lane `ctrl` names (0 for a lane without a source)
+#endif
 }  // namespace kw
