@@ -39,7 +39,7 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
 #define KB_Z(field, n) do { void* p_ = zalloc(std::max<size_t>((size_t)(n), 1) * sizeof(*b.field)); if (!p_) return KAI_ERR_HIP; b.field = (decltype(b.field))p_; } while (0)
     KB_Z(q_height, Q + 1); KB_Z(h_off, b.n_h + 1); KB_Z(h_nodes, Q + 1); KB_Z(q_srank, Q + 1);
     KB_Z(j_clsmask, J); KB_Z(j_ucls, J); KB_Z(cur_sp, Q + 1); KB_Z(qual, 4);
-    KB_Z(q_cnt, Q + 1); KB_Z(q_ebase, Q + 1); KB_Z(q_kbase, Q + 1); KB_Z(q_valid, Q + 1); KB_Z(q_nk, Q + 1); KB_Z(q_sent, Q + 1); KB_Z(q_taken, Q + 1); KB_Z(q_complete, Q + 1);
+    KB_Z(q_cnt, Q + 1); KB_Z(q_ebase, Q + 1); KB_Z(q_kbase, Q + 1); KB_Z(q_valid, Q + 1); KB_Z(q_nk, Q + 1); KB_Z(q_sent, Q + 1); KB_Z(q_taken, Q + 1); KB_Z(q_complete, Q + 1); KB_Z(plan_tot, 2);
     KB_Z(pk, b.pool_k); KB_Z(sp, b.pool_k); KB_Z(k_owner, b.pool_k);
     KB_Z(el_leaf, b.pool_e); KB_Z(el_ck, b.pool_e); KB_Z(el_next, b.pool_e); KB_Z(e_job, b.pool_e); KB_Z(e_grank, b.pool_e); KB_Z(e_flag, b.pool_e);
     KB_Z(d_res, (size_t)b.pool_e * 3); KB_Z(d_meta, b.pool_e); KB_Z(d_spres, (size_t)b.pool_k * 3); KB_Z(d_spj, b.pool_k);

@@ -114,6 +114,7 @@ KW_BODY void kb_plan_setup(const KaiCtx& c, RoundParams rp) {
         if (t == T - 1) { int te = 0, tk = 0; for (int w = 0; w < nw; w++) { te += s_part[w]; tk += s_part[32 + w]; } s_carry[0] += te; s_carry[1] += tk; }
         kw::sync();
     }
+    if (t == 0) { b.plan_tot[0] = s_carry[0]; b.plan_tot[1] = s_carry[1]; }
 }
 
 // inclusive running maximum of a PlanKey over the lanes, seeded with `carry` (valid when have_carry)
@@ -205,7 +206,7 @@ KW_BODY void kb_plan_leaf(const KaiCtx& c, RoundParams rp) {
 KW_BODY void kb_plan_rank(const KaiCtx& c, RoundParams rp) {
     const BatchCtx& b = c.bt;
     const int g = kw::bid() * kw::bdim() + kw::tid();
-    if (g >= rp.n_slots) return;  // key slots in use this round (upper bound)
+    if (g >= rp.n_slots || g >= b.plan_tot[1]) return;  // key slots in use this round (the host's upper bound / what k_plan_setup laid out)
     const int cq = b.k_owner[g];
     if (cq < 0 || cq >= c.Q) return;
     const int i = g - b.q_kbase[cq];
@@ -214,10 +215,25 @@ KW_BODY void kb_plan_rank(const KaiCtx& c, RoundParams rp) {
     if (b.q_height[x] != rp.height) return;
     const PlanKey key = b.pk[g];
     int rank = i;
-    for (int k = c.q_child_off[x]; k < c.q_child_off[x + 1]; k++) {
-        const int s = c.q_children[k]; if (s == cq) continue;
-        const int n = b.q_nk[s]; if (n == 0) continue;
-        rank += plan_lower_bound(b.pk + b.q_kbase[s], n, key);
+    // the binary searches in the siblings' streams, eight siblings in lock-step: a step's eight loads are independent and in flight together (one search after the other is a chain of
+    // ~12 dependent L2 round trips per sibling: r06l, 0.23 ms of a full plan and 0.1 ms of every short one)
+    const int c0 = c.q_child_off[x], c1 = c.q_child_off[x + 1];
+    if (c1 - c0 <= 3) {  // a narrow tree: one or two siblings, searched one after the other (eight loads per step would be seven too many)
+        for (int k = c0; k < c1; k++) { const int s2 = c.q_children[k]; if (s2 == cq) continue; const int n = b.q_nk[s2]; if (n) rank += plan_lower_bound(b.pk + b.q_kbase[s2], n, key); }
+    } else
+    for (int k0 = c0; k0 < c1; k0 += 8) {
+        int lo[8], hi[8], kbs[8];
+        for (int j = 0; j < 8; j++) {
+            const int k = k0 + j < c1 ? k0 + j : c1 - 1; const int s2 = c.q_children[k];
+            lo[j] = 0; hi[j] = (k0 + j < c1 && s2 != cq) ? b.q_nk[s2] : 0; kbs[j] = b.q_kbase[s2];
+        }
+        for (bool more = true; more;) {
+            more = false;
+            PlanKey m[8]; int mid[8];
+            for (int j = 0; j < 8; j++) { mid[j] = (lo[j] + hi[j]) >> 1; m[j] = b.pk[kbs[j] + (lo[j] < hi[j] ? mid[j] : 0)]; }  // (unconditional loads: a finished search re-reads its stream's first key)
+            for (int j = 0; j < 8; j++) { const bool act = lo[j] < hi[j], less = pk_less(m[j], key); lo[j] = (act && less) ? mid[j] + 1 : lo[j]; hi[j] = (act && !less) ? mid[j] : hi[j]; more = more || lo[j] < hi[j]; }
+        }
+        for (int j = 0; j < 8; j++) rank += lo[j];
     }
     const int V = b.q_valid[cq], cap = b.q_cnt[x] + (c.q_child_off[x + 1] - c.q_child_off[x]);
     if (rank >= cap) return;  // beyond a sentinel: never used
@@ -237,6 +253,7 @@ KW_BODY void kb_plan_rank(const KaiCtx& c, RoundParams rp) {
 KW_BODY void kb_plan_gather(const KaiCtx& c, RoundParams rp) {
     const BatchCtx& b = c.bt;
     const int p = kw::bid() * kw::bdim() + kw::tid();
+    if (p >= b.plan_tot[0]) return;
     int lo = b.h_off[rp.height], hi = b.h_off[rp.height + 1];  // nodes of this height, their regions ascending in the pools (k_plan_setup lays them out in h_nodes order)
     if (lo >= hi || p < b.q_ebase[b.h_nodes[lo]]) return;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.q_ebase[b.h_nodes[mid]] <= p) lo = mid; else hi = mid; }

@@ -46,6 +46,7 @@ struct BatchCtx {
     // per round
     KAI_GP(int32_t) q_cnt, q_ebase, q_kbase, q_valid, q_nk, q_sent, q_taken;  // [Q+1]
     KAI_GP(uint8_t) q_complete;  // [Q+1]
+    KAI_GP(int32_t) plan_tot;    // [2] element / key slots the round's regions take (k_plan_setup): the per-slot kernels leave beyond them (the host sizes their grids by an upper bound)
     KAI_GP(PlanKey) pk;          // [pool_k] running maximum of the node's keys
     KAI_GP(int32_t) sp;          // [pool_k] stale-path job after t selections
     KAI_GP(int32_t) k_owner;     // [pool_k] queue node that wrote the key slot

@@ -34,7 +34,7 @@ constexpr int KFL_XR = 32;                                 // entries of a hand-
 constexpr int KFL_SHORT = 16;                              // a gang of one class with at most this many tasks is "short": the stretch reserves its commands' room in the ring up front
 constexpr int KFL_PAIRS = KFL_LMAX * (KFL_LMAX - 1) / 2;   // (source level g, target level g2 < g)
 // a command, 8 bytes: bits 0-3 g, 4-7 g2, 8-11 per, 12-22 k | the upper word: tbase — the first k nodes of level g take `per` tasks each and move to level g2 (0: no level); their tasks are t_node[tbase ..)
-KW_BODY uint64_t kfl_cmd(int g, int g2, int k, int per, int tbase) { return (uint64_t)(uint32_t)(g | (g2 << 4) | (per << 8) | (k << 12)) | ((uint64_t)(uint32_t)tbase << 32); }
+KW_BODY uint64_t kfl_cmd(int g, int g2, int k, int per, int tbase) { return (uint64_t)((uint32_t)g | ((uint32_t)g2 << 4) | ((uint32_t)per << 8) | ((uint32_t)k << 12)) | ((uint64_t)(uint32_t)tbase << 32); }
 struct FlMove { uint64_t mask; int32_t w; int32_t seq; };  // the nodes `mask` of word w (bit 30 of w: the command's last entry); seq = the entry's number in its ring + 1, stored last (release)
 struct FlLds {
     uint64_t ring[KFL_RING];
@@ -188,15 +188,15 @@ KW_BODY void kb_fill_levels(const KaiCtx& c, RoundParams rp, BucketParams bp) {
                     const int cg = kw::bcast(cnt, (g - 1) & 63);
                     int k = kq < cg ? kq : cg; k = k > 1 ? k : 1; k = g ? k : 0;  // min(kq, nodes of the level), at least the one node; no level: nothing moves
                     const int per = r < rem ? r : rem, g2 = g - per * qc;
-                    KFL_EMIT(g, g2 & 15, k, per, first + placed);  // (a failed step writes a slot that stays unpublished)
+                    KFL_EMIT(g, g2, k, per, first + placed);  // (a failed step writes a slot that stays unpublished: whatever its fields hold)
                     KFL_EVENT(g, g2, k);
                     placed += k * per;
                 }
                 KFL_T(2);
                 const bool ok = !fail;
                 okm |= (uint64_t)ok << jj;
-                decisions += ok ? nt : placed + 1;  // a gang that found no node for its next task booked the tasks it placed and that one
-                rollbacks += ok ? 0 : 2;
+                decisions += placed + (int)fail;  // every task placed is a decision (a gang that fits places them all); a gang that found no node for its next task booked that one too
+                rollbacks += 2 * (int)fail;
                 cnt = ok ? cnt : cnt_s; nz = ok ? nz : nz_s; wp = ok ? wp : wp_s;  // Statement.Rollback: nothing was published
                 if (wp - pub >= 64) { kw::lds_store_rel(&L.head, wp); pub = wp; }
                 const bool mism = (flag == BF_OK) != ok;  // the job ended differently from its prediction: it is the round's last
