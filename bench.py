@@ -196,7 +196,7 @@ def main():
         if sharded:
             engine["exchanges_per_step"] = int(st.reserved[0])
         engine.update({"path": "batch (plan / fill / apply rounds)", "rounds": rounds, "mispredicted_jobs": int(st.reserved[6]), "fill_wave_cycles": int(st.reserved[5]),
-                       "fill_kernel": fill_kernel, "fill_block_loads": int(st.reserved[1]) & ((1 << 48) - 1), "plan_ms": plan_ms, "fill_ms": fill_ms, "apply_ms": apply_ms,
+                       "fill_kernel": fill_kernel, "round_loop": "on the device (RoundCtl / k_round_next: the host enqueues ahead and never drains the stream between rounds)" if (int(st.reserved[1]) >> 59) & 1 else "on the host (one drain of the stream per round)", "fill_block_loads": int(st.reserved[1]) & ((1 << 48) - 1), "plan_ms": plan_ms, "fill_ms": fill_ms, "apply_ms": apply_ms,
                        "fill_cycles_per_decision": int(st.reserved[5]) / max(fill_dec, 1)})
         # the dominant kernel: k_fill, `rounds` launches per step, timed with HIP events on its stream around every launch (kai_core.hip DevLauncher)
         alg_bytes_launch = fill_dec * b_dec / max(rounds, 1); avg_launch_ms = fill_ms / max(rounds, 1)

@@ -19,6 +19,7 @@ struct BatchStats {
     int64_t decisions = 0, attempted = 0, committed = 0, rollbacks = 0, ops = 0;
     int64_t fill_cycles = 0, fill_load = 0, fill_update = 0, fill_rescan = 0, block_loads = 0, rescans1 = 0, rescans2 = 0, rescans3 = 0;
     int32_t drain = 0, ran = 0, max_h = 0, buckets = 0;  // buckets: the fill ran on kai_fill_buckets.hpp
+    int32_t st_on_device = 0, dev_loop = 0;  // the sums are in the engine's state already (k_round_finish): the caller adds nothing; dev_loop: the round loop's state lived on the device
     int64_t exchanges = 0;  // node-sharded group: all-gathers of the action
 };
 
@@ -45,7 +46,7 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     KB_Z(d_res, (size_t)b.pool_e * 3); KB_Z(d_meta, b.pool_e); KB_Z(d_spres, (size_t)b.pool_k * 3); KB_Z(d_spj, b.pool_k);
     KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_stmt, J + 1); KB_Z(g_first, J + 1); KB_Z(g_nt, J + 1); KB_Z(g_ucls, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
     KB_Z(t_cls, P); KB_Z(t_node, P);
-    KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1); KB_Z(cls_cap, 64);
+    KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1); KB_Z(cls_cap, 64); KB_Z(ctl, 1);
     KB_Z(bk_words, (size_t)KBK_GMAX * c.NB); KB_Z(bk_ok, (size_t)std::max(c.C, 1) * c.NB); KB_Z(bk_meta, sizeof(BucketMeta) / 4);
     if (world > 1) {  // node-axis sharding: contiguous 64-node-block ranges in name-rank order, offers of K nodes per class and rank
         b.world = world; b.rank = rank;
@@ -135,32 +136,40 @@ inline int batch_policy() { const char* e = std::getenv("KAI_BATCH_POLICY"); con
 template <class L>
 int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStats& bs, int64_t ops_base0 = 0, int64_t stmt_base0 = 0) {
     bs = BatchStats{};
+    c.bt.dev_loop = 0;
     if (!c.bt.enabled || c.action != KAI_ACTION_ALLOCATE || c.queue_depth > 0 || !c.fast_ok) return 0;
     const int TB = 256, Q = c.Q, J = c.J;
     int32_t qual[4] = {0, 0, 0, 0};
     if (int rc = l.write((void*)c.bt.qual, qual, sizeof qual)) return rc;
     if (Q) { l.static_rank((Q + TB - 1) / TB, TB, c); l.static_check((Q + TB - 1) / TB, TB, c); }
     if (J) l.qualify((J + TB - 1) / TB, TB, c);
+    // (behind the qualification, before its verdict is read: the node records and the sets' build write arrays of this path only, and one drain of the stream then answers both)
+    const bool sharded = c.bt.world > 1;
+    const bool try_sets = !sharded && c.C >= 1 && !std::getenv("KAI_FILL_GENERAL");
+    l.nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
+    if (try_sets) {
+        BucketMeta m{};
+        if (int rc = l.write((void*)c.bt.bk_meta, &m, sizeof m)) return rc;
+        l.bucket_build(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
+    }
     if (int rc = l.read(qual, (const void*)c.bt.qual, sizeof qual)) return rc;
     if (qual[0] || qual[1]) return 0;
     if (c.bt.world > 1 && qual[3] > c.bt.shard_k) return 0;  // a gang that needs more nodes of one rank than a rank offers per exchange would stall mid-action: this group does not take the action
     bs.ran = 1;
     int remaining = qual[2];
-    l.nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
-    const bool sharded = c.bt.world > 1;
     int l1_in_lds = 0; const size_t dyn = batch_fill_lds(c, l1_in_lds);
     RoundParams rp{}; rp.mode = 1;
     FillStatus fs{};
     // bin-packed GPU classes on nodes where only the devices can bind: the fill over sets of nodes by free devices, all in LDS (kai_fill_buckets.hpp);
     // KAI_FILL_GENERAL=1 keeps the general kernel (A/B runs, tests)
     bool buckets = false; BucketParams bp{}; size_t dyn_bk = 0;
-    if (!sharded && c.C >= 1 && !std::getenv("KAI_FILL_GENERAL")) {
+    if (try_sets) {
         BucketMeta m{};
-        if (int rc = l.write((void*)c.bt.bk_meta, &m, sizeof m)) return rc;
-        l.bucket_build(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
         if (int rc = l.read(&m, (const void*)c.bt.bk_meta, sizeof m)) return rc;
         buckets = batch_bucket_params(c, m, bp, dyn_bk);
     }
+    const bool dev_loop = !sharded && !std::getenv("KAI_BATCH_HOST_LOOP");  // rounds without the host (below)
+    bs.dev_loop = dev_loop ? 1 : 0;
     // ... and, when no class carries a static bitmap of its own, as two wavefronts side by side: the planned order over the levels' populations, the sets behind a command ring
     // (kai_fill_counts.hpp); KAI_FILL_ONE_WAVE=1 keeps the one-wave kernel (A/B runs, tests)
     const bool counts = buckets && bp.n_ok == 0 && !std::getenv("KAI_FILL_UNBATCHED") && !std::getenv("KAI_FILL_ONE_WAVE") && dyn_bk + sizeof(FcLds) <= (size_t)(160 - 16) * 1024;
@@ -172,7 +181,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
                    const int b0 = c.bt.n_lo / KAI_BLOCK, b1 = (c.bt.n_hi + KAI_BLOCK - 1) / KAI_BLOCK; (void)b0; (void)b1;
                    l.index_from_recs(std::max(1, c.NB), 64, c, (const NodeRec*)c.bt.nrec, c.N, (uint64_t*)c.sum1_key, (int32_t*)c.sum1_node, c.NB, 0, c.NB);
                    if (int rc = batch_fill_sharded(l, c, rp, fs, bs.exchanges)) return rc; }
-    else { if (levels) l.fill_levels(1, fill_tb, dyn_bk, c, rp, bp); else if (counts) l.fill_counts(1, 256, dyn_bk, c, rp, bp); else if (buckets) l.fill_buckets(1, 256, dyn_bk, c, rp, bp); else l.fill(1, 64, dyn, c, rp, l1_in_lds); if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; }
+    else { if (levels) l.fill_levels(1, fill_tb, dyn_bk, c, rp, bp); else if (counts) l.fill_counts(1, 256, dyn_bk, c, rp, bp); else if (buckets) l.fill_buckets(1, 256, dyn_bk, c, rp, bp); else l.fill(1, 64, dyn, c, rp, l1_in_lds); if (!dev_loop) if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; }  // (k_round_init reads the verdict on the device)
     int H = 256;  // jobs a leaf offers per round: everything a usual leaf holds (a plan is cheap next to the rounds a short one costs); halved while most of a plan is thrown away
     if (const char* e = std::getenv("KAI_BATCH_H0")) { const int v = std::atoi(e); if (v >= 8) H = v; }
     int64_t ops_base = ops_base0, stmt_base = stmt_base0;
@@ -180,13 +189,14 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     c.bt.cap_on = capacity ? 1 : 0;
     { int32_t z[64]; for (int k = 0; k < 64; k++) z[k] = 0; if (capacity) if (int rc = l.write((void*)c.bt.cls_cap, z, sizeof z)) return rc; }
     if (!capacity) { int32_t inf[64]; for (int k = 0; k < 64; k++) inf[k] = 0x7fffffff; if (int rc = l.write((void*)c.bt.cls_cap, inf, sizeof inf)) return rc; }
-    while (remaining > 0) {
-        if (fs.all_dead) { bs.drain = 1; break; }
+    // one round's plan / fill / apply kernels for a plan that looks H jobs into every leaf with at most `left` jobs queued (upper bounds when the loop's state lives on the device:
+    // the per-slot kernels leave beyond what k_plan_setup laid out)
+    auto enqueue_round = [&](int H, int left, int64_t ops_base, int64_t stmt_base) -> int {
         // tasks of every scan class the cluster still holds (for the plan's prediction of gangs that no longer fit; the fill verifies every prediction, so this only
         // saves rounds): summed here, read by k_plan_leaf, zeroed again by k_plan_emit
         if (capacity && c.C >= 1) l.class_capacity(std::max(1, c.NB), 64, c, buckets ? 1 : 0, bp.levels);
         rp = RoundParams{}; rp.h_leaf = H; rp.mode = 0; rp.pad2 = std::getenv("KAI_FILL_UNBATCHED") ? 1 : 0;
-        const int64_t e_bound = std::min<int64_t>(remaining, (int64_t)shape.n_leaves * H);
+        const int64_t e_bound = std::min<int64_t>(left, (int64_t)shape.n_leaves * H);
         const int64_t slots = std::min<int64_t>(c.bt.pool_k, e_bound * shape.n_heights + Q + 1);
         rp.n_slots = (int32_t)slots;
         l.plan_setup(1, 256, c, rp);
@@ -209,22 +219,62 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         else l.fill(1, 64, dyn, c, rp, l1_in_lds);
         l.apply_jobs(std::max(1, (int)((e_bound + TB - 1) / TB)), TB, c, ops_base, stmt_base);
         if (Q) l.apply_nodes((Q + TB - 1) / TB, TB, c);
+        return 0;
+    };
+    const int policy = batch_policy();
+    const bool trace = std::getenv("KAI_BATCH_TRACE") != nullptr;
+    if (dev_loop) {
+        // Rounds without the host.  The loop's state (RoundCtl) lives on the device: k_round_next closes a round behind its apply kernels, the next round's kernels read how far to plan
+        // and where their output starts from it, and leave at once when it says done.  The host only keeps the stream fed: it enqueues round r while round r-1 runs, sized by the state
+        // after round r-2 — which it reads from a pinned copy, stream-ordered, without ever draining the stream (a drain per round was 0.1 ms of idle device: `profiles/r06l_*`,
+        // 0.86 of config 5's 24.3 ms and a quarter of config 2's 1.5).  One round is enqueued in vain at the end (its kernels find `done` and leave).
+        c.bt.dev_loop = 1;
+        l.round_init(c, remaining, H, policy, ops_base, stmt_base);
+        if (int rc = l.round_post(0, (const void*)c.bt.ctl, sizeof(RoundCtl))) return rc;
+        RoundCtl seen{}; seen.H = H; seen.remaining = remaining;
+        const int64_t max_rounds = (int64_t)remaining + 2;  // (every round executes at least one job)
+        int64_t printed = 0;
+        for (int64_t r = 1;; r++) {
+            if (r >= 2) {
+                if (int rc = l.round_wait((int)((r - 2) % KB_ROUND_SLOTS), &seen, sizeof seen)) return rc;
+                if (seen.fault) return KAI_ERR_DEVICE_FAULT;
+                if (trace && seen.rounds > printed) { printed = seen.rounds; std::fprintf(stderr, "kai batch round %lld: H %d planned %d executed %d mismatch %d decisions %lld steps %lld committed %lld remaining %d\n", (long long)seen.rounds, seen.last_h, seen.last_planned, seen.last_done, seen.last_mismatch, (long long)seen.last_decisions, (long long)seen.last_steps, (long long)seen.last_committed, seen.remaining); }
+                if (seen.done) break;
+                if (r > max_rounds) return KAI_ERR_DEVICE_FAULT;
+            }
+            const int h_ub = r >= 2 ? kb_round_policy(policy, seen.H, false, 0, 0) : H;  // round r-1 may have widened the plan
+            l.round_begin((int)(r % KB_ROUND_SLOTS));
+            if (int rc = enqueue_round(h_ub, seen.remaining, 0, 0)) return rc;
+            l.round_next(c);
+            if (int rc = l.round_post((int)(r % KB_ROUND_SLOTS), (const void*)c.bt.ctl, sizeof(RoundCtl))) return rc;
+        }
+        l.round_finish(c);
+        c.bt.dev_loop = 0;
+        bs.rounds = seen.rounds; bs.mismatches = seen.mismatches; bs.planned = seen.planned; bs.max_h = seen.max_h;
+        bs.decisions = seen.decisions; bs.attempted = seen.attempted; bs.committed = seen.committed; bs.rollbacks = seen.rollbacks; bs.ops = seen.ops;
+        bs.fill_cycles = seen.fill_cycles; bs.fill_load = seen.fill_load; bs.fill_update = seen.fill_update; bs.fill_rescan = seen.fill_rescan;
+        bs.block_loads = seen.block_loads; bs.rescans1 = seen.rescans1; bs.rescans2 = seen.rescans2; bs.rescans3 = seen.rescans3;
+        bs.drain = seen.drain; bs.st_on_device = 1;
+        return 0;
+    }
+    // the loop on the host (a node-sharded group, whose fill is a host-driven exchange loop of its own; KAI_BATCH_HOST_LOOP=1: A/B runs, tests): one drain of the stream per round
+    while (remaining > 0) {
+        if (fs.all_dead) { bs.drain = 1; break; }
+        if (int rc = enqueue_round(H, remaining, ops_base, stmt_base)) return rc;
         if (!sharded) { if (int rc = l.read(&fs, (const void*)c.bt.fs, sizeof fs)) return rc; } else if (int rc = l.read(nullptr, nullptr, 0)) return rc;
         if (fs.n_done <= 0) return KAI_ERR_DEVICE_FAULT;  // a round always executes at least one job
         bs.rounds++; bs.mismatches += fs.mismatch; bs.planned += fs.planned; bs.max_h = std::max(bs.max_h, H);
         bs.decisions += fs.decisions; bs.attempted += fs.attempted; bs.committed += fs.committed; bs.rollbacks += fs.rollbacks; bs.ops += fs.ops;
         bs.fill_cycles += fs.cycles_total; bs.fill_load += fs.cycles_load; bs.fill_update += fs.cycles_update; bs.fill_rescan += fs.cycles_rescan;
         bs.block_loads += fs.block_loads; bs.rescans1 += fs.rescans1; bs.rescans2 += fs.rescans2; bs.rescans3 += fs.rescans3;
-        if (std::getenv("KAI_BATCH_TRACE")) std::fprintf(stderr, "kai batch round %lld: H %d planned %d executed %d mismatch %d decisions %lld steps %lld committed %lld remaining %d\n", (long long)bs.rounds, H, fs.planned, fs.n_done, fs.mismatch, (long long)fs.decisions, (long long)fs.rescans2, (long long)fs.committed, remaining - fs.n_done);
+        if (trace) std::fprintf(stderr, "kai batch round %lld: H %d planned %d executed %d mismatch %d decisions %lld steps %lld committed %lld remaining %d\n", (long long)bs.rounds, H, fs.planned, fs.n_done, fs.mismatch, (long long)fs.decisions, (long long)fs.rescans2, (long long)fs.committed, remaining - fs.n_done);
         ops_base += fs.ops; stmt_base += fs.committed; remaining -= fs.n_done;
         // How far the next plan looks.  A round without a surprise: back to the full depth at once (a leaf rarely holds more than 256 queued jobs, so that plan covers the whole
         // queue; climbing back by doubling cost config 5 two rounds of ~0.6 ms each); a plan mostly thrown away: a QUARTER as far (the next surprise is usually close: the short
         // plans in between are the cheaper the shorter they are).  Measured against the rule of rounds 1-4 (x2 up, /2 down): config 5 45.1 -> 42.9 ms, config 3 100.2 -> 99.0,
         // config 2 2.13 -> 1.89 (`profiles/r05s_*`).  KAI_BATCH_POLICY selects the other rules of that A/B run (0: x2 up, /2 down; 1: x4 up; 2: full depth at once, /2 down;
-        // 3: x4 up, /4 down).
-        const int policy = batch_policy();
-        if (!fs.mismatch) H = std::min(policy == 0 ? H * 2 : (policy == 1 || policy == 3) ? H * 4 : std::max(H * 2, 256), 1 << 20);
-        else if ((int64_t)fs.n_done * 4 < fs.planned) H = std::max((policy == 3 || policy == 4) ? H / 4 : H / 2, 8);  // most of the plan was thrown away
+        // 3: x4 up, /4 down).  (kb_round_policy, kai_batch_kernels.hpp: the same rule for the loop on the device.)
+        H = kb_round_policy(policy, H, fs.mismatch != 0, fs.n_done, fs.planned);
     }
     return 0;
 }

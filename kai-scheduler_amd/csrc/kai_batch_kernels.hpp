@@ -24,6 +24,8 @@ constexpr int KB_PLACED_MAX = 1024;  // tasks of one gang the fill kernel can ro
 
 KW_BODY bool kb_is_leaf(const KaiCtx& c, int q) { return q < c.Q && c.q_child_off[q + 1] == c.q_child_off[q]; }
 KW_BODY int kb_parent(const KaiCtx& c, int q) { int p = c.q_parent[q]; return p < 0 ? c.Q : p; }
+// rounds without the host (RoundCtl): a round that was enqueued ahead of the loop's end has nothing to do — every kernel of a round starts with this
+KW_BODY bool kb_round_off(const BatchCtx& b) { return b.dev_loop && b.ctl->done; }
 
 // ------------------------------------------------------------------------------------------------------ per action
 // static sibling order (queue_order.go:214-240): rank = number of siblings that sort before q; flagged when the relation is not a strict
@@ -80,6 +82,8 @@ KW_BODY void kb_build_nrec(const KaiCtx& c) {
 // ------------------------------------------------------------------------------------------------------ plan: setup
 // candidate counts (a leaf offers its next h_leaf jobs), stream regions of every node in the pools.  One workgroup.
 KW_BODY void kb_plan_setup(const KaiCtx& c, RoundParams rp) {
+    if (kb_round_off(c.bt)) return;
+    if (c.bt.dev_loop) rp.h_leaf = c.bt.ctl->H;  // how far this plan looks: the loop's state lives on the device
     const BatchCtx& b = c.bt;
     const int T = kw::bdim(), t = kw::tid(), Q = c.Q;
     for (int q = t; q <= Q; q += T) {
@@ -142,6 +146,7 @@ KW_BODY PlanKey kb_wave_scan_max(PlanKey v, bool valid, PlanKey carry, bool have
 // (sequential in effect: a gate failure changes the shares every later job sees — resolved per 64-job chunk by re-scanning from the first
 // failure), predicts node fit from the dead classes, and emits the key the leaf competes with before each pop.
 KW_BODY void kb_plan_leaf(const KaiCtx& c, RoundParams rp) {
+    if (kb_round_off(c.bt)) return;
     const BatchCtx& b = c.bt;
     const int q = kw::bid() * (kw::bdim() >> 6) + (kw::tid() >> 6), lane = kw::lane();
     if (q >= c.Q || !kb_is_leaf(c, q)) return;
@@ -204,6 +209,7 @@ KW_BODY void kb_plan_leaf(const KaiCtx& c, RoundParams rp) {
 // One thread per key slot of a child whose parent has height rp.height: its rank in the parent's merged stream = its index in its own stream
 // + the number of smaller running-maximum keys in every sibling stream (keys of different siblings never tie: w3 is the sibling rank).
 KW_BODY void kb_plan_rank(const KaiCtx& c, RoundParams rp) {
+    if (kb_round_off(c.bt)) return;
     const BatchCtx& b = c.bt;
     const int g = kw::bid() * kw::bdim() + kw::tid();
     if (g >= rp.n_slots || g >= b.plan_tot[1]) return;  // key slots in use this round (the host's upper bound / what k_plan_setup laid out)
@@ -251,6 +257,7 @@ KW_BODY void kb_plan_rank(const KaiCtx& c, RoundParams rp) {
 // resources of the stale-path job the node's key before that pop is read through — gathered here chip-wide, so that the scan (ONE workgroup per node, walking its stream chunk by
 // chunk) reads coalesced arrays instead of waiting out three dependent loads per element and chunk (r05u: 1.4 of the 1.9 ms of a 300 k-element plan were k_plan_scan).
 KW_BODY void kb_plan_gather(const KaiCtx& c, RoundParams rp) {
+    if (kb_round_off(c.bt)) return;
     const BatchCtx& b = c.bt;
     const int p = kw::bid() * kw::bdim() + kw::tid();
     if (p >= b.plan_tot[0]) return;
@@ -335,6 +342,7 @@ KW_BODY void kb_block_excl_max(PlanScanLds& L, PlanKey v, bool valid, PlanKey ca
 // values (r06c: the 38 k-position streams of config 5's eight top-level queues took 1.03 ms of a 1.9 ms plan at one position per thread).  Sums in another order are exact on this
 // path (HostPrep::batch_units).
 KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
+    if (kb_round_off(c.bt)) return;
     const BatchCtx& b = c.bt;
     KW_SHARED PlanScanLds L; KW_SHARED int32_t s_sum; KW_SHARED int32_t s_incomplete;
     constexpr int E = KB_PLAN_SCAN_ELEMS;
@@ -438,6 +446,7 @@ KW_BODY void kb_plan_scan(const KaiCtx& c, RoundParams rp) {
 }
 // the planned global order: one thread per position of the virtual root's valid stream
 KW_BODY void kb_plan_emit(const KaiCtx& c) {
+    if (kb_round_off(c.bt)) return;
     const BatchCtx& b = c.bt;
     const int t = kw::bid() * kw::bdim() + kw::tid();
     if (t < 64 && b.cap_on) b.cls_cap[t] = 0;  // (the plan's leaves have read it: ready for the next round's sum)
@@ -753,6 +762,7 @@ KW_BODY void kb_fill_state(const KaiCtx& c, RoundParams rp, FillState& f) {
 // with R = 4 (the class key folds to its shortest form); L1L: block level of the index in LDS / in HBM.
 template <int MODE, bool SPEC, bool L1L>
 KW_BODY void kb_fill_variant(const KaiCtx& c, RoundParams rp) {
+    if (kb_round_off(c.bt)) return;
     KW_SHARED FillLds L;
     FillState f; kb_fill_state(c, rp, f);
     if (L1L) { L1Lds l1; l1.e = (KW_LDS_PTR(IdxE))(kw::dyn_lds() + (size_t)c.C * f.NSB * sizeof(IdxE)); l1.NB = f.NB; kb_fill_run<MODE, SPEC>(c, rp, L, f, l1, true); }
@@ -760,6 +770,7 @@ KW_BODY void kb_fill_variant(const KaiCtx& c, RoundParams rp) {
 }
 KW_BODY bool kb_fill_spec(const KaiCtx& c) { return (c.plugins & KB_KEY_PLUGINS) == KB_KEY_PLUGINS && c.R == 4; }
 KW_BODY void kb_fill(const KaiCtx& c, RoundParams rp, int l1_in_lds) {  // every variant behind one entry: the emulator's form (tests/host_sim)
+    if (kb_round_off(c.bt)) return;
     KW_SHARED FillLds L;
     const int lane = kw::lane();
     FillState f; f.bcur = -1; f.sbcur = -1; f.c1k = f.c2k = 0; f.c1n = f.c2n = 0; f.c1_dirty = f.c2_dirty = false; f.n_loads = f.n_r1 = f.n_r2 = f.n_r3 = 0; f.pend_n = -1; f.pend_cls = 0; f.pend_key = 0; f.topk = 0; f.topn = KB_INF; for (int i = 0; i < 4; i++) f.cy[i] = 0;
@@ -905,6 +916,8 @@ KW_BODY void kb_shard_scatter(const KaiCtx& c, int total) {
 // commit order, pod-set / job counters, node accounting, proportion event handlers up the queue chain (proportion.go:443-465).
 // Quantities add exactly in any order (HostPrep::batch_units), so f64 atomics reproduce the sequential sums bit for bit.
 KW_BODY void kb_apply_jobs(const KaiCtx& c, int64_t ops_base, int64_t stmt_base) {
+    if (kb_round_off(c.bt)) return;
+    if (c.bt.dev_loop) { ops_base = c.bt.ctl->ops_base; stmt_base = c.bt.ctl->stmt_base; }  // where the round's operations / Statements start in the action's output
     const BatchCtx& b = c.bt;
     const int t = kw::bid() * kw::bdim() + kw::tid();
     if (t >= b.fs[0].n_done) return;
@@ -933,6 +946,7 @@ KW_BODY void kb_apply_jobs(const KaiCtx& c, int64_t ops_base, int64_t stmt_base)
 }
 // how far every queue node got inside the executed prefix: leaf cursors, stale-path jobs of the inner nodes
 KW_BODY void kb_apply_nodes(const KaiCtx& c) {
+    if (kb_round_off(c.bt)) return;
     const BatchCtx& b = c.bt;
     const int x = kw::bid() * kw::bdim() + kw::tid();
     if (x >= c.Q) return;
@@ -943,6 +957,44 @@ KW_BODY void kb_apply_nodes(const KaiCtx& c) {
     if (lo == 0) return;
     if (leaf) c.lq_cur[x] += lo;
     else b.cur_sp[x] = lo < b.q_nk[x] ? b.sp[b.q_kbase[x] + lo] : -1;
+}
+
+// ------------------------------------------------------------------------------------------------------ rounds without the host
+// What batch_allocate's loop did between two rounds on the host — read the fill's status, add it to the action's sums, move the output bases, decide how far the next plan looks
+// (the rule and its measurements: kai_batch_driver.hpp batch_round_policy), stop when the queue is empty or no class fits anywhere — as ONE thread behind the round's apply kernels.
+KW_BODY void kb_round_init(const KaiCtx& c, int remaining, int H0, int policy, int64_t ops_base, int64_t stmt_base) {  // behind the mode-1 fill: its verdict on the classes opens the loop
+    if (kw::bid() != 0 || kw::tid() != 0) return;
+    const BatchCtx& b = c.bt;
+    RoundCtl r{};
+    r.H = H0; r.remaining = remaining; r.policy = policy; r.ops_base = ops_base; r.stmt_base = stmt_base;
+    if (remaining <= 0) r.done = 1;
+    else if (b.fs[0].all_dead) { r.done = 1; r.drain = 1; }
+    b.ctl[0] = r;
+}
+KW_BODY void kb_round_next(const KaiCtx& c) {
+    if (kw::bid() != 0 || kw::tid() != 0) return;
+    const BatchCtx& b = c.bt;
+    RoundCtl r = b.ctl[0];
+    if (r.done) return;
+    const FillStatus fs = b.fs[0];
+    if (fs.n_done <= 0) { r.fault = 1; r.done = 1; b.ctl[0] = r; return; }  // a round always executes at least one job
+    r.rounds++; r.mismatches += fs.mismatch; r.planned += fs.planned; r.max_h = r.max_h > r.H ? r.max_h : r.H;
+    r.decisions += fs.decisions; r.attempted += fs.attempted; r.committed += fs.committed; r.rollbacks += fs.rollbacks; r.ops += fs.ops;
+    r.fill_cycles += fs.cycles_total; r.fill_load += fs.cycles_load; r.fill_update += fs.cycles_update; r.fill_rescan += fs.cycles_rescan;
+    r.block_loads += fs.block_loads; r.rescans1 += fs.rescans1; r.rescans2 += fs.rescans2; r.rescans3 += fs.rescans3;
+    r.last_h = r.H; r.last_planned = fs.planned; r.last_done = fs.n_done; r.last_mismatch = fs.mismatch; r.last_decisions = fs.decisions; r.last_steps = fs.rescans2; r.last_committed = fs.committed;
+    r.ops_base += fs.ops; r.stmt_base += fs.committed; r.remaining -= fs.n_done;
+    r.H = kb_round_policy(r.policy, r.H, fs.mismatch != 0, fs.n_done, fs.planned);
+    if (r.remaining <= 0) r.done = 1;
+    else if (fs.all_dead) { r.done = 1; r.drain = 1; }
+    b.ctl[0] = r;
+}
+// the action's sums into the engine's state (what the host added to a copy of it after its loop)
+KW_BODY void kb_round_finish(const KaiCtx& c) {
+    if (kw::bid() != 0 || kw::tid() != 0) return;
+    const RoundCtl r = c.bt.ctl[0];
+    c.st->decisions += r.decisions; c.st->jobs_attempted += r.attempted; c.st->jobs_committed += r.committed; c.st->rollbacks += r.rollbacks; c.st->out_len += r.ops; c.st->stmts += r.committed;
+    c.st->index_queries += r.decisions; c.st->drain_pending = r.drain;
 }
 
 #if defined(__HIPCC__)
@@ -959,6 +1011,9 @@ __global__ void k_plan_emit(KaiCtx c) { kb_plan_emit(c); }
 template <int MODE, bool SPEC, bool L1L> __global__ void __launch_bounds__(64) k_fill(KaiCtx c, RoundParams rp) { kb_fill_variant<MODE, SPEC, L1L>(c, rp); }
 __global__ void k_apply_jobs(KaiCtx c, long long ops_base, long long stmt_base) { kb_apply_jobs(c, (int64_t)ops_base, (int64_t)stmt_base); }
 __global__ void k_apply_nodes(KaiCtx c) { kb_apply_nodes(c); }
+__global__ void k_round_init(KaiCtx c, int remaining, int H0, int policy, long long ops_base, long long stmt_base) { kb_round_init(c, remaining, H0, policy, (int64_t)ops_base, (int64_t)stmt_base); }
+__global__ void k_round_next(KaiCtx c) { kb_round_next(c); }
+__global__ void k_round_finish(KaiCtx c) { kb_round_finish(c); }
 __global__ void k_index_from_recs(KaiCtx c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { kb_index_from_recs(c, (KAI_GP(const NodeRec))recs, n_recs, (KAI_GP(uint64_t))l1k, (KAI_GP(int32_t))l1n, nb, blk0, blk1); }
 __global__ void k_shard_mask_nrec(KaiCtx c) { kb_shard_mask_nrec(c); }
 __global__ void k_shard_keys(KaiCtx c) { kb_shard_keys(c); }

@@ -19,6 +19,31 @@ struct FillStatus {  // written by the fill kernel, read by the host between rou
     int64_t block_loads, rescans1, rescans2, rescans3;
 };
 
+// The round loop's state on the device (rounds without the host): what batch_allocate's loop kept in host variables between rounds — how far the next plan looks, what is left of the
+// queue, where the round's operations / Statements start in the action's output — and the action's sums of the rounds' FillStatus.  k_round_next closes a round on it; every plan /
+// fill / apply kernel of a round the host enqueued ahead leaves at once when `done` is set.  The host reads it (pinned copy, stream-ordered) one round behind, to size the next grids.
+struct RoundCtl {
+    int32_t H, remaining, done, drain, fault, policy, rounds, max_h;
+    int64_t ops_base, stmt_base;
+    int64_t mismatches, planned, decisions, attempted, committed, rollbacks, ops;
+    int64_t fill_cycles, fill_load, fill_update, fill_rescan, block_loads, rescans1, rescans2, rescans3;
+    int32_t last_h, last_planned, last_done, last_mismatch;  // the round just closed (KAI_BATCH_TRACE)
+    int64_t last_decisions, last_steps, last_committed;
+};
+
+enum { KB_ROUND_SLOTS = 4 };  // pinned copies of RoundCtl the host reads behind the stream (round r in slot r % 4; the host is at most two rounds behind)
+// How far the next plan looks.  A round without a surprise: back to the full depth at once (a leaf rarely holds more than 256 queued jobs, so that plan covers the whole queue);
+// a plan mostly thrown away: a QUARTER as far (the next surprise is usually close: the short plans in between are the cheaper the shorter they are).  KAI_BATCH_POLICY selects the
+// other rules of round 5's A/B run (0: x2 up, /2 down; 1: x4 up; 2: full depth at once, /2 down; 3: x4 up, /4 down; 4, the default: full depth at once, /4 down).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int kb_round_policy(int policy, int H, bool mismatch, int n_done, int planned) {
+    if (!mismatch) { const int up = policy == 0 ? H * 2 : (policy == 1 || policy == 3) ? H * 4 : (H * 2 > 256 ? H * 2 : 256); return up < (1 << 20) ? up : (1 << 20); }
+    if ((int64_t)n_done * 4 < planned) { const int dn = (policy == 3 || policy == 4) ? H / 4 : H / 2; return dn > 8 ? dn : 8; }  // most of the plan was thrown away
+    return H;
+}
+
 // per-node record of the fill kernel: everything the class key reads of one node, 64 bytes, node-major (one wave loads a 64-node block as 4 KB).
 // The static predicates (class_fit table, DRA / MIG rules, readiness, worker labels: plugins/predicates/predicates.go:173-262 minus the resource
 // and pod-count checks) are folded into okmask when the records are built.
@@ -72,6 +97,8 @@ struct BatchCtx {
     KAI_GP(int32_t) bk_meta;     // BucketMeta
     KAI_GP(FillStatus) fs;       // [1]
     KAI_GP(uint64_t) dead_mask;  // [1]
+    KAI_GP(RoundCtl) ctl;        // [1] the round loop's state (dev_loop: the kernels take h_leaf / the output bases from it and leave when it says done)
+    int32_t dev_loop, pad_dl;
     KAI_GP(int32_t) cls_cap;     // [64] tasks of scan class k the cluster still holds at the round's start (k_class_capacity): a gang of one class that asks for more is predicted BF_DEAD
     // node-axis sharding over the GPUs of one node: this rank owns the nodes [n_lo, n_hi); everything else is replicated.
     // Per exchange every rank offers, per scan class, its K best nodes (records) and the key it holds back (its K+1st: the floor); the

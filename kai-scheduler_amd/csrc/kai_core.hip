@@ -57,6 +57,8 @@ struct kai_core {
     void* rccl_comm = nullptr;  // the library's own communicator (kai_shard_attach_rccl): the exchange is an ncclAllGather on `stream`, no host round trip
     bool shared = false; int32_t* d_group0 = nullptr; int32_t next_group0 = 0; int32_t *d_np_off = nullptr, *d_np_pods = nullptr;  // shared GPUs: initial groups, each node's active pods in UID order
     hipEvent_t bev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // rounds without the host (kai_batch_driver.hpp): per slot the round's phase events (plan start, fill start, fill end, apply end), the event behind its RoundCtl copy, the pinned copy
+    hipEvent_t rev[KB_ROUND_SLOTS][5] = {}; unsigned char* rpin = nullptr; bool rev_ready = false;
     double batch_plan_ms = 0, batch_fill_ms = 0, batch_apply_ms = 0;
     // victim actions on several workgroups (kai_engine_solver.inc solve_partial_multi): every array a KaiCtx field points to, so that each workgroup gets a replica
     struct AllocRec { size_t field_off; char* base; size_t bytes; };
@@ -263,11 +265,13 @@ int launch_open_kernels(kai_core* core) {
 // the batch path's kernels on the session's stream (kai_batch_driver.hpp's Launcher)
 struct DevLauncher {
     kai_core* core; int rc = 0; unsigned fill_attr_mask = 0; size_t fill_attr_dyn = 0;
+    hipEvent_t* pev = nullptr;  // the phase events the next round records into: the session's four (loop on the host) or a slot's (rounds without the host)
+    hipEvent_t ev(int i) { return pev ? pev[i] : core->bev[i]; }
     void static_rank(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_static_rank, dim3(g), dim3(b), 0, core->stream, c); }
     void static_check(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_static_check, dim3(g), dim3(b), 0, core->stream, c); }
     void qualify(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_qualify, dim3(g), dim3(b), 0, core->stream, c); }
     void nrec(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_batch_nrec, dim3(g), dim3(b), 0, core->stream, c); }
-    void plan_setup(int g, int b, const KaiCtx& c, RoundParams rp) { (void)hipEventRecord(core->bev[0], core->stream); hipLaunchKernelGGL(k_plan_setup, dim3(g), dim3(b), 0, core->stream, c, rp); }
+    void plan_setup(int g, int b, const KaiCtx& c, RoundParams rp) { (void)hipEventRecord(ev(0), core->stream); hipLaunchKernelGGL(k_plan_setup, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_leaf(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_leaf, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_rank(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_rank, dim3(g), dim3(b), 0, core->stream, c, rp); }
     void plan_gather(int g, int b, const KaiCtx& c, RoundParams rp) { hipLaunchKernelGGL(k_plan_gather, dim3(g), dim3(b), 0, core->stream, c, rp); }
@@ -280,38 +284,38 @@ struct DevLauncher {
         hipLaunchKernelGGL((k_fill<MODE, SPEC, L1L>), dim3(g), dim3(b), dyn, core->stream, c, rp);
     }
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) {
-        if (rp.mode == 0 || (rp.mode == 2 && rp.start == 0)) (void)hipEventRecord(core->bev[1], core->stream);  // a sharded round: from its first virtual fill …
+        if (rp.mode == 0 || (rp.mode == 2 && rp.start == 0)) (void)hipEventRecord(ev(1), core->stream);  // a sharded round: from its first virtual fill …
         const bool spec = (c.plugins & KB_KEY_PLUGINS) == KB_KEY_PLUGINS && c.R == 4, sh = rp.mode == 2;
         if (sh) { if (spec) { if (l1) fill_launch<FM_SHARDED, true, true>(g, b, dyn, c, rp); else fill_launch<FM_SHARDED, true, false>(g, b, dyn, c, rp); }
                   else { if (l1) fill_launch<FM_SHARDED, false, true>(g, b, dyn, c, rp); else fill_launch<FM_SHARDED, false, false>(g, b, dyn, c, rp); } }
         else { if (spec) { if (l1) fill_launch<FM_PLAIN, true, true>(g, b, dyn, c, rp); else fill_launch<FM_PLAIN, true, false>(g, b, dyn, c, rp); }
                else { if (l1) fill_launch<FM_PLAIN, false, true>(g, b, dyn, c, rp); else fill_launch<FM_PLAIN, false, false>(g, b, dyn, c, rp); } }
-        if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);                                       // … to its last (exchanges included)
+        if (rp.mode != 1) (void)hipEventRecord(ev(2), core->stream);                                       // … to its last (exchanges included)
     }
     bool fill_bk_attr_set = false;
     void bucket_build(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_bucket_build, dim3(g), dim3(b), 0, core->stream, c); }
     bool fill_ct_attr_set = false;
     void fill_counts(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
         if (!fill_ct_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_counts), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_ct_attr_set = true; }
-        if (rp.mode == 0) (void)hipEventRecord(core->bev[1], core->stream);
+        if (rp.mode == 0) (void)hipEventRecord(ev(1), core->stream);
         hipLaunchKernelGGL(k_fill_counts, dim3(g), dim3(b), dyn, core->stream, c, rp, bp);
-        if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);
+        if (rp.mode != 1) (void)hipEventRecord(ev(2), core->stream);
     }
     bool fill_lv_attr_set = false;
     void fill_levels(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
         if (!fill_lv_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_levels), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_lv_attr_set = true; }
-        if (rp.mode == 0) (void)hipEventRecord(core->bev[1], core->stream);
+        if (rp.mode == 0) (void)hipEventRecord(ev(1), core->stream);
         hipLaunchKernelGGL(k_fill_levels, dim3(g), dim3(b), dyn, core->stream, c, rp, bp);
-        if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);
+        if (rp.mode != 1) (void)hipEventRecord(ev(2), core->stream);
     }
     void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
         if (!fill_bk_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_buckets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_bk_attr_set = true; }
-        if (rp.mode == 0) (void)hipEventRecord(core->bev[1], core->stream);
+        if (rp.mode == 0) (void)hipEventRecord(ev(1), core->stream);
         hipLaunchKernelGGL(k_fill_buckets, dim3(g), dim3(b), dyn, core->stream, c, rp, bp);
-        if (rp.mode != 1) (void)hipEventRecord(core->bev[2], core->stream);
+        if (rp.mode != 1) (void)hipEventRecord(ev(2), core->stream);
     }
     void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { hipLaunchKernelGGL(k_apply_jobs, dim3(g), dim3(b), 0, core->stream, c, (long long)ops_base, (long long)stmt_base); }
-    void apply_nodes(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_apply_nodes, dim3(g), dim3(b), 0, core->stream, c); (void)hipEventRecord(core->bev[3], core->stream); timed = true; }
+    void apply_nodes(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_apply_nodes, dim3(g), dim3(b), 0, core->stream, c); (void)hipEventRecord(ev(3), core->stream); timed = true; }
     bool timed = false;
     void index_from_recs(int g, int b, const KaiCtx& c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { hipLaunchKernelGGL(k_index_from_recs, dim3(g), dim3(b), 0, core->stream, c, recs, n_recs, l1k, l1n, nb, blk0, blk1); }
     void shard_mask_nrec(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_shard_mask_nrec, dim3(g), dim3(b), 0, core->stream, c); }
@@ -341,6 +345,38 @@ struct DevLauncher {
                 core->batch_plan_ms += p; core->batch_fill_ms += f; core->batch_apply_ms += a;
             } else (void)hipGetLastError();  // an event that was not recorded this round: not an error of the path
             timed = false;
+        }
+        return KAI_OK;
+    }
+    // ---- rounds without the host: the loop's state on the device, its copies in pinned memory
+    void round_init(const KaiCtx& c, int remaining, int H0, int policy, int64_t ops_base, int64_t stmt_base) { hipLaunchKernelGGL(k_round_init, dim3(1), dim3(64), 0, core->stream, c, remaining, H0, policy, (long long)ops_base, (long long)stmt_base); }
+    void round_next(const KaiCtx& c) { hipLaunchKernelGGL(k_round_next, dim3(1), dim3(64), 0, core->stream, c); }
+    void round_finish(const KaiCtx& c) { hipLaunchKernelGGL(k_round_finish, dim3(1), dim3(64), 0, core->stream, c); pev = nullptr; }
+    bool round_ready() {
+        if (core->rev_ready) return true;
+        for (auto& slot : core->rev) for (hipEvent_t& e : slot) if (!e && hipEventCreate(&e) != hipSuccess) return false;
+        if (!core->rpin) { void* p = nullptr; if (hipHostMalloc(&p, (size_t)KB_ROUND_SLOTS * 256, hipHostMallocDefault) != hipSuccess) return false; core->rpin = static_cast<unsigned char*>(p); }
+        static_assert(sizeof(RoundCtl) <= 256, "a pinned slot holds one RoundCtl");
+        return core->rev_ready = true;
+    }
+    void round_begin(int slot) { if (round_ready()) pev = core->rev[slot]; }
+    unsigned timed_slots = 0;
+    int round_post(int slot, const void* src, size_t n) {  // the state behind round `slot`, stream-ordered into the slot's pinned copy
+        if (!round_ready()) { core->err = "batch path: no events / pinned memory for the round loop"; return KAI_ERR_HIP; }
+        if (hipMemcpyAsync(core->rpin + (size_t)slot * 256, src, n, hipMemcpyDeviceToHost, core->stream) != hipSuccess || hipEventRecord(core->rev[slot][4], core->stream) != hipSuccess) { core->err = "batch path: the round's state copy failed"; return KAI_ERR_HIP; }
+        if (timed) { timed_slots |= 1u << slot; timed = false; }
+        return KAI_OK;
+    }
+    int round_wait(int slot, void* dst, size_t n) {  // waits for that copy — not for the stream: the next round is already behind it
+        hipError_t e1 = hipEventSynchronize(core->rev[slot][4]), e2 = hipGetLastError();
+        if (e1 != hipSuccess || e2 != hipSuccess) { core->err = std::string("batch path: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2); return KAI_ERR_HIP; }
+        if (rc) return rc;
+        std::memcpy(dst, core->rpin + (size_t)slot * 256, n);
+        if (timed_slots & (1u << slot)) {
+            float a = 0, f = 0, p = 0; hipEvent_t* e = core->rev[slot];
+            if (hipEventElapsedTime(&p, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&f, e[1], e[2]) == hipSuccess && hipEventElapsedTime(&a, e[2], e[3]) == hipSuccess) { core->batch_plan_ms += p; core->batch_fill_ms += f; core->batch_apply_ms += a; }
+            else (void)hipGetLastError();
+            timed_slots &= ~(1u << slot);
         }
         return KAI_OK;
     }
@@ -519,6 +555,8 @@ int kai_core_destroy(kai_core* core) {
     if (core->ev0) (void)hipEventDestroy(core->ev0);
     if (core->ev1) (void)hipEventDestroy(core->ev1);
     for (hipEvent_t e : core->bev) if (e) (void)hipEventDestroy(e);
+    for (auto& slot : core->rev) for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
+    if (core->rpin) (void)hipHostFree(core->rpin);
     if (core->stream) (void)hipStreamDestroy(core->stream);
     delete core;
     return KAI_OK;
@@ -927,7 +965,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         int rcb = batch_allocate(dl, c, core->shape, bs);
         if (rcb) { if (core->err == "ok") core->err = "batch path failed"; return rcb; }
         if (bs.ran && bs.buckets) core->index_stale = true;
-        if (bs.ran) {
+        if (bs.ran && !bs.st_on_device) {
             EngineState sb{};
             HIP_TRY(core, hipMemcpyAsync(&sb, KAI_VP(c.st), sizeof(sb), hipMemcpyDeviceToHost, core->stream));
             HIP_TRY(core, hipStreamSynchronize(core->stream));
@@ -1014,7 +1052,7 @@ int kai_action_execute(kai_core* core, int action, kai_op* ops_out, int64_t ops_
         core->stats.reserved[4] = bs.rounds; core->stats.reserved[5] = bs.fill_cycles; core->stats.reserved[6] = bs.mismatches;
         auto us = [](double ms) { int64_t v = (int64_t)(ms * 1000.0); return v < 0 ? (int64_t)0 : v > 0x1fffff ? (int64_t)0x1fffff : v; };
         core->stats.reserved[7] = (us(core->batch_plan_ms) << 42) | (us(core->batch_fill_ms) << 21) | us(core->batch_apply_ms);
-        core->stats.reserved[1] = (bs.block_loads & ((1ll << 48) - 1)) | ((int64_t)(bs.buckets ? 1 : 0) << 62) | ((int64_t)(bs.buckets >= 2 ? 1 : 0) << 61) | ((int64_t)(bs.buckets == 3 ? 1 : 0) << 60); /* bit 62: the fill ran on the sets by free devices (kai_fill_buckets.hpp), bit 61: behind a counting machine (kai_fill_counts.hpp), bit 60: with a wavefront per level (kai_fill_levels.hpp) */ core->stats.reserved[0] = core->world > 1 ? bs.exchanges : core->stats.reserved[0];
+        core->stats.reserved[1] = (bs.block_loads & ((1ll << 48) - 1)) | ((int64_t)(bs.buckets ? 1 : 0) << 62) | ((int64_t)(bs.buckets >= 2 ? 1 : 0) << 61) | ((int64_t)(bs.buckets == 3 ? 1 : 0) << 60) | ((int64_t)(bs.dev_loop ? 1 : 0) << 59); /* bit 59: the round loop's state lived on the device (rounds without the host), bit 62: the fill ran on the sets by free devices (kai_fill_buckets.hpp), bit 61: behind a counting machine (kai_fill_counts.hpp), bit 60: with a wavefront per level (kai_fill_levels.hpp) */ core->stats.reserved[0] = core->world > 1 ? bs.exchanges : core->stats.reserved[0];
         if (std::getenv("KAI_PROF")) std::fprintf(stderr, "kai batch%s: rounds %lld mismatches %lld planned %lld max_h %d | fill cycles %lld load %lld update %lld rescan %lld | block loads %lld rescans %lld %lld %lld | plan %.3f ms fill %.3f ms apply %.3f ms\n",
             bs.buckets ? " (bucket fill)" : "", (long long)bs.rounds, (long long)bs.mismatches, (long long)bs.planned, bs.max_h, (long long)bs.fill_cycles, (long long)bs.fill_load, (long long)bs.fill_update, (long long)bs.fill_rescan,
             (long long)bs.block_loads, (long long)bs.rescans1, (long long)bs.rescans2, (long long)bs.rescans3, core->batch_plan_ms, core->batch_fill_ms, core->batch_apply_ms);

@@ -170,6 +170,7 @@ KW_BODY uint64_t bk_move(const BkView& v, uint64_t& s2, int& cnt, int n, int fro
 
 // workgroup of 256: all four wavefronts move the state between its HBM home and LDS, wavefront 0 walks the planned order
 KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
+    if (kb_round_off(c.bt)) return;
     KW_SHARED BkLds L;
     const BatchCtx& b = c.bt;
     const int tid = kw::tid(), T = kw::bdim(), lane = kw::lane(), C = c.C;
@@ -383,6 +384,7 @@ KW_BODY void kb_fill_buckets(const KaiCtx& c, RoundParams rp, BucketParams bp) {
 // class that asks for more tasks than the cluster holds cannot fit — and stays unfit, free resources only shrink during allocate); the fill verifies every prediction.
 // One wavefront per 64-node block.
 KW_BODY void kb_class_capacity(const KaiCtx& c, int buckets, int levels) {
+    if (kb_round_off(c.bt)) return;
     const BatchCtx& b = c.bt;
     const int w = kw::bid() * (kw::bdim() >> 6) + (kw::tid() >> 6), lane = kw::lane(), NW = c.NB;
     if (w >= NW) return;

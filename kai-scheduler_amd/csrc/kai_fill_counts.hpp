@@ -29,6 +29,7 @@ struct FcMove { int32_t w, cmd; uint64_t mask; };  // hand-over from the worker 
 struct FcLds { FcCmd ring[KFC_RING]; FcMove xring[KFC_RING]; int32_t cnt0[KBK_GMAX]; int32_t head, tail0, tail1, done, xhead, xtail, pad0, pad1; int64_t a_wait, b_idle[2], b_total[2]; };  // (the clocks: profiling)
 
 KW_BODY void kb_fill_counts(const KaiCtx& c, RoundParams rp, BucketParams bp) {
+    if (kb_round_off(c.bt)) return;
     KW_SHARED FcLds L;
     const BatchCtx& b = c.bt;
     const int tid = kw::tid(), T = kw::bdim(), lane = kw::lane(), C = c.C;

@@ -73,6 +73,7 @@ KW_BODY void kfl_classify(FlStretch& s, int ucls, int qk, int capq) {
 }
 
 KW_BODY void kb_fill_levels(const KaiCtx& c, RoundParams rp, BucketParams bp) {
+    if (kb_round_off(c.bt)) return;
     KW_SHARED FlLds L;
     const BatchCtx& b = c.bt;
     const int tid = kw::tid(), T = kw::bdim(), lane = kw::lane(), C = c.C;

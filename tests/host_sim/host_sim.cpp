@@ -231,7 +231,8 @@ struct HostLauncher {
             (long long)f.committed, (long long)nat.fs.committed, (long long)f.rollbacks, (long long)nat.fs.rollbacks, (long long)f.ops, (long long)nat.fs.ops, (unsigned long long)f.dead_mask, (unsigned long long)nat.fs.dead_mask);
         g_native_fill_ms += nat.ms; g_native_fill_launches++; g_native_fill_decisions += nat.fs.decisions; if (!same) g_native_fill_diffs++;
     }
-    void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); }); }); }
+    static bool round_off(const KaiCtx& c) { return c.bt.dev_loop && c.bt.ctl->done; }  // a round enqueued ahead of the loop's end: its kernels leave at once (no shadow, no dump)
+    void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { if (round_off(c)) return; with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_buckets(c, rp, bp); }); }); }
     // KAI_HOSTSIM_FILL_DUMP=<prefix>: inputs and outputs of every fill launch over >= 1 000 planned jobs as <prefix>_<n>.bin (what tools/micro/fill_bench.hip replays on the MI355X)
     static void fill_dump(const KaiCtx& c, RoundParams rp, BucketParams bp, bool outputs) {
         const char* pre = std::getenv("KAI_HOSTSIM_FILL_DUMP"); if (!pre || rp.mode == 1) return;
@@ -251,8 +252,8 @@ struct HostLauncher {
         }
         std::fclose(f);
     }
-    void fill_levels(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { fill_dump(c, rp, bp, false); with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_levels(c, rp, bp); }); }); fill_dump(c, rp, bp, true); }
-    void fill_counts(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_counts(c, rp, bp); }); }); }
+    void fill_levels(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { if (round_off(c)) return; fill_dump(c, rp, bp, false); with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_levels(c, rp, bp); }); }); fill_dump(c, rp, bp, true); }
+    void fill_counts(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) { if (round_off(c)) return; with_native_shadow(c, rp, bp, [&] { kw::launch(g, b, dyn, [&] { kb_fill_counts(c, rp, bp); }); }); }
     void apply_jobs(int g, int b, const KaiCtx& c, int64_t ops_base, int64_t stmt_base) { kw::launch(g, b, 0, [&] { kb_apply_jobs(c, ops_base, stmt_base); }); }
     void apply_nodes(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_apply_nodes(c); }); }
     void index_from_recs(int g, int b, const KaiCtx& c, const NodeRec* recs, int n_recs, uint64_t* l1k, int32_t* l1n, int nb, int blk0, int blk1) { kw::launch(g, b, 0, [&] { kb_index_from_recs(c, recs, n_recs, l1k, l1n, nb, blk0, blk1); }); }
@@ -264,6 +265,14 @@ struct HostLauncher {
     void shard_scatter(int g, int b, const KaiCtx& c, int total) { kw::launch(g, b, 0, [&] { kb_shard_scatter(c, total); }); }
     int (*ag_fn)(void*, const void*, void*, int64_t) = nullptr; void* ag_user = nullptr;
     int allgather(const void* send, void* recv, int64_t bytes) { return ag_fn ? ag_fn(ag_user, send, recv, bytes) : (int)KAI_ERR_COMM; }  // the test's gloo all-gather
+    // rounds without the host: launches complete where they are made, so the "pinned copies" are plain copies
+    RoundCtl rslot[KB_ROUND_SLOTS];
+    void round_init(const KaiCtx& c, int remaining, int H0, int policy, int64_t ops_base, int64_t stmt_base) { kw::launch(1, 64, 0, [&] { kb_round_init(c, remaining, H0, policy, ops_base, stmt_base); }); }
+    void round_next(const KaiCtx& c) { kw::launch(1, 64, 0, [&] { kb_round_next(c); }); }
+    void round_finish(const KaiCtx& c) { kw::launch(1, 64, 0, [&] { kb_round_finish(c); }); }
+    void round_begin(int) {}
+    int round_post(int slot, const void* src, size_t n) { std::memcpy(&rslot[slot], src, n); return 0; }
+    int round_wait(int slot, void* dst, size_t n) { std::memcpy(dst, &rslot[slot], n); return 0; }
     int read(void* dst, const void* src, size_t n) { if (n) std::memcpy(dst, src, n); return 0; }
     int write(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); return 0; }
 };
@@ -605,8 +614,9 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
             HostLauncher hl; BatchStats bs; hl.ag_fn = g_sh_fn; hl.ag_user = g_sh_user;
             if (int rc = batch_allocate(hl, c, prep.shape, bs, c.st->out_len, c.st->stmts)) return rc;
             if (bs.ran) {
-                c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops; c.st->stmts += bs.committed;
-                c.st->drain_pending = bs.drain; batch_rounds += bs.rounds; batch_actions++; bucket_actions += bs.buckets ? 1 : 0; counts_actions += bs.buckets >= 2 ? 1 : 0; levels_actions += bs.buckets == 3 ? 1 : 0;
+                if (!bs.st_on_device) { c.st->decisions += bs.decisions; c.st->jobs_attempted += bs.attempted; c.st->jobs_committed += bs.committed; c.st->rollbacks += bs.rollbacks; c.st->out_len += bs.ops; c.st->stmts += bs.committed;
+                                        c.st->drain_pending = bs.drain; }
+                batch_rounds += bs.rounds; batch_actions++; bucket_actions += bs.buckets ? 1 : 0; counts_actions += bs.buckets >= 2 ? 1 : 0; levels_actions += bs.buckets == 3 ? 1 : 0;
                 if (bs.buckets) index_stale = true;
                 g_sh_exchanges = bs.exchanges;
             } else {

@@ -279,3 +279,21 @@ def test_bucket_fill_levels():
     assert _buckets(run_both(snap, abi.default_config())) == 1
     snap = synth.make_snapshot(130, 900, 5403, prefill=0.97)  # nearly full: most classes are dead from the start, gangs roll back
     assert _buckets(run_both(snap, abi.default_config())) == 1
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_round_loop_on_the_device_against_the_loop_on_the_host(seed, monkeypatch):
+    """Rounds without the host (RoundCtl, k_round_next): the loop's state on the device, rounds enqueued ahead and the one too many at the end — against the loop that reads the
+    fill's status on the host after every round (KAI_BATCH_HOST_LOOP=1): same operations, same counters, same number of rounds; both against the oracle."""
+    snap = regular_snapshot(100 + seed) if seed % 2 else synth.make_snapshot(40 + 30 * seed, 400 + 150 * seed, 7700 + seed, queue_levels=[(2, 2), (3, 4), (1,), (2, 2, 2)][seed % 4],
+                                                                               prefill=0.1 * (seed % 7), gpu_mix=((8, .6), (4, .4)), limits_frac=0.3 if seed % 3 == 0 else 0.0)
+    cfg = abi.default_config(k_value=0.5, gpu_strategy=(abi.BINPACK, abi.SPREAD)[(seed // 2) % 2])
+    if seed % 4 == 3:
+        monkeypatch.setenv("KAI_BATCH_H0", "8")  # short first plans: many rounds, the plan's depth moves both ways
+    dev = run_both(snap, cfg)
+    monkeypatch.setenv("KAI_BATCH_HOST_LOOP", "1")
+    host = HostSim.run(snap, cfg)
+    assert host.stats.reserved[4] == 1 and dev.stats.reserved[4] == 1
+    assert_same(host, dev)
+    assert stats_tuple(host.stats) == stats_tuple(dev.stats)
+    assert host.stats.reserved[5] == dev.stats.reserved[5], "the two loops took different numbers of rounds"

@@ -3,7 +3,8 @@
 against the oracle: operations, Statement numbers, pod / node state, shares and the (decisions, attempted, committed, rollbacks) counters.
 usage: batch_campaign.py <seed lo> <seed hi> [gpu]     (default: the host-compiled engine with the kernels on the emulator; `gpu`: the device through the C ABI)
 CAMPAIGN_SECONDS bounds the run.  Every seed also runs with one placement per step (KAI_FILL_UNBATCHED) when the seed is odd, with the general kernel when seed % 5 == 0, with the
-two-worker kernel of kai_fill_counts.hpp instead of kai_fill_levels.hpp when seed % 7 == 3."""
+two-worker kernel of kai_fill_counts.hpp instead of kai_fill_levels.hpp when seed % 7 == 3, with the round loop on the host (KAI_BATCH_HOST_LOOP) instead of on the device when
+seed % 4 == 2, with first plans of 8 jobs per leaf (KAI_BATCH_H0: many rounds) when seed % 9 == 4."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
@@ -24,7 +25,9 @@ for seed in range(lo, hi):
                            gpus_per_pod=(1, 2, 4, 8) if seed % 4 else (1, 3, 5), gang_sizes=sizes, gang_p=probs, mem_per_gpu=(8, 32)[seed % 2] * S.GIB, cpu_per_gpu=(2000.0, 4000.0)[seed % 2],
                            lexi_names=bool(seed % 7 == 0), queue_prios=(100, 200) if seed % 2 else (100,), oqws=(1.0, 2.0) if seed % 3 else (1.0,), nonpreempt_frac=0.1 * (seed % 3), usage_max=0.2 * (seed % 2))
     cfg = T.abi.default_config(gpu_strategy=T.abi.BINPACK if seed % 6 else T.abi.SPREAD, k_value=(0.0, 0.5, 1.0)[seed % 3])
-    for k in ("KAI_FILL_UNBATCHED", "KAI_FILL_GENERAL", "KAI_FILL_TWO_WORKERS"): os.environ.pop(k, None)
+    for k in ("KAI_FILL_UNBATCHED", "KAI_FILL_GENERAL", "KAI_FILL_TWO_WORKERS", "KAI_BATCH_HOST_LOOP", "KAI_BATCH_H0"): os.environ.pop(k, None)
+    if seed % 4 == 2: os.environ["KAI_BATCH_HOST_LOOP"] = "1"
+    if seed % 9 == 4: os.environ["KAI_BATCH_H0"] = "8"
     if seed % 7 == 3: os.environ["KAI_FILL_TWO_WORKERS"] = "1"
     if seed % 2: os.environ["KAI_FILL_UNBATCHED"] = "1"
     if seed % 5 == 0: os.environ["KAI_FILL_GENERAL"] = "1"
