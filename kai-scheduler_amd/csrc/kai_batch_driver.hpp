@@ -44,6 +44,7 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     KB_Z(pk, b.pool_k); KB_Z(sp, b.pool_k); KB_Z(k_owner, b.pool_k);
     KB_Z(el_leaf, b.pool_e); KB_Z(el_ck, b.pool_e); KB_Z(el_next, b.pool_e); KB_Z(e_job, b.pool_e); KB_Z(e_grank, b.pool_e); KB_Z(e_flag, b.pool_e);
     KB_Z(d_res, (size_t)b.pool_e * 3); KB_Z(d_meta, b.pool_e); KB_Z(d_spres, (size_t)b.pool_k * 3); KB_Z(d_spj, b.pool_k);
+    { const size_t n_sg = (size_t)b.pool_e / KPS_SEG + (size_t)Q + 2; KB_Z(sg_tot, n_sg * 6); KB_Z(sg_key, n_sg); KB_Z(sg_kvalid, n_sg); KB_Z(sg_fb, Q + 1); KB_Z(d_ab, (size_t)b.pool_k * 3); }
     KB_Z(g_job, J + 1); KB_Z(g_opoff, J + 1); KB_Z(g_stmt, J + 1); KB_Z(g_first, J + 1); KB_Z(g_nt, J + 1); KB_Z(g_ucls, J + 1); KB_Z(g_flag, J + 1); KB_Z(g_out, J + 1);
     KB_Z(t_cls, P); KB_Z(t_node, P);
     KB_Z(nrec, (size_t)c.NB * KAI_BLOCK); KB_Z(fs, 1); KB_Z(dead_mask, 1); KB_Z(cls_cap, 64); KB_Z(ctl, 1);
@@ -191,6 +192,13 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     if (!capacity) { int32_t inf[64]; for (int k = 0; k < 64; k++) inf[k] = 0x7fffffff; if (int rc = l.write((void*)c.bt.cls_cap, inf, sizeof inf)) return rc; }
     // one round's plan / fill / apply kernels for a plan that looks H jobs into every leaf with at most `left` jobs queued (upper bounds when the loop's state lives on the device:
     // the per-slot kernels leave beyond what k_plan_setup laid out)
+    // positions per node from which a height's streams are cut into segments (KAI_PLAN_SEG_MIN: A/B runs, tests; the emulator's default is small so that the tests' clusters take both forms)
+#if defined(__HIPCC__)
+    int64_t seg_min = 4096;
+#else
+    int64_t seg_min = 96;
+#endif
+    if (const char* e = std::getenv("KAI_PLAN_SEG_MIN")) { const long long v = std::atoll(e); if (v >= 1) seg_min = v; }
     auto enqueue_round = [&](int H, int left, int64_t ops_base, int64_t stmt_base) -> int {
         // tasks of every scan class the cluster still holds (for the plan's prediction of gangs that no longer fit; the fill verifies every prediction, so this only
         // saves rounds): summed here, read by k_plan_leaf, zeroed again by k_plan_emit
@@ -208,6 +216,13 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
             // one workgroup per queue node of this height, sized by what a node's stream can hold this round: a long stream is bound by the keys' f64 divisions (more wavefronts
             // hide more of them: r06g, 38 k positions per node: 1.03 ms at 512 threads x 1 position, 0.48 ms at 1 024 x 4), a short one by the barriers of its few steps
             const int64_t per_node = e_bound / std::max(shape.h_count[h], 1);
+            // ... and a height of few nodes with long streams is cut into segments of KPS_SEG positions, a workgroup each, in four launches (kai_plan_segments.hpp)
+            const int64_t segs = (e_bound + 1 + KPS_SEG - 1) / KPS_SEG;
+            if (h + 1 < shape.n_heights && per_node >= seg_min && segs * shape.h_count[h] <= 32768) {
+                const int g = (int)(segs * shape.h_count[h]);
+                l.seg_sum(g, KPS_T, c, rp, (int)segs); l.seg_gate(g, KPS_T, c, rp, (int)segs); l.seg_keys(g, KPS_T, c, rp, (int)segs); l.seg_max(g, KPS_T, c, rp, (int)segs);
+                continue;
+            }
             const int scan_tb = std::min(KB_PLAN_SCAN_THREADS, per_node >= 8192 ? 1024 : per_node >= 1024 ? 512 : per_node >= 192 ? 128 : 64);
             l.plan_scan(std::max(shape.h_count[h], 1), scan_tb, c, rp);
         }

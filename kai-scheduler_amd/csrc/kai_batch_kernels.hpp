@@ -1028,3 +1028,4 @@ __global__ void k_shard_scatter(KaiCtx c, int total) { kb_shard_scatter(c, total
 #include "kai_fill_buckets.hpp"
 #include "kai_fill_counts.hpp"
 #include "kai_fill_levels.hpp"
+#include "kai_plan_segments.hpp"

@@ -31,6 +31,13 @@ struct RoundCtl {
     int64_t last_decisions, last_steps, last_committed;
 };
 
+// k_plan_scan cut into segments (kai_plan_segments.hpp): a workgroup of KPS_T threads takes KPS_SEG consecutive positions of a node's stream, KPS_E per thread
+#if defined(__HIPCC__)
+enum { KPS_T = 256, KPS_E = 4 };
+#else
+enum { KPS_T = 64, KPS_E = 2 };  // the emulator: short segments, so that the tests' small clusters cut their streams into several
+#endif
+enum { KPS_SEG = KPS_T * KPS_E };
 enum { KB_ROUND_SLOTS = 4 };  // pinned copies of RoundCtl the host reads behind the stream (round r in slot r % 4; the host is at most two rounds behind)
 // How far the next plan looks.  A round without a surprise: back to the full depth at once (a leaf rarely holds more than 256 queued jobs, so that plan covers the whole queue);
 // a plan mostly thrown away: a QUARTER as far (the next surprise is usually close: the short plans in between are the cheaper the shorter they are).  KAI_BATCH_POLICY selects the
@@ -84,6 +91,13 @@ struct BatchCtx {
     KAI_GP(uint8_t) d_meta;      // [pool_e] its flag (BF_*) | non-preemptible << 2
     KAI_GP(double) d_spres;      // [pool_k][3] resources of the stale-path job the node's key is read through before pop t
     KAI_GP(int32_t) d_spj;       // [pool_k] that job
+    // k_plan_scan cut into segments (kai_plan_segments.hpp): per segment slot the sums of its jobs' resources and its last running-maximum key; per node the first job its gate turns
+    // away; per key position the shares before it
+    KAI_GP(double) sg_tot;       // [n_sg][6]
+    KAI_GP(PlanKey) sg_key;      // [n_sg]
+    KAI_GP(int32_t) sg_kvalid;   // [n_sg]
+    KAI_GP(int32_t) sg_fb;       // [Q+1]
+    KAI_GP(double) d_ab;         // [pool_k][3]
     // global order + task stream
     KAI_GP(int32_t) g_stmt;      // [J+1] committed jobs before this one in the round (its Statement number minus the round's base)
     KAI_GP(int32_t) g_job, g_opoff;  // [J+1] planned global order: job, offset of its operations among the round's committed ones

@@ -61,7 +61,10 @@ def _queue_tree(levels, rng, total_gpu, zipf=False, limits_frac=0.0, prios=(100,
 def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill=0.3, gpu_mix=((8, 1.0),), cpu_only_frac=0.0,
                   gang_sizes=(1, 2, 4, 8), gang_p=(0.4, 0.2, 0.2, 0.2), gpus_per_pod=(1, 2, 4, 8), zipf=False, limits_frac=0.0,
                   queue_prios=(100,), oqws=(1.0,), nonpreempt_frac=0.0, usage_max=0.0, lexi_names=False, single_pod_jobs=False,
-                  uniform_nodes=False, cpu_per_gpu=4000.0, mem_per_gpu=32 * GIB, elastic_frac=0.0, multi_podset_frac=0.0, task_prio_frac=0.0) -> abi.Snapshot:
+                  uniform_nodes=False, cpu_per_gpu=4000.0, mem_per_gpu=32 * GIB, elastic_frac=0.0, multi_podset_frac=0.0, task_prio_frac=0.0,
+                  inner_limits_frac=0.0) -> abi.Snapshot:
+    """inner_limits_frac: that share of the INNER queues gets a GPU limit of 0.3 .. 1.2 times what their subtree deserves (drawn from a generator of its own: the snapshots of
+    every other parameter set stay what they were) — a parent queue that turns jobs away while its leaves would still take them (capacity gate up the chain, proportion.go)."""
     rng = np.random.default_rng(seed)
     R = 4
     N = n_nodes
@@ -80,6 +83,11 @@ def make_snapshot(n_nodes, n_pending_pods, seed, *, queue_levels=(2, 2), prefill
     total_gpu = float(gpus.sum())
     qt = _queue_tree(list(queue_levels), rng, total_gpu, zipf=zipf, limits_frac=limits_frac, prios=queue_prios, oqws=oqws, usage_max=usage_max)
     leaves = qt["leaves"]
+    if inner_limits_frac > 0:
+        rng2 = np.random.default_rng(seed + 7717)
+        inner = np.setdiff1d(np.arange(len(qt["parent"])), leaves)
+        pick = inner[rng2.random(len(inner)) < inner_limits_frac]
+        qt["limit"][abi.Q_GPU, pick] = np.floor(qt["deserved"][abi.Q_GPU, pick] * (0.3 + 0.9 * rng2.random(len(pick)))) + 1
 
     # ---- pending gangs
     mean_size = 1.0 if single_pod_jobs else max(float(np.dot(gang_sizes, gang_p)), 1e-9)

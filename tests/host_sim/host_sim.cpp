@@ -204,6 +204,10 @@ struct HostLauncher {
     void plan_rank(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_rank(c, rp); }); }
     void plan_gather(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_gather(c, rp); }); }
     void plan_scan(int g, int b, const KaiCtx& c, RoundParams rp) { kw::launch(g, b, 0, [&] { kb_plan_scan(c, rp); }); }
+    void seg_sum(int g, int b, const KaiCtx& c, RoundParams rp, int segs) { kw::launch(g, b, 0, [&] { kb_seg_sum(c, rp, segs); }); }
+    void seg_gate(int g, int b, const KaiCtx& c, RoundParams rp, int segs) { kw::launch(g, b, 0, [&] { kb_seg_gate(c, rp, segs); }); }
+    void seg_keys(int g, int b, const KaiCtx& c, RoundParams rp, int segs) { kw::launch(g, b, 0, [&] { kb_seg_keys(c, rp, segs); }); }
+    void seg_max(int g, int b, const KaiCtx& c, RoundParams rp, int segs) { kw::launch(g, b, 0, [&] { kb_seg_max(c, rp, segs); }); }
     void plan_emit(int g, int b, const KaiCtx& c) { kw::launch(g, b, 0, [&] { kb_plan_emit(c); }); }
     void class_capacity(int g, int b, const KaiCtx& c, int buckets, int levels) { kw::launch(g, b, 0, [&] { kb_class_capacity(c, buckets, levels); }); }
     void fill(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, int l1) { kw::launch(g, b, dyn, [&] { kb_fill(c, rp, l1); }); }

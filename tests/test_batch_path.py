@@ -297,3 +297,30 @@ def test_round_loop_on_the_device_against_the_loop_on_the_host(seed, monkeypatch
     assert_same(host, dev)
     assert stats_tuple(host.stats) == stats_tuple(dev.stats)
     assert host.stats.reserved[5] == dev.stats.reserved[5], "the two loops took different numbers of rounds"
+
+
+def inner_limits_snapshot(seed):
+    """queue trees whose INNER queues carry GPU limits: a parent turns jobs away that its leaf would still take — the gate of an inner node ends its stream inside the plan
+    (k_plan_scan pass 1 / k_seg_gate), which the leaf-only limits of the other generators never reach"""
+    rng = np.random.default_rng(6600 + seed)
+    snap = synth.make_snapshot(int(rng.integers(20, 250)), int(rng.integers(100, 1500)), 6600 + seed, queue_levels=[(2, 3), (3, 4), (2, 2, 2), (1, 5), (4,)][seed % 5], prefill=float(rng.random()) * 0.6,
+                               gpu_mix=[((8, 1.0),), ((8, .6), (4, .4))][seed % 2], zipf=bool(seed % 2), limits_frac=0.3 if seed % 3 == 0 else 0.0, inner_limits_frac=(0.5, 1.0)[seed % 2],
+                               gang_sizes=(1, 2, 4), gang_p=(.6, .3, .1), gpus_per_pod=(1, 2) if seed % 4 else (1, 2, 4, 8), nonpreempt_frac=0.2 * (seed % 2), queue_prios=(100, 200) if seed % 2 else (100,))
+    cfg = abi.default_config(k_value=(0.0, 0.5, 1.0)[seed % 3], gpu_strategy=abi.BINPACK if seed % 4 else abi.SPREAD)
+    return snap, cfg
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_plan_scan_in_segments_against_one_workgroup_per_node_and_the_oracle(seed, monkeypatch):
+    """kai_plan_segments.hpp: a node's stream cut into segments on different workgroups (sums of the segments before, the first job turned away as a minimum over the segments,
+    the running maximum of the segments before) against k_plan_scan (one workgroup per node) and the oracle — on trees whose inner queues turn jobs away (odd seeds: every inner
+    queue limited) and on the plain generator (leaf limits only).  The emulator's segments hold 128 positions, so streams of a few hundred jobs take several."""
+    snap, cfg = inner_limits_snapshot(seed) if seed < 6 else (regular_snapshot(200 + seed), abi.default_config(k_value=0.5))
+    monkeypatch.setenv("KAI_PLAN_SEG_MIN", "1")           # every height below the root in segments
+    seg = run_both(snap, cfg)
+    monkeypatch.setenv("KAI_PLAN_SEG_MIN", "1000000000")  # never
+    one = HostSim.run(snap, cfg)
+    assert one.stats.reserved[4] == 1
+    assert_same(one, seg)
+    assert stats_tuple(one.stats) == stats_tuple(seg.stats)
+    assert one.stats.reserved[5] == seg.stats.reserved[5], "the two forms of the scan planned different rounds"

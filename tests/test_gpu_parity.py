@@ -536,6 +536,57 @@ def test_gpu_counts_fill_against_the_one_wave_kernel_and_the_oracle(gpu, seed, m
     assert_same(one, ref); assert stats_tuple(one.stats) == stats_tuple(ref.stats)
 
 
+def on_device_loop(stats):
+    """the round loop's state lived on the device (RoundCtl / k_round_next: rounds without the host; bit 59 of reserved[1])"""
+    return bool((int(stats.reserved[1]) >> 59) & 1)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_gpu_round_loop_on_the_device_against_the_loop_on_the_host(gpu, seed, monkeypatch):
+    """Rounds without the host: the next round's kernels are on the stream before the last round's status has been seen (they read how far to plan and where their output starts
+    from RoundCtl; the round enqueued in vain at the end finds `done` and leaves) — against the loop that drains the stream after every round (KAI_BATCH_HOST_LOOP=1) and the
+    oracle: same operations, Statement numbers, counters, rounds.  Every fourth seed starts with plans of 8 jobs per leaf (many rounds, the depth moves both ways)."""
+    import test_batch_path as B
+    snap = B.regular_snapshot(100 + seed) if seed % 2 else T.pkg.synth.make_snapshot(40 + 30 * seed, 400 + 150 * seed, 7700 + seed, queue_levels=[(2, 2), (3, 4), (1,), (2, 2, 2)][seed % 4],
+                                                                                     prefill=0.1 * (seed % 7), gpu_mix=((8, .6), (4, .4)), limits_frac=0.3 if seed % 3 == 0 else 0.0)
+    cfg = T.abi.default_config(k_value=0.5, gpu_strategy=(T.abi.BINPACK, T.abi.SPREAD)[(seed // 2) % 2])
+    if seed % 4 == 3:
+        monkeypatch.setenv("KAI_BATCH_H0", "8")
+    ref = T.Oracle.run(snap, cfg)
+    dev = run_gpu(snap, cfg)
+    assert_same(dev, ref); assert stats_tuple(dev.stats) == stats_tuple(ref.stats)
+    assert dev.stats.reserved[3] >= 0 and on_device_loop(dev.stats)
+    monkeypatch.setenv("KAI_BATCH_HOST_LOOP", "1")
+    host = run_gpu(snap, cfg)
+    assert not on_device_loop(host.stats)
+    assert_same(host, ref); assert stats_tuple(host.stats) == stats_tuple(ref.stats)
+    assert int(host.stats.reserved[4]) == int(dev.stats.reserved[4]), "the two loops took different numbers of rounds"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_plan_scan_in_segments_against_one_workgroup_per_node(gpu, seed, monkeypatch):
+    """kai_plan_segments.hpp on the device (segments of 1 024 positions): forced for every height below the root (KAI_PLAN_SEG_MIN=1) against k_plan_scan (never) and the oracle;
+    trees with limited inner queues (their gate ends a stream inside the plan) and plain ones; seeds 6, 7: streams of several thousand jobs per top-level queue (several segments)."""
+    import test_batch_path as B
+    if seed < 4:
+        snap, cfg = B.inner_limits_snapshot(seed)
+    elif seed < 6:
+        snap, cfg = B.regular_snapshot(200 + seed), T.abi.default_config(k_value=0.5)
+    else:
+        snap = T.pkg.synth.make_snapshot(1200, 14000, 8800 + seed, queue_levels=(2, 3), prefill=0.3, gang_sizes=(1, 2), gang_p=(.8, .2), gpus_per_pod=(1, 2), zipf=True, limits_frac=0.3,
+                                         inner_limits_frac=1.0 if seed == 7 else 0.0, nonpreempt_frac=0.1)
+        cfg = T.abi.default_config(k_value=0.5)
+    ref = T.Oracle.run(snap, cfg)
+    monkeypatch.setenv("KAI_PLAN_SEG_MIN", "1")
+    seg = run_gpu(snap, cfg)
+    assert int(seg.stats.reserved[4]) >= 1, "the allocate action did not take the batch path"
+    assert_same(seg, ref); assert stats_tuple(seg.stats) == stats_tuple(ref.stats)
+    monkeypatch.setenv("KAI_PLAN_SEG_MIN", "1000000000")
+    one = run_gpu(snap, cfg)
+    assert_same(one, ref); assert stats_tuple(one.stats) == stats_tuple(ref.stats)
+    assert int(one.stats.reserved[4]) == int(seg.stats.reserved[4]), "the two forms of the scan planned different rounds"
+
+
 def test_gpu_bucket_fill_corners(gpu):
     """what k_bucket_build turns away (another resource may bind first, 32 devices per node) runs on the general kernel; static predicates per class, 16
     devices per node, a nearly full cluster run on the bucket kernel — all equal to the oracle"""

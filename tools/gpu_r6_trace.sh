@@ -12,15 +12,21 @@ import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].split("<")[0].replace("kai::", "").replace("void ", "")
 print("# one cycle (bench.py --steps 1 --warmup 0), rocprofv3 --kernel-trace: kernels in launch order, grouped into rounds at every k_plan_setup; microseconds")
-rnd, acc = 0, {}
+rnd, acc, span, prev_end = 0, {}, [None, None], None
 def flush():
-    if acc: print(f"round {rnd:2d}: " + "  ".join(f"{k} {v[0]:.0f} us x{v[1]}" for k, v in acc.items()) + f"  | total {sum(v[0] for v in acc.values()):.0f} us")
+    global prev_end
+    if acc:
+        tot = sum(v[0] for v in acc.values())
+        print(f"round {rnd:2d}: " + "  ".join(f"{k} {v[0]:.0f} us x{v[1]}" for k, v in acc.items()) + f"  | total {tot:.0f} us, span {(span[1] - span[0]) / 1e3:.0f} us (gaps inside {(span[1] - span[0]) / 1e3 - tot:.0f} us), idle before {((span[0] - prev_end) / 1e3 if prev_end else 0):.0f} us")
+        prev_end = span[1]
 for r in rows:
     n = name(r)
-    if n == "k_plan_setup": flush(); rnd += 1; acc = {}
+    if n in ("k_plan_setup", "k_class_capacity") and (n == "k_class_capacity" or "k_class_capacity" not in acc): flush(); rnd += 1; acc = {}; span = [None, None]
     if rnd == 0 and not n.startswith(("k_batch", "k_bucket", "k_fill", "k_class")): continue
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     a = acc.setdefault(n, [0.0, 0]); a[0] += d; a[1] += 1
+    if span[0] is None: span[0] = int(r["Start_Timestamp"])
+    span[1] = int(r["End_Timestamp"])
 flush()
 for k in ("k_plan_scan", "k_plan_rank", "k_plan_gather", "k_plan_leaf"):
     print(f"# {k} launches in order (us):", " ".join(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.0f}" for r in rows if name(r) == k))
@@ -29,5 +35,5 @@ busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if 
 print(f"# action span {(t1 - t0) / 1e3:.0f} us, kernels busy {busy / 1e3:.0f} us, gaps {(t1 - t0 - busy) / 1e3:.0f} us")
 PY
 cat gpurun_out/${TAG}_${CFG}_kernels_per_round.txt | cut -c1-420
-rm -rf gpurun_out/prof_${TAG}_$CFG
+cp "$f" gpurun_out/${TAG}_${CFG}_kernel_trace.csv 2>/dev/null; rm -rf gpurun_out/prof_${TAG}_$CFG
 done
