@@ -141,7 +141,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     if (!c.bt.enabled || c.action != KAI_ACTION_ALLOCATE || c.queue_depth > 0 || !c.fast_ok) return 0;
     const int TB = 256, Q = c.Q, J = c.J;
     int32_t qual[4] = {0, 0, 0, 0};
-    if (int rc = l.write((void*)c.bt.qual, qual, sizeof qual)) return rc;
+    if (int rc = l.zero((void*)c.bt.qual, sizeof qual)) return rc;
     if (Q) { l.static_rank((Q + TB - 1) / TB, TB, c); l.static_check((Q + TB - 1) / TB, TB, c); }
     if (J) l.qualify((J + TB - 1) / TB, TB, c);
     // (behind the qualification, before its verdict is read: the node records and the sets' build write arrays of this path only, and one drain of the stream then answers both)
@@ -149,8 +149,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     const bool try_sets = !sharded && c.C >= 1 && !std::getenv("KAI_FILL_GENERAL");
     l.nrec(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
     if (try_sets) {
-        BucketMeta m{};
-        if (int rc = l.write((void*)c.bt.bk_meta, &m, sizeof m)) return rc;
+        if (int rc = l.zero((void*)c.bt.bk_meta, sizeof(BucketMeta))) return rc;
         l.bucket_build(std::max(1, (c.NB * KAI_BLOCK + TB - 1) / TB), TB, c);
     }
     if (int rc = l.read(qual, (const void*)c.bt.qual, sizeof qual)) return rc;
@@ -188,7 +187,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
     int64_t ops_base = ops_base0, stmt_base = stmt_base0;
     const bool capacity = !sharded && !std::getenv("KAI_BATCH_NO_CAPACITY");  // (a rank of a node-sharded group sees its own nodes only: no capacity prediction there)
     c.bt.cap_on = capacity ? 1 : 0;
-    { int32_t z[64]; for (int k = 0; k < 64; k++) z[k] = 0; if (capacity) if (int rc = l.write((void*)c.bt.cls_cap, z, sizeof z)) return rc; }
+    if (capacity) if (int rc = l.zero((void*)c.bt.cls_cap, 64 * sizeof(int32_t))) return rc;
     if (!capacity) { int32_t inf[64]; for (int k = 0; k < 64; k++) inf[k] = 0x7fffffff; if (int rc = l.write((void*)c.bt.cls_cap, inf, sizeof inf)) return rc; }
     // one round's plan / fill / apply kernels for a plan that looks H jobs into every leaf with at most `left` jobs queued (upper bounds when the loop's state lives on the device:
     // the per-slot kernels leave beyond what k_plan_setup laid out)
@@ -207,7 +206,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         const int64_t e_bound = std::min<int64_t>(left, (int64_t)shape.n_leaves * H);
         const int64_t slots = std::min<int64_t>(c.bt.pool_k, e_bound * shape.n_heights + Q + 1);
         rp.n_slots = (int32_t)slots;
-        l.plan_setup(1, 256, c, rp);
+        l.plan_setup(1, KB_PLAN_SETUP_THREADS, c, rp);
         l.plan_leaf(std::max(Q, 1), 64, c, rp);
         for (int h = 1; h < shape.n_heights; h++) {
             rp.height = h;
@@ -249,7 +248,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
         RoundCtl seen{}; seen.H = H; seen.remaining = remaining;
         const int64_t max_rounds = (int64_t)remaining + 2;  // (every round executes at least one job)
         int64_t printed = 0;
-        for (int64_t r = 1;; r++) {
+        for (int64_t r = 1; remaining > 0; r++) {  // (nothing queued: no round at all)
             if (r >= 2) {
                 if (int rc = l.round_wait((int)((r - 2) % KB_ROUND_SLOTS), &seen, sizeof seen)) return rc;
                 if (seen.fault) return KAI_ERR_DEVICE_FAULT;

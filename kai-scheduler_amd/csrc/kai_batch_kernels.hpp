@@ -16,7 +16,9 @@ constexpr int KB_INF = 0x7fffffff;
 #if defined(__HIPCC__)
 constexpr int KB_PLAN_SCAN_THREADS = 1024; // workgroup of k_plan_scan (a multiple of 64, at most 1024): the scan is latency bound (f64 divisions of the keys), more wavefronts hide more of it
 constexpr int KB_PLAN_SCAN_ELEMS = 4;      // positions of a stream per thread and step
+constexpr int KB_PLAN_SETUP_THREADS = 1024; // the one workgroup of k_plan_setup (passes over the Q + 1 queue nodes: config 5's 2 185 in 3 steps instead of 9)
 #else
+constexpr int KB_PLAN_SETUP_THREADS = 128;
 constexpr int KB_PLAN_SCAN_THREADS = 128;  // the emulator runs every thread as a fiber: two waves exercise the same code
 constexpr int KB_PLAN_SCAN_ELEMS = 3;      // (an odd count: positions, threads and waves fall out of step)
 #endif
@@ -1002,7 +1004,7 @@ __global__ void k_batch_static_rank(KaiCtx c) { kb_static_rank(c); }
 __global__ void k_batch_static_check(KaiCtx c) { kb_static_check(c); }
 __global__ void k_batch_qualify(KaiCtx c) { kb_qualify(c); }
 __global__ void k_batch_nrec(KaiCtx c) { kb_build_nrec(c); }
-__global__ void k_plan_setup(KaiCtx c, RoundParams rp) { kb_plan_setup(c, rp); }
+__global__ void __launch_bounds__(1024) k_plan_setup(KaiCtx c, RoundParams rp) { kb_plan_setup(c, rp); }
 __global__ void k_plan_leaf(KaiCtx c, RoundParams rp) { kb_plan_leaf(c, rp); }
 __global__ void k_plan_rank(KaiCtx c, RoundParams rp) { kb_plan_rank(c, rp); }
 __global__ void k_plan_gather(KaiCtx c, RoundParams rp) { kb_plan_gather(c, rp); }

@@ -59,6 +59,7 @@ struct kai_core {
     hipEvent_t bev[4] = {nullptr, nullptr, nullptr, nullptr};
     // rounds without the host (kai_batch_driver.hpp): per slot the round's phase events (plan start, fill start, fill end, apply end), the event behind its RoundCtl copy, the pinned copy
     hipEvent_t rev[KB_ROUND_SLOTS][5] = {}; unsigned char* rpin = nullptr; bool rev_ready = false;
+    size_t fill_dyn_set[3] = {0, 0, 0};  // dynamic-LDS ceiling already set for k_fill_buckets / k_fill_counts / k_fill_levels (hipFuncSetAttribute is per process and device: once, not once per action)
     double batch_plan_ms = 0, batch_fill_ms = 0, batch_apply_ms = 0;
     // victim actions on several workgroups (kai_engine_solver.inc solve_partial_multi): every array a KaiCtx field points to, so that each workgroup gets a replica
     struct AllocRec { size_t field_off; char* base; size_t bytes; };
@@ -296,24 +297,21 @@ struct DevLauncher {
                else { if (l1) fill_launch<FM_PLAIN, false, true>(g, b, dyn, c, rp); else fill_launch<FM_PLAIN, false, false>(g, b, dyn, c, rp); } }
         if (rp.mode != 1) (void)hipEventRecord(ev(2), core->stream);                                       // … to its last (exchanges included)
     }
-    bool fill_bk_attr_set = false;
     void bucket_build(int g, int b, const KaiCtx& c) { hipLaunchKernelGGL(k_bucket_build, dim3(g), dim3(b), 0, core->stream, c); }
-    bool fill_ct_attr_set = false;
     void fill_counts(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
-        if (!fill_ct_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_counts), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_ct_attr_set = true; }
+        if (dyn > core->fill_dyn_set[1]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_counts), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; else core->fill_dyn_set[1] = dyn; }
         if (rp.mode == 0) (void)hipEventRecord(ev(1), core->stream);
         hipLaunchKernelGGL(k_fill_counts, dim3(g), dim3(b), dyn, core->stream, c, rp, bp);
         if (rp.mode != 1) (void)hipEventRecord(ev(2), core->stream);
     }
-    bool fill_lv_attr_set = false;
     void fill_levels(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
-        if (!fill_lv_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_levels), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_lv_attr_set = true; }
+        if (dyn > core->fill_dyn_set[2]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_levels), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; else core->fill_dyn_set[2] = dyn; }
         if (rp.mode == 0) (void)hipEventRecord(ev(1), core->stream);
         hipLaunchKernelGGL(k_fill_levels, dim3(g), dim3(b), dyn, core->stream, c, rp, bp);
         if (rp.mode != 1) (void)hipEventRecord(ev(2), core->stream);
     }
     void fill_buckets(int g, int b, size_t dyn, const KaiCtx& c, RoundParams rp, BucketParams bp) {
-        if (!fill_bk_attr_set) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_buckets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; fill_bk_attr_set = true; }
+        if (dyn > core->fill_dyn_set[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fill_buckets), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) rc = KAI_ERR_HIP; else core->fill_dyn_set[0] = dyn; }
         if (rp.mode == 0) (void)hipEventRecord(ev(1), core->stream);
         hipLaunchKernelGGL(k_fill_buckets, dim3(g), dim3(b), dyn, core->stream, c, rp, bp);
         if (rp.mode != 1) (void)hipEventRecord(ev(2), core->stream);
@@ -385,6 +383,7 @@ struct DevLauncher {
         return KAI_OK;
     }
     int write(void* dst, const void* src, size_t n) { return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, core->stream) == hipSuccess ? KAI_OK : KAI_ERR_HIP; }
+    int zero(void* dst, size_t n) { return hipMemsetAsync(dst, 0, n, core->stream) == hipSuccess ? KAI_OK : KAI_ERR_HIP; }  // (a copy from pageable host memory is staged and waited for; a memset is a launch)
 };
 // ---- victim actions of a node-sharded group: the host side of a wave's exchange (kai_victim_shard.hpp XShardHost) against the device
 struct DevXIo {

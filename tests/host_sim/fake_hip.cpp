@@ -32,6 +32,7 @@ hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { std::lock_guard<std::mutex> lk(g_m); *e = (hipEvent_t)(g_tok += 16); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
 // Device memory comes from ONE arena at a fixed address, handed out by a bump pointer: two processes that allocate the same sizes in the same order get the same addresses, so the
 // pointers the library stores IN device memory (the session context, replica tables) do not make their images differ.  (Fresh pages read as zeros: the padding between the library's

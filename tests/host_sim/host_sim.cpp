@@ -279,6 +279,7 @@ struct HostLauncher {
     int round_wait(int slot, void* dst, size_t n) { std::memcpy(dst, &rslot[slot], n); return 0; }
     int read(void* dst, const void* src, size_t n) { if (n) std::memcpy(dst, src, n); return 0; }
     int write(void* dst, const void* src, size_t n) { std::memcpy(dst, src, n); return 0; }
+    int zero(void* dst, size_t n) { std::memset(dst, 0, n); return 0; }
 };
 
 template <class T> T* own(std::vector<std::vector<char>>& pool, size_t n) {

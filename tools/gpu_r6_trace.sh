@@ -2,7 +2,7 @@
 # per-LAUNCH kernel trace of ONE config-5 cycle (and one config-2 cycle), grouped into rounds
 TAG=${1:-r06g}; R="$GRAFT_REPO_ROOT"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
 export KAI_BENCH_OTHER_SHAPES=0 KAI_BENCH_OPEN_LEG=0 KAI_BENCH_NATIVE_FILL=0
-for CFG in C5 C2; do
+for CFG in ${TRACE_CONFIGS:-C5 C2}; do
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/prof_${TAG}_$CFG" -- python "$R/bench.py" --config $CFG --steps 1 --warmup 0 --cpu-sample 0 > "$R/gpurun_out/${TAG}_launches_$CFG.log" 2>&1; echo "trace $CFG rc=$?"
 cd "$R"
