@@ -245,7 +245,7 @@ def main():
                 "achieved_physical_GBs": (traffic / (avg_launch_ms * 1e-3) / 1e9) if (traffic and avg_launch_ms > 0) else None, "waves_resident": 10 if levels else 4 if buckets else 1, "waves_working": 10 if levels else 3 if counts else 1,
                 "traffic_source": "static: profiles/pmc_traffic.json = FETCH_SIZE + WRITE_SIZE of the fill kernel from committed rocprofv3 --pmc passes of this command (counters need their own passes; not collected in this run)" if traffic else "no --pmc pass of this kernel on file",
                 "kernel": fill_kernel, "launches_per_step": rounds, "avg_launch_ms": avg_launch_ms, "decisions_per_launch": fill_dec / max(rounds, 1), "algorithmic_bytes_per_launch": alg_bytes_launch,
-                "other_kernels": {"plan (k_plan_leaf / rank / scan / emit)": {"ms_per_step": plan_ms}, "apply (k_apply_jobs / nodes)": {"ms_per_step": apply_ms},
+                "other_kernels": {"plan (k_plan_setup / leaf / rank / gather / scan or k_seg_* / emit)": {"ms_per_step": plan_ms}, "apply (k_apply_jobs / nodes)": {"ms_per_step": apply_ms},
                                   "k_drain": {"decisions": drained, "note": "jobs popped after no class fits anywhere: resolved chip-wide without touching a node; NOT counted in this roofline"}},
                 "note": note}
     else:

@@ -38,7 +38,7 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     b.n_h = prep.n_heights; b.pool_e = (int32_t)batch_pool_e(prep, J, Q); b.pool_k = (int32_t)batch_pool_k(prep, J, Q);
 #define KB_Z2(field, n) do { void* p_ = zalloc(std::max<size_t>((size_t)(n), 1) * sizeof(*b.field)); if (!p_) return KAI_ERR_HIP; b.field = (decltype(b.field))p_; } while (0)
 #define KB_Z(field, n) do { void* p_ = zalloc(std::max<size_t>((size_t)(n), 1) * sizeof(*b.field)); if (!p_) return KAI_ERR_HIP; b.field = (decltype(b.field))p_; } while (0)
-    KB_Z(q_height, Q + 1); KB_Z(h_off, b.n_h + 1); KB_Z(h_nodes, Q + 1); KB_Z(q_srank, Q + 1);
+    KB_Z(q_height, Q + 1); KB_Z(h_off, b.n_h + 1); KB_Z(h_nodes, Q + 1); KB_Z(q_srank, Q + 1); KB_Z(q_islot, Q + 1);
     KB_Z(j_clsmask, J); KB_Z(j_ucls, J); KB_Z(cur_sp, Q + 1); KB_Z(qual, 4);
     KB_Z(q_cnt, Q + 1); KB_Z(q_ebase, Q + 1); KB_Z(q_kbase, Q + 1); KB_Z(q_valid, Q + 1); KB_Z(q_nk, Q + 1); KB_Z(q_sent, Q + 1); KB_Z(q_taken, Q + 1); KB_Z(q_complete, Q + 1); KB_Z(plan_tot, 2);
     KB_Z(pk, b.pool_k); KB_Z(sp, b.pool_k); KB_Z(k_owner, b.pool_k);
@@ -66,6 +66,8 @@ int batch_bind(KaiCtx& c, const HostPrep& prep, ZAlloc&& zalloc, Upload&& upload
     if (int rc = upload((void*)b.q_height, prep.q_height.data(), prep.q_height.size() * 4)) return rc;
     if (int rc = upload((void*)b.h_off, prep.h_off.data(), prep.h_off.size() * 4)) return rc;
     if (int rc = upload((void*)b.h_nodes, prep.h_nodes.data(), prep.h_nodes.size() * 4)) return rc;
+    b.n_inner = prep.n_inner;
+    if (!prep.q_islot.empty()) if (int rc = upload((void*)b.q_islot, prep.q_islot.data(), prep.q_islot.size() * 4)) return rc;
 #undef KB_Z
 #undef KB_Z2
     return 0;

@@ -13,6 +13,7 @@ constexpr int KB_INF = 0x7fffffff;
 #define KB_T(var)
 #define KB_ACC(slot, t0)
 #endif
+constexpr int KB_APPLY_INNER = 1024;  // inner queue nodes whose shares k_apply_jobs sums per workgroup in LDS (48 KB); the nodes beyond take the atomics directly
 #if defined(__HIPCC__)
 constexpr int KB_PLAN_SCAN_THREADS = 1024; // workgroup of k_plan_scan (a multiple of 64, at most 1024): the scan is latency bound (f64 divisions of the keys), more wavefronts hide more of it
 constexpr int KB_PLAN_SCAN_ELEMS = 4;      // positions of a stream per thread and step
@@ -921,29 +922,46 @@ KW_BODY void kb_apply_jobs(const KaiCtx& c, int64_t ops_base, int64_t stmt_base)
     if (kb_round_off(c.bt)) return;
     if (c.bt.dev_loop) { ops_base = c.bt.ctl->ops_base; stmt_base = c.bt.ctl->stmt_base; }  // where the round's operations / Statements start in the action's output
     const BatchCtx& b = c.bt;
-    const int t = kw::bid() * kw::bdim() + kw::tid();
-    if (t >= b.fs[0].n_done) return;
-    if (b.g_out[t] != BF_OK || b.g_flag[t] == BF_GATE) return;
-    const int j = b.g_job[t], first = c.j_first_pod[j], nt = c.j_tta_n[j], s = c.j_first_ps[j];
-    double sum[3] = {0, 0, 0};
-    for (int i = 0; i < nt; i++) {
-        const int p = c.tta[first + i], n = b.t_node[first + i];
-        kai_op o; o.seq = ops_base + b.g_opoff[t] + i; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j; o.stmt = (int32_t)(stmt_base + b.g_stmt[t]); o.pad = 0;
-        c.out_ops[o.seq] = o;
-        c.p_status[p] = KAI_POD_BINDING; c.p_node[p] = n; c.p_on_node[p] = n; c.p_on_node_status[p] = KAI_POD_ALLOCATED; c.p_accepted[p] = 1; c.p_virtual[p] = 1;
-        for (int r = 0; r < c.R; r++) {
-            const double v = c.p_req[(size_t)r * c.P + p]; if (v == 0) continue;
-            kw::atomic_add((double*)&c.n_used[(size_t)r * c.N + n], v); kw::atomic_add((double*)&c.n_idle[(size_t)r * c.N + n], -v);
+    const int tid = kw::tid(), T = kw::bdim(), t = kw::bid() * T + tid, n_done = b.fs[0].n_done;
+    if (kw::bid() * T >= n_done) return;  // (the same for the whole workgroup)
+    // The shares of the INNER queue nodes are summed per workgroup in LDS first: every committed job adds to every node of its chain, and the few top-level queues took tens of
+    // thousands of f64 atomics each on one cache line (config 5's big round: 72 k jobs x 3 resources on 8 top-level queues; the kernel was bound by those lines, 0.27 ms).  Leaves
+    // (thousands of them, a handful of jobs each) are added to directly.  Sums in another order are exact on this path (HostPrep::batch_units).
+    KW_SHARED double s_acc[KB_APPLY_INNER * 6];
+    const int n_in = b.n_inner < KB_APPLY_INNER ? b.n_inner : KB_APPLY_INNER;
+    for (int i = tid; i < n_in * 6; i += T) s_acc[i] = 0.0;
+    kw::sync();
+    if (t < n_done && b.g_out[t] == BF_OK && b.g_flag[t] != BF_GATE) {
+        const int j = b.g_job[t], first = c.j_first_pod[j], nt = c.j_tta_n[j], s = c.j_first_ps[j];
+        double sum[3] = {0, 0, 0};
+        for (int i = 0; i < nt; i++) {
+            const int p = c.tta[first + i], n = b.t_node[first + i];
+            kai_op o; o.seq = ops_base + b.g_opoff[t] + i; o.kind = KAI_OP_ALLOCATE; o.pod = p; o.node = n; o.job = j; o.stmt = (int32_t)(stmt_base + b.g_stmt[t]); o.pad = 0;
+            c.out_ops[o.seq] = o;
+            c.p_status[p] = KAI_POD_BINDING; c.p_node[p] = n; c.p_on_node[p] = n; c.p_on_node_status[p] = KAI_POD_ALLOCATED; c.p_accepted[p] = 1; c.p_virtual[p] = 1;
+            for (int r = 0; r < c.R; r++) {
+                const double v = c.p_req[(size_t)r * c.P + p]; if (v == 0) continue;
+                kw::atomic_add((double*)&c.n_used[(size_t)r * c.N + n], v); kw::atomic_add((double*)&c.n_idle[(size_t)r * c.N + n], -v);
+            }
+            sum[0] += c.p_req[(size_t)KAI_RES_CPU * c.P + p]; sum[1] += c.p_req[(size_t)KAI_RES_MEM * c.P + p]; sum[2] += c.p_req[(size_t)KAI_RES_GPU * c.P + p];
         }
-        sum[0] += c.p_req[(size_t)KAI_RES_CPU * c.P + p]; sum[1] += c.p_req[(size_t)KAI_RES_MEM * c.P + p]; sum[2] += c.p_req[(size_t)KAI_RES_GPU * c.P + p];
+        c.s_active_alloc[s] += nt; c.s_active_used[s] += nt; c.j_n_pending[j] -= nt; c.j_tta_valid[j] = 0;
+        for (int k = 0; k < 3; k++) c.j_allocated[(size_t)j * 4 + k] += sum[k];
+        const bool np = !c.j_preempt[j];
+        for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) {
+            const int slot = b.q_islot[q];
+            for (int k = 0; k < 3; k++) {
+                if (sum[k] == 0) continue;
+                if (slot >= 0 && slot < n_in) { kw::atomic_add(&s_acc[slot * 6 + k], sum[k]); if (np) kw::atomic_add(&s_acc[slot * 6 + 3 + k], sum[k]); }
+                else { kw::atomic_add((double*)&c.q_share[(size_t)q * 3 + k].allocated, sum[k]); if (np) kw::atomic_add((double*)&c.q_share[(size_t)q * 3 + k].allocated_np, sum[k]); }
+            }
+        }
     }
-    c.s_active_alloc[s] += nt; c.s_active_used[s] += nt; c.j_n_pending[j] -= nt; c.j_tta_valid[j] = 0;
-    for (int k = 0; k < 3; k++) c.j_allocated[(size_t)j * 4 + k] += sum[k];
-    const bool np = !c.j_preempt[j];
-    for (int q = c.j_queue[j]; q >= 0; q = c.q_parent[q]) for (int k = 0; k < 3; k++) {
-        if (sum[k] == 0) continue;
-        kw::atomic_add((double*)&c.q_share[(size_t)q * 3 + k].allocated, sum[k]);
-        if (np) kw::atomic_add((double*)&c.q_share[(size_t)q * 3 + k].allocated_np, sum[k]);
+    kw::sync();
+    for (int i = tid; i < n_in * 6; i += T) {
+        const double v = s_acc[i]; if (v == 0) continue;
+        const int q = b.h_nodes[b.h_off[1] + i / 6], k = i % 3;
+        if (i % 6 < 3) kw::atomic_add((double*)&c.q_share[(size_t)q * 3 + k].allocated, v); else kw::atomic_add((double*)&c.q_share[(size_t)q * 3 + k].allocated_np, v);
     }
 }
 // how far every queue node got inside the executed prefix: leaf cursors, stale-path jobs of the inner nodes

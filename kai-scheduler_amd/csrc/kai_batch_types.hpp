@@ -70,6 +70,7 @@ struct BatchCtx {
     KAI_GP(int32_t) h_off;       // [n_h+1]
     KAI_GP(int32_t) h_nodes;     // [Q+1] queue nodes by ascending height
     KAI_GP(int32_t) q_srank;     // [Q] static rank among siblings: allocatable-share dominance, creation time (queue_order.go:214-240)
+    KAI_GP(int32_t) q_islot;     // [Q+1] inner queue nodes numbered in h_nodes order behind the leaves (slot s = h_nodes[h_off[1] + s]), -1 = leaf / virtual root: k_apply_jobs sums their shares per workgroup in LDS
     // per action
     KAI_GP(uint64_t) j_clsmask;  // [J] scan classes of the job's chunk
     KAI_GP(int32_t) j_ucls;      // [J] the one scan class of the job's chunk, -1 = mixed
@@ -112,7 +113,7 @@ struct BatchCtx {
     KAI_GP(FillStatus) fs;       // [1]
     KAI_GP(uint64_t) dead_mask;  // [1]
     KAI_GP(RoundCtl) ctl;        // [1] the round loop's state (dev_loop: the kernels take h_leaf / the output bases from it and leave when it says done)
-    int32_t dev_loop, pad_dl;
+    int32_t dev_loop, n_inner;   // n_inner: inner queue nodes (q_islot)
     KAI_GP(int32_t) cls_cap;     // [64] tasks of scan class k the cluster still holds at the round's start (k_class_capacity): a gang of one class that asks for more is predicted BF_DEAD
     // node-axis sharding over the GPUs of one node: this rank owns the nodes [n_lo, n_hi); everything else is replicated.
     // Per exchange every rank offers, per scan class, its K best nodes (records) and the key it holds back (its K+1st: the floor); the

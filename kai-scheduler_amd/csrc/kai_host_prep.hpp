@@ -124,6 +124,7 @@ struct HostPrep {
     // batch path (kai_batch.hpp): queue nodes by height (leaf = 0, the virtual root at index Q on top), and whether the snapshot's quantities add
     // exactly in any order (the batch path sums shares and node accounting in parallel)
     struct BatchShape { int n_leaves = 0, n_heights = 0; std::vector<int> h_count; };
+    std::vector<int32_t> q_islot; int n_inner = 0;  // inner queue nodes numbered in h_nodes order behind the leaves (-1: leaf / virtual root)
     std::vector<int32_t> q_height, h_off, h_nodes; int n_heights = 0, batch_ok = 0, exact_sums = 0; BatchShape shape;  // exact_sums: sums of node / pod quantities do not depend on the order of addition
 
     // the required arrays of a snapshot with that many nodes / pods / pod-sets / jobs / queues: the first one that is missing, as a message (nullptr: all there)
@@ -297,6 +298,8 @@ struct HostPrep {
         for (int q = 0; q <= Q; q++) { h_off[q_height[q] + 1]++; shape.h_count[q_height[q]]++; }
         for (int h = 0; h < n_heights; h++) h_off[h + 1] += h_off[h];
         { std::vector<int32_t> fill(h_off.begin(), h_off.end() - 1); for (int q = 0; q <= Q; q++) h_nodes[fill[q_height[q]]++] = q; }
+        q_islot.assign((size_t)Q + 1, -1); n_inner = 0;
+        for (int i = n_heights > 1 ? h_off[1] : Q + 1; i <= Q; i++) { const int q = h_nodes[i]; if (q < Q) { q_islot[(size_t)q] = i - h_off[1]; n_inner = i - h_off[1] + 1; } }
         for (int q = 0; q < Q; q++) if (child_off[q + 1] == child_off[q]) shape.n_leaves++;
         // exact sums: per resource every quantity is a non-negative integer multiple of one power of two, and the totals stay below 2^53 units
         exact_sums = 1;
