@@ -165,8 +165,11 @@ def main():
         step(False)
     barrier()
     t0 = time.perf_counter()
+    step_wall = []
     for _ in range(args.steps):
+        t_w = time.perf_counter()
         st = step(True)
+        step_wall.append((time.perf_counter() - t_w) * 1e3)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = pkg.dist.max_over_ranks(elapsed, device=red_dev)
@@ -271,7 +274,7 @@ def main():
         "decisions_per_s": {"all": total_decisions / elapsed, "fill": (total_decisions - drained * args.steps * (1 if sharded else world)) / elapsed if batch else None,
                             "drained": (drained * args.steps * (1 if sharded else world)) / elapsed if batch else None},
         "config": {"workload": desc, "nodes": N, "pods": snap.n_pods, "jobs": snap.n_jobs, "queues": snap.n_queues,
-                   "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2], "action_ms": k_ms,
+                   "decisions_per_step": decisions, "placements_per_step": placed, "p50_cycle_latency_ms": lat[len(lat) // 2], "step_wall_ms": {"p50": sorted(step_wall)[len(step_wall) // 2], "min": min(step_wall), "max": max(step_wall), "note": "host clock around each timed step (ms_per_step is their mean): a max far above the p50 is a host hiccup inside the timed region, not device time"}, "action_ms": k_ms,
                    "session_open_ms": float(np.mean(open_ms)), "parallelism": "1 GPU" if world == 1 else (f"node axis of one snapshot sharded over {world} GPUs: per exchange every rank offers its 128 best nodes per scan class, all-gather over RCCL / xGMI, the same virtual fill on every rank"
                                                                       if sharded else f"{world} scheduling shards, one per GPU, no data-path collective"),
                    "snapshot_gen_s": round(gen_s, 2), "host_to_hbm_s": round(upload_s, 3), "engine": engine},
