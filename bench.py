@@ -94,11 +94,12 @@ def main():
     idx = CONFIGS[args.config]
     actions = tuple(a for a in (args.actions or ("allocate,consolidation,reclaim" if args.config == "C4" else "allocate")).split(",") if a)
     t0 = time.time()
-    # N > 1, default (SURVEY 8e / north_star's split): the ranks shard the NODE axis of ONE snapshot — strong scaling; per exchange every rank offers its best nodes
-    # per scan class, one all-gather over RCCL / xGMI, the same virtual fill on every rank (DESIGN.md section 7 says why this cannot beat one GPU: the fill is one
-    # dependency chain and an exchange only adds to it).  The same GPUs as independent scheduling shards (how KAI itself scales out: a scheduler instance per node pool,
-    # conf/scheduler_conf.go:95-112; weak scaling, no data-path collective) run as a second leg beside it (`replicas`).  KAI_BENCH_MULTI=replicas swaps the two.
-    sharded = world > 1 and os.environ.get("KAI_BENCH_MULTI", "shard") == "shard"
+    # N > 1, default: REPLICAS — the GPUs as independent scheduling shards of the same shape (how KAI itself scales out: a scheduler instance per node pool,
+    # conf/scheduler_conf.go:95-112), weak scaling, no data-path collective: for the allocate action this is the multi-GPU mode that pays ("replicas only").
+    # KAI_BENCH_MULTI=shard: the ranks shard the NODE axis of ONE snapshot instead (per exchange every rank offers its best nodes per scan class, one all-gather over
+    # RCCL / xGMI, the same virtual fill on every rank — built and protocol-tested, but the fill is one dependency chain and an exchange only adds to it: strong scaling below 1),
+    # with the replicas as a second leg beside it.
+    sharded = world > 1 and os.environ.get("KAI_BENCH_MULTI", "replicas") == "shard"
     snap, cfg, desc = pkg.synth.config(idx, args.scale, seed_offset=0 if (sharded or world == 1) else pkg.dist.shard_seed(0, rank), mixed=args.mixed)
     if args.queue_depth > 0:
         for a in ("consolidation", "reclaim", "preempt"):
@@ -425,7 +426,7 @@ def main():
             tot2 = pkg.dist.sum_over_ranks(d2 * args.steps, device=red_dev)
             ssn2.close(); core2.destroy()
             out["replicas"] = {"value": tot2 / el2, "unit": "placements/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "weak",
-                               "note": f"{world} independent scheduling shards of the same shape, one per GPU, no data-path collective (KAI_BENCH_MULTI=replicas makes this the reported value)"}
+                               "note": f"{world} independent scheduling shards of the same shape, one per GPU, no data-path collective (the default for N > 1)"}
         except Exception as e:  # the second leg is additional evidence: it must not take the sharded result down with it (every rank runs the same code, so a failure is common to all)
             out["replicas"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and args.config == "C5" and args.scale == 1.0 and not args.mixed and args.fractions == 0 and actions == ("allocate",) and os.environ.get("KAI_BENCH_OTHER_SHAPES", "1") != "0":

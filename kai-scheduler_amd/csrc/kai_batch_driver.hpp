@@ -254,7 +254,7 @@ int batch_allocate(L& l, KaiCtx& c, const HostPrep::BatchShape& shape, BatchStat
             if (r >= 2) {
                 if (int rc = l.round_wait((int)((r - 2) % KB_ROUND_SLOTS), &seen, sizeof seen)) return rc;
                 if (seen.fault) return KAI_ERR_DEVICE_FAULT;
-                if (trace && seen.rounds > printed) { printed = seen.rounds; std::fprintf(stderr, "kai batch round %lld: H %d planned %d executed %d mismatch %d decisions %lld steps %lld committed %lld remaining %d\n", (long long)seen.rounds, seen.last_h, seen.last_planned, seen.last_done, seen.last_mismatch, (long long)seen.last_decisions, (long long)seen.last_steps, (long long)seen.last_committed, seen.remaining); }
+                if (trace && seen.rounds > printed) { printed = seen.rounds; std::fprintf(stderr, "kai batch round %lld: H %d planned %d executed %d mismatch %d decisions %lld steps %lld committed %lld remaining %d\n", (long long)seen.rounds, seen.last_h, seen.last_planned, seen.last_done, seen.last_mismatch, (long long)seen.last_decisions, (long long)seen.last_steps, (long long)seen.last_committed, seen.remaining); if (seen.last_mismatch) std::fprintf(stderr, "kai batch round %lld: mispredicted job: predicted %d actual %d tasks %d class %d\n", (long long)seen.rounds, seen.mm_flag, seen.mm_out, seen.mm_nt, seen.mm_cls); }
                 if (seen.done) break;
                 if (r > max_rounds) return KAI_ERR_DEVICE_FAULT;
             }

@@ -1003,6 +1003,7 @@ KW_BODY void kb_round_next(const KaiCtx& c) {
     r.fill_cycles += fs.cycles_total; r.fill_load += fs.cycles_load; r.fill_update += fs.cycles_update; r.fill_rescan += fs.cycles_rescan;
     r.block_loads += fs.block_loads; r.rescans1 += fs.rescans1; r.rescans2 += fs.rescans2; r.rescans3 += fs.rescans3;
     r.last_h = r.H; r.last_planned = fs.planned; r.last_done = fs.n_done; r.last_mismatch = fs.mismatch; r.last_decisions = fs.decisions; r.last_steps = fs.rescans2; r.last_committed = fs.committed;
+    if (fs.mismatch) { const int t = fs.n_done - 1; r.mm_flag = b.g_flag[t]; r.mm_out = b.g_out[t]; r.mm_nt = b.g_nt[t]; r.mm_cls = b.g_ucls[t]; }
     r.ops_base += fs.ops; r.stmt_base += fs.committed; r.remaining -= fs.n_done;
     r.H = kb_round_policy(r.policy, r.H, fs.mismatch != 0, fs.n_done, fs.planned);
     if (r.remaining <= 0) r.done = 1;

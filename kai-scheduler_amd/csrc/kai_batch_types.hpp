@@ -29,6 +29,7 @@ struct RoundCtl {
     int64_t fill_cycles, fill_load, fill_update, fill_rescan, block_loads, rescans1, rescans2, rescans3;
     int32_t last_h, last_planned, last_done, last_mismatch;  // the round just closed (KAI_BATCH_TRACE)
     int64_t last_decisions, last_steps, last_committed;
+    int32_t mm_flag, mm_out, mm_nt, mm_cls;  // the mispredicted job of that round: predicted / actual outcome, tasks, its one scan class (-1: several)
 };
 
 // k_plan_scan cut into segments (kai_plan_segments.hpp): a workgroup of KPS_T threads takes KPS_SEG consecutive positions of a node's stream, KPS_E per thread
