@@ -639,6 +639,7 @@ static int session_open_impl(kai_core* core, const kai_snapshot_soa* s) {
     // ---- index structures (pure re-orderings / groupings of the input; kai_host_prep.hpp)
     const auto t_staged = tnow();
     HostPrep& prep = core->prep;
+    prep.shared_pods = sp.any ? &sp : nullptr;
     try { if (prep.build(core->cfg, s, core->err)) return KAI_ERR_INVALID_ARG; }  // (the staged copies read the handle's pinned buffer: kai_session_open drains the stream on every failure)
     catch (const std::bad_alloc&) { throw; }  // (a worker thread's included: kai_parallel.hpp carries it here)
     catch (const std::exception& e) { core->err = std::string("host preparation: ") + e.what(); return KAI_ERR_INVALID_ARG; }
@@ -743,7 +744,9 @@ static int session_open_impl(kai_core* core, const kai_snapshot_soa* s) {
         TRY(dzero_f(core, c.ng_mark, (size_t)N)); TRY(dzero_f(core, c.ng_has_alloc, (size_t)N));
         TRY(dupload_f(core, c.next_new_group, &next_new, (size_t)1)); core->next_group0 = next_new;
         c.shared_on = shared ? 1 : 0;
-        if (shared || sp.mig) { c.use_index = 0; c.all_tracked = 0; c.fast_ok = 0; core->fast_ok0 = 0; }  // every scan by brute force: the class keys know neither fractions, the gpusharingorder score nor the MIG predicates
+        // shared GPUs: the pods that ask for a fraction are in no class (brute-force scans over the nodes' GPU groups), the other classes stay indexed with the gpusharingorder bit in their
+        // keys (kai_engine.hpp key_shared_layout; KAI_SHARED_INDEX=0: every scan by brute force, as before round 6); MIG rows: every scan by brute force (the class keys do not know the MIG predicates)
+        if (shared || sp.mig) { c.all_tracked = 0; const char* e = std::getenv("KAI_SHARED_INDEX"); const int lvl = e ? std::atoi(e) : 2; if (sp.mig || lvl == 0) c.use_index = 0; if (sp.mig || lvl < 2) { c.fast_ok = 0; core->fast_ok0 = 0; } }  // (2: gangs without a fraction pod also keep the staged job path)
         // each node's active pods in UID order: the shared-GPU guards of addTaskResources are order sensitive (nodes_fake/nodes.go:289-302 adds tasks by UID)
         std::vector<int32_t> np_off((size_t)N + 1, 0), np_pods;
         if (shared) {

@@ -300,7 +300,7 @@ struct KaiCtx {
     uint32_t plugins; int32_t gpu_strategy, cpu_strategy, restrict_nodes; double k_value;
     int32_t C, NB, NSB, use_index, all_tracked, queue_depth, fast_ok, pad1;
     // nodes
-    KAI_GP(const double) n_alloc; KAI_GP(const uint32_t) n_flags; KAI_GP(const int32_t) n_gpu_count; KAI_GP(const int32_t) n_class;
+    KAI_GP(const double) n_alloc; KAI_GP(uint32_t) n_flags /* static but for the two internal summary bits of the node's shared GPUs (SgNode::refit) */; KAI_GP(const int32_t) n_gpu_count; KAI_GP(const int32_t) n_class;
     KAI_GP(double) n_idle, n_rel, n_used;
     // pods
     KAI_GP(const double) p_req; KAI_GP(const int32_t) p_job, p_podset; KAI_GP(const uint32_t) p_flags; KAI_GP(const int32_t) p_class, p_nominated, p_scls;
@@ -472,6 +472,8 @@ KAI_HD bool fits(const KaiCtx& c, const double* req, int n, bool with_releasing)
 // written, whatever its value; a slot is that entry for the three maps together (ng_has_alloc tells whether AllocatedSharedGPUsMemory has
 // the key).  Maps are ranged in ascending group id (the oracle's canonical order).
 // ------------------------------------------------------------------------------------------------------
+constexpr uint32_t KAI_NODE_SHARE_FIT0_I = 0x10000000u, KAI_NODE_SHARE_FIT1_I = 0x20000000u;  // internal, dynamic (SgNode::refit): some used shared GPU of the node can take a task of 0 MiB / of a whole
+                                                                                                  // device's memory — the gpusharingorder score of the classes that ask for no fraction (class_key_regs)
 constexpr int KAI_GMAX = 32;  // (the slot masks ng_mark / ng_has_alloc are 32 bits; 16 slots overflowed once in 6·10^5 campaign cycles: entries that rolled-back simulations leave
                               // booked — the reference's own residue, gpu_sharing_node_info.go:102-105 — cannot be taken over)
 constexpr int KAI_NEW_GROUP = 1 << 20;  // ids from here on: non-numeric group names (UUIDs) — "new" for predicates.go:320-330
@@ -504,6 +506,12 @@ struct SgNode {
     KAI_HD bool releasing_from_shared(int s) const { return used(s) != 0 && rel(s) == used(s); }                                        // :253-263 (a found key with value 0 != used)
     KAI_HD bool fit_on_group(int s, int64_t mem) const { return used(s) != 0 && gpu_mem() - alloc(s) + rel(s) - mem >= 0 && alloc(s) != rel(s); }  // IsTaskFitOnGpuGroup :350-354
     KAI_HD bool enough_idle(int s, int64_t mem) const { return ((c.ng_has_alloc[n] >> s) & 1u) && gpu_mem() - alloc(s) - mem >= 0; }              // EnoughIdleResourcesOnGpu :356-363
+    // the node's summary bits for the class keys: kept in n_flags by everything that changes a group (node accounting at session open, node_apply), read by load_node
+    KAI_HD void refit() const {
+        uint32_t f = 0;
+        for (int s = 0; s < KAI_GMAX; s++) if (id(s) >= 0) { if (fit_on_group(s, 0)) f |= KAI_NODE_SHARE_FIT0_I; if (fit_on_group(s, mem_of(1.0))) f |= KAI_NODE_SHARE_FIT1_I; }
+        c.n_flags[n] = (c.n_flags[n] & ~(KAI_NODE_SHARE_FIT0_I | KAI_NODE_SHARE_FIT1_I)) | f;
+    }
     KAI_HD int count_fit(int64_t mem) const { for (int s = 0; s < KAI_GMAX; s++) if (id(s) >= 0 && fit_on_group(s, mem)) return 1; return 0; }  // fractionTaskGpusAllocatableDeviceCount: stops at the device count of the task, 1
     // addSharedTaskResourcesPerPodGroup :83-136 / removeSharedTaskResourcesPerPodGroup :153-235; false = table full
     KAI_HD bool add(int status, int64_t mem, int g) const {
@@ -713,7 +721,16 @@ KAI_HD bool scan_node_score(const KaiCtx& c, const ScanReq& q, int n, double& sc
 struct NodeRegs {
     double idle[KAI_MAX_RES], rel[KAI_MAX_RES], alloc_cpu, alloc_gpu;
     uint32_t flags; int32_t ncls, gpu_count;
+    uint32_t share_fit;  // shared GPUs: bit 0 / bit 1 = some used shared GPU of the node can take a task of 0 MiB (a CPU-only task) / of a whole device's memory (gpusharingorder)
 };
+#ifdef KAI_SHARED_GPUS
+// The gpusharingorder score of a class that asks for no fraction (plugins/gpusharingorder/gpusharingorder.go:29-44 with GetResourceGpuMemory of portion 0 or 1):
+// a layout of the key with one more bit above the others (1000 dominates 100 + 10 + 9), used whenever the session has shared GPUs and the plugin.
+KAI_HD bool key_shared_layout(const KaiCtx& c) { return c.shared_on && (c.plugins & KAI_PLUGIN_GPUSHARINGORDER); }
+#else
+KAI_HD bool key_shared_layout(const KaiCtx&) { return false; }
+#endif
+KAI_HD int key_avail_bit(const KaiCtx& c) { return key_shared_layout(c) ? 62 : 63; }
 KAI_HD void load_node(const KaiCtx& c, int n, NodeRegs& s) {
 #if defined(__HIPCC__)
 #pragma unroll
@@ -725,6 +742,10 @@ KAI_HD void load_node(const KaiCtx& c, int n, NodeRegs& s) {
     }
     s.alloc_cpu = c.n_alloc[(size_t)KAI_RES_CPU * c.N + n]; s.alloc_gpu = c.n_alloc[(size_t)KAI_RES_GPU * c.N + n];
     s.flags = c.n_flags[n]; s.ncls = c.n_class[n]; s.gpu_count = c.n_gpu_count[n];
+    s.share_fit = 0;
+#ifdef KAI_SHARED_GPUS
+    if (key_shared_layout(c)) s.share_fit = (s.flags >> 28) & 3u;  // KAI_NODE_SHARE_FIT0_I / FIT1_I, kept by SgNode::refit
+#endif
 }
 KAI_HD uint64_t class_key_regs(const KaiCtx& c, const ClassRec& k, const NodeRegs& s) {
     // FittingNode: fit on Idle+Releasing (api/node_info/node_info.go:190-206, 361-382) …
@@ -756,8 +777,10 @@ KAI_HD uint64_t class_key_regs(const KaiCtx& c, const ClassRec& k, const NodeReg
         }
     }
     uint64_t key = 0;
-    if ((c.plugins & KAI_PLUGIN_NODEAVAILABILITY) && (k.best_effort || fit_idle)) key |= 1ull << 63;
-    if ((c.plugins & KAI_PLUGIN_RESOURCETYPE) && k.cpu_only && cpu_node) key |= 1ull << 62;
+    const bool lay = key_shared_layout(c);  // (then spread classes are not admitted: their 62 placement bits leave no room, kai_host_prep.hpp)
+    if (lay && (s.share_fit & (k.req[KAI_RES_GPU] >= 1 ? 2u : 1u))) key |= 1ull << 63;
+    if ((c.plugins & KAI_PLUGIN_NODEAVAILABILITY) && (k.best_effort || fit_idle)) key |= 1ull << (lay ? 62 : 63);
+    if ((c.plugins & KAI_PLUGIN_RESOURCETYPE) && k.cpu_only && cpu_node) key |= 1ull << (lay ? 61 : 62);
     uint64_t v = 1;
     if (c.plugins & KAI_PLUGIN_NODEPLACEMENT) {
         const bool gpu = k.r_place == KAI_RES_GPU;
@@ -1054,7 +1077,7 @@ struct Engine {
 #ifdef KAI_SHARED_GPUS
         if (pod_shared(p)) {  // addSharedTaskResources / removeSharedTaskResources with the group of the node's own copy
             SgNode g{cx(), n}; const int grp = grp_of_copy != -2 ? grp_of_copy : cx().p_on_group[p];
-            if (grp >= 0) { bool ok = sign > 0 ? g.add(status, cx().p_mem[p], grp) : g.remove(status, cx().p_mem[p], grp); if (!ok) fault(FAULT_INTERNAL); }
+            if (grp >= 0) { bool ok = sign > 0 ? g.add(status, cx().p_mem[p], grp) : g.remove(status, cx().p_mem[p], grp); if (!ok) fault(FAULT_INTERNAL); if (cx().use_index) g.refit(); }
         }
 #endif
         mark_dirty(n);
@@ -1848,7 +1871,7 @@ struct Engine {
             int nom = (cx().plugins & KAI_PLUGIN_NOMINATEDNODE) ? cx().p_nominated[p] : -1;
             if (nom >= 0) { key = class_key(cx(), cr, nom); if (key) n = nom; }  // +1e6 outranks every other sum (plugins/nominatednode/nominatednode.go:29-41)
             if (n < 0) { flush_index(); be.class_top(cx(), k, key, n); el().h.index_queries++; if (!key) n = -1; }
-            if (n >= 0) allocatable = (cx().plugins & KAI_PLUGIN_NODEAVAILABILITY) ? (key >> 63) != 0 : (cr.best_effort || fits(cx(), cr.req, n, false));
+            if (n >= 0) allocatable = (cx().plugins & KAI_PLUGIN_NODEAVAILABILITY) ? ((key >> key_avail_bit(cx())) & 1) != 0 : (cr.best_effort || fits(cx(), cr.req, n, false));
             return n;
         }
         ScanReq q; fill_req(q, p);

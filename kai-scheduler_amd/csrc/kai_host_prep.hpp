@@ -415,8 +415,13 @@ struct HostPrep {
     //   spread on r: the divisor (gpu.count label or Allocatable) is an integer in [Allocatable, 2^22] so the ratio stays in [0,1]
     //     and distinct ratios stay distinct after the sum.
     // The KAI_CMAX most frequent admissible classes among PENDING pods are indexed; other pods use the brute-force scan.
+    // Shared GPUs (round 6): a pod that asks for a fraction (or MiB) of one device is in no class — its fit, predicates and score read the node's GPU groups (brute-force scan) —
+    // and does not count in the integer guard of the GPU column; the other pods' classes stay indexed, their keys carry the gpusharingorder bit (kai_engine.hpp key_shared_layout).
+    // MIG rows keep every scan on brute force (the caller turns the index off).
+    const SharedPods* shared_pods = nullptr;  // set by the caller before build() when the snapshot has shared-GPU requests
     void build_classes(const kai_config& cfg, const kai_snapshot_soa* s) {
         const int N = s->n_nodes, P = s->n_pods, R = s->n_res;
+        const uint8_t* sh = (shared_pods && shared_pods->any) ? shared_pods->shared.data() : nullptr;
         par_fill(pod_scls, (size_t)P, -1); classes.clear(); all_tracked = 1;
         // the staged job path needs "fits on Idle+Releasing" == "fits on Idle" for every node: nothing releasing, nothing pipelined
         fast_ok = cfg.engine_mode == 2 ? 0 : 1;
@@ -446,7 +451,7 @@ struct HostPrep {
                 for (size_t p = p0; p < p1; p++) {
                     if (s->pod_status[p] & (KAI_POD_RELEASING | KAI_POD_PIPELINED)) f |= 1;
                     if (!integral(cpu[p], 1073741824.0)) f |= 2;
-                    if (!integral(gpu[p], 1073741824.0)) f |= 4;
+                    if (!(sh && sh[p]) && !integral(gpu[p], 1073741824.0)) f |= 4;
                 }
                 flags[(size_t)ci] = f;
             });
@@ -459,7 +464,7 @@ struct HostPrep {
         std::map<Key, int> ids; std::vector<Key> keys; std::vector<int64_t> freq; raw_vector<int32_t> pod_cls((size_t)P);  // (every element is written by the classification below)
         {
             const int K = chunk_count((size_t)P);
-            struct Local { std::vector<Key> keys; std::vector<int64_t> freq; };
+            struct Local { std::vector<Key> keys; std::vector<int64_t> freq; bool untracked = false; };
             std::vector<Local> loc((size_t)K);
             auto make_key = [&](size_t p, Key& k) { std::memset(&k, 0, sizeof k); for (int r = 0; r < R; r++) { double v = s->pod_req[(size_t)r * P + p]; k.req[r] = v == 0 ? 0.0 : v; } k.pc = s->pod_class ? s->pod_class[p] : 0; };  // folds -0.0
             parallel_chunks((size_t)P, [&](int ci, size_t p0, size_t p1) {
@@ -470,12 +475,13 @@ struct HostPrep {
                     if (last >= 0 && std::memcmp(&L.keys[(size_t)last], &k, sizeof(Key)) == 0) id = last;
                     else { auto it = lid.find(k); if (it == lid.end()) { id = (int)L.keys.size(); lid[k] = id; L.keys.push_back(k); L.freq.push_back(0); } else id = it->second; }
                     last = id; pod_cls[p] = id;  // chunk-local id for now
-                    if (s->pod_status[p] == KAI_POD_PENDING) L.freq[(size_t)id]++;
+                    if (s->pod_status[p] == KAI_POD_PENDING) { if (sh && sh[p]) L.untracked = true; else L.freq[(size_t)id]++; }
                 }
             });
             std::vector<std::vector<int>> to_global((size_t)K);
             for (int ci = 0; ci < K; ci++) {
                 Local& L = loc[(size_t)ci]; to_global[(size_t)ci].resize(L.keys.size());
+                if (L.untracked) all_tracked = 0;
                 for (size_t i = 0; i < L.keys.size(); i++) {
                     auto it = ids.find(L.keys[i]);
                     int id; if (it == ids.end()) { id = (int)keys.size(); ids[L.keys[i]] = id; keys.push_back(L.keys[i]); freq.push_back(0); } else id = it->second;
@@ -491,6 +497,7 @@ struct HostPrep {
             const Key& k = keys[id];
             bool cpu_only = !(k.req[KAI_RES_GPU] > 0);
             bool admissible = !(cfg.plugins & KAI_PLUGIN_NODEPLACEMENT) || ok_res[cpu_only ? 0 : 1];
+            if (sh && (cfg.plugins & KAI_PLUGIN_NODEPLACEMENT) && (cfg.plugins & KAI_PLUGIN_GPUSHARINGORDER) && (cpu_only ? cfg.cpu_strategy : cfg.gpu_strategy) == KAI_SPREAD) admissible = false;  // no room for the sharing bit above a spread key
             if (freq[id] == 0) continue;  // only classes that have pending pods are ever queried by the allocate action
             if (!admissible || (int)classes.size() >= KAI_CMAX) { all_tracked = 0; continue; }
             ClassRec cr; std::memset(&cr, 0, sizeof cr);
@@ -501,7 +508,7 @@ struct HostPrep {
             cr.best_effort = be; cr.r_place = cpu_only ? KAI_RES_CPU : KAI_RES_GPU; cr.strategy = cpu_only ? cfg.cpu_strategy : cfg.gpu_strategy;
             remap[id] = (int)classes.size(); classes.push_back(cr);
         }
-        parallel_chunks((size_t)P, [&](int, size_t p0, size_t p1) { for (size_t p = p0; p < p1; p++) pod_scls[p] = remap[(size_t)pod_cls[p]]; });
+        parallel_chunks((size_t)P, [&](int, size_t p0, size_t p1) { for (size_t p = p0; p < p1; p++) pod_scls[p] = (sh && sh[p]) ? -1 : remap[(size_t)pod_cls[p]]; });
         int NB = (N + KAI_BLOCK - 1) / KAI_BLOCK, NSB = (NB + 63) / 64;
         if (NSB > KAI_NSB_MAX) { classes.clear(); par_fill(pod_scls, (size_t)P, -1); all_tracked = 0; }  // beyond the LDS level: brute force
     }

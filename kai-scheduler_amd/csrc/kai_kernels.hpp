@@ -71,6 +71,7 @@ __global__ void k_node_accounting_shared(KaiCtx c, const int32_t* np_off, const 
         }
         if (frac && c.p_on_group[p] >= 0) { SgNode g{c, n}; if (!g.add(st, c.p_mem[p], c.p_on_group[p])) { c.st->fault = FAULT_INTERNAL; c.st->fault_line = __LINE__; } }
     }
+    { SgNode g{c, n}; g.refit(); }  // the class keys' summary bits of the node's groups (also clears what an earlier session of this snapshot left: kai_session_reset)
 }
 #endif
 

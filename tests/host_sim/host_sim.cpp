@@ -360,6 +360,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     }
     std::vector<std::vector<char>> pool;
     HostPrep prep; std::string err;
+    prep.shared_pods = sp.any ? &sp : nullptr;
     if (prep.build(*cfg, s, err)) return KAI_ERR_INVALID_ARG;
     {   // the other constants kai_session_open writes on the device instead of sending them (kai_core.hip: prep.groups_default, !prep.any_nominated) — checked on every snapshot the CPU suite runs
         bool ok = true;
@@ -382,7 +383,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.plugins = cfg->plugins; c.gpu_strategy = cfg->gpu_strategy; c.cpu_strategy = cfg->cpu_strategy; c.restrict_nodes = cfg->restrict_node_scheduling;
     c.k_value = cfg->k_value <= 0.0 ? 0.0 : cfg->k_value;
     std::vector<int32_t> zerop(P, 0); std::vector<uint32_t> zeropu(P, 0); uint8_t one = 1;
-    c.n_alloc = copy(pool, prep.node_alloc.data(), (size_t)R * N); c.n_flags = copy(pool, prep.node_flags.data(), N);
+    c.n_alloc = copy(pool, prep.node_alloc.data(), (size_t)R * N); c.n_flags = const_cast<uint32_t*>(copy(pool, prep.node_flags.data(), N));
     c.n_gpu_count = copy(pool, prep.node_gpu_count.data(), N); c.n_class = copy(pool, prep.node_class.data(), N);
     c.p_req = copy(pool, s->pod_req, (size_t)R * P); c.p_job = copy(pool, s->pod_job, P); c.p_podset = copy(pool, s->pod_podset, P);
     c.p_flags = copy(pool, s->pod_flags ? s->pod_flags : zeropu.data(), P); c.p_class = copy(pool, s->pod_class ? s->pod_class : zerop.data(), P);
@@ -397,7 +398,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
     c.j_pods_sorted = copy(pool, prep.sorted.data(), P); c.q_child_off = copy(pool, prep.child_off.data(), Q + 2); c.q_children = copy(pool, prep.children.data(), std::max(Q, 1));
     c.q_job_off = copy(pool, prep.job_off.data(), Q + 1); c.jobs_static = copy(pool, prep.jobs_static.data(), std::max(J, 1)); c.q_depth_order = copy(pool, prep.depth_order.data(), Q);
     c.C = (int)prep.classes.size(); c.NB = (N + KAI_BLOCK - 1) / KAI_BLOCK; c.NSB = (c.NB + 63) / 64; c.use_index = c.C > 0; c.all_tracked = prep.all_tracked; c.fast_ok = prep.fast_ok; c.exact_sums = prep.exact_sums;
-    if (shared || sp.mig) { c.use_index = 0; c.all_tracked = 0; c.fast_ok = 0; }  // every scan by brute force: the class keys know neither fractions nor the gpusharingorder score
+    if (shared || sp.mig) { c.all_tracked = 0; const char* e = std::getenv("KAI_SHARED_INDEX"); const int lvl = e ? std::atoi(e) : 2; if (sp.mig || lvl == 0) c.use_index = 0; if (sp.mig || lvl < 2) c.fast_ok = 0; }  // as kai_session_open: fractions in no class, the others indexed with the gpusharingorder bit
     { int d = cfg->queue_depth[KAI_ACTION_ALLOCATE]; c.queue_depth = d > 0 ? d : 0; }
     c.cls = copy(pool, prep.classes.data(), prep.classes.size());
     c.T = prep.T; c.TL = prep.TL; c.D = prep.D; c.G = prep.G; c.W = (N + 31) / 32;
@@ -463,6 +464,7 @@ extern "C" int kai_hostsim_run(const kai_config* cfg, const kai_snapshot_soa* s,
         }
         if (shared && c.p_shared[p] && c.p_on_group[p] >= 0) { SgNode g{c, n}; if (!g.add(st, c.p_mem[p], c.p_on_group[p])) return KAI_ERR_UNSUPPORTED; }
     }
+    if (shared) for (int n = 0; n < N; n++) { SgNode g{c, n}; g.refit(); }  // as k_node_accounting_shared
     if (c.plugins & KAI_PLUGIN_PROPORTION) {  // k_total_nodes + k_total_foreign
         for (int n = 0; n < N; n++) {
             uint32_t f = c.n_flags[n]; if (f & KAI_NODE_NOT_READY) continue;

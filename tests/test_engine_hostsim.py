@@ -272,6 +272,30 @@ def test_hostsim_fraction_fuzz(seed):
     _same_groups(snap, res, ref)
 
 
+@pytest.mark.parametrize("level", (0, 1, 2))
+@pytest.mark.parametrize("seed", range(24))
+def test_hostsim_shared_gpus_keep_the_class_index(seed, level, monkeypatch):
+    """Round 6: in a session with shared GPUs the pods that ask for a fraction (or MiB) of a device are in no scan class — brute-force passes over the nodes' GPU groups —
+    while every other class keeps its arg-max index, the gpusharingorder score as one more key bit above the others (kai_engine.hpp key_shared_layout, kai_host_prep.hpp
+    build_classes).  KAI_SHARED_INDEX = 0: no index (the form before round 6), 1: index, general job path, 2 (default): index + the staged job path for gangs without a
+    fraction pod.  Mid-size clusters with CPU-only classes, whole-GPU classes of several sizes and fractions, every level against the oracle; with the index most decisions
+    are index queries."""
+    monkeypatch.setenv("KAI_SHARED_INDEX", str(level))
+    S = T.pkg.synth
+    snap = S.make_snapshot(40 + 17 * (seed % 7), 700 + 90 * (seed % 5), 5100 + seed, queue_levels=((2, 3), (3,), (2, 2, 2))[seed % 3], prefill=(0.2, 0.5, 0.8)[seed % 3],
+                           gpu_mix=((8, .6), (4, .2), (0, .2)), cpu_only_frac=0.25, limits_frac=0.2 if seed % 2 else 0.0)
+    S.add_fractions(snap, seed, frac=(0.3, 0.7)[seed % 2], portions=(0.25, 0.5, 0.75), memory_requests=0.3 if seed % 4 == 3 else 0.0)
+    cfg = T.abi.default_config(k_value=(0.0, 0.5, 1.0)[seed % 3], gpu_strategy=T.abi.SPREAD if seed % 6 == 5 else T.abi.BINPACK)
+    if seed % 4 == 3: cfg.min_node_gpu_memory = 100
+    if seed % 5 == 0: cfg.plugins = (cfg.plugins & ~T.abi.PLUGINS["gpupack"]) | T.abi.PLUGINS["gpuspread"]
+    if seed % 7 == 3: cfg.plugins &= ~T.abi.PLUGINS["gpusharingorder"]
+    ref = T.Oracle.run(snap, cfg, ("allocate",))
+    res = HostSim.run(snap, cfg, ("allocate",))
+    assert_same(res, ref, share_tol=1e-9)
+    _same_groups(snap, res, ref)
+    if level > 0 and int(res.stats.decisions) > 200: assert int(res.stats.node_scans) < int(res.stats.decisions) // 2  # (every pass over the nodes counts, also the ones a kept answer stands for)
+
+
 @pytest.mark.parametrize("seed", range(60))
 def test_hostsim_gpu_memory_fuzz(seed, monkeypatch):
     """Requests for MiB of one device beside fractions (ABI v5 pod_gpu_memory): what they take on a shared device, their accepted quota
