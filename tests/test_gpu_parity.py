@@ -730,6 +730,46 @@ def test_gpu_fraction_fuzz(gpu, seed):
         _same_groups(snap, res, ref)
 
 
+@pytest.mark.parametrize("level", (0, 1, 2))
+@pytest.mark.parametrize("seed", range(0, 24, 3))
+def test_gpu_shared_gpus_keep_the_class_index(gpu, seed, level, monkeypatch):
+    """Round 6: a session with shared GPUs keeps the arg-max index of every class that asks for no fraction (the gpusharingorder score as one more key bit, the node's summary
+    bits kept by SgNode::refit), fraction pods are brute-force passes; KAI_SHARED_INDEX 0 / 1 / 2 = no index / index / index + staged job path (default).  Same clusters as
+    tests/test_engine_hostsim.py::test_hostsim_shared_gpus_keep_the_class_index, on the device against the oracle; allocate, then a full cycle on the same snapshot."""
+    from test_engine_hostsim import _same_groups, FRAC_ACTS
+    monkeypatch.setenv("KAI_SHARED_INDEX", str(level))
+    S = T.pkg.synth
+    snap = S.make_snapshot(40 + 17 * (seed % 7), 700 + 90 * (seed % 5), 5100 + seed, queue_levels=((2, 3), (3,), (2, 2, 2))[seed % 3], prefill=(0.2, 0.5, 0.8)[seed % 3],
+                           gpu_mix=((8, .6), (4, .2), (0, .2)), cpu_only_frac=0.25, limits_frac=0.2 if seed % 2 else 0.0)
+    S.add_fractions(snap, seed, frac=(0.3, 0.7)[seed % 2], portions=(0.25, 0.5, 0.75), memory_requests=0.3 if seed % 4 == 3 else 0.0)
+    cfg = T.abi.default_config(k_value=(0.0, 0.5, 1.0)[seed % 3], gpu_strategy=T.abi.SPREAD if seed % 6 == 5 else T.abi.BINPACK, max_consolidation_preemptees=16)
+    if seed % 4 == 3: cfg.min_node_gpu_memory = 100
+    if seed % 5 == 0: cfg.plugins = (cfg.plugins & ~T.abi.PLUGINS["gpupack"]) | T.abi.PLUGINS["gpuspread"]
+    if seed % 7 == 3: cfg.plugins &= ~T.abi.PLUGINS["gpusharingorder"]
+    for acts in (("allocate",), FRAC_ACTS[seed % len(FRAC_ACTS)]):
+        ref = T.Oracle.run(snap, cfg, acts)
+        res = run_gpu(snap, cfg, acts)
+        assert_same_tol(res, ref)
+        _same_groups(snap, res, ref)
+        if level > 0 and acts == ("allocate",) and int(res.stats.decisions) > 200: assert int(res.stats.node_scans) < int(res.stats.decisions) // 2
+
+
+@pytest.mark.parametrize("level", (2, 1))
+def test_gpu_config3_with_fractions_hashes_to_the_oracles(gpu, level, monkeypatch):
+    """BASELINE config 3 with 30 % of its one-GPU pods as fractions of a device (bench.py's other_shapes.c3_fractions_30) at full size: the operations must hash to the ORACLE's
+    end-to-end run (profiles/full_size_pins.json C3fractions30) with the class index kept for the other classes — 2 202 passes over the nodes instead of one per decision."""
+    import json, os
+    monkeypatch.setenv("KAI_SHARED_INDEX", str(level))
+    with open(os.path.join(T.ROOT, "profiles", "full_size_pins.json")) as f:
+        pin = json.load(f)["C3fractions30"]
+    snap, cfg, desc = T.pkg.synth.config(2, 1.0)
+    T.pkg.synth.add_fractions(snap, 7, frac=0.3)
+    assert (snap.n_nodes, snap.n_pods) == (pin["nodes"], pin["pods"])
+    res = run_gpu(snap, cfg)
+    assert len(res.ops) == pin["ops"] and T.ops_sha256(res.ops) == pin["ops_sha256"]
+    assert int(res.stats.node_scans) < int(res.stats.decisions) // 10
+
+
 @pytest.mark.parametrize("seed,ci", ((5592, 5), (8881176, 5), (31415658, 5)))
 def test_gpu_victim_tasks_keep_their_eviction_order(gpu, seed, ci):
     """The two campaign cycles with fractions under allocate + consolidation + reclaim + preempt that differed from the oracle in rounds 1-2
