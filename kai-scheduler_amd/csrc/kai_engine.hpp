@@ -2490,6 +2490,7 @@ struct Engine {
         double ja[3] = {ja0, ja1, ja2};
         const bool preds = cx().plugins & KAI_PLUGIN_PREDICATES;
         int done = 0; bool ok = true;
+        int run_n = -1; uint64_t run_key = 0;
         for (int i = 0; i < nt; i++) {  // allocateTask :121-163
 #ifdef KAI_PROF_LOOP
             int64_t L0 = be.clock();
@@ -2503,8 +2504,12 @@ struct Engine {
 #ifdef KAI_PROF_LOOP
             int64_t L1 = be.clock(); el().h.prof[8] += L1 - L0;
 #endif
-            flush_index();
-            uint64_t key; int n; be.class_top(cx(), f.cls[i], key, n); el().h.index_queries++;
+            // A run of tasks of one class (round 6): the task before went to node run_n, the class's arg-max with key run_key, and since then only that node changed — by this
+            // lane.  If its key for the class did not drop (bin-packing: a fuller node scores higher) and it still fits, no other node can have overtaken it (they are unchanged, and
+            // among equal keys run_n was the lowest index): the task follows without waiting for the index, whose refresh is published once per run (k_fill's lazy follow, kai_batch_kernels.hpp).
+            uint64_t key = 0; int n = -1;
+            if (run_n >= 0 && f.cls[i] == f.cls[i - 1]) { const uint64_t kap = class_key(cx(), cx().cls[f.cls[i]], run_n); if (kap != 0 && kap >= run_key) { key = kap; n = run_n; } }
+            if (n < 0) { flush_index(); be.class_top(cx(), f.cls[i], key, n); el().h.index_queries++; }
 #ifdef KAI_PROF_LOOP
             int64_t L2 = be.clock(); el().h.prof[9] += L2 - L1;
 #endif
@@ -2523,7 +2528,8 @@ struct Engine {
             int64_t L3 = be.clock(); el().h.prof[10] += L3 - L2;
 #endif
             mark_dirty(n);
-            flush_index();  // published now, awaited by the next reader of the index: overlaps the bookkeeping below, the commit and the next pop
+            run_n = n; run_key = key;
+            if (!(i + 1 < nt && f.cls[i + 1] == f.cls[i])) flush_index();  // published now, awaited by the next reader of the index: overlaps the bookkeeping below, the commit and the next pop (a run's next task may follow without it: it is published when the run ends or breaks)
 #ifdef KAI_PROF_LOOP
             int64_t L4 = be.clock(); el().h.prof[11] += L4 - L3;
 #endif

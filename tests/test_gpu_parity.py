@@ -746,7 +746,7 @@ def test_gpu_shared_gpus_keep_the_class_index(gpu, seed, level, monkeypatch):
     if seed % 4 == 3: cfg.min_node_gpu_memory = 100
     if seed % 5 == 0: cfg.plugins = (cfg.plugins & ~T.abi.PLUGINS["gpupack"]) | T.abi.PLUGINS["gpuspread"]
     if seed % 7 == 3: cfg.plugins &= ~T.abi.PLUGINS["gpusharingorder"]
-    for acts in (("allocate",), FRAC_ACTS[seed % len(FRAC_ACTS)]):
+    for acts in (("allocate",), FRAC_ACTS[seed % len(FRAC_ACTS)]) if level == 2 else (("allocate",),):  # (the victim actions never read the index: one level carries the full cycle)
         ref = T.Oracle.run(snap, cfg, acts)
         res = run_gpu(snap, cfg, acts)
         assert_same_tol(res, ref)
