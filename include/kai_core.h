@@ -165,7 +165,7 @@ typedef struct kai_snapshot_soa {
     /* ---- nodes: api/node_info/node_info.go:68-105 ---- */
     int32_t n_nodes;
     const double* node_allocatable;   /* [R][N] status.allocatable */
-    const uint32_t* node_flags;       /* [N] KAI_NODE_* */
+    const uint32_t* node_flags;       /* [N] KAI_NODE_* (bits 28-31 are ignored: the library keeps flags of its own there) */
     const int32_t* node_gpu_count;    /* [N] nvidia.com/gpu.count label, -1 when absent (node_info.go:619-640) */
     const uint32_t* node_name_rank;   /* [N] rank of the node name, byte-wise ascending, unique */
     const int32_t* node_class;        /* [N] column of class_fit */

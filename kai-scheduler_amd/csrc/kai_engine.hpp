@@ -2515,6 +2515,7 @@ struct Engine {
 #endif
             if (!key) { el().fail_no_node = true; ok = false; break; }
             // Statement.Allocate :297-358 → NodeInfo.AddTask → addTaskResources (node_info.go:457-493)
+            bool next_fits = true;  // would one more task with this request still fit on the node (a hint for the follow step below; the class key decides)
             {   // all loads first (independent, one latency), then the stores: same values, same operations
                 double u[KAI_MAX_RES], id[KAI_MAX_RES];
                 for (int r = 0; r < KAI_MAX_RES; r++) if (r < cx().R) { size_t x = (size_t)r * cx().N + n; u[r] = cx().n_used[x]; id[r] = cx().n_idle[x]; }
@@ -2522,14 +2523,18 @@ struct Engine {
                     double v = rq[r]; if (v == 0) continue;
                     size_t x = (size_t)r * cx().N + n;
                     cx().n_used[x] = u[r] + v; cx().n_idle[x] = id[r] - v;
+                    if (v > id[r] - v) next_fits = false;
                 }
             }
 #ifdef KAI_PROF_LOOP
             int64_t L3 = be.clock(); el().h.prof[10] += L3 - L2;
 #endif
             mark_dirty(n);
-            run_n = n; run_key = key;
-            if (!(i + 1 < nt && f.cls[i + 1] == f.cls[i])) flush_index();  // published now, awaited by the next reader of the index: overlaps the bookkeeping below, the commit and the next pop (a run's next task may follow without it: it is published when the run ends or breaks)
+            // the refresh is published now — awaited by the next reader of the index, it overlaps the bookkeeping below, the commit and the next pop — unless the next task is
+            // expected to follow onto this node (same class, the node has room for it, a strategy under which a fuller node does not score lower): then once, when the run ends or breaks
+            const bool defer = i + 1 < nt && f.cls[i + 1] == f.cls[i] && next_fits && cx().cls[f.cls[i]].strategy != KAI_SPREAD;
+            run_n = defer ? n : -1; run_key = key;
+            if (!defer) flush_index();
 #ifdef KAI_PROF_LOOP
             int64_t L4 = be.clock(); el().h.prof[11] += L4 - L3;
 #endif

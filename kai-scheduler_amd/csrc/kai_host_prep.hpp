@@ -171,7 +171,7 @@ struct HostPrep {
         for (int i = 0; i < N; i++) {
             int o = perm[i];
             for (int r = 0; r < R; r++) node_alloc[(size_t)r * N + i] = s->node_allocatable[(size_t)r * N + o];
-            node_flags[i] = s->node_flags[o]; node_gpu_count[i] = s->node_gpu_count ? s->node_gpu_count[o] : -1; node_class[i] = s->node_class ? s->node_class[o] : 0;
+            node_flags[i] = s->node_flags[o] & 0x0FFFFFFFu /* the four highest bits are the library's own (kai_engine.hpp KAI_NODE_*_I) */; node_gpu_count[i] = s->node_gpu_count ? s->node_gpu_count[o] : -1; node_class[i] = s->node_class ? s->node_class[o] : 0;
             if (node_class[i] < 0 || node_class[i] >= std::max(1, s->n_node_classes)) return fail("node_class out of range");
         }
         lap(1);
