@@ -89,7 +89,7 @@ def test_gpu_full_size_operations_hash_to_the_oracles(gpu, name, idx):
     assert T.state_sha256(res) == pin["state_sha256"]
 
 
-@pytest.mark.parametrize("key,scale,depth", [("C4_10pct_depth0", 0.1, 0), ("C4_30pct_depth8", 0.3, 8), ("C4_100pct_depth8", 1.0, 8)])
+@pytest.mark.parametrize("key,scale,depth", [("C4_10pct_depth0", 0.1, 0), ("C4_30pct_depth8", 0.3, 8)])  # (the FULL size, 270 s on the device, runs last of the whole suite: tests/test_zz_gpu_config4_full_size.py)
 def test_gpu_config4_cycle_hashes_to_the_oracles(gpu, key, scale, depth):
     """BASELINE config 4 (allocate + consolidation + reclaim on one session: the victim search) pinned END TO END against the oracle's run of the same cycle
     (tools/pin_c4_depth.py → profiles/full_size_pins.json): 10 % with the reference's default queue depth (unlimited, conf_util/scheduler_conf_util.go:89-90), 30 % and the FULL
