@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, session 4, closing set of the final library (follow step published only when the next task is not expected to follow; caller's node flags masked): the shapes the
 # sequential engine serves hashed against their pins, host clocks of the small victim-action benchmarks, then the whole -m gpu suite + smoke + the default bench line + device campaigns
-TAG=${1:-r08e}; R="$GRAFT_REPO_ROOT"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
+TAG=${1:-r08f}; R="$GRAFT_REPO_ROOT"; cd "$R"; mkdir -p gpurun_out; export TMPDIR=/tmp
 KAI_PROF=1 KAI_BENCH_OTHER_SHAPES=0 timeout 600 python bench.py --config C3 --fractions 0.3 --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/${TAG}_bench_c3_fractions.json 2> gpurun_out/${TAG}_bench_c3_fractions.err; echo "c3 fractions rc=$?"
 KAI_PROF=1 KAI_BENCH_OTHER_SHAPES=0 timeout 600 python bench.py --config C5 --mixed --steps 2 --warmup 1 --cpu-sample 0 > gpurun_out/${TAG}_bench_c5_mixed.json 2> gpurun_out/${TAG}_bench_c5_mixed.err; echo "c5 mixed rc=$?"
 python - <<PY
