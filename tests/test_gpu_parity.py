@@ -730,6 +730,22 @@ def test_gpu_fraction_fuzz(gpu, seed):
         _same_groups(snap, res, ref)
 
 
+@pytest.mark.parametrize("idx,scale", [(1, 1.0), (2, 0.1), (4, 0.01)])
+def test_gpu_a_run_of_one_class_follows_its_node(gpu, idx, scale):
+    """The staged job path of the sequential engine on the device (kai_engine.hpp allocate_job_fast, round 6): consecutive tasks of one scan class keep landing on the node the
+    class's arg-max pointed to while that node's key does not drop, without a query of the index (its refresh is published once per run).  Same operations, states and shares
+    as the oracle and as the path without the staged jobs (engine_mode 2: one query per decision); fewer index queries than that path."""
+    snap, cfg, _ = T.pkg.synth.config(idx, scale)
+    ref = T.Oracle.run(snap, cfg, ("allocate",))
+    cfg.engine_mode = 3
+    res = run_gpu(snap, cfg, ("allocate",))
+    assert_same(res, ref)
+    cfg.engine_mode = 2
+    gen = run_gpu(snap, cfg, ("allocate",))
+    assert_same(gen, ref)
+    assert int(res.stats.reserved[0]) < int(gen.stats.reserved[0])  # index queries
+
+
 @pytest.mark.parametrize("level", (0, 1, 2))
 @pytest.mark.parametrize("seed", range(0, 24, 3))
 def test_gpu_shared_gpus_keep_the_class_index(gpu, seed, level, monkeypatch):
