@@ -272,6 +272,24 @@ def test_hostsim_fraction_fuzz(seed):
     _same_groups(snap, res, ref)
 
 
+def test_hostsim_callers_high_node_flag_bits_are_ignored():
+    """Bits 28-31 of kai_snapshot_soa.node_flags belong to the library (legacy-MIG mark, the two summary bits of a node's shared GPUs): whatever the caller leaves there is
+    masked at session open (kai_host_prep.hpp) — a shared-GPU session with garbage in them places exactly as without."""
+    S = T.pkg.synth
+    def build():
+        snap = S.make_snapshot(60, 800, 7311, queue_levels=(2, 3), prefill=0.5, gpu_mix=((8, .6), (4, .2), (0, .2)), cpu_only_frac=0.25)
+        S.add_fractions(snap, 3, frac=0.5, portions=(0.25, 0.5, 0.75))
+        return snap
+    cfg = T.abi.default_config(k_value=0.5)
+    clean = HostSim.run(build(), cfg, ("allocate",))
+    dirty_snap = build()
+    dirty_snap.arrays["node_flags"] = (dirty_snap.arrays["node_flags"].astype(np.uint32) | np.uint32(0xF0000000)).astype(dirty_snap.arrays["node_flags"].dtype)
+    dirty_snap.finalize()
+    dirty = HostSim.run(dirty_snap, cfg, ("allocate",))
+    assert clean.ops == dirty.ops and (clean.pod_node == dirty.pod_node).all()
+    assert_same(dirty, T.Oracle.run(build(), cfg, ("allocate",)), share_tol=1e-9)
+
+
 @pytest.mark.parametrize("idx,scale", [(1, 1.0), (2, 0.1), (4, 0.01)])
 def test_hostsim_a_run_of_one_class_follows_its_node(idx, scale):
     """The staged job path of the sequential engine (kai_engine.hpp allocate_job_fast, round 6): consecutive tasks of one scan class keep landing on the node the class's arg-max
